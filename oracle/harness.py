@@ -1,0 +1,169 @@
+"""Test-side drivers for the CPU oracle and (when built) the real reference binary.
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, tests/golden/make_golden.py, bench.py's cpu_baseline
+leg and __graft_entry__.smoke(); never by aligngraph_amd/.
+
+* ``synth(out, **kw)``           run tools/agx_synth (seeded synthetic tmp/ directory)
+* ``run_oracle(tmp, unit, ...)`` call oracle/liboracle.so (this repo's restatement) through ctypes
+* ``run_reference(run_dir)``     replay a prepared run directory through oracle/_ref/AlignGraph_ref*
+                                 with ``--resume`` (AG:4748-4760) and aligner stubs on PATH
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SYNTH = os.path.join(ROOT, "build", "agx_synth")
+LIBORACLE = os.path.join(HERE, "liboracle.so")
+REF_O0 = os.path.join(HERE, "_ref", "AlignGraph_ref")
+REF_O2 = os.path.join(HERE, "_ref", "AlignGraph_ref_O2")
+STUBS = os.path.join(HERE, "ref_stubs")
+
+
+def build():
+    """Compile the oracle, the generator and (if /root/reference exists) oracle/_ref."""
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+    src = os.path.join(ROOT, "tools", "agx_synth.cpp")
+    if not os.path.exists(SYNTH) or os.path.getmtime(SYNTH) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", SYNTH, src])
+
+
+def synth(out, **kw):
+    """kw: seed=1, chroms="50000", pairs=10000, L=100, ... (see tools/agx_synth.cpp Params)."""
+    if not os.path.exists(SYNTH):
+        build()
+    if os.path.exists(out):
+        shutil.rmtree(out)
+    cmd = [SYNTH, "--out", out]
+    for k, v in kw.items():
+        cmd += ["--" + k.replace("_", "-"), str(v)]
+    subprocess.check_call(cmd)
+    return out
+
+
+def read_meta(run_dir):
+    meta = {"unit_len": []}
+    with open(os.path.join(run_dir, "synth_meta.txt")) as f:
+        for line in f:
+            t = line.split()
+            if t[0] == "unit":
+                meta["unit_len"].append(int(t[3]))
+            else:
+                meta[t[0]] = int(t[1])
+    return meta
+
+
+class _Result(ctypes.Structure):
+    _fields_ = [
+        ("initial_contigs", ctypes.c_void_p), ("initial_len", ctypes.c_size_t),
+        ("pre_extended", ctypes.c_void_p), ("pre_len", ctypes.c_size_t),
+        ("extended", ctypes.c_void_p), ("extended_len", ctypes.c_size_t),
+        ("error", ctypes.c_char * 256),
+        ("n_pos", ctypes.c_uint32), ("n_nodes", ctypes.c_uint32), ("n_edges", ctypes.c_uint32),
+        ("node_start", ctypes.POINTER(ctypes.c_uint32)), ("node_key", ctypes.POINTER(ctypes.c_uint32)),
+        ("node_cnt", ctypes.POINTER(ctypes.c_int32)), ("node_slen", ctypes.POINTER(ctypes.c_uint32)),
+        ("edge_start", ctypes.POINTER(ctypes.c_uint32)), ("edge_dst", ctypes.POINTER(ctypes.c_uint32)),
+    ]
+
+
+_lib = None
+
+
+def _oracle():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBORACLE):
+            build()
+        _lib = ctypes.CDLL(LIBORACLE)
+        _lib.agx_oracle_run_unit.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_long, ctypes.c_int, ctypes.POINTER(_Result)]
+        _lib.agx_oracle_run_unit.restype = ctypes.c_int
+        _lib.agx_oracle_free.argtypes = [ctypes.POINTER(_Result)]
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def run_oracle(tmp_dir, unit, k=5, insert_variation=50, coverage=20, batch=1000000, graph=False):
+    """Returns dict(initial=bytes, pre=bytes, extended=bytes[, graph=dict of numpy arrays])."""
+    lib = _oracle()
+    r = _Result()
+    rc = lib.agx_oracle_run_unit(tmp_dir.encode(), unit, k, insert_variation, coverage, batch, 1 if graph else 0, ctypes.byref(r))
+    if rc != 0:
+        msg = r.error.decode()
+        lib.agx_oracle_free(ctypes.byref(r))
+        raise OracleError(msg)
+    out = {
+        "initial": ctypes.string_at(r.initial_contigs, r.initial_len),
+        "pre": ctypes.string_at(r.pre_extended, r.pre_len),
+        "extended": ctypes.string_at(r.extended, r.extended_len),
+    }
+    if graph:
+        import numpy as np
+
+        def arr(p, n, dt):
+            return np.ctypeslib.as_array(p, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+        out["graph"] = {
+            "n_pos": r.n_pos, "n_nodes": r.n_nodes, "n_edges": r.n_edges,
+            "node_start": arr(r.node_start, r.n_pos + 1, "uint32"),
+            "node_key": arr(r.node_key, r.n_nodes * 6, "uint32").reshape(-1, 6),
+            "node_cnt": arr(r.node_cnt, r.n_nodes * 6, "int32").reshape(-1, 6),
+            "node_slen": arr(r.node_slen, r.n_nodes, "uint32"),
+            "edge_start": arr(r.edge_start, r.n_nodes + 1, "uint32"),
+            "edge_dst": arr(r.edge_dst, r.n_edges, "uint32"),
+        }
+    lib.agx_oracle_free(ctypes.byref(r))
+    return out
+
+
+def have_reference(opt=True):
+    return os.path.exists(REF_O2 if opt else REF_O0)
+
+
+def run_reference(run_dir, opt=True, keep=False):
+    """Copy run_dir to a scratch sibling, replay it with the real reference through --resume, and return
+    (outputs, stage_seconds): outputs[u] = dict(initial=, pre=, extended=) for every unit; stage_seconds is the
+    wall time between the reference's own "(0)"/"RESUMED" and last "(5) Contigs scaffolded" stdout markers."""
+    exe = REF_O2 if opt else REF_O0
+    if not os.path.exists(exe):
+        raise FileNotFoundError(exe)
+    work = run_dir.rstrip("/") + ".ref"
+    if os.path.exists(work):
+        shutil.rmtree(work)
+    shutil.copytree(run_dir, work)
+    env = dict(os.environ)
+    env["PATH"] = STUBS + os.pathsep + env.get("PATH", "")
+    p = subprocess.Popen([exe, "--resume"], cwd=work, env=env, stdout=subprocess.PIPE, bufsize=0)
+    t0 = t1 = None
+    buf = b""
+    while True:
+        chunk = p.stdout.read(4096)
+        now = time.perf_counter()
+        if not chunk:
+            break
+        buf += chunk
+        if t0 is None and b"RESUMED SUCCESSFULLY" in buf:
+            t0 = now
+        if b"(5) Contigs scaffolded" in chunk:
+            t1 = now
+    rc = p.wait()
+    if rc != 0 or b"FINISHED SUCCESSFULLY" not in buf:
+        raise RuntimeError("reference failed (rc=%d): %s" % (rc, buf[-400:].decode(errors="replace")))
+    outs = []
+    u = 0
+    while os.path.exists(os.path.join(work, "tmp", "_extended_contigs.%d.fa" % u)):
+        o = {}
+        for key, name in (("initial", "_initial_contigs"), ("pre", "_pre_extended_contigs"), ("extended", "_extended_contigs")):
+            with open(os.path.join(work, "tmp", "%s.%d.fa" % (name, u)), "rb") as f:
+                o[key] = f.read()
+        outs.append(o)
+        u += 1
+    if not keep:
+        shutil.rmtree(work)
+    return outs, (t1 - t0 if t0 is not None and t1 is not None else None)
