@@ -1,0 +1,404 @@
+// agx_core.h — data layout and per-lane algorithm of the MI355X graph-build engine.
+//
+// Everything here is written once and compiled twice: by hipcc into the gfx950 kernels
+// (agx_kernels.hip) and by g++ into the test-only serial executor (tests/hostsim) that lets the
+// CPU test-suite check the re-formulated algorithm against the oracle without a GPU.
+// The product library never runs these functions on the host.
+//
+// Re-formulation of the reference's node build (AG = /root/reference/AlignGraph/AlignGraph.cpp):
+//
+//  * The reference applies one "event" per aligned read index (updateGenomeWithRead, AG:1635-1870 ->
+//    updateKMer, AG:1353-1624): a k1 half at position P (match-or-insert, coverage++, base vote) and a
+//    k2 half at the next position N (match-or-insert only).  The k2 half of an event and the k1 half of
+//    the same read's next event address the same position with the same key, so here every
+//    (hit, position) pair carries ONE "arrival": K1 (count + vote), CHAIN (count, no vote, empty k-mer —
+//    the positions the reference walks through when a read insertion sits next to a reference gap,
+//    AG:1730-1751) or K2ONLY (the last position a read reaches, AG:1484-1500: insert with coverage 0).
+//  * A bucket's variants are only ever appended, and `compatible` (AG:1293-1312) is reflexive, so the
+//    variant an arrival resolves to is the first compatible variant of the FINAL bucket.  Node build is
+//    therefore one in-order sweep per position (lanes = positions, hits applied in SAM order), and edge
+//    build (AG:1589-1623) is a second sweep that re-resolves both ends of every event against the final
+//    buckets — no atomics, no dependence on scheduling, bit-exact by construction.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define AGX_HD __host__ __device__ __forceinline__
+#else
+#define AGX_HD inline
+#endif
+
+typedef uint32_t agx_u32;
+typedef uint16_t agx_u16;
+typedef uint8_t agx_u8;
+
+#define AGX_NONE 0xFFFFFFFFu
+#define AGX_TILE 64u          // positions per tile = lanes per wavefront
+#define AGX_MAXV_LDS 4u       // variants per position held in LDS; tiles that need more are re-run with global scratch
+#define AGX_MAXV_BIG 64u      // variants per position in the global-scratch fallback
+#define AGX_MAXE 4u           // out-edges stored inline per node; more go to the overflow list
+#define AGX_EP25 25           // 5*EP (AG:39, 1296)
+
+// ---- packed inputs (host -> device) -----------------------------------------------------------------
+
+struct agx_run { agx_u32 q, t, n; };          // n read bases from read index q sit on reference offsets t.. (Segment, AG:44-49)
+
+// One (pair, hit) that passed the identity filter of loadReadAli (AG:1261), in SAM order.
+struct agx_hit {
+    agx_u32 slot1;            // mate1's slot in the read-base blob; mate2 is slot1+1
+    agx_u32 pos1, pos2;       // "simple" mates (one M run covering the whole read): reference offset of read index 0
+    agx_u32 runs1, runs2;     // first run in the run pool (non-simple mates)
+    agx_u16 nruns1, nruns2;   // 0 = simple
+    agx_u16 len;              // read length (mates are equal length, AG:3454)
+    agx_u8 rev1, rev2;        // SAM FLAG 0x10 of each mate
+    agx_u8 back;              // number of earlier kept hits of the same pair
+    agx_u8 pad[3];
+};
+
+// per-position conti-mer key (the part of ContiMer, AG:51-62, that node build reads)
+struct agx_cmkey { agx_u32 cid, coff; };
+
+// ---- derived per-hit record (device, written by hit_prep) ---------------------------------------------
+
+enum { AGX_HF_AREV = 1, AGX_HF_SKIP = 2 };
+
+struct agx_dhit {
+    agx_u32 a_t0, b_t0;       // simple mate: reference offset of read index 0 ("a" = the left mate, AG:1672-1679)
+    agx_u32 a_runs, b_runs;
+    agx_u32 a_slot;           // read slot of the a mate
+    agx_u16 len, jstar;       // jstar: read index of the K2ONLY arrival, 0xFFFF if none
+    agx_u16 a_nruns, b_nruns; // 0 = simple
+    agx_u32 flags;
+    agx_u32 x_lo, x_hi;       // first / last position that receives an arrival (x_lo > x_hi: none)
+};
+
+// ---- node table (device -> host) ----------------------------------------------------------------------
+
+enum { AGX_NF_DEAD = 1, AGX_NF_CONTIG = 2, AGX_NF_EOVF = 4 };   // pruned (AG:1912-1915); contigOffset != -1 (AG:2004); edges in overflow list
+
+// k-mer string reference: the k-mer of a node is reads[slot] (oriented) [q, q+len)
+struct agx_sref { agx_u32 slot; agx_u32 qlen; };   // qlen = first | len<<16 | rev<<31; `first` is the stored (file-orientation) index of
+                                                   // the k-mer's first base: forward reads run first, first+1, ..; reverse reads run first, first-1, .. complemented
+
+// bucket fields while a tile is being swept (struct-of-arrays: field-major, then variant, then lane)
+enum { AGX_F_CID = 0, AGX_F_COFF, AGX_F_CID0, AGX_F_COFF0, AGX_F_OFF0, AGX_F_COV, AGX_F_A, AGX_F_C, AGX_F_G, AGX_F_T, AGX_F_N, AGX_F_S0, AGX_F_S1, AGX_NF };
+
+struct agx_key { agx_u32 cid, coff, cid0, coff0, off0; };   // chromosomeID0 is 0 iff off0 != NONE inside a unit
+
+AGX_HD int agx_absdiff(agx_u32 a, agx_u32 b) { int d = (int)(a - b); return d < 0 ? -d : d; }   // abs((int)(a-b)), AG:1296
+
+// clauses of `compatible` (AG:1293-1312, OPTIMIZATION on): A on (contigID, contigOffset), B on the mate's, C on the mate position
+AGX_HD bool agx_clause_ab(agx_u32 ac, agx_u32 ao, agx_u32 bc, agx_u32 bo, int win) {
+    return ac == AGX_NONE || bc == AGX_NONE || ac != bc || agx_absdiff(ao, bo) <= win;
+}
+AGX_HD bool agx_clause_c(agx_u32 ao, agx_u32 bo, int win) { return ao == AGX_NONE || bo == AGX_NONE || agx_absdiff(ao, bo) <= win; }
+
+// A bucket view: base points at this lane's column; element (variant v, field f) is base[(v*AGX_NF+f)*stride]
+struct agx_bucket { agx_u32 *base; agx_u32 stride; agx_u32 maxv; };
+AGX_HD agx_u32 &agx_b(const agx_bucket &b, agx_u32 v, agx_u32 f) { return b.base[(v * AGX_NF + f) * b.stride]; }
+
+AGX_HD bool agx_compatible(const agx_key &k, const agx_bucket &b, agx_u32 v, int iv) {
+    return agx_clause_ab(k.cid, k.coff, agx_b(b, v, AGX_F_CID), agx_b(b, v, AGX_F_COFF), AGX_EP25) &&
+           agx_clause_ab(k.cid0, k.coff0, agx_b(b, v, AGX_F_CID0), agx_b(b, v, AGX_F_COFF0), 2 * iv + AGX_EP25) &&
+           agx_clause_c(k.off0, agx_b(b, v, AGX_F_OFF0), 2 * iv + AGX_EP25);
+}
+
+// ---- read geometry ---------------------------------------------------------------------------------------
+
+// reference offset of read index q of the b mate, or NONE
+AGX_HD agx_u32 agx_pos_b(const agx_dhit &d, const agx_run *runs, agx_u32 q) {
+    if (d.b_nruns == 0) return d.b_t0 + q;
+    for (agx_u32 i = 0; i < d.b_nruns; i++) { const agx_run r = runs[d.b_runs + i]; if (q >= r.q && q < r.q + r.n) return r.t + (q - r.q); }
+    return AGX_NONE;
+}
+
+enum { AGX_AT_K1 = 0, AGX_AT_K2ONLY = 1, AGX_AT_CHAIN = 2 };
+
+struct agx_arrival {
+    agx_u32 type, q, slen;    // q: read index whose base votes / starts the k-mer string
+    agx_u32 p0;               // mate position (or NONE)
+    agx_u32 has_succ, xs, p0s;  // successor arrival of the same hit: position and its mate position (the event's N / N0)
+};
+
+// What hit d contributes at position X (if anything).  Follows the event loop of AG:1681-1859; k = k-mer length.
+AGX_HD bool agx_decode_arrival(const agx_dhit &d, const agx_run *runs, agx_u32 X, agx_u32 k, agx_arrival &a) {
+    const agx_u32 L = d.len;
+    if (L <= k) return false;
+    const agx_u32 lim = L - k;
+    const agx_u32 nr = d.a_nruns == 0 ? 1u : d.a_nruns;
+    agx_run r = d.a_nruns == 0 ? agx_run{0u, d.a_t0, L} : runs[d.a_runs];
+    for (agx_u32 i = 0; i < nr; i++) {
+        agx_run nx = (i + 1 < nr) ? runs[d.a_runs + i + 1] : agx_run{0u, 0u, 0u};
+        if (X >= r.t && X - r.t < r.n) {
+            const agx_u32 q = r.q + (X - r.t);
+            a.q = q; a.p0 = agx_pos_b(d, runs, q); a.has_succ = 0; a.xs = 0; a.p0s = AGX_NONE;
+            // An index is an event SOURCE (k1: count + vote) iff it is aligned, below lim and not the last aligned index of the
+            // read; jstar is the first aligned index that is not a source: it only ever receives the k2 half (AG:1484-1500).
+            if (q == d.jstar) { a.type = AGX_AT_K2ONLY; a.slen = (L - q) < k ? (L - q) : k; return true; }
+            if (q < d.jstar) {
+                a.type = AGX_AT_K1; a.slen = k; a.has_succ = 1;
+                if (X - r.t + 1 < r.n) { a.xs = X + 1; a.p0s = agx_pos_b(d, runs, q + 1); }                            // ordinary, AG:1841-1857
+                else if (nx.q == q + 1 || nx.t == X + 1) { a.xs = nx.t; a.p0s = agx_pos_b(d, runs, nx.q); }            // deletion AG:1822-1838 / insertion AG:1707-1727
+                else { a.xs = X + 1; a.p0s = AGX_NONE; }                                                               // first step of a chain, AG:1736
+                return true;
+            }
+            return false;
+        }
+        if (i + 1 < nr && X >= r.t + r.n && X < nx.t) {                       // between two runs
+            const agx_u32 p = r.q + r.n - 1;
+            if (nx.q >= p + 2 && p < lim) {                                   // read insertion next to a reference gap: chain, AG:1737-1749
+                a.type = AGX_AT_CHAIN; a.q = 0; a.slen = 0; a.p0 = AGX_NONE; a.has_succ = 1; a.xs = X + 1;
+                a.p0s = (X + 1 == nx.t) ? agx_pos_b(d, runs, nx.q) : AGX_NONE;
+                return true;
+            }
+            return false;
+        }
+        r = nx;
+    }
+    return false;
+}
+
+// oriented base q of a read stored at `p` with length L (reverseComplement, AG:854-865: only ACGT complemented)
+AGX_HD char agx_base_at(const char *p, agx_u32 L, agx_u32 q, bool rev) {
+    if (!rev) return p[q];
+    const char c = p[L - 1 - q];
+    return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+}
+
+// ---- hit_prep: orientation, left-mate choice, multi-hit suppression, arrival span (AG:1648-1679) -------------
+
+AGX_HD agx_u32 agx_idx0_pos(const agx_hit &h, const agx_run *runs) {     // positionSets[hit][0] of mate1
+    if (h.nruns1 == 0) return h.pos1;
+    const agx_run r = runs[h.runs1];
+    return r.q == 0 ? r.t : AGX_NONE;
+}
+
+// returns 0 ok, 1 = same-strand mates ("BOWTIE ALIGNMENT ERROR", AG:1667-1671)
+AGX_HD int agx_hit_prep(const agx_hit *hits, const agx_run *runs, agx_u32 h, agx_u32 k, agx_dhit &d) {
+    const agx_hit H = hits[h];
+    d.flags = 0; d.len = H.len; d.jstar = 0xFFFF; d.x_lo = 1; d.x_hi = 0;
+    d.a_t0 = d.b_t0 = d.a_runs = d.b_runs = d.a_slot = 0; d.a_nruns = d.b_nruns = 0;
+    const agx_u32 me = agx_idx0_pos(H, runs);
+    for (agx_u32 e = 1; e <= H.back; e++)
+        if (agx_absdiff(me, agx_idx0_pos(hits[h - e], runs)) < (int)H.len) { d.flags = AGX_HF_SKIP; return 0; }     // AG:1650-1655
+    if (H.rev1 == H.rev2) { d.flags = AGX_HF_SKIP; return 1; }
+    const agx_u32 L = H.len;
+    if (L <= k) { d.flags = AGX_HF_SKIP; return 0; }
+    const agx_u32 lim = L - k;
+    // swap so that "a" is the left mate: some index < lim aligned in both mates with pos1 > pos2 (AG:1672-1679)
+    bool swap = false;
+    {
+        const agx_u32 n1 = H.nruns1 ? H.nruns1 : 1u, n2 = H.nruns2 ? H.nruns2 : 1u;
+        for (agx_u32 i = 0; i < n1 && !swap; i++) {
+            const agx_run r1 = H.nruns1 ? runs[H.runs1 + i] : agx_run{0u, H.pos1, L};
+            for (agx_u32 j = 0; j < n2; j++) {
+                const agx_run r2 = H.nruns2 ? runs[H.runs2 + j] : agx_run{0u, H.pos2, L};
+                agx_u32 lo = r1.q > r2.q ? r1.q : r2.q, hi1 = r1.q + r1.n, hi2 = r2.q + r2.n;
+                agx_u32 hi = hi1 < hi2 ? hi1 : hi2; if (hi > lim) hi = lim;
+                if (lo < hi && (r1.t + (lo - r1.q)) > (r2.t + (lo - r2.q))) { swap = true; break; }   // difference is constant on the overlap
+            }
+        }
+    }
+    if (!swap) {
+        d.a_t0 = H.pos1; d.b_t0 = H.pos2; d.a_runs = H.runs1; d.b_runs = H.runs2; d.a_nruns = H.nruns1; d.b_nruns = H.nruns2;
+        d.a_slot = H.slot1; if (H.rev1) d.flags |= AGX_HF_AREV;
+    } else {
+        d.a_t0 = H.pos2; d.b_t0 = H.pos1; d.a_runs = H.runs2; d.b_runs = H.runs1; d.a_nruns = H.nruns2; d.b_nruns = H.nruns1;
+        d.a_slot = H.slot1 + 1; if (H.rev2) d.flags |= AGX_HF_AREV;
+    }
+    // arrival span and the K2ONLY index.  Sources are the aligned indices below cut = min(lim, last aligned index);
+    // jstar = first aligned index >= cut (a read whose last aligned index is below lim ends there, e.g. a trailing soft clip)
+    const agx_u32 nr = d.a_nruns ? d.a_nruns : 1u;
+    agx_u32 q_last = 0; bool any = false;
+    for (agx_u32 i = 0; i < nr; i++) { const agx_run r = d.a_nruns ? runs[d.a_runs + i] : agx_run{0u, d.a_t0, L}; if (r.n) { q_last = r.q + r.n - 1; any = true; } }
+    if (!any) { d.flags |= AGX_HF_SKIP; return 0; }
+    const agx_u32 cut = lim < q_last ? lim : q_last;
+    agx_u32 first_x = 0, last_x = 0; bool below = false, have_first = false;
+    for (agx_u32 i = 0; i < nr; i++) {
+        const agx_run r = d.a_nruns ? runs[d.a_runs + i] : agx_run{0u, d.a_t0, L};
+        if (r.n == 0) continue;
+        if (!have_first) { first_x = r.t; have_first = true; }
+        if (r.q < cut) below = true;
+        if (r.q + r.n > cut) {                              // this run holds the first aligned index >= cut
+            const agx_u32 j = r.q >= cut ? r.q : cut;
+            d.jstar = (agx_u16)j; last_x = r.t + (j - r.q);
+            break;
+        }
+    }
+    if (!below) { d.flags |= AGX_HF_SKIP; return 0; }       // no source index: the hit emits no event
+    d.x_lo = first_x; d.x_hi = last_x;
+    return 0;
+}
+
+// ---- node sweep: one lane = one position --------------------------------------------------------------------
+
+struct agx_sweep_args {
+    // static graph inputs
+    const agx_u32 *cm_start;      // [n_pos+1] conti-mers of position x are cm[cm_start[x] .. cm_start[x+1])
+    const agx_cmkey *cm;
+    const char *ref;              // [n_pos] reference base per position (incl. appended positions)
+    // reads
+    const agx_dhit *dhit;
+    const agx_run *runs;
+    const char *bases; agx_u32 stride;   // read slot s starts at bases + s*stride
+    // tile lists
+    const agx_u32 *tile_off;      // [n_tiles+1]
+    const agx_u32 *tile_hits;     // hit ids, ascending inside a tile
+    agx_u32 n_pos, n_tiles, k; int iv; int coverage;
+    // node table
+    agx_u32 *node_start;          // [n_pos]
+    agx_u8 *node_cnt;             // [n_pos]
+    agx_u32 *nk_cid, *nk_coff, *nk_cid0, *nk_coff0, *nk_off0;   // [pool]
+    agx_u32 *n_xpos;              // position of each node (the walk follows edges by node id)
+    agx_u8 *n_base, *n_flags;     // consensus base ('X' = none: use the reference base, AG:1997-2001), AGX_NF_*
+    agx_sref *n_sref;
+    agx_u32 *n_next;              // [pool*AGX_MAXE]
+    int *n_counts;                // optional [pool*6] cov,A,C,G,T,N (parity/debug), may be null
+    agx_u32 pool_cap;
+};
+
+AGX_HD agx_u32 agx_vote_field(char c) { return c == 'A' ? AGX_F_A : c == 'C' ? AGX_F_C : c == 'G' ? AGX_F_G : c == 'T' ? AGX_F_T : AGX_F_N; }
+
+// first compatible variant or append (AG:1375-1390 / 1493-1506).  Returns the index, or NONE when the bucket is full.
+AGX_HD agx_u32 agx_match_or_insert(const agx_bucket &b, agx_u32 &cnt, const agx_key &key, int iv, bool is_k1, agx_u32 s0, agx_u32 s1) {
+    agx_u32 v = 0;
+    for (; v < cnt; v++) if (agx_compatible(key, b, v, iv)) break;
+    if (v == cnt) {
+        if (cnt == b.maxv) return AGX_NONE;
+        agx_b(b, v, AGX_F_CID) = key.cid; agx_b(b, v, AGX_F_COFF) = key.coff; agx_b(b, v, AGX_F_CID0) = key.cid0; agx_b(b, v, AGX_F_COFF0) = key.coff0;
+        agx_b(b, v, AGX_F_OFF0) = key.off0; agx_b(b, v, AGX_F_COV) = 0;
+        agx_b(b, v, AGX_F_A) = 0; agx_b(b, v, AGX_F_C) = 0; agx_b(b, v, AGX_F_G) = 0; agx_b(b, v, AGX_F_T) = 0; agx_b(b, v, AGX_F_N) = 0;
+        agx_b(b, v, AGX_F_S0) = s0; agx_b(b, v, AGX_F_S1) = s1;
+        cnt++;
+    }
+    if (is_k1) agx_b(b, v, AGX_F_COV) += 1;
+    return v;
+}
+
+// Candidate keys of an arrival at X with mate position p0 (AG:1369-1477): {conti-mers at X | none} x {conti-mers at p0 | none}, X-major.
+// Calls f(key) for each; f returns false to stop.
+template <class F>
+AGX_HD void agx_for_candidates(const agx_sweep_args &A, agx_u32 cx_s, agx_u32 cx_n, agx_u32 p0, F f) {
+    agx_u32 c0_s = 0, c0_n = 0;
+    if (p0 != AGX_NONE) { c0_s = A.cm_start[p0]; c0_n = A.cm_start[p0 + 1] - c0_s; }
+    const agx_u32 nx = cx_n ? cx_n : 1u, n0 = c0_n ? c0_n : 1u;
+    for (agx_u32 i = 0; i < nx; i++) {
+        agx_key key; key.off0 = p0;
+        if (cx_n) { const agx_cmkey c = A.cm[cx_s + i]; key.cid = c.cid; key.coff = c.coff; } else { key.cid = AGX_NONE; key.coff = AGX_NONE; }
+        for (agx_u32 j = 0; j < n0; j++) {
+            if (c0_n) { const agx_cmkey c = A.cm[c0_s + j]; key.cid0 = c.cid; key.coff0 = c.coff; } else { key.cid0 = AGX_NONE; key.coff0 = AGX_NONE; }
+            if (!f(key)) return;
+        }
+    }
+}
+
+// The whole in-order sweep of one position.  Returns false if the bucket overflowed (tile must be re-run with a larger bucket).
+AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, const agx_bucket &b, agx_u32 &cnt) {
+    cnt = 0;
+    if (X >= A.n_pos) return true;
+    const agx_u32 cx_s = A.cm_start[X], cx_n = A.cm_start[X + 1] - cx_s;
+    bool ok = true;
+    const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
+    for (agx_u32 i = lo; i < hi; i++) {
+        const agx_u32 h = A.tile_hits[i];
+        const agx_dhit d = A.dhit[h];
+        agx_arrival a;
+        if (!agx_decode_arrival(d, A.runs, X, A.k, a)) continue;
+        const bool rev = (d.flags & AGX_HF_AREV) != 0;
+        const bool is_k1 = a.type != AGX_AT_K2ONLY;
+        const agx_u32 s0 = d.a_slot, s1 = (a.slen ? (rev ? (agx_u32)d.len - 1u - a.q : a.q) : 0u) | (a.slen << 16) | (rev ? 0x80000000u : 0u);
+        agx_u32 vf = AGX_NF;
+        if (a.type == AGX_AT_K1) vf = agx_vote_field(agx_base_at(A.bases + (size_t)d.a_slot * A.stride, d.len, a.q, rev));
+        agx_for_candidates(A, cx_s, cx_n, a.p0, [&](const agx_key &key) {
+            const agx_u32 v = agx_match_or_insert(b, cnt, key, A.iv, is_k1, s0, s1);
+            if (v == AGX_NONE) { ok = false; return false; }
+            if (vf != AGX_NF) agx_b(b, v, vf) += 1;
+            return true;
+        });
+        if (!ok) return false;
+    }
+    return true;
+}
+
+// consensus base of a node (max, AG:1944-1952): 'X' if no votes; ties resolve A>C>G>T>N
+AGX_HD char agx_consensus(agx_u32 a, agx_u32 c, agx_u32 g, agx_u32 t, agx_u32 n) {
+    if (!(a | c | g | t | n)) return 'X';
+    if (a >= c && a >= g && a >= t && a >= n) return 'A';
+    if (c >= a && c >= g && c >= t && c >= n) return 'C';
+    if (g >= a && g >= c && g >= t && g >= n) return 'G';
+    if (t >= a && t >= c && t >= g && t >= n) return 'T';
+    return 'N';
+}
+
+// write this position's bucket to the node table at node ids [base, base+cnt); prune (AG:1904-1918) and consensus fused in
+AGX_HD void agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bucket &b, agx_u32 cnt, agx_u32 base) {
+    if (X >= A.n_pos) return;
+    A.node_start[X] = base; A.node_cnt[X] = (agx_u8)cnt;
+    for (agx_u32 v = 0; v < cnt; v++) {
+        const agx_u32 id = base + v;
+        const agx_u32 cid = agx_b(b, v, AGX_F_CID), coff = agx_b(b, v, AGX_F_COFF), cov = agx_b(b, v, AGX_F_COV);
+        A.nk_cid[id] = cid; A.nk_coff[id] = coff; A.nk_cid0[id] = agx_b(b, v, AGX_F_CID0); A.nk_coff0[id] = agx_b(b, v, AGX_F_COFF0);
+        A.nk_off0[id] = agx_b(b, v, AGX_F_OFF0); A.n_xpos[id] = X;
+        const agx_u32 va = agx_b(b, v, AGX_F_A), vc = agx_b(b, v, AGX_F_C), vg = agx_b(b, v, AGX_F_G), vt = agx_b(b, v, AGX_F_T), vn = agx_b(b, v, AGX_F_N);
+        A.n_base[id] = (agx_u8)agx_consensus(va, vc, vg, vt, vn);
+        agx_u8 fl = 0;
+        if (cid == AGX_NONE && (int)cov < A.coverage) fl |= AGX_NF_DEAD;
+        if (coff != AGX_NONE) fl |= AGX_NF_CONTIG;
+        A.n_flags[id] = fl;
+        agx_sref s; s.slot = agx_b(b, v, AGX_F_S0); s.qlen = agx_b(b, v, AGX_F_S1); A.n_sref[id] = s;
+        for (agx_u32 e = 0; e < AGX_MAXE; e++) A.n_next[(size_t)id * AGX_MAXE + e] = AGX_NONE;
+        if (A.n_counts) { int *c = A.n_counts + (size_t)id * 6; c[0] = (int)cov; c[1] = (int)va; c[2] = (int)vc; c[3] = (int)vg; c[4] = (int)vt; c[5] = (int)vn; }
+    }
+}
+
+// ---- edge sweep (AG:1589-1623) ---------------------------------------------------------------------------------
+
+struct agx_edge_ovf { agx_u32 src, dst; };
+
+// first compatible variant of the FINAL bucket at position x for key; NONE if x has no compatible variant (cannot happen for a real arrival)
+AGX_HD agx_u32 agx_resolve(const agx_sweep_args &A, agx_u32 x, const agx_key &k) {
+    const agx_u32 s = A.node_start[x], n = A.node_cnt[x];
+    for (agx_u32 v = 0; v < n; v++) {
+        const agx_u32 id = s + v;
+        if (agx_clause_ab(k.cid, k.coff, A.nk_cid[id], A.nk_coff[id], AGX_EP25) &&
+            agx_clause_ab(k.cid0, k.coff0, A.nk_cid0[id], A.nk_coff0[id], 2 * A.iv + AGX_EP25) &&
+            agx_clause_c(k.off0, A.nk_off0[id], 2 * A.iv + AGX_EP25)) return id;
+    }
+    return AGX_NONE;
+}
+
+// All out-edges of the nodes at position X.  Only this lane ever writes n_next of X's nodes, so plain stores suffice.
+// ovf/ovf_count: global overflow list for nodes with more than AGX_MAXE out-edges (appended with an atomic by the caller-supplied functor).
+template <class OVF>
+AGX_HD void agx_edge_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, OVF push_overflow) {
+    if (X >= A.n_pos) return;
+    if (A.node_cnt[X] == 0) return;
+    const agx_u32 cx_s = A.cm_start[X], cx_n = A.cm_start[X + 1] - cx_s;
+    const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
+    for (agx_u32 i = lo; i < hi; i++) {
+        const agx_u32 h = A.tile_hits[i];
+        const agx_dhit d = A.dhit[h];
+        agx_arrival a;
+        if (!agx_decode_arrival(d, A.runs, X, A.k, a) || !a.has_succ) continue;
+        if (a.xs >= A.n_pos) continue;
+        const agx_u32 sx_s = A.cm_start[a.xs], sx_n = A.cm_start[a.xs + 1] - sx_s;
+        agx_for_candidates(A, cx_s, cx_n, a.p0, [&](const agx_key &k1) {
+            const agx_u32 src = agx_resolve(A, X, k1);
+            if (src == AGX_NONE) return true;
+            agx_for_candidates(A, sx_s, sx_n, a.p0s, [&](const agx_key &k2) {
+                const agx_u32 dst = agx_resolve(A, a.xs, k2);
+                if (dst == AGX_NONE) return true;
+                // contig-consistency between the two STORED keys (AG:1602-1615)
+                if (!(agx_clause_ab(A.nk_cid[dst], A.nk_coff[dst], A.nk_cid[src], A.nk_coff[src], AGX_EP25) &&
+                      agx_clause_ab(A.nk_cid0[dst], A.nk_coff0[dst], A.nk_cid0[src], A.nk_coff0[src], 2 * A.iv + AGX_EP25))) return true;
+                agx_u32 *slots = A.n_next + (size_t)src * AGX_MAXE;
+                agx_u32 e = 0;
+                for (; e < AGX_MAXE; e++) { if (slots[e] == dst) return true; if (slots[e] == AGX_NONE) { slots[e] = dst; return true; } }
+                A.n_flags[src] |= AGX_NF_EOVF;
+                push_overflow(src, dst);      // duplicates are removed on the host
+                return true;
+            });
+            return true;
+        });
+    }
+}

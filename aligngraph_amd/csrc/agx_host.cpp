@@ -1,0 +1,416 @@
+// agx_host.cpp — host-side loaders: the reference's tmp/ text files -> packed arrays for the device.
+//
+// Mirrors, for one unit, loadGenome (AG:287-320), loadContigAlignment (AG:1219-1231: loadSeq AG:322-359,
+// loadContiAli AG:817-852 with parseBLAT AG:406-522 and updateContig AG:763-815, updateGenomeWithContig
+// AG:884-1217) and the parsing half of loadReadAlignment (loadSeq AG:361-404, loadReadAli AG:1233-1277 with
+// parseBOWTIE AG:181-285).  AG = /root/reference/AlignGraph/AlignGraph.cpp.
+//
+// Contig threading stays on the host on purpose: it is ~1 % of the reference's time, inherently ordered
+// (a placement is skipped when it meets a position that already carries two conti-mers, AG:908-920) and its
+// result is a static, read-only input of the kernels.
+//
+// Inputs the reference would mis-handle by reading out of bounds are rejected here with an error instead
+// (listed in DESIGN.md "Rejected inputs"): SAM not sorted by read id, CIGAR length != read length,
+// a RNAME / tName that does not resolve to the unit sequence, alignments beyond the unit sequence.
+#include "agx_host.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace agx {
+namespace {
+
+// read-only view of a whole file
+struct FileView {
+    const char *p = nullptr; size_t n = 0; int fd = -1; bool mapped = false;
+    explicit FileView(const std::string &path) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw Error{E_IO, "CANNOT OPEN FILE! (" + path + ")"};
+        struct stat st; if (fstat(fd, &st) != 0) { ::close(fd); throw Error{E_IO, "cannot stat " + path}; }
+        n = (size_t)st.st_size;
+        if (n) {
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); throw Error{E_IO, "cannot map " + path}; }
+            p = (const char *)m; mapped = true;
+            madvise(m, n, MADV_SEQUENTIAL);
+        }
+    }
+    ~FileView() { if (mapped) munmap((void *)p, n); if (fd >= 0) ::close(fd); }
+    FileView(const FileView &) = delete; FileView &operator=(const FileView &) = delete;
+};
+
+// getline + `if(buf[0]==0) break` of the reference: an empty line ends the input
+struct LineReader {
+    const char *p, *e; bool saw_empty = false;
+    LineReader(const char *b, size_t n) : p(b), e(b + n) {}
+    bool next(const char *&s, size_t &len) {
+        if (p >= e) { saw_empty = true; return false; }    // (callers that care check the last byte themselves)
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+        const char *le = nl ? nl : e;
+        s = p; len = (size_t)(le - p); p = nl ? nl + 1 : e;
+        if (len == 0 || s[0] == 0) { saw_empty = true; return false; }
+        return true;
+    }
+};
+
+inline int to_int(const char *s, size_t n) {      // atoi semantics on a bounded field
+    size_t i = 0; while (i < n && (s[i] == ' ' || (s[i] >= 9 && s[i] <= 13))) i++;
+    bool neg = false; if (i < n && (s[i] == '-' || s[i] == '+')) { neg = s[i] == '-'; i++; }
+    long long v = 0; for (; i < n && s[i] >= '0' && s[i] <= '9'; i++) { v = v * 10 + (s[i] - '0'); if (v > 0x7fffffffffffLL) break; }
+    return (int)(neg ? -v : v);
+}
+
+inline void rc_inplace(std::string &s) {
+    std::reverse(s.begin(), s.end());
+    for (auto &c : s) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+}
+
+inline void fasta_body(std::string &out, const char *s, size_t n) {
+    for (size_t i = 0; i < n; i += 60) { const size_t m = n - i < 60 ? n - i : 60; out.append(s + i, m); out.push_back('\n'); }
+}
+
+struct ContigSeq {
+    std::string nuc; int real_id = 0; int placed = 0;
+    std::vector<std::vector<agx_u32> > sets;   // per placement: per-base reference offset or NONE
+    std::vector<int> fr;
+};
+
+struct Psl { agx_u32 tID, tStart, tEnd, tGap, sID, sStart, sEnd, sGap, sSize, fr; };
+
+void parse_psl_line(const char *s, size_t n, Psl &r, std::vector<agx_run> &seg) {
+    const char *f[21]; size_t fl[21]; int nf = 0; const char *b = s, *e = s + n;
+    for (const char *c = s; c <= e && nf < 21; c++) if (c == e || *c == '\t') { f[nf] = b; fl[nf] = (size_t)(c - b); nf++; b = c + 1; }
+    for (; nf < 21; nf++) { f[nf] = e; fl[nf] = 0; }
+    seg.clear();
+    for (int col = 18; col <= 20; col++) {
+        size_t sp = 0; const char *st = f[col];
+        for (const char *c = f[col]; c < f[col] + fl[col]; c++) if (*c == ',') {
+            const agx_u32 v = (agx_u32)to_int(st, (size_t)(c - st)); st = c + 1;
+            if (col == 18) seg.push_back(agx_run{AGX_NONE, AGX_NONE, v});
+            else if (sp < seg.size()) { if (col == 19) seg[sp].q = v; else seg[sp].t = v; }
+            sp++;
+        }
+    }
+    r.fr = fl[8] ? (f[8][0] == '+' ? 0u : 1u) : AGX_NONE;
+    r.tID = (agx_u32)to_int(f[13], fl[13]); r.tStart = (agx_u32)to_int(f[15], fl[15]); r.tEnd = (agx_u32)to_int(f[16], fl[16]);
+    r.tGap = (agx_u32)to_int(f[7], fl[7]); r.sStart = (agx_u32)to_int(f[11], fl[11]); r.sEnd = (agx_u32)to_int(f[12], fl[12]);
+    r.sGap = (agx_u32)to_int(f[5], fl[5]); r.sSize = (agx_u32)to_int(f[10], fl[10]);
+    size_t dot = 0; while (dot < fl[9] && f[9][dot] != '.') dot++;
+    r.sID = (agx_u32)to_int(f[9], dot);
+}
+
+// keepPositions (AG:731-748) on the last placement of contig `id`
+bool keeps_last(const std::vector<ContigSeq> &c, agx_u32 id, double thr) {
+    if (id == AGX_NONE || c[id].sets.empty()) return true;
+    const std::vector<agx_u32> &last = c[id].sets.back();
+    size_t m = 0; for (agx_u32 v : last) m += v != AGX_NONE;
+    return (double)m / (double)last.size() >= thr;
+}
+
+}  // namespace
+
+// loadGenome, AG:287-320
+void load_unit_reference(const std::string &path, std::string &ref) {
+    FileView fv(path); LineReader in(fv.p, fv.n);
+    const char *s; size_t n; int records = 0;
+    ref.clear(); ref.reserve(fv.n);
+    while (in.next(s, n)) {
+        if (s[0] == '>') { if (++records > 1) throw Error{E_UNSUPPORTED, "unit genome file holds more than one record"}; continue; }
+        if (!records) throw Error{E_FORMAT, "unit genome file has no header line"};
+        ref.append(s, n);
+    }
+}
+
+// loadContigAlignment, AG:1219-1231
+void thread_contigs_from_files(const std::string &contigs_fa, const std::string &psl_path, Threads &T) {
+    std::vector<ContigSeq> cs;
+    {   // loadSeq, AG:322-359
+        FileView fv(contigs_fa); LineReader in(fv.p, fv.n); const char *s; size_t n;
+        while (in.next(s, n)) {
+            if (s[0] == '>') {
+                size_t i = 0; while (i < n && s[i] != '.') i++;
+                if (i == n) throw Error{E_FORMAT, "contig header without '.' in " + contigs_fa};
+                cs.emplace_back(); cs.back().real_id = to_int(s + i + 1, n - i - 1);
+            } else { if (cs.empty()) throw Error{E_FORMAT, "sequence before header in " + contigs_fa}; cs.back().nuc.append(s, n); }
+        }
+    }
+    const agx_u32 n_ref = (agx_u32)T.ref.size();
+    T.n_ref = n_ref;
+    {   // loadContiAli, AG:817-852 (sourceIDBak starts at -1 for every unit, AG:4781)
+        FileView fv(psl_path); LineReader in(fv.p, fv.n); const char *s; size_t n;
+        Psl r; std::vector<agx_run> seg; agx_u32 bak = AGX_NONE, last_parsed = AGX_NONE;
+        while (in.next(s, n)) {
+            parse_psl_line(s, n, r, seg); last_parsed = r.sID;
+            const bool keep = (double)(agx_u32)(r.sEnd - r.sStart - r.sGap) / r.sSize >= 0.5 &&
+                              (double)(agx_u32)(r.tEnd - r.tStart - r.tGap) / (agx_u32)(r.tEnd - r.tStart) >= 0.5 && r.sSize > 200;
+            if (!keep) continue;
+            if (r.tID != 0) throw Error{E_UNSUPPORTED, "PSL target is not the unit sequence"};
+            if (r.sID >= cs.size()) throw Error{E_FORMAT, "PSL names a contig that is not in _contigs.fa"};
+            ContigSeq &q = cs[r.sID];
+            for (const agx_run &g : seg) {
+                if ((size_t)g.q + g.n > q.nuc.size() || g.q == AGX_NONE) throw Error{E_FORMAT, "PSL block beyond the contig"};
+                if ((unsigned long long)g.t + g.n > n_ref) throw Error{E_FORMAT, "PSL block beyond the unit sequence"};
+            }
+            auto open_set = [&]() { q.sets.emplace_back(q.nuc.size(), AGX_NONE); q.fr.push_back((int)r.fr); };
+            if (r.sID != bak) {                                                       // updateContig, AG:772-785
+                if (!keeps_last(cs, bak, 0.5)) { cs[bak].sets.pop_back(); cs[bak].fr.pop_back(); }
+                open_set(); bak = r.sID;
+            } else {                                                                  // AG:786-806: a block that meets a filled base opens a new placement
+                bool hit = false;
+                for (const agx_run &g : seg) { for (agx_u32 i = g.q; i < g.q + g.n && !hit; i++) hit = q.sets.back()[i] != AGX_NONE; if (hit) break; }
+                if (hit) { if (!keeps_last(cs, r.sID, 0.5)) { q.sets.pop_back(); q.fr.pop_back(); } open_set(); }
+            }
+            std::vector<agx_u32> &set = q.sets.back();
+            for (const agx_run &g : seg) for (agx_u32 i = 0; i < g.n; i++) set[g.q + i] = g.t + i;
+        }
+        // AG:830-836: reached only through an empty line, i.e. when the file is empty or ends with '\n'
+        const bool through_empty_line = fv.n == 0 || fv.p[fv.n - 1] == '\n' || in.p < in.e;
+        if (through_empty_line && last_parsed != AGX_NONE && last_parsed < cs.size() && !keeps_last(cs, last_parsed, 0.5)) cs[last_parsed].sets.pop_back();
+    }
+
+    // updateGenomeWithContig, AG:884-1217 — per-position conti-mer lists kept as index-linked pools while threading
+    struct Cell { ContiMer m; int next; };
+    std::vector<Cell> pool;
+    std::vector<int> head(n_ref, -1), tail(n_ref, -1);
+    std::vector<agx_u32> count(n_ref, 0);
+    auto push_cm = [&](agx_u32 x, const ContiMer &m) {
+        const int id = (int)pool.size(); pool.push_back(Cell{m, -1});
+        if (tail[x] < 0) head[x] = id; else pool[tail[x]].next = id;
+        tail[x] = id; count[x]++;
+    };
+    auto push_pos = [&](char nuc) { T.ref.push_back(nuc); head.push_back(-1); tail.push_back(-1); count.push_back(0); };
+    agx_u32 off = 0, next_off = AGX_NONE; bool has_next = false;     // function-scope in the reference: survive from one placement to the next
+    for (size_t sp = 0; sp < cs.size(); sp++) {
+        ContigSeq &q = cs[sp];
+        size_t pp = 0;
+    again:
+        for (; pp < q.sets.size(); pp++) {
+            const std::vector<agx_u32> &set = q.sets[pp];
+            const size_t len = set.size();
+            for (size_t e = 0; e < pp; e++) if (agx_absdiff(set[0], q.sets[e][0]) < (int)q.nuc.size()) { pp++; goto again; }      // AG:902-907
+            for (size_t i = 0; i + 1 < len; i++) if (set[i] != AGX_NONE && count[set[i]] >= 2) { pp++; goto again; }              // AG:908-920
+            if (pp >= q.fr.size()) throw Error{E_FORMAT, "contig placement without strand"};
+            const bool rc = q.fr[pp] == 1;
+            if (rc) rc_inplace(q.nuc);
+            q.placed = 1;
+            size_t i;
+            for (i = 0; i + 1 < len; i++) {
+                if (set[i] == AGX_NONE) continue;
+                off = set[i]; next_off = set[i + 1]; has_next = next_off != AGX_NONE;
+                const char nuc = q.nuc[i];
+                if (!has_next) {                                                        // contig bases missing from the reference, AG:940-1045 ("large insertion" arm; SI=0)
+                    for (size_t np = i + 2; np < len; np++) {
+                        if (set[np] == AGX_NONE) continue;
+                        has_next = true; next_off = set[np];
+                        push_cm(off, ContiMer{nuc, (agx_u32)sp, (agx_u32)i, (agx_u32)T.ref.size(), 0});
+                        for (size_t j = 0; j + 2 < np - i; j++) {
+                            const char b = q.nuc[i + 1 + j];
+                            push_pos(b);
+                            push_cm((agx_u32)T.ref.size() - 1, ContiMer{b, (agx_u32)sp, (agx_u32)(i + 1 + j), (agx_u32)T.ref.size(), 0});
+                        }
+                        const char b = q.nuc[np - 1];
+                        push_pos(b);
+                        push_cm((agx_u32)T.ref.size() - 1, ContiMer{b, (agx_u32)sp, (agx_u32)(np - 1), next_off, count[next_off]});
+                        i = np - 1;
+                        break;
+                    }
+                } else {
+                    push_cm(off, ContiMer{nuc, (agx_u32)sp, (agx_u32)i, next_off, count[next_off]});       // ordinary AG:1099-1118 and deletion AG:1075-1097 (SD=0)
+                }
+            }
+            const agx_u32 at = has_next ? next_off : off;                                                  // terminal conti-mer carries the reference base, AG:1121-1148
+            push_cm(at, ContiMer{T.ref[at], (agx_u32)sp, (agx_u32)i, AGX_NONE, AGX_NONE});
+            if (rc) rc_inplace(q.nuc);
+        }
+    }
+    const size_t n_pos = T.ref.size();
+    T.cm_start.assign(n_pos + 1, 0); T.cm.clear(); T.cm.reserve(pool.size());
+    for (size_t x = 0; x < n_pos; x++) { T.cm_start[x] = (agx_u32)T.cm.size(); for (int c = head[x]; c >= 0; c = pool[c].next) T.cm.push_back(pool[c].m); }
+    T.cm_start[n_pos] = (agx_u32)T.cm.size();
+
+    // tmp/_initial_contigs.<u>.fa, AG:1179-1216: runs of equal realID form one real contig; it is written when >= 50 % of its
+    // chunks were placed on this unit
+    T.initial_contigs.clear();
+    std::vector<std::string> real; std::vector<int> placed, total; int id_bak = -1;
+    for (const ContigSeq &q : cs) {
+        if (q.real_id != id_bak) { real.emplace_back(); placed.push_back(0); total.push_back(0); id_bak = q.real_id; }
+        total.back()++; placed.back() += q.placed; real.back() += q.nuc;
+    }
+    for (size_t g = 0; g < real.size(); g++)
+        if ((double)placed[g] / (double)total[g] >= 0.5) {
+            T.initial_contigs += ">" + std::to_string(g) + "\n";
+            fasta_body(T.initial_contigs, real[g].data(), real[g].size());
+        }
+}
+
+namespace {
+
+struct Mate { agx_u32 id; agx_u32 fr; bool aligned; agx_u32 pos0; agx_u32 total, ins, del, clipL, clipR; size_t run0; agx_u32 nruns; };
+
+// parseBOWTIE, AG:181-285; M runs are appended to `runs`
+void parse_sam_line(const char *s, size_t n, Mate &m, std::vector<agx_run> &runs) {
+    const char *f[6]; size_t fl[6]; int nf = 0; const char *b = s, *e = s + n;
+    for (const char *c = s; nf < 6; c++) {
+        if (c >= e || *c == '\t') { f[nf] = b; fl[nf] = (size_t)((c < e ? c : e) - b); nf++; b = c + 1; if (c >= e) break; }
+    }
+    for (; nf < 6; nf++) { f[nf] = e; fl[nf] = 0; }
+    m.id = (agx_u32)to_int(f[0], fl[0]);
+    m.fr = (to_int(f[1], fl[1]) & 0x10) ? 1u : 0u;
+    m.run0 = runs.size(); m.nruns = 0; m.total = m.ins = m.del = m.clipL = m.clipR = 0; m.pos0 = 0;
+    m.aligned = !(fl[2] > 0 && f[2][0] == '*');
+    if (!m.aligned) return;
+    size_t dot = 0; while (dot < fl[2] && f[2][dot] != '.') dot++;
+    if (dot != fl[2] && to_int(f[2], dot) != 0) throw Error{E_UNSUPPORTED, "SAM RNAME does not resolve to the unit sequence"};
+    const int pos1 = to_int(f[3], fl[3]);
+    int ins = 0, del = 0, total = 0, start = 0, end = 0, first = 1, num = 0;
+    for (size_t i = 0; i < fl[5]; i++) {
+        const char c = f[5][i];
+        if (c >= '0' && c <= '9') { num = num * 10 + (c - '0'); continue; }
+        if (c == 'I') { ins += num; total += num; }
+        else if (c == 'D') del += num;
+        else if (c == 'M') { if (num > 0) { runs.push_back(agx_run{(agx_u32)total, (agx_u32)(pos1 + total + del - start - ins - 1), (agx_u32)num}); m.nruns++; } total += num; first = 0; }
+        else if (c == 'S' && first) { start = num; total += num; first = 0; }
+        else if (c == 'S') { end = num; total += num; }
+        else if (c != '*') throw Error{E_FORMAT, std::string("unknown character: ") + c};
+        num = 0;
+    }
+    m.total = (agx_u32)total; m.ins = (agx_u32)ins; m.del = (agx_u32)del; m.clipL = (agx_u32)start; m.clipR = (agx_u32)end; m.pos0 = (agx_u32)(pos1 - 1);
+}
+
+// the identity filter of loadReadAli, AG:1261, in the reference's unsigned arithmetic
+inline bool passes(const Mate &m) {
+    const agx_u32 sEnd = m.total - m.clipR, tEnd = m.pos0 + (m.total + m.del - m.ins);
+    return (double)(agx_u32)(sEnd - m.clipL - m.ins) / m.total >= 0.6 && (double)(agx_u32)(tEnd - m.pos0 - m.del) / (agx_u32)(tEnd - m.pos0) >= 0.6;
+}
+
+}  // namespace
+
+// loadReadAlignment's parsing half: batches of `batch` pairs (AG:37, 361-404), SAM line pairs (AG:1233-1277)
+void load_pairs_from_files(const std::string &reads_fa, const std::string &sam_path, long batch, agx_u32 k, Pairs &P) {
+    P = Pairs();
+    FileView rf(reads_fa), sf(sam_path);
+    if (batch <= 0) batch = 1000000;
+
+    // ---- pass 1 over the SAM: kept hits, in order, with the batch-boundary rule applied ----------------
+    std::vector<agx_u32> hit_id;                 // read id per kept hit
+    {
+        // number of pairs in the reads file decides where the last batch ends: count header lines
+        unsigned long long headers = 0;
+        for (const char *c = rf.p, *e = rf.p + rf.n; c < e;) {
+            if (*c == '>') headers++;
+            const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+            if (!nl) break;
+            if (nl == c) break;                  // empty line ends the file for the reference
+            c = nl + 1;
+        }
+        P.n_pairs_in_file = headers / 2;
+    }
+    const long long N = (long long)P.n_pairs_in_file, B = batch;
+    if (N == 0) throw Error{E_FORMAT, "reads file holds no pairs"};
+    // batch n loads pairs [lo, hi]; `final_batch` = loadSeq reached the end of the reads file while loading it (AG:397).
+    // A reads file of exactly m*B pairs is followed by one EMPTY batch (lo = N) in which every alignment is skipped (AG:1258).
+    long long lo = 0, hi = std::min<long long>(B, N) - 1;
+    bool final_batch = hi == N - 1 && N % B != 0;
+    LineReader in(sf.p, sf.n); const char *s; size_t n;
+    Mate m1, m2; agx_u32 prev_id = 0; bool any = false; agx_u32 back = 0;
+    for (;;) {
+        if (!in.next(s, n)) break;
+        if (s[0] == '@') continue;
+        const size_t mark = P.runs.size();
+        parse_sam_line(s, n, m1, P.runs);
+        if (!in.next(s, n)) throw Error{E_FORMAT, "BROKEN BOWTIE FILE"};
+        parse_sam_line(s, n, m2, P.runs);
+        P.n_sam_pairs++;
+        const long long id = (long long)m1.id;
+        if (id < lo) {
+            P.runs.resize(mark);
+            if (lo > hi) continue;                           // the empty last batch skips everything
+            throw Error{E_UNSUPPORTED, "SAM is not sorted by read id (bowtie2 --reorder output expected)"};
+        }
+        if (id > hi) {                                       // AG:1259: this line pair is consumed and lost; the next batch begins
+            P.runs.resize(mark);
+            if (final_batch) break;
+            lo = hi + 1; hi = std::min<long long>(lo + B, N) - 1;
+            final_batch = lo == N || (hi == N - 1 && N % B != 0);
+            continue;
+        }
+        const bool keep = m1.aligned && m2.aligned && passes(m1) && passes(m2);
+        if (!keep) { P.runs.resize(mark); continue; }
+        if (m1.id != m2.id) throw Error{E_UNSUPPORTED, "SAM mates of one pair are not on adjacent lines"};
+        if (any && m1.id < prev_id) throw Error{E_UNSUPPORTED, "SAM is not sorted by read id (bowtie2 --reorder output expected)"};
+        back = (any && m1.id == prev_id) ? back + 1 : 0;
+        if (back > 250) throw Error{E_UNSUPPORTED, "more than 250 hits for one pair"};
+        prev_id = m1.id; any = true;
+        agx_hit h; memset(&h, 0, sizeof h);
+        h.slot1 = m1.id;                                       // read id for now; turned into a slot in pass 2
+        h.len = 0; h.rev1 = (agx_u8)m1.fr; h.rev2 = (agx_u8)m2.fr; h.back = (agx_u8)back;
+        auto fill = [&](const Mate &m, agx_u32 &pos, agx_u32 &r0, agx_u16 &nr) {
+            // "simple" = a single M run that covers the whole read
+            if (m.nruns == 1 && P.runs[m.run0].q == 0 && P.runs[m.run0].n == m.total) { pos = P.runs[m.run0].t; r0 = 0; nr = 0; }
+            else { pos = 0; r0 = (agx_u32)m.run0; nr = (agx_u16)m.nruns; if (m.nruns > 60000) throw Error{E_UNSUPPORTED, "CIGAR with too many runs"}; }
+        };
+        fill(m1, h.pos1, h.runs1, h.nruns1); fill(m2, h.pos2, h.runs2, h.nruns2);
+        // drop the runs of simple mates from the pool (keeps it small); non-simple runs must stay contiguous per mate
+        if (h.nruns1 == 0 && h.nruns2 == 0) P.runs.resize(mark);
+        else if (h.nruns1 == 0) {           // mate1 simple, mate2 not: move mate2's runs down
+            for (agx_u32 i = 0; i < m2.nruns; i++) P.runs[mark + i] = P.runs[m2.run0 + i];
+            h.runs2 = (agx_u32)mark; P.runs.resize(mark + m2.nruns);
+        } else if (h.nruns2 == 0) P.runs.resize(m1.run0 + m1.nruns);
+        for (int w = 0; w < 2; w++) {       // runs must advance on the reference (SAM guarantees it)
+            const agx_u32 r0 = w ? h.runs2 : h.runs1, nr = w ? h.nruns2 : h.nruns1;
+            for (agx_u32 i = 1; i < nr; i++) if (P.runs[r0 + i].t < P.runs[r0 + i - 1].t + P.runs[r0 + i - 1].n) throw Error{E_UNSUPPORTED, "alignment runs do not advance on the reference"};
+        }
+        if (m1.total != m2.total) throw Error{E_UNSUPPORTED, "mates of one pair have different CIGAR lengths"};
+        if (m1.total > 65000) throw Error{E_UNSUPPORTED, "read longer than 65000"};
+        h.len = (agx_u16)m1.total;
+        P.hits.push_back(h);
+        hit_id.push_back(m1.id);
+    }
+    P.n_kept = P.hits.size();
+
+    // ---- pass 2 over the reads file: copy the bases of pairs that have kept hits ------------------------
+    agx_u32 maxlen = 0;
+    for (const agx_hit &h : P.hits) maxlen = std::max<agx_u32>(maxlen, h.len);
+    P.stride = (maxlen + 15u) & ~15u;
+    if (P.hits.empty()) return;
+    if (k >= 32768) throw Error{E_ARG, "k too large"};
+    // distinct ids in order
+    size_t n_ids = 0; { agx_u32 last = 0; for (size_t i = 0; i < hit_id.size(); i++) if (i == 0 || hit_id[i] != last) { n_ids++; last = hit_id[i]; } }
+    P.n_slots = (agx_u32)(2 * n_ids);
+    P.bases.assign((size_t)P.n_slots * P.stride, 'N');
+    const char *c = rf.p, *e = rf.p + rf.n;
+    unsigned long long rec = 0;                 // record index in the reads file: record 2i, 2i+1 = mates of pair i
+    size_t hi_idx = 0; agx_u32 slot = 0;
+    auto next_line = [&](const char *&ls, size_t &ln) -> bool {
+        if (c >= e) return false;
+        const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+        const char *le = nl ? nl : e; ls = c; ln = (size_t)(le - c); c = nl ? nl + 1 : e;
+        return ln != 0;
+    };
+    while (hi_idx < P.hits.size()) {
+        const agx_u32 want = hit_id[hi_idx];
+        const char *ls; size_t ln;
+        // skip to record 2*want
+        while (rec < 2ull * want) { if (!next_line(ls, ln) || !next_line(ls, ln)) throw Error{E_FORMAT, "reads file ends before a read named by the SAM"}; rec++; }
+        for (int mate = 0; mate < 2; mate++) {
+            if (!next_line(ls, ln) || ls[0] != '>') throw Error{E_FORMAT, "reads file: header expected"};
+            if (!next_line(ls, ln)) throw Error{E_FORMAT, "reads file: sequence expected"};
+            rec++;
+            if (ln > P.stride || ln != P.hits[hi_idx].len) throw Error{E_UNSUPPORTED, "CIGAR length differs from the read length"};
+            memcpy(&P.bases[(size_t)(slot + mate) * P.stride], ls, ln);
+        }
+        while (hi_idx < P.hits.size() && hit_id[hi_idx] == want) {
+            if (P.hits[hi_idx].len != P.hits[hi_idx - P.hits[hi_idx].back].len) throw Error{E_UNSUPPORTED, "hits of one pair disagree on the read length"};
+            P.hits[hi_idx].slot1 = slot; hi_idx++;
+        }
+        slot += 2;
+    }
+}
+
+}  // namespace agx

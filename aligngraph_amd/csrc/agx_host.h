@@ -1,0 +1,58 @@
+// agx_host.h — host-side containers shared by the loader, the engine and the walk.
+#pragma once
+#include <string>
+#include <vector>
+#include "agx_core.h"
+
+namespace agx {
+
+struct Error { int code; std::string msg; };   // thrown inside the library, converted to a return code at the C-ABI
+
+// error codes (include/agx.h mirrors these)
+enum {
+    E_OK = 0, E_IO = -1, E_FORMAT = -2, E_UNSUPPORTED = -3, E_ALIGNMENT = -4, E_DEVICE = -5, E_ARG = -6, E_OVERFLOW = -7, E_NOGPU = -8
+};
+
+// full conti-mer (ContiMer, AG:51-62): key for node build + what the walk follows
+struct ContiMer { char nuc; agx_u32 cid, coff, next_off, next_item; };   // next_off == NONE: chain end
+
+// Result of contig threading (updateGenomeWithContig, AG:884-1217) for one unit
+struct Threads {
+    std::string ref;                       // reference bases followed by the positions appended for contig insertions (AG:1016, 1036)
+    agx_u32 n_ref = 0;                     // length of the original unit sequence
+    std::vector<agx_u32> cm_start;         // [n_pos+1]
+    std::vector<ContiMer> cm;
+    std::string initial_contigs;           // bytes of tmp/_initial_contigs.<u>.fa
+};
+
+// Packed read alignments of one unit (loadSeq/loadReadAli, AG:361-404, 1233-1277)
+struct Pairs {
+    std::vector<agx_hit> hits;             // processing order
+    std::vector<agx_run> runs;
+    std::string bases;                     // read slot s occupies [s*stride, s*stride+len)
+    agx_u32 stride = 0;
+    agx_u32 n_slots = 0;
+    unsigned long long n_pairs_in_file = 0, n_sam_pairs = 0, n_kept = 0;
+};
+
+// Node table + edges as downloaded from the device (or produced by the test executor)
+struct GraphView {
+    agx_u32 n_pos = 0, n_nodes = 0;
+    const agx_u32 *node_start = nullptr; const agx_u8 *node_cnt = nullptr;
+    const agx_u8 *base = nullptr; const agx_u8 *flags = nullptr;
+    const agx_u32 *off0 = nullptr; const agx_u32 *xpos = nullptr; const agx_sref *sref = nullptr;
+    const agx_u32 *next = nullptr;                          // [n_nodes*AGX_MAXE]
+    const agx_edge_ovf *ovf = nullptr; size_t n_ovf = 0;     // unsorted, may hold duplicates
+};
+
+struct UnitOutput { std::string initial_contigs, pre_extended, extended; };
+
+// agx_host.cpp
+void load_unit_reference(const std::string &path, std::string &ref);
+void thread_contigs_from_files(const std::string &contigs_fa, const std::string &psl, Threads &T);   // T.ref must hold the unit sequence
+void load_pairs_from_files(const std::string &reads_fa, const std::string &sam, long batch, agx_u32 k, Pairs &P);
+
+// agx_walk.cpp
+void walk_join_scaffold(const Threads &T, const Pairs &P, const GraphView &G, UnitOutput &out);
+
+}  // namespace agx

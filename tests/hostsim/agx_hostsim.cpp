@@ -1,0 +1,169 @@
+// agx_hostsim — TEST-ONLY serial executor of the engine's kernels.
+//
+// Runs exactly the per-lane functions of aligngraph_amd/csrc/agx_core.h that the gfx950 kernels run
+// (hit_prep -> tile binning -> node sweep -> edge sweep), one "lane" after another on the CPU, followed by
+// the product's own host walk.  It exists so that `pytest -m "not gpu"` can check the re-formulated algorithm
+// (merged arrivals, in-order tile sweeps, edges resolved against final buckets) against the oracle in a
+// container without a GPU.  It is never linked into libagx.so and the product API cannot reach it.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../aligngraph_amd/csrc/agx_host.h"
+
+using namespace agx;
+
+namespace {
+
+struct SimGraph {
+    std::vector<agx_u32> node_start; std::vector<agx_u8> node_cnt;
+    std::vector<agx_u32> cid, coff, cid0, coff0, off0, xpos, next;
+    std::vector<agx_u8> base, flags; std::vector<agx_sref> sref; std::vector<int> counts;
+    std::vector<agx_edge_ovf> ovf;
+    agx_u32 n_nodes = 0;
+    void reserve(size_t cap) {
+        cid.resize(cap); coff.resize(cap); cid0.resize(cap); coff0.resize(cap); off0.resize(cap); xpos.resize(cap); next.resize(cap * AGX_MAXE);
+        base.resize(cap); flags.resize(cap); sref.resize(cap); counts.resize(cap * 6);
+    }
+};
+
+void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage, agx_u32 maxv_first, SimGraph &S, int &n_big_tiles) {
+    const agx_u32 n_pos = (agx_u32)T.ref.size();
+    const agx_u32 n_tiles = (n_pos + AGX_TILE - 1) / AGX_TILE;
+    // hit_prep
+    std::vector<agx_dhit> dh(P.hits.size());
+    for (agx_u32 h = 0; h < P.hits.size(); h++)
+        if (agx_hit_prep(P.hits.data(), P.runs.data(), h, k, dh[h]) != 0) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
+    // binning: (tile, hit) pairs in (tile, hit) order
+    std::vector<std::vector<agx_u32> > lists(n_tiles);
+    for (agx_u32 h = 0; h < dh.size(); h++) {
+        if (dh[h].flags & AGX_HF_SKIP) continue;
+        if (dh[h].x_hi >= n_pos) throw Error{E_FORMAT, "alignment beyond the end of the unit sequence"};
+        for (agx_u32 t = dh[h].x_lo / AGX_TILE; t <= dh[h].x_hi / AGX_TILE; t++) lists[t].push_back(h);
+    }
+    std::vector<agx_u32> tile_off(n_tiles + 1, 0), tile_hits;
+    for (agx_u32 t = 0; t < n_tiles; t++) { tile_off[t] = (agx_u32)tile_hits.size(); tile_hits.insert(tile_hits.end(), lists[t].begin(), lists[t].end()); }
+    tile_off[n_tiles] = (agx_u32)tile_hits.size();
+
+    std::vector<agx_cmkey> cmk(T.cm.size());
+    for (size_t i = 0; i < T.cm.size(); i++) cmk[i] = agx_cmkey{T.cm[i].cid, T.cm[i].coff};
+
+    S.node_start.assign(n_pos, 0); S.node_cnt.assign(n_pos, 0);
+    S.reserve((size_t)n_pos * 2 + 1024);
+    agx_sweep_args A; memset(&A, 0, sizeof A);
+    A.cm_start = T.cm_start.data(); A.cm = cmk.data(); A.ref = T.ref.data();
+    A.dhit = dh.data(); A.runs = P.runs.data(); A.bases = P.bases.data(); A.stride = P.stride;
+    A.tile_off = tile_off.data(); A.tile_hits = tile_hits.data();
+    A.n_pos = n_pos; A.n_tiles = n_tiles; A.k = k; A.iv = iv; A.coverage = coverage;
+    auto bind = [&]() {
+        A.node_start = S.node_start.data(); A.node_cnt = S.node_cnt.data();
+        A.nk_cid = S.cid.data(); A.nk_coff = S.coff.data(); A.nk_cid0 = S.cid0.data(); A.nk_coff0 = S.coff0.data(); A.nk_off0 = S.off0.data();
+        A.n_xpos = S.xpos.data(); A.n_base = S.base.data(); A.n_flags = S.flags.data(); A.n_sref = S.sref.data(); A.n_next = S.next.data();
+        A.n_counts = S.counts.data(); A.pool_cap = (agx_u32)S.cid.size();
+    };
+    bind();
+    n_big_tiles = 0;
+    agx_u32 pool = 0;
+    std::vector<agx_u32> lds((size_t)AGX_NF * maxv_first * AGX_TILE), big;
+    for (agx_u32 t = 0; t < n_tiles; t++) {
+        agx_u32 cnt[AGX_TILE]; bool ok = true;
+        agx_bucket b{nullptr, AGX_TILE, maxv_first};
+        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) { b.base = lds.data() + lane; ok &= agx_node_sweep_lane(A, t, t * AGX_TILE + lane, b, cnt[lane]); }
+        agx_u32 *store = lds.data(); agx_u32 maxv = maxv_first;
+        if (!ok) {                                     // the fallback the engine runs for overflowed tiles
+            n_big_tiles++;
+            big.assign((size_t)AGX_NF * AGX_MAXV_BIG * AGX_TILE, 0); store = big.data(); maxv = AGX_MAXV_BIG;
+            agx_bucket bb{nullptr, AGX_TILE, maxv};
+            for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
+                bb.base = store + lane;
+                if (!agx_node_sweep_lane(A, t, t * AGX_TILE + lane, bb, cnt[lane])) throw Error{E_OVERFLOW, "more than AGX_MAXV_BIG node variants at one position"};
+            }
+        }
+        agx_u32 total = 0; for (agx_u32 lane = 0; lane < AGX_TILE; lane++) total += cnt[lane];
+        if (pool + total > S.cid.size()) { S.reserve((pool + total) * 2); bind(); }
+        agx_bucket wb{nullptr, AGX_TILE, maxv};
+        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) { wb.base = store + lane; agx_node_write_lane(A, t * AGX_TILE + lane, wb, cnt[lane], pool); pool += cnt[lane]; }
+    }
+    S.n_nodes = pool;
+    for (agx_u32 t = 0; t < n_tiles; t++)
+        for (agx_u32 lane = 0; lane < AGX_TILE; lane++)
+            agx_edge_sweep_lane(A, t, t * AGX_TILE + lane, [&](agx_u32 s, agx_u32 d) { S.ovf.push_back(agx_edge_ovf{s, d}); });
+}
+
+char *dup_buf(const std::string &s) { char *p = (char *)malloc(s.size() + 1); memcpy(p, s.data(), s.size()); p[s.size()] = 0; return p; }
+
+}  // namespace
+
+extern "C" {
+
+typedef struct {
+    char *initial_contigs; size_t initial_len;
+    char *pre_extended; size_t pre_len;
+    char *extended; size_t extended_len;
+    char error[256];
+    uint32_t n_pos, n_nodes, n_edges; int32_t n_big_tiles;
+    uint32_t *node_start;   // canonical (position-ordered) numbering, same layout as the oracle's dump
+    uint32_t *node_key; int32_t *node_cnt; uint32_t *node_slen; uint32_t *edge_start; uint32_t *edge_dst;   // edge_dst sorted per node
+} agx_hostsim_result;
+
+int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int coverage, long batch, int maxv_first, int want_graph, agx_hostsim_result *out) {
+    memset(out, 0, sizeof *out);
+    try {
+        const std::string d = tmp_dir, u = std::to_string(unit);
+        Threads T; Pairs P;
+        load_unit_reference(d + "/_genome." + u + ".fa", T.ref);
+        thread_contigs_from_files(d + "/_contigs.fa", d + "/_contigs_genome." + u + ".psl", T);
+        load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + u + ".bowtie", batch, (agx_u32)k, P);
+        SimGraph S; int nbig = 0;
+        simulate(T, P, (agx_u32)k, iv, coverage, maxv_first > 0 ? (agx_u32)maxv_first : AGX_MAXV_LDS, S, nbig);
+        GraphView G; G.n_pos = (agx_u32)T.ref.size(); G.n_nodes = S.n_nodes; G.node_start = S.node_start.data(); G.node_cnt = S.node_cnt.data();
+        G.base = S.base.data(); G.flags = S.flags.data(); G.off0 = S.off0.data(); G.xpos = S.xpos.data(); G.sref = S.sref.data(); G.next = S.next.data();
+        G.ovf = S.ovf.data(); G.n_ovf = S.ovf.size();
+        UnitOutput O; walk_join_scaffold(T, P, G, O);
+        out->initial_contigs = dup_buf(O.initial_contigs); out->initial_len = O.initial_contigs.size();
+        out->pre_extended = dup_buf(O.pre_extended); out->pre_len = O.pre_extended.size();
+        out->extended = dup_buf(O.extended); out->extended_len = O.extended.size();
+        out->n_big_tiles = nbig;
+        if (want_graph) {
+            const agx_u32 n_pos = G.n_pos, nn = S.n_nodes;
+            out->n_pos = n_pos; out->n_nodes = nn;
+            out->node_start = (uint32_t *)malloc(4 * ((size_t)n_pos + 1));
+            std::vector<agx_u32> canon(nn);
+            agx_u32 id = 0;
+            for (agx_u32 x = 0; x < n_pos; x++) { out->node_start[x] = id; for (agx_u32 v = 0; v < S.node_cnt[x]; v++) canon[S.node_start[x] + v] = id++; }
+            out->node_start[n_pos] = id;
+            out->node_key = (uint32_t *)malloc(4 * 6 * ((size_t)nn + 1)); out->node_cnt = (int32_t *)malloc(4 * 6 * ((size_t)nn + 1));
+            out->node_slen = (uint32_t *)malloc(4 * ((size_t)nn + 1)); out->edge_start = (uint32_t *)malloc(4 * ((size_t)nn + 1));
+            std::vector<std::vector<agx_u32> > adj(nn);
+            for (agx_u32 v = 0; v < nn; v++) for (agx_u32 e = 0; e < AGX_MAXE; e++) if (S.next[(size_t)v * AGX_MAXE + e] != AGX_NONE) adj[canon[v]].push_back(canon[S.next[(size_t)v * AGX_MAXE + e]]);
+            for (const agx_edge_ovf &e : S.ovf) adj[canon[e.src]].push_back(canon[e.dst]);
+            size_t ne = 0;
+            for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); ne += a.size(); }
+            out->n_edges = (uint32_t)ne; out->edge_dst = (uint32_t *)malloc(4 * (ne + 1));
+            size_t eo = 0;
+            for (agx_u32 v = 0; v < nn; v++) {
+                const agx_u32 c = canon[v];
+                uint32_t *kk = out->node_key + 6 * (size_t)c;
+                kk[0] = S.cid[v]; kk[1] = S.coff[v]; kk[2] = S.cid0[v]; kk[3] = S.coff0[v]; kk[4] = S.off0[v] == AGX_NONE ? AGX_NONE : 0; kk[5] = S.off0[v];
+                memcpy(out->node_cnt + 6 * (size_t)c, S.counts.data() + 6 * (size_t)v, 24);
+                out->node_slen[c] = (S.sref[v].qlen >> 16) & 0x7FFF;
+            }
+            for (agx_u32 c = 0; c < nn; c++) { out->edge_start[c] = (uint32_t)eo; for (agx_u32 d2 : adj[c]) out->edge_dst[eo++] = d2; }
+            out->edge_start[nn] = (uint32_t)eo;
+        }
+        return 0;
+    } catch (const Error &e) {
+        snprintf(out->error, sizeof out->error, "%s", e.msg.c_str());
+        return e.code ? e.code : -1;
+    }
+}
+
+void agx_hostsim_free(agx_hostsim_result *r) {
+    free(r->initial_contigs); free(r->pre_extended); free(r->extended);
+    free(r->node_start); free(r->node_key); free(r->node_cnt); free(r->node_slen); free(r->edge_start); free(r->edge_dst);
+    memset(r, 0, sizeof *r);
+}
+
+}  // extern "C"

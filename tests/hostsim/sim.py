@@ -1,0 +1,73 @@
+"""ctypes driver of tests/hostsim/libagx_hostsim.so (TEST-ONLY serial executor of the engine kernels)."""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "libagx_hostsim.so")
+SRC = [os.path.join(HERE, "agx_hostsim.cpp"), os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_host.cpp"),
+       os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_walk.cpp")]
+DEPS = SRC + [os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_core.h"), os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_host.h")]
+
+
+def build():
+    if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in DEPS):
+        return
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-fPIC", "-shared", "-o", LIB] + SRC)
+
+
+class _Result(ctypes.Structure):
+    _fields_ = [
+        ("initial_contigs", ctypes.c_void_p), ("initial_len", ctypes.c_size_t),
+        ("pre_extended", ctypes.c_void_p), ("pre_len", ctypes.c_size_t),
+        ("extended", ctypes.c_void_p), ("extended_len", ctypes.c_size_t),
+        ("error", ctypes.c_char * 256),
+        ("n_pos", ctypes.c_uint32), ("n_nodes", ctypes.c_uint32), ("n_edges", ctypes.c_uint32), ("n_big_tiles", ctypes.c_int32),
+        ("node_start", ctypes.POINTER(ctypes.c_uint32)), ("node_key", ctypes.POINTER(ctypes.c_uint32)),
+        ("node_cnt", ctypes.POINTER(ctypes.c_int32)), ("node_slen", ctypes.POINTER(ctypes.c_uint32)),
+        ("edge_start", ctypes.POINTER(ctypes.c_uint32)), ("edge_dst", ctypes.POINTER(ctypes.c_uint32)),
+    ]
+
+
+_lib = None
+
+
+class SimError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%d: %s" % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+def run(tmp_dir, unit, k=5, insert_variation=50, coverage=20, batch=1000000, maxv_first=0, graph=False):
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(LIB)
+        _lib.agx_hostsim_run_unit.argtypes = [ctypes.c_char_p] + [ctypes.c_int] * 4 + [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_Result)]
+        _lib.agx_hostsim_free.argtypes = [ctypes.POINTER(_Result)]
+    r = _Result()
+    rc = _lib.agx_hostsim_run_unit(tmp_dir.encode(), unit, k, insert_variation, coverage, batch, maxv_first, 1 if graph else 0, ctypes.byref(r))
+    if rc != 0:
+        msg = r.error.decode()
+        _lib.agx_hostsim_free(ctypes.byref(r))
+        raise SimError(rc, msg)
+    out = {"initial": ctypes.string_at(r.initial_contigs, r.initial_len), "pre": ctypes.string_at(r.pre_extended, r.pre_len),
+           "extended": ctypes.string_at(r.extended, r.extended_len), "n_big_tiles": r.n_big_tiles}
+    if graph:
+        import numpy as np
+
+        def arr(p, n, dt):
+            return np.ctypeslib.as_array(p, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+        out["graph"] = {
+            "n_pos": r.n_pos, "n_nodes": r.n_nodes, "n_edges": r.n_edges,
+            "node_start": arr(r.node_start, r.n_pos + 1, "uint32"),
+            "node_key": arr(r.node_key, r.n_nodes * 6, "uint32").reshape(-1, 6),
+            "node_cnt": arr(r.node_cnt, r.n_nodes * 6, "int32").reshape(-1, 6),
+            "node_slen": arr(r.node_slen, r.n_nodes, "uint32"),
+            "edge_start": arr(r.edge_start, r.n_nodes + 1, "uint32"),
+            "edge_dst": arr(r.edge_dst, r.n_edges, "uint32"),
+        }
+    _lib.agx_hostsim_free(ctypes.byref(r))
+    return out
