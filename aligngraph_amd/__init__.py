@@ -1,0 +1,198 @@
+"""aligngraph_amd — ctypes binding of libagx.so (include/agx.h), the MI355X engine for AlignGraph's per-unit
+graph build + extend path (reference seam: AlignGraph/AlignGraph.cpp:4765-4783).
+
+The library is the product; this module only loads it, mirrors the C structs and raises on error codes.
+There is no CPU fallback: without a HIP device `Unit(...)` raises AgxError(AGX_E_NOGPU).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libagx.so")
+
+AGX_OK, AGX_E_IO, AGX_E_FORMAT, AGX_E_UNSUPPORTED, AGX_E_ALIGNMENT, AGX_E_DEVICE, AGX_E_ARG, AGX_E_OVERFLOW, AGX_E_NOGPU = 0, -1, -2, -3, -4, -5, -6, -7, -8
+AGX_FLAG_KEEP_COUNTS = 1
+
+# every symbol include/agx.h declares (tests check that the built library exports all of them)
+EXPORTS = [
+    "agx_version", "agx_device_count", "agx_unit_create", "agx_unit_destroy", "agx_unit_error", "agx_unit_set_reference",
+    "agx_unit_set_contig_threads", "agx_unit_push_pairs", "agx_unit_load_files", "agx_unit_upload", "agx_unit_build",
+    "agx_unit_finish", "agx_result_free", "agx_unit_stats", "agx_unit_graph", "agx_graph_free", "agx_run_unit",
+]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_uint32), ("insert_variation", ctypes.c_uint32), ("coverage", ctypes.c_uint32),
+                ("batch", ctypes.c_uint32), ("device", ctypes.c_int32), ("flags", ctypes.c_uint32)]
+
+
+class Run(ctypes.Structure):
+    _fields_ = [("q", ctypes.c_uint32), ("t", ctypes.c_uint32), ("n", ctypes.c_uint32)]
+
+
+class Hit(ctypes.Structure):
+    _fields_ = [("slot1", ctypes.c_uint32), ("pos1", ctypes.c_uint32), ("pos2", ctypes.c_uint32), ("runs1", ctypes.c_uint32),
+                ("runs2", ctypes.c_uint32), ("nruns1", ctypes.c_uint16), ("nruns2", ctypes.c_uint16), ("len", ctypes.c_uint16),
+                ("rev1", ctypes.c_uint8), ("rev2", ctypes.c_uint8), ("back", ctypes.c_uint8), ("pad", ctypes.c_uint8 * 3)]
+
+
+class ContiMer(ctypes.Structure):
+    _fields_ = [("cid", ctypes.c_uint32), ("coff", ctypes.c_uint32), ("next_off", ctypes.c_uint32), ("next_item", ctypes.c_uint32),
+                ("nuc", ctypes.c_char), ("pad", ctypes.c_char * 3)]
+
+
+class PairBatch(ctypes.Structure):
+    _fields_ = [("hits", ctypes.POINTER(Hit)), ("n_hits", ctypes.c_uint64), ("runs", ctypes.POINTER(Run)), ("n_runs", ctypes.c_uint64),
+                ("bases", ctypes.c_char_p), ("stride", ctypes.c_uint32), ("n_slots", ctypes.c_uint32)]
+
+
+class Result(ctypes.Structure):
+    _fields_ = [("initial_contigs", ctypes.c_void_p), ("initial_len", ctypes.c_size_t), ("pre_extended", ctypes.c_void_p),
+                ("pre_len", ctypes.c_size_t), ("extended", ctypes.c_void_p), ("extended_len", ctypes.c_size_t)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("n_pos", "n_ref", "n_hits", "n_runs", "n_nodes", "n_tiles", "n_tile_entries", "n_big_tiles",
+                                                "n_edge_overflow", "pairs_in_file", "sam_line_pairs")] + \
+               [(n, ctypes.c_double) for n in ("ms_parse", "ms_thread", "ms_upload", "ms_prep", "ms_bin", "ms_node_sweep", "ms_node_big",
+                                                "ms_edge_sweep", "ms_download", "ms_walk")] + \
+               [("node_sweep_launches", ctypes.c_uint32), ("edge_sweep_launches", ctypes.c_uint32)]
+
+
+class Graph(ctypes.Structure):
+    _fields_ = [("n_pos", ctypes.c_uint32), ("n_nodes", ctypes.c_uint32), ("n_edges", ctypes.c_uint32),
+                ("node_start", ctypes.POINTER(ctypes.c_uint32)), ("node_key", ctypes.POINTER(ctypes.c_uint32)),
+                ("node_cnt", ctypes.POINTER(ctypes.c_int32)), ("node_slen", ctypes.POINTER(ctypes.c_uint32)),
+                ("edge_start", ctypes.POINTER(ctypes.c_uint32)), ("edge_dst", ctypes.POINTER(ctypes.c_uint32))]
+
+
+class AgxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("agx error %d: %s" % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+_lib = None
+
+
+def lib():
+    """Loads libagx.so (build it first with `python -m aligngraph_amd.build` or __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError("%s is missing: run `python aligngraph_amd/build.py` (needs hipcc)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.agx_version.restype = ctypes.c_char_p
+        L.agx_device_count.restype = ctypes.c_int
+        L.agx_unit_create.argtypes = [ctypes.POINTER(Params), ctypes.POINTER(ctypes.c_void_p)]
+        L.agx_unit_destroy.argtypes = [ctypes.c_void_p]
+        L.agx_unit_destroy.restype = None
+        L.agx_unit_error.argtypes = [ctypes.c_void_p]
+        L.agx_unit_error.restype = ctypes.c_char_p
+        L.agx_unit_set_reference.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint32]
+        L.agx_unit_set_contig_threads.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),
+                                                  ctypes.POINTER(ContiMer), ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+        L.agx_unit_push_pairs.argtypes = [ctypes.c_void_p, ctypes.POINTER(PairBatch)]
+        L.agx_unit_load_files.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+        for f in ("agx_unit_upload", "agx_unit_build"):
+            getattr(L, f).argtypes = [ctypes.c_void_p]
+        L.agx_unit_finish.argtypes = [ctypes.c_void_p, ctypes.POINTER(Result)]
+        L.agx_result_free.argtypes = [ctypes.POINTER(Result)]
+        L.agx_result_free.restype = None
+        L.agx_unit_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
+        L.agx_unit_graph.argtypes = [ctypes.c_void_p, ctypes.POINTER(Graph)]
+        L.agx_graph_free.argtypes = [ctypes.POINTER(Graph)]
+        L.agx_graph_free.restype = None
+        L.agx_run_unit.argtypes = [ctypes.POINTER(Params), ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Result), ctypes.c_char_p, ctypes.c_size_t]
+        _lib = L
+    return _lib
+
+
+def device_count():
+    return lib().agx_device_count()
+
+
+def _take(res):
+    out = {"initial": ctypes.string_at(res.initial_contigs, res.initial_len) if res.initial_contigs else b"",
+           "pre": ctypes.string_at(res.pre_extended, res.pre_len) if res.pre_extended else b"",
+           "extended": ctypes.string_at(res.extended, res.extended_len) if res.extended else b""}
+    lib().agx_result_free(ctypes.byref(res))
+    return out
+
+
+class Unit:
+    """One reference unit (chromosome or --part slice): the body of the reference's unit loop, AG:4765-4783."""
+
+    def __init__(self, k=5, insert_variation=50, coverage=20, batch=0, device=0, keep_counts=False):
+        self._h = ctypes.c_void_p()
+        self.params = Params(k, insert_variation, coverage, batch, device, AGX_FLAG_KEEP_COUNTS if keep_counts else 0)
+        rc = lib().agx_unit_create(ctypes.byref(self.params), ctypes.byref(self._h))
+        if rc != AGX_OK:
+            self._h = ctypes.c_void_p()
+            raise AgxError(rc, "no HIP device (libagx has no CPU path)" if rc == AGX_E_NOGPU else "agx_unit_create failed")
+
+    def _check(self, rc):
+        if rc != AGX_OK:
+            raise AgxError(rc, lib().agx_unit_error(self._h).decode(errors="replace"))
+
+    def close(self):
+        if self._h:
+            lib().agx_unit_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_files(self, tmp_dir, unit):
+        self._check(lib().agx_unit_load_files(self._h, tmp_dir.encode(), unit))
+
+    def upload(self):
+        self._check(lib().agx_unit_upload(self._h))
+
+    def build(self):
+        self._check(lib().agx_unit_build(self._h))
+
+    def finish(self):
+        r = Result()
+        self._check(lib().agx_unit_finish(self._h, ctypes.byref(r)))
+        return _take(r)
+
+    def stats(self):
+        s = Stats()
+        self._check(lib().agx_unit_stats(self._h, ctypes.byref(s)))
+        return {n: getattr(s, n) for n, _ in Stats._fields_}
+
+    def graph(self):
+        import numpy as np
+        g = Graph()
+        self._check(lib().agx_unit_graph(self._h, ctypes.byref(g)))
+
+        def arr(p, n, dt):
+            return np.ctypeslib.as_array(p, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+        out = {"n_pos": g.n_pos, "n_nodes": g.n_nodes, "n_edges": g.n_edges,
+               "node_start": arr(g.node_start, g.n_pos + 1, "uint32"), "node_key": arr(g.node_key, g.n_nodes * 6, "uint32").reshape(-1, 6),
+               "node_cnt": arr(g.node_cnt, g.n_nodes * 6, "int32").reshape(-1, 6), "node_slen": arr(g.node_slen, g.n_nodes, "uint32"),
+               "edge_start": arr(g.edge_start, g.n_nodes + 1, "uint32"), "edge_dst": arr(g.edge_dst, g.n_edges, "uint32")}
+        lib().agx_graph_free(ctypes.byref(g))
+        return out
+
+
+def run_unit(tmp_dir, unit, k=5, insert_variation=50, coverage=20, batch=0, device=0, write_files=False):
+    """The five-call seam in one call (agx_run_unit)."""
+    p = Params(k, insert_variation, coverage, batch, device, 0)
+    r = Result()
+    err = ctypes.create_string_buffer(512)
+    rc = lib().agx_run_unit(ctypes.byref(p), tmp_dir.encode(), unit, 1 if write_files else 0, ctypes.byref(r), err, 512)
+    if rc != AGX_OK:
+        raise AgxError(rc, err.value.decode(errors="replace"))
+    return _take(r)

@@ -1,0 +1,51 @@
+"""Builds aligngraph_amd/libagx.so for gfx950 (hipcc for the kernels, g++ for the host side)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libagx.so")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HOST_SRC = ["agx_engine.cpp", "agx_host.cpp", "agx_walk.cpp"]
+DEV_SRC = ["agx_kernels.hip"]
+HEADERS = ["agx_core.h", "agx_host.h", "agx_kargs.h", os.path.join("..", "..", "include", "agx.h")]
+
+
+def _stale(out, deps):
+    return not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.path.join(ROCM, "bin", "hipcc")
+    objdir = os.path.join(HERE, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for s in DEV_SRC:
+        o = os.path.join(objdir, s + ".o")
+        if force or _stale(o, [os.path.join(CSRC, s)] + hdrs):
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, s), "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(o)
+    for s in HOST_SRC:
+        o = os.path.join(objdir, s + ".o")
+        if force or _stale(o, [os.path.join(CSRC, s)] + hdrs):
+            cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"),
+                   "-c", os.path.join(CSRC, s), "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

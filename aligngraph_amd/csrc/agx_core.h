@@ -21,6 +21,7 @@
 //    buckets — no atomics, no dependence on scheduling, bit-exact by construction.
 #pragma once
 #include <stdint.h>
+#include "../../include/agx.h"
 
 #if defined(__HIPCC__)
 #define AGX_HD __host__ __device__ __forceinline__
@@ -41,19 +42,7 @@ typedef uint8_t agx_u8;
 
 // ---- packed inputs (host -> device) -----------------------------------------------------------------
 
-struct agx_run { agx_u32 q, t, n; };          // n read bases from read index q sit on reference offsets t.. (Segment, AG:44-49)
-
-// One (pair, hit) that passed the identity filter of loadReadAli (AG:1261), in SAM order.
-struct agx_hit {
-    agx_u32 slot1;            // mate1's slot in the read-base blob; mate2 is slot1+1
-    agx_u32 pos1, pos2;       // "simple" mates (one M run covering the whole read): reference offset of read index 0
-    agx_u32 runs1, runs2;     // first run in the run pool (non-simple mates)
-    agx_u16 nruns1, nruns2;   // 0 = simple
-    agx_u16 len;              // read length (mates are equal length, AG:3454)
-    agx_u8 rev1, rev2;        // SAM FLAG 0x10 of each mate
-    agx_u8 back;              // number of earlier kept hits of the same pair
-    agx_u8 pad[3];
-};
+// agx_run and agx_hit are part of the public packed-array boundary: include/agx.h
 
 // per-position conti-mer key (the part of ContiMer, AG:51-62, that node build reads)
 struct agx_cmkey { agx_u32 cid, coff; };

@@ -1,0 +1,458 @@
+// agx_engine.cpp — unit object, device memory, kernel sequencing and the C-ABI of libagx.so (include/agx.h).
+//
+// One agx_unit = one reference unit (chromosome or --part slice) = the body of the reference's unit loop
+// (AG:4765-4783).  Device residency: every packed input is uploaded once (agx_unit_upload) and stays in HBM;
+// agx_unit_build only launches kernels on the unit's own HIP stream; agx_unit_finish downloads the node table
+// into pinned host memory and runs the sequential walk.  No CPU fallback exists: a host without a HIP device
+// gets AGX_E_NOGPU from agx_unit_create.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "agx_host.h"
+
+#include "agx_kargs.h"
+
+using namespace agx;
+
+namespace {
+
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw Error{E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)}; } while (0)
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+template <class T> struct DBuf {            // device buffer
+    T *p = nullptr; size_t n = 0;
+    void alloc(size_t count) { if (count <= n && p) return; release(); if (count) { HIP_OK(hipMalloc((void **)&p, count * sizeof(T))); n = count; } }
+    void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+    ~DBuf() { release(); }
+    DBuf() = default; DBuf(const DBuf &) = delete; DBuf &operator=(const DBuf &) = delete;
+};
+template <class T> struct PBuf {            // pinned host buffer
+    T *p = nullptr; size_t n = 0;
+    void alloc(size_t count) { if (count <= n && p) return; release(); if (count) { HIP_OK(hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault)); n = count; } }
+    void release() { if (p) hipHostFree(p); p = nullptr; n = 0; }
+    ~PBuf() { release(); }
+    PBuf() = default; PBuf(const PBuf &) = delete; PBuf &operator=(const PBuf &) = delete;
+};
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr; bool used = false;
+    void init() { HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); }
+    void destroy() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); a = b = nullptr; }
+    double ms() const { if (!used) return 0; float f = 0; hipEventElapsedTime(&f, a, b); return f; }
+};
+
+}  // namespace
+
+struct agx_unit {
+    agx_params prm{};
+    std::string err;
+    Threads T; Pairs P;
+    bool have_ref = false, have_threads = false, uploaded = false, built = false, downloaded = false;
+    hipStream_t st = nullptr;
+    // inputs on the device
+    DBuf<agx_u32> d_cm_start; DBuf<agx_cmkey> d_cm; DBuf<char> d_ref;
+    DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<char> d_bases;
+    // derived
+    DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_hits, d_scan_tmp, d_words;   // d_words: counters/status
+    // node table
+    agx_u32 pool_cap = 0, ovf_cap = 0;
+    DBuf<agx_u32> d_node_start; DBuf<agx_u8> d_node_cnt;
+    DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
+    DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_big_list, d_scratch;
+    // downloaded
+    PBuf<agx_u32> h_node_start, h_off0, h_xpos, h_next; PBuf<agx_u8> h_node_cnt, h_base, h_flags; PBuf<agx_sref> h_sref; PBuf<agx_edge_ovf> h_ovf;
+    PBuf<agx_u32> h_words;
+    agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0;
+    EventPair ev_prep, ev_bin, ev_node, ev_big, ev_edge;
+    agx_stats stats{};
+    ~agx_unit() { ev_prep.destroy(); ev_bin.destroy(); ev_node.destroy(); ev_big.destroy(); ev_edge.destroy(); if (st) hipStreamDestroy(st); }
+};
+
+namespace {
+
+enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_N = 8 };
+
+void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
+    memset(&S, 0, sizeof S);
+    S.cm_start = u->d_cm_start.p; S.cm = u->d_cm.p; S.ref = u->d_ref.p;
+    S.dhit = u->d_dhit.p; S.runs = u->d_runs.p; S.bases = u->d_bases.p; S.stride = u->P.stride;
+    S.tile_off = u->d_tile_off.p; S.tile_hits = u->d_tile_hits.p;
+    S.n_pos = (agx_u32)u->T.ref.size(); S.n_tiles = u->n_tiles; S.k = u->prm.k; S.iv = (int)u->prm.insert_variation; S.coverage = (int)u->prm.coverage;
+    S.node_start = u->d_node_start.p; S.node_cnt = u->d_node_cnt.p;
+    S.nk_cid = u->d_cid.p; S.nk_coff = u->d_coff.p; S.nk_cid0 = u->d_cid0.p; S.nk_coff0 = u->d_coff0.p; S.nk_off0 = u->d_off0.p;
+    S.n_xpos = u->d_xpos.p; S.n_base = u->d_base.p; S.n_flags = u->d_flags.p; S.n_sref = u->d_sref.p; S.n_next = u->d_next.p;
+    S.n_counts = (u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? u->d_counts.p : nullptr;
+    S.pool_cap = u->pool_cap;
+}
+
+void alloc_pool(agx_unit *u, agx_u32 cap) {
+    u->pool_cap = cap;
+    u->d_cid.alloc(cap); u->d_coff.alloc(cap); u->d_cid0.alloc(cap); u->d_coff0.alloc(cap); u->d_off0.alloc(cap); u->d_xpos.alloc(cap);
+    u->d_next.alloc((size_t)cap * AGX_MAXE); u->d_base.alloc(cap); u->d_flags.alloc(cap); u->d_sref.alloc(cap);
+    if (u->prm.flags & AGX_FLAG_KEEP_COUNTS) u->d_counts.alloc((size_t)cap * 6);
+}
+
+void do_upload(agx_unit *u) {
+    if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
+    const double t0 = now_ms();
+    HIP_OK(hipSetDevice(u->prm.device));
+    const size_t n_pos = u->T.ref.size();
+    if (n_pos == 0 || n_pos >= 0xFFFFFF00ull) throw Error{E_ARG, "unit sequence is empty or too long"};
+    if (u->T.cm_start.size() != n_pos + 1) throw Error{E_ARG, "contig thread table does not match the position count"};
+    std::vector<agx_cmkey> keys(u->T.cm.size());
+    for (size_t i = 0; i < keys.size(); i++) keys[i] = agx_cmkey{u->T.cm[i].cid, u->T.cm[i].coff};
+    u->d_cm_start.alloc(n_pos + 1); u->d_cm.alloc(keys.size() + 1); u->d_ref.alloc(n_pos);
+    HIP_OK(hipMemcpyAsync(u->d_cm_start.p, u->T.cm_start.data(), (n_pos + 1) * 4, hipMemcpyHostToDevice, u->st));
+    if (!keys.empty()) HIP_OK(hipMemcpyAsync(u->d_cm.p, keys.data(), keys.size() * sizeof(agx_cmkey), hipMemcpyHostToDevice, u->st));
+    HIP_OK(hipMemcpyAsync(u->d_ref.p, u->T.ref.data(), n_pos, hipMemcpyHostToDevice, u->st));
+    const size_t nh = u->P.hits.size();
+    u->d_hits.alloc(nh + 1); u->d_runs.alloc(u->P.runs.size() + 1); u->d_bases.alloc(u->P.bases.size() + 16); u->d_dhit.alloc(nh + 1);
+    if (nh) HIP_OK(hipMemcpyAsync(u->d_hits.p, u->P.hits.data(), nh * sizeof(agx_hit), hipMemcpyHostToDevice, u->st));
+    if (!u->P.runs.empty()) HIP_OK(hipMemcpyAsync(u->d_runs.p, u->P.runs.data(), u->P.runs.size() * sizeof(agx_run), hipMemcpyHostToDevice, u->st));
+    if (!u->P.bases.empty()) HIP_OK(hipMemcpyAsync(u->d_bases.p, u->P.bases.data(), u->P.bases.size(), hipMemcpyHostToDevice, u->st));
+    u->n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
+    u->d_tile_cnt.alloc((size_t)u->n_tiles + 1); u->d_tile_off.alloc((size_t)u->n_tiles + 2); u->d_cursor.alloc((size_t)u->n_tiles + 1);
+    const size_t nb = ((size_t)u->n_tiles + 1 + 1023) / 1024;
+    u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16);
+    u->d_words.alloc(W_N); u->h_words.alloc(W_N);
+    u->d_node_start.alloc(n_pos); u->d_node_cnt.alloc(n_pos);
+    if (u->pool_cap == 0) alloc_pool(u, (agx_u32)std::min<size_t>(2 * n_pos + 4096, 0xFFFFFF00ull));
+    if (u->ovf_cap == 0) { u->ovf_cap = 1u << 16; u->d_ovf.alloc(u->ovf_cap); }
+    HIP_OK(hipStreamSynchronize(u->st));
+    u->uploaded = true; u->built = false; u->downloaded = false;
+    u->stats.ms_upload = now_ms() - t0;
+}
+
+void read_words(agx_unit *u) {
+    HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, W_N * 4, hipMemcpyDeviceToHost, u->st));
+    HIP_OK(hipStreamSynchronize(u->st));
+}
+
+void do_build(agx_unit *u) {
+    if (!u->uploaded) do_upload(u);
+    HIP_OK(hipSetDevice(u->prm.device));
+    const agx_u32 n_pos = (agx_u32)u->T.ref.size(), nh = (agx_u32)u->P.hits.size();
+    hipStream_t st = u->st;
+    u->stats.node_sweep_launches = u->stats.edge_sweep_launches = 0;
+
+    // ---- hit_prep + tile histogram ----
+    HIP_OK(hipMemsetAsync(u->d_words.p, 0, W_N * 4, st));
+    HIP_OK(hipMemsetAsync(u->d_tile_cnt.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
+    HIP_OK(hipMemsetAsync(u->d_cursor.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
+    HIP_OK(hipEventRecord(u->ev_prep.a, st));
+    agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR};
+    agx_launch_hit_prep(&PA, st);
+    HIP_OK(hipEventRecord(u->ev_prep.b, st)); u->ev_prep.used = true;
+
+    // ---- tile lists ----
+    HIP_OK(hipEventRecord(u->ev_bin.a, st));
+    agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
+    HIP_OK(hipMemcpyAsync(u->h_words.p + W_N - 1, u->d_tile_off.p + u->n_tiles, 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (u->h_words.p[W_ERR] & 1u) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
+    if (u->h_words.p[W_ERR] & 2u) throw Error{E_UNSUPPORTED, "read alignment beyond the end of the unit sequence"};
+    u->n_tile_entries = u->h_words.p[W_N - 1];
+    u->d_unsorted.alloc((size_t)u->n_tile_entries + 1); u->d_tile_hits.alloc((size_t)u->n_tile_entries + 1);
+    agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p};
+    agx_launch_bin_fill(&BA, st);
+    agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->d_tile_hits.p, u->n_tiles, st);
+    HIP_OK(hipEventRecord(u->ev_bin.b, st)); u->ev_bin.used = true;
+
+    // ---- node sweep (re-run with a larger pool if the first guess was too small) ----
+    u->d_big_list.alloc((size_t)u->n_tiles + 1);
+    for (;;) {
+        HIP_OK(hipMemsetAsync(u->d_words.p + W_POOL, 0, 3 * 4, st));     // pool counter, big count, status
+        agx_node_kargs K; fill_sweep_args(u, K.S);
+        K.pool_counter = u->d_words.p + W_POOL; K.big_count = u->d_words.p + W_BIGCOUNT; K.big_list = u->d_big_list.p; K.status = u->d_words.p + W_STATUS;
+        K.tile_list = nullptr; K.n_list = 0; K.scratch = nullptr;
+        HIP_OK(hipEventRecord(u->ev_node.a, st));
+        agx_launch_node_sweep(&K, st);
+        HIP_OK(hipEventRecord(u->ev_node.b, st)); u->ev_node.used = true; u->stats.node_sweep_launches++;
+        read_words(u);
+        u->n_big = u->h_words.p[W_BIGCOUNT];
+        u->ev_big.used = false;
+        if (u->n_big && !(u->h_words.p[W_STATUS] & 1u)) {
+            // tiles whose buckets outgrew LDS: same sweep with buckets in global scratch, in chunks that bound the scratch size
+            const agx_u32 chunk = 4096;
+            u->d_scratch.alloc((size_t)std::min(u->n_big, chunk) * AGX_NF * AGX_MAXV_BIG * 64);
+            HIP_OK(hipEventRecord(u->ev_big.a, st));
+            for (agx_u32 off = 0; off < u->n_big; off += chunk) {
+                K.tile_list = u->d_big_list.p + off; K.n_list = std::min(chunk, u->n_big - off); K.scratch = u->d_scratch.p;
+                agx_launch_node_sweep_big(&K, st);
+            }
+            HIP_OK(hipEventRecord(u->ev_big.b, st)); u->ev_big.used = true;
+            read_words(u);
+        }
+        if (u->h_words.p[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 64 node variants at one position"};
+        const unsigned long long want = u->h_words.p[W_POOL];
+        if ((u->h_words.p[W_STATUS] & 1u) || want > u->pool_cap) {
+            const unsigned long long cap = std::min<unsigned long long>(std::max<unsigned long long>(want + want / 4 + 4096, 2ull * u->pool_cap), 0xFFFFFF00ull);
+            if (cap <= u->pool_cap) throw Error{E_OVERFLOW, "node table exceeds 2^32 entries"};
+            u->d_cid.release(); u->d_coff.release(); u->d_cid0.release(); u->d_coff0.release(); u->d_off0.release(); u->d_xpos.release();
+            u->d_next.release(); u->d_base.release(); u->d_flags.release(); u->d_sref.release(); u->d_counts.release();
+            alloc_pool(u, (agx_u32)cap);
+            continue;
+        }
+        u->n_nodes = (agx_u32)want;
+        break;
+    }
+
+    // ---- edge sweep (re-run with a larger overflow list if needed; slot writes are idempotent) ----
+    for (;;) {
+        HIP_OK(hipMemsetAsync(u->d_words.p + W_OVFCOUNT, 0, 4, st));
+        agx_edge_kargs E; fill_sweep_args(u, E.S); E.ovf = u->d_ovf.p; E.ovf_count = u->d_words.p + W_OVFCOUNT; E.ovf_cap = u->ovf_cap;
+        HIP_OK(hipEventRecord(u->ev_edge.a, st));
+        agx_launch_edge_sweep(&E, st);
+        HIP_OK(hipEventRecord(u->ev_edge.b, st)); u->ev_edge.used = true; u->stats.edge_sweep_launches++;
+        read_words(u);
+        const agx_u32 c = u->h_words.p[W_OVFCOUNT];
+        if (c > u->ovf_cap) { u->ovf_cap = c + c / 2 + 1024; u->d_ovf.release(); u->d_ovf.alloc(u->ovf_cap); continue; }
+        u->n_ovf = c;
+        break;
+    }
+    HIP_OK(hipGetLastError());
+    u->built = true; u->downloaded = false;
+    u->stats.ms_prep = u->ev_prep.ms(); u->stats.ms_bin = u->ev_bin.ms(); u->stats.ms_node_sweep = u->ev_node.ms();
+    u->stats.ms_node_big = u->ev_big.ms(); u->stats.ms_edge_sweep = u->ev_edge.ms();
+}
+
+void do_download(agx_unit *u) {
+    if (!u->built) do_build(u);
+    const double t0 = now_ms();
+    const size_t n_pos = u->T.ref.size(), nn = u->n_nodes;
+    hipStream_t st = u->st;
+    u->h_node_start.alloc(n_pos); u->h_node_cnt.alloc(n_pos);
+    u->h_off0.alloc(nn + 1); u->h_xpos.alloc(nn + 1); u->h_next.alloc((nn + 1) * AGX_MAXE); u->h_base.alloc(nn + 1); u->h_flags.alloc(nn + 1); u->h_sref.alloc(nn + 1);
+    u->h_ovf.alloc((size_t)u->n_ovf + 1);
+    HIP_OK(hipMemcpyAsync(u->h_node_start.p, u->d_node_start.p, n_pos * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(u->h_node_cnt.p, u->d_node_cnt.p, n_pos, hipMemcpyDeviceToHost, st));
+    if (nn) {
+        HIP_OK(hipMemcpyAsync(u->h_off0.p, u->d_off0.p, nn * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_xpos.p, u->d_xpos.p, nn * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_next.p, u->d_next.p, nn * AGX_MAXE * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_base.p, u->d_base.p, nn, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_flags.p, u->d_flags.p, nn, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_sref.p, u->d_sref.p, nn * sizeof(agx_sref), hipMemcpyDeviceToHost, st));
+    }
+    if (u->n_ovf) HIP_OK(hipMemcpyAsync(u->h_ovf.p, u->d_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    u->downloaded = true;
+    u->stats.ms_download = now_ms() - t0;
+}
+
+GraphView view_of(agx_unit *u) {
+    GraphView G; G.n_pos = (agx_u32)u->T.ref.size(); G.n_nodes = u->n_nodes; G.node_start = u->h_node_start.p; G.node_cnt = u->h_node_cnt.p;
+    G.base = u->h_base.p; G.flags = u->h_flags.p; G.off0 = u->h_off0.p; G.xpos = u->h_xpos.p; G.sref = u->h_sref.p; G.next = u->h_next.p;
+    G.ovf = u->h_ovf.p; G.n_ovf = u->n_ovf;
+    return G;
+}
+
+char *dup_buf(const std::string &s) { char *p = (char *)malloc(s.size() + 1); if (p) { memcpy(p, s.data(), s.size()); p[s.size()] = 0; } return p; }
+
+template <class F> int guarded(agx_unit *u, F f) {
+    try { f(); return AGX_OK; }
+    catch (const Error &e) { if (u) u->err = e.msg; return e.code ? e.code : AGX_E_ARG; }
+    catch (const std::bad_alloc &) { if (u) u->err = "out of host memory"; return AGX_E_ARG; }
+    catch (const std::exception &e) { if (u) u->err = e.what(); return AGX_E_ARG; }
+}
+
+void write_file(const std::string &path, const std::string &data) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) throw Error{E_IO, "CANNOT OPEN FILE! (" + path + ")"};
+    if (!data.empty() && fwrite(data.data(), 1, data.size(), f) != data.size()) { fclose(f); throw Error{E_IO, "short write to " + path}; }
+    fclose(f);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *agx_version(void) { return "aligngraph_amd 0.1 (gfx950)"; }
+
+int agx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+int agx_unit_create(const agx_params *p, agx_unit **out) {
+    if (!p || !out) return AGX_E_ARG;
+    *out = nullptr;
+    if (p->k == 0 || p->k >= 32768) return AGX_E_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return AGX_E_NOGPU;
+    if (p->device < 0 || p->device >= n) return AGX_E_ARG;
+    agx_unit *u = new (std::nothrow) agx_unit();
+    if (!u) return AGX_E_ARG;
+    u->prm = *p; if (u->prm.batch == 0) u->prm.batch = 1000000;
+    const int rc = guarded(u, [&] {
+        HIP_OK(hipSetDevice(p->device));
+        HIP_OK(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
+        u->ev_prep.init(); u->ev_bin.init(); u->ev_node.init(); u->ev_big.init(); u->ev_edge.init();
+    });
+    if (rc != AGX_OK) { delete u; return rc; }
+    *out = u;
+    return AGX_OK;
+}
+
+void agx_unit_destroy(agx_unit *u) { if (u) { hipSetDevice(u->prm.device); delete u; } }
+
+const char *agx_unit_error(const agx_unit *u) { return u ? u->err.c_str() : "null unit"; }
+
+int agx_unit_set_reference(agx_unit *u, const char *bases, uint32_t n) {
+    if (!u || (!bases && n)) return AGX_E_ARG;
+    return guarded(u, [&] { u->T = Threads(); u->T.ref.assign(bases, n); u->T.n_ref = n; u->have_ref = true; u->have_threads = false; u->uploaded = false; u->built = false; });
+}
+
+int agx_unit_set_contig_threads(agx_unit *u, const char *appended, uint32_t n_appended, const uint32_t *cm_start, const agx_contimer *cm, uint32_t n_cm,
+                                const char *initial_contigs, size_t initial_len) {
+    if (!u || !cm_start || (!cm && n_cm) || (!appended && n_appended)) return AGX_E_ARG;
+    return guarded(u, [&] {
+        if (!u->have_ref) throw Error{E_ARG, "set the reference first"};
+        u->T.ref.resize(u->T.n_ref); u->T.ref.append(appended ? appended : "", n_appended);
+        const size_t n_pos = u->T.ref.size();
+        u->T.cm_start.assign(cm_start, cm_start + n_pos + 1);
+        if (u->T.cm_start[n_pos] != n_cm) throw Error{E_ARG, "cm_start does not end at n_cm"};
+        u->T.cm.resize(n_cm);
+        for (uint32_t i = 0; i < n_cm; i++) {
+            if (cm[i].next_off != AGX_NONE && cm[i].next_off >= n_pos) throw Error{E_ARG, "conti-mer link beyond the position array"};
+            u->T.cm[i] = ContiMer{cm[i].nuc, cm[i].cid, cm[i].coff, cm[i].next_off, cm[i].next_item};
+        }
+        u->T.initial_contigs.assign(initial_contigs ? initial_contigs : "", initial_len);
+        u->have_threads = true; u->uploaded = false; u->built = false;
+    });
+}
+
+int agx_unit_push_pairs(agx_unit *u, const agx_pair_batch *b) {
+    if (!u || !b) return AGX_E_ARG;
+    return guarded(u, [&] {
+        if (u->P.hits.empty()) { u->P = Pairs(); u->P.stride = b->stride; }
+        if (b->stride != u->P.stride) throw Error{E_ARG, "all batches of a unit must use one read stride"};
+        const agx_u32 slot0 = u->P.n_slots, run0 = (agx_u32)u->P.runs.size();
+        for (uint64_t i = 0; i < b->n_hits; i++) {
+            agx_hit h = b->hits[i];
+            if (h.len == 0 || h.len > b->stride || (uint64_t)h.slot1 + 1 >= b->n_slots) throw Error{E_ARG, "hit names a read slot outside the batch"};
+            if ((h.nruns1 && (uint64_t)h.runs1 + h.nruns1 > b->n_runs) || (h.nruns2 && (uint64_t)h.runs2 + h.nruns2 > b->n_runs)) throw Error{E_ARG, "hit names runs outside the batch"};
+            if (h.back > i) throw Error{E_ARG, "hit.back reaches before the batch"};
+            h.slot1 += slot0; if (h.nruns1) h.runs1 += run0; if (h.nruns2) h.runs2 += run0;
+            u->P.hits.push_back(h);
+        }
+        u->P.runs.insert(u->P.runs.end(), b->runs, b->runs + b->n_runs);
+        u->P.bases.append(b->bases, (size_t)b->n_slots * b->stride);
+        u->P.n_slots += b->n_slots;
+        u->uploaded = false; u->built = false;
+    });
+}
+
+int agx_unit_load_files(agx_unit *u, const char *tmp_dir, int unit) {
+    if (!u || !tmp_dir) return AGX_E_ARG;
+    return guarded(u, [&] {
+        const std::string d = tmp_dir, s = std::to_string(unit);
+        double t0 = now_ms();
+        u->T = Threads(); u->P = Pairs();
+        load_unit_reference(d + "/_genome." + s + ".fa", u->T.ref);
+        thread_contigs_from_files(d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", u->T);
+        u->stats.ms_thread = now_ms() - t0; t0 = now_ms();
+        load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie", (long)u->prm.batch, u->prm.k, u->P);
+        u->stats.ms_parse = now_ms() - t0;
+        u->have_ref = u->have_threads = true; u->uploaded = false; u->built = false;
+    });
+}
+
+int agx_unit_upload(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_upload(u); }); }
+int agx_unit_build(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_build(u); }); }
+
+int agx_unit_finish(agx_unit *u, agx_result *r) {
+    if (!u || !r) return AGX_E_ARG;
+    memset(r, 0, sizeof *r);
+    return guarded(u, [&] {
+        if (!u->downloaded) do_download(u);
+        const double t0 = now_ms();
+        UnitOutput O; walk_join_scaffold(u->T, u->P, view_of(u), O);
+        u->stats.ms_walk = now_ms() - t0;
+        r->initial_contigs = dup_buf(O.initial_contigs); r->initial_len = O.initial_contigs.size();
+        r->pre_extended = dup_buf(O.pre_extended); r->pre_len = O.pre_extended.size();
+        r->extended = dup_buf(O.extended); r->extended_len = O.extended.size();
+    });
+}
+
+void agx_result_free(agx_result *r) { if (!r) return; free(r->initial_contigs); free(r->pre_extended); free(r->extended); memset(r, 0, sizeof *r); }
+
+int agx_unit_stats(const agx_unit *u, agx_stats *s) {
+    if (!u || !s) return AGX_E_ARG;
+    *s = u->stats;
+    s->n_pos = u->T.ref.size(); s->n_ref = u->T.n_ref; s->n_hits = u->P.hits.size(); s->n_runs = u->P.runs.size(); s->n_nodes = u->n_nodes;
+    s->n_tiles = u->n_tiles; s->n_tile_entries = u->n_tile_entries; s->n_big_tiles = u->n_big; s->n_edge_overflow = u->n_ovf;
+    s->pairs_in_file = u->P.n_pairs_in_file; s->sam_line_pairs = u->P.n_sam_pairs;
+    return AGX_OK;
+}
+
+int agx_unit_graph(agx_unit *u, agx_graph *g) {
+    if (!u || !g) return AGX_E_ARG;
+    memset(g, 0, sizeof *g);
+    return guarded(u, [&] {
+        if (!u->downloaded) do_download(u);
+        const agx_u32 n_pos = (agx_u32)u->T.ref.size(), nn = u->n_nodes;
+        std::vector<agx_u32> cid(nn), coff(nn), cid0(nn), coff0(nn); std::vector<int> counts;
+        if (nn) {
+            HIP_OK(hipMemcpy(cid.data(), u->d_cid.p, (size_t)nn * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(coff.data(), u->d_coff.p, (size_t)nn * 4, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(cid0.data(), u->d_cid0.p, (size_t)nn * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(coff0.data(), u->d_coff0.p, (size_t)nn * 4, hipMemcpyDeviceToHost));
+            if (u->prm.flags & AGX_FLAG_KEEP_COUNTS) { counts.resize((size_t)nn * 6); HIP_OK(hipMemcpy(counts.data(), u->d_counts.p, (size_t)nn * 24, hipMemcpyDeviceToHost)); }
+        }
+        g->n_pos = n_pos; g->n_nodes = nn;
+        g->node_start = (uint32_t *)malloc(4 * ((size_t)n_pos + 1)); g->node_key = (uint32_t *)malloc(24 * ((size_t)nn + 1)); g->node_cnt = (int32_t *)malloc(24 * ((size_t)nn + 1));
+        g->node_slen = (uint32_t *)malloc(4 * ((size_t)nn + 1)); g->edge_start = (uint32_t *)malloc(4 * ((size_t)nn + 1));
+        std::vector<agx_u32> canon(nn); agx_u32 id = 0;
+        for (agx_u32 x = 0; x < n_pos; x++) { g->node_start[x] = id; for (agx_u32 v = 0; v < u->h_node_cnt.p[x]; v++) canon[u->h_node_start.p[x] + v] = id++; }
+        g->node_start[n_pos] = id;
+        if (id != nn) throw Error{E_DEVICE, "node table is inconsistent (count mismatch)"};
+        std::vector<std::vector<agx_u32> > adj(nn);
+        for (agx_u32 v = 0; v < nn; v++) for (agx_u32 e = 0; e < AGX_MAXE; e++) { const agx_u32 d = u->h_next.p[(size_t)v * AGX_MAXE + e]; if (d != AGX_NONE) adj[canon[v]].push_back(canon[d]); }
+        for (agx_u32 i = 0; i < u->n_ovf; i++) adj[canon[u->h_ovf.p[i].src]].push_back(canon[u->h_ovf.p[i].dst]);
+        size_t ne = 0;
+        for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); ne += a.size(); }
+        g->n_edges = (uint32_t)ne; g->edge_dst = (uint32_t *)malloc(4 * (ne + 1));
+        for (agx_u32 v = 0; v < nn; v++) {
+            const agx_u32 c = canon[v]; uint32_t *kk = g->node_key + 6 * (size_t)c;
+            kk[0] = cid[v]; kk[1] = coff[v]; kk[2] = cid0[v]; kk[3] = coff0[v]; kk[4] = u->h_off0.p[v] == AGX_NONE ? AGX_NONE : 0; kk[5] = u->h_off0.p[v];
+            if (!counts.empty()) memcpy(g->node_cnt + 6 * (size_t)c, counts.data() + 6 * (size_t)v, 24); else for (int j = 0; j < 6; j++) g->node_cnt[6 * (size_t)c + j] = -1;
+            g->node_slen[c] = (u->h_sref.p[v].qlen >> 16) & 0x7FFF;
+        }
+        size_t eo = 0;
+        for (agx_u32 c = 0; c < nn; c++) { g->edge_start[c] = (uint32_t)eo; for (agx_u32 d : adj[c]) g->edge_dst[eo++] = d; }
+        g->edge_start[nn] = (uint32_t)eo;
+    });
+}
+
+void agx_graph_free(agx_graph *g) {
+    if (!g) return;
+    free(g->node_start); free(g->node_key); free(g->node_cnt); free(g->node_slen); free(g->edge_start); free(g->edge_dst); memset(g, 0, sizeof *g);
+}
+
+int agx_run_unit(const agx_params *p, const char *tmp_dir, int unit, int write_files, agx_result *r, char *err, size_t err_len) {
+    if (err && err_len) err[0] = 0;
+    agx_unit *u = nullptr;
+    int rc = agx_unit_create(p, &u);
+    if (rc != AGX_OK) { if (err && err_len) snprintf(err, err_len, "%s", rc == AGX_E_NOGPU ? "no HIP device" : "bad parameters"); return rc; }
+    rc = agx_unit_load_files(u, tmp_dir, unit);
+    if (rc == AGX_OK) rc = agx_unit_upload(u);
+    if (rc == AGX_OK) rc = agx_unit_build(u);
+    if (rc == AGX_OK) rc = agx_unit_finish(u, r);
+    if (rc == AGX_OK && write_files)
+        rc = guarded(u, [&] {
+            const std::string d = tmp_dir, s = std::to_string(unit);
+            write_file(d + "/_initial_contigs." + s + ".fa", std::string(r->initial_contigs, r->initial_len));
+            write_file(d + "/_pre_extended_contigs." + s + ".fa", std::string(r->pre_extended, r->pre_len));
+            write_file(d + "/_extended_contigs." + s + ".fa", std::string(r->extended, r->extended_len));
+        });
+    if (rc != AGX_OK && err && err_len) snprintf(err, err_len, "%s", agx_unit_error(u));
+    agx_unit_destroy(u);
+    return rc;
+}
+
+}  // extern "C"

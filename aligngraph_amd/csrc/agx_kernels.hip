@@ -1,0 +1,187 @@
+// agx_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the graph-build engine.
+//
+// All kernels are integer / byte work bound by memory latency and HBM/L2 traffic; none of it is matrix-shaped,
+// so there is no MFMA here by design.  The layout rules that matter are the ones for wave64 streaming kernels:
+//   * one wavefront (64 lanes) owns one tile of 64 consecutive reference positions; lanes never exchange data
+//     while a tile is swept, so there is no __syncthreads() anywhere on the hot path;
+//   * per-position node buckets live in LDS as [field][variant][lane] so that every bucket access of a
+//     wavefront is one conflict-free ds_read/ds_write_b32 (lane -> consecutive bank);
+//   * everything a wavefront reads per hit (tile list entry, derived hit record, CIGAR runs) is wave-uniform:
+//     the tile index is forced into an SGPR with readfirstlane so those loads become scalar (s_load) traffic;
+//   * per-lane global reads are position-consecutive across lanes (read bases, mate conti-mer lookups, node
+//     keys of the successor position) and therefore coalesce.
+// The per-lane algorithm itself is in agx_core.h (shared with the CPU test executor).
+#include <hip/hip_runtime.h>
+#include "agx_kargs.h"
+
+#define AGX_WAVES_PER_BLOCK 4
+
+// ---- hit_prep: one thread per hit -------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
+    const agx_u32 h = blockIdx.x * 256u + threadIdx.x;
+    if (h >= A.n_hits) return;
+    agx_dhit d;
+    const int rc = agx_hit_prep(A.hits, A.runs, h, A.k, d);
+    if (rc) atomicOr(A.err, 1u);
+    if (!(d.flags & AGX_HF_SKIP)) {
+        if (d.x_hi >= A.n_pos || d.x_lo > d.x_hi) { atomicOr(A.err, 2u); d.flags |= AGX_HF_SKIP; }
+        else for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++) atomicAdd(&A.tile_cnt[t], 1u);
+    }
+    A.dhit[h] = d;
+}
+
+// ---- exclusive scan of a u32 array (three small kernels; n_tiles is 10^4..10^7) ------------------------------------
+// each block scans 1024 elements (256 threads x 4)
+__global__ void __launch_bounds__(256) agx_k_scan_blocks(const agx_u32 *in, agx_u32 *out, agx_u32 *block_sums, agx_u32 n) {
+    __shared__ agx_u32 sh[256];
+    const agx_u32 base = blockIdx.x * 1024u + threadIdx.x * 4u;
+    agx_u32 v[4], s = 0;
+    for (int i = 0; i < 4; i++) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (agx_u32 off = 1; off < 256; off <<= 1) {
+        agx_u32 t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    agx_u32 run = sh[threadIdx.x] - s;      // exclusive prefix of this thread's first element
+    for (int i = 0; i < 4; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
+    if (threadIdx.x == 255 && block_sums) block_sums[blockIdx.x] = sh[255];
+}
+__global__ void __launch_bounds__(256) agx_k_scan_add(agx_u32 *out, const agx_u32 *block_offsets, agx_u32 n) {
+    const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] += block_offsets[i / 1024u];
+}
+
+// ---- tile lists: scatter, then rank-sort each list so that hits are applied in SAM order ---------------------------
+__global__ void __launch_bounds__(256) agx_k_bin_fill(agx_bin_args A) {
+    const agx_u32 h = blockIdx.x * 256u + threadIdx.x;
+    if (h >= A.n_hits) return;
+    const agx_dhit d = A.dhit[h];
+    if (d.flags & AGX_HF_SKIP) return;
+    for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++) A.unsorted[A.tile_off[t] + atomicAdd(&A.cursor[t], 1u)] = h;
+}
+
+// one wavefront per tile; hit ids are unique, so an element's rank is the number of smaller elements
+#define AGX_SORT_LDS 2048
+__global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles) {
+    __shared__ agx_u32 sh[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS];
+    const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
+    if (tile >= n_tiles) return;
+    const agx_u32 lo = tile_off[tile], n = tile_off[tile + 1] - lo;
+    const agx_u32 *src = unsorted + lo;
+    if (n <= AGX_SORT_LDS) {
+        for (agx_u32 i = lane; i < n; i += 64) sh[wave][i] = src[i];
+        // single wavefront: LDS writes above are visible to its own later reads after the implicit waitcnt
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        for (agx_u32 i = lane; i < n; i += 64) {
+            const agx_u32 v = sh[wave][i]; agx_u32 r = 0;
+            for (agx_u32 j = 0; j < n; j++) r += sh[wave][j] < v;
+            sorted[lo + r] = v;
+        }
+    } else {                                            // pile-ups larger than the LDS window: same rank sort straight from L2
+        for (agx_u32 i = lane; i < n; i += 64) {
+            const agx_u32 v = src[i]; agx_u32 r = 0;
+            for (agx_u32 j = 0; j < n; j++) r += src[j] < v;
+            sorted[lo + r] = v;
+        }
+    }
+}
+
+// ---- node sweep ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ agx_u32 agx_wave_incl_scan(agx_u32 v, agx_u32 lane) {
+    for (agx_u32 off = 1; off < 64; off <<= 1) { const agx_u32 t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
+    return v;
+}
+
+template <bool BIG>
+__global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
+    __shared__ agx_u32 lds[BIG ? 1 : AGX_WAVES_PER_BLOCK][BIG ? 1 : AGX_NF * AGX_MAXV_LDS * 64];
+    const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const agx_u32 slot = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
+    agx_u32 tile;
+    if (BIG) { if (slot >= K.n_list) return; tile = __builtin_amdgcn_readfirstlane(K.tile_list[slot]); }
+    else { if (slot >= K.S.n_tiles) return; tile = slot; }
+    const agx_u32 X = tile * AGX_TILE + lane;
+    agx_bucket b;
+    if (BIG) { b.base = K.scratch + (size_t)slot * (AGX_NF * AGX_MAXV_BIG * 64) + lane; b.maxv = AGX_MAXV_BIG; }
+    else { b.base = &lds[wave][lane]; b.maxv = AGX_MAXV_LDS; }
+    b.stride = 64;
+    agx_u32 cnt = 0;
+    const bool ok = agx_node_sweep_lane(K.S, tile, X, b, cnt);
+    if (__ballot(!ok) != 0ull) {                       // wave-uniform
+        if (lane == 0) {
+            if (BIG) atomicOr(K.status, 2u);
+            else K.big_list[atomicAdd(K.big_count, 1u)] = tile;
+        }
+        return;
+    }
+    const agx_u32 incl = agx_wave_incl_scan(cnt, lane);
+    const agx_u32 total = __shfl(incl, 63, 64);
+    agx_u32 base = 0;
+    if (lane == 0) base = atomicAdd(K.pool_counter, total);
+    base = __shfl(base, 0, 64);
+    if ((unsigned long long)base + total > K.S.pool_cap) { if (lane == 0) atomicOr(K.status, 1u); return; }
+    agx_node_write_lane(K.S, X, b, cnt, base + incl - cnt);
+}
+
+// ---- edge sweep -------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
+    const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
+    if (tile >= K.S.n_tiles) return;
+    agx_edge_sweep_lane(K.S, tile, tile * AGX_TILE + lane, [&](agx_u32 s, agx_u32 d) {
+        const agx_u32 i = atomicAdd(K.ovf_count, 1u);
+        if (i < K.ovf_cap) K.ovf[i] = agx_edge_ovf{s, d};
+    });
+}
+
+// ---- host-callable launchers (kept in this translation unit so that the engine is plain C++) -------------------------
+extern "C" {
+
+void agx_launch_hit_prep(const agx_prep_args *A, hipStream_t st) {
+    if (A->n_hits) hipLaunchKernelGGL(agx_k_hit_prep, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
+}
+
+// exclusive scan of in[0..n) into out[0..n]; out[n] = total.  tmp must hold ceil(n/1024)+ceil(n/1024^2)+.. + 8 words.
+void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u32 *tmp, hipStream_t st) {
+    // scan n+1 elements (a trailing zero-extended element gives the total in out[n]); callers allocate in with n+1 entries, in[n]=0
+    const agx_u32 m = n + 1;
+    const agx_u32 nb = (m + 1023) / 1024;
+    if (nb == 1) { hipLaunchKernelGGL(agx_k_scan_blocks, dim3(1), dim3(256), 0, st, in, out, (agx_u32 *)nullptr, m); return; }
+    agx_u32 *sums = tmp, *sums_scanned = tmp + nb + 1;
+    hipLaunchKernelGGL(agx_k_scan_blocks, dim3(nb), dim3(256), 0, st, in, out, sums, m);
+    // scan the block sums (recursively; nb <= 2^22 for 2^32 elements, two levels are enough in practice)
+    const agx_u32 nb2 = (nb + 1023) / 1024;
+    if (nb2 == 1) hipLaunchKernelGGL(agx_k_scan_blocks, dim3(1), dim3(256), 0, st, sums, sums_scanned, (agx_u32 *)nullptr, nb);
+    else {
+        agx_u32 *sums2 = sums_scanned + nb + 1, *sums2_scanned = sums2 + nb2 + 1;
+        hipLaunchKernelGGL(agx_k_scan_blocks, dim3(nb2), dim3(256), 0, st, sums, sums_scanned, sums2, nb);
+        hipLaunchKernelGGL(agx_k_scan_blocks, dim3(1), dim3(256), 0, st, sums2, sums2_scanned, (agx_u32 *)nullptr, nb2);   // nb2 <= 1024 for n < 2^30
+        hipLaunchKernelGGL(agx_k_scan_add, dim3((nb + 255) / 256), dim3(256), 0, st, sums_scanned, sums2_scanned, nb);
+    }
+    hipLaunchKernelGGL(agx_k_scan_add, dim3((m + 255) / 256), dim3(256), 0, st, out, sums_scanned, m);
+}
+
+void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {
+    if (A->n_hits) hipLaunchKernelGGL(agx_k_bin_fill, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
+}
+void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, hipStream_t st) {
+    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, sorted, n_tiles);
+}
+void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
+    const agx_u32 n = K->S.n_tiles;
+    if (n) hipLaunchKernelGGL(agx_k_node_sweep<false>, dim3((n + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
+}
+void agx_launch_node_sweep_big(const agx_node_kargs *K, hipStream_t st) {
+    const agx_u32 n = K->n_list;
+    if (n) hipLaunchKernelGGL(agx_k_node_sweep<true>, dim3((n + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
+}
+void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
+    const agx_u32 n = K->S.n_tiles;
+    if (n) hipLaunchKernelGGL(agx_k_edge_sweep, dim3((n + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+/* agx.h — C-ABI of libagx.so, the MI355X engine for AlignGraph's per-unit graph build + extend path.
+ *
+ * The reference (baoe/AlignGraph, one C++03 file "AG" = AlignGraph/AlignGraph.cpp) has no plugin or FFI
+ * interface; the drop-in seam is the body of its unit loop (AG:4765-4783):
+ *
+ *     loadGenome(genome, u);  loadContigAlignment(genome, u);  loadReadAlignment(genome, k, iv, u, mrl);
+ *     extendContigs(genome, coverage, k, u);  scaffoldContigs(genome, u);
+ *
+ * which reads tmp/_genome.u.fa, tmp/_contigs.fa, tmp/_contigs_genome.u.psl, tmp/_reads.fa and
+ * tmp/_reads_genome.u.bowtie and writes tmp/_initial_contigs.u.fa, tmp/_pre_extended_contigs.u.fa and
+ * tmp/_extended_contigs.u.fa.  agx_run_unit() replaces exactly those five calls (INTEGRATION.md shows the
+ * three-line patch); the finer-grained entry points below split the same work at the packed-array boundary
+ * so that a caller can keep inputs resident on the device and time host parsing, upload, kernels and the
+ * walk separately.
+ *
+ * Plain C: pointers and sizes only, no C++ or torch types.  Every function returns AGX_OK (0) or a negative
+ * AGX_E_* code; the message is available from agx_unit_error().  Nothing here ever exits the process or throws
+ * across the boundary (the reference prints to stdout and exit(-1)s; INTEGRATION.md maps codes back to its
+ * messages).  There is no CPU fallback: without a HIP device agx_unit_create() fails with AGX_E_NOGPU.
+ *
+ * Threading: an agx_unit is single-owner.  Distinct units may be driven concurrently on distinct devices.
+ */
+#ifndef AGX_H
+#define AGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGX_OK 0
+#define AGX_E_IO (-1)          /* "CANNOT OPEN FILE!"                                   AG:317, 356, 401, 849, 1274 */
+#define AGX_E_FORMAT (-2)      /* "BROKEN BOWTIE FILE", "unknown character: c"           AG:1253, 267 */
+#define AGX_E_UNSUPPORTED (-3) /* inputs the reference would index out of bounds on (DESIGN.md "Rejected inputs") */
+#define AGX_E_ALIGNMENT (-4)   /* "BOWTIE ALIGNMENT ERROR" (mates on the same strand)    AG:1669 */
+#define AGX_E_DEVICE (-5)      /* HIP runtime error */
+#define AGX_E_ARG (-6)
+#define AGX_E_OVERFLOW (-7)    /* more than 64 node variants at one position */
+#define AGX_E_NOGPU (-8)
+
+typedef struct agx_unit agx_unit;
+
+/* Scalars of the unit loop: --kMer, --insertVariation, --coverage (AG:4701) and the compile-time BATCH (AG:37). */
+typedef struct {
+    uint32_t k;                /* default 5 */
+    uint32_t insert_variation; /* default 50 */
+    uint32_t coverage;         /* default 20 */
+    uint32_t batch;            /* pairs per read batch; 0 = 1000000 (AG:37) */
+    int32_t device;            /* HIP device ordinal */
+    uint32_t flags;            /* AGX_FLAG_* */
+} agx_params;
+
+#define AGX_FLAG_KEEP_COUNTS 1u /* keep per-node coverage and base votes on the device for agx_unit_graph() */
+
+/* ---- packed inputs -------------------------------------------------------------------------------- */
+
+/* n read bases from read index q sit on reference offsets t, t+1, ...  (Segment, AG:44-49) */
+typedef struct { uint32_t q, t, n; } agx_run;
+
+/* One (pair, hit) that passed the identity filter of loadReadAli (AG:1261), in SAM order. */
+typedef struct {
+    uint32_t slot1;         /* mate1's slot in the read-base blob; mate2 is slot1+1 */
+    uint32_t pos1, pos2;    /* "simple" mates (one M run covering the whole read): reference offset of read index 0 */
+    uint32_t runs1, runs2;  /* first run in the run pool (non-simple mates) */
+    uint16_t nruns1, nruns2; /* 0 = simple */
+    uint16_t len;           /* read length; mates are equal length (AG:3454) */
+    uint8_t rev1, rev2;     /* SAM FLAG 0x10 of each mate */
+    uint8_t back;           /* number of earlier kept hits of the same pair */
+    uint8_t pad[3];
+} agx_hit;
+
+/* ContiMer (AG:51-62) inside a unit: the chromosome id is always 0 */
+typedef struct { uint32_t cid, coff, next_off, next_item; char nuc; char pad[3]; } agx_contimer;
+
+typedef struct {
+    const agx_hit *hits; uint64_t n_hits;
+    const agx_run *runs; uint64_t n_runs;
+    const char *bases;      /* read slot s occupies bases[s*stride .. s*stride+len) in reads-file orientation */
+    uint32_t stride, n_slots;
+} agx_pair_batch;
+
+/* ---- outputs --------------------------------------------------------------------------------------- */
+
+typedef struct {
+    char *initial_contigs; size_t initial_len;   /* bytes of tmp/_initial_contigs.u.fa      (AG:1179-1216) */
+    char *pre_extended;    size_t pre_len;       /* bytes of tmp/_pre_extended_contigs.u.fa (AG:2176-2189) */
+    char *extended;        size_t extended_len;  /* bytes of tmp/_extended_contigs.u.fa     (AG:2451-2463) */
+} agx_result;
+
+typedef struct {
+    uint64_t n_pos, n_ref, n_hits, n_runs, n_nodes, n_tiles, n_tile_entries, n_big_tiles, n_edge_overflow;
+    uint64_t pairs_in_file, sam_line_pairs;
+    double ms_parse, ms_thread, ms_upload, ms_prep, ms_bin, ms_node_sweep, ms_node_big, ms_edge_sweep, ms_download, ms_walk;
+    uint32_t node_sweep_launches, edge_sweep_launches;
+} agx_stats;
+
+/* Node/edge tables in canonical numbering (position-major, variant order), for parity tests. malloc'd; free with agx_graph_free. */
+typedef struct {
+    uint32_t n_pos, n_nodes, n_edges;
+    uint32_t *node_start;   /* [n_pos+1] */
+    uint32_t *node_key;     /* [n_nodes*6] contigID, contigOffset, contigID0, contigOffset0, chromosomeID0, chromosomeOffset0 */
+    int32_t *node_cnt;      /* [n_nodes*6] coverage, A, C, G, T, N   (needs AGX_FLAG_KEEP_COUNTS, else all -1) */
+    uint32_t *node_slen;    /* [n_nodes] length of the stored k-mer string */
+    uint32_t *edge_start;   /* [n_nodes+1] */
+    uint32_t *edge_dst;     /* [n_edges] sorted per node */
+} agx_graph;
+
+/* ---- entry points ------------------------------------------------------------------------------------ */
+
+const char *agx_version(void);
+int agx_device_count(void);                                   /* HIP devices visible; 0 when there is no GPU */
+
+int agx_unit_create(const agx_params *p, agx_unit **out);
+void agx_unit_destroy(agx_unit *u);
+const char *agx_unit_error(const agx_unit *u);
+
+/* Packed-array boundary.  Pointers are borrowed for the call; the unit keeps its own copy. */
+int agx_unit_set_reference(agx_unit *u, const char *bases, uint32_t n);                       /* replaces loadGenome, AG:287-320 */
+int agx_unit_set_contig_threads(agx_unit *u, const char *appended, uint32_t n_appended,      /* result of updateGenomeWithContig, AG:884-1217 */
+                                const uint32_t *cm_start, const agx_contimer *cm, uint32_t n_cm,
+                                const char *initial_contigs, size_t initial_len);
+int agx_unit_push_pairs(agx_unit *u, const agx_pair_batch *b);                                /* result of loadSeq + loadReadAli, AG:361-404, 1233-1277 */
+
+/* Host loaders: the reference's own text files -> the three calls above. */
+int agx_unit_load_files(agx_unit *u, const char *tmp_dir, int unit);
+
+int agx_unit_upload(agx_unit *u);                /* host -> HBM */
+int agx_unit_build(agx_unit *u);                 /* kernels: updateGenomeWithRead/updateKMer (AG:1635-1870, 1353-1624) + filterLowCoverage (AG:1904-1918) */
+int agx_unit_finish(agx_unit *u, agx_result *r); /* HBM -> host, then extdContigs1/2 + scaffoldContigs (AG:1954-2464) */
+void agx_result_free(agx_result *r);
+
+int agx_unit_stats(const agx_unit *u, agx_stats *s);
+int agx_unit_graph(agx_unit *u, agx_graph *g);   /* after agx_unit_build */
+void agx_graph_free(agx_graph *g);
+
+/* The five-call seam in one call.  write_files != 0 also writes the three files under tmp_dir like the reference does. */
+int agx_run_unit(const agx_params *p, const char *tmp_dir, int unit, int write_files, agx_result *r, char *err, size_t err_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGX_H */

@@ -1,0 +1,75 @@
+import io
+import json
+import os
+import sys
+import tarfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+GOLDEN_CASES = sorted(f[:-7] for f in os.listdir(GOLDEN) if f.endswith(".tar.gz"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class GoldenCase:
+    """A tests/golden/<name>.tar.gz unpacked into a scratch directory."""
+
+    def __init__(self, name, dest):
+        self.name = name
+        self.dir = str(dest)
+        with tarfile.open(os.path.join(GOLDEN, name + ".tar.gz")) as tar:
+            tar.extractall(self.dir)
+        with open(os.path.join(self.dir, "params.json")) as f:
+            self.params = json.load(f)
+        self.tmp = os.path.join(self.dir, "tmp")
+
+    def expected(self, coverage, unit):
+        out = {}
+        for key, fn in (("initial", "_initial_contigs"), ("pre", "_pre_extended_contigs"), ("extended", "_extended_contigs")):
+            with open(os.path.join(self.dir, "expected", str(coverage), "%s.%d.fa" % (fn, unit)), "rb") as f:
+                out[key] = f.read()
+        return out
+
+
+@pytest.fixture(params=GOLDEN_CASES)
+def golden(request, tmp_path):
+    return GoldenCase(request.param, tmp_path)
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Builds the oracle, the generator and the CPU test executor once per session."""
+    import harness
+    from hostsim import sim
+    harness.build()
+    sim.build()
+    return True
+
+
+def graph_mismatch(go, gs, counts=True):
+    """First difference between two canonical graph dumps (oracle order-of-insertion edges are sorted here), or None."""
+    import numpy as np
+    if go["n_pos"] != gs["n_pos"] or go["n_nodes"] != gs["n_nodes"]:
+        return "sizes: n_pos %d/%d n_nodes %d/%d" % (go["n_pos"], gs["n_pos"], go["n_nodes"], gs["n_nodes"])
+    keys = ["node_start", "node_key", "node_slen"] + (["node_cnt"] if counts else [])
+    for k in keys:
+        if not np.array_equal(go[k], gs[k]):
+            return k
+    if go["n_edges"] != gs["n_edges"]:
+        return "n_edges %d/%d" % (go["n_edges"], gs["n_edges"])
+
+    def canon(g):
+        es = g["edge_start"].astype(np.int64)
+        owner = np.repeat(np.arange(g["n_nodes"]), np.diff(es))
+        return g["edge_dst"][np.lexsort((g["edge_dst"], owner))]
+    if not np.array_equal(go["edge_start"], gs["edge_start"]) or not np.array_equal(canon(go), canon(gs)):
+        return "edges"
+    return None

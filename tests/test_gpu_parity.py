@@ -1,0 +1,105 @@
+"""Parity tests proper (-m gpu): the HIP engine through the C-ABI against the oracle and the reference's golden vectors."""
+import os
+
+import pytest
+
+import harness as H
+from conftest import graph_mismatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def agx():
+    import aligngraph_amd as A
+    if not os.path.exists(A.LIB_PATH):
+        from aligngraph_amd import build as B
+        B.build()
+    assert A.device_count() > 0, "no HIP device: the gpu tests must run on the MI355X box"
+    return A
+
+
+def run_engine(agx, tmp, unit, k, iv, cov, batch=0, graph=False):
+    with agx.Unit(k=k, insert_variation=iv, coverage=cov, batch=batch, keep_counts=graph) as u:
+        u.load_files(tmp, unit)
+        u.upload()
+        u.build()
+        out = u.finish()
+        out["stats"] = u.stats()
+        if graph:
+            out["graph"] = u.graph()
+    return out
+
+
+def test_golden_vectors(agx, golden, built):
+    p = golden.params
+    for cov in p["coverages"]:
+        for u in range(p["units"]):
+            got = run_engine(agx, golden.tmp, u, p["k"], p["insert_variation"], cov)
+            exp = golden.expected(cov, u)
+            for key in ("initial", "pre", "extended"):
+                assert got[key] == exp[key], "%s cov=%d unit=%d %s" % (golden.name, cov, u, key)
+
+
+CONFIGS = [
+    dict(seed=201, chroms="60000", pairs=20000, coverage=5, contig_min=1500, contig_max=3000),
+    dict(seed=202, chroms="40000", pairs=12000, coverage=3, L=50, k=8, read_indel=0.3, read_clip=0.3, indel=0.005, multi=0.3),
+    dict(seed=203, chroms="30000", pairs=9000, coverage=5, frag_sd=300, insert_variation=10),
+    dict(seed=204, chroms="30000,20000", part=2, pairs=10000, coverage=4, L=150, k=21, contig_min=300, contig_max=2000, contig_overlap=0.5,
+         contig_dup=0.3, contig_split=0.5, contig_minus=1.0),
+    dict(seed=205, chroms="300000", pairs=60000, coverage=5),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "seed%d" % c["seed"])
+def test_node_edge_tables_and_outputs_match_oracle(agx, cfg, built, tmp_path):
+    run = H.synth(str(tmp_path / "run"), sam_seq=0, **cfg)
+    meta = H.read_meta(run)
+    tmp = os.path.join(run, "tmp")
+    for u in range(meta["units"]):
+        o = H.run_oracle(tmp, u, meta["k"], meta["insert_variation"], meta["coverage"], graph=True)
+        g = run_engine(agx, tmp, u, meta["k"], meta["insert_variation"], meta["coverage"], graph=True)
+        assert graph_mismatch(o["graph"], g["graph"]) is None
+        for key in ("initial", "pre", "extended"):
+            assert o[key] == g[key], key
+        if cfg.get("frag_sd") == 300:
+            assert g["stats"]["n_big_tiles"] > 0
+
+
+def test_run_unit_writes_the_three_files(agx, built, tmp_path):
+    run = H.synth(str(tmp_path / "run"), seed=31, chroms="20000", pairs=5000, coverage=5, sam_seq=0)
+    tmp = os.path.join(run, "tmp")
+    o = H.run_oracle(tmp, 0, 5, 50, 5)
+    got = agx.run_unit(tmp, 0, k=5, insert_variation=50, coverage=5, write_files=True)
+    for key, fn in (("initial", "_initial_contigs.0.fa"), ("pre", "_pre_extended_contigs.0.fa"), ("extended", "_extended_contigs.0.fa")):
+        assert got[key] == o[key]
+        assert open(os.path.join(tmp, fn), "rb").read() == o[key]
+
+
+def test_rebuild_is_idempotent_and_batch_rule(agx, built, tmp_path):
+    run = H.synth(str(tmp_path / "run"), seed=7, chroms="8000", pairs=2300, coverage=3, multi=0.3, sam_seq=0)
+    tmp = os.path.join(run, "tmp")
+    o = H.run_oracle(tmp, 0, 5, 50, 3, batch=500)
+    with agx.Unit(k=5, insert_variation=50, coverage=3, batch=500) as u:
+        u.load_files(tmp, 0); u.upload()
+        for _ in range(3):
+            u.build()
+            got = u.finish()
+            assert got["pre"] == o["pre"] and got["extended"] == o["extended"]
+
+
+def test_errors_come_back_as_codes(agx, built, tmp_path):
+    run = H.synth(str(tmp_path / "run"), seed=5, chroms="5000", pairs=200, coverage=2, sam_seq=0, multi=0, read_indel=0, read_clip=0, read_badclip=0)
+    tmp = os.path.join(run, "tmp")
+    sam = os.path.join(tmp, "_reads_genome.0.bowtie")
+    lines = open(sam).read().split("\n")
+    f = lines[0].split("\t"); g = lines[1].split("\t")
+    g[1] = str((int(g[1]) & ~0x10) | (int(f[1]) & 0x10))
+    open(sam, "w").write("\n".join([lines[0], "\t".join(g)] + lines[2:]))
+    with pytest.raises(agx.AgxError) as e:
+        run_engine(agx, tmp, 0, 5, 50, 2)
+    assert e.value.code == agx.AGX_E_ALIGNMENT and "BOWTIE ALIGNMENT ERROR" in e.value.msg
+    os.remove(sam)
+    with pytest.raises(agx.AgxError) as e:
+        run_engine(agx, tmp, 0, 5, 50, 2)
+    assert e.value.code == agx.AGX_E_IO

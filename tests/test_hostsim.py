@@ -1,0 +1,97 @@
+"""CPU checks of the engine's algorithm: the per-lane kernel functions of aligngraph_amd/csrc/agx_core.h, run serially by
+tests/hostsim, plus the product's host loaders and host walk, against the oracle and the reference's golden vectors.
+(The kernels themselves run in tests/test_gpu_parity.py, -m gpu.)"""
+import os
+
+import pytest
+
+import harness as H
+from conftest import graph_mismatch
+from hostsim import sim
+
+
+def test_golden_vectors(golden, built):
+    p = golden.params
+    for cov in p["coverages"]:
+        for u in range(p["units"]):
+            got = sim.run(golden.tmp, u, p["k"], p["insert_variation"], cov)
+            exp = golden.expected(cov, u)
+            for key in ("initial", "pre", "extended"):
+                assert got[key] == exp[key], "%s cov=%d unit=%d %s" % (golden.name, cov, u, key)
+
+
+CONFIGS = [
+    dict(seed=101, chroms="40000", pairs=12000, coverage=5, contig_min=1500, contig_max=3000),
+    dict(seed=102, chroms="30000", pairs=9000, coverage=3, L=50, k=8, read_indel=0.3, read_clip=0.3, indel=0.005, multi=0.3),
+    dict(seed=103, chroms="30000", pairs=9000, coverage=5, frag_sd=300, insert_variation=10),          # buckets outgrow the LDS window
+    dict(seed=104, chroms="20000,20000", part=2, pairs=8000, coverage=4, L=150, k=21, contig_min=300, contig_max=2000, contig_overlap=0.5,
+         contig_dup=0.3, contig_split=0.5, contig_minus=1.0),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "seed%d" % c["seed"])
+@pytest.mark.parametrize("maxv", [0, 1])
+def test_node_and_edge_tables_match_oracle(cfg, maxv, built, tmp_path):
+    kw = dict(cfg)
+    run = H.synth(str(tmp_path / "run"), sam_seq=0, **kw)
+    meta = H.read_meta(run)
+    tmp = os.path.join(run, "tmp")
+    for u in range(meta["units"]):
+        o = H.run_oracle(tmp, u, meta["k"], meta["insert_variation"], meta["coverage"], graph=True)
+        s = sim.run(tmp, u, meta["k"], meta["insert_variation"], meta["coverage"], maxv_first=maxv, graph=True)
+        assert graph_mismatch(o["graph"], s["graph"]) is None
+        for key in ("initial", "pre", "extended"):
+            assert o[key] == s[key], key
+        if maxv == 1 or cfg.get("frag_sd") == 300:
+            assert s["n_big_tiles"] > 0          # the global-scratch fallback really ran
+
+
+def test_batch_boundary_drops_first_pair_of_next_batch(built, tmp_path):
+    # AG:1258-1259 with BATCH shrunk to 500 pairs: oracle and engine loaders must lose the same line pairs
+    run = H.synth(str(tmp_path / "run"), seed=7, chroms="8000", pairs=2300, coverage=3, multi=0.3, sam_seq=0)
+    tmp = os.path.join(run, "tmp")
+    a = H.run_oracle(tmp, 0, 5, 50, 3, batch=500, graph=True)
+    b = sim.run(tmp, 0, 5, 50, 3, batch=500, graph=True)
+    c = H.run_oracle(tmp, 0, 5, 50, 3, batch=1000000, graph=True)
+    assert graph_mismatch(a["graph"], b["graph"]) is None and a["pre"] == b["pre"] and a["extended"] == b["extended"]
+    assert graph_mismatch(a["graph"], c["graph"]) is not None     # the dropped pairs are visible in the counts
+    # a reads file of exactly m*BATCH pairs is followed by one empty batch
+    d = H.run_oracle(tmp, 0, 5, 50, 3, batch=2300, graph=True)
+    e = sim.run(tmp, 0, 5, 50, 3, batch=2300, graph=True)
+    assert graph_mismatch(d["graph"], e["graph"]) is None and d["pre"] == e["pre"]
+    f = H.run_oracle(tmp, 0, 5, 50, 3, batch=1150, graph=True)
+    g = sim.run(tmp, 0, 5, 50, 3, batch=1150, graph=True)
+    assert graph_mismatch(f["graph"], g["graph"]) is None and f["pre"] == g["pre"]
+
+
+def test_empty_and_ragged_inputs(built, tmp_path):
+    run = H.synth(str(tmp_path / "run"), seed=9, chroms="6000", pairs=400, coverage=2, sam_seq=0)
+    tmp = os.path.join(run, "tmp")
+    # no contig alignments at all
+    open(os.path.join(tmp, "_contigs_genome.0.psl"), "w").close()
+    a = H.run_oracle(tmp, 0, 5, 50, 2, graph=True); b = sim.run(tmp, 0, 5, 50, 2, graph=True)
+    assert graph_mismatch(a["graph"], b["graph"]) is None and a["pre"] == b["pre"] and a["extended"] == b["extended"] and a["initial"] == b["initial"]
+    # no read alignments at all: every position stays empty, outputs are empty files
+    open(os.path.join(tmp, "_reads_genome.0.bowtie"), "w").close()
+    a = H.run_oracle(tmp, 0, 5, 50, 2, graph=True); b = sim.run(tmp, 0, 5, 50, 2, graph=True)
+    assert a["graph"]["n_nodes"] == 0 and b["graph"]["n_nodes"] == 0 and a["pre"] == b["pre"] == b"" and a["extended"] == b["extended"] == b""
+
+
+def test_loader_rejects_what_the_reference_would_misread(built, tmp_path):
+    run = H.synth(str(tmp_path / "run"), seed=5, chroms="5000", pairs=200, coverage=2, sam_seq=0, multi=0, read_indel=0, read_clip=0, read_badclip=0)
+    tmp = os.path.join(run, "tmp")
+    sam = os.path.join(tmp, "_reads_genome.0.bowtie")
+    lines = open(sam).read().split("\n")
+    open(sam, "w").write("\n".join(lines[2:4] + lines[0:2] + lines[4:]))          # not sorted by read id
+    with pytest.raises(sim.SimError, match="not sorted"):
+        sim.run(tmp, 0, 5, 50, 2)
+    f = lines[0].split("\t"); f[5] = "90M"
+    open(sam, "w").write("\n".join(["\t".join(f)] + lines[1:]))                  # CIGAR shorter than the read
+    with pytest.raises(sim.SimError):
+        sim.run(tmp, 0, 5, 50, 2)
+    open(sam, "w").write(lines[0] + "\n")
+    with pytest.raises(sim.SimError, match="BROKEN BOWTIE FILE"):
+        sim.run(tmp, 0, 5, 50, 2)
+    os.remove(sam)
+    with pytest.raises(sim.SimError, match="CANNOT OPEN FILE"):
+        sim.run(tmp, 0, 5, 50, 2)
