@@ -324,6 +324,7 @@ int agx_unit_set_contig_threads(agx_unit *u, const char *appended, uint32_t n_ap
             u->T.cm[i] = ContiMer{cm[i].nuc, cm[i].cid, cm[i].coff, cm[i].next_off, cm[i].next_item};
         }
         u->T.initial_contigs.assign(initial_contigs ? initial_contigs : "", initial_len);
+        build_chains(u->T);
         u->have_threads = true; u->uploaded = false; u->built = false;
     });
 }

@@ -233,6 +233,7 @@ void thread_contigs_from_files(const std::string &contigs_fa, const std::string 
     T.cm_start.assign(n_pos + 1, 0); T.cm.clear(); T.cm.reserve(pool.size());
     for (size_t x = 0; x < n_pos; x++) { T.cm_start[x] = (agx_u32)T.cm.size(); for (int c = head[x]; c >= 0; c = pool[c].next) T.cm.push_back(pool[c].m); }
     T.cm_start[n_pos] = (agx_u32)T.cm.size();
+    build_chains(T);
 
     // tmp/_initial_contigs.<u>.fa, AG:1179-1216: runs of equal realID form one real contig; it is written when >= 50 % of its
     // chunks were placed on this unit

@@ -9,7 +9,9 @@
 #include "agx_host.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace agx {
@@ -89,10 +91,12 @@ void walk(Walker &W, std::string &pre_out, std::vector<Rec> &written) {
             agx_u32 last = cur;
             while ((mode == 1 && !W.done[cur]) || mode == 0) {
                 if (mode == 0) {                            // on a conti-mer, AG:2061-2138
-                    const ContiMer &m = T.cm[T.cm_start[cpp] + ipp];
-                    C.nuc.push_back(m.nuc); C.extended = 1;
-                    if (m.next_off != AGX_NONE) { pos_bak = m.next_off; cpp = m.next_off; ipp = m.next_item; }
-                    else {
+                    // follow the conti-mer chain to its end in one append (the reference steps through it one base at a time)
+                    const agx_u32 ci = T.cm_start[cpp] + ipp, ch = T.cm_chain[ci];
+                    const size_t from = T.chain_off[ch] + T.cm_idx[ci], to = T.chain_off[ch + 1];
+                    C.nuc.append(T.chain_str, from, to - from); C.extended = 1;
+                    if (to - from > 1) { pos_bak = T.chain_end_pos[ch]; cpp = pos_bak; }
+                    {
                         // chain end: hop onto the k-mer graph only through the single live node here and its single live edge (AG:2093-2136)
                         const agx_u32 b0 = G.node_start[cpp], bn = G.node_cnt[cpp];
                         agx_u32 live = 0, item = 0;
@@ -199,14 +203,50 @@ void scaffold(const Threads &T, const GraphView &G, std::vector<Rec> &c, std::st
 
 }  // namespace
 
+// chains of conti-mers: heads are the conti-mers nobody links to
+void build_chains(Threads &T) {
+    const size_t n = T.cm.size(), n_pos = T.ref.size();
+    T.cm_chain.assign(n, AGX_NONE); T.cm_idx.assign(n, 0); T.chain_off.assign(1, 0); T.chain_end_pos.clear(); T.chain_str.clear();
+    T.chain_str.reserve(n);
+    std::vector<agx_u8> linked(n, 0);
+    auto index_of = [&](agx_u32 off, agx_u32 item) -> size_t {
+        if (off >= n_pos || T.cm_start[off] + item >= T.cm_start[off + 1]) throw Error{E_ARG, "conti-mer link to a missing entry"};
+        return (size_t)T.cm_start[off] + item;
+    };
+    for (size_t i = 0; i < n; i++) if (T.cm[i].next_off != AGX_NONE) linked[index_of(T.cm[i].next_off, T.cm[i].next_item)] = 1;
+    std::vector<agx_u32> pos_of(n);
+    for (size_t x = 0; x < n_pos; x++) for (agx_u32 i = T.cm_start[x]; i < T.cm_start[x + 1]; i++) pos_of[i] = (agx_u32)x;
+    for (size_t h = 0; h < n; h++) {
+        if (linked[h]) continue;
+        const agx_u32 ch = (agx_u32)T.chain_end_pos.size();
+        size_t c = h; agx_u32 idx = 0;
+        for (;;) {
+            if (T.cm_chain[c] != AGX_NONE) throw Error{E_ARG, "conti-mer chains are not simple lists"};
+            T.cm_chain[c] = ch; T.cm_idx[c] = idx++; T.chain_str.push_back(T.cm[c].nuc);
+            if (T.cm[c].next_off == AGX_NONE) break;
+            c = index_of(T.cm[c].next_off, T.cm[c].next_item);
+        }
+        T.chain_end_pos.push_back(pos_of[c]); T.chain_off.push_back(T.chain_str.size());
+    }
+    for (size_t i = 0; i < n; i++) if (T.cm_chain[i] == AGX_NONE) throw Error{E_ARG, "conti-mer cycle"};
+}
+
 void walk_join_scaffold(const Threads &T, const Pairs &P, const GraphView &G, UnitOutput &out) {
+    if (T.cm_chain.size() != T.cm.size()) throw Error{E_ARG, "conti-mer chains were not built"};
     Walker W(T, P, G);
     std::vector<Rec> recs;
     out.initial_contigs = T.initial_contigs;
     out.pre_extended.clear(); out.extended.clear();
+    const bool timing = getenv("AGX_WALK_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
     walk(W, out.pre_extended, recs);
+    double t1 = now();
     join(recs);
+    double t2 = now();
     scaffold(T, G, recs, out.extended);
+    double t3 = now();
+    if (timing) fprintf(stderr, "[agx walk] walk %.1f ms, join %.1f ms, scaffold %.1f ms, %zu records\n", t1 - t0, t2 - t1, t3 - t2, recs.size());
 }
 
 }  // namespace agx

@@ -38,6 +38,7 @@ def synth(out, **kw):
         build()
     if os.path.exists(out):
         shutil.rmtree(out)
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     cmd = [SYNTH, "--out", out]
     for k, v in kw.items():
         cmd += ["--" + k.replace("_", "-"), str(v)]
