@@ -1,0 +1,63 @@
+"""Unit sharding across the GPUs of one node and the path's only exchange step.
+
+Units (chromosomes or --part slices) are independent (AG:4765-4783 shares no state between iterations), so
+multi-GPU is: assign units to ranks, build each on its own device, gather the per-unit FASTA byte buffers on rank 0.
+`torch.distributed` is plumbing only: backend "nccl" (= RCCL over xGMI) with device tensors on the GPU box, "gloo" with
+CPU tensors in the CPU test-suite.
+"""
+
+
+def assign_units(sizes, world):
+    """Longest-processing-time-first: returns world lists of unit indices; deterministic."""
+    order = sorted(range(len(sizes)), key=lambda u: (-sizes[u], u))
+    load = [0] * world
+    out = [[] for _ in range(world)]
+    for u in order:
+        r = min(range(world), key=lambda i: (load[i], i))
+        out[r].append(u)
+        load[r] += sizes[u]
+    return [sorted(x) for x in out]
+
+
+def gather_bytes(payload, dist, device, rank, world, dst=0):
+    """gather-v of one bytes object per rank to `dst`: all_gather of the 8-byte sizes, then one padded gather.
+    xGMI is point-to-point, so every peer->root transfer rides its own link; the payload (<= one unit's FASTA) is tiny
+    next to the build.  Returns the list of payloads on dst, None elsewhere."""
+    import torch
+    if dist is None or world == 1:
+        return [payload]
+    n = torch.tensor([len(payload)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    buf = torch.zeros(cap, dtype=torch.uint8, device=device)
+    if payload:
+        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    outs = [torch.zeros(cap, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, outs, dst=dst)
+    if rank != dst:
+        return None
+    return [bytes(o[:s].cpu().numpy().tobytes()) for o, s in zip(outs, sizes)]
+
+
+def pack_units(unit_ids, blobs):
+    """Length-prefixed concatenation of (unit id, bytes) so that one gather carries all units of a rank."""
+    import struct
+    out = [struct.pack("<I", len(unit_ids))]
+    for u, b in zip(unit_ids, blobs):
+        out.append(struct.pack("<IQ", u, len(b)))
+        out.append(b)
+    return b"".join(out)
+
+
+def unpack_units(payload):
+    import struct
+    (n,), p = struct.unpack_from("<I", payload, 0), 4
+    out = {}
+    for _ in range(n):
+        u, ln = struct.unpack_from("<IQ", payload, p)
+        p += 12
+        out[u] = payload[p:p + ln]
+        p += ln
+    return out
