@@ -55,7 +55,7 @@ class Stats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in ("n_pos", "n_ref", "n_hits", "n_runs", "n_nodes", "n_tiles", "n_tile_entries", "n_big_tiles",
                                                 "n_edge_overflow", "pairs_in_file", "sam_line_pairs")] + \
                [(n, ctypes.c_double) for n in ("ms_parse", "ms_thread", "ms_upload", "ms_prep", "ms_bin", "ms_node_sweep", "ms_node_big",
-                                                "ms_edge_sweep", "ms_download", "ms_walk")] + \
+                                                "ms_edge_sweep", "ms_compact", "ms_download", "ms_walk")] + \
                [("node_sweep_launches", ctypes.c_uint32), ("edge_sweep_launches", ctypes.c_uint32)]
 
 

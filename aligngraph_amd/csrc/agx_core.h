@@ -391,3 +391,77 @@ AGX_HD void agx_edge_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
         });
     }
 }
+
+// ---- walk preparation: alive-node renumbering and forced-run flags -------------------------------------------------------
+// The path walk (AG:1954-2204) only ever stands on nodes that survived the coverage prune.  After the edge sweep the
+// surviving ("alive") nodes get walk ids ("aid") laid out so that the main strand of the graph is contiguous:
+//     aid = X                          for the FIRST alive variant of position X          (main block, one slot per position)
+//     aid = n_pos + side_start[X] + j  for the (j+1)-th further alive variant of X       (side block, position-major)
+// so scanning "every position, every variant, if untraversed" (AG:1972-1978) is: slot X, then X's side range.
+// Out-edges are rewritten in aids with pruned targets dropped (a pruned node is `traversed` from the start, AG:1915, and
+// can never count as a live successor, AG:2027).  Every node gets a `cont` byte: 1 iff its only alive successor is aid+1.
+// Standing on such a node the walk has exactly one choice — step to aid+1 if that node is still unvisited, else stop
+// (AG:2020-2046) — so the host replays a run of cont==1 nodes with memchr/memcpy (the first already-visited node ends the
+// run) and only evaluates real branch points, jumps and dead ends.
+
+struct agx_compact_args {
+    // node table, old ids
+    const agx_u32 *node_start; const agx_u8 *node_cnt; const agx_u8 *n_flags; const agx_u8 *n_base; const agx_u32 *n_xpos;
+    const agx_u32 *nk_off0; const agx_sref *n_sref; const agx_u32 *n_next; const char *ref;
+    agx_u32 n_pos, n_nodes;
+    agx_u32 *side_cnt;             // [n_pos+1] alive variants beyond the first, per position (input of the scan)
+    const agx_u32 *side_start;     // [n_pos+1] exclusive scan of side_cnt
+    agx_u32 *aid_of;               // [n_nodes] walk id or NONE
+    // outputs indexed by aid, [n_pos + n_side]
+    char *a_str; agx_u8 *a_contig, *a_cont, *a_flags, *a_absent; agx_u32 *a_xpos, *a_off0, *a_next; agx_sref *a_sref;
+    const agx_edge_ovf *ovf; agx_u32 n_ovf; agx_edge_ovf *a_ovf;   // overflow edges rewritten in aids (edges touching pruned nodes become NONE/NONE)
+};
+
+AGX_HD void agx_side_count_pos(const agx_compact_args &A, agx_u32 X) {
+    if (X >= A.n_pos) return;
+    const agx_u32 s = A.node_start[X], n = A.node_cnt[X]; agx_u32 c = 0;
+    for (agx_u32 v = 0; v < n; v++) c += (A.n_flags[s + v] & AGX_NF_DEAD) ? 0u : 1u;
+    A.side_cnt[X] = c ? c - 1 : 0;
+}
+
+// per position, after the scan: walk ids of its nodes; main slots without an alive node are marked absent (= visited from the start)
+AGX_HD void agx_assign_aid_pos(const agx_compact_args &A, agx_u32 X) {
+    if (X >= A.n_pos) return;
+    const agx_u32 s = A.node_start[X], n = A.node_cnt[X]; agx_u32 side = A.n_pos + A.side_start[X]; bool first = true;
+    for (agx_u32 v = 0; v < n; v++) {
+        if (A.n_flags[s + v] & AGX_NF_DEAD) { A.aid_of[s + v] = AGX_NONE; continue; }
+        if (first) { A.aid_of[s + v] = X; first = false; } else A.aid_of[s + v] = side++;
+    }
+    A.a_absent[X] = first ? 1 : 0;
+    if (first) { A.a_cont[X] = 0; A.a_contig[X] = 0; A.a_str[X] = 'N'; A.a_flags[X] = 0; for (agx_u32 e = 0; e < AGX_MAXE; e++) A.a_next[(size_t)X * AGX_MAXE + e] = AGX_NONE; }
+}
+
+// per old node: write its record at its walk id
+AGX_HD void agx_emit_alive_node(const agx_compact_args &A, agx_u32 v) {
+    if (v >= A.n_nodes) return;
+    const agx_u32 a = A.aid_of[v];
+    if (a == AGX_NONE) return;
+    const agx_u32 x = A.n_xpos[v];
+    const char c = (char)A.n_base[v];
+    A.a_str[a] = c != 'X' ? c : A.ref[x];                 // consensus, else the reference base (AG:1997-2001)
+    A.a_contig[a] = (A.n_flags[v] & AGX_NF_CONTIG) ? 1 : 0;
+    A.a_flags[a] = A.n_flags[v] & AGX_NF_EOVF;
+    if (a >= A.n_pos) A.a_absent[a] = 0;
+    A.a_xpos[a] = x; A.a_off0[a] = A.nk_off0[v]; A.a_sref[a] = A.n_sref[v];
+    agx_u32 k = 0;
+    for (agx_u32 e = 0; e < AGX_MAXE; e++) {
+        const agx_u32 t = A.n_next[(size_t)v * AGX_MAXE + e];
+        if (t == AGX_NONE) break;
+        const agx_u32 ta = A.aid_of[t];
+        if (ta == AGX_NONE) continue;
+        A.a_next[(size_t)a * AGX_MAXE + k++] = ta;
+    }
+    A.a_cont[a] = (k == 1 && !(A.n_flags[v] & AGX_NF_EOVF) && A.a_next[(size_t)a * AGX_MAXE] == a + 1) ? 1 : 0;
+    for (; k < AGX_MAXE; k++) A.a_next[(size_t)a * AGX_MAXE + k] = AGX_NONE;
+}
+
+AGX_HD void agx_emit_alive_ovf(const agx_compact_args &A, agx_u32 i) {
+    if (i >= A.n_ovf) return;
+    const agx_u32 s = A.aid_of[A.ovf[i].src], d = A.aid_of[A.ovf[i].dst];
+    A.a_ovf[i] = (s == AGX_NONE || d == AGX_NONE) ? agx_edge_ovf{AGX_NONE, AGX_NONE} : agx_edge_ovf{s, d};
+}

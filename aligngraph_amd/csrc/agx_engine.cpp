@@ -30,14 +30,14 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 template <class T> struct DBuf {            // device buffer
     T *p = nullptr; size_t n = 0;
     void alloc(size_t count) { if (count <= n && p) return; release(); if (count) { HIP_OK(hipMalloc((void **)&p, count * sizeof(T))); n = count; } }
-    void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
     ~DBuf() { release(); }
     DBuf() = default; DBuf(const DBuf &) = delete; DBuf &operator=(const DBuf &) = delete;
 };
 template <class T> struct PBuf {            // pinned host buffer
     T *p = nullptr; size_t n = 0;
     void alloc(size_t count) { if (count <= n && p) return; release(); if (count) { HIP_OK(hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault)); n = count; } }
-    void release() { if (p) hipHostFree(p); p = nullptr; n = 0; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
     ~PBuf() { release(); }
     PBuf() = default; PBuf(const PBuf &) = delete; PBuf &operator=(const PBuf &) = delete;
 };
@@ -45,8 +45,8 @@ template <class T> struct PBuf {            // pinned host buffer
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr; bool used = false;
     void init() { HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); }
-    void destroy() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); a = b = nullptr; }
-    double ms() const { if (!used) return 0; float f = 0; hipEventElapsedTime(&f, a, b); return f; }
+    void destroy() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); a = b = nullptr; }
+    double ms() const { if (!used) return 0; float f = 0; (void)hipEventElapsedTime(&f, a, b); return f; }
 };
 
 }  // namespace
@@ -67,13 +67,18 @@ struct agx_unit {
     DBuf<agx_u32> d_node_start; DBuf<agx_u8> d_node_cnt;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_big_list, d_scratch;
+    // walk graph (agx_core.h "walk preparation")
+    agx_u32 n_ids = 0, ids_cap = 0;
+    DBuf<agx_u32> d_side_cnt, d_side_start, d_aid_of, d_a_xpos, d_a_off0, d_a_next; DBuf<char> d_a_str;
+    DBuf<agx_u8> d_a_contig, d_a_cont, d_a_flags, d_a_absent; DBuf<agx_sref> d_a_sref; DBuf<agx_edge_ovf> d_a_ovf;
     // downloaded
-    PBuf<agx_u32> h_node_start, h_off0, h_xpos, h_next; PBuf<agx_u8> h_node_cnt, h_base, h_flags; PBuf<agx_sref> h_sref; PBuf<agx_edge_ovf> h_ovf;
+    PBuf<agx_u32> h_side_start, h_a_xpos, h_a_off0, h_a_next; PBuf<char> h_a_str; PBuf<agx_u8> h_node_cnt, h_a_contig, h_a_cont, h_a_flags, h_a_absent;
+    PBuf<agx_sref> h_a_sref; PBuf<agx_edge_ovf> h_a_ovf;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0;
-    EventPair ev_prep, ev_bin, ev_node, ev_big, ev_edge;
+    EventPair ev_prep, ev_bin, ev_node, ev_big, ev_edge, ev_compact;
     agx_stats stats{};
-    ~agx_unit() { ev_prep.destroy(); ev_bin.destroy(); ev_node.destroy(); ev_big.destroy(); ev_edge.destroy(); if (st) hipStreamDestroy(st); }
+    ~agx_unit() { ev_prep.destroy(); ev_bin.destroy(); ev_node.destroy(); ev_big.destroy(); ev_edge.destroy(); ev_compact.destroy(); if (st) (void)hipStreamDestroy(st); }
 };
 
 namespace {
@@ -219,40 +224,74 @@ void do_build(agx_unit *u) {
         u->n_ovf = c;
         break;
     }
+
+    // ---- walk preparation: side counts -> scan -> walk ids, node records, rewritten edges, forced-run flags ----
+    {
+        agx_compact_args C; memset(&C, 0, sizeof C);
+        u->d_side_cnt.alloc((size_t)n_pos + 2); u->d_side_start.alloc((size_t)n_pos + 2); u->d_aid_of.alloc((size_t)u->n_nodes + 1);
+        const size_t nbs = ((size_t)n_pos + 1 + 1023) / 1024;
+        u->d_scan_tmp.alloc(2 * (nbs + 1) + 2 * ((nbs + 1023) / 1024 + 1) + 16);
+        C.node_start = u->d_node_start.p; C.node_cnt = u->d_node_cnt.p; C.n_flags = u->d_flags.p; C.n_base = u->d_base.p; C.n_xpos = u->d_xpos.p;
+        C.nk_off0 = u->d_off0.p; C.n_sref = u->d_sref.p; C.n_next = u->d_next.p; C.ref = u->d_ref.p; C.n_pos = n_pos; C.n_nodes = u->n_nodes;
+        C.side_cnt = u->d_side_cnt.p; C.side_start = u->d_side_start.p; C.aid_of = u->d_aid_of.p;
+        HIP_OK(hipEventRecord(u->ev_compact.a, st));
+        HIP_OK(hipMemsetAsync(u->d_side_cnt.p + n_pos, 0, 4, st));
+        agx_launch_side_count(&C, st);
+        agx_launch_exclusive_scan(u->d_side_cnt.p, u->d_side_start.p, n_pos, u->d_scan_tmp.p, st);
+        HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_side_start.p + n_pos, 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        const unsigned long long ids = (unsigned long long)n_pos + u->h_words.p[0];
+        if (ids >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "walk graph exceeds 2^32 ids"};
+        u->n_ids = (agx_u32)ids;
+        if (u->n_ids > u->ids_cap) {
+            const size_t cap = (size_t)u->n_ids + u->n_ids / 8 + 1024; u->ids_cap = (agx_u32)std::min<size_t>(cap, 0xFFFFFF00ull);
+            u->d_a_str.alloc(cap); u->d_a_contig.alloc(cap); u->d_a_cont.alloc(cap); u->d_a_flags.alloc(cap); u->d_a_absent.alloc(cap);
+            u->d_a_xpos.alloc(cap); u->d_a_off0.alloc(cap); u->d_a_next.alloc(cap * AGX_MAXE); u->d_a_sref.alloc(cap);
+        }
+        u->d_a_ovf.alloc((size_t)u->n_ovf + 1);
+        C.a_str = u->d_a_str.p; C.a_contig = u->d_a_contig.p; C.a_cont = u->d_a_cont.p; C.a_flags = u->d_a_flags.p; C.a_absent = u->d_a_absent.p;
+        C.a_xpos = u->d_a_xpos.p; C.a_off0 = u->d_a_off0.p; C.a_next = u->d_a_next.p; C.a_sref = u->d_a_sref.p;
+        C.ovf = u->d_ovf.p; C.n_ovf = u->n_ovf; C.a_ovf = u->d_a_ovf.p;
+        agx_launch_compact(&C, st);
+        HIP_OK(hipEventRecord(u->ev_compact.b, st)); u->ev_compact.used = true;
+    }
     HIP_OK(hipGetLastError());
     u->built = true; u->downloaded = false;
     u->stats.ms_prep = u->ev_prep.ms(); u->stats.ms_bin = u->ev_bin.ms(); u->stats.ms_node_sweep = u->ev_node.ms();
-    u->stats.ms_node_big = u->ev_big.ms(); u->stats.ms_edge_sweep = u->ev_edge.ms();
+    u->stats.ms_node_big = u->ev_big.ms(); u->stats.ms_edge_sweep = u->ev_edge.ms(); u->stats.ms_compact = u->ev_compact.ms();
 }
 
 void do_download(agx_unit *u) {
     if (!u->built) do_build(u);
     const double t0 = now_ms();
-    const size_t n_pos = u->T.ref.size(), nn = u->n_nodes;
+    const size_t n_pos = u->T.ref.size(), ni = u->n_ids;
     hipStream_t st = u->st;
-    u->h_node_start.alloc(n_pos); u->h_node_cnt.alloc(n_pos);
-    u->h_off0.alloc(nn + 1); u->h_xpos.alloc(nn + 1); u->h_next.alloc((nn + 1) * AGX_MAXE); u->h_base.alloc(nn + 1); u->h_flags.alloc(nn + 1); u->h_sref.alloc(nn + 1);
-    u->h_ovf.alloc((size_t)u->n_ovf + 1);
-    HIP_OK(hipMemcpyAsync(u->h_node_start.p, u->d_node_start.p, n_pos * 4, hipMemcpyDeviceToHost, st));
+    u->h_side_start.alloc(n_pos + 1); u->h_node_cnt.alloc(n_pos);
+    u->h_a_str.alloc(ni + 1); u->h_a_contig.alloc(ni + 1); u->h_a_cont.alloc(ni + 1); u->h_a_flags.alloc(ni + 1); u->h_a_absent.alloc(ni + 1);
+    u->h_a_xpos.alloc(ni + 1); u->h_a_off0.alloc(ni + 1); u->h_a_next.alloc((ni + 1) * AGX_MAXE); u->h_a_sref.alloc(ni + 1); u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
+    HIP_OK(hipMemcpyAsync(u->h_side_start.p, u->d_side_start.p, (n_pos + 1) * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(u->h_node_cnt.p, u->d_node_cnt.p, n_pos, hipMemcpyDeviceToHost, st));
-    if (nn) {
-        HIP_OK(hipMemcpyAsync(u->h_off0.p, u->d_off0.p, nn * 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_xpos.p, u->d_xpos.p, nn * 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_next.p, u->d_next.p, nn * AGX_MAXE * 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_base.p, u->d_base.p, nn, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_flags.p, u->d_flags.p, nn, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_sref.p, u->d_sref.p, nn * sizeof(agx_sref), hipMemcpyDeviceToHost, st));
+    if (ni) {
+        HIP_OK(hipMemcpyAsync(u->h_a_str.p, u->d_a_str.p, ni, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_a_contig.p, u->d_a_contig.p, ni, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_a_cont.p, u->d_a_cont.p, ni, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_a_flags.p, u->d_a_flags.p, ni, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_a_absent.p, u->d_a_absent.p, ni, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_a_xpos.p, u->d_a_xpos.p, ni * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_a_off0.p, u->d_a_off0.p, ni * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_a_next.p, u->d_a_next.p, ni * AGX_MAXE * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_a_sref.p, u->d_a_sref.p, ni * sizeof(agx_sref), hipMemcpyDeviceToHost, st));
     }
-    if (u->n_ovf) HIP_OK(hipMemcpyAsync(u->h_ovf.p, u->d_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf), hipMemcpyDeviceToHost, st));
+    if (u->n_ovf) HIP_OK(hipMemcpyAsync(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     u->downloaded = true;
     u->stats.ms_download = now_ms() - t0;
 }
 
 GraphView view_of(agx_unit *u) {
-    GraphView G; G.n_pos = (agx_u32)u->T.ref.size(); G.n_nodes = u->n_nodes; G.node_start = u->h_node_start.p; G.node_cnt = u->h_node_cnt.p;
-    G.base = u->h_base.p; G.flags = u->h_flags.p; G.off0 = u->h_off0.p; G.xpos = u->h_xpos.p; G.sref = u->h_sref.p; G.next = u->h_next.p;
-    G.ovf = u->h_ovf.p; G.n_ovf = u->n_ovf;
+    GraphView G; G.n_pos = (agx_u32)u->T.ref.size(); G.n_ids = u->n_ids; G.side_start = u->h_side_start.p; G.node_cnt = u->h_node_cnt.p;
+    G.absent = u->h_a_absent.p; G.str = u->h_a_str.p; G.contig = u->h_a_contig.p; G.cont = u->h_a_cont.p; G.flags = u->h_a_flags.p;
+    G.xpos = u->h_a_xpos.p; G.off0 = u->h_a_off0.p; G.sref = u->h_a_sref.p; G.next = u->h_a_next.p; G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf;
     return G;
 }
 
@@ -293,14 +332,14 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
     const int rc = guarded(u, [&] {
         HIP_OK(hipSetDevice(p->device));
         HIP_OK(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
-        u->ev_prep.init(); u->ev_bin.init(); u->ev_node.init(); u->ev_big.init(); u->ev_edge.init();
+        u->ev_prep.init(); u->ev_bin.init(); u->ev_node.init(); u->ev_big.init(); u->ev_edge.init(); u->ev_compact.init();
     });
     if (rc != AGX_OK) { delete u; return rc; }
     *out = u;
     return AGX_OK;
 }
 
-void agx_unit_destroy(agx_unit *u) { if (u) { hipSetDevice(u->prm.device); delete u; } }
+void agx_unit_destroy(agx_unit *u) { if (u) { (void)hipSetDevice(u->prm.device); delete u; } }
 
 const char *agx_unit_error(const agx_unit *u) { return u ? u->err.c_str() : "null unit"; }
 
@@ -397,32 +436,38 @@ int agx_unit_graph(agx_unit *u, agx_graph *g) {
     if (!u || !g) return AGX_E_ARG;
     memset(g, 0, sizeof *g);
     return guarded(u, [&] {
-        if (!u->downloaded) do_download(u);
+        if (!u->built) do_build(u);
+        HIP_OK(hipStreamSynchronize(u->st));
         const agx_u32 n_pos = (agx_u32)u->T.ref.size(), nn = u->n_nodes;
-        std::vector<agx_u32> cid(nn), coff(nn), cid0(nn), coff0(nn); std::vector<int> counts;
+        std::vector<agx_u32> node_start(n_pos), cid(nn), coff(nn), cid0(nn), coff0(nn), off0(nn), next((size_t)nn * AGX_MAXE); std::vector<agx_u8> node_cnt(n_pos);
+        std::vector<agx_sref> sref(nn); std::vector<int> counts; std::vector<agx_edge_ovf> ovf(u->n_ovf);
+        HIP_OK(hipMemcpy(node_start.data(), u->d_node_start.p, (size_t)n_pos * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(node_cnt.data(), u->d_node_cnt.p, n_pos, hipMemcpyDeviceToHost));
         if (nn) {
             HIP_OK(hipMemcpy(cid.data(), u->d_cid.p, (size_t)nn * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(coff.data(), u->d_coff.p, (size_t)nn * 4, hipMemcpyDeviceToHost));
             HIP_OK(hipMemcpy(cid0.data(), u->d_cid0.p, (size_t)nn * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(coff0.data(), u->d_coff0.p, (size_t)nn * 4, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(off0.data(), u->d_off0.p, (size_t)nn * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(next.data(), u->d_next.p, (size_t)nn * AGX_MAXE * 4, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(sref.data(), u->d_sref.p, (size_t)nn * sizeof(agx_sref), hipMemcpyDeviceToHost));
             if (u->prm.flags & AGX_FLAG_KEEP_COUNTS) { counts.resize((size_t)nn * 6); HIP_OK(hipMemcpy(counts.data(), u->d_counts.p, (size_t)nn * 24, hipMemcpyDeviceToHost)); }
         }
+        if (u->n_ovf) HIP_OK(hipMemcpy(ovf.data(), u->d_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf), hipMemcpyDeviceToHost));
         g->n_pos = n_pos; g->n_nodes = nn;
         g->node_start = (uint32_t *)malloc(4 * ((size_t)n_pos + 1)); g->node_key = (uint32_t *)malloc(24 * ((size_t)nn + 1)); g->node_cnt = (int32_t *)malloc(24 * ((size_t)nn + 1));
         g->node_slen = (uint32_t *)malloc(4 * ((size_t)nn + 1)); g->edge_start = (uint32_t *)malloc(4 * ((size_t)nn + 1));
         std::vector<agx_u32> canon(nn); agx_u32 id = 0;
-        for (agx_u32 x = 0; x < n_pos; x++) { g->node_start[x] = id; for (agx_u32 v = 0; v < u->h_node_cnt.p[x]; v++) canon[u->h_node_start.p[x] + v] = id++; }
+        for (agx_u32 x = 0; x < n_pos; x++) { g->node_start[x] = id; for (agx_u32 v = 0; v < node_cnt[x]; v++) canon[node_start[x] + v] = id++; }
         g->node_start[n_pos] = id;
         if (id != nn) throw Error{E_DEVICE, "node table is inconsistent (count mismatch)"};
         std::vector<std::vector<agx_u32> > adj(nn);
-        for (agx_u32 v = 0; v < nn; v++) for (agx_u32 e = 0; e < AGX_MAXE; e++) { const agx_u32 d = u->h_next.p[(size_t)v * AGX_MAXE + e]; if (d != AGX_NONE) adj[canon[v]].push_back(canon[d]); }
-        for (agx_u32 i = 0; i < u->n_ovf; i++) adj[canon[u->h_ovf.p[i].src]].push_back(canon[u->h_ovf.p[i].dst]);
+        for (agx_u32 v = 0; v < nn; v++) for (agx_u32 e = 0; e < AGX_MAXE; e++) { const agx_u32 d = next[(size_t)v * AGX_MAXE + e]; if (d != AGX_NONE) adj[canon[v]].push_back(canon[d]); }
+        for (agx_u32 i = 0; i < u->n_ovf; i++) adj[canon[ovf[i].src]].push_back(canon[ovf[i].dst]);
         size_t ne = 0;
         for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); ne += a.size(); }
         g->n_edges = (uint32_t)ne; g->edge_dst = (uint32_t *)malloc(4 * (ne + 1));
         for (agx_u32 v = 0; v < nn; v++) {
             const agx_u32 c = canon[v]; uint32_t *kk = g->node_key + 6 * (size_t)c;
-            kk[0] = cid[v]; kk[1] = coff[v]; kk[2] = cid0[v]; kk[3] = coff0[v]; kk[4] = u->h_off0.p[v] == AGX_NONE ? AGX_NONE : 0; kk[5] = u->h_off0.p[v];
+            kk[0] = cid[v]; kk[1] = coff[v]; kk[2] = cid0[v]; kk[3] = coff0[v]; kk[4] = off0[v] == AGX_NONE ? AGX_NONE : 0; kk[5] = off0[v];
             if (!counts.empty()) memcpy(g->node_cnt + 6 * (size_t)c, counts.data() + 6 * (size_t)v, 24); else for (int j = 0; j < 6; j++) g->node_cnt[6 * (size_t)c + j] = -1;
-            g->node_slen[c] = (u->h_sref.p[v].qlen >> 16) & 0x7FFF;
+            g->node_slen[c] = (sref[v].qlen >> 16) & 0x7FFF;
         }
         size_t eo = 0;
         for (agx_u32 c = 0; c < nn; c++) { g->edge_start[c] = (uint32_t)eo; for (agx_u32 d : adj[c]) g->edge_dst[eo++] = d; }

@@ -42,14 +42,18 @@ struct Pairs {
     unsigned long long n_pairs_in_file = 0, n_sam_pairs = 0, n_kept = 0;
 };
 
-// Node table + edges as downloaded from the device (or produced by the test executor)
+// Walk graph as downloaded from the device (or produced by the test executor); see agx_core.h "walk preparation".
+// Walk ids: [0, n_pos) = first alive variant of each position (absent[] = 1 where there is none), [n_pos, n_ids) = further variants.
 struct GraphView {
-    agx_u32 n_pos = 0, n_nodes = 0;
-    const agx_u32 *node_start = nullptr; const agx_u8 *node_cnt = nullptr;
-    const agx_u8 *base = nullptr; const agx_u8 *flags = nullptr;
-    const agx_u32 *off0 = nullptr; const agx_u32 *xpos = nullptr; const agx_sref *sref = nullptr;
-    const agx_u32 *next = nullptr;                          // [n_nodes*AGX_MAXE]
-    const agx_edge_ovf *ovf = nullptr; size_t n_ovf = 0;     // unsorted, may hold duplicates
+    agx_u32 n_pos = 0, n_ids = 0;
+    const agx_u32 *side_start = nullptr;                    // [n_pos+1] side variants of position x are n_pos+side_start[x] .. n_pos+side_start[x+1]
+    const agx_u8 *node_cnt = nullptr;                       // [n_pos] ALL variants incl. pruned ones (scaffold gap rule, AG:2428)
+    const agx_u8 *absent = nullptr;                         // [n_ids] 1 = no node at this id (treated as visited)
+    const char *str = nullptr;                              // [n_ids] base a node emits
+    const agx_u8 *contig = nullptr, *cont = nullptr, *flags = nullptr;   // contigOffset != -1; forced step to id+1; AGX_NF_EOVF
+    const agx_u32 *xpos = nullptr, *off0 = nullptr; const agx_sref *sref = nullptr;
+    const agx_u32 *next = nullptr;                          // [n_ids*AGX_MAXE] alive successors, NONE padded
+    const agx_edge_ovf *ovf = nullptr; size_t n_ovf = 0;     // walk ids; NONE/NONE entries and duplicates are ignored
 };
 
 struct UnitOutput { std::string initial_contigs, pre_extended, extended; };

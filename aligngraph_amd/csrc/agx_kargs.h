@@ -32,4 +32,7 @@ void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_
 void agx_launch_node_sweep(const agx_node_kargs *, hipStream_t);
 void agx_launch_node_sweep_big(const agx_node_kargs *, hipStream_t);
 void agx_launch_edge_sweep(const agx_edge_kargs *, hipStream_t);
+// walk preparation (agx_core.h): per-position side counts; then (after the scan) ids, records and overflow edges
+void agx_launch_side_count(const agx_compact_args *, hipStream_t);
+void agx_launch_compact(const agx_compact_args *, hipStream_t);
 }

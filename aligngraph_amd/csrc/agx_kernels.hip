@@ -138,6 +138,12 @@ __global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
     });
 }
 
+// ---- walk preparation: renumber surviving nodes, rewrite edges, mark forced runs (agx_core.h) -------------------------------
+__global__ void __launch_bounds__(256) agx_k_side_count(agx_compact_args A) { agx_side_count_pos(A, blockIdx.x * 256u + threadIdx.x); }
+__global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A) { agx_assign_aid_pos(A, blockIdx.x * 256u + threadIdx.x); }
+__global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A) { agx_emit_alive_node(A, blockIdx.x * 256u + threadIdx.x); }
+__global__ void __launch_bounds__(256) agx_k_emit_ovf(agx_compact_args A) { agx_emit_alive_ovf(A, blockIdx.x * 256u + threadIdx.x); }
+
 // ---- host-callable launchers (kept in this translation unit so that the engine is plain C++) -------------------------
 extern "C" {
 
@@ -182,6 +188,15 @@ void agx_launch_node_sweep_big(const agx_node_kargs *K, hipStream_t st) {
 void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;
     if (n) hipLaunchKernelGGL(agx_k_edge_sweep, dim3((n + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
+}
+
+void agx_launch_side_count(const agx_compact_args *A, hipStream_t st) {
+    if (A->n_pos) hipLaunchKernelGGL(agx_k_side_count, dim3((A->n_pos + 255) / 256), dim3(256), 0, st, *A);
+}
+void agx_launch_compact(const agx_compact_args *A, hipStream_t st) {
+    if (A->n_pos) hipLaunchKernelGGL(agx_k_assign_aid, dim3((A->n_pos + 255) / 256), dim3(256), 0, st, *A);
+    if (A->n_nodes) hipLaunchKernelGGL(agx_k_emit_alive, dim3((A->n_nodes + 255) / 256), dim3(256), 0, st, *A);
+    if (A->n_ovf) hipLaunchKernelGGL(agx_k_emit_ovf, dim3((A->n_ovf + 255) / 256), dim3(256), 0, st, *A);
 }
 
 }  // extern "C"

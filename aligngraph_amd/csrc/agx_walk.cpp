@@ -23,6 +23,10 @@ struct Rec {                 // Contig, AG:123-139
     std::string nuc;
 };
 
+// A walk is first recorded as a list of byte ranges (runs of node bases, conti-mer chain suffixes, the trailing k-mer);
+// most walks end up contained in the previously written record (AG:2176) and are dropped without ever being copied.
+struct Seg { const char *p; size_t n; };
+
 inline bool contains(agx_u32 sID1, agx_u32 sOff1, agx_u32 eID1, agx_u32 eOff1, agx_u32 sID2, agx_u32 sOff2, agx_u32 eID2, agx_u32 eOff2) {
     return sID1 == sID2 && eID1 == eID2 && sOff1 <= sOff2 && eOff1 >= eOff2;      // AG:1897-1902
 }
@@ -33,15 +37,15 @@ inline void fasta_body(std::string &out, const char *s, size_t n) {
 
 struct Walker {
     const Threads &T; const Pairs &P; const GraphView &G;
-    std::vector<agx_u8> done;                       // traversed flag per node, seeded with the prune result
+    std::vector<agx_u8> done;                       // traversed flag per ALIVE node (pruned nodes never reach the host)
     std::vector<agx_edge_ovf> ovf;                  // sorted, unique
-    Walker(const Threads &t, const Pairs &p, const GraphView &g) : T(t), P(p), G(g), done(g.n_nodes) {
-        for (agx_u32 i = 0; i < g.n_nodes; i++) done[i] = (g.flags[i] & AGX_NF_DEAD) ? 1 : 0;
-        ovf.assign(g.ovf, g.ovf + g.n_ovf);
+    Walker(const Threads &t, const Pairs &p, const GraphView &g) : T(t), P(p), G(g), done((size_t)g.n_ids + 8, 1) {
+        if (g.n_ids) memcpy(done.data(), g.absent, g.n_ids);              // ids without a node count as visited; the tail is a sentinel
+        for (size_t i = 0; i < g.n_ovf; i++) if (g.ovf[i].src != AGX_NONE) ovf.push_back(g.ovf[i]);
         std::sort(ovf.begin(), ovf.end(), [](const agx_edge_ovf &a, const agx_edge_ovf &b) { return a.src != b.src ? a.src < b.src : a.dst < b.dst; });
         ovf.erase(std::unique(ovf.begin(), ovf.end(), [](const agx_edge_ovf &a, const agx_edge_ovf &b) { return a.src == b.src && a.dst == b.dst; }), ovf.end());
     }
-    // the single live successor of node v, if it has exactly one (AG:2020-2033); returns the count, capped at 2
+    // number of live (unvisited) successors of node v, capped at 2; target = the last one seen (AG:2020-2033)
     int live_successors(agx_u32 v, agx_u32 &target) const {
         int n = 0;
         const agx_u32 *s = G.next + (size_t)v * AGX_MAXE;
@@ -66,6 +70,14 @@ struct Walker {
             else { const char c = p[first - i]; out.push_back(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c); }
         }
     }
+    // first unvisited node with id in [from, n) (n if none): the position scan of AG:1972-1978 in walk-id space
+    agx_u32 next_live(agx_u32 from, agx_u32 n) const {
+        agx_u32 i = from;
+        while (i < n && (i & 7u)) { if (!done[i]) return i; i++; }
+        for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, &done[i], 8); if (w != 0x0101010101010101ull) break; }
+        while (i < n && done[i]) i++;
+        return i < n ? i : n;
+    }
 };
 
 std::string header_of(agx_u32 id, const Rec &c) {      // AG:2178
@@ -74,45 +86,58 @@ std::string header_of(agx_u32 id, const Rec &c) {      // AG:2178
     return buf;
 }
 
-// extdContigs1, AG:1954-2204
+// extdContigs1, AG:1954-2204, replayed on the alive-compacted graph.  Alive ids are position-major, so "for every
+// position, for every variant, if untraversed" (AG:1972-1978) is "for every alive id in order, if not done".
 void walk(Walker &W, std::string &pre_out, std::vector<Rec> &written) {
     const GraphView &G = W.G; const Threads &T = W.T;
     agx_u32 seqID = 0, sIDBak = AGX_NONE, sOffBak = AGX_NONE, eIDBak = AGX_NONE, eOffBak = AGX_NONE;
     agx_u32 pos_bak = 0;                         // cppBak of the reference (function scope)
     std::string kmer;
+    std::vector<Seg> segs;
+    agx_u8 *done = W.done.data();
+    unsigned long long n_walks = 0, n_hops = 0, n_runs = 0, n_general = 0, run_nodes = 0, od_hist[8] = {0};
     for (agx_u32 cp = 0; cp < G.n_pos;) {
-        const agx_u32 n0 = G.node_start[cp], nc = G.node_cnt[cp];
-        for (agx_u32 ip = 0; ip < nc; ip++) {
-            if (W.done[n0 + ip]) continue;
+        // variants of position cp in order: its main slot, then its side range
+        const agx_u32 s_lo = G.n_pos + G.side_start[cp], s_hi = G.n_pos + G.side_start[cp + 1];
+        for (agx_u32 vi = 0, start = cp; vi <= s_hi - s_lo; vi++, start = s_lo + vi - 1) {
+            if (done[start]) continue;
             Rec C; C.sID = 0; C.sOff = cp; C.extended = 0;
-            agx_u32 cur = n0 + ip;               // current k-mer node (mode 1)
+            segs.clear(); n_walks++;
+            agx_u32 cur = start;                 // current k-mer node (mode 1)
             C.sID0 = G.off0[cur] == AGX_NONE ? AGX_NONE : 0; C.sOff0 = G.off0[cur];
-            agx_u32 cpp = cp, ipp = ip; int mode = 1;      // mode = kMerTag
+            agx_u32 cpp = cp, ipp = 0; int mode = 1;      // mode = kMerTag
             agx_u32 last = cur;
-            while ((mode == 1 && !W.done[cur]) || mode == 0) {
+            while ((mode == 1 && !done[cur]) || mode == 0) {
                 if (mode == 0) {                            // on a conti-mer, AG:2061-2138
                     // follow the conti-mer chain to its end in one append (the reference steps through it one base at a time)
                     const agx_u32 ci = T.cm_start[cpp] + ipp, ch = T.cm_chain[ci];
                     const size_t from = T.chain_off[ch] + T.cm_idx[ci], to = T.chain_off[ch + 1];
-                    C.nuc.append(T.chain_str, from, to - from); C.extended = 1;
+                    segs.push_back(Seg{T.chain_str.data() + from, to - from}); C.extended = 1; n_hops++;
                     if (to - from > 1) { pos_bak = T.chain_end_pos[ch]; cpp = pos_bak; }
-                    {
-                        // chain end: hop onto the k-mer graph only through the single live node here and its single live edge (AG:2093-2136)
-                        const agx_u32 b0 = G.node_start[cpp], bn = G.node_cnt[cpp];
-                        agx_u32 live = 0, item = 0;
-                        for (agx_u32 v = 0; v < bn; v++) if (!W.done[b0 + v]) { live++; item = b0 + v; }
-                        agx_u32 tgt = 0; int ns = 0;
-                        if (live == 1) ns = W.live_successors(item, tgt);
-                        if (ns == 1) { cur = tgt; pos_bak = G.xpos[tgt]; cpp = pos_bak; mode = W.done[cur] ? -2 : 1; }
-                        else mode = -2;
-                    }
+                    // chain end: hop onto the k-mer graph only through the single live node here and its single live edge (AG:2093-2136)
+                    agx_u32 live = 0, item = 0;
+                    if (!done[cpp]) { live++; item = cpp; }
+                    for (agx_u32 v = G.n_pos + G.side_start[cpp]; v < G.n_pos + G.side_start[cpp + 1]; v++) if (!done[v]) { live++; item = v; }
+                    agx_u32 tgt = 0; int ns = 0;
+                    if (live == 1) ns = W.live_successors(item, tgt);
+                    if (ns == 1) { cur = tgt; pos_bak = G.xpos[tgt]; cpp = pos_bak; mode = done[cur] ? -2 : 1; }
+                    else mode = -2;
                 } else {                                    // on a k-mer node, AG:1995-2060
-                    const char c = (char)G.base[cur];
-                    C.nuc.push_back(c != 'X' ? c : T.ref[cpp]);
-                    if (G.flags[cur] & AGX_NF_CONTIG) C.extended = 1;
-                    W.done[cur] = 1; last = cur;
+                    // forced run: while cont[] holds and the next node is unvisited the reference steps cur -> cur+1 (unique live successor)
+                    agx_u32 j = cur;
+                    if (G.cont[cur]) {
+                        const agx_u8 *z = (const agx_u8 *)memchr(G.cont + cur, 0, G.n_ids - cur);         // first node of the run without a forced step
+                        const agx_u32 run_end = z ? (agx_u32)(z - G.cont) : G.n_ids - 1;
+                        const agx_u8 *d = (const agx_u8 *)memchr(done + cur + 1, 1, run_end - cur);       // first already-visited node inside the run
+                        j = d ? (agx_u32)(d - done) - 1 : run_end;
+                    }
+                    segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!G.cont[j]) { n_general++; int od = 0; for (agx_u32 e = 0; e < AGX_MAXE; e++) od += G.next[(size_t)j * AGX_MAXE + e] != AGX_NONE; od_hist[od]++; }
+                    if (!C.extended && memchr(G.contig + cur, 1, (size_t)j - cur + 1)) C.extended = 1;
+                    memset(done + cur, 1, (size_t)j - cur + 1);
+                    if (j > cur) pos_bak = G.xpos[j];
+                    cur = j; last = j; cpp = G.xpos[j];
                     agx_u32 tgt = 0;
-                    const int ns = W.live_successors(cur, tgt);
+                    const int ns = G.cont[cur] ? 0 : W.live_successors(cur, tgt);      // cont && stopped: its only alive successor is already visited
                     if (ns == 1) { cur = tgt; pos_bak = G.xpos[tgt]; cpp = pos_bak; }
                     else {
                         const agx_u32 c0 = T.cm_start[cpp], cn = T.cm_start[cpp + 1] - c0;
@@ -126,18 +151,31 @@ void walk(Walker &W, std::string &pre_out, std::vector<Rec> &written) {
             if (mode == 1 || mode == -1) {
                 C.eID0 = G.off0[cur] == AGX_NONE ? AGX_NONE : 0; C.eOff0 = G.off0[cur];
                 W.kmer_string(last, kmer);
-                if (kmer.size() > 1) C.nuc.append(kmer, 1, std::string::npos);
+                if (kmer.size() > 1) segs.push_back(Seg{kmer.data() + 1, kmer.size() - 1});
                 C.eOff = C.eOff + (agx_u32)kmer.size() - 1; C.eOff0 = C.eOff0 + (agx_u32)kmer.size() - 1;
             } else { C.eID0 = AGX_NONE; C.eOff0 = AGX_NONE; }
             if (!contains(sIDBak, sOffBak, eIDBak, eOffBak, C.sID, C.sOff, C.eID, C.eOff)) {        // AG:2176-2189
+                size_t total = 0; for (const Seg &g : segs) total += g.n;
+                C.nuc.reserve(total); for (const Seg &g : segs) C.nuc.append(g.p, g.n);
                 pre_out += header_of(seqID++, C);
                 fasta_body(pre_out, C.nuc.data(), C.nuc.size());
                 sIDBak = C.sID; sOffBak = C.sOff; eIDBak = C.eID; eOffBak = C.eOff;
                 written.push_back(std::move(C));
             }
         }
-        if (eOffBak - sOffBak > 100000 && eIDBak == 0 && cp + 1000 < eOffBak) cp += 1000; else cp++;     // AG:2194-2202
+        // AG:2194-2202: inside a written record longer than 100 kb the scan jumps 1000 positions at a time; otherwise it moves to the
+        // next position — and positions without an unvisited node do nothing, so jump straight to the next unvisited node's position
+        if (eOffBak - sOffBak > 100000 && eIDBak == 0 && cp + 1000 < eOffBak) cp += 1000;
+        else {
+            // the +1000 rule is re-evaluated at every position on the way, but it can only switch ON again after a new record is
+            // written, which needs an unvisited node: skipping node-less positions one by one or at once is the same
+            const agx_u32 m = W.next_live(cp + 1, G.n_pos);                                  // main slot id == position
+            const agx_u32 sd = W.next_live(G.n_pos + G.side_start[cp + 1], G.n_ids);
+            const agx_u32 sp = sd < G.n_ids ? G.xpos[sd] : G.n_pos;
+            cp = m < sp ? m : sp;
+        }
     }
+    if (getenv("AGX_WALK_TIMING")) fprintf(stderr, "[agx walk] walks %llu, contig hops %llu, runs %llu (%llu nodes), general evaluations %llu (outdeg 0:%llu 1:%llu 2:%llu 3:%llu 4:%llu)\n", n_walks, n_hops, n_runs, run_nodes, n_general, od_hist[0], od_hist[1], od_hist[2], od_hist[3], od_hist[4]);
 }
 
 }  // namespace

@@ -92,7 +92,7 @@ typedef struct {
 typedef struct {
     uint64_t n_pos, n_ref, n_hits, n_runs, n_nodes, n_tiles, n_tile_entries, n_big_tiles, n_edge_overflow;
     uint64_t pairs_in_file, sam_line_pairs;
-    double ms_parse, ms_thread, ms_upload, ms_prep, ms_bin, ms_node_sweep, ms_node_big, ms_edge_sweep, ms_download, ms_walk;
+    double ms_parse, ms_thread, ms_upload, ms_prep, ms_bin, ms_node_sweep, ms_node_big, ms_edge_sweep, ms_compact, ms_download, ms_walk;
     uint32_t node_sweep_launches, edge_sweep_launches;
 } agx_stats;
 

@@ -23,6 +23,10 @@ struct SimGraph {
     std::vector<agx_u8> base, flags; std::vector<agx_sref> sref; std::vector<int> counts;
     std::vector<agx_edge_ovf> ovf;
     agx_u32 n_nodes = 0;
+    // alive-compacted view (agx_core.h "walk preparation")
+    agx_u32 n_ids = 0;
+    std::vector<agx_u32> side_cnt, side_start, aid_of, a_xpos, a_off0, a_next; std::string a_str;
+    std::vector<agx_u8> a_contig, a_cont, a_flags, a_absent; std::vector<agx_sref> a_sref; std::vector<agx_edge_ovf> a_ovf;
     void reserve(size_t cap) {
         cid.resize(cap); coff.resize(cap); cid0.resize(cap); coff0.resize(cap); off0.resize(cap); xpos.resize(cap); next.resize(cap * AGX_MAXE);
         base.resize(cap); flags.resize(cap); sref.resize(cap); counts.resize(cap * 6);
@@ -90,6 +94,26 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     for (agx_u32 t = 0; t < n_tiles; t++)
         for (agx_u32 lane = 0; lane < AGX_TILE; lane++)
             agx_edge_sweep_lane(A, t, t * AGX_TILE + lane, [&](agx_u32 s, agx_u32 d) { S.ovf.push_back(agx_edge_ovf{s, d}); });
+
+    // walk preparation, the same per-element functions the compaction kernels run
+    agx_compact_args C; memset(&C, 0, sizeof C);
+    S.side_cnt.assign((size_t)n_pos + 1, 0); S.side_start.assign((size_t)n_pos + 1, 0); S.aid_of.assign((size_t)S.n_nodes + 1, AGX_NONE);
+    C.node_start = S.node_start.data(); C.node_cnt = S.node_cnt.data(); C.n_flags = S.flags.data(); C.n_base = S.base.data(); C.n_xpos = S.xpos.data();
+    C.nk_off0 = S.off0.data(); C.n_sref = S.sref.data(); C.n_next = S.next.data(); C.ref = T.ref.data(); C.n_pos = n_pos; C.n_nodes = S.n_nodes;
+    C.side_cnt = S.side_cnt.data(); C.side_start = S.side_start.data(); C.aid_of = S.aid_of.data();
+    for (agx_u32 x = 0; x < n_pos; x++) agx_side_count_pos(C, x);
+    agx_u32 run = 0; for (agx_u32 x = 0; x <= n_pos; x++) { S.side_start[x] = run; run += S.side_cnt[x]; }
+    S.n_ids = n_pos + run;
+    const size_t na = (size_t)S.n_ids + 1;
+    S.a_str.assign(na, 0); S.a_contig.assign(na, 0); S.a_cont.assign(na, 0); S.a_flags.assign(na, 0); S.a_absent.assign(na, 1);
+    S.a_xpos.assign(na, 0); S.a_off0.assign(na, 0); S.a_next.assign(na * AGX_MAXE, AGX_NONE); S.a_sref.assign(na, agx_sref{0, 0});
+    S.a_ovf.assign(S.ovf.size() + 1, agx_edge_ovf{AGX_NONE, AGX_NONE});
+    C.a_str = &S.a_str[0]; C.a_contig = S.a_contig.data(); C.a_cont = S.a_cont.data(); C.a_flags = S.a_flags.data(); C.a_absent = S.a_absent.data();
+    C.a_xpos = S.a_xpos.data(); C.a_off0 = S.a_off0.data(); C.a_next = S.a_next.data(); C.a_sref = S.a_sref.data();
+    C.ovf = S.ovf.data(); C.n_ovf = (agx_u32)S.ovf.size(); C.a_ovf = S.a_ovf.data();
+    for (agx_u32 x = 0; x < n_pos; x++) agx_assign_aid_pos(C, x);
+    for (agx_u32 v = 0; v < S.n_nodes; v++) agx_emit_alive_node(C, v);
+    for (agx_u32 i = 0; i < C.n_ovf; i++) agx_emit_alive_ovf(C, i);
 }
 
 char *dup_buf(const std::string &s) { char *p = (char *)malloc(s.size() + 1); memcpy(p, s.data(), s.size()); p[s.size()] = 0; return p; }
@@ -118,9 +142,10 @@ int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int cover
         load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + u + ".bowtie", batch, (agx_u32)k, P);
         SimGraph S; int nbig = 0;
         simulate(T, P, (agx_u32)k, iv, coverage, maxv_first > 0 ? (agx_u32)maxv_first : AGX_MAXV_LDS, S, nbig);
-        GraphView G; G.n_pos = (agx_u32)T.ref.size(); G.n_nodes = S.n_nodes; G.node_start = S.node_start.data(); G.node_cnt = S.node_cnt.data();
-        G.base = S.base.data(); G.flags = S.flags.data(); G.off0 = S.off0.data(); G.xpos = S.xpos.data(); G.sref = S.sref.data(); G.next = S.next.data();
-        G.ovf = S.ovf.data(); G.n_ovf = S.ovf.size();
+        GraphView G; G.n_pos = (agx_u32)T.ref.size(); G.n_ids = S.n_ids; G.side_start = S.side_start.data(); G.node_cnt = S.node_cnt.data();
+        G.absent = S.a_absent.data(); G.str = S.a_str.data(); G.contig = S.a_contig.data(); G.cont = S.a_cont.data(); G.flags = S.a_flags.data();
+        G.xpos = S.a_xpos.data(); G.off0 = S.a_off0.data(); G.sref = S.a_sref.data(); G.next = S.a_next.data();
+        G.ovf = S.a_ovf.data(); G.n_ovf = S.ovf.size();
         UnitOutput O; walk_join_scaffold(T, P, G, O);
         out->initial_contigs = dup_buf(O.initial_contigs); out->initial_len = O.initial_contigs.size();
         out->pre_extended = dup_buf(O.pre_extended); out->pre_len = O.pre_extended.size();
