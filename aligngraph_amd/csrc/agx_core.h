@@ -404,6 +404,11 @@ AGX_HD void agx_edge_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
 // (AG:2020-2046) — so the host replays a run of cont==1 nodes with memchr/memcpy (the first already-visited node ends the
 // run) and only evaluates real branch points, jumps and dead ends.
 
+// per-node record the walk reads at branch points, record starts and record ends: one 32-byte line instead of four arrays
+struct agx_walknode { agx_u32 next[AGX_MAXE]; agx_u32 off0, xpos; agx_sref sref; };
+
+enum { AGX_WM_CONT = 1, AGX_WM_CONTIG = 2, AGX_WM_ABSENT = 128 };   // forced step to id+1; contigOffset != -1 (AG:2004); no node at this id
+
 struct agx_compact_args {
     // node table, old ids
     const agx_u32 *node_start; const agx_u8 *node_cnt; const agx_u8 *n_flags; const agx_u8 *n_base; const agx_u32 *n_xpos;
@@ -413,7 +418,7 @@ struct agx_compact_args {
     const agx_u32 *side_start;     // [n_pos+1] exclusive scan of side_cnt
     agx_u32 *aid_of;               // [n_nodes] walk id or NONE
     // outputs indexed by aid, [n_pos + n_side]
-    char *a_str; agx_u8 *a_contig, *a_cont, *a_flags, *a_absent; agx_u32 *a_xpos, *a_off0, *a_next; agx_sref *a_sref;
+    char *a_str; agx_u8 *a_meta; agx_walknode *a_node;   // a_meta: AGX_WM_* bits
     const agx_edge_ovf *ovf; agx_u32 n_ovf; agx_edge_ovf *a_ovf;   // overflow edges rewritten in aids (edges touching pruned nodes become NONE/NONE)
 };
 
@@ -432,8 +437,7 @@ AGX_HD void agx_assign_aid_pos(const agx_compact_args &A, agx_u32 X) {
         if (A.n_flags[s + v] & AGX_NF_DEAD) { A.aid_of[s + v] = AGX_NONE; continue; }
         if (first) { A.aid_of[s + v] = X; first = false; } else A.aid_of[s + v] = side++;
     }
-    A.a_absent[X] = first ? 1 : 0;
-    if (first) { A.a_cont[X] = 0; A.a_contig[X] = 0; A.a_str[X] = 'N'; A.a_flags[X] = 0; for (agx_u32 e = 0; e < AGX_MAXE; e++) A.a_next[(size_t)X * AGX_MAXE + e] = AGX_NONE; }
+    if (first) { A.a_meta[X] = AGX_WM_ABSENT; A.a_str[X] = 'N'; agx_walknode w; for (agx_u32 e = 0; e < AGX_MAXE; e++) w.next[e] = AGX_NONE; w.off0 = AGX_NONE; w.xpos = X; w.sref = agx_sref{0, 0}; A.a_node[X] = w; }
 }
 
 // per old node: write its record at its walk id
@@ -444,20 +448,19 @@ AGX_HD void agx_emit_alive_node(const agx_compact_args &A, agx_u32 v) {
     const agx_u32 x = A.n_xpos[v];
     const char c = (char)A.n_base[v];
     A.a_str[a] = c != 'X' ? c : A.ref[x];                 // consensus, else the reference base (AG:1997-2001)
-    A.a_contig[a] = (A.n_flags[v] & AGX_NF_CONTIG) ? 1 : 0;
-    A.a_flags[a] = A.n_flags[v] & AGX_NF_EOVF;
-    if (a >= A.n_pos) A.a_absent[a] = 0;
-    A.a_xpos[a] = x; A.a_off0[a] = A.nk_off0[v]; A.a_sref[a] = A.n_sref[v];
+    agx_walknode w; w.off0 = A.nk_off0[v]; w.xpos = x; w.sref = A.n_sref[v];
     agx_u32 k = 0;
     for (agx_u32 e = 0; e < AGX_MAXE; e++) {
         const agx_u32 t = A.n_next[(size_t)v * AGX_MAXE + e];
         if (t == AGX_NONE) break;
         const agx_u32 ta = A.aid_of[t];
-        if (ta == AGX_NONE) continue;
-        A.a_next[(size_t)a * AGX_MAXE + k++] = ta;
+        if (ta != AGX_NONE) w.next[k++] = ta;
     }
-    A.a_cont[a] = (k == 1 && !(A.n_flags[v] & AGX_NF_EOVF) && A.a_next[(size_t)a * AGX_MAXE] == a + 1) ? 1 : 0;
-    for (; k < AGX_MAXE; k++) A.a_next[(size_t)a * AGX_MAXE + k] = AGX_NONE;
+    // a node whose edges spilled to the overflow list keeps all four slots... unless some pointed at pruned nodes: mark it
+    // by never being `cont`; the host consults the overflow list for every node it finds there
+    A.a_meta[a] = (agx_u8)(((k == 1 && !(A.n_flags[v] & AGX_NF_EOVF) && w.next[0] == a + 1) ? AGX_WM_CONT : 0) | ((A.n_flags[v] & AGX_NF_CONTIG) ? AGX_WM_CONTIG : 0));
+    for (; k < AGX_MAXE; k++) w.next[k] = AGX_NONE;
+    A.a_node[a] = w;
 }
 
 AGX_HD void agx_emit_alive_ovf(const agx_compact_args &A, agx_u32 i) {

@@ -69,11 +69,11 @@ struct agx_unit {
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_big_list, d_scratch;
     // walk graph (agx_core.h "walk preparation")
     agx_u32 n_ids = 0, ids_cap = 0;
-    DBuf<agx_u32> d_side_cnt, d_side_start, d_aid_of, d_a_xpos, d_a_off0, d_a_next; DBuf<char> d_a_str;
-    DBuf<agx_u8> d_a_contig, d_a_cont, d_a_flags, d_a_absent; DBuf<agx_sref> d_a_sref; DBuf<agx_edge_ovf> d_a_ovf;
+    DBuf<agx_u32> d_side_cnt, d_side_start, d_aid_of; DBuf<char> d_a_str;
+    DBuf<agx_u8> d_a_meta; DBuf<agx_walknode> d_a_node; DBuf<agx_edge_ovf> d_a_ovf;
     // downloaded
-    PBuf<agx_u32> h_side_start, h_a_xpos, h_a_off0, h_a_next; PBuf<char> h_a_str; PBuf<agx_u8> h_node_cnt, h_a_contig, h_a_cont, h_a_flags, h_a_absent;
-    PBuf<agx_sref> h_a_sref; PBuf<agx_edge_ovf> h_a_ovf;
+    PBuf<agx_u32> h_side_start; PBuf<char> h_a_str; PBuf<agx_u8> h_node_cnt, h_a_meta;
+    PBuf<agx_walknode> h_a_node; PBuf<agx_edge_ovf> h_a_ovf;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0;
     EventPair ev_prep, ev_bin, ev_node, ev_big, ev_edge, ev_compact;
@@ -245,15 +245,14 @@ void do_build(agx_unit *u) {
         u->n_ids = (agx_u32)ids;
         if (u->n_ids > u->ids_cap) {
             const size_t cap = (size_t)u->n_ids + u->n_ids / 8 + 1024; u->ids_cap = (agx_u32)std::min<size_t>(cap, 0xFFFFFF00ull);
-            u->d_a_str.alloc(cap); u->d_a_contig.alloc(cap); u->d_a_cont.alloc(cap); u->d_a_flags.alloc(cap); u->d_a_absent.alloc(cap);
-            u->d_a_xpos.alloc(cap); u->d_a_off0.alloc(cap); u->d_a_next.alloc(cap * AGX_MAXE); u->d_a_sref.alloc(cap);
+            u->d_a_str.alloc(cap); u->d_a_meta.alloc(cap + 16); u->d_a_node.alloc(cap);
         }
         u->d_a_ovf.alloc((size_t)u->n_ovf + 1);
-        C.a_str = u->d_a_str.p; C.a_contig = u->d_a_contig.p; C.a_cont = u->d_a_cont.p; C.a_flags = u->d_a_flags.p; C.a_absent = u->d_a_absent.p;
-        C.a_xpos = u->d_a_xpos.p; C.a_off0 = u->d_a_off0.p; C.a_next = u->d_a_next.p; C.a_sref = u->d_a_sref.p;
+        C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_node = u->d_a_node.p;
         C.ovf = u->d_ovf.p; C.n_ovf = u->n_ovf; C.a_ovf = u->d_a_ovf.p;
         agx_launch_compact(&C, st);
         HIP_OK(hipEventRecord(u->ev_compact.b, st)); u->ev_compact.used = true;
+        HIP_OK(hipStreamSynchronize(st));
     }
     HIP_OK(hipGetLastError());
     u->built = true; u->downloaded = false;
@@ -267,31 +266,26 @@ void do_download(agx_unit *u) {
     const size_t n_pos = u->T.ref.size(), ni = u->n_ids;
     hipStream_t st = u->st;
     u->h_side_start.alloc(n_pos + 1); u->h_node_cnt.alloc(n_pos);
-    u->h_a_str.alloc(ni + 1); u->h_a_contig.alloc(ni + 1); u->h_a_cont.alloc(ni + 1); u->h_a_flags.alloc(ni + 1); u->h_a_absent.alloc(ni + 1);
-    u->h_a_xpos.alloc(ni + 1); u->h_a_off0.alloc(ni + 1); u->h_a_next.alloc((ni + 1) * AGX_MAXE); u->h_a_sref.alloc(ni + 1); u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
+    u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 16); u->h_a_node.alloc(ni + 1);
+    u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
     HIP_OK(hipMemcpyAsync(u->h_side_start.p, u->d_side_start.p, (n_pos + 1) * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(u->h_node_cnt.p, u->d_node_cnt.p, n_pos, hipMemcpyDeviceToHost, st));
     if (ni) {
         HIP_OK(hipMemcpyAsync(u->h_a_str.p, u->d_a_str.p, ni, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_a_contig.p, u->d_a_contig.p, ni, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_a_cont.p, u->d_a_cont.p, ni, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_a_flags.p, u->d_a_flags.p, ni, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_a_absent.p, u->d_a_absent.p, ni, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_a_xpos.p, u->d_a_xpos.p, ni * 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_a_off0.p, u->d_a_off0.p, ni * 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_a_next.p, u->d_a_next.p, ni * AGX_MAXE * 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_a_sref.p, u->d_a_sref.p, ni * sizeof(agx_sref), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_a_meta.p, u->d_a_meta.p, ni, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_a_node.p, u->d_a_node.p, ni * sizeof(agx_walknode), hipMemcpyDeviceToHost, st));
     }
     if (u->n_ovf) HIP_OK(hipMemcpyAsync(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
+    memset(u->h_a_meta.p + ni, 0, 16);
     u->downloaded = true;
     u->stats.ms_download = now_ms() - t0;
 }
 
 GraphView view_of(agx_unit *u) {
     GraphView G; G.n_pos = (agx_u32)u->T.ref.size(); G.n_ids = u->n_ids; G.side_start = u->h_side_start.p; G.node_cnt = u->h_node_cnt.p;
-    G.absent = u->h_a_absent.p; G.str = u->h_a_str.p; G.contig = u->h_a_contig.p; G.cont = u->h_a_cont.p; G.flags = u->h_a_flags.p;
-    G.xpos = u->h_a_xpos.p; G.off0 = u->h_a_off0.p; G.sref = u->h_a_sref.p; G.next = u->h_a_next.p; G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf;
+    G.meta = u->h_a_meta.p; G.str = u->h_a_str.p; G.node = u->h_a_node.p;
+    G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf;
     return G;
 }
 
@@ -415,9 +409,9 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
         const double t0 = now_ms();
         UnitOutput O; walk_join_scaffold(u->T, u->P, view_of(u), O);
         u->stats.ms_walk = now_ms() - t0;
-        r->initial_contigs = dup_buf(O.initial_contigs); r->initial_len = O.initial_contigs.size();
-        r->pre_extended = dup_buf(O.pre_extended); r->pre_len = O.pre_extended.size();
-        r->extended = dup_buf(O.extended); r->extended_len = O.extended.size();
+        r->initial_contigs = dup_buf(u->T.initial_contigs); r->initial_len = u->T.initial_contigs.size();
+        r->pre_len = O.pre_extended.n; r->pre_extended = O.pre_extended.release();
+        r->extended_len = O.extended.n; r->extended = O.extended.release();
     });
 }
 

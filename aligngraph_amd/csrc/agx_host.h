@@ -1,5 +1,7 @@
 // agx_host.h — host-side containers shared by the loader, the engine and the walk.
 #pragma once
+#include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 #include "agx_core.h"
@@ -29,6 +31,10 @@ struct Threads {
     std::vector<size_t> chain_off;          // [n_chains+1] chain c's bases are chain_str[chain_off[c] .. chain_off[c+1])
     std::vector<agx_u32> chain_end_pos;     // position of the chain's terminal conti-mer
     std::string chain_str;
+    // what a walk does when it leaves the k-mer graph at position x (AG:2047-2057): exactly one conti-mer there, with a next ->
+    // append chain_str[str_off, str_off+len) and land on end_pos; len == 0: no hop possible
+    struct Hop { size_t str_off; agx_u32 len, end_pos; };
+    std::vector<Hop> hop;                   // [n_pos]
 };
 void build_chains(Threads &T);
 
@@ -48,15 +54,23 @@ struct GraphView {
     agx_u32 n_pos = 0, n_ids = 0;
     const agx_u32 *side_start = nullptr;                    // [n_pos+1] side variants of position x are n_pos+side_start[x] .. n_pos+side_start[x+1]
     const agx_u8 *node_cnt = nullptr;                       // [n_pos] ALL variants incl. pruned ones (scaffold gap rule, AG:2428)
-    const agx_u8 *absent = nullptr;                         // [n_ids] 1 = no node at this id (treated as visited)
+    const agx_u8 *meta = nullptr;                           // [n_ids + 16] AGX_WM_* bits (padding reads as 0)
     const char *str = nullptr;                              // [n_ids] base a node emits
-    const agx_u8 *contig = nullptr, *cont = nullptr, *flags = nullptr;   // contigOffset != -1; forced step to id+1; AGX_NF_EOVF
-    const agx_u32 *xpos = nullptr, *off0 = nullptr; const agx_sref *sref = nullptr;
-    const agx_u32 *next = nullptr;                          // [n_ids*AGX_MAXE] alive successors, NONE padded
+    const agx_walknode *node = nullptr;                     // [n_ids] alive successors (NONE padded), mate offset, position, k-mer reference
     const agx_edge_ovf *ovf = nullptr; size_t n_ovf = 0;     // walk ids; NONE/NONE entries and duplicates are ignored
 };
 
-struct UnitOutput { std::string initial_contigs, pre_extended, extended; };
+// malloc-backed output buffer whose storage can be handed to the C caller without another copy
+struct OutBuf {
+    char *p = nullptr; size_t n = 0, cap = 0;
+    OutBuf() = default; OutBuf(const OutBuf &) = delete; OutBuf &operator=(const OutBuf &) = delete;
+    ~OutBuf() { free(p); }
+    void reserve(size_t c) { if (c + 1 > cap) { char *q = (char *)realloc(p, c + 1); if (!q) throw Error{E_ARG, "out of host memory"}; p = q; cap = c + 1; } }
+    char *grow(size_t add) { if (n + add + 1 > cap) reserve((n + add) + (n + add) / 2 + 64); char *w = p + n; n += add; return w; }
+    void append(const char *s, size_t len) { memcpy(grow(len), s, len); }
+    char *release() { if (!p) reserve(0); p[n] = 0; char *r = p; p = nullptr; n = cap = 0; return r; }
+};
+struct UnitOutput { OutBuf pre_extended, extended; };
 
 // agx_host.cpp
 void load_unit_reference(const std::string &path, std::string &ref);

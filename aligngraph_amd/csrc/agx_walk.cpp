@@ -39,8 +39,8 @@ struct Walker {
     const Threads &T; const Pairs &P; const GraphView &G;
     std::vector<agx_u8> done;                       // traversed flag per ALIVE node (pruned nodes never reach the host)
     std::vector<agx_edge_ovf> ovf;                  // sorted, unique
-    Walker(const Threads &t, const Pairs &p, const GraphView &g) : T(t), P(p), G(g), done((size_t)g.n_ids + 8, 1) {
-        if (g.n_ids) memcpy(done.data(), g.absent, g.n_ids);              // ids without a node count as visited; the tail is a sentinel
+    Walker(const Threads &t, const Pairs &p, const GraphView &g) : T(t), P(p), G(g), done((size_t)g.n_ids + 24, 1) {
+        for (size_t i = 0; i < g.n_ids; i++) done[i] = g.meta[i] >> 7;     // ids without a node count as visited; the tail is a sentinel
         for (size_t i = 0; i < g.n_ovf; i++) if (g.ovf[i].src != AGX_NONE) ovf.push_back(g.ovf[i]);
         std::sort(ovf.begin(), ovf.end(), [](const agx_edge_ovf &a, const agx_edge_ovf &b) { return a.src != b.src ? a.src < b.src : a.dst < b.dst; });
         ovf.erase(std::unique(ovf.begin(), ovf.end(), [](const agx_edge_ovf &a, const agx_edge_ovf &b) { return a.src == b.src && a.dst == b.dst; }), ovf.end());
@@ -48,9 +48,9 @@ struct Walker {
     // number of live (unvisited) successors of node v, capped at 2; target = the last one seen (AG:2020-2033)
     int live_successors(agx_u32 v, agx_u32 &target) const {
         int n = 0;
-        const agx_u32 *s = G.next + (size_t)v * AGX_MAXE;
+        const agx_u32 *s = G.node[v].next;
         for (agx_u32 e = 0; e < AGX_MAXE && s[e] != AGX_NONE; e++) if (!done[s[e]]) { target = s[e]; if (++n > 1) return n; }
-        if (G.flags[v] & AGX_NF_EOVF) {
+        if (!ovf.empty()) {                             // nodes with more than AGX_MAXE out-edges (rare): the rest is in the overflow list
             auto it = std::lower_bound(ovf.begin(), ovf.end(), v, [](const agx_edge_ovf &a, agx_u32 key) { return a.src < key; });
             for (; it != ovf.end() && it->src == v; ++it) {
                 bool inl = false; for (agx_u32 e = 0; e < AGX_MAXE; e++) inl |= s[e] == it->dst;
@@ -61,7 +61,7 @@ struct Walker {
     }
     // k-mer string of node v from its read reference (agx_sref)
     void kmer_string(agx_u32 v, std::string &out) const {
-        const agx_sref r = G.sref[v];
+        const agx_sref r = G.node[v].sref;
         const agx_u32 first = r.qlen & 0xFFFFu, len = (r.qlen >> 16) & 0x7FFFu; const bool rev = (r.qlen >> 31) != 0;
         out.clear();
         const char *p = P.bases.data() + (size_t)r.slot * P.stride;
@@ -80,22 +80,17 @@ struct Walker {
     }
 };
 
-std::string header_of(agx_u32 id, const Rec &c) {      // AG:2178
-    char buf[256];
-    std::snprintf(buf, sizeof buf, ">%u, %d, %u, %u, %u, %u, %u, %u, %u, %u \n", id, c.extended, c.sID, c.sOff, c.eID, c.eOff, c.sID0, c.sOff0, c.eID0, c.eOff0);
-    return buf;
-}
-
 // extdContigs1, AG:1954-2204, replayed on the alive-compacted graph.  Alive ids are position-major, so "for every
 // position, for every variant, if untraversed" (AG:1972-1978) is "for every alive id in order, if not done".
-void walk(Walker &W, std::string &pre_out, std::vector<Rec> &written) {
+void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
     const GraphView &G = W.G; const Threads &T = W.T;
     agx_u32 seqID = 0, sIDBak = AGX_NONE, sOffBak = AGX_NONE, eIDBak = AGX_NONE, eOffBak = AGX_NONE;
     agx_u32 pos_bak = 0;                         // cppBak of the reference (function scope)
     std::string kmer;
     std::vector<Seg> segs;
+    pre_out.reserve((size_t)G.n_ids + G.n_ids / 32 + 4096);
     agx_u8 *done = W.done.data();
-    unsigned long long n_walks = 0, n_hops = 0, n_runs = 0, n_general = 0, run_nodes = 0, od_hist[8] = {0};
+    unsigned long long n_walks = 0, n_hops = 0, n_runs = 0, n_general = 0, run_nodes = 0;
     for (agx_u32 cp = 0; cp < G.n_pos;) {
         // variants of position cp in order: its main slot, then its side range
         const agx_u32 s_lo = G.n_pos + G.side_start[cp], s_hi = G.n_pos + G.side_start[cp + 1];
@@ -104,61 +99,65 @@ void walk(Walker &W, std::string &pre_out, std::vector<Rec> &written) {
             Rec C; C.sID = 0; C.sOff = cp; C.extended = 0;
             segs.clear(); n_walks++;
             agx_u32 cur = start;                 // current k-mer node (mode 1)
-            C.sID0 = G.off0[cur] == AGX_NONE ? AGX_NONE : 0; C.sOff0 = G.off0[cur];
-            agx_u32 cpp = cp, ipp = 0; int mode = 1;      // mode = kMerTag
+            C.sID0 = G.node[cur].off0 == AGX_NONE ? AGX_NONE : 0; C.sOff0 = G.node[cur].off0;
+            agx_u32 cpp = cp; int mode = 1;               // mode = kMerTag
             agx_u32 last = cur;
             while ((mode == 1 && !done[cur]) || mode == 0) {
                 if (mode == 0) {                            // on a conti-mer, AG:2061-2138
-                    // follow the conti-mer chain to its end in one append (the reference steps through it one base at a time)
-                    const agx_u32 ci = T.cm_start[cpp] + ipp, ch = T.cm_chain[ci];
-                    const size_t from = T.chain_off[ch] + T.cm_idx[ci], to = T.chain_off[ch + 1];
-                    segs.push_back(Seg{T.chain_str.data() + from, to - from}); C.extended = 1; n_hops++;
-                    if (to - from > 1) { pos_bak = T.chain_end_pos[ch]; cpp = pos_bak; }
-                    // chain end: hop onto the k-mer graph only through the single live node here and its single live edge (AG:2093-2136)
+                    // the whole conti-mer chain in one segment (the reference steps through it one base at a time), then its end:
+                    // hop back onto the k-mer graph only through the single live node there and its single live edge (AG:2093-2136)
+                    const Threads::Hop &h = T.hop[cpp];
+                    segs.push_back(Seg{T.chain_str.data() + h.str_off, h.len}); C.extended = 1; n_hops++;
+                    pos_bak = h.end_pos; cpp = h.end_pos;
                     agx_u32 live = 0, item = 0;
                     if (!done[cpp]) { live++; item = cpp; }
                     for (agx_u32 v = G.n_pos + G.side_start[cpp]; v < G.n_pos + G.side_start[cpp + 1]; v++) if (!done[v]) { live++; item = v; }
                     agx_u32 tgt = 0; int ns = 0;
                     if (live == 1) ns = W.live_successors(item, tgt);
-                    if (ns == 1) { cur = tgt; pos_bak = G.xpos[tgt]; cpp = pos_bak; mode = done[cur] ? -2 : 1; }
+                    if (ns == 1) { cur = tgt; pos_bak = tgt < G.n_pos ? tgt : G.node[tgt].xpos; cpp = pos_bak; mode = done[cur] ? -2 : 1; }
                     else mode = -2;
                 } else {                                    // on a k-mer node, AG:1995-2060
-                    // forced run: while cont[] holds and the next node is unvisited the reference steps cur -> cur+1 (unique live successor)
-                    agx_u32 j = cur;
-                    if (G.cont[cur]) {
-                        const agx_u8 *z = (const agx_u8 *)memchr(G.cont + cur, 0, G.n_ids - cur);         // first node of the run without a forced step
-                        const agx_u32 run_end = z ? (agx_u32)(z - G.cont) : G.n_ids - 1;
-                        const agx_u8 *d = (const agx_u8 *)memchr(done + cur + 1, 1, run_end - cur);       // first already-visited node inside the run
-                        j = d ? (agx_u32)(d - done) - 1 : run_end;
+                    // forced run: while the cont bit holds and the next node is unvisited the reference steps cur -> cur+1 (its unique live
+                    // successor).  Eight nodes per iteration: all cont bits set and none of the eight successors visited.
+                    agx_u32 j = cur; agx_u8 seen = 0;
+                    for (;;) {
+                        uint64_t mw, dw; memcpy(&mw, G.meta + j, 8); memcpy(&dw, done + j + 1, 8);
+                        if ((mw & 0x0101010101010101ull) == 0x0101010101010101ull && dw == 0) {
+                            mw |= mw >> 32; mw |= mw >> 16; mw |= mw >> 8; seen |= (agx_u8)mw; j += 8; continue;
+                        }
+                        bool stop = false;
+                        for (int b8 = 0; b8 < 8; b8++) { const agx_u8 m = G.meta[j]; seen |= m; if (!(m & AGX_WM_CONT) || done[j + 1]) { stop = true; break; } j++; }
+                        if (stop) break;
                     }
-                    segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!G.cont[j]) { n_general++; int od = 0; for (agx_u32 e = 0; e < AGX_MAXE; e++) od += G.next[(size_t)j * AGX_MAXE + e] != AGX_NONE; od_hist[od]++; }
-                    if (!C.extended && memchr(G.contig + cur, 1, (size_t)j - cur + 1)) C.extended = 1;
+                    segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!(G.meta[j] & AGX_WM_CONT)) n_general++;
+                    if (seen & AGX_WM_CONTIG) C.extended = 1;
                     memset(done + cur, 1, (size_t)j - cur + 1);
-                    if (j > cur) pos_bak = G.xpos[j];
-                    cur = j; last = j; cpp = G.xpos[j];
+                    const agx_u32 xj = j < G.n_pos ? j : G.node[j].xpos;      // main ids are positions
+                    if (j > cur) pos_bak = xj;
+                    cur = j; last = j; cpp = xj;
                     agx_u32 tgt = 0;
-                    const int ns = G.cont[cur] ? 0 : W.live_successors(cur, tgt);      // cont && stopped: its only alive successor is already visited
-                    if (ns == 1) { cur = tgt; pos_bak = G.xpos[tgt]; cpp = pos_bak; }
-                    else {
-                        const agx_u32 c0 = T.cm_start[cpp], cn = T.cm_start[cpp + 1] - c0;
-                        if (cn == 1 && T.cm[c0].next_off != AGX_NONE) { pos_bak = T.cm[c0].next_off; ipp = T.cm[c0].next_item; cpp = pos_bak; mode = 0; }
-                        else mode = -1;
-                    }
+                    const int ns = (G.meta[cur] & AGX_WM_CONT) ? 0 : W.live_successors(cur, tgt);      // cont && stopped: its only alive successor is already visited
+                    if (ns == 1) { cur = tgt; pos_bak = tgt < G.n_pos ? tgt : G.node[tgt].xpos; cpp = pos_bak; }
+                    else if (T.hop[cpp].len) mode = 0;                          // exactly one conti-mer here and it has a next (AG:2047-2057)
+                    else mode = -1;
                 }
             }
             // end bookkeeping, AG:2142-2173
             C.eID = 0; C.eOff = mode == 1 ? pos_bak : cpp;
             if (mode == 1 || mode == -1) {
-                C.eID0 = G.off0[cur] == AGX_NONE ? AGX_NONE : 0; C.eOff0 = G.off0[cur];
+                C.eID0 = G.node[cur].off0 == AGX_NONE ? AGX_NONE : 0; C.eOff0 = G.node[cur].off0;
                 W.kmer_string(last, kmer);
                 if (kmer.size() > 1) segs.push_back(Seg{kmer.data() + 1, kmer.size() - 1});
                 C.eOff = C.eOff + (agx_u32)kmer.size() - 1; C.eOff0 = C.eOff0 + (agx_u32)kmer.size() - 1;
             } else { C.eID0 = AGX_NONE; C.eOff0 = AGX_NONE; }
             if (!contains(sIDBak, sOffBak, eIDBak, eOffBak, C.sID, C.sOff, C.eID, C.eOff)) {        // AG:2176-2189
                 size_t total = 0; for (const Seg &g : segs) total += g.n;
-                C.nuc.reserve(total); for (const Seg &g : segs) C.nuc.append(g.p, g.n);
-                pre_out += header_of(seqID++, C);
-                fasta_body(pre_out, C.nuc.data(), C.nuc.size());
+                C.nuc.resize(total); { char *w = &C.nuc[0]; for (const Seg &g : segs) { memcpy(w, g.p, g.n); w += g.n; } }
+                char hdr[256];
+                const int hl = std::snprintf(hdr, sizeof hdr, ">%u, %d, %u, %u, %u, %u, %u, %u, %u, %u \n", seqID++, C.extended, C.sID, C.sOff, C.eID, C.eOff, C.sID0, C.sOff0, C.eID0, C.eOff0);
+                const size_t lines = (total + 59) / 60;
+                char *w = pre_out.grow((size_t)hl + total + lines); memcpy(w, hdr, (size_t)hl); w += hl;
+                for (size_t i = 0; i < total; i += 60) { const size_t m = total - i < 60 ? total - i : 60; memcpy(w, C.nuc.data() + i, m); w += m; *w++ = '\n'; }
                 sIDBak = C.sID; sOffBak = C.sOff; eIDBak = C.eID; eOffBak = C.eOff;
                 written.push_back(std::move(C));
             }
@@ -171,11 +170,11 @@ void walk(Walker &W, std::string &pre_out, std::vector<Rec> &written) {
             // written, which needs an unvisited node: skipping node-less positions one by one or at once is the same
             const agx_u32 m = W.next_live(cp + 1, G.n_pos);                                  // main slot id == position
             const agx_u32 sd = W.next_live(G.n_pos + G.side_start[cp + 1], G.n_ids);
-            const agx_u32 sp = sd < G.n_ids ? G.xpos[sd] : G.n_pos;
+            const agx_u32 sp = sd < G.n_ids ? G.node[sd].xpos : G.n_pos;
             cp = m < sp ? m : sp;
         }
     }
-    if (getenv("AGX_WALK_TIMING")) fprintf(stderr, "[agx walk] walks %llu, contig hops %llu, runs %llu (%llu nodes), general evaluations %llu (outdeg 0:%llu 1:%llu 2:%llu 3:%llu 4:%llu)\n", n_walks, n_hops, n_runs, run_nodes, n_general, od_hist[0], od_hist[1], od_hist[2], od_hist[3], od_hist[4]);
+    if (getenv("AGX_WALK_TIMING")) fprintf(stderr, "[agx walk] walks %llu, contig hops %llu, runs %llu (%llu nodes), general evaluations %llu\n", n_walks, n_hops, n_runs, run_nodes, n_general);
 }
 
 }  // namespace
@@ -201,8 +200,8 @@ void join(std::vector<Rec> &c) {
             for (int q = cp + 1; q < n; q++) if (c[q].extended != 2) { if (c[cp].eOff >= c[q].sOff) { cand = q; ncand++; } else break; }
             if (ncand != 1) break;
             Rec &d = c[cand]; d.extended = 2;
-            const int from = (int)(c[cp].eOff - d.sOff + 1);
-            for (size_t np = (size_t)from; np < d.nuc.size(); np++) c[cp].nuc.push_back(d.nuc[np]);
+            const size_t from = (size_t)(int)(c[cp].eOff - d.sOff + 1);      // (int) -> size_t as in the reference's loop test (AG:2368-2370)
+            if (from < d.nuc.size()) c[cp].nuc.append(d.nuc, from, std::string::npos);
             c[cp].eID = d.eID; c[cp].eOff = d.eOff; c[cp].eID0 = d.eID0; c[cp].eOff0 = d.eOff0;
         }
     }
@@ -214,12 +213,12 @@ inline int overlaps(agx_u32 x1, agx_u32 y1, agx_u32 x2, agx_u32 y2) {      // AG
 }
 
 // scaffoldContigs, AG:2396-2464
-void scaffold(const Threads &T, const GraphView &G, std::vector<Rec> &c, std::string &out) {
+void scaffold(const Threads &T, const GraphView &G, std::vector<Rec> &c, OutBuf &out) {
     std::vector<std::string> sc;
     const agx_u32 n = (agx_u32)c.size();
     for (agx_u32 cp = 0; cp < n; cp++) {
         if (!(c[cp].sID != AGX_NONE && c[cp].extended == 1)) continue;
-        sc.push_back(c[cp].nuc); c[cp].sID = AGX_NONE;
+        sc.push_back(std::move(c[cp].nuc)); c[cp].sID = AGX_NONE;      // a record is used at most once (sID = -1 marks it, AG:2411)
         bool cont = true;
         while (c[cp].sID0 == c[cp].eID0 && cont) {
             cont = false;
@@ -236,7 +235,14 @@ void scaffold(const Threads &T, const GraphView &G, std::vector<Rec> &c, std::st
             }
         }
     }
-    for (size_t i = 0; i < sc.size(); i++) { out += ">" + std::to_string(i) + "\n"; fasta_body(out, sc[i].data(), sc[i].size()); }
+    size_t total = 0; for (const std::string &x : sc) total += x.size() + x.size() / 60 + 16;
+    out.reserve(total);
+    for (size_t i = 0; i < sc.size(); i++) {
+        char hdr[32]; const int hl = std::snprintf(hdr, sizeof hdr, ">%zu\n", i);
+        const size_t n = sc[i].size(), lines = (n + 59) / 60;
+        char *w = out.grow((size_t)hl + n + lines); memcpy(w, hdr, (size_t)hl); w += hl;
+        for (size_t j = 0; j < n; j += 60) { const size_t m = n - j < 60 ? n - j : 60; memcpy(w, sc[i].data() + j, m); w += m; *w++ = '\n'; }
+    }
 }
 
 }  // namespace
@@ -267,14 +273,22 @@ void build_chains(Threads &T) {
         T.chain_end_pos.push_back(pos_of[c]); T.chain_off.push_back(T.chain_str.size());
     }
     for (size_t i = 0; i < n; i++) if (T.cm_chain[i] == AGX_NONE) throw Error{E_ARG, "conti-mer cycle"};
+    T.hop.assign(n_pos, Threads::Hop{0, 0, 0});
+    for (size_t x = 0; x < n_pos; x++) {
+        if (T.cm_start[x + 1] - T.cm_start[x] != 1) continue;
+        const ContiMer &m = T.cm[T.cm_start[x]];
+        if (m.next_off == AGX_NONE) continue;
+        const size_t nx = index_of(m.next_off, m.next_item);          // the walk continues ON the next conti-mer (AG:2049-2055)
+        const agx_u32 ch = T.cm_chain[nx];
+        const size_t from = T.chain_off[ch] + T.cm_idx[nx];
+        T.hop[x] = Threads::Hop{from, (agx_u32)(T.chain_off[ch + 1] - from), T.chain_end_pos[ch]};
+    }
 }
 
 void walk_join_scaffold(const Threads &T, const Pairs &P, const GraphView &G, UnitOutput &out) {
     if (T.cm_chain.size() != T.cm.size()) throw Error{E_ARG, "conti-mer chains were not built"};
     Walker W(T, P, G);
     std::vector<Rec> recs;
-    out.initial_contigs = T.initial_contigs;
-    out.pre_extended.clear(); out.extended.clear();
     const bool timing = getenv("AGX_WALK_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();

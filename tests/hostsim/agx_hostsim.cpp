@@ -25,8 +25,8 @@ struct SimGraph {
     agx_u32 n_nodes = 0;
     // alive-compacted view (agx_core.h "walk preparation")
     agx_u32 n_ids = 0;
-    std::vector<agx_u32> side_cnt, side_start, aid_of, a_xpos, a_off0, a_next; std::string a_str;
-    std::vector<agx_u8> a_contig, a_cont, a_flags, a_absent; std::vector<agx_sref> a_sref; std::vector<agx_edge_ovf> a_ovf;
+    std::vector<agx_u32> side_cnt, side_start, aid_of; std::string a_str;
+    std::vector<agx_u8> a_meta; std::vector<agx_walknode> a_node; std::vector<agx_edge_ovf> a_ovf;
     void reserve(size_t cap) {
         cid.resize(cap); coff.resize(cap); cid0.resize(cap); coff0.resize(cap); off0.resize(cap); xpos.resize(cap); next.resize(cap * AGX_MAXE);
         base.resize(cap); flags.resize(cap); sref.resize(cap); counts.resize(cap * 6);
@@ -105,11 +105,10 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     agx_u32 run = 0; for (agx_u32 x = 0; x <= n_pos; x++) { S.side_start[x] = run; run += S.side_cnt[x]; }
     S.n_ids = n_pos + run;
     const size_t na = (size_t)S.n_ids + 1;
-    S.a_str.assign(na, 0); S.a_contig.assign(na, 0); S.a_cont.assign(na, 0); S.a_flags.assign(na, 0); S.a_absent.assign(na, 1);
-    S.a_xpos.assign(na, 0); S.a_off0.assign(na, 0); S.a_next.assign(na * AGX_MAXE, AGX_NONE); S.a_sref.assign(na, agx_sref{0, 0});
+    S.a_str.assign(na, 0); S.a_meta.assign(na + 16, 0);
+    S.a_node.assign(na, agx_walknode{{AGX_NONE, AGX_NONE, AGX_NONE, AGX_NONE}, AGX_NONE, 0, agx_sref{0, 0}});
     S.a_ovf.assign(S.ovf.size() + 1, agx_edge_ovf{AGX_NONE, AGX_NONE});
-    C.a_str = &S.a_str[0]; C.a_contig = S.a_contig.data(); C.a_cont = S.a_cont.data(); C.a_flags = S.a_flags.data(); C.a_absent = S.a_absent.data();
-    C.a_xpos = S.a_xpos.data(); C.a_off0 = S.a_off0.data(); C.a_next = S.a_next.data(); C.a_sref = S.a_sref.data();
+    C.a_str = &S.a_str[0]; C.a_meta = S.a_meta.data(); C.a_node = S.a_node.data();
     C.ovf = S.ovf.data(); C.n_ovf = (agx_u32)S.ovf.size(); C.a_ovf = S.a_ovf.data();
     for (agx_u32 x = 0; x < n_pos; x++) agx_assign_aid_pos(C, x);
     for (agx_u32 v = 0; v < S.n_nodes; v++) agx_emit_alive_node(C, v);
@@ -143,13 +142,12 @@ int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int cover
         SimGraph S; int nbig = 0;
         simulate(T, P, (agx_u32)k, iv, coverage, maxv_first > 0 ? (agx_u32)maxv_first : AGX_MAXV_LDS, S, nbig);
         GraphView G; G.n_pos = (agx_u32)T.ref.size(); G.n_ids = S.n_ids; G.side_start = S.side_start.data(); G.node_cnt = S.node_cnt.data();
-        G.absent = S.a_absent.data(); G.str = S.a_str.data(); G.contig = S.a_contig.data(); G.cont = S.a_cont.data(); G.flags = S.a_flags.data();
-        G.xpos = S.a_xpos.data(); G.off0 = S.a_off0.data(); G.sref = S.a_sref.data(); G.next = S.a_next.data();
+        G.meta = S.a_meta.data(); G.str = S.a_str.data(); G.node = S.a_node.data();
         G.ovf = S.a_ovf.data(); G.n_ovf = S.ovf.size();
         UnitOutput O; walk_join_scaffold(T, P, G, O);
-        out->initial_contigs = dup_buf(O.initial_contigs); out->initial_len = O.initial_contigs.size();
-        out->pre_extended = dup_buf(O.pre_extended); out->pre_len = O.pre_extended.size();
-        out->extended = dup_buf(O.extended); out->extended_len = O.extended.size();
+        out->initial_contigs = dup_buf(T.initial_contigs); out->initial_len = T.initial_contigs.size();
+        out->pre_len = O.pre_extended.n; out->pre_extended = O.pre_extended.release();
+        out->extended_len = O.extended.n; out->extended = O.extended.release();
         out->n_big_tiles = nbig;
         if (want_graph) {
             const agx_u32 n_pos = G.n_pos, nn = S.n_nodes;
