@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libagx.so")
+LIB_PATH = os.environ.get("AGX_LIB_PATH", os.path.join(_HERE, "libagx.so"))   # override only for kernel A/B experiments
 
 AGX_OK, AGX_E_IO, AGX_E_FORMAT, AGX_E_UNSUPPORTED, AGX_E_ALIGNMENT, AGX_E_DEVICE, AGX_E_ARG, AGX_E_OVERFLOW, AGX_E_NOGPU = 0, -1, -2, -3, -4, -5, -6, -7, -8
 AGX_FLAG_KEEP_COUNTS = 1
@@ -16,7 +16,7 @@ AGX_FLAG_KEEP_COUNTS = 1
 # every symbol include/agx.h declares (tests check that the built library exports all of them)
 EXPORTS = [
     "agx_version", "agx_device_count", "agx_unit_create", "agx_unit_destroy", "agx_unit_error", "agx_unit_set_reference",
-    "agx_unit_set_contig_threads", "agx_unit_push_pairs", "agx_unit_load_files", "agx_unit_upload", "agx_unit_build",
+    "agx_unit_set_contig_threads", "agx_unit_push_pairs", "agx_unit_load_files", "agx_unit_upload", "agx_unit_build", "agx_unit_download",
     "agx_unit_finish", "agx_result_free", "agx_unit_stats", "agx_unit_graph", "agx_graph_free", "agx_run_unit",
 ]
 
@@ -95,7 +95,7 @@ def lib():
                                                   ctypes.POINTER(ContiMer), ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
         L.agx_unit_push_pairs.argtypes = [ctypes.c_void_p, ctypes.POINTER(PairBatch)]
         L.agx_unit_load_files.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
-        for f in ("agx_unit_upload", "agx_unit_build"):
+        for f in ("agx_unit_upload", "agx_unit_build", "agx_unit_download"):
             getattr(L, f).argtypes = [ctypes.c_void_p]
         L.agx_unit_finish.argtypes = [ctypes.c_void_p, ctypes.POINTER(Result)]
         L.agx_result_free.argtypes = [ctypes.POINTER(Result)]
@@ -161,6 +161,9 @@ class Unit:
 
     def build(self):
         self._check(lib().agx_unit_build(self._h))
+
+    def download(self):
+        self._check(lib().agx_unit_download(self._h))
 
     def finish(self):
         r = Result()

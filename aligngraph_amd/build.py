@@ -16,16 +16,20 @@ def _stale(out, deps):
     return not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, defines=(), out=None, tag=""):
+    """defines/out/tag: build an experimental variant (e.g. defines=["AGX_MAXV_LDS=2u"], out="/tmp/libagx_v2.so", tag="v2")."""
+    global LIB
+    lib = out or LIB
     hipcc = os.path.join(ROCM, "bin", "hipcc")
-    objdir = os.path.join(HERE, "_obj")
+    objdir = os.path.join(HERE, "_obj" + tag)
+    dflags = ["-D" + d for d in defines]
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     for s in DEV_SRC:
         o = os.path.join(objdir, s + ".o")
         if force or _stale(o, [os.path.join(CSRC, s)] + hdrs):
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, s), "-o", o]
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + dflags + ["-c", os.path.join(CSRC, s), "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
@@ -33,18 +37,18 @@ def build(force=False, verbose=False):
     for s in HOST_SRC:
         o = os.path.join(objdir, s + ".o")
         if force or _stale(o, [os.path.join(CSRC, s)] + hdrs):
-            cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"),
-                   "-c", os.path.join(CSRC, s), "-o", o]
+            cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include")] + dflags + \
+                  ["-c", os.path.join(CSRC, s), "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
         objs.append(o)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -35,7 +35,9 @@ typedef uint8_t agx_u8;
 
 #define AGX_NONE 0xFFFFFFFFu
 #define AGX_TILE 64u          // positions per tile = lanes per wavefront
+#ifndef AGX_MAXV_LDS
 #define AGX_MAXV_LDS 4u       // variants per position held in LDS; tiles that need more are re-run with global scratch
+#endif
 #define AGX_MAXV_BIG 64u      // variants per position in the global-scratch fallback
 #define AGX_MAXE 4u           // out-edges stored inline per node; more go to the overflow list
 #define AGX_EP25 25           // 5*EP (AG:39, 1296)
@@ -356,13 +358,31 @@ AGX_HD agx_u32 agx_resolve(const agx_sweep_args &A, agx_u32 x, const agx_key &k)
     return AGX_NONE;
 }
 
-// All out-edges of the nodes at position X.  Only this lane ever writes n_next of X's nodes, so plain stores suffice.
-// ovf/ovf_count: global overflow list for nodes with more than AGX_MAXE out-edges (appended with an atomic by the caller-supplied functor).
+// contig-consistency between the STORED keys of an edge's two ends (AG:1602-1615)
+AGX_HD bool agx_edge_allowed(const agx_sweep_args &A, agx_u32 src, agx_u32 dst) {
+    return agx_clause_ab(A.nk_cid[dst], A.nk_coff[dst], A.nk_cid[src], A.nk_coff[src], AGX_EP25) &&
+           agx_clause_ab(A.nk_cid0[dst], A.nk_coff0[dst], A.nk_cid0[src], A.nk_coff0[src], 2 * A.iv + AGX_EP25);
+}
+
+// All out-edges of the nodes at position X.  Only this lane ever writes n_next / n_flags of X's nodes, so plain stores suffice.
+// own_*: node_start/node_cnt of X; nb_*: of X+1 (0 nodes beyond the end).  push_overflow(src, dst) appends to the global overflow list.
+//
+// Fast path (the common case): X holds ONE variant, so every arrival at X resolved to it — no candidate keys, no compatibility
+// tests; if the successor is X+1 and that holds one variant too, the edge's other end is known as well and the contig-consistency
+// predicate is evaluated once per lane.  The four inline slots of such a node live in registers until the sweep ends.
 template <class OVF>
-AGX_HD void agx_edge_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, OVF push_overflow) {
-    if (X >= A.n_pos) return;
-    if (A.node_cnt[X] == 0) return;
+AGX_HD void agx_edge_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, agx_u32 own_start, agx_u32 own_cnt, agx_u32 nb_start, agx_u32 nb_cnt, OVF push_overflow) {
+    if (X >= A.n_pos || own_cnt == 0) return;
+    const bool fast = own_cnt == 1;
     const agx_u32 cx_s = A.cm_start[X], cx_n = A.cm_start[X + 1] - cx_s;
+    agx_u32 s0 = AGX_NONE, s1 = AGX_NONE, s2 = AGX_NONE, s3 = AGX_NONE;     // slots of the single node (fast lanes)
+    bool spilled = false;
+    int nb_ok = -1;                                                         // predicate (own -> single neighbour): unknown / no / yes
+    auto put_fast = [&](agx_u32 dst) {
+        if (s0 == dst || s1 == dst || s2 == dst || s3 == dst) return;
+        if (s0 == AGX_NONE) s0 = dst; else if (s1 == AGX_NONE) s1 = dst; else if (s2 == AGX_NONE) s2 = dst; else if (s3 == AGX_NONE) s3 = dst;
+        else { spilled = true; push_overflow(own_start, dst); }             // duplicates are removed on the host
+    };
     const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
     for (agx_u32 i = lo; i < hi; i++) {
         const agx_u32 h = A.tile_hits[i];
@@ -370,25 +390,39 @@ AGX_HD void agx_edge_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
         agx_arrival a;
         if (!agx_decode_arrival(d, A.runs, X, A.k, a) || !a.has_succ) continue;
         if (a.xs >= A.n_pos) continue;
+        if (fast && a.xs == X + 1 && nb_cnt == 1) {
+            if (nb_ok < 0) nb_ok = agx_edge_allowed(A, own_start, nb_start) ? 1 : 0;
+            if (nb_ok) put_fast(nb_start);
+            continue;
+        }
         const agx_u32 sx_s = A.cm_start[a.xs], sx_n = A.cm_start[a.xs + 1] - sx_s;
+        if (fast) {
+            agx_for_candidates(A, sx_s, sx_n, a.p0s, [&](const agx_key &k2) {
+                const agx_u32 dst = agx_resolve(A, a.xs, k2);
+                if (dst != AGX_NONE && agx_edge_allowed(A, own_start, dst)) put_fast(dst);
+                return true;
+            });
+            continue;
+        }
         agx_for_candidates(A, cx_s, cx_n, a.p0, [&](const agx_key &k1) {
             const agx_u32 src = agx_resolve(A, X, k1);
             if (src == AGX_NONE) return true;
             agx_for_candidates(A, sx_s, sx_n, a.p0s, [&](const agx_key &k2) {
                 const agx_u32 dst = agx_resolve(A, a.xs, k2);
-                if (dst == AGX_NONE) return true;
-                // contig-consistency between the two STORED keys (AG:1602-1615)
-                if (!(agx_clause_ab(A.nk_cid[dst], A.nk_coff[dst], A.nk_cid[src], A.nk_coff[src], AGX_EP25) &&
-                      agx_clause_ab(A.nk_cid0[dst], A.nk_coff0[dst], A.nk_cid0[src], A.nk_coff0[src], 2 * A.iv + AGX_EP25))) return true;
+                if (dst == AGX_NONE || !agx_edge_allowed(A, src, dst)) return true;
                 agx_u32 *slots = A.n_next + (size_t)src * AGX_MAXE;
-                agx_u32 e = 0;
-                for (; e < AGX_MAXE; e++) { if (slots[e] == dst) return true; if (slots[e] == AGX_NONE) { slots[e] = dst; return true; } }
+                for (agx_u32 e = 0; e < AGX_MAXE; e++) { if (slots[e] == dst) return true; if (slots[e] == AGX_NONE) { slots[e] = dst; return true; } }
                 A.n_flags[src] |= AGX_NF_EOVF;
-                push_overflow(src, dst);      // duplicates are removed on the host
+                push_overflow(src, dst);
                 return true;
             });
             return true;
         });
+    }
+    if (fast) {
+        agx_u32 *slots = A.n_next + (size_t)own_start * AGX_MAXE;
+        slots[0] = s0; slots[1] = s1; slots[2] = s2; slots[3] = s3;
+        if (spilled) A.n_flags[own_start] |= AGX_NF_EOVF;
     }
 }
 

@@ -400,6 +400,7 @@ int agx_unit_load_files(agx_unit *u, const char *tmp_dir, int unit) {
 
 int agx_unit_upload(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_upload(u); }); }
 int agx_unit_build(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_build(u); }); }
+int agx_unit_download(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_download(u); }); }
 
 int agx_unit_finish(agx_unit *u, agx_result *r) {
     if (!u || !r) return AGX_E_ARG;

@@ -132,7 +132,13 @@ __global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
     if (tile >= K.S.n_tiles) return;
-    agx_edge_sweep_lane(K.S, tile, tile * AGX_TILE + lane, [&](agx_u32 s, agx_u32 d) {
+    const agx_u32 X = tile * AGX_TILE + lane;
+    agx_u32 own_start = 0, own_cnt = 0;
+    if (X < K.S.n_pos) { own_start = K.S.node_start[X]; own_cnt = K.S.node_cnt[X]; }
+    // the neighbour position's bucket header comes from the next lane; the last lane reads the next tile's first position
+    agx_u32 nb_start = __shfl_down(own_start, 1, 64), nb_cnt = __shfl_down(own_cnt, 1, 64);
+    if (lane == 63) { nb_start = 0; nb_cnt = 0; if (X + 1 < K.S.n_pos) { nb_start = K.S.node_start[X + 1]; nb_cnt = K.S.node_cnt[X + 1]; } }
+    agx_edge_sweep_lane(K.S, tile, X, own_start, own_cnt, nb_start, nb_cnt, [&](agx_u32 s, agx_u32 d) {
         const agx_u32 i = atomicAdd(K.ovf_count, 1u);
         if (i < K.ovf_cap) K.ovf[i] = agx_edge_ovf{s, d};
     });

@@ -128,7 +128,8 @@ int agx_unit_load_files(agx_unit *u, const char *tmp_dir, int unit);
 
 int agx_unit_upload(agx_unit *u);                /* host -> HBM */
 int agx_unit_build(agx_unit *u);                 /* kernels: updateGenomeWithRead/updateKMer (AG:1635-1870, 1353-1624) + filterLowCoverage (AG:1904-1918) */
-int agx_unit_finish(agx_unit *u, agx_result *r); /* HBM -> host, then extdContigs1/2 + scaffoldContigs (AG:1954-2464) */
+int agx_unit_download(agx_unit *u);              /* HBM -> pinned host memory (walk graph); implied by agx_unit_finish */
+int agx_unit_finish(agx_unit *u, agx_result *r); /* (download, then) extdContigs1/2 + scaffoldContigs (AG:1954-2464) on the host */
 void agx_result_free(agx_result *r);
 
 int agx_unit_stats(const agx_unit *u, agx_stats *s);

@@ -92,8 +92,12 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     }
     S.n_nodes = pool;
     for (agx_u32 t = 0; t < n_tiles; t++)
-        for (agx_u32 lane = 0; lane < AGX_TILE; lane++)
-            agx_edge_sweep_lane(A, t, t * AGX_TILE + lane, [&](agx_u32 s, agx_u32 d) { S.ovf.push_back(agx_edge_ovf{s, d}); });
+        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
+            const agx_u32 X = t * AGX_TILE + lane;
+            if (X >= n_pos) continue;
+            const agx_u32 nbs = X + 1 < n_pos ? S.node_start[X + 1] : 0, nbc = X + 1 < n_pos ? S.node_cnt[X + 1] : 0;
+            agx_edge_sweep_lane(A, t, X, S.node_start[X], S.node_cnt[X], nbs, nbc, [&](agx_u32 s, agx_u32 d) { S.ovf.push_back(agx_edge_ovf{s, d}); });
+        }
 
     // walk preparation, the same per-element functions the compaction kernels run
     agx_compact_args C; memset(&C, 0, sizeof C);
