@@ -114,10 +114,21 @@ struct agx_arrival {
 // What hit d contributes at position X (if anything).  Follows the event loop of AG:1681-1859; k = k-mer length.
 AGX_HD bool agx_decode_arrival(const agx_dhit &d, const agx_run *runs, agx_u32 X, agx_u32 k, agx_arrival &a) {
     const agx_u32 L = d.len;
+    if (d.a_nruns == 0) {
+        // fast path (nine hits out of ten): the a mate is one full-length run, so read index q sits on a_t0+q, every index
+        // below jstar (= L-k here) is an event source whose successor is the next position, and jstar itself is K2ONLY.
+        // Hits with L <= k carry AGX_HF_SKIP and are never listed, so jstar is valid.
+        const agx_u32 q = X - d.a_t0;                       // wraps to a huge value left of the read
+        if (q > d.jstar) return false;
+        a.q = q; a.p0 = agx_pos_b(d, runs, q);
+        if (q == d.jstar) { a.type = AGX_AT_K2ONLY; a.slen = (L - q) < k ? (L - q) : k; a.has_succ = 0; a.xs = 0; a.p0s = AGX_NONE; return true; }
+        a.type = AGX_AT_K1; a.slen = k; a.has_succ = 1; a.xs = X + 1; a.p0s = agx_pos_b(d, runs, q + 1);
+        return true;
+    }
     if (L <= k) return false;
     const agx_u32 lim = L - k;
-    const agx_u32 nr = d.a_nruns == 0 ? 1u : d.a_nruns;
-    agx_run r = d.a_nruns == 0 ? agx_run{0u, d.a_t0, L} : runs[d.a_runs];
+    const agx_u32 nr = d.a_nruns;
+    agx_run r = runs[d.a_runs];
     for (agx_u32 i = 0; i < nr; i++) {
         agx_run nx = (i + 1 < nr) ? runs[d.a_runs + i + 1] : agx_run{0u, 0u, 0u};
         if (X >= r.t && X - r.t < r.n) {
@@ -283,32 +294,77 @@ AGX_HD void agx_for_candidates(const agx_sweep_args &A, agx_u32 cx_s, agx_u32 cx
     }
 }
 
-// The whole in-order sweep of one position.  Returns false if the bucket overflowed (tile must be re-run with a larger bucket).
-AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, const agx_bucket &b, agx_u32 &cnt) {
+// Everything one arrival needs from memory.  The sweep fetches it ONE HIT AHEAD of its use, so the dependent global loads
+// (mate conti-mer range -> first entry, vote base) of hit i+1 are in flight while hit i updates the bucket in LDS.
+struct agx_pre {
+    agx_u32 has, type, p0;                 // arrival present at this position; AGX_AT_*; mate position
+    agx_u32 c0_s, c0_n; agx_cmkey c0;      // conti-mers at the mate position, and the first of them
+    agx_u32 s0, s1; char base;             // k-mer string reference of this arrival; its vote base
+};
+
+AGX_HD void agx_arrival_fetch(const agx_sweep_args &A, const agx_dhit &d, agx_u32 X, agx_pre &p) {
+    agx_arrival a;
+    p.has = agx_decode_arrival(d, A.runs, X, A.k, a) ? 1u : 0u;
+    p.c0_s = 0; p.c0_n = 0; p.c0 = agx_cmkey{AGX_NONE, AGX_NONE}; p.base = 0; p.s0 = 0; p.s1 = 0; p.type = 0; p.p0 = AGX_NONE;
+    if (!p.has) return;
+    const bool rev = (d.flags & AGX_HF_AREV) != 0;
+    p.type = a.type; p.p0 = a.p0;
+    p.s0 = d.a_slot;
+    p.s1 = (a.slen ? (rev ? (agx_u32)d.len - 1u - a.q : a.q) : 0u) | (a.slen << 16) | (rev ? 0x80000000u : 0u);
+    if (a.p0 != AGX_NONE) { p.c0_s = A.cm_start[a.p0]; p.c0_n = A.cm_start[a.p0 + 1] - p.c0_s; if (p.c0_n) p.c0 = A.cm[p.c0_s]; }
+    if (a.type == AGX_AT_K1) p.base = agx_base_at(A.bases + (size_t)d.a_slot * A.stride, d.len, a.q, rev);
+}
+
+// The whole in-order sweep of one position.  get(i) returns the derived hit record of tile-list entry i (the kernels stage 64
+// records at a time across the lanes of the wavefront and broadcast them; the test executor reads memory directly).
+// Returns false if the bucket overflowed (the tile is then re-run with a larger bucket).
+template <class GET>
+AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, const agx_bucket &b, agx_u32 &cnt, GET get) {
     cnt = 0;
-    if (X >= A.n_pos) return true;
-    const agx_u32 cx_s = A.cm_start[X], cx_n = A.cm_start[X + 1] - cx_s;
+    const bool live = X < A.n_pos;                       // lanes beyond the end still take part in the staging of hit records
+    agx_u32 cx_s = 0, cx_n = 0; agx_cmkey cx0 = agx_cmkey{AGX_NONE, AGX_NONE};
+    if (live) { cx_s = A.cm_start[X]; cx_n = A.cm_start[X + 1] - cx_s; if (cx_n) cx0 = A.cm[cx_s]; }
     bool ok = true;
     const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
+    auto fetch = [&](agx_u32 i, agx_pre &p) { p.has = 0; if (i < hi) { const agx_dhit d = get(i); if (live) agx_arrival_fetch(A, d, X, p); } };
+    // Branch-light on purpose: on wave64 every per-lane `if` costs exec-mask bookkeeping on the scalar unit, and the sweep runs
+    // this body ~35 times per position.  The common case — one candidate key, compatible with variant 0 — is straight-line
+    // code under a single `has` mask; everything else (several conti-mers, later variants, inserts) goes through slow().
+    auto slow = [&](const agx_pre &p, bool is_k1, agx_u32 vf) {
+        const agx_u32 nx = cx_n ? cx_n : 1u, n0 = p.c0_n ? p.c0_n : 1u;
+        for (agx_u32 ci = 0; ci < nx && ok; ci++) {                      // candidate keys, X-major (AG:1369-1477)
+            agx_key key; key.off0 = p.p0;
+            const agx_cmkey cx = cx_n ? (ci == 0 ? cx0 : A.cm[cx_s + ci]) : agx_cmkey{AGX_NONE, AGX_NONE};
+            key.cid = cx.cid; key.coff = cx.coff;
+            for (agx_u32 cj = 0; cj < n0; cj++) {
+                const agx_cmkey c0 = p.c0_n ? (cj == 0 ? p.c0 : A.cm[p.c0_s + cj]) : agx_cmkey{AGX_NONE, AGX_NONE};
+                key.cid0 = c0.cid; key.coff0 = c0.coff;
+                const agx_u32 v = agx_match_or_insert(b, cnt, key, A.iv, is_k1, p.s0, p.s1);
+                if (v == AGX_NONE) { ok = false; break; }
+                if (vf != AGX_NF) agx_b(b, v, vf) += 1;
+            }
+        }
+    };
+    auto apply = [&](const agx_pre &p) {
+        if (!p.has || !ok) return;
+        const bool is_k1 = p.type != AGX_AT_K2ONLY;
+        const agx_u32 vf = p.type == AGX_AT_K1 ? agx_vote_field(p.base) : (agx_u32)AGX_NF;
+        agx_key key; key.cid = cx0.cid; key.coff = cx0.coff; key.cid0 = p.c0.cid; key.coff0 = p.c0.coff; key.off0 = p.p0;   // cx0 / c0 are NONE when absent
+        const bool one = cx_n <= 1 && p.c0_n <= 1;
+        if (one && cnt > 0 && agx_compatible(key, b, 0, A.iv)) {
+            if (is_k1) agx_b(b, 0, AGX_F_COV) += 1;
+            if (vf != AGX_NF) agx_b(b, 0, vf) += 1;
+        } else slow(p, is_k1, vf);
+    };
+    // software pipeline, two records in flight: the loads of hit i+1 are issued before hit i touches the bucket
+    agx_pre cur, nxt;
+    fetch(lo, cur);
     for (agx_u32 i = lo; i < hi; i++) {
-        const agx_u32 h = A.tile_hits[i];
-        const agx_dhit d = A.dhit[h];
-        agx_arrival a;
-        if (!agx_decode_arrival(d, A.runs, X, A.k, a)) continue;
-        const bool rev = (d.flags & AGX_HF_AREV) != 0;
-        const bool is_k1 = a.type != AGX_AT_K2ONLY;
-        const agx_u32 s0 = d.a_slot, s1 = (a.slen ? (rev ? (agx_u32)d.len - 1u - a.q : a.q) : 0u) | (a.slen << 16) | (rev ? 0x80000000u : 0u);
-        agx_u32 vf = AGX_NF;
-        if (a.type == AGX_AT_K1) vf = agx_vote_field(agx_base_at(A.bases + (size_t)d.a_slot * A.stride, d.len, a.q, rev));
-        agx_for_candidates(A, cx_s, cx_n, a.p0, [&](const agx_key &key) {
-            const agx_u32 v = agx_match_or_insert(b, cnt, key, A.iv, is_k1, s0, s1);
-            if (v == AGX_NONE) { ok = false; return false; }
-            if (vf != AGX_NF) agx_b(b, v, vf) += 1;
-            return true;
-        });
-        if (!ok) return false;
+        fetch(i + 1, nxt);
+        apply(cur);
+        cur = nxt;
     }
-    return true;
+    return ok;
 }
 
 // consensus base of a node (max, AG:1944-1952): 'X' if no votes; ties resolve A>C>G>T>N
@@ -370,25 +426,29 @@ AGX_HD bool agx_edge_allowed(const agx_sweep_args &A, agx_u32 src, agx_u32 dst) 
 // Fast path (the common case): X holds ONE variant, so every arrival at X resolved to it — no candidate keys, no compatibility
 // tests; if the successor is X+1 and that holds one variant too, the edge's other end is known as well and the contig-consistency
 // predicate is evaluated once per lane.  The four inline slots of such a node live in registers until the sweep ends.
-template <class OVF>
-AGX_HD void agx_edge_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, agx_u32 own_start, agx_u32 own_cnt, agx_u32 nb_start, agx_u32 nb_cnt, OVF push_overflow) {
-    if (X >= A.n_pos || own_cnt == 0) return;
+template <class GET, class OVF>
+AGX_HD void agx_edge_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, agx_u32 own_start, agx_u32 own_cnt, agx_u32 nb_start, agx_u32 nb_cnt, GET get, OVF push_overflow) {
+    const bool live = X < A.n_pos && own_cnt != 0;        // idle lanes still take part in the staging of hit records
+    if (X >= A.n_pos) { X = 0; }
     const bool fast = own_cnt == 1;
-    const agx_u32 cx_s = A.cm_start[X], cx_n = A.cm_start[X + 1] - cx_s;
+    agx_u32 cx_s = 0, cx_n = 0;
+    if (live && !fast) { cx_s = A.cm_start[X]; cx_n = A.cm_start[X + 1] - cx_s; }
     agx_u32 s0 = AGX_NONE, s1 = AGX_NONE, s2 = AGX_NONE, s3 = AGX_NONE;     // slots of the single node (fast lanes)
     bool spilled = false;
     int nb_ok = -1;                                                         // predicate (own -> single neighbour): unknown / no / yes
-    auto put_fast = [&](agx_u32 dst) {
-        if (s0 == dst || s1 == dst || s2 == dst || s3 == dst) return;
-        if (s0 == AGX_NONE) s0 = dst; else if (s1 == AGX_NONE) s1 = dst; else if (s2 == AGX_NONE) s2 = dst; else if (s3 == AGX_NONE) s3 = dst;
-        else { spilled = true; push_overflow(own_start, dst); }             // duplicates are removed on the host
+    auto put_fast = [&](agx_u32 dst) {                                       // set insert into four register slots, select-only
+        bool ins = !(s0 == dst || s1 == dst || s2 == dst || s3 == dst);
+        const bool e0 = ins && s0 == AGX_NONE; s0 = e0 ? dst : s0; ins = ins && !e0;
+        const bool e1 = ins && s1 == AGX_NONE; s1 = e1 ? dst : s1; ins = ins && !e1;
+        const bool e2 = ins && s2 == AGX_NONE; s2 = e2 ? dst : s2; ins = ins && !e2;
+        const bool e3 = ins && s3 == AGX_NONE; s3 = e3 ? dst : s3; ins = ins && !e3;
+        if (ins) { spilled = true; push_overflow(own_start, dst); }         // duplicates are removed on the host
     };
     const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
     for (agx_u32 i = lo; i < hi; i++) {
-        const agx_u32 h = A.tile_hits[i];
-        const agx_dhit d = A.dhit[h];
+        const agx_dhit d = get(i);
         agx_arrival a;
-        if (!agx_decode_arrival(d, A.runs, X, A.k, a) || !a.has_succ) continue;
+        if (!live || !agx_decode_arrival(d, A.runs, X, A.k, a) || !a.has_succ) continue;
         if (a.xs >= A.n_pos) continue;
         if (fast && a.xs == X + 1 && nb_cnt == 1) {
             if (nb_ok < 0) nb_ok = agx_edge_allowed(A, own_start, nb_start) ? 1 : 0;
@@ -419,7 +479,7 @@ AGX_HD void agx_edge_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
             return true;
         });
     }
-    if (fast) {
+    if (live && fast) {
         agx_u32 *slots = A.n_next + (size_t)own_start * AGX_MAXE;
         slots[0] = s0; slots[1] = s1; slots[2] = s2; slots[3] = s3;
         if (spilled) A.n_flags[own_start] |= AGX_NF_EOVF;

@@ -90,6 +90,38 @@ __global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, 
     }
 }
 
+// ---- staging of hit records ----------------------------------------------------------------------------------------------
+// A tile's sweep reads its hit list strictly in order and every lane needs every record.  Instead of two dependent
+// wave-uniform loads per hit (list entry -> record) the wavefront stages 64 records at a time: lane l loads record l of the
+// chunk into its own registers (one coalesced gather), and the loop broadcasts record j with v_readlane — the derived hit
+// record then lives in SGPRs and most of the arrival decode runs on the scalar unit.
+struct agx_wave_hits {
+    const agx_u32 *tile_hits; const agx_dhit *dhit; agx_u32 hi, lane, base; bool primed;
+    agx_u32 r0, r1, r2, r3, r4, r5, r6, r7;       // a_t0, b_t0, a_runs, b_runs, a_slot, len|jstar<<16, a_nruns|b_nruns<<16, flags
+    __device__ __forceinline__ agx_wave_hits(const agx_u32 *th, const agx_dhit *dh, agx_u32 hi_, agx_u32 lane_)
+        : tile_hits(th), dhit(dh), hi(hi_), lane(lane_), base(0), primed(false), r0(0), r1(0), r2(0), r3(0), r4(0), r5(0), r6(0), r7(0) {}
+    __device__ __forceinline__ agx_dhit operator()(agx_u32 i) {
+        if (!primed || i - base >= 64u) {                // wave-uniform: i is the loop counter
+            base = i; primed = true;
+            const agx_u32 idx = i + lane;
+            if (idx < hi) {
+                const agx_dhit d = dhit[tile_hits[idx]];
+                r0 = d.a_t0; r1 = d.b_t0; r2 = d.a_runs; r3 = d.b_runs; r4 = d.a_slot; r5 = (agx_u32)d.len | ((agx_u32)d.jstar << 16);
+                r6 = (agx_u32)d.a_nruns | ((agx_u32)d.b_nruns << 16); r7 = d.flags;
+            }
+        }
+        const int j = (int)(i - base);
+        agx_dhit d;
+        d.a_t0 = (agx_u32)__builtin_amdgcn_readlane((int)r0, j); d.b_t0 = (agx_u32)__builtin_amdgcn_readlane((int)r1, j);
+        d.a_runs = (agx_u32)__builtin_amdgcn_readlane((int)r2, j); d.b_runs = (agx_u32)__builtin_amdgcn_readlane((int)r3, j);
+        d.a_slot = (agx_u32)__builtin_amdgcn_readlane((int)r4, j);
+        const agx_u32 lj = (agx_u32)__builtin_amdgcn_readlane((int)r5, j), nn = (agx_u32)__builtin_amdgcn_readlane((int)r6, j);
+        d.len = (agx_u16)(lj & 0xFFFFu); d.jstar = (agx_u16)(lj >> 16); d.a_nruns = (agx_u16)(nn & 0xFFFFu); d.b_nruns = (agx_u16)(nn >> 16);
+        d.flags = (agx_u32)__builtin_amdgcn_readlane((int)r7, j); d.x_lo = 0; d.x_hi = 0;
+        return d;
+    }
+};
+
 // ---- node sweep ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ agx_u32 agx_wave_incl_scan(agx_u32 v, agx_u32 lane) {
     for (agx_u32 off = 1; off < 64; off <<= 1) { const agx_u32 t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
@@ -110,7 +142,8 @@ __global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
     else { b.base = &lds[wave][lane]; b.maxv = AGX_MAXV_LDS; }
     b.stride = 64;
     agx_u32 cnt = 0;
-    const bool ok = agx_node_sweep_lane(K.S, tile, X, b, cnt);
+    agx_wave_hits hits(K.S.tile_hits, K.S.dhit, K.S.tile_off[tile + 1], lane);
+    const bool ok = agx_node_sweep_lane(K.S, tile, X, b, cnt, hits);
     if (__ballot(!ok) != 0ull) {                       // wave-uniform
         if (lane == 0) {
             if (BIG) atomicOr(K.status, 2u);
@@ -138,7 +171,8 @@ __global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
     // the neighbour position's bucket header comes from the next lane; the last lane reads the next tile's first position
     agx_u32 nb_start = __shfl_down(own_start, 1, 64), nb_cnt = __shfl_down(own_cnt, 1, 64);
     if (lane == 63) { nb_start = 0; nb_cnt = 0; if (X + 1 < K.S.n_pos) { nb_start = K.S.node_start[X + 1]; nb_cnt = K.S.node_cnt[X + 1]; } }
-    agx_edge_sweep_lane(K.S, tile, X, own_start, own_cnt, nb_start, nb_cnt, [&](agx_u32 s, agx_u32 d) {
+    agx_wave_hits hits(K.S.tile_hits, K.S.dhit, K.S.tile_off[tile + 1], lane);
+    agx_edge_sweep_lane(K.S, tile, X, own_start, own_cnt, nb_start, nb_cnt, hits, [&](agx_u32 s, agx_u32 d) {
         const agx_u32 i = atomicAdd(K.ovf_count, 1u);
         if (i < K.ovf_cap) K.ovf[i] = agx_edge_ovf{s, d};
     });

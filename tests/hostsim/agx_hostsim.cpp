@@ -70,11 +70,12 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     bind();
     n_big_tiles = 0;
     agx_u32 pool = 0;
+    auto get = [&](agx_u32 i) { return dh[tile_hits[i]]; };
     std::vector<agx_u32> lds((size_t)AGX_NF * maxv_first * AGX_TILE), big;
     for (agx_u32 t = 0; t < n_tiles; t++) {
         agx_u32 cnt[AGX_TILE]; bool ok = true;
         agx_bucket b{nullptr, AGX_TILE, maxv_first};
-        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) { b.base = lds.data() + lane; ok &= agx_node_sweep_lane(A, t, t * AGX_TILE + lane, b, cnt[lane]); }
+        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) { b.base = lds.data() + lane; ok &= agx_node_sweep_lane(A, t, t * AGX_TILE + lane, b, cnt[lane], get); }
         agx_u32 *store = lds.data(); agx_u32 maxv = maxv_first;
         if (!ok) {                                     // the fallback the engine runs for overflowed tiles
             n_big_tiles++;
@@ -82,7 +83,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
             agx_bucket bb{nullptr, AGX_TILE, maxv};
             for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
                 bb.base = store + lane;
-                if (!agx_node_sweep_lane(A, t, t * AGX_TILE + lane, bb, cnt[lane])) throw Error{E_OVERFLOW, "more than AGX_MAXV_BIG node variants at one position"};
+                if (!agx_node_sweep_lane(A, t, t * AGX_TILE + lane, bb, cnt[lane], get)) throw Error{E_OVERFLOW, "more than AGX_MAXV_BIG node variants at one position"};
             }
         }
         agx_u32 total = 0; for (agx_u32 lane = 0; lane < AGX_TILE; lane++) total += cnt[lane];
@@ -96,7 +97,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
             const agx_u32 X = t * AGX_TILE + lane;
             if (X >= n_pos) continue;
             const agx_u32 nbs = X + 1 < n_pos ? S.node_start[X + 1] : 0, nbc = X + 1 < n_pos ? S.node_cnt[X + 1] : 0;
-            agx_edge_sweep_lane(A, t, X, S.node_start[X], S.node_cnt[X], nbs, nbc, [&](agx_u32 s, agx_u32 d) { S.ovf.push_back(agx_edge_ovf{s, d}); });
+            agx_edge_sweep_lane(A, t, X, S.node_start[X], S.node_cnt[X], nbs, nbc, get, [&](agx_u32 s, agx_u32 d) { S.ovf.push_back(agx_edge_ovf{s, d}); });
         }
 
     // walk preparation, the same per-element functions the compaction kernels run
