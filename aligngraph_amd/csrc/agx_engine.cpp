@@ -63,12 +63,12 @@ struct agx_unit {
     // derived
     DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_hits, d_scan_tmp, d_words;   // d_words: counters/status
     // node table
-    agx_u32 pool_cap = 0, ovf_cap = 0;
+    agx_u32 pool_cap = 0, ovf_cap = 0, list_cap = 0;
     DBuf<agx_u32> d_node_start; DBuf<agx_u8> d_node_cnt;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_big_list, d_scratch;
     // walk graph (agx_core.h "walk preparation")
-    agx_u32 n_ids = 0, ids_cap = 0;
+    agx_u32 n_ids = 0;
     DBuf<agx_u32> d_side_cnt, d_side_start, d_aid_of; DBuf<char> d_a_str;
     DBuf<agx_u8> d_a_meta; DBuf<agx_walknode> d_a_node; DBuf<agx_edge_ovf> d_a_ovf;
     // downloaded
@@ -125,9 +125,9 @@ void do_upload(agx_unit *u) {
     if (!u->P.bases.empty()) HIP_OK(hipMemcpyAsync(u->d_bases.p, u->P.bases.data(), u->P.bases.size(), hipMemcpyHostToDevice, u->st));
     u->n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
     u->d_tile_cnt.alloc((size_t)u->n_tiles + 1); u->d_tile_off.alloc((size_t)u->n_tiles + 2); u->d_cursor.alloc((size_t)u->n_tiles + 1);
-    const size_t nb = ((size_t)u->n_tiles + 1 + 1023) / 1024;
+    const size_t nb = ((size_t)n_pos + 1 + 1023) / 1024;              // sized for the longer of the two scans (positions)
     u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16);
-    u->d_words.alloc(W_N); u->h_words.alloc(W_N);
+    u->d_words.alloc(W_N); u->h_words.alloc(W_N + 4);
     u->d_node_start.alloc(n_pos); u->d_node_cnt.alloc(n_pos);
     if (u->pool_cap == 0) alloc_pool(u, (agx_u32)std::min<size_t>(2 * n_pos + 4096, 0xFFFFFF00ull));
     if (u->ovf_cap == 0) { u->ovf_cap = 1u << 16; u->d_ovf.alloc(u->ovf_cap); }
@@ -136,125 +136,97 @@ void do_upload(agx_unit *u) {
     u->stats.ms_upload = now_ms() - t0;
 }
 
-void read_words(agx_unit *u) {
-    HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, W_N * 4, hipMemcpyDeviceToHost, u->st));
-    HIP_OK(hipStreamSynchronize(u->st));
-}
-
+// All kernels of one build are queued back to back with the current buffer capacities; the counters they produce (tile-list
+// entries, nodes, overflowed tiles, edge overflow, side variants) are read after ONE synchronisation.  A capacity that proved too
+// small is grown and the build repeats — that only ever happens on the first build of a unit.
 void do_build(agx_unit *u) {
     if (!u->uploaded) do_upload(u);
     HIP_OK(hipSetDevice(u->prm.device));
     const agx_u32 n_pos = (agx_u32)u->T.ref.size(), nh = (agx_u32)u->P.hits.size();
     hipStream_t st = u->st;
     u->stats.node_sweep_launches = u->stats.edge_sweep_launches = 0;
-
-    // ---- hit_prep + tile histogram ----
-    HIP_OK(hipMemsetAsync(u->d_words.p, 0, W_N * 4, st));
-    HIP_OK(hipMemsetAsync(u->d_tile_cnt.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
-    HIP_OK(hipMemsetAsync(u->d_cursor.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
-    HIP_OK(hipEventRecord(u->ev_prep.a, st));
-    agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR};
-    agx_launch_hit_prep(&PA, st);
-    HIP_OK(hipEventRecord(u->ev_prep.b, st)); u->ev_prep.used = true;
-
-    // ---- tile lists ----
-    HIP_OK(hipEventRecord(u->ev_bin.a, st));
-    agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
-    HIP_OK(hipMemcpyAsync(u->h_words.p + W_N - 1, u->d_tile_off.p + u->n_tiles, 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
-    if (u->h_words.p[W_ERR] & 1u) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
-    if (u->h_words.p[W_ERR] & 2u) throw Error{E_UNSUPPORTED, "read alignment beyond the end of the unit sequence"};
-    u->n_tile_entries = u->h_words.p[W_N - 1];
-    u->d_unsorted.alloc((size_t)u->n_tile_entries + 1); u->d_tile_hits.alloc((size_t)u->n_tile_entries + 1);
-    agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p};
-    agx_launch_bin_fill(&BA, st);
-    agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->d_tile_hits.p, u->n_tiles, st);
-    HIP_OK(hipEventRecord(u->ev_bin.b, st)); u->ev_bin.used = true;
-
-    // ---- node sweep (re-run with a larger pool if the first guess was too small) ----
+    if (u->list_cap == 0) u->list_cap = (agx_u32)std::min<size_t>((size_t)nh * 3 + 1024, 0xFFFFFF00ull);
     u->d_big_list.alloc((size_t)u->n_tiles + 1);
-    for (;;) {
-        HIP_OK(hipMemsetAsync(u->d_words.p + W_POOL, 0, 3 * 4, st));     // pool counter, big count, status
+    u->d_scratch.alloc((size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64);
+    for (int attempt = 0;; attempt++) {
+        if (attempt > 8) throw Error{E_DEVICE, "build did not converge"};
+        u->d_unsorted.alloc((size_t)u->list_cap + 1); u->d_tile_hits.alloc((size_t)u->list_cap + 1);
+        u->d_aid_of.alloc((size_t)u->pool_cap + 1);
+        const size_t ids_cap = (size_t)n_pos + u->pool_cap;                       // side variants <= nodes <= pool_cap
+        u->d_a_str.alloc(ids_cap + 1); u->d_a_meta.alloc(ids_cap + 16); u->d_a_node.alloc(ids_cap + 1); u->d_a_ovf.alloc((size_t)u->ovf_cap + 1);
+        u->d_side_cnt.alloc((size_t)n_pos + 2); u->d_side_start.alloc((size_t)n_pos + 2);
+
+        HIP_OK(hipMemsetAsync(u->d_words.p, 0, W_N * 4, st));
+        HIP_OK(hipMemsetAsync(u->d_tile_cnt.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
+        HIP_OK(hipMemsetAsync(u->d_cursor.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
+        // ---- hit_prep + tile histogram ----
+        HIP_OK(hipEventRecord(u->ev_prep.a, st));
+        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR};
+        agx_launch_hit_prep(&PA, st);
+        HIP_OK(hipEventRecord(u->ev_prep.b, st)); u->ev_prep.used = true;
+        // ---- tile lists ----
+        HIP_OK(hipEventRecord(u->ev_bin.a, st));
+        agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
+        agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap};
+        agx_launch_bin_fill(&BA, st);
+        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->d_tile_hits.p, u->n_tiles, u->list_cap, st);
+        HIP_OK(hipEventRecord(u->ev_bin.b, st)); u->ev_bin.used = true;
+        // ---- node sweep: LDS pass, then the global-scratch pass over whatever tiles overflowed (device-side count) ----
         agx_node_kargs K; fill_sweep_args(u, K.S);
         K.pool_counter = u->d_words.p + W_POOL; K.big_count = u->d_words.p + W_BIGCOUNT; K.big_list = u->d_big_list.p; K.status = u->d_words.p + W_STATUS;
-        K.tile_list = nullptr; K.n_list = 0; K.scratch = nullptr;
+        K.list_cap = u->list_cap; K.big_n = u->d_words.p + W_BIGCOUNT; K.scratch = u->d_scratch.p;
         HIP_OK(hipEventRecord(u->ev_node.a, st));
         agx_launch_node_sweep(&K, st);
         HIP_OK(hipEventRecord(u->ev_node.b, st)); u->ev_node.used = true; u->stats.node_sweep_launches++;
-        read_words(u);
-        u->n_big = u->h_words.p[W_BIGCOUNT];
-        u->ev_big.used = false;
-        if (u->n_big && !(u->h_words.p[W_STATUS] & 1u)) {
-            // tiles whose buckets outgrew LDS: same sweep with buckets in global scratch, in chunks that bound the scratch size
-            const agx_u32 chunk = 4096;
-            u->d_scratch.alloc((size_t)std::min(u->n_big, chunk) * AGX_NF * AGX_MAXV_BIG * 64);
-            HIP_OK(hipEventRecord(u->ev_big.a, st));
-            for (agx_u32 off = 0; off < u->n_big; off += chunk) {
-                K.tile_list = u->d_big_list.p + off; K.n_list = std::min(chunk, u->n_big - off); K.scratch = u->d_scratch.p;
-                agx_launch_node_sweep_big(&K, st);
-            }
-            HIP_OK(hipEventRecord(u->ev_big.b, st)); u->ev_big.used = true;
-            read_words(u);
-        }
-        if (u->h_words.p[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 64 node variants at one position"};
-        const unsigned long long want = u->h_words.p[W_POOL];
-        if ((u->h_words.p[W_STATUS] & 1u) || want > u->pool_cap) {
-            const unsigned long long cap = std::min<unsigned long long>(std::max<unsigned long long>(want + want / 4 + 4096, 2ull * u->pool_cap), 0xFFFFFF00ull);
-            if (cap <= u->pool_cap) throw Error{E_OVERFLOW, "node table exceeds 2^32 entries"};
-            u->d_cid.release(); u->d_coff.release(); u->d_cid0.release(); u->d_coff0.release(); u->d_off0.release(); u->d_xpos.release();
-            u->d_next.release(); u->d_base.release(); u->d_flags.release(); u->d_sref.release(); u->d_counts.release();
-            alloc_pool(u, (agx_u32)cap);
-            continue;
-        }
-        u->n_nodes = (agx_u32)want;
-        break;
-    }
-
-    // ---- edge sweep (re-run with a larger overflow list if needed; slot writes are idempotent) ----
-    for (;;) {
-        HIP_OK(hipMemsetAsync(u->d_words.p + W_OVFCOUNT, 0, 4, st));
-        agx_edge_kargs E; fill_sweep_args(u, E.S); E.ovf = u->d_ovf.p; E.ovf_count = u->d_words.p + W_OVFCOUNT; E.ovf_cap = u->ovf_cap;
+        HIP_OK(hipEventRecord(u->ev_big.a, st));
+        agx_launch_node_sweep_big(&K, st);
+        HIP_OK(hipEventRecord(u->ev_big.b, st)); u->ev_big.used = true;
+        // ---- edge sweep ----
+        agx_edge_kargs E; fill_sweep_args(u, E.S); E.ovf = u->d_ovf.p; E.ovf_count = u->d_words.p + W_OVFCOUNT; E.ovf_cap = u->ovf_cap; E.list_cap = u->list_cap;
         HIP_OK(hipEventRecord(u->ev_edge.a, st));
         agx_launch_edge_sweep(&E, st);
         HIP_OK(hipEventRecord(u->ev_edge.b, st)); u->ev_edge.used = true; u->stats.edge_sweep_launches++;
-        read_words(u);
-        const agx_u32 c = u->h_words.p[W_OVFCOUNT];
-        if (c > u->ovf_cap) { u->ovf_cap = c + c / 2 + 1024; u->d_ovf.release(); u->d_ovf.alloc(u->ovf_cap); continue; }
-        u->n_ovf = c;
-        break;
-    }
-
-    // ---- walk preparation: side counts -> scan -> walk ids, node records, rewritten edges, forced-run flags ----
-    {
+        // ---- walk preparation: side counts -> scan -> walk ids, node records, rewritten edges, forced-run flags ----
         agx_compact_args C; memset(&C, 0, sizeof C);
-        u->d_side_cnt.alloc((size_t)n_pos + 2); u->d_side_start.alloc((size_t)n_pos + 2); u->d_aid_of.alloc((size_t)u->n_nodes + 1);
-        const size_t nbs = ((size_t)n_pos + 1 + 1023) / 1024;
-        u->d_scan_tmp.alloc(2 * (nbs + 1) + 2 * ((nbs + 1023) / 1024 + 1) + 16);
         C.node_start = u->d_node_start.p; C.node_cnt = u->d_node_cnt.p; C.n_flags = u->d_flags.p; C.n_base = u->d_base.p; C.n_xpos = u->d_xpos.p;
-        C.nk_off0 = u->d_off0.p; C.n_sref = u->d_sref.p; C.n_next = u->d_next.p; C.ref = u->d_ref.p; C.n_pos = n_pos; C.n_nodes = u->n_nodes;
+        C.nk_off0 = u->d_off0.p; C.n_sref = u->d_sref.p; C.n_next = u->d_next.p; C.ref = u->d_ref.p; C.n_pos = n_pos; C.n_nodes = 0;
         C.side_cnt = u->d_side_cnt.p; C.side_start = u->d_side_start.p; C.aid_of = u->d_aid_of.p;
+        C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_node = u->d_a_node.p; C.ovf = u->d_ovf.p; C.n_ovf = 0; C.a_ovf = u->d_a_ovf.p;
         HIP_OK(hipEventRecord(u->ev_compact.a, st));
         HIP_OK(hipMemsetAsync(u->d_side_cnt.p + n_pos, 0, 4, st));
         agx_launch_side_count(&C, st);
         agx_launch_exclusive_scan(u->d_side_cnt.p, u->d_side_start.p, n_pos, u->d_scan_tmp.p, st);
-        HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_side_start.p + n_pos, 4, hipMemcpyDeviceToHost, st));
+        agx_launch_compact(&C, u->d_words.p + W_POOL, u->pool_cap, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
+        HIP_OK(hipEventRecord(u->ev_compact.b, st)); u->ev_compact.used = true;
+        // ---- the one synchronisation ----
+        HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, W_N * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_words.p + W_N, u->d_tile_off.p + u->n_tiles, 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_words.p + W_N + 1, u->d_side_start.p + n_pos, 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
-        const unsigned long long ids = (unsigned long long)n_pos + u->h_words.p[0];
+        HIP_OK(hipGetLastError());
+        const agx_u32 *w = u->h_words.p;
+        if (w[W_ERR] & 1u) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
+        if (w[W_ERR] & 2u) throw Error{E_UNSUPPORTED, "read alignment beyond the end of the unit sequence"};
+        u->n_tile_entries = w[W_N];
+        if (u->n_tile_entries > u->list_cap) { u->list_cap = u->n_tile_entries + u->n_tile_entries / 8 + 1024; u->d_unsorted.release(); u->d_tile_hits.release(); continue; }
+        if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 64 node variants at one position"};
+        const unsigned long long want = w[W_POOL];
+        if ((w[W_STATUS] & 1u) || want > u->pool_cap) {
+            const unsigned long long cap = std::min<unsigned long long>(std::max<unsigned long long>(want + want / 4 + 4096, 2ull * u->pool_cap), 0xFFFFFF00ull);
+            if (cap <= u->pool_cap) throw Error{E_OVERFLOW, "node table exceeds 2^32 entries"};
+            u->d_cid.release(); u->d_coff.release(); u->d_cid0.release(); u->d_coff0.release(); u->d_off0.release(); u->d_xpos.release();
+            u->d_next.release(); u->d_base.release(); u->d_flags.release(); u->d_sref.release(); u->d_counts.release();
+            u->d_aid_of.release(); u->d_a_str.release(); u->d_a_meta.release(); u->d_a_node.release();
+            alloc_pool(u, (agx_u32)cap);
+            continue;
+        }
+        if (w[W_OVFCOUNT] > u->ovf_cap) { u->ovf_cap = w[W_OVFCOUNT] + w[W_OVFCOUNT] / 2 + 1024; u->d_ovf.release(); u->d_ovf.alloc(u->ovf_cap); u->d_a_ovf.release(); continue; }
+        u->n_nodes = (agx_u32)want; u->n_big = w[W_BIGCOUNT]; u->n_ovf = w[W_OVFCOUNT];
+        const unsigned long long ids = (unsigned long long)n_pos + w[W_N + 1];
         if (ids >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "walk graph exceeds 2^32 ids"};
         u->n_ids = (agx_u32)ids;
-        if (u->n_ids > u->ids_cap) {
-            const size_t cap = (size_t)u->n_ids + u->n_ids / 8 + 1024; u->ids_cap = (agx_u32)std::min<size_t>(cap, 0xFFFFFF00ull);
-            u->d_a_str.alloc(cap); u->d_a_meta.alloc(cap + 16); u->d_a_node.alloc(cap);
-        }
-        u->d_a_ovf.alloc((size_t)u->n_ovf + 1);
-        C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_node = u->d_a_node.p;
-        C.ovf = u->d_ovf.p; C.n_ovf = u->n_ovf; C.a_ovf = u->d_a_ovf.p;
-        agx_launch_compact(&C, st);
-        HIP_OK(hipEventRecord(u->ev_compact.b, st)); u->ev_compact.used = true;
-        HIP_OK(hipStreamSynchronize(st));
+        break;
     }
-    HIP_OK(hipGetLastError());
     u->built = true; u->downloaded = false;
     u->stats.ms_prep = u->ev_prep.ms(); u->stats.ms_bin = u->ev_bin.ms(); u->stats.ms_node_sweep = u->ev_node.ms();
     u->stats.ms_node_big = u->ev_big.ms(); u->stats.ms_edge_sweep = u->ev_edge.ms(); u->stats.ms_compact = u->ev_compact.ms();

@@ -60,17 +60,18 @@ __global__ void __launch_bounds__(256) agx_k_bin_fill(agx_bin_args A) {
     if (h >= A.n_hits) return;
     const agx_dhit d = A.dhit[h];
     if (d.flags & AGX_HF_SKIP) return;
-    for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++) A.unsorted[A.tile_off[t] + atomicAdd(&A.cursor[t], 1u)] = h;
+    for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++) { const agx_u32 at = A.tile_off[t] + atomicAdd(&A.cursor[t], 1u); if (at < A.cap) A.unsorted[at] = h; }
 }
 
 // one wavefront per tile; hit ids are unique, so an element's rank is the number of smaller elements
 #define AGX_SORT_LDS 2048
-__global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles) {
+__global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap) {
     __shared__ agx_u32 sh[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
     if (tile >= n_tiles) return;
     const agx_u32 lo = tile_off[tile], n = tile_off[tile + 1] - lo;
+    if (tile_off[tile + 1] > cap) return;                // lists did not fit: the host grows them and re-runs
     const agx_u32 *src = unsorted + lo;
     if (n <= AGX_SORT_LDS) {
         for (agx_u32 i = lane; i < n; i += 64) sh[wave][i] = src[i];
@@ -133,38 +134,41 @@ __global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
     __shared__ agx_u32 lds[BIG ? 1 : AGX_WAVES_PER_BLOCK][BIG ? 1 : AGX_NF * AGX_MAXV_LDS * 64];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const agx_u32 slot = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
-    agx_u32 tile;
-    if (BIG) { if (slot >= K.n_list) return; tile = __builtin_amdgcn_readfirstlane(K.tile_list[slot]); }
-    else { if (slot >= K.S.n_tiles) return; tile = slot; }
-    const agx_u32 X = tile * AGX_TILE + lane;
-    agx_bucket b;
+    agx_bucket b; b.stride = 64;
     if (BIG) { b.base = K.scratch + (size_t)slot * (AGX_NF * AGX_MAXV_BIG * 64) + lane; b.maxv = AGX_MAXV_BIG; }
     else { b.base = &lds[wave][lane]; b.maxv = AGX_MAXV_LDS; }
-    b.stride = 64;
-    agx_u32 cnt = 0;
-    agx_wave_hits hits(K.S.tile_hits, K.S.dhit, K.S.tile_off[tile + 1], lane);
-    const bool ok = agx_node_sweep_lane(K.S, tile, X, b, cnt, hits);
-    if (__ballot(!ok) != 0ull) {                       // wave-uniform
-        if (lane == 0) {
-            if (BIG) atomicOr(K.status, 2u);
-            else K.big_list[atomicAdd(K.big_count, 1u)] = tile;
+    // LDS pass: one tile per wavefront.  Fallback pass: a fixed set of wavefronts strides over the list of overflowed tiles.
+    const agx_u32 n_work = BIG ? __builtin_amdgcn_readfirstlane(*K.big_n) : K.S.n_tiles;
+    for (agx_u32 w = slot; w < n_work; w += BIG ? AGX_BIG_WAVES : 0xFFFFFFFFu) {
+        const agx_u32 tile = BIG ? __builtin_amdgcn_readfirstlane(K.big_list[w]) : w;
+        if (K.S.tile_off[tile + 1] > K.list_cap) return;
+        const agx_u32 X = tile * AGX_TILE + lane;
+        agx_u32 cnt = 0;
+        agx_wave_hits hits(K.S.tile_hits, K.S.dhit, K.S.tile_off[tile + 1], lane);
+        const bool ok = agx_node_sweep_lane(K.S, tile, X, b, cnt, hits);
+        if (__ballot(!ok) != 0ull) {                       // wave-uniform
+            if (lane == 0) {
+                if (BIG) atomicOr(K.status, 2u);
+                else K.big_list[atomicAdd(K.big_count, 1u)] = tile;
+            }
+            if (BIG) continue; else return;
         }
-        return;
+        const agx_u32 incl = agx_wave_incl_scan(cnt, lane);
+        const agx_u32 total = __shfl(incl, 63, 64);
+        agx_u32 base = 0;
+        if (lane == 0) base = atomicAdd(K.pool_counter, total);
+        base = __shfl(base, 0, 64);
+        if ((unsigned long long)base + total > K.S.pool_cap) { if (lane == 0) atomicOr(K.status, 1u); if (BIG) continue; else return; }
+        agx_node_write_lane(K.S, X, b, cnt, base + incl - cnt);
+        if (!BIG) return;
     }
-    const agx_u32 incl = agx_wave_incl_scan(cnt, lane);
-    const agx_u32 total = __shfl(incl, 63, 64);
-    agx_u32 base = 0;
-    if (lane == 0) base = atomicAdd(K.pool_counter, total);
-    base = __shfl(base, 0, 64);
-    if ((unsigned long long)base + total > K.S.pool_cap) { if (lane == 0) atomicOr(K.status, 1u); return; }
-    agx_node_write_lane(K.S, X, b, cnt, base + incl - cnt);
 }
 
 // ---- edge sweep -------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
-    if (tile >= K.S.n_tiles) return;
+    if (tile >= K.S.n_tiles || K.S.tile_off[tile + 1] > K.list_cap) return;
     const agx_u32 X = tile * AGX_TILE + lane;
     agx_u32 own_start = 0, own_cnt = 0;
     if (X < K.S.n_pos) { own_start = K.S.node_start[X]; own_cnt = K.S.node_cnt[X]; }
@@ -181,8 +185,10 @@ __global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
 // ---- walk preparation: renumber surviving nodes, rewrite edges, mark forced runs (agx_core.h) -------------------------------
 __global__ void __launch_bounds__(256) agx_k_side_count(agx_compact_args A) { agx_side_count_pos(A, blockIdx.x * 256u + threadIdx.x); }
 __global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A) { agx_assign_aid_pos(A, blockIdx.x * 256u + threadIdx.x); }
-__global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A) { agx_emit_alive_node(A, blockIdx.x * 256u + threadIdx.x); }
-__global__ void __launch_bounds__(256) agx_k_emit_ovf(agx_compact_args A) { agx_emit_alive_ovf(A, blockIdx.x * 256u + threadIdx.x); }
+__global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A, const agx_u32 *n_nodes_dev) { A.n_nodes = *n_nodes_dev; agx_emit_alive_node(A, blockIdx.x * 256u + threadIdx.x); }
+__global__ void __launch_bounds__(256) agx_k_emit_ovf(agx_compact_args A, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap) {
+    const agx_u32 n = *n_ovf_dev; A.n_ovf = n < ovf_cap ? n : ovf_cap; agx_emit_alive_ovf(A, blockIdx.x * 256u + threadIdx.x);
+}
 
 // ---- host-callable launchers (kept in this translation unit so that the engine is plain C++) -------------------------
 extern "C" {
@@ -214,16 +220,15 @@ void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u
 void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_bin_fill, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
 }
-void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, hipStream_t st) {
-    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, sorted, n_tiles);
+void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap, hipStream_t st) {
+    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, sorted, n_tiles, cap);
 }
 void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;
     if (n) hipLaunchKernelGGL(agx_k_node_sweep<false>, dim3((n + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
 }
 void agx_launch_node_sweep_big(const agx_node_kargs *K, hipStream_t st) {
-    const agx_u32 n = K->n_list;
-    if (n) hipLaunchKernelGGL(agx_k_node_sweep<true>, dim3((n + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
+    hipLaunchKernelGGL(agx_k_node_sweep<true>, dim3(AGX_BIG_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
 }
 void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;
@@ -233,10 +238,10 @@ void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
 void agx_launch_side_count(const agx_compact_args *A, hipStream_t st) {
     if (A->n_pos) hipLaunchKernelGGL(agx_k_side_count, dim3((A->n_pos + 255) / 256), dim3(256), 0, st, *A);
 }
-void agx_launch_compact(const agx_compact_args *A, hipStream_t st) {
+void agx_launch_compact(const agx_compact_args *A, const agx_u32 *n_nodes_dev, agx_u32 pool_cap, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t st) {
     if (A->n_pos) hipLaunchKernelGGL(agx_k_assign_aid, dim3((A->n_pos + 255) / 256), dim3(256), 0, st, *A);
-    if (A->n_nodes) hipLaunchKernelGGL(agx_k_emit_alive, dim3((A->n_nodes + 255) / 256), dim3(256), 0, st, *A);
-    if (A->n_ovf) hipLaunchKernelGGL(agx_k_emit_ovf, dim3((A->n_ovf + 255) / 256), dim3(256), 0, st, *A);
+    if (pool_cap) hipLaunchKernelGGL(agx_k_emit_alive, dim3((pool_cap + 255) / 256), dim3(256), 0, st, *A, n_nodes_dev);
+    if (ovf_cap) hipLaunchKernelGGL(agx_k_emit_ovf, dim3((ovf_cap + 255) / 256), dim3(256), 0, st, *A, n_ovf_dev, ovf_cap);
 }
 
 }  // extern "C"
