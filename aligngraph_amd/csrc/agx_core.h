@@ -96,68 +96,71 @@ AGX_HD bool agx_compatible(const agx_key &k, const agx_bucket &b, agx_u32 v, int
 
 // ---- read geometry ---------------------------------------------------------------------------------------
 
-// reference offset of read index q of the b mate, or NONE
+// reference offset of read index q of the b mate, or NONE.  Select-only: the loop count is wave-uniform, q is per lane.
 AGX_HD agx_u32 agx_pos_b(const agx_dhit &d, const agx_run *runs, agx_u32 q) {
     if (d.b_nruns == 0) return d.b_t0 + q;
-    for (agx_u32 i = 0; i < d.b_nruns; i++) { const agx_run r = runs[d.b_runs + i]; if (q >= r.q && q < r.q + r.n) return r.t + (q - r.q); }
-    return AGX_NONE;
+    agx_u32 res = AGX_NONE;
+    for (agx_u32 i = 0; i < d.b_nruns; i++) { const agx_run r = runs[d.b_runs + i]; const agx_u32 o = q - r.q; res = (q >= r.q && o < r.n) ? r.t + o : res; }
+    return res;
 }
 
 enum { AGX_AT_K1 = 0, AGX_AT_K2ONLY = 1, AGX_AT_CHAIN = 2 };
 
 struct agx_arrival {
+    agx_u32 has;              // 0: the hit contributes nothing at this position
     agx_u32 type, q, slen;    // q: read index whose base votes / starts the k-mer string
     agx_u32 p0;               // mate position (or NONE)
     agx_u32 has_succ, xs, p0s;  // successor arrival of the same hit: position and its mate position (the event's N / N0)
 };
 
 // What hit d contributes at position X (if anything).  Follows the event loop of AG:1681-1859; k = k-mer length.
-AGX_HD bool agx_decode_arrival(const agx_dhit &d, const agx_run *runs, agx_u32 X, agx_u32 k, agx_arrival &a) {
-    const agx_u32 L = d.len;
-    if (d.a_nruns == 0) {
-        // fast path (nine hits out of ten): the a mate is one full-length run, so read index q sits on a_t0+q, every index
-        // below jstar (= L-k here) is an event source whose successor is the next position, and jstar itself is K2ONLY.
+//
+// Written without per-lane branches: every `if` on a lane-varying condition costs exec-mask bookkeeping on wave64, and this runs
+// once per (hit, position).  All loops below have wave-uniform trip counts (run counts of the hit), all decisions are selects.
+AGX_HD agx_arrival agx_decode_arrival(const agx_dhit &d, const agx_run *runs, agx_u32 X, agx_u32 k) {
+    agx_arrival a;
+    const agx_u32 L = d.len, js = d.jstar;
+    if (d.a_nruns == 0 && d.b_nruns == 0) {
+        // nine hits out of ten: both mates are one full-length run.  Read index q sits on a_t0+q; every index below jstar (= L-k)
+        // is an event source whose successor is the next position; jstar itself only receives the k2 half (K2ONLY).
         // Hits with L <= k carry AGX_HF_SKIP and are never listed, so jstar is valid.
         const agx_u32 q = X - d.a_t0;                       // wraps to a huge value left of the read
-        if (q > d.jstar) return false;
-        a.q = q; a.p0 = agx_pos_b(d, runs, q);
-        if (q == d.jstar) { a.type = AGX_AT_K2ONLY; a.slen = (L - q) < k ? (L - q) : k; a.has_succ = 0; a.xs = 0; a.p0s = AGX_NONE; return true; }
-        a.type = AGX_AT_K1; a.slen = k; a.has_succ = 1; a.xs = X + 1; a.p0s = agx_pos_b(d, runs, q + 1);
-        return true;
+        const bool last = q == js;
+        a.has = q <= js ? 1u : 0u; a.type = last ? AGX_AT_K2ONLY : AGX_AT_K1; a.q = q; a.slen = k;
+        a.p0 = d.b_t0 + q; a.has_succ = last ? 0u : 1u; a.xs = X + 1; a.p0s = d.b_t0 + q + 1;
+        return a;
     }
-    if (L <= k) return false;
-    const agx_u32 lim = L - k;
-    const agx_u32 nr = d.a_nruns;
-    agx_run r = runs[d.a_runs];
+    const agx_u32 lim = L > k ? L - k : 0u;
+    const agx_u32 nr = d.a_nruns == 0 ? 1u : d.a_nruns;
+    a.has = 0; a.type = AGX_AT_K1; a.q = 0; a.slen = 0; a.p0 = AGX_NONE; a.has_succ = 0; a.xs = X + 1; a.p0s = AGX_NONE;
+    agx_u32 qsucc = AGX_NONE;                              // read index that supplies the successor's mate position (NONE: none)
+    agx_run r = d.a_nruns == 0 ? agx_run{0u, d.a_t0, L} : runs[d.a_runs];
     for (agx_u32 i = 0; i < nr; i++) {
-        agx_run nx = (i + 1 < nr) ? runs[d.a_runs + i + 1] : agx_run{0u, 0u, 0u};
-        if (X >= r.t && X - r.t < r.n) {
-            const agx_u32 q = r.q + (X - r.t);
-            a.q = q; a.p0 = agx_pos_b(d, runs, q); a.has_succ = 0; a.xs = 0; a.p0s = AGX_NONE;
-            // An index is an event SOURCE (k1: count + vote) iff it is aligned, below lim and not the last aligned index of the
-            // read; jstar is the first aligned index that is not a source: it only ever receives the k2 half (AG:1484-1500).
-            if (q == d.jstar) { a.type = AGX_AT_K2ONLY; a.slen = (L - q) < k ? (L - q) : k; return true; }
-            if (q < d.jstar) {
-                a.type = AGX_AT_K1; a.slen = k; a.has_succ = 1;
-                if (X - r.t + 1 < r.n) { a.xs = X + 1; a.p0s = agx_pos_b(d, runs, q + 1); }                            // ordinary, AG:1841-1857
-                else if (nx.q == q + 1 || nx.t == X + 1) { a.xs = nx.t; a.p0s = agx_pos_b(d, runs, nx.q); }            // deletion AG:1822-1838 / insertion AG:1707-1727
-                else { a.xs = X + 1; a.p0s = AGX_NONE; }                                                               // first step of a chain, AG:1736
-                return true;
-            }
-            return false;
-        }
-        if (i + 1 < nr && X >= r.t + r.n && X < nx.t) {                       // between two runs
-            const agx_u32 p = r.q + r.n - 1;
-            if (nx.q >= p + 2 && p < lim) {                                   // read insertion next to a reference gap: chain, AG:1737-1749
-                a.type = AGX_AT_CHAIN; a.q = 0; a.slen = 0; a.p0 = AGX_NONE; a.has_succ = 1; a.xs = X + 1;
-                a.p0s = (X + 1 == nx.t) ? agx_pos_b(d, runs, nx.q) : AGX_NONE;
-                return true;
-            }
-            return false;
-        }
+        const bool has_nx = i + 1 < nr;
+        const agx_run nx = has_nx ? runs[d.a_runs + i + 1] : agx_run{0u, 0u, 0u};
+        // X inside this run: index q.  Sources are the aligned indices below jstar; jstar is the first aligned index that is not a
+        // source (at or beyond L-k, or the read's last aligned index) and only receives the k2 half (AG:1484-1500).
+        const agx_u32 off = X - r.t, q = r.q + off;
+        const bool in_run = X >= r.t && off < r.n, is_last = q == js, is_src = q < js;
+        const bool hit_run = in_run && (is_last || is_src);
+        const bool end_of_run = off + 1 >= r.n;
+        const bool direct = has_nx && (nx.q == q + 1 || nx.t == X + 1);       // deletion AG:1822-1838 / insertion AG:1707-1727; else a chain starts (AG:1736)
+        // X between this run and the next: a read insertion next to a reference gap walks through these positions (AG:1737-1749)
+        const agx_u32 p = r.q + r.n - 1;
+        const bool in_gap = has_nx && X >= r.t + r.n && X < nx.t && nx.q >= p + 2 && p < lim;
+        a.has = (hit_run || in_gap) ? 1u : a.has;
+        a.type = hit_run ? (is_last ? (agx_u32)AGX_AT_K2ONLY : (agx_u32)AGX_AT_K1) : (in_gap ? (agx_u32)AGX_AT_CHAIN : a.type);
+        a.q = hit_run ? q : a.q;
+        a.slen = hit_run ? (is_last ? ((L - q) < k ? (L - q) : k) : k) : a.slen;
+        a.has_succ = hit_run ? (is_last ? 0u : 1u) : (in_gap ? 1u : a.has_succ);
+        a.xs = (hit_run && end_of_run && direct) ? nx.t : a.xs;
+        qsucc = hit_run ? (is_last ? AGX_NONE : (end_of_run ? (direct ? nx.q : AGX_NONE) : q + 1)) : (in_gap ? ((X + 1 == nx.t) ? nx.q : AGX_NONE) : qsucc);
         r = nx;
     }
-    return false;
+    const agx_u32 p0 = agx_pos_b(d, runs, a.q), p0s = agx_pos_b(d, runs, qsucc);
+    a.p0 = (a.has && a.type != AGX_AT_CHAIN) ? p0 : AGX_NONE;
+    a.p0s = qsucc != AGX_NONE ? p0s : AGX_NONE;
+    return a;
 }
 
 // oriented base q of a read stored at `p` with length L (reverseComplement, AG:854-865: only ACGT complemented)
@@ -303,8 +306,8 @@ struct agx_pre {
 };
 
 AGX_HD void agx_arrival_fetch(const agx_sweep_args &A, const agx_dhit &d, agx_u32 X, agx_pre &p) {
-    agx_arrival a;
-    p.has = agx_decode_arrival(d, A.runs, X, A.k, a) ? 1u : 0u;
+    const agx_arrival a = agx_decode_arrival(d, A.runs, X, A.k);
+    p.has = a.has;
     p.c0_s = 0; p.c0_n = 0; p.c0 = agx_cmkey{AGX_NONE, AGX_NONE}; p.base = 0; p.s0 = 0; p.s1 = 0; p.type = 0; p.p0 = AGX_NONE;
     if (!p.has) return;
     const bool rev = (d.flags & AGX_HF_AREV) != 0;
@@ -447,9 +450,8 @@ AGX_HD void agx_edge_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
     const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
     for (agx_u32 i = lo; i < hi; i++) {
         const agx_dhit d = get(i);
-        agx_arrival a;
-        if (!live || !agx_decode_arrival(d, A.runs, X, A.k, a) || !a.has_succ) continue;
-        if (a.xs >= A.n_pos) continue;
+        const agx_arrival a = agx_decode_arrival(d, A.runs, X, A.k);
+        if (!live || !a.has || !a.has_succ || a.xs >= A.n_pos) continue;
         if (fast && a.xs == X + 1 && nb_cnt == 1) {
             if (nb_ok < 0) nb_ok = agx_edge_allowed(A, own_start, nb_start) ? 1 : 0;
             if (nb_ok) put_fast(nb_start);
