@@ -6,6 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libagx.so")
+CLI = os.path.join(HERE, "AlignGraph_amd")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HOST_SRC = ["agx_engine.cpp", "agx_host.cpp", "agx_walk.cpp"]
 DEV_SRC = ["agx_kernels.hip"]
@@ -48,6 +49,14 @@ def build(force=False, verbose=False, defines=(), out=None, tag=""):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    # the AlignGraph-compatible command line (rows f1/f3/f4): plain C++ against the C-ABI
+    if out is None:
+        cli_src = os.path.join(CSRC, "agx_cli.cpp")
+        if force or _stale(CLI, [cli_src, lib, os.path.join(HERE, "..", "include", "agx.h")]):
+            cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread", cli_src, "-o", CLI, "-L" + HERE, "-lagx", "-Wl,-rpath,$ORIGIN"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
     return lib
 
 

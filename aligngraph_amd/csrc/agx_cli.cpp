@@ -1,0 +1,502 @@
+// agx_cli.cpp — `AlignGraph_amd`: the reference's command line, tmp/ contract, checkpoint/resume and final outputs around the
+// MI355X engine.
+//
+// Mirrors main() of /root/reference/AlignGraph/AlignGraph.cpp ("AG", lines 4696-4796) stage by stage:
+//   argv -> command.txt -> parameters (getParameters, AG:4329-4646)  ·  formalizeInput / formalizeGenome (AG:3228-3518)
+//   bowtie2 + pblat|blat through system() with the reference's exact command strings, two threads (AG:3581-3735), distributeAlignments
+//   (AG:3545-3579)  ·  tmp/_checkpoint.txt + --resume (AG:4648-4680, 4724-4760)  ·  the unit loop (AG:4765-4783) = libagx, units spread
+//   over the visible GPUs  ·  refinement (AG:2864-3195) -> --extendedContig / --remainingContig (+ in.fa / ex.fa, AG:24 TEST).
+// stdout carries the reference's own progress lines.  Not carried over (they exit with a message): --fastMap (NUCMER + delta2psl,
+// AG:524-729) and --misassemblyRemoval (AG:3821-4297, row f2); `ps euf >> mem.txt` (AG:4778) is not run.
+//
+// Everything here is text plumbing around the path; the compute is agx_run_unit's (include/agx.h).
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+#include <sys/stat.h>
+
+#include "../../include/agx.h"
+
+using std::cout; using std::endl; using std::string; using std::vector;
+
+namespace {
+
+struct Options {
+    string read1, read2, contig, genome, ext, rmn;
+    int tagRead1 = 0, tagRead2 = 0, tagContig = 0, tagGenome = 0, tagExt = 0, tagRmn = 0, tagK = 0, tagLow = 0, tagHigh = 0, tagIV = 0, tagCov = 0, tagPart = 0;
+    int fastMap = 0, ratioCheck = 0, uniqueExtension = 0, iterativeMap = 0, misassemblyRemoval = 0, resume = 0;
+    int k = 5, distanceLow = 0, distanceHigh = 99999, coverage = 20, insertVariation = 50, part = 1;      // defaults of AG:4701
+};
+
+void usage() {   // AG:4304-4327, verbatim program output (user-visible contract)
+    cout << "AlignGraph --read1 reads_1.fa --read2 reads_2.fa --contig contigs.fa --genome genome.fa --distanceLow distanceLow --distanceHigh distancehigh --extendedContig extendedContigs.fa --remainingContig remainingContigs.fa [--kMer k --insertVariation insertVariation --covereage coverage --part p --ratioCheck --iterativeMap --misassemblyRemoval --resume]" << endl;
+    cout << "Inputs:" << endl;
+    cout << "--read1 is the the first pair of PE DNA reads in fasta format" << endl;
+    cout << "--read2 is the the second pair of PE DNA reads in fasta format" << endl;
+    cout << "--contig is the initial contigs in fasta format" << endl;
+    cout << "--genome is the reference genome in fasta format" << endl;
+    cout << "--distanceLow is the lower bound of alignment distance between the first and second pairs of PE DNA reads (recommended: max{insert length - 1000, single read length})" << endl;
+    cout << "--distanceHigh is the upper bound of alignment distance between the first and second pairs of PE DNA reads (recommended: insert length + 1000)" << endl;
+    cout << "Outputs:" << endl;
+    cout << "--extendedContig is the extended contig file in fasta format" << endl;
+    cout << "--remainingContig is the not extended initial contig file in fasta format" << endl;
+    cout << "Options:" << endl;
+    cout << "--kMer is the k-mer size (default: 5)" << endl;
+    cout << "--insertVariation is the small variation of insert length (default: 50)" << endl;
+    cout << "--coverage is the minimum coverage to keep a path in de Bruijn graph (default: 20)" << endl;
+    cout << "--part is the number of parts a chromosome is divided into when it is loaded to reduce memory requirement (default: 1)" << endl;
+    cout << "--fastMap calls NUCMER to make fast but less sensitive and accurate contig alignment instead of BLAT (default: none)" << endl;
+    cout << "--ratioCheck checks read alignment ratio to the reference beforehand and warns if the ratio is too low; may take a little more time (default: none)" << endl;
+    cout << "--iterativeMap aligns reads to one chromosome and then another rather than directly to the genome, which increases sensitivity while loses precision (default: none)" << endl;
+    cout << "--misassemblyRemoval detects and then breaks at or removes misassembed regions (default: none)" << endl;
+    cout << "--resume resumes the previous unfinished running from several checkpoints (default: none)" << endl;
+}
+
+[[noreturn]] void die_usage() { usage(); exit(-1); }
+[[noreturn]] void die(const char *msg) { cout << msg << endl; exit(-1); }
+
+// the reference reads every text file with getline + `if(buf[0]==0) break`
+vector<string> read_lines(const string &path, bool &ok) {
+    vector<string> v; std::ifstream in(path.c_str());
+    ok = in.is_open();
+    if (!ok) return v;
+    string buf;
+    while (in.good()) { std::getline(in, buf); if (buf.empty() || buf[0] == 0) break; v.push_back(buf); }
+    return v;
+}
+
+string itoa(long long n) { std::stringstream ss; ss << n; return ss.str(); }
+
+bool can_read(const string &p) { std::ifstream f(p.c_str()); return f.is_open(); }
+
+// getParameters, AG:4329-4646: one token per line; a flag may appear once; integers must round-trip through atoi
+void parse_params(const string &file, Options &o) {
+    bool ok; vector<string> t = read_lines(file, ok);
+    if (!ok) die("CANNOT OPEN FILE!");
+    const int count = (int)t.size();
+    auto value = [&](int &i, int &tag) -> string { if (tag == 1 || i == count - 1) die_usage(); tag = 1; return t[++i]; };
+    auto integer = [&](int &i, int &tag, int &dst) { const string v = value(i, tag); dst = atoi(v.c_str()); if (itoa(dst) != v) die_usage(); };
+    auto infile = [&](int &i, int &tag, string &dst) { dst = value(i, tag); if (!can_read(dst)) { cout << "CANNOT OPEN FILE!" << endl; die_usage(); } };
+    auto outfile = [&](int &i, int &tag, string &dst) { dst = value(i, tag); std::ofstream f(dst.c_str()); if (!f.is_open()) { cout << "CANNOT OPEN FILE!" << endl; die_usage(); } };
+    auto flag = [&](int &tag) { if (tag == 1) die_usage(); tag = 1; };
+    for (int i = 0; i < count; i++) {
+        const string &b = t[i];
+        if (b == "--read1") infile(i, o.tagRead1, o.read1);
+        else if (b == "--read2") infile(i, o.tagRead2, o.read2);
+        else if (b == "--contig") infile(i, o.tagContig, o.contig);
+        else if (b == "--genome") infile(i, o.tagGenome, o.genome);
+        else if (b == "--distanceLow") integer(i, o.tagLow, o.distanceLow);
+        else if (b == "--distanceHigh") integer(i, o.tagHigh, o.distanceHigh);
+        else if (b == "--extendedContig") outfile(i, o.tagExt, o.ext);          // opening truncates the file right away, like ofstream::open (AG:4477)
+        else if (b == "--remainingContig") outfile(i, o.tagRmn, o.rmn);
+        else if (b == "--kMer") integer(i, o.tagK, o.k);
+        else if (b == "--insertVariation") integer(i, o.tagIV, o.insertVariation);
+        else if (b == "--coverage") integer(i, o.tagCov, o.coverage);
+        else if (b == "--part") integer(i, o.tagPart, o.part);
+        else if (b == "--fastMap") flag(o.fastMap);
+        else if (b == "--ratioCheck") flag(o.ratioCheck);
+        else if (b == "--uniqueExtension") flag(o.uniqueExtension);
+        else if (b == "--iterativeMap") flag(o.iterativeMap);
+        else if (b == "--misassemblyRemoval") flag(o.misassemblyRemoval);
+        else if (b == "--resume") { if (o.resume == 1 || count != 1) die_usage(); o.resume = 1; }
+        else die_usage();
+    }
+}
+
+// maxReadLength, AG:3197-3226
+int max_read_length(const string &path) {
+    bool ok; vector<string> t = read_lines(path, ok);
+    if (!ok) die("CANNOT OPEN FILE!");
+    int mx = 0, len = 0;
+    for (const string &b : t) { if (b[0] == '>') { mx = std::max(mx, len); len = 0; } else len += (int)b.size(); }
+    return std::max(mx, len);
+}
+
+void put60(std::ostream &o, const string &s) {          // 60 columns, newline after the last base; nothing at all for an empty sequence
+    for (size_t i = 0; i < s.size(); i += 60) o << s.substr(i, 60) << '\n';
+}
+
+struct Fasta { vector<string> id, seq; };
+Fasta read_fasta(const string &path) {
+    bool ok; vector<string> t = read_lines(path, ok);
+    if (!ok) die("CANNOT OPEN FILE!");
+    Fasta f;
+    for (const string &b : t) { if (b[0] == '>') { f.id.push_back(b.substr(1)); f.seq.push_back(string()); } else if (!f.seq.empty()) f.seq.back() += b; }
+    return f;
+}
+
+// formalizeInput (contigs), AG:3228-3319: contigs > 200 bp become ">seqID.realID" records (>= 1 Mb: 1 Mb chunks sharing realID), the rest is chaff
+void formalize_contigs(const string &path, vector<string> &contigIds) {
+    const Fasta f = read_fasta(path);
+    std::ofstream out("tmp/_contigs.fa"), chaff("tmp/_chaff.fa");
+    const size_t CHUNK = 1000000;
+    unsigned long seqID = 0, realID = 0;
+    contigIds.clear();
+    for (size_t c = 0; c < f.seq.size(); c++) {
+        const string &s = f.seq[c];
+        if (s.size() > 200) {
+            if (s.size() < CHUNK) { out << ">" << seqID++ << "." << realID << '\n'; put60(out, s); }
+            else {
+                // AG:3279-3292: a new header after every full chunk unless fewer than 61 bases remain; columns restart in each chunk
+                out << ">" << seqID++ << "." << realID << '\n';
+                size_t total = 0;
+                for (size_t p = 0; p < s.size(); p++) {
+                    out << s[p];
+                    if ((p + 1) % CHUNK == 0 && p + 61 < s.size()) { total += CHUNK; out << '\n' << ">" << seqID++ << "." << realID << '\n'; continue; }
+                    if ((p + 1 - total) % 60 == 0 || p == s.size() - 1) out << '\n';
+                }
+            }
+            realID++;
+            contigIds.push_back(f.id[c]);
+        } else { chaff << ">" << f.id[c] << '\n'; put60(chaff, s); }
+    }
+}
+
+// formalizeGenome, AG:3347-3418: one unit per (chromosome, part); part boundaries at multiples of size/p
+int formalize_genome(const string &path, int p, vector<string> &genomeIds) {
+    const Fasta f = read_fasta(path);
+    for (const string &id : f.id) genomeIds.push_back(id);                       // NOT cleared: a --resume run appends again, like the reference (AG:3367)
+    std::ofstream all("tmp/_genome.fa");
+    int unit = 0;
+    for (size_t g = 0; g < f.seq.size(); g++) {
+        const string &s = f.seq[g];
+        std::ofstream out(("tmp/_genome." + itoa(unit) + ".fa").c_str());
+        out << ">0" << '\n'; all << ">" << unit << '\n';
+        const size_t step = s.size() / (size_t)p;
+        int q = 1;
+        for (size_t c = 0; c < s.size(); c++) {
+            out << s[c]; all << s[c];
+            const bool cut = step != 0 && (c + 1) % step == 0 && q < p;
+            if ((c + 1) % 60 == 0 || c == s.size() - 1 || cut) { out << '\n'; all << '\n'; }
+            if (c != s.size() - 1 && cut) {
+                out.close(); unit++; q++;
+                out.open(("tmp/_genome." + itoa(unit) + ".fa").c_str());
+                out << ">0" << '\n'; all << ">" << unit << '\n';
+            }
+        }
+        out.close(); unit++;
+    }
+    return unit;
+}
+
+// formalizeInput (reads), AG:3420-3518: pairs renamed 0..N-1, mates cut to the shorter of the two
+int formalize_reads(const string &p1, const string &p2) {
+    std::ifstream in1(p1.c_str()), in2(p2.c_str());
+    if (!in1.is_open() || !in2.is_open()) die("CANNOT OPEN FILE!");
+    std::ofstream out("tmp/_reads.fa"), out1("tmp/_reads_1.fa"), out2("tmp/_reads_2.fa");
+    string b1, b2, r1, r2; unsigned long id = 0;
+    auto flush = [&]() {
+        if (r1.empty() || r2.empty()) return;
+        const size_t n = std::min(r1.size(), r2.size());
+        out << ">" << id << '\n' << r1.substr(0, n) << '\n' << ">" << id << '\n' << r2.substr(0, n) << '\n';
+        out1 << ">" << id << '\n' << r1.substr(0, n) << '\n';
+        out2 << ">" << id << '\n' << r2.substr(0, n) << '\n';
+        id++;
+    };
+    while (in1.good() && in2.good()) {
+        std::getline(in1, b1); std::getline(in2, b2);
+        const bool e1 = b1.empty() || b1[0] == 0, e2 = b2.empty() || b2[0] == 0;
+        if (e1 && e2) break;
+        if (e1 != e2) die("INCONSISTENT PE FILES!");
+        if (b1[0] == '>' && b2[0] == '>') { flush(); r1.clear(); r2.clear(); }
+        else if (b1[0] != '>' && b2[0] != '>') { r1 += b1; r2 += b2; }
+        else die("INCONSISTENT PE FILES!");
+    }
+    flush();
+    return (int)id;
+}
+
+// distributeAlignments, AG:3545-3579 with parseBT, AG:3520-3543: a SAM line goes to the unit its RNAME (atoi of <=9 chars) names; '@' lines
+// are dropped; an empty line ends the scan
+void distribute_alignments(int units) {
+    bool ok; (void)ok;
+    std::ifstream in("tmp/_reads_genome.bowtie");
+    if (!in.is_open()) die("CANNOT OPEN FILE!");
+    vector<std::ofstream *> out;
+    for (int u = 0; u < units; u++) out.push_back(new std::ofstream(("tmp/_reads_genome." + itoa(u) + ".bowtie").c_str()));
+    string buf;
+    while (in.good()) {
+        std::getline(in, buf);
+        if (!buf.empty() && buf[0] == '@') continue;
+        if (buf.empty() || buf[0] == 0) break;
+        // parseBT: third tab-separated field; any '*' in it means unaligned; a missing field reads as "" -> unit 0 (atoi)
+        string rname; size_t a = buf.find('\t');
+        if (a != string::npos) { a = buf.find('\t', a + 1); if (a != string::npos) { const size_t b = buf.find('\t', a + 1); rname = buf.substr(a + 1, b == string::npos ? string::npos : b - a - 1); } }
+        if (rname.find('*') != string::npos) continue;
+        const int u = atoi(rname.substr(0, 9).c_str());
+        if (u >= 0 && u < units) *out[u] << buf << '\n';
+    }
+    for (auto *o : out) { o->close(); delete o; }
+}
+
+int run(const string &cmd) { return system(cmd.c_str()); }
+
+// task0 / task1 of parallelMap, AG:3581-3735: the two aligners run side by side, command strings unchanged
+void align_everything(const Options &o, int units) {
+    std::thread reads([&]() {
+        const string lo = itoa(o.distanceLow), hi = itoa(o.distanceHigh);
+        const string opts = "bowtie2 -f --no-mixed -k 5 -p 8 --local --mp 3,1 --rdg 2,1 --rfg 2,1 --score-min G,5,2 -I " + lo + " -X " + hi + " --no-discordant -x ";
+        if (o.iterativeMap == 1) {
+            for (int u = 0; u < units; u++) {
+                run("bowtie2-build -f tmp/_genome." + itoa(u) + ".fa tmp/_genome." + itoa(u) + " > bowtie_doc.txt 2> bowtie_doc.txt");
+                run(opts + "tmp/_genome." + itoa(u) + " -1 tmp/_reads_1.fa -2 tmp/_reads_2.fa --reorder > tmp/_reads_genome." + itoa(u) + ".bowtie 2> bowtie_doc.txt");
+            }
+        } else {
+            run("bowtie2-build -f tmp/_genome.fa tmp/_genome > bowtie_doc.txt 2> bowtie_doc.txt");
+            run(opts + "tmp/_genome -1 tmp/_reads_1.fa -2 tmp/_reads_2.fa --reorder > tmp/_reads_genome.bowtie 2> bowtie_doc.txt");
+            distribute_alignments(units);
+        }
+    });
+    std::thread contigs([&]() {
+        for (int u = 0; u < units; u++) {
+            const string io = "tmp/_genome." + itoa(u) + ".fa tmp/_contigs.fa -noHead tmp/_contigs_genome." + itoa(u) + ".psl -fastMap";
+            if (run("pblat " + io + " -threads=8 > blat_doc.txt 2> blat_doc.txt") != 0)
+                if (run("blat " + io + " > blat_doc.txt 2> blat_doc.txt") != 0) die("BLAT CALL FAILED!");
+        }
+    });
+    reads.join(); contigs.join();
+}
+
+// the SAM fields checkRatio looks at (parseBOWTIE, AG:181-285) and its identity filter (AG:3790)
+bool sam_pair_passes(const string &l1, const string &l2, unsigned &id) {
+    auto parse = [](const string &l, unsigned &qid, bool &aligned, unsigned &total, unsigned &ins, unsigned &del, unsigned &cl, unsigned &cr) {
+        vector<string> f; size_t a = 0;
+        for (int i = 0; i < 6; i++) { size_t b = l.find('\t', a); f.push_back(l.substr(a, b == string::npos ? string::npos : b - a)); if (b == string::npos) break; a = b + 1; }
+        f.resize(6);
+        qid = (unsigned)atoi(f[0].c_str()); aligned = !(f[2].size() && f[2][0] == '*');
+        total = ins = del = cl = cr = 0; bool first = true; unsigned num = 0;
+        for (char c : f[5]) {
+            if (c >= '0' && c <= '9') { num = num * 10 + (unsigned)(c - '0'); continue; }
+            if (c == 'I') { ins += num; total += num; } else if (c == 'D') del += num; else if (c == 'M') { total += num; first = false; }
+            else if (c == 'S' && first) { cl = num; total += num; first = false; } else if (c == 'S') { cr = num; total += num; }
+            else if (c != '*') { cout << "unknown character: " << c << endl; exit(-1); }
+            num = 0;
+        }
+    };
+    unsigned id2, t1, i1, d1, l1c, r1c, t2, i2, d2, l2c, r2c; bool a1, a2;
+    parse(l1, id, a1, t1, i1, d1, l1c, r1c); parse(l2, id2, a2, t2, i2, d2, l2c, r2c);
+    auto ok = [](unsigned total, unsigned ins, unsigned del, unsigned cl, unsigned cr) {
+        const unsigned sEnd = total - cr, tLen = total + del - ins;
+        return (double)(unsigned)(sEnd - cl - ins) / total >= 0.6 && (double)(unsigned)(tLen - del) / tLen >= 0.6;
+    };
+    return a1 && a2 && ok(t1, i1, d1, l1c, r1c) && ok(t2, i2, d2, l2c, r2c);
+}
+
+// checkRatio, AG:3751-3819.  The reference re-opens one ifstream without closing it, so only unit 0's alignments are ever read (AG:3779-3783).
+void check_ratio(int units) {
+    bool ok; vector<string> r = read_lines("tmp/_reads_1.fa", ok);
+    if (!ok) die("CANNOT OPEN FILE!");
+    // NB the reference counts '>' lines with `while(good) getline` WITHOUT the empty-line break, but a reads file has no empty lines
+    size_t n = 0; for (const string &b : r) n += b[0] == '>';
+    vector<int> reads(n, 0);
+    if (units > 0) {
+        vector<string> t = read_lines("tmp/_reads_genome.0.bowtie", ok);
+        if (!ok) die("CANNOT OPEN FILE!");
+        for (size_t i = 0; i < t.size(); i++) {
+            if (t[i][0] == '@') continue;
+            if (i + 1 >= t.size()) die("BROKEN BOWTIE FILE");
+            unsigned id; const bool pass = sam_pair_passes(t[i], t[i + 1], id); i++;
+            if (pass && id < reads.size()) reads[id] = 1;
+        }
+    }
+    size_t aligned = 0; for (int v : reads) aligned += v == 1;
+    const double ratio = aligned == 0 ? 0 : (double)aligned / reads.size();
+    cout << " - " << ratio * 100 << "% reads aligned ";
+    if (ratio < 0.25) cout << "(warning: ratio below 25%; hard to guarantee good results)" << endl; else cout << endl;
+}
+
+// ---- refinement, AG:2864-3195 -------------------------------------------------------------------------------------------------
+struct PslHit { unsigned tID, tStart, tEnd, tGap, sID, sStart, sEnd, sGap, sSize, tSize, realSourceSize; };
+PslHit parse_psl(const string &l) {   // parseBLAT, AG:406-522 (the columns refinement uses)
+    vector<string> f; size_t a = 0;
+    for (;;) { size_t b = l.find('\t', a); f.push_back(l.substr(a, b == string::npos ? string::npos : b - a)); if (b == string::npos) break; a = b + 1; }
+    f.resize(21);
+    auto U = [&](int i) { return (unsigned)atoi(f[i].c_str()); };
+    PslHit h; h.tID = U(13); h.tStart = U(15); h.tEnd = U(16); h.tGap = U(7); h.sStart = U(11); h.sEnd = U(12); h.sGap = U(5); h.sSize = U(10); h.tSize = U(14);
+    const string q = f[9].substr(0, 100);                                   // 100-byte field buffer of the reference
+    const size_t dot = q.find('.');
+    if (dot != string::npos) { h.sID = (unsigned)atoi(q.substr(0, dot).c_str()); h.realSourceSize = (unsigned)atoi(q.substr(dot + 1).c_str()); }
+    else { h.sID = (unsigned)atoi(q.c_str()); h.realSourceSize = h.sSize; }
+    return h;
+}
+
+void refinement(const Options &o, int units, const vector<string> &genomeIds, const vector<string> &contigIds) {
+    std::ofstream ini("in.fa"), ext("ex.fa");                                // the reference is built with TEST defined (AG:24)
+    const size_t SMALL = 20000;
+    for (int u = 0; u < units; u++) {                                         // first 20 kb of every initial contig, AG:2891-2953
+        const Fasta f = read_fasta("tmp/_initial_contigs." + itoa(u) + ".fa");
+        std::ofstream out(("tmp/_short_initial_contigs." + itoa(u) + ".fa").c_str());
+        for (size_t j = 0; j < f.seq.size(); j++) {
+            const int num = atoi(f.id[j].c_str());
+            if (f.seq[j].size() > SMALL) { out << ">" << num << "." << f.seq[j].size() << '\n'; put60(out, f.seq[j].substr(0, SMALL)); }
+            else { out << ">" << num << '\n'; put60(out, f.seq[j]); }
+        }
+    }
+    for (int u = 0; u < units; u++) {                                         // AG:2974-2982
+        const string io = "tmp/_extended_contigs." + itoa(u) + ".fa tmp/_short_initial_contigs." + itoa(u) + ".fa -noHead tmp/_short_initial_contigs_extended_contigs." + itoa(u) + ".psl -fastMap";
+        if (run("pblat " + io + " -threads=8 > blat_doc.txt 2> blat_doc.txt") != 0)
+            if (run("blat " + io + " > blat_doc.txt 2> blat_doc.txt") != 0) die("BLAT CALL FAILED!");
+    }
+    // initial contigs by realID (runs of equal id after the '.'), AG:2985-3014
+    vector<string> init; vector<int> initTags;
+    {
+        bool ok; vector<string> t = read_lines("tmp/_contigs.fa", ok);
+        if (!ok) { cout << "CANNOT OPEN FILE!" << endl; return; }
+        int idBak = -1;
+        for (const string &b : t) {
+            if (b[0] == '>') { const size_t d = b.find('.'); const int id = atoi(d == string::npos ? "" : b.substr(d + 1).c_str()); if (id != idBak) { init.push_back(string()); initTags.push_back(0); idBak = id; } }
+            else if (!init.empty()) init.back() += b;
+        }
+    }
+    std::ofstream e(o.ext.c_str(), std::ios::app), r(o.rmn.c_str(), std::ios::app);   // both were truncated when the parameters were read
+    vector<vector<int> > extdInitMap;                                         // grows by every unit's records and is never cleared (AG:3035): part of the output
+    int seqID = 0;
+    for (int u = 0; u < units; u++) {
+        const Fasta x = read_fasta("tmp/_extended_contigs." + itoa(u) + ".fa");
+        vector<int> extdTags(x.seq.size(), 0);
+        for (size_t j = 0; j < x.seq.size(); j++) extdInitMap.push_back(vector<int>());
+        bool ok; vector<string> psl = read_lines("tmp/_short_initial_contigs_extended_contigs." + itoa(u) + ".psl", ok);
+        if (!ok) { cout << "CANNOT OPEN FILE!" << endl; return; }
+        int targetIDBak = -1;
+        for (const string &line : psl) {
+            const PslHit h = parse_psl(line);
+            if (!((double)(unsigned)(h.sEnd - h.sStart - h.sGap) / h.sSize >= 0.8 && (double)(unsigned)(h.tEnd - h.tStart - h.tGap) / (double)(unsigned)(h.tEnd - h.tStart) >= 0.8 &&
+                  h.tSize > h.realSourceSize + 100 && h.realSourceSize > h.tSize / 100)) continue;
+            if (h.tID >= extdTags.size() || h.sID >= initTags.size() || h.tID >= extdInitMap.size()) continue;   // the reference would write out of bounds
+            if (o.uniqueExtension == 1) {                                     // AG:3061-3081
+                if (initTags[h.sID] > 0 && targetIDBak != -1) {
+                    if (extdTags[targetIDBak] < extdTags[h.tID]) {
+                        extdTags[targetIDBak] = 0; if (!extdInitMap[targetIDBak].empty()) extdInitMap[targetIDBak].pop_back();
+                        extdTags[h.tID] = (int)h.tSize; initTags[h.sID] = 1; extdInitMap[h.tID].push_back((int)h.sID);
+                    }
+                } else { extdTags[h.tID] = (int)h.tSize; initTags[h.sID] = 1; extdInitMap[h.tID].push_back((int)h.sID); }
+                targetIDBak = (int)h.tID;
+            } else { extdTags[h.tID] = 1; initTags[h.sID] = 1; extdInitMap[h.tID].push_back((int)h.sID); }
+        }
+        for (size_t j = 0; j < extdTags.size(); j++) {
+            if (extdTags[j] <= 0) continue;
+            // genomeIds is indexed by UNIT in the reference (AG:3102); with --part > 1 that runs past its end (undefined there): empty here
+            e << ">" << "AlignGraph" << seqID << " @ " << ((size_t)u < genomeIds.size() ? genomeIds[u] : string()) << " : ";
+            for (int s : extdInitMap[j]) e << ((size_t)s < contigIds.size() ? contigIds[s] : string()) << " ; ";
+            e << '\n';
+            ext << ">" << u << ": " << seqID << '\n';
+            seqID++;
+            put60(e, x.seq[j]); put60(ext, x.seq[j]);
+        }
+    }
+    for (size_t i = 0; i < initTags.size(); i++)
+        if (initTags[i] == 0) { r << ">" << (i < contigIds.size() ? contigIds[i] : string()) << '\n'; put60(r, init[i]); }
+    {
+        bool ok; vector<string> chaff = read_lines("tmp/_chaff.fa", ok);
+        if (!ok) { cout << "CANNOT OPEN FILE!" << endl; return; }
+        for (const string &b : chaff) r << b << '\n';
+    }
+    for (size_t i = 0; i < initTags.size(); i++) if (initTags[i] == 1) { ini << ">" << i << '\n'; put60(ini, init[i]); }
+}
+
+// ---- the unit loop on the GPUs --------------------------------------------------------------------------------------------------
+// Units are independent (AG:4779-4781 clears all state between them): a work queue feeds one host thread per device slot; progress
+// lines and checkpoints are emitted in unit order, as the sequential reference would.
+void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
+    const int ndev_all = agx_device_count();
+    if (ndev_all <= 0) die("NO HIP DEVICE: AlignGraph_amd needs a GPU (there is no CPU path)");
+    int ndev = ndev_all;
+    if (const char *e = getenv("AGX_DEVICES")) ndev = std::max(1, std::min(ndev_all, atoi(e)));
+    const int per_dev = std::max(1, getenv("AGX_UNITS_PER_DEVICE") ? atoi(getenv("AGX_UNITS_PER_DEVICE")) : 2);   // >1: one unit's host walk overlaps another's kernels
+    std::atomic<int> next(first);
+    vector<int> state(units, 0); vector<string> errors(units);
+    std::mutex mu; int reported = first;
+    auto report = [&]() {                                                     // under mu: flush finished units in order
+        while (reported < units && state[reported] != 0) {
+            cout << endl << "CHROMOSOME " << reported << ": " << endl;
+            if (state[reported] < 0) { cout << errors[reported] << endl; exit(-1); }
+            cout << "(1) Chromosome loaded" << endl << "(2) Contig alignment loaded" << endl << "(3) Read alignment loaded" << endl
+                 << "(4) Contigs extended" << endl << "(5) Contigs scaffolded" << endl;
+            wcp << itoa(reported + 1) << endl;                                // setCheckpoint, AG:4782
+            reported++;
+        }
+    };
+    vector<std::thread> workers;
+    for (int d = 0; d < ndev; d++) for (int s = 0; s < per_dev; s++)
+        workers.emplace_back([&, d]() {
+            for (;;) {
+                const int u = next.fetch_add(1);
+                if (u >= units) return;
+                agx_params p = {(uint32_t)o.k, (uint32_t)o.insertVariation, (uint32_t)o.coverage, 0, d, 0};
+                agx_result r; char err[512];
+                const int rc = agx_run_unit(&p, "tmp", u, 1, &r, err, sizeof err);
+                if (rc == AGX_OK) agx_result_free(&r);
+                std::lock_guard<std::mutex> g(mu);
+                if (rc != AGX_OK) { string m = err; const size_t cut = m.find(" ("); errors[u] = cut == string::npos ? m : m.substr(0, cut); state[u] = -1; }
+                else state[u] = 1;
+                report();
+            }
+        });
+    for (auto &t : workers) t.join();
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    cout << "AlignGraph: algorithm for secondary de novo genome assembly guided by closely related references" << endl;
+    cout << "By Ergude Bao, CS Department, UC-Riverside. All Rights Reserved" << endl << endl;
+    const time_t start = time(NULL);
+    {
+        std::ofstream wcmd("command.txt");
+        if (!wcmd.is_open()) { cout << "CANNOT OPEN FILE!" << endl; return 0; }
+        for (int i = 1; i < argc; i++) wcmd << argv[i] << endl;
+    }
+    Options o; parse_params("command.txt", o);
+    vector<string> genomeIds, contigIds;
+    int units = 0, cp = 0; time_t startAlign, endAlign; std::ofstream wcp;
+    if (o.resume == 0) {
+        if (o.tagRead1 == 0 || o.tagRead2 == 0 || o.tagContig == 0 || o.tagGenome == 0 || o.tagExt == 0 || o.tagRmn == 0 || o.k <= 0 || o.tagLow == 0 || o.tagHigh == 0 ||
+            o.distanceLow > o.distanceHigh || o.distanceLow < 0 || o.insertVariation < 0 || o.part < 1 || o.part > 10 || o.k > max_read_length(o.read1) || o.k > max_read_length(o.read2)) {
+            usage(); return 0;                                                // AG:4726-4730 (exit status 0)
+        }
+        if (o.fastMap) die("--fastMap (NUCMER + delta2psl) is not supported by AlignGraph_amd");
+        if (o.misassemblyRemoval) die("--misassemblyRemoval is not supported by AlignGraph_amd");
+        if (run("bowtie2 -h > bowtie_doc.txt 2> bowtie_doc.txt") != 0) die("BOWTIE2 CALL FAILED!");   // testAligners, AG:4682-4694
+        mkdir("tmp", 0777);
+        { std::ofstream wcmd("tmp/_command.txt"); for (int i = 1; i < argc; i++) wcmd << argv[i] << endl; }
+        wcp.open("tmp/_checkpoint.txt");
+        formalize_reads(o.read1, o.read2);
+        formalize_contigs(o.contig, contigIds);
+        units = formalize_genome(o.genome, o.part, genomeIds);
+        startAlign = time(NULL);
+        align_everything(o, units);
+        endAlign = time(NULL);
+        cout << "(0) Alignment finished" << endl;
+        wcp << "0" << endl;
+    } else {
+        bool ok; vector<string> c = read_lines("tmp/_checkpoint.txt", ok);
+        if (!ok) die("CANNOT OPEN FILE!");
+        cp = -1; for (const string &s : c) cp = atoi(s.c_str());
+        if (cp == -1) die("NOT REACHED CHECKPOINT. PLEASE RERUN!");
+        o = Options(); parse_params("tmp/_command.txt", o);                   // AG:4752-4753 (the tags start from the --resume parse in the reference; only resume itself carries over)
+        o.resume = 1;
+        if (o.fastMap) die("--fastMap (NUCMER + delta2psl) is not supported by AlignGraph_amd");
+        if (o.misassemblyRemoval) die("--misassemblyRemoval is not supported by AlignGraph_amd");
+        cout << "RESUMED SUCCESSFULLY :-)" << endl;
+        wcp.open("tmp/_checkpoint.txt", std::ios::app);
+        formalize_contigs(o.contig, contigIds);
+        units = formalize_genome(o.genome, o.part, genomeIds);
+        startAlign = endAlign = time(NULL);
+    }
+    if (o.ratioCheck == 1) check_ratio(units);
+    if (cp < units) run_units(o, cp, units, wcp);
+    refinement(o, units, genomeIds, contigIds);
+    const time_t end = time(NULL);
+    cout << endl << "FINISHED SUCCESSFULLY for " << end - start << " seconds (" << endAlign - startAlign << " seconds for alignment) :-)" << endl;
+    return 0;
+}

@@ -83,6 +83,7 @@ struct Params {
     double mate1_left = 0.5;
     int sam_seq = 1;  // write SEQ/QUAL columns like bowtie2 does
     int shuffle_units = 1;
+    int e2e = 0;       // also write the user-level inputs of a fresh run: reads_1.fa, reads_2.fa and stub/ (what the aligner stubs replay)
 };
 
 void die(const char *m) { std::fprintf(stderr, "agx_synth: %s\n", m); std::exit(2); }
@@ -116,7 +117,7 @@ Params parse_args(int argc, char **argv) {
         OPT_D("--read-err", read_err) OPT_D("--read-indel", read_indel) OPT_D("--read-clip", read_clip)
         OPT_D("--read-badclip", read_badclip) OPT_D("--read-n", read_n)
         OPT_D("--multi", multi) OPT_D("--multi-near", multi_near) OPT_D("--unaligned", unaligned)
-        OPT_D("--mate1-left", mate1_left) OPT_I("--sam-seq", sam_seq) OPT_I("--shuffle-units", shuffle_units)
+        OPT_D("--mate1-left", mate1_left) OPT_I("--sam-seq", sam_seq) OPT_I("--shuffle-units", shuffle_units) OPT_I("--e2e", e2e)
         if (a == "--chroms") { P.chroms = parse_list(v); continue; }
         std::fprintf(stderr, "agx_synth: unknown option %s\n", a.c_str()); std::exit(2);
     }
@@ -368,6 +369,15 @@ int main(int argc, char **argv) {
             }
             (void)prev_e;
             std::fclose(psl);
+            if (P.e2e) {           // what the pblat/blat stub replays for this unit
+                mkdirs(P.out + "/stub");
+                std::string a = path("tmp/_contigs_genome." + std::to_string(u) + ".psl"), b = path("stub/_contigs_genome." + std::to_string(u) + ".psl");
+                FILE *fi = std::fopen(a.c_str(), "rb"), *fo = std::fopen(b.c_str(), "wb");
+                if (!fi || !fo) die("cannot copy psl");
+                char buf[65536]; size_t n;
+                while ((n = std::fread(buf, 1, sizeof buf, fi)) > 0) std::fwrite(buf, 1, n, fo);
+                std::fclose(fi); std::fclose(fo);
+            }
         }
         std::fclose(cf); std::fclose(tc); std::fclose(chaff);
     }
@@ -386,6 +396,14 @@ int main(int argc, char **argv) {
             if (P.shuffle_units) for (int64_t j = N - 1; j > 0; j--) std::swap(unit_of[j], unit_of[R.below(j + 1)]);
         }
         FILE *rf = open("tmp/_reads.fa");
+        FILE *u1 = nullptr, *u2 = nullptr, *gsam = nullptr;
+        if (P.e2e) {
+            mkdirs(P.out + "/stub");
+            u1 = open("reads_1.fa"); u2 = open("reads_2.fa"); gsam = open("stub/reads_genome.sam");
+            std::fputs("@HD\tVN:1.0\tSO:unsorted\n", gsam);
+            for (int u = 0; u < NU; u++) std::fprintf(gsam, "@SQ\tSN:%d\tLN:%lld\n", u, (long long)unit_len[u]);
+            std::fputs("@PG\tID:bowtie2\tPN:bowtie2\tVN:stub\n", gsam);
+        }
         std::vector<FILE *> sam(NU);
         for (int u = 0; u < NU; u++) sam[u] = open("tmp/_reads_genome." + std::to_string(u) + ".bowtie");
         const int L = P.L;
@@ -404,14 +422,20 @@ int main(int argc, char **argv) {
             std::string left_file = left.seq_fwd, right_file = revcomp(right.seq_fwd);
             const std::string &m1 = m1_left ? left_file : right_file, &m2 = m1_left ? right_file : left_file;
             std::fprintf(rf, ">%lld\n%s\n>%lld\n%s\n", (long long)id, m1.c_str(), (long long)id, m2.c_str());
-            if (R.coin(P.unaligned)) continue;
+            if (P.e2e) { std::fprintf(u1, ">frag%lld/1 synthetic\n%s\n", (long long)id, m1.c_str()); std::fprintf(u2, ">frag%lld/2 synthetic\n%s\n", (long long)id, m2.c_str()); }
+            auto unaligned_pair = [&]() {
+                if (!P.e2e) return;
+                std::fprintf(gsam, "%lld\t77\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\tYT:Z:UP\n%lld\t141\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\tYT:Z:UP\n",
+                             (long long)id, m1.c_str(), qual.c_str(), (long long)id, m2.c_str(), qual.c_str());
+            };
+            if (R.coin(P.unaligned)) { unaligned_pair(); continue; }
 
             int clipLl = 0, clipLr = 0, clipRl = 0, clipRr = 0;
             if (R.coin(P.read_clip)) { (R.coin(0.5) ? clipLl : clipLr) = (int)R.range(1, 15); }
             if (R.coin(P.read_clip)) { (R.coin(0.5) ? clipRl : clipRr) = (int)R.range(1, 15); }
             if (R.coin(P.read_badclip)) { (R.coin(0.5) ? clipLr : clipRl) = (int)R.range(L * 45 / 100, L * 55 / 100); }
             Aln al, ar;
-            if (!make_aln(left.r, clipLl, clipLr, al) || !make_aln(right.r, clipRl, clipRr, ar)) continue;
+            if (!make_aln(left.r, clipLl, clipLr, al) || !make_aln(right.r, clipRl, clipRr, ar)) { unaligned_pair(); continue; }
 
             auto emit = [&](bool secondary, const Aln &aL, const Aln &aR) {
                 // mate1 first, then mate2 — bowtie2 prints the pair in that order
@@ -421,13 +445,16 @@ int main(int argc, char **argv) {
                     const Aln &A = is_left ? aL : aR, &B = is_left ? aR : aL;
                     const std::string &seq = is_left ? left.seq_fwd : right.seq_fwd;
                     long long tlen = is_left ? (long long)(aR.pos1 + L - aL.pos1) : -(long long)(aR.pos1 + L - aL.pos1);
-                    if (P.sam_seq)
-                        std::fprintf(sam[u], "%lld\t%d\t%d\t%lld\t42\t%s\t=\t%lld\t%lld\t%s\t%s\tAS:i:%d\tYS:i:%d\tYT:Z:CP\n",
-                                     (long long)id, flag, u, (long long)A.pos1, A.cigar.c_str(), (long long)B.pos1, tlen,
-                                     seq.c_str(), qual.c_str(), 2 * L - 6, 2 * L - 4);
-                    else
-                        std::fprintf(sam[u], "%lld\t%d\t%d\t%lld\t42\t%s\t=\t%lld\t%lld\t*\t*\n",
-                                     (long long)id, flag, u, (long long)A.pos1, A.cigar.c_str(), (long long)B.pos1, tlen);
+                    for (FILE *dst : {sam[u], gsam}) {
+                        if (!dst) continue;
+                        if (P.sam_seq)
+                            std::fprintf(dst, "%lld\t%d\t%d\t%lld\t42\t%s\t=\t%lld\t%lld\t%s\t%s\tAS:i:%d\tYS:i:%d\tYT:Z:CP\n",
+                                         (long long)id, flag, u, (long long)A.pos1, A.cigar.c_str(), (long long)B.pos1, tlen,
+                                         seq.c_str(), qual.c_str(), 2 * L - 6, 2 * L - 4);
+                        else
+                            std::fprintf(dst, "%lld\t%d\t%d\t%lld\t42\t%s\t=\t%lld\t%lld\t*\t*\n",
+                                         (long long)id, flag, u, (long long)A.pos1, A.cigar.c_str(), (long long)B.pos1, tlen);
+                    }
                 }
             };
             emit(false, al, ar);
@@ -446,6 +473,7 @@ int main(int argc, char **argv) {
             }
         }
         std::fclose(rf);
+        if (P.e2e) { std::fclose(u1); std::fclose(u2); std::fclose(gsam); }
         for (auto f : sam) std::fclose(f);
     }
 
@@ -457,8 +485,10 @@ int main(int argc, char **argv) {
                         "--kMer\n%d\n--coverage\n%d\n--insertVariation\n%d\n--part\n%d\n", P.k, P.coverage, P.insert_variation, P.part);
         std::fclose(c);
         FILE *cp = open("tmp/_checkpoint.txt"); std::fputs("0\n", cp); std::fclose(cp);
-        FILE *r1 = open("reads_1.fa"); std::fclose(r1);   // --resume re-opens but never reads them
-        FILE *r2 = open("reads_2.fa"); std::fclose(r2);
+        if (!P.e2e) {
+            FILE *r1 = open("reads_1.fa"); std::fclose(r1);   // --resume re-opens but never reads them
+            FILE *r2 = open("reads_2.fa"); std::fclose(r2);
+        }
         FILE *m = open("synth_meta.txt");
         std::fprintf(m, "units %d\npairs %lld\nL %d\nk %d\ncoverage %d\ninsert_variation %d\nseed %llu\n", NU, (long long)P.pairs, P.L, P.k,
                      P.coverage, P.insert_variation, (unsigned long long)P.seed);
