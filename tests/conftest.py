@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-GOLDEN_CASES = sorted(f[:-7] for f in os.listdir(GOLDEN) if f.endswith(".tar.gz"))
+GOLDEN_CASES = sorted(f[:-7] for f in os.listdir(GOLDEN) if f.endswith(".tar.gz") and f != "e2e.tar.gz")   # e2e: whole-run fixture of tests/test_cli.py
 
 
 def pytest_configure(config):
