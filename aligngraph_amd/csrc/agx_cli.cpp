@@ -6,8 +6,8 @@
 //   bowtie2 + pblat|blat through system() with the reference's exact command strings, two threads (AG:3581-3735), distributeAlignments
 //   (AG:3545-3579)  ·  tmp/_checkpoint.txt + --resume (AG:4648-4680, 4724-4760)  ·  the unit loop (AG:4765-4783) = libagx, units spread
 //   over the visible GPUs  ·  refinement (AG:2864-3195) -> --extendedContig / --remainingContig (+ in.fa / ex.fa, AG:24 TEST).
-// stdout carries the reference's own progress lines.  Not carried over (they exit with a message): --fastMap (NUCMER + delta2psl,
-// AG:524-729) and --misassemblyRemoval (AG:3821-4297, row f2); `ps euf >> mem.txt` (AG:4778) is not run.
+// misassembly removal (AG:3821-4297, row f2).  stdout carries the reference's own progress lines.  Not carried over: --fastMap
+// (NUCMER + delta2psl, AG:524-729) exits with a message; `ps euf >> mem.txt` (AG:4778) is not run.
 //
 // Everything here is text plumbing around the path; the compute is agx_run_unit's (include/agx.h).
 #include <algorithm>
@@ -136,9 +136,10 @@ Fasta read_fasta(const string &path) {
 }
 
 // formalizeInput (contigs), AG:3228-3319: contigs > 200 bp become ">seqID.realID" records (>= 1 Mb: 1 Mb chunks sharing realID), the rest is chaff
-void formalize_contigs(const string &path, vector<string> &contigIds) {
+void formalize_contigs(const string &path, vector<string> &contigIds, const string &dest = "tmp/_contigs.fa") {
     const Fasta f = read_fasta(path);
-    std::ofstream out("tmp/_contigs.fa"), chaff("tmp/_chaff.fa");
+    std::ofstream out(dest.c_str()), chaff;
+    if (dest == "tmp/_contigs.fa") chaff.open("tmp/_chaff.fa");            // only the initial contigs keep their chaff (AG:3242); elsewhere short records vanish
     const size_t CHUNK = 1000000;
     unsigned long seqID = 0, realID = 0;
     contigIds.clear();
@@ -404,6 +405,175 @@ void refinement(const Options &o, int units, const vector<string> &genomeIds, co
     for (size_t i = 0; i < initTags.size(); i++) if (initTags[i] == 1) { ini << ">" << i << '\n'; put60(ini, init[i]); }
 }
 
+// ---- misassembly removal, AG:3821-4297 (row f2) ------------------------------------------------------------------------------------
+// Per-base read coverage on the output contigs + contig-to-genome alignment blocks -> unaligned, thinly covered stretches are cut
+// out and contigs are split there.  Integer / ratio rules are kept literally, including the order-dependent clean-up passes.
+struct CBase { char base; int cov; };
+struct CPos { int tID; unsigned sStart, sEnd, tStart, tEnd; int fr; };
+const CPos CP_NONE = {-1, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, -1};
+
+inline int masb_conflict(unsigned x1, unsigned y1, unsigned x2, unsigned y2) {      // AG:3986-3993
+    return (x1 <= x2 && x2 <= y1 && y1 <= y2 && (int)y1 - (int)x2 >= 100) || (x2 <= x1 && x1 <= y2 && y2 <= y1 && (int)y2 - (int)x1 >= 100) ||
+           (x1 <= x2 && x2 <= y2 && y2 <= y1 && (int)y2 - (int)x2 >= 100) || (x2 <= x1 && x1 <= y1 && y1 <= y2 && (int)y1 - (int)x1 >= 100) ||
+           (x1 <= x2 && y2 <= y1) || (x2 <= x1 && y1 <= y2);
+}
+inline int masb_close(unsigned y1, unsigned x2, unsigned threshold) { return (unsigned)abs((int)x2 - (int)y1) < threshold; }   // AG:3995-4001 (int vs unsigned compare)
+inline int masb_overlap(unsigned x1, unsigned y1, unsigned x2, unsigned y2) {       // AG:2388-2394
+    return (x1 <= x2 && x2 <= y1 && y1 <= y2 && (int)y1 - (int)x2 > 0) || (x2 <= x1 && x1 <= y2 && y2 <= y1 && (int)y2 - (int)x1 > 0) ||
+           (x1 <= x2 && x2 <= y2 && y2 <= y1 && (int)y2 - (int)x2 > 0) || (x2 <= x1 && x1 <= y1 && y1 <= y2 && (int)y1 - (int)x1 > 0);
+}
+
+void remove_misassembly(const Options &o, const string &file, const string &id, vector<string> &contigIds) {
+    const string fa = "tmp/_" + id + "_contigs.fa";
+    formalize_contigs(file, contigIds, fa);                                        // AG:4288-4290; contigIds now names THIS file's records
+    // makeAlignment, AG:3821-3851
+    run("bowtie2-build -f tmp/_" + id + "_contigs.fa tmp/_" + id + "_contigs > bowtie_doc.txt 2> bowtie_doc.txt");
+    run("bowtie2 -f --no-mixed -k 1 -p 8 -I " + itoa(o.distanceLow) + " -X " + itoa(o.distanceHigh) + " --no-discordant -x tmp/_" + id +
+        "_contigs -1 tmp/_reads_1.fa -2 tmp/_reads_2.fa --reorder > tmp/_reads_" + id + "_contigs.bowtie 2> bowtie_doc.txt");
+    {
+        const string io = "tmp/_genome.fa tmp/_" + id + "_contigs.fa -noHead tmp/_" + id + "_contigs_genome.psl -fastMap";
+        if (run("pblat " + io + " -threads=8 > blat_doc.txt 2> blat_doc.txt") != 0)
+            if (run("blat " + io + " > blat_doc.txt 2> blat_doc.txt") != 0) die("BLAT CALL FAILED!");
+    }
+    // loadPreContigs, AG:3853-3891: one coverage counter per base of every chunk record
+    bool ok; vector<string> lines = read_lines(fa, ok);
+    if (!ok) die("CANNOT OPEN FILE!");
+    vector<vector<CBase> > pre; vector<int> realOf;
+    for (const string &b : lines) {
+        if (b[0] == '>') { pre.push_back(vector<CBase>()); const size_t d = b.find('.'); realOf.push_back(atoi(d == string::npos ? "" : b.substr(d + 1, 9).c_str())); }
+        else if (!pre.empty()) for (char c : b) pre.back().push_back(CBase{c, 0});
+    }
+    // loadReadAlignment, AG:3940-3984: +1 over [POS-1, POS-1 + CIGAR span on the contig) for both mates of every aligned pair
+    {
+        vector<string> sam = read_lines("tmp/_reads_" + id + "_contigs.bowtie", ok);
+        if (!ok) die("CANNOT OPEN FILE!");
+        auto span = [](const string &l, int &tid, unsigned &ts, unsigned &te) {
+            vector<string> f; size_t a = 0;
+            for (int i = 0; i < 6; i++) { size_t b = l.find('\t', a); f.push_back(l.substr(a, b == string::npos ? string::npos : b - a)); if (b == string::npos) break; a = b + 1; }
+            f.resize(6);
+            if (f[2].size() && f[2][0] == '*') { tid = -1; return; }
+            const size_t dot = f[2].find('.');
+            tid = dot == string::npos ? 0 : atoi(f[2].substr(0, dot).c_str());      // parseBOWTIE: RNAME "seqID.realID" -> seqID (AG:277-280)
+            int total = 0, ins = 0, del = 0; unsigned num = 0;
+            for (char c : f[5]) {
+                if (c >= '0' && c <= '9') { num = num * 10 + (unsigned)(c - '0'); continue; }
+                if (c == 'I') { ins += (int)num; total += (int)num; } else if (c == 'D') del += (int)num; else if (c == 'M' || c == 'S') total += (int)num;
+                else if (c != '*') { cout << "unknown character: " << c << endl; exit(-1); }
+                num = 0;
+            }
+            ts = (unsigned)(atoi(f[3].c_str()) - 1); te = ts + (unsigned)(total + del - ins);
+        };
+        for (size_t i = 0; i < sam.size(); i++) {
+            if (sam[i][0] == '@') continue;
+            if (i + 1 >= sam.size()) die("BROKEN BOWTIE FILE!");
+            int t1, t2; unsigned s1 = 0, e1 = 0, s2 = 0, e2 = 0;
+            span(sam[i], t1, s1, e1); span(sam[i + 1], t2, s2, e2); i++;
+            if (t1 == -1 || t2 == -1) continue;
+            if ((size_t)t1 >= pre.size() || (size_t)t2 >= pre.size()) continue;       // the reference would write out of bounds
+            for (int bp = (int)s1; bp < (int)e1; bp++) if ((size_t)bp < pre[t1].size()) pre[t1][bp].cov++;
+            for (int bp = (int)s2; bp < (int)e2; bp++) if ((size_t)bp < pre[t2].size()) pre[t2][bp].cov++;
+        }
+    }
+    // loadContigs, AG:3893-3938: chunks of one real contig are concatenated (a new contig starts when realID grows)
+    vector<vector<CBase> > contigs; int realBak = -1;
+    for (size_t i = 0; i < pre.size(); i++) { if (realOf[i] > realBak) { contigs.push_back(vector<CBase>()); realBak = realOf[i]; } if (!contigs.empty()) contigs.back().insert(contigs.back().end(), pre[i].begin(), pre[i].end()); }
+    // loadContigAlignment, AG:4003-4145
+    vector<vector<CPos> > pos(contigs.size());
+    {
+        vector<string> psl = read_lines("tmp/_" + id + "_contigs_genome.psl", ok);
+        if (!ok) die("CANNOT OPEN FILE!");
+        int realBak2 = -1; unsigned sourceIDBak = 0;
+        for (const string &line : psl) {
+            vector<string> f; size_t a = 0;
+            for (;;) { size_t b = line.find('\t', a); f.push_back(line.substr(a, b == string::npos ? string::npos : b - a)); if (b == string::npos) break; a = b + 1; }
+            f.resize(21);
+            const PslHit h = parse_psl(line);
+            const int realSourceID = (int)h.realSourceSize;                          // parseBLAT's return value: the number after the '.', else qSize
+            const int fr = f[8].empty() ? -1 : (f[8][0] == '+' ? 0 : 1);
+            if (realSourceID > realBak2) { realBak2 = realSourceID; sourceIDBak = h.sID; }
+            const unsigned sStart = (h.sID - sourceIDBak) * 1000000u + h.sStart, sEnd = (h.sID - sourceIDBak) * 1000000u + h.sEnd;
+            if (!(sEnd - sStart >= 100 && (double)(unsigned)(sEnd - sStart - h.sGap) / (unsigned)(sEnd - sStart) >= 0.1 &&
+                  (double)(unsigned)(h.tEnd - h.tStart - h.tGap) / (double)(unsigned)(h.tEnd - h.tStart) >= 0.1)) continue;
+            if (realSourceID < 0 || (size_t)realSourceID >= pos.size()) continue;      // out of bounds in the reference
+            vector<CPos> &P = pos[realSourceID];
+            int keep = 1;
+            for (size_t pp = 0; pp < P.size(); pp++)
+                if (P[pp].tID != -1 && (int)h.tID == P[pp].tID && masb_conflict(sStart, sEnd, P[pp].sStart, P[pp].sEnd)) {
+                    if (sEnd - sStart < P[pp].sEnd - P[pp].sStart) keep = 0; else P[pp] = CP_NONE;
+                }
+            if (keep) P.push_back(CPos{(int)h.tID, sStart, sEnd, h.tStart, h.tEnd, fr});
+        }
+    }
+    for (size_t sp = 0; sp < pos.size(); sp++) {                                      // join consecutive local alignments, AG:4068-4081
+        vector<CPos> &P = pos[sp];
+        for (int pp = 0; pp < (int)P.size(); pp++)
+            for (int q = 0; q < (int)P.size(); q++)
+                if (q != pp && P[pp].tID != -1 && P[q].tID != -1 && P[pp].tID == P[q].tID &&
+                    masb_close(P[pp].sEnd, P[q].sStart, (unsigned)(abs((int)P[pp].sEnd - (int)P[pp].sStart) / 10)) &&
+                    masb_close(P[pp].tEnd, P[q].tStart, (unsigned)(abs((int)P[pp].tEnd - (int)P[pp].tStart) / 10)) && P[pp].fr == P[q].fr) {
+                    P[pp].sEnd = P[q].sEnd; P[pp].tEnd = P[q].tEnd; P[q] = CP_NONE; q = 0;   // (the loop increment makes the rescan start at 1, as in the reference)
+                }
+    }
+    for (size_t sp = 0; sp < pos.size(); sp++) {                                      // of two conflicting placements the longer stays, AG:4083-4090
+        vector<CPos> &P = pos[sp];
+        for (size_t pp = 0; pp < P.size(); pp++) for (size_t q = pp + 1; q < P.size(); q++)
+            if (P[pp].tID != -1 && P[q].tID != -1 && masb_conflict(P[pp].sStart, P[pp].sEnd, P[q].sStart, P[q].sEnd)) {
+                if (P[pp].sEnd - P[pp].sStart > P[q].sEnd - P[q].sStart) P[q] = CP_NONE; else P[pp] = CP_NONE;
+            }
+    }
+    for (size_t sp = 0; sp < pos.size(); sp++) {                                      // overlapping / adjacent placements are cut at the thinnest base, AG:4093-4141
+        vector<CPos> &P = pos[sp]; const vector<CBase> &C = contigs[sp];
+        for (size_t pp = 0; pp < P.size(); pp++) for (size_t q = pp + 1; q < P.size(); q++) {
+            if (P[pp].tID != -1 && P[q].tID != -1 && masb_overlap(P[pp].sStart, P[pp].sEnd, P[q].sStart, P[q].sEnd)) {
+                int mn = 99999, mp = -1, start, end;
+                if (P[pp].sStart <= P[q].sStart) { start = (int)P[q].sStart; end = (int)P[pp].sEnd - 1; } else { start = (int)P[pp].sStart; end = (int)P[q].sEnd - 1; }
+                for (int bp = start; bp <= end; bp++) if (bp >= 0 && (size_t)bp < C.size() && C[bp].cov < mn) { mn = C[bp].cov; mp = bp; }
+                if (P[pp].sStart <= P[q].sStart) { P[pp].sEnd = (unsigned)mp; P[q].sStart = (unsigned)(mp + 1); } else { P[q].sEnd = (unsigned)mp; P[pp].sStart = (unsigned)(mp + 1); }
+            } else if (P[pp].tID != -1 && P[q].tID != -1 && P[pp].sEnd == P[q].sStart) {
+                if (P[pp].sEnd - 1 < C.size() && P[q].sStart < C.size() && C[P[pp].sEnd - 1].cov < C[P[q].sStart].cov) P[pp].sEnd--; else P[q].sStart++;
+            } else if (P[pp].tID != -1 && P[q].tID != -1 && P[q].sEnd == P[pp].sStart) {
+                if (P[q].sEnd - 1 < C.size() && P[pp].sStart < C.size() && C[P[q].sEnd - 1].cov < C[P[pp].sStart].cov) P[q].sEnd--; else P[pp].sStart++;
+            }
+        }
+    }
+    // removeMasb, AG:4147-4279: cov becomes -1 (keep) or -2 (remove)
+    for (size_t cp = 0; cp < pos.size(); cp++) {
+        vector<CBase> &C = contigs[cp]; const vector<CPos> &P = pos[cp];
+        bool whole = false;
+        for (const CPos &p : P) if (p.tID != -1 && (double)(unsigned)(p.sEnd - p.sStart) / C.size() >= 0.8) { whole = true; break; }
+        if (whole) { for (CBase &b : C) b.cov = -1; continue; }
+        for (const CPos &p : P) if (p.tID != -1) for (int bp = (int)p.sStart; (unsigned)bp < p.sEnd; bp++) if ((size_t)bp < C.size()) C[bp].cov = -1;
+        int start = 0, end = 0, total = 0; const int n = (int)C.size();
+        for (int bp = 0; bp < n; bp++) {
+            if (C[bp].cov == -1) continue;
+            if (bp != 0 && bp != n - 1 && C[bp - 1].cov == -1 && C[bp + 1].cov == -1) { C[bp].cov = C[bp].cov < o.coverage ? -2 : -1; continue; }
+            if (bp == 0 || C[bp - 1].cov == -1) { start = bp; total = C[bp].cov; }
+            else if (bp == n - 1 || C[bp + 1].cov == -1) {
+                end = bp; total += C[bp].cov;
+                const int v = total / (end - start + 1) < o.coverage ? -2 : -1;
+                for (int b2 = start; b2 <= end; b2++) C[b2].cov = v;
+            } else total += C[bp].cov;
+        }
+    }
+    std::ofstream out(("corrected_" + file).c_str());
+    if (!out.is_open()) die("CANNOT OPEN FILE!");
+    for (size_t cp = 0; cp < contigs.size(); cp++) {
+        const vector<CBase> &C = contigs[cp]; vector<string> parts; const int n = (int)C.size();
+        for (int bp = 0; bp < n; bp++) {
+            // (the reference reads C[bp-1] at bp == 0 — one element before the array; it can only matter if that stray value were -2)
+            if ((parts.empty() && C[bp].cov == -1) || (bp > 0 && C[bp - 1].cov == -2 && C[bp].cov == -1)) parts.push_back(string());
+            if (C[bp].cov == -1 && !parts.empty()) parts.back().push_back(C[bp].base);
+            if (bp == n - 1 || (C[bp].cov == -1 && C[bp + 1].cov == -2)) if (!parts.empty() && parts.back().size() <= 200) parts.pop_back();
+        }
+        for (size_t sp = 0; sp < parts.size(); sp++) {
+            const string name = cp < contigIds.size() ? contigIds[cp] : string();
+            if (parts.size() == 1) out << ">" << name << '\n'; else out << ">" << name << " : part" << sp << '\n';
+            put60(out, parts[sp]);
+        }
+    }
+    if (id == "remaining") { vector<string> chaff = read_lines("tmp/_chaff.fa", ok); if (ok) for (const string &b : chaff) out << b << '\n'; }
+}
+
 // ---- the unit loop on the GPUs --------------------------------------------------------------------------------------------------
 // Units are independent (AG:4779-4781 clears all state between them): a work queue feeds one host thread per device slot; progress
 // lines and checkpoints are emitted in unit order, as the sequential reference would.
@@ -465,7 +635,6 @@ int main(int argc, char **argv) {
             usage(); return 0;                                                // AG:4726-4730 (exit status 0)
         }
         if (o.fastMap) die("--fastMap (NUCMER + delta2psl) is not supported by AlignGraph_amd");
-        if (o.misassemblyRemoval) die("--misassemblyRemoval is not supported by AlignGraph_amd");
         if (run("bowtie2 -h > bowtie_doc.txt 2> bowtie_doc.txt") != 0) die("BOWTIE2 CALL FAILED!");   // testAligners, AG:4682-4694
         mkdir("tmp", 0777);
         { std::ofstream wcmd("tmp/_command.txt"); for (int i = 1; i < argc; i++) wcmd << argv[i] << endl; }
@@ -486,7 +655,6 @@ int main(int argc, char **argv) {
         o = Options(); parse_params("tmp/_command.txt", o);                   // AG:4752-4753 (the tags start from the --resume parse in the reference; only resume itself carries over)
         o.resume = 1;
         if (o.fastMap) die("--fastMap (NUCMER + delta2psl) is not supported by AlignGraph_amd");
-        if (o.misassemblyRemoval) die("--misassemblyRemoval is not supported by AlignGraph_amd");
         cout << "RESUMED SUCCESSFULLY :-)" << endl;
         wcp.open("tmp/_checkpoint.txt", std::ios::app);
         formalize_contigs(o.contig, contigIds);
@@ -496,6 +664,11 @@ int main(int argc, char **argv) {
     if (o.ratioCheck == 1) check_ratio(units);
     if (cp < units) run_units(o, cp, units, wcp);
     refinement(o, units, genomeIds, contigIds);
+    if (o.misassemblyRemoval == 1) {                                          // AG:4787-4792
+        remove_misassembly(o, o.ext, "extended", contigIds);
+        remove_misassembly(o, o.rmn, "remaining", contigIds);
+        cout << endl << "(6) Misassemblies removed" << endl;
+    }
     const time_t end = time(NULL);
     cout << endl << "FINISHED SUCCESSFULLY for " << end - start << " seconds (" << endAlign - startAlign << " seconds for alignment) :-)" << endl;
     return 0;

@@ -23,6 +23,7 @@ BASE = ["--read1", "reads_1.fa", "--read2", "reads_2.fa", "--contig", "contigs.f
 VARIANTS = {
     "default": BASE + ["--coverage", "4"],
     "flags": BASE + ["--coverage", "3", "--kMer", "7", "--insertVariation", "40", "--ratioCheck", "--uniqueExtension"],
+    "masb": BASE + ["--coverage", "3", "--misassemblyRemoval"],
     # (--part > 1 is not in the end-to-end set: the reference indexes genomeIds by unit in refinement, AG:3102, and crashes on it)
 }
 INPUTS = ["reads_1.fa", "reads_2.fa", "contigs.fa", "genome.fa", "stub/reads_genome.sam"]
@@ -49,15 +50,16 @@ def main():
         for name, args in VARIANTS.items():
             part = int(args[args.index("--part") + 1]) if "--part" in args else 1
             # the aligner stubs replay per-unit data, so the data set is generated with the same --part the command uses
-            src = H.synth("/tmp/golden_e2e_" + name, seed=21, chroms="12000,9000", part=part, pairs=4000, coverage=4, e2e=1, sam_seq=0,
-                          contig_min=600, contig_max=3000, multi=0.1)
+            extra = dict(seed=17, chimeric=0.5, contig_overlap=0.3, contig_min=500, contig_max=3500) if name == "masb" else dict(seed=21, contig_min=600, contig_max=3000)
+            src = H.synth("/tmp/golden_e2e_" + name, chroms="12000,9000", part=part, pairs=4000, coverage=4, e2e=1, sam_seq=0, multi=0.1, **extra)
             work, out = run_reference(src, args)
             for fn in INPUTS + ["stub/" + f for f in sorted(os.listdir(os.path.join(src, "stub"))) if f.endswith(".psl")]:
                 add("%s/in/%s" % (name, fn), open(os.path.join(src, fn), "rb").read())
             add("%s/args.txt" % name, "\n".join(args).encode())
             add("%s/expected/stdout.txt" % name, out)
-            for fn in ("e.fa", "r.fa", "in.fa", "ex.fa"):
-                add("%s/expected/%s" % (name, fn), open(os.path.join(work, fn), "rb").read())
+            for fn in ("e.fa", "r.fa", "in.fa", "ex.fa", "corrected_e.fa", "corrected_r.fa"):
+                if os.path.exists(os.path.join(work, fn)):
+                    add("%s/expected/%s" % (name, fn), open(os.path.join(work, fn), "rb").read())
             for fn in sorted(os.listdir(os.path.join(work, "tmp"))):
                 if fn.startswith(("_initial_contigs", "_pre_extended_contigs", "_extended_contigs", "_short_initial", "_checkpoint", "_contigs.fa", "_chaff", "_genome")):
                     add("%s/expected/tmp/%s" % (name, fn), open(os.path.join(work, "tmp", fn), "rb").read())

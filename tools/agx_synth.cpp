@@ -77,6 +77,7 @@ struct Params {
     int64_t contig_min = 2000, contig_max = 50000, gap_min = 500, gap_max = 2000;
     double contig_minus = 0.3, contig_split = 0.15, contig_dup = 0.05, contig_overlap = 0.1, contig_lowid = 0.03;
     double short_contig = 0.05;
+    double chimeric = 0.0;   // probability that a contig is a misassembly: piece + 300 random bases + a piece from elsewhere (exercises misassembly removal)
     double frag_mean = 500, frag_sd = 30;
     double read_err = 0.002, read_indel = 0.10, read_clip = 0.05, read_badclip = 0.01, read_n = 0.0005;
     double multi = 0.05, multi_near = 0.3, unaligned = 0.02;
@@ -112,7 +113,7 @@ Params parse_args(int argc, char **argv) {
         OPT_D("--snp", snp) OPT_D("--indel", indel)
         OPT_I("--contig-min", contig_min) OPT_I("--contig-max", contig_max) OPT_I("--gap-min", gap_min) OPT_I("--gap-max", gap_max)
         OPT_D("--contig-minus", contig_minus) OPT_D("--contig-split", contig_split) OPT_D("--contig-dup", contig_dup)
-        OPT_D("--contig-overlap", contig_overlap) OPT_D("--contig-lowid", contig_lowid) OPT_D("--short-contig", short_contig)
+        OPT_D("--contig-overlap", contig_overlap) OPT_D("--contig-lowid", contig_lowid) OPT_D("--short-contig", short_contig) OPT_D("--chimeric", chimeric)
         OPT_D("--frag-mean", frag_mean) OPT_D("--frag-sd", frag_sd)
         OPT_D("--read-err", read_err) OPT_D("--read-indel", read_indel) OPT_D("--read-clip", read_clip)
         OPT_D("--read-badclip", read_badclip) OPT_D("--read-n", read_n)
@@ -324,6 +325,12 @@ int main(int argc, char **argv) {
                 if (len <= 250) break;
                 int64_t s = t, e = t + len;
                 std::string seq = U.tgt.substr(s, len);
+                const bool chim = R.coin(P.chimeric) && T > 4000;
+                if (chim) {                        // junk + a second piece from a random other place; only the first piece is reported to the threading PSL
+                    for (int j = 0; j < 300; j++) seq.push_back(ACGT[R.below(4)]);
+                    const int64_t l2 = std::min<int64_t>(len, 1500), s2 = R.range(0, T - l2 - 1);
+                    seq += U.tgt.substr(s2, l2);
+                }
                 char strand = R.coin(P.contig_minus) ? '-' : '+';
                 std::string name = "contig_" + std::to_string(nameID++);
                 std::fprintf(cf, ">%s\n", name.c_str());
@@ -334,15 +341,17 @@ int main(int argc, char **argv) {
                 seqID++; realID++;
 
                 std::vector<Block> b = blocks_of(U, s, e);
+                const int64_t qsize = (int64_t)seq.size();
+                if (strand == '-' && chim) for (auto &blk : b) blk.q += qsize - len;   // blocks are in reverse-complemented query coordinates
                 if (!b.empty()) {
                     if (R.coin(P.contig_lowid)) {
-                        psl_line(psl, b, 0, b.size(), strand, qname, len, (int64_t)U.ref.size(), len, 0);   // fails identity filter
+                        psl_line(psl, b, 0, b.size(), strand, qname, qsize, (int64_t)U.ref.size(), len, 0);   // fails identity filter
                     } else if (b.size() >= 2 && R.coin(P.contig_split)) {
                         size_t cut = 1 + R.below(b.size() - 1);
-                        psl_line(psl, b, 0, cut, strand, qname, len, (int64_t)U.ref.size(), 0, 0);
-                        psl_line(psl, b, cut, b.size(), strand, qname, len, (int64_t)U.ref.size(), 0, 0);
+                        psl_line(psl, b, 0, cut, strand, qname, qsize, (int64_t)U.ref.size(), 0, 0);
+                        psl_line(psl, b, cut, b.size(), strand, qname, qsize, (int64_t)U.ref.size(), 0, 0);
                     } else {
-                        psl_line(psl, b, 0, b.size(), strand, qname, len, (int64_t)U.ref.size(), 0, 0);
+                        psl_line(psl, b, 0, b.size(), strand, qname, qsize, (int64_t)U.ref.size(), 0, 0);
                     }
                     if (R.coin(P.contig_dup)) {   // a second, repeat-like placement of the same contig elsewhere
                         int64_t G = (int64_t)U.ref.size();
@@ -350,7 +359,7 @@ int main(int argc, char **argv) {
                         if (G > sub + 10) {
                             int64_t where = R.range(0, G - sub - 1);
                             std::vector<Block> d = {{0, where, sub}};
-                            psl_line(psl, d, 0, 1, strand, qname, len, G, 0, 0);
+                            psl_line(psl, d, 0, 1, strand, qname, qsize, G, 0, 0);
                         }
                     }
                 }
