@@ -34,7 +34,7 @@ class Case:
         self.work = os.path.join(self.dir, "in")
         self.exp = os.path.join(self.dir, "expected")
         self.args = open(os.path.join(self.dir, "args.txt")).read().split("\n")
-        self.units = len([f for f in os.listdir(os.path.join(self.exp, "tmp")) if f.startswith("_extended_contigs.")])
+        self.units = len([f for f in os.listdir(os.path.join(self.exp, "tmp")) if re.fullmatch(r"_extended_contigs\.\d+\.fa", f)])
 
     def run(self, cli, args):
         env = dict(os.environ, PATH=STUBS + os.pathsep + os.environ["PATH"], AGX_STUB_DIR=os.path.join(self.work, "stub"))
@@ -65,7 +65,7 @@ def test_front_half_and_refinement_match_reference(cli, name, tmp_path):
     assert c.got("tmp/_checkpoint.txt") == b"0\n"
     # hand over the reference's unit outputs and resume at the end of the unit loop
     for fn in os.listdir(os.path.join(c.exp, "tmp")):
-        if fn.startswith(("_initial_contigs", "_pre_extended_contigs", "_extended_contigs")):
+        if re.fullmatch(r"_(initial|pre_extended|extended)_contigs\.\d+\.fa", fn):
             shutil.copy(os.path.join(c.exp, "tmp", fn), os.path.join(c.work, "tmp", fn))
     with open(os.path.join(c.work, "tmp", "_checkpoint.txt"), "a") as f:
         f.write("%d\n" % c.units)
