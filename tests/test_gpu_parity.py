@@ -103,3 +103,61 @@ def test_errors_come_back_as_codes(agx, built, tmp_path):
     with pytest.raises(agx.AgxError) as e:
         run_engine(agx, tmp, 0, 5, 50, 2)
     assert e.value.code == agx.AGX_E_IO
+
+
+def test_packed_array_boundary_matches_text_path(agx, built, tmp_path):
+    """agx_unit_set_reference / _set_contig_threads / _push_pairs (the packed boundary of SURVEY §8b) fed by hand must give the bytes the
+    text loaders + oracle give for the equivalent files: gap-free FR pairs on a contig-free unit, two batches."""
+    import ctypes
+    import random
+    rnd = random.Random(5)
+    G, L, N = 3000, 60, 400
+    ref = "".join(rnd.choice("ACGT") for _ in range(G))
+    comp = str.maketrans("ACGT", "TGCA")
+    pairs = []
+    for i in range(N):
+        s = rnd.randrange(0, G - 400)
+        f = rnd.randrange(200, 380)
+        left, right = ref[s:s + L], ref[s + f - L:s + f]
+        m1_left = rnd.random() < 0.5
+        pairs.append((s, s + f - L, left, right.translate(comp)[::-1], m1_left))
+    # the same data as the reference's tmp/ files, for the oracle
+    tmp = tmp_path / "tmp"
+    tmp.mkdir()
+    (tmp / "_genome.0.fa").write_text(">0\n" + "\n".join(ref[i:i + 60] for i in range(0, G, 60)) + "\n")
+    (tmp / "_contigs.fa").write_text("")
+    (tmp / "_contigs_genome.0.psl").write_text("")
+    with open(tmp / "_reads.fa", "w") as rf, open(tmp / "_reads_genome.0.bowtie", "w") as sf:
+        for i, (pl, pr, fl, fr_, m1_left) in enumerate(pairs):
+            m1, m2 = (fl, fr_) if m1_left else (fr_, fl)
+            rf.write(">%d\n%s\n>%d\n%s\n" % (i, m1, i, m2))
+            p1, p2 = (pl, pr) if m1_left else (pr, pl)
+            f1, f2 = (99, 147) if m1_left else (83, 163)
+            sf.write("%d\t%d\t0\t%d\t42\t%dM\t=\t%d\t0\t*\t*\n%d\t%d\t0\t%d\t42\t%dM\t=\t%d\t0\t*\t*\n" % (i, f1, p1 + 1, L, p2 + 1, i, f2, p2 + 1, L, p1 + 1))
+    want = H.run_oracle(str(tmp), 0, 5, 50, 2)
+    # the packed boundary, two batches
+    with agx.Unit(k=5, insert_variation=50, coverage=2) as u:
+        L_ = agx.lib()
+        u._check(L_.agx_unit_set_reference(u._h, ref.encode(), G))
+        cm_start = (ctypes.c_uint32 * (G + 1))()
+        u._check(L_.agx_unit_set_contig_threads(u._h, None, 0, cm_start, None, 0, b"", 0))
+        stride = 64
+        for lo, hi in ((0, 150), (150, N)):
+            n = hi - lo
+            hits = (agx.Hit * n)()
+            bases = bytearray(b"N" * (2 * n * stride))
+            for j, (pl, pr, fl, fr_, m1_left) in enumerate(pairs[lo:hi]):
+                m1, m2 = (fl, fr_) if m1_left else (fr_, fl)
+                bases[(2 * j) * stride:(2 * j) * stride + L] = m1.encode()
+                bases[(2 * j + 1) * stride:(2 * j + 1) * stride + L] = m2.encode()
+                h = hits[j]
+                h.slot1 = 2 * j
+                h.pos1, h.pos2 = (pl, pr) if m1_left else (pr, pl)
+                h.len = L
+                h.rev1, h.rev2 = (0, 1) if m1_left else (1, 0)
+            b = agx.PairBatch(hits, n, None, 0, bytes(bases), stride, 2 * n)
+            u._check(L_.agx_unit_push_pairs(u._h, ctypes.byref(b)))
+        u.upload(); u.build()
+        got = u.finish()
+    assert got["pre"] == want["pre"] and got["extended"] == want["extended"] and got["initial"] == want["initial"] == b""
+    assert want["pre"].count(b">") > 0
