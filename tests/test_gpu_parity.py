@@ -161,3 +161,19 @@ def test_packed_array_boundary_matches_text_path(agx, built, tmp_path):
         got = u.finish()
     assert got["pre"] == want["pre"] and got["extended"] == want["extended"] and got["initial"] == want["initial"] == b""
     assert want["pre"].count(b">") > 0
+
+
+def test_empty_and_ragged_inputs(agx, built, tmp_path):
+    run = H.synth(str(tmp_path / "run"), seed=9, chroms="6000", pairs=400, coverage=2, sam_seq=0)
+    tmp = os.path.join(run, "tmp")
+    open(os.path.join(tmp, "_contigs_genome.0.psl"), "w").close()               # no contig alignments
+    a = H.run_oracle(tmp, 0, 5, 50, 2, graph=True)
+    b = run_engine(agx, tmp, 0, 5, 50, 2, graph=True)
+    assert graph_mismatch(a["graph"], b["graph"]) is None and all(a[k] == b[k] for k in ("initial", "pre", "extended"))
+    open(os.path.join(tmp, "_reads_genome.0.bowtie"), "w").close()              # no read alignments: empty graph, empty outputs
+    b = run_engine(agx, tmp, 0, 5, 50, 2, graph=True)
+    assert b["graph"]["n_nodes"] == 0 and b["pre"] == b"" and b["extended"] == b""
+    # k as long as the reads: every hit is skipped (the reference's loop bound underflows there; here nothing is emitted)
+    run2 = H.synth(str(tmp_path / "run2"), seed=10, chroms="6000", pairs=300, L=40, coverage=2, sam_seq=0)
+    b = run_engine(agx, os.path.join(run2, "tmp"), 0, 40, 50, 2, graph=True)
+    assert b["graph"]["n_nodes"] == 0
