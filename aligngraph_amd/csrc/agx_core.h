@@ -253,6 +253,7 @@ struct agx_sweep_args {
     // node table
     agx_u32 *node_start;          // [n_pos]
     agx_u8 *node_cnt;             // [n_pos]
+    agx_u8 *pos_succ;             // [n_pos] bit 0: some arrival at x steps to x+1 (written by the node sweep, read by the edge build)
     agx_u32 *nk_cid, *nk_coff, *nk_cid0, *nk_coff0, *nk_off0;   // [pool]
     agx_u32 *n_xpos;              // position of each node (the walk follows edges by node id)
     agx_u8 *n_base, *n_flags;     // consensus base ('X' = none: use the reference base, AG:1997-2001), AGX_NF_*
@@ -300,7 +301,7 @@ AGX_HD void agx_for_candidates(const agx_sweep_args &A, agx_u32 cx_s, agx_u32 cx
 // Everything one arrival needs from memory.  The sweep fetches it ONE HIT AHEAD of its use, so the dependent global loads
 // (mate conti-mer range -> first entry, vote base) of hit i+1 are in flight while hit i updates the bucket in LDS.
 struct agx_pre {
-    agx_u32 has, type, p0;                 // arrival present at this position; AGX_AT_*; mate position
+    agx_u32 has, type, p0, step1;          // arrival present at this position; AGX_AT_*; mate position; its successor is position+1
     agx_u32 c0_s, c0_n; agx_cmkey c0;      // conti-mers at the mate position, and the first of them
     agx_u32 s0, s1; char base;             // k-mer string reference of this arrival; its vote base
 };
@@ -308,8 +309,9 @@ struct agx_pre {
 AGX_HD void agx_arrival_fetch(const agx_sweep_args &A, const agx_dhit &d, agx_u32 X, agx_pre &p) {
     const agx_arrival a = agx_decode_arrival(d, A.runs, X, A.k);
     p.has = a.has;
-    p.c0_s = 0; p.c0_n = 0; p.c0 = agx_cmkey{AGX_NONE, AGX_NONE}; p.base = 0; p.s0 = 0; p.s1 = 0; p.type = 0; p.p0 = AGX_NONE;
+    p.c0_s = 0; p.c0_n = 0; p.c0 = agx_cmkey{AGX_NONE, AGX_NONE}; p.base = 0; p.s0 = 0; p.s1 = 0; p.type = 0; p.p0 = AGX_NONE; p.step1 = 0;
     if (!p.has) return;
+    p.step1 = (a.has_succ && a.xs == X + 1) ? 1u : 0u;
     const bool rev = (d.flags & AGX_HF_AREV) != 0;
     p.type = a.type; p.p0 = a.p0;
     p.s0 = d.a_slot;
@@ -322,8 +324,8 @@ AGX_HD void agx_arrival_fetch(const agx_sweep_args &A, const agx_dhit &d, agx_u3
 // records at a time across the lanes of the wavefront and broadcast them; the test executor reads memory directly).
 // Returns false if the bucket overflowed (the tile is then re-run with a larger bucket).
 template <class GET>
-AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, const agx_bucket &b, agx_u32 &cnt, GET get) {
-    cnt = 0;
+AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, const agx_bucket &b, agx_u32 &cnt, agx_u32 &pflag, GET get) {
+    cnt = 0; pflag = 0;
     const bool live = X < A.n_pos;                       // lanes beyond the end still take part in the staging of hit records
     agx_u32 cx_s = 0, cx_n = 0; agx_cmkey cx0 = agx_cmkey{AGX_NONE, AGX_NONE};
     if (live) { cx_s = A.cm_start[X]; cx_n = A.cm_start[X + 1] - cx_s; if (cx_n) cx0 = A.cm[cx_s]; }
@@ -350,6 +352,7 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
     };
     auto apply = [&](const agx_pre &p) {
         if (!p.has || !ok) return;
+        pflag |= p.step1;
         const bool is_k1 = p.type != AGX_AT_K2ONLY;
         const agx_u32 vf = p.type == AGX_AT_K1 ? agx_vote_field(p.base) : (agx_u32)AGX_NF;
         agx_key key; key.cid = cx0.cid; key.coff = cx0.coff; key.cid0 = p.c0.cid; key.coff0 = p.c0.coff; key.off0 = p.p0;   // cx0 / c0 are NONE when absent
@@ -381,9 +384,9 @@ AGX_HD char agx_consensus(agx_u32 a, agx_u32 c, agx_u32 g, agx_u32 t, agx_u32 n)
 }
 
 // write this position's bucket to the node table at node ids [base, base+cnt); prune (AG:1904-1918) and consensus fused in
-AGX_HD void agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bucket &b, agx_u32 cnt, agx_u32 base) {
+AGX_HD void agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bucket &b, agx_u32 cnt, agx_u32 base, agx_u32 pflag) {
     if (X >= A.n_pos) return;
-    A.node_start[X] = base; A.node_cnt[X] = (agx_u8)cnt;
+    A.node_start[X] = base; A.node_cnt[X] = (agx_u8)cnt; A.pos_succ[X] = (agx_u8)pflag;
     for (agx_u32 v = 0; v < cnt; v++) {
         const agx_u32 id = base + v;
         const agx_u32 cid = agx_b(b, v, AGX_F_CID), coff = agx_b(b, v, AGX_F_COFF), cov = agx_b(b, v, AGX_F_COV);
@@ -423,22 +426,23 @@ AGX_HD bool agx_edge_allowed(const agx_sweep_args &A, agx_u32 src, agx_u32 dst) 
            agx_clause_ab(A.nk_cid0[dst], A.nk_coff0[dst], A.nk_cid0[src], A.nk_coff0[src], 2 * A.iv + AGX_EP25);
 }
 
-// All out-edges of the nodes at position X.  Only this lane ever writes n_next / n_flags of X's nodes, so plain stores suffice.
-// own_*: node_start/node_cnt of X; nb_*: of X+1 (0 nodes beyond the end).  push_overflow(src, dst) appends to the global overflow list.
-//
-// Fast path (the common case): X holds ONE variant, so every arrival at X resolved to it — no candidate keys, no compatibility
-// tests; if the successor is X+1 and that holds one variant too, the edge's other end is known as well and the contig-consistency
-// predicate is evaluated once per lane.  The four inline slots of such a node live in registers until the sweep ends.
+// Edge build, pass A (lanes = positions).  Where a position holds ONE variant every arrival resolved to it, so no candidate keys and
+// no compatibility tests are needed on the source side:
+//   * if x+1 holds one variant too, the edge x -> x+1 exists iff the node sweep saw an arrival stepping to x+1 (pos_succ) and the
+//     contig-consistency predicate of the two stored keys holds — no per-hit work at all;
+//   * steps that do not go to x+1 (read deletions, AG:1822-1838) can only come from hits whose a mate has several runs: only those
+//     (one hit in ten) are decoded here, the destination is resolved against the final bucket there.
+// Positions with several variants, or whose neighbour x+1 has several, return true ("slow"): pass B re-resolves every hit for them.
+// Only this lane writes n_next / n_flags of x's node in this pass, so plain stores suffice.
 template <class GET, class OVF>
-AGX_HD void agx_edge_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, agx_u32 own_start, agx_u32 own_cnt, agx_u32 nb_start, agx_u32 nb_cnt, GET get, OVF push_overflow) {
+AGX_HD bool agx_edge_fast_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, agx_u32 own_start, agx_u32 own_cnt, agx_u32 nb_start, agx_u32 nb_cnt, GET get, OVF push_overflow) {
     const bool live = X < A.n_pos && own_cnt != 0;        // idle lanes still take part in the staging of hit records
-    if (X >= A.n_pos) { X = 0; }
-    const bool fast = own_cnt == 1;
-    agx_u32 cx_s = 0, cx_n = 0;
-    if (live && !fast) { cx_s = A.cm_start[X]; cx_n = A.cm_start[X + 1] - cx_s; }
-    agx_u32 s0 = AGX_NONE, s1 = AGX_NONE, s2 = AGX_NONE, s3 = AGX_NONE;     // slots of the single node (fast lanes)
+    if (X >= A.n_pos) X = 0;
+    const bool fast = live && own_cnt == 1;
+    const bool slow = live && (own_cnt >= 2 || nb_cnt >= 2);
+    agx_u32 s0 = AGX_NONE, s1 = AGX_NONE, s2 = AGX_NONE, s3 = AGX_NONE;     // slots of the single node
     bool spilled = false;
-    int nb_ok = -1;                                                         // predicate (own -> single neighbour): unknown / no / yes
+    if (fast && nb_cnt == 1 && (A.pos_succ[X] & 1u) && agx_edge_allowed(A, own_start, nb_start)) s0 = nb_start;
     auto put_fast = [&](agx_u32 dst) {                                       // set insert into four register slots, select-only
         bool ins = !(s0 == dst || s1 == dst || s2 == dst || s3 == dst);
         const bool e0 = ins && s0 == AGX_NONE; s0 = e0 ? dst : s0; ins = ins && !e0;
@@ -450,42 +454,48 @@ AGX_HD void agx_edge_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
     const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
     for (agx_u32 i = lo; i < hi; i++) {
         const agx_dhit d = get(i);
+        if (d.a_nruns == 0) continue;                                       // wave-uniform: a single-run mate only ever steps to x+1
         const agx_arrival a = agx_decode_arrival(d, A.runs, X, A.k);
-        if (!live || !a.has || !a.has_succ || a.xs >= A.n_pos) continue;
-        if (fast && a.xs == X + 1 && nb_cnt == 1) {
-            if (nb_ok < 0) nb_ok = agx_edge_allowed(A, own_start, nb_start) ? 1 : 0;
-            if (nb_ok) put_fast(nb_start);
-            continue;
-        }
+        if (!fast || !a.has || !a.has_succ || a.xs >= A.n_pos || a.xs == X + 1) continue;
         const agx_u32 sx_s = A.cm_start[a.xs], sx_n = A.cm_start[a.xs + 1] - sx_s;
-        if (fast) {
-            agx_for_candidates(A, sx_s, sx_n, a.p0s, [&](const agx_key &k2) {
-                const agx_u32 dst = agx_resolve(A, a.xs, k2);
-                if (dst != AGX_NONE && agx_edge_allowed(A, own_start, dst)) put_fast(dst);
-                return true;
-            });
-            continue;
-        }
-        agx_for_candidates(A, cx_s, cx_n, a.p0, [&](const agx_key &k1) {
-            const agx_u32 src = agx_resolve(A, X, k1);
-            if (src == AGX_NONE) return true;
-            agx_for_candidates(A, sx_s, sx_n, a.p0s, [&](const agx_key &k2) {
-                const agx_u32 dst = agx_resolve(A, a.xs, k2);
-                if (dst == AGX_NONE || !agx_edge_allowed(A, src, dst)) return true;
-                agx_u32 *slots = A.n_next + (size_t)src * AGX_MAXE;
-                for (agx_u32 e = 0; e < AGX_MAXE; e++) { if (slots[e] == dst) return true; if (slots[e] == AGX_NONE) { slots[e] = dst; return true; } }
-                A.n_flags[src] |= AGX_NF_EOVF;
-                push_overflow(src, dst);
-                return true;
-            });
+        agx_for_candidates(A, sx_s, sx_n, a.p0s, [&](const agx_key &k2) {
+            const agx_u32 dst = agx_resolve(A, a.xs, k2);
+            if (dst != AGX_NONE && agx_edge_allowed(A, own_start, dst)) put_fast(dst);
             return true;
         });
     }
-    if (live && fast) {
+    if (fast) {
         agx_u32 *slots = A.n_next + (size_t)own_start * AGX_MAXE;
         slots[0] = s0; slots[1] = s1; slots[2] = s2; slots[3] = s3;
         if (spilled) A.n_flags[own_start] |= AGX_NF_EOVF;
     }
+    return slow;
+}
+
+// Edge build, pass B (lanes = hits): every edge out of a slow position x that ONE hit contributes (AG:1589-1623).  Edge order is
+// irrelevant to the walk (it only counts unvisited successors, AG:2020-2033), so the hits of x's tile are resolved in parallel and
+// INS(src, dst) performs a set insert into src's slots (compare-and-swap on the device).
+template <class INS>
+AGX_HD void agx_edge_slow_hit(const agx_sweep_args &A, agx_u32 X, const agx_dhit &d, INS ins) {
+    const agx_arrival a = agx_decode_arrival(d, A.runs, X, A.k);
+    if (!a.has || !a.has_succ || a.xs >= A.n_pos) return;
+    // X is wave-uniform on the device (one wavefront per slow position), and so is X+1 — the usual successor.  Keeping the two cases
+    // apart lets every bucket/conti-mer load of the common case go through the scalar cache instead of 64 per-lane gathers.
+    const agx_u32 cx_s = A.cm_start[X], cx_n = A.cm_start[X + 1] - cx_s;
+    const bool step1 = a.xs == X + 1;
+    const agx_u32 xs = step1 ? X + 1 : a.xs;
+    agx_u32 sx_s, sx_n;
+    if (step1) { sx_s = A.cm_start[X + 1]; sx_n = A.cm_start[X + 2] - sx_s; } else { sx_s = A.cm_start[xs]; sx_n = A.cm_start[xs + 1] - sx_s; }
+    agx_for_candidates(A, cx_s, cx_n, a.p0, [&](const agx_key &k1) {
+        const agx_u32 src = agx_resolve(A, X, k1);
+        if (src == AGX_NONE) return true;
+        agx_for_candidates(A, sx_s, sx_n, a.p0s, [&](const agx_key &k2) {
+            const agx_u32 dst = step1 ? agx_resolve(A, X + 1, k2) : agx_resolve(A, xs, k2);
+            if (dst != AGX_NONE && agx_edge_allowed(A, src, dst)) ins(src, dst);
+            return true;
+        });
+        return true;
+    });
 }
 
 // ---- walk preparation: alive-node renumbering and forced-run flags -------------------------------------------------------

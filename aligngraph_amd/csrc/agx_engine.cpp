@@ -64,7 +64,7 @@ struct agx_unit {
     DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_hits, d_scan_tmp, d_words;   // d_words: counters/status
     // node table
     agx_u32 pool_cap = 0, ovf_cap = 0, list_cap = 0;
-    DBuf<agx_u32> d_node_start; DBuf<agx_u8> d_node_cnt;
+    DBuf<agx_u32> d_node_start, d_slow_list; DBuf<agx_u8> d_node_cnt, d_pos_succ;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_big_list, d_scratch;
     // walk graph (agx_core.h "walk preparation")
@@ -83,7 +83,7 @@ struct agx_unit {
 
 namespace {
 
-enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_N = 8 };
+enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_N = 8 };
 
 void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     memset(&S, 0, sizeof S);
@@ -91,7 +91,7 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     S.dhit = u->d_dhit.p; S.runs = u->d_runs.p; S.bases = u->d_bases.p; S.stride = u->P.stride;
     S.tile_off = u->d_tile_off.p; S.tile_hits = u->d_tile_hits.p;
     S.n_pos = (agx_u32)u->T.ref.size(); S.n_tiles = u->n_tiles; S.k = u->prm.k; S.iv = (int)u->prm.insert_variation; S.coverage = (int)u->prm.coverage;
-    S.node_start = u->d_node_start.p; S.node_cnt = u->d_node_cnt.p;
+    S.node_start = u->d_node_start.p; S.node_cnt = u->d_node_cnt.p; S.pos_succ = u->d_pos_succ.p;
     S.nk_cid = u->d_cid.p; S.nk_coff = u->d_coff.p; S.nk_cid0 = u->d_cid0.p; S.nk_coff0 = u->d_coff0.p; S.nk_off0 = u->d_off0.p;
     S.n_xpos = u->d_xpos.p; S.n_base = u->d_base.p; S.n_flags = u->d_flags.p; S.n_sref = u->d_sref.p; S.n_next = u->d_next.p;
     S.n_counts = (u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? u->d_counts.p : nullptr;
@@ -128,7 +128,7 @@ void do_upload(agx_unit *u) {
     const size_t nb = ((size_t)n_pos + 1 + 1023) / 1024;              // sized for the longer of the two scans (positions)
     u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16);
     u->d_words.alloc(W_N); u->h_words.alloc(W_N + 4);
-    u->d_node_start.alloc(n_pos); u->d_node_cnt.alloc(n_pos);
+    u->d_node_start.alloc(n_pos); u->d_node_cnt.alloc(n_pos); u->d_pos_succ.alloc(n_pos); u->d_slow_list.alloc(n_pos + 64);
     if (u->pool_cap == 0) alloc_pool(u, (agx_u32)std::min<size_t>(2 * n_pos + 4096, 0xFFFFFF00ull));
     if (u->ovf_cap == 0) { u->ovf_cap = 1u << 16; u->d_ovf.alloc(u->ovf_cap); }
     HIP_OK(hipStreamSynchronize(u->st));
@@ -183,6 +183,7 @@ void do_build(agx_unit *u) {
         HIP_OK(hipEventRecord(u->ev_big.b, st)); u->ev_big.used = true;
         // ---- edge sweep ----
         agx_edge_kargs E; fill_sweep_args(u, E.S); E.ovf = u->d_ovf.p; E.ovf_count = u->d_words.p + W_OVFCOUNT; E.ovf_cap = u->ovf_cap; E.list_cap = u->list_cap;
+        E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
         HIP_OK(hipEventRecord(u->ev_edge.a, st));
         agx_launch_edge_sweep(&E, st);
         HIP_OK(hipEventRecord(u->ev_edge.b, st)); u->ev_edge.used = true; u->stats.edge_sweep_launches++;

@@ -21,7 +21,11 @@ struct agx_node_kargs {
     agx_u32 *scratch;          // fallback pass: one [AGX_NF*AGX_MAXV_BIG*64] bucket area per resident wavefront
 };
 
-struct agx_edge_kargs { agx_sweep_args S; agx_edge_ovf *ovf; agx_u32 *ovf_count; agx_u32 ovf_cap; agx_u32 list_cap; };
+struct agx_edge_kargs {
+    agx_sweep_args S; agx_edge_ovf *ovf; agx_u32 *ovf_count; agx_u32 ovf_cap; agx_u32 list_cap;
+    agx_u32 *slow_list; agx_u32 *slow_count;   // positions that need the per-hit pass (device-side list)
+};
+#define AGX_SLOW_WAVES 8192u    // resident wavefronts of the per-hit edge pass (stride over the slow list)
 
 extern "C" {
 void agx_launch_hit_prep(const agx_prep_args *, hipStream_t);
@@ -31,7 +35,7 @@ void agx_launch_bin_fill(const agx_bin_args *, hipStream_t);
 void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap, hipStream_t);
 void agx_launch_node_sweep(const agx_node_kargs *, hipStream_t);
 void agx_launch_node_sweep_big(const agx_node_kargs *, hipStream_t);
-void agx_launch_edge_sweep(const agx_edge_kargs *, hipStream_t);
+void agx_launch_edge_sweep(const agx_edge_kargs *, hipStream_t);          // pass A (lanes = positions), then pass B (lanes = hits)
 // walk preparation (agx_core.h): per-position side counts; then (after the scan) ids, records and overflow edges
 // n_nodes / n_ovf are read from device memory (the node-pool and overflow counters), so no host round trip separates the sweeps
 // from the walk preparation; the grids are sized by the capacities.

@@ -143,9 +143,9 @@ __global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
         const agx_u32 tile = BIG ? __builtin_amdgcn_readfirstlane(K.big_list[w]) : w;
         if (K.S.tile_off[tile + 1] > K.list_cap) return;
         const agx_u32 X = tile * AGX_TILE + lane;
-        agx_u32 cnt = 0;
+        agx_u32 cnt = 0, pflag = 0;
         agx_wave_hits hits(K.S.tile_hits, K.S.dhit, K.S.tile_off[tile + 1], lane);
-        const bool ok = agx_node_sweep_lane(K.S, tile, X, b, cnt, hits);
+        const bool ok = agx_node_sweep_lane(K.S, tile, X, b, cnt, pflag, hits);
         if (__ballot(!ok) != 0ull) {                       // wave-uniform
             if (lane == 0) {
                 if (BIG) atomicOr(K.status, 2u);
@@ -159,12 +159,14 @@ __global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
         if (lane == 0) base = atomicAdd(K.pool_counter, total);
         base = __shfl(base, 0, 64);
         if ((unsigned long long)base + total > K.S.pool_cap) { if (lane == 0) atomicOr(K.status, 1u); if (BIG) continue; else return; }
-        agx_node_write_lane(K.S, X, b, cnt, base + incl - cnt);
+        agx_node_write_lane(K.S, X, b, cnt, base + incl - cnt, pflag);
         if (!BIG) return;
     }
 }
 
-// ---- edge sweep -------------------------------------------------------------------------------------------------------
+// ---- edge build ---------------------------------------------------------------------------------------------------------
+// pass A: one wavefront per tile, lanes = positions (agx_edge_fast_lane); slow positions are compacted into a list with a
+// wave ballot + one atomicAdd per wavefront
 __global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
@@ -176,10 +178,50 @@ __global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
     agx_u32 nb_start = __shfl_down(own_start, 1, 64), nb_cnt = __shfl_down(own_cnt, 1, 64);
     if (lane == 63) { nb_start = 0; nb_cnt = 0; if (X + 1 < K.S.n_pos) { nb_start = K.S.node_start[X + 1]; nb_cnt = K.S.node_cnt[X + 1]; } }
     agx_wave_hits hits(K.S.tile_hits, K.S.dhit, K.S.tile_off[tile + 1], lane);
-    agx_edge_sweep_lane(K.S, tile, X, own_start, own_cnt, nb_start, nb_cnt, hits, [&](agx_u32 s, agx_u32 d) {
+    const bool slow = agx_edge_fast_lane(K.S, tile, X, own_start, own_cnt, nb_start, nb_cnt, hits, [&](agx_u32 s, agx_u32 d) {
         const agx_u32 i = atomicAdd(K.ovf_count, 1u);
         if (i < K.ovf_cap) K.ovf[i] = agx_edge_ovf{s, d};
     });
+    const unsigned long long m = __ballot(slow);
+    if (m) {
+        agx_u32 base = 0;
+        if (lane == 0) base = atomicAdd(K.slow_count, (agx_u32)__popcll(m));
+        base = __shfl(base, 0, 64);
+        if (slow) K.slow_list[base + (agx_u32)__popcll(m & ((1ull << lane) - 1ull))] = X;
+    }
+}
+
+// pass B: a fixed set of wavefronts strides over the slow positions; lanes = hits of the position's tile (agx_edge_slow_hit)
+__global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
+    const agx_u32 lane = threadIdx.x & 63u;
+    const agx_u32 wave = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    const agx_u32 n = __builtin_amdgcn_readfirstlane(*K.slow_count);
+    for (agx_u32 w = wave; w < n; w += AGX_SLOW_WAVES) {
+        const agx_u32 X = __builtin_amdgcn_readfirstlane(K.slow_list[w]);
+        const agx_u32 tile = X / AGX_TILE;
+        const agx_u32 lo = K.S.tile_off[tile], hi = K.S.tile_off[tile + 1];
+        for (agx_u32 i = lo + lane; i < hi; i += 64) {
+            const agx_dhit d = K.S.dhit[K.S.tile_hits[i]];
+            agx_edge_slow_hit(K.S, X, d, [&](agx_u32 src, agx_u32 dst) {
+                agx_u32 *slots = K.S.n_next + (size_t)src * AGX_MAXE;
+                // A slot only ever changes from NONE to its final value, so a plain (possibly stale) 16-byte read can prove presence;
+                // only an apparent NONE needs the compare-and-swap at L2.
+                const uint4 seen = *reinterpret_cast<const uint4 *>(slots);
+                if (seen.x == dst || seen.y == dst || seen.z == dst || seen.w == dst) return;
+                const agx_u32 sv[4] = {seen.x, seen.y, seen.z, seen.w};
+                for (agx_u32 e = 0; e < AGX_MAXE; e++) {
+                    agx_u32 cur = sv[e];
+                    if (cur == AGX_NONE) { cur = atomicCAS(&slots[e], AGX_NONE, dst); if (cur == AGX_NONE) return; }
+                    if (cur == dst) return;
+                }
+                // more than AGX_MAXE distinct successors: overflow list (duplicates are removed on the host) + flag in the node's byte
+                const agx_u32 i2 = atomicAdd(K.ovf_count, 1u);
+                if (i2 < K.ovf_cap) K.ovf[i2] = agx_edge_ovf{src, dst};
+                const size_t addr = (size_t)(K.S.n_flags + src);
+                atomicOr((agx_u32 *)(addr & ~(size_t)3), (agx_u32)AGX_NF_EOVF << (8u * (agx_u32)(addr & 3)));
+            });
+        }
+    }
 }
 
 // ---- walk preparation: renumber surviving nodes, rewrite edges, mark forced runs (agx_core.h) -------------------------------
@@ -232,7 +274,9 @@ void agx_launch_node_sweep_big(const agx_node_kargs *K, hipStream_t st) {
 }
 void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;
-    if (n) hipLaunchKernelGGL(agx_k_edge_sweep, dim3((n + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
+    if (!n) return;
+    hipLaunchKernelGGL(agx_k_edge_sweep, dim3((n + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
+    hipLaunchKernelGGL(agx_k_edge_slow, dim3(AGX_SLOW_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
 }
 
 void agx_launch_side_count(const agx_compact_args *A, hipStream_t st) {

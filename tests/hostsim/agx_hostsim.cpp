@@ -18,7 +18,7 @@ using namespace agx;
 namespace {
 
 struct SimGraph {
-    std::vector<agx_u32> node_start; std::vector<agx_u8> node_cnt;
+    std::vector<agx_u32> node_start; std::vector<agx_u8> node_cnt, pos_succ;
     std::vector<agx_u32> cid, coff, cid0, coff0, off0, xpos, next;
     std::vector<agx_u8> base, flags; std::vector<agx_sref> sref; std::vector<int> counts;
     std::vector<agx_edge_ovf> ovf;
@@ -54,7 +54,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     std::vector<agx_cmkey> cmk(T.cm.size());
     for (size_t i = 0; i < T.cm.size(); i++) cmk[i] = agx_cmkey{T.cm[i].cid, T.cm[i].coff};
 
-    S.node_start.assign(n_pos, 0); S.node_cnt.assign(n_pos, 0);
+    S.node_start.assign(n_pos, 0); S.node_cnt.assign(n_pos, 0); S.pos_succ.assign(n_pos, 0);
     S.reserve((size_t)n_pos * 2 + 1024);
     agx_sweep_args A; memset(&A, 0, sizeof A);
     A.cm_start = T.cm_start.data(); A.cm = cmk.data(); A.ref = T.ref.data();
@@ -62,7 +62,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     A.tile_off = tile_off.data(); A.tile_hits = tile_hits.data();
     A.n_pos = n_pos; A.n_tiles = n_tiles; A.k = k; A.iv = iv; A.coverage = coverage;
     auto bind = [&]() {
-        A.node_start = S.node_start.data(); A.node_cnt = S.node_cnt.data();
+        A.node_start = S.node_start.data(); A.node_cnt = S.node_cnt.data(); A.pos_succ = S.pos_succ.data();
         A.nk_cid = S.cid.data(); A.nk_coff = S.coff.data(); A.nk_cid0 = S.cid0.data(); A.nk_coff0 = S.coff0.data(); A.nk_off0 = S.off0.data();
         A.n_xpos = S.xpos.data(); A.n_base = S.base.data(); A.n_flags = S.flags.data(); A.n_sref = S.sref.data(); A.n_next = S.next.data();
         A.n_counts = S.counts.data(); A.pool_cap = (agx_u32)S.cid.size();
@@ -73,9 +73,9 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     auto get = [&](agx_u32 i) { return dh[tile_hits[i]]; };
     std::vector<agx_u32> lds((size_t)AGX_NF * maxv_first * AGX_TILE), big;
     for (agx_u32 t = 0; t < n_tiles; t++) {
-        agx_u32 cnt[AGX_TILE]; bool ok = true;
+        agx_u32 cnt[AGX_TILE], pflag[AGX_TILE]; bool ok = true;
         agx_bucket b{nullptr, AGX_TILE, maxv_first};
-        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) { b.base = lds.data() + lane; ok &= agx_node_sweep_lane(A, t, t * AGX_TILE + lane, b, cnt[lane], get); }
+        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) { b.base = lds.data() + lane; ok &= agx_node_sweep_lane(A, t, t * AGX_TILE + lane, b, cnt[lane], pflag[lane], get); }
         agx_u32 *store = lds.data(); agx_u32 maxv = maxv_first;
         if (!ok) {                                     // the fallback the engine runs for overflowed tiles
             n_big_tiles++;
@@ -83,22 +83,33 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
             agx_bucket bb{nullptr, AGX_TILE, maxv};
             for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
                 bb.base = store + lane;
-                if (!agx_node_sweep_lane(A, t, t * AGX_TILE + lane, bb, cnt[lane], get)) throw Error{E_OVERFLOW, "more than AGX_MAXV_BIG node variants at one position"};
+                if (!agx_node_sweep_lane(A, t, t * AGX_TILE + lane, bb, cnt[lane], pflag[lane], get)) throw Error{E_OVERFLOW, "more than AGX_MAXV_BIG node variants at one position"};
             }
         }
         agx_u32 total = 0; for (agx_u32 lane = 0; lane < AGX_TILE; lane++) total += cnt[lane];
         if (pool + total > S.cid.size()) { S.reserve((pool + total) * 2); bind(); }
         agx_bucket wb{nullptr, AGX_TILE, maxv};
-        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) { wb.base = store + lane; agx_node_write_lane(A, t * AGX_TILE + lane, wb, cnt[lane], pool); pool += cnt[lane]; }
+        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) { wb.base = store + lane; agx_node_write_lane(A, t * AGX_TILE + lane, wb, cnt[lane], pool, pflag[lane]); pool += cnt[lane]; }
     }
     S.n_nodes = pool;
+    // edge build: pass A (lanes = positions) collects the slow positions, pass B resolves every hit of their tiles
+    std::vector<agx_u32> slow;
     for (agx_u32 t = 0; t < n_tiles; t++)
         for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
             const agx_u32 X = t * AGX_TILE + lane;
             if (X >= n_pos) continue;
             const agx_u32 nbs = X + 1 < n_pos ? S.node_start[X + 1] : 0, nbc = X + 1 < n_pos ? S.node_cnt[X + 1] : 0;
-            agx_edge_sweep_lane(A, t, X, S.node_start[X], S.node_cnt[X], nbs, nbc, get, [&](agx_u32 s, agx_u32 d) { S.ovf.push_back(agx_edge_ovf{s, d}); });
+            if (agx_edge_fast_lane(A, t, X, S.node_start[X], S.node_cnt[X], nbs, nbc, get, [&](agx_u32 s, agx_u32 d) { S.ovf.push_back(agx_edge_ovf{s, d}); })) slow.push_back(X);
         }
+    for (agx_u32 X : slow) {
+        const agx_u32 t = X / AGX_TILE;
+        for (agx_u32 i = tile_off[t]; i < tile_off[t + 1]; i++)
+            agx_edge_slow_hit(A, X, dh[tile_hits[i]], [&](agx_u32 src, agx_u32 dst) {
+                agx_u32 *slots = S.next.data() + (size_t)src * AGX_MAXE;
+                for (agx_u32 e = 0; e < AGX_MAXE; e++) { if (slots[e] == AGX_NONE) slots[e] = dst; if (slots[e] == dst) return; }
+                S.flags[src] |= AGX_NF_EOVF; S.ovf.push_back(agx_edge_ovf{src, dst});
+            });
+    }
 
     // walk preparation, the same per-element functions the compaction kernels run
     agx_compact_args C; memset(&C, 0, sizeof C);
