@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("AGX_LIB_PATH", os.path.join(_HERE, "libagx.so"))   # 
 
 AGX_OK, AGX_E_IO, AGX_E_FORMAT, AGX_E_UNSUPPORTED, AGX_E_ALIGNMENT, AGX_E_DEVICE, AGX_E_ARG, AGX_E_OVERFLOW, AGX_E_NOGPU = 0, -1, -2, -3, -4, -5, -6, -7, -8
 AGX_FLAG_KEEP_COUNTS = 1
+AGX_FLAG_SPARSE_MIN = 2
 
 # every symbol include/agx.h declares (tests check that the built library exports all of them)
 EXPORTS = [
@@ -56,7 +57,8 @@ class Stats(ctypes.Structure):
                                                 "n_edge_overflow", "pairs_in_file", "sam_line_pairs")] + \
                [(n, ctypes.c_double) for n in ("ms_parse", "ms_thread", "ms_upload", "ms_prep", "ms_bin", "ms_node_sweep", "ms_node_big",
                                                 "ms_edge_sweep", "ms_compact", "ms_download", "ms_walk")] + \
-               [("node_sweep_launches", ctypes.c_uint32), ("edge_sweep_launches", ctypes.c_uint32)]
+               [("node_sweep_launches", ctypes.c_uint32), ("edge_sweep_launches", ctypes.c_uint32)] + \
+               [(n, ctypes.c_uint64) for n in ("n_walk_ids", "n_special", "n_fetched", "download_bytes")]
 
 
 class Graph(ctypes.Structure):
@@ -124,9 +126,9 @@ def _take(res):
 class Unit:
     """One reference unit (chromosome or --part slice): the body of the reference's unit loop, AG:4765-4783."""
 
-    def __init__(self, k=5, insert_variation=50, coverage=20, batch=0, device=0, keep_counts=False):
+    def __init__(self, k=5, insert_variation=50, coverage=20, batch=0, device=0, keep_counts=False, flags=0):
         self._h = ctypes.c_void_p()
-        self.params = Params(k, insert_variation, coverage, batch, device, AGX_FLAG_KEEP_COUNTS if keep_counts else 0)
+        self.params = Params(k, insert_variation, coverage, batch, device, (AGX_FLAG_KEEP_COUNTS if keep_counts else 0) | flags)
         rc = lib().agx_unit_create(ctypes.byref(self.params), ctypes.byref(self._h))
         if rc != AGX_OK:
             self._h = ctypes.c_void_p()

@@ -513,8 +513,21 @@ AGX_HD void agx_edge_slow_hit(const agx_sweep_args &A, agx_u32 X, const agx_dhit
 // per-node record the walk reads at branch points, record starts and record ends: one 32-byte line instead of four arrays
 struct agx_walknode { agx_u32 next[AGX_MAXE]; agx_u32 off0, xpos; agx_sref sref; };
 
-enum { AGX_WM_CONT = 1, AGX_WM_CONTIG = 2, AGX_WM_ABSENT = 128 };   // forced step to id+1; contigOffset != -1 (AG:2004); no node at this id
+// a_meta bits: forced step to id+1; contigOffset != -1 (AG:2004); (main ids) the position has further alive variants in the side
+// block; (main ids) the position holds at least one variant, pruned or not (scaffold gap rule, AG:2428); no node at this id
+enum { AGX_WM_CONT = 1, AGX_WM_CONTIG = 2, AGX_WM_SIDE = 4, AGX_WM_ANY = 8, AGX_WM_ABSENT = 128 };
 
+// The host walk reads a node's 32-byte record only where a walk can start, stop, branch or land: everything inside a forced run is
+// covered by the meta and base bytes.  The device therefore hands over a SPARSE record table: the records of the "special" ids in id
+// order, a bitmap of which ids are special and a per-64-ids rank (popcount prefix) to find a record.  Special ids are
+//   - every side id (their position is read from the record),
+//   - every id without the cont bit (branch points, dead ends) and every id whose predecessor id lacks it (run heads: the only
+//     places the position scan of AG:1972-1978 can start a walk, since a cont predecessor drags its successor along),
+//   - every edge target of an id without the cont bit, and the id just before such a target (a run stops in front of a node that a
+//     jump has already visited),
+//   - every main id of a position where a conti-mer chain ends (the hop back onto the k-mer graph, AG:2093-2136, reads the node there).
+// The one place a walk stands anywhere else is after the reference's +1000 position skip inside long records (AG:2194-2202), which
+// can start a walk in the middle of a forced run; the host then fetches that record from the full table that stays on the device.
 struct agx_compact_args {
     // node table, old ids
     const agx_u32 *node_start; const agx_u8 *node_cnt; const agx_u8 *n_flags; const agx_u8 *n_base; const agx_u32 *n_xpos;
@@ -526,6 +539,11 @@ struct agx_compact_args {
     // outputs indexed by aid, [n_pos + n_side]
     char *a_str; agx_u8 *a_meta; agx_walknode *a_node;   // a_meta: AGX_WM_* bits
     const agx_edge_ovf *ovf; agx_u32 n_ovf; agx_edge_ovf *a_ovf;   // overflow edges rewritten in aids (edges touching pruned nodes become NONE/NONE)
+    agx_u8 *a_mark;                // [n_ids+1] zeroed before; 1 = edge target of a non-cont id, or main id of a chain-end position
+    agx_u32 *side_xpos;            // [n_side] position of every side id (sorted: the side block is position-major)
+    // sparse record table
+    agx_u32 n_ids, sparse_min;     // sparse_min (test hook): only the side ids are special, every other record comes through the fetch path
+    unsigned long long *sp_bits; agx_u32 *sp_cnt; const agx_u32 *sp_rank; agx_walknode *sp_node;
 };
 
 AGX_HD void agx_side_count_pos(const agx_compact_args &A, agx_u32 X) {
@@ -543,7 +561,7 @@ AGX_HD void agx_assign_aid_pos(const agx_compact_args &A, agx_u32 X) {
         if (A.n_flags[s + v] & AGX_NF_DEAD) { A.aid_of[s + v] = AGX_NONE; continue; }
         if (first) { A.aid_of[s + v] = X; first = false; } else A.aid_of[s + v] = side++;
     }
-    if (first) { A.a_meta[X] = AGX_WM_ABSENT; A.a_str[X] = 'N'; agx_walknode w; for (agx_u32 e = 0; e < AGX_MAXE; e++) w.next[e] = AGX_NONE; w.off0 = AGX_NONE; w.xpos = X; w.sref = agx_sref{0, 0}; A.a_node[X] = w; }
+    if (first) { A.a_meta[X] = (agx_u8)(AGX_WM_ABSENT | (n ? AGX_WM_ANY : 0)); A.a_str[X] = 'N'; agx_walknode w; for (agx_u32 e = 0; e < AGX_MAXE; e++) w.next[e] = AGX_NONE; w.off0 = AGX_NONE; w.xpos = X; w.sref = agx_sref{0, 0}; A.a_node[X] = w; }
 }
 
 // per old node: write its record at its walk id
@@ -564,7 +582,12 @@ AGX_HD void agx_emit_alive_node(const agx_compact_args &A, agx_u32 v) {
     }
     // a node whose edges spilled to the overflow list keeps all four slots... unless some pointed at pruned nodes: mark it
     // by never being `cont`; the host consults the overflow list for every node it finds there
-    A.a_meta[a] = (agx_u8)(((k == 1 && !(A.n_flags[v] & AGX_NF_EOVF) && w.next[0] == a + 1) ? AGX_WM_CONT : 0) | ((A.n_flags[v] & AGX_NF_CONTIG) ? AGX_WM_CONTIG : 0));
+    const bool cont = k == 1 && !(A.n_flags[v] & AGX_NF_EOVF) && w.next[0] == a + 1;
+    agx_u8 m = (agx_u8)((cont ? AGX_WM_CONT : 0) | ((A.n_flags[v] & AGX_NF_CONTIG) ? AGX_WM_CONTIG : 0));
+    if (a < A.n_pos) m |= (agx_u8)(AGX_WM_ANY | (A.side_start[x + 1] > A.side_start[x] ? AGX_WM_SIDE : 0));
+    else A.side_xpos[a - A.n_pos] = x;
+    A.a_meta[a] = m;
+    if (!cont) for (agx_u32 e = 0; e < k; e++) A.a_mark[w.next[e]] = 1;      // racing stores of the same value
     for (; k < AGX_MAXE; k++) w.next[k] = AGX_NONE;
     A.a_node[a] = w;
 }
@@ -573,4 +596,15 @@ AGX_HD void agx_emit_alive_ovf(const agx_compact_args &A, agx_u32 i) {
     if (i >= A.n_ovf) return;
     const agx_u32 s = A.aid_of[A.ovf[i].src], d = A.aid_of[A.ovf[i].dst];
     A.a_ovf[i] = (s == AGX_NONE || d == AGX_NONE) ? agx_edge_ovf{AGX_NONE, AGX_NONE} : agx_edge_ovf{s, d};
+    if (s != AGX_NONE && d != AGX_NONE) A.a_mark[d] = 1;      // the source spilled, so it is never cont
+}
+
+// is walk id a special (does its record go into the sparse table)?  Runs after every a_meta / a_mark store of the unit.
+AGX_HD bool agx_special_id(const agx_compact_args &A, agx_u32 a) {
+    if (a >= A.n_ids) return false;
+    const agx_u8 m = A.a_meta[a];
+    if (m & AGX_WM_ABSENT) return false;
+    if (a >= A.n_pos) return true;
+    if (A.sparse_min) return false;
+    return !(m & AGX_WM_CONT) || a == 0 || !(A.a_meta[a - 1] & AGX_WM_CONT) || A.a_mark[a] || A.a_mark[a + 1];
 }

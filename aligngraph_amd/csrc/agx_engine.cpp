@@ -70,10 +70,12 @@ struct agx_unit {
     // walk graph (agx_core.h "walk preparation")
     agx_u32 n_ids = 0;
     DBuf<agx_u32> d_side_cnt, d_side_start, d_aid_of; DBuf<char> d_a_str;
-    DBuf<agx_u8> d_a_meta; DBuf<agx_walknode> d_a_node; DBuf<agx_edge_ovf> d_a_ovf;
-    // downloaded
-    PBuf<agx_u32> h_side_start; PBuf<char> h_a_str; PBuf<agx_u8> h_node_cnt, h_a_meta;
-    PBuf<agx_walknode> h_a_node; PBuf<agx_edge_ovf> h_a_ovf;
+    DBuf<agx_u8> d_a_meta, d_a_mark; DBuf<agx_walknode> d_a_node, d_sp_node; DBuf<agx_edge_ovf> d_a_ovf;
+    DBuf<agx_u32> d_chain_end, d_side_xpos, d_sp_cnt, d_sp_rank; DBuf<unsigned long long> d_sp_bits;
+    agx_u32 n_chain_end = 0, n_special = 0, n_words = 0;
+    // downloaded: the walk graph with its sparse record table (agx_core.h); the full record table stays on the device
+    PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
+    PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_edge_ovf> h_a_ovf;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0;
     EventPair ev_prep, ev_bin, ev_node, ev_big, ev_edge, ev_compact;
@@ -127,7 +129,12 @@ void do_upload(agx_unit *u) {
     u->d_tile_cnt.alloc((size_t)u->n_tiles + 1); u->d_tile_off.alloc((size_t)u->n_tiles + 2); u->d_cursor.alloc((size_t)u->n_tiles + 1);
     const size_t nb = ((size_t)n_pos + 1 + 1023) / 1024;              // sized for the longer of the two scans (positions)
     u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16);
-    u->d_words.alloc(W_N); u->h_words.alloc(W_N + 4);
+    u->d_words.alloc(W_N); u->h_words.alloc(W_N + 4); u->h_fetch.alloc(2 * (n_pos / 1000 + 2));
+    {   // positions where a conti-mer chain ends: their main walk ids belong to the sparse record table (agx_core.h)
+        std::vector<agx_u32> ce(u->T.chain_end_pos); std::sort(ce.begin(), ce.end()); ce.erase(std::unique(ce.begin(), ce.end()), ce.end());
+        u->n_chain_end = (agx_u32)ce.size(); u->d_chain_end.alloc(ce.size() + 1);
+        if (!ce.empty()) HIP_OK(hipMemcpy(u->d_chain_end.p, ce.data(), ce.size() * 4, hipMemcpyHostToDevice));
+    }
     u->d_node_start.alloc(n_pos); u->d_node_cnt.alloc(n_pos); u->d_pos_succ.alloc(n_pos); u->d_slow_list.alloc(n_pos + 64);
     if (u->pool_cap == 0) alloc_pool(u, (agx_u32)std::min<size_t>(2 * n_pos + 4096, 0xFFFFFF00ull));
     if (u->ovf_cap == 0) { u->ovf_cap = 1u << 16; u->d_ovf.alloc(u->ovf_cap); }
@@ -155,6 +162,11 @@ void do_build(agx_unit *u) {
         const size_t ids_cap = (size_t)n_pos + u->pool_cap;                       // side variants <= nodes <= pool_cap
         u->d_a_str.alloc(ids_cap + 1); u->d_a_meta.alloc(ids_cap + 16); u->d_a_node.alloc(ids_cap + 1); u->d_a_ovf.alloc((size_t)u->ovf_cap + 1);
         u->d_side_cnt.alloc((size_t)n_pos + 2); u->d_side_start.alloc((size_t)n_pos + 2);
+        u->n_words = (agx_u32)(ids_cap / 64 + 1);
+        u->d_a_mark.alloc(ids_cap + 2); u->d_side_xpos.alloc((size_t)u->pool_cap + 1); u->d_sp_node.alloc(ids_cap + 1);
+        u->d_sp_bits.alloc((size_t)u->n_words + 1); u->d_sp_cnt.alloc((size_t)u->n_words + 1); u->d_sp_rank.alloc((size_t)u->n_words + 2);
+        {   const size_t nb = ((size_t)std::max<size_t>(n_pos, u->n_words) + 1 + 1023) / 1024;
+            u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16); }
 
         HIP_OK(hipMemsetAsync(u->d_words.p, 0, W_N * 4, st));
         HIP_OK(hipMemsetAsync(u->d_tile_cnt.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
@@ -194,15 +206,22 @@ void do_build(agx_unit *u) {
         C.side_cnt = u->d_side_cnt.p; C.side_start = u->d_side_start.p; C.aid_of = u->d_aid_of.p;
         C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_node = u->d_a_node.p; C.ovf = u->d_ovf.p; C.n_ovf = 0; C.a_ovf = u->d_a_ovf.p;
         HIP_OK(hipEventRecord(u->ev_compact.a, st));
+        C.a_mark = u->d_a_mark.p; C.side_xpos = u->d_side_xpos.p; C.sparse_min = (u->prm.flags & AGX_FLAG_SPARSE_MIN) ? 1u : 0u;
+        C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p;
         HIP_OK(hipMemsetAsync(u->d_side_cnt.p + n_pos, 0, 4, st));
+        HIP_OK(hipMemsetAsync(u->d_a_mark.p, 0, ids_cap + 2, st));
+        HIP_OK(hipMemsetAsync(u->d_sp_cnt.p + u->n_words, 0, 4, st));
         agx_launch_side_count(&C, st);
         agx_launch_exclusive_scan(u->d_side_cnt.p, u->d_side_start.p, n_pos, u->d_scan_tmp.p, st);
+        agx_launch_mark_list(u->d_chain_end.p, u->n_chain_end, u->d_a_mark.p, st);
         agx_launch_compact(&C, u->d_words.p + W_POOL, u->pool_cap, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
+        agx_launch_special(&C, u->n_words, u->d_sp_rank.p, u->d_scan_tmp.p, st);
         HIP_OK(hipEventRecord(u->ev_compact.b, st)); u->ev_compact.used = true;
         // ---- the one synchronisation ----
         HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, W_N * 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(u->h_words.p + W_N, u->d_tile_off.p + u->n_tiles, 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(u->h_words.p + W_N + 1, u->d_side_start.p + n_pos, 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_words.p + W_N + 2, u->d_sp_rank.p + u->n_words, 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         HIP_OK(hipGetLastError());
         const agx_u32 *w = u->h_words.p;
@@ -218,6 +237,7 @@ void do_build(agx_unit *u) {
             u->d_cid.release(); u->d_coff.release(); u->d_cid0.release(); u->d_coff0.release(); u->d_off0.release(); u->d_xpos.release();
             u->d_next.release(); u->d_base.release(); u->d_flags.release(); u->d_sref.release(); u->d_counts.release();
             u->d_aid_of.release(); u->d_a_str.release(); u->d_a_meta.release(); u->d_a_node.release();
+            u->d_a_mark.release(); u->d_side_xpos.release(); u->d_sp_node.release(); u->d_sp_bits.release(); u->d_sp_cnt.release(); u->d_sp_rank.release();
             alloc_pool(u, (agx_u32)cap);
             continue;
         }
@@ -225,7 +245,7 @@ void do_build(agx_unit *u) {
         u->n_nodes = (agx_u32)want; u->n_big = w[W_BIGCOUNT]; u->n_ovf = w[W_OVFCOUNT];
         const unsigned long long ids = (unsigned long long)n_pos + w[W_N + 1];
         if (ids >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "walk graph exceeds 2^32 ids"};
-        u->n_ids = (agx_u32)ids;
+        u->n_ids = (agx_u32)ids; u->n_special = w[W_N + 2];
         break;
     }
     u->built = true; u->downloaded = false;
@@ -238,26 +258,47 @@ void do_download(agx_unit *u) {
     const double t0 = now_ms();
     const size_t n_pos = u->T.ref.size(), ni = u->n_ids;
     hipStream_t st = u->st;
-    u->h_side_start.alloc(n_pos + 1); u->h_node_cnt.alloc(n_pos);
-    u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 16); u->h_a_node.alloc(ni + 1);
+    const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
+    u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 16); u->h_side_xpos.alloc(nside + 1);
+    u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1);
     u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
-    HIP_OK(hipMemcpyAsync(u->h_side_start.p, u->d_side_start.p, (n_pos + 1) * 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(u->h_node_cnt.p, u->d_node_cnt.p, n_pos, hipMemcpyDeviceToHost, st));
     if (ni) {
         HIP_OK(hipMemcpyAsync(u->h_a_str.p, u->d_a_str.p, ni, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(u->h_a_meta.p, u->d_a_meta.p, ni, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_a_node.p, u->d_a_node.p, ni * sizeof(agx_walknode), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_sp_bits.p, u->d_sp_bits.p, nw * 8, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_sp_rank.p, u->d_sp_rank.p, nw * 4, hipMemcpyDeviceToHost, st));
     }
+    if (nside) HIP_OK(hipMemcpyAsync(u->h_side_xpos.p, u->d_side_xpos.p, nside * 4, hipMemcpyDeviceToHost, st));
+    if (ns) HIP_OK(hipMemcpyAsync(u->h_sp_node.p, u->d_sp_node.p, ns * sizeof(agx_walknode), hipMemcpyDeviceToHost, st));
     if (u->n_ovf) HIP_OK(hipMemcpyAsync(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     memset(u->h_a_meta.p + ni, 0, 16);
+    u->stats.n_walk_ids = ni; u->stats.n_special = ns;
+    u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * sizeof(agx_walknode) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
     u->downloaded = true;
     u->stats.ms_download = now_ms() - t0;
 }
 
+// records of non-special walk ids, straight from the full table in HBM (agx_core.h "walk preparation"): one strided copy
+void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *out) {
+    agx_unit *u = (agx_unit *)ctx;
+    const size_t n = (size_t)rows * width;
+    if (!n) return;
+    if ((size_t)first + (size_t)(rows - 1) * stride + width > u->n_ids) throw Error{E_ARG, "record fetch beyond the walk graph"};
+    HIP_OK(hipSetDevice(u->prm.device));
+    u->h_fetch.alloc(n);
+    if (rows == 1) HIP_OK(hipMemcpyAsync(u->h_fetch.p, u->d_a_node.p + first, n * sizeof(agx_walknode), hipMemcpyDeviceToHost, u->st));
+    else HIP_OK(hipMemcpy2DAsync(u->h_fetch.p, width * sizeof(agx_walknode), u->d_a_node.p + first, (size_t)stride * sizeof(agx_walknode),
+                                  width * sizeof(agx_walknode), rows, hipMemcpyDeviceToHost, u->st));
+    HIP_OK(hipStreamSynchronize(u->st));
+    memcpy(out, u->h_fetch.p, n * sizeof(agx_walknode));
+}
+
 GraphView view_of(agx_unit *u) {
-    GraphView G; G.n_pos = (agx_u32)u->T.ref.size(); G.n_ids = u->n_ids; G.side_start = u->h_side_start.p; G.node_cnt = u->h_node_cnt.p;
-    G.meta = u->h_a_meta.p; G.str = u->h_a_str.p; G.node = u->h_a_node.p;
+    GraphView G; G.n_pos = (agx_u32)u->T.ref.size(); G.n_ids = u->n_ids;
+    G.meta = u->h_a_meta.p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
+    G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.n_special = u->n_special;
+    G.fetch = fetch_records; G.fetch_ctx = u;
     G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf;
     return G;
 }
@@ -382,7 +423,7 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
         if (!u->downloaded) do_download(u);
         const double t0 = now_ms();
         UnitOutput O; walk_join_scaffold(u->T, u->P, view_of(u), O);
-        u->stats.ms_walk = now_ms() - t0;
+        u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = O.n_fetched;
         r->initial_contigs = dup_buf(u->T.initial_contigs); r->initial_len = u->T.initial_contigs.size();
         r->pre_len = O.pre_extended.n; r->pre_extended = O.pre_extended.release();
         r->extended_len = O.extended.n; r->extended = O.extended.release();

@@ -49,14 +49,18 @@ struct Pairs {
 };
 
 // Walk graph as downloaded from the device (or produced by the test executor); see agx_core.h "walk preparation".
-// Walk ids: [0, n_pos) = first alive variant of each position (absent[] = 1 where there is none), [n_pos, n_ids) = further variants.
+// Walk ids: [0, n_pos) = first alive variant of each position (AGX_WM_ABSENT where there is none), [n_pos, n_ids) = further variants.
+// Node records come as the sparse table of the special ids; any other id (only reachable after the +1000 skip) goes through fetch().
 struct GraphView {
     agx_u32 n_pos = 0, n_ids = 0;
-    const agx_u32 *side_start = nullptr;                    // [n_pos+1] side variants of position x are n_pos+side_start[x] .. n_pos+side_start[x+1]
-    const agx_u8 *node_cnt = nullptr;                       // [n_pos] ALL variants incl. pruned ones (scaffold gap rule, AG:2428)
     const agx_u8 *meta = nullptr;                           // [n_ids + 16] AGX_WM_* bits (padding reads as 0)
     const char *str = nullptr;                              // [n_ids] base a node emits
-    const agx_walknode *node = nullptr;                     // [n_ids] alive successors (NONE padded), mate offset, position, k-mer reference
+    const agx_u32 *side_xpos = nullptr;                     // [n_ids - n_pos] position of each side id, non-decreasing
+    const unsigned long long *sp_bits = nullptr;            // [n_ids/64 + 1] special-id bitmap
+    const agx_u32 *sp_rank = nullptr;                       // [n_ids/64 + 1] special ids before each 64-id word
+    const agx_walknode *sp_node = nullptr; agx_u32 n_special = 0;   // records of the special ids, id order
+    // records of non-special ids: `rows` groups of `width` consecutive ids, group r starting at first + r*stride, into out[rows*width]
+    void (*fetch)(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *out) = nullptr; void *fetch_ctx = nullptr;
     const agx_edge_ovf *ovf = nullptr; size_t n_ovf = 0;     // walk ids; NONE/NONE entries and duplicates are ignored
 };
 
@@ -70,7 +74,7 @@ struct OutBuf {
     void append(const char *s, size_t len) { memcpy(grow(len), s, len); }
     char *release() { if (!p) reserve(0); p[n] = 0; char *r = p; p = nullptr; n = cap = 0; return r; }
 };
-struct UnitOutput { OutBuf pre_extended, extended; };
+struct UnitOutput { OutBuf pre_extended, extended; unsigned long long n_fetched = 0; };
 
 // agx_host.cpp
 void load_unit_reference(const std::string &path, std::string &ref);

@@ -41,5 +41,7 @@ void agx_launch_edge_sweep(const agx_edge_kargs *, hipStream_t);          // pas
 // from the walk preparation; the grids are sized by the capacities.
 void agx_launch_side_count(const agx_compact_args *, hipStream_t);
 void agx_launch_compact(const agx_compact_args *, const agx_u32 *n_nodes_dev, agx_u32 pool_cap, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t);
+void agx_launch_mark_list(const agx_u32 *list, agx_u32 n, agx_u8 *mark, hipStream_t);
+void agx_launch_special(const agx_compact_args *, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, hipStream_t);
 #define AGX_BIG_WAVES 256u      // resident wavefronts of the global-scratch fallback pass
 }

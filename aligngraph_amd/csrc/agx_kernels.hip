@@ -232,6 +232,28 @@ __global__ void __launch_bounds__(256) agx_k_emit_ovf(agx_compact_args A, const 
     const agx_u32 n = *n_ovf_dev; A.n_ovf = n < ovf_cap ? n : ovf_cap; agx_emit_alive_ovf(A, blockIdx.x * 256u + threadIdx.x);
 }
 
+// chain-end positions (host list) -> a_mark
+__global__ void __launch_bounds__(256) agx_k_mark_list(const agx_u32 *list, agx_u32 n, agx_u8 *mark) {
+    const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) mark[list[i]] = 1;
+}
+// one wave per 64 ids: the special-id bitmap word and its popcount (input of the rank scan); words past n_ids are written as zero
+__global__ void __launch_bounds__(256) agx_k_special_bits(agx_compact_args A, agx_u32 n_words) {
+    A.n_ids = A.n_pos + A.side_start[A.n_pos];
+    const agx_u32 a = blockIdx.x * 256u + threadIdx.x, w = a >> 6;
+    if (w >= n_words) return;                                                   // wave-uniform
+    const unsigned long long bits = __ballot(agx_special_id(A, a));
+    if ((threadIdx.x & 63u) == 0) { A.sp_bits[w] = bits; A.sp_cnt[w] = (agx_u32)__popcll(bits); }
+}
+// gather the special records in id order
+__global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, agx_u32 n_words) {
+    const agx_u32 a = blockIdx.x * 256u + threadIdx.x, w = a >> 6;
+    if (w >= n_words) return;
+    const unsigned long long bits = A.sp_bits[w];
+    const agx_u32 lane = threadIdx.x & 63u;
+    if ((bits >> lane) & 1ull) A.sp_node[A.sp_rank[w] + (agx_u32)__popcll(bits & ((1ull << lane) - 1ull))] = A.a_node[a];
+}
+
 // ---- host-callable launchers (kept in this translation unit so that the engine is plain C++) -------------------------
 extern "C" {
 
@@ -286,6 +308,17 @@ void agx_launch_compact(const agx_compact_args *A, const agx_u32 *n_nodes_dev, a
     if (A->n_pos) hipLaunchKernelGGL(agx_k_assign_aid, dim3((A->n_pos + 255) / 256), dim3(256), 0, st, *A);
     if (pool_cap) hipLaunchKernelGGL(agx_k_emit_alive, dim3((pool_cap + 255) / 256), dim3(256), 0, st, *A, n_nodes_dev);
     if (ovf_cap) hipLaunchKernelGGL(agx_k_emit_ovf, dim3((ovf_cap + 255) / 256), dim3(256), 0, st, *A, n_ovf_dev, ovf_cap);
+}
+void agx_launch_mark_list(const agx_u32 *list, agx_u32 n, agx_u8 *mark, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(agx_k_mark_list, dim3((n + 255) / 256), dim3(256), 0, st, list, n, mark);
+}
+// sparse record table over n_words 64-id words (the id capacity; the live id count is read on the device); scan_tmp as for the scans
+void agx_launch_special(const agx_compact_args *A, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, hipStream_t st) {
+    if (!n_words) return;
+    const agx_u32 blocks = (agx_u32)(((unsigned long long)n_words * 64u + 255u) / 256u);
+    hipLaunchKernelGGL(agx_k_special_bits, dim3(blocks), dim3(256), 0, st, *A, n_words);
+    agx_launch_exclusive_scan(A->sp_cnt, sp_rank, n_words, scan_tmp, st);
+    hipLaunchKernelGGL(agx_k_special_emit, dim3(blocks), dim3(256), 0, st, *A, n_words);
 }
 
 }  // extern "C"

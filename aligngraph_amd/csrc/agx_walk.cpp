@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 
 namespace agx {
 namespace {
@@ -45,10 +46,46 @@ struct Walker {
         std::sort(ovf.begin(), ovf.end(), [](const agx_edge_ovf &a, const agx_edge_ovf &b) { return a.src != b.src ? a.src < b.src : a.dst < b.dst; });
         ovf.erase(std::unique(ovf.begin(), ovf.end(), [](const agx_edge_ovf &a, const agx_edge_ovf &b) { return a.src == b.src && a.dst == b.dst; }), ovf.end());
     }
+    // record of node v: from the sparse table of special ids, else (a walk started inside a forced run after the +1000 skip,
+    // agx_core.h) from the full table through the fetch hook
+    mutable unsigned long long n_fetched = 0;
+    mutable std::unordered_map<agx_u32, agx_walknode> extra;      // records fetched so far (a few per 1000 positions of long records)
+    mutable std::vector<agx_walknode> rows;
+    agx_walknode node(agx_u32 v) const {
+        const unsigned long long w = G.sp_bits[v >> 6], bit = 1ull << (v & 63u);
+        if (w & bit) return G.sp_node[G.sp_rank[v >> 6] + (agx_u32)__builtin_popcountll(w & (bit - 1))];
+        const auto it = extra.find(v);
+        if (it != extra.end()) return it->second;
+        if (!G.fetch) throw Error{E_ARG, "walk graph without a record fetch hook"};
+        agx_walknode r; G.fetch(G.fetch_ctx, v, 1, 1, 1, &r); n_fetched++;
+        extra.emplace(v, r);
+        return r;
+    }
+    // A record longer than 100 kb was just written while the scan stands at cp: the scan will now sample every 1000th position up to
+    // its end (AG:2194-2202) and may start walks in the middle of forced runs there.  Those main ids, and the ids right before them
+    // (where a later run stops in front of them), are not in the sparse table: get them in one strided copy.
+    void prefetch_skip_positions(agx_u32 cp, agx_u32 end) const {
+        if (!G.fetch || cp + 1000 >= end) return;
+        const agx_u32 n = (end - cp - 1) / 1000;                   // cp + 1000*i < end for i = 1..n
+        rows.resize((size_t)n * 2);
+        G.fetch(G.fetch_ctx, cp + 999, 1000, n, 2, rows.data());
+        for (agx_u32 i = 0; i < n; i++) { extra.emplace(cp + 999 + i * 1000, rows[2 * (size_t)i]); extra.emplace(cp + 1000 + i * 1000, rows[2 * (size_t)i + 1]); }
+    }
+    agx_u32 pos_of(agx_u32 v) const { return v < G.n_pos ? v : G.side_xpos[v - G.n_pos]; }      // main ids are positions
+    // side ids of position x: [lo, hi)
+    void side_range(agx_u32 x, agx_u32 &lo, agx_u32 &hi) const {
+        if (!(G.meta[x] & AGX_WM_SIDE)) { lo = hi = G.n_pos; return; }
+        const agx_u32 *b = G.side_xpos, *e = G.side_xpos + (G.n_ids - G.n_pos);
+        const agx_u32 *l = std::lower_bound(b, e, x), *h = l;
+        while (h < e && *h == x) h++;
+        lo = G.n_pos + (agx_u32)(l - b); hi = G.n_pos + (agx_u32)(h - b);
+    }
     // number of live (unvisited) successors of node v, capped at 2; target = the last one seen (AG:2020-2033)
     int live_successors(agx_u32 v, agx_u32 &target) const {
+        if (G.meta[v] & AGX_WM_CONT) { if (done[v + 1]) return 0; target = v + 1; return 1; }      // its only alive successor is v+1
         int n = 0;
-        const agx_u32 *s = G.node[v].next;
+        const agx_walknode rec = node(v);
+        const agx_u32 *s = rec.next;
         for (agx_u32 e = 0; e < AGX_MAXE && s[e] != AGX_NONE; e++) if (!done[s[e]]) { target = s[e]; if (++n > 1) return n; }
         if (!ovf.empty()) {                             // nodes with more than AGX_MAXE out-edges (rare): the rest is in the overflow list
             auto it = std::lower_bound(ovf.begin(), ovf.end(), v, [](const agx_edge_ovf &a, agx_u32 key) { return a.src < key; });
@@ -61,7 +98,7 @@ struct Walker {
     }
     // k-mer string of node v from its read reference (agx_sref)
     void kmer_string(agx_u32 v, std::string &out) const {
-        const agx_sref r = G.node[v].sref;
+        const agx_sref r = node(v).sref;
         const agx_u32 first = r.qlen & 0xFFFFu, len = (r.qlen >> 16) & 0x7FFFu; const bool rev = (r.qlen >> 31) != 0;
         out.clear();
         const char *p = P.bases.data() + (size_t)r.slot * P.stride;
@@ -91,15 +128,19 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
     pre_out.reserve((size_t)G.n_ids + G.n_ids / 32 + 4096);
     agx_u8 *done = W.done.data();
     unsigned long long n_walks = 0, n_hops = 0, n_runs = 0, n_general = 0, run_nodes = 0;
+    const agx_u32 n_side = G.n_ids - G.n_pos;
+    agx_u32 sc = 0;                              // side index cursor: every side id before it lies at a position < cp
     for (agx_u32 cp = 0; cp < G.n_pos;) {
         // variants of position cp in order: its main slot, then its side range
-        const agx_u32 s_lo = G.n_pos + G.side_start[cp], s_hi = G.n_pos + G.side_start[cp + 1];
+        while (sc < n_side && G.side_xpos[sc] < cp) sc++;
+        agx_u32 sh = sc; while (sh < n_side && G.side_xpos[sh] == cp) sh++;
+        const agx_u32 s_lo = G.n_pos + sc, s_hi = G.n_pos + sh;
         for (agx_u32 vi = 0, start = cp; vi <= s_hi - s_lo; vi++, start = s_lo + vi - 1) {
             if (done[start]) continue;
             Rec C; C.sID = 0; C.sOff = cp; C.extended = 0;
             segs.clear(); n_walks++;
             agx_u32 cur = start;                 // current k-mer node (mode 1)
-            C.sID0 = G.node[cur].off0 == AGX_NONE ? AGX_NONE : 0; C.sOff0 = G.node[cur].off0;
+            { const agx_u32 o = W.node(cur).off0; C.sID0 = o == AGX_NONE ? AGX_NONE : 0; C.sOff0 = o; }
             agx_u32 cpp = cp; int mode = 1;               // mode = kMerTag
             agx_u32 last = cur;
             while ((mode == 1 && !done[cur]) || mode == 0) {
@@ -111,10 +152,11 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
                     pos_bak = h.end_pos; cpp = h.end_pos;
                     agx_u32 live = 0, item = 0;
                     if (!done[cpp]) { live++; item = cpp; }
-                    for (agx_u32 v = G.n_pos + G.side_start[cpp]; v < G.n_pos + G.side_start[cpp + 1]; v++) if (!done[v]) { live++; item = v; }
+                    agx_u32 h_lo, h_hi; W.side_range(cpp, h_lo, h_hi);
+                    for (agx_u32 v = h_lo; v < h_hi; v++) if (!done[v]) { live++; item = v; }
                     agx_u32 tgt = 0; int ns = 0;
                     if (live == 1) ns = W.live_successors(item, tgt);
-                    if (ns == 1) { cur = tgt; pos_bak = tgt < G.n_pos ? tgt : G.node[tgt].xpos; cpp = pos_bak; mode = done[cur] ? -2 : 1; }
+                    if (ns == 1) { cur = tgt; pos_bak = W.pos_of(tgt); cpp = pos_bak; mode = done[cur] ? -2 : 1; }
                     else mode = -2;
                 } else {                                    // on a k-mer node, AG:1995-2060
                     // forced run: while the cont bit holds and the next node is unvisited the reference steps cur -> cur+1 (its unique live
@@ -132,12 +174,12 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
                     segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!(G.meta[j] & AGX_WM_CONT)) n_general++;
                     if (seen & AGX_WM_CONTIG) C.extended = 1;
                     memset(done + cur, 1, (size_t)j - cur + 1);
-                    const agx_u32 xj = j < G.n_pos ? j : G.node[j].xpos;      // main ids are positions
+                    const agx_u32 xj = W.pos_of(j);
                     if (j > cur) pos_bak = xj;
                     cur = j; last = j; cpp = xj;
                     agx_u32 tgt = 0;
                     const int ns = (G.meta[cur] & AGX_WM_CONT) ? 0 : W.live_successors(cur, tgt);      // cont && stopped: its only alive successor is already visited
-                    if (ns == 1) { cur = tgt; pos_bak = tgt < G.n_pos ? tgt : G.node[tgt].xpos; cpp = pos_bak; }
+                    if (ns == 1) { cur = tgt; pos_bak = W.pos_of(tgt); cpp = pos_bak; }
                     else if (T.hop[cpp].len) mode = 0;                          // exactly one conti-mer here and it has a next (AG:2047-2057)
                     else mode = -1;
                 }
@@ -145,7 +187,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
             // end bookkeeping, AG:2142-2173
             C.eID = 0; C.eOff = mode == 1 ? pos_bak : cpp;
             if (mode == 1 || mode == -1) {
-                C.eID0 = G.node[cur].off0 == AGX_NONE ? AGX_NONE : 0; C.eOff0 = G.node[cur].off0;
+                { const agx_u32 o = W.node(cur).off0; C.eID0 = o == AGX_NONE ? AGX_NONE : 0; C.eOff0 = o; }
                 W.kmer_string(last, kmer);
                 if (kmer.size() > 1) segs.push_back(Seg{kmer.data() + 1, kmer.size() - 1});
                 C.eOff = C.eOff + (agx_u32)kmer.size() - 1; C.eOff0 = C.eOff0 + (agx_u32)kmer.size() - 1;
@@ -159,6 +201,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
                 char *w = pre_out.grow((size_t)hl + total + lines); memcpy(w, hdr, (size_t)hl); w += hl;
                 for (size_t i = 0; i < total; i += 60) { const size_t m = total - i < 60 ? total - i : 60; memcpy(w, C.nuc.data() + i, m); w += m; *w++ = '\n'; }
                 sIDBak = C.sID; sOffBak = C.sOff; eIDBak = C.eID; eOffBak = C.eOff;
+                if (eOffBak - sOffBak > 100000) W.prefetch_skip_positions(cp, eOffBak < G.n_pos ? eOffBak : G.n_pos);
                 written.push_back(std::move(C));
             }
         }
@@ -169,8 +212,8 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
             // the +1000 rule is re-evaluated at every position on the way, but it can only switch ON again after a new record is
             // written, which needs an unvisited node: skipping node-less positions one by one or at once is the same
             const agx_u32 m = W.next_live(cp + 1, G.n_pos);                                  // main slot id == position
-            const agx_u32 sd = W.next_live(G.n_pos + G.side_start[cp + 1], G.n_ids);
-            const agx_u32 sp = sd < G.n_ids ? G.node[sd].xpos : G.n_pos;
+            const agx_u32 sd = W.next_live(s_hi, G.n_ids);
+            const agx_u32 sp = sd < G.n_ids ? G.side_xpos[sd - G.n_pos] : G.n_pos;
             cp = m < sp ? m : sp;
         }
     }
@@ -226,7 +269,7 @@ void scaffold(const Threads &T, const GraphView &G, std::vector<Rec> &c, OutBuf 
                 if (!(c[cp].eID0 == c[q].sID && c[q].sID == c[q].eID && overlaps(c[cp].sOff0, c[cp].eOff0, c[q].sOff, c[q].eOff) && c[q].extended == 1)) continue;
                 if (c[q].sOff > c[cp].eOff) {
                     const agx_u32 gap = c[q].sOff - c[cp].eOff - 1; agx_u32 covered = 0;
-                    for (agx_u32 i = 0; i < gap; i++) { const agx_u32 x = c[cp].eOff + i + 1; if (G.node_cnt[x] > 0 || T.cm_start[x + 1] > T.cm_start[x]) covered++; }
+                    for (agx_u32 i = 0; i < gap; i++) { const agx_u32 x = c[cp].eOff + i + 1; if ((G.meta[x] & AGX_WM_ANY) || T.cm_start[x + 1] > T.cm_start[x]) covered++; }
                     if (gap == 0 || (double)(int)covered / gap >= 0.5) sc.back().append(T.ref, c[cp].eOff + 1, gap);
                     else continue;
                 }
@@ -298,7 +341,8 @@ void walk_join_scaffold(const Threads &T, const Pairs &P, const GraphView &G, Un
     double t2 = now();
     scaffold(T, G, recs, out.extended);
     double t3 = now();
-    if (timing) fprintf(stderr, "[agx walk] walk %.1f ms, join %.1f ms, scaffold %.1f ms, %zu records\n", t1 - t0, t2 - t1, t3 - t2, recs.size());
+    out.n_fetched = W.n_fetched;
+    if (timing) fprintf(stderr, "[agx walk] walk %.1f ms, join %.1f ms, scaffold %.1f ms, %zu records, %u special ids of %u, %llu records fetched\n", t1 - t0, t2 - t1, t3 - t2, recs.size(), G.n_special, G.n_ids, W.n_fetched);
 }
 
 }  // namespace agx

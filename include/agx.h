@@ -53,6 +53,7 @@ typedef struct {
 } agx_params;
 
 #define AGX_FLAG_KEEP_COUNTS 1u /* keep per-node coverage and base votes on the device for agx_unit_graph() */
+#define AGX_FLAG_SPARSE_MIN  2u /* test hook: download node records of the side ids only, read all others one by one from the device */
 
 /* ---- packed inputs -------------------------------------------------------------------------------- */
 
@@ -94,6 +95,7 @@ typedef struct {
     uint64_t pairs_in_file, sam_line_pairs;
     double ms_parse, ms_thread, ms_upload, ms_prep, ms_bin, ms_node_sweep, ms_node_big, ms_edge_sweep, ms_compact, ms_download, ms_walk;
     uint32_t node_sweep_launches, edge_sweep_launches;
+    uint64_t n_walk_ids, n_special, n_fetched, download_bytes;   /* walk graph: ids, node records downloaded, records fetched one by one, D2H bytes */
 } agx_stats;
 
 /* Node/edge tables in canonical numbering (position-major, variant order), for parity tests. malloc'd; free with agx_graph_free. */

@@ -6,6 +6,8 @@
 // (merged arrivals, in-order tile sweeps, edges resolved against final buckets) against the oracle in a
 // container without a GPU.  It is never linked into libagx.so and the product API cannot reach it.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -26,7 +28,8 @@ struct SimGraph {
     // alive-compacted view (agx_core.h "walk preparation")
     agx_u32 n_ids = 0;
     std::vector<agx_u32> side_cnt, side_start, aid_of; std::string a_str;
-    std::vector<agx_u8> a_meta; std::vector<agx_walknode> a_node; std::vector<agx_edge_ovf> a_ovf;
+    std::vector<agx_u8> a_meta, a_mark; std::vector<agx_walknode> a_node, sp_node; std::vector<agx_edge_ovf> a_ovf;
+    std::vector<agx_u32> side_xpos, sp_cnt, sp_rank; std::vector<unsigned long long> sp_bits; agx_u32 n_special = 0;
     void reserve(size_t cap) {
         cid.resize(cap); coff.resize(cap); cid0.resize(cap); coff0.resize(cap); off0.resize(cap); xpos.resize(cap); next.resize(cap * AGX_MAXE);
         base.resize(cap); flags.resize(cap); sref.resize(cap); counts.resize(cap * 6);
@@ -126,9 +129,25 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     S.a_ovf.assign(S.ovf.size() + 1, agx_edge_ovf{AGX_NONE, AGX_NONE});
     C.a_str = &S.a_str[0]; C.a_meta = S.a_meta.data(); C.a_node = S.a_node.data();
     C.ovf = S.ovf.data(); C.n_ovf = (agx_u32)S.ovf.size(); C.a_ovf = S.a_ovf.data();
+    S.a_mark.assign(na + 1, 0); S.side_xpos.assign((size_t)run + 1, 0);
+    C.a_mark = S.a_mark.data(); C.side_xpos = S.side_xpos.data(); C.n_ids = S.n_ids;
+    C.sparse_min = getenv("AGX_SIM_SPARSE_MIN") ? 1u : 0u;
+    for (agx_u32 p : T.chain_end_pos) S.a_mark[p] = 1;                               // agx_k_mark_list
     for (agx_u32 x = 0; x < n_pos; x++) agx_assign_aid_pos(C, x);
     for (agx_u32 v = 0; v < S.n_nodes; v++) agx_emit_alive_node(C, v);
     for (agx_u32 i = 0; i < C.n_ovf; i++) agx_emit_alive_ovf(C, i);
+    // sparse record table: bitmap words, rank scan, gather (agx_k_special_bits / scan / agx_k_special_emit)
+    const agx_u32 n_words = S.n_ids / 64 + 1;
+    S.sp_bits.assign((size_t)n_words + 1, 0); S.sp_cnt.assign((size_t)n_words + 1, 0); S.sp_rank.assign((size_t)n_words + 1, 0);
+    for (agx_u32 w = 0; w < n_words; w++) {
+        unsigned long long bits = 0;
+        for (agx_u32 l = 0; l < 64; l++) if (agx_special_id(C, w * 64 + l)) bits |= 1ull << l;
+        S.sp_bits[w] = bits; S.sp_cnt[w] = (agx_u32)__builtin_popcountll(bits);
+    }
+    agx_u32 acc = 0; for (agx_u32 w = 0; w <= n_words; w++) { S.sp_rank[w] = acc; acc += S.sp_cnt[w]; }
+    S.n_special = S.sp_rank[n_words]; S.sp_node.resize((size_t)S.n_special + 1);
+    for (agx_u32 w = 0; w < n_words; w++) for (agx_u32 l = 0; l < 64; l++) if ((S.sp_bits[w] >> l) & 1ull)
+        S.sp_node[S.sp_rank[w] + (agx_u32)__builtin_popcountll(S.sp_bits[w] & ((1ull << l) - 1ull))] = S.a_node[(size_t)w * 64 + l];
 }
 
 char *dup_buf(const std::string &s) { char *p = (char *)malloc(s.size() + 1); memcpy(p, s.data(), s.size()); p[s.size()] = 0; return p; }
@@ -145,6 +164,7 @@ typedef struct {
     uint32_t n_pos, n_nodes, n_edges; int32_t n_big_tiles;
     uint32_t *node_start;   // canonical (position-ordered) numbering, same layout as the oracle's dump
     uint32_t *node_key; int32_t *node_cnt; uint32_t *node_slen; uint32_t *edge_start; uint32_t *edge_dst;   // edge_dst sorted per node
+    uint64_t n_walk_ids, n_special, n_fetched;   // walk graph: ids, records in the sparse table, records read through the fetch hook
 } agx_hostsim_result;
 
 int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int coverage, long batch, int maxv_first, int want_graph, agx_hostsim_result *out) {
@@ -157,14 +177,23 @@ int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int cover
         load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + u + ".bowtie", batch, (agx_u32)k, P);
         SimGraph S; int nbig = 0;
         simulate(T, P, (agx_u32)k, iv, coverage, maxv_first > 0 ? (agx_u32)maxv_first : AGX_MAXV_LDS, S, nbig);
-        GraphView G; G.n_pos = (agx_u32)T.ref.size(); G.n_ids = S.n_ids; G.side_start = S.side_start.data(); G.node_cnt = S.node_cnt.data();
-        G.meta = S.a_meta.data(); G.str = S.a_str.data(); G.node = S.a_node.data();
+        GraphView G; G.n_pos = (agx_u32)T.ref.size(); G.n_ids = S.n_ids;
+        G.meta = S.a_meta.data(); G.str = S.a_str.data(); G.side_xpos = S.side_xpos.data();
+        G.sp_bits = S.sp_bits.data(); G.sp_rank = S.sp_rank.data(); G.sp_node = S.sp_node.data(); G.n_special = S.n_special;
+        G.fetch = [](void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *o) {
+            for (agx_u32 r = 0; r < rows; r++) for (agx_u32 c = 0; c < width; c++) o[(size_t)r * width + c] = ((SimGraph *)ctx)->a_node.at((size_t)first + (size_t)r * stride + c);
+        }; G.fetch_ctx = &S;
         G.ovf = S.a_ovf.data(); G.n_ovf = S.ovf.size();
+        if (const char *rep = getenv("AGX_WALK_REPEAT")) {           // walk micro-benchmark: best of N on an already built graph
+            double best = 1e30;
+            for (int i = 0; i < atoi(rep); i++) { UnitOutput Q; const auto t0 = std::chrono::steady_clock::now(); walk_join_scaffold(T, P, G, Q); const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); if (ms < best) best = ms; }
+            fprintf(stderr, "[hostsim] walk+join+scaffold best of %s: %.2f ms\n", rep, best);
+        }
         UnitOutput O; walk_join_scaffold(T, P, G, O);
         out->initial_contigs = dup_buf(T.initial_contigs); out->initial_len = T.initial_contigs.size();
         out->pre_len = O.pre_extended.n; out->pre_extended = O.pre_extended.release();
         out->extended_len = O.extended.n; out->extended = O.extended.release();
-        out->n_big_tiles = nbig;
+        out->n_big_tiles = nbig; out->n_walk_ids = S.n_ids; out->n_special = S.n_special; out->n_fetched = O.n_fetched;
         if (want_graph) {
             const agx_u32 n_pos = G.n_pos, nn = S.n_nodes;
             out->n_pos = n_pos; out->n_nodes = nn;

@@ -27,6 +27,7 @@ class _Result(ctypes.Structure):
         ("node_start", ctypes.POINTER(ctypes.c_uint32)), ("node_key", ctypes.POINTER(ctypes.c_uint32)),
         ("node_cnt", ctypes.POINTER(ctypes.c_int32)), ("node_slen", ctypes.POINTER(ctypes.c_uint32)),
         ("edge_start", ctypes.POINTER(ctypes.c_uint32)), ("edge_dst", ctypes.POINTER(ctypes.c_uint32)),
+        ("n_walk_ids", ctypes.c_uint64), ("n_special", ctypes.c_uint64), ("n_fetched", ctypes.c_uint64),
     ]
 
 
@@ -54,7 +55,8 @@ def run(tmp_dir, unit, k=5, insert_variation=50, coverage=20, batch=1000000, max
         _lib.agx_hostsim_free(ctypes.byref(r))
         raise SimError(rc, msg)
     out = {"initial": ctypes.string_at(r.initial_contigs, r.initial_len), "pre": ctypes.string_at(r.pre_extended, r.pre_len),
-           "extended": ctypes.string_at(r.extended, r.extended_len), "n_big_tiles": r.n_big_tiles}
+           "extended": ctypes.string_at(r.extended, r.extended_len), "n_big_tiles": r.n_big_tiles,
+           "n_walk_ids": r.n_walk_ids, "n_special": r.n_special, "n_fetched": r.n_fetched}
     if graph:
         import numpy as np
 

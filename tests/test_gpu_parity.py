@@ -19,8 +19,8 @@ def agx():
     return A
 
 
-def run_engine(agx, tmp, unit, k, iv, cov, batch=0, graph=False):
-    with agx.Unit(k=k, insert_variation=iv, coverage=cov, batch=batch, keep_counts=graph) as u:
+def run_engine(agx, tmp, unit, k, iv, cov, batch=0, graph=False, flags=0):
+    with agx.Unit(k=k, insert_variation=iv, coverage=cov, batch=batch, keep_counts=graph, flags=flags) as u:
         u.load_files(tmp, unit)
         u.upload()
         u.build()
@@ -64,6 +64,23 @@ def test_node_edge_tables_and_outputs_match_oracle(agx, cfg, built, tmp_path):
             assert o[key] == g[key], key
         if cfg.get("frag_sd") == 300:
             assert g["stats"]["n_big_tiles"] > 0
+
+
+def test_sparse_record_table_and_device_fetch(agx, built, tmp_path):
+    # see tests/test_hostsim.py::test_sparse_record_table_and_fetch_hook; here the records come from the kernels and the fetch hook
+    # reads the full table that stays in HBM
+    run = H.synth(str(tmp_path / "run"), seed=105, chroms="300000", pairs=60000, coverage=5, contig_min=120000, contig_max=200000, sam_seq=0)
+    meta = H.read_meta(run)
+    tmp = os.path.join(run, "tmp")
+    o = H.run_oracle(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
+    g = run_engine(agx, tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
+    m = run_engine(agx, tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"], flags=agx.AGX_FLAG_SPARSE_MIN)
+    for key in ("initial", "pre", "extended"):
+        assert o[key] == g[key] == m[key], key
+    gs, ms = g["stats"], m["stats"]
+    assert gs["n_special"] * 4 < gs["n_walk_ids"] and gs["n_fetched"] <= 8       # the skip positions come in one strided copy per long record
+    assert ms["n_special"] < gs["n_special"] and ms["n_fetched"] > 100
+    assert gs["download_bytes"] < 8 * gs["n_walk_ids"]                 # was 40 bytes per id with the dense record table
 
 
 def test_run_unit_writes_the_three_files(agx, built, tmp_path):

@@ -46,6 +46,24 @@ def test_node_and_edge_tables_match_oracle(cfg, maxv, built, tmp_path):
             assert s["n_big_tiles"] > 0          # the global-scratch fallback really ran
 
 
+def test_sparse_record_table_and_fetch_hook(built, tmp_path, monkeypatch):
+    # The walk reads node records from the sparse table of "special" ids (agx_core.h, walk preparation); only the +1000 position skip
+    # inside records longer than 100 kb (AG:2194-2202) can put it on another id, which then comes through the fetch hook.  A 300 kb
+    # unit with 120-200 kb contigs exercises both; with the table cut down to the side ids nearly every record takes the fetch path.
+    run = H.synth(str(tmp_path / "run"), seed=105, chroms="300000", pairs=60000, coverage=5, contig_min=120000, contig_max=200000, sam_seq=0)
+    meta = H.read_meta(run)
+    tmp = os.path.join(run, "tmp")
+    o = H.run_oracle(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
+    assert max(len(r) for r in o["pre"].split(b">")) > 100000
+    s = sim.run(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
+    monkeypatch.setenv("AGX_SIM_SPARSE_MIN", "1")
+    m = sim.run(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
+    for key in ("initial", "pre", "extended"):
+        assert o[key] == s[key] == m[key], key
+    assert s["n_special"] * 4 < s["n_walk_ids"] and s["n_fetched"] <= 8          # the skip positions come in one strided copy per long record
+    assert m["n_special"] < s["n_special"] and m["n_fetched"] > 100
+
+
 def test_batch_boundary_drops_first_pair_of_next_batch(built, tmp_path):
     # AG:1258-1259 with BATCH shrunk to 500 pairs: oracle and engine loaders must lose the same line pairs
     run = H.synth(str(tmp_path / "run"), seed=7, chroms="8000", pairs=2300, coverage=3, multi=0.3, sam_seq=0)
