@@ -48,6 +48,10 @@ typedef uint8_t agx_u8;
 
 // per-position conti-mer key (the part of ContiMer, AG:51-62, that node build reads)
 struct agx_cmkey { agx_u32 cid, coff; };
+// per-position head of the conti-mer table, built on the device at upload: the first conti-mer of the position (NONE/NONE if there is
+// none), how many there are and where they start.  One 16-byte load tells the node sweep everything the common case needs about a
+// position instead of two offsets and a dependent key load.
+struct agx_cmhead { agx_u32 cid, coff, n, start; };
 
 // ---- derived per-hit record (device, written by hit_prep) ---------------------------------------------
 
@@ -78,20 +82,31 @@ struct agx_key { agx_u32 cid, coff, cid0, coff0, off0; };   // chromosomeID0 is 
 
 AGX_HD int agx_absdiff(agx_u32 a, agx_u32 b) { int d = (int)(a - b); return d < 0 ? -d : d; }   // abs((int)(a-b)), AG:1296
 
-// clauses of `compatible` (AG:1293-1312, OPTIMIZATION on): A on (contigID, contigOffset), B on the mate's, C on the mate position
-AGX_HD bool agx_clause_ab(agx_u32 ac, agx_u32 ao, agx_u32 bc, agx_u32 bo, int win) {
-    return ac == AGX_NONE || bc == AGX_NONE || ac != bc || agx_absdiff(ao, bo) <= win;
+// clauses of `compatible` (AG:1293-1312, OPTIMIZATION on): A on (contigID, contigOffset), B on the mate's, C on the mate position.
+// Written as integer arithmetic with `&` / `|` (no short-circuit): on wave64 every lane-varying `&&` turns into an exec-mask
+// branch, and these run once per (hit, position).  |a-b| <= win  <=>  (u32)(a - b + win) <= 2*win  (win >= 0, |a-b| < 2^31).
+AGX_HD agx_u32 agx_within(agx_u32 a, agx_u32 b, int win) { return (agx_u32)(a - b + (agx_u32)win) <= 2u * (agx_u32)win ? 1u : 0u; }
+// true unless both ids are set and equal and the offsets are further apart than win
+AGX_HD agx_u32 agx_clause_ab(agx_u32 ac, agx_u32 ao, agx_u32 bc, agx_u32 bo, int win) {
+    return ((agx_u32)(ac != bc) | (agx_u32)(ac == AGX_NONE) | agx_within(ao, bo, win)) & 1u;
 }
-AGX_HD bool agx_clause_c(agx_u32 ao, agx_u32 bo, int win) { return ao == AGX_NONE || bo == AGX_NONE || agx_absdiff(ao, bo) <= win; }
+AGX_HD agx_u32 agx_clause_c(agx_u32 ao, agx_u32 bo, int win) { return ((agx_u32)(ao == AGX_NONE) | (agx_u32)(bo == AGX_NONE) | agx_within(ao, bo, win)) & 1u; }
 
 // A bucket view: base points at this lane's column; element (variant v, field f) is base[(v*AGX_NF+f)*stride]
 struct agx_bucket { agx_u32 *base; agx_u32 stride; agx_u32 maxv; };
 AGX_HD agx_u32 &agx_b(const agx_bucket &b, agx_u32 v, agx_u32 f) { return b.base[(v * AGX_NF + f) * b.stride]; }
+// counter update of a bucket word.  In the LDS node sweep it is a wave-private LDS add (one ds_add_u32 instead of
+// read / wait / add / write); everywhere else it is the plain read-modify-write.
+template <bool LDS_ADD> AGX_HD void agx_bucket_add(agx_u32 &ref, agx_u32 val) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (LDS_ADD) { (void)__hip_atomic_fetch_add(&ref, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); return; }
+#endif
+    ref += val;
+}
 
 AGX_HD bool agx_compatible(const agx_key &k, const agx_bucket &b, agx_u32 v, int iv) {
-    return agx_clause_ab(k.cid, k.coff, agx_b(b, v, AGX_F_CID), agx_b(b, v, AGX_F_COFF), AGX_EP25) &&
-           agx_clause_ab(k.cid0, k.coff0, agx_b(b, v, AGX_F_CID0), agx_b(b, v, AGX_F_COFF0), 2 * iv + AGX_EP25) &&
-           agx_clause_c(k.off0, agx_b(b, v, AGX_F_OFF0), 2 * iv + AGX_EP25);
+    const agx_u32 c = agx_b(b, v, AGX_F_CID), o = agx_b(b, v, AGX_F_COFF), c0 = agx_b(b, v, AGX_F_CID0), o0 = agx_b(b, v, AGX_F_COFF0), m = agx_b(b, v, AGX_F_OFF0);
+    return (agx_clause_ab(k.cid, k.coff, c, o, AGX_EP25) & agx_clause_ab(k.cid0, k.coff0, c0, o0, 2 * iv + AGX_EP25) & agx_clause_c(k.off0, m, 2 * iv + AGX_EP25)) != 0;
 }
 
 // ---- read geometry ---------------------------------------------------------------------------------------
@@ -235,12 +250,19 @@ AGX_HD int agx_hit_prep(const agx_hit *hits, const agx_run *runs, agx_u32 h, agx
     return 0;
 }
 
+// conti-mer head of position x (upload-time kernel / test executor)
+AGX_HD void agx_cm_head_pos(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 x) {
+    const agx_u32 s = cm_start[x], n = cm_start[x + 1] - s;
+    head[x] = n ? agx_cmhead{cm[s].cid, cm[s].coff, n, s} : agx_cmhead{AGX_NONE, AGX_NONE, 0u, s};
+}
+
 // ---- node sweep: one lane = one position --------------------------------------------------------------------
 
 struct agx_sweep_args {
     // static graph inputs
     const agx_u32 *cm_start;      // [n_pos+1] conti-mers of position x are cm[cm_start[x] .. cm_start[x+1])
     const agx_cmkey *cm;
+    const agx_cmhead *cm_head;    // [n_pos]
     const char *ref;              // [n_pos] reference base per position (incl. appended positions)
     // reads
     const agx_dhit *dhit;
@@ -249,6 +271,11 @@ struct agx_sweep_args {
     // tile lists
     const agx_u32 *tile_off;      // [n_tiles+1]
     const agx_u32 *tile_hits;     // hit ids, ascending inside a tile
+#if defined(__HIPCC__)
+    const uint4 *tile_recs;       // [entries][2] first 32 bytes of dhit[tile_hits[i]] (device only: the kernels' scalar record stream)
+#else
+    const void *tile_recs;
+#endif
     agx_u32 n_pos, n_tiles, k; int iv; int coverage;
     // node table
     agx_u32 *node_start;          // [n_pos]
@@ -263,7 +290,15 @@ struct agx_sweep_args {
     agx_u32 pool_cap;
 };
 
-AGX_HD agx_u32 agx_vote_field(char c) { return c == 'A' ? AGX_F_A : c == 'C' ? AGX_F_C : c == 'G' ? AGX_F_G : c == 'T' ? AGX_F_T : AGX_F_N; }
+// bucket field that the oriented base of a read votes for, from the STORED character c (file orientation) and the strand:
+// (c>>1)&3 maps A,C,T,G to 0,1,2,3; complementing (reverseComplement, AG:854-865: only ACGT are complemented) is ^2 there; any
+// other character votes N on either strand.  Table lookups in immediates, no branches.
+AGX_HD agx_u32 agx_vote_field(agx_u32 c, bool rev) {
+    const agx_u32 idx = (c >> 1) & 3u;
+    const bool acgt = c == ((0x47544341u >> (idx * 8u)) & 0xFFu);                 // "ACTG"[idx]
+    const agx_u32 f = (((AGX_F_A) | (AGX_F_C << 4) | (AGX_F_T << 8) | (AGX_F_G << 12)) >> ((idx ^ (rev ? 2u : 0u)) * 4u)) & 0xFu;
+    return acgt ? f : (agx_u32)AGX_F_N;
+}
 
 // first compatible variant or append (AG:1375-1390 / 1493-1506).  Returns the index, or NONE when the bucket is full.
 AGX_HD agx_u32 agx_match_or_insert(const agx_bucket &b, agx_u32 &cnt, const agx_key &key, int iv, bool is_k1, agx_u32 s0, agx_u32 s1) {
@@ -302,47 +337,50 @@ AGX_HD void agx_for_candidates(const agx_sweep_args &A, agx_u32 cx_s, agx_u32 cx
 // (mate conti-mer range -> first entry, vote base) of hit i+1 are in flight while hit i updates the bucket in LDS.
 struct agx_pre {
     agx_u32 has, type, p0, step1;          // arrival present at this position; AGX_AT_*; mate position; its successor is position+1
-    agx_u32 c0_s, c0_n; agx_cmkey c0;      // conti-mers at the mate position, and the first of them
-    agx_u32 s0, s1; char base;             // k-mer string reference of this arrival; its vote base
+    agx_cmhead h; agx_u32 mate;            // conti-mer head of the mate position as loaded (position 0 if there is no mate), mate present
+    agx_u32 s0, s1, cbyte, rev;            // k-mer string reference of this arrival; stored character of its base and the read's strand
 };
 
-AGX_HD void agx_arrival_fetch(const agx_sweep_args &A, const agx_dhit &d, agx_u32 X, agx_pre &p) {
+// Straight-line on purpose (no lane-varying branch, the two loads are issued for every lane with clamped indices): the number of
+// loads in flight at any point of the sweep's loop is then static, and the compiler can wait for exactly the older buffer's loads
+// (s_waitcnt vmcnt(2)) instead of draining everything.  Nothing loaded here is touched before apply().
+AGX_HD void agx_arrival_fetch(const agx_sweep_args &A, const agx_dhit &d, agx_u32 X, bool enable, agx_pre &p) {
     const agx_arrival a = agx_decode_arrival(d, A.runs, X, A.k);
-    p.has = a.has;
-    p.c0_s = 0; p.c0_n = 0; p.c0 = agx_cmkey{AGX_NONE, AGX_NONE}; p.base = 0; p.s0 = 0; p.s1 = 0; p.type = 0; p.p0 = AGX_NONE; p.step1 = 0;
-    if (!p.has) return;
-    p.step1 = (a.has_succ && a.xs == X + 1) ? 1u : 0u;
+    const bool has = enable && a.has != 0;
     const bool rev = (d.flags & AGX_HF_AREV) != 0;
-    p.type = a.type; p.p0 = a.p0;
+    p.has = has ? 1u : 0u;
+    p.step1 = (has && a.has_succ && a.xs == X + 1) ? 1u : 0u;
+    p.type = a.type; p.p0 = a.p0; p.rev = rev ? 1u : 0u;
     p.s0 = d.a_slot;
-    p.s1 = (a.slen ? (rev ? (agx_u32)d.len - 1u - a.q : a.q) : 0u) | (a.slen << 16) | (rev ? 0x80000000u : 0u);
-    if (a.p0 != AGX_NONE) { p.c0_s = A.cm_start[a.p0]; p.c0_n = A.cm_start[a.p0 + 1] - p.c0_s; if (p.c0_n) p.c0 = A.cm[p.c0_s]; }
-    if (a.type == AGX_AT_K1) p.base = agx_base_at(A.bases + (size_t)d.a_slot * A.stride, d.len, a.q, rev);
+    const agx_u32 stored = rev ? (agx_u32)d.len - 1u - a.q : a.q;                 // index of the arrival's base in the stored read
+    p.s1 = (a.slen ? stored : 0u) | (a.slen << 16) | (rev ? 0x80000000u : 0u);
+    p.mate = (has && a.p0 != AGX_NONE) ? 1u : 0u;
+    p.h = A.cm_head[p.mate ? a.p0 : 0u];                                           // no mate: position 0, discarded by apply()
+    p.cbyte = (agx_u8)A.bases[(size_t)d.a_slot * A.stride + ((has && a.type == AGX_AT_K1) ? stored : 0u)];
 }
 
 // The whole in-order sweep of one position.  get(i) returns the derived hit record of tile-list entry i (the kernels stage 64
 // records at a time across the lanes of the wavefront and broadcast them; the test executor reads memory directly).
 // Returns false if the bucket overflowed (the tile is then re-run with a larger bucket).
-template <class GET>
+template <bool LDS_ADD, class GET>
 AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, const agx_bucket &b, agx_u32 &cnt, agx_u32 &pflag, GET get) {
     cnt = 0; pflag = 0;
     const bool live = X < A.n_pos;                       // lanes beyond the end still take part in the staging of hit records
     agx_u32 cx_s = 0, cx_n = 0; agx_cmkey cx0 = agx_cmkey{AGX_NONE, AGX_NONE};
-    if (live) { cx_s = A.cm_start[X]; cx_n = A.cm_start[X + 1] - cx_s; if (cx_n) cx0 = A.cm[cx_s]; }
+    if (live) { const agx_cmhead h = A.cm_head[X]; cx_s = h.start; cx_n = h.n; cx0 = agx_cmkey{h.cid, h.coff}; }
     bool ok = true;
     const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
-    auto fetch = [&](agx_u32 i, agx_pre &p) { p.has = 0; if (i < hi) { const agx_dhit d = get(i); if (live) agx_arrival_fetch(A, d, X, p); } };
     // Branch-light on purpose: on wave64 every per-lane `if` costs exec-mask bookkeeping on the scalar unit, and the sweep runs
     // this body ~35 times per position.  The common case — one candidate key, compatible with variant 0 — is straight-line
     // code under a single `has` mask; everything else (several conti-mers, later variants, inserts) goes through slow().
-    auto slow = [&](const agx_pre &p, bool is_k1, agx_u32 vf) {
-        const agx_u32 nx = cx_n ? cx_n : 1u, n0 = p.c0_n ? p.c0_n : 1u;
+    auto slow = [&](const agx_pre &p, agx_u32 c0_s, agx_u32 c0_n, agx_cmkey c0_first, bool is_k1, agx_u32 vf) {
+        const agx_u32 nx = cx_n ? cx_n : 1u, n0 = c0_n ? c0_n : 1u;
         for (agx_u32 ci = 0; ci < nx && ok; ci++) {                      // candidate keys, X-major (AG:1369-1477)
             agx_key key; key.off0 = p.p0;
             const agx_cmkey cx = cx_n ? (ci == 0 ? cx0 : A.cm[cx_s + ci]) : agx_cmkey{AGX_NONE, AGX_NONE};
             key.cid = cx.cid; key.coff = cx.coff;
             for (agx_u32 cj = 0; cj < n0; cj++) {
-                const agx_cmkey c0 = p.c0_n ? (cj == 0 ? p.c0 : A.cm[p.c0_s + cj]) : agx_cmkey{AGX_NONE, AGX_NONE};
+                const agx_cmkey c0 = c0_n ? (cj == 0 ? c0_first : A.cm[c0_s + cj]) : agx_cmkey{AGX_NONE, AGX_NONE};
                 key.cid0 = c0.cid; key.coff0 = c0.coff;
                 const agx_u32 v = agx_match_or_insert(b, cnt, key, A.iv, is_k1, p.s0, p.s1);
                 if (v == AGX_NONE) { ok = false; break; }
@@ -350,25 +388,40 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
             }
         }
     };
+    // The common case — one candidate key, compatible with variant 0 — is straight-line code without a lane-varying branch: the
+    // five key words of variant 0 are read unconditionally, the verdict is integer arithmetic, and the two counter updates are LDS
+    // adds of 0 or 1 (agx_bucket_add: ds_add_u32 in the LDS pass).  Only lanes that need another variant, an insert or several
+    // candidate keys enter slow().
     auto apply = [&](const agx_pre &p) {
-        if (!p.has || !ok) return;
+        const agx_u32 has = p.has & (ok ? 1u : 0u);
         pflag |= p.step1;
-        const bool is_k1 = p.type != AGX_AT_K2ONLY;
-        const agx_u32 vf = p.type == AGX_AT_K1 ? agx_vote_field(p.base) : (agx_u32)AGX_NF;
-        agx_key key; key.cid = cx0.cid; key.coff = cx0.coff; key.cid0 = p.c0.cid; key.coff0 = p.c0.coff; key.off0 = p.p0;   // cx0 / c0 are NONE when absent
-        const bool one = cx_n <= 1 && p.c0_n <= 1;
-        if (one && cnt > 0 && agx_compatible(key, b, 0, A.iv)) {
-            if (is_k1) agx_b(b, 0, AGX_F_COV) += 1;
-            if (vf != AGX_NF) agx_b(b, 0, vf) += 1;
-        } else slow(p, is_k1, vf);
+        const agx_u32 is_k1 = p.type != AGX_AT_K2ONLY ? 1u : 0u;
+        const agx_u32 vfield = agx_vote_field(p.cbyte, p.rev != 0);
+        const agx_u32 vf = p.type == AGX_AT_K1 ? vfield : (agx_u32)AGX_NF;
+        const agx_u32 c0_n = p.mate ? p.h.n : 0u;
+        const agx_cmkey c0k = agx_cmkey{p.mate ? p.h.cid : AGX_NONE, p.mate ? p.h.coff : AGX_NONE};        // NONE/NONE when the position has none
+        const agx_u32 c = agx_b(b, 0, AGX_F_CID), o = agx_b(b, 0, AGX_F_COFF), c0 = agx_b(b, 0, AGX_F_CID0), o0 = agx_b(b, 0, AGX_F_COFF0), m = agx_b(b, 0, AGX_F_OFF0);
+        const agx_u32 compat = agx_clause_ab(cx0.cid, cx0.coff, c, o, AGX_EP25) & agx_clause_ab(c0k.cid, c0k.coff, c0, o0, 2 * A.iv + AGX_EP25) &
+                               agx_clause_c(p.p0, m, 2 * A.iv + AGX_EP25);                   // cx0 / c0 are NONE when absent
+        const agx_u32 fast = has & compat & (agx_u32)(cx_n <= 1) & (agx_u32)(c0_n <= 1) & (agx_u32)(cnt > 0);
+        const agx_u32 vote = fast & (agx_u32)(vf != AGX_NF);
+        agx_bucket_add<LDS_ADD>(agx_b(b, 0, AGX_F_COV), fast & is_k1);
+        agx_bucket_add<LDS_ADD>(agx_b(b, 0, vote ? vf : (agx_u32)AGX_F_COV), vote);
+        if (has & (fast ^ 1u)) slow(p, p.h.start, c0_n, c0k, is_k1 != 0, vf);
     };
-    // software pipeline, two records in flight: the loads of hit i+1 are issued before hit i touches the bucket
-    agx_pre cur, nxt;
-    fetch(lo, cur);
-    for (agx_u32 i = lo; i < hi; i++) {
-        fetch(i + 1, nxt);
-        apply(cur);
-        cur = nxt;
+    // software pipeline over two arrival buffers that are never copied (a register copy would have to wait for the loads): buffer
+    // A serves the even hits of the list, B the odd ones; a buffer is refilled for the hit two places ahead right after it has been
+    // applied, so its two per-lane loads have a whole apply + fetch of the other buffer to complete.  The derived hit records
+    // (wave-uniform, scalar loads in the kernels) are read two further hits ahead.
+    auto rec = [&](agx_u32 i) { return i < hi ? get(i) : agx_dhit{0, 0, 0, 0, 0, 0, 0, 0, 0, AGX_HF_SKIP, 1, 0}; };
+    auto fetch = [&](const agx_dhit &d, bool valid, agx_pre &p) { agx_arrival_fetch(A, d, X, valid && live, p); };
+    agx_pre pa, pb;
+    { const agx_dhit d0 = rec(lo); fetch(d0, lo < hi, pa); }
+    { const agx_dhit d1 = rec(lo + 1); fetch(d1, lo + 1 < hi, pb); }
+    agx_dhit da = rec(lo + 2), db = rec(lo + 3);
+    for (agx_u32 i = lo; i < hi; i += 2) {
+        apply(pa); fetch(da, i + 2 < hi, pa); da = rec(i + 4);
+        apply(pb); fetch(db, i + 3 < hi, pb); db = rec(i + 5);
     }
     return ok;
 }
@@ -413,8 +466,8 @@ AGX_HD agx_u32 agx_resolve(const agx_sweep_args &A, agx_u32 x, const agx_key &k)
     const agx_u32 s = A.node_start[x], n = A.node_cnt[x];
     for (agx_u32 v = 0; v < n; v++) {
         const agx_u32 id = s + v;
-        if (agx_clause_ab(k.cid, k.coff, A.nk_cid[id], A.nk_coff[id], AGX_EP25) &&
-            agx_clause_ab(k.cid0, k.coff0, A.nk_cid0[id], A.nk_coff0[id], 2 * A.iv + AGX_EP25) &&
+        if (agx_clause_ab(k.cid, k.coff, A.nk_cid[id], A.nk_coff[id], AGX_EP25) &
+            agx_clause_ab(k.cid0, k.coff0, A.nk_cid0[id], A.nk_coff0[id], 2 * A.iv + AGX_EP25) &
             agx_clause_c(k.off0, A.nk_off0[id], 2 * A.iv + AGX_EP25)) return id;
     }
     return AGX_NONE;
@@ -422,8 +475,8 @@ AGX_HD agx_u32 agx_resolve(const agx_sweep_args &A, agx_u32 x, const agx_key &k)
 
 // contig-consistency between the STORED keys of an edge's two ends (AG:1602-1615)
 AGX_HD bool agx_edge_allowed(const agx_sweep_args &A, agx_u32 src, agx_u32 dst) {
-    return agx_clause_ab(A.nk_cid[dst], A.nk_coff[dst], A.nk_cid[src], A.nk_coff[src], AGX_EP25) &&
-           agx_clause_ab(A.nk_cid0[dst], A.nk_coff0[dst], A.nk_cid0[src], A.nk_coff0[src], 2 * A.iv + AGX_EP25);
+    return (agx_clause_ab(A.nk_cid[dst], A.nk_coff[dst], A.nk_cid[src], A.nk_coff[src], AGX_EP25) &
+            agx_clause_ab(A.nk_cid0[dst], A.nk_coff0[dst], A.nk_cid0[src], A.nk_coff0[src], 2 * A.iv + AGX_EP25)) != 0;
 }
 
 // Edge build, pass A (lanes = positions).  Where a position holds ONE variant every arrival resolved to it, so no candidate keys and
@@ -452,8 +505,10 @@ AGX_HD bool agx_edge_fast_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X,
         if (ins) { spilled = true; push_overflow(own_start, dst); }         // duplicates are removed on the host
     };
     const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
+    agx_dhit dn = lo < hi ? get(lo) : agx_dhit{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (agx_u32 i = lo; i < hi; i++) {
-        const agx_dhit d = get(i);
+        const agx_dhit d = dn;
+        if (i + 1 < hi) dn = get(i + 1);                                    // record stream, one entry ahead
         if (d.a_nruns == 0) continue;                                       // wave-uniform: a single-run mate only ever steps to x+1
         const agx_arrival a = agx_decode_arrival(d, A.runs, X, A.k);
         if (!fast || !a.has || !a.has_succ || a.xs >= A.n_pos || a.xs == X + 1) continue;

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "agx_host.h"
@@ -58,10 +59,10 @@ struct agx_unit {
     bool have_ref = false, have_threads = false, uploaded = false, built = false, downloaded = false;
     hipStream_t st = nullptr;
     // inputs on the device
-    DBuf<agx_u32> d_cm_start; DBuf<agx_cmkey> d_cm; DBuf<char> d_ref;
+    DBuf<agx_u32> d_cm_start; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref;
     DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<char> d_bases;
     // derived
-    DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_hits, d_scan_tmp, d_words;   // d_words: counters/status
+    DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_hits, d_tile_recs, d_scan_tmp, d_words;   // d_words: counters/status
     // node table
     agx_u32 pool_cap = 0, ovf_cap = 0, list_cap = 0;
     DBuf<agx_u32> d_node_start, d_slow_list; DBuf<agx_u8> d_node_cnt, d_pos_succ;
@@ -85,13 +86,20 @@ struct agx_unit {
 
 namespace {
 
+// One build at a time per device, on the GPU as well as in the launch order: every build's first kernel waits (stream-side) for the
+// event the previous build recorded behind its last kernel, so units built from several host threads run their kernel chains back to
+// back without host round trips in between, and per-kernel HIP-event times stay those of an exclusive device.  Copies to the host
+// (download, record fetches) are not part of the turn and overlap the next unit's kernels.
+struct DeviceTurn { std::mutex m; hipEvent_t last = nullptr; };
+DeviceTurn &turn_of(int device) { static DeviceTurn turns[64]; return turns[device & 63]; }
+
 enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_N = 8 };
 
 void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     memset(&S, 0, sizeof S);
-    S.cm_start = u->d_cm_start.p; S.cm = u->d_cm.p; S.ref = u->d_ref.p;
+    S.cm_start = u->d_cm_start.p; S.cm = u->d_cm.p; S.cm_head = u->d_cm_head.p; S.ref = u->d_ref.p;
     S.dhit = u->d_dhit.p; S.runs = u->d_runs.p; S.bases = u->d_bases.p; S.stride = u->P.stride;
-    S.tile_off = u->d_tile_off.p; S.tile_hits = u->d_tile_hits.p;
+    S.tile_off = u->d_tile_off.p; S.tile_hits = u->d_tile_hits.p; S.tile_recs = (decltype(S.tile_recs))u->d_tile_recs.p;
     S.n_pos = (agx_u32)u->T.ref.size(); S.n_tiles = u->n_tiles; S.k = u->prm.k; S.iv = (int)u->prm.insert_variation; S.coverage = (int)u->prm.coverage;
     S.node_start = u->d_node_start.p; S.node_cnt = u->d_node_cnt.p; S.pos_succ = u->d_pos_succ.p;
     S.nk_cid = u->d_cid.p; S.nk_coff = u->d_coff.p; S.nk_cid0 = u->d_cid0.p; S.nk_coff0 = u->d_coff0.p; S.nk_off0 = u->d_off0.p;
@@ -120,6 +128,8 @@ void do_upload(agx_unit *u) {
     HIP_OK(hipMemcpyAsync(u->d_cm_start.p, u->T.cm_start.data(), (n_pos + 1) * 4, hipMemcpyHostToDevice, u->st));
     if (!keys.empty()) HIP_OK(hipMemcpyAsync(u->d_cm.p, keys.data(), keys.size() * sizeof(agx_cmkey), hipMemcpyHostToDevice, u->st));
     HIP_OK(hipMemcpyAsync(u->d_ref.p, u->T.ref.data(), n_pos, hipMemcpyHostToDevice, u->st));
+    u->d_cm_head.alloc(n_pos + 1);
+    agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, (agx_u32)n_pos, u->st);
     const size_t nh = u->P.hits.size();
     u->d_hits.alloc(nh + 1); u->d_runs.alloc(u->P.runs.size() + 1); u->d_bases.alloc(u->P.bases.size() + 16); u->d_dhit.alloc(nh + 1);
     if (nh) HIP_OK(hipMemcpyAsync(u->d_hits.p, u->P.hits.data(), nh * sizeof(agx_hit), hipMemcpyHostToDevice, u->st));
@@ -157,7 +167,7 @@ void do_build(agx_unit *u) {
     u->d_scratch.alloc((size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64);
     for (int attempt = 0;; attempt++) {
         if (attempt > 8) throw Error{E_DEVICE, "build did not converge"};
-        u->d_unsorted.alloc((size_t)u->list_cap + 1); u->d_tile_hits.alloc((size_t)u->list_cap + 1);
+        u->d_unsorted.alloc((size_t)u->list_cap + 1); u->d_tile_hits.alloc((size_t)u->list_cap + 1); u->d_tile_recs.alloc(((size_t)u->list_cap + 4) * 8);
         u->d_aid_of.alloc((size_t)u->pool_cap + 1);
         const size_t ids_cap = (size_t)n_pos + u->pool_cap;                       // side variants <= nodes <= pool_cap
         u->d_a_str.alloc(ids_cap + 1); u->d_a_meta.alloc(ids_cap + 16); u->d_a_node.alloc(ids_cap + 1); u->d_a_ovf.alloc((size_t)u->ovf_cap + 1);
@@ -168,6 +178,10 @@ void do_build(agx_unit *u) {
         {   const size_t nb = ((size_t)std::max<size_t>(n_pos, u->n_words) + 1 + 1023) / 1024;
             u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16); }
 
+        DeviceTurn &turn = turn_of(u->prm.device);
+        std::unique_lock<std::mutex> my_turn(turn.m);
+        if (turn.last) HIP_OK(hipStreamWaitEvent(st, turn.last, 0));
+        else HIP_OK(hipEventCreateWithFlags(&turn.last, hipEventDisableTiming));
         HIP_OK(hipMemsetAsync(u->d_words.p, 0, W_N * 4, st));
         HIP_OK(hipMemsetAsync(u->d_tile_cnt.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
         HIP_OK(hipMemsetAsync(u->d_cursor.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
@@ -181,7 +195,7 @@ void do_build(agx_unit *u) {
         agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
         agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap};
         agx_launch_bin_fill(&BA, st);
-        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->d_tile_hits.p, u->n_tiles, u->list_cap, st);
+        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->d_tile_hits.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, st);
         HIP_OK(hipEventRecord(u->ev_bin.b, st)); u->ev_bin.used = true;
         // ---- node sweep: LDS pass, then the global-scratch pass over whatever tiles overflowed (device-side count) ----
         agx_node_kargs K; fill_sweep_args(u, K.S);
@@ -222,13 +236,15 @@ void do_build(agx_unit *u) {
         HIP_OK(hipMemcpyAsync(u->h_words.p + W_N, u->d_tile_off.p + u->n_tiles, 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(u->h_words.p + W_N + 1, u->d_side_start.p + n_pos, 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(u->h_words.p + W_N + 2, u->d_sp_rank.p + u->n_words, 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipEventRecord(turn.last, st));
+        my_turn.unlock();
         HIP_OK(hipStreamSynchronize(st));
         HIP_OK(hipGetLastError());
         const agx_u32 *w = u->h_words.p;
         if (w[W_ERR] & 1u) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
         if (w[W_ERR] & 2u) throw Error{E_UNSUPPORTED, "read alignment beyond the end of the unit sequence"};
         u->n_tile_entries = w[W_N];
-        if (u->n_tile_entries > u->list_cap) { u->list_cap = u->n_tile_entries + u->n_tile_entries / 8 + 1024; u->d_unsorted.release(); u->d_tile_hits.release(); continue; }
+        if (u->n_tile_entries > u->list_cap) { u->list_cap = u->n_tile_entries + u->n_tile_entries / 8 + 1024; u->d_unsorted.release(); u->d_tile_hits.release(); u->d_tile_recs.release(); continue; }
         if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 64 node variants at one position"};
         const unsigned long long want = w[W_POOL];
         if ((w[W_STATUS] & 1u) || want > u->pool_cap) {

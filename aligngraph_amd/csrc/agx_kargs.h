@@ -28,11 +28,12 @@ struct agx_edge_kargs {
 #define AGX_SLOW_WAVES 8192u    // resident wavefronts of the per-hit edge pass (stride over the slow list)
 
 extern "C" {
+void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t);
 void agx_launch_hit_prep(const agx_prep_args *, hipStream_t);
 // exclusive scan of in[0..n] (n+1 entries, in[n] must be 0) into out[0..n]; out[n] = total
 void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u32 *tmp, hipStream_t);
 void agx_launch_bin_fill(const agx_bin_args *, hipStream_t);
-void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap, hipStream_t);
+void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, hipStream_t);
 void agx_launch_node_sweep(const agx_node_kargs *, hipStream_t);
 void agx_launch_node_sweep_big(const agx_node_kargs *, hipStream_t);
 void agx_launch_edge_sweep(const agx_edge_kargs *, hipStream_t);          // pass A (lanes = positions), then pass B (lanes = hits)

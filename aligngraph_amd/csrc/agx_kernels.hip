@@ -16,6 +16,12 @@
 
 #define AGX_WAVES_PER_BLOCK 4
 
+// ---- upload time: per-position head of the conti-mer table ---------------------------------------------------------
+__global__ void __launch_bounds__(256) agx_k_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos) {
+    const agx_u32 x = blockIdx.x * 256u + threadIdx.x;
+    if (x < n_pos) agx_cm_head_pos(cm_start, cm, head, x);
+}
+
 // ---- hit_prep: one thread per hit -------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
     const agx_u32 h = blockIdx.x * 256u + threadIdx.x;
@@ -65,7 +71,16 @@ __global__ void __launch_bounds__(256) agx_k_bin_fill(agx_bin_args A) {
 
 // one wavefront per tile; hit ids are unique, so an element's rank is the number of smaller elements
 #define AGX_SORT_LDS 2048
-__global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap) {
+// Besides the sorted hit ids the kernel writes the tile's RECORD list: the first 32 bytes of each hit's derived record, in list order,
+// so that the sweeps read one sequential, wave-uniform stream (scalar loads) instead of chasing list entry -> record.
+__device__ __forceinline__ void agx_put_rec(uint4 *recs, agx_u32 at, const agx_dhit *dhit, agx_u32 h) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(dhit + h);             // agx_dhit is 40 bytes: 8-byte aligned only
+    const uint2 *s2 = reinterpret_cast<const uint2 *>(src);
+    const uint2 a = s2[0], b = s2[1], c = s2[2], d = s2[3];
+    recs[2 * (size_t)at] = make_uint4(a.x, a.y, b.x, b.y); recs[2 * (size_t)at + 1] = make_uint4(c.x, c.y, d.x, d.y);
+}
+__global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap,
+                                                       const agx_dhit *dhit, uint4 *recs) {
     __shared__ agx_u32 sh[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
@@ -80,45 +95,33 @@ __global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, 
         for (agx_u32 i = lane; i < n; i += 64) {
             const agx_u32 v = sh[wave][i]; agx_u32 r = 0;
             for (agx_u32 j = 0; j < n; j++) r += sh[wave][j] < v;
-            sorted[lo + r] = v;
+            sorted[lo + r] = v; agx_put_rec(recs, lo + r, dhit, v);
         }
     } else {                                            // pile-ups larger than the LDS window: same rank sort straight from L2
         for (agx_u32 i = lane; i < n; i += 64) {
             const agx_u32 v = src[i]; agx_u32 r = 0;
             for (agx_u32 j = 0; j < n; j++) r += src[j] < v;
-            sorted[lo + r] = v;
+            sorted[lo + r] = v; agx_put_rec(recs, lo + r, dhit, v);
         }
     }
 }
 
-// ---- staging of hit records ----------------------------------------------------------------------------------------------
-// A tile's sweep reads its hit list strictly in order and every lane needs every record.  Instead of two dependent
-// wave-uniform loads per hit (list entry -> record) the wavefront stages 64 records at a time: lane l loads record l of the
-// chunk into its own registers (one coalesced gather), and the loop broadcasts record j with v_readlane — the derived hit
-// record then lives in SGPRs and most of the arrival decode runs on the scalar unit.
-struct agx_wave_hits {
-    const agx_u32 *tile_hits; const agx_dhit *dhit; agx_u32 hi, lane, base; bool primed;
-    agx_u32 r0, r1, r2, r3, r4, r5, r6, r7;       // a_t0, b_t0, a_runs, b_runs, a_slot, len|jstar<<16, a_nruns|b_nruns<<16, flags
-    __device__ __forceinline__ agx_wave_hits(const agx_u32 *th, const agx_dhit *dh, agx_u32 hi_, agx_u32 lane_)
-        : tile_hits(th), dhit(dh), hi(hi_), lane(lane_), base(0), primed(false), r0(0), r1(0), r2(0), r3(0), r4(0), r5(0), r6(0), r7(0) {}
-    __device__ __forceinline__ agx_dhit operator()(agx_u32 i) {
-        if (!primed || i - base >= 64u) {                // wave-uniform: i is the loop counter
-            base = i; primed = true;
-            const agx_u32 idx = i + lane;
-            if (idx < hi) {
-                const agx_dhit d = dhit[tile_hits[idx]];
-                r0 = d.a_t0; r1 = d.b_t0; r2 = d.a_runs; r3 = d.b_runs; r4 = d.a_slot; r5 = (agx_u32)d.len | ((agx_u32)d.jstar << 16);
-                r6 = (agx_u32)d.a_nruns | ((agx_u32)d.b_nruns << 16); r7 = d.flags;
-            }
-        }
-        const int j = (int)(i - base);
+// ---- hit records of a tile ------------------------------------------------------------------------------------------------
+// A tile's sweep reads its record list strictly in order and every lane needs every record: the list index is wave-uniform, so the
+// read goes through the constant address space and becomes one s_load_dwordx8 into SGPRs (the list was written by an earlier
+// kernel).  Scalar loads are counted by lgkmcnt, not vmcnt: waiting for a record never drains the per-lane global loads that the
+// sweep keeps in flight one hit ahead, and most of the arrival decode runs on the scalar unit.
+struct agx_tile_recs {
+    const uint4 *recs;
+    __device__ __forceinline__ agx_dhit operator()(agx_u32 i) const {
+        typedef agx_u32 v4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(4))) v4 *cptr;
+        const cptr p = (cptr)(recs + 2 * (size_t)i);
+        const v4 a = p[0], b = p[1];
         agx_dhit d;
-        d.a_t0 = (agx_u32)__builtin_amdgcn_readlane((int)r0, j); d.b_t0 = (agx_u32)__builtin_amdgcn_readlane((int)r1, j);
-        d.a_runs = (agx_u32)__builtin_amdgcn_readlane((int)r2, j); d.b_runs = (agx_u32)__builtin_amdgcn_readlane((int)r3, j);
-        d.a_slot = (agx_u32)__builtin_amdgcn_readlane((int)r4, j);
-        const agx_u32 lj = (agx_u32)__builtin_amdgcn_readlane((int)r5, j), nn = (agx_u32)__builtin_amdgcn_readlane((int)r6, j);
-        d.len = (agx_u16)(lj & 0xFFFFu); d.jstar = (agx_u16)(lj >> 16); d.a_nruns = (agx_u16)(nn & 0xFFFFu); d.b_nruns = (agx_u16)(nn >> 16);
-        d.flags = (agx_u32)__builtin_amdgcn_readlane((int)r7, j); d.x_lo = 0; d.x_hi = 0;
+        d.a_t0 = a.x; d.b_t0 = a.y; d.a_runs = a.z; d.b_runs = a.w; d.a_slot = b.x;
+        d.len = (agx_u16)(b.y & 0xFFFFu); d.jstar = (agx_u16)(b.y >> 16); d.a_nruns = (agx_u16)(b.z & 0xFFFFu); d.b_nruns = (agx_u16)(b.z >> 16);
+        d.flags = b.w; d.x_lo = 0; d.x_hi = 0;
         return d;
     }
 };
@@ -144,8 +147,8 @@ __global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
         if (K.S.tile_off[tile + 1] > K.list_cap) return;
         const agx_u32 X = tile * AGX_TILE + lane;
         agx_u32 cnt = 0, pflag = 0;
-        agx_wave_hits hits(K.S.tile_hits, K.S.dhit, K.S.tile_off[tile + 1], lane);
-        const bool ok = agx_node_sweep_lane(K.S, tile, X, b, cnt, pflag, hits);
+        const agx_tile_recs hits{K.S.tile_recs};
+        const bool ok = agx_node_sweep_lane<!BIG>(K.S, tile, X, b, cnt, pflag, hits);
         if (__ballot(!ok) != 0ull) {                       // wave-uniform
             if (lane == 0) {
                 if (BIG) atomicOr(K.status, 2u);
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
     // the neighbour position's bucket header comes from the next lane; the last lane reads the next tile's first position
     agx_u32 nb_start = __shfl_down(own_start, 1, 64), nb_cnt = __shfl_down(own_cnt, 1, 64);
     if (lane == 63) { nb_start = 0; nb_cnt = 0; if (X + 1 < K.S.n_pos) { nb_start = K.S.node_start[X + 1]; nb_cnt = K.S.node_cnt[X + 1]; } }
-    agx_wave_hits hits(K.S.tile_hits, K.S.dhit, K.S.tile_off[tile + 1], lane);
+    const agx_tile_recs hits{K.S.tile_recs};
     const bool slow = agx_edge_fast_lane(K.S, tile, X, own_start, own_cnt, nb_start, nb_cnt, hits, [&](agx_u32 s, agx_u32 d) {
         const agx_u32 i = atomicAdd(K.ovf_count, 1u);
         if (i < K.ovf_cap) K.ovf[i] = agx_edge_ovf{s, d};
@@ -201,7 +204,11 @@ __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
         const agx_u32 tile = X / AGX_TILE;
         const agx_u32 lo = K.S.tile_off[tile], hi = K.S.tile_off[tile + 1];
         for (agx_u32 i = lo + lane; i < hi; i += 64) {
-            const agx_dhit d = K.S.dhit[K.S.tile_hits[i]];
+            const uint4 ra = K.S.tile_recs[2 * (size_t)i], rb = K.S.tile_recs[2 * (size_t)i + 1];      // lanes = consecutive list entries
+            agx_dhit d;
+            d.a_t0 = ra.x; d.b_t0 = ra.y; d.a_runs = ra.z; d.b_runs = ra.w; d.a_slot = rb.x;
+            d.len = (agx_u16)(rb.y & 0xFFFFu); d.jstar = (agx_u16)(rb.y >> 16); d.a_nruns = (agx_u16)(rb.z & 0xFFFFu); d.b_nruns = (agx_u16)(rb.z >> 16);
+            d.flags = rb.w; d.x_lo = 0; d.x_hi = 0;
             agx_edge_slow_hit(K.S, X, d, [&](agx_u32 src, agx_u32 dst) {
                 agx_u32 *slots = K.S.n_next + (size_t)src * AGX_MAXE;
                 // A slot only ever changes from NONE to its final value, so a plain (possibly stale) 16-byte read can prove presence;
@@ -257,6 +264,9 @@ __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, ag
 // ---- host-callable launchers (kept in this translation unit so that the engine is plain C++) -------------------------
 extern "C" {
 
+void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t st) {
+    if (n_pos) hipLaunchKernelGGL(agx_k_cm_head, dim3((n_pos + 255) / 256), dim3(256), 0, st, cm_start, cm, head, n_pos);
+}
 void agx_launch_hit_prep(const agx_prep_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_hit_prep, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
 }
@@ -284,8 +294,8 @@ void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u
 void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_bin_fill, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
 }
-void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap, hipStream_t st) {
-    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, sorted, n_tiles, cap);
+void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, hipStream_t st) {
+    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, sorted, n_tiles, cap, dhit, (uint4 *)recs);
 }
 void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;

@@ -60,7 +60,9 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     S.node_start.assign(n_pos, 0); S.node_cnt.assign(n_pos, 0); S.pos_succ.assign(n_pos, 0);
     S.reserve((size_t)n_pos * 2 + 1024);
     agx_sweep_args A; memset(&A, 0, sizeof A);
-    A.cm_start = T.cm_start.data(); A.cm = cmk.data(); A.ref = T.ref.data();
+    std::vector<agx_cmhead> cmh((size_t)n_pos + 1);
+    for (agx_u32 x = 0; x < n_pos; x++) agx_cm_head_pos(T.cm_start.data(), cmk.data(), cmh.data(), x);
+    A.cm_start = T.cm_start.data(); A.cm = cmk.data(); A.cm_head = cmh.data(); A.ref = T.ref.data();
     A.dhit = dh.data(); A.runs = P.runs.data(); A.bases = P.bases.data(); A.stride = P.stride;
     A.tile_off = tile_off.data(); A.tile_hits = tile_hits.data();
     A.n_pos = n_pos; A.n_tiles = n_tiles; A.k = k; A.iv = iv; A.coverage = coverage;
@@ -78,7 +80,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     for (agx_u32 t = 0; t < n_tiles; t++) {
         agx_u32 cnt[AGX_TILE], pflag[AGX_TILE]; bool ok = true;
         agx_bucket b{nullptr, AGX_TILE, maxv_first};
-        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) { b.base = lds.data() + lane; ok &= agx_node_sweep_lane(A, t, t * AGX_TILE + lane, b, cnt[lane], pflag[lane], get); }
+        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) { b.base = lds.data() + lane; ok &= agx_node_sweep_lane<false>(A, t, t * AGX_TILE + lane, b, cnt[lane], pflag[lane], get); }
         agx_u32 *store = lds.data(); agx_u32 maxv = maxv_first;
         if (!ok) {                                     // the fallback the engine runs for overflowed tiles
             n_big_tiles++;
@@ -86,7 +88,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
             agx_bucket bb{nullptr, AGX_TILE, maxv};
             for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
                 bb.base = store + lane;
-                if (!agx_node_sweep_lane(A, t, t * AGX_TILE + lane, bb, cnt[lane], pflag[lane], get)) throw Error{E_OVERFLOW, "more than AGX_MAXV_BIG node variants at one position"};
+                if (!agx_node_sweep_lane<false>(A, t, t * AGX_TILE + lane, bb, cnt[lane], pflag[lane], get)) throw Error{E_OVERFLOW, "more than AGX_MAXV_BIG node variants at one position"};
             }
         }
         agx_u32 total = 0; for (agx_u32 lane = 0; lane < AGX_TILE; lane++) total += cnt[lane];
