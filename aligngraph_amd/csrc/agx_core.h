@@ -553,6 +553,70 @@ AGX_HD void agx_edge_slow_hit(const agx_sweep_args &A, agx_u32 X, const agx_dhit
     });
 }
 
+// Pass B, common case.  Everything about the slow position X itself is wave-uniform on the device: its bucket, the bucket of X+1 (the
+// usual successor), their conti-mers.  When both buckets are small the stored keys are loaded ONCE per position (scalar loads, SGPRs)
+// and every hit resolves both ends of its edge against them in registers — no per-hit walk through the node table.  A hit then only
+// names one of at most 16 (source variant, target variant) pairs; the pairs a position produces are OR-ed over its hits and inserted
+// once each.  Hits whose successor is not X+1, or that have several candidate keys, take agx_edge_slow_hit as before.
+#define AGX_SLOW_V 4u
+struct agx_slow_ctx {
+    agx_u32 reg;                                   // 1: the register path applies to this position
+    agx_u32 s, n, s1, n1;                          // buckets of X and X+1 (node ids s..s+n-1, s1..s1+n1-1)
+    agx_cmkey cx, sx;                              // the conti-mer of X / of X+1 (NONE/NONE if none)
+    agx_key kx[AGX_SLOW_V], kx1[AGX_SLOW_V];       // stored keys of the variants
+    agx_u32 allowed;                               // bit vs*AGX_SLOW_V+vd: edge s+vs -> s1+vd passes agx_edge_allowed
+};
+
+AGX_HD agx_u32 agx_key_compatible(const agx_key &k, const agx_key &st, int iv) {
+    return agx_clause_ab(k.cid, k.coff, st.cid, st.coff, AGX_EP25) & agx_clause_ab(k.cid0, k.coff0, st.cid0, st.coff0, 2 * iv + AGX_EP25) &
+           agx_clause_c(k.off0, st.off0, 2 * iv + AGX_EP25);
+}
+
+AGX_HD void agx_edge_slow_ctx(const agx_sweep_args &A, agx_u32 X, agx_slow_ctx &c) {
+    c.s = A.node_start[X]; c.n = A.node_cnt[X]; c.s1 = 0; c.n1 = 0; c.allowed = 0;
+    c.cx = agx_cmkey{AGX_NONE, AGX_NONE}; c.sx = c.cx;
+    const bool has1 = X + 1 < A.n_pos;
+    if (has1) { c.s1 = A.node_start[X + 1]; c.n1 = A.node_cnt[X + 1]; }
+    const agx_cmhead hx = A.cm_head[X], hx1 = has1 ? A.cm_head[X + 1] : agx_cmhead{AGX_NONE, AGX_NONE, 0u, 0u};
+    c.reg = (has1 && c.n <= AGX_SLOW_V && c.n1 <= AGX_SLOW_V && hx.n <= 1 && hx1.n <= 1) ? 1u : 0u;
+    if (!c.reg) return;
+    c.cx = agx_cmkey{hx.cid, hx.coff}; c.sx = agx_cmkey{hx1.cid, hx1.coff};
+    const agx_key none = agx_key{AGX_NONE, AGX_NONE, AGX_NONE, AGX_NONE, AGX_NONE};
+    for (agx_u32 v = 0; v < AGX_SLOW_V; v++) {
+        c.kx[v] = none; c.kx1[v] = none;
+        if (v < c.n) { const agx_u32 id = c.s + v; c.kx[v] = agx_key{A.nk_cid[id], A.nk_coff[id], A.nk_cid0[id], A.nk_coff0[id], A.nk_off0[id]}; }
+        if (v < c.n1) { const agx_u32 id = c.s1 + v; c.kx1[v] = agx_key{A.nk_cid[id], A.nk_coff[id], A.nk_cid0[id], A.nk_coff0[id], A.nk_off0[id]}; }
+    }
+    for (agx_u32 vs = 0; vs < AGX_SLOW_V; vs++) for (agx_u32 vd = 0; vd < AGX_SLOW_V; vd++) {
+        if (vs >= c.n || vd >= c.n1) continue;
+        const agx_u32 ok = agx_clause_ab(c.kx1[vd].cid, c.kx1[vd].coff, c.kx[vs].cid, c.kx[vs].coff, AGX_EP25) &
+                           agx_clause_ab(c.kx1[vd].cid0, c.kx1[vd].coff0, c.kx[vs].cid0, c.kx[vs].coff0, 2 * A.iv + AGX_EP25);      // agx_edge_allowed
+        c.allowed |= ok << (vs * AGX_SLOW_V + vd);
+    }
+}
+
+// one hit of a slow position: returns the (source, target) pair it contributes as a bit (0: none), or — for hits off the register
+// path — resolves through the node table and inserts through ins() right away
+template <class INS>
+AGX_HD agx_u32 agx_edge_slow_pair(const agx_sweep_args &A, const agx_slow_ctx &c, agx_u32 X, const agx_dhit &d, bool enable, INS ins) {
+    const agx_arrival a = agx_decode_arrival(d, A.runs, X, A.k);
+    const bool act = enable && a.has && a.has_succ && a.xs < A.n_pos;
+    const bool mate = act && a.p0 != AGX_NONE, mates = act && a.p0s != AGX_NONE;
+    const agx_cmhead h0 = A.cm_head[mate ? a.p0 : 0u], h0s = A.cm_head[mates ? a.p0s : 0u];                 // clamped, unconditional loads
+    const bool quick = act && c.reg && a.xs == X + 1 && (!mate || h0.n <= 1) && (!mates || h0s.n <= 1);
+    if (act && !quick) agx_edge_slow_hit(A, X, d, ins);
+    const agx_key k1 = agx_key{c.cx.cid, c.cx.coff, mate ? h0.cid : AGX_NONE, mate ? h0.coff : AGX_NONE, a.p0};
+    const agx_key k2 = agx_key{c.sx.cid, c.sx.coff, mates ? h0s.cid : AGX_NONE, mates ? h0s.coff : AGX_NONE, a.p0s};
+    agx_u32 vs = AGX_NONE, vd = AGX_NONE;
+    for (agx_u32 v = 0; v < AGX_SLOW_V; v++) {                                     // first compatible variant (agx_resolve), select-only
+        const bool m1 = v < c.n && agx_key_compatible(k1, c.kx[v], A.iv) != 0, m2 = v < c.n1 && agx_key_compatible(k2, c.kx1[v], A.iv) != 0;
+        vs = (vs == AGX_NONE && m1) ? v : vs; vd = (vd == AGX_NONE && m2) ? v : vd;
+    }
+    const bool hit = quick && vs != AGX_NONE && vd != AGX_NONE;
+    const agx_u32 bit = 1u << ((hit ? vs : 0u) * AGX_SLOW_V + (hit ? vd : 0u));
+    return (hit && (c.allowed & bit)) ? bit : 0u;
+}
+
 // ---- walk preparation: alive-node renumbering and forced-run flags -------------------------------------------------------
 // The path walk (AG:1954-2204) only ever stands on nodes that survived the coverage prune.  After the edge sweep the
 // surviving ("alive") nodes get walk ids ("aid") laid out so that the main strand of the graph is contiguous:

@@ -194,7 +194,29 @@ __global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
     }
 }
 
-// pass B: a fixed set of wavefronts strides over the slow positions; lanes = hits of the position's tile (agx_edge_slow_hit)
+// pass B: a fixed set of wavefronts strides over the slow positions; lanes = hits of the position's tile.  The position's own data
+// (both buckets' stored keys, conti-mers, the allowed-edge matrix) is wave-uniform and loaded once (agx_edge_slow_ctx); a hit on the
+// register path only reports which (source, target) pair it produces, the pairs are OR-ed across the wavefront with ballots and each
+// distinct pair is inserted once, by its own lane.
+__device__ __forceinline__ void agx_slot_insert(const agx_edge_kargs &K, agx_u32 src, agx_u32 dst) {
+    agx_u32 *slots = K.S.n_next + (size_t)src * AGX_MAXE;
+    // A slot only ever changes from NONE to its final value, so a plain (possibly stale) 16-byte read can prove presence;
+    // only an apparent NONE needs the compare-and-swap at L2.
+    const uint4 seen = *reinterpret_cast<const uint4 *>(slots);
+    if (seen.x == dst || seen.y == dst || seen.z == dst || seen.w == dst) return;
+    const agx_u32 sv[4] = {seen.x, seen.y, seen.z, seen.w};
+    for (agx_u32 e = 0; e < AGX_MAXE; e++) {
+        agx_u32 cur = sv[e];
+        if (cur == AGX_NONE) { cur = atomicCAS(&slots[e], AGX_NONE, dst); if (cur == AGX_NONE) return; }
+        if (cur == dst) return;
+    }
+    // more than AGX_MAXE distinct successors: overflow list (duplicates are removed on the host) + flag in the node's byte
+    const agx_u32 i2 = atomicAdd(K.ovf_count, 1u);
+    if (i2 < K.ovf_cap) K.ovf[i2] = agx_edge_ovf{src, dst};
+    const size_t addr = (size_t)(K.S.n_flags + src);
+    atomicOr((agx_u32 *)(addr & ~(size_t)3), (agx_u32)AGX_NF_EOVF << (8u * (agx_u32)(addr & 3)));
+}
+
 __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
     const agx_u32 lane = threadIdx.x & 63u;
     const agx_u32 wave = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
@@ -203,30 +225,25 @@ __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
         const agx_u32 X = __builtin_amdgcn_readfirstlane(K.slow_list[w]);
         const agx_u32 tile = X / AGX_TILE;
         const agx_u32 lo = K.S.tile_off[tile], hi = K.S.tile_off[tile + 1];
-        for (agx_u32 i = lo + lane; i < hi; i += 64) {
-            const uint4 ra = K.S.tile_recs[2 * (size_t)i], rb = K.S.tile_recs[2 * (size_t)i + 1];      // lanes = consecutive list entries
+        agx_slow_ctx c; agx_edge_slow_ctx(K.S, X, c);
+        agx_u32 pairs = 0;
+        for (agx_u32 base = lo; base < hi; base += 64) {                     // wave-uniform trip count
+            const agx_u32 i = base + lane; const bool on = i < hi;
+            const size_t at = on ? i : lo;
+            const uint4 ra = K.S.tile_recs[2 * at], rb = K.S.tile_recs[2 * at + 1];      // lanes = consecutive list entries
             agx_dhit d;
             d.a_t0 = ra.x; d.b_t0 = ra.y; d.a_runs = ra.z; d.b_runs = ra.w; d.a_slot = rb.x;
             d.len = (agx_u16)(rb.y & 0xFFFFu); d.jstar = (agx_u16)(rb.y >> 16); d.a_nruns = (agx_u16)(rb.z & 0xFFFFu); d.b_nruns = (agx_u16)(rb.z >> 16);
             d.flags = rb.w; d.x_lo = 0; d.x_hi = 0;
-            agx_edge_slow_hit(K.S, X, d, [&](agx_u32 src, agx_u32 dst) {
-                agx_u32 *slots = K.S.n_next + (size_t)src * AGX_MAXE;
-                // A slot only ever changes from NONE to its final value, so a plain (possibly stale) 16-byte read can prove presence;
-                // only an apparent NONE needs the compare-and-swap at L2.
-                const uint4 seen = *reinterpret_cast<const uint4 *>(slots);
-                if (seen.x == dst || seen.y == dst || seen.z == dst || seen.w == dst) return;
-                const agx_u32 sv[4] = {seen.x, seen.y, seen.z, seen.w};
-                for (agx_u32 e = 0; e < AGX_MAXE; e++) {
-                    agx_u32 cur = sv[e];
-                    if (cur == AGX_NONE) { cur = atomicCAS(&slots[e], AGX_NONE, dst); if (cur == AGX_NONE) return; }
-                    if (cur == dst) return;
-                }
-                // more than AGX_MAXE distinct successors: overflow list (duplicates are removed on the host) + flag in the node's byte
-                const agx_u32 i2 = atomicAdd(K.ovf_count, 1u);
-                if (i2 < K.ovf_cap) K.ovf[i2] = agx_edge_ovf{src, dst};
-                const size_t addr = (size_t)(K.S.n_flags + src);
-                atomicOr((agx_u32 *)(addr & ~(size_t)3), (agx_u32)AGX_NF_EOVF << (8u * (agx_u32)(addr & 3)));
-            });
+            pairs |= agx_edge_slow_pair(K.S, c, X, d, on, [&](agx_u32 src, agx_u32 dst) { agx_slot_insert(K, src, dst); });
+        }
+        if (c.reg) {
+            agx_u32 all = 0;                                                 // OR over the wavefront, one ballot per possible pair
+            for (agx_u32 vs = 0; vs < c.n; vs++) for (agx_u32 vd = 0; vd < c.n1; vd++) {
+                const agx_u32 bit = 1u << (vs * AGX_SLOW_V + vd);
+                if (__ballot((pairs & bit) != 0) != 0ull) all |= bit;
+            }
+            if (lane < AGX_SLOW_V * AGX_SLOW_V && ((all >> lane) & 1u)) agx_slot_insert(K, c.s + lane / AGX_SLOW_V, c.s1 + lane % AGX_SLOW_V);
         }
     }
 }

@@ -108,12 +108,15 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
         }
     for (agx_u32 X : slow) {
         const agx_u32 t = X / AGX_TILE;
-        for (agx_u32 i = tile_off[t]; i < tile_off[t + 1]; i++)
-            agx_edge_slow_hit(A, X, dh[tile_hits[i]], [&](agx_u32 src, agx_u32 dst) {
-                agx_u32 *slots = S.next.data() + (size_t)src * AGX_MAXE;
-                for (agx_u32 e = 0; e < AGX_MAXE; e++) { if (slots[e] == AGX_NONE) slots[e] = dst; if (slots[e] == dst) return; }
-                S.flags[src] |= AGX_NF_EOVF; S.ovf.push_back(agx_edge_ovf{src, dst});
-            });
+        auto ins = [&](agx_u32 src, agx_u32 dst) {
+            agx_u32 *slots = S.next.data() + (size_t)src * AGX_MAXE;
+            for (agx_u32 e = 0; e < AGX_MAXE; e++) { if (slots[e] == AGX_NONE) slots[e] = dst; if (slots[e] == dst) return; }
+            S.flags[src] |= AGX_NF_EOVF; S.ovf.push_back(agx_edge_ovf{src, dst});
+        };
+        agx_slow_ctx c; agx_edge_slow_ctx(A, X, c);
+        agx_u32 pairs = 0;
+        for (agx_u32 i = tile_off[t]; i < tile_off[t + 1]; i++) pairs |= agx_edge_slow_pair(A, c, X, dh[tile_hits[i]], true, ins);
+        for (agx_u32 b = 0; b < AGX_SLOW_V * AGX_SLOW_V; b++) if ((pairs >> b) & 1u) ins(c.s + b / AGX_SLOW_V, c.s1 + b % AGX_SLOW_V);
     }
 
     // walk preparation, the same per-element functions the compaction kernels run
