@@ -58,7 +58,8 @@ class Stats(ctypes.Structure):
                [(n, ctypes.c_double) for n in ("ms_parse", "ms_thread", "ms_upload", "ms_prep", "ms_bin", "ms_node_sweep", "ms_node_big",
                                                 "ms_edge_sweep", "ms_compact", "ms_download", "ms_walk")] + \
                [("node_sweep_launches", ctypes.c_uint32), ("edge_sweep_launches", ctypes.c_uint32)] + \
-               [(n, ctypes.c_uint64) for n in ("n_walk_ids", "n_special", "n_fetched", "download_bytes")]
+               [(n, ctypes.c_uint64) for n in ("n_walk_ids", "n_special", "n_fetched", "download_bytes")] + \
+               [(n, ctypes.c_double) for n in ("ms_edge_fast", "ms_edge_slow")]
 
 
 class Graph(ctypes.Structure):

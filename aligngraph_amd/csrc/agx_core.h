@@ -480,51 +480,45 @@ AGX_HD bool agx_edge_allowed(const agx_sweep_args &A, agx_u32 src, agx_u32 dst) 
 }
 
 // Edge build, pass A (lanes = positions).  Where a position holds ONE variant every arrival resolved to it, so no candidate keys and
-// no compatibility tests are needed on the source side:
-//   * if x+1 holds one variant too, the edge x -> x+1 exists iff the node sweep saw an arrival stepping to x+1 (pos_succ) and the
-//     contig-consistency predicate of the two stored keys holds — no per-hit work at all;
-//   * steps that do not go to x+1 (read deletions, AG:1822-1838) can only come from hits whose a mate has several runs: only those
-//     (one hit in ten) are decoded here, the destination is resolved against the final bucket there.
+// no compatibility tests are needed on the source side: if x+1 holds one variant too, the edge x -> x+1 exists iff the node sweep saw
+// an arrival stepping to x+1 (pos_succ) and the contig-consistency predicate of the two stored keys holds — no per-hit work at all.
 // Positions with several variants, or whose neighbour x+1 has several, return true ("slow"): pass B re-resolves every hit for them.
-// Only this lane writes n_next / n_flags of x's node in this pass, so plain stores suffice.
-template <class GET, class OVF>
-AGX_HD bool agx_edge_fast_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, agx_u32 own_start, agx_u32 own_cnt, agx_u32 nb_start, agx_u32 nb_cnt, GET get, OVF push_overflow) {
-    const bool live = X < A.n_pos && own_cnt != 0;        // idle lanes still take part in the staging of hit records
+// Only this lane writes n_next of x's node in this pass, so plain stores suffice.  Steps that do not go to x+1 are pass J's.
+AGX_HD bool agx_edge_fast_lane(const agx_sweep_args &A, agx_u32 X, agx_u32 own_start, agx_u32 own_cnt, agx_u32 nb_start, agx_u32 nb_cnt) {
+    const bool live = X < A.n_pos && own_cnt != 0;
     if (X >= A.n_pos) X = 0;
     const bool fast = live && own_cnt == 1;
     const bool slow = live && (own_cnt >= 2 || nb_cnt >= 2);
-    agx_u32 s0 = AGX_NONE, s1 = AGX_NONE, s2 = AGX_NONE, s3 = AGX_NONE;     // slots of the single node
-    bool spilled = false;
-    if (fast && nb_cnt == 1 && (A.pos_succ[X] & 1u) && agx_edge_allowed(A, own_start, nb_start)) s0 = nb_start;
-    auto put_fast = [&](agx_u32 dst) {                                       // set insert into four register slots, select-only
-        bool ins = !(s0 == dst || s1 == dst || s2 == dst || s3 == dst);
-        const bool e0 = ins && s0 == AGX_NONE; s0 = e0 ? dst : s0; ins = ins && !e0;
-        const bool e1 = ins && s1 == AGX_NONE; s1 = e1 ? dst : s1; ins = ins && !e1;
-        const bool e2 = ins && s2 == AGX_NONE; s2 = e2 ? dst : s2; ins = ins && !e2;
-        const bool e3 = ins && s3 == AGX_NONE; s3 = e3 ? dst : s3; ins = ins && !e3;
-        if (ins) { spilled = true; push_overflow(own_start, dst); }         // duplicates are removed on the host
-    };
-    const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
-    agx_dhit dn = lo < hi ? get(lo) : agx_dhit{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (agx_u32 i = lo; i < hi; i++) {
-        const agx_dhit d = dn;
-        if (i + 1 < hi) dn = get(i + 1);                                    // record stream, one entry ahead
-        if (d.a_nruns == 0) continue;                                       // wave-uniform: a single-run mate only ever steps to x+1
+    if (fast) {
+        agx_u32 s0 = AGX_NONE;
+        if (nb_cnt == 1 && (A.pos_succ[X] & 1u) && agx_edge_allowed(A, own_start, nb_start)) s0 = nb_start;
+        agx_u32 *slots = A.n_next + (size_t)own_start * AGX_MAXE;
+        slots[0] = s0; slots[1] = AGX_NONE; slots[2] = AGX_NONE; slots[3] = AGX_NONE;
+    }
+    return slow;
+}
+
+// Edge build, pass J (lanes = hits): steps that do not go to x+1 (read deletions, AG:1822-1838).  They only exist where a run of the
+// hit's a mate ends, so each hit with several runs (one hit in ten) visits its run ends; sources with one variant are handled here
+// (set insert through INS, after pass A's plain stores), sources with several variants belong to pass B like all their other edges.
+template <class INS>
+AGX_HD void agx_edge_jump_hit(const agx_sweep_args &A, const agx_dhit &d, INS ins) {
+    if ((d.flags & AGX_HF_SKIP) || d.a_nruns < 2) return;
+    for (agx_u32 i = 0; i + 1 < d.a_nruns; i++) {
+        const agx_run r = A.runs[d.a_runs + i];
+        if (r.n == 0) continue;
+        const agx_u32 X = r.t + r.n - 1;
+        if (X >= A.n_pos || A.node_cnt[X] != 1) continue;
         const agx_arrival a = agx_decode_arrival(d, A.runs, X, A.k);
-        if (!fast || !a.has || !a.has_succ || a.xs >= A.n_pos || a.xs == X + 1) continue;
+        if (!a.has || !a.has_succ || a.xs >= A.n_pos || a.xs == X + 1) continue;
+        const agx_u32 src = A.node_start[X];
         const agx_u32 sx_s = A.cm_start[a.xs], sx_n = A.cm_start[a.xs + 1] - sx_s;
         agx_for_candidates(A, sx_s, sx_n, a.p0s, [&](const agx_key &k2) {
             const agx_u32 dst = agx_resolve(A, a.xs, k2);
-            if (dst != AGX_NONE && agx_edge_allowed(A, own_start, dst)) put_fast(dst);
+            if (dst != AGX_NONE && agx_edge_allowed(A, src, dst)) ins(src, dst);
             return true;
         });
     }
-    if (fast) {
-        agx_u32 *slots = A.n_next + (size_t)own_start * AGX_MAXE;
-        slots[0] = s0; slots[1] = s1; slots[2] = s2; slots[3] = s3;
-        if (spilled) A.n_flags[own_start] |= AGX_NF_EOVF;
-    }
-    return slow;
 }
 
 // Edge build, pass B (lanes = hits): every edge out of a slow position x that ONE hit contributes (AG:1589-1623).  Edge order is

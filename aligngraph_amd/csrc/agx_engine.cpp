@@ -79,9 +79,9 @@ struct agx_unit {
     PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_edge_ovf> h_a_ovf;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0;
-    EventPair ev_prep, ev_bin, ev_node, ev_big, ev_edge, ev_compact;
+    EventPair ev_prep, ev_bin, ev_node, ev_big, ev_edge, ev_slow, ev_compact;
     agx_stats stats{};
-    ~agx_unit() { ev_prep.destroy(); ev_bin.destroy(); ev_node.destroy(); ev_big.destroy(); ev_edge.destroy(); ev_compact.destroy(); if (st) (void)hipStreamDestroy(st); }
+    ~agx_unit() { ev_prep.destroy(); ev_bin.destroy(); ev_node.destroy(); ev_big.destroy(); ev_edge.destroy(); ev_slow.destroy(); ev_compact.destroy(); if (st) (void)hipStreamDestroy(st); }
 };
 
 namespace {
@@ -211,8 +211,11 @@ void do_build(agx_unit *u) {
         agx_edge_kargs E; fill_sweep_args(u, E.S); E.ovf = u->d_ovf.p; E.ovf_count = u->d_words.p + W_OVFCOUNT; E.ovf_cap = u->ovf_cap; E.list_cap = u->list_cap;
         E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
         HIP_OK(hipEventRecord(u->ev_edge.a, st));
-        agx_launch_edge_sweep(&E, st);
+        agx_launch_edge_sweep(&E, nh, st);
         HIP_OK(hipEventRecord(u->ev_edge.b, st)); u->ev_edge.used = true; u->stats.edge_sweep_launches++;
+        HIP_OK(hipEventRecord(u->ev_slow.a, st));
+        agx_launch_edge_slow(&E, st);
+        HIP_OK(hipEventRecord(u->ev_slow.b, st)); u->ev_slow.used = true;
         // ---- walk preparation: side counts -> scan -> walk ids, node records, rewritten edges, forced-run flags ----
         agx_compact_args C; memset(&C, 0, sizeof C);
         C.node_start = u->d_node_start.p; C.node_cnt = u->d_node_cnt.p; C.n_flags = u->d_flags.p; C.n_base = u->d_base.p; C.n_xpos = u->d_xpos.p;
@@ -266,7 +269,7 @@ void do_build(agx_unit *u) {
     }
     u->built = true; u->downloaded = false;
     u->stats.ms_prep = u->ev_prep.ms(); u->stats.ms_bin = u->ev_bin.ms(); u->stats.ms_node_sweep = u->ev_node.ms();
-    u->stats.ms_node_big = u->ev_big.ms(); u->stats.ms_edge_sweep = u->ev_edge.ms(); u->stats.ms_compact = u->ev_compact.ms();
+    u->stats.ms_node_big = u->ev_big.ms(); u->stats.ms_edge_fast = u->ev_edge.ms(); u->stats.ms_edge_slow = u->ev_slow.ms(); u->stats.ms_edge_sweep = u->stats.ms_edge_fast + u->stats.ms_edge_slow; u->stats.ms_compact = u->ev_compact.ms();
 }
 
 void do_download(agx_unit *u) {
@@ -356,7 +359,7 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
     const int rc = guarded(u, [&] {
         HIP_OK(hipSetDevice(p->device));
         HIP_OK(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
-        u->ev_prep.init(); u->ev_bin.init(); u->ev_node.init(); u->ev_big.init(); u->ev_edge.init(); u->ev_compact.init();
+        u->ev_prep.init(); u->ev_bin.init(); u->ev_node.init(); u->ev_big.init(); u->ev_edge.init(); u->ev_slow.init(); u->ev_compact.init();
     });
     if (rc != AGX_OK) { delete u; return rc; }
     *out = u;

@@ -36,7 +36,8 @@ void agx_launch_bin_fill(const agx_bin_args *, hipStream_t);
 void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, hipStream_t);
 void agx_launch_node_sweep(const agx_node_kargs *, hipStream_t);
 void agx_launch_node_sweep_big(const agx_node_kargs *, hipStream_t);
-void agx_launch_edge_sweep(const agx_edge_kargs *, hipStream_t);          // pass A (lanes = positions), then pass B (lanes = hits)
+void agx_launch_edge_sweep(const agx_edge_kargs *, agx_u32 n_hits, hipStream_t);   // pass A (lanes = positions), pass J (lanes = hits: steps that skip positions)
+void agx_launch_edge_slow(const agx_edge_kargs *, hipStream_t);           // pass B (lanes = hits of the slow positions pass A listed)
 // walk preparation (agx_core.h): per-position side counts; then (after the scan) ids, records and overflow edges
 // n_nodes / n_ovf are read from device memory (the node-pool and overflow counters), so no host round trip separates the sweeps
 // from the walk preparation; the grids are sized by the capacities.

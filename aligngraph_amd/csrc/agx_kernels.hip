@@ -168,23 +168,17 @@ __global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
 }
 
 // ---- edge build ---------------------------------------------------------------------------------------------------------
-// pass A: one wavefront per tile, lanes = positions (agx_edge_fast_lane); slow positions are compacted into a list with a
+// pass A: one thread per position (agx_edge_fast_lane), a pure streaming kernel; slow positions are compacted into a list with a
 // wave ballot + one atomicAdd per wavefront
 __global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
-    const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
-    if (tile >= K.S.n_tiles || K.S.tile_off[tile + 1] > K.list_cap) return;
-    const agx_u32 X = tile * AGX_TILE + lane;
+    const agx_u32 lane = threadIdx.x & 63u;
+    const agx_u32 X = blockIdx.x * 256u + threadIdx.x;
     agx_u32 own_start = 0, own_cnt = 0;
     if (X < K.S.n_pos) { own_start = K.S.node_start[X]; own_cnt = K.S.node_cnt[X]; }
-    // the neighbour position's bucket header comes from the next lane; the last lane reads the next tile's first position
+    // the neighbour position's bucket header comes from the next lane; the last lane reads the next wavefront's first position
     agx_u32 nb_start = __shfl_down(own_start, 1, 64), nb_cnt = __shfl_down(own_cnt, 1, 64);
     if (lane == 63) { nb_start = 0; nb_cnt = 0; if (X + 1 < K.S.n_pos) { nb_start = K.S.node_start[X + 1]; nb_cnt = K.S.node_cnt[X + 1]; } }
-    const agx_tile_recs hits{K.S.tile_recs};
-    const bool slow = agx_edge_fast_lane(K.S, tile, X, own_start, own_cnt, nb_start, nb_cnt, hits, [&](agx_u32 s, agx_u32 d) {
-        const agx_u32 i = atomicAdd(K.ovf_count, 1u);
-        if (i < K.ovf_cap) K.ovf[i] = agx_edge_ovf{s, d};
-    });
+    const bool slow = agx_edge_fast_lane(K.S, X, own_start, own_cnt, nb_start, nb_cnt);
     const unsigned long long m = __ballot(slow);
     if (m) {
         agx_u32 base = 0;
@@ -215,6 +209,14 @@ __device__ __forceinline__ void agx_slot_insert(const agx_edge_kargs &K, agx_u32
     if (i2 < K.ovf_cap) K.ovf[i2] = agx_edge_ovf{src, dst};
     const size_t addr = (size_t)(K.S.n_flags + src);
     atomicOr((agx_u32 *)(addr & ~(size_t)3), (agx_u32)AGX_NF_EOVF << (8u * (agx_u32)(addr & 3)));
+}
+
+// pass J: one thread per hit; only hits whose a mate has several runs do anything (agx_edge_jump_hit)
+__global__ void __launch_bounds__(256) agx_k_edge_jump(agx_edge_kargs K, agx_u32 n_hits) {
+    const agx_u32 h = blockIdx.x * 256u + threadIdx.x;
+    if (h >= n_hits) return;
+    const agx_dhit d = K.S.dhit[h];
+    agx_edge_jump_hit(K.S, d, [&](agx_u32 src, agx_u32 dst) { agx_slot_insert(K, src, dst); });
 }
 
 __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
@@ -312,7 +314,8 @@ void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_bin_fill, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
 }
 void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, hipStream_t st) {
-    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, sorted, n_tiles, cap, dhit, (uint4 *)recs);
+    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, sorted, n_tiles, cap, dhit,
+                                    (uint4 *)recs);
 }
 void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;
@@ -321,11 +324,13 @@ void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
 void agx_launch_node_sweep_big(const agx_node_kargs *K, hipStream_t st) {
     hipLaunchKernelGGL(agx_k_node_sweep<true>, dim3(AGX_BIG_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
 }
-void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
-    const agx_u32 n = K->S.n_tiles;
-    if (!n) return;
-    hipLaunchKernelGGL(agx_k_edge_sweep, dim3((n + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
-    hipLaunchKernelGGL(agx_k_edge_slow, dim3(AGX_SLOW_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
+void agx_launch_edge_sweep(const agx_edge_kargs *K, agx_u32 n_hits, hipStream_t st) {
+    const agx_u32 n = K->S.n_pos;
+    if (n) hipLaunchKernelGGL(agx_k_edge_sweep, dim3((n + 255) / 256), dim3(256), 0, st, *K);
+    if (n && n_hits) hipLaunchKernelGGL(agx_k_edge_jump, dim3((n_hits + 255) / 256), dim3(256), 0, st, *K, n_hits);
+}
+void agx_launch_edge_slow(const agx_edge_kargs *K, hipStream_t st) {
+    if (K->S.n_tiles) hipLaunchKernelGGL(agx_k_edge_slow, dim3(AGX_SLOW_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
 }
 
 void agx_launch_side_count(const agx_compact_args *A, hipStream_t st) {

@@ -96,6 +96,7 @@ typedef struct {
     double ms_parse, ms_thread, ms_upload, ms_prep, ms_bin, ms_node_sweep, ms_node_big, ms_edge_sweep, ms_compact, ms_download, ms_walk;
     uint32_t node_sweep_launches, edge_sweep_launches;
     uint64_t n_walk_ids, n_special, n_fetched, download_bytes;   /* walk graph: ids, node records downloaded, records fetched one by one, D2H bytes */
+    double ms_edge_fast, ms_edge_slow;                           /* the two kernels of ms_edge_sweep: pass A (lanes = positions), pass B (lanes = hits) */
 } agx_stats;
 
 /* Node/edge tables in canonical numbering (position-major, variant order), for parity tests. malloc'd; free with agx_graph_free. */

@@ -97,22 +97,21 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
         for (agx_u32 lane = 0; lane < AGX_TILE; lane++) { wb.base = store + lane; agx_node_write_lane(A, t * AGX_TILE + lane, wb, cnt[lane], pool, pflag[lane]); pool += cnt[lane]; }
     }
     S.n_nodes = pool;
-    // edge build: pass A (lanes = positions) collects the slow positions, pass B resolves every hit of their tiles
+    // edge build: pass A (lanes = positions) writes the x -> x+1 edges of single-variant positions and collects the slow positions,
+    // pass J (lanes = hits) adds the steps that do not go to x+1, pass B resolves every hit of the slow positions' tiles
+    auto ins = [&](agx_u32 src, agx_u32 dst) {
+        agx_u32 *slots = S.next.data() + (size_t)src * AGX_MAXE;
+        for (agx_u32 e = 0; e < AGX_MAXE; e++) { if (slots[e] == AGX_NONE) slots[e] = dst; if (slots[e] == dst) return; }
+        S.flags[src] |= AGX_NF_EOVF; S.ovf.push_back(agx_edge_ovf{src, dst});
+    };
     std::vector<agx_u32> slow;
-    for (agx_u32 t = 0; t < n_tiles; t++)
-        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
-            const agx_u32 X = t * AGX_TILE + lane;
-            if (X >= n_pos) continue;
-            const agx_u32 nbs = X + 1 < n_pos ? S.node_start[X + 1] : 0, nbc = X + 1 < n_pos ? S.node_cnt[X + 1] : 0;
-            if (agx_edge_fast_lane(A, t, X, S.node_start[X], S.node_cnt[X], nbs, nbc, get, [&](agx_u32 s, agx_u32 d) { S.ovf.push_back(agx_edge_ovf{s, d}); })) slow.push_back(X);
-        }
+    for (agx_u32 X = 0; X < n_pos; X++) {
+        const agx_u32 nbs = X + 1 < n_pos ? S.node_start[X + 1] : 0, nbc = X + 1 < n_pos ? S.node_cnt[X + 1] : 0;
+        if (agx_edge_fast_lane(A, X, S.node_start[X], S.node_cnt[X], nbs, nbc)) slow.push_back(X);
+    }
+    for (size_t h = 0; h < dh.size(); h++) agx_edge_jump_hit(A, dh[h], ins);
     for (agx_u32 X : slow) {
         const agx_u32 t = X / AGX_TILE;
-        auto ins = [&](agx_u32 src, agx_u32 dst) {
-            agx_u32 *slots = S.next.data() + (size_t)src * AGX_MAXE;
-            for (agx_u32 e = 0; e < AGX_MAXE; e++) { if (slots[e] == AGX_NONE) slots[e] = dst; if (slots[e] == dst) return; }
-            S.flags[src] |= AGX_NF_EOVF; S.ovf.push_back(agx_edge_ovf{src, dst});
-        };
         agx_slow_ctx c; agx_edge_slow_ctx(A, X, c);
         agx_u32 pairs = 0;
         for (agx_u32 i = tile_off[t]; i < tile_off[t + 1]; i++) pairs |= agx_edge_slow_pair(A, c, X, dh[tile_hits[i]], true, ins);
