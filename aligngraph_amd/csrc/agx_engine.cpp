@@ -278,7 +278,7 @@ void do_download(agx_unit *u) {
     const size_t n_pos = u->T.ref.size(), ni = u->n_ids;
     hipStream_t st = u->st;
     const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
-    u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 16); u->h_side_xpos.alloc(nside + 1);
+    u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(nside + 1);
     u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1);
     u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
     if (ni) {
@@ -291,7 +291,7 @@ void do_download(agx_unit *u) {
     if (ns) HIP_OK(hipMemcpyAsync(u->h_sp_node.p, u->d_sp_node.p, ns * sizeof(agx_walknode), hipMemcpyDeviceToHost, st));
     if (u->n_ovf) HIP_OK(hipMemcpyAsync(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    memset(u->h_a_meta.p + ni, 0, 16);
+    memset(u->h_a_meta.p + ni, 0, 64);
     u->stats.n_walk_ids = ni; u->stats.n_special = ns;
     u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * sizeof(agx_walknode) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
     u->downloaded = true;

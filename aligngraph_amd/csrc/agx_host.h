@@ -53,7 +53,7 @@ struct Pairs {
 // Node records come as the sparse table of the special ids; any other id (only reachable after the +1000 skip) goes through fetch().
 struct GraphView {
     agx_u32 n_pos = 0, n_ids = 0;
-    const agx_u8 *meta = nullptr;                           // [n_ids + 16] AGX_WM_* bits (padding reads as 0)
+    const agx_u8 *meta = nullptr;                           // [n_ids + 64] AGX_WM_* bits (padding reads as 0)
     const char *str = nullptr;                              // [n_ids] base a node emits
     const agx_u32 *side_xpos = nullptr;                     // [n_ids - n_pos] position of each side id, non-decreasing
     const unsigned long long *sp_bits = nullptr;            // [n_ids/64 + 1] special-id bitmap

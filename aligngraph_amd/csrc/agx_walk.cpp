@@ -14,6 +14,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <unordered_map>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace agx {
 namespace {
@@ -36,11 +39,47 @@ inline void fasta_body(std::string &out, const char *s, size_t n) {
     for (size_t i = 0; i < n; i += 60) { const size_t m = n - i < 60 ? n - i : 60; out.append(s + i, m); out.push_back('\n'); }
 }
 
+// End of the forced run that starts at node `cur`: the first j >= cur whose cont bit is clear or whose successor j+1 is already
+// visited (the reference steps cur -> cur+1 while its unique live successor is unvisited, AG:2020-2046).  `seen` collects the meta
+// bits of the nodes passed.  meta and done are padded by 64 bytes (meta: zeros, done: ones), so whole-vector reads past j are safe.
+inline agx_u32 run_end_scalar(const agx_u8 *meta, const agx_u8 *done, agx_u32 j, agx_u8 &seen) {
+    for (;;) {
+        uint64_t mw, dw; memcpy(&mw, meta + j, 8); memcpy(&dw, done + j + 1, 8);
+        if ((mw & 0x0101010101010101ull) == 0x0101010101010101ull && dw == 0) { mw |= mw >> 32; mw |= mw >> 16; mw |= mw >> 8; seen |= (agx_u8)mw; j += 8; continue; }
+        for (int b8 = 0; b8 < 8; b8++) { const agx_u8 m = meta[j]; seen |= m; if (!(m & AGX_WM_CONT) || done[j + 1]) return j; j++; }
+    }
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline agx_u32 run_end_avx2(const agx_u8 *meta, const agx_u8 *done, agx_u32 j, agx_u8 &seen) {
+    const __m256i one = _mm256_set1_epi8(1);
+    __m256i acc = _mm256_setzero_si256();
+    for (;;) {
+        const __m256i m = _mm256_loadu_si256((const __m256i *)(meta + j)), d = _mm256_loadu_si256((const __m256i *)(done + j + 1));
+        // a node lets the run pass iff its cont bit is set and its successor is unvisited
+        const __m256i pass = _mm256_andnot_si256(_mm256_cmpeq_epi8(d, one), _mm256_cmpeq_epi8(_mm256_and_si256(m, one), one));
+        const unsigned stop = ~(unsigned)_mm256_movemask_epi8(pass);
+        if (stop == 0) { acc = _mm256_or_si256(acc, m); j += 32; continue; }
+        const unsigned k = (unsigned)__builtin_ctz(stop);                       // the run ends ON node j+k
+        alignas(32) agx_u8 lanes[32]; _mm256_store_si256((__m256i *)lanes, acc);
+        for (int i = 0; i < 32; i++) seen |= lanes[i];
+        for (unsigned i = 0; i <= k; i++) seen |= meta[j + i];
+        return j + k;
+    }
+}
+#endif
+typedef agx_u32 (*run_end_fn)(const agx_u8 *, const agx_u8 *, agx_u32, agx_u8 &);
+inline run_end_fn pick_run_end() {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2")) return run_end_avx2;
+#endif
+    return run_end_scalar;
+}
+
 struct Walker {
     const Threads &T; const Pairs &P; const GraphView &G;
     std::vector<agx_u8> done;                       // traversed flag per ALIVE node (pruned nodes never reach the host)
     std::vector<agx_edge_ovf> ovf;                  // sorted, unique
-    Walker(const Threads &t, const Pairs &p, const GraphView &g) : T(t), P(p), G(g), done((size_t)g.n_ids + 24, 1) {
+    Walker(const Threads &t, const Pairs &p, const GraphView &g) : T(t), P(p), G(g), done((size_t)g.n_ids + 72, 1) {
         for (size_t i = 0; i < g.n_ids; i++) done[i] = g.meta[i] >> 7;     // ids without a node count as visited; the tail is a sentinel
         for (size_t i = 0; i < g.n_ovf; i++) if (g.ovf[i].src != AGX_NONE) ovf.push_back(g.ovf[i]);
         std::sort(ovf.begin(), ovf.end(), [](const agx_edge_ovf &a, const agx_edge_ovf &b) { return a.src != b.src ? a.src < b.src : a.dst < b.dst; });
@@ -127,6 +166,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
     std::vector<Seg> segs;
     pre_out.reserve((size_t)G.n_ids + G.n_ids / 32 + 4096);
     agx_u8 *done = W.done.data();
+    const run_end_fn run_end = pick_run_end();
     unsigned long long n_walks = 0, n_hops = 0, n_runs = 0, n_general = 0, run_nodes = 0;
     const agx_u32 n_side = G.n_ids - G.n_pos;
     agx_u32 sc = 0;                              // side index cursor: every side id before it lies at a position < cp
@@ -160,21 +200,14 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
                     else mode = -2;
                 } else {                                    // on a k-mer node, AG:1995-2060
                     // forced run: while the cont bit holds and the next node is unvisited the reference steps cur -> cur+1 (its unique live
-                    // successor).  Eight nodes per iteration: all cont bits set and none of the eight successors visited.
-                    agx_u32 j = cur; agx_u8 seen = 0;
-                    for (;;) {
-                        uint64_t mw, dw; memcpy(&mw, G.meta + j, 8); memcpy(&dw, done + j + 1, 8);
-                        if ((mw & 0x0101010101010101ull) == 0x0101010101010101ull && dw == 0) {
-                            mw |= mw >> 32; mw |= mw >> 16; mw |= mw >> 8; seen |= (agx_u8)mw; j += 8; continue;
-                        }
-                        bool stop = false;
-                        for (int b8 = 0; b8 < 8; b8++) { const agx_u8 m = G.meta[j]; seen |= m; if (!(m & AGX_WM_CONT) || done[j + 1]) { stop = true; break; } j++; }
-                        if (stop) break;
-                    }
+                    // successor).
+                    agx_u8 seen = 0;
+                    const agx_u32 j = run_end(G.meta, done, cur, seen);
+                    const agx_u32 xj = W.pos_of(j);
+                    __builtin_prefetch(&T.hop[xj]);                             // most walks leave the k-mer graph here, onto a conti-mer chain
                     segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!(G.meta[j] & AGX_WM_CONT)) n_general++;
                     if (seen & AGX_WM_CONTIG) C.extended = 1;
                     memset(done + cur, 1, (size_t)j - cur + 1);
-                    const agx_u32 xj = W.pos_of(j);
                     if (j > cur) pos_bak = xj;
                     cur = j; last = j; cpp = xj;
                     agx_u32 tgt = 0;
@@ -194,7 +227,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
             } else { C.eID0 = AGX_NONE; C.eOff0 = AGX_NONE; }
             if (!contains(sIDBak, sOffBak, eIDBak, eOffBak, C.sID, C.sOff, C.eID, C.eOff)) {        // AG:2176-2189
                 size_t total = 0; for (const Seg &g : segs) total += g.n;
-                C.nuc.resize(total); { char *w = &C.nuc[0]; for (const Seg &g : segs) { memcpy(w, g.p, g.n); w += g.n; } }
+                C.nuc.reserve(total); for (const Seg &g : segs) C.nuc.append(g.p, g.n);
                 char hdr[256];
                 const int hl = std::snprintf(hdr, sizeof hdr, ">%u, %d, %u, %u, %u, %u, %u, %u, %u, %u \n", seqID++, C.extended, C.sID, C.sOff, C.eID, C.eOff, C.sID0, C.sOff0, C.eID0, C.eOff0);
                 const size_t lines = (total + 59) / 60;

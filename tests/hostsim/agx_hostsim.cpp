@@ -128,7 +128,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     agx_u32 run = 0; for (agx_u32 x = 0; x <= n_pos; x++) { S.side_start[x] = run; run += S.side_cnt[x]; }
     S.n_ids = n_pos + run;
     const size_t na = (size_t)S.n_ids + 1;
-    S.a_str.assign(na, 0); S.a_meta.assign(na + 16, 0);
+    S.a_str.assign(na, 0); S.a_meta.assign(na + 64, 0);
     S.a_node.assign(na, agx_walknode{{AGX_NONE, AGX_NONE, AGX_NONE, AGX_NONE}, AGX_NONE, 0, agx_sref{0, 0}});
     S.a_ovf.assign(S.ovf.size() + 1, agx_edge_ovf{AGX_NONE, AGX_NONE});
     C.a_str = &S.a_str[0]; C.a_meta = S.a_meta.data(); C.a_node = S.a_node.data();
