@@ -582,7 +582,7 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
     if (ndev_all <= 0) die("NO HIP DEVICE: AlignGraph_amd needs a GPU (there is no CPU path)");
     int ndev = ndev_all;
     if (const char *e = getenv("AGX_DEVICES")) ndev = std::max(1, std::min(ndev_all, atoi(e)));
-    const int per_dev = std::max(1, getenv("AGX_UNITS_PER_DEVICE") ? atoi(getenv("AGX_UNITS_PER_DEVICE")) : 2);   // >1: one unit's host walk overlaps another's kernels
+    const int per_dev = std::max(1, getenv("AGX_UNITS_PER_DEVICE") ? atoi(getenv("AGX_UNITS_PER_DEVICE")) : 4);   // >1: the text parsing and host walk of one unit overlap the kernels of others
     std::atomic<int> next(first);
     vector<int> state(units, 0); vector<string> errors(units);
     std::mutex mu; int reported = first;

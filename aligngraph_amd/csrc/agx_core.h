@@ -36,7 +36,8 @@ typedef uint8_t agx_u8;
 #define AGX_NONE 0xFFFFFFFFu
 #define AGX_TILE 64u          // positions per tile = lanes per wavefront
 #ifndef AGX_MAXV_LDS
-#define AGX_MAXV_LDS 4u       // variants per position held in LDS; tiles that need more are re-run with global scratch
+#define AGX_MAXV_LDS 3u       // variants per position held in LDS (3: 10 KB per wavefront -> 4 wavefronts per SIMD; 4 -> 3, measured 15 % slower);
+                              // tiles that need more are re-run with global scratch
 #endif
 #define AGX_MAXV_BIG 64u      // variants per position in the global-scratch fallback
 #define AGX_MAXE 4u           // out-edges stored inline per node; more go to the overflow list
