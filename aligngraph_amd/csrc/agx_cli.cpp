@@ -6,8 +6,8 @@
 //   bowtie2 + pblat|blat through system() with the reference's exact command strings, two threads (AG:3581-3735), distributeAlignments
 //   (AG:3545-3579)  ·  tmp/_checkpoint.txt + --resume (AG:4648-4680, 4724-4760)  ·  the unit loop (AG:4765-4783) = libagx, units spread
 //   over the visible GPUs  ·  refinement (AG:2864-3195) -> --extendedContig / --remainingContig (+ in.fa / ex.fa, AG:24 TEST).
-// misassembly removal (AG:3821-4297, row f2).  stdout carries the reference's own progress lines.  Not carried over: --fastMap
-// (NUCMER + delta2psl, AG:524-729) exits with a message; `ps euf >> mem.txt` (AG:4778) is not run.
+// misassembly removal (AG:3821-4297, row f2).  stdout carries the reference's own progress lines.  --fastMap runs NUCMER in place of
+// BLAT and converts its .delta files with delta2psl (AG:524-729).  `ps euf >> mem.txt` (AG:4778) is not run.
 //
 // Everything here is text plumbing around the path; the compute is agx_run_unit's (include/agx.h).
 #include <algorithm>
@@ -242,6 +242,100 @@ void distribute_alignments(int units) {
 
 int run(const string &cmd) { return system(cmd.c_str()); }
 
+// parseDelta, AG:524-586: the first four blank-separated items of a .delta line as integers.  Item 0 drops every '>'; an item of
+// the form "a.b" yields a and "real" part b — except that the reference fills the second item's real part starting at the index where
+// the first item's real part ended (one shared counter, AG:573), so after a dotted first item a dotted second item reads as 0.
+void parse_delta(const string &buf, int &a, int &b, int &c, int &d, int &realA, int &realB) {
+    string item[4];
+    int it = 0;
+    for (size_t i = 0; i < buf.size(); i++) {
+        if (buf[i] == ' ') { it++; continue; }
+        if (buf[i] == '\0') break;
+        if (it == 0 && buf[i] != '>') item[0].push_back(buf[i]);
+        if (it >= 1 && it <= 3) item[it].push_back(buf[i]);
+    }
+    auto split = [](const string &x, string &head, string &real) -> bool {    // digits before the first '.', all non-'.' characters after it
+        const size_t dot = x.find('.');
+        head = x.substr(0, dot);
+        real.clear();
+        if (dot == string::npos) return false;
+        for (size_t i = dot + 1; i < x.size(); i++) if (x[i] != '.') real.push_back(x[i]);
+        return true;
+    };
+    string ha, ra, hb, rb;
+    const bool aTag = split(item[0], ha, ra), bTag = split(item[1], hb, rb);
+    a = atoi(ha.c_str()); realA = aTag ? atoi(ra.c_str()) : -1;
+    b = atoi(hb.c_str()); realB = bTag ? ((aTag && !ra.empty()) ? 0 : atoi(rb.c_str())) : -1;
+    c = atoi(item[2].c_str()); d = atoi(item[3].c_str());
+}
+
+// delta2psl, AG:588-729: NUCMER's .delta -> the 21-column PSL the loaders read ("NA" where the reference has nothing to say).
+// The output name keeps everything before the second '.' of the input name (AG:601).
+void delta2psl(const string &st0) {
+    std::ifstream in(st0.c_str());
+    const size_t d1 = st0.find('.', 0), d2 = d1 == string::npos ? string::npos : st0.find('.', d1 + 1);
+    std::ofstream out((st0.substr(0, d2) + ".psl").c_str());
+    if (!in.is_open()) die("CANNOT OPEN FILE!");
+    struct Seg3 { unsigned sourceStart, targetStart, size; };
+    string buf;
+    int targetID = 0, sourceID = 0, targetSize = 0, sourceSize = 0, realTargetID = 0, realSourceID = 0, dummy = 0;
+    getline(in, buf); getline(in, buf);
+    while (in.good()) {
+        string align; vector<Seg3> seg; int sourceGap = 0, targetGap = 0;
+        int targetStart, targetEnd, sourceStart, sourceEnd;
+        getline(in, buf);
+        if (buf.empty() || buf[0] == '\0') break;
+        if (buf[0] == '>') { parse_delta(buf, targetID, sourceID, targetSize, sourceSize, realTargetID, realSourceID); getline(in, buf); }
+        parse_delta(buf, targetStart, targetEnd, sourceStart, sourceEnd, dummy, dummy);
+        char fr = '+';
+        if (!(sourceStart < sourceEnd)) { fr = '-'; std::swap(sourceStart, sourceEnd); }
+        getline(in, buf);
+        while (buf.empty() || buf[0] != '0') {                                // one signed distance per indel, "0" ends the alignment
+            if (!in.good()) die("BROKEN DELTA FILE");                         // (the reference never leaves this loop on a truncated file)
+            const int b = atoi(buf.c_str());
+            for (int i = 1; i < abs(b); i++) align.push_back('M');
+            if (b > 0) { align.push_back('I'); targetGap++; } else { align.push_back('D'); sourceGap++; }
+            getline(in, buf);
+        }
+        for (int i = (int)align.size(); i < (sourceEnd - sourceStart + 1) + targetGap; i++) align.push_back('M');
+        const int n = (int)align.size();
+        for (int i = 0, j = 0; i < n; i++) {                                   // block starts on the query ...
+            if (align[i] != 'I') j++;
+            if ((i == 0 && align[i] == 'M') || (i >= 1 && (align[i - 1] == 'I' || align[i - 1] == 'D') && align[i] == 'M'))
+                seg.push_back(Seg3{(unsigned)(sourceStart - 1 + j), (unsigned)-1, (unsigned)-1});
+        }
+        for (int i = 0, j = 0, sp = 0; i < n; i++) {                           // ... on the target ...
+            if (align[i] != 'D') j++;
+            if ((i == 0 && align[i] == 'M') || (i >= 1 && (align[i - 1] == 'I' || align[i - 1] == 'D') && align[i] == 'M'))
+                seg[sp++].targetStart = (unsigned)(targetStart - 1 + j);
+        }
+        for (int i = 0, j = 0, sp = 0; i < n; i++) {                           // ... and their lengths
+            if (align[i] == 'M') j++;
+            if (i + 1 < n && align[i] == 'M' && (align[i + 1] == 'I' || align[i + 1] == 'D')) { seg[sp++].size = (unsigned)j; j = 0; }
+            if (i == n - 1 && align[i] == 'M') seg[sp].size = (unsigned)j;
+        }
+        sourceStart--; targetStart--;
+        for (Seg3 &g : seg) { g.sourceStart--; g.targetStart--; }
+        out << "NA\tNA\tNA\tNA\tNA\t" << sourceGap << "\tNA\t" << targetGap << "\t" << fr << "\t";
+        if (realSourceID != -1) out << sourceID << "." << realSourceID << "\t"; else out << sourceID << "\t";
+        out << sourceSize << "\t" << sourceStart << "\t" << sourceEnd << "\t";
+        if (realTargetID != -1) out << targetID << "." << realTargetID << "\t"; else out << targetID << "\t";
+        out << targetSize << "\t" << targetStart << "\t" << targetEnd << "\tNA\t";
+        for (const Seg3 &g : seg) out << g.size << ",";
+        out << "\t";
+        for (const Seg3 &g : seg) out << g.sourceStart << ",";
+        out << "\t";
+        for (const Seg3 &g : seg) out << g.targetStart << ",";
+        out << endl;
+    }
+}
+
+// NUCMER in place of BLAT (--fastMap): a failed call leaves an empty .delta behind (AG:3634-3641, 2962-2969, 3833-3840)
+void nucmer_to_psl(const string &ref, const string &qry, const string &prefix, const string &delta) {
+    if (run("nucmer " + ref + " " + qry + " -p " + prefix + " > nucmer_doc.txt 2> nucmer_doc.txt") != 0) run("touch " + delta);
+    delta2psl(delta);
+}
+
 // task0 / task1 of parallelMap, AG:3581-3735: the two aligners run side by side, command strings unchanged
 void align_everything(const Options &o, int units) {
     std::thread reads([&]() {
@@ -260,6 +354,7 @@ void align_everything(const Options &o, int units) {
     });
     std::thread contigs([&]() {
         for (int u = 0; u < units; u++) {
+            if (o.fastMap == 1) { nucmer_to_psl("tmp/_genome." + itoa(u) + ".fa", "tmp/_contigs.fa", "tmp/_contigs_genome." + itoa(u), "tmp/_contigs_genome." + itoa(u) + ".delta"); continue; }
             const string io = "tmp/_genome." + itoa(u) + ".fa tmp/_contigs.fa -noHead tmp/_contigs_genome." + itoa(u) + ".psl -fastMap";
             if (run("pblat " + io + " -threads=8 > blat_doc.txt 2> blat_doc.txt") != 0)
                 if (run("blat " + io + " > blat_doc.txt 2> blat_doc.txt") != 0) die("BLAT CALL FAILED!");
@@ -343,7 +438,12 @@ void refinement(const Options &o, int units, const vector<string> &genomeIds, co
             else { out << ">" << num << '\n'; put60(out, f.seq[j]); }
         }
     }
-    for (int u = 0; u < units; u++) {                                         // AG:2974-2982
+    for (int u = 0; u < units; u++) {                                         // AG:2957-2982
+        if (o.fastMap == 1) {
+            const string pre = "tmp/_short_initial_contigs_extended_contigs." + itoa(u);
+            nucmer_to_psl("tmp/_extended_contigs." + itoa(u) + ".fa", "tmp/_short_initial_contigs." + itoa(u) + ".fa", pre, pre + ".delta");
+            continue;
+        }
         const string io = "tmp/_extended_contigs." + itoa(u) + ".fa tmp/_short_initial_contigs." + itoa(u) + ".fa -noHead tmp/_short_initial_contigs_extended_contigs." + itoa(u) + ".psl -fastMap";
         if (run("pblat " + io + " -threads=8 > blat_doc.txt 2> blat_doc.txt") != 0)
             if (run("blat " + io + " > blat_doc.txt 2> blat_doc.txt") != 0) die("BLAT CALL FAILED!");
@@ -430,7 +530,9 @@ void remove_misassembly(const Options &o, const string &file, const string &id, 
     run("bowtie2-build -f tmp/_" + id + "_contigs.fa tmp/_" + id + "_contigs > bowtie_doc.txt 2> bowtie_doc.txt");
     run("bowtie2 -f --no-mixed -k 1 -p 8 -I " + itoa(o.distanceLow) + " -X " + itoa(o.distanceHigh) + " --no-discordant -x tmp/_" + id +
         "_contigs -1 tmp/_reads_1.fa -2 tmp/_reads_2.fa --reorder > tmp/_reads_" + id + "_contigs.bowtie 2> bowtie_doc.txt");
-    {
+    if (o.fastMap == 1)                            // the reference hands NUCMER a prefix that already ends in ".delta" (AG:3833), so its output is never found
+        nucmer_to_psl("tmp/_genome.fa", "tmp/_" + id + "_contigs.fa", "tmp/_" + id + "_contigs_genome.delta", "tmp/_" + id + "_contigs_genome.delta");
+    else {
         const string io = "tmp/_genome.fa tmp/_" + id + "_contigs.fa -noHead tmp/_" + id + "_contigs_genome.psl -fastMap";
         if (run("pblat " + io + " -threads=8 > blat_doc.txt 2> blat_doc.txt") != 0)
             if (run("blat " + io + " > blat_doc.txt 2> blat_doc.txt") != 0) die("BLAT CALL FAILED!");
@@ -634,8 +736,8 @@ int main(int argc, char **argv) {
             o.distanceLow > o.distanceHigh || o.distanceLow < 0 || o.insertVariation < 0 || o.part < 1 || o.part > 10 || o.k > max_read_length(o.read1) || o.k > max_read_length(o.read2)) {
             usage(); return 0;                                                // AG:4726-4730 (exit status 0)
         }
-        if (o.fastMap) die("--fastMap (NUCMER + delta2psl) is not supported by AlignGraph_amd");
         if (run("bowtie2 -h > bowtie_doc.txt 2> bowtie_doc.txt") != 0) die("BOWTIE2 CALL FAILED!");   // testAligners, AG:4682-4694
+        if (o.fastMap == 1 && run("nucmer -h > nucmer_doc.txt 2> nucmer_doc.txt") != 0) die("NUCMER CALL FAILED!");
         mkdir("tmp", 0777);
         { std::ofstream wcmd("tmp/_command.txt"); for (int i = 1; i < argc; i++) wcmd << argv[i] << endl; }
         wcp.open("tmp/_checkpoint.txt");
@@ -654,7 +756,6 @@ int main(int argc, char **argv) {
         if (cp == -1) die("NOT REACHED CHECKPOINT. PLEASE RERUN!");
         o = Options(); parse_params("tmp/_command.txt", o);                   // AG:4752-4753 (the tags start from the --resume parse in the reference; only resume itself carries over)
         o.resume = 1;
-        if (o.fastMap) die("--fastMap (NUCMER + delta2psl) is not supported by AlignGraph_amd");
         cout << "RESUMED SUCCESSFULLY :-)" << endl;
         wcp.open("tmp/_checkpoint.txt", std::ios::app);
         formalize_contigs(o.contig, contigIds);

@@ -412,17 +412,20 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
     };
     // software pipeline over two arrival buffers that are never copied (a register copy would have to wait for the loads): buffer
     // A serves the even hits of the list, B the odd ones; a buffer is refilled for the hit two places ahead right after it has been
-    // applied, so its two per-lane loads have a whole apply + fetch of the other buffer to complete.  The derived hit records
-    // (wave-uniform, scalar loads in the kernels) are read two further hits ahead.
-    auto rec = [&](agx_u32 i) { return i < hi ? get(i) : agx_dhit{0, 0, 0, 0, 0, 0, 0, 0, 0, AGX_HF_SKIP, 1, 0}; };
+    // applied, so its two per-lane loads have a whole apply + fetch of the other buffer to complete.  The derived hit record
+    // (wave-uniform, a scalar load in the kernels) of the next refill is requested before the apply that precedes it.  Indices past
+    // the end of the list read its last record again and are masked out.
+    if (lo == hi) return true;
+    auto rec = [&](agx_u32 i) { return get(i < hi ? i : hi - 1); };
     auto fetch = [&](const agx_dhit &d, bool valid, agx_pre &p) { agx_arrival_fetch(A, d, X, valid && live, p); };
     agx_pre pa, pb;
-    { const agx_dhit d0 = rec(lo); fetch(d0, lo < hi, pa); }
+    { const agx_dhit d0 = rec(lo); fetch(d0, true, pa); }
     { const agx_dhit d1 = rec(lo + 1); fetch(d1, lo + 1 < hi, pb); }
-    agx_dhit da = rec(lo + 2), db = rec(lo + 3);
     for (agx_u32 i = lo; i < hi; i += 2) {
-        apply(pa); fetch(da, i + 2 < hi, pa); da = rec(i + 4);
-        apply(pb); fetch(db, i + 3 < hi, pb); db = rec(i + 5);
+        const agx_dhit da = rec(i + 2);
+        apply(pa); fetch(da, i + 2 < hi, pa);
+        const agx_dhit db = rec(i + 3);
+        apply(pb); fetch(db, i + 3 < hi, pb);
     }
     return ok;
 }

@@ -2,7 +2,7 @@
 
 A whole AlignGraph run, front to back, on seeded synthetic inputs with the aligners replaced by the deterministic test stubs of
 tests/e2e_stubs/ (bowtie2 replays a pre-generated SAM, pblat replays the contig PSL and runs an exact matcher for the refinement
-step).  The REAL reference binary (README build; the -O2 build cannot run the aligner threads) is run for every command variant and
+step, nucmer writes the same alignments as .delta files for the --fastMap variant).  The REAL reference binary (README build; the -O2 build cannot run the aligner threads) is run for every command variant and
 its stdout, its final FASTA files and its per-unit tmp/ outputs are stored as the expected bytes.  Data only — no reference source.
 """
 import io
@@ -24,6 +24,7 @@ VARIANTS = {
     "default": BASE + ["--coverage", "4"],
     "flags": BASE + ["--coverage", "3", "--kMer", "7", "--insertVariation", "40", "--ratioCheck", "--uniqueExtension"],
     "masb": BASE + ["--coverage", "3", "--misassemblyRemoval"],
+    "fastmap": BASE + ["--coverage", "4", "--fastMap"],              # NUCMER (stub) + the reference's own delta2psl
     # (--part > 1 is not in the end-to-end set: the reference indexes genomeIds by unit in refinement, AG:3102, and crashes on it)
 }
 INPUTS = ["reads_1.fa", "reads_2.fa", "contigs.fa", "genome.fa", "stub/reads_genome.sam"]
@@ -51,6 +52,8 @@ def main():
             part = int(args[args.index("--part") + 1]) if "--part" in args else 1
             # the aligner stubs replay per-unit data, so the data set is generated with the same --part the command uses
             extra = dict(seed=17, chimeric=0.5, contig_overlap=0.3, contig_min=500, contig_max=3500) if name == "masb" else dict(seed=21, contig_min=600, contig_max=3000)
+            if name == "fastmap":
+                extra = dict(seed=23, contig_min=600, contig_max=3000, contig_minus=0.5)       # both strands through delta2psl
             src = H.synth("/tmp/golden_e2e_" + name, chroms="12000,9000", part=part, pairs=4000, coverage=4, e2e=1, sam_seq=0, multi=0.1, **extra)
             work, out = run_reference(src, args)
             for fn in INPUTS + ["stub/" + f for f in sorted(os.listdir(os.path.join(src, "stub"))) if f.endswith(".psl")]:
@@ -61,7 +64,10 @@ def main():
                 if os.path.exists(os.path.join(work, fn)):
                     add("%s/expected/%s" % (name, fn), open(os.path.join(work, fn), "rb").read())
             for fn in sorted(os.listdir(os.path.join(work, "tmp"))):
-                if fn.startswith(("_initial_contigs", "_pre_extended_contigs", "_extended_contigs", "_short_initial", "_checkpoint", "_contigs.fa", "_chaff", "_genome")):
+                keep = ("_initial_contigs", "_pre_extended_contigs", "_extended_contigs", "_short_initial", "_checkpoint", "_contigs.fa", "_chaff", "_genome")
+                if "--fastMap" in args:
+                    keep += ("_contigs_genome",)                      # NUCMER's .delta and what delta2psl made of it
+                if fn.startswith(keep):
                     add("%s/expected/tmp/%s" % (name, fn), open(os.path.join(work, "tmp", fn), "rb").read())
             print(name, "extended records:", open(os.path.join(work, "e.fa")).read().count(">"), "remaining:", open(os.path.join(work, "r.fa")).read().count(">"))
             print(out.decode()[-300:])

@@ -51,7 +51,7 @@ def strip_time(out):
     return re.sub(rb"for \d+ seconds \(\d+ seconds for alignment\)", b"for N seconds (N seconds for alignment)", out)
 
 
-@pytest.mark.parametrize("name", ["default", "flags", "masb"])
+@pytest.mark.parametrize("name", ["default", "flags", "masb", "fastmap"])
 def test_front_half_and_refinement_match_reference(cli, name, tmp_path):
     import aligngraph_amd as A
     if A.device_count() > 0:
@@ -60,7 +60,7 @@ def test_front_half_and_refinement_match_reference(cli, name, tmp_path):
     p = c.run(cli, c.args)
     assert p.returncode == 255 and b"(0) Alignment finished" in p.stdout and b"NO HIP DEVICE" in p.stdout     # loud, not a fallback
     for fn in os.listdir(os.path.join(c.exp, "tmp")):
-        if fn.startswith(("_contigs.fa", "_chaff", "_genome")):
+        if fn.startswith(("_contigs.fa", "_chaff", "_genome", "_contigs_genome")):     # _contigs_genome.*: --fastMap's .delta and delta2psl's PSL
             assert c.got("tmp/" + fn) == c.expected("tmp/" + fn), fn
     assert c.got("tmp/_checkpoint.txt") == b"0\n"
     # hand over the reference's unit outputs and resume at the end of the unit loop
@@ -75,7 +75,9 @@ def test_front_half_and_refinement_match_reference(cli, name, tmp_path):
         if os.path.exists(os.path.join(c.exp, fn)):
             assert c.got(fn) == c.expected(fn), fn
     for fn in os.listdir(os.path.join(c.exp, "tmp")):
-        if fn.startswith("_short_initial_contigs."):
+        if fn.startswith("_short_initial_contigs"):                                       # incl. the refinement alignment of --fastMap (.delta, .psl)
+            if fn.endswith(".psl") and "--fastMap" not in c.args:
+                continue
             assert c.got("tmp/" + fn) == c.expected("tmp/" + fn), fn
 
 
@@ -96,7 +98,7 @@ def test_usage_and_parameter_errors(cli, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["default", "flags", "masb"])
+@pytest.mark.parametrize("name", ["default", "flags", "masb", "fastmap"])
 def test_full_run_matches_reference(cli, name, tmp_path):
     c = Case(name, tmp_path)
     p = c.run(cli, c.args)
