@@ -41,6 +41,82 @@ def gather_bytes(payload, dist, device, rank, world, dst=0):
     return [bytes(o[:s].cpu().numpy().tobytes()) for o, s in zip(outs, sizes)]
 
 
+class UnitGather:
+    """The same gather-v for a loop that runs it every step: persistent staging buffers (pinned on the GPU box), one all_reduce(MAX) of
+    the payload size per step instead of an all_gather + world host reads, the transfers queued without blocking, and no bytes objects
+    built on the root until someone asks.  Per step the calling thread pays one 8-byte device-to-host read plus a memcpy of its own
+    payload; the root's device-to-host copy of the world x cap gather buffer completes behind an event.
+
+    step(payload) -> handle; handle.payloads() on dst gives the list of payloads (bytes) of that step, None elsewhere.  A handle
+    reads the persistent buffers, so it is only good until the next step()."""
+
+    class _Handle:
+        def __init__(self, owner, sizes_host, event, host, cap):
+            self._o, self._sizes, self._event, self._host, self._cap = owner, sizes_host, event, host, cap
+
+        def payloads(self):
+            if self._host is None:
+                return None
+            if self._event is not None:
+                self._event.synchronize()
+            flat = self._host.numpy()
+            out = []
+            for r in range(self._o.world):
+                n = int.from_bytes(flat[r * self._cap:r * self._cap + 8].tobytes(), "little")
+                out.append(flat[r * self._cap + 8:r * self._cap + 8 + n].tobytes())
+            return out
+
+    def __init__(self, dist, device, rank, world, dst=0):
+        self.dist, self.device, self.rank, self.world, self.dst = dist, device, rank, world, dst
+        self.cap = 0
+        self._stage = self._dev = self._recv = self._recv_host = self._staged = None
+
+    def _grow(self, cap):
+        import torch
+        pin = self.device.type == "cuda"
+        self.cap = cap
+        self._staged = None
+        self._stage = torch.zeros(cap, dtype=torch.uint8, pin_memory=pin)
+        self._dev = torch.zeros(cap, dtype=torch.uint8, device=self.device)
+        if self.rank == self.dst:
+            self._recv = [torch.zeros(cap, dtype=torch.uint8, device=self.device) for _ in range(self.world)]
+            self._recv_host = torch.zeros(cap * self.world, dtype=torch.uint8, pin_memory=pin)
+
+    def step(self, payload):
+        import torch
+        if self.dist is None or self.world == 1:
+            class _Local:
+                def payloads(_s):
+                    return [payload]
+            return _Local()
+        need = torch.tensor([len(payload) + 8], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(need, op=self.dist.ReduceOp.MAX)
+        need = int(need.item())
+        if need > self.cap:
+            self._grow((need + need // 8 + (1 << 20)) & ~((1 << 20) - 1))       # every rank sees the same maximum, so the same capacity
+        if self._staged is not None:
+            self._staged.synchronize()                                          # the previous step's host-to-device copy has read the staging buffer
+        st = self._stage.numpy()
+        st[:8] = memoryview(len(payload).to_bytes(8, "little"))
+        if payload:
+            st[8:8 + len(payload)] = memoryview(payload)
+        self._dev.copy_(self._stage, non_blocking=True)
+        if self.device.type == "cuda":
+            self._staged = torch.cuda.Event()
+            self._staged.record()
+        self.dist.gather(self._dev, self._recv if self.rank == self.dst else None, dst=self.dst)
+        if self.rank != self.dst:
+            return UnitGather._Handle(self, None, None, None, self.cap)
+        host = self._recv_host
+        for r in range(self.world):
+            host[r * self.cap:(r + 1) * self.cap].copy_(self._recv[r], non_blocking=True)
+        event = None
+        if self.device.type == "cuda":
+            event = torch.cuda.Event()
+            event.record()
+        return UnitGather._Handle(self, None, event, host, self.cap)
+
+
 def pack_units(unit_ids, blobs):
     """Length-prefixed concatenation of (unit id, bytes) so that one gather carries all units of a rank."""
     import struct

@@ -34,11 +34,21 @@ def _worker(rank, world, port, run, meta, q):
     mine = shard.assign_units(meta["unit_len"], world)[rank]
     blobs = [H.run_oracle(os.path.join(run, "tmp"), u, meta["k"], meta["insert_variation"], meta["coverage"])["extended"] for u in mine]
     got = shard.gather_bytes(shard.pack_units(mine, blobs), dist, torch.device("cpu"), rank, world)
+    # the per-step variant bench.py uses: persistent buffers, growing capacity, several steps
+    g = shard.UnitGather(dist, torch.device("cpu"), rank, world)
+    steps = [g.step(shard.pack_units(mine[:n], blobs[:n])).payloads() for n in (0, len(mine), 1)]
     if rank == 0:
         merged = {}
         for payload in got:
             merged.update(shard.unpack_units(payload))
+        again = {}
+        for payload in steps[1]:
+            again.update(shard.unpack_units(payload))
+        assert again == merged and all(shard.unpack_units(p) == {} for p in steps[0])
+        assert sum(len(shard.unpack_units(p)) for p in steps[2]) == sum(1 for r in shard.assign_units(meta["unit_len"], world) if r)
         q.put(merged)
+    else:
+        assert steps == [None, None, None]
     dist.barrier()
     dist.destroy_process_group()
 
