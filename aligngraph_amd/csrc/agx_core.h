@@ -93,6 +93,14 @@ AGX_HD agx_u32 agx_clause_ab(agx_u32 ac, agx_u32 ao, agx_u32 bc, agx_u32 bo, int
 }
 AGX_HD agx_u32 agx_clause_c(agx_u32 ao, agx_u32 bo, int win) { return ((agx_u32)(ao == AGX_NONE) | (agx_u32)(bo == AGX_NONE) | agx_within(ao, bo, win)) & 1u; }
 
+// Wave-uniform read of a table that the running kernel never writes.  On the device the load goes through the constant address space,
+// so a uniform index makes it a scalar load (s_load_*, scalar cache) instead of 64 identical per-lane requests; the host reads normally.
+#if defined(__HIP_DEVICE_COMPILE__)
+AGX_HD agx_u32 agx_uload(const agx_u32 *p, size_t i) { return ((const __attribute__((address_space(4))) agx_u32 *)p)[i]; }
+#else
+AGX_HD agx_u32 agx_uload(const agx_u32 *p, size_t i) { return p[i]; }
+#endif
+
 // A bucket view: base points at this lane's column; element (variant v, field f) is base[(v*AGX_NF+f)*stride]
 struct agx_bucket { agx_u32 *base; agx_u32 stride; agx_u32 maxv; };
 AGX_HD agx_u32 &agx_b(const agx_bucket &b, agx_u32 v, agx_u32 f) { return b.base[(v * AGX_NF + f) * b.stride]; }
@@ -571,19 +579,28 @@ AGX_HD agx_u32 agx_key_compatible(const agx_key &k, const agx_key &st, int iv) {
 }
 
 AGX_HD void agx_edge_slow_ctx(const agx_sweep_args &A, agx_u32 X, agx_slow_ctx &c) {
-    c.s = A.node_start[X]; c.n = A.node_cnt[X]; c.s1 = 0; c.n1 = 0; c.allowed = 0;
+    c.s = agx_uload(A.node_start, X); c.n = A.node_cnt[X]; c.s1 = 0; c.n1 = 0; c.allowed = 0;
     c.cx = agx_cmkey{AGX_NONE, AGX_NONE}; c.sx = c.cx;
     const bool has1 = X + 1 < A.n_pos;
-    if (has1) { c.s1 = A.node_start[X + 1]; c.n1 = A.node_cnt[X + 1]; }
-    const agx_cmhead hx = A.cm_head[X], hx1 = has1 ? A.cm_head[X + 1] : agx_cmhead{AGX_NONE, AGX_NONE, 0u, 0u};
-    c.reg = (has1 && c.n <= AGX_SLOW_V && c.n1 <= AGX_SLOW_V && hx.n <= 1 && hx1.n <= 1) ? 1u : 0u;
+    if (has1) { c.s1 = agx_uload(A.node_start, X + 1); c.n1 = A.node_cnt[X + 1]; }
+    const agx_u32 *hw = reinterpret_cast<const agx_u32 *>(A.cm_head);            // {cid, coff, n, start} per position
+    const agx_u32 hx_n = agx_uload(hw, 4 * (size_t)X + 2), hx1_n = has1 ? agx_uload(hw, 4 * (size_t)X + 6) : 0u;
+    c.reg = (has1 && c.n <= AGX_SLOW_V && c.n1 <= AGX_SLOW_V && hx_n <= 1 && hx1_n <= 1) ? 1u : 0u;
     if (!c.reg) return;
-    c.cx = agx_cmkey{hx.cid, hx.coff}; c.sx = agx_cmkey{hx1.cid, hx1.coff};
+    c.cx = agx_cmkey{agx_uload(hw, 4 * (size_t)X), agx_uload(hw, 4 * (size_t)X + 1)};
+    c.sx = agx_cmkey{agx_uload(hw, 4 * (size_t)X + 4), agx_uload(hw, 4 * (size_t)X + 5)};
     const agx_key none = agx_key{AGX_NONE, AGX_NONE, AGX_NONE, AGX_NONE, AGX_NONE};
     for (agx_u32 v = 0; v < AGX_SLOW_V; v++) {
         c.kx[v] = none; c.kx1[v] = none;
-        if (v < c.n) { const agx_u32 id = c.s + v; c.kx[v] = agx_key{A.nk_cid[id], A.nk_coff[id], A.nk_cid0[id], A.nk_coff0[id], A.nk_off0[id]}; }
-        if (v < c.n1) { const agx_u32 id = c.s1 + v; c.kx1[v] = agx_key{A.nk_cid[id], A.nk_coff[id], A.nk_cid0[id], A.nk_coff0[id], A.nk_off0[id]}; }
+        // the device reads all AGX_SLOW_V rows of both buckets in one batch of scalar loads (rows past a bucket's end are other nodes'
+        // keys inside the pool, which is allocated with that much slack, and are never looked at)
+#if defined(__HIP_DEVICE_COMPILE__)
+        const bool in0 = true, in1 = true;
+#else
+        const bool in0 = v < c.n, in1 = v < c.n1;
+#endif
+        if (in0) { const size_t id = (size_t)c.s + v; c.kx[v] = agx_key{agx_uload(A.nk_cid, id), agx_uload(A.nk_coff, id), agx_uload(A.nk_cid0, id), agx_uload(A.nk_coff0, id), agx_uload(A.nk_off0, id)}; }
+        if (in1) { const size_t id = (size_t)c.s1 + v; c.kx1[v] = agx_key{agx_uload(A.nk_cid, id), agx_uload(A.nk_coff, id), agx_uload(A.nk_cid0, id), agx_uload(A.nk_coff0, id), agx_uload(A.nk_off0, id)}; }
     }
     for (agx_u32 vs = 0; vs < AGX_SLOW_V; vs++) for (agx_u32 vd = 0; vd < AGX_SLOW_V; vd++) {
         if (vs >= c.n || vd >= c.n1) continue;

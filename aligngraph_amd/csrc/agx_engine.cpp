@@ -110,7 +110,8 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
 
 void alloc_pool(agx_unit *u, agx_u32 cap) {
     u->pool_cap = cap;
-    u->d_cid.alloc(cap); u->d_coff.alloc(cap); u->d_cid0.alloc(cap); u->d_coff0.alloc(cap); u->d_off0.alloc(cap); u->d_xpos.alloc(cap);
+    const size_t kcap = (size_t)cap + AGX_SLOW_V;      // slack: the edge pass reads whole AGX_SLOW_V-row batches of keys (agx_edge_slow_ctx)
+    u->d_cid.alloc(kcap); u->d_coff.alloc(kcap); u->d_cid0.alloc(kcap); u->d_coff0.alloc(kcap); u->d_off0.alloc(kcap); u->d_xpos.alloc(cap);
     u->d_next.alloc((size_t)cap * AGX_MAXE); u->d_base.alloc(cap); u->d_flags.alloc(cap); u->d_sref.alloc(cap);
     if (u->prm.flags & AGX_FLAG_KEEP_COUNTS) u->d_counts.alloc((size_t)cap * 6);
 }

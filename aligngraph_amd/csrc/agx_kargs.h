@@ -25,7 +25,7 @@ struct agx_edge_kargs {
     agx_sweep_args S; agx_edge_ovf *ovf; agx_u32 *ovf_count; agx_u32 ovf_cap; agx_u32 list_cap;
     agx_u32 *slow_list; agx_u32 *slow_count;   // positions that need the per-hit pass (device-side list)
 };
-#define AGX_SLOW_WAVES 8192u    // resident wavefronts of the per-hit edge pass (stride over the slow list)
+#define AGX_SLOW_WAVES 8192u    // wavefronts of the per-hit edge pass if the occupancy query fails (normally: as many as are resident at once)
 
 extern "C" {
 void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t);

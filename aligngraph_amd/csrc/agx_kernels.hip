@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
     const agx_u32 lane = threadIdx.x & 63u;
     const agx_u32 wave = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     const agx_u32 n = __builtin_amdgcn_readfirstlane(*K.slow_count);
-    for (agx_u32 w = wave; w < n; w += AGX_SLOW_WAVES) {
+    const agx_u32 n_waves = gridDim.x * AGX_WAVES_PER_BLOCK;
+    for (agx_u32 w = wave; w < n; w += n_waves) {
         const agx_u32 X = __builtin_amdgcn_readfirstlane(K.slow_list[w]);
         const agx_u32 tile = X / AGX_TILE;
         const agx_u32 lo = K.S.tile_off[tile], hi = K.S.tile_off[tile + 1];
@@ -330,7 +331,15 @@ void agx_launch_edge_sweep(const agx_edge_kargs *K, agx_u32 n_hits, hipStream_t 
     if (n && n_hits) hipLaunchKernelGGL(agx_k_edge_jump, dim3((n_hits + 255) / 256), dim3(256), 0, st, *K, n_hits);
 }
 void agx_launch_edge_slow(const agx_edge_kargs *K, hipStream_t st) {
-    if (K->S.n_tiles) hipLaunchKernelGGL(agx_k_edge_slow, dim3(AGX_SLOW_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
+    // persistent wavefronts: exactly as many blocks as the device holds at once (a second, partial round of blocks would idle most CUs)
+    static int blocks = 0;
+    if (!blocks) {
+        int per_cu = 0, dev = 0; hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agx_k_edge_slow, 256, 0) == hipSuccess && per_cu > 0 &&
+            hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) blocks = per_cu * prop.multiProcessorCount;
+        else blocks = AGX_SLOW_WAVES / AGX_WAVES_PER_BLOCK;
+    }
+    if (K->S.n_tiles) hipLaunchKernelGGL(agx_k_edge_slow, dim3((unsigned)blocks), dim3(256), 0, st, *K);
 }
 
 void agx_launch_side_count(const agx_compact_args *A, hipStream_t st) {
