@@ -345,7 +345,7 @@ AGX_HD void agx_for_candidates(const agx_sweep_args &A, agx_u32 cx_s, agx_u32 cx
 // Everything one arrival needs from memory.  The sweep fetches it ONE HIT AHEAD of its use, so the dependent global loads
 // (mate conti-mer range -> first entry, vote base) of hit i+1 are in flight while hit i updates the bucket in LDS.
 struct agx_pre {
-    agx_u32 has, type, p0, step1;          // arrival present at this position; AGX_AT_*; mate position; its successor is position+1
+    agx_u32 has, type, p0, step1, jump;    // arrival present at this position; AGX_AT_*; mate position; its successor is position+1 / some other position
     agx_cmhead h; agx_u32 mate;            // conti-mer head of the mate position as loaded (position 0 if there is no mate), mate present
     agx_u32 s0, s1, cbyte, rev;            // k-mer string reference of this arrival; stored character of its base and the read's strand
 };
@@ -359,6 +359,7 @@ AGX_HD void agx_arrival_fetch(const agx_sweep_args &A, const agx_dhit &d, agx_u3
     const bool rev = (d.flags & AGX_HF_AREV) != 0;
     p.has = has ? 1u : 0u;
     p.step1 = (has && a.has_succ && a.xs == X + 1) ? 1u : 0u;
+    p.jump = (has && a.has_succ && a.xs != X + 1) ? 2u : 0u;
     p.type = a.type; p.p0 = a.p0; p.rev = rev ? 1u : 0u;
     p.s0 = d.a_slot;
     const agx_u32 stored = rev ? (agx_u32)d.len - 1u - a.q : a.q;                 // index of the arrival's base in the stored read
@@ -371,8 +372,12 @@ AGX_HD void agx_arrival_fetch(const agx_sweep_args &A, const agx_dhit &d, agx_u3
 // The whole in-order sweep of one position.  get(i) returns the derived hit record of tile-list entry i (the kernels stage 64
 // records at a time across the lanes of the wavefront and broadcast them; the test executor reads memory directly).
 // Returns false if the bucket overflowed (the tile is then re-run with a larger bucket).
-template <bool LDS_ADD, class GET>
-AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, const agx_bucket &b, agx_u32 &cnt, agx_u32 &pflag, GET get) {
+// exch(vm, step1) is called once per hit by every lane, in lockstep on the device: vm = the variants this hit's arrival touched at this
+// position (bit v), step1 = the hit steps from here to position+1.  It is how the sweep hands the x -> x+1 edges to agx_edge_merge:
+// an event's k2 half at x+1 is the same hit's arrival there, so the edge set of x is the union over hits of (variants at x) x (variants
+// at x+1) — known as soon as both lanes have applied the hit.
+template <bool LDS_ADD, class GET, class EXCH>
+AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, const agx_bucket &b, agx_u32 &cnt, agx_u32 &pflag, GET get, EXCH exch) {
     cnt = 0; pflag = 0;
     const bool live = X < A.n_pos;                       // lanes beyond the end still take part in the staging of hit records
     agx_u32 cx_s = 0, cx_n = 0; agx_cmkey cx0 = agx_cmkey{AGX_NONE, AGX_NONE};
@@ -382,7 +387,7 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
     // Branch-light on purpose: on wave64 every per-lane `if` costs exec-mask bookkeeping on the scalar unit, and the sweep runs
     // this body ~35 times per position.  The common case — one candidate key, compatible with variant 0 — is straight-line
     // code under a single `has` mask; everything else (several conti-mers, later variants, inserts) goes through slow().
-    auto slow = [&](const agx_pre &p, agx_u32 c0_s, agx_u32 c0_n, agx_cmkey c0_first, bool is_k1, agx_u32 vf) {
+    auto slow = [&](const agx_pre &p, agx_u32 c0_s, agx_u32 c0_n, agx_cmkey c0_first, bool is_k1, agx_u32 vf, agx_u32 &vm) {
         const agx_u32 nx = cx_n ? cx_n : 1u, n0 = c0_n ? c0_n : 1u;
         for (agx_u32 ci = 0; ci < nx && ok; ci++) {                      // candidate keys, X-major (AG:1369-1477)
             agx_key key; key.off0 = p.p0;
@@ -393,6 +398,7 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
                 key.cid0 = c0.cid; key.coff0 = c0.coff;
                 const agx_u32 v = agx_match_or_insert(b, cnt, key, A.iv, is_k1, p.s0, p.s1);
                 if (v == AGX_NONE) { ok = false; break; }
+                vm |= 1u << (v & 31u);
                 if (vf != AGX_NF) agx_b(b, v, vf) += 1;
             }
         }
@@ -403,7 +409,7 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
     // candidate keys enter slow().
     auto apply = [&](const agx_pre &p) {
         const agx_u32 has = p.has & (ok ? 1u : 0u);
-        pflag |= p.step1;
+        pflag |= p.step1 | p.jump;
         const agx_u32 is_k1 = p.type != AGX_AT_K2ONLY ? 1u : 0u;
         const agx_u32 vfield = agx_vote_field(p.cbyte, p.rev != 0);
         const agx_u32 vf = p.type == AGX_AT_K1 ? vfield : (agx_u32)AGX_NF;
@@ -416,7 +422,9 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
         const agx_u32 vote = fast & (agx_u32)(vf != AGX_NF);
         agx_bucket_add<LDS_ADD>(agx_b(b, 0, AGX_F_COV), fast & is_k1);
         agx_bucket_add<LDS_ADD>(agx_b(b, 0, vote ? vf : (agx_u32)AGX_F_COV), vote);
-        if (has & (fast ^ 1u)) slow(p, p.h.start, c0_n, c0k, is_k1 != 0, vf);
+        agx_u32 vm = fast;                                                          // the straight-line case touches variant 0
+        if (has & (fast ^ 1u)) slow(p, p.h.start, c0_n, c0k, is_k1 != 0, vf, vm);
+        exch(vm, p.step1);
     };
     // software pipeline over two arrival buffers that are never copied (a register copy would have to wait for the loads): buffer
     // A serves the even hits of the list, B the odd ones; a buffer is refilled for the hit two places ahead right after it has been
@@ -448,14 +456,27 @@ AGX_HD char agx_consensus(agx_u32 a, agx_u32 c, agx_u32 g, agx_u32 t, agx_u32 n)
     return 'N';
 }
 
-// write this position's bucket to the node table at node ids [base, base+cnt); prune (AG:1904-1918) and consensus fused in
-AGX_HD void agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bucket &b, agx_u32 cnt, agx_u32 base, agx_u32 pflag) {
+// x -> x+1 edges of one hit, accumulated per position as a bit matrix: bit v*AGX_EM_W + w = variant v here has an edge to variant w of the
+// next position.  Only kept for buckets of up to AGX_EM_W variants (the LDS sweep); larger buckets leave their edges to the edge passes.
+#define AGX_EM_W 4u
+AGX_HD void agx_edge_merge(agx_u32 &emask, agx_u32 vm, agx_u32 vm_next, agx_u32 step1) {
+    const agx_u32 row = step1 ? (vm_next & ((1u << AGX_EM_W) - 1u)) : 0u;
+    for (agx_u32 v = 0; v < AGX_EM_W; v++) emask |= ((vm >> v) & 1u) ? row << (v * AGX_EM_W) : 0u;
+}
+
+// write this position's bucket to the node table at node ids [base, base+cnt); prune (AG:1904-1918) and consensus fused in.
+// edges != 0: the sweep's edge matrix is complete for this position (the next position lies in the same tile, both buckets stayed within
+// AGX_EM_W variants): its x -> x+1 edges are written here — bn is the next position's bucket, [nbase, nbase+ncnt) its node ids — after the
+// contig-consistency test between the two stored keys (AG:1602-1615), and bit 7 of pos_succ tells the edge passes so.
+AGX_HD void agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bucket &b, agx_u32 cnt, agx_u32 base, agx_u32 pflag,
+                                bool edges, agx_u32 emask, const agx_bucket &bn, agx_u32 nbase, agx_u32 ncnt) {
     if (X >= A.n_pos) return;
-    A.node_start[X] = base; A.node_cnt[X] = (agx_u8)cnt; A.pos_succ[X] = (agx_u8)pflag;
+    A.node_start[X] = base; A.node_cnt[X] = (agx_u8)cnt; A.pos_succ[X] = (agx_u8)(pflag | (edges ? 0x80u : 0u));
     for (agx_u32 v = 0; v < cnt; v++) {
         const agx_u32 id = base + v;
         const agx_u32 cid = agx_b(b, v, AGX_F_CID), coff = agx_b(b, v, AGX_F_COFF), cov = agx_b(b, v, AGX_F_COV);
-        A.nk_cid[id] = cid; A.nk_coff[id] = coff; A.nk_cid0[id] = agx_b(b, v, AGX_F_CID0); A.nk_coff0[id] = agx_b(b, v, AGX_F_COFF0);
+        const agx_u32 cid0 = agx_b(b, v, AGX_F_CID0), coff0 = agx_b(b, v, AGX_F_COFF0);
+        A.nk_cid[id] = cid; A.nk_coff[id] = coff; A.nk_cid0[id] = cid0; A.nk_coff0[id] = coff0;
         A.nk_off0[id] = agx_b(b, v, AGX_F_OFF0); A.n_xpos[id] = X;
         const agx_u32 va = agx_b(b, v, AGX_F_A), vc = agx_b(b, v, AGX_F_C), vg = agx_b(b, v, AGX_F_G), vt = agx_b(b, v, AGX_F_T), vn = agx_b(b, v, AGX_F_N);
         A.n_base[id] = (agx_u8)agx_consensus(va, vc, vg, vt, vn);
@@ -464,7 +485,16 @@ AGX_HD void agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bu
         if (coff != AGX_NONE) fl |= AGX_NF_CONTIG;
         A.n_flags[id] = fl;
         agx_sref s; s.slot = agx_b(b, v, AGX_F_S0); s.qlen = agx_b(b, v, AGX_F_S1); A.n_sref[id] = s;
-        for (agx_u32 e = 0; e < AGX_MAXE; e++) A.n_next[(size_t)id * AGX_MAXE + e] = AGX_NONE;
+        agx_u32 slot[AGX_MAXE]; agx_u32 k = 0;
+        for (agx_u32 e = 0; e < AGX_MAXE; e++) slot[e] = AGX_NONE;
+        if (edges && v < AGX_EM_W)
+            for (agx_u32 w = 0; w < AGX_EM_W && w < ncnt; w++) {
+                if (!((emask >> (v * AGX_EM_W + w)) & 1u)) continue;
+                const agx_u32 ok = agx_clause_ab(agx_b(bn, w, AGX_F_CID), agx_b(bn, w, AGX_F_COFF), cid, coff, AGX_EP25) &
+                                   agx_clause_ab(agx_b(bn, w, AGX_F_CID0), agx_b(bn, w, AGX_F_COFF0), cid0, coff0, 2 * A.iv + AGX_EP25);       // agx_edge_allowed
+                if (ok) slot[k++] = nbase + w;
+            }
+        for (agx_u32 e = 0; e < AGX_MAXE; e++) A.n_next[(size_t)id * AGX_MAXE + e] = slot[e];
         if (A.n_counts) { int *c = A.n_counts + (size_t)id * 6; c[0] = (int)cov; c[1] = (int)va; c[2] = (int)vc; c[3] = (int)vg; c[4] = (int)vt; c[5] = (int)vn; }
     }
 }
@@ -496,14 +526,20 @@ AGX_HD bool agx_edge_allowed(const agx_sweep_args &A, agx_u32 src, agx_u32 dst) 
 // an arrival stepping to x+1 (pos_succ) and the contig-consistency predicate of the two stored keys holds — no per-hit work at all.
 // Positions with several variants, or whose neighbour x+1 has several, return true ("slow"): pass B re-resolves every hit for them.
 // Only this lane writes n_next of x's node in this pass, so plain stores suffice.  Steps that do not go to x+1 are pass J's.
+// Since the node sweep writes the x -> x+1 edges itself wherever x+1 lies in the same tile (agx_edge_merge), this pass is left with
+// the last position of every tile and with tiles whose buckets outgrew LDS.
 AGX_HD bool agx_edge_fast_lane(const agx_sweep_args &A, agx_u32 X, agx_u32 own_start, agx_u32 own_cnt, agx_u32 nb_start, agx_u32 nb_cnt) {
     const bool live = X < A.n_pos && own_cnt != 0;
     if (X >= A.n_pos) X = 0;
+    const agx_u32 ps = A.pos_succ[X];
+    // The node sweep already wrote this position's x -> x+1 edges (bit 7): all that can be missing are steps to other positions, which
+    // pass J adds for single-variant sources; a multi-variant source with such a step (bit 1) goes through pass B once more.
+    if (ps & 0x80u) return live && own_cnt >= 2 && (ps & 2u);
     const bool fast = live && own_cnt == 1;
     const bool slow = live && (own_cnt >= 2 || nb_cnt >= 2);
     if (fast) {
         agx_u32 s0 = AGX_NONE;
-        if (nb_cnt == 1 && (A.pos_succ[X] & 1u) && agx_edge_allowed(A, own_start, nb_start)) s0 = nb_start;
+        if (nb_cnt == 1 && (ps & 1u) && agx_edge_allowed(A, own_start, nb_start)) s0 = nb_start;
         agx_u32 *slots = A.n_next + (size_t)own_start * AGX_MAXE;
         slots[0] = s0; slots[1] = AGX_NONE; slots[2] = AGX_NONE; slots[3] = AGX_NONE;
     }

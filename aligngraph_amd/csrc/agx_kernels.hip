@@ -146,9 +146,13 @@ __global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
         const agx_u32 tile = BIG ? __builtin_amdgcn_readfirstlane(K.big_list[w]) : w;
         if (K.S.tile_off[tile + 1] > K.list_cap) return;
         const agx_u32 X = tile * AGX_TILE + lane;
-        agx_u32 cnt = 0, pflag = 0;
+        agx_u32 cnt = 0, pflag = 0, emask = 0;
         const agx_tile_recs hits{K.S.tile_recs};
-        const bool ok = agx_node_sweep_lane<!BIG>(K.S, tile, X, b, cnt, pflag, hits);
+        // every lane hands the variants a hit touched to its left neighbour (agx_edge_merge): the x -> x+1 edges of 63 of the tile's 64
+        // positions fall out of the sweep itself; the fallback pass leaves them to the edge passes (its buckets exceed the edge matrix)
+        const bool ok = agx_node_sweep_lane<!BIG>(K.S, tile, X, b, cnt, pflag, hits, [&](agx_u32 vm, agx_u32 step1) {
+            if (!BIG) agx_edge_merge(emask, vm, (agx_u32)__shfl_down((int)vm, 1, 64), step1);
+        });
         if (__ballot(!ok) != 0ull) {                       // wave-uniform
             if (lane == 0) {
                 if (BIG) atomicOr(K.status, 2u);
@@ -162,7 +166,11 @@ __global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
         if (lane == 0) base = atomicAdd(K.pool_counter, total);
         base = __shfl(base, 0, 64);
         if ((unsigned long long)base + total > K.S.pool_cap) { if (lane == 0) atomicOr(K.status, 1u); if (BIG) continue; else return; }
-        agx_node_write_lane(K.S, X, b, cnt, base + incl - cnt, pflag);
+        const agx_u32 my_base = base + incl - cnt;
+        const agx_u32 nbase = (agx_u32)__shfl_down((int)my_base, 1, 64), ncnt = (agx_u32)__shfl_down((int)cnt, 1, 64);
+        agx_bucket bn = b; bn.base = b.base + 1;           // the next position's bucket is the next lane's column
+        const bool edges = !BIG && lane < 63u && X + 1 < K.S.n_pos && cnt <= AGX_EM_W && ncnt <= AGX_EM_W;
+        agx_node_write_lane(K.S, X, b, cnt, my_base, pflag, edges, emask, bn, nbase, ncnt);
         if (!BIG) return;
     }
 }

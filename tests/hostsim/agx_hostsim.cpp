@@ -79,8 +79,14 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     std::vector<agx_u32> lds((size_t)AGX_NF * maxv_first * AGX_TILE), big;
     for (agx_u32 t = 0; t < n_tiles; t++) {
         agx_u32 cnt[AGX_TILE], pflag[AGX_TILE]; bool ok = true;
+        // what every lane hands to its left neighbour per hit (the kernel does it with a wave shuffle inside the sweep's loop)
+        struct Touch { agx_u32 vm, step1; };
+        std::vector<Touch> touched[AGX_TILE];
         agx_bucket b{nullptr, AGX_TILE, maxv_first};
-        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) { b.base = lds.data() + lane; ok &= agx_node_sweep_lane<false>(A, t, t * AGX_TILE + lane, b, cnt[lane], pflag[lane], get); }
+        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
+            b.base = lds.data() + lane;
+            ok &= agx_node_sweep_lane<false>(A, t, t * AGX_TILE + lane, b, cnt[lane], pflag[lane], get, [&](agx_u32 vm, agx_u32 step1) { touched[lane].push_back(Touch{vm, step1}); });
+        }
         agx_u32 *store = lds.data(); agx_u32 maxv = maxv_first;
         if (!ok) {                                     // the fallback the engine runs for overflowed tiles
             n_big_tiles++;
@@ -88,13 +94,22 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
             agx_bucket bb{nullptr, AGX_TILE, maxv};
             for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
                 bb.base = store + lane;
-                if (!agx_node_sweep_lane<false>(A, t, t * AGX_TILE + lane, bb, cnt[lane], pflag[lane], get)) throw Error{E_OVERFLOW, "more than AGX_MAXV_BIG node variants at one position"};
+                if (!agx_node_sweep_lane<false>(A, t, t * AGX_TILE + lane, bb, cnt[lane], pflag[lane], get, [](agx_u32, agx_u32) {})) throw Error{E_OVERFLOW, "more than AGX_MAXV_BIG node variants at one position"};
             }
         }
         agx_u32 total = 0; for (agx_u32 lane = 0; lane < AGX_TILE; lane++) total += cnt[lane];
         if (pool + total > S.cid.size()) { S.reserve((pool + total) * 2); bind(); }
-        agx_bucket wb{nullptr, AGX_TILE, maxv};
-        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) { wb.base = store + lane; agx_node_write_lane(A, t * AGX_TILE + lane, wb, cnt[lane], pool, pflag[lane]); pool += cnt[lane]; }
+        agx_bucket wb{nullptr, AGX_TILE, maxv}, wn{nullptr, AGX_TILE, maxv};
+        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
+            const agx_u32 X = t * AGX_TILE + lane;
+            wb.base = store + lane; wn.base = store + lane + 1;
+            const agx_u32 ncnt = lane + 1 < AGX_TILE ? cnt[lane + 1] : 0;
+            const bool edges = ok && lane < AGX_TILE - 1 && X + 1 < n_pos && cnt[lane] <= AGX_EM_W && ncnt <= AGX_EM_W;
+            agx_u32 emask = 0;
+            if (edges) for (size_t i = 0; i < touched[lane].size(); i++) agx_edge_merge(emask, touched[lane][i].vm, touched[lane + 1][i].vm, touched[lane][i].step1);
+            agx_node_write_lane(A, X, wb, cnt[lane], pool, pflag[lane], edges, emask, wn, pool + cnt[lane], ncnt);
+            pool += cnt[lane];
+        }
     }
     S.n_nodes = pool;
     // edge build: pass A (lanes = positions) writes the x -> x+1 edges of single-variant positions and collects the slow positions,
