@@ -461,7 +461,9 @@ AGX_HD char agx_consensus(agx_u32 a, agx_u32 c, agx_u32 g, agx_u32 t, agx_u32 n)
 #define AGX_EM_W 4u
 AGX_HD void agx_edge_merge(agx_u32 &emask, agx_u32 vm, agx_u32 vm_next, agx_u32 step1) {
     const agx_u32 row = step1 ? (vm_next & ((1u << AGX_EM_W) - 1u)) : 0u;
-    for (agx_u32 v = 0; v < AGX_EM_W; v++) emask |= ((vm >> v) & 1u) ? row << (v * AGX_EM_W) : 0u;
+    // variant bit v of vm moved to bit v*AGX_EM_W; times row (< 2^AGX_EM_W, so the partial products cannot overlap) puts a copy of row there
+    const agx_u32 spread = (vm & 1u) | ((vm & 2u) << (AGX_EM_W - 1u)) | ((vm & 4u) << (2u * AGX_EM_W - 2u)) | ((vm & 8u) << (3u * AGX_EM_W - 3u));
+    emask |= spread * row;
 }
 
 // write this position's bucket to the node table at node ids [base, base+cnt); prune (AG:1904-1918) and consensus fused in.

@@ -151,7 +151,8 @@ __global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
         // every lane hands the variants a hit touched to its left neighbour (agx_edge_merge): the x -> x+1 edges of 63 of the tile's 64
         // positions fall out of the sweep itself; the fallback pass leaves them to the edge passes (its buckets exceed the edge matrix)
         const bool ok = agx_node_sweep_lane<!BIG>(K.S, tile, X, b, cnt, pflag, hits, [&](agx_u32 vm, agx_u32 step1) {
-            if (!BIG) agx_edge_merge(emask, vm, (agx_u32)__shfl_down((int)vm, 1, 64), step1);
+            // lane i reads lane i+1 with one DPP move (wave_shl:1; the last lane reads 0: its edges belong to the edge passes)
+            if (!BIG) agx_edge_merge(emask, vm, (agx_u32)__builtin_amdgcn_update_dpp(0, (int)vm, 0x130, 0xF, 0xF, true), step1);
         });
         if (__ballot(!ok) != 0ull) {                       // wave-uniform
             if (lane == 0) {
