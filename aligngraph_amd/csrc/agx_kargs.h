@@ -7,6 +7,7 @@ struct agx_prep_args {
     const agx_hit *hits; const agx_run *runs; agx_dhit *dhit; agx_u32 n_hits, k, n_pos;
     agx_u32 *tile_cnt;        // [n_tiles] number of hits overlapping each tile
     agx_u32 *err;             // bit 0: same-strand mates; bit 1: alignment beyond the unit sequence
+    agx_u8 *multi_run;        // [n_hits] 1: a kept hit whose a mate has several runs (the only hits the edge build's pass J looks at)
 };
 
 struct agx_bin_args { const agx_dhit *dhit; agx_u32 n_hits; const agx_u32 *tile_off; agx_u32 *cursor; agx_u32 *unsorted; agx_u32 cap; };   // cap: entries the lists can hold
@@ -24,6 +25,7 @@ struct agx_node_kargs {
 struct agx_edge_kargs {
     agx_sweep_args S; agx_edge_ovf *ovf; agx_u32 *ovf_count; agx_u32 ovf_cap; agx_u32 list_cap;
     agx_u32 *slow_list; agx_u32 *slow_count;   // positions that need the per-hit pass (device-side list)
+    const agx_u8 *multi_run;                   // [n_hits] from hit_prep
 };
 #define AGX_SLOW_WAVES 8192u    // wavefronts of the per-hit edge pass if the occupancy query fails (normally: as many as are resident at once)
 

@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
         else for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++) atomicAdd(&A.tile_cnt[t], 1u);
     }
     A.dhit[h] = d;
+    A.multi_run[h] = (!(d.flags & AGX_HF_SKIP) && d.a_nruns >= 2) ? 1 : 0;
 }
 
 // ---- exclusive scan of a u32 array (three small kernels; n_tiles is 10^4..10^7) ------------------------------------
@@ -182,12 +183,16 @@ __global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
 __global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
     const agx_u32 lane = threadIdx.x & 63u;
     const agx_u32 X = blockIdx.x * 256u + threadIdx.x;
+    // the node sweep has already written the edges of most positions (bit 7 of pos_succ): those lanes only read that byte
+    const agx_u32 ps = X < K.S.n_pos ? K.S.pos_succ[X] : 0x80u;
+    const bool need = !(ps & 0x80u) || (ps & 2u);
     agx_u32 own_start = 0, own_cnt = 0;
-    if (X < K.S.n_pos) { own_start = K.S.node_start[X]; own_cnt = K.S.node_cnt[X]; }
-    // the neighbour position's bucket header comes from the next lane; the last lane reads the next wavefront's first position
+    if (need && X < K.S.n_pos) { own_start = K.S.node_start[X]; own_cnt = K.S.node_cnt[X]; }
+    // the neighbour position's bucket header comes from the next lane (a lane that needs it either is the tile's last lane, which reads
+    // it itself, or sits in a tile the fallback pass wrote, where every lane loaded its own)
     agx_u32 nb_start = __shfl_down(own_start, 1, 64), nb_cnt = __shfl_down(own_cnt, 1, 64);
     if (lane == 63) { nb_start = 0; nb_cnt = 0; if (X + 1 < K.S.n_pos) { nb_start = K.S.node_start[X + 1]; nb_cnt = K.S.node_cnt[X + 1]; } }
-    const bool slow = agx_edge_fast_lane(K.S, X, own_start, own_cnt, nb_start, nb_cnt);
+    const bool slow = need && agx_edge_fast_lane(K.S, X, own_start, own_cnt, nb_start, nb_cnt);
     const unsigned long long m = __ballot(slow);
     if (m) {
         agx_u32 base = 0;
@@ -223,7 +228,7 @@ __device__ __forceinline__ void agx_slot_insert(const agx_edge_kargs &K, agx_u32
 // pass J: one thread per hit; only hits whose a mate has several runs do anything (agx_edge_jump_hit)
 __global__ void __launch_bounds__(256) agx_k_edge_jump(agx_edge_kargs K, agx_u32 n_hits) {
     const agx_u32 h = blockIdx.x * 256u + threadIdx.x;
-    if (h >= n_hits) return;
+    if (h >= n_hits || !K.multi_run[h]) return;
     const agx_dhit d = K.S.dhit[h];
     agx_edge_jump_hit(K.S, d, [&](agx_u32 src, agx_u32 dst) { agx_slot_insert(K, src, dst); });
 }
