@@ -16,9 +16,12 @@
 //    AG:1730-1751) or K2ONLY (the last position a read reaches, AG:1484-1500: insert with coverage 0).
 //  * A bucket's variants are only ever appended, and `compatible` (AG:1293-1312) is reflexive, so the
 //    variant an arrival resolves to is the first compatible variant of the FINAL bucket.  Node build is
-//    therefore one in-order sweep per position (lanes = positions, hits applied in SAM order), and edge
-//    build (AG:1589-1623) is a second sweep that re-resolves both ends of every event against the final
-//    buckets — no atomics, no dependence on scheduling, bit-exact by construction.
+//    therefore one in-order sweep per position (lanes = positions, hits applied in SAM order).
+//  * An event's edge (AG:1589-1623) joins the variants its k1 half touched at P with the variants its k2 half
+//    touched at N — i.e. with the variants the same hit's arrival touched at N.  Where N = P+1 lies in the same
+//    tile the two lanes exchange those variant sets while they sweep and the edges are written with the nodes;
+//    everything else (tile boundaries, steps that skip positions, overflowed buckets) is re-resolved against the
+//    final buckets by the edge passes.  Edge sets are sets: no dependence on scheduling, bit-exact by construction.
 #pragma once
 #include <stdint.h>
 #include "../../include/agx.h"

@@ -2,12 +2,12 @@
 //
 // All kernels are integer / byte work bound by memory latency and HBM/L2 traffic; none of it is matrix-shaped,
 // so there is no MFMA here by design.  The layout rules that matter are the ones for wave64 streaming kernels:
-//   * one wavefront (64 lanes) owns one tile of 64 consecutive reference positions; lanes never exchange data
-//     while a tile is swept, so there is no __syncthreads() anywhere on the hot path;
+//   * one wavefront (64 lanes) owns one tile of 64 consecutive reference positions; the only data lanes exchange
+//     while a tile is swept is one DPP lane shift per hit, so there is no __syncthreads() anywhere on the hot path;
 //   * per-position node buckets live in LDS as [field][variant][lane] so that every bucket access of a
 //     wavefront is one conflict-free ds_read/ds_write_b32 (lane -> consecutive bank);
-//   * everything a wavefront reads per hit (tile list entry, derived hit record, CIGAR runs) is wave-uniform:
-//     the tile index is forced into an SGPR with readfirstlane so those loads become scalar (s_load) traffic;
+//   * everything a wavefront reads per hit (the tile's record stream, CIGAR runs) is wave-uniform and goes through
+//     the constant address space: scalar (s_load) traffic that never waits on the per-lane loads in flight;
 //   * per-lane global reads are position-consecutive across lanes (read bases, mate conti-mer lookups, node
 //     keys of the successor position) and therefore coalesce.
 // The per-lane algorithm itself is in agx_core.h (shared with the CPU test executor).
