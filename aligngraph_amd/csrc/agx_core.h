@@ -719,6 +719,7 @@ struct agx_compact_args {
     // sparse record table
     agx_u32 n_ids, sparse_min;     // sparse_min (test hook): only the side ids are special, every other record comes through the fetch path
     unsigned long long *sp_bits; agx_u32 *sp_cnt; const agx_u32 *sp_rank; agx_walknode *sp_node;
+    const agx_u32 *abort;          // device only: the node sweeps' status word (non-zero: the node table is incomplete, the kernels do nothing)
 };
 
 AGX_HD void agx_side_count_pos(const agx_compact_args &A, agx_u32 X) {

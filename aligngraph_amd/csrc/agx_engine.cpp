@@ -93,6 +93,10 @@ namespace {
 struct DeviceTurn { std::mutex m; hipEvent_t last = nullptr; };
 DeviceTurn &turn_of(int device) { static DeviceTurn turns[64]; return turns[device & 63]; }
 
+// AGX_DEBUG_SYNC=1: synchronise after every launch group of a build and name it on stderr — a memory fault then points at its kernel
+static const bool g_debug_sync = getenv("AGX_DEBUG_SYNC") != nullptr;
+#define AGX_CHECKPOINT(name) do { if (g_debug_sync) { hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, "[agx debug] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
+
 enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_N = 8 };
 
 void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
@@ -190,6 +194,7 @@ void do_build(agx_unit *u) {
         HIP_OK(hipEventRecord(u->ev_prep.a, st));
         agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, u->d_multi_run.p};
         agx_launch_hit_prep(&PA, st);
+        AGX_CHECKPOINT("hit_prep");
         HIP_OK(hipEventRecord(u->ev_prep.b, st)); u->ev_prep.used = true;
         // ---- tile lists ----
         HIP_OK(hipEventRecord(u->ev_bin.a, st));
@@ -197,6 +202,7 @@ void do_build(agx_unit *u) {
         agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap};
         agx_launch_bin_fill(&BA, st);
         agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->d_tile_hits.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, st);
+        AGX_CHECKPOINT("tile_sort");
         HIP_OK(hipEventRecord(u->ev_bin.b, st)); u->ev_bin.used = true;
         // ---- node sweep: LDS pass, then the global-scratch pass over whatever tiles overflowed (device-side count) ----
         agx_node_kargs K; fill_sweep_args(u, K.S);
@@ -204,18 +210,24 @@ void do_build(agx_unit *u) {
         K.list_cap = u->list_cap; K.big_n = u->d_words.p + W_BIGCOUNT; K.scratch = u->d_scratch.p;
         HIP_OK(hipEventRecord(u->ev_node.a, st));
         agx_launch_node_sweep(&K, st);
+        AGX_CHECKPOINT("node_sweep");
         HIP_OK(hipEventRecord(u->ev_node.b, st)); u->ev_node.used = true; u->stats.node_sweep_launches++;
         HIP_OK(hipEventRecord(u->ev_big.a, st));
         agx_launch_node_sweep_big(&K, st);
+        AGX_CHECKPOINT("node_sweep_big");
         HIP_OK(hipEventRecord(u->ev_big.b, st)); u->ev_big.used = true;
         // ---- edge sweep ----
         agx_edge_kargs E; fill_sweep_args(u, E.S); E.ovf = u->d_ovf.p; E.ovf_count = u->d_words.p + W_OVFCOUNT; E.ovf_cap = u->ovf_cap; E.list_cap = u->list_cap;
-        E.multi_run = u->d_multi_run.p; E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
+        E.multi_run = u->d_multi_run.p; E.abort = u->d_words.p + W_STATUS; E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
         HIP_OK(hipEventRecord(u->ev_edge.a, st));
-        agx_launch_edge_sweep(&E, nh, st);
+        agx_launch_edge_sweep(&E, st);
+        AGX_CHECKPOINT("edge_sweep");
+        agx_launch_edge_jump(&E, nh, st);
+        AGX_CHECKPOINT("edge_jump");
         HIP_OK(hipEventRecord(u->ev_edge.b, st)); u->ev_edge.used = true; u->stats.edge_sweep_launches++;
         HIP_OK(hipEventRecord(u->ev_slow.a, st));
         agx_launch_edge_slow(&E, st);
+        AGX_CHECKPOINT("edge_slow");
         HIP_OK(hipEventRecord(u->ev_slow.b, st)); u->ev_slow.used = true;
         // ---- walk preparation: side counts -> scan -> walk ids, node records, rewritten edges, forced-run flags ----
         agx_compact_args C; memset(&C, 0, sizeof C);
@@ -224,16 +236,20 @@ void do_build(agx_unit *u) {
         C.side_cnt = u->d_side_cnt.p; C.side_start = u->d_side_start.p; C.aid_of = u->d_aid_of.p;
         C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_node = u->d_a_node.p; C.ovf = u->d_ovf.p; C.n_ovf = 0; C.a_ovf = u->d_a_ovf.p;
         HIP_OK(hipEventRecord(u->ev_compact.a, st));
+        C.abort = u->d_words.p + W_STATUS;
         C.a_mark = u->d_a_mark.p; C.side_xpos = u->d_side_xpos.p; C.sparse_min = (u->prm.flags & AGX_FLAG_SPARSE_MIN) ? 1u : 0u;
         C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p;
         HIP_OK(hipMemsetAsync(u->d_side_cnt.p + n_pos, 0, 4, st));
         HIP_OK(hipMemsetAsync(u->d_a_mark.p, 0, ids_cap + 2, st));
         HIP_OK(hipMemsetAsync(u->d_sp_cnt.p + u->n_words, 0, 4, st));
         agx_launch_side_count(&C, st);
+        AGX_CHECKPOINT("side_count");
         agx_launch_exclusive_scan(u->d_side_cnt.p, u->d_side_start.p, n_pos, u->d_scan_tmp.p, st);
         agx_launch_mark_list(u->d_chain_end.p, u->n_chain_end, u->d_a_mark.p, st);
         agx_launch_compact(&C, u->d_words.p + W_POOL, u->pool_cap, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
+        AGX_CHECKPOINT("compact");
         agx_launch_special(&C, u->n_words, u->d_sp_rank.p, u->d_scan_tmp.p, st);
+        AGX_CHECKPOINT("special");
         HIP_OK(hipEventRecord(u->ev_compact.b, st)); u->ev_compact.used = true;
         // ---- the one synchronisation ----
         HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, W_N * 4, hipMemcpyDeviceToHost, st));

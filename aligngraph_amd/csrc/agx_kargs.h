@@ -16,7 +16,7 @@ struct agx_node_kargs {
     agx_sweep_args S;
     agx_u32 *pool_counter;     // next free node id
     agx_u32 *big_count; agx_u32 *big_list;   // tiles whose buckets did not fit in LDS
-    agx_u32 *status;           // bit 0: node pool exhausted; bit 1: bucket overflow in the global-scratch pass
+    agx_u32 *status;           // bit 0: node pool exhausted; bit 1: bucket overflow in the global-scratch pass; bit 2: tile lists too small
     agx_u32 list_cap;          // capacity of tile_hits: a tile whose list ends beyond it is skipped (the host re-runs with larger lists)
     const agx_u32 *big_n;      // fallback pass: number of tiles in big_list, read on the device (no host round trip)
     agx_u32 *scratch;          // fallback pass: one [AGX_NF*AGX_MAXV_BIG*64] bucket area per resident wavefront
@@ -26,6 +26,7 @@ struct agx_edge_kargs {
     agx_sweep_args S; agx_edge_ovf *ovf; agx_u32 *ovf_count; agx_u32 ovf_cap; agx_u32 list_cap;
     agx_u32 *slow_list; agx_u32 *slow_count;   // positions that need the per-hit pass (device-side list)
     const agx_u8 *multi_run;                   // [n_hits] from hit_prep
+    const agx_u32 *abort;                      // the node sweeps' status word: non-zero = the node table is incomplete, do nothing
 };
 #define AGX_SLOW_WAVES 8192u    // wavefronts of the per-hit edge pass if the occupancy query fails (normally: as many as are resident at once)
 
@@ -38,7 +39,8 @@ void agx_launch_bin_fill(const agx_bin_args *, hipStream_t);
 void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, hipStream_t);
 void agx_launch_node_sweep(const agx_node_kargs *, hipStream_t);
 void agx_launch_node_sweep_big(const agx_node_kargs *, hipStream_t);
-void agx_launch_edge_sweep(const agx_edge_kargs *, agx_u32 n_hits, hipStream_t);   // pass A (lanes = positions), pass J (lanes = hits: steps that skip positions)
+void agx_launch_edge_sweep(const agx_edge_kargs *, hipStream_t);                   // pass A (lanes = positions)
+void agx_launch_edge_jump(const agx_edge_kargs *, agx_u32 n_hits, hipStream_t);    // pass J (lanes = hits: steps that skip positions)
 void agx_launch_edge_slow(const agx_edge_kargs *, hipStream_t);           // pass B (lanes = hits of the slow positions pass A listed)
 // walk preparation (agx_core.h): per-position side counts; then (after the scan) ids, records and overflow edges
 // n_nodes / n_ovf are read from device memory (the node-pool and overflow counters), so no host round trip separates the sweeps

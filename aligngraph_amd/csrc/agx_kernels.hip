@@ -16,6 +16,11 @@
 
 #define AGX_WAVES_PER_BLOCK 4
 
+// A build queues all its kernels before the host has seen a single counter.  If the node sweeps had to give up (node pool or tile lists too
+// small: the host grows them and repeats the build; a bucket beyond 64 variants: an error) parts of the node table were never written, so
+// every kernel behind the sweeps first looks at the status word the sweeps leave on the device and does nothing if it is set.
+#define AGX_RETURN_IF_ABORTED(word) do { if (__builtin_amdgcn_readfirstlane((int)*(word)) != 0) return; } while (0)
+
 // ---- upload time: per-position head of the conti-mer table ---------------------------------------------------------
 __global__ void __launch_bounds__(256) agx_k_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos) {
     const agx_u32 x = blockIdx.x * 256u + threadIdx.x;
@@ -145,7 +150,7 @@ __global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
     const agx_u32 n_work = BIG ? __builtin_amdgcn_readfirstlane(*K.big_n) : K.S.n_tiles;
     for (agx_u32 w = slot; w < n_work; w += BIG ? AGX_BIG_WAVES : 0xFFFFFFFFu) {
         const agx_u32 tile = BIG ? __builtin_amdgcn_readfirstlane(K.big_list[w]) : w;
-        if (K.S.tile_off[tile + 1] > K.list_cap) return;
+        if (K.S.tile_off[tile + 1] > K.list_cap) { if (lane == 0) atomicOr(K.status, 4u); return; }      // lists did not fit: nothing after the sweeps may run
         const agx_u32 X = tile * AGX_TILE + lane;
         agx_u32 cnt = 0, pflag = 0, emask = 0;
         const agx_tile_recs hits{K.S.tile_recs};
@@ -181,6 +186,7 @@ __global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
 // pass A: one thread per position (agx_edge_fast_lane), a pure streaming kernel; slow positions are compacted into a list with a
 // wave ballot + one atomicAdd per wavefront
 __global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
+    AGX_RETURN_IF_ABORTED(K.abort);
     const agx_u32 lane = threadIdx.x & 63u;
     const agx_u32 X = blockIdx.x * 256u + threadIdx.x;
     // the node sweep has already written the edges of most positions (bit 7 of pos_succ): those lanes only read that byte
@@ -227,6 +233,7 @@ __device__ __forceinline__ void agx_slot_insert(const agx_edge_kargs &K, agx_u32
 
 // pass J: one thread per hit; only hits whose a mate has several runs do anything (agx_edge_jump_hit)
 __global__ void __launch_bounds__(256) agx_k_edge_jump(agx_edge_kargs K, agx_u32 n_hits) {
+    AGX_RETURN_IF_ABORTED(K.abort);
     const agx_u32 h = blockIdx.x * 256u + threadIdx.x;
     if (h >= n_hits || !K.multi_run[h]) return;
     const agx_dhit d = K.S.dhit[h];
@@ -234,6 +241,7 @@ __global__ void __launch_bounds__(256) agx_k_edge_jump(agx_edge_kargs K, agx_u32
 }
 
 __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
+    AGX_RETURN_IF_ABORTED(K.abort);
     const agx_u32 lane = threadIdx.x & 63u;
     const agx_u32 wave = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     const agx_u32 n = __builtin_amdgcn_readfirstlane(*K.slow_count);
@@ -266,10 +274,14 @@ __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
 }
 
 // ---- walk preparation: renumber surviving nodes, rewrite edges, mark forced runs (agx_core.h) -------------------------------
-__global__ void __launch_bounds__(256) agx_k_side_count(agx_compact_args A) { agx_side_count_pos(A, blockIdx.x * 256u + threadIdx.x); }
-__global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A) { agx_assign_aid_pos(A, blockIdx.x * 256u + threadIdx.x); }
-__global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A, const agx_u32 *n_nodes_dev) { A.n_nodes = *n_nodes_dev; agx_emit_alive_node(A, blockIdx.x * 256u + threadIdx.x); }
+__global__ void __launch_bounds__(256) agx_k_side_count(agx_compact_args A) { AGX_RETURN_IF_ABORTED(A.abort); agx_side_count_pos(A, blockIdx.x * 256u + threadIdx.x); }
+__global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A) { AGX_RETURN_IF_ABORTED(A.abort); agx_assign_aid_pos(A, blockIdx.x * 256u + threadIdx.x); }
+__global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A, const agx_u32 *n_nodes_dev) {
+    AGX_RETURN_IF_ABORTED(A.abort);
+    A.n_nodes = *n_nodes_dev; agx_emit_alive_node(A, blockIdx.x * 256u + threadIdx.x);
+}
 __global__ void __launch_bounds__(256) agx_k_emit_ovf(agx_compact_args A, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap) {
+    AGX_RETURN_IF_ABORTED(A.abort);
     const agx_u32 n = *n_ovf_dev; A.n_ovf = n < ovf_cap ? n : ovf_cap; agx_emit_alive_ovf(A, blockIdx.x * 256u + threadIdx.x);
 }
 
@@ -280,6 +292,7 @@ __global__ void __launch_bounds__(256) agx_k_mark_list(const agx_u32 *list, agx_
 }
 // one wave per 64 ids: the special-id bitmap word and its popcount (input of the rank scan); words past n_ids are written as zero
 __global__ void __launch_bounds__(256) agx_k_special_bits(agx_compact_args A, agx_u32 n_words) {
+    AGX_RETURN_IF_ABORTED(A.abort);
     A.n_ids = A.n_pos + A.side_start[A.n_pos];
     const agx_u32 a = blockIdx.x * 256u + threadIdx.x, w = a >> 6;
     if (w >= n_words) return;                                                   // wave-uniform
@@ -288,6 +301,7 @@ __global__ void __launch_bounds__(256) agx_k_special_bits(agx_compact_args A, ag
 }
 // gather the special records in id order
 __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, agx_u32 n_words) {
+    AGX_RETURN_IF_ABORTED(A.abort);
     const agx_u32 a = blockIdx.x * 256u + threadIdx.x, w = a >> 6;
     if (w >= n_words) return;
     const unsigned long long bits = A.sp_bits[w];
@@ -339,10 +353,12 @@ void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
 void agx_launch_node_sweep_big(const agx_node_kargs *K, hipStream_t st) {
     hipLaunchKernelGGL(agx_k_node_sweep<true>, dim3(AGX_BIG_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
 }
-void agx_launch_edge_sweep(const agx_edge_kargs *K, agx_u32 n_hits, hipStream_t st) {
+void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_pos;
     if (n) hipLaunchKernelGGL(agx_k_edge_sweep, dim3((n + 255) / 256), dim3(256), 0, st, *K);
-    if (n && n_hits) hipLaunchKernelGGL(agx_k_edge_jump, dim3((n_hits + 255) / 256), dim3(256), 0, st, *K, n_hits);
+}
+void agx_launch_edge_jump(const agx_edge_kargs *K, agx_u32 n_hits, hipStream_t st) {
+    if (K->S.n_pos && n_hits) hipLaunchKernelGGL(agx_k_edge_jump, dim3((n_hits + 255) / 256), dim3(256), 0, st, *K, n_hits);
 }
 void agx_launch_edge_slow(const agx_edge_kargs *K, hipStream_t st) {
     // persistent wavefronts: exactly as many blocks as the device holds at once (a second, partial round of blocks would idle most CUs)
