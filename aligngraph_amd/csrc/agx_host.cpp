@@ -115,6 +115,16 @@ bool keeps_last(const std::vector<ContigSeq> &c, agx_u32 id, double thr) {
 
 }  // namespace
 
+void advise_huge(void *p, size_t n) {
+#if defined(__linux__) && defined(MADV_HUGEPAGE)
+    const size_t huge = (size_t)2 << 20;
+    const uintptr_t lo = ((uintptr_t)p + huge - 1) & ~(uintptr_t)(huge - 1), hi = ((uintptr_t)p + n) & ~(uintptr_t)(huge - 1);
+    if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+#else
+    (void)p; (void)n;
+#endif
+}
+
 // loadGenome, AG:287-320
 void load_unit_reference(const std::string &path, std::string &ref) {
     FileView fv(path); LineReader in(fv.p, fv.n);

@@ -64,12 +64,20 @@ struct GraphView {
     const agx_edge_ovf *ovf = nullptr; size_t n_ovf = 0;     // walk ids; NONE/NONE entries and duplicates are ignored
 };
 
+// Megabyte-sized buffers that are written once, front to back (outputs, the walk's visited bytes): ask for transparent huge pages where
+// the kernel offers them on request (THP "madvise" mode), so first-touch costs a few faults instead of one per 4 KB.  Advisory only.
+void advise_huge(void *p, size_t n);
+
 // malloc-backed output buffer whose storage can be handed to the C caller without another copy
 struct OutBuf {
     char *p = nullptr; size_t n = 0, cap = 0;
     OutBuf() = default; OutBuf(const OutBuf &) = delete; OutBuf &operator=(const OutBuf &) = delete;
     ~OutBuf() { free(p); }
-    void reserve(size_t c) { if (c + 1 > cap) { char *q = (char *)realloc(p, c + 1); if (!q) throw Error{E_ARG, "out of host memory"}; p = q; cap = c + 1; } }
+    void reserve(size_t c) {
+        if (c + 1 <= cap) return;
+        char *q = (char *)realloc(p, c + 1); if (!q) throw Error{E_ARG, "out of host memory"};
+        p = q; cap = c + 1; advise_huge(p, cap);
+    }
     char *grow(size_t add) { if (n + add + 1 > cap) reserve((n + add) + (n + add) / 2 + 64); char *w = p + n; n += add; return w; }
     void append(const char *s, size_t len) { memcpy(grow(len), s, len); }
     char *release() { if (!p) reserve(0); p[n] = 0; char *r = p; p = nullptr; n = cap = 0; return r; }

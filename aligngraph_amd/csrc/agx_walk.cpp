@@ -79,7 +79,9 @@ struct Walker {
     const Threads &T; const Pairs &P; const GraphView &G;
     std::vector<agx_u8> done;                       // traversed flag per ALIVE node (pruned nodes never reach the host)
     std::vector<agx_edge_ovf> ovf;                  // sorted, unique
-    Walker(const Threads &t, const Pairs &p, const GraphView &g) : T(t), P(p), G(g), done((size_t)g.n_ids + 72, 1) {
+    Walker(const Threads &t, const Pairs &p, const GraphView &g) : T(t), P(p), G(g) {
+        done.reserve((size_t)g.n_ids + 72); advise_huge(done.data(), done.capacity());
+        done.resize((size_t)g.n_ids + 72, 1);
         for (size_t i = 0; i < g.n_ids; i++) done[i] = g.meta[i] >> 7;     // ids without a node count as visited; the tail is a sentinel
         for (size_t i = 0; i < g.n_ovf; i++) if (g.ovf[i].src != AGX_NONE) ovf.push_back(g.ovf[i]);
         std::sort(ovf.begin(), ovf.end(), [](const agx_edge_ovf &a, const agx_edge_ovf &b) { return a.src != b.src ? a.src < b.src : a.dst < b.dst; });
@@ -162,7 +164,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
     const GraphView &G = W.G; const Threads &T = W.T;
     agx_u32 seqID = 0, sIDBak = AGX_NONE, sOffBak = AGX_NONE, eIDBak = AGX_NONE, eOffBak = AGX_NONE;
     agx_u32 pos_bak = 0;                         // cppBak of the reference (function scope)
-    std::string kmer;
+    std::string kmer; agx_u32 klen = 0, klast = 0;
     std::vector<Seg> segs;
     pre_out.reserve((size_t)G.n_ids + G.n_ids / 32 + 4096);
     agx_u8 *done = W.done.data();
@@ -221,11 +223,13 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
             C.eID = 0; C.eOff = mode == 1 ? pos_bak : cpp;
             if (mode == 1 || mode == -1) {
                 { const agx_u32 o = W.node(cur).off0; C.eID0 = o == AGX_NONE ? AGX_NONE : 0; C.eOff0 = o; }
-                W.kmer_string(last, kmer);
-                if (kmer.size() > 1) segs.push_back(Seg{kmer.data() + 1, kmer.size() - 1});
-                C.eOff = C.eOff + (agx_u32)kmer.size() - 1; C.eOff0 = C.eOff0 + (agx_u32)kmer.size() - 1;
-            } else { C.eID0 = AGX_NONE; C.eOff0 = AGX_NONE; }
+                // the record ends with the last node's k-mer string minus its first base; only its LENGTH matters until the record is known
+                // to be written (most are dropped below), so the read bases are not touched yet
+                klen = (W.node(last).sref.qlen >> 16) & 0x7FFFu; klast = last;
+                C.eOff = C.eOff + klen - 1; C.eOff0 = C.eOff0 + klen - 1;
+            } else { C.eID0 = AGX_NONE; C.eOff0 = AGX_NONE; klen = 0; }
             if (!contains(sIDBak, sOffBak, eIDBak, eOffBak, C.sID, C.sOff, C.eID, C.eOff)) {        // AG:2176-2189
+                if (klen > 1) { W.kmer_string(klast, kmer); segs.push_back(Seg{kmer.data() + 1, kmer.size() - 1}); }
                 size_t total = 0; for (const Seg &g : segs) total += g.n;
                 C.nuc.reserve(total); for (const Seg &g : segs) C.nuc.append(g.p, g.n);
                 char hdr[256];
