@@ -19,6 +19,7 @@ EXPORTS = [
     "agx_version", "agx_device_count", "agx_unit_create", "agx_unit_destroy", "agx_unit_error", "agx_unit_set_reference",
     "agx_unit_set_contig_threads", "agx_unit_push_pairs", "agx_unit_load_files", "agx_unit_upload", "agx_unit_build", "agx_unit_download",
     "agx_unit_finish", "agx_result_free", "agx_unit_stats", "agx_unit_graph", "agx_graph_free", "agx_run_unit",
+    "agx_reads_open", "agx_reads_close", "agx_unit_load_files_shared", "agx_run_unit_shared",
 ]
 
 
@@ -98,6 +99,10 @@ def lib():
                                                   ctypes.POINTER(ContiMer), ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
         L.agx_unit_push_pairs.argtypes = [ctypes.c_void_p, ctypes.POINTER(PairBatch)]
         L.agx_unit_load_files.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+        L.agx_reads_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_char_p, ctypes.c_size_t]
+        L.agx_reads_close.argtypes = [ctypes.c_void_p]
+        L.agx_reads_close.restype = None
+        L.agx_unit_load_files_shared.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
         for f in ("agx_unit_upload", "agx_unit_build", "agx_unit_download"):
             getattr(L, f).argtypes = [ctypes.c_void_p]
         L.agx_unit_finish.argtypes = [ctypes.c_void_p, ctypes.POINTER(Result)]
@@ -122,6 +127,29 @@ def _take(res):
            "extended": ctypes.string_at(res.extended, res.extended_len) if res.extended else b""}
     lib().agx_result_free(ctypes.byref(res))
     return out
+
+
+class Reads:
+    """tmp/_reads.fa mapped and indexed once (agx_reads); pass it to Unit.load_files of every unit of the run."""
+
+    def __init__(self, path):
+        self._h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        rc = lib().agx_reads_open(path.encode(), ctypes.byref(self._h), err, 512)
+        if rc != AGX_OK:
+            self._h = ctypes.c_void_p()
+            raise AgxError(rc, err.value.decode(errors="replace"))
+
+    def close(self):
+        if self._h:
+            lib().agx_reads_close(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class Unit:
@@ -156,8 +184,9 @@ class Unit:
         except Exception:
             pass
 
-    def load_files(self, tmp_dir, unit):
-        self._check(lib().agx_unit_load_files(self._h, tmp_dir.encode(), unit))
+    def load_files(self, tmp_dir, unit, reads=None):
+        """reads: an optional Reads (tmp/_reads.fa opened once for all units of a run)."""
+        self._check(lib().agx_unit_load_files_shared(self._h, tmp_dir.encode(), unit, reads._h if reads is not None else None))
 
     def upload(self):
         self._check(lib().agx_unit_upload(self._h))

@@ -685,6 +685,8 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
     int ndev = ndev_all;
     if (const char *e = getenv("AGX_DEVICES")) ndev = std::max(1, std::min(ndev_all, atoi(e)));
     const int per_dev = std::max(1, getenv("AGX_UNITS_PER_DEVICE") ? atoi(getenv("AGX_UNITS_PER_DEVICE")) : 4);   // >1: the text parsing and host walk of one unit overlap the kernels of others
+    // every unit reads tmp/_reads.fa (AG:1880): map and index it once for all of them
+    agx_reads *reads = nullptr; { char err[512]; if (agx_reads_open("tmp/_reads.fa", &reads, err, sizeof err) != AGX_OK) reads = nullptr; }   // (a missing file is reported by the first unit, as before)
     std::atomic<int> next(first);
     vector<int> state(units, 0); vector<string> errors(units);
     std::mutex mu; int reported = first;
@@ -706,7 +708,7 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
                 if (u >= units) return;
                 agx_params p = {(uint32_t)o.k, (uint32_t)o.insertVariation, (uint32_t)o.coverage, 0, d, 0};
                 agx_result r; char err[512];
-                const int rc = agx_run_unit(&p, "tmp", u, 1, &r, err, sizeof err);
+                const int rc = agx_run_unit_shared(&p, "tmp", u, 1, reads, &r, err, sizeof err);
                 if (rc == AGX_OK) agx_result_free(&r);
                 std::lock_guard<std::mutex> g(mu);
                 if (rc != AGX_OK) { string m = err; const size_t cut = m.find(" ("); errors[u] = cut == string::npos ? m : m.substr(0, cut); state[u] = -1; }
@@ -715,6 +717,7 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
             }
         });
     for (auto &t : workers) t.join();
+    agx_reads_close(reads);
 }
 
 }  // namespace

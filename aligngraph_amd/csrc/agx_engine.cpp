@@ -433,7 +433,21 @@ int agx_unit_push_pairs(agx_unit *u, const agx_pair_batch *b) {
     });
 }
 
-int agx_unit_load_files(agx_unit *u, const char *tmp_dir, int unit) {
+struct agx_reads { agx::ReadsIndex *idx; };
+
+int agx_reads_open(const char *reads_fa, agx_reads **out, char *err, size_t err_len) {
+    if (!reads_fa || !out) return AGX_E_ARG;
+    *out = nullptr;
+    try { agx_reads *r = new agx_reads{nullptr}; r->idx = reads_index_open(reads_fa); *out = r; return AGX_OK; }
+    catch (const Error &e) { if (err && err_len) snprintf(err, err_len, "%s", e.msg.c_str()); return e.code ? e.code : AGX_E_ARG; }
+    catch (const std::exception &e) { if (err && err_len) snprintf(err, err_len, "%s", e.what()); return AGX_E_ARG; }
+}
+
+void agx_reads_close(agx_reads *reads) { if (reads) { reads_index_close(reads->idx); delete reads; } }
+
+int agx_unit_load_files(agx_unit *u, const char *tmp_dir, int unit) { return agx_unit_load_files_shared(u, tmp_dir, unit, nullptr); }
+
+int agx_unit_load_files_shared(agx_unit *u, const char *tmp_dir, int unit, const agx_reads *reads) {
     if (!u || !tmp_dir) return AGX_E_ARG;
     return guarded(u, [&] {
         const std::string d = tmp_dir, s = std::to_string(unit);
@@ -442,7 +456,7 @@ int agx_unit_load_files(agx_unit *u, const char *tmp_dir, int unit) {
         load_unit_reference(d + "/_genome." + s + ".fa", u->T.ref);
         thread_contigs_from_files(d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", u->T);
         u->stats.ms_thread = now_ms() - t0; t0 = now_ms();
-        load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie", (long)u->prm.batch, u->prm.k, u->P);
+        load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie", (long)u->prm.batch, u->prm.k, u->P, reads ? reads->idx : nullptr);
         u->stats.ms_parse = now_ms() - t0;
         u->have_ref = u->have_threads = true; u->uploaded = false; u->built = false;
     });
@@ -526,11 +540,15 @@ void agx_graph_free(agx_graph *g) {
 }
 
 int agx_run_unit(const agx_params *p, const char *tmp_dir, int unit, int write_files, agx_result *r, char *err, size_t err_len) {
+    return agx_run_unit_shared(p, tmp_dir, unit, write_files, nullptr, r, err, err_len);
+}
+
+int agx_run_unit_shared(const agx_params *p, const char *tmp_dir, int unit, int write_files, const agx_reads *reads, agx_result *r, char *err, size_t err_len) {
     if (err && err_len) err[0] = 0;
     agx_unit *u = nullptr;
     int rc = agx_unit_create(p, &u);
     if (rc != AGX_OK) { if (err && err_len) snprintf(err, err_len, "%s", rc == AGX_E_NOGPU ? "no HIP device" : "bad parameters"); return rc; }
-    rc = agx_unit_load_files(u, tmp_dir, unit);
+    rc = agx_unit_load_files_shared(u, tmp_dir, unit, reads);
     if (rc == AGX_OK) rc = agx_unit_upload(u);
     if (rc == AGX_OK) rc = agx_unit_build(u);
     if (rc == AGX_OK) rc = agx_unit_finish(u, r);

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
+#include <memory>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -303,17 +304,43 @@ inline bool passes(const Mate &m) {
 }  // namespace
 
 // loadReadAlignment's parsing half: batches of `batch` pairs (AG:37, 361-404), SAM line pairs (AG:1233-1277)
-void load_pairs_from_files(const std::string &reads_fa, const std::string &sam_path, long batch, agx_u32 k, Pairs &P) {
+// One pass over tmp/_reads.fa: where every line pair (header, sequence) starts, up to the first empty line (which ends the file for
+// the reference's getline loops), and how many header lines there are (what decides the batch boundaries, AG:361-404).
+struct ReadsIndex {
+    FileView fv;
+    std::vector<uint64_t> rec_off;              // offset of the first line of record r (a record = two lines)
+    unsigned long long headers = 0;
+    explicit ReadsIndex(const std::string &path) : fv(path) {
+        const char *b = fv.p, *c = b, *e = b + fv.n;
+        unsigned long long line = 0;
+        while (c < e) {
+            const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+            if (nl == c) break;                  // empty line
+            if (*c == '>') headers++;
+            if ((line & 1ull) == 0) rec_off.push_back((uint64_t)(c - b));
+            line++;
+            if (!nl) break;
+            c = nl + 1;
+        }
+        if (fv.mapped) madvise((void *)fv.p, fv.n, MADV_RANDOM);
+    }
+};
+ReadsIndex *reads_index_open(const std::string &reads_fa) { return new ReadsIndex(reads_fa); }
+void reads_index_close(ReadsIndex *r) { delete r; }
+
+void load_pairs_from_files(const std::string &reads_fa, const std::string &sam_path, long batch, agx_u32 k, Pairs &P, const ReadsIndex *reads) {
     P = Pairs();
-    FileView rf(reads_fa), sf(sam_path);
+    std::unique_ptr<FileView> own_rf(reads ? nullptr : new FileView(reads_fa));
+    const FileView &rf = reads ? reads->fv : *own_rf;
+    FileView sf(sam_path);
     if (batch <= 0) batch = 1000000;
 
     // ---- pass 1 over the SAM: kept hits, in order, with the batch-boundary rule applied ----------------
     std::vector<agx_u32> hit_id;                 // read id per kept hit
     {
         // number of pairs in the reads file decides where the last batch ends: count header lines
-        unsigned long long headers = 0;
-        for (const char *c = rf.p, *e = rf.p + rf.n; c < e;) {
+        unsigned long long headers = reads ? reads->headers : 0;
+        for (const char *c = rf.p, *e = rf.p + rf.n; !reads && c < e;) {
             if (*c == '>') headers++;
             const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
             if (!nl) break;
@@ -408,6 +435,10 @@ void load_pairs_from_files(const std::string &reads_fa, const std::string &sam_p
         const agx_u32 want = hit_id[hi_idx];
         const char *ls; size_t ln;
         // skip to record 2*want
+        if (reads && rec < 2ull * want) {
+            if (2ull * want >= reads->rec_off.size()) throw Error{E_FORMAT, "reads file ends before a read named by the SAM"};
+            c = rf.p + reads->rec_off[2ull * want]; rec = 2ull * want;
+        }
         while (rec < 2ull * want) { if (!next_line(ls, ln) || !next_line(ls, ln)) throw Error{E_FORMAT, "reads file ends before a read named by the SAM"}; rec++; }
         for (int mate = 0; mate < 2; mate++) {
             if (!next_line(ls, ln) || ls[0] != '>') throw Error{E_FORMAT, "reads file: header expected"};

@@ -87,7 +87,13 @@ struct UnitOutput { OutBuf pre_extended, extended; unsigned long long n_fetched 
 // agx_host.cpp
 void load_unit_reference(const std::string &path, std::string &ref);
 void thread_contigs_from_files(const std::string &contigs_fa, const std::string &psl, Threads &T);   // T.ref must hold the unit sequence
-void load_pairs_from_files(const std::string &reads_fa, const std::string &sam, long batch, agx_u32 k, Pairs &P);
+// tmp/_reads.fa mapped once with the byte offset of every record: the units of one run (AG:1880 re-reads the whole file for each of
+// them) then only touch the reads their own SAM names.  Immutable after open(); shared by any number of threads.
+struct ReadsIndex;
+ReadsIndex *reads_index_open(const std::string &reads_fa);
+void reads_index_close(ReadsIndex *);
+// reads: optional index of reads_fa (nullptr: the file is scanned here)
+void load_pairs_from_files(const std::string &reads_fa, const std::string &sam, long batch, agx_u32 k, Pairs &P, const ReadsIndex *reads = nullptr);
 
 // agx_walk.cpp
 void walk_join_scaffold(const Threads &T, const Pairs &P, const GraphView &G, UnitOutput &out);

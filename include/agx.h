@@ -129,6 +129,14 @@ int agx_unit_push_pairs(agx_unit *u, const agx_pair_batch *b);                  
 /* Host loaders: the reference's own text files -> the three calls above. */
 int agx_unit_load_files(agx_unit *u, const char *tmp_dir, int unit);
 
+/* tmp/_reads.fa is the same file for every unit of a run, and the reference reads all of it for each unit (loadSeq under
+ * loadReadAlignment, AG:1880).  An agx_reads maps it once and indexes its records; the _shared loaders then touch only the reads a
+ * unit's own alignments name.  Immutable once opened: any number of host threads may load units from one agx_reads. */
+typedef struct agx_reads agx_reads;
+int agx_reads_open(const char *reads_fa, agx_reads **out, char *err, size_t err_len);
+void agx_reads_close(agx_reads *reads);
+int agx_unit_load_files_shared(agx_unit *u, const char *tmp_dir, int unit, const agx_reads *reads);   /* reads == NULL: same as agx_unit_load_files */
+
 int agx_unit_upload(agx_unit *u);                /* host -> HBM */
 int agx_unit_build(agx_unit *u);                 /* kernels: updateGenomeWithRead/updateKMer (AG:1635-1870, 1353-1624) + filterLowCoverage (AG:1904-1918) */
 int agx_unit_download(agx_unit *u);              /* HBM -> pinned host memory (walk graph); implied by agx_unit_finish */
@@ -141,6 +149,7 @@ void agx_graph_free(agx_graph *g);
 
 /* The five-call seam in one call.  write_files != 0 also writes the three files under tmp_dir like the reference does. */
 int agx_run_unit(const agx_params *p, const char *tmp_dir, int unit, int write_files, agx_result *r, char *err, size_t err_len);
+int agx_run_unit_shared(const agx_params *p, const char *tmp_dir, int unit, int write_files, const agx_reads *reads, agx_result *r, char *err, size_t err_len);
 
 #ifdef __cplusplus
 }

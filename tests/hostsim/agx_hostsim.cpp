@@ -193,7 +193,11 @@ int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int cover
         Threads T; Pairs P;
         load_unit_reference(d + "/_genome." + u + ".fa", T.ref);
         thread_contigs_from_files(d + "/_contigs.fa", d + "/_contigs_genome." + u + ".psl", T);
-        load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + u + ".bowtie", batch, (agx_u32)k, P);
+        if (getenv("AGX_SIM_READS_INDEX")) {            // the loader path of agx_unit_load_files_shared
+            ReadsIndex *ri = reads_index_open(d + "/_reads.fa");
+            try { load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + u + ".bowtie", batch, (agx_u32)k, P, ri); } catch (...) { reads_index_close(ri); throw; }
+            reads_index_close(ri);
+        } else load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + u + ".bowtie", batch, (agx_u32)k, P);
         SimGraph S; int nbig = 0;
         simulate(T, P, (agx_u32)k, iv, coverage, maxv_first > 0 ? (agx_u32)maxv_first : AGX_MAXV_LDS, S, nbig);
         GraphView G; G.n_pos = (agx_u32)T.ref.size(); G.n_ids = S.n_ids;

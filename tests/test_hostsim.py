@@ -64,6 +64,33 @@ def test_sparse_record_table_and_fetch_hook(built, tmp_path, monkeypatch):
     assert m["n_special"] < s["n_special"] and m["n_fetched"] > 100
 
 
+def test_shared_reads_index_loads_the_same_pairs(built, tmp_path, monkeypatch):
+    # agx_reads (one map + record index of tmp/_reads.fa for all units of a run) against the per-unit scan of the file, including the
+    # batch rule with a shrunk BATCH and reads files that end in an empty line
+    run = H.synth(str(tmp_path / "run"), seed=108, chroms="9000,7000,5000", pairs=3000, coverage=3, multi=0.3, unaligned=0.2, sam_seq=0)
+    meta = H.read_meta(run)
+    tmp = os.path.join(run, "tmp")
+    for batch in (0, 700):
+        plain = [sim.run(tmp, u, meta["k"], meta["insert_variation"], meta["coverage"], batch=batch or 1000000, graph=True) for u in range(meta["units"])]
+        monkeypatch.setenv("AGX_SIM_READS_INDEX", "1")
+        shared = [sim.run(tmp, u, meta["k"], meta["insert_variation"], meta["coverage"], batch=batch or 1000000, graph=True) for u in range(meta["units"])]
+        monkeypatch.delenv("AGX_SIM_READS_INDEX")
+        for a, b in zip(plain, shared):
+            assert graph_mismatch(a["graph"], b["graph"]) is None
+            for key in ("initial", "pre", "extended"):
+                assert a[key] == b[key], key
+        for u, s in enumerate(plain):
+            o = H.run_oracle(tmp, u, meta["k"], meta["insert_variation"], meta["coverage"], batch=batch or 1000000)
+            assert o["extended"] == s["extended"]
+    with open(os.path.join(tmp, "_reads.fa"), "a") as f:          # an empty line ends the file for both loaders; records behind it do not exist
+        f.write("\n>9999999\nACGT\n")
+    for shared_loader in (False, True):
+        if shared_loader:
+            monkeypatch.setenv("AGX_SIM_READS_INDEX", "1")
+        again = sim.run(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"], batch=700)
+        assert again["extended"] == plain[0]["extended"] and again["pre"] == plain[0]["pre"]
+
+
 def test_batch_boundary_drops_first_pair_of_next_batch(built, tmp_path):
     # AG:1258-1259 with BATCH shrunk to 500 pairs: oracle and engine loaders must lose the same line pairs
     run = H.synth(str(tmp_path / "run"), seed=7, chroms="8000", pairs=2300, coverage=3, multi=0.3, sam_seq=0)
