@@ -18,6 +18,17 @@
 #include <immintrin.h>
 #endif
 
+// -DAGX_WALK_PROF: cycle counts per section of the walk, printed with AGX_WALK_TIMING (development aid, compiled out by default)
+#if defined(AGX_WALK_PROF) && defined(__x86_64__)
+#include <x86intrin.h>
+static unsigned long long g_prof[12];
+#define AGX_PT(i) do { const unsigned long long t_ = __rdtsc(); g_prof[i] += t_ - tp_; tp_ = t_; } while (0)
+#define AGX_PT_START unsigned long long tp_ = __rdtsc()
+#else
+#define AGX_PT(i) do { } while (0)
+#define AGX_PT_START do { } while (0)
+#endif
+
 namespace agx {
 namespace {
 
@@ -33,6 +44,13 @@ struct Seg { const char *p; size_t n; };
 
 inline bool contains(agx_u32 sID1, agx_u32 sOff1, agx_u32 eID1, agx_u32 eOff1, agx_u32 sID2, agx_u32 sOff2, agx_u32 eID2, agx_u32 eOff2) {
     return sID1 == sID2 && eID1 == eID2 && sOff1 <= sOff2 && eOff1 >= eOff2;      // AG:1897-1902
+}
+
+inline char *put_u32(char *w, agx_u32 v) {      // decimal, no padding
+    char t[10]; int n = 0;
+    do { t[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
+    while (n) *w++ = t[--n];
+    return w;
 }
 
 inline void fasta_body(std::string &out, const char *s, size_t n) {
@@ -67,6 +85,33 @@ __attribute__((target("avx2"))) inline agx_u32 run_end_avx2(const agx_u8 *meta, 
     }
 }
 #endif
+// first index i in [from, n) with done[i] == 0 (n if none); done is padded with ones
+inline agx_u32 next_zero_scalar(const agx_u8 *done, agx_u32 from, agx_u32 n) {
+    agx_u32 i = from;
+    while (i < n && (i & 7u)) { if (!done[i]) return i; i++; }
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, &done[i], 8); if (w != 0x0101010101010101ull) break; }
+    while (i < n && done[i]) i++;
+    return i < n ? i : n;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline agx_u32 next_zero_avx2(const agx_u8 *done, agx_u32 from, agx_u32 n) {
+    agx_u32 i = from;
+    const __m256i zero = _mm256_setzero_si256();
+    for (; i + 32 <= n; i += 32) {
+        const unsigned m = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(done + i)), zero));
+        if (m) return i + (agx_u32)__builtin_ctz(m);
+    }
+    while (i < n && done[i]) i++;
+    return i < n ? i : n;
+}
+#endif
+typedef agx_u32 (*next_zero_fn)(const agx_u8 *, agx_u32, agx_u32);
+inline next_zero_fn pick_next_zero() {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2")) return next_zero_avx2;
+#endif
+    return next_zero_scalar;
+}
 typedef agx_u32 (*run_end_fn)(const agx_u8 *, const agx_u8 *, agx_u32, agx_u8 &);
 inline run_end_fn pick_run_end() {
 #if defined(__x86_64__)
@@ -149,13 +194,8 @@ struct Walker {
         }
     }
     // first unvisited node with id in [from, n) (n if none): the position scan of AG:1972-1978 in walk-id space
-    agx_u32 next_live(agx_u32 from, agx_u32 n) const {
-        agx_u32 i = from;
-        while (i < n && (i & 7u)) { if (!done[i]) return i; i++; }
-        for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, &done[i], 8); if (w != 0x0101010101010101ull) break; }
-        while (i < n && done[i]) i++;
-        return i < n ? i : n;
-    }
+    next_zero_fn next_zero = pick_next_zero();
+    agx_u32 next_live(agx_u32 from, agx_u32 n) const { return from < n ? next_zero(done.data(), from, n) : n; }
 };
 
 // extdContigs1, AG:1954-2204, replayed on the alive-compacted graph.  Alive ids are position-major, so "for every
@@ -168,10 +208,12 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
     std::vector<Seg> segs;
     pre_out.reserve((size_t)G.n_ids + G.n_ids / 32 + 4096);
     agx_u8 *done = W.done.data();
+    AGX_PT_START;
     const run_end_fn run_end = pick_run_end();
     unsigned long long n_walks = 0, n_hops = 0, n_runs = 0, n_general = 0, run_nodes = 0;
     const agx_u32 n_side = G.n_ids - G.n_pos;
     agx_u32 sc = 0;                              // side index cursor: every side id before it lies at a position < cp
+    agx_u32 side_live = G.n_pos, main_live = 0;  // cached "first unvisited side / main id" of the position scan (see below)
     for (agx_u32 cp = 0; cp < G.n_pos;) {
         // variants of position cp in order: its main slot, then its side range
         while (sc < n_side && G.side_xpos[sc] < cp) sc++;
@@ -179,17 +221,19 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
         const agx_u32 s_lo = G.n_pos + sc, s_hi = G.n_pos + sh;
         for (agx_u32 vi = 0, start = cp; vi <= s_hi - s_lo; vi++, start = s_lo + vi - 1) {
             if (done[start]) continue;
+            AGX_PT(8);
             Rec C; C.sID = 0; C.sOff = cp; C.extended = 0;
             segs.clear(); n_walks++;
             agx_u32 cur = start;                 // current k-mer node (mode 1)
             { const agx_u32 o = W.node(cur).off0; C.sID0 = o == AGX_NONE ? AGX_NONE : 0; C.sOff0 = o; }
+            AGX_PT(0);
             agx_u32 cpp = cp; int mode = 1;               // mode = kMerTag
             agx_u32 last = cur;
             while ((mode == 1 && !done[cur]) || mode == 0) {
                 if (mode == 0) {                            // on a conti-mer, AG:2061-2138
                     // the whole conti-mer chain in one segment (the reference steps through it one base at a time), then its end:
                     // hop back onto the k-mer graph only through the single live node there and its single live edge (AG:2093-2136)
-                    const Threads::Hop &h = T.hop[cpp];
+                    AGX_PT(7); const Threads::Hop &h = T.hop[cpp];
                     segs.push_back(Seg{T.chain_str.data() + h.str_off, h.len}); C.extended = 1; n_hops++;
                     pos_bak = h.end_pos; cpp = h.end_pos;
                     agx_u32 live = 0, item = 0;
@@ -200,23 +244,27 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
                     if (live == 1) ns = W.live_successors(item, tgt);
                     if (ns == 1) { cur = tgt; pos_bak = W.pos_of(tgt); cpp = pos_bak; mode = done[cur] ? -2 : 1; }
                     else mode = -2;
+                    AGX_PT(1);
                 } else {                                    // on a k-mer node, AG:1995-2060
                     // forced run: while the cont bit holds and the next node is unvisited the reference steps cur -> cur+1 (its unique live
                     // successor).
                     agx_u8 seen = 0;
                     const agx_u32 j = run_end(G.meta, done, cur, seen);
                     const agx_u32 xj = W.pos_of(j);
-                    __builtin_prefetch(&T.hop[xj]);                             // most walks leave the k-mer graph here, onto a conti-mer chain
+                    __builtin_prefetch(&T.hop[xj]);
+                    AGX_PT(2);                             // most walks leave the k-mer graph here, onto a conti-mer chain
                     segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!(G.meta[j] & AGX_WM_CONT)) n_general++;
                     if (seen & AGX_WM_CONTIG) C.extended = 1;
                     memset(done + cur, 1, (size_t)j - cur + 1);
                     if (j > cur) pos_bak = xj;
                     cur = j; last = j; cpp = xj;
+                    AGX_PT(3);
                     agx_u32 tgt = 0;
                     const int ns = (G.meta[cur] & AGX_WM_CONT) ? 0 : W.live_successors(cur, tgt);      // cont && stopped: its only alive successor is already visited
                     if (ns == 1) { cur = tgt; pos_bak = W.pos_of(tgt); cpp = pos_bak; }
                     else if (T.hop[cpp].len) mode = 0;                          // exactly one conti-mer here and it has a next (AG:2047-2057)
                     else mode = -1;
+                    AGX_PT(4);
                 }
             }
             // end bookkeeping, AG:2142-2173
@@ -228,12 +276,20 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
                 klen = (W.node(last).sref.qlen >> 16) & 0x7FFFu; klast = last;
                 C.eOff = C.eOff + klen - 1; C.eOff0 = C.eOff0 + klen - 1;
             } else { C.eID0 = AGX_NONE; C.eOff0 = AGX_NONE; klen = 0; }
+            AGX_PT(5);
             if (!contains(sIDBak, sOffBak, eIDBak, eOffBak, C.sID, C.sOff, C.eID, C.eOff)) {        // AG:2176-2189
                 if (klen > 1) { W.kmer_string(klast, kmer); segs.push_back(Seg{kmer.data() + 1, kmer.size() - 1}); }
                 size_t total = 0; for (const Seg &g : segs) total += g.n;
                 C.nuc.reserve(total); for (const Seg &g : segs) C.nuc.append(g.p, g.n);
-                char hdr[256];
-                const int hl = std::snprintf(hdr, sizeof hdr, ">%u, %d, %u, %u, %u, %u, %u, %u, %u, %u \n", seqID++, C.extended, C.sID, C.sOff, C.eID, C.eOff, C.sID0, C.sOff0, C.eID0, C.eOff0);
+                char hdr[256];                    // ">%u, %d, %u, %u, %u, %u, %u, %u, %u, %u \n" (AG:2180-2183) without going through printf
+                int hl = 0;
+                {
+                    const agx_u32 f[10] = {seqID++, (agx_u32)C.extended, C.sID, C.sOff, C.eID, C.eOff, C.sID0, C.sOff0, C.eID0, C.eOff0};
+                    char *w = hdr; *w++ = '>';
+                    for (int i = 0; i < 10; i++) { w = put_u32(w, f[i]); if (i < 9) { *w++ = ','; *w++ = ' '; } }
+                    *w++ = ' '; *w++ = '\n';
+                    hl = (int)(w - hdr);
+                }
                 const size_t lines = (total + 59) / 60;
                 char *w = pre_out.grow((size_t)hl + total + lines); memcpy(w, hdr, (size_t)hl); w += hl;
                 for (size_t i = 0; i < total; i += 60) { const size_t m = total - i < 60 ? total - i : 60; memcpy(w, C.nuc.data() + i, m); w += m; *w++ = '\n'; }
@@ -241,19 +297,34 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
                 if (eOffBak - sOffBak > 100000) W.prefetch_skip_positions(cp, eOffBak < G.n_pos ? eOffBak : G.n_pos);
                 written.push_back(std::move(C));
             }
+            AGX_PT(6);
         }
+        AGX_PT(9);
         // AG:2194-2202: inside a written record longer than 100 kb the scan jumps 1000 positions at a time; otherwise it moves to the
         // next position — and positions without an unvisited node do nothing, so jump straight to the next unvisited node's position
         if (eOffBak - sOffBak > 100000 && eIDBak == 0 && cp + 1000 < eOffBak) cp += 1000;
         else {
             // the +1000 rule is re-evaluated at every position on the way, but it can only switch ON again after a new record is
             // written, which needs an unvisited node: skipping node-less positions one by one or at once is the same
-            const agx_u32 m = W.next_live(cp + 1, G.n_pos);                                  // main slot id == position
-            const agx_u32 sd = W.next_live(s_hi, G.n_ids);
+            // first unvisited main id (= position) after cp and first unvisited side id from s_hi on.  Visited nodes stay visited and both
+            // bounds only grow, so a previous answer is still the answer unless it has been passed or visited since: each block is scanned
+            // once over the whole walk, not once per step (a long record leaves thousands of side nodes behind, each a step of its own)
+            if (main_live <= cp || (main_live < G.n_pos && done[main_live])) main_live = W.next_live(main_live > cp + 1 ? main_live : cp + 1, G.n_pos);
+            const agx_u32 m = main_live;                                                     // main slot id == position
+            if (side_live < s_hi || (side_live < G.n_ids && done[side_live])) side_live = W.next_live(side_live > s_hi ? side_live : s_hi, G.n_ids);
+            const agx_u32 sd = side_live;
             const agx_u32 sp = sd < G.n_ids ? G.side_xpos[sd - G.n_pos] : G.n_pos;
             cp = m < sp ? m : sp;
         }
+        AGX_PT(10);
     }
+#if defined(AGX_WALK_PROF) && defined(__x86_64__)
+    if (getenv("AGX_WALK_TIMING")) {
+        fprintf(stderr, "[agx walk] Mcycles: start %.1f, hop %.1f, run scan %.1f, mark %.1f, successors %.1f, end %.1f, contain+write %.1f, between %.1f, position scan %.1f (+ %.1f after the last variant, %.1f next position)\n",
+                g_prof[0] / 1e6, g_prof[1] / 1e6, g_prof[2] / 1e6, g_prof[3] / 1e6, g_prof[4] / 1e6, g_prof[5] / 1e6, g_prof[6] / 1e6, g_prof[7] / 1e6, g_prof[8] / 1e6, g_prof[9] / 1e6, g_prof[10] / 1e6);
+        memset(g_prof, 0, sizeof g_prof);
+    }
+#endif
     if (getenv("AGX_WALK_TIMING")) fprintf(stderr, "[agx walk] walks %llu, contig hops %llu, runs %llu (%llu nodes), general evaluations %llu\n", n_walks, n_hops, n_runs, run_nodes, n_general);
 }
 
