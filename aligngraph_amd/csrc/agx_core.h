@@ -688,6 +688,11 @@ AGX_HD agx_u32 agx_edge_slow_pair(const agx_sweep_args &A, const agx_slow_ctx &c
 // per-node record the walk reads at branch points, record starts and record ends: one 32-byte line instead of four arrays
 struct agx_walknode { agx_u32 next[AGX_MAXE]; agx_u32 off0, xpos; agx_sref sref; };
 
+// what a walk does when it leaves the k-mer graph at a position (AG:2047-2057): exactly one conti-mer there, with a next -> append
+// chain_str[str_off, str_off+len) and land on end_pos; len == 0: no hop possible.  Kept per position on the host (Threads::hop) and,
+// gathered by the device for the special ids, next to their records in the sparse table.
+struct agx_hop { agx_u32 str_off, len, end_pos; };
+
 // a_meta bits: forced step to id+1; contigOffset != -1 (AG:2004); (main ids) the position has further alive variants in the side
 // block; (main ids) the position holds at least one variant, pruned or not (scaffold gap rule, AG:2428); no node at this id
 enum { AGX_WM_CONT = 1, AGX_WM_CONTIG = 2, AGX_WM_SIDE = 4, AGX_WM_ANY = 8, AGX_WM_ABSENT = 128 };
@@ -719,6 +724,7 @@ struct agx_compact_args {
     // sparse record table
     agx_u32 n_ids, sparse_min;     // sparse_min (test hook): only the side ids are special, every other record comes through the fetch path
     unsigned long long *sp_bits; agx_u32 *sp_cnt; const agx_u32 *sp_rank; agx_walknode *sp_node;
+    const agx_hop *hop; agx_hop *sp_hop;   // per-position hop table (input) and its gather for the special ids
     const agx_u32 *abort;          // device only: the node sweeps' status word (non-zero: the node table is incomplete, the kernels do nothing)
 };
 

@@ -72,11 +72,11 @@ struct agx_unit {
     agx_u32 n_ids = 0;
     DBuf<agx_u32> d_side_cnt, d_side_start, d_aid_of; DBuf<char> d_a_str;
     DBuf<agx_u8> d_a_meta, d_a_mark; DBuf<agx_walknode> d_a_node, d_sp_node; DBuf<agx_edge_ovf> d_a_ovf;
-    DBuf<agx_u32> d_chain_end, d_side_xpos, d_sp_cnt, d_sp_rank; DBuf<unsigned long long> d_sp_bits;
+    DBuf<agx_u32> d_chain_end, d_side_xpos, d_sp_cnt, d_sp_rank; DBuf<unsigned long long> d_sp_bits; DBuf<agx_hop> d_hop, d_sp_hop;
     agx_u32 n_chain_end = 0, n_special = 0, n_words = 0;
     // downloaded: the walk graph with its sparse record table (agx_core.h); the full record table stays on the device
     PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
-    PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_edge_ovf> h_a_ovf;
+    PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_hop> h_sp_hop; PBuf<agx_edge_ovf> h_a_ovf;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0;
     EventPair ev_prep, ev_bin, ev_node, ev_big, ev_edge, ev_slow, ev_compact;
@@ -145,6 +145,9 @@ void do_upload(agx_unit *u) {
     const size_t nb = ((size_t)n_pos + 1 + 1023) / 1024;              // sized for the longer of the two scans (positions)
     u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16);
     u->d_words.alloc(W_N); u->h_words.alloc(W_N + 4); u->h_fetch.alloc(2 * (n_pos / 1000 + 2));
+    if (u->T.hop.size() != n_pos) throw Error{E_ARG, "conti-mer chains were not built"};
+    u->d_hop.alloc(n_pos + 1);
+    HIP_OK(hipMemcpy(u->d_hop.p, u->T.hop.data(), n_pos * sizeof(agx_hop), hipMemcpyHostToDevice));
     {   // positions where a conti-mer chain ends: their main walk ids belong to the sparse record table (agx_core.h)
         std::vector<agx_u32> ce(u->T.chain_end_pos); std::sort(ce.begin(), ce.end()); ce.erase(std::unique(ce.begin(), ce.end()), ce.end());
         u->n_chain_end = (agx_u32)ce.size(); u->d_chain_end.alloc(ce.size() + 1);
@@ -178,7 +181,7 @@ void do_build(agx_unit *u) {
         u->d_a_str.alloc(ids_cap + 1); u->d_a_meta.alloc(ids_cap + 16); u->d_a_node.alloc(ids_cap + 1); u->d_a_ovf.alloc((size_t)u->ovf_cap + 1);
         u->d_side_cnt.alloc((size_t)n_pos + 2); u->d_side_start.alloc((size_t)n_pos + 2);
         u->n_words = (agx_u32)(ids_cap / 64 + 1);
-        u->d_a_mark.alloc(ids_cap + 2); u->d_side_xpos.alloc((size_t)u->pool_cap + 1); u->d_sp_node.alloc(ids_cap + 1);
+        u->d_a_mark.alloc(ids_cap + 2); u->d_side_xpos.alloc((size_t)u->pool_cap + 1); u->d_sp_node.alloc(ids_cap + 1); u->d_sp_hop.alloc(ids_cap + 1);
         u->d_sp_bits.alloc((size_t)u->n_words + 1); u->d_sp_cnt.alloc((size_t)u->n_words + 1); u->d_sp_rank.alloc((size_t)u->n_words + 2);
         {   const size_t nb = ((size_t)std::max<size_t>(n_pos, u->n_words) + 1 + 1023) / 1024;
             u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16); }
@@ -238,7 +241,7 @@ void do_build(agx_unit *u) {
         HIP_OK(hipEventRecord(u->ev_compact.a, st));
         C.abort = u->d_words.p + W_STATUS;
         C.a_mark = u->d_a_mark.p; C.side_xpos = u->d_side_xpos.p; C.sparse_min = (u->prm.flags & AGX_FLAG_SPARSE_MIN) ? 1u : 0u;
-        C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p;
+        C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p; C.hop = u->d_hop.p; C.sp_hop = u->d_sp_hop.p;
         HIP_OK(hipMemsetAsync(u->d_side_cnt.p + n_pos, 0, 4, st));
         HIP_OK(hipMemsetAsync(u->d_a_mark.p, 0, ids_cap + 2, st));
         HIP_OK(hipMemsetAsync(u->d_sp_cnt.p + u->n_words, 0, 4, st));
@@ -273,7 +276,7 @@ void do_build(agx_unit *u) {
             u->d_cid.release(); u->d_coff.release(); u->d_cid0.release(); u->d_coff0.release(); u->d_off0.release(); u->d_xpos.release();
             u->d_next.release(); u->d_base.release(); u->d_flags.release(); u->d_sref.release(); u->d_counts.release();
             u->d_aid_of.release(); u->d_a_str.release(); u->d_a_meta.release(); u->d_a_node.release();
-            u->d_a_mark.release(); u->d_side_xpos.release(); u->d_sp_node.release(); u->d_sp_bits.release(); u->d_sp_cnt.release(); u->d_sp_rank.release();
+            u->d_a_mark.release(); u->d_side_xpos.release(); u->d_sp_node.release(); u->d_sp_hop.release(); u->d_sp_bits.release(); u->d_sp_cnt.release(); u->d_sp_rank.release();
             alloc_pool(u, (agx_u32)cap);
             continue;
         }
@@ -296,7 +299,7 @@ void do_download(agx_unit *u) {
     hipStream_t st = u->st;
     const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
     u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(nside + 1);
-    u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1);
+    u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 1);
     u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
     if (ni) {
         HIP_OK(hipMemcpyAsync(u->h_a_str.p, u->d_a_str.p, ni, hipMemcpyDeviceToHost, st));
@@ -306,11 +309,12 @@ void do_download(agx_unit *u) {
     }
     if (nside) HIP_OK(hipMemcpyAsync(u->h_side_xpos.p, u->d_side_xpos.p, nside * 4, hipMemcpyDeviceToHost, st));
     if (ns) HIP_OK(hipMemcpyAsync(u->h_sp_node.p, u->d_sp_node.p, ns * sizeof(agx_walknode), hipMemcpyDeviceToHost, st));
+    if (ns) HIP_OK(hipMemcpyAsync(u->h_sp_hop.p, u->d_sp_hop.p, ns * sizeof(agx_hop), hipMemcpyDeviceToHost, st));
     if (u->n_ovf) HIP_OK(hipMemcpyAsync(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     memset(u->h_a_meta.p + ni, 0, 64);
     u->stats.n_walk_ids = ni; u->stats.n_special = ns;
-    u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * sizeof(agx_walknode) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
+    u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
     u->downloaded = true;
     u->stats.ms_download = now_ms() - t0;
 }
@@ -333,7 +337,7 @@ void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u
 GraphView view_of(agx_unit *u) {
     GraphView G; G.n_pos = (agx_u32)u->T.ref.size(); G.n_ids = u->n_ids;
     G.meta = u->h_a_meta.p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
-    G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.n_special = u->n_special;
+    G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.sp_hop = u->h_sp_hop.p; G.n_special = u->n_special;
     G.fetch = fetch_records; G.fetch_ctx = u;
     G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf;
     return G;

@@ -31,10 +31,8 @@ struct Threads {
     std::vector<size_t> chain_off;          // [n_chains+1] chain c's bases are chain_str[chain_off[c] .. chain_off[c+1])
     std::vector<agx_u32> chain_end_pos;     // position of the chain's terminal conti-mer
     std::string chain_str;
-    // what a walk does when it leaves the k-mer graph at position x (AG:2047-2057): exactly one conti-mer there, with a next ->
-    // append chain_str[str_off, str_off+len) and land on end_pos; len == 0: no hop possible
-    struct Hop { size_t str_off; agx_u32 len, end_pos; };
-    std::vector<Hop> hop;                   // [n_pos]
+    // per-position hop table (agx_hop, agx_core.h)
+    std::vector<agx_hop> hop;               // [n_pos]
 };
 void build_chains(Threads &T);
 
@@ -59,6 +57,7 @@ struct GraphView {
     const unsigned long long *sp_bits = nullptr;            // [n_ids/64 + 1] special-id bitmap
     const agx_u32 *sp_rank = nullptr;                       // [n_ids/64 + 1] special ids before each 64-id word
     const agx_walknode *sp_node = nullptr; agx_u32 n_special = 0;   // records of the special ids, id order
+    const agx_hop *sp_hop = nullptr;                        // [n_special] hop entry of each special id's position (optional: else Threads::hop)
     // records of non-special ids: `rows` groups of `width` consecutive ids, group r starting at first + r*stride, into out[rows*width]
     void (*fetch)(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *out) = nullptr; void *fetch_ctx = nullptr;
     const agx_edge_ovf *ovf = nullptr; size_t n_ovf = 0;     // walk ids; NONE/NONE entries and duplicates are ignored

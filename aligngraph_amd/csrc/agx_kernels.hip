@@ -306,7 +306,11 @@ __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, ag
     if (w >= n_words) return;
     const unsigned long long bits = A.sp_bits[w];
     const agx_u32 lane = threadIdx.x & 63u;
-    if ((bits >> lane) & 1ull) A.sp_node[A.sp_rank[w] + (agx_u32)__popcll(bits & ((1ull << lane) - 1ull))] = A.a_node[a];
+    if ((bits >> lane) & 1ull) {
+        const agx_u32 at = A.sp_rank[w] + (agx_u32)__popcll(bits & ((1ull << lane) - 1ull));
+        A.sp_node[at] = A.a_node[a];
+        A.sp_hop[at] = A.hop[a < A.n_pos ? a : A.side_xpos[a - A.n_pos]];
+    }
 }
 
 // ---- host-callable launchers (kept in this translation unit so that the engine is plain C++) -------------------------

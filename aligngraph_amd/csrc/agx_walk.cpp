@@ -22,8 +22,9 @@
 #if defined(AGX_WALK_PROF) && defined(__x86_64__)
 #include <x86intrin.h>
 static unsigned long long g_prof[12];
-#define AGX_PT(i) do { const unsigned long long t_ = __rdtsc(); g_prof[i] += t_ - tp_; tp_ = t_; } while (0)
-#define AGX_PT_START unsigned long long tp_ = __rdtsc()
+// (lfence: without it the out-of-order core reads the counter early and a section's cache misses are billed to a later one)
+#define AGX_PT(i) do { _mm_lfence(); const unsigned long long t_ = __rdtsc(); g_prof[i] += t_ - tp_; tp_ = t_; } while (0)
+#define AGX_PT_START _mm_lfence(); unsigned long long tp_ = __rdtsc()
 #else
 #define AGX_PT(i) do { } while (0)
 #define AGX_PT_START do { } while (0)
@@ -137,9 +138,19 @@ struct Walker {
     mutable unsigned long long n_fetched = 0;
     mutable std::unordered_map<agx_u32, agx_walknode> extra;      // records fetched so far (a few per 1000 positions of long records)
     mutable std::vector<agx_walknode> rows;
-    agx_walknode node(agx_u32 v) const {
+    agx_u32 rank_of(agx_u32 v) const {              // index of v in the sparse table, NONE if v is not a special id
         const unsigned long long w = G.sp_bits[v >> 6], bit = 1ull << (v & 63u);
-        if (w & bit) return G.sp_node[G.sp_rank[v >> 6] + (agx_u32)__builtin_popcountll(w & (bit - 1))];
+        return (w & bit) ? G.sp_rank[v >> 6] + (agx_u32)__builtin_popcountll(w & (bit - 1)) : AGX_NONE;
+    }
+    // hop entry of node v at position x: next to v's record in the sparse table (one cache line away from what the walk just read)
+    // instead of a random access into the per-position table
+    agx_hop hop_of(agx_u32 v, agx_u32 x) const {
+        const agx_u32 r = G.sp_hop ? rank_of(v) : AGX_NONE;
+        return r != AGX_NONE ? G.sp_hop[r] : T.hop[x];
+    }
+    agx_walknode node(agx_u32 v) const {
+        const agx_u32 at = rank_of(v);
+        if (at != AGX_NONE) return G.sp_node[at];
         const auto it = extra.find(v);
         if (it != extra.end()) return it->second;
         if (!G.fetch) throw Error{E_ARG, "walk graph without a record fetch hook"};
@@ -205,6 +216,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
     agx_u32 seqID = 0, sIDBak = AGX_NONE, sOffBak = AGX_NONE, eIDBak = AGX_NONE, eOffBak = AGX_NONE;
     agx_u32 pos_bak = 0;                         // cppBak of the reference (function scope)
     std::string kmer; agx_u32 klen = 0, klast = 0;
+    agx_hop hcur{0, 0, 0};                       // hop entry of the position the walk is about to leave the k-mer graph at
     std::vector<Seg> segs;
     pre_out.reserve((size_t)G.n_ids + G.n_ids / 32 + 4096);
     agx_u8 *done = W.done.data();
@@ -233,7 +245,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
                 if (mode == 0) {                            // on a conti-mer, AG:2061-2138
                     // the whole conti-mer chain in one segment (the reference steps through it one base at a time), then its end:
                     // hop back onto the k-mer graph only through the single live node there and its single live edge (AG:2093-2136)
-                    AGX_PT(7); const Threads::Hop &h = T.hop[cpp];
+                    AGX_PT(7); const agx_hop h = hcur;
                     segs.push_back(Seg{T.chain_str.data() + h.str_off, h.len}); C.extended = 1; n_hops++;
                     pos_bak = h.end_pos; cpp = h.end_pos;
                     agx_u32 live = 0, item = 0;
@@ -251,7 +263,6 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
                     agx_u8 seen = 0;
                     const agx_u32 j = run_end(G.meta, done, cur, seen);
                     const agx_u32 xj = W.pos_of(j);
-                    __builtin_prefetch(&T.hop[xj]);
                     AGX_PT(2);                             // most walks leave the k-mer graph here, onto a conti-mer chain
                     segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!(G.meta[j] & AGX_WM_CONT)) n_general++;
                     if (seen & AGX_WM_CONTIG) C.extended = 1;
@@ -262,7 +273,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
                     agx_u32 tgt = 0;
                     const int ns = (G.meta[cur] & AGX_WM_CONT) ? 0 : W.live_successors(cur, tgt);      // cont && stopped: its only alive successor is already visited
                     if (ns == 1) { cur = tgt; pos_bak = W.pos_of(tgt); cpp = pos_bak; }
-                    else if (T.hop[cpp].len) mode = 0;                          // exactly one conti-mer here and it has a next (AG:2047-2057)
+                    else if ((hcur = W.hop_of(j, xj)).len) mode = 0;            // exactly one conti-mer here and it has a next (AG:2047-2057)
                     else mode = -1;
                     AGX_PT(4);
                 }
@@ -424,7 +435,8 @@ void build_chains(Threads &T) {
         T.chain_end_pos.push_back(pos_of[c]); T.chain_off.push_back(T.chain_str.size());
     }
     for (size_t i = 0; i < n; i++) if (T.cm_chain[i] == AGX_NONE) throw Error{E_ARG, "conti-mer cycle"};
-    T.hop.assign(n_pos, Threads::Hop{0, 0, 0});
+    if (T.chain_str.size() >= 0xFFFFFFFFull) throw Error{E_ARG, "conti-mer chains exceed 2^32 bases"};
+    T.hop.assign(n_pos, agx_hop{0, 0, 0});
     for (size_t x = 0; x < n_pos; x++) {
         if (T.cm_start[x + 1] - T.cm_start[x] != 1) continue;
         const ContiMer &m = T.cm[T.cm_start[x]];
@@ -432,7 +444,7 @@ void build_chains(Threads &T) {
         const size_t nx = index_of(m.next_off, m.next_item);          // the walk continues ON the next conti-mer (AG:2049-2055)
         const agx_u32 ch = T.cm_chain[nx];
         const size_t from = T.chain_off[ch] + T.cm_idx[nx];
-        T.hop[x] = Threads::Hop{from, (agx_u32)(T.chain_off[ch + 1] - from), T.chain_end_pos[ch]};
+        T.hop[x] = agx_hop{(agx_u32)from, (agx_u32)(T.chain_off[ch + 1] - from), T.chain_end_pos[ch]};
     }
 }
 

@@ -28,7 +28,7 @@ struct SimGraph {
     // alive-compacted view (agx_core.h "walk preparation")
     agx_u32 n_ids = 0;
     std::vector<agx_u32> side_cnt, side_start, aid_of; std::string a_str;
-    std::vector<agx_u8> a_meta, a_mark; std::vector<agx_walknode> a_node, sp_node; std::vector<agx_edge_ovf> a_ovf;
+    std::vector<agx_u8> a_meta, a_mark; std::vector<agx_walknode> a_node, sp_node; std::vector<agx_hop> sp_hop; std::vector<agx_edge_ovf> a_ovf;
     std::vector<agx_u32> side_xpos, sp_cnt, sp_rank; std::vector<unsigned long long> sp_bits; agx_u32 n_special = 0;
     void reserve(size_t cap) {
         cid.resize(cap); coff.resize(cap); cid0.resize(cap); coff0.resize(cap); off0.resize(cap); xpos.resize(cap); next.resize(cap * AGX_MAXE);
@@ -164,9 +164,13 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
         S.sp_bits[w] = bits; S.sp_cnt[w] = (agx_u32)__builtin_popcountll(bits);
     }
     agx_u32 acc = 0; for (agx_u32 w = 0; w <= n_words; w++) { S.sp_rank[w] = acc; acc += S.sp_cnt[w]; }
-    S.n_special = S.sp_rank[n_words]; S.sp_node.resize((size_t)S.n_special + 1);
+    S.n_special = S.sp_rank[n_words]; S.sp_node.resize((size_t)S.n_special + 1); S.sp_hop.resize((size_t)S.n_special + 1);
     for (agx_u32 w = 0; w < n_words; w++) for (agx_u32 l = 0; l < 64; l++) if ((S.sp_bits[w] >> l) & 1ull)
-        S.sp_node[S.sp_rank[w] + (agx_u32)__builtin_popcountll(S.sp_bits[w] & ((1ull << l) - 1ull))] = S.a_node[(size_t)w * 64 + l];
+    {
+        const agx_u32 a = w * 64 + l, at = S.sp_rank[w] + (agx_u32)__builtin_popcountll(S.sp_bits[w] & ((1ull << l) - 1ull));
+        S.sp_node[at] = S.a_node[a];
+        S.sp_hop[at] = T.hop[a < n_pos ? a : S.side_xpos[a - n_pos]];
+    }
 }
 
 char *dup_buf(const std::string &s) { char *p = (char *)malloc(s.size() + 1); memcpy(p, s.data(), s.size()); p[s.size()] = 0; return p; }
@@ -202,7 +206,7 @@ int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int cover
         simulate(T, P, (agx_u32)k, iv, coverage, maxv_first > 0 ? (agx_u32)maxv_first : AGX_MAXV_LDS, S, nbig);
         GraphView G; G.n_pos = (agx_u32)T.ref.size(); G.n_ids = S.n_ids;
         G.meta = S.a_meta.data(); G.str = S.a_str.data(); G.side_xpos = S.side_xpos.data();
-        G.sp_bits = S.sp_bits.data(); G.sp_rank = S.sp_rank.data(); G.sp_node = S.sp_node.data(); G.n_special = S.n_special;
+        G.sp_bits = S.sp_bits.data(); G.sp_rank = S.sp_rank.data(); G.sp_node = S.sp_node.data(); G.sp_hop = S.sp_hop.data(); G.n_special = S.n_special;
         G.fetch = [](void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *o) {
             for (agx_u32 r = 0; r < rows; r++) for (agx_u32 c = 0; c < width; c++) o[(size_t)r * width + c] = ((SimGraph *)ctx)->a_node.at((size_t)first + (size_t)r * stride + c);
         }; G.fetch_ctx = &S;
