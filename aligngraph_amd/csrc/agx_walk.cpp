@@ -71,17 +71,18 @@ inline agx_u32 run_end_scalar(const agx_u8 *meta, const agx_u8 *done, agx_u32 j,
 #if defined(__x86_64__)
 __attribute__((target("avx2"))) inline agx_u32 run_end_avx2(const agx_u8 *meta, const agx_u8 *done, agx_u32 j, agx_u8 &seen) {
     const __m256i one = _mm256_set1_epi8(1);
-    __m256i acc = _mm256_setzero_si256();
+    unsigned contig = 0;                                                        // lanes (nodes passed) whose AGX_WM_CONTIG bit is set
     for (;;) {
         const __m256i m = _mm256_loadu_si256((const __m256i *)(meta + j)), d = _mm256_loadu_si256((const __m256i *)(done + j + 1));
         // a node lets the run pass iff its cont bit is set and its successor is unvisited
         const __m256i pass = _mm256_andnot_si256(_mm256_cmpeq_epi8(d, one), _mm256_cmpeq_epi8(_mm256_and_si256(m, one), one));
         const unsigned stop = ~(unsigned)_mm256_movemask_epi8(pass);
-        if (stop == 0) { acc = _mm256_or_si256(acc, m); j += 32; continue; }
+        const unsigned cbits = (unsigned)_mm256_movemask_epi8(_mm256_slli_epi16(m, 6));       // bit 1 of every byte -> its sign bit
+        if (stop == 0) { contig |= cbits; j += 32; continue; }
         const unsigned k = (unsigned)__builtin_ctz(stop);                       // the run ends ON node j+k
-        alignas(32) agx_u8 lanes[32]; _mm256_store_si256((__m256i *)lanes, acc);
-        for (int i = 0; i < 32; i++) seen |= lanes[i];
-        for (unsigned i = 0; i <= k; i++) seen |= meta[j + i];
+        contig |= cbits & (k == 31 ? 0xFFFFFFFFu : ((2u << k) - 1u));
+        // the walk only asks whether a node with a contig offset was passed (AG:2004): that is the one bit reported
+        if (contig) seen |= AGX_WM_CONTIG;
         return j + k;
     }
 }
