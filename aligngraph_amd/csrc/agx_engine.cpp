@@ -90,7 +90,9 @@ namespace {
 // event the previous build recorded behind its last kernel, so units built from several host threads run their kernel chains back to
 // back without host round trips in between, and per-kernel HIP-event times stay those of an exclusive device.  Copies to the host
 // (download, record fetches) are not part of the turn and overlap the next unit's kernels.
-struct DeviceTurn { std::mutex m; hipEvent_t last = nullptr; };
+struct DeviceTurn { std::mutex m; hipEvent_t last = nullptr, last_sweeps = nullptr; };
+// AGX_OVERLAP_PREP=1 (experiment): the next unit's sweeps may start while this unit's walk-preparation kernels still run
+static const bool g_overlap_prep = getenv("AGX_OVERLAP_PREP") != nullptr;
 DeviceTurn &turn_of(int device) { static DeviceTurn turns[64]; return turns[device & 63]; }
 
 // AGX_DEBUG_SYNC=1: synchronise after every launch group of a build and name it on stderr — a memory fault then points at its kernel
@@ -188,8 +190,8 @@ void do_build(agx_unit *u) {
 
         DeviceTurn &turn = turn_of(u->prm.device);
         std::unique_lock<std::mutex> my_turn(turn.m);
-        if (turn.last) HIP_OK(hipStreamWaitEvent(st, turn.last, 0));
-        else HIP_OK(hipEventCreateWithFlags(&turn.last, hipEventDisableTiming));
+        if (!turn.last) { HIP_OK(hipEventCreateWithFlags(&turn.last, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&turn.last_sweeps, hipEventDisableTiming)); HIP_OK(hipEventRecord(turn.last, st)); HIP_OK(hipEventRecord(turn.last_sweeps, st)); }
+        HIP_OK(hipStreamWaitEvent(st, g_overlap_prep ? turn.last_sweeps : turn.last, 0));
         HIP_OK(hipMemsetAsync(u->d_words.p, 0, W_N * 4, st));
         HIP_OK(hipMemsetAsync(u->d_tile_cnt.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
         HIP_OK(hipMemsetAsync(u->d_cursor.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
