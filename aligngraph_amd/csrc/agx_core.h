@@ -293,6 +293,7 @@ struct agx_sweep_args {
     agx_u32 *node_start;          // [n_pos]
     agx_u8 *node_cnt;             // [n_pos]
     agx_u8 *pos_succ;             // [n_pos] bit 0: some arrival at x steps to x+1 (written by the node sweep, read by the edge build)
+    agx_u32 *side_cnt;            // [n_pos] surviving variants beyond the first (input of the walk preparation's scan), written with the nodes
     agx_u32 *nk_cid, *nk_coff, *nk_cid0, *nk_coff0, *nk_off0;   // [pool]
     agx_u32 *n_xpos;              // position of each node (the walk follows edges by node id)
     agx_u8 *n_base, *n_flags;     // consensus base ('X' = none: use the reference base, AG:1997-2001), AGX_NF_*
@@ -477,6 +478,7 @@ AGX_HD void agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bu
                                 bool edges, agx_u32 emask, const agx_bucket &bn, agx_u32 nbase, agx_u32 ncnt) {
     if (X >= A.n_pos) return;
     A.node_start[X] = base; A.node_cnt[X] = (agx_u8)cnt; A.pos_succ[X] = (agx_u8)(pflag | (edges ? 0x80u : 0u));
+    agx_u32 alive = 0;
     for (agx_u32 v = 0; v < cnt; v++) {
         const agx_u32 id = base + v;
         const agx_u32 cid = agx_b(b, v, AGX_F_CID), coff = agx_b(b, v, AGX_F_COFF), cov = agx_b(b, v, AGX_F_COV);
@@ -486,7 +488,7 @@ AGX_HD void agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bu
         const agx_u32 va = agx_b(b, v, AGX_F_A), vc = agx_b(b, v, AGX_F_C), vg = agx_b(b, v, AGX_F_G), vt = agx_b(b, v, AGX_F_T), vn = agx_b(b, v, AGX_F_N);
         A.n_base[id] = (agx_u8)agx_consensus(va, vc, vg, vt, vn);
         agx_u8 fl = 0;
-        if (cid == AGX_NONE && (int)cov < A.coverage) fl |= AGX_NF_DEAD;
+        if (cid == AGX_NONE && (int)cov < A.coverage) fl |= AGX_NF_DEAD; else alive++;
         if (coff != AGX_NONE) fl |= AGX_NF_CONTIG;
         A.n_flags[id] = fl;
         agx_sref s; s.slot = agx_b(b, v, AGX_F_S0); s.qlen = agx_b(b, v, AGX_F_S1); A.n_sref[id] = s;
@@ -502,6 +504,7 @@ AGX_HD void agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bu
         for (agx_u32 e = 0; e < AGX_MAXE; e++) A.n_next[(size_t)id * AGX_MAXE + e] = slot[e];
         if (A.n_counts) { int *c = A.n_counts + (size_t)id * 6; c[0] = (int)cov; c[1] = (int)va; c[2] = (int)vc; c[3] = (int)vg; c[4] = (int)vt; c[5] = (int)vn; }
     }
+    A.side_cnt[X] = alive ? alive - 1 : 0;          // walk ids: the first surviving variant takes the position's main id, the others go to the side block
 }
 
 // ---- edge sweep (AG:1589-1623) ---------------------------------------------------------------------------------
@@ -713,7 +716,6 @@ struct agx_compact_args {
     const agx_u32 *node_start; const agx_u8 *node_cnt; const agx_u8 *n_flags; const agx_u8 *n_base; const agx_u32 *n_xpos;
     const agx_u32 *nk_off0; const agx_sref *n_sref; const agx_u32 *n_next; const char *ref;
     agx_u32 n_pos, n_nodes;
-    agx_u32 *side_cnt;             // [n_pos+1] alive variants beyond the first, per position (input of the scan)
     const agx_u32 *side_start;     // [n_pos+1] exclusive scan of side_cnt
     agx_u32 *aid_of;               // [n_nodes] walk id or NONE
     // outputs indexed by aid, [n_pos + n_side]
@@ -727,13 +729,6 @@ struct agx_compact_args {
     const agx_hop *hop; agx_hop *sp_hop;   // per-position hop table (input) and its gather for the special ids
     const agx_u32 *abort;          // device only: the node sweeps' status word (non-zero: the node table is incomplete, the kernels do nothing)
 };
-
-AGX_HD void agx_side_count_pos(const agx_compact_args &A, agx_u32 X) {
-    if (X >= A.n_pos) return;
-    const agx_u32 s = A.node_start[X], n = A.node_cnt[X]; agx_u32 c = 0;
-    for (agx_u32 v = 0; v < n; v++) c += (A.n_flags[s + v] & AGX_NF_DEAD) ? 0u : 1u;
-    A.side_cnt[X] = c ? c - 1 : 0;
-}
 
 // per position, after the scan: walk ids of its nodes; main slots without an alive node are marked absent (= visited from the start)
 AGX_HD void agx_assign_aid_pos(const agx_compact_args &A, agx_u32 X) {

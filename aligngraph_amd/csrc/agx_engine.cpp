@@ -107,7 +107,7 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     S.dhit = u->d_dhit.p; S.runs = u->d_runs.p; S.bases = u->d_bases.p; S.stride = u->P.stride;
     S.tile_off = u->d_tile_off.p; S.tile_hits = u->d_tile_hits.p; S.tile_recs = (decltype(S.tile_recs))u->d_tile_recs.p;
     S.n_pos = (agx_u32)u->T.ref.size(); S.n_tiles = u->n_tiles; S.k = u->prm.k; S.iv = (int)u->prm.insert_variation; S.coverage = (int)u->prm.coverage;
-    S.node_start = u->d_node_start.p; S.node_cnt = u->d_node_cnt.p; S.pos_succ = u->d_pos_succ.p;
+    S.node_start = u->d_node_start.p; S.node_cnt = u->d_node_cnt.p; S.pos_succ = u->d_pos_succ.p; S.side_cnt = u->d_side_cnt.p;
     S.nk_cid = u->d_cid.p; S.nk_coff = u->d_coff.p; S.nk_cid0 = u->d_cid0.p; S.nk_coff0 = u->d_coff0.p; S.nk_off0 = u->d_off0.p;
     S.n_xpos = u->d_xpos.p; S.n_base = u->d_base.p; S.n_flags = u->d_flags.p; S.n_sref = u->d_sref.p; S.n_next = u->d_next.p;
     S.n_counts = (u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? u->d_counts.p : nullptr;
@@ -238,7 +238,7 @@ void do_build(agx_unit *u) {
         agx_compact_args C; memset(&C, 0, sizeof C);
         C.node_start = u->d_node_start.p; C.node_cnt = u->d_node_cnt.p; C.n_flags = u->d_flags.p; C.n_base = u->d_base.p; C.n_xpos = u->d_xpos.p;
         C.nk_off0 = u->d_off0.p; C.n_sref = u->d_sref.p; C.n_next = u->d_next.p; C.ref = u->d_ref.p; C.n_pos = n_pos; C.n_nodes = 0;
-        C.side_cnt = u->d_side_cnt.p; C.side_start = u->d_side_start.p; C.aid_of = u->d_aid_of.p;
+        C.side_start = u->d_side_start.p; C.aid_of = u->d_aid_of.p;
         C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_node = u->d_a_node.p; C.ovf = u->d_ovf.p; C.n_ovf = 0; C.a_ovf = u->d_a_ovf.p;
         HIP_OK(hipEventRecord(u->ev_compact.a, st));
         C.abort = u->d_words.p + W_STATUS;
@@ -247,8 +247,6 @@ void do_build(agx_unit *u) {
         HIP_OK(hipMemsetAsync(u->d_side_cnt.p + n_pos, 0, 4, st));
         HIP_OK(hipMemsetAsync(u->d_a_mark.p, 0, ids_cap + 2, st));
         HIP_OK(hipMemsetAsync(u->d_sp_cnt.p + u->n_words, 0, 4, st));
-        agx_launch_side_count(&C, st);
-        AGX_CHECKPOINT("side_count");
         agx_launch_exclusive_scan(u->d_side_cnt.p, u->d_side_start.p, n_pos, u->d_scan_tmp.p, st);
         agx_launch_mark_list(u->d_chain_end.p, u->n_chain_end, u->d_a_mark.p, st);
         agx_launch_compact(&C, u->d_words.p + W_POOL, u->pool_cap, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);

@@ -42,10 +42,9 @@ void agx_launch_node_sweep_big(const agx_node_kargs *, hipStream_t);
 void agx_launch_edge_sweep(const agx_edge_kargs *, hipStream_t);                   // pass A (lanes = positions)
 void agx_launch_edge_jump(const agx_edge_kargs *, agx_u32 n_hits, hipStream_t);    // pass J (lanes = hits: steps that skip positions)
 void agx_launch_edge_slow(const agx_edge_kargs *, hipStream_t);           // pass B (lanes = hits of the slow positions pass A listed)
-// walk preparation (agx_core.h): per-position side counts; then (after the scan) ids, records and overflow edges
+// walk preparation (agx_core.h): after the scan of the side counts the node sweep left behind: ids, records and overflow edges
 // n_nodes / n_ovf are read from device memory (the node-pool and overflow counters), so no host round trip separates the sweeps
 // from the walk preparation; the grids are sized by the capacities.
-void agx_launch_side_count(const agx_compact_args *, hipStream_t);
 void agx_launch_compact(const agx_compact_args *, const agx_u32 *n_nodes_dev, agx_u32 pool_cap, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t);
 void agx_launch_mark_list(const agx_u32 *list, agx_u32 n, agx_u8 *mark, hipStream_t);
 void agx_launch_special(const agx_compact_args *, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, hipStream_t);

@@ -42,13 +42,15 @@ __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
     A.multi_run[h] = (!(d.flags & AGX_HF_SKIP) && d.a_nruns >= 2) ? 1 : 0;
 }
 
-// ---- exclusive scan of a u32 array (three small kernels; n_tiles is 10^4..10^7) ------------------------------------
-// each block scans 1024 elements (256 threads x 4)
+// ---- exclusive scan of a u32 array (three small kernels up to 16 M elements: blocks, block sums, add) --------------------
+// each block scans AGX_SCAN_BLOCK elements (256 threads x AGX_SCAN_ITEMS)
+#define AGX_SCAN_ITEMS 16
+#define AGX_SCAN_BLOCK (256u * AGX_SCAN_ITEMS)
 __global__ void __launch_bounds__(256) agx_k_scan_blocks(const agx_u32 *in, agx_u32 *out, agx_u32 *block_sums, agx_u32 n) {
     __shared__ agx_u32 sh[256];
-    const agx_u32 base = blockIdx.x * 1024u + threadIdx.x * 4u;
-    agx_u32 v[4], s = 0;
-    for (int i = 0; i < 4; i++) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
+    const agx_u32 base = blockIdx.x * AGX_SCAN_BLOCK + threadIdx.x * AGX_SCAN_ITEMS;
+    agx_u32 v[AGX_SCAN_ITEMS], s = 0;
+    for (int i = 0; i < AGX_SCAN_ITEMS; i++) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
     sh[threadIdx.x] = s;
     __syncthreads();
     for (agx_u32 off = 1; off < 256; off <<= 1) {
@@ -58,12 +60,12 @@ __global__ void __launch_bounds__(256) agx_k_scan_blocks(const agx_u32 *in, agx_
         __syncthreads();
     }
     agx_u32 run = sh[threadIdx.x] - s;      // exclusive prefix of this thread's first element
-    for (int i = 0; i < 4; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
+    for (int i = 0; i < AGX_SCAN_ITEMS; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
     if (threadIdx.x == 255 && block_sums) block_sums[blockIdx.x] = sh[255];
 }
 __global__ void __launch_bounds__(256) agx_k_scan_add(agx_u32 *out, const agx_u32 *block_offsets, agx_u32 n) {
     const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) out[i] += block_offsets[i / 1024u];
+    if (i < n) out[i] += block_offsets[i / AGX_SCAN_BLOCK];
 }
 
 // ---- tile lists: scatter, then rank-sort each list so that hits are applied in SAM order ---------------------------
@@ -274,7 +276,6 @@ __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
 }
 
 // ---- walk preparation: renumber surviving nodes, rewrite edges, mark forced runs (agx_core.h) -------------------------------
-__global__ void __launch_bounds__(256) agx_k_side_count(agx_compact_args A) { AGX_RETURN_IF_ABORTED(A.abort); agx_side_count_pos(A, blockIdx.x * 256u + threadIdx.x); }
 __global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A) { AGX_RETURN_IF_ABORTED(A.abort); agx_assign_aid_pos(A, blockIdx.x * 256u + threadIdx.x); }
 __global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A, const agx_u32 *n_nodes_dev) {
     AGX_RETURN_IF_ABORTED(A.abort);
@@ -323,21 +324,21 @@ void agx_launch_hit_prep(const agx_prep_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_hit_prep, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
 }
 
-// exclusive scan of in[0..n) into out[0..n]; out[n] = total.  tmp must hold ceil(n/1024)+ceil(n/1024^2)+.. + 8 words.
+// exclusive scan of in[0..n) into out[0..n]; out[n] = total.  tmp must hold 2*(ceil(n/4096)+1) + 2*(ceil(n/4096^2)+1) + 8 words (the engine sizes it for blocks of 1024).
 void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u32 *tmp, hipStream_t st) {
     // scan n+1 elements (a trailing zero-extended element gives the total in out[n]); callers allocate in with n+1 entries, in[n]=0
     const agx_u32 m = n + 1;
-    const agx_u32 nb = (m + 1023) / 1024;
+    const agx_u32 nb = (m + AGX_SCAN_BLOCK - 1) / AGX_SCAN_BLOCK;
     if (nb == 1) { hipLaunchKernelGGL(agx_k_scan_blocks, dim3(1), dim3(256), 0, st, in, out, (agx_u32 *)nullptr, m); return; }
     agx_u32 *sums = tmp, *sums_scanned = tmp + nb + 1;
     hipLaunchKernelGGL(agx_k_scan_blocks, dim3(nb), dim3(256), 0, st, in, out, sums, m);
     // scan the block sums (recursively; nb <= 2^22 for 2^32 elements, two levels are enough in practice)
-    const agx_u32 nb2 = (nb + 1023) / 1024;
+    const agx_u32 nb2 = (nb + AGX_SCAN_BLOCK - 1) / AGX_SCAN_BLOCK;
     if (nb2 == 1) hipLaunchKernelGGL(agx_k_scan_blocks, dim3(1), dim3(256), 0, st, sums, sums_scanned, (agx_u32 *)nullptr, nb);
     else {
         agx_u32 *sums2 = sums_scanned + nb + 1, *sums2_scanned = sums2 + nb2 + 1;
         hipLaunchKernelGGL(agx_k_scan_blocks, dim3(nb2), dim3(256), 0, st, sums, sums_scanned, sums2, nb);
-        hipLaunchKernelGGL(agx_k_scan_blocks, dim3(1), dim3(256), 0, st, sums2, sums2_scanned, (agx_u32 *)nullptr, nb2);   // nb2 <= 1024 for n < 2^30
+        hipLaunchKernelGGL(agx_k_scan_blocks, dim3(1), dim3(256), 0, st, sums2, sums2_scanned, (agx_u32 *)nullptr, nb2);   // nb2 <= 4096 for n < 2^32
         hipLaunchKernelGGL(agx_k_scan_add, dim3((nb + 255) / 256), dim3(256), 0, st, sums_scanned, sums2_scanned, nb);
     }
     hipLaunchKernelGGL(agx_k_scan_add, dim3((m + 255) / 256), dim3(256), 0, st, out, sums_scanned, m);
@@ -376,9 +377,6 @@ void agx_launch_edge_slow(const agx_edge_kargs *K, hipStream_t st) {
     if (K->S.n_tiles) hipLaunchKernelGGL(agx_k_edge_slow, dim3((unsigned)blocks), dim3(256), 0, st, *K);
 }
 
-void agx_launch_side_count(const agx_compact_args *A, hipStream_t st) {
-    if (A->n_pos) hipLaunchKernelGGL(agx_k_side_count, dim3((A->n_pos + 255) / 256), dim3(256), 0, st, *A);
-}
 void agx_launch_compact(const agx_compact_args *A, const agx_u32 *n_nodes_dev, agx_u32 pool_cap, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t st) {
     if (A->n_pos) hipLaunchKernelGGL(agx_k_assign_aid, dim3((A->n_pos + 255) / 256), dim3(256), 0, st, *A);
     if (pool_cap) hipLaunchKernelGGL(agx_k_emit_alive, dim3((pool_cap + 255) / 256), dim3(256), 0, st, *A, n_nodes_dev);

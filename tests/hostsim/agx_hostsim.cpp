@@ -57,7 +57,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     std::vector<agx_cmkey> cmk(T.cm.size());
     for (size_t i = 0; i < T.cm.size(); i++) cmk[i] = agx_cmkey{T.cm[i].cid, T.cm[i].coff};
 
-    S.node_start.assign(n_pos, 0); S.node_cnt.assign(n_pos, 0); S.pos_succ.assign(n_pos, 0);
+    S.node_start.assign(n_pos, 0); S.node_cnt.assign(n_pos, 0); S.pos_succ.assign(n_pos, 0); S.side_cnt.assign((size_t)n_pos + 1, 0);
     S.reserve((size_t)n_pos * 2 + 1024);
     agx_sweep_args A; memset(&A, 0, sizeof A);
     std::vector<agx_cmhead> cmh((size_t)n_pos + 1);
@@ -67,7 +67,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     A.tile_off = tile_off.data(); A.tile_hits = tile_hits.data();
     A.n_pos = n_pos; A.n_tiles = n_tiles; A.k = k; A.iv = iv; A.coverage = coverage;
     auto bind = [&]() {
-        A.node_start = S.node_start.data(); A.node_cnt = S.node_cnt.data(); A.pos_succ = S.pos_succ.data();
+        A.node_start = S.node_start.data(); A.node_cnt = S.node_cnt.data(); A.pos_succ = S.pos_succ.data(); A.side_cnt = S.side_cnt.data();
         A.nk_cid = S.cid.data(); A.nk_coff = S.coff.data(); A.nk_cid0 = S.cid0.data(); A.nk_coff0 = S.coff0.data(); A.nk_off0 = S.off0.data();
         A.n_xpos = S.xpos.data(); A.n_base = S.base.data(); A.n_flags = S.flags.data(); A.n_sref = S.sref.data(); A.n_next = S.next.data();
         A.n_counts = S.counts.data(); A.pool_cap = (agx_u32)S.cid.size();
@@ -135,11 +135,10 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
 
     // walk preparation, the same per-element functions the compaction kernels run
     agx_compact_args C; memset(&C, 0, sizeof C);
-    S.side_cnt.assign((size_t)n_pos + 1, 0); S.side_start.assign((size_t)n_pos + 1, 0); S.aid_of.assign((size_t)S.n_nodes + 1, AGX_NONE);
+    S.side_start.assign((size_t)n_pos + 1, 0); S.aid_of.assign((size_t)S.n_nodes + 1, AGX_NONE);      // (side_cnt was written with the nodes)
     C.node_start = S.node_start.data(); C.node_cnt = S.node_cnt.data(); C.n_flags = S.flags.data(); C.n_base = S.base.data(); C.n_xpos = S.xpos.data();
     C.nk_off0 = S.off0.data(); C.n_sref = S.sref.data(); C.n_next = S.next.data(); C.ref = T.ref.data(); C.n_pos = n_pos; C.n_nodes = S.n_nodes;
-    C.side_cnt = S.side_cnt.data(); C.side_start = S.side_start.data(); C.aid_of = S.aid_of.data();
-    for (agx_u32 x = 0; x < n_pos; x++) agx_side_count_pos(C, x);
+    C.side_start = S.side_start.data(); C.aid_of = S.aid_of.data();
     agx_u32 run = 0; for (agx_u32 x = 0; x <= n_pos; x++) { S.side_start[x] = run; run += S.side_cnt[x]; }
     S.n_ids = n_pos + run;
     const size_t na = (size_t)S.n_ids + 1;
