@@ -3,7 +3,7 @@
 TEST INFRASTRUCTURE ONLY — imported by tests/, tests/golden/make_golden.py, bench.py's cpu_baseline
 leg and __graft_entry__.smoke(); never by aligngraph_amd/.
 
-* ``synth(out, **kw)``           run tools/agx_synth (seeded synthetic tmp/ directory)
+* ``synth(out, **kw)``           tools/agx_data.synth (seeded synthetic tmp/ directory; re-exported)
 * ``run_oracle(tmp, unit, ...)`` call oracle/liboracle.so (this repo's restatement) through ctypes
 * ``run_reference(run_dir)``     replay a prepared run directory through oracle/_ref/AlignGraph_ref*
                                  with ``--resume`` (AG:4748-4760) and aligner stubs on PATH
@@ -12,6 +12,7 @@ import ctypes
 import os
 import shutil
 import subprocess
+import sys
 import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -21,41 +22,19 @@ LIBORACLE = os.path.join(HERE, "liboracle.so")
 REF_O0 = os.path.join(HERE, "_ref", "AlignGraph_ref")
 REF_O2 = os.path.join(HERE, "_ref", "AlignGraph_ref_O2")
 STUBS = os.path.join(HERE, "ref_stubs")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import agx_data  # noqa: E402
 
 
 def build():
     """Compile the oracle, the generator and (if /root/reference exists) oracle/_ref."""
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     subprocess.check_call(["make", "-s", "-C", HERE, "all"])
-    src = os.path.join(ROOT, "tools", "agx_synth.cpp")
-    if not os.path.exists(SYNTH) or os.path.getmtime(SYNTH) < os.path.getmtime(src):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", SYNTH, src])
+    agx_data.build()
 
 
-def synth(out, **kw):
-    """kw: seed=1, chroms="50000", pairs=10000, L=100, ... (see tools/agx_synth.cpp Params)."""
-    if not os.path.exists(SYNTH):
-        build()
-    if os.path.exists(out):
-        shutil.rmtree(out)
-    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
-    cmd = [SYNTH, "--out", out]
-    for k, v in kw.items():
-        cmd += ["--" + k.replace("_", "-"), str(v)]
-    subprocess.check_call(cmd)
-    return out
-
-
-def read_meta(run_dir):
-    meta = {"unit_len": []}
-    with open(os.path.join(run_dir, "synth_meta.txt")) as f:
-        for line in f:
-            t = line.split()
-            if t[0] == "unit":
-                meta["unit_len"].append(int(t[3]))
-            else:
-                meta[t[0]] = int(t[1])
-    return meta
+synth = agx_data.synth            # the generator lives in tools/ (it is not part of the checker); kept here for the tests' convenience
+read_meta = agx_data.read_meta
 
 
 class _Result(ctypes.Structure):

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """One-off scale check on the GPU box: a cfg4-sized unit (default 62 M positions, one --part slice of human chr1) with a thin read set,
-engine vs oracle byte for byte, plus timings and device memory.  Usage: python tools/big_check.py [--genome N] [--pairs N]"""
+engine vs oracle byte for byte, plus timings and device memory.  Usage: python tests/tools/big_check.py [--genome N] [--pairs N]"""
 import argparse
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import aligngraph_amd as A  # noqa: E402

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Whole-run comparison on the GPU box: the real reference binary (README build, oracle/_ref/AlignGraph_ref) vs AlignGraph_amd on the same
 synthetic inputs with the deterministic aligner stubs of tests/e2e_stubs/.  Prints both wall times (stages after "(0) Alignment finished"
-for the reference) and checks that every output file is identical.  Usage: python tools/e2e_compare.py [--chroms a,b,..] [--pairs N]"""
+for the reference) and checks that every output file is identical.  Usage: python tests/tools/e2e_compare.py [--chroms a,b,..] [--pairs N]"""
 import argparse
 import filecmp
 import os
@@ -10,7 +10,7 @@ import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import harness as H  # noqa: E402
 

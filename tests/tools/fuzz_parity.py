@@ -3,7 +3,7 @@
 coverage threshold, units), each compared byte for byte (three output files + node/edge tables) between the oracle and
   --engine hostsim : the kernels' per-lane functions on the CPU serial executor (tests/hostsim; no GPU needed), or
   --engine gpu     : the HIP engine through the C-ABI.
-Usage: python tools/fuzz_parity.py [--n 40] [--seed 1] [--engine hostsim|gpu]"""
+Usage: python tests/tools/fuzz_parity.py [--n 40] [--seed 1] [--engine hostsim|gpu]"""
 import argparse
 import os
 import random
@@ -11,7 +11,7 @@ import shutil
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

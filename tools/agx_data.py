@@ -1,0 +1,42 @@
+"""Seeded synthetic inputs: builds and drives tools/agx_synth (writes a reference-style run directory: genome.fa, contigs.fa, tmp/_genome.N.fa,
+tmp/_contigs.fa, tmp/_contigs_genome.N.psl, tmp/_reads.fa, tmp/_reads_genome.N.bowtie, ...).  Plain data generation — nothing here knows
+the algorithm, the oracle or the reference; bench.py, the tests and the tools all get their inputs through it."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SYNTH = os.path.join(ROOT, "build", "agx_synth")
+
+
+def build():
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    src = os.path.join(HERE, "agx_synth.cpp")
+    if not os.path.exists(SYNTH) or os.path.getmtime(SYNTH) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", SYNTH, src])
+
+
+def synth(out, **kw):
+    """kw: seed=1, chroms="50000", pairs=10000, L=100, ... (see tools/agx_synth.cpp Params)."""
+    build()
+    if os.path.exists(out):
+        shutil.rmtree(out)
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+    cmd = [SYNTH, "--out", out]
+    for k, v in kw.items():
+        cmd += ["--" + k.replace("_", "-"), str(v)]
+    subprocess.check_call(cmd)
+    return out
+
+
+def read_meta(run_dir):
+    meta = {"unit_len": []}
+    with open(os.path.join(run_dir, "synth_meta.txt")) as f:
+        for line in f:
+            t = line.split()
+            if t[0] == "unit":
+                meta["unit_len"].append(int(t[3]))
+            else:
+                meta[t[0]] = int(t[1])
+    return meta
