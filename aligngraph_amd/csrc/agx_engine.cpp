@@ -294,6 +294,7 @@ void do_build(agx_unit *u) {
 
 void do_download(agx_unit *u) {
     if (!u->built) do_build(u);
+    HIP_OK(hipSetDevice(u->prm.device));             // the calling thread may never have touched this device
     const double t0 = now_ms();
     const size_t n_pos = u->T.ref.size(), ni = u->n_ids;
     hipStream_t st = u->st;
@@ -500,6 +501,7 @@ int agx_unit_graph(agx_unit *u, agx_graph *g) {
     memset(g, 0, sizeof *g);
     return guarded(u, [&] {
         if (!u->built) do_build(u);
+        HIP_OK(hipSetDevice(u->prm.device));
         HIP_OK(hipStreamSynchronize(u->st));
         const agx_u32 n_pos = (agx_u32)u->T.ref.size(), nn = u->n_nodes;
         std::vector<agx_u32> node_start(n_pos), cid(nn), coff(nn), cid0(nn), coff0(nn), off0(nn), next((size_t)nn * AGX_MAXE); std::vector<agx_u8> node_cnt(n_pos);
