@@ -190,13 +190,6 @@ AGX_HD agx_arrival agx_decode_arrival(const agx_dhit &d, const agx_run *runs, ag
     return a;
 }
 
-// oriented base q of a read stored at `p` with length L (reverseComplement, AG:854-865: only ACGT complemented)
-AGX_HD char agx_base_at(const char *p, agx_u32 L, agx_u32 q, bool rev) {
-    if (!rev) return p[q];
-    const char c = p[L - 1 - q];
-    return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
-}
-
 // ---- hit_prep: orientation, left-mate choice, multi-hit suppression, arrival span (AG:1648-1679) -------------
 
 AGX_HD agx_u32 agx_idx0_pos(const agx_hit &h, const agx_run *runs) {     // positionSets[hit][0] of mate1
@@ -282,9 +275,9 @@ struct agx_sweep_args {
     const char *bases; agx_u32 stride;   // read slot s starts at bases + s*stride
     // tile lists
     const agx_u32 *tile_off;      // [n_tiles+1]
-    const agx_u32 *tile_hits;     // hit ids, ascending inside a tile
 #if defined(__HIPCC__)
-    const uint4 *tile_recs;       // [entries][2] first 32 bytes of dhit[tile_hits[i]] (device only: the kernels' scalar record stream)
+    const uint4 *tile_recs;       // [entries][2] first 32 bytes of the derived record of every list entry, hits in SAM order inside a tile
+                                  // (device only: the kernels' scalar record stream; the test executor reads dhit through its own lists)
 #else
     const void *tile_recs;
 #endif

@@ -62,7 +62,7 @@ struct agx_unit {
     DBuf<agx_u32> d_cm_start; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref;
     DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<char> d_bases;
     // derived
-    DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_hits, d_tile_recs, d_scan_tmp, d_words;   // d_words: counters/status
+    DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_recs, d_scan_tmp, d_words;   // d_words: counters/status
     // node table
     agx_u32 pool_cap = 0, ovf_cap = 0, list_cap = 0;
     DBuf<agx_u32> d_node_start, d_slow_list; DBuf<agx_u8> d_node_cnt, d_pos_succ, d_multi_run;
@@ -105,7 +105,7 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     memset(&S, 0, sizeof S);
     S.cm_start = u->d_cm_start.p; S.cm = u->d_cm.p; S.cm_head = u->d_cm_head.p; S.ref = u->d_ref.p;
     S.dhit = u->d_dhit.p; S.runs = u->d_runs.p; S.bases = u->d_bases.p; S.stride = u->P.stride;
-    S.tile_off = u->d_tile_off.p; S.tile_hits = u->d_tile_hits.p; S.tile_recs = (decltype(S.tile_recs))u->d_tile_recs.p;
+    S.tile_off = u->d_tile_off.p; S.tile_recs = (decltype(S.tile_recs))u->d_tile_recs.p;
     S.n_pos = (agx_u32)u->T.ref.size(); S.n_tiles = u->n_tiles; S.k = u->prm.k; S.iv = (int)u->prm.insert_variation; S.coverage = (int)u->prm.coverage;
     S.node_start = u->d_node_start.p; S.node_cnt = u->d_node_cnt.p; S.pos_succ = u->d_pos_succ.p; S.side_cnt = u->d_side_cnt.p;
     S.nk_cid = u->d_cid.p; S.nk_coff = u->d_coff.p; S.nk_cid0 = u->d_cid0.p; S.nk_coff0 = u->d_coff0.p; S.nk_off0 = u->d_off0.p;
@@ -177,7 +177,7 @@ void do_build(agx_unit *u) {
     u->d_scratch.alloc((size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64);
     for (int attempt = 0;; attempt++) {
         if (attempt > 8) throw Error{E_DEVICE, "build did not converge"};
-        u->d_unsorted.alloc((size_t)u->list_cap + 1); u->d_tile_hits.alloc((size_t)u->list_cap + 1); u->d_tile_recs.alloc(((size_t)u->list_cap + 4) * 8);
+        u->d_unsorted.alloc((size_t)u->list_cap + 1); u->d_tile_recs.alloc(((size_t)u->list_cap + 4) * 8);
         u->d_aid_of.alloc((size_t)u->pool_cap + 1);
         const size_t ids_cap = (size_t)n_pos + u->pool_cap;                       // side variants <= nodes <= pool_cap
         u->d_a_str.alloc(ids_cap + 1); u->d_a_meta.alloc(ids_cap + 16); u->d_a_node.alloc(ids_cap + 1); u->d_a_ovf.alloc((size_t)u->ovf_cap + 1);
@@ -206,7 +206,7 @@ void do_build(agx_unit *u) {
         agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
         agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap};
         agx_launch_bin_fill(&BA, st);
-        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->d_tile_hits.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, st);
+        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, st);
         AGX_CHECKPOINT("tile_sort");
         HIP_OK(hipEventRecord(u->ev_bin.b, st)); u->ev_bin.used = true;
         // ---- node sweep: LDS pass, then the global-scratch pass over whatever tiles overflowed (device-side count) ----
@@ -267,7 +267,7 @@ void do_build(agx_unit *u) {
         if (w[W_ERR] & 1u) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
         if (w[W_ERR] & 2u) throw Error{E_UNSUPPORTED, "read alignment beyond the end of the unit sequence"};
         u->n_tile_entries = w[W_N];
-        if (u->n_tile_entries > u->list_cap) { u->list_cap = u->n_tile_entries + u->n_tile_entries / 8 + 1024; u->d_unsorted.release(); u->d_tile_hits.release(); u->d_tile_recs.release(); continue; }
+        if (u->n_tile_entries > u->list_cap) { u->list_cap = u->n_tile_entries + u->n_tile_entries / 8 + 1024; u->d_unsorted.release(); u->d_tile_recs.release(); continue; }
         if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 64 node variants at one position"};
         const unsigned long long want = w[W_POOL];
         if ((w[W_STATUS] & 1u) || want > u->pool_cap) {

@@ -17,7 +17,7 @@ struct agx_node_kargs {
     agx_u32 *pool_counter;     // next free node id
     agx_u32 *big_count; agx_u32 *big_list;   // tiles whose buckets did not fit in LDS
     agx_u32 *status;           // bit 0: node pool exhausted; bit 1: bucket overflow in the global-scratch pass; bit 2: tile lists too small
-    agx_u32 list_cap;          // capacity of tile_hits: a tile whose list ends beyond it is skipped (the host re-runs with larger lists)
+    agx_u32 list_cap;          // capacity of the tile lists: a tile whose list ends beyond it is skipped (the host re-runs with larger lists)
     const agx_u32 *big_n;      // fallback pass: number of tiles in big_list, read on the device (no host round trip)
     agx_u32 *scratch;          // fallback pass: one [AGX_NF*AGX_MAXV_BIG*64] bucket area per resident wavefront
 };
@@ -36,7 +36,7 @@ void agx_launch_hit_prep(const agx_prep_args *, hipStream_t);
 // exclusive scan of in[0..n] (n+1 entries, in[n] must be 0) into out[0..n]; out[n] = total
 void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u32 *tmp, hipStream_t);
 void agx_launch_bin_fill(const agx_bin_args *, hipStream_t);
-void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, hipStream_t);
+void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, hipStream_t);
 void agx_launch_node_sweep(const agx_node_kargs *, hipStream_t);
 void agx_launch_node_sweep_big(const agx_node_kargs *, hipStream_t);
 void agx_launch_edge_sweep(const agx_edge_kargs *, hipStream_t);                   // pass A (lanes = positions)

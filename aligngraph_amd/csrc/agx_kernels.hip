@@ -79,15 +79,15 @@ __global__ void __launch_bounds__(256) agx_k_bin_fill(agx_bin_args A) {
 
 // one wavefront per tile; hit ids are unique, so an element's rank is the number of smaller elements
 #define AGX_SORT_LDS 2048
-// Besides the sorted hit ids the kernel writes the tile's RECORD list: the first 32 bytes of each hit's derived record, in list order,
-// so that the sweeps read one sequential, wave-uniform stream (scalar loads) instead of chasing list entry -> record.
+// The kernel writes the tile's RECORD list: the first 32 bytes of each listed hit's derived record, in SAM (= hit id) order, so that the
+// sweeps read one sequential, wave-uniform stream (scalar loads) instead of chasing list entry -> record.
 __device__ __forceinline__ void agx_put_rec(uint4 *recs, agx_u32 at, const agx_dhit *dhit, agx_u32 h) {
     const uint4 *src = reinterpret_cast<const uint4 *>(dhit + h);             // agx_dhit is 40 bytes: 8-byte aligned only
     const uint2 *s2 = reinterpret_cast<const uint2 *>(src);
     const uint2 a = s2[0], b = s2[1], c = s2[2], d = s2[3];
     recs[2 * (size_t)at] = make_uint4(a.x, a.y, b.x, b.y); recs[2 * (size_t)at + 1] = make_uint4(c.x, c.y, d.x, d.y);
 }
-__global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap,
+__global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap,
                                                        const agx_dhit *dhit, uint4 *recs) {
     __shared__ agx_u32 sh[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -103,13 +103,13 @@ __global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, 
         for (agx_u32 i = lane; i < n; i += 64) {
             const agx_u32 v = sh[wave][i]; agx_u32 r = 0;
             for (agx_u32 j = 0; j < n; j++) r += sh[wave][j] < v;
-            sorted[lo + r] = v; agx_put_rec(recs, lo + r, dhit, v);
+            agx_put_rec(recs, lo + r, dhit, v);
         }
     } else {                                            // pile-ups larger than the LDS window: same rank sort straight from L2
         for (agx_u32 i = lane; i < n; i += 64) {
             const agx_u32 v = src[i]; agx_u32 r = 0;
             for (agx_u32 j = 0; j < n; j++) r += src[j] < v;
-            sorted[lo + r] = v; agx_put_rec(recs, lo + r, dhit, v);
+            agx_put_rec(recs, lo + r, dhit, v);
         }
     }
 }
@@ -347,8 +347,8 @@ void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u
 void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_bin_fill, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
 }
-void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 *sorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, hipStream_t st) {
-    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, sorted, n_tiles, cap, dhit,
+void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, hipStream_t st) {
+    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, n_tiles, cap, dhit,
                                     (uint4 *)recs);
 }
 void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {

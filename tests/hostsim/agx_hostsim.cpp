@@ -64,7 +64,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     for (agx_u32 x = 0; x < n_pos; x++) agx_cm_head_pos(T.cm_start.data(), cmk.data(), cmh.data(), x);
     A.cm_start = T.cm_start.data(); A.cm = cmk.data(); A.cm_head = cmh.data(); A.ref = T.ref.data();
     A.dhit = dh.data(); A.runs = P.runs.data(); A.bases = P.bases.data(); A.stride = P.stride;
-    A.tile_off = tile_off.data(); A.tile_hits = tile_hits.data();
+    A.tile_off = tile_off.data();
     A.n_pos = n_pos; A.n_tiles = n_tiles; A.k = k; A.iv = iv; A.coverage = coverage;
     auto bind = [&]() {
         A.node_start = S.node_start.data(); A.node_cnt = S.node_cnt.data(); A.pos_succ = S.pos_succ.data(); A.side_cnt = S.side_cnt.data();
