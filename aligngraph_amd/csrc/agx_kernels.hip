@@ -15,6 +15,9 @@
 #include "agx_kargs.h"
 
 #define AGX_WAVES_PER_BLOCK 4
+#ifndef AGX_SWEEP_WAVES
+#define AGX_SWEEP_WAVES 1           // wavefronts per block of the node sweep: tiles differ in length, and a block's LDS is only released when its last wavefront ends
+#endif
 
 // A build queues all its kernels before the host has seen a single counter.  If the node sweeps had to give up (node pool or tile lists too
 // small: the host grows them and repeats the build; a bucket beyond 64 variants: an error) parts of the node table were never written, so
@@ -141,10 +144,10 @@ __device__ __forceinline__ agx_u32 agx_wave_incl_scan(agx_u32 v, agx_u32 lane) {
 }
 
 template <bool BIG>
-__global__ void __launch_bounds__(256) agx_k_node_sweep(agx_node_kargs K) {
-    __shared__ agx_u32 lds[BIG ? 1 : AGX_WAVES_PER_BLOCK][BIG ? 1 : AGX_NF * AGX_MAXV_LDS * 64];
+__global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_node_kargs K) {
+    __shared__ agx_u32 lds[BIG ? 1 : AGX_SWEEP_WAVES][BIG ? 1 : AGX_NF * AGX_MAXV_LDS * 64];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const agx_u32 slot = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
+    const agx_u32 slot = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_SWEEP_WAVES + wave);
     agx_bucket b; b.stride = 64;
     if (BIG) { b.base = K.scratch + (size_t)slot * (AGX_NF * AGX_MAXV_BIG * 64) + lane; b.maxv = AGX_MAXV_BIG; }
     else { b.base = &lds[wave][lane]; b.maxv = AGX_MAXV_LDS; }
@@ -353,10 +356,10 @@ void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_
 }
 void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;
-    if (n) hipLaunchKernelGGL(agx_k_node_sweep<false>, dim3((n + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
+    if (n) hipLaunchKernelGGL(agx_k_node_sweep<false>, dim3((n + AGX_SWEEP_WAVES - 1) / AGX_SWEEP_WAVES), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
 }
 void agx_launch_node_sweep_big(const agx_node_kargs *K, hipStream_t st) {
-    hipLaunchKernelGGL(agx_k_node_sweep<true>, dim3(AGX_BIG_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
+    hipLaunchKernelGGL(agx_k_node_sweep<true>, dim3(AGX_BIG_WAVES / AGX_SWEEP_WAVES), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
 }
 void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_pos;
