@@ -188,6 +188,7 @@ void thread_contigs_from_files(const std::string &contigs_fa, const std::string 
     // updateGenomeWithContig, AG:884-1217 — per-position conti-mer lists kept as index-linked pools while threading
     struct Cell { ContiMer m; int next; };
     std::vector<Cell> pool;
+    { size_t bases = 0; for (const ContigSeq &q : cs) bases += q.nuc.size() * (q.sets.empty() ? 0 : 1); pool.reserve(bases + cs.size() + 16); }     // about one conti-mer per placed contig base
     std::vector<int> head(n_ref, -1), tail(n_ref, -1);
     std::vector<agx_u32> count(n_ref, 0);
     auto push_cm = [&](agx_u32 x, const ContiMer &m) {
