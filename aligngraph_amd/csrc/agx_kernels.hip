@@ -15,8 +15,9 @@
 #include "agx_kargs.h"
 
 #define AGX_WAVES_PER_BLOCK 4
+#define AGX_XCDS 8u                 // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
 #ifndef AGX_SWEEP_WAVES
-#define AGX_SWEEP_WAVES 1           // wavefronts per block of the node sweep: tiles differ in length, and a block's LDS is only released when its last wavefront ends
+#define AGX_SWEEP_WAVES 4           // wavefronts (= consecutive tiles) per block of the node sweep (1, 2, 4 run equally fast; 4 keeps neighbours on one CU)
 #endif
 
 // A build queues all its kernels before the host has seen a single counter.  If the node sweeps had to give up (node pool or tile lists too
@@ -147,7 +148,12 @@ template <bool BIG>
 __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_node_kargs K) {
     __shared__ agx_u32 lds[BIG ? 1 : AGX_SWEEP_WAVES][BIG ? 1 : AGX_NF * AGX_MAXV_LDS * 64];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const agx_u32 slot = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_SWEEP_WAVES + wave);
+    // Workgroups are handed to the 8 XCDs round-robin and every XCD has its own L2.  Neighbouring tiles read the same hit records, read
+    // bases and conti-mer heads, so block b takes the (b / 8)-th block of tiles of XCD (b % 8)'s contiguous share of the unit rather than
+    // tile block b: what one tile pulled into an L2 is there for its neighbours.
+    agx_u32 blk = blockIdx.x;
+    if (!BIG) { const agx_u32 share = (gridDim.x + AGX_XCDS - 1) / AGX_XCDS; blk = (blockIdx.x % AGX_XCDS) * share + blockIdx.x / AGX_XCDS; }
+    const agx_u32 slot = __builtin_amdgcn_readfirstlane(blk * AGX_SWEEP_WAVES + wave);
     agx_bucket b; b.stride = 64;
     if (BIG) { b.base = K.scratch + (size_t)slot * (AGX_NF * AGX_MAXV_BIG * 64) + lane; b.maxv = AGX_MAXV_BIG; }
     else { b.base = &lds[wave][lane]; b.maxv = AGX_MAXV_LDS; }
@@ -356,7 +362,9 @@ void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_
 }
 void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;
-    if (n) hipLaunchKernelGGL(agx_k_node_sweep<false>, dim3((n + AGX_SWEEP_WAVES - 1) / AGX_SWEEP_WAVES), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
+    // a multiple of the XCD count so that every XCD's share has the same number of blocks (blocks past the last tile do nothing)
+    const agx_u32 nb = (n + AGX_SWEEP_WAVES - 1) / AGX_SWEEP_WAVES, grid = (nb + AGX_XCDS - 1) / AGX_XCDS * AGX_XCDS;
+    if (n) hipLaunchKernelGGL(agx_k_node_sweep<false>, dim3(grid), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
 }
 void agx_launch_node_sweep_big(const agx_node_kargs *K, hipStream_t st) {
     hipLaunchKernelGGL(agx_k_node_sweep<true>, dim3(AGX_BIG_WAVES / AGX_SWEEP_WAVES), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
