@@ -17,7 +17,8 @@
 #define AGX_WAVES_PER_BLOCK 4
 #define AGX_XCDS 8u                 // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
 #ifndef AGX_SWEEP_WAVES
-#define AGX_SWEEP_WAVES 4           // wavefronts (= consecutive tiles) per block of the node sweep (1, 2, 4 run equally fast; 4 keeps neighbours on one CU)
+#define AGX_SWEEP_WAVES 1           // wavefronts (= consecutive tiles) per block of the node sweep: measured 0.924 / 0.926 / 0.938 / 1.011 ms for 1 / 2 / 4 / 8
+                                    // (tiles differ in length and a block's LDS is only released when its last wavefront ends)
 #endif
 
 // A build queues all its kernels before the host has seen a single counter.  If the node sweeps had to give up (node pool or tile lists too
