@@ -8,9 +8,12 @@ struct agx_prep_args {
     agx_u32 *tile_cnt;        // [n_tiles] number of hits overlapping each tile
     agx_u32 *err;             // bit 0: same-strand mates; bit 1: alignment beyond the unit sequence
     agx_u8 *multi_run;        // [n_hits] 1: a kept hit whose a mate has several runs (the only hits the edge build's pass J looks at)
+    uint4 *rank4;             // [n_hits] what the histogram's atomicAdd returned for the hit's first four tiles = its slot in each tile's list
+    agx_u32 *rank_overflow;   // set when some hit spans more than four tiles: the lists are then filled with a second round of atomics
 };
 
-struct agx_bin_args { const agx_dhit *dhit; agx_u32 n_hits; const agx_u32 *tile_off; agx_u32 *cursor; agx_u32 *unsorted; agx_u32 cap; };   // cap: entries the lists can hold
+struct agx_bin_args { const agx_dhit *dhit; agx_u32 n_hits; const agx_u32 *tile_off; agx_u32 *cursor; agx_u32 *unsorted; agx_u32 cap;   // cap: entries the lists can hold
+                      const uint4 *rank4; const agx_u32 *rank_overflow; };
 
 struct agx_node_kargs {
     agx_sweep_args S;

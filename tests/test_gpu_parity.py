@@ -48,6 +48,7 @@ CONFIGS = [
     dict(seed=204, chroms="30000,20000", part=2, pairs=10000, coverage=4, L=150, k=21, contig_min=300, contig_max=2000, contig_overlap=0.5,
          contig_dup=0.3, contig_split=0.5, contig_minus=1.0),
     dict(seed=205, chroms="300000", pairs=60000, coverage=5),
+    dict(seed=207, chroms="50000", pairs=4000, coverage=3, L=250, k=11, read_indel=0.3),      # spans of five tiles: the binning's second round of atomics
     # found by tests/tools/fuzz_parity.py: narrow windows (insert_variation 0) on short deep units -> most tiles outgrow LDS and the node pool's
     # first guess (2 x positions) is too small, so the first build gives up half-way and is repeated with a larger pool
     dict(seed=860528, chroms="5551,21059", part=2, pairs=9239, L=36, k=3, coverage=3, insert_variation=0, snp=0.02, indel=0.001, contig_min=2000,
