@@ -213,6 +213,7 @@ void do_build(agx_unit *u) {
         agx_node_kargs K; fill_sweep_args(u, K.S);
         K.pool_counter = u->d_words.p + W_POOL; K.big_count = u->d_words.p + W_BIGCOUNT; K.big_list = u->d_big_list.p; K.status = u->d_words.p + W_STATUS;
         K.list_cap = u->list_cap; K.big_n = u->d_words.p + W_BIGCOUNT; K.scratch = u->d_scratch.p;
+        K.slow_list = u->d_slow_list.p; K.slow_count = u->d_words.p + W_SLOWCOUNT;
         HIP_OK(hipEventRecord(u->ev_node.a, st));
         agx_launch_node_sweep(&K, st);
         AGX_CHECKPOINT("node_sweep");
@@ -223,7 +224,7 @@ void do_build(agx_unit *u) {
         HIP_OK(hipEventRecord(u->ev_big.b, st)); u->ev_big.used = true;
         // ---- edge sweep ----
         agx_edge_kargs E; fill_sweep_args(u, E.S); E.ovf = u->d_ovf.p; E.ovf_count = u->d_words.p + W_OVFCOUNT; E.ovf_cap = u->ovf_cap; E.list_cap = u->list_cap;
-        E.multi_run = u->d_multi_run.p; E.abort = u->d_words.p + W_STATUS; E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
+        E.multi_run = u->d_multi_run.p; E.abort = u->d_words.p + W_STATUS; E.big_list = u->d_big_list.p; E.big_n = u->d_words.p + W_BIGCOUNT; E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
         HIP_OK(hipEventRecord(u->ev_edge.a, st));
         agx_launch_edge_sweep(&E, st);
         AGX_CHECKPOINT("edge_sweep");

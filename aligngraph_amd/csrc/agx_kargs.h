@@ -23,6 +23,7 @@ struct agx_node_kargs {
     agx_u32 list_cap;          // capacity of the tile lists: a tile whose list ends beyond it is skipped (the host re-runs with larger lists)
     const agx_u32 *big_n;      // fallback pass: number of tiles in big_list, read on the device (no host round trip)
     agx_u32 *scratch;          // fallback pass: one [AGX_NF*AGX_MAXV_BIG*64] bucket area per resident wavefront
+    agx_u32 *slow_list; agx_u32 *slow_count;   // the edge build's pass-B list: the sweep itself enters multi-variant positions with a position-skipping step
 };
 
 struct agx_edge_kargs {
@@ -30,6 +31,7 @@ struct agx_edge_kargs {
     agx_u32 *slow_list; agx_u32 *slow_count;   // positions that need the per-hit pass (device-side list)
     const agx_u8 *multi_run;                   // [n_hits] from hit_prep
     const agx_u32 *abort;                      // the node sweeps' status word: non-zero = the node table is incomplete, do nothing
+    const agx_u32 *big_list; const agx_u32 *big_n;   // tiles the fallback pass wrote (their edges are all pass A/B's)
 };
 #define AGX_SLOW_WAVES 8192u    // wavefronts of the per-hit edge pass if the occupancy query fails (normally: as many as are resident at once)
 

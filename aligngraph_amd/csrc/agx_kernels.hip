@@ -15,6 +15,7 @@
 #include "agx_kargs.h"
 
 #define AGX_WAVES_PER_BLOCK 4
+static_assert(AGX_MAXV_LDS <= AGX_EM_W, "the LDS sweep writes the x -> x+1 edges of every position it finishes: its buckets must fit the edge matrix");
 #define AGX_XCDS 8u                 // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
 #ifndef AGX_SWEEP_WAVES
 #define AGX_SWEEP_WAVES 1           // wavefronts (= consecutive tiles) per block of the node sweep: measured 0.924 / 0.926 / 0.938 / 1.011 ms for 1 / 2 / 4 / 8
@@ -201,33 +202,48 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
         agx_bucket bn = b; bn.base = b.base + 1;           // the next position's bucket is the next lane's column
         const bool edges = !BIG && lane < 63u && X + 1 < K.S.n_pos && cnt <= AGX_EM_W && ncnt <= AGX_EM_W;
         agx_node_write_lane(K.S, X, b, cnt, my_base, pflag, edges, emask, bn, nbase, ncnt);
+        // a multi-variant position whose x -> x+1 edges are done but which also steps elsewhere goes through pass B for those steps
+        if (edges && cnt >= 2 && (pflag & 2u)) K.slow_list[atomicAdd(K.slow_count, 1u)] = X;
         if (!BIG) return;
     }
 }
 
 // ---- edge build ---------------------------------------------------------------------------------------------------------
-// pass A: one thread per position (agx_edge_fast_lane), a pure streaming kernel; slow positions are compacted into a list with a
-// wave ballot + one atomicAdd per wavefront
+// pass A (agx_edge_fast_lane) over what the node sweep could not finish: the last position of every tile (thread per tile) and all
+// positions of the tiles the fallback pass wrote (wavefront per tile); slow positions are appended to pass B's list with a wave
+// ballot + one atomicAdd per wavefront
+__device__ __forceinline__ void agx_append_slow(const agx_edge_kargs &K, bool slow, agx_u32 X, agx_u32 lane) {
+    const unsigned long long m = __ballot(slow);
+    if (!m) return;
+    agx_u32 base = 0;
+    if (lane == 0) base = atomicAdd(K.slow_count, (agx_u32)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (slow) K.slow_list[base + (agx_u32)__popcll(m & ((1ull << lane) - 1ull))] = X;
+}
 __global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
     AGX_RETURN_IF_ABORTED(K.abort);
+    const agx_u32 t = blockIdx.x * 256u + threadIdx.x;
+    const agx_u32 X = t * AGX_TILE + (AGX_TILE - 1u);
+    bool slow = false;
+    if (t < K.S.n_tiles && X < K.S.n_pos) {
+        agx_u32 nb_start = 0, nb_cnt = 0;
+        if (X + 1 < K.S.n_pos) { nb_start = K.S.node_start[X + 1]; nb_cnt = K.S.node_cnt[X + 1]; }
+        slow = agx_edge_fast_lane(K.S, X, K.S.node_start[X], K.S.node_cnt[X], nb_start, nb_cnt);
+    }
+    agx_append_slow(K, slow, X, threadIdx.x & 63u);
+}
+__global__ void __launch_bounds__(256) agx_k_edge_bigtiles(agx_edge_kargs K) {
+    AGX_RETURN_IF_ABORTED(K.abort);
     const agx_u32 lane = threadIdx.x & 63u;
-    const agx_u32 X = blockIdx.x * 256u + threadIdx.x;
-    // the node sweep has already written the edges of most positions (bit 7 of pos_succ): those lanes only read that byte
-    const agx_u32 ps = X < K.S.n_pos ? K.S.pos_succ[X] : 0x80u;
-    const bool need = !(ps & 0x80u) || (ps & 2u);
-    agx_u32 own_start = 0, own_cnt = 0;
-    if (need && X < K.S.n_pos) { own_start = K.S.node_start[X]; own_cnt = K.S.node_cnt[X]; }
-    // the neighbour position's bucket header comes from the next lane (a lane that needs it either is the tile's last lane, which reads
-    // it itself, or sits in a tile the fallback pass wrote, where every lane loaded its own)
-    agx_u32 nb_start = __shfl_down(own_start, 1, 64), nb_cnt = __shfl_down(own_cnt, 1, 64);
-    if (lane == 63) { nb_start = 0; nb_cnt = 0; if (X + 1 < K.S.n_pos) { nb_start = K.S.node_start[X + 1]; nb_cnt = K.S.node_cnt[X + 1]; } }
-    const bool slow = need && agx_edge_fast_lane(K.S, X, own_start, own_cnt, nb_start, nb_cnt);
-    const unsigned long long m = __ballot(slow);
-    if (m) {
-        agx_u32 base = 0;
-        if (lane == 0) base = atomicAdd(K.slow_count, (agx_u32)__popcll(m));
-        base = __shfl(base, 0, 64);
-        if (slow) K.slow_list[base + (agx_u32)__popcll(m & ((1ull << lane) - 1ull))] = X;
+    const agx_u32 n = __builtin_amdgcn_readfirstlane((int)*K.big_n);
+    for (agx_u32 w = blockIdx.x * AGX_WAVES_PER_BLOCK + (threadIdx.x >> 6); w < n; w += gridDim.x * AGX_WAVES_PER_BLOCK) {
+        const agx_u32 X = K.big_list[w] * AGX_TILE + lane;
+        agx_u32 own_start = 0, own_cnt = 0;
+        if (X < K.S.n_pos) { own_start = K.S.node_start[X]; own_cnt = K.S.node_cnt[X]; }
+        const agx_u32 nb_start = __shfl_down(own_start, 1, 64), nb_cnt = __shfl_down(own_cnt, 1, 64);
+        // (the tile's last position is agx_k_edge_sweep's)
+        const bool slow = lane < AGX_TILE - 1u && agx_edge_fast_lane(K.S, X, own_start, own_cnt, nb_start, nb_cnt);
+        agx_append_slow(K, slow, X, lane);
     }
 }
 
@@ -382,8 +398,10 @@ void agx_launch_node_sweep_big(const agx_node_kargs *K, hipStream_t st) {
     hipLaunchKernelGGL(agx_k_node_sweep<true>, dim3(AGX_BIG_WAVES / AGX_SWEEP_WAVES), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
 }
 void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
-    const agx_u32 n = K->S.n_pos;
-    if (n) hipLaunchKernelGGL(agx_k_edge_sweep, dim3((n + 255) / 256), dim3(256), 0, st, *K);
+    const agx_u32 n = K->S.n_tiles;
+    if (!n) return;
+    hipLaunchKernelGGL(agx_k_edge_sweep, dim3((n + 255) / 256), dim3(256), 0, st, *K);
+    hipLaunchKernelGGL(agx_k_edge_bigtiles, dim3(AGX_BIG_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
 }
 void agx_launch_edge_jump(const agx_edge_kargs *K, agx_u32 n_hits, hipStream_t st) {
     if (K->S.n_pos && n_hits) hipLaunchKernelGGL(agx_k_edge_jump, dim3((n_hits + 255) / 256), dim3(256), 0, st, *K, n_hits);
