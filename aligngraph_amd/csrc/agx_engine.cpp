@@ -65,7 +65,7 @@ struct agx_unit {
     DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_recs, d_scan_tmp, d_words;   // d_words: counters/status
     // node table
     agx_u32 pool_cap = 0, ovf_cap = 0, list_cap = 0;
-    DBuf<agx_u32> d_node_start, d_slow_list, d_rank4; DBuf<agx_u8> d_node_cnt, d_pos_succ, d_multi_run;
+    DBuf<agx_u32> d_node_start, d_slow_list, d_rank4, d_perm; DBuf<agx_u8> d_node_cnt, d_pos_succ, d_multi_run;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_big_list, d_scratch;
     // walk graph (agx_core.h "walk preparation")
@@ -143,6 +143,19 @@ void do_upload(agx_unit *u) {
     if (!u->P.runs.empty()) HIP_OK(hipMemcpyAsync(u->d_runs.p, u->P.runs.data(), u->P.runs.size() * sizeof(agx_run), hipMemcpyHostToDevice, u->st));
     if (!u->P.bases.empty()) HIP_OK(hipMemcpyAsync(u->d_bases.p, u->P.bases.data(), u->P.bases.size(), hipMemcpyHostToDevice, u->st));
     u->n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
+    {   // hit ids sorted by the tile their left end falls into (counting sort): agx_k_hit_prep walks them in this order so that the hits
+        // of one wavefront share tiles and their histogram atomics can be combined
+        std::vector<agx_u32> first((size_t)u->n_tiles + 1, 0), perm(nh);
+        auto tile_of = [&](const agx_hit &h) -> agx_u32 {
+            const agx_u32 p1 = h.nruns1 ? u->P.runs[h.runs1].t : h.pos1, p2 = h.nruns2 ? u->P.runs[h.runs2].t : h.pos2;
+            return std::min<agx_u32>(std::min(p1, p2) / AGX_TILE, u->n_tiles - 1);
+        };
+        for (size_t i = 0; i < nh; i++) first[tile_of(u->P.hits[i]) + 1]++;
+        for (size_t t = 0; t < u->n_tiles; t++) first[t + 1] += first[t];
+        for (size_t i = 0; i < nh; i++) perm[first[tile_of(u->P.hits[i])]++] = (agx_u32)i;
+        u->d_perm.alloc(nh + 1);
+        if (nh) HIP_OK(hipMemcpy(u->d_perm.p, perm.data(), nh * 4, hipMemcpyHostToDevice));
+    }
     u->d_tile_cnt.alloc((size_t)u->n_tiles + 1); u->d_tile_off.alloc((size_t)u->n_tiles + 2); u->d_cursor.alloc((size_t)u->n_tiles + 1);
     const size_t nb = ((size_t)n_pos + 1 + 1023) / 1024;              // sized for the longer of the two scans (positions)
     u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16);
@@ -197,7 +210,7 @@ void do_build(agx_unit *u) {
         HIP_OK(hipMemsetAsync(u->d_cursor.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
         // ---- hit_prep + tile histogram ----
         HIP_OK(hipEventRecord(u->ev_prep.a, st));
-        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, u->d_multi_run.p, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
+        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_perm.p, u->d_tile_cnt.p, u->d_words.p + W_ERR, u->d_multi_run.p, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
         agx_launch_hit_prep(&PA, st);
         AGX_CHECKPOINT("hit_prep");
         HIP_OK(hipEventRecord(u->ev_prep.b, st)); u->ev_prep.used = true;

@@ -5,6 +5,7 @@
 
 struct agx_prep_args {
     const agx_hit *hits; const agx_run *runs; agx_dhit *dhit; agx_u32 n_hits, k, n_pos;
+    const agx_u32 *perm;      // [n_hits] hit ids sorted by the tile of their left end (upload time)
     agx_u32 *tile_cnt;        // [n_tiles] number of hits overlapping each tile
     agx_u32 *err;             // bit 0: same-strand mates; bit 1: alignment beyond the unit sequence
     agx_u8 *multi_run;        // [n_hits] 1: a kept hit whose a mate has several runs (the only hits the edge build's pass J looks at)

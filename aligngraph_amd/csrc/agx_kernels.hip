@@ -34,25 +34,47 @@ __global__ void __launch_bounds__(256) agx_k_cm_head(const agx_u32 *cm_start, co
 }
 
 // ---- hit_prep: one thread per hit -------------------------------------------------------------------------------
+// Threads take the hits in the order of `perm` (upload time: hits sorted by the tile their left end falls into), so the 64 hits of a
+// wavefront fall into a handful of tiles.  Device-scope atomics are the expensive part of binning on this chip (8 L2s: they are resolved
+// behind them): the wavefront adds up its hits per tile and issues ONE atomicAdd per distinct tile, and what that returns is also each
+// hit's slot in the tile's list, so that bin_fill scatters without atomics.
 __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
-    const agx_u32 h = blockIdx.x * 256u + threadIdx.x;
-    if (h >= A.n_hits) return;
-    agx_dhit d;
-    const int rc = agx_hit_prep(A.hits, A.runs, h, A.k, d);
-    if (rc) atomicOr(A.err, 1u);
-    if (!(d.flags & AGX_HF_SKIP)) {
-        if (d.x_hi >= A.n_pos || d.x_lo > d.x_hi) { atomicOr(A.err, 2u); d.flags |= AGX_HF_SKIP; }
-        else {
-            // Device-scope atomics are the expensive part of binning on this chip (8 L2s: they are resolved behind them), so the histogram's
-            // atomicAdd doubles as the hit's slot in each tile's list: bin_fill then scatters without a second round of atomics.
-            agx_u32 r[4] = {0, 0, 0, 0}; agx_u32 i = 0;
-            for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++, i++) { const agx_u32 at = atomicAdd(&A.tile_cnt[t], 1u); if (i < 4) r[i] = at; }
-            if (i > 4) atomicOr(A.rank_overflow, 1u);
-            A.rank4[h] = make_uint4(r[0], r[1], r[2], r[3]);
+    const agx_u32 i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool mine = i < A.n_hits;
+    const agx_u32 h = mine ? A.perm[i] : 0u;
+    agx_dhit d; d.flags = AGX_HF_SKIP; d.x_lo = 1; d.x_hi = 0; d.a_nruns = 0;
+    if (mine) {
+        const int rc = agx_hit_prep(A.hits, A.runs, h, A.k, d);
+        if (rc) atomicOr(A.err, 1u);
+        if (!(d.flags & AGX_HF_SKIP) && (d.x_hi >= A.n_pos || d.x_lo > d.x_hi)) { atomicOr(A.err, 2u); d.flags |= AGX_HF_SKIP; }
+    }
+    const bool kept = mine && !(d.flags & AGX_HF_SKIP);
+    const agx_u32 t0 = kept ? d.x_lo / AGX_TILE : 0u, t1 = kept ? d.x_hi / AGX_TILE : 0u;
+    agx_u32 r[4] = {0, 0, 0, 0};
+    for (agx_u32 s = 0; s < 4; s++) {                                        // the hit's s-th tile
+        const agx_u32 t = t0 + s;
+        bool pending = kept && t <= t1;
+        for (;;) {                                                           // one round per distinct tile among the wavefront's pending lanes
+            const unsigned long long m = __ballot(pending);
+            if (!m) break;
+            const int leader = __builtin_ctzll(m);
+            const agx_u32 tl = (agx_u32)__shfl((int)t, leader, 64);
+            const bool same = pending && t == tl;
+            const unsigned long long ms = __ballot(same);
+            agx_u32 base = 0;
+            if ((int)lane == leader) base = atomicAdd(&A.tile_cnt[tl], (agx_u32)__popcll(ms));
+            base = (agx_u32)__shfl((int)base, leader, 64);
+            if (same) { r[s] = base + (agx_u32)__popcll(ms & ((1ull << lane) - 1ull)); pending = false; }
         }
     }
+    if (kept && t1 - t0 >= 4) {                                              // spans more than four tiles: count the rest, and tell bin_fill to take its own slots
+        for (agx_u32 t = t0 + 4; t <= t1; t++) atomicAdd(&A.tile_cnt[t], 1u);
+        atomicOr(A.rank_overflow, 1u);
+    }
+    if (!mine) return;
+    A.rank4[h] = make_uint4(r[0], r[1], r[2], r[3]);
     A.dhit[h] = d;
-    A.multi_run[h] = (!(d.flags & AGX_HF_SKIP) && d.a_nruns >= 2) ? 1 : 0;
+    A.multi_run[h] = (kept && d.a_nruns >= 2) ? 1 : 0;
 }
 
 // ---- exclusive scan of a u32 array (three small kernels up to 16 M elements: blocks, block sums, add) --------------------
