@@ -720,6 +720,7 @@ struct agx_compact_args {
     agx_u32 n_ids, sparse_min;     // sparse_min (test hook): only the side ids are special, every other record comes through the fetch path
     unsigned long long *sp_bits; agx_u32 *sp_cnt; const agx_u32 *sp_rank; agx_walknode *sp_node;
     const agx_hop *hop; agx_hop *sp_hop;   // per-position hop table (input) and its gather for the special ids
+    agx_u32 sp_cap;                        // records the sparse table can hold (the host grows it and repeats the build if there are more)
     const agx_u32 *abort;          // device only: the node sweeps' status word (non-zero: the node table is incomplete, the kernels do nothing)
 };
 

@@ -64,7 +64,7 @@ struct agx_unit {
     // derived
     DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_recs, d_scan_tmp, d_words;   // d_words: counters/status
     // node table
-    agx_u32 pool_cap = 0, ovf_cap = 0, list_cap = 0;
+    agx_u32 pool_cap = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
     DBuf<agx_u32> d_node_start, d_slow_list, d_rank4, d_perm; DBuf<agx_u8> d_node_cnt, d_pos_succ, d_multi_run;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_big_list, d_scratch;
@@ -169,8 +169,11 @@ void do_upload(agx_unit *u) {
         if (!ce.empty()) HIP_OK(hipMemcpy(u->d_chain_end.p, ce.data(), ce.size() * 4, hipMemcpyHostToDevice));
     }
     u->d_node_start.alloc(n_pos); u->d_node_cnt.alloc(n_pos); u->d_pos_succ.alloc(n_pos); u->d_slow_list.alloc(n_pos + 64);
-    if (u->pool_cap == 0) alloc_pool(u, (agx_u32)std::min<size_t>(2 * n_pos + 4096, 0xFFFFFF00ull));
-    if (u->ovf_cap == 0) { u->ovf_cap = 1u << 16; u->d_ovf.alloc(u->ovf_cap); }
+    // first guesses; every one of them is grown from the device-side counters if a build proves it too small (first build of a unit only).
+    // AGX_TEST_SMALL_CAPS (tests) starts them absurdly small so that every regrow path runs.
+    const bool tiny = getenv("AGX_TEST_SMALL_CAPS") != nullptr;
+    if (u->pool_cap == 0) alloc_pool(u, (agx_u32)std::min<size_t>(tiny ? n_pos / 8 + 64 : n_pos + n_pos / 4 + 4096, 0xFFFFFF00ull));
+    if (u->ovf_cap == 0) { u->ovf_cap = tiny ? 4u : 1u << 16; u->d_ovf.alloc(u->ovf_cap); }
     HIP_OK(hipStreamSynchronize(u->st));
     u->uploaded = true; u->built = false; u->downloaded = false;
     u->stats.ms_upload = now_ms() - t0;
@@ -185,7 +188,7 @@ void do_build(agx_unit *u) {
     const agx_u32 n_pos = (agx_u32)u->T.ref.size(), nh = (agx_u32)u->P.hits.size();
     hipStream_t st = u->st;
     u->stats.node_sweep_launches = u->stats.edge_sweep_launches = 0;
-    if (u->list_cap == 0) u->list_cap = (agx_u32)std::min<size_t>((size_t)nh * 3 + 1024, 0xFFFFFF00ull);
+    if (u->list_cap == 0) u->list_cap = (agx_u32)std::min<size_t>(getenv("AGX_TEST_SMALL_CAPS") ? (size_t)nh / 2 + 16 : (size_t)nh * 3 + 1024, 0xFFFFFF00ull);
     u->d_big_list.alloc((size_t)u->n_tiles + 1);
     u->d_scratch.alloc((size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64);
     for (int attempt = 0;; attempt++) {
@@ -196,7 +199,9 @@ void do_build(agx_unit *u) {
         u->d_a_str.alloc(ids_cap + 1); u->d_a_meta.alloc(ids_cap + 16); u->d_a_node.alloc(ids_cap + 1); u->d_a_ovf.alloc((size_t)u->ovf_cap + 1);
         u->d_side_cnt.alloc((size_t)n_pos + 2); u->d_side_start.alloc((size_t)n_pos + 2);
         u->n_words = (agx_u32)(ids_cap / 64 + 1);
-        u->d_a_mark.alloc(ids_cap + 2); u->d_side_xpos.alloc((size_t)u->pool_cap + 1); u->d_sp_node.alloc(ids_cap + 1); u->d_sp_hop.alloc(ids_cap + 1);
+        u->d_a_mark.alloc(ids_cap + 2); u->d_side_xpos.alloc((size_t)u->pool_cap + 1);
+        if (u->sp_cap == 0) u->sp_cap = (agx_u32)std::min<size_t>(getenv("AGX_TEST_SMALL_CAPS") ? 32 : ids_cap / 4 + 4096, 0xFFFFFF00ull);      // special ids: 8 % on the bench unit
+        u->d_sp_node.alloc((size_t)u->sp_cap + 1); u->d_sp_hop.alloc((size_t)u->sp_cap + 1);
         u->d_sp_bits.alloc((size_t)u->n_words + 1); u->d_sp_cnt.alloc((size_t)u->n_words + 1); u->d_sp_rank.alloc((size_t)u->n_words + 2);
         {   const size_t nb = ((size_t)std::max<size_t>(n_pos, u->n_words) + 1 + 1023) / 1024;
             u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16); }
@@ -257,7 +262,7 @@ void do_build(agx_unit *u) {
         HIP_OK(hipEventRecord(u->ev_compact.a, st));
         C.abort = u->d_words.p + W_STATUS;
         C.a_mark = u->d_a_mark.p; C.side_xpos = u->d_side_xpos.p; C.sparse_min = (u->prm.flags & AGX_FLAG_SPARSE_MIN) ? 1u : 0u;
-        C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p; C.hop = u->d_hop.p; C.sp_hop = u->d_sp_hop.p;
+        C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p; C.hop = u->d_hop.p; C.sp_hop = u->d_sp_hop.p; C.sp_cap = u->sp_cap;
         HIP_OK(hipMemsetAsync(u->d_side_cnt.p + n_pos, 0, 4, st));
         HIP_OK(hipMemsetAsync(u->d_a_mark.p, 0, ids_cap + 2, st));
         HIP_OK(hipMemsetAsync(u->d_sp_cnt.p + u->n_words, 0, 4, st));
@@ -290,7 +295,7 @@ void do_build(agx_unit *u) {
             u->d_cid.release(); u->d_coff.release(); u->d_cid0.release(); u->d_coff0.release(); u->d_off0.release(); u->d_xpos.release();
             u->d_next.release(); u->d_base.release(); u->d_flags.release(); u->d_sref.release(); u->d_counts.release();
             u->d_aid_of.release(); u->d_a_str.release(); u->d_a_meta.release(); u->d_a_node.release();
-            u->d_a_mark.release(); u->d_side_xpos.release(); u->d_sp_node.release(); u->d_sp_hop.release(); u->d_sp_bits.release(); u->d_sp_cnt.release(); u->d_sp_rank.release();
+            u->d_a_mark.release(); u->d_side_xpos.release(); u->d_sp_bits.release(); u->d_sp_cnt.release(); u->d_sp_rank.release();
             alloc_pool(u, (agx_u32)cap);
             continue;
         }
@@ -298,6 +303,7 @@ void do_build(agx_unit *u) {
         u->n_nodes = (agx_u32)want; u->n_big = w[W_BIGCOUNT]; u->n_ovf = w[W_OVFCOUNT];
         const unsigned long long ids = (unsigned long long)n_pos + w[W_N + 1];
         if (ids >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "walk graph exceeds 2^32 ids"};
+        if (w[W_N + 2] > u->sp_cap) { u->sp_cap = w[W_N + 2] + w[W_N + 2] / 8 + 1024; u->d_sp_node.release(); u->d_sp_hop.release(); continue; }
         u->n_ids = (agx_u32)ids; u->n_special = w[W_N + 2];
         break;
     }

@@ -368,6 +368,7 @@ __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, ag
     const agx_u32 lane = threadIdx.x & 63u;
     if ((bits >> lane) & 1ull) {
         const agx_u32 at = A.sp_rank[w] + (agx_u32)__popcll(bits & ((1ull << lane) - 1ull));
+        if (at >= A.sp_cap) return;                                           // table too small: the host sees the count and repeats the build
         A.sp_node[at] = A.a_node[a];
         A.sp_hop[at] = A.hop[a < A.n_pos ? a : A.side_xpos[a - A.n_pos]];
     }

@@ -89,6 +89,22 @@ def test_sparse_record_table_and_device_fetch(agx, built, tmp_path):
     assert gs["download_bytes"] < 8 * gs["n_walk_ids"]                 # was 40 bytes per id with the dense record table
 
 
+def test_every_capacity_regrows_from_the_device_counters(agx, built, tmp_path, monkeypatch):
+    # A build queues all its kernels against first-guess capacities (tile lists, node pool, edge overflow list, sparse record table) and
+    # only then reads the counters; AGX_TEST_SMALL_CAPS starts every one of them far too small, so the build has to be repeated once per
+    # capacity — and the kernels behind a sweep that gave up must not touch the half-written node table.
+    run = H.synth(str(tmp_path / "run"), seed=208, chroms="60000", pairs=20000, coverage=4, insert_variation=10, frag_sd=150, contig_overlap=0.4, sam_seq=0)
+    meta = H.read_meta(run)
+    tmp = os.path.join(run, "tmp")
+    o = H.run_oracle(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"], graph=True)
+    monkeypatch.setenv("AGX_TEST_SMALL_CAPS", "1")
+    g = run_engine(agx, tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"], graph=True)
+    assert graph_mismatch(o["graph"], g["graph"]) is None
+    for key in ("initial", "pre", "extended"):
+        assert o[key] == g[key], key
+    assert g["stats"]["n_edge_overflow"] > 4            # the overflow list really outgrew its first guess
+
+
 def test_run_unit_writes_the_three_files(agx, built, tmp_path):
     run = H.synth(str(tmp_path / "run"), seed=31, chroms="20000", pairs=5000, coverage=5, sam_seq=0)
     tmp = os.path.join(run, "tmp")
