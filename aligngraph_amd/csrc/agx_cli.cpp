@@ -12,6 +12,7 @@
 // Everything here is text plumbing around the path; the compute is agx_run_unit's (include/agx.h).
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -687,6 +688,14 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
     const int per_dev = std::max(1, getenv("AGX_UNITS_PER_DEVICE") ? atoi(getenv("AGX_UNITS_PER_DEVICE")) : 4);   // >1: the text parsing and host walk of one unit overlap the kernels of others
     // every unit reads tmp/_reads.fa (AG:1880): map and index it once for all of them
     agx_reads *reads = nullptr; { char err[512]; if (agx_reads_open("tmp/_reads.fa", &reads, err, sizeof err) != AGX_OK) reads = nullptr; }   // (a missing file is reported by the first unit, as before)
+    // Units of very different sizes share a device: each is admitted only while the estimated HBM footprints of the units in flight
+    // stay below 85 % of the device's memory (a unit larger than that still runs, alone).  Estimate: ~260 B per reference position (node
+    // pool, walk graph, conti-mer tables at their first-guess capacities) + ~2 B per byte of the unit's SAM file (hits, tile records, read
+    // bases) + 256 MB.
+    auto file_bytes = [](const string &p) -> double { struct stat st; return stat(p.c_str(), &st) == 0 ? (double)st.st_size : 0.0; };
+    vector<double> budget(ndev, 0.0), used(ndev, 0.0);
+    for (int d = 0; d < ndev; d++) { uint64_t fr = 0, tot = 0; budget[d] = agx_device_memory(d, &fr, &tot) == AGX_OK ? 0.85 * (double)tot : 1e18; }
+    std::mutex mem_mu; std::condition_variable mem_cv;
     std::atomic<int> next(first);
     vector<int> state(units, 0); vector<string> errors(units);
     std::mutex mu; int reported = first;
@@ -706,10 +715,14 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
             for (;;) {
                 const int u = next.fetch_add(1);
                 if (u >= units) return;
+                const double est = 260.0 * file_bytes("tmp/_genome." + itoa(u) + ".fa") + 2.0 * file_bytes("tmp/_reads_genome." + itoa(u) + ".bowtie") + 256e6;
+                { std::unique_lock<std::mutex> g(mem_mu); mem_cv.wait(g, [&] { return used[d] == 0.0 || used[d] + est <= budget[d]; }); used[d] += est; }
                 agx_params p = {(uint32_t)o.k, (uint32_t)o.insertVariation, (uint32_t)o.coverage, 0, d, 0};
                 agx_result r; char err[512];
                 const int rc = agx_run_unit_shared(&p, "tmp", u, 1, reads, &r, err, sizeof err);
                 if (rc == AGX_OK) agx_result_free(&r);
+                { std::lock_guard<std::mutex> g(mem_mu); used[d] -= est; if (used[d] < 1.0) used[d] = 0.0; }
+                mem_cv.notify_all();
                 std::lock_guard<std::mutex> g(mu);
                 if (rc != AGX_OK) { string m = err; const size_t cut = m.find(" ("); errors[u] = cut == string::npos ? m : m.substr(0, cut); state[u] = -1; }
                 else state[u] = 1;

@@ -388,6 +388,14 @@ const char *agx_version(void) { return "aligngraph_amd 0.1 (gfx950)"; }
 
 int agx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
+int agx_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    size_t f = 0, t = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) return AGX_E_DEVICE;
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return AGX_OK;
+}
+
 int agx_unit_create(const agx_params *p, agx_unit **out) {
     if (!p || !out) return AGX_E_ARG;
     *out = nullptr;
