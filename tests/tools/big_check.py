@@ -28,14 +28,12 @@ with A.Unit(k=5, insert_variation=50, coverage=a.coverage) as u:
     t = time.time(); u.build(); t_b2 = time.time() - t
     t = time.time(); got = u.finish(); t_f = time.time() - t
     st = u.stats()
+    import ctypes
+    fr, tot = ctypes.c_uint64(), ctypes.c_uint64()
+    A.lib().agx_device_memory(0, ctypes.byref(fr), ctypes.byref(tot))
+    print("device memory in use with the unit resident: %.1f GB of %.0f GB (%.0f B per position)" % ((tot.value - fr.value) / 2**30, tot.value / 2**30, (tot.value - fr.value) / st["n_pos"]))
 print("load %.2fs upload %.2fs first build %.3fs rebuild %.3fs download+walk %.3fs" % (t_load, t_up, t_b1, t_b2, t_f))
 print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()})
-try:
-    import torch
-    free, total = torch.cuda.mem_get_info()
-    print("device memory in use after the unit was freed: %.1f GB of %.0f GB" % ((total - free) / 2**30, total / 2**30))
-except Exception as e:
-    print("mem info unavailable", e)
 if not a.no_oracle:
     t = time.time(); want = H.run_oracle(tmp, 0, 5, 50, a.coverage); print("oracle %.1fs" % (time.time() - t))
     for k in ("initial", "pre", "extended"):
