@@ -15,11 +15,13 @@
 #include "agx_host.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
 #include <memory>
+#include <thread>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -356,31 +358,23 @@ void load_pairs_from_files(const std::string &reads_fa, const std::string &sam_p
     // A reads file of exactly m*B pairs is followed by one EMPTY batch (lo = N) in which every alignment is skipped (AG:1258).
     long long lo = 0, hi = std::min<long long>(B, N) - 1;
     bool final_batch = hi == N - 1 && N % B != 0;
-    LineReader in(sf.p, sf.n); const char *s; size_t n;
-    Mate m1, m2; agx_u32 prev_id = 0; bool any = false; agx_u32 back = 0;
-    for (;;) {
-        if (!in.next(s, n)) break;
-        if (s[0] == '@') continue;
-        const size_t mark = P.runs.size();
-        parse_sam_line(s, n, m1, P.runs);
-        if (!in.next(s, n)) throw Error{E_FORMAT, "BROKEN BOWTIE FILE"};
-        parse_sam_line(s, n, m2, P.runs);
+    agx_u32 prev_id = 0; bool any = false; agx_u32 back = 0;
+    // one parsed line pair -> at most one kept hit.  m.run0 indexes `src`.  Returns false when the final batch is over (AG:1259).
+    auto consume = [&](const Mate &m1, const Mate &m2, const agx_run *src) -> bool {
         P.n_sam_pairs++;
         const long long id = (long long)m1.id;
         if (id < lo) {
-            P.runs.resize(mark);
-            if (lo > hi) continue;                           // the empty last batch skips everything
+            if (lo > hi) return true;                            // the empty last batch skips everything
             throw Error{E_UNSUPPORTED, "SAM is not sorted by read id (bowtie2 --reorder output expected)"};
         }
-        if (id > hi) {                                       // AG:1259: this line pair is consumed and lost; the next batch begins
-            P.runs.resize(mark);
-            if (final_batch) break;
+        if (id > hi) {                                           // AG:1259: this line pair is consumed and lost; the next batch begins
+            if (final_batch) return false;
             lo = hi + 1; hi = std::min<long long>(lo + B, N) - 1;
             final_batch = lo == N || (hi == N - 1 && N % B != 0);
-            continue;
+            return true;
         }
         const bool keep = m1.aligned && m2.aligned && passes(m1) && passes(m2);
-        if (!keep) { P.runs.resize(mark); continue; }
+        if (!keep) return true;
         if (m1.id != m2.id) throw Error{E_UNSUPPORTED, "SAM mates of one pair are not on adjacent lines"};
         if (any && m1.id < prev_id) throw Error{E_UNSUPPORTED, "SAM is not sorted by read id (bowtie2 --reorder output expected)"};
         back = (any && m1.id == prev_id) ? back + 1 : 0;
@@ -390,26 +384,105 @@ void load_pairs_from_files(const std::string &reads_fa, const std::string &sam_p
         h.slot1 = m1.id;                                       // read id for now; turned into a slot in pass 2
         h.len = 0; h.rev1 = (agx_u8)m1.fr; h.rev2 = (agx_u8)m2.fr; h.back = (agx_u8)back;
         auto fill = [&](const Mate &m, agx_u32 &pos, agx_u32 &r0, agx_u16 &nr) {
-            // "simple" = a single M run that covers the whole read
-            if (m.nruns == 1 && P.runs[m.run0].q == 0 && P.runs[m.run0].n == m.total) { pos = P.runs[m.run0].t; r0 = 0; nr = 0; }
-            else { pos = 0; r0 = (agx_u32)m.run0; nr = (agx_u16)m.nruns; if (m.nruns > 60000) throw Error{E_UNSUPPORTED, "CIGAR with too many runs"}; }
+            // "simple" = a single M run that covers the whole read; only the runs of non-simple mates go to the pool, contiguous per mate
+            if (m.nruns == 1 && src[m.run0].q == 0 && src[m.run0].n == m.total) { pos = src[m.run0].t; r0 = 0; nr = 0; return; }
+            if (m.nruns > 60000) throw Error{E_UNSUPPORTED, "CIGAR with too many runs"};
+            pos = 0; r0 = (agx_u32)P.runs.size(); nr = (agx_u16)m.nruns;
+            P.runs.insert(P.runs.end(), src + m.run0, src + m.run0 + m.nruns);
+            for (agx_u32 i = 1; i < nr; i++)                     // runs must advance on the reference (SAM guarantees it)
+                if (P.runs[r0 + i].t < P.runs[r0 + i - 1].t + P.runs[r0 + i - 1].n) throw Error{E_UNSUPPORTED, "alignment runs do not advance on the reference"};
         };
         fill(m1, h.pos1, h.runs1, h.nruns1); fill(m2, h.pos2, h.runs2, h.nruns2);
-        // drop the runs of simple mates from the pool (keeps it small); non-simple runs must stay contiguous per mate
-        if (h.nruns1 == 0 && h.nruns2 == 0) P.runs.resize(mark);
-        else if (h.nruns1 == 0) {           // mate1 simple, mate2 not: move mate2's runs down
-            for (agx_u32 i = 0; i < m2.nruns; i++) P.runs[mark + i] = P.runs[m2.run0 + i];
-            h.runs2 = (agx_u32)mark; P.runs.resize(mark + m2.nruns);
-        } else if (h.nruns2 == 0) P.runs.resize(m1.run0 + m1.nruns);
-        for (int w = 0; w < 2; w++) {       // runs must advance on the reference (SAM guarantees it)
-            const agx_u32 r0 = w ? h.runs2 : h.runs1, nr = w ? h.nruns2 : h.nruns1;
-            for (agx_u32 i = 1; i < nr; i++) if (P.runs[r0 + i].t < P.runs[r0 + i - 1].t + P.runs[r0 + i - 1].n) throw Error{E_UNSUPPORTED, "alignment runs do not advance on the reference"};
-        }
         if (m1.total != m2.total) throw Error{E_UNSUPPORTED, "mates of one pair have different CIGAR lengths"};
         if (m1.total > 65000) throw Error{E_UNSUPPORTED, "read longer than 65000"};
         h.len = (agx_u16)m1.total;
         P.hits.push_back(h);
         hit_id.push_back(m1.id);
+        return true;
+    };
+
+    // Parsing the text (field splitting, CIGAR walk) is the expensive part and independent per line pair; the rules above are cheap but
+    // sequential.  Large, clean files (no '@' lines, no empty line before the end) are therefore cut into byte ranges aligned to line
+    // pairs, parsed on several threads into per-range buffers and consumed in order.  Anything else takes the one-thread path below.
+    struct Range { const char *lo = nullptr, *hi = nullptr; size_t lines = 0; bool odd = false, at = false, empty = false;
+                   std::vector<std::pair<Mate, Mate> > pairs; std::vector<agx_run> runs; bool broken = false, failed = false; Error err{0, ""}; };
+    unsigned threads = 1;
+    if (const char *e = getenv("AGX_LOAD_THREADS")) threads = (unsigned)std::min(64, std::max(1, atoi(e)));      // tests force the multi-thread path on small files
+    else threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), sf.n / (4u << 20) + 1);
+    bool parallel_done = false;
+    if (threads > 1 && sf.n > 0) {
+        std::vector<Range> R(threads);
+        const char *fb = sf.p, *fe = sf.p + sf.n;
+        auto line_start_at_or_after = [&](const char *c) -> const char * {       // first line start >= c
+            if (c <= fb) return fb;
+            const char *nl = (const char *)memchr(c - 1, '\n', (size_t)(fe - (c - 1)));
+            return nl ? nl + 1 : fe;
+        };
+        for (unsigned t = 0; t < threads; t++) R[t].lo = line_start_at_or_after(fb + sf.n / threads * t);
+        for (unsigned t = 0; t < threads; t++) R[t].hi = t + 1 < threads ? R[t + 1].lo : fe;
+        auto for_all = [&](auto fn) { std::vector<std::thread> th; for (unsigned t = 1; t < threads; t++) th.emplace_back(fn, t); fn(0u); for (auto &x : th) x.join(); };
+        const bool lt = getenv("AGX_LOAD_TIMING") != nullptr; auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }; const double ta = tnow();
+        for_all([&](unsigned t) {                                               // phase A: lines per range; anything that needs the one-thread path
+            Range &r = R[t];
+            for (const char *c = r.lo; c < r.hi;) {
+                const char *nl = (const char *)memchr(c, '\n', (size_t)(fe - c));
+                if (nl == c) { r.empty = true; return; }
+                if (*c == '@') { r.at = true; return; }
+                r.lines++;
+                if (!nl) break;
+                c = nl + 1;
+            }
+        });
+        const double tb = tnow();
+        bool clean = true; size_t before = 0;
+        for (Range &r : R) { clean &= !r.at && !r.empty; r.odd = (before & 1) != 0; before += r.lines; }
+        if (clean) {
+            for_all([&](unsigned t) {                                           // phase B: parse the pairs that START in this range
+                Range &r = R[t];
+                auto next = [&](const char *&c, const char *&ls, size_t &ln) -> bool {
+                    if (c >= fe) return false;
+                    const char *nl = (const char *)memchr(c, '\n', (size_t)(fe - c));
+                    ls = c; ln = (size_t)((nl ? nl : fe) - c); c = nl ? nl + 1 : fe;
+                    return true;
+                };
+                const char *c = r.lo, *ls = r.lo; size_t ln = 0;
+                if (r.odd && !next(c, ls, ln)) return;                          // the previous range's last pair ends with this range's first line
+                r.pairs.reserve(r.lines / 2 + 1);
+                try {
+                    while (c < r.hi) {
+                        std::pair<Mate, Mate> pr;
+                        next(c, ls, ln); parse_sam_line(ls, ln, pr.first, r.runs);
+                        if (!next(c, ls, ln)) { r.broken = true; return; }
+                        parse_sam_line(ls, ln, pr.second, r.runs);
+                        r.pairs.push_back(pr);
+                    }
+                } catch (const Error &e) { r.failed = true; r.err = e; }
+            });
+            const double tc = tnow();
+            bool go = true;
+            for (Range &r : R) {                                                // phase C: the sequential rules, in file order
+                for (const auto &pr : r.pairs) if (go && !consume(pr.first, pr.second, r.runs.data())) go = false;
+                if (!go) break;
+                if (r.failed) throw r.err;                                      // the line pair after the last parsed one could not be parsed
+                if (r.broken) throw Error{E_FORMAT, "BROKEN BOWTIE FILE"};
+                std::vector<std::pair<Mate, Mate> >().swap(r.pairs); std::vector<agx_run>().swap(r.runs);
+            }
+            parallel_done = true;
+            if (lt) fprintf(stderr, "[agx load] SAM on %u threads: line count %.1f ms, parse %.1f ms, rules %.1f ms\n", threads, tb - ta, tc - tb, tnow() - tc);
+        }
+    }
+    if (!parallel_done) {
+        LineReader in(sf.p, sf.n); const char *s; size_t n;
+        Mate m1, m2; std::vector<agx_run> tmp;
+        for (;;) {
+            if (!in.next(s, n)) break;
+            if (s[0] == '@') continue;
+            tmp.clear();
+            parse_sam_line(s, n, m1, tmp);
+            if (!in.next(s, n)) throw Error{E_FORMAT, "BROKEN BOWTIE FILE"};
+            parse_sam_line(s, n, m2, tmp);
+            if (!consume(m1, m2, tmp.data())) break;
+        }
     }
     P.n_kept = P.hits.size();
 

@@ -14,7 +14,7 @@ DEPS = SRC + [os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_core.h"), os.pat
 def build():
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in DEPS):
         return
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-fPIC", "-shared", "-o", LIB] + SRC)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-fPIC", "-shared", "-pthread", "-o", LIB] + SRC)
 
 
 class _Result(ctypes.Structure):

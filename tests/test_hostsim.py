@@ -91,6 +91,33 @@ def test_shared_reads_index_loads_the_same_pairs(built, tmp_path, monkeypatch):
         assert again["extended"] == plain[0]["extended"] and again["pre"] == plain[0]["pre"]
 
 
+@pytest.mark.parametrize("threads", [2, 3, 7])
+def test_multi_thread_sam_parsing_is_the_one_thread_loader(built, tmp_path, monkeypatch, threads):
+    # large SAM files are cut into line-pair-aligned byte ranges and parsed on several threads (agx_host.cpp); forced here on small files,
+    # with multi-hit pairs, unaligned pairs, CIGARs with several runs and a shrunk BATCH, against the one-thread path
+    run = H.synth(str(tmp_path / "run"), seed=109, chroms="15000,9000", pairs=5000, coverage=3, multi=0.3, unaligned=0.2, read_indel=0.4, read_clip=0.2, sam_seq=0)
+    meta = H.read_meta(run)
+    tmp = os.path.join(run, "tmp")
+    for u in range(meta["units"]):
+        for batch in (1000000, 900):
+            monkeypatch.setenv("AGX_LOAD_THREADS", "1")
+            one = sim.run(tmp, u, meta["k"], meta["insert_variation"], meta["coverage"], batch=batch, graph=True)
+            monkeypatch.setenv("AGX_LOAD_THREADS", str(threads))
+            many = sim.run(tmp, u, meta["k"], meta["insert_variation"], meta["coverage"], batch=batch, graph=True)
+            assert graph_mismatch(one["graph"], many["graph"]) is None
+            for key in ("initial", "pre", "extended"):
+                assert one[key] == many[key], key
+    # an odd number of lines is reported when its place in the file is reached, whichever thread found it
+    sam = os.path.join(tmp, "_reads_genome.0.bowtie")
+    lines = open(sam).read().split("\n")
+    open(sam, "w").write("\n".join(lines[:len(lines) // 2 | 1]) + "\n")
+    for t in ("1", str(threads)):
+        monkeypatch.setenv("AGX_LOAD_THREADS", t)
+        with pytest.raises(sim.SimError) as e:
+            sim.run(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
+        assert "BROKEN BOWTIE FILE" in e.value.msg
+
+
 def test_batch_boundary_drops_first_pair_of_next_batch(built, tmp_path):
     # AG:1258-1259 with BATCH shrunk to 500 pairs: oracle and engine loaders must lose the same line pairs
     run = H.synth(str(tmp_path / "run"), seed=7, chroms="8000", pairs=2300, coverage=3, multi=0.3, sam_seq=0)

@@ -9,7 +9,7 @@ import agx_data as D
 run=D.synth('/tmp/wp_run', seed=1000, chroms="4600000", pairs=1000000, coverage=5)
 from hostsim import sim
 # profile build of the serial executor
-subprocess.check_call(["g++","-O2","-std=c++17","-fPIC","-shared","-DAGX_WALK_PROF","-o",sim.LIB]+sim.SRC)
+subprocess.check_call(["g++","-O2","-std=c++17","-fPIC","-shared","-pthread","-DAGX_WALK_PROF","-o",sim.LIB]+sim.SRC)
 os.environ['AGX_WALK_REPEAT']='6'; os.environ['AGX_WALK_TIMING']='1'
 sim.run(run+'/tmp',0,5,50,5)
 PY
