@@ -309,21 +309,69 @@ inline bool passes(const Mate &m) {
 // loadReadAlignment's parsing half: batches of `batch` pairs (AG:37, 361-404), SAM line pairs (AG:1233-1277)
 // One pass over tmp/_reads.fa: where every line pair (header, sequence) starts, up to the first empty line (which ends the file for
 // the reference's getline loops), and how many header lines there are (what decides the batch boundaries, AG:361-404).
+unsigned loader_threads(size_t bytes) {
+    if (const char *e = getenv("AGX_LOAD_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(e)));      // tests force the multi-thread paths on small files
+    return (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), bytes / (4u << 20) + 1);
+}
+template <class F> void on_threads(unsigned threads, F fn) {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < threads; t++) th.emplace_back(fn, t);
+    fn(0u);
+    for (auto &x : th) x.join();
+}
+
 struct ReadsIndex {
     FileView fv;
     std::vector<uint64_t> rec_off;              // offset of the first line of record r (a record = two lines)
     unsigned long long headers = 0;
     explicit ReadsIndex(const std::string &path) : fv(path) {
-        const char *b = fv.p, *c = b, *e = b + fv.n;
-        unsigned long long line = 0;
-        while (c < e) {
-            const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
-            if (nl == c) break;                  // empty line
-            if (*c == '>') headers++;
-            if ((line & 1ull) == 0) rec_off.push_back((uint64_t)(c - b));
-            line++;
-            if (!nl) break;
-            c = nl + 1;
+        const char *b = fv.p, *e = b + fv.n;
+        const unsigned threads = loader_threads(fv.n);
+        bool done = false;
+        if (threads > 1 && fv.n) {                // byte ranges cut at line starts; a file with an empty line takes the one-thread scan
+            struct Range { const char *lo, *hi; size_t lines = 0, heads = 0; bool empty = false; };
+            std::vector<Range> R(threads);
+            auto line_start = [&](const char *c) -> const char * { if (c <= b) return b; const char *nl = (const char *)memchr(c - 1, '\n', (size_t)(e - (c - 1))); return nl ? nl + 1 : e; };
+            for (unsigned t = 0; t < threads; t++) R[t].lo = line_start(b + fv.n / threads * t);
+            for (unsigned t = 0; t < threads; t++) R[t].hi = t + 1 < threads ? R[t + 1].lo : e;
+            on_threads(threads, [&](unsigned t) {
+                Range &r = R[t];
+                for (const char *c = r.lo; c < r.hi;) {
+                    const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+                    if (nl == c) { r.empty = true; return; }
+                    r.heads += *c == '>'; r.lines++;
+                    if (!nl) break;
+                    c = nl + 1;
+                }
+            });
+            bool clean = true; size_t total = 0;
+            std::vector<size_t> before(threads, 0);
+            for (unsigned t = 0; t < threads; t++) { clean &= !R[t].empty; before[t] = total; total += R[t].lines; headers += R[t].heads; }
+            if (clean) {
+                rec_off.assign((total + 1) / 2, 0);
+                on_threads(threads, [&](unsigned t) {
+                    size_t line = before[t];
+                    for (const char *c = R[t].lo; c < R[t].hi; line++) {
+                        if ((line & 1) == 0) rec_off[line / 2] = (uint64_t)(c - b);
+                        const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+                        if (!nl) break;
+                        c = nl + 1;
+                    }
+                });
+                done = true;
+            } else headers = 0;
+        }
+        if (!done) {
+            const char *c = b; unsigned long long line = 0;
+            while (c < e) {
+                const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+                if (nl == c) break;                  // empty line
+                if (*c == '>') headers++;
+                if ((line & 1ull) == 0) rec_off.push_back((uint64_t)(c - b));
+                line++;
+                if (!nl) break;
+                c = nl + 1;
+            }
         }
         if (fv.mapped) madvise((void *)fv.p, fv.n, MADV_RANDOM);
     }
@@ -333,25 +381,15 @@ void reads_index_close(ReadsIndex *r) { delete r; }
 
 void load_pairs_from_files(const std::string &reads_fa, const std::string &sam_path, long batch, agx_u32 k, Pairs &P, const ReadsIndex *reads) {
     P = Pairs();
-    std::unique_ptr<FileView> own_rf(reads ? nullptr : new FileView(reads_fa));
-    const FileView &rf = reads ? reads->fv : *own_rf;
+    std::unique_ptr<ReadsIndex> own_reads(reads ? nullptr : new ReadsIndex(reads_fa));       // no shared index: build one for this unit
+    if (!reads) reads = own_reads.get();
+    const FileView &rf = reads->fv;
     FileView sf(sam_path);
     if (batch <= 0) batch = 1000000;
 
     // ---- pass 1 over the SAM: kept hits, in order, with the batch-boundary rule applied ----------------
     std::vector<agx_u32> hit_id;                 // read id per kept hit
-    {
-        // number of pairs in the reads file decides where the last batch ends: count header lines
-        unsigned long long headers = reads ? reads->headers : 0;
-        for (const char *c = rf.p, *e = rf.p + rf.n; !reads && c < e;) {
-            if (*c == '>') headers++;
-            const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
-            if (!nl) break;
-            if (nl == c) break;                  // empty line ends the file for the reference
-            c = nl + 1;
-        }
-        P.n_pairs_in_file = headers / 2;
-    }
+    P.n_pairs_in_file = reads->headers / 2;      // decides where the last batch ends: header lines up to the first empty line
     const long long N = (long long)P.n_pairs_in_file, B = batch;
     if (N == 0) throw Error{E_FORMAT, "reads file holds no pairs"};
     // batch n loads pairs [lo, hi]; `final_batch` = loadSeq reached the end of the reads file while loading it (AG:397).
@@ -407,8 +445,7 @@ void load_pairs_from_files(const std::string &reads_fa, const std::string &sam_p
     struct Range { const char *lo = nullptr, *hi = nullptr; size_t lines = 0; bool odd = false, at = false, empty = false;
                    std::vector<std::pair<Mate, Mate> > pairs; std::vector<agx_run> runs; bool broken = false, failed = false; Error err{0, ""}; };
     unsigned threads = 1;
-    if (const char *e = getenv("AGX_LOAD_THREADS")) threads = (unsigned)std::min(64, std::max(1, atoi(e)));      // tests force the multi-thread path on small files
-    else threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), sf.n / (4u << 20) + 1);
+    threads = loader_threads(sf.n);
     bool parallel_done = false;
     if (threads > 1 && sf.n > 0) {
         std::vector<Range> R(threads);
@@ -420,7 +457,7 @@ void load_pairs_from_files(const std::string &reads_fa, const std::string &sam_p
         };
         for (unsigned t = 0; t < threads; t++) R[t].lo = line_start_at_or_after(fb + sf.n / threads * t);
         for (unsigned t = 0; t < threads; t++) R[t].hi = t + 1 < threads ? R[t + 1].lo : fe;
-        auto for_all = [&](auto fn) { std::vector<std::thread> th; for (unsigned t = 1; t < threads; t++) th.emplace_back(fn, t); fn(0u); for (auto &x : th) x.join(); };
+        auto for_all = [&](auto fn) { on_threads(threads, fn); };
         const bool lt = getenv("AGX_LOAD_TIMING") != nullptr; auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }; const double ta = tnow();
         for_all([&](unsigned t) {                                               // phase A: lines per range; anything that needs the one-thread path
             Range &r = R[t];
@@ -496,37 +533,39 @@ void load_pairs_from_files(const std::string &reads_fa, const std::string &sam_p
     size_t n_ids = 0; { agx_u32 last = 0; for (size_t i = 0; i < hit_id.size(); i++) if (i == 0 || hit_id[i] != last) { n_ids++; last = hit_id[i]; } }
     P.n_slots = (agx_u32)(2 * n_ids);
     P.bases.assign((size_t)P.n_slots * P.stride, 'N');
-    const char *c = rf.p, *e = rf.p + rf.n;
-    unsigned long long rec = 0;                 // record index in the reads file: record 2i, 2i+1 = mates of pair i
-    size_t hi_idx = 0; agx_u32 slot = 0;
-    auto next_line = [&](const char *&ls, size_t &ln) -> bool {
-        if (c >= e) return false;
-        const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
-        const char *le = nl ? nl : e; ls = c; ln = (size_t)(le - c); c = nl ? nl + 1 : e;
-        return ln != 0;
-    };
-    while (hi_idx < P.hits.size()) {
-        const agx_u32 want = hit_id[hi_idx];
-        const char *ls; size_t ln;
-        // skip to record 2*want
-        if (reads && rec < 2ull * want) {
-            if (2ull * want >= reads->rec_off.size()) throw Error{E_FORMAT, "reads file ends before a read named by the SAM"};
-            c = rf.p + reads->rec_off[2ull * want]; rec = 2ull * want;
-        }
-        while (rec < 2ull * want) { if (!next_line(ls, ln) || !next_line(ls, ln)) throw Error{E_FORMAT, "reads file ends before a read named by the SAM"}; rec++; }
-        for (int mate = 0; mate < 2; mate++) {
-            if (!next_line(ls, ln) || ls[0] != '>') throw Error{E_FORMAT, "reads file: header expected"};
-            if (!next_line(ls, ln)) throw Error{E_FORMAT, "reads file: sequence expected"};
-            rec++;
-            if (ln > P.stride || ln != P.hits[hi_idx].len) throw Error{E_UNSUPPORTED, "CIGAR length differs from the read length"};
-            memcpy(&P.bases[(size_t)(slot + mate) * P.stride], ls, ln);
-        }
-        while (hi_idx < P.hits.size() && hit_id[hi_idx] == want) {
-            if (P.hits[hi_idx].len != P.hits[hi_idx - P.hits[hi_idx].back].len) throw Error{E_UNSUPPORTED, "hits of one pair disagree on the read length"};
-            P.hits[hi_idx].slot1 = slot; hi_idx++;
-        }
-        slot += 2;
+    // slots in hit order (sequential, cheap), then the bases of every slot through the record index (independent per slot)
+    struct Slot { agx_u32 id; agx_u32 len; };
+    std::vector<Slot> slots; slots.reserve(n_ids);
+    for (size_t i = 0; i < P.hits.size(); i++) {
+        if (i == 0 || hit_id[i] != hit_id[i - 1]) slots.push_back(Slot{hit_id[i], P.hits[i].len});
+        if (P.hits[i].len != P.hits[i - P.hits[i].back].len) throw Error{E_UNSUPPORTED, "hits of one pair disagree on the read length"};
+        P.hits[i].slot1 = (agx_u32)(2 * (slots.size() - 1));
     }
+    const char *fb = rf.p, *fe = rf.p + rf.n;
+    const unsigned copy_threads = loader_threads(slots.size() * 64);
+    std::vector<size_t> bad(copy_threads, (size_t)-1); std::vector<Error> bad_err(copy_threads, Error{0, ""});
+    on_threads(copy_threads, [&](unsigned t) {
+        const size_t s0 = slots.size() * t / copy_threads, s1 = slots.size() * (t + 1) / copy_threads;
+        for (size_t si = s0; si < s1; si++) {
+            const unsigned long long r0 = 2ull * slots[si].id;
+            try {
+                if (r0 >= reads->rec_off.size()) throw Error{E_FORMAT, "reads file ends before a read named by the SAM"};
+                for (int mate = 0; mate < 2; mate++) {
+                    if (r0 + mate >= reads->rec_off.size()) throw Error{E_FORMAT, "reads file: header expected"};
+                    const char *c = fb + reads->rec_off[r0 + mate];
+                    if (c >= fe || *c != '>') throw Error{E_FORMAT, "reads file: header expected"};
+                    const char *nl = (const char *)memchr(c, '\n', (size_t)(fe - c));
+                    if (!nl || nl + 1 >= fe) throw Error{E_FORMAT, "reads file: sequence expected"};
+                    const char *ls = nl + 1, *nl2 = (const char *)memchr(ls, '\n', (size_t)(fe - ls));
+                    const size_t ln = (size_t)((nl2 ? nl2 : fe) - ls);
+                    if (ln == 0) throw Error{E_FORMAT, "reads file: sequence expected"};
+                    if (ln > P.stride || ln != slots[si].len) throw Error{E_UNSUPPORTED, "CIGAR length differs from the read length"};
+                    memcpy(&P.bases[(2 * si + (size_t)mate) * P.stride], ls, ln);
+                }
+            } catch (const Error &e) { bad[t] = si; bad_err[t] = e; return; }
+        }
+    });
+    for (unsigned t = 0; t < copy_threads; t++) if (bad[t] != (size_t)-1) throw bad_err[t];      // ranges are in slot order: the first failure in file order
 }
 
 }  // namespace agx

@@ -116,6 +116,17 @@ def test_multi_thread_sam_parsing_is_the_one_thread_loader(built, tmp_path, monk
         with pytest.raises(sim.SimError) as e:
             sim.run(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
         assert "BROKEN BOWTIE FILE" in e.value.msg
+    # the reads file is indexed and copied on the same threads: reads that are not as long as their CIGAR says are the same error either way
+    reads = os.path.join(tmp, "_reads.fa")
+    rl = open(reads).read().split("\n")
+    open(reads, "w").write("\n".join(x[:-1] if i > len(rl) // 2 and i % 2 else x for i, x in enumerate(rl)))
+    msgs = []
+    for t in ("1", str(threads)):
+        monkeypatch.setenv("AGX_LOAD_THREADS", t)
+        with pytest.raises(sim.SimError) as e:
+            sim.run(tmp, 1, meta["k"], meta["insert_variation"], meta["coverage"])
+        msgs.append(e.value.msg)
+    assert msgs[0] == msgs[1] and "CIGAR length differs from the read length" in msgs[0]
 
 
 def test_batch_boundary_drops_first_pair_of_next_batch(built, tmp_path):
