@@ -255,8 +255,10 @@ AGX_HD int agx_hit_prep(const agx_hit *hits, const agx_run *runs, agx_u32 h, agx
     return 0;
 }
 
-// conti-mer head of position x (upload-time kernel / test executor)
-AGX_HD void agx_cm_head_pos(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 x) {
+// conti-mer head of position x (upload-time kernel / test executor).  The table has n_pos + 1 entries: entry n_pos is the head of "no
+// position" (no conti-mers), which the node sweep loads for an arrival without a mate position instead of selecting afterwards.
+AGX_HD void agx_cm_head_pos(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 x, agx_u32 n_pos) {
+    if (x == n_pos) { head[x] = agx_cmhead{AGX_NONE, AGX_NONE, 0u, 0u}; return; }
     const agx_u32 s = cm_start[x], n = cm_start[x + 1] - s;
     head[x] = n ? agx_cmhead{cm[s].cid, cm[s].coff, n, s} : agx_cmhead{AGX_NONE, AGX_NONE, 0u, s};
 }
@@ -267,12 +269,12 @@ struct agx_sweep_args {
     // static graph inputs
     const agx_u32 *cm_start;      // [n_pos+1] conti-mers of position x are cm[cm_start[x] .. cm_start[x+1])
     const agx_cmkey *cm;
-    const agx_cmhead *cm_head;    // [n_pos]
+    const agx_cmhead *cm_head;    // [n_pos + 1], the last one empty (agx_cm_head_pos)
     const char *ref;              // [n_pos] reference base per position (incl. appended positions)
     // reads
     const agx_dhit *dhit;
     const agx_run *runs;
-    const char *bases; agx_u32 stride;   // read slot s starts at bases + s*stride
+    const agx_u8 *vcodes; agx_u32 stride; // vote codes (agx_vote_code) of the read bases: read slot s starts at vcodes + s*stride
     // tile lists
     const agx_u32 *tile_off;      // [n_tiles+1]
 #if defined(__HIPCC__)
@@ -305,6 +307,9 @@ AGX_HD agx_u32 agx_vote_field(agx_u32 c, bool rev) {
     const agx_u32 f = (((AGX_F_A) | (AGX_F_C << 4) | (AGX_F_T << 8) | (AGX_F_G << 12)) >> ((idx ^ (rev ? 2u : 0u)) * 4u)) & 0xFu;
     return acgt ? f : (agx_u32)AGX_F_N;
 }
+// The sweeps read the read bases as vote codes: low nibble = the field a forward-strand read votes for with this character, high nibble
+// = the field a reverse-strand read votes for.  The device copy of the read-base blob is translated once per upload.
+AGX_HD agx_u8 agx_vote_code(agx_u32 c) { return (agx_u8)(agx_vote_field(c, false) | (agx_vote_field(c, true) << 4)); }
 
 // first compatible variant or append (AG:1375-1390 / 1493-1506).  Returns the index, or NONE when the bucket is full.
 AGX_HD agx_u32 agx_match_or_insert(const agx_bucket &b, agx_u32 &cnt, const agx_key &key, int iv, bool is_k1, agx_u32 s0, agx_u32 s1) {
@@ -344,7 +349,7 @@ AGX_HD void agx_for_candidates(const agx_sweep_args &A, agx_u32 cx_s, agx_u32 cx
 struct agx_pre {
     agx_u32 has, type, p0, step1, jump;    // arrival present at this position; AGX_AT_*; mate position; its successor is position+1 / some other position
     agx_cmhead h; agx_u32 mate;            // conti-mer head of the mate position as loaded (position 0 if there is no mate), mate present
-    agx_u32 s0, s1, cbyte, rev;            // k-mer string reference of this arrival; stored character of its base and the read's strand
+    agx_u32 s0, s1, cbyte, rev;            // k-mer string reference of this arrival; vote code of its base (agx_vote_code) and the read's strand
 };
 
 // Straight-line on purpose (no lane-varying branch, the two loads are issued for every lane with clamped indices): the number of
@@ -362,15 +367,26 @@ AGX_HD void agx_arrival_fetch(const agx_sweep_args &A, const agx_dhit &d, agx_u3
     const agx_u32 stored = rev ? (agx_u32)d.len - 1u - a.q : a.q;                 // index of the arrival's base in the stored read
     p.s1 = (a.slen ? stored : 0u) | (a.slen << 16) | (rev ? 0x80000000u : 0u);
     p.mate = (has && a.p0 != AGX_NONE) ? 1u : 0u;
-    p.h = A.cm_head[p.mate ? a.p0 : 0u];                                           // no mate: position 0, discarded by apply()
-    p.cbyte = (agx_u8)A.bases[(size_t)d.a_slot * A.stride + ((has && a.type == AGX_AT_K1) ? stored : 0u)];
+    p.h = A.cm_head[p.mate ? a.p0 : A.n_pos];                                      // no mate: the empty head
+    p.cbyte = A.vcodes[(size_t)d.a_slot * A.stride + ((has && a.type == AGX_AT_K1) ? stored : 0u)];
 }
+
+// x -> x+1 edges of one hit, accumulated per position as a bit matrix: bit v*AGX_EM_W + w = variant v here has an edge to variant w of the
+// next position.  Only kept for buckets of up to AGX_EM_W variants (the LDS sweep); larger buckets leave their edges to the edge passes.
+#define AGX_EM_W 4u
+// variant bit v of vm moved to bit v*AGX_EM_W
+AGX_HD agx_u32 agx_edge_spread(agx_u32 vm) {
+    return (vm & 1u) | ((vm & 2u) << (AGX_EM_W - 1u)) | ((vm & 4u) << (2u * AGX_EM_W - 2u)) | ((vm & 8u) << (3u * AGX_EM_W - 3u));
+}
+// sp = agx_edge_spread of the variants the hit touched here if it steps to position+1, else 0; vm_next = the variants it touched there.
+// sp times the row (< 2^AGX_EM_W, so the partial products cannot overlap) puts a copy of the row at every touched variant.
+AGX_HD void agx_edge_merge(agx_u32 &emask, agx_u32 sp, agx_u32 vm_next) { emask |= sp * (vm_next & ((1u << AGX_EM_W) - 1u)); }
 
 // The whole in-order sweep of one position.  get(i) returns the derived hit record of tile-list entry i (the kernels stage 64
 // records at a time across the lanes of the wavefront and broadcast them; the test executor reads memory directly).
 // Returns false if the bucket overflowed (the tile is then re-run with a larger bucket).
-// exch(vm, step1) is called once per hit by every lane, in lockstep on the device: vm = the variants this hit's arrival touched at this
-// position (bit v), step1 = the hit steps from here to position+1.  It is how the sweep hands the x -> x+1 edges to agx_edge_merge:
+// exch(vm, sp) is called once per hit by every lane, in lockstep on the device: vm = the variants this hit's arrival touched at this
+// position (bit v), sp = the same set in agx_edge_spread form if the hit steps from here to position+1, else 0.  It is how the sweep hands the x -> x+1 edges to agx_edge_merge:
 // an event's k2 half at x+1 is the same hit's arrival there, so the edge set of x is the union over hits of (variants at x) x (variants
 // at x+1) — known as soon as both lanes have applied the hit.
 template <bool LDS_ADD, class GET, class EXCH>
@@ -400,28 +416,33 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
             }
         }
     };
-    // The common case — one candidate key, compatible with variant 0 — is straight-line code without a lane-varying branch: the
-    // five key words of variant 0 are read unconditionally, the verdict is integer arithmetic, and the two counter updates are LDS
-    // adds of 0 or 1 (agx_bucket_add: ds_add_u32 in the LDS pass).  Only lanes that need another variant, an insert or several
-    // candidate keys enter slow().
+    // The common case — one candidate key, compatible with variant 0 — is straight-line code without a lane-varying branch and without
+    // a read of the bucket.  A variant's key never changes once it is stored, so the lane keeps variant 0's mate-side key words in
+    // registers from the moment it exists (v0_*); the position-side clause (AG:1375) needs no test at all there: with at most one
+    // conti-mer at X every arrival carries the same (contigID, contigOffset) that variant 0 stored, and with several the arrival goes
+    // through slow() anyway (v0_ok = 0).  The verdict is integer arithmetic and the two counter updates are LDS adds of 0 or 1
+    // (agx_bucket_add: ds_add_u32 in the LDS pass), so the loop's fast path never waits for LDS.  Only lanes that need another variant,
+    // an insert or several candidate keys enter slow().
+    agx_u32 v0_ok = 0, v0_c0 = AGX_NONE, v0_o0 = AGX_NONE, v0_m = AGX_NONE;
     auto apply = [&](const agx_pre &p) {
-        const agx_u32 has = p.has & (ok ? 1u : 0u);
+        const agx_u32 has = p.has;                                                  // (a lane whose bucket overflowed keeps going: the tile is swept again)
         pflag |= p.step1 | p.jump;
-        const agx_u32 is_k1 = p.type != AGX_AT_K2ONLY ? 1u : 0u;
-        const agx_u32 vfield = agx_vote_field(p.cbyte, p.rev != 0);
-        const agx_u32 vf = p.type == AGX_AT_K1 ? vfield : (agx_u32)AGX_NF;
-        const agx_u32 c0_n = p.mate ? p.h.n : 0u;
-        const agx_cmkey c0k = agx_cmkey{p.mate ? p.h.cid : AGX_NONE, p.mate ? p.h.coff : AGX_NONE};        // NONE/NONE when the position has none
-        const agx_u32 c = agx_b(b, 0, AGX_F_CID), o = agx_b(b, 0, AGX_F_COFF), c0 = agx_b(b, 0, AGX_F_CID0), o0 = agx_b(b, 0, AGX_F_COFF0), m = agx_b(b, 0, AGX_F_OFF0);
-        const agx_u32 compat = agx_clause_ab(cx0.cid, cx0.coff, c, o, AGX_EP25) & agx_clause_ab(c0k.cid, c0k.coff, c0, o0, 2 * A.iv + AGX_EP25) &
-                               agx_clause_c(p.p0, m, 2 * A.iv + AGX_EP25);                   // cx0 / c0 are NONE when absent
-        const agx_u32 fast = has & compat & (agx_u32)(cx_n <= 1) & (agx_u32)(c0_n <= 1) & (agx_u32)(cnt > 0);
-        const agx_u32 vote = fast & (agx_u32)(vf != AGX_NF);
+        const agx_u32 is_k1 = p.type != AGX_AT_K2ONLY ? 1u : 0u, votes = p.type == AGX_AT_K1 ? 1u : 0u;
+        const agx_u32 vfield = (p.cbyte >> (p.rev ? 4u : 0u)) & 15u;
+        const agx_u32 c0_n = p.h.n;
+        const agx_cmkey c0k = agx_cmkey{p.h.cid, p.h.coff};                        // NONE/NONE when the mate position has none (or there is no mate)
+        const agx_u32 compat = agx_clause_ab(c0k.cid, c0k.coff, v0_c0, v0_o0, 2 * A.iv + AGX_EP25) & agx_clause_c(p.p0, v0_m, 2 * A.iv + AGX_EP25);
+        const agx_u32 fast = has & v0_ok & compat & (agx_u32)(c0_n <= 1);
+        const agx_u32 vote = fast & votes;
         agx_bucket_add<LDS_ADD>(agx_b(b, 0, AGX_F_COV), fast & is_k1);
-        agx_bucket_add<LDS_ADD>(agx_b(b, 0, vote ? vf : (agx_u32)AGX_F_COV), vote);
-        agx_u32 vm = fast;                                                          // the straight-line case touches variant 0
-        if (has & (fast ^ 1u)) slow(p, p.h.start, c0_n, c0k, is_k1 != 0, vf, vm);
-        exch(vm, p.step1);
+        agx_bucket_add<LDS_ADD>(agx_b(b, 0, vote ? vfield : (agx_u32)AGX_F_COV), vote);
+        agx_u32 vm = fast, sp = fast & p.step1;                                     // the straight-line case touches variant 0
+        if (has & (fast ^ 1u)) {
+            if (ok) slow(p, p.h.start, c0_n, c0k, is_k1 != 0, votes ? vfield : (agx_u32)AGX_NF, vm);
+            sp = p.step1 ? agx_edge_spread(vm) : 0u;
+            if (cnt) { v0_ok = cx_n <= 1 ? 1u : 0u; v0_c0 = agx_b(b, 0, AGX_F_CID0); v0_o0 = agx_b(b, 0, AGX_F_COFF0); v0_m = agx_b(b, 0, AGX_F_OFF0); }
+        }
+        exch(vm, sp);
     };
     // software pipeline over two arrival buffers that are never copied (a register copy would have to wait for the loads): buffer
     // A serves the even hits of the list, B the odd ones; a buffer is refilled for the hit two places ahead right after it has been
@@ -451,16 +472,6 @@ AGX_HD char agx_consensus(agx_u32 a, agx_u32 c, agx_u32 g, agx_u32 t, agx_u32 n)
     if (g >= a && g >= c && g >= t && g >= n) return 'G';
     if (t >= a && t >= c && t >= g && t >= n) return 'T';
     return 'N';
-}
-
-// x -> x+1 edges of one hit, accumulated per position as a bit matrix: bit v*AGX_EM_W + w = variant v here has an edge to variant w of the
-// next position.  Only kept for buckets of up to AGX_EM_W variants (the LDS sweep); larger buckets leave their edges to the edge passes.
-#define AGX_EM_W 4u
-AGX_HD void agx_edge_merge(agx_u32 &emask, agx_u32 vm, agx_u32 vm_next, agx_u32 step1) {
-    const agx_u32 row = step1 ? (vm_next & ((1u << AGX_EM_W) - 1u)) : 0u;
-    // variant bit v of vm moved to bit v*AGX_EM_W; times row (< 2^AGX_EM_W, so the partial products cannot overlap) puts a copy of row there
-    const agx_u32 spread = (vm & 1u) | ((vm & 2u) << (AGX_EM_W - 1u)) | ((vm & 4u) << (2u * AGX_EM_W - 2u)) | ((vm & 8u) << (3u * AGX_EM_W - 3u));
-    emask |= spread * row;
 }
 
 // write this position's bucket to the node table at node ids [base, base+cnt); prune (AG:1904-1918) and consensus fused in.

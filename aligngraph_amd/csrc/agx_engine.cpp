@@ -104,7 +104,7 @@ enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SL
 void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     memset(&S, 0, sizeof S);
     S.cm_start = u->d_cm_start.p; S.cm = u->d_cm.p; S.cm_head = u->d_cm_head.p; S.ref = u->d_ref.p;
-    S.dhit = u->d_dhit.p; S.runs = u->d_runs.p; S.bases = u->d_bases.p; S.stride = u->P.stride;
+    S.dhit = u->d_dhit.p; S.runs = u->d_runs.p; S.vcodes = reinterpret_cast<const agx_u8 *>(u->d_bases.p); S.stride = u->P.stride;
     S.tile_off = u->d_tile_off.p; S.tile_recs = (decltype(S.tile_recs))u->d_tile_recs.p;
     S.n_pos = (agx_u32)u->T.ref.size(); S.n_tiles = u->n_tiles; S.k = u->prm.k; S.iv = (int)u->prm.insert_variation; S.coverage = (int)u->prm.coverage;
     S.node_start = u->d_node_start.p; S.node_cnt = u->d_node_cnt.p; S.pos_succ = u->d_pos_succ.p; S.side_cnt = u->d_side_cnt.p;
@@ -141,7 +141,10 @@ void do_upload(agx_unit *u) {
     u->d_hits.alloc(nh + 1); u->d_runs.alloc(u->P.runs.size() + 1); u->d_bases.alloc(u->P.bases.size() + 16); u->d_dhit.alloc(nh + 1); u->d_multi_run.alloc(nh + 1); u->d_rank4.alloc(4 * ((size_t)nh + 1));
     if (nh) HIP_OK(hipMemcpyAsync(u->d_hits.p, u->P.hits.data(), nh * sizeof(agx_hit), hipMemcpyHostToDevice, u->st));
     if (!u->P.runs.empty()) HIP_OK(hipMemcpyAsync(u->d_runs.p, u->P.runs.data(), u->P.runs.size() * sizeof(agx_run), hipMemcpyHostToDevice, u->st));
-    if (!u->P.bases.empty()) HIP_OK(hipMemcpyAsync(u->d_bases.p, u->P.bases.data(), u->P.bases.size(), hipMemcpyHostToDevice, u->st));
+    if (!u->P.bases.empty()) {              // the device copy holds vote codes (agx_vote_code), translated in place; the characters stay on the host for the walk
+        HIP_OK(hipMemcpyAsync(u->d_bases.p, u->P.bases.data(), u->P.bases.size(), hipMemcpyHostToDevice, u->st));
+        agx_launch_vote_codes(u->d_bases.p, (u->P.bases.size() + 15) / 16 * 16, u->st);
+    }
     u->n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
     {   // hit ids sorted by the tile their left end falls into (counting sort): agx_k_hit_prep walks them in this order so that the hits
         // of one wavefront share tiles and their histogram atomics can be combined

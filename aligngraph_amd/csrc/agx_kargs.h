@@ -37,7 +37,8 @@ struct agx_edge_kargs {
 #define AGX_SLOW_WAVES 8192u    // wavefronts of the per-hit edge pass if the occupancy query fails (normally: as many as are resident at once)
 
 extern "C" {
-void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t);
+void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t);      // n_pos + 1 heads
+void agx_launch_vote_codes(void *blob, size_t n_bytes16, hipStream_t);      // read bases -> agx_vote_code, in place; n_bytes16 a multiple of 16
 void agx_launch_hit_prep(const agx_prep_args *, hipStream_t);
 // exclusive scan of in[0..n] (n+1 entries, in[n] must be 0) into out[0..n]; out[n] = total
 void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u32 *tmp, hipStream_t);

@@ -30,7 +30,20 @@ static_assert(AGX_MAXV_LDS <= AGX_EM_W, "the LDS sweep writes the x -> x+1 edges
 // ---- upload time: per-position head of the conti-mer table ---------------------------------------------------------
 __global__ void __launch_bounds__(256) agx_k_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos) {
     const agx_u32 x = blockIdx.x * 256u + threadIdx.x;
-    if (x < n_pos) agx_cm_head_pos(cm_start, cm, head, x);
+    if (x <= n_pos) agx_cm_head_pos(cm_start, cm, head, x, n_pos);
+}
+// read bases -> vote codes, in place (16 characters per thread; the blob is padded to a multiple of 16)
+__global__ void __launch_bounds__(256) agx_k_vote_codes(uint4 *blob, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n16) return;
+    uint4 v = blob[i];
+    agx_u32 w[4] = {v.x, v.y, v.z, v.w};
+    for (int j = 0; j < 4; j++) {
+        agx_u32 o = 0;
+        for (int b = 0; b < 4; b++) o |= (agx_u32)agx_vote_code((w[j] >> (8 * b)) & 0xFFu) << (8 * b);
+        w[j] = o;
+    }
+    blob[i] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // ---- hit_prep: one thread per hit -------------------------------------------------------------------------------
@@ -202,9 +215,9 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
         const agx_tile_recs hits{K.S.tile_recs};
         // every lane hands the variants a hit touched to its left neighbour (agx_edge_merge): the x -> x+1 edges of 63 of the tile's 64
         // positions fall out of the sweep itself; the fallback pass leaves them to the edge passes (its buckets exceed the edge matrix)
-        const bool ok = agx_node_sweep_lane<!BIG>(K.S, tile, X, b, cnt, pflag, hits, [&](agx_u32 vm, agx_u32 step1) {
+        const bool ok = agx_node_sweep_lane<!BIG>(K.S, tile, X, b, cnt, pflag, hits, [&](agx_u32 vm, agx_u32 sp) {
             // lane i reads lane i+1 with one DPP move (wave_shl:1; the last lane reads 0: its edges belong to the edge passes)
-            if (!BIG) agx_edge_merge(emask, vm, (agx_u32)__builtin_amdgcn_update_dpp(0, (int)vm, 0x130, 0xF, 0xF, true), step1);
+            if (!BIG) agx_edge_merge(emask, sp, (agx_u32)__builtin_amdgcn_update_dpp(0, (int)vm, 0x130, 0xF, 0xF, true));
         });
         if (__ballot(!ok) != 0ull) {                       // wave-uniform
             if (lane == 0) {
@@ -378,7 +391,11 @@ __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, ag
 extern "C" {
 
 void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t st) {
-    if (n_pos) hipLaunchKernelGGL(agx_k_cm_head, dim3((n_pos + 255) / 256), dim3(256), 0, st, cm_start, cm, head, n_pos);
+    hipLaunchKernelGGL(agx_k_cm_head, dim3(n_pos / 256 + 1), dim3(256), 0, st, cm_start, cm, head, n_pos);
+}
+void agx_launch_vote_codes(void *blob, size_t n_bytes16, hipStream_t st) {
+    const size_t n16 = n_bytes16 / 16;
+    if (n16) hipLaunchKernelGGL(agx_k_vote_codes, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (uint4 *)blob, n16);
 }
 void agx_launch_hit_prep(const agx_prep_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_hit_prep, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);

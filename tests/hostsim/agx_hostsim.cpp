@@ -60,10 +60,12 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     S.node_start.assign(n_pos, 0); S.node_cnt.assign(n_pos, 0); S.pos_succ.assign(n_pos, 0); S.side_cnt.assign((size_t)n_pos + 1, 0);
     S.reserve((size_t)n_pos * 2 + 1024);
     agx_sweep_args A; memset(&A, 0, sizeof A);
+    std::vector<agx_u8> vcodes(P.bases.size());             // the engine translates its device copy of the read bases at upload
+    for (size_t i = 0; i < P.bases.size(); i++) vcodes[i] = agx_vote_code((agx_u8)P.bases[i]);
     std::vector<agx_cmhead> cmh((size_t)n_pos + 1);
-    for (agx_u32 x = 0; x < n_pos; x++) agx_cm_head_pos(T.cm_start.data(), cmk.data(), cmh.data(), x);
+    for (agx_u32 x = 0; x <= n_pos; x++) agx_cm_head_pos(T.cm_start.data(), cmk.data(), cmh.data(), x, n_pos);
     A.cm_start = T.cm_start.data(); A.cm = cmk.data(); A.cm_head = cmh.data(); A.ref = T.ref.data();
-    A.dhit = dh.data(); A.runs = P.runs.data(); A.bases = P.bases.data(); A.stride = P.stride;
+    A.dhit = dh.data(); A.runs = P.runs.data(); A.vcodes = vcodes.data(); A.stride = P.stride;
     A.tile_off = tile_off.data();
     A.n_pos = n_pos; A.n_tiles = n_tiles; A.k = k; A.iv = iv; A.coverage = coverage;
     auto bind = [&]() {
@@ -80,12 +82,12 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     for (agx_u32 t = 0; t < n_tiles; t++) {
         agx_u32 cnt[AGX_TILE], pflag[AGX_TILE]; bool ok = true;
         // what every lane hands to its left neighbour per hit (the kernel does it with a wave shuffle inside the sweep's loop)
-        struct Touch { agx_u32 vm, step1; };
+        struct Touch { agx_u32 vm, sp; };
         std::vector<Touch> touched[AGX_TILE];
         agx_bucket b{nullptr, AGX_TILE, maxv_first};
         for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
             b.base = lds.data() + lane;
-            ok &= agx_node_sweep_lane<false>(A, t, t * AGX_TILE + lane, b, cnt[lane], pflag[lane], get, [&](agx_u32 vm, agx_u32 step1) { touched[lane].push_back(Touch{vm, step1}); });
+            ok &= agx_node_sweep_lane<false>(A, t, t * AGX_TILE + lane, b, cnt[lane], pflag[lane], get, [&](agx_u32 vm, agx_u32 sp) { touched[lane].push_back(Touch{vm, sp}); });
         }
         agx_u32 *store = lds.data(); agx_u32 maxv = maxv_first;
         if (!ok) {                                     // the fallback the engine runs for overflowed tiles
@@ -106,7 +108,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
             const agx_u32 ncnt = lane + 1 < AGX_TILE ? cnt[lane + 1] : 0;
             const bool edges = ok && lane < AGX_TILE - 1 && X + 1 < n_pos && cnt[lane] <= AGX_EM_W && ncnt <= AGX_EM_W;
             agx_u32 emask = 0;
-            if (edges) for (size_t i = 0; i < touched[lane].size(); i++) agx_edge_merge(emask, touched[lane][i].vm, touched[lane + 1][i].vm, touched[lane][i].step1);
+            if (edges) for (size_t i = 0; i < touched[lane].size(); i++) agx_edge_merge(emask, touched[lane][i].sp, touched[lane + 1][i].vm);
             agx_node_write_lane(A, X, wb, cnt[lane], pool, pflag[lane], edges, emask, wn, pool + cnt[lane], ncnt);
             pool += cnt[lane];
         }
