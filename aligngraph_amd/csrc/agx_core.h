@@ -38,11 +38,16 @@ typedef uint8_t agx_u8;
 
 #define AGX_NONE 0xFFFFFFFFu
 #define AGX_TILE 64u          // positions per tile = lanes per wavefront
+// The node pool is cut into one slice per AGX_REGION_TILES consecutive tiles, each with its own allocation counter (agx_k_node_sweep).
+#define AGX_REGION_TILES 32u
+#define AGX_REGION_PAD 32u      // counters sit 128 bytes apart
+// The node sweep runs in three passes with growing buckets; a tile whose bucket overflows is swept again by the next pass.
 #ifndef AGX_MAXV_LDS
-#define AGX_MAXV_LDS 3u       // variants per position held in LDS (3: 10 KB per wavefront -> 4 wavefronts per SIMD; 4 -> 3, measured 15 % slower);
-                              // tiles that need more are re-run with global scratch
+#define AGX_MAXV_LDS 2u       // pass 0, every tile: variants per position held in LDS (2: 6.5 KB per wavefront -> 6 wavefronts per SIMD; the sweep
+                              // waits on memory more than it computes: 0.66 ms with 2, 0.73 ms with 3 (4 wavefronts per SIMD) on the bench unit)
 #endif
-#define AGX_MAXV_BIG 64u      // variants per position in the global-scratch fallback
+#define AGX_MAXV_MID 4u       // pass 1, LDS again (13 KB per wavefront): the widest bucket whose x -> x+1 edges still fit the sweep's edge matrix
+#define AGX_MAXV_BIG 64u      // pass 2: buckets in global scratch
 #define AGX_MAXE 4u           // out-edges stored inline per node; more go to the overflow list
 #define AGX_EP25 25           // 5*EP (AG:39, 1296)
 
@@ -719,9 +724,9 @@ struct agx_compact_args {
     // node table, old ids
     const agx_u32 *node_start; const agx_u8 *node_cnt; const agx_u8 *n_flags; const agx_u8 *n_base; const agx_u32 *n_xpos;
     const agx_u32 *nk_off0; const agx_sref *n_sref; const agx_u32 *n_next; const char *ref;
-    agx_u32 n_pos, n_nodes;
+    agx_u32 n_pos;
     const agx_u32 *side_start;     // [n_pos+1] exclusive scan of side_cnt
-    agx_u32 *aid_of;               // [n_nodes] walk id or NONE
+    agx_u32 *aid_of;               // [pool] walk id or NONE
     // outputs indexed by aid, [n_pos + n_side]
     char *a_str; agx_u8 *a_meta; agx_walknode *a_node;   // a_meta: AGX_WM_* bits
     const agx_edge_ovf *ovf; agx_u32 n_ovf; agx_edge_ovf *a_ovf;   // overflow edges rewritten in aids (edges touching pruned nodes become NONE/NONE)
@@ -748,7 +753,6 @@ AGX_HD void agx_assign_aid_pos(const agx_compact_args &A, agx_u32 X) {
 
 // per old node: write its record at its walk id
 AGX_HD void agx_emit_alive_node(const agx_compact_args &A, agx_u32 v) {
-    if (v >= A.n_nodes) return;
     const agx_u32 a = A.aid_of[v];
     if (a == AGX_NONE) return;
     const agx_u32 x = A.n_xpos[v];
@@ -772,6 +776,13 @@ AGX_HD void agx_emit_alive_node(const agx_compact_args &A, agx_u32 v) {
     if (!cont) for (agx_u32 e = 0; e < k; e++) A.a_mark[w.next[e]] = 1;      // racing stores of the same value
     for (; k < AGX_MAXE; k++) w.next[k] = AGX_NONE;
     A.a_node[a] = w;
+}
+
+// per position: its nodes (the node table is only ever entered through node_start / node_cnt: the pool it lives in has unused slots)
+AGX_HD void agx_emit_alive_pos(const agx_compact_args &A, agx_u32 X) {
+    if (X >= A.n_pos) return;
+    const agx_u32 s = A.node_start[X], n = A.node_cnt[X];
+    for (agx_u32 v = 0; v < n; v++) agx_emit_alive_node(A, s + v);
 }
 
 AGX_HD void agx_emit_alive_ovf(const agx_compact_args &A, agx_u32 i) {

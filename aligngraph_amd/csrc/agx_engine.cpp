@@ -65,9 +65,10 @@ struct agx_unit {
     DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_recs, d_scan_tmp, d_words;   // d_words: counters/status
     // node table
     agx_u32 pool_cap = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
+    DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
     DBuf<agx_u32> d_node_start, d_slow_list, d_rank4, d_perm; DBuf<agx_u8> d_node_cnt, d_pos_succ, d_multi_run;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
-    DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_big_list, d_scratch;
+    DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch;
     // walk graph (agx_core.h "walk preparation")
     agx_u32 n_ids = 0;
     DBuf<agx_u32> d_side_cnt, d_side_start, d_aid_of; DBuf<char> d_a_str;
@@ -78,7 +79,7 @@ struct agx_unit {
     PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
     PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_hop> h_sp_hop; PBuf<agx_edge_ovf> h_a_ovf;
     PBuf<agx_u32> h_words;
-    agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0;
+    agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
     EventPair ev_prep, ev_bin, ev_node, ev_big, ev_edge, ev_slow, ev_compact;
     agx_stats stats{};
     ~agx_unit() { ev_prep.destroy(); ev_bin.destroy(); ev_node.destroy(); ev_big.destroy(); ev_edge.destroy(); ev_slow.destroy(); ev_compact.destroy(); if (st) (void)hipStreamDestroy(st); }
@@ -99,7 +100,7 @@ DeviceTurn &turn_of(int device) { static DeviceTurn turns[64]; return turns[devi
 static const bool g_debug_sync = getenv("AGX_DEBUG_SYNC") != nullptr;
 #define AGX_CHECKPOINT(name) do { if (g_debug_sync) { hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, "[agx debug] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
 
-enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_RANKOVF = 6, W_N = 8 };
+enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_RANKOVF = 6, W_MIDCOUNT = 7, W_N = 8 };
 
 void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     memset(&S, 0, sizeof S);
@@ -112,6 +113,24 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     S.n_xpos = u->d_xpos.p; S.n_base = u->d_base.p; S.n_flags = u->d_flags.p; S.n_sref = u->d_sref.p; S.n_next = u->d_next.p;
     S.n_counts = (u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? u->d_counts.p : nullptr;
     S.pool_cap = u->pool_cap;
+}
+
+// Slices of the node pool, one per region.  Without a measurement every region gets the same share; after a build in which a slice ran out,
+// `demand` holds what every region asked for (the counters keep counting past the end of a slice) and the slices are cut to that plus slack.
+// Returns the ids the layout needs.
+unsigned long long layout_regions(agx_unit *u, const agx_u32 *demand, bool apply) {
+    const agx_u32 R = u->n_regions;
+    std::vector<agx_u32> off((size_t)R + 1, 0);
+    unsigned long long at = 0;
+    for (agx_u32 r = 0; r < R; r++) {
+        off[r] = (agx_u32)std::min<unsigned long long>(at, 0xFFFFFFFFull);
+        at += demand ? (unsigned long long)demand[r] + demand[r] / 8 + 64 : u->pool_cap / R;
+    }
+    if (!apply || at > u->pool_cap) return at;
+    off[R] = (agx_u32)at;
+    u->d_region_off.alloc((size_t)R + 1); u->d_pool_cnt.alloc((size_t)R * AGX_REGION_PAD);
+    HIP_OK(hipMemcpy(u->d_region_off.p, off.data(), ((size_t)R + 1) * 4, hipMemcpyHostToDevice));
+    return at;
 }
 
 void alloc_pool(agx_unit *u, agx_u32 cap) {
@@ -176,6 +195,8 @@ void do_upload(agx_unit *u) {
     // AGX_TEST_SMALL_CAPS (tests) starts them absurdly small so that every regrow path runs.
     const bool tiny = getenv("AGX_TEST_SMALL_CAPS") != nullptr;
     if (u->pool_cap == 0) alloc_pool(u, (agx_u32)std::min<size_t>(tiny ? n_pos / 8 + 64 : n_pos + n_pos / 4 + 4096, 0xFFFFFF00ull));
+    u->n_regions = (u->n_tiles + AGX_REGION_TILES - 1) / AGX_REGION_TILES;
+    layout_regions(u, nullptr, true);
     if (u->ovf_cap == 0) { u->ovf_cap = tiny ? 4u : 1u << 16; u->d_ovf.alloc(u->ovf_cap); }
     HIP_OK(hipStreamSynchronize(u->st));
     u->uploaded = true; u->built = false; u->downloaded = false;
@@ -192,7 +213,7 @@ void do_build(agx_unit *u) {
     hipStream_t st = u->st;
     u->stats.node_sweep_launches = u->stats.edge_sweep_launches = 0;
     if (u->list_cap == 0) u->list_cap = (agx_u32)std::min<size_t>(getenv("AGX_TEST_SMALL_CAPS") ? (size_t)nh / 2 + 16 : (size_t)nh * 3 + 1024, 0xFFFFFF00ull);
-    u->d_big_list.alloc((size_t)u->n_tiles + 1);
+    u->d_big_list.alloc((size_t)u->n_tiles + 1); u->d_mid_list.alloc((size_t)u->n_tiles + 1);
     u->d_scratch.alloc((size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64);
     for (int attempt = 0;; attempt++) {
         if (attempt > 8) throw Error{E_DEVICE, "build did not converge"};
@@ -216,6 +237,7 @@ void do_build(agx_unit *u) {
         HIP_OK(hipMemsetAsync(u->d_words.p, 0, W_N * 4, st));
         HIP_OK(hipMemsetAsync(u->d_tile_cnt.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
         HIP_OK(hipMemsetAsync(u->d_cursor.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
+        HIP_OK(hipMemsetAsync(u->d_pool_cnt.p, 0, (size_t)u->n_regions * AGX_REGION_PAD * 4, st));
         // ---- hit_prep + tile histogram ----
         HIP_OK(hipEventRecord(u->ev_prep.a, st));
         agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_perm.p, u->d_tile_cnt.p, u->d_words.p + W_ERR, u->d_multi_run.p, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
@@ -230,9 +252,10 @@ void do_build(agx_unit *u) {
         agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, st);
         AGX_CHECKPOINT("tile_sort");
         HIP_OK(hipEventRecord(u->ev_bin.b, st)); u->ev_bin.used = true;
-        // ---- node sweep: LDS pass, then the global-scratch pass over whatever tiles overflowed (device-side count) ----
+        // ---- node sweep: every tile with small LDS buckets, then the tiles that overflowed with wider ones, then with global scratch (device-side lists) ----
         agx_node_kargs K; fill_sweep_args(u, K.S);
-        K.pool_counter = u->d_words.p + W_POOL; K.big_count = u->d_words.p + W_BIGCOUNT; K.big_list = u->d_big_list.p; K.status = u->d_words.p + W_STATUS;
+        K.pool_cnt = u->d_pool_cnt.p; K.region_off = u->d_region_off.p; K.mid_count = u->d_words.p + W_MIDCOUNT; K.mid_list = u->d_mid_list.p; K.mid_n = u->d_words.p + W_MIDCOUNT;
+        K.big_count = u->d_words.p + W_BIGCOUNT; K.big_list = u->d_big_list.p; K.status = u->d_words.p + W_STATUS;
         K.list_cap = u->list_cap; K.big_n = u->d_words.p + W_BIGCOUNT; K.scratch = u->d_scratch.p;
         K.slow_list = u->d_slow_list.p; K.slow_count = u->d_words.p + W_SLOWCOUNT;
         HIP_OK(hipEventRecord(u->ev_node.a, st));
@@ -242,6 +265,7 @@ void do_build(agx_unit *u) {
         HIP_OK(hipEventRecord(u->ev_big.a, st));
         agx_launch_node_sweep_big(&K, st);
         AGX_CHECKPOINT("node_sweep_big");
+        agx_launch_pool_sum(u->d_pool_cnt.p, u->n_regions, u->d_words.p + W_POOL, st);
         HIP_OK(hipEventRecord(u->ev_big.b, st)); u->ev_big.used = true;
         // ---- edge sweep ----
         agx_edge_kargs E; fill_sweep_args(u, E.S); E.ovf = u->d_ovf.p; E.ovf_count = u->d_words.p + W_OVFCOUNT; E.ovf_cap = u->ovf_cap; E.list_cap = u->list_cap;
@@ -259,7 +283,7 @@ void do_build(agx_unit *u) {
         // ---- walk preparation: side counts -> scan -> walk ids, node records, rewritten edges, forced-run flags ----
         agx_compact_args C; memset(&C, 0, sizeof C);
         C.node_start = u->d_node_start.p; C.node_cnt = u->d_node_cnt.p; C.n_flags = u->d_flags.p; C.n_base = u->d_base.p; C.n_xpos = u->d_xpos.p;
-        C.nk_off0 = u->d_off0.p; C.n_sref = u->d_sref.p; C.n_next = u->d_next.p; C.ref = u->d_ref.p; C.n_pos = n_pos; C.n_nodes = 0;
+        C.nk_off0 = u->d_off0.p; C.n_sref = u->d_sref.p; C.n_next = u->d_next.p; C.ref = u->d_ref.p; C.n_pos = n_pos;
         C.side_start = u->d_side_start.p; C.aid_of = u->d_aid_of.p;
         C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_node = u->d_a_node.p; C.ovf = u->d_ovf.p; C.n_ovf = 0; C.a_ovf = u->d_a_ovf.p;
         HIP_OK(hipEventRecord(u->ev_compact.a, st));
@@ -271,7 +295,7 @@ void do_build(agx_unit *u) {
         HIP_OK(hipMemsetAsync(u->d_sp_cnt.p + u->n_words, 0, 4, st));
         agx_launch_exclusive_scan(u->d_side_cnt.p, u->d_side_start.p, n_pos, u->d_scan_tmp.p, st);
         agx_launch_mark_list(u->d_chain_end.p, u->n_chain_end, u->d_a_mark.p, st);
-        agx_launch_compact(&C, u->d_words.p + W_POOL, u->pool_cap, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
+        agx_launch_compact(&C, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
         AGX_CHECKPOINT("compact");
         agx_launch_special(&C, u->n_words, u->d_sp_rank.p, u->d_scan_tmp.p, st);
         AGX_CHECKPOINT("special");
@@ -291,19 +315,25 @@ void do_build(agx_unit *u) {
         u->n_tile_entries = w[W_N];
         if (u->n_tile_entries > u->list_cap) { u->list_cap = u->n_tile_entries + u->n_tile_entries / 8 + 1024; u->d_unsorted.release(); u->d_tile_recs.release(); continue; }
         if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 64 node variants at one position"};
-        const unsigned long long want = w[W_POOL];
-        if ((w[W_STATUS] & 1u) || want > u->pool_cap) {
-            const unsigned long long cap = std::min<unsigned long long>(std::max<unsigned long long>(want + want / 4 + 4096, 2ull * u->pool_cap), 0xFFFFFF00ull);
-            if (cap <= u->pool_cap) throw Error{E_OVERFLOW, "node table exceeds 2^32 entries"};
-            u->d_cid.release(); u->d_coff.release(); u->d_cid0.release(); u->d_coff0.release(); u->d_off0.release(); u->d_xpos.release();
-            u->d_next.release(); u->d_base.release(); u->d_flags.release(); u->d_sref.release(); u->d_counts.release();
-            u->d_aid_of.release(); u->d_a_str.release(); u->d_a_meta.release(); u->d_a_node.release();
-            u->d_a_mark.release(); u->d_side_xpos.release(); u->d_sp_bits.release(); u->d_sp_cnt.release(); u->d_sp_rank.release();
-            alloc_pool(u, (agx_u32)cap);
+        if (w[W_STATUS] & 1u) {                  // a region's slice of the node pool ran out: cut the slices to what the regions asked for
+            std::vector<agx_u32> padded((size_t)u->n_regions * AGX_REGION_PAD), demand(u->n_regions);
+            HIP_OK(hipMemcpy(padded.data(), u->d_pool_cnt.p, padded.size() * 4, hipMemcpyDeviceToHost));
+            for (agx_u32 r = 0; r < u->n_regions; r++) demand[r] = padded[(size_t)r * AGX_REGION_PAD];
+            const unsigned long long need = layout_regions(u, demand.data(), false);
+            if (need >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "node table exceeds 2^32 entries"};
+            if (need > u->pool_cap) {
+                u->d_cid.release(); u->d_coff.release(); u->d_cid0.release(); u->d_coff0.release(); u->d_off0.release(); u->d_xpos.release();
+                u->d_next.release(); u->d_base.release(); u->d_flags.release(); u->d_sref.release(); u->d_counts.release();
+                u->d_aid_of.release(); u->d_a_str.release(); u->d_a_meta.release(); u->d_a_node.release();
+                u->d_a_mark.release(); u->d_side_xpos.release(); u->d_sp_bits.release(); u->d_sp_cnt.release(); u->d_sp_rank.release();
+                alloc_pool(u, (agx_u32)need);
+            }
+            layout_regions(u, demand.data(), true);
             continue;
         }
+        const unsigned long long want = w[W_POOL];
         if (w[W_OVFCOUNT] > u->ovf_cap) { u->ovf_cap = w[W_OVFCOUNT] + w[W_OVFCOUNT] / 2 + 1024; u->d_ovf.release(); u->d_ovf.alloc(u->ovf_cap); u->d_a_ovf.release(); continue; }
-        u->n_nodes = (agx_u32)want; u->n_big = w[W_BIGCOUNT]; u->n_ovf = w[W_OVFCOUNT];
+        u->n_nodes = (agx_u32)want; u->n_big = w[W_BIGCOUNT]; u->n_mid = w[W_MIDCOUNT]; u->n_ovf = w[W_OVFCOUNT];
         const unsigned long long ids = (unsigned long long)n_pos + w[W_N + 1];
         if (ids >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "walk graph exceeds 2^32 ids"};
         if (w[W_N + 2] > u->sp_cap) { u->sp_cap = w[W_N + 2] + w[W_N + 2] / 8 + 1024; u->d_sp_node.release(); u->d_sp_hop.release(); continue; }
@@ -522,7 +552,7 @@ int agx_unit_stats(const agx_unit *u, agx_stats *s) {
     if (!u || !s) return AGX_E_ARG;
     *s = u->stats;
     s->n_pos = u->T.ref.size(); s->n_ref = u->T.n_ref; s->n_hits = u->P.hits.size(); s->n_runs = u->P.runs.size(); s->n_nodes = u->n_nodes;
-    s->n_tiles = u->n_tiles; s->n_tile_entries = u->n_tile_entries; s->n_big_tiles = u->n_big; s->n_edge_overflow = u->n_ovf;
+    s->n_tiles = u->n_tiles; s->n_tile_entries = u->n_tile_entries; s->n_big_tiles = u->n_big; s->n_mid_tiles = u->n_mid; s->n_edge_overflow = u->n_ovf;
     s->pairs_in_file = u->P.n_pairs_in_file; s->sam_line_pairs = u->P.n_sam_pairs;
     return AGX_OK;
 }
@@ -534,33 +564,40 @@ int agx_unit_graph(agx_unit *u, agx_graph *g) {
         if (!u->built) do_build(u);
         HIP_OK(hipSetDevice(u->prm.device));
         HIP_OK(hipStreamSynchronize(u->st));
-        const agx_u32 n_pos = (agx_u32)u->T.ref.size(), nn = u->n_nodes;
-        std::vector<agx_u32> node_start(n_pos), cid(nn), coff(nn), cid0(nn), coff0(nn), off0(nn), next((size_t)nn * AGX_MAXE); std::vector<agx_u8> node_cnt(n_pos);
-        std::vector<agx_sref> sref(nn); std::vector<int> counts; std::vector<agx_edge_ovf> ovf(u->n_ovf);
+        // the pool has unused slots (one slice per region): the arrays come down whole, nodes are reached through node_start / node_cnt
+        const agx_u32 n_pos = (agx_u32)u->T.ref.size(), nn = u->n_nodes, cap = u->pool_cap;
+        std::vector<agx_u32> node_start(n_pos), cid(cap), coff(cap), cid0(cap), coff0(cap), off0(cap), next((size_t)cap * AGX_MAXE); std::vector<agx_u8> node_cnt(n_pos);
+        std::vector<agx_sref> sref(cap); std::vector<int> counts; std::vector<agx_edge_ovf> ovf(u->n_ovf);
         HIP_OK(hipMemcpy(node_start.data(), u->d_node_start.p, (size_t)n_pos * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(node_cnt.data(), u->d_node_cnt.p, n_pos, hipMemcpyDeviceToHost));
-        if (nn) {
-            HIP_OK(hipMemcpy(cid.data(), u->d_cid.p, (size_t)nn * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(coff.data(), u->d_coff.p, (size_t)nn * 4, hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(cid0.data(), u->d_cid0.p, (size_t)nn * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(coff0.data(), u->d_coff0.p, (size_t)nn * 4, hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(off0.data(), u->d_off0.p, (size_t)nn * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(next.data(), u->d_next.p, (size_t)nn * AGX_MAXE * 4, hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(sref.data(), u->d_sref.p, (size_t)nn * sizeof(agx_sref), hipMemcpyDeviceToHost));
-            if (u->prm.flags & AGX_FLAG_KEEP_COUNTS) { counts.resize((size_t)nn * 6); HIP_OK(hipMemcpy(counts.data(), u->d_counts.p, (size_t)nn * 24, hipMemcpyDeviceToHost)); }
+        if (cap) {
+            HIP_OK(hipMemcpy(cid.data(), u->d_cid.p, (size_t)cap * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(coff.data(), u->d_coff.p, (size_t)cap * 4, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(cid0.data(), u->d_cid0.p, (size_t)cap * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(coff0.data(), u->d_coff0.p, (size_t)cap * 4, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(off0.data(), u->d_off0.p, (size_t)cap * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(next.data(), u->d_next.p, (size_t)cap * AGX_MAXE * 4, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(sref.data(), u->d_sref.p, (size_t)cap * sizeof(agx_sref), hipMemcpyDeviceToHost));
+            if (u->prm.flags & AGX_FLAG_KEEP_COUNTS) { counts.resize((size_t)cap * 6); HIP_OK(hipMemcpy(counts.data(), u->d_counts.p, (size_t)cap * 24, hipMemcpyDeviceToHost)); }
         }
         if (u->n_ovf) HIP_OK(hipMemcpy(ovf.data(), u->d_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf), hipMemcpyDeviceToHost));
         g->n_pos = n_pos; g->n_nodes = nn;
         g->node_start = (uint32_t *)malloc(4 * ((size_t)n_pos + 1)); g->node_key = (uint32_t *)malloc(24 * ((size_t)nn + 1)); g->node_cnt = (int32_t *)malloc(24 * ((size_t)nn + 1));
         g->node_slen = (uint32_t *)malloc(4 * ((size_t)nn + 1)); g->edge_start = (uint32_t *)malloc(4 * ((size_t)nn + 1));
-        std::vector<agx_u32> canon(nn); agx_u32 id = 0;
-        for (agx_u32 x = 0; x < n_pos; x++) { g->node_start[x] = id; for (agx_u32 v = 0; v < node_cnt[x]; v++) canon[node_start[x] + v] = id++; }
+        std::vector<agx_u32> canon(cap, AGX_NONE), slot_of(nn); agx_u32 id = 0;
+        for (agx_u32 x = 0; x < n_pos; x++) {
+            g->node_start[x] = id;
+            for (agx_u32 v = 0; v < node_cnt[x]; v++) {
+                if ((size_t)node_start[x] + v >= cap || id >= nn) throw Error{E_DEVICE, "node table is inconsistent (count mismatch)"};
+                slot_of[id] = node_start[x] + v; canon[node_start[x] + v] = id++;
+            }
+        }
         g->node_start[n_pos] = id;
         if (id != nn) throw Error{E_DEVICE, "node table is inconsistent (count mismatch)"};
         std::vector<std::vector<agx_u32> > adj(nn);
-        for (agx_u32 v = 0; v < nn; v++) for (agx_u32 e = 0; e < AGX_MAXE; e++) { const agx_u32 d = next[(size_t)v * AGX_MAXE + e]; if (d != AGX_NONE) adj[canon[v]].push_back(canon[d]); }
+        for (agx_u32 c = 0; c < nn; c++) for (agx_u32 e = 0; e < AGX_MAXE; e++) { const agx_u32 d = next[(size_t)slot_of[c] * AGX_MAXE + e]; if (d != AGX_NONE) adj[c].push_back(canon[d]); }
         for (agx_u32 i = 0; i < u->n_ovf; i++) adj[canon[ovf[i].src]].push_back(canon[ovf[i].dst]);
         size_t ne = 0;
         for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); ne += a.size(); }
         g->n_edges = (uint32_t)ne; g->edge_dst = (uint32_t *)malloc(4 * (ne + 1));
-        for (agx_u32 v = 0; v < nn; v++) {
-            const agx_u32 c = canon[v]; uint32_t *kk = g->node_key + 6 * (size_t)c;
+        for (agx_u32 c = 0; c < nn; c++) {
+            const agx_u32 v = slot_of[c]; uint32_t *kk = g->node_key + 6 * (size_t)c;
             kk[0] = cid[v]; kk[1] = coff[v]; kk[2] = cid0[v]; kk[3] = coff0[v]; kk[4] = off0[v] == AGX_NONE ? AGX_NONE : 0; kk[5] = off0[v];
             if (!counts.empty()) memcpy(g->node_cnt + 6 * (size_t)c, counts.data() + 6 * (size_t)v, 24); else for (int j = 0; j < 6; j++) g->node_cnt[6 * (size_t)c + j] = -1;
             g->node_slen[c] = (sref[v].qlen >> 16) & 0x7FFF;

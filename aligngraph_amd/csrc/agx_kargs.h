@@ -18,11 +18,14 @@ struct agx_bin_args { const agx_dhit *dhit; agx_u32 n_hits; const agx_u32 *tile_
 
 struct agx_node_kargs {
     agx_sweep_args S;
-    agx_u32 *pool_counter;     // next free node id
-    agx_u32 *big_count; agx_u32 *big_list;   // tiles whose buckets did not fit in LDS
-    agx_u32 *status;           // bit 0: node pool exhausted; bit 1: bucket overflow in the global-scratch pass; bit 2: tile lists too small
+    agx_u32 *pool_cnt;         // node ids handed out per region (counter r at pool_cnt[r * AGX_REGION_PAD]); keeps counting past the slice's end
+    const agx_u32 *region_off; // [regions + 1] first node id of every region's slice of the pool
+    agx_u32 *mid_count; agx_u32 *mid_list;   // tiles whose buckets did not fit pass 0's
+    agx_u32 *big_count; agx_u32 *big_list;   // tiles whose buckets did not fit pass 1's either
+    agx_u32 *status;           // bit 0: a region's slice of the node pool exhausted; bit 1: bucket overflow in the global-scratch pass; bit 2: tile lists too small
     agx_u32 list_cap;          // capacity of the tile lists: a tile whose list ends beyond it is skipped (the host re-runs with larger lists)
-    const agx_u32 *big_n;      // fallback pass: number of tiles in big_list, read on the device (no host round trip)
+    const agx_u32 *big_n;      // passes 1 and 2: number of tiles in mid_list / big_list, read on the device (no host round trip)
+    const agx_u32 *mid_n;
     agx_u32 *scratch;          // fallback pass: one [AGX_NF*AGX_MAXV_BIG*64] bucket area per resident wavefront
     agx_u32 *slow_list; agx_u32 *slow_count;   // the edge build's pass-B list: the sweep itself enters multi-variant positions with a position-skipping step
 };
@@ -52,8 +55,10 @@ void agx_launch_edge_slow(const agx_edge_kargs *, hipStream_t);           // pas
 // walk preparation (agx_core.h): after the scan of the side counts the node sweep left behind: ids, records and overflow edges
 // n_nodes / n_ovf are read from device memory (the node-pool and overflow counters), so no host round trip separates the sweeps
 // from the walk preparation; the grids are sized by the capacities.
-void agx_launch_compact(const agx_compact_args *, const agx_u32 *n_nodes_dev, agx_u32 pool_cap, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t);
+void agx_launch_compact(const agx_compact_args *, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t);
+void agx_launch_pool_sum(const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, hipStream_t);      // nodes handed out = sum of the region counters
 void agx_launch_mark_list(const agx_u32 *list, agx_u32 n, agx_u8 *mark, hipStream_t);
 void agx_launch_special(const agx_compact_args *, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, hipStream_t);
+#define AGX_MID_WAVES 3072u     // wavefronts of pass 1 (3 per SIMD fit its LDS buckets); they stride over the list of tiles pass 0 gave up on
 #define AGX_BIG_WAVES 256u      // resident wavefronts of the global-scratch fallback pass
 }

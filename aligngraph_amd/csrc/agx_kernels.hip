@@ -15,7 +15,7 @@
 #include "agx_kargs.h"
 
 #define AGX_WAVES_PER_BLOCK 4
-static_assert(AGX_MAXV_LDS <= AGX_EM_W, "the LDS sweep writes the x -> x+1 edges of every position it finishes: its buckets must fit the edge matrix");
+static_assert(AGX_MAXV_LDS <= AGX_EM_W && AGX_MAXV_MID <= AGX_EM_W, "the LDS sweep writes the x -> x+1 edges of every position it finishes: its buckets must fit the edge matrix");
 #define AGX_XCDS 8u                 // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
 #ifndef AGX_SWEEP_WAVES
 #define AGX_SWEEP_WAVES 1           // wavefronts (= consecutive tiles) per block of the node sweep: measured 0.924 / 0.926 / 0.938 / 1.011 ms for 1 / 2 / 4 / 8
@@ -192,46 +192,66 @@ __device__ __forceinline__ agx_u32 agx_wave_incl_scan(agx_u32 v, agx_u32 lane) {
     return v;
 }
 
-template <bool BIG>
+template <int PASS>      // 0: every tile, AGX_MAXV_LDS variants in LDS; 1: the tiles pass 0 gave up on, AGX_MAXV_MID in LDS; 2: the rest, AGX_MAXV_BIG in global scratch
 __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_node_kargs K) {
-    __shared__ agx_u32 lds[BIG ? 1 : AGX_SWEEP_WAVES][BIG ? 1 : AGX_NF * AGX_MAXV_LDS * 64];
+    constexpr bool BIG = PASS == 2;
+    constexpr agx_u32 MAXV = PASS == 0 ? AGX_MAXV_LDS : AGX_MAXV_MID;
+    __shared__ agx_u32 lds[BIG ? 1 : AGX_SWEEP_WAVES][BIG ? 1 : AGX_NF * MAXV * 64];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // Workgroups are handed to the 8 XCDs round-robin and every XCD has its own L2.  Neighbouring tiles read the same hit records, read
     // bases and conti-mer heads, so block b takes the (b / 8)-th block of tiles of XCD (b % 8)'s contiguous share of the unit rather than
     // tile block b: what one tile pulled into an L2 is there for its neighbours.
     agx_u32 blk = blockIdx.x;
-    if (!BIG) { const agx_u32 share = (gridDim.x + AGX_XCDS - 1) / AGX_XCDS; blk = (blockIdx.x % AGX_XCDS) * share + blockIdx.x / AGX_XCDS; }
+    if (PASS == 0) { const agx_u32 share = (gridDim.x + AGX_XCDS - 1) / AGX_XCDS; blk = (blockIdx.x % AGX_XCDS) * share + blockIdx.x / AGX_XCDS; }
     const agx_u32 slot = __builtin_amdgcn_readfirstlane(blk * AGX_SWEEP_WAVES + wave);
     agx_bucket b; b.stride = 64;
     if (BIG) { b.base = K.scratch + (size_t)slot * (AGX_NF * AGX_MAXV_BIG * 64) + lane; b.maxv = AGX_MAXV_BIG; }
-    else { b.base = &lds[wave][lane]; b.maxv = AGX_MAXV_LDS; }
-    // LDS pass: one tile per wavefront.  Fallback pass: a fixed set of wavefronts strides over the list of overflowed tiles.
-    const agx_u32 n_work = BIG ? __builtin_amdgcn_readfirstlane(*K.big_n) : K.S.n_tiles;
-    for (agx_u32 w = slot; w < n_work; w += BIG ? AGX_BIG_WAVES : 0xFFFFFFFFu) {
-        const agx_u32 tile = BIG ? __builtin_amdgcn_readfirstlane(K.big_list[w]) : w;
+    else { b.base = &lds[wave][lane]; b.maxv = MAXV; }
+    // pass 0: one tile per wavefront.  Passes 1 and 2: a fixed set of wavefronts strides over the list of overflowed tiles.
+    const agx_u32 n_work = PASS == 0 ? K.S.n_tiles : __builtin_amdgcn_readfirstlane(*(PASS == 1 ? K.mid_n : K.big_n));
+    for (agx_u32 w = slot; w < n_work; w += PASS == 0 ? 0xFFFFFFFFu : PASS == 1 ? AGX_MID_WAVES : AGX_BIG_WAVES) {
+        const agx_u32 tile = PASS == 0 ? w : __builtin_amdgcn_readfirstlane((PASS == 1 ? K.mid_list : K.big_list)[w]);
         if (K.S.tile_off[tile + 1] > K.list_cap) { if (lane == 0) atomicOr(K.status, 4u); return; }      // lists did not fit: nothing after the sweeps may run
         const agx_u32 X = tile * AGX_TILE + lane;
         agx_u32 cnt = 0, pflag = 0, emask = 0;
         const agx_tile_recs hits{K.S.tile_recs};
+#ifdef AGX_EXP_WARM
+        agx_u32 warm = 0;
+        { const agx_u32 lo = K.S.tile_off[tile], hi = K.S.tile_off[tile + 1];
+          for (agx_u32 i = lo + lane; i < hi; i += 64) warm ^= *reinterpret_cast<const volatile agx_u32 *>(K.S.tile_recs + 2 * (size_t)i); }
+#endif
         // every lane hands the variants a hit touched to its left neighbour (agx_edge_merge): the x -> x+1 edges of 63 of the tile's 64
         // positions fall out of the sweep itself; the fallback pass leaves them to the edge passes (its buckets exceed the edge matrix)
         const bool ok = agx_node_sweep_lane<!BIG>(K.S, tile, X, b, cnt, pflag, hits, [&](agx_u32 vm, agx_u32 sp) {
             // lane i reads lane i+1 with one DPP move (wave_shl:1; the last lane reads 0: its edges belong to the edge passes)
             if (!BIG) agx_edge_merge(emask, sp, (agx_u32)__builtin_amdgcn_update_dpp(0, (int)vm, 0x130, 0xF, 0xF, true));
         });
+#ifdef AGX_EXP_WARM
+        asm volatile("" :: "v"(warm));
+#endif
         if (__ballot(!ok) != 0ull) {                       // wave-uniform
             if (lane == 0) {
                 if (BIG) atomicOr(K.status, 2u);
-                else K.big_list[atomicAdd(K.big_count, 1u)] = tile;
+                else if (PASS == 1) K.big_list[atomicAdd(K.big_count, 1u)] = tile;
+                else K.mid_list[atomicAdd(K.mid_count, 1u)] = tile;
             }
-            if (BIG) continue; else return;
+            if (PASS != 0) continue; else return;
         }
         const agx_u32 incl = agx_wave_incl_scan(cnt, lane);
         const agx_u32 total = __shfl(incl, 63, 64);
         agx_u32 base = 0;
-        if (lane == 0) base = atomicAdd(K.pool_counter, total);
-        base = __shfl(base, 0, 64);
-        if ((unsigned long long)base + total > K.S.pool_cap) { if (lane == 0) atomicOr(K.status, 1u); if (BIG) continue; else return; }
+        // Node ids come from the slice of the pool that belongs to this tile's region, through the region's own counter: a single
+        // counter for the whole unit is one address that every tile's returning device-scope atomic has to queue for (measured: 0.2 ms
+        // of a 0.93 ms sweep).  The ids of a unit are therefore not dense; everything downstream enters the table through node_start.
+        const agx_u32 region = tile / AGX_REGION_TILES;
+        const agx_u32 r_lo = agx_uload(K.region_off, region), r_hi = agx_uload(K.region_off, region + 1);
+#ifdef AGX_EXP_NOATOMIC
+        base = r_lo + (tile % AGX_REGION_TILES) * 80u;      // timing experiment only
+#else
+        if (lane == 0) base = atomicAdd(K.pool_cnt + (size_t)region * AGX_REGION_PAD, total);
+        base = r_lo + (agx_u32)__shfl(base, 0, 64);
+#endif
+        if ((unsigned long long)base + total > r_hi) { if (lane == 0) atomicOr(K.status, 1u); if (PASS != 0) continue; else return; }
         const agx_u32 my_base = base + incl - cnt;
         const agx_u32 nbase = (agx_u32)__shfl_down((int)my_base, 1, 64), ncnt = (agx_u32)__shfl_down((int)cnt, 1, 64);
         agx_bucket bn = b; bn.base = b.base + 1;           // the next position's bucket is the next lane's column
@@ -239,7 +259,7 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
         agx_node_write_lane(K.S, X, b, cnt, my_base, pflag, edges, emask, bn, nbase, ncnt);
         // a multi-variant position whose x -> x+1 edges are done but which also steps elsewhere goes through pass B for those steps
         if (edges && cnt >= 2 && (pflag & 2u)) K.slow_list[atomicAdd(K.slow_count, 1u)] = X;
-        if (!BIG) return;
+        if (PASS == 0) return;
     }
 }
 
@@ -349,9 +369,12 @@ __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
 
 // ---- walk preparation: renumber surviving nodes, rewrite edges, mark forced runs (agx_core.h) -------------------------------
 __global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A) { AGX_RETURN_IF_ABORTED(A.abort); agx_assign_aid_pos(A, blockIdx.x * 256u + threadIdx.x); }
-__global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A, const agx_u32 *n_nodes_dev) {
-    AGX_RETURN_IF_ABORTED(A.abort);
-    A.n_nodes = *n_nodes_dev; agx_emit_alive_node(A, blockIdx.x * 256u + threadIdx.x);
+__global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A) { AGX_RETURN_IF_ABORTED(A.abort); agx_emit_alive_pos(A, blockIdx.x * 256u + threadIdx.x); }
+__global__ void __launch_bounds__(256) agx_k_pool_sum(const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum) {      // *sum zeroed before
+    const agx_u32 r = blockIdx.x * 256u + threadIdx.x;
+    agx_u32 t = r < regions ? pool_cnt[(size_t)r * AGX_REGION_PAD] : 0u;
+    for (agx_u32 o = 32; o; o >>= 1) t += __shfl_down(t, o, 64);
+    if ((threadIdx.x & 63u) == 0 && t) atomicAdd(sum, t);          // a unit has fewer than 2^32 nodes (the slices' layout is refused otherwise)
 }
 __global__ void __launch_bounds__(256) agx_k_emit_ovf(agx_compact_args A, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap) {
     AGX_RETURN_IF_ABORTED(A.abort);
@@ -432,10 +455,11 @@ void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;
     // a multiple of the XCD count so that every XCD's share has the same number of blocks (blocks past the last tile do nothing)
     const agx_u32 nb = (n + AGX_SWEEP_WAVES - 1) / AGX_SWEEP_WAVES, grid = (nb + AGX_XCDS - 1) / AGX_XCDS * AGX_XCDS;
-    if (n) hipLaunchKernelGGL(agx_k_node_sweep<false>, dim3(grid), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
+    if (n) hipLaunchKernelGGL(agx_k_node_sweep<0>, dim3(grid), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
 }
 void agx_launch_node_sweep_big(const agx_node_kargs *K, hipStream_t st) {
-    hipLaunchKernelGGL(agx_k_node_sweep<true>, dim3(AGX_BIG_WAVES / AGX_SWEEP_WAVES), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
+    hipLaunchKernelGGL(agx_k_node_sweep<1>, dim3(AGX_MID_WAVES / AGX_SWEEP_WAVES), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
+    hipLaunchKernelGGL(agx_k_node_sweep<2>, dim3(AGX_BIG_WAVES / AGX_SWEEP_WAVES), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
 }
 void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;
@@ -458,9 +482,12 @@ void agx_launch_edge_slow(const agx_edge_kargs *K, hipStream_t st) {
     if (K->S.n_tiles) hipLaunchKernelGGL(agx_k_edge_slow, dim3((unsigned)blocks), dim3(256), 0, st, *K);
 }
 
-void agx_launch_compact(const agx_compact_args *A, const agx_u32 *n_nodes_dev, agx_u32 pool_cap, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t st) {
+void agx_launch_pool_sum(const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, hipStream_t st) {
+    if (regions) hipLaunchKernelGGL(agx_k_pool_sum, dim3((regions + 255) / 256), dim3(256), 0, st, pool_cnt, regions, sum);
+}
+void agx_launch_compact(const agx_compact_args *A, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t st) {
     if (A->n_pos) hipLaunchKernelGGL(agx_k_assign_aid, dim3((A->n_pos + 255) / 256), dim3(256), 0, st, *A);
-    if (pool_cap) hipLaunchKernelGGL(agx_k_emit_alive, dim3((pool_cap + 255) / 256), dim3(256), 0, st, *A, n_nodes_dev);
+    if (A->n_pos) hipLaunchKernelGGL(agx_k_emit_alive, dim3((A->n_pos + 255) / 256), dim3(256), 0, st, *A);
     if (ovf_cap) hipLaunchKernelGGL(agx_k_emit_ovf, dim3((ovf_cap + 255) / 256), dim3(256), 0, st, *A, n_ovf_dev, ovf_cap);
 }
 void agx_launch_mark_list(const agx_u32 *list, agx_u32 n, agx_u8 *mark, hipStream_t st) {

@@ -97,6 +97,7 @@ typedef struct {
     uint32_t node_sweep_launches, edge_sweep_launches;
     uint64_t n_walk_ids, n_special, n_fetched, download_bytes;   /* walk graph: ids, node records downloaded, records fetched one by one, D2H bytes */
     double ms_edge_fast, ms_edge_slow;                           /* the two kernels of ms_edge_sweep: pass A (lanes = positions), pass B (lanes = hits) */
+    uint64_t n_mid_tiles;                                        /* tiles swept again with wider LDS buckets (n_big_tiles: of those, again with global scratch) */
 } agx_stats;
 
 /* Node/edge tables in canonical numbering (position-major, variant order), for parity tests. malloc'd; free with agx_graph_free. */

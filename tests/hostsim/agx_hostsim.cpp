@@ -139,7 +139,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     agx_compact_args C; memset(&C, 0, sizeof C);
     S.side_start.assign((size_t)n_pos + 1, 0); S.aid_of.assign((size_t)S.n_nodes + 1, AGX_NONE);      // (side_cnt was written with the nodes)
     C.node_start = S.node_start.data(); C.node_cnt = S.node_cnt.data(); C.n_flags = S.flags.data(); C.n_base = S.base.data(); C.n_xpos = S.xpos.data();
-    C.nk_off0 = S.off0.data(); C.n_sref = S.sref.data(); C.n_next = S.next.data(); C.ref = T.ref.data(); C.n_pos = n_pos; C.n_nodes = S.n_nodes;
+    C.nk_off0 = S.off0.data(); C.n_sref = S.sref.data(); C.n_next = S.next.data(); C.ref = T.ref.data(); C.n_pos = n_pos;
     C.side_start = S.side_start.data(); C.aid_of = S.aid_of.data();
     agx_u32 run = 0; for (agx_u32 x = 0; x <= n_pos; x++) { S.side_start[x] = run; run += S.side_cnt[x]; }
     S.n_ids = n_pos + run;
@@ -154,7 +154,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     C.sparse_min = getenv("AGX_SIM_SPARSE_MIN") ? 1u : 0u;
     for (agx_u32 p : T.chain_end_pos) S.a_mark[p] = 1;                               // agx_k_mark_list
     for (agx_u32 x = 0; x < n_pos; x++) agx_assign_aid_pos(C, x);
-    for (agx_u32 v = 0; v < S.n_nodes; v++) agx_emit_alive_node(C, v);
+    for (agx_u32 X = 0; X < n_pos; X++) agx_emit_alive_pos(C, X);
     for (agx_u32 i = 0; i < C.n_ovf; i++) agx_emit_alive_ovf(C, i);
     // sparse record table: bitmap words, rank scan, gather (agx_k_special_bits / scan / agx_k_special_emit)
     const agx_u32 n_words = S.n_ids / 64 + 1;
