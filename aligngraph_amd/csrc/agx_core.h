@@ -293,7 +293,9 @@ struct agx_sweep_args {
     agx_u32 *node_start;          // [n_pos]
     agx_u8 *node_cnt;             // [n_pos]
     agx_u8 *pos_succ;             // [n_pos] bit 0: some arrival at x steps to x+1 (written by the node sweep, read by the edge build)
-    agx_u32 *side_cnt;            // [n_pos] surviving variants beyond the first (input of the walk preparation's scan), written with the nodes
+    agx_u32 *side_pk;             // [n_pos] written with the nodes: surviving variants beyond the first ("side ids") of this position << 16 | side ids of the
+                                  // tile's earlier positions; tile_side[tile] = side ids of the whole tile (input of the walk preparation's scan)
+    agx_u32 *tile_side;
     agx_u32 *nk_cid, *nk_coff, *nk_cid0, *nk_coff0, *nk_off0;   // [pool]
     agx_u32 *n_xpos;              // position of each node (the walk follows edges by node id)
     agx_u8 *n_base, *n_flags;     // consensus base ('X' = none: use the reference base, AG:1997-2001), AGX_NF_*
@@ -483,9 +485,10 @@ AGX_HD char agx_consensus(agx_u32 a, agx_u32 c, agx_u32 g, agx_u32 t, agx_u32 n)
 // edges != 0: the sweep's edge matrix is complete for this position (the next position lies in the same tile, both buckets stayed within
 // AGX_EM_W variants): its x -> x+1 edges are written here — bn is the next position's bucket, [nbase, nbase+ncnt) its node ids — after the
 // contig-consistency test between the two stored keys (AG:1602-1615), and bit 7 of pos_succ tells the edge passes so.
-AGX_HD void agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bucket &b, agx_u32 cnt, agx_u32 base, agx_u32 pflag,
-                                bool edges, agx_u32 emask, const agx_bucket &bn, agx_u32 nbase, agx_u32 ncnt) {
-    if (X >= A.n_pos) return;
+// Returns the position's side ids (surviving variants beyond the first); the caller turns them into side_pk / tile_side.
+AGX_HD agx_u32 agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bucket &b, agx_u32 cnt, agx_u32 base, agx_u32 pflag,
+                                   bool edges, agx_u32 emask, const agx_bucket &bn, agx_u32 nbase, agx_u32 ncnt) {
+    if (X >= A.n_pos) return 0;
     A.node_start[X] = base; A.node_cnt[X] = (agx_u8)cnt; A.pos_succ[X] = (agx_u8)(pflag | (edges ? 0x80u : 0u));
     agx_u32 alive = 0;
     for (agx_u32 v = 0; v < cnt; v++) {
@@ -513,8 +516,9 @@ AGX_HD void agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bu
         for (agx_u32 e = 0; e < AGX_MAXE; e++) A.n_next[(size_t)id * AGX_MAXE + e] = slot[e];
         if (A.n_counts) { int *c = A.n_counts + (size_t)id * 6; c[0] = (int)cov; c[1] = (int)va; c[2] = (int)vc; c[3] = (int)vg; c[4] = (int)vt; c[5] = (int)vn; }
     }
-    A.side_cnt[X] = alive ? alive - 1 : 0;          // walk ids: the first surviving variant takes the position's main id, the others go to the side block
+    return alive ? alive - 1 : 0;                   // walk ids: the first surviving variant takes the position's main id, the others go to the side block
 }
+AGX_HD agx_u32 agx_side_pack(agx_u32 before_in_tile, agx_u32 here) { return before_in_tile | (here << 16); }
 
 // ---- edge sweep (AG:1589-1623) ---------------------------------------------------------------------------------
 
@@ -725,7 +729,8 @@ struct agx_compact_args {
     const agx_u32 *node_start; const agx_u8 *node_cnt; const agx_u8 *n_flags; const agx_u8 *n_base; const agx_u32 *n_xpos;
     const agx_u32 *nk_off0; const agx_sref *n_sref; const agx_u32 *n_next; const char *ref;
     agx_u32 n_pos;
-    const agx_u32 *side_start;     // [n_pos+1] exclusive scan of side_cnt
+    const agx_u32 *side_pk;        // [n_pos] agx_side_pack
+    const agx_u32 *tile_side_start; // [n_tiles+1] exclusive scan of tile_side: side ids of all earlier tiles
     agx_u32 *aid_of;               // [pool] walk id or NONE
     // outputs indexed by aid, [n_pos + n_side]
     char *a_str; agx_u8 *a_meta; agx_walknode *a_node;   // a_meta: AGX_WM_* bits
@@ -743,7 +748,7 @@ struct agx_compact_args {
 // per position, after the scan: walk ids of its nodes; main slots without an alive node are marked absent (= visited from the start)
 AGX_HD void agx_assign_aid_pos(const agx_compact_args &A, agx_u32 X) {
     if (X >= A.n_pos) return;
-    const agx_u32 s = A.node_start[X], n = A.node_cnt[X]; agx_u32 side = A.n_pos + A.side_start[X]; bool first = true;
+    const agx_u32 s = A.node_start[X], n = A.node_cnt[X]; agx_u32 side = A.n_pos + A.tile_side_start[X / AGX_TILE] + (A.side_pk[X] & 0xFFFFu); bool first = true;
     for (agx_u32 v = 0; v < n; v++) {
         if (A.n_flags[s + v] & AGX_NF_DEAD) { A.aid_of[s + v] = AGX_NONE; continue; }
         if (first) { A.aid_of[s + v] = X; first = false; } else A.aid_of[s + v] = side++;
@@ -770,7 +775,7 @@ AGX_HD void agx_emit_alive_node(const agx_compact_args &A, agx_u32 v) {
     // by never being `cont`; the host consults the overflow list for every node it finds there
     const bool cont = k == 1 && !(A.n_flags[v] & AGX_NF_EOVF) && w.next[0] == a + 1;
     agx_u8 m = (agx_u8)((cont ? AGX_WM_CONT : 0) | ((A.n_flags[v] & AGX_NF_CONTIG) ? AGX_WM_CONTIG : 0));
-    if (a < A.n_pos) m |= (agx_u8)(AGX_WM_ANY | (A.side_start[x + 1] > A.side_start[x] ? AGX_WM_SIDE : 0));
+    if (a < A.n_pos) m |= (agx_u8)(AGX_WM_ANY | ((A.side_pk[x] >> 16) ? AGX_WM_SIDE : 0));
     else A.side_xpos[a - A.n_pos] = x;
     A.a_meta[a] = m;
     if (!cont) for (agx_u32 e = 0; e < k; e++) A.a_mark[w.next[e]] = 1;      // racing stores of the same value

@@ -43,11 +43,15 @@ template <class T> struct PBuf {            // pinned host buffer
     PBuf() = default; PBuf(const PBuf &) = delete; PBuf &operator=(const PBuf &) = delete;
 };
 
-struct EventPair {
-    hipEvent_t a = nullptr, b = nullptr; bool used = false;
-    void init() { HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); }
-    void destroy() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); a = b = nullptr; }
-    double ms() const { if (!used) return 0; float f = 0; (void)hipEventElapsedTime(&f, a, b); return f; }
+// Section boundaries of a build on the unit's stream: the end of one section is the start of the next (one record instead of two: an
+// event record costs the stream about as much as a small kernel).
+enum { B_START = 0, B_PREP, B_BIN, B_NODE, B_BIG, B_EDGE, B_SLOW, B_COMPACT, B_N };
+struct Boundaries {
+    hipEvent_t e[B_N] = {}; bool used = false;
+    void init() { for (auto &x : e) HIP_OK(hipEventCreate(&x)); }
+    void destroy() { for (auto &x : e) { if (x) (void)hipEventDestroy(x); x = nullptr; } }
+    void mark(int b, hipStream_t st) { HIP_OK(hipEventRecord(e[b], st)); }
+    double ms(int b) const { if (!used) return 0; float f = 0; (void)hipEventElapsedTime(&f, e[b - 1], e[b]); return f; }      // section that ends at boundary b
 };
 
 }  // namespace
@@ -66,12 +70,12 @@ struct agx_unit {
     // node table
     agx_u32 pool_cap = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
     DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
-    DBuf<agx_u32> d_node_start, d_slow_list, d_rank4, d_perm; DBuf<agx_u8> d_node_cnt, d_pos_succ, d_multi_run;
+    DBuf<agx_u32> d_node_start, d_slow_list, d_rank4, d_perm; DBuf<agx_u8> d_node_cnt, d_pos_succ; DBuf<agx_u32> d_jump_list; agx_u32 n_jump = 0;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch;
     // walk graph (agx_core.h "walk preparation")
     agx_u32 n_ids = 0;
-    DBuf<agx_u32> d_side_cnt, d_side_start, d_aid_of; DBuf<char> d_a_str;
+    DBuf<agx_u32> d_side_pk, d_tile_side, d_tile_side_start, d_aid_of; DBuf<char> d_a_str;
     DBuf<agx_u8> d_a_meta, d_a_mark; DBuf<agx_walknode> d_a_node, d_sp_node; DBuf<agx_edge_ovf> d_a_ovf;
     DBuf<agx_u32> d_chain_end, d_side_xpos, d_sp_cnt, d_sp_rank; DBuf<unsigned long long> d_sp_bits; DBuf<agx_hop> d_hop, d_sp_hop;
     agx_u32 n_chain_end = 0, n_special = 0, n_words = 0;
@@ -80,20 +84,19 @@ struct agx_unit {
     PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_hop> h_sp_hop; PBuf<agx_edge_ovf> h_a_ovf;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
-    EventPair ev_prep, ev_bin, ev_node, ev_big, ev_edge, ev_slow, ev_compact;
+    Boundaries ev; hipEvent_t ev_done = nullptr;      // recorded on the device's build stream behind the unit's last kernel
     agx_stats stats{};
-    ~agx_unit() { ev_prep.destroy(); ev_bin.destroy(); ev_node.destroy(); ev_big.destroy(); ev_edge.destroy(); ev_slow.destroy(); ev_compact.destroy(); if (st) (void)hipStreamDestroy(st); }
+    ~agx_unit() { ev.destroy(); if (ev_done) (void)hipEventDestroy(ev_done); if (st) (void)hipStreamDestroy(st); }
 };
 
 namespace {
 
-// One build at a time per device, on the GPU as well as in the launch order: every build's first kernel waits (stream-side) for the
-// event the previous build recorded behind its last kernel, so units built from several host threads run their kernel chains back to
-// back without host round trips in between, and per-kernel HIP-event times stay those of an exclusive device.  Copies to the host
-// (download, record fetches) are not part of the turn and overlap the next unit's kernels.
-struct DeviceTurn { std::mutex m; hipEvent_t last = nullptr, last_sweeps = nullptr; };
-// AGX_OVERLAP_PREP=1 (experiment): the next unit's sweeps may start while this unit's walk-preparation kernels still run
-static const bool g_overlap_prep = getenv("AGX_OVERLAP_PREP") != nullptr;
+// One build at a time per device, on the GPU as well as in the launch order: all builds of a device are queued on ONE stream, under a
+// mutex that a host thread holds only while it enqueues its unit's kernel chain.  Units built from several host threads then run their
+// chains back to back — no host round trip and no cross-stream event wait in between (a stream-side wait on another stream's event
+// costs tens of microseconds per build here) — and per-kernel HIP-event times stay those of an exclusive device.  Uploads and copies to
+// the host (counter words, download, record fetches) use the unit's own stream and overlap the next unit's kernels.
+struct DeviceTurn { std::mutex m; hipStream_t build = nullptr; };
 DeviceTurn &turn_of(int device) { static DeviceTurn turns[64]; return turns[device & 63]; }
 
 // AGX_DEBUG_SYNC=1: synchronise after every launch group of a build and name it on stderr — a memory fault then points at its kernel
@@ -108,7 +111,7 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     S.dhit = u->d_dhit.p; S.runs = u->d_runs.p; S.vcodes = reinterpret_cast<const agx_u8 *>(u->d_bases.p); S.stride = u->P.stride;
     S.tile_off = u->d_tile_off.p; S.tile_recs = (decltype(S.tile_recs))u->d_tile_recs.p;
     S.n_pos = (agx_u32)u->T.ref.size(); S.n_tiles = u->n_tiles; S.k = u->prm.k; S.iv = (int)u->prm.insert_variation; S.coverage = (int)u->prm.coverage;
-    S.node_start = u->d_node_start.p; S.node_cnt = u->d_node_cnt.p; S.pos_succ = u->d_pos_succ.p; S.side_cnt = u->d_side_cnt.p;
+    S.node_start = u->d_node_start.p; S.node_cnt = u->d_node_cnt.p; S.pos_succ = u->d_pos_succ.p; S.side_pk = u->d_side_pk.p; S.tile_side = u->d_tile_side.p;
     S.nk_cid = u->d_cid.p; S.nk_coff = u->d_coff.p; S.nk_cid0 = u->d_cid0.p; S.nk_coff0 = u->d_coff0.p; S.nk_off0 = u->d_off0.p;
     S.n_xpos = u->d_xpos.p; S.n_base = u->d_base.p; S.n_flags = u->d_flags.p; S.n_sref = u->d_sref.p; S.n_next = u->d_next.p;
     S.n_counts = (u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? u->d_counts.p : nullptr;
@@ -157,12 +160,18 @@ void do_upload(agx_unit *u) {
     u->d_cm_head.alloc(n_pos + 1);
     agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, (agx_u32)n_pos, u->st);
     const size_t nh = u->P.hits.size();
-    u->d_hits.alloc(nh + 1); u->d_runs.alloc(u->P.runs.size() + 1); u->d_bases.alloc(u->P.bases.size() + 16); u->d_dhit.alloc(nh + 1); u->d_multi_run.alloc(nh + 1); u->d_rank4.alloc(4 * ((size_t)nh + 1));
+    u->d_hits.alloc(nh + 1); u->d_runs.alloc(u->P.runs.size() + 1); u->d_bases.alloc(u->P.bases.size() + 16); u->d_dhit.alloc(nh + 1); u->d_rank4.alloc(4 * ((size_t)nh + 1));
     if (nh) HIP_OK(hipMemcpyAsync(u->d_hits.p, u->P.hits.data(), nh * sizeof(agx_hit), hipMemcpyHostToDevice, u->st));
     if (!u->P.runs.empty()) HIP_OK(hipMemcpyAsync(u->d_runs.p, u->P.runs.data(), u->P.runs.size() * sizeof(agx_run), hipMemcpyHostToDevice, u->st));
     if (!u->P.bases.empty()) {              // the device copy holds vote codes (agx_vote_code), translated in place; the characters stay on the host for the walk
         HIP_OK(hipMemcpyAsync(u->d_bases.p, u->P.bases.data(), u->P.bases.size(), hipMemcpyHostToDevice, u->st));
         agx_launch_vote_codes(u->d_bases.p, (u->P.bases.size() + 15) / 16 * 16, u->st);
+    }
+    {   // hits with a mate of several runs: the edge build's pass J starts from this list
+        std::vector<agx_u32> jl;
+        for (size_t h = 0; h < nh; h++) if (u->P.hits[h].nruns1 >= 2 || u->P.hits[h].nruns2 >= 2) jl.push_back((agx_u32)h);
+        u->n_jump = (agx_u32)jl.size(); u->d_jump_list.alloc(jl.size() + 1);
+        if (!jl.empty()) HIP_OK(hipMemcpyAsync(u->d_jump_list.p, jl.data(), jl.size() * 4, hipMemcpyHostToDevice, u->st));
     }
     u->n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
     {   // hit ids sorted by the tile their left end falls into (counting sort): agx_k_hit_prep walks them in this order so that the hits
@@ -181,7 +190,7 @@ void do_upload(agx_unit *u) {
     u->d_tile_cnt.alloc((size_t)u->n_tiles + 1); u->d_tile_off.alloc((size_t)u->n_tiles + 2); u->d_cursor.alloc((size_t)u->n_tiles + 1);
     const size_t nb = ((size_t)n_pos + 1 + 1023) / 1024;              // sized for the longer of the two scans (positions)
     u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16);
-    u->d_words.alloc(W_N); u->h_words.alloc(W_N + 4); u->h_fetch.alloc(2 * (n_pos / 1000 + 2));
+    u->d_words.alloc(W_N + 4); u->h_words.alloc(W_N + 4); u->h_fetch.alloc(2 * (n_pos / 1000 + 2));
     if (u->T.hop.size() != n_pos) throw Error{E_ARG, "conti-mer chains were not built"};
     u->d_hop.alloc(n_pos + 1);
     HIP_OK(hipMemcpy(u->d_hop.p, u->T.hop.data(), n_pos * sizeof(agx_hop), hipMemcpyHostToDevice));
@@ -210,7 +219,7 @@ void do_build(agx_unit *u) {
     if (!u->uploaded) do_upload(u);
     HIP_OK(hipSetDevice(u->prm.device));
     const agx_u32 n_pos = (agx_u32)u->T.ref.size(), nh = (agx_u32)u->P.hits.size();
-    hipStream_t st = u->st;
+    hipStream_t st = nullptr;              // the device's build stream, taken with the turn
     u->stats.node_sweep_launches = u->stats.edge_sweep_launches = 0;
     if (u->list_cap == 0) u->list_cap = (agx_u32)std::min<size_t>(getenv("AGX_TEST_SMALL_CAPS") ? (size_t)nh / 2 + 16 : (size_t)nh * 3 + 1024, 0xFFFFFF00ull);
     u->d_big_list.alloc((size_t)u->n_tiles + 1); u->d_mid_list.alloc((size_t)u->n_tiles + 1);
@@ -221,7 +230,7 @@ void do_build(agx_unit *u) {
         u->d_aid_of.alloc((size_t)u->pool_cap + 1);
         const size_t ids_cap = (size_t)n_pos + u->pool_cap;                       // side variants <= nodes <= pool_cap
         u->d_a_str.alloc(ids_cap + 1); u->d_a_meta.alloc(ids_cap + 16); u->d_a_node.alloc(ids_cap + 1); u->d_a_ovf.alloc((size_t)u->ovf_cap + 1);
-        u->d_side_cnt.alloc((size_t)n_pos + 2); u->d_side_start.alloc((size_t)n_pos + 2);
+        u->d_side_pk.alloc((size_t)n_pos + 2); u->d_tile_side.alloc((size_t)u->n_tiles + 2); u->d_tile_side_start.alloc((size_t)u->n_tiles + 2);
         u->n_words = (agx_u32)(ids_cap / 64 + 1);
         u->d_a_mark.alloc(ids_cap + 2); u->d_side_xpos.alloc((size_t)u->pool_cap + 1);
         if (u->sp_cap == 0) u->sp_cap = (agx_u32)std::min<size_t>(getenv("AGX_TEST_SMALL_CAPS") ? 32 : ids_cap / 4 + 4096, 0xFFFFFF00ull);      // special ids: 8 % on the bench unit
@@ -232,82 +241,76 @@ void do_build(agx_unit *u) {
 
         DeviceTurn &turn = turn_of(u->prm.device);
         std::unique_lock<std::mutex> my_turn(turn.m);
-        if (!turn.last) { HIP_OK(hipEventCreateWithFlags(&turn.last, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&turn.last_sweeps, hipEventDisableTiming)); HIP_OK(hipEventRecord(turn.last, st)); HIP_OK(hipEventRecord(turn.last_sweeps, st)); }
-        HIP_OK(hipStreamWaitEvent(st, g_overlap_prep ? turn.last_sweeps : turn.last, 0));
-        HIP_OK(hipMemsetAsync(u->d_words.p, 0, W_N * 4, st));
-        HIP_OK(hipMemsetAsync(u->d_tile_cnt.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
-        HIP_OK(hipMemsetAsync(u->d_cursor.p, 0, ((size_t)u->n_tiles + 1) * 4, st));
-        HIP_OK(hipMemsetAsync(u->d_pool_cnt.p, 0, (size_t)u->n_regions * AGX_REGION_PAD * 4, st));
+        if (!turn.build) HIP_OK(hipStreamCreateWithFlags(&turn.build, hipStreamNonBlocking));
+        st = turn.build;
+        {   // everything a build counts into or marks, zeroed by one kernel and one fill (every command on the stream costs a few microseconds)
+            agx_zero_args Z; memset(&Z, 0, sizeof Z);
+            auto seg = [&](int i, agx_u32 *ptr, size_t words) { Z.p[i] = ptr; Z.n[i] = (agx_u32)words; };
+            seg(0, u->d_words.p, W_N + 4); seg(1, u->d_tile_cnt.p, (size_t)u->n_tiles + 1); seg(2, u->d_cursor.p, (size_t)u->n_tiles + 1);
+            seg(3, u->d_pool_cnt.p, (size_t)u->n_regions * AGX_REGION_PAD); seg(4, u->d_tile_side.p + u->n_tiles, 1); seg(5, u->d_sp_cnt.p + u->n_words, 1);
+            agx_launch_zero(&Z, st);
+            HIP_OK(hipMemsetAsync(u->d_a_mark.p, 0, ids_cap + 2, st));
+        }
         // ---- hit_prep + tile histogram ----
-        HIP_OK(hipEventRecord(u->ev_prep.a, st));
-        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_perm.p, u->d_tile_cnt.p, u->d_words.p + W_ERR, u->d_multi_run.p, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
+        u->ev.mark(B_START, st);
+        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_perm.p, u->d_tile_cnt.p, u->d_words.p + W_ERR, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
         agx_launch_hit_prep(&PA, st);
         AGX_CHECKPOINT("hit_prep");
-        HIP_OK(hipEventRecord(u->ev_prep.b, st)); u->ev_prep.used = true;
+        u->ev.mark(B_PREP, st);
         // ---- tile lists ----
-        HIP_OK(hipEventRecord(u->ev_bin.a, st));
         agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
         agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, (const uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
         agx_launch_bin_fill(&BA, st);
         agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, st);
         AGX_CHECKPOINT("tile_sort");
-        HIP_OK(hipEventRecord(u->ev_bin.b, st)); u->ev_bin.used = true;
+        u->ev.mark(B_BIN, st);
         // ---- node sweep: every tile with small LDS buckets, then the tiles that overflowed with wider ones, then with global scratch (device-side lists) ----
         agx_node_kargs K; fill_sweep_args(u, K.S);
         K.pool_cnt = u->d_pool_cnt.p; K.region_off = u->d_region_off.p; K.mid_count = u->d_words.p + W_MIDCOUNT; K.mid_list = u->d_mid_list.p; K.mid_n = u->d_words.p + W_MIDCOUNT;
         K.big_count = u->d_words.p + W_BIGCOUNT; K.big_list = u->d_big_list.p; K.status = u->d_words.p + W_STATUS;
         K.list_cap = u->list_cap; K.big_n = u->d_words.p + W_BIGCOUNT; K.scratch = u->d_scratch.p;
         K.slow_list = u->d_slow_list.p; K.slow_count = u->d_words.p + W_SLOWCOUNT;
-        HIP_OK(hipEventRecord(u->ev_node.a, st));
         agx_launch_node_sweep(&K, st);
         AGX_CHECKPOINT("node_sweep");
-        HIP_OK(hipEventRecord(u->ev_node.b, st)); u->ev_node.used = true; u->stats.node_sweep_launches++;
-        HIP_OK(hipEventRecord(u->ev_big.a, st));
+        u->ev.mark(B_NODE, st); u->stats.node_sweep_launches++;
         agx_launch_node_sweep_big(&K, st);
         AGX_CHECKPOINT("node_sweep_big");
         agx_launch_pool_sum(u->d_pool_cnt.p, u->n_regions, u->d_words.p + W_POOL, st);
-        HIP_OK(hipEventRecord(u->ev_big.b, st)); u->ev_big.used = true;
+        u->ev.mark(B_BIG, st);
         // ---- edge sweep ----
         agx_edge_kargs E; fill_sweep_args(u, E.S); E.ovf = u->d_ovf.p; E.ovf_count = u->d_words.p + W_OVFCOUNT; E.ovf_cap = u->ovf_cap; E.list_cap = u->list_cap;
-        E.multi_run = u->d_multi_run.p; E.abort = u->d_words.p + W_STATUS; E.big_list = u->d_big_list.p; E.big_n = u->d_words.p + W_BIGCOUNT; E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
-        HIP_OK(hipEventRecord(u->ev_edge.a, st));
+        E.jump_list = u->d_jump_list.p; E.n_jump = u->n_jump; E.abort = u->d_words.p + W_STATUS; E.big_list = u->d_big_list.p; E.big_n = u->d_words.p + W_BIGCOUNT; E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
         agx_launch_edge_sweep(&E, st);
         AGX_CHECKPOINT("edge_sweep");
-        agx_launch_edge_jump(&E, nh, st);
+        agx_launch_edge_jump(&E, st);
         AGX_CHECKPOINT("edge_jump");
-        HIP_OK(hipEventRecord(u->ev_edge.b, st)); u->ev_edge.used = true; u->stats.edge_sweep_launches++;
-        HIP_OK(hipEventRecord(u->ev_slow.a, st));
+        u->ev.mark(B_EDGE, st); u->stats.edge_sweep_launches++;
         agx_launch_edge_slow(&E, st);
         AGX_CHECKPOINT("edge_slow");
-        HIP_OK(hipEventRecord(u->ev_slow.b, st)); u->ev_slow.used = true;
+        u->ev.mark(B_SLOW, st);
         // ---- walk preparation: side counts -> scan -> walk ids, node records, rewritten edges, forced-run flags ----
         agx_compact_args C; memset(&C, 0, sizeof C);
         C.node_start = u->d_node_start.p; C.node_cnt = u->d_node_cnt.p; C.n_flags = u->d_flags.p; C.n_base = u->d_base.p; C.n_xpos = u->d_xpos.p;
         C.nk_off0 = u->d_off0.p; C.n_sref = u->d_sref.p; C.n_next = u->d_next.p; C.ref = u->d_ref.p; C.n_pos = n_pos;
-        C.side_start = u->d_side_start.p; C.aid_of = u->d_aid_of.p;
+        C.side_pk = u->d_side_pk.p; C.tile_side_start = u->d_tile_side_start.p; C.aid_of = u->d_aid_of.p;
         C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_node = u->d_a_node.p; C.ovf = u->d_ovf.p; C.n_ovf = 0; C.a_ovf = u->d_a_ovf.p;
-        HIP_OK(hipEventRecord(u->ev_compact.a, st));
         C.abort = u->d_words.p + W_STATUS;
         C.a_mark = u->d_a_mark.p; C.side_xpos = u->d_side_xpos.p; C.sparse_min = (u->prm.flags & AGX_FLAG_SPARSE_MIN) ? 1u : 0u;
         C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p; C.hop = u->d_hop.p; C.sp_hop = u->d_sp_hop.p; C.sp_cap = u->sp_cap;
-        HIP_OK(hipMemsetAsync(u->d_side_cnt.p + n_pos, 0, 4, st));
-        HIP_OK(hipMemsetAsync(u->d_a_mark.p, 0, ids_cap + 2, st));
-        HIP_OK(hipMemsetAsync(u->d_sp_cnt.p + u->n_words, 0, 4, st));
-        agx_launch_exclusive_scan(u->d_side_cnt.p, u->d_side_start.p, n_pos, u->d_scan_tmp.p, st);
+        agx_launch_exclusive_scan(u->d_tile_side.p, u->d_tile_side_start.p, u->n_tiles, u->d_scan_tmp.p, st);      // per tile: the sweep has scanned inside the tiles
         agx_launch_mark_list(u->d_chain_end.p, u->n_chain_end, u->d_a_mark.p, st);
         agx_launch_compact(&C, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
         AGX_CHECKPOINT("compact");
         agx_launch_special(&C, u->n_words, u->d_sp_rank.p, u->d_scan_tmp.p, st);
         AGX_CHECKPOINT("special");
-        HIP_OK(hipEventRecord(u->ev_compact.b, st)); u->ev_compact.used = true;
+        u->ev.mark(B_COMPACT, st); u->ev.used = true;
         // ---- the one synchronisation ----
-        HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, W_N * 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_words.p + W_N, u->d_tile_off.p + u->n_tiles, 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_words.p + W_N + 1, u->d_side_start.p + n_pos, 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_words.p + W_N + 2, u->d_sp_rank.p + u->n_words, 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipEventRecord(turn.last, st));
+        agx_launch_collect(u->d_words.p + W_N, u->d_tile_off.p + u->n_tiles, u->d_tile_side_start.p + u->n_tiles, u->d_sp_rank.p + u->n_words, st);
+        HIP_OK(hipEventRecord(u->ev_done, st));
         my_turn.unlock();
-        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipStreamWaitEvent(u->st, u->ev_done, 0));
+        HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, (W_N + 4) * 4, hipMemcpyDeviceToHost, u->st));
+        HIP_OK(hipStreamSynchronize(u->st));
         HIP_OK(hipGetLastError());
         const agx_u32 *w = u->h_words.p;
         if (w[W_ERR] & 1u) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
@@ -341,8 +344,8 @@ void do_build(agx_unit *u) {
         break;
     }
     u->built = true; u->downloaded = false;
-    u->stats.ms_prep = u->ev_prep.ms(); u->stats.ms_bin = u->ev_bin.ms(); u->stats.ms_node_sweep = u->ev_node.ms();
-    u->stats.ms_node_big = u->ev_big.ms(); u->stats.ms_edge_fast = u->ev_edge.ms(); u->stats.ms_edge_slow = u->ev_slow.ms(); u->stats.ms_edge_sweep = u->stats.ms_edge_fast + u->stats.ms_edge_slow; u->stats.ms_compact = u->ev_compact.ms();
+    u->stats.ms_prep = u->ev.ms(B_PREP); u->stats.ms_bin = u->ev.ms(B_BIN); u->stats.ms_node_sweep = u->ev.ms(B_NODE);
+    u->stats.ms_node_big = u->ev.ms(B_BIG); u->stats.ms_edge_fast = u->ev.ms(B_EDGE); u->stats.ms_edge_slow = u->ev.ms(B_SLOW); u->stats.ms_edge_sweep = u->stats.ms_edge_fast + u->stats.ms_edge_slow; u->stats.ms_compact = u->ev.ms(B_COMPACT);
 }
 
 void do_download(agx_unit *u) {
@@ -442,7 +445,7 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
     const int rc = guarded(u, [&] {
         HIP_OK(hipSetDevice(p->device));
         HIP_OK(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
-        u->ev_prep.init(); u->ev_bin.init(); u->ev_node.init(); u->ev_big.init(); u->ev_edge.init(); u->ev_slow.init(); u->ev_compact.init();
+        u->ev.init(); HIP_OK(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming));
     });
     if (rc != AGX_OK) { delete u; return rc; }
     *out = u;

@@ -8,7 +8,6 @@ struct agx_prep_args {
     const agx_u32 *perm;      // [n_hits] hit ids sorted by the tile of their left end (upload time)
     agx_u32 *tile_cnt;        // [n_tiles] number of hits overlapping each tile
     agx_u32 *err;             // bit 0: same-strand mates; bit 1: alignment beyond the unit sequence
-    agx_u8 *multi_run;        // [n_hits] 1: a kept hit whose a mate has several runs (the only hits the edge build's pass J looks at)
     uint4 *rank4;             // [n_hits] what the histogram's atomicAdd returned for the hit's first four tiles = its slot in each tile's list
     agx_u32 *rank_overflow;   // set when some hit spans more than four tiles: the lists are then filled with a second round of atomics
 };
@@ -33,13 +32,18 @@ struct agx_node_kargs {
 struct agx_edge_kargs {
     agx_sweep_args S; agx_edge_ovf *ovf; agx_u32 *ovf_count; agx_u32 ovf_cap; agx_u32 list_cap;
     agx_u32 *slow_list; agx_u32 *slow_count;   // positions that need the per-hit pass (device-side list)
-    const agx_u8 *multi_run;                   // [n_hits] from hit_prep
+    const agx_u32 *jump_list; agx_u32 n_jump;  // hits with a mate of several runs (upload time): the only hits the edge build's pass J looks at
     const agx_u32 *abort;                      // the node sweeps' status word: non-zero = the node table is incomplete, do nothing
     const agx_u32 *big_list; const agx_u32 *big_n;   // tiles the fallback pass wrote (their edges are all pass A/B's)
 };
 #define AGX_SLOW_WAVES 8192u    // wavefronts of the per-hit edge pass if the occupancy query fails (normally: as many as are resident at once)
 
 extern "C" {
+// one kernel that zeroes up to eight u32 ranges
+struct agx_zero_args { agx_u32 *p[8]; agx_u32 n[8]; };
+void agx_launch_zero(const agx_zero_args *, hipStream_t);
+// the three totals the host wants next to the counter words: out[0..2] = *a, *b, *c
+void agx_launch_collect(agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *c, hipStream_t);
 void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t);      // n_pos + 1 heads
 void agx_launch_vote_codes(void *blob, size_t n_bytes16, hipStream_t);      // read bases -> agx_vote_code, in place; n_bytes16 a multiple of 16
 void agx_launch_hit_prep(const agx_prep_args *, hipStream_t);
@@ -50,7 +54,7 @@ void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_
 void agx_launch_node_sweep(const agx_node_kargs *, hipStream_t);
 void agx_launch_node_sweep_big(const agx_node_kargs *, hipStream_t);
 void agx_launch_edge_sweep(const agx_edge_kargs *, hipStream_t);                   // pass A (lanes = positions)
-void agx_launch_edge_jump(const agx_edge_kargs *, agx_u32 n_hits, hipStream_t);    // pass J (lanes = hits: steps that skip positions)
+void agx_launch_edge_jump(const agx_edge_kargs *, hipStream_t);    // pass J (lanes = hits: steps that skip positions)
 void agx_launch_edge_slow(const agx_edge_kargs *, hipStream_t);           // pass B (lanes = hits of the slow positions pass A listed)
 // walk preparation (agx_core.h): after the scan of the side counts the node sweep left behind: ids, records and overflow edges
 // n_nodes / n_ovf are read from device memory (the node-pool and overflow counters), so no host round trip separates the sweeps

@@ -32,6 +32,11 @@ __global__ void __launch_bounds__(256) agx_k_cm_head(const agx_u32 *cm_start, co
     const agx_u32 x = blockIdx.x * 256u + threadIdx.x;
     if (x <= n_pos) agx_cm_head_pos(cm_start, cm, head, x, n_pos);
 }
+__global__ void __launch_bounds__(256) agx_k_zero(agx_zero_args Z) {
+    agx_u32 i = blockIdx.x * 256u + threadIdx.x;
+    for (int s = 0; s < 8; s++) { if (i < Z.n[s]) { Z.p[s][i] = 0u; return; } i -= Z.n[s]; }
+}
+__global__ void agx_k_collect(agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *c) { out[0] = *a; out[1] = *b; out[2] = *c; }
 // read bases -> vote codes, in place (16 characters per thread; the blob is padded to a multiple of 16)
 __global__ void __launch_bounds__(256) agx_k_vote_codes(uint4 *blob, size_t n16) {
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
@@ -63,23 +68,28 @@ __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
     }
     const bool kept = mine && !(d.flags & AGX_HF_SKIP);
     const agx_u32 t0 = kept ? d.x_lo / AGX_TILE : 0u, t1 = kept ? d.x_hi / AGX_TILE : 0u;
-    agx_u32 r[4] = {0, 0, 0, 0};
+    // The lanes of a wavefront are in tile order (perm), so the lanes that want the same tile as their s-th one are neighbours: a run
+    // of equal tile numbers.  The first pending lane of every run adds the run's pending lanes to the tile's counter — all runs in the
+    // same atomic instruction, and the four instructions (s = 0..3) back to back: the wavefront waits for one round trip, not for one per
+    // distinct tile.  (Nothing depends on the order: equal tiles that are not neighbours just become two runs.)
+    agx_u32 r[4] = {0, 0, 0, 0}, base[4] = {0, 0, 0, 0}, lead[4] = {0, 0, 0, 0};
+    bool pend[4];
+    const unsigned long long below = (1ull << lane) - 1ull;
     for (agx_u32 s = 0; s < 4; s++) {                                        // the hit's s-th tile
         const agx_u32 t = t0 + s;
-        bool pending = kept && t <= t1;
-        for (;;) {                                                           // one round per distinct tile among the wavefront's pending lanes
-            const unsigned long long m = __ballot(pending);
-            if (!m) break;
-            const int leader = __builtin_ctzll(m);
-            const agx_u32 tl = (agx_u32)__shfl((int)t, leader, 64);
-            const bool same = pending && t == tl;
-            const unsigned long long ms = __ballot(same);
-            agx_u32 base = 0;
-            if ((int)lane == leader) base = atomicAdd(&A.tile_cnt[tl], (agx_u32)__popcll(ms));
-            base = (agx_u32)__shfl((int)base, leader, 64);
-            if (same) { r[s] = base + (agx_u32)__popcll(ms & ((1ull << lane) - 1ull)); pending = false; }
-        }
+        pend[s] = kept && t <= t1;
+        const agx_u32 tp = (agx_u32)__shfl_up((int)t, 1, 64);
+        const unsigned long long starts = __ballot(lane == 0 || t != tp) , pm = __ballot(pend[s]);
+        const agx_u32 first = 63u - (agx_u32)__builtin_clzll(starts & (below | (1ull << lane)));        // first lane of my run
+        const unsigned long long after = starts & ~(below | (1ull << lane));                                 // run starts above me
+        const agx_u32 end = after ? (agx_u32)__builtin_ctzll(after) : 64u;                                    // one past my run
+        const unsigned long long run = (end == 64u ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << first) - 1ull);
+        const unsigned long long p = pm & run;                                                                 // pending lanes of my run
+        lead[s] = p ? (agx_u32)__builtin_ctzll(p) : 0u;
+        r[s] = (agx_u32)__popcll(p & below);
+        if (pend[s] && lane == lead[s]) base[s] = atomicAdd(&A.tile_cnt[t], (agx_u32)__popcll(p));
     }
+    for (agx_u32 s = 0; s < 4; s++) { const agx_u32 bs = (agx_u32)__shfl((int)base[s], (int)lead[s], 64); r[s] = pend[s] ? r[s] + bs : 0u; }
     if (kept && t1 - t0 >= 4) {                                              // spans more than four tiles: count the rest, and tell bin_fill to take its own slots
         for (agx_u32 t = t0 + 4; t <= t1; t++) atomicAdd(&A.tile_cnt[t], 1u);
         atomicOr(A.rank_overflow, 1u);
@@ -87,7 +97,6 @@ __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
     if (!mine) return;
     A.rank4[h] = make_uint4(r[0], r[1], r[2], r[3]);
     A.dhit[h] = d;
-    A.multi_run[h] = (kept && d.a_nruns >= 2) ? 1 : 0;
 }
 
 // ---- exclusive scan of a u32 array (three small kernels up to 16 M elements: blocks, block sums, add) --------------------
@@ -256,7 +265,10 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
         const agx_u32 nbase = (agx_u32)__shfl_down((int)my_base, 1, 64), ncnt = (agx_u32)__shfl_down((int)cnt, 1, 64);
         agx_bucket bn = b; bn.base = b.base + 1;           // the next position's bucket is the next lane's column
         const bool edges = !BIG && lane < 63u && X + 1 < K.S.n_pos && cnt <= AGX_EM_W && ncnt <= AGX_EM_W;
-        agx_node_write_lane(K.S, X, b, cnt, my_base, pflag, edges, emask, bn, nbase, ncnt);
+        const agx_u32 side = agx_node_write_lane(K.S, X, b, cnt, my_base, pflag, edges, emask, bn, nbase, ncnt);
+        const agx_u32 side_incl = agx_wave_incl_scan(side, lane);
+        if (X < K.S.n_pos) K.S.side_pk[X] = agx_side_pack(side_incl - side, side);
+        if (lane == 63u) K.S.tile_side[tile] = side_incl;
         // a multi-variant position whose x -> x+1 edges are done but which also steps elsewhere goes through pass B for those steps
         if (edges && cnt >= 2 && (pflag & 2u)) K.slow_list[atomicAdd(K.slow_count, 1u)] = X;
         if (PASS == 0) return;
@@ -325,12 +337,13 @@ __device__ __forceinline__ void agx_slot_insert(const agx_edge_kargs &K, agx_u32
     atomicOr((agx_u32 *)(addr & ~(size_t)3), (agx_u32)AGX_NF_EOVF << (8u * (agx_u32)(addr & 3)));
 }
 
-// pass J: one thread per hit; only hits whose a mate has several runs do anything (agx_edge_jump_hit)
-__global__ void __launch_bounds__(256) agx_k_edge_jump(agx_edge_kargs K, agx_u32 n_hits) {
+// pass J: one thread per hit with a mate of several runs (one hit in ten; the list is made at upload time); agx_edge_jump_hit drops the
+// ones that were skipped or whose a mate is the simple one
+__global__ void __launch_bounds__(256) agx_k_edge_jump(agx_edge_kargs K) {
     AGX_RETURN_IF_ABORTED(K.abort);
-    const agx_u32 h = blockIdx.x * 256u + threadIdx.x;
-    if (h >= n_hits || !K.multi_run[h]) return;
-    const agx_dhit d = K.S.dhit[h];
+    const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= K.n_jump) return;
+    const agx_dhit d = K.S.dhit[K.jump_list[i]];
     agx_edge_jump_hit(K.S, d, [&](agx_u32 src, agx_u32 dst) { agx_slot_insert(K, src, dst); });
 }
 
@@ -389,7 +402,7 @@ __global__ void __launch_bounds__(256) agx_k_mark_list(const agx_u32 *list, agx_
 // one wave per 64 ids: the special-id bitmap word and its popcount (input of the rank scan); words past n_ids are written as zero
 __global__ void __launch_bounds__(256) agx_k_special_bits(agx_compact_args A, agx_u32 n_words) {
     AGX_RETURN_IF_ABORTED(A.abort);
-    A.n_ids = A.n_pos + A.side_start[A.n_pos];
+    A.n_ids = A.n_pos + A.tile_side_start[(A.n_pos + AGX_TILE - 1) / AGX_TILE];
     const agx_u32 a = blockIdx.x * 256u + threadIdx.x, w = a >> 6;
     if (w >= n_words) return;                                                   // wave-uniform
     const unsigned long long bits = __ballot(agx_special_id(A, a));
@@ -415,6 +428,13 @@ extern "C" {
 
 void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t st) {
     hipLaunchKernelGGL(agx_k_cm_head, dim3(n_pos / 256 + 1), dim3(256), 0, st, cm_start, cm, head, n_pos);
+}
+void agx_launch_zero(const agx_zero_args *Z, hipStream_t st) {
+    unsigned long long total = 0; for (int s = 0; s < 8; s++) total += Z->n[s];
+    if (total) hipLaunchKernelGGL(agx_k_zero, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *Z);
+}
+void agx_launch_collect(agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *c, hipStream_t st) {
+    hipLaunchKernelGGL(agx_k_collect, dim3(1), dim3(1), 0, st, out, a, b, c);
 }
 void agx_launch_vote_codes(void *blob, size_t n_bytes16, hipStream_t st) {
     const size_t n16 = n_bytes16 / 16;
@@ -467,8 +487,8 @@ void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
     hipLaunchKernelGGL(agx_k_edge_sweep, dim3((n + 255) / 256), dim3(256), 0, st, *K);
     hipLaunchKernelGGL(agx_k_edge_bigtiles, dim3(AGX_BIG_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
 }
-void agx_launch_edge_jump(const agx_edge_kargs *K, agx_u32 n_hits, hipStream_t st) {
-    if (K->S.n_pos && n_hits) hipLaunchKernelGGL(agx_k_edge_jump, dim3((n_hits + 255) / 256), dim3(256), 0, st, *K, n_hits);
+void agx_launch_edge_jump(const agx_edge_kargs *K, hipStream_t st) {
+    if (K->S.n_pos && K->n_jump) hipLaunchKernelGGL(agx_k_edge_jump, dim3((K->n_jump + 255) / 256), dim3(256), 0, st, *K);
 }
 void agx_launch_edge_slow(const agx_edge_kargs *K, hipStream_t st) {
     // persistent wavefronts: exactly as many blocks as the device holds at once (a second, partial round of blocks would idle most CUs)

@@ -27,7 +27,7 @@ struct SimGraph {
     agx_u32 n_nodes = 0;
     // alive-compacted view (agx_core.h "walk preparation")
     agx_u32 n_ids = 0;
-    std::vector<agx_u32> side_cnt, side_start, aid_of; std::string a_str;
+    std::vector<agx_u32> side_pk, tile_side, tile_side_start, aid_of; std::string a_str;
     std::vector<agx_u8> a_meta, a_mark; std::vector<agx_walknode> a_node, sp_node; std::vector<agx_hop> sp_hop; std::vector<agx_edge_ovf> a_ovf;
     std::vector<agx_u32> side_xpos, sp_cnt, sp_rank; std::vector<unsigned long long> sp_bits; agx_u32 n_special = 0;
     void reserve(size_t cap) {
@@ -57,7 +57,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     std::vector<agx_cmkey> cmk(T.cm.size());
     for (size_t i = 0; i < T.cm.size(); i++) cmk[i] = agx_cmkey{T.cm[i].cid, T.cm[i].coff};
 
-    S.node_start.assign(n_pos, 0); S.node_cnt.assign(n_pos, 0); S.pos_succ.assign(n_pos, 0); S.side_cnt.assign((size_t)n_pos + 1, 0);
+    S.node_start.assign(n_pos, 0); S.node_cnt.assign(n_pos, 0); S.pos_succ.assign(n_pos, 0); S.side_pk.assign((size_t)n_pos + 1, 0); S.tile_side.assign((size_t)n_tiles + 1, 0);
     S.reserve((size_t)n_pos * 2 + 1024);
     agx_sweep_args A; memset(&A, 0, sizeof A);
     std::vector<agx_u8> vcodes(P.bases.size());             // the engine translates its device copy of the read bases at upload
@@ -69,7 +69,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     A.tile_off = tile_off.data();
     A.n_pos = n_pos; A.n_tiles = n_tiles; A.k = k; A.iv = iv; A.coverage = coverage;
     auto bind = [&]() {
-        A.node_start = S.node_start.data(); A.node_cnt = S.node_cnt.data(); A.pos_succ = S.pos_succ.data(); A.side_cnt = S.side_cnt.data();
+        A.node_start = S.node_start.data(); A.node_cnt = S.node_cnt.data(); A.pos_succ = S.pos_succ.data(); A.side_pk = S.side_pk.data(); A.tile_side = S.tile_side.data();
         A.nk_cid = S.cid.data(); A.nk_coff = S.coff.data(); A.nk_cid0 = S.cid0.data(); A.nk_coff0 = S.coff0.data(); A.nk_off0 = S.off0.data();
         A.n_xpos = S.xpos.data(); A.n_base = S.base.data(); A.n_flags = S.flags.data(); A.n_sref = S.sref.data(); A.n_next = S.next.data();
         A.n_counts = S.counts.data(); A.pool_cap = (agx_u32)S.cid.size();
@@ -102,6 +102,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
         agx_u32 total = 0; for (agx_u32 lane = 0; lane < AGX_TILE; lane++) total += cnt[lane];
         if (pool + total > S.cid.size()) { S.reserve((pool + total) * 2); bind(); }
         agx_bucket wb{nullptr, AGX_TILE, maxv}, wn{nullptr, AGX_TILE, maxv};
+        agx_u32 side_before = 0;                       // the kernel's wave scan
         for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
             const agx_u32 X = t * AGX_TILE + lane;
             wb.base = store + lane; wn.base = store + lane + 1;
@@ -109,9 +110,12 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
             const bool edges = ok && lane < AGX_TILE - 1 && X + 1 < n_pos && cnt[lane] <= AGX_EM_W && ncnt <= AGX_EM_W;
             agx_u32 emask = 0;
             if (edges) for (size_t i = 0; i < touched[lane].size(); i++) agx_edge_merge(emask, touched[lane][i].sp, touched[lane + 1][i].vm);
-            agx_node_write_lane(A, X, wb, cnt[lane], pool, pflag[lane], edges, emask, wn, pool + cnt[lane], ncnt);
+            const agx_u32 side = agx_node_write_lane(A, X, wb, cnt[lane], pool, pflag[lane], edges, emask, wn, pool + cnt[lane], ncnt);
+            if (X < n_pos) S.side_pk[X] = agx_side_pack(side_before, side);
+            side_before += side;
             pool += cnt[lane];
         }
+        S.tile_side[t] = side_before;
     }
     S.n_nodes = pool;
     // edge build: pass A (lanes = positions) writes the x -> x+1 edges of single-variant positions and collects the slow positions,
@@ -137,11 +141,11 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
 
     // walk preparation, the same per-element functions the compaction kernels run
     agx_compact_args C; memset(&C, 0, sizeof C);
-    S.side_start.assign((size_t)n_pos + 1, 0); S.aid_of.assign((size_t)S.n_nodes + 1, AGX_NONE);      // (side_cnt was written with the nodes)
+    S.tile_side_start.assign((size_t)n_tiles + 1, 0); S.aid_of.assign((size_t)S.n_nodes + 1, AGX_NONE);      // (side_cnt was written with the nodes)
     C.node_start = S.node_start.data(); C.node_cnt = S.node_cnt.data(); C.n_flags = S.flags.data(); C.n_base = S.base.data(); C.n_xpos = S.xpos.data();
     C.nk_off0 = S.off0.data(); C.n_sref = S.sref.data(); C.n_next = S.next.data(); C.ref = T.ref.data(); C.n_pos = n_pos;
-    C.side_start = S.side_start.data(); C.aid_of = S.aid_of.data();
-    agx_u32 run = 0; for (agx_u32 x = 0; x <= n_pos; x++) { S.side_start[x] = run; run += S.side_cnt[x]; }
+    C.side_pk = S.side_pk.data(); C.tile_side_start = S.tile_side_start.data(); C.aid_of = S.aid_of.data();
+    agx_u32 run = 0; for (agx_u32 t = 0; t <= n_tiles; t++) { S.tile_side_start[t] = run; run += S.tile_side[t]; }
     S.n_ids = n_pos + run;
     const size_t na = (size_t)S.n_ids + 1;
     S.a_str.assign(na, 0); S.a_meta.assign(na + 64, 0);
