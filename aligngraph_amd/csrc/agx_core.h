@@ -203,14 +203,21 @@ AGX_HD agx_u32 agx_idx0_pos(const agx_hit &h, const agx_run *runs) {     // posi
     return r.q == 0 ? r.t : AGX_NONE;
 }
 
-// returns 0 ok, 1 = same-strand mates ("BOWTIE ALIGNMENT ERROR", AG:1667-1671)
-AGX_HD int agx_hit_prep(const agx_hit *hits, const agx_run *runs, agx_u32 h, agx_u32 k, agx_dhit &d) {
-    const agx_hit H = hits[h];
-    d.flags = 0; d.len = H.len; d.jstar = 0xFFFF; d.x_lo = 1; d.x_hi = 0;
-    d.a_t0 = d.b_t0 = d.a_runs = d.b_runs = d.a_slot = 0; d.a_nruns = d.b_nruns = 0;
+// A later hit of a pair whose mate1 lands within a read length of an earlier kept hit of the same pair is dropped (AG:1650-1655).  Needs
+// the hits in file order: evaluated on the host at upload time (the device copy of the hits is in tile order).
+AGX_HD bool agx_hit_dup(const agx_hit *hits, const agx_run *runs, agx_u32 h) {
+    const agx_hit &H = hits[h];
     const agx_u32 me = agx_idx0_pos(H, runs);
     for (agx_u32 e = 1; e <= H.back; e++)
-        if (agx_absdiff(me, agx_idx0_pos(hits[h - e], runs)) < (int)H.len) { d.flags = AGX_HF_SKIP; return 0; }     // AG:1650-1655
+        if (agx_absdiff(me, agx_idx0_pos(hits[h - e], runs)) < (int)H.len) return true;
+    return false;
+}
+
+// returns 0 ok, 1 = same-strand mates ("BOWTIE ALIGNMENT ERROR", AG:1667-1671)
+AGX_HD int agx_hit_prep(const agx_hit &H, bool dup, const agx_run *runs, agx_u32 k, agx_dhit &d) {
+    d.flags = 0; d.len = H.len; d.jstar = 0xFFFF; d.x_lo = 1; d.x_hi = 0;
+    d.a_t0 = d.b_t0 = d.a_runs = d.b_runs = d.a_slot = 0; d.a_nruns = d.b_nruns = 0;
+    if (dup) { d.flags = AGX_HF_SKIP; return 0; }
     if (H.rev1 == H.rev2) { d.flags = AGX_HF_SKIP; return 1; }
     const agx_u32 L = H.len;
     if (L <= k) { d.flags = AGX_HF_SKIP; return 0; }

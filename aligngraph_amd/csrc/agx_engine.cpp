@@ -161,21 +161,17 @@ void do_upload(agx_unit *u) {
     agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, (agx_u32)n_pos, u->st);
     const size_t nh = u->P.hits.size();
     u->d_hits.alloc(nh + 1); u->d_runs.alloc(u->P.runs.size() + 1); u->d_bases.alloc(u->P.bases.size() + 16); u->d_dhit.alloc(nh + 1); u->d_rank4.alloc(4 * ((size_t)nh + 1));
-    if (nh) HIP_OK(hipMemcpyAsync(u->d_hits.p, u->P.hits.data(), nh * sizeof(agx_hit), hipMemcpyHostToDevice, u->st));
     if (!u->P.runs.empty()) HIP_OK(hipMemcpyAsync(u->d_runs.p, u->P.runs.data(), u->P.runs.size() * sizeof(agx_run), hipMemcpyHostToDevice, u->st));
     if (!u->P.bases.empty()) {              // the device copy holds vote codes (agx_vote_code), translated in place; the characters stay on the host for the walk
         HIP_OK(hipMemcpyAsync(u->d_bases.p, u->P.bases.data(), u->P.bases.size(), hipMemcpyHostToDevice, u->st));
         agx_launch_vote_codes(u->d_bases.p, (u->P.bases.size() + 15) / 16 * 16, u->st);
     }
-    {   // hits with a mate of several runs: the edge build's pass J starts from this list
-        std::vector<agx_u32> jl;
-        for (size_t h = 0; h < nh; h++) if (u->P.hits[h].nruns1 >= 2 || u->P.hits[h].nruns2 >= 2) jl.push_back((agx_u32)h);
-        u->n_jump = (agx_u32)jl.size(); u->d_jump_list.alloc(jl.size() + 1);
-        if (!jl.empty()) HIP_OK(hipMemcpyAsync(u->d_jump_list.p, jl.data(), jl.size() * 4, hipMemcpyHostToDevice, u->st));
-    }
     u->n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
-    {   // hit ids sorted by the tile their left end falls into (counting sort): agx_k_hit_prep walks them in this order so that the hits
-        // of one wavefront share tiles and their histogram atomics can be combined
+    {   // The device gets the hits in the order of the tile their left end falls into (counting sort): the hits of one wavefront of
+        // agx_k_hit_prep then share tiles (their histogram atomics combine), neighbouring threads read and write neighbouring records in all
+        // binning kernels, and a tile's list names records that lie together.  file_order[] takes a device hit number back to its place in
+        // the SAM file, which is the order the tile lists are sorted into.  What needs the file order itself — dropping a later hit of a
+        // pair that lands on an earlier one (agx_hit_dup) — is decided here and travels in the record's pad byte.
         std::vector<agx_u32> first((size_t)u->n_tiles + 1, 0), perm(nh);
         auto tile_of = [&](const agx_hit &h) -> agx_u32 {
             const agx_u32 p1 = h.nruns1 ? u->P.runs[h.runs1].t : h.pos1, p2 = h.nruns2 ? u->P.runs[h.runs2].t : h.pos2;
@@ -184,8 +180,15 @@ void do_upload(agx_unit *u) {
         for (size_t i = 0; i < nh; i++) first[tile_of(u->P.hits[i]) + 1]++;
         for (size_t t = 0; t < u->n_tiles; t++) first[t + 1] += first[t];
         for (size_t i = 0; i < nh; i++) perm[first[tile_of(u->P.hits[i])]++] = (agx_u32)i;
-        u->d_perm.alloc(nh + 1);
-        if (nh) HIP_OK(hipMemcpy(u->d_perm.p, perm.data(), nh * 4, hipMemcpyHostToDevice));
+        std::vector<agx_hit> sorted(nh); std::vector<agx_u32> jl;
+        for (size_t i = 0; i < nh; i++) {
+            sorted[i] = u->P.hits[perm[i]];
+            sorted[i].pad[0] = (sorted[i].back && agx_hit_dup(u->P.hits.data(), u->P.runs.data(), perm[i])) ? 1 : 0; sorted[i].pad[1] = sorted[i].pad[2] = 0;
+            if (sorted[i].nruns1 >= 2 || sorted[i].nruns2 >= 2) jl.push_back((agx_u32)i);      // a mate of several runs: the edge build's pass J starts from this list
+        }
+        u->d_perm.alloc(nh + 1); u->n_jump = (agx_u32)jl.size(); u->d_jump_list.alloc(jl.size() + 1);
+        if (nh) { HIP_OK(hipMemcpy(u->d_perm.p, perm.data(), nh * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(u->d_hits.p, sorted.data(), nh * sizeof(agx_hit), hipMemcpyHostToDevice)); }
+        if (!jl.empty()) HIP_OK(hipMemcpy(u->d_jump_list.p, jl.data(), jl.size() * 4, hipMemcpyHostToDevice));
     }
     u->d_tile_cnt.alloc((size_t)u->n_tiles + 1); u->d_tile_off.alloc((size_t)u->n_tiles + 2); u->d_cursor.alloc((size_t)u->n_tiles + 1);
     const size_t nb = ((size_t)n_pos + 1 + 1023) / 1024;              // sized for the longer of the two scans (positions)
@@ -253,7 +256,7 @@ void do_build(agx_unit *u) {
         }
         // ---- hit_prep + tile histogram ----
         u->ev.mark(B_START, st);
-        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_perm.p, u->d_tile_cnt.p, u->d_words.p + W_ERR, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
+        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
         agx_launch_hit_prep(&PA, st);
         AGX_CHECKPOINT("hit_prep");
         u->ev.mark(B_PREP, st);
@@ -261,7 +264,7 @@ void do_build(agx_unit *u) {
         agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
         agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, (const uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
         agx_launch_bin_fill(&BA, st);
-        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, st);
+        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_perm.p, u->d_dhit.p, u->d_tile_recs.p, st);
         AGX_CHECKPOINT("tile_sort");
         u->ev.mark(B_BIN, st);
         // ---- node sweep: every tile with small LDS buckets, then the tiles that overflowed with wider ones, then with global scratch (device-side lists) ----
@@ -275,7 +278,6 @@ void do_build(agx_unit *u) {
         u->ev.mark(B_NODE, st); u->stats.node_sweep_launches++;
         agx_launch_node_sweep_big(&K, st);
         AGX_CHECKPOINT("node_sweep_big");
-        agx_launch_pool_sum(u->d_pool_cnt.p, u->n_regions, u->d_words.p + W_POOL, st);
         u->ev.mark(B_BIG, st);
         // ---- edge sweep ----
         agx_edge_kargs E; fill_sweep_args(u, E.S); E.ovf = u->d_ovf.p; E.ovf_count = u->d_words.p + W_OVFCOUNT; E.ovf_cap = u->ovf_cap; E.list_cap = u->list_cap;
@@ -298,14 +300,13 @@ void do_build(agx_unit *u) {
         C.a_mark = u->d_a_mark.p; C.side_xpos = u->d_side_xpos.p; C.sparse_min = (u->prm.flags & AGX_FLAG_SPARSE_MIN) ? 1u : 0u;
         C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p; C.hop = u->d_hop.p; C.sp_hop = u->d_sp_hop.p; C.sp_cap = u->sp_cap;
         agx_launch_exclusive_scan(u->d_tile_side.p, u->d_tile_side_start.p, u->n_tiles, u->d_scan_tmp.p, st);      // per tile: the sweep has scanned inside the tiles
-        agx_launch_mark_list(u->d_chain_end.p, u->n_chain_end, u->d_a_mark.p, st);
-        agx_launch_compact(&C, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
+        agx_launch_compact(&C, u->d_chain_end.p, u->n_chain_end, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
         AGX_CHECKPOINT("compact");
         agx_launch_special(&C, u->n_words, u->d_sp_rank.p, u->d_scan_tmp.p, st);
         AGX_CHECKPOINT("special");
         u->ev.mark(B_COMPACT, st); u->ev.used = true;
         // ---- the one synchronisation ----
-        agx_launch_collect(u->d_words.p + W_N, u->d_tile_off.p + u->n_tiles, u->d_tile_side_start.p + u->n_tiles, u->d_sp_rank.p + u->n_words, st);
+        agx_launch_collect(u->d_words.p + W_N, u->d_tile_off.p + u->n_tiles, u->d_tile_side_start.p + u->n_tiles, u->d_sp_rank.p + u->n_words, u->d_pool_cnt.p, u->n_regions, u->d_words.p + W_POOL, st);
         HIP_OK(hipEventRecord(u->ev_done, st));
         my_turn.unlock();
         HIP_OK(hipStreamWaitEvent(u->st, u->ev_done, 0));

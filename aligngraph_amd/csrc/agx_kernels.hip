@@ -36,7 +36,16 @@ __global__ void __launch_bounds__(256) agx_k_zero(agx_zero_args Z) {
     agx_u32 i = blockIdx.x * 256u + threadIdx.x;
     for (int s = 0; s < 8; s++) { if (i < Z.n[s]) { Z.p[s][i] = 0u; return; } i -= Z.n[s]; }
 }
-__global__ void agx_k_collect(agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *c) { out[0] = *a; out[1] = *b; out[2] = *c; }
+// the last kernel of a build: the totals the host reads next to the counter words — out[0..2] = *a, *b, *c, *sum = nodes handed out (the
+// sum of the region counters; a unit has fewer than 2^32 nodes: the slices' layout is refused otherwise)
+__global__ void __launch_bounds__(256) agx_k_collect(agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *c, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum) {
+    __shared__ agx_u32 part[256];
+    agx_u32 t = 0;
+    for (agx_u32 r = threadIdx.x; r < regions; r += 256u) t += pool_cnt[(size_t)r * AGX_REGION_PAD];
+    part[threadIdx.x] = t; __syncthreads();
+    for (agx_u32 o = 128; o; o >>= 1) { if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) { out[0] = *a; out[1] = *b; out[2] = *c; *sum = part[0]; }
+}
 // read bases -> vote codes, in place (16 characters per thread; the blob is padded to a multiple of 16)
 __global__ void __launch_bounds__(256) agx_k_vote_codes(uint4 *blob, size_t n16) {
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
@@ -52,17 +61,17 @@ __global__ void __launch_bounds__(256) agx_k_vote_codes(uint4 *blob, size_t n16)
 }
 
 // ---- hit_prep: one thread per hit -------------------------------------------------------------------------------
-// Threads take the hits in the order of `perm` (upload time: hits sorted by the tile their left end falls into), so the 64 hits of a
-// wavefront fall into a handful of tiles.  Device-scope atomics are the expensive part of binning on this chip (8 L2s: they are resolved
+// The device copy of the hits is in the order of the tile their left end falls into (upload time), so the 64 hits of a wavefront fall
+// into a handful of tiles and every per-hit read and write of the binning kernels is coalesced.  Device-scope atomics are the expensive part of binning on this chip (8 L2s: they are resolved
 // behind them): the wavefront adds up its hits per tile and issues ONE atomicAdd per distinct tile, and what that returns is also each
 // hit's slot in the tile's list, so that bin_fill scatters without atomics.
 __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
-    const agx_u32 i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
-    const bool mine = i < A.n_hits;
-    const agx_u32 h = mine ? A.perm[i] : 0u;
+    const agx_u32 h = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool mine = h < A.n_hits;
     agx_dhit d; d.flags = AGX_HF_SKIP; d.x_lo = 1; d.x_hi = 0; d.a_nruns = 0;
     if (mine) {
-        const int rc = agx_hit_prep(A.hits, A.runs, h, A.k, d);
+        const agx_hit H = A.hits[h];
+        const int rc = agx_hit_prep(H, H.pad[0] != 0, A.runs, A.k, d);
         if (rc) atomicOr(A.err, 1u);
         if (!(d.flags & AGX_HF_SKIP) && (d.x_hi >= A.n_pos || d.x_lo > d.x_hi)) { atomicOr(A.err, 2u); d.flags |= AGX_HF_SKIP; }
     }
@@ -138,7 +147,7 @@ __global__ void __launch_bounds__(256) agx_k_bin_fill(agx_bin_args A) {
         for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++) { const agx_u32 at = A.tile_off[t] + atomicAdd(&A.cursor[t], 1u); if (at < A.cap) A.unsorted[at] = h; }
 }
 
-// one wavefront per tile; hit ids are unique, so an element's rank is the number of smaller elements
+// one wavefront per tile; a hit's place in the file is unique, so an element's rank is the number of smaller keys
 #define AGX_SORT_LDS 2048
 // The kernel writes the tile's RECORD list: the first 32 bytes of each listed hit's derived record, in SAM (= hit id) order, so that the
 // sweeps read one sequential, wave-uniform stream (scalar loads) instead of chasing list entry -> record.
@@ -148,8 +157,9 @@ __device__ __forceinline__ void agx_put_rec(uint4 *recs, agx_u32 at, const agx_d
     const uint2 a = s2[0], b = s2[1], c = s2[2], d = s2[3];
     recs[2 * (size_t)at] = make_uint4(a.x, a.y, b.x, b.y); recs[2 * (size_t)at + 1] = make_uint4(c.x, c.y, d.x, d.y);
 }
+// (list entries are hit numbers in the device's tile order; file_order[] gives a hit's place in the SAM file, the sort key)
 __global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap,
-                                                       const agx_dhit *dhit, uint4 *recs) {
+                                                       const agx_u32 *file_order, const agx_dhit *dhit, uint4 *recs) {
     __shared__ agx_u32 sh[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
@@ -158,18 +168,18 @@ __global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, 
     if (tile_off[tile + 1] > cap) return;                // lists did not fit: the host grows them and re-runs
     const agx_u32 *src = unsorted + lo;
     if (n <= AGX_SORT_LDS) {
-        for (agx_u32 i = lane; i < n; i += 64) sh[wave][i] = src[i];
+        for (agx_u32 i = lane; i < n; i += 64) sh[wave][i] = file_order[src[i]];
         // single wavefront: LDS writes above are visible to its own later reads after the implicit waitcnt
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         for (agx_u32 i = lane; i < n; i += 64) {
-            const agx_u32 v = sh[wave][i]; agx_u32 r = 0;
-            for (agx_u32 j = 0; j < n; j++) r += sh[wave][j] < v;
-            agx_put_rec(recs, lo + r, dhit, v);
+            const agx_u32 key = sh[wave][i]; agx_u32 r = 0;
+            for (agx_u32 j = 0; j < n; j++) r += sh[wave][j] < key;
+            agx_put_rec(recs, lo + r, dhit, src[i]);
         }
     } else {                                            // pile-ups larger than the LDS window: same rank sort straight from L2
         for (agx_u32 i = lane; i < n; i += 64) {
-            const agx_u32 v = src[i]; agx_u32 r = 0;
-            for (agx_u32 j = 0; j < n; j++) r += src[j] < v;
+            const agx_u32 v = src[i], key = file_order[v]; agx_u32 r = 0;
+            for (agx_u32 j = 0; j < n; j++) r += file_order[src[j]] < key;
             agx_put_rec(recs, lo + r, dhit, v);
         }
     }
@@ -287,28 +297,29 @@ __device__ __forceinline__ void agx_append_slow(const agx_edge_kargs &K, bool sl
     base = __shfl(base, 0, 64);
     if (slow) K.slow_list[base + (agx_u32)__popcll(m & ((1ull << lane) - 1ull))] = X;
 }
-__global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K) {
-    AGX_RETURN_IF_ABORTED(K.abort);
-    const agx_u32 t = blockIdx.x * 256u + threadIdx.x;
-    const agx_u32 X = t * AGX_TILE + (AGX_TILE - 1u);
-    bool slow = false;
-    if (t < K.S.n_tiles && X < K.S.n_pos) {
-        agx_u32 nb_start = 0, nb_cnt = 0;
-        if (X + 1 < K.S.n_pos) { nb_start = K.S.node_start[X + 1]; nb_cnt = K.S.node_cnt[X + 1]; }
-        slow = agx_edge_fast_lane(K.S, X, K.S.node_start[X], K.S.node_cnt[X], nb_start, nb_cnt);
-    }
-    agx_append_slow(K, slow, X, threadIdx.x & 63u);
-}
-__global__ void __launch_bounds__(256) agx_k_edge_bigtiles(agx_edge_kargs K) {
+__global__ void __launch_bounds__(256) agx_k_edge_sweep(agx_edge_kargs K, agx_u32 boundary_blocks) {
     AGX_RETURN_IF_ABORTED(K.abort);
     const agx_u32 lane = threadIdx.x & 63u;
-    const agx_u32 n = __builtin_amdgcn_readfirstlane((int)*K.big_n);
-    for (agx_u32 w = blockIdx.x * AGX_WAVES_PER_BLOCK + (threadIdx.x >> 6); w < n; w += gridDim.x * AGX_WAVES_PER_BLOCK) {
+    if (blockIdx.x < boundary_blocks) {                  // the last position of every tile: one thread each
+        const agx_u32 t = blockIdx.x * 256u + threadIdx.x;
+        const agx_u32 X = t * AGX_TILE + (AGX_TILE - 1u);
+        bool slow = false;
+        if (t < K.S.n_tiles && X < K.S.n_pos) {
+            agx_u32 nb_start = 0, nb_cnt = 0;
+            if (X + 1 < K.S.n_pos) { nb_start = K.S.node_start[X + 1]; nb_cnt = K.S.node_cnt[X + 1]; }
+            slow = agx_edge_fast_lane(K.S, X, K.S.node_start[X], K.S.node_cnt[X], nb_start, nb_cnt);
+        }
+        agx_append_slow(K, slow, X, lane);
+        return;
+    }
+    // the other blocks: all positions of the tiles that the global-scratch pass wrote, one wavefront per tile
+    const agx_u32 n = __builtin_amdgcn_readfirstlane((int)*K.big_n), blk = blockIdx.x - boundary_blocks, n_blk = gridDim.x - boundary_blocks;
+    for (agx_u32 w = blk * AGX_WAVES_PER_BLOCK + (threadIdx.x >> 6); w < n; w += n_blk * AGX_WAVES_PER_BLOCK) {
         const agx_u32 X = K.big_list[w] * AGX_TILE + lane;
         agx_u32 own_start = 0, own_cnt = 0;
         if (X < K.S.n_pos) { own_start = K.S.node_start[X]; own_cnt = K.S.node_cnt[X]; }
         const agx_u32 nb_start = __shfl_down(own_start, 1, 64), nb_cnt = __shfl_down(own_cnt, 1, 64);
-        // (the tile's last position is agx_k_edge_sweep's)
+        // (the tile's last position belongs to the boundary blocks)
         const bool slow = lane < AGX_TILE - 1u && agx_edge_fast_lane(K.S, X, own_start, own_cnt, nb_start, nb_cnt);
         agx_append_slow(K, slow, X, lane);
     }
@@ -381,23 +392,20 @@ __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
 }
 
 // ---- walk preparation: renumber surviving nodes, rewrite edges, mark forced runs (agx_core.h) -------------------------------
-__global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A) { AGX_RETURN_IF_ABORTED(A.abort); agx_assign_aid_pos(A, blockIdx.x * 256u + threadIdx.x); }
-__global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A) { AGX_RETURN_IF_ABORTED(A.abort); agx_emit_alive_pos(A, blockIdx.x * 256u + threadIdx.x); }
-__global__ void __launch_bounds__(256) agx_k_pool_sum(const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum) {      // *sum zeroed before
-    const agx_u32 r = blockIdx.x * 256u + threadIdx.x;
-    agx_u32 t = r < regions ? pool_cnt[(size_t)r * AGX_REGION_PAD] : 0u;
-    for (agx_u32 o = 32; o; o >>= 1) t += __shfl_down(t, o, 64);
-    if ((threadIdx.x & 63u) == 0 && t) atomicAdd(sum, t);          // a unit has fewer than 2^32 nodes (the slices' layout is refused otherwise)
-}
-__global__ void __launch_bounds__(256) agx_k_emit_ovf(agx_compact_args A, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap) {
+// (the first threads also mark the main ids of the chain-end positions: a_mark is complete before anything reads it)
+__global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A, const agx_u32 *chain_end, agx_u32 n_chain_end) {
     AGX_RETURN_IF_ABORTED(A.abort);
-    const agx_u32 n = *n_ovf_dev; A.n_ovf = n < ovf_cap ? n : ovf_cap; agx_emit_alive_ovf(A, blockIdx.x * 256u + threadIdx.x);
-}
-
-// chain-end positions (host list) -> a_mark
-__global__ void __launch_bounds__(256) agx_k_mark_list(const agx_u32 *list, agx_u32 n, agx_u8 *mark) {
     const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) mark[list[i]] = 1;
+    if (i < n_chain_end) A.a_mark[chain_end[i]] = 1;
+    agx_assign_aid_pos(A, i);
+}
+// (the first threads also rewrite the overflow edges)
+__global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap) {
+    AGX_RETURN_IF_ABORTED(A.abort);
+    const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
+    const agx_u32 n = *n_ovf_dev; A.n_ovf = n < ovf_cap ? n : ovf_cap;
+    agx_emit_alive_ovf(A, i);
+    agx_emit_alive_pos(A, i);
 }
 // one wave per 64 ids: the special-id bitmap word and its popcount (input of the rank scan); words past n_ids are written as zero
 __global__ void __launch_bounds__(256) agx_k_special_bits(agx_compact_args A, agx_u32 n_words) {
@@ -433,8 +441,8 @@ void agx_launch_zero(const agx_zero_args *Z, hipStream_t st) {
     unsigned long long total = 0; for (int s = 0; s < 8; s++) total += Z->n[s];
     if (total) hipLaunchKernelGGL(agx_k_zero, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *Z);
 }
-void agx_launch_collect(agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *c, hipStream_t st) {
-    hipLaunchKernelGGL(agx_k_collect, dim3(1), dim3(1), 0, st, out, a, b, c);
+void agx_launch_collect(agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *c, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, hipStream_t st) {
+    hipLaunchKernelGGL(agx_k_collect, dim3(1), dim3(256), 0, st, out, a, b, c, pool_cnt, regions, sum);
 }
 void agx_launch_vote_codes(void *blob, size_t n_bytes16, hipStream_t st) {
     const size_t n16 = n_bytes16 / 16;
@@ -467,8 +475,8 @@ void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u
 void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_bin_fill, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
 }
-void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, hipStream_t st) {
-    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, n_tiles, cap, dhit,
+void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_u32 *file_order, const agx_dhit *dhit, void *recs, hipStream_t st) {
+    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, n_tiles, cap, file_order, dhit,
                                     (uint4 *)recs);
 }
 void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
@@ -484,8 +492,8 @@ void agx_launch_node_sweep_big(const agx_node_kargs *K, hipStream_t st) {
 void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;
     if (!n) return;
-    hipLaunchKernelGGL(agx_k_edge_sweep, dim3((n + 255) / 256), dim3(256), 0, st, *K);
-    hipLaunchKernelGGL(agx_k_edge_bigtiles, dim3(AGX_BIG_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K);
+    const agx_u32 nb = (n + 255) / 256;
+    hipLaunchKernelGGL(agx_k_edge_sweep, dim3(nb + AGX_BIG_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K, nb);
 }
 void agx_launch_edge_jump(const agx_edge_kargs *K, hipStream_t st) {
     if (K->S.n_pos && K->n_jump) hipLaunchKernelGGL(agx_k_edge_jump, dim3((K->n_jump + 255) / 256), dim3(256), 0, st, *K);
@@ -502,16 +510,10 @@ void agx_launch_edge_slow(const agx_edge_kargs *K, hipStream_t st) {
     if (K->S.n_tiles) hipLaunchKernelGGL(agx_k_edge_slow, dim3((unsigned)blocks), dim3(256), 0, st, *K);
 }
 
-void agx_launch_pool_sum(const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, hipStream_t st) {
-    if (regions) hipLaunchKernelGGL(agx_k_pool_sum, dim3((regions + 255) / 256), dim3(256), 0, st, pool_cnt, regions, sum);
-}
-void agx_launch_compact(const agx_compact_args *A, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t st) {
-    if (A->n_pos) hipLaunchKernelGGL(agx_k_assign_aid, dim3((A->n_pos + 255) / 256), dim3(256), 0, st, *A);
-    if (A->n_pos) hipLaunchKernelGGL(agx_k_emit_alive, dim3((A->n_pos + 255) / 256), dim3(256), 0, st, *A);
-    if (ovf_cap) hipLaunchKernelGGL(agx_k_emit_ovf, dim3((ovf_cap + 255) / 256), dim3(256), 0, st, *A, n_ovf_dev, ovf_cap);
-}
-void agx_launch_mark_list(const agx_u32 *list, agx_u32 n, agx_u8 *mark, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(agx_k_mark_list, dim3((n + 255) / 256), dim3(256), 0, st, list, n, mark);
+void agx_launch_compact(const agx_compact_args *A, const agx_u32 *chain_end, agx_u32 n_chain_end, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t st) {
+    const agx_u32 n1 = A->n_pos > n_chain_end ? A->n_pos : n_chain_end, n2 = A->n_pos > ovf_cap ? A->n_pos : ovf_cap;
+    if (n1) hipLaunchKernelGGL(agx_k_assign_aid, dim3((n1 + 255) / 256), dim3(256), 0, st, *A, chain_end, n_chain_end);
+    if (n2) hipLaunchKernelGGL(agx_k_emit_alive, dim3((n2 + 255) / 256), dim3(256), 0, st, *A, n_ovf_dev, ovf_cap);
 }
 // sparse record table over n_words 64-id words (the id capacity; the live id count is read on the device); scan_tmp as for the scans
 void agx_launch_special(const agx_compact_args *A, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, hipStream_t st) {
