@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("AGX_LIB_PATH", os.path.join(_HERE, "libagx.so"))   # 
 AGX_OK, AGX_E_IO, AGX_E_FORMAT, AGX_E_UNSUPPORTED, AGX_E_ALIGNMENT, AGX_E_DEVICE, AGX_E_ARG, AGX_E_OVERFLOW, AGX_E_NOGPU = 0, -1, -2, -3, -4, -5, -6, -7, -8
 AGX_FLAG_KEEP_COUNTS = 1
 AGX_FLAG_SPARSE_MIN = 2
+AGX_FLAG_TIME_SECTIONS = 4
 
 # every symbol include/agx.h declares (tests check that the built library exports all of them)
 EXPORTS = [

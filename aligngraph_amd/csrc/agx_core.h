@@ -740,7 +740,8 @@ struct agx_compact_args {
     const agx_u32 *tile_side_start; // [n_tiles+1] exclusive scan of tile_side: side ids of all earlier tiles
     agx_u32 *aid_of;               // [pool] walk id or NONE
     // outputs indexed by aid, [n_pos + n_side]
-    char *a_str; agx_u8 *a_meta; agx_walknode *a_node;   // a_meta: AGX_WM_* bits
+    char *a_str; agx_u8 *a_meta;   // a_meta: AGX_WM_* bits
+    agx_u32 *a_nid;                // node of every walk id (NONE: absent main id): node records are built from the node table where one is wanted (agx_walk_record)
     const agx_edge_ovf *ovf; agx_u32 n_ovf; agx_edge_ovf *a_ovf;   // overflow edges rewritten in aids (edges touching pruned nodes become NONE/NONE)
     agx_u8 *a_mark;                // [n_ids+1] zeroed before; 1 = edge target of a non-cont id, or main id of a chain-end position
     agx_u32 *side_xpos;            // [n_side] position of every side id (sorted: the side block is position-major)
@@ -760,17 +761,41 @@ AGX_HD void agx_assign_aid_pos(const agx_compact_args &A, agx_u32 X) {
         if (A.n_flags[s + v] & AGX_NF_DEAD) { A.aid_of[s + v] = AGX_NONE; continue; }
         if (first) { A.aid_of[s + v] = X; first = false; } else A.aid_of[s + v] = side++;
     }
-    if (first) { A.a_meta[X] = (agx_u8)(AGX_WM_ABSENT | (n ? AGX_WM_ANY : 0)); A.a_str[X] = 'N'; agx_walknode w; for (agx_u32 e = 0; e < AGX_MAXE; e++) w.next[e] = AGX_NONE; w.off0 = AGX_NONE; w.xpos = X; w.sref = agx_sref{0, 0}; A.a_node[X] = w; }
+    if (first) { A.a_meta[X] = (agx_u8)(AGX_WM_ABSENT | (n ? AGX_WM_ANY : 0)); A.a_str[X] = 'N'; A.a_nid[X] = AGX_NONE; }
 }
 
-// per old node: write its record at its walk id
-AGX_HD void agx_emit_alive_node(const agx_compact_args &A, agx_u32 v) {
+// per old node of position x: string character, flags and marks of its walk id
+AGX_HD void agx_emit_alive_node(const agx_compact_args &A, agx_u32 v, agx_u32 x) {
     const agx_u32 a = A.aid_of[v];
     if (a == AGX_NONE) return;
-    const agx_u32 x = A.n_xpos[v];
     const char c = (char)A.n_base[v];
     A.a_str[a] = c != 'X' ? c : A.ref[x];                 // consensus, else the reference base (AG:1997-2001)
-    agx_walknode w; w.off0 = A.nk_off0[v]; w.xpos = x; w.sref = A.n_sref[v];
+    A.a_nid[a] = v;
+    agx_u32 next[AGX_MAXE]; agx_u32 k = 0;
+    for (agx_u32 e = 0; e < AGX_MAXE; e++) {
+        const agx_u32 t = A.n_next[(size_t)v * AGX_MAXE + e];
+        if (t == AGX_NONE) break;
+        const agx_u32 ta = A.aid_of[t];
+        if (ta != AGX_NONE) next[k++] = ta;
+    }
+    // a node whose edges spilled to the overflow list keeps all four slots... unless some pointed at pruned nodes: mark it
+    // by never being `cont`; the host consults the overflow list for every node it finds there
+    const bool cont = k == 1 && !(A.n_flags[v] & AGX_NF_EOVF) && next[0] == a + 1;
+    agx_u8 m = (agx_u8)((cont ? AGX_WM_CONT : 0) | ((A.n_flags[v] & AGX_NF_CONTIG) ? AGX_WM_CONTIG : 0));
+    if (a < A.n_pos) m |= (agx_u8)(AGX_WM_ANY | ((A.side_pk[x] >> 16) ? AGX_WM_SIDE : 0));
+    else A.side_xpos[a - A.n_pos] = x;
+    A.a_meta[a] = m;
+    if (!cont) for (agx_u32 e = 0; e < k; e++) A.a_mark[next[e]] = 1;      // racing stores of the same value
+}
+
+// The node record of walk id a (successor ids in slot order with the pruned ones dropped, mate offset, position, k-mer string
+// reference), from the node table.  Only the special ids' records travel to the host with the graph (agx_k_special_emit); the walk asks
+// for any other one by id (the +1000 skip, AG:2194-2202) and gets it from the same function.
+AGX_HD agx_walknode agx_walk_record(const agx_compact_args &A, agx_u32 a) {
+    agx_walknode w; for (agx_u32 e = 0; e < AGX_MAXE; e++) w.next[e] = AGX_NONE;
+    const agx_u32 v = A.a_nid[a];
+    if (v == AGX_NONE) { w.off0 = AGX_NONE; w.xpos = a; w.sref = agx_sref{0, 0}; return w; }       // a main id without a surviving node
+    w.off0 = A.nk_off0[v]; w.xpos = A.n_xpos[v]; w.sref = A.n_sref[v];
     agx_u32 k = 0;
     for (agx_u32 e = 0; e < AGX_MAXE; e++) {
         const agx_u32 t = A.n_next[(size_t)v * AGX_MAXE + e];
@@ -778,23 +803,14 @@ AGX_HD void agx_emit_alive_node(const agx_compact_args &A, agx_u32 v) {
         const agx_u32 ta = A.aid_of[t];
         if (ta != AGX_NONE) w.next[k++] = ta;
     }
-    // a node whose edges spilled to the overflow list keeps all four slots... unless some pointed at pruned nodes: mark it
-    // by never being `cont`; the host consults the overflow list for every node it finds there
-    const bool cont = k == 1 && !(A.n_flags[v] & AGX_NF_EOVF) && w.next[0] == a + 1;
-    agx_u8 m = (agx_u8)((cont ? AGX_WM_CONT : 0) | ((A.n_flags[v] & AGX_NF_CONTIG) ? AGX_WM_CONTIG : 0));
-    if (a < A.n_pos) m |= (agx_u8)(AGX_WM_ANY | ((A.side_pk[x] >> 16) ? AGX_WM_SIDE : 0));
-    else A.side_xpos[a - A.n_pos] = x;
-    A.a_meta[a] = m;
-    if (!cont) for (agx_u32 e = 0; e < k; e++) A.a_mark[w.next[e]] = 1;      // racing stores of the same value
-    for (; k < AGX_MAXE; k++) w.next[k] = AGX_NONE;
-    A.a_node[a] = w;
+    return w;
 }
 
 // per position: its nodes (the node table is only ever entered through node_start / node_cnt: the pool it lives in has unused slots)
 AGX_HD void agx_emit_alive_pos(const agx_compact_args &A, agx_u32 X) {
     if (X >= A.n_pos) return;
     const agx_u32 s = A.node_start[X], n = A.node_cnt[X];
-    for (agx_u32 v = 0; v < n; v++) agx_emit_alive_node(A, s + v);
+    for (agx_u32 v = 0; v < n; v++) agx_emit_alive_node(A, s + v, X);
 }
 
 AGX_HD void agx_emit_alive_ovf(const agx_compact_args &A, agx_u32 i) {

@@ -47,11 +47,12 @@ template <class T> struct PBuf {            // pinned host buffer
 // event record costs the stream about as much as a small kernel).
 enum { B_START = 0, B_PREP, B_BIN, B_NODE, B_BIG, B_EDGE, B_SLOW, B_COMPACT, B_N };
 struct Boundaries {
-    hipEvent_t e[B_N] = {}; bool used = false;
+    hipEvent_t e[B_N] = {}; bool at[B_N] = {}; bool all = false;      // at[b]: boundary b was marked in the last build; all: mark every boundary (AGX_FLAG_TIME_SECTIONS)
     void init() { for (auto &x : e) HIP_OK(hipEventCreate(&x)); }
     void destroy() { for (auto &x : e) { if (x) (void)hipEventDestroy(x); x = nullptr; } }
-    void mark(int b, hipStream_t st) { HIP_OK(hipEventRecord(e[b], st)); }
-    double ms(int b) const { if (!used) return 0; float f = 0; (void)hipEventElapsedTime(&f, e[b - 1], e[b]); return f; }      // section that ends at boundary b
+    void begin() { for (bool &x : at) x = false; }
+    void mark(int b, hipStream_t st) { if (!all && b != B_BIN && b != B_NODE) return; HIP_OK(hipEventRecord(e[b], st)); at[b] = true; }      // the node sweep is always timed
+    double ms(int b) const { if (!at[b - 1] || !at[b]) return 0; float f = 0; (void)hipEventElapsedTime(&f, e[b - 1], e[b]); return f; }      // section that ends at boundary b
 };
 
 }  // namespace
@@ -76,7 +77,7 @@ struct agx_unit {
     // walk graph (agx_core.h "walk preparation")
     agx_u32 n_ids = 0;
     DBuf<agx_u32> d_side_pk, d_tile_side, d_tile_side_start, d_aid_of; DBuf<char> d_a_str;
-    DBuf<agx_u8> d_a_meta, d_a_mark; DBuf<agx_walknode> d_a_node, d_sp_node; DBuf<agx_edge_ovf> d_a_ovf;
+    DBuf<agx_u8> d_a_meta, d_a_mark; DBuf<agx_walknode> d_fetch, d_sp_node; DBuf<agx_u32> d_a_nid; DBuf<agx_edge_ovf> d_a_ovf; agx_compact_args walk_args{};      // walk_args: the last build's, for record fetches
     DBuf<agx_u32> d_chain_end, d_side_xpos, d_sp_cnt, d_sp_rank; DBuf<unsigned long long> d_sp_bits; DBuf<agx_hop> d_hop, d_sp_hop;
     agx_u32 n_chain_end = 0, n_special = 0, n_words = 0;
     // downloaded: the walk graph with its sparse record table (agx_core.h); the full record table stays on the device
@@ -232,7 +233,7 @@ void do_build(agx_unit *u) {
         u->d_unsorted.alloc((size_t)u->list_cap + 1); u->d_tile_recs.alloc(((size_t)u->list_cap + 4) * 8);
         u->d_aid_of.alloc((size_t)u->pool_cap + 1);
         const size_t ids_cap = (size_t)n_pos + u->pool_cap;                       // side variants <= nodes <= pool_cap
-        u->d_a_str.alloc(ids_cap + 1); u->d_a_meta.alloc(ids_cap + 16); u->d_a_node.alloc(ids_cap + 1); u->d_a_ovf.alloc((size_t)u->ovf_cap + 1);
+        u->d_a_str.alloc(ids_cap + 1); u->d_a_meta.alloc(ids_cap + 16); u->d_a_nid.alloc(ids_cap + 1); u->d_a_ovf.alloc((size_t)u->ovf_cap + 1);
         u->d_side_pk.alloc((size_t)n_pos + 2); u->d_tile_side.alloc((size_t)u->n_tiles + 2); u->d_tile_side_start.alloc((size_t)u->n_tiles + 2);
         u->n_words = (agx_u32)(ids_cap / 64 + 1);
         u->d_a_mark.alloc(ids_cap + 2); u->d_side_xpos.alloc((size_t)u->pool_cap + 1);
@@ -255,7 +256,7 @@ void do_build(agx_unit *u) {
             HIP_OK(hipMemsetAsync(u->d_a_mark.p, 0, ids_cap + 2, st));
         }
         // ---- hit_prep + tile histogram ----
-        u->ev.mark(B_START, st);
+        u->ev.begin(); u->ev.mark(B_START, st);
         agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
         agx_launch_hit_prep(&PA, st);
         AGX_CHECKPOINT("hit_prep");
@@ -295,7 +296,7 @@ void do_build(agx_unit *u) {
         C.node_start = u->d_node_start.p; C.node_cnt = u->d_node_cnt.p; C.n_flags = u->d_flags.p; C.n_base = u->d_base.p; C.n_xpos = u->d_xpos.p;
         C.nk_off0 = u->d_off0.p; C.n_sref = u->d_sref.p; C.n_next = u->d_next.p; C.ref = u->d_ref.p; C.n_pos = n_pos;
         C.side_pk = u->d_side_pk.p; C.tile_side_start = u->d_tile_side_start.p; C.aid_of = u->d_aid_of.p;
-        C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_node = u->d_a_node.p; C.ovf = u->d_ovf.p; C.n_ovf = 0; C.a_ovf = u->d_a_ovf.p;
+        C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_nid = u->d_a_nid.p; C.ovf = u->d_ovf.p; C.n_ovf = 0; C.a_ovf = u->d_a_ovf.p;
         C.abort = u->d_words.p + W_STATUS;
         C.a_mark = u->d_a_mark.p; C.side_xpos = u->d_side_xpos.p; C.sparse_min = (u->prm.flags & AGX_FLAG_SPARSE_MIN) ? 1u : 0u;
         C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p; C.hop = u->d_hop.p; C.sp_hop = u->d_sp_hop.p; C.sp_cap = u->sp_cap;
@@ -303,8 +304,9 @@ void do_build(agx_unit *u) {
         agx_launch_compact(&C, u->d_chain_end.p, u->n_chain_end, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
         AGX_CHECKPOINT("compact");
         agx_launch_special(&C, u->n_words, u->d_sp_rank.p, u->d_scan_tmp.p, st);
+        u->walk_args = C;
         AGX_CHECKPOINT("special");
-        u->ev.mark(B_COMPACT, st); u->ev.used = true;
+        u->ev.mark(B_COMPACT, st);
         // ---- the one synchronisation ----
         agx_launch_collect(u->d_words.p + W_N, u->d_tile_off.p + u->n_tiles, u->d_tile_side_start.p + u->n_tiles, u->d_sp_rank.p + u->n_words, u->d_pool_cnt.p, u->n_regions, u->d_words.p + W_POOL, st);
         HIP_OK(hipEventRecord(u->ev_done, st));
@@ -328,7 +330,7 @@ void do_build(agx_unit *u) {
             if (need > u->pool_cap) {
                 u->d_cid.release(); u->d_coff.release(); u->d_cid0.release(); u->d_coff0.release(); u->d_off0.release(); u->d_xpos.release();
                 u->d_next.release(); u->d_base.release(); u->d_flags.release(); u->d_sref.release(); u->d_counts.release();
-                u->d_aid_of.release(); u->d_a_str.release(); u->d_a_meta.release(); u->d_a_node.release();
+                u->d_aid_of.release(); u->d_a_str.release(); u->d_a_meta.release(); u->d_a_nid.release();
                 u->d_a_mark.release(); u->d_side_xpos.release(); u->d_sp_bits.release(); u->d_sp_cnt.release(); u->d_sp_rank.release();
                 alloc_pool(u, (agx_u32)need);
             }
@@ -377,17 +379,17 @@ void do_download(agx_unit *u) {
     u->stats.ms_download = now_ms() - t0;
 }
 
-// records of non-special walk ids, straight from the full table in HBM (agx_core.h "walk preparation"): one strided copy
+// records of non-special walk ids: built on the device from the node table, which stays in HBM (agx_walk_record), then one copy
 void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *out) {
     agx_unit *u = (agx_unit *)ctx;
     const size_t n = (size_t)rows * width;
     if (!n) return;
-    if ((size_t)first + (size_t)(rows - 1) * stride + width > u->n_ids) throw Error{E_ARG, "record fetch beyond the walk graph"};
+    if ((size_t)first + (size_t)(rows - 1) * stride + width > u->n_ids || n > 0x7FFFFFFFull) throw Error{E_ARG, "record fetch beyond the walk graph"};
     HIP_OK(hipSetDevice(u->prm.device));
-    u->h_fetch.alloc(n);
-    if (rows == 1) HIP_OK(hipMemcpyAsync(u->h_fetch.p, u->d_a_node.p + first, n * sizeof(agx_walknode), hipMemcpyDeviceToHost, u->st));
-    else HIP_OK(hipMemcpy2DAsync(u->h_fetch.p, width * sizeof(agx_walknode), u->d_a_node.p + first, (size_t)stride * sizeof(agx_walknode),
-                                  width * sizeof(agx_walknode), rows, hipMemcpyDeviceToHost, u->st));
+    u->h_fetch.alloc(n); u->d_fetch.alloc(n);
+    agx_compact_args C = u->walk_args; C.n_ids = u->n_ids;
+    agx_launch_fetch_records(&C, first, stride, rows, width, u->d_fetch.p, u->st);
+    HIP_OK(hipMemcpyAsync(u->h_fetch.p, u->d_fetch.p, n * sizeof(agx_walknode), hipMemcpyDeviceToHost, u->st));
     HIP_OK(hipStreamSynchronize(u->st));
     memcpy(out, u->h_fetch.p, n * sizeof(agx_walknode));
 }
@@ -446,7 +448,7 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
     const int rc = guarded(u, [&] {
         HIP_OK(hipSetDevice(p->device));
         HIP_OK(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
-        u->ev.init(); HIP_OK(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming));
+        u->ev.init(); u->ev.all = (u->prm.flags & AGX_FLAG_TIME_SECTIONS) != 0; HIP_OK(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming));
     });
     if (rc != AGX_OK) { delete u; return rc; }
     *out = u;

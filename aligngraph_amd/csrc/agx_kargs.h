@@ -60,6 +60,7 @@ void agx_launch_edge_slow(const agx_edge_kargs *, hipStream_t);           // pas
 // walk preparation (agx_core.h): after the scan of the side counts the node sweep left behind: ids, records and overflow edges
 // n_nodes / n_ovf are read from device memory (the node-pool and overflow counters), so no host round trip separates the sweeps
 // from the walk preparation; the grids are sized by the capacities.
+void agx_launch_fetch_records(const agx_compact_args *, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *out, hipStream_t);
 void agx_launch_compact(const agx_compact_args *, const agx_u32 *chain_end, agx_u32 n_chain_end, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t);
 void agx_launch_special(const agx_compact_args *, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, hipStream_t);
 #define AGX_MID_WAVES 3072u     // wavefronts of pass 1 (3 per SIMD fit its LDS buckets); they stride over the list of tiles pass 0 gave up on

@@ -426,9 +426,16 @@ __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, ag
     if ((bits >> lane) & 1ull) {
         const agx_u32 at = A.sp_rank[w] + (agx_u32)__popcll(bits & ((1ull << lane) - 1ull));
         if (at >= A.sp_cap) return;                                           // table too small: the host sees the count and repeats the build
-        A.sp_node[at] = A.a_node[a];
+        A.sp_node[at] = agx_walk_record(A, a);
         A.sp_hop[at] = A.hop[a < A.n_pos ? a : A.side_xpos[a - A.n_pos]];
     }
+}
+
+// records of the walk ids first + r*stride + c (r < rows, c < width), row-major into out: what the walk fetches one by one
+__global__ void __launch_bounds__(256) agx_k_fetch_records(agx_compact_args A, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *out) {
+    const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= rows * width) return;
+    out[i] = agx_walk_record(A, first + (i / width) * stride + i % width);
 }
 
 // ---- host-callable launchers (kept in this translation unit so that the engine is plain C++) -------------------------
@@ -510,6 +517,10 @@ void agx_launch_edge_slow(const agx_edge_kargs *K, hipStream_t st) {
     if (K->S.n_tiles) hipLaunchKernelGGL(agx_k_edge_slow, dim3((unsigned)blocks), dim3(256), 0, st, *K);
 }
 
+void agx_launch_fetch_records(const agx_compact_args *A, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *out, hipStream_t st) {
+    const agx_u32 n = rows * width;
+    if (n) hipLaunchKernelGGL(agx_k_fetch_records, dim3((n + 255) / 256), dim3(256), 0, st, *A, first, stride, rows, width, out);
+}
 void agx_launch_compact(const agx_compact_args *A, const agx_u32 *chain_end, agx_u32 n_chain_end, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t st) {
     const agx_u32 n1 = A->n_pos > n_chain_end ? A->n_pos : n_chain_end, n2 = A->n_pos > ovf_cap ? A->n_pos : ovf_cap;
     if (n1) hipLaunchKernelGGL(agx_k_assign_aid, dim3((n1 + 255) / 256), dim3(256), 0, st, *A, chain_end, n_chain_end);

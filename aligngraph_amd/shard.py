@@ -70,26 +70,33 @@ class UnitGather:
         self.dist, self.device, self.rank, self.world, self.dst = dist, device, rank, world, dst
         self.cap = 0
         self._stage = self._dev = self._recv = self._recv_host = self._staged = None
+        self._side = None                     # root, GPU box: the device-to-host copies of the gathered buffers run on their own stream, so the
+        self._copied = None                   # next step's size exchange (a host read) does not wait for them
 
     def _grow(self, cap):
         import torch
         pin = self.device.type == "cuda"
+        if self._copied is not None:
+            self._copied.synchronize()
         self.cap = cap
-        self._staged = None
+        self._staged = self._copied = None
         self._stage = torch.zeros(cap, dtype=torch.uint8, pin_memory=pin)
         self._dev = torch.zeros(cap, dtype=torch.uint8, device=self.device)
         if self.rank == self.dst:
             self._recv = [torch.zeros(cap, dtype=torch.uint8, device=self.device) for _ in range(self.world)]
             self._recv_host = torch.zeros(cap * self.world, dtype=torch.uint8, pin_memory=pin)
 
-    def step(self, payload):
+    def step(self, payload, head=b""):
+        """payload (and an optional short head in front of it, so that a caller need not join the two) -> handle"""
+        import numpy as np
         import torch
         if self.dist is None or self.world == 1:
             class _Local:
                 def payloads(_s):
-                    return [payload]
+                    return [head + payload if head else payload]
             return _Local()
-        need = torch.tensor([len(payload) + 8], dtype=torch.int64, device=self.device)
+        total = len(head) + len(payload)
+        need = torch.tensor([total + 8], dtype=torch.int64, device=self.device)
         self.dist.all_reduce(need, op=self.dist.ReduceOp.MAX)
         need = int(need.item())
         if need > self.cap:
@@ -97,24 +104,35 @@ class UnitGather:
         if self._staged is not None:
             self._staged.synchronize()                                          # the previous step's host-to-device copy has read the staging buffer
         st = self._stage.numpy()
-        st[:8] = memoryview(len(payload).to_bytes(8, "little"))
+        st[:8] = np.frombuffer(total.to_bytes(8, "little"), dtype=np.uint8)
+        if head:
+            st[8:8 + len(head)] = np.frombuffer(head, dtype=np.uint8)
         if payload:
-            st[8:8 + len(payload)] = memoryview(payload)
+            st[8 + len(head):8 + total] = np.frombuffer(payload, dtype=np.uint8)     # the one host copy of the payload
         self._dev.copy_(self._stage, non_blocking=True)
         if self.device.type == "cuda":
             self._staged = torch.cuda.Event()
             self._staged.record()
+        cuda = self.device.type == "cuda"
+        if cuda and self.rank == self.dst and self._copied is not None:
+            torch.cuda.current_stream().wait_event(self._copied)                # the previous step's copies have read the receive buffers
         self.dist.gather(self._dev, self._recv if self.rank == self.dst else None, dst=self.dst)
         if self.rank != self.dst:
             return UnitGather._Handle(self, None, None, None, self.cap)
         host = self._recv_host
-        for r in range(self.world):
-            host[r * self.cap:(r + 1) * self.cap].copy_(self._recv[r], non_blocking=True)
-        event = None
-        if self.device.type == "cuda":
-            event = torch.cuda.Event()
-            event.record()
-        return UnitGather._Handle(self, None, event, host, self.cap)
+        if not cuda:
+            for r in range(self.world):
+                host[r * self.cap:(r + 1) * self.cap].copy_(self._recv[r])
+            return UnitGather._Handle(self, None, None, host, self.cap)
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            for r in range(self.world):
+                host[r * self.cap:(r + 1) * self.cap].copy_(self._recv[r], non_blocking=True)
+            self._copied = torch.cuda.Event()
+            self._copied.record()
+        return UnitGather._Handle(self, None, self._copied, host, self.cap)
 
 
 def pack_units(unit_ids, blobs):
@@ -125,6 +143,12 @@ def pack_units(unit_ids, blobs):
         out.append(struct.pack("<IQ", u, len(b)))
         out.append(b)
     return b"".join(out)
+
+
+def unit_header(unit_id, length):
+    """What pack_units([unit_id], [blob]) puts in front of the blob."""
+    import struct
+    return struct.pack("<IIQ", 1, unit_id, length)
 
 
 def unpack_units(payload):

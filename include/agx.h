@@ -53,6 +53,8 @@ typedef struct {
 } agx_params;
 
 #define AGX_FLAG_KEEP_COUNTS 1u /* keep per-node coverage and base votes on the device for agx_unit_graph() */
+#define AGX_FLAG_TIME_SECTIONS 4u /* time every section of a build (agx_stats ms_prep .. ms_compact); without it only ms_node_sweep is measured: an event
+                                     record between two kernels costs the stream about as much as a small kernel */
 #define AGX_FLAG_SPARSE_MIN  2u /* test hook: download node records of the side ids only, read all others one by one from the device */
 
 /* ---- packed inputs -------------------------------------------------------------------------------- */

@@ -28,7 +28,7 @@ struct SimGraph {
     // alive-compacted view (agx_core.h "walk preparation")
     agx_u32 n_ids = 0;
     std::vector<agx_u32> side_pk, tile_side, tile_side_start, aid_of; std::string a_str;
-    std::vector<agx_u8> a_meta, a_mark; std::vector<agx_walknode> a_node, sp_node; std::vector<agx_hop> sp_hop; std::vector<agx_edge_ovf> a_ovf;
+    std::vector<agx_u8> a_meta, a_mark; std::vector<agx_walknode> sp_node; std::vector<agx_u32> a_nid; agx_compact_args walk_args; std::vector<agx_hop> sp_hop; std::vector<agx_edge_ovf> a_ovf;
     std::vector<agx_u32> side_xpos, sp_cnt, sp_rank; std::vector<unsigned long long> sp_bits; agx_u32 n_special = 0;
     void reserve(size_t cap) {
         cid.resize(cap); coff.resize(cap); cid0.resize(cap); coff0.resize(cap); off0.resize(cap); xpos.resize(cap); next.resize(cap * AGX_MAXE);
@@ -149,9 +149,9 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     S.n_ids = n_pos + run;
     const size_t na = (size_t)S.n_ids + 1;
     S.a_str.assign(na, 0); S.a_meta.assign(na + 64, 0);
-    S.a_node.assign(na, agx_walknode{{AGX_NONE, AGX_NONE, AGX_NONE, AGX_NONE}, AGX_NONE, 0, agx_sref{0, 0}});
+    S.a_nid.assign(na, AGX_NONE);
     S.a_ovf.assign(S.ovf.size() + 1, agx_edge_ovf{AGX_NONE, AGX_NONE});
-    C.a_str = &S.a_str[0]; C.a_meta = S.a_meta.data(); C.a_node = S.a_node.data();
+    C.a_str = &S.a_str[0]; C.a_meta = S.a_meta.data(); C.a_nid = S.a_nid.data();
     C.ovf = S.ovf.data(); C.n_ovf = (agx_u32)S.ovf.size(); C.a_ovf = S.a_ovf.data();
     S.a_mark.assign(na + 1, 0); S.side_xpos.assign((size_t)run + 1, 0);
     C.a_mark = S.a_mark.data(); C.side_xpos = S.side_xpos.data(); C.n_ids = S.n_ids;
@@ -173,9 +173,10 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     for (agx_u32 w = 0; w < n_words; w++) for (agx_u32 l = 0; l < 64; l++) if ((S.sp_bits[w] >> l) & 1ull)
     {
         const agx_u32 a = w * 64 + l, at = S.sp_rank[w] + (agx_u32)__builtin_popcountll(S.sp_bits[w] & ((1ull << l) - 1ull));
-        S.sp_node[at] = S.a_node[a];
+        S.sp_node[at] = agx_walk_record(C, a);
         S.sp_hop[at] = T.hop[a < n_pos ? a : S.side_xpos[a - n_pos]];
     }
+    S.walk_args = C;
 }
 
 char *dup_buf(const std::string &s) { char *p = (char *)malloc(s.size() + 1); memcpy(p, s.data(), s.size()); p[s.size()] = 0; return p; }
@@ -213,7 +214,7 @@ int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int cover
         G.meta = S.a_meta.data(); G.str = S.a_str.data(); G.side_xpos = S.side_xpos.data();
         G.sp_bits = S.sp_bits.data(); G.sp_rank = S.sp_rank.data(); G.sp_node = S.sp_node.data(); G.sp_hop = S.sp_hop.data(); G.n_special = S.n_special;
         G.fetch = [](void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *o) {
-            for (agx_u32 r = 0; r < rows; r++) for (agx_u32 c = 0; c < width; c++) o[(size_t)r * width + c] = ((SimGraph *)ctx)->a_node.at((size_t)first + (size_t)r * stride + c);
+            for (agx_u32 r = 0; r < rows; r++) for (agx_u32 c = 0; c < width; c++) { const SimGraph *g = (const SimGraph *)ctx; const size_t a = (size_t)first + (size_t)r * stride + c; if (a >= g->n_ids) throw Error{E_ARG, "record fetch beyond the walk graph"}; o[(size_t)r * width + c] = agx_walk_record(g->walk_args, (agx_u32)a); }
         }; G.fetch_ctx = &S;
         G.ovf = S.a_ovf.data(); G.n_ovf = S.ovf.size();
         if (const char *rep = getenv("AGX_WALK_REPEAT")) {           // walk micro-benchmark: best of N on an already built graph

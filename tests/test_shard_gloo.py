@@ -20,6 +20,7 @@ def test_assign_units_is_lpt_and_deterministic():
 
 
 def test_pack_roundtrip():
+    assert shard.unit_header(7, 3) + b"abc" == shard.pack_units([7], [b"abc"])
     blob = shard.pack_units([3, 0], [b"abc", b""])
     assert shard.unpack_units(blob) == {3: b"abc", 0: b""}
     assert shard.unpack_units(shard.pack_units([], [])) == {}
@@ -37,6 +38,8 @@ def _worker(rank, world, port, run, meta, q):
     # the per-step variant bench.py uses: persistent buffers, growing capacity, several steps
     g = shard.UnitGather(dist, torch.device("cpu"), rank, world)
     steps = [g.step(shard.pack_units(mine[:n], blobs[:n])).payloads() for n in (0, len(mine), 1)]
+    # ... and the form that saves the host-side join: a short head in front of one unit's bytes
+    headed = g.step(blobs[0], head=shard.unit_header(mine[0], len(blobs[0]))).payloads() if mine else g.step(b"", head=shard.pack_units([], [])).payloads()
     if rank == 0:
         merged = {}
         for payload in got:
@@ -46,9 +49,13 @@ def _worker(rank, world, port, run, meta, q):
             again.update(shard.unpack_units(payload))
         assert again == merged and all(shard.unpack_units(p) == {} for p in steps[0])
         assert sum(len(shard.unpack_units(p)) for p in steps[2]) == sum(1 for r in shard.assign_units(meta["unit_len"], world) if r)
+        firsts = {}
+        for payload in headed:
+            firsts.update(shard.unpack_units(payload))
+        assert firsts == {r[0]: merged[r[0]] for r in shard.assign_units(meta["unit_len"], world) if r}
         q.put(merged)
     else:
-        assert steps == [None, None, None]
+        assert steps == [None, None, None] and headed is None
     dist.barrier()
     dist.destroy_process_group()
 

@@ -11,7 +11,7 @@ a = ap.parse_args()
 run = "/tmp/agx_sweep_time"
 if not os.path.exists(os.path.join(run, "tmp")):
     D.synth(run, seed=1000, chroms=a.genome, pairs=a.pairs, L=100, k=5, coverage=5)
-with A.Unit(k=5, insert_variation=50, coverage=5) as u:
+with A.Unit(k=5, insert_variation=50, coverage=5, flags=A.AGX_FLAG_TIME_SECTIONS) as u:
     u.load_files(os.path.join(run, "tmp"), 0); u.upload()
     acc = {}
     for i in range(a.n + 2):
