@@ -61,7 +61,7 @@ class Stats(ctypes.Structure):
                                                 "ms_edge_sweep", "ms_compact", "ms_download", "ms_walk")] + \
                [("node_sweep_launches", ctypes.c_uint32), ("edge_sweep_launches", ctypes.c_uint32)] + \
                [(n, ctypes.c_uint64) for n in ("n_walk_ids", "n_special", "n_fetched", "download_bytes")] + \
-               [(n, ctypes.c_double) for n in ("ms_edge_fast", "ms_edge_slow")] + [("n_mid_tiles", ctypes.c_uint64)]
+               [(n, ctypes.c_double) for n in ("ms_edge_fast", "ms_edge_slow")] + [("n_mid_tiles", ctypes.c_uint64), ("ms_build_span", ctypes.c_double)]
 
 
 class Graph(ctypes.Structure):

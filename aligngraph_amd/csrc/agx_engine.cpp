@@ -46,16 +46,21 @@ template <class T> struct PBuf {            // pinned host buffer
 // Section boundaries of a build on the unit's stream: the end of one section is the start of the next (one record instead of two: an
 // event record costs the stream about as much as a small kernel).
 enum { B_START = 0, B_PREP, B_BIN, B_NODE, B_BIG, B_EDGE, B_SLOW, B_COMPACT, B_N };
+// (two more events bracket the whole build: Boundaries::first / last)
 struct Boundaries {
-    hipEvent_t e[B_N] = {}; bool at[B_N] = {}; bool all = false;      // at[b]: boundary b was marked in the last build; all: mark every boundary (AGX_FLAG_TIME_SECTIONS)
-    void init() { for (auto &x : e) HIP_OK(hipEventCreate(&x)); }
-    void destroy() { for (auto &x : e) { if (x) (void)hipEventDestroy(x); x = nullptr; } }
+    hipEvent_t e[B_N] = {}, first = nullptr, last = nullptr; bool at[B_N] = {}; bool all = false;      // at[b]: boundary b was marked in the last build; all: mark every boundary (AGX_FLAG_TIME_SECTIONS)
+    void init() { for (auto &x : e) HIP_OK(hipEventCreate(&x)); HIP_OK(hipEventCreate(&first)); HIP_OK(hipEventCreate(&last)); }
+    double span() const { float f = 0; return hipEventElapsedTime(&f, first, last) == hipSuccess ? f : 0; }
+    void destroy() { for (auto &x : e) { if (x) (void)hipEventDestroy(x); x = nullptr; } if (first) (void)hipEventDestroy(first); if (last) (void)hipEventDestroy(last); first = last = nullptr; }
     void begin() { for (bool &x : at) x = false; }
     void mark(int b, hipStream_t st) { if (!all && b != B_BIN && b != B_NODE) return; HIP_OK(hipEventRecord(e[b], st)); at[b] = true; }      // the node sweep is always timed
     double ms(int b) const { if (!at[b - 1] || !at[b]) return 0; float f = 0; (void)hipEventElapsedTime(&f, e[b - 1], e[b]); return f; }      // section that ends at boundary b
 };
 
 }  // namespace
+
+// a captured segment of a build's kernel chain
+struct GraphSeg { hipGraphExec_t exec = nullptr; void reset() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; } };
 
 struct agx_unit {
     agx_params prm{};
@@ -85,9 +90,11 @@ struct agx_unit {
     PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_hop> h_sp_hop; PBuf<agx_edge_ovf> h_a_ovf;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
+    GraphSeg g_front, g_back; int builds_ok = 0;      // successful builds since the buffers / capacities last changed
+    void drop_graphs() { g_front.reset(); g_back.reset(); builds_ok = 0; }
     Boundaries ev; hipEvent_t ev_done = nullptr;      // recorded on the device's build stream behind the unit's last kernel
     agx_stats stats{};
-    ~agx_unit() { ev.destroy(); if (ev_done) (void)hipEventDestroy(ev_done); if (st) (void)hipStreamDestroy(st); }
+    ~agx_unit() { g_front.reset(); g_back.reset(); ev.destroy(); if (ev_done) (void)hipEventDestroy(ev_done); if (st) (void)hipStreamDestroy(st); }
 };
 
 namespace {
@@ -98,6 +105,9 @@ namespace {
 // costs tens of microseconds per build here) — and per-kernel HIP-event times stay those of an exclusive device.  Uploads and copies to
 // the host (counter words, download, record fetches) use the unit's own stream and overlap the next unit's kernels.
 struct DeviceTurn { std::mutex m; hipStream_t build = nullptr; };
+// AGX_GRAPHS=1 (experiment): from a unit's third build on, the kernel chains in front of and behind the main sweep are replayed as captured
+// graphs.  Off by default: measured slower than enqueuing the ~30 commands one by one (1.56 vs 1.46 ms per step on the same box, ROCm 7.2).
+static const bool g_use_graphs = getenv("AGX_GRAPHS") != nullptr;
 DeviceTurn &turn_of(int device) { static DeviceTurn turns[64]; return turns[device & 63]; }
 
 // AGX_DEBUG_SYNC=1: synchronise after every launch group of a build and name it on stderr — a memory fault then points at its kernel
@@ -146,6 +156,7 @@ void alloc_pool(agx_unit *u, agx_u32 cap) {
 }
 
 void do_upload(agx_unit *u) {
+    u->drop_graphs();
     if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
     const double t0 = now_ms();
     HIP_OK(hipSetDevice(u->prm.device));
@@ -244,9 +255,27 @@ void do_build(agx_unit *u) {
             u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16); }
 
         DeviceTurn &turn = turn_of(u->prm.device);
+        const bool use_graph = g_use_graphs && !g_debug_sync && !u->ev.all;
+        auto run_segment = [&](GraphSeg &gs, auto &enqueue) {
+            if (use_graph && gs.exec) { HIP_OK(hipGraphLaunch(gs.exec, st)); return; }
+            if (!use_graph || u->builds_ok < 2) { enqueue(); return; }
+            HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            hipGraph_t g = nullptr;
+            try { enqueue(); } catch (...) { (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); throw; }
+            HIP_OK(hipStreamEndCapture(st, &g));
+            const hipError_t e = hipGraphInstantiate(&gs.exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) { gs.exec = nullptr; throw Error{E_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)}; }
+            HIP_OK(hipGraphLaunch(gs.exec, st));
+        };
         std::unique_lock<std::mutex> my_turn(turn.m);
         if (!turn.build) HIP_OK(hipStreamCreateWithFlags(&turn.build, hipStreamNonBlocking));
         st = turn.build;
+        HIP_OK(hipEventRecord(u->ev.first, st));
+        // The kernel chain in front of the main sweep and the one behind it; the main sweep is launched between its two timing events.
+        // (With AGX_GRAPHS=1 the two chains are stream captures replayed as graphs from a unit's third build on: same buffers, same
+        // capacities, same arguments.)
+        auto front = [&]() {
         {   // everything a build counts into or marks, zeroed by one kernel and one fill (every command on the stream costs a few microseconds)
             agx_zero_args Z; memset(&Z, 0, sizeof Z);
             auto seg = [&](int i, agx_u32 *ptr, size_t words) { Z.p[i] = ptr; Z.n[i] = (agx_u32)words; };
@@ -267,6 +296,8 @@ void do_build(agx_unit *u) {
         agx_launch_bin_fill(&BA, st);
         agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_perm.p, u->d_dhit.p, u->d_tile_recs.p, st);
         AGX_CHECKPOINT("tile_sort");
+        };
+        run_segment(u->g_front, front);
         u->ev.mark(B_BIN, st);
         // ---- node sweep: every tile with small LDS buckets, then the tiles that overflowed with wider ones, then with global scratch (device-side lists) ----
         agx_node_kargs K; fill_sweep_args(u, K.S);
@@ -277,6 +308,7 @@ void do_build(agx_unit *u) {
         agx_launch_node_sweep(&K, st);
         AGX_CHECKPOINT("node_sweep");
         u->ev.mark(B_NODE, st); u->stats.node_sweep_launches++;
+        auto back = [&]() {
         agx_launch_node_sweep_big(&K, st);
         AGX_CHECKPOINT("node_sweep_big");
         u->ev.mark(B_BIG, st);
@@ -287,7 +319,7 @@ void do_build(agx_unit *u) {
         AGX_CHECKPOINT("edge_sweep");
         agx_launch_edge_jump(&E, st);
         AGX_CHECKPOINT("edge_jump");
-        u->ev.mark(B_EDGE, st); u->stats.edge_sweep_launches++;
+        u->ev.mark(B_EDGE, st);
         agx_launch_edge_slow(&E, st);
         AGX_CHECKPOINT("edge_slow");
         u->ev.mark(B_SLOW, st);
@@ -309,6 +341,10 @@ void do_build(agx_unit *u) {
         u->ev.mark(B_COMPACT, st);
         // ---- the one synchronisation ----
         agx_launch_collect(u->d_words.p + W_N, u->d_tile_off.p + u->n_tiles, u->d_tile_side_start.p + u->n_tiles, u->d_sp_rank.p + u->n_words, u->d_pool_cnt.p, u->n_regions, u->d_words.p + W_POOL, st);
+        };
+        run_segment(u->g_back, back);
+        u->stats.edge_sweep_launches++;
+        HIP_OK(hipEventRecord(u->ev.last, st));
         HIP_OK(hipEventRecord(u->ev_done, st));
         my_turn.unlock();
         HIP_OK(hipStreamWaitEvent(u->st, u->ev_done, 0));
@@ -319,7 +355,7 @@ void do_build(agx_unit *u) {
         if (w[W_ERR] & 1u) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
         if (w[W_ERR] & 2u) throw Error{E_UNSUPPORTED, "read alignment beyond the end of the unit sequence"};
         u->n_tile_entries = w[W_N];
-        if (u->n_tile_entries > u->list_cap) { u->list_cap = u->n_tile_entries + u->n_tile_entries / 8 + 1024; u->d_unsorted.release(); u->d_tile_recs.release(); continue; }
+        if (u->n_tile_entries > u->list_cap) { u->list_cap = u->n_tile_entries + u->n_tile_entries / 8 + 1024; u->d_unsorted.release(); u->d_tile_recs.release(); u->drop_graphs(); continue; }
         if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 64 node variants at one position"};
         if (w[W_STATUS] & 1u) {                  // a region's slice of the node pool ran out: cut the slices to what the regions asked for
             std::vector<agx_u32> padded((size_t)u->n_regions * AGX_REGION_PAD), demand(u->n_regions);
@@ -335,18 +371,20 @@ void do_build(agx_unit *u) {
                 alloc_pool(u, (agx_u32)need);
             }
             layout_regions(u, demand.data(), true);
+            u->drop_graphs();
             continue;
         }
         const unsigned long long want = w[W_POOL];
-        if (w[W_OVFCOUNT] > u->ovf_cap) { u->ovf_cap = w[W_OVFCOUNT] + w[W_OVFCOUNT] / 2 + 1024; u->d_ovf.release(); u->d_ovf.alloc(u->ovf_cap); u->d_a_ovf.release(); continue; }
+        if (w[W_OVFCOUNT] > u->ovf_cap) { u->ovf_cap = w[W_OVFCOUNT] + w[W_OVFCOUNT] / 2 + 1024; u->d_ovf.release(); u->d_ovf.alloc(u->ovf_cap); u->d_a_ovf.release(); u->drop_graphs(); continue; }
         u->n_nodes = (agx_u32)want; u->n_big = w[W_BIGCOUNT]; u->n_mid = w[W_MIDCOUNT]; u->n_ovf = w[W_OVFCOUNT];
         const unsigned long long ids = (unsigned long long)n_pos + w[W_N + 1];
         if (ids >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "walk graph exceeds 2^32 ids"};
-        if (w[W_N + 2] > u->sp_cap) { u->sp_cap = w[W_N + 2] + w[W_N + 2] / 8 + 1024; u->d_sp_node.release(); u->d_sp_hop.release(); continue; }
+        if (w[W_N + 2] > u->sp_cap) { u->sp_cap = w[W_N + 2] + w[W_N + 2] / 8 + 1024; u->d_sp_node.release(); u->d_sp_hop.release(); u->drop_graphs(); continue; }
         u->n_ids = (agx_u32)ids; u->n_special = w[W_N + 2];
         break;
     }
-    u->built = true; u->downloaded = false;
+    u->built = true; u->downloaded = false; u->builds_ok++;
+    u->stats.ms_build_span = u->ev.span();
     u->stats.ms_prep = u->ev.ms(B_PREP); u->stats.ms_bin = u->ev.ms(B_BIN); u->stats.ms_node_sweep = u->ev.ms(B_NODE);
     u->stats.ms_node_big = u->ev.ms(B_BIG); u->stats.ms_edge_fast = u->ev.ms(B_EDGE); u->stats.ms_edge_slow = u->ev.ms(B_SLOW); u->stats.ms_edge_sweep = u->stats.ms_edge_fast + u->stats.ms_edge_slow; u->stats.ms_compact = u->ev.ms(B_COMPACT);
 }
