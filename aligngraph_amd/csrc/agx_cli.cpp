@@ -689,7 +689,7 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
     // every unit reads tmp/_reads.fa (AG:1880): map and index it once for all of them
     agx_reads *reads = nullptr; { char err[512]; if (agx_reads_open("tmp/_reads.fa", &reads, err, sizeof err) != AGX_OK) reads = nullptr; }   // (a missing file is reported by the first unit, as before)
     // Units of very different sizes share a device: each is admitted only while the estimated HBM footprints of the units in flight
-    // stay below 85 % of the device's memory (a unit larger than that still runs, alone).  Estimate: ~260 B per reference position (node
+    // stay below 85 % of the device's memory (a unit larger than that still runs, alone).  Estimate: ~200 B per reference position (node
     // pool, walk graph, conti-mer tables at their first-guess capacities) + ~2 B per byte of the unit's SAM file (hits, tile records, read
     // bases) + 256 MB.
     auto file_bytes = [](const string &p) -> double { struct stat st; return stat(p.c_str(), &st) == 0 ? (double)st.st_size : 0.0; };
@@ -715,7 +715,7 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
             for (;;) {
                 const int u = next.fetch_add(1);
                 if (u >= units) return;
-                const double est = 260.0 * file_bytes("tmp/_genome." + itoa(u) + ".fa") + 2.0 * file_bytes("tmp/_reads_genome." + itoa(u) + ".bowtie") + 256e6;
+                const double est = 200.0 * file_bytes("tmp/_genome." + itoa(u) + ".fa") + 2.0 * file_bytes("tmp/_reads_genome." + itoa(u) + ".bowtie") + 256e6;
                 { std::unique_lock<std::mutex> g(mem_mu); mem_cv.wait(g, [&] { return used[d] == 0.0 || used[d] + est <= budget[d]; }); used[d] += est; }
                 agx_params p = {(uint32_t)o.k, (uint32_t)o.insertVariation, (uint32_t)o.coverage, 0, d, 0};
                 agx_result r; char err[512];
