@@ -131,6 +131,38 @@ def _take(res):
     return out
 
 
+class ResultViews:
+    """The three output buffers of agx_unit_finish without a Python copy: view(name) is a numpy uint8 array over the C buffer (valid until
+    free()), bytes(name) a copy.  A loop that runs many units from several threads should not hold the interpreter lock for megabytes of
+    byte-string copies per unit (bench.py)."""
+    _FIELDS = {"initial": ("initial_contigs", "initial_len"), "pre": ("pre_extended", "pre_len"), "extended": ("extended", "extended_len")}
+
+    def __init__(self, res):
+        self._res = res
+
+    def view(self, name):
+        import numpy as np
+        p, n = (getattr(self._res, f) for f in self._FIELDS[name])
+        if not p or not n:
+            return np.zeros(0, dtype=np.uint8)
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(n,))
+
+    def bytes(self, name):
+        p, n = (getattr(self._res, f) for f in self._FIELDS[name])
+        return ctypes.string_at(p, n) if p else b""
+
+    def free(self):
+        if self._res is not None:
+            lib().agx_result_free(ctypes.byref(self._res))
+            self._res = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Reads:
     """tmp/_reads.fa mapped and indexed once (agx_reads); pass it to Unit.load_files of every unit of the run."""
 
@@ -203,6 +235,11 @@ class Unit:
         r = Result()
         self._check(lib().agx_unit_finish(self._h, ctypes.byref(r)))
         return _take(r)
+
+    def finish_views(self):
+        r = Result()
+        self._check(lib().agx_unit_finish(self._h, ctypes.byref(r)))
+        return ResultViews(r)
 
     def stats(self):
         s = Stats()

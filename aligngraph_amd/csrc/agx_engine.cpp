@@ -104,7 +104,9 @@ namespace {
 // chains back to back — no host round trip and no cross-stream event wait in between (a stream-side wait on another stream's event
 // costs tens of microseconds per build here) — and per-kernel HIP-event times stay those of an exclusive device.  Uploads and copies to
 // the host (counter words, download, record fetches) use the unit's own stream and overlap the next unit's kernels.
-struct DeviceTurn { std::mutex m; hipStream_t build = nullptr; };
+struct DeviceTurn { std::mutex m; hipStream_t build = nullptr; hipEvent_t prev_last = nullptr; };
+// AGX_TRACE_GAP=1 (diagnostic, units must outlive each other's builds): print the idle time of the build stream in front of every build
+static const bool g_trace_gap = getenv("AGX_TRACE_GAP") != nullptr;
 // AGX_GRAPHS=1 (experiment): from a unit's third build on, the kernel chains in front of and behind the main sweep are replayed as captured
 // graphs.  Off by default: measured slower than enqueuing the ~30 commands one by one (1.56 vs 1.46 ms per step on the same box, ROCm 7.2).
 static const bool g_use_graphs = getenv("AGX_GRAPHS") != nullptr;
@@ -269,9 +271,10 @@ void do_build(agx_unit *u) {
             HIP_OK(hipGraphLaunch(gs.exec, st));
         };
         std::unique_lock<std::mutex> my_turn(turn.m);
-        if (!turn.build) HIP_OK(hipStreamCreateWithFlags(&turn.build, hipStreamNonBlocking));
+        if (!turn.build) HIP_OK(hipStreamCreateWithFlags(&turn.build, hipStreamNonBlocking));      // (a high-priority stream was tried: its kernels run 50 % slower)
         st = turn.build;
         HIP_OK(hipEventRecord(u->ev.first, st));
+        hipEvent_t gap_from = turn.prev_last; turn.prev_last = u->ev.last;
         // The kernel chain in front of the main sweep and the one behind it; the main sweep is launched between its two timing events.
         // (With AGX_GRAPHS=1 the two chains are stream captures replayed as graphs from a unit's third build on: same buffers, same
         // capacities, same arguments.)
@@ -351,6 +354,7 @@ void do_build(agx_unit *u) {
         HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, (W_N + 4) * 4, hipMemcpyDeviceToHost, u->st));
         HIP_OK(hipStreamSynchronize(u->st));
         HIP_OK(hipGetLastError());
+        if (g_trace_gap && gap_from && gap_from != u->ev.last) { float f = 0; if (hipEventElapsedTime(&f, gap_from, u->ev.first) == hipSuccess) fprintf(stderr, "[agx gap] %.3f ms idle before a %.3f ms build\n", f, u->ev.span()); else (void)hipGetLastError(); }
         const agx_u32 *w = u->h_words.p;
         if (w[W_ERR] & 1u) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
         if (w[W_ERR] & 2u) throw Error{E_UNSUPPORTED, "read alignment beyond the end of the unit sequence"};

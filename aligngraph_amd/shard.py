@@ -87,13 +87,15 @@ class UnitGather:
             self._recv_host = torch.zeros(cap * self.world, dtype=torch.uint8, pin_memory=pin)
 
     def step(self, payload, head=b""):
-        """payload (and an optional short head in front of it, so that a caller need not join the two) -> handle"""
+        """payload — bytes or a 1-D uint8 numpy array — and an optional short head in front of it (so that a caller need not join the two)
+        -> handle.  The payload is read before step() returns, except with a single rank, where the handle keeps a reference to it."""
         import numpy as np
         import torch
         if self.dist is None or self.world == 1:
             class _Local:
                 def payloads(_s):
-                    return [head + payload if head else payload]
+                    body = payload if isinstance(payload, (bytes, bytearray)) else payload.tobytes()
+                    return [head + body if head else body]
             return _Local()
         total = len(head) + len(payload)
         need = torch.tensor([total + 8], dtype=torch.int64, device=self.device)
@@ -107,8 +109,8 @@ class UnitGather:
         st[:8] = np.frombuffer(total.to_bytes(8, "little"), dtype=np.uint8)
         if head:
             st[8:8 + len(head)] = np.frombuffer(head, dtype=np.uint8)
-        if payload:
-            st[8 + len(head):8 + total] = np.frombuffer(payload, dtype=np.uint8)     # the one host copy of the payload
+        if len(payload):
+            st[8 + len(head):8 + total] = np.frombuffer(payload, dtype=np.uint8) if isinstance(payload, (bytes, bytearray)) else payload      # the one host copy of the payload
         self._dev.copy_(self._stage, non_blocking=True)
         if self.device.type == "cuda":
             self._staged = torch.cuda.Event()

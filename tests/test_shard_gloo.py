@@ -39,7 +39,8 @@ def _worker(rank, world, port, run, meta, q):
     g = shard.UnitGather(dist, torch.device("cpu"), rank, world)
     steps = [g.step(shard.pack_units(mine[:n], blobs[:n])).payloads() for n in (0, len(mine), 1)]
     # ... and the form that saves the host-side join: a short head in front of one unit's bytes
-    headed = g.step(blobs[0], head=shard.unit_header(mine[0], len(blobs[0]))).payloads() if mine else g.step(b"", head=shard.pack_units([], [])).payloads()
+    import numpy as np
+    headed = g.step(np.frombuffer(blobs[0], dtype=np.uint8), head=shard.unit_header(mine[0], len(blobs[0]))).payloads() if mine else g.step(b"", head=shard.pack_units([], [])).payloads()
     if rank == 0:
         merged = {}
         for payload in got:
