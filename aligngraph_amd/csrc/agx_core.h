@@ -46,6 +46,9 @@ typedef uint8_t agx_u8;
 #define AGX_MAXV_LDS 2u       // pass 0, every tile: variants per position held in LDS (2: 6.5 KB per wavefront -> 6 wavefronts per SIMD; the sweep
                               // waits on memory more than it computes: 0.66 ms with 2, 0.73 ms with 3 (4 wavefronts per SIMD) on the bench unit)
 #endif
+#ifndef AGX_SWEEP_FIRST
+#define AGX_SWEEP_FIRST 1        // straight-line store of a position's first variant (0: everything that leaves the fast path takes the general path)
+#endif
 #define AGX_MAXV_MID 4u       // pass 1, LDS again (13 KB per wavefront): the widest bucket whose x -> x+1 edges still fit the sweep's edge matrix
 #define AGX_MAXV_BIG 64u      // pass 2: buckets in global scratch
 #define AGX_MAXE 4u           // out-edges stored inline per node; more go to the overflow list
@@ -452,9 +455,21 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
         agx_bucket_add<LDS_ADD>(agx_b(b, 0, vote ? vfield : (agx_u32)AGX_F_COV), vote);
         agx_u32 vm = fast, sp = fast & p.step1;                                     // the straight-line case touches variant 0
         if (has & (fast ^ 1u)) {
-            if (ok) slow(p, p.h.start, c0_n, c0k, is_k1 != 0, votes ? vfield : (agx_u32)AGX_NF, vm);
-            sp = p.step1 ? agx_edge_spread(vm) : 0u;
-            if (cnt) { v0_ok = cx_n <= 1 ? 1u : 0u; v0_c0 = agx_b(b, 0, AGX_F_CID0); v0_o0 = agx_b(b, 0, AGX_F_COFF0); v0_m = agx_b(b, 0, AGX_F_OFF0); }
+            if (AGX_SWEEP_FIRST && cnt == 0 && cx_n <= 1 && c0_n <= 1) {
+                // The first arrival at a position with one candidate key — most of what leaves the fast path (7 % of the list entries on the
+                // bench unit create a variant somewhere) — stores variant 0 without the general path's loops over candidates and variants.
+                agx_b(b, 0, AGX_F_CID) = cx0.cid; agx_b(b, 0, AGX_F_COFF) = cx0.coff; agx_b(b, 0, AGX_F_CID0) = c0k.cid; agx_b(b, 0, AGX_F_COFF0) = c0k.coff;
+                agx_b(b, 0, AGX_F_OFF0) = p.p0; agx_b(b, 0, AGX_F_COV) = is_k1;
+                agx_b(b, 0, AGX_F_A) = 0; agx_b(b, 0, AGX_F_C) = 0; agx_b(b, 0, AGX_F_G) = 0; agx_b(b, 0, AGX_F_T) = 0; agx_b(b, 0, AGX_F_N) = 0;
+                agx_b(b, 0, AGX_F_S0) = p.s0; agx_b(b, 0, AGX_F_S1) = p.s1;
+                if (votes) agx_b(b, 0, vfield) = 1;
+                cnt = 1; vm = 1u; sp = p.step1;
+                v0_ok = 1u; v0_c0 = c0k.cid; v0_o0 = c0k.coff; v0_m = p.p0;
+            } else {
+                if (ok) slow(p, p.h.start, c0_n, c0k, is_k1 != 0, votes ? vfield : (agx_u32)AGX_NF, vm);
+                sp = p.step1 ? agx_edge_spread(vm) : 0u;
+                if (cnt) { v0_ok = cx_n <= 1 ? 1u : 0u; v0_c0 = agx_b(b, 0, AGX_F_CID0); v0_o0 = agx_b(b, 0, AGX_F_COFF0); v0_m = agx_b(b, 0, AGX_F_OFF0); }
+            }
         }
         exch(vm, sp);
     };

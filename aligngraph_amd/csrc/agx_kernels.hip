@@ -234,20 +234,12 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
         const agx_u32 X = tile * AGX_TILE + lane;
         agx_u32 cnt = 0, pflag = 0, emask = 0;
         const agx_tile_recs hits{K.S.tile_recs};
-#ifdef AGX_EXP_WARM
-        agx_u32 warm = 0;
-        { const agx_u32 lo = K.S.tile_off[tile], hi = K.S.tile_off[tile + 1];
-          for (agx_u32 i = lo + lane; i < hi; i += 64) warm ^= *reinterpret_cast<const volatile agx_u32 *>(K.S.tile_recs + 2 * (size_t)i); }
-#endif
         // every lane hands the variants a hit touched to its left neighbour (agx_edge_merge): the x -> x+1 edges of 63 of the tile's 64
         // positions fall out of the sweep itself; the fallback pass leaves them to the edge passes (its buckets exceed the edge matrix)
         const bool ok = agx_node_sweep_lane<!BIG>(K.S, tile, X, b, cnt, pflag, hits, [&](agx_u32 vm, agx_u32 sp) {
             // lane i reads lane i+1 with one DPP move (wave_shl:1; the last lane reads 0: its edges belong to the edge passes)
             if (!BIG) agx_edge_merge(emask, sp, (agx_u32)__builtin_amdgcn_update_dpp(0, (int)vm, 0x130, 0xF, 0xF, true));
         });
-#ifdef AGX_EXP_WARM
-        asm volatile("" :: "v"(warm));
-#endif
         if (__ballot(!ok) != 0ull) {                       // wave-uniform
             if (lane == 0) {
                 if (BIG) atomicOr(K.status, 2u);
@@ -264,12 +256,8 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
         // of a 0.93 ms sweep).  The ids of a unit are therefore not dense; everything downstream enters the table through node_start.
         const agx_u32 region = tile / AGX_REGION_TILES;
         const agx_u32 r_lo = agx_uload(K.region_off, region), r_hi = agx_uload(K.region_off, region + 1);
-#ifdef AGX_EXP_NOATOMIC
-        base = r_lo + (tile % AGX_REGION_TILES) * 80u;      // timing experiment only
-#else
         if (lane == 0) base = atomicAdd(K.pool_cnt + (size_t)region * AGX_REGION_PAD, total);
         base = r_lo + (agx_u32)__shfl(base, 0, 64);
-#endif
         if ((unsigned long long)base + total > r_hi) { if (lane == 0) atomicOr(K.status, 1u); if (PASS != 0) continue; else return; }
         const agx_u32 my_base = base + incl - cnt;
         const agx_u32 nbase = (agx_u32)__shfl_down((int)my_base, 1, 64), ncnt = (agx_u32)__shfl_down((int)cnt, 1, 64);
