@@ -59,9 +59,6 @@ struct Boundaries {
 
 }  // namespace
 
-// a captured segment of a build's kernel chain
-struct GraphSeg { hipGraphExec_t exec = nullptr; void reset() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; } };
-
 struct agx_unit {
     agx_params prm{};
     std::string err;
@@ -90,26 +87,22 @@ struct agx_unit {
     PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_hop> h_sp_hop; PBuf<agx_edge_ovf> h_a_ovf;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
-    GraphSeg g_front, g_back; int builds_ok = 0;      // successful builds since the buffers / capacities last changed
-    void drop_graphs() { g_front.reset(); g_back.reset(); builds_ok = 0; }
-    Boundaries ev; hipEvent_t ev_done = nullptr;      // recorded on the device's build stream behind the unit's last kernel
+    Boundaries ev; hipEvent_t ev_front = nullptr, ev_done = nullptr;      // recorded on the device's build stream behind the unit's last kernel
     agx_stats stats{};
-    ~agx_unit() { g_front.reset(); g_back.reset(); ev.destroy(); if (ev_done) (void)hipEventDestroy(ev_done); if (st) (void)hipStreamDestroy(st); }
+    ~agx_unit() { ev.destroy(); if (ev_front) (void)hipEventDestroy(ev_front); if (ev_done) (void)hipEventDestroy(ev_done); if (st) (void)hipStreamDestroy(st); }
 };
 
 namespace {
 
-// One build at a time per device, on the GPU as well as in the launch order: all builds of a device are queued on ONE stream, under a
-// mutex that a host thread holds only while it enqueues its unit's kernel chain.  Units built from several host threads then run their
-// chains back to back — no host round trip and no cross-stream event wait in between (a stream-side wait on another stream's event
-// costs tens of microseconds per build here) — and per-kernel HIP-event times stay those of an exclusive device.  Uploads and copies to
-// the host (counter words, download, record fetches) use the unit's own stream and overlap the next unit's kernels.
-struct DeviceTurn { std::mutex m; hipStream_t build = nullptr; hipEvent_t prev_last = nullptr; };
-// AGX_TRACE_GAP=1 (diagnostic, units must outlive each other's builds): print the idle time of the build stream in front of every build
-static const bool g_trace_gap = getenv("AGX_TRACE_GAP") != nullptr;
-// AGX_GRAPHS=1 (experiment): from a unit's third build on, the kernel chains in front of and behind the main sweep are replayed as captured
-// graphs.  Off by default: measured slower than enqueuing the ~30 commands one by one (1.56 vs 1.46 ms per step on the same box, ROCm 7.2).
-static const bool g_use_graphs = getenv("AGX_GRAPHS") != nullptr;
+// One build at a time per device, on the GPU as well as in the launch order.  All builds of a device are queued on TWO streams, under a
+// mutex that a host thread holds only while it enqueues its unit's kernel chain: `main` carries the node sweep and everything behind it
+// (edge passes, walk preparation), `front` what comes before the sweep (zeroing, hit preparation, binning).  Units built from several
+// host threads run their chains back to back — no host round trip in between — and the FRONT of build n+1 runs beside the BACK of build n:
+// it starts when sweep n is done (an event) and sweep n+1 waits for it (another).  The node sweep itself never shares the device, so its
+// HIP-event time is that of an exclusive GPU; the other sections are timed in exclusive builds (AGX_FLAG_TIME_SECTIONS serialises the two
+// streams).  Uploads and copies to the host (counter words, download, record fetches) use the unit's own stream.
+struct DeviceTurn { std::mutex m; hipStream_t main = nullptr, front = nullptr; hipEvent_t sweep_done[2] = {nullptr, nullptr}, build_done[2] = {nullptr, nullptr};
+                    unsigned long long n = 0; bool prev_exclusive = false; };      // n: builds queued so far; events alternate between two handles
 DeviceTurn &turn_of(int device) { static DeviceTurn turns[64]; return turns[device & 63]; }
 
 // AGX_DEBUG_SYNC=1: synchronise after every launch group of a build and name it on stderr — a memory fault then points at its kernel
@@ -158,7 +151,6 @@ void alloc_pool(agx_unit *u, agx_u32 cap) {
 }
 
 void do_upload(agx_unit *u) {
-    u->drop_graphs();
     if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
     const double t0 = now_ms();
     HIP_OK(hipSetDevice(u->prm.device));
@@ -257,28 +249,16 @@ void do_build(agx_unit *u) {
             u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16); }
 
         DeviceTurn &turn = turn_of(u->prm.device);
-        const bool use_graph = g_use_graphs && !g_debug_sync && !u->ev.all;
-        auto run_segment = [&](GraphSeg &gs, auto &enqueue) {
-            if (use_graph && gs.exec) { HIP_OK(hipGraphLaunch(gs.exec, st)); return; }
-            if (!use_graph || u->builds_ok < 2) { enqueue(); return; }
-            HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            hipGraph_t g = nullptr;
-            try { enqueue(); } catch (...) { (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); throw; }
-            HIP_OK(hipStreamEndCapture(st, &g));
-            const hipError_t e = hipGraphInstantiate(&gs.exec, g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-            if (e != hipSuccess) { gs.exec = nullptr; throw Error{E_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)}; }
-            HIP_OK(hipGraphLaunch(gs.exec, st));
-        };
         std::unique_lock<std::mutex> my_turn(turn.m);
-        if (!turn.build) HIP_OK(hipStreamCreateWithFlags(&turn.build, hipStreamNonBlocking));      // (a high-priority stream was tried: its kernels run 50 % slower)
-        st = turn.build;
+        if (!turn.main) {
+            HIP_OK(hipStreamCreateWithFlags(&turn.main, hipStreamNonBlocking)); HIP_OK(hipStreamCreateWithFlags(&turn.front, hipStreamNonBlocking));
+            for (auto &e : turn.sweep_done) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto &e : turn.build_done) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        // ---- front (its own stream): may run beside the previous build's edge passes and walk preparation, not beside its sweep ----
+        st = turn.front;
+        if (turn.n) HIP_OK(hipStreamWaitEvent(st, (u->ev.all || turn.prev_exclusive) ? turn.build_done[(turn.n - 1) & 1] : turn.sweep_done[(turn.n - 1) & 1], 0));
         HIP_OK(hipEventRecord(u->ev.first, st));
-        hipEvent_t gap_from = turn.prev_last; turn.prev_last = u->ev.last;
-        // The kernel chain in front of the main sweep and the one behind it; the main sweep is launched between its two timing events.
-        // (With AGX_GRAPHS=1 the two chains are stream captures replayed as graphs from a unit's third build on: same buffers, same
-        // capacities, same arguments.)
-        auto front = [&]() {
         {   // everything a build counts into or marks, zeroed by one kernel and one fill (every command on the stream costs a few microseconds)
             agx_zero_args Z; memset(&Z, 0, sizeof Z);
             auto seg = [&](int i, agx_u32 *ptr, size_t words) { Z.p[i] = ptr; Z.n[i] = (agx_u32)words; };
@@ -299,8 +279,10 @@ void do_build(agx_unit *u) {
         agx_launch_bin_fill(&BA, st);
         agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_perm.p, u->d_dhit.p, u->d_tile_recs.p, st);
         AGX_CHECKPOINT("tile_sort");
-        };
-        run_segment(u->g_front, front);
+        HIP_OK(hipEventRecord(u->ev_front, st));
+        // ---- main stream ----
+        st = turn.main;
+        HIP_OK(hipStreamWaitEvent(st, u->ev_front, 0));
         u->ev.mark(B_BIN, st);
         // ---- node sweep: every tile with small LDS buckets, then the tiles that overflowed with wider ones, then with global scratch (device-side lists) ----
         agx_node_kargs K; fill_sweep_args(u, K.S);
@@ -311,7 +293,7 @@ void do_build(agx_unit *u) {
         agx_launch_node_sweep(&K, st);
         AGX_CHECKPOINT("node_sweep");
         u->ev.mark(B_NODE, st); u->stats.node_sweep_launches++;
-        auto back = [&]() {
+        HIP_OK(hipEventRecord(turn.sweep_done[turn.n & 1], st));
         agx_launch_node_sweep_big(&K, st);
         AGX_CHECKPOINT("node_sweep_big");
         u->ev.mark(B_BIG, st);
@@ -344,22 +326,21 @@ void do_build(agx_unit *u) {
         u->ev.mark(B_COMPACT, st);
         // ---- the one synchronisation ----
         agx_launch_collect(u->d_words.p + W_N, u->d_tile_off.p + u->n_tiles, u->d_tile_side_start.p + u->n_tiles, u->d_sp_rank.p + u->n_words, u->d_pool_cnt.p, u->n_regions, u->d_words.p + W_POOL, st);
-        };
-        run_segment(u->g_back, back);
         u->stats.edge_sweep_launches++;
         HIP_OK(hipEventRecord(u->ev.last, st));
         HIP_OK(hipEventRecord(u->ev_done, st));
+        HIP_OK(hipEventRecord(turn.build_done[turn.n & 1], st));
+        turn.n++; turn.prev_exclusive = u->ev.all;
         my_turn.unlock();
         HIP_OK(hipStreamWaitEvent(u->st, u->ev_done, 0));
         HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, (W_N + 4) * 4, hipMemcpyDeviceToHost, u->st));
         HIP_OK(hipStreamSynchronize(u->st));
         HIP_OK(hipGetLastError());
-        if (g_trace_gap && gap_from && gap_from != u->ev.last) { float f = 0; if (hipEventElapsedTime(&f, gap_from, u->ev.first) == hipSuccess) fprintf(stderr, "[agx gap] %.3f ms idle before a %.3f ms build\n", f, u->ev.span()); else (void)hipGetLastError(); }
         const agx_u32 *w = u->h_words.p;
         if (w[W_ERR] & 1u) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
         if (w[W_ERR] & 2u) throw Error{E_UNSUPPORTED, "read alignment beyond the end of the unit sequence"};
         u->n_tile_entries = w[W_N];
-        if (u->n_tile_entries > u->list_cap) { u->list_cap = u->n_tile_entries + u->n_tile_entries / 8 + 1024; u->d_unsorted.release(); u->d_tile_recs.release(); u->drop_graphs(); continue; }
+        if (u->n_tile_entries > u->list_cap) { u->list_cap = u->n_tile_entries + u->n_tile_entries / 8 + 1024; u->d_unsorted.release(); u->d_tile_recs.release(); continue; }
         if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 64 node variants at one position"};
         if (w[W_STATUS] & 1u) {                  // a region's slice of the node pool ran out: cut the slices to what the regions asked for
             std::vector<agx_u32> padded((size_t)u->n_regions * AGX_REGION_PAD), demand(u->n_regions);
@@ -375,19 +356,18 @@ void do_build(agx_unit *u) {
                 alloc_pool(u, (agx_u32)need);
             }
             layout_regions(u, demand.data(), true);
-            u->drop_graphs();
-            continue;
+                    continue;
         }
         const unsigned long long want = w[W_POOL];
-        if (w[W_OVFCOUNT] > u->ovf_cap) { u->ovf_cap = w[W_OVFCOUNT] + w[W_OVFCOUNT] / 2 + 1024; u->d_ovf.release(); u->d_ovf.alloc(u->ovf_cap); u->d_a_ovf.release(); u->drop_graphs(); continue; }
+        if (w[W_OVFCOUNT] > u->ovf_cap) { u->ovf_cap = w[W_OVFCOUNT] + w[W_OVFCOUNT] / 2 + 1024; u->d_ovf.release(); u->d_ovf.alloc(u->ovf_cap); u->d_a_ovf.release(); continue; }
         u->n_nodes = (agx_u32)want; u->n_big = w[W_BIGCOUNT]; u->n_mid = w[W_MIDCOUNT]; u->n_ovf = w[W_OVFCOUNT];
         const unsigned long long ids = (unsigned long long)n_pos + w[W_N + 1];
         if (ids >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "walk graph exceeds 2^32 ids"};
-        if (w[W_N + 2] > u->sp_cap) { u->sp_cap = w[W_N + 2] + w[W_N + 2] / 8 + 1024; u->d_sp_node.release(); u->d_sp_hop.release(); u->drop_graphs(); continue; }
+        if (w[W_N + 2] > u->sp_cap) { u->sp_cap = w[W_N + 2] + w[W_N + 2] / 8 + 1024; u->d_sp_node.release(); u->d_sp_hop.release(); continue; }
         u->n_ids = (agx_u32)ids; u->n_special = w[W_N + 2];
         break;
     }
-    u->built = true; u->downloaded = false; u->builds_ok++;
+    u->built = true; u->downloaded = false;
     u->stats.ms_build_span = u->ev.span();
     u->stats.ms_prep = u->ev.ms(B_PREP); u->stats.ms_bin = u->ev.ms(B_BIN); u->stats.ms_node_sweep = u->ev.ms(B_NODE);
     u->stats.ms_node_big = u->ev.ms(B_BIG); u->stats.ms_edge_fast = u->ev.ms(B_EDGE); u->stats.ms_edge_slow = u->ev.ms(B_SLOW); u->stats.ms_edge_sweep = u->stats.ms_edge_fast + u->stats.ms_edge_slow; u->stats.ms_compact = u->ev.ms(B_COMPACT);
@@ -490,7 +470,7 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
     const int rc = guarded(u, [&] {
         HIP_OK(hipSetDevice(p->device));
         HIP_OK(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
-        u->ev.init(); u->ev.all = (u->prm.flags & AGX_FLAG_TIME_SECTIONS) != 0; HIP_OK(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming));
+        u->ev.init(); u->ev.all = (u->prm.flags & AGX_FLAG_TIME_SECTIONS) != 0; HIP_OK(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&u->ev_front, hipEventDisableTiming));
     });
     if (rc != AGX_OK) { delete u; return rc; }
     *out = u;
