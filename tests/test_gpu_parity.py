@@ -127,6 +127,39 @@ def test_rebuild_is_idempotent_and_batch_rule(agx, built, tmp_path):
             assert got["pre"] == o["pre"] and got["extended"] == o["extended"]
 
 
+def test_units_built_from_several_threads_share_the_device(agx, built, tmp_path):
+    # the way bench.py and AlignGraph_amd drive a device: every unit has a host thread that keeps rebuilding / walking it.  libagx queues the
+    # builds of a device on two shared streams (the front of one build beside the back of the previous one, sweeps one after the other);
+    # whatever the interleaving, every build must give its own unit's bytes.  One of the units times its sections (exclusive builds).
+    import threading
+    run = H.synth(str(tmp_path / "run"), seed=411, chroms="30000,22000,16000,9000", pairs=24000, coverage=3, multi=0.2, read_indel=0.2, sam_seq=0)
+    meta = H.read_meta(run)
+    tmp = os.path.join(run, "tmp")
+    want = [H.run_oracle(tmp, u, meta["k"], meta["insert_variation"], meta["coverage"]) for u in range(meta["units"])]
+    errors = []
+
+    def worker(i):
+        try:
+            with agx.Unit(k=meta["k"], insert_variation=meta["insert_variation"], coverage=meta["coverage"],
+                          flags=agx.AGX_FLAG_TIME_SECTIONS if i == 1 else 0) as u:
+                unit = i % meta["units"]
+                u.load_files(tmp, unit); u.upload()
+                for _ in range(12):
+                    u.build(); u.download()
+                    got = u.finish()
+                    for key in ("initial", "pre", "extended"):
+                        assert got[key] == want[unit][key], (i, key)
+        except BaseException as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2 * meta["units"])]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[0]
+
+
 def test_errors_come_back_as_codes(agx, built, tmp_path):
     run = H.synth(str(tmp_path / "run"), seed=5, chroms="5000", pairs=200, coverage=2, sam_seq=0, multi=0, read_indel=0, read_clip=0, read_badclip=0)
     tmp = os.path.join(run, "tmp")
