@@ -87,9 +87,9 @@ struct agx_unit {
     PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_hop> h_sp_hop; PBuf<agx_edge_ovf> h_a_ovf;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
-    Boundaries ev; hipEvent_t ev_front = nullptr, ev_done = nullptr;      // recorded on the device's build stream behind the unit's last kernel
+    Boundaries ev; hipEvent_t ev_front = nullptr, ev_passA = nullptr, ev_passJ = nullptr, ev_done = nullptr;      // recorded on the device's build stream behind the unit's last kernel
     agx_stats stats{};
-    ~agx_unit() { ev.destroy(); if (ev_front) (void)hipEventDestroy(ev_front); if (ev_done) (void)hipEventDestroy(ev_done); if (st) (void)hipStreamDestroy(st); }
+    ~agx_unit() { ev.destroy(); if (ev_front) (void)hipEventDestroy(ev_front); if (ev_passA) (void)hipEventDestroy(ev_passA); if (ev_passJ) (void)hipEventDestroy(ev_passJ); if (ev_done) (void)hipEventDestroy(ev_done); if (st) (void)hipStreamDestroy(st); }
 };
 
 namespace {
@@ -302,12 +302,24 @@ void do_build(agx_unit *u) {
         E.jump_list = u->d_jump_list.p; E.n_jump = u->n_jump; E.abort = u->d_words.p + W_STATUS; E.big_list = u->d_big_list.p; E.big_n = u->d_words.p + W_BIGCOUNT; E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
         agx_launch_edge_sweep(&E, st);
         AGX_CHECKPOINT("edge_sweep");
-        agx_launch_edge_jump(&E, st);
-        AGX_CHECKPOINT("edge_jump");
+        // Passes J and B insert edges out of different sources (positions with one variant / with several) and both wait on memory more than
+        // they compute: J goes to the front stream, behind pass A and in front of the next build's front, and runs beside B.  (Timed builds
+        // keep everything on the main stream.)
+        const bool side_j = !u->ev.all && !g_debug_sync;
+        if (side_j) {
+            HIP_OK(hipEventRecord(u->ev_passA, st));
+            HIP_OK(hipStreamWaitEvent(turn.front, u->ev_passA, 0));
+            agx_launch_edge_jump(&E, turn.front);
+            HIP_OK(hipEventRecord(u->ev_passJ, turn.front));
+        } else {
+            agx_launch_edge_jump(&E, st);
+            AGX_CHECKPOINT("edge_jump");
+        }
         u->ev.mark(B_EDGE, st);
         agx_launch_edge_slow(&E, st);
         AGX_CHECKPOINT("edge_slow");
         u->ev.mark(B_SLOW, st);
+        if (side_j) HIP_OK(hipStreamWaitEvent(st, u->ev_passJ, 0));
         // ---- walk preparation: side counts -> scan -> walk ids, node records, rewritten edges, forced-run flags ----
         agx_compact_args C; memset(&C, 0, sizeof C);
         C.node_start = u->d_node_start.p; C.node_cnt = u->d_node_cnt.p; C.n_flags = u->d_flags.p; C.n_base = u->d_base.p; C.n_xpos = u->d_xpos.p;
@@ -470,7 +482,7 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
     const int rc = guarded(u, [&] {
         HIP_OK(hipSetDevice(p->device));
         HIP_OK(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
-        u->ev.init(); u->ev.all = (u->prm.flags & AGX_FLAG_TIME_SECTIONS) != 0; HIP_OK(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&u->ev_front, hipEventDisableTiming));
+        u->ev.init(); u->ev.all = (u->prm.flags & AGX_FLAG_TIME_SECTIONS) != 0; HIP_OK(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&u->ev_front, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&u->ev_passA, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&u->ev_passJ, hipEventDisableTiming));
     });
     if (rc != AGX_OK) { delete u; return rc; }
     *out = u;
