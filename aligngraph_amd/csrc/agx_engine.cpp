@@ -87,9 +87,9 @@ struct agx_unit {
     PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_hop> h_sp_hop; PBuf<agx_edge_ovf> h_a_ovf;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
-    Boundaries ev; hipEvent_t ev_front = nullptr, ev_passA = nullptr, ev_passJ = nullptr, ev_done = nullptr;      // recorded on the device's build stream behind the unit's last kernel
+    Boundaries ev; hipEvent_t ev_front = nullptr, ev_passA = nullptr, ev_passJ = nullptr;      // recorded on the device's build stream behind the unit's last kernel
     agx_stats stats{};
-    ~agx_unit() { ev.destroy(); if (ev_front) (void)hipEventDestroy(ev_front); if (ev_passA) (void)hipEventDestroy(ev_passA); if (ev_passJ) (void)hipEventDestroy(ev_passJ); if (ev_done) (void)hipEventDestroy(ev_done); if (st) (void)hipStreamDestroy(st); }
+    ~agx_unit() { ev.destroy(); if (ev_front) (void)hipEventDestroy(ev_front); if (ev_passA) (void)hipEventDestroy(ev_passA); if (ev_passJ) (void)hipEventDestroy(ev_passJ); if (st) (void)hipStreamDestroy(st); }
 };
 
 namespace {
@@ -102,7 +102,7 @@ namespace {
 // HIP-event time is that of an exclusive GPU; the other sections are timed in exclusive builds (AGX_FLAG_TIME_SECTIONS serialises the two
 // streams).  Uploads and copies to the host (counter words, download, record fetches) use the unit's own stream.
 struct DeviceTurn { std::mutex m; hipStream_t main = nullptr, front = nullptr; hipEvent_t sweep_done[2] = {nullptr, nullptr}, build_done[2] = {nullptr, nullptr};
-                    unsigned long long n = 0; bool prev_exclusive = false; };      // n: builds queued so far; events alternate between two handles
+                    unsigned long long n = 0; bool prev_exclusive = false; hipEvent_t prev_node = nullptr; };      // n: builds queued so far; events alternate between two handles
 DeviceTurn &turn_of(int device) { static DeviceTurn turns[64]; return turns[device & 63]; }
 
 // AGX_DEBUG_SYNC=1: synchronise after every launch group of a build and name it on stderr — a memory fault then points at its kernel
@@ -258,7 +258,7 @@ void do_build(agx_unit *u) {
         // ---- front (its own stream): may run beside the previous build's edge passes and walk preparation, not beside its sweep ----
         st = turn.front;
         if (turn.n) HIP_OK(hipStreamWaitEvent(st, (u->ev.all || turn.prev_exclusive) ? turn.build_done[(turn.n - 1) & 1] : turn.sweep_done[(turn.n - 1) & 1], 0));
-        HIP_OK(hipEventRecord(u->ev.first, st));
+        if (u->ev.all) HIP_OK(hipEventRecord(u->ev.first, st));      // (every event record costs the stream a few microseconds: untimed builds record only what orders them)
         {   // everything a build counts into or marks, zeroed by one kernel and one fill (every command on the stream costs a few microseconds)
             agx_zero_args Z; memset(&Z, 0, sizeof Z);
             auto seg = [&](int i, agx_u32 *ptr, size_t words) { Z.p[i] = ptr; Z.n[i] = (agx_u32)words; };
@@ -293,6 +293,7 @@ void do_build(agx_unit *u) {
         agx_launch_node_sweep(&K, st);
         AGX_CHECKPOINT("node_sweep");
         u->ev.mark(B_NODE, st); u->stats.node_sweep_launches++;
+        hipEvent_t trace_from = turn.prev_node; turn.prev_node = u->ev.e[B_NODE];
         HIP_OK(hipEventRecord(turn.sweep_done[turn.n & 1], st));
         agx_launch_node_sweep_big(&K, st);
         AGX_CHECKPOINT("node_sweep_big");
@@ -339,15 +340,17 @@ void do_build(agx_unit *u) {
         // ---- the one synchronisation ----
         agx_launch_collect(u->d_words.p + W_N, u->d_tile_off.p + u->n_tiles, u->d_tile_side_start.p + u->n_tiles, u->d_sp_rank.p + u->n_words, u->d_pool_cnt.p, u->n_regions, u->d_words.p + W_POOL, st);
         u->stats.edge_sweep_launches++;
-        HIP_OK(hipEventRecord(u->ev.last, st));
-        HIP_OK(hipEventRecord(u->ev_done, st));
-        HIP_OK(hipEventRecord(turn.build_done[turn.n & 1], st));
+        if (u->ev.all) HIP_OK(hipEventRecord(u->ev.last, st));
+        hipEvent_t done = turn.build_done[turn.n & 1];                       // (a stream wait binds to the record that precedes it: the handle may be recorded again later)
+        HIP_OK(hipEventRecord(done, st));
+        HIP_OK(hipStreamWaitEvent(u->st, done, 0));
         turn.n++; turn.prev_exclusive = u->ev.all;
         my_turn.unlock();
-        HIP_OK(hipStreamWaitEvent(u->st, u->ev_done, 0));
         HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, (W_N + 4) * 4, hipMemcpyDeviceToHost, u->st));
         HIP_OK(hipStreamSynchronize(u->st));
         HIP_OK(hipGetLastError());
+        if (getenv("AGX_TRACE_GAP") && trace_from && trace_from != u->ev.e[B_NODE]) {      // diagnostic (units must outlive each other's builds): end of the previous sweep -> start of this one
+            float f = 0; if (hipEventElapsedTime(&f, trace_from, u->ev.e[B_BIN]) == hipSuccess) fprintf(stderr, "[agx gap] %.3f ms between sweeps, %.3f ms sweep\n", f, u->ev.ms(B_NODE)); else (void)hipGetLastError(); }
         const agx_u32 *w = u->h_words.p;
         if (w[W_ERR] & 1u) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
         if (w[W_ERR] & 2u) throw Error{E_UNSUPPORTED, "read alignment beyond the end of the unit sequence"};
@@ -380,7 +383,7 @@ void do_build(agx_unit *u) {
         break;
     }
     u->built = true; u->downloaded = false;
-    u->stats.ms_build_span = u->ev.span();
+    u->stats.ms_build_span = u->ev.all ? u->ev.span() : 0.0;
     u->stats.ms_prep = u->ev.ms(B_PREP); u->stats.ms_bin = u->ev.ms(B_BIN); u->stats.ms_node_sweep = u->ev.ms(B_NODE);
     u->stats.ms_node_big = u->ev.ms(B_BIG); u->stats.ms_edge_fast = u->ev.ms(B_EDGE); u->stats.ms_edge_slow = u->ev.ms(B_SLOW); u->stats.ms_edge_sweep = u->stats.ms_edge_fast + u->stats.ms_edge_slow; u->stats.ms_compact = u->ev.ms(B_COMPACT);
 }
@@ -482,7 +485,7 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
     const int rc = guarded(u, [&] {
         HIP_OK(hipSetDevice(p->device));
         HIP_OK(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
-        u->ev.init(); u->ev.all = (u->prm.flags & AGX_FLAG_TIME_SECTIONS) != 0; HIP_OK(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&u->ev_front, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&u->ev_passA, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&u->ev_passJ, hipEventDisableTiming));
+        u->ev.init(); u->ev.all = (u->prm.flags & AGX_FLAG_TIME_SECTIONS) != 0; HIP_OK(hipEventCreateWithFlags(&u->ev_front, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&u->ev_passA, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&u->ev_passJ, hipEventDisableTiming));
     });
     if (rc != AGX_OK) { delete u; return rc; }
     *out = u;

@@ -100,7 +100,7 @@ typedef struct {
     uint64_t n_walk_ids, n_special, n_fetched, download_bytes;   /* walk graph: ids, node records downloaded, records fetched one by one, D2H bytes */
     double ms_edge_fast, ms_edge_slow;                           /* the two kernels of ms_edge_sweep: pass A (lanes = positions), pass B (lanes = hits) */
     uint64_t n_mid_tiles;                                        /* tiles swept again with wider LDS buckets (n_big_tiles: of those, again with global scratch) */
-    double ms_build_span;                                        /* device time from the first to the last command of the build (all kernels and the gaps between them) */
+    double ms_build_span;                                        /* with AGX_FLAG_TIME_SECTIONS: device time from the first to the last command of the build (all kernels and the gaps between them) */
 } agx_stats;
 
 /* Node/edge tables in canonical numbering (position-major, variant order), for parity tests. malloc'd; free with agx_graph_free. */
