@@ -69,7 +69,7 @@ struct agx_unit {
     DBuf<agx_u32> d_cm_start; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref;
     DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<char> d_bases;
     // derived
-    DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_recs, d_scan_tmp, d_words;   // d_words: counters/status
+    DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_recs, d_scan_tmp, d_words; DBuf<unsigned long long> d_scan_desc; size_t scan_desc_n = 0;      // descriptors of the three one-launch scans   // d_words: counters/status
     // node table
     agx_u32 pool_cap = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
     DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
@@ -105,6 +105,8 @@ struct DeviceTurn { std::mutex m; hipStream_t main = nullptr, front = nullptr; h
                     unsigned long long n = 0; bool prev_exclusive = false; hipEvent_t prev_node = nullptr; };      // n: builds queued so far; events alternate between two handles
 DeviceTurn &turn_of(int device) { static DeviceTurn turns[64]; return turns[device & 63]; }
 
+// AGX_SCAN_LEGACY=1: the scans of a build as three launches each instead of one (decoupled look-back)
+static const bool g_scan1 = getenv("AGX_SCAN_LEGACY") == nullptr;
 // AGX_DEBUG_SYNC=1: synchronise after every launch group of a build and name it on stderr — a memory fault then points at its kernel
 static const bool g_debug_sync = getenv("AGX_DEBUG_SYNC") != nullptr;
 #define AGX_CHECKPOINT(name) do { if (g_debug_sync) { hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, "[agx debug] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
@@ -246,7 +248,8 @@ void do_build(agx_unit *u) {
         u->d_sp_node.alloc((size_t)u->sp_cap + 1); u->d_sp_hop.alloc((size_t)u->sp_cap + 1);
         u->d_sp_bits.alloc((size_t)u->n_words + 1); u->d_sp_cnt.alloc((size_t)u->n_words + 1); u->d_sp_rank.alloc((size_t)u->n_words + 2);
         {   const size_t nb = ((size_t)std::max<size_t>(n_pos, u->n_words) + 1 + 1023) / 1024;
-            u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16); }
+            u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16);
+            u->scan_desc_n = (std::max<size_t>(u->n_tiles, u->n_words) + 1) / 4096 + 2; u->d_scan_desc.alloc(3 * u->scan_desc_n); }
 
         DeviceTurn &turn = turn_of(u->prm.device);
         std::unique_lock<std::mutex> my_turn(turn.m);
@@ -264,6 +267,7 @@ void do_build(agx_unit *u) {
             auto seg = [&](int i, agx_u32 *ptr, size_t words) { Z.p[i] = ptr; Z.n[i] = (agx_u32)words; };
             seg(0, u->d_words.p, W_N + 4); seg(1, u->d_tile_cnt.p, (size_t)u->n_tiles + 1); seg(2, u->d_cursor.p, (size_t)u->n_tiles + 1);
             seg(3, u->d_pool_cnt.p, (size_t)u->n_regions * AGX_REGION_PAD); seg(4, u->d_tile_side.p + u->n_tiles, 1); seg(5, u->d_sp_cnt.p + u->n_words, 1);
+            seg(6, reinterpret_cast<agx_u32 *>(u->d_scan_desc.p), 6 * u->scan_desc_n);
             agx_launch_zero(&Z, st);
             HIP_OK(hipMemsetAsync(u->d_a_mark.p, 0, ids_cap + 2, st));
         }
@@ -274,7 +278,8 @@ void do_build(agx_unit *u) {
         AGX_CHECKPOINT("hit_prep");
         u->ev.mark(B_PREP, st);
         // ---- tile lists ----
-        agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
+        if (g_scan1) agx_launch_exclusive_scan1(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_desc.p, st);
+        else agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
         agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, (const uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
         agx_launch_bin_fill(&BA, st);
         agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_perm.p, u->d_dhit.p, u->d_tile_recs.p, st);
@@ -330,15 +335,16 @@ void do_build(agx_unit *u) {
         C.abort = u->d_words.p + W_STATUS;
         C.a_mark = u->d_a_mark.p; C.side_xpos = u->d_side_xpos.p; C.sparse_min = (u->prm.flags & AGX_FLAG_SPARSE_MIN) ? 1u : 0u;
         C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p; C.hop = u->d_hop.p; C.sp_hop = u->d_sp_hop.p; C.sp_cap = u->sp_cap;
-        agx_launch_exclusive_scan(u->d_tile_side.p, u->d_tile_side_start.p, u->n_tiles, u->d_scan_tmp.p, st);      // per tile: the sweep has scanned inside the tiles
+        if (g_scan1) agx_launch_exclusive_scan1(u->d_tile_side.p, u->d_tile_side_start.p, u->n_tiles, u->d_scan_desc.p + u->scan_desc_n, st);
+        else agx_launch_exclusive_scan(u->d_tile_side.p, u->d_tile_side_start.p, u->n_tiles, u->d_scan_tmp.p, st);      // per tile: the sweep has scanned inside the tiles
         agx_launch_compact(&C, u->d_chain_end.p, u->n_chain_end, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
         AGX_CHECKPOINT("compact");
-        agx_launch_special(&C, u->n_words, u->d_sp_rank.p, u->d_scan_tmp.p, st);
+        agx_launch_special(&C, u->n_words, u->d_sp_rank.p, u->d_scan_tmp.p, g_scan1 ? u->d_scan_desc.p + 2 * u->scan_desc_n : nullptr,
+                           u->d_words.p + W_N, u->d_tile_off.p + u->n_tiles, u->d_tile_side_start.p + u->n_tiles, u->d_pool_cnt.p, u->n_regions, u->d_words.p + W_POOL, st);
         u->walk_args = C;
         AGX_CHECKPOINT("special");
         u->ev.mark(B_COMPACT, st);
         // ---- the one synchronisation ----
-        agx_launch_collect(u->d_words.p + W_N, u->d_tile_off.p + u->n_tiles, u->d_tile_side_start.p + u->n_tiles, u->d_sp_rank.p + u->n_words, u->d_pool_cnt.p, u->n_regions, u->d_words.p + W_POOL, st);
         u->stats.edge_sweep_launches++;
         if (u->ev.all) HIP_OK(hipEventRecord(u->ev.last, st));
         hipEvent_t done = turn.build_done[turn.n & 1];                       // (a stream wait binds to the record that precedes it: the handle may be recorded again later)

@@ -43,13 +43,12 @@ extern "C" {
 // one kernel that zeroes up to eight u32 ranges
 struct agx_zero_args { agx_u32 *p[8]; agx_u32 n[8]; };
 void agx_launch_zero(const agx_zero_args *, hipStream_t);
-// the totals the host wants next to the counter words: out[0..2] = *a, *b, *c; *sum = nodes handed out = sum of the region counters
-void agx_launch_collect(agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *c, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, hipStream_t);
 void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t);      // n_pos + 1 heads
 void agx_launch_vote_codes(void *blob, size_t n_bytes16, hipStream_t);      // read bases -> agx_vote_code, in place; n_bytes16 a multiple of 16
 void agx_launch_hit_prep(const agx_prep_args *, hipStream_t);
 // exclusive scan of in[0..n] (n+1 entries, in[n] must be 0) into out[0..n]; out[n] = total
 void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u32 *tmp, hipStream_t);
+void agx_launch_exclusive_scan1(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsigned long long *desc, hipStream_t);      // one launch; desc: ceil((n+1)/4096) zeroed words
 void agx_launch_bin_fill(const agx_bin_args *, hipStream_t);
 void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_u32 *file_order, const agx_dhit *dhit, void *recs, hipStream_t);
 void agx_launch_node_sweep(const agx_node_kargs *, hipStream_t);
@@ -62,7 +61,10 @@ void agx_launch_edge_slow(const agx_edge_kargs *, hipStream_t);           // pas
 // from the walk preparation; the grids are sized by the capacities.
 void agx_launch_fetch_records(const agx_compact_args *, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *out, hipStream_t);
 void agx_launch_compact(const agx_compact_args *, const agx_u32 *chain_end, agx_u32 n_chain_end, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t);
-void agx_launch_special(const agx_compact_args *, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, hipStream_t);
+// special ids: bitmap, rank scan (desc: the one-launch scan; null: the three-launch one with scan_tmp), records; block 0 of the last kernel also leaves the
+// totals the host reads: out[0..2] = *a, *b, sp_rank[n_words]; *sum = nodes handed out = the sum of the region counters
+void agx_launch_special(const agx_compact_args *, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, unsigned long long *desc,
+                        agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, hipStream_t);
 #define AGX_MID_WAVES 3072u     // wavefronts of pass 1 (3 per SIMD fit its LDS buckets); they stride over the list of tiles pass 0 gave up on
 #define AGX_BIG_WAVES 256u      // resident wavefronts of the global-scratch fallback pass
 }

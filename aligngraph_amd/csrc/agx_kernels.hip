@@ -36,15 +36,16 @@ __global__ void __launch_bounds__(256) agx_k_zero(agx_zero_args Z) {
     agx_u32 i = blockIdx.x * 256u + threadIdx.x;
     for (int s = 0; s < 8; s++) { if (i < Z.n[s]) { Z.p[s][i] = 0u; return; } i -= Z.n[s]; }
 }
-// the last kernel of a build: the totals the host reads next to the counter words — out[0..2] = *a, *b, *c, *sum = nodes handed out (the
-// sum of the region counters; a unit has fewer than 2^32 nodes: the slices' layout is refused otherwise)
-__global__ void __launch_bounds__(256) agx_k_collect(agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *c, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum) {
+// The totals the host reads next to the counter words — out[0..2] = *a, *b, *c, *sum = nodes handed out (the sum of the region counters; a
+// unit has fewer than 2^32 nodes: the slices' layout is refused otherwise).  Done by block 0 of the build's last kernel.
+struct agx_collect_args { agx_u32 *out; const agx_u32 *a, *b, *c, *pool_cnt; agx_u32 regions; agx_u32 *sum; };
+__device__ __forceinline__ void agx_collect_block(const agx_collect_args &G) {
     __shared__ agx_u32 part[256];
     agx_u32 t = 0;
-    for (agx_u32 r = threadIdx.x; r < regions; r += 256u) t += pool_cnt[(size_t)r * AGX_REGION_PAD];
+    for (agx_u32 r = threadIdx.x; r < G.regions; r += 256u) t += G.pool_cnt[(size_t)r * AGX_REGION_PAD];
     part[threadIdx.x] = t; __syncthreads();
     for (agx_u32 o = 128; o; o >>= 1) { if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) { out[0] = *a; out[1] = *b; out[2] = *c; *sum = part[0]; }
+    if (threadIdx.x == 0) { G.out[0] = *G.a; G.out[1] = *G.b; G.out[2] = *G.c; *G.sum = part[0]; }
 }
 // read bases -> vote codes, in place (16 characters per thread; the blob is padded to a multiple of 16)
 __global__ void __launch_bounds__(256) agx_k_vote_codes(uint4 *blob, size_t n16) {
@@ -132,6 +133,54 @@ __global__ void __launch_bounds__(256) agx_k_scan_blocks(const agx_u32 *in, agx_
 __global__ void __launch_bounds__(256) agx_k_scan_add(agx_u32 *out, const agx_u32 *block_offsets, agx_u32 n) {
     const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) out[i] += block_offsets[i / AGX_SCAN_BLOCK];
+}
+
+// The same scan in ONE launch (decoupled look-back): every block publishes the sum of its 4096 elements in a 64-bit descriptor (flag in the top
+// bits, value below), then finds its exclusive prefix by looking back over its predecessors' descriptors — a wavefront reads 64 of them at a
+// time — until it meets one that already holds an inclusive prefix, and publishes its own.  Blocks are dispatched in order, so a predecessor
+// is always running or done.  desc[] must be zero when the kernel starts.  (A command boundary costs the stream ~8 us: three launches per scan
+// were most of what a small scan cost.)
+#define AGX_SCAN_AGG (1ull << 62)
+#define AGX_SCAN_PFX (2ull << 62)
+__global__ void __launch_bounds__(256) agx_k_scan_lookback(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsigned long long *desc) {
+    __shared__ agx_u32 sh[256];
+    __shared__ agx_u32 sh_excl;
+    const agx_u32 b = blockIdx.x, base = b * AGX_SCAN_BLOCK + threadIdx.x * AGX_SCAN_ITEMS;
+    agx_u32 v[AGX_SCAN_ITEMS], s = 0;
+    for (int i = 0; i < AGX_SCAN_ITEMS; i++) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (agx_u32 off = 1; off < 256; off <<= 1) {
+        agx_u32 t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const agx_u32 total = sh[255];
+    if (threadIdx.x < 64) {                               // the first wavefront looks back
+        const agx_u32 lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_store(&desc[b], (b == 0 ? AGX_SCAN_PFX : AGX_SCAN_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        agx_u32 excl = 0;
+        for (long long hi = (long long)b - 1; hi >= 0;) {                     // window of predecessors hi, hi-1, .., hi-63
+            const long long j = hi - lane;
+            unsigned long long d = AGX_SCAN_PFX;                              // lanes before block 0: a prefix of 0
+            if (j >= 0) do { d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((d >> 62) == 0);
+            const unsigned long long pfx = __ballot((d >> 62) == 2);
+            const agx_u32 stop = pfx ? (agx_u32)__builtin_ctzll(pfx) : 63u;   // nearest predecessor that holds an inclusive prefix
+            agx_u32 part = lane <= stop ? (agx_u32)d : 0u;
+            for (agx_u32 o = 32; o; o >>= 1) part += __shfl_down(part, o, 64);
+            excl += __shfl(part, 0, 64);
+            if (pfx) break;
+            hi -= 64;
+        }
+        if (lane == 0) {
+            if (b) __hip_atomic_store(&desc[b], AGX_SCAN_PFX | (unsigned long long)(agx_u32)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_excl = excl;
+        }
+    }
+    __syncthreads();
+    agx_u32 run = sh_excl + sh[threadIdx.x] - s;
+    for (int i = 0; i < AGX_SCAN_ITEMS; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
 }
 
 // ---- tile lists: scatter, then rank-sort each list so that hits are applied in SAM order ---------------------------
@@ -405,7 +454,8 @@ __global__ void __launch_bounds__(256) agx_k_special_bits(agx_compact_args A, ag
     if ((threadIdx.x & 63u) == 0) { A.sp_bits[w] = bits; A.sp_cnt[w] = (agx_u32)__popcll(bits); }
 }
 // gather the special records in id order
-__global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, agx_u32 n_words) {
+__global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, agx_u32 n_words, agx_collect_args G) {
+    if (blockIdx.x == 0) agx_collect_block(G);          // (also when the build was aborted: the host sizes the retry from these)
     AGX_RETURN_IF_ABORTED(A.abort);
     const agx_u32 a = blockIdx.x * 256u + threadIdx.x, w = a >> 6;
     if (w >= n_words) return;
@@ -436,9 +486,6 @@ void agx_launch_zero(const agx_zero_args *Z, hipStream_t st) {
     unsigned long long total = 0; for (int s = 0; s < 8; s++) total += Z->n[s];
     if (total) hipLaunchKernelGGL(agx_k_zero, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *Z);
 }
-void agx_launch_collect(agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *c, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, hipStream_t st) {
-    hipLaunchKernelGGL(agx_k_collect, dim3(1), dim3(256), 0, st, out, a, b, c, pool_cnt, regions, sum);
-}
 void agx_launch_vote_codes(void *blob, size_t n_bytes16, hipStream_t st) {
     const size_t n16 = n_bytes16 / 16;
     if (n16) hipLaunchKernelGGL(agx_k_vote_codes, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (uint4 *)blob, n16);
@@ -465,6 +512,12 @@ void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u
         hipLaunchKernelGGL(agx_k_scan_add, dim3((nb + 255) / 256), dim3(256), 0, st, sums_scanned, sums2_scanned, nb);
     }
     hipLaunchKernelGGL(agx_k_scan_add, dim3((m + 255) / 256), dim3(256), 0, st, out, sums_scanned, m);
+}
+
+// the one-launch form; desc: ceil((n+1)/4096) zeroed 64-bit words
+void agx_launch_exclusive_scan1(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsigned long long *desc, hipStream_t st) {
+    const agx_u32 m = n + 1;                              // callers allocate in with n+1 entries, in[n] = 0: out[n] = total
+    hipLaunchKernelGGL(agx_k_scan_lookback, dim3((m + AGX_SCAN_BLOCK - 1) / AGX_SCAN_BLOCK), dim3(256), 0, st, in, out, m, desc);
 }
 
 void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {
@@ -515,12 +568,13 @@ void agx_launch_compact(const agx_compact_args *A, const agx_u32 *chain_end, agx
     if (n2) hipLaunchKernelGGL(agx_k_emit_alive, dim3((n2 + 255) / 256), dim3(256), 0, st, *A, n_ovf_dev, ovf_cap);
 }
 // sparse record table over n_words 64-id words (the id capacity; the live id count is read on the device); scan_tmp as for the scans
-void agx_launch_special(const agx_compact_args *A, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, hipStream_t st) {
-    if (!n_words) return;
+void agx_launch_special(const agx_compact_args *A, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, unsigned long long *desc,
+                        agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, hipStream_t st) {
+    const agx_collect_args G{out, a, b, sp_rank + n_words, pool_cnt, regions, sum};
     const agx_u32 blocks = (agx_u32)(((unsigned long long)n_words * 64u + 255u) / 256u);
     hipLaunchKernelGGL(agx_k_special_bits, dim3(blocks), dim3(256), 0, st, *A, n_words);
-    agx_launch_exclusive_scan(A->sp_cnt, sp_rank, n_words, scan_tmp, st);
-    hipLaunchKernelGGL(agx_k_special_emit, dim3(blocks), dim3(256), 0, st, *A, n_words);
+    if (desc) agx_launch_exclusive_scan1(A->sp_cnt, sp_rank, n_words, desc, st); else agx_launch_exclusive_scan(A->sp_cnt, sp_rank, n_words, scan_tmp, st);
+    hipLaunchKernelGGL(agx_k_special_emit, dim3(blocks), dim3(256), 0, st, *A, n_words, G);
 }
 
 }  // extern "C"
