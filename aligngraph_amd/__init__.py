@@ -17,7 +17,7 @@ AGX_FLAG_TIME_SECTIONS = 4
 
 # every symbol include/agx.h declares (tests check that the built library exports all of them)
 EXPORTS = [
-    "agx_version", "agx_device_count", "agx_device_memory", "agx_unit_create", "agx_unit_destroy", "agx_unit_error", "agx_unit_set_reference",
+    "agx_version", "agx_device_count", "agx_device_memory", "agx_selftest_scan", "agx_unit_create", "agx_unit_destroy", "agx_unit_error", "agx_unit_set_reference",
     "agx_unit_set_contig_threads", "agx_unit_push_pairs", "agx_unit_load_files", "agx_unit_upload", "agx_unit_build", "agx_unit_download",
     "agx_unit_finish", "agx_result_free", "agx_unit_stats", "agx_unit_graph", "agx_graph_free", "agx_run_unit",
     "agx_reads_open", "agx_reads_close", "agx_unit_load_files_shared", "agx_run_unit_shared",
@@ -100,6 +100,7 @@ def lib():
                                                   ctypes.POINTER(ContiMer), ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
         L.agx_unit_push_pairs.argtypes = [ctypes.c_void_p, ctypes.POINTER(PairBatch)]
         L.agx_device_memory.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+        L.agx_selftest_scan.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         L.agx_unit_load_files.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.agx_reads_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_char_p, ctypes.c_size_t]
         L.agx_reads_close.argtypes = [ctypes.c_void_p]

@@ -470,6 +470,25 @@ const char *agx_version(void) { return "aligngraph_amd 0.1 (gfx950)"; }
 
 int agx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
+int agx_selftest_scan(int device, uint32_t n, uint32_t seed) {
+    try {
+        HIP_OK(hipSetDevice(device));
+        std::vector<agx_u32> in((size_t)n + 1, 0), want((size_t)n + 1), got((size_t)n + 1);
+        agx_u32 x = seed * 2654435761u + 1u, acc = 0;
+        for (uint32_t i = 0; i < n; i++) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; in[i] = (x % 5u == 0) ? x % 97u : 0u; }       // mostly zeros, like the side-id counts
+        for (uint32_t i = 0; i <= n; i++) { want[i] = acc; acc += in[i]; }
+        const size_t nb = ((size_t)n + 1 + 4095) / 4096;
+        DBuf<agx_u32> d_in, d_out; DBuf<unsigned long long> d_desc;
+        d_in.alloc((size_t)n + 1); d_out.alloc((size_t)n + 1); d_desc.alloc(nb + 1);
+        HIP_OK(hipMemcpy(d_in.p, in.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemset(d_desc.p, 0, (nb + 1) * 8)); HIP_OK(hipMemset(d_out.p, 0xFF, ((size_t)n + 1) * 4));
+        agx_launch_exclusive_scan1(d_in.p, d_out.p, n, d_desc.p, nullptr);
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemcpy(got.data(), d_out.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+        return got == want ? AGX_OK : AGX_E_DEVICE;
+    } catch (const Error &) { return AGX_E_DEVICE; }
+}
+
 int agx_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
     size_t f = 0, t = 0;
     if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) return AGX_E_DEVICE;

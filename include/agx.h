@@ -119,6 +119,7 @@ typedef struct {
 const char *agx_version(void);
 int agx_device_count(void);                                   /* HIP devices visible; 0 when there is no GPU */
 int agx_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);   /* HBM of one device (hipMemGetInfo) */
+int agx_selftest_scan(int device, uint32_t n, uint32_t seed);   /* test hook: the build's one-launch prefix scan over n pseudo-random counts against a host scan; AGX_OK or AGX_E_DEVICE */
 
 int agx_unit_create(const agx_params *p, agx_unit **out);
 void agx_unit_destroy(agx_unit *u);

@@ -160,6 +160,13 @@ def test_units_built_from_several_threads_share_the_device(agx, built, tmp_path)
     assert not errors, errors[0]
 
 
+def test_one_launch_scan_against_a_host_scan(agx):
+    # the decoupled look-back scan of the build (tile histogram, side ids, special ids): one block, block edges, more than one look-back
+    # window of 64 predecessors (a unit needs 16 M positions for that), a few hundred windows
+    for n, seed in ((0, 1), (1, 2), (4094, 3), (4095, 4), (4096, 5), (4097, 6), (72000, 7), (300000, 8), (1200000, 9), (20000000, 10), (20000001, 11)):
+        assert agx.lib().agx_selftest_scan(0, n, seed) == 0, n
+
+
 def test_errors_come_back_as_codes(agx, built, tmp_path):
     run = H.synth(str(tmp_path / "run"), seed=5, chroms="5000", pairs=200, coverage=2, sam_seq=0, multi=0, read_indel=0, read_clip=0, read_badclip=0)
     tmp = os.path.join(run, "tmp")
