@@ -715,7 +715,8 @@ AGX_HD agx_u32 agx_edge_slow_pair(const agx_sweep_args &A, const agx_slow_ctx &c
 // The path walk (AG:1954-2204) only ever stands on nodes that survived the coverage prune.  After the edge sweep the
 // surviving ("alive") nodes get walk ids ("aid") laid out so that the main strand of the graph is contiguous:
 //     aid = X                          for the FIRST alive variant of position X          (main block, one slot per position)
-//     aid = n_pos + side_start[X] + j  for the (j+1)-th further alive variant of X       (side block, position-major)
+//     aid = n_pos + side ids of all earlier positions + j  for the (j+1)-th further alive variant of X   (side block, position-major;
+//           = tile_side_start[tile of X] + the in-tile prefix the node sweep left in side_pk[X])
 // so scanning "every position, every variant, if untraversed" (AG:1972-1978) is: slot X, then X's side range.
 // Out-edges are rewritten in aids with pruned targets dropped (a pruned node is `traversed` from the start, AG:1915, and
 // can never count as a live successor, AG:2027).  Every node gets a `cont` byte: 1 iff its only alive successor is aid+1.

@@ -141,7 +141,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
 
     // walk preparation, the same per-element functions the compaction kernels run
     agx_compact_args C; memset(&C, 0, sizeof C);
-    S.tile_side_start.assign((size_t)n_tiles + 1, 0); S.aid_of.assign((size_t)S.n_nodes + 1, AGX_NONE);      // (side_cnt was written with the nodes)
+    S.tile_side_start.assign((size_t)n_tiles + 1, 0); S.aid_of.assign((size_t)S.n_nodes + 1, AGX_NONE);      // (side_pk / tile_side were written with the nodes)
     C.node_start = S.node_start.data(); C.node_cnt = S.node_cnt.data(); C.n_flags = S.flags.data(); C.n_base = S.base.data(); C.n_xpos = S.xpos.data();
     C.nk_off0 = S.off0.data(); C.n_sref = S.sref.data(); C.n_next = S.next.data(); C.ref = T.ref.data(); C.n_pos = n_pos;
     C.side_pk = S.side_pk.data(); C.tile_side_start = S.tile_side_start.data(); C.aid_of = S.aid_of.data();
@@ -156,7 +156,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     S.a_mark.assign(na + 1, 0); S.side_xpos.assign((size_t)run + 1, 0);
     C.a_mark = S.a_mark.data(); C.side_xpos = S.side_xpos.data(); C.n_ids = S.n_ids;
     C.sparse_min = getenv("AGX_SIM_SPARSE_MIN") ? 1u : 0u;
-    for (agx_u32 p : T.chain_end_pos) S.a_mark[p] = 1;                               // agx_k_mark_list
+    for (agx_u32 p : T.chain_end_pos) S.a_mark[p] = 1;                               // (the first threads of agx_k_assign_aid)
     for (agx_u32 x = 0; x < n_pos; x++) agx_assign_aid_pos(C, x);
     for (agx_u32 X = 0; X < n_pos; X++) agx_emit_alive_pos(C, X);
     for (agx_u32 i = 0; i < C.n_ovf; i++) agx_emit_alive_ovf(C, i);
