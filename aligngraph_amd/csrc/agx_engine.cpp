@@ -86,6 +86,7 @@ struct agx_unit {
     PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
     PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_hop> h_sp_hop; PBuf<agx_edge_ovf> h_a_ovf;
     PBuf<agx_u32> h_words;
+    bool fallback = false;      // queue the node sweep's fallback passes (set by the first build that overflowed a bucket of the main pass)
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
     Boundaries ev; hipEvent_t ev_front = nullptr, ev_passA = nullptr, ev_passJ = nullptr;      // recorded on the device's build stream behind the unit's last kernel
     agx_stats stats{};
@@ -294,13 +295,13 @@ void do_build(agx_unit *u) {
         K.pool_cnt = u->d_pool_cnt.p; K.region_off = u->d_region_off.p; K.mid_count = u->d_words.p + W_MIDCOUNT; K.mid_list = u->d_mid_list.p; K.mid_n = u->d_words.p + W_MIDCOUNT;
         K.big_count = u->d_words.p + W_BIGCOUNT; K.big_list = u->d_big_list.p; K.status = u->d_words.p + W_STATUS;
         K.list_cap = u->list_cap; K.big_n = u->d_words.p + W_BIGCOUNT; K.scratch = u->d_scratch.p;
-        K.slow_list = u->d_slow_list.p; K.slow_count = u->d_words.p + W_SLOWCOUNT;
+        K.slow_list = u->d_slow_list.p; K.slow_count = u->d_words.p + W_SLOWCOUNT; K.fallback_queued = u->fallback ? 1u : 0u;
         agx_launch_node_sweep(&K, st);
         AGX_CHECKPOINT("node_sweep");
         u->ev.mark(B_NODE, st); u->stats.node_sweep_launches++;
         hipEvent_t trace_from = turn.prev_node; turn.prev_node = u->ev.e[B_NODE];
         HIP_OK(hipEventRecord(turn.sweep_done[turn.n & 1], st));
-        agx_launch_node_sweep_big(&K, st);
+        if (u->fallback) agx_launch_node_sweep_big(&K, st);      // (two launches that most units never need: see the status bit 3 retry below)
         AGX_CHECKPOINT("node_sweep_big");
         u->ev.mark(B_BIG, st);
         // ---- edge sweep ----
@@ -362,6 +363,7 @@ void do_build(agx_unit *u) {
         if (w[W_ERR] & 2u) throw Error{E_UNSUPPORTED, "read alignment beyond the end of the unit sequence"};
         u->n_tile_entries = w[W_N];
         if (u->n_tile_entries > u->list_cap) { u->list_cap = u->n_tile_entries + u->n_tile_entries / 8 + 1024; u->d_unsorted.release(); u->d_tile_recs.release(); continue; }
+        if (w[W_STATUS] & 8u) { u->fallback = true; continue; }      // some tile needs wider buckets: from now on this unit's builds queue the fallback passes
         if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 64 node variants at one position"};
         if (w[W_STATUS] & 1u) {                  // a region's slice of the node pool ran out: cut the slices to what the regions asked for
             std::vector<agx_u32> padded((size_t)u->n_regions * AGX_REGION_PAD), demand(u->n_regions);

@@ -22,7 +22,8 @@ struct agx_node_kargs {
     const agx_u32 *region_off; // [regions + 1] first node id of every region's slice of the pool
     agx_u32 *mid_count; agx_u32 *mid_list;   // tiles whose buckets did not fit pass 0's
     agx_u32 *big_count; agx_u32 *big_list;   // tiles whose buckets did not fit pass 1's either
-    agx_u32 *status;           // bit 0: a region's slice of the node pool exhausted; bit 1: bucket overflow in the global-scratch pass; bit 2: tile lists too small
+    agx_u32 fallback_queued;   // the two fallback passes are queued behind the main pass (a unit's builds start without them: most units never overflow a bucket)
+    agx_u32 *status;           // bit 3: a tile overflowed the main pass and no fallback pass is queued; bit 0: a region's slice of the node pool exhausted; bit 1: bucket overflow in the global-scratch pass; bit 2: tile lists too small
     agx_u32 list_cap;          // capacity of the tile lists: a tile whose list ends beyond it is skipped (the host re-runs with larger lists)
     const agx_u32 *big_n;      // passes 1 and 2: number of tiles in mid_list / big_list, read on the device (no host round trip)
     const agx_u32 *mid_n;

@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
             if (lane == 0) {
                 if (BIG) atomicOr(K.status, 2u);
                 else if (PASS == 1) K.big_list[atomicAdd(K.big_count, 1u)] = tile;
-                else K.mid_list[atomicAdd(K.mid_count, 1u)] = tile;
+                else { K.mid_list[atomicAdd(K.mid_count, 1u)] = tile; if (!K.fallback_queued) atomicOr(K.status, 8u); }      // nobody will sweep it again in this build
             }
             if (PASS != 0) continue; else return;
         }
