@@ -18,8 +18,7 @@
 static_assert(AGX_MAXV_LDS <= AGX_EM_W && AGX_MAXV_MID <= AGX_EM_W, "the LDS sweep writes the x -> x+1 edges of every position it finishes: its buckets must fit the edge matrix");
 #define AGX_XCDS 8u                 // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
 #ifndef AGX_SWEEP_WAVES
-#define AGX_SWEEP_WAVES 1           // wavefronts (= consecutive tiles) per block of the node sweep: measured 0.924 / 0.926 / 0.938 / 1.011 ms for 1 / 2 / 4 / 8
-                                    // (tiles differ in length and a block's LDS is only released when its last wavefront ends)
+#define AGX_SWEEP_WAVES 4           // wavefronts (= consecutive tiles) per block of the node sweep: measured 0.655 / 0.656 / 0.640 / 0.779 / 0.706 ms for 1 / 2 / 4 / 6 / 8
 #endif
 
 // A build queues all its kernels before the host has seen a single counter.  If the node sweeps had to give up (node pool or tile lists too
