@@ -39,7 +39,9 @@ typedef uint8_t agx_u8;
 #define AGX_NONE 0xFFFFFFFFu
 #define AGX_TILE 64u          // positions per tile = lanes per wavefront
 // The node pool is cut into one slice per AGX_REGION_TILES consecutive tiles, each with its own allocation counter (agx_k_node_sweep).
+#ifndef AGX_REGION_TILES
 #define AGX_REGION_TILES 32u
+#endif
 #define AGX_REGION_PAD 32u      // counters sit 128 bytes apart
 // The node sweep runs in three passes with growing buckets; a tile whose bucket overflows is swept again by the next pass.
 #ifndef AGX_MAXV_LDS
