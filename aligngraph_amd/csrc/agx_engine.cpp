@@ -106,6 +106,8 @@ struct DeviceTurn { std::mutex m; hipStream_t main = nullptr, front = nullptr; h
                     unsigned long long n = 0; bool prev_exclusive = false; hipEvent_t prev_node = nullptr; };      // n: builds queued so far; events alternate between two handles
 DeviceTurn &turn_of(int device) { static DeviceTurn turns[64]; return turns[device & 63]; }
 
+// AGX_TRACE_GAP=1: diagnostic for loops that rebuild long-lived units (see do_build)
+static const bool g_trace_gap = getenv("AGX_TRACE_GAP") != nullptr;
 // AGX_SCAN_LEGACY=1: the scans of a build as three launches each instead of one (decoupled look-back)
 static const bool g_scan1 = getenv("AGX_SCAN_LEGACY") == nullptr;
 // AGX_DEBUG_SYNC=1: synchronise after every launch group of a build and name it on stderr — a memory fault then points at its kernel
@@ -356,7 +358,7 @@ void do_build(agx_unit *u) {
         HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, (W_N + 4) * 4, hipMemcpyDeviceToHost, u->st));
         HIP_OK(hipStreamSynchronize(u->st));
         HIP_OK(hipGetLastError());
-        if (getenv("AGX_TRACE_GAP") && trace_from && trace_from != u->ev.e[B_NODE]) {      // diagnostic (units must outlive each other's builds): end of the previous sweep -> start of this one
+        if (g_trace_gap && trace_from && trace_from != u->ev.e[B_NODE]) {      // diagnostic (units must outlive each other's builds): end of the previous sweep -> start of this one
             float f = 0; if (hipEventElapsedTime(&f, trace_from, u->ev.e[B_BIN]) == hipSuccess) fprintf(stderr, "[agx gap] %.3f ms between sweeps, %.3f ms sweep\n", f, u->ev.ms(B_NODE)); else (void)hipGetLastError(); }
         const agx_u32 *w = u->h_words.p;
         if (w[W_ERR] & 1u) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};

@@ -547,13 +547,12 @@ void agx_launch_edge_jump(const agx_edge_kargs *K, hipStream_t st) {
 }
 void agx_launch_edge_slow(const agx_edge_kargs *K, hipStream_t st) {
     // persistent wavefronts: exactly as many blocks as the device holds at once (a second, partial round of blocks would idle most CUs)
-    static int blocks = 0;
-    if (!blocks) {
+    static const int blocks = [] {          // (initialised once, thread-safe: builds are queued from several host threads)
         int per_cu = 0, dev = 0; hipDeviceProp_t prop;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agx_k_edge_slow, 256, 0) == hipSuccess && per_cu > 0 &&
-            hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) blocks = per_cu * prop.multiProcessorCount;
-        else blocks = AGX_SLOW_WAVES / AGX_WAVES_PER_BLOCK;
-    }
+            hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) return per_cu * prop.multiProcessorCount;
+        return (int)(AGX_SLOW_WAVES / AGX_WAVES_PER_BLOCK);
+    }();
     if (K->S.n_tiles) hipLaunchKernelGGL(agx_k_edge_slow, dim3((unsigned)blocks), dim3(256), 0, st, *K);
 }
 
