@@ -191,14 +191,15 @@ void thread_contigs_from_files(const std::string &contigs_fa, const std::string 
     struct Cell { ContiMer m; int next; };
     std::vector<Cell> pool;
     { size_t bases = 0; for (const ContigSeq &q : cs) bases += q.nuc.size() * (q.sets.empty() ? 0 : 1); pool.reserve(bases + cs.size() + 16); }     // about one conti-mer per placed contig base
-    std::vector<int> head(n_ref, -1), tail(n_ref, -1);
-    std::vector<agx_u32> count(n_ref, 0);
+    struct Slot { int head, tail; agx_u32 count; };      // one line per position instead of three arrays: threading touches all three together
+    std::vector<Slot> slot(n_ref, Slot{-1, -1, 0});
     auto push_cm = [&](agx_u32 x, const ContiMer &m) {
         const int id = (int)pool.size(); pool.push_back(Cell{m, -1});
-        if (tail[x] < 0) head[x] = id; else pool[tail[x]].next = id;
-        tail[x] = id; count[x]++;
+        Slot &s = slot[x];
+        if (s.tail < 0) s.head = id; else pool[s.tail].next = id;
+        s.tail = id; s.count++;
     };
-    auto push_pos = [&](char nuc) { T.ref.push_back(nuc); head.push_back(-1); tail.push_back(-1); count.push_back(0); };
+    auto push_pos = [&](char nuc) { T.ref.push_back(nuc); slot.push_back(Slot{-1, -1, 0}); };
     agx_u32 off = 0, next_off = AGX_NONE; bool has_next = false;     // function-scope in the reference: survive from one placement to the next
     for (size_t sp = 0; sp < cs.size(); sp++) {
         ContigSeq &q = cs[sp];
@@ -208,7 +209,7 @@ void thread_contigs_from_files(const std::string &contigs_fa, const std::string 
             const std::vector<agx_u32> &set = q.sets[pp];
             const size_t len = set.size();
             for (size_t e = 0; e < pp; e++) if (agx_absdiff(set[0], q.sets[e][0]) < (int)q.nuc.size()) { pp++; goto again; }      // AG:902-907
-            for (size_t i = 0; i + 1 < len; i++) if (set[i] != AGX_NONE && count[set[i]] >= 2) { pp++; goto again; }              // AG:908-920
+            for (size_t i = 0; i + 1 < len; i++) if (set[i] != AGX_NONE && slot[set[i]].count >= 2) { pp++; goto again; }              // AG:908-920
             if (pp >= q.fr.size()) throw Error{E_FORMAT, "contig placement without strand"};
             const bool rc = q.fr[pp] == 1;
             if (rc) rc_inplace(q.nuc);
@@ -230,12 +231,12 @@ void thread_contigs_from_files(const std::string &contigs_fa, const std::string 
                         }
                         const char b = q.nuc[np - 1];
                         push_pos(b);
-                        push_cm((agx_u32)T.ref.size() - 1, ContiMer{b, (agx_u32)sp, (agx_u32)(np - 1), next_off, count[next_off]});
+                        push_cm((agx_u32)T.ref.size() - 1, ContiMer{b, (agx_u32)sp, (agx_u32)(np - 1), next_off, slot[next_off].count});
                         i = np - 1;
                         break;
                     }
                 } else {
-                    push_cm(off, ContiMer{nuc, (agx_u32)sp, (agx_u32)i, next_off, count[next_off]});       // ordinary AG:1099-1118 and deletion AG:1075-1097 (SD=0)
+                    push_cm(off, ContiMer{nuc, (agx_u32)sp, (agx_u32)i, next_off, slot[next_off].count});       // ordinary AG:1099-1118 and deletion AG:1075-1097 (SD=0)
                 }
             }
             const agx_u32 at = has_next ? next_off : off;                                                  // terminal conti-mer carries the reference base, AG:1121-1148
@@ -245,7 +246,7 @@ void thread_contigs_from_files(const std::string &contigs_fa, const std::string 
     }
     const size_t n_pos = T.ref.size();
     T.cm_start.assign(n_pos + 1, 0); T.cm.clear(); T.cm.reserve(pool.size());
-    for (size_t x = 0; x < n_pos; x++) { T.cm_start[x] = (agx_u32)T.cm.size(); for (int c = head[x]; c >= 0; c = pool[c].next) T.cm.push_back(pool[c].m); }
+    for (size_t x = 0; x < n_pos; x++) { T.cm_start[x] = (agx_u32)T.cm.size(); for (int c = slot[x].head; c >= 0; c = pool[c].next) T.cm.push_back(pool[c].m); }
     T.cm_start[n_pos] = (agx_u32)T.cm.size();
     build_chains(T);
 

@@ -27,7 +27,6 @@ struct Threads {
     std::string initial_contigs;           // bytes of tmp/_initial_contigs.<u>.fa
     // Conti-mer chains (one per contig placement): following `next` from a conti-mer never looks at mutable state
     // (AG:2064-2072), so the walk appends a precomputed suffix instead of chasing pointers.  Built by build_chains().
-    std::vector<agx_u32> cm_chain, cm_idx;  // per conti-mer: its chain and its index in that chain
     std::vector<size_t> chain_off;          // [n_chains+1] chain c's bases are chain_str[chain_off[c] .. chain_off[c+1])
     std::vector<agx_u32> chain_end_pos;     // position of the chain's terminal conti-mer
     std::string chain_str;

@@ -413,44 +413,42 @@ void scaffold(const Threads &T, const GraphView &G, std::vector<Rec> &c, OutBuf 
 // chains of conti-mers: heads are the conti-mers nobody links to
 void build_chains(Threads &T) {
     const size_t n = T.cm.size(), n_pos = T.ref.size();
-    T.cm_chain.assign(n, AGX_NONE); T.cm_idx.assign(n, 0); T.chain_off.assign(1, 0); T.chain_end_pos.clear(); T.chain_str.clear();
+    T.chain_off.assign(1, 0); T.chain_end_pos.clear(); T.chain_str.clear();
     T.chain_str.reserve(n);
-    std::vector<agx_u8> linked(n, 0);
+    T.hop.assign(n_pos, agx_hop{0, 0, 0});
+    std::vector<agx_u8> state(n, 0);                     // 1: some conti-mer links to it (not a chain head); 2: visited
     auto index_of = [&](agx_u32 off, agx_u32 item) -> size_t {
         if (off >= n_pos || T.cm_start[off] + item >= T.cm_start[off + 1]) throw Error{E_ARG, "conti-mer link to a missing entry"};
         return (size_t)T.cm_start[off] + item;
     };
-    for (size_t i = 0; i < n; i++) if (T.cm[i].next_off != AGX_NONE) linked[index_of(T.cm[i].next_off, T.cm[i].next_item)] = 1;
-    std::vector<agx_u32> pos_of(n);
-    for (size_t x = 0; x < n_pos; x++) for (agx_u32 i = T.cm_start[x]; i < T.cm_start[x + 1]; i++) pos_of[i] = (agx_u32)x;
-    for (size_t h = 0; h < n; h++) {
-        if (linked[h]) continue;
-        const agx_u32 ch = (agx_u32)T.chain_end_pos.size();
-        size_t c = h; agx_u32 idx = 0;
+    for (size_t i = 0; i < n; i++) if (T.cm[i].next_off != AGX_NONE) state[index_of(T.cm[i].next_off, T.cm[i].next_item)] = 1;
+    // One traversal per chain, heads in conti-mer order.  A position with exactly one conti-mer that has a next gets its hop entry (the walk
+    // continues ON the next conti-mer, AG:2049-2055: the chain's bases from there on, and where the chain ends) while the chain is
+    // followed; length and landing position are filled in when its end is known.
+    std::vector<agx_u32> pending;                        // positions of this chain whose hop entry waits for the chain's end
+    size_t visited = 0;
+    for (size_t x = 0; x < n_pos; x++) for (size_t h = T.cm_start[x]; h < T.cm_start[x + 1]; h++) {
+        if (state[h]) continue;                          // linked to (or, never true here, visited): not a head
+        pending.clear();
+        size_t c = h; agx_u32 pos = (agx_u32)x;
         for (;;) {
-            if (T.cm_chain[c] != AGX_NONE) throw Error{E_ARG, "conti-mer chains are not simple lists"};
-            T.cm_chain[c] = ch; T.cm_idx[c] = idx++; T.chain_str.push_back(T.cm[c].nuc);
-            if (T.cm[c].next_off == AGX_NONE) break;
-            c = index_of(T.cm[c].next_off, T.cm[c].next_item);
+            if (state[c] == 2) throw Error{E_ARG, "conti-mer chains are not simple lists"};
+            state[c] = 2; visited++;
+            T.chain_str.push_back(T.cm[c].nuc);
+            const ContiMer &m = T.cm[c];
+            if (m.next_off == AGX_NONE) break;
+            if (T.cm_start[pos + 1] - T.cm_start[pos] == 1) { T.hop[pos].str_off = (agx_u32)T.chain_str.size(); pending.push_back(pos); }     // (the next conti-mer's base is pushed next)
+            c = index_of(m.next_off, m.next_item); pos = m.next_off;
         }
-        T.chain_end_pos.push_back(pos_of[c]); T.chain_off.push_back(T.chain_str.size());
+        if (T.chain_str.size() >= 0xFFFFFFFFull) throw Error{E_ARG, "conti-mer chains exceed 2^32 bases"};
+        for (agx_u32 p : pending) { T.hop[p].len = (agx_u32)(T.chain_str.size() - T.hop[p].str_off); T.hop[p].end_pos = pos; }
+        T.chain_end_pos.push_back(pos); T.chain_off.push_back(T.chain_str.size());
     }
-    for (size_t i = 0; i < n; i++) if (T.cm_chain[i] == AGX_NONE) throw Error{E_ARG, "conti-mer cycle"};
-    if (T.chain_str.size() >= 0xFFFFFFFFull) throw Error{E_ARG, "conti-mer chains exceed 2^32 bases"};
-    T.hop.assign(n_pos, agx_hop{0, 0, 0});
-    for (size_t x = 0; x < n_pos; x++) {
-        if (T.cm_start[x + 1] - T.cm_start[x] != 1) continue;
-        const ContiMer &m = T.cm[T.cm_start[x]];
-        if (m.next_off == AGX_NONE) continue;
-        const size_t nx = index_of(m.next_off, m.next_item);          // the walk continues ON the next conti-mer (AG:2049-2055)
-        const agx_u32 ch = T.cm_chain[nx];
-        const size_t from = T.chain_off[ch] + T.cm_idx[nx];
-        T.hop[x] = agx_hop{(agx_u32)from, (agx_u32)(T.chain_off[ch + 1] - from), T.chain_end_pos[ch]};
-    }
+    if (visited != n) throw Error{E_ARG, "conti-mer cycle"};
 }
 
 void walk_join_scaffold(const Threads &T, const Pairs &P, const GraphView &G, UnitOutput &out) {
-    if (T.cm_chain.size() != T.cm.size()) throw Error{E_ARG, "conti-mer chains were not built"};
+    if (T.hop.size() != T.ref.size()) throw Error{E_ARG, "conti-mer chains were not built"};
     Walker W(T, P, G);
     std::vector<Rec> recs;
     const bool timing = getenv("AGX_WALK_TIMING") != nullptr;
