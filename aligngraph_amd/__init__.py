@@ -21,6 +21,7 @@ EXPORTS = [
     "agx_unit_set_contig_threads", "agx_unit_push_pairs", "agx_unit_load_files", "agx_unit_upload", "agx_unit_build", "agx_unit_download",
     "agx_unit_finish", "agx_result_free", "agx_unit_stats", "agx_unit_graph", "agx_graph_free", "agx_run_unit",
     "agx_reads_open", "agx_reads_close", "agx_unit_load_files_shared", "agx_run_unit_shared",
+    "agx_unit_stage", "agx_unit_release", "agx_pool_trim",
 ]
 
 
@@ -61,7 +62,10 @@ class Stats(ctypes.Structure):
                                                 "ms_edge_sweep", "ms_compact", "ms_download", "ms_walk")] + \
                [("node_sweep_launches", ctypes.c_uint32), ("edge_sweep_launches", ctypes.c_uint32)] + \
                [(n, ctypes.c_uint64) for n in ("n_walk_ids", "n_special", "n_fetched", "download_bytes")] + \
-               [(n, ctypes.c_double) for n in ("ms_edge_fast", "ms_edge_slow")] + [("n_mid_tiles", ctypes.c_uint64), ("ms_build_span", ctypes.c_double)]
+               [(n, ctypes.c_double) for n in ("ms_edge_fast", "ms_edge_slow")] + [("n_mid_tiles", ctypes.c_uint64), ("ms_build_span", ctypes.c_double)] + \
+               [(n, ctypes.c_double) for n in ("ms_stage", "ms_upload_dev")] + \
+               [(n, ctypes.c_uint64) for n in ("upload_bytes", "device_bytes", "pinned_bytes_cached", "device_bytes_cached", "n_spilled")] + \
+               [("build_attempts", ctypes.c_uint32), ("pad_", ctypes.c_uint32)]
 
 
 class Graph(ctypes.Structure):
@@ -106,7 +110,9 @@ def lib():
         L.agx_reads_close.argtypes = [ctypes.c_void_p]
         L.agx_reads_close.restype = None
         L.agx_unit_load_files_shared.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
-        for f in ("agx_unit_upload", "agx_unit_build", "agx_unit_download"):
+        L.agx_pool_trim.argtypes = [ctypes.c_int]
+        L.agx_pool_trim.restype = None
+        for f in ("agx_unit_upload", "agx_unit_build", "agx_unit_download", "agx_unit_stage", "agx_unit_release"):
             getattr(L, f).argtypes = [ctypes.c_void_p]
         L.agx_unit_finish.argtypes = [ctypes.c_void_p, ctypes.POINTER(Result)]
         L.agx_result_free.argtypes = [ctypes.POINTER(Result)]
@@ -122,6 +128,13 @@ def lib():
 
 def device_count():
     return lib().agx_device_count()
+
+
+def pool_trim(device=0, host=True):
+    """Frees what the library's memory caches hold: HBM blocks of `device` and (host=True) the pinned host blocks."""
+    lib().agx_pool_trim(device)
+    if host:
+        lib().agx_pool_trim(-1)
 
 
 def _take(res):
@@ -223,8 +236,15 @@ class Unit:
         """reads: an optional Reads (tmp/_reads.fa opened once for all units of a run)."""
         self._check(lib().agx_unit_load_files_shared(self._h, tmp_dir.encode(), unit, reads._h if reads is not None else None))
 
+    def stage(self):
+        self._check(lib().agx_unit_stage(self._h))
+
     def upload(self):
         self._check(lib().agx_unit_upload(self._h))
+
+    def release(self):
+        """HBM and download buffers back to the library's caches; the staged inputs stay (upload again = a new unit)."""
+        self._check(lib().agx_unit_release(self._h))
 
     def build(self):
         self._check(lib().agx_unit_build(self._h))

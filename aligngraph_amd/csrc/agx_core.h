@@ -91,6 +91,7 @@ struct agx_sref { agx_u32 slot; agx_u32 qlen; };   // qlen = first | len<<16 | r
 
 // bucket fields while a tile is being swept (struct-of-arrays: field-major, then variant, then lane)
 enum { AGX_F_CID = 0, AGX_F_COFF, AGX_F_CID0, AGX_F_COFF0, AGX_F_OFF0, AGX_F_COV, AGX_F_A, AGX_F_C, AGX_F_G, AGX_F_T, AGX_F_N, AGX_F_S0, AGX_F_S1, AGX_NF };
+static_assert(AGX_F_C == AGX_F_A + 1 && AGX_F_G == AGX_F_A + 2 && AGX_F_T == AGX_F_A + 3 && AGX_F_N == AGX_F_A + 4, "agx_class_vote_code relies on the order of the vote counters");
 
 struct agx_key { agx_u32 cid, coff, cid0, coff0, off0; };   // chromosomeID0 is 0 iff off0 != NONE inside a unit
 
@@ -208,8 +209,8 @@ AGX_HD agx_u32 agx_idx0_pos(const agx_hit &h, const agx_run *runs) {     // posi
     return r.q == 0 ? r.t : AGX_NONE;
 }
 
-// A later hit of a pair whose mate1 lands within a read length of an earlier kept hit of the same pair is dropped (AG:1650-1655).  Needs
-// the hits in file order: evaluated on the host at upload time (the device copy of the hits is in tile order).
+// A later hit of a pair whose mate1 lands within a read length of an earlier hit of the same pair is dropped (AG:1650-1655).  hits[] is in
+// file order (the hits of a pair are neighbours): hit_prep evaluates it per hit.
 AGX_HD bool agx_hit_dup(const agx_hit *hits, const agx_run *runs, agx_u32 h) {
     const agx_hit &H = hits[h];
     const agx_u32 me = agx_idx0_pos(H, runs);
@@ -317,18 +318,24 @@ struct agx_sweep_args {
     agx_u32 pool_cap;
 };
 
-// bucket field that the oriented base of a read votes for, from the STORED character c (file orientation) and the strand:
-// (c>>1)&3 maps A,C,T,G to 0,1,2,3; complementing (reverseComplement, AG:854-865: only ACGT are complemented) is ^2 there; any
-// other character votes N on either strand.  Table lookups in immediates, no branches.
-AGX_HD agx_u32 agx_vote_field(agx_u32 c, bool rev) {
+// What a read base votes for (updateKBases, AG:1340-1351, after reverseComplement, AG:854-865: only ACGT are complemented).
+// A stored character (file orientation) has one of five CLASSES: A, C, G, T = 0..3, anything else = 4; (c>>1)&3 maps A,C,T,G to
+// 0,1,2,3, so swapping 2 and 3 gives the class.  The packed-array boundary carries the classes, two per byte (4 bits each: the k-mer
+// strings, which must keep every byte, stay on the host); the device expands them once per upload into VOTE CODES — low nibble = the
+// bucket field a forward-strand read votes for with this base, high nibble = the field a reverse-strand read votes for — so that the
+// sweep's vote is one bit-field extract.  The four base counters are consecutive fields in A, C, G, T order: complementing is 3 - class.
+AGX_HD agx_u32 agx_base_class(agx_u32 c) {
     const agx_u32 idx = (c >> 1) & 3u;
     const bool acgt = c == ((0x47544341u >> (idx * 8u)) & 0xFFu);                 // "ACTG"[idx]
-    const agx_u32 f = (((AGX_F_A) | (AGX_F_C << 4) | (AGX_F_T << 8) | (AGX_F_G << 12)) >> ((idx ^ (rev ? 2u : 0u)) * 4u)) & 0xFu;
-    return acgt ? f : (agx_u32)AGX_F_N;
+    return acgt ? (idx ^ (idx >> 1)) : 4u;
 }
-// The sweeps read the read bases as vote codes: low nibble = the field a forward-strand read votes for with this character, high nibble
-// = the field a reverse-strand read votes for.  The device copy of the read-base blob is translated once per upload.
-AGX_HD agx_u8 agx_vote_code(agx_u32 c) { return (agx_u8)(agx_vote_field(c, false) | (agx_vote_field(c, true) << 4)); }
+AGX_HD agx_u8 agx_class_vote_code(agx_u32 cls) {
+    const agx_u32 fwd = cls < 4u ? (agx_u32)AGX_F_A + cls : (agx_u32)AGX_F_N, rev = cls < 4u ? (agx_u32)AGX_F_A + 3u - cls : (agx_u32)AGX_F_N;
+    return (agx_u8)(fwd | (rev << 4));
+}
+AGX_HD agx_u8 agx_vote_code(agx_u32 c) { return agx_class_vote_code(agx_base_class(c)); }
+// packed classes: base 2j of a read slot in the low nibble of byte j, base 2j+1 in the high nibble
+AGX_HD agx_u8 agx_pack_classes(agx_u32 c_even, agx_u32 c_odd) { return (agx_u8)(agx_base_class(c_even) | (agx_base_class(c_odd) << 4)); }
 
 // first compatible variant or append (AG:1375-1390 / 1493-1506).  Returns the index, or NONE when the bucket is full.
 AGX_HD agx_u32 agx_match_or_insert(const agx_bucket &b, agx_u32 &cnt, const agx_key &key, int iv, bool is_k1, agx_u32 s0, agx_u32 s1) {
@@ -730,8 +737,8 @@ AGX_HD agx_u32 agx_edge_slow_pair(const agx_sweep_args &A, const agx_slow_ctx &c
 struct agx_walknode { agx_u32 next[AGX_MAXE]; agx_u32 off0, xpos; agx_sref sref; };
 
 // what a walk does when it leaves the k-mer graph at a position (AG:2047-2057): exactly one conti-mer there, with a next -> append
-// chain_str[str_off, str_off+len) and land on end_pos; len == 0: no hop possible.  Kept per position on the host (Threads::hop) and,
-// gathered by the device for the special ids, next to their records in the sparse table.
+// chain_str[str_off, str_off+len) and land on end_pos; len == 0: no hop possible.  Kept per position on the host (Threads::hop); the
+// engine gathers the entries of the special ids' positions next to their records when it downloads the sparse table.
 struct agx_hop { agx_u32 str_off, len, end_pos; };
 
 // a_meta bits: forced step to id+1; contigOffset != -1 (AG:2004); (main ids) the position has further alive variants in the side
@@ -766,7 +773,6 @@ struct agx_compact_args {
     // sparse record table
     agx_u32 n_ids, sparse_min;     // sparse_min (test hook): only the side ids are special, every other record comes through the fetch path
     unsigned long long *sp_bits; agx_u32 *sp_cnt; const agx_u32 *sp_rank; agx_walknode *sp_node;
-    const agx_hop *hop; agx_hop *sp_hop;   // per-position hop table (input) and its gather for the special ids
     agx_u32 sp_cap;                        // records the sparse table can hold (the host grows it and repeats the build if there are more)
     const agx_u32 *abort;          // device only: the node sweeps' status word (non-zero: the node table is incomplete, the kernels do nothing)
 };

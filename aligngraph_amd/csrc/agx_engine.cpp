@@ -1,10 +1,16 @@
 // agx_engine.cpp — unit object, device memory, kernel sequencing and the C-ABI of libagx.so (include/agx.h).
 //
 // One agx_unit = one reference unit (chromosome or --part slice) = the body of the reference's unit loop
-// (AG:4765-4783).  Device residency: every packed input is uploaded once (agx_unit_upload) and stays in HBM;
-// agx_unit_build only launches kernels on the unit's own HIP stream; agx_unit_finish downloads the node table
-// into pinned host memory and runs the sequential walk.  No CPU fallback exists: a host without a HIP device
-// gets AGX_E_NOGPU from agx_unit_create.
+// (AG:4765-4783).  In the application every unit is NEW data and is built once, so what a unit costs is the whole way
+// from its packed arrays in host memory to its output bytes in host memory (SURVEY §8d's T_core):
+//   stage    (when the arrays are handed over, outside T_core) the arrays the device wants are packed into pinned memory: hits and runs
+//            as they are, the read bases as 4-bit classes, the conti-mer keys without the walk's fields;
+//   upload   one block of HBM for everything the unit will ever hold (agx_mem.h), asynchronous copies at PCIe rate on the unit's own
+//            stream — beside other units' kernels —, two small kernels (conti-mer heads, vote codes), an event;
+//   build    all kernels queued back to back on the device's two build streams behind that event, ONE synchronisation, capacities
+//            chosen so that a first build does not have to be repeated;
+//   download the walk graph into cached pinned buffers; finish = the sequential host walk.
+// No CPU fallback exists: a host without a HIP device gets AGX_E_NOGPU from agx_unit_create.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -14,9 +20,11 @@
 #include <cstring>
 #include <string>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "agx_host.h"
+#include "agx_mem.h"
 
 #include "agx_kargs.h"
 
@@ -24,24 +32,9 @@ using namespace agx;
 
 namespace {
 
-#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw Error{E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)}; } while (0)
+#define HIP_OK(expr) AGX_HIP_OK(expr)
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-template <class T> struct DBuf {            // device buffer
-    T *p = nullptr; size_t n = 0;
-    void alloc(size_t count) { if (count <= n && p) return; release(); if (count) { HIP_OK(hipMalloc((void **)&p, count * sizeof(T))); n = count; } }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-    ~DBuf() { release(); }
-    DBuf() = default; DBuf(const DBuf &) = delete; DBuf &operator=(const DBuf &) = delete;
-};
-template <class T> struct PBuf {            // pinned host buffer
-    T *p = nullptr; size_t n = 0;
-    void alloc(size_t count) { if (count <= n && p) return; release(); if (count) { HIP_OK(hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault)); n = count; } }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
-    ~PBuf() { release(); }
-    PBuf() = default; PBuf(const PBuf &) = delete; PBuf &operator=(const PBuf &) = delete;
-};
 
 // Section boundaries of a build on the unit's stream: the end of one section is the start of the next (one record instead of two: an
 // event record costs the stream about as much as a small kernel).
@@ -57,40 +50,56 @@ struct Boundaries {
     double ms(int b) const { if (!at[b - 1] || !at[b]) return 0; float f = 0; (void)hipEventElapsedTime(&f, e[b - 1], e[b]); return f; }      // section that ends at boundary b
 };
 
+template <class F> void on_threads(unsigned threads, F fn) {
+    std::vector<std::thread> th;
+    try { for (unsigned t = 1; t < threads; t++) th.emplace_back(fn, t); } catch (...) { for (auto &x : th) x.join(); throw; }
+    fn(0u);
+    for (auto &x : th) x.join();
+}
+
 }  // namespace
 
 struct agx_unit {
     agx_params prm{};
     std::string err;
     Threads T; Pairs P;
-    bool have_ref = false, have_threads = false, uploaded = false, built = false, downloaded = false;
+    bool have_ref = false, have_threads = false, staged = false, uploaded = false, built = false, downloaded = false;
     hipStream_t st = nullptr;
+    DevArena arena;
+    // staged inputs: what the device wants of T and P, in pinned memory (stage_inputs)
+    PBuf<agx_hit> s_hits; PBuf<agx_run> s_runs; PBuf<agx_u8> s_codes; PBuf<char> s_ref; PBuf<agx_u32> s_cm_start, s_chain_end, s_region_off; PBuf<agx_cmkey> s_cm;
+    size_t nh = 0, n_runs = 0, n_cm = 0, n_codes = 0; agx_u32 maxlen = 0;      // n_codes: bytes of packed classes (two bases each)
     // inputs on the device
     DBuf<agx_u32> d_cm_start; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref;
-    DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<char> d_bases;
+    DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<agx_u8> d_codes, d_vcodes;
     // derived
     DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_recs, d_scan_tmp, d_words; DBuf<unsigned long long> d_scan_desc; size_t scan_desc_n = 0;      // descriptors of the three one-launch scans   // d_words: counters/status
     // node table
-    agx_u32 pool_cap = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
+    agx_u32 pool_cap = 0, spill_lo = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
     DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
-    DBuf<agx_u32> d_node_start, d_slow_list, d_rank4, d_perm; DBuf<agx_u8> d_node_cnt, d_pos_succ; DBuf<agx_u32> d_jump_list; agx_u32 n_jump = 0;
+    DBuf<agx_u32> d_node_start, d_slow_list, d_rank4; DBuf<agx_u8> d_node_cnt, d_pos_succ; DBuf<agx_u32> d_jump_list;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch;
     // walk graph (agx_core.h "walk preparation")
     agx_u32 n_ids = 0;
     DBuf<agx_u32> d_side_pk, d_tile_side, d_tile_side_start, d_aid_of; DBuf<char> d_a_str;
     DBuf<agx_u8> d_a_meta, d_a_mark; DBuf<agx_walknode> d_fetch, d_sp_node; DBuf<agx_u32> d_a_nid; DBuf<agx_edge_ovf> d_a_ovf; agx_compact_args walk_args{};      // walk_args: the last build's, for record fetches
-    DBuf<agx_u32> d_chain_end, d_side_xpos, d_sp_cnt, d_sp_rank; DBuf<unsigned long long> d_sp_bits; DBuf<agx_hop> d_hop, d_sp_hop;
+    DBuf<agx_u32> d_chain_end, d_side_xpos, d_sp_cnt, d_sp_rank; DBuf<unsigned long long> d_sp_bits;
     agx_u32 n_chain_end = 0, n_special = 0, n_words = 0;
     // downloaded: the walk graph with its sparse record table (agx_core.h); the full record table stays on the device
     PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
-    PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_hop> h_sp_hop; PBuf<agx_edge_ovf> h_a_ovf;
+    PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_edge_ovf> h_a_ovf;
+    std::vector<agx_hop> h_sp_hop;      // hop entries of the special ids' positions, gathered on the host from the per-position table
     PBuf<agx_u32> h_words;
-    bool fallback = false;      // queue the node sweep's fallback passes (set by the first build that overflowed a bucket of the main pass)
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
-    Boundaries ev; hipEvent_t ev_front = nullptr, ev_passA = nullptr, ev_passJ = nullptr;      // recorded on the device's build stream behind the unit's last kernel
+    Boundaries ev; hipEvent_t ev_front = nullptr, ev_passA = nullptr, ev_passJ = nullptr, ev_up0 = nullptr, ev_uploaded = nullptr, ev_dl = nullptr;
+    bool up_timed = false;
     agx_stats stats{};
-    ~agx_unit() { ev.destroy(); if (ev_front) (void)hipEventDestroy(ev_front); if (ev_passA) (void)hipEventDestroy(ev_passA); if (ev_passJ) (void)hipEventDestroy(ev_passJ); if (st) (void)hipStreamDestroy(st); }
+    ~agx_unit() {
+        ev.destroy();
+        for (hipEvent_t e : {ev_front, ev_passA, ev_passJ, ev_up0, ev_uploaded, ev_dl}) if (e) (void)hipEventDestroy(e);
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    }
 };
 
 namespace {
@@ -112,14 +121,16 @@ static const bool g_trace_gap = getenv("AGX_TRACE_GAP") != nullptr;
 static const bool g_scan1 = getenv("AGX_SCAN_LEGACY") == nullptr;
 // AGX_DEBUG_SYNC=1: synchronise after every launch group of a build and name it on stderr — a memory fault then points at its kernel
 static const bool g_debug_sync = getenv("AGX_DEBUG_SYNC") != nullptr;
+// AGX_TEST_SMALL_CAPS=1 (tests): every capacity starts absurdly small, so that every regrow path runs
+static const bool g_tiny = getenv("AGX_TEST_SMALL_CAPS") != nullptr;
 #define AGX_CHECKPOINT(name) do { if (g_debug_sync) { hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, "[agx debug] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
 
-enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_RANKOVF = 6, W_MIDCOUNT = 7, W_N = 8 };
+enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_RANKOVF = 6, W_MIDCOUNT = 7, W_JUMPCOUNT = 8, W_SPILL = 9, W_N = 10 };
 
 void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     memset(&S, 0, sizeof S);
     S.cm_start = u->d_cm_start.p; S.cm = u->d_cm.p; S.cm_head = u->d_cm_head.p; S.ref = u->d_ref.p;
-    S.dhit = u->d_dhit.p; S.runs = u->d_runs.p; S.vcodes = reinterpret_cast<const agx_u8 *>(u->d_bases.p); S.stride = u->P.stride;
+    S.dhit = u->d_dhit.p; S.runs = u->d_runs.p; S.vcodes = u->d_vcodes.p; S.stride = u->P.stride;
     S.tile_off = u->d_tile_off.p; S.tile_recs = (decltype(S.tile_recs))u->d_tile_recs.p;
     S.n_pos = (agx_u32)u->T.ref.size(); S.n_tiles = u->n_tiles; S.k = u->prm.k; S.iv = (int)u->prm.insert_variation; S.coverage = (int)u->prm.coverage;
     S.node_start = u->d_node_start.p; S.node_cnt = u->d_node_cnt.p; S.pos_succ = u->d_pos_succ.p; S.side_pk = u->d_side_pk.p; S.tile_side = u->d_tile_side.p;
@@ -129,130 +140,167 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     S.pool_cap = u->pool_cap;
 }
 
-// Slices of the node pool, one per region.  Without a measurement every region gets the same share; after a build in which a slice ran out,
-// `demand` holds what every region asked for (the counters keep counting past the end of a slice) and the slices are cut to that plus slack.
-// Returns the ids the layout needs.
-unsigned long long layout_regions(agx_unit *u, const agx_u32 *demand, bool apply) {
+// ---- staging: the packed arrays a unit was handed, in the form and the memory the upload wants -------------------------------------
+// Runs when the arrays are handed over (end of agx_unit_load_files, or agx_unit_stage after the last agx_unit_push_pairs; implied by an
+// upload that finds nothing staged).  The read bases cross PCIe as 4-bit classes (agx_pack_classes): half the bytes of the largest array.
+void stage_inputs(agx_unit *u) {
+    if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
+    const double t0 = now_ms();
+    HIP_OK(hipSetDevice(u->prm.device));            // (registering host memory needs a current device)
+    const size_t n_pos = u->T.ref.size();
+    if (n_pos == 0 || n_pos >= 0xFFFFFF00ull) throw Error{E_ARG, "unit sequence is empty or too long"};
+    if (u->T.cm_start.size() != n_pos + 1) throw Error{E_ARG, "contig thread table does not match the position count"};
+    if (u->T.hop.size() != n_pos) throw Error{E_ARG, "conti-mer chains were not built"};
+    u->nh = u->P.hits.size(); u->n_runs = u->P.runs.size(); u->n_cm = u->T.cm.size();
+    u->maxlen = 0; for (const agx_hit &h : u->P.hits) u->maxlen = std::max<agx_u32>(u->maxlen, h.len);
+    if (u->P.stride & 15u) throw Error{E_ARG, "read stride must be a multiple of 16"};
+    const size_t n_bases = u->P.bases.size();       // n_slots * stride
+    u->n_codes = n_bases / 2;
+    u->s_hits.alloc(u->nh + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16);
+    u->s_ref.alloc(n_pos); u->s_cm_start.alloc(n_pos + 1); u->s_cm.alloc(u->n_cm + 1);
+    std::vector<agx_u32> ce(u->T.chain_end_pos); std::sort(ce.begin(), ce.end()); ce.erase(std::unique(ce.begin(), ce.end()), ce.end());      // positions where a conti-mer chain
+    u->n_chain_end = (agx_u32)ce.size(); u->s_chain_end.alloc(ce.size() + 1);                                                                 // ends: their main walk ids are special
+    if (!ce.empty()) memcpy(u->s_chain_end.p, ce.data(), ce.size() * 4);
+    const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), (n_bases + n_pos * 16) / (8u << 20) + 1);
+    const char *bases = u->P.bases.data(); agx_u8 *codes = u->s_codes.p;
+    on_threads(threads, [&](unsigned t) {
+        auto part = [&](size_t n, size_t &lo, size_t &hi) { lo = n * t / threads; hi = n * (t + 1) / threads; };
+        size_t lo, hi;
+        part(u->n_codes, lo, hi); for (size_t i = lo; i < hi; i++) codes[i] = agx_pack_classes((agx_u8)bases[2 * i], (agx_u8)bases[2 * i + 1]);
+        part(u->nh, lo, hi); if (hi > lo) memcpy(u->s_hits.p + lo, u->P.hits.data() + lo, (hi - lo) * sizeof(agx_hit));
+        part(u->n_runs, lo, hi); if (hi > lo) memcpy(u->s_runs.p + lo, u->P.runs.data() + lo, (hi - lo) * sizeof(agx_run));
+        part(n_pos, lo, hi); memcpy(u->s_ref.p + lo, u->T.ref.data() + lo, hi - lo);
+        part(n_pos + 1, lo, hi); memcpy(u->s_cm_start.p + lo, u->T.cm_start.data() + lo, (hi - lo) * 4);
+        part(u->n_cm, lo, hi); for (size_t i = lo; i < hi; i++) u->s_cm.p[i] = agx_cmkey{u->T.cm[i].cid, u->T.cm[i].coff};
+    });
+    u->staged = true; u->uploaded = false; u->built = false; u->downloaded = false;
+    u->stats.ms_stage = now_ms() - t0;
+}
+
+// ---- capacities ---------------------------------------------------------------------------------------------------------------------
+// First guesses, made so that a unit's first build is normally its only one (every capacity is still checked on the device and grown
+// from the device-side counters if it proves too small: tests force that with AGX_TEST_SMALL_CAPS).
+agx_u32 spill_min(const agx_unit *u) { const size_t n_pos = u->T.ref.size(); return (agx_u32)std::min<size_t>(g_tiny ? 64 : n_pos / 8 + 65536, 0x10000000u); }
+
+// Slices of the node pool, one per region, and the spill area behind them.  Without a measurement every region gets the same share of
+// `main_cap` ids; after a build in which the pool ran out, `demand` holds what every region asked for (the counters keep counting) and the
+// slices are cut to that plus slack.  Returns the ids the layout needs; applies it (queues the copy on the unit's stream) if they fit.
+unsigned long long layout_regions(agx_unit *u, const agx_u32 *demand, agx_u32 main_cap, bool apply) {
     const agx_u32 R = u->n_regions;
-    std::vector<agx_u32> off((size_t)R + 1, 0);
+    u->s_region_off.alloc((size_t)R + 1);
+    agx_u32 *off = u->s_region_off.p;
     unsigned long long at = 0;
     for (agx_u32 r = 0; r < R; r++) {
         off[r] = (agx_u32)std::min<unsigned long long>(at, 0xFFFFFFFFull);
-        at += demand ? (unsigned long long)demand[r] + demand[r] / 8 + 64 : u->pool_cap / R;
+        at += demand ? (unsigned long long)demand[r] + demand[r] / 8 + 64 : main_cap / R;
     }
-    if (!apply || at > u->pool_cap) return at;
-    off[R] = (agx_u32)at;
-    u->d_region_off.alloc((size_t)R + 1); u->d_pool_cnt.alloc((size_t)R * AGX_REGION_PAD);
-    HIP_OK(hipMemcpy(u->d_region_off.p, off.data(), ((size_t)R + 1) * 4, hipMemcpyHostToDevice));
-    return at;
+    const unsigned long long need = at + spill_min(u);
+    if (!apply || need > u->pool_cap) return need;
+    off[R] = (agx_u32)at; u->spill_lo = (agx_u32)at;
+    HIP_OK(hipMemcpyAsync(u->d_region_off.p, off, ((size_t)R + 1) * 4, hipMemcpyHostToDevice, u->st));
+    return need;
 }
 
 void alloc_pool(agx_unit *u, agx_u32 cap) {
     u->pool_cap = cap;
+    DevArena &a = u->arena;
     const size_t kcap = (size_t)cap + AGX_SLOW_V;      // slack: the edge pass reads whole AGX_SLOW_V-row batches of keys (agx_edge_slow_ctx)
-    u->d_cid.alloc(kcap); u->d_coff.alloc(kcap); u->d_cid0.alloc(kcap); u->d_coff0.alloc(kcap); u->d_off0.alloc(kcap); u->d_xpos.alloc(cap);
-    u->d_next.alloc((size_t)cap * AGX_MAXE); u->d_base.alloc(cap); u->d_flags.alloc(cap); u->d_sref.alloc(cap);
-    if (u->prm.flags & AGX_FLAG_KEEP_COUNTS) u->d_counts.alloc((size_t)cap * 6);
+    for (auto *b : {&u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0}) { b->release(); b->alloc(a, kcap); }
+    u->d_xpos.release(); u->d_xpos.alloc(a, cap); u->d_next.release(); u->d_next.alloc(a, (size_t)cap * AGX_MAXE);
+    u->d_base.release(); u->d_base.alloc(a, cap); u->d_flags.release(); u->d_flags.alloc(a, cap); u->d_sref.release(); u->d_sref.alloc(a, cap);
+    if (u->prm.flags & AGX_FLAG_KEEP_COUNTS) { u->d_counts.release(); u->d_counts.alloc(a, (size_t)cap * 6); }
+    // walk-graph arrays indexed by walk id: side variants <= nodes <= pool_cap
+    const size_t n_pos = u->T.ref.size(), ids_cap = n_pos + cap;
+    u->d_aid_of.release(); u->d_aid_of.alloc(a, (size_t)cap + 1);
+    u->d_a_str.release(); u->d_a_str.alloc(a, ids_cap + 1); u->d_a_meta.release(); u->d_a_meta.alloc(a, ids_cap + 16); u->d_a_nid.release(); u->d_a_nid.alloc(a, ids_cap + 1);
+    u->d_a_mark.release(); u->d_a_mark.alloc(a, ids_cap + 2); u->d_side_xpos.release(); u->d_side_xpos.alloc(a, (size_t)cap + 1);
+    u->n_words = (agx_u32)(ids_cap / 64 + 1);
+    u->d_sp_bits.release(); u->d_sp_bits.alloc(a, (size_t)u->n_words + 1); u->d_sp_cnt.release(); u->d_sp_cnt.alloc(a, (size_t)u->n_words + 1);
+    u->d_sp_rank.release(); u->d_sp_rank.alloc(a, (size_t)u->n_words + 2);
+    const size_t nb = ((size_t)std::max<size_t>(n_pos, u->n_words) + 1 + 1023) / 1024;
+    u->d_scan_tmp.release(); u->d_scan_tmp.alloc(a, 2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16);
+    u->scan_desc_n = (std::max<size_t>(u->n_tiles, u->n_words) + 1) / 4096 + 2; u->d_scan_desc.release(); u->d_scan_desc.alloc(a, 3 * u->scan_desc_n);
 }
+void alloc_lists(agx_unit *u, agx_u32 cap) { u->list_cap = cap; u->d_unsorted.release(); u->d_unsorted.alloc(u->arena, (size_t)cap + 1); u->d_tile_recs.release(); u->d_tile_recs.alloc(u->arena, ((size_t)cap + 4) * 8); }
+void alloc_ovf(agx_unit *u, agx_u32 cap) { u->ovf_cap = cap; u->d_ovf.release(); u->d_ovf.alloc(u->arena, cap); u->d_a_ovf.release(); u->d_a_ovf.alloc(u->arena, (size_t)cap + 1); }
+void alloc_sparse(agx_unit *u, agx_u32 cap) { u->sp_cap = cap; u->d_sp_node.release(); u->d_sp_node.alloc(u->arena, (size_t)cap + 1); }
 
+void do_release(agx_unit *u);
+
+// Everything a unit holds on the device is taken here, from ONE block of HBM sized by the sum; then the inputs are copied (asynchronously,
+// from the staged pinned arrays, on the unit's own stream: beside whatever other units run on the device) and the two upload-time kernels
+// are queued.  Nothing waits on the host: the build's first kernel waits for ev_uploaded on the device.
 void do_upload(agx_unit *u) {
-    if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
+    if (!u->staged) stage_inputs(u);
+    if (u->arena.used()) do_release(u);              // uploaded before: start over (the unit's blocks go through the cache)
     const double t0 = now_ms();
     HIP_OK(hipSetDevice(u->prm.device));
-    const size_t n_pos = u->T.ref.size();
-    if (n_pos == 0 || n_pos >= 0xFFFFFF00ull) throw Error{E_ARG, "unit sequence is empty or too long"};
-    if (u->T.cm_start.size() != n_pos + 1) throw Error{E_ARG, "contig thread table does not match the position count"};
-    std::vector<agx_cmkey> keys(u->T.cm.size());
-    for (size_t i = 0; i < keys.size(); i++) keys[i] = agx_cmkey{u->T.cm[i].cid, u->T.cm[i].coff};
-    u->d_cm_start.alloc(n_pos + 1); u->d_cm.alloc(keys.size() + 1); u->d_ref.alloc(n_pos);
-    HIP_OK(hipMemcpyAsync(u->d_cm_start.p, u->T.cm_start.data(), (n_pos + 1) * 4, hipMemcpyHostToDevice, u->st));
-    if (!keys.empty()) HIP_OK(hipMemcpyAsync(u->d_cm.p, keys.data(), keys.size() * sizeof(agx_cmkey), hipMemcpyHostToDevice, u->st));
-    HIP_OK(hipMemcpyAsync(u->d_ref.p, u->T.ref.data(), n_pos, hipMemcpyHostToDevice, u->st));
-    u->d_cm_head.alloc(n_pos + 1);
-    agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, (agx_u32)n_pos, u->st);
-    const size_t nh = u->P.hits.size();
-    u->d_hits.alloc(nh + 1); u->d_runs.alloc(u->P.runs.size() + 1); u->d_bases.alloc(u->P.bases.size() + 16); u->d_dhit.alloc(nh + 1); u->d_rank4.alloc(4 * ((size_t)nh + 1));
-    if (!u->P.runs.empty()) HIP_OK(hipMemcpyAsync(u->d_runs.p, u->P.runs.data(), u->P.runs.size() * sizeof(agx_run), hipMemcpyHostToDevice, u->st));
-    if (!u->P.bases.empty()) {              // the device copy holds vote codes (agx_vote_code), translated in place; the characters stay on the host for the walk
-        HIP_OK(hipMemcpyAsync(u->d_bases.p, u->P.bases.data(), u->P.bases.size(), hipMemcpyHostToDevice, u->st));
-        agx_launch_vote_codes(u->d_bases.p, (u->P.bases.size() + 15) / 16 * 16, u->st);
-    }
+    const size_t n_pos = u->T.ref.size(), nh = u->nh;
+    u->arena.device = u->prm.device;
     u->n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
-    {   // The device gets the hits in the order of the tile their left end falls into (counting sort): the hits of one wavefront of
-        // agx_k_hit_prep then share tiles (their histogram atomics combine), neighbouring threads read and write neighbouring records in all
-        // binning kernels, and a tile's list names records that lie together.  file_order[] takes a device hit number back to its place in
-        // the SAM file, which is the order the tile lists are sorted into.  What needs the file order itself — dropping a later hit of a
-        // pair that lands on an earlier one (agx_hit_dup) — is decided here and travels in the record's pad byte.
-        std::vector<agx_u32> first((size_t)u->n_tiles + 1, 0), perm(nh);
-        auto tile_of = [&](const agx_hit &h) -> agx_u32 {
-            const agx_u32 p1 = h.nruns1 ? u->P.runs[h.runs1].t : h.pos1, p2 = h.nruns2 ? u->P.runs[h.runs2].t : h.pos2;
-            return std::min<agx_u32>(std::min(p1, p2) / AGX_TILE, u->n_tiles - 1);
-        };
-        for (size_t i = 0; i < nh; i++) first[tile_of(u->P.hits[i]) + 1]++;
-        for (size_t t = 0; t < u->n_tiles; t++) first[t + 1] += first[t];
-        for (size_t i = 0; i < nh; i++) perm[first[tile_of(u->P.hits[i])]++] = (agx_u32)i;
-        std::vector<agx_hit> sorted(nh); std::vector<agx_u32> jl;
-        for (size_t i = 0; i < nh; i++) {
-            sorted[i] = u->P.hits[perm[i]];
-            sorted[i].pad[0] = (sorted[i].back && agx_hit_dup(u->P.hits.data(), u->P.runs.data(), perm[i])) ? 1 : 0; sorted[i].pad[1] = sorted[i].pad[2] = 0;
-            if (sorted[i].nruns1 >= 2 || sorted[i].nruns2 >= 2) jl.push_back((agx_u32)i);      // a mate of several runs: the edge build's pass J starts from this list
-        }
-        u->d_perm.alloc(nh + 1); u->n_jump = (agx_u32)jl.size(); u->d_jump_list.alloc(jl.size() + 1);
-        if (nh) { HIP_OK(hipMemcpy(u->d_perm.p, perm.data(), nh * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(u->d_hits.p, sorted.data(), nh * sizeof(agx_hit), hipMemcpyHostToDevice)); }
-        if (!jl.empty()) HIP_OK(hipMemcpy(u->d_jump_list.p, jl.data(), jl.size() * 4, hipMemcpyHostToDevice));
-    }
-    u->d_tile_cnt.alloc((size_t)u->n_tiles + 1); u->d_tile_off.alloc((size_t)u->n_tiles + 2); u->d_cursor.alloc((size_t)u->n_tiles + 1);
-    const size_t nb = ((size_t)n_pos + 1 + 1023) / 1024;              // sized for the longer of the two scans (positions)
-    u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16);
-    u->d_words.alloc(W_N + 4); u->h_words.alloc(W_N + 4); u->h_fetch.alloc(2 * (n_pos / 1000 + 2));
-    if (u->T.hop.size() != n_pos) throw Error{E_ARG, "conti-mer chains were not built"};
-    u->d_hop.alloc(n_pos + 1);
-    HIP_OK(hipMemcpy(u->d_hop.p, u->T.hop.data(), n_pos * sizeof(agx_hop), hipMemcpyHostToDevice));
-    {   // positions where a conti-mer chain ends: their main walk ids belong to the sparse record table (agx_core.h)
-        std::vector<agx_u32> ce(u->T.chain_end_pos); std::sort(ce.begin(), ce.end()); ce.erase(std::unique(ce.begin(), ce.end()), ce.end());
-        u->n_chain_end = (agx_u32)ce.size(); u->d_chain_end.alloc(ce.size() + 1);
-        if (!ce.empty()) HIP_OK(hipMemcpy(u->d_chain_end.p, ce.data(), ce.size() * 4, hipMemcpyHostToDevice));
-    }
-    u->d_node_start.alloc(n_pos); u->d_node_cnt.alloc(n_pos); u->d_pos_succ.alloc(n_pos); u->d_slow_list.alloc(n_pos + 64);
-    // first guesses; every one of them is grown from the device-side counters if a build proves it too small (first build of a unit only).
-    // AGX_TEST_SMALL_CAPS (tests) starts them absurdly small so that every regrow path runs.
-    const bool tiny = getenv("AGX_TEST_SMALL_CAPS") != nullptr;
-    if (u->pool_cap == 0) alloc_pool(u, (agx_u32)std::min<size_t>(tiny ? n_pos / 8 + 64 : n_pos + n_pos / 4 + 4096, 0xFFFFFF00ull));
     u->n_regions = (u->n_tiles + AGX_REGION_TILES - 1) / AGX_REGION_TILES;
-    layout_regions(u, nullptr, true);
-    if (u->ovf_cap == 0) { u->ovf_cap = tiny ? 4u : 1u << 16; u->d_ovf.alloc(u->ovf_cap); }
-    HIP_OK(hipStreamSynchronize(u->st));
+    const size_t n_bases = u->n_codes * 2;
+    // capacities of a first build
+    const agx_u32 main_cap = (agx_u32)std::min<size_t>(g_tiny ? n_pos / 8 + 64 : n_pos + n_pos / 4 + 4096, 0xE0000000ull);
+    const agx_u32 pool_cap = u->pool_cap ? u->pool_cap : main_cap + spill_min(u);
+    // a hit's arrivals span len - k + 1 positions = 1 + (span - 1) / 64 tiles on average
+    const double per_hit = 1.0 + (u->maxlen > u->prm.k ? (double)(u->maxlen - u->prm.k) : 0.0) / AGX_TILE;
+    const agx_u32 list_cap = u->list_cap ? u->list_cap : (agx_u32)std::min<double>(g_tiny ? (double)nh / 2 + 16 : (double)nh * per_hit * 1.1 + 4096, 4.0e9);
+    const agx_u32 ovf_cap = u->ovf_cap ? u->ovf_cap : (g_tiny ? 4u : 1u << 16);
+    const size_t ids_cap = n_pos + pool_cap;
+    const agx_u32 sp_cap = u->sp_cap ? u->sp_cap : (agx_u32)std::min<size_t>(g_tiny ? 32 : ids_cap / 4 + 4096, 0xFFFFFF00ull);      // special ids: 8 % on the bench unit
+    {   // one block for all of it (what the takes below add up to, plus the alignment of ~90 buffers)
+        const size_t per_pos = 4 + 16 + 1 + 4 + 1 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_hit) + sizeof(agx_dhit) + 16 + 4;
+        const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
+        const size_t total = n_pos * per_pos + u->n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases +
+                             (size_t)pool_cap * per_slot + ids_cap * per_id + (size_t)list_cap * 36 + (size_t)ovf_cap * 16 + (size_t)sp_cap * sizeof(agx_walknode) +
+                             (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64 * 4 + (size_t)u->n_regions * AGX_REGION_PAD * 4 + (64u << 10) * 100;
+        u->arena.reserve(total + total / 64);
+    }
+    DevArena &a = u->arena;
+    u->d_cm_start.alloc(a, n_pos + 1); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos); u->d_cm_head.alloc(a, n_pos + 1);
+    u->d_hits.alloc(a, nh + 1); u->d_runs.alloc(a, u->n_runs + 1); u->d_codes.alloc(a, u->n_codes + 16); u->d_vcodes.alloc(a, n_bases + 16);
+    u->d_dhit.alloc(a, nh + 1); u->d_rank4.alloc(a, 4 * (nh + 1)); u->d_jump_list.alloc(a, nh + 1);
+    u->d_tile_cnt.alloc(a, (size_t)u->n_tiles + 1); u->d_tile_off.alloc(a, (size_t)u->n_tiles + 2); u->d_cursor.alloc(a, (size_t)u->n_tiles + 1);
+    u->d_words.alloc(a, W_N + 6); u->h_words.alloc(W_N + 6);
+    u->d_chain_end.alloc(a, (size_t)u->n_chain_end + 1);
+    u->d_node_start.alloc(a, n_pos); u->d_node_cnt.alloc(a, n_pos); u->d_pos_succ.alloc(a, n_pos); u->d_slow_list.alloc(a, n_pos + 64);
+    u->d_side_pk.alloc(a, n_pos + 2); u->d_tile_side.alloc(a, (size_t)u->n_tiles + 2); u->d_tile_side_start.alloc(a, (size_t)u->n_tiles + 2);
+    u->d_big_list.alloc(a, (size_t)u->n_tiles + 1); u->d_mid_list.alloc(a, (size_t)u->n_tiles + 1);
+    u->d_scratch.alloc(a, (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64);
+    u->d_region_off.alloc(a, (size_t)u->n_regions + 1); u->d_pool_cnt.alloc(a, (size_t)u->n_regions * AGX_REGION_PAD);
+    alloc_pool(u, pool_cap); alloc_lists(u, list_cap); alloc_ovf(u, ovf_cap); alloc_sparse(u, sp_cap);
+    // copies
+    hipStream_t st = u->st;
+    u->up_timed = u->ev.all;
+    if (u->up_timed) HIP_OK(hipEventRecord(u->ev_up0, st));
+    auto up = [&](void *dst, const void *src, size_t bytes) { if (bytes) HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); };
+    up(u->d_cm_start.p, u->s_cm_start.p, (n_pos + 1) * 4); up(u->d_cm.p, u->s_cm.p, u->n_cm * sizeof(agx_cmkey)); up(u->d_ref.p, u->s_ref.p, n_pos);
+    agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, (agx_u32)n_pos, st);
+    up(u->d_hits.p, u->s_hits.p, nh * sizeof(agx_hit)); up(u->d_runs.p, u->s_runs.p, u->n_runs * sizeof(agx_run));
+    up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);
+    up(u->d_codes.p, u->s_codes.p, u->n_codes);
+    agx_launch_expand_codes(u->d_codes.p, u->d_vcodes.p, (n_bases + 15) / 16 * 16, st);
+    layout_regions(u, nullptr, pool_cap - spill_min(u), true);
+    HIP_OK(hipEventRecord(u->ev_uploaded, st));
     u->uploaded = true; u->built = false; u->downloaded = false;
     u->stats.ms_upload = now_ms() - t0;
+    u->stats.upload_bytes = (n_pos + 1) * 4 + u->n_cm * sizeof(agx_cmkey) + n_pos + nh * sizeof(agx_hit) + u->n_runs * sizeof(agx_run) + (size_t)u->n_chain_end * 4 + u->n_codes + ((size_t)u->n_regions + 1) * 4;
+    u->stats.device_bytes = u->arena.capacity();
 }
 
 // All kernels of one build are queued back to back with the current buffer capacities; the counters they produce (tile-list
 // entries, nodes, overflowed tiles, edge overflow, side variants) are read after ONE synchronisation.  A capacity that proved too
-// small is grown and the build repeats — that only ever happens on the first build of a unit.
+// small is grown and the build repeats — the first guesses (do_upload) are made so that this is rare.
 void do_build(agx_unit *u) {
     if (!u->uploaded) do_upload(u);
     HIP_OK(hipSetDevice(u->prm.device));
-    const agx_u32 n_pos = (agx_u32)u->T.ref.size(), nh = (agx_u32)u->P.hits.size();
+    const agx_u32 n_pos = (agx_u32)u->T.ref.size(), nh = (agx_u32)u->nh;
     hipStream_t st = nullptr;              // the device's build stream, taken with the turn
     u->stats.node_sweep_launches = u->stats.edge_sweep_launches = 0;
-    if (u->list_cap == 0) u->list_cap = (agx_u32)std::min<size_t>(getenv("AGX_TEST_SMALL_CAPS") ? (size_t)nh / 2 + 16 : (size_t)nh * 3 + 1024, 0xFFFFFF00ull);
-    u->d_big_list.alloc((size_t)u->n_tiles + 1); u->d_mid_list.alloc((size_t)u->n_tiles + 1);
-    u->d_scratch.alloc((size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64);
     for (int attempt = 0;; attempt++) {
         if (attempt > 8) throw Error{E_DEVICE, "build did not converge"};
-        u->d_unsorted.alloc((size_t)u->list_cap + 1); u->d_tile_recs.alloc(((size_t)u->list_cap + 4) * 8);
-        u->d_aid_of.alloc((size_t)u->pool_cap + 1);
         const size_t ids_cap = (size_t)n_pos + u->pool_cap;                       // side variants <= nodes <= pool_cap
-        u->d_a_str.alloc(ids_cap + 1); u->d_a_meta.alloc(ids_cap + 16); u->d_a_nid.alloc(ids_cap + 1); u->d_a_ovf.alloc((size_t)u->ovf_cap + 1);
-        u->d_side_pk.alloc((size_t)n_pos + 2); u->d_tile_side.alloc((size_t)u->n_tiles + 2); u->d_tile_side_start.alloc((size_t)u->n_tiles + 2);
-        u->n_words = (agx_u32)(ids_cap / 64 + 1);
-        u->d_a_mark.alloc(ids_cap + 2); u->d_side_xpos.alloc((size_t)u->pool_cap + 1);
-        if (u->sp_cap == 0) u->sp_cap = (agx_u32)std::min<size_t>(getenv("AGX_TEST_SMALL_CAPS") ? 32 : ids_cap / 4 + 4096, 0xFFFFFF00ull);      // special ids: 8 % on the bench unit
-        u->d_sp_node.alloc((size_t)u->sp_cap + 1); u->d_sp_hop.alloc((size_t)u->sp_cap + 1);
-        u->d_sp_bits.alloc((size_t)u->n_words + 1); u->d_sp_cnt.alloc((size_t)u->n_words + 1); u->d_sp_rank.alloc((size_t)u->n_words + 2);
-        {   const size_t nb = ((size_t)std::max<size_t>(n_pos, u->n_words) + 1 + 1023) / 1024;
-            u->d_scan_tmp.alloc(2 * (nb + 1) + 2 * ((nb + 1023) / 1024 + 1) + 16);
-            u->scan_desc_n = (std::max<size_t>(u->n_tiles, u->n_words) + 1) / 4096 + 2; u->d_scan_desc.alloc(3 * u->scan_desc_n); }
 
         DeviceTurn &turn = turn_of(u->prm.device);
         std::unique_lock<std::mutex> my_turn(turn.m);
@@ -263,12 +311,13 @@ void do_build(agx_unit *u) {
         }
         // ---- front (its own stream): may run beside the previous build's edge passes and walk preparation, not beside its sweep ----
         st = turn.front;
+        HIP_OK(hipStreamWaitEvent(st, u->ev_uploaded, 0));      // the unit's inputs (and a region layout that a retry re-cut) are in HBM
         if (turn.n) HIP_OK(hipStreamWaitEvent(st, (u->ev.all || turn.prev_exclusive) ? turn.build_done[(turn.n - 1) & 1] : turn.sweep_done[(turn.n - 1) & 1], 0));
         if (u->ev.all) HIP_OK(hipEventRecord(u->ev.first, st));      // (every event record costs the stream a few microseconds: untimed builds record only what orders them)
         {   // everything a build counts into or marks, zeroed by one kernel and one fill (every command on the stream costs a few microseconds)
             agx_zero_args Z; memset(&Z, 0, sizeof Z);
             auto seg = [&](int i, agx_u32 *ptr, size_t words) { Z.p[i] = ptr; Z.n[i] = (agx_u32)words; };
-            seg(0, u->d_words.p, W_N + 4); seg(1, u->d_tile_cnt.p, (size_t)u->n_tiles + 1); seg(2, u->d_cursor.p, (size_t)u->n_tiles + 1);
+            seg(0, u->d_words.p, W_N + 6); seg(1, u->d_tile_cnt.p, (size_t)u->n_tiles + 1); seg(2, u->d_cursor.p, (size_t)u->n_tiles + 1);
             seg(3, u->d_pool_cnt.p, (size_t)u->n_regions * AGX_REGION_PAD); seg(4, u->d_tile_side.p + u->n_tiles, 1); seg(5, u->d_sp_cnt.p + u->n_words, 1);
             seg(6, reinterpret_cast<agx_u32 *>(u->d_scan_desc.p), 6 * u->scan_desc_n);
             agx_launch_zero(&Z, st);
@@ -276,7 +325,8 @@ void do_build(agx_unit *u) {
         }
         // ---- hit_prep + tile histogram ----
         u->ev.begin(); u->ev.mark(B_START, st);
-        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
+        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF,
+                         u->d_jump_list.p, u->d_words.p + W_JUMPCOUNT};
         agx_launch_hit_prep(&PA, st);
         AGX_CHECKPOINT("hit_prep");
         u->ev.mark(B_PREP, st);
@@ -285,7 +335,7 @@ void do_build(agx_unit *u) {
         else agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
         agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, (const uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
         agx_launch_bin_fill(&BA, st);
-        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_perm.p, u->d_dhit.p, u->d_tile_recs.p, st);
+        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, st);
         AGX_CHECKPOINT("tile_sort");
         HIP_OK(hipEventRecord(u->ev_front, st));
         // ---- main stream ----
@@ -294,21 +344,22 @@ void do_build(agx_unit *u) {
         u->ev.mark(B_BIN, st);
         // ---- node sweep: every tile with small LDS buckets, then the tiles that overflowed with wider ones, then with global scratch (device-side lists) ----
         agx_node_kargs K; fill_sweep_args(u, K.S);
-        K.pool_cnt = u->d_pool_cnt.p; K.region_off = u->d_region_off.p; K.mid_count = u->d_words.p + W_MIDCOUNT; K.mid_list = u->d_mid_list.p; K.mid_n = u->d_words.p + W_MIDCOUNT;
+        K.pool_cnt = u->d_pool_cnt.p; K.region_off = u->d_region_off.p; K.spill_lo = u->spill_lo; K.spill_cnt = u->d_words.p + W_SPILL;
+        K.mid_count = u->d_words.p + W_MIDCOUNT; K.mid_list = u->d_mid_list.p; K.mid_n = u->d_words.p + W_MIDCOUNT;
         K.big_count = u->d_words.p + W_BIGCOUNT; K.big_list = u->d_big_list.p; K.status = u->d_words.p + W_STATUS;
         K.list_cap = u->list_cap; K.big_n = u->d_words.p + W_BIGCOUNT; K.scratch = u->d_scratch.p;
-        K.slow_list = u->d_slow_list.p; K.slow_count = u->d_words.p + W_SLOWCOUNT; K.fallback_queued = u->fallback ? 1u : 0u;
+        K.slow_list = u->d_slow_list.p; K.slow_count = u->d_words.p + W_SLOWCOUNT; K.fallback_queued = 1u;
         agx_launch_node_sweep(&K, st);
         AGX_CHECKPOINT("node_sweep");
         u->ev.mark(B_NODE, st); u->stats.node_sweep_launches++;
         hipEvent_t trace_from = turn.prev_node; turn.prev_node = u->ev.e[B_NODE];
         HIP_OK(hipEventRecord(turn.sweep_done[turn.n & 1], st));
-        if (u->fallback) agx_launch_node_sweep_big(&K, st);      // (two launches that most units never need: see the status bit 3 retry below)
-        AGX_CHECKPOINT("node_sweep_big");
+        agx_launch_node_sweep_big(&K, st);      // the two fallback passes: they find their (usually empty) tile lists on the device.  A unit is built once, so they
+        AGX_CHECKPOINT("node_sweep_big");       // are always queued: two idle launches cost less than repeating the build of a unit that turns out to need them
         u->ev.mark(B_BIG, st);
         // ---- edge sweep ----
         agx_edge_kargs E; fill_sweep_args(u, E.S); E.ovf = u->d_ovf.p; E.ovf_count = u->d_words.p + W_OVFCOUNT; E.ovf_cap = u->ovf_cap; E.list_cap = u->list_cap;
-        E.jump_list = u->d_jump_list.p; E.n_jump = u->n_jump; E.abort = u->d_words.p + W_STATUS; E.big_list = u->d_big_list.p; E.big_n = u->d_words.p + W_BIGCOUNT; E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
+        E.jump_list = u->d_jump_list.p; E.n_jump = u->d_words.p + W_JUMPCOUNT; E.n_hits = nh; E.abort = u->d_words.p + W_STATUS; E.big_list = u->d_big_list.p; E.big_n = u->d_words.p + W_BIGCOUNT; E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
         agx_launch_edge_sweep(&E, st);
         AGX_CHECKPOINT("edge_sweep");
         // Passes J and B insert edges out of different sources (positions with one variant / with several) and both wait on memory more than
@@ -337,7 +388,7 @@ void do_build(agx_unit *u) {
         C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_nid = u->d_a_nid.p; C.ovf = u->d_ovf.p; C.n_ovf = 0; C.a_ovf = u->d_a_ovf.p;
         C.abort = u->d_words.p + W_STATUS;
         C.a_mark = u->d_a_mark.p; C.side_xpos = u->d_side_xpos.p; C.sparse_min = (u->prm.flags & AGX_FLAG_SPARSE_MIN) ? 1u : 0u;
-        C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p; C.hop = u->d_hop.p; C.sp_hop = u->d_sp_hop.p; C.sp_cap = u->sp_cap;
+        C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p; C.sp_cap = u->sp_cap;
         if (g_scan1) agx_launch_exclusive_scan1(u->d_tile_side.p, u->d_tile_side_start.p, u->n_tiles, u->d_scan_desc.p + u->scan_desc_n, st);
         else agx_launch_exclusive_scan(u->d_tile_side.p, u->d_tile_side_start.p, u->n_tiles, u->d_scan_tmp.p, st);      // per tile: the sweep has scanned inside the tiles
         agx_launch_compact(&C, u->d_chain_end.p, u->n_chain_end, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
@@ -355,7 +406,7 @@ void do_build(agx_unit *u) {
         HIP_OK(hipStreamWaitEvent(u->st, done, 0));
         turn.n++; turn.prev_exclusive = u->ev.all;
         my_turn.unlock();
-        HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, (W_N + 4) * 4, hipMemcpyDeviceToHost, u->st));
+        HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, (W_N + 6) * 4, hipMemcpyDeviceToHost, u->st));
         HIP_OK(hipStreamSynchronize(u->st));
         HIP_OK(hipGetLastError());
         if (g_trace_gap && trace_from && trace_from != u->ev.e[B_NODE]) {      // diagnostic (units must outlive each other's builds): end of the previous sweep -> start of this one
@@ -364,38 +415,37 @@ void do_build(agx_unit *u) {
         if (w[W_ERR] & 1u) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
         if (w[W_ERR] & 2u) throw Error{E_UNSUPPORTED, "read alignment beyond the end of the unit sequence"};
         u->n_tile_entries = w[W_N];
-        if (u->n_tile_entries > u->list_cap) { u->list_cap = u->n_tile_entries + u->n_tile_entries / 8 + 1024; u->d_unsorted.release(); u->d_tile_recs.release(); continue; }
-        if (w[W_STATUS] & 8u) { u->fallback = true; continue; }      // some tile needs wider buckets: from now on this unit's builds queue the fallback passes
-        if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 64 node variants at one position"};
-        if (w[W_STATUS] & 1u) {                  // a region's slice of the node pool ran out: cut the slices to what the regions asked for
-            std::vector<agx_u32> padded((size_t)u->n_regions * AGX_REGION_PAD), demand(u->n_regions);
-            HIP_OK(hipMemcpy(padded.data(), u->d_pool_cnt.p, padded.size() * 4, hipMemcpyDeviceToHost));
-            for (agx_u32 r = 0; r < u->n_regions; r++) demand[r] = padded[(size_t)r * AGX_REGION_PAD];
-            const unsigned long long need = layout_regions(u, demand.data(), false);
-            if (need >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "node table exceeds 2^32 entries"};
-            if (need > u->pool_cap) {
-                u->d_cid.release(); u->d_coff.release(); u->d_cid0.release(); u->d_coff0.release(); u->d_off0.release(); u->d_xpos.release();
-                u->d_next.release(); u->d_base.release(); u->d_flags.release(); u->d_sref.release(); u->d_counts.release();
-                u->d_aid_of.release(); u->d_a_str.release(); u->d_a_meta.release(); u->d_a_nid.release();
-                u->d_a_mark.release(); u->d_side_xpos.release(); u->d_sp_bits.release(); u->d_sp_cnt.release(); u->d_sp_rank.release();
-                alloc_pool(u, (agx_u32)need);
-            }
-            layout_regions(u, demand.data(), true);
-                    continue;
+        // a capacity that was too small: take a larger buffer (the arena keeps the old one until the unit is released) and build again.
+        // Whatever a retry changes on the device goes through the unit's stream and a fresh ev_uploaded, which the next attempt waits for.
+        bool again = false;
+        if (u->n_tile_entries > u->list_cap) { alloc_lists(u, u->n_tile_entries + u->n_tile_entries / 8 + 1024); again = true; }
+        else {
+            if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 64 node variants at one position"};
+            if (w[W_STATUS] & 1u) {                  // the node pool ran out: cut the slices to what the regions asked for
+                std::vector<agx_u32> padded((size_t)u->n_regions * AGX_REGION_PAD), demand(u->n_regions);
+                HIP_OK(hipMemcpyAsync(padded.data(), u->d_pool_cnt.p, padded.size() * 4, hipMemcpyDeviceToHost, u->st)); HIP_OK(hipStreamSynchronize(u->st));
+                for (agx_u32 r = 0; r < u->n_regions; r++) demand[r] = padded[(size_t)r * AGX_REGION_PAD];
+                const unsigned long long need = layout_regions(u, demand.data(), 0, false);
+                if (need >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "node table exceeds 2^32 entries"};
+                if (need > u->pool_cap) alloc_pool(u, (agx_u32)need);
+                layout_regions(u, demand.data(), 0, true);
+                again = true;
+            } else if (w[W_OVFCOUNT] > u->ovf_cap) { alloc_ovf(u, w[W_OVFCOUNT] + w[W_OVFCOUNT] / 2 + 1024); again = true; }
+            else if (w[W_N + 2] > u->sp_cap) { alloc_sparse(u, w[W_N + 2] + w[W_N + 2] / 8 + 1024); again = true; }
         }
-        const unsigned long long want = w[W_POOL];
-        if (w[W_OVFCOUNT] > u->ovf_cap) { u->ovf_cap = w[W_OVFCOUNT] + w[W_OVFCOUNT] / 2 + 1024; u->d_ovf.release(); u->d_ovf.alloc(u->ovf_cap); u->d_a_ovf.release(); continue; }
-        u->n_nodes = (agx_u32)want; u->n_big = w[W_BIGCOUNT]; u->n_mid = w[W_MIDCOUNT]; u->n_ovf = w[W_OVFCOUNT];
+        if (again) { HIP_OK(hipEventRecord(u->ev_uploaded, u->st)); continue; }
+        u->n_nodes = w[W_POOL]; u->n_big = w[W_BIGCOUNT]; u->n_mid = w[W_MIDCOUNT]; u->n_ovf = w[W_OVFCOUNT];
         const unsigned long long ids = (unsigned long long)n_pos + w[W_N + 1];
         if (ids >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "walk graph exceeds 2^32 ids"};
-        if (w[W_N + 2] > u->sp_cap) { u->sp_cap = w[W_N + 2] + w[W_N + 2] / 8 + 1024; u->d_sp_node.release(); u->d_sp_hop.release(); continue; }
         u->n_ids = (agx_u32)ids; u->n_special = w[W_N + 2];
+        u->stats.build_attempts = (uint32_t)attempt + 1; u->stats.n_spilled = w[W_SPILL];
         break;
     }
     u->built = true; u->downloaded = false;
     u->stats.ms_build_span = u->ev.all ? u->ev.span() : 0.0;
     u->stats.ms_prep = u->ev.ms(B_PREP); u->stats.ms_bin = u->ev.ms(B_BIN); u->stats.ms_node_sweep = u->ev.ms(B_NODE);
     u->stats.ms_node_big = u->ev.ms(B_BIG); u->stats.ms_edge_fast = u->ev.ms(B_EDGE); u->stats.ms_edge_slow = u->ev.ms(B_SLOW); u->stats.ms_edge_sweep = u->stats.ms_edge_fast + u->stats.ms_edge_slow; u->stats.ms_compact = u->ev.ms(B_COMPACT);
+    if (u->up_timed) { float f = 0; if (hipEventElapsedTime(&f, u->ev_up0, u->ev_uploaded) == hipSuccess) u->stats.ms_upload_dev = f; else (void)hipGetLastError(); }
 }
 
 void do_download(agx_unit *u) {
@@ -406,24 +456,57 @@ void do_download(agx_unit *u) {
     hipStream_t st = u->st;
     const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
     u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(nside + 1);
-    u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 1);
+    u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1);
     u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
     if (ni) {
-        HIP_OK(hipMemcpyAsync(u->h_a_str.p, u->d_a_str.p, ni, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_a_meta.p, u->d_a_meta.p, ni, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(u->h_sp_bits.p, u->d_sp_bits.p, nw * 8, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(u->h_sp_rank.p, u->d_sp_rank.p, nw * 4, hipMemcpyDeviceToHost, st));
     }
     if (nside) HIP_OK(hipMemcpyAsync(u->h_side_xpos.p, u->d_side_xpos.p, nside * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipEventRecord(u->ev_dl, st));            // the special-id bitmap and the side ids' positions are on the host
+    if (ni) {
+        HIP_OK(hipMemcpyAsync(u->h_a_str.p, u->d_a_str.p, ni, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(u->h_a_meta.p, u->d_a_meta.p, ni, hipMemcpyDeviceToHost, st));
+    }
     if (ns) HIP_OK(hipMemcpyAsync(u->h_sp_node.p, u->d_sp_node.p, ns * sizeof(agx_walknode), hipMemcpyDeviceToHost, st));
-    if (ns) HIP_OK(hipMemcpyAsync(u->h_sp_hop.p, u->d_sp_hop.p, ns * sizeof(agx_hop), hipMemcpyDeviceToHost, st));
     if (u->n_ovf) HIP_OK(hipMemcpyAsync(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf), hipMemcpyDeviceToHost, st));
+    // While the larger copies run: the hop entry of every special id's position, in id order, next to where the walk will read the id's
+    // record (the per-position table stays on the host: it is 12 bytes per position that the device would only gather and send back).
+    HIP_OK(hipEventSynchronize(u->ev_dl));
+    u->h_sp_hop.resize(ns + 1);
+    {
+        size_t at = 0; const agx_hop *hop = u->T.hop.data();
+        for (size_t w = 0; w < nw && at < ns; w++) {
+            for (unsigned long long bits = u->h_sp_bits.p[w]; bits && at < ns; bits &= bits - 1) {
+                const size_t a = w * 64 + (size_t)__builtin_ctzll(bits);
+                u->h_sp_hop[at++] = hop[a < n_pos ? a : u->h_side_xpos.p[a - n_pos]];
+            }
+        }
+        if (at != ns) throw Error{E_DEVICE, "special-id bitmap and record count disagree"};
+    }
     HIP_OK(hipStreamSynchronize(st));
     memset(u->h_a_meta.p + ni, 0, 64);
     u->stats.n_walk_ids = ni; u->stats.n_special = ns;
-    u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
+    u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * sizeof(agx_walknode) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
     u->downloaded = true;
     u->stats.ms_download = now_ms() - t0;
+}
+
+// Gives back everything the unit holds on the device and its download buffers (to the caches of agx_mem.h: the next unit of the run takes
+// them without a driver call).  The inputs stay staged: the unit can be uploaded again as if it were new.
+void do_release(agx_unit *u) {
+    if (u->st) { (void)hipSetDevice(u->prm.device); (void)hipStreamSynchronize(u->st); }
+    for (auto *b : {&u->d_cm_start, &u->d_tile_cnt, &u->d_tile_off, &u->d_cursor, &u->d_unsorted, &u->d_tile_recs, &u->d_scan_tmp, &u->d_words, &u->d_pool_cnt, &u->d_region_off, &u->d_node_start,
+                    &u->d_slow_list, &u->d_rank4, &u->d_jump_list, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
+                    &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
+    for (auto *b : {&u->d_node_cnt, &u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
+    u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
+    u->d_ovf.release(); u->d_a_ovf.release(); u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
+    u->arena.reset();
+    u->h_a_str.release(); u->h_a_meta.release(); u->h_side_xpos.release(); u->h_sp_rank.release(); u->h_sp_bits.release(); u->h_sp_node.release(); u->h_fetch.release(); u->h_a_ovf.release();
+    std::vector<agx_hop>().swap(u->h_sp_hop);
+    u->pool_cap = u->spill_lo = u->ovf_cap = u->list_cap = u->sp_cap = 0;
+    u->uploaded = u->built = u->downloaded = false;
 }
 
 // records of non-special walk ids: built on the device from the node table, which stays in HBM (agx_walk_record), then one copy
@@ -433,7 +516,7 @@ void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u
     if (!n) return;
     if ((size_t)first + (size_t)(rows - 1) * stride + width > u->n_ids || n > 0x7FFFFFFFull) throw Error{E_ARG, "record fetch beyond the walk graph"};
     HIP_OK(hipSetDevice(u->prm.device));
-    u->h_fetch.alloc(n); u->d_fetch.alloc(n);
+    u->h_fetch.alloc(n); u->d_fetch.alloc(u->arena, n);
     agx_compact_args C = u->walk_args; C.n_ids = u->n_ids;
     agx_launch_fetch_records(&C, first, stride, rows, width, u->d_fetch.p, u->st);
     HIP_OK(hipMemcpyAsync(u->h_fetch.p, u->d_fetch.p, n * sizeof(agx_walknode), hipMemcpyDeviceToHost, u->st));
@@ -444,7 +527,7 @@ void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u
 GraphView view_of(agx_unit *u) {
     GraphView G; G.n_pos = (agx_u32)u->T.ref.size(); G.n_ids = u->n_ids;
     G.meta = u->h_a_meta.p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
-    G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.sp_hop = u->h_sp_hop.p; G.n_special = u->n_special;
+    G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.sp_hop = u->h_sp_hop.data(); G.n_special = u->n_special;
     G.fetch = fetch_records; G.fetch_ctx = u;
     G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf;
     return G;
@@ -482,8 +565,9 @@ int agx_selftest_scan(int device, uint32_t n, uint32_t seed) {
         for (uint32_t i = 0; i < n; i++) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; in[i] = (x % 5u == 0) ? x % 97u : 0u; }       // mostly zeros, like the side-id counts
         for (uint32_t i = 0; i <= n; i++) { want[i] = acc; acc += in[i]; }
         const size_t nb = ((size_t)n + 1 + 4095) / 4096;
+        DevArena arena; arena.device = device;
         DBuf<agx_u32> d_in, d_out; DBuf<unsigned long long> d_desc;
-        d_in.alloc((size_t)n + 1); d_out.alloc((size_t)n + 1); d_desc.alloc(nb + 1);
+        d_in.alloc(arena, (size_t)n + 1); d_out.alloc(arena, (size_t)n + 1); d_desc.alloc(arena, nb + 1);
         HIP_OK(hipMemcpy(d_in.p, in.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
         HIP_OK(hipMemset(d_desc.p, 0, (nb + 1) * 8)); HIP_OK(hipMemset(d_out.p, 0xFF, ((size_t)n + 1) * 4));
         agx_launch_exclusive_scan1(d_in.p, d_out.p, n, d_desc.p, nullptr);
@@ -514,20 +598,22 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
     const int rc = guarded(u, [&] {
         HIP_OK(hipSetDevice(p->device));
         HIP_OK(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
-        u->ev.init(); u->ev.all = (u->prm.flags & AGX_FLAG_TIME_SECTIONS) != 0; HIP_OK(hipEventCreateWithFlags(&u->ev_front, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&u->ev_passA, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&u->ev_passJ, hipEventDisableTiming));
+        u->ev.init(); u->ev.all = (u->prm.flags & AGX_FLAG_TIME_SECTIONS) != 0;
+        for (hipEvent_t *e : {&u->ev_front, &u->ev_passA, &u->ev_passJ, &u->ev_dl}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        HIP_OK(hipEventCreate(&u->ev_up0)); HIP_OK(hipEventCreate(&u->ev_uploaded));
     });
     if (rc != AGX_OK) { delete u; return rc; }
     *out = u;
     return AGX_OK;
 }
 
-void agx_unit_destroy(agx_unit *u) { if (u) { (void)hipSetDevice(u->prm.device); delete u; } }
+void agx_unit_destroy(agx_unit *u) { if (u) { (void)hipSetDevice(u->prm.device); do_release(u); delete u; } }
 
 const char *agx_unit_error(const agx_unit *u) { return u ? u->err.c_str() : "null unit"; }
 
 int agx_unit_set_reference(agx_unit *u, const char *bases, uint32_t n) {
     if (!u || (!bases && n)) return AGX_E_ARG;
-    return guarded(u, [&] { u->T = Threads(); u->T.ref.assign(bases, n); u->T.n_ref = n; u->have_ref = true; u->have_threads = false; u->uploaded = false; u->built = false; });
+    return guarded(u, [&] { u->T = Threads(); u->T.ref.assign(bases, n); u->T.n_ref = n; u->have_ref = true; u->have_threads = false; u->staged = false; u->uploaded = false; u->built = false; });
 }
 
 int agx_unit_set_contig_threads(agx_unit *u, const char *appended, uint32_t n_appended, const uint32_t *cm_start, const agx_contimer *cm, uint32_t n_cm,
@@ -546,7 +632,7 @@ int agx_unit_set_contig_threads(agx_unit *u, const char *appended, uint32_t n_ap
         }
         u->T.initial_contigs.assign(initial_contigs ? initial_contigs : "", initial_len);
         build_chains(u->T);
-        u->have_threads = true; u->uploaded = false; u->built = false;
+        u->have_threads = true; u->staged = false; u->uploaded = false; u->built = false;
     });
 }
 
@@ -567,7 +653,7 @@ int agx_unit_push_pairs(agx_unit *u, const agx_pair_batch *b) {
         u->P.runs.insert(u->P.runs.end(), b->runs, b->runs + b->n_runs);
         u->P.bases.append(b->bases, (size_t)b->n_slots * b->stride);
         u->P.n_slots += b->n_slots;
-        u->uploaded = false; u->built = false;
+        u->staged = false; u->uploaded = false; u->built = false;
     });
 }
 
@@ -596,11 +682,15 @@ int agx_unit_load_files_shared(agx_unit *u, const char *tmp_dir, int unit, const
         u->stats.ms_thread = now_ms() - t0; t0 = now_ms();
         load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie", (long)u->prm.batch, u->prm.k, u->P, reads ? reads->idx : nullptr);
         u->stats.ms_parse = now_ms() - t0;
-        u->have_ref = u->have_threads = true; u->uploaded = false; u->built = false;
+        u->have_ref = u->have_threads = true; u->staged = false; u->uploaded = false; u->built = false;
+        stage_inputs(u);
     });
 }
 
+int agx_unit_stage(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { stage_inputs(u); }); }
 int agx_unit_upload(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_upload(u); }); }
+int agx_unit_release(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_release(u); }); }
+void agx_pool_trim(int device) { if (device >= 0) dev_trim(device); else host_trim(); }
 int agx_unit_build(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_build(u); }); }
 int agx_unit_download(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_download(u); }); }
 
@@ -623,7 +713,7 @@ void agx_result_free(agx_result *r) { if (!r) return; free(r->initial_contigs); 
 int agx_unit_stats(const agx_unit *u, agx_stats *s) {
     if (!u || !s) return AGX_E_ARG;
     *s = u->stats;
-    s->n_pos = u->T.ref.size(); s->n_ref = u->T.n_ref; s->n_hits = u->P.hits.size(); s->n_runs = u->P.runs.size(); s->n_nodes = u->n_nodes;
+    s->n_pos = u->T.ref.size(); s->n_ref = u->T.n_ref; s->n_hits = u->P.hits.size(); s->n_runs = u->P.runs.size(); s->pinned_bytes_cached = host_cache().held(); s->device_bytes_cached = dev_cache(u->prm.device).held(); s->n_nodes = u->n_nodes;
     s->n_tiles = u->n_tiles; s->n_tile_entries = u->n_tile_entries; s->n_big_tiles = u->n_big; s->n_mid_tiles = u->n_mid; s->n_edge_overflow = u->n_ovf;
     s->pairs_in_file = u->P.n_pairs_in_file; s->sam_line_pairs = u->P.n_sam_pairs;
     return AGX_OK;

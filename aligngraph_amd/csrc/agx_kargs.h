@@ -4,13 +4,13 @@
 #include "agx_core.h"
 
 struct agx_prep_args {
-    const agx_hit *hits;      // [n_hits] in the order of the tile their left end falls into (upload time): the 64 hits of a wavefront share a handful of
-                              // tiles, and every per-hit array of the build (dhit, rank4, the tile lists' entries) uses this numbering; pad[0] = agx_hit_dup
+    const agx_hit *hits;      // [n_hits] in SAM file order: a hit's number is its place in the file, the order the tile lists are sorted into
     const agx_run *runs; agx_dhit *dhit; agx_u32 n_hits, k, n_pos;
     agx_u32 *tile_cnt;        // [n_tiles] number of hits overlapping each tile
     agx_u32 *err;             // bit 0: same-strand mates; bit 1: alignment beyond the unit sequence
     uint4 *rank4;             // [n_hits] what the histogram's atomicAdd returned for the hit's first four tiles = its slot in each tile's list
     agx_u32 *rank_overflow;   // set when some hit spans more than four tiles: the lists are then filled with a second round of atomics
+    agx_u32 *jump_list, *jump_count;   // kept hits with a mate of several runs (any order): what pass J of the edge build looks at
 };
 
 struct agx_bin_args { const agx_dhit *dhit; agx_u32 n_hits; const agx_u32 *tile_off; agx_u32 *cursor; agx_u32 *unsorted; agx_u32 cap;   // cap: entries the lists can hold
@@ -20,6 +20,7 @@ struct agx_node_kargs {
     agx_sweep_args S;
     agx_u32 *pool_cnt;         // node ids handed out per region (counter r at pool_cnt[r * AGX_REGION_PAD]); keeps counting past the slice's end
     const agx_u32 *region_off; // [regions + 1] first node id of every region's slice of the pool
+    agx_u32 spill_lo; agx_u32 *spill_cnt;   // ids [spill_lo, pool_cap) behind the slices, for regions whose slice is full (one counter)
     agx_u32 *mid_count; agx_u32 *mid_list;   // tiles whose buckets did not fit pass 0's
     agx_u32 *big_count; agx_u32 *big_list;   // tiles whose buckets did not fit pass 1's either
     agx_u32 fallback_queued;   // the two fallback passes are queued behind the main pass (a unit's builds start without them: most units never overflow a bucket)
@@ -34,7 +35,7 @@ struct agx_node_kargs {
 struct agx_edge_kargs {
     agx_sweep_args S; agx_edge_ovf *ovf; agx_u32 *ovf_count; agx_u32 ovf_cap; agx_u32 list_cap;
     agx_u32 *slow_list; agx_u32 *slow_count;   // positions that need the per-hit pass (device-side list)
-    const agx_u32 *jump_list; agx_u32 n_jump;  // hits with a mate of several runs (upload time): the only hits the edge build's pass J looks at
+    const agx_u32 *jump_list; const agx_u32 *n_jump; agx_u32 n_hits;  // hits with a mate of several runs (listed by hit_prep, length on the device): the only hits pass J looks at
     const agx_u32 *abort;                      // the node sweeps' status word: non-zero = the node table is incomplete, do nothing
     const agx_u32 *big_list; const agx_u32 *big_n;   // tiles the fallback pass wrote (their edges are all pass A/B's)
 };
@@ -45,13 +46,13 @@ extern "C" {
 struct agx_zero_args { agx_u32 *p[8]; agx_u32 n[8]; };
 void agx_launch_zero(const agx_zero_args *, hipStream_t);
 void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t);      // n_pos + 1 heads
-void agx_launch_vote_codes(void *blob, size_t n_bytes16, hipStream_t);      // read bases -> agx_vote_code, in place; n_bytes16 a multiple of 16
+void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16, hipStream_t);      // packed base classes (agx_pack_classes) -> agx_vote_code bytes; n_bases16 a multiple of 16
 void agx_launch_hit_prep(const agx_prep_args *, hipStream_t);
 // exclusive scan of in[0..n] (n+1 entries, in[n] must be 0) into out[0..n]; out[n] = total
 void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u32 *tmp, hipStream_t);
 void agx_launch_exclusive_scan1(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsigned long long *desc, hipStream_t);      // one launch; desc: ceil((n+1)/4096) zeroed words
 void agx_launch_bin_fill(const agx_bin_args *, hipStream_t);
-void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_u32 *file_order, const agx_dhit *dhit, void *recs, hipStream_t);
+void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, hipStream_t);
 void agx_launch_node_sweep(const agx_node_kargs *, hipStream_t);
 void agx_launch_node_sweep_big(const agx_node_kargs *, hipStream_t);
 void agx_launch_edge_sweep(const agx_edge_kargs *, hipStream_t);                   // pass A (lanes = positions)

@@ -46,41 +46,45 @@ __device__ __forceinline__ void agx_collect_block(const agx_collect_args &G) {
     for (agx_u32 o = 128; o; o >>= 1) { if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) { G.out[0] = *G.a; G.out[1] = *G.b; G.out[2] = *G.c; *G.sum = part[0]; }
 }
-// read bases -> vote codes, in place (16 characters per thread; the blob is padded to a multiple of 16)
-__global__ void __launch_bounds__(256) agx_k_vote_codes(uint4 *blob, size_t n16) {
+// packed base classes (4 bits per base, what crosses PCIe) -> vote codes (one byte per base, what the sweeps gather): 16 bases per thread
+__global__ void __launch_bounds__(256) agx_k_expand_codes(const uint2 *packed, uint4 *vcodes, size_t n16) {
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n16) return;
-    uint4 v = blob[i];
-    agx_u32 w[4] = {v.x, v.y, v.z, v.w};
+    const uint2 v = packed[i];
+    const agx_u32 in[2] = {v.x, v.y};
+    agx_u32 w[4];
     for (int j = 0; j < 4; j++) {
         agx_u32 o = 0;
-        for (int b = 0; b < 4; b++) o |= (agx_u32)agx_vote_code((w[j] >> (8 * b)) & 0xFFu) << (8 * b);
+        for (int b = 0; b < 4; b++) o |= (agx_u32)agx_class_vote_code((in[j >> 1] >> (16 * (j & 1) + 4 * b)) & 0xFu) << (8 * b);
         w[j] = o;
     }
-    blob[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    vcodes[i] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // ---- hit_prep: one thread per hit -------------------------------------------------------------------------------
-// The device copy of the hits is in the order of the tile their left end falls into (upload time), so the 64 hits of a wavefront fall
-// into a handful of tiles and every per-hit read and write of the binning kernels is coalesced.  Device-scope atomics are the expensive part of binning on this chip (8 L2s: they are resolved
-// behind them): the wavefront adds up its hits per tile and issues ONE atomicAdd per distinct tile, and what that returns is also each
-// hit's slot in the tile's list, so that bin_fill scatters without atomics.
+// Hits arrive in SAM file order (a unit is built once: sorting them by tile first costs more than it saves the binning kernels).
+// Device-scope atomics are the expensive part of binning on this chip (8 L2s: they are resolved behind them): neighbouring lanes that want
+// the same tile add up and issue ONE atomicAdd, and what that returns is also each hit's slot in the tile's list, so that bin_fill
+// scatters without atomics.  The kernel also decides the one rule that needs the file order (a later hit of a pair landing on an earlier
+// one is dropped, AG:1650-1655) and lists the hits pass J of the edge build has to look at.
 __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
     const agx_u32 h = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
     const bool mine = h < A.n_hits;
     agx_dhit d; d.flags = AGX_HF_SKIP; d.x_lo = 1; d.x_hi = 0; d.a_nruns = 0;
+    bool jump = false;
     if (mine) {
         const agx_hit H = A.hits[h];
-        const int rc = agx_hit_prep(H, H.pad[0] != 0, A.runs, A.k, d);
+        const int rc = agx_hit_prep(H, H.back != 0 && agx_hit_dup(A.hits, A.runs, h), A.runs, A.k, d);
+        jump = H.nruns1 >= 2 || H.nruns2 >= 2;             // a mate of several runs: the only hits that can step over positions
         if (rc) atomicOr(A.err, 1u);
         if (!(d.flags & AGX_HF_SKIP) && (d.x_hi >= A.n_pos || d.x_lo > d.x_hi)) { atomicOr(A.err, 2u); d.flags |= AGX_HF_SKIP; }
     }
     const bool kept = mine && !(d.flags & AGX_HF_SKIP);
     const agx_u32 t0 = kept ? d.x_lo / AGX_TILE : 0u, t1 = kept ? d.x_hi / AGX_TILE : 0u;
-    // The lanes of a wavefront are in tile order (perm), so the lanes that want the same tile as their s-th one are neighbours: a run
-    // of equal tile numbers.  The first pending lane of every run adds the run's pending lanes to the tile's counter — all runs in the
-    // same atomic instruction, and the four instructions (s = 0..3) back to back: the wavefront waits for one round trip, not for one per
-    // distinct tile.  (Nothing depends on the order: equal tiles that are not neighbours just become two runs.)
+    // Lanes that want the same tile as their s-th one and are neighbours form a run of equal tile numbers (pile-ups, hits of one pair).
+    // The first pending lane of every run adds the run's pending lanes to the tile's counter — all runs in the same atomic instruction,
+    // and the four instructions (s = 0..3) back to back: the wavefront waits for one round trip, not for one per distinct tile.
+    // (Nothing depends on the order: equal tiles that are not neighbours just become two runs.)
     agx_u32 r[4] = {0, 0, 0, 0}, base[4] = {0, 0, 0, 0}, lead[4] = {0, 0, 0, 0};
     bool pend[4];
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -102,6 +106,15 @@ __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
     if (kept && t1 - t0 >= 4) {                                              // spans more than four tiles: count the rest, and tell bin_fill to take its own slots
         for (agx_u32 t = t0 + 4; t <= t1; t++) atomicAdd(&A.tile_cnt[t], 1u);
         atomicOr(A.rank_overflow, 1u);
+    }
+    {   // pass J's list (order irrelevant: its edge inserts are set inserts)
+        const unsigned long long jm = __ballot(jump && kept);
+        if (jm) {
+            agx_u32 jb = 0;
+            if (lane == (agx_u32)__builtin_ctzll(jm)) jb = atomicAdd(A.jump_count, (agx_u32)__popcll(jm));
+            jb = (agx_u32)__shfl((int)jb, __builtin_ctzll(jm), 64);
+            if (jump && kept) A.jump_list[jb + (agx_u32)__popcll(jm & below)] = h;
+        }
     }
     if (!mine) return;
     A.rank4[h] = make_uint4(r[0], r[1], r[2], r[3]);
@@ -205,9 +218,9 @@ __device__ __forceinline__ void agx_put_rec(uint4 *recs, agx_u32 at, const agx_d
     const uint2 a = s2[0], b = s2[1], c = s2[2], d = s2[3];
     recs[2 * (size_t)at] = make_uint4(a.x, a.y, b.x, b.y); recs[2 * (size_t)at + 1] = make_uint4(c.x, c.y, d.x, d.y);
 }
-// (list entries are hit numbers in the device's tile order; file_order[] gives a hit's place in the SAM file, the sort key)
+// (list entries are hit numbers = places in the SAM file: the sort key)
 __global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap,
-                                                       const agx_u32 *file_order, const agx_dhit *dhit, uint4 *recs) {
+                                                       const agx_dhit *dhit, uint4 *recs) {
     __shared__ agx_u32 sh[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
@@ -216,19 +229,19 @@ __global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, 
     if (tile_off[tile + 1] > cap) return;                // lists did not fit: the host grows them and re-runs
     const agx_u32 *src = unsorted + lo;
     if (n <= AGX_SORT_LDS) {
-        for (agx_u32 i = lane; i < n; i += 64) sh[wave][i] = file_order[src[i]];
+        for (agx_u32 i = lane; i < n; i += 64) sh[wave][i] = src[i];
         // single wavefront: LDS writes above are visible to its own later reads after the implicit waitcnt
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         for (agx_u32 i = lane; i < n; i += 64) {
             const agx_u32 key = sh[wave][i]; agx_u32 r = 0;
             for (agx_u32 j = 0; j < n; j++) r += sh[wave][j] < key;
-            agx_put_rec(recs, lo + r, dhit, src[i]);
+            agx_put_rec(recs, lo + r, dhit, key);
         }
     } else {                                            // pile-ups larger than the LDS window: same rank sort straight from L2
         for (agx_u32 i = lane; i < n; i += 64) {
-            const agx_u32 v = src[i], key = file_order[v]; agx_u32 r = 0;
-            for (agx_u32 j = 0; j < n; j++) r += file_order[src[j]] < key;
-            agx_put_rec(recs, lo + r, dhit, v);
+            const agx_u32 key = src[i]; agx_u32 r = 0;
+            for (agx_u32 j = 0; j < n; j++) r += src[j] < key;
+            agx_put_rec(recs, lo + r, dhit, key);
         }
     }
 }
@@ -304,9 +317,18 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
         // of a 0.93 ms sweep).  The ids of a unit are therefore not dense; everything downstream enters the table through node_start.
         const agx_u32 region = tile / AGX_REGION_TILES;
         const agx_u32 r_lo = agx_uload(K.region_off, region), r_hi = agx_uload(K.region_off, region + 1);
-        if (lane == 0) base = atomicAdd(K.pool_cnt + (size_t)region * AGX_REGION_PAD, total);
-        base = r_lo + (agx_u32)__shfl(base, 0, 64);
-        if ((unsigned long long)base + total > r_hi) { if (lane == 0) atomicOr(K.status, 1u); if (PASS != 0) continue; else return; }
+        // A region whose slice is full takes its ids from the spill area behind the slices (one counter for the unit, touched by the few
+        // tiles that get there): the first build of a unit has no measurement to cut the slices by, and must not need a second one.
+        if (lane == 0) {
+            const agx_u32 at = r_lo + atomicAdd(K.pool_cnt + (size_t)region * AGX_REGION_PAD, total);
+            base = at;
+            if ((unsigned long long)at + total > r_hi) {
+                const unsigned long long sp = (unsigned long long)K.spill_lo + atomicAdd(K.spill_cnt, total);
+                base = sp + total <= K.S.pool_cap ? (agx_u32)sp : AGX_NONE;
+            }
+        }
+        base = (agx_u32)__shfl(base, 0, 64);
+        if (base == AGX_NONE) { if (lane == 0) atomicOr(K.status, 1u); if (PASS != 0) continue; else return; }
         const agx_u32 my_base = base + incl - cnt;
         const agx_u32 nbase = (agx_u32)__shfl_down((int)my_base, 1, 64), ncnt = (agx_u32)__shfl_down((int)cnt, 1, 64);
         agx_bucket bn = b; bn.base = b.base + 1;           // the next position's bucket is the next lane's column
@@ -384,14 +406,15 @@ __device__ __forceinline__ void agx_slot_insert(const agx_edge_kargs &K, agx_u32
     atomicOr((agx_u32 *)(addr & ~(size_t)3), (agx_u32)AGX_NF_EOVF << (8u * (agx_u32)(addr & 3)));
 }
 
-// pass J: one thread per hit with a mate of several runs (one hit in ten; the list is made at upload time); agx_edge_jump_hit drops the
-// ones that were skipped or whose a mate is the simple one
+// pass J: the hits with a mate of several runs (one hit in ten; hit_prep lists them); agx_edge_jump_hit drops the ones whose a mate is the
+// simple one.  The list's length is read on the device.
 __global__ void __launch_bounds__(256) agx_k_edge_jump(agx_edge_kargs K) {
     AGX_RETURN_IF_ABORTED(K.abort);
-    const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= K.n_jump) return;
-    const agx_dhit d = K.S.dhit[K.jump_list[i]];
-    agx_edge_jump_hit(K.S, d, [&](agx_u32 src, agx_u32 dst) { agx_slot_insert(K, src, dst); });
+    const agx_u32 n = __builtin_amdgcn_readfirstlane((int)*K.n_jump);
+    for (agx_u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const agx_dhit d = K.S.dhit[K.jump_list[i]];
+        agx_edge_jump_hit(K.S, d, [&](agx_u32 src, agx_u32 dst) { agx_slot_insert(K, src, dst); });
+    }
 }
 
 __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
@@ -464,7 +487,6 @@ __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, ag
         const agx_u32 at = A.sp_rank[w] + (agx_u32)__popcll(bits & ((1ull << lane) - 1ull));
         if (at >= A.sp_cap) return;                                           // table too small: the host sees the count and repeats the build
         A.sp_node[at] = agx_walk_record(A, a);
-        A.sp_hop[at] = A.hop[a < A.n_pos ? a : A.side_xpos[a - A.n_pos]];
     }
 }
 
@@ -485,9 +507,9 @@ void agx_launch_zero(const agx_zero_args *Z, hipStream_t st) {
     unsigned long long total = 0; for (int s = 0; s < 8; s++) total += Z->n[s];
     if (total) hipLaunchKernelGGL(agx_k_zero, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *Z);
 }
-void agx_launch_vote_codes(void *blob, size_t n_bytes16, hipStream_t st) {
-    const size_t n16 = n_bytes16 / 16;
-    if (n16) hipLaunchKernelGGL(agx_k_vote_codes, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (uint4 *)blob, n16);
+void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16, hipStream_t st) {
+    const size_t n16 = n_bases16 / 16;
+    if (n16) hipLaunchKernelGGL(agx_k_expand_codes, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const uint2 *)packed, (uint4 *)vcodes, n16);
 }
 void agx_launch_hit_prep(const agx_prep_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_hit_prep, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
@@ -522,8 +544,8 @@ void agx_launch_exclusive_scan1(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsi
 void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_bin_fill, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
 }
-void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_u32 *file_order, const agx_dhit *dhit, void *recs, hipStream_t st) {
-    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, n_tiles, cap, file_order, dhit,
+void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, hipStream_t st) {
+    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, n_tiles, cap, dhit,
                                     (uint4 *)recs);
 }
 void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
@@ -543,7 +565,8 @@ void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
     hipLaunchKernelGGL(agx_k_edge_sweep, dim3(nb + AGX_BIG_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K, nb);
 }
 void agx_launch_edge_jump(const agx_edge_kargs *K, hipStream_t st) {
-    if (K->S.n_pos && K->n_jump) hipLaunchKernelGGL(agx_k_edge_jump, dim3((K->n_jump + 255) / 256), dim3(256), 0, st, *K);
+    const agx_u32 blocks = (K->n_hits / 10u + 255u) / 256u + 1u;      // about one thread per listed hit; more entries than that are strided over
+    if (K->S.n_pos && K->n_hits) hipLaunchKernelGGL(agx_k_edge_jump, dim3(blocks < 2048u ? blocks : 2048u), dim3(256), 0, st, *K);
 }
 void agx_launch_edge_slow(const agx_edge_kargs *K, hipStream_t st) {
     // persistent wavefronts: exactly as many blocks as the device holds at once (a second, partial round of blocks would idle most CUs)

@@ -1,14 +1,27 @@
 #!/usr/bin/env python3
 """bench.py — aligned reads/sec through graph build + extend (BASELINE.json metric) on N MI355X GPUs of one node.
 
-A "step" is one pass of the hot path (kernels: hit prep, tile binning, node sweep, edge sweep; then node-table download
-and the host walk/join/scaffold) over one unit-sized batch of synthetic aligned reads whose packed arrays are ALREADY
-RESIDENT IN HBM when the timed region starts (text parsing and upload are reported separately, never inside `value`).
+What is timed is SURVEY §8(d)'s T_core of a whole job, the way the application runs it (AG:4765-4783: one unit after another, every unit
+new data): a "step" takes every unit of the configuration from its packed arrays in host memory to its three output byte buffers in
+host memory — upload (one HBM block per unit, PCIe copies), the unit's FIRST build (all kernels, capacities sized on the spot, a repeat
+if one proves too small), download of the walk graph, the sequential host walk/join/scaffold — with the units pipelined against each other
+on the device exactly as AlignGraph_amd pipelines them (a worker thread per unit in flight, largest unit first).  Every step starts from
+nothing on the device: with --pool cold (the default) the library's memory caches are emptied first, so every step pays its allocations
+like the first units of a fresh process do; the units' packed arrays stay staged in host memory between steps, as T_core defines.
 
-Workload at N=1: BASELINE.json configs[1] shape — 4.6 Mb reference (E. coli K-12 size), 1M 2x100 bp pairs, contigs cut
-from a mutated target, k=5 — generated by tools/agx_synth (seeded).  Multi-GPU (driver launches one rank per GPU with
-torch.distributed.run): units are independent, so every rank runs its own unit of the same size (weak
-scaling), and each step ends with the path's only exchange: an RCCL gather of the extended-contig FASTA bytes to rank 0.
+    value = 2 * pairs of the configuration / seconds per step            (whole job, all GPUs)
+
+Text parsing of the five per-unit files (T_unit = parse + T_core) is measured once while the inputs are loaded and reported beside it.
+
+Configurations (--config; BASELINE.json `configs`, synthetic data of that shape from tools/agx_synth, seeded):
+    cfg3 (default)  A. thaliana shape: 5 units of 30.4 / 19.7 / 23.5 / 18.6 / 27.0 Mb, 20 M 2x100 bp pairs, k=5      <- the north-star 1-GPU target
+    cfg2            E. coli shape: one 4.6 Mb unit, 1 M pairs
+    cfg4            human chr1 shape: 249 Mb --part 4 (4 units of 62 Mb), 60 M pairs (needs ~25 GB of scratch disk and a few minutes to generate)
+    custom          --chroms / --pairs / --part
+
+Multi-GPU (driver: torch.distributed.run, one rank per GPU): units are the shard — assigned longest-first to the least
+loaded rank (shard.assign_units), each rank runs its own list, and ONE gather of the extended-contig bytes to rank 0 ends the step
+(RCCL).  Total work is fixed: "scaling": "strong".
 
 Prints ONE JSON line on rank 0.
 """
@@ -23,6 +36,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {
+    # name: (chromosome lengths, --part, pairs, L, label)
+    "cfg2": ([4600000], 1, 1000000, 100, "configs[1]: E. coli K-12 shape, one 4.6 Mb unit, 1M 2x100 bp pairs"),
+    "cfg3": ([30427671, 19698289, 23459830, 18585056, 26975502], 1, 20000000, 100,
+             "configs[2]: A. thaliana shape (TAIR10 chromosome lengths), 5 units / 119.1 Mb, 20M 2x100 bp pairs"),
+    "cfg4": ([248956422], 4, 60000000, 100, "configs[3]: human chr1 shape (GRCh38 length), --part 4 = 4 units of 62 Mb, 60M 2x100 bp pairs"),
+}
 
 
 def algorithmic_bytes(n_pairs, L, k, n_pos):
@@ -52,29 +73,42 @@ def pin_to_gpu_numa_node(torch, index):
         return "not pinned (%s)" % e
 
 
+def n50_of(fasta_bytes):
+    """Eval-AlignGraph's rule, EV:372-380."""
+    lens = sorted((len("".join(rec.split("\n")[1:])) for rec in fasta_bytes.decode().split(">")[1:]), reverse=True)
+    tot, acc = sum(lens), 0
+    for ln in lens:
+        acc += ln
+        if acc > tot / 2:
+            return ln
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1024)
-    ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--genome", type=int, default=4600000)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS) + ["custom"])
+    ap.add_argument("--chroms", default="4600000", help="custom: comma-separated chromosome lengths")
+    ap.add_argument("--part", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1000000)
     ap.add_argument("--L", type=int, default=100)
     ap.add_argument("--k", type=int, default=5)
-    ap.add_argument("--coverage", type=int, default=5)
+    ap.add_argument("--coverage", type=int, default=5, help="--coverage of the run (the reference's default 20 is above the graph depth of these read sets: SURVEY §8d)")
+    ap.add_argument("--pool", default="cold", choices=["cold", "warm"],
+                    help="cold: the library's device and pinned-memory caches are emptied before every step (every step allocates like a fresh process); "
+                         "warm: they keep what earlier steps left (units 6, 7, .. of a long run)")
+    ap.add_argument("--inflight", type=int, default=0, help="units in flight per GPU = worker threads (0: all of the rank's units, at most 8)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=200000, help="pairs in the bounded CPU-baseline sample (0 = skip)")
-    ap.add_argument("--pipeline", type=int, default=12, choices=range(1, 33),
-                    help="resident copies of the unit, each with a worker thread that takes the next step and runs build -> download -> host "
-                         "walk; the kernels of one unit run while other units are being walked on other cores, exactly as the independent "
-                         "units of a multi-unit run overlap (kernels of different units never overlap each other); 1 = strictly serial "
-                         "steps (its latency is always reported as serial_step_ms)")
     ap.add_argument("--workdir", default=os.environ.get("AGX_BENCH_DIR", "/tmp/agx_bench"))
-    ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--keep", action="store_true", help="keep the generated inputs (a later run with the same configuration re-uses them)")
     args = ap.parse_args()
 
     import torch
     import aligngraph_amd as A
     import agx_data as D                        # synthetic inputs (tools/); nothing under oracle/ is imported outside the cpu_baseline leg
+    from aligngraph_amd import shard
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -101,218 +135,223 @@ def main():
             dist.barrier()
     assert A.device_count() > local_rank, "bench.py needs a HIP device (no CPU fallback exists)"
     torch.cuda.set_device(local_rank)
+    gdev = torch.device("cpu") if share else torch.device("cuda", local_rank)
     numa_note = pin_to_gpu_numa_node(torch, local_rank) if os.environ.get("AGX_BENCH_NO_PIN") != "1" else "not pinned (AGX_BENCH_NO_PIN=1)"
 
-    # ---- synthetic unit of this rank (text files like the reference's tmp/), parsed by the product's host loaders ----
-    run = os.path.join(args.workdir, "rank%d" % rank)
-    t0 = time.perf_counter()
+    if args.config == "custom":
+        chroms, part, pairs, L = [int(x) for x in args.chroms.split(",")], args.part, args.pairs, args.L
+        label = "custom: chromosomes %s, --part %d, %d 2x%d bp pairs" % (args.chroms, part, pairs, L)
+    else:
+        chroms, part, pairs, L, label = CONFIGS[args.config]
+    k = args.k
+
+    # ---- synthetic inputs (text files like the reference's tmp/): rank 0 generates, every rank parses its own units ----
     extra = {}
     for kv in filter(None, os.environ.get("AGX_BENCH_SYNTH", "").split(",")):      # experiments only (e.g. contig_overlap=0): changes the workload, the
         key, _, val = kv.partition("=")                                             # JSON line then says so in config.workload
         extra[key] = val
-    D.synth(run, seed=1000 + rank, chroms=str(args.genome), pairs=args.pairs, L=args.L, k=args.k, coverage=args.coverage, **extra)
+    run = os.path.join(args.workdir, "%s_p%d_k%d" % ("_".join(str(c) for c in chroms), pairs, k) + ("_x" if extra else ""))
+    t0 = time.perf_counter()
+    stamp = os.path.join(run, "synth_meta.txt")
+    if rank == 0 and not os.path.exists(stamp):
+        D.synth(run, seed=1000, chroms=",".join(str(c) for c in chroms), part=part, pairs=pairs, L=L, k=k, coverage=args.coverage, sam_seq=0, **extra)
+    if dist:
+        dist.barrier()
     t_gen = time.perf_counter() - t0
     tmp = os.path.join(run, "tmp")
-    units = [A.Unit(k=args.k, insert_variation=50, coverage=args.coverage, device=local_rank) for _ in range(args.pipeline)]
-    unit = units[0]
-    t0 = time.perf_counter()
-    for u in units:
-        u.load_files(tmp, 0)
-    t_parse = (time.perf_counter() - t0) / len(units)
-    t0 = time.perf_counter()
-    for u in units:
-        u.upload()
-    torch.cuda.synchronize()
-    t_upload = (time.perf_counter() - t0) / len(units)
-    for u in units:                                     # first build of every resident unit: sizes its device buffers (setup, like the upload)
-        u.build()
+    unit_len = D.read_meta(run)["unit_len"]
+    n_units = len(unit_len)
+    mine = shard.plan(unit_len, rank, world)                               # longest-first onto the least loaded rank, longest first within the rank
+    reads = A.Reads(os.path.join(tmp, "_reads.fa")) if mine else None      # tmp/_reads.fa mapped and indexed once for all units (agx_reads)
+    units, t_parse, t_stage = {}, 0.0, 0.0
+    for uu in mine:
+        un = A.Unit(k=k, insert_variation=50, coverage=args.coverage, device=local_rank)
+        t1 = time.perf_counter()
+        un.load_files(tmp, uu, reads=reads)                                # text -> packed arrays, staged in pinned memory (T_unit - T_core)
+        t_parse += time.perf_counter() - t1
+        t_stage += un.stats()["ms_stage"] * 1e-3
+        units[uu] = un
+    if reads is not None:
+        reads.close()
+    my_pairs = sum(units[uu].stats()["sam_line_pairs"] for uu in mine)
 
-    import queue
-    import threading
-    from aligngraph_amd import shard
-    gdev = torch.device("cpu") if share else torch.device("cuda", local_rank)
-    unit_gather = shard.UnitGather(dist, gdev, rank, world)
+    inflight = args.inflight or min(8, max(1, len(mine)))
+    unit_stats = {}
 
-    def gather_extended(ext):
-        """The path's only exchange: extended-contig bytes of every rank's unit -> rank 0, over RCCL.  Returns a handle; the
-        root's copy into host memory completes behind an event (the timed region ends with a device synchronisation)."""
-        return unit_gather.step(ext, head=shard.unit_header(rank, len(ext)))      # = pack_units([rank], [ext]) without joining the bytes on the host
+    def run_unit(uu):
+        """One unit from its staged packed arrays to its output bytes: upload -> first build -> download -> walk -> release.  Runs on one of
+        shard.run_job's worker threads (ctypes releases the interpreter lock, so the walks of several units run on several cores while
+        libagx queues their kernel chains on the device's build streams)."""
+        un = units[uu]
+        t_a = time.perf_counter()
+        un.upload()                        # HBM block + asynchronous PCIe copies + conti-mer heads, vote codes
+        un.build()                         # hit prep, binning, node sweep (+ edges), edge passes, walk preparation: the unit's first build
+        t_b = time.perf_counter()
+        un.download()                      # walk graph -> pinned host memory
+        res = un.finish_views()            # host walk/join/scaffold; the outputs stay in C memory until they are packed for the gather
+        st = un.stats()
+        st["s_upload_build"], st["s_total"] = t_b - t_a, time.perf_counter() - t_a
+        un.release()                       # HBM and download buffers back to the library
+        unit_stats[uu] = st
+        ext = res.bytes("extended")
+        res.free()
+        return ext
 
-    kern = {"ms_prep": 0.0, "ms_bin": 0.0, "ms_node_sweep": 0.0, "ms_node_big": 0.0, "ms_edge_fast": 0.0, "ms_edge_slow": 0.0, "ms_compact": 0.0, "ms_download": 0.0, "ms_walk": 0.0, "ms_build_span": 0.0}
-    last = {}
+    def run_job():
+        """One step: this rank's units (longest first) through run_unit on `inflight` worker threads, then the path's only exchange — one
+        gather of the extended contigs to rank 0 (aligngraph_amd/shard.py: the function the world_size-2 gloo test drives)."""
+        if args.pool == "cold":
+            A.pool_trim(local_rank, host=True)
+        return shard.run_job(unit_len, rank, world, run_unit, dist, gdev, inflight=inflight)
 
-    def run_steps(n, record):
-        """n steps over the resident units.  Every unit has a worker thread that keeps taking the next step number and runs build ->
-        download -> host walk on its unit (ctypes releases the GIL, so the walks of several units run on several cores while libagx
-        queues the builds of a device on its two build streams: the node sweeps run one after the other, so their HIP-event times are those
-        of an exclusive GPU).  The main thread gathers every finished step's extended contigs; all ranks gather once per step."""
-        ticket = iter(range(n))
-        take = threading.Lock()
-        done = queue.Queue()
-
-        def worker(u):
-            try:
-                while True:
-                    with take:
-                        i = next(ticket, None)
-                    if i is None:
-                        return
-                    u.build()                          # hit prep, binning, node sweep (+ edges), edge passes, walk preparation
-                    u.download()                       # walk graph -> pinned host memory on the unit's own stream (overlaps other units' kernels)
-                    res = u.finish_views()             # host walk/join/scaffold; the outputs stay in C memory (no interpreter-lock-held copies)
-                    done.put((i, res, u.stats()))
-            except BaseException as e:                 # surfaces in the main thread
-                done.put(e)
-
-        threads = [threading.Thread(target=worker, args=(u,)) for u in units]
-        for t in threads:
-            t.start()
-        for _ in range(n):
-            item = done.get()
-            if isinstance(item, BaseException):
-                raise item
-            i, res, st = item
-            gathered = gather_extended(res.view("extended"))
-            if record:
-                for key in kern:
-                    kern[key] += st[key]
-            prev = last.get("res")
-            last["res"], last["gathered"], last["st"] = res, gathered, st
-            if prev is not None:
-                prev.free()                            # (with one rank the gather handle only references the previous step's buffer)
-        for t in threads:
-            t.join()
-
-    run_steps(args.warmup, False)
+    for _ in range(args.warmup):
+        run_job()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(args.steps, True)
+    gathered = None
+    for _ in range(args.steps):
+        gathered = run_job()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    tot = torch.tensor([elapsed, t_parse, t_stage, float(my_pairs)], dtype=torch.float64, device=gdev)
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    out, st = {"extended": last["res"].bytes("extended")}, last["st"]
-    for key in kern:
-        kern[key] /= max(1, args.steps)
-    # The timed region measures only the node sweep on the device (two event records per build); the other sections of a build are timed
-    # here, outside it, on one more resident unit built with AGX_FLAG_TIME_SECTIONS (an event record between two kernels costs the
-    # stream about as much as a small kernel, and a build has eight boundaries).
-    torch.cuda.synchronize()
-    with A.Unit(k=args.k, insert_variation=50, coverage=args.coverage, device=local_rank, flags=A.AGX_FLAG_TIME_SECTIONS) as ub:
-        ub.load_files(tmp, 0); ub.upload()
-        reps = 8
-        for i in range(reps + 2):
-            ub.build()
-            if i >= 2:
-                sb = ub.stats()
-                for key in ("ms_prep", "ms_bin", "ms_node_big", "ms_edge_fast", "ms_edge_slow", "ms_compact", "ms_build_span"):
-                    kern[key] += sb[key] / reps
-    # strictly serial latency of one step (build -> download -> walk), outside the timed region, for the record
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(3):
-        unit.build(); unit.download(); unit.finish()
-    serial_ms = 1e3 * (time.perf_counter() - t1) / 3
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed, t_parse_max = float(mx[0].item()), float(mx[1].item())
+    else:
+        t_parse_max = t_parse
+    sam_pairs_total = int(tot[3].item())
 
-    # ---- parity spot-check of what was timed: the oracle on a bounded sample is the CPU baseline below; here only a checksum ----
-    n50 = None
-    if rank == 0:
-        got = last["gathered"].payloads()                # what the last step's gather left in rank 0's host memory: every rank's unit
-        assert len(got) == world and shard.unpack_units(got[0]) == {0: out["extended"]}
-        lens = sorted((len("".join(rec.split("\n")[1:])) for rec in out["extended"].decode().split(">")[1:]), reverse=True)
-        tot, acc = sum(lens), 0
-        for ln in lens:                                  # Eval-AlignGraph's rule, EV:372-380
-            acc += ln
-            if acc > tot / 2:
-                n50 = ln
-                break
+    # ---- after the timed region, rank 0: kernel sections of the largest unit (exclusive builds with section events) ----
+    kern, big_stats = {}, None
+    if rank == 0 and mine:
+        big = mine[0]
+        with A.Unit(k=k, insert_variation=50, coverage=args.coverage, device=local_rank, flags=A.AGX_FLAG_TIME_SECTIONS) as ub:
+            ub.load_files(tmp, big)
+            keys = ("ms_upload_dev", "ms_prep", "ms_bin", "ms_node_sweep", "ms_node_big", "ms_edge_fast", "ms_edge_slow", "ms_compact", "ms_build_span")
+            reps = 4
+            for i in range(reps + 1):                  # (the first one also loads the kernels' code)
+                ub.upload(); ub.build()
+                if i >= 1:
+                    sb = ub.stats()
+                    for key in keys:
+                        kern[key] = kern.get(key, 0.0) + sb[key] / reps
+            big_stats = ub.stats()
+            # the same unit rebuilt while resident (what r01's headline timed): kernels only, no upload, no download, no walk
+            t1 = time.perf_counter()
+            for _ in range(16):
+                ub.build()
+            kern["ms_resident_rebuild"] = 1e3 * (time.perf_counter() - t1) / 16
 
-    # ---- CPU baseline on rank 0 at N=1: the real reference binary (oracle/_ref, -O2 build, 1 thread) on a bounded sample ----
+    # ---- parity spot-check of what was timed + CPU baseline on rank 0 at N=1: the real reference binary (oracle/_ref, -O2, 1 thread) ----
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample_pairs > 0:
-        frac = args.cpu_sample_pairs / float(args.pairs)
-        sg = max(20000, int(args.genome * frac))
+        total_len = sum(chroms)
+        frac = args.cpu_sample_pairs / float(pairs)
+        sg = max(20000, int(total_len * frac))
         srun = os.path.join(args.workdir, "cpu_sample")
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import harness as H                     # the checker: reference binary (oracle/_ref) or the oracle, CPU baseline leg only
-        D.synth(srun, seed=999, chroms=str(sg), pairs=args.cpu_sample_pairs, L=args.L, k=args.k, coverage=args.coverage)
-        sample = "%d pairs 2x%d on a %d bp unit (same depth as the timed workload), stages (1)-(5)" % (args.cpu_sample_pairs, args.L, sg)
-        cores = 1
+        D.synth(srun, seed=999, chroms=str(sg), pairs=args.cpu_sample_pairs, L=L, k=k, coverage=args.coverage)
+        sample = "%d pairs 2x%d on a %d bp unit (same depth as the timed workload), stages (1)-(5), text parsing included" % (args.cpu_sample_pairs, L, sg)
         if H.have_reference(True):
             ref_out, secs = H.run_reference(srun, opt=True)
             kind, val = "reference", 2.0 * args.cpu_sample_pairs / secs
             # the GPU engine must reproduce the reference bytes on this very sample
-            with A.Unit(k=args.k, insert_variation=50, coverage=args.coverage, device=local_rank) as u2:
+            with A.Unit(k=k, insert_variation=50, coverage=args.coverage, device=local_rank) as u2:
                 u2.load_files(os.path.join(srun, "tmp"), 0)
                 u2.build()
-                mine = u2.finish()
-            assert all(mine[k2] == ref_out[0][k2] for k2 in ("initial", "pre", "extended")), "engine output differs from the reference binary on the CPU sample"
+                got = u2.finish()
+            assert all(got[k2] == ref_out[0][k2] for k2 in ("initial", "pre", "extended")), "engine output differs from the reference binary on the CPU sample"
         else:
             t1 = time.perf_counter()
-            H.run_oracle(os.path.join(srun, "tmp"), 0, args.k, 50, args.coverage)
+            H.run_oracle(os.path.join(srun, "tmp"), 0, k, 50, args.coverage)
             secs = time.perf_counter() - t1
             kind, val = "port", 2.0 * args.cpu_sample_pairs / secs
-        cpu = {"value": round(val, 1), "unit": "reads/s", "cores": cores, "kind": kind, "sample": sample, "seconds": round(secs, 2)}
+        cpu = {"value": round(val, 1), "unit": "reads/s", "cores": 1, "kind": kind, "sample": sample, "seconds": round(secs, 2)}
 
     if rank == 0:
-        reads_per_step = 2.0 * args.pairs * world
-        value = reads_per_step * args.steps / elapsed
-        n_pos = st["n_pos"]
-        abytes = algorithmic_bytes(args.pairs, args.L, args.k, n_pos)
-        # the dominant kernel is the node sweep's main pass, agx_k_node_sweep<0>, timed live in every step of the timed region; the two
-        # fallback launches behind it do part of the same work only if some tile overflowed the main pass's buckets
-        fallback = st["n_mid_tiles"] > 0
-        kernels = {"node_sweep": kern["ms_node_sweep"] + (kern["ms_node_big"] if fallback else 0.0), "edge_sweep": kern["ms_edge_fast"], "edge_slow": kern["ms_edge_slow"]}
-        dom = max(kernels, key=kernels.get)
-        dom_ms = kernels[dom]
-        achieved = abytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        all_kernel_ms = kern["ms_prep"] + kern["ms_bin"] + kern["ms_node_sweep"] + kern["ms_node_big"] + kernels["edge_sweep"] + kernels["edge_slow"] + kern["ms_compact"]
-        traffic = None
+        outs = gathered
+        assert sorted(outs) == list(range(n_units)), "the gather did not deliver every unit"
+        all_ext = b"".join(outs[uu] for uu in range(n_units))
+        reads_per_step = 2.0 * pairs
+        sec_per_step = elapsed / args.steps
+        value = reads_per_step / sec_per_step
+        # roofline of the dominant kernel (agx_k_node_sweep<0>) over rank 0's units in the last timed step: SURVEY §8d's algorithmic bytes of
+        # those units over the HIP-event time of their sweeps; next to it the HBM bytes the counters saw (profiles/) over the same time
+        sw_ms = sum(unit_stats[uu]["ms_node_sweep"] for uu in mine)
+        abytes = sum(algorithmic_bytes(unit_stats[uu]["sam_line_pairs"], L, k, unit_stats[uu]["n_pos"]) for uu in mine)
+        achieved = abytes / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else 0.0
+        traffic = hbm_rate = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom)
+                per_entry = json.load(open(pmc)).get("node_sweep_bytes_per_tile_entry")      # measured HBM bytes of the sweep per (tile, hit) list entry
+                entries = sum(unit_stats[uu]["n_tile_entries"] for uu in mine)
+                if per_entry:
+                    traffic = int(per_entry * entries)
+                    hbm_rate = traffic / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else None
             except Exception:
                 traffic = None
+        per_unit = {str(uu): {"positions": unit_stats[uu]["n_pos"], "sam_pairs": unit_stats[uu]["sam_line_pairs"], "hits": unit_stats[uu]["n_hits"],
+                              "upload_MB": round(unit_stats[uu]["upload_bytes"] / 1e6, 1), "hbm_MB": round(unit_stats[uu]["device_bytes"] / 1e6, 1),
+                              "ms_node_sweep": round(unit_stats[uu]["ms_node_sweep"], 3), "ms_download": round(unit_stats[uu]["ms_download"], 2),
+                              "ms_walk": round(unit_stats[uu]["ms_walk"], 2), "ms_upload_to_built": round(1e3 * unit_stats[uu]["s_upload_build"], 2),
+                              "ms_unit_total": round(1e3 * unit_stats[uu]["s_total"], 2), "download_MB": round(unit_stats[uu]["download_bytes"] / 1e6, 1),
+                              "build_attempts": unit_stats[uu]["build_attempts"], "spilled_ids": unit_stats[uu]["n_spilled"],
+                              "mid_tiles": unit_stats[uu]["n_mid_tiles"], "big_tiles": unit_stats[uu]["n_big_tiles"]} for uu in mine}
         line = {
             "metric": "aligned reads/sec through graph build+extend", "value": round(value, 1), "unit": "reads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic" if not share else "synthetic (AGX_BENCH_SHARE_GPU plumbing test: ranks share a GPU, gloo gather)",
-            "config": {"workload": "configs[1]: %.1f Mb unit (E. coli K-12 size), %d 2x%d bp pairs per GPU, k=%d, --coverage %d, synthetic target at 1%% SNP + 0.1%% indel"
-                       % (args.genome / 1e6, args.pairs, args.L, args.k, args.coverage) + (" [NON-STANDARD generator options: %s]" % os.environ["AGX_BENCH_SYNTH"] if extra else ""),
-                       "units_per_gpu": 1, "parallelism": "unit-sharded x%d, RCCL gather of extended contigs" % world},
-            "roofline": {"bound": "hbm", "kernel": {"node_sweep": "agx_k_node_sweep<0>" + (" + fallback passes <1>, <2>" if fallback else "")}.get(dom, "agx_k_" + dom), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": abytes,
-                         "kernel_ms": round(dom_ms, 4), "all_kernels_ms": round(all_kernel_ms, 4),
-                         "frac_all_kernels": round(abytes / (all_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if all_kernel_ms > 0 else None},
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * sec_per_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic" if not share else "synthetic (AGX_BENCH_SHARE_GPU plumbing test: ranks share a GPU, gloo gather)",
+            "config": {"workload": label + ", k=%d, --coverage %d, synthetic target at 1%% SNP + 0.1%% indel" % (k, args.coverage)
+                       + (" [NON-STANDARD generator options: %s]" % os.environ["AGX_BENCH_SYNTH"] if extra else ""),
+                       "name": args.config, "units": n_units, "unit_positions": unit_len,
+                       "timed_region": "T_core per step: every unit new to the device (upload + first build + download + host walk), %s memory pools" % args.pool,
+                       "units_in_flight_per_gpu": inflight,
+                       "parallelism": "units sharded longest-first over %d GPU%s, one RCCL gather of extended contigs per job" % (world, "" if world == 1 else "s")},
+            "t_core_s": round(sec_per_step, 4),
+            "t_unit_s": round(sec_per_step + t_parse_max, 4),
+            "t_unit_note": "t_core_s + text parsing and staging of the per-unit input files (slowest rank, units parsed one after another on up to 8 threads: %.2f s)" % t_parse_max,
+            "value_t_unit": round(reads_per_step / (sec_per_step + t_parse_max), 1),
+            "roofline": {"bound": "hbm", "kernel": "agx_k_node_sweep<0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "achieved_note": "SURVEY 8(d) model: algorithmic bytes of rank 0's units / HIP-event time of their node sweeps in the last timed step; NOT measured HBM bandwidth",
+                         "algorithmic_bytes": abytes, "kernel_ms": round(sw_ms, 4),
+                         "traffic": traffic, "achieved_hbm": round(hbm_rate, 1) if hbm_rate else None,
+                         "frac_hbm": round(hbm_rate / HBM_PEAK_GBS, 4) if hbm_rate else None,
+                         "traffic_note": "HBM bytes from the PMC counters (profiles/pmc_traffic.json: bytes per tile-list entry of the sweep, measured with rocprofv3 --pmc) x this run's list entries; achieved_hbm = traffic / kernel_ms"},
             "cpu_baseline": cpu,
-            "breakdown_ms": {k2: round(v, 3) for k2, v in kern.items()},
-            "breakdown_note": "ms_node_sweep, ms_download, ms_walk: means over the timed steps; the other sections and ms_build_span (first to last command of an exclusive build): 8 builds with section events after the timed region",
-            "pipeline_depth": args.pipeline, "serial_step_ms": round(serial_ms, 3), "host": numa_note,
-            "untimed_s": {"generate": round(t_gen, 2), "parse_text": round(t_parse, 2), "upload": round(t_upload, 3)},
-            "graph": {"positions": n_pos, "hits": st["n_hits"], "nodes": st["n_nodes"], "tile_entries": st["n_tile_entries"],
-                      "mid_tiles": st["n_mid_tiles"], "big_tiles": st["n_big_tiles"], "edge_overflow": st["n_edge_overflow"],
-                      "walk_ids": st["n_walk_ids"], "node_records_downloaded": st["n_special"], "node_records_fetched": st["n_fetched"],
-                      "download_MB": round(st["download_bytes"] / 1e6, 1)},
-            "output": {"extended_contigs": out["extended"].count(b">"), "extended_bytes": len(out["extended"]), "N50": n50},
+            "breakdown_ms_largest_unit": {k2: round(v, 3) for k2, v in kern.items()},
+            "breakdown_note": "largest unit of rank 0, exclusive builds with section events after the timed region (4 uploads + first builds); ms_resident_rebuild = r01's headline quantity (rebuild of a resident unit, kernels only)",
+            "units": per_unit,
+            "host": numa_note,
+            "untimed_s": {"generate": round(t_gen, 2), "parse_text": round(float(tot[1].item()), 2), "stage_of_which": round(float(tot[2].item()), 3)},
+            "sam_line_pairs": sam_pairs_total,
+            "output": {"extended_contigs": all_ext.count(b">"), "extended_bytes": len(all_ext), "N50": n50_of(all_ext)},
         }
+        if big_stats is not None:
+            line["graph_largest_unit"] = {"positions": big_stats["n_pos"], "hits": big_stats["n_hits"], "nodes": big_stats["n_nodes"], "tile_entries": big_stats["n_tile_entries"],
+                                          "walk_ids": big_stats["n_walk_ids"], "edge_overflow": big_stats["n_edge_overflow"]}
         print(json.dumps(line))
-    for u in units:
-        u.close()
-    if not args.keep:
+    for un in units.values():
+        un.close()
+    if not args.keep and rank == 0:
         import shutil
+        if dist:
+            dist.barrier()
         shutil.rmtree(run, ignore_errors=True)
-        if rank == 0:
-            shutil.rmtree(os.path.join(args.workdir, "cpu_sample"), ignore_errors=True)
-            shutil.rmtree(os.path.join(args.workdir, "cpu_sample.ref"), ignore_errors=True)
-    if dist:
+        shutil.rmtree(os.path.join(args.workdir, "cpu_sample"), ignore_errors=True)
+        shutil.rmtree(os.path.join(args.workdir, "cpu_sample.ref"), ignore_errors=True)
+    elif dist:
         dist.barrier()
+    if dist:
         dist.destroy_process_group()
 
 

@@ -71,7 +71,7 @@ typedef struct {
     uint16_t len;           /* read length; mates are equal length (AG:3454) */
     uint8_t rev1, rev2;     /* SAM FLAG 0x10 of each mate */
     uint8_t back;           /* number of earlier kept hits of the same pair */
-    uint8_t pad[3];
+    uint8_t pad[3];         /* ignored */
 } agx_hit;
 
 /* ContiMer (AG:51-62) inside a unit: the chromosome id is always 0 */
@@ -101,6 +101,12 @@ typedef struct {
     double ms_edge_fast, ms_edge_slow;                           /* the two kernels of ms_edge_sweep: pass A (lanes = positions), pass B (lanes = hits) */
     uint64_t n_mid_tiles;                                        /* tiles swept again with wider LDS buckets (n_big_tiles: of those, again with global scratch) */
     double ms_build_span;                                        /* with AGX_FLAG_TIME_SECTIONS: device time from the first to the last command of the build (all kernels and the gaps between them) */
+    double ms_stage;                                             /* packing the handed-over arrays into pinned upload buffers (agx_unit_stage) */
+    double ms_upload_dev;                                        /* with AGX_FLAG_TIME_SECTIONS: device time of the upload (copies + its two kernels) on the unit's stream */
+    uint64_t upload_bytes, device_bytes;                         /* bytes copied host -> HBM by the upload; HBM held by the unit */
+    uint64_t pinned_bytes_cached, device_bytes_cached;           /* free blocks in the library's pinned-host and device caches (agx_pool_trim releases them) */
+    uint64_t n_spilled;                                          /* node ids taken from the pool's spill area (regions whose slice was full) */
+    uint32_t build_attempts, pad_;                               /* 1 unless a capacity had to grow and the build was repeated */
 } agx_stats;
 
 /* Node/edge tables in canonical numbering (position-major, variant order), for parity tests. malloc'd; free with agx_graph_free. */
@@ -143,11 +149,15 @@ int agx_reads_open(const char *reads_fa, agx_reads **out, char *err, size_t err_
 void agx_reads_close(agx_reads *reads);
 int agx_unit_load_files_shared(agx_unit *u, const char *tmp_dir, int unit, const agx_reads *reads);   /* reads == NULL: same as agx_unit_load_files */
 
-int agx_unit_upload(agx_unit *u);                /* host -> HBM */
+int agx_unit_stage(agx_unit *u);                 /* packs what was handed over into pinned upload buffers (read bases as 4-bit classes); done by agx_unit_load_files,
+                                                    implied by agx_unit_upload after agx_unit_push_pairs */
+int agx_unit_upload(agx_unit *u);                /* staged arrays -> HBM: one device block, asynchronous copies; returns without waiting (the build waits on the device) */
 int agx_unit_build(agx_unit *u);                 /* kernels: updateGenomeWithRead/updateKMer (AG:1635-1870, 1353-1624) + filterLowCoverage (AG:1904-1918) */
 int agx_unit_download(agx_unit *u);              /* HBM -> pinned host memory (walk graph); implied by agx_unit_finish */
 int agx_unit_finish(agx_unit *u, agx_result *r); /* (download, then) extdContigs1/2 + scaffoldContigs (AG:1954-2464) on the host */
 void agx_result_free(agx_result *r);
+int agx_unit_release(agx_unit *u);               /* gives the unit's HBM and download buffers back to the library's caches; the staged inputs stay: upload again = a new unit */
+void agx_pool_trim(int device);                  /* frees the cached HBM blocks of a device (device >= 0) or the cached pinned host blocks (device < 0) */
 
 int agx_unit_stats(const agx_unit *u, agx_stats *s);
 int agx_unit_graph(agx_unit *u, agx_graph *g);   /* after agx_unit_build */

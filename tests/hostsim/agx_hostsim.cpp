@@ -60,8 +60,11 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     S.node_start.assign(n_pos, 0); S.node_cnt.assign(n_pos, 0); S.pos_succ.assign(n_pos, 0); S.side_pk.assign((size_t)n_pos + 1, 0); S.tile_side.assign((size_t)n_tiles + 1, 0);
     S.reserve((size_t)n_pos * 2 + 1024);
     agx_sweep_args A; memset(&A, 0, sizeof A);
-    std::vector<agx_u8> vcodes(P.bases.size());             // the engine translates its device copy of the read bases at upload
-    for (size_t i = 0; i < P.bases.size(); i++) vcodes[i] = agx_vote_code((agx_u8)P.bases[i]);
+    std::vector<agx_u8> vcodes(P.bases.size());             // the engine stages the read bases as packed classes and expands them on the device at upload
+    for (size_t i = 0; i + 1 < P.bases.size(); i += 2) {
+        const agx_u8 pk = agx_pack_classes((agx_u8)P.bases[i], (agx_u8)P.bases[i + 1]);
+        vcodes[i] = agx_class_vote_code(pk & 15u); vcodes[i + 1] = agx_class_vote_code(pk >> 4);
+    }
     std::vector<agx_cmhead> cmh((size_t)n_pos + 1);
     for (agx_u32 x = 0; x <= n_pos; x++) agx_cm_head_pos(T.cm_start.data(), cmk.data(), cmh.data(), x, n_pos);
     A.cm_start = T.cm_start.data(); A.cm = cmk.data(); A.cm_head = cmh.data(); A.ref = T.ref.data();

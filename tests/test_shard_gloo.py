@@ -1,5 +1,6 @@
 """The N>1 path on CPU: world_size-2 gloo processes shard units, compute them (the oracle stands in for the GPU build in this
-CPU-only test), and gather the per-unit extended contigs on rank 0 through aligngraph_amd.shard — the same code bench.py runs over RCCL."""
+CPU-only test), and gather the per-unit extended contigs on rank 0 through aligngraph_amd.shard.run_job — the very function bench.py
+--gpus N runs over RCCL with the HIP engine as run_unit."""
 import os
 import socket
 
@@ -20,10 +21,25 @@ def test_assign_units_is_lpt_and_deterministic():
 
 
 def test_pack_roundtrip():
-    assert shard.unit_header(7, 3) + b"abc" == shard.pack_units([7], [b"abc"])
     blob = shard.pack_units([3, 0], [b"abc", b""])
     assert shard.unpack_units(blob) == {3: b"abc", 0: b""}
     assert shard.unpack_units(shard.pack_units([], [])) == {}
+
+
+def test_plan_is_longest_first_within_the_rank():
+    sizes = [30, 20, 23, 19, 27]
+    plans = [shard.plan(sizes, r, 2) for r in range(2)]
+    assert sorted(u for pl in plans for u in pl) == list(range(5))
+    for pl in plans:
+        assert [sizes[u] for u in pl] == sorted((sizes[u] for u in pl), reverse=True)
+    assert shard.plan(sizes, 0, 1) == [0, 4, 2, 1, 3]                 # one GPU: all five, largest first (cfg3's order in bench.py)
+
+
+def test_run_job_single_rank_needs_no_process_group():
+    got = shard.run_job([3, 9, 5], 0, 1, lambda u: b"unit%d" % u, None, None, inflight=2)
+    assert got == {0: b"unit0", 1: b"unit1", 2: b"unit2"}
+    with pytest.raises(ZeroDivisionError):
+        shard.run_job([1, 2], 0, 1, lambda u: 1 // 0, None, None)
 
 
 def _worker(rank, world, port, run, meta, q):
@@ -32,31 +48,18 @@ def _worker(rank, world, port, run, meta, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    mine = shard.assign_units(meta["unit_len"], world)[rank]
-    blobs = [H.run_oracle(os.path.join(run, "tmp"), u, meta["k"], meta["insert_variation"], meta["coverage"])["extended"] for u in mine]
-    got = shard.gather_bytes(shard.pack_units(mine, blobs), dist, torch.device("cpu"), rank, world)
-    # the per-step variant bench.py uses: persistent buffers, growing capacity, several steps
-    g = shard.UnitGather(dist, torch.device("cpu"), rank, world)
-    steps = [g.step(shard.pack_units(mine[:n], blobs[:n])).payloads() for n in (0, len(mine), 1)]
-    # ... and the form that saves the host-side join: a short head in front of one unit's bytes
-    import numpy as np
-    headed = g.step(np.frombuffer(blobs[0], dtype=np.uint8), head=shard.unit_header(mine[0], len(blobs[0]))).payloads() if mine else g.step(b"", head=shard.pack_units([], [])).payloads()
+    ran = []
+
+    def run_unit(u):
+        ran.append(u)
+        return H.run_oracle(os.path.join(run, "tmp"), u, meta["k"], meta["insert_variation"], meta["coverage"])["extended"]
+
+    for job in range(2):                               # bench.py runs the job once per step
+        merged = shard.run_job(meta["unit_len"], rank, world, run_unit, dist, torch.device("cpu"), inflight=2)
+        assert sorted(ran[-len(shard.plan(meta["unit_len"], rank, world)):]) == sorted(shard.plan(meta["unit_len"], rank, world))
+        assert (merged is not None) == (rank == 0)
     if rank == 0:
-        merged = {}
-        for payload in got:
-            merged.update(shard.unpack_units(payload))
-        again = {}
-        for payload in steps[1]:
-            again.update(shard.unpack_units(payload))
-        assert again == merged and all(shard.unpack_units(p) == {} for p in steps[0])
-        assert sum(len(shard.unpack_units(p)) for p in steps[2]) == sum(1 for r in shard.assign_units(meta["unit_len"], world) if r)
-        firsts = {}
-        for payload in headed:
-            firsts.update(shard.unpack_units(payload))
-        assert firsts == {r[0]: merged[r[0]] for r in shard.assign_units(meta["unit_len"], world) if r}
         q.put(merged)
-    else:
-        assert steps == [None, None, None] and headed is None
     dist.barrier()
     dist.destroy_process_group()
 

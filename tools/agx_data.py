@@ -14,7 +14,7 @@ def build():
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     src = os.path.join(HERE, "agx_synth.cpp")
     if not os.path.exists(SYNTH) or os.path.getmtime(SYNTH) < os.path.getmtime(src):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", SYNTH, src])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", SYNTH, src])
 
 
 def synth(out, **kw):

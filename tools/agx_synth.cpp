@@ -23,7 +23,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include <sys/stat.h>
 
@@ -85,6 +89,10 @@ struct Params {
     int sam_seq = 1;  // write SEQ/QUAL columns like bowtie2 does
     int shuffle_units = 1;
     int e2e = 0;       // also write the user-level inputs of a fresh run: reads_1.fa, reads_2.fa and stub/ (what the aligner stubs replay)
+    // threads > 0: reads and SAM records are generated in chunks of 65536 pairs, each from its own generator seeded by (seed, chunk), on
+    // that many threads; the files are the same for every thread count, but differ from the ones the default single-stream mode writes
+    // (which the committed golden fixtures came from).  Large bench / test inputs use it; not with e2e.
+    int threads = 0;
 };
 
 void die(const char *m) { std::fprintf(stderr, "agx_synth: %s\n", m); std::exit(2); }
@@ -118,11 +126,13 @@ Params parse_args(int argc, char **argv) {
         OPT_D("--read-err", read_err) OPT_D("--read-indel", read_indel) OPT_D("--read-clip", read_clip)
         OPT_D("--read-badclip", read_badclip) OPT_D("--read-n", read_n)
         OPT_D("--multi", multi) OPT_D("--multi-near", multi_near) OPT_D("--unaligned", unaligned)
-        OPT_D("--mate1-left", mate1_left) OPT_I("--sam-seq", sam_seq) OPT_I("--shuffle-units", shuffle_units) OPT_I("--e2e", e2e)
+        OPT_D("--mate1-left", mate1_left) OPT_I("--sam-seq", sam_seq) OPT_I("--shuffle-units", shuffle_units) OPT_I("--e2e", e2e) OPT_I("--threads", threads)
         if (a == "--chroms") { P.chroms = parse_list(v); continue; }
         std::fprintf(stderr, "agx_synth: unknown option %s\n", a.c_str()); std::exit(2);
     }
     if (P.part < 1 || P.part > 10) die("--part must be 1..10");
+    if (P.threads > 0 && P.e2e) die("--threads is not available with --e2e");
+    if (P.threads > 256) P.threads = 256;
     return P;
 }
 
@@ -391,6 +401,100 @@ int main(int argc, char **argv) {
         std::fclose(cf); std::fclose(tc); std::fclose(chaff);
     }
 
+    // ---- reads + SAM, chunked mode (--threads) ----
+    if (P.threads > 0) {
+        const int64_t N = P.pairs, C = 65536, NC = (N + C - 1) / C;
+        const int L = P.L;
+        std::vector<double> cum(NU); { double tot = 0; for (auto l : unit_len) tot += (double)l; double a = 0; for (int u = 0; u < NU; u++) { a += (double)unit_len[u] / tot; cum[u] = a; } cum[NU - 1] = 2.0; }
+        struct Chunk { std::string reads; std::vector<std::string> sam; bool ready = false; };
+        std::vector<Chunk> chunks((size_t)NC);
+        std::atomic<int64_t> next_chunk(0);
+        std::mutex mu; std::condition_variable cv; int64_t written = 0;                 // chunks [0, written) are on disk; workers stay at most 4 * threads chunks ahead
+        auto make_chunk = [&](int64_t c) {
+            Chunk &K = chunks[(size_t)c]; K.sam.assign(NU, std::string());
+            uint64_t sd = P.seed * 0x9E3779B97F4A7C15ull + (uint64_t)(c + 1) * 0xD1B54A32D192ED03ull;
+            Rng R(sd);
+            char buf[512];
+            K.reads.reserve((size_t)C * (2 * L + 24));
+            for (int64_t id = c * C; id < std::min(N, (c + 1) * C); id++) {
+                const double pick = R.uni();
+                int u = 0; while (pick >= cum[u]) u++;
+                const Unit &U = units[u];
+                const int64_t T = (int64_t)U.tgt.size();
+                int64_t f = (int64_t)std::llround(P.frag_mean + P.frag_sd * R.normal());
+                if (f < L + 1) f = L + 1;
+                if (f > T) f = T;
+                const int64_t s0 = R.range(0, T - f);
+                Mate left = cut_read(U, s0, L, P, R), right = cut_read(U, s0 + f - L, L, P, R);
+                const bool m1_left = R.coin(P.mate1_left);
+                const std::string left_file = left.seq_fwd, right_file = revcomp(right.seq_fwd);
+                const std::string &m1 = m1_left ? left_file : right_file, &m2 = m1_left ? right_file : left_file;
+                int n = std::snprintf(buf, sizeof buf, ">%lld\n", (long long)id);
+                K.reads.append(buf, n); K.reads += m1; K.reads.push_back('\n'); K.reads.append(buf, n); K.reads += m2; K.reads.push_back('\n');
+                if (R.coin(P.unaligned)) continue;
+                int clipLl = 0, clipLr = 0, clipRl = 0, clipRr = 0;
+                if (R.coin(P.read_clip)) { (R.coin(0.5) ? clipLl : clipLr) = (int)R.range(1, 15); }
+                if (R.coin(P.read_clip)) { (R.coin(0.5) ? clipRl : clipRr) = (int)R.range(1, 15); }
+                if (R.coin(P.read_badclip)) { (R.coin(0.5) ? clipLr : clipRl) = (int)R.range(L * 45 / 100, L * 55 / 100); }
+                Aln al, ar;
+                if (!make_aln(left.r, clipLl, clipLr, al) || !make_aln(right.r, clipRl, clipRr, ar)) continue;
+                std::string qual; if (P.sam_seq) qual.assign(L, 'I');
+                auto emit = [&](bool secondary, const Aln &aL, const Aln &aR) {
+                    for (int m = 0; m < 2; m++) {
+                        const bool is_left = (m == 0) == m1_left;
+                        const int flag = 0x1 | 0x2 | (m == 0 ? 0x40 : 0x80) | (is_left ? 0x20 : 0x10) | (secondary ? 0x100 : 0);
+                        const Aln &A = is_left ? aL : aR, &B = is_left ? aR : aL;
+                        const long long tlen = is_left ? (long long)(aR.pos1 + L - aL.pos1) : -(long long)(aR.pos1 + L - aL.pos1);
+                        std::string &dst = K.sam[u];
+                        int w = std::snprintf(buf, sizeof buf, "%lld\t%d\t%d\t%lld\t42\t%s\t=\t%lld\t%lld\t", (long long)id, flag, u, (long long)A.pos1, A.cigar.c_str(), (long long)B.pos1, tlen);
+                        dst.append(buf, w);
+                        if (P.sam_seq) { dst += is_left ? left.seq_fwd : right.seq_fwd; dst.push_back('\t'); dst += qual; w = std::snprintf(buf, sizeof buf, "\tAS:i:%d\tYS:i:%d\tYT:Z:CP\n", 2 * L - 6, 2 * L - 4); dst.append(buf, w); }
+                        else dst += "*\t*\n";
+                    }
+                };
+                emit(false, al, ar);
+                if (R.coin(P.multi)) {
+                    const int64_t G = (int64_t)U.ref.size();
+                    Aln bl, br;
+                    const std::string allM = std::to_string(L) + "M";
+                    if (R.coin(P.multi_near)) {
+                        const int64_t d = R.range(-(L - 1), L - 1);
+                        bl.pos1 = std::max<int64_t>(1, al.pos1 + d); br.pos1 = std::max<int64_t>(1, ar.pos1 + d);
+                    } else {
+                        const int64_t w = R.range(1, std::max<int64_t>(1, G - f - 1));
+                        bl.pos1 = w; br.pos1 = w + f - L;
+                    }
+                    if (bl.pos1 + L <= G && br.pos1 + L <= G) { bl.cigar = br.cigar = allM; emit(true, bl, br); }
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < P.threads; t++) th.emplace_back([&] {
+            for (;;) {
+                const int64_t c = next_chunk.fetch_add(1);
+                if (c >= NC) return;
+                { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return c < written + 4 * (int64_t)P.threads; }); }
+                make_chunk(c);
+                { std::lock_guard<std::mutex> g(mu); chunks[(size_t)c].ready = true; }
+                cv.notify_all();
+            }
+        });
+        FILE *rf = open("tmp/_reads.fa");
+        std::vector<FILE *> sam(NU);
+        for (int u = 0; u < NU; u++) sam[u] = open("tmp/_reads_genome." + std::to_string(u) + ".bowtie");
+        for (int64_t c = 0; c < NC; c++) {
+            { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return chunks[(size_t)c].ready; }); }
+            Chunk &K = chunks[(size_t)c];
+            std::fwrite(K.reads.data(), 1, K.reads.size(), rf);
+            for (int u = 0; u < NU; u++) std::fwrite(K.sam[u].data(), 1, K.sam[u].size(), sam[u]);
+            std::string().swap(K.reads); std::vector<std::string>().swap(K.sam);
+            { std::lock_guard<std::mutex> g(mu); written = c + 1; }
+            cv.notify_all();
+        }
+        for (auto &t : th) t.join();
+        std::fclose(rf);
+        for (auto f : sam) std::fclose(f);
+    } else
     // ---- reads + SAM ----
     {
         int64_t N = P.pairs;
