@@ -132,7 +132,8 @@ def device_count():
 
 def pool_trim(device=0, host=True):
     """Frees what the library's memory caches hold: HBM blocks of `device` and (host=True) the pinned host blocks."""
-    lib().agx_pool_trim(device)
+    if device >= 0:
+        lib().agx_pool_trim(device)
     if host:
         lib().agx_pool_trim(-1)
 

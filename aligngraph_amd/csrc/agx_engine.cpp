@@ -112,7 +112,10 @@ namespace {
 // HIP-event time is that of an exclusive GPU; the other sections are timed in exclusive builds (AGX_FLAG_TIME_SECTIONS serialises the two
 // streams).  Uploads and copies to the host (counter words, download, record fetches) use the unit's own stream.
 struct DeviceTurn { std::mutex m; hipStream_t main = nullptr, front = nullptr; hipEvent_t sweep_done[2] = {nullptr, nullptr}, build_done[2] = {nullptr, nullptr};
-                    unsigned long long n = 0; bool prev_exclusive = false; hipEvent_t prev_node = nullptr; };      // n: builds queued so far; events alternate between two handles
+                    unsigned long long n = 0; bool prev_exclusive = false; hipEvent_t prev_node = nullptr;      // n: builds queued so far; events alternate between two handles
+                    // Uploads of a device go one after the other (each waits, on the device, for the one queued before it): PCIe is one pipe,
+                    // and five uploads that share it all finish late — first in, first built, and its host walk runs beside the uploads of the rest.
+                    std::mutex up_m; hipEvent_t up_done[2] = {nullptr, nullptr}; unsigned long long up_n = 0; };
 DeviceTurn &turn_of(int device) { static DeviceTurn turns[64]; return turns[device & 63]; }
 
 // AGX_TRACE_GAP=1: diagnostic for loops that rebuild long-lived units (see do_build)
@@ -121,8 +124,8 @@ static const bool g_trace_gap = getenv("AGX_TRACE_GAP") != nullptr;
 static const bool g_scan1 = getenv("AGX_SCAN_LEGACY") == nullptr;
 // AGX_DEBUG_SYNC=1: synchronise after every launch group of a build and name it on stderr — a memory fault then points at its kernel
 static const bool g_debug_sync = getenv("AGX_DEBUG_SYNC") != nullptr;
-// AGX_TEST_SMALL_CAPS=1 (tests): every capacity starts absurdly small, so that every regrow path runs
-static const bool g_tiny = getenv("AGX_TEST_SMALL_CAPS") != nullptr;
+// AGX_TEST_SMALL_CAPS=1 (tests; read at every upload): every capacity starts absurdly small, so that every regrow path runs
+#define g_tiny (getenv("AGX_TEST_SMALL_CAPS") != nullptr)
 #define AGX_CHECKPOINT(name) do { if (g_debug_sync) { hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, "[agx debug] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
 
 enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_RANKOVF = 6, W_MIDCOUNT = 7, W_JUMPCOUNT = 8, W_SPILL = 9, W_N = 10 };
@@ -272,9 +275,17 @@ void do_upload(agx_unit *u) {
     alloc_pool(u, pool_cap); alloc_lists(u, list_cap); alloc_ovf(u, ovf_cap); alloc_sparse(u, sp_cap);
     // copies
     hipStream_t st = u->st;
+    DeviceTurn &turn = turn_of(u->prm.device);
+    std::unique_lock<std::mutex> up_turn(turn.up_m);
+    for (auto &e : turn.up_done) if (!e) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (turn.up_n) HIP_OK(hipStreamWaitEvent(st, turn.up_done[(turn.up_n - 1) & 1], 0));
     u->up_timed = u->ev.all;
     if (u->up_timed) HIP_OK(hipEventRecord(u->ev_up0, st));
-    auto up = [&](void *dst, const void *src, size_t bytes) { if (bytes) HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); };
+    // (AGX_UP_CHUNK_MB: experiment knob — copies cut into pieces of that size, so that other streams' copies can get in between)
+    static const size_t chunk = getenv("AGX_UP_CHUNK_MB") ? (size_t)atoi(getenv("AGX_UP_CHUNK_MB")) << 20 : 0;
+    auto up = [&](void *dst, const void *src, size_t bytes) {
+        for (size_t at = 0; at < bytes;) { const size_t m = chunk ? std::min(chunk, bytes - at) : bytes; HIP_OK(hipMemcpyAsync((char *)dst + at, (const char *)src + at, m, hipMemcpyHostToDevice, st)); at += m; }
+    };
     up(u->d_cm_start.p, u->s_cm_start.p, (n_pos + 1) * 4); up(u->d_cm.p, u->s_cm.p, u->n_cm * sizeof(agx_cmkey)); up(u->d_ref.p, u->s_ref.p, n_pos);
     agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, (agx_u32)n_pos, st);
     up(u->d_hits.p, u->s_hits.p, nh * sizeof(agx_hit)); up(u->d_runs.p, u->s_runs.p, u->n_runs * sizeof(agx_run));
@@ -283,6 +294,8 @@ void do_upload(agx_unit *u) {
     agx_launch_expand_codes(u->d_codes.p, u->d_vcodes.p, (n_bases + 15) / 16 * 16, st);
     layout_regions(u, nullptr, pool_cap - spill_min(u), true);
     HIP_OK(hipEventRecord(u->ev_uploaded, st));
+    HIP_OK(hipEventRecord(turn.up_done[turn.up_n & 1], st)); turn.up_n++;
+    up_turn.unlock();
     u->uploaded = true; u->built = false; u->downloaded = false;
     u->stats.ms_upload = now_ms() - t0;
     u->stats.upload_bytes = (n_pos + 1) * 4 + u->n_cm * sizeof(agx_cmkey) + n_pos + nh * sizeof(agx_hit) + u->n_runs * sizeof(agx_run) + (size_t)u->n_chain_end * 4 + u->n_codes + ((size_t)u->n_regions + 1) * 4;
@@ -472,19 +485,30 @@ void do_download(agx_unit *u) {
     if (u->n_ovf) HIP_OK(hipMemcpyAsync(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf), hipMemcpyDeviceToHost, st));
     // While the larger copies run: the hop entry of every special id's position, in id order, next to where the walk will read the id's
     // record (the per-position table stays on the host: it is 12 bytes per position that the device would only gather and send back).
+    const double t1 = now_ms();
     HIP_OK(hipEventSynchronize(u->ev_dl));
+    const double t2 = now_ms();
     u->h_sp_hop.resize(ns + 1);
-    {
-        size_t at = 0; const agx_hop *hop = u->T.hop.data();
-        for (size_t w = 0; w < nw && at < ns; w++) {
-            for (unsigned long long bits = u->h_sp_bits.p[w]; bits && at < ns; bits &= bits - 1) {
-                const size_t a = w * 64 + (size_t)__builtin_ctzll(bits);
-                u->h_sp_hop[at++] = hop[a < n_pos ? a : u->h_side_xpos.p[a - n_pos]];
+    {   // (a few threads: one cache miss per special id into a table of 12 bytes per position; the rank array says where every word's entries go)
+        const agx_hop *hop = u->T.hop.data(); const unsigned long long *bits = u->h_sp_bits.p; const agx_u32 *rank = u->h_sp_rank.p, *side_x = u->h_side_xpos.p;
+        agx_hop *out = u->h_sp_hop.data();
+        const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(6u, std::max(1u, std::thread::hardware_concurrency())), ns / 65536 + 1);
+        std::vector<int> bad(threads, 0);
+        on_threads(threads, [&](unsigned t) {
+            for (size_t w = nw * t / threads, w1 = nw * (t + 1) / threads; w < w1; w++) {
+                size_t at = rank[w];
+                for (unsigned long long b = bits[w]; b; b &= b - 1) {
+                    if (at >= ns) { bad[t] = 1; return; }
+                    const size_t a = w * 64 + (size_t)__builtin_ctzll(b);
+                    out[at++] = hop[a < n_pos ? a : side_x[a - n_pos]];
+                }
             }
-        }
-        if (at != ns) throw Error{E_DEVICE, "special-id bitmap and record count disagree"};
+        });
+        for (int b : bad) if (b) throw Error{E_DEVICE, "special-id bitmap and record count disagree"};
     }
+    const double t3 = now_ms();
     HIP_OK(hipStreamSynchronize(st));
+    if (getenv("AGX_DL_TIMING")) fprintf(stderr, "[agx download] buffers %.2f ms, first copies %.2f ms, hop gather %.2f ms, rest of the copies %.2f ms (%zu ids, %zu records)\n", t1 - t0, t2 - t1, t3 - t2, now_ms() - t3, ni, ns);
     memset(u->h_a_meta.p + ni, 0, 64);
     u->stats.n_walk_ids = ni; u->stats.n_special = ns;
     u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * sizeof(agx_walknode) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);

@@ -26,11 +26,13 @@ def plan(unit_sizes, rank, world):
     return sorted(mine, key=lambda u: (-unit_sizes[u], u))
 
 
-def run_job(unit_sizes, rank, world, run_unit, dist, device, inflight=8, dst=0):
+def run_job(unit_sizes, rank, world, run_unit, dist, device, inflight=8, dst=0, start_unit=None):
     """One whole job the way bench.py --gpus N and the gloo test run it: this rank's units (plan) through run_unit(u) -> bytes on up to
     `inflight` worker threads that take the next unit as they finish one, then the path's ONLY exchange — one gather of every rank's
-    per-unit bytes to rank `dst` (north_star: "gather of extended contigs at the end").  Returns {unit: bytes} of ALL units
-    on dst, None elsewhere."""
+    per-unit bytes to rank `dst` (north_star: "gather of extended contigs at the end").  run_unit may return anything with
+    the buffer interface (bytes, a numpy uint8 view of C memory).  start_unit(u), if given, is called when a worker TAKES unit u, in plan
+    order and one at a time (bench.py queues the unit's upload there: uploads then reach the device largest unit first, whatever the
+    threads do next).  Returns {unit: bytes-like} of ALL units on dst, None elsewhere."""
     import threading
     mine = plan(unit_sizes, rank, world)
     out, errs = {}, []
@@ -41,6 +43,8 @@ def run_job(unit_sizes, rank, world, run_unit, dist, device, inflight=8, dst=0):
             while True:
                 with take:
                     u = next(nxt, None)
+                    if u is not None and start_unit is not None:
+                        start_unit(u)
                 if u is None:
                     return
                 out[u] = run_unit(u)
@@ -54,6 +58,8 @@ def run_job(unit_sizes, rank, world, run_unit, dist, device, inflight=8, dst=0):
         t.join()
     if errs:
         raise errs[0]
+    if dist is None or world == 1:
+        return out                                     # one rank: the outputs are where they are wanted already — nothing is copied
     got = gather_bytes(pack_units(mine, [out[u] for u in mine]), dist, device, rank, world, dst)
     if got is None:
         return None
@@ -76,8 +82,8 @@ def gather_bytes(payload, dist, device, rank, world, dst=0):
     sizes = [int(s.item()) for s in sizes]
     cap = max(max(sizes), 1)
     buf = torch.zeros(cap, dtype=torch.uint8, device=device)
-    if payload:
-        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    if len(payload):
+        buf[:len(payload)] = torch.frombuffer(payload if isinstance(payload, bytearray) else bytearray(payload), dtype=torch.uint8).to(device)
     outs = [torch.zeros(cap, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
     dist.gather(buf, outs, dst=dst)
     if rank != dst:
@@ -86,13 +92,13 @@ def gather_bytes(payload, dist, device, rank, world, dst=0):
 
 
 def pack_units(unit_ids, blobs):
-    """Length-prefixed concatenation of (unit id, bytes) so that one gather carries all units of a rank."""
+    """Length-prefixed concatenation of (unit id, bytes-like) so that one gather carries all units of a rank (one copy of the payload)."""
     import struct
     out = [struct.pack("<I", len(unit_ids))]
     for u, b in zip(unit_ids, blobs):
         out.append(struct.pack("<IQ", u, len(b)))
         out.append(b)
-    return b"".join(out)
+    return bytearray().join(out)
 
 
 def unpack_units(payload):
@@ -102,6 +108,6 @@ def unpack_units(payload):
     for _ in range(n):
         u, ln = struct.unpack_from("<IQ", payload, p)
         p += 12
-        out[u] = payload[p:p + ln]
+        out[u] = bytes(payload[p:p + ln])
         p += ln
     return out

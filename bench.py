@@ -6,8 +6,9 @@ new data): a "step" takes every unit of the configuration from its packed arrays
 host memory — upload (one HBM block per unit, PCIe copies), the unit's FIRST build (all kernels, capacities sized on the spot, a repeat
 if one proves too small), download of the walk graph, the sequential host walk/join/scaffold — with the units pipelined against each other
 on the device exactly as AlignGraph_amd pipelines them (a worker thread per unit in flight, largest unit first).  Every step starts from
-nothing on the device: with --pool cold (the default) the library's memory caches are emptied first, so every step pays its allocations
-like the first units of a fresh process do; the units' packed arrays stay staged in host memory between steps, as T_core defines.
+nothing on the device; the library's pinned-host cache is emptied first (--pool host-cold, the default), so every step maps, faults and
+registers its download buffers like the first units of a fresh process do (--pool cold also gives the HBM blocks back to the driver; see
+--help for why that is not the default); the units' packed arrays stay staged in host memory between steps, as T_core defines.
 
     value = 2 * pairs of the configuration / seconds per step            (whole job, all GPUs)
 
@@ -96,9 +97,12 @@ def main():
     ap.add_argument("--L", type=int, default=100)
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--coverage", type=int, default=5, help="--coverage of the run (the reference's default 20 is above the graph depth of these read sets: SURVEY §8d)")
-    ap.add_argument("--pool", default="cold", choices=["cold", "warm"],
-                    help="cold: the library's device and pinned-memory caches are emptied before every step (every step allocates like a fresh process); "
-                         "warm: they keep what earlier steps left (units 6, 7, .. of a long run)")
+    ap.add_argument("--pool", default="host-cold", choices=["cold", "host-cold", "warm"],
+                    help="what the library's memory caches hold when a step starts.  host-cold (default): the pinned-host cache is emptied before every "
+                         "step, so every step maps, faults and registers its download buffers like the first units of a fresh process; HBM blocks are "
+                         "kept (a fresh hipMalloc costs 0.2-0.7 ms per unit, profiles/r02_membench.txt — but HBM that was just given back to the "
+                         "driver can stall the next hipMalloc for seconds, profiles/r02_recycle.txt: an artefact of the loop, not of the application).  "
+                         "cold: both caches emptied.  warm: both keep what earlier steps left (units 6, 7, .. of a long run)")
     ap.add_argument("--inflight", type=int, default=0, help="units in flight per GPU = worker threads (0: all of the rank's units, at most 8)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=200000, help="pairs in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--workdir", default=os.environ.get("AGX_BENCH_DIR", "/tmp/agx_bench"))
@@ -154,7 +158,8 @@ def main():
     t0 = time.perf_counter()
     stamp = os.path.join(run, "synth_meta.txt")
     if rank == 0 and not os.path.exists(stamp):
-        D.synth(run, seed=1000, chroms=",".join(str(c) for c in chroms), part=part, pairs=pairs, L=L, k=k, coverage=args.coverage, sam_seq=0, **extra)
+        D.synth(run, seed=1000, chroms=",".join(str(c) for c in chroms), part=part, pairs=pairs, L=L, k=k, coverage=args.coverage, sam_seq=0,
+                threads=min(32, os.cpu_count() or 1), **extra)
     if dist:
         dist.barrier()
     t_gen = time.perf_counter() - t0
@@ -176,15 +181,14 @@ def main():
     my_pairs = sum(units[uu].stats()["sam_line_pairs"] for uu in mine)
 
     inflight = args.inflight or min(8, max(1, len(mine)))
-    unit_stats = {}
+    unit_stats, held, t_start = {}, {}, {}
 
     def run_unit(uu):
-        """One unit from its staged packed arrays to its output bytes: upload -> first build -> download -> walk -> release.  Runs on one of
+        """One unit from its staged packed arrays to its output bytes: (upload: start_unit) -> first build -> download -> walk -> release.  Runs on one of
         shard.run_job's worker threads (ctypes releases the interpreter lock, so the walks of several units run on several cores while
         libagx queues their kernel chains on the device's build streams)."""
         un = units[uu]
-        t_a = time.perf_counter()
-        un.upload()                        # HBM block + asynchronous PCIe copies + conti-mer heads, vote codes
+        t_a = t_start[uu]
         un.build()                         # hit prep, binning, node sweep (+ edges), edge passes, walk preparation: the unit's first build
         t_b = time.perf_counter()
         un.download()                      # walk graph -> pinned host memory
@@ -193,16 +197,25 @@ def main():
         st["s_upload_build"], st["s_total"] = t_b - t_a, time.perf_counter() - t_a
         un.release()                       # HBM and download buffers back to the library
         unit_stats[uu] = st
-        ext = res.bytes("extended")
-        res.free()
-        return ext
+        old, held[uu] = held.get(uu), res  # the outputs stay where agx_unit_finish left them (C memory): a view, no interpreter-lock-held copy
+        if old is not None:
+            old.free()
+        return res.view("extended")
+
+    def start_unit(uu):
+        """Called by shard.run_job when a worker takes the unit, in plan order: queues the upload (one HBM block, asynchronous PCIe copies,
+        conti-mer heads, vote codes) and returns — the uploads of a device run one after the other in this order."""
+        t_start[uu] = time.perf_counter()
+        units[uu].upload()
 
     def run_job():
         """One step: this rank's units (longest first) through run_unit on `inflight` worker threads, then the path's only exchange — one
         gather of the extended contigs to rank 0 (aligngraph_amd/shard.py: the function the world_size-2 gloo test drives)."""
         if args.pool == "cold":
             A.pool_trim(local_rank, host=True)
-        return shard.run_job(unit_len, rank, world, run_unit, dist, gdev, inflight=inflight)
+        elif args.pool == "host-cold":
+            A.pool_trim(-1, host=True)
+        return shard.run_job(unit_len, rank, world, run_unit, dist, gdev, inflight=inflight, start_unit=start_unit)
 
     for _ in range(args.warmup):
         run_job()
@@ -276,7 +289,7 @@ def main():
         cpu = {"value": round(val, 1), "unit": "reads/s", "cores": 1, "kind": kind, "sample": sample, "seconds": round(secs, 2)}
 
     if rank == 0:
-        outs = gathered
+        outs = {uu: bytes(v) for uu, v in gathered.items()}
         assert sorted(outs) == list(range(n_units)), "the gather did not deliver every unit"
         all_ext = b"".join(outs[uu] for uu in range(n_units))
         reads_per_step = 2.0 * pairs
@@ -340,6 +353,8 @@ def main():
             line["graph_largest_unit"] = {"positions": big_stats["n_pos"], "hits": big_stats["n_hits"], "nodes": big_stats["n_nodes"], "tile_entries": big_stats["n_tile_entries"],
                                           "walk_ids": big_stats["n_walk_ids"], "edge_overflow": big_stats["n_edge_overflow"]}
         print(json.dumps(line))
+    for r in held.values():
+        r.free()
     for un in units.values():
         un.close()
     if not args.keep and rank == 0:

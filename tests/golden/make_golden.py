@@ -31,7 +31,38 @@ CASES = {
     "multiunit": (dict(seed=14, chroms="16000,10000", part=2, pairs=6000, L=100, k=5, contig_min=500, contig_max=3000, sam_seq=0), [4]),
     "k21_L150": (dict(seed=15, chroms="20000", pairs=3000, L=150, k=21, insert_variation=30, contig_min=1000, contig_max=5000, read_indel=0.2,
                       read_clip=0.2, sam_seq=1), [5]),
+    # the SAME pairs as a forward-order twin, with the read ids reversed (pair i becomes pair N-1-i in tmp/_reads.fa and in
+    # the SAM): pins the first-come rule of a bucket's variants (AG:1381 vs 1386) — the stored keys of a node are those of the first
+    # read to arrive, and they reach the output headers.  main() checks that the reference's output really differs from the twin's.
+    "reversed": (dict(seed=16, chroms="20000", pairs=5000, L=100, k=5, contig_min=800, contig_max=4000, read_indel=0.2, read_clip=0.2,
+                      multi=0.2, frag_sd=60, sam_seq=0), [5]),
 }
+REVERSED = {"reversed"}
+
+
+def reverse_pair_order(run, units):
+    """Renumbers the pairs of a generated run N-1-i and rewrites tmp/_reads.fa and every unit's SAM in the new id order (the hits of one
+    pair keep their order: bowtie2 -k prints them best first)."""
+    tmp = os.path.join(run, "tmp")
+    recs = open(os.path.join(tmp, "_reads.fa")).read().split(">")[1:]
+    n = len(recs) // 2
+    with open(os.path.join(tmp, "_reads.fa"), "w") as f:
+        for new in range(n):
+            old = n - 1 - new
+            for m in (0, 1):
+                f.write(">%d\n%s\n" % (new, recs[2 * old + m].split("\n")[1]))
+    for u in range(units):
+        path = os.path.join(tmp, "_reads_genome.%d.bowtie" % u)
+        lines = open(path).read().split("\n")
+        lines = [ln for ln in lines if ln]
+        pairs = [(n - 1 - int(lines[i].split("\t")[0]), i) for i in range(0, len(lines), 2)]
+        pairs.sort()                                   # stable: the hits of one pair stay in their order
+        with open(path, "w") as f:
+            for new, i in pairs:
+                for ln in (lines[i], lines[i + 1]):
+                    t = ln.split("\t"); t[0] = str(new)
+                    f.write("\t".join(t) + "\n")
+
 
 INPUTS = ("_genome.%d.fa", "_contigs_genome.%d.psl", "_reads_genome.%d.bowtie")
 
@@ -41,8 +72,14 @@ def main():
     if not (H.have_reference(True) and H.have_reference(False)):
         raise SystemExit("oracle/_ref is not built (needs /root/reference)")
     for name, (kw, coverages) in CASES.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:          # regenerate only the named cases (a .tar.gz carries its creation time)
+            continue
         run = H.synth("/tmp/golden_" + name, coverage=coverages[0], **kw)
         meta = H.read_meta(run)
+        forward = None
+        if name in REVERSED:
+            forward, _ = H.run_reference(run, opt=True)
+            reverse_pair_order(run, meta["units"])
         expected = {}
         for cov in coverages:
             # coverage is read from tmp/_command.txt by --resume
@@ -55,6 +92,9 @@ def main():
             o0, _ = H.run_reference(run, opt=False)
             assert o2 == o0, "README build and -O2 build of the reference disagree on " + name
             expected[cov] = o2
+            if forward is not None:
+                assert o2 != forward, "reversing the read order does not change the reference's output: the fixture pins nothing"
+                print("   forward / reversed pre-extended records:", [o["pre"].count(b">") for o in forward], [o["pre"].count(b">") for o in o2])
             for u, o in enumerate(o2):
                 mine = H.run_oracle(os.path.join(run, "tmp"), u, meta["k"], meta["insert_variation"], cov)
                 assert all(mine[k] == o[k] for k in ("initial", "pre", "extended")), "oracle differs from the reference on %s unit %d" % (name, u)

@@ -1,0 +1,151 @@
+"""Parity at BASELINE.json's configuration sizes (-m gpu): the HIP engine through the C-ABI on
+
+  * configs[1] (E. coli shape, 4.6 Mb, exactly 1 000 000 pairs) and a 1 000 100-pair unit, against md5s of the REAL reference's output
+    files (tests/golden/big_md5.json, made by tests/golden/make_golden_big.py in the build container; the inputs are regenerated here
+    from the seed and their md5s are checked first);
+  * configs[2] (A. thaliana shape: 5 units, 119 Mb, 20 M pairs) at full size, every unit byte for byte against the oracle (five oracle
+    runs on five host threads beside the GPU work) — driven through the very job loop bench.py times (shard.run_job, pipelined units);
+  * one --part 4 slice of configs[3] (human chr1 shape: 62 Mb, 15 M pairs) at full size against the serial CPU executor of the kernels'
+    lane functions (tests/hostsim; the oracle needs minutes for it), plus rebuild determinism with every capacity started too small.
+
+AGX_SKIP_BIG=1 skips the two multi-minute cases.
+"""
+import hashlib
+import json
+import os
+import threading
+
+import pytest
+
+import harness as H
+
+pytestmark = pytest.mark.gpu
+BIG = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_md5.json")))
+THREADS = min(32, os.cpu_count() or 1)
+slow = pytest.mark.skipif(os.environ.get("AGX_SKIP_BIG") == "1", reason="AGX_SKIP_BIG=1")
+
+
+@pytest.fixture(scope="module")
+def agx():
+    import aligngraph_amd as A
+    if not os.path.exists(A.LIB_PATH):
+        from aligngraph_amd import build as B
+        B.build()
+    assert A.device_count() > 0, "no HIP device: the gpu tests must run on the MI355X box"
+    return A
+
+
+def md5_file(path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("case", sorted(BIG))
+def test_full_size_unit_matches_the_reference_md5(agx, case, built, tmp_path):
+    from golden import big_cases
+    e = BIG[case]
+    run = big_cases.generate(case, str(tmp_path / "run"))
+    tmp = os.path.join(run, "tmp")
+    for fn, want in e["inputs_md5"].items():
+        assert md5_file(os.path.join(tmp, fn)) == want, "the generator no longer reproduces %s of %s: regenerate tests/golden/big_md5.json" % (fn, case)
+    with agx.Unit(k=e["k"], insert_variation=e["insert_variation"], coverage=e["coverage"]) as u:
+        u.load_files(tmp, 0)
+        u.upload(); u.build()
+        got = u.finish()
+        st = u.stats()
+    for key, want in e["expected"].items():
+        assert len(got[key]) == want["bytes"] and hashlib.md5(got[key]).hexdigest() == want["md5"], "%s: %s differs from the reference binary's output" % (case, key)
+    assert st["build_attempts"] == 1, "a unit of this shape must not need a second build"
+    if case == "batch2":
+        assert st["pairs_in_file"] == 1000100 and st["n_hits"] < st["sam_line_pairs"]          # the second batch exists, and line pairs were dropped
+
+
+CFG3 = [30427671, 19698289, 23459830, 18585056, 26975502]          # = bench.py CONFIGS["cfg3"]
+
+
+@slow
+def test_cfg3_full_size_every_unit_matches_the_oracle(agx, built, tmp_path):
+    from aligngraph_amd import shard
+    run = H.synth(str(tmp_path / "run"), seed=1000, chroms=",".join(map(str, CFG3)), pairs=20000000, L=100, k=5, coverage=5, sam_seq=0, threads=THREADS)
+    tmp = os.path.join(run, "tmp")
+    meta = H.read_meta(run)
+    assert meta["unit_len"] == CFG3
+    want, errs = {}, []
+
+    def oracle(uu):
+        try:
+            want[uu] = H.run_oracle(tmp, uu, 5, 50, 5)
+        except BaseException as e:
+            errs.append(e)
+    checkers = [threading.Thread(target=oracle, args=(uu,)) for uu in range(5)]
+    for t in checkers:
+        t.start()
+    units, got, stats = {}, {}, {}
+    with agx.Reads(os.path.join(tmp, "_reads.fa")) as reads:
+        for uu in range(5):
+            units[uu] = agx.Unit(k=5, insert_variation=50, coverage=5)
+            units[uu].load_files(tmp, uu, reads=reads)
+
+    def start_unit(uu):                                # bench.py's start_unit / run_unit
+        units[uu].upload()
+
+    def run_unit(uu):
+        un = units[uu]
+        un.build(); un.download()
+        got[uu] = un.finish()
+        stats[uu] = un.stats()
+        un.release()
+        return got[uu]["extended"]
+    for job in range(2):                               # the second job runs on recycled memory blocks
+        out = shard.run_job(meta["unit_len"], 0, 1, run_unit, None, None, inflight=5, start_unit=start_unit)
+        assert sorted(out) == list(range(5))
+        if job == 0:
+            first = {uu: dict(got[uu]) for uu in range(5)}
+    for un in units.values():
+        un.close()
+    for t in checkers:
+        t.join()
+    assert not errs, errs
+    for uu in range(5):
+        for key in ("initial", "pre", "extended"):
+            assert first[uu][key] == want[uu][key], "unit %d: %s differs from the oracle" % (uu, key)
+            assert got[uu][key] == want[uu][key], "unit %d: %s differs from the oracle in the second job" % (uu, key)
+        assert stats[uu]["build_attempts"] == 1
+    assert sum(stats[uu]["sam_line_pairs"] for uu in range(5)) > 20000000          # 20 M pairs, 5 % of them with a second hit, 2 % unaligned
+
+
+@slow
+def test_cfg4_part_full_size_matches_the_serial_executor(agx, built, tmp_path, monkeypatch):
+    from hostsim import sim
+    n = 248956422 // 4                                 # one --part 4 slice of human chr1 (GRCh38 length): formalizeGenome's split rule, AG:3382-3413
+    run = H.synth(str(tmp_path / "run"), seed=1004, chroms=str(n), pairs=15000000, L=100, k=5, coverage=5, sam_seq=0, threads=THREADS)
+    tmp = os.path.join(run, "tmp")
+    want, errs = {}, []
+
+    def serial():
+        try:
+            want.update(sim.run(tmp, 0, k=5, insert_variation=50, coverage=5))
+        except BaseException as e:
+            errs.append(e)
+    t = threading.Thread(target=serial)
+    t.start()
+    with agx.Unit(k=5, insert_variation=50, coverage=5) as u:
+        u.load_files(tmp, 0)
+        u.upload(); u.build()
+        got = u.finish()
+        st = u.stats()
+        assert st["n_pos"] >= n and st["build_attempts"] == 1
+        monkeypatch.setenv("AGX_TEST_SMALL_CAPS", "1")          # every capacity far too small: tile lists, node pool, sparse table all regrow
+    with agx.Unit(k=5, insert_variation=50, coverage=5) as u2:
+        u2.load_files(tmp, 0)
+        u2.upload(); u2.build()
+        again = u2.finish()
+        assert u2.stats()["build_attempts"] > 1
+    t.join()
+    assert not errs, errs
+    for key in ("initial", "pre", "extended"):
+        assert got[key] == again[key], "%s differs between a first build and one whose capacities regrew" % key
+        assert got[key] == want[key], "%s differs from the serial executor" % key

@@ -103,6 +103,7 @@ def test_every_capacity_regrows_from_the_device_counters(agx, built, tmp_path, m
     for key in ("initial", "pre", "extended"):
         assert o[key] == g[key], key
     assert g["stats"]["n_edge_overflow"] > 4            # the overflow list really outgrew its first guess
+    assert g["stats"]["build_attempts"] >= 4            # tile lists, node pool, overflow list, sparse record table
 
 
 def test_run_unit_writes_the_three_files(agx, built, tmp_path):

@@ -9,8 +9,33 @@
 #include <thread>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-int main() {
+// recycle: what HBM costs when it goes back to the driver and comes out again (is freed memory wiped before it is handed out?)
+static void recycle() {
+    hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (size_t gb : {1, 8, 30}) {
+        const size_t n = gb << 30; void *a = nullptr, *b = nullptr;
+        double t0 = now(); CK(hipMalloc(&a, n)); double t1 = now();
+        CK(hipMemsetAsync(a, 1, n, st)); CK(hipStreamSynchronize(st)); double t2 = now();
+        CK(hipFree(a)); double t3 = now();
+        CK(hipMalloc(&b, n)); double t4 = now();
+        CK(hipMemsetAsync(b, 2, 256, st)); CK(hipStreamSynchronize(st)); double t5 = now();
+        CK(hipMemsetAsync(b, 2, n, st)); CK(hipStreamSynchronize(st)); double t6 = now();
+        CK(hipFree(b)); double t7 = now();
+        printf("%2zu GB: hipMalloc %.2f ms, fill %.2f, hipFree %.2f, hipMalloc again %.2f, first kernel on it %.2f, fill %.2f, hipFree %.2f\n", gb, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t7 - t6);
+    }
+    // five blocks from five threads, freed, and taken again at once (what bench.py --pool cold does between two steps)
+    for (int round = 0; round < 3; round++) {
+        void *p[5]; double t0 = now();
+        std::vector<std::thread> T; for (int i = 0; i < 5; i++) T.emplace_back([&, i] { CK(hipSetDevice(0)); CK(hipMalloc(&p[i], (size_t)6 << 30)); }); for (auto &x : T) x.join();
+        double t1 = now();
+        for (int i = 0; i < 5; i++) CK(hipMemsetAsync(p[i], 1, (size_t)6 << 30, st)); CK(hipStreamSynchronize(st)); double t2 = now();
+        for (int i = 0; i < 5; i++) CK(hipFree(p[i])); double t3 = now();
+        printf("round %d: 5 x hipMalloc(6 GB) on 5 threads %.2f ms, fill %.2f ms, 5 x hipFree %.2f ms\n", round, t1 - t0, t2 - t1, t3 - t2);
+    }
+}
+int main(int argc, char **argv) {
     CK(hipSetDevice(0)); CK(hipFree(0));
+    if (argc > 1 && !strcmp(argv[1], "recycle")) { recycle(); return 0; }
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (size_t mb : {1, 16, 64, 256, 1024, 4096}) {
         const size_t n = mb << 20;
