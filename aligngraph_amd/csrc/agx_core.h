@@ -281,6 +281,35 @@ AGX_HD void agx_cm_head_pos(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cm
     head[x] = n ? agx_cmhead{cm[s].cid, cm[s].coff, n, s} : agx_cmhead{AGX_NONE, AGX_NONE, 0u, s};
 }
 
+// ---- conti-mer threads as runs ------------------------------------------------------------------------------------------------
+// A contig placement threads one conti-mer per position along consecutive positions (AG:884-1217), with the contig offset moving in
+// step, until an indel makes it jump.  So the conti-mer tables cross PCIe as RUNS (40 bytes per run instead of 4 bytes per position and 8
+// per conti-mer): element j of a run is the rank-th conti-mer of position pos0 + j, (cid, coff0 + j * dcoff).  The runs also carry what
+// the walk needs when it leaves the k-mer graph at one of their positions (agx_hop): following the chain from element j appends
+// chain_str[hop_str0 + j, .. + hop_len0 - j) and lands on hop_end.  build_chains() (host) makes them; the device expands them at upload.
+struct agx_cmseg { agx_u32 pos0, len, cid, coff0, dcoff, rank, hop_str0, hop_len0, hop_end, elem0; };   // elem0: elements of all earlier runs
+
+// run that holds element e (runs in elem0 order)
+AGX_HD agx_u32 agx_seg_of_elem(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 e) {
+    agx_u32 lo = 0, hi = n_segs;                          // last run with elem0 <= e
+    while (hi - lo > 1) { const agx_u32 mid = lo + (hi - lo) / 2; if (segs[mid].elem0 <= e) lo = mid; else hi = mid; }
+    return lo;
+}
+struct agx_hop;
+// hop entry of position x from the runs: defined where x carries exactly one conti-mer (its run has rank 0; the first n_seg0 runs are the
+// rank-0 ones, sorted by pos0) that has a next
+template <class HOP> AGX_HD HOP agx_seg_hop(const agx_cmseg *segs, agx_u32 n_seg0, const agx_u32 *cm_start, agx_u32 x) {
+    HOP h; h.str_off = 0; h.len = 0; h.end_pos = 0;
+    if (n_seg0 == 0 || cm_start[x + 1] - cm_start[x] != 1) return h;
+    agx_u32 lo = 0, hi = n_seg0;                          // last rank-0 run with pos0 <= x
+    while (hi - lo > 1) { const agx_u32 mid = lo + (hi - lo) / 2; if (segs[mid].pos0 <= x) lo = mid; else hi = mid; }
+    const agx_cmseg g = segs[lo];
+    const agx_u32 j = x - g.pos0;
+    if (x < g.pos0 || j >= g.len || j >= g.hop_len0) return h;      // (j == hop_len0: the chain's last conti-mer, nothing to follow)
+    h.str_off = g.hop_str0 + j; h.len = g.hop_len0 - j; h.end_pos = g.hop_end;
+    return h;
+}
+
 // ---- node sweep: one lane = one position --------------------------------------------------------------------
 
 struct agx_sweep_args {
@@ -316,7 +345,15 @@ struct agx_sweep_args {
     agx_u32 *n_next;              // [pool*AGX_MAXE]
     int *n_counts;                // optional [pool*6] cov,A,C,G,T,N (parity/debug), may be null
     agx_u32 pool_cap;
+    agx_u32 *sweep_stats;         // profiling builds only (-DAGX_SWEEP_STATS): event counters of the node sweep, else null
 };
+
+// profiling hook of the node sweep: counts wavefronts in which some lane meets `cond` (slot i) and the lanes that do (slot i + 1)
+#if defined(AGX_SWEEP_STATS) && defined(__HIP_DEVICE_COMPILE__)
+#define AGX_STAT(A, i, cond) do { const unsigned long long m_ = __ballot(cond); if (m_ && (A).sweep_stats && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m_)) { atomicAdd((A).sweep_stats + (i), 1u); atomicAdd((A).sweep_stats + (i) + 1, (agx_u32)__popcll(m_)); } } while (0)
+#else
+#define AGX_STAT(A, i, cond) do { } while (0)
+#endif
 
 // What a read base votes for (updateKBases, AG:1340-1351, after reverseComplement, AG:854-865: only ACGT are complemented).
 // A stored character (file orientation) has one of five CLASSES: A, C, G, T = 0..3, anything else = 4; (c>>1)&3 maps A,C,T,G to
@@ -463,6 +500,10 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
         agx_bucket_add<LDS_ADD>(agx_b(b, 0, AGX_F_COV), fast & is_k1);
         agx_bucket_add<LDS_ADD>(agx_b(b, 0, vote ? vfield : (agx_u32)AGX_F_COV), vote);
         agx_u32 vm = fast, sp = fast & p.step1;                                     // the straight-line case touches variant 0
+        AGX_STAT(A, 0, true); AGX_STAT(A, 2, has != 0); AGX_STAT(A, 4, (has & (fast ^ 1u)) != 0);
+        AGX_STAT(A, 6, (has & (fast ^ 1u)) != 0 && !(cnt == 0 && cx_n <= 1 && c0_n <= 1));
+        AGX_STAT(A, 8, (has & (fast ^ 1u)) != 0 && cnt != 0 && cx_n <= 1 && c0_n <= 1 && v0_ok && !compat);      // one candidate, variant 0 exists and is not it
+        AGX_STAT(A, 10, (has & (fast ^ 1u)) != 0 && (cx_n > 1 || c0_n > 1));                                        // several candidate keys
         if (has & (fast ^ 1u)) {
             if (AGX_SWEEP_FIRST && cnt == 0 && cx_n <= 1 && c0_n <= 1) {
                 // The first arrival at a position with one candidate key — most of what leaves the fast path (7 % of the list entries on the
@@ -489,7 +530,7 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
     // the end of the list read its last record again and are masked out.
     if (lo == hi) return true;
     auto rec = [&](agx_u32 i) { return get(i < hi ? i : hi - 1); };
-    auto fetch = [&](const agx_dhit &d, bool valid, agx_pre &p) { agx_arrival_fetch(A, d, X, valid && live, p); };
+    auto fetch = [&](const agx_dhit &d, bool valid, agx_pre &p) { AGX_STAT(A, 12, valid && (d.a_nruns | d.b_nruns) != 0); agx_arrival_fetch(A, d, X, valid && live, p); };
     agx_pre pa, pb;
     { const agx_dhit d0 = rec(lo); fetch(d0, true, pa); }
     { const agx_dhit d1 = rec(lo + 1); fetch(d1, lo + 1 < hi, pb); }
@@ -774,6 +815,7 @@ struct agx_compact_args {
     agx_u32 n_ids, sparse_min;     // sparse_min (test hook): only the side ids are special, every other record comes through the fetch path
     unsigned long long *sp_bits; agx_u32 *sp_cnt; const agx_u32 *sp_rank; agx_walknode *sp_node;
     agx_u32 sp_cap;                        // records the sparse table can hold (the host grows it and repeats the build if there are more)
+    const agx_cmseg *segs; agx_u32 n_seg0; const agx_u32 *cm_start; agx_hop *sp_hop;   // device only: hop entries of the special ids' positions, from the runs
     const agx_u32 *abort;          // device only: the node sweeps' status word (non-zero: the node table is incomplete, the kernels do nothing)
 };
 

@@ -67,10 +67,10 @@ struct agx_unit {
     hipStream_t st = nullptr;
     DevArena arena;
     // staged inputs: what the device wants of T and P, in pinned memory (stage_inputs)
-    PBuf<agx_hit> s_hits; PBuf<agx_run> s_runs; PBuf<agx_u8> s_codes; PBuf<char> s_ref; PBuf<agx_u32> s_cm_start, s_chain_end, s_region_off; PBuf<agx_cmkey> s_cm;
+    PBuf<agx_hit> s_hits; PBuf<agx_run> s_runs; PBuf<agx_u8> s_codes; PBuf<char> s_ref; PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
     size_t nh = 0, n_runs = 0, n_cm = 0, n_codes = 0; agx_u32 maxlen = 0;      // n_codes: bytes of packed classes (two bases each)
     // inputs on the device
-    DBuf<agx_u32> d_cm_start; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref;
+    DBuf<agx_u32> d_cm_start, d_cm_cnt; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref; DBuf<agx_cmseg> d_segs; DBuf<unsigned long long> d_up_desc;
     DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<agx_u8> d_codes, d_vcodes;
     // derived
     DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_recs, d_scan_tmp, d_words; DBuf<unsigned long long> d_scan_desc; size_t scan_desc_n = 0;      // descriptors of the three one-launch scans   // d_words: counters/status
@@ -88,8 +88,7 @@ struct agx_unit {
     agx_u32 n_chain_end = 0, n_special = 0, n_words = 0;
     // downloaded: the walk graph with its sparse record table (agx_core.h); the full record table stays on the device
     PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
-    PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_edge_ovf> h_a_ovf;
-    std::vector<agx_hop> h_sp_hop;      // hop entries of the special ids' positions, gathered on the host from the per-position table
+    PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_edge_ovf> h_a_ovf; PBuf<agx_hop> h_sp_hop; DBuf<agx_hop> d_sp_hop;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
     Boundaries ev; hipEvent_t ev_front = nullptr, ev_passA = nullptr, ev_passJ = nullptr, ev_up0 = nullptr, ev_uploaded = nullptr, ev_dl = nullptr;
@@ -113,8 +112,10 @@ namespace {
 // streams).  Uploads and copies to the host (counter words, download, record fetches) use the unit's own stream.
 struct DeviceTurn { std::mutex m; hipStream_t main = nullptr, front = nullptr; hipEvent_t sweep_done[2] = {nullptr, nullptr}, build_done[2] = {nullptr, nullptr};
                     unsigned long long n = 0; bool prev_exclusive = false; hipEvent_t prev_node = nullptr;      // n: builds queued so far; events alternate between two handles
-                    // Uploads of a device go one after the other (each waits, on the device, for the one queued before it): PCIe is one pipe,
-                    // and five uploads that share it all finish late — first in, first built, and its host walk runs beside the uploads of the rest.
+                    // Uploads of a device go one after the other: PCIe is one pipe, and five uploads that share it all finish late — first in,
+                    // first built, and its host walk runs beside the uploads of the rest.  The wait for the previous upload is on the HOST:
+                    // a stream that waits for an event blocks the hardware queue it shares with other streams (a unit's download sat 20-40 ms
+                    // behind other units' streams that were waiting for their upload turn).
                     std::mutex up_m; hipEvent_t up_done[2] = {nullptr, nullptr}; unsigned long long up_n = 0; };
 DeviceTurn &turn_of(int device) { static DeviceTurn turns[64]; return turns[device & 63]; }
 
@@ -141,6 +142,7 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     S.n_xpos = u->d_xpos.p; S.n_base = u->d_base.p; S.n_flags = u->d_flags.p; S.n_sref = u->d_sref.p; S.n_next = u->d_next.p;
     S.n_counts = (u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? u->d_counts.p : nullptr;
     S.pool_cap = u->pool_cap;
+    S.sweep_stats = nullptr;
 }
 
 // ---- staging: the packed arrays a unit was handed, in the form and the memory the upload wants -------------------------------------
@@ -154,17 +156,19 @@ void stage_inputs(agx_unit *u) {
     if (n_pos == 0 || n_pos >= 0xFFFFFF00ull) throw Error{E_ARG, "unit sequence is empty or too long"};
     if (u->T.cm_start.size() != n_pos + 1) throw Error{E_ARG, "contig thread table does not match the position count"};
     if (u->T.hop.size() != n_pos) throw Error{E_ARG, "conti-mer chains were not built"};
+    { size_t el = 0; for (const agx_cmseg &g : u->T.segs) el += g.len; if (el != u->T.cm.size()) throw Error{E_ARG, "conti-mer runs were not built"}; }
     u->nh = u->P.hits.size(); u->n_runs = u->P.runs.size(); u->n_cm = u->T.cm.size();
     u->maxlen = 0; for (const agx_hit &h : u->P.hits) u->maxlen = std::max<agx_u32>(u->maxlen, h.len);
     if (u->P.stride & 15u) throw Error{E_ARG, "read stride must be a multiple of 16"};
     const size_t n_bases = u->P.bases.size();       // n_slots * stride
     u->n_codes = n_bases / 2;
     u->s_hits.alloc(u->nh + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16);
-    u->s_ref.alloc(n_pos); u->s_cm_start.alloc(n_pos + 1); u->s_cm.alloc(u->n_cm + 1);
+    u->s_ref.alloc(n_pos); u->n_segs = u->T.segs.size(); u->s_segs.alloc(u->n_segs + 1);
+    if (u->n_segs) memcpy(u->s_segs.p, u->T.segs.data(), u->n_segs * sizeof(agx_cmseg));
     std::vector<agx_u32> ce(u->T.chain_end_pos); std::sort(ce.begin(), ce.end()); ce.erase(std::unique(ce.begin(), ce.end()), ce.end());      // positions where a conti-mer chain
     u->n_chain_end = (agx_u32)ce.size(); u->s_chain_end.alloc(ce.size() + 1);                                                                 // ends: their main walk ids are special
     if (!ce.empty()) memcpy(u->s_chain_end.p, ce.data(), ce.size() * 4);
-    const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), (n_bases + n_pos * 16) / (8u << 20) + 1);
+    const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), (n_bases + n_pos) / (8u << 20) + 1);
     const char *bases = u->P.bases.data(); agx_u8 *codes = u->s_codes.p;
     on_threads(threads, [&](unsigned t) {
         auto part = [&](size_t n, size_t &lo, size_t &hi) { lo = n * t / threads; hi = n * (t + 1) / threads; };
@@ -173,8 +177,6 @@ void stage_inputs(agx_unit *u) {
         part(u->nh, lo, hi); if (hi > lo) memcpy(u->s_hits.p + lo, u->P.hits.data() + lo, (hi - lo) * sizeof(agx_hit));
         part(u->n_runs, lo, hi); if (hi > lo) memcpy(u->s_runs.p + lo, u->P.runs.data() + lo, (hi - lo) * sizeof(agx_run));
         part(n_pos, lo, hi); memcpy(u->s_ref.p + lo, u->T.ref.data() + lo, hi - lo);
-        part(n_pos + 1, lo, hi); memcpy(u->s_cm_start.p + lo, u->T.cm_start.data() + lo, (hi - lo) * 4);
-        part(u->n_cm, lo, hi); for (size_t i = lo; i < hi; i++) u->s_cm.p[i] = agx_cmkey{u->T.cm[i].cid, u->T.cm[i].coff};
     });
     u->staged = true; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0;
@@ -226,7 +228,7 @@ void alloc_pool(agx_unit *u, agx_u32 cap) {
 }
 void alloc_lists(agx_unit *u, agx_u32 cap) { u->list_cap = cap; u->d_unsorted.release(); u->d_unsorted.alloc(u->arena, (size_t)cap + 1); u->d_tile_recs.release(); u->d_tile_recs.alloc(u->arena, ((size_t)cap + 4) * 8); }
 void alloc_ovf(agx_unit *u, agx_u32 cap) { u->ovf_cap = cap; u->d_ovf.release(); u->d_ovf.alloc(u->arena, cap); u->d_a_ovf.release(); u->d_a_ovf.alloc(u->arena, (size_t)cap + 1); }
-void alloc_sparse(agx_unit *u, agx_u32 cap) { u->sp_cap = cap; u->d_sp_node.release(); u->d_sp_node.alloc(u->arena, (size_t)cap + 1); }
+void alloc_sparse(agx_unit *u, agx_u32 cap) { u->sp_cap = cap; u->d_sp_node.release(); u->d_sp_node.alloc(u->arena, (size_t)cap + 1); u->d_sp_hop.release(); u->d_sp_hop.alloc(u->arena, (size_t)cap + 2); }
 
 void do_release(agx_unit *u);
 
@@ -261,11 +263,12 @@ void do_upload(agx_unit *u) {
         u->arena.reserve(total + total / 64);
     }
     DevArena &a = u->arena;
-    u->d_cm_start.alloc(a, n_pos + 1); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos); u->d_cm_head.alloc(a, n_pos + 1);
+    u->d_cm_start.alloc(a, n_pos + 2); u->d_cm_cnt.alloc(a, n_pos + 2); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos); u->d_cm_head.alloc(a, n_pos + 1);
+    u->d_segs.alloc(a, u->n_segs + 1); u->d_up_desc.alloc(a, (n_pos + 2) / 4096 + 2);
     u->d_hits.alloc(a, nh + 1); u->d_runs.alloc(a, u->n_runs + 1); u->d_codes.alloc(a, u->n_codes + 16); u->d_vcodes.alloc(a, n_bases + 16);
     u->d_dhit.alloc(a, nh + 1); u->d_rank4.alloc(a, 4 * (nh + 1)); u->d_jump_list.alloc(a, nh + 1);
     u->d_tile_cnt.alloc(a, (size_t)u->n_tiles + 1); u->d_tile_off.alloc(a, (size_t)u->n_tiles + 2); u->d_cursor.alloc(a, (size_t)u->n_tiles + 1);
-    u->d_words.alloc(a, W_N + 6); u->h_words.alloc(W_N + 6);
+    u->d_words.alloc(a, W_N + 6 + 16); u->h_words.alloc(W_N + 6 + 16);
     u->d_chain_end.alloc(a, (size_t)u->n_chain_end + 1);
     u->d_node_start.alloc(a, n_pos); u->d_node_cnt.alloc(a, n_pos); u->d_pos_succ.alloc(a, n_pos); u->d_slow_list.alloc(a, n_pos + 64);
     u->d_side_pk.alloc(a, n_pos + 2); u->d_tile_side.alloc(a, (size_t)u->n_tiles + 2); u->d_tile_side_start.alloc(a, (size_t)u->n_tiles + 2);
@@ -278,7 +281,7 @@ void do_upload(agx_unit *u) {
     DeviceTurn &turn = turn_of(u->prm.device);
     std::unique_lock<std::mutex> up_turn(turn.up_m);
     for (auto &e : turn.up_done) if (!e) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (turn.up_n) HIP_OK(hipStreamWaitEvent(st, turn.up_done[(turn.up_n - 1) & 1], 0));
+    if (turn.up_n) HIP_OK(hipEventSynchronize(turn.up_done[(turn.up_n - 1) & 1]));
     u->up_timed = u->ev.all;
     if (u->up_timed) HIP_OK(hipEventRecord(u->ev_up0, st));
     // (AGX_UP_CHUNK_MB: experiment knob — copies cut into pieces of that size, so that other streams' copies can get in between)
@@ -286,7 +289,10 @@ void do_upload(agx_unit *u) {
     auto up = [&](void *dst, const void *src, size_t bytes) {
         for (size_t at = 0; at < bytes;) { const size_t m = chunk ? std::min(chunk, bytes - at) : bytes; HIP_OK(hipMemcpyAsync((char *)dst + at, (const char *)src + at, m, hipMemcpyHostToDevice, st)); at += m; }
     };
-    up(u->d_cm_start.p, u->s_cm_start.p, (n_pos + 1) * 4); up(u->d_cm.p, u->s_cm.p, u->n_cm * sizeof(agx_cmkey)); up(u->d_ref.p, u->s_ref.p, n_pos);
+    // conti-mer tables: their runs cross PCIe (agx_cmseg), the device expands them — count per position, scan, keys — and makes the heads
+    up(u->d_segs.p, u->s_segs.p, u->n_segs * sizeof(agx_cmseg)); up(u->d_ref.p, u->s_ref.p, n_pos);
+    HIP_OK(hipMemsetAsync(u->d_cm_cnt.p, 0, (n_pos + 2) * 4, st)); HIP_OK(hipMemsetAsync(u->d_up_desc.p, 0, ((n_pos + 2) / 4096 + 2) * 8, st));
+    agx_launch_seg_expand(u->d_segs.p, (agx_u32)u->n_segs, (agx_u32)u->n_cm, u->d_cm_cnt.p, u->d_cm_start.p, u->d_cm.p, (agx_u32)n_pos, u->d_up_desc.p, st);
     agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, (agx_u32)n_pos, st);
     up(u->d_hits.p, u->s_hits.p, nh * sizeof(agx_hit)); up(u->d_runs.p, u->s_runs.p, u->n_runs * sizeof(agx_run));
     up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);
@@ -298,7 +304,7 @@ void do_upload(agx_unit *u) {
     up_turn.unlock();
     u->uploaded = true; u->built = false; u->downloaded = false;
     u->stats.ms_upload = now_ms() - t0;
-    u->stats.upload_bytes = (n_pos + 1) * 4 + u->n_cm * sizeof(agx_cmkey) + n_pos + nh * sizeof(agx_hit) + u->n_runs * sizeof(agx_run) + (size_t)u->n_chain_end * 4 + u->n_codes + ((size_t)u->n_regions + 1) * 4;
+    u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + n_pos + nh * sizeof(agx_hit) + u->n_runs * sizeof(agx_run) + (size_t)u->n_chain_end * 4 + u->n_codes + ((size_t)u->n_regions + 1) * 4;
     u->stats.device_bytes = u->arena.capacity();
 }
 
@@ -315,6 +321,9 @@ void do_build(agx_unit *u) {
         if (attempt > 8) throw Error{E_DEVICE, "build did not converge"};
         const size_t ids_cap = (size_t)n_pos + u->pool_cap;                       // side variants <= nodes <= pool_cap
 
+        // The build streams are shared by all units of the device: nothing is queued on them that could wait long.  The unit's upload is
+        // awaited here, on the host, before the turn is taken.
+        HIP_OK(hipEventSynchronize(u->ev_uploaded));
         DeviceTurn &turn = turn_of(u->prm.device);
         std::unique_lock<std::mutex> my_turn(turn.m);
         if (!turn.main) {
@@ -324,13 +333,13 @@ void do_build(agx_unit *u) {
         }
         // ---- front (its own stream): may run beside the previous build's edge passes and walk preparation, not beside its sweep ----
         st = turn.front;
-        HIP_OK(hipStreamWaitEvent(st, u->ev_uploaded, 0));      // the unit's inputs (and a region layout that a retry re-cut) are in HBM
+        HIP_OK(hipStreamWaitEvent(st, u->ev_uploaded, 0));      // the unit's inputs (and a region layout that a retry re-cut) are in HBM (already: see below)
         if (turn.n) HIP_OK(hipStreamWaitEvent(st, (u->ev.all || turn.prev_exclusive) ? turn.build_done[(turn.n - 1) & 1] : turn.sweep_done[(turn.n - 1) & 1], 0));
         if (u->ev.all) HIP_OK(hipEventRecord(u->ev.first, st));      // (every event record costs the stream a few microseconds: untimed builds record only what orders them)
         {   // everything a build counts into or marks, zeroed by one kernel and one fill (every command on the stream costs a few microseconds)
             agx_zero_args Z; memset(&Z, 0, sizeof Z);
             auto seg = [&](int i, agx_u32 *ptr, size_t words) { Z.p[i] = ptr; Z.n[i] = (agx_u32)words; };
-            seg(0, u->d_words.p, W_N + 6); seg(1, u->d_tile_cnt.p, (size_t)u->n_tiles + 1); seg(2, u->d_cursor.p, (size_t)u->n_tiles + 1);
+            seg(0, u->d_words.p, W_N + 6 + 16); seg(1, u->d_tile_cnt.p, (size_t)u->n_tiles + 1); seg(2, u->d_cursor.p, (size_t)u->n_tiles + 1);
             seg(3, u->d_pool_cnt.p, (size_t)u->n_regions * AGX_REGION_PAD); seg(4, u->d_tile_side.p + u->n_tiles, 1); seg(5, u->d_sp_cnt.p + u->n_words, 1);
             seg(6, reinterpret_cast<agx_u32 *>(u->d_scan_desc.p), 6 * u->scan_desc_n);
             agx_launch_zero(&Z, st);
@@ -357,6 +366,9 @@ void do_build(agx_unit *u) {
         u->ev.mark(B_BIN, st);
         // ---- node sweep: every tile with small LDS buckets, then the tiles that overflowed with wider ones, then with global scratch (device-side lists) ----
         agx_node_kargs K; fill_sweep_args(u, K.S);
+#ifdef AGX_SWEEP_STATS
+        K.S.sweep_stats = u->d_words.p + W_N + 6;
+#endif
         K.pool_cnt = u->d_pool_cnt.p; K.region_off = u->d_region_off.p; K.spill_lo = u->spill_lo; K.spill_cnt = u->d_words.p + W_SPILL;
         K.mid_count = u->d_words.p + W_MIDCOUNT; K.mid_list = u->d_mid_list.p; K.mid_n = u->d_words.p + W_MIDCOUNT;
         K.big_count = u->d_words.p + W_BIGCOUNT; K.big_list = u->d_big_list.p; K.status = u->d_words.p + W_STATUS;
@@ -402,6 +414,7 @@ void do_build(agx_unit *u) {
         C.abort = u->d_words.p + W_STATUS;
         C.a_mark = u->d_a_mark.p; C.side_xpos = u->d_side_xpos.p; C.sparse_min = (u->prm.flags & AGX_FLAG_SPARSE_MIN) ? 1u : 0u;
         C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p; C.sp_cap = u->sp_cap;
+        C.segs = u->d_segs.p; C.n_seg0 = u->T.n_seg0; C.cm_start = u->d_cm_start.p; C.sp_hop = u->d_sp_hop.p;
         if (g_scan1) agx_launch_exclusive_scan1(u->d_tile_side.p, u->d_tile_side_start.p, u->n_tiles, u->d_scan_desc.p + u->scan_desc_n, st);
         else agx_launch_exclusive_scan(u->d_tile_side.p, u->d_tile_side_start.p, u->n_tiles, u->d_scan_tmp.p, st);      // per tile: the sweep has scanned inside the tiles
         agx_launch_compact(&C, u->d_chain_end.p, u->n_chain_end, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
@@ -419,7 +432,8 @@ void do_build(agx_unit *u) {
         HIP_OK(hipStreamWaitEvent(u->st, done, 0));
         turn.n++; turn.prev_exclusive = u->ev.all;
         my_turn.unlock();
-        HIP_OK(hipMemcpyAsync(u->h_words.p, u->d_words.p, (W_N + 6) * 4, hipMemcpyDeviceToHost, u->st));
+        {   void *dst = u->h_words.dev(); const void *src = u->d_words.p; const size_t bytes = (W_N + 6 + 16) * 4;      // (by a kernel: a copy command would queue behind
+            agx_launch_copy_out(&dst, &src, &bytes, 1, u->st); }                                                            // the uploads other units have waiting on the SDMA rings)
         HIP_OK(hipStreamSynchronize(u->st));
         HIP_OK(hipGetLastError());
         if (g_trace_gap && trace_from && trace_from != u->ev.e[B_NODE]) {      // diagnostic (units must outlive each other's builds): end of the previous sweep -> start of this one
@@ -452,6 +466,12 @@ void do_build(agx_unit *u) {
         if (ids >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "walk graph exceeds 2^32 ids"};
         u->n_ids = (agx_u32)ids; u->n_special = w[W_N + 2];
         u->stats.build_attempts = (uint32_t)attempt + 1; u->stats.n_spilled = w[W_SPILL];
+#ifdef AGX_SWEEP_STATS
+        {   const agx_u32 *c = w + W_N + 6;
+            fprintf(stderr, "[agx sweep stats] wave-entries %u (lanes with an arrival %u = %.1f per entry); leave the fast path: %u entries / %u lanes; of those not a first store: %u / %u; "
+                            "variant 0 incompatible: %u / %u; several candidate keys: %u / %u; entries with a multi-run record %u\n",
+                    c[0], c[3], c[0] ? (double)c[3] / c[0] : 0.0, c[4], c[5], c[6], c[7], c[8], c[9], c[10], c[11], c[12]); }
+#endif
         break;
     }
     u->built = true; u->downloaded = false;
@@ -469,49 +489,23 @@ void do_download(agx_unit *u) {
     hipStream_t st = u->st;
     const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
     u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(nside + 1);
-    u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1);
+    u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2);
     u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
-    if (ni) {
-        HIP_OK(hipMemcpyAsync(u->h_sp_bits.p, u->d_sp_bits.p, nw * 8, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_sp_rank.p, u->d_sp_rank.p, nw * 4, hipMemcpyDeviceToHost, st));
+    // a kernel stores the walk graph into the pinned buffers (agx_k_copy_out: copy commands would queue behind other units' uploads)
+    {
+        void *dst[8]; const void *src[8]; size_t bytes[8]; int n = 0;
+        auto add = [&](void *h, const void *d, size_t b) { if (b) { dst[n] = h; src[n] = d; bytes[n] = b; n++; } };
+        if (ni) { add(u->h_sp_bits.dev(), u->d_sp_bits.p, nw * 8); add(u->h_sp_rank.dev(), u->d_sp_rank.p, nw * 4); add(u->h_a_str.dev(), u->d_a_str.p, ni); add(u->h_a_meta.dev(), u->d_a_meta.p, ni); }
+        add(u->h_side_xpos.dev(), u->d_side_xpos.p, nside * 4);
+        add(u->h_sp_node.dev(), u->d_sp_node.p, ns * sizeof(agx_walknode)); add(u->h_sp_hop.dev(), u->d_sp_hop.p, ns * sizeof(agx_hop)); add(u->h_a_ovf.dev(), u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf));
+        agx_launch_copy_out(dst, src, bytes, n, st);
     }
-    if (nside) HIP_OK(hipMemcpyAsync(u->h_side_xpos.p, u->d_side_xpos.p, nside * 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipEventRecord(u->ev_dl, st));            // the special-id bitmap and the side ids' positions are on the host
-    if (ni) {
-        HIP_OK(hipMemcpyAsync(u->h_a_str.p, u->d_a_str.p, ni, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(u->h_a_meta.p, u->d_a_meta.p, ni, hipMemcpyDeviceToHost, st));
-    }
-    if (ns) HIP_OK(hipMemcpyAsync(u->h_sp_node.p, u->d_sp_node.p, ns * sizeof(agx_walknode), hipMemcpyDeviceToHost, st));
-    if (u->n_ovf) HIP_OK(hipMemcpyAsync(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf), hipMemcpyDeviceToHost, st));
-    // While the larger copies run: the hop entry of every special id's position, in id order, next to where the walk will read the id's
-    // record (the per-position table stays on the host: it is 12 bytes per position that the device would only gather and send back).
     const double t1 = now_ms();
-    HIP_OK(hipEventSynchronize(u->ev_dl));
-    const double t2 = now_ms();
-    u->h_sp_hop.resize(ns + 1);
-    {   // (a few threads: one cache miss per special id into a table of 12 bytes per position; the rank array says where every word's entries go)
-        const agx_hop *hop = u->T.hop.data(); const unsigned long long *bits = u->h_sp_bits.p; const agx_u32 *rank = u->h_sp_rank.p, *side_x = u->h_side_xpos.p;
-        agx_hop *out = u->h_sp_hop.data();
-        const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(6u, std::max(1u, std::thread::hardware_concurrency())), ns / 65536 + 1);
-        std::vector<int> bad(threads, 0);
-        on_threads(threads, [&](unsigned t) {
-            for (size_t w = nw * t / threads, w1 = nw * (t + 1) / threads; w < w1; w++) {
-                size_t at = rank[w];
-                for (unsigned long long b = bits[w]; b; b &= b - 1) {
-                    if (at >= ns) { bad[t] = 1; return; }
-                    const size_t a = w * 64 + (size_t)__builtin_ctzll(b);
-                    out[at++] = hop[a < n_pos ? a : side_x[a - n_pos]];
-                }
-            }
-        });
-        for (int b : bad) if (b) throw Error{E_DEVICE, "special-id bitmap and record count disagree"};
-    }
-    const double t3 = now_ms();
     HIP_OK(hipStreamSynchronize(st));
-    if (getenv("AGX_DL_TIMING")) fprintf(stderr, "[agx download] buffers %.2f ms, first copies %.2f ms, hop gather %.2f ms, rest of the copies %.2f ms (%zu ids, %zu records)\n", t1 - t0, t2 - t1, t3 - t2, now_ms() - t3, ni, ns);
+    if (getenv("AGX_DL_TIMING")) fprintf(stderr, "[agx download] buffers %.2f ms, copies %.2f ms (%zu ids, %zu records)\n", t1 - t0, now_ms() - t1, ni, ns);
     memset(u->h_a_meta.p + ni, 0, 64);
     u->stats.n_walk_ids = ni; u->stats.n_special = ns;
-    u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * sizeof(agx_walknode) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
+    u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
     u->downloaded = true;
     u->stats.ms_download = now_ms() - t0;
 }
@@ -524,11 +518,11 @@ void do_release(agx_unit *u) {
                     &u->d_slow_list, &u->d_rank4, &u->d_jump_list, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     for (auto *b : {&u->d_node_cnt, &u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
-    u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
+    u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_sp_hop.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
     u->d_ovf.release(); u->d_a_ovf.release(); u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
     u->arena.reset();
     u->h_a_str.release(); u->h_a_meta.release(); u->h_side_xpos.release(); u->h_sp_rank.release(); u->h_sp_bits.release(); u->h_sp_node.release(); u->h_fetch.release(); u->h_a_ovf.release();
-    std::vector<agx_hop>().swap(u->h_sp_hop);
+    u->h_sp_hop.release();
     u->pool_cap = u->spill_lo = u->ovf_cap = u->list_cap = u->sp_cap = 0;
     u->uploaded = u->built = u->downloaded = false;
 }
@@ -551,7 +545,7 @@ void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u
 GraphView view_of(agx_unit *u) {
     GraphView G; G.n_pos = (agx_u32)u->T.ref.size(); G.n_ids = u->n_ids;
     G.meta = u->h_a_meta.p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
-    G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.sp_hop = u->h_sp_hop.data(); G.n_special = u->n_special;
+    G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.sp_hop = u->h_sp_hop.p; G.n_special = u->n_special;
     G.fetch = fetch_records; G.fetch_ctx = u;
     G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf;
     return G;

@@ -32,6 +32,8 @@ struct Threads {
     std::string chain_str;
     // per-position hop table (agx_hop, agx_core.h)
     std::vector<agx_hop> hop;               // [n_pos]
+    // the same chains as runs (agx_cmseg): what the device gets instead of cm_start / cm / hop.  The first n_seg0 are the rank-0 runs, by position.
+    std::vector<agx_cmseg> segs; agx_u32 n_seg0 = 0;
 };
 void build_chains(Threads &T);
 

@@ -45,6 +45,7 @@ extern "C" {
 // one kernel that zeroes up to eight u32 ranges
 struct agx_zero_args { agx_u32 *p[8]; agx_u32 n[8]; };
 void agx_launch_zero(const agx_zero_args *, hipStream_t);
+void agx_launch_seg_expand(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 n_elems, agx_u32 *cnt, agx_u32 *cm_start, agx_cmkey *cm, agx_u32 n_pos, unsigned long long *desc, hipStream_t);      // runs -> cm_start[n_pos + 1], cm
 void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t);      // n_pos + 1 heads
 void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16, hipStream_t);      // packed base classes (agx_pack_classes) -> agx_vote_code bytes; n_bases16 a multiple of 16
 void agx_launch_hit_prep(const agx_prep_args *, hipStream_t);
@@ -61,6 +62,7 @@ void agx_launch_edge_slow(const agx_edge_kargs *, hipStream_t);           // pas
 // walk preparation (agx_core.h): after the scan of the side counts the node sweep left behind: ids, records and overflow edges
 // n_nodes / n_ovf are read from device memory (the node-pool and overflow counters), so no host round trip separates the sweeps
 // from the walk preparation; the grids are sized by the capacities.
+void agx_launch_copy_out(void *const *dst, const void *const *src, const size_t *bytes, int n, hipStream_t);      // HBM -> registered host memory, by a kernel
 void agx_launch_fetch_records(const agx_compact_args *, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *out, hipStream_t);
 void agx_launch_compact(const agx_compact_args *, const agx_u32 *chain_end, agx_u32 n_chain_end, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t);
 // special ids: bitmap, rank scan (desc: the one-launch scan; null: the three-launch one with scan_tmp), records; block 0 of the last kernel also leaves the

@@ -26,7 +26,22 @@ static_assert(AGX_MAXV_LDS <= AGX_EM_W && AGX_MAXV_MID <= AGX_EM_W, "the LDS swe
 // every kernel behind the sweeps first looks at the status word the sweeps leave on the device and does nothing if it is set.
 #define AGX_RETURN_IF_ABORTED(word) do { if (__builtin_amdgcn_readfirstlane((int)*(word)) != 0) return; } while (0)
 
-// ---- upload time: per-position head of the conti-mer table ---------------------------------------------------------
+// ---- upload time: the conti-mer tables from their runs (agx_cmseg), then the per-position heads -----------------------------------
+// one thread per conti-mer: cnt[x] = highest rank + 1 (the ranks of a position are 0 .. count - 1); after the scan of cnt, the keys
+__global__ void __launch_bounds__(256) agx_k_seg_count(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 n_elems, agx_u32 *cnt) {
+    const agx_u32 e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= n_elems) return;
+    const agx_cmseg g = segs[agx_seg_of_elem(segs, n_segs, e)];
+    atomicMax(&cnt[g.pos0 + (e - g.elem0)], g.rank + 1u);
+}
+__global__ void __launch_bounds__(256) agx_k_seg_fill(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 n_elems, const agx_u32 *cm_start, agx_cmkey *cm) {
+    const agx_u32 e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= n_elems) return;
+    const agx_cmseg g = segs[agx_seg_of_elem(segs, n_segs, e)];
+    const agx_u32 j = e - g.elem0;
+    cm[cm_start[g.pos0 + j] + g.rank] = agx_cmkey{g.cid, g.coff0 + j * g.dcoff};
+}
+
 __global__ void __launch_bounds__(256) agx_k_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos) {
     const agx_u32 x = blockIdx.x * 256u + threadIdx.x;
     if (x <= n_pos) agx_cm_head_pos(cm_start, cm, head, x, n_pos);
@@ -487,6 +502,7 @@ __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, ag
         const agx_u32 at = A.sp_rank[w] + (agx_u32)__popcll(bits & ((1ull << lane) - 1ull));
         if (at >= A.sp_cap) return;                                           // table too small: the host sees the count and repeats the build
         A.sp_node[at] = agx_walk_record(A, a);
+        A.sp_hop[at] = agx_seg_hop<agx_hop>(A.segs, A.n_seg0, A.cm_start, a < A.n_pos ? a : A.side_xpos[a - A.n_pos]);
     }
 }
 
@@ -497,9 +513,27 @@ __global__ void __launch_bounds__(256) agx_k_fetch_records(agx_compact_args A, a
     out[i] = agx_walk_record(A, first + (i / width) * stride + i % width);
 }
 
+// ---- download: HBM -> pinned host memory by a kernel -----------------------------------------------------------------------
+// Copies queued with hipMemcpyAsync go through the SDMA rings in the order they were queued, on whatever stream: a unit's download sat
+// behind the UPLOADS other units had already queued (and which were themselves waiting for their turn) for 20-40 ms.  A kernel that stores
+// straight into the registered host buffers has no such queue: up to four (dst, src, 16-byte words) segments per launch.
+typedef agx_u32 agx_v4 __attribute__((ext_vector_type(4)));
+struct agx_copy_args { agx_v4 *dst[4]; const agx_v4 *src[4]; unsigned long long n16[4]; };
+__global__ void __launch_bounds__(256) agx_k_copy_out(agx_copy_args C) {
+    for (int s = 0; s < 4; s++)
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < C.n16[s]; i += (unsigned long long)gridDim.x * 256u)
+            __builtin_nontemporal_store(__builtin_nontemporal_load(&C.src[s][i]), &C.dst[s][i]);
+}
+
 // ---- host-callable launchers (kept in this translation unit so that the engine is plain C++) -------------------------
 extern "C" {
 
+// cnt: [n_pos + 1] zeroed; desc: the one-launch scan's zeroed descriptors (ceil((n_pos + 2) / 4096) words)
+void agx_launch_seg_expand(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 n_elems, agx_u32 *cnt, agx_u32 *cm_start, agx_cmkey *cm, agx_u32 n_pos, unsigned long long *desc, hipStream_t st) {
+    if (n_elems) hipLaunchKernelGGL(agx_k_seg_count, dim3((n_elems + 255) / 256), dim3(256), 0, st, segs, n_segs, n_elems, cnt);
+    agx_launch_exclusive_scan1(cnt, cm_start, n_pos, desc, st);
+    if (n_elems) hipLaunchKernelGGL(agx_k_seg_fill, dim3((n_elems + 255) / 256), dim3(256), 0, st, segs, n_segs, n_elems, cm_start, cm);
+}
 void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t st) {
     hipLaunchKernelGGL(agx_k_cm_head, dim3(n_pos / 256 + 1), dim3(256), 0, st, cm_start, cm, head, n_pos);
 }
@@ -579,6 +613,16 @@ void agx_launch_edge_slow(const agx_edge_kargs *K, hipStream_t st) {
     if (K->S.n_tiles) hipLaunchKernelGGL(agx_k_edge_slow, dim3((unsigned)blocks), dim3(256), 0, st, *K);
 }
 
+// dst: device-visible addresses of pinned host buffers; bytes are rounded up to 16 (the buffers are padded)
+void agx_launch_copy_out(void *const *dst, const void *const *src, const size_t *bytes, int n, hipStream_t st) {
+    for (int at = 0; at < n; at += 4) {
+        agx_copy_args C; unsigned long long total = 0;
+        for (int s = 0; s < 4; s++) { const bool on = at + s < n; C.dst[s] = on ? (agx_v4 *)dst[at + s] : nullptr; C.src[s] = on ? (const agx_v4 *)src[at + s] : nullptr; C.n16[s] = on ? (bytes[at + s] + 15) / 16 : 0; total += C.n16[s]; }
+        if (!total) continue;
+        const unsigned long long want = (total + 256ull * 8 - 1) / (256ull * 8);       // ~8 words per thread
+        hipLaunchKernelGGL(agx_k_copy_out, dim3((unsigned)(want < 1 ? 1 : want > 512 ? 512 : want)), dim3(256), 0, st, C);
+    }
+}
 void agx_launch_fetch_records(const agx_compact_args *A, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *out, hipStream_t st) {
     const agx_u32 n = rows * width;
     if (n) hipLaunchKernelGGL(agx_k_fetch_records, dim3((n + 255) / 256), dim3(256), 0, st, *A, first, stride, rows, width, out);

@@ -102,7 +102,7 @@ inline MemBlock host_block(size_t need) {
     void *p = mmap(nullptr, need, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (p == MAP_FAILED) throw Error{E_ARG, "out of host memory"};
     (void)madvise(p, need, MADV_HUGEPAGE);
-    hipError_t e = hipHostRegister(p, need, hipHostRegisterDefault);
+    hipError_t e = hipHostRegister(p, need, hipHostRegisterPortable | hipHostRegisterMapped);
     if (e != hipSuccess) { (void)hipGetLastError(); munmap(p, need); throw Error{E_DEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e)}; }
     return MemBlock{p, need};
 }
@@ -117,6 +117,7 @@ template <class T> struct PBuf {            // pinned host buffer: one cached bl
         blk = host_block(count * sizeof(T)); p = (T *)blk.p; n = blk.n / sizeof(T);
     }
     void release() { host_cache().give(blk); blk = MemBlock(); p = nullptr; n = 0; }
+    void *dev() const { void *d = nullptr; if (p) AGX_HIP_OK(hipHostGetDevicePointer(&d, p, 0)); return d; }      // the address kernels use for this buffer
     ~PBuf() { release(); }
     PBuf() = default; PBuf(const PBuf &) = delete; PBuf &operator=(const PBuf &) = delete;
 };

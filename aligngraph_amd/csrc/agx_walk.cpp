@@ -427,24 +427,40 @@ void build_chains(Threads &T) {
     // followed; length and landing position are filled in when its end is known.
     std::vector<agx_u32> pending;                        // positions of this chain whose hop entry waits for the chain's end
     size_t visited = 0;
+    T.segs.clear(); T.n_seg0 = 0;
     for (size_t x = 0; x < n_pos; x++) for (size_t h = T.cm_start[x]; h < T.cm_start[x + 1]; h++) {
         if (state[h]) continue;                          // linked to (or, never true here, visited): not a head
         pending.clear();
         size_t c = h; agx_u32 pos = (agx_u32)x;
-        for (;;) {
+        const size_t seg_first = T.segs.size(), str_base = T.chain_str.size();
+        for (agx_u32 i = 0;; i++) {
             if (state[c] == 2) throw Error{E_ARG, "conti-mer chains are not simple lists"};
             state[c] = 2; visited++;
             T.chain_str.push_back(T.cm[c].nuc);
             const ContiMer &m = T.cm[c];
+            {   // the chain as runs (agx_cmseg): extend the open run or start one.  hop_len0 holds the element's index until the chain's end is known
+                const agx_u32 rank = (agx_u32)(c - T.cm_start[pos]);
+                agx_cmseg *g = T.segs.size() > seg_first ? &T.segs.back() : nullptr;
+                const bool joins = g && pos == g->pos0 + g->len && rank == g->rank && m.cid == g->cid && (g->len == 1 || m.coff == g->coff0 + g->len * g->dcoff);
+                if (joins) { if (g->len == 1) g->dcoff = m.coff - g->coff0; g->len++; }
+                else T.segs.push_back(agx_cmseg{pos, 1u, m.cid, m.coff, 0u, rank, (agx_u32)(str_base + i + 1), i, 0u, 0u});
+            }
             if (m.next_off == AGX_NONE) break;
             if (T.cm_start[pos + 1] - T.cm_start[pos] == 1) { T.hop[pos].str_off = (agx_u32)T.chain_str.size(); pending.push_back(pos); }     // (the next conti-mer's base is pushed next)
             c = index_of(m.next_off, m.next_item); pos = m.next_off;
         }
         if (T.chain_str.size() >= 0xFFFFFFFFull) throw Error{E_ARG, "conti-mer chains exceed 2^32 bases"};
         for (agx_u32 p : pending) { T.hop[p].len = (agx_u32)(T.chain_str.size() - T.hop[p].str_off); T.hop[p].end_pos = pos; }
+        {   const agx_u32 last = (agx_u32)(T.chain_str.size() - str_base - 1);       // index of the chain's last conti-mer
+            for (size_t g = seg_first; g < T.segs.size(); g++) { T.segs[g].hop_len0 = last - T.segs[g].hop_len0; T.segs[g].hop_end = pos; } }
         T.chain_end_pos.push_back(pos); T.chain_off.push_back(T.chain_str.size());
     }
     if (visited != n) throw Error{E_ARG, "conti-mer cycle"};
+    // rank-0 runs first, by position (the device finds the run of a position by bisection); then elem0 = running element count
+    std::stable_sort(T.segs.begin(), T.segs.end(), [](const agx_cmseg &a, const agx_cmseg &b) { return (a.rank != 0) != (b.rank != 0) ? a.rank == 0 : (a.rank == 0 && a.pos0 < b.pos0); });
+    agx_u32 e = 0;
+    for (agx_cmseg &g : T.segs) { g.elem0 = e; e += g.len; if (g.rank == 0) T.n_seg0++; }
+    if (e != n) throw Error{E_ARG, "conti-mer runs do not cover the conti-mers"};
 }
 
 void walk_join_scaffold(const Threads &T, const Pairs &P, const GraphView &G, UnitOutput &out) {

@@ -54,8 +54,23 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     for (agx_u32 t = 0; t < n_tiles; t++) { tile_off[t] = (agx_u32)tile_hits.size(); tile_hits.insert(tile_hits.end(), lists[t].begin(), lists[t].end()); }
     tile_off[n_tiles] = (agx_u32)tile_hits.size();
 
+    // The engine uploads the conti-mer tables as runs (agx_cmseg) and expands them on the device: count = highest rank + 1 per position,
+    // scan, fill (agx_k_seg_count / agx_k_seg_fill).  The same element functions here; the result must be the loader's tables, and the hop
+    // entries derived from the runs must be the loader's too.
     std::vector<agx_cmkey> cmk(T.cm.size());
-    for (size_t i = 0; i < T.cm.size(); i++) cmk[i] = agx_cmkey{T.cm[i].cid, T.cm[i].coff};
+    {
+        std::vector<agx_u32> cnt((size_t)n_pos + 1, 0), start((size_t)n_pos + 1, 0);
+        const agx_u32 n_el = (agx_u32)T.cm.size(), ns = (agx_u32)T.segs.size();
+        for (agx_u32 e = 0; e < n_el; e++) { const agx_cmseg &g = T.segs[agx_seg_of_elem(T.segs.data(), ns, e)]; const agx_u32 x = g.pos0 + (e - g.elem0); if (x >= n_pos) throw Error{E_ARG, "conti-mer run beyond the positions"}; cnt[x] = std::max(cnt[x], g.rank + 1); }
+        agx_u32 acc = 0; for (agx_u32 x = 0; x <= n_pos; x++) { start[x] = acc; acc += cnt[x]; }
+        if (start != T.cm_start) throw Error{E_ARG, "conti-mer runs: cm_start differs"};
+        for (agx_u32 e = 0; e < n_el; e++) { const agx_cmseg &g = T.segs[agx_seg_of_elem(T.segs.data(), ns, e)]; const agx_u32 j = e - g.elem0; cmk[start[g.pos0 + j] + g.rank] = agx_cmkey{g.cid, g.coff0 + j * g.dcoff}; }
+        for (size_t i = 0; i < T.cm.size(); i++) if (cmk[i].cid != T.cm[i].cid || cmk[i].coff != T.cm[i].coff) throw Error{E_ARG, "conti-mer runs: keys differ"};
+        for (agx_u32 x = 0; x < n_pos; x++) {
+            const agx_hop h = agx_seg_hop<agx_hop>(T.segs.data(), T.n_seg0, T.cm_start.data(), x);
+            if (h.len != T.hop[x].len || (h.len && (h.str_off != T.hop[x].str_off || h.end_pos != T.hop[x].end_pos))) throw Error{E_ARG, "conti-mer runs: hop entries differ"};
+        }
+    }
 
     S.node_start.assign(n_pos, 0); S.node_cnt.assign(n_pos, 0); S.pos_succ.assign(n_pos, 0); S.side_pk.assign((size_t)n_pos + 1, 0); S.tile_side.assign((size_t)n_tiles + 1, 0);
     S.reserve((size_t)n_pos * 2 + 1024);
