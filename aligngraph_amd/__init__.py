@@ -130,11 +130,14 @@ def device_count():
     return lib().agx_device_count()
 
 
-def pool_trim(device=0, host=True):
-    """Frees what the library's memory caches hold: HBM blocks of `device` and (host=True) the pinned host blocks."""
+def pool_trim(device=0, host=True, retire_host=False):
+    """Frees what the library's memory caches hold: HBM blocks of `device` (>= 0) and (host=True) the pinned host blocks.  retire_host: the
+    cached pinned blocks are only taken out of circulation (later allocations map and register fresh memory); a pool_trim(host=True) unmaps them."""
     if device >= 0:
         lib().agx_pool_trim(device)
-    if host:
+    if retire_host:
+        lib().agx_pool_trim(-2)
+    elif host:
         lib().agx_pool_trim(-1)
 
 

@@ -219,8 +219,30 @@ AGX_HD bool agx_hit_dup(const agx_hit *hits, const agx_run *runs, agx_u32 h) {
     return false;
 }
 
-// returns 0 ok, 1 = same-strand mates ("BOWTIE ALIGNMENT ERROR", AG:1667-1671)
-AGX_HD int agx_hit_prep(const agx_hit &H, bool dup, const agx_run *runs, agx_u32 k, agx_dhit &d) {
+// Which mate is the LEFT one ("a": the mate whose aligned indices emit the events, AG:1644, 1672-1679)?  true = mate2: some read index below
+// L - k is aligned in both mates with mate1's position beyond mate2's.  Decided where the arrays are packed (the engine's staging): only
+// the a mate's bases are ever read by the build, so only they cross PCIe, in one row per (pair, a mate) — the staged hit carries the
+// row in slot1 and this verdict in pad[0].
+AGX_HD bool agx_hit_left_is_mate2(const agx_hit &H, const agx_run *runs, agx_u32 k) {
+    const agx_u32 L = H.len;
+    if (L <= k) return false;
+    const agx_u32 lim = L - k;
+    const agx_u32 n1 = H.nruns1 ? H.nruns1 : 1u, n2 = H.nruns2 ? H.nruns2 : 1u;
+    for (agx_u32 i = 0; i < n1; i++) {
+        const agx_run r1 = H.nruns1 ? runs[H.runs1 + i] : agx_run{0u, H.pos1, L};
+        for (agx_u32 j = 0; j < n2; j++) {
+            const agx_run r2 = H.nruns2 ? runs[H.runs2 + j] : agx_run{0u, H.pos2, L};
+            agx_u32 lo = r1.q > r2.q ? r1.q : r2.q, hi1 = r1.q + r1.n, hi2 = r2.q + r2.n;
+            agx_u32 hi = hi1 < hi2 ? hi1 : hi2; if (hi > lim) hi = lim;
+            if (lo < hi && (r1.t + (lo - r1.q)) > (r2.t + (lo - r2.q))) return true;   // difference is constant on the overlap
+        }
+    }
+    return false;
+}
+
+// returns 0 ok, 1 = same-strand mates ("BOWTIE ALIGNMENT ERROR", AG:1667-1671).  swap: agx_hit_left_is_mate2; a_slot: where the a mate's
+// bases are (the device: the staged row; the test executor: the read slot)
+AGX_HD int agx_hit_prep(const agx_hit &H, bool dup, bool swap, agx_u32 a_slot, const agx_run *runs, agx_u32 k, agx_dhit &d) {
     d.flags = 0; d.len = H.len; d.jstar = 0xFFFF; d.x_lo = 1; d.x_hi = 0;
     d.a_t0 = d.b_t0 = d.a_runs = d.b_runs = d.a_slot = 0; d.a_nruns = d.b_nruns = 0;
     if (dup) { d.flags = AGX_HF_SKIP; return 0; }
@@ -228,26 +250,13 @@ AGX_HD int agx_hit_prep(const agx_hit &H, bool dup, const agx_run *runs, agx_u32
     const agx_u32 L = H.len;
     if (L <= k) { d.flags = AGX_HF_SKIP; return 0; }
     const agx_u32 lim = L - k;
-    // swap so that "a" is the left mate: some index < lim aligned in both mates with pos1 > pos2 (AG:1672-1679)
-    bool swap = false;
-    {
-        const agx_u32 n1 = H.nruns1 ? H.nruns1 : 1u, n2 = H.nruns2 ? H.nruns2 : 1u;
-        for (agx_u32 i = 0; i < n1 && !swap; i++) {
-            const agx_run r1 = H.nruns1 ? runs[H.runs1 + i] : agx_run{0u, H.pos1, L};
-            for (agx_u32 j = 0; j < n2; j++) {
-                const agx_run r2 = H.nruns2 ? runs[H.runs2 + j] : agx_run{0u, H.pos2, L};
-                agx_u32 lo = r1.q > r2.q ? r1.q : r2.q, hi1 = r1.q + r1.n, hi2 = r2.q + r2.n;
-                agx_u32 hi = hi1 < hi2 ? hi1 : hi2; if (hi > lim) hi = lim;
-                if (lo < hi && (r1.t + (lo - r1.q)) > (r2.t + (lo - r2.q))) { swap = true; break; }   // difference is constant on the overlap
-            }
-        }
-    }
+    d.a_slot = a_slot;
     if (!swap) {
         d.a_t0 = H.pos1; d.b_t0 = H.pos2; d.a_runs = H.runs1; d.b_runs = H.runs2; d.a_nruns = H.nruns1; d.b_nruns = H.nruns2;
-        d.a_slot = H.slot1; if (H.rev1) d.flags |= AGX_HF_AREV;
+        if (H.rev1) d.flags |= AGX_HF_AREV;
     } else {
         d.a_t0 = H.pos2; d.b_t0 = H.pos1; d.a_runs = H.runs2; d.b_runs = H.runs1; d.a_nruns = H.nruns2; d.b_nruns = H.nruns1;
-        d.a_slot = H.slot1 + 1; if (H.rev2) d.flags |= AGX_HF_AREV;
+        if (H.rev2) d.flags |= AGX_HF_AREV;
     }
     // arrival span and the K2ONLY index.  Sources are the aligned indices below cut = min(lim, last aligned index);
     // jstar = first aligned index >= cut (a read whose last aligned index is below lim ends there, e.g. a trailing soft clip)

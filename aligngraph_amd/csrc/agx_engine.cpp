@@ -35,6 +35,13 @@ namespace {
 #define HIP_OK(expr) AGX_HIP_OK(expr)
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// AGX_TRACE=1: one stderr line per stage of every unit with host times (ms since the first line): who waited for whom in a pipelined job
+static const bool g_trace = getenv("AGX_TRACE") != nullptr;
+void trace(const void *unit, const char *what, double from_ms, size_t n_pos) {
+    if (!g_trace) return;
+    static const double t00 = now_ms();
+    fprintf(stderr, "[agx trace] unit %p (%zu pos) %-22s %9.2f -> %9.2f ms\n", unit, n_pos, what, from_ms - t00, now_ms() - t00);
+}
 
 // Section boundaries of a build on the unit's stream: the end of one section is the start of the next (one record instead of two: an
 // event record costs the stream about as much as a small kernel).
@@ -69,6 +76,7 @@ struct agx_unit {
     // staged inputs: what the device wants of T and P, in pinned memory (stage_inputs)
     PBuf<agx_hit> s_hits; PBuf<agx_run> s_runs; PBuf<agx_u8> s_codes; PBuf<char> s_ref; PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
     size_t nh = 0, n_runs = 0, n_cm = 0, n_codes = 0; agx_u32 maxlen = 0;      // n_codes: bytes of packed classes (two bases each)
+    std::vector<agx_u32> row_slot;      // staged read bases: one row per (pair, a mate) that some hit uses; row -> read slot
     // inputs on the device
     DBuf<agx_u32> d_cm_start, d_cm_cnt; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref; DBuf<agx_cmseg> d_segs; DBuf<unsigned long long> d_up_desc;
     DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<agx_u8> d_codes, d_vcodes;
@@ -160,23 +168,46 @@ void stage_inputs(agx_unit *u) {
     u->nh = u->P.hits.size(); u->n_runs = u->P.runs.size(); u->n_cm = u->T.cm.size();
     u->maxlen = 0; for (const agx_hit &h : u->P.hits) u->maxlen = std::max<agx_u32>(u->maxlen, h.len);
     if (u->P.stride & 15u) throw Error{E_ARG, "read stride must be a multiple of 16"};
-    const size_t n_bases = u->P.bases.size();       // n_slots * stride
-    u->n_codes = n_bases / 2;
-    u->s_hits.alloc(u->nh + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16);
+    u->s_hits.alloc(u->nh + 1); u->s_runs.alloc(u->n_runs + 1);
     u->s_ref.alloc(n_pos); u->n_segs = u->T.segs.size(); u->s_segs.alloc(u->n_segs + 1);
     if (u->n_segs) memcpy(u->s_segs.p, u->T.segs.data(), u->n_segs * sizeof(agx_cmseg));
     std::vector<agx_u32> ce(u->T.chain_end_pos); std::sort(ce.begin(), ce.end()); ce.erase(std::unique(ce.begin(), ce.end()), ce.end());      // positions where a conti-mer chain
     u->n_chain_end = (agx_u32)ce.size(); u->s_chain_end.alloc(ce.size() + 1);                                                                 // ends: their main walk ids are special
     if (!ce.empty()) memcpy(u->s_chain_end.p, ce.data(), ce.size() * 4);
-    const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), (n_bases + n_pos) / (8u << 20) + 1);
+    const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), (u->P.bases.size() + n_pos) / (8u << 20) + 1);
+    // Hits: as they are, except that slot1 becomes the ROW of the a mate's bases and pad[0] says which mate that is (agx_hit_left_is_mate2).
+    // Only the a mate's bases are read by the build (the right mate only supplies positions, AG:1644): one row per (pair, a mate), first come.
+    const agx_run *runs = u->P.runs.data(); const agx_u32 k = u->prm.k;
+    on_threads(threads, [&](unsigned t) {
+        for (size_t i = u->nh * t / threads, hi = u->nh * (t + 1) / threads; i < hi; i++) {
+            agx_hit h = u->P.hits[i];
+            h.pad[0] = agx_hit_left_is_mate2(h, runs, k) ? 1 : 0; h.pad[1] = h.pad[2] = 0;
+            u->s_hits.p[i] = h;
+        }
+        size_t lo, hi;
+        lo = u->n_runs * t / threads; hi = u->n_runs * (t + 1) / threads; if (hi > lo) memcpy(u->s_runs.p + lo, runs + lo, (hi - lo) * sizeof(agx_run));
+        lo = n_pos * t / threads; hi = n_pos * (t + 1) / threads; memcpy(u->s_ref.p + lo, u->T.ref.data() + lo, hi - lo);
+    });
+    {
+        std::vector<agx_u32> row_of((size_t)u->P.n_slots + 1, AGX_NONE);
+        u->row_slot.clear(); u->row_slot.reserve(u->P.n_slots / 2 + 16);
+        for (size_t i = 0; i < u->nh; i++) {
+            agx_hit &h = u->s_hits.p[i];
+            const agx_u32 sa = h.slot1 + (h.pad[0] & 1u);
+            if (sa >= u->P.n_slots) throw Error{E_ARG, "hit names a read slot outside the unit"};
+            if (row_of[sa] == AGX_NONE) { row_of[sa] = (agx_u32)u->row_slot.size(); u->row_slot.push_back(sa); }
+            h.slot1 = row_of[sa];
+        }
+    }
+    const size_t half = u->P.stride / 2, n_rows = u->row_slot.size();
+    u->n_codes = n_rows * half;
+    u->s_codes.alloc(u->n_codes + 16);
     const char *bases = u->P.bases.data(); agx_u8 *codes = u->s_codes.p;
     on_threads(threads, [&](unsigned t) {
-        auto part = [&](size_t n, size_t &lo, size_t &hi) { lo = n * t / threads; hi = n * (t + 1) / threads; };
-        size_t lo, hi;
-        part(u->n_codes, lo, hi); for (size_t i = lo; i < hi; i++) codes[i] = agx_pack_classes((agx_u8)bases[2 * i], (agx_u8)bases[2 * i + 1]);
-        part(u->nh, lo, hi); if (hi > lo) memcpy(u->s_hits.p + lo, u->P.hits.data() + lo, (hi - lo) * sizeof(agx_hit));
-        part(u->n_runs, lo, hi); if (hi > lo) memcpy(u->s_runs.p + lo, u->P.runs.data() + lo, (hi - lo) * sizeof(agx_run));
-        part(n_pos, lo, hi); memcpy(u->s_ref.p + lo, u->T.ref.data() + lo, hi - lo);
+        for (size_t r = n_rows * t / threads, hi = n_rows * (t + 1) / threads; r < hi; r++) {
+            const char *src = bases + (size_t)u->row_slot[r] * u->P.stride; agx_u8 *dst = codes + r * half;
+            for (size_t j = 0; j < half; j++) dst[j] = agx_pack_classes((agx_u8)src[2 * j], (agx_u8)src[2 * j + 1]);
+        }
     });
     u->staged = true; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0;
@@ -279,9 +310,13 @@ void do_upload(agx_unit *u) {
     // copies
     hipStream_t st = u->st;
     DeviceTurn &turn = turn_of(u->prm.device);
+    trace(u, "upload: allocate", t0, n_pos);
+    const double tw = now_ms();
     std::unique_lock<std::mutex> up_turn(turn.up_m);
     for (auto &e : turn.up_done) if (!e) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (turn.up_n) HIP_OK(hipEventSynchronize(turn.up_done[(turn.up_n - 1) & 1]));
+    trace(u, "upload: wait for turn", tw, n_pos);
+    const double tq = now_ms();
     u->up_timed = u->ev.all;
     if (u->up_timed) HIP_OK(hipEventRecord(u->ev_up0, st));
     // (AGX_UP_CHUNK_MB: experiment knob — copies cut into pieces of that size, so that other streams' copies can get in between)
@@ -302,6 +337,7 @@ void do_upload(agx_unit *u) {
     HIP_OK(hipEventRecord(u->ev_uploaded, st));
     HIP_OK(hipEventRecord(turn.up_done[turn.up_n & 1], st)); turn.up_n++;
     up_turn.unlock();
+    trace(u, "upload: queue copies", tq, n_pos);
     u->uploaded = true; u->built = false; u->downloaded = false;
     u->stats.ms_upload = now_ms() - t0;
     u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + n_pos + nh * sizeof(agx_hit) + u->n_runs * sizeof(agx_run) + (size_t)u->n_chain_end * 4 + u->n_codes + ((size_t)u->n_regions + 1) * 4;
@@ -323,7 +359,10 @@ void do_build(agx_unit *u) {
 
         // The build streams are shared by all units of the device: nothing is queued on them that could wait long.  The unit's upload is
         // awaited here, on the host, before the turn is taken.
+        const double tb0 = now_ms();
         HIP_OK(hipEventSynchronize(u->ev_uploaded));
+        trace(u, "build: wait for upload", tb0, n_pos);
+        const double tb1 = now_ms();
         DeviceTurn &turn = turn_of(u->prm.device);
         std::unique_lock<std::mutex> my_turn(turn.m);
         if (!turn.main) {
@@ -432,9 +471,12 @@ void do_build(agx_unit *u) {
         HIP_OK(hipStreamWaitEvent(u->st, done, 0));
         turn.n++; turn.prev_exclusive = u->ev.all;
         my_turn.unlock();
+        trace(u, "build: queue kernels", tb1, n_pos);
+        const double tb2 = now_ms();
         {   void *dst = u->h_words.dev(); const void *src = u->d_words.p; const size_t bytes = (W_N + 6 + 16) * 4;      // (by a kernel: a copy command would queue behind
             agx_launch_copy_out(&dst, &src, &bytes, 1, u->st); }                                                            // the uploads other units have waiting on the SDMA rings)
         HIP_OK(hipStreamSynchronize(u->st));
+        trace(u, "build: wait for kernels", tb2, n_pos);
         HIP_OK(hipGetLastError());
         if (g_trace_gap && trace_from && trace_from != u->ev.e[B_NODE]) {      // diagnostic (units must outlive each other's builds): end of the previous sweep -> start of this one
             float f = 0; if (hipEventElapsedTime(&f, trace_from, u->ev.e[B_BIN]) == hipSuccess) fprintf(stderr, "[agx gap] %.3f ms between sweeps, %.3f ms sweep\n", f, u->ev.ms(B_NODE)); else (void)hipGetLastError(); }
@@ -508,11 +550,14 @@ void do_download(agx_unit *u) {
     u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
     u->downloaded = true;
     u->stats.ms_download = now_ms() - t0;
+    trace(u, "download", t0, n_pos);
 }
 
 // Gives back everything the unit holds on the device and its download buffers (to the caches of agx_mem.h: the next unit of the run takes
 // them without a driver call).  The inputs stay staged: the unit can be uploaded again as if it were new.
 void do_release(agx_unit *u) {
+    const double tr0 = now_ms();
+    struct Tr { agx_unit *u; double t; ~Tr() { trace(u, "release", t, u->T.ref.size()); } } tr{u, tr0};
     if (u->st) { (void)hipSetDevice(u->prm.device); (void)hipStreamSynchronize(u->st); }
     for (auto *b : {&u->d_cm_start, &u->d_tile_cnt, &u->d_tile_off, &u->d_cursor, &u->d_unsorted, &u->d_tile_recs, &u->d_scan_tmp, &u->d_words, &u->d_pool_cnt, &u->d_region_off, &u->d_node_start,
                     &u->d_slow_list, &u->d_rank4, &u->d_jump_list, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
@@ -547,7 +592,7 @@ GraphView view_of(agx_unit *u) {
     G.meta = u->h_a_meta.p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
     G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.sp_hop = u->h_sp_hop.p; G.n_special = u->n_special;
     G.fetch = fetch_records; G.fetch_ctx = u;
-    G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf;
+    G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf; G.row_slot = u->row_slot.data();
     return G;
 }
 
@@ -708,7 +753,7 @@ int agx_unit_load_files_shared(agx_unit *u, const char *tmp_dir, int unit, const
 int agx_unit_stage(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { stage_inputs(u); }); }
 int agx_unit_upload(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_upload(u); }); }
 int agx_unit_release(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_release(u); }); }
-void agx_pool_trim(int device) { if (device >= 0) dev_trim(device); else host_trim(); }
+void agx_pool_trim(int device) { if (device >= 0) dev_trim(device); else if (device == -1) host_trim(); else host_retire(); }
 int agx_unit_build(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_build(u); }); }
 int agx_unit_download(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_download(u); }); }
 
@@ -720,6 +765,7 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
         const double t0 = now_ms();
         UnitOutput O; walk_join_scaffold(u->T, u->P, view_of(u), O);
         u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = O.n_fetched;
+        trace(u, "walk", t0, u->T.ref.size());
         r->initial_contigs = dup_buf(u->T.initial_contigs); r->initial_len = u->T.initial_contigs.size();
         r->pre_len = O.pre_extended.n; r->pre_extended = O.pre_extended.release();
         r->extended_len = O.extended.n; r->extended = O.extended.release();

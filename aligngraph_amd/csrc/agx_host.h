@@ -62,6 +62,7 @@ struct GraphView {
     // records of non-special ids: `rows` groups of `width` consecutive ids, group r starting at first + r*stride, into out[rows*width]
     void (*fetch)(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *out) = nullptr; void *fetch_ctx = nullptr;
     const agx_edge_ovf *ovf = nullptr; size_t n_ovf = 0;     // walk ids; NONE/NONE entries and duplicates are ignored
+    const agx_u32 *row_slot = nullptr;                      // k-mer string references name rows of the staged read bases: row -> read slot (null: they name read slots)
 };
 
 // Megabyte-sized buffers that are written once, front to back (outputs, the walk's visited bytes): ask for transparent huge pages where

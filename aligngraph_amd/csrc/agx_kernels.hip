@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
     bool jump = false;
     if (mine) {
         const agx_hit H = A.hits[h];
-        const int rc = agx_hit_prep(H, H.back != 0 && agx_hit_dup(A.hits, A.runs, h), A.runs, A.k, d);
+        const int rc = agx_hit_prep(H, H.back != 0 && agx_hit_dup(A.hits, A.runs, h), (H.pad[0] & 1u) != 0, H.slot1, A.runs, A.k, d);      // staged hit: slot1 = row of the a mate's bases
         jump = H.nruns1 >= 2 || H.nruns2 >= 2;             // a mate of several runs: the only hits that can step over positions
         if (rc) atomicOr(A.err, 1u);
         if (!(d.flags & AGX_HF_SKIP) && (d.x_hi >= A.n_pos || d.x_lo > d.x_hi)) { atomicOr(A.err, 2u); d.flags |= AGX_HF_SKIP; }

@@ -106,7 +106,16 @@ inline MemBlock host_block(size_t need) {
     if (e != hipSuccess) { (void)hipGetLastError(); munmap(p, need); throw Error{E_DEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e)}; }
     return MemBlock{p, need};
 }
-inline void host_trim() { for (const MemBlock &c : host_cache().drain()) { (void)hipHostUnregister(c.p); munmap(c.p, c.n); } }
+inline std::vector<MemBlock> &host_retired() { static std::vector<MemBlock> v; return v; }
+inline std::mutex &host_retired_mutex() { static std::mutex m; return m; }
+// retire: the cached blocks are never handed out again but stay mapped until the next host_trim — a measurement loop that wants every
+// job to map, fault and register fresh buffers (like a new process) without also paying for unmapping the previous job's inside its clock
+inline void host_retire() { std::vector<MemBlock> v = host_cache().drain(); std::lock_guard<std::mutex> g(host_retired_mutex()); host_retired().insert(host_retired().end(), v.begin(), v.end()); }
+inline void host_trim() {
+    std::vector<MemBlock> v = host_cache().drain();
+    { std::lock_guard<std::mutex> g(host_retired_mutex()); v.insert(v.end(), host_retired().begin(), host_retired().end()); host_retired().clear(); }
+    for (const MemBlock &c : v) { (void)hipHostUnregister(c.p); munmap(c.p, c.n); }
+}
 
 template <class T> struct PBuf {            // pinned host buffer: one cached block each
     T *p = nullptr; size_t n = 0; MemBlock blk;

@@ -199,7 +199,7 @@ struct Walker {
         const agx_sref r = node(v).sref;
         const agx_u32 first = r.qlen & 0xFFFFu, len = (r.qlen >> 16) & 0x7FFFu; const bool rev = (r.qlen >> 31) != 0;
         out.clear();
-        const char *p = P.bases.data() + (size_t)r.slot * P.stride;
+        const char *p = P.bases.data() + (size_t)(G.row_slot ? G.row_slot[r.slot] : r.slot) * P.stride;
         for (agx_u32 i = 0; i < len; i++) {
             if (!rev) out.push_back(p[first + i]);
             else { const char c = p[first - i]; out.push_back(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c); }

