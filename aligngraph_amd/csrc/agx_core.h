@@ -69,7 +69,7 @@ struct agx_cmhead { agx_u32 cid, coff, n, start; };
 
 // ---- derived per-hit record (device, written by hit_prep) ---------------------------------------------
 
-enum { AGX_HF_AREV = 1, AGX_HF_SKIP = 2 };
+enum { AGX_HF_AREV = 1, AGX_HF_SKIP = 2, AGX_HF_BNONE = 4 };      // BNONE (tile records only): the b mate is unaligned over the whole piece
 
 struct agx_dhit {
     agx_u32 a_t0, b_t0;       // simple mate: reference offset of read index 0 ("a" = the left mate, AG:1672-1679)
@@ -159,13 +159,17 @@ AGX_HD agx_arrival agx_decode_arrival(const agx_dhit &d, const agx_run *runs, ag
     agx_arrival a;
     const agx_u32 L = d.len, js = d.jstar;
     if (d.a_nruns == 0 && d.b_nruns == 0) {
-        // nine hits out of ten: both mates are one full-length run.  Read index q sits on a_t0+q; every index below jstar (= L-k)
-        // is an event source whose successor is the next position; jstar itself only receives the k2 half (K2ONLY).
+        // A LINEAR PIECE: read indices qs .. qe (a_runs = qs | qe << 16) sit on a_t0 + q, their mate positions on b_t0 + q (or nowhere:
+        // AGX_HF_BNONE), every index below jstar is an event source whose successor is the next position, jstar itself only receives the
+        // k2 half (K2ONLY).  A hit whose mates are both one full-length run is one piece (qs = 0, qe = jstar: hit_prep writes it so);
+        // agx_tile_record() cuts the other hits into the piece that covers a tile wherever there is one.
         // Hits with L <= k carry AGX_HF_SKIP and are never listed, so jstar is valid.
-        const agx_u32 q = X - d.a_t0;                       // wraps to a huge value left of the read
-        const bool last = q == js;
-        a.has = q <= js ? 1u : 0u; a.type = last ? AGX_AT_K2ONLY : AGX_AT_K1; a.q = q; a.slen = k;
-        a.p0 = d.b_t0 + q; a.has_succ = last ? 0u : 1u; a.xs = X + 1; a.p0s = d.b_t0 + q + 1;
+        const agx_u32 q = X - d.a_t0;                       // wraps to a huge value left of the piece
+        const agx_u32 qs = d.a_runs & 0xFFFFu, qe = d.a_runs >> 16;
+        const bool last = q == js, bnone = (d.flags & AGX_HF_BNONE) != 0;
+        a.has = (q - qs) <= (qe - qs) ? 1u : 0u; a.type = last ? AGX_AT_K2ONLY : AGX_AT_K1; a.q = q;
+        a.slen = last ? ((L - q) < k ? (L - q) : k) : k;
+        a.p0 = bnone ? AGX_NONE : d.b_t0 + q; a.has_succ = last ? 0u : 1u; a.xs = X + 1; a.p0s = bnone ? AGX_NONE : d.b_t0 + q + 1;
         return a;
     }
     const agx_u32 lim = L > k ? L - k : 0u;
@@ -279,7 +283,44 @@ AGX_HD int agx_hit_prep(const agx_hit &H, bool dup, bool swap, agx_u32 a_slot, c
     }
     if (!below) { d.flags |= AGX_HF_SKIP; return 0; }       // no source index: the hit emits no event
     d.x_lo = first_x; d.x_hi = last_x;
+    if (d.a_nruns == 0 && d.b_nruns == 0) { d.a_runs = (agx_u32)d.jstar << 16; d.b_runs = 0; }      // one linear piece (agx_decode_arrival): qs = 0, qe = jstar
     return 0;
+}
+
+// The record of hit d in the list of tile `tile`: d itself, or — where the hit's arrivals inside the tile are ONE linear piece — that piece
+// in the form agx_decode_arrival decodes with a handful of scalar operations (three hits in eight have an indel or a soft clip in one of
+// their mates, but a break point lies in one tile: the other tiles the hit touches see a single run of the a mate against a single run, or
+// a hole, of the b mate).  A piece must give, for every position of the tile, exactly what the general decode gives: the same index, type
+// and mate position, the successor on the next position with the next mate position.
+AGX_HD agx_dhit agx_tile_record(const agx_dhit &d, const agx_run *runs, agx_u32 tile, agx_u32 k) {
+    if ((d.a_nruns == 0 && d.b_nruns == 0) || (d.flags & AGX_HF_SKIP)) return d;
+    const agx_u32 L = d.len, js = d.jstar, t0 = tile * AGX_TILE;
+    const agx_u32 xs = d.x_lo > t0 ? d.x_lo : t0, xe = d.x_hi < t0 + AGX_TILE - 1u ? d.x_hi : t0 + AGX_TILE - 1u;
+    if (xs > xe || js == 0xFFFFu || L <= k) return d;
+    // the a run that holds xs must hold xe, and xe + 1 too if xe is an event source (its successor is then the next position)
+    const agx_u32 na = d.a_nruns ? d.a_nruns : 1u;
+    agx_run r = agx_run{0u, 0u, 0u}; bool found = false;
+    for (agx_u32 i = 0; i < na; i++) { const agx_run c = d.a_nruns ? runs[d.a_runs + i] : agx_run{0u, d.a_t0, L}; if (c.n && xs >= c.t && xs - c.t < c.n) { r = c; found = true; } }
+    if (!found || xe - r.t >= r.n) return d;
+    const agx_u32 qs = r.q + (xs - r.t), qe = r.q + (xe - r.t);
+    if (qe > js) return d;                                  // (cannot happen: x_hi is jstar's position)
+    if (qe < js && xe + 1u - r.t >= r.n) return d;
+    const agx_u32 qe2 = qe < js ? qe + 1u : qe;             // the last index whose mate position is looked at
+    // the b mate over qs .. qe2: one run, or nothing at all
+    const agx_u32 nb = d.b_nruns ? d.b_nruns : 1u;
+    agx_run rb = agx_run{0u, 0u, 0u}; bool in_b = false, touches = false;
+    for (agx_u32 i = 0; i < nb; i++) {
+        const agx_run c = d.b_nruns ? runs[d.b_runs + i] : agx_run{0u, d.b_t0, L};
+        if (!c.n) continue;
+        if (qs >= c.q && qs - c.q < c.n) { rb = c; in_b = true; }
+        if (c.q <= qe2 && c.q + c.n > qs) touches = true;
+    }
+    if (in_b && qe2 - rb.q >= rb.n) return d;
+    if (!in_b && touches) return d;
+    agx_dhit p = d;
+    p.a_t0 = r.t - r.q; p.b_t0 = in_b ? rb.t - rb.q : 0u; p.a_runs = qs | (qe << 16); p.b_runs = 0; p.a_nruns = p.b_nruns = 0;
+    if (!in_b) p.flags |= AGX_HF_BNONE;
+    return p;
 }
 
 // conti-mer head of position x (upload-time kernel / test executor).  The table has n_pos + 1 entries: entry n_pos is the head of "no

@@ -396,7 +396,7 @@ void do_build(agx_unit *u) {
         else agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
         agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, (const uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
         agx_launch_bin_fill(&BA, st);
-        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, st);
+        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, u->d_runs.p, u->prm.k, st);
         AGX_CHECKPOINT("tile_sort");
         HIP_OK(hipEventRecord(u->ev_front, st));
         // ---- main stream ----

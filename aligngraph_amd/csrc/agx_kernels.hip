@@ -225,17 +225,17 @@ __global__ void __launch_bounds__(256) agx_k_bin_fill(agx_bin_args A) {
 
 // one wavefront per tile; a hit's place in the file is unique, so an element's rank is the number of smaller keys
 #define AGX_SORT_LDS 2048
-// The kernel writes the tile's RECORD list: the first 32 bytes of each listed hit's derived record, in SAM (= hit id) order, so that the
-// sweeps read one sequential, wave-uniform stream (scalar loads) instead of chasing list entry -> record.
-__device__ __forceinline__ void agx_put_rec(uint4 *recs, agx_u32 at, const agx_dhit *dhit, agx_u32 h) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(dhit + h);             // agx_dhit is 40 bytes: 8-byte aligned only
-    const uint2 *s2 = reinterpret_cast<const uint2 *>(src);
-    const uint2 a = s2[0], b = s2[1], c = s2[2], d = s2[3];
-    recs[2 * (size_t)at] = make_uint4(a.x, a.y, b.x, b.y); recs[2 * (size_t)at + 1] = make_uint4(c.x, c.y, d.x, d.y);
+// The kernel writes the tile's RECORD list: 32 bytes per listed hit, in SAM (= hit id) order, so that the sweeps read one sequential,
+// wave-uniform stream (scalar loads) instead of chasing list entry -> record.  A record is the first 32 bytes of agx_tile_record(): the
+// hit's derived record, or the linear piece of it that covers this tile.
+__device__ __forceinline__ void agx_put_rec(uint4 *recs, agx_u32 at, const agx_dhit *dhit, agx_u32 h, const agx_run *runs, agx_u32 tile, agx_u32 k) {
+    const agx_dhit d = agx_tile_record(dhit[h], runs, tile, k);
+    recs[2 * (size_t)at] = make_uint4(d.a_t0, d.b_t0, d.a_runs, d.b_runs);
+    recs[2 * (size_t)at + 1] = make_uint4(d.a_slot, (agx_u32)d.len | ((agx_u32)d.jstar << 16), (agx_u32)d.a_nruns | ((agx_u32)d.b_nruns << 16), d.flags);
 }
 // (list entries are hit numbers = places in the SAM file: the sort key)
 __global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap,
-                                                       const agx_dhit *dhit, uint4 *recs) {
+                                                       const agx_dhit *dhit, uint4 *recs, const agx_run *runs, agx_u32 k) {
     __shared__ agx_u32 sh[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
@@ -250,13 +250,13 @@ __global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, 
         for (agx_u32 i = lane; i < n; i += 64) {
             const agx_u32 key = sh[wave][i]; agx_u32 r = 0;
             for (agx_u32 j = 0; j < n; j++) r += sh[wave][j] < key;
-            agx_put_rec(recs, lo + r, dhit, key);
+            agx_put_rec(recs, lo + r, dhit, key, runs, tile, k);
         }
     } else {                                            // pile-ups larger than the LDS window: same rank sort straight from L2
         for (agx_u32 i = lane; i < n; i += 64) {
             const agx_u32 key = src[i]; agx_u32 r = 0;
             for (agx_u32 j = 0; j < n; j++) r += src[j] < key;
-            agx_put_rec(recs, lo + r, dhit, key);
+            agx_put_rec(recs, lo + r, dhit, key, runs, tile, k);
         }
     }
 }
@@ -578,9 +578,9 @@ void agx_launch_exclusive_scan1(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsi
 void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_bin_fill, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
 }
-void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, hipStream_t st) {
+void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, const agx_run *runs, agx_u32 k, hipStream_t st) {
     if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, n_tiles, cap, dhit,
-                                    (uint4 *)recs);
+                                    (uint4 *)recs, runs, k);
 }
 void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;

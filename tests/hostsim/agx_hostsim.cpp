@@ -52,8 +52,24 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
         for (agx_u32 t = dh[h].x_lo / AGX_TILE; t <= dh[h].x_hi / AGX_TILE; t++) lists[t].push_back(h);
     }
     std::vector<agx_u32> tile_off(n_tiles + 1, 0), tile_hits;
-    for (agx_u32 t = 0; t < n_tiles; t++) { tile_off[t] = (agx_u32)tile_hits.size(); tile_hits.insert(tile_hits.end(), lists[t].begin(), lists[t].end()); }
+    std::vector<agx_dhit> tile_recs;                       // what agx_k_tile_sort writes: per list entry the hit's record for THAT tile (agx_tile_record)
+    for (agx_u32 t = 0; t < n_tiles; t++) {
+        tile_off[t] = (agx_u32)tile_hits.size(); tile_hits.insert(tile_hits.end(), lists[t].begin(), lists[t].end());
+        for (agx_u32 h : lists[t]) {
+            const agx_dhit piece = agx_tile_record(dh[h], P.runs.data(), t, k);
+            // a piece must decode, on every position of its tile, to exactly what the hit's full record decodes to
+            for (agx_u32 X = t * AGX_TILE; X < (t + 1) * AGX_TILE && X < n_pos; X++) {
+                const agx_arrival a = agx_decode_arrival(dh[h], P.runs.data(), X, k), b = agx_decode_arrival(piece, P.runs.data(), X, k);
+                const bool same = a.has == b.has && (!a.has || (a.type == b.type && a.q == b.q && a.slen == b.slen && a.p0 == b.p0 && a.has_succ == b.has_succ &&
+                                  (!a.has_succ || (a.xs == b.xs && a.p0s == b.p0s))));
+                if (!same) throw Error{E_ARG, "a tile record decodes differently from the hit's record"};
+            }
+            tile_recs.push_back(piece);
+        }
+    }
     tile_off[n_tiles] = (agx_u32)tile_hits.size();
+    if (getenv("AGX_SIM_STATS")) { size_t lin = 0, cx = 0, cx_hits = 0; for (const agx_dhit &r : tile_recs) (r.a_nruns | r.b_nruns) ? cx++ : lin++; for (const agx_dhit &r : dh) if (!(r.flags & AGX_HF_SKIP) && (r.a_nruns | r.b_nruns)) cx_hits++;
+        fprintf(stderr, "[hostsim] tile-list entries: %zu linear pieces, %zu general records (%.1f %%); hits with a multi-run mate: %zu of %zu\n", lin, cx, 100.0 * cx / (lin + cx + 1e-9), cx_hits, dh.size()); }
 
     // The engine uploads the conti-mer tables as runs (agx_cmseg) and expands them on the device: count = highest rank + 1 per position,
     // scan, fill (agx_k_seg_count / agx_k_seg_fill).  The same element functions here; the result must be the loader's tables, and the hop
@@ -96,7 +112,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     bind();
     n_big_tiles = 0;
     agx_u32 pool = 0;
-    auto get = [&](agx_u32 i) { return dh[tile_hits[i]]; };
+    auto get = [&](agx_u32 i) { return tile_recs[i]; };
     std::vector<agx_u32> lds((size_t)AGX_NF * maxv_first * AGX_TILE), big;
     for (agx_u32 t = 0; t < n_tiles; t++) {
         agx_u32 cnt[AGX_TILE], pflag[AGX_TILE]; bool ok = true;
@@ -154,7 +170,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
         const agx_u32 t = X / AGX_TILE;
         agx_slow_ctx c; agx_edge_slow_ctx(A, X, c);
         agx_u32 pairs = 0;
-        for (agx_u32 i = tile_off[t]; i < tile_off[t + 1]; i++) pairs |= agx_edge_slow_pair(A, c, X, dh[tile_hits[i]], true, ins);
+        for (agx_u32 i = tile_off[t]; i < tile_off[t + 1]; i++) pairs |= agx_edge_slow_pair(A, c, X, tile_recs[i], true, ins);
         for (agx_u32 b = 0; b < AGX_SLOW_V * AGX_SLOW_V; b++) if ((pairs >> b) & 1u) ins(c.s + b / AGX_SLOW_V, c.s1 + b % AGX_SLOW_V);
     }
 
