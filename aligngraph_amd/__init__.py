@@ -21,7 +21,7 @@ EXPORTS = [
     "agx_unit_set_contig_threads", "agx_unit_push_pairs", "agx_unit_load_files", "agx_unit_upload", "agx_unit_build", "agx_unit_download",
     "agx_unit_finish", "agx_result_free", "agx_unit_stats", "agx_unit_graph", "agx_graph_free", "agx_run_unit",
     "agx_reads_open", "agx_reads_close", "agx_unit_load_files_shared", "agx_run_unit_shared",
-    "agx_unit_stage", "agx_unit_release", "agx_pool_trim",
+    "agx_unit_stage", "agx_unit_release", "agx_pool_trim", "agx_unit_cache_build", "agx_unit_cache_save",
 ]
 
 
@@ -65,7 +65,7 @@ class Stats(ctypes.Structure):
                [(n, ctypes.c_double) for n in ("ms_edge_fast", "ms_edge_slow")] + [("n_mid_tiles", ctypes.c_uint64), ("ms_build_span", ctypes.c_double)] + \
                [(n, ctypes.c_double) for n in ("ms_stage", "ms_upload_dev")] + \
                [(n, ctypes.c_uint64) for n in ("upload_bytes", "device_bytes", "pinned_bytes_cached", "device_bytes_cached", "n_spilled")] + \
-               [("build_attempts", ctypes.c_uint32), ("pad_", ctypes.c_uint32)]
+               [("build_attempts", ctypes.c_uint32), ("from_cache", ctypes.c_uint32)]
 
 
 class Graph(ctypes.Structure):
@@ -110,6 +110,8 @@ def lib():
         L.agx_reads_close.argtypes = [ctypes.c_void_p]
         L.agx_reads_close.restype = None
         L.agx_unit_load_files_shared.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
+        L.agx_unit_cache_build.argtypes = [ctypes.POINTER(Params), ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+        L.agx_unit_cache_save.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.agx_pool_trim.argtypes = [ctypes.c_int]
         L.agx_pool_trim.restype = None
         for f in ("agx_unit_upload", "agx_unit_build", "agx_unit_download", "agx_unit_stage", "agx_unit_release"):
@@ -240,6 +242,10 @@ class Unit:
         """reads: an optional Reads (tmp/_reads.fa opened once for all units of a run)."""
         self._check(lib().agx_unit_load_files_shared(self._h, tmp_dir.encode(), unit, reads._h if reads is not None else None))
 
+    def cache_save(self, tmp_dir, unit):
+        """Writes tmp_dir/_agx_unit.<unit>.bin from this unit (just loaded from the text files of tmp_dir, unit)."""
+        self._check(lib().agx_unit_cache_save(self._h, tmp_dir.encode(), unit))
+
     def stage(self):
         self._check(lib().agx_unit_stage(self._h))
 
@@ -284,6 +290,15 @@ class Unit:
                "edge_start": arr(g.edge_start, g.n_nodes + 1, "uint32"), "edge_dst": arr(g.edge_dst, g.n_edges, "uint32")}
         lib().agx_graph_free(ctypes.byref(g))
         return out
+
+
+def cache_build(tmp_dir, unit, batch=0, device=0, reads=None):
+    """Writes tmp_dir/_agx_unit.<unit>.bin (the unit's staged arrays) from the five text files; load_files then takes it instead of the text."""
+    p = Params(5, 50, 20, batch, device, 0)
+    err = ctypes.create_string_buffer(512)
+    rc = lib().agx_unit_cache_build(ctypes.byref(p), tmp_dir.encode(), unit, reads._h if reads is not None else None, err, 512)
+    if rc != AGX_OK:
+        raise AgxError(rc, err.value.decode(errors="replace"))
 
 
 def run_unit(tmp_dir, unit, k=5, insert_variation=50, coverage=20, batch=0, device=0, write_files=False):

@@ -362,6 +362,21 @@ void align_everything(const Options &o, int units) {
         }
     });
     reads.join(); contigs.join();
+    // The units' binary caches: the five text files of every unit parsed ONCE, here where the reference distributes the
+    // alignments (AG:3545-3579), into tmp/_agx_unit.<u>.bin; the unit loop — of this run and of every --resume — then reads no text.  The
+    // text files stay what the contract says they are.  Failures are not errors here: the unit loop falls back to the text and reports.
+    if (!getenv("AGX_NO_CACHE") && agx_device_count() > 0) {
+        agx_reads *rd = nullptr; { char err[512]; if (agx_reads_open("tmp/_reads.fa", &rd, err, sizeof err) != AGX_OK) rd = nullptr; }
+        std::atomic<int> nextu(0);
+        vector<std::thread> th;
+        for (int t = 0; t < std::min(units, 4); t++) th.emplace_back([&]() {
+            for (;;) { const int u = nextu.fetch_add(1); if (u >= units) return;
+                agx_params p = {(uint32_t)o.k, (uint32_t)o.insertVariation, (uint32_t)o.coverage, 0, 0, 0}; char err[512];
+                (void)agx_unit_cache_build(&p, "tmp", u, rd, err, sizeof err); }
+        });
+        for (auto &t : th) t.join();
+        agx_reads_close(rd);
+    }
 }
 
 // the SAM fields checkRatio looks at (parseBOWTIE, AG:181-285) and its identity filter (AG:3790)
@@ -696,13 +711,19 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
     vector<double> budget(ndev, 0.0), used(ndev, 0.0);
     for (int d = 0; d < ndev; d++) { uint64_t fr = 0, tot = 0; budget[d] = agx_device_memory(d, &fr, &tot) == AGX_OK ? 0.85 * (double)tot : 1e18; }
     std::mutex mem_mu; std::condition_variable mem_cv;
-    std::atomic<int> next(first);
+    // Longest unit first (its host walk then runs beside the uploads and kernels of the shorter ones); progress lines and
+    // checkpoints still come out in unit order.  A unit that fails stops the hand-out; the message is printed by the main thread once the
+    // workers are back (an exit() from a worker would tear HIP down under the other workers' feet).
+    vector<int> order; for (int u = first; u < units; u++) order.push_back(u);
+    vector<double> weight(units, 0.0);
+    for (int u = first; u < units; u++) weight[u] = 200.0 * file_bytes("tmp/_genome." + itoa(u) + ".fa") + 2.0 * file_bytes("tmp/_reads_genome." + itoa(u) + ".bowtie");
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] > weight[b]; });
+    std::atomic<size_t> next(0); std::atomic<bool> failed(false);
     vector<int> state(units, 0); vector<string> errors(units);
     std::mutex mu; int reported = first;
-    auto report = [&]() {                                                     // under mu: flush finished units in order
-        while (reported < units && state[reported] != 0) {
+    auto report = [&]() {                                                     // under mu: flush finished units in order, up to the first failure
+        while (reported < units && state[reported] > 0) {
             cout << endl << "CHROMOSOME " << reported << ": " << endl;
-            if (state[reported] < 0) { cout << errors[reported] << endl; exit(-1); }
             cout << "(1) Chromosome loaded" << endl << "(2) Contig alignment loaded" << endl << "(3) Read alignment loaded" << endl
                  << "(4) Contigs extended" << endl << "(5) Contigs scaffolded" << endl;
             wcp << itoa(reported + 1) << endl;                                // setCheckpoint, AG:4782
@@ -713,24 +734,30 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
     for (int d = 0; d < ndev; d++) for (int s = 0; s < per_dev; s++)
         workers.emplace_back([&, d]() {
             for (;;) {
-                const int u = next.fetch_add(1);
-                if (u >= units) return;
-                const double est = 200.0 * file_bytes("tmp/_genome." + itoa(u) + ".fa") + 2.0 * file_bytes("tmp/_reads_genome." + itoa(u) + ".bowtie") + 256e6;
+                const size_t at = next.fetch_add(1);
+                if (at >= order.size() || failed.load()) return;
+                const int u = order[at];
+                const double est = weight[u] + 256e6;
                 { std::unique_lock<std::mutex> g(mem_mu); mem_cv.wait(g, [&] { return used[d] == 0.0 || used[d] + est <= budget[d]; }); used[d] += est; }
                 agx_params p = {(uint32_t)o.k, (uint32_t)o.insertVariation, (uint32_t)o.coverage, 0, d, 0};
                 agx_result r; char err[512];
-                const int rc = agx_run_unit_shared(&p, "tmp", u, 1, reads, &r, err, sizeof err);
+                int rc = AGX_E_ARG;
+                try { rc = agx_run_unit_shared(&p, "tmp", u, 1, reads, &r, err, sizeof err); } catch (...) { snprintf(err, sizeof err, "internal error"); }
                 if (rc == AGX_OK) agx_result_free(&r);
                 { std::lock_guard<std::mutex> g(mem_mu); used[d] -= est; if (used[d] < 1.0) used[d] = 0.0; }
                 mem_cv.notify_all();
                 std::lock_guard<std::mutex> g(mu);
-                if (rc != AGX_OK) { string m = err; const size_t cut = m.find(" ("); errors[u] = cut == string::npos ? m : m.substr(0, cut); state[u] = -1; }
+                if (rc != AGX_OK) { string m = err; const size_t cut = m.find(" ("); errors[u] = cut == string::npos ? m : m.substr(0, cut); state[u] = -1; failed.store(true); }
                 else state[u] = 1;
                 report();
             }
         });
     for (auto &t : workers) t.join();
     agx_reads_close(reads);
+    if (failed.load()) {                                                      // the first unit (in unit order) that did not finish: what the sequential reference would have stopped at
+        int u = reported; while (u < units && state[u] >= 0) u++;
+        if (u < units) { cout << endl << "CHROMOSOME " << u << ": " << endl << errors[u] << endl; cout.flush(); exit(-1); }
+    }
 }
 
 }  // namespace

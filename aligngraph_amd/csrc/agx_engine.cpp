@@ -12,6 +12,9 @@
 //   download the walk graph into cached pinned buffers; finish = the sequential host walk.
 // No CPU fallback exists: a host without a HIP device gets AGX_E_NOGPU from agx_unit_create.
 #include <hip/hip_runtime_api.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -20,6 +23,7 @@
 #include <cstring>
 #include <string>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -57,11 +61,14 @@ struct Boundaries {
     double ms(int b) const { if (!at[b - 1] || !at[b]) return 0; float f = 0; (void)hipEventElapsedTime(&f, e[b - 1], e[b]); return f; }      // section that ends at boundary b
 };
 
-template <class F> void on_threads(unsigned threads, F fn) {
-    std::vector<std::thread> th;
-    try { for (unsigned t = 1; t < threads; t++) th.emplace_back(fn, t); } catch (...) { for (auto &x : th) x.join(); throw; }
-    fn(0u);
+template <class F> void on_threads(unsigned threads, F fn) {      // (as in agx_host.cpp: nothing leaves a worker thread as an exception)
+    std::vector<std::thread> th; std::vector<std::exception_ptr> ex(threads);
+    auto guarded = [&](unsigned t) { try { fn(t); } catch (...) { ex[t] = std::current_exception(); } };
+    std::vector<unsigned> mine{0u};
+    for (unsigned t = 1; t < threads; t++) { try { th.emplace_back(guarded, t); } catch (const std::system_error &) { mine.push_back(t); } }
+    for (unsigned t : mine) guarded(t);
     for (auto &x : th) x.join();
+    for (auto &e : ex) if (e) std::rethrow_exception(e);
 }
 
 }  // namespace
@@ -69,7 +76,10 @@ template <class F> void on_threads(unsigned threads, F fn) {
 struct agx_unit {
     agx_params prm{};
     std::string err;
-    Threads T; Pairs P;
+    Threads T; Pairs P;                 // what the loaders / the packed-array calls filled (empty when the unit came out of a cache file)
+    UnitView V;                         // what everything downstream reads: into T / P, or into the mapped cache file
+    struct Mapped { void *p = nullptr; size_t n = 0; void reset() { if (p) munmap(p, n); p = nullptr; n = 0; } ~Mapped() { reset(); } } cache_map;
+    agx_u32 n_seg0 = 0, stride = 0, n_slots = 0; unsigned long long pairs_in_file = 0, sam_pairs = 0;
     bool have_ref = false, have_threads = false, staged = false, uploaded = false, built = false, downloaded = false;
     hipStream_t st = nullptr;
     DevArena arena;
@@ -142,9 +152,9 @@ enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SL
 void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     memset(&S, 0, sizeof S);
     S.cm_start = u->d_cm_start.p; S.cm = u->d_cm.p; S.cm_head = u->d_cm_head.p; S.ref = u->d_ref.p;
-    S.dhit = u->d_dhit.p; S.runs = u->d_runs.p; S.vcodes = u->d_vcodes.p; S.stride = u->P.stride;
+    S.dhit = u->d_dhit.p; S.runs = u->d_runs.p; S.vcodes = u->d_vcodes.p; S.stride = u->stride;
     S.tile_off = u->d_tile_off.p; S.tile_recs = (decltype(S.tile_recs))u->d_tile_recs.p;
-    S.n_pos = (agx_u32)u->T.ref.size(); S.n_tiles = u->n_tiles; S.k = u->prm.k; S.iv = (int)u->prm.insert_variation; S.coverage = (int)u->prm.coverage;
+    S.n_pos = (agx_u32)u->V.n_pos; S.n_tiles = u->n_tiles; S.k = u->prm.k; S.iv = (int)u->prm.insert_variation; S.coverage = (int)u->prm.coverage;
     S.node_start = u->d_node_start.p; S.node_cnt = u->d_node_cnt.p; S.pos_succ = u->d_pos_succ.p; S.side_pk = u->d_side_pk.p; S.tile_side = u->d_tile_side.p;
     S.nk_cid = u->d_cid.p; S.nk_coff = u->d_coff.p; S.nk_cid0 = u->d_cid0.p; S.nk_coff0 = u->d_coff0.p; S.nk_off0 = u->d_off0.p;
     S.n_xpos = u->d_xpos.p; S.n_base = u->d_base.p; S.n_flags = u->d_flags.p; S.n_sref = u->d_sref.p; S.n_next = u->d_next.p;
@@ -160,6 +170,8 @@ void stage_inputs(agx_unit *u) {
     if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
     const double t0 = now_ms();
     HIP_OK(hipSetDevice(u->prm.device));            // (registering host memory needs a current device)
+    u->V = view_of(u->T, u->P); u->cache_map.reset();
+    u->n_seg0 = u->T.n_seg0; u->stride = u->P.stride; u->n_slots = u->P.n_slots; u->pairs_in_file = u->P.n_pairs_in_file; u->sam_pairs = u->P.n_sam_pairs;
     const size_t n_pos = u->T.ref.size();
     if (n_pos == 0 || n_pos >= 0xFFFFFF00ull) throw Error{E_ARG, "unit sequence is empty or too long"};
     if (u->T.cm_start.size() != n_pos + 1) throw Error{E_ARG, "contig thread table does not match the position count"};
@@ -213,10 +225,104 @@ void stage_inputs(agx_unit *u) {
     u->stats.ms_stage = now_ms() - t0;
 }
 
+// ---- unit cache file ----------------------------------------------------------------------------------------------------------------
+// tmp/_agx_unit.<u>.bin: a unit's STAGED form, written once (AlignGraph_amd does it when it distributes the alignments, AG:3545-3579;
+// agx_unit_cache_build) so that a unit loop that finds it neither reads nor parses text: the arrays the upload wants are read straight into
+// pinned memory, what only the host walk looks at (conti-mer counts, chain suffixes, read bases for the k-mer tails of written records) is
+// mapped and paged in where it is touched.  Valid for one BATCH size and for exactly the five text files it was made from (size and
+// modification time of each are in the header): anything else and the loader falls back to the text.
+namespace cache {
+enum { S_HITS = 0, S_RUNS, S_CODES, S_SEGS, S_CHAIN_END, S_ROW_SLOT, S_REF, S_CM_START, S_CHAIN_STR, S_INITIAL, S_BASES, S_N };
+struct Header {
+    char magic[8]; agx_u32 version, batch; unsigned long long stamp[5][2];
+    unsigned long long n_pos, n_ref, nh, n_runs, n_cm, n_segs, n_seg0, n_rows, n_chain_end, n_codes, pairs_in_file, sam_pairs;
+    agx_u32 stride, maxlen, n_slots, pad;
+    unsigned long long off[S_N], len[S_N];
+};
+const char MAGIC[8] = {'A', 'G', 'X', 'U', 'N', 'I', 'T', '2'};
+void stamps(const std::string &d, int unit, unsigned long long st[5][2]) {
+    const std::string s = std::to_string(unit);
+    const std::string f[5] = {d + "/_genome." + s + ".fa", d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie"};
+    for (int i = 0; i < 5; i++) { struct stat sb; if (stat(f[i].c_str(), &sb) != 0) { st[i][0] = st[i][1] = ~0ull; continue; }
+        st[i][0] = (unsigned long long)sb.st_size; st[i][1] = (unsigned long long)sb.st_mtim.tv_sec * 1000000000ull + (unsigned long long)sb.st_mtim.tv_nsec; }
+}
+std::string path_of(const std::string &d, int unit) { return d + "/_agx_unit." + std::to_string(unit) + ".bin"; }
+}  // namespace cache
+
+void save_cache(agx_unit *u, const std::string &dir, int unit) {
+    using namespace cache;
+    if (!u->staged || u->cache_map.p) throw Error{E_ARG, "nothing staged from text"};
+    Header H; memset(&H, 0, sizeof H); memcpy(H.magic, MAGIC, 8); H.version = 1; H.batch = u->prm.batch;
+    stamps(dir, unit, H.stamp);
+    H.n_pos = u->V.n_pos; H.n_ref = u->V.n_ref; H.nh = u->nh; H.n_runs = u->n_runs; H.n_cm = u->n_cm; H.n_segs = u->n_segs; H.n_seg0 = u->n_seg0; H.n_rows = u->row_slot.size();
+    H.n_chain_end = u->n_chain_end; H.n_codes = u->n_codes; H.pairs_in_file = u->pairs_in_file; H.sam_pairs = u->sam_pairs; H.stride = u->stride; H.maxlen = u->maxlen; H.n_slots = u->n_slots;
+    const void *ptr[S_N] = {u->s_hits.p, u->s_runs.p, u->s_codes.p, u->s_segs.p, u->s_chain_end.p, u->row_slot.data(), u->V.ref, u->V.cm_start, u->V.chain_str, u->V.initial, u->V.bases};
+    const unsigned long long len[S_N] = {u->nh * sizeof(agx_hit), u->n_runs * sizeof(agx_run), u->n_codes, u->n_segs * sizeof(agx_cmseg), (unsigned long long)u->n_chain_end * 4, u->row_slot.size() * 4,
+                                         u->V.n_pos, (u->V.n_pos + 1) * 4, u->T.chain_str.size(), u->V.n_initial, (unsigned long long)u->n_slots * u->stride};
+    unsigned long long at = (sizeof(Header) + 4095) & ~4095ull;
+    for (int i = 0; i < S_N; i++) { H.off[i] = at; H.len[i] = len[i]; at = (at + len[i] + 4095) & ~4095ull; }
+    const std::string path = path_of(dir, unit), part = path + ".part";
+    FILE *f = fopen(part.c_str(), "wb");
+    if (!f) throw Error{E_IO, "CANNOT OPEN FILE! (" + part + ")"};
+    bool ok = fwrite(&H, sizeof H, 1, f) == 1;
+    for (int i = 0; i < S_N && ok; i++) ok = fseek(f, (long)H.off[i], SEEK_SET) == 0 && (len[i] == 0 || fwrite(ptr[i], 1, len[i], f) == len[i]);
+    ok = ok && fflush(f) == 0 && ftruncate(fileno(f), (off_t)at) == 0;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(part.c_str(), path.c_str()) != 0) { (void)remove(part.c_str()); throw Error{E_IO, "cannot write " + path}; }
+}
+
+// true: the unit is staged from the cache file.  false: no usable cache (missing, another batch size, older than its sources, damaged).
+bool load_cache(agx_unit *u, const std::string &dir, int unit) {
+    using namespace cache;
+    if (getenv("AGX_NO_CACHE")) return false;
+    const std::string path = path_of(dir, unit);
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
+    Header H; struct stat sb;
+    if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof H || pread(fd, &H, sizeof H, 0) != (ssize_t)sizeof H) return false;
+    unsigned long long st[5][2]; stamps(dir, unit, st);
+    if (memcmp(H.magic, MAGIC, 8) != 0 || H.version != 1 || H.batch != u->prm.batch || memcmp(st, H.stamp, sizeof st) != 0) return false;
+    for (int i = 0; i < S_N; i++) if (H.off[i] + H.len[i] > (unsigned long long)sb.st_size) return false;
+    if (H.n_pos == 0 || H.n_pos >= 0xFFFFFF00ull || H.len[S_REF] != H.n_pos || H.len[S_CM_START] != (H.n_pos + 1) * 4 || H.len[S_HITS] != H.nh * sizeof(agx_hit) || H.len[S_RUNS] != H.n_runs * sizeof(agx_run) ||
+        H.len[S_CODES] != H.n_codes || H.len[S_SEGS] != H.n_segs * sizeof(agx_cmseg) || H.len[S_ROW_SLOT] != H.n_rows * 4 || H.len[S_BASES] != (unsigned long long)H.n_slots * H.stride || (H.stride & 15u) ||
+        H.len[S_CHAIN_END] != H.n_chain_end * 4) return false;
+    HIP_OK(hipSetDevice(u->prm.device));
+    const double t0 = now_ms();
+    void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) return false;
+    u->T = Threads(); u->P = Pairs(); u->cache_map.reset(); u->cache_map.p = m; u->cache_map.n = (size_t)sb.st_size;
+    const char *base = (const char *)m;
+    u->nh = H.nh; u->n_runs = H.n_runs; u->n_cm = H.n_cm; u->n_segs = H.n_segs; u->n_seg0 = (agx_u32)H.n_seg0; u->n_chain_end = (agx_u32)H.n_chain_end; u->n_codes = H.n_codes;
+    u->pairs_in_file = H.pairs_in_file; u->sam_pairs = H.sam_pairs; u->stride = H.stride; u->maxlen = H.maxlen; u->n_slots = H.n_slots;
+    u->s_hits.alloc(u->nh + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16); u->s_segs.alloc(u->n_segs + 1); u->s_chain_end.alloc((size_t)u->n_chain_end + 1); u->s_ref.alloc(H.n_pos);
+    // the staged arrays: read into the pinned buffers, a few threads, large pieces
+    struct Piece { void *dst; unsigned long long off, len; };
+    std::vector<Piece> pieces;
+    auto cut = [&](void *dst, int sec) { for (unsigned long long a = 0; a < H.len[sec]; a += 32ull << 20) pieces.push_back(Piece{(char *)dst + a, H.off[sec] + a, std::min<unsigned long long>(32ull << 20, H.len[sec] - a)}); };
+    cut(u->s_hits.p, S_HITS); cut(u->s_runs.p, S_RUNS); cut(u->s_codes.p, S_CODES); cut(u->s_segs.p, S_SEGS); cut(u->s_chain_end.p, S_CHAIN_END); cut(u->s_ref.p, S_REF);
+    const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), pieces.size() ? pieces.size() : 1);
+    std::vector<int> bad(threads, 0);
+    on_threads(threads, [&](unsigned t) {
+        for (size_t i = t; i < pieces.size(); i += threads) {
+            size_t done = 0;
+            while (done < pieces[i].len) { const ssize_t r = pread(fd, (char *)pieces[i].dst + done, pieces[i].len - done, (off_t)(pieces[i].off + done)); if (r <= 0) { bad[t] = 1; return; } done += (size_t)r; }
+        }
+    });
+    for (int b : bad) if (b) { u->cache_map.reset(); return false; }
+    u->row_slot.assign((const agx_u32 *)(base + H.off[S_ROW_SLOT]), (const agx_u32 *)(base + H.off[S_ROW_SLOT]) + H.n_rows);
+    UnitView V; V.ref = u->s_ref.p; V.n_pos = H.n_pos; V.n_ref = (agx_u32)H.n_ref; V.cm_start = (const agx_u32 *)(base + H.off[S_CM_START]); V.chain_str = base + H.off[S_CHAIN_STR];
+    V.hop = nullptr; V.bases = base + H.off[S_BASES]; V.stride = H.stride; V.initial = base + H.off[S_INITIAL]; V.n_initial = H.len[S_INITIAL];
+    u->V = V;
+    u->have_ref = u->have_threads = true; u->staged = true; u->uploaded = false; u->built = false; u->downloaded = false;
+    u->stats.ms_stage = now_ms() - t0; u->stats.ms_parse = 0; u->stats.ms_thread = 0; u->stats.from_cache = 1;
+    return true;
+}
+
 // ---- capacities ---------------------------------------------------------------------------------------------------------------------
 // First guesses, made so that a unit's first build is normally its only one (every capacity is still checked on the device and grown
 // from the device-side counters if it proves too small: tests force that with AGX_TEST_SMALL_CAPS).
-agx_u32 spill_min(const agx_unit *u) { const size_t n_pos = u->T.ref.size(); return (agx_u32)std::min<size_t>(g_tiny ? 64 : n_pos / 8 + 65536, 0x10000000u); }
+agx_u32 spill_min(const agx_unit *u) { const size_t n_pos = u->V.n_pos; return (agx_u32)std::min<size_t>(g_tiny ? 64 : n_pos / 8 + 65536, 0x10000000u); }
 
 // Slices of the node pool, one per region, and the spill area behind them.  Without a measurement every region gets the same share of
 // `main_cap` ids; after a build in which the pool ran out, `demand` holds what every region asked for (the counters keep counting) and the
@@ -246,7 +352,7 @@ void alloc_pool(agx_unit *u, agx_u32 cap) {
     u->d_base.release(); u->d_base.alloc(a, cap); u->d_flags.release(); u->d_flags.alloc(a, cap); u->d_sref.release(); u->d_sref.alloc(a, cap);
     if (u->prm.flags & AGX_FLAG_KEEP_COUNTS) { u->d_counts.release(); u->d_counts.alloc(a, (size_t)cap * 6); }
     // walk-graph arrays indexed by walk id: side variants <= nodes <= pool_cap
-    const size_t n_pos = u->T.ref.size(), ids_cap = n_pos + cap;
+    const size_t n_pos = u->V.n_pos, ids_cap = n_pos + cap;
     u->d_aid_of.release(); u->d_aid_of.alloc(a, (size_t)cap + 1);
     u->d_a_str.release(); u->d_a_str.alloc(a, ids_cap + 1); u->d_a_meta.release(); u->d_a_meta.alloc(a, ids_cap + 16); u->d_a_nid.release(); u->d_a_nid.alloc(a, ids_cap + 1);
     u->d_a_mark.release(); u->d_a_mark.alloc(a, ids_cap + 2); u->d_side_xpos.release(); u->d_side_xpos.alloc(a, (size_t)cap + 1);
@@ -271,7 +377,7 @@ void do_upload(agx_unit *u) {
     if (u->arena.used()) do_release(u);              // uploaded before: start over (the unit's blocks go through the cache)
     const double t0 = now_ms();
     HIP_OK(hipSetDevice(u->prm.device));
-    const size_t n_pos = u->T.ref.size(), nh = u->nh;
+    const size_t n_pos = u->V.n_pos, nh = u->nh;
     u->arena.device = u->prm.device;
     u->n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
     u->n_regions = (u->n_tiles + AGX_REGION_TILES - 1) / AGX_REGION_TILES;
@@ -350,7 +456,7 @@ void do_upload(agx_unit *u) {
 void do_build(agx_unit *u) {
     if (!u->uploaded) do_upload(u);
     HIP_OK(hipSetDevice(u->prm.device));
-    const agx_u32 n_pos = (agx_u32)u->T.ref.size(), nh = (agx_u32)u->nh;
+    const agx_u32 n_pos = (agx_u32)u->V.n_pos, nh = (agx_u32)u->nh;
     hipStream_t st = nullptr;              // the device's build stream, taken with the turn
     u->stats.node_sweep_launches = u->stats.edge_sweep_launches = 0;
     for (int attempt = 0;; attempt++) {
@@ -453,7 +559,7 @@ void do_build(agx_unit *u) {
         C.abort = u->d_words.p + W_STATUS;
         C.a_mark = u->d_a_mark.p; C.side_xpos = u->d_side_xpos.p; C.sparse_min = (u->prm.flags & AGX_FLAG_SPARSE_MIN) ? 1u : 0u;
         C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p; C.sp_cap = u->sp_cap;
-        C.segs = u->d_segs.p; C.n_seg0 = u->T.n_seg0; C.cm_start = u->d_cm_start.p; C.sp_hop = u->d_sp_hop.p;
+        C.segs = u->d_segs.p; C.n_seg0 = u->n_seg0; C.cm_start = u->d_cm_start.p; C.sp_hop = u->d_sp_hop.p;
         if (g_scan1) agx_launch_exclusive_scan1(u->d_tile_side.p, u->d_tile_side_start.p, u->n_tiles, u->d_scan_desc.p + u->scan_desc_n, st);
         else agx_launch_exclusive_scan(u->d_tile_side.p, u->d_tile_side_start.p, u->n_tiles, u->d_scan_tmp.p, st);      // per tile: the sweep has scanned inside the tiles
         agx_launch_compact(&C, u->d_chain_end.p, u->n_chain_end, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
@@ -527,7 +633,7 @@ void do_download(agx_unit *u) {
     if (!u->built) do_build(u);
     HIP_OK(hipSetDevice(u->prm.device));             // the calling thread may never have touched this device
     const double t0 = now_ms();
-    const size_t n_pos = u->T.ref.size(), ni = u->n_ids;
+    const size_t n_pos = u->V.n_pos, ni = u->n_ids;
     hipStream_t st = u->st;
     const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
     u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(nside + 1);
@@ -557,7 +663,7 @@ void do_download(agx_unit *u) {
 // them without a driver call).  The inputs stay staged: the unit can be uploaded again as if it were new.
 void do_release(agx_unit *u) {
     const double tr0 = now_ms();
-    struct Tr { agx_unit *u; double t; ~Tr() { trace(u, "release", t, u->T.ref.size()); } } tr{u, tr0};
+    struct Tr { agx_unit *u; double t; ~Tr() { trace(u, "release", t, u->V.n_pos); } } tr{u, tr0};
     if (u->st) { (void)hipSetDevice(u->prm.device); (void)hipStreamSynchronize(u->st); }
     for (auto *b : {&u->d_cm_start, &u->d_tile_cnt, &u->d_tile_off, &u->d_cursor, &u->d_unsorted, &u->d_tile_recs, &u->d_scan_tmp, &u->d_words, &u->d_pool_cnt, &u->d_region_off, &u->d_node_start,
                     &u->d_slow_list, &u->d_rank4, &u->d_jump_list, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
@@ -588,7 +694,7 @@ void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u
 }
 
 GraphView view_of(agx_unit *u) {
-    GraphView G; G.n_pos = (agx_u32)u->T.ref.size(); G.n_ids = u->n_ids;
+    GraphView G; G.n_pos = (agx_u32)u->V.n_pos; G.n_ids = u->n_ids;
     G.meta = u->h_a_meta.p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
     G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.sp_hop = u->h_sp_hop.p; G.n_special = u->n_special;
     G.fetch = fetch_records; G.fetch_ctx = u;
@@ -738,6 +844,8 @@ int agx_unit_load_files_shared(agx_unit *u, const char *tmp_dir, int unit, const
     if (!u || !tmp_dir) return AGX_E_ARG;
     return guarded(u, [&] {
         const std::string d = tmp_dir, s = std::to_string(unit);
+        u->stats.from_cache = 0;
+        if (load_cache(u, d, unit)) return;               // the unit's staged form, written when the alignments were distributed (agx_unit_cache_build)
         double t0 = now_ms();
         u->T = Threads(); u->P = Pairs();
         load_unit_reference(d + "/_genome." + s + ".fa", u->T.ref);
@@ -749,6 +857,21 @@ int agx_unit_load_files_shared(agx_unit *u, const char *tmp_dir, int unit, const
         stage_inputs(u);
     });
 }
+
+int agx_unit_cache_build(const agx_params *p, const char *tmp_dir, int unit, const agx_reads *reads, char *err, size_t err_len) {
+    if (err && err_len) err[0] = 0;
+    if (!p || !tmp_dir) return AGX_E_ARG;
+    agx_unit *u = nullptr;
+    int rc = agx_unit_create(p, &u);
+    if (rc != AGX_OK) { if (err && err_len) snprintf(err, err_len, "%s", rc == AGX_E_NOGPU ? "no HIP device" : "bad parameters"); return rc; }
+    rc = agx_unit_load_files_shared(u, tmp_dir, unit, reads);      // (takes a current cache file if there is one)
+    if (rc == AGX_OK && !u->stats.from_cache) rc = guarded(u, [&] { save_cache(u, tmp_dir, unit); });
+    if (rc != AGX_OK && err && err_len) snprintf(err, err_len, "%s", agx_unit_error(u));
+    agx_unit_destroy(u);
+    return rc;
+}
+
+int agx_unit_cache_save(agx_unit *u, const char *tmp_dir, int unit) { if (!u || !tmp_dir) return AGX_E_ARG; return guarded(u, [&] { save_cache(u, tmp_dir, unit); }); }
 
 int agx_unit_stage(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { stage_inputs(u); }); }
 int agx_unit_upload(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_upload(u); }); }
@@ -763,10 +886,10 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
     return guarded(u, [&] {
         if (!u->downloaded) do_download(u);
         const double t0 = now_ms();
-        UnitOutput O; walk_join_scaffold(u->T, u->P, view_of(u), O);
+        UnitOutput O; walk_join_scaffold(u->V, view_of(u), O);
         u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = O.n_fetched;
-        trace(u, "walk", t0, u->T.ref.size());
-        r->initial_contigs = dup_buf(u->T.initial_contigs); r->initial_len = u->T.initial_contigs.size();
+        trace(u, "walk", t0, u->V.n_pos);
+        r->initial_contigs = dup_buf(std::string(u->V.initial, u->V.n_initial)); r->initial_len = u->V.n_initial;
         r->pre_len = O.pre_extended.n; r->pre_extended = O.pre_extended.release();
         r->extended_len = O.extended.n; r->extended = O.extended.release();
     });
@@ -777,9 +900,9 @@ void agx_result_free(agx_result *r) { if (!r) return; free(r->initial_contigs); 
 int agx_unit_stats(const agx_unit *u, agx_stats *s) {
     if (!u || !s) return AGX_E_ARG;
     *s = u->stats;
-    s->n_pos = u->T.ref.size(); s->n_ref = u->T.n_ref; s->n_hits = u->P.hits.size(); s->n_runs = u->P.runs.size(); s->pinned_bytes_cached = host_cache().held(); s->device_bytes_cached = dev_cache(u->prm.device).held(); s->n_nodes = u->n_nodes;
+    s->n_pos = u->staged ? u->V.n_pos : u->T.ref.size(); s->n_ref = u->staged ? u->V.n_ref : u->T.n_ref; s->n_hits = u->staged ? u->nh : u->P.hits.size(); s->n_runs = u->staged ? u->n_runs : u->P.runs.size(); s->pinned_bytes_cached = host_cache().held(); s->device_bytes_cached = dev_cache(u->prm.device).held(); s->n_nodes = u->n_nodes;
     s->n_tiles = u->n_tiles; s->n_tile_entries = u->n_tile_entries; s->n_big_tiles = u->n_big; s->n_mid_tiles = u->n_mid; s->n_edge_overflow = u->n_ovf;
-    s->pairs_in_file = u->P.n_pairs_in_file; s->sam_line_pairs = u->P.n_sam_pairs;
+    s->pairs_in_file = u->pairs_in_file; s->sam_line_pairs = u->sam_pairs;
     return AGX_OK;
 }
 
@@ -791,7 +914,7 @@ int agx_unit_graph(agx_unit *u, agx_graph *g) {
         HIP_OK(hipSetDevice(u->prm.device));
         HIP_OK(hipStreamSynchronize(u->st));
         // the pool has unused slots (one slice per region): the arrays come down whole, nodes are reached through node_start / node_cnt
-        const agx_u32 n_pos = (agx_u32)u->T.ref.size(), nn = u->n_nodes, cap = u->pool_cap;
+        const agx_u32 n_pos = (agx_u32)u->V.n_pos, nn = u->n_nodes, cap = u->pool_cap;
         std::vector<agx_u32> node_start(n_pos), cid(cap), coff(cap), cid0(cap), coff0(cap), off0(cap), next((size_t)cap * AGX_MAXE); std::vector<agx_u8> node_cnt(n_pos);
         std::vector<agx_sref> sref(cap); std::vector<int> counts; std::vector<agx_edge_ovf> ovf(u->n_ovf);
         HIP_OK(hipMemcpy(node_start.data(), u->d_node_start.p, (size_t)n_pos * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(node_cnt.data(), u->d_node_cnt.p, n_pos, hipMemcpyDeviceToHost));
@@ -860,6 +983,7 @@ int agx_run_unit_shared(const agx_params *p, const char *tmp_dir, int unit, int 
             write_file(d + "/_extended_contigs." + s + ".fa", std::string(r->extended, r->extended_len));
         });
     if (rc != AGX_OK && err && err_len) snprintf(err, err_len, "%s", agx_unit_error(u));
+    if (rc != AGX_OK && r) agx_result_free(r);          // (a failed write of the three files leaves nothing allocated behind)
     agx_unit_destroy(u);
     return rc;
 }

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <fcntl.h>
 #include <memory>
+#include <system_error>
 #include <thread>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -314,11 +315,17 @@ unsigned loader_threads(size_t bytes) {
     if (const char *e = getenv("AGX_LOAD_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(e)));      // tests force the multi-thread paths on small files
     return (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), bytes / (4u << 20) + 1);
 }
+// fn(t) on `threads` threads.  Nothing may leave a worker thread as an exception (it would terminate the process behind a C ABI that promises
+// return codes): whatever a worker throws is carried to the caller and rethrown there; a thread that cannot be started just leaves its
+// share to be done here.
 template <class F> void on_threads(unsigned threads, F fn) {
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < threads; t++) th.emplace_back(fn, t);
-    fn(0u);
+    std::vector<std::thread> th; std::vector<std::exception_ptr> ex(threads);
+    auto guarded = [&](unsigned t) { try { fn(t); } catch (...) { ex[t] = std::current_exception(); } };
+    std::vector<unsigned> mine{0u};
+    for (unsigned t = 1; t < threads; t++) { try { th.emplace_back(guarded, t); } catch (const std::system_error &) { mine.push_back(t); } }
+    for (unsigned t : mine) guarded(t);
     for (auto &x : th) x.join();
+    for (auto &e : ex) if (e) std::rethrow_exception(e);
 }
 
 struct ReadsIndex {

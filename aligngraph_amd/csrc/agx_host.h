@@ -47,6 +47,22 @@ struct Pairs {
     unsigned long long n_pairs_in_file = 0, n_sam_pairs = 0, n_kept = 0;
 };
 
+// What the host walk (and the engine's staging) reads of a loaded unit, wherever it lives: in the loader's containers (Threads / Pairs) or in
+// a mapped unit cache file (agx_engine.cpp).
+struct UnitView {
+    const char *ref = nullptr; size_t n_pos = 0; agx_u32 n_ref = 0;   // unit sequence + appended positions
+    const agx_u32 *cm_start = nullptr;                                // [n_pos + 1]
+    const char *chain_str = nullptr;                                  // conti-mer chain suffixes (agx_hop::str_off points in here)
+    const agx_hop *hop = nullptr;                                     // per-position hop table, or null: then GraphView::sp_hop is the only source
+    const char *bases = nullptr; agx_u32 stride = 0;                  // read bases, slot s at bases + s * stride (k-mer strings of written records)
+    const char *initial = nullptr; size_t n_initial = 0;              // bytes of tmp/_initial_contigs.<u>.fa
+};
+inline UnitView view_of(const Threads &T, const Pairs &P) {
+    UnitView V; V.ref = T.ref.data(); V.n_pos = T.ref.size(); V.n_ref = T.n_ref; V.cm_start = T.cm_start.data(); V.chain_str = T.chain_str.data();
+    V.hop = T.hop.size() == T.ref.size() ? T.hop.data() : nullptr; V.bases = P.bases.data(); V.stride = P.stride; V.initial = T.initial_contigs.data(); V.n_initial = T.initial_contigs.size();
+    return V;
+}
+
 // Walk graph as downloaded from the device (or produced by the test executor); see agx_core.h "walk preparation".
 // Walk ids: [0, n_pos) = first alive variant of each position (AGX_WM_ABSENT where there is none), [n_pos, n_ids) = further variants.
 // Node records come as the sparse table of the special ids; any other id (only reachable after the +1000 skip) goes through fetch().
@@ -58,7 +74,7 @@ struct GraphView {
     const unsigned long long *sp_bits = nullptr;            // [n_ids/64 + 1] special-id bitmap
     const agx_u32 *sp_rank = nullptr;                       // [n_ids/64 + 1] special ids before each 64-id word
     const agx_walknode *sp_node = nullptr; agx_u32 n_special = 0;   // records of the special ids, id order
-    const agx_hop *sp_hop = nullptr;                        // [n_special] hop entry of each special id's position (optional: else Threads::hop)
+    const agx_hop *sp_hop = nullptr;                        // [n_special] hop entry of each special id's position (optional: else UnitView::hop)
     // records of non-special ids: `rows` groups of `width` consecutive ids, group r starting at first + r*stride, into out[rows*width]
     void (*fetch)(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *out) = nullptr; void *fetch_ctx = nullptr;
     const agx_edge_ovf *ovf = nullptr; size_t n_ovf = 0;     // walk ids; NONE/NONE entries and duplicates are ignored
@@ -97,6 +113,6 @@ void reads_index_close(ReadsIndex *);
 void load_pairs_from_files(const std::string &reads_fa, const std::string &sam, long batch, agx_u32 k, Pairs &P, const ReadsIndex *reads = nullptr);
 
 // agx_walk.cpp
-void walk_join_scaffold(const Threads &T, const Pairs &P, const GraphView &G, UnitOutput &out);
+void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out);
 
 }  // namespace agx

@@ -123,10 +123,10 @@ inline run_end_fn pick_run_end() {
 }
 
 struct Walker {
-    const Threads &T; const Pairs &P; const GraphView &G;
+    const UnitView &V; const GraphView &G;
     std::vector<agx_u8> done;                       // traversed flag per ALIVE node (pruned nodes never reach the host)
     std::vector<agx_edge_ovf> ovf;                  // sorted, unique
-    Walker(const Threads &t, const Pairs &p, const GraphView &g) : T(t), P(p), G(g) {
+    Walker(const UnitView &v, const GraphView &g) : V(v), G(g) {
         done.reserve((size_t)g.n_ids + 72); advise_huge(done.data(), done.capacity());
         done.resize((size_t)g.n_ids + 72, 1);
         for (size_t i = 0; i < g.n_ids; i++) done[i] = g.meta[i] >> 7;     // ids without a node count as visited; the tail is a sentinel
@@ -147,7 +147,9 @@ struct Walker {
     // instead of a random access into the per-position table
     agx_hop hop_of(agx_u32 v, agx_u32 x) const {
         const agx_u32 r = G.sp_hop ? rank_of(v) : AGX_NONE;
-        return r != AGX_NONE ? G.sp_hop[r] : T.hop[x];
+        if (r != AGX_NONE) return G.sp_hop[r];
+        if (!V.hop) throw Error{E_ARG, "no hop entry for a position outside the sparse table"};
+        return V.hop[x];
     }
     agx_walknode node(agx_u32 v) const {
         const agx_u32 at = rank_of(v);
@@ -199,7 +201,7 @@ struct Walker {
         const agx_sref r = node(v).sref;
         const agx_u32 first = r.qlen & 0xFFFFu, len = (r.qlen >> 16) & 0x7FFFu; const bool rev = (r.qlen >> 31) != 0;
         out.clear();
-        const char *p = P.bases.data() + (size_t)(G.row_slot ? G.row_slot[r.slot] : r.slot) * P.stride;
+        const char *p = V.bases + (size_t)(G.row_slot ? G.row_slot[r.slot] : r.slot) * V.stride;
         for (agx_u32 i = 0; i < len; i++) {
             if (!rev) out.push_back(p[first + i]);
             else { const char c = p[first - i]; out.push_back(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c); }
@@ -213,7 +215,7 @@ struct Walker {
 // extdContigs1, AG:1954-2204, replayed on the alive-compacted graph.  Alive ids are position-major, so "for every
 // position, for every variant, if untraversed" (AG:1972-1978) is "for every alive id in order, if not done".
 void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
-    const GraphView &G = W.G; const Threads &T = W.T;
+    const GraphView &G = W.G; const UnitView &V = W.V;
     agx_u32 seqID = 0, sIDBak = AGX_NONE, sOffBak = AGX_NONE, eIDBak = AGX_NONE, eOffBak = AGX_NONE;
     agx_u32 pos_bak = 0;                         // cppBak of the reference (function scope)
     std::string kmer; agx_u32 klen = 0, klast = 0;
@@ -247,7 +249,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
                     // the whole conti-mer chain in one segment (the reference steps through it one base at a time), then its end:
                     // hop back onto the k-mer graph only through the single live node there and its single live edge (AG:2093-2136)
                     AGX_PT(7); const agx_hop h = hcur;
-                    segs.push_back(Seg{T.chain_str.data() + h.str_off, h.len}); C.extended = 1; n_hops++;
+                    segs.push_back(Seg{V.chain_str + h.str_off, h.len}); C.extended = 1; n_hops++;
                     pos_bak = h.end_pos; cpp = h.end_pos;
                     agx_u32 live = 0, item = 0;
                     if (!done[cpp]) { live++; item = cpp; }
@@ -376,7 +378,7 @@ inline int overlaps(agx_u32 x1, agx_u32 y1, agx_u32 x2, agx_u32 y2) {      // AG
 }
 
 // scaffoldContigs, AG:2396-2464
-void scaffold(const Threads &T, const GraphView &G, std::vector<Rec> &c, OutBuf &out) {
+void scaffold(const UnitView &V, const GraphView &G, std::vector<Rec> &c, OutBuf &out) {
     std::vector<std::string> sc;
     const agx_u32 n = (agx_u32)c.size();
     for (agx_u32 cp = 0; cp < n; cp++) {
@@ -389,8 +391,8 @@ void scaffold(const Threads &T, const GraphView &G, std::vector<Rec> &c, OutBuf 
                 if (!(c[cp].eID0 == c[q].sID && c[q].sID == c[q].eID && overlaps(c[cp].sOff0, c[cp].eOff0, c[q].sOff, c[q].eOff) && c[q].extended == 1)) continue;
                 if (c[q].sOff > c[cp].eOff) {
                     const agx_u32 gap = c[q].sOff - c[cp].eOff - 1; agx_u32 covered = 0;
-                    for (agx_u32 i = 0; i < gap; i++) { const agx_u32 x = c[cp].eOff + i + 1; if ((G.meta[x] & AGX_WM_ANY) || T.cm_start[x + 1] > T.cm_start[x]) covered++; }
-                    if (gap == 0 || (double)(int)covered / gap >= 0.5) sc.back().append(T.ref, c[cp].eOff + 1, gap);
+                    for (agx_u32 i = 0; i < gap; i++) { const agx_u32 x = c[cp].eOff + i + 1; if ((G.meta[x] & AGX_WM_ANY) || V.cm_start[x + 1] > V.cm_start[x]) covered++; }
+                    if (gap == 0 || (double)(int)covered / gap >= 0.5) sc.back().append(V.ref + c[cp].eOff + 1, gap);
                     else continue;
                 }
                 sc.back() += c[q].nuc; c[q].sID = AGX_NONE; cp = q; cont = true;
@@ -463,9 +465,9 @@ void build_chains(Threads &T) {
     if (e != n) throw Error{E_ARG, "conti-mer runs do not cover the conti-mers"};
 }
 
-void walk_join_scaffold(const Threads &T, const Pairs &P, const GraphView &G, UnitOutput &out) {
-    if (T.hop.size() != T.ref.size()) throw Error{E_ARG, "conti-mer chains were not built"};
-    Walker W(T, P, G);
+void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out) {
+    if (!V.hop && !G.sp_hop) throw Error{E_ARG, "conti-mer chains were not built"};
+    Walker W(V, G);
     std::vector<Rec> recs;
     const bool timing = getenv("AGX_WALK_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -474,7 +476,7 @@ void walk_join_scaffold(const Threads &T, const Pairs &P, const GraphView &G, Un
     double t1 = now();
     join(recs);
     double t2 = now();
-    scaffold(T, G, recs, out.extended);
+    scaffold(V, G, recs, out.extended);
     double t3 = now();
     out.n_fetched = W.n_fetched;
     if (timing) fprintf(stderr, "[agx walk] walk %.1f ms, join %.1f ms, scaffold %.1f ms, %zu records, %u special ids of %u, %llu records fetched\n", t1 - t0, t2 - t1, t3 - t2, recs.size(), G.n_special, G.n_ids, W.n_fetched);

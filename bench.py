@@ -168,16 +168,26 @@ def main():
     n_units = len(unit_len)
     mine = shard.plan(unit_len, rank, world)                               # longest-first onto the least loaded rank, longest first within the rank
     reads = A.Reads(os.path.join(tmp, "_reads.fa")) if mine else None      # tmp/_reads.fa mapped and indexed once for all units (agx_reads)
-    units, t_parse, t_stage = {}, 0.0, 0.0
+    units, t_parse, t_stage, t_cached = {}, 0.0, 0.0, 0.0
     for uu in mine:
         un = A.Unit(k=k, insert_variation=50, coverage=args.coverage, device=local_rank)
+        os.environ["AGX_NO_CACHE"] = "1"
         t1 = time.perf_counter()
         un.load_files(tmp, uu, reads=reads)                                # text -> packed arrays, staged in pinned memory (T_unit - T_core)
         t_parse += time.perf_counter() - t1
+        del os.environ["AGX_NO_CACHE"]
         t_stage += un.stats()["ms_stage"] * 1e-3
-        units[uu] = un
+        un.cache_save(tmp, uu)                                             # the unit's binary cache (what AlignGraph_amd writes when it distributes the alignments)
+        un.close()
     if reads is not None:
         reads.close()
+    for uu in mine:                                                        # the units the timed steps run: loaded from their cache files
+        un = A.Unit(k=k, insert_variation=50, coverage=args.coverage, device=local_rank)
+        t1 = time.perf_counter()
+        un.load_files(tmp, uu)
+        t_cached += time.perf_counter() - t1
+        assert un.stats()["from_cache"] == 1
+        units[uu] = un
     my_pairs = sum(units[uu].stats()["sam_line_pairs"] for uu in mine)
 
     inflight = args.inflight or min(8, max(1, len(mine)))
@@ -230,14 +240,14 @@ def main():
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    tot = torch.tensor([elapsed, t_parse, t_stage, float(my_pairs)], dtype=torch.float64, device=gdev)
+    tot = torch.tensor([elapsed, t_parse, t_stage, float(my_pairs), t_cached], dtype=torch.float64, device=gdev)
     if dist:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed, t_parse_max = float(mx[0].item()), float(mx[1].item())
+        elapsed, t_parse_max, t_cached_max = float(mx[0].item()), float(mx[1].item()), float(mx[4].item())
     else:
-        t_parse_max = t_parse
+        t_parse_max, t_cached_max = t_parse, t_cached
     sam_pairs_total = int(tot[3].item())
 
     A.pool_trim(-1, host=True)
@@ -334,6 +344,9 @@ def main():
             "t_unit_s": round(sec_per_step + t_parse_max, 4),
             "t_unit_note": "t_core_s + text parsing and staging of the per-unit input files (slowest rank, units parsed one after another on up to 8 threads: %.2f s)" % t_parse_max,
             "value_t_unit": round(reads_per_step / (sec_per_step + t_parse_max), 1),
+            "t_unit_cached_s": round(sec_per_step + t_cached_max, 4),
+            "t_unit_cached_note": "t_core_s + loading every unit from its binary cache file (tmp/_agx_unit.<u>.bin, written where the alignments are distributed; one unit after another: %.3f s) instead of parsing text — what the timed steps' units were loaded from" % t_cached_max,
+            "value_t_unit_cached": round(reads_per_step / (sec_per_step + t_cached_max), 1),
             "roofline": {"bound": "hbm", "kernel": "agx_k_node_sweep<0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "achieved_note": "SURVEY 8(d) model: algorithmic bytes of rank 0's units / HIP-event time of their node sweeps in the last timed step; NOT measured HBM bandwidth",

@@ -106,7 +106,8 @@ typedef struct {
     uint64_t upload_bytes, device_bytes;                         /* bytes copied host -> HBM by the upload; HBM held by the unit */
     uint64_t pinned_bytes_cached, device_bytes_cached;           /* free blocks in the library's pinned-host and device caches (agx_pool_trim releases them) */
     uint64_t n_spilled;                                          /* node ids taken from the pool's spill area (regions whose slice was full) */
-    uint32_t build_attempts, pad_;                               /* 1 unless a capacity had to grow and the build was repeated */
+    uint32_t build_attempts, from_cache;                         /* build_attempts: 1 unless a capacity had to grow and the build was repeated; from_cache: the unit was
+                                                                    loaded from its cache file (agx_unit_cache_build), not from the text files */
 } agx_stats;
 
 /* Node/edge tables in canonical numbering (position-major, variant order), for parity tests. malloc'd; free with agx_graph_free. */
@@ -148,6 +149,13 @@ typedef struct agx_reads agx_reads;
 int agx_reads_open(const char *reads_fa, agx_reads **out, char *err, size_t err_len);
 void agx_reads_close(agx_reads *reads);
 int agx_unit_load_files_shared(agx_unit *u, const char *tmp_dir, int unit, const agx_reads *reads);   /* reads == NULL: same as agx_unit_load_files */
+
+/* The binary cache of a unit's parsed inputs: tmp_dir/_agx_unit.<unit>.bin holds the unit's staged arrays, made from the
+ * five text files once — AlignGraph_amd does it where the reference distributes the alignments (AG:3545-3579).  agx_unit_load_files* take
+ * the cache instead of the text whenever it is current (same BATCH, the text files unchanged in size and modification time; AGX_NO_CACHE=1 in
+ * the environment turns that off).  p: only batch and device matter. */
+int agx_unit_cache_build(const agx_params *p, const char *tmp_dir, int unit, const agx_reads *reads, char *err, size_t err_len);
+int agx_unit_cache_save(agx_unit *u, const char *tmp_dir, int unit);   /* the same file from a unit that agx_unit_load_files has just loaded from the text of (tmp_dir, unit) */
 
 int agx_unit_stage(agx_unit *u);                 /* packs what was handed over into pinned upload buffers (read bases as 4-bit classes); done by agx_unit_load_files,
                                                     implied by agx_unit_upload after agx_unit_push_pairs */

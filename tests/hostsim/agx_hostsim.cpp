@@ -254,10 +254,10 @@ int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int cover
         G.ovf = S.a_ovf.data(); G.n_ovf = S.ovf.size();
         if (const char *rep = getenv("AGX_WALK_REPEAT")) {           // walk micro-benchmark: best of N on an already built graph
             double best = 1e30;
-            for (int i = 0; i < atoi(rep); i++) { UnitOutput Q; const auto t0 = std::chrono::steady_clock::now(); walk_join_scaffold(T, P, G, Q); const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); if (ms < best) best = ms; }
+            for (int i = 0; i < atoi(rep); i++) { UnitOutput Q; const auto t0 = std::chrono::steady_clock::now(); walk_join_scaffold(view_of(T, P), G, Q); const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); if (ms < best) best = ms; }
             fprintf(stderr, "[hostsim] walk+join+scaffold best of %s: %.2f ms\n", rep, best);
         }
-        UnitOutput O; walk_join_scaffold(T, P, G, O);
+        UnitOutput O; walk_join_scaffold(view_of(T, P), G, O);
         out->initial_contigs = dup_buf(T.initial_contigs); out->initial_len = T.initial_contigs.size();
         out->pre_len = O.pre_extended.n; out->pre_extended = O.pre_extended.release();
         out->extended_len = O.extended.n; out->extended = O.extended.release();

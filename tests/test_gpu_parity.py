@@ -257,3 +257,40 @@ def test_empty_and_ragged_inputs(agx, built, tmp_path):
     run2 = H.synth(str(tmp_path / "run2"), seed=10, chroms="6000", pairs=300, L=40, coverage=2, sam_seq=0)
     b = run_engine(agx, os.path.join(run2, "tmp"), 0, 40, 50, 2, graph=True)
     assert b["graph"]["n_nodes"] == 0
+
+
+def test_unit_cache_file_replaces_the_text(agx, built, tmp_path, monkeypatch):
+    """tmp/_agx_unit.<u>.bin holds a unit's staged arrays; load_files takes it instead of the five text files as long as it
+    is current, and falls back to the text when a source file changed, when the batch size differs or when the file is damaged."""
+    run = H.synth(str(tmp_path / "run"), seed=41, chroms="50000,30000", pairs=16000, coverage=4, read_indel=0.2, multi=0.2, contig_overlap=0.3, sam_seq=0)
+    tmp = os.path.join(run, "tmp")
+    want = [H.run_oracle(tmp, uu, 5, 50, 4) for uu in range(2)]
+
+    def load_and_run(uu, batch=0):
+        with agx.Unit(k=5, insert_variation=50, coverage=4, batch=batch) as u:
+            u.load_files(tmp, uu)
+            st0 = u.stats()
+            u.upload(); u.build()
+            got = u.finish()
+            for key in ("initial", "pre", "extended"):
+                assert got[key] == want[uu][key], key
+            return st0
+    assert load_and_run(0)["from_cache"] == 0
+    agx.cache_build(tmp, 0)                                  # from the text, as AlignGraph_amd does after the aligners
+    with agx.Unit(k=5, insert_variation=50, coverage=4) as u:   # ... or from a unit that has just parsed the text
+        u.load_files(tmp, 1)
+        u.cache_save(tmp, 1)
+    for uu in range(2):
+        st = load_and_run(uu)
+        assert st["from_cache"] == 1 and st["ms_parse"] == 0 and st["n_hits"] > 0 and st["sam_line_pairs"] > 0
+    assert load_and_run(0, batch=5000)["from_cache"] == 0    # another BATCH keeps other pairs (AG:1258-1259): not this cache
+    monkeypatch.setenv("AGX_NO_CACHE", "1")
+    assert load_and_run(0)["from_cache"] == 0
+    monkeypatch.delenv("AGX_NO_CACHE")
+    sam = os.path.join(tmp, "_reads_genome.0.bowtie")
+    os.utime(sam, ns=(os.stat(sam).st_atime_ns, os.stat(sam).st_mtime_ns + 10**9))      # a source file touched: stale
+    assert load_and_run(0)["from_cache"] == 0 and load_and_run(1)["from_cache"] == 1
+    path = os.path.join(tmp, "_agx_unit.1.bin")
+    with open(path, "r+b") as f:
+        f.truncate(os.path.getsize(path) // 2)                # damaged
+    assert load_and_run(1)["from_cache"] == 0
