@@ -53,6 +53,7 @@ typedef uint8_t agx_u8;
 #endif
 #define AGX_MAXV_MID 4u       // pass 1, LDS again (13 KB per wavefront): the widest bucket whose x -> x+1 edges still fit the sweep's edge matrix
 #define AGX_MAXV_BIG 64u      // pass 2: buckets in global scratch
+#define AGX_MAXV_HUGE 255u    // pass 3, queued only for a unit that has met a position beyond 64 variants: as many as node_cnt (one byte) can count
 #define AGX_MAXE 4u           // out-edges stored inline per node; more go to the overflow list
 #define AGX_EP25 25           // 5*EP (AG:39, 1296)
 

@@ -97,7 +97,7 @@ struct agx_unit {
     DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
     DBuf<agx_u32> d_node_start, d_slow_list, d_rank4; DBuf<agx_u8> d_node_cnt, d_pos_succ; DBuf<agx_u32> d_jump_list;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
-    DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch;
+    DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch, d_huge_list, d_scratch_huge; bool huge = false;      // huge: pass 3 of the node sweep is queued (a build met a position beyond AGX_MAXV_BIG variants)
     // walk graph (agx_core.h "walk preparation")
     agx_u32 n_ids = 0;
     DBuf<agx_u32> d_side_pk, d_tile_side, d_tile_side_start, d_aid_of; DBuf<char> d_a_str;
@@ -147,7 +147,7 @@ static const bool g_debug_sync = getenv("AGX_DEBUG_SYNC") != nullptr;
 #define g_tiny (getenv("AGX_TEST_SMALL_CAPS") != nullptr)
 #define AGX_CHECKPOINT(name) do { if (g_debug_sync) { hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, "[agx debug] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
 
-enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_RANKOVF = 6, W_MIDCOUNT = 7, W_JUMPCOUNT = 8, W_SPILL = 9, W_N = 10 };
+enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_RANKOVF = 6, W_MIDCOUNT = 7, W_JUMPCOUNT = 8, W_SPILL = 9, W_HUGECOUNT = 10, W_N = 11 };
 
 void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     memset(&S, 0, sizeof S);
@@ -519,12 +519,14 @@ void do_build(agx_unit *u) {
         K.big_count = u->d_words.p + W_BIGCOUNT; K.big_list = u->d_big_list.p; K.status = u->d_words.p + W_STATUS;
         K.list_cap = u->list_cap; K.big_n = u->d_words.p + W_BIGCOUNT; K.scratch = u->d_scratch.p;
         K.slow_list = u->d_slow_list.p; K.slow_count = u->d_words.p + W_SLOWCOUNT; K.fallback_queued = 1u;
+        K.huge_count = u->d_words.p + W_HUGECOUNT; K.huge_n = u->d_words.p + W_HUGECOUNT; K.huge_list = u->d_huge_list.p; K.scratch_huge = u->d_scratch_huge.p; K.huge_queued = u->huge ? 1u : 0u;
         agx_launch_node_sweep(&K, st);
         AGX_CHECKPOINT("node_sweep");
         u->ev.mark(B_NODE, st); u->stats.node_sweep_launches++;
         hipEvent_t trace_from = turn.prev_node; turn.prev_node = u->ev.e[B_NODE];
         HIP_OK(hipEventRecord(turn.sweep_done[turn.n & 1], st));
         agx_launch_node_sweep_big(&K, st);      // the two fallback passes: they find their (usually empty) tile lists on the device.  A unit is built once, so they
+        if (u->huge) agx_launch_node_sweep_huge(&K, st);
         AGX_CHECKPOINT("node_sweep_big");       // are always queued: two idle launches cost less than repeating the build of a unit that turns out to need them
         u->ev.mark(B_BIG, st);
         // ---- edge sweep ----
@@ -595,7 +597,11 @@ void do_build(agx_unit *u) {
         bool again = false;
         if (u->n_tile_entries > u->list_cap) { alloc_lists(u, u->n_tile_entries + u->n_tile_entries / 8 + 1024); again = true; }
         else {
-            if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 64 node variants at one position"};
+            if ((w[W_STATUS] & 2u) && !u->huge) {     // a position beyond the 64 variants of pass 2 (deep repeats under a wide --distanceHigh): queue pass 3 and build again
+                u->huge = true; u->d_huge_list.alloc(u->arena, (size_t)u->n_tiles + 1); u->d_scratch_huge.alloc(u->arena, (size_t)AGX_HUGE_WAVES * AGX_NF * AGX_MAXV_HUGE * 64);
+                HIP_OK(hipEventRecord(u->ev_uploaded, u->st)); continue;
+            }
+            if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 255 node variants at one position"};
             if (w[W_STATUS] & 1u) {                  // the node pool ran out: cut the slices to what the regions asked for
                 std::vector<agx_u32> padded((size_t)u->n_regions * AGX_REGION_PAD), demand(u->n_regions);
                 HIP_OK(hipMemcpyAsync(padded.data(), u->d_pool_cnt.p, padded.size() * 4, hipMemcpyDeviceToHost, u->st)); HIP_OK(hipStreamSynchronize(u->st));
@@ -670,7 +676,7 @@ void do_release(agx_unit *u) {
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     for (auto *b : {&u->d_node_cnt, &u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
     u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_sp_hop.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
-    u->d_ovf.release(); u->d_a_ovf.release(); u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
+    u->d_ovf.release(); u->d_a_ovf.release(); u->d_huge_list.release(); u->d_scratch_huge.release(); u->huge = false; u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
     u->arena.reset();
     u->h_a_str.release(); u->h_a_meta.release(); u->h_side_xpos.release(); u->h_sp_rank.release(); u->h_sp_bits.release(); u->h_sp_node.release(); u->h_fetch.release(); u->h_a_ovf.release();
     u->h_sp_hop.release();

@@ -29,6 +29,7 @@ struct agx_node_kargs {
     const agx_u32 *big_n;      // passes 1 and 2: number of tiles in mid_list / big_list, read on the device (no host round trip)
     const agx_u32 *mid_n;
     agx_u32 *scratch;          // fallback pass: one [AGX_NF*AGX_MAXV_BIG*64] bucket area per resident wavefront
+    agx_u32 *huge_count; agx_u32 *huge_list; const agx_u32 *huge_n; agx_u32 *scratch_huge; agx_u32 huge_queued;   // pass 3 (AGX_MAXV_HUGE variants): tiles pass 2 gave up on
     agx_u32 *slow_list; agx_u32 *slow_count;   // the edge build's pass-B list: the sweep itself enters multi-variant positions with a position-skipping step
 };
 
@@ -71,4 +72,6 @@ void agx_launch_special(const agx_compact_args *, agx_u32 n_words, agx_u32 *sp_r
                         agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, hipStream_t);
 #define AGX_MID_WAVES 3072u     // wavefronts of pass 1 (3 per SIMD fit its LDS buckets); they stride over the list of tiles pass 0 gave up on
 #define AGX_BIG_WAVES 256u      // resident wavefronts of the global-scratch fallback pass
+#define AGX_HUGE_WAVES 32u      // wavefronts of pass 3 (0.85 MB of scratch each)
+void agx_launch_node_sweep_huge(const agx_node_kargs *, hipStream_t);
 }

@@ -287,9 +287,11 @@ __device__ __forceinline__ agx_u32 agx_wave_incl_scan(agx_u32 v, agx_u32 lane) {
     return v;
 }
 
-template <int PASS>      // 0: every tile, AGX_MAXV_LDS variants in LDS; 1: the tiles pass 0 gave up on, AGX_MAXV_MID in LDS; 2: the rest, AGX_MAXV_BIG in global scratch
+template <int PASS>      // 0: every tile, AGX_MAXV_LDS variants in LDS; 1: the tiles pass 0 gave up on, AGX_MAXV_MID in LDS; 2: the rest, AGX_MAXV_BIG in global scratch;
+                         // 3: what even that cannot hold, AGX_MAXV_HUGE in global scratch (only queued for units that need it)
 __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_node_kargs K) {
-    constexpr bool BIG = PASS == 2;
+    constexpr bool BIG = PASS >= 2;
+    constexpr agx_u32 MAXV_G = PASS == 3 ? AGX_MAXV_HUGE : AGX_MAXV_BIG;
     constexpr agx_u32 MAXV = PASS == 0 ? AGX_MAXV_LDS : AGX_MAXV_MID;
     __shared__ agx_u32 lds[BIG ? 1 : AGX_SWEEP_WAVES][BIG ? 1 : AGX_NF * MAXV * 64];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -300,12 +302,12 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
     if (PASS == 0) { const agx_u32 share = (gridDim.x + AGX_XCDS - 1) / AGX_XCDS; blk = (blockIdx.x % AGX_XCDS) * share + blockIdx.x / AGX_XCDS; }
     const agx_u32 slot = __builtin_amdgcn_readfirstlane(blk * AGX_SWEEP_WAVES + wave);
     agx_bucket b; b.stride = 64;
-    if (BIG) { b.base = K.scratch + (size_t)slot * (AGX_NF * AGX_MAXV_BIG * 64) + lane; b.maxv = AGX_MAXV_BIG; }
+    if (BIG) { b.base = (PASS == 3 ? K.scratch_huge : K.scratch) + (size_t)slot * (AGX_NF * MAXV_G * 64) + lane; b.maxv = MAXV_G; }
     else { b.base = &lds[wave][lane]; b.maxv = MAXV; }
     // pass 0: one tile per wavefront.  Passes 1 and 2: a fixed set of wavefronts strides over the list of overflowed tiles.
-    const agx_u32 n_work = PASS == 0 ? K.S.n_tiles : __builtin_amdgcn_readfirstlane(*(PASS == 1 ? K.mid_n : K.big_n));
-    for (agx_u32 w = slot; w < n_work; w += PASS == 0 ? 0xFFFFFFFFu : PASS == 1 ? AGX_MID_WAVES : AGX_BIG_WAVES) {
-        const agx_u32 tile = PASS == 0 ? w : __builtin_amdgcn_readfirstlane((PASS == 1 ? K.mid_list : K.big_list)[w]);
+    const agx_u32 n_work = PASS == 0 ? K.S.n_tiles : __builtin_amdgcn_readfirstlane(*(PASS == 1 ? K.mid_n : PASS == 2 ? K.big_n : K.huge_n));
+    for (agx_u32 w = slot; w < n_work; w += PASS == 0 ? 0xFFFFFFFFu : PASS == 1 ? AGX_MID_WAVES : PASS == 2 ? AGX_BIG_WAVES : AGX_HUGE_WAVES) {
+        const agx_u32 tile = PASS == 0 ? w : __builtin_amdgcn_readfirstlane((PASS == 1 ? K.mid_list : PASS == 2 ? K.big_list : K.huge_list)[w]);
         if (K.S.tile_off[tile + 1] > K.list_cap) { if (lane == 0) atomicOr(K.status, 4u); return; }      // lists did not fit: nothing after the sweeps may run
         const agx_u32 X = tile * AGX_TILE + lane;
         agx_u32 cnt = 0, pflag = 0, emask = 0;
@@ -318,7 +320,8 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
         });
         if (__ballot(!ok) != 0ull) {                       // wave-uniform
             if (lane == 0) {
-                if (BIG) atomicOr(K.status, 2u);
+                if (PASS == 3 || (PASS == 2 && !K.huge_queued)) atomicOr(K.status, 2u);      // beyond every bucket that is queued: the host queues pass 3 and repeats, or gives up
+                else if (PASS == 2) K.huge_list[atomicAdd(K.huge_count, 1u)] = tile;
                 else if (PASS == 1) K.big_list[atomicAdd(K.big_count, 1u)] = tile;
                 else { K.mid_list[atomicAdd(K.mid_count, 1u)] = tile; if (!K.fallback_queued) atomicOr(K.status, 8u); }      // nobody will sweep it again in this build
             }
@@ -591,6 +594,9 @@ void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
 void agx_launch_node_sweep_big(const agx_node_kargs *K, hipStream_t st) {
     hipLaunchKernelGGL(agx_k_node_sweep<1>, dim3(AGX_MID_WAVES / AGX_SWEEP_WAVES), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
     hipLaunchKernelGGL(agx_k_node_sweep<2>, dim3(AGX_BIG_WAVES / AGX_SWEEP_WAVES), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
+}
+void agx_launch_node_sweep_huge(const agx_node_kargs *K, hipStream_t st) {
+    hipLaunchKernelGGL(agx_k_node_sweep<3>, dim3(AGX_HUGE_WAVES / AGX_SWEEP_WAVES), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);
 }
 void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;

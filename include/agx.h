@@ -37,7 +37,7 @@ extern "C" {
 #define AGX_E_ALIGNMENT (-4)   /* "BOWTIE ALIGNMENT ERROR" (mates on the same strand)    AG:1669 */
 #define AGX_E_DEVICE (-5)      /* HIP runtime error */
 #define AGX_E_ARG (-6)
-#define AGX_E_OVERFLOW (-7)    /* more than 64 node variants at one position */
+#define AGX_E_OVERFLOW (-7)    /* more than 255 node variants at one position (the reference's vector<KMer> is unbounded, AG:1375-1390) */
 #define AGX_E_NOGPU (-8)
 
 typedef struct agx_unit agx_unit;

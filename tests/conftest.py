@@ -73,3 +73,30 @@ def graph_mismatch(go, gs, counts=True):
     if not np.array_equal(go["edge_start"], gs["edge_start"]) or not np.array_equal(canon(go), canon(gs)):
         return "edges"
     return None
+
+
+def write_pileup_unit(run, n_pairs, spacing=300, genome_len=60000, seed=5):
+    """A hand-made unit (no contigs) in which `n_pairs` pairs share ONE left-mate alignment while their right mates lie `spacing` apart:
+    at each of the ~96 positions of the left mate every pair adds a node variant of its own (the mate positions differ by more than
+    2 * insertVariation + 25, AG:1296-1307) — what deep repeats under a wide --distanceHigh do.  Returns the tmp/ directory."""
+    import random
+    rnd = random.Random(seed)
+    tmp = os.path.join(run, "tmp")
+    os.makedirs(tmp, exist_ok=True)
+    g = "".join(rnd.choice("ACGT") for _ in range(genome_len))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    with open(os.path.join(tmp, "_genome.0.fa"), "w") as f:
+        f.write(">0\n" + "".join(g[i:i + 60] + "\n" for i in range(0, genome_len, 60)))
+    open(os.path.join(tmp, "_contigs.fa"), "w").close()
+    open(os.path.join(tmp, "_contigs_genome.0.psl"), "w").close()
+    left = 1000
+    with open(os.path.join(tmp, "_reads.fa"), "w") as rf, open(os.path.join(tmp, "_reads_genome.0.bowtie"), "w") as sf:
+        for i in range(n_pairs):
+            right = 2000 + spacing * i
+            assert right + 100 <= genome_len
+            m1 = g[left:left + 100]
+            m2 = "".join(comp[c] for c in reversed(g[right:right + 100]))
+            rf.write(">%d\n%s\n>%d\n%s\n" % (i, m1, i, m2))
+            sf.write("%d\t99\t0\t%d\t42\t100M\t=\t%d\t%d\t*\t*\n" % (i, left + 1, right + 1, right + 100 - left))
+            sf.write("%d\t147\t0\t%d\t42\t100M\t=\t%d\t%d\t*\t*\n" % (i, right + 1, left + 1, -(right + 100 - left)))
+    return tmp
