@@ -315,7 +315,8 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                per_entry = json.load(open(pmc)).get("node_sweep_bytes_per_tile_entry")      # measured HBM bytes of the sweep per (tile, hit) list entry
+                tab = json.load(open(pmc))      # measured HBM bytes of the sweep per (tile, hit) list entry, for this configuration if it was profiled
+                per_entry = tab.get("node_sweep_bytes_per_tile_entry_by_config", {}).get(args.config, tab.get("node_sweep_bytes_per_tile_entry"))
                 entries = sum(unit_stats[uu]["n_tile_entries"] for uu in mine)
                 if per_entry:
                     traffic = int(per_entry * entries)
