@@ -95,7 +95,7 @@ struct agx_unit {
     // node table
     agx_u32 pool_cap = 0, spill_lo = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
     DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
-    DBuf<agx_u32> d_node_start, d_slow_list, d_rank4; DBuf<agx_u8> d_node_cnt, d_pos_succ; DBuf<agx_u32> d_jump_list;
+    DBuf<agx_u32> d_node_start, d_slow_list, d_rank4; DBuf<agx_u8> d_node_cnt, d_pos_succ;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch, d_huge_list, d_scratch_huge; bool huge = false;      // huge: pass 3 of the node sweep is queued (a build met a position beyond AGX_MAXV_BIG variants)
     // walk graph (agx_core.h "walk preparation")
@@ -403,7 +403,7 @@ void do_upload(agx_unit *u) {
     u->d_cm_start.alloc(a, n_pos + 2); u->d_cm_cnt.alloc(a, n_pos + 2); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos); u->d_cm_head.alloc(a, n_pos + 1);
     u->d_segs.alloc(a, u->n_segs + 1); u->d_up_desc.alloc(a, (n_pos + 2) / 4096 + 2);
     u->d_hits.alloc(a, nh + 1); u->d_runs.alloc(a, u->n_runs + 1); u->d_codes.alloc(a, u->n_codes + 16); u->d_vcodes.alloc(a, n_bases + 16);
-    u->d_dhit.alloc(a, nh + 1); u->d_rank4.alloc(a, 4 * (nh + 1)); u->d_jump_list.alloc(a, nh + 1);
+    u->d_dhit.alloc(a, nh + 1); u->d_rank4.alloc(a, 4 * (nh + 1));
     u->d_tile_cnt.alloc(a, (size_t)u->n_tiles + 1); u->d_tile_off.alloc(a, (size_t)u->n_tiles + 2); u->d_cursor.alloc(a, (size_t)u->n_tiles + 1);
     u->d_words.alloc(a, W_N + 6 + 16); u->h_words.alloc(W_N + 6 + 16);
     u->d_chain_end.alloc(a, (size_t)u->n_chain_end + 1);
@@ -492,8 +492,7 @@ void do_build(agx_unit *u) {
         }
         // ---- hit_prep + tile histogram ----
         u->ev.begin(); u->ev.mark(B_START, st);
-        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF,
-                         u->d_jump_list.p, u->d_words.p + W_JUMPCOUNT};
+        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
         agx_launch_hit_prep(&PA, st);
         AGX_CHECKPOINT("hit_prep");
         u->ev.mark(B_PREP, st);
@@ -531,7 +530,7 @@ void do_build(agx_unit *u) {
         u->ev.mark(B_BIG, st);
         // ---- edge sweep ----
         agx_edge_kargs E; fill_sweep_args(u, E.S); E.ovf = u->d_ovf.p; E.ovf_count = u->d_words.p + W_OVFCOUNT; E.ovf_cap = u->ovf_cap; E.list_cap = u->list_cap;
-        E.jump_list = u->d_jump_list.p; E.n_jump = u->d_words.p + W_JUMPCOUNT; E.n_hits = nh; E.abort = u->d_words.p + W_STATUS; E.big_list = u->d_big_list.p; E.big_n = u->d_words.p + W_BIGCOUNT; E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
+        E.n_hits = nh; E.abort = u->d_words.p + W_STATUS; E.big_list = u->d_big_list.p; E.big_n = u->d_words.p + W_BIGCOUNT; E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
         agx_launch_edge_sweep(&E, st);
         AGX_CHECKPOINT("edge_sweep");
         // Passes J and B insert edges out of different sources (positions with one variant / with several) and both wait on memory more than
@@ -672,7 +671,7 @@ void do_release(agx_unit *u) {
     struct Tr { agx_unit *u; double t; ~Tr() { trace(u, "release", t, u->V.n_pos); } } tr{u, tr0};
     if (u->st) { (void)hipSetDevice(u->prm.device); (void)hipStreamSynchronize(u->st); }
     for (auto *b : {&u->d_cm_start, &u->d_tile_cnt, &u->d_tile_off, &u->d_cursor, &u->d_unsorted, &u->d_tile_recs, &u->d_scan_tmp, &u->d_words, &u->d_pool_cnt, &u->d_region_off, &u->d_node_start,
-                    &u->d_slow_list, &u->d_rank4, &u->d_jump_list, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
+                    &u->d_slow_list, &u->d_rank4, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     for (auto *b : {&u->d_node_cnt, &u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
     u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_sp_hop.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();

@@ -10,7 +10,6 @@ struct agx_prep_args {
     agx_u32 *err;             // bit 0: same-strand mates; bit 1: alignment beyond the unit sequence
     uint4 *rank4;             // [n_hits] what the histogram's atomicAdd returned for the hit's first four tiles = its slot in each tile's list
     agx_u32 *rank_overflow;   // set when some hit spans more than four tiles: the lists are then filled with a second round of atomics
-    agx_u32 *jump_list, *jump_count;   // kept hits with a mate of several runs (any order): what pass J of the edge build looks at
 };
 
 struct agx_bin_args { const agx_dhit *dhit; agx_u32 n_hits; const agx_u32 *tile_off; agx_u32 *cursor; agx_u32 *unsorted; agx_u32 cap;   // cap: entries the lists can hold
@@ -36,7 +35,7 @@ struct agx_node_kargs {
 struct agx_edge_kargs {
     agx_sweep_args S; agx_edge_ovf *ovf; agx_u32 *ovf_count; agx_u32 ovf_cap; agx_u32 list_cap;
     agx_u32 *slow_list; agx_u32 *slow_count;   // positions that need the per-hit pass (device-side list)
-    const agx_u32 *jump_list; const agx_u32 *n_jump; agx_u32 n_hits;  // hits with a mate of several runs (listed by hit_prep, length on the device): the only hits pass J looks at
+    agx_u32 n_hits;                            // pass J looks at every hit's derived record (a list of the candidates cost more to make than it saved)
     const agx_u32 *abort;                      // the node sweeps' status word: non-zero = the node table is incomplete, do nothing
     const agx_u32 *big_list; const agx_u32 *big_n;   // tiles the fallback pass wrote (their edges are all pass A/B's)
 };

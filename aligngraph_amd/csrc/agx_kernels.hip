@@ -81,16 +81,15 @@ __global__ void __launch_bounds__(256) agx_k_expand_codes(const uint2 *packed, u
 // Device-scope atomics are the expensive part of binning on this chip (8 L2s: they are resolved behind them): neighbouring lanes that want
 // the same tile add up and issue ONE atomicAdd, and what that returns is also each hit's slot in the tile's list, so that bin_fill
 // scatters without atomics.  The kernel also decides the one rule that needs the file order (a later hit of a pair landing on an earlier
-// one is dropped, AG:1650-1655) and lists the hits pass J of the edge build has to look at.
+// one is dropped, AG:1650-1655).  (It used to append the hits with a multi-run mate to a list for pass J of the edge build: one returning
+// atomic per wavefront on ONE counter — 16 k of them, 0.18 ms of a 0.23 ms kernel: a single word takes ~88 such atomics per microsecond.)
 __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
     const agx_u32 h = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
     const bool mine = h < A.n_hits;
     agx_dhit d; d.flags = AGX_HF_SKIP; d.x_lo = 1; d.x_hi = 0; d.a_nruns = 0;
-    bool jump = false;
     if (mine) {
         const agx_hit H = A.hits[h];
         const int rc = agx_hit_prep(H, H.back != 0 && agx_hit_dup(A.hits, A.runs, h), (H.pad[0] & 1u) != 0, H.slot1, A.runs, A.k, d);      // staged hit: slot1 = row of the a mate's bases
-        jump = H.nruns1 >= 2 || H.nruns2 >= 2;             // a mate of several runs: the only hits that can step over positions
         if (rc) atomicOr(A.err, 1u);
         if (!(d.flags & AGX_HF_SKIP) && (d.x_hi >= A.n_pos || d.x_lo > d.x_hi)) { atomicOr(A.err, 2u); d.flags |= AGX_HF_SKIP; }
     }
@@ -115,21 +114,16 @@ __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
         const unsigned long long p = pm & run;                                                                 // pending lanes of my run
         lead[s] = p ? (agx_u32)__builtin_ctzll(p) : 0u;
         r[s] = (agx_u32)__popcll(p & below);
+#ifdef AGX_EXP_WG_ATOMICS      // timing experiment only (results are wrong): what the histogram costs if its atomics stay in the XCD's L2
+        if (pend[s] && lane == lead[s]) base[s] = __hip_atomic_fetch_add(&A.tile_cnt[t], (agx_u32)__popcll(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
         if (pend[s] && lane == lead[s]) base[s] = atomicAdd(&A.tile_cnt[t], (agx_u32)__popcll(p));
+#endif
     }
     for (agx_u32 s = 0; s < 4; s++) { const agx_u32 bs = (agx_u32)__shfl((int)base[s], (int)lead[s], 64); r[s] = pend[s] ? r[s] + bs : 0u; }
     if (kept && t1 - t0 >= 4) {                                              // spans more than four tiles: count the rest, and tell bin_fill to take its own slots
         for (agx_u32 t = t0 + 4; t <= t1; t++) atomicAdd(&A.tile_cnt[t], 1u);
         atomicOr(A.rank_overflow, 1u);
-    }
-    {   // pass J's list (order irrelevant: its edge inserts are set inserts)
-        const unsigned long long jm = __ballot(jump && kept);
-        if (jm) {
-            agx_u32 jb = 0;
-            if (lane == (agx_u32)__builtin_ctzll(jm)) jb = atomicAdd(A.jump_count, (agx_u32)__popcll(jm));
-            jb = (agx_u32)__shfl((int)jb, __builtin_ctzll(jm), 64);
-            if (jump && kept) A.jump_list[jb + (agx_u32)__popcll(jm & below)] = h;
-        }
     }
     if (!mine) return;
     A.rank4[h] = make_uint4(r[0], r[1], r[2], r[3]);
@@ -424,15 +418,15 @@ __device__ __forceinline__ void agx_slot_insert(const agx_edge_kargs &K, agx_u32
     atomicOr((agx_u32 *)(addr & ~(size_t)3), (agx_u32)AGX_NF_EOVF << (8u * (agx_u32)(addr & 3)));
 }
 
-// pass J: the hits with a mate of several runs (one hit in ten; hit_prep lists them); agx_edge_jump_hit drops the ones whose a mate is the
-// simple one.  The list's length is read on the device.
+// pass J: one thread per hit; agx_edge_jump_hit drops the ones that were skipped or whose a mate is a single run (five hits in six)
 __global__ void __launch_bounds__(256) agx_k_edge_jump(agx_edge_kargs K) {
     AGX_RETURN_IF_ABORTED(K.abort);
-    const agx_u32 n = __builtin_amdgcn_readfirstlane((int)*K.n_jump);
-    for (agx_u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const agx_dhit d = K.S.dhit[K.jump_list[i]];
-        agx_edge_jump_hit(K.S, d, [&](agx_u32 src, agx_u32 dst) { agx_slot_insert(K, src, dst); });
-    }
+    const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= K.n_hits) return;
+    const agx_u32 fl = K.S.dhit[i].flags, nr = K.S.dhit[i].a_nruns;      // (two words of the record decide for most hits)
+    if ((fl & AGX_HF_SKIP) || nr < 2) return;
+    const agx_dhit d = K.S.dhit[i];
+    agx_edge_jump_hit(K.S, d, [&](agx_u32 src, agx_u32 dst) { agx_slot_insert(K, src, dst); });
 }
 
 __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
@@ -605,8 +599,7 @@ void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
     hipLaunchKernelGGL(agx_k_edge_sweep, dim3(nb + AGX_BIG_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K, nb);
 }
 void agx_launch_edge_jump(const agx_edge_kargs *K, hipStream_t st) {
-    const agx_u32 blocks = (K->n_hits / 10u + 255u) / 256u + 1u;      // about one thread per listed hit; more entries than that are strided over
-    if (K->S.n_pos && K->n_hits) hipLaunchKernelGGL(agx_k_edge_jump, dim3(blocks < 2048u ? blocks : 2048u), dim3(256), 0, st, *K);
+    if (K->S.n_pos && K->n_hits) hipLaunchKernelGGL(agx_k_edge_jump, dim3((K->n_hits + 255u) / 256u), dim3(256), 0, st, *K);
 }
 void agx_launch_edge_slow(const agx_edge_kargs *K, hipStream_t st) {
     // persistent wavefronts: exactly as many blocks as the device holds at once (a second, partial round of blocks would idle most CUs)
