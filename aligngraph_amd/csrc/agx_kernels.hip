@@ -156,52 +156,59 @@ __global__ void __launch_bounds__(256) agx_k_scan_add(agx_u32 *out, const agx_u3
     if (i < n) out[i] += block_offsets[i / AGX_SCAN_BLOCK];
 }
 
-// The same scan in ONE launch (decoupled look-back): every block publishes the sum of its 4096 elements in a 64-bit descriptor (flag in the top
+// The same scan in ONE launch (decoupled look-back): every block of 4096 elements publishes its sum in a 64-bit descriptor (flag in the top
 // bits, value below), then finds its exclusive prefix by looking back over its predecessors' descriptors — a wavefront reads 64 of them at a
-// time — until it meets one that already holds an inclusive prefix, and publishes its own.  Blocks are dispatched in order, so a predecessor
-// is always running or done.  desc[] must be zero when the kernel starts.  (A command boundary costs the stream ~8 us: three launches per scan
-// were most of what a small scan cost.)
+// time — until it meets one that already holds an inclusive prefix, and publishes its own.  desc[] must be zero when the kernel starts.
+// (A command boundary costs the stream ~8 us: three launches per scan were most of what a small scan cost.)
+// A block that looks back spins until its predecessors have published, so a predecessor must never be a block that cannot start: HIP does
+// not promise dispatch in blockIdx order.  The grid is therefore capped at AGX_SCAN_GRID workgroups — few enough to be resident all at
+// once (8 per CU fit) — and workgroup g takes the 4096-element blocks g, g + grid, g + 2 grid, .. in that order: whatever a block waits
+// for belongs to a workgroup that is running or has only earlier blocks to finish first.
 #define AGX_SCAN_AGG (1ull << 62)
 #define AGX_SCAN_PFX (2ull << 62)
-__global__ void __launch_bounds__(256) agx_k_scan_lookback(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsigned long long *desc) {
+#define AGX_SCAN_GRID 1024u
+__global__ void __launch_bounds__(256) agx_k_scan_lookback(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsigned long long *desc, agx_u32 n_blocks) {
     __shared__ agx_u32 sh[256];
     __shared__ agx_u32 sh_excl;
-    const agx_u32 b = blockIdx.x, base = b * AGX_SCAN_BLOCK + threadIdx.x * AGX_SCAN_ITEMS;
-    agx_u32 v[AGX_SCAN_ITEMS], s = 0;
-    for (int i = 0; i < AGX_SCAN_ITEMS; i++) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (agx_u32 off = 1; off < 256; off <<= 1) {
-        agx_u32 t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+    for (agx_u32 b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const agx_u32 base = b * AGX_SCAN_BLOCK + threadIdx.x * AGX_SCAN_ITEMS;
+        agx_u32 v[AGX_SCAN_ITEMS], s = 0;
+        for (int i = 0; i < AGX_SCAN_ITEMS; i++) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
+        __syncthreads();                                      // (the previous block's readers of sh / sh_excl are done)
+        sh[threadIdx.x] = s;
         __syncthreads();
-        sh[threadIdx.x] += t;
+        for (agx_u32 off = 1; off < 256; off <<= 1) {
+            agx_u32 t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const agx_u32 total = sh[255];
+        if (threadIdx.x < 64) {                               // the first wavefront looks back
+            const agx_u32 lane = threadIdx.x;
+            if (lane == 0) __hip_atomic_store(&desc[b], (b == 0 ? AGX_SCAN_PFX : AGX_SCAN_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            agx_u32 excl = 0;
+            for (long long hi = (long long)b - 1; hi >= 0;) {                     // window of predecessors hi, hi-1, .., hi-63
+                const long long j = hi - lane;
+                unsigned long long d = AGX_SCAN_PFX;                              // lanes before block 0: a prefix of 0
+                if (j >= 0) do { d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((d >> 62) == 0);
+                const unsigned long long pfx = __ballot((d >> 62) == 2);
+                const agx_u32 stop = pfx ? (agx_u32)__builtin_ctzll(pfx) : 63u;   // nearest predecessor that holds an inclusive prefix
+                agx_u32 part = lane <= stop ? (agx_u32)d : 0u;
+                for (agx_u32 o = 32; o; o >>= 1) part += __shfl_down(part, o, 64);
+                excl += __shfl(part, 0, 64);
+                if (pfx) break;
+                hi -= 64;
+            }
+            if (lane == 0) {
+                if (b) __hip_atomic_store(&desc[b], AGX_SCAN_PFX | (unsigned long long)(agx_u32)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh_excl = excl;
+            }
+        }
         __syncthreads();
+        agx_u32 run = sh_excl + sh[threadIdx.x] - s;
+        for (int i = 0; i < AGX_SCAN_ITEMS; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
     }
-    const agx_u32 total = sh[255];
-    if (threadIdx.x < 64) {                               // the first wavefront looks back
-        const agx_u32 lane = threadIdx.x;
-        if (lane == 0) __hip_atomic_store(&desc[b], (b == 0 ? AGX_SCAN_PFX : AGX_SCAN_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        agx_u32 excl = 0;
-        for (long long hi = (long long)b - 1; hi >= 0;) {                     // window of predecessors hi, hi-1, .., hi-63
-            const long long j = hi - lane;
-            unsigned long long d = AGX_SCAN_PFX;                              // lanes before block 0: a prefix of 0
-            if (j >= 0) do { d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((d >> 62) == 0);
-            const unsigned long long pfx = __ballot((d >> 62) == 2);
-            const agx_u32 stop = pfx ? (agx_u32)__builtin_ctzll(pfx) : 63u;   // nearest predecessor that holds an inclusive prefix
-            agx_u32 part = lane <= stop ? (agx_u32)d : 0u;
-            for (agx_u32 o = 32; o; o >>= 1) part += __shfl_down(part, o, 64);
-            excl += __shfl(part, 0, 64);
-            if (pfx) break;
-            hi -= 64;
-        }
-        if (lane == 0) {
-            if (b) __hip_atomic_store(&desc[b], AGX_SCAN_PFX | (unsigned long long)(agx_u32)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh_excl = excl;
-        }
-    }
-    __syncthreads();
-    agx_u32 run = sh_excl + sh[threadIdx.x] - s;
-    for (int i = 0; i < AGX_SCAN_ITEMS; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
 }
 
 // ---- tile lists: scatter, then rank-sort each list so that hits are applied in SAM order ---------------------------
@@ -569,7 +576,8 @@ void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u
 // the one-launch form; desc: ceil((n+1)/4096) zeroed 64-bit words
 void agx_launch_exclusive_scan1(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsigned long long *desc, hipStream_t st) {
     const agx_u32 m = n + 1;                              // callers allocate in with n+1 entries, in[n] = 0: out[n] = total
-    hipLaunchKernelGGL(agx_k_scan_lookback, dim3((m + AGX_SCAN_BLOCK - 1) / AGX_SCAN_BLOCK), dim3(256), 0, st, in, out, m, desc);
+    const agx_u32 nb = (m + AGX_SCAN_BLOCK - 1) / AGX_SCAN_BLOCK;
+    hipLaunchKernelGGL(agx_k_scan_lookback, dim3(nb < AGX_SCAN_GRID ? nb : AGX_SCAN_GRID), dim3(256), 0, st, in, out, m, desc, nb);
 }
 
 void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {
