@@ -430,18 +430,21 @@ void do_upload(agx_unit *u) {
     auto up = [&](void *dst, const void *src, size_t bytes) {
         for (size_t at = 0; at < bytes;) { const size_t m = chunk ? std::min(chunk, bytes - at) : bytes; HIP_OK(hipMemcpyAsync((char *)dst + at, (const char *)src + at, m, hipMemcpyHostToDevice, st)); at += m; }
     };
-    // conti-mer tables: their runs cross PCIe (agx_cmseg), the device expands them — count per position, scan, keys — and makes the heads
+    // ALL COPIES FIRST, the upload's kernels behind them: the copy engines need no CU, but a kernel queued on this stream while another
+    // unit's node sweep holds every CU waits for it — and with it every copy queued behind that kernel (the rocprofv3 trace of a cfg3 job
+    // showed 4-5 ms of idle PCIe per unit that way, profiles/r02_overlap.txt).  The next unit's turn begins when the copies are done.
     up(u->d_segs.p, u->s_segs.p, u->n_segs * sizeof(agx_cmseg)); up(u->d_ref.p, u->s_ref.p, n_pos);
-    HIP_OK(hipMemsetAsync(u->d_cm_cnt.p, 0, (n_pos + 2) * 4, st)); HIP_OK(hipMemsetAsync(u->d_up_desc.p, 0, ((n_pos + 2) / 4096 + 2) * 8, st));
-    agx_launch_seg_expand(u->d_segs.p, (agx_u32)u->n_segs, (agx_u32)u->n_cm, u->d_cm_cnt.p, u->d_cm_start.p, u->d_cm.p, (agx_u32)n_pos, u->d_up_desc.p, st);
-    agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, (agx_u32)n_pos, st);
     up(u->d_hits.p, u->s_hits.p, nh * sizeof(agx_hit)); up(u->d_runs.p, u->s_runs.p, u->n_runs * sizeof(agx_run));
     up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);
     up(u->d_codes.p, u->s_codes.p, u->n_codes);
-    agx_launch_expand_codes(u->d_codes.p, u->d_vcodes.p, (n_bases + 15) / 16 * 16, st);
     layout_regions(u, nullptr, pool_cap - spill_min(u), true);
-    HIP_OK(hipEventRecord(u->ev_uploaded, st));
     HIP_OK(hipEventRecord(turn.up_done[turn.up_n & 1], st)); turn.up_n++;
+    // conti-mer tables from their runs (agx_cmseg): count per position, scan, keys, heads; read bases: 4-bit classes -> vote codes
+    HIP_OK(hipMemsetAsync(u->d_cm_cnt.p, 0, (n_pos + 2) * 4, st)); HIP_OK(hipMemsetAsync(u->d_up_desc.p, 0, ((n_pos + 2) / 4096 + 2) * 8, st));
+    agx_launch_seg_expand(u->d_segs.p, (agx_u32)u->n_segs, (agx_u32)u->n_cm, u->d_cm_cnt.p, u->d_cm_start.p, u->d_cm.p, (agx_u32)n_pos, u->d_up_desc.p, st);
+    agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, (agx_u32)n_pos, st);
+    agx_launch_expand_codes(u->d_codes.p, u->d_vcodes.p, (n_bases + 15) / 16 * 16, st);
+    HIP_OK(hipEventRecord(u->ev_uploaded, st));
     up_turn.unlock();
     trace(u, "upload: queue copies", tq, n_pos);
     u->uploaded = true; u->built = false; u->downloaded = false;
@@ -580,6 +583,12 @@ void do_build(agx_unit *u) {
         my_turn.unlock();
         trace(u, "build: queue kernels", tb1, n_pos);
         const double tb2 = now_ms();
+        if (attempt == 0) {     // while the kernels run: the download's pinned buffers, by estimate (walk ids ~ 1.05 x positions, special ids ~ 8 % of them) — mapping
+                                // and registering them costs 5-9 ms for a cold cache, which otherwise sits between the build and the walk; do_download re-sizes what is too small
+            const size_t ni = (size_t)n_pos + n_pos / 8 + 4096, nw = ni / 64 + 1, ns = ni / 8 + 4096;
+            u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(n_pos / 8 + 4097);
+            u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2); u->h_a_ovf.alloc(64);
+        }
         {   void *dst = u->h_words.dev(); const void *src = u->d_words.p; const size_t bytes = (W_N + 6 + 16) * 4;      // (by a kernel: a copy command would queue behind
             agx_launch_copy_out(&dst, &src, &bytes, 1, u->st); }                                                            // the uploads other units have waiting on the SDMA rings)
         HIP_OK(hipStreamSynchronize(u->st));
