@@ -17,7 +17,8 @@ Text parsing of the five per-unit files (T_unit = parse + T_core) is measured on
 Configurations (--config; BASELINE.json `configs`, synthetic data of that shape from tools/agx_synth, seeded):
     cfg3 (default)  A. thaliana shape: 5 units of 30.4 / 19.7 / 23.5 / 18.6 / 27.0 Mb, 20 M 2x100 bp pairs, k=5      <- the north-star 1-GPU target
     cfg2            E. coli shape: one 4.6 Mb unit, 1 M pairs
-    cfg4            human chr1 shape: 249 Mb --part 4 (4 units of 62 Mb), 60 M pairs (needs ~25 GB of scratch disk and a few minutes to generate)
+    cfg4            human chr1 shape: 249 Mb --part 4 (4 units of 62 Mb), 60 M pairs (needs ~40 GB of scratch disk)
+    cfg5s           whole-human shape SCALED 1/16: 24 units of 15.6 .. 3.6 Mb, 25 M 2x150 bp pairs (the shard shape of configs[4], for --gpus 8)
     custom          --chroms / --pairs / --part
 
 Multi-GPU (driver: torch.distributed.run, one rank per GPU): units are the shard — assigned longest-first to the least
@@ -44,6 +45,10 @@ CONFIGS = {
     "cfg3": ([30427671, 19698289, 23459830, 18585056, 26975502], 1, 20000000, 100,
              "configs[2]: A. thaliana shape (TAIR10 chromosome lengths), 5 units / 119.1 Mb, 20M 2x100 bp pairs"),
     "cfg4": ([248956422], 4, 60000000, 100, "configs[3]: human chr1 shape (GRCh38 length), --part 4 = 4 units of 62 Mb, 60M 2x100 bp pairs"),
+    # configs[4] (whole human, 24 units, 400M 2x150 bp pairs) does not fit a bench run: the same 24-unit shape at 1/16 of the lengths and pairs
+    "cfg5s": ([c // 16 for c in (248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622,
+                                133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415)],
+              1, 25000000, 150, "configs[4] SCALED 1/16: GRCh38 chromosome lengths / 16 (24 units, 193 Mb), 25M 2x150 bp pairs — the 8-GPU shard shape, not the configuration itself"),
 }
 
 
