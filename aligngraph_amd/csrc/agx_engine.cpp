@@ -716,8 +716,6 @@ GraphView view_of(agx_unit *u) {
     return G;
 }
 
-char *dup_buf(const std::string &s) { char *p = (char *)malloc(s.size() + 1); if (p) { memcpy(p, s.data(), s.size()); p[s.size()] = 0; } return p; }
-
 template <class F> int guarded(agx_unit *u, F f) {
     try { f(); return AGX_OK; }
     catch (const Error &e) { if (u) u->err = e.msg; return e.code ? e.code : AGX_E_ARG; }
@@ -903,7 +901,10 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
         UnitOutput O; walk_join_scaffold(u->V, view_of(u), O);
         u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = O.n_fetched;
         trace(u, "walk", t0, u->V.n_pos);
-        r->initial_contigs = dup_buf(std::string(u->V.initial, u->V.n_initial)); r->initial_len = u->V.n_initial;
+        r->initial_contigs = (char *)malloc(u->V.n_initial + 1); r->initial_len = u->V.n_initial;      // (one copy: a 30 Mb unit's initial contigs are 30 MB)
+        if (!r->initial_contigs) throw Error{E_ARG, "out of host memory"};
+        if (u->V.n_initial) memcpy(r->initial_contigs, u->V.initial, u->V.n_initial);
+        r->initial_contigs[u->V.n_initial] = 0;
         r->pre_len = O.pre_extended.n; r->pre_extended = O.pre_extended.release();
         r->extended_len = O.extended.n; r->extended = O.extended.release();
     });

@@ -124,12 +124,16 @@ inline run_end_fn pick_run_end() {
 
 struct Walker {
     const UnitView &V; const GraphView &G;
-    std::vector<agx_u8> done;                       // traversed flag per ALIVE node (pruned nodes never reach the host)
+    // traversed flag per ALIVE node (pruned nodes never reach the host).  Written once, front to back, from the meta bytes (a vector would fill the
+    // 30 MB of a large unit twice: once with its initial value, once with the flags)
+    struct Bytes { agx_u8 *p = nullptr; size_t n = 0; ~Bytes() { free(p); } agx_u8 *data() { return p; } const agx_u8 *data() const { return p; } agx_u8 &operator[](size_t i) { return p[i]; } const agx_u8 &operator[](size_t i) const { return p[i]; } } done;
     std::vector<agx_edge_ovf> ovf;                  // sorted, unique
     Walker(const UnitView &v, const GraphView &g) : V(v), G(g) {
-        done.reserve((size_t)g.n_ids + 72); advise_huge(done.data(), done.capacity());
-        done.resize((size_t)g.n_ids + 72, 1);
-        for (size_t i = 0; i < g.n_ids; i++) done[i] = g.meta[i] >> 7;     // ids without a node count as visited; the tail is a sentinel
+        done.n = (size_t)g.n_ids + 72; done.p = (agx_u8 *)malloc(done.n);
+        if (!done.p) throw Error{E_ARG, "out of host memory"};
+        advise_huge(done.p, done.n);
+        { agx_u8 *d = done.p; const agx_u8 *m = g.meta; const size_t n = g.n_ids; for (size_t i = 0; i < n; i++) d[i] = m[i] >> 7; }     // ids without a node count as visited
+        memset(done.p + g.n_ids, 1, 72);            // the tail is a sentinel
         for (size_t i = 0; i < g.n_ovf; i++) if (g.ovf[i].src != AGX_NONE) ovf.push_back(g.ovf[i]);
         std::sort(ovf.begin(), ovf.end(), [](const agx_edge_ovf &a, const agx_edge_ovf &b) { return a.src != b.src ? a.src < b.src : a.dst < b.dst; });
         ovf.erase(std::unique(ovf.begin(), ovf.end(), [](const agx_edge_ovf &a, const agx_edge_ovf &b) { return a.src == b.src && a.dst == b.dst; }), ovf.end());
@@ -467,10 +471,11 @@ void build_chains(Threads &T) {
 
 void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out) {
     if (!V.hop && !G.sp_hop) throw Error{E_ARG, "conti-mer chains were not built"};
-    Walker W(V, G);
-    std::vector<Rec> recs;
     const bool timing = getenv("AGX_WALK_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double ts = now();
+    Walker W(V, G);
+    std::vector<Rec> recs;
     double t0 = now();
     walk(W, out.pre_extended, recs);
     double t1 = now();
@@ -479,7 +484,7 @@ void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out) 
     scaffold(V, G, recs, out.extended);
     double t3 = now();
     out.n_fetched = W.n_fetched;
-    if (timing) fprintf(stderr, "[agx walk] walk %.1f ms, join %.1f ms, scaffold %.1f ms, %zu records, %u special ids of %u, %llu records fetched\n", t1 - t0, t2 - t1, t3 - t2, recs.size(), G.n_special, G.n_ids, W.n_fetched);
+    if (timing) fprintf(stderr, "[agx walk] set-up %.1f ms, walk %.1f ms, join %.1f ms, scaffold %.1f ms, %zu records, %u special ids of %u, %llu records fetched\n", t0 - ts, t1 - t0, t2 - t1, t3 - t2, recs.size(), G.n_special, G.n_ids, W.n_fetched);
 }
 
 }  // namespace agx
