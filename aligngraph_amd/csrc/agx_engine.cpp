@@ -447,6 +447,15 @@ void do_upload(agx_unit *u) {
     HIP_OK(hipEventRecord(u->ev_uploaded, st));
     up_turn.unlock();
     trace(u, "upload: queue copies", tq, n_pos);
+    {   // While the copies run: the download's pinned buffers, by estimate (walk ids ~ 1.05 x positions, special ids ~ 8 % of them).  Mapping and
+        // registering them costs 5-9 ms for a cold cache; here it hides behind this unit's own copies (between the build and the download it
+        // was on the unit's critical path; beside the build's kernels, or at the start of do_build, it held up the other units' HIP calls:
+        // 102 and 95 ms per cfg3 job against 88 here); do_download re-sizes what is too small
+        const size_t ni = n_pos + n_pos / 8 + 4096, nw = ni / 64 + 1, ns = ni / 8 + 4096;
+        u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(n_pos / 8 + 4097);
+        u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2); u->h_a_ovf.alloc(64);
+    }
+
     u->uploaded = true; u->built = false; u->downloaded = false;
     u->stats.ms_upload = now_ms() - t0;
     u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + n_pos + nh * sizeof(agx_hit) + u->n_runs * sizeof(agx_run) + (size_t)u->n_chain_end * 4 + u->n_codes + ((size_t)u->n_regions + 1) * 4;
@@ -583,12 +592,6 @@ void do_build(agx_unit *u) {
         my_turn.unlock();
         trace(u, "build: queue kernels", tb1, n_pos);
         const double tb2 = now_ms();
-        if (attempt == 0) {     // while the kernels run: the download's pinned buffers, by estimate (walk ids ~ 1.05 x positions, special ids ~ 8 % of them) — mapping
-                                // and registering them costs 5-9 ms for a cold cache, which otherwise sits between the build and the walk; do_download re-sizes what is too small
-            const size_t ni = (size_t)n_pos + n_pos / 8 + 4096, nw = ni / 64 + 1, ns = ni / 8 + 4096;
-            u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(n_pos / 8 + 4097);
-            u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2); u->h_a_ovf.alloc(64);
-        }
         {   void *dst = u->h_words.dev(); const void *src = u->d_words.p; const size_t bytes = (W_N + 6 + 16) * 4;      // (by a kernel: a copy command would queue behind
             agx_launch_copy_out(&dst, &src, &bytes, 1, u->st); }                                                            // the uploads other units have waiting on the SDMA rings)
         HIP_OK(hipStreamSynchronize(u->st));
