@@ -81,6 +81,8 @@ struct agx_unit {
     struct Mapped { void *p = nullptr; size_t n = 0; void reset() { if (p) munmap(p, n); p = nullptr; n = 0; } ~Mapped() { reset(); } } cache_map;
     agx_u32 n_seg0 = 0, stride = 0, n_slots = 0; unsigned long long pairs_in_file = 0, sam_pairs = 0;
     bool have_ref = false, have_threads = false, staged = false, uploaded = false, built = false, downloaded = false;
+    UnitOutput out; OutBuf out_initial; bool out_ready = false;      // output buffers of the next finish, reserved and touched by a helper thread while the unit is uploaded and built (prepare_outputs)
+    std::thread out_helper;
     hipStream_t st = nullptr;
     DevArena arena;
     // staged inputs: what the device wants of T and P, in pinned memory (stage_inputs)
@@ -146,6 +148,9 @@ static const bool g_debug_sync = getenv("AGX_DEBUG_SYNC") != nullptr;
 // AGX_TEST_SMALL_CAPS=1 (tests; read at every upload): every capacity starts absurdly small, so that every regrow path runs
 #define g_tiny (getenv("AGX_TEST_SMALL_CAPS") != nullptr)
 #define AGX_CHECKPOINT(name) do { if (g_debug_sync) { hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, "[agx debug] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
+
+void drop_outputs(agx_unit *u);     // before a unit's inputs change: the helper that prepares the output buffers reads them
+void start_helper(agx_unit *u);
 
 enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_RANKOVF = 6, W_MIDCOUNT = 7, W_JUMPCOUNT = 8, W_SPILL = 9, W_HUGECOUNT = 10, W_N = 11 };
 
@@ -291,6 +296,7 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     const double t0 = now_ms();
     void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (m == MAP_FAILED) return false;
+    drop_outputs(u);
     u->T = Threads(); u->P = Pairs(); u->cache_map.reset(); u->cache_map.p = m; u->cache_map.n = (size_t)sb.st_size;
     const char *base = (const char *)m;
     u->nh = H.nh; u->n_runs = H.n_runs; u->n_cm = H.n_cm; u->n_segs = H.n_segs; u->n_seg0 = (agx_u32)H.n_seg0; u->n_chain_end = (agx_u32)H.n_chain_end; u->n_codes = H.n_codes;
@@ -376,6 +382,7 @@ void do_upload(agx_unit *u) {
     if (!u->staged) stage_inputs(u);
     if (u->arena.used()) do_release(u);              // uploaded before: start over (the unit's blocks go through the cache)
     const double t0 = now_ms();
+    start_helper(u);
     HIP_OK(hipSetDevice(u->prm.device));
     const size_t n_pos = u->V.n_pos, nh = u->nh;
     u->arena.device = u->prm.device;
@@ -460,6 +467,30 @@ void do_upload(agx_unit *u) {
     u->stats.ms_upload = now_ms() - t0;
     u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + n_pos + nh * sizeof(agx_hit) + u->n_runs * sizeof(agx_run) + (size_t)u->n_chain_end * 4 + u->n_codes + ((size_t)u->n_regions + 1) * 4;
     u->stats.device_bytes = u->arena.capacity();
+}
+
+// The three output buffers of a unit: reserved by estimate (the walk grows what is too small), every page touched, the initial contigs
+// copied.  A 30 Mb unit's outputs are 100 MB of fresh memory: faulted in inside the walk and after it they cost 8-10 ms of the unit's
+// critical path, and 20 ms on the unit's own worker before the build (five workers faulting at once).  So a helper thread makes them while
+// the unit is uploaded and built; agx_unit_finish joins it.
+void prepare_outputs(agx_unit *u) {
+    if (u->out_ready) return;
+    try {
+        const size_t n_pos = u->V.n_pos;
+        u->out.pre_extended.n = 0; u->out.extended.n = 0; u->out_initial.n = 0;
+        u->out.pre_extended.reserve(n_pos + n_pos / 8 + 8192); u->out.pre_extended.prefault();
+        u->out.extended.reserve(n_pos + n_pos / 16 + 4096); u->out.extended.prefault();
+        u->out_initial.reserve(u->V.n_initial);                      // (one copy: a 30 Mb unit's initial contigs are 30 MB)
+        if (u->V.n_initial) u->out_initial.append(u->V.initial, u->V.n_initial);
+        u->out_ready = true;
+    } catch (...) { u->out_ready = false; }                              // out of memory: agx_unit_finish tries again on its own thread and reports
+}
+void join_helper(agx_unit *u) { if (u->out_helper.joinable()) u->out_helper.join(); }
+void drop_outputs(agx_unit *u) { join_helper(u); u->out_ready = false; }
+void start_helper(agx_unit *u) {
+    join_helper(u);
+    if (u->out_ready) return;
+    try { u->out_helper = std::thread(prepare_outputs, u); } catch (...) { }      // no thread to be had: finish prepares the outputs itself
 }
 
 // All kernels of one build are queued back to back with the current buffer capacities; the counters they produce (tile-list
@@ -693,6 +724,8 @@ void do_release(agx_unit *u) {
     u->h_sp_hop.release();
     u->pool_cap = u->spill_lo = u->ovf_cap = u->list_cap = u->sp_cap = 0;
     u->uploaded = u->built = u->downloaded = false;
+    join_helper(u);
+    u->out.pre_extended.clear(); u->out.extended.clear(); u->out_initial.clear(); u->out_ready = false;
 }
 
 // records of non-special walk ids: built on the device from the node table, which stays in HBM (agx_walk_record), then one copy
@@ -712,7 +745,7 @@ void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u
 
 GraphView view_of(agx_unit *u) {
     GraphView G; G.n_pos = (agx_u32)u->V.n_pos; G.n_ids = u->n_ids;
-    G.meta = u->h_a_meta.p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
+    G.meta = u->h_a_meta.p; G.meta_rw = u->h_a_meta.p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
     G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.sp_hop = u->h_sp_hop.p; G.n_special = u->n_special;
     G.fetch = fetch_records; G.fetch_ctx = u;
     G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf; G.row_slot = u->row_slot.data();
@@ -797,7 +830,7 @@ const char *agx_unit_error(const agx_unit *u) { return u ? u->err.c_str() : "nul
 
 int agx_unit_set_reference(agx_unit *u, const char *bases, uint32_t n) {
     if (!u || (!bases && n)) return AGX_E_ARG;
-    return guarded(u, [&] { u->T = Threads(); u->T.ref.assign(bases, n); u->T.n_ref = n; u->have_ref = true; u->have_threads = false; u->staged = false; u->uploaded = false; u->built = false; });
+    return guarded(u, [&] { drop_outputs(u); u->T = Threads(); u->T.ref.assign(bases, n); u->T.n_ref = n; u->have_ref = true; u->have_threads = false; u->staged = false; u->uploaded = false; u->built = false; });
 }
 
 int agx_unit_set_contig_threads(agx_unit *u, const char *appended, uint32_t n_appended, const uint32_t *cm_start, const agx_contimer *cm, uint32_t n_cm,
@@ -805,6 +838,7 @@ int agx_unit_set_contig_threads(agx_unit *u, const char *appended, uint32_t n_ap
     if (!u || !cm_start || (!cm && n_cm) || (!appended && n_appended)) return AGX_E_ARG;
     return guarded(u, [&] {
         if (!u->have_ref) throw Error{E_ARG, "set the reference first"};
+        drop_outputs(u);
         u->T.ref.resize(u->T.n_ref); u->T.ref.append(appended ? appended : "", n_appended);
         const size_t n_pos = u->T.ref.size();
         u->T.cm_start.assign(cm_start, cm_start + n_pos + 1);
@@ -823,6 +857,7 @@ int agx_unit_set_contig_threads(agx_unit *u, const char *appended, uint32_t n_ap
 int agx_unit_push_pairs(agx_unit *u, const agx_pair_batch *b) {
     if (!u || !b) return AGX_E_ARG;
     return guarded(u, [&] {
+        drop_outputs(u);
         if (u->P.hits.empty()) { u->P = Pairs(); u->P.stride = b->stride; }
         if (b->stride != u->P.stride) throw Error{E_ARG, "all batches of a unit must use one read stride"};
         const agx_u32 slot0 = u->P.n_slots, run0 = (agx_u32)u->P.runs.size();
@@ -862,6 +897,7 @@ int agx_unit_load_files_shared(agx_unit *u, const char *tmp_dir, int unit, const
         u->stats.from_cache = 0;
         if (load_cache(u, d, unit)) return;               // the unit's staged form, written when the alignments were distributed (agx_unit_cache_build)
         double t0 = now_ms();
+        drop_outputs(u);
         u->T = Threads(); u->P = Pairs();
         load_unit_reference(d + "/_genome." + s + ".fa", u->T.ref);
         thread_contigs_from_files(d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", u->T);
@@ -901,15 +937,17 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
     return guarded(u, [&] {
         if (!u->downloaded) do_download(u);
         const double t0 = now_ms();
-        UnitOutput O; walk_join_scaffold(u->V, view_of(u), O);
-        u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = O.n_fetched;
+        join_helper(u);
+        prepare_outputs(u);               // (a unit whose helper could not make them, or that is finished a second time)
+        if (!u->out_ready) throw Error{E_ARG, "out of host memory"};
+        u->downloaded = false;            // the walk marks the downloaded meta bytes: another finish downloads again
+        u->out_ready = false;             // (an error below leaves the buffers to the next prepare_outputs)
+        walk_join_scaffold(u->V, view_of(u), u->out);
+        u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = u->out.n_fetched;
         trace(u, "walk", t0, u->V.n_pos);
-        r->initial_contigs = (char *)malloc(u->V.n_initial + 1); r->initial_len = u->V.n_initial;      // (one copy: a 30 Mb unit's initial contigs are 30 MB)
-        if (!r->initial_contigs) throw Error{E_ARG, "out of host memory"};
-        if (u->V.n_initial) memcpy(r->initial_contigs, u->V.initial, u->V.n_initial);
-        r->initial_contigs[u->V.n_initial] = 0;
-        r->pre_len = O.pre_extended.n; r->pre_extended = O.pre_extended.release();
-        r->extended_len = O.extended.n; r->extended = O.extended.release();
+        r->initial_len = u->out_initial.n; r->initial_contigs = u->out_initial.release();
+        r->pre_len = u->out.pre_extended.n; r->pre_extended = u->out.pre_extended.release();
+        r->extended_len = u->out.extended.n; r->extended = u->out.extended.release();
     });
 }
 

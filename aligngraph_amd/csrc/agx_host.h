@@ -69,6 +69,7 @@ inline UnitView view_of(const Threads &T, const Pairs &P) {
 struct GraphView {
     agx_u32 n_pos = 0, n_ids = 0;
     const agx_u8 *meta = nullptr;                           // [n_ids + 64] AGX_WM_* bits (padding reads as 0)
+    agx_u8 *meta_rw = nullptr;                              // null, or == meta: the walk may keep its visited marks in meta's bit 7 (the array is consumed by the walk)
     const char *str = nullptr;                              // [n_ids] base a node emits
     const agx_u32 *side_xpos = nullptr;                     // [n_ids - n_pos] position of each side id, non-decreasing
     const unsigned long long *sp_bits = nullptr;            // [n_ids/64 + 1] special-id bitmap
@@ -98,6 +99,10 @@ struct OutBuf {
     char *grow(size_t add) { if (n + add + 1 > cap) reserve((n + add) + (n + add) / 2 + 64); char *w = p + n; n += add; return w; }
     void append(const char *s, size_t len) { memcpy(grow(len), s, len); }
     char *release() { if (!p) reserve(0); p[n] = 0; char *r = p; p = nullptr; n = cap = 0; return r; }
+    // touches every page of the capacity: the first-touch faults (and the kernel's zeroing) of a 30 MB output happen where the caller has
+    // time to spare instead of inside the walk
+    void prefault() { for (size_t i = 0; i < cap; i += 4096) p[i] = 0; }
+    void clear() { free(p); p = nullptr; n = cap = 0; }
 };
 struct UnitOutput { OutBuf pre_extended, extended; unsigned long long n_fetched = 0; };
 

@@ -13,6 +13,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
 #include <unordered_map>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -33,15 +36,39 @@ static unsigned long long g_prof[12];
 namespace agx {
 namespace {
 
+// Bases of a record are kept as a list of byte ranges — runs of node bases in the downloaded walk graph, conti-mer chain suffixes, reference
+// stretches, trailing k-mers — from the walk to the last output byte: most walks end up contained in the previously written record
+// (AG:2176) and are dropped without ever being copied, and the join and the scaffolder concatenate lists instead of re-copying 30 MB
+// of strings (their string appends were a quarter of a large unit's host time).  Every range outlives the outputs: the walk graph and
+// the unit's tables belong to the caller, the k-mer tails to walk_join_scaffold's arena.
+struct Seg { const char *p; size_t n; };
+struct Bases {
+    std::vector<Seg> segs; size_t len = 0;
+    void add(const char *p, size_t n) { if (n) { segs.push_back(Seg{p, n}); len += n; } }
+    void add_from(const Bases &o, size_t from) {          // o's bases from index `from` on (std::string::append(o, from, npos))
+        for (const Seg &g : o.segs) { if (from >= g.n) { from -= g.n; continue; } add(g.p + from, g.n - from); from = 0; }
+    }
+};
 struct Rec {                 // Contig, AG:123-139
     int extended;
     agx_u32 sID, sOff, eID, eOff, sID0, sOff0, eID0, eOff0;
-    std::string nuc;
+    Bases nuc;
 };
 
-// A walk is first recorded as a list of byte ranges (runs of node bases, conti-mer chain suffixes, the trailing k-mer);
-// most walks end up contained in the previously written record (AG:2176) and are dropped without ever being copied.
-struct Seg { const char *p; size_t n; };
+// FASTA body, 60 columns (AG:2184-2188), written across range boundaries
+struct LineWriter {
+    char *w; unsigned col = 0;
+    explicit LineWriter(char *at) : w(at) {}
+    void put(const char *p, size_t n) {
+        while (n) {
+            const size_t m = n < 60u - col ? n : 60u - col;
+            memcpy(w, p, m); w += m; p += m; n -= m; col += (unsigned)m;
+            if (col == 60u) { *w++ = '\n'; col = 0; }
+        }
+    }
+    void put(const Bases &b) { for (const Seg &g : b.segs) put(g.p, g.n); }
+    char *end() { if (col) { *w++ = '\n'; col = 0; } return w; }
+};
 
 inline bool contains(agx_u32 sID1, agx_u32 sOff1, agx_u32 eID1, agx_u32 eOff1, agx_u32 sID2, agx_u32 sOff2, agx_u32 eID2, agx_u32 eOff2) {
     return sID1 == sID2 && eID1 == eID2 && sOff1 <= sOff2 && eOff1 >= eOff2;      // AG:1897-1902
@@ -54,29 +81,29 @@ inline char *put_u32(char *w, agx_u32 v) {      // decimal, no padding
     return w;
 }
 
-inline void fasta_body(std::string &out, const char *s, size_t n) {
-    for (size_t i = 0; i < n; i += 60) { const size_t m = n - i < 60 ? n - i : 60; out.append(s + i, m); out.push_back('\n'); }
-}
-
+// The walk's "traversed" flag of a node is bit 7 of its meta byte: the device sets it on ids without a node (AGX_WM_ABSENT: they count as
+// visited), the walk sets it on the nodes it passes.  One byte array serves the run scan, the marks and the position scan.
+#define AGX_WM_VISITED AGX_WM_ABSENT
 // End of the forced run that starts at node `cur`: the first j >= cur whose cont bit is clear or whose successor j+1 is already
 // visited (the reference steps cur -> cur+1 while its unique live successor is unvisited, AG:2020-2046).  `seen` collects the meta
-// bits of the nodes passed.  meta and done are padded by 64 bytes (meta: zeros, done: ones), so whole-vector reads past j are safe.
-inline agx_u32 run_end_scalar(const agx_u8 *meta, const agx_u8 *done, agx_u32 j, agx_u8 &seen) {
+// bits of the nodes passed.  meta is padded by 64 zero bytes, so whole-vector reads past j are safe (and stop there: no cont bit).
+inline agx_u32 run_end_scalar(const agx_u8 *meta, agx_u32 j, agx_u8 &seen) {
     for (;;) {
-        uint64_t mw, dw; memcpy(&mw, meta + j, 8); memcpy(&dw, done + j + 1, 8);
-        if ((mw & 0x0101010101010101ull) == 0x0101010101010101ull && dw == 0) { mw |= mw >> 32; mw |= mw >> 16; mw |= mw >> 8; seen |= (agx_u8)mw; j += 8; continue; }
-        for (int b8 = 0; b8 < 8; b8++) { const agx_u8 m = meta[j]; seen |= m; if (!(m & AGX_WM_CONT) || done[j + 1]) return j; j++; }
+        uint64_t mw, dw; memcpy(&mw, meta + j, 8); memcpy(&dw, meta + j + 1, 8);
+        if ((mw & 0x0101010101010101ull) == 0x0101010101010101ull && (dw & 0x8080808080808080ull) == 0) { mw |= mw >> 32; mw |= mw >> 16; mw |= mw >> 8; seen |= (agx_u8)mw; j += 8; continue; }
+        for (int b8 = 0; b8 < 8; b8++) { const agx_u8 m = meta[j]; seen |= m; if (!(m & AGX_WM_CONT) || (meta[j + 1] & AGX_WM_VISITED)) return j; j++; }
     }
 }
+// marks nodes [a, b] visited
+inline void mark_scalar(agx_u8 *meta, agx_u32 a, agx_u32 b) { for (agx_u32 i = a; i <= b; i++) meta[i] |= AGX_WM_VISITED; }
 #if defined(__x86_64__)
-__attribute__((target("avx2"))) inline agx_u32 run_end_avx2(const agx_u8 *meta, const agx_u8 *done, agx_u32 j, agx_u8 &seen) {
-    const __m256i one = _mm256_set1_epi8(1);
+__attribute__((target("avx2"))) inline agx_u32 run_end_avx2(const agx_u8 *meta, agx_u32 j, agx_u8 &seen) {
     unsigned contig = 0;                                                        // lanes (nodes passed) whose AGX_WM_CONTIG bit is set
     for (;;) {
-        const __m256i m = _mm256_loadu_si256((const __m256i *)(meta + j)), d = _mm256_loadu_si256((const __m256i *)(done + j + 1));
-        // a node lets the run pass iff its cont bit is set and its successor is unvisited
-        const __m256i pass = _mm256_andnot_si256(_mm256_cmpeq_epi8(d, one), _mm256_cmpeq_epi8(_mm256_and_si256(m, one), one));
-        const unsigned stop = ~(unsigned)_mm256_movemask_epi8(pass);
+        const __m256i m = _mm256_loadu_si256((const __m256i *)(meta + j)), d = _mm256_loadu_si256((const __m256i *)(meta + j + 1));
+        // a node lets the run pass iff its cont bit (bit 0 -> the byte's sign bit) is set and its successor's visited bit (the sign bit) is clear
+        const unsigned pass = (unsigned)_mm256_movemask_epi8(_mm256_slli_epi16(m, 7)) & ~(unsigned)_mm256_movemask_epi8(d);
+        const unsigned stop = ~pass;
         const unsigned cbits = (unsigned)_mm256_movemask_epi8(_mm256_slli_epi16(m, 6));       // bit 1 of every byte -> its sign bit
         if (stop == 0) { contig |= cbits; j += 32; continue; }
         const unsigned k = (unsigned)__builtin_ctz(stop);                       // the run ends ON node j+k
@@ -86,24 +113,29 @@ __attribute__((target("avx2"))) inline agx_u32 run_end_avx2(const agx_u8 *meta, 
         return j + k;
     }
 }
+__attribute__((target("avx2"))) inline void mark_avx2(agx_u8 *meta, agx_u32 a, agx_u32 b) {
+    const __m256i v = _mm256_set1_epi8((char)AGX_WM_VISITED);
+    agx_u32 i = a;
+    for (; i + 31 <= b; i += 32) _mm256_storeu_si256((__m256i *)(meta + i), _mm256_or_si256(_mm256_loadu_si256((const __m256i *)(meta + i)), v));
+    for (; i <= b; i++) meta[i] |= AGX_WM_VISITED;
+}
 #endif
-// first index i in [from, n) with done[i] == 0 (n if none); done is padded with ones
-inline agx_u32 next_zero_scalar(const agx_u8 *done, agx_u32 from, agx_u32 n) {
+// first unvisited index i in [from, n) (n if none)
+inline agx_u32 next_zero_scalar(const agx_u8 *meta, agx_u32 from, agx_u32 n) {
     agx_u32 i = from;
-    while (i < n && (i & 7u)) { if (!done[i]) return i; i++; }
-    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, &done[i], 8); if (w != 0x0101010101010101ull) break; }
-    while (i < n && done[i]) i++;
+    while (i < n && (i & 7u)) { if (!(meta[i] & AGX_WM_VISITED)) return i; i++; }
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, &meta[i], 8); if ((w & 0x8080808080808080ull) != 0x8080808080808080ull) break; }
+    while (i < n && (meta[i] & AGX_WM_VISITED)) i++;
     return i < n ? i : n;
 }
 #if defined(__x86_64__)
-__attribute__((target("avx2"))) inline agx_u32 next_zero_avx2(const agx_u8 *done, agx_u32 from, agx_u32 n) {
+__attribute__((target("avx2"))) inline agx_u32 next_zero_avx2(const agx_u8 *meta, agx_u32 from, agx_u32 n) {
     agx_u32 i = from;
-    const __m256i zero = _mm256_setzero_si256();
     for (; i + 32 <= n; i += 32) {
-        const unsigned m = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(done + i)), zero));
+        const unsigned m = ~(unsigned)_mm256_movemask_epi8(_mm256_loadu_si256((const __m256i *)(meta + i)));
         if (m) return i + (agx_u32)__builtin_ctz(m);
     }
-    while (i < n && done[i]) i++;
+    while (i < n && (meta[i] & AGX_WM_VISITED)) i++;
     return i < n ? i : n;
 }
 #endif
@@ -114,7 +146,14 @@ inline next_zero_fn pick_next_zero() {
 #endif
     return next_zero_scalar;
 }
-typedef agx_u32 (*run_end_fn)(const agx_u8 *, const agx_u8 *, agx_u32, agx_u8 &);
+typedef agx_u32 (*run_end_fn)(const agx_u8 *, agx_u32, agx_u8 &);
+typedef void (*mark_fn)(agx_u8 *, agx_u32, agx_u32);
+inline mark_fn pick_mark() {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2")) return mark_avx2;
+#endif
+    return mark_scalar;
+}
 inline run_end_fn pick_run_end() {
 #if defined(__x86_64__)
     if (__builtin_cpu_supports("avx2")) return run_end_avx2;
@@ -124,16 +163,19 @@ inline run_end_fn pick_run_end() {
 
 struct Walker {
     const UnitView &V; const GraphView &G;
-    // traversed flag per ALIVE node (pruned nodes never reach the host).  Written once, front to back, from the meta bytes (a vector would fill the
-    // 30 MB of a large unit twice: once with its initial value, once with the flags)
-    struct Bytes { agx_u8 *p = nullptr; size_t n = 0; ~Bytes() { free(p); } agx_u8 *data() { return p; } const agx_u8 *data() const { return p; } agx_u8 &operator[](size_t i) { return p[i]; } const agx_u8 &operator[](size_t i) const { return p[i]; } } done;
+    // meta bytes with the traversed flags in bit 7 (AGX_WM_VISITED): the caller's own array if it may be written (GraphView::meta_rw: the
+    // engine's download buffer — no copy, no first-touch faults on the unit's critical path), else a copy
+    agx_u8 *m = nullptr; agx_u8 *owned = nullptr;
+    ~Walker() { free(owned); }
+    bool visited(agx_u32 v) const { return (m[v] & AGX_WM_VISITED) != 0; }
     std::vector<agx_edge_ovf> ovf;                  // sorted, unique
     Walker(const UnitView &v, const GraphView &g) : V(v), G(g) {
-        done.n = (size_t)g.n_ids + 72; done.p = (agx_u8 *)malloc(done.n);
-        if (!done.p) throw Error{E_ARG, "out of host memory"};
-        advise_huge(done.p, done.n);
-        { agx_u8 *d = done.p; const agx_u8 *m = g.meta; const size_t n = g.n_ids; for (size_t i = 0; i < n; i++) d[i] = m[i] >> 7; }     // ids without a node count as visited
-        memset(done.p + g.n_ids, 1, 72);            // the tail is a sentinel
+        if (g.meta_rw) { if (g.meta_rw != g.meta) throw Error{E_ARG, "meta_rw must be the meta array"}; m = g.meta_rw; }
+        else {
+            const size_t n = (size_t)g.n_ids + 64;
+            owned = (agx_u8 *)malloc(n); if (!owned) throw Error{E_ARG, "out of host memory"};
+            advise_huge(owned, n); memcpy(owned, g.meta, n); m = owned;
+        }
         for (size_t i = 0; i < g.n_ovf; i++) if (g.ovf[i].src != AGX_NONE) ovf.push_back(g.ovf[i]);
         std::sort(ovf.begin(), ovf.end(), [](const agx_edge_ovf &a, const agx_edge_ovf &b) { return a.src != b.src ? a.src < b.src : a.dst < b.dst; });
         ovf.erase(std::unique(ovf.begin(), ovf.end(), [](const agx_edge_ovf &a, const agx_edge_ovf &b) { return a.src == b.src && a.dst == b.dst; }), ovf.end());
@@ -178,7 +220,7 @@ struct Walker {
     agx_u32 pos_of(agx_u32 v) const { return v < G.n_pos ? v : G.side_xpos[v - G.n_pos]; }      // main ids are positions
     // side ids of position x: [lo, hi)
     void side_range(agx_u32 x, agx_u32 &lo, agx_u32 &hi) const {
-        if (!(G.meta[x] & AGX_WM_SIDE)) { lo = hi = G.n_pos; return; }
+        if (!(m[x] & AGX_WM_SIDE)) { lo = hi = G.n_pos; return; }
         const agx_u32 *b = G.side_xpos, *e = G.side_xpos + (G.n_ids - G.n_pos);
         const agx_u32 *l = std::lower_bound(b, e, x), *h = l;
         while (h < e && *h == x) h++;
@@ -186,16 +228,16 @@ struct Walker {
     }
     // number of live (unvisited) successors of node v, capped at 2; target = the last one seen (AG:2020-2033)
     int live_successors(agx_u32 v, agx_u32 &target) const {
-        if (G.meta[v] & AGX_WM_CONT) { if (done[v + 1]) return 0; target = v + 1; return 1; }      // its only alive successor is v+1
+        if (m[v] & AGX_WM_CONT) { if (visited(v + 1)) return 0; target = v + 1; return 1; }      // its only alive successor is v+1
         int n = 0;
         const agx_walknode rec = node(v);
         const agx_u32 *s = rec.next;
-        for (agx_u32 e = 0; e < AGX_MAXE && s[e] != AGX_NONE; e++) if (!done[s[e]]) { target = s[e]; if (++n > 1) return n; }
+        for (agx_u32 e = 0; e < AGX_MAXE && s[e] != AGX_NONE; e++) if (!visited(s[e])) { target = s[e]; if (++n > 1) return n; }
         if (!ovf.empty()) {                             // nodes with more than AGX_MAXE out-edges (rare): the rest is in the overflow list
             auto it = std::lower_bound(ovf.begin(), ovf.end(), v, [](const agx_edge_ovf &a, agx_u32 key) { return a.src < key; });
             for (; it != ovf.end() && it->src == v; ++it) {
                 bool inl = false; for (agx_u32 e = 0; e < AGX_MAXE; e++) inl |= s[e] == it->dst;
-                if (!inl && !done[it->dst]) { target = it->dst; if (++n > 1) return n; }
+                if (!inl && !visited(it->dst)) { target = it->dst; if (++n > 1) return n; }
             }
         }
         return n;
@@ -213,12 +255,12 @@ struct Walker {
     }
     // first unvisited node with id in [from, n) (n if none): the position scan of AG:1972-1978 in walk-id space
     next_zero_fn next_zero = pick_next_zero();
-    agx_u32 next_live(agx_u32 from, agx_u32 n) const { return from < n ? next_zero(done.data(), from, n) : n; }
+    agx_u32 next_live(agx_u32 from, agx_u32 n) const { return from < n ? next_zero(m, from, n) : n; }
 };
 
 // extdContigs1, AG:1954-2204, replayed on the alive-compacted graph.  Alive ids are position-major, so "for every
 // position, for every variant, if untraversed" (AG:1972-1978) is "for every alive id in order, if not done".
-void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
+void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, std::deque<std::string> &tails) {
     const GraphView &G = W.G; const UnitView &V = W.V;
     agx_u32 seqID = 0, sIDBak = AGX_NONE, sOffBak = AGX_NONE, eIDBak = AGX_NONE, eOffBak = AGX_NONE;
     agx_u32 pos_bak = 0;                         // cppBak of the reference (function scope)
@@ -226,7 +268,9 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
     agx_hop hcur{0, 0, 0};                       // hop entry of the position the walk is about to leave the k-mer graph at
     std::vector<Seg> segs;
     pre_out.reserve((size_t)G.n_ids + G.n_ids / 32 + 4096);
-    agx_u8 *done = W.done.data();
+    agx_u8 *const m = W.m;
+    auto done = [m](agx_u32 v) { return (m[v] & AGX_WM_VISITED) != 0; };
+    const mark_fn mark = pick_mark();
     AGX_PT_START;
     const run_end_fn run_end = pick_run_end();
     unsigned long long n_walks = 0, n_hops = 0, n_runs = 0, n_general = 0, run_nodes = 0;
@@ -239,7 +283,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
         agx_u32 sh = sc; while (sh < n_side && G.side_xpos[sh] == cp) sh++;
         const agx_u32 s_lo = G.n_pos + sc, s_hi = G.n_pos + sh;
         for (agx_u32 vi = 0, start = cp; vi <= s_hi - s_lo; vi++, start = s_lo + vi - 1) {
-            if (done[start]) continue;
+            if (done(start)) continue;
             AGX_PT(8);
             Rec C; C.sID = 0; C.sOff = cp; C.extended = 0;
             segs.clear(); n_walks++;
@@ -248,7 +292,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
             AGX_PT(0);
             agx_u32 cpp = cp; int mode = 1;               // mode = kMerTag
             agx_u32 last = cur;
-            while ((mode == 1 && !done[cur]) || mode == 0) {
+            while ((mode == 1 && !done(cur)) || mode == 0) {
                 if (mode == 0) {                            // on a conti-mer, AG:2061-2138
                     // the whole conti-mer chain in one segment (the reference steps through it one base at a time), then its end:
                     // hop back onto the k-mer graph only through the single live node there and its single live edge (AG:2093-2136)
@@ -256,29 +300,29 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
                     segs.push_back(Seg{V.chain_str + h.str_off, h.len}); C.extended = 1; n_hops++;
                     pos_bak = h.end_pos; cpp = h.end_pos;
                     agx_u32 live = 0, item = 0;
-                    if (!done[cpp]) { live++; item = cpp; }
+                    if (!done(cpp)) { live++; item = cpp; }
                     agx_u32 h_lo, h_hi; W.side_range(cpp, h_lo, h_hi);
-                    for (agx_u32 v = h_lo; v < h_hi; v++) if (!done[v]) { live++; item = v; }
+                    for (agx_u32 v = h_lo; v < h_hi; v++) if (!done(v)) { live++; item = v; }
                     agx_u32 tgt = 0; int ns = 0;
                     if (live == 1) ns = W.live_successors(item, tgt);
-                    if (ns == 1) { cur = tgt; pos_bak = W.pos_of(tgt); cpp = pos_bak; mode = done[cur] ? -2 : 1; }
+                    if (ns == 1) { cur = tgt; pos_bak = W.pos_of(tgt); cpp = pos_bak; mode = done(cur) ? -2 : 1; }
                     else mode = -2;
                     AGX_PT(1);
                 } else {                                    // on a k-mer node, AG:1995-2060
                     // forced run: while the cont bit holds and the next node is unvisited the reference steps cur -> cur+1 (its unique live
                     // successor).
                     agx_u8 seen = 0;
-                    const agx_u32 j = run_end(G.meta, done, cur, seen);
+                    const agx_u32 j = run_end(m, cur, seen);
                     const agx_u32 xj = W.pos_of(j);
                     AGX_PT(2);                             // most walks leave the k-mer graph here, onto a conti-mer chain
-                    segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!(G.meta[j] & AGX_WM_CONT)) n_general++;
+                    segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!(m[j] & AGX_WM_CONT)) n_general++;
                     if (seen & AGX_WM_CONTIG) C.extended = 1;
-                    memset(done + cur, 1, (size_t)j - cur + 1);
+                    mark(m, cur, j);
                     if (j > cur) pos_bak = xj;
                     cur = j; last = j; cpp = xj;
                     AGX_PT(3);
                     agx_u32 tgt = 0;
-                    const int ns = (G.meta[cur] & AGX_WM_CONT) ? 0 : W.live_successors(cur, tgt);      // cont && stopped: its only alive successor is already visited
+                    const int ns = (m[cur] & AGX_WM_CONT) ? 0 : W.live_successors(cur, tgt);      // cont && stopped: its only alive successor is already visited
                     if (ns == 1) { cur = tgt; pos_bak = W.pos_of(tgt); cpp = pos_bak; }
                     else if ((hcur = W.hop_of(j, xj)).len) mode = 0;            // exactly one conti-mer here and it has a next (AG:2047-2057)
                     else mode = -1;
@@ -296,9 +340,10 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
             } else { C.eID0 = AGX_NONE; C.eOff0 = AGX_NONE; klen = 0; }
             AGX_PT(5);
             if (!contains(sIDBak, sOffBak, eIDBak, eOffBak, C.sID, C.sOff, C.eID, C.eOff)) {        // AG:2176-2189
-                if (klen > 1) { W.kmer_string(klast, kmer); segs.push_back(Seg{kmer.data() + 1, kmer.size() - 1}); }
-                size_t total = 0; for (const Seg &g : segs) total += g.n;
-                C.nuc.reserve(total); for (const Seg &g : segs) C.nuc.append(g.p, g.n);
+                if (klen > 1) { W.kmer_string(klast, kmer); tails.push_back(kmer); segs.push_back(Seg{tails.back().data() + 1, tails.back().size() - 1}); }
+                C.nuc.segs.reserve(segs.size());
+                for (const Seg &g : segs) C.nuc.add(g.p, g.n);
+                const size_t total = C.nuc.len;
                 char hdr[256];                    // ">%u, %d, %u, %u, %u, %u, %u, %u, %u, %u \n" (AG:2180-2183) without going through printf
                 int hl = 0;
                 {
@@ -309,8 +354,8 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
                     hl = (int)(w - hdr);
                 }
                 const size_t lines = (total + 59) / 60;
-                char *w = pre_out.grow((size_t)hl + total + lines); memcpy(w, hdr, (size_t)hl); w += hl;
-                for (size_t i = 0; i < total; i += 60) { const size_t m = total - i < 60 ? total - i : 60; memcpy(w, C.nuc.data() + i, m); w += m; *w++ = '\n'; }
+                char *w = pre_out.grow((size_t)hl + total + lines); memcpy(w, hdr, (size_t)hl);
+                LineWriter lw(w + hl); lw.put(C.nuc); lw.end();
                 sIDBak = C.sID; sOffBak = C.sOff; eIDBak = C.eID; eOffBak = C.eOff;
                 if (eOffBak - sOffBak > 100000) W.prefetch_skip_positions(cp, eOffBak < G.n_pos ? eOffBak : G.n_pos);
                 written.push_back(std::move(C));
@@ -327,9 +372,9 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written) {
             // first unvisited main id (= position) after cp and first unvisited side id from s_hi on.  Visited nodes stay visited and both
             // bounds only grow, so a previous answer is still the answer unless it has been passed or visited since: each block is scanned
             // once over the whole walk, not once per step (a long record leaves thousands of side nodes behind, each a step of its own)
-            if (main_live <= cp || (main_live < G.n_pos && done[main_live])) main_live = W.next_live(main_live > cp + 1 ? main_live : cp + 1, G.n_pos);
+            if (main_live <= cp || (main_live < G.n_pos && done(main_live))) main_live = W.next_live(main_live > cp + 1 ? main_live : cp + 1, G.n_pos);
             const agx_u32 m = main_live;                                                     // main slot id == position
-            if (side_live < s_hi || (side_live < G.n_ids && done[side_live])) side_live = W.next_live(side_live > s_hi ? side_live : s_hi, G.n_ids);
+            if (side_live < s_hi || (side_live < G.n_ids && done(side_live))) side_live = W.next_live(side_live > s_hi ? side_live : s_hi, G.n_ids);
             const agx_u32 sd = side_live;
             const agx_u32 sp = sd < G.n_ids ? G.side_xpos[sd - G.n_pos] : G.n_pos;
             cp = m < sp ? m : sp;
@@ -370,7 +415,7 @@ void join(std::vector<Rec> &c) {
             if (ncand != 1) break;
             Rec &d = c[cand]; d.extended = 2;
             const size_t from = (size_t)(int)(c[cp].eOff - d.sOff + 1);      // (int) -> size_t as in the reference's loop test (AG:2368-2370)
-            if (from < d.nuc.size()) c[cp].nuc.append(d.nuc, from, std::string::npos);
+            if (from < d.nuc.len) c[cp].nuc.add_from(d.nuc, from);
             c[cp].eID = d.eID; c[cp].eOff = d.eOff; c[cp].eID0 = d.eID0; c[cp].eOff0 = d.eOff0;
         }
     }
@@ -383,11 +428,11 @@ inline int overlaps(agx_u32 x1, agx_u32 y1, agx_u32 x2, agx_u32 y2) {      // AG
 
 // scaffoldContigs, AG:2396-2464
 void scaffold(const UnitView &V, const GraphView &G, std::vector<Rec> &c, OutBuf &out) {
-    std::vector<std::string> sc;
+    std::vector<Bases> sc;
     const agx_u32 n = (agx_u32)c.size();
     for (agx_u32 cp = 0; cp < n; cp++) {
         if (!(c[cp].sID != AGX_NONE && c[cp].extended == 1)) continue;
-        sc.push_back(std::move(c[cp].nuc)); c[cp].sID = AGX_NONE;      // a record is used at most once (sID = -1 marks it, AG:2411)
+        sc.push_back(std::move(c[cp].nuc)); c[cp].nuc = Bases(); c[cp].sID = AGX_NONE;      // a record is used at most once (sID = -1 marks it, AG:2411)
         bool cont = true;
         while (c[cp].sID0 == c[cp].eID0 && cont) {
             cont = false;
@@ -396,21 +441,21 @@ void scaffold(const UnitView &V, const GraphView &G, std::vector<Rec> &c, OutBuf
                 if (c[q].sOff > c[cp].eOff) {
                     const agx_u32 gap = c[q].sOff - c[cp].eOff - 1; agx_u32 covered = 0;
                     for (agx_u32 i = 0; i < gap; i++) { const agx_u32 x = c[cp].eOff + i + 1; if ((G.meta[x] & AGX_WM_ANY) || V.cm_start[x + 1] > V.cm_start[x]) covered++; }
-                    if (gap == 0 || (double)(int)covered / gap >= 0.5) sc.back().append(V.ref + c[cp].eOff + 1, gap);
+                    if (gap == 0 || (double)(int)covered / gap >= 0.5) sc.back().add(V.ref + c[cp].eOff + 1, gap);
                     else continue;
                 }
-                sc.back() += c[q].nuc; c[q].sID = AGX_NONE; cp = q; cont = true;
+                sc.back().add_from(c[q].nuc, 0); c[q].sID = AGX_NONE; cp = q; cont = true;
                 break;
             }
         }
     }
-    size_t total = 0; for (const std::string &x : sc) total += x.size() + x.size() / 60 + 16;
+    size_t total = 0; for (const Bases &x : sc) total += x.len + x.len / 60 + 16;
     out.reserve(total);
     for (size_t i = 0; i < sc.size(); i++) {
         char hdr[32]; const int hl = std::snprintf(hdr, sizeof hdr, ">%zu\n", i);
-        const size_t n = sc[i].size(), lines = (n + 59) / 60;
-        char *w = out.grow((size_t)hl + n + lines); memcpy(w, hdr, (size_t)hl); w += hl;
-        for (size_t j = 0; j < n; j += 60) { const size_t m = n - j < 60 ? n - j : 60; memcpy(w, sc[i].data() + j, m); w += m; *w++ = '\n'; }
+        const size_t n = sc[i].len, lines = (n + 59) / 60;
+        char *w = out.grow((size_t)hl + n + lines); memcpy(w, hdr, (size_t)hl);
+        LineWriter lw(w + hl); lw.put(sc[i]); lw.end();
     }
 }
 
@@ -476,8 +521,9 @@ void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out) 
     const double ts = now();
     Walker W(V, G);
     std::vector<Rec> recs;
+    std::deque<std::string> tails;                    // trailing k-mers of the written records (the other byte ranges live in the caller's tables)
     double t0 = now();
-    walk(W, out.pre_extended, recs);
+    walk(W, out.pre_extended, recs, tails);
     double t1 = now();
     join(recs);
     double t2 = now();

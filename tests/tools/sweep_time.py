@@ -8,7 +8,7 @@ import agx_data as D
 import aligngraph_amd as A
 ap = argparse.ArgumentParser(); ap.add_argument("--n", type=int, default=20); ap.add_argument("--genome", default="4600000"); ap.add_argument("--pairs", type=int, default=1000000)
 a = ap.parse_args()
-run = "/tmp/agx_sweep_time"
+run = "/tmp/agx_sweep_time_%s_%d" % (a.genome, a.pairs)
 if not os.path.exists(os.path.join(run, "tmp")):
     D.synth(run, seed=1000, chroms=a.genome, pairs=a.pairs, L=100, k=5, coverage=5)
 with A.Unit(k=5, insert_variation=50, coverage=5, flags=A.AGX_FLAG_TIME_SECTIONS) as u:
