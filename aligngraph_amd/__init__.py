@@ -14,6 +14,7 @@ AGX_OK, AGX_E_IO, AGX_E_FORMAT, AGX_E_UNSUPPORTED, AGX_E_ALIGNMENT, AGX_E_DEVICE
 AGX_FLAG_KEEP_COUNTS = 1
 AGX_FLAG_SPARSE_MIN = 2
 AGX_FLAG_TIME_SECTIONS = 4
+AGX_FLAG_ONE_SHOT = 8
 
 # every symbol include/agx.h declares (tests check that the built library exports all of them)
 EXPORTS = [

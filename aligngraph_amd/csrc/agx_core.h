@@ -424,6 +424,12 @@ AGX_HD agx_u8 agx_class_vote_code(agx_u32 cls) {
 AGX_HD agx_u8 agx_vote_code(agx_u32 c) { return agx_class_vote_code(agx_base_class(c)); }
 // packed classes: base 2j of a read slot in the low nibble of byte j, base 2j+1 in the high nibble
 AGX_HD agx_u8 agx_pack_classes(agx_u32 c_even, agx_u32 c_odd) { return (agx_u8)(agx_base_class(c_even) | (agx_base_class(c_odd) << 4)); }
+// What crosses PCIe: TWO bits per base (the class of A, C, G, T; 0 for anything else), base j of a row in bits 2*(j & 3) of byte j >> 2,
+// plus the list of the bases inside a read that are "anything else" (index into the vote-code array = row * stride + j): the upload-time
+// kernel expands the 2-bit classes and then patches the listed bytes.  Reads carry few such bases; every one costs 8 bytes instead of half a bit.
+AGX_HD agx_u8 agx_pack_classes2(agx_u32 c0, agx_u32 c1, agx_u32 c2, agx_u32 c3) {
+    return (agx_u8)((agx_base_class(c0) & 3u) | ((agx_base_class(c1) & 3u) << 2) | ((agx_base_class(c2) & 3u) << 4) | ((agx_base_class(c3) & 3u) << 6));
+}
 
 // first compatible variant or append (AG:1375-1390 / 1493-1506).  Returns the index, or NONE when the bucket is full.
 AGX_HD agx_u32 agx_match_or_insert(const agx_bucket &b, agx_u32 &cnt, const agx_key &key, int iv, bool is_k1, agx_u32 s0, agx_u32 s1) {

@@ -25,6 +25,8 @@
 #include <mutex>
 #include <system_error>
 #include <thread>
+#include <condition_variable>
+#include <functional>
 #include <vector>
 
 #include "agx_host.h"
@@ -73,6 +75,40 @@ template <class F> void on_threads(unsigned threads, F fn) {      // (as in agx_
 
 }  // namespace
 
+// One helper thread per unit, started with the unit and asleep until it is handed work: what a unit can prepare while its upload and
+// build run (the pinned download buffers, the output buffers) without its worker waiting for it.  Not started on demand: creating a
+// thread maps a stack, and that waits for the address-space lock that another unit's hipHostRegister holds for milliseconds.
+struct UnitHelper {
+    enum { DL = 0, OUT = 1, SLOTS = 2 };
+    std::thread th; std::mutex m; std::condition_variable cv;
+    std::function<void()> job[SLOTS]; bool queued[SLOTS] = {false, false}, running[SLOTS] = {false, false}; bool stop = false, started = false;
+    void start() {
+        if (started) return;
+        th = std::thread([this] {
+            std::unique_lock<std::mutex> l(m);
+            for (;;) {
+                cv.wait(l, [this] { return stop || queued[DL] || queued[OUT]; });
+                if (stop) return;
+                const int s = queued[DL] ? DL : OUT;
+                std::function<void()> f = std::move(job[s]); queued[s] = false; running[s] = true;
+                l.unlock();
+                try { f(); } catch (...) { }
+                l.lock(); running[s] = false; cv.notify_all();
+            }
+        });
+        started = true;
+    }
+    bool submit(int s, std::function<void()> f) {       // false: no helper (the caller does the work itself, later)
+        if (!started) return false;
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !queued[s] && !running[s]; });
+        job[s] = std::move(f); queued[s] = true; cv.notify_all();
+        return true;
+    }
+    void wait(int s) { if (!started) return; std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !queued[s] && !running[s]; }); }
+    ~UnitHelper() { if (started) { { std::lock_guard<std::mutex> l(m); stop = true; } cv.notify_all(); th.join(); } }
+};
+
 struct agx_unit {
     agx_params prm{};
     std::string err;
@@ -81,17 +117,19 @@ struct agx_unit {
     struct Mapped { void *p = nullptr; size_t n = 0; void reset() { if (p) munmap(p, n); p = nullptr; n = 0; } ~Mapped() { reset(); } } cache_map;
     agx_u32 n_seg0 = 0, stride = 0, n_slots = 0; unsigned long long pairs_in_file = 0, sam_pairs = 0;
     bool have_ref = false, have_threads = false, staged = false, uploaded = false, built = false, downloaded = false;
+    bool consumed = false;             // AGX_FLAG_ONE_SHOT: the download has overwritten the staged inputs
+    bool expanded = false;             // the conti-mer tables and vote codes have been made from what was uploaded (opens the unit's first build)
+    hipEvent_t ev_built = nullptr;     // this unit's build commands are done (waited for on the host; ev_dl: its download)
     UnitOutput out; OutBuf out_initial; bool out_ready = false;      // output buffers of the next finish, reserved and touched by a helper thread while the unit is uploaded and built (prepare_outputs)
-    std::thread out_helper;
-    hipStream_t st = nullptr;
+    UnitHelper helper;
     DevArena arena;
     // staged inputs: what the device wants of T and P, in pinned memory (stage_inputs)
-    PBuf<agx_hit> s_hits; PBuf<agx_run> s_runs; PBuf<agx_u8> s_codes; PBuf<char> s_ref; PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
-    size_t nh = 0, n_runs = 0, n_cm = 0, n_codes = 0; agx_u32 maxlen = 0;      // n_codes: bytes of packed classes (two bases each)
+    PBuf<agx_hit> s_hits; PBuf<agx_run> s_runs; PBuf<agx_u8> s_codes; PBuf<unsigned long long> s_other; size_t n_other = 0; PBuf<char> s_ref; PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
+    size_t nh = 0, n_runs = 0, n_cm = 0, n_codes = 0; agx_u32 maxlen = 0;      // n_codes: bytes of packed classes (four bases each); n_other: listed bases that are not A, C, G, T
     std::vector<agx_u32> row_slot;      // staged read bases: one row per (pair, a mate) that some hit uses; row -> read slot
     // inputs on the device
     DBuf<agx_u32> d_cm_start, d_cm_cnt; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref; DBuf<agx_cmseg> d_segs; DBuf<unsigned long long> d_up_desc;
-    DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<agx_u8> d_codes, d_vcodes;
+    DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<agx_u8> d_codes, d_vcodes; DBuf<unsigned long long> d_other;
     // derived
     DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_recs, d_scan_tmp, d_words; DBuf<unsigned long long> d_scan_desc; size_t scan_desc_n = 0;      // descriptors of the three one-launch scans   // d_words: counters/status
     // node table
@@ -116,8 +154,7 @@ struct agx_unit {
     agx_stats stats{};
     ~agx_unit() {
         ev.destroy();
-        for (hipEvent_t e : {ev_front, ev_passA, ev_passJ, ev_up0, ev_uploaded, ev_dl}) if (e) (void)hipEventDestroy(e);
-        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        for (hipEvent_t e : {ev_front, ev_passA, ev_passJ, ev_up0, ev_uploaded, ev_dl, ev_built}) if (e) (void)hipEventDestroy(e);
     }
 };
 
@@ -130,13 +167,24 @@ namespace {
 // it starts when sweep n is done (an event) and sweep n+1 waits for it (another).  The node sweep itself never shares the device, so its
 // HIP-event time is that of an exclusive GPU; the other sections are timed in exclusive builds (AGX_FLAG_TIME_SECTIONS serialises the two
 // streams).  Uploads and copies to the host (counter words, download, record fetches) use the unit's own stream.
-struct DeviceTurn { std::mutex m; hipStream_t main = nullptr, front = nullptr; hipEvent_t sweep_done[2] = {nullptr, nullptr}, build_done[2] = {nullptr, nullptr};
+// Four streams per device serve all of its units: `up` carries the units' upload copies and nothing else, one unit after the other in the
+// order they were queued (PCIe is one pipe: five uploads that share it all finish late; first in, first built, and its host walk runs
+// beside the uploads of the rest); `front` and `main` carry the builds (see do_build); `down` the downloads.  Not a stream per unit: HIP
+// maps its streams onto four hardware queues, and two streams that share one run their commands in the order they were queued — a
+// build's first kernels sat 6 ms behind ANOTHER unit's upload copies, downloads 6-11 ms behind other units' kernels (profiles/r02_timeline_*.txt).
+struct DeviceTurn { std::mutex m; hipStream_t main = nullptr, front = nullptr, up = nullptr, down = nullptr;
+                    hipEvent_t sweep_done[2] = {nullptr, nullptr}, build_done[2] = {nullptr, nullptr};
                     unsigned long long n = 0; bool prev_exclusive = false; hipEvent_t prev_node = nullptr;      // n: builds queued so far; events alternate between two handles
-                    // Uploads of a device go one after the other: PCIe is one pipe, and five uploads that share it all finish late — first in,
-                    // first built, and its host walk runs beside the uploads of the rest.  The wait for the previous upload is on the HOST:
-                    // a stream that waits for an event blocks the hardware queue it shares with other streams (a unit's download sat 20-40 ms
-                    // behind other units' streams that were waiting for their upload turn).
-                    std::mutex up_m; hipEvent_t up_done[2] = {nullptr, nullptr}; unsigned long long up_n = 0; };
+                    std::mutex up_m, down_m, make_m;
+                    void make() {       // (device current)
+                        std::lock_guard<std::mutex> l(make_m);
+                        if (main) return;
+                        HIP_OK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking)); HIP_OK(hipStreamCreateWithFlags(&front, hipStreamNonBlocking));
+                        HIP_OK(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+                        for (auto &e : sweep_done) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                        for (auto &e : build_done) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                        HIP_OK(hipStreamCreateWithFlags(&main, hipStreamNonBlocking));
+                    } };
 DeviceTurn &turn_of(int device) { static DeviceTurn turns[64]; return turns[device & 63]; }
 
 // AGX_TRACE_GAP=1: diagnostic for loops that rebuild long-lived units (see do_build)
@@ -149,6 +197,7 @@ static const bool g_debug_sync = getenv("AGX_DEBUG_SYNC") != nullptr;
 #define g_tiny (getenv("AGX_TEST_SMALL_CAPS") != nullptr)
 #define AGX_CHECKPOINT(name) do { if (g_debug_sync) { hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, "[agx debug] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
 
+void join_dl_helper(agx_unit *u);
 void drop_outputs(agx_unit *u);     // before a unit's inputs change: the helper that prepares the output buffers reads them
 void start_helper(agx_unit *u);
 
@@ -170,7 +219,8 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
 
 // ---- staging: the packed arrays a unit was handed, in the form and the memory the upload wants -------------------------------------
 // Runs when the arrays are handed over (end of agx_unit_load_files, or agx_unit_stage after the last agx_unit_push_pairs; implied by an
-// upload that finds nothing staged).  The read bases cross PCIe as 4-bit classes (agx_pack_classes): half the bytes of the largest array.
+// upload that finds nothing staged).  The read bases cross PCIe as 2-bit classes plus a list of the few bases that are not A, C, G or T
+// (agx_pack_classes2): a quarter of the bytes of the largest array.
 void stage_inputs(agx_unit *u) {
     if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
     const double t0 = now_ms();
@@ -205,28 +255,35 @@ void stage_inputs(agx_unit *u) {
         lo = u->n_runs * t / threads; hi = u->n_runs * (t + 1) / threads; if (hi > lo) memcpy(u->s_runs.p + lo, runs + lo, (hi - lo) * sizeof(agx_run));
         lo = n_pos * t / threads; hi = n_pos * (t + 1) / threads; memcpy(u->s_ref.p + lo, u->T.ref.data() + lo, hi - lo);
     });
+    std::vector<agx_u16> row_len;                       // read length of every row: bases beyond it are never looked at
     {
         std::vector<agx_u32> row_of((size_t)u->P.n_slots + 1, AGX_NONE);
-        u->row_slot.clear(); u->row_slot.reserve(u->P.n_slots / 2 + 16);
+        u->row_slot.clear(); u->row_slot.reserve(u->P.n_slots / 2 + 16); row_len.reserve(u->P.n_slots / 2 + 16);
         for (size_t i = 0; i < u->nh; i++) {
             agx_hit &h = u->s_hits.p[i];
             const agx_u32 sa = h.slot1 + (h.pad[0] & 1u);
             if (sa >= u->P.n_slots) throw Error{E_ARG, "hit names a read slot outside the unit"};
-            if (row_of[sa] == AGX_NONE) { row_of[sa] = (agx_u32)u->row_slot.size(); u->row_slot.push_back(sa); }
+            if (row_of[sa] == AGX_NONE) { row_of[sa] = (agx_u32)u->row_slot.size(); u->row_slot.push_back(sa); row_len.push_back(h.len); }
+            else if (row_len[row_of[sa]] < h.len) row_len[row_of[sa]] = h.len;
             h.slot1 = row_of[sa];
         }
     }
-    const size_t half = u->P.stride / 2, n_rows = u->row_slot.size();
-    u->n_codes = n_rows * half;
+    const size_t quarter = u->P.stride / 4, n_rows = u->row_slot.size();
+    u->n_codes = n_rows * quarter;
     u->s_codes.alloc(u->n_codes + 16);
     const char *bases = u->P.bases.data(); agx_u8 *codes = u->s_codes.p;
+    std::vector<std::vector<unsigned long long>> other(threads);
     on_threads(threads, [&](unsigned t) {
         for (size_t r = n_rows * t / threads, hi = n_rows * (t + 1) / threads; r < hi; r++) {
-            const char *src = bases + (size_t)u->row_slot[r] * u->P.stride; agx_u8 *dst = codes + r * half;
-            for (size_t j = 0; j < half; j++) dst[j] = agx_pack_classes((agx_u8)src[2 * j], (agx_u8)src[2 * j + 1]);
+            const char *src = bases + (size_t)u->row_slot[r] * u->P.stride; agx_u8 *dst = codes + r * quarter;
+            for (size_t j = 0; j < quarter; j++) dst[j] = agx_pack_classes2((agx_u8)src[4 * j], (agx_u8)src[4 * j + 1], (agx_u8)src[4 * j + 2], (agx_u8)src[4 * j + 3]);
+            for (size_t j = 0, n = std::min<size_t>(row_len[r], u->P.stride); j < n; j++) if (agx_base_class((agx_u8)src[j]) == 4u) other[t].push_back((unsigned long long)r * u->P.stride + j);
         }
     });
-    u->staged = true; u->uploaded = false; u->built = false; u->downloaded = false;
+    u->n_other = 0; for (const auto &o : other) u->n_other += o.size();
+    u->s_other.alloc(u->n_other + 1);
+    { size_t at = 0; for (const auto &o : other) { if (!o.empty()) memcpy(u->s_other.p + at, o.data(), o.size() * 8); at += o.size(); } }      // (threads take ascending row ranges: the list is sorted)
+    u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0;
 }
 
@@ -237,14 +294,14 @@ void stage_inputs(agx_unit *u) {
 // mapped and paged in where it is touched.  Valid for one BATCH size and for exactly the five text files it was made from (size and
 // modification time of each are in the header): anything else and the loader falls back to the text.
 namespace cache {
-enum { S_HITS = 0, S_RUNS, S_CODES, S_SEGS, S_CHAIN_END, S_ROW_SLOT, S_REF, S_CM_START, S_CHAIN_STR, S_INITIAL, S_BASES, S_N };
+enum { S_HITS = 0, S_RUNS, S_CODES, S_SEGS, S_CHAIN_END, S_ROW_SLOT, S_REF, S_CM_START, S_CHAIN_STR, S_INITIAL, S_BASES, S_OTHER, S_N };
 struct Header {
     char magic[8]; agx_u32 version, batch; unsigned long long stamp[5][2];
     unsigned long long n_pos, n_ref, nh, n_runs, n_cm, n_segs, n_seg0, n_rows, n_chain_end, n_codes, pairs_in_file, sam_pairs;
     agx_u32 stride, maxlen, n_slots, pad;
     unsigned long long off[S_N], len[S_N];
 };
-const char MAGIC[8] = {'A', 'G', 'X', 'U', 'N', 'I', 'T', '2'};
+const char MAGIC[8] = {'A', 'G', 'X', 'U', 'N', 'I', 'T', '3'};
 void stamps(const std::string &d, int unit, unsigned long long st[5][2]) {
     const std::string s = std::to_string(unit);
     const std::string f[5] = {d + "/_genome." + s + ".fa", d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie"};
@@ -261,9 +318,9 @@ void save_cache(agx_unit *u, const std::string &dir, int unit) {
     stamps(dir, unit, H.stamp);
     H.n_pos = u->V.n_pos; H.n_ref = u->V.n_ref; H.nh = u->nh; H.n_runs = u->n_runs; H.n_cm = u->n_cm; H.n_segs = u->n_segs; H.n_seg0 = u->n_seg0; H.n_rows = u->row_slot.size();
     H.n_chain_end = u->n_chain_end; H.n_codes = u->n_codes; H.pairs_in_file = u->pairs_in_file; H.sam_pairs = u->sam_pairs; H.stride = u->stride; H.maxlen = u->maxlen; H.n_slots = u->n_slots;
-    const void *ptr[S_N] = {u->s_hits.p, u->s_runs.p, u->s_codes.p, u->s_segs.p, u->s_chain_end.p, u->row_slot.data(), u->V.ref, u->V.cm_start, u->V.chain_str, u->V.initial, u->V.bases};
+    const void *ptr[S_N] = {u->s_hits.p, u->s_runs.p, u->s_codes.p, u->s_segs.p, u->s_chain_end.p, u->row_slot.data(), u->V.ref, u->V.cm_start, u->V.chain_str, u->V.initial, u->V.bases, u->s_other.p};
     const unsigned long long len[S_N] = {u->nh * sizeof(agx_hit), u->n_runs * sizeof(agx_run), u->n_codes, u->n_segs * sizeof(agx_cmseg), (unsigned long long)u->n_chain_end * 4, u->row_slot.size() * 4,
-                                         u->V.n_pos, (u->V.n_pos + 1) * 4, u->T.chain_str.size(), u->V.n_initial, (unsigned long long)u->n_slots * u->stride};
+                                         u->V.n_pos, (u->V.n_pos + 1) * 4, u->T.chain_str.size(), u->V.n_initial, (unsigned long long)u->n_slots * u->stride, (unsigned long long)u->n_other * 8};
     unsigned long long at = (sizeof(Header) + 4095) & ~4095ull;
     for (int i = 0; i < S_N; i++) { H.off[i] = at; H.len[i] = len[i]; at = (at + len[i] + 4095) & ~4095ull; }
     const std::string path = path_of(dir, unit), part = path + ".part";
@@ -291,7 +348,7 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     for (int i = 0; i < S_N; i++) if (H.off[i] + H.len[i] > (unsigned long long)sb.st_size) return false;
     if (H.n_pos == 0 || H.n_pos >= 0xFFFFFF00ull || H.len[S_REF] != H.n_pos || H.len[S_CM_START] != (H.n_pos + 1) * 4 || H.len[S_HITS] != H.nh * sizeof(agx_hit) || H.len[S_RUNS] != H.n_runs * sizeof(agx_run) ||
         H.len[S_CODES] != H.n_codes || H.len[S_SEGS] != H.n_segs * sizeof(agx_cmseg) || H.len[S_ROW_SLOT] != H.n_rows * 4 || H.len[S_BASES] != (unsigned long long)H.n_slots * H.stride || (H.stride & 15u) ||
-        H.len[S_CHAIN_END] != H.n_chain_end * 4) return false;
+        H.len[S_CHAIN_END] != H.n_chain_end * 4 || H.n_codes != H.n_rows * (H.stride / 4) || (H.len[S_OTHER] & 7u)) return false;
     HIP_OK(hipSetDevice(u->prm.device));
     const double t0 = now_ms();
     void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -299,14 +356,14 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     drop_outputs(u);
     u->T = Threads(); u->P = Pairs(); u->cache_map.reset(); u->cache_map.p = m; u->cache_map.n = (size_t)sb.st_size;
     const char *base = (const char *)m;
-    u->nh = H.nh; u->n_runs = H.n_runs; u->n_cm = H.n_cm; u->n_segs = H.n_segs; u->n_seg0 = (agx_u32)H.n_seg0; u->n_chain_end = (agx_u32)H.n_chain_end; u->n_codes = H.n_codes;
+    u->nh = H.nh; u->n_runs = H.n_runs; u->n_cm = H.n_cm; u->n_segs = H.n_segs; u->n_seg0 = (agx_u32)H.n_seg0; u->n_chain_end = (agx_u32)H.n_chain_end; u->n_codes = H.n_codes; u->n_other = H.len[S_OTHER] / 8;
     u->pairs_in_file = H.pairs_in_file; u->sam_pairs = H.sam_pairs; u->stride = H.stride; u->maxlen = H.maxlen; u->n_slots = H.n_slots;
-    u->s_hits.alloc(u->nh + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16); u->s_segs.alloc(u->n_segs + 1); u->s_chain_end.alloc((size_t)u->n_chain_end + 1); u->s_ref.alloc(H.n_pos);
+    u->s_hits.alloc(u->nh + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16); u->s_other.alloc(u->n_other + 1); u->s_segs.alloc(u->n_segs + 1); u->s_chain_end.alloc((size_t)u->n_chain_end + 1); u->s_ref.alloc(H.n_pos);
     // the staged arrays: read into the pinned buffers, a few threads, large pieces
     struct Piece { void *dst; unsigned long long off, len; };
     std::vector<Piece> pieces;
     auto cut = [&](void *dst, int sec) { for (unsigned long long a = 0; a < H.len[sec]; a += 32ull << 20) pieces.push_back(Piece{(char *)dst + a, H.off[sec] + a, std::min<unsigned long long>(32ull << 20, H.len[sec] - a)}); };
-    cut(u->s_hits.p, S_HITS); cut(u->s_runs.p, S_RUNS); cut(u->s_codes.p, S_CODES); cut(u->s_segs.p, S_SEGS); cut(u->s_chain_end.p, S_CHAIN_END); cut(u->s_ref.p, S_REF);
+    cut(u->s_hits.p, S_HITS); cut(u->s_runs.p, S_RUNS); cut(u->s_codes.p, S_CODES); cut(u->s_other.p, S_OTHER); cut(u->s_segs.p, S_SEGS); cut(u->s_chain_end.p, S_CHAIN_END); cut(u->s_ref.p, S_REF);
     const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), pieces.size() ? pieces.size() : 1);
     std::vector<int> bad(threads, 0);
     on_threads(threads, [&](unsigned t) {
@@ -316,11 +373,12 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
         }
     });
     for (int b : bad) if (b) { u->cache_map.reset(); return false; }
+    { const unsigned long long n_bases = H.n_rows * (unsigned long long)H.stride; for (size_t i = 0; i < u->n_other; i++) if (u->s_other.p[i] >= n_bases) { u->cache_map.reset(); return false; } }
     u->row_slot.assign((const agx_u32 *)(base + H.off[S_ROW_SLOT]), (const agx_u32 *)(base + H.off[S_ROW_SLOT]) + H.n_rows);
     UnitView V; V.ref = u->s_ref.p; V.n_pos = H.n_pos; V.n_ref = (agx_u32)H.n_ref; V.cm_start = (const agx_u32 *)(base + H.off[S_CM_START]); V.chain_str = base + H.off[S_CHAIN_STR];
     V.hop = nullptr; V.bases = base + H.off[S_BASES]; V.stride = H.stride; V.initial = base + H.off[S_INITIAL]; V.n_initial = H.len[S_INITIAL];
     u->V = V;
-    u->have_ref = u->have_threads = true; u->staged = true; u->uploaded = false; u->built = false; u->downloaded = false;
+    u->have_ref = u->have_threads = true; u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0; u->stats.ms_parse = 0; u->stats.ms_thread = 0; u->stats.from_cache = 1;
     return true;
 }
@@ -333,7 +391,7 @@ agx_u32 spill_min(const agx_unit *u) { const size_t n_pos = u->V.n_pos; return (
 // Slices of the node pool, one per region, and the spill area behind them.  Without a measurement every region gets the same share of
 // `main_cap` ids; after a build in which the pool ran out, `demand` holds what every region asked for (the counters keep counting) and the
 // slices are cut to that plus slack.  Returns the ids the layout needs; applies it (queues the copy on the unit's stream) if they fit.
-unsigned long long layout_regions(agx_unit *u, const agx_u32 *demand, agx_u32 main_cap, bool apply) {
+unsigned long long layout_regions(agx_unit *u, const agx_u32 *demand, agx_u32 main_cap, bool apply, hipStream_t st) {
     const agx_u32 R = u->n_regions;
     u->s_region_off.alloc((size_t)R + 1);
     agx_u32 *off = u->s_region_off.p;
@@ -345,7 +403,7 @@ unsigned long long layout_regions(agx_unit *u, const agx_u32 *demand, agx_u32 ma
     const unsigned long long need = at + spill_min(u);
     if (!apply || need > u->pool_cap) return need;
     off[R] = (agx_u32)at; u->spill_lo = (agx_u32)at;
-    HIP_OK(hipMemcpyAsync(u->d_region_off.p, off, ((size_t)R + 1) * 4, hipMemcpyHostToDevice, u->st));
+    HIP_OK(hipMemcpyAsync(u->d_region_off.p, off, ((size_t)R + 1) * 4, hipMemcpyHostToDevice, st));
     return need;
 }
 
@@ -379,16 +437,16 @@ void do_release(agx_unit *u);
 // from the staged pinned arrays, on the unit's own stream: beside whatever other units run on the device) and the two upload-time kernels
 // are queued.  Nothing waits on the host: the build's first kernel waits for ev_uploaded on the device.
 void do_upload(agx_unit *u) {
+    if (u->consumed) throw Error{E_ARG, "one-shot unit: hand its inputs over again before another upload"};
     if (!u->staged) stage_inputs(u);
     if (u->arena.used()) do_release(u);              // uploaded before: start over (the unit's blocks go through the cache)
     const double t0 = now_ms();
-    start_helper(u);
     HIP_OK(hipSetDevice(u->prm.device));
     const size_t n_pos = u->V.n_pos, nh = u->nh;
     u->arena.device = u->prm.device;
     u->n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
     u->n_regions = (u->n_tiles + AGX_REGION_TILES - 1) / AGX_REGION_TILES;
-    const size_t n_bases = u->n_codes * 2;
+    const size_t n_bases = u->n_codes * 4;
     // capacities of a first build
     const agx_u32 main_cap = (agx_u32)std::min<size_t>(g_tiny ? n_pos / 8 + 64 : n_pos + n_pos / 4 + 4096, 0xE0000000ull);
     const agx_u32 pool_cap = u->pool_cap ? u->pool_cap : main_cap + spill_min(u);
@@ -401,7 +459,7 @@ void do_upload(agx_unit *u) {
     {   // one block for all of it (what the takes below add up to, plus the alignment of ~90 buffers)
         const size_t per_pos = 4 + 16 + 1 + 4 + 1 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_hit) + sizeof(agx_dhit) + 16 + 4;
         const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
-        const size_t total = n_pos * per_pos + u->n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases +
+        const size_t total = n_pos * per_pos + u->n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases + u->n_other * 8 +
                              (size_t)pool_cap * per_slot + ids_cap * per_id + (size_t)list_cap * 36 + (size_t)ovf_cap * 16 + (size_t)sp_cap * sizeof(agx_walknode) +
                              (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64 * 4 + (size_t)u->n_regions * AGX_REGION_PAD * 4 + (64u << 10) * 100;
         u->arena.reserve(total + total / 64);
@@ -409,7 +467,7 @@ void do_upload(agx_unit *u) {
     DevArena &a = u->arena;
     u->d_cm_start.alloc(a, n_pos + 2); u->d_cm_cnt.alloc(a, n_pos + 2); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos); u->d_cm_head.alloc(a, n_pos + 1);
     u->d_segs.alloc(a, u->n_segs + 1); u->d_up_desc.alloc(a, (n_pos + 2) / 4096 + 2);
-    u->d_hits.alloc(a, nh + 1); u->d_runs.alloc(a, u->n_runs + 1); u->d_codes.alloc(a, u->n_codes + 16); u->d_vcodes.alloc(a, n_bases + 16);
+    u->d_hits.alloc(a, nh + 1); u->d_runs.alloc(a, u->n_runs + 1); u->d_codes.alloc(a, u->n_codes + 16); u->d_vcodes.alloc(a, n_bases + 16); u->d_other.alloc(a, u->n_other + 1);
     u->d_dhit.alloc(a, nh + 1); u->d_rank4.alloc(a, 4 * (nh + 1));
     u->d_tile_cnt.alloc(a, (size_t)u->n_tiles + 1); u->d_tile_off.alloc(a, (size_t)u->n_tiles + 2); u->d_cursor.alloc(a, (size_t)u->n_tiles + 1);
     u->d_words.alloc(a, W_N + 6 + 16); u->h_words.alloc(W_N + 6 + 16);
@@ -420,52 +478,54 @@ void do_upload(agx_unit *u) {
     u->d_scratch.alloc(a, (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64);
     u->d_region_off.alloc(a, (size_t)u->n_regions + 1); u->d_pool_cnt.alloc(a, (size_t)u->n_regions * AGX_REGION_PAD);
     alloc_pool(u, pool_cap); alloc_lists(u, list_cap); alloc_ovf(u, ovf_cap); alloc_sparse(u, sp_cap);
-    // copies
-    hipStream_t st = u->st;
+    // copies: all of them on the device's upload stream, behind those of the units queued before.  The kernels that expand what was copied
+    // (conti-mer tables, vote codes) open the unit's first build instead of following the copies here: a kernel on this stream would wait for
+    // CUs while another unit's node sweep holds them all, and every later unit's copies with it.
     DeviceTurn &turn = turn_of(u->prm.device);
+    turn.make();
+    hipStream_t st = turn.up;
     trace(u, "upload: allocate", t0, n_pos);
-    const double tw = now_ms();
-    std::unique_lock<std::mutex> up_turn(turn.up_m);
-    for (auto &e : turn.up_done) if (!e) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (turn.up_n) HIP_OK(hipEventSynchronize(turn.up_done[(turn.up_n - 1) & 1]));
-    trace(u, "upload: wait for turn", tw, n_pos);
     const double tq = now_ms();
-    u->up_timed = u->ev.all;
-    if (u->up_timed) HIP_OK(hipEventRecord(u->ev_up0, st));
-    // (AGX_UP_CHUNK_MB: experiment knob — copies cut into pieces of that size, so that other streams' copies can get in between)
-    static const size_t chunk = getenv("AGX_UP_CHUNK_MB") ? (size_t)atoi(getenv("AGX_UP_CHUNK_MB")) << 20 : 0;
-    auto up = [&](void *dst, const void *src, size_t bytes) {
-        for (size_t at = 0; at < bytes;) { const size_t m = chunk ? std::min(chunk, bytes - at) : bytes; HIP_OK(hipMemcpyAsync((char *)dst + at, (const char *)src + at, m, hipMemcpyHostToDevice, st)); at += m; }
-    };
-    // ALL COPIES FIRST, the upload's kernels behind them: the copy engines need no CU, but a kernel queued on this stream while another
-    // unit's node sweep holds every CU waits for it — and with it every copy queued behind that kernel (the rocprofv3 trace of a cfg3 job
-    // showed 4-5 ms of idle PCIe per unit that way, profiles/r02_overlap.txt).  The next unit's turn begins when the copies are done.
-    up(u->d_segs.p, u->s_segs.p, u->n_segs * sizeof(agx_cmseg)); up(u->d_ref.p, u->s_ref.p, n_pos);
-    up(u->d_hits.p, u->s_hits.p, nh * sizeof(agx_hit)); up(u->d_runs.p, u->s_runs.p, u->n_runs * sizeof(agx_run));
-    up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);
-    up(u->d_codes.p, u->s_codes.p, u->n_codes);
-    layout_regions(u, nullptr, pool_cap - spill_min(u), true);
-    HIP_OK(hipEventRecord(turn.up_done[turn.up_n & 1], st)); turn.up_n++;
-    // conti-mer tables from their runs (agx_cmseg): count per position, scan, keys, heads; read bases: 4-bit classes -> vote codes
-    HIP_OK(hipMemsetAsync(u->d_cm_cnt.p, 0, (n_pos + 2) * 4, st)); HIP_OK(hipMemsetAsync(u->d_up_desc.p, 0, ((n_pos + 2) / 4096 + 2) * 8, st));
-    agx_launch_seg_expand(u->d_segs.p, (agx_u32)u->n_segs, (agx_u32)u->n_cm, u->d_cm_cnt.p, u->d_cm_start.p, u->d_cm.p, (agx_u32)n_pos, u->d_up_desc.p, st);
-    agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, (agx_u32)n_pos, st);
-    agx_launch_expand_codes(u->d_codes.p, u->d_vcodes.p, (n_bases + 15) / 16 * 16, st);
-    HIP_OK(hipEventRecord(u->ev_uploaded, st));
-    up_turn.unlock();
-    trace(u, "upload: queue copies", tq, n_pos);
-    {   // While the copies run: the download's pinned buffers, by estimate (walk ids ~ 1.05 x positions, special ids ~ 8 % of them).  Mapping and
-        // registering them costs 5-9 ms for a cold cache; here it hides behind this unit's own copies (between the build and the download it
-        // was on the unit's critical path; beside the build's kernels, or at the start of do_build, it held up the other units' HIP calls:
-        // 102 and 95 ms per cfg3 job against 88 here); do_download re-sizes what is too small
-        const size_t ni = n_pos + n_pos / 8 + 4096, nw = ni / 64 + 1, ns = ni / 8 + 4096;
-        u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(n_pos / 8 + 4097);
-        u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2); u->h_a_ovf.alloc(64);
+    {
+        std::lock_guard<std::mutex> up_turn(turn.up_m);
+        u->up_timed = u->ev.all;
+        if (u->up_timed) HIP_OK(hipEventRecord(u->ev_up0, st));
+        // (AGX_UP_CHUNK_MB: experiment knob — copies cut into pieces of that size)
+        static const size_t chunk = getenv("AGX_UP_CHUNK_MB") ? (size_t)atoi(getenv("AGX_UP_CHUNK_MB")) << 20 : 0;
+        auto up = [&](void *dst, const void *src, size_t bytes) {
+            for (size_t at = 0; at < bytes;) { const size_t m = chunk ? std::min(chunk, bytes - at) : bytes; HIP_OK(hipMemcpyAsync((char *)dst + at, (const char *)src + at, m, hipMemcpyHostToDevice, st)); at += m; }
+        };
+        up(u->d_segs.p, u->s_segs.p, u->n_segs * sizeof(agx_cmseg)); up(u->d_ref.p, u->s_ref.p, n_pos);
+        up(u->d_hits.p, u->s_hits.p, nh * sizeof(agx_hit)); up(u->d_runs.p, u->s_runs.p, u->n_runs * sizeof(agx_run));
+        up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);
+        up(u->d_codes.p, u->s_codes.p, u->n_codes); up(u->d_other.p, u->s_other.p, u->n_other * 8);
+        layout_regions(u, nullptr, pool_cap - spill_min(u), true, st);
+        HIP_OK(hipEventRecord(u->ev_uploaded, st));
     }
+    u->expanded = false;
+    trace(u, "upload: queue copies", tq, n_pos);
+    // While the copies run: the download's pinned buffers, by estimate (walk ids ~ 1.05 x positions, special ids ~ 8 % of them), on a helper
+    // thread.  Mapping and registering them costs 5-13 ms for a cold cache.  Between the build and the download that was on the unit's critical
+    // path; on the unit's worker right here it kept the NEXT unit's upload from starting (a job hands its units out one at a time); beside the
+    // build's kernels, or at the start of do_build, it held up the other units' HIP calls.  do_download joins the helper and re-sizes what is too small.
+    auto dl_buffers = [u, n_pos] {
+        static std::mutex one_at_a_time;      // five units pinning memory at once take five times as long each, and stall everything else that touches the address space
+        std::lock_guard<std::mutex> l(one_at_a_time);
+        const double th0 = now_ms();
+        try {
+            if (hipSetDevice(u->prm.device) != hipSuccess) return;
+            const size_t ni = n_pos + n_pos / 8 + 4096, nw = ni / 64 + 1, ns = ni / 8 + 4096;
+            u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(n_pos / 8 + 4097);
+            u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2); u->h_a_ovf.alloc(64);
+        } catch (...) { }                               // do_download allocates what is missing and reports
+        trace(u, "helper: download buffers", th0, n_pos);
+    };
+    if (!(u->prm.flags & AGX_FLAG_ONE_SHOT)) u->helper.submit(UnitHelper::DL, dl_buffers);      // (a one-shot unit's download borrows the staged inputs' memory: nothing to pin)
+    start_helper(u);                                     // then the output buffers
 
     u->uploaded = true; u->built = false; u->downloaded = false;
     u->stats.ms_upload = now_ms() - t0;
-    u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + n_pos + nh * sizeof(agx_hit) + u->n_runs * sizeof(agx_run) + (size_t)u->n_chain_end * 4 + u->n_codes + ((size_t)u->n_regions + 1) * 4;
+    u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + n_pos + nh * sizeof(agx_hit) + u->n_runs * sizeof(agx_run) + (size_t)u->n_chain_end * 4 + u->n_codes + u->n_other * 8 + ((size_t)u->n_regions + 1) * 4;
     u->stats.device_bytes = u->arena.capacity();
 }
 
@@ -475,6 +535,8 @@ void do_upload(agx_unit *u) {
 // the unit is uploaded and built; agx_unit_finish joins it.
 void prepare_outputs(agx_unit *u) {
     if (u->out_ready) return;
+    static std::mutex one_at_a_time;
+    std::lock_guard<std::mutex> l(one_at_a_time);
     try {
         const size_t n_pos = u->V.n_pos;
         u->out.pre_extended.n = 0; u->out.extended.n = 0; u->out_initial.n = 0;
@@ -485,12 +547,13 @@ void prepare_outputs(agx_unit *u) {
         u->out_ready = true;
     } catch (...) { u->out_ready = false; }                              // out of memory: agx_unit_finish tries again on its own thread and reports
 }
-void join_helper(agx_unit *u) { if (u->out_helper.joinable()) u->out_helper.join(); }
+void join_helper(agx_unit *u) { u->helper.wait(UnitHelper::OUT); }
+void join_dl_helper(agx_unit *u) { u->helper.wait(UnitHelper::DL); }
 void drop_outputs(agx_unit *u) { join_helper(u); u->out_ready = false; }
 void start_helper(agx_unit *u) {
     join_helper(u);
     if (u->out_ready) return;
-    try { u->out_helper = std::thread(prepare_outputs, u); } catch (...) { }      // no thread to be had: finish prepares the outputs itself
+    u->helper.submit(UnitHelper::OUT, [u] { const double th0 = now_ms(); prepare_outputs(u); trace(u, "helper: output buffers", th0, u->V.n_pos); });      // (no helper: finish prepares the outputs itself)
 }
 
 // All kernels of one build are queued back to back with the current buffer capacities; the counters they produce (tile-list
@@ -514,16 +577,18 @@ void do_build(agx_unit *u) {
         const double tb1 = now_ms();
         DeviceTurn &turn = turn_of(u->prm.device);
         std::unique_lock<std::mutex> my_turn(turn.m);
-        if (!turn.main) {
-            HIP_OK(hipStreamCreateWithFlags(&turn.main, hipStreamNonBlocking)); HIP_OK(hipStreamCreateWithFlags(&turn.front, hipStreamNonBlocking));
-            for (auto &e : turn.sweep_done) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            for (auto &e : turn.build_done) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
         // ---- front (its own stream): may run beside the previous build's edge passes and walk preparation, not beside its sweep ----
         st = turn.front;
-        HIP_OK(hipStreamWaitEvent(st, u->ev_uploaded, 0));      // the unit's inputs (and a region layout that a retry re-cut) are in HBM (already: see below)
         if (turn.n) HIP_OK(hipStreamWaitEvent(st, (u->ev.all || turn.prev_exclusive) ? turn.build_done[(turn.n - 1) & 1] : turn.sweep_done[(turn.n - 1) & 1], 0));
         if (u->ev.all) HIP_OK(hipEventRecord(u->ev.first, st));      // (every event record costs the stream a few microseconds: untimed builds record only what orders them)
+        if (!u->expanded) {   // the unit's first build: conti-mer tables from their runs (agx_cmseg: count per position, scan, keys, heads); read bases: 2-bit classes and the list of other bases -> vote codes
+            const size_t n_bases = u->n_codes * 4;
+            HIP_OK(hipMemsetAsync(u->d_cm_cnt.p, 0, ((size_t)n_pos + 2) * 4, st)); HIP_OK(hipMemsetAsync(u->d_up_desc.p, 0, (((size_t)n_pos + 2) / 4096 + 2) * 8, st));
+            agx_launch_seg_expand(u->d_segs.p, (agx_u32)u->n_segs, (agx_u32)u->n_cm, u->d_cm_cnt.p, u->d_cm_start.p, u->d_cm.p, n_pos, u->d_up_desc.p, st);
+            agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, n_pos, st);
+            agx_launch_expand_codes(u->d_codes.p, u->d_vcodes.p, (n_bases + 15) / 16 * 16, u->d_other.p, u->n_other, st);
+            u->expanded = true;
+        }
         {   // everything a build counts into or marks, zeroed by one kernel and one fill (every command on the stream costs a few microseconds)
             agx_zero_args Z; memset(&Z, 0, sizeof Z);
             auto seg = [&](int i, agx_u32 *ptr, size_t words) { Z.p[i] = ptr; Z.n[i] = (agx_u32)words; };
@@ -616,16 +681,15 @@ void do_build(agx_unit *u) {
         // ---- the one synchronisation ----
         u->stats.edge_sweep_launches++;
         if (u->ev.all) HIP_OK(hipEventRecord(u->ev.last, st));
-        hipEvent_t done = turn.build_done[turn.n & 1];                       // (a stream wait binds to the record that precedes it: the handle may be recorded again later)
-        HIP_OK(hipEventRecord(done, st));
-        HIP_OK(hipStreamWaitEvent(u->st, done, 0));
+        HIP_OK(hipEventRecord(turn.build_done[turn.n & 1], st));               // (a stream wait binds to the record that precedes it: the handle may be recorded again later)
+        {   void *dst = u->h_words.dev(); const void *src = u->d_words.p; const size_t bytes = (W_N + 6 + 16) * 4;      // the counters, by a kernel at the end of the chain (a copy
+            agx_launch_copy_out(&dst, &src, &bytes, 1, st); }                                                              // command would queue behind the uploads on the copy engines)
+        HIP_OK(hipEventRecord(u->ev_built, st));
         turn.n++; turn.prev_exclusive = u->ev.all;
         my_turn.unlock();
         trace(u, "build: queue kernels", tb1, n_pos);
         const double tb2 = now_ms();
-        {   void *dst = u->h_words.dev(); const void *src = u->d_words.p; const size_t bytes = (W_N + 6 + 16) * 4;      // (by a kernel: a copy command would queue behind
-            agx_launch_copy_out(&dst, &src, &bytes, 1, u->st); }                                                            // the uploads other units have waiting on the SDMA rings)
-        HIP_OK(hipStreamSynchronize(u->st));
+        HIP_OK(hipEventSynchronize(u->ev_built));
         trace(u, "build: wait for kernels", tb2, n_pos);
         HIP_OK(hipGetLastError());
         if (g_trace_gap && trace_from && trace_from != u->ev.e[B_NODE]) {      // diagnostic (units must outlive each other's builds): end of the previous sweep -> start of this one
@@ -635,28 +699,28 @@ void do_build(agx_unit *u) {
         if (w[W_ERR] & 2u) throw Error{E_UNSUPPORTED, "read alignment beyond the end of the unit sequence"};
         u->n_tile_entries = w[W_N];
         // a capacity that was too small: take a larger buffer (the arena keeps the old one until the unit is released) and build again.
-        // Whatever a retry changes on the device goes through the unit's stream and a fresh ev_uploaded, which the next attempt waits for.
+        // Whatever a retry changes on the device goes through the download stream and a fresh ev_uploaded, which the next attempt waits for.
         bool again = false;
         if (u->n_tile_entries > u->list_cap) { alloc_lists(u, u->n_tile_entries + u->n_tile_entries / 8 + 1024); again = true; }
         else {
             if ((w[W_STATUS] & 2u) && !u->huge) {     // a position beyond the 64 variants of pass 2 (deep repeats under a wide --distanceHigh): queue pass 3 and build again
                 u->huge = true; u->d_huge_list.alloc(u->arena, (size_t)u->n_tiles + 1); u->d_scratch_huge.alloc(u->arena, (size_t)AGX_HUGE_WAVES * AGX_NF * AGX_MAXV_HUGE * 64);
-                HIP_OK(hipEventRecord(u->ev_uploaded, u->st)); continue;
+                HIP_OK(hipEventRecord(u->ev_uploaded, turn.down)); continue;
             }
             if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 255 node variants at one position"};
             if (w[W_STATUS] & 1u) {                  // the node pool ran out: cut the slices to what the regions asked for
                 std::vector<agx_u32> padded((size_t)u->n_regions * AGX_REGION_PAD), demand(u->n_regions);
-                HIP_OK(hipMemcpyAsync(padded.data(), u->d_pool_cnt.p, padded.size() * 4, hipMemcpyDeviceToHost, u->st)); HIP_OK(hipStreamSynchronize(u->st));
+                HIP_OK(hipMemcpyAsync(padded.data(), u->d_pool_cnt.p, padded.size() * 4, hipMemcpyDeviceToHost, turn.down)); HIP_OK(hipStreamSynchronize(turn.down));
                 for (agx_u32 r = 0; r < u->n_regions; r++) demand[r] = padded[(size_t)r * AGX_REGION_PAD];
-                const unsigned long long need = layout_regions(u, demand.data(), 0, false);
+                const unsigned long long need = layout_regions(u, demand.data(), 0, false, turn.down);
                 if (need >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "node table exceeds 2^32 entries"};
                 if (need > u->pool_cap) alloc_pool(u, (agx_u32)need);
-                layout_regions(u, demand.data(), 0, true);
+                layout_regions(u, demand.data(), 0, true, turn.down);
                 again = true;
             } else if (w[W_OVFCOUNT] > u->ovf_cap) { alloc_ovf(u, w[W_OVFCOUNT] + w[W_OVFCOUNT] / 2 + 1024); again = true; }
             else if (w[W_N + 2] > u->sp_cap) { alloc_sparse(u, w[W_N + 2] + w[W_N + 2] / 8 + 1024); again = true; }
         }
-        if (again) { HIP_OK(hipEventRecord(u->ev_uploaded, u->st)); continue; }
+        if (again) { HIP_OK(hipEventRecord(u->ev_uploaded, turn.down)); continue; }
         u->n_nodes = w[W_POOL]; u->n_big = w[W_BIGCOUNT]; u->n_mid = w[W_MIDCOUNT]; u->n_ovf = w[W_OVFCOUNT];
         const unsigned long long ids = (unsigned long long)n_pos + w[W_N + 1];
         if (ids >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "walk graph exceeds 2^32 ids"};
@@ -682,22 +746,41 @@ void do_download(agx_unit *u) {
     HIP_OK(hipSetDevice(u->prm.device));             // the calling thread may never have touched this device
     const double t0 = now_ms();
     const size_t n_pos = u->V.n_pos, ni = u->n_ids;
-    hipStream_t st = u->st;
+    DeviceTurn &turn = turn_of(u->prm.device);
     const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
+    join_dl_helper(u);
+    if (u->prm.flags & AGX_FLAG_ONE_SHOT) {
+        // The inputs are in HBM and will not be uploaded again: their staged copies are dead pinned memory.  The download's arrays are cut
+        // from the largest of those blocks, largest array first; what does not fit (thin read sets) gets a buffer of its own below.
+        struct Room { char *at; size_t left; } room[5] = {{(char *)u->s_hits.p, u->s_hits.block_bytes()}, {(char *)u->s_codes.p, u->s_codes.block_bytes()},
+                                                          {(char *)u->s_runs.p, u->s_runs.block_bytes()}, {(char *)u->s_other.p, u->s_other.block_bytes()}, {(char *)u->s_segs.p, u->s_segs.block_bytes()}};
+        auto cut = [&](auto &buf, size_t count) {
+            using T = typename std::remove_reference<decltype(*buf.p)>::type;
+            const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+            for (Room &r : room) if (r.at && r.left >= bytes) { buf.borrow((T *)r.at, count); r.at += bytes; r.left -= bytes; return; }
+        };
+        u->consumed = true; u->staged = false;
+        cut(u->h_sp_node, ns + 1); cut(u->h_a_meta, ni + 64); cut(u->h_a_str, ni + 1); cut(u->h_sp_hop, ns + 2); cut(u->h_side_xpos, nside + 1);
+        cut(u->h_sp_bits, nw + 1); cut(u->h_sp_rank, nw + 1); cut(u->h_a_ovf, (size_t)u->n_ovf + 1);
+    }
     u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(nside + 1);
     u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2);
     u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
-    // a kernel stores the walk graph into the pinned buffers (agx_k_copy_out: copy commands would queue behind other units' uploads)
+    // the walk graph into the pinned buffers, by the copy engines on the device's download stream (r02 first used a kernel for this — its
+    // copies seemed to queue behind other units' uploads; that was the shared hardware queue, not the engines, and the kernel's wavefronts
+    // slowed the next unit's build: the five builds of a cfg3 job ended at 45 ms with it, at 36 ms without)
     {
         void *dst[8]; const void *src[8]; size_t bytes[8]; int n = 0;
         auto add = [&](void *h, const void *d, size_t b) { if (b) { dst[n] = h; src[n] = d; bytes[n] = b; n++; } };
-        if (ni) { add(u->h_sp_bits.dev(), u->d_sp_bits.p, nw * 8); add(u->h_sp_rank.dev(), u->d_sp_rank.p, nw * 4); add(u->h_a_str.dev(), u->d_a_str.p, ni); add(u->h_a_meta.dev(), u->d_a_meta.p, ni); }
-        add(u->h_side_xpos.dev(), u->d_side_xpos.p, nside * 4);
-        add(u->h_sp_node.dev(), u->d_sp_node.p, ns * sizeof(agx_walknode)); add(u->h_sp_hop.dev(), u->d_sp_hop.p, ns * sizeof(agx_hop)); add(u->h_a_ovf.dev(), u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf));
-        agx_launch_copy_out(dst, src, bytes, n, st);
+        if (ni) { add(u->h_sp_bits.p, u->d_sp_bits.p, nw * 8); add(u->h_sp_rank.p, u->d_sp_rank.p, nw * 4); add(u->h_a_str.p, u->d_a_str.p, ni); add(u->h_a_meta.p, u->d_a_meta.p, ni); }
+        add(u->h_side_xpos.p, u->d_side_xpos.p, nside * 4);
+        add(u->h_sp_node.p, u->d_sp_node.p, ns * sizeof(agx_walknode)); add(u->h_sp_hop.p, u->d_sp_hop.p, ns * sizeof(agx_hop)); add(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf));
+        std::lock_guard<std::mutex> l(turn.down_m);
+        for (int i = 0; i < n; i++) HIP_OK(hipMemcpyAsync(dst[i], src[i], bytes[i], hipMemcpyDeviceToHost, turn.down));
+        HIP_OK(hipEventRecord(u->ev_dl, turn.down));
     }
     const double t1 = now_ms();
-    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipEventSynchronize(u->ev_dl));
     if (getenv("AGX_DL_TIMING")) fprintf(stderr, "[agx download] buffers %.2f ms, copies %.2f ms (%zu ids, %zu records)\n", t1 - t0, now_ms() - t1, ni, ns);
     memset(u->h_a_meta.p + ni, 0, 64);
     u->stats.n_walk_ids = ni; u->stats.n_special = ns;
@@ -712,11 +795,13 @@ void do_download(agx_unit *u) {
 void do_release(agx_unit *u) {
     const double tr0 = now_ms();
     struct Tr { agx_unit *u; double t; ~Tr() { trace(u, "release", t, u->V.n_pos); } } tr{u, tr0};
-    if (u->st) { (void)hipSetDevice(u->prm.device); (void)hipStreamSynchronize(u->st); }
+    join_dl_helper(u);                                 // (it fills the download buffers released below)
+    if (u->uploaded) { (void)hipSetDevice(u->prm.device); (void)hipEventSynchronize(u->ev_uploaded); (void)hipEventSynchronize(u->ev_built); (void)hipEventSynchronize(u->ev_dl); }      // (its commands are done before its memory goes)
     for (auto *b : {&u->d_cm_start, &u->d_tile_cnt, &u->d_tile_off, &u->d_cursor, &u->d_unsorted, &u->d_tile_recs, &u->d_scan_tmp, &u->d_words, &u->d_pool_cnt, &u->d_region_off, &u->d_node_start,
                     &u->d_slow_list, &u->d_rank4, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     for (auto *b : {&u->d_node_cnt, &u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
+    u->d_other.release();
     u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_sp_hop.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
     u->d_ovf.release(); u->d_a_ovf.release(); u->d_huge_list.release(); u->d_scratch_huge.release(); u->huge = false; u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
     u->arena.reset();
@@ -737,9 +822,11 @@ void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u
     HIP_OK(hipSetDevice(u->prm.device));
     u->h_fetch.alloc(n); u->d_fetch.alloc(u->arena, n);
     agx_compact_args C = u->walk_args; C.n_ids = u->n_ids;
-    agx_launch_fetch_records(&C, first, stride, rows, width, u->d_fetch.p, u->st);
-    HIP_OK(hipMemcpyAsync(u->h_fetch.p, u->d_fetch.p, n * sizeof(agx_walknode), hipMemcpyDeviceToHost, u->st));
-    HIP_OK(hipStreamSynchronize(u->st));
+    DeviceTurn &turn = turn_of(u->prm.device);
+    std::lock_guard<std::mutex> l(turn.down_m);
+    agx_launch_fetch_records(&C, first, stride, rows, width, u->d_fetch.p, turn.down);
+    HIP_OK(hipMemcpyAsync(u->h_fetch.p, u->d_fetch.p, n * sizeof(agx_walknode), hipMemcpyDeviceToHost, turn.down));
+    HIP_OK(hipStreamSynchronize(turn.down));
     memcpy(out, u->h_fetch.p, n * sizeof(agx_walknode));
 }
 
@@ -813,10 +900,10 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
     if (!u) return AGX_E_ARG;
     u->prm = *p; if (u->prm.batch == 0) u->prm.batch = 1000000;
     const int rc = guarded(u, [&] {
+        try { u->helper.start(); } catch (...) { }      // (without it the unit prepares its buffers on the caller's threads)
         HIP_OK(hipSetDevice(p->device));
-        HIP_OK(hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking));
         u->ev.init(); u->ev.all = (u->prm.flags & AGX_FLAG_TIME_SECTIONS) != 0;
-        for (hipEvent_t *e : {&u->ev_front, &u->ev_passA, &u->ev_passJ, &u->ev_dl}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t *e : {&u->ev_front, &u->ev_passA, &u->ev_passJ, &u->ev_dl, &u->ev_built}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         HIP_OK(hipEventCreate(&u->ev_up0)); HIP_OK(hipEventCreate(&u->ev_uploaded));
     });
     if (rc != AGX_OK) { delete u; return rc; }
@@ -913,7 +1000,8 @@ int agx_unit_cache_build(const agx_params *p, const char *tmp_dir, int unit, con
     if (err && err_len) err[0] = 0;
     if (!p || !tmp_dir) return AGX_E_ARG;
     agx_unit *u = nullptr;
-    int rc = agx_unit_create(p, &u);
+    agx_params once; if (p) { once = *p; once.flags |= AGX_FLAG_ONE_SHOT; }      // loaded, built and thrown away here
+    int rc = agx_unit_create(p ? &once : nullptr, &u);
     if (rc != AGX_OK) { if (err && err_len) snprintf(err, err_len, "%s", rc == AGX_E_NOGPU ? "no HIP device" : "bad parameters"); return rc; }
     rc = agx_unit_load_files_shared(u, tmp_dir, unit, reads);      // (takes a current cache file if there is one)
     if (rc == AGX_OK && !u->stats.from_cache) rc = guarded(u, [&] { save_cache(u, tmp_dir, unit); });
@@ -968,7 +1056,7 @@ int agx_unit_graph(agx_unit *u, agx_graph *g) {
     return guarded(u, [&] {
         if (!u->built) do_build(u);
         HIP_OK(hipSetDevice(u->prm.device));
-        HIP_OK(hipStreamSynchronize(u->st));
+        HIP_OK(hipEventSynchronize(u->ev_built));
         // the pool has unused slots (one slice per region): the arrays come down whole, nodes are reached through node_start / node_cnt
         const agx_u32 n_pos = (agx_u32)u->V.n_pos, nn = u->n_nodes, cap = u->pool_cap;
         std::vector<agx_u32> node_start(n_pos), cid(cap), coff(cap), cid0(cap), coff0(cap), off0(cap), next((size_t)cap * AGX_MAXE); std::vector<agx_u8> node_cnt(n_pos);

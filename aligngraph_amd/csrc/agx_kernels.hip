@@ -61,19 +61,23 @@ __device__ __forceinline__ void agx_collect_block(const agx_collect_args &G) {
     for (agx_u32 o = 128; o; o >>= 1) { if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) { G.out[0] = *G.a; G.out[1] = *G.b; G.out[2] = *G.c; *G.sum = part[0]; }
 }
-// packed base classes (4 bits per base, what crosses PCIe) -> vote codes (one byte per base, what the sweeps gather): 16 bases per thread
-__global__ void __launch_bounds__(256) agx_k_expand_codes(const uint2 *packed, uint4 *vcodes, size_t n16) {
+// packed base classes (2 bits per base, what crosses PCIe: agx_pack_classes2) -> vote codes (one byte per base, what the sweeps gather): 16 bases per thread;
+// then the bases that are not A, C, G or T, from their list
+__global__ void __launch_bounds__(256) agx_k_expand_codes(const agx_u32 *packed, uint4 *vcodes, size_t n16) {
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n16) return;
-    const uint2 v = packed[i];
-    const agx_u32 in[2] = {v.x, v.y};
+    const agx_u32 v = packed[i];
     agx_u32 w[4];
     for (int j = 0; j < 4; j++) {
         agx_u32 o = 0;
-        for (int b = 0; b < 4; b++) o |= (agx_u32)agx_class_vote_code((in[j >> 1] >> (16 * (j & 1) + 4 * b)) & 0xFu) << (8 * b);
+        for (int b = 0; b < 4; b++) o |= (agx_u32)agx_class_vote_code((v >> (8 * j + 2 * b)) & 3u) << (8 * b);
         w[j] = o;
     }
     vcodes[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__global__ void __launch_bounds__(256) agx_k_patch_codes(const unsigned long long *other, size_t n, agx_u8 *vcodes) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) vcodes[other[i]] = agx_class_vote_code(4u);
 }
 
 // ---- hit_prep: one thread per hit -------------------------------------------------------------------------------
@@ -545,9 +549,10 @@ void agx_launch_zero(const agx_zero_args *Z, hipStream_t st) {
     unsigned long long total = 0; for (int s = 0; s < 8; s++) total += Z->n[s];
     if (total) hipLaunchKernelGGL(agx_k_zero, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *Z);
 }
-void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16, hipStream_t st) {
+void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16, const unsigned long long *other, size_t n_other, hipStream_t st) {
     const size_t n16 = n_bases16 / 16;
-    if (n16) hipLaunchKernelGGL(agx_k_expand_codes, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const uint2 *)packed, (uint4 *)vcodes, n16);
+    if (n16) hipLaunchKernelGGL(agx_k_expand_codes, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const agx_u32 *)packed, (uint4 *)vcodes, n16);
+    if (n_other) hipLaunchKernelGGL(agx_k_patch_codes, dim3((unsigned)((n_other + 255) / 256)), dim3(256), 0, st, other, n_other, (agx_u8 *)vcodes);
 }
 void agx_launch_hit_prep(const agx_prep_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_hit_prep, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);

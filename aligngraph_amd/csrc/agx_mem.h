@@ -126,6 +126,8 @@ template <class T> struct PBuf {            // pinned host buffer: one cached bl
         blk = host_block(count * sizeof(T)); p = (T *)blk.p; n = blk.n / sizeof(T);
     }
     void release() { host_cache().give(blk); blk = MemBlock(); p = nullptr; n = 0; }
+    void borrow(T *host, size_t count) { release(); p = host; n = count; }      // a piece of another buffer's block (pinned by its owner, who outlives the loan)
+    size_t block_bytes() const { return blk.n; }
     void *dev() const { void *d = nullptr; if (p) AGX_HIP_OK(hipHostGetDevicePointer(&d, p, 0)); return d; }      // the address kernels use for this buffer
     ~PBuf() { release(); }
     PBuf() = default; PBuf(const PBuf &) = delete; PBuf &operator=(const PBuf &) = delete;

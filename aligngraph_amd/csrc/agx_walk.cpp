@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory_resource>
 #include <string>
 #include <vector>
 #include <unordered_map>
@@ -42,8 +43,12 @@ namespace {
 // of strings (their string appends were a quarter of a large unit's host time).  Every range outlives the outputs: the walk graph and
 // the unit's tables belong to the caller, the k-mer tails to walk_join_scaffold's arena.
 struct Seg { const char *p; size_t n; };
+// (the lists live in walk_join_scaffold's monotonic arena: a few large blocks instead of one small allocation per record — a thread's
+// malloc arena grows a page at a time, through mprotect, and that waits for the address-space lock whenever another unit is pinning memory)
+typedef std::pmr::memory_resource Arena;
 struct Bases {
-    std::vector<Seg> segs; size_t len = 0;
+    std::pmr::vector<Seg> segs; size_t len = 0;
+    explicit Bases(Arena *a) : segs(a) {}
     void add(const char *p, size_t n) { if (n) { segs.push_back(Seg{p, n}); len += n; } }
     void add_from(const Bases &o, size_t from) {          // o's bases from index `from` on (std::string::append(o, from, npos))
         for (const Seg &g : o.segs) { if (from >= g.n) { from -= g.n; continue; } add(g.p + from, g.n - from); from = 0; }
@@ -53,6 +58,7 @@ struct Rec {                 // Contig, AG:123-139
     int extended;
     agx_u32 sID, sOff, eID, eOff, sID0, sOff0, eID0, eOff0;
     Bases nuc;
+    explicit Rec(Arena *a) : nuc(a) {}
 };
 
 // FASTA body, 60 columns (AG:2184-2188), written across range boundaries
@@ -260,7 +266,7 @@ struct Walker {
 
 // extdContigs1, AG:1954-2204, replayed on the alive-compacted graph.  Alive ids are position-major, so "for every
 // position, for every variant, if untraversed" (AG:1972-1978) is "for every alive id in order, if not done".
-void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, std::deque<std::string> &tails) {
+void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena) {
     const GraphView &G = W.G; const UnitView &V = W.V;
     agx_u32 seqID = 0, sIDBak = AGX_NONE, sOffBak = AGX_NONE, eIDBak = AGX_NONE, eOffBak = AGX_NONE;
     agx_u32 pos_bak = 0;                         // cppBak of the reference (function scope)
@@ -285,7 +291,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, std::deque<std:
         for (agx_u32 vi = 0, start = cp; vi <= s_hi - s_lo; vi++, start = s_lo + vi - 1) {
             if (done(start)) continue;
             AGX_PT(8);
-            Rec C; C.sID = 0; C.sOff = cp; C.extended = 0;
+            Rec C(arena); C.sID = 0; C.sOff = cp; C.extended = 0;
             segs.clear(); n_walks++;
             agx_u32 cur = start;                 // current k-mer node (mode 1)
             { const agx_u32 o = W.node(cur).off0; C.sID0 = o == AGX_NONE ? AGX_NONE : 0; C.sOff0 = o; }
@@ -340,7 +346,11 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, std::deque<std:
             } else { C.eID0 = AGX_NONE; C.eOff0 = AGX_NONE; klen = 0; }
             AGX_PT(5);
             if (!contains(sIDBak, sOffBak, eIDBak, eOffBak, C.sID, C.sOff, C.eID, C.eOff)) {        // AG:2176-2189
-                if (klen > 1) { W.kmer_string(klast, kmer); tails.push_back(kmer); segs.push_back(Seg{tails.back().data() + 1, tails.back().size() - 1}); }
+                if (klen > 1) {                  // the record's trailing k-mer: its bytes go to the arena (every other range lives in the caller's tables)
+                    W.kmer_string(klast, kmer);
+                    char *t = (char *)arena->allocate(kmer.size() - 1, 1); memcpy(t, kmer.data() + 1, kmer.size() - 1);
+                    segs.push_back(Seg{t, kmer.size() - 1});
+                }
                 C.nuc.segs.reserve(segs.size());
                 for (const Seg &g : segs) C.nuc.add(g.p, g.n);
                 const size_t total = C.nuc.len;
@@ -427,12 +437,12 @@ inline int overlaps(agx_u32 x1, agx_u32 y1, agx_u32 x2, agx_u32 y2) {      // AG
 }
 
 // scaffoldContigs, AG:2396-2464
-void scaffold(const UnitView &V, const GraphView &G, std::vector<Rec> &c, OutBuf &out) {
-    std::vector<Bases> sc;
+void scaffold(const UnitView &V, const GraphView &G, std::vector<Rec> &c, OutBuf &out, Arena *arena) {
+    std::vector<Bases> sc; sc.reserve(c.size());
     const agx_u32 n = (agx_u32)c.size();
     for (agx_u32 cp = 0; cp < n; cp++) {
         if (!(c[cp].sID != AGX_NONE && c[cp].extended == 1)) continue;
-        sc.push_back(std::move(c[cp].nuc)); c[cp].nuc = Bases(); c[cp].sID = AGX_NONE;      // a record is used at most once (sID = -1 marks it, AG:2411)
+        sc.push_back(std::move(c[cp].nuc)); c[cp].nuc = Bases(arena); c[cp].sID = AGX_NONE;      // a record is used at most once (sID = -1 marks it, AG:2411)
         bool cont = true;
         while (c[cp].sID0 == c[cp].eID0 && cont) {
             cont = false;
@@ -520,14 +530,14 @@ void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out) 
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double ts = now();
     Walker W(V, G);
-    std::vector<Rec> recs;
-    std::deque<std::string> tails;                    // trailing k-mers of the written records (the other byte ranges live in the caller's tables)
+    std::pmr::monotonic_buffer_resource arena((size_t)8 << 20);      // byte-range lists and trailing k-mers of the written records
+    std::vector<Rec> recs; recs.reserve((size_t)G.n_pos / 1024 + 1024);
     double t0 = now();
-    walk(W, out.pre_extended, recs, tails);
+    walk(W, out.pre_extended, recs, &arena);
     double t1 = now();
     join(recs);
     double t2 = now();
-    scaffold(V, G, recs, out.extended);
+    scaffold(V, G, recs, out.extended, &arena);
     double t3 = now();
     out.n_fetched = W.n_fetched;
     if (timing) fprintf(stderr, "[agx walk] set-up %.1f ms, walk %.1f ms, join %.1f ms, scaffold %.1f ms, %zu records, %u special ids of %u, %llu records fetched\n", t0 - ts, t1 - t0, t2 - t1, t3 - t2, recs.size(), G.n_special, G.n_ids, W.n_fetched);

@@ -108,6 +108,10 @@ def main():
                          "kept (a fresh hipMalloc costs 0.2-0.7 ms per unit, profiles/r02_membench.txt — but HBM that was just given back to the "
                          "driver can stall the next hipMalloc for seconds, profiles/r02_recycle.txt: an artefact of the loop, not of the application).  "
                          "cold: both caches emptied.  warm: both keep what earlier steps left (units 6, 7, .. of a long run)")
+    ap.add_argument("--reupload", action="store_true",
+                    help="time the SAME unit objects in every step (their staged inputs are uploaded again and again, the downloads land in freshly pinned "
+                         "buffers).  Default: every step gets its own set of units, loaded from the unit caches before the clock starts and used once "
+                         "(AGX_FLAG_ONE_SHOT, what agx_run_unit and AlignGraph_amd do: a unit's download lands in the pinned memory of its dead inputs)")
     ap.add_argument("--inflight", type=int, default=0, help="units in flight per GPU = worker threads (0: all of the rank's units, at most 8)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=200000, help="pairs in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--workdir", default=os.environ.get("AGX_BENCH_DIR", "/tmp/agx_bench"))
@@ -186,13 +190,22 @@ def main():
         un.close()
     if reads is not None:
         reads.close()
-    for uu in mine:                                                        # the units the timed steps run: loaded from their cache files
-        un = A.Unit(k=k, insert_variation=50, coverage=args.coverage, device=local_rank)
-        t1 = time.perf_counter()
-        un.load_files(tmp, uu)
-        t_cached += time.perf_counter() - t1
-        assert un.stats()["from_cache"] == 1
-        units[uu] = un
+    # the units the timed steps run, loaded from their cache files: one set per step (every unit of the application is new data and is
+    # uploaded once), or one set for all steps with --reupload
+    n_sets = 1 if args.reupload else args.steps + args.warmup
+    unit_sets = []
+    for si in range(n_sets):
+        one = {}
+        for uu in mine:
+            un = A.Unit(k=k, insert_variation=50, coverage=args.coverage, device=local_rank, flags=0 if args.reupload else A.AGX_FLAG_ONE_SHOT)
+            t1 = time.perf_counter()
+            un.load_files(tmp, uu)
+            if si == 0:
+                t_cached += time.perf_counter() - t1
+            assert un.stats()["from_cache"] == 1
+            one[uu] = un
+        unit_sets.append(one)
+    units = dict(unit_sets[0])
     my_pairs = sum(units[uu].stats()["sam_line_pairs"] for uu in mine)
 
     inflight = args.inflight or min(8, max(1, len(mine)))
@@ -223,6 +236,8 @@ def main():
         t_start[uu] = time.perf_counter()
         units[uu].upload()
 
+    step_no = [0]
+
     def run_job():
         """One step: this rank's units (longest first) through run_unit on `inflight` worker threads, then the path's only exchange — one
         gather of the extended contigs to rank 0 (aligngraph_amd/shard.py: the function the world_size-2 gloo test drives)."""
@@ -230,6 +245,7 @@ def main():
             A.pool_trim(local_rank, host=True)
         elif args.pool == "host-cold":
             A.pool_trim(-1, retire_host=True)          # (the previous steps' buffers are unmapped after the timed region)
+        units.clear(); units.update(unit_sets[step_no[0] % n_sets]); step_no[0] += 1
         return shard.run_job(unit_len, rank, world, run_unit, dist, gdev, inflight=inflight, start_unit=start_unit)
 
     for _ in range(args.warmup):
@@ -343,7 +359,7 @@ def main():
             "config": {"workload": label + ", k=%d, --coverage %d, synthetic target at 1%% SNP + 0.1%% indel" % (k, args.coverage)
                        + (" [NON-STANDARD generator options: %s]" % os.environ["AGX_BENCH_SYNTH"] if extra else ""),
                        "name": args.config, "units": n_units, "unit_positions": unit_len,
-                       "timed_region": "T_core per step: every unit new to the device (upload + first build + download + host walk), %s memory pools" % args.pool,
+                       "timed_region": "T_core per step: every unit new to the device (upload + first build + download + host walk), %s memory pools, %s" % (args.pool, "the same units uploaded again every step" if args.reupload else "a fresh set of one-shot units per step (loaded from the unit caches before the clock)"),
                        "units_in_flight_per_gpu": inflight,
                        "parallelism": "units sharded longest-first over %d GPU%s, one RCCL gather of extended contigs per job" % (world, "" if world == 1 else "s")},
             "t_core_s": round(sec_per_step, 4),
@@ -375,8 +391,9 @@ def main():
         print(json.dumps(line))
     for r in held.values():
         r.free()
-    for un in units.values():
-        un.close()
+    for one in unit_sets:
+        for un in one.values():
+            un.close()
     if not args.keep and rank == 0:
         import shutil
         if dist:

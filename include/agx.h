@@ -56,6 +56,9 @@ typedef struct {
 #define AGX_FLAG_TIME_SECTIONS 4u /* time every section of a build (agx_stats ms_prep .. ms_compact); without it only ms_node_sweep is measured: an event
                                      record between two kernels costs the stream about as much as a small kernel */
 #define AGX_FLAG_SPARSE_MIN  2u /* test hook: download node records of the side ids only, read all others one by one from the device */
+#define AGX_FLAG_ONE_SHOT    8u /* the unit is uploaded ONCE after its inputs were handed over (the application's flow, agx_run_unit): once they are in HBM the
+                                     staged input arrays are dead, and the download lands in that pinned memory instead of mapping and pinning 5 bytes per
+                                     position of fresh memory per unit.  Another upload needs the inputs handed over again (agx_unit_load_files / push_pairs) */
 
 /* ---- packed inputs -------------------------------------------------------------------------------- */
 

@@ -93,10 +93,11 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     S.reserve((size_t)n_pos * 2 + 1024);
     agx_sweep_args A; memset(&A, 0, sizeof A);
     std::vector<agx_u8> vcodes(P.bases.size());             // the engine stages the read bases as packed classes and expands them on the device at upload
-    for (size_t i = 0; i + 1 < P.bases.size(); i += 2) {
-        const agx_u8 pk = agx_pack_classes((agx_u8)P.bases[i], (agx_u8)P.bases[i + 1]);
-        vcodes[i] = agx_class_vote_code(pk & 15u); vcodes[i + 1] = agx_class_vote_code(pk >> 4);
+    for (size_t i = 0; i + 3 < P.bases.size(); i += 4) {      // (2-bit classes, then the bases that are not A, C, G, T: agx_pack_classes2)
+        const agx_u8 pk = agx_pack_classes2((agx_u8)P.bases[i], (agx_u8)P.bases[i + 1], (agx_u8)P.bases[i + 2], (agx_u8)P.bases[i + 3]);
+        for (int b = 0; b < 4; b++) vcodes[i + b] = agx_class_vote_code((pk >> (2 * b)) & 3u);
     }
+    for (size_t i = 0; i < P.bases.size(); i++) if (agx_base_class((agx_u8)P.bases[i]) == 4u) vcodes[i] = agx_class_vote_code(4u);
     std::vector<agx_cmhead> cmh((size_t)n_pos + 1);
     for (agx_u32 x = 0; x <= n_pos; x++) agx_cm_head_pos(T.cm_start.data(), cmk.data(), cmh.data(), x, n_pos);
     A.cm_start = T.cm_start.data(); A.cm = cmk.data(); A.cm_head = cmh.data(); A.ref = T.ref.data();
