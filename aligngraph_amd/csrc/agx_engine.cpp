@@ -766,9 +766,10 @@ void do_download(agx_unit *u) {
     u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(nside + 1);
     u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2);
     u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
-    // the walk graph into the pinned buffers, by the copy engines on the device's download stream (r02 first used a kernel for this — its
-    // copies seemed to queue behind other units' uploads; that was the shared hardware queue, not the engines, and the kernel's wavefronts
-    // slowed the next unit's build: the five builds of a cfg3 job ended at 45 ms with it, at 36 ms without)
+    // the walk graph into the pinned buffers: plain copy commands on the device's download stream.  (r02 first used a kernel of its own for
+    // this — copy commands seemed to queue behind other units' uploads; that was the hardware queue the streams shared.  Its stores to host
+    // memory slowed whatever ran beside it, the next unit's binning most of all: the five builds of a cfg3 job ended at 45 ms with it, at
+    // 42-45 ms with grids of 16-128 blocks, at 35 ms with the runtime's copies.)
     {
         void *dst[8]; const void *src[8]; size_t bytes[8]; int n = 0;
         auto add = [&](void *h, const void *d, size_t b) { if (b) { dst[n] = h; src[n] = d; bytes[n] = b; n++; } };

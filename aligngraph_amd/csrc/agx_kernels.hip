@@ -521,10 +521,9 @@ __global__ void __launch_bounds__(256) agx_k_fetch_records(agx_compact_args A, a
     out[i] = agx_walk_record(A, first + (i / width) * stride + i % width);
 }
 
-// ---- download: HBM -> pinned host memory by a kernel -----------------------------------------------------------------------
-// Copies queued with hipMemcpyAsync go through the SDMA rings in the order they were queued, on whatever stream: a unit's download sat
-// behind the UPLOADS other units had already queued (and which were themselves waiting for their turn) for 20-40 ms.  A kernel that stores
-// straight into the registered host buffers has no such queue: up to four (dst, src, 16-byte words) segments per launch.
+// ---- HBM -> pinned host memory by a kernel ------------------------------------------------------------------------------------
+// For the few counter words a build hands to the host: they leave with the last command of the build's own chain instead of a copy on another
+// stream.  (It also carried the downloads for a while; see do_download for why it no longer does.)  Up to four (dst, src, 16-byte words) segments per launch.
 typedef agx_u32 agx_v4 __attribute__((ext_vector_type(4)));
 struct agx_copy_args { agx_v4 *dst[4]; const agx_v4 *src[4]; unsigned long long n16[4]; };
 __global__ void __launch_bounds__(256) agx_k_copy_out(agx_copy_args C) {

@@ -66,11 +66,17 @@ struct LineWriter {
     char *w; unsigned col = 0;
     explicit LineWriter(char *at) : w(at) {}
     void put(const char *p, size_t n) {
-        while (n) {
+        if (col) {                                   // finish the open line
             const size_t m = n < 60u - col ? n : 60u - col;
             memcpy(w, p, m); w += m; p += m; n -= m; col += (unsigned)m;
-            if (col == 60u) { *w++ = '\n'; col = 0; }
+            if (col < 60u) return;
+            *w++ = '\n'; col = 0;
         }
+        // whole lines: a 64-byte move per line (its last four bytes are overwritten by the newline and the next line) instead of a
+        // length-dispatching memcpy of 60 — half a million lines per 30 MB output
+        for (; n >= 64; n -= 60, p += 60, w += 61) { memcpy(w, p, 64); w[60] = '\n'; }
+        if (n >= 60) { memcpy(w, p, 60); w[60] = '\n'; w += 61; p += 60; n -= 60; }
+        memcpy(w, p, n); w += n; col = (unsigned)n;
     }
     void put(const Bases &b) { for (const Seg &g : b.segs) put(g.p, g.n); }
     char *end() { if (col) { *w++ = '\n'; col = 0; } return w; }
