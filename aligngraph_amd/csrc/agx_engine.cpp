@@ -79,17 +79,17 @@ template <class F> void on_threads(unsigned threads, F fn) {      // (as in agx_
 // build run (the pinned download buffers, the output buffers) without its worker waiting for it.  Not started on demand: creating a
 // thread maps a stack, and that waits for the address-space lock that another unit's hipHostRegister holds for milliseconds.
 struct UnitHelper {
-    enum { DL = 0, OUT = 1, SLOTS = 2 };
+    enum { DL = 0, OUT = 1, WALK = 2, SLOTS = 3 };      // (taken in this order)
     std::thread th; std::mutex m; std::condition_variable cv;
-    std::function<void()> job[SLOTS]; bool queued[SLOTS] = {false, false}, running[SLOTS] = {false, false}; bool stop = false, started = false;
+    std::function<void()> job[SLOTS]; bool queued[SLOTS] = {false, false, false}, running[SLOTS] = {false, false, false}; bool stop = false, started = false;
     void start() {
         if (started) return;
         th = std::thread([this] {
             std::unique_lock<std::mutex> l(m);
             for (;;) {
-                cv.wait(l, [this] { return stop || queued[DL] || queued[OUT]; });
+                cv.wait(l, [this] { return stop || queued[DL] || queued[OUT] || queued[WALK]; });
                 if (stop) return;
-                const int s = queued[DL] ? DL : OUT;
+                const int s = queued[DL] ? DL : queued[OUT] ? OUT : WALK;
                 std::function<void()> f = std::move(job[s]); queued[s] = false; running[s] = true;
                 l.unlock();
                 try { f(); } catch (...) { }
@@ -434,8 +434,9 @@ void alloc_sparse(agx_unit *u, agx_u32 cap) { u->sp_cap = cap; u->d_sp_node.rele
 void do_release(agx_unit *u);
 
 // Everything a unit holds on the device is taken here, from ONE block of HBM sized by the sum; then the inputs are copied (asynchronously,
-// from the staged pinned arrays, on the unit's own stream: beside whatever other units run on the device) and the two upload-time kernels
-// are queued.  Nothing waits on the host: the build's first kernel waits for ev_uploaded on the device.
+// from the staged pinned arrays, on the device's upload stream: behind the copies of the units queued before, beside whatever kernels run on
+// the device) and the unit's helper thread is handed what can be prepared meanwhile.  Nothing waits on the host; the unit's first build
+// waits for ev_uploaded (on the host) and then expands what was copied.
 void do_upload(agx_unit *u) {
     if (u->consumed) throw Error{E_ARG, "one-shot unit: hand its inputs over again before another upload"};
     if (!u->staged) stage_inputs(u);
@@ -486,7 +487,7 @@ void do_upload(agx_unit *u) {
     hipStream_t st = turn.up;
     trace(u, "upload: allocate", t0, n_pos);
     const double tq = now_ms();
-    {
+    try {
         std::lock_guard<std::mutex> up_turn(turn.up_m);
         u->up_timed = u->ev.all;
         if (u->up_timed) HIP_OK(hipEventRecord(u->ev_up0, st));
@@ -501,7 +502,7 @@ void do_upload(agx_unit *u) {
         up(u->d_codes.p, u->s_codes.p, u->n_codes); up(u->d_other.p, u->s_other.p, u->n_other * 8);
         layout_regions(u, nullptr, pool_cap - spill_min(u), true, st);
         HIP_OK(hipEventRecord(u->ev_uploaded, st));
-    }
+    } catch (...) { (void)hipStreamSynchronize(st); throw; }      // (copies that were queued before the failure must not outlive the unit's HBM block)
     u->expanded = false;
     trace(u, "upload: queue copies", tq, n_pos);
     // While the copies run: the download's pinned buffers, by estimate (walk ids ~ 1.05 x positions, special ids ~ 8 % of them), on a helper
@@ -1031,7 +1032,12 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
         if (!u->out_ready) throw Error{E_ARG, "out of host memory"};
         u->downloaded = false;            // the walk marks the downloaded meta bytes: another finish downloads again
         u->out_ready = false;             // (an error below leaves the buffers to the next prepare_outputs)
-        walk_join_scaffold(u->V, view_of(u), u->out);
+        struct Second : Assistant {            // the unit's helper thread copies the written records' bases into the outputs while the walk goes on
+            agx_unit *u; explicit Second(agx_unit *x) : u(x) {}
+            void run(std::function<void()> f) override { if (!u->helper.submit(UnitHelper::WALK, std::move(f))) throw Error{E_ARG, "no helper thread"}; }
+            void wait() override { u->helper.wait(UnitHelper::WALK); }
+        } second(u);
+        walk_join_scaffold(u->V, view_of(u), u->out, u->helper.started ? &second : nullptr);
         u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = u->out.n_fetched;
         trace(u, "walk", t0, u->V.n_pos);
         r->initial_len = u->out_initial.n; r->initial_contigs = u->out_initial.release();

@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 #include "agx_core.h"
@@ -118,6 +119,9 @@ void reads_index_close(ReadsIndex *);
 void load_pairs_from_files(const std::string &reads_fa, const std::string &sam, long batch, agx_u32 k, Pairs &P, const ReadsIndex *reads = nullptr);
 
 // agx_walk.cpp
-void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out);
+// A second thread the walk may hand work to (the engine: the unit's helper thread): run(f) starts f there, wait() returns when it is done.
+// The walk itself is sequential by specification; copying the written records' bases into the outputs is not.
+struct Assistant { virtual void run(std::function<void()> f) = 0; virtual void wait() = 0; virtual ~Assistant() {} };
+void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out, Assistant *assistant = nullptr);
 
 }  // namespace agx

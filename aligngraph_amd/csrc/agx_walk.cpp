@@ -9,6 +9,8 @@
 #include "agx_host.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +63,13 @@ struct Rec {                 // Contig, AG:123-139
     explicit Rec(Arena *a) : nuc(a) {}
 };
 
+inline char *put_u32(char *w, agx_u32 v) {      // decimal, no padding
+    char t[10]; int n = 0;
+    do { t[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
+    while (n) *w++ = t[--n];
+    return w;
+}
+
 // FASTA body, 60 columns (AG:2184-2188), written across range boundaries
 struct LineWriter {
     char *w; unsigned col = 0;
@@ -82,16 +91,64 @@ struct LineWriter {
     char *end() { if (col) { *w++ = '\n'; col = 0; } return w; }
 };
 
+// One written record of the walk as the pre-extended output needs it: the ten header numbers (AG:2180-2183) and the byte ranges of its bases as
+// they were when it was written (a snapshot: the join appends to the record's list later, and a list that grows moves to new arena memory
+// while the old stays valid).  Formatting them is the assistant thread's work while the walk goes on (PreFormat), or this thread's.
+struct PreJob { agx_u32 f[10]; const Seg *segs; size_t n_segs, total; };
+inline void format_pre(OutBuf &out, const PreJob &j) {
+    char hdr[256];                        // ">%u, %d, %u, %u, %u, %u, %u, %u, %u, %u \n" without going through printf
+    char *h = hdr; *h++ = '>';
+    for (int i = 0; i < 10; i++) { h = put_u32(h, j.f[i]); if (i < 9) { *h++ = ','; *h++ = ' '; } }
+    *h++ = ' '; *h++ = '\n';
+    const size_t hl = (size_t)(h - hdr), lines = (j.total + 59) / 60;
+    char *w = out.grow(hl + j.total + lines); memcpy(w, hdr, hl);
+    LineWriter lw(w + hl); for (size_t i = 0; i < j.n_segs; i++) lw.put(j.segs[i].p, j.segs[i].n); lw.end();
+}
+// The records the walk publishes, formatted in order by the assistant while the walk is still going.  The job array never moves (records
+// beyond its capacity are left to the walk's own thread, after the walk); `published` hands a job over, `finished` ends the assistant's loop.
+struct PreFormat {
+    OutBuf &out; Assistant *assistant;
+    std::vector<PreJob> jobs, late; size_t cap = 0;
+    std::atomic<size_t> published{0}; std::atomic<bool> finished{false}, failed{false};
+    PreFormat(OutBuf &o, Assistant *a, size_t capacity) : out(o), assistant(a), cap(a ? capacity : 0) {
+        if (!assistant) return;
+        jobs.reserve(cap);
+        assistant->run([this] {
+            try {
+                size_t at = 0; unsigned idle = 0;
+                for (;;) {
+                    const size_t n = published.load(std::memory_order_acquire);
+                    if (at < n) { while (at < n) format_pre(out, jobs[at++]); idle = 0; continue; }
+                    if (finished.load(std::memory_order_acquire) && at == published.load(std::memory_order_acquire)) return;
+                    if (++idle < 64) {
+#if defined(__x86_64__)
+                        _mm_pause();
+#endif
+                    } else std::this_thread::sleep_for(std::chrono::microseconds(20));
+                }
+            } catch (...) { failed.store(true); }
+        });
+    }
+    void add(const PreJob &j) {
+        if (!assistant) { format_pre(out, j); return; }
+        if (jobs.size() < cap) { jobs.push_back(j); published.store(jobs.size(), std::memory_order_release); }
+        else late.push_back(j);
+    }
+    void finish() {                       // everything is in `out` when this returns
+        if (!assistant) return;
+        finished.store(true, std::memory_order_release);
+        assistant->wait();
+        if (failed.load()) throw Error{E_ARG, "out of host memory"};
+        for (const PreJob &j : late) format_pre(out, j);
+        late.clear();
+    }
+    ~PreFormat() { if (assistant && !finished.load()) { finished.store(true, std::memory_order_release); assistant->wait(); } }      // (the walk threw)
+};
+
 inline bool contains(agx_u32 sID1, agx_u32 sOff1, agx_u32 eID1, agx_u32 eOff1, agx_u32 sID2, agx_u32 sOff2, agx_u32 eID2, agx_u32 eOff2) {
     return sID1 == sID2 && eID1 == eID2 && sOff1 <= sOff2 && eOff1 >= eOff2;      // AG:1897-1902
 }
 
-inline char *put_u32(char *w, agx_u32 v) {      // decimal, no padding
-    char t[10]; int n = 0;
-    do { t[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
-    while (n) *w++ = t[--n];
-    return w;
-}
 
 // The walk's "traversed" flag of a node is bit 7 of its meta byte: the device sets it on ids without a node (AGX_WM_ABSENT: they count as
 // visited), the walk sets it on the nodes it passes.  One byte array serves the run scan, the marks and the position scan.
@@ -272,7 +329,7 @@ struct Walker {
 
 // extdContigs1, AG:1954-2204, replayed on the alive-compacted graph.  Alive ids are position-major, so "for every
 // position, for every variant, if untraversed" (AG:1972-1978) is "for every alive id in order, if not done".
-void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena) {
+void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena, Assistant *assistant) {
     const GraphView &G = W.G; const UnitView &V = W.V;
     agx_u32 seqID = 0, sIDBak = AGX_NONE, sOffBak = AGX_NONE, eIDBak = AGX_NONE, eOffBak = AGX_NONE;
     agx_u32 pos_bak = 0;                         // cppBak of the reference (function scope)
@@ -280,6 +337,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena) {
     agx_hop hcur{0, 0, 0};                       // hop entry of the position the walk is about to leave the k-mer graph at
     std::vector<Seg> segs;
     pre_out.reserve((size_t)G.n_ids + G.n_ids / 32 + 4096);
+    PreFormat pre(pre_out, assistant, (size_t)G.n_pos / 256 + 65536);
     agx_u8 *const m = W.m;
     auto done = [m](agx_u32 v) { return (m[v] & AGX_WM_VISITED) != 0; };
     const mark_fn mark = pick_mark();
@@ -359,19 +417,9 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena) {
                 }
                 C.nuc.segs.reserve(segs.size());
                 for (const Seg &g : segs) C.nuc.add(g.p, g.n);
-                const size_t total = C.nuc.len;
-                char hdr[256];                    // ">%u, %d, %u, %u, %u, %u, %u, %u, %u, %u \n" (AG:2180-2183) without going through printf
-                int hl = 0;
-                {
-                    const agx_u32 f[10] = {seqID++, (agx_u32)C.extended, C.sID, C.sOff, C.eID, C.eOff, C.sID0, C.sOff0, C.eID0, C.eOff0};
-                    char *w = hdr; *w++ = '>';
-                    for (int i = 0; i < 10; i++) { w = put_u32(w, f[i]); if (i < 9) { *w++ = ','; *w++ = ' '; } }
-                    *w++ = ' '; *w++ = '\n';
-                    hl = (int)(w - hdr);
-                }
-                const size_t lines = (total + 59) / 60;
-                char *w = pre_out.grow((size_t)hl + total + lines); memcpy(w, hdr, (size_t)hl);
-                LineWriter lw(w + hl); lw.put(C.nuc); lw.end();
+                {   PreJob j; const agx_u32 f[10] = {seqID++, (agx_u32)C.extended, C.sID, C.sOff, C.eID, C.eOff, C.sID0, C.sOff0, C.eID0, C.eOff0};
+                    memcpy(j.f, f, sizeof f); j.segs = C.nuc.segs.data(); j.n_segs = C.nuc.segs.size(); j.total = C.nuc.len;
+                    pre.add(j); }
                 sIDBak = C.sID; sOffBak = C.sOff; eIDBak = C.eID; eOffBak = C.eOff;
                 if (eOffBak - sOffBak > 100000) W.prefetch_skip_positions(cp, eOffBak < G.n_pos ? eOffBak : G.n_pos);
                 written.push_back(std::move(C));
@@ -397,6 +445,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena) {
         }
         AGX_PT(10);
     }
+    pre.finish();
 #if defined(AGX_WALK_PROF) && defined(__x86_64__)
     if (getenv("AGX_WALK_TIMING")) {
         fprintf(stderr, "[agx walk] Mcycles: start %.1f, hop %.1f, run scan %.1f, mark %.1f, successors %.1f, end %.1f, contain+write %.1f, between %.1f, position scan %.1f (+ %.1f after the last variant, %.1f next position)\n",
@@ -443,7 +492,7 @@ inline int overlaps(agx_u32 x1, agx_u32 y1, agx_u32 x2, agx_u32 y2) {      // AG
 }
 
 // scaffoldContigs, AG:2396-2464
-void scaffold(const UnitView &V, const GraphView &G, std::vector<Rec> &c, OutBuf &out, Arena *arena) {
+void scaffold(const UnitView &V, const GraphView &G, std::vector<Rec> &c, OutBuf &out, Arena *arena, Assistant *assistant) {
     std::vector<Bases> sc; sc.reserve(c.size());
     const agx_u32 n = (agx_u32)c.size();
     for (agx_u32 cp = 0; cp < n; cp++) {
@@ -465,14 +514,25 @@ void scaffold(const UnitView &V, const GraphView &G, std::vector<Rec> &c, OutBuf
             }
         }
     }
-    size_t total = 0; for (const Bases &x : sc) total += x.len + x.len / 60 + 16;
-    out.reserve(total);
-    for (size_t i = 0; i < sc.size(); i++) {
-        char hdr[32]; const int hl = std::snprintf(hdr, sizeof hdr, ">%zu\n", i);
-        const size_t n = sc[i].len, lines = (n + 59) / 60;
-        char *w = out.grow((size_t)hl + n + lines); memcpy(w, hdr, (size_t)hl);
-        LineWriter lw(w + hl); lw.put(sc[i]); lw.end();
-    }
+    // output: every scaffold's place is known before a byte is written, so the assistant formats the first half while this thread formats the second
+    std::vector<size_t> at(sc.size() + 1, 0);
+    auto header = [](char *hdr, size_t i) { char *h = hdr; *h++ = '>'; char t[24]; int n = 0; do { t[n++] = (char)('0' + i % 10); i /= 10; } while (i); while (n) *h++ = t[--n]; *h++ = '\n'; return (size_t)(h - hdr); };
+    for (size_t i = 0; i < sc.size(); i++) { char hdr[32]; at[i + 1] = at[i] + header(hdr, i) + sc[i].len + (sc[i].len + 59) / 60; }
+    const size_t total = at[sc.size()];
+    out.n = 0; char *base = out.grow(total);
+    auto format = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            char hdr[32]; const size_t hl = header(hdr, i);
+            char *w = base + at[i]; memcpy(w, hdr, hl);
+            LineWriter lw(w + hl); lw.put(sc[i]); lw.end();
+        }
+    };
+    size_t mid = 0; while (mid < sc.size() && at[mid] < total / 2) mid++;
+    if (assistant && mid > 0 && total > (1u << 16)) {
+        assistant->run([&] { format(0, mid); });
+        struct Wait { Assistant *a; ~Wait() { a->wait(); } } wait{assistant};      // (also if this half throws)
+        format(mid, sc.size());
+    } else format(0, sc.size());
 }
 
 }  // namespace
@@ -530,7 +590,7 @@ void build_chains(Threads &T) {
     if (e != n) throw Error{E_ARG, "conti-mer runs do not cover the conti-mers"};
 }
 
-void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out) {
+void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out, Assistant *assistant) {
     if (!V.hop && !G.sp_hop) throw Error{E_ARG, "conti-mer chains were not built"};
     const bool timing = getenv("AGX_WALK_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -539,11 +599,11 @@ void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out) 
     std::pmr::monotonic_buffer_resource arena((size_t)8 << 20);      // byte-range lists and trailing k-mers of the written records
     std::vector<Rec> recs; recs.reserve((size_t)G.n_pos / 1024 + 1024);
     double t0 = now();
-    walk(W, out.pre_extended, recs, &arena);
+    walk(W, out.pre_extended, recs, &arena, assistant);
     double t1 = now();
     join(recs);
     double t2 = now();
-    scaffold(V, G, recs, out.extended, &arena);
+    scaffold(V, G, recs, out.extended, &arena, assistant);
     double t3 = now();
     out.n_fetched = W.n_fetched;
     if (timing) fprintf(stderr, "[agx walk] set-up %.1f ms, walk %.1f ms, join %.1f ms, scaffold %.1f ms, %zu records, %u special ids of %u, %llu records fetched\n", t0 - ts, t1 - t0, t2 - t1, t3 - t2, recs.size(), G.n_special, G.n_ids, W.n_fetched);

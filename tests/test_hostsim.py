@@ -56,10 +56,13 @@ def test_sparse_record_table_and_fetch_hook(built, tmp_path, monkeypatch):
     o = H.run_oracle(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
     assert max(len(r) for r in o["pre"].split(b">")) > 100000
     s = sim.run(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
+    monkeypatch.setenv("AGX_SIM_ASSISTANT", "1")             # the outputs written by a second thread while the walk goes on, as in the engine
+    a = sim.run(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
+    monkeypatch.delenv("AGX_SIM_ASSISTANT")
     monkeypatch.setenv("AGX_SIM_SPARSE_MIN", "1")
     m = sim.run(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
     for key in ("initial", "pre", "extended"):
-        assert o[key] == s[key] == m[key], key
+        assert o[key] == s[key] == m[key] == a[key], key
     assert s["n_special"] * 4 < s["n_walk_ids"] and s["n_fetched"] <= 8          # the skip positions come in one strided copy per long record
     assert m["n_special"] < s["n_special"] and m["n_fetched"] > 100
 
