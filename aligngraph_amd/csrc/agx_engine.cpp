@@ -778,7 +778,7 @@ void do_download(agx_unit *u) {
         add(u->h_side_xpos.p, u->d_side_xpos.p, nside * 4);
         add(u->h_sp_node.p, u->d_sp_node.p, ns * sizeof(agx_walknode)); add(u->h_sp_hop.p, u->d_sp_hop.p, ns * sizeof(agx_hop)); add(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf));
         std::lock_guard<std::mutex> l(turn.down_m);
-        for (int i = 0; i < n; i++) HIP_OK(hipMemcpyAsync(dst[i], src[i], bytes[i], hipMemcpyDeviceToHost, turn.down));
+        for (int i = 0; i < n; i++) HIP_OK(hipMemcpyAsync(dst[i], src[i], bytes[i], hipMemcpyDeviceToHost, turn.down));      // (the runtime does them with its own copy kernel, not the SDMA engines: rocprofv3 shows __amd_rocclr_copyBuffer)
         HIP_OK(hipEventRecord(u->ev_dl, turn.down));
     }
     const double t1 = now_ms();

@@ -268,7 +268,13 @@ struct Walker {
     }
     agx_walknode node(agx_u32 v) const {
         const agx_u32 at = rank_of(v);
-        if (at != AGX_NONE) return G.sp_node[at];
+        if (at != AGX_NONE) {
+            // the walk asks for records in nearly increasing rank order (two streams: main ids and side ids), and for the hop entry of the same
+            // rank a few hundred cycles later: ask for that line now, and for the records and hop entries a few ranks ahead
+            if (G.sp_hop) { __builtin_prefetch(G.sp_hop + at); __builtin_prefetch(G.sp_hop + at + 8); }
+            __builtin_prefetch(G.sp_node + at + 6);
+            return G.sp_node[at];
+        }
         const auto it = extra.find(v);
         if (it != extra.end()) return it->second;
         if (!G.fetch) throw Error{E_ARG, "walk graph without a record fetch hook"};
