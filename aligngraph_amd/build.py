@@ -45,7 +45,7 @@ def build(force=False, verbose=False, defines=(), out=None, tag=""):
             subprocess.check_call(cmd)
         objs.append(o)
     if force or _stale(lib, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-L" + os.path.join(ROCM, "lib"), "-lhsa-runtime64"]      # (HSA: the downloads go through its asynchronous copy)
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -12,6 +12,8 @@
 //   download the walk graph into cached pinned buffers; finish = the sequential host walk.
 // No CPU fallback exists: a host without a HIP device gets AGX_E_NOGPU from agx_unit_create.
 #include <hip/hip_runtime_api.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -75,6 +77,53 @@ template <class F> void on_threads(unsigned threads, F fn) {      // (as in agx_
 
 }  // namespace
 
+// Downloads through the HSA runtime's asynchronous copy, i.e. the SDMA engines.  hipMemcpyAsync does a device-to-host copy into registered
+// memory with a copy KERNEL of its own (rocprofv3: __amd_rocclr_copyBuffer), and a kernel that stores to host memory slows what runs beside
+// it — under rocprofv3 the next unit's agx_k_tile_sort ran 2.6-4.2 ms instead of 0.8 and the device window of a cfg3 job was 49 ms instead of
+// 42 (profiles/r02_f_timeline.txt vs r02_g_timeline.txt; un-profiled the job takes the same 59 ms either way: the builds are not what the
+// last walks wait for).  The engines move the same bytes at the same 56 GB/s (tests/tools/sdma_d2h.cpp) and leave the CUs alone.  Set up
+// once per process; if anything about it fails (AGX_NO_SDMA_DOWNLOAD forces that) the copies go through HIP.
+struct HsaCopy {
+    bool ok = false; hsa_agent_t cpu{}; std::vector<hsa_agent_t> gpu; std::vector<std::string> uuid;      // uuid: "GPU-<16 hex digits>" of each GPU agent
+    static hsa_status_t on_agent(hsa_agent_t a, void *p) {
+        HsaCopy *H = (HsaCopy *)p; hsa_device_type_t t;
+        if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+        if (t == HSA_DEVICE_TYPE_CPU && !H->cpu.handle) H->cpu = a;
+        if (t == HSA_DEVICE_TYPE_GPU) {
+            char id[32] = {0};
+            (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_UUID, id);
+            H->gpu.push_back(a); H->uuid.push_back(std::string(id, strnlen(id, 21)));
+        }
+        return HSA_STATUS_SUCCESS;
+    }
+    HsaCopy() {
+        if (getenv("AGX_NO_SDMA_DOWNLOAD")) return;
+        if (hsa_init() != HSA_STATUS_SUCCESS) return;
+        if (hsa_iterate_agents(on_agent, this) != HSA_STATUS_SUCCESS) return;
+        ok = cpu.handle != 0 && !gpu.empty();
+    }
+    // the agent of HIP device `device`, by its UUID (the two runtimes need not number the devices alike, and report different PCI
+    // addresses inside a container); one device on either side is that device; false: not found
+    bool agent_of(int device, hsa_agent_t &out) const {
+        static std::mutex m; static int known[64]; static hsa_agent_t agent[64];      // known: 0 not asked yet, 1 found, -1 not found
+        std::lock_guard<std::mutex> l(m);
+        int &k = known[device & 63];
+        if (!k) {
+            k = -1;
+            hipDeviceProp_t prop;
+            if (ok && hipGetDeviceProperties(&prop, device) == hipSuccess) {
+                const std::string want = "GPU-" + std::string(prop.uuid.bytes, strnlen(prop.uuid.bytes, 16));
+                int n_hip = 0;
+                for (size_t i = 0; i < gpu.size(); i++) if (uuid[i] == want && want.size() > 4) { agent[device & 63] = gpu[i]; k = 1; break; }
+                if (k != 1 && gpu.size() == 1 && hipGetDeviceCount(&n_hip) == hipSuccess && n_hip == 1) { agent[device & 63] = gpu[0]; k = 1; }
+            }
+        }
+        if (k == 1) out = agent[device & 63];
+        return k == 1;
+    }
+};
+const HsaCopy &hsa_copy() { static const HsaCopy h; return h; }
+
 // One helper thread per unit, started with the unit and asleep until it is handed work: what a unit can prepare while its upload and
 // build run (the pinned download buffers, the output buffers) without its worker waiting for it.  Not started on demand: creating a
 // thread maps a stack, and that waits for the address-space lock that another unit's hipHostRegister holds for milliseconds.
@@ -122,6 +171,7 @@ struct agx_unit {
     hipEvent_t ev_built = nullptr;     // this unit's build commands are done (waited for on the host; ev_dl: its download)
     UnitOutput out; OutBuf out_initial; bool out_ready = false;      // output buffers of the next finish, reserved and touched by a helper thread while the unit is uploaded and built (prepare_outputs)
     UnitHelper helper;
+    hsa_signal_t dl_signal{}; hsa_agent_t dl_agent{}; bool dl_sdma = false;      // downloads by the SDMA engines (HsaCopy)
     DevArena arena;
     // staged inputs: what the device wants of T and P, in pinned memory (stage_inputs)
     PBuf<agx_hit> s_hits; PBuf<agx_run> s_runs; PBuf<agx_u8> s_codes; PBuf<unsigned long long> s_other; size_t n_other = 0; PBuf<char> s_ref; PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
@@ -155,6 +205,7 @@ struct agx_unit {
     ~agx_unit() {
         ev.destroy();
         for (hipEvent_t e : {ev_front, ev_passA, ev_passJ, ev_up0, ev_uploaded, ev_dl, ev_built}) if (e) (void)hipEventDestroy(e);
+        if (dl_signal.handle) (void)hsa_signal_destroy(dl_signal);
     }
 };
 
@@ -777,9 +828,20 @@ void do_download(agx_unit *u) {
         if (ni) { add(u->h_sp_bits.p, u->d_sp_bits.p, nw * 8); add(u->h_sp_rank.p, u->d_sp_rank.p, nw * 4); add(u->h_a_str.p, u->d_a_str.p, ni); add(u->h_a_meta.p, u->d_a_meta.p, ni); }
         add(u->h_side_xpos.p, u->d_side_xpos.p, nside * 4);
         add(u->h_sp_node.p, u->d_sp_node.p, ns * sizeof(agx_walknode)); add(u->h_sp_hop.p, u->d_sp_hop.p, ns * sizeof(agx_hop)); add(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf));
-        std::lock_guard<std::mutex> l(turn.down_m);
-        for (int i = 0; i < n; i++) HIP_OK(hipMemcpyAsync(dst[i], src[i], bytes[i], hipMemcpyDeviceToHost, turn.down));      // (the runtime does them with its own copy kernel, not the SDMA engines: rocprofv3 shows __amd_rocclr_copyBuffer)
-        HIP_OK(hipEventRecord(u->ev_dl, turn.down));
+        bool by_engines = u->dl_sdma && n > 0;
+        if (by_engines) {                            // (the build is complete and visible: this thread has waited for its last command)
+            hsa_signal_store_relaxed(u->dl_signal, n);
+            int queued = 0;
+            for (; queued < n; queued++) if (hsa_amd_memory_async_copy(dst[queued], hsa_copy().cpu, src[queued], u->dl_agent, bytes[queued], 0, nullptr, u->dl_signal) != HSA_STATUS_SUCCESS) break;
+            if (queued < n) hsa_signal_subtract_relaxed(u->dl_signal, n - queued);      // what was queued still counts down
+            const hsa_signal_value_t v = hsa_signal_wait_scacquire(u->dl_signal, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+            if (queued < n || v < 0) { u->dl_sdma = false; by_engines = false; }        // the engines refused: this and every later download of the unit through HIP
+        }
+        if (!by_engines) {
+            std::lock_guard<std::mutex> l(turn.down_m);
+            for (int i = 0; i < n; i++) HIP_OK(hipMemcpyAsync(dst[i], src[i], bytes[i], hipMemcpyDeviceToHost, turn.down));
+            HIP_OK(hipEventRecord(u->ev_dl, turn.down));
+        }
     }
     const double t1 = now_ms();
     HIP_OK(hipEventSynchronize(u->ev_dl));
@@ -789,7 +851,7 @@ void do_download(agx_unit *u) {
     u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
     u->downloaded = true;
     u->stats.ms_download = now_ms() - t0;
-    trace(u, "download", t0, n_pos);
+    trace(u, u->dl_sdma ? "download (copy engines)" : "download (hipMemcpyAsync)", t0, n_pos);
 }
 
 // Gives back everything the unit holds on the device and its download buffers (to the caches of agx_mem.h: the next unit of the run takes
@@ -907,6 +969,7 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
         u->ev.init(); u->ev.all = (u->prm.flags & AGX_FLAG_TIME_SECTIONS) != 0;
         for (hipEvent_t *e : {&u->ev_front, &u->ev_passA, &u->ev_passJ, &u->ev_dl, &u->ev_built}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         HIP_OK(hipEventCreate(&u->ev_up0)); HIP_OK(hipEventCreate(&u->ev_uploaded));
+        u->dl_sdma = hsa_copy().agent_of(p->device, u->dl_agent) && hsa_signal_create(0, 0, nullptr, &u->dl_signal) == HSA_STATUS_SUCCESS;
     });
     if (rc != AGX_OK) { delete u; return rc; }
     *out = u;
@@ -1051,7 +1114,8 @@ void agx_result_free(agx_result *r) { if (!r) return; free(r->initial_contigs); 
 int agx_unit_stats(const agx_unit *u, agx_stats *s) {
     if (!u || !s) return AGX_E_ARG;
     *s = u->stats;
-    s->n_pos = u->staged ? u->V.n_pos : u->T.ref.size(); s->n_ref = u->staged ? u->V.n_ref : u->T.n_ref; s->n_hits = u->staged ? u->nh : u->P.hits.size(); s->n_runs = u->staged ? u->n_runs : u->P.runs.size(); s->pinned_bytes_cached = host_cache().held(); s->device_bytes_cached = dev_cache(u->prm.device).held(); s->n_nodes = u->n_nodes;
+    const bool st = u->staged || u->consumed;      // (a one-shot unit's staged inputs are gone after its download; their counts are not)
+    s->n_pos = st ? u->V.n_pos : u->T.ref.size(); s->n_ref = st ? u->V.n_ref : u->T.n_ref; s->n_hits = st ? u->nh : u->P.hits.size(); s->n_runs = st ? u->n_runs : u->P.runs.size(); s->pinned_bytes_cached = host_cache().held(); s->device_bytes_cached = dev_cache(u->prm.device).held(); s->n_nodes = u->n_nodes;
     s->n_tiles = u->n_tiles; s->n_tile_entries = u->n_tile_entries; s->n_big_tiles = u->n_big; s->n_mid_tiles = u->n_mid; s->n_edge_overflow = u->n_ovf;
     s->pairs_in_file = u->pairs_in_file; s->sam_line_pairs = u->sam_pairs;
     return AGX_OK;
