@@ -51,7 +51,7 @@ void trace(const void *unit, const char *what, double from_ms, size_t n_pos) {
     fprintf(stderr, "[agx trace] unit %p (%zu pos) %-22s %9.2f -> %9.2f ms\n", unit, n_pos, what, from_ms - t00, now_ms() - t00);
 }
 
-// Section boundaries of a build on the unit's stream: the end of one section is the start of the next (one record instead of two: an
+// Section boundaries of a build on the build streams: the end of one section is the start of the next (one record instead of two: an
 // event record costs the stream about as much as a small kernel).
 enum { B_START = 0, B_PREP, B_BIN, B_NODE, B_BIG, B_EDGE, B_SLOW, B_COMPACT, B_N };
 // (two more events bracket the whole build: Boundaries::first / last)
@@ -217,7 +217,7 @@ namespace {
 // host threads run their chains back to back — no host round trip in between — and the FRONT of build n+1 runs beside the BACK of build n:
 // it starts when sweep n is done (an event) and sweep n+1 waits for it (another).  The node sweep itself never shares the device, so its
 // HIP-event time is that of an exclusive GPU; the other sections are timed in exclusive builds (AGX_FLAG_TIME_SECTIONS serialises the two
-// streams).  Uploads and copies to the host (counter words, download, record fetches) use the unit's own stream.
+// streams).
 // Four streams per device serve all of its units: `up` carries the units' upload copies and nothing else, one unit after the other in the
 // order they were queued (PCIe is one pipe: five uploads that share it all finish late; first in, first built, and its host walk runs
 // beside the uploads of the rest); `front` and `main` carry the builds (see do_build); `down` the downloads.  Not a stream per unit: HIP
@@ -441,7 +441,7 @@ agx_u32 spill_min(const agx_unit *u) { const size_t n_pos = u->V.n_pos; return (
 
 // Slices of the node pool, one per region, and the spill area behind them.  Without a measurement every region gets the same share of
 // `main_cap` ids; after a build in which the pool ran out, `demand` holds what every region asked for (the counters keep counting) and the
-// slices are cut to that plus slack.  Returns the ids the layout needs; applies it (queues the copy on the unit's stream) if they fit.
+// slices are cut to that plus slack.  Returns the ids the layout needs; applies it (queues the copy on `st`) if they fit.
 unsigned long long layout_regions(agx_unit *u, const agx_u32 *demand, agx_u32 main_cap, bool apply, hipStream_t st) {
     const agx_u32 R = u->n_regions;
     u->s_region_off.alloc((size_t)R + 1);

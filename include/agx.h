@@ -105,7 +105,7 @@ typedef struct {
     uint64_t n_mid_tiles;                                        /* tiles swept again with wider LDS buckets (n_big_tiles: of those, again with global scratch) */
     double ms_build_span;                                        /* with AGX_FLAG_TIME_SECTIONS: device time from the first to the last command of the build (all kernels and the gaps between them) */
     double ms_stage;                                             /* packing the handed-over arrays into pinned upload buffers (agx_unit_stage) */
-    double ms_upload_dev;                                        /* with AGX_FLAG_TIME_SECTIONS: device time of the upload (copies + its two kernels) on the unit's stream */
+    double ms_upload_dev;                                        /* with AGX_FLAG_TIME_SECTIONS: device time of the unit's upload copies on the device's upload stream */
     uint64_t upload_bytes, device_bytes;                         /* bytes copied host -> HBM by the upload; HBM held by the unit */
     uint64_t pinned_bytes_cached, device_bytes_cached;           /* free blocks in the library's pinned-host and device caches (agx_pool_trim releases them) */
     uint64_t n_spilled;                                          /* node ids taken from the pool's spill area (regions whose slice was full) */
@@ -162,12 +162,12 @@ int agx_unit_cache_save(agx_unit *u, const char *tmp_dir, int unit);   /* the sa
 
 int agx_unit_stage(agx_unit *u);                 /* packs what was handed over into pinned upload buffers (read bases as 4-bit classes); done by agx_unit_load_files,
                                                     implied by agx_unit_upload after agx_unit_push_pairs */
-int agx_unit_upload(agx_unit *u);                /* staged arrays -> HBM: one device block, asynchronous copies; returns without waiting (the build waits on the device) */
+int agx_unit_upload(agx_unit *u);                /* staged arrays -> HBM: one device block, asynchronous copies behind those of the device's earlier uploads; returns without waiting */
 int agx_unit_build(agx_unit *u);                 /* kernels: updateGenomeWithRead/updateKMer (AG:1635-1870, 1353-1624) + filterLowCoverage (AG:1904-1918) */
 int agx_unit_download(agx_unit *u);              /* HBM -> pinned host memory (walk graph); implied by agx_unit_finish */
 int agx_unit_finish(agx_unit *u, agx_result *r); /* (download, then) extdContigs1/2 + scaffoldContigs (AG:1954-2464) on the host */
 void agx_result_free(agx_result *r);
-int agx_unit_release(agx_unit *u);               /* gives the unit's HBM and download buffers back to the library's caches; the staged inputs stay: upload again = a new unit */
+int agx_unit_release(agx_unit *u);               /* gives the unit's HBM and download buffers back to the library's caches; the staged inputs stay: upload again = a new unit (not AGX_FLAG_ONE_SHOT units: their inputs are gone after the download) */
 void agx_pool_trim(int device);                  /* device >= 0: frees the cached HBM blocks of that device; -1: frees the cached (and retired) pinned host blocks;
                                                     -2: retires the cached pinned host blocks (never handed out again, unmapped by the next -1): what a
                                                     measurement loop uses so that every job maps and registers fresh buffers without paying for unmapping old ones */
