@@ -293,9 +293,10 @@ class Unit:
         return out
 
 
-def cache_build(tmp_dir, unit, batch=0, device=0, reads=None):
-    """Writes tmp_dir/_agx_unit.<unit>.bin (the unit's staged arrays) from the five text files; load_files then takes it instead of the text."""
-    p = Params(5, 50, 20, batch, device, 0)
+def cache_build(tmp_dir, unit, batch=0, device=0, reads=None, k=5):
+    """Writes tmp_dir/_agx_unit.<unit>.bin (the unit's staged arrays) from the five text files; load_files then takes it instead of the text
+    (units of the same k and batch size only)."""
+    p = Params(k, 50, 20, batch, device, 0)
     err = ctypes.create_string_buffer(512)
     rc = lib().agx_unit_cache_build(ctypes.byref(p), tmp_dir.encode(), unit, reads._h if reads is not None else None, err, 512)
     if rc != AGX_OK:

@@ -342,14 +342,14 @@ void stage_inputs(agx_unit *u) {
 // tmp/_agx_unit.<u>.bin: a unit's STAGED form, written once (AlignGraph_amd does it when it distributes the alignments, AG:3545-3579;
 // agx_unit_cache_build) so that a unit loop that finds it neither reads nor parses text: the arrays the upload wants are read straight into
 // pinned memory, what only the host walk looks at (conti-mer counts, chain suffixes, read bases for the k-mer tails of written records) is
-// mapped and paged in where it is touched.  Valid for one BATCH size and for exactly the five text files it was made from (size and
+// mapped and paged in where it is touched.  Valid for one BATCH size, one k and for exactly the five text files it was made from (size and
 // modification time of each are in the header): anything else and the loader falls back to the text.
 namespace cache {
 enum { S_HITS = 0, S_RUNS, S_CODES, S_SEGS, S_CHAIN_END, S_ROW_SLOT, S_REF, S_CM_START, S_CHAIN_STR, S_INITIAL, S_BASES, S_OTHER, S_N };
 struct Header {
     char magic[8]; agx_u32 version, batch; unsigned long long stamp[5][2];
     unsigned long long n_pos, n_ref, nh, n_runs, n_cm, n_segs, n_seg0, n_rows, n_chain_end, n_codes, pairs_in_file, sam_pairs;
-    agx_u32 stride, maxlen, n_slots, pad;
+    agx_u32 stride, maxlen, n_slots, k;          // k: the staged hits name their left mate, which depends on it (agx_hit_left_is_mate2)
     unsigned long long off[S_N], len[S_N];
 };
 const char MAGIC[8] = {'A', 'G', 'X', 'U', 'N', 'I', 'T', '3'};
@@ -368,7 +368,7 @@ void save_cache(agx_unit *u, const std::string &dir, int unit) {
     Header H; memset(&H, 0, sizeof H); memcpy(H.magic, MAGIC, 8); H.version = 1; H.batch = u->prm.batch;
     stamps(dir, unit, H.stamp);
     H.n_pos = u->V.n_pos; H.n_ref = u->V.n_ref; H.nh = u->nh; H.n_runs = u->n_runs; H.n_cm = u->n_cm; H.n_segs = u->n_segs; H.n_seg0 = u->n_seg0; H.n_rows = u->row_slot.size();
-    H.n_chain_end = u->n_chain_end; H.n_codes = u->n_codes; H.pairs_in_file = u->pairs_in_file; H.sam_pairs = u->sam_pairs; H.stride = u->stride; H.maxlen = u->maxlen; H.n_slots = u->n_slots;
+    H.n_chain_end = u->n_chain_end; H.n_codes = u->n_codes; H.pairs_in_file = u->pairs_in_file; H.sam_pairs = u->sam_pairs; H.stride = u->stride; H.maxlen = u->maxlen; H.n_slots = u->n_slots; H.k = u->prm.k;
     const void *ptr[S_N] = {u->s_hits.p, u->s_runs.p, u->s_codes.p, u->s_segs.p, u->s_chain_end.p, u->row_slot.data(), u->V.ref, u->V.cm_start, u->V.chain_str, u->V.initial, u->V.bases, u->s_other.p};
     const unsigned long long len[S_N] = {u->nh * sizeof(agx_hit), u->n_runs * sizeof(agx_run), u->n_codes, u->n_segs * sizeof(agx_cmseg), (unsigned long long)u->n_chain_end * 4, u->row_slot.size() * 4,
                                          u->V.n_pos, (u->V.n_pos + 1) * 4, u->T.chain_str.size(), u->V.n_initial, (unsigned long long)u->n_slots * u->stride, (unsigned long long)u->n_other * 8};
@@ -395,7 +395,7 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     Header H; struct stat sb;
     if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof H || pread(fd, &H, sizeof H, 0) != (ssize_t)sizeof H) return false;
     unsigned long long st[5][2]; stamps(dir, unit, st);
-    if (memcmp(H.magic, MAGIC, 8) != 0 || H.version != 1 || H.batch != u->prm.batch || memcmp(st, H.stamp, sizeof st) != 0) return false;
+    if (memcmp(H.magic, MAGIC, 8) != 0 || H.version != 1 || H.batch != u->prm.batch || H.k != u->prm.k || memcmp(st, H.stamp, sizeof st) != 0) return false;
     for (int i = 0; i < S_N; i++) if (H.off[i] + H.len[i] > (unsigned long long)sb.st_size) return false;
     if (H.n_pos == 0 || H.n_pos >= 0xFFFFFF00ull || H.len[S_REF] != H.n_pos || H.len[S_CM_START] != (H.n_pos + 1) * 4 || H.len[S_HITS] != H.nh * sizeof(agx_hit) || H.len[S_RUNS] != H.n_runs * sizeof(agx_run) ||
         H.len[S_CODES] != H.n_codes || H.len[S_SEGS] != H.n_segs * sizeof(agx_cmseg) || H.len[S_ROW_SLOT] != H.n_rows * 4 || H.len[S_BASES] != (unsigned long long)H.n_slots * H.stride || (H.stride & 15u) ||

@@ -8,6 +8,9 @@
   * one --part 4 slice of configs[3] (human chr1 shape: 62 Mb, 15 M pairs) at full size against the serial CPU executor of the kernels'
     lane functions (tests/hostsim; the oracle needs minutes for it), plus rebuild determinism with every capacity started too small.
 
+  * configs[4]'s 24-unit shard SHAPE (GRCh38 chromosome lengths / 256, 2x150 bp reads), one-shot units from their cache files through the
+    job loop, every unit against the oracle.
+
 AGX_SKIP_BIG=1 skips the two multi-minute cases.
 """
 import hashlib
@@ -115,6 +118,64 @@ def test_cfg3_full_size_every_unit_matches_the_oracle(agx, built, tmp_path):
             assert got[uu][key] == want[uu][key], "unit %d: %s differs from the oracle in the second job" % (uu, key)
         assert stats[uu]["build_attempts"] == 1
     assert sum(stats[uu]["sam_line_pairs"] for uu in range(5)) > 20000000          # 20 M pairs, 5 % of them with a second hit, 2 % unaligned
+
+
+HUMAN = (248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622, 133275309, 114364328,
+         107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415)      # GRCh38, = bench.py CONFIGS["cfg5s"] x 16
+
+
+def test_cfg5_shard_shape_at_1_256_every_unit_matches_the_oracle(agx, built, tmp_path):
+    """configs[4] (whole human: 24 units, 2x150 bp reads) cannot run here at full size; its SHAPE can: the 24 chromosome lengths / 256 (12 Mb),
+    1.5 M pairs of 2x150, every unit a one-shot unit from its cache file through the job loop (what `bench.py --config cfg5s` times at 1/16),
+    every unit byte for byte against the oracle."""
+    from aligngraph_amd import shard
+    lens = [c // 256 for c in HUMAN]
+    run = H.synth(str(tmp_path / "run"), seed=1005, chroms=",".join(map(str, lens)), pairs=1500000, L=150, k=5, coverage=5, sam_seq=0, threads=THREADS)
+    tmp = os.path.join(run, "tmp")
+    meta = H.read_meta(run)
+    assert meta["unit_len"] == lens
+    want, errs, nxt, lock = {}, [], iter(range(24)), threading.Lock()
+
+    def oracle():
+        try:
+            while True:
+                with lock:
+                    uu = next(nxt, None)
+                if uu is None:
+                    return
+                want[uu] = H.run_oracle(tmp, uu, 5, 50, 5)
+        except BaseException as e:
+            errs.append(e)
+    checkers = [threading.Thread(target=oracle) for _ in range(min(8, THREADS))]
+    for t in checkers:
+        t.start()
+    with agx.Reads(os.path.join(tmp, "_reads.fa")) as reads:
+        for uu in range(24):
+            agx.cache_build(tmp, uu, reads=reads, k=5)
+    units, got, stats = {}, {}, {}
+    for uu in range(24):
+        units[uu] = agx.Unit(k=5, insert_variation=50, coverage=5, flags=agx.AGX_FLAG_ONE_SHOT)
+        units[uu].load_files(tmp, uu)
+        assert units[uu].stats()["from_cache"] == 1
+
+    def run_unit(uu):
+        un = units[uu]
+        un.build(); un.download()
+        got[uu] = un.finish()
+        stats[uu] = un.stats()
+        un.release()
+        return got[uu]["extended"]
+    out = shard.run_job(lens, 0, 1, run_unit, None, None, inflight=8, start_unit=lambda uu: units[uu].upload())
+    assert sorted(out) == list(range(24))
+    for un in units.values():
+        un.close()
+    for t in checkers:
+        t.join()
+    assert not errs, errs
+    for uu in range(24):
+        for key in ("initial", "pre", "extended"):
+            assert got[uu][key] == want[uu][key], "unit %d: %s differs from the oracle" % (uu, key)
+        assert stats[uu]["build_attempts"] == 1 and stats[uu]["n_pos"] >= lens[uu]
 
 
 @slow

@@ -285,6 +285,9 @@ def test_unit_cache_file_replaces_the_text(agx, built, tmp_path, monkeypatch):
         st = load_and_run(uu)
         assert st["from_cache"] == 1 and st["ms_parse"] == 0 and st["n_hits"] > 0 and st["sam_line_pairs"] > 0
     assert load_and_run(0, batch=5000)["from_cache"] == 0    # another BATCH keeps other pairs (AG:1258-1259): not this cache
+    with agx.Unit(k=7, insert_variation=50, coverage=4) as u:  # another k names other left mates: not this cache
+        u.load_files(tmp, 0)
+        assert u.stats()["from_cache"] == 0
     monkeypatch.setenv("AGX_NO_CACHE", "1")
     assert load_and_run(0)["from_cache"] == 0
     monkeypatch.delenv("AGX_NO_CACHE")
