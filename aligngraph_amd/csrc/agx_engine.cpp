@@ -199,12 +199,12 @@ struct agx_unit {
     PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_edge_ovf> h_a_ovf; PBuf<agx_hop> h_sp_hop; DBuf<agx_hop> d_sp_hop;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
-    Boundaries ev; hipEvent_t ev_front = nullptr, ev_passA = nullptr, ev_passJ = nullptr, ev_up0 = nullptr, ev_uploaded = nullptr, ev_dl = nullptr;
+    Boundaries ev; hipEvent_t ev_front = nullptr, ev_passA = nullptr, ev_passJ = nullptr, ev_up0 = nullptr, ev_uploaded = nullptr, ev_dl = nullptr, ev_hits = nullptr;      // ev_hits: everything but the read bases is in HBM
     bool up_timed = false;
     agx_stats stats{};
     ~agx_unit() {
         ev.destroy();
-        for (hipEvent_t e : {ev_front, ev_passA, ev_passJ, ev_up0, ev_uploaded, ev_dl, ev_built}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ev_front, ev_passA, ev_passJ, ev_up0, ev_uploaded, ev_dl, ev_built, ev_hits}) if (e) (void)hipEventDestroy(e);
         if (dl_signal.handle) (void)hsa_signal_destroy(dl_signal);
     }
 };
@@ -550,6 +550,7 @@ void do_upload(agx_unit *u) {
         up(u->d_segs.p, u->s_segs.p, u->n_segs * sizeof(agx_cmseg)); up(u->d_ref.p, u->s_ref.p, n_pos);
         up(u->d_hits.p, u->s_hits.p, nh * sizeof(agx_hit)); up(u->d_runs.p, u->s_runs.p, u->n_runs * sizeof(agx_run));
         up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);
+        HIP_OK(hipEventRecord(u->ev_hits, st));         // what the front of the build needs (conti-mer tables, hit preparation, binning) is there: it starts while the read bases still travel
         up(u->d_codes.p, u->s_codes.p, u->n_codes); up(u->d_other.p, u->s_other.p, u->n_other * 8);
         layout_regions(u, nullptr, pool_cap - spill_min(u), true, st);
         HIP_OK(hipEventRecord(u->ev_uploaded, st));
@@ -624,7 +625,8 @@ void do_build(agx_unit *u) {
         // The build streams are shared by all units of the device: nothing is queued on them that could wait long.  The unit's upload is
         // awaited here, on the host, before the turn is taken.
         const double tb0 = now_ms();
-        HIP_OK(hipEventSynchronize(u->ev_uploaded));
+        const bool early = !u->expanded && attempt == 0;      // a unit's first build starts on the arrays that arrive first; the read bases are waited for on the device, in front of their first use
+        HIP_OK(hipEventSynchronize(early ? u->ev_hits : u->ev_uploaded));
         trace(u, "build: wait for upload", tb0, n_pos);
         const double tb1 = now_ms();
         DeviceTurn &turn = turn_of(u->prm.device);
@@ -633,13 +635,10 @@ void do_build(agx_unit *u) {
         st = turn.front;
         if (turn.n) HIP_OK(hipStreamWaitEvent(st, (u->ev.all || turn.prev_exclusive) ? turn.build_done[(turn.n - 1) & 1] : turn.sweep_done[(turn.n - 1) & 1], 0));
         if (u->ev.all) HIP_OK(hipEventRecord(u->ev.first, st));      // (every event record costs the stream a few microseconds: untimed builds record only what orders them)
-        if (!u->expanded) {   // the unit's first build: conti-mer tables from their runs (agx_cmseg: count per position, scan, keys, heads); read bases: 2-bit classes and the list of other bases -> vote codes
-            const size_t n_bases = u->n_codes * 4;
+        if (!u->expanded) {   // the unit's first build: conti-mer tables from their runs (agx_cmseg: count per position, scan, keys, heads); the read bases follow behind the binning
             HIP_OK(hipMemsetAsync(u->d_cm_cnt.p, 0, ((size_t)n_pos + 2) * 4, st)); HIP_OK(hipMemsetAsync(u->d_up_desc.p, 0, (((size_t)n_pos + 2) / 4096 + 2) * 8, st));
             agx_launch_seg_expand(u->d_segs.p, (agx_u32)u->n_segs, (agx_u32)u->n_cm, u->d_cm_cnt.p, u->d_cm_start.p, u->d_cm.p, n_pos, u->d_up_desc.p, st);
             agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, n_pos, st);
-            agx_launch_expand_codes(u->d_codes.p, u->d_vcodes.p, (n_bases + 15) / 16 * 16, u->d_other.p, u->n_other, st);
-            u->expanded = true;
         }
         {   // everything a build counts into or marks, zeroed by one kernel and one fill (every command on the stream costs a few microseconds)
             agx_zero_args Z; memset(&Z, 0, sizeof Z);
@@ -663,6 +662,12 @@ void do_build(agx_unit *u) {
         agx_launch_bin_fill(&BA, st);
         agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, u->d_runs.p, u->prm.k, st);
         AGX_CHECKPOINT("tile_sort");
+        if (!u->expanded) {   // the vote codes (and the region layout, the last copy of the upload) are first needed by the sweep
+            const size_t n_bases = u->n_codes * 4;
+            if (early) HIP_OK(hipStreamWaitEvent(st, u->ev_uploaded, 0));      // (at most the tail of this unit's own upload: nothing else is ever waited for on a build stream)
+            agx_launch_expand_codes(u->d_codes.p, u->d_vcodes.p, (n_bases + 15) / 16 * 16, u->d_other.p, u->n_other, st);
+            u->expanded = true;
+        }
         HIP_OK(hipEventRecord(u->ev_front, st));
         // ---- main stream ----
         st = turn.main;
@@ -967,7 +972,7 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
         try { u->helper.start(); } catch (...) { }      // (without it the unit prepares its buffers on the caller's threads)
         HIP_OK(hipSetDevice(p->device));
         u->ev.init(); u->ev.all = (u->prm.flags & AGX_FLAG_TIME_SECTIONS) != 0;
-        for (hipEvent_t *e : {&u->ev_front, &u->ev_passA, &u->ev_passJ, &u->ev_dl, &u->ev_built}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t *e : {&u->ev_front, &u->ev_passA, &u->ev_passJ, &u->ev_dl, &u->ev_built, &u->ev_hits}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         HIP_OK(hipEventCreate(&u->ev_up0)); HIP_OK(hipEventCreate(&u->ev_uploaded));
         u->dl_sdma = hsa_copy().agent_of(p->device, u->dl_agent) && hsa_signal_create(0, 0, nullptr, &u->dl_signal) == HSA_STATUS_SUCCESS;
     });
