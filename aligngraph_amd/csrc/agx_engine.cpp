@@ -547,11 +547,11 @@ void do_upload(agx_unit *u) {
         auto up = [&](void *dst, const void *src, size_t bytes) {
             for (size_t at = 0; at < bytes;) { const size_t m = chunk ? std::min(chunk, bytes - at) : bytes; HIP_OK(hipMemcpyAsync((char *)dst + at, (const char *)src + at, m, hipMemcpyHostToDevice, st)); at += m; }
         };
-        up(u->d_segs.p, u->s_segs.p, u->n_segs * sizeof(agx_cmseg)); up(u->d_ref.p, u->s_ref.p, n_pos);
+        up(u->d_segs.p, u->s_segs.p, u->n_segs * sizeof(agx_cmseg));
         up(u->d_hits.p, u->s_hits.p, nh * sizeof(agx_hit)); up(u->d_runs.p, u->s_runs.p, u->n_runs * sizeof(agx_run));
-        up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);
-        HIP_OK(hipEventRecord(u->ev_hits, st));         // what the front of the build needs (conti-mer tables, hit preparation, binning) is there: it starts while the read bases still travel
-        up(u->d_codes.p, u->s_codes.p, u->n_codes); up(u->d_other.p, u->s_other.p, u->n_other * 8);
+        HIP_OK(hipEventRecord(u->ev_hits, st));         // what the front of the build needs (conti-mer tables, hit preparation, binning) is there: it starts while the rest still travels
+        up(u->d_codes.p, u->s_codes.p, u->n_codes); up(u->d_other.p, u->s_other.p, u->n_other * 8);      // first needed by the sweep
+        up(u->d_ref.p, u->s_ref.p, n_pos); up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);      // first needed by the walk preparation
         layout_regions(u, nullptr, pool_cap - spill_min(u), true, st);
         HIP_OK(hipEventRecord(u->ev_uploaded, st));
     } catch (...) { (void)hipStreamSynchronize(st); throw; }      // (copies that were queued before the failure must not outlive the unit's HBM block)
