@@ -625,7 +625,7 @@ void do_build(agx_unit *u) {
         // The build streams are shared by all units of the device: nothing is queued on them that could wait long.  The unit's upload is
         // awaited here, on the host, before the turn is taken.
         const double tb0 = now_ms();
-        const bool early = !u->expanded && attempt == 0;      // a unit's first build starts on the arrays that arrive first; the read bases are waited for on the device, in front of their first use
+        const bool early = !u->expanded && attempt == 0 && !u->ev.all;      // a unit's first build starts on the arrays that arrive first; the read bases are waited for on the device, in front of their first use (not in builds that time their sections: those would time the wait)
         HIP_OK(hipEventSynchronize(early ? u->ev_hits : u->ev_uploaded));
         trace(u, "build: wait for upload", tb0, n_pos);
         const double tb1 = now_ms();
