@@ -183,10 +183,17 @@ __attribute__((target("avx2"))) inline agx_u32 run_end_avx2(const agx_u8 *meta, 
     }
 }
 __attribute__((target("avx2"))) inline void mark_avx2(agx_u8 *meta, agx_u32 a, agx_u32 b) {
-    const __m256i v = _mm256_set1_epi8((char)AGX_WM_VISITED);
-    agx_u32 i = a;
-    for (; i + 31 <= b; i += 32) _mm256_storeu_si256((__m256i *)(meta + i), _mm256_or_si256(_mm256_loadu_si256((const __m256i *)(meta + i)), v));
-    for (; i <= b; i++) meta[i] |= AGX_WM_VISITED;
+    const agx_u32 n = b - a + 1;
+    if (n >= 32) {                                   // whole vectors from the front, then one that ends on b (setting a bit twice is setting it)
+        const __m256i v = _mm256_set1_epi8((char)AGX_WM_VISITED);
+        for (agx_u32 i = a; i + 31 < b; i += 32) _mm256_storeu_si256((__m256i *)(meta + i), _mm256_or_si256(_mm256_loadu_si256((const __m256i *)(meta + i)), v));
+        agx_u8 *t = meta + b - 31;
+        _mm256_storeu_si256((__m256i *)t, _mm256_or_si256(_mm256_loadu_si256((const __m256i *)t), v));
+    } else if (n >= 8) {                             // two overlapping 8-byte words per step
+        agx_u32 i = a;
+        for (; i + 7 < b; i += 8) { uint64_t w; memcpy(&w, meta + i, 8); w |= 0x8080808080808080ull; memcpy(meta + i, &w, 8); }
+        uint64_t w; memcpy(&w, meta + b - 7, 8); w |= 0x8080808080808080ull; memcpy(meta + b - 7, &w, 8);
+    } else for (agx_u32 i = a; i <= b; i++) meta[i] |= AGX_WM_VISITED;
 }
 #endif
 // first unvisited index i in [from, n) (n if none)
@@ -254,9 +261,12 @@ struct Walker {
     mutable unsigned long long n_fetched = 0;
     mutable std::unordered_map<agx_u32, agx_walknode> extra;      // records fetched so far (a few per 1000 positions of long records)
     mutable std::vector<agx_walknode> rows;
+    mutable agx_u32 last_v = AGX_NONE, last_at = AGX_NONE;      // a walk asks for the same id several times (start, successors, hop entry, end)
     agx_u32 rank_of(agx_u32 v) const {              // index of v in the sparse table, NONE if v is not a special id
+        if (v == last_v) return last_at;
         const unsigned long long w = G.sp_bits[v >> 6], bit = 1ull << (v & 63u);
-        return (w & bit) ? G.sp_rank[v >> 6] + (agx_u32)__builtin_popcountll(w & (bit - 1)) : AGX_NONE;
+        last_v = v;
+        return last_at = (w & bit) ? G.sp_rank[v >> 6] + (agx_u32)__builtin_popcountll(w & (bit - 1)) : AGX_NONE;
     }
     // hop entry of node v at position x: next to v's record in the sparse table (one cache line away from what the walk just read)
     // instead of a random access into the per-position table
