@@ -124,6 +124,10 @@ struct HsaCopy {
 };
 const HsaCopy &hsa_copy() { static const HsaCopy h; return h; }
 
+// positions from which a unit's host walk is split between two walkers (= walk_split's default in agx_walk.cpp; AGX_WALK_SPLIT_MIN, read at every download, overrides both: tests)
+inline size_t two_walkers_min() { const char *e = getenv("AGX_WALK_SPLIT_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)24000000; }
+#define AGX_TWO_WALKERS_MIN two_walkers_min()
+
 // One helper thread per unit, started with the unit and asleep until it is handed work: what a unit can prepare while its upload and
 // build run (the pinned download buffers, the output buffers) without its worker waiting for it.  Not started on demand: creating a
 // thread maps a stack, and that waits for the address-space lock that another unit's hipHostRegister holds for milliseconds.
@@ -195,7 +199,7 @@ struct agx_unit {
     DBuf<agx_u32> d_chain_end, d_side_xpos, d_sp_cnt, d_sp_rank; DBuf<unsigned long long> d_sp_bits;
     agx_u32 n_chain_end = 0, n_special = 0, n_words = 0;
     // downloaded: the walk graph with its sparse record table (agx_core.h); the full record table stays on the device
-    PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
+    PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta, h_a_meta2 /* a second copy of the meta bytes for the walk's second walker (large units) */; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
     PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_edge_ovf> h_a_ovf; PBuf<agx_hop> h_sp_hop; DBuf<agx_hop> d_sp_hop;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
@@ -569,6 +573,7 @@ void do_upload(agx_unit *u) {
             if (hipSetDevice(u->prm.device) != hipSuccess) return;
             const size_t ni = n_pos + n_pos / 8 + 4096, nw = ni / 64 + 1, ns = ni / 8 + 4096;
             u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(n_pos / 8 + 4097);
+            if (n_pos >= AGX_TWO_WALKERS_MIN) u->h_a_meta2.alloc(ni + 64);
             u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2); u->h_a_ovf.alloc(64);
         } catch (...) { }                               // do_download allocates what is missing and reports
         trace(u, "helper: download buffers", th0, n_pos);
@@ -805,6 +810,7 @@ void do_download(agx_unit *u) {
     const size_t n_pos = u->V.n_pos, ni = u->n_ids;
     DeviceTurn &turn = turn_of(u->prm.device);
     const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
+    const bool two = n_pos >= AGX_TWO_WALKERS_MIN && u->helper.started;      // a large unit is walked by two walkers (agx_walk.cpp: walk_split): the second one gets its own copy of the meta bytes
     join_dl_helper(u);
     if (u->prm.flags & AGX_FLAG_ONE_SHOT) {
         // The inputs are in HBM and will not be uploaded again: their staged copies are dead pinned memory.  The download's arrays are cut
@@ -817,10 +823,11 @@ void do_download(agx_unit *u) {
             for (Room &r : room) if (r.at && r.left >= bytes) { buf.borrow((T *)r.at, count); r.at += bytes; r.left -= bytes; return; }
         };
         u->consumed = true; u->staged = false;
-        cut(u->h_sp_node, ns + 1); cut(u->h_a_meta, ni + 64); cut(u->h_a_str, ni + 1); cut(u->h_sp_hop, ns + 2); cut(u->h_side_xpos, nside + 1);
+        cut(u->h_sp_node, ns + 1); cut(u->h_a_meta, ni + 64); cut(u->h_a_str, ni + 1); if (two) cut(u->h_a_meta2, ni + 64); cut(u->h_sp_hop, ns + 2); cut(u->h_side_xpos, nside + 1);
         cut(u->h_sp_bits, nw + 1); cut(u->h_sp_rank, nw + 1); cut(u->h_a_ovf, (size_t)u->n_ovf + 1);
     }
     u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(nside + 1);
+    if (two) u->h_a_meta2.alloc(ni + 64); else u->h_a_meta2.release();
     u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2);
     u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
     // the walk graph into the pinned buffers: plain copy commands on the device's download stream.  (r02 first used a kernel of its own for
@@ -828,9 +835,9 @@ void do_download(agx_unit *u) {
     // memory slowed whatever ran beside it, the next unit's binning most of all: the five builds of a cfg3 job ended at 45 ms with it, at
     // 42-45 ms with grids of 16-128 blocks, at 35 ms with the runtime's copies.)
     {
-        void *dst[8]; const void *src[8]; size_t bytes[8]; int n = 0;
+        void *dst[9]; const void *src[9]; size_t bytes[9]; int n = 0;
         auto add = [&](void *h, const void *d, size_t b) { if (b) { dst[n] = h; src[n] = d; bytes[n] = b; n++; } };
-        if (ni) { add(u->h_sp_bits.p, u->d_sp_bits.p, nw * 8); add(u->h_sp_rank.p, u->d_sp_rank.p, nw * 4); add(u->h_a_str.p, u->d_a_str.p, ni); add(u->h_a_meta.p, u->d_a_meta.p, ni); }
+        if (ni) { add(u->h_sp_bits.p, u->d_sp_bits.p, nw * 8); add(u->h_sp_rank.p, u->d_sp_rank.p, nw * 4); add(u->h_a_str.p, u->d_a_str.p, ni); add(u->h_a_meta.p, u->d_a_meta.p, ni); if (two) add(u->h_a_meta2.p, u->d_a_meta.p, ni); }
         add(u->h_side_xpos.p, u->d_side_xpos.p, nside * 4);
         add(u->h_sp_node.p, u->d_sp_node.p, ns * sizeof(agx_walknode)); add(u->h_sp_hop.p, u->d_sp_hop.p, ns * sizeof(agx_hop)); add(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf));
         bool by_engines = u->dl_sdma && n > 0;
@@ -851,7 +858,7 @@ void do_download(agx_unit *u) {
     const double t1 = now_ms();
     HIP_OK(hipEventSynchronize(u->ev_dl));
     if (getenv("AGX_DL_TIMING")) fprintf(stderr, "[agx download] buffers %.2f ms, copies %.2f ms (%zu ids, %zu records)\n", t1 - t0, now_ms() - t1, ni, ns);
-    memset(u->h_a_meta.p + ni, 0, 64);
+    memset(u->h_a_meta.p + ni, 0, 64); if (two) memset(u->h_a_meta2.p + ni, 0, 64);
     u->stats.n_walk_ids = ni; u->stats.n_special = ns;
     u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
     u->downloaded = true;
@@ -874,7 +881,7 @@ void do_release(agx_unit *u) {
     u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_sp_hop.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
     u->d_ovf.release(); u->d_a_ovf.release(); u->d_huge_list.release(); u->d_scratch_huge.release(); u->huge = false; u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
     u->arena.reset();
-    u->h_a_str.release(); u->h_a_meta.release(); u->h_side_xpos.release(); u->h_sp_rank.release(); u->h_sp_bits.release(); u->h_sp_node.release(); u->h_fetch.release(); u->h_a_ovf.release();
+    u->h_a_str.release(); u->h_a_meta.release(); u->h_a_meta2.release(); u->h_side_xpos.release(); u->h_sp_rank.release(); u->h_sp_bits.release(); u->h_sp_node.release(); u->h_fetch.release(); u->h_a_ovf.release();
     u->h_sp_hop.release();
     u->pool_cap = u->spill_lo = u->ovf_cap = u->list_cap = u->sp_cap = 0;
     u->uploaded = u->built = u->downloaded = false;
@@ -889,10 +896,10 @@ void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u
     if (!n) return;
     if ((size_t)first + (size_t)(rows - 1) * stride + width > u->n_ids || n > 0x7FFFFFFFull) throw Error{E_ARG, "record fetch beyond the walk graph"};
     HIP_OK(hipSetDevice(u->prm.device));
+    DeviceTurn &turn = turn_of(u->prm.device);
+    std::lock_guard<std::mutex> l(turn.down_m);      // (also: the two walkers of a large unit share the unit's fetch buffers)
     u->h_fetch.alloc(n); u->d_fetch.alloc(u->arena, n);
     agx_compact_args C = u->walk_args; C.n_ids = u->n_ids;
-    DeviceTurn &turn = turn_of(u->prm.device);
-    std::lock_guard<std::mutex> l(turn.down_m);
     agx_launch_fetch_records(&C, first, stride, rows, width, u->d_fetch.p, turn.down);
     HIP_OK(hipMemcpyAsync(u->h_fetch.p, u->d_fetch.p, n * sizeof(agx_walknode), hipMemcpyDeviceToHost, turn.down));
     HIP_OK(hipStreamSynchronize(turn.down));
@@ -901,7 +908,7 @@ void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u
 
 GraphView view_of(agx_unit *u) {
     GraphView G; G.n_pos = (agx_u32)u->V.n_pos; G.n_ids = u->n_ids;
-    G.meta = u->h_a_meta.p; G.meta_rw = u->h_a_meta.p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
+    G.meta = u->h_a_meta.p; G.meta_rw = u->h_a_meta.p; G.meta2 = u->h_a_meta2.p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
     G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.sp_hop = u->h_sp_hop.p; G.n_special = u->n_special;
     G.fetch = fetch_records; G.fetch_ctx = u;
     G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf; G.row_slot = u->row_slot.data();

@@ -244,6 +244,10 @@ struct Walker {
     agx_u8 *m = nullptr; agx_u8 *owned = nullptr;
     ~Walker() { free(owned); }
     bool visited(agx_u32 v) const { return (m[v] & AGX_WM_VISITED) != 0; }
+    // A speculative walker (walk_split below) may only look at nodes of positions [look_lo, look_hi): what it finds anywhere else is not
+    // what the sequential walk would find there.  It gives up (invalid) the moment an edge or a conti-mer chain leads outside.  (The record fetch hook serves both walkers: it must be callable from two threads.)
+    bool spec = false; agx_u32 look_lo = 0, look_hi = 0xFFFFFFFFu; mutable bool invalid = false; mutable agx_u32 gave_up_at = AGX_NONE;
+    bool may_look(agx_u32 v) const { if (!spec) return true; const agx_u32 x = pos_of(v); if (x >= look_lo && x < look_hi) return true; invalid = true; gave_up_at = x; return false; }
     std::vector<agx_edge_ovf> ovf;                  // sorted, unique
     Walker(const UnitView &v, const GraphView &g) : V(v), G(g) {
         if (g.meta_rw) { if (g.meta_rw != g.meta) throw Error{E_ARG, "meta_rw must be the meta array"}; m = g.meta_rw; }
@@ -317,12 +321,12 @@ struct Walker {
         int n = 0;
         const agx_walknode rec = node(v);
         const agx_u32 *s = rec.next;
-        for (agx_u32 e = 0; e < AGX_MAXE && s[e] != AGX_NONE; e++) if (!visited(s[e])) { target = s[e]; if (++n > 1) return n; }
+        for (agx_u32 e = 0; e < AGX_MAXE && s[e] != AGX_NONE; e++) { if (!may_look(s[e])) return 2; if (!visited(s[e])) { target = s[e]; if (++n > 1) return n; } }
         if (!ovf.empty()) {                             // nodes with more than AGX_MAXE out-edges (rare): the rest is in the overflow list
             auto it = std::lower_bound(ovf.begin(), ovf.end(), v, [](const agx_edge_ovf &a, agx_u32 key) { return a.src < key; });
             for (; it != ovf.end() && it->src == v; ++it) {
                 bool inl = false; for (agx_u32 e = 0; e < AGX_MAXE; e++) inl |= s[e] == it->dst;
-                if (!inl && !visited(it->dst)) { target = it->dst; if (++n > 1) return n; }
+                if (!inl) { if (!may_look(it->dst)) return 2; if (!visited(it->dst)) { target = it->dst; if (++n > 1) return n; } }
             }
         }
         return n;
@@ -345,123 +349,158 @@ struct Walker {
 
 // extdContigs1, AG:1954-2204, replayed on the alive-compacted graph.  Alive ids are position-major, so "for every
 // position, for every variant, if untraversed" (AG:1972-1978) is "for every alive id in order, if not done".
-void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena, Assistant *assistant) {
-    const GraphView &G = W.G; const UnitView &V = W.V;
-    agx_u32 seqID = 0, sIDBak = AGX_NONE, sOffBak = AGX_NONE, eIDBak = AGX_NONE, eOffBak = AGX_NONE;
+//
+// Everything the position scan carries from one position to the next (the function-scope variables of the reference) is in WalkState, so
+// the scan can be stopped at a position and taken up again — by the same walker, or by another one that arrives at the same state (walk_split).
+struct WalkState {
+    agx_u32 cp = 0;                              // the position the scan stands at
+    agx_u32 seqID = 0, sIDBak = AGX_NONE, sOffBak = AGX_NONE, eIDBak = AGX_NONE, eOffBak = AGX_NONE;      // records written so far; the last one written (AG:2176)
     agx_u32 pos_bak = 0;                         // cppBak of the reference (function scope)
-    std::string kmer; agx_u32 klen = 0, klast = 0;
-    agx_hop hcur{0, 0, 0};                       // hop entry of the position the walk is about to leave the k-mer graph at
-    std::vector<Seg> segs;
-    pre_out.reserve((size_t)G.n_ids + G.n_ids / 32 + 4096);
-    PreFormat pre(pre_out, assistant, (size_t)G.n_pos / 256 + 65536);
-    agx_u8 *const m = W.m;
-    auto done = [m](agx_u32 v) { return (m[v] & AGX_WM_VISITED) != 0; };
-    const mark_fn mark = pick_mark();
-    AGX_PT_START;
-    const run_end_fn run_end = pick_run_end();
+    bool same_scan(const WalkState &o) const { return cp == o.cp && sIDBak == o.sIDBak && sOffBak == o.sOffBak && eIDBak == o.eIDBak && eOffBak == o.eOffBak && pos_bak == o.pos_bak; }
+};
+typedef std::vector<std::pair<agx_u32, agx_u32>> MarkLog;      // id ranges [a, b] marked visited
+
+struct WalkRun {
+    Walker &W; Arena *arena;
+    WalkState st;
+    std::vector<Rec> &written; PreFormat *pre;   // pre: format the written records as they come; else their jobs are kept (jobs) for later
+    std::vector<PreJob> jobs;
+    bool keep = true;                            // false: a warm-up — records are decided and remembered as "the last one written", not kept
+    MarkLog *log = nullptr; agx_u32 log_main = 0, log_side = 0;      // log the marks that reach main ids >= log_main or side ids >= log_side
+    const std::atomic<bool> *cancel = nullptr;
     unsigned long long n_walks = 0, n_hops = 0, n_runs = 0, n_general = 0, run_nodes = 0;
-    const agx_u32 n_side = G.n_ids - G.n_pos;
-    agx_u32 sc = 0;                              // side index cursor: every side id before it lies at a position < cp
-    agx_u32 side_live = G.n_pos, main_live = 0;  // cached "first unvisited side / main id" of the position scan (see below)
-    for (agx_u32 cp = 0; cp < G.n_pos;) {
-        // variants of position cp in order: its main slot, then its side range
-        while (sc < n_side && G.side_xpos[sc] < cp) sc++;
-        agx_u32 sh = sc; while (sh < n_side && G.side_xpos[sh] == cp) sh++;
-        const agx_u32 s_lo = G.n_pos + sc, s_hi = G.n_pos + sh;
-        for (agx_u32 vi = 0, start = cp; vi <= s_hi - s_lo; vi++, start = s_lo + vi - 1) {
-            if (done(start)) continue;
-            AGX_PT(8);
-            Rec C(arena); C.sID = 0; C.sOff = cp; C.extended = 0;
-            segs.clear(); n_walks++;
-            agx_u32 cur = start;                 // current k-mer node (mode 1)
-            { const agx_u32 o = W.node(cur).off0; C.sID0 = o == AGX_NONE ? AGX_NONE : 0; C.sOff0 = o; }
-            AGX_PT(0);
-            agx_u32 cpp = cp; int mode = 1;               // mode = kMerTag
-            agx_u32 last = cur;
-            while ((mode == 1 && !done(cur)) || mode == 0) {
-                if (mode == 0) {                            // on a conti-mer, AG:2061-2138
-                    // the whole conti-mer chain in one segment (the reference steps through it one base at a time), then its end:
-                    // hop back onto the k-mer graph only through the single live node there and its single live edge (AG:2093-2136)
-                    AGX_PT(7); const agx_hop h = hcur;
-                    segs.push_back(Seg{V.chain_str + h.str_off, h.len}); C.extended = 1; n_hops++;
-                    pos_bak = h.end_pos; cpp = h.end_pos;
-                    agx_u32 live = 0, item = 0;
-                    if (!done(cpp)) { live++; item = cpp; }
-                    agx_u32 h_lo, h_hi; W.side_range(cpp, h_lo, h_hi);
-                    for (agx_u32 v = h_lo; v < h_hi; v++) if (!done(v)) { live++; item = v; }
-                    agx_u32 tgt = 0; int ns = 0;
-                    if (live == 1) ns = W.live_successors(item, tgt);
-                    if (ns == 1) { cur = tgt; pos_bak = W.pos_of(tgt); cpp = pos_bak; mode = done(cur) ? -2 : 1; }
-                    else mode = -2;
-                    AGX_PT(1);
-                } else {                                    // on a k-mer node, AG:1995-2060
-                    // forced run: while the cont bit holds and the next node is unvisited the reference steps cur -> cur+1 (its unique live
-                    // successor).
-                    agx_u8 seen = 0;
-                    const agx_u32 j = run_end(m, cur, seen);
-                    const agx_u32 xj = W.pos_of(j);
-                    AGX_PT(2);                             // most walks leave the k-mer graph here, onto a conti-mer chain
-                    segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!(m[j] & AGX_WM_CONT)) n_general++;
-                    if (seen & AGX_WM_CONTIG) C.extended = 1;
-                    mark(m, cur, j);
-                    if (j > cur) pos_bak = xj;
-                    cur = j; last = j; cpp = xj;
-                    AGX_PT(3);
-                    agx_u32 tgt = 0;
-                    const int ns = (m[cur] & AGX_WM_CONT) ? 0 : W.live_successors(cur, tgt);      // cont && stopped: its only alive successor is already visited
-                    if (ns == 1) { cur = tgt; pos_bak = W.pos_of(tgt); cpp = pos_bak; }
-                    else if ((hcur = W.hop_of(j, xj)).len) mode = 0;            // exactly one conti-mer here and it has a next (AG:2047-2057)
-                    else mode = -1;
-                    AGX_PT(4);
-                }
-            }
-            // end bookkeeping, AG:2142-2173
-            C.eID = 0; C.eOff = mode == 1 ? pos_bak : cpp;
-            if (mode == 1 || mode == -1) {
-                { const agx_u32 o = W.node(cur).off0; C.eID0 = o == AGX_NONE ? AGX_NONE : 0; C.eOff0 = o; }
-                // the record ends with the last node's k-mer string minus its first base; only its LENGTH matters until the record is known
-                // to be written (most are dropped below), so the read bases are not touched yet
-                klen = (W.node(last).sref.qlen >> 16) & 0x7FFFu; klast = last;
-                C.eOff = C.eOff + klen - 1; C.eOff0 = C.eOff0 + klen - 1;
-            } else { C.eID0 = AGX_NONE; C.eOff0 = AGX_NONE; klen = 0; }
-            AGX_PT(5);
-            if (!contains(sIDBak, sOffBak, eIDBak, eOffBak, C.sID, C.sOff, C.eID, C.eOff)) {        // AG:2176-2189
-                if (klen > 1) {                  // the record's trailing k-mer: its bytes go to the arena (every other range lives in the caller's tables)
-                    W.kmer_string(klast, kmer);
-                    char *t = (char *)arena->allocate(kmer.size() - 1, 1); memcpy(t, kmer.data() + 1, kmer.size() - 1);
-                    segs.push_back(Seg{t, kmer.size() - 1});
-                }
-                C.nuc.segs.reserve(segs.size());
-                for (const Seg &g : segs) C.nuc.add(g.p, g.n);
-                {   PreJob j; const agx_u32 f[10] = {seqID++, (agx_u32)C.extended, C.sID, C.sOff, C.eID, C.eOff, C.sID0, C.sOff0, C.eID0, C.eOff0};
-                    memcpy(j.f, f, sizeof f); j.segs = C.nuc.segs.data(); j.n_segs = C.nuc.segs.size(); j.total = C.nuc.len;
-                    pre.add(j); }
-                sIDBak = C.sID; sOffBak = C.sOff; eIDBak = C.eID; eOffBak = C.eOff;
-                if (eOffBak - sOffBak > 100000) W.prefetch_skip_positions(cp, eOffBak < G.n_pos ? eOffBak : G.n_pos);
-                written.push_back(std::move(C));
-            }
-            AGX_PT(6);
-        }
-        AGX_PT(9);
-        // AG:2194-2202: inside a written record longer than 100 kb the scan jumps 1000 positions at a time; otherwise it moves to the
-        // next position — and positions without an unvisited node do nothing, so jump straight to the next unvisited node's position
-        if (eOffBak - sOffBak > 100000 && eIDBak == 0 && cp + 1000 < eOffBak) cp += 1000;
-        else {
-            // the +1000 rule is re-evaluated at every position on the way, but it can only switch ON again after a new record is
-            // written, which needs an unvisited node: skipping node-less positions one by one or at once is the same
-            // first unvisited main id (= position) after cp and first unvisited side id from s_hi on.  Visited nodes stay visited and both
-            // bounds only grow, so a previous answer is still the answer unless it has been passed or visited since: each block is scanned
-            // once over the whole walk, not once per step (a long record leaves thousands of side nodes behind, each a step of its own)
-            if (main_live <= cp || (main_live < G.n_pos && done(main_live))) main_live = W.next_live(main_live > cp + 1 ? main_live : cp + 1, G.n_pos);
-            const agx_u32 m = main_live;                                                     // main slot id == position
-            if (side_live < s_hi || (side_live < G.n_ids && done(side_live))) side_live = W.next_live(side_live > s_hi ? side_live : s_hi, G.n_ids);
-            const agx_u32 sd = side_live;
-            const agx_u32 sp = sd < G.n_ids ? G.side_xpos[sd - G.n_pos] : G.n_pos;
-            cp = m < sp ? m : sp;
-        }
-        AGX_PT(10);
+    WalkRun(Walker &w, Arena *a, std::vector<Rec> &out, PreFormat *p) : W(w), arena(a), written(out), pre(p) {}
+    void note_marks(agx_u32 a, agx_u32 b) {      // (a run lies in the main block or in the side block)
+        if (a < W.G.n_pos) { if (b >= log_main) log->push_back({a < log_main ? log_main : a, b}); }
+        else if (b >= log_side) log->push_back({a < log_side ? log_side : a, b});
     }
-    pre.finish();
+    // the scan from st.cp until it stands at a position >= stop (or the walker gave up / was cancelled): st is where it stands then
+    void go(agx_u32 stop) {
+        const GraphView &G = W.G; const UnitView &V = W.V;
+        agx_u32 &seqID = st.seqID, &sIDBak = st.sIDBak, &sOffBak = st.sOffBak, &eIDBak = st.eIDBak, &eOffBak = st.eOffBak, &pos_bak = st.pos_bak;
+        std::string kmer; agx_u32 klen = 0, klast = 0;
+        agx_hop hcur{0, 0, 0};                       // hop entry of the position the walk is about to leave the k-mer graph at
+        std::vector<Seg> segs;
+        agx_u8 *const m = W.m;
+        auto done = [m](agx_u32 v) { return (m[v] & AGX_WM_VISITED) != 0; };
+        const mark_fn mark = pick_mark();
+        AGX_PT_START;
+        const run_end_fn run_end = pick_run_end();
+        const agx_u32 n_side = G.n_ids - G.n_pos;
+        if (stop > G.n_pos) stop = G.n_pos;
+        agx_u32 sc = (agx_u32)(std::lower_bound(G.side_xpos, G.side_xpos + n_side, st.cp) - G.side_xpos);      // side index cursor: every side id before it lies at a position < cp
+        agx_u32 side_live = G.n_pos + sc, main_live = st.cp;  // cached "first unvisited side / main id" of the position scan (see below; recomputed when stale)
+        agx_u32 cp = st.cp;
+        for (; cp < stop;) {
+            if (W.invalid || (cancel && cancel->load(std::memory_order_relaxed))) break;
+            // variants of position cp in order: its main slot, then its side range
+            while (sc < n_side && G.side_xpos[sc] < cp) sc++;
+            agx_u32 sh = sc; while (sh < n_side && G.side_xpos[sh] == cp) sh++;
+            const agx_u32 s_lo = G.n_pos + sc, s_hi = G.n_pos + sh;
+            for (agx_u32 vi = 0, start = cp; vi <= s_hi - s_lo; vi++, start = s_lo + vi - 1) {
+                if (done(start)) continue;
+                AGX_PT(8);
+                Rec C(arena); C.sID = 0; C.sOff = cp; C.extended = 0;
+                segs.clear(); n_walks++;
+                agx_u32 cur = start;                 // current k-mer node (mode 1)
+                { const agx_u32 o = W.node(cur).off0; C.sID0 = o == AGX_NONE ? AGX_NONE : 0; C.sOff0 = o; }
+                AGX_PT(0);
+                agx_u32 cpp = cp; int mode = 1;               // mode = kMerTag
+                agx_u32 last = cur;
+                while ((mode == 1 && !done(cur)) || mode == 0) {
+                    if (mode == 0) {                            // on a conti-mer, AG:2061-2138
+                        // the whole conti-mer chain in one segment (the reference steps through it one base at a time), then its end:
+                        // hop back onto the k-mer graph only through the single live node there and its single live edge (AG:2093-2136)
+                        AGX_PT(7); const agx_hop h = hcur;
+                        segs.push_back(Seg{V.chain_str + h.str_off, h.len}); C.extended = 1; n_hops++;
+                        pos_bak = h.end_pos; cpp = h.end_pos;
+                        if (!W.may_look(cpp)) { mode = -2; break; }      // (a speculative walker: the chain lands outside what it may look at)
+                        agx_u32 live = 0, item = 0;
+                        if (!done(cpp)) { live++; item = cpp; }
+                        agx_u32 h_lo, h_hi; W.side_range(cpp, h_lo, h_hi);
+                        for (agx_u32 v = h_lo; v < h_hi; v++) if (!done(v)) { live++; item = v; }
+                        agx_u32 tgt = 0; int ns = 0;
+                        if (live == 1) ns = W.live_successors(item, tgt);
+                        if (ns == 1) { cur = tgt; pos_bak = W.pos_of(tgt); cpp = pos_bak; mode = done(cur) ? -2 : 1; }
+                        else mode = -2;
+                        AGX_PT(1);
+                    } else {                                    // on a k-mer node, AG:1995-2060
+                        // forced run: while the cont bit holds and the next node is unvisited the reference steps cur -> cur+1 (its unique live
+                        // successor).
+                        agx_u8 seen = 0;
+                        const agx_u32 j = run_end(m, cur, seen);
+                        const agx_u32 xj = W.pos_of(j);
+                        if (W.spec && (xj < W.look_lo || xj >= W.look_hi)) { W.invalid = true; W.gave_up_at = xj; }      // (the run left what this walker may look at)
+                        AGX_PT(2);                             // most walks leave the k-mer graph here, onto a conti-mer chain
+                        segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!(m[j] & AGX_WM_CONT)) n_general++;
+                        if (seen & AGX_WM_CONTIG) C.extended = 1;
+                        mark(m, cur, j);
+                        if (log && j >= log_main) note_marks(cur, j);
+                        if (j > cur) pos_bak = xj;
+                        cur = j; last = j; cpp = xj;
+                        AGX_PT(3);
+                        agx_u32 tgt = 0;
+                        const int ns = (m[cur] & AGX_WM_CONT) ? 0 : W.live_successors(cur, tgt);      // cont && stopped: its only alive successor is already visited
+                        if (ns == 1) { cur = tgt; pos_bak = W.pos_of(tgt); cpp = pos_bak; }
+                        else if ((hcur = W.hop_of(j, xj)).len) mode = 0;            // exactly one conti-mer here and it has a next (AG:2047-2057)
+                        else mode = -1;
+                        AGX_PT(4);
+                    }
+                }
+                // end bookkeeping, AG:2142-2173
+                C.eID = 0; C.eOff = mode == 1 ? pos_bak : cpp;
+                if (mode == 1 || mode == -1) {
+                    { const agx_u32 o = W.node(cur).off0; C.eID0 = o == AGX_NONE ? AGX_NONE : 0; C.eOff0 = o; }
+                    // the record ends with the last node's k-mer string minus its first base; only its LENGTH matters until the record is known
+                    // to be written (most are dropped below), so the read bases are not touched yet
+                    klen = (W.node(last).sref.qlen >> 16) & 0x7FFFu; klast = last;
+                    C.eOff = C.eOff + klen - 1; C.eOff0 = C.eOff0 + klen - 1;
+                } else { C.eID0 = AGX_NONE; C.eOff0 = AGX_NONE; klen = 0; }
+                AGX_PT(5);
+                if (!contains(sIDBak, sOffBak, eIDBak, eOffBak, C.sID, C.sOff, C.eID, C.eOff)) {        // AG:2176-2189
+                    if (klen > 1) {                  // the record's trailing k-mer: its bytes go to the arena (every other range lives in the caller's tables)
+                        W.kmer_string(klast, kmer);
+                        char *t = (char *)arena->allocate(kmer.size() - 1, 1); memcpy(t, kmer.data() + 1, kmer.size() - 1);
+                        segs.push_back(Seg{t, kmer.size() - 1});
+                    }
+                    C.nuc.segs.reserve(segs.size());
+                    for (const Seg &g : segs) C.nuc.add(g.p, g.n);
+                    sIDBak = C.sID; sOffBak = C.sOff; eIDBak = C.eID; eOffBak = C.eOff;
+                    if (eOffBak - sOffBak > 100000) W.prefetch_skip_positions(cp, eOffBak < G.n_pos ? eOffBak : G.n_pos);
+                    if (keep) {
+                        PreJob j; const agx_u32 f[10] = {seqID, (agx_u32)C.extended, C.sID, C.sOff, C.eID, C.eOff, C.sID0, C.sOff0, C.eID0, C.eOff0};
+                        memcpy(j.f, f, sizeof f); j.segs = C.nuc.segs.data(); j.n_segs = C.nuc.segs.size(); j.total = C.nuc.len;
+                        if (pre) pre->add(j); else jobs.push_back(j);
+                        written.push_back(std::move(C));
+                    }
+                    seqID++;
+                }
+                AGX_PT(6);
+            }
+            AGX_PT(9);
+            // AG:2194-2202: inside a written record longer than 100 kb the scan jumps 1000 positions at a time; otherwise it moves to the
+            // next position — and positions without an unvisited node do nothing, so jump straight to the next unvisited node's position
+            if (eOffBak - sOffBak > 100000 && eIDBak == 0 && cp + 1000 < eOffBak) cp += 1000;
+            else {
+                // the +1000 rule is re-evaluated at every position on the way, but it can only switch ON again after a new record is
+                // written, which needs an unvisited node: skipping node-less positions one by one or at once is the same
+                // first unvisited main id (= position) after cp and first unvisited side id from s_hi on.  Visited nodes stay visited and both
+                // bounds only grow, so a previous answer is still the answer unless it has been passed or visited since: each block is scanned
+                // once over the whole walk, not once per step (a long record leaves thousands of side nodes behind, each a step of its own)
+                if (main_live <= cp || (main_live < G.n_pos && done(main_live))) main_live = W.next_live(main_live > cp + 1 ? main_live : cp + 1, G.n_pos);
+                const agx_u32 m = main_live;                                                     // main slot id == position
+                if (side_live < s_hi || (side_live < G.n_ids && done(side_live))) side_live = W.next_live(side_live > s_hi ? side_live : s_hi, G.n_ids);
+                const agx_u32 sd = side_live;
+                const agx_u32 sp = sd < G.n_ids ? G.side_xpos[sd - G.n_pos] : G.n_pos;
+                cp = m < sp ? m : sp;
+            }
+            AGX_PT(10);
+    }
+        st.cp = cp;
+    }
+};
+
+inline void walk_report(const WalkRun &r) {
 #if defined(AGX_WALK_PROF) && defined(__x86_64__)
     if (getenv("AGX_WALK_TIMING")) {
         fprintf(stderr, "[agx walk] Mcycles: start %.1f, hop %.1f, run scan %.1f, mark %.1f, successors %.1f, end %.1f, contain+write %.1f, between %.1f, position scan %.1f (+ %.1f after the last variant, %.1f next position)\n",
@@ -469,7 +508,163 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena, A
         memset(g_prof, 0, sizeof g_prof);
     }
 #endif
-    if (getenv("AGX_WALK_TIMING")) fprintf(stderr, "[agx walk] walks %llu, contig hops %llu, runs %llu (%llu nodes), general evaluations %llu\n", n_walks, n_hops, n_runs, run_nodes, n_general);
+    if (getenv("AGX_WALK_TIMING")) fprintf(stderr, "[agx walk] walks %llu, contig hops %llu, runs %llu (%llu nodes), general evaluations %llu\n", r.n_walks, r.n_hops, r.n_runs, r.run_nodes, r.n_general);
+}
+
+// The whole scan by one walker (the written records are formatted by the assistant while it goes on, if there is one).
+void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena, Assistant *assistant) {
+    pre_out.reserve((size_t)W.G.n_ids + W.G.n_ids / 32 + 4096);
+    PreFormat pre(pre_out, assistant, (size_t)W.G.n_pos / 256 + 65536);
+    WalkRun run(W, arena, written, &pre);
+    run.go(W.G.n_pos);
+    pre.finish();
+    walk_report(run);
+}
+
+// ---- the scan by two walkers ---------------------------------------------------------------------------------------------------
+// The walk is sequential by specification, but what it carries from position to position is small (WalkState) and what a walk touches is
+// near where it starts: records end at the next branch, a conti-mer chain lands a contig's length further.  So a second walker B starts a
+// warm-up stretch before the middle position c on a pristine copy of the visited bytes, and when the first walker A — the sequential walk
+// itself — arrives at c, the two states are compared: where the scan stands, the last record written, and every node at or behind c that
+// either has visited.  Equal states have equal futures: B's records from c on ARE the sequential walk's, provided B never looked at a node
+// in front of c or in the appended positions behind the reference (which A may have visited and B not) — B checks that as it goes and
+// gives up if an edge or a conti-mer chain leads there.  If anything differs A simply walks on through B's half: the
+// result is the sequential walk's either way, only the time differs.  The appended positions are walked last, by A, on the merged marks.
+inline void clip_marks(const MarkLog &log, agx_u32 main_lo, agx_u32 main_hi, agx_u32 n_pos, agx_u32 side_lo, agx_u32 side_hi, MarkLog &out) {
+    out.clear();
+    for (const auto &r : log) {
+        agx_u32 a = r.first, b = r.second;
+        if (b < n_pos) { if (a < main_lo) a = main_lo; if (b >= main_hi) { if (main_hi == 0) continue; b = main_hi - 1; } }
+        else { if (a < side_lo) a = side_lo; if (b >= side_hi) { if (side_hi == 0) continue; b = side_hi - 1; } }
+        if (a <= b) out.push_back({a, b});
+    }
+    std::sort(out.begin(), out.end());
+    size_t k = 0;
+    for (size_t i = 0; i < out.size(); i++) {
+        if (k && out[i].first <= out[k - 1].second + 1) { if (out[i].second > out[k - 1].second) out[k - 1].second = out[i].second; }
+        else out[k++] = out[i];
+    }
+    out.resize(k);
+}
+
+// false: not split (too small, no second copy of the meta bytes, no assistant): the caller walks the usual way
+bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena, Arena *arena_b, Assistant *assistant) {
+    const agx_u32 min_ref = getenv("AGX_WALK_SPLIT_MIN") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_MIN"), nullptr, 10) : 24000000u;
+    const agx_u32 warm = getenv("AGX_WALK_SPLIT_WARMUP") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_WARMUP"), nullptr, 10) : 400000u;
+    const agx_u32 n_ref = V.n_ref < G.n_pos ? V.n_ref : G.n_pos;
+    if (!assistant || !G.meta2 || n_ref < min_ref || n_ref < 4 || getenv("AGX_WALK_NO_SPLIT")) return false;
+    const agx_u32 c = n_ref / 2, w0 = c > warm ? c - warm : 0;
+    const agx_u32 n_side = G.n_ids - G.n_pos;
+    const agx_u32 side_c = G.n_pos + (agx_u32)(std::lower_bound(G.side_xpos, G.side_xpos + n_side, c) - G.side_xpos);
+    const agx_u32 side_ref = G.n_pos + (agx_u32)(std::lower_bound(G.side_xpos, G.side_xpos + n_side, n_ref) - G.side_xpos);
+    pre_out.reserve((size_t)G.n_ids + G.n_ids / 32 + 4096);
+
+    // B: its own visited bytes, its own arena; warm-up from w0 to c, then the second half up to the end of the reference
+    GraphView G2 = G; G2.meta = G.meta2; G2.meta_rw = G.meta2; G2.meta2 = nullptr;
+    Walker WB(V, G2);
+    std::vector<Rec> recs_b; recs_b.reserve((size_t)G.n_pos / 2048 + 1024);
+    MarkLog log_b; WalkState at_c_b; bool b_ok = false; std::string b_error;
+    std::atomic<bool> cancel{false};
+    WalkRun B(WB, arena_b, recs_b, nullptr);      // (B's lists and k-mer tails live in the caller's second arena: they outlive this function, and an arena serves one thread)
+    assistant->run([&] {
+        try {
+            WB.spec = true;                             // (looks anywhere during the warm-up)
+            B.cancel = &cancel; B.st.cp = w0; B.keep = false; B.log = &log_b; B.log_main = 0; B.log_side = G.n_pos;
+            B.go(c);                                    // warm-up: decides records, keeps none; every mark is logged
+            at_c_b = B.st;
+            // What the warm-up marked behind the reference (appended positions) is forgotten: B does not know what the sequential walk has
+            // visited there, so it must not find anything visited there that it marked itself — it finds those nodes unvisited, at most, and
+            // gives up when a walk leads to them.  (Its marks in front of c are never looked at again: whatever leads there makes it give up.)
+            for (const auto &r : log_b) for (agx_u32 i = r.first; i <= r.second; i++) if (i < G.n_pos ? i >= n_ref : i >= side_ref) WB.m[i] &= (agx_u8)~AGX_WM_VISITED;
+            B.keep = true; B.log = nullptr; B.st.seqID = 0;
+            WB.look_lo = c; WB.look_hi = n_ref;
+            if (!WB.invalid && !cancel.load()) B.go(n_ref);
+            b_ok = !WB.invalid && !cancel.load() && B.st.cp >= n_ref;
+        } catch (const Error &e) { b_error = e.msg; } catch (const std::exception &e) { b_error = e.what(); }
+    });
+    struct Join { Assistant *a; std::atomic<bool> &c; bool joined = false; void now() { if (!joined) { a->wait(); joined = true; } } ~Join() { c.store(true); now(); } } join{assistant, cancel};
+
+    auto clock = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tw0 = clock();
+    // A: the sequential walk up to c, its marks at and behind c logged
+    MarkLog log_a;
+    WalkRun A(WA, arena, written, nullptr);
+    A.log = &log_a; A.log_main = c; A.log_side = side_c;
+    A.go(c);
+    A.log = nullptr;
+    const size_t a_first = A.jobs.size();               // A's records in front of c
+    const double tw1 = clock();
+    join.now();
+    const double tw2 = clock();                                         // (B is done with its half, or gave up)
+    bool same = b_ok && b_error.empty() && A.st.same_scan(at_c_b);
+    if (same) {
+        MarkLog ma, mb;
+        clip_marks(log_a, c, n_ref, G.n_pos, side_c, side_ref, ma); clip_marks(log_b, c, n_ref, G.n_pos, side_c, side_ref, mb);
+        same = ma == mb;
+    }
+    const bool timing = getenv("AGX_WALK_TIMING") != nullptr;
+    if (timing && !same && b_ok) {                      // what differs where the walkers meet
+        MarkLog ma, mb;
+        clip_marks(log_a, c, n_ref, G.n_pos, side_c, side_ref, ma); clip_marks(log_b, c, n_ref, G.n_pos, side_c, side_ref, mb);
+        size_t d = 0; while (d < ma.size() && d < mb.size() && ma[d] == mb[d]) d++;
+        fprintf(stderr, "[agx walk] meeting at %u: first walker stands at %u, last record %u..%u; second at %u, last record %u..%u; marks behind the meeting point: %zu vs %zu ranges",
+                c, A.st.cp, A.st.sOffBak, A.st.eOffBak, at_c_b.cp, at_c_b.sOffBak, at_c_b.eOffBak, ma.size(), mb.size());
+        if (d < ma.size()) fprintf(stderr, ", first walker's range %zu = [%u, %u]", d, ma[d].first, ma[d].second);
+        if (d < mb.size()) fprintf(stderr, ", second's = [%u, %u]", mb[d].first, mb[d].second);
+        fprintf(stderr, "\n");
+    }
+    if (same) {
+        // B's half is the sequential walk's: its records behind A's, numbered on; its marks into A's bytes (the appended positions are walked on those)
+        const agx_u32 shift = A.st.seqID;
+        for (PreJob &j : B.jobs) j.f[0] += shift;
+        for (Rec &r : recs_b) written.push_back(std::move(r));
+        auto merge = [&](agx_u32 lo, agx_u32 hi) {
+            agx_u32 i = lo;
+            for (; i < hi && (i & 7u); i++) WA.m[i] |= (agx_u8)(WB.m[i] & AGX_WM_VISITED);
+            for (; i + 8 <= hi; i += 8) { uint64_t a, b; memcpy(&a, WA.m + i, 8); memcpy(&b, WB.m + i, 8); a |= b & 0x8080808080808080ull; memcpy(WA.m + i, &a, 8); }
+            for (; i < hi; i++) WA.m[i] |= (agx_u8)(WB.m[i] & AGX_WM_VISITED);
+        };
+        merge(c, n_ref); merge(side_c, side_ref);
+        A.st = B.st; A.st.seqID = shift + B.st.seqID; WA.n_fetched += WB.n_fetched;
+        A.n_walks += B.n_walks; A.n_hops += B.n_hops; A.n_runs += B.n_runs; A.n_general += B.n_general; A.run_nodes += B.run_nodes;
+    }
+    if (timing) {
+        if (same) fprintf(stderr, "[agx walk] split at %u (warm-up from %u): the second walker's half stands\n", c, w0);
+        else if (!b_error.empty()) fprintf(stderr, "[agx walk] split at %u: the second walker failed (%s): walked on by the first walker\n", c, b_error.c_str());
+        else if (WB.invalid) fprintf(stderr, "[agx walk] split at %u: the second walker gave up (a walk led to position %u, outside [%u, %u)): walked on by the first walker\n", c, WB.gave_up_at, c, n_ref);
+        else fprintf(stderr, "[agx walk] split at %u (warm-up from %u): states differ at the meeting point: walked on by the first walker\n", c, w0);
+    }
+    const double tw3 = clock();
+    A.go(G.n_pos);                                      // the appended positions — or everything from c on, if B's half does not stand
+    const double tw4 = clock();
+    // the pre-extended output: every record's place is known now, so the assistant formats the first half while this thread formats the second
+    std::vector<PreJob> all; all.reserve(A.jobs.size() + (same ? B.jobs.size() : 0));
+    all.insert(all.end(), A.jobs.begin(), A.jobs.begin() + (long)a_first);      // A's in front of c, B's half, A's behind it
+    if (same) all.insert(all.end(), B.jobs.begin(), B.jobs.end());
+    all.insert(all.end(), A.jobs.begin() + (long)a_first, A.jobs.end());
+    std::vector<size_t> at(all.size() + 1, 0);
+    auto header_len = [](const PreJob &j) { size_t n = 1 + 9 * 2 + 2; for (int i = 0; i < 10; i++) { agx_u32 v = j.f[i]; do { n++; v /= 10u; } while (v); } return n; };
+    for (size_t i = 0; i < all.size(); i++) at[i + 1] = at[i] + header_len(all[i]) + all[i].total + (all[i].total + 59) / 60;
+    const size_t total = at[all.size()];
+    pre_out.n = 0; char *base = pre_out.grow(total);
+    auto format = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            const PreJob &j = all[i];
+            char *h = base + at[i]; *h++ = '>';
+            for (int f = 0; f < 10; f++) { h = put_u32(h, j.f[f]); if (f < 9) { *h++ = ','; *h++ = ' '; } }
+            *h++ = ' '; *h++ = '\n';
+            LineWriter lw(h); for (size_t g = 0; g < j.n_segs; g++) lw.put(j.segs[g].p, j.segs[g].n); lw.end();
+        }
+    };
+    size_t mid = 0; while (mid < all.size() && at[mid] < total / 2) mid++;
+    if (mid > 0 && total > (1u << 16)) {
+        assistant->run([&] { format(0, mid); });
+        struct Wait { Assistant *a; ~Wait() { a->wait(); } } wait{assistant};
+        format(mid, all.size());
+    } else format(0, all.size());
+    if (timing) fprintf(stderr, "[agx walk] two walkers: first half %.1f ms, waited %.1f ms for the second, compare + merge %.1f ms, rest %.1f ms, formatting %.1f ms\n", tw1 - tw0, tw2 - tw1, tw3 - tw2, tw4 - tw3, clock() - tw4);
+    walk_report(A);
+    return true;
 }
 
 }  // namespace
@@ -511,13 +706,29 @@ inline int overlaps(agx_u32 x1, agx_u32 y1, agx_u32 x2, agx_u32 y2) {      // AG
 void scaffold(const UnitView &V, const GraphView &G, std::vector<Rec> &c, OutBuf &out, Arena *arena, Assistant *assistant) {
     std::vector<Bases> sc; sc.reserve(c.size());
     const agx_u32 n = (agx_u32)c.size();
+    // The reference looks at EVERY later record for one that overlaps the mate range [sOff0, eOff0] of the current one (AG:2415-2447): 52 k
+    // records of a 62 Mb unit made that 25-40 ms.  Every clause of overlap() needs sOff(q) <= eOff0 and sOff0 <= eOff(q); the records are
+    // in scan order (sOff never decreases), so the candidates are the stretch from the first record that can still reach sOff0 (none is
+    // longer than `longest`) to the last one that starts at or before eOff0 — the same first match, found without the rest.
+    std::vector<agx_u32> s_off(n); agx_u32 longest = 0; bool ordered = true;
+    for (agx_u32 i = 0; i < n; i++) {
+        s_off[i] = c[i].sOff;
+        if (i && s_off[i] < s_off[i - 1]) ordered = false;
+        if (c[i].eOff < c[i].sOff) longest = 0xFFFFFFFFu; else if (c[i].eOff - c[i].sOff > longest) longest = c[i].eOff - c[i].sOff;
+    }
     for (agx_u32 cp = 0; cp < n; cp++) {
         if (!(c[cp].sID != AGX_NONE && c[cp].extended == 1)) continue;
         sc.push_back(std::move(c[cp].nuc)); c[cp].nuc = Bases(arena); c[cp].sID = AGX_NONE;      // a record is used at most once (sID = -1 marks it, AG:2411)
         bool cont = true;
         while (c[cp].sID0 == c[cp].eID0 && cont) {
             cont = false;
-            for (agx_u32 q = cp + 1; q < n; q++) {
+            agx_u32 q = cp + 1;
+            if (ordered && longest != 0xFFFFFFFFu && c[cp].sOff0 > longest) {      // records that end in front of sOff0 cannot overlap
+                const agx_u32 from = (agx_u32)(std::lower_bound(s_off.begin(), s_off.end(), c[cp].sOff0 - longest) - s_off.begin());
+                if (from > q) q = from;
+            }
+            for (; q < n; q++) {
+                if (ordered && c[q].sOff > c[cp].eOff0) break;      // nor can any record from here on
                 if (!(c[cp].eID0 == c[q].sID && c[q].sID == c[q].eID && overlaps(c[cp].sOff0, c[cp].eOff0, c[q].sOff, c[q].eOff) && c[q].extended == 1)) continue;
                 if (c[q].sOff > c[cp].eOff) {
                     const agx_u32 gap = c[q].sOff - c[cp].eOff - 1; agx_u32 covered = 0;
@@ -530,6 +741,7 @@ void scaffold(const UnitView &V, const GraphView &G, std::vector<Rec> &c, OutBuf
             }
         }
     }
+    const double t_dec = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
     // output: every scaffold's place is known before a byte is written, so the assistant formats the first half while this thread formats the second
     std::vector<size_t> at(sc.size() + 1, 0);
     auto header = [](char *hdr, size_t i) { char *h = hdr; *h++ = '>'; char t[24]; int n = 0; do { t[n++] = (char)('0' + i % 10); i /= 10; } while (i); while (n) *h++ = t[--n]; *h++ = '\n'; return (size_t)(h - hdr); };
@@ -549,6 +761,7 @@ void scaffold(const UnitView &V, const GraphView &G, std::vector<Rec> &c, OutBuf
         struct Wait { Assistant *a; ~Wait() { a->wait(); } } wait{assistant};      // (also if this half throws)
         format(mid, sc.size());
     } else format(0, sc.size());
+    if (getenv("AGX_WALK_TIMING")) fprintf(stderr, "[agx walk] scaffold: output %.1f ms of it (%zu scaffolds, %zu bytes)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_dec, sc.size(), total);
 }
 
 }  // namespace
@@ -613,9 +826,10 @@ void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out, 
     const double ts = now();
     Walker W(V, G);
     std::pmr::monotonic_buffer_resource arena((size_t)8 << 20);      // byte-range lists and trailing k-mers of the written records
+    std::pmr::monotonic_buffer_resource arena2((size_t)1 << 20);     // the second walker's (walk_split): an arena serves one thread
     std::vector<Rec> recs; recs.reserve((size_t)G.n_pos / 1024 + 1024);
     double t0 = now();
-    walk(W, out.pre_extended, recs, &arena, assistant);
+    if (!walk_split(W, V, G, out.pre_extended, recs, &arena, &arena2, assistant)) walk(W, out.pre_extended, recs, &arena, assistant);
     double t1 = now();
     join(recs);
     double t2 = now();

@@ -259,6 +259,21 @@ def test_empty_and_ragged_inputs(agx, built, tmp_path):
     assert b["graph"]["n_nodes"] == 0
 
 
+def test_walk_by_two_walkers_gives_the_same_bytes(agx, built, tmp_path, monkeypatch):
+    """Large units are walked by two walkers (agx_walk.cpp: walk_split): forced here on a small unit, with a warm-up stretch that lets the
+    second walker's half stand and with one so short that the first walker has to walk on — the oracle's bytes either way."""
+    run = H.synth(str(tmp_path / "run"), seed=77, chroms="400000", pairs=80000, coverage=4, read_indel=0.2, multi=0.2, contig_overlap=0.3, sam_seq=0)
+    tmp = os.path.join(run, "tmp")
+    want = H.run_oracle(tmp, 0, 5, 50, 4)
+    monkeypatch.setenv("AGX_WALK_SPLIT_MIN", "0")
+    for warm in ("400000", "50000", "20"):
+        monkeypatch.setenv("AGX_WALK_SPLIT_WARMUP", warm)
+        for flags in (0, agx.AGX_FLAG_ONE_SHOT):
+            got = run_engine(agx, tmp, 0, 5, 50, 4, flags=flags)
+            for key in ("initial", "pre", "extended"):
+                assert got[key] == want[key], (warm, flags, key)
+
+
 def test_unit_cache_file_replaces_the_text(agx, built, tmp_path, monkeypatch):
     """tmp/_agx_unit.<u>.bin holds a unit's staged arrays; load_files takes it instead of the five text files as long as it
     is current, and falls back to the text when a source file changed, when the batch size differs or when the file is damaged."""

@@ -67,6 +67,22 @@ def test_sparse_record_table_and_fetch_hook(built, tmp_path, monkeypatch):
     assert m["n_special"] < s["n_special"] and m["n_fetched"] > 100
 
 
+@pytest.mark.parametrize("warm", ["1000000", "30000", "2000", "0"])
+def test_walk_by_two_walkers_is_the_sequential_walk(built, tmp_path, monkeypatch, warm):
+    # agx_walk.cpp: walk_split — a second walker starts a warm-up stretch in front of the middle of the unit on its own copy of the visited
+    # bytes; where the first walker arrives the two states are compared, and the second half either stands or is walked again.  The
+    # oracle's bytes whatever the warm-up is worth (long enough, marginal, far too short, none).
+    run = H.synth(str(tmp_path / "run"), seed=109, chroms="260000", pairs=52000, coverage=4, read_indel=0.2, multi=0.2, contig_overlap=0.4, contig_minus=0.5, sam_seq=0)
+    meta = H.read_meta(run)
+    tmp = os.path.join(run, "tmp")
+    o = H.run_oracle(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
+    for key, val in (("AGX_SIM_ASSISTANT", "1"), ("AGX_SIM_SPLIT", "1"), ("AGX_WALK_SPLIT_MIN", "0"), ("AGX_WALK_SPLIT_WARMUP", warm)):
+        monkeypatch.setenv(key, val)
+    s = sim.run(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
+    for key in ("initial", "pre", "extended"):
+        assert o[key] == s[key], key
+
+
 def test_shared_reads_index_loads_the_same_pairs(built, tmp_path, monkeypatch):
     # agx_reads (one map + record index of tmp/_reads.fa for all units of a run) against the per-unit scan of the file, including the
     # batch rule with a shrunk BATCH and reads files that end in an empty line
