@@ -593,8 +593,11 @@ void do_upload(agx_unit *u) {
 // the unit is uploaded and built; agx_unit_finish joins it.
 void prepare_outputs(agx_unit *u) {
     if (u->out_ready) return;
-    static std::mutex one_at_a_time;
-    std::lock_guard<std::mutex> l(one_at_a_time);
+    // a few at a time: with huge pages five threads touching fresh memory at once cost each other 20 % (tests/tools/faultbench.cpp), but 24 units
+    // taking strict turns made the last small units of a cfg5s job wait 3 ms for buffers that take 1 ms to make
+    struct Slots { std::mutex m; std::condition_variable cv; int free = 4; } static slots;
+    { std::unique_lock<std::mutex> l(slots.m); slots.cv.wait(l, [] { return slots.free > 0; }); slots.free--; }
+    struct Give { ~Give() { { std::lock_guard<std::mutex> l(slots.m); slots.free++; } slots.cv.notify_one(); } } give;
     try {
         const size_t n_pos = u->V.n_pos;
         u->out.pre_extended.n = 0; u->out.extended.n = 0; u->out_initial.n = 0;
