@@ -127,6 +127,8 @@ const HsaCopy &hsa_copy() { static const HsaCopy h; return h; }
 // positions from which a unit's host walk is split between two walkers (= walk_split's default in agx_walk.cpp; AGX_WALK_SPLIT_MIN, read at every download, overrides both: tests)
 inline size_t two_walkers_min() { const char *e = getenv("AGX_WALK_SPLIT_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)24000000; }
 #define AGX_TWO_WALKERS_MIN two_walkers_min()
+// walkers for a unit of n_pos positions: one per 15.5 M positions from the threshold on, at most four (walk_split decides the same way from what it is given)
+inline int walkers_wanted(size_t n_pos) { if (n_pos < AGX_TWO_WALKERS_MIN) return 1; const char *e = getenv("AGX_WALK_SPLIT_WALKERS"); int k = e ? atoi(e) : (int)(n_pos / 15500000u); return k < 2 ? 2 : k > 4 ? 4 : k; }
 
 // One helper thread per unit, started with the unit and asleep until it is handed work: what a unit can prepare while its upload and
 // build run (the pinned download buffers, the output buffers) without its worker waiting for it.  Not started on demand: creating a
@@ -161,6 +163,39 @@ struct UnitHelper {
     void wait(int s) { if (!started) return; std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !queued[s] && !running[s]; }); }
     ~UnitHelper() { if (started) { { std::lock_guard<std::mutex> l(m); stop = true; } cv.notify_all(); th.join(); } }
 };
+
+// The further walkers of large units (agx_walk.cpp: walk_split; the first extra one is the unit's own helper): a small pool for the process, made
+// when the first large unit is finished.  A unit takes what is free and walks with fewer walkers if that is less than it wanted.
+struct WalkerPool {
+    enum { N = 12 };
+    struct Slot { std::thread th; std::mutex m; std::condition_variable cv; std::function<void()> job; bool queued = false, running = false, taken = false, stop = false; };
+    Slot slot[N]; std::mutex take_m; bool started = false;
+    void start() {
+        if (started) return;
+        started = true;
+        for (Slot &s : slot) {
+            try {
+                s.th = std::thread([&s] {
+                    std::unique_lock<std::mutex> l(s.m);
+                    for (;;) {
+                        s.cv.wait(l, [&s] { return s.stop || s.queued; });
+                        if (s.stop) return;
+                        std::function<void()> f = std::move(s.job); s.queued = false; s.running = true;
+                        l.unlock();
+                        try { f(); } catch (...) { }
+                        l.lock(); s.running = false; s.cv.notify_all();
+                    }
+                });
+            } catch (...) { s.taken = true; }        // (never handed out)
+        }
+    }
+    int take() { std::lock_guard<std::mutex> l(take_m); start(); for (int i = 0; i < N; i++) if (!slot[i].taken) { slot[i].taken = true; return i; } return -1; }
+    void give(int i) { std::lock_guard<std::mutex> l(take_m); slot[i].taken = false; }
+    void run(int i, std::function<void()> f) { Slot &s = slot[i]; std::unique_lock<std::mutex> l(s.m); s.cv.wait(l, [&s] { return !s.queued && !s.running; }); s.job = std::move(f); s.queued = true; s.cv.notify_all(); }
+    void wait(int i) { Slot &s = slot[i]; std::unique_lock<std::mutex> l(s.m); s.cv.wait(l, [&s] { return !s.queued && !s.running; }); }
+    ~WalkerPool() { for (Slot &s : slot) if (s.th.joinable()) { { std::lock_guard<std::mutex> l(s.m); s.stop = true; } s.cv.notify_all(); s.th.join(); } }
+};
+WalkerPool &walker_pool() { static WalkerPool p; return p; }
 
 struct agx_unit {
     agx_params prm{};
@@ -199,7 +234,7 @@ struct agx_unit {
     DBuf<agx_u32> d_chain_end, d_side_xpos, d_sp_cnt, d_sp_rank; DBuf<unsigned long long> d_sp_bits;
     agx_u32 n_chain_end = 0, n_special = 0, n_words = 0;
     // downloaded: the walk graph with its sparse record table (agx_core.h); the full record table stays on the device
-    PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta, h_a_meta2 /* a second copy of the meta bytes for the walk's second walker (large units) */; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
+    PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta, h_a_metas[3] /* further copies of the meta bytes for the walk's other walkers (large units) */; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
     PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_edge_ovf> h_a_ovf; PBuf<agx_hop> h_sp_hop; DBuf<agx_hop> d_sp_hop;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
@@ -573,7 +608,7 @@ void do_upload(agx_unit *u) {
             if (hipSetDevice(u->prm.device) != hipSuccess) return;
             const size_t ni = n_pos + n_pos / 8 + 4096, nw = ni / 64 + 1, ns = ni / 8 + 4096;
             u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(n_pos / 8 + 4097);
-            if (n_pos >= AGX_TWO_WALKERS_MIN) u->h_a_meta2.alloc(ni + 64);
+            for (int w = 0; w < walkers_wanted(n_pos) - 1; w++) u->h_a_metas[w].alloc(ni + 64);
             u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2); u->h_a_ovf.alloc(64);
         } catch (...) { }                               // do_download allocates what is missing and reports
         trace(u, "helper: download buffers", th0, n_pos);
@@ -813,7 +848,7 @@ void do_download(agx_unit *u) {
     const size_t n_pos = u->V.n_pos, ni = u->n_ids;
     DeviceTurn &turn = turn_of(u->prm.device);
     const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
-    const bool two = n_pos >= AGX_TWO_WALKERS_MIN && u->helper.started;      // a large unit is walked by two walkers (agx_walk.cpp: walk_split): the second one gets its own copy of the meta bytes
+    const int copies = u->helper.started ? walkers_wanted(n_pos) - 1 : 0;      // a large unit is walked by several walkers (agx_walk.cpp: walk_split): each further one gets its own copy of the meta bytes
     join_dl_helper(u);
     if (u->prm.flags & AGX_FLAG_ONE_SHOT) {
         // The inputs are in HBM and will not be uploaded again: their staged copies are dead pinned memory.  The download's arrays are cut
@@ -826,11 +861,11 @@ void do_download(agx_unit *u) {
             for (Room &r : room) if (r.at && r.left >= bytes) { buf.borrow((T *)r.at, count); r.at += bytes; r.left -= bytes; return; }
         };
         u->consumed = true; u->staged = false;
-        cut(u->h_sp_node, ns + 1); cut(u->h_a_meta, ni + 64); cut(u->h_a_str, ni + 1); if (two) cut(u->h_a_meta2, ni + 64); cut(u->h_sp_hop, ns + 2); cut(u->h_side_xpos, nside + 1);
+        cut(u->h_sp_node, ns + 1); cut(u->h_a_meta, ni + 64); cut(u->h_a_str, ni + 1); for (int w = 0; w < copies; w++) cut(u->h_a_metas[w], ni + 64); cut(u->h_sp_hop, ns + 2); cut(u->h_side_xpos, nside + 1);
         cut(u->h_sp_bits, nw + 1); cut(u->h_sp_rank, nw + 1); cut(u->h_a_ovf, (size_t)u->n_ovf + 1);
     }
     u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(nside + 1);
-    if (two) u->h_a_meta2.alloc(ni + 64); else u->h_a_meta2.release();
+    for (int w = 0; w < 3; w++) { if (w < copies) u->h_a_metas[w].alloc(ni + 64); else u->h_a_metas[w].release(); }
     u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2);
     u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
     // the walk graph into the pinned buffers: plain copy commands on the device's download stream.  (r02 first used a kernel of its own for
@@ -838,9 +873,9 @@ void do_download(agx_unit *u) {
     // memory slowed whatever ran beside it, the next unit's binning most of all: the five builds of a cfg3 job ended at 45 ms with it, at
     // 42-45 ms with grids of 16-128 blocks, at 35 ms with the runtime's copies.)
     {
-        void *dst[9]; const void *src[9]; size_t bytes[9]; int n = 0;
+        void *dst[12]; const void *src[12]; size_t bytes[12]; int n = 0;
         auto add = [&](void *h, const void *d, size_t b) { if (b) { dst[n] = h; src[n] = d; bytes[n] = b; n++; } };
-        if (ni) { add(u->h_sp_bits.p, u->d_sp_bits.p, nw * 8); add(u->h_sp_rank.p, u->d_sp_rank.p, nw * 4); add(u->h_a_str.p, u->d_a_str.p, ni); add(u->h_a_meta.p, u->d_a_meta.p, ni); if (two) add(u->h_a_meta2.p, u->d_a_meta.p, ni); }
+        if (ni) { add(u->h_sp_bits.p, u->d_sp_bits.p, nw * 8); add(u->h_sp_rank.p, u->d_sp_rank.p, nw * 4); add(u->h_a_str.p, u->d_a_str.p, ni); add(u->h_a_meta.p, u->d_a_meta.p, ni); for (int w = 0; w < copies; w++) add(u->h_a_metas[w].p, u->d_a_meta.p, ni); }
         add(u->h_side_xpos.p, u->d_side_xpos.p, nside * 4);
         add(u->h_sp_node.p, u->d_sp_node.p, ns * sizeof(agx_walknode)); add(u->h_sp_hop.p, u->d_sp_hop.p, ns * sizeof(agx_hop)); add(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf));
         bool by_engines = u->dl_sdma && n > 0;
@@ -861,7 +896,7 @@ void do_download(agx_unit *u) {
     const double t1 = now_ms();
     HIP_OK(hipEventSynchronize(u->ev_dl));
     if (getenv("AGX_DL_TIMING")) fprintf(stderr, "[agx download] buffers %.2f ms, copies %.2f ms (%zu ids, %zu records)\n", t1 - t0, now_ms() - t1, ni, ns);
-    memset(u->h_a_meta.p + ni, 0, 64); if (two) memset(u->h_a_meta2.p + ni, 0, 64);
+    memset(u->h_a_meta.p + ni, 0, 64); for (int w = 0; w < copies; w++) memset(u->h_a_metas[w].p + ni, 0, 64);
     u->stats.n_walk_ids = ni; u->stats.n_special = ns;
     u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
     u->downloaded = true;
@@ -884,7 +919,7 @@ void do_release(agx_unit *u) {
     u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_sp_hop.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
     u->d_ovf.release(); u->d_a_ovf.release(); u->d_huge_list.release(); u->d_scratch_huge.release(); u->huge = false; u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
     u->arena.reset();
-    u->h_a_str.release(); u->h_a_meta.release(); u->h_a_meta2.release(); u->h_side_xpos.release(); u->h_sp_rank.release(); u->h_sp_bits.release(); u->h_sp_node.release(); u->h_fetch.release(); u->h_a_ovf.release();
+    u->h_a_str.release(); u->h_a_meta.release(); for (auto &b : u->h_a_metas) b.release(); u->h_side_xpos.release(); u->h_sp_rank.release(); u->h_sp_bits.release(); u->h_sp_node.release(); u->h_fetch.release(); u->h_a_ovf.release();
     u->h_sp_hop.release();
     u->pool_cap = u->spill_lo = u->ovf_cap = u->list_cap = u->sp_cap = 0;
     u->uploaded = u->built = u->downloaded = false;
@@ -900,7 +935,7 @@ void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u
     if ((size_t)first + (size_t)(rows - 1) * stride + width > u->n_ids || n > 0x7FFFFFFFull) throw Error{E_ARG, "record fetch beyond the walk graph"};
     HIP_OK(hipSetDevice(u->prm.device));
     DeviceTurn &turn = turn_of(u->prm.device);
-    std::lock_guard<std::mutex> l(turn.down_m);      // (also: the two walkers of a large unit share the unit's fetch buffers)
+    std::lock_guard<std::mutex> l(turn.down_m);      // (also: the walkers of a large unit share the unit's fetch buffers)
     u->h_fetch.alloc(n); u->d_fetch.alloc(u->arena, n);
     agx_compact_args C = u->walk_args; C.n_ids = u->n_ids;
     agx_launch_fetch_records(&C, first, stride, rows, width, u->d_fetch.p, turn.down);
@@ -911,7 +946,7 @@ void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u
 
 GraphView view_of(agx_unit *u) {
     GraphView G; G.n_pos = (agx_u32)u->V.n_pos; G.n_ids = u->n_ids;
-    G.meta = u->h_a_meta.p; G.meta_rw = u->h_a_meta.p; G.meta2 = u->h_a_meta2.p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
+    G.meta = u->h_a_meta.p; G.meta_rw = u->h_a_meta.p; for (int w = 0; w < 3; w++) G.meta_copy[w] = u->h_a_metas[w].p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
     G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.sp_hop = u->h_sp_hop.p; G.n_special = u->n_special;
     G.fetch = fetch_records; G.fetch_ctx = u;
     G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf; G.row_slot = u->row_slot.data();
@@ -1110,11 +1145,17 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
         if (!u->out_ready) throw Error{E_ARG, "out of host memory"};
         u->downloaded = false;            // the walk marks the downloaded meta bytes: another finish downloads again
         u->out_ready = false;             // (an error below leaves the buffers to the next prepare_outputs)
-        struct Second : Assistant {            // the unit's helper thread copies the written records' bases into the outputs while the walk goes on
-            agx_unit *u; explicit Second(agx_unit *x) : u(x) {}
-            void run(std::function<void()> f) override { if (!u->helper.submit(UnitHelper::WALK, std::move(f))) throw Error{E_ARG, "no helper thread"}; }
-            void wait() override { u->helper.wait(UnitHelper::WALK); }
-        } second(u);
+        struct Helpers : Assistant {           // helper 0: the unit's own thread (formats the written records while the walk goes on, or walks a stretch); 1..: pool threads for further walkers
+            agx_unit *u; int pool[3] = {-1, -1, -1}; int n_pool = 0;
+            Helpers(agx_unit *x, int extra) : u(x) { for (int i = 0; i < extra && i < 3; i++) { const int t = walker_pool().take(); if (t < 0) break; pool[n_pool++] = t; } }
+            ~Helpers() override { for (int i = 0; i < n_pool; i++) { walker_pool().wait(pool[i]); walker_pool().give(pool[i]); } }
+            int helpers() const override { return 1 + n_pool; }
+            void run(std::function<void()> f, int who) override {
+                if (who == 0) { if (!u->helper.submit(UnitHelper::WALK, std::move(f))) throw Error{E_ARG, "no helper thread"}; }
+                else walker_pool().run(pool[who - 1], std::move(f));
+            }
+            void wait(int who) override { if (who == 0) u->helper.wait(UnitHelper::WALK); else walker_pool().wait(pool[who - 1]); }
+        } second(u, walkers_wanted(u->V.n_pos) - 2);
         walk_join_scaffold(u->V, view_of(u), u->out, u->helper.started ? &second : nullptr);
         u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = u->out.n_fetched;
         trace(u, "walk", t0, u->V.n_pos);

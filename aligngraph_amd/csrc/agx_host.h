@@ -71,7 +71,7 @@ struct GraphView {
     agx_u32 n_pos = 0, n_ids = 0;
     const agx_u8 *meta = nullptr;                           // [n_ids + 64] AGX_WM_* bits (padding reads as 0)
     agx_u8 *meta_rw = nullptr;                              // null, or == meta: the walk may keep its visited marks in meta's bit 7 (the array is consumed by the walk)
-    agx_u8 *meta2 = nullptr;                                // null, or a second copy of meta that the walk may consume as well: a large unit is then walked by two walkers (agx_walk.cpp: walk_split)
+    agx_u8 *meta_copy[3] = {nullptr, nullptr, nullptr};     // further copies of meta that the walk may consume as well: a large unit is then walked by several walkers, one per copy + 1 (agx_walk.cpp: walk_split)
     const char *str = nullptr;                              // [n_ids] base a node emits
     const agx_u32 *side_xpos = nullptr;                     // [n_ids - n_pos] position of each side id, non-decreasing
     const unsigned long long *sp_bits = nullptr;            // [n_ids/64 + 1] special-id bitmap
@@ -122,7 +122,9 @@ void load_pairs_from_files(const std::string &reads_fa, const std::string &sam, 
 // agx_walk.cpp
 // A second thread the walk may hand work to (the engine: the unit's helper thread): run(f) starts f there, wait() returns when it is done.
 // The walk itself is sequential by specification; copying the written records' bases into the outputs is not.
-struct Assistant { virtual void run(std::function<void()> f) = 0; virtual void wait() = 0; virtual ~Assistant() {} };
+struct Assistant {          // (helpers(): how many threads there are; `who` picks one)
+    virtual void run(std::function<void()> f, int who = 0) = 0; virtual void wait(int who = 0) = 0; virtual int helpers() const { return 1; } virtual ~Assistant() {}
+};
 void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out, Assistant *assistant = nullptr);
 
 }  // namespace agx

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <memory_resource>
 #include <string>
 #include <vector>
@@ -521,7 +522,7 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena, A
     walk_report(run);
 }
 
-// ---- the scan by two walkers ---------------------------------------------------------------------------------------------------
+// ---- the scan by several walkers ---------------------------------------------------------------------------------------------------
 // The walk is sequential by specification, but what it carries from position to position is small (WalkState) and what a walk touches is
 // near where it starts: records end at the next branch, a conti-mer chain lands a contig's length further.  So a second walker B starts a
 // warm-up stretch before the middle position c on a pristine copy of the visited bytes, and when the first walker A — the sequential walk
@@ -547,122 +548,155 @@ inline void clip_marks(const MarkLog &log, agx_u32 main_lo, agx_u32 main_hi, agx
     out.resize(k);
 }
 
-// false: not split (too small, no second copy of the meta bytes, no assistant): the caller walks the usual way
-bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena, Arena *arena_b, Assistant *assistant) {
+// One speculative walker: its own visited bytes (a pristine copy of the meta bytes), its own arena, its stretch [c, c_next) of the reference
+struct SpecWalker {
+    agx_u32 c = 0, c_next = 0, w0 = 0, side_c = 0, side_next = 0;
+    GraphView G; std::unique_ptr<Walker> W; std::unique_ptr<WalkRun> R; std::vector<Rec> recs;
+    MarkLog log; size_t n_warm = 0;              // every mark of the warm-up, then the marks of the stretch that reach c_next or further
+    WalkState at_c;                              // where it stood when it arrived at c
+    bool ok = false; std::string error;
+};
+
+// false: not split (too small, no copy of the meta bytes, no assistant): the caller walks the usual way
+bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena, Arena *const *more_arenas, Assistant *assistant) {
     const agx_u32 min_ref = getenv("AGX_WALK_SPLIT_MIN") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_MIN"), nullptr, 10) : 24000000u;
     const agx_u32 warm = getenv("AGX_WALK_SPLIT_WARMUP") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_WARMUP"), nullptr, 10) : 400000u;
     const agx_u32 n_ref = V.n_ref < G.n_pos ? V.n_ref : G.n_pos;
-    if (!assistant || !G.meta2 || n_ref < min_ref || n_ref < 4 || getenv("AGX_WALK_NO_SPLIT")) return false;
-    const agx_u32 c = n_ref / 2, w0 = c > warm ? c - warm : 0;
+    if (!assistant || !G.meta_copy[0] || n_ref < min_ref || n_ref < 16 || getenv("AGX_WALK_NO_SPLIT")) return false;
+    // walkers: one per 15.5 M positions (at least two), as many as there are copies of the meta bytes and helper threads, at most four
+    int K = getenv("AGX_WALK_SPLIT_WALKERS") ? atoi(getenv("AGX_WALK_SPLIT_WALKERS")) : (int)(n_ref / 15500000u);
+    if (K < 2) K = 2;
+    if (K > 4) K = 4;
+    { int copies = 0; while (copies < 3 && G.meta_copy[copies]) copies++; if (K > 1 + copies) K = 1 + copies; if (K > 1 + assistant->helpers()) K = 1 + assistant->helpers(); }
+    if (K < 2) return false;
     const agx_u32 n_side = G.n_ids - G.n_pos;
-    const agx_u32 side_c = G.n_pos + (agx_u32)(std::lower_bound(G.side_xpos, G.side_xpos + n_side, c) - G.side_xpos);
-    const agx_u32 side_ref = G.n_pos + (agx_u32)(std::lower_bound(G.side_xpos, G.side_xpos + n_side, n_ref) - G.side_xpos);
+    auto side_of = [&](agx_u32 x) { return G.n_pos + (agx_u32)(std::lower_bound(G.side_xpos, G.side_xpos + n_side, x) - G.side_xpos); };
+    const agx_u32 side_ref = side_of(n_ref);
     pre_out.reserve((size_t)G.n_ids + G.n_ids / 32 + 4096);
-
-    // B: its own visited bytes, its own arena; warm-up from w0 to c, then the second half up to the end of the reference
-    GraphView G2 = G; G2.meta = G.meta2; G2.meta_rw = G.meta2; G2.meta2 = nullptr;
-    Walker WB(V, G2);
-    std::vector<Rec> recs_b; recs_b.reserve((size_t)G.n_pos / 2048 + 1024);
-    MarkLog log_b; WalkState at_c_b; bool b_ok = false; std::string b_error;
-    std::atomic<bool> cancel{false};
-    WalkRun B(WB, arena_b, recs_b, nullptr);      // (B's lists and k-mer tails live in the caller's second arena: they outlive this function, and an arena serves one thread)
-    assistant->run([&] {
-        try {
-            WB.spec = true;                             // (looks anywhere during the warm-up)
-            B.cancel = &cancel; B.st.cp = w0; B.keep = false; B.log = &log_b; B.log_main = 0; B.log_side = G.n_pos;
-            B.go(c);                                    // warm-up: decides records, keeps none; every mark is logged
-            at_c_b = B.st;
-            // What the warm-up marked behind the reference (appended positions) is forgotten: B does not know what the sequential walk has
-            // visited there, so it must not find anything visited there that it marked itself — it finds those nodes unvisited, at most, and
-            // gives up when a walk leads to them.  (Its marks in front of c are never looked at again: whatever leads there makes it give up.)
-            for (const auto &r : log_b) for (agx_u32 i = r.first; i <= r.second; i++) if (i < G.n_pos ? i >= n_ref : i >= side_ref) WB.m[i] &= (agx_u8)~AGX_WM_VISITED;
-            B.keep = true; B.log = nullptr; B.st.seqID = 0;
-            WB.look_lo = c; WB.look_hi = n_ref;
-            if (!WB.invalid && !cancel.load()) B.go(n_ref);
-            b_ok = !WB.invalid && !cancel.load() && B.st.cp >= n_ref;
-        } catch (const Error &e) { b_error = e.msg; } catch (const std::exception &e) { b_error = e.what(); }
-    });
-    struct Join { Assistant *a; std::atomic<bool> &c; bool joined = false; void now() { if (!joined) { a->wait(); joined = true; } } ~Join() { c.store(true); now(); } } join{assistant, cancel};
-
+    const bool timing = getenv("AGX_WALK_TIMING") != nullptr;
     auto clock = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+
+    std::atomic<bool> cancel{false};
+    std::vector<SpecWalker> B((size_t)K - 1);
+    for (int i = 1; i < K; i++) {
+        SpecWalker &b = B[(size_t)i - 1];
+        b.c = (agx_u32)((unsigned long long)n_ref * (unsigned)i / (unsigned)K); b.c_next = i + 1 < K ? (agx_u32)((unsigned long long)n_ref * (unsigned)(i + 1) / (unsigned)K) : n_ref;
+        b.w0 = b.c > warm ? b.c - warm : 0; b.side_c = side_of(b.c); b.side_next = side_of(b.c_next);
+        b.G = G; b.G.meta = G.meta_copy[i - 1]; b.G.meta_rw = G.meta_copy[i - 1]; for (auto &mc : b.G.meta_copy) mc = nullptr;
+        b.W.reset(new Walker(V, b.G));
+        b.recs.reserve((size_t)G.n_pos / 2048 + 1024);
+        b.R.reset(new WalkRun(*b.W, more_arenas[i - 1], b.recs, nullptr));      // (its lists and k-mer tails live in one of the caller's arenas: they outlive this function, and an arena serves one thread)
+    }
+    // they start: warm-up from w0 to c, then the stretch [c, c_next)
+    struct Join { Assistant *a; int n; std::atomic<bool> &c; std::vector<bool> joined; void now(int i) { if (!joined[(size_t)i]) { a->wait(i); joined[(size_t)i] = true; } } ~Join() { c.store(true); for (int i = 0; i < n; i++) now(i); } } join{assistant, K - 1, cancel, std::vector<bool>((size_t)K - 1, false)};
+    for (int i = 1; i < K; i++) {
+        SpecWalker *bp = &B[(size_t)i - 1];
+        assistant->run([bp, &cancel, &G, n_ref, side_ref] {
+            SpecWalker &b = *bp; Walker &W = *b.W; WalkRun &R = *b.R;
+            try {
+                W.spec = true;                              // (looks anywhere during the warm-up)
+                R.cancel = &cancel; R.st.cp = b.w0; R.keep = false; R.log = &b.log; R.log_main = 0; R.log_side = G.n_pos;
+                R.go(b.c);                                  // warm-up: decides records, keeps none; every mark is logged
+                b.at_c = R.st; b.n_warm = b.log.size();
+                // What the warm-up marked behind the reference (appended positions) is forgotten: this walker does not know what the sequential
+                // walk has visited there, so it must not find anything visited there that it marked itself — it finds those nodes unvisited, at
+                // most, and gives up when a walk leads to them.  (Its marks in front of c are never looked at again: whatever leads there makes it give up.)
+                for (const auto &r : b.log) for (agx_u32 v = r.first; v <= r.second; v++) if (v < G.n_pos ? v >= n_ref : v >= side_ref) W.m[v] &= (agx_u8)~AGX_WM_VISITED;
+                R.keep = true; R.st.seqID = 0;
+                if (b.c_next < n_ref) { R.log_main = b.c_next; R.log_side = b.side_next; } else R.log = nullptr;      // (the next walker is checked against what reaches its stretch)
+                W.look_lo = b.c; W.look_hi = n_ref;
+                if (const char *e = getenv("AGX_WALK_SPLIT_LOOK")) { const unsigned long long hi = (unsigned long long)b.c + strtoull(e, nullptr, 10); if (hi < n_ref) W.look_hi = (agx_u32)hi; }      // test hook: a narrow view makes the walker give up
+                if (!W.invalid && !cancel.load()) R.go(b.c_next);
+                b.ok = !W.invalid && !cancel.load() && R.st.cp >= b.c_next;
+            } catch (const Error &e) { b.error = e.msg; } catch (const std::exception &e) { b.error = e.what(); }
+        }, i - 1);
+    }
+
     const double tw0 = clock();
-    // A: the sequential walk up to c, its marks at and behind c logged
+    // A: the sequential walk up to the first meeting point, its marks at and behind it logged
     MarkLog log_a;
     WalkRun A(WA, arena, written, nullptr);
-    A.log = &log_a; A.log_main = c; A.log_side = side_c;
-    A.go(c);
+    A.log = &log_a; A.log_main = B[0].c; A.log_side = B[0].side_c;
+    A.go(B[0].c);
     A.log = nullptr;
-    const size_t a_first = A.jobs.size();               // A's records in front of c
+    const size_t a_first = A.jobs.size();               // A's records in front of the first meeting point
     const double tw1 = clock();
-    join.now();
-    const double tw2 = clock();                                         // (B is done with its half, or gave up)
-    bool same = b_ok && b_error.empty() && A.st.same_scan(at_c_b);
-    if (same) {
-        MarkLog ma, mb;
-        clip_marks(log_a, c, n_ref, G.n_pos, side_c, side_ref, ma); clip_marks(log_b, c, n_ref, G.n_pos, side_c, side_ref, mb);
-        same = ma == mb;
+    // the walkers' stretches, one after the other: each stands if the walker arrived at its c in the state the sequential walk is in there
+    const MarkLog *truth = &log_a; WalkState at = A.st; int stood = 0; MarkLog ma, mb;
+    for (int i = 1; i < K; i++) {
+        SpecWalker &b = B[(size_t)i - 1];
+        join.now(i - 1);
+        bool same = b.ok && b.error.empty() && at.same_scan(b.at_c);
+        if (same) {
+            MarkLog warm_marks(b.log.begin(), b.log.begin() + (long)b.n_warm);
+            clip_marks(*truth, b.c, n_ref, G.n_pos, b.side_c, side_ref, ma); clip_marks(warm_marks, b.c, n_ref, G.n_pos, b.side_c, side_ref, mb);
+            same = ma == mb;
+        }
+        if (timing) {
+            if (same) fprintf(stderr, "[agx walk] walker %d of %d, [%u, %u) after a warm-up from %u: its stretch stands\n", i + 1, K, b.c, b.c_next, b.w0);
+            else if (!b.error.empty()) fprintf(stderr, "[agx walk] walker %d of %d failed (%s): walked on by the first walker from %u\n", i + 1, K, b.error.c_str(), b.c);
+            else if (b.W->invalid) fprintf(stderr, "[agx walk] walker %d of %d gave up (a walk led to position %u, outside [%u, %u)): walked on by the first walker from %u\n", i + 1, K, b.W->gave_up_at, b.c, n_ref, b.c);
+            else fprintf(stderr, "[agx walk] walker %d of %d, [%u, %u) after a warm-up from %u: states differ at the meeting point (scan at %u / %u, last record %u..%u / %u..%u, %zu / %zu mark ranges): walked on by the first walker\n",
+                         i + 1, K, b.c, b.c_next, b.w0, at.cp, b.at_c.cp, at.sOffBak, at.eOffBak, b.at_c.sOffBak, b.at_c.eOffBak, ma.size(), mb.size());
+        }
+        if (!same) break;
+        // its stretch is the sequential walk's: the state where it ends is the sequential walk's there, and so is every mark that reaches further
+        const agx_u32 shift = at.seqID;
+        for (PreJob &j : b.R->jobs) j.f[0] += shift;
+        at = b.R->st; at.seqID = shift + b.R->st.seqID;
+        truth = &b.log; stood = i;
     }
-    const bool timing = getenv("AGX_WALK_TIMING") != nullptr;
-    if (timing && !same && b_ok) {                      // what differs where the walkers meet
-        MarkLog ma, mb;
-        clip_marks(log_a, c, n_ref, G.n_pos, side_c, side_ref, ma); clip_marks(log_b, c, n_ref, G.n_pos, side_c, side_ref, mb);
-        size_t d = 0; while (d < ma.size() && d < mb.size() && ma[d] == mb[d]) d++;
-        fprintf(stderr, "[agx walk] meeting at %u: first walker stands at %u, last record %u..%u; second at %u, last record %u..%u; marks behind the meeting point: %zu vs %zu ranges",
-                c, A.st.cp, A.st.sOffBak, A.st.eOffBak, at_c_b.cp, at_c_b.sOffBak, at_c_b.eOffBak, ma.size(), mb.size());
-        if (d < ma.size()) fprintf(stderr, ", first walker's range %zu = [%u, %u]", d, ma[d].first, ma[d].second);
-        if (d < mb.size()) fprintf(stderr, ", second's = [%u, %u]", mb[d].first, mb[d].second);
-        fprintf(stderr, "\n");
-    }
-    if (same) {
-        // B's half is the sequential walk's: its records behind A's, numbered on; its marks into A's bytes (the appended positions are walked on those)
-        const agx_u32 shift = A.st.seqID;
-        for (PreJob &j : B.jobs) j.f[0] += shift;
-        for (Rec &r : recs_b) written.push_back(std::move(r));
+    cancel.store(true);                                 // (walkers behind one that does not stand walk for nothing)
+    for (int i = stood; i < K - 1; i++) join.now(i);
+    const double tw2 = clock();
+    // what stands: the records behind A's, numbered on; the marks into A's bytes (the appended positions — and whatever did not stand — are walked on those)
+    for (int i = 1; i <= stood; i++) {
+        SpecWalker &b = B[(size_t)i - 1];
+        for (Rec &r : b.recs) written.push_back(std::move(r));
+        const agx_u8 *src = b.W->m;
         auto merge = [&](agx_u32 lo, agx_u32 hi) {
-            agx_u32 i = lo;
-            for (; i < hi && (i & 7u); i++) WA.m[i] |= (agx_u8)(WB.m[i] & AGX_WM_VISITED);
-            for (; i + 8 <= hi; i += 8) { uint64_t a, b; memcpy(&a, WA.m + i, 8); memcpy(&b, WB.m + i, 8); a |= b & 0x8080808080808080ull; memcpy(WA.m + i, &a, 8); }
-            for (; i < hi; i++) WA.m[i] |= (agx_u8)(WB.m[i] & AGX_WM_VISITED);
+            agx_u32 v = lo;
+            for (; v < hi && (v & 7u); v++) WA.m[v] |= (agx_u8)(src[v] & AGX_WM_VISITED);
+            for (; v + 8 <= hi; v += 8) { uint64_t x, y; memcpy(&x, WA.m + v, 8); memcpy(&y, src + v, 8); x |= y & 0x8080808080808080ull; memcpy(WA.m + v, &x, 8); }
+            for (; v < hi; v++) WA.m[v] |= (agx_u8)(src[v] & AGX_WM_VISITED);
         };
-        merge(c, n_ref); merge(side_c, side_ref);
-        A.st = B.st; A.st.seqID = shift + B.st.seqID; WA.n_fetched += WB.n_fetched;
-        A.n_walks += B.n_walks; A.n_hops += B.n_hops; A.n_runs += B.n_runs; A.n_general += B.n_general; A.run_nodes += B.run_nodes;
+        // (what a walker marked behind its own stretch is in the next walker's bytes as well — that is what was compared — unless this is the last one that stands)
+        if (i < stood) { merge(b.c, b.c_next); merge(b.side_c, b.side_next); } else { merge(b.c, n_ref); merge(b.side_c, side_ref); }
+        WA.n_fetched += b.W->n_fetched;
+        A.n_walks += b.R->n_walks; A.n_hops += b.R->n_hops; A.n_runs += b.R->n_runs; A.n_general += b.R->n_general; A.run_nodes += b.R->run_nodes;
     }
-    if (timing) {
-        if (same) fprintf(stderr, "[agx walk] split at %u (warm-up from %u): the second walker's half stands\n", c, w0);
-        else if (!b_error.empty()) fprintf(stderr, "[agx walk] split at %u: the second walker failed (%s): walked on by the first walker\n", c, b_error.c_str());
-        else if (WB.invalid) fprintf(stderr, "[agx walk] split at %u: the second walker gave up (a walk led to position %u, outside [%u, %u)): walked on by the first walker\n", c, WB.gave_up_at, c, n_ref);
-        else fprintf(stderr, "[agx walk] split at %u (warm-up from %u): states differ at the meeting point: walked on by the first walker\n", c, w0);
-    }
+    if (stood) A.st = at;
     const double tw3 = clock();
-    A.go(G.n_pos);                                      // the appended positions — or everything from c on, if B's half does not stand
+    A.go(G.n_pos);                                      // the appended positions — and everything from the first stretch that did not stand
     const double tw4 = clock();
-    // the pre-extended output: every record's place is known now, so the assistant formats the first half while this thread formats the second
-    std::vector<PreJob> all; all.reserve(A.jobs.size() + (same ? B.jobs.size() : 0));
-    all.insert(all.end(), A.jobs.begin(), A.jobs.begin() + (long)a_first);      // A's in front of c, B's half, A's behind it
-    if (same) all.insert(all.end(), B.jobs.begin(), B.jobs.end());
+    // the pre-extended output: every record's place is known now, so the helpers format their shares while this thread formats the last one
+    std::vector<PreJob> all;
+    all.insert(all.end(), A.jobs.begin(), A.jobs.begin() + (long)a_first);      // A's in front of the first meeting point, the stretches that stand, A's behind them
+    for (int i = 1; i <= stood; i++) all.insert(all.end(), B[(size_t)i - 1].R->jobs.begin(), B[(size_t)i - 1].R->jobs.end());
     all.insert(all.end(), A.jobs.begin() + (long)a_first, A.jobs.end());
-    std::vector<size_t> at(all.size() + 1, 0);
+    std::vector<size_t> place(all.size() + 1, 0);
     auto header_len = [](const PreJob &j) { size_t n = 1 + 9 * 2 + 2; for (int i = 0; i < 10; i++) { agx_u32 v = j.f[i]; do { n++; v /= 10u; } while (v); } return n; };
-    for (size_t i = 0; i < all.size(); i++) at[i + 1] = at[i] + header_len(all[i]) + all[i].total + (all[i].total + 59) / 60;
-    const size_t total = at[all.size()];
+    for (size_t i = 0; i < all.size(); i++) place[i + 1] = place[i] + header_len(all[i]) + all[i].total + (all[i].total + 59) / 60;
+    const size_t total = place[all.size()];
     pre_out.n = 0; char *base = pre_out.grow(total);
     auto format = [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; i++) {
             const PreJob &j = all[i];
-            char *h = base + at[i]; *h++ = '>';
+            char *h = base + place[i]; *h++ = '>';
             for (int f = 0; f < 10; f++) { h = put_u32(h, j.f[f]); if (f < 9) { *h++ = ','; *h++ = ' '; } }
             *h++ = ' '; *h++ = '\n';
             LineWriter lw(h); for (size_t g = 0; g < j.n_segs; g++) lw.put(j.segs[g].p, j.segs[g].n); lw.end();
         }
     };
-    size_t mid = 0; while (mid < all.size() && at[mid] < total / 2) mid++;
-    if (mid > 0 && total > (1u << 16)) {
-        assistant->run([&] { format(0, mid); });
-        struct Wait { Assistant *a; ~Wait() { a->wait(); } } wait{assistant};
-        format(mid, all.size());
-    } else format(0, all.size());
-    if (timing) fprintf(stderr, "[agx walk] two walkers: first half %.1f ms, waited %.1f ms for the second, compare + merge %.1f ms, rest %.1f ms, formatting %.1f ms\n", tw1 - tw0, tw2 - tw1, tw3 - tw2, tw4 - tw3, clock() - tw4);
+    {
+        const int shares = total > (1u << 16) ? K : 1;
+        std::vector<size_t> cut((size_t)shares + 1, all.size()); cut[0] = 0;
+        for (int t = 1; t < shares; t++) { size_t m = cut[(size_t)t - 1]; while (m < all.size() && place[m] < total / (unsigned)shares * (unsigned)t) m++; cut[(size_t)t] = m; }
+        struct Wait { Assistant *a; int n; ~Wait() { for (int i = 0; i < n; i++) a->wait(i); } } wait{assistant, shares - 1};
+        for (int t = 0; t + 1 < shares; t++) { const size_t lo = cut[(size_t)t], hi = cut[(size_t)t + 1]; assistant->run([&format, lo, hi] { format(lo, hi); }, t); }
+        format(cut[(size_t)shares - 1], all.size());
+    }
+    if (timing) fprintf(stderr, "[agx walk] %d walkers, %d stretches stood: first stretch %.1f ms, waited %.1f ms for the others, merge %.1f ms, rest %.1f ms, formatting %.1f ms\n", K, stood, tw1 - tw0, tw2 - tw1, tw3 - tw2, tw4 - tw3, clock() - tw4);
     walk_report(A);
     return true;
 }
@@ -826,10 +860,11 @@ void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out, 
     const double ts = now();
     Walker W(V, G);
     std::pmr::monotonic_buffer_resource arena((size_t)8 << 20);      // byte-range lists and trailing k-mers of the written records
-    std::pmr::monotonic_buffer_resource arena2((size_t)1 << 20);     // the second walker's (walk_split): an arena serves one thread
+    std::pmr::monotonic_buffer_resource arena2((size_t)1 << 20), arena3((size_t)1 << 20), arena4((size_t)1 << 20);     // the other walkers' (walk_split): an arena serves one thread
+    Arena *const more_arenas[3] = {&arena2, &arena3, &arena4};
     std::vector<Rec> recs; recs.reserve((size_t)G.n_pos / 1024 + 1024);
     double t0 = now();
-    if (!walk_split(W, V, G, out.pre_extended, recs, &arena, &arena2, assistant)) walk(W, out.pre_extended, recs, &arena, assistant);
+    if (!walk_split(W, V, G, out.pre_extended, recs, &arena, more_arenas, assistant)) walk(W, out.pre_extended, recs, &arena, assistant);
     double t1 = now();
     join(recs);
     double t2 = now();

@@ -259,19 +259,20 @@ def test_empty_and_ragged_inputs(agx, built, tmp_path):
     assert b["graph"]["n_nodes"] == 0
 
 
-def test_walk_by_two_walkers_gives_the_same_bytes(agx, built, tmp_path, monkeypatch):
-    """Large units are walked by two walkers (agx_walk.cpp: walk_split): forced here on a small unit, with a warm-up stretch that lets the
-    second walker's half stand and with one so short that the first walker has to walk on — the oracle's bytes either way."""
+def test_walk_by_several_walkers_gives_the_same_bytes(agx, built, tmp_path, monkeypatch):
+    """Large units are walked by two to four walkers (agx_walk.cpp: walk_split): forced here on a small unit, with warm-up stretches that let the
+    other walkers' stretches stand and with some so short that the first walker has to walk on — the oracle's bytes either way."""
     run = H.synth(str(tmp_path / "run"), seed=77, chroms="400000", pairs=80000, coverage=4, read_indel=0.2, multi=0.2, contig_overlap=0.3, sam_seq=0)
     tmp = os.path.join(run, "tmp")
     want = H.run_oracle(tmp, 0, 5, 50, 4)
     monkeypatch.setenv("AGX_WALK_SPLIT_MIN", "0")
-    for warm in ("400000", "50000", "20"):
+    for walkers, warm in (("2", "400000"), ("2", "50000"), ("2", "20"), ("3", "50000"), ("4", "400000"), ("4", "30000")):
+        monkeypatch.setenv("AGX_WALK_SPLIT_WALKERS", walkers)
         monkeypatch.setenv("AGX_WALK_SPLIT_WARMUP", warm)
         for flags in (0, agx.AGX_FLAG_ONE_SHOT):
             got = run_engine(agx, tmp, 0, 5, 50, 4, flags=flags)
             for key in ("initial", "pre", "extended"):
-                assert got[key] == want[key], (warm, flags, key)
+                assert got[key] == want[key], (walkers, warm, flags, key)
 
 
 def test_unit_cache_file_replaces_the_text(agx, built, tmp_path, monkeypatch):

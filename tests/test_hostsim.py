@@ -68,7 +68,7 @@ def test_sparse_record_table_and_fetch_hook(built, tmp_path, monkeypatch):
 
 
 @pytest.mark.parametrize("warm", ["1000000", "30000", "2000", "0"])
-def test_walk_by_two_walkers_is_the_sequential_walk(built, tmp_path, monkeypatch, warm):
+def test_walk_by_several_walkers_is_the_sequential_walk(built, tmp_path, monkeypatch, warm):
     # agx_walk.cpp: walk_split — a second walker starts a warm-up stretch in front of the middle of the unit on its own copy of the visited
     # bytes; where the first walker arrives the two states are compared, and the second half either stands or is walked again.  The
     # oracle's bytes whatever the warm-up is worth (long enough, marginal, far too short, none).
@@ -76,11 +76,15 @@ def test_walk_by_two_walkers_is_the_sequential_walk(built, tmp_path, monkeypatch
     meta = H.read_meta(run)
     tmp = os.path.join(run, "tmp")
     o = H.run_oracle(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
-    for key, val in (("AGX_SIM_ASSISTANT", "1"), ("AGX_SIM_SPLIT", "1"), ("AGX_WALK_SPLIT_MIN", "0"), ("AGX_WALK_SPLIT_WARMUP", warm)):
+    for key, val in (("AGX_SIM_ASSISTANT", "1"), ("AGX_SIM_SPLIT", "3"), ("AGX_WALK_SPLIT_MIN", "0"), ("AGX_WALK_SPLIT_WARMUP", warm)):
         monkeypatch.setenv(key, val)
-    s = sim.run(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
-    for key in ("initial", "pre", "extended"):
-        assert o[key] == s[key], key
+    for walkers, look in (("2", None), ("3", None), ("4", None), ("4", "20000")):      # look: the walkers see 20 kb of their stretch only: they give up
+        monkeypatch.setenv("AGX_WALK_SPLIT_WALKERS", walkers)
+        if look:
+            monkeypatch.setenv("AGX_WALK_SPLIT_LOOK", look)
+        s = sim.run(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
+        for key in ("initial", "pre", "extended"):
+            assert o[key] == s[key], (walkers, look, key)
 
 
 def test_shared_reads_index_loads_the_same_pairs(built, tmp_path, monkeypatch):
