@@ -5,7 +5,8 @@
 // depends on which nodes earlier walks already consumed (AG:2027-2033, 2096-2113), the position scan skips ahead
 // inside long records (AG:2194-2202) and a record is suppressed against the previously WRITTEN one (AG:2176).
 // It therefore runs on the host over the flat node table the kernels produced: prune flags and consensus bases
-// were fused into the node sweep, so the walk touches 1 byte of state per node plus its out-edge slots.
+// were fused into the node sweep, so the walk touches 1 byte of state per node plus its out-edge slots.  Large units are walked by
+// several walkers whose stretches are checked against each other where they meet (walk_split): the result is the sequential walk's.
 #include "agx_host.h"
 
 #include <algorithm>
