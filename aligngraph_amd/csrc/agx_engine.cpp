@@ -125,7 +125,7 @@ struct HsaCopy {
 const HsaCopy &hsa_copy() { static const HsaCopy h; return h; }
 
 // positions from which a unit's host walk is split between two walkers (= walk_split's default in agx_walk.cpp; AGX_WALK_SPLIT_MIN, read at every download, overrides both: tests)
-inline size_t two_walkers_min() { const char *e = getenv("AGX_WALK_SPLIT_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)16000000; }
+inline size_t two_walkers_min() { const char *e = getenv("AGX_WALK_SPLIT_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4000000; }
 #define AGX_TWO_WALKERS_MIN two_walkers_min()
 // walkers for a unit of n_pos positions: one per 15.5 M positions from the threshold on, at most four (walk_split decides the same way from what it is given)
 inline int walkers_wanted(size_t n_pos) { if (n_pos < AGX_TWO_WALKERS_MIN) return 1; const char *e = getenv("AGX_WALK_SPLIT_WALKERS"); int k = e ? atoi(e) : (int)(n_pos / 15500000u); return k < 2 ? 2 : k > 4 ? 4 : k; }

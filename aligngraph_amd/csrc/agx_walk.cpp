@@ -560,7 +560,7 @@ struct SpecWalker {
 
 // false: not split (too small, no copy of the meta bytes, no assistant): the caller walks the usual way
 bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena, Arena *const *more_arenas, Assistant *assistant) {
-    const agx_u32 min_ref = getenv("AGX_WALK_SPLIT_MIN") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_MIN"), nullptr, 10) : 16000000u;
+    const agx_u32 min_ref = getenv("AGX_WALK_SPLIT_MIN") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_MIN"), nullptr, 10) : 4000000u;
     const agx_u32 warm = getenv("AGX_WALK_SPLIT_WARMUP") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_WARMUP"), nullptr, 10) : 400000u;
     const agx_u32 n_ref = V.n_ref < G.n_pos ? V.n_ref : G.n_pos;
     if (!assistant || !G.meta_copy[0] || n_ref < min_ref || n_ref < 16 || getenv("AGX_WALK_NO_SPLIT")) return false;
