@@ -6,13 +6,15 @@ new data): a "step" takes every unit of the configuration from its packed arrays
 host memory — upload (one HBM block per unit, PCIe copies), the unit's FIRST build (all kernels, capacities sized on the spot, a repeat
 if one proves too small), download of the walk graph, the sequential host walk/join/scaffold — with the units pipelined against each other
 on the device exactly as AlignGraph_amd pipelines them (a worker thread per unit in flight, largest unit first).  Every step starts from
-nothing on the device; the library's pinned-host cache is emptied first (--pool host-cold, the default), so every step maps, faults and
-registers its download buffers like the first units of a fresh process do (--pool cold also gives the HBM blocks back to the driver; see
---help for why that is not the default); the units' packed arrays stay staged in host memory between steps, as T_core defines.
+nothing on the device and gets its OWN set of units, loaded from the unit caches before the clock starts and used once, as the application
+uses a unit (AGX_FLAG_ONE_SHOT: the download lands in the pinned memory of the unit's dead staged inputs); --reupload times the same unit
+objects in every step instead, whose downloads then need freshly pinned buffers (the library's pinned-host cache is emptied before every
+step: --pool host-cold, the default; --pool cold also gives the HBM blocks back to the driver; see --help for why that is not the default).
 
     value = 2 * pairs of the configuration / seconds per step            (whole job, all GPUs)
 
-Text parsing of the five per-unit files (T_unit = parse + T_core) is measured once while the inputs are loaded and reported beside it.
+Text parsing of the five per-unit files (T_unit = parse + T_core) is measured once while the inputs are loaded (up to four units side by
+side, as AlignGraph_amd parses them) and reported beside it, and so is loading the units from their binary caches.
 
 Configurations (--config; BASELINE.json `configs`, synthetic data of that shape from tools/agx_synth, seeded):
     cfg3 (default)  A. thaliana shape: 5 units of 30.4 / 19.7 / 23.5 / 18.6 / 27.0 Mb, 20 M 2x100 bp pairs, k=5      <- the north-star 1-GPU target
@@ -104,7 +106,8 @@ def main():
     ap.add_argument("--coverage", type=int, default=5, help="--coverage of the run (the reference's default 20 is above the graph depth of these read sets: SURVEY §8d)")
     ap.add_argument("--pool", default="host-cold", choices=["cold", "host-cold", "warm"],
                     help="what the library's memory caches hold when a step starts.  host-cold (default): the pinned-host cache is emptied before every "
-                         "step, so every step maps, faults and registers its download buffers like the first units of a fresh process; HBM blocks are "
+                         "step, so a step that needs pinned memory (--reupload: its download buffers; one-shot units need none) maps, faults and registers "
+                         "it like the first units of a fresh process; HBM blocks are "
                          "kept (a fresh hipMalloc costs 0.2-0.7 ms per unit, profiles/r02_membench.txt — but HBM that was just given back to the "
                          "driver can stall the next hipMalloc for seconds, profiles/r02_recycle.txt: an artefact of the loop, not of the application).  "
                          "cold: both caches emptied.  warm: both keep what earlier steps left (units 6, 7, .. of a long run)")
