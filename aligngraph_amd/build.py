@@ -8,9 +8,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libagx.so")
 CLI = os.path.join(HERE, "AlignGraph_amd")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
-HOST_SRC = ["agx_engine.cpp", "agx_host.cpp", "agx_walk.cpp"]
+HOST_SRC = ["agx_engine.cpp", "agx_host.cpp", "agx_walk.cpp", "agx_load.cpp"]
 DEV_SRC = ["agx_kernels.hip"]
-HEADERS = ["agx_core.h", "agx_host.h", "agx_kargs.h", os.path.join("..", "..", "include", "agx.h")]
+HEADERS = ["agx_core.h", "agx_host.h", "agx_parse.h", "agx_mem.h", "agx_kargs.h", os.path.join("..", "..", "include", "agx.h")]
 
 
 def _stale(out, deps):

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <mutex>
 #include <system_error>
@@ -203,7 +204,7 @@ struct agx_unit {
     Threads T; Pairs P;                 // what the loaders / the packed-array calls filled (empty when the unit came out of a cache file)
     UnitView V;                         // what everything downstream reads: into T / P, or into the mapped cache file
     struct Mapped { void *p = nullptr; size_t n = 0; void reset() { if (p) munmap(p, n); p = nullptr; n = 0; } ~Mapped() { reset(); } } cache_map;
-    agx_u32 n_seg0 = 0, stride = 0, n_slots = 0; unsigned long long pairs_in_file = 0, sam_pairs = 0;
+    agx_u32 n_seg0 = 0, stride = 0, n_slots = 0, n_rows = 0; unsigned long long pairs_in_file = 0, sam_pairs = 0;
     bool have_ref = false, have_threads = false, staged = false, uploaded = false, built = false, downloaded = false;
     bool consumed = false;             // AGX_FLAG_ONE_SHOT: the download has overwritten the staged inputs
     bool expanded = false;             // the conti-mer tables and vote codes have been made from what was uploaded (opens the unit's first build)
@@ -215,7 +216,11 @@ struct agx_unit {
     // staged inputs: what the device wants of T and P, in pinned memory (stage_inputs)
     PBuf<agx_hit> s_hits; PBuf<agx_run> s_runs; PBuf<agx_u8> s_codes; PBuf<unsigned long long> s_other; size_t n_other = 0; PBuf<char> s_ref; PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
     size_t nh = 0, n_runs = 0, n_cm = 0, n_codes = 0; agx_u32 maxlen = 0;      // n_codes: bytes of packed classes (four bases each); n_other: listed bases that are not A, C, G, T
-    std::vector<agx_u32> row_slot;      // staged read bases: one row per (pair, a mate) that some hit uses; row -> read slot
+    std::vector<agx_u32> row_slot;      // staged read bases: one row per (pair, a mate) that some hit uses; row -> read slot (general loader / agx_unit_push_pairs)
+    std::vector<uint64_t> row_off;      // fast loader: row -> where the read's bases start in the mapped reads file (the bases are never copied: the walk reads the k-mer tails of written records there)
+    std::shared_ptr<agx::ReadsIndex> reads_keep;      // the reads file that row_off points into (shared with the caller's agx_reads, or the unit's own)
+    std::unique_ptr<agx::FileView> reads_map;          // the same for a unit that came out of its cache file: only the mapping, no index
+    bool pairs_staged = false;          // the fast loader has written hits, runs, codes and the list of other bases straight into the staged buffers
     // inputs on the device
     DBuf<agx_u32> d_cm_start, d_cm_cnt; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref; DBuf<agx_cmseg> d_segs; DBuf<unsigned long long> d_up_desc;
     DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<agx_u8> d_codes, d_vcodes; DBuf<unsigned long long> d_other;
@@ -310,69 +315,51 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
 // ---- staging: the packed arrays a unit was handed, in the form and the memory the upload wants -------------------------------------
 // Runs when the arrays are handed over (end of agx_unit_load_files, or agx_unit_stage after the last agx_unit_push_pairs; implied by an
 // upload that finds nothing staged).  The read bases cross PCIe as 2-bit classes plus a list of the few bases that are not A, C, G or T
-// (agx_pack_classes2): a quarter of the bytes of the largest array.
+// (agx_pack_classes2): a quarter of the bytes of the largest array.  The read alignments are staged by stage_pairs() (agx_load.cpp) —
+// or were written into the staged buffers by the fast loader while it parsed (u->pairs_staged).
+struct UnitSink : StageSink {
+    agx_unit *u; explicit UnitSink(agx_unit *x) : u(x) {}
+    void *take(int which, size_t bytes) override {
+        switch (which) {
+        case SA_HITS:  u->s_hits.alloc(bytes / sizeof(agx_hit) + 1); return u->s_hits.p;
+        case SA_RUNS:  u->s_runs.alloc(bytes / sizeof(agx_run) + 1); return u->s_runs.p;
+        case SA_CODES: u->s_codes.alloc(bytes); return u->s_codes.p;
+        default:       u->s_other.alloc(bytes / 8 + 1); return u->s_other.p;
+        }
+    }
+};
+void adopt_pairs(agx_unit *u, StagedPairs &S) {      // the staged read alignments' counts and the host-side row table
+    u->nh = S.nh; u->n_runs = S.n_runs; u->n_codes = S.n_codes; u->n_other = S.n_other; u->stride = S.stride; u->maxlen = S.maxlen;
+    u->pairs_in_file = S.n_pairs_in_file; u->sam_pairs = S.n_sam_pairs;
+    u->row_off.swap(S.row_off); u->row_slot.swap(S.row_slot); u->n_rows = S.n_rows;
+}
 void stage_inputs(agx_unit *u) {
     if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
     const double t0 = now_ms();
     HIP_OK(hipSetDevice(u->prm.device));            // (registering host memory needs a current device)
-    u->V = view_of(u->T, u->P); u->cache_map.reset();
-    u->n_seg0 = u->T.n_seg0; u->stride = u->P.stride; u->n_slots = u->P.n_slots; u->pairs_in_file = u->P.n_pairs_in_file; u->sam_pairs = u->P.n_sam_pairs;
+    u->cache_map.reset(); u->reads_map.reset();
     const size_t n_pos = u->T.ref.size();
     if (n_pos == 0 || n_pos >= 0xFFFFFF00ull) throw Error{E_ARG, "unit sequence is empty or too long"};
-    if (u->T.cm_start.size() != n_pos + 1) throw Error{E_ARG, "contig thread table does not match the position count"};
-    if (u->T.hop.size() != n_pos) throw Error{E_ARG, "conti-mer chains were not built"};
-    { size_t el = 0; for (const agx_cmseg &g : u->T.segs) el += g.len; if (el != u->T.cm.size()) throw Error{E_ARG, "conti-mer runs were not built"}; }
-    u->nh = u->P.hits.size(); u->n_runs = u->P.runs.size(); u->n_cm = u->T.cm.size();
-    u->maxlen = 0; for (const agx_hit &h : u->P.hits) u->maxlen = std::max<agx_u32>(u->maxlen, h.len);
-    if (u->P.stride & 15u) throw Error{E_ARG, "read stride must be a multiple of 16"};
-    u->s_hits.alloc(u->nh + 1); u->s_runs.alloc(u->n_runs + 1);
+    if (u->T.cm_cnt.size() != n_pos) throw Error{E_ARG, "conti-mer chains were not built"};
+    { size_t el = 0; for (const agx_cmseg &g : u->T.segs) el += g.len; if (el != u->T.n_cm) throw Error{E_ARG, "conti-mer runs were not built"}; }
+    u->n_seg0 = u->T.n_seg0; u->n_cm = u->T.n_cm;
     u->s_ref.alloc(n_pos); u->n_segs = u->T.segs.size(); u->s_segs.alloc(u->n_segs + 1);
     if (u->n_segs) memcpy(u->s_segs.p, u->T.segs.data(), u->n_segs * sizeof(agx_cmseg));
     std::vector<agx_u32> ce(u->T.chain_end_pos); std::sort(ce.begin(), ce.end()); ce.erase(std::unique(ce.begin(), ce.end()), ce.end());      // positions where a conti-mer chain
     u->n_chain_end = (agx_u32)ce.size(); u->s_chain_end.alloc(ce.size() + 1);                                                                 // ends: their main walk ids are special
     if (!ce.empty()) memcpy(u->s_chain_end.p, ce.data(), ce.size() * 4);
-    const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), (u->P.bases.size() + n_pos) / (8u << 20) + 1);
-    // Hits: as they are, except that slot1 becomes the ROW of the a mate's bases and pad[0] says which mate that is (agx_hit_left_is_mate2).
-    // Only the a mate's bases are read by the build (the right mate only supplies positions, AG:1644): one row per (pair, a mate), first come.
-    const agx_run *runs = u->P.runs.data(); const agx_u32 k = u->prm.k;
-    on_threads(threads, [&](unsigned t) {
-        for (size_t i = u->nh * t / threads, hi = u->nh * (t + 1) / threads; i < hi; i++) {
-            agx_hit h = u->P.hits[i];
-            h.pad[0] = agx_hit_left_is_mate2(h, runs, k) ? 1 : 0; h.pad[1] = h.pad[2] = 0;
-            u->s_hits.p[i] = h;
-        }
-        size_t lo, hi;
-        lo = u->n_runs * t / threads; hi = u->n_runs * (t + 1) / threads; if (hi > lo) memcpy(u->s_runs.p + lo, runs + lo, (hi - lo) * sizeof(agx_run));
-        lo = n_pos * t / threads; hi = n_pos * (t + 1) / threads; memcpy(u->s_ref.p + lo, u->T.ref.data() + lo, hi - lo);
-    });
-    std::vector<agx_u16> row_len;                       // read length of every row: bases beyond it are never looked at
-    {
-        std::vector<agx_u32> row_of((size_t)u->P.n_slots + 1, AGX_NONE);
-        u->row_slot.clear(); u->row_slot.reserve(u->P.n_slots / 2 + 16); row_len.reserve(u->P.n_slots / 2 + 16);
-        for (size_t i = 0; i < u->nh; i++) {
-            agx_hit &h = u->s_hits.p[i];
-            const agx_u32 sa = h.slot1 + (h.pad[0] & 1u);
-            if (sa >= u->P.n_slots) throw Error{E_ARG, "hit names a read slot outside the unit"};
-            if (row_of[sa] == AGX_NONE) { row_of[sa] = (agx_u32)u->row_slot.size(); u->row_slot.push_back(sa); row_len.push_back(h.len); }
-            else if (row_len[row_of[sa]] < h.len) row_len[row_of[sa]] = h.len;
-            h.slot1 = row_of[sa];
-        }
+    const unsigned threads = loader_threads(u->P.bases.size() + n_pos + u->nh * 64);
+    on_threads(std::min(threads, 8u), [&](unsigned t) { const unsigned T = std::min(threads, 8u); const size_t lo = n_pos * t / T, hi = n_pos * (t + 1) / T; memcpy(u->s_ref.p + lo, u->T.ref.data() + lo, hi - lo); });
+    if (!u->pairs_staged) {
+        UnitSink sink(u); StagedPairs S;
+        u->n_slots = u->P.n_slots;
+        stage_pairs(u->P, u->prm.k, threads, sink, S);
+        adopt_pairs(u, S);
     }
-    const size_t quarter = u->P.stride / 4, n_rows = u->row_slot.size();
-    u->n_codes = n_rows * quarter;
-    u->s_codes.alloc(u->n_codes + 16);
-    const char *bases = u->P.bases.data(); agx_u8 *codes = u->s_codes.p;
-    std::vector<std::vector<unsigned long long>> other(threads);
-    on_threads(threads, [&](unsigned t) {
-        for (size_t r = n_rows * t / threads, hi = n_rows * (t + 1) / threads; r < hi; r++) {
-            const char *src = bases + (size_t)u->row_slot[r] * u->P.stride; agx_u8 *dst = codes + r * quarter;
-            for (size_t j = 0; j < quarter; j++) dst[j] = agx_pack_classes2((agx_u8)src[4 * j], (agx_u8)src[4 * j + 1], (agx_u8)src[4 * j + 2], (agx_u8)src[4 * j + 3]);
-            for (size_t j = 0, n = std::min<size_t>(row_len[r], u->P.stride); j < n; j++) if (agx_base_class((agx_u8)src[j]) == 4u) other[t].push_back((unsigned long long)r * u->P.stride + j);
-        }
-    });
-    u->n_other = 0; for (const auto &o : other) u->n_other += o.size();
-    u->s_other.alloc(u->n_other + 1);
-    { size_t at = 0; for (const auto &o : other) { if (!o.empty()) memcpy(u->s_other.p + at, o.data(), o.size() * 8); at += o.size(); } }      // (threads take ascending row ranges: the list is sorted)
+    UnitView V = view_of(u->T, u->P);
+    V.ref = u->s_ref.p;                                 // (the staged copy: one-shot downloads never land in it)
+    if (u->pairs_staged) { V.bases = u->reads_keep ? u->reads_keep->fv.p : nullptr; V.stride = u->stride; V.row_off = u->row_off.data(); }
+    u->V = V;
     u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0;
 }
@@ -384,14 +371,17 @@ void stage_inputs(agx_unit *u) {
 // mapped and paged in where it is touched.  Valid for one BATCH size, one k and for exactly the five text files it was made from (size and
 // modification time of each are in the header): anything else and the loader falls back to the text.
 namespace cache {
-enum { S_HITS = 0, S_RUNS, S_CODES, S_SEGS, S_CHAIN_END, S_ROW_SLOT, S_REF, S_CM_START, S_CHAIN_STR, S_INITIAL, S_BASES, S_OTHER, S_N };
+enum { S_HITS = 0, S_RUNS, S_CODES, S_SEGS, S_CHAIN_END, S_ROWS, S_REF, S_CM_CNT, S_CHAIN_STR, S_INITIAL, S_BASES, S_OTHER, S_N };
 struct Header {
     char magic[8]; agx_u32 version, batch; unsigned long long stamp[5][2];
     unsigned long long n_pos, n_ref, nh, n_runs, n_cm, n_segs, n_seg0, n_rows, n_chain_end, n_codes, pairs_in_file, sam_pairs;
     agx_u32 stride, maxlen, n_slots, k;          // k: the staged hits name their left mate, which depends on it (agx_hit_left_is_mate2)
+    agx_u32 rows_in_reads;                       // 1: S_ROWS holds 64-bit offsets into tmp/_reads.fa (whose size and time are part of the stamp), S_BASES is empty; 0: S_ROWS holds the
+                                                 // read slot of every row and S_BASES the slots' bases (units that the general loader parsed)
+    agx_u32 sizes[4];                            // sizeof agx_hit, agx_run, agx_cmseg, Header: a file written by another layout is not this one
     unsigned long long off[S_N], len[S_N];
 };
-const char MAGIC[8] = {'A', 'G', 'X', 'U', 'N', 'I', 'T', '3'};
+const char MAGIC[8] = {'A', 'G', 'X', 'U', 'N', 'I', 'T', '4'};
 void stamps(const std::string &d, int unit, unsigned long long st[5][2]) {
     const std::string s = std::to_string(unit);
     const std::string f[5] = {d + "/_genome." + s + ".fa", d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie"};
@@ -404,22 +394,37 @@ std::string path_of(const std::string &d, int unit) { return d + "/_agx_unit." +
 void save_cache(agx_unit *u, const std::string &dir, int unit) {
     using namespace cache;
     if (!u->staged || u->cache_map.p) throw Error{E_ARG, "nothing staged from text"};
-    Header H; memset(&H, 0, sizeof H); memcpy(H.magic, MAGIC, 8); H.version = 1; H.batch = u->prm.batch;
+    Header H; memset(&H, 0, sizeof H); memcpy(H.magic, MAGIC, 8); H.version = 2; H.batch = u->prm.batch;
     stamps(dir, unit, H.stamp);
-    H.n_pos = u->V.n_pos; H.n_ref = u->V.n_ref; H.nh = u->nh; H.n_runs = u->n_runs; H.n_cm = u->n_cm; H.n_segs = u->n_segs; H.n_seg0 = u->n_seg0; H.n_rows = u->row_slot.size();
+    const bool in_reads = u->pairs_staged;
+    H.n_pos = u->V.n_pos; H.n_ref = u->V.n_ref; H.nh = u->nh; H.n_runs = u->n_runs; H.n_cm = u->n_cm; H.n_segs = u->n_segs; H.n_seg0 = u->n_seg0; H.n_rows = u->n_rows;
     H.n_chain_end = u->n_chain_end; H.n_codes = u->n_codes; H.pairs_in_file = u->pairs_in_file; H.sam_pairs = u->sam_pairs; H.stride = u->stride; H.maxlen = u->maxlen; H.n_slots = u->n_slots; H.k = u->prm.k;
-    const void *ptr[S_N] = {u->s_hits.p, u->s_runs.p, u->s_codes.p, u->s_segs.p, u->s_chain_end.p, u->row_slot.data(), u->V.ref, u->V.cm_start, u->V.chain_str, u->V.initial, u->V.bases, u->s_other.p};
-    const unsigned long long len[S_N] = {u->nh * sizeof(agx_hit), u->n_runs * sizeof(agx_run), u->n_codes, u->n_segs * sizeof(agx_cmseg), (unsigned long long)u->n_chain_end * 4, u->row_slot.size() * 4,
-                                         u->V.n_pos, (u->V.n_pos + 1) * 4, u->T.chain_str.size(), u->V.n_initial, (unsigned long long)u->n_slots * u->stride, (unsigned long long)u->n_other * 8};
+    H.rows_in_reads = in_reads ? 1u : 0u; H.sizes[0] = sizeof(agx_hit); H.sizes[1] = sizeof(agx_run); H.sizes[2] = sizeof(agx_cmseg); H.sizes[3] = sizeof(Header);
+    const void *ptr[S_N] = {u->s_hits.p, u->s_runs.p, u->s_codes.p, u->s_segs.p, u->s_chain_end.p, in_reads ? (const void *)u->row_off.data() : (const void *)u->row_slot.data(), u->V.ref, u->V.cm_cnt,
+                            u->V.chain_str, u->V.initial, in_reads ? nullptr : u->V.bases, u->s_other.p};
+    const unsigned long long len[S_N] = {u->nh * sizeof(agx_hit), u->n_runs * sizeof(agx_run), u->n_codes, u->n_segs * sizeof(agx_cmseg), (unsigned long long)u->n_chain_end * 4, (unsigned long long)u->n_rows * (in_reads ? 8 : 4),
+                                         u->V.n_pos, u->V.n_pos, u->T.chain_str.size(), u->V.n_initial, in_reads ? 0ull : (unsigned long long)u->n_slots * u->stride, (unsigned long long)u->n_other * 8};
     unsigned long long at = (sizeof(Header) + 4095) & ~4095ull;
     for (int i = 0; i < S_N; i++) { H.off[i] = at; H.len[i] = len[i]; at = (at + len[i] + 4095) & ~4095ull; }
     const std::string path = path_of(dir, unit), part = path + ".part";
-    FILE *f = fopen(part.c_str(), "wb");
-    if (!f) throw Error{E_IO, "CANNOT OPEN FILE! (" + part + ")"};
-    bool ok = fwrite(&H, sizeof H, 1, f) == 1;
-    for (int i = 0; i < S_N && ok; i++) ok = fseek(f, (long)H.off[i], SEEK_SET) == 0 && (len[i] == 0 || fwrite(ptr[i], 1, len[i], f) == len[i]);
-    ok = ok && fflush(f) == 0 && ftruncate(fileno(f), (off_t)at) == 0;
-    ok = (fclose(f) == 0) && ok;
+    const int fd = open(part.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) throw Error{E_IO, "CANNOT OPEN FILE! (" + part + ")"};
+    bool ok = ftruncate(fd, (off_t)at) == 0 && pwrite(fd, &H, sizeof H, 0) == (ssize_t)sizeof H;
+    if (ok) {      // the sections, large pieces on a few threads
+        struct Piece { const char *src; unsigned long long off, len; };
+        std::vector<Piece> pieces;
+        for (int i = 0; i < S_N; i++) for (unsigned long long a = 0; a < len[i]; a += 32ull << 20) pieces.push_back(Piece{(const char *)ptr[i] + a, H.off[i] + a, std::min<unsigned long long>(32ull << 20, len[i] - a)});
+        const unsigned threads = (unsigned)std::min<size_t>(8, pieces.size() ? pieces.size() : 1);
+        std::vector<int> bad(threads, 0);
+        on_threads(threads, [&](unsigned t) {
+            for (size_t i = t; i < pieces.size(); i += threads) {
+                size_t done = 0;
+                while (done < pieces[i].len) { const ssize_t w = pwrite(fd, pieces[i].src + done, pieces[i].len - done, (off_t)(pieces[i].off + done)); if (w <= 0) { bad[t] = 1; return; } done += (size_t)w; }
+            }
+        });
+        for (int b : bad) ok = ok && !b;
+    }
+    ok = (close(fd) == 0) && ok;
     if (!ok || rename(part.c_str(), path.c_str()) != 0) { (void)remove(part.c_str()); throw Error{E_IO, "cannot write " + path}; }
 }
 
@@ -434,20 +439,25 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     Header H; struct stat sb;
     if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof H || pread(fd, &H, sizeof H, 0) != (ssize_t)sizeof H) return false;
     unsigned long long st[5][2]; stamps(dir, unit, st);
-    if (memcmp(H.magic, MAGIC, 8) != 0 || H.version != 1 || H.batch != u->prm.batch || H.k != u->prm.k || memcmp(st, H.stamp, sizeof st) != 0) return false;
-    for (int i = 0; i < S_N; i++) if (H.off[i] + H.len[i] > (unsigned long long)sb.st_size) return false;
-    if (H.n_pos == 0 || H.n_pos >= 0xFFFFFF00ull || H.len[S_REF] != H.n_pos || H.len[S_CM_START] != (H.n_pos + 1) * 4 || H.len[S_HITS] != H.nh * sizeof(agx_hit) || H.len[S_RUNS] != H.n_runs * sizeof(agx_run) ||
-        H.len[S_CODES] != H.n_codes || H.len[S_SEGS] != H.n_segs * sizeof(agx_cmseg) || H.len[S_ROW_SLOT] != H.n_rows * 4 || H.len[S_BASES] != (unsigned long long)H.n_slots * H.stride || (H.stride & 15u) ||
-        H.len[S_CHAIN_END] != H.n_chain_end * 4 || H.n_codes != H.n_rows * (H.stride / 4) || (H.len[S_OTHER] & 7u)) return false;
+    if (memcmp(H.magic, MAGIC, 8) != 0 || H.version != 2 || H.batch != u->prm.batch || H.k != u->prm.k || memcmp(st, H.stamp, sizeof st) != 0) return false;
+    if (H.sizes[0] != sizeof(agx_hit) || H.sizes[1] != sizeof(agx_run) || H.sizes[2] != sizeof(agx_cmseg) || H.sizes[3] != sizeof(Header)) return false;
+    for (int i = 0; i < S_N; i++) if (H.off[i] > (unsigned long long)sb.st_size || H.len[i] > (unsigned long long)sb.st_size - H.off[i]) return false;
+    const bool in_reads = H.rows_in_reads == 1;
+    if (H.n_pos == 0 || H.n_pos >= 0xFFFFFF00ull || H.n_ref > H.n_pos || H.len[S_REF] != H.n_pos || H.len[S_CM_CNT] != H.n_pos || H.len[S_HITS] != H.nh * sizeof(agx_hit) || H.len[S_RUNS] != H.n_runs * sizeof(agx_run) ||
+        H.len[S_CODES] != H.n_codes || H.len[S_SEGS] != H.n_segs * sizeof(agx_cmseg) || H.n_seg0 > H.n_segs || H.len[S_ROWS] != H.n_rows * (in_reads ? 8 : 4) || (H.stride & 15u) ||
+        H.len[S_BASES] != (in_reads ? 0ull : (unsigned long long)H.n_slots * H.stride) || H.len[S_CHAIN_END] != H.n_chain_end * 4 || H.n_codes != H.n_rows * (H.stride / 4) || (H.len[S_OTHER] & 7u) ||
+        H.nh >= 0xFFFFFFFFull || H.n_runs >= 0xFFFFFFFFull || H.n_rows >= 0x7FFFFFFFull || H.maxlen > H.stride) return false;
     HIP_OK(hipSetDevice(u->prm.device));
     const double t0 = now_ms();
+    std::unique_ptr<FileView> reads_map;
+    if (in_reads) { try { reads_map.reset(new FileView(dir + "/_reads.fa")); } catch (const Error &) { return false; } if (reads_map->n != st[3][0]) return false; }
     void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (m == MAP_FAILED) return false;
     drop_outputs(u);
-    u->T = Threads(); u->P = Pairs(); u->cache_map.reset(); u->cache_map.p = m; u->cache_map.n = (size_t)sb.st_size;
+    u->T = Threads(); u->P = Pairs(); u->cache_map.reset(); u->cache_map.p = m; u->cache_map.n = (size_t)sb.st_size; u->reads_keep.reset(); u->reads_map.reset();
     const char *base = (const char *)m;
     u->nh = H.nh; u->n_runs = H.n_runs; u->n_cm = H.n_cm; u->n_segs = H.n_segs; u->n_seg0 = (agx_u32)H.n_seg0; u->n_chain_end = (agx_u32)H.n_chain_end; u->n_codes = H.n_codes; u->n_other = H.len[S_OTHER] / 8;
-    u->pairs_in_file = H.pairs_in_file; u->sam_pairs = H.sam_pairs; u->stride = H.stride; u->maxlen = H.maxlen; u->n_slots = H.n_slots;
+    u->pairs_in_file = H.pairs_in_file; u->sam_pairs = H.sam_pairs; u->stride = H.stride; u->maxlen = H.maxlen; u->n_slots = H.n_slots; u->n_rows = (agx_u32)H.n_rows;
     u->s_hits.alloc(u->nh + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16); u->s_other.alloc(u->n_other + 1); u->s_segs.alloc(u->n_segs + 1); u->s_chain_end.alloc((size_t)u->n_chain_end + 1); u->s_ref.alloc(H.n_pos);
     // the staged arrays: read into the pinned buffers, a few threads, large pieces
     struct Piece { void *dst; unsigned long long off, len; };
@@ -462,12 +472,34 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
             while (done < pieces[i].len) { const ssize_t r = pread(fd, (char *)pieces[i].dst + done, pieces[i].len - done, (off_t)(pieces[i].off + done)); if (r <= 0) { bad[t] = 1; return; } done += (size_t)r; }
         }
     });
-    for (int b : bad) if (b) { u->cache_map.reset(); return false; }
-    { const unsigned long long n_bases = H.n_rows * (unsigned long long)H.stride; for (size_t i = 0; i < u->n_other; i++) if (u->s_other.p[i] >= n_bases) { u->cache_map.reset(); return false; } }
-    u->row_slot.assign((const agx_u32 *)(base + H.off[S_ROW_SLOT]), (const agx_u32 *)(base + H.off[S_ROW_SLOT]) + H.n_rows);
-    UnitView V; V.ref = u->s_ref.p; V.n_pos = H.n_pos; V.n_ref = (agx_u32)H.n_ref; V.cm_start = (const agx_u32 *)(base + H.off[S_CM_START]); V.chain_str = base + H.off[S_CHAIN_STR];
-    V.hop = nullptr; V.bases = base + H.off[S_BASES]; V.stride = H.stride; V.initial = base + H.off[S_INITIAL]; V.n_initial = H.len[S_INITIAL];
-    u->V = V;
+    bool fine = true;
+    for (int b : bad) fine = fine && !b;
+    // what the device and the walk index with must be in range: a file whose lengths are intact but whose content is not is a reason to parse the text again, not to read out of bounds
+    if (fine) {
+        const unsigned long long n_bases = H.n_rows * (unsigned long long)H.stride;
+        for (size_t i = 0; i < u->n_other && fine; i++) fine = u->s_other.p[i] < n_bases;
+        std::vector<int> bad2(threads, 0);
+        on_threads(threads, [&](unsigned t) {
+            for (size_t i = u->nh * t / threads, hi = u->nh * (t + 1) / threads; i < hi; i++) {
+                const agx_hit &h = u->s_hits.p[i];
+                if (h.slot1 >= H.n_rows || h.len == 0 || h.len > H.maxlen || (h.nruns1 && (unsigned long long)h.runs1 + h.nruns1 > H.n_runs) || (h.nruns2 && (unsigned long long)h.runs2 + h.nruns2 > H.n_runs) || h.back > i) { bad2[t] = 1; return; }
+            }
+        });
+        for (int b : bad2) fine = fine && !b;
+        unsigned long long el = 0;
+        for (size_t i = 0; i < u->n_segs && fine; i++) { const agx_cmseg &g = u->s_segs.p[i]; fine = (unsigned long long)g.pos0 + g.len <= H.n_pos && g.hop_end < H.n_pos && (unsigned long long)g.hop_str0 + g.hop_len0 <= H.len[S_CHAIN_STR] + 1 && g.elem0 == el; el += g.len; }
+        fine = fine && el == H.n_cm;
+        for (size_t i = 0; i < u->n_chain_end && fine; i++) fine = u->s_chain_end.p[i] < H.n_pos;
+        if (fine && in_reads) { const uint64_t *ro = (const uint64_t *)(base + H.off[S_ROWS]); for (size_t r = 0; r < H.n_rows && fine; r++) fine = ro[r] + H.stride <= reads_map->n + 16 && ro[r] < reads_map->n; }
+        if (fine && !in_reads) { const agx_u32 *rs = (const agx_u32 *)(base + H.off[S_ROWS]); for (size_t r = 0; r < H.n_rows && fine; r++) fine = rs[r] < H.n_slots; }
+    }
+    if (!fine) { u->cache_map.reset(); return false; }
+    UnitView V; V.ref = u->s_ref.p; V.n_pos = H.n_pos; V.n_ref = (agx_u32)H.n_ref; V.cm_cnt = (const agx_u8 *)(base + H.off[S_CM_CNT]); V.chain_str = base + H.off[S_CHAIN_STR];
+    V.hop = nullptr; V.segs = (const agx_cmseg *)(base + H.off[S_SEGS]); V.n_seg0 = (agx_u32)H.n_seg0; V.stride = H.stride; V.initial = base + H.off[S_INITIAL]; V.n_initial = H.len[S_INITIAL];
+    u->row_off.clear(); u->row_slot.clear();
+    if (in_reads) { u->reads_map = std::move(reads_map); V.bases = u->reads_map->p; V.row_off = (const uint64_t *)(base + H.off[S_ROWS]); }
+    else { V.bases = base + H.off[S_BASES]; u->row_slot.assign((const agx_u32 *)(base + H.off[S_ROWS]), (const agx_u32 *)(base + H.off[S_ROWS]) + H.n_rows); }
+    u->V = V; u->pairs_staged = false;
     u->have_ref = u->have_threads = true; u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0; u->stats.ms_parse = 0; u->stats.ms_thread = 0; u->stats.from_cache = 1;
     return true;
@@ -853,8 +885,10 @@ void do_download(agx_unit *u) {
     if (u->prm.flags & AGX_FLAG_ONE_SHOT) {
         // The inputs are in HBM and will not be uploaded again: their staged copies are dead pinned memory.  The download's arrays are cut
         // from the largest of those blocks, largest array first; what does not fit (thin read sets) gets a buffer of its own below.
-        struct Room { char *at; size_t left; } room[5] = {{(char *)u->s_hits.p, u->s_hits.block_bytes()}, {(char *)u->s_codes.p, u->s_codes.block_bytes()},
-                                                          {(char *)u->s_runs.p, u->s_runs.block_bytes()}, {(char *)u->s_other.p, u->s_other.block_bytes()}, {(char *)u->s_segs.p, u->s_segs.block_bytes()}};
+        struct Room { char *at; size_t left; } room[4] = {{(char *)u->s_hits.p, u->s_hits.block_bytes()}, {(char *)u->s_codes.p, u->s_codes.block_bytes()},
+                                                          {(char *)u->s_runs.p, u->s_runs.block_bytes()}, {(char *)u->s_other.p, u->s_other.block_bytes()}};
+        // (a loan from an earlier download of this unit object must not survive into alloc() below: the memory it names has been handed out again)
+        u->h_sp_node.release(); u->h_a_meta.release(); u->h_a_str.release(); for (auto &b : u->h_a_metas) b.release(); u->h_sp_hop.release(); u->h_side_xpos.release(); u->h_sp_bits.release(); u->h_sp_rank.release(); u->h_a_ovf.release();
         auto cut = [&](auto &buf, size_t count) {
             using T = typename std::remove_reference<decltype(*buf.p)>::type;
             const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
@@ -884,7 +918,8 @@ void do_download(agx_unit *u) {
             int queued = 0;
             for (; queued < n; queued++) if (hsa_amd_memory_async_copy(dst[queued], hsa_copy().cpu, src[queued], u->dl_agent, bytes[queued], 0, nullptr, u->dl_signal) != HSA_STATUS_SUCCESS) break;
             if (queued < n) hsa_signal_subtract_relaxed(u->dl_signal, n - queued);      // what was queued still counts down
-            const hsa_signal_value_t v = hsa_signal_wait_scacquire(u->dl_signal, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+            hsa_signal_value_t v;
+            do v = hsa_signal_wait_scacquire(u->dl_signal, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED); while (v >= 1);      // (the wait may return early: only a value below 1 means the copies are done)
             if (queued < n || v < 0) { u->dl_sdma = false; by_engines = false; }        // the engines refused: this and every later download of the unit through HIP
         }
         if (!by_engines) {
@@ -949,7 +984,7 @@ GraphView view_of(agx_unit *u) {
     G.meta = u->h_a_meta.p; G.meta_rw = u->h_a_meta.p; for (int w = 0; w < 3; w++) G.meta_copy[w] = u->h_a_metas[w].p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
     G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.sp_hop = u->h_sp_hop.p; G.n_special = u->n_special;
     G.fetch = fetch_records; G.fetch_ctx = u;
-    G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf; G.row_slot = u->row_slot.data();
+    G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf; G.row_slot = u->row_slot.empty() ? nullptr : u->row_slot.data();
     return G;
 }
 
@@ -1060,6 +1095,7 @@ int agx_unit_push_pairs(agx_unit *u, const agx_pair_batch *b) {
     if (!u || !b) return AGX_E_ARG;
     return guarded(u, [&] {
         drop_outputs(u);
+        if (u->pairs_staged) { u->pairs_staged = false; u->row_off.clear(); u->reads_keep.reset(); u->P = Pairs(); }
         if (u->P.hits.empty()) { u->P = Pairs(); u->P.stride = b->stride; }
         if (b->stride != u->P.stride) throw Error{E_ARG, "all batches of a unit must use one read stride"};
         const agx_u32 slot0 = u->P.n_slots, run0 = (agx_u32)u->P.runs.size();
@@ -1078,36 +1114,71 @@ int agx_unit_push_pairs(agx_unit *u, const agx_pair_batch *b) {
     });
 }
 
-struct agx_reads { agx::ReadsIndex *idx; };
+struct agx_reads { std::shared_ptr<agx::ReadsIndex> idx; };
 
 int agx_reads_open(const char *reads_fa, agx_reads **out, char *err, size_t err_len) {
     if (!reads_fa || !out) return AGX_E_ARG;
     *out = nullptr;
-    try { agx_reads *r = new agx_reads{nullptr}; r->idx = reads_index_open(reads_fa); *out = r; return AGX_OK; }
+    try { std::unique_ptr<agx_reads> r(new agx_reads); r->idx.reset(reads_index_open(reads_fa), reads_index_close); *out = r.release(); return AGX_OK; }
     catch (const Error &e) { if (err && err_len) snprintf(err, err_len, "%s", e.msg.c_str()); return e.code ? e.code : AGX_E_ARG; }
     catch (const std::exception &e) { if (err && err_len) snprintf(err, err_len, "%s", e.what()); return AGX_E_ARG; }
 }
 
-void agx_reads_close(agx_reads *reads) { if (reads) { reads_index_close(reads->idx); delete reads; } }
+void agx_reads_close(agx_reads *reads) { delete reads; }      // (units that were loaded through it keep the mapping alive for as long as they need it)
 
 int agx_unit_load_files(agx_unit *u, const char *tmp_dir, int unit) { return agx_unit_load_files_shared(u, tmp_dir, unit, nullptr); }
 
+// The five text files of a unit -> staged arrays.  Three independent pieces of work — the unit sequence + contig threading, the read alignments, and
+// (without a shared agx_reads) the index of tmp/_reads.fa — of which the first runs on a thread of its own beside the others.  Each piece first
+// tries the fast loader (agx_load.cpp) and takes the general one (agx_host.cpp) when that declines; AGX_NO_FAST_LOAD=1 turns the fast ones off.
 int agx_unit_load_files_shared(agx_unit *u, const char *tmp_dir, int unit, const agx_reads *reads) {
     if (!u || !tmp_dir) return AGX_E_ARG;
     return guarded(u, [&] {
         const std::string d = tmp_dir, s = std::to_string(unit);
         u->stats.from_cache = 0;
         if (load_cache(u, d, unit)) return;               // the unit's staged form, written when the alignments were distributed (agx_unit_cache_build)
-        double t0 = now_ms();
+        const double t0 = now_ms();
+        const bool fast = getenv("AGX_NO_FAST_LOAD") == nullptr;
         drop_outputs(u);
-        u->T = Threads(); u->P = Pairs();
-        load_unit_reference(d + "/_genome." + s + ".fa", u->T.ref);
-        thread_contigs_from_files(d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", u->T);
-        u->stats.ms_thread = now_ms() - t0; t0 = now_ms();
-        load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie", (long)u->prm.batch, u->prm.k, u->P, reads ? reads->idx : nullptr);
-        u->stats.ms_parse = now_ms() - t0;
-        u->have_ref = u->have_threads = true; u->staged = false; u->uploaded = false; u->built = false;
+        HIP_OK(hipSetDevice(u->prm.device));              // (the fast loader writes into pinned memory, and registering it needs a current device)
+        u->T = Threads(); u->P = Pairs(); u->pairs_staged = false; u->row_off.clear(); u->row_slot.clear(); u->reads_keep.reset(); u->reads_map.reset(); u->cache_map.reset();
+        u->staged = false; u->uploaded = false; u->built = false;
+        double ms_thread = 0;
+        std::exception_ptr thread_err;
+        auto threads_job = [&] {
+            try {
+                const double a = now_ms();
+                load_unit_reference(d + "/_genome." + s + ".fa", u->T.ref);
+                if (!(fast && thread_contigs_fast(d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", u->T)))
+                    thread_contigs_from_files(d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", u->T);
+                ms_thread = now_ms() - a;
+            } catch (...) { thread_err = std::current_exception(); }
+        };
+        std::thread side; bool side_started = false;
+        try { side = std::thread(threads_job); side_started = true; } catch (const std::system_error &) { }
+        struct Join { std::thread &t; bool on; ~Join() { if (on && t.joinable()) t.join(); } } join{side, side_started};
+        if (!side_started) threads_job();
+        if (thread_err && !side_started) std::rethrow_exception(thread_err);      // (the reference loads the genome and the contig alignment first: their errors come first)
+        const double tp0 = now_ms();
+        std::exception_ptr pairs_err;
+        try {
+            const std::string sam = d + "/_reads_genome." + s + ".bowtie";
+            std::shared_ptr<ReadsIndex> idx = reads ? reads->idx : std::shared_ptr<ReadsIndex>(reads_index_open(d + "/_reads.fa"), reads_index_close);
+            bool done = false;
+            if (fast) {
+                struct stat sb; const size_t sam_bytes = stat(sam.c_str(), &sb) == 0 ? (size_t)sb.st_size : 0;
+                UnitSink sink(u); StagedPairs S;
+                if (load_pairs_fast(*idx, sam, (long)u->prm.batch, u->prm.k, loader_threads(sam_bytes), sink, S)) { adopt_pairs(u, S); u->pairs_staged = true; u->reads_keep = idx; u->n_slots = 0; done = true; }
+            }
+            if (!done) load_pairs_from_files(d + "/_reads.fa", sam, (long)u->prm.batch, u->prm.k, u->P, idx.get());
+        } catch (...) { pairs_err = std::current_exception(); }
+        if (side_started) { side.join(); join.on = false; }
+        if (thread_err) std::rethrow_exception(thread_err);
+        if (pairs_err) std::rethrow_exception(pairs_err);
+        u->stats.ms_thread = ms_thread; u->stats.ms_parse = now_ms() - tp0;
+        u->have_ref = u->have_threads = true;
         stage_inputs(u);
+        u->stats.ms_stage = now_ms() - t0 - u->stats.ms_parse;      // (what the load took beyond the read alignments: staging, and whatever of the contig threading was not hidden behind them)
     });
 }
 
@@ -1240,7 +1311,8 @@ int agx_run_unit(const agx_params *p, const char *tmp_dir, int unit, int write_f
 int agx_run_unit_shared(const agx_params *p, const char *tmp_dir, int unit, int write_files, const agx_reads *reads, agx_result *r, char *err, size_t err_len) {
     if (err && err_len) err[0] = 0;
     agx_unit *u = nullptr;
-    int rc = agx_unit_create(p, &u);
+    agx_params once; if (p) { once = *p; once.flags |= AGX_FLAG_ONE_SHOT; }      // created, loaded, uploaded once, finished and destroyed here: the download may land in the dead staged inputs
+    int rc = agx_unit_create(p ? &once : nullptr, &u);
     if (rc != AGX_OK) { if (err && err_len) snprintf(err, err_len, "%s", rc == AGX_E_NOGPU ? "no HIP device" : "bad parameters"); return rc; }
     rc = agx_unit_load_files_shared(u, tmp_dir, unit, reads);
     if (rc == AGX_OK) rc = agx_unit_upload(u);

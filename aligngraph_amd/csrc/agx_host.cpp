@@ -13,6 +13,7 @@
 // (listed in DESIGN.md "Rejected inputs"): SAM not sorted by read id, CIGAR length != read length,
 // a RNAME / tName that does not resolve to the unit sequence, alignments beyond the unit sequence.
 #include "agx_host.h"
+#include "agx_parse.h"
 
 #include <algorithm>
 #include <chrono>
@@ -23,91 +24,36 @@
 #include <memory>
 #include <system_error>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 namespace agx {
+
+FileView::FileView(const std::string &path) {
+    fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw Error{E_IO, "CANNOT OPEN FILE! (" + path + ")"};
+    struct stat st; if (fstat(fd, &st) != 0) { ::close(fd); throw Error{E_IO, "cannot stat " + path}; }
+    n = (size_t)st.st_size;
+    if (n) {
+        void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { ::close(fd); throw Error{E_IO, "cannot map " + path}; }
+        p = (const char *)m; mapped = true;
+        madvise(m, n, MADV_SEQUENTIAL);
+    }
+}
+FileView::~FileView() { if (mapped) munmap((void *)p, n); if (fd >= 0) ::close(fd); }
+
 namespace {
-
-// read-only view of a whole file
-struct FileView {
-    const char *p = nullptr; size_t n = 0; int fd = -1; bool mapped = false;
-    explicit FileView(const std::string &path) {
-        fd = ::open(path.c_str(), O_RDONLY);
-        if (fd < 0) throw Error{E_IO, "CANNOT OPEN FILE! (" + path + ")"};
-        struct stat st; if (fstat(fd, &st) != 0) { ::close(fd); throw Error{E_IO, "cannot stat " + path}; }
-        n = (size_t)st.st_size;
-        if (n) {
-            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m == MAP_FAILED) { ::close(fd); throw Error{E_IO, "cannot map " + path}; }
-            p = (const char *)m; mapped = true;
-            madvise(m, n, MADV_SEQUENTIAL);
-        }
-    }
-    ~FileView() { if (mapped) munmap((void *)p, n); if (fd >= 0) ::close(fd); }
-    FileView(const FileView &) = delete; FileView &operator=(const FileView &) = delete;
-};
-
-// getline + `if(buf[0]==0) break` of the reference: an empty line ends the input
-struct LineReader {
-    const char *p, *e; bool saw_empty = false;
-    LineReader(const char *b, size_t n) : p(b), e(b + n) {}
-    bool next(const char *&s, size_t &len) {
-        if (p >= e) { saw_empty = true; return false; }    // (callers that care check the last byte themselves)
-        const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
-        const char *le = nl ? nl : e;
-        s = p; len = (size_t)(le - p); p = nl ? nl + 1 : e;
-        if (len == 0 || s[0] == 0) { saw_empty = true; return false; }
-        return true;
-    }
-};
-
-inline int to_int(const char *s, size_t n) {      // atoi semantics on a bounded field
-    size_t i = 0; while (i < n && (s[i] == ' ' || (s[i] >= 9 && s[i] <= 13))) i++;
-    bool neg = false; if (i < n && (s[i] == '-' || s[i] == '+')) { neg = s[i] == '-'; i++; }
-    long long v = 0; for (; i < n && s[i] >= '0' && s[i] <= '9'; i++) { v = v * 10 + (s[i] - '0'); if (v > 0x7fffffffffffLL) break; }
-    return (int)(neg ? -v : v);
-}
-
-inline void rc_inplace(std::string &s) {
-    std::reverse(s.begin(), s.end());
-    for (auto &c : s) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
-}
-
-inline void fasta_body(std::string &out, const char *s, size_t n) {
-    for (size_t i = 0; i < n; i += 60) { const size_t m = n - i < 60 ? n - i : 60; out.append(s + i, m); out.push_back('\n'); }
-}
 
 struct ContigSeq {
     std::string nuc; int real_id = 0; int placed = 0;
     std::vector<std::vector<agx_u32> > sets;   // per placement: per-base reference offset or NONE
     std::vector<int> fr;
 };
-
-struct Psl { agx_u32 tID, tStart, tEnd, tGap, sID, sStart, sEnd, sGap, sSize, fr; };
-
-void parse_psl_line(const char *s, size_t n, Psl &r, std::vector<agx_run> &seg) {
-    const char *f[21]; size_t fl[21]; int nf = 0; const char *b = s, *e = s + n;
-    for (const char *c = s; c <= e && nf < 21; c++) if (c == e || *c == '\t') { f[nf] = b; fl[nf] = (size_t)(c - b); nf++; b = c + 1; }
-    for (; nf < 21; nf++) { f[nf] = e; fl[nf] = 0; }
-    seg.clear();
-    for (int col = 18; col <= 20; col++) {
-        size_t sp = 0; const char *st = f[col];
-        for (const char *c = f[col]; c < f[col] + fl[col]; c++) if (*c == ',') {
-            const agx_u32 v = (agx_u32)to_int(st, (size_t)(c - st)); st = c + 1;
-            if (col == 18) seg.push_back(agx_run{AGX_NONE, AGX_NONE, v});
-            else if (sp < seg.size()) { if (col == 19) seg[sp].q = v; else seg[sp].t = v; }
-            sp++;
-        }
-    }
-    r.fr = fl[8] ? (f[8][0] == '+' ? 0u : 1u) : AGX_NONE;
-    r.tID = (agx_u32)to_int(f[13], fl[13]); r.tStart = (agx_u32)to_int(f[15], fl[15]); r.tEnd = (agx_u32)to_int(f[16], fl[16]);
-    r.tGap = (agx_u32)to_int(f[7], fl[7]); r.sStart = (agx_u32)to_int(f[11], fl[11]); r.sEnd = (agx_u32)to_int(f[12], fl[12]);
-    r.sGap = (agx_u32)to_int(f[5], fl[5]); r.sSize = (agx_u32)to_int(f[10], fl[10]);
-    size_t dot = 0; while (dot < fl[9] && f[9][dot] != '.') dot++;
-    r.sID = (agx_u32)to_int(f[9], dot);
-}
 
 // keepPositions (AG:731-748) on the last placement of contig `id`
 bool keeps_last(const std::vector<ContigSeq> &c, agx_u32 id, double thr) {
@@ -144,6 +90,7 @@ void load_unit_reference(const std::string &path, std::string &ref) {
 // loadContigAlignment, AG:1219-1231
 void thread_contigs_from_files(const std::string &contigs_fa, const std::string &psl_path, Threads &T) {
     std::vector<ContigSeq> cs;
+    const bool lt = getenv("AGX_LOAD_TIMING") != nullptr; auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }; double tt[8]; tt[0] = tnow();
     {   // loadSeq, AG:322-359
         FileView fv(contigs_fa); LineReader in(fv.p, fv.n); const char *s; size_t n;
         while (in.next(s, n)) {
@@ -155,7 +102,7 @@ void thread_contigs_from_files(const std::string &contigs_fa, const std::string 
         }
     }
     const agx_u32 n_ref = (agx_u32)T.ref.size();
-    T.n_ref = n_ref;
+    T.n_ref = n_ref; tt[1] = tnow();
     {   // loadContiAli, AG:817-852 (sourceIDBak starts at -1 for every unit, AG:4781)
         FileView fv(psl_path); LineReader in(fv.p, fv.n); const char *s; size_t n;
         Psl r; std::vector<agx_run> seg; agx_u32 bak = AGX_NONE, last_parsed = AGX_NONE;
@@ -188,6 +135,7 @@ void thread_contigs_from_files(const std::string &contigs_fa, const std::string 
         if (through_empty_line && last_parsed != AGX_NONE && last_parsed < cs.size() && !keeps_last(cs, last_parsed, 0.5)) cs[last_parsed].sets.pop_back();
     }
 
+    tt[2] = tnow();
     // updateGenomeWithContig, AG:884-1217 — per-position conti-mer lists kept as index-linked pools while threading
     struct Cell { ContiMer m; int next; };
     std::vector<Cell> pool;
@@ -245,11 +193,12 @@ void thread_contigs_from_files(const std::string &contigs_fa, const std::string 
             if (rc) rc_inplace(q.nuc);
         }
     }
+    tt[3] = tnow();
     const size_t n_pos = T.ref.size();
     T.cm_start.assign(n_pos + 1, 0); T.cm.clear(); T.cm.reserve(pool.size());
     for (size_t x = 0; x < n_pos; x++) { T.cm_start[x] = (agx_u32)T.cm.size(); for (int c = slot[x].head; c >= 0; c = pool[c].next) T.cm.push_back(pool[c].m); }
-    T.cm_start[n_pos] = (agx_u32)T.cm.size();
-    build_chains(T);
+    T.cm_start[n_pos] = (agx_u32)T.cm.size(); tt[4] = tnow();
+    build_chains(T); tt[5] = tnow();
 
     // tmp/_initial_contigs.<u>.fa, AG:1179-1216: runs of equal realID form one real contig; it is written when >= 50 % of its
     // chunks were placed on this unit
@@ -264,56 +213,23 @@ void thread_contigs_from_files(const std::string &contigs_fa, const std::string 
             T.initial_contigs += ">" + std::to_string(g) + "\n";
             fasta_body(T.initial_contigs, real[g].data(), real[g].size());
         }
+    if (lt) fprintf(stderr, "[agx load] contigs: fasta %.1f ms, psl + sets %.1f ms, threading %.1f ms, flatten %.1f ms, chains %.1f ms, initial %.1f ms\n", tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tnow() - tt[5]);
 }
-
-namespace {
-
-struct Mate { agx_u32 id; agx_u32 fr; bool aligned; agx_u32 pos0; agx_u32 total, ins, del, clipL, clipR; size_t run0; agx_u32 nruns; };
-
-// parseBOWTIE, AG:181-285; M runs are appended to `runs`
-void parse_sam_line(const char *s, size_t n, Mate &m, std::vector<agx_run> &runs) {
-    const char *f[6]; size_t fl[6]; int nf = 0; const char *b = s, *e = s + n;
-    for (const char *c = s; nf < 6; c++) {
-        if (c >= e || *c == '\t') { f[nf] = b; fl[nf] = (size_t)((c < e ? c : e) - b); nf++; b = c + 1; if (c >= e) break; }
-    }
-    for (; nf < 6; nf++) { f[nf] = e; fl[nf] = 0; }
-    m.id = (agx_u32)to_int(f[0], fl[0]);
-    m.fr = (to_int(f[1], fl[1]) & 0x10) ? 1u : 0u;
-    m.run0 = runs.size(); m.nruns = 0; m.total = m.ins = m.del = m.clipL = m.clipR = 0; m.pos0 = 0;
-    m.aligned = !(fl[2] > 0 && f[2][0] == '*');
-    if (!m.aligned) return;
-    size_t dot = 0; while (dot < fl[2] && f[2][dot] != '.') dot++;
-    if (dot != fl[2] && to_int(f[2], dot) != 0) throw Error{E_UNSUPPORTED, "SAM RNAME does not resolve to the unit sequence"};
-    const int pos1 = to_int(f[3], fl[3]);
-    int ins = 0, del = 0, total = 0, start = 0, end = 0, first = 1, num = 0;
-    for (size_t i = 0; i < fl[5]; i++) {
-        const char c = f[5][i];
-        if (c >= '0' && c <= '9') { num = num * 10 + (c - '0'); continue; }
-        if (c == 'I') { ins += num; total += num; }
-        else if (c == 'D') del += num;
-        else if (c == 'M') { if (num > 0) { runs.push_back(agx_run{(agx_u32)total, (agx_u32)(pos1 + total + del - start - ins - 1), (agx_u32)num}); m.nruns++; } total += num; first = 0; }
-        else if (c == 'S' && first) { start = num; total += num; first = 0; }
-        else if (c == 'S') { end = num; total += num; }
-        else if (c != '*') throw Error{E_FORMAT, std::string("unknown character: ") + c};
-        num = 0;
-    }
-    m.total = (agx_u32)total; m.ins = (agx_u32)ins; m.del = (agx_u32)del; m.clipL = (agx_u32)start; m.clipR = (agx_u32)end; m.pos0 = (agx_u32)(pos1 - 1);
-}
-
-// the identity filter of loadReadAli, AG:1261, in the reference's unsigned arithmetic
-inline bool passes(const Mate &m) {
-    const agx_u32 sEnd = m.total - m.clipR, tEnd = m.pos0 + (m.total + m.del - m.ins);
-    return (double)(agx_u32)(sEnd - m.clipL - m.ins) / m.total >= 0.6 && (double)(agx_u32)(tEnd - m.pos0 - m.del) / (agx_u32)(tEnd - m.pos0) >= 0.6;
-}
-
-}  // namespace
 
 // loadReadAlignment's parsing half: batches of `batch` pairs (AG:37, 361-404), SAM line pairs (AG:1233-1277)
 // One pass over tmp/_reads.fa: where every line pair (header, sequence) starts, up to the first empty line (which ends the file for
 // the reference's getline loops), and how many header lines there are (what decides the batch boundaries, AG:361-404).
+unsigned usable_cpus() {
+    cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int n = CPU_COUNT(&set); if (n > 0) return (unsigned)n; }
+    return std::max(1u, std::thread::hardware_concurrency());
+}
+// A unit's loader runs beside the loaders of the other units in flight (AlignGraph_amd: four; bench.py: all of a rank's units): a quarter of the
+// cores this process may use each, between 8 and 32, and no more than one per 2 MB of input.
 unsigned loader_threads(size_t bytes) {
     if (const char *e = getenv("AGX_LOAD_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(e)));      // tests force the multi-thread paths on small files
-    return (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), bytes / (4u << 20) + 1);
+    const unsigned cores = usable_cpus(), share = std::min(32u, std::max(8u, cores / 4));
+    return (unsigned)std::min<size_t>(std::min(share, cores), bytes / (2u << 20) + 1);
 }
 // fn(t) on `threads` threads.  Nothing may leave a worker thread as an exception (it would terminate the process behind a C ABI that promises
 // return codes): whatever a worker throws is carried to the caller and rethrown there; a thread that cannot be started just leaves its
@@ -328,11 +244,7 @@ template <class F> void on_threads(unsigned threads, F fn) {
     for (auto &e : ex) if (e) std::rethrow_exception(e);
 }
 
-struct ReadsIndex {
-    FileView fv;
-    std::vector<uint64_t> rec_off;              // offset of the first line of record r (a record = two lines)
-    unsigned long long headers = 0;
-    explicit ReadsIndex(const std::string &path) : fv(path) {
+ReadsIndex::ReadsIndex(const std::string &path) : fv(path) {
         const char *b = fv.p, *e = b + fv.n;
         const unsigned threads = loader_threads(fv.n);
         bool done = false;
@@ -382,8 +294,8 @@ struct ReadsIndex {
             }
         }
         if (fv.mapped) madvise((void *)fv.p, fv.n, MADV_RANDOM);
-    }
-};
+}
+
 ReadsIndex *reads_index_open(const std::string &reads_fa) { return new ReadsIndex(reads_fa); }
 void reads_index_close(ReadsIndex *r) { delete r; }
 
@@ -574,6 +486,42 @@ void load_pairs_from_files(const std::string &reads_fa, const std::string &sam_p
         }
     });
     for (unsigned t = 0; t < copy_threads; t++) if (bad[t] != (size_t)-1) throw bad_err[t];      // ranges are in slot order: the first failure in file order
+}
+
+// ---- Team ---------------------------------------------------------------------------------------------------------------------------
+struct Team::Impl {
+    std::vector<std::thread> th; std::mutex m; std::condition_variable cv_go, cv_done;
+    const std::function<void(unsigned)> *fn = nullptr; unsigned long long gen = 0; unsigned pending = 0; bool stop = false;
+    std::vector<std::exception_ptr> ex;
+};
+Team::Team(unsigned threads) : impl_(new Impl), n_(threads ? threads : 1) {
+    Impl &I = *impl_; I.ex.resize(n_);
+    unsigned started = 1;
+    for (unsigned t = 1; t < n_; t++) {
+        try {
+            I.th.emplace_back([&I, t] {
+                unsigned long long seen = 0;
+                for (;;) {
+                    const std::function<void(unsigned)> *f;
+                    { std::unique_lock<std::mutex> l(I.m); I.cv_go.wait(l, [&] { return I.stop || I.gen != seen; }); if (I.stop) return; seen = I.gen; f = I.fn; }
+                    try { (*f)(t); } catch (...) { I.ex[t] = std::current_exception(); }
+                    { std::lock_guard<std::mutex> l(I.m); if (--I.pending == 0) I.cv_done.notify_all(); }
+                }
+            });
+            started++;
+        } catch (const std::system_error &) { break; }      // fewer threads than asked for: the team is as large as what could be started
+    }
+    n_ = started;
+}
+Team::~Team() { { std::lock_guard<std::mutex> l(impl_->m); impl_->stop = true; } impl_->cv_go.notify_all(); for (auto &t : impl_->th) t.join(); delete impl_; }
+void Team::run(const std::function<void(unsigned)> &fn) {
+    Impl &I = *impl_;
+    for (auto &e : I.ex) e = nullptr;
+    { std::lock_guard<std::mutex> l(I.m); I.fn = &fn; I.pending = n_ - 1; I.gen++; }
+    I.cv_go.notify_all();
+    try { fn(0); } catch (...) { I.ex[0] = std::current_exception(); }
+    { std::unique_lock<std::mutex> l(I.m); I.cv_done.wait(l, [&] { return I.pending == 0; }); }
+    for (auto &e : I.ex) if (e) std::rethrow_exception(e);
 }
 
 }  // namespace agx

@@ -23,8 +23,10 @@ struct ContiMer { char nuc; agx_u32 cid, coff, next_off, next_item; };   // next
 struct Threads {
     std::string ref;                       // reference bases followed by the positions appended for contig insertions (AG:1016, 1036)
     agx_u32 n_ref = 0;                     // length of the original unit sequence
-    std::vector<agx_u32> cm_start;         // [n_pos+1]
-    std::vector<ContiMer> cm;
+    std::vector<agx_u32> cm_start;         // [n_pos+1]   (general loader only; the fast loader keeps counts and runs)
+    std::vector<ContiMer> cm;              //             (general loader only)
+    std::vector<agx_u8> cm_cnt;            // [n_pos] conti-mers per position
+    size_t n_cm = 0;                       // conti-mers in all (= cm.size() where cm is kept)
     std::string initial_contigs;           // bytes of tmp/_initial_contigs.<u>.fa
     // Conti-mer chains (one per contig placement): following `next` from a conti-mer never looks at mutable state
     // (AG:2064-2072), so the walk appends a precomputed suffix instead of chasing pointers.  Built by build_chains().
@@ -52,15 +54,21 @@ struct Pairs {
 // a mapped unit cache file (agx_engine.cpp).
 struct UnitView {
     const char *ref = nullptr; size_t n_pos = 0; agx_u32 n_ref = 0;   // unit sequence + appended positions
-    const agx_u32 *cm_start = nullptr;                                // [n_pos + 1]
+    const agx_u32 *cm_start = nullptr;                                // [n_pos + 1], or null: then cm_cnt
+    const agx_u8 *cm_cnt = nullptr;                                   // [n_pos] conti-mers per position (the fast loader and the unit cache keep counts, not a prefix)
     const char *chain_str = nullptr;                                  // conti-mer chain suffixes (agx_hop::str_off points in here)
-    const agx_hop *hop = nullptr;                                     // per-position hop table, or null: then GraphView::sp_hop is the only source
+    const agx_hop *hop = nullptr;                                     // per-position hop table, or null: then GraphView::sp_hop, and for ids outside it the runs below
+    const agx_cmseg *segs = nullptr; agx_u32 n_seg0 = 0;              // the conti-mer chains as runs (rank-0 runs first, by position): hop entries by bisection (agx_seg_hop)
     const char *bases = nullptr; agx_u32 stride = 0;                  // read bases, slot s at bases + s * stride (k-mer strings of written records)
+    const uint64_t *row_off = nullptr;                                // or: row r of the staged read bases starts at bases + row_off[r] (the mapped reads file; GraphView::row_slot is then not consulted)
+    bool has_cm(size_t x) const { return cm_cnt ? cm_cnt[x] != 0 : cm_start[x + 1] > cm_start[x]; }
+    agx_u32 cm_count(size_t x) const { return cm_cnt ? cm_cnt[x] : cm_start[x + 1] - cm_start[x]; }
     const char *initial = nullptr; size_t n_initial = 0;              // bytes of tmp/_initial_contigs.<u>.fa
 };
 inline UnitView view_of(const Threads &T, const Pairs &P) {
-    UnitView V; V.ref = T.ref.data(); V.n_pos = T.ref.size(); V.n_ref = T.n_ref; V.cm_start = T.cm_start.data(); V.chain_str = T.chain_str.data();
-    V.hop = T.hop.size() == T.ref.size() ? T.hop.data() : nullptr; V.bases = P.bases.data(); V.stride = P.stride; V.initial = T.initial_contigs.data(); V.n_initial = T.initial_contigs.size();
+    UnitView V; V.ref = T.ref.data(); V.n_pos = T.ref.size(); V.n_ref = T.n_ref; V.cm_start = T.cm_start.size() == T.ref.size() + 1 ? T.cm_start.data() : nullptr;
+    V.cm_cnt = T.cm_cnt.size() == T.ref.size() ? T.cm_cnt.data() : nullptr; V.chain_str = T.chain_str.data();
+    V.hop = T.hop.size() == T.ref.size() ? T.hop.data() : nullptr; V.segs = T.segs.data(); V.n_seg0 = T.n_seg0; V.bases = P.bases.data(); V.stride = P.stride; V.initial = T.initial_contigs.data(); V.n_initial = T.initial_contigs.size();
     return V;
 }
 
@@ -108,12 +116,58 @@ struct OutBuf {
 };
 struct UnitOutput { OutBuf pre_extended, extended; unsigned long long n_fetched = 0; };
 
+// read-only view of a whole file (mmap)
+struct FileView {
+    const char *p = nullptr; size_t n = 0; int fd = -1; bool mapped = false;
+    explicit FileView(const std::string &path);
+    ~FileView();
+    FileView(const FileView &) = delete; FileView &operator=(const FileView &) = delete;
+};
+
+// Threads of a loader: `threads` workers that live as long as the team and run one function after another (a phase of a loader = one run()).
+// Nothing leaves a worker as an exception: what one throws is rethrown by run() on the caller's thread.
+class Team {
+public:
+    explicit Team(unsigned threads);
+    ~Team();
+    unsigned size() const { return n_; }
+    void run(const std::function<void(unsigned)> &fn);      // fn(t) for t in [0, size()), t = 0 on the calling thread
+private:
+    struct Impl; Impl *impl_; unsigned n_;
+};
+unsigned loader_threads(size_t bytes);      // AGX_LOAD_THREADS, else by the size of the input and the cores this process may use
+
+// agx_load.cpp — the fast loaders.  Each returns false when the input is anything but the well-formed common case (an '@' line, an empty line in the
+// middle, ids out of order, blocks that overlap, whatever would be an error): the caller then takes the general loader of agx_host.cpp, which follows
+// the reference line by line and reports errors in its order.  What they return is byte for byte what the general loader + staging produce.
+enum { SA_HITS = 0, SA_RUNS, SA_CODES, SA_OTHER, SA_N };
+struct StageSink { virtual void *take(int which, size_t bytes) = 0; virtual ~StageSink() {} };      // where the staged arrays live (the engine: pinned memory)
+struct StagedPairs {        // what the upload wants of a unit's read alignments (agx_engine.cpp: stage)
+    agx_hit *hits = nullptr; size_t nh = 0;              // slot1 = ROW of the left mate's bases, pad[0] = which mate that is
+    agx_run *runs = nullptr; size_t n_runs = 0;
+    agx_u8 *codes = nullptr; size_t n_codes = 0;         // 2-bit classes, stride / 4 bytes per row
+    unsigned long long *other = nullptr; size_t n_other = 0;   // bases that are not A, C, G, T: row * stride + index, ascending
+    agx_u32 stride = 0, maxlen = 0, n_rows = 0;
+    std::vector<uint64_t> row_off;                       // fast loader: where each row's bases start in the reads file
+    std::vector<agx_u32> row_slot;                       // general loader: the read slot (Pairs::bases) of each row
+    unsigned long long n_pairs_in_file = 0, n_sam_pairs = 0;
+};
+struct ReadsIndex;
+bool thread_contigs_fast(const std::string &contigs_fa, const std::string &psl, Threads &T);      // T.ref must hold the unit sequence (left as it was on false)
+bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam, long batch, agx_u32 k, unsigned threads, StageSink &sink, StagedPairs &S);
+void stage_pairs(const Pairs &P, agx_u32 k, unsigned threads, StageSink &sink, StagedPairs &S);     // the same arrays from what the general loader (or agx_unit_push_pairs) holds
+
 // agx_host.cpp
 void load_unit_reference(const std::string &path, std::string &ref);
 void thread_contigs_from_files(const std::string &contigs_fa, const std::string &psl, Threads &T);   // T.ref must hold the unit sequence
 // tmp/_reads.fa mapped once with the byte offset of every record: the units of one run (AG:1880 re-reads the whole file for each of
 // them) then only touch the reads their own SAM names.  Immutable after open(); shared by any number of threads.
-struct ReadsIndex;
+struct ReadsIndex {
+    FileView fv;
+    std::vector<uint64_t> rec_off;              // offset of the first line of record r (a record = two lines)
+    unsigned long long headers = 0;             // header lines up to the first empty line
+    explicit ReadsIndex(const std::string &path);
+};
 ReadsIndex *reads_index_open(const std::string &reads_fa);
 void reads_index_close(ReadsIndex *);
 // reads: optional index of reads_fa (nullptr: the file is scanned here)

@@ -1,0 +1,660 @@
+// agx_load.cpp — the fast host loaders: a unit's text files -> the arrays the upload wants, at memory speed.
+//
+// Rows a2-a5 and a15 of the path: parseBOWTIE AG:181-285, loadSeq AG:361-404, updateContig/keepPositions AG:731-815,
+// loadReadAli AG:1233-1277, and the feeders parseBLAT AG:406-522, loadContiAli AG:817-852, updateGenomeWithContig AG:884-1217.  The general
+// loaders of agx_host.cpp follow the reference line by line (and base by base) and stay the definition: they take every input, and
+// report every error in the reference's order.  What is here takes the well-formed common case — bowtie2 --reorder output without '@'
+// lines, BLAT blocks that advance, files that end with one newline — on all the cores the process may use, and produces byte for byte
+// what the general loader + the engine's staging produce (tests/test_fast_loader.py compares them on every fixture and on random
+// generator settings); whatever it does not recognise makes it return false, and the caller takes the general path.
+//
+//   contig threading   A placement of a contig is a list of PSL blocks.  The general loader expands it to one reference offset per contig base,
+//                      pushes one conti-mer per base into per-position lists, and build_chains() then recovers RUNS (agx_cmseg) from the
+//                      lists.  Here the runs come straight from the blocks: the only per-position state threading needs is how many
+//                      conti-mers a position already carries (the rank of the next one, AG:1106, and the two-conti-mer rule, AG:908-920) —
+//                      one byte per position, scanned and bumped a block at a time.
+//   read alignments    the SAM file cut into byte ranges at line-pair boundaries, every range parsed on its own thread into hits in their
+//                      final form; the rules that look across lines (batch boundaries AG:1258-1259, hits per pair, rows of read bases) are
+//                      prefix computations over the ranges; the left mate of every hit (AG:1672-1679) is decided where it is parsed and only
+//                      its bases are fetched from the mapped reads file, straight into 2-bit classes in the upload buffer.
+#include "agx_host.h"
+#include "agx_parse.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+namespace agx {
+namespace {
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+const bool g_timing = getenv("AGX_LOAD_TIMING") != nullptr;
+
+// ---- line scanning ----------------------------------------------------------------------------------------------------------------------
+// One pass over a byte range that starts at a line start: f(start_of_line) for every line, until the range ends or a line is empty or begins
+// with a NUL byte (the reference's getline loops stop there: `if(buf[0]==0) break`).  Returns where the scan stopped: `hi`, or the start
+// of the line that ends the input.  32 bytes at a time: newline and NUL masks, line starts = newline mask shifted by one.
+template <class F> inline const char *scan_lines_scalar(const char *lo, const char *hi, F f) {
+    const char *c = lo;
+    while (c < hi) {
+        if (*c == '\n' || *c == 0) return c;
+        f(c);
+        const char *nl = (const char *)memchr(c, '\n', (size_t)(hi - c));
+        if (!nl) return hi;
+        c = nl + 1;
+    }
+    return hi;
+}
+#if defined(__x86_64__)
+template <class F> __attribute__((target("avx2"))) inline const char *scan_lines_avx2(const char *lo, const char *hi, F f) {
+    const __m256i vnl = _mm256_set1_epi8('\n'), vz = _mm256_setzero_si256();
+    uint32_t carry = 1;                                  // the byte before `lo` ends a line
+    const char *c = lo;
+    for (; c + 32 <= hi; c += 32) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)c);
+        const uint32_t nl = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, vnl)), nul = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, vz));
+        uint32_t starts = (nl << 1) | carry;
+        carry = nl >> 31;
+        if (!starts) continue;
+        const uint32_t stop = starts & (nl | nul);
+        if (stop) { const uint32_t below = (stop & (0u - stop)) - 1u; for (uint32_t m = starts & below; m; m &= m - 1) f(c + __builtin_ctz(m)); return c + __builtin_ctz(stop); }
+        for (uint32_t m = starts; m; m &= m - 1) f(c + __builtin_ctz(m));
+    }
+    // tail: the last (partial) chunk byte by byte
+    if (c < hi) {
+        if (carry) { if (*c == '\n' || *c == 0) return c; f(c); }
+        for (const char *d = c; d + 1 < hi; d++) if (*d == '\n') { if (d[1] == '\n' || d[1] == 0) return d + 1; f(d + 1); }
+    }
+    return hi;
+}
+#endif
+template <class F> inline const char *scan_lines(const char *lo, const char *hi, F f) {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2")) return scan_lines_avx2(lo, hi, f);
+#endif
+    return scan_lines_scalar(lo, hi, f);
+}
+
+// number of '\n' in [lo, hi)
+inline size_t count_newlines_scalar(const char *lo, const char *hi) { size_t n = 0; for (const char *c = lo; c < hi; c++) n += *c == '\n'; return n; }
+#if defined(__x86_64__)
+__attribute__((target("avx2,popcnt"))) inline size_t count_newlines_avx2(const char *lo, const char *hi) {
+    const __m256i vnl = _mm256_set1_epi8('\n'); size_t n = 0; const char *c = lo;
+    for (; c + 32 <= hi; c += 32) n += (size_t)__builtin_popcount((uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)c), vnl)));
+    for (; c < hi; c++) n += *c == '\n';
+    return n;
+}
+#endif
+inline size_t count_newlines(const char *lo, const char *hi) {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2")) return count_newlines_avx2(lo, hi);
+#endif
+    return count_newlines_scalar(lo, hi);
+}
+
+// length of the prefix of p[0..n) whose bytes all equal p[0]
+inline size_t run_same(const agx_u8 *p, size_t n) {
+    const agx_u8 v = p[0]; size_t i = 1;
+    const uint64_t pat = 0x0101010101010101ull * v;
+    while (i < n && ((uintptr_t)(p + i) & 7u)) { if (p[i] != v) return i; i++; }
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); if (w != pat) break; }
+    while (i < n && p[i] == v) i++;
+    return i;
+}
+inline bool any_at_least(const agx_u8 *p, size_t n, agx_u8 v) { agx_u8 m = 0; for (size_t i = 0; i < n; i++) m = p[i] > m ? p[i] : m; return m >= v; }      // (vectorises)
+
+// ---- contig threading -------------------------------------------------------------------------------------------------------------------
+struct ContigRec {
+    const char *hdr = nullptr, *body = nullptr, *end = nullptr;     // header line, first byte behind it, end of the record's lines
+    int real_id = 0; size_t len = (size_t)-1;                       // bases (body bytes that are not '\n'), counted when first asked for
+    std::string nuc; bool have_nuc = false;                         // the bases without the line breaks, made when first asked for
+    int placed = 0;
+    size_t length() { if (len == (size_t)-1) len = (size_t)(end - body) - count_newlines(body, end); return len; }
+    const std::string &bases() {
+        if (!have_nuc) {
+            nuc.resize(length()); char *w = &nuc[0];
+            for (const char *c = body; c < end;) { const char *nl = (const char *)memchr(c, '\n', (size_t)(end - c)); const size_t m = (size_t)((nl ? nl : end) - c); memcpy(w, c, m); w += m; c = nl ? nl + 1 : end; }
+            have_nuc = true;
+        }
+        return nuc;
+    }
+    // the record's lines are already what fasta_body() would write for its bases: 60 per line, every line ended
+    bool wrapped60() {
+        const size_t n = length(), lines = (n + 59) / 60;
+        if ((size_t)(end - body) != n + lines) return false;
+        for (size_t l = 0; l < lines; l++) { const size_t at = l + 1 < lines ? (l + 1) * 61 - 1 : n + lines - 1; if (body[at] != '\n') return false; }
+        return true;
+    }
+};
+struct Place { std::vector<agx_run> blk; int fr = 0; size_t filled = 0; };
+
+inline char comp_base(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c; }
+
+}  // namespace
+
+bool thread_contigs_fast(const std::string &contigs_fa, const std::string &psl_path, Threads &T) {
+    double tt[8]; tt[0] = now_ms();
+    const agx_u32 n_ref = (agx_u32)T.ref.size();
+    if (n_ref == 0) return false;
+    FileView cf(contigs_fa), pf(psl_path);
+    // ---- loadSeq, AG:322-359: where every record of tmp/_contigs.fa is (no base is copied yet) ----
+    std::vector<ContigRec> cs;
+    {
+        std::vector<const char *> heads; bool body_first = false; bool first = true;
+        const char *stop = scan_lines(cf.p, cf.p + cf.n, [&](const char *c) { if (*c == '>') heads.push_back(c); else if (first) body_first = true; first = false; });
+        if (body_first) return false;                        // "sequence before header": the general loader reports it
+        cs.resize(heads.size());
+        for (size_t i = 0; i < heads.size(); i++) {
+            ContigRec &r = cs[i]; r.hdr = heads[i]; r.end = i + 1 < heads.size() ? heads[i + 1] : stop;
+            const char *nl = (const char *)memchr(r.hdr, '\n', (size_t)(r.end - r.hdr));
+            const char *he = nl ? nl : r.end; r.body = nl ? nl + 1 : r.end;
+            const char *dot = (const char *)memchr(r.hdr, '.', (size_t)(he - r.hdr));
+            if (!dot) return false;
+            r.real_id = to_int(dot + 1, (size_t)(he - dot - 1));
+        }
+    }
+    tt[1] = now_ms();
+    // ---- loadContiAli, AG:817-852 with updateContig, AG:763-815: placements as block lists ----
+    std::vector<std::vector<Place>> sets(cs.size());
+    {
+        LineReader in(pf.p, pf.n); const char *s; size_t n;
+        Psl r; std::vector<agx_run> seg; agx_u32 bak = AGX_NONE, last_parsed = AGX_NONE;
+        auto keeps_last = [&](agx_u32 id) -> bool {           // keepPositions, AG:731-748
+            if (id == AGX_NONE || sets[id].empty()) return true;
+            return (double)sets[id].back().filled / (double)cs[id].length() >= 0.5;
+        };
+        while (in.next(s, n)) {
+            parse_psl_line(s, n, r, seg); last_parsed = r.sID;
+            const bool keep = (double)(agx_u32)(r.sEnd - r.sStart - r.sGap) / r.sSize >= 0.5 &&
+                              (double)(agx_u32)(r.tEnd - r.tStart - r.tGap) / (agx_u32)(r.tEnd - r.tStart) >= 0.5 && r.sSize > 200;
+            if (!keep) continue;
+            if (r.tID != 0 || r.sID >= cs.size()) return false;
+            const size_t len = cs[r.sID].length();
+            if (len < 2 || len >= 0x7FFFFFFFu) return false;
+            size_t q_at = 0, filled = 0;
+            for (const agx_run &g : seg) {                    // blocks that advance on the contig and lie inside contig and unit (anything else: the general loader decides)
+                if (g.q == AGX_NONE || g.t == AGX_NONE || g.q < q_at || (size_t)g.q + g.n > len || (unsigned long long)g.t + g.n > n_ref) return false;
+                q_at = (size_t)g.q + g.n; filled += g.n;
+            }
+            std::vector<Place> &ps = sets[r.sID];
+            auto open_set = [&]() { ps.emplace_back(); ps.back().fr = (int)r.fr; };
+            if (r.sID != bak) {
+                if (!keeps_last(bak)) sets[bak].pop_back();
+                open_set(); bak = r.sID;
+            } else {                                          // AG:786-806: a block that meets a filled base opens a new placement
+                bool hit = false;
+                for (const agx_run &g : seg) { if (!g.n) continue; for (const agx_run &o : ps.back().blk) if (g.q < o.q + o.n && o.q < g.q + g.n) { hit = true; break; } if (hit) break; }
+                if (hit) { if (!keeps_last(r.sID)) ps.pop_back(); open_set(); }
+            }
+            Place &pl = ps.back();
+            for (const agx_run &g : seg) if (g.n) pl.blk.push_back(g);
+            pl.filled += filled;
+        }
+        const bool through_empty_line = pf.n == 0 || pf.p[pf.n - 1] == '\n' || in.p < in.e;       // AG:830-836
+        if (through_empty_line && last_parsed != AGX_NONE && last_parsed < cs.size() && !keeps_last(last_parsed)) sets[last_parsed].pop_back();
+    }
+    tt[2] = now_ms();
+    // ---- updateGenomeWithContig, AG:884-1217, a block at a time ----
+    struct Chain { agx_u32 head_pos, head_rank, end_pos, n_elem; size_t seg_first, seg_n, str_at; };
+    std::vector<Chain> chains; std::vector<agx_cmseg> segs; std::string str;             // str: the chains' bases in threading order
+    std::vector<agx_u8> cnt(n_ref, 0);
+    std::string appended;
+    size_t n_cm = 0;
+    { size_t bases = 0; for (size_t sp = 0; sp < cs.size(); sp++) if (!sets[sp].empty()) bases += cs[sp].length(); str.reserve(bases + 16); cnt.reserve((size_t)n_ref + bases / 16 + 16); }
+    std::string oriented;
+    for (size_t sp = 0; sp < cs.size(); sp++) {
+        std::vector<Place> &ps = sets[sp];
+        if (ps.empty()) continue;
+        ContigRec &q = cs[sp];
+        const size_t len = q.length();
+        for (Place &pl : ps) std::sort(pl.blk.begin(), pl.blk.end(), [](const agx_run &a, const agx_run &b) { return a.q < b.q; });
+        auto set0 = [&](const Place &pl) -> agx_u32 { return !pl.blk.empty() && pl.blk[0].q == 0 ? pl.blk[0].t : AGX_NONE; };
+        for (size_t pp = 0; pp < ps.size(); pp++) {
+            const Place &pl = ps[pp];
+            if (pl.blk.empty()) return false;
+            bool skip = false;
+            for (size_t e = 0; e < pp && !skip; e++) skip = agx_absdiff(set0(pl), set0(ps[e])) < (int)len;                       // AG:902-907
+            for (size_t b = 0; b < pl.blk.size() && !skip; b++) {                                                                // AG:908-920: bases 0 .. len-2
+                const agx_run &g = pl.blk[b]; const size_t n = (size_t)g.q + g.n == len ? g.n - 1 : g.n;
+                skip = n && any_at_least(&cnt[g.t], n, 2);
+            }
+            if (skip) continue;
+            if (pl.blk[0].q + 1 >= len) return false;            // no aligned base below len-1: the reference then works with what the previous placement left behind
+            if (pl.fr != 0 && pl.fr != 1) return false;
+            const bool rc = pl.fr == 1;
+            q.placed = 1;
+            const agx_u32 i0 = pl.blk[0].q, i_last = pl.blk.back().q + pl.blk.back().n - 1;
+            const bool trailing = (size_t)i_last + 1 < len;      // the contig's last bases are unaligned: the terminal conti-mer sits on the last aligned base's position
+            Chain ch; ch.seg_first = segs.size(); ch.str_at = str.size(); ch.n_elem = i_last - i0 + 1;
+            // one element of the chain: the join rule of build_chains()
+            auto add_elem = [&](agx_u32 pos, agx_u32 coff, agx_u32 rank, agx_u32 idx) {
+                agx_cmseg *g = segs.size() > ch.seg_first ? &segs.back() : nullptr;
+                const bool joins = g && pos == g->pos0 + g->len && rank == g->rank && (g->len == 1 || coff == g->coff0 + g->len * g->dcoff);
+                if (joins) { if (g->len == 1) g->dcoff = coff - g->coff0; g->len++; }
+                else segs.push_back(agx_cmseg{pos, 1u, (agx_u32)sp, coff, 0u, rank, idx + 1u, idx, 0u, 0u});      // hop_str0, hop_len0: relative to the chain until it is placed
+            };
+            // n elements on consecutive positions with consecutive contig offsets, all of rank `rank`
+            auto add_run = [&](agx_u32 pos0, agx_u32 n, agx_u32 coff0, agx_u32 rank, agx_u32 idx) {
+                agx_u32 j = 0;
+                for (; j < n; j++) {
+                    const agx_cmseg *g = segs.size() > ch.seg_first ? &segs.back() : nullptr;
+                    if (g && g->len >= 2 && g->dcoff == 1 && g->rank == rank && g->pos0 + g->len == pos0 + j && g->coff0 + g->len == coff0 + j) break;
+                    add_elem(pos0 + j, coff0 + j, rank, idx + j);
+                }
+                if (j < n) segs.back().len += n - j;
+            };
+            bool first = true;
+            for (size_t b = 0; b < pl.blk.size(); b++) {
+                const agx_run &g = pl.blk[b];
+                const bool last_blk = b + 1 == pl.blk.size();
+                const agx_u32 n_run = last_blk && trailing ? g.n - 1 : g.n;          // (trailing: the last aligned base's element is the terminal one, with the contig's LAST offset)
+                for (agx_u32 j = 0; j < n_run;) {                                      // stretches of equal count = equal rank
+                    const agx_u32 c = cnt[g.t + j]; const agx_u32 m = (agx_u32)run_same(&cnt[g.t + j], n_run - j);
+                    if (c >= 250) return false;
+                    if (first) { ch.head_pos = g.t + j; ch.head_rank = c; first = false; }
+                    add_run(g.t + j, m, g.q + j, c, g.q + j - i0);
+                    j += m;
+                }
+                for (agx_u32 j = 0; j < n_run; j++) cnt[g.t + j]++;
+                if (last_blk) {
+                    if (trailing) {
+                        const agx_u32 pos = g.t + g.n - 1, c = cnt[pos];
+                        if (c >= 250) return false;
+                        if (first) { ch.head_pos = pos; ch.head_rank = c; first = false; }
+                        add_elem(pos, (agx_u32)(len - 1), c, i_last - i0); cnt[pos]++;
+                        ch.end_pos = pos;
+                    } else ch.end_pos = g.t + g.n - 1;
+                } else {
+                    const agx_run &nx = pl.blk[b + 1];
+                    const agx_u32 gap = nx.q - (g.q + g.n);                           // contig bases missing from the reference: new positions behind the unit (AG:974-1040; SI = 0)
+                    if (gap) {
+                        const size_t p0 = cnt.size();
+                        if (p0 + gap >= 0xFFFFFF00ull) return false;
+                        add_run((agx_u32)p0, gap, g.q + g.n, 0u, g.q + g.n - i0);
+                        cnt.insert(cnt.end(), gap, (agx_u8)1);
+                        appended.resize(appended.size() + gap);                        // (filled below with the oriented bases)
+                    }
+                }
+            }
+            // the chain's bases: the contig's bases i0 .. i_last in the placement's orientation, the last one replaced by the reference base under the terminal conti-mer (AG:1129, 1143)
+            const std::string &nuc = q.bases();
+            const size_t at = str.size(); str.resize(at + ch.n_elem);
+            if (!rc) memcpy(&str[at], nuc.data() + i0, ch.n_elem);
+            else for (agx_u32 j = 0; j < ch.n_elem; j++) str[at + j] = comp_base(nuc[len - 1 - (i0 + j)]);
+            {   // appended positions carry the contig bases of the gaps
+                size_t w = appended.size();
+                for (size_t b = pl.blk.size() - 1; b-- > 0;) { const agx_run &g = pl.blk[b], &nx = pl.blk[b + 1]; const agx_u32 gap = nx.q - (g.q + g.n); if (gap) { w -= gap; memcpy(&appended[w], &str[at + (g.q + g.n - i0)], gap); } }
+            }
+            str[at + ch.n_elem - 1] = T.ref[ch.end_pos];
+            ch.seg_n = segs.size() - ch.seg_first;
+            n_cm += ch.n_elem;
+            chains.push_back(ch);
+        }
+    }
+    if (n_cm >= 0xFFFFFFFFull) return false;
+    tt[3] = now_ms();
+    // ---- the chains in build_chains()' order (by head position, then rank), their runs, then the runs in the device's order ----
+    std::vector<size_t> order(chains.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return chains[a].head_pos != chains[b].head_pos ? chains[a].head_pos < chains[b].head_pos : chains[a].head_rank < chains[b].head_rank; });
+    T.chain_off.assign(1, 0); T.chain_end_pos.clear(); T.chain_str.clear(); T.chain_str.resize(str.size());
+    T.segs.clear(); T.segs.reserve(segs.size()); T.n_seg0 = 0;
+    size_t str_base = 0;
+    for (size_t oi : order) {
+        const Chain &ch = chains[oi];
+        memcpy(&T.chain_str[str_base], &str[ch.str_at], ch.n_elem);
+        for (size_t g = ch.seg_first; g < ch.seg_first + ch.seg_n; g++) {
+            agx_cmseg s = segs[g];
+            s.hop_str0 += (agx_u32)str_base; s.hop_len0 = (ch.n_elem - 1) - s.hop_len0; s.hop_end = ch.end_pos;
+            T.segs.push_back(s);
+        }
+        str_base += ch.n_elem;
+        T.chain_end_pos.push_back(ch.end_pos); T.chain_off.push_back(str_base);
+    }
+    std::stable_sort(T.segs.begin(), T.segs.end(), [](const agx_cmseg &a, const agx_cmseg &b) { return (a.rank != 0) != (b.rank != 0) ? a.rank == 0 : (a.rank == 0 && a.pos0 < b.pos0); });
+    { agx_u32 e = 0; for (agx_cmseg &g : T.segs) { g.elem0 = e; e += g.len; if (g.rank == 0) T.n_seg0++; } if (e != n_cm) return false; }
+    T.n_ref = n_ref; T.ref.append(appended);
+    T.cm_cnt.swap(cnt); T.n_cm = n_cm; T.cm_start.clear(); T.cm.clear(); T.hop.clear();
+    tt[4] = now_ms();
+    // ---- tmp/_initial_contigs.<u>.fa, AG:1179-1216 ----
+    T.initial_contigs.clear();
+    {
+        size_t total_bytes = 0;
+        struct Group { size_t first, n; int placed; };
+        std::vector<Group> groups; int id_bak = -1;
+        for (size_t i = 0; i < cs.size(); i++) {
+            if (groups.empty() || cs[i].real_id != id_bak) { groups.push_back(Group{i, 0, 0}); id_bak = cs[i].real_id; }
+            groups.back().n++; groups.back().placed += cs[i].placed;
+        }
+        for (const Group &g : groups) if ((double)g.placed / (double)g.n >= 0.5) for (size_t i = g.first; i < g.first + g.n; i++) total_bytes += (size_t)(cs[i].end - cs[i].body) + 16;
+        T.initial_contigs.reserve(total_bytes + 64);
+        std::string joined;
+        for (size_t gi = 0; gi < groups.size(); gi++) {
+            const Group &g = groups[gi];
+            if ((double)g.placed / (double)g.n < 0.5) continue;
+            T.initial_contigs += ">" + std::to_string(gi) + "\n";
+            if (g.n == 1 && cs[g.first].wrapped60()) { T.initial_contigs.append(cs[g.first].body, (size_t)(cs[g.first].end - cs[g.first].body)); continue; }
+            joined.clear(); for (size_t i = g.first; i < g.first + g.n; i++) joined += cs[i].bases();
+            fasta_body(T.initial_contigs, joined.data(), joined.size());
+        }
+    }
+    if (g_timing) fprintf(stderr, "[agx load] contigs (fast): scan %.1f ms, psl %.1f ms, threading %.1f ms, order %.1f ms, initial %.1f ms\n", tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], now_ms() - tt[4]);
+    return true;
+}
+
+// ---- read alignments ----------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// 2-bit classes of one row: `len` bases at src (file orientation), quarter = stride / 4 bytes at dst; bases that are not A, C, G, T are listed
+inline void pack_row(const char *src, size_t len, agx_u8 *dst, size_t quarter, unsigned long long row_base, std::vector<unsigned long long> &other) {
+    size_t j = 0;
+    for (; j + 4 <= len; j += 4) {
+        const agx_u32 c0 = agx_base_class((agx_u8)src[j]), c1 = agx_base_class((agx_u8)src[j + 1]), c2 = agx_base_class((agx_u8)src[j + 2]), c3 = agx_base_class((agx_u8)src[j + 3]);
+        dst[j >> 2] = (agx_u8)((c0 & 3u) | ((c1 & 3u) << 2) | ((c2 & 3u) << 4) | ((c3 & 3u) << 6));
+        if ((c0 | c1 | c2 | c3) & 4u) { if (c0 == 4u) other.push_back(row_base + j); if (c1 == 4u) other.push_back(row_base + j + 1); if (c2 == 4u) other.push_back(row_base + j + 2); if (c3 == 4u) other.push_back(row_base + j + 3); }
+    }
+    if (j < len) {
+        agx_u32 b = 0;
+        for (size_t i = j; i < len; i++) { const agx_u32 c = agx_base_class((agx_u8)src[i]); b |= (c & 3u) << (2 * (i - j)); if (c == 4u) other.push_back(row_base + i); }
+        dst[j >> 2] = (agx_u8)b; j += 4;
+    }
+    for (size_t b = j >> 2; b < quarter; b++) dst[b] = 0;                 // (the general path pads the row with 'N': class 4, packed as 0)
+}
+
+}  // namespace
+
+// The general path's staging of the read alignments (what agx_engine.cpp's stage_inputs did inline): hits as they are, except that slot1 becomes
+// the ROW of the left mate's bases and pad[0] says which mate that is; one row of 2-bit classes per (pair, left mate), first come.
+void stage_pairs(const Pairs &P, agx_u32 k, unsigned threads, StageSink &sink, StagedPairs &S) {
+    S = StagedPairs();
+    const size_t nh = P.hits.size(), n_runs = P.runs.size();
+    if (P.stride & 15u) throw Error{E_ARG, "read stride must be a multiple of 16"};
+    S.nh = nh; S.n_runs = n_runs; S.stride = P.stride; S.n_pairs_in_file = P.n_pairs_in_file; S.n_sam_pairs = P.n_sam_pairs;
+    S.hits = (agx_hit *)sink.take(SA_HITS, (nh + 1) * sizeof(agx_hit)); S.runs = (agx_run *)sink.take(SA_RUNS, (n_runs + 1) * sizeof(agx_run));
+    for (const agx_hit &h : P.hits) S.maxlen = std::max<agx_u32>(S.maxlen, h.len);
+    const agx_run *runs = P.runs.data();
+    Team team(std::max(1u, threads));
+    const unsigned T = team.size();
+    team.run([&](unsigned t) {
+        for (size_t i = nh * t / T, hi = nh * (t + 1) / T; i < hi; i++) {
+            agx_hit h = P.hits[i];
+            h.pad[0] = agx_hit_left_is_mate2(h, runs, k) ? 1 : 0; h.pad[1] = h.pad[2] = 0;
+            S.hits[i] = h;
+        }
+        const size_t lo = n_runs * t / T, hi = n_runs * (t + 1) / T; if (hi > lo) memcpy(S.runs + lo, runs + lo, (hi - lo) * sizeof(agx_run));
+    });
+    std::vector<agx_u16> row_len;                       // read length of every row: bases beyond it are never looked at
+    {
+        std::vector<agx_u32> row_of((size_t)P.n_slots + 1, AGX_NONE);
+        S.row_slot.reserve(P.n_slots / 2 + 16); row_len.reserve(P.n_slots / 2 + 16);
+        for (size_t i = 0; i < nh; i++) {
+            agx_hit &h = S.hits[i];
+            const agx_u32 sa = h.slot1 + (h.pad[0] & 1u);
+            if (sa >= P.n_slots) throw Error{E_ARG, "hit names a read slot outside the unit"};
+            if (row_of[sa] == AGX_NONE) { row_of[sa] = (agx_u32)S.row_slot.size(); S.row_slot.push_back(sa); row_len.push_back(h.len); }
+            else if (row_len[row_of[sa]] < h.len) row_len[row_of[sa]] = h.len;
+            h.slot1 = row_of[sa];
+        }
+    }
+    const size_t quarter = P.stride / 4, n_rows = S.row_slot.size();
+    S.n_rows = (agx_u32)n_rows; S.n_codes = n_rows * quarter;
+    S.codes = (agx_u8 *)sink.take(SA_CODES, S.n_codes + 16);
+    const char *bases = P.bases.data();
+    std::vector<std::vector<unsigned long long>> other(T);
+    team.run([&](unsigned t) {
+        for (size_t r = n_rows * t / T, hi = n_rows * (t + 1) / T; r < hi; r++)
+            pack_row(bases + (size_t)S.row_slot[r] * P.stride, std::min<size_t>(row_len[r], P.stride), S.codes + r * quarter, quarter, (unsigned long long)r * P.stride, other[t]);
+    });
+    for (const auto &o : other) S.n_other += o.size();
+    S.other = (unsigned long long *)sink.take(SA_OTHER, (S.n_other + 1) * 8);
+    { size_t at = 0; for (const auto &o : other) { if (!o.empty()) memcpy(S.other + at, o.data(), o.size() * 8); at += o.size(); } }      // (threads take ascending row ranges: the list is sorted)
+}
+
+// loadReadAlignment's parsing half (loadSeq AG:361-404, loadReadAli AG:1233-1277 with parseBOWTIE AG:181-285 and updateContig AG:763-815) and the
+// staging, in one go.  See the head of the file.
+bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long batch, agx_u32 k, unsigned threads, StageSink &sink, StagedPairs &S) {
+    S = StagedPairs();
+    double tt[8]; tt[0] = now_ms();
+    FileView sf(sam_path);
+    if (batch <= 0) batch = 1000000;
+    const long long N = (long long)(reads.headers / 2), B = batch;
+    if (N == 0 || sf.n == 0 || k >= 32768) return false;
+    S.n_pairs_in_file = (unsigned long long)N;
+    struct Range {
+        const char *lo = nullptr, *hi = nullptr; size_t lines = 0; bool odd = false, bad = false;
+        std::vector<agx_u32> ids;                         // read id of every line pair that starts here
+        std::vector<agx_hit> cand; std::vector<agx_u32> cand_pair; std::vector<agx_run> runs;      // pairs that pass the identity filter: slot1 = read id, run indices local; which pair each is
+        size_t pair_base = 0;                             // global index of the first pair
+        // after the batch rule (phase C): what stays, in final form but local numbering
+        size_t n_keep = 0, n_runs = 0, lead_n = 0; agx_u32 maxlen = 0;
+        agx_u32 lead_rows = 0, n_rows_local = 0;          // rows opened by the leading group (the hits of the range's first read id), and by the whole range, as if nothing came before
+        agx_u32 last_id = 0, last_count = 0; agx_u32 last_row[2] = {AGX_NONE, AGX_NONE};      // the range's last group: kept hits, rows of its mates (local numbering)
+        bool single_group = false, lead_fixed = false;
+        size_t hit_base = 0, run_base = 0; agx_u32 row_base = 0, row_shift = 0;               // row_shift: rows the leading group did not have to open after all (C3)
+        std::vector<unsigned long long> other;
+    };
+    Team team(std::max(1u, threads));
+    const unsigned T = team.size();
+    std::vector<Range> R(T);
+    const char *fb = sf.p, *fe = sf.p + sf.n;
+    auto line_start_at_or_after = [&](const char *c) -> const char * {
+        if (c <= fb) return fb;
+        const char *nl = (const char *)memchr(c - 1, '\n', (size_t)(fe - (c - 1)));
+        return nl ? nl + 1 : fe;
+    };
+    for (unsigned t = 0; t < T; t++) R[t].lo = line_start_at_or_after(fb + sf.n / T * t);
+    for (unsigned t = 0; t < T; t++) R[t].hi = t + 1 < T ? R[t + 1].lo : fe;
+    // ---- phase A: lines per range; '@' lines or an empty line anywhere: not the common case ----
+    team.run([&](unsigned t) {
+        Range &r = R[t]; size_t n = 0; bool at = false;
+        const char *stop = scan_lines(r.lo, r.hi, [&](const char *c) { n++; at |= *c == '@'; });
+        r.lines = n; r.bad = at || stop != r.hi;
+    });
+    { size_t before = 0; for (Range &r : R) { if (r.bad) return false; r.odd = (before & 1) != 0; r.pair_base = (before + 1) / 2; before += r.lines; } if (before & 1) return false; }      // (odd line count: "BROKEN BOWTIE FILE")
+    tt[1] = now_ms();
+    // ---- phase B: parse the line pairs that START in each range; the identity filter (AG:1261); hits in their packed form ----
+    team.run([&](unsigned t) {
+        Range &r = R[t];
+        auto next = [&](const char *&c, const char *&ls, size_t &ln) -> bool {
+            if (c >= fe) return false;
+            const char *nl = (const char *)memchr(c, '\n', (size_t)(fe - c));
+            ls = c; ln = (size_t)((nl ? nl : fe) - c); c = nl ? nl + 1 : fe;
+            return true;
+        };
+        const char *c = r.lo, *ls = r.lo; size_t ln = 0;
+        if (r.odd && !next(c, ls, ln)) return;
+        r.ids.reserve(r.lines / 2 + 1); r.cand.reserve(r.lines / 2 + 1); r.cand_pair.reserve(r.lines / 2 + 1);
+        std::vector<agx_run> tmp; Mate m1, m2;
+        try {
+            while (c < r.hi) {
+                tmp.clear();
+                next(c, ls, ln); parse_sam_line(ls, ln, m1, tmp);
+                if (!next(c, ls, ln)) { r.bad = true; return; }
+                parse_sam_line(ls, ln, m2, tmp);
+                if (!r.ids.empty() && m1.id < r.ids.back()) { r.bad = true; return; }             // ids must not decrease (bowtie2 --reorder)
+                r.ids.push_back(m1.id);
+                if (!(m1.aligned && m2.aligned && passes(m1) && passes(m2))) continue;
+                if (m1.id != m2.id || m1.total != m2.total || m1.total > 65000 || m1.total == 0) { r.bad = true; return; }
+                agx_hit h; memset(&h, 0, sizeof h);
+                h.slot1 = m1.id; h.len = (agx_u16)m1.total; h.rev1 = (agx_u8)m1.fr; h.rev2 = (agx_u8)m2.fr;
+                bool ok = true;
+                auto fill = [&](const Mate &m, agx_u32 &pos, agx_u32 &r0, agx_u16 &nr) {
+                    if (m.nruns == 1 && tmp[m.run0].q == 0 && tmp[m.run0].n == m.total) { pos = tmp[m.run0].t; r0 = 0; nr = 0; return; }
+                    if (m.nruns > 60000) { ok = false; return; }
+                    pos = 0; r0 = (agx_u32)r.runs.size(); nr = (agx_u16)m.nruns;
+                    r.runs.insert(r.runs.end(), tmp.begin() + (long)m.run0, tmp.begin() + (long)(m.run0 + m.nruns));
+                    for (agx_u32 i = 1; i < nr; i++) if (r.runs[r0 + i].t < r.runs[r0 + i - 1].t + r.runs[r0 + i - 1].n) ok = false;
+                };
+                fill(m1, h.pos1, h.runs1, h.nruns1); fill(m2, h.pos2, h.runs2, h.nruns2);
+                if (!ok) { r.bad = true; return; }
+                h.pad[0] = agx_hit_left_is_mate2(h, r.runs.data(), k) ? 1 : 0;                      // the left mate (AG:1672-1679): decided here, where the runs are at hand
+                r.cand.push_back(h); r.cand_pair.push_back((agx_u32)(r.ids.size() - 1));
+            }
+        } catch (const Error &) { r.bad = true; }
+    });
+    for (Range &r : R) if (r.bad) return false;
+    tt[2] = now_ms();
+    // ---- phase C1: the batch rule (AG:361-404, 1258-1259) over the ids, which do not decrease: binary searches instead of a scan ----
+    size_t M = 0; { agx_u32 prev = 0; bool any = false; for (Range &r : R) { if (!r.ids.empty()) { if (any && r.ids.front() < prev) return false; prev = r.ids.back(); any = true; } if (r.pair_base != M) return false; M += r.ids.size(); } }
+    // first pair at or behind `from` whose id is beyond `hi`
+    auto first_beyond = [&](size_t from, long long hi) -> size_t {
+        for (unsigned t = 0; t < T; t++) {
+            const Range &r = R[t];
+            if (r.ids.empty() || r.pair_base + r.ids.size() <= from) continue;
+            if ((long long)r.ids.back() <= hi) continue;
+            const size_t lo_i = from > r.pair_base ? from - r.pair_base : 0;
+            const auto it = hi < 0 ? r.ids.begin() + (long)lo_i : std::upper_bound(r.ids.begin() + (long)lo_i, r.ids.end(), (agx_u32)std::min<long long>(hi, 0xFFFFFFFFll));
+            if (it != r.ids.end()) return r.pair_base + (size_t)(it - r.ids.begin());
+        }
+        return M;
+    };
+    std::vector<std::pair<size_t, size_t>> dead;          // [from, to) pair indices that leave nothing behind
+    size_t consumed = M;
+    {
+        long long lo = 0, hi = std::min<long long>(B, N) - 1;
+        bool final_batch = hi == N - 1 && N % B != 0;
+        size_t pos = 0;
+        for (;;) {
+            const size_t j = first_beyond(pos, hi);
+            if (lo > hi && j > pos) dead.emplace_back(pos, j);      // the empty last batch skips everything (AG:1258)
+            if (j >= M) break;
+            if (final_batch) { consumed = j + 1; dead.emplace_back(j, M); break; }      // AG:1259 in the last batch: the scan ends
+            dead.emplace_back(j, j + 1);                                                  // AG:1259: this line pair is consumed and lost; the next batch begins
+            lo = hi + 1; hi = std::min<long long>(lo + B, N) - 1;
+            final_batch = lo == N || (hi == N - 1 && N % B != 0);
+            pos = j + 1;
+        }
+    }
+    S.n_sam_pairs = consumed;
+    tt[3] = now_ms();
+    // ---- phase C2: what stays of every range; per pair: hits so far (agx_hit::back), rows of read bases — one per (pair, left mate), opened by the
+    //      first hit that needs it — numbered as if nothing came before the range ----
+    team.run([&](unsigned t) {
+        Range &r = R[t];
+        size_t w = 0;
+        {   // drop the dead pairs' hits; their runs stay in the local pool and are simply never copied
+            size_t d = 0;
+            for (size_t i = 0; i < r.cand.size(); i++) {
+                const size_t gp = r.pair_base + r.cand_pair[i];
+                while (d < dead.size() && dead[d].second <= gp) d++;
+                if (d < dead.size() && dead[d].first <= gp) continue;
+                r.cand[w++] = r.cand[i];
+            }
+            r.cand.resize(w); r.cand_pair.assign(w, 0);          // from here on: the hit's row (low 31 bits) and whether it opens it (bit 31)
+        }
+        r.n_keep = w;
+        if (!w) return;
+        agx_u32 cur = r.cand[0].slot1, count = 0, row[2] = {AGX_NONE, AGX_NONE}, rows = 0; bool lead = true; agx_u16 cur_len = r.cand[0].len;
+        for (size_t i = 0; i < w; i++) {
+            agx_hit &h = r.cand[i];
+            if (h.slot1 != cur) {
+                if (lead) { r.lead_n = i; r.lead_rows = rows; lead = false; }
+                cur = h.slot1; count = 0; row[0] = row[1] = AGX_NONE; cur_len = h.len;
+            }
+            if (h.len != cur_len || count > 250) { r.bad = true; return; }      // "hits of one pair disagree on the read length", "more than 250 hits for one pair"
+            h.back = (agx_u8)count; count++;
+            const unsigned m = h.pad[0] & 1u;
+            agx_u32 info = 0;
+            if (row[m] == AGX_NONE) { row[m] = rows++; info = 0x80000000u; }
+            r.cand_pair[i] = info | row[m];
+            r.n_runs += (size_t)h.nruns1 + h.nruns2;
+            r.maxlen = std::max<agx_u32>(r.maxlen, h.len);
+        }
+        if (lead) { r.lead_n = w; r.lead_rows = rows; r.single_group = true; }
+        r.n_rows_local = rows;
+        r.last_id = cur; r.last_count = count; r.last_row[0] = row[0]; r.last_row[1] = row[1];
+    });
+    for (Range &r : R) if (r.bad) return false;
+    // ---- phase C3 (sequential, a few operations per range): where every range's hits, runs and rows go; a pair whose hits straddle a range boundary ----
+    size_t nh = 0, n_runs = 0; agx_u32 n_rows = 0, maxlen = 0;
+    {
+        bool have = false; agx_u32 c_id = 0, c_count = 0, c_row[2] = {AGX_NONE, AGX_NONE}; agx_u16 c_len = 0;      // the pair the ranges so far ended with: its kept hits, the rows of its mates (final numbering)
+        for (Range &r : R) {
+            r.hit_base = nh; r.run_base = n_runs; r.row_base = n_rows; r.row_shift = 0; r.lead_fixed = false;
+            nh += r.n_keep; n_runs += r.n_runs; maxlen = std::max(maxlen, r.maxlen);
+            if (!r.n_keep) continue;
+            const bool joins = have && c_id == r.cand[0].slot1;
+            agx_u32 lead_row[2] = {AGX_NONE, AGX_NONE};
+            if (joins) {                                   // the leading group continues the previous ranges' last pair: its hits counted on, rows that exist are used
+                lead_row[0] = c_row[0]; lead_row[1] = c_row[1];
+                agx_u32 opened = 0;
+                for (size_t i = 0; i < r.lead_n; i++) {
+                    agx_hit &h = r.cand[i];
+                    const unsigned cnt = c_count + (unsigned)i;
+                    if (cnt > 250 || h.len != c_len) return false;
+                    h.back = (agx_u8)cnt;
+                    const unsigned m = h.pad[0] & 1u;
+                    agx_u32 info = 0;
+                    if (lead_row[m] == AGX_NONE) { lead_row[m] = r.row_base + opened++; info = 0x80000000u; }
+                    r.cand_pair[i] = info | lead_row[m];
+                }
+                r.lead_fixed = true; r.row_shift = r.lead_rows - opened;
+            } else {
+                for (size_t i = 0; i < r.lead_n; i++) { const unsigned m = r.cand[i].pad[0] & 1u; if (lead_row[m] == AGX_NONE) lead_row[m] = r.row_base + (r.cand_pair[i] & 0x7FFFFFFFu); }
+            }
+            n_rows += r.n_rows_local - r.row_shift;
+            if (r.single_group) { c_count = (joins ? c_count : 0) + (agx_u32)r.lead_n; c_row[0] = lead_row[0]; c_row[1] = lead_row[1]; }
+            else { c_count = r.last_count; for (int m = 0; m < 2; m++) c_row[m] = r.last_row[m] == AGX_NONE ? AGX_NONE : r.row_base + r.last_row[m] - r.row_shift; }
+            c_id = r.last_id; c_len = r.cand[r.n_keep - 1].len;
+            have = true;
+        }
+    }
+    if (nh == 0) {          // nothing kept: what the general loader leaves (no rows, stride 0)
+        S.hits = (agx_hit *)sink.take(SA_HITS, sizeof(agx_hit)); S.runs = (agx_run *)sink.take(SA_RUNS, sizeof(agx_run));
+        S.codes = (agx_u8 *)sink.take(SA_CODES, 16); S.other = (unsigned long long *)sink.take(SA_OTHER, 8);
+        return true;
+    }
+    if (n_runs >= 0xFFFFFFFFull) return false;
+    const agx_u32 stride = (maxlen + 15u) & ~15u; const size_t quarter = stride / 4;
+    S.nh = nh; S.n_runs = n_runs; S.stride = stride; S.maxlen = maxlen; S.n_rows = n_rows; S.n_codes = (size_t)n_rows * quarter;
+    S.hits = (agx_hit *)sink.take(SA_HITS, (nh + 1) * sizeof(agx_hit)); S.runs = (agx_run *)sink.take(SA_RUNS, (n_runs + 1) * sizeof(agx_run));
+    S.codes = (agx_u8 *)sink.take(SA_CODES, S.n_codes + 16);
+    S.row_off.assign(n_rows, 0);
+    tt[4] = now_ms();
+    // ---- phase D: hits and runs to their final places; the left mates' bases from the reads file, as 2-bit classes, by the hit that opens the row ----
+    const char *rb = reads.fv.p, *re = reads.fv.p + reads.fv.n;
+    team.run([&](unsigned t) {
+        Range &r = R[t];
+        size_t run_at = r.run_base;
+        for (size_t i = 0; i < r.n_keep; i++) {
+            agx_hit h = r.cand[i];
+            const agx_u32 id = h.slot1, info = r.cand_pair[i];
+            const bool opens = (info & 0x80000000u) != 0;
+            const agx_u32 row = (r.lead_fixed && i < r.lead_n) ? (info & 0x7FFFFFFFu) : r.row_base + (info & 0x7FFFFFFFu) - r.row_shift;
+            const unsigned m = h.pad[0] & 1u;
+            if (h.nruns1) { memcpy(S.runs + run_at, r.runs.data() + h.runs1, (size_t)h.nruns1 * sizeof(agx_run)); h.runs1 = (agx_u32)run_at; run_at += h.nruns1; }
+            if (h.nruns2) { memcpy(S.runs + run_at, r.runs.data() + h.runs2, (size_t)h.nruns2 * sizeof(agx_run)); h.runs2 = (agx_u32)run_at; run_at += h.nruns2; }
+            h.slot1 = row; h.pad[1] = h.pad[2] = 0;
+            S.hits[r.hit_base + i] = h;
+            if (!opens) continue;
+            // both mates' records are looked at (the general loader checks both), the left mate's bases are packed
+            const unsigned long long r0 = 2ull * id;
+            if (r0 + 1 >= reads.rec_off.size()) { r.bad = true; return; }
+            for (unsigned mate = 0; mate < 2; mate++) {
+                const char *c = rb + reads.rec_off[r0 + mate];
+                if (c >= re || *c != '>') { r.bad = true; return; }
+                const char *nl = (const char *)memchr(c, '\n', (size_t)(re - c));
+                if (!nl || nl + 1 >= re) { r.bad = true; return; }
+                const char *ls = nl + 1, *nl2 = (const char *)memchr(ls, '\n', (size_t)(re - ls));
+                const size_t ln = (size_t)((nl2 ? nl2 : re) - ls);
+                if (ln == 0 || ln != h.len) { r.bad = true; return; }
+                if (mate == m) { S.row_off[row] = (uint64_t)(ls - rb); pack_row(ls, ln, S.codes + (size_t)row * quarter, quarter, (unsigned long long)row * stride, r.other); }
+            }
+        }
+    });
+    for (Range &r : R) if (r.bad) return false;
+    for (const Range &r : R) S.n_other += r.other.size();
+    S.other = (unsigned long long *)sink.take(SA_OTHER, (S.n_other + 1) * 8);
+    {   // rows ascend with the ranges, except that a leading group may have filled a row that an earlier range opened: sort if that happened
+        size_t at = 0; bool sorted = true; unsigned long long prev = 0;
+        for (const Range &r : R) { for (unsigned long long v : r.other) { if (v < prev) sorted = false; prev = v; S.other[at++] = v; } }
+        if (!sorted) std::sort(S.other, S.other + S.n_other);
+    }
+    if (g_timing) fprintf(stderr, "[agx load] SAM (fast) on %u threads: line count %.1f ms, parse %.1f ms, batch rule %.1f ms, groups %.1f ms, place + read bases %.1f ms\n", T, tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], now_ms() - tt[4]);
+    return true;
+}
+
+}  // namespace agx

@@ -1,0 +1,106 @@
+// agx_parse.h — line-level parsers shared by the general loader (agx_host.cpp) and the fast loader (agx_load.cpp).  Internal.
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "agx_host.h"
+
+namespace agx {
+namespace {
+
+// getline + `if(buf[0]==0) break` of the reference: an empty line ends the input
+struct LineReader {
+    const char *p, *e; bool saw_empty = false;
+    LineReader(const char *b, size_t n) : p(b), e(b + n) {}
+    bool next(const char *&s, size_t &len) {
+        if (p >= e) { saw_empty = true; return false; }    // (callers that care check the last byte themselves)
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+        const char *le = nl ? nl : e;
+        s = p; len = (size_t)(le - p); p = nl ? nl + 1 : e;
+        if (len == 0 || s[0] == 0) { saw_empty = true; return false; }
+        return true;
+    }
+};
+
+inline int to_int(const char *s, size_t n) {      // atoi semantics on a bounded field
+    size_t i = 0; while (i < n && (s[i] == ' ' || (s[i] >= 9 && s[i] <= 13))) i++;
+    bool neg = false; if (i < n && (s[i] == '-' || s[i] == '+')) { neg = s[i] == '-'; i++; }
+    long long v = 0; for (; i < n && s[i] >= '0' && s[i] <= '9'; i++) { v = v * 10 + (s[i] - '0'); if (v > 0x7fffffffffffLL) break; }
+    return (int)(neg ? -v : v);
+}
+
+inline void rc_inplace(std::string &s) {
+    std::reverse(s.begin(), s.end());
+    for (auto &c : s) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+}
+
+inline void fasta_body(std::string &out, const char *s, size_t n) {
+    for (size_t i = 0; i < n; i += 60) { const size_t m = n - i < 60 ? n - i : 60; out.append(s + i, m); out.push_back('\n'); }
+}
+
+struct Psl { agx_u32 tID, tStart, tEnd, tGap, sID, sStart, sEnd, sGap, sSize, fr; };
+
+void parse_psl_line(const char *s, size_t n, Psl &r, std::vector<agx_run> &seg) {
+    const char *f[21]; size_t fl[21]; int nf = 0; const char *b = s, *e = s + n;
+    for (const char *c = s; c <= e && nf < 21; c++) if (c == e || *c == '\t') { f[nf] = b; fl[nf] = (size_t)(c - b); nf++; b = c + 1; }
+    for (; nf < 21; nf++) { f[nf] = e; fl[nf] = 0; }
+    seg.clear();
+    for (int col = 18; col <= 20; col++) {
+        size_t sp = 0; const char *st = f[col];
+        for (const char *c = f[col]; c < f[col] + fl[col]; c++) if (*c == ',') {
+            const agx_u32 v = (agx_u32)to_int(st, (size_t)(c - st)); st = c + 1;
+            if (col == 18) seg.push_back(agx_run{AGX_NONE, AGX_NONE, v});
+            else if (sp < seg.size()) { if (col == 19) seg[sp].q = v; else seg[sp].t = v; }
+            sp++;
+        }
+    }
+    r.fr = fl[8] ? (f[8][0] == '+' ? 0u : 1u) : AGX_NONE;
+    r.tID = (agx_u32)to_int(f[13], fl[13]); r.tStart = (agx_u32)to_int(f[15], fl[15]); r.tEnd = (agx_u32)to_int(f[16], fl[16]);
+    r.tGap = (agx_u32)to_int(f[7], fl[7]); r.sStart = (agx_u32)to_int(f[11], fl[11]); r.sEnd = (agx_u32)to_int(f[12], fl[12]);
+    r.sGap = (agx_u32)to_int(f[5], fl[5]); r.sSize = (agx_u32)to_int(f[10], fl[10]);
+    size_t dot = 0; while (dot < fl[9] && f[9][dot] != '.') dot++;
+    r.sID = (agx_u32)to_int(f[9], dot);
+}
+
+struct Mate { agx_u32 id; agx_u32 fr; bool aligned; agx_u32 pos0; agx_u32 total, ins, del, clipL, clipR; size_t run0; agx_u32 nruns; };
+
+// parseBOWTIE, AG:181-285; M runs are appended to `runs`
+void parse_sam_line(const char *s, size_t n, Mate &m, std::vector<agx_run> &runs) {
+    const char *f[6]; size_t fl[6]; int nf = 0; const char *b = s, *e = s + n;
+    for (const char *c = s; nf < 6; c++) {
+        if (c >= e || *c == '\t') { f[nf] = b; fl[nf] = (size_t)((c < e ? c : e) - b); nf++; b = c + 1; if (c >= e) break; }
+    }
+    for (; nf < 6; nf++) { f[nf] = e; fl[nf] = 0; }
+    m.id = (agx_u32)to_int(f[0], fl[0]);
+    m.fr = (to_int(f[1], fl[1]) & 0x10) ? 1u : 0u;
+    m.run0 = runs.size(); m.nruns = 0; m.total = m.ins = m.del = m.clipL = m.clipR = 0; m.pos0 = 0;
+    m.aligned = !(fl[2] > 0 && f[2][0] == '*');
+    if (!m.aligned) return;
+    size_t dot = 0; while (dot < fl[2] && f[2][dot] != '.') dot++;
+    if (dot != fl[2] && to_int(f[2], dot) != 0) throw Error{E_UNSUPPORTED, "SAM RNAME does not resolve to the unit sequence"};
+    const int pos1 = to_int(f[3], fl[3]);
+    int ins = 0, del = 0, total = 0, start = 0, end = 0, first = 1, num = 0;
+    for (size_t i = 0; i < fl[5]; i++) {
+        const char c = f[5][i];
+        if (c >= '0' && c <= '9') { num = num * 10 + (c - '0'); continue; }
+        if (c == 'I') { ins += num; total += num; }
+        else if (c == 'D') del += num;
+        else if (c == 'M') { if (num > 0) { runs.push_back(agx_run{(agx_u32)total, (agx_u32)(pos1 + total + del - start - ins - 1), (agx_u32)num}); m.nruns++; } total += num; first = 0; }
+        else if (c == 'S' && first) { start = num; total += num; first = 0; }
+        else if (c == 'S') { end = num; total += num; }
+        else if (c != '*') throw Error{E_FORMAT, std::string("unknown character: ") + c};
+        num = 0;
+    }
+    m.total = (agx_u32)total; m.ins = (agx_u32)ins; m.del = (agx_u32)del; m.clipL = (agx_u32)start; m.clipR = (agx_u32)end; m.pos0 = (agx_u32)(pos1 - 1);
+}
+
+// the identity filter of loadReadAli, AG:1261, in the reference's unsigned arithmetic
+inline bool passes(const Mate &m) {
+    const agx_u32 sEnd = m.total - m.clipR, tEnd = m.pos0 + (m.total + m.del - m.ins);
+    return (double)(agx_u32)(sEnd - m.clipL - m.ins) / m.total >= 0.6 && (double)(agx_u32)(tEnd - m.pos0 - m.del) / (agx_u32)(tEnd - m.pos0) >= 0.6;
+}
+
+
+}  // namespace
+}  // namespace agx

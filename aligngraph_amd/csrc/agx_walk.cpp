@@ -279,8 +279,17 @@ struct Walker {
     agx_hop hop_of(agx_u32 v, agx_u32 x) const {
         const agx_u32 r = G.sp_hop ? rank_of(v) : AGX_NONE;
         if (r != AGX_NONE) return G.sp_hop[r];
-        if (!V.hop) throw Error{E_ARG, "no hop entry for a position outside the sparse table"};
-        return V.hop[x];
+        if (V.hop) return V.hop[x];
+        // no per-position table (units from the fast loader or a cache file): the entry from the conti-mer runs, as the device computes it for the special ids
+        agx_hop h{0, 0, 0};
+        if (!V.segs || V.n_seg0 == 0 || V.cm_count(x) != 1) return h;
+        agx_u32 lo = 0, hi = V.n_seg0;                          // last rank-0 run with pos0 <= x
+        while (hi - lo > 1) { const agx_u32 mid = lo + (hi - lo) / 2; if (V.segs[mid].pos0 <= x) lo = mid; else hi = mid; }
+        const agx_cmseg &g = V.segs[lo];
+        const agx_u32 j = x - g.pos0;
+        if (x < g.pos0 || j >= g.len || j >= g.hop_len0) return h;
+        h.str_off = g.hop_str0 + j; h.len = g.hop_len0 - j; h.end_pos = g.hop_end;
+        return h;
     }
     agx_walknode node(agx_u32 v) const {
         const agx_u32 at = rank_of(v);
@@ -338,7 +347,7 @@ struct Walker {
         const agx_sref r = node(v).sref;
         const agx_u32 first = r.qlen & 0xFFFFu, len = (r.qlen >> 16) & 0x7FFFu; const bool rev = (r.qlen >> 31) != 0;
         out.clear();
-        const char *p = V.bases + (size_t)(G.row_slot ? G.row_slot[r.slot] : r.slot) * V.stride;
+        const char *p = V.row_off ? V.bases + V.row_off[r.slot] : V.bases + (size_t)(G.row_slot ? G.row_slot[r.slot] : r.slot) * V.stride;
         for (agx_u32 i = 0; i < len; i++) {
             if (!rev) out.push_back(p[first + i]);
             else { const char c = p[first - i]; out.push_back(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c); }
@@ -767,7 +776,7 @@ void scaffold(const UnitView &V, const GraphView &G, std::vector<Rec> &c, OutBuf
                 if (!(c[cp].eID0 == c[q].sID && c[q].sID == c[q].eID && overlaps(c[cp].sOff0, c[cp].eOff0, c[q].sOff, c[q].eOff) && c[q].extended == 1)) continue;
                 if (c[q].sOff > c[cp].eOff) {
                     const agx_u32 gap = c[q].sOff - c[cp].eOff - 1; agx_u32 covered = 0;
-                    for (agx_u32 i = 0; i < gap; i++) { const agx_u32 x = c[cp].eOff + i + 1; if ((G.meta[x] & AGX_WM_ANY) || V.cm_start[x + 1] > V.cm_start[x]) covered++; }
+                    for (agx_u32 i = 0; i < gap; i++) { const agx_u32 x = c[cp].eOff + i + 1; if ((G.meta[x] & AGX_WM_ANY) || V.has_cm(x)) covered++; }
                     if (gap == 0 || (double)(int)covered / gap >= 0.5) sc.back().add(V.ref + c[cp].eOff + 1, gap);
                     else continue;
                 }
@@ -852,10 +861,12 @@ void build_chains(Threads &T) {
     agx_u32 e = 0;
     for (agx_cmseg &g : T.segs) { g.elem0 = e; e += g.len; if (g.rank == 0) T.n_seg0++; }
     if (e != n) throw Error{E_ARG, "conti-mer runs do not cover the conti-mers"};
+    T.n_cm = n; T.cm_cnt.resize(n_pos);
+    for (size_t x = 0; x < n_pos; x++) { const agx_u32 c = T.cm_start[x + 1] - T.cm_start[x]; if (c > 255) throw Error{E_UNSUPPORTED, "more than 255 conti-mers at one position"}; T.cm_cnt[x] = (agx_u8)c; }
 }
 
 void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out, Assistant *assistant) {
-    if (!V.hop && !G.sp_hop) throw Error{E_ARG, "conti-mer chains were not built"};
+    if (!V.hop && !G.sp_hop && !V.segs) throw Error{E_ARG, "conti-mer chains were not built"};
     const bool timing = getenv("AGX_WALK_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double ts = now();

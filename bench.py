@@ -179,15 +179,19 @@ def main():
     unit_len = D.read_meta(run)["unit_len"]
     n_units = len(unit_len)
     mine = shard.plan(unit_len, rank, world)                               # longest-first onto the least loaded rank, longest first within the rank
+    t1 = time.perf_counter()
     reads = A.Reads(os.path.join(tmp, "_reads.fa")) if mine else None      # tmp/_reads.fa mapped and indexed once for all units (agx_reads)
+    t_index = time.perf_counter() - t1
     units, t_parse, t_stage, t_cached = {}, 0.0, 0.0, 0.0
-    parse_threads = max(1, min(len(mine), 4))                              # units parsed side by side, as AlignGraph_amd builds their caches (4 at a time)
-    stage_s = {}
+    parse_threads = max(1, min(len(mine), 8))                              # units loaded side by side (each on its share of the cores: agx_host.cpp loader_threads)
+    stage_s, load_ms = {}, {}
 
     def parse_unit(uu):
         un = A.Unit(k=k, insert_variation=50, coverage=args.coverage, device=local_rank)
         un.load_files(tmp, uu, reads=reads)                                # text -> packed arrays, staged in pinned memory (T_unit - T_core)
-        stage_s[uu] = un.stats()["ms_stage"] * 1e-3
+        st = un.stats()
+        stage_s[uu] = st["ms_stage"] * 1e-3
+        load_ms[uu] = {"contigs": round(st["ms_thread"], 1), "read_alignments": round(st["ms_parse"], 1), "rest": round(st["ms_stage"], 1)}
         return un
 
     os.environ["AGX_NO_CACHE"] = "1"
@@ -386,7 +390,10 @@ def main():
                        "parallelism": "units sharded longest-first over %d GPU%s, one RCCL gather of extended contigs per job" % (world, "" if world == 1 else "s")},
             "t_core_s": round(sec_per_step, 4),
             "t_unit_s": round(sec_per_step + t_parse_max, 4),
-            "t_unit_note": "t_core_s + text parsing and staging of the per-unit input files (slowest rank; up to 4 units side by side, each on up to 8 threads: %.2f s)" % t_parse_max,
+            "t_unit_note": "t_core_s + text parsing and staging of the per-unit input files: the five text files of every unit -> staged arrays in pinned memory (slowest rank; its units side by side, each on its share of the cores: %.3f s); the one-off index of tmp/_reads.fa (%.3f s on rank 0, shared by all units of a run) is not in it" % (t_parse_max, t_index),
+            "load_ms_per_unit": {str(uu): load_ms[uu] for uu in mine},
+            "load_note": "per unit, wall: contigs = unit sequence + contig threading (on a thread of its own, beside the read alignments); read_alignments = SAM parsing, left-mate decision, rows of 2-bit read bases straight into the pinned upload buffers; rest = what the load took beyond the read alignments",
+            "reads_index_s": round(t_index, 3),
             "value_t_unit": round(reads_per_step / (sec_per_step + t_parse_max), 1),
             "t_unit_cached_s": round(sec_per_step + t_cached_max, 4),
             "t_unit_cached_note": "t_core_s + loading every unit from its binary cache file (tmp/_agx_unit.<u>.bin, written where the alignments are distributed; up to 4 units side by side: %.3f s) instead of parsing text — what the timed steps' units were loaded from" % t_cached_max,

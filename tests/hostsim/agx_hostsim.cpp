@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -315,3 +316,76 @@ void agx_hostsim_free(agx_hostsim_result *r) {
 }
 
 }  // extern "C"
+
+// ---- fast loaders against the general loaders (tests/test_fast_loader.py) -----------------------------------------------------------------
+// Loads one unit's text files both ways and compares everything the engine takes from either.  Returns a bit mask of which fast loader declined
+// (1: contig threading, 2: read alignments; both are then served by the general path in the product), or a negative number with a message when
+// the two disagree — including "the general loader reports an error and the fast one accepts the input".
+namespace {
+struct VecSink : StageSink { std::vector<char> buf[SA_N]; void *take(int w, size_t b) override { buf[w].assign(b + 64, 0); return buf[w].data(); } };
+}
+extern "C" int agx_hostsim_compare_loaders(const char *tmp_dir, int unit, int k, long batch, int threads, char *msg, size_t msg_len) {
+    auto say = [&](const std::string &m) { if (msg && msg_len) snprintf(msg, msg_len, "%s", m.c_str()); };
+    say("");
+    const std::string d = tmp_dir, s = std::to_string(unit);
+    int declined = 0;
+    try {
+        // ---- contigs ----
+        Threads T1, T2; bool slow_ok = true; std::string slow_err;
+        std::string ref;
+        try { load_unit_reference(d + "/_genome." + s + ".fa", ref); } catch (const Error &e) { say("genome: " + e.msg); return 64; }
+        T1.ref = ref; T2.ref = ref;
+        try { thread_contigs_from_files(d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", T1); } catch (const Error &e) { slow_ok = false; slow_err = e.msg; }
+        bool fast_ok = false;
+        try { fast_ok = thread_contigs_fast(d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", T2); } catch (const Error &e) { if (slow_ok) { say("fast contig threading threw: " + e.msg); return -1; } }
+        if (!slow_ok && fast_ok) { say("general contig threading fails (" + slow_err + ") but the fast one accepts the input"); return -2; }
+        if (!fast_ok) { declined |= 1; if (T2.ref != ref) { say("fast contig threading declined but changed the reference"); return -3; } }
+        if (slow_ok && fast_ok) {
+            auto bad = [&](const char *what) { say(std::string("contig threading differs: ") + what); return -10; };
+            if (T1.ref != T2.ref) return bad("ref");
+            if (T1.n_ref != T2.n_ref) return bad("n_ref");
+            if (T1.n_cm != T2.n_cm) return bad("n_cm");
+            if (T1.cm_cnt != T2.cm_cnt) return bad("cm_cnt");
+            if (T1.n_seg0 != T2.n_seg0) return bad("n_seg0");
+            if (T1.segs.size() != T2.segs.size()) return bad("number of runs");
+            for (size_t i = 0; i < T1.segs.size(); i++) if (memcmp(&T1.segs[i], &T2.segs[i], sizeof(agx_cmseg)) != 0) { char b[256]; const agx_cmseg &x = T1.segs[i], &y = T2.segs[i];
+                snprintf(b, sizeof b, "run %zu: general (pos0 %u len %u cid %u coff0 %u dcoff %u rank %u str0 %u len0 %u end %u elem0 %u) fast (%u %u %u %u %u %u %u %u %u %u)", i,
+                         x.pos0, x.len, x.cid, x.coff0, x.dcoff, x.rank, x.hop_str0, x.hop_len0, x.hop_end, x.elem0, y.pos0, y.len, y.cid, y.coff0, y.dcoff, y.rank, y.hop_str0, y.hop_len0, y.hop_end, y.elem0); return bad(b); }
+            if (T1.chain_str != T2.chain_str) return bad("chain_str");
+            if (T1.chain_off != T2.chain_off) return bad("chain_off");
+            if (T1.chain_end_pos != T2.chain_end_pos) return bad("chain_end_pos");
+            if (T1.initial_contigs != T2.initial_contigs) return bad("initial_contigs");
+        }
+        // ---- read alignments ----
+        std::unique_ptr<ReadsIndex, void (*)(ReadsIndex *)> ri(nullptr, reads_index_close);
+        try { ri.reset(reads_index_open(d + "/_reads.fa")); } catch (const Error &e) { say("reads: " + e.msg); return 64; }
+        Pairs P; VecSink A, B; StagedPairs SA, SB; slow_ok = true;
+        try { load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie", batch, (agx_u32)k, P, ri.get()); stage_pairs(P, (agx_u32)k, (unsigned)threads, A, SA); } catch (const Error &e) { slow_ok = false; slow_err = e.msg; }
+        fast_ok = false;
+        try { fast_ok = load_pairs_fast(*ri, d + "/_reads_genome." + s + ".bowtie", batch, (agx_u32)k, (unsigned)threads, B, SB); } catch (const Error &e) { if (slow_ok) { say("fast read loader threw: " + e.msg); return -4; } }
+        if (!slow_ok && fast_ok) { say("general read loader fails (" + slow_err + ") but the fast one accepts the input"); return -5; }
+        if (!fast_ok) declined |= 2;
+        if (slow_ok && fast_ok) {
+            auto bad = [&](const std::string &what) { say("read alignments differ: " + what); return -20; };
+            if (SA.nh != SB.nh) return bad("number of hits " + std::to_string(SA.nh) + " / " + std::to_string(SB.nh));
+            if (SA.n_runs != SB.n_runs) return bad("number of runs");
+            if (SA.n_sam_pairs != SB.n_sam_pairs) return bad("n_sam_pairs " + std::to_string(SA.n_sam_pairs) + " / " + std::to_string(SB.n_sam_pairs));
+            if (SA.n_pairs_in_file != SB.n_pairs_in_file) return bad("n_pairs_in_file");
+            if (SA.nh) { if (SA.stride != SB.stride) return bad("stride");
+            if (SA.maxlen != SB.maxlen) return bad("maxlen"); };
+            if (SA.n_rows != SB.n_rows) return bad("rows " + std::to_string(SA.n_rows) + " / " + std::to_string(SB.n_rows));
+            for (size_t i = 0; i < SA.nh; i++) if (memcmp(&SA.hits[i], &SB.hits[i], sizeof(agx_hit)) != 0) { char b[256]; const agx_hit &x = SA.hits[i], &y = SB.hits[i];
+                snprintf(b, sizeof b, "hit %zu: general (row %u pos %u %u runs %u+%u %u+%u len %u rev %u%u back %u left %u) fast (row %u pos %u %u runs %u+%u %u+%u len %u rev %u%u back %u left %u)", i,
+                         x.slot1, x.pos1, x.pos2, x.runs1, x.nruns1, x.runs2, x.nruns2, x.len, x.rev1, x.rev2, x.back, x.pad[0], y.slot1, y.pos1, y.pos2, y.runs1, y.nruns1, y.runs2, y.nruns2, y.len, y.rev1, y.rev2, y.back, y.pad[0]); return bad(b); }
+            if (SA.n_runs && memcmp(SA.runs, SB.runs, SA.n_runs * sizeof(agx_run)) != 0) return bad("runs");
+            if (SA.n_codes != SB.n_codes || (SA.n_codes && memcmp(SA.codes, SB.codes, SA.n_codes) != 0)) return bad("codes");
+            if (SA.n_other != SB.n_other || (SA.n_other && memcmp(SA.other, SB.other, SA.n_other * 8) != 0)) return bad("list of other bases");
+            std::vector<agx_u16> row_len(SA.n_rows, 0);
+            for (size_t i = 0; i < SA.nh; i++) row_len[SA.hits[i].slot1] = std::max(row_len[SA.hits[i].slot1], SA.hits[i].len);
+            if (SB.row_off.size() != SA.n_rows || SA.row_slot.size() != SA.n_rows) return bad("row tables");
+            for (size_t r = 0; r < SA.n_rows; r++) if (memcmp(P.bases.data() + (size_t)SA.row_slot[r] * P.stride, ri->fv.p + SB.row_off[r], row_len[r]) != 0) return bad("bases of row " + std::to_string(r));
+        }
+    } catch (const Error &e) { say("unexpected: " + e.msg); return -99; }
+    catch (const std::exception &e) { say(std::string("unexpected: ") + e.what()); return -99; }
+    return declined;
+}

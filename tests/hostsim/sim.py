@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libagx_hostsim.so")
 SRC = [os.path.join(HERE, "agx_hostsim.cpp"), os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_host.cpp"),
-       os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_walk.cpp")]
-DEPS = SRC + [os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_core.h"), os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_host.h")]
+       os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_walk.cpp"), os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_load.cpp")]
+DEPS = SRC + [os.path.join(ROOT, "aligngraph_amd", "csrc", h) for h in ("agx_core.h", "agx_host.h", "agx_parse.h")]
 
 
 def build():
@@ -73,3 +73,16 @@ def run(tmp_dir, unit, k=5, insert_variation=50, coverage=20, batch=1000000, max
         }
     _lib.agx_hostsim_free(ctypes.byref(r))
     return out
+
+
+def compare_loaders(tmp_dir, unit, k=5, batch=1000000, threads=4):
+    """Fast loaders (agx_load.cpp) against the general loaders on one unit's text files: returns the bit mask of fast loaders that declined
+    (1 contigs, 2 read alignments); raises SimError when the two disagree."""
+    build()
+    lib = ctypes.CDLL(LIB)
+    lib.agx_hostsim_compare_loaders.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    msg = ctypes.create_string_buffer(1024)
+    rc = lib.agx_hostsim_compare_loaders(tmp_dir.encode(), unit, k, batch, threads, msg, 1024)
+    if rc < 0 or rc >= 64:
+        raise SimError(rc, msg.value.decode())
+    return rc
