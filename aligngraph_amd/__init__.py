@@ -312,3 +312,17 @@ def run_unit(tmp_dir, unit, k=5, insert_variation=50, coverage=20, batch=0, devi
     if rc != AGX_OK:
         raise AgxError(rc, err.value.decode(errors="replace"))
     return _take(r)
+
+
+def usable_cpus():
+    """CPUs this process can keep busy: its affinity mask capped by the CPU quota of its control group (cgroup v2 cpu.max) — what the loaders size
+    their thread teams by (agx_host.cpp: usable_cpus)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    return n

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
+#include <map>
 #include <memory>
 #include <system_error>
 #include <thread>
@@ -79,7 +80,7 @@ void advise_huge(void *p, size_t n) {
 void load_unit_reference(const std::string &path, std::string &ref) {
     FileView fv(path); LineReader in(fv.p, fv.n);
     const char *s; size_t n; int records = 0;
-    ref.clear(); ref.reserve(fv.n);
+    { std::string fresh; fresh.reserve(fv.n + fv.n / 64 + 4096); advise_huge(&fresh[0], fresh.capacity()); ref.swap(fresh); }      // (room for the positions contig threading appends; huge pages: 30 MB of fresh 4 KB pages cost more than reading the file)
     while (in.next(s, n)) {
         if (s[0] == '>') { if (++records > 1) throw Error{E_UNSUPPORTED, "unit genome file holds more than one record"}; continue; }
         if (!records) throw Error{E_FORMAT, "unit genome file has no header line"};
@@ -219,16 +220,27 @@ void thread_contigs_from_files(const std::string &contigs_fa, const std::string 
 // loadReadAlignment's parsing half: batches of `batch` pairs (AG:37, 361-404), SAM line pairs (AG:1233-1277)
 // One pass over tmp/_reads.fa: where every line pair (header, sequence) starts, up to the first empty line (which ends the file for
 // the reference's getline loops), and how many header lines there are (what decides the batch boundaries, AG:361-404).
+// CPUs this process can keep busy: its affinity mask, capped by the CPU quota of its control group (cgroup v2 cpu.max "quota period": a container
+// on a 256-thread host may be allowed 16 CPUs' worth of time per period — threads beyond that only take turns being throttled)
 unsigned usable_cpus() {
-    cpu_set_t set; CPU_ZERO(&set);
-    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int n = CPU_COUNT(&set); if (n > 0) return (unsigned)n; }
-    return std::max(1u, std::thread::hardware_concurrency());
+    static const unsigned cached = [] {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set; CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = (unsigned)c; }
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64]; long long period = 0;
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { const long long quota = atoll(q); if (quota > 0) n = (unsigned)std::max<long long>(1, std::min<long long>(n, (quota + period - 1) / period)); }
+            fclose(f);
+        }
+        return n;
+    }();
+    return cached;
 }
 // A unit's loader runs beside the loaders of the other units in flight (AlignGraph_amd: four; bench.py: all of a rank's units): a quarter of the
-// cores this process may use each, between 8 and 32, and no more than one per 2 MB of input.
+// CPUs this process can keep busy each, between 4 and 32, and no more than one per 2 MB of input.
 unsigned loader_threads(size_t bytes) {
     if (const char *e = getenv("AGX_LOAD_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(e)));      // tests force the multi-thread paths on small files
-    const unsigned cores = usable_cpus(), share = std::min(32u, std::max(8u, cores / 4));
+    const unsigned cores = usable_cpus(), share = std::min(32u, std::max(4u, cores / 4));
     return (unsigned)std::min<size_t>(std::min(share, cores), bytes / (2u << 20) + 1);
 }
 // fn(t) on `threads` threads.  Nothing may leave a worker thread as an exception (it would terminate the process behind a C ABI that promises
@@ -486,6 +498,39 @@ void load_pairs_from_files(const std::string &reads_fa, const std::string &sam_p
         }
     });
     for (unsigned t = 0; t < copy_threads; t++) if (bad[t] != (size_t)-1) throw bad_err[t];      // ranges are in slot order: the first failure in file order
+}
+
+// ---- Scratch ------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct ScratchCache {
+    std::mutex m; std::multimap<size_t, void *> free_; size_t held = 0;
+    static size_t limit() { static const size_t l = getenv("AGX_SCRATCH_CACHE_MB") ? (size_t)atoll(getenv("AGX_SCRATCH_CACHE_MB")) << 20 : (size_t)16 << 30; return l; }
+};
+ScratchCache &scratch_cache() { static ScratchCache *c = new ScratchCache; return *c; }      // (never destroyed: worker threads may still give memory back at exit)
+inline size_t scratch_round(size_t n) { size_t c = (size_t)2 << 20; while (c < n) c <<= 1; return c; }
+}  // namespace
+void Scratch::take(size_t bytes) {
+    give();
+    const size_t need = scratch_round(bytes ? bytes : 1);
+    ScratchCache &C = scratch_cache();
+    { std::lock_guard<std::mutex> l(C.m); auto it = C.free_.find(need); if (it != C.free_.end()) { p = it->second; n = need; C.held -= need; C.free_.erase(it); return; } }
+    void *m = mmap(nullptr, need, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) throw Error{E_ARG, "out of host memory"};
+    advise_huge(m, need);
+    p = m; n = need;
+}
+void Scratch::give() {
+    if (!p) return;
+    ScratchCache &C = scratch_cache();
+    bool keep;
+    { std::lock_guard<std::mutex> l(C.m); keep = C.held + n <= ScratchCache::limit(); if (keep) { C.free_.emplace(n, p); C.held += n; } }
+    if (!keep) munmap(p, n);
+    p = nullptr; n = 0;
+}
+void scratch_trim() {
+    ScratchCache &C = scratch_cache(); std::vector<std::pair<size_t, void *>> v;
+    { std::lock_guard<std::mutex> l(C.m); for (auto &kv : C.free_) v.push_back(kv); C.free_.clear(); C.held = 0; }
+    for (auto &kv : v) munmap(kv.second, kv.first);
 }
 
 // ---- Team ---------------------------------------------------------------------------------------------------------------------------

@@ -1,5 +1,6 @@
 // agx_host.h — host-side containers shared by the loader, the engine and the walk.
 #pragma once
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -135,6 +136,33 @@ public:
 private:
     struct Impl; Impl *impl_; unsigned n_;
 };
+// Scratch memory of the loaders: anonymous mappings, huge pages asked for, kept in a process-wide cache when they are given back (a unit's
+// loader touches as much temporary memory as it produces output; fresh 4 KB pages cost it more than the parsing itself, and 160 threads faulting
+// them in at once wait for each other on the address-space lock — the next unit finds the pages of the last one already there).
+struct Scratch {
+    void *p = nullptr; size_t n = 0;
+    Scratch() = default; explicit Scratch(size_t bytes) { take(bytes); }
+    ~Scratch() { give(); }
+    Scratch(const Scratch &) = delete; Scratch &operator=(const Scratch &) = delete;
+    Scratch(Scratch &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    Scratch &operator=(Scratch &&o) noexcept { if (this != &o) { give(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    void take(size_t bytes); void give();
+};
+void scratch_trim();      // unmaps what the cache holds
+// fixed-capacity array in scratch memory (the capacity is an upper bound known before the fill; grow() for the rare case that it was a guess)
+template <class T> struct SBuf {
+    Scratch s; T *p = nullptr; size_t n = 0, cap = 0;
+    SBuf() = default;
+    SBuf(SBuf &&o) noexcept : s(std::move(o.s)), p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    SBuf &operator=(SBuf &&o) noexcept { if (this != &o) { s = std::move(o.s); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; } return *this; }
+    void reserve(size_t c) { if (c <= cap) return; Scratch m(c * sizeof(T) + 64); if (n) memcpy(m.p, p, n * sizeof(T)); s = std::move(m); p = (T *)s.p; cap = c; }
+    void push_back(const T &v) { if (n == cap) reserve(cap ? cap * 2 : 1024); p[n++] = v; }
+    void append(const T *src, size_t k) { if (n + k > cap) reserve(std::max(cap * 2, n + k)); memcpy(p + n, src, k * sizeof(T)); n += k; }
+    T &operator[](size_t i) { return p[i]; } const T &operator[](size_t i) const { return p[i]; }
+    T &back() { return p[n - 1]; } const T &back() const { return p[n - 1]; } size_t size() const { return n; } bool empty() const { return n == 0; } void resize_down(size_t k) { n = k; }
+    T *begin() { return p; } T *end() { return p + n; } const T *begin() const { return p; } const T *end() const { return p + n; } T *data() { return p; } const T *data() const { return p; }
+};
+
 unsigned loader_threads(size_t bytes);      // AGX_LOAD_THREADS, else by the size of the input and the cores this process may use
 
 // agx_load.cpp — the fast loaders.  Each returns false when the input is anything but the well-formed common case (an '@' line, an empty line in the

@@ -20,9 +20,11 @@
 #include "agx_host.h"
 #include "agx_parse.h"
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <sys/mman.h>
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -110,22 +112,30 @@ inline bool any_at_least(const agx_u8 *p, size_t n, agx_u8 v) { agx_u8 m = 0; fo
 struct ContigRec {
     const char *hdr = nullptr, *body = nullptr, *end = nullptr;     // header line, first byte behind it, end of the record's lines
     int real_id = 0; size_t len = (size_t)-1;                       // bases (body bytes that are not '\n'), counted when first asked for
-    std::string nuc; bool have_nuc = false;                         // the bases without the line breaks, made when first asked for
+    const char *nuc = nullptr;                                      // the bases without the line breaks (in the caller's arena), made when first asked for
     int placed = 0;
     size_t length() { if (len == (size_t)-1) len = (size_t)(end - body) - count_newlines(body, end); return len; }
-    const std::string &bases() {
-        if (!have_nuc) {
-            nuc.resize(length()); char *w = &nuc[0];
+    const char *bases(SBuf<char> &arena) {      // (the arena is sized for every contig that can be asked for: it never moves)
+        if (!nuc) {
+            char *w = arena.p + arena.n; nuc = w; arena.n += length();
+            if (wrapped60()) {          // 60 bases and a line break, over and over: copies of a fixed size instead of a search for every line end
+                const size_t n = length(), full = n / 60; const char *c = body;
+                for (size_t l = 0; l < full; l++, c += 61, w += 60) memcpy(w, c, 60);
+                if (n % 60) memcpy(w, c, n % 60);
+            } else
             for (const char *c = body; c < end;) { const char *nl = (const char *)memchr(c, '\n', (size_t)(end - c)); const size_t m = (size_t)((nl ? nl : end) - c); memcpy(w, c, m); w += m; c = nl ? nl + 1 : end; }
-            have_nuc = true;
         }
         return nuc;
     }
     // the record's lines are already what fasta_body() would write for its bases: 60 per line, every line ended
+    int w60 = -1;
     bool wrapped60() {
+        if (w60 >= 0) return w60 != 0;
         const size_t n = length(), lines = (n + 59) / 60;
+        w60 = 0;
         if ((size_t)(end - body) != n + lines) return false;
         for (size_t l = 0; l < lines; l++) { const size_t at = l + 1 < lines ? (l + 1) * 61 - 1 : n + lines - 1; if (body[at] != '\n') return false; }
+        w60 = 1;
         return true;
     }
 };
@@ -198,14 +208,18 @@ bool thread_contigs_fast(const std::string &contigs_fa, const std::string &psl_p
     }
     tt[2] = now_ms();
     // ---- updateGenomeWithContig, AG:884-1217, a block at a time ----
-    struct Chain { agx_u32 head_pos, head_rank, end_pos, n_elem; size_t seg_first, seg_n, str_at; };
-    std::vector<Chain> chains; std::vector<agx_cmseg> segs; std::string str;             // str: the chains' bases in threading order
-    std::vector<agx_u8> cnt(n_ref, 0);
-    std::string appended;
+    struct Chain { agx_u32 head_pos, head_rank, end_pos, n_elem, sp, i0; bool rc; size_t seg_first, seg_n; };
+    std::vector<Chain> chains; std::vector<agx_cmseg> segs;
+    size_t placed_bases = 0, group_bases = 0;
+    for (size_t sp = 0; sp < cs.size(); sp++) if (!sets[sp].empty()) placed_bases += cs[sp].length();
+    // conti-mers per position, in place in T.cm_cnt (fresh memory, huge pages asked for; room for the positions that contig insertions append)
+    std::vector<agx_u8> &cnt = T.cm_cnt;
+    { std::vector<agx_u8> fresh; fresh.reserve((size_t)n_ref + placed_bases / 8 + 4096); advise_huge(fresh.data(), fresh.capacity()); fresh.assign(n_ref, 0); cnt.swap(fresh); }
+    struct Gap { agx_u32 sp, q0, n; bool rc; };            // contig bases that became new positions, in the order the positions were appended
+    std::vector<Gap> gaps; size_t n_appended = 0;
     size_t n_cm = 0;
-    { size_t bases = 0; for (size_t sp = 0; sp < cs.size(); sp++) if (!sets[sp].empty()) bases += cs[sp].length(); str.reserve(bases + 16); cnt.reserve((size_t)n_ref + bases / 16 + 16); }
-    std::string oriented;
-    for (size_t sp = 0; sp < cs.size(); sp++) {
+    bool failed = false;
+    for (size_t sp = 0; sp < cs.size() && !failed; sp++) {
         std::vector<Place> &ps = sets[sp];
         if (ps.empty()) continue;
         ContigRec &q = cs[sp];
@@ -214,7 +228,7 @@ bool thread_contigs_fast(const std::string &contigs_fa, const std::string &psl_p
         auto set0 = [&](const Place &pl) -> agx_u32 { return !pl.blk.empty() && pl.blk[0].q == 0 ? pl.blk[0].t : AGX_NONE; };
         for (size_t pp = 0; pp < ps.size(); pp++) {
             const Place &pl = ps[pp];
-            if (pl.blk.empty()) return false;
+            if (pl.blk.empty()) { failed = true; break; }
             bool skip = false;
             for (size_t e = 0; e < pp && !skip; e++) skip = agx_absdiff(set0(pl), set0(ps[e])) < (int)len;                       // AG:902-907
             for (size_t b = 0; b < pl.blk.size() && !skip; b++) {                                                                // AG:908-920: bases 0 .. len-2
@@ -222,13 +236,13 @@ bool thread_contigs_fast(const std::string &contigs_fa, const std::string &psl_p
                 skip = n && any_at_least(&cnt[g.t], n, 2);
             }
             if (skip) continue;
-            if (pl.blk[0].q + 1 >= len) return false;            // no aligned base below len-1: the reference then works with what the previous placement left behind
-            if (pl.fr != 0 && pl.fr != 1) return false;
+            if (pl.blk[0].q + 1 >= len) { failed = true; break; }      // no aligned base below len-1: the reference then works with what the previous placement left behind
+            if (pl.fr != 0 && pl.fr != 1) { failed = true; break; }
             const bool rc = pl.fr == 1;
             q.placed = 1;
             const agx_u32 i0 = pl.blk[0].q, i_last = pl.blk.back().q + pl.blk.back().n - 1;
             const bool trailing = (size_t)i_last + 1 < len;      // the contig's last bases are unaligned: the terminal conti-mer sits on the last aligned base's position
-            Chain ch; ch.seg_first = segs.size(); ch.str_at = str.size(); ch.n_elem = i_last - i0 + 1;
+            Chain ch; ch.seg_first = segs.size(); ch.n_elem = i_last - i0 + 1; ch.sp = (agx_u32)sp; ch.i0 = i0; ch.rc = rc; ch.head_pos = ch.head_rank = ch.end_pos = 0;
             // one element of the chain: the join rule of build_chains()
             auto add_elem = [&](agx_u32 pos, agx_u32 coff, agx_u32 rank, agx_u32 idx) {
                 agx_cmseg *g = segs.size() > ch.seg_first ? &segs.back() : nullptr;
@@ -247,22 +261,23 @@ bool thread_contigs_fast(const std::string &contigs_fa, const std::string &psl_p
                 if (j < n) segs.back().len += n - j;
             };
             bool first = true;
-            for (size_t b = 0; b < pl.blk.size(); b++) {
+            for (size_t b = 0; b < pl.blk.size() && !failed; b++) {
                 const agx_run &g = pl.blk[b];
                 const bool last_blk = b + 1 == pl.blk.size();
                 const agx_u32 n_run = last_blk && trailing ? g.n - 1 : g.n;          // (trailing: the last aligned base's element is the terminal one, with the contig's LAST offset)
                 for (agx_u32 j = 0; j < n_run;) {                                      // stretches of equal count = equal rank
                     const agx_u32 c = cnt[g.t + j]; const agx_u32 m = (agx_u32)run_same(&cnt[g.t + j], n_run - j);
-                    if (c >= 250) return false;
+                    if (c >= 250) { failed = true; break; }
                     if (first) { ch.head_pos = g.t + j; ch.head_rank = c; first = false; }
                     add_run(g.t + j, m, g.q + j, c, g.q + j - i0);
                     j += m;
                 }
-                for (agx_u32 j = 0; j < n_run; j++) cnt[g.t + j]++;
+                if (failed) break;
+                { agx_u8 *pc = &cnt[g.t]; for (agx_u32 j = 0; j < n_run; j++) pc[j]++; }
                 if (last_blk) {
                     if (trailing) {
                         const agx_u32 pos = g.t + g.n - 1, c = cnt[pos];
-                        if (c >= 250) return false;
+                        if (c >= 250) { failed = true; break; }
                         if (first) { ch.head_pos = pos; ch.head_rank = c; first = false; }
                         add_elem(pos, (agx_u32)(len - 1), c, i_last - i0); cnt[pos]++;
                         ch.end_pos = pos;
@@ -272,76 +287,81 @@ bool thread_contigs_fast(const std::string &contigs_fa, const std::string &psl_p
                     const agx_u32 gap = nx.q - (g.q + g.n);                           // contig bases missing from the reference: new positions behind the unit (AG:974-1040; SI = 0)
                     if (gap) {
                         const size_t p0 = cnt.size();
-                        if (p0 + gap >= 0xFFFFFF00ull) return false;
+                        if (p0 + gap >= 0xFFFFFF00ull) { failed = true; break; }
                         add_run((agx_u32)p0, gap, g.q + g.n, 0u, g.q + g.n - i0);
                         cnt.insert(cnt.end(), gap, (agx_u8)1);
-                        appended.resize(appended.size() + gap);                        // (filled below with the oriented bases)
+                        gaps.push_back(Gap{(agx_u32)sp, g.q + g.n, gap, rc}); n_appended += gap;
                     }
                 }
             }
-            // the chain's bases: the contig's bases i0 .. i_last in the placement's orientation, the last one replaced by the reference base under the terminal conti-mer (AG:1129, 1143)
-            const std::string &nuc = q.bases();
-            const size_t at = str.size(); str.resize(at + ch.n_elem);
-            if (!rc) memcpy(&str[at], nuc.data() + i0, ch.n_elem);
-            else for (agx_u32 j = 0; j < ch.n_elem; j++) str[at + j] = comp_base(nuc[len - 1 - (i0 + j)]);
-            {   // appended positions carry the contig bases of the gaps
-                size_t w = appended.size();
-                for (size_t b = pl.blk.size() - 1; b-- > 0;) { const agx_run &g = pl.blk[b], &nx = pl.blk[b + 1]; const agx_u32 gap = nx.q - (g.q + g.n); if (gap) { w -= gap; memcpy(&appended[w], &str[at + (g.q + g.n - i0)], gap); } }
-            }
-            str[at + ch.n_elem - 1] = T.ref[ch.end_pos];
+            if (failed) break;
             ch.seg_n = segs.size() - ch.seg_first;
             n_cm += ch.n_elem;
             chains.push_back(ch);
         }
     }
-    if (n_cm >= 0xFFFFFFFFull) return false;
+    if (failed || n_cm >= 0xFFFFFFFFull) { T.cm_cnt.clear(); return false; }
     tt[3] = now_ms();
+    // ---- the bases: contigs that were placed (chains, appended positions) and the members of real contigs that will be written, without their line breaks ----
+    struct Group { size_t first, n; int placed; };
+    std::vector<Group> groups;
+    { int id_bak = -1; for (size_t i = 0; i < cs.size(); i++) { if (groups.empty() || cs[i].real_id != id_bak) { groups.push_back(Group{i, 0, 0}); id_bak = cs[i].real_id; } groups.back().n++; groups.back().placed += cs[i].placed; } }
+    for (const Group &g : groups) if (g.n > 1 && (double)g.placed / (double)g.n >= 0.5) for (size_t i = g.first; i < g.first + g.n; i++) if (sets[i].empty()) group_bases += cs[i].length();
+    SBuf<char> arena; arena.reserve(placed_bases + group_bases + 64);
+    // a contig's bases [from, from + n) in the placement's orientation (rc: reverse complement of the stored sequence, AG:854-865)
+    auto oriented = [&](agx_u32 sp, bool rc, size_t from, size_t n, char *dst) {
+        const char *nuc = cs[sp].bases(arena); const size_t len = cs[sp].length();
+        if (!rc) memcpy(dst, nuc + from, n);
+        else for (size_t j = 0; j < n; j++) dst[j] = comp_base(nuc[len - 1 - (from + j)]);
+    };
     // ---- the chains in build_chains()' order (by head position, then rank), their runs, then the runs in the device's order ----
     std::vector<size_t> order(chains.size());
     for (size_t i = 0; i < order.size(); i++) order[i] = i;
     std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return chains[a].head_pos != chains[b].head_pos ? chains[a].head_pos < chains[b].head_pos : chains[a].head_rank < chains[b].head_rank; });
-    T.chain_off.assign(1, 0); T.chain_end_pos.clear(); T.chain_str.clear(); T.chain_str.resize(str.size());
+    T.chain_off.assign(1, 0); T.chain_end_pos.clear();
+    { std::string fresh; fresh.reserve(n_cm + 16); advise_huge(&fresh[0], fresh.capacity()); fresh.resize(n_cm); T.chain_str.swap(fresh); }
     T.segs.clear(); T.segs.reserve(segs.size()); T.n_seg0 = 0;
     size_t str_base = 0;
     for (size_t oi : order) {
         const Chain &ch = chains[oi];
-        memcpy(&T.chain_str[str_base], &str[ch.str_at], ch.n_elem);
+        // the contig's bases i0 .. i_last, the last one replaced by the reference base under the terminal conti-mer (AG:1129, 1143)
+        oriented(ch.sp, ch.rc, ch.i0, ch.n_elem, &T.chain_str[str_base]);
+        T.chain_str[str_base + ch.n_elem - 1] = T.ref[ch.end_pos];
         for (size_t g = ch.seg_first; g < ch.seg_first + ch.seg_n; g++) {
-            agx_cmseg s = segs[g];
-            s.hop_str0 += (agx_u32)str_base; s.hop_len0 = (ch.n_elem - 1) - s.hop_len0; s.hop_end = ch.end_pos;
-            T.segs.push_back(s);
+            agx_cmseg sgm = segs[g];
+            sgm.hop_str0 += (agx_u32)str_base; sgm.hop_len0 = (ch.n_elem - 1) - sgm.hop_len0; sgm.hop_end = ch.end_pos;
+            T.segs.push_back(sgm);
         }
         str_base += ch.n_elem;
         T.chain_end_pos.push_back(ch.end_pos); T.chain_off.push_back(str_base);
     }
     std::stable_sort(T.segs.begin(), T.segs.end(), [](const agx_cmseg &a, const agx_cmseg &b) { return (a.rank != 0) != (b.rank != 0) ? a.rank == 0 : (a.rank == 0 && a.pos0 < b.pos0); });
-    { agx_u32 e = 0; for (agx_cmseg &g : T.segs) { g.elem0 = e; e += g.len; if (g.rank == 0) T.n_seg0++; } if (e != n_cm) return false; }
-    T.n_ref = n_ref; T.ref.append(appended);
-    T.cm_cnt.swap(cnt); T.n_cm = n_cm; T.cm_start.clear(); T.cm.clear(); T.hop.clear();
+    { agx_u32 e = 0; for (agx_cmseg &g : T.segs) { g.elem0 = e; e += g.len; if (g.rank == 0) T.n_seg0++; } if (e != n_cm) { T.cm_cnt.clear(); return false; } }
+    T.n_ref = n_ref;
+    { const size_t at = T.ref.size(); T.ref.resize(at + n_appended); size_t w = at; for (const Gap &g : gaps) { oriented(g.sp, g.rc, g.q0, g.n, &T.ref[w]); w += g.n; } }      // appended positions carry the contig bases of the gaps
+    T.n_cm = n_cm; T.cm_start.clear(); T.cm.clear(); T.hop.clear();
     tt[4] = now_ms();
     // ---- tmp/_initial_contigs.<u>.fa, AG:1179-1216 ----
     T.initial_contigs.clear();
     {
         size_t total_bytes = 0;
-        struct Group { size_t first, n; int placed; };
-        std::vector<Group> groups; int id_bak = -1;
-        for (size_t i = 0; i < cs.size(); i++) {
-            if (groups.empty() || cs[i].real_id != id_bak) { groups.push_back(Group{i, 0, 0}); id_bak = cs[i].real_id; }
-            groups.back().n++; groups.back().placed += cs[i].placed;
-        }
         for (const Group &g : groups) if ((double)g.placed / (double)g.n >= 0.5) for (size_t i = g.first; i < g.first + g.n; i++) total_bytes += (size_t)(cs[i].end - cs[i].body) + 16;
-        T.initial_contigs.reserve(total_bytes + 64);
+        { std::string fresh; fresh.reserve(total_bytes + 64); advise_huge(&fresh[0], fresh.capacity()); T.initial_contigs.swap(fresh); }
         std::string joined;
         for (size_t gi = 0; gi < groups.size(); gi++) {
             const Group &g = groups[gi];
             if ((double)g.placed / (double)g.n < 0.5) continue;
             T.initial_contigs += ">" + std::to_string(gi) + "\n";
             if (g.n == 1 && cs[g.first].wrapped60()) { T.initial_contigs.append(cs[g.first].body, (size_t)(cs[g.first].end - cs[g.first].body)); continue; }
-            joined.clear(); for (size_t i = g.first; i < g.first + g.n; i++) joined += cs[i].bases();
+            joined.clear();
+            for (size_t i = g.first; i < g.first + g.n; i++) {
+                if (g.n > 1 || !sets[i].empty()) joined.append(cs[i].bases(arena), cs[i].length());
+                else { ContigRec &r = cs[i]; for (const char *c = r.body; c < r.end;) { const char *nl = (const char *)memchr(c, '\n', (size_t)(r.end - c)); joined.append(c, (size_t)((nl ? nl : r.end) - c)); c = nl ? nl + 1 : r.end; } }
+            }
             fasta_body(T.initial_contigs, joined.data(), joined.size());
         }
     }
-    if (g_timing) fprintf(stderr, "[agx load] contigs (fast): scan %.1f ms, psl %.1f ms, threading %.1f ms, order %.1f ms, initial %.1f ms\n", tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], now_ms() - tt[4]);
+    if (g_timing) fprintf(stderr, "[agx load] contigs (fast): scan %.1f ms, psl %.1f ms, threading %.1f ms, bases + order %.1f ms, initial %.1f ms\n", tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], now_ms() - tt[4]);
     return true;
 }
 
@@ -349,8 +369,7 @@ bool thread_contigs_fast(const std::string &contigs_fa, const std::string &psl_p
 namespace {
 
 // 2-bit classes of one row: `len` bases at src (file orientation), quarter = stride / 4 bytes at dst; bases that are not A, C, G, T are listed
-inline void pack_row(const char *src, size_t len, agx_u8 *dst, size_t quarter, unsigned long long row_base, std::vector<unsigned long long> &other) {
-    size_t j = 0;
+inline void pack_row_scalar(const char *src, size_t j, size_t len, agx_u8 *dst, size_t quarter, unsigned long long row_base, std::vector<unsigned long long> &other) {
     for (; j + 4 <= len; j += 4) {
         const agx_u32 c0 = agx_base_class((agx_u8)src[j]), c1 = agx_base_class((agx_u8)src[j + 1]), c2 = agx_base_class((agx_u8)src[j + 2]), c3 = agx_base_class((agx_u8)src[j + 3]);
         dst[j >> 2] = (agx_u8)((c0 & 3u) | ((c1 & 3u) << 2) | ((c2 & 3u) << 4) | ((c3 & 3u) << 6));
@@ -363,6 +382,76 @@ inline void pack_row(const char *src, size_t len, agx_u8 *dst, size_t quarter, u
     }
     for (size_t b = j >> 2; b < quarter; b++) dst[b] = 0;                 // (the general path pads the row with 'N': class 4, packed as 0)
 }
+#if defined(__x86_64__)
+// 32 bases per step: agx_base_class() on byte lanes ((c >> 1) & 3 picks the expected letter of "ACTG" by table look-up; equal = that class, else "other"),
+// then four 2-bit classes per byte through two multiply-adds
+__attribute__((target("avx2"))) inline void pack_row_avx2(const char *src, size_t len, agx_u8 *dst, size_t quarter, unsigned long long row_base, std::vector<unsigned long long> &other) {
+    const __m256i letters = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i three = _mm256_set1_epi8(3), one = _mm256_set1_epi8(1), m14 = _mm256_set1_epi16(0x0401), m116 = _mm256_set1_epi32(0x00100001);
+    const __m256i gather = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    size_t j = 0;
+    for (; j + 32 <= len; j += 32) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)(src + j));
+        const __m256i idx = _mm256_and_si256(_mm256_srli_epi16(v, 1), three);
+        const __m256i ok = _mm256_cmpeq_epi8(_mm256_shuffle_epi8(letters, idx), v);
+        const __m256i cls = _mm256_and_si256(_mm256_xor_si256(idx, _mm256_and_si256(_mm256_srli_epi16(idx, 1), one)), ok);
+        const __m256i t32 = _mm256_madd_epi16(_mm256_maddubs_epi16(cls, m14), m116);
+        const __m256i sh = _mm256_shuffle_epi8(t32, gather);
+        const uint32_t lo = (uint32_t)_mm256_extract_epi32(sh, 0), hi = (uint32_t)_mm256_extract_epi32(sh, 4);
+        memcpy(dst + (j >> 2), &lo, 4); memcpy(dst + (j >> 2) + 4, &hi, 4);
+        for (uint32_t bad = ~(uint32_t)_mm256_movemask_epi8(ok); bad; bad &= bad - 1) other.push_back(row_base + j + (unsigned)__builtin_ctz(bad));
+    }
+    pack_row_scalar(src, j, len, dst, quarter, row_base, other);
+}
+#endif
+inline void pack_row(const char *src, size_t len, agx_u8 *dst, size_t quarter, unsigned long long row_base, std::vector<unsigned long long> &other) {
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) { pack_row_avx2(src, len, dst, quarter, row_base, other); return; }
+#endif
+    pack_row_scalar(src, 0, len, dst, quarter, row_base, other);
+}
+
+// One SAM line, the common shape — QNAME, FLAG and POS plain numbers, RNAME without a '.', CIGAR of M, I, D, S — in one forward scan: what parse_sam_line()
+// (agx_parse.h; parseBOWTIE, AG:181-285) computes.  false: anything else; the caller then hands the line to parse_sam_line(), which knows all of it.
+inline bool parse_sam_line_fast(const char *s, const char *e, Mate &m, std::vector<agx_run> &runs) {
+    const char *c = s, *b = s;
+    agx_u32 id = 0; while (c < e && (unsigned)(*c - '0') <= 9u) id = id * 10u + (unsigned)(*c++ - '0');
+    if (c == b || c - b > 9 || c >= e || *c != '\t') return false;
+    b = ++c;
+    agx_u32 flag = 0; while (c < e && (unsigned)(*c - '0') <= 9u) flag = flag * 10u + (unsigned)(*c++ - '0');
+    if (c == b || c - b > 9 || c >= e || *c != '\t') return false;
+    b = ++c;
+    m.id = id; m.fr = (flag & 0x10u) ? 1u : 0u;
+    m.run0 = runs.size(); m.nruns = 0; m.total = m.ins = m.del = m.clipL = m.clipR = 0; m.pos0 = 0;
+    while (c < e && *c != '\t') { if (*c == '.') return false; c++; }
+    m.aligned = !(c > b && *b == '*');
+    if (!m.aligned) return true;
+    if (c >= e) return false;
+    b = ++c;
+    agx_u32 pos1 = 0; while (c < e && (unsigned)(*c - '0') <= 9u) pos1 = pos1 * 10u + (unsigned)(*c++ - '0');
+    if (c == b || c - b > 9 || c >= e || *c != '\t') return false;
+    ++c;
+    while (c < e && *c != '\t') c++;                      // MAPQ
+    if (c >= e) return false;
+    ++c;
+    int ins = 0, del = 0, total = 0, start = 0, end = 0, first = 1, num = 0, digits = 0;
+    for (; c < e && *c != '\t'; c++) {
+        const char ch = *c;
+        if ((unsigned)(ch - '0') <= 9u) { num = num * 10 + (ch - '0'); if (++digits > 8) return false; continue; }
+        if (ch == 'M') { if (num > 0) { runs.push_back(agx_run{(agx_u32)total, (agx_u32)((int)pos1 + total + del - start - ins - 1), (agx_u32)num}); m.nruns++; } total += num; first = 0; }
+        else if (ch == 'I') { ins += num; total += num; }
+        else if (ch == 'D') del += num;
+        else if (ch == 'S' && first) { start = num; total += num; first = 0; }
+        else if (ch == 'S') { end = num; total += num; }
+        else return false;
+        num = 0; digits = 0;
+    }
+    m.total = (agx_u32)total; m.ins = (agx_u32)ins; m.del = (agx_u32)del; m.clipL = (agx_u32)start; m.clipR = (agx_u32)end; m.pos0 = pos1 - 1u;
+    return true;
+}
+// the identity filter (passes(), AG:1261): a mate without indels or clips has both ratios at exactly 1
+inline bool passes_fast(const Mate &m) { return ((m.ins | m.del | m.clipL | m.clipR) == 0 && m.total != 0) || passes(m); }
 
 }  // namespace
 
@@ -423,10 +512,10 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
     const long long N = (long long)(reads.headers / 2), B = batch;
     if (N == 0 || sf.n == 0 || k >= 32768) return false;
     S.n_pairs_in_file = (unsigned long long)N;
-    struct Range {
+    struct alignas(128) Range {      // (one per thread: no two on a cache line)
         const char *lo = nullptr, *hi = nullptr; size_t lines = 0; bool odd = false, bad = false;
-        std::vector<agx_u32> ids;                         // read id of every line pair that starts here
-        std::vector<agx_hit> cand; std::vector<agx_u32> cand_pair; std::vector<agx_run> runs;      // pairs that pass the identity filter: slot1 = read id, run indices local; which pair each is
+        SBuf<agx_u32> ids;                                // read id of every line pair that starts here
+        SBuf<agx_hit> cand; SBuf<agx_u32> cand_pair; SBuf<agx_run> runs;      // pairs that pass the identity filter: slot1 = read id, run indices local; which pair each is
         size_t pair_base = 0;                             // global index of the first pair
         // after the batch rule (phase C): what stays, in final form but local numbering
         size_t n_keep = 0, n_runs = 0, lead_n = 0; agx_u32 maxlen = 0;
@@ -437,8 +526,16 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
         std::vector<unsigned long long> other;
     };
     Team team(std::max(1u, threads));
-    const unsigned T = team.size();
+    const unsigned n_thr = team.size();
+    // More ranges than threads, handed out as threads become free: a thread that shares its core (or lost it for a while) takes fewer of them
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)n_thr * (n_thr > 1 ? 6 : 1), sf.n / (256u << 10) + 1));
     std::vector<Range> R(T);
+    std::vector<double> busy(3 * (size_t)n_thr * 16, 0.0);      // per thread and phase (padded)
+    std::atomic<unsigned> next_range{0};
+    auto each_range = [&](int phase, const std::function<void(Range &)> &fn) {
+        next_range.store(0);
+        team.run([&](unsigned t) { const double a = now_ms(); for (unsigned i; (i = next_range.fetch_add(1)) < T;) fn(R[i]); busy[((size_t)phase * n_thr + t) * 16] = now_ms() - a; });
+    };
     const char *fb = sf.p, *fe = sf.p + sf.n;
     auto line_start_at_or_after = [&](const char *c) -> const char * {
         if (c <= fb) return fb;
@@ -448,16 +545,21 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
     for (unsigned t = 0; t < T; t++) R[t].lo = line_start_at_or_after(fb + sf.n / T * t);
     for (unsigned t = 0; t < T; t++) R[t].hi = t + 1 < T ? R[t + 1].lo : fe;
     // ---- phase A: lines per range; '@' lines or an empty line anywhere: not the common case ----
-    team.run([&](unsigned t) {
-        Range &r = R[t]; size_t n = 0; bool at = false;
+    each_range(0, [&](Range &r) {
+        size_t n = 0; bool at = false;
+#if defined(__linux__)
+        {   // map the range's pages in one call instead of one fault per 64 KB (MADV_POPULATE_READ, Linux 5.14; an older kernel says EINVAL and the scan faults them in)
+            const uintptr_t a = (uintptr_t)r.lo & ~(uintptr_t)4095, z = ((uintptr_t)r.hi + 4095) & ~(uintptr_t)4095;
+            if (z > a) (void)madvise((void *)a, z - a, 22 /* MADV_POPULATE_READ */);
+        }
+#endif
         const char *stop = scan_lines(r.lo, r.hi, [&](const char *c) { n++; at |= *c == '@'; });
         r.lines = n; r.bad = at || stop != r.hi;
     });
     { size_t before = 0; for (Range &r : R) { if (r.bad) return false; r.odd = (before & 1) != 0; r.pair_base = (before + 1) / 2; before += r.lines; } if (before & 1) return false; }      // (odd line count: "BROKEN BOWTIE FILE")
     tt[1] = now_ms();
     // ---- phase B: parse the line pairs that START in each range; the identity filter (AG:1261); hits in their packed form ----
-    team.run([&](unsigned t) {
-        Range &r = R[t];
+    each_range(0, [&](Range &r) {
         auto next = [&](const char *&c, const char *&ls, size_t &ln) -> bool {
             if (c >= fe) return false;
             const char *nl = (const char *)memchr(c, '\n', (size_t)(fe - c));
@@ -466,39 +568,44 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
         };
         const char *c = r.lo, *ls = r.lo; size_t ln = 0;
         if (r.odd && !next(c, ls, ln)) return;
-        r.ids.reserve(r.lines / 2 + 1); r.cand.reserve(r.lines / 2 + 1); r.cand_pair.reserve(r.lines / 2 + 1);
-        std::vector<agx_run> tmp; Mate m1, m2;
+        // (the arrays are filled through locals: the Range structs of neighbouring threads are neighbours in memory)
+        SBuf<agx_u32> ids, cand_pair; SBuf<agx_hit> cand; SBuf<agx_run> runs;
+        ids.reserve(r.lines / 2 + 2); cand.reserve(r.lines / 2 + 2); cand_pair.reserve(r.lines / 2 + 2); runs.reserve(r.lines + 1024);
+        std::vector<agx_run> tmp; tmp.reserve(256); Mate m1, m2;
+        bool bad = false; agx_u32 last_id = 0; bool any = false;
         try {
             while (c < r.hi) {
                 tmp.clear();
-                next(c, ls, ln); parse_sam_line(ls, ln, m1, tmp);
-                if (!next(c, ls, ln)) { r.bad = true; return; }
-                parse_sam_line(ls, ln, m2, tmp);
-                if (!r.ids.empty() && m1.id < r.ids.back()) { r.bad = true; return; }             // ids must not decrease (bowtie2 --reorder)
-                r.ids.push_back(m1.id);
-                if (!(m1.aligned && m2.aligned && passes(m1) && passes(m2))) continue;
-                if (m1.id != m2.id || m1.total != m2.total || m1.total > 65000 || m1.total == 0) { r.bad = true; return; }
+                next(c, ls, ln); if (!parse_sam_line_fast(ls, ls + ln, m1, tmp)) { tmp.clear(); parse_sam_line(ls, ln, m1, tmp); }
+                if (!next(c, ls, ln)) { bad = true; break; }
+                { const size_t keep = tmp.size(); if (!parse_sam_line_fast(ls, ls + ln, m2, tmp)) { tmp.resize(keep); parse_sam_line(ls, ln, m2, tmp); } }
+                if (any && m1.id < last_id) { bad = true; break; }             // ids must not decrease (bowtie2 --reorder)
+                last_id = m1.id; any = true;
+                ids.push_back(m1.id);
+                if (!(m1.aligned && m2.aligned && passes_fast(m1) && passes_fast(m2))) continue;
+                if (m1.id != m2.id || m1.total != m2.total || m1.total > 65000 || m1.total == 0) { bad = true; break; }
                 agx_hit h; memset(&h, 0, sizeof h);
                 h.slot1 = m1.id; h.len = (agx_u16)m1.total; h.rev1 = (agx_u8)m1.fr; h.rev2 = (agx_u8)m2.fr;
                 bool ok = true;
                 auto fill = [&](const Mate &m, agx_u32 &pos, agx_u32 &r0, agx_u16 &nr) {
                     if (m.nruns == 1 && tmp[m.run0].q == 0 && tmp[m.run0].n == m.total) { pos = tmp[m.run0].t; r0 = 0; nr = 0; return; }
                     if (m.nruns > 60000) { ok = false; return; }
-                    pos = 0; r0 = (agx_u32)r.runs.size(); nr = (agx_u16)m.nruns;
-                    r.runs.insert(r.runs.end(), tmp.begin() + (long)m.run0, tmp.begin() + (long)(m.run0 + m.nruns));
-                    for (agx_u32 i = 1; i < nr; i++) if (r.runs[r0 + i].t < r.runs[r0 + i - 1].t + r.runs[r0 + i - 1].n) ok = false;
+                    pos = 0; r0 = (agx_u32)runs.size(); nr = (agx_u16)m.nruns;
+                    runs.append(tmp.data() + m.run0, m.nruns);
+                    for (agx_u32 i = 1; i < nr; i++) if (runs[r0 + i].t < runs[r0 + i - 1].t + runs[r0 + i - 1].n) ok = false;
                 };
                 fill(m1, h.pos1, h.runs1, h.nruns1); fill(m2, h.pos2, h.runs2, h.nruns2);
-                if (!ok) { r.bad = true; return; }
-                h.pad[0] = agx_hit_left_is_mate2(h, r.runs.data(), k) ? 1 : 0;                      // the left mate (AG:1672-1679): decided here, where the runs are at hand
-                r.cand.push_back(h); r.cand_pair.push_back((agx_u32)(r.ids.size() - 1));
+                if (!ok) { bad = true; break; }
+                h.pad[0] = agx_hit_left_is_mate2(h, runs.data(), k) ? 1 : 0;                      // the left mate (AG:1672-1679): decided here, where the runs are at hand
+                cand.push_back(h); cand_pair.push_back((agx_u32)(ids.size() - 1));
             }
-        } catch (const Error &) { r.bad = true; }
+        } catch (const Error &) { bad = true; }
+        r.ids = std::move(ids); r.cand = std::move(cand); r.cand_pair = std::move(cand_pair); r.runs = std::move(runs); r.bad = bad;
     });
     for (Range &r : R) if (r.bad) return false;
     tt[2] = now_ms();
     // ---- phase C1: the batch rule (AG:361-404, 1258-1259) over the ids, which do not decrease: binary searches instead of a scan ----
-    size_t M = 0; { agx_u32 prev = 0; bool any = false; for (Range &r : R) { if (!r.ids.empty()) { if (any && r.ids.front() < prev) return false; prev = r.ids.back(); any = true; } if (r.pair_base != M) return false; M += r.ids.size(); } }
+    size_t M = 0; { agx_u32 prev = 0; bool any = false; for (Range &r : R) { if (!r.ids.empty()) { if (any && r.ids[0] < prev) return false; prev = r.ids.back(); any = true; } if (r.pair_base != M) return false; M += r.ids.size(); } }
     // first pair at or behind `from` whose id is beyond `hi`
     auto first_beyond = [&](size_t from, long long hi) -> size_t {
         for (unsigned t = 0; t < T; t++) {
@@ -506,7 +613,7 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
             if (r.ids.empty() || r.pair_base + r.ids.size() <= from) continue;
             if ((long long)r.ids.back() <= hi) continue;
             const size_t lo_i = from > r.pair_base ? from - r.pair_base : 0;
-            const auto it = hi < 0 ? r.ids.begin() + (long)lo_i : std::upper_bound(r.ids.begin() + (long)lo_i, r.ids.end(), (agx_u32)std::min<long long>(hi, 0xFFFFFFFFll));
+            const agx_u32 *it = hi < 0 ? r.ids.begin() + lo_i : std::upper_bound(r.ids.begin() + lo_i, r.ids.end(), (agx_u32)std::min<long long>(hi, 0xFFFFFFFFll));
             if (it != r.ids.end()) return r.pair_base + (size_t)(it - r.ids.begin());
         }
         return M;
@@ -532,8 +639,7 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
     tt[3] = now_ms();
     // ---- phase C2: what stays of every range; per pair: hits so far (agx_hit::back), rows of read bases — one per (pair, left mate), opened by the
     //      first hit that needs it — numbered as if nothing came before the range ----
-    team.run([&](unsigned t) {
-        Range &r = R[t];
+    each_range(1, [&](Range &r) {
         size_t w = 0;
         {   // drop the dead pairs' hits; their runs stay in the local pool and are simply never copied
             size_t d = 0;
@@ -543,7 +649,7 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
                 if (d < dead.size() && dead[d].first <= gp) continue;
                 r.cand[w++] = r.cand[i];
             }
-            r.cand.resize(w); r.cand_pair.assign(w, 0);          // from here on: the hit's row (low 31 bits) and whether it opens it (bit 31)
+            r.cand.resize_down(w); r.cand_pair.resize_down(w);     // from here on: the hit's row (low 31 bits) and whether it opens it (bit 31)
         }
         r.n_keep = w;
         if (!w) return;
@@ -608,6 +714,7 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
         return true;
     }
     if (n_runs >= 0xFFFFFFFFull) return false;
+    tt[5] = now_ms();
     const agx_u32 stride = (maxlen + 15u) & ~15u; const size_t quarter = stride / 4;
     S.nh = nh; S.n_runs = n_runs; S.stride = stride; S.maxlen = maxlen; S.n_rows = n_rows; S.n_codes = (size_t)n_rows * quarter;
     S.hits = (agx_hit *)sink.take(SA_HITS, (nh + 1) * sizeof(agx_hit)); S.runs = (agx_run *)sink.take(SA_RUNS, (n_runs + 1) * sizeof(agx_run));
@@ -616,10 +723,12 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
     tt[4] = now_ms();
     // ---- phase D: hits and runs to their final places; the left mates' bases from the reads file, as 2-bit classes, by the hit that opens the row ----
     const char *rb = reads.fv.p, *re = reads.fv.p + reads.fv.n;
-    team.run([&](unsigned t) {
-        Range &r = R[t];
+    each_range(2, [&](Range &r) {
         size_t run_at = r.run_base;
         for (size_t i = 0; i < r.n_keep; i++) {
+            // the reads are spread over the whole (mapped) reads file: every row is two cache misses and a TLB miss unless it is asked for ahead of time
+            if (i + 24 < r.n_keep && (r.cand_pair[i + 24] & 0x80000000u)) { const unsigned long long pr = 2ull * r.cand[i + 24].slot1; if (pr + 1 < reads.rec_off.size()) __builtin_prefetch(&reads.rec_off[pr]); }
+            if (i + 12 < r.n_keep && (r.cand_pair[i + 12] & 0x80000000u)) { const unsigned long long pr = 2ull * r.cand[i + 12].slot1; if (pr + 1 < reads.rec_off.size()) { const char *pc = rb + reads.rec_off[pr + (r.cand[i + 12].pad[0] & 1u)]; __builtin_prefetch(pc); __builtin_prefetch(pc + 64); } }
             agx_hit h = r.cand[i];
             const agx_u32 id = h.slot1, info = r.cand_pair[i];
             const bool opens = (info & 0x80000000u) != 0;
@@ -653,7 +762,12 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
         for (const Range &r : R) { for (unsigned long long v : r.other) { if (v < prev) sorted = false; prev = v; S.other[at++] = v; } }
         if (!sorted) std::sort(S.other, S.other + S.n_other);
     }
-    if (g_timing) fprintf(stderr, "[agx load] SAM (fast) on %u threads: line count %.1f ms, parse %.1f ms, batch rule %.1f ms, groups %.1f ms, place + read bases %.1f ms\n", T, tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], now_ms() - tt[4]);
+    if (g_timing) {
+        auto stat = [&](int phase, char *out) { double lo = 1e30, hi = 0, sum = 0; for (unsigned t = 0; t < n_thr; t++) { const double v = busy[((size_t)phase * n_thr + t) * 16]; lo = std::min(lo, v); hi = std::max(hi, v); sum += v; } snprintf(out, 64, "%.1f/%.1f/%.1f", lo, sum / n_thr, hi); };
+        char sb[64], sc[64], sd[64]; stat(0, sb); stat(1, sc); stat(2, sd);
+        fprintf(stderr, "[agx load] SAM (fast) on %u threads: line count %.1f ms, parse %.1f ms (threads min/avg/max %s), batch rule %.1f ms, groups + buffers %.1f ms (threads %s; buffers %.1f), place + read bases %.1f ms (threads %s)\n",
+                n_thr, tt[1] - tt[0], tt[2] - tt[1], sb, tt[3] - tt[2], tt[4] - tt[3], sc, tt[4] - tt[5], now_ms() - tt[4], sd);
+    }
     return true;
 }
 

@@ -195,6 +195,9 @@ def main():
         return un
 
     os.environ["AGX_NO_CACHE"] = "1"
+    cpus = A.usable_cpus()
+    if "AGX_LOAD_THREADS" not in os.environ and mine:                      # the rank's units are loaded side by side: the CPUs this process can keep busy (affinity, cgroup quota) shared between them
+        os.environ["AGX_LOAD_THREADS"] = str(max(2, min(32, cpus // min(len(mine), parse_threads))))
     t1 = time.perf_counter()
     if mine:
         from concurrent.futures import ThreadPoolExecutor
@@ -393,7 +396,7 @@ def main():
             "t_unit_note": "t_core_s + text parsing and staging of the per-unit input files: the five text files of every unit -> staged arrays in pinned memory (slowest rank; its units side by side, each on its share of the cores: %.3f s); the one-off index of tmp/_reads.fa (%.3f s on rank 0, shared by all units of a run) is not in it" % (t_parse_max, t_index),
             "load_ms_per_unit": {str(uu): load_ms[uu] for uu in mine},
             "load_note": "per unit, wall: contigs = unit sequence + contig threading (on a thread of its own, beside the read alignments); read_alignments = SAM parsing, left-mate decision, rows of 2-bit read bases straight into the pinned upload buffers; rest = what the load took beyond the read alignments",
-            "reads_index_s": round(t_index, 3),
+            "reads_index_s": round(t_index, 3), "usable_cpus": cpus, "load_threads_per_unit": int(os.environ.get("AGX_LOAD_THREADS", "0")),
             "value_t_unit": round(reads_per_step / (sec_per_step + t_parse_max), 1),
             "t_unit_cached_s": round(sec_per_step + t_cached_max, 4),
             "t_unit_cached_note": "t_core_s + loading every unit from its binary cache file (tmp/_agx_unit.<u>.bin, written where the alignments are distributed; up to 4 units side by side: %.3f s) instead of parsing text — what the timed steps' units were loaded from" % t_cached_max,
