@@ -16,6 +16,7 @@
 #include "agx_parse.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -256,56 +257,58 @@ template <class F> void on_threads(unsigned threads, F fn) {
     for (auto &e : ex) if (e) std::rethrow_exception(e);
 }
 
+// One record = a header line and a sequence line; the index holds where every record starts, up to the first empty line (which ends the file for
+// the reference's getline loops), and how many header lines there are (what decides the batch boundaries, AG:361-404).  Two passes at SIMD speed
+// (count the lines of every byte range, then write every other line start to its place) on the cores this process can keep busy.
 ReadsIndex::ReadsIndex(const std::string &path) : fv(path) {
-        const char *b = fv.p, *e = b + fv.n;
-        const unsigned threads = loader_threads(fv.n);
-        bool done = false;
-        if (threads > 1 && fv.n) {                // byte ranges cut at line starts; a file with an empty line takes the one-thread scan
-            struct Range { const char *lo, *hi; size_t lines = 0, heads = 0; bool empty = false; };
-            std::vector<Range> R(threads);
-            auto line_start = [&](const char *c) -> const char * { if (c <= b) return b; const char *nl = (const char *)memchr(c - 1, '\n', (size_t)(e - (c - 1))); return nl ? nl + 1 : e; };
-            for (unsigned t = 0; t < threads; t++) R[t].lo = line_start(b + fv.n / threads * t);
-            for (unsigned t = 0; t < threads; t++) R[t].hi = t + 1 < threads ? R[t + 1].lo : e;
-            on_threads(threads, [&](unsigned t) {
-                Range &r = R[t];
-                for (const char *c = r.lo; c < r.hi;) {
-                    const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
-                    if (nl == c) { r.empty = true; return; }
-                    r.heads += *c == '>'; r.lines++;
-                    if (!nl) break;
-                    c = nl + 1;
+    const char *b = fv.p, *e = b + fv.n;
+    const unsigned threads = (unsigned)std::min<size_t>(getenv("AGX_LOAD_THREADS") ? loader_threads(fv.n) : usable_cpus(), fv.n / (1u << 20) + 1);
+    bool done = false;
+    if (threads > 1 && fv.n) {                // byte ranges cut at line starts; a file with an empty line takes the one-thread scan
+        Team team(threads);
+        const unsigned n_thr = team.size(), nr = n_thr * 4;
+        struct alignas(64) Range { const char *lo, *hi; size_t lines = 0, heads = 0; bool clean = true; };
+        std::vector<Range> R(nr);
+        auto line_start = [&](const char *c) -> const char * { if (c <= b) return b; const char *nl = (const char *)memchr(c - 1, '\n', (size_t)(e - (c - 1))); return nl ? nl + 1 : e; };
+        for (unsigned t = 0; t < nr; t++) R[t].lo = line_start(b + fv.n / nr * t);
+        for (unsigned t = 0; t < nr; t++) R[t].hi = t + 1 < nr ? R[t + 1].lo : e;
+        std::atomic<unsigned> next{0};
+        team.run([&](unsigned) {
+            for (unsigned i; (i = next.fetch_add(1)) < nr;) {
+                Range &r = R[i]; size_t n = 0, h = 0;
+                const char *stop = scan_lines(r.lo, r.hi, [&](const char *c) { n++; h += *c == '>'; });
+                // (scan_lines also stops at a line that begins with a NUL byte; the one-thread scan below decides what that means here)
+                r.lines = n; r.heads = h; r.clean = stop == r.hi;
+            }
+        });
+        bool clean = true; size_t total = 0;
+        std::vector<size_t> before(nr, 0);
+        for (unsigned t = 0; t < nr; t++) { clean &= R[t].clean; before[t] = total; total += R[t].lines; headers += R[t].heads; }
+        if (clean) {
+            rec_off.reserve((total + 1) / 2 + 1); rec_off.n = (total + 1) / 2;
+            next.store(0);
+            team.run([&](unsigned) {
+                for (unsigned i; (i = next.fetch_add(1)) < nr;) {
+                    size_t line = before[i]; uint64_t *out = rec_off.p;
+                    scan_lines(R[i].lo, R[i].hi, [&](const char *c) { if ((line & 1) == 0) out[line >> 1] = (uint64_t)(c - b); line++; });
                 }
             });
-            bool clean = true; size_t total = 0;
-            std::vector<size_t> before(threads, 0);
-            for (unsigned t = 0; t < threads; t++) { clean &= !R[t].empty; before[t] = total; total += R[t].lines; headers += R[t].heads; }
-            if (clean) {
-                rec_off.assign((total + 1) / 2, 0);
-                on_threads(threads, [&](unsigned t) {
-                    size_t line = before[t];
-                    for (const char *c = R[t].lo; c < R[t].hi; line++) {
-                        if ((line & 1) == 0) rec_off[line / 2] = (uint64_t)(c - b);
-                        const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
-                        if (!nl) break;
-                        c = nl + 1;
-                    }
-                });
-                done = true;
-            } else headers = 0;
+            done = true;
+        } else headers = 0;
+    }
+    if (!done) {
+        const char *c = b; unsigned long long line = 0;
+        while (c < e) {
+            const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+            if (nl == c) break;                  // empty line
+            if (*c == '>') headers++;
+            if ((line & 1ull) == 0) rec_off.push_back((uint64_t)(c - b));
+            line++;
+            if (!nl) break;
+            c = nl + 1;
         }
-        if (!done) {
-            const char *c = b; unsigned long long line = 0;
-            while (c < e) {
-                const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
-                if (nl == c) break;                  // empty line
-                if (*c == '>') headers++;
-                if ((line & 1ull) == 0) rec_off.push_back((uint64_t)(c - b));
-                line++;
-                if (!nl) break;
-                c = nl + 1;
-            }
-        }
-        if (fv.mapped) madvise((void *)fv.p, fv.n, MADV_RANDOM);
+    }
+    if (fv.mapped) madvise((void *)fv.p, fv.n, MADV_RANDOM);
 }
 
 ReadsIndex *reads_index_open(const std::string &reads_fa) { return new ReadsIndex(reads_fa); }

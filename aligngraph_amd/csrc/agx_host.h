@@ -192,7 +192,7 @@ void thread_contigs_from_files(const std::string &contigs_fa, const std::string 
 // them) then only touch the reads their own SAM names.  Immutable after open(); shared by any number of threads.
 struct ReadsIndex {
     FileView fv;
-    std::vector<uint64_t> rec_off;              // offset of the first line of record r (a record = two lines)
+    SBuf<uint64_t> rec_off;                     // offset of the first line of record r (a record = two lines)
     unsigned long long headers = 0;             // header lines up to the first empty line
     explicit ReadsIndex(const std::string &path);
 };

@@ -35,68 +35,6 @@ namespace {
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 const bool g_timing = getenv("AGX_LOAD_TIMING") != nullptr;
 
-// ---- line scanning ----------------------------------------------------------------------------------------------------------------------
-// One pass over a byte range that starts at a line start: f(start_of_line) for every line, until the range ends or a line is empty or begins
-// with a NUL byte (the reference's getline loops stop there: `if(buf[0]==0) break`).  Returns where the scan stopped: `hi`, or the start
-// of the line that ends the input.  32 bytes at a time: newline and NUL masks, line starts = newline mask shifted by one.
-template <class F> inline const char *scan_lines_scalar(const char *lo, const char *hi, F f) {
-    const char *c = lo;
-    while (c < hi) {
-        if (*c == '\n' || *c == 0) return c;
-        f(c);
-        const char *nl = (const char *)memchr(c, '\n', (size_t)(hi - c));
-        if (!nl) return hi;
-        c = nl + 1;
-    }
-    return hi;
-}
-#if defined(__x86_64__)
-template <class F> __attribute__((target("avx2"))) inline const char *scan_lines_avx2(const char *lo, const char *hi, F f) {
-    const __m256i vnl = _mm256_set1_epi8('\n'), vz = _mm256_setzero_si256();
-    uint32_t carry = 1;                                  // the byte before `lo` ends a line
-    const char *c = lo;
-    for (; c + 32 <= hi; c += 32) {
-        const __m256i v = _mm256_loadu_si256((const __m256i *)c);
-        const uint32_t nl = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, vnl)), nul = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, vz));
-        uint32_t starts = (nl << 1) | carry;
-        carry = nl >> 31;
-        if (!starts) continue;
-        const uint32_t stop = starts & (nl | nul);
-        if (stop) { const uint32_t below = (stop & (0u - stop)) - 1u; for (uint32_t m = starts & below; m; m &= m - 1) f(c + __builtin_ctz(m)); return c + __builtin_ctz(stop); }
-        for (uint32_t m = starts; m; m &= m - 1) f(c + __builtin_ctz(m));
-    }
-    // tail: the last (partial) chunk byte by byte
-    if (c < hi) {
-        if (carry) { if (*c == '\n' || *c == 0) return c; f(c); }
-        for (const char *d = c; d + 1 < hi; d++) if (*d == '\n') { if (d[1] == '\n' || d[1] == 0) return d + 1; f(d + 1); }
-    }
-    return hi;
-}
-#endif
-template <class F> inline const char *scan_lines(const char *lo, const char *hi, F f) {
-#if defined(__x86_64__)
-    if (__builtin_cpu_supports("avx2")) return scan_lines_avx2(lo, hi, f);
-#endif
-    return scan_lines_scalar(lo, hi, f);
-}
-
-// number of '\n' in [lo, hi)
-inline size_t count_newlines_scalar(const char *lo, const char *hi) { size_t n = 0; for (const char *c = lo; c < hi; c++) n += *c == '\n'; return n; }
-#if defined(__x86_64__)
-__attribute__((target("avx2,popcnt"))) inline size_t count_newlines_avx2(const char *lo, const char *hi) {
-    const __m256i vnl = _mm256_set1_epi8('\n'); size_t n = 0; const char *c = lo;
-    for (; c + 32 <= hi; c += 32) n += (size_t)__builtin_popcount((uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)c), vnl)));
-    for (; c < hi; c++) n += *c == '\n';
-    return n;
-}
-#endif
-inline size_t count_newlines(const char *lo, const char *hi) {
-#if defined(__x86_64__)
-    if (__builtin_cpu_supports("avx2")) return count_newlines_avx2(lo, hi);
-#endif
-    return count_newlines_scalar(lo, hi);
-}
-
 // length of the prefix of p[0..n) whose bytes all equal p[0]
 inline size_t run_same(const agx_u8 *p, size_t n) {
     const agx_u8 v = p[0]; size_t i = 1;
@@ -727,8 +665,8 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
         size_t run_at = r.run_base;
         for (size_t i = 0; i < r.n_keep; i++) {
             // the reads are spread over the whole (mapped) reads file: every row is two cache misses and a TLB miss unless it is asked for ahead of time
-            if (i + 24 < r.n_keep && (r.cand_pair[i + 24] & 0x80000000u)) { const unsigned long long pr = 2ull * r.cand[i + 24].slot1; if (pr + 1 < reads.rec_off.size()) __builtin_prefetch(&reads.rec_off[pr]); }
-            if (i + 12 < r.n_keep && (r.cand_pair[i + 12] & 0x80000000u)) { const unsigned long long pr = 2ull * r.cand[i + 12].slot1; if (pr + 1 < reads.rec_off.size()) { const char *pc = rb + reads.rec_off[pr + (r.cand[i + 12].pad[0] & 1u)]; __builtin_prefetch(pc); __builtin_prefetch(pc + 64); } }
+            if (i + 40 < r.n_keep && (r.cand_pair[i + 40] & 0x80000000u)) { const unsigned long long pr = 2ull * r.cand[i + 40].slot1; if (pr + 1 < reads.rec_off.size()) __builtin_prefetch(&reads.rec_off[pr]); }
+            if (i + 20 < r.n_keep && (r.cand_pair[i + 20] & 0x80000000u)) { const unsigned long long pr = 2ull * r.cand[i + 20].slot1; if (pr + 1 < reads.rec_off.size()) { const char *pc = rb + reads.rec_off[pr]; __builtin_prefetch(pc); __builtin_prefetch(pc + 64); __builtin_prefetch(pc + 128); __builtin_prefetch(pc + 192); } }      // (both mates' records are looked at: four lines)
             agx_hit h = r.cand[i];
             const agx_u32 id = h.slot1, info = r.cand_pair[i];
             const bool opens = (info & 0x80000000u) != 0;

@@ -5,6 +5,9 @@
 #include <string>
 #include <vector>
 #include "agx_host.h"
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace agx {
 namespace {
@@ -22,6 +25,68 @@ struct LineReader {
         return true;
     }
 };
+
+// ---- line scanning ----------------------------------------------------------------------------------------------------------------------
+// One pass over a byte range that starts at a line start: f(start_of_line) for every line, until the range ends or a line is empty or begins
+// with a NUL byte (the reference's getline loops stop there: `if(buf[0]==0) break`).  Returns where the scan stopped: `hi`, or the start
+// of the line that ends the input.  32 bytes at a time: newline and NUL masks, line starts = newline mask shifted by one.
+template <class F> inline const char *scan_lines_scalar(const char *lo, const char *hi, F f) {
+    const char *c = lo;
+    while (c < hi) {
+        if (*c == '\n' || *c == 0) return c;
+        f(c);
+        const char *nl = (const char *)memchr(c, '\n', (size_t)(hi - c));
+        if (!nl) return hi;
+        c = nl + 1;
+    }
+    return hi;
+}
+#if defined(__x86_64__)
+template <class F> __attribute__((target("avx2"))) inline const char *scan_lines_avx2(const char *lo, const char *hi, F f) {
+    const __m256i vnl = _mm256_set1_epi8('\n'), vz = _mm256_setzero_si256();
+    uint32_t carry = 1;                                  // the byte before `lo` ends a line
+    const char *c = lo;
+    for (; c + 32 <= hi; c += 32) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)c);
+        const uint32_t nl = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, vnl)), nul = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, vz));
+        uint32_t starts = (nl << 1) | carry;
+        carry = nl >> 31;
+        if (!starts) continue;
+        const uint32_t stop = starts & (nl | nul);
+        if (stop) { const uint32_t below = (stop & (0u - stop)) - 1u; for (uint32_t m = starts & below; m; m &= m - 1) f(c + __builtin_ctz(m)); return c + __builtin_ctz(stop); }
+        for (uint32_t m = starts; m; m &= m - 1) f(c + __builtin_ctz(m));
+    }
+    // tail: the last (partial) chunk byte by byte
+    if (c < hi) {
+        if (carry) { if (*c == '\n' || *c == 0) return c; f(c); }
+        for (const char *d = c; d + 1 < hi; d++) if (*d == '\n') { if (d[1] == '\n' || d[1] == 0) return d + 1; f(d + 1); }
+    }
+    return hi;
+}
+#endif
+template <class F> inline const char *scan_lines(const char *lo, const char *hi, F f) {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2")) return scan_lines_avx2(lo, hi, f);
+#endif
+    return scan_lines_scalar(lo, hi, f);
+}
+
+// number of '\n' in [lo, hi)
+inline size_t count_newlines_scalar(const char *lo, const char *hi) { size_t n = 0; for (const char *c = lo; c < hi; c++) n += *c == '\n'; return n; }
+#if defined(__x86_64__)
+__attribute__((target("avx2,popcnt"))) inline size_t count_newlines_avx2(const char *lo, const char *hi) {
+    const __m256i vnl = _mm256_set1_epi8('\n'); size_t n = 0; const char *c = lo;
+    for (; c + 32 <= hi; c += 32) n += (size_t)__builtin_popcount((uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)c), vnl)));
+    for (; c < hi; c++) n += *c == '\n';
+    return n;
+}
+#endif
+inline size_t count_newlines(const char *lo, const char *hi) {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2")) return count_newlines_avx2(lo, hi);
+#endif
+    return count_newlines_scalar(lo, hi);
+}
 
 inline int to_int(const char *s, size_t n) {      // atoi semantics on a bounded field
     size_t i = 0; while (i < n && (s[i] == ' ' || (s[i] >= 9 && s[i] <= 13))) i++;
