@@ -113,6 +113,7 @@ def lib():
         L.agx_unit_load_files_shared.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
         L.agx_unit_cache_build.argtypes = [ctypes.POINTER(Params), ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         L.agx_unit_cache_save.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+        L.agx_unit_hbm_needed.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
         L.agx_pool_trim.argtypes = [ctypes.c_int]
         L.agx_pool_trim.restype = None
         for f in ("agx_unit_upload", "agx_unit_build", "agx_unit_download", "agx_unit_stage", "agx_unit_release"):
@@ -249,6 +250,12 @@ class Unit:
 
     def stage(self):
         self._check(lib().agx_unit_stage(self._h))
+
+    def hbm_needed(self):
+        """HBM the upload of this (loaded) unit will take at its first-guess capacities: what AlignGraph_amd admits units to a device by."""
+        v = ctypes.c_uint64(0)
+        self._check(lib().agx_unit_hbm_needed(self._h, ctypes.byref(v)))
+        return v.value
 
     def upload(self):
         self._check(lib().agx_unit_upload(self._h))

@@ -703,10 +703,9 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
     const int per_dev = std::max(1, getenv("AGX_UNITS_PER_DEVICE") ? atoi(getenv("AGX_UNITS_PER_DEVICE")) : 4);   // >1: the text parsing and host walk of one unit overlap the kernels of others
     // every unit reads tmp/_reads.fa (AG:1880): map and index it once for all of them
     agx_reads *reads = nullptr; { char err[512]; if (agx_reads_open("tmp/_reads.fa", &reads, err, sizeof err) != AGX_OK) reads = nullptr; }   // (a missing file is reported by the first unit, as before)
-    // Units of very different sizes share a device: each is admitted only while the estimated HBM footprints of the units in flight
-    // stay below 85 % of the device's memory (a unit larger than that still runs, alone).  Estimate: ~200 B per reference position (node
-    // pool, walk graph, conti-mer tables at their first-guess capacities) + ~2 B per byte of the unit's SAM file (hits, tile records, read
-    // bases) + 256 MB.
+    // Units of very different sizes share a device: a unit is loaded (host work only), asked what its upload will take (agx_unit_hbm_needed: the one
+    // block of HBM sized from its staged counts) and admitted only while the blocks of the units in flight stay below 85 % of the device's memory
+    // (a unit larger than that still runs, alone).  A build that has to grow a capacity takes more than its block: the 15 % are for that.
     auto file_bytes = [](const string &p) -> double { struct stat st; return stat(p.c_str(), &st) == 0 ? (double)st.st_size : 0.0; };
     vector<double> budget(ndev, 0.0), used(ndev, 0.0);
     for (int d = 0; d < ndev; d++) { uint64_t fr = 0, tot = 0; budget[d] = agx_device_memory(d, &fr, &tot) == AGX_OK ? 0.85 * (double)tot : 1e18; }
@@ -715,7 +714,7 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
     // checkpoints still come out in unit order.  A unit that fails stops the hand-out; the message is printed by the main thread once the
     // workers are back (an exit() from a worker would tear HIP down under the other workers' feet).
     vector<int> order; for (int u = first; u < units; u++) order.push_back(u);
-    vector<double> weight(units, 0.0);
+    vector<double> weight(units, 0.0);         // (only orders the hand-out: the unit sequence and its alignments decide how long a unit takes)
     for (int u = first; u < units; u++) weight[u] = 200.0 * file_bytes("tmp/_genome." + itoa(u) + ".fa") + 2.0 * file_bytes("tmp/_reads_genome." + itoa(u) + ".bowtie");
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] > weight[b]; });
     std::atomic<size_t> next(0); std::atomic<bool> failed(false);
@@ -737,15 +736,30 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
                 const size_t at = next.fetch_add(1);
                 if (at >= order.size() || failed.load()) return;
                 const int u = order[at];
-                const double est = weight[u] + 256e6;
-                { std::unique_lock<std::mutex> g(mem_mu); mem_cv.wait(g, [&] { return used[d] == 0.0 || used[d] + est <= budget[d]; }); used[d] += est; }
-                agx_params p = {(uint32_t)o.k, (uint32_t)o.insertVariation, (uint32_t)o.coverage, 0, d, 0};
-                agx_result r; char err[512];
-                int rc = AGX_E_ARG;
-                try { rc = agx_run_unit_shared(&p, "tmp", u, 1, reads, &r, err, sizeof err); } catch (...) { snprintf(err, sizeof err, "internal error"); }
-                if (rc == AGX_OK) agx_result_free(&r);
-                { std::lock_guard<std::mutex> g(mem_mu); used[d] -= est; if (used[d] < 1.0) used[d] = 0.0; }
-                mem_cv.notify_all();
+                // the five calls of the unit loop (AG:4768-4776) through the split entry points of agx_run_unit, with the admission between load and upload
+                agx_params p = {(uint32_t)o.k, (uint32_t)o.insertVariation, (uint32_t)o.coverage, 0, d, AGX_FLAG_ONE_SHOT};
+                agx_result r; memset(&r, 0, sizeof r); char err[512]; err[0] = 0;
+                agx_unit *un = nullptr;
+                int rc = agx_unit_create(&p, &un);
+                if (rc != AGX_OK) snprintf(err, sizeof err, "%s", rc == AGX_E_NOGPU ? "no HIP device" : "bad parameters");
+                double est = 0; bool admitted = false;
+                if (rc == AGX_OK) rc = agx_unit_load_files_shared(un, "tmp", u, reads);
+                if (rc == AGX_OK) { uint64_t need = 0; rc = agx_unit_hbm_needed(un, &need); est = (double)need; }
+                if (rc == AGX_OK) { std::unique_lock<std::mutex> g(mem_mu); mem_cv.wait(g, [&] { return used[d] == 0.0 || used[d] + est <= budget[d]; }); used[d] += est; admitted = true; }
+                if (rc == AGX_OK) rc = agx_unit_upload(un);
+                if (rc == AGX_OK) rc = agx_unit_build(un);
+                if (rc == AGX_OK) rc = agx_unit_finish(un, &r);
+                if (rc != AGX_OK && un && !err[0]) snprintf(err, sizeof err, "%s", agx_unit_error(un));
+                agx_unit_destroy(un);                                          // (its HBM goes back before the next unit is admitted)
+                if (admitted) { { std::lock_guard<std::mutex> g(mem_mu); used[d] -= est; if (used[d] < 1.0) used[d] = 0.0; } mem_cv.notify_all(); }
+                if (rc == AGX_OK) {
+                    const string su = itoa(u);
+                    auto put = [&](const string &path, const char *data, size_t len) { FILE *f = fopen(path.c_str(), "wb"); bool ok = f != nullptr; if (f) { ok = len == 0 || fwrite(data, 1, len, f) == len; ok = (fclose(f) == 0) && ok; } if (!ok && rc == AGX_OK) { rc = AGX_E_IO; snprintf(err, sizeof err, "CANNOT OPEN FILE!"); } };
+                    put("tmp/_initial_contigs." + su + ".fa", r.initial_contigs, r.initial_len);
+                    put("tmp/_pre_extended_contigs." + su + ".fa", r.pre_extended, r.pre_len);
+                    put("tmp/_extended_contigs." + su + ".fa", r.extended, r.extended_len);
+                }
+                agx_result_free(&r);
                 std::lock_guard<std::mutex> g(mu);
                 if (rc != AGX_OK) { string m = err; const size_t cut = m.find(" ("); errors[u] = cut == string::npos ? m : m.substr(0, cut); state[u] = -1; failed.store(true); }
                 else state[u] = 1;

@@ -555,6 +555,32 @@ void alloc_sparse(agx_unit *u, agx_u32 cap) { u->sp_cap = cap; u->d_sp_node.rele
 
 void do_release(agx_unit *u);
 
+// Capacities of a unit's first build and the HBM they add up to (what do_upload reserves as one block; AlignGraph_amd admits a unit to a device by it:
+// agx_unit_hbm_needed).  From the staged counts: positions, hits, runs, conti-mers, read rows.
+struct Plan { agx_u32 pool_cap, list_cap, ovf_cap, sp_cap; size_t total; };
+Plan plan_capacities(const agx_unit *u) {
+    const size_t n_pos = u->V.n_pos, nh = u->nh;
+    const agx_u32 n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE), n_regions = (n_tiles + AGX_REGION_TILES - 1) / AGX_REGION_TILES;
+    const size_t n_bases = u->n_codes * 4;
+    Plan P;
+    const agx_u32 main_cap = (agx_u32)std::min<size_t>(g_tiny ? n_pos / 8 + 64 : n_pos + n_pos / 4 + 4096, 0xE0000000ull);
+    P.pool_cap = u->pool_cap ? u->pool_cap : main_cap + spill_min(u);
+    // a hit's arrivals span len - k + 1 positions = 1 + (span - 1) / 64 tiles on average
+    const double per_hit = 1.0 + (u->maxlen > u->prm.k ? (double)(u->maxlen - u->prm.k) : 0.0) / AGX_TILE;
+    P.list_cap = u->list_cap ? u->list_cap : (agx_u32)std::min<double>(g_tiny ? (double)nh / 2 + 16 : (double)nh * per_hit * 1.1 + 4096, 4.0e9);
+    P.ovf_cap = u->ovf_cap ? u->ovf_cap : (g_tiny ? 4u : 1u << 16);
+    const size_t ids_cap = n_pos + P.pool_cap;
+    P.sp_cap = u->sp_cap ? u->sp_cap : (agx_u32)std::min<size_t>(g_tiny ? 32 : ids_cap / 4 + 4096, 0xFFFFFF00ull);      // special ids: 8 % on the bench unit
+    // what the takes of do_upload add up to, plus the alignment of ~90 buffers
+    const size_t per_pos = 4 + 16 + 1 + 4 + 1 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_hit) + sizeof(agx_dhit) + 16 + 4;
+    const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
+    const size_t total = n_pos * per_pos + n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases + u->n_other * 8 +
+                         (size_t)P.pool_cap * per_slot + ids_cap * per_id + (size_t)P.list_cap * 36 + (size_t)P.ovf_cap * 16 + (size_t)P.sp_cap * (sizeof(agx_walknode) + sizeof(agx_hop)) +
+                         (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64 * 4 + (size_t)n_regions * AGX_REGION_PAD * 4 + (64u << 10) * 100;
+    P.total = total + total / 64;
+    return P;
+}
+
 // Everything a unit holds on the device is taken here, from ONE block of HBM sized by the sum; then the inputs are copied (asynchronously,
 // from the staged pinned arrays, on the device's upload stream: behind the copies of the units queued before, beside whatever kernels run on
 // the device) and the unit's helper thread is handed what can be prepared meanwhile.  Nothing waits on the host; the unit's first build
@@ -570,23 +596,9 @@ void do_upload(agx_unit *u) {
     u->n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
     u->n_regions = (u->n_tiles + AGX_REGION_TILES - 1) / AGX_REGION_TILES;
     const size_t n_bases = u->n_codes * 4;
-    // capacities of a first build
-    const agx_u32 main_cap = (agx_u32)std::min<size_t>(g_tiny ? n_pos / 8 + 64 : n_pos + n_pos / 4 + 4096, 0xE0000000ull);
-    const agx_u32 pool_cap = u->pool_cap ? u->pool_cap : main_cap + spill_min(u);
-    // a hit's arrivals span len - k + 1 positions = 1 + (span - 1) / 64 tiles on average
-    const double per_hit = 1.0 + (u->maxlen > u->prm.k ? (double)(u->maxlen - u->prm.k) : 0.0) / AGX_TILE;
-    const agx_u32 list_cap = u->list_cap ? u->list_cap : (agx_u32)std::min<double>(g_tiny ? (double)nh / 2 + 16 : (double)nh * per_hit * 1.1 + 4096, 4.0e9);
-    const agx_u32 ovf_cap = u->ovf_cap ? u->ovf_cap : (g_tiny ? 4u : 1u << 16);
-    const size_t ids_cap = n_pos + pool_cap;
-    const agx_u32 sp_cap = u->sp_cap ? u->sp_cap : (agx_u32)std::min<size_t>(g_tiny ? 32 : ids_cap / 4 + 4096, 0xFFFFFF00ull);      // special ids: 8 % on the bench unit
-    {   // one block for all of it (what the takes below add up to, plus the alignment of ~90 buffers)
-        const size_t per_pos = 4 + 16 + 1 + 4 + 1 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_hit) + sizeof(agx_dhit) + 16 + 4;
-        const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
-        const size_t total = n_pos * per_pos + u->n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases + u->n_other * 8 +
-                             (size_t)pool_cap * per_slot + ids_cap * per_id + (size_t)list_cap * 36 + (size_t)ovf_cap * 16 + (size_t)sp_cap * sizeof(agx_walknode) +
-                             (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64 * 4 + (size_t)u->n_regions * AGX_REGION_PAD * 4 + (64u << 10) * 100;
-        u->arena.reserve(total + total / 64);
-    }
+    const Plan plan = plan_capacities(u);
+    const agx_u32 pool_cap = plan.pool_cap, list_cap = plan.list_cap, ovf_cap = plan.ovf_cap, sp_cap = plan.sp_cap;
+    u->arena.reserve(plan.total);                        // one block for all of it
     DevArena &a = u->arena;
     u->d_cm_start.alloc(a, n_pos + 2); u->d_cm_cnt.alloc(a, n_pos + 2); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos); u->d_cm_head.alloc(a, n_pos + 1);
     u->d_segs.alloc(a, u->n_segs + 1); u->d_up_desc.alloc(a, (n_pos + 2) / 4096 + 2);
@@ -1197,6 +1209,11 @@ int agx_unit_cache_build(const agx_params *p, const char *tmp_dir, int unit, con
 }
 
 int agx_unit_cache_save(agx_unit *u, const char *tmp_dir, int unit) { if (!u || !tmp_dir) return AGX_E_ARG; return guarded(u, [&] { save_cache(u, tmp_dir, unit); }); }
+
+int agx_unit_hbm_needed(agx_unit *u, uint64_t *bytes) {
+    if (!u || !bytes) return AGX_E_ARG;
+    return guarded(u, [&] { if (!u->staged) stage_inputs(u); *bytes = round_block(plan_capacities(u).total); });
+}
 
 int agx_unit_stage(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { stage_inputs(u); }); }
 int agx_unit_upload(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_upload(u); }); }

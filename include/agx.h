@@ -162,6 +162,8 @@ int agx_unit_cache_save(agx_unit *u, const char *tmp_dir, int unit);   /* the sa
 
 int agx_unit_stage(agx_unit *u);                 /* packs what was handed over into pinned upload buffers (read bases as 4-bit classes); done by agx_unit_load_files,
                                                     implied by agx_unit_upload after agx_unit_push_pairs */
+int agx_unit_hbm_needed(agx_unit *u, uint64_t *bytes);   /* the HBM block agx_unit_upload will take for this (loaded) unit at its first-guess capacities: what a caller that shares a
+                                                    device between units of very different sizes admits them by (AlignGraph_amd); a build that has to grow a capacity takes more */
 int agx_unit_upload(agx_unit *u);                /* staged arrays -> HBM: one device block, asynchronous copies behind those of the device's earlier uploads; returns without waiting */
 int agx_unit_build(agx_unit *u);                 /* kernels: updateGenomeWithRead/updateKMer (AG:1635-1870, 1353-1624) + filterLowCoverage (AG:1904-1918) */
 int agx_unit_download(agx_unit *u);              /* HBM -> pinned host memory (walk graph); implied by agx_unit_finish */

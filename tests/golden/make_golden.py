@@ -36,6 +36,10 @@ CASES = {
     # read to arrive, and they reach the output headers.  main() checks that the reference's output really differs from the twin's.
     "reversed": (dict(seed=16, chroms="20000", pairs=5000, L=100, k=5, contig_min=800, contig_max=4000, read_indel=0.2, read_clip=0.2,
                       multi=0.2, frag_sd=60, sam_seq=0), [5]),
+    # trimmed reads: 40 % of the pairs cut to 60 / 75 / 90 bp (the mates of a pair share a length, AG:3454; the event loop bound is per pair,
+    # AG:1672/1681), with indels, clips and multi-hits on both kinds — pairs of different lengths in one unit, one row stride for all of them
+    "mixedlen": (dict(seed=17, chroms="30000", pairs=6000, L=100, k=5, mixed_len=0.4, contig_min=800, contig_max=4000, read_indel=0.3, read_clip=0.3,
+                      multi=0.2, frag_sd=60, sam_seq=0), [5]),
 }
 REVERSED = {"reversed"}
 

@@ -86,6 +86,7 @@ struct Params {
     double read_err = 0.002, read_indel = 0.10, read_clip = 0.05, read_badclip = 0.01, read_n = 0.0005;
     double multi = 0.05, multi_near = 0.3, unaligned = 0.02;
     double mate1_left = 0.5;
+    double mixed_len = 0.0;  // probability that a pair is TRIMMED: both mates cut to one shorter length (60 %, 75 % or 90 % of L), as formalizeInput equalises the mates of a pair (AG:3454).  Single-stream mode only
     int sam_seq = 1;  // write SEQ/QUAL columns like bowtie2 does
     int shuffle_units = 1;
     int e2e = 0;       // also write the user-level inputs of a fresh run: reads_1.fa, reads_2.fa and stub/ (what the aligner stubs replay)
@@ -126,7 +127,7 @@ Params parse_args(int argc, char **argv) {
         OPT_D("--read-err", read_err) OPT_D("--read-indel", read_indel) OPT_D("--read-clip", read_clip)
         OPT_D("--read-badclip", read_badclip) OPT_D("--read-n", read_n)
         OPT_D("--multi", multi) OPT_D("--multi-near", multi_near) OPT_D("--unaligned", unaligned)
-        OPT_D("--mate1-left", mate1_left) OPT_I("--sam-seq", sam_seq) OPT_I("--shuffle-units", shuffle_units) OPT_I("--e2e", e2e) OPT_I("--threads", threads)
+        OPT_D("--mate1-left", mate1_left) OPT_D("--mixed-len", mixed_len) OPT_I("--sam-seq", sam_seq) OPT_I("--shuffle-units", shuffle_units) OPT_I("--e2e", e2e) OPT_I("--threads", threads)
         if (a == "--chroms") { P.chroms = parse_list(v); continue; }
         std::fprintf(stderr, "agx_synth: unknown option %s\n", a.c_str()); std::exit(2);
     }
@@ -519,9 +520,10 @@ int main(int argc, char **argv) {
         }
         std::vector<FILE *> sam(NU);
         for (int u = 0; u < NU; u++) sam[u] = open("tmp/_reads_genome." + std::to_string(u) + ".bowtie");
-        const int L = P.L;
-        std::string qual(L, 'I');
         for (int64_t id = 0; id < N; id++) {
+            int L = P.L;
+            if (P.mixed_len > 0 && R.coin(P.mixed_len)) { const int pct[3] = {60, 75, 90}; L = std::max(P.k + 6, P.L * pct[R.range(0, 2)] / 100); }      // (no draw at all when the option is off: the committed fixtures came from that stream)
+            std::string qual(L, 'I');
             int u = unit_of[id];
             const Unit &U = units[u];
             int64_t T = (int64_t)U.tgt.size();
