@@ -22,7 +22,7 @@ EXPORTS = [
     "agx_unit_set_contig_threads", "agx_unit_push_pairs", "agx_unit_load_files", "agx_unit_upload", "agx_unit_build", "agx_unit_download",
     "agx_unit_finish", "agx_result_free", "agx_unit_stats", "agx_unit_graph", "agx_graph_free", "agx_run_unit",
     "agx_reads_open", "agx_reads_close", "agx_unit_load_files_shared", "agx_run_unit_shared",
-    "agx_unit_stage", "agx_unit_release", "agx_pool_trim", "agx_unit_cache_build", "agx_unit_cache_save",
+    "agx_unit_stage", "agx_unit_release", "agx_pool_trim", "agx_unit_cache_build", "agx_unit_cache_save", "agx_unit_hbm_needed",
 ]
 
 

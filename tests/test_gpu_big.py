@@ -181,112 +181,101 @@ def test_cfg5_shard_shape_at_1_256_every_unit_matches_the_oracle(agx, built, tmp
 
 
 @slow
-def test_cfg4_all_four_part_slices_match_the_oracle(agx, built, tmp_path, monkeypatch):
-    """configs[3] at full size: human chr1 (GRCh38 length) cut by --part 4 (formalizeGenome's rule, AG:3382-3413) into four units of 62 Mb, 60 M
-    pairs of 2x100 — all four through the job loop bench.py times, every unit byte for byte against the ORACLE (four oracle runs on four host
-    threads, started first), then one slice again with every capacity started too small."""
+def test_human_sized_units_cfg4_slices_and_chr1_whole(agx, built, tmp_path, monkeypatch):
+    """The two human-scale shapes in ONE test, so that their CPU checkers (minutes each) run side by side while the GPU does both:
+
+    * configs[3] at full size: human chr1 (GRCh38 length) cut by --part 4 (formalizeGenome's rule, AG:3382-3413) into four units of 62 Mb, 60 M
+      pairs of 2x100 — all four through the job loop bench.py times, every unit byte for byte against the ORACLE (four oracle runs on four host
+      threads), then one slice again with every capacity started too small;
+    * the largest unit of configs[4] (whole human, 24 units) at its real size: chr1 WHOLE — 248 956 422 positions, 2x150 bp reads at the
+      configuration's depth (400 M pairs x 249 / 3100 Mb = 32 M pairs), --coverage 5 — as ONE unit: 4x the positions of anything else in the suite,
+      32 read batches (BATCH, AG:37: a line pair lost at each boundary, AG:1258-1259), four walkers.  Checked: one build with the first-guess
+      capacities, HBM = what AlignGraph_amd admits it by (agx_unit_hbm_needed), output bytes equal to those of the serial CPU executor of the
+      kernels' lane functions (tests/hostsim) and to a second build whose capacities all started too small."""
     import shutil
     from aligngraph_amd import shard
-    run = H.synth(str(tmp_path / "run"), seed=1004, chroms="248956422", part=4, pairs=60000000, L=100, k=5, coverage=5, sam_seq=0, threads=THREADS)
-    tmp = os.path.join(run, "tmp")
-    meta = H.read_meta(run)
-    lens = meta["unit_len"]
+    from hostsim import sim
+    run4 = H.synth(str(tmp_path / "cfg4"), seed=1004, chroms="248956422", part=4, pairs=60000000, L=100, k=5, coverage=5, sam_seq=0, threads=THREADS)
+    tmp4 = os.path.join(run4, "tmp")
+    lens = H.read_meta(run4)["unit_len"]
     assert len(lens) == 4 and sum(lens) == 248956422
-    want, errs = {}, []
+    n1, pairs1 = 248956422, 32000000
+    run1 = H.synth(str(tmp_path / "chr1"), seed=1006, chroms=str(n1), pairs=pairs1, L=150, k=5, coverage=5, sam_seq=0, threads=THREADS)
+    tmp1 = os.path.join(run1, "tmp")
+    want4, want1, errs = {}, {}, []
 
     def oracle(uu):
         try:
-            want[uu] = H.run_oracle(tmp, uu, 5, 50, 5)
+            want4[uu] = H.run_oracle(tmp4, uu, 5, 50, 5)
         except BaseException as e:
             errs.append(e)
-    checkers = [threading.Thread(target=oracle, args=(uu,)) for uu in range(4)]
+
+    def serial():
+        try:
+            want1.update(sim.run(tmp1, 0, k=5, insert_variation=50, coverage=5))
+        except BaseException as e:
+            errs.append(e)
+    checkers = [threading.Thread(target=serial)] + [threading.Thread(target=oracle, args=(uu,)) for uu in range(4)]
     for t in checkers:
         t.start()
-    units, got, stats = {}, {}, {}
-    with agx.Reads(os.path.join(tmp, "_reads.fa")) as reads:
+
+    # ---- cfg4: four slices through the job loop ----
+    units, got4, stats4 = {}, {}, {}
+    with agx.Reads(os.path.join(tmp4, "_reads.fa")) as reads:
         for uu in range(4):
             units[uu] = agx.Unit(k=5, insert_variation=50, coverage=5, flags=agx.AGX_FLAG_ONE_SHOT)
-            units[uu].load_files(tmp, uu, reads=reads)
+            units[uu].load_files(tmp4, uu, reads=reads)
             assert units[uu].stats()["from_cache"] == 0
 
     def run_unit(uu):
         un = units[uu]
         un.build(); un.download()
-        got[uu] = un.finish()
-        stats[uu] = un.stats()
+        got4[uu] = un.finish()
+        stats4[uu] = un.stats()
         un.release()
-        return got[uu]["extended"]
+        return got4[uu]["extended"]
     out = shard.run_job(lens, 0, 1, run_unit, None, None, inflight=4, start_unit=lambda uu: units[uu].upload())
     assert sorted(out) == list(range(4))
     for un in units.values():
         un.close()
     monkeypatch.setenv("AGX_TEST_SMALL_CAPS", "1")          # every capacity far too small: tile lists, node pool, sparse table all regrow
     with agx.Unit(k=5, insert_variation=50, coverage=5) as u2:
-        u2.load_files(tmp, 3)
+        u2.load_files(tmp4, 3)
         u2.upload(); u2.build()
-        again = u2.finish()
+        again4 = u2.finish()
         assert u2.stats()["build_attempts"] > 1
     monkeypatch.delenv("AGX_TEST_SMALL_CAPS")
-    for t in checkers:
-        t.join()
-    shutil.rmtree(run, ignore_errors=True)
-    assert not errs, errs
-    for uu in range(4):
-        for key in ("initial", "pre", "extended"):
-            assert got[uu][key] == want[uu][key], "slice %d: %s differs from the oracle" % (uu, key)
-        assert stats[uu]["build_attempts"] == 1 and stats[uu]["n_pos"] >= lens[uu]
-    for key in ("initial", "pre", "extended"):
-        assert again[key] == want[3][key], "%s of slice 3 differs from the oracle after its capacities regrew" % key
-    assert sum(stats[uu]["sam_line_pairs"] for uu in range(4)) > 60000000
 
-
-@slow
-def test_chr1_sized_unit_2x150_is_built_once_within_the_hbm_estimate(agx, built, tmp_path, monkeypatch):
-    """The largest unit of configs[4] (whole human, 24 units): chr1 WHOLE — 248 956 422 positions, 2x150 bp reads at the configuration's depth
-    (400 M pairs x 249 / 3100 Mb = 32 M pairs), --coverage 5 — as ONE unit: 4x the positions of anything else in the suite, 32 read batches
-    (BATCH, AG:37: 31 lost line pairs, AG:1258-1259), four walkers.  Checked: one build with the first-guess capacities, HBM within what
-    AlignGraph_amd's admission estimate reserves for it, output bytes equal to those of the serial CPU executor of the kernels' lane functions
-    (tests/hostsim, on a host thread beside the GPU work; AGX_CHR1_NO_SERIAL=1 leaves that out) and to a second build whose capacities all
-    started too small."""
-    import shutil
-    from hostsim import sim
-    n, pairs = 248956422, 32000000
-    run = H.synth(str(tmp_path / "run"), seed=1006, chroms=str(n), pairs=pairs, L=150, k=5, coverage=5, sam_seq=0, threads=THREADS)
-    tmp = os.path.join(run, "tmp")
-    want, errs = {}, []
-
-    def serial():
-        try:
-            want.update(sim.run(tmp, 0, k=5, insert_variation=50, coverage=5))
-        except BaseException as e:
-            errs.append(e)
-    t = threading.Thread(target=serial)
-    if os.environ.get("AGX_CHR1_NO_SERIAL") != "1":
-        t.start()
+    # ---- chr1 whole as one unit ----
     with agx.Unit(k=5, insert_variation=50, coverage=5) as u:
-        u.load_files(tmp, 0)
+        u.load_files(tmp1, 0)
         estimate = u.hbm_needed()                          # what AlignGraph_amd admits the unit to a device by (agx_cli.cpp run_units)
         u.upload(); u.build()
-        got = u.finish()
+        got1 = u.finish()
         st = u.stats()
-    assert st["n_pos"] >= n and st["build_attempts"] == 1, st
-    assert st["pairs_in_file"] == pairs and st["sam_line_pairs"] - st["n_hits"] >= 31          # 31 batch boundaries, a line pair lost at each
-    assert st["device_bytes"] <= estimate, "the unit took %.1f GB of HBM, AlignGraph_amd admits it with %.1f GB" % (st["device_bytes"] / 1e9, estimate / 1e9)
-    assert estimate < 100e9, "a chr1-sized unit is estimated at %.1f GB of HBM" % (estimate / 1e9)
+    assert st["n_pos"] >= n1 and st["build_attempts"] == 1, st
+    assert st["pairs_in_file"] == pairs1 and st["sam_line_pairs"] - st["n_hits"] >= 31          # 31 batch boundaries, a line pair lost at each
+    assert st["device_bytes"] <= estimate < 100e9, "the unit took %.1f GB of HBM, AlignGraph_amd admits it with %.1f GB" % (st["device_bytes"] / 1e9, estimate / 1e9)
     print("chr1-sized unit: %.1f GB of HBM (estimate %.1f GB), %d hits, %d nodes, node sweep %.2f ms, walk %.1f ms" % (st["device_bytes"] / 1e9, estimate / 1e9, st["n_hits"], st["n_nodes"], st["ms_node_sweep"], st["ms_walk"]))
     monkeypatch.setenv("AGX_TEST_SMALL_CAPS", "1")
     with agx.Unit(k=5, insert_variation=50, coverage=5) as u2:
-        u2.load_files(tmp, 0)
+        u2.load_files(tmp1, 0)
         u2.upload(); u2.build()
-        again = u2.finish()
+        again1 = u2.finish()
         assert u2.stats()["build_attempts"] > 1
     monkeypatch.delenv("AGX_TEST_SMALL_CAPS")
-    if t.is_alive() or want or errs:
+
+    for t in checkers:
         t.join()
-    shutil.rmtree(run, ignore_errors=True)
+    shutil.rmtree(run4, ignore_errors=True); shutil.rmtree(run1, ignore_errors=True)
     assert not errs, errs
+    for uu in range(4):
+        for key in ("initial", "pre", "extended"):
+            assert got4[uu][key] == want4[uu][key], "cfg4 slice %d: %s differs from the oracle" % (uu, key)
+        assert stats4[uu]["build_attempts"] == 1 and stats4[uu]["n_pos"] >= lens[uu]
+    assert sum(stats4[uu]["sam_line_pairs"] for uu in range(4)) > 60000000
     for key in ("initial", "pre", "extended"):
-        assert got[key] == again[key], "%s differs between a first build and one whose capacities regrew" % key
-        if want:
-            assert got[key] == want[key], "%s differs from the serial executor" % key
-    assert got["extended"].count(b">") > 100 and len(got["extended"]) > 0.9 * n
+        assert again4[key] == want4[3][key], "cfg4: %s of slice 3 differs from the oracle after its capacities regrew" % key
+        assert got1[key] == again1[key], "chr1: %s differs between a first build and one whose capacities regrew" % key
+        assert got1[key] == want1[key], "chr1: %s differs from the serial executor" % key
+    assert got1["extended"].count(b">") > 100 and len(got1["extended"]) > 0.9 * n1
