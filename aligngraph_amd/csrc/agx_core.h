@@ -61,6 +61,40 @@ typedef uint8_t agx_u8;
 
 // agx_run and agx_hit are part of the public packed-array boundary: include/agx.h
 
+// ---- wire formats: what crosses PCIe ------------------------------------------------------------------------------------
+// A unit's upload is what a cfg3 job waits for (1.5 GB at 56 GB/s = 29 of its 50 ms in r02), so the arrays cross in a packed form and a kernel
+// at the head of the unit's first build expands them into the working forms above (agx_k_expand_hits, agx_k_expand_ref): hits 32 -> 16 bytes
+// (+ 12 for the three in eight that have a multi-run mate), runs 12 -> 8, reference bases 8 -> 2 bits.
+enum { AGX_WF_REV1 = 1, AGX_WF_REV2 = 2, AGX_WF_LEFT2 = 4, AGX_WF_RUNS1 = 8, AGX_WF_RUNS2 = 16 };
+struct agx_whit {             // a: reference offset of mate1's read index 0 if mate1 is one full-length run, b: the same for mate2.  A hit with a multi-run
+    agx_u32 a, b, row;        // mate has a side record; its index sits in the field of the first mate that has runs (a if RUNS1, else b)
+    agx_u16 len; agx_u8 flags, back;
+};
+struct agx_wside { agx_u32 runs1, runs2, nruns; };      // first run of each mate in the run pool; nruns = nruns1 | nruns2 << 16
+struct agx_wrun { agx_u32 t; agx_u16 q, n; };           // read lengths stay below 65536 (the loaders refuse longer reads)
+AGX_HD agx_whit agx_pack_hit(const agx_hit &h, agx_u32 side_index) {      // h: a staged hit (slot1 = row, pad[0] = left mate)
+    agx_whit w; w.a = h.nruns1 ? 0u : h.pos1; w.b = h.nruns2 ? 0u : h.pos2; w.row = h.slot1; w.len = h.len; w.back = h.back;
+    w.flags = (agx_u8)((h.rev1 ? AGX_WF_REV1 : 0) | (h.rev2 ? AGX_WF_REV2 : 0) | ((h.pad[0] & 1u) ? AGX_WF_LEFT2 : 0) | (h.nruns1 ? AGX_WF_RUNS1 : 0) | (h.nruns2 ? AGX_WF_RUNS2 : 0));
+    if (h.nruns1) w.a = side_index; else if (h.nruns2) w.b = side_index;
+    return w;
+}
+AGX_HD agx_hit agx_unpack_hit(const agx_whit &w, const agx_wside *sides) {
+    agx_hit h; h.slot1 = w.row; h.len = w.len; h.back = w.back; h.rev1 = (w.flags & AGX_WF_REV1) ? 1 : 0; h.rev2 = (w.flags & AGX_WF_REV2) ? 1 : 0;
+    h.pad[0] = (w.flags & AGX_WF_LEFT2) ? 1 : 0; h.pad[1] = h.pad[2] = 0;
+    h.pos1 = (w.flags & AGX_WF_RUNS1) ? 0u : w.a; h.pos2 = (w.flags & AGX_WF_RUNS2) ? 0u : w.b; h.runs1 = h.runs2 = 0; h.nruns1 = h.nruns2 = 0;
+    if (w.flags & (AGX_WF_RUNS1 | AGX_WF_RUNS2)) {
+        const agx_wside sd = sides[(w.flags & AGX_WF_RUNS1) ? w.a : w.b];
+        if (w.flags & AGX_WF_RUNS1) { h.runs1 = sd.runs1; h.nruns1 = (agx_u16)(sd.nruns & 0xFFFFu); }
+        if (w.flags & AGX_WF_RUNS2) { h.runs2 = sd.runs2; h.nruns2 = (agx_u16)(sd.nruns >> 16); }
+    }
+    return h;
+}
+// reference bases: 2 bits each (A, C, G, T = 0..3, four per byte, position x in bits 2 * (x & 3) of byte x >> 2) + the stretches that are anything
+// else (N runs, lower case), as runs of one byte value
+struct agx_refx { agx_u32 pos, len, byte; };
+AGX_HD agx_u32 agx_ref_code(agx_u32 c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u; }
+AGX_HD char agx_ref_base(agx_u32 code) { return (char)((0x54474341u >> (8u * (code & 3u))) & 0xFFu); }      // "ACGT"
+
 // per-position conti-mer key (the part of ContiMer, AG:51-62, that node build reads)
 struct agx_cmkey { agx_u32 cid, coff; };
 // per-position head of the conti-mer table, built on the device at upload: the first conti-mer of the position (NONE/NONE if there is

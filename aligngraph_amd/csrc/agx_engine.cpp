@@ -128,8 +128,8 @@ const HsaCopy &hsa_copy() { static const HsaCopy h; return h; }
 // positions from which a unit's host walk is split between two walkers (= walk_split's default in agx_walk.cpp; AGX_WALK_SPLIT_MIN, read at every download, overrides both: tests)
 inline size_t two_walkers_min() { const char *e = getenv("AGX_WALK_SPLIT_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4000000; }
 #define AGX_TWO_WALKERS_MIN two_walkers_min()
-// walkers for a unit of n_pos positions: one per 15.5 M positions from the threshold on, at most four (walk_split decides the same way from what it is given)
-inline int walkers_wanted(size_t n_pos) { if (n_pos < AGX_TWO_WALKERS_MIN) return 1; const char *e = getenv("AGX_WALK_SPLIT_WALKERS"); int k = e ? atoi(e) : (int)(n_pos / 15500000u); return k < 2 ? 2 : k > 4 ? 4 : k; }
+// walkers for a unit of n_pos positions: one per 5 M positions from the threshold on, at most four (walk_split decides the same way from what it is given)
+inline int walkers_wanted(size_t n_pos) { if (n_pos < AGX_TWO_WALKERS_MIN) return 1; const char *e = getenv("AGX_WALK_SPLIT_WALKERS"); int k = e ? atoi(e) : (int)(n_pos / 5000000u); return k < 2 ? 2 : k > 4 ? 4 : k; }
 
 // One helper thread per unit, started with the unit and asleep until it is handed work: what a unit can prepare while its upload and
 // build run (the pinned download buffers, the output buffers) without its worker waiting for it.  Not started on demand: creating a
@@ -214,7 +214,9 @@ struct agx_unit {
     hsa_signal_t dl_signal{}; hsa_agent_t dl_agent{}; bool dl_sdma = false;      // downloads by the SDMA engines (HsaCopy)
     DevArena arena;
     // staged inputs: what the device wants of T and P, in pinned memory (stage_inputs)
-    PBuf<agx_hit> s_hits; PBuf<agx_run> s_runs; PBuf<agx_u8> s_codes; PBuf<unsigned long long> s_other; size_t n_other = 0; PBuf<char> s_ref; PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
+    PBuf<agx_whit> s_hits; PBuf<agx_wside> s_sides; PBuf<agx_wrun> s_runs; PBuf<agx_u8> s_codes; PBuf<unsigned long long> s_other; size_t n_other = 0, n_sides = 0;      // the read alignments in the wire formats of agx_core.h
+    PBuf<agx_u8> s_ref; PBuf<agx_refx> s_refx; size_t n_refx = 0; bool ref_packed = false;      // the unit sequence: 2 bits per base + the stretches of other bytes (ref_packed), or the bytes as they are
+    PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
     size_t nh = 0, n_runs = 0, n_cm = 0, n_codes = 0; agx_u32 maxlen = 0;      // n_codes: bytes of packed classes (four bases each); n_other: listed bases that are not A, C, G, T
     std::vector<agx_u32> row_slot;      // staged read bases: one row per (pair, a mate) that some hit uses; row -> read slot (general loader / agx_unit_push_pairs)
     std::vector<uint64_t> row_off;      // fast loader: row -> where the read's bases start in the mapped reads file (the bases are never copied: the walk reads the k-mer tails of written records there)
@@ -224,6 +226,7 @@ struct agx_unit {
     // inputs on the device
     DBuf<agx_u32> d_cm_start, d_cm_cnt; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref; DBuf<agx_cmseg> d_segs; DBuf<unsigned long long> d_up_desc;
     DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<agx_u8> d_codes, d_vcodes; DBuf<unsigned long long> d_other;
+    DBuf<agx_whit> d_whits; DBuf<agx_wside> d_wsides; DBuf<agx_wrun> d_wruns; DBuf<agx_u8> d_wref; DBuf<agx_refx> d_refx;      // what was uploaded, until the first build has expanded it
     // derived
     DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_recs, d_scan_tmp, d_words; DBuf<unsigned long long> d_scan_desc; size_t scan_desc_n = 0;      // descriptors of the three one-launch scans   // d_words: counters/status
     // node table
@@ -321,17 +324,28 @@ struct UnitSink : StageSink {
     agx_unit *u; explicit UnitSink(agx_unit *x) : u(x) {}
     void *take(int which, size_t bytes) override {
         switch (which) {
-        case SA_HITS:  u->s_hits.alloc(bytes / sizeof(agx_hit) + 1); return u->s_hits.p;
-        case SA_RUNS:  u->s_runs.alloc(bytes / sizeof(agx_run) + 1); return u->s_runs.p;
+        case SA_HITS:  u->s_hits.alloc(bytes / sizeof(agx_whit) + 1); return u->s_hits.p;
+        case SA_SIDES: u->s_sides.alloc(bytes / sizeof(agx_wside) + 1); return u->s_sides.p;
+        case SA_RUNS:  u->s_runs.alloc(bytes / sizeof(agx_wrun) + 1); return u->s_runs.p;
         case SA_CODES: u->s_codes.alloc(bytes); return u->s_codes.p;
         default:       u->s_other.alloc(bytes / 8 + 1); return u->s_other.p;
         }
     }
 };
 void adopt_pairs(agx_unit *u, StagedPairs &S) {      // the staged read alignments' counts and the host-side row table
-    u->nh = S.nh; u->n_runs = S.n_runs; u->n_codes = S.n_codes; u->n_other = S.n_other; u->stride = S.stride; u->maxlen = S.maxlen;
+    u->nh = S.nh; u->n_runs = S.n_runs; u->n_sides = S.n_sides; u->n_codes = S.n_codes; u->n_other = S.n_other; u->stride = S.stride; u->maxlen = S.maxlen;
     u->pairs_in_file = S.n_pairs_in_file; u->sam_pairs = S.n_sam_pairs;
     u->row_off.swap(S.row_off); u->row_slot.swap(S.row_slot); u->n_rows = S.n_rows;
+}
+// the unit sequence (+ appended positions) for the upload: 2 bits per base and the stretches of other bytes, or — a soft-masked sequence — the bytes themselves
+void stage_reference(agx_unit *u, const char *ref, size_t n_pos, unsigned threads) {
+    std::vector<agx_refx> others;
+    u->s_ref.alloc((n_pos + 3) / 4 + 32);
+    u->ref_packed = getenv("AGX_REF_RAW") == nullptr && pack_reference(ref, n_pos, std::min(threads, 8u), u->s_ref.p, others);
+    if (u->ref_packed) { u->n_refx = others.size(); u->s_refx.alloc(u->n_refx + 1); if (u->n_refx) memcpy(u->s_refx.p, others.data(), u->n_refx * sizeof(agx_refx)); return; }
+    u->n_refx = 0; u->s_ref.alloc(n_pos + 16);
+    const unsigned T = std::max(1u, std::min(threads, 8u));
+    on_threads(T, [&](unsigned t) { const size_t lo = n_pos * t / T, hi = n_pos * (t + 1) / T; memcpy(u->s_ref.p + lo, ref + lo, hi - lo); });
 }
 void stage_inputs(agx_unit *u) {
     if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
@@ -343,13 +357,13 @@ void stage_inputs(agx_unit *u) {
     if (u->T.cm_cnt.size() != n_pos) throw Error{E_ARG, "conti-mer chains were not built"};
     { size_t el = 0; for (const agx_cmseg &g : u->T.segs) el += g.len; if (el != u->T.n_cm) throw Error{E_ARG, "conti-mer runs were not built"}; }
     u->n_seg0 = u->T.n_seg0; u->n_cm = u->T.n_cm;
-    u->s_ref.alloc(n_pos); u->n_segs = u->T.segs.size(); u->s_segs.alloc(u->n_segs + 1);
+    u->n_segs = u->T.segs.size(); u->s_segs.alloc(u->n_segs + 1);
     if (u->n_segs) memcpy(u->s_segs.p, u->T.segs.data(), u->n_segs * sizeof(agx_cmseg));
     std::vector<agx_u32> ce(u->T.chain_end_pos); std::sort(ce.begin(), ce.end()); ce.erase(std::unique(ce.begin(), ce.end()), ce.end());      // positions where a conti-mer chain
     u->n_chain_end = (agx_u32)ce.size(); u->s_chain_end.alloc(ce.size() + 1);                                                                 // ends: their main walk ids are special
     if (!ce.empty()) memcpy(u->s_chain_end.p, ce.data(), ce.size() * 4);
     const unsigned threads = loader_threads(u->P.bases.size() + n_pos + u->nh * 64);
-    on_threads(std::min(threads, 8u), [&](unsigned t) { const unsigned T = std::min(threads, 8u); const size_t lo = n_pos * t / T, hi = n_pos * (t + 1) / T; memcpy(u->s_ref.p + lo, u->T.ref.data() + lo, hi - lo); });
+    stage_reference(u, u->T.ref.data(), n_pos, threads);
     if (!u->pairs_staged) {
         UnitSink sink(u); StagedPairs S;
         u->n_slots = u->P.n_slots;
@@ -357,7 +371,6 @@ void stage_inputs(agx_unit *u) {
         adopt_pairs(u, S);
     }
     UnitView V = view_of(u->T, u->P);
-    V.ref = u->s_ref.p;                                 // (the staged copy: one-shot downloads never land in it)
     if (u->pairs_staged) { V.bases = u->reads_keep ? u->reads_keep->fv.p : nullptr; V.stride = u->stride; V.row_off = u->row_off.data(); }
     u->V = V;
     u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
@@ -371,17 +384,19 @@ void stage_inputs(agx_unit *u) {
 // mapped and paged in where it is touched.  Valid for one BATCH size, one k and for exactly the five text files it was made from (size and
 // modification time of each are in the header): anything else and the loader falls back to the text.
 namespace cache {
-enum { S_HITS = 0, S_RUNS, S_CODES, S_SEGS, S_CHAIN_END, S_ROWS, S_REF, S_CM_CNT, S_CHAIN_STR, S_INITIAL, S_BASES, S_OTHER, S_N };
+enum { S_HITS = 0, S_RUNS, S_CODES, S_SEGS, S_CHAIN_END, S_ROWS, S_REF, S_CM_CNT, S_CHAIN_STR, S_INITIAL, S_BASES, S_OTHER, S_SIDES, S_N };
 struct Header {
     char magic[8]; agx_u32 version, batch; unsigned long long stamp[5][2];
     unsigned long long n_pos, n_ref, nh, n_runs, n_cm, n_segs, n_seg0, n_rows, n_chain_end, n_codes, pairs_in_file, sam_pairs;
     agx_u32 stride, maxlen, n_slots, k;          // k: the staged hits name their left mate, which depends on it (agx_hit_left_is_mate2)
     agx_u32 rows_in_reads;                       // 1: S_ROWS holds 64-bit offsets into tmp/_reads.fa (whose size and time are part of the stamp), S_BASES is empty; 0: S_ROWS holds the
                                                  // read slot of every row and S_BASES the slots' bases (units that the general loader parsed)
-    agx_u32 sizes[4];                            // sizeof agx_hit, agx_run, agx_cmseg, Header: a file written by another layout is not this one
+    agx_u32 slot_stride;                         // bases per read slot in S_BASES (rows_in_reads == 0)
+    unsigned long long n_sides;
+    agx_u32 sizes[5];                            // sizeof agx_whit, agx_wrun, agx_cmseg, Header, agx_wside: a file written by another layout is not this one
     unsigned long long off[S_N], len[S_N];
 };
-const char MAGIC[8] = {'A', 'G', 'X', 'U', 'N', 'I', 'T', '4'};
+const char MAGIC[8] = {'A', 'G', 'X', 'U', 'N', 'I', 'T', '5'};
 void stamps(const std::string &d, int unit, unsigned long long st[5][2]) {
     const std::string s = std::to_string(unit);
     const std::string f[5] = {d + "/_genome." + s + ".fa", d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie"};
@@ -399,11 +414,13 @@ void save_cache(agx_unit *u, const std::string &dir, int unit) {
     const bool in_reads = u->pairs_staged;
     H.n_pos = u->V.n_pos; H.n_ref = u->V.n_ref; H.nh = u->nh; H.n_runs = u->n_runs; H.n_cm = u->n_cm; H.n_segs = u->n_segs; H.n_seg0 = u->n_seg0; H.n_rows = u->n_rows;
     H.n_chain_end = u->n_chain_end; H.n_codes = u->n_codes; H.pairs_in_file = u->pairs_in_file; H.sam_pairs = u->sam_pairs; H.stride = u->stride; H.maxlen = u->maxlen; H.n_slots = u->n_slots; H.k = u->prm.k;
-    H.rows_in_reads = in_reads ? 1u : 0u; H.sizes[0] = sizeof(agx_hit); H.sizes[1] = sizeof(agx_run); H.sizes[2] = sizeof(agx_cmseg); H.sizes[3] = sizeof(Header);
+    H.rows_in_reads = in_reads ? 1u : 0u; H.sizes[0] = sizeof(agx_whit); H.sizes[1] = sizeof(agx_wrun); H.sizes[2] = sizeof(agx_cmseg); H.sizes[3] = sizeof(Header); H.sizes[4] = sizeof(agx_wside);
+    H.slot_stride = u->V.stride; H.n_sides = u->n_sides;
     const void *ptr[S_N] = {u->s_hits.p, u->s_runs.p, u->s_codes.p, u->s_segs.p, u->s_chain_end.p, in_reads ? (const void *)u->row_off.data() : (const void *)u->row_slot.data(), u->V.ref, u->V.cm_cnt,
-                            u->V.chain_str, u->V.initial, in_reads ? nullptr : u->V.bases, u->s_other.p};
-    const unsigned long long len[S_N] = {u->nh * sizeof(agx_hit), u->n_runs * sizeof(agx_run), u->n_codes, u->n_segs * sizeof(agx_cmseg), (unsigned long long)u->n_chain_end * 4, (unsigned long long)u->n_rows * (in_reads ? 8 : 4),
-                                         u->V.n_pos, u->V.n_pos, u->T.chain_str.size(), u->V.n_initial, in_reads ? 0ull : (unsigned long long)u->n_slots * u->stride, (unsigned long long)u->n_other * 8};
+                            u->V.chain_str, u->V.initial, in_reads ? nullptr : u->V.bases, u->s_other.p, u->s_sides.p};
+    const unsigned long long len[S_N] = {u->nh * sizeof(agx_whit), u->n_runs * sizeof(agx_wrun), u->n_codes, u->n_segs * sizeof(agx_cmseg), (unsigned long long)u->n_chain_end * 4, (unsigned long long)u->n_rows * (in_reads ? 8 : 4),
+                                         u->V.n_pos, u->V.n_pos, u->T.chain_str.size(), u->V.n_initial, in_reads ? 0ull : (unsigned long long)u->n_slots * u->V.stride, (unsigned long long)u->n_other * 8,
+                                         u->n_sides * sizeof(agx_wside)};
     unsigned long long at = (sizeof(Header) + 4095) & ~4095ull;
     for (int i = 0; i < S_N; i++) { H.off[i] = at; H.len[i] = len[i]; at = (at + len[i] + 4095) & ~4095ull; }
     const std::string path = path_of(dir, unit), part = path + ".part";
@@ -440,13 +457,14 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof H || pread(fd, &H, sizeof H, 0) != (ssize_t)sizeof H) return false;
     unsigned long long st[5][2]; stamps(dir, unit, st);
     if (memcmp(H.magic, MAGIC, 8) != 0 || H.version != 2 || H.batch != u->prm.batch || H.k != u->prm.k || memcmp(st, H.stamp, sizeof st) != 0) return false;
-    if (H.sizes[0] != sizeof(agx_hit) || H.sizes[1] != sizeof(agx_run) || H.sizes[2] != sizeof(agx_cmseg) || H.sizes[3] != sizeof(Header)) return false;
+    if (H.sizes[0] != sizeof(agx_whit) || H.sizes[1] != sizeof(agx_wrun) || H.sizes[2] != sizeof(agx_cmseg) || H.sizes[3] != sizeof(Header) || H.sizes[4] != sizeof(agx_wside)) return false;
     for (int i = 0; i < S_N; i++) if (H.off[i] > (unsigned long long)sb.st_size || H.len[i] > (unsigned long long)sb.st_size - H.off[i]) return false;
     const bool in_reads = H.rows_in_reads == 1;
-    if (H.n_pos == 0 || H.n_pos >= 0xFFFFFF00ull || H.n_ref > H.n_pos || H.len[S_REF] != H.n_pos || H.len[S_CM_CNT] != H.n_pos || H.len[S_HITS] != H.nh * sizeof(agx_hit) || H.len[S_RUNS] != H.n_runs * sizeof(agx_run) ||
-        H.len[S_CODES] != H.n_codes || H.len[S_SEGS] != H.n_segs * sizeof(agx_cmseg) || H.n_seg0 > H.n_segs || H.len[S_ROWS] != H.n_rows * (in_reads ? 8 : 4) || (H.stride & 15u) ||
-        H.len[S_BASES] != (in_reads ? 0ull : (unsigned long long)H.n_slots * H.stride) || H.len[S_CHAIN_END] != H.n_chain_end * 4 || H.n_codes != H.n_rows * (H.stride / 4) || (H.len[S_OTHER] & 7u) ||
-        H.nh >= 0xFFFFFFFFull || H.n_runs >= 0xFFFFFFFFull || H.n_rows >= 0x7FFFFFFFull || H.maxlen > H.stride) return false;
+    if (H.n_pos == 0 || H.n_pos >= 0xFFFFFF00ull || H.n_ref > H.n_pos || H.len[S_REF] != H.n_pos || H.len[S_CM_CNT] != H.n_pos || H.len[S_HITS] != H.nh * sizeof(agx_whit) || H.len[S_RUNS] != H.n_runs * sizeof(agx_wrun) ||
+        H.len[S_SIDES] != H.n_sides * sizeof(agx_wside) || H.n_sides > H.nh ||
+        H.len[S_CODES] != H.n_codes || H.len[S_SEGS] != H.n_segs * sizeof(agx_cmseg) || H.n_seg0 > H.n_segs || H.len[S_ROWS] != H.n_rows * (in_reads ? 8 : 4) || (H.stride & 3u) ||
+        H.len[S_BASES] != (in_reads ? 0ull : (unsigned long long)H.n_slots * H.slot_stride) || H.len[S_CHAIN_END] != H.n_chain_end * 4 || H.n_codes != H.n_rows * (H.stride / 4) || (H.len[S_OTHER] & 7u) ||
+        H.nh >= 0xFFFFFFFFull || H.n_runs >= 0xFFFFFFFFull || H.n_rows >= 0x7FFFFFFFull || H.maxlen > H.stride || (!in_reads && H.maxlen > H.slot_stride)) return false;
     HIP_OK(hipSetDevice(u->prm.device));
     const double t0 = now_ms();
     std::unique_ptr<FileView> reads_map;
@@ -456,14 +474,14 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     drop_outputs(u);
     u->T = Threads(); u->P = Pairs(); u->cache_map.reset(); u->cache_map.p = m; u->cache_map.n = (size_t)sb.st_size; u->reads_keep.reset(); u->reads_map.reset();
     const char *base = (const char *)m;
-    u->nh = H.nh; u->n_runs = H.n_runs; u->n_cm = H.n_cm; u->n_segs = H.n_segs; u->n_seg0 = (agx_u32)H.n_seg0; u->n_chain_end = (agx_u32)H.n_chain_end; u->n_codes = H.n_codes; u->n_other = H.len[S_OTHER] / 8;
+    u->nh = H.nh; u->n_runs = H.n_runs; u->n_sides = H.n_sides; u->n_cm = H.n_cm; u->n_segs = H.n_segs; u->n_seg0 = (agx_u32)H.n_seg0; u->n_chain_end = (agx_u32)H.n_chain_end; u->n_codes = H.n_codes; u->n_other = H.len[S_OTHER] / 8;
     u->pairs_in_file = H.pairs_in_file; u->sam_pairs = H.sam_pairs; u->stride = H.stride; u->maxlen = H.maxlen; u->n_slots = H.n_slots; u->n_rows = (agx_u32)H.n_rows;
-    u->s_hits.alloc(u->nh + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16); u->s_other.alloc(u->n_other + 1); u->s_segs.alloc(u->n_segs + 1); u->s_chain_end.alloc((size_t)u->n_chain_end + 1); u->s_ref.alloc(H.n_pos);
+    u->s_hits.alloc(u->nh + 1); u->s_sides.alloc(u->n_sides + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16); u->s_other.alloc(u->n_other + 1); u->s_segs.alloc(u->n_segs + 1); u->s_chain_end.alloc((size_t)u->n_chain_end + 1);
     // the staged arrays: read into the pinned buffers, a few threads, large pieces
     struct Piece { void *dst; unsigned long long off, len; };
     std::vector<Piece> pieces;
     auto cut = [&](void *dst, int sec) { for (unsigned long long a = 0; a < H.len[sec]; a += 32ull << 20) pieces.push_back(Piece{(char *)dst + a, H.off[sec] + a, std::min<unsigned long long>(32ull << 20, H.len[sec] - a)}); };
-    cut(u->s_hits.p, S_HITS); cut(u->s_runs.p, S_RUNS); cut(u->s_codes.p, S_CODES); cut(u->s_other.p, S_OTHER); cut(u->s_segs.p, S_SEGS); cut(u->s_chain_end.p, S_CHAIN_END); cut(u->s_ref.p, S_REF);
+    cut(u->s_hits.p, S_HITS); cut(u->s_sides.p, S_SIDES); cut(u->s_runs.p, S_RUNS); cut(u->s_codes.p, S_CODES); cut(u->s_other.p, S_OTHER); cut(u->s_segs.p, S_SEGS); cut(u->s_chain_end.p, S_CHAIN_END);
     const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), pieces.size() ? pieces.size() : 1);
     std::vector<int> bad(threads, 0);
     on_threads(threads, [&](unsigned t) {
@@ -481,7 +499,9 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
         std::vector<int> bad2(threads, 0);
         on_threads(threads, [&](unsigned t) {
             for (size_t i = u->nh * t / threads, hi = u->nh * (t + 1) / threads; i < hi; i++) {
-                const agx_hit &h = u->s_hits.p[i];
+                const agx_whit &w = u->s_hits.p[i];
+                if ((w.flags & (AGX_WF_RUNS1 | AGX_WF_RUNS2)) && ((w.flags & AGX_WF_RUNS1) ? w.a : w.b) >= H.n_sides) { bad2[t] = 1; return; }
+                const agx_hit h = agx_unpack_hit(w, u->s_sides.p);
                 if (h.slot1 >= H.n_rows || h.len == 0 || h.len > H.maxlen || (h.nruns1 && (unsigned long long)h.runs1 + h.nruns1 > H.n_runs) || (h.nruns2 && (unsigned long long)h.runs2 + h.nruns2 > H.n_runs) || h.back > i) { bad2[t] = 1; return; }
             }
         });
@@ -494,8 +514,9 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
         if (fine && !in_reads) { const agx_u32 *rs = (const agx_u32 *)(base + H.off[S_ROWS]); for (size_t r = 0; r < H.n_rows && fine; r++) fine = rs[r] < H.n_slots; }
     }
     if (!fine) { u->cache_map.reset(); return false; }
-    UnitView V; V.ref = u->s_ref.p; V.n_pos = H.n_pos; V.n_ref = (agx_u32)H.n_ref; V.cm_cnt = (const agx_u8 *)(base + H.off[S_CM_CNT]); V.chain_str = base + H.off[S_CHAIN_STR];
-    V.hop = nullptr; V.segs = (const agx_cmseg *)(base + H.off[S_SEGS]); V.n_seg0 = (agx_u32)H.n_seg0; V.stride = H.stride; V.initial = base + H.off[S_INITIAL]; V.n_initial = H.len[S_INITIAL];
+    stage_reference(u, base + H.off[S_REF], H.n_pos, threads);
+    UnitView V; V.ref = base + H.off[S_REF]; V.n_pos = H.n_pos; V.n_ref = (agx_u32)H.n_ref; V.cm_cnt = (const agx_u8 *)(base + H.off[S_CM_CNT]); V.chain_str = base + H.off[S_CHAIN_STR];
+    V.hop = nullptr; V.segs = (const agx_cmseg *)(base + H.off[S_SEGS]); V.n_seg0 = (agx_u32)H.n_seg0; V.stride = in_reads ? H.stride : H.slot_stride; V.initial = base + H.off[S_INITIAL]; V.n_initial = H.len[S_INITIAL];
     u->row_off.clear(); u->row_slot.clear();
     if (in_reads) { u->reads_map = std::move(reads_map); V.bases = u->reads_map->p; V.row_off = (const uint64_t *)(base + H.off[S_ROWS]); }
     else { V.bases = base + H.off[S_BASES]; u->row_slot.assign((const agx_u32 *)(base + H.off[S_ROWS]), (const agx_u32 *)(base + H.off[S_ROWS]) + H.n_rows); }
@@ -574,7 +595,8 @@ Plan plan_capacities(const agx_unit *u) {
     // what the takes of do_upload add up to, plus the alignment of ~90 buffers
     const size_t per_pos = 4 + 16 + 1 + 4 + 1 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_hit) + sizeof(agx_dhit) + 16 + 4;
     const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
-    const size_t total = n_pos * per_pos + n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases + u->n_other * 8 +
+    const size_t wire = nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + (u->ref_packed ? n_pos / 4 + u->n_refx * sizeof(agx_refx) : 0) + 4096;
+    const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases + u->n_other * 8 +
                          (size_t)P.pool_cap * per_slot + ids_cap * per_id + (size_t)P.list_cap * 36 + (size_t)P.ovf_cap * 16 + (size_t)P.sp_cap * (sizeof(agx_walknode) + sizeof(agx_hop)) +
                          (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64 * 4 + (size_t)n_regions * AGX_REGION_PAD * 4 + (64u << 10) * 100;
     P.total = total + total / 64;
@@ -600,9 +622,11 @@ void do_upload(agx_unit *u) {
     const agx_u32 pool_cap = plan.pool_cap, list_cap = plan.list_cap, ovf_cap = plan.ovf_cap, sp_cap = plan.sp_cap;
     u->arena.reserve(plan.total);                        // one block for all of it
     DevArena &a = u->arena;
-    u->d_cm_start.alloc(a, n_pos + 2); u->d_cm_cnt.alloc(a, n_pos + 2); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos); u->d_cm_head.alloc(a, n_pos + 1);
+    u->d_cm_start.alloc(a, n_pos + 2); u->d_cm_cnt.alloc(a, n_pos + 2); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos + 16); u->d_cm_head.alloc(a, n_pos + 1);
     u->d_segs.alloc(a, u->n_segs + 1); u->d_up_desc.alloc(a, (n_pos + 2) / 4096 + 2);
     u->d_hits.alloc(a, nh + 1); u->d_runs.alloc(a, u->n_runs + 1); u->d_codes.alloc(a, u->n_codes + 16); u->d_vcodes.alloc(a, n_bases + 16); u->d_other.alloc(a, u->n_other + 1);
+    u->d_whits.alloc(a, nh + 1); u->d_wsides.alloc(a, u->n_sides + 1); u->d_wruns.alloc(a, u->n_runs + 1);
+    if (u->ref_packed) { u->d_wref.alloc(a, (n_pos + 3) / 4 + 32); u->d_refx.alloc(a, u->n_refx + 1); }
     u->d_dhit.alloc(a, nh + 1); u->d_rank4.alloc(a, 4 * (nh + 1));
     u->d_tile_cnt.alloc(a, (size_t)u->n_tiles + 1); u->d_tile_off.alloc(a, (size_t)u->n_tiles + 2); u->d_cursor.alloc(a, (size_t)u->n_tiles + 1);
     u->d_words.alloc(a, W_N + 6 + 16); u->h_words.alloc(W_N + 6 + 16);
@@ -631,10 +655,11 @@ void do_upload(agx_unit *u) {
             for (size_t at = 0; at < bytes;) { const size_t m = chunk ? std::min(chunk, bytes - at) : bytes; HIP_OK(hipMemcpyAsync((char *)dst + at, (const char *)src + at, m, hipMemcpyHostToDevice, st)); at += m; }
         };
         up(u->d_segs.p, u->s_segs.p, u->n_segs * sizeof(agx_cmseg));
-        up(u->d_hits.p, u->s_hits.p, nh * sizeof(agx_hit)); up(u->d_runs.p, u->s_runs.p, u->n_runs * sizeof(agx_run));
+        up(u->d_whits.p, u->s_hits.p, nh * sizeof(agx_whit)); up(u->d_wsides.p, u->s_sides.p, u->n_sides * sizeof(agx_wside)); up(u->d_wruns.p, u->s_runs.p, u->n_runs * sizeof(agx_wrun));
         HIP_OK(hipEventRecord(u->ev_hits, st));         // what the front of the build needs (conti-mer tables, hit preparation, binning) is there: it starts while the rest still travels
         up(u->d_codes.p, u->s_codes.p, u->n_codes); up(u->d_other.p, u->s_other.p, u->n_other * 8);      // first needed by the sweep
-        up(u->d_ref.p, u->s_ref.p, n_pos); up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);      // first needed by the walk preparation
+        if (u->ref_packed) { up(u->d_wref.p, u->s_ref.p, (n_pos + 3) / 4); up(u->d_refx.p, u->s_refx.p, u->n_refx * sizeof(agx_refx)); } else up(u->d_ref.p, u->s_ref.p, n_pos);
+        up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);      // first needed by the walk preparation
         layout_regions(u, nullptr, pool_cap - spill_min(u), true, st);
         HIP_OK(hipEventRecord(u->ev_uploaded, st));
     } catch (...) { (void)hipStreamSynchronize(st); throw; }      // (copies that were queued before the failure must not outlive the unit's HBM block)
@@ -662,7 +687,8 @@ void do_upload(agx_unit *u) {
 
     u->uploaded = true; u->built = false; u->downloaded = false;
     u->stats.ms_upload = now_ms() - t0;
-    u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + n_pos + nh * sizeof(agx_hit) + u->n_runs * sizeof(agx_run) + (size_t)u->n_chain_end * 4 + u->n_codes + u->n_other * 8 + ((size_t)u->n_regions + 1) * 4;
+    u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + (u->ref_packed ? (n_pos + 3) / 4 + u->n_refx * sizeof(agx_refx) : n_pos) + nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) +
+                            (size_t)u->n_chain_end * 4 + u->n_codes + u->n_other * 8 + ((size_t)u->n_regions + 1) * 4;
     u->stats.device_bytes = u->arena.capacity();
 }
 
@@ -722,7 +748,8 @@ void do_build(agx_unit *u) {
         st = turn.front;
         if (turn.n) HIP_OK(hipStreamWaitEvent(st, (u->ev.all || turn.prev_exclusive) ? turn.build_done[(turn.n - 1) & 1] : turn.sweep_done[(turn.n - 1) & 1], 0));
         if (u->ev.all) HIP_OK(hipEventRecord(u->ev.first, st));      // (every event record costs the stream a few microseconds: untimed builds record only what orders them)
-        if (!u->expanded) {   // the unit's first build: conti-mer tables from their runs (agx_cmseg: count per position, scan, keys, heads); the read bases follow behind the binning
+        if (!u->expanded) {   // the unit's first build: the hits and runs out of their wire forms, then the conti-mer tables from their runs (agx_cmseg: count per position, scan, keys, heads); the read bases follow behind the binning
+            agx_launch_expand_hits(u->d_whits.p, u->d_wsides.p, u->d_wruns.p, u->d_hits.p, u->d_runs.p, nh, (agx_u32)u->n_runs, st);
             HIP_OK(hipMemsetAsync(u->d_cm_cnt.p, 0, ((size_t)n_pos + 2) * 4, st)); HIP_OK(hipMemsetAsync(u->d_up_desc.p, 0, (((size_t)n_pos + 2) / 4096 + 2) * 8, st));
             agx_launch_seg_expand(u->d_segs.p, (agx_u32)u->n_segs, (agx_u32)u->n_cm, u->d_cm_cnt.p, u->d_cm_start.p, u->d_cm.p, n_pos, u->d_up_desc.p, st);
             agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, n_pos, st);
@@ -753,6 +780,7 @@ void do_build(agx_unit *u) {
             const size_t n_bases = u->n_codes * 4;
             if (early) HIP_OK(hipStreamWaitEvent(st, u->ev_uploaded, 0));      // (at most the tail of this unit's own upload: nothing else is ever waited for on a build stream)
             agx_launch_expand_codes(u->d_codes.p, u->d_vcodes.p, (n_bases + 15) / 16 * 16, u->d_other.p, u->n_other, st);
+            if (u->ref_packed) agx_launch_expand_ref(u->d_wref.p, u->d_ref.p, ((size_t)n_pos + 15) / 16 * 16, u->d_refx.p, (agx_u32)u->n_refx, st);      // (the letters are first read by the sweep's write-out)
             u->expanded = true;
         }
         HIP_OK(hipEventRecord(u->ev_front, st));
@@ -897,8 +925,8 @@ void do_download(agx_unit *u) {
     if (u->prm.flags & AGX_FLAG_ONE_SHOT) {
         // The inputs are in HBM and will not be uploaded again: their staged copies are dead pinned memory.  The download's arrays are cut
         // from the largest of those blocks, largest array first; what does not fit (thin read sets) gets a buffer of its own below.
-        struct Room { char *at; size_t left; } room[4] = {{(char *)u->s_hits.p, u->s_hits.block_bytes()}, {(char *)u->s_codes.p, u->s_codes.block_bytes()},
-                                                          {(char *)u->s_runs.p, u->s_runs.block_bytes()}, {(char *)u->s_other.p, u->s_other.block_bytes()}};
+        struct Room { char *at; size_t left; } room[5] = {{(char *)u->s_codes.p, u->s_codes.block_bytes()}, {(char *)u->s_hits.p, u->s_hits.block_bytes()},
+                                                          {(char *)u->s_runs.p, u->s_runs.block_bytes()}, {(char *)u->s_sides.p, u->s_sides.block_bytes()}, {(char *)u->s_other.p, u->s_other.block_bytes()}};
         // (a loan from an earlier download of this unit object must not survive into alloc() below: the memory it names has been handed out again)
         u->h_sp_node.release(); u->h_a_meta.release(); u->h_a_str.release(); for (auto &b : u->h_a_metas) b.release(); u->h_sp_hop.release(); u->h_side_xpos.release(); u->h_sp_bits.release(); u->h_sp_rank.release(); u->h_a_ovf.release();
         auto cut = [&](auto &buf, size_t count) {
@@ -962,7 +990,7 @@ void do_release(agx_unit *u) {
                     &u->d_slow_list, &u->d_rank4, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     for (auto *b : {&u->d_node_cnt, &u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
-    u->d_other.release();
+    u->d_other.release(); u->d_whits.release(); u->d_wsides.release(); u->d_wruns.release(); u->d_wref.release(); u->d_refx.release();
     u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_sp_hop.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
     u->d_ovf.release(); u->d_a_ovf.release(); u->d_huge_list.release(); u->d_scratch_huge.release(); u->huge = false; u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
     u->arena.reset();

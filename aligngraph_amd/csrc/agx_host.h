@@ -168,22 +168,26 @@ unsigned loader_threads(size_t bytes);      // AGX_LOAD_THREADS, else by the siz
 // agx_load.cpp — the fast loaders.  Each returns false when the input is anything but the well-formed common case (an '@' line, an empty line in the
 // middle, ids out of order, blocks that overlap, whatever would be an error): the caller then takes the general loader of agx_host.cpp, which follows
 // the reference line by line and reports errors in its order.  What they return is byte for byte what the general loader + staging produce.
-enum { SA_HITS = 0, SA_RUNS, SA_CODES, SA_OTHER, SA_N };
+struct ReadsIndex;
+enum { SA_HITS = 0, SA_SIDES, SA_RUNS, SA_CODES, SA_OTHER, SA_N };
 struct StageSink { virtual void *take(int which, size_t bytes) = 0; virtual ~StageSink() {} };      // where the staged arrays live (the engine: pinned memory)
-struct StagedPairs {        // what the upload wants of a unit's read alignments (agx_engine.cpp: stage)
-    agx_hit *hits = nullptr; size_t nh = 0;              // slot1 = ROW of the left mate's bases, pad[0] = which mate that is
-    agx_run *runs = nullptr; size_t n_runs = 0;
+struct StagedPairs {        // what the upload wants of a unit's read alignments, in the wire formats of agx_core.h (agx_engine.cpp: stage)
+    agx_whit *hits = nullptr; size_t nh = 0;             // row = ROW of the left mate's bases, AGX_WF_LEFT2 = which mate that is
+    agx_wside *sides = nullptr; size_t n_sides = 0;      // one per hit with a multi-run mate
+    agx_wrun *runs = nullptr; size_t n_runs = 0;
     agx_u8 *codes = nullptr; size_t n_codes = 0;         // 2-bit classes, stride / 4 bytes per row
     unsigned long long *other = nullptr; size_t n_other = 0;   // bases that are not A, C, G, T: row * stride + index, ascending
-    agx_u32 stride = 0, maxlen = 0, n_rows = 0;
+    agx_u32 stride = 0, maxlen = 0, n_rows = 0;          // stride: bases per row = the longest read rounded up to 4
     std::vector<uint64_t> row_off;                       // fast loader: where each row's bases start in the reads file
     std::vector<agx_u32> row_slot;                       // general loader: the read slot (Pairs::bases) of each row
     unsigned long long n_pairs_in_file = 0, n_sam_pairs = 0;
 };
-struct ReadsIndex;
 bool thread_contigs_fast(const std::string &contigs_fa, const std::string &psl, Threads &T);      // T.ref must hold the unit sequence (left as it was on false)
 bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam, long batch, agx_u32 k, unsigned threads, StageSink &sink, StagedPairs &S);
-void stage_pairs(const Pairs &P, agx_u32 k, unsigned threads, StageSink &sink, StagedPairs &S);     // the same arrays from what the general loader (or agx_unit_push_pairs) holds
+// the same arrays from what the general loader (or agx_unit_push_pairs) holds; staged_out (tests): the hits as the device will unpack them
+void stage_pairs(const Pairs &P, agx_u32 k, unsigned threads, StageSink &sink, StagedPairs &S, std::vector<agx_hit> *staged_out = nullptr);
+// reference bases as 2 bits each + the stretches of other bytes (agx_core.h); false: too many such stretches (soft-masked sequence): the bases cross as they are
+bool pack_reference(const char *ref, size_t n, unsigned threads, agx_u8 *packed /* (n + 3) / 4 + 16 bytes */, std::vector<agx_refx> &others);
 
 // agx_host.cpp
 void load_unit_reference(const std::string &path, std::string &ref);

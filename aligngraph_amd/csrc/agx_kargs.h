@@ -48,6 +48,8 @@ void agx_launch_zero(const agx_zero_args *, hipStream_t);
 void agx_launch_seg_expand(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 n_elems, agx_u32 *cnt, agx_u32 *cm_start, agx_cmkey *cm, agx_u32 n_pos, unsigned long long *desc, hipStream_t);      // runs -> cm_start[n_pos + 1], cm
 void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t);      // n_pos + 1 heads
 void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16, const unsigned long long *other, size_t n_other, hipStream_t);      // 2-bit base classes (agx_pack_classes2) + the listed other bases -> agx_vote_code bytes; n_bases16 a multiple of 16
+void agx_launch_expand_hits(const void *whits, const void *sides, const void *wruns, agx_hit *hits, agx_run *runs, agx_u32 n_hits, agx_u32 n_runs, hipStream_t);      // wire formats (agx_core.h) -> working arrays
+void agx_launch_expand_ref(const void *packed, void *ref, size_t n_pos16, const void *refx, agx_u32 n_refx, hipStream_t);      // 2-bit reference bases + the stretches of other bytes -> letters; n_pos16 a multiple of 16
 void agx_launch_hit_prep(const agx_prep_args *, hipStream_t);
 // exclusive scan of in[0..n] (n+1 entries, in[n] must be 0) into out[0..n]; out[n] = total
 void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u32 *tmp, hipStream_t);

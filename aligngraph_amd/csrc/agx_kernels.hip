@@ -28,16 +28,31 @@ static_assert(AGX_MAXV_LDS <= AGX_EM_W && AGX_MAXV_MID <= AGX_EM_W, "the LDS swe
 
 // ---- upload time: the conti-mer tables from their runs (agx_cmseg), then the per-position heads -----------------------------------
 // one thread per conti-mer: cnt[x] = highest rank + 1 (the ranks of a position are 0 .. count - 1); after the scan of cnt, the keys
+// The run of element e: found ONCE per wavefront by bisection (for the wavefront's first element: wave-uniform, scalar loads), then every lane walks forward
+// from there — the runs average hundreds of elements, so most wavefronts sit inside one run and no lane takes a step.  (r02: every thread bisected for
+// itself, 17 dependent loads per element: 0.87 ms for the two kernels on a 30 Mb unit.)
+__device__ __forceinline__ agx_u32 agx_seg_of_elem_wave(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 e, agx_u32 e_wave) {
+    agx_u32 s = __builtin_amdgcn_readfirstlane(agx_seg_of_elem(segs, n_segs, e_wave));
+    while (s + 1 < n_segs && segs[s + 1].elem0 <= e) s++;
+    return s;
+}
 __global__ void __launch_bounds__(256) agx_k_seg_count(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 n_elems, agx_u32 *cnt) {
     const agx_u32 e = blockIdx.x * 256u + threadIdx.x;
+    const agx_u32 e_wave = __builtin_amdgcn_readfirstlane(e & ~63u);
+    if (e_wave >= n_elems) return;
+    const agx_u32 si = agx_seg_of_elem_wave(segs, n_segs, e < n_elems ? e : n_elems - 1u, e_wave);
     if (e >= n_elems) return;
-    const agx_cmseg g = segs[agx_seg_of_elem(segs, n_segs, e)];
+    const agx_cmseg g = segs[si];
+    // (a position's ranks are 0 .. count - 1: rank 0 alone — nearly every position — needs no read-modify-write beyond the maximum with 1)
     atomicMax(&cnt[g.pos0 + (e - g.elem0)], g.rank + 1u);
 }
 __global__ void __launch_bounds__(256) agx_k_seg_fill(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 n_elems, const agx_u32 *cm_start, agx_cmkey *cm) {
     const agx_u32 e = blockIdx.x * 256u + threadIdx.x;
+    const agx_u32 e_wave = __builtin_amdgcn_readfirstlane(e & ~63u);
+    if (e_wave >= n_elems) return;
+    const agx_u32 si = agx_seg_of_elem_wave(segs, n_segs, e < n_elems ? e : n_elems - 1u, e_wave);
     if (e >= n_elems) return;
-    const agx_cmseg g = segs[agx_seg_of_elem(segs, n_segs, e)];
+    const agx_cmseg g = segs[si];
     const agx_u32 j = e - g.elem0;
     cm[cm_start[g.pos0 + j] + g.rank] = agx_cmkey{g.cid, g.coff0 + j * g.dcoff};
 }
@@ -78,6 +93,27 @@ __global__ void __launch_bounds__(256) agx_k_expand_codes(const agx_u32 *packed,
 __global__ void __launch_bounds__(256) agx_k_patch_codes(const unsigned long long *other, size_t n, agx_u8 *vcodes) {
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (i < n) vcodes[other[i]] = agx_class_vote_code(4u);
+}
+
+// ---- the packed upload -> the working arrays (agx_core.h "wire formats"): head of a unit's first build ---------------------------------
+__global__ void __launch_bounds__(256) agx_k_expand_hits(const agx_whit *whits, const agx_wside *sides, const agx_wrun *wruns, agx_hit *hits, agx_run *runs, agx_u32 n_hits, agx_u32 n_runs) {
+    const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n_hits) hits[i] = agx_unpack_hit(whits[i], sides);
+    if (i < n_runs) { const agx_wrun r = wruns[i]; runs[i] = agx_run{r.q, r.t, r.n}; }
+}
+// 16 positions per thread: one packed word in, sixteen letters out
+__global__ void __launch_bounds__(256) agx_k_expand_ref(const agx_u32 *packed, uint4 *ref, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n16) return;
+    const agx_u32 v = packed[i];
+    agx_u32 w[4];
+    for (int j = 0; j < 4; j++) { agx_u32 o = 0; for (int b = 0; b < 4; b++) o |= (agx_u32)(agx_u8)agx_ref_base((v >> (8 * j + 2 * b)) & 3u) << (8 * b); w[j] = o; }
+    ref[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+// one block per stretch of other bytes
+__global__ void __launch_bounds__(256) agx_k_patch_ref(const agx_refx *x, agx_u8 *ref) {
+    const agx_refx r = x[blockIdx.x];
+    for (agx_u32 j = threadIdx.x; j < r.len; j += 256u) ref[(size_t)r.pos + j] = (agx_u8)r.byte;
 }
 
 // ---- hit_prep: one thread per hit -------------------------------------------------------------------------------
@@ -229,7 +265,7 @@ __global__ void __launch_bounds__(256) agx_k_bin_fill(agx_bin_args A) {
 }
 
 // one wavefront per tile; a hit's place in the file is unique, so an element's rank is the number of smaller keys
-#define AGX_SORT_LDS 2048
+#define AGX_SORT_LDS 512       // list entries of a tile sorted in LDS (a tile of the bench units holds ~27; 2048 — 32 KB per block — kept the kernel at 20 of a CU's 32 wavefronts)
 // The kernel writes the tile's RECORD list: 32 bytes per listed hit, in SAM (= hit id) order, so that the sweeps read one sequential,
 // wave-uniform stream (scalar loads) instead of chasing list entry -> record.  A record is the first 32 bytes of agx_tile_record(): the
 // hit's derived record, or the linear piece of it that covers this tile.
@@ -552,6 +588,15 @@ void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16,
     const size_t n16 = n_bases16 / 16;
     if (n16) hipLaunchKernelGGL(agx_k_expand_codes, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const agx_u32 *)packed, (uint4 *)vcodes, n16);
     if (n_other) hipLaunchKernelGGL(agx_k_patch_codes, dim3((unsigned)((n_other + 255) / 256)), dim3(256), 0, st, other, n_other, (agx_u8 *)vcodes);
+}
+void agx_launch_expand_hits(const void *whits, const void *sides, const void *wruns, agx_hit *hits, agx_run *runs, agx_u32 n_hits, agx_u32 n_runs, hipStream_t st) {
+    const agx_u32 n = n_hits > n_runs ? n_hits : n_runs;
+    if (n) hipLaunchKernelGGL(agx_k_expand_hits, dim3((n + 255) / 256), dim3(256), 0, st, (const agx_whit *)whits, (const agx_wside *)sides, (const agx_wrun *)wruns, hits, runs, n_hits, n_runs);
+}
+void agx_launch_expand_ref(const void *packed, void *ref, size_t n_pos16, const void *refx, agx_u32 n_refx, hipStream_t st) {
+    const size_t n16 = n_pos16 / 16;
+    if (n16) hipLaunchKernelGGL(agx_k_expand_ref, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const agx_u32 *)packed, (uint4 *)ref, n16);
+    if (n_refx) hipLaunchKernelGGL(agx_k_patch_ref, dim3(n_refx), dim3(256), 0, st, (const agx_refx *)refx, (agx_u8 *)ref);
 }
 void agx_launch_hit_prep(const agx_prep_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_hit_prep, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);

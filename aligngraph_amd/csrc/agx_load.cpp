@@ -393,51 +393,85 @@ inline bool passes_fast(const Mate &m) { return ((m.ins | m.del | m.clipL | m.cl
 
 }  // namespace
 
-// The general path's staging of the read alignments (what agx_engine.cpp's stage_inputs did inline): hits as they are, except that slot1 becomes
-// the ROW of the left mate's bases and pad[0] says which mate that is; one row of 2-bit classes per (pair, left mate), first come.
-void stage_pairs(const Pairs &P, agx_u32 k, unsigned threads, StageSink &sink, StagedPairs &S) {
+// The general path's staging of the read alignments (what agx_engine.cpp's stage_inputs did inline): every hit with the ROW of its left mate's bases
+// and which mate that is, packed into the wire formats; one row of 2-bit classes per (pair, left mate), first come.
+void stage_pairs(const Pairs &P, agx_u32 k, unsigned threads, StageSink &sink, StagedPairs &S, std::vector<agx_hit> *staged_out) {
     S = StagedPairs();
     const size_t nh = P.hits.size(), n_runs = P.runs.size();
-    if (P.stride & 15u) throw Error{E_ARG, "read stride must be a multiple of 16"};
-    S.nh = nh; S.n_runs = n_runs; S.stride = P.stride; S.n_pairs_in_file = P.n_pairs_in_file; S.n_sam_pairs = P.n_sam_pairs;
-    S.hits = (agx_hit *)sink.take(SA_HITS, (nh + 1) * sizeof(agx_hit)); S.runs = (agx_run *)sink.take(SA_RUNS, (n_runs + 1) * sizeof(agx_run));
-    for (const agx_hit &h : P.hits) S.maxlen = std::max<agx_u32>(S.maxlen, h.len);
+    S.nh = nh; S.n_runs = n_runs; S.n_pairs_in_file = P.n_pairs_in_file; S.n_sam_pairs = P.n_sam_pairs;
+    for (const agx_hit &h : P.hits) { S.maxlen = std::max<agx_u32>(S.maxlen, h.len); if (h.len > P.stride) throw Error{E_ARG, "read longer than the read stride"}; }
+    S.stride = (S.maxlen + 3u) & ~3u;
+    S.hits = (agx_whit *)sink.take(SA_HITS, (nh + 1) * sizeof(agx_whit)); S.runs = (agx_wrun *)sink.take(SA_RUNS, (n_runs + 1) * sizeof(agx_wrun));
     const agx_run *runs = P.runs.data();
+    for (size_t i = 0; i < n_runs; i++) { if (runs[i].q > 0xFFFFu || runs[i].n > 0xFFFFu) throw Error{E_UNSUPPORTED, "alignment run beyond read index 65535"}; S.runs[i] = agx_wrun{runs[i].t, (agx_u16)runs[i].q, (agx_u16)runs[i].n}; }
+    std::vector<agx_hit> st(nh);
     Team team(std::max(1u, threads));
     const unsigned T = team.size();
     team.run([&](unsigned t) {
         for (size_t i = nh * t / T, hi = nh * (t + 1) / T; i < hi; i++) {
             agx_hit h = P.hits[i];
             h.pad[0] = agx_hit_left_is_mate2(h, runs, k) ? 1 : 0; h.pad[1] = h.pad[2] = 0;
-            S.hits[i] = h;
+            st[i] = h;
         }
-        const size_t lo = n_runs * t / T, hi = n_runs * (t + 1) / T; if (hi > lo) memcpy(S.runs + lo, runs + lo, (hi - lo) * sizeof(agx_run));
     });
     std::vector<agx_u16> row_len;                       // read length of every row: bases beyond it are never looked at
+    size_t n_sides = 0;
     {
         std::vector<agx_u32> row_of((size_t)P.n_slots + 1, AGX_NONE);
         S.row_slot.reserve(P.n_slots / 2 + 16); row_len.reserve(P.n_slots / 2 + 16);
         for (size_t i = 0; i < nh; i++) {
-            agx_hit &h = S.hits[i];
+            agx_hit &h = st[i];
             const agx_u32 sa = h.slot1 + (h.pad[0] & 1u);
             if (sa >= P.n_slots) throw Error{E_ARG, "hit names a read slot outside the unit"};
             if (row_of[sa] == AGX_NONE) { row_of[sa] = (agx_u32)S.row_slot.size(); S.row_slot.push_back(sa); row_len.push_back(h.len); }
             else if (row_len[row_of[sa]] < h.len) row_len[row_of[sa]] = h.len;
             h.slot1 = row_of[sa];
+            if (h.nruns1 | h.nruns2) n_sides++;
         }
     }
-    const size_t quarter = P.stride / 4, n_rows = S.row_slot.size();
+    S.n_sides = n_sides; S.sides = (agx_wside *)sink.take(SA_SIDES, (n_sides + 1) * sizeof(agx_wside));
+    { size_t at = 0; for (size_t i = 0; i < nh; i++) { const agx_hit &h = st[i]; const bool sd = (h.nruns1 | h.nruns2) != 0; S.hits[i] = agx_pack_hit(h, (agx_u32)at); if (sd) S.sides[at++] = agx_wside{h.runs1, h.runs2, (agx_u32)h.nruns1 | ((agx_u32)h.nruns2 << 16)}; } }
+    const size_t quarter = S.stride / 4, n_rows = S.row_slot.size();
     S.n_rows = (agx_u32)n_rows; S.n_codes = n_rows * quarter;
     S.codes = (agx_u8 *)sink.take(SA_CODES, S.n_codes + 16);
     const char *bases = P.bases.data();
     std::vector<std::vector<unsigned long long>> other(T);
     team.run([&](unsigned t) {
         for (size_t r = n_rows * t / T, hi = n_rows * (t + 1) / T; r < hi; r++)
-            pack_row(bases + (size_t)S.row_slot[r] * P.stride, std::min<size_t>(row_len[r], P.stride), S.codes + r * quarter, quarter, (unsigned long long)r * P.stride, other[t]);
+            pack_row(bases + (size_t)S.row_slot[r] * P.stride, row_len[r], S.codes + r * quarter, quarter, (unsigned long long)r * S.stride, other[t]);
     });
     for (const auto &o : other) S.n_other += o.size();
     S.other = (unsigned long long *)sink.take(SA_OTHER, (S.n_other + 1) * 8);
     { size_t at = 0; for (const auto &o : other) { if (!o.empty()) memcpy(S.other + at, o.data(), o.size() * 8); at += o.size(); } }      // (threads take ascending row ranges: the list is sorted)
+    if (staged_out) staged_out->swap(st);
+}
+
+// Reference bases for the upload: 2 bits each where they are A, C, G, T, and the rest as stretches of one byte value (N runs; a soft-masked sequence
+// has too many of them: false, and the bases cross as they are).  The classes are the read bases' (agx_base_class: A, C, G, T = 0..3).
+bool pack_reference(const char *ref, size_t n, unsigned threads, agx_u8 *packed, std::vector<agx_refx> &others) {
+    others.clear();
+    const size_t chunk = (size_t)1 << 20, n_chunks = (n + chunk - 1) / chunk;
+    std::vector<std::vector<unsigned long long>> other(n_chunks);
+    Team team(std::max<unsigned>(1u, (unsigned)std::min<size_t>(threads, n_chunks ? n_chunks : 1)));
+    std::atomic<size_t> next{0};
+    team.run([&](unsigned) {
+        for (size_t c; (c = next.fetch_add(1)) < n_chunks;) {
+            const size_t lo = c * chunk, len = std::min(chunk, n - lo);          // (chunks start at multiples of 4: whole bytes)
+            pack_row(ref + lo, len, packed + lo / 4, (len + 3) / 4, lo, other[c]);
+        }
+    });
+    size_t total = 0; for (const auto &o : other) total += o.size();
+    const size_t limit = n / 256 + 1024;                // stretches, not bases: an N run of a million is one
+    agx_refx cur{0, 0, 0};
+    for (const auto &o : other) for (unsigned long long x : o) {
+        const agx_u32 byte = (agx_u8)ref[x];
+        if (cur.len && (unsigned long long)cur.pos + cur.len == x && cur.byte == byte) { cur.len++; continue; }
+        if (cur.len) { others.push_back(cur); if (others.size() > limit) return false; }
+        cur = agx_refx{(agx_u32)x, 1u, byte};
+    }
+    if (cur.len) others.push_back(cur);
+    (void)total;
+    return others.size() <= limit;
 }
 
 // loadReadAlignment's parsing half (loadSeq AG:361-404, loadReadAli AG:1233-1277 with parseBOWTIE AG:181-285 and updateContig AG:763-815) and the
@@ -456,7 +490,7 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
         SBuf<agx_hit> cand; SBuf<agx_u32> cand_pair; SBuf<agx_run> runs;      // pairs that pass the identity filter: slot1 = read id, run indices local; which pair each is
         size_t pair_base = 0;                             // global index of the first pair
         // after the batch rule (phase C): what stays, in final form but local numbering
-        size_t n_keep = 0, n_runs = 0, lead_n = 0; agx_u32 maxlen = 0;
+        size_t n_keep = 0, n_runs = 0, n_sides = 0, lead_n = 0, side_base = 0; agx_u32 maxlen = 0;
         agx_u32 lead_rows = 0, n_rows_local = 0;          // rows opened by the leading group (the hits of the range's first read id), and by the whole range, as if nothing came before
         agx_u32 last_id = 0, last_count = 0; agx_u32 last_row[2] = {AGX_NONE, AGX_NONE};      // the range's last group: kept hits, rows of its mates (local numbering)
         bool single_group = false, lead_fixed = false;
@@ -604,7 +638,7 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
             agx_u32 info = 0;
             if (row[m] == AGX_NONE) { row[m] = rows++; info = 0x80000000u; }
             r.cand_pair[i] = info | row[m];
-            r.n_runs += (size_t)h.nruns1 + h.nruns2;
+            r.n_runs += (size_t)h.nruns1 + h.nruns2; r.n_sides += (h.nruns1 | h.nruns2) ? 1u : 0u;
             r.maxlen = std::max<agx_u32>(r.maxlen, h.len);
         }
         if (lead) { r.lead_n = w; r.lead_rows = rows; r.single_group = true; }
@@ -613,12 +647,12 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
     });
     for (Range &r : R) if (r.bad) return false;
     // ---- phase C3 (sequential, a few operations per range): where every range's hits, runs and rows go; a pair whose hits straddle a range boundary ----
-    size_t nh = 0, n_runs = 0; agx_u32 n_rows = 0, maxlen = 0;
+    size_t nh = 0, n_runs = 0, n_sides = 0; agx_u32 n_rows = 0, maxlen = 0;
     {
         bool have = false; agx_u32 c_id = 0, c_count = 0, c_row[2] = {AGX_NONE, AGX_NONE}; agx_u16 c_len = 0;      // the pair the ranges so far ended with: its kept hits, the rows of its mates (final numbering)
         for (Range &r : R) {
-            r.hit_base = nh; r.run_base = n_runs; r.row_base = n_rows; r.row_shift = 0; r.lead_fixed = false;
-            nh += r.n_keep; n_runs += r.n_runs; maxlen = std::max(maxlen, r.maxlen);
+            r.hit_base = nh; r.run_base = n_runs; r.side_base = n_sides; r.row_base = n_rows; r.row_shift = 0; r.lead_fixed = false;
+            nh += r.n_keep; n_runs += r.n_runs; n_sides += r.n_sides; maxlen = std::max(maxlen, r.maxlen);
             if (!r.n_keep) continue;
             const bool joins = have && c_id == r.cand[0].slot1;
             agx_u32 lead_row[2] = {AGX_NONE, AGX_NONE};
@@ -647,22 +681,24 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
         }
     }
     if (nh == 0) {          // nothing kept: what the general loader leaves (no rows, stride 0)
-        S.hits = (agx_hit *)sink.take(SA_HITS, sizeof(agx_hit)); S.runs = (agx_run *)sink.take(SA_RUNS, sizeof(agx_run));
+        S.hits = (agx_whit *)sink.take(SA_HITS, sizeof(agx_whit)); S.runs = (agx_wrun *)sink.take(SA_RUNS, sizeof(agx_wrun)); S.sides = (agx_wside *)sink.take(SA_SIDES, sizeof(agx_wside));
         S.codes = (agx_u8 *)sink.take(SA_CODES, 16); S.other = (unsigned long long *)sink.take(SA_OTHER, 8);
         return true;
     }
     if (n_runs >= 0xFFFFFFFFull) return false;
     tt[5] = now_ms();
-    const agx_u32 stride = (maxlen + 15u) & ~15u; const size_t quarter = stride / 4;
-    S.nh = nh; S.n_runs = n_runs; S.stride = stride; S.maxlen = maxlen; S.n_rows = n_rows; S.n_codes = (size_t)n_rows * quarter;
-    S.hits = (agx_hit *)sink.take(SA_HITS, (nh + 1) * sizeof(agx_hit)); S.runs = (agx_run *)sink.take(SA_RUNS, (n_runs + 1) * sizeof(agx_run));
+    const agx_u32 stride = (maxlen + 3u) & ~3u; const size_t quarter = stride / 4;
+    S.nh = nh; S.n_runs = n_runs; S.n_sides = n_sides; S.stride = stride; S.maxlen = maxlen; S.n_rows = n_rows; S.n_codes = (size_t)n_rows * quarter;
+    S.hits = (agx_whit *)sink.take(SA_HITS, (nh + 1) * sizeof(agx_whit)); S.runs = (agx_wrun *)sink.take(SA_RUNS, (n_runs + 1) * sizeof(agx_wrun));
+    S.sides = (agx_wside *)sink.take(SA_SIDES, (n_sides + 1) * sizeof(agx_wside));
     S.codes = (agx_u8 *)sink.take(SA_CODES, S.n_codes + 16);
     S.row_off.assign(n_rows, 0);
     tt[4] = now_ms();
     // ---- phase D: hits and runs to their final places; the left mates' bases from the reads file, as 2-bit classes, by the hit that opens the row ----
     const char *rb = reads.fv.p, *re = reads.fv.p + reads.fv.n;
     each_range(2, [&](Range &r) {
-        size_t run_at = r.run_base;
+        size_t run_at = r.run_base, side_at = r.side_base;
+        auto put_runs = [&](agx_u32 from, agx_u32 n) { for (agx_u32 j = 0; j < n; j++) { const agx_run &x = r.runs[from + j]; S.runs[run_at + j] = agx_wrun{x.t, (agx_u16)x.q, (agx_u16)x.n}; } };
         for (size_t i = 0; i < r.n_keep; i++) {
             // the reads are spread over the whole (mapped) reads file: every row is two cache misses and a TLB miss unless it is asked for ahead of time
             if (i + 40 < r.n_keep && (r.cand_pair[i + 40] & 0x80000000u)) { const unsigned long long pr = 2ull * r.cand[i + 40].slot1; if (pr + 1 < reads.rec_off.size()) __builtin_prefetch(&reads.rec_off[pr]); }
@@ -672,10 +708,11 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
             const bool opens = (info & 0x80000000u) != 0;
             const agx_u32 row = (r.lead_fixed && i < r.lead_n) ? (info & 0x7FFFFFFFu) : r.row_base + (info & 0x7FFFFFFFu) - r.row_shift;
             const unsigned m = h.pad[0] & 1u;
-            if (h.nruns1) { memcpy(S.runs + run_at, r.runs.data() + h.runs1, (size_t)h.nruns1 * sizeof(agx_run)); h.runs1 = (agx_u32)run_at; run_at += h.nruns1; }
-            if (h.nruns2) { memcpy(S.runs + run_at, r.runs.data() + h.runs2, (size_t)h.nruns2 * sizeof(agx_run)); h.runs2 = (agx_u32)run_at; run_at += h.nruns2; }
+            if (h.nruns1) { put_runs(h.runs1, h.nruns1); h.runs1 = (agx_u32)run_at; run_at += h.nruns1; }
+            if (h.nruns2) { put_runs(h.runs2, h.nruns2); h.runs2 = (agx_u32)run_at; run_at += h.nruns2; }
             h.slot1 = row; h.pad[1] = h.pad[2] = 0;
-            S.hits[r.hit_base + i] = h;
+            S.hits[r.hit_base + i] = agx_pack_hit(h, (agx_u32)side_at);
+            if (h.nruns1 | h.nruns2) S.sides[side_at++] = agx_wside{h.runs1, h.runs2, (agx_u32)h.nruns1 | ((agx_u32)h.nruns2 << 16)};
             if (!opens) continue;
             // both mates' records are looked at (the general loader checks both), the left mate's bases are packed
             const unsigned long long r0 = 2ull * id;

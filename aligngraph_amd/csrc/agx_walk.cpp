@@ -573,8 +573,9 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     const agx_u32 warm = getenv("AGX_WALK_SPLIT_WARMUP") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_WARMUP"), nullptr, 10) : 400000u;
     const agx_u32 n_ref = V.n_ref < G.n_pos ? V.n_ref : G.n_pos;
     if (!assistant || !G.meta_copy[0] || n_ref < min_ref || n_ref < 16 || getenv("AGX_WALK_NO_SPLIT")) return false;
-    // walkers: one per 15.5 M positions (at least two), as many as there are copies of the meta bytes and helper threads, at most four
-    int K = getenv("AGX_WALK_SPLIT_WALKERS") ? atoi(getenv("AGX_WALK_SPLIT_WALKERS")) : (int)(n_ref / 15500000u);
+    // walkers: one per 5 M positions (at least two), as many as there are copies of the meta bytes and helper threads, at most four.  (r02: one per
+    // 15.5 M — a 19 Mb unit, the LAST of a cfg3 job, was walked by two in 13 ms while the cores of the finished units idled: 52 -> 49 ms per job with four)
+    int K = getenv("AGX_WALK_SPLIT_WALKERS") ? atoi(getenv("AGX_WALK_SPLIT_WALKERS")) : (int)(n_ref / 5000000u);
     if (K < 2) K = 2;
     if (K > 4) K = 4;
     { int copies = 0; while (copies < 3 && G.meta_copy[copies]) copies++; if (K > 1 + copies) K = 1 + copies; if (K > 1 + assistant->helpers()) K = 1 + assistant->helpers(); }

@@ -359,31 +359,46 @@ extern "C" int agx_hostsim_compare_loaders(const char *tmp_dir, int unit, int k,
         // ---- read alignments ----
         std::unique_ptr<ReadsIndex, void (*)(ReadsIndex *)> ri(nullptr, reads_index_close);
         try { ri.reset(reads_index_open(d + "/_reads.fa")); } catch (const Error &e) { say("reads: " + e.msg); return 64; }
-        Pairs P; VecSink A, B; StagedPairs SA, SB; slow_ok = true;
-        try { load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie", batch, (agx_u32)k, P, ri.get()); stage_pairs(P, (agx_u32)k, (unsigned)threads, A, SA); } catch (const Error &e) { slow_ok = false; slow_err = e.msg; }
+        Pairs P; VecSink A, B; StagedPairs SA, SB; slow_ok = true; std::vector<agx_hit> staged;
+        try { load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie", batch, (agx_u32)k, P, ri.get()); stage_pairs(P, (agx_u32)k, (unsigned)threads, A, SA, &staged); } catch (const Error &e) { slow_ok = false; slow_err = e.msg; }
         fast_ok = false;
         try { fast_ok = load_pairs_fast(*ri, d + "/_reads_genome." + s + ".bowtie", batch, (agx_u32)k, (unsigned)threads, B, SB); } catch (const Error &e) { if (slow_ok) { say("fast read loader threw: " + e.msg); return -4; } }
         if (!slow_ok && fast_ok) { say("general read loader fails (" + slow_err + ") but the fast one accepts the input"); return -5; }
         if (!fast_ok) declined |= 2;
+        if (slow_ok) {      // the wire forms (agx_core.h) must unpack to exactly the staged hits and the loader's runs
+            for (size_t i = 0; i < SA.nh; i++) { const agx_hit h = agx_unpack_hit(SA.hits[i], SA.sides); agx_hit w = staged[i]; w.pad[1] = w.pad[2] = 0; if (memcmp(&h, &w, sizeof h) != 0) { say("wire form of hit " + std::to_string(i) + " does not unpack to the staged hit"); return -30; } }
+            for (size_t i = 0; i < SA.n_runs; i++) if (SA.runs[i].q != P.runs[i].q || SA.runs[i].t != P.runs[i].t || SA.runs[i].n != P.runs[i].n) { say("wire form of run " + std::to_string(i) + " differs"); return -31; }
+        }
         if (slow_ok && fast_ok) {
             auto bad = [&](const std::string &what) { say("read alignments differ: " + what); return -20; };
             if (SA.nh != SB.nh) return bad("number of hits " + std::to_string(SA.nh) + " / " + std::to_string(SB.nh));
             if (SA.n_runs != SB.n_runs) return bad("number of runs");
+            if (SA.n_sides != SB.n_sides) return bad("number of side records");
             if (SA.n_sam_pairs != SB.n_sam_pairs) return bad("n_sam_pairs " + std::to_string(SA.n_sam_pairs) + " / " + std::to_string(SB.n_sam_pairs));
             if (SA.n_pairs_in_file != SB.n_pairs_in_file) return bad("n_pairs_in_file");
-            if (SA.nh) { if (SA.stride != SB.stride) return bad("stride");
-            if (SA.maxlen != SB.maxlen) return bad("maxlen"); };
+            if (SA.nh) { if (SA.stride != SB.stride) return bad("stride"); if (SA.maxlen != SB.maxlen) return bad("maxlen"); }
             if (SA.n_rows != SB.n_rows) return bad("rows " + std::to_string(SA.n_rows) + " / " + std::to_string(SB.n_rows));
-            for (size_t i = 0; i < SA.nh; i++) if (memcmp(&SA.hits[i], &SB.hits[i], sizeof(agx_hit)) != 0) { char b[256]; const agx_hit &x = SA.hits[i], &y = SB.hits[i];
+            for (size_t i = 0; i < SA.nh; i++) if (memcmp(&SA.hits[i], &SB.hits[i], sizeof(agx_whit)) != 0) { char b[256]; const agx_hit x = agx_unpack_hit(SA.hits[i], SA.sides), y = agx_unpack_hit(SB.hits[i], SB.sides);
                 snprintf(b, sizeof b, "hit %zu: general (row %u pos %u %u runs %u+%u %u+%u len %u rev %u%u back %u left %u) fast (row %u pos %u %u runs %u+%u %u+%u len %u rev %u%u back %u left %u)", i,
                          x.slot1, x.pos1, x.pos2, x.runs1, x.nruns1, x.runs2, x.nruns2, x.len, x.rev1, x.rev2, x.back, x.pad[0], y.slot1, y.pos1, y.pos2, y.runs1, y.nruns1, y.runs2, y.nruns2, y.len, y.rev1, y.rev2, y.back, y.pad[0]); return bad(b); }
-            if (SA.n_runs && memcmp(SA.runs, SB.runs, SA.n_runs * sizeof(agx_run)) != 0) return bad("runs");
+            if (SA.n_sides && memcmp(SA.sides, SB.sides, SA.n_sides * sizeof(agx_wside)) != 0) return bad("side records");
+            if (SA.n_runs && memcmp(SA.runs, SB.runs, SA.n_runs * sizeof(agx_wrun)) != 0) return bad("runs");
             if (SA.n_codes != SB.n_codes || (SA.n_codes && memcmp(SA.codes, SB.codes, SA.n_codes) != 0)) return bad("codes");
             if (SA.n_other != SB.n_other || (SA.n_other && memcmp(SA.other, SB.other, SA.n_other * 8) != 0)) return bad("list of other bases");
             std::vector<agx_u16> row_len(SA.n_rows, 0);
-            for (size_t i = 0; i < SA.nh; i++) row_len[SA.hits[i].slot1] = std::max(row_len[SA.hits[i].slot1], SA.hits[i].len);
+            for (size_t i = 0; i < SA.nh; i++) row_len[SA.hits[i].row] = std::max(row_len[SA.hits[i].row], SA.hits[i].len);
             if (SB.row_off.size() != SA.n_rows || SA.row_slot.size() != SA.n_rows) return bad("row tables");
             for (size_t r = 0; r < SA.n_rows; r++) if (memcmp(P.bases.data() + (size_t)SA.row_slot[r] * P.stride, ri->fv.p + SB.row_off[r], row_len[r]) != 0) return bad("bases of row " + std::to_string(r));
+        }
+        // the reference bases in their wire form: what the device would expand them to
+        {
+            std::vector<agx_u8> packed((ref.size() + 3) / 4 + 64); std::vector<agx_refx> others;
+            if (pack_reference(ref.data(), ref.size(), (unsigned)threads, packed.data(), others)) {
+                std::string back(ref.size(), '?');
+                for (size_t x = 0; x < ref.size(); x++) back[x] = agx_ref_base((packed[x >> 2] >> (2 * (x & 3))) & 3u);
+                for (const agx_refx &o : others) for (agx_u32 j = 0; j < o.len; j++) back[(size_t)o.pos + j] = (char)o.byte;
+                if (back != ref) { say("reference bases do not survive their wire form"); return -32; }
+            }
         }
     } catch (const Error &e) { say("unexpected: " + e.msg); return -99; }
     catch (const std::exception &e) { say(std::string("unexpected: ") + e.what()); return -99; }

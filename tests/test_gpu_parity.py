@@ -334,3 +334,29 @@ def test_positions_beyond_64_variants_take_the_last_pass(agx, built, tmp_path, n
     for key in ("initial", "pre", "extended"):
         assert o[key] == g[key], key
     assert g["stats"]["build_attempts"] == 2 and g["stats"]["n_big_tiles"] >= 1
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_reference_bytes_that_are_not_acgt_survive_the_packed_upload(agx, built, tmp_path, masked):
+    """The unit sequence crosses PCIe as 2 bits per base + the stretches of other bytes (agx_core.h wire formats); the reference emits a position's
+    own byte wherever a walk falls back on it (AG:1997-2001) and fills gaps with it (AG:2426-2435).  An N run, IUPAC codes and — masked — lower case
+    over half the unit (too many stretches: the bytes then cross as they are) must come out as the oracle writes them."""
+    run = H.synth(str(tmp_path / "run"), seed=31, chroms="40000", pairs=6000, coverage=3, contig_min=1500, contig_max=3000, sam_seq=0)
+    tmp = os.path.join(run, "tmp")
+    path = os.path.join(tmp, "_genome.0.fa")
+    head, body = open(path).read().split("\n", 1)
+    seq = list(body.replace("\n", ""))
+    seq[5000:5800] = "N" * 800
+    for i in (100, 101, 9000, 20001, 39999):
+        seq[i] = "RYKMSW"[i % 6]
+    if masked:
+        for i in range(10000, 30000):
+            if i % 7 < 3:
+                seq[i] = seq[i].lower()
+    seq = "".join(seq)
+    open(path, "w").write(head + "\n" + "".join(seq[i:i + 60] + "\n" for i in range(0, len(seq), 60)))
+    want = H.run_oracle(tmp, 0, 5, 50, 3)
+    got = run_engine(agx, tmp, 0, 5, 50, 3)
+    for key in ("initial", "pre", "extended"):
+        assert got[key] == want[key], key
+    assert b"N" * 100 in got["extended"] or b"N" * 100 in got["pre"] or True      # (whether a walk crosses the N run depends on the reads; the bytes were compared above)
