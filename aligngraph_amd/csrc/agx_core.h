@@ -380,6 +380,23 @@ AGX_HD agx_u32 agx_seg_of_elem(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 e)
     while (hi - lo > 1) { const agx_u32 mid = lo + (hi - lo) / 2; if (segs[mid].elem0 <= e) lo = mid; else hi = mid; }
     return lo;
 }
+// The tables straight from the runs, without a count pass and a scan (r03): the host knows how many conti-mers every position carries (it threaded
+// them), so it sends the COUNTS as runs — [pos0, pos0 + len) carry cnt conti-mers each, `base` before them — and both runs lists cut into chunks
+// (run, offset) that a block takes without searching.  A position's cm_start and, where it is empty, its head come from its count run; the keys, and the
+// head of every position that has conti-mers (written by its rank-0 element), from the conti-mer runs.
+struct agx_cntrun { agx_u32 pos0, len, cnt, base; };
+struct agx_chunk { agx_u32 run, off; };
+#define AGX_CM_CHUNK 2048u
+AGX_HD void agx_cm_layout_pos(const agx_cntrun &r, agx_u32 j, agx_u32 *cm_start, agx_cmhead *head) {      // position r.pos0 + j
+    const agx_u32 x = r.pos0 + j, s = r.base + j * r.cnt;
+    cm_start[x] = s;
+    if (r.cnt == 0) head[x] = agx_cmhead{AGX_NONE, AGX_NONE, 0u, s};
+}
+AGX_HD void agx_cm_fill_elem(const agx_cmseg &g, agx_u32 j, const agx_u32 *cm_start, agx_cmkey *cm, agx_cmhead *head) {      // element j of run g
+    const agx_u32 x = g.pos0 + j, s = cm_start[x], n = cm_start[x + 1] - s, coff = g.coff0 + j * g.dcoff;
+    cm[s + g.rank] = agx_cmkey{g.cid, coff};
+    if (g.rank == 0) head[x] = agx_cmhead{g.cid, coff, n, s};
+}
 struct agx_hop;
 // hop entry of position x from the runs: defined where x carries exactly one conti-mer (its run has rank 0; the first n_seg0 runs are the
 // rank-0 ones, sorted by pos0) that has a next

@@ -217,6 +217,7 @@ struct agx_unit {
     PBuf<agx_whit> s_hits; PBuf<agx_wside> s_sides; PBuf<agx_wrun> s_runs; PBuf<agx_u8> s_codes; PBuf<unsigned long long> s_other; size_t n_other = 0, n_sides = 0;      // the read alignments in the wire formats of agx_core.h
     PBuf<agx_u8> s_ref; PBuf<agx_refx> s_refx; size_t n_refx = 0; bool ref_packed = false;      // the unit sequence: 2 bits per base + the stretches of other bytes (ref_packed), or the bytes as they are
     PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
+    PBuf<agx_cntrun> s_cntruns; PBuf<agx_chunk> s_cntchunks, s_segchunks; size_t n_cntruns = 0, n_cntchunks = 0, n_segchunks = 0;      // what the device builds the conti-mer tables from (build_cm_layout)
     size_t nh = 0, n_runs = 0, n_cm = 0, n_codes = 0; agx_u32 maxlen = 0;      // n_codes: bytes of packed classes (four bases each); n_other: listed bases that are not A, C, G, T
     std::vector<agx_u32> row_slot;      // staged read bases: one row per (pair, a mate) that some hit uses; row -> read slot (general loader / agx_unit_push_pairs)
     std::vector<uint64_t> row_off;      // fast loader: row -> where the read's bases start in the mapped reads file (the bases are never copied: the walk reads the k-mer tails of written records there)
@@ -226,6 +227,7 @@ struct agx_unit {
     // inputs on the device
     DBuf<agx_u32> d_cm_start, d_cm_cnt; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref; DBuf<agx_cmseg> d_segs; DBuf<unsigned long long> d_up_desc;
     DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<agx_u8> d_codes, d_vcodes; DBuf<unsigned long long> d_other;
+    DBuf<agx_cntrun> d_cntruns; DBuf<agx_chunk> d_cntchunks, d_segchunks;
     DBuf<agx_whit> d_whits; DBuf<agx_wside> d_wsides; DBuf<agx_wrun> d_wruns; DBuf<agx_u8> d_wref; DBuf<agx_refx> d_refx;      // what was uploaded, until the first build has expanded it
     // derived
     DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_recs, d_scan_tmp, d_words; DBuf<unsigned long long> d_scan_desc; size_t scan_desc_n = 0;      // descriptors of the three one-launch scans   // d_words: counters/status
@@ -337,6 +339,14 @@ void adopt_pairs(agx_unit *u, StagedPairs &S) {      // the staged read alignmen
     u->pairs_in_file = S.n_pairs_in_file; u->sam_pairs = S.n_sam_pairs;
     u->row_off.swap(S.row_off); u->row_slot.swap(S.row_slot); u->n_rows = S.n_rows;
 }
+void stage_cm_layout(agx_unit *u, const agx_u8 *cm_cnt, size_t n_pos, const agx_cmseg *segs, size_t n_segs) {
+    CmLayout L; build_cm_layout(cm_cnt, n_pos, segs, n_segs, L);
+    u->n_cntruns = L.cnt_runs.size(); u->n_cntchunks = L.cnt_chunks.size(); u->n_segchunks = L.seg_chunks.size();
+    u->s_cntruns.alloc(u->n_cntruns + 1); u->s_cntchunks.alloc(u->n_cntchunks + 1); u->s_segchunks.alloc(u->n_segchunks + 1);
+    if (u->n_cntruns) memcpy(u->s_cntruns.p, L.cnt_runs.data(), u->n_cntruns * sizeof(agx_cntrun));
+    if (u->n_cntchunks) memcpy(u->s_cntchunks.p, L.cnt_chunks.data(), u->n_cntchunks * sizeof(agx_chunk));
+    if (u->n_segchunks) memcpy(u->s_segchunks.p, L.seg_chunks.data(), u->n_segchunks * sizeof(agx_chunk));
+}
 // the unit sequence (+ appended positions) for the upload: 2 bits per base and the stretches of other bytes, or — a soft-masked sequence — the bytes themselves
 void stage_reference(agx_unit *u, const char *ref, size_t n_pos, unsigned threads) {
     std::vector<agx_refx> others;
@@ -364,6 +374,7 @@ void stage_inputs(agx_unit *u) {
     if (!ce.empty()) memcpy(u->s_chain_end.p, ce.data(), ce.size() * 4);
     const unsigned threads = loader_threads(u->P.bases.size() + n_pos + u->nh * 64);
     stage_reference(u, u->T.ref.data(), n_pos, threads);
+    stage_cm_layout(u, u->T.cm_cnt.data(), n_pos, u->T.segs.data(), u->n_segs);
     if (!u->pairs_staged) {
         UnitSink sink(u); StagedPairs S;
         u->n_slots = u->P.n_slots;
@@ -515,6 +526,7 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     }
     if (!fine) { u->cache_map.reset(); return false; }
     stage_reference(u, base + H.off[S_REF], H.n_pos, threads);
+    stage_cm_layout(u, (const agx_u8 *)(base + H.off[S_CM_CNT]), H.n_pos, u->s_segs.p, u->n_segs);
     UnitView V; V.ref = base + H.off[S_REF]; V.n_pos = H.n_pos; V.n_ref = (agx_u32)H.n_ref; V.cm_cnt = (const agx_u8 *)(base + H.off[S_CM_CNT]); V.chain_str = base + H.off[S_CHAIN_STR];
     V.hop = nullptr; V.segs = (const agx_cmseg *)(base + H.off[S_SEGS]); V.n_seg0 = (agx_u32)H.n_seg0; V.stride = in_reads ? H.stride : H.slot_stride; V.initial = base + H.off[S_INITIAL]; V.n_initial = H.len[S_INITIAL];
     u->row_off.clear(); u->row_slot.clear();
@@ -622,8 +634,8 @@ void do_upload(agx_unit *u) {
     const agx_u32 pool_cap = plan.pool_cap, list_cap = plan.list_cap, ovf_cap = plan.ovf_cap, sp_cap = plan.sp_cap;
     u->arena.reserve(plan.total);                        // one block for all of it
     DevArena &a = u->arena;
-    u->d_cm_start.alloc(a, n_pos + 2); u->d_cm_cnt.alloc(a, n_pos + 2); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos + 16); u->d_cm_head.alloc(a, n_pos + 1);
-    u->d_segs.alloc(a, u->n_segs + 1); u->d_up_desc.alloc(a, (n_pos + 2) / 4096 + 2);
+    u->d_cm_start.alloc(a, n_pos + 2); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos + 16); u->d_cm_head.alloc(a, n_pos + 1);
+    u->d_segs.alloc(a, u->n_segs + 1); u->d_cntruns.alloc(a, u->n_cntruns + 1); u->d_cntchunks.alloc(a, u->n_cntchunks + 1); u->d_segchunks.alloc(a, u->n_segchunks + 1);
     u->d_hits.alloc(a, nh + 1); u->d_runs.alloc(a, u->n_runs + 1); u->d_codes.alloc(a, u->n_codes + 16); u->d_vcodes.alloc(a, n_bases + 16); u->d_other.alloc(a, u->n_other + 1);
     u->d_whits.alloc(a, nh + 1); u->d_wsides.alloc(a, u->n_sides + 1); u->d_wruns.alloc(a, u->n_runs + 1);
     if (u->ref_packed) { u->d_wref.alloc(a, (n_pos + 3) / 4 + 32); u->d_refx.alloc(a, u->n_refx + 1); }
@@ -654,7 +666,8 @@ void do_upload(agx_unit *u) {
         auto up = [&](void *dst, const void *src, size_t bytes) {
             for (size_t at = 0; at < bytes;) { const size_t m = chunk ? std::min(chunk, bytes - at) : bytes; HIP_OK(hipMemcpyAsync((char *)dst + at, (const char *)src + at, m, hipMemcpyHostToDevice, st)); at += m; }
         };
-        up(u->d_segs.p, u->s_segs.p, u->n_segs * sizeof(agx_cmseg));
+        up(u->d_segs.p, u->s_segs.p, u->n_segs * sizeof(agx_cmseg)); up(u->d_cntruns.p, u->s_cntruns.p, u->n_cntruns * sizeof(agx_cntrun));
+        up(u->d_cntchunks.p, u->s_cntchunks.p, u->n_cntchunks * sizeof(agx_chunk)); up(u->d_segchunks.p, u->s_segchunks.p, u->n_segchunks * sizeof(agx_chunk));
         up(u->d_whits.p, u->s_hits.p, nh * sizeof(agx_whit)); up(u->d_wsides.p, u->s_sides.p, u->n_sides * sizeof(agx_wside)); up(u->d_wruns.p, u->s_runs.p, u->n_runs * sizeof(agx_wrun));
         HIP_OK(hipEventRecord(u->ev_hits, st));         // what the front of the build needs (conti-mer tables, hit preparation, binning) is there: it starts while the rest still travels
         up(u->d_codes.p, u->s_codes.p, u->n_codes); up(u->d_other.p, u->s_other.p, u->n_other * 8);      // first needed by the sweep
@@ -687,7 +700,7 @@ void do_upload(agx_unit *u) {
 
     u->uploaded = true; u->built = false; u->downloaded = false;
     u->stats.ms_upload = now_ms() - t0;
-    u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + (u->ref_packed ? (n_pos + 3) / 4 + u->n_refx * sizeof(agx_refx) : n_pos) + nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) +
+    u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + u->n_cntruns * sizeof(agx_cntrun) + (u->n_cntchunks + u->n_segchunks) * sizeof(agx_chunk) + (u->ref_packed ? (n_pos + 3) / 4 + u->n_refx * sizeof(agx_refx) : n_pos) + nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) +
                             (size_t)u->n_chain_end * 4 + u->n_codes + u->n_other * 8 + ((size_t)u->n_regions + 1) * 4;
     u->stats.device_bytes = u->arena.capacity();
 }
@@ -750,9 +763,7 @@ void do_build(agx_unit *u) {
         if (u->ev.all) HIP_OK(hipEventRecord(u->ev.first, st));      // (every event record costs the stream a few microseconds: untimed builds record only what orders them)
         if (!u->expanded) {   // the unit's first build: the hits and runs out of their wire forms, then the conti-mer tables from their runs (agx_cmseg: count per position, scan, keys, heads); the read bases follow behind the binning
             agx_launch_expand_hits(u->d_whits.p, u->d_wsides.p, u->d_wruns.p, u->d_hits.p, u->d_runs.p, nh, (agx_u32)u->n_runs, st);
-            HIP_OK(hipMemsetAsync(u->d_cm_cnt.p, 0, ((size_t)n_pos + 2) * 4, st)); HIP_OK(hipMemsetAsync(u->d_up_desc.p, 0, (((size_t)n_pos + 2) / 4096 + 2) * 8, st));
-            agx_launch_seg_expand(u->d_segs.p, (agx_u32)u->n_segs, (agx_u32)u->n_cm, u->d_cm_cnt.p, u->d_cm_start.p, u->d_cm.p, n_pos, u->d_up_desc.p, st);
-            agx_launch_cm_head(u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, n_pos, st);
+            agx_launch_cm_tables(u->d_cntruns.p, u->d_cntchunks.p, (agx_u32)u->n_cntchunks, u->d_segs.p, u->d_segchunks.p, (agx_u32)u->n_segchunks, u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, n_pos, (agx_u32)u->n_cm, st);
         }
         {   // everything a build counts into or marks, zeroed by one kernel and one fill (every command on the stream costs a few microseconds)
             agx_zero_args Z; memset(&Z, 0, sizeof Z);
@@ -991,7 +1002,7 @@ void do_release(agx_unit *u) {
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     for (auto *b : {&u->d_node_cnt, &u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
     u->d_other.release(); u->d_whits.release(); u->d_wsides.release(); u->d_wruns.release(); u->d_wref.release(); u->d_refx.release();
-    u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_sp_hop.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
+    u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_cntruns.release(); u->d_cntchunks.release(); u->d_segchunks.release(); u->d_sp_hop.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
     u->d_ovf.release(); u->d_a_ovf.release(); u->d_huge_list.release(); u->d_scratch_huge.release(); u->huge = false; u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
     u->arena.reset();
     u->h_a_str.release(); u->h_a_meta.release(); for (auto &b : u->h_a_metas) b.release(); u->h_side_xpos.release(); u->h_sp_rank.release(); u->h_sp_bits.release(); u->h_sp_node.release(); u->h_fetch.release(); u->h_a_ovf.release();

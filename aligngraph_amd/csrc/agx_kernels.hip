@@ -57,6 +57,22 @@ __global__ void __launch_bounds__(256) agx_k_seg_fill(const agx_cmseg *segs, agx
     cm[cm_start[g.pos0 + j] + g.rank] = agx_cmkey{g.cid, g.coff0 + j * g.dcoff};
 }
 
+// ---- r03: the same tables in two streaming kernels (agx_core.h: agx_cntrun, agx_chunk) --------------------------------------------------
+// one block per chunk of a count run: cm_start of its positions (+ the heads of empty positions); thread 0 of block 0 closes the table
+__global__ void __launch_bounds__(256) agx_k_cm_layout(const agx_cntrun *runs, const agx_chunk *chunks, agx_u32 *cm_start, agx_cmhead *head, agx_u32 n_pos, agx_u32 n_cm) {
+    const agx_chunk c = chunks[blockIdx.x];
+    const agx_cntrun r = runs[c.run];
+    const agx_u32 n = r.len - c.off < AGX_CM_CHUNK ? r.len - c.off : AGX_CM_CHUNK;
+    for (agx_u32 j = threadIdx.x; j < n; j += 256u) agx_cm_layout_pos(r, c.off + j, cm_start, head);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { cm_start[n_pos] = n_cm; head[n_pos] = agx_cmhead{AGX_NONE, AGX_NONE, 0u, 0u}; }      // entry n_pos: the head of "no position"
+}
+// one block per chunk of a conti-mer run: keys, and the heads of the positions whose first conti-mer is here
+__global__ void __launch_bounds__(256) agx_k_cm_fill(const agx_cmseg *segs, const agx_chunk *chunks, const agx_u32 *cm_start, agx_cmkey *cm, agx_cmhead *head) {
+    const agx_chunk c = chunks[blockIdx.x];
+    const agx_cmseg g = segs[c.run];
+    const agx_u32 n = g.len - c.off < AGX_CM_CHUNK ? g.len - c.off : AGX_CM_CHUNK;
+    for (agx_u32 j = threadIdx.x; j < n; j += 256u) agx_cm_fill_elem(g, c.off + j, cm_start, cm, head);
+}
 __global__ void __launch_bounds__(256) agx_k_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos) {
     const agx_u32 x = blockIdx.x * 256u + threadIdx.x;
     if (x <= n_pos) agx_cm_head_pos(cm_start, cm, head, x, n_pos);
@@ -541,12 +557,31 @@ __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, ag
     const agx_u32 a = blockIdx.x * 256u + threadIdx.x, w = a >> 6;
     if (w >= n_words) return;
     const unsigned long long bits = A.sp_bits[w];
+    if (!bits) return;                                                        // wave-uniform
     const agx_u32 lane = threadIdx.x & 63u;
-    if ((bits >> lane) & 1ull) {
+    const bool on = ((bits >> lane) & 1ull) != 0;
+    const agx_u32 x = on ? (a < A.n_pos ? a : A.side_xpos[a - A.n_pos]) : 0xFFFFFFFFu;
+    // The hop entry of a position comes from the rank-0 run that holds it (agx_seg_hop: bisection over the runs, sorted by position).  The ids of a word
+    // are 64 neighbours — main ids are positions, side ids are in position order —, so the bisection runs ONCE per wavefront, for its lowest position,
+    // and every lane walks forward from there (r02: 17 dependent loads per special id; 0.62 ms of this kernel on a 30 Mb unit).
+    agx_u32 xmin = x;
+    for (agx_u32 o = 32; o; o >>= 1) { const agx_u32 t = (agx_u32)__shfl_xor((int)xmin, (int)o, 64); xmin = t < xmin ? t : xmin; }
+    agx_u32 s0 = 0;
+    if (A.n_seg0) { agx_u32 lo = 0, hi = A.n_seg0; while (hi - lo > 1) { const agx_u32 mid = lo + (hi - lo) / 2; if (agx_uload(&A.segs[0].pos0 + (size_t)mid * (sizeof(agx_cmseg) / 4), 0) <= xmin) lo = mid; else hi = mid; } s0 = lo; }
+    if (on) {
         const agx_u32 at = A.sp_rank[w] + (agx_u32)__popcll(bits & ((1ull << lane) - 1ull));
         if (at >= A.sp_cap) return;                                           // table too small: the host sees the count and repeats the build
         A.sp_node[at] = agx_walk_record(A, a);
-        A.sp_hop[at] = agx_seg_hop<agx_hop>(A.segs, A.n_seg0, A.cm_start, a < A.n_pos ? a : A.side_xpos[a - A.n_pos]);
+        agx_hop h; h.str_off = 0; h.len = 0; h.end_pos = 0;
+        if (A.n_seg0 && A.cm_start[x + 1] - A.cm_start[x] == 1u) {
+            agx_u32 si = s0, steps = 0;
+            while (si + 1 < A.n_seg0 && A.segs[si + 1].pos0 <= x && steps < 8u) { si++; steps++; }      // last rank-0 run with pos0 <= x: a few steps behind the wavefront's
+            if (steps == 8u) { agx_u32 lo = si, hi = A.n_seg0; while (hi - lo > 1) { const agx_u32 mid = lo + (hi - lo) / 2; if (A.segs[mid].pos0 <= x) lo = mid; else hi = mid; } si = lo; }      // (the one word that holds the last main ids and the first side ids)
+            const agx_cmseg g = A.segs[si];
+            const agx_u32 j = x - g.pos0;
+            if (x >= g.pos0 && j < g.len && j < g.hop_len0) { h.str_off = g.hop_str0 + j; h.len = g.hop_len0 - j; h.end_pos = g.hop_end; }
+        }
+        A.sp_hop[at] = h;
     }
 }
 
@@ -576,6 +611,11 @@ void agx_launch_seg_expand(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 n_elem
     if (n_elems) hipLaunchKernelGGL(agx_k_seg_count, dim3((n_elems + 255) / 256), dim3(256), 0, st, segs, n_segs, n_elems, cnt);
     agx_launch_exclusive_scan1(cnt, cm_start, n_pos, desc, st);
     if (n_elems) hipLaunchKernelGGL(agx_k_seg_fill, dim3((n_elems + 255) / 256), dim3(256), 0, st, segs, n_segs, n_elems, cm_start, cm);
+}
+void agx_launch_cm_tables(const void *cnt_runs, const void *cnt_chunks, agx_u32 n_cnt_chunks, const agx_cmseg *segs, const void *seg_chunks, agx_u32 n_seg_chunks,
+                           agx_u32 *cm_start, agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, agx_u32 n_cm, hipStream_t st) {
+    if (n_cnt_chunks) hipLaunchKernelGGL(agx_k_cm_layout, dim3(n_cnt_chunks), dim3(256), 0, st, (const agx_cntrun *)cnt_runs, (const agx_chunk *)cnt_chunks, cm_start, head, n_pos, n_cm);
+    if (n_seg_chunks) hipLaunchKernelGGL(agx_k_cm_fill, dim3(n_seg_chunks), dim3(256), 0, st, segs, (const agx_chunk *)seg_chunks, cm_start, cm, head);
 }
 void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t st) {
     hipLaunchKernelGGL(agx_k_cm_head, dim3(n_pos / 256 + 1), dim3(256), 0, st, cm_start, cm, head, n_pos);

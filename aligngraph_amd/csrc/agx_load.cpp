@@ -446,6 +446,20 @@ void stage_pairs(const Pairs &P, agx_u32 k, unsigned threads, StageSink &sink, S
     if (staged_out) staged_out->swap(st);
 }
 
+void build_cm_layout(const agx_u8 *cm_cnt, size_t n_pos, const agx_cmseg *segs, size_t n_segs, CmLayout &L) {
+    L.cnt_runs.clear(); L.cnt_chunks.clear(); L.seg_chunks.clear();
+    unsigned long long base = 0;
+    for (size_t x = 0; x < n_pos;) {
+        const size_t m = run_same(cm_cnt + x, n_pos - x);
+        const agx_u32 run = (agx_u32)L.cnt_runs.size();
+        L.cnt_runs.push_back(agx_cntrun{(agx_u32)x, (agx_u32)m, cm_cnt[x], (agx_u32)base});
+        for (size_t off = 0; off < m; off += AGX_CM_CHUNK) L.cnt_chunks.push_back(agx_chunk{run, (agx_u32)off});
+        base += (unsigned long long)m * cm_cnt[x]; x += m;
+    }
+    if (base >= 0xFFFFFFFFull) throw Error{E_ARG, "conti-mer table exceeds 2^32 entries"};
+    for (size_t g = 0; g < n_segs; g++) for (agx_u32 off = 0; off < segs[g].len; off += AGX_CM_CHUNK) L.seg_chunks.push_back(agx_chunk{(agx_u32)g, off});
+}
+
 // Reference bases for the upload: 2 bits each where they are A, C, G, T, and the rest as stretches of one byte value (N runs; a soft-masked sequence
 // has too many of them: false, and the bases cross as they are).  The classes are the read bases' (agx_base_class: A, C, G, T = 0..3).
 bool pack_reference(const char *ref, size_t n, unsigned threads, agx_u8 *packed, std::vector<agx_refx> &others) {

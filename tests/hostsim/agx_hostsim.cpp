@@ -102,6 +102,17 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     for (size_t i = 0; i < P.bases.size(); i++) if (agx_base_class((agx_u8)P.bases[i]) == 4u) vcodes[i] = agx_class_vote_code(4u);
     std::vector<agx_cmhead> cmh((size_t)n_pos + 1);
     for (agx_u32 x = 0; x <= n_pos; x++) agx_cm_head_pos(T.cm_start.data(), cmk.data(), cmh.data(), x, n_pos);
+    {   // r03: the device builds the same three tables from the count runs and the conti-mer runs in chunks (agx_k_cm_layout, agx_k_cm_fill): the element
+        // functions of those kernels over the host's chunk tables must give exactly the tables above
+        CmLayout L; build_cm_layout(T.cm_cnt.data(), n_pos, T.segs.data(), T.segs.size(), L);
+        std::vector<agx_u32> start2((size_t)n_pos + 1, 0xDEADBEEFu); std::vector<agx_cmkey> cm2(T.cm.size(), agx_cmkey{0xDEADBEEFu, 0xDEADBEEFu}); std::vector<agx_cmhead> head2((size_t)n_pos + 1, agx_cmhead{1u, 2u, 3u, 4u});
+        for (const agx_chunk &c : L.cnt_chunks) { const agx_cntrun &r = L.cnt_runs[c.run]; const agx_u32 n = std::min<agx_u32>(r.len - c.off, AGX_CM_CHUNK); for (agx_u32 j = 0; j < n; j++) agx_cm_layout_pos(r, c.off + j, start2.data(), head2.data()); }
+        start2[n_pos] = (agx_u32)T.cm.size(); head2[n_pos] = agx_cmhead{AGX_NONE, AGX_NONE, 0u, 0u};
+        for (const agx_chunk &c : L.seg_chunks) { const agx_cmseg &g = T.segs[c.run]; const agx_u32 n = std::min<agx_u32>(g.len - c.off, AGX_CM_CHUNK); for (agx_u32 j = 0; j < n; j++) agx_cm_fill_elem(g, c.off + j, start2.data(), cm2.data(), head2.data()); }
+        if (start2 != T.cm_start) throw Error{E_ARG, "chunked conti-mer tables: cm_start differs"};
+        if (cm2.size() && memcmp(cm2.data(), cmk.data(), cm2.size() * sizeof(agx_cmkey)) != 0) throw Error{E_ARG, "chunked conti-mer tables: keys differ"};
+        if (memcmp(head2.data(), cmh.data(), head2.size() * sizeof(agx_cmhead)) != 0) throw Error{E_ARG, "chunked conti-mer tables: heads differ"};
+    }
     A.cm_start = T.cm_start.data(); A.cm = cmk.data(); A.cm_head = cmh.data(); A.ref = T.ref.data();
     A.dhit = dh.data(); A.runs = P.runs.data(); A.vcodes = vcodes.data(); A.stride = P.stride;
     A.tile_off = tile_off.data();
