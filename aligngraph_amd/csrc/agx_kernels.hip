@@ -217,12 +217,12 @@ __global__ void __launch_bounds__(256) agx_k_scan_add(agx_u32 *out, const agx_u3
 // time — until it meets one that already holds an inclusive prefix, and publishes its own.  desc[] must be zero when the kernel starts.
 // (A command boundary costs the stream ~8 us: three launches per scan were most of what a small scan cost.)
 // A block that looks back spins until its predecessors have published, so a predecessor must never be a block that cannot start: HIP does
-// not promise dispatch in blockIdx order.  The grid is therefore capped at AGX_SCAN_GRID workgroups — few enough to be resident all at
-// once (8 per CU fit) — and workgroup g takes the 4096-element blocks g, g + grid, g + 2 grid, .. in that order: whatever a block waits
+// not promise dispatch in blockIdx order.  The grid is therefore capped at what the device holds at once (agx_scan_grid: from the occupancy
+// query, halved because two build streams may scan at the same time) and workgroup g takes the 4096-element blocks g, g + grid, g + 2 grid, .. in that order: whatever a block waits
 // for belongs to a workgroup that is running or has only earlier blocks to finish first.
 #define AGX_SCAN_AGG (1ull << 62)
 #define AGX_SCAN_PFX (2ull << 62)
-#define AGX_SCAN_GRID 1024u
+#define AGX_SCAN_GRID 1024u      // upper bound; the launcher takes what the device at hand holds at once (agx_scan_grid)
 __global__ void __launch_bounds__(256) agx_k_scan_lookback(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsigned long long *desc, agx_u32 n_blocks) {
     __shared__ agx_u32 sh[256];
     __shared__ agx_u32 sh_excl;
@@ -663,10 +663,25 @@ void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u
 }
 
 // the one-launch form; desc: ceil((n+1)/4096) zeroed 64-bit words
+// Workgroups of the one-launch scan: every one of them must be resident for the look-back to be safe (see agx_k_scan_lookback), also on a partition of
+// the chip (CPX: 32 CUs) and while a second scan runs on the device's other build stream: half of what the occupancy query says the device
+// holds, per device, at most AGX_SCAN_GRID.
+static agx_u32 agx_scan_grid() {
+    static agx_u32 grid[64];      // 0 = not asked yet
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return 64u;
+    agx_u32 &g = grid[dev & 63];
+    if (!g) {
+        int per_cu = 0; hipDeviceProp_t prop; agx_u32 v = 64u;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agx_k_scan_lookback, 256, 0) == hipSuccess && per_cu > 0 && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            v = (agx_u32)per_cu * (agx_u32)prop.multiProcessorCount / 2u;
+        g = v < 16u ? 16u : v > AGX_SCAN_GRID ? AGX_SCAN_GRID : v;
+    }
+    return g;
+}
 void agx_launch_exclusive_scan1(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsigned long long *desc, hipStream_t st) {
     const agx_u32 m = n + 1;                              // callers allocate in with n+1 entries, in[n] = 0: out[n] = total
-    const agx_u32 nb = (m + AGX_SCAN_BLOCK - 1) / AGX_SCAN_BLOCK;
-    hipLaunchKernelGGL(agx_k_scan_lookback, dim3(nb < AGX_SCAN_GRID ? nb : AGX_SCAN_GRID), dim3(256), 0, st, in, out, m, desc, nb);
+    const agx_u32 nb = (m + AGX_SCAN_BLOCK - 1) / AGX_SCAN_BLOCK, grid = agx_scan_grid();
+    hipLaunchKernelGGL(agx_k_scan_lookback, dim3(nb < grid ? nb : grid), dim3(256), 0, st, in, out, m, desc, nb);
 }
 
 void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {

@@ -70,25 +70,34 @@ def run_job(unit_sizes, rank, world, run_unit, dist, device, inflight=8, dst=0, 
 
 
 def gather_bytes(payload, dist, device, rank, world, dst=0):
-    """gather-v of one bytes object per rank to `dst`: all_gather of the 8-byte sizes, then one padded gather.
-    xGMI is point-to-point, so every peer->root transfer rides its own link; the payload (<= one unit's FASTA) is tiny
-    next to the build.  Returns the list of payloads on dst, None elsewhere."""
+    """gather-v of one bytes object per rank to `dst`: an all_gather of the 8-byte sizes, then every peer sends exactly its bytes to the root and
+    the root posts all its receives at once (grouped point-to-point: RCCL's ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd under backend
+    "nccl").  xGMI is point-to-point, so every peer->root transfer rides its own link, and nobody pads to the largest payload.  Returns the
+    list of payloads on dst, None elsewhere."""
     import torch
     if dist is None or world == 1:
         return [payload]
     n = torch.tensor([len(payload)], dtype=torch.int64, device=device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    cap = max(max(sizes), 1)
-    buf = torch.zeros(cap, dtype=torch.uint8, device=device)
-    if len(payload):
-        buf[:len(payload)] = torch.frombuffer(payload if isinstance(payload, bytearray) else bytearray(payload), dtype=torch.uint8).to(device)
-    outs = [torch.zeros(cap, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, outs, dst=dst)
+    sizes = [int(v) for v in torch.cat(sizes).cpu().tolist()]          # (one device -> host copy for all of them)
     if rank != dst:
+        if len(payload):
+            buf = torch.frombuffer(payload if isinstance(payload, bytearray) else bytearray(payload), dtype=torch.uint8).to(device)
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, dst)]):
+                req.wait()
         return None
-    return [bytes(o[:s].cpu().numpy().tobytes()) for o, s in zip(outs, sizes)]
+    bufs = {r: torch.empty(sizes[r], dtype=torch.uint8, device=device) for r in range(world) if r != dst and sizes[r]}
+    if bufs:
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.irecv, b, r) for r, b in bufs.items()]):
+            req.wait()
+    out = []
+    for r in range(world):
+        if r == dst:
+            out.append(bytes(payload))
+        else:
+            out.append(bufs[r].cpu().numpy().tobytes() if r in bufs else b"")
+    return out
 
 
 def pack_units(unit_ids, blobs):

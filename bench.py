@@ -113,7 +113,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS) + ["custom"])
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS) + ["custom"],
+                    help="default: cfg3 on one GPU (the north-star 1-GPU configuration); with --gpus N > 1: cfg5s, the 24-unit whole-human shard shape (cfg3 has five units: "
+                         "three of eight ranks would idle)")
+    ap.add_argument("--same-config-steps", type=int, default=4, help="N > 1: after the timed N-rank steps rank 0 runs the SAME job alone on its GPU for this many steps "
+                                                                      "(single_gpu_ms_same_config, speedup_vs_1gpu in the JSON line); 0 = skip")
+    ap.add_argument("--host-gb", type=float, default=96.0, help="host memory a rank may hold in staged unit sets; more steps than fit re-upload the same unit objects (as --reupload)")
     ap.add_argument("--chroms", default="4600000", help="custom: comma-separated chromosome lengths")
     ap.add_argument("--part", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1000000)
@@ -170,6 +175,8 @@ def main():
     gdev = torch.device("cpu") if share else torch.device("cuda", local_rank)
     numa_note = pin_to_gpu_numa_node(torch, local_rank) if os.environ.get("AGX_BENCH_NO_PIN") != "1" else "not pinned (AGX_BENCH_NO_PIN=1)"
 
+    if args.config is None:
+        args.config = "cfg3" if world == 1 else "cfg5s"
     if args.config == "custom":
         chroms, part, pairs, L = [int(x) for x in args.chroms.split(",")], args.part, args.pairs, args.L
         label = "custom: chromosomes %s, --part %d, %d 2x%d bp pairs" % (args.chroms, part, pairs, L)
@@ -200,7 +207,7 @@ def main():
     t_index = time.perf_counter() - t1
     units, t_parse, t_stage, t_cached = {}, 0.0, 0.0, 0.0
     parse_threads = max(1, min(len(mine), 8))                              # units loaded side by side (each on its share of the cores: agx_host.cpp loader_threads)
-    stage_s, load_ms = {}, {}
+    stage_s, load_ms, un_bytes = {}, {}, {}
 
     def parse_unit(uu):
         un = A.Unit(k=k, insert_variation=50, coverage=args.coverage, device=local_rank)
@@ -208,6 +215,7 @@ def main():
         st = un.stats()
         stage_s[uu] = st["ms_stage"] * 1e-3
         load_ms[uu] = {"contigs": round(st["ms_thread"], 1), "read_alignments": round(st["ms_parse"], 1), "rest": round(st["ms_stage"], 1)}
+        un_bytes[uu] = un.hbm_needed() // 8 + 2 * st["n_pos"]          # staged arrays + output buffers of a unit, roughly: what a set of units holds in host memory
         return un
 
     os.environ["AGX_NO_CACHE"] = "1"
@@ -231,11 +239,14 @@ def main():
         reads.close()
     # the units the timed steps run, loaded from their cache files: one set per step (every unit of the application is new data and is
     # uploaded once), or one set for all steps with --reupload
-    n_sets = 1 if args.reupload else args.steps + args.warmup
+    per_set = sum(un_bytes.values()) if un_bytes else 0
+    fit = max(1, int(args.host_gb * 1e9 // max(1, per_set)))
+    reupload = args.reupload or fit < args.steps + args.warmup      # (a one-shot unit is used once: every step needs a set of its own in host memory)
+    n_sets = 1 if reupload else args.steps + args.warmup
     unit_sets = []
 
     def load_unit(uu):
-        un = A.Unit(k=k, insert_variation=50, coverage=args.coverage, device=local_rank, flags=0 if args.reupload else A.AGX_FLAG_ONE_SHOT)
+        un = A.Unit(k=k, insert_variation=50, coverage=args.coverage, device=local_rank, flags=0 if reupload else A.AGX_FLAG_ONE_SHOT)
         un.load_files(tmp, uu)
         assert un.stats()["from_cache"] == 1
         return un
@@ -317,6 +328,28 @@ def main():
     sam_pairs_total = int(tot[3].item())
 
     A.pool_trim(-1, host=True)
+    # ---- N > 1: the SAME job on ONE GPU (rank 0 alone, all units), so that the speed-up does not rest on comparing different driver runs ----
+    single_ms = None
+    if dist:
+        dist.barrier()
+        if rank == 0 and args.same_config_steps > 0:
+            everything = shard.plan(unit_len, 0, 1)
+            ms = []
+            for it in range(args.same_config_steps + 1):                 # (the first one is a warm-up)
+                one = {}
+                with ThreadPoolExecutor(max_workers=parse_threads) as ex:
+                    one = dict(zip(everything, ex.map(load_unit, everything)))
+                units.clear(); units.update(one)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                shard.run_job(unit_len, 0, 1, run_unit, None, gdev, inflight=min(8, len(everything)), start_unit=start_unit)
+                torch.cuda.synchronize()
+                if it:
+                    ms.append(1e3 * (time.perf_counter() - t1))
+                for un in one.values():
+                    un.close()
+            single_ms = sum(ms) / len(ms)
+        dist.barrier()
     # ---- after the timed region, rank 0: kernel sections of the largest unit (exclusive builds with section events) ----
     kern, big_stats = {}, None
     if rank == 0 and mine:
@@ -427,9 +460,11 @@ def main():
             "config": {"workload": label + ", k=%d, --coverage %d, synthetic target at 1%% SNP + 0.1%% indel" % (k, args.coverage)
                        + (" [NON-STANDARD generator options: %s]" % os.environ["AGX_BENCH_SYNTH"] if extra else ""),
                        "name": args.config, "units": n_units, "unit_positions": unit_len,
-                       "timed_region": "T_core per step: every unit new to the device (upload + first build + download + host walk), %s memory pools, %s" % (args.pool, "the same units uploaded again every step" if args.reupload else "a fresh set of one-shot units per step (loaded from the unit caches before the clock)"),
+                       "timed_region": "T_core per step: every unit new to the device (upload + first build + download + host walk), %s memory pools, %s" % (args.pool, "the same units uploaded again every step" if reupload else "a fresh set of one-shot units per step (loaded from the unit caches before the clock)"),
                        "units_in_flight_per_gpu": inflight,
                        "parallelism": "units sharded longest-first over %d GPU%s, one RCCL gather of extended contigs per job" % (world, "" if world == 1 else "s")},
+            "single_gpu_ms_same_config": round(single_ms, 3) if single_ms else None,
+            "speedup_vs_1gpu": round(single_ms / (1e3 * sec_per_step), 3) if single_ms else None,
             "t_core_s": round(sec_per_step, 4),
             "t_unit_s": round(sec_per_step + t_parse_max, 4),
             "t_unit_note": "t_core_s + text parsing and staging of the per-unit input files: the five text files of every unit -> staged arrays in pinned memory (slowest rank; its units side by side, each on its share of the cores: %.3f s); the one-off index of tmp/_reads.fa (%.3f s on rank 0, shared by all units of a run) is not in it" % (t_parse_max, t_index),
@@ -467,6 +502,10 @@ def main():
         if big_stats is not None:
             line["graph_largest_unit"] = {"positions": big_stats["n_pos"], "hits": big_stats["n_hits"], "nodes": big_stats["n_nodes"], "tile_entries": big_stats["n_tile_entries"],
                                           "walk_ids": big_stats["n_walk_ids"], "edge_overflow": big_stats["n_edge_overflow"]}
+        if os.environ.get("AGX_BENCH_DIGEST"):                                  # tests: what the job delivered to rank 0, unit by unit
+            import hashlib
+            with open(os.environ["AGX_BENCH_DIGEST"], "w") as f:
+                json.dump({str(uu): hashlib.md5(outs[uu]).hexdigest() for uu in range(n_units)}, f)
         print(json.dumps(line))
     for r in held.values():
         r.free()
