@@ -214,7 +214,7 @@ struct agx_unit {
     hsa_signal_t dl_signal{}; hsa_agent_t dl_agent{}; bool dl_sdma = false;      // downloads by the SDMA engines (HsaCopy)
     DevArena arena;
     // staged inputs: what the device wants of T and P, in pinned memory (stage_inputs)
-    PBuf<agx_whit> s_hits; PBuf<agx_wside> s_sides; PBuf<agx_wrun> s_runs; PBuf<agx_u8> s_codes; PBuf<unsigned long long> s_other; size_t n_other = 0, n_sides = 0;      // the read alignments in the wire formats of agx_core.h
+    PBuf<agx_whit> s_hits; PBuf<agx_wside> s_sides; PBuf<agx_wrun> s_runs; PBuf<agx_u8> s_codes; PBuf<unsigned long long> s_other; PBuf<agx_u32> s_jump; size_t n_other = 0, n_sides = 0, n_jump = 0;      // the read alignments in the wire formats of agx_core.h
     PBuf<agx_u8> s_ref; PBuf<agx_refx> s_refx; size_t n_refx = 0; bool ref_packed = false;      // the unit sequence: 2 bits per base + the stretches of other bytes (ref_packed), or the bytes as they are
     PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
     PBuf<agx_cntrun> s_cntruns; PBuf<agx_chunk> s_cntchunks, s_segchunks; size_t n_cntruns = 0, n_cntchunks = 0, n_segchunks = 0;      // what the device builds the conti-mer tables from (build_cm_layout)
@@ -227,7 +227,7 @@ struct agx_unit {
     // inputs on the device
     DBuf<agx_u32> d_cm_start, d_cm_cnt; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref; DBuf<agx_cmseg> d_segs; DBuf<unsigned long long> d_up_desc;
     DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<agx_u8> d_codes, d_vcodes; DBuf<unsigned long long> d_other;
-    DBuf<agx_cntrun> d_cntruns; DBuf<agx_chunk> d_cntchunks, d_segchunks;
+    DBuf<agx_cntrun> d_cntruns; DBuf<agx_chunk> d_cntchunks, d_segchunks; DBuf<agx_u32> d_jump;
     DBuf<agx_whit> d_whits; DBuf<agx_wside> d_wsides; DBuf<agx_wrun> d_wruns; DBuf<agx_u8> d_wref; DBuf<agx_refx> d_refx;      // what was uploaded, until the first build has expanded it
     // derived
     DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_recs, d_scan_tmp, d_words; DBuf<unsigned long long> d_scan_desc; size_t scan_desc_n = 0;      // descriptors of the three one-launch scans   // d_words: counters/status
@@ -330,12 +330,13 @@ struct UnitSink : StageSink {
         case SA_SIDES: u->s_sides.alloc(bytes / sizeof(agx_wside) + 1); return u->s_sides.p;
         case SA_RUNS:  u->s_runs.alloc(bytes / sizeof(agx_wrun) + 1); return u->s_runs.p;
         case SA_CODES: u->s_codes.alloc(bytes); return u->s_codes.p;
+        case SA_JUMP:  u->s_jump.alloc(bytes / 4 + 1); return u->s_jump.p;
         default:       u->s_other.alloc(bytes / 8 + 1); return u->s_other.p;
         }
     }
 };
 void adopt_pairs(agx_unit *u, StagedPairs &S) {      // the staged read alignments' counts and the host-side row table
-    u->nh = S.nh; u->n_runs = S.n_runs; u->n_sides = S.n_sides; u->n_codes = S.n_codes; u->n_other = S.n_other; u->stride = S.stride; u->maxlen = S.maxlen;
+    u->nh = S.nh; u->n_runs = S.n_runs; u->n_sides = S.n_sides; u->n_jump = S.n_jump; u->n_codes = S.n_codes; u->n_other = S.n_other; u->stride = S.stride; u->maxlen = S.maxlen;
     u->pairs_in_file = S.n_pairs_in_file; u->sam_pairs = S.n_sam_pairs;
     u->row_off.swap(S.row_off); u->row_slot.swap(S.row_slot); u->n_rows = S.n_rows;
 }
@@ -395,7 +396,7 @@ void stage_inputs(agx_unit *u) {
 // mapped and paged in where it is touched.  Valid for one BATCH size, one k and for exactly the five text files it was made from (size and
 // modification time of each are in the header): anything else and the loader falls back to the text.
 namespace cache {
-enum { S_HITS = 0, S_RUNS, S_CODES, S_SEGS, S_CHAIN_END, S_ROWS, S_REF, S_CM_CNT, S_CHAIN_STR, S_INITIAL, S_BASES, S_OTHER, S_SIDES, S_N };
+enum { S_HITS = 0, S_RUNS, S_CODES, S_SEGS, S_CHAIN_END, S_ROWS, S_REF, S_CM_CNT, S_CHAIN_STR, S_INITIAL, S_BASES, S_OTHER, S_SIDES, S_JUMP, S_N };
 struct Header {
     char magic[8]; agx_u32 version, batch; unsigned long long stamp[5][2];
     unsigned long long n_pos, n_ref, nh, n_runs, n_cm, n_segs, n_seg0, n_rows, n_chain_end, n_codes, pairs_in_file, sam_pairs;
@@ -403,11 +404,11 @@ struct Header {
     agx_u32 rows_in_reads;                       // 1: S_ROWS holds 64-bit offsets into tmp/_reads.fa (whose size and time are part of the stamp), S_BASES is empty; 0: S_ROWS holds the
                                                  // read slot of every row and S_BASES the slots' bases (units that the general loader parsed)
     agx_u32 slot_stride;                         // bases per read slot in S_BASES (rows_in_reads == 0)
-    unsigned long long n_sides;
+    unsigned long long n_sides, n_jump;
     agx_u32 sizes[5];                            // sizeof agx_whit, agx_wrun, agx_cmseg, Header, agx_wside: a file written by another layout is not this one
     unsigned long long off[S_N], len[S_N];
 };
-const char MAGIC[8] = {'A', 'G', 'X', 'U', 'N', 'I', 'T', '5'};
+const char MAGIC[8] = {'A', 'G', 'X', 'U', 'N', 'I', 'T', '6'};
 void stamps(const std::string &d, int unit, unsigned long long st[5][2]) {
     const std::string s = std::to_string(unit);
     const std::string f[5] = {d + "/_genome." + s + ".fa", d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie"};
@@ -426,12 +427,12 @@ void save_cache(agx_unit *u, const std::string &dir, int unit) {
     H.n_pos = u->V.n_pos; H.n_ref = u->V.n_ref; H.nh = u->nh; H.n_runs = u->n_runs; H.n_cm = u->n_cm; H.n_segs = u->n_segs; H.n_seg0 = u->n_seg0; H.n_rows = u->n_rows;
     H.n_chain_end = u->n_chain_end; H.n_codes = u->n_codes; H.pairs_in_file = u->pairs_in_file; H.sam_pairs = u->sam_pairs; H.stride = u->stride; H.maxlen = u->maxlen; H.n_slots = u->n_slots; H.k = u->prm.k;
     H.rows_in_reads = in_reads ? 1u : 0u; H.sizes[0] = sizeof(agx_whit); H.sizes[1] = sizeof(agx_wrun); H.sizes[2] = sizeof(agx_cmseg); H.sizes[3] = sizeof(Header); H.sizes[4] = sizeof(agx_wside);
-    H.slot_stride = u->V.stride; H.n_sides = u->n_sides;
+    H.slot_stride = u->V.stride; H.n_sides = u->n_sides; H.n_jump = u->n_jump;
     const void *ptr[S_N] = {u->s_hits.p, u->s_runs.p, u->s_codes.p, u->s_segs.p, u->s_chain_end.p, in_reads ? (const void *)u->row_off.data() : (const void *)u->row_slot.data(), u->V.ref, u->V.cm_cnt,
-                            u->V.chain_str, u->V.initial, in_reads ? nullptr : u->V.bases, u->s_other.p, u->s_sides.p};
+                            u->V.chain_str, u->V.initial, in_reads ? nullptr : u->V.bases, u->s_other.p, u->s_sides.p, u->s_jump.p};
     const unsigned long long len[S_N] = {u->nh * sizeof(agx_whit), u->n_runs * sizeof(agx_wrun), u->n_codes, u->n_segs * sizeof(agx_cmseg), (unsigned long long)u->n_chain_end * 4, (unsigned long long)u->n_rows * (in_reads ? 8 : 4),
                                          u->V.n_pos, u->V.n_pos, u->T.chain_str.size(), u->V.n_initial, in_reads ? 0ull : (unsigned long long)u->n_slots * u->V.stride, (unsigned long long)u->n_other * 8,
-                                         u->n_sides * sizeof(agx_wside)};
+                                         u->n_sides * sizeof(agx_wside), (unsigned long long)u->n_jump * 4};
     unsigned long long at = (sizeof(Header) + 4095) & ~4095ull;
     for (int i = 0; i < S_N; i++) { H.off[i] = at; H.len[i] = len[i]; at = (at + len[i] + 4095) & ~4095ull; }
     const std::string path = path_of(dir, unit), part = path + ".part";
@@ -472,7 +473,7 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     for (int i = 0; i < S_N; i++) if (H.off[i] > (unsigned long long)sb.st_size || H.len[i] > (unsigned long long)sb.st_size - H.off[i]) return false;
     const bool in_reads = H.rows_in_reads == 1;
     if (H.n_pos == 0 || H.n_pos >= 0xFFFFFF00ull || H.n_ref > H.n_pos || H.len[S_REF] != H.n_pos || H.len[S_CM_CNT] != H.n_pos || H.len[S_HITS] != H.nh * sizeof(agx_whit) || H.len[S_RUNS] != H.n_runs * sizeof(agx_wrun) ||
-        H.len[S_SIDES] != H.n_sides * sizeof(agx_wside) || H.n_sides > H.nh ||
+        H.len[S_SIDES] != H.n_sides * sizeof(agx_wside) || H.n_sides > H.nh || H.len[S_JUMP] != H.n_jump * 4 || H.n_jump > H.nh ||
         H.len[S_CODES] != H.n_codes || H.len[S_SEGS] != H.n_segs * sizeof(agx_cmseg) || H.n_seg0 > H.n_segs || H.len[S_ROWS] != H.n_rows * (in_reads ? 8 : 4) || (H.stride & 3u) ||
         H.len[S_BASES] != (in_reads ? 0ull : (unsigned long long)H.n_slots * H.slot_stride) || H.len[S_CHAIN_END] != H.n_chain_end * 4 || H.n_codes != H.n_rows * (H.stride / 4) || (H.len[S_OTHER] & 7u) ||
         H.nh >= 0xFFFFFFFFull || H.n_runs >= 0xFFFFFFFFull || H.n_rows >= 0x7FFFFFFFull || H.maxlen > H.stride || (!in_reads && H.maxlen > H.slot_stride)) return false;
@@ -485,14 +486,14 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     drop_outputs(u);
     u->T = Threads(); u->P = Pairs(); u->cache_map.reset(); u->cache_map.p = m; u->cache_map.n = (size_t)sb.st_size; u->reads_keep.reset(); u->reads_map.reset();
     const char *base = (const char *)m;
-    u->nh = H.nh; u->n_runs = H.n_runs; u->n_sides = H.n_sides; u->n_cm = H.n_cm; u->n_segs = H.n_segs; u->n_seg0 = (agx_u32)H.n_seg0; u->n_chain_end = (agx_u32)H.n_chain_end; u->n_codes = H.n_codes; u->n_other = H.len[S_OTHER] / 8;
+    u->nh = H.nh; u->n_runs = H.n_runs; u->n_sides = H.n_sides; u->n_jump = H.n_jump; u->n_cm = H.n_cm; u->n_segs = H.n_segs; u->n_seg0 = (agx_u32)H.n_seg0; u->n_chain_end = (agx_u32)H.n_chain_end; u->n_codes = H.n_codes; u->n_other = H.len[S_OTHER] / 8;
     u->pairs_in_file = H.pairs_in_file; u->sam_pairs = H.sam_pairs; u->stride = H.stride; u->maxlen = H.maxlen; u->n_slots = H.n_slots; u->n_rows = (agx_u32)H.n_rows;
-    u->s_hits.alloc(u->nh + 1); u->s_sides.alloc(u->n_sides + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16); u->s_other.alloc(u->n_other + 1); u->s_segs.alloc(u->n_segs + 1); u->s_chain_end.alloc((size_t)u->n_chain_end + 1);
+    u->s_hits.alloc(u->nh + 1); u->s_sides.alloc(u->n_sides + 1); u->s_jump.alloc(u->n_jump + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16); u->s_other.alloc(u->n_other + 1); u->s_segs.alloc(u->n_segs + 1); u->s_chain_end.alloc((size_t)u->n_chain_end + 1);
     // the staged arrays: read into the pinned buffers, a few threads, large pieces
     struct Piece { void *dst; unsigned long long off, len; };
     std::vector<Piece> pieces;
     auto cut = [&](void *dst, int sec) { for (unsigned long long a = 0; a < H.len[sec]; a += 32ull << 20) pieces.push_back(Piece{(char *)dst + a, H.off[sec] + a, std::min<unsigned long long>(32ull << 20, H.len[sec] - a)}); };
-    cut(u->s_hits.p, S_HITS); cut(u->s_sides.p, S_SIDES); cut(u->s_runs.p, S_RUNS); cut(u->s_codes.p, S_CODES); cut(u->s_other.p, S_OTHER); cut(u->s_segs.p, S_SEGS); cut(u->s_chain_end.p, S_CHAIN_END);
+    cut(u->s_hits.p, S_HITS); cut(u->s_sides.p, S_SIDES); cut(u->s_jump.p, S_JUMP); cut(u->s_runs.p, S_RUNS); cut(u->s_codes.p, S_CODES); cut(u->s_other.p, S_OTHER); cut(u->s_segs.p, S_SEGS); cut(u->s_chain_end.p, S_CHAIN_END);
     const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), pieces.size() ? pieces.size() : 1);
     std::vector<int> bad(threads, 0);
     on_threads(threads, [&](unsigned t) {
@@ -517,6 +518,12 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
             }
         });
         for (int b : bad2) fine = fine && !b;
+        for (size_t i = 0; i < u->n_jump && fine; i++) {      // exactly the hits whose left mate has several runs, ascending (pass J looks at no other hit)
+            const agx_u32 h = u->s_jump.p[i];
+            fine = h < u->nh && (i == 0 || u->s_jump.p[i - 1] < h);
+            if (fine) { const agx_hit x = agx_unpack_hit(u->s_hits.p[h], u->s_sides.p); fine = ((x.pad[0] & 1u) ? x.nruns2 : x.nruns1) >= 2; }
+        }
+        if (fine) { size_t want = 0; for (size_t i = 0; i < u->nh; i++) { const agx_whit &w = u->s_hits.p[i]; if (w.flags & ((w.flags & AGX_WF_LEFT2) ? AGX_WF_RUNS2 : AGX_WF_RUNS1)) { const agx_hit x = agx_unpack_hit(w, u->s_sides.p); want += ((x.pad[0] & 1u) ? x.nruns2 : x.nruns1) >= 2; } } fine = want == u->n_jump; }
         unsigned long long el = 0;
         for (size_t i = 0; i < u->n_segs && fine; i++) { const agx_cmseg &g = u->s_segs.p[i]; fine = (unsigned long long)g.pos0 + g.len <= H.n_pos && g.hop_end < H.n_pos && (unsigned long long)g.hop_str0 + g.hop_len0 <= H.len[S_CHAIN_STR] + 1 && g.elem0 == el; el += g.len; }
         fine = fine && el == H.n_cm;
@@ -607,7 +614,7 @@ Plan plan_capacities(const agx_unit *u) {
     // what the takes of do_upload add up to, plus the alignment of ~90 buffers
     const size_t per_pos = 4 + 16 + 1 + 4 + 1 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_hit) + sizeof(agx_dhit) + 16 + 4;
     const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
-    const size_t wire = nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + (u->ref_packed ? n_pos / 4 + u->n_refx * sizeof(agx_refx) : 0) + 4096;
+    const size_t wire = nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 + (u->ref_packed ? n_pos / 4 + u->n_refx * sizeof(agx_refx) : 0) + 4096;
     const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases + u->n_other * 8 +
                          (size_t)P.pool_cap * per_slot + ids_cap * per_id + (size_t)P.list_cap * 36 + (size_t)P.ovf_cap * 16 + (size_t)P.sp_cap * (sizeof(agx_walknode) + sizeof(agx_hop)) +
                          (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64 * 4 + (size_t)n_regions * AGX_REGION_PAD * 4 + (64u << 10) * 100;
@@ -637,7 +644,7 @@ void do_upload(agx_unit *u) {
     u->d_cm_start.alloc(a, n_pos + 2); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos + 16); u->d_cm_head.alloc(a, n_pos + 1);
     u->d_segs.alloc(a, u->n_segs + 1); u->d_cntruns.alloc(a, u->n_cntruns + 1); u->d_cntchunks.alloc(a, u->n_cntchunks + 1); u->d_segchunks.alloc(a, u->n_segchunks + 1);
     u->d_hits.alloc(a, nh + 1); u->d_runs.alloc(a, u->n_runs + 1); u->d_codes.alloc(a, u->n_codes + 16); u->d_vcodes.alloc(a, n_bases + 16); u->d_other.alloc(a, u->n_other + 1);
-    u->d_whits.alloc(a, nh + 1); u->d_wsides.alloc(a, u->n_sides + 1); u->d_wruns.alloc(a, u->n_runs + 1);
+    u->d_whits.alloc(a, nh + 1); u->d_wsides.alloc(a, u->n_sides + 1); u->d_wruns.alloc(a, u->n_runs + 1); u->d_jump.alloc(a, u->n_jump + 1);
     if (u->ref_packed) { u->d_wref.alloc(a, (n_pos + 3) / 4 + 32); u->d_refx.alloc(a, u->n_refx + 1); }
     u->d_dhit.alloc(a, nh + 1); u->d_rank4.alloc(a, 4 * (nh + 1));
     u->d_tile_cnt.alloc(a, (size_t)u->n_tiles + 1); u->d_tile_off.alloc(a, (size_t)u->n_tiles + 2); u->d_cursor.alloc(a, (size_t)u->n_tiles + 1);
@@ -668,7 +675,7 @@ void do_upload(agx_unit *u) {
         };
         up(u->d_segs.p, u->s_segs.p, u->n_segs * sizeof(agx_cmseg)); up(u->d_cntruns.p, u->s_cntruns.p, u->n_cntruns * sizeof(agx_cntrun));
         up(u->d_cntchunks.p, u->s_cntchunks.p, u->n_cntchunks * sizeof(agx_chunk)); up(u->d_segchunks.p, u->s_segchunks.p, u->n_segchunks * sizeof(agx_chunk));
-        up(u->d_whits.p, u->s_hits.p, nh * sizeof(agx_whit)); up(u->d_wsides.p, u->s_sides.p, u->n_sides * sizeof(agx_wside)); up(u->d_wruns.p, u->s_runs.p, u->n_runs * sizeof(agx_wrun));
+        up(u->d_whits.p, u->s_hits.p, nh * sizeof(agx_whit)); up(u->d_wsides.p, u->s_sides.p, u->n_sides * sizeof(agx_wside)); up(u->d_wruns.p, u->s_runs.p, u->n_runs * sizeof(agx_wrun)); up(u->d_jump.p, u->s_jump.p, u->n_jump * 4);
         HIP_OK(hipEventRecord(u->ev_hits, st));         // what the front of the build needs (conti-mer tables, hit preparation, binning) is there: it starts while the rest still travels
         up(u->d_codes.p, u->s_codes.p, u->n_codes); up(u->d_other.p, u->s_other.p, u->n_other * 8);      // first needed by the sweep
         if (u->ref_packed) { up(u->d_wref.p, u->s_ref.p, (n_pos + 3) / 4); up(u->d_refx.p, u->s_refx.p, u->n_refx * sizeof(agx_refx)); } else up(u->d_ref.p, u->s_ref.p, n_pos);
@@ -700,7 +707,7 @@ void do_upload(agx_unit *u) {
 
     u->uploaded = true; u->built = false; u->downloaded = false;
     u->stats.ms_upload = now_ms() - t0;
-    u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + u->n_cntruns * sizeof(agx_cntrun) + (u->n_cntchunks + u->n_segchunks) * sizeof(agx_chunk) + (u->ref_packed ? (n_pos + 3) / 4 + u->n_refx * sizeof(agx_refx) : n_pos) + nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) +
+    u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + u->n_cntruns * sizeof(agx_cntrun) + (u->n_cntchunks + u->n_segchunks) * sizeof(agx_chunk) + (u->ref_packed ? (n_pos + 3) / 4 + u->n_refx * sizeof(agx_refx) : n_pos) + nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 +
                             (size_t)u->n_chain_end * 4 + u->n_codes + u->n_other * 8 + ((size_t)u->n_regions + 1) * 4;
     u->stats.device_bytes = u->arena.capacity();
 }
@@ -821,7 +828,7 @@ void do_build(agx_unit *u) {
         u->ev.mark(B_BIG, st);
         // ---- edge sweep ----
         agx_edge_kargs E; fill_sweep_args(u, E.S); E.ovf = u->d_ovf.p; E.ovf_count = u->d_words.p + W_OVFCOUNT; E.ovf_cap = u->ovf_cap; E.list_cap = u->list_cap;
-        E.n_hits = nh; E.abort = u->d_words.p + W_STATUS; E.big_list = u->d_big_list.p; E.big_n = u->d_words.p + W_BIGCOUNT; E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
+        E.n_hits = nh; E.jump_list = u->d_jump.p; E.n_jump = (agx_u32)u->n_jump; E.abort = u->d_words.p + W_STATUS; E.big_list = u->d_big_list.p; E.big_n = u->d_words.p + W_BIGCOUNT; E.slow_list = u->d_slow_list.p; E.slow_count = u->d_words.p + W_SLOWCOUNT;
         agx_launch_edge_sweep(&E, st);
         AGX_CHECKPOINT("edge_sweep");
         // Passes J and B insert edges out of different sources (positions with one variant / with several) and both wait on memory more than
@@ -1002,7 +1009,7 @@ void do_release(agx_unit *u) {
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     for (auto *b : {&u->d_node_cnt, &u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
     u->d_other.release(); u->d_whits.release(); u->d_wsides.release(); u->d_wruns.release(); u->d_wref.release(); u->d_refx.release();
-    u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_cntruns.release(); u->d_cntchunks.release(); u->d_segchunks.release(); u->d_sp_hop.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
+    u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_cntruns.release(); u->d_cntchunks.release(); u->d_segchunks.release(); u->d_jump.release(); u->d_sp_hop.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
     u->d_ovf.release(); u->d_a_ovf.release(); u->d_huge_list.release(); u->d_scratch_huge.release(); u->huge = false; u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
     u->arena.reset();
     u->h_a_str.release(); u->h_a_meta.release(); for (auto &b : u->h_a_metas) b.release(); u->h_side_xpos.release(); u->h_sp_rank.release(); u->h_sp_bits.release(); u->h_sp_node.release(); u->h_fetch.release(); u->h_a_ovf.release();

@@ -169,7 +169,7 @@ unsigned loader_threads(size_t bytes);      // AGX_LOAD_THREADS, else by the siz
 // middle, ids out of order, blocks that overlap, whatever would be an error): the caller then takes the general loader of agx_host.cpp, which follows
 // the reference line by line and reports errors in its order.  What they return is byte for byte what the general loader + staging produce.
 struct ReadsIndex;
-enum { SA_HITS = 0, SA_SIDES, SA_RUNS, SA_CODES, SA_OTHER, SA_N };
+enum { SA_HITS = 0, SA_SIDES, SA_RUNS, SA_CODES, SA_OTHER, SA_JUMP, SA_N };
 struct StageSink { virtual void *take(int which, size_t bytes) = 0; virtual ~StageSink() {} };      // where the staged arrays live (the engine: pinned memory)
 struct StagedPairs {        // what the upload wants of a unit's read alignments, in the wire formats of agx_core.h (agx_engine.cpp: stage)
     agx_whit *hits = nullptr; size_t nh = 0;             // row = ROW of the left mate's bases, AGX_WF_LEFT2 = which mate that is
@@ -177,6 +177,7 @@ struct StagedPairs {        // what the upload wants of a unit's read alignments
     agx_wrun *runs = nullptr; size_t n_runs = 0;
     agx_u8 *codes = nullptr; size_t n_codes = 0;         // 2-bit classes, stride / 4 bytes per row
     unsigned long long *other = nullptr; size_t n_other = 0;   // bases that are not A, C, G, T: row * stride + index, ascending
+    agx_u32 *jump = nullptr; size_t n_jump = 0;          // the hits whose LEFT mate has two or more runs, ascending: the only ones pass J of the edge build has to look at (agx_edge_jump_hit)
     agx_u32 stride = 0, maxlen = 0, n_rows = 0;          // stride: bases per row = the longest read rounded up to 4
     std::vector<uint64_t> row_off;                       // fast loader: where each row's bases start in the reads file
     std::vector<agx_u32> row_slot;                       // general loader: the read slot (Pairs::bases) of each row

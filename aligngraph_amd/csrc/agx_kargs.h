@@ -35,7 +35,7 @@ struct agx_node_kargs {
 struct agx_edge_kargs {
     agx_sweep_args S; agx_edge_ovf *ovf; agx_u32 *ovf_count; agx_u32 ovf_cap; agx_u32 list_cap;
     agx_u32 *slow_list; agx_u32 *slow_count;   // positions that need the per-hit pass (device-side list)
-    agx_u32 n_hits;                            // pass J looks at every hit's derived record (a list of the candidates cost more to make than it saved)
+    agx_u32 n_hits; const agx_u32 *jump_list; agx_u32 n_jump;      // pass J: the hits whose left mate has several runs (listed by the host's staging)
     const agx_u32 *abort;                      // the node sweeps' status word: non-zero = the node table is incomplete, do nothing
     const agx_u32 *big_list; const agx_u32 *big_n;   // tiles the fallback pass wrote (their edges are all pass A/B's)
 };

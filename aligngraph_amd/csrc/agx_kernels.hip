@@ -481,14 +481,15 @@ __device__ __forceinline__ void agx_slot_insert(const agx_edge_kargs &K, agx_u32
     atomicOr((agx_u32 *)(addr & ~(size_t)3), (agx_u32)AGX_NF_EOVF << (8u * (agx_u32)(addr & 3)));
 }
 
-// pass J: one thread per hit; agx_edge_jump_hit drops the ones that were skipped or whose a mate is a single run (five hits in six)
+// pass J: one thread per hit whose left mate has several runs (one hit in six; the host lists them when it stages the hits: r02 looked at two words
+// of every hit's derived record to find them, 0.23 ms on a 30 Mb unit); agx_edge_jump_hit drops the ones hit_prep skipped
 __global__ void __launch_bounds__(256) agx_k_edge_jump(agx_edge_kargs K) {
     AGX_RETURN_IF_ABORTED(K.abort);
     const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= K.n_hits) return;
-    const agx_u32 fl = K.S.dhit[i].flags, nr = K.S.dhit[i].a_nruns;      // (two words of the record decide for most hits)
-    if ((fl & AGX_HF_SKIP) || nr < 2) return;
-    const agx_dhit d = K.S.dhit[i];
+    if (i >= K.n_jump) return;
+    const agx_u32 h = K.jump_list[i];
+    if (h >= K.n_hits) return;
+    const agx_dhit d = K.S.dhit[h];
     agx_edge_jump_hit(K.S, d, [&](agx_u32 src, agx_u32 dst) { agx_slot_insert(K, src, dst); });
 }
 
@@ -711,7 +712,7 @@ void agx_launch_edge_sweep(const agx_edge_kargs *K, hipStream_t st) {
     hipLaunchKernelGGL(agx_k_edge_sweep, dim3(nb + AGX_BIG_WAVES / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *K, nb);
 }
 void agx_launch_edge_jump(const agx_edge_kargs *K, hipStream_t st) {
-    if (K->S.n_pos && K->n_hits) hipLaunchKernelGGL(agx_k_edge_jump, dim3((K->n_hits + 255u) / 256u), dim3(256), 0, st, *K);
+    if (K->S.n_pos && K->n_jump) hipLaunchKernelGGL(agx_k_edge_jump, dim3((K->n_jump + 255u) / 256u), dim3(256), 0, st, *K);
 }
 void agx_launch_edge_slow(const agx_edge_kargs *K, hipStream_t st) {
     // persistent wavefronts: exactly as many blocks as the device holds at once (a second, partial round of blocks would idle most CUs)

@@ -431,6 +431,8 @@ void stage_pairs(const Pairs &P, agx_u32 k, unsigned threads, StageSink &sink, S
     }
     S.n_sides = n_sides; S.sides = (agx_wside *)sink.take(SA_SIDES, (n_sides + 1) * sizeof(agx_wside));
     { size_t at = 0; for (size_t i = 0; i < nh; i++) { const agx_hit &h = st[i]; const bool sd = (h.nruns1 | h.nruns2) != 0; S.hits[i] = agx_pack_hit(h, (agx_u32)at); if (sd) S.sides[at++] = agx_wside{h.runs1, h.runs2, (agx_u32)h.nruns1 | ((agx_u32)h.nruns2 << 16)}; } }
+    { size_t nj = 0; for (const agx_hit &h : st) nj += ((h.pad[0] & 1u) ? h.nruns2 : h.nruns1) >= 2; S.n_jump = nj; S.jump = (agx_u32 *)sink.take(SA_JUMP, (nj + 1) * 4);
+      size_t at = 0; for (size_t i = 0; i < nh; i++) if (((st[i].pad[0] & 1u) ? st[i].nruns2 : st[i].nruns1) >= 2) S.jump[at++] = (agx_u32)i; }
     const size_t quarter = S.stride / 4, n_rows = S.row_slot.size();
     S.n_rows = (agx_u32)n_rows; S.n_codes = n_rows * quarter;
     S.codes = (agx_u8 *)sink.take(SA_CODES, S.n_codes + 16);
@@ -504,7 +506,7 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
         SBuf<agx_hit> cand; SBuf<agx_u32> cand_pair; SBuf<agx_run> runs;      // pairs that pass the identity filter: slot1 = read id, run indices local; which pair each is
         size_t pair_base = 0;                             // global index of the first pair
         // after the batch rule (phase C): what stays, in final form but local numbering
-        size_t n_keep = 0, n_runs = 0, n_sides = 0, lead_n = 0, side_base = 0; agx_u32 maxlen = 0;
+        size_t n_keep = 0, n_runs = 0, n_sides = 0, n_jump = 0, lead_n = 0, side_base = 0, jump_base = 0; agx_u32 maxlen = 0;
         agx_u32 lead_rows = 0, n_rows_local = 0;          // rows opened by the leading group (the hits of the range's first read id), and by the whole range, as if nothing came before
         agx_u32 last_id = 0, last_count = 0; agx_u32 last_row[2] = {AGX_NONE, AGX_NONE};      // the range's last group: kept hits, rows of its mates (local numbering)
         bool single_group = false, lead_fixed = false;
@@ -652,7 +654,7 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
             agx_u32 info = 0;
             if (row[m] == AGX_NONE) { row[m] = rows++; info = 0x80000000u; }
             r.cand_pair[i] = info | row[m];
-            r.n_runs += (size_t)h.nruns1 + h.nruns2; r.n_sides += (h.nruns1 | h.nruns2) ? 1u : 0u;
+            r.n_runs += (size_t)h.nruns1 + h.nruns2; r.n_sides += (h.nruns1 | h.nruns2) ? 1u : 0u; r.n_jump += (m ? h.nruns2 : h.nruns1) >= 2 ? 1u : 0u;
             r.maxlen = std::max<agx_u32>(r.maxlen, h.len);
         }
         if (lead) { r.lead_n = w; r.lead_rows = rows; r.single_group = true; }
@@ -661,12 +663,12 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
     });
     for (Range &r : R) if (r.bad) return false;
     // ---- phase C3 (sequential, a few operations per range): where every range's hits, runs and rows go; a pair whose hits straddle a range boundary ----
-    size_t nh = 0, n_runs = 0, n_sides = 0; agx_u32 n_rows = 0, maxlen = 0;
+    size_t nh = 0, n_runs = 0, n_sides = 0, n_jump = 0; agx_u32 n_rows = 0, maxlen = 0;
     {
         bool have = false; agx_u32 c_id = 0, c_count = 0, c_row[2] = {AGX_NONE, AGX_NONE}; agx_u16 c_len = 0;      // the pair the ranges so far ended with: its kept hits, the rows of its mates (final numbering)
         for (Range &r : R) {
-            r.hit_base = nh; r.run_base = n_runs; r.side_base = n_sides; r.row_base = n_rows; r.row_shift = 0; r.lead_fixed = false;
-            nh += r.n_keep; n_runs += r.n_runs; n_sides += r.n_sides; maxlen = std::max(maxlen, r.maxlen);
+            r.hit_base = nh; r.run_base = n_runs; r.side_base = n_sides; r.jump_base = n_jump; r.row_base = n_rows; r.row_shift = 0; r.lead_fixed = false;
+            nh += r.n_keep; n_runs += r.n_runs; n_sides += r.n_sides; n_jump += r.n_jump; maxlen = std::max(maxlen, r.maxlen);
             if (!r.n_keep) continue;
             const bool joins = have && c_id == r.cand[0].slot1;
             agx_u32 lead_row[2] = {AGX_NONE, AGX_NONE};
@@ -696,7 +698,7 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
     }
     if (nh == 0) {          // nothing kept: what the general loader leaves (no rows, stride 0)
         S.hits = (agx_whit *)sink.take(SA_HITS, sizeof(agx_whit)); S.runs = (agx_wrun *)sink.take(SA_RUNS, sizeof(agx_wrun)); S.sides = (agx_wside *)sink.take(SA_SIDES, sizeof(agx_wside));
-        S.codes = (agx_u8 *)sink.take(SA_CODES, 16); S.other = (unsigned long long *)sink.take(SA_OTHER, 8);
+        S.codes = (agx_u8 *)sink.take(SA_CODES, 16); S.other = (unsigned long long *)sink.take(SA_OTHER, 8); S.jump = (agx_u32 *)sink.take(SA_JUMP, 4);
         return true;
     }
     if (n_runs >= 0xFFFFFFFFull) return false;
@@ -706,12 +708,13 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
     S.hits = (agx_whit *)sink.take(SA_HITS, (nh + 1) * sizeof(agx_whit)); S.runs = (agx_wrun *)sink.take(SA_RUNS, (n_runs + 1) * sizeof(agx_wrun));
     S.sides = (agx_wside *)sink.take(SA_SIDES, (n_sides + 1) * sizeof(agx_wside));
     S.codes = (agx_u8 *)sink.take(SA_CODES, S.n_codes + 16);
+    S.n_jump = n_jump; S.jump = (agx_u32 *)sink.take(SA_JUMP, (n_jump + 1) * 4);
     S.row_off.assign(n_rows, 0);
     tt[4] = now_ms();
     // ---- phase D: hits and runs to their final places; the left mates' bases from the reads file, as 2-bit classes, by the hit that opens the row ----
     const char *rb = reads.fv.p, *re = reads.fv.p + reads.fv.n;
     each_range(2, [&](Range &r) {
-        size_t run_at = r.run_base, side_at = r.side_base;
+        size_t run_at = r.run_base, side_at = r.side_base, jump_at = r.jump_base;
         auto put_runs = [&](agx_u32 from, agx_u32 n) { for (agx_u32 j = 0; j < n; j++) { const agx_run &x = r.runs[from + j]; S.runs[run_at + j] = agx_wrun{x.t, (agx_u16)x.q, (agx_u16)x.n}; } };
         for (size_t i = 0; i < r.n_keep; i++) {
             // the reads are spread over the whole (mapped) reads file: every row is two cache misses and a TLB miss unless it is asked for ahead of time
@@ -725,6 +728,7 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
             if (h.nruns1) { put_runs(h.runs1, h.nruns1); h.runs1 = (agx_u32)run_at; run_at += h.nruns1; }
             if (h.nruns2) { put_runs(h.runs2, h.nruns2); h.runs2 = (agx_u32)run_at; run_at += h.nruns2; }
             h.slot1 = row; h.pad[1] = h.pad[2] = 0;
+            if ((m ? h.nruns2 : h.nruns1) >= 2) S.jump[jump_at++] = (agx_u32)(r.hit_base + i);
             S.hits[r.hit_base + i] = agx_pack_hit(h, (agx_u32)side_at);
             if (h.nruns1 | h.nruns2) S.sides[side_at++] = agx_wside{h.runs1, h.runs2, (agx_u32)h.nruns1 | ((agx_u32)h.nruns2 << 16)};
             if (!opens) continue;

@@ -376,6 +376,11 @@ extern "C" int agx_hostsim_compare_loaders(const char *tmp_dir, int unit, int k,
         try { fast_ok = load_pairs_fast(*ri, d + "/_reads_genome." + s + ".bowtie", batch, (agx_u32)k, (unsigned)threads, B, SB); } catch (const Error &e) { if (slow_ok) { say("fast read loader threw: " + e.msg); return -4; } }
         if (!slow_ok && fast_ok) { say("general read loader fails (" + slow_err + ") but the fast one accepts the input"); return -5; }
         if (!fast_ok) declined |= 2;
+        if (slow_ok) {      // pass J's list: exactly the hits whose left mate has several runs
+            size_t at = 0;
+            for (size_t i = 0; i < staged.size(); i++) if (((staged[i].pad[0] & 1u) ? staged[i].nruns2 : staged[i].nruns1) >= 2) { if (at >= SA.n_jump || SA.jump[at] != i) { say("list of hits for pass J is wrong at hit " + std::to_string(i)); return -33; } at++; }
+            if (at != SA.n_jump) { say("list of hits for pass J is too long"); return -33; }
+        }
         if (slow_ok) {      // the wire forms (agx_core.h) must unpack to exactly the staged hits and the loader's runs
             for (size_t i = 0; i < SA.nh; i++) { const agx_hit h = agx_unpack_hit(SA.hits[i], SA.sides); agx_hit w = staged[i]; w.pad[1] = w.pad[2] = 0; if (memcmp(&h, &w, sizeof h) != 0) { say("wire form of hit " + std::to_string(i) + " does not unpack to the staged hit"); return -30; } }
             for (size_t i = 0; i < SA.n_runs; i++) if (SA.runs[i].q != P.runs[i].q || SA.runs[i].t != P.runs[i].t || SA.runs[i].n != P.runs[i].n) { say("wire form of run " + std::to_string(i) + " differs"); return -31; }
@@ -394,6 +399,7 @@ extern "C" int agx_hostsim_compare_loaders(const char *tmp_dir, int unit, int k,
                          x.slot1, x.pos1, x.pos2, x.runs1, x.nruns1, x.runs2, x.nruns2, x.len, x.rev1, x.rev2, x.back, x.pad[0], y.slot1, y.pos1, y.pos2, y.runs1, y.nruns1, y.runs2, y.nruns2, y.len, y.rev1, y.rev2, y.back, y.pad[0]); return bad(b); }
             if (SA.n_sides && memcmp(SA.sides, SB.sides, SA.n_sides * sizeof(agx_wside)) != 0) return bad("side records");
             if (SA.n_runs && memcmp(SA.runs, SB.runs, SA.n_runs * sizeof(agx_wrun)) != 0) return bad("runs");
+            if (SA.n_jump != SB.n_jump || (SA.n_jump && memcmp(SA.jump, SB.jump, SA.n_jump * 4) != 0)) return bad("list of hits for pass J");
             if (SA.n_codes != SB.n_codes || (SA.n_codes && memcmp(SA.codes, SB.codes, SA.n_codes) != 0)) return bad("codes");
             if (SA.n_other != SB.n_other || (SA.n_other && memcmp(SA.other, SB.other, SA.n_other * 8) != 0)) return bad("list of other bases");
             std::vector<agx_u16> row_len(SA.n_rows, 0);
