@@ -128,8 +128,8 @@ const HsaCopy &hsa_copy() { static const HsaCopy h; return h; }
 // positions from which a unit's host walk is split between two walkers (= walk_split's default in agx_walk.cpp; AGX_WALK_SPLIT_MIN, read at every download, overrides both: tests)
 inline size_t two_walkers_min() { const char *e = getenv("AGX_WALK_SPLIT_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4000000; }
 #define AGX_TWO_WALKERS_MIN two_walkers_min()
-// walkers for a unit of n_pos positions: one per 5 M positions from the threshold on, at most four (walk_split decides the same way from what it is given)
-inline int walkers_wanted(size_t n_pos) { if (n_pos < AGX_TWO_WALKERS_MIN) return 1; const char *e = getenv("AGX_WALK_SPLIT_WALKERS"); int k = e ? atoi(e) : (int)(n_pos / 5000000u); return k < 2 ? 2 : k > 4 ? 4 : k; }
+// walkers for a unit of n_pos positions: one per 5 M positions from the threshold on, at most four — eight if asked for (walk_split decides the same way from what it is given)
+inline int walkers_wanted(size_t n_pos) { if (n_pos < AGX_TWO_WALKERS_MIN) return 1; const char *e = getenv("AGX_WALK_SPLIT_WALKERS"); int k = e ? atoi(e) : std::min(4, (int)(n_pos / 5000000u)); return k < 2 ? 2 : k > 1 + GraphView::MAX_COPIES ? 1 + GraphView::MAX_COPIES : k; }
 
 // One helper thread per unit, started with the unit and asleep until it is handed work: what a unit can prepare while its upload and
 // build run (the pinned download buffers, the output buffers) without its worker waiting for it.  Not started on demand: creating a
@@ -168,7 +168,7 @@ struct UnitHelper {
 // The further walkers of large units (agx_walk.cpp: walk_split; the first extra one is the unit's own helper): a small pool for the process, made
 // when the first large unit is finished.  A unit takes what is free and walks with fewer walkers if that is less than it wanted.
 struct WalkerPool {
-    enum { N = 12 };
+    enum { N = 32 };
     struct Slot { std::thread th; std::mutex m; std::condition_variable cv; std::function<void()> job; bool queued = false, running = false, taken = false, stop = false; };
     Slot slot[N]; std::mutex take_m; bool started = false;
     void start() {
@@ -244,7 +244,7 @@ struct agx_unit {
     DBuf<agx_u32> d_chain_end, d_side_xpos, d_sp_cnt, d_sp_rank; DBuf<unsigned long long> d_sp_bits;
     agx_u32 n_chain_end = 0, n_special = 0, n_words = 0;
     // downloaded: the walk graph with its sparse record table (agx_core.h); the full record table stays on the device
-    PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta, h_a_metas[3] /* further copies of the meta bytes for the walk's other walkers (large units) */; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
+    PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta, h_a_metas[GraphView::MAX_COPIES] /* further copies of the meta bytes for the walk's other walkers (large units) */; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
     PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_edge_ovf> h_a_ovf; PBuf<agx_hop> h_sp_hop; DBuf<agx_hop> d_sp_hop;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
@@ -957,7 +957,7 @@ void do_download(agx_unit *u) {
         cut(u->h_sp_bits, nw + 1); cut(u->h_sp_rank, nw + 1); cut(u->h_a_ovf, (size_t)u->n_ovf + 1);
     }
     u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(nside + 1);
-    for (int w = 0; w < 3; w++) { if (w < copies) u->h_a_metas[w].alloc(ni + 64); else u->h_a_metas[w].release(); }
+    for (int w = 0; w < GraphView::MAX_COPIES; w++) { if (w < copies) u->h_a_metas[w].alloc(ni + 64); else u->h_a_metas[w].release(); }
     u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2);
     u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
     // the walk graph into the pinned buffers: plain copy commands on the device's download stream.  (r02 first used a kernel of its own for
@@ -965,7 +965,7 @@ void do_download(agx_unit *u) {
     // memory slowed whatever ran beside it, the next unit's binning most of all: the five builds of a cfg3 job ended at 45 ms with it, at
     // 42-45 ms with grids of 16-128 blocks, at 35 ms with the runtime's copies.)
     {
-        void *dst[12]; const void *src[12]; size_t bytes[12]; int n = 0;
+        void *dst[24]; const void *src[24]; size_t bytes[24]; int n = 0;
         auto add = [&](void *h, const void *d, size_t b) { if (b) { dst[n] = h; src[n] = d; bytes[n] = b; n++; } };
         if (ni) { add(u->h_sp_bits.p, u->d_sp_bits.p, nw * 8); add(u->h_sp_rank.p, u->d_sp_rank.p, nw * 4); add(u->h_a_str.p, u->d_a_str.p, ni); add(u->h_a_meta.p, u->d_a_meta.p, ni); for (int w = 0; w < copies; w++) add(u->h_a_metas[w].p, u->d_a_meta.p, ni); }
         add(u->h_side_xpos.p, u->d_side_xpos.p, nside * 4);
@@ -1039,7 +1039,7 @@ void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u
 
 GraphView view_of(agx_unit *u) {
     GraphView G; G.n_pos = (agx_u32)u->V.n_pos; G.n_ids = u->n_ids;
-    G.meta = u->h_a_meta.p; G.meta_rw = u->h_a_meta.p; for (int w = 0; w < 3; w++) G.meta_copy[w] = u->h_a_metas[w].p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
+    G.meta = u->h_a_meta.p; G.meta_rw = u->h_a_meta.p; for (int w = 0; w < GraphView::MAX_COPIES; w++) G.meta_copy[w] = u->h_a_metas[w].p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
     G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.sp_hop = u->h_sp_hop.p; G.n_special = u->n_special;
     G.fetch = fetch_records; G.fetch_ctx = u;
     G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf; G.row_slot = u->row_slot.empty() ? nullptr : u->row_slot.data();
@@ -1280,8 +1280,8 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
         u->downloaded = false;            // the walk marks the downloaded meta bytes: another finish downloads again
         u->out_ready = false;             // (an error below leaves the buffers to the next prepare_outputs)
         struct Helpers : Assistant {           // helper 0: the unit's own thread (formats the written records while the walk goes on, or walks a stretch); 1..: pool threads for further walkers
-            agx_unit *u; int pool[3] = {-1, -1, -1}; int n_pool = 0;
-            Helpers(agx_unit *x, int extra) : u(x) { for (int i = 0; i < extra && i < 3; i++) { const int t = walker_pool().take(); if (t < 0) break; pool[n_pool++] = t; } }
+            agx_unit *u; int pool[GraphView::MAX_COPIES] = {-1, -1, -1, -1, -1, -1, -1}; int n_pool = 0;
+            Helpers(agx_unit *x, int extra) : u(x) { for (int i = 0; i < extra && i < GraphView::MAX_COPIES - 1; i++) { const int t = walker_pool().take(); if (t < 0) break; pool[n_pool++] = t; } }
             ~Helpers() override { for (int i = 0; i < n_pool; i++) { walker_pool().wait(pool[i]); walker_pool().give(pool[i]); } }
             int helpers() const override { return 1 + n_pool; }
             void run(std::function<void()> f, int who) override {

@@ -80,7 +80,8 @@ struct GraphView {
     agx_u32 n_pos = 0, n_ids = 0;
     const agx_u8 *meta = nullptr;                           // [n_ids + 64] AGX_WM_* bits (padding reads as 0)
     agx_u8 *meta_rw = nullptr;                              // null, or == meta: the walk may keep its visited marks in meta's bit 7 (the array is consumed by the walk)
-    agx_u8 *meta_copy[3] = {nullptr, nullptr, nullptr};     // further copies of meta that the walk may consume as well: a large unit is then walked by several walkers, one per copy + 1 (agx_walk.cpp: walk_split)
+    enum { MAX_COPIES = 7 };
+    agx_u8 *meta_copy[MAX_COPIES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // further copies of meta that the walk may consume as well: a large unit is then walked by several walkers, one per copy + 1 (agx_walk.cpp: walk_split)
     const char *str = nullptr;                              // [n_ids] base a node emits
     const agx_u32 *side_xpos = nullptr;                     // [n_ids - n_pos] position of each side id, non-decreasing
     const unsigned long long *sp_bits = nullptr;            // [n_ids/64 + 1] special-id bitmap

@@ -573,12 +573,14 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     const agx_u32 warm = getenv("AGX_WALK_SPLIT_WARMUP") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_WARMUP"), nullptr, 10) : 400000u;
     const agx_u32 n_ref = V.n_ref < G.n_pos ? V.n_ref : G.n_pos;
     if (!assistant || !G.meta_copy[0] || n_ref < min_ref || n_ref < 16 || getenv("AGX_WALK_NO_SPLIT")) return false;
-    // walkers: one per 5 M positions (at least two), as many as there are copies of the meta bytes and helper threads, at most four.  (r02: one per
-    // 15.5 M — a 19 Mb unit, the LAST of a cfg3 job, was walked by two in 13 ms while the cores of the finished units idled: 52 -> 49 ms per job with four)
-    int K = getenv("AGX_WALK_SPLIT_WALKERS") ? atoi(getenv("AGX_WALK_SPLIT_WALKERS")) : (int)(n_ref / 5000000u);
+    // walkers: one per 5 M positions (at least two), as many as there are copies of the meta bytes and helper threads, at most four unless asked for
+    // (AGX_WALK_SPLIT_WALKERS: up to eight).  r02: one per 15.5 M — a 19 Mb unit, the LAST of a cfg3 job, was walked by two in 13 ms while the cores of the
+    // finished units idled: 52 -> 49 ms per job with four.  More than four buy little: every further walker needs its own copy of the meta bytes
+    // (0.36 ms of download for a 19 Mb unit, in front of the walk) and saves less than that of the walk.
+    int K = getenv("AGX_WALK_SPLIT_WALKERS") ? atoi(getenv("AGX_WALK_SPLIT_WALKERS")) : std::min(4, (int)(n_ref / 5000000u));
     if (K < 2) K = 2;
-    if (K > 4) K = 4;
-    { int copies = 0; while (copies < 3 && G.meta_copy[copies]) copies++; if (K > 1 + copies) K = 1 + copies; if (K > 1 + assistant->helpers()) K = 1 + assistant->helpers(); }
+    if (K > 1 + GraphView::MAX_COPIES) K = 1 + GraphView::MAX_COPIES;
+    { int copies = 0; while (copies < GraphView::MAX_COPIES && G.meta_copy[copies]) copies++; if (K > 1 + copies) K = 1 + copies; if (K > 1 + assistant->helpers()) K = 1 + assistant->helpers(); }
     if (K < 2) return false;
     const agx_u32 n_side = G.n_ids - G.n_pos;
     auto side_of = [&](agx_u32 x) { return G.n_pos + (agx_u32)(std::lower_bound(G.side_xpos, G.side_xpos + n_side, x) - G.side_xpos); };
@@ -873,8 +875,8 @@ void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out, 
     const double ts = now();
     Walker W(V, G);
     std::pmr::monotonic_buffer_resource arena((size_t)8 << 20);      // byte-range lists and trailing k-mers of the written records
-    std::pmr::monotonic_buffer_resource arena2((size_t)1 << 20), arena3((size_t)1 << 20), arena4((size_t)1 << 20);     // the other walkers' (walk_split): an arena serves one thread
-    Arena *const more_arenas[3] = {&arena2, &arena3, &arena4};
+    std::pmr::monotonic_buffer_resource arena2((size_t)1 << 20), arena3((size_t)1 << 20), arena4((size_t)1 << 20), arena5((size_t)1 << 20), arena6((size_t)1 << 20), arena7((size_t)1 << 20), arena8((size_t)1 << 20);     // the other walkers' (walk_split): an arena serves one thread
+    Arena *const more_arenas[GraphView::MAX_COPIES] = {&arena2, &arena3, &arena4, &arena5, &arena6, &arena7, &arena8};
     std::vector<Rec> recs; recs.reserve((size_t)G.n_pos / 1024 + 1024);
     double t0 = now();
     if (!walk_split(W, V, G, out.pre_extended, recs, &arena, more_arenas, assistant)) walk(W, out.pre_extended, recs, &arena, assistant);
