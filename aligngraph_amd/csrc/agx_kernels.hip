@@ -527,20 +527,82 @@ __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
 }
 
 // ---- walk preparation: renumber surviving nodes, rewrite edges, mark forced runs (agx_core.h) -------------------------------
+// One thread per position is a chain of dependent loads (node_start -> flags -> edge slots -> the targets' walk ids -> marks): with every CU full the
+// kernels' time was the depth of that chain times 57 rounds of resident threads over a 30 M-position unit (r02: 0.21 + 0.64 ms).  r03: a thread takes
+// AGX_WP_POS positions (a block's threads side by side in each of them: the accesses stay coalesced) and issues the loads of all of them level by level; positions
+// with one variant — nearly all — are finished from those registers, the others go through the general lane function.
+#define AGX_WP_POS 4u
 // (the first threads also mark the main ids of the chain-end positions: a_mark is complete before anything reads it)
 __global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A, const agx_u32 *chain_end, agx_u32 n_chain_end) {
     AGX_RETURN_IF_ABORTED(A.abort);
-    const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n_chain_end) A.a_mark[chain_end[i]] = 1;
-    agx_assign_aid_pos(A, i);
+    const agx_u32 base = blockIdx.x * (256u * AGX_WP_POS) + threadIdx.x;
+    agx_u32 s[AGX_WP_POS], n[AGX_WP_POS], fl[AGX_WP_POS];
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
+        const agx_u32 X = base + j * 256u;
+        if (X < n_chain_end) A.a_mark[chain_end[X]] = 1;
+        const bool in = X < A.n_pos;
+        s[j] = in ? A.node_start[X] : 0u; n[j] = in ? A.node_cnt[X] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) fl[j] = n[j] == 1u ? A.n_flags[s[j]] : 0u;
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
+        const agx_u32 X = base + j * 256u;
+        if (n[j] == 0xFFFFFFFFu) continue;
+        if (n[j] == 1u && !(fl[j] & AGX_NF_DEAD)) A.aid_of[s[j]] = X;                      // the position's only variant, alive: its main id
+        else if (n[j] <= 1u) {                                                           // no alive variant here
+            if (n[j]) A.aid_of[s[j]] = AGX_NONE;
+            A.a_meta[X] = (agx_u8)(AGX_WM_ABSENT | (n[j] ? AGX_WM_ANY : 0)); A.a_str[X] = 'N'; A.a_nid[X] = AGX_NONE;
+        } else agx_assign_aid_pos(A, X);
+    }
 }
 // (the first threads also rewrite the overflow edges)
 __global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap) {
     AGX_RETURN_IF_ABORTED(A.abort);
-    const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
-    const agx_u32 n = *n_ovf_dev; A.n_ovf = n < ovf_cap ? n : ovf_cap;
-    agx_emit_alive_ovf(A, i);
-    agx_emit_alive_pos(A, i);
+    const agx_u32 base = blockIdx.x * (256u * AGX_WP_POS) + threadIdx.x;
+    const agx_u32 n_ovf = *n_ovf_dev; A.n_ovf = n_ovf < ovf_cap ? n_ovf : ovf_cap;
+    agx_u32 s[AGX_WP_POS], n[AGX_WP_POS], a[AGX_WP_POS], fl[AGX_WP_POS], pk[AGX_WP_POS]; char rf[AGX_WP_POS], bs[AGX_WP_POS]; uint4 nx[AGX_WP_POS];
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
+        const agx_u32 X = base + j * 256u;
+        agx_emit_alive_ovf(A, X);
+        const bool in = X < A.n_pos;
+        s[j] = in ? A.node_start[X] : 0u; n[j] = in ? A.node_cnt[X] : 0u; pk[j] = in ? A.side_pk[X] : 0u; rf[j] = in ? A.ref[X] : 'N';
+    }
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
+        const bool one = n[j] == 1u;
+        a[j] = one ? A.aid_of[s[j]] : AGX_NONE; fl[j] = one ? A.n_flags[s[j]] : 0u; bs[j] = one ? (char)A.n_base[s[j]] : 'X';
+        nx[j] = one ? *reinterpret_cast<const uint4 *>(A.n_next + (size_t)s[j] * AGX_MAXE) : make_uint4(AGX_NONE, AGX_NONE, AGX_NONE, AGX_NONE);
+    }
+    agx_u32 ta[AGX_WP_POS][AGX_MAXE];
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
+        const agx_u32 t[AGX_MAXE] = {nx[j].x, nx[j].y, nx[j].z, nx[j].w};
+        bool open = a[j] != AGX_NONE;                     // (the slots are filled front to back: the first NONE ends the list)
+#pragma unroll
+        for (agx_u32 e = 0; e < AGX_MAXE; e++) { open = open && t[e] != AGX_NONE; ta[j][e] = open ? A.aid_of[t[e]] : AGX_NONE; }
+    }
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
+        const agx_u32 X = base + j * 256u;
+        if (n[j] > 1u) { agx_emit_alive_pos(A, X); continue; }
+        if (n[j] == 0u || a[j] == AGX_NONE) continue;
+        // agx_emit_alive_node() for the one variant of X, from what was loaded above
+        const agx_u32 v = s[j], id = a[j];
+        A.a_str[id] = bs[j] != 'X' ? bs[j] : rf[j];
+        A.a_nid[id] = v;
+        agx_u32 next[AGX_MAXE]; agx_u32 k = 0;
+#pragma unroll
+        for (agx_u32 e = 0; e < AGX_MAXE; e++) if (ta[j][e] != AGX_NONE) next[k++] = ta[j][e];
+        const bool cont = k == 1 && !(fl[j] & AGX_NF_EOVF) && next[0] == id + 1;
+        agx_u8 m = (agx_u8)((cont ? AGX_WM_CONT : 0) | ((fl[j] & AGX_NF_CONTIG) ? AGX_WM_CONTIG : 0));
+        if (id < A.n_pos) m |= (agx_u8)(AGX_WM_ANY | ((pk[j] >> 16) ? AGX_WM_SIDE : 0));
+        else A.side_xpos[id - A.n_pos] = X;
+        A.a_meta[id] = m;
+        if (!cont) for (agx_u32 e = 0; e < k; e++) A.a_mark[next[e]] = 1;      // racing stores of the same value
+    }
 }
 // one wave per 64 ids: the special-id bitmap word and its popcount (input of the rank scan); words past n_ids are written as zero
 __global__ void __launch_bounds__(256) agx_k_special_bits(agx_compact_args A, agx_u32 n_words) {
@@ -741,8 +803,8 @@ void agx_launch_fetch_records(const agx_compact_args *A, agx_u32 first, agx_u32 
 }
 void agx_launch_compact(const agx_compact_args *A, const agx_u32 *chain_end, agx_u32 n_chain_end, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t st) {
     const agx_u32 n1 = A->n_pos > n_chain_end ? A->n_pos : n_chain_end, n2 = A->n_pos > ovf_cap ? A->n_pos : ovf_cap;
-    if (n1) hipLaunchKernelGGL(agx_k_assign_aid, dim3((n1 + 255) / 256), dim3(256), 0, st, *A, chain_end, n_chain_end);
-    if (n2) hipLaunchKernelGGL(agx_k_emit_alive, dim3((n2 + 255) / 256), dim3(256), 0, st, *A, n_ovf_dev, ovf_cap);
+    if (n1) hipLaunchKernelGGL(agx_k_assign_aid, dim3((n1 + 256 * AGX_WP_POS - 1) / (256 * AGX_WP_POS)), dim3(256), 0, st, *A, chain_end, n_chain_end);
+    if (n2) hipLaunchKernelGGL(agx_k_emit_alive, dim3((n2 + 256 * AGX_WP_POS - 1) / (256 * AGX_WP_POS)), dim3(256), 0, st, *A, n_ovf_dev, ovf_cap);
 }
 // sparse record table over n_words 64-id words (the id capacity; the live id count is read on the device); scan_tmp as for the scans
 void agx_launch_special(const agx_compact_args *A, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, unsigned long long *desc,

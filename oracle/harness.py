@@ -26,11 +26,52 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import agx_data  # noqa: E402
 
 
+REF_SRC = "/root/reference/AlignGraph/AlignGraph.cpp"
+REF_PATCHED = os.path.join(HERE, "_ref", "AlignGraph_patched")
+# what replaces the five calls of the reference's unit loop (AG:4768-4776)
+INTEGRATION_PATCH = '''		agx_params p = { (uint32_t) k, (uint32_t) insertVariation, (uint32_t) coverage, 0 /* BATCH = 1000000 */, 0 /* device */, 0 };
+		agx_result r; char err[512];
+		int rc = agx_run_unit(&p, "tmp", chromosomeID, /*write_files=*/1, &r, err, sizeof err);
+		if(rc != AGX_OK) { string m = err; cout << m.substr(0, m.find(" (")) << endl; exit(-1); }
+		agx_result_free(&r);
+'''
+
+
+def patch_reference_source(src):
+    """The reference's source text with INTEGRATION.md §1 applied: include agx.h, the five calls replaced by agx_run_unit."""
+    first, last = "\t\tloadGenome(genome, chromosomeID);\n", '\t\tcout << "(5) Contigs scaffolded" << endl;\n'
+    a = src.rindex(first)
+    b = src.index(last, a)
+    assert src.count(first) == 1 or a > src.index("int main(")
+    return '#include "agx.h"\n' + src[:a] + INTEGRATION_PATCH + src[b:]
+
+
+def build_patched_reference(out=REF_PATCHED, workdir=None):
+    """Where the reference's source is present (the build container) and libagx.so is built: the reference WITH the INTEGRATION.md patch, linked against
+    libagx.so, as oracle/_ref/AlignGraph_patched — a git-ignored artefact like the reference binaries beside it (it rides to the GPU box with them; the
+    patched source text only ever exists in a scratch directory).  tests/test_gpu_patched_reference.py runs a unit through it on the GPU."""
+    import tempfile
+    lib = os.path.join(ROOT, "aligngraph_amd", "libagx.so")
+    if not os.path.exists(REF_SRC) or not os.path.exists(lib):
+        return None
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(REF_SRC), os.path.getmtime(os.path.join(ROOT, "include", "agx.h")), os.path.getmtime(__file__)):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with tempfile.TemporaryDirectory(dir=workdir) as d:
+        cpp = os.path.join(d, "AlignGraph_patched.cpp")
+        with open(cpp, "w", encoding="latin-1") as f:
+            f.write(patch_reference_source(open(REF_SRC, encoding="latin-1").read()))
+        subprocess.check_call(["g++", "-w", "-O2", "-o", out, cpp, "-I" + os.path.join(ROOT, "include"), "-L" + os.path.dirname(lib), "-lagx", "-lpthread",
+                               "-Wl,-rpath,$ORIGIN/../../aligngraph_amd"])
+    return out
+
+
 def build():
-    """Compile the oracle, the generator and (if /root/reference exists) oracle/_ref."""
+    """Compile the oracle, the generator and (if /root/reference exists) oracle/_ref — the reference as it is, and with the INTEGRATION.md patch."""
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     subprocess.check_call(["make", "-s", "-C", HERE, "all"])
     agx_data.build()
+    build_patched_reference()
 
 
 synth = agx_data.synth            # the generator lives in tools/ (it is not part of the checker); kept here for the tests' convenience
@@ -106,14 +147,14 @@ def have_reference(opt=True):
     return os.path.exists(REF_O2 if opt else REF_O0)
 
 
-def run_reference(run_dir, opt=True, keep=False):
+def run_reference(run_dir, opt=True, keep=False, exe=None, suffix=".ref"):
     """Copy run_dir to a scratch sibling, replay it with the real reference through --resume, and return
     (outputs, stage_seconds): outputs[u] = dict(initial=, pre=, extended=) for every unit; stage_seconds is the
     wall time between the reference's own "(0)"/"RESUMED" and last "(5) Contigs scaffolded" stdout markers."""
-    exe = REF_O2 if opt else REF_O0
+    exe = exe or (REF_O2 if opt else REF_O0)
     if not os.path.exists(exe):
         raise FileNotFoundError(exe)
-    work = run_dir.rstrip("/") + ".ref"
+    work = run_dir.rstrip("/") + suffix
     if os.path.exists(work):
         shutil.rmtree(work)
     shutil.copytree(run_dir, work)
