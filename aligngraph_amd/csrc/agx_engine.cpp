@@ -128,8 +128,9 @@ const HsaCopy &hsa_copy() { static const HsaCopy h; return h; }
 // positions from which a unit's host walk is split between two walkers (= walk_split's default in agx_walk.cpp; AGX_WALK_SPLIT_MIN, read at every download, overrides both: tests)
 inline size_t two_walkers_min() { const char *e = getenv("AGX_WALK_SPLIT_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4000000; }
 #define AGX_TWO_WALKERS_MIN two_walkers_min()
-// walkers for a unit of n_pos positions: one per 5 M positions from the threshold on, at most four — eight if asked for (walk_split decides the same way from what it is given)
-inline int walkers_wanted(size_t n_pos) { if (n_pos < AGX_TWO_WALKERS_MIN) return 1; const char *e = getenv("AGX_WALK_SPLIT_WALKERS"); int k = e ? atoi(e) : std::min(4, (int)(n_pos / 5000000u)); return k < 2 ? 2 : k > 1 + GraphView::MAX_COPIES ? 1 + GraphView::MAX_COPIES : k; }
+// walkers for a unit of n_pos positions: one per 2.5 M positions from the threshold on, two to eight (walk_split takes as many as it is given copies of the meta bytes
+// for: do_download decides that by what the other units' walks leave of the CPUs this process can keep busy)
+inline int walkers_wanted(size_t n_pos) { if (n_pos < AGX_TWO_WALKERS_MIN) return 1; const char *e = getenv("AGX_WALK_SPLIT_WALKERS"); int k = e ? atoi(e) : (int)(n_pos / 2500000u); return k < 2 ? 2 : k > 1 + GraphView::MAX_COPIES ? 1 + GraphView::MAX_COPIES : k; }
 
 // One helper thread per unit, started with the unit and asleep until it is handed work: what a unit can prepare while its upload and
 // build run (the pinned download buffers, the output buffers) without its worker waiting for it.  Not started on demand: creating a
@@ -191,6 +192,7 @@ struct WalkerPool {
         }
     }
     int take() { std::lock_guard<std::mutex> l(take_m); start(); for (int i = 0; i < N; i++) if (!slot[i].taken) { slot[i].taken = true; return i; } return -1; }
+    int busy() { std::lock_guard<std::mutex> l(take_m); int n = 0; for (int i = 0; i < N; i++) n += slot[i].taken && slot[i].th.joinable() ? 1 : 0; return started ? n : 0; }      // walkers of other units at work right now
     void give(int i) { std::lock_guard<std::mutex> l(take_m); slot[i].taken = false; }
     void run(int i, std::function<void()> f) { Slot &s = slot[i]; std::unique_lock<std::mutex> l(s.m); s.cv.wait(l, [&s] { return !s.queued && !s.running; }); s.job = std::move(f); s.queued = true; s.cv.notify_all(); }
     void wait(int i) { Slot &s = slot[i]; std::unique_lock<std::mutex> l(s.m); s.cv.wait(l, [&s] { return !s.queued && !s.running; }); }
@@ -217,6 +219,7 @@ struct agx_unit {
     PBuf<agx_whit> s_hits; PBuf<agx_wside> s_sides; PBuf<agx_wrun> s_runs; PBuf<agx_u8> s_codes; PBuf<unsigned long long> s_other; PBuf<agx_u32> s_jump; size_t n_other = 0, n_sides = 0, n_jump = 0;      // the read alignments in the wire formats of agx_core.h
     PBuf<agx_u8> s_ref; PBuf<agx_refx> s_refx; size_t n_refx = 0; bool ref_packed = false;      // the unit sequence: 2 bits per base + the stretches of other bytes (ref_packed), or the bytes as they are
     PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
+    PBuf<char> s_landing;               // one-shot units: what the download needs beyond the dead staged inputs it lands in, pinned when the unit is staged (not inside T_core)
     PBuf<agx_cntrun> s_cntruns; PBuf<agx_chunk> s_cntchunks, s_segchunks; size_t n_cntruns = 0, n_cntchunks = 0, n_segchunks = 0;      // what the device builds the conti-mer tables from (build_cm_layout)
     size_t nh = 0, n_runs = 0, n_cm = 0, n_codes = 0; agx_u32 maxlen = 0;      // n_codes: bytes of packed classes (four bases each); n_other: listed bases that are not A, C, G, T
     std::vector<agx_u32> row_slot;      // staged read bases: one row per (pair, a mate) that some hit uses; row -> read slot (general loader / agx_unit_push_pairs)
@@ -358,6 +361,18 @@ void stage_reference(agx_unit *u, const char *ref, size_t n_pos, unsigned thread
     const unsigned T = std::max(1u, std::min(threads, 8u));
     on_threads(T, [&](unsigned t) { const size_t lo = n_pos * t / T, hi = n_pos * (t + 1) / T; memcpy(u->s_ref.p + lo, ref + lo, hi - lo); });
 }
+// A one-shot unit's download lands in the pinned memory of its staged inputs, which are dead once they are in HBM (do_download).  Since r03 those are packed
+// (wire formats) and smaller than the walk graph of a unit with four walkers: what is missing is pinned here, by estimate (walk ids ~ 1.06 x positions, special
+// ids ~ 8 % of them), while the unit is staged — inside T_core mapping and registering it cost 1 ms per unit.
+void reserve_landing(agx_unit *u) {
+    if (!(u->prm.flags & AGX_FLAG_ONE_SHOT)) { u->s_landing.release(); return; }
+    const size_t n_pos = u->V.n_pos, ni = n_pos + n_pos / 16 + 4096, ns = ni / 10 + 4096;
+    const size_t copies = (size_t)walkers_wanted(n_pos) - 1 > 3 ? 3 : (size_t)walkers_wanted(n_pos) - 1;
+    const size_t need = (2 + copies) * (ni + 512) + ns * (sizeof(agx_walknode) + sizeof(agx_hop) + 64) + ni / 4 + (4u << 20);
+    const size_t have = u->s_codes.block_bytes() + u->s_hits.block_bytes() + u->s_runs.block_bytes() + u->s_sides.block_bytes() + u->s_other.block_bytes();
+    // (a buffer must fit one block: count the blocks at 85 %)
+    if (need > have * 85 / 100) u->s_landing.alloc(need - have * 85 / 100 + (ni + 512)); else u->s_landing.release();
+}
 void stage_inputs(agx_unit *u) {
     if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
     const double t0 = now_ms();
@@ -385,6 +400,7 @@ void stage_inputs(agx_unit *u) {
     UnitView V = view_of(u->T, u->P);
     if (u->pairs_staged) { V.bases = u->reads_keep ? u->reads_keep->fv.p : nullptr; V.stride = u->stride; V.row_off = u->row_off.data(); }
     u->V = V;
+    reserve_landing(u);
     u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0;
 }
@@ -540,6 +556,7 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     if (in_reads) { u->reads_map = std::move(reads_map); V.bases = u->reads_map->p; V.row_off = (const uint64_t *)(base + H.off[S_ROWS]); }
     else { V.bases = base + H.off[S_BASES]; u->row_slot.assign((const agx_u32 *)(base + H.off[S_ROWS]), (const agx_u32 *)(base + H.off[S_ROWS]) + H.n_rows); }
     u->V = V; u->pairs_staged = false;
+    reserve_landing(u);
     u->have_ref = u->have_threads = true; u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0; u->stats.ms_parse = 0; u->stats.ms_thread = 0; u->stats.from_cache = 1;
     return true;
@@ -697,7 +714,7 @@ void do_upload(agx_unit *u) {
             if (hipSetDevice(u->prm.device) != hipSuccess) return;
             const size_t ni = n_pos + n_pos / 8 + 4096, nw = ni / 64 + 1, ns = ni / 8 + 4096;
             u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(n_pos / 8 + 4097);
-            for (int w = 0; w < walkers_wanted(n_pos) - 1; w++) u->h_a_metas[w].alloc(ni + 64);
+            for (int w = 0; w < std::min(3, walkers_wanted(n_pos) - 1); w++) u->h_a_metas[w].alloc(ni + 64);
             u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2); u->h_a_ovf.alloc(64);
         } catch (...) { }                               // do_download allocates what is missing and reports
         trace(u, "helper: download buffers", th0, n_pos);
@@ -938,12 +955,24 @@ void do_download(agx_unit *u) {
     const size_t n_pos = u->V.n_pos, ni = u->n_ids;
     DeviceTurn &turn = turn_of(u->prm.device);
     const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
-    const int copies = u->helper.started ? walkers_wanted(n_pos) - 1 : 0;      // a large unit is walked by several walkers (agx_walk.cpp: walk_split): each further one gets its own copy of the meta bytes
+    // A large unit is walked by several walkers (agx_walk.cpp: walk_split); each further one gets its own copy of the meta bytes — 0.36 ms of download per copy of a
+    // 19 Mb unit, in front of the walk.  Up to four walkers always; beyond that only what the walks of the other units leave of the CPUs (the LAST unit of a job,
+    // whose walk nothing hides, finds them all idle: 11 -> 8 ms), and — one-shot units — only what fits the dead staged inputs beside the rest of the download.
+    int copies = u->helper.started ? walkers_wanted(n_pos) - 1 : 0;
+    if (copies > 3 && !getenv("AGX_WALK_SPLIT_WALKERS")) {
+        const int idle = (int)usable_cpus() - 2 - 2 * walker_pool().busy();      // (a walker and the thread that formats its records)
+        copies = std::max(3, std::min(copies, idle / 1 - 1));
+        if (u->prm.flags & AGX_FLAG_ONE_SHOT) {
+            const size_t room = u->s_codes.block_bytes() + u->s_hits.block_bytes() + u->s_runs.block_bytes() + u->s_sides.block_bytes() + u->s_landing.block_bytes();
+            const size_t base = 2 * (ni + 512) + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + nside * 4 + nw * 12 + (1u << 20);
+            while (copies > 3 && base + (size_t)copies * (ni + 512) > room * 9 / 10) copies--;
+        }
+    }
     join_dl_helper(u);
     if (u->prm.flags & AGX_FLAG_ONE_SHOT) {
         // The inputs are in HBM and will not be uploaded again: their staged copies are dead pinned memory.  The download's arrays are cut
         // from the largest of those blocks, largest array first; what does not fit (thin read sets) gets a buffer of its own below.
-        struct Room { char *at; size_t left; } room[5] = {{(char *)u->s_codes.p, u->s_codes.block_bytes()}, {(char *)u->s_hits.p, u->s_hits.block_bytes()},
+        struct Room { char *at; size_t left; } room[6] = {{(char *)u->s_codes.p, u->s_codes.block_bytes()}, {(char *)u->s_hits.p, u->s_hits.block_bytes()}, {(char *)u->s_landing.p, u->s_landing.block_bytes()},
                                                           {(char *)u->s_runs.p, u->s_runs.block_bytes()}, {(char *)u->s_sides.p, u->s_sides.block_bytes()}, {(char *)u->s_other.p, u->s_other.block_bytes()}};
         // (a loan from an earlier download of this unit object must not survive into alloc() below: the memory it names has been handed out again)
         u->h_sp_node.release(); u->h_a_meta.release(); u->h_a_str.release(); for (auto &b : u->h_a_metas) b.release(); u->h_sp_hop.release(); u->h_side_xpos.release(); u->h_sp_bits.release(); u->h_sp_rank.release(); u->h_a_ovf.release();
@@ -1289,7 +1318,7 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
                 else walker_pool().run(pool[who - 1], std::move(f));
             }
             void wait(int who) override { if (who == 0) u->helper.wait(UnitHelper::WALK); else walker_pool().wait(pool[who - 1]); }
-        } second(u, walkers_wanted(u->V.n_pos) - 2);
+        } second(u, [u] { int c = 0; while (c < GraphView::MAX_COPIES && u->h_a_metas[c].p) c++; return c - 1; }());      // one thread per copy of the meta bytes: the unit's helper + pool threads
         walk_join_scaffold(u->V, view_of(u), u->out, u->helper.started ? &second : nullptr);
         u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = u->out.n_fetched;
         trace(u, "walk", t0, u->V.n_pos);

@@ -573,11 +573,10 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     const agx_u32 warm = getenv("AGX_WALK_SPLIT_WARMUP") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_WARMUP"), nullptr, 10) : 400000u;
     const agx_u32 n_ref = V.n_ref < G.n_pos ? V.n_ref : G.n_pos;
     if (!assistant || !G.meta_copy[0] || n_ref < min_ref || n_ref < 16 || getenv("AGX_WALK_NO_SPLIT")) return false;
-    // walkers: one per 5 M positions (at least two), as many as there are copies of the meta bytes and helper threads, at most four unless asked for
-    // (AGX_WALK_SPLIT_WALKERS: up to eight).  r02: one per 15.5 M — a 19 Mb unit, the LAST of a cfg3 job, was walked by two in 13 ms while the cores of the
-    // finished units idled: 52 -> 49 ms per job with four.  More than four buy little: every further walker needs its own copy of the meta bytes
-    // (0.36 ms of download for a 19 Mb unit, in front of the walk) and saves less than that of the walk.
-    int K = getenv("AGX_WALK_SPLIT_WALKERS") ? atoi(getenv("AGX_WALK_SPLIT_WALKERS")) : std::min(4, (int)(n_ref / 5000000u));
+    // walkers: one per 2.5 M positions (at least two, at most eight), as many as there are copies of the meta bytes and helper threads — the engine makes three
+    // copies for a large unit and more only while the CPUs are not busy with other units' walks (do_download).  r02: one per 15.5 M, at most four — a 19 Mb
+    // unit, the LAST of a cfg3 job, was walked by two in 13 ms while the cores of the finished units idled.
+    int K = getenv("AGX_WALK_SPLIT_WALKERS") ? atoi(getenv("AGX_WALK_SPLIT_WALKERS")) : (int)(n_ref / 2500000u);      // (the caller decides how many copies of the meta bytes there are: that caps it below)
     if (K < 2) K = 2;
     if (K > 1 + GraphView::MAX_COPIES) K = 1 + GraphView::MAX_COPIES;
     { int copies = 0; while (copies < GraphView::MAX_COPIES && G.meta_copy[copies]) copies++; if (K > 1 + copies) K = 1 + copies; if (K > 1 + assistant->helpers()) K = 1 + assistant->helpers(); }
