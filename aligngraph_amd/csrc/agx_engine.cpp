@@ -128,9 +128,8 @@ const HsaCopy &hsa_copy() { static const HsaCopy h; return h; }
 // positions from which a unit's host walk is split between two walkers (= walk_split's default in agx_walk.cpp; AGX_WALK_SPLIT_MIN, read at every download, overrides both: tests)
 inline size_t two_walkers_min() { const char *e = getenv("AGX_WALK_SPLIT_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4000000; }
 #define AGX_TWO_WALKERS_MIN two_walkers_min()
-// walkers for a unit of n_pos positions: one per 2.5 M positions from the threshold on, two to eight (walk_split takes as many as it is given copies of the meta bytes
-// for: do_download decides that by what the other units' walks leave of the CPUs this process can keep busy)
-inline int walkers_wanted(size_t n_pos) { if (n_pos < AGX_TWO_WALKERS_MIN) return 1; const char *e = getenv("AGX_WALK_SPLIT_WALKERS"); int k = e ? atoi(e) : (int)(n_pos / 2500000u); return k < 2 ? 2 : k > 1 + GraphView::MAX_COPIES ? 1 + GraphView::MAX_COPIES : k; }
+// walkers for a unit of n_pos positions: one per 5 M positions from the threshold on, two to four — up to eight if asked for (walk_split takes as many as it is given copies of the meta bytes for)
+inline int walkers_wanted(size_t n_pos) { if (n_pos < AGX_TWO_WALKERS_MIN) return 1; const char *e = getenv("AGX_WALK_SPLIT_WALKERS"); int k = e ? atoi(e) : std::min(4, (int)(n_pos / 5000000u)); return k < 2 ? 2 : k > 1 + GraphView::MAX_COPIES ? 1 + GraphView::MAX_COPIES : k; }
 
 // One helper thread per unit, started with the unit and asleep until it is handed work: what a unit can prepare while its upload and
 // build run (the pinned download buffers, the output buffers) without its worker waiting for it.  Not started on demand: creating a
@@ -955,19 +954,10 @@ void do_download(agx_unit *u) {
     const size_t n_pos = u->V.n_pos, ni = u->n_ids;
     DeviceTurn &turn = turn_of(u->prm.device);
     const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
-    // A large unit is walked by several walkers (agx_walk.cpp: walk_split); each further one gets its own copy of the meta bytes — 0.36 ms of download per copy of a
-    // 19 Mb unit, in front of the walk.  Up to four walkers always; beyond that only what the walks of the other units leave of the CPUs (the LAST unit of a job,
-    // whose walk nothing hides, finds them all idle: 11 -> 8 ms), and — one-shot units — only what fits the dead staged inputs beside the rest of the download.
-    int copies = u->helper.started ? walkers_wanted(n_pos) - 1 : 0;
-    if (copies > 3 && !getenv("AGX_WALK_SPLIT_WALKERS")) {
-        const int idle = (int)usable_cpus() - 2 - 2 * walker_pool().busy();      // (a walker and the thread that formats its records)
-        copies = std::max(3, std::min(copies, idle / 1 - 1));
-        if (u->prm.flags & AGX_FLAG_ONE_SHOT) {
-            const size_t room = u->s_codes.block_bytes() + u->s_hits.block_bytes() + u->s_runs.block_bytes() + u->s_sides.block_bytes() + u->s_landing.block_bytes();
-            const size_t base = 2 * (ni + 512) + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + nside * 4 + nw * 12 + (1u << 20);
-            while (copies > 3 && base + (size_t)copies * (ni + 512) > room * 9 / 10) copies--;
-        }
-    }
+    // A large unit is walked by several walkers (agx_walk.cpp: walk_split); each further one gets its own copy of the meta bytes: 0.36-0.6 ms of download per
+    // copy, in front of the walk.  Four walkers at most unless asked for: with up to eight (tried in r03, for units whose walk finds the CPUs idle) the
+    // downloads of a cfg3 job went from 2.8-5.5 to 6.7-9 ms and the job from 42.3 to 45.4 ms, for walks 1 ms shorter.
+    const int copies = u->helper.started ? walkers_wanted(n_pos) - 1 : 0;
     join_dl_helper(u);
     if (u->prm.flags & AGX_FLAG_ONE_SHOT) {
         // The inputs are in HBM and will not be uploaded again: their staged copies are dead pinned memory.  The download's arrays are cut

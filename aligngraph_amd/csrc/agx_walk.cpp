@@ -573,10 +573,10 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     const agx_u32 warm = getenv("AGX_WALK_SPLIT_WARMUP") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_WARMUP"), nullptr, 10) : 400000u;
     const agx_u32 n_ref = V.n_ref < G.n_pos ? V.n_ref : G.n_pos;
     if (!assistant || !G.meta_copy[0] || n_ref < min_ref || n_ref < 16 || getenv("AGX_WALK_NO_SPLIT")) return false;
-    // walkers: one per 2.5 M positions (at least two, at most eight), as many as there are copies of the meta bytes and helper threads — the engine makes three
-    // copies for a large unit and more only while the CPUs are not busy with other units' walks (do_download).  r02: one per 15.5 M, at most four — a 19 Mb
-    // unit, the LAST of a cfg3 job, was walked by two in 13 ms while the cores of the finished units idled.
-    int K = getenv("AGX_WALK_SPLIT_WALKERS") ? atoi(getenv("AGX_WALK_SPLIT_WALKERS")) : (int)(n_ref / 2500000u);      // (the caller decides how many copies of the meta bytes there are: that caps it below)
+    // walkers: one per 5 M positions (two to four; up to eight if asked for), as many as there are copies of the meta bytes and helper threads.  r02: one per
+    // 15.5 M — a 19 Mb unit, the LAST of a cfg3 job, was walked by two in 13 ms while the cores of the finished units idled.  More than four do not pay: every
+    // walker needs its own copy of the meta bytes, and the copies cost the download more than they save the walk (agx_engine.cpp: do_download).
+    int K = getenv("AGX_WALK_SPLIT_WALKERS") ? atoi(getenv("AGX_WALK_SPLIT_WALKERS")) : std::min(4, (int)(n_ref / 5000000u));
     if (K < 2) K = 2;
     if (K > 1 + GraphView::MAX_COPIES) K = 1 + GraphView::MAX_COPIES;
     { int copies = 0; while (copies < GraphView::MAX_COPIES && G.meta_copy[copies]) copies++; if (K > 1 + copies) K = 1 + copies; if (K > 1 + assistant->helpers()) K = 1 + assistant->helpers(); }
