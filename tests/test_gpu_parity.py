@@ -89,6 +89,29 @@ def test_sparse_record_table_and_device_fetch(agx, built, tmp_path):
     assert gs["download_bytes"] < 8 * gs["n_walk_ids"]                 # was 40 bytes per id with the dense record table
 
 
+@pytest.mark.parametrize("general_loader", [False, True])
+def test_hop_entries_outside_the_sparse_table_come_from_the_runs(agx, built, tmp_path, monkeypatch, general_loader):
+    """a unit without a per-position hop table (every unit since r03: the fast loader keeps none, nor does the cache file) must still find the hop
+    entry of a main id that is not in the sparse table — AGX_FLAG_SPARSE_MIN puts every main id there, long contigs make the walk hop on and off them.  The
+    walk takes it from the conti-mer runs by bisection (Walker::hop_of), as the device does for the special ids.  From the text (both loaders) and from the cache file."""
+    if general_loader:
+        monkeypatch.setenv("AGX_NO_FAST_LOAD", "1")
+    run = H.synth(str(tmp_path / "run"), seed=106, chroms="300000", pairs=50000, coverage=5, contig_min=60000, contig_max=150000, contig_overlap=0.3, sam_seq=0)
+    tmp = os.path.join(run, "tmp")
+    want = H.run_oracle(tmp, 0, 5, 50, 5)
+    for cached in (False, True):
+        if cached:
+            agx.cache_build(tmp, 0)
+        with agx.Unit(k=5, insert_variation=50, coverage=5, flags=agx.AGX_FLAG_SPARSE_MIN) as u:
+            u.load_files(tmp, 0)
+            assert u.stats()["from_cache"] == (1 if cached else 0)
+            u.upload(); u.build()
+            got = u.finish()
+            assert u.stats()["n_fetched"] > 100
+        for key in ("initial", "pre", "extended"):
+            assert got[key] == want[key], (key, cached)
+
+
 def test_every_capacity_regrows_from_the_device_counters(agx, built, tmp_path, monkeypatch):
     # A build queues all its kernels against first-guess capacities (tile lists, node pool, edge overflow list, sparse record table) and
     # only then reads the counters; AGX_TEST_SMALL_CAPS starts every one of them far too small, so the build has to be repeated once per
