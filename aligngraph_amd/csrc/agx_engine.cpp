@@ -367,7 +367,7 @@ void reserve_landing(agx_unit *u) {
     if (!(u->prm.flags & AGX_FLAG_ONE_SHOT)) { u->s_landing.release(); return; }
     const size_t n_pos = u->V.n_pos, ni = n_pos + n_pos / 16 + 4096, ns = ni / 10 + 4096;
     const size_t copies = (size_t)walkers_wanted(n_pos) - 1 > 3 ? 3 : (size_t)walkers_wanted(n_pos) - 1;
-    const size_t need = (2 + copies) * (ni + 512) + ns * (sizeof(agx_walknode) + sizeof(agx_hop) + 64) + ni / 4 + (4u << 20);
+    const size_t need = (2 + copies) * (ni + 512) + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + ni / 4 + (4u << 20);
     const size_t have = u->s_codes.block_bytes() + u->s_hits.block_bytes() + u->s_runs.block_bytes() + u->s_sides.block_bytes() + u->s_other.block_bytes();
     // (a buffer must fit one block: count the blocks at 85 %)
     if (need > have * 85 / 100) u->s_landing.alloc(need - have * 85 / 100 + (ni + 512)); else u->s_landing.release();
