@@ -236,7 +236,7 @@ struct agx_unit {
     // node table
     agx_u32 pool_cap = 0, spill_lo = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
     DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
-    DBuf<agx_u32> d_node_start, d_slow_list, d_rank4, d_span; DBuf<agx_u8> d_node_cnt, d_pos_succ;
+    DBuf<agx_u32> d_node_start, d_slow_list, d_rank4; DBuf<agx_u8> d_node_cnt, d_pos_succ;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch, d_huge_list, d_scratch_huge; bool huge = false;      // huge: pass 3 of the node sweep is queued (a build met a position beyond AGX_MAXV_BIG variants)
     // walk graph (agx_core.h "walk preparation")
@@ -523,27 +523,22 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     if (fine) {
         const unsigned long long n_bases = H.n_rows * (unsigned long long)H.stride;
         for (size_t i = 0; i < u->n_other && fine; i++) fine = u->s_other.p[i] < n_bases;
-        std::vector<int> bad2(threads, 0); std::vector<size_t> jumps(threads, 0);
+        std::vector<int> bad2(threads, 0);
         on_threads(threads, [&](unsigned t) {
-            size_t nj = 0;
             for (size_t i = u->nh * t / threads, hi = u->nh * (t + 1) / threads; i < hi; i++) {
                 const agx_whit &w = u->s_hits.p[i];
-                if (w.row >= H.n_rows || w.len == 0 || w.len > H.maxlen || w.back > i) { bad2[t] = 1; return; }
-                if (!(w.flags & (AGX_WF_RUNS1 | AGX_WF_RUNS2))) continue;                 // five hits in eight: nothing else to look at
-                if (((w.flags & AGX_WF_RUNS1) ? w.a : w.b) >= H.n_sides) { bad2[t] = 1; return; }
+                if ((w.flags & (AGX_WF_RUNS1 | AGX_WF_RUNS2)) && ((w.flags & AGX_WF_RUNS1) ? w.a : w.b) >= H.n_sides) { bad2[t] = 1; return; }
                 const agx_hit h = agx_unpack_hit(w, u->s_sides.p);
-                if ((h.nruns1 && (unsigned long long)h.runs1 + h.nruns1 > H.n_runs) || (h.nruns2 && (unsigned long long)h.runs2 + h.nruns2 > H.n_runs)) { bad2[t] = 1; return; }
-                nj += ((h.pad[0] & 1u) ? h.nruns2 : h.nruns1) >= 2;
+                if (h.slot1 >= H.n_rows || h.len == 0 || h.len > H.maxlen || (h.nruns1 && (unsigned long long)h.runs1 + h.nruns1 > H.n_runs) || (h.nruns2 && (unsigned long long)h.runs2 + h.nruns2 > H.n_runs) || h.back > i) { bad2[t] = 1; return; }
             }
-            jumps[t] = nj;
         });
         for (int b : bad2) fine = fine && !b;
-        { size_t want = 0; for (size_t v : jumps) want += v; fine = fine && want == u->n_jump; }      // pass J's list names exactly the hits whose left mate has several runs: as many, ...
-        for (size_t i = 0; i < u->n_jump && fine; i++) {      // ... ascending, each one of them
+        for (size_t i = 0; i < u->n_jump && fine; i++) {      // exactly the hits whose left mate has several runs, ascending (pass J looks at no other hit)
             const agx_u32 h = u->s_jump.p[i];
             fine = h < u->nh && (i == 0 || u->s_jump.p[i - 1] < h);
-            if (fine) { const agx_whit &w = u->s_hits.p[h]; fine = (w.flags & ((w.flags & AGX_WF_LEFT2) ? AGX_WF_RUNS2 : AGX_WF_RUNS1)) != 0; if (fine) { const agx_hit x = agx_unpack_hit(w, u->s_sides.p); fine = ((x.pad[0] & 1u) ? x.nruns2 : x.nruns1) >= 2; } }
+            if (fine) { const agx_hit x = agx_unpack_hit(u->s_hits.p[h], u->s_sides.p); fine = ((x.pad[0] & 1u) ? x.nruns2 : x.nruns1) >= 2; }
         }
+        if (fine) { size_t want = 0; for (size_t i = 0; i < u->nh; i++) { const agx_whit &w = u->s_hits.p[i]; if (w.flags & ((w.flags & AGX_WF_LEFT2) ? AGX_WF_RUNS2 : AGX_WF_RUNS1)) { const agx_hit x = agx_unpack_hit(w, u->s_sides.p); want += ((x.pad[0] & 1u) ? x.nruns2 : x.nruns1) >= 2; } } fine = want == u->n_jump; }
         unsigned long long el = 0;
         for (size_t i = 0; i < u->n_segs && fine; i++) { const agx_cmseg &g = u->s_segs.p[i]; fine = (unsigned long long)g.pos0 + g.len <= H.n_pos && g.hop_end < H.n_pos && (unsigned long long)g.hop_str0 + g.hop_len0 <= H.len[S_CHAIN_STR] + 1 && g.elem0 == el; el += g.len; }
         fine = fine && el == H.n_cm;
@@ -633,7 +628,7 @@ Plan plan_capacities(const agx_unit *u) {
     const size_t ids_cap = n_pos + P.pool_cap;
     P.sp_cap = u->sp_cap ? u->sp_cap : (agx_u32)std::min<size_t>(g_tiny ? 32 : ids_cap / 4 + 4096, 0xFFFFFF00ull);      // special ids: 8 % on the bench unit
     // what the takes of do_upload add up to, plus the alignment of ~90 buffers
-    const size_t per_pos = 4 + 16 + 1 + 4 + 1 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_hit) + sizeof(agx_dhit) + 16 + 8 + 4;
+    const size_t per_pos = 4 + 16 + 1 + 4 + 1 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_hit) + sizeof(agx_dhit) + 16 + 4;
     const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
     const size_t wire = nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 + (u->ref_packed ? n_pos / 4 + u->n_refx * sizeof(agx_refx) : 0) + 4096;
     const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases + u->n_other * 8 +
@@ -667,7 +662,7 @@ void do_upload(agx_unit *u) {
     u->d_hits.alloc(a, nh + 1); u->d_runs.alloc(a, u->n_runs + 1); u->d_codes.alloc(a, u->n_codes + 16); u->d_vcodes.alloc(a, n_bases + 16); u->d_other.alloc(a, u->n_other + 1);
     u->d_whits.alloc(a, nh + 1); u->d_wsides.alloc(a, u->n_sides + 1); u->d_wruns.alloc(a, u->n_runs + 1); u->d_jump.alloc(a, u->n_jump + 1);
     if (u->ref_packed) { u->d_wref.alloc(a, (n_pos + 3) / 4 + 32); u->d_refx.alloc(a, u->n_refx + 1); }
-    u->d_dhit.alloc(a, nh + 2); u->d_rank4.alloc(a, 4 * (nh + 1)); u->d_span.alloc(a, 2 * (nh + 1));
+    u->d_dhit.alloc(a, nh + 1); u->d_rank4.alloc(a, 4 * (nh + 1));
     u->d_tile_cnt.alloc(a, (size_t)u->n_tiles + 1); u->d_tile_off.alloc(a, (size_t)u->n_tiles + 2); u->d_cursor.alloc(a, (size_t)u->n_tiles + 1);
     u->d_words.alloc(a, W_N + 6 + 16); u->h_words.alloc(W_N + 6 + 16);
     u->d_chain_end.alloc(a, (size_t)u->n_chain_end + 1);
@@ -804,14 +799,14 @@ void do_build(agx_unit *u) {
         }
         // ---- hit_prep + tile histogram ----
         u->ev.begin(); u->ev.mark(B_START, st);
-        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF, (uint2 *)u->d_span.p};
+        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
         agx_launch_hit_prep(&PA, st);
         AGX_CHECKPOINT("hit_prep");
         u->ev.mark(B_PREP, st);
         // ---- tile lists ----
         if (g_scan1) agx_launch_exclusive_scan1(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_desc.p, st);
         else agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
-        agx_bin_args BA{(const uint2 *)u->d_span.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, (const uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
+        agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, (const uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
         agx_launch_bin_fill(&BA, st);
         agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, u->d_runs.p, u->prm.k, st);
         AGX_CHECKPOINT("tile_sort");
@@ -1029,7 +1024,7 @@ void do_release(agx_unit *u) {
     join_dl_helper(u);                                 // (it fills the download buffers released below)
     if (u->uploaded) { (void)hipSetDevice(u->prm.device); (void)hipEventSynchronize(u->ev_uploaded); (void)hipEventSynchronize(u->ev_built); (void)hipEventSynchronize(u->ev_dl); }      // (its commands are done before its memory goes)
     for (auto *b : {&u->d_cm_start, &u->d_tile_cnt, &u->d_tile_off, &u->d_cursor, &u->d_unsorted, &u->d_tile_recs, &u->d_scan_tmp, &u->d_words, &u->d_pool_cnt, &u->d_region_off, &u->d_node_start,
-                    &u->d_slow_list, &u->d_rank4, &u->d_span, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
+                    &u->d_slow_list, &u->d_rank4, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     for (auto *b : {&u->d_node_cnt, &u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
     u->d_other.release(); u->d_whits.release(); u->d_wsides.release(); u->d_wruns.release(); u->d_wref.release(); u->d_refx.release();

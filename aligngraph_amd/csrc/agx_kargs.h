@@ -10,10 +10,9 @@ struct agx_prep_args {
     agx_u32 *err;             // bit 0: same-strand mates; bit 1: alignment beyond the unit sequence
     uint4 *rank4;             // [n_hits] what the histogram's atomicAdd returned for the hit's first four tiles = its slot in each tile's list
     agx_u32 *rank_overflow;   // set when some hit spans more than four tiles: the lists are then filled with a second round of atomics
-    uint2 *span;              // [n_hits] (x_lo, x_hi) of the derived record, side by side: all bin_fill needs of it
 };
 
-struct agx_bin_args { const uint2 *span; agx_u32 n_hits; const agx_u32 *tile_off; agx_u32 *cursor; agx_u32 *unsorted; agx_u32 cap;   // cap: entries the lists can hold
+struct agx_bin_args { const agx_dhit *dhit; agx_u32 n_hits; const agx_u32 *tile_off; agx_u32 *cursor; agx_u32 *unsorted; agx_u32 cap;   // cap: entries the lists can hold
                       const uint4 *rank4; const agx_u32 *rank_overflow; };
 
 struct agx_node_kargs {

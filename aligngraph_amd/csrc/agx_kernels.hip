@@ -181,25 +181,9 @@ __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
         for (agx_u32 t = t0 + 4; t <= t1; t++) atomicAdd(&A.tile_cnt[t], 1u);
         atomicOr(A.rank_overflow, 1u);
     }
-    if (mine) { A.rank4[h] = make_uint4(r[0], r[1], r[2], r[3]); A.span[h] = kept ? make_uint2(d.x_lo, d.x_hi) : make_uint2(1u, 0u); }      // span: what bin_fill needs of the record (a skipped hit: the empty range 1..0)
-    // The derived record is 40 bytes: stored field by field a wavefront issues ten scattered 4-byte stores over its 2560 contiguous bytes, and the counters
-    // saw 2.7 x the bytes go to HBM (partly written lines).  Through LDS it leaves as 160 16-byte pieces, lanes side by side.
-    __shared__ agx_u32 stage[4][64 * 10];
-    static_assert(sizeof(agx_dhit) == 40, "agx_k_hit_prep stages the derived record as ten words");
-    const agx_u32 wave = threadIdx.x >> 6;
-    { const agx_u32 *w = reinterpret_cast<const agx_u32 *>(&d);
-#pragma unroll
-      for (int j = 0; j < 10; j++) stage[wave][lane * 10u + j] = w[j]; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (one wavefront reads what it wrote itself)
-    const agx_u32 h0 = blockIdx.x * 256u + wave * 64u;           // the wavefront's first hit
-    if (h0 >= A.n_hits) return;
-    const agx_u32 n_here = A.n_hits - h0 < 64u ? A.n_hits - h0 : 64u, pieces = (n_here * 10u + 3u) / 4u;      // (the array has a spare record: the last piece may run into it)
-    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<agx_u32 *>(A.dhit) + (size_t)h0 * 10u);
-#pragma unroll
-    for (agx_u32 i = 0; i < 3; i++) {
-        const agx_u32 c = lane + 64u * i;
-        if (c < pieces) dst[c] = make_uint4(stage[wave][4 * c], stage[wave][4 * c + 1], stage[wave][4 * c + 2], stage[wave][4 * c + 3]);
-    }
+    if (!mine) return;
+    A.rank4[h] = make_uint4(r[0], r[1], r[2], r[3]);
+    A.dhit[h] = d;
 }
 
 // ---- exclusive scan of a u32 array (three small kernels up to 16 M elements: blocks, block sums, add) --------------------
@@ -287,13 +271,13 @@ __global__ void __launch_bounds__(256) agx_k_scan_lookback(const agx_u32 *in, ag
 __global__ void __launch_bounds__(256) agx_k_bin_fill(agx_bin_args A) {
     const agx_u32 h = blockIdx.x * 256u + threadIdx.x;
     if (h >= A.n_hits) return;
-    const uint2 sp = A.span[h];                              // first and last position with an arrival (hit_prep; a skipped hit: 1..0)
-    if (sp.x > sp.y) return;
+    const agx_dhit d = A.dhit[h];
+    if (d.flags & AGX_HF_SKIP) return;
     if (__builtin_amdgcn_readfirstlane((int)*A.rank_overflow) == 0) {
         const uint4 r4 = A.rank4[h]; const agx_u32 r[4] = {r4.x, r4.y, r4.z, r4.w}; agx_u32 i = 0;
-        for (agx_u32 t = sp.x / AGX_TILE; t <= sp.y / AGX_TILE; t++, i++) { const agx_u32 at = A.tile_off[t] + r[i & 3u]; if (at < A.cap) A.unsorted[at] = h; }
+        for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++, i++) { const agx_u32 at = A.tile_off[t] + r[i & 3u]; if (at < A.cap) A.unsorted[at] = h; }
     } else      // some hit spans more than four tiles (reads beyond ~190 bases, long deletions): every hit takes its slots from a second counter
-        for (agx_u32 t = sp.x / AGX_TILE; t <= sp.y / AGX_TILE; t++) { const agx_u32 at = A.tile_off[t] + atomicAdd(&A.cursor[t], 1u); if (at < A.cap) A.unsorted[at] = h; }
+        for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++) { const agx_u32 at = A.tile_off[t] + atomicAdd(&A.cursor[t], 1u); if (at < A.cap) A.unsorted[at] = h; }
 }
 
 // one wavefront per tile; a hit's place in the file is unique, so an element's rank is the number of smaller keys
