@@ -523,22 +523,27 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     if (fine) {
         const unsigned long long n_bases = H.n_rows * (unsigned long long)H.stride;
         for (size_t i = 0; i < u->n_other && fine; i++) fine = u->s_other.p[i] < n_bases;
-        std::vector<int> bad2(threads, 0);
+        std::vector<int> bad2(threads, 0); std::vector<size_t> jumps(threads, 0);
         on_threads(threads, [&](unsigned t) {
+            size_t nj = 0;
             for (size_t i = u->nh * t / threads, hi = u->nh * (t + 1) / threads; i < hi; i++) {
                 const agx_whit &w = u->s_hits.p[i];
-                if ((w.flags & (AGX_WF_RUNS1 | AGX_WF_RUNS2)) && ((w.flags & AGX_WF_RUNS1) ? w.a : w.b) >= H.n_sides) { bad2[t] = 1; return; }
+                if (w.row >= H.n_rows || w.len == 0 || w.len > H.maxlen || w.back > i) { bad2[t] = 1; return; }
+                if (!(w.flags & (AGX_WF_RUNS1 | AGX_WF_RUNS2))) continue;                 // five hits in eight: nothing else to look at
+                if (((w.flags & AGX_WF_RUNS1) ? w.a : w.b) >= H.n_sides) { bad2[t] = 1; return; }
                 const agx_hit h = agx_unpack_hit(w, u->s_sides.p);
-                if (h.slot1 >= H.n_rows || h.len == 0 || h.len > H.maxlen || (h.nruns1 && (unsigned long long)h.runs1 + h.nruns1 > H.n_runs) || (h.nruns2 && (unsigned long long)h.runs2 + h.nruns2 > H.n_runs) || h.back > i) { bad2[t] = 1; return; }
+                if ((h.nruns1 && (unsigned long long)h.runs1 + h.nruns1 > H.n_runs) || (h.nruns2 && (unsigned long long)h.runs2 + h.nruns2 > H.n_runs)) { bad2[t] = 1; return; }
+                nj += ((h.pad[0] & 1u) ? h.nruns2 : h.nruns1) >= 2;
             }
+            jumps[t] = nj;
         });
         for (int b : bad2) fine = fine && !b;
-        for (size_t i = 0; i < u->n_jump && fine; i++) {      // exactly the hits whose left mate has several runs, ascending (pass J looks at no other hit)
+        { size_t want = 0; for (size_t v : jumps) want += v; fine = fine && want == u->n_jump; }      // pass J's list names exactly the hits whose left mate has several runs: as many, ...
+        for (size_t i = 0; i < u->n_jump && fine; i++) {      // ... ascending, each one of them
             const agx_u32 h = u->s_jump.p[i];
             fine = h < u->nh && (i == 0 || u->s_jump.p[i - 1] < h);
-            if (fine) { const agx_hit x = agx_unpack_hit(u->s_hits.p[h], u->s_sides.p); fine = ((x.pad[0] & 1u) ? x.nruns2 : x.nruns1) >= 2; }
+            if (fine) { const agx_whit &w = u->s_hits.p[h]; fine = (w.flags & ((w.flags & AGX_WF_LEFT2) ? AGX_WF_RUNS2 : AGX_WF_RUNS1)) != 0; if (fine) { const agx_hit x = agx_unpack_hit(w, u->s_sides.p); fine = ((x.pad[0] & 1u) ? x.nruns2 : x.nruns1) >= 2; } }
         }
-        if (fine) { size_t want = 0; for (size_t i = 0; i < u->nh; i++) { const agx_whit &w = u->s_hits.p[i]; if (w.flags & ((w.flags & AGX_WF_LEFT2) ? AGX_WF_RUNS2 : AGX_WF_RUNS1)) { const agx_hit x = agx_unpack_hit(w, u->s_sides.p); want += ((x.pad[0] & 1u) ? x.nruns2 : x.nruns1) >= 2; } } fine = want == u->n_jump; }
         unsigned long long el = 0;
         for (size_t i = 0; i < u->n_segs && fine; i++) { const agx_cmseg &g = u->s_segs.p[i]; fine = (unsigned long long)g.pos0 + g.len <= H.n_pos && g.hop_end < H.n_pos && (unsigned long long)g.hop_str0 + g.hop_len0 <= H.len[S_CHAIN_STR] + 1 && g.elem0 == el; el += g.len; }
         fine = fine && el == H.n_cm;
@@ -547,8 +552,11 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
         if (fine && !in_reads) { const agx_u32 *rs = (const agx_u32 *)(base + H.off[S_ROWS]); for (size_t r = 0; r < H.n_rows && fine; r++) fine = rs[r] < H.n_slots; }
     }
     if (!fine) { u->cache_map.reset(); return false; }
+    const double tv = now_ms();
     stage_reference(u, base + H.off[S_REF], H.n_pos, threads);
+    const double tr = now_ms();
     stage_cm_layout(u, (const agx_u8 *)(base + H.off[S_CM_CNT]), H.n_pos, u->s_segs.p, u->n_segs);
+    if (getenv("AGX_LOAD_TIMING")) fprintf(stderr, "[agx load] cache: buffers + read + checks %.1f ms, reference %.1f ms, conti-mer layout %.1f ms\n", tv - t0, tr - tv, now_ms() - tr);
     UnitView V; V.ref = base + H.off[S_REF]; V.n_pos = H.n_pos; V.n_ref = (agx_u32)H.n_ref; V.cm_cnt = (const agx_u8 *)(base + H.off[S_CM_CNT]); V.chain_str = base + H.off[S_CHAIN_STR];
     V.hop = nullptr; V.segs = (const agx_cmseg *)(base + H.off[S_SEGS]); V.n_seg0 = (agx_u32)H.n_seg0; V.stride = in_reads ? H.stride : H.slot_stride; V.initial = base + H.off[S_INITIAL]; V.n_initial = H.len[S_INITIAL];
     u->row_off.clear(); u->row_slot.clear();
