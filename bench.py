@@ -13,19 +13,23 @@ step: --pool host-cold, the default; --pool cold also gives the HBM blocks back 
 
     value = 2 * pairs of the configuration / seconds per step            (whole job, all GPUs)
 
-Text parsing of the five per-unit files (T_unit = parse + T_core) is measured once while the inputs are loaded (up to four units side by
-side, as AlignGraph_amd parses them) and reported beside it, and so is loading the units from their binary caches.
+Text parsing of the five per-unit files (T_unit = parse + T_core: the scope of the reference's stages (1)-(5), the like-for-like comparison) is measured
+once while the inputs are loaded (a rank's units side by side, each on its share of the CPUs the process can keep busy) and reported beside it
+(`t_unit_s`, `value_t_unit`, `load_ms_per_unit`), and so is loading the units from their binary caches.  `roofline` carries `frac` (bytes the dominant
+kernel cannot avoid / its time / HBM peak), `frac_hbm` (counter traffic), `job_frac` (SURVEY 8(d)'s algorithmic bytes / T_core / peak), `frac_8d_model`
+(r01/r02's quantity, which passes 1) and a `pcie` block; `cpu_baseline` the reference binary on one CPU and, under `parallel`, one process per usable CPU.
 
 Configurations (--config; BASELINE.json `configs`, synthetic data of that shape from tools/agx_synth, seeded):
     cfg3 (default)  A. thaliana shape: 5 units of 30.4 / 19.7 / 23.5 / 18.6 / 27.0 Mb, 20 M 2x100 bp pairs, k=5      <- the north-star 1-GPU target
     cfg2            E. coli shape: one 4.6 Mb unit, 1 M pairs
     cfg4            human chr1 shape: 249 Mb --part 4 (4 units of 62 Mb), 60 M pairs (needs ~40 GB of scratch disk)
-    cfg5s           whole-human shape SCALED 1/16: 24 units of 15.6 .. 3.6 Mb, 25 M 2x150 bp pairs (the shard shape of configs[4], for --gpus 8)
+    cfg5s           whole-human shape SCALED 1/16: 24 units of 15.6 .. 3.6 Mb, 25 M 2x150 bp pairs (the shard shape of configs[4]; the default with --gpus N > 1)
     custom          --chroms / --pairs / --part
 
 Multi-GPU (driver: torch.distributed.run, one rank per GPU): units are the shard — assigned longest-first to the least
 loaded rank (shard.assign_units), each rank runs its own list, and ONE gather of the extended-contig bytes to rank 0 ends the step
-(RCCL).  Total work is fixed: "scaling": "strong".
+(RCCL: sizes by all_gather, then exact-size point-to-point sends to the root).  Total work is fixed: "scaling": "strong".  After the timed N-rank steps rank 0 runs the
+same job alone on its GPU (`single_gpu_ms_same_config`, `speedup_vs_1gpu`).
 
 Prints ONE JSON line on rank 0.
 """
