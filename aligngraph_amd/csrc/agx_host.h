@@ -191,8 +191,9 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam, long batch
 void stage_pairs(const Pairs &P, agx_u32 k, unsigned threads, StageSink &sink, StagedPairs &S, std::vector<agx_hit> *staged_out = nullptr);
 // reference bases as 2 bits each + the stretches of other bytes (agx_core.h); false: too many such stretches (soft-masked sequence): the bases cross as they are
 // what the device builds the conti-mer tables from besides the runs themselves (agx_core.h: agx_cntrun, agx_chunk): the counts as runs, and both run lists in chunks
-struct CmLayout { std::vector<agx_cntrun> cnt_runs; std::vector<agx_chunk> cnt_chunks, seg_chunks; };
-void build_cm_layout(const agx_u8 *cm_cnt, size_t n_pos, const agx_cmseg *segs, size_t n_segs, CmLayout &L);
+struct CmLayout { std::vector<agx_cntrun> cnt_runs; std::vector<agx_chunk> cnt_chunks, seg_chunks; std::vector<agx_u32> seg_index; };
+void build_seg_index(const agx_cmseg *segs, size_t n_seg0, size_t n_pos, std::vector<agx_u32> &index);      // agx_compact_args::seg_index
+void build_cm_layout(const agx_u8 *cm_cnt, size_t n_pos, const agx_cmseg *segs, size_t n_segs, CmLayout &L);      // (seg_index is built separately: it needs n_seg0)
 bool pack_reference(const char *ref, size_t n, unsigned threads, agx_u8 *packed /* (n + 3) / 4 + 16 bytes */, std::vector<agx_refx> &others);
 
 // agx_host.cpp

@@ -629,8 +629,9 @@ __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, ag
     // and every lane walks forward from there (r02: 17 dependent loads per special id; 0.62 ms of this kernel on a 30 Mb unit).
     agx_u32 xmin = x;
     for (agx_u32 o = 32; o; o >>= 1) { const agx_u32 t = (agx_u32)__shfl_xor((int)xmin, (int)o, 64); xmin = t < xmin ? t : xmin; }
-    agx_u32 s0 = 0;
-    if (A.n_seg0) { agx_u32 lo = 0, hi = A.n_seg0; while (hi - lo > 1) { const agx_u32 mid = lo + (hi - lo) / 2; if (agx_uload(&A.segs[0].pos0 + (size_t)mid * (sizeof(agx_cmseg) / 4), 0) <= xmin) lo = mid; else hi = mid; } s0 = lo; }
+    // (r03, second step: not even one bisection per wavefront — 17 dependent loads in a kernel whose time IS its depth of dependent loads — but one look
+    // into the host's index of the runs, an entry per 1024 positions, and a few steps forward from there)
+    const agx_u32 s0 = A.n_seg0 && xmin != 0xFFFFFFFFu ? agx_uload(A.seg_index, xmin / AGX_SEG_INDEX) : 0u;
     if (on) {
         const agx_u32 at = A.sp_rank[w] + (agx_u32)__popcll(bits & ((1ull << lane) - 1ull));
         if (at >= A.sp_cap) return;                                           // table too small: the host sees the count and repeats the build
@@ -638,8 +639,8 @@ __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, ag
         agx_hop h; h.str_off = 0; h.len = 0; h.end_pos = 0;
         if (A.n_seg0 && A.cm_start[x + 1] - A.cm_start[x] == 1u) {
             agx_u32 si = s0, steps = 0;
-            while (si + 1 < A.n_seg0 && A.segs[si + 1].pos0 <= x && steps < 8u) { si++; steps++; }      // last rank-0 run with pos0 <= x: a few steps behind the wavefront's
-            if (steps == 8u) { agx_u32 lo = si, hi = A.n_seg0; while (hi - lo > 1) { const agx_u32 mid = lo + (hi - lo) / 2; if (A.segs[mid].pos0 <= x) lo = mid; else hi = mid; } si = lo; }      // (the one word that holds the last main ids and the first side ids)
+            while (si + 1 < A.n_seg0 && A.segs[si + 1].pos0 <= x && steps < 16u) { si++; steps++; }      // last rank-0 run with pos0 <= x: a few steps behind the index entry
+            if (steps == 16u) { agx_u32 lo = si, hi = A.n_seg0; while (hi - lo > 1) { const agx_u32 mid = lo + (hi - lo) / 2; if (A.segs[mid].pos0 <= x) lo = mid; else hi = mid; } si = lo; }      // (the one word that holds the last main ids and the first side ids)
             const agx_cmseg g = A.segs[si];
             const agx_u32 j = x - g.pos0;
             if (x >= g.pos0 && j < g.len && j < g.hop_len0) { h.str_off = g.hop_str0 + j; h.len = g.hop_len0 - j; h.end_pos = g.hop_end; }

@@ -462,6 +462,17 @@ void build_cm_layout(const agx_u8 *cm_cnt, size_t n_pos, const agx_cmseg *segs, 
     for (size_t g = 0; g < n_segs; g++) for (agx_u32 off = 0; off < segs[g].len; off += AGX_CM_CHUNK) L.seg_chunks.push_back(agx_chunk{(agx_u32)g, off});
 }
 
+// index of the rank-0 runs (the first n_seg0, sorted by position): entry i = the last run that starts at or before position i * AGX_SEG_INDEX, 0 if none does
+void build_seg_index(const agx_cmseg *segs, size_t n_seg0, size_t n_pos, std::vector<agx_u32> &index) {
+    index.assign(n_pos / AGX_SEG_INDEX + 2, 0u);
+    size_t si = 0;
+    for (size_t i = 0; i < index.size(); i++) {
+        const unsigned long long x = (unsigned long long)i * AGX_SEG_INDEX;
+        while (si + 1 < n_seg0 && segs[si + 1].pos0 <= x) si++;
+        index[i] = (agx_u32)si;
+    }
+}
+
 // Reference bases for the upload: 2 bits each where they are A, C, G, T, and the rest as stretches of one byte value (N runs; a soft-masked sequence
 // has too many of them: false, and the bases cross as they are).  The classes are the read bases' (agx_base_class: A, C, G, T = 0..3).
 bool pack_reference(const char *ref, size_t n, unsigned threads, agx_u8 *packed, std::vector<agx_refx> &others) {
