@@ -802,8 +802,8 @@ void do_build(agx_unit *u) {
             agx_zero_args Z; memset(&Z, 0, sizeof Z);
             auto seg = [&](int i, agx_u32 *ptr, size_t words) { Z.p[i] = ptr; Z.n[i] = (agx_u32)words; };
             seg(0, u->d_words.p, W_N + 6 + 16); seg(1, u->d_tile_cnt.p, (size_t)u->n_tiles + 1); seg(2, u->d_cursor.p, (size_t)u->n_tiles + 1);
-            seg(3, u->d_pool_cnt.p, (size_t)u->n_regions * AGX_REGION_PAD); seg(4, u->d_tile_side.p + u->n_tiles, 1); seg(5, u->d_sp_cnt.p + u->n_words, 1);
-            seg(6, reinterpret_cast<agx_u32 *>(u->d_scan_desc.p), 6 * u->scan_desc_n);
+            seg(3, u->d_pool_cnt.p, (size_t)u->n_regions * AGX_REGION_PAD); seg(4, u->d_tile_side.p + u->n_tiles, 1); seg(5, u->d_sp_cnt.p, (size_t)u->n_words + 1);
+            seg(6, reinterpret_cast<agx_u32 *>(u->d_scan_desc.p), 6 * u->scan_desc_n); seg(7, reinterpret_cast<agx_u32 *>(u->d_sp_bits.p), 2 * ((size_t)u->n_words + 1));      // (the special-id kernels write and read the words of the live ids only)
             agx_launch_zero(&Z, st);
             HIP_OK(hipMemsetAsync(u->d_a_mark.p, 0, ids_cap + 2, st));
         }

@@ -604,14 +604,24 @@ __global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A, cons
         if (!cont) for (agx_u32 e = 0; e < k; e++) A.a_mark[next[e]] = 1;      // racing stores of the same value
     }
 }
-// one wave per 64 ids: the special-id bitmap word and its popcount (input of the rank scan); words past n_ids are written as zero
+// the special-id bitmap and its popcounts (input of the rank scan).  A wavefront takes four 64-id words — every lane one id of each, so that their loads
+// are in flight together — and writes nothing for words past the live ids: sp_bits / sp_cnt are zeroed at the start of the build (the grid covers the id
+// CAPACITY, 2.4 x the live ids of a first build: r02 spent 0.42 ms here on a 30 Mb unit, most of it rounds of threads that only found out they were idle)
+#define AGX_SB_WORDS 4u
 __global__ void __launch_bounds__(256) agx_k_special_bits(agx_compact_args A, agx_u32 n_words) {
     AGX_RETURN_IF_ABORTED(A.abort);
     A.n_ids = A.n_pos + A.tile_side_start[(A.n_pos + AGX_TILE - 1) / AGX_TILE];
-    const agx_u32 a = blockIdx.x * 256u + threadIdx.x, w = a >> 6;
-    if (w >= n_words) return;                                                   // wave-uniform
-    const unsigned long long bits = __ballot(agx_special_id(A, a));
-    if ((threadIdx.x & 63u) == 0) { A.sp_bits[w] = bits; A.sp_cnt[w] = (agx_u32)__popcll(bits); }
+    const agx_u32 lane = threadIdx.x & 63u;
+    const agx_u32 w0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4u + (threadIdx.x >> 6)) * AGX_SB_WORDS);
+    if (w0 >= n_words || (unsigned long long)w0 * 64u >= A.n_ids) return;          // wave-uniform
+    bool f[AGX_SB_WORDS];
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_SB_WORDS; j++) f[j] = agx_special_id(A, (w0 + j) * 64u + lane);
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_SB_WORDS; j++) {
+        const unsigned long long bits = __ballot(f[j]);
+        if (lane == 0 && w0 + j < n_words) { A.sp_bits[w0 + j] = bits; A.sp_cnt[w0 + j] = (agx_u32)__popcll(bits); }
+    }
 }
 // gather the special records in id order
 __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, agx_u32 n_words, agx_collect_args G) {
@@ -812,7 +822,7 @@ void agx_launch_special(const agx_compact_args *A, agx_u32 n_words, agx_u32 *sp_
                         agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, hipStream_t st) {
     const agx_collect_args G{out, a, b, sp_rank + n_words, pool_cnt, regions, sum};
     const agx_u32 blocks = (agx_u32)(((unsigned long long)n_words * 64u + 255u) / 256u);
-    hipLaunchKernelGGL(agx_k_special_bits, dim3(blocks), dim3(256), 0, st, *A, n_words);
+    hipLaunchKernelGGL(agx_k_special_bits, dim3((n_words + 4u * AGX_SB_WORDS - 1u) / (4u * AGX_SB_WORDS)), dim3(256), 0, st, *A, n_words);
     if (desc) agx_launch_exclusive_scan1(A->sp_cnt, sp_rank, n_words, desc, st); else agx_launch_exclusive_scan(A->sp_cnt, sp_rank, n_words, scan_tmp, st);
     hipLaunchKernelGGL(agx_k_special_emit, dim3(blocks), dim3(256), 0, st, *A, n_words, G);
 }
