@@ -219,7 +219,7 @@ def main():
         st = un.stats()
         stage_s[uu] = st["ms_stage"] * 1e-3
         load_ms[uu] = {"contigs": round(st["ms_thread"], 1), "read_alignments": round(st["ms_parse"], 1), "rest": round(st["ms_stage"], 1)}
-        un_bytes[uu] = un.hbm_needed() // 8 + 2 * st["n_pos"]          # staged arrays + output buffers of a unit, roughly: what a set of units holds in host memory
+        un_bytes[uu] = un.hbm_needed() // 16 + st["n_pos"]             # what a staged one-shot unit holds in (pinned) host memory, generously: wire arrays + the download's landing area (cfg3's largest: 0.38 GB staged, 0.48 by this)
         return un
 
     os.environ["AGX_NO_CACHE"] = "1"
