@@ -128,8 +128,9 @@ const HsaCopy &hsa_copy() { static const HsaCopy h; return h; }
 // positions from which a unit's host walk is split between two walkers (= walk_split's default in agx_walk.cpp; AGX_WALK_SPLIT_MIN, read at every download, overrides both: tests)
 inline size_t two_walkers_min() { const char *e = getenv("AGX_WALK_SPLIT_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4000000; }
 #define AGX_TWO_WALKERS_MIN two_walkers_min()
-// walkers for a unit of n_pos positions: one per 5 M positions from the threshold on, two to four — up to eight if asked for (walk_split takes as many as it is given copies of the meta bytes for)
-inline int walkers_wanted(size_t n_pos) { if (n_pos < AGX_TWO_WALKERS_MIN) return 1; const char *e = getenv("AGX_WALK_SPLIT_WALKERS"); int k = e ? atoi(e) : std::min(4, (int)(n_pos / 5000000u)); return k < 2 ? 2 : k > 1 + GraphView::MAX_COPIES ? 1 + GraphView::MAX_COPIES : k; }
+// walkers for a unit of n_pos positions (walkers_for, agx_host.h) and the copies of the meta bytes they need: one each up to four walkers, three shared by more
+inline int walkers_wanted(size_t n_pos) { return n_pos < AGX_TWO_WALKERS_MIN ? 1 : walkers_for(n_pos); }
+inline int meta_copies(size_t n_pos) { const int k = walkers_wanted(n_pos) - 1; return k > GraphView::SHARED_COPIES ? GraphView::SHARED_COPIES : k; }
 
 // One helper thread per unit, started with the unit and asleep until it is handed work: what a unit can prepare while its upload and
 // build run (the pinned download buffers, the output buffers) without its worker waiting for it.  Not started on demand: creating a
@@ -368,7 +369,7 @@ void stage_reference(agx_unit *u, const char *ref, size_t n_pos, unsigned thread
 void reserve_landing(agx_unit *u) {
     if (!(u->prm.flags & AGX_FLAG_ONE_SHOT)) { u->s_landing.release(); return; }
     const size_t n_pos = u->V.n_pos, ni = n_pos + n_pos / 16 + 4096, ns = ni / 10 + 4096;
-    const size_t copies = (size_t)walkers_wanted(n_pos) - 1 > 3 ? 3 : (size_t)walkers_wanted(n_pos) - 1;
+    const size_t copies = (size_t)meta_copies(n_pos);
     const size_t need = (2 + copies) * (ni + 512) + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + ni / 4 + (4u << 20);
     const size_t have = u->s_codes.block_bytes() + u->s_hits.block_bytes() + u->s_runs.block_bytes() + u->s_sides.block_bytes() + u->s_other.block_bytes();
     // (a buffer must fit one block: count the blocks at 85 %)
@@ -723,7 +724,7 @@ void do_upload(agx_unit *u) {
             if (hipSetDevice(u->prm.device) != hipSuccess) return;
             const size_t ni = n_pos + n_pos / 8 + 4096, nw = ni / 64 + 1, ns = ni / 8 + 4096;
             u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(n_pos / 8 + 4097);
-            for (int w = 0; w < std::min(3, walkers_wanted(n_pos) - 1); w++) u->h_a_metas[w].alloc(ni + 64);
+            for (int w = 0; w < meta_copies(n_pos); w++) u->h_a_metas[w].alloc(ni + 64);
             u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2); u->h_a_ovf.alloc(64);
         } catch (...) { }                               // do_download allocates what is missing and reports
         trace(u, "helper: download buffers", th0, n_pos);
@@ -964,10 +965,10 @@ void do_download(agx_unit *u) {
     const size_t n_pos = u->V.n_pos, ni = u->n_ids;
     DeviceTurn &turn = turn_of(u->prm.device);
     const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
-    // A large unit is walked by several walkers (agx_walk.cpp: walk_split); each further one gets its own copy of the meta bytes: 0.36-0.6 ms of download per
-    // copy, in front of the walk.  Four walkers at most unless asked for: with up to eight (tried in r03, for units whose walk finds the CPUs idle) the
-    // downloads of a cfg3 job went from 2.8-5.5 to 6.7-9 ms and the job from 42.3 to 45.4 ms, for walks 1 ms shorter.
-    const int copies = u->helper.started ? walkers_wanted(n_pos) - 1 : 0;
+    // A large unit is walked by several walkers (agx_walk.cpp: walk_split) on copies of the meta bytes: 0.36-0.6 ms of download per copy, in front of the
+    // walk.  Three copies at most: more than four walkers share them (r03 first gave every walker its own: with up to eight the downloads of a cfg3 job
+    // went from 2.8-5.5 to 6.7-9 ms and the job from 42.3 to 45.4 ms, for walks 1 ms shorter).
+    const int copies = u->helper.started ? meta_copies(n_pos) : 0;
     join_dl_helper(u);
     if (u->prm.flags & AGX_FLAG_ONE_SHOT) {
         // The inputs are in HBM and will not be uploaded again: their staged copies are dead pinned memory.  The download's arrays are cut
@@ -1318,7 +1319,7 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
                 else walker_pool().run(pool[who - 1], std::move(f));
             }
             void wait(int who) override { if (who == 0) u->helper.wait(UnitHelper::WALK); else walker_pool().wait(pool[who - 1]); }
-        } second(u, [u] { int c = 0; while (c < GraphView::MAX_COPIES && u->h_a_metas[c].p) c++; return c - 1; }());      // one thread per copy of the meta bytes: the unit's helper + pool threads
+        } second(u, u->h_a_metas[0].p ? walkers_wanted(u->V.n_pos) - 2 : 0);      // one thread per further walker: the unit's helper + pool threads
         walk_join_scaffold(u->V, view_of(u), u->out, u->helper.started ? &second : nullptr);
         u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = u->out.n_fetched;
         trace(u, "walk", t0, u->V.n_pos);

@@ -328,7 +328,7 @@ struct Walker {
     }
     // number of live (unvisited) successors of node v, capped at 2; target = the last one seen (AG:2020-2033)
     int live_successors(agx_u32 v, agx_u32 &target) const {
-        if (m[v] & AGX_WM_CONT) { if (visited(v + 1)) return 0; target = v + 1; return 1; }      // its only alive successor is v+1
+        if (m[v] & AGX_WM_CONT) { if (spec && v >= G.n_pos && !may_look(v + 1)) return 2; if (visited(v + 1)) return 0; target = v + 1; return 1; }      // its only alive successor is v+1
         int n = 0;
         const agx_walknode rec = node(v);
         const agx_u32 *s = rec.next;
@@ -441,7 +441,8 @@ struct WalkRun {
                         agx_u8 seen = 0;
                         const agx_u32 j = run_end(m, cur, seen);
                         const agx_u32 xj = W.pos_of(j);
-                        if (W.spec && (xj < W.look_lo || xj >= W.look_hi)) { W.invalid = true; W.gave_up_at = xj; }      // (the run left what this walker may look at)
+                        // (a run over side ids ends on what the NEXT side id's byte says, and that id may lie many positions further)
+                        if (W.spec && (xj < W.look_lo || xj >= W.look_hi || (j >= G.n_pos && j + 1 < G.n_ids && W.pos_of(j + 1) >= W.look_hi))) { W.invalid = true; W.gave_up_at = xj; mode = -2; break; }      // (the run left what this walker may look at: nothing is marked — the bytes out there may be another walker's)
                         AGX_PT(2);                             // most walks leave the k-mer graph here, onto a conti-mer chain
                         segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!(m[j] & AGX_WM_CONT)) n_general++;
                         if (seen & AGX_WM_CONTIG) C.extended = 1;
@@ -560,7 +561,7 @@ inline void clip_marks(const MarkLog &log, agx_u32 main_lo, agx_u32 main_hi, agx
 
 // One speculative walker: its own visited bytes (a pristine copy of the meta bytes), its own arena, its stretch [c, c_next) of the reference
 struct SpecWalker {
-    agx_u32 c = 0, c_next = 0, w0 = 0, side_c = 0, side_next = 0;
+    agx_u32 c = 0, c_next = 0, w0 = 0, side_c = 0, side_next = 0, warm_lo = 0, warm_hi = 0xFFFFFFFFu, look_hi = 0, win_hi = 0, side_win_hi = 0;
     GraphView G; std::unique_ptr<Walker> W; std::unique_ptr<WalkRun> R; std::vector<Rec> recs;
     MarkLog log; size_t n_warm = 0;              // every mark of the warm-up, then the marks of the stretch that reach c_next or further
     WalkState at_c;                              // where it stood when it arrived at c
@@ -573,14 +574,20 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     const agx_u32 warm = getenv("AGX_WALK_SPLIT_WARMUP") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_WARMUP"), nullptr, 10) : 400000u;
     const agx_u32 n_ref = V.n_ref < G.n_pos ? V.n_ref : G.n_pos;
     if (!assistant || !G.meta_copy[0] || n_ref < min_ref || n_ref < 16 || getenv("AGX_WALK_NO_SPLIT")) return false;
-    // walkers: one per 5 M positions (two to four; up to eight if asked for), as many as there are copies of the meta bytes and helper threads.  r02: one per
-    // 15.5 M — a 19 Mb unit, the LAST of a cfg3 job, was walked by two in 13 ms while the cores of the finished units idled.  More than four do not pay: every
-    // walker needs its own copy of the meta bytes, and the copies cost the download more than they save the walk (agx_engine.cpp: do_download).
-    int K = getenv("AGX_WALK_SPLIT_WALKERS") ? atoi(getenv("AGX_WALK_SPLIT_WALKERS")) : std::min(4, (int)(n_ref / 5000000u));
-    if (K < 2) K = 2;
+    // walkers: one per 2.5 M positions, two to eight, as many as there are helper threads.  Up to four walkers each have a copy of the meta bytes of their
+    // own (r02/r03a).  More than four SHARE three copies: walker i works on copy (i-1) % 3 and may only look at positions [c(i-1), c(i+2)) — one stretch
+    // back for its warm-up, its own stretch, one stretch ahead — so the walkers on one copy touch disjoint bytes (walks are local: a record ends at the
+    // next branch, a conti-mer chain lands a contig's length further; one that does lead further makes the walker give up, as a look in front of its
+    // stretch always did).  Copies cost the download 0.4-0.6 ms each, in front of the walk (agx_engine.cpp: do_download): three is what four walkers needed already.
+    int K = walkers_for(n_ref);
     if (K > 1 + GraphView::MAX_COPIES) K = 1 + GraphView::MAX_COPIES;
-    { int copies = 0; while (copies < GraphView::MAX_COPIES && G.meta_copy[copies]) copies++; if (K > 1 + copies) K = 1 + copies; if (K > 1 + assistant->helpers()) K = 1 + assistant->helpers(); }
+    int copies = 0; while (copies < GraphView::MAX_COPIES && G.meta_copy[copies]) copies++;
+    if (K > 1 + assistant->helpers()) K = 1 + assistant->helpers();
+    if (K > 1 + copies && (copies < 3 || n_ref / (unsigned)K < 2 * warm + 256)) K = 1 + copies;      // (sharing needs three copies and stretches longer than the warm-up)
     if (K < 2) return false;
+    const bool shared = K > 1 + copies;
+    const agx_u32 slack = 64;                           // a walker reads a few bytes past the node it stands on (the end of a run, the cont successor)
+    auto cut_at = [&](int i) { return i >= K ? n_ref : (agx_u32)((unsigned long long)n_ref * (unsigned)i / (unsigned)K); };
     const agx_u32 n_side = G.n_ids - G.n_pos;
     auto side_of = [&](agx_u32 x) { return G.n_pos + (agx_u32)(std::lower_bound(G.side_xpos, G.side_xpos + n_side, x) - G.side_xpos); };
     const agx_u32 side_ref = side_of(n_ref);
@@ -592,9 +599,13 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     std::vector<SpecWalker> B((size_t)K - 1);
     for (int i = 1; i < K; i++) {
         SpecWalker &b = B[(size_t)i - 1];
-        b.c = (agx_u32)((unsigned long long)n_ref * (unsigned)i / (unsigned)K); b.c_next = i + 1 < K ? (agx_u32)((unsigned long long)n_ref * (unsigned)(i + 1) / (unsigned)K) : n_ref;
+        b.c = cut_at(i); b.c_next = cut_at(i + 1);
         b.w0 = b.c > warm ? b.c - warm : 0; b.side_c = side_of(b.c); b.side_next = side_of(b.c_next);
-        b.G = G; b.G.meta = G.meta_copy[i - 1]; b.G.meta_rw = G.meta_copy[i - 1]; for (auto &mc : b.G.meta_copy) mc = nullptr;
+        // what it may look at while it warms up / on its stretch, and how far its marks can reach (win_hi: where the next walker on the same bytes begins)
+        b.warm_lo = shared && i > 1 ? cut_at(i - 1) + slack : 0; b.warm_hi = shared && i + 2 < K ? cut_at(i + 2) - slack : 0xFFFFFFFFu;
+        b.look_hi = shared && i + 2 < K ? cut_at(i + 2) - slack : n_ref; b.win_hi = shared && i + 2 < K ? cut_at(i + 2) : n_ref; b.side_win_hi = b.win_hi < n_ref ? side_of(b.win_hi) : side_ref;
+        agx_u8 *const bytes = G.meta_copy[shared ? (i - 1) % 3 : i - 1];
+        b.G = G; b.G.meta = bytes; b.G.meta_rw = bytes; for (auto &mc : b.G.meta_copy) mc = nullptr;
         b.W.reset(new Walker(V, b.G));
         b.recs.reserve((size_t)G.n_pos / 2048 + 1024);
         b.R.reset(new WalkRun(*b.W, more_arenas[i - 1], b.recs, nullptr));      // (its lists and k-mer tails live in one of the caller's arenas: they outlive this function, and an arena serves one thread)
@@ -606,7 +617,7 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
         assistant->run([bp, &cancel, &G, n_ref, side_ref] {
             SpecWalker &b = *bp; Walker &W = *b.W; WalkRun &R = *b.R;
             try {
-                W.spec = true;                              // (looks anywhere during the warm-up)
+                W.spec = true; W.look_lo = b.warm_lo; W.look_hi = b.warm_hi;      // (looks anywhere during the warm-up, unless it shares its bytes)
                 R.cancel = &cancel; R.st.cp = b.w0; R.keep = false; R.log = &b.log; R.log_main = 0; R.log_side = G.n_pos;
                 R.go(b.c);                                  // warm-up: decides records, keeps none; every mark is logged
                 b.at_c = R.st; b.n_warm = b.log.size();
@@ -616,8 +627,8 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
                 for (const auto &r : b.log) for (agx_u32 v = r.first; v <= r.second; v++) if (v < G.n_pos ? v >= n_ref : v >= side_ref) W.m[v] &= (agx_u8)~AGX_WM_VISITED;
                 R.keep = true; R.st.seqID = 0;
                 if (b.c_next < n_ref) { R.log_main = b.c_next; R.log_side = b.side_next; } else R.log = nullptr;      // (the next walker is checked against what reaches its stretch)
-                W.look_lo = b.c; W.look_hi = n_ref;
-                if (const char *e = getenv("AGX_WALK_SPLIT_LOOK")) { const unsigned long long hi = (unsigned long long)b.c + strtoull(e, nullptr, 10); if (hi < n_ref) W.look_hi = (agx_u32)hi; }      // test hook: a narrow view makes the walker give up
+                W.look_lo = b.c; W.look_hi = b.look_hi;
+                if (const char *e = getenv("AGX_WALK_SPLIT_LOOK")) { const unsigned long long hi = (unsigned long long)b.c + strtoull(e, nullptr, 10); if (hi < W.look_hi) W.look_hi = (agx_u32)hi; }      // test hook: a narrow view makes the walker give up
                 if (!W.invalid && !cancel.load()) R.go(b.c_next);
                 b.ok = !W.invalid && !cancel.load() && R.st.cp >= b.c_next;
             } catch (const Error &e) { b.error = e.msg; } catch (const std::exception &e) { b.error = e.what(); }
@@ -647,7 +658,7 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
         if (timing) {
             if (same) fprintf(stderr, "[agx walk] walker %d of %d, [%u, %u) after a warm-up from %u: its stretch stands\n", i + 1, K, b.c, b.c_next, b.w0);
             else if (!b.error.empty()) fprintf(stderr, "[agx walk] walker %d of %d failed (%s): walked on by the first walker from %u\n", i + 1, K, b.error.c_str(), b.c);
-            else if (b.W->invalid) fprintf(stderr, "[agx walk] walker %d of %d gave up (a walk led to position %u, outside [%u, %u)): walked on by the first walker from %u\n", i + 1, K, b.W->gave_up_at, b.c, n_ref, b.c);
+            else if (b.W->invalid) fprintf(stderr, "[agx walk] walker %d of %d gave up (a walk led to position %u, outside [%u, %u)): walked on by the first walker from %u\n", i + 1, K, b.W->gave_up_at, b.W->look_lo, b.W->look_hi, b.c);
             else fprintf(stderr, "[agx walk] walker %d of %d, [%u, %u) after a warm-up from %u: states differ at the meeting point (scan at %u / %u, last record %u..%u / %u..%u, %zu / %zu mark ranges): walked on by the first walker\n",
                          i + 1, K, b.c, b.c_next, b.w0, at.cp, b.at_c.cp, at.sOffBak, at.eOffBak, b.at_c.sOffBak, b.at_c.eOffBak, ma.size(), mb.size());
         }
@@ -661,19 +672,28 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     cancel.store(true);                                 // (walkers behind one that does not stand walk for nothing)
     for (int i = stood; i < K - 1; i++) join.now(i);
     const double tw2 = clock();
-    // what stands: the records behind A's, numbered on; the marks into A's bytes (the appended positions — and whatever did not stand — are walked on those)
-    for (int i = 1; i <= stood; i++) {
-        SpecWalker &b = B[(size_t)i - 1];
-        for (Rec &r : b.recs) written.push_back(std::move(r));
-        const agx_u8 *src = b.W->m;
-        auto merge = [&](agx_u32 lo, agx_u32 hi) {
+    // what stands: the records behind A's, numbered on; the marks into A's bytes (the appended positions — and whatever did not stand — are walked on those).
+    // The walkers' threads are idle now: each merges its own walker's marks (disjoint ranges of A's bytes), this thread the last one's.
+    {
+        auto merge = [&WA](const agx_u8 *src, agx_u32 lo, agx_u32 hi) {
             agx_u32 v = lo;
             for (; v < hi && (v & 7u); v++) WA.m[v] |= (agx_u8)(src[v] & AGX_WM_VISITED);
             for (; v + 8 <= hi; v += 8) { uint64_t x, y; memcpy(&x, WA.m + v, 8); memcpy(&y, src + v, 8); x |= y & 0x8080808080808080ull; memcpy(WA.m + v, &x, 8); }
             for (; v < hi; v++) WA.m[v] |= (agx_u8)(src[v] & AGX_WM_VISITED);
         };
-        // (what a walker marked behind its own stretch is in the next walker's bytes as well — that is what was compared — unless this is the last one that stands)
-        if (i < stood) { merge(b.c, b.c_next); merge(b.side_c, b.side_next); } else { merge(b.c, n_ref); merge(b.side_c, side_ref); }
+        // (what a walker marked behind its own stretch is in the next walker's bytes as well — that is what was compared — unless this is the last one that
+        // stands; walkers that share bytes: the bytes behind that one's window are another walker's)
+        auto merge_of = [&](int i) {
+            const SpecWalker &b = B[(size_t)i - 1]; const agx_u8 *src = b.W->m;
+            if (i < stood) { merge(src, b.c, b.c_next); merge(src, b.side_c, b.side_next); } else { merge(src, b.c, b.win_hi); merge(src, b.side_c, b.side_win_hi); }
+        };
+        struct Wait { Assistant *a; int n; ~Wait() { for (int i = 0; i < n; i++) a->wait(i); } } wait{assistant, stood > 1 ? stood - 1 : 0};
+        for (int i = 1; i < stood; i++) assistant->run([&merge_of, i] { merge_of(i); }, i - 1);
+        if (stood) merge_of(stood);
+    }
+    for (int i = 1; i <= stood; i++) {
+        SpecWalker &b = B[(size_t)i - 1];
+        for (Rec &r : b.recs) written.push_back(std::move(r));
         WA.n_fetched += b.W->n_fetched;
         A.n_walks += b.R->n_walks; A.n_hops += b.R->n_hops; A.n_runs += b.R->n_runs; A.n_general += b.R->n_general; A.run_nodes += b.R->run_nodes;
     }

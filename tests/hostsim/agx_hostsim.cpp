@@ -261,7 +261,7 @@ int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int cover
         simulate(T, P, (agx_u32)k, iv, coverage, maxv_first > 0 ? (agx_u32)maxv_first : AGX_MAXV_LDS, S, nbig);
         GraphView G; G.n_pos = (agx_u32)T.ref.size(); G.n_ids = S.n_ids;
         G.meta = S.a_meta.data(); G.str = S.a_str.data(); G.side_xpos = S.side_xpos.data();
-        std::vector<agx_u8> meta_copy[3];                        // AGX_SIM_SPLIT=n: n (1..3) further copies of the meta bytes, so that the walk is done by n + 1 walkers (needs AGX_SIM_ASSISTANT=1)
+        std::vector<agx_u8> meta_copy[3];                        // AGX_SIM_SPLIT=n: n (1..3) further copies of the meta bytes, so that the walk is done by n + 1 walkers — or, with three copies, by up to eight that share them (needs AGX_SIM_ASSISTANT=1)
         if (const char *e = getenv("AGX_SIM_SPLIT")) for (int i = 0; i < 3 && i < atoi(e); i++) { meta_copy[i] = S.a_meta; G.meta_copy[i] = meta_copy[i].data(); }
         G.sp_bits = S.sp_bits.data(); G.sp_rank = S.sp_rank.data(); G.sp_node = S.sp_node.data(); G.sp_hop = S.sp_hop.data(); G.n_special = S.n_special;
         G.fetch = [](void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *o) {
@@ -275,11 +275,11 @@ int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int cover
         }
         // AGX_SIM_ASSISTANT=1: with a second thread for the outputs, as the engine runs it (the written records are formatted while the walk goes on)
         struct ThreadAssistant : Assistant {
-            std::thread t[3];
+            std::thread t[7];
             void run(std::function<void()> f, int who) override { wait(who); t[who] = std::thread(std::move(f)); }
             void wait(int who) override { if (t[who].joinable()) t[who].join(); }
-            int helpers() const override { return 3; }
-            ~ThreadAssistant() override { for (int i = 0; i < 3; i++) wait(i); }
+            int helpers() const override { return 7; }
+            ~ThreadAssistant() override { for (int i = 0; i < 7; i++) wait(i); }
         } second;
         UnitOutput O; walk_join_scaffold(view_of(T, P), G, O, getenv("AGX_SIM_ASSISTANT") ? &second : nullptr);
         out->initial_contigs = dup_buf(T.initial_contigs); out->initial_len = T.initial_contigs.size();

@@ -78,10 +78,14 @@ def test_walk_by_several_walkers_is_the_sequential_walk(built, tmp_path, monkeyp
     o = H.run_oracle(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
     for key, val in (("AGX_SIM_ASSISTANT", "1"), ("AGX_SIM_SPLIT", "3"), ("AGX_WALK_SPLIT_MIN", "0"), ("AGX_WALK_SPLIT_WARMUP", warm)):
         monkeypatch.setenv(key, val)
-    for walkers, look in (("2", None), ("3", None), ("4", None), ("4", "20000")):      # look: the walkers see 20 kb of their stretch only: they give up
+    # look: the walkers see 20 kb of their stretch only: they give up.  More than four walkers share the three copies of the visited bytes, each behind
+    # its own window of three stretches (short warm-ups only: the stretches must be longer than the warm-up for that)
+    for walkers, look in (("2", None), ("3", None), ("4", None), ("4", "20000"), ("5", None), ("8", None), ("8", "20000")):
         monkeypatch.setenv("AGX_WALK_SPLIT_WALKERS", walkers)
         if look:
             monkeypatch.setenv("AGX_WALK_SPLIT_LOOK", look)
+        else:
+            monkeypatch.delenv("AGX_WALK_SPLIT_LOOK", raising=False)
         s = sim.run(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
         for key in ("initial", "pre", "extended"):
             assert o[key] == s[key], (walkers, look, key)
@@ -220,3 +224,32 @@ def test_positions_with_more_variants_than_the_sweeps_first_buckets(built, tmp_p
     assert graph_mismatch(o["graph"], s["graph"]) is None
     for key in ("initial", "pre", "extended"):
         assert o[key] == s[key], key
+
+
+def test_more_than_four_walkers_share_three_copies_of_the_visited_bytes(built, tmp_path, monkeypatch, capfd):
+    # walk_split with five to eight walkers: walker i works on copy (i-1) % 3 of the visited bytes, behind a window of three stretches, so the walkers on one
+    # copy never touch the same byte.  The oracle's bytes, with stretches that stand (so the merge of shared copies is what the appended positions are walked
+    # on) and with walkers that give up at the edge of a narrow window.
+    run = H.synth(str(tmp_path / "run"), seed=131, chroms="1000000", pairs=200000, coverage=4, read_indel=0.2, multi=0.2, contig_overlap=0.4, contig_minus=0.5, sam_seq=0)
+    meta = H.read_meta(run)
+    tmp = os.path.join(run, "tmp")
+    o = H.run_oracle(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
+    for key, val in (("AGX_SIM_ASSISTANT", "1"), ("AGX_SIM_SPLIT", "3"), ("AGX_WALK_SPLIT_MIN", "0"), ("AGX_WALK_TIMING", "1")):
+        monkeypatch.setenv(key, val)
+    stood = {}
+    for walkers, warm, look in (("5", "40000", None), ("6", "40000", None), ("7", "40000", None), ("8", "40000", None), ("8", "5000", None), ("8", "40000", "60000")):
+        monkeypatch.setenv("AGX_WALK_SPLIT_WALKERS", walkers)
+        monkeypatch.setenv("AGX_WALK_SPLIT_WARMUP", warm)
+        if look:
+            monkeypatch.setenv("AGX_WALK_SPLIT_LOOK", look)
+        else:
+            monkeypatch.delenv("AGX_WALK_SPLIT_LOOK", raising=False)
+        capfd.readouterr()
+        s = sim.run(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
+        err = capfd.readouterr().err
+        for key in ("initial", "pre", "extended"):
+            assert o[key] == s[key], (walkers, warm, look, key)
+        line = [ln for ln in err.splitlines() if "stretches stood" in ln]
+        assert line and ("%s walkers" % walkers) in line[0], err[-2000:]
+        stood[(walkers, warm, look)] = int(line[0].split(" walkers, ")[1].split()[0])
+    assert max(stood.values()) >= 4, stood                      # the shared-copy path with most stretches standing was walked
