@@ -28,6 +28,8 @@
 #include <mutex>
 #include <system_error>
 #include <thread>
+#include <pthread.h>
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <vector>
@@ -49,7 +51,24 @@ static const bool g_trace = getenv("AGX_TRACE") != nullptr;
 void trace(const void *unit, const char *what, double from_ms, size_t n_pos) {
     if (!g_trace) return;
     static const double t00 = now_ms();
-    fprintf(stderr, "[agx trace] unit %p (%zu pos) %-22s %9.2f -> %9.2f ms\n", unit, n_pos, what, from_ms - t00, now_ms() - t00);
+    // (+ the CPU time of the calling thread since its previous line: a stage that waits should cost none)
+    static thread_local double cpu_last = 0;
+    timespec ts{}; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); const double cpu = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    fprintf(stderr, "[agx trace] unit %p (%zu pos) %-22s %9.2f -> %9.2f ms   (thread cpu +%.2f ms)\n", unit, n_pos, what, from_ms - t00, now_ms() - t00, cpu - cpu_last);
+    cpu_last = cpu;
+}
+
+// Wait for an event asleep.  hipEventSynchronize spins whatever the event's flags say (ROCm 7.2: the five unit threads of a cfg3 job burned 25 ms of CPU each waiting
+// for uploads and builds — a third of the job's CPU time, beside the walkers of the units in front of them, on a box whose control group grants 16 CPUs): a short
+// spin for what is about to finish, then queries between short sleeps (a sleep of 20 us takes 70-80 with the default timer slack: that is the price of a wake-up).
+hipError_t wait_event(hipEvent_t e) {
+    static const bool spin = getenv("AGX_SPIN_WAIT") != nullptr;
+    if (spin) return hipEventSynchronize(e);
+    for (int i = 0; i < 64; i++) { const hipError_t r = hipEventQuery(e); if (r != hipErrorNotReady) return r; }
+    for (;;) {
+        const timespec ts{0, 20000}; nanosleep(&ts, nullptr);
+        const hipError_t r = hipEventQuery(e); if (r != hipErrorNotReady) return r;
+    }
 }
 
 // Section boundaries of a build on the build streams: the end of one section is the start of the next (one record instead of two: an
@@ -142,6 +161,7 @@ struct UnitHelper {
     void start() {
         if (started) return;
         th = std::thread([this] {
+            pthread_setname_np(pthread_self(), "agx-helper");
             std::unique_lock<std::mutex> l(m);
             for (;;) {
                 cv.wait(l, [this] { return stop || queued[DL] || queued[OUT] || queued[WALK]; });
@@ -169,7 +189,7 @@ struct UnitHelper {
 // The further walkers of large units (agx_walk.cpp: walk_split; the first extra one is the unit's own helper): a small pool for the process, made
 // when the first large unit is finished.  A unit takes what is free and walks with fewer walkers if that is less than it wanted.
 struct WalkerPool {
-    enum { N = 32 };
+    enum { N = 64 };
     struct Slot { std::thread th; std::mutex m; std::condition_variable cv; std::function<void()> job; bool queued = false, running = false, taken = false, stop = false; };
     Slot slot[N]; std::mutex take_m; bool started = false;
     void start() {
@@ -178,6 +198,7 @@ struct WalkerPool {
         for (Slot &s : slot) {
             try {
                 s.th = std::thread([&s] {
+                    pthread_setname_np(pthread_self(), "agx-walker");
                     std::unique_lock<std::mutex> l(s.m);
                     for (;;) {
                         s.cv.wait(l, [&s] { return s.stop || s.queued; });
@@ -199,6 +220,19 @@ struct WalkerPool {
     ~WalkerPool() { for (Slot &s : slot) if (s.th.joinable()) { { std::lock_guard<std::mutex> l(s.m); s.stop = true; } s.cv.notify_all(); s.th.join(); } }
 };
 WalkerPool &walker_pool() { static WalkerPool p; return p; }
+// Units of this process that are uploaded (or on their way up) and whose walk has not begun: the walks that will follow the one that begins now.
+std::atomic<int> g_on_the_way{0};
+// Walkers for the unit whose walk begins now.  With other units on the way the walks of a pipelined job overlap, two or three at a time: each takes half the CPUs
+// this process may use at most.  The walk that has nothing behind it is the job's tail — the device is idle by then, the earlier walks are ending — and takes what
+// its size asks for (walkers_wanted) of all the CPUs that are not walking.
+inline int walkers_now(size_t n_pos, int behind) {
+    const int want = walkers_wanted(n_pos);
+    if (want <= 4 || getenv("AGX_WALK_SPLIT_WALKERS")) return want;
+    const int cpus = (int)usable_cpus(), half = cpus / 2 < 4 ? 4 : cpus / 2;
+    if (behind > 0) return want < half ? want : half;
+    const int idle = cpus - walker_pool().busy() - 1;
+    return want <= idle ? want : idle > half ? idle : want < half ? want : half;
+}
 
 struct agx_unit {
     agx_params prm{};
@@ -208,6 +242,7 @@ struct agx_unit {
     struct Mapped { void *p = nullptr; size_t n = 0; void reset() { if (p) munmap(p, n); p = nullptr; n = 0; } ~Mapped() { reset(); } } cache_map;
     agx_u32 n_seg0 = 0, stride = 0, n_slots = 0, n_rows = 0; unsigned long long pairs_in_file = 0, sam_pairs = 0;
     bool have_ref = false, have_threads = false, staged = false, uploaded = false, built = false, downloaded = false;
+    bool counted_on_the_way = false;    // in g_on_the_way (below) since its upload, until its walk begins or it is released
     bool consumed = false;             // AGX_FLAG_ONE_SHOT: the download has overwritten the staged inputs
     bool expanded = false;             // the conti-mer tables and vote codes have been made from what was uploaded (opens the unit's first build)
     hipEvent_t ev_built = nullptr;     // this unit's build commands are done (waited for on the host; ev_dl: its download)
@@ -659,6 +694,7 @@ void do_upload(agx_unit *u) {
     if (u->arena.used()) do_release(u);              // uploaded before: start over (the unit's blocks go through the cache)
     const double t0 = now_ms();
     HIP_OK(hipSetDevice(u->prm.device));
+    if (!u->counted_on_the_way) { u->counted_on_the_way = true; g_on_the_way.fetch_add(1); }
     const size_t n_pos = u->V.n_pos, nh = u->nh;
     u->arena.device = u->prm.device;
     u->n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
@@ -786,7 +822,7 @@ void do_build(agx_unit *u) {
         // awaited here, on the host, before the turn is taken.
         const double tb0 = now_ms();
         const bool early = !u->expanded && attempt == 0 && !u->ev.all;      // a unit's first build starts on the arrays that arrive first; the read bases are waited for on the device, in front of their first use (not in builds that time their sections: those would time the wait)
-        HIP_OK(hipEventSynchronize(early ? u->ev_hits : u->ev_uploaded));
+        HIP_OK(wait_event(early ? u->ev_hits : u->ev_uploaded));
         trace(u, "build: wait for upload", tb0, n_pos);
         const double tb1 = now_ms();
         DeviceTurn &turn = turn_of(u->prm.device);
@@ -906,7 +942,7 @@ void do_build(agx_unit *u) {
         my_turn.unlock();
         trace(u, "build: queue kernels", tb1, n_pos);
         const double tb2 = now_ms();
-        HIP_OK(hipEventSynchronize(u->ev_built));
+        HIP_OK(wait_event(u->ev_built));
         trace(u, "build: wait for kernels", tb2, n_pos);
         HIP_OK(hipGetLastError());
         if (g_trace_gap && trace_from && trace_from != u->ev.e[B_NODE]) {      // diagnostic (units must outlive each other's builds): end of the previous sweep -> start of this one
@@ -1017,7 +1053,7 @@ void do_download(agx_unit *u) {
         }
     }
     const double t1 = now_ms();
-    HIP_OK(hipEventSynchronize(u->ev_dl));
+    HIP_OK(wait_event(u->ev_dl));
     if (getenv("AGX_DL_TIMING")) fprintf(stderr, "[agx download] buffers %.2f ms, copies %.2f ms (%zu ids, %zu records)\n", t1 - t0, now_ms() - t1, ni, ns);
     memset(u->h_a_meta.p + ni, 0, 64); for (int w = 0; w < copies; w++) memset(u->h_a_metas[w].p + ni, 0, 64);
     u->stats.n_walk_ids = ni; u->stats.n_special = ns;
@@ -1031,6 +1067,7 @@ void do_download(agx_unit *u) {
 // them without a driver call).  The inputs stay staged: the unit can be uploaded again as if it were new.
 void do_release(agx_unit *u) {
     const double tr0 = now_ms();
+    if (u->counted_on_the_way) { u->counted_on_the_way = false; g_on_the_way.fetch_sub(1); }
     struct Tr { agx_unit *u; double t; ~Tr() { trace(u, "release", t, u->V.n_pos); } } tr{u, tr0};
     join_dl_helper(u);                                 // (it fills the download buffers released below)
     if (u->uploaded) { (void)hipSetDevice(u->prm.device); (void)hipEventSynchronize(u->ev_uploaded); (void)hipEventSynchronize(u->ev_built); (void)hipEventSynchronize(u->ev_dl); }      // (its commands are done before its memory goes)
@@ -1140,7 +1177,8 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
         try { u->helper.start(); } catch (...) { }      // (without it the unit prepares its buffers on the caller's threads)
         HIP_OK(hipSetDevice(p->device));
         u->ev.init(); u->ev.all = (u->prm.flags & AGX_FLAG_TIME_SECTIONS) != 0;
-        for (hipEvent_t *e : {&u->ev_front, &u->ev_passA, &u->ev_passJ, &u->ev_dl, &u->ev_built, &u->ev_hits}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t *e : {&u->ev_front, &u->ev_passA, &u->ev_passJ}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t *e : {&u->ev_dl, &u->ev_built, &u->ev_hits}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         HIP_OK(hipEventCreate(&u->ev_up0)); HIP_OK(hipEventCreate(&u->ev_uploaded));
         u->dl_sdma = hsa_copy().agent_of(p->device, u->dl_agent) && hsa_signal_create(0, 0, nullptr, &u->dl_signal) == HSA_STATUS_SUCCESS;
     });
@@ -1308,10 +1346,12 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
         prepare_outputs(u);               // (a unit whose helper could not make them, or that is finished a second time)
         if (!u->out_ready) throw Error{E_ARG, "out of host memory"};
         u->downloaded = false;            // the walk marks the downloaded meta bytes: another finish downloads again
+        int behind = g_on_the_way.load();
+        if (u->counted_on_the_way) { u->counted_on_the_way = false; behind = g_on_the_way.fetch_sub(1) - 1; }
         u->out_ready = false;             // (an error below leaves the buffers to the next prepare_outputs)
         struct Helpers : Assistant {           // helper 0: the unit's own thread (formats the written records while the walk goes on, or walks a stretch); 1..: pool threads for further walkers
-            agx_unit *u; int pool[GraphView::MAX_COPIES] = {-1, -1, -1, -1, -1, -1, -1}; int n_pool = 0;
-            Helpers(agx_unit *x, int extra) : u(x) { for (int i = 0; i < extra && i < GraphView::MAX_COPIES - 1; i++) { const int t = walker_pool().take(); if (t < 0) break; pool[n_pool++] = t; } }
+            agx_unit *u; int pool[GraphView::MAX_WALKERS] = {}; int n_pool = 0;
+            Helpers(agx_unit *x, int extra) : u(x) { for (int i = 0; i < extra && i < GraphView::MAX_WALKERS - 2; i++) { const int t = walker_pool().take(); if (t < 0) break; pool[n_pool++] = t; } }
             ~Helpers() override { for (int i = 0; i < n_pool; i++) { walker_pool().wait(pool[i]); walker_pool().give(pool[i]); } }
             int helpers() const override { return 1 + n_pool; }
             void run(std::function<void()> f, int who) override {
@@ -1319,7 +1359,7 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
                 else walker_pool().run(pool[who - 1], std::move(f));
             }
             void wait(int who) override { if (who == 0) u->helper.wait(UnitHelper::WALK); else walker_pool().wait(pool[who - 1]); }
-        } second(u, u->h_a_metas[0].p ? walkers_wanted(u->V.n_pos) - 2 : 0);      // one thread per further walker: the unit's helper + pool threads
+        } second(u, u->h_a_metas[0].p ? walkers_now(u->V.n_pos, behind) - 2 : 0);      // one thread per further walker: the unit's helper + pool threads
         walk_join_scaffold(u->V, view_of(u), u->out, u->helper.started ? &second : nullptr);
         u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = u->out.n_fetched;
         trace(u, "walk", t0, u->V.n_pos);
@@ -1347,7 +1387,7 @@ int agx_unit_graph(agx_unit *u, agx_graph *g) {
     return guarded(u, [&] {
         if (!u->built) do_build(u);
         HIP_OK(hipSetDevice(u->prm.device));
-        HIP_OK(hipEventSynchronize(u->ev_built));
+        HIP_OK(wait_event(u->ev_built));
         // the pool has unused slots (one slice per region): the arrays come down whole, nodes are reached through node_start / node_cnt
         const agx_u32 n_pos = (agx_u32)u->V.n_pos, nn = u->n_nodes, cap = u->pool_cap;
         std::vector<agx_u32> node_start(n_pos), cid(cap), coff(cap), cid0(cap), coff0(cap), off0(cap), next((size_t)cap * AGX_MAXE); std::vector<agx_u8> node_cnt(n_pos);

@@ -26,6 +26,7 @@
 #include <memory>
 #include <system_error>
 #include <thread>
+#include <pthread.h>
 #include <mutex>
 #include <condition_variable>
 #include <sched.h>
@@ -548,6 +549,7 @@ Team::Team(unsigned threads) : impl_(new Impl), n_(threads ? threads : 1) {
     for (unsigned t = 1; t < n_; t++) {
         try {
             I.th.emplace_back([&I, t] {
+                pthread_setname_np(pthread_self(), "agx-team");
                 unsigned long long seen = 0;
                 for (;;) {
                     const std::function<void(unsigned)> *f;

@@ -80,9 +80,9 @@ struct GraphView {
     agx_u32 n_pos = 0, n_ids = 0;
     const agx_u8 *meta = nullptr;                           // [n_ids + 64] AGX_WM_* bits (padding reads as 0)
     agx_u8 *meta_rw = nullptr;                              // null, or == meta: the walk may keep its visited marks in meta's bit 7 (the array is consumed by the walk)
-    enum { MAX_COPIES = 7, SHARED_COPIES = 3 };
+    enum { MAX_COPIES = 7, SHARED_COPIES = 3, MAX_WALKERS = 16 };
     // further copies of meta that the walk may consume as well: a large unit is then walked by several walkers (agx_walk.cpp: walk_split) — one per copy + 1, or,
-    // given SHARED_COPIES copies, any number up to 1 + MAX_COPIES, three walkers apart on the same copy
+    // given SHARED_COPIES copies, any number up to MAX_WALKERS, three walkers apart on the same copy
     agx_u8 *meta_copy[MAX_COPIES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const char *str = nullptr;                              // [n_ids] base a node emits
     const agx_u32 *side_xpos = nullptr;                     // [n_ids - n_pos] position of each side id, non-decreasing
@@ -168,13 +168,12 @@ template <class T> struct SBuf {
 
 unsigned usable_cpus();                   // CPUs this process can keep busy: its affinity mask capped by the CPU quota of its control group
 unsigned loader_threads(size_t bytes);      // AGX_LOAD_THREADS, else by the size of the input and the cores this process may use
-// walkers of a unit of n positions (agx_walk.cpp: walk_split): AGX_WALK_SPLIT_WALKERS, else one per 2.5 M positions, two to eight, and no more than half the
-// CPUs this process may use (the walks of a pipelined job's units overlap)
+// walkers of a unit of n positions at most (agx_walk.cpp: walk_split): AGX_WALK_SPLIT_WALKERS, else one per 1.2 M positions, two to sixteen.  The engine hands
+// out fewer when the CPUs this process may use are busy with the walks of other units (agx_engine.cpp: agx_unit_finish).
 inline int walkers_for(size_t n) {
     const char *e = getenv("AGX_WALK_SPLIT_WALKERS");
-    int k = e ? atoi(e) : (int)(n / 2500000u);
-    if (!e) { const int half = (int)(usable_cpus() / 2); if (k > half) k = half; if (k > 8) k = 8; }
-    return k < 2 ? 2 : k > 1 + GraphView::MAX_COPIES ? 1 + GraphView::MAX_COPIES : k;
+    const int k = e ? atoi(e) : (int)(n / 1200000u);
+    return k < 2 ? 2 : k > GraphView::MAX_WALKERS ? (int)GraphView::MAX_WALKERS : k;
 }
 
 // agx_load.cpp — the fast loaders.  Each returns false when the input is anything but the well-formed common case (an '@' line, an empty line in the

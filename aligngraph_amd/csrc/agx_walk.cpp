@@ -566,6 +566,7 @@ struct SpecWalker {
     MarkLog log; size_t n_warm = 0;              // every mark of the warm-up, then the marks of the stretch that reach c_next or further
     WalkState at_c;                              // where it stood when it arrived at c
     bool ok = false; std::string error;
+    double t_run = 0, t_warm = 0, t_done = 0;     // (AGX_WALK_TIMING) when its thread began, arrived at c, arrived at c_next
 };
 
 // false: not split (too small, no copy of the meta bytes, no assistant): the caller walks the usual way
@@ -574,20 +575,24 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     const agx_u32 warm = getenv("AGX_WALK_SPLIT_WARMUP") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_WARMUP"), nullptr, 10) : 400000u;
     const agx_u32 n_ref = V.n_ref < G.n_pos ? V.n_ref : G.n_pos;
     if (!assistant || !G.meta_copy[0] || n_ref < min_ref || n_ref < 16 || getenv("AGX_WALK_NO_SPLIT")) return false;
-    // walkers: one per 2.5 M positions, two to eight, as many as there are helper threads.  Up to four walkers each have a copy of the meta bytes of their
+    // walkers: one per 1.2 M positions, two to sixteen, as many as there are helper threads.  Up to four walkers each have a copy of the meta bytes of their
     // own (r02/r03a).  More than four SHARE three copies: walker i works on copy (i-1) % 3 and may only look at positions [c(i-1), c(i+2)) — one stretch
     // back for its warm-up, its own stretch, one stretch ahead — so the walkers on one copy touch disjoint bytes (walks are local: a record ends at the
     // next branch, a conti-mer chain lands a contig's length further; one that does lead further makes the walker give up, as a look in front of its
     // stretch always did).  Copies cost the download 0.4-0.6 ms each, in front of the walk (agx_engine.cpp: do_download): three is what four walkers needed already.
     int K = walkers_for(n_ref);
-    if (K > 1 + GraphView::MAX_COPIES) K = 1 + GraphView::MAX_COPIES;
     int copies = 0; while (copies < GraphView::MAX_COPIES && G.meta_copy[copies]) copies++;
     if (K > 1 + assistant->helpers()) K = 1 + assistant->helpers();
-    if (K > 1 + copies && (copies < 3 || n_ref / (unsigned)K < 2 * warm + 256)) K = 1 + copies;      // (sharing needs three copies and stretches longer than the warm-up)
+    if (K > 1 + copies) {                                // (sharing needs three copies and stretches of at least two warm-ups)
+        const int fit = (int)(n_ref / (2ull * warm + 256));
+        if (copies < GraphView::SHARED_COPIES || fit <= 1 + copies) K = 1 + copies; else if (K > fit) K = fit;
+    }
     if (K < 2) return false;
     const bool shared = K > 1 + copies;
     const agx_u32 slack = 64;                           // a walker reads a few bytes past the node it stands on (the end of a run, the cont successor)
-    auto cut_at = [&](int i) { return i >= K ? n_ref : (agx_u32)((unsigned long long)n_ref * (unsigned)i / (unsigned)K); };
+    // the first walker has no warm-up to walk: its stretch is longer by one, so that all arrive at about the same time
+    const agx_u32 lead = n_ref / (unsigned)K > 4 * warm ? warm : 0;
+    auto cut_at = [&](int i) { return i >= K ? n_ref : i <= 0 ? 0 : lead + (agx_u32)((unsigned long long)(n_ref - lead) * (unsigned)i / (unsigned)K); };
     const agx_u32 n_side = G.n_ids - G.n_pos;
     auto side_of = [&](agx_u32 x) { return G.n_pos + (agx_u32)(std::lower_bound(G.side_xpos, G.side_xpos + n_side, x) - G.side_xpos); };
     const agx_u32 side_ref = side_of(n_ref);
@@ -595,6 +600,7 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     const bool timing = getenv("AGX_WALK_TIMING") != nullptr;
     auto clock = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
+    const double t_enter = clock();
     std::atomic<bool> cancel{false};
     std::vector<SpecWalker> B((size_t)K - 1);
     for (int i = 1; i < K; i++) {
@@ -604,7 +610,7 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
         // what it may look at while it warms up / on its stretch, and how far its marks can reach (win_hi: where the next walker on the same bytes begins)
         b.warm_lo = shared && i > 1 ? cut_at(i - 1) + slack : 0; b.warm_hi = shared && i + 2 < K ? cut_at(i + 2) - slack : 0xFFFFFFFFu;
         b.look_hi = shared && i + 2 < K ? cut_at(i + 2) - slack : n_ref; b.win_hi = shared && i + 2 < K ? cut_at(i + 2) : n_ref; b.side_win_hi = b.win_hi < n_ref ? side_of(b.win_hi) : side_ref;
-        agx_u8 *const bytes = G.meta_copy[shared ? (i - 1) % 3 : i - 1];
+        agx_u8 *const bytes = G.meta_copy[shared ? (i - 1) % GraphView::SHARED_COPIES : i - 1];
         b.G = G; b.G.meta = bytes; b.G.meta_rw = bytes; for (auto &mc : b.G.meta_copy) mc = nullptr;
         b.W.reset(new Walker(V, b.G));
         b.recs.reserve((size_t)G.n_pos / 2048 + 1024);
@@ -616,11 +622,13 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
         SpecWalker *bp = &B[(size_t)i - 1];
         assistant->run([bp, &cancel, &G, n_ref, side_ref] {
             SpecWalker &b = *bp; Walker &W = *b.W; WalkRun &R = *b.R;
+            auto clk = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+            b.t_run = clk();
             try {
                 W.spec = true; W.look_lo = b.warm_lo; W.look_hi = b.warm_hi;      // (looks anywhere during the warm-up, unless it shares its bytes)
                 R.cancel = &cancel; R.st.cp = b.w0; R.keep = false; R.log = &b.log; R.log_main = 0; R.log_side = G.n_pos;
                 R.go(b.c);                                  // warm-up: decides records, keeps none; every mark is logged
-                b.at_c = R.st; b.n_warm = b.log.size();
+                b.at_c = R.st; b.n_warm = b.log.size(); b.t_warm = clk();
                 // What the warm-up marked behind the reference (appended positions) is forgotten: this walker does not know what the sequential
                 // walk has visited there, so it must not find anything visited there that it marked itself — it finds those nodes unvisited, at
                 // most, and gives up when a walk leads to them.  (Its marks in front of c are never looked at again: whatever leads there makes it give up.)
@@ -630,7 +638,7 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
                 W.look_lo = b.c; W.look_hi = b.look_hi;
                 if (const char *e = getenv("AGX_WALK_SPLIT_LOOK")) { const unsigned long long hi = (unsigned long long)b.c + strtoull(e, nullptr, 10); if (hi < W.look_hi) W.look_hi = (agx_u32)hi; }      // test hook: a narrow view makes the walker give up
                 if (!W.invalid && !cancel.load()) R.go(b.c_next);
-                b.ok = !W.invalid && !cancel.load() && R.st.cp >= b.c_next;
+                b.ok = !W.invalid && !cancel.load() && R.st.cp >= b.c_next; b.t_done = clk();
             } catch (const Error &e) { b.error = e.msg; } catch (const std::exception &e) { b.error = e.what(); }
         }, i - 1);
     }
@@ -656,7 +664,7 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
             same = ma == mb;
         }
         if (timing) {
-            if (same) fprintf(stderr, "[agx walk] walker %d of %d, [%u, %u) after a warm-up from %u: its stretch stands\n", i + 1, K, b.c, b.c_next, b.w0);
+            if (same) fprintf(stderr, "[agx walk] walker %d of %d, [%u, %u) after a warm-up from %u: its stretch stands (began at %.2f ms, warm-up %.2f ms, stretch %.2f ms)\n", i + 1, K, b.c, b.c_next, b.w0, b.t_run - t_enter, b.t_warm - b.t_run, b.t_done - b.t_warm);
             else if (!b.error.empty()) fprintf(stderr, "[agx walk] walker %d of %d failed (%s): walked on by the first walker from %u\n", i + 1, K, b.error.c_str(), b.c);
             else if (b.W->invalid) fprintf(stderr, "[agx walk] walker %d of %d gave up (a walk led to position %u, outside [%u, %u)): walked on by the first walker from %u\n", i + 1, K, b.W->gave_up_at, b.W->look_lo, b.W->look_hi, b.c);
             else fprintf(stderr, "[agx walk] walker %d of %d, [%u, %u) after a warm-up from %u: states differ at the meeting point (scan at %u / %u, last record %u..%u / %u..%u, %zu / %zu mark ranges): walked on by the first walker\n",
@@ -728,6 +736,7 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
         for (int t = 0; t + 1 < shares; t++) { const size_t lo = cut[(size_t)t], hi = cut[(size_t)t + 1]; assistant->run([&format, lo, hi] { format(lo, hi); }, t); }
         format(cut[(size_t)shares - 1], all.size());
     }
+    if (timing) fprintf(stderr, "[agx walk] first walker began at %.2f ms\n", tw0 - t_enter);
     if (timing) fprintf(stderr, "[agx walk] %d walkers, %d stretches stood: first stretch %.1f ms, waited %.1f ms for the others, merge %.1f ms, rest %.1f ms, formatting %.1f ms\n", K, stood, tw1 - tw0, tw2 - tw1, tw3 - tw2, tw4 - tw3, clock() - tw4);
     walk_report(A);
     return true;
@@ -894,8 +903,9 @@ void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out, 
     const double ts = now();
     Walker W(V, G);
     std::pmr::monotonic_buffer_resource arena((size_t)8 << 20);      // byte-range lists and trailing k-mers of the written records
-    std::pmr::monotonic_buffer_resource arena2((size_t)1 << 20), arena3((size_t)1 << 20), arena4((size_t)1 << 20), arena5((size_t)1 << 20), arena6((size_t)1 << 20), arena7((size_t)1 << 20), arena8((size_t)1 << 20);     // the other walkers' (walk_split): an arena serves one thread
-    Arena *const more_arenas[GraphView::MAX_COPIES] = {&arena2, &arena3, &arena4, &arena5, &arena6, &arena7, &arena8};
+    std::vector<std::unique_ptr<std::pmr::monotonic_buffer_resource>> others;      // the other walkers' (walk_split): an arena serves one thread (nothing is allocated before its first use)
+    Arena *more_arenas[GraphView::MAX_WALKERS - 1];
+    for (int i = 0; i < GraphView::MAX_WALKERS - 1; i++) { others.emplace_back(new std::pmr::monotonic_buffer_resource((size_t)1 << 20)); more_arenas[i] = others.back().get(); }
     std::vector<Rec> recs; recs.reserve((size_t)G.n_pos / 1024 + 1024);
     double t0 = now();
     if (!walk_split(W, V, G, out.pre_extended, recs, &arena, more_arenas, assistant)) walk(W, out.pre_extended, recs, &arena, assistant);

@@ -313,7 +313,21 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    def thread_cpu():                                   # AGX_BENCH_THREAD_CPU=1 (development aid): CPU seconds of every thread of this process, by thread name
+        out = {}
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                with open("/proc/self/task/%s/stat" % tid) as f:
+                    st = f.read()
+                name = st[st.index("(") + 1:st.rindex(")")]
+                fld = st[st.rindex(")") + 2:].split()
+                out[int(tid)] = (name, (int(fld[11]) + int(fld[12])) / os.sysconf("SC_CLK_TCK"))
+            except (OSError, ValueError):
+                pass
+        return out
+    thr0 = thread_cpu() if os.environ.get("AGX_BENCH_THREAD_CPU") else None
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     gathered = None
     for _ in range(args.steps):
         gathered = run_job()
@@ -321,6 +335,16 @@ def main():
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    cpu_s_per_step = (time.process_time() - cpu0) / max(1, args.steps)      # every thread of this process (walkers, helpers, the runtime's), user + system
+    if thr0 is not None and rank == 0:
+        by_name = {}
+        for tid, (name, sec) in thread_cpu().items():
+            d = sec - thr0.get(tid, (name, 0.0))[1]
+            n, tot = by_name.get(name, (0, 0.0))
+            by_name[name] = (n + 1, tot + d)
+        by_name["(threads that ended: the job's unit threads)"] = (0, cpu_s_per_step * max(1, args.steps) - sum(t for _, t in by_name.values()))
+        for name, (n, tot) in sorted(by_name.items(), key=lambda kv: -kv[1][1]):
+            print("[bench] threads %-16s x%-3d %8.1f ms of CPU per step" % (name, n, 1e3 * tot / max(1, args.steps)), file=sys.stderr)
     tot = torch.tensor([elapsed, t_parse, t_stage, float(my_pairs), t_cached], dtype=torch.float64, device=gdev)
     if dist:
         mx = tot.clone()
@@ -357,7 +381,7 @@ def main():
     # ---- after the timed region, rank 0: kernel sections of the largest unit (exclusive builds with section events) ----
     kern, big_stats = {}, None
     if rank == 0 and mine:
-        big = mine[0]
+        big = max(mine, key=lambda uu: (unit_len[uu], -uu))
         with A.Unit(k=k, insert_variation=50, coverage=args.coverage, device=local_rank, flags=A.AGX_FLAG_TIME_SECTIONS) as ub:
             ub.load_files(tmp, big)
             keys = ("ms_upload_dev", "ms_prep", "ms_bin", "ms_node_sweep", "ms_node_big", "ms_edge_fast", "ms_edge_slow", "ms_compact", "ms_build_span")
@@ -467,6 +491,7 @@ def main():
                        "timed_region": "T_core per step: every unit new to the device (upload + first build + download + host walk), %s memory pools, %s" % (args.pool, "the same units uploaded again every step" if reupload else "a fresh set of one-shot units per step (loaded from the unit caches before the clock)"),
                        "units_in_flight_per_gpu": inflight,
                        "parallelism": "units sharded longest-first over %d GPU%s, one RCCL gather of extended contigs per job" % (world, "" if world == 1 else "s")},
+            "host_cpu_ms_per_step": round(1e3 * cpu_s_per_step, 2),      # CPU time of rank 0's process inside the timed region, per step (a 16-CPU quota gives 16 x ms_per_step)
             "single_gpu_ms_same_config": round(single_ms, 3) if single_ms else None,
             "speedup_vs_1gpu": round(single_ms / (1e3 * sec_per_step), 3) if single_ms else None,
             "t_core_s": round(sec_per_step, 4),

@@ -275,11 +275,11 @@ int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int cover
         }
         // AGX_SIM_ASSISTANT=1: with a second thread for the outputs, as the engine runs it (the written records are formatted while the walk goes on)
         struct ThreadAssistant : Assistant {
-            std::thread t[7];
+            std::thread t[15];
             void run(std::function<void()> f, int who) override { wait(who); t[who] = std::thread(std::move(f)); }
             void wait(int who) override { if (t[who].joinable()) t[who].join(); }
-            int helpers() const override { return 7; }
-            ~ThreadAssistant() override { for (int i = 0; i < 7; i++) wait(i); }
+            int helpers() const override { return 15; }
+            ~ThreadAssistant() override { for (int i = 0; i < 15; i++) wait(i); }
         } second;
         UnitOutput O; walk_join_scaffold(view_of(T, P), G, O, getenv("AGX_SIM_ASSISTANT") ? &second : nullptr);
         out->initial_contigs = dup_buf(T.initial_contigs); out->initial_len = T.initial_contigs.size();

@@ -283,14 +283,14 @@ def test_empty_and_ragged_inputs(agx, built, tmp_path):
 
 
 def test_walk_by_several_walkers_gives_the_same_bytes(agx, built, tmp_path, monkeypatch):
-    """Large units are walked by two to eight walkers (agx_walk.cpp: walk_split; more than four share three copies of the visited bytes): forced here on
+    """Large units are walked by two to sixteen walkers (agx_walk.cpp: walk_split; more than four share three copies of the visited bytes): forced here on
     a small unit, with warm-up stretches that let the other walkers' stretches stand and with some so short that the first walker has to walk on — the
     oracle's bytes either way."""
     run = H.synth(str(tmp_path / "run"), seed=77, chroms="400000", pairs=80000, coverage=4, read_indel=0.2, multi=0.2, contig_overlap=0.3, sam_seq=0)
     tmp = os.path.join(run, "tmp")
     want = H.run_oracle(tmp, 0, 5, 50, 4)
     monkeypatch.setenv("AGX_WALK_SPLIT_MIN", "0")
-    for walkers, warm in (("2", "400000"), ("2", "50000"), ("2", "20"), ("3", "50000"), ("4", "400000"), ("4", "30000"), ("6", "20000"), ("8", "20000"), ("8", "2000")):
+    for walkers, warm in (("2", "400000"), ("2", "50000"), ("2", "20"), ("3", "50000"), ("4", "400000"), ("4", "30000"), ("6", "20000"), ("8", "20000"), ("8", "2000"), ("16", "10000")):
         monkeypatch.setenv("AGX_WALK_SPLIT_WALKERS", walkers)
         monkeypatch.setenv("AGX_WALK_SPLIT_WARMUP", warm)
         for flags in (0, agx.AGX_FLAG_ONE_SHOT):

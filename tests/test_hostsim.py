@@ -237,7 +237,8 @@ def test_more_than_four_walkers_share_three_copies_of_the_visited_bytes(built, t
     for key, val in (("AGX_SIM_ASSISTANT", "1"), ("AGX_SIM_SPLIT", "3"), ("AGX_WALK_SPLIT_MIN", "0"), ("AGX_WALK_TIMING", "1")):
         monkeypatch.setenv(key, val)
     stood = {}
-    for walkers, warm, look in (("5", "40000", None), ("6", "40000", None), ("7", "40000", None), ("8", "40000", None), ("8", "5000", None), ("8", "40000", "60000")):
+    for walkers, warm, look in (("5", "40000", None), ("6", "40000", None), ("7", "40000", None), ("8", "40000", None), ("8", "5000", None), ("8", "40000", "60000"),
+                                ("12", "20000", None), ("16", "20000", None)):
         monkeypatch.setenv("AGX_WALK_SPLIT_WALKERS", walkers)
         monkeypatch.setenv("AGX_WALK_SPLIT_WARMUP", warm)
         if look:
