@@ -147,9 +147,8 @@ const HsaCopy &hsa_copy() { static const HsaCopy h; return h; }
 // positions from which a unit's host walk is split between two walkers (= walk_split's default in agx_walk.cpp; AGX_WALK_SPLIT_MIN, read at every download, overrides both: tests)
 inline size_t two_walkers_min() { const char *e = getenv("AGX_WALK_SPLIT_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4000000; }
 #define AGX_TWO_WALKERS_MIN two_walkers_min()
-// walkers for a unit of n_pos positions (walkers_for, agx_host.h) and the copies of the meta bytes they need: one each up to four walkers, three shared by more
+// walkers for a unit of n_pos positions (walkers_for, agx_host.h)
 inline int walkers_wanted(size_t n_pos) { return n_pos < AGX_TWO_WALKERS_MIN ? 1 : walkers_for(n_pos); }
-inline int meta_copies(size_t n_pos) { const int k = walkers_wanted(n_pos) - 1; return k > GraphView::SHARED_COPIES ? GraphView::SHARED_COPIES : k; }
 
 // One helper thread per unit, started with the unit and asleep until it is handed work: what a unit can prepare while its upload and
 // build run (the pinned download buffers, the output buffers) without its worker waiting for it.  Not started on demand: creating a
@@ -282,7 +281,7 @@ struct agx_unit {
     DBuf<agx_u32> d_chain_end, d_side_xpos, d_sp_cnt, d_sp_rank; DBuf<unsigned long long> d_sp_bits;
     agx_u32 n_chain_end = 0, n_special = 0, n_words = 0;
     // downloaded: the walk graph with its sparse record table (agx_core.h); the full record table stays on the device
-    PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta, h_a_metas[GraphView::MAX_COPIES] /* further copies of the meta bytes for the walk's other walkers (large units) */; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
+    PBuf<char> h_a_str; PBuf<agx_u8> h_a_meta; PBuf<agx_u32> h_side_xpos, h_sp_rank; PBuf<unsigned long long> h_sp_bits;
     PBuf<agx_walknode> h_sp_node, h_fetch; PBuf<agx_edge_ovf> h_a_ovf; PBuf<agx_hop> h_sp_hop; DBuf<agx_hop> d_sp_hop;
     PBuf<agx_u32> h_words;
     agx_u32 n_nodes = 0, n_ovf = 0, n_tiles = 0, n_tile_entries = 0, n_big = 0, n_mid = 0;
@@ -399,13 +398,12 @@ void stage_reference(agx_unit *u, const char *ref, size_t n_pos, unsigned thread
     on_threads(T, [&](unsigned t) { const size_t lo = n_pos * t / T, hi = n_pos * (t + 1) / T; memcpy(u->s_ref.p + lo, ref + lo, hi - lo); });
 }
 // A one-shot unit's download lands in the pinned memory of its staged inputs, which are dead once they are in HBM (do_download).  Since r03 those are packed
-// (wire formats) and smaller than the walk graph of a unit with four walkers: what is missing is pinned here, by estimate (walk ids ~ 1.06 x positions, special
+// (wire formats) and can be smaller than the walk graph: what is missing is pinned here, by estimate (walk ids ~ 1.06 x positions, special
 // ids ~ 8 % of them), while the unit is staged — inside T_core mapping and registering it cost 1 ms per unit.
 void reserve_landing(agx_unit *u) {
     if (!(u->prm.flags & AGX_FLAG_ONE_SHOT)) { u->s_landing.release(); return; }
     const size_t n_pos = u->V.n_pos, ni = n_pos + n_pos / 16 + 4096, ns = ni / 10 + 4096;
-    const size_t copies = (size_t)meta_copies(n_pos);
-    const size_t need = (2 + copies) * (ni + 512) + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + ni / 4 + (4u << 20);
+    const size_t need = 2 * (ni + 512) + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + ni / 4 + (4u << 20);
     const size_t have = u->s_codes.block_bytes() + u->s_hits.block_bytes() + u->s_runs.block_bytes() + u->s_sides.block_bytes() + u->s_other.block_bytes();
     // (a buffer must fit one block: count the blocks at 85 %)
     if (need > have * 85 / 100) u->s_landing.alloc(need - have * 85 / 100 + (ni + 512)); else u->s_landing.release();
@@ -760,7 +758,6 @@ void do_upload(agx_unit *u) {
             if (hipSetDevice(u->prm.device) != hipSuccess) return;
             const size_t ni = n_pos + n_pos / 8 + 4096, nw = ni / 64 + 1, ns = ni / 8 + 4096;
             u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(n_pos / 8 + 4097);
-            for (int w = 0; w < meta_copies(n_pos); w++) u->h_a_metas[w].alloc(ni + 64);
             u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2); u->h_a_ovf.alloc(64);
         } catch (...) { }                               // do_download allocates what is missing and reports
         trace(u, "helper: download buffers", th0, n_pos);
@@ -1001,10 +998,6 @@ void do_download(agx_unit *u) {
     const size_t n_pos = u->V.n_pos, ni = u->n_ids;
     DeviceTurn &turn = turn_of(u->prm.device);
     const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
-    // A large unit is walked by several walkers (agx_walk.cpp: walk_split) on copies of the meta bytes: 0.36-0.6 ms of download per copy, in front of the
-    // walk.  Three copies at most: more than four walkers share them (r03 first gave every walker its own: with up to eight the downloads of a cfg3 job
-    // went from 2.8-5.5 to 6.7-9 ms and the job from 42.3 to 45.4 ms, for walks 1 ms shorter).
-    const int copies = u->helper.started ? meta_copies(n_pos) : 0;
     join_dl_helper(u);
     if (u->prm.flags & AGX_FLAG_ONE_SHOT) {
         // The inputs are in HBM and will not be uploaded again: their staged copies are dead pinned memory.  The download's arrays are cut
@@ -1012,18 +1005,17 @@ void do_download(agx_unit *u) {
         struct Room { char *at; size_t left; } room[6] = {{(char *)u->s_codes.p, u->s_codes.block_bytes()}, {(char *)u->s_hits.p, u->s_hits.block_bytes()}, {(char *)u->s_landing.p, u->s_landing.block_bytes()},
                                                           {(char *)u->s_runs.p, u->s_runs.block_bytes()}, {(char *)u->s_sides.p, u->s_sides.block_bytes()}, {(char *)u->s_other.p, u->s_other.block_bytes()}};
         // (a loan from an earlier download of this unit object must not survive into alloc() below: the memory it names has been handed out again)
-        u->h_sp_node.release(); u->h_a_meta.release(); u->h_a_str.release(); for (auto &b : u->h_a_metas) b.release(); u->h_sp_hop.release(); u->h_side_xpos.release(); u->h_sp_bits.release(); u->h_sp_rank.release(); u->h_a_ovf.release();
+        u->h_sp_node.release(); u->h_a_meta.release(); u->h_a_str.release(); u->h_sp_hop.release(); u->h_side_xpos.release(); u->h_sp_bits.release(); u->h_sp_rank.release(); u->h_a_ovf.release();
         auto cut = [&](auto &buf, size_t count) {
             using T = typename std::remove_reference<decltype(*buf.p)>::type;
             const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
             for (Room &r : room) if (r.at && r.left >= bytes) { buf.borrow((T *)r.at, count); r.at += bytes; r.left -= bytes; return; }
         };
         u->consumed = true; u->staged = false;
-        cut(u->h_sp_node, ns + 1); cut(u->h_a_meta, ni + 64); cut(u->h_a_str, ni + 1); for (int w = 0; w < copies; w++) cut(u->h_a_metas[w], ni + 64); cut(u->h_sp_hop, ns + 2); cut(u->h_side_xpos, nside + 1);
+        cut(u->h_sp_node, ns + 1); cut(u->h_a_meta, ni + 64); cut(u->h_a_str, ni + 1); cut(u->h_sp_hop, ns + 2); cut(u->h_side_xpos, nside + 1);
         cut(u->h_sp_bits, nw + 1); cut(u->h_sp_rank, nw + 1); cut(u->h_a_ovf, (size_t)u->n_ovf + 1);
     }
     u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(nside + 1);
-    for (int w = 0; w < GraphView::MAX_COPIES; w++) { if (w < copies) u->h_a_metas[w].alloc(ni + 64); else u->h_a_metas[w].release(); }
     u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2);
     u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
     // the walk graph into the pinned buffers: plain copy commands on the device's download stream.  (r02 first used a kernel of its own for
@@ -1033,7 +1025,7 @@ void do_download(agx_unit *u) {
     {
         void *dst[24]; const void *src[24]; size_t bytes[24]; int n = 0;
         auto add = [&](void *h, const void *d, size_t b) { if (b) { dst[n] = h; src[n] = d; bytes[n] = b; n++; } };
-        if (ni) { add(u->h_sp_bits.p, u->d_sp_bits.p, nw * 8); add(u->h_sp_rank.p, u->d_sp_rank.p, nw * 4); add(u->h_a_str.p, u->d_a_str.p, ni); add(u->h_a_meta.p, u->d_a_meta.p, ni); for (int w = 0; w < copies; w++) add(u->h_a_metas[w].p, u->d_a_meta.p, ni); }
+        if (ni) { add(u->h_sp_bits.p, u->d_sp_bits.p, nw * 8); add(u->h_sp_rank.p, u->d_sp_rank.p, nw * 4); add(u->h_a_str.p, u->d_a_str.p, ni); add(u->h_a_meta.p, u->d_a_meta.p, ni); }
         add(u->h_side_xpos.p, u->d_side_xpos.p, nside * 4);
         add(u->h_sp_node.p, u->d_sp_node.p, ns * sizeof(agx_walknode)); add(u->h_sp_hop.p, u->d_sp_hop.p, ns * sizeof(agx_hop)); add(u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf));
         bool by_engines = u->dl_sdma && n > 0;
@@ -1055,7 +1047,7 @@ void do_download(agx_unit *u) {
     const double t1 = now_ms();
     HIP_OK(wait_event(u->ev_dl));
     if (getenv("AGX_DL_TIMING")) fprintf(stderr, "[agx download] buffers %.2f ms, copies %.2f ms (%zu ids, %zu records)\n", t1 - t0, now_ms() - t1, ni, ns);
-    memset(u->h_a_meta.p + ni, 0, 64); for (int w = 0; w < copies; w++) memset(u->h_a_metas[w].p + ni, 0, 64);
+    memset(u->h_a_meta.p + ni, 0, 64);
     u->stats.n_walk_ids = ni; u->stats.n_special = ns;
     u->stats.download_bytes = 2 * ni + nw * 12 + nside * 4 + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
     u->downloaded = true;
@@ -1079,7 +1071,7 @@ void do_release(agx_unit *u) {
     u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_cntruns.release(); u->d_cntchunks.release(); u->d_segchunks.release(); u->d_jump.release(); u->d_segindex.release(); u->d_sp_hop.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
     u->d_ovf.release(); u->d_a_ovf.release(); u->d_huge_list.release(); u->d_scratch_huge.release(); u->huge = false; u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
     u->arena.reset();
-    u->h_a_str.release(); u->h_a_meta.release(); for (auto &b : u->h_a_metas) b.release(); u->h_side_xpos.release(); u->h_sp_rank.release(); u->h_sp_bits.release(); u->h_sp_node.release(); u->h_fetch.release(); u->h_a_ovf.release();
+    u->h_a_str.release(); u->h_a_meta.release(); u->h_side_xpos.release(); u->h_sp_rank.release(); u->h_sp_bits.release(); u->h_sp_node.release(); u->h_fetch.release(); u->h_a_ovf.release();
     u->h_sp_hop.release();
     u->pool_cap = u->spill_lo = u->ovf_cap = u->list_cap = u->sp_cap = 0;
     u->uploaded = u->built = u->downloaded = false;
@@ -1106,7 +1098,7 @@ void fetch_records(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u
 
 GraphView view_of(agx_unit *u) {
     GraphView G; G.n_pos = (agx_u32)u->V.n_pos; G.n_ids = u->n_ids;
-    G.meta = u->h_a_meta.p; G.meta_rw = u->h_a_meta.p; for (int w = 0; w < GraphView::MAX_COPIES; w++) G.meta_copy[w] = u->h_a_metas[w].p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
+    G.meta = u->h_a_meta.p; G.meta_rw = u->h_a_meta.p; G.str = u->h_a_str.p; G.side_xpos = u->h_side_xpos.p;
     G.sp_bits = u->h_sp_bits.p; G.sp_rank = u->h_sp_rank.p; G.sp_node = u->h_sp_node.p; G.sp_hop = u->h_sp_hop.p; G.n_special = u->n_special;
     G.fetch = fetch_records; G.fetch_ctx = u;
     G.ovf = u->h_a_ovf.p; G.n_ovf = u->n_ovf; G.row_slot = u->row_slot.empty() ? nullptr : u->row_slot.data();
@@ -1359,7 +1351,7 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
                 else walker_pool().run(pool[who - 1], std::move(f));
             }
             void wait(int who) override { if (who == 0) u->helper.wait(UnitHelper::WALK); else walker_pool().wait(pool[who - 1]); }
-        } second(u, u->h_a_metas[0].p ? walkers_now(u->V.n_pos, behind) - 2 : 0);      // one thread per further walker: the unit's helper + pool threads
+        } second(u, walkers_now(u->V.n_pos, behind) - 2);      // one thread per further walker: the unit's helper + pool threads
         walk_join_scaffold(u->V, view_of(u), u->out, u->helper.started ? &second : nullptr);
         u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = u->out.n_fetched;
         trace(u, "walk", t0, u->V.n_pos);

@@ -80,10 +80,7 @@ struct GraphView {
     agx_u32 n_pos = 0, n_ids = 0;
     const agx_u8 *meta = nullptr;                           // [n_ids + 64] AGX_WM_* bits (padding reads as 0)
     agx_u8 *meta_rw = nullptr;                              // null, or == meta: the walk may keep its visited marks in meta's bit 7 (the array is consumed by the walk)
-    enum { MAX_COPIES = 7, SHARED_COPIES = 3, MAX_WALKERS = 16 };
-    // further copies of meta that the walk may consume as well: a large unit is then walked by several walkers (agx_walk.cpp: walk_split) — one per copy + 1, or,
-    // given SHARED_COPIES copies, any number up to MAX_WALKERS, three walkers apart on the same copy
-    agx_u8 *meta_copy[MAX_COPIES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    enum { MAX_WALKERS = 16 };                              // a large unit is walked by several walkers (agx_walk.cpp: walk_split), each of the further ones on a window of meta that it copies for itself
     const char *str = nullptr;                              // [n_ids] base a node emits
     const agx_u32 *side_xpos = nullptr;                     // [n_ids - n_pos] position of each side id, non-decreasing
     const unsigned long long *sp_bits = nullptr;            // [n_ids/64 + 1] special-id bitmap

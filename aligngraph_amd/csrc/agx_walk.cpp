@@ -559,37 +559,34 @@ inline void clip_marks(const MarkLog &log, agx_u32 main_lo, agx_u32 main_hi, agx
     out.resize(k);
 }
 
-// One speculative walker: its own visited bytes (a pristine copy of the meta bytes), its own arena, its stretch [c, c_next) of the reference
+// One speculative walker: its own visited bytes (a window of the meta bytes, copied while they are pristine), its own arena, its stretch [c, c_next) of the reference
 struct SpecWalker {
-    agx_u32 c = 0, c_next = 0, w0 = 0, side_c = 0, side_next = 0, warm_lo = 0, warm_hi = 0xFFFFFFFFu, look_hi = 0, win_hi = 0, side_win_hi = 0;
+    agx_u32 c = 0, c_next = 0, w0 = 0, side_c = 0, side_next = 0, warm_lo = 0, warm_hi = 0xFFFFFFFFu, look_hi = 0, win_lo = 0, win_hi = 0, side_win_hi = 0, copy_hi = 0, side_copy_lo = 0, side_copy_hi = 0;
+    Scratch bytes;                               // its visited bytes: as long as the table, only the window filled in
     GraphView G; std::unique_ptr<Walker> W; std::unique_ptr<WalkRun> R; std::vector<Rec> recs;
     MarkLog log; size_t n_warm = 0;              // every mark of the warm-up, then the marks of the stretch that reach c_next or further
     WalkState at_c;                              // where it stood when it arrived at c
     bool ok = false; std::string error;
-    double t_run = 0, t_warm = 0, t_done = 0;     // (AGX_WALK_TIMING) when its thread began, arrived at c, arrived at c_next
+    double t_run = 0, t_copy = 0, t_warm = 0, t_done = 0;     // (AGX_WALK_TIMING) when its thread began, had its window, arrived at c, arrived at c_next
 };
 
-// false: not split (too small, no copy of the meta bytes, no assistant): the caller walks the usual way
+// false: not split (too small, no assistant): the caller walks the usual way
 bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena, Arena *const *more_arenas, Assistant *assistant) {
     const agx_u32 min_ref = getenv("AGX_WALK_SPLIT_MIN") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_MIN"), nullptr, 10) : 4000000u;
     const agx_u32 warm = getenv("AGX_WALK_SPLIT_WARMUP") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_WARMUP"), nullptr, 10) : 400000u;
     const agx_u32 n_ref = V.n_ref < G.n_pos ? V.n_ref : G.n_pos;
-    if (!assistant || !G.meta_copy[0] || n_ref < min_ref || n_ref < 16 || getenv("AGX_WALK_NO_SPLIT")) return false;
-    // walkers: one per 1.2 M positions, two to sixteen, as many as there are helper threads.  Up to four walkers each have a copy of the meta bytes of their
-    // own (r02/r03a).  More than four SHARE three copies: walker i works on copy (i-1) % 3 and may only look at positions [c(i-1), c(i+2)) — one stretch
-    // back for its warm-up, its own stretch, one stretch ahead — so the walkers on one copy touch disjoint bytes (walks are local: a record ends at the
-    // next branch, a conti-mer chain lands a contig's length further; one that does lead further makes the walker give up, as a look in front of its
-    // stretch always did).  Copies cost the download 0.4-0.6 ms each, in front of the walk (agx_engine.cpp: do_download): three is what four walkers needed already.
+    if (!assistant || n_ref < min_ref || n_ref < 16 || getenv("AGX_WALK_NO_SPLIT")) return false;
+    // walkers: one per 1.2 M positions, two to sixteen, as many as there are helper threads.  Every further walker works on visited bytes of its own: a
+    // WINDOW of the meta bytes that it copies itself, before anybody walks, from the first walker's still pristine array — two warm-ups (one stretch at
+    // most) back from its stretch, the stretch, one stretch ahead — and it may only look at nodes inside the window (walks are local: a record ends
+    // at the next branch, a conti-mer chain lands a contig's length further; one that does lead further makes the walker give up, as a look in front of
+    // its stretch always did).  r02/r03a downloaded one whole copy of the meta bytes per walker instead: 0.4-0.6 ms of PCIe each in front of the walk,
+    // 37 % of a unit's download with three of them; a window is 3/K of the bytes, copied by K - 1 threads side by side in 0.2-0.4 ms.
     int K = walkers_for(n_ref);
-    int copies = 0; while (copies < GraphView::MAX_COPIES && G.meta_copy[copies]) copies++;
     if (K > 1 + assistant->helpers()) K = 1 + assistant->helpers();
-    if (K > 1 + copies) {                                // (sharing needs three copies and stretches of at least two warm-ups)
-        const int fit = (int)(n_ref / (2ull * warm + 256));
-        if (copies < GraphView::SHARED_COPIES || fit <= 1 + copies) K = 1 + copies; else if (K > fit) K = fit;
-    }
-    if (K < 2) return false;
-    const bool shared = K > 1 + copies;
     const agx_u32 slack = 64;                           // a walker reads a few bytes past the node it stands on (the end of a run, the cont successor)
+    if (K > (int)(n_ref / (8 * slack))) K = (int)(n_ref / (8 * slack));
+    if (K < 2) return false;
     // the first walker has no warm-up to walk: its stretch is longer by one, so that all arrive at about the same time
     const agx_u32 lead = n_ref / (unsigned)K > 4 * warm ? warm : 0;
     auto cut_at = [&](int i) { return i >= K ? n_ref : i <= 0 ? 0 : lead + (agx_u32)((unsigned long long)(n_ref - lead) * (unsigned)i / (unsigned)K); };
@@ -602,30 +599,42 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
 
     const double t_enter = clock();
     std::atomic<bool> cancel{false};
+    std::atomic<int> copied{0};
+    const agx_u8 *const pristine = WA.m;                // (nobody marks it before every window is copied)
     std::vector<SpecWalker> B((size_t)K - 1);
     for (int i = 1; i < K; i++) {
         SpecWalker &b = B[(size_t)i - 1];
         b.c = cut_at(i); b.c_next = cut_at(i + 1);
-        b.w0 = b.c > warm ? b.c - warm : 0; b.side_c = side_of(b.c); b.side_next = side_of(b.c_next);
-        // what it may look at while it warms up / on its stretch, and how far its marks can reach (win_hi: where the next walker on the same bytes begins)
-        b.warm_lo = shared && i > 1 ? cut_at(i - 1) + slack : 0; b.warm_hi = shared && i + 2 < K ? cut_at(i + 2) - slack : 0xFFFFFFFFu;
-        b.look_hi = shared && i + 2 < K ? cut_at(i + 2) - slack : n_ref; b.win_hi = shared && i + 2 < K ? cut_at(i + 2) : n_ref; b.side_win_hi = b.win_hi < n_ref ? side_of(b.win_hi) : side_ref;
-        agx_u8 *const bytes = G.meta_copy[shared ? (i - 1) % GraphView::SHARED_COPIES : i - 1];
-        b.G = G; b.G.meta = bytes; b.G.meta_rw = bytes; for (auto &mc : b.G.meta_copy) mc = nullptr;
+        b.side_c = side_of(b.c); b.side_next = side_of(b.c_next);
+        // its window: main ids [win_lo, win_hi), or to the end of the table (the last two walkers: the appended positions behind the reference too); what it may
+        // look at while it warms up / on its stretch lies `slack` inside
+        const bool open_end = i + 2 >= K;
+        // (behind it: the warm-up and as much again, one stretch at most)
+        const agx_u32 back = 2 * warm + slack < b.c - cut_at(i - 1) ? 2 * warm + slack : b.c - cut_at(i - 1);
+        b.win_lo = b.c - back; b.win_hi = open_end ? n_ref : cut_at(i + 2); b.side_win_hi = open_end ? side_ref : side_of(b.win_hi);
+        b.copy_hi = open_end ? G.n_pos : b.win_hi; b.side_copy_lo = side_of(b.win_lo); b.side_copy_hi = open_end ? G.n_ids : b.side_win_hi;
+        b.warm_lo = b.win_lo ? b.win_lo + slack : 0; b.warm_hi = open_end ? 0xFFFFFFFFu : b.win_hi - slack; b.look_hi = open_end ? n_ref : b.win_hi - slack;
+        b.w0 = b.c > warm ? b.c - warm : 0; if (b.w0 < b.warm_lo) b.w0 = b.warm_lo;
+        b.bytes.take((size_t)G.n_ids + 64);
+        b.G = G; b.G.meta = (const agx_u8 *)b.bytes.p; b.G.meta_rw = (agx_u8 *)b.bytes.p;
         b.W.reset(new Walker(V, b.G));
         b.recs.reserve((size_t)G.n_pos / 2048 + 1024);
         b.R.reset(new WalkRun(*b.W, more_arenas[i - 1], b.recs, nullptr));      // (its lists and k-mer tails live in one of the caller's arenas: they outlive this function, and an arena serves one thread)
     }
-    // they start: warm-up from w0 to c, then the stretch [c, c_next)
+    // they start: copy the window, warm-up from w0 to c, then the stretch [c, c_next)
     struct Join { Assistant *a; int n; std::atomic<bool> &c; std::vector<bool> joined; void now(int i) { if (!joined[(size_t)i]) { a->wait(i); joined[(size_t)i] = true; } } ~Join() { c.store(true); for (int i = 0; i < n; i++) now(i); } } join{assistant, K - 1, cancel, std::vector<bool>((size_t)K - 1, false)};
     for (int i = 1; i < K; i++) {
         SpecWalker *bp = &B[(size_t)i - 1];
-        assistant->run([bp, &cancel, &G, n_ref, side_ref] {
+        assistant->run([bp, &cancel, &copied, pristine, &G, n_ref, side_ref] {
             SpecWalker &b = *bp; Walker &W = *b.W; WalkRun &R = *b.R;
             auto clk = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
             b.t_run = clk();
+            struct Copied { std::atomic<int> &n; bool done = false; void now() { if (!done) { done = true; n.fetch_add(1, std::memory_order_release); } } ~Copied() { now(); } } copied_mark{copied};      // (the first walker waits for this count whatever happens here)
             try {
-                W.spec = true; W.look_lo = b.warm_lo; W.look_hi = b.warm_hi;      // (looks anywhere during the warm-up, unless it shares its bytes)
+                memcpy(W.m + b.win_lo, pristine + b.win_lo, (size_t)b.copy_hi - b.win_lo);
+                memcpy(W.m + b.side_copy_lo, pristine + b.side_copy_lo, (size_t)b.side_copy_hi - b.side_copy_lo + (b.side_copy_hi == G.n_ids ? 64 : 0));      // (+ the padding behind the table)
+                copied_mark.now(); b.t_copy = clk();
+                W.spec = true; W.look_lo = b.warm_lo; W.look_hi = b.warm_hi;
                 R.cancel = &cancel; R.st.cp = b.w0; R.keep = false; R.log = &b.log; R.log_main = 0; R.log_side = G.n_pos;
                 R.go(b.c);                                  // warm-up: decides records, keeps none; every mark is logged
                 b.at_c = R.st; b.n_warm = b.log.size(); b.t_warm = clk();
@@ -641,6 +650,12 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
                 b.ok = !W.invalid && !cancel.load() && R.st.cp >= b.c_next; b.t_done = clk();
             } catch (const Error &e) { b.error = e.msg; } catch (const std::exception &e) { b.error = e.what(); }
         }, i - 1);
+    }
+    // (the first walker's bytes are the source of the windows: it walks when they are all taken)
+    while (copied.load(std::memory_order_acquire) < K - 1) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
     }
 
     const double tw0 = clock();
@@ -664,7 +679,7 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
             same = ma == mb;
         }
         if (timing) {
-            if (same) fprintf(stderr, "[agx walk] walker %d of %d, [%u, %u) after a warm-up from %u: its stretch stands (began at %.2f ms, warm-up %.2f ms, stretch %.2f ms)\n", i + 1, K, b.c, b.c_next, b.w0, b.t_run - t_enter, b.t_warm - b.t_run, b.t_done - b.t_warm);
+            if (same) fprintf(stderr, "[agx walk] walker %d of %d, [%u, %u) after a warm-up from %u: its stretch stands (began at %.2f ms, window %.2f ms, warm-up %.2f ms, stretch %.2f ms)\n", i + 1, K, b.c, b.c_next, b.w0, b.t_run - t_enter, b.t_copy - b.t_run, b.t_warm - b.t_copy, b.t_done - b.t_warm);
             else if (!b.error.empty()) fprintf(stderr, "[agx walk] walker %d of %d failed (%s): walked on by the first walker from %u\n", i + 1, K, b.error.c_str(), b.c);
             else if (b.W->invalid) fprintf(stderr, "[agx walk] walker %d of %d gave up (a walk led to position %u, outside [%u, %u)): walked on by the first walker from %u\n", i + 1, K, b.W->gave_up_at, b.W->look_lo, b.W->look_hi, b.c);
             else fprintf(stderr, "[agx walk] walker %d of %d, [%u, %u) after a warm-up from %u: states differ at the meeting point (scan at %u / %u, last record %u..%u / %u..%u, %zu / %zu mark ranges): walked on by the first walker\n",
@@ -681,8 +696,10 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     for (int i = stood; i < K - 1; i++) join.now(i);
     const double tw2 = clock();
     // what stands: the records behind A's, numbered on; the marks into A's bytes (the appended positions — and whatever did not stand — are walked on those).
-    // The walkers' threads are idle now: each merges its own walker's marks (disjoint ranges of A's bytes), this thread the last one's.
-    {
+    // The walkers' threads are idle now: each merges its own walker's marks (disjoint ranges of A's bytes), this thread the last one's.  (Nothing is
+    // merged when nobody will look: every stretch stood and no unvisited node is left at the appended positions behind the reference — only the first
+    // walker's bytes can say so: the others never mark there.)
+    if (!(stood == K - 1 && WA.next_live(n_ref, G.n_pos) >= G.n_pos && WA.next_live(side_ref, G.n_ids) >= G.n_ids)) {
         auto merge = [&WA](const agx_u8 *src, agx_u32 lo, agx_u32 hi) {
             agx_u32 v = lo;
             for (; v < hi && (v & 7u); v++) WA.m[v] |= (agx_u8)(src[v] & AGX_WM_VISITED);
@@ -736,7 +753,7 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
         for (int t = 0; t + 1 < shares; t++) { const size_t lo = cut[(size_t)t], hi = cut[(size_t)t + 1]; assistant->run([&format, lo, hi] { format(lo, hi); }, t); }
         format(cut[(size_t)shares - 1], all.size());
     }
-    if (timing) fprintf(stderr, "[agx walk] first walker began at %.2f ms\n", tw0 - t_enter);
+    if (timing) fprintf(stderr, "[agx walk] first walker began at %.2f ms; %u appended positions behind the reference\n", tw0 - t_enter, G.n_pos - n_ref);
     if (timing) fprintf(stderr, "[agx walk] %d walkers, %d stretches stood: first stretch %.1f ms, waited %.1f ms for the others, merge %.1f ms, rest %.1f ms, formatting %.1f ms\n", K, stood, tw1 - tw0, tw2 - tw1, tw3 - tw2, tw4 - tw3, clock() - tw4);
     walk_report(A);
     return true;

@@ -261,8 +261,6 @@ int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int cover
         simulate(T, P, (agx_u32)k, iv, coverage, maxv_first > 0 ? (agx_u32)maxv_first : AGX_MAXV_LDS, S, nbig);
         GraphView G; G.n_pos = (agx_u32)T.ref.size(); G.n_ids = S.n_ids;
         G.meta = S.a_meta.data(); G.str = S.a_str.data(); G.side_xpos = S.side_xpos.data();
-        std::vector<agx_u8> meta_copy[3];                        // AGX_SIM_SPLIT=n: n (1..3) further copies of the meta bytes, so that the walk is done by n + 1 walkers — or, with three copies, by up to eight that share them (needs AGX_SIM_ASSISTANT=1)
-        if (const char *e = getenv("AGX_SIM_SPLIT")) for (int i = 0; i < 3 && i < atoi(e); i++) { meta_copy[i] = S.a_meta; G.meta_copy[i] = meta_copy[i].data(); }
         G.sp_bits = S.sp_bits.data(); G.sp_rank = S.sp_rank.data(); G.sp_node = S.sp_node.data(); G.sp_hop = S.sp_hop.data(); G.n_special = S.n_special;
         G.fetch = [](void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *o) {
             for (agx_u32 r = 0; r < rows; r++) for (agx_u32 c = 0; c < width; c++) { const SimGraph *g = (const SimGraph *)ctx; const size_t a = (size_t)first + (size_t)r * stride + c; if (a >= g->n_ids) throw Error{E_ARG, "record fetch beyond the walk graph"}; o[(size_t)r * width + c] = agx_walk_record(g->walk_args, (agx_u32)a); }
