@@ -587,8 +587,9 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     const agx_u32 slack = 64;                           // a walker reads a few bytes past the node it stands on (the end of a run, the cont successor)
     if (K > (int)(n_ref / (8 * slack))) K = (int)(n_ref / (8 * slack));
     if (K < 2) return false;
-    // the first walker has no warm-up to walk: its stretch is longer by one, so that all arrive at about the same time
-    const agx_u32 lead = n_ref / (unsigned)K > 4 * warm ? warm : 0;
+    // the first walker has no window to copy and no warm-up to walk (which goes at half the speed of a stretch: cold memory, every mark logged): its stretch is
+    // longer by two warm-ups, so that all arrive at about the same time
+    const agx_u32 lead = n_ref / (unsigned)K > 4 * warm ? 2 * warm : 0;
     auto cut_at = [&](int i) { return i >= K ? n_ref : i <= 0 ? 0 : lead + (agx_u32)((unsigned long long)(n_ref - lead) * (unsigned)i / (unsigned)K); };
     const agx_u32 n_side = G.n_ids - G.n_pos;
     auto side_of = [&](agx_u32 x) { return G.n_pos + (agx_u32)(std::lower_bound(G.side_xpos, G.side_xpos + n_side, x) - G.side_xpos); };
