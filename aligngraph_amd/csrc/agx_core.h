@@ -250,13 +250,14 @@ AGX_HD agx_u32 agx_idx0_pos(const agx_hit &h, const agx_run *runs) {     // posi
 
 // A later hit of a pair whose mate1 lands within a read length of an earlier hit of the same pair is dropped (AG:1650-1655).  hits[] is in
 // file order (the hits of a pair are neighbours): hit_prep evaluates it per hit.
-AGX_HD bool agx_hit_dup(const agx_hit *hits, const agx_run *runs, agx_u32 h) {
-    const agx_hit &H = hits[h];
+template <class GET> AGX_HD bool agx_hit_dup_by(GET hit_at, const agx_run *runs, agx_u32 h) {      // hit_at(i): hit i (the device unpacks the wire format on the way)
+    const agx_hit H = hit_at(h);
     const agx_u32 me = agx_idx0_pos(H, runs);
     for (agx_u32 e = 1; e <= H.back; e++)
-        if (agx_absdiff(me, agx_idx0_pos(hits[h - e], runs)) < (int)H.len) return true;
+        if (agx_absdiff(me, agx_idx0_pos(hit_at(h - e), runs)) < (int)H.len) return true;
     return false;
 }
+AGX_HD bool agx_hit_dup(const agx_hit *hits, const agx_run *runs, agx_u32 h) { return agx_hit_dup_by([hits](agx_u32 i) { return hits[i]; }, runs, h); }
 
 // Which mate is the LEFT one ("a": the mate whose aligned indices emit the events, AG:1644, 1672-1679)?  true = mate2: some read index below
 // L - k is aligned in both mates with mate1's position beyond mate2's.  Decided where the arrays are packed (the engine's staging): only

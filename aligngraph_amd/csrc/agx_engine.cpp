@@ -263,7 +263,7 @@ struct agx_unit {
     bool pairs_staged = false;          // the fast loader has written hits, runs, codes and the list of other bases straight into the staged buffers
     // inputs on the device
     DBuf<agx_u32> d_cm_start, d_cm_cnt; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref; DBuf<agx_cmseg> d_segs; DBuf<unsigned long long> d_up_desc;
-    DBuf<agx_hit> d_hits; DBuf<agx_run> d_runs; DBuf<agx_u8> d_codes, d_vcodes; DBuf<unsigned long long> d_other;
+    DBuf<agx_run> d_runs; DBuf<agx_u8> d_codes, d_vcodes; DBuf<unsigned long long> d_other;
     DBuf<agx_cntrun> d_cntruns; DBuf<agx_chunk> d_cntchunks, d_segchunks; DBuf<agx_u32> d_jump, d_segindex;
     DBuf<agx_whit> d_whits; DBuf<agx_wside> d_wsides; DBuf<agx_wrun> d_wruns; DBuf<agx_u8> d_wref; DBuf<agx_refx> d_refx;      // what was uploaded, until the first build has expanded it
     // derived
@@ -271,7 +271,7 @@ struct agx_unit {
     // node table
     agx_u32 pool_cap = 0, spill_lo = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
     DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
-    DBuf<agx_u32> d_node_start, d_slow_list, d_rank4; DBuf<agx_u8> d_node_cnt, d_pos_succ;
+    DBuf<agx_u32> d_node_start, d_slow_list, d_rank4, d_slots; agx_u32 slot_cap = 0; DBuf<agx_u8> d_node_cnt, d_pos_succ;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch, d_huge_list, d_scratch_huge; bool huge = false;      // huge: pass 3 of the node sweep is queued (a build met a position beyond AGX_MAXV_BIG variants)
     // walk graph (agx_core.h "walk preparation")
@@ -338,7 +338,7 @@ void join_dl_helper(agx_unit *u);
 void drop_outputs(agx_unit *u);     // before a unit's inputs change: the helper that prepares the output buffers reads them
 void start_helper(agx_unit *u);
 
-enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_RANKOVF = 6, W_MIDCOUNT = 7, W_JUMPCOUNT = 8, W_SPILL = 9, W_HUGECOUNT = 10, W_N = 11 };
+enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_RANKOVF = 6, W_SLOTOVF = 7 /* (behind W_RANKOVF: tile_sort reads the pair) */, W_MIDCOUNT = 8, W_JUMPCOUNT = 9, W_SPILL = 10, W_HUGECOUNT = 11, W_N = 12 };
 
 void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     memset(&S, 0, sizeof S);
@@ -657,7 +657,7 @@ void do_release(agx_unit *u);
 
 // Capacities of a unit's first build and the HBM they add up to (what do_upload reserves as one block; AlignGraph_amd admits a unit to a device by it:
 // agx_unit_hbm_needed).  From the staged counts: positions, hits, runs, conti-mers, read rows.
-struct Plan { agx_u32 pool_cap, list_cap, ovf_cap, sp_cap; size_t total; };
+struct Plan { agx_u32 pool_cap, list_cap, ovf_cap, sp_cap, slot_cap; size_t total; };
 Plan plan_capacities(const agx_unit *u) {
     const size_t n_pos = u->V.n_pos, nh = u->nh;
     const agx_u32 n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE), n_regions = (n_tiles + AGX_REGION_TILES - 1) / AGX_REGION_TILES;
@@ -669,13 +669,15 @@ Plan plan_capacities(const agx_unit *u) {
     const double per_hit = 1.0 + (u->maxlen > u->prm.k ? (double)(u->maxlen - u->prm.k) : 0.0) / AGX_TILE;
     P.list_cap = u->list_cap ? u->list_cap : (agx_u32)std::min<double>(g_tiny ? (double)nh / 2 + 16 : (double)nh * per_hit * 1.1 + 4096, 4.0e9);
     P.ovf_cap = u->ovf_cap ? u->ovf_cap : (g_tiny ? 4u : 1u << 16);
+    // slots of a tile's own list (hit_prep): a power of two above twice the average list, 32 to 256 (lists beyond it go through bin_fill: agx_kargs.h)
+    {   const double avg = n_tiles ? (double)nh * per_hit / n_tiles : 0.0; agx_u32 c = 32; while (c < 256 && c < 2.2 * avg) c <<= 1; P.slot_cap = g_tiny ? 2u : c; }
     const size_t ids_cap = n_pos + P.pool_cap;
     P.sp_cap = u->sp_cap ? u->sp_cap : (agx_u32)std::min<size_t>(g_tiny ? 32 : ids_cap / 4 + 4096, 0xFFFFFF00ull);      // special ids: 8 % on the bench unit
     // what the takes of do_upload add up to, plus the alignment of ~90 buffers
-    const size_t per_pos = 4 + 16 + 1 + 4 + 1 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_hit) + sizeof(agx_dhit) + 16 + 4;
+    const size_t per_pos = 4 + 16 + 1 + 4 + 1 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_dhit) + 16 + 4;
     const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
     const size_t wire = nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 + (u->ref_packed ? n_pos / 4 + u->n_refx * sizeof(agx_refx) : 0) + 4096;
-    const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases + u->n_other * 8 +
+    const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + (size_t)n_tiles * P.slot_cap * 4 + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases + u->n_other * 8 +
                          (size_t)P.pool_cap * per_slot + ids_cap * per_id + (size_t)P.list_cap * 36 + (size_t)P.ovf_cap * 16 + (size_t)P.sp_cap * (sizeof(agx_walknode) + sizeof(agx_hop)) +
                          (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64 * 4 + (size_t)n_regions * AGX_REGION_PAD * 4 + (64u << 10) * 100;
     P.total = total + total / 64;
@@ -704,10 +706,11 @@ void do_upload(agx_unit *u) {
     DevArena &a = u->arena;
     u->d_cm_start.alloc(a, n_pos + 2); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos + 16); u->d_cm_head.alloc(a, n_pos + 1);
     u->d_segs.alloc(a, u->n_segs + 1); u->d_cntruns.alloc(a, u->n_cntruns + 1); u->d_cntchunks.alloc(a, u->n_cntchunks + 1); u->d_segchunks.alloc(a, u->n_segchunks + 1); u->d_segindex.alloc(a, u->n_segindex + 1);
-    u->d_hits.alloc(a, nh + 1); u->d_runs.alloc(a, u->n_runs + 1); u->d_codes.alloc(a, u->n_codes + 16); u->d_vcodes.alloc(a, n_bases + 16); u->d_other.alloc(a, u->n_other + 1);
+    u->d_runs.alloc(a, u->n_runs + 1); u->d_codes.alloc(a, u->n_codes + 16); u->d_vcodes.alloc(a, n_bases + 16); u->d_other.alloc(a, u->n_other + 1);
     u->d_whits.alloc(a, nh + 1); u->d_wsides.alloc(a, u->n_sides + 1); u->d_wruns.alloc(a, u->n_runs + 1); u->d_jump.alloc(a, u->n_jump + 1);
     if (u->ref_packed) { u->d_wref.alloc(a, (n_pos + 3) / 4 + 32); u->d_refx.alloc(a, u->n_refx + 1); }
     u->d_dhit.alloc(a, nh + 1); u->d_rank4.alloc(a, 4 * (nh + 1));
+    u->slot_cap = plan.slot_cap; u->d_slots.alloc(a, (size_t)u->n_tiles * u->slot_cap + 1);
     u->d_tile_cnt.alloc(a, (size_t)u->n_tiles + 1); u->d_tile_off.alloc(a, (size_t)u->n_tiles + 2); u->d_cursor.alloc(a, (size_t)u->n_tiles + 1);
     u->d_words.alloc(a, W_N + 6 + 16); u->h_words.alloc(W_N + 6 + 16);
     u->d_chain_end.alloc(a, (size_t)u->n_chain_end + 1);
@@ -829,7 +832,7 @@ void do_build(agx_unit *u) {
         if (turn.n) HIP_OK(hipStreamWaitEvent(st, (u->ev.all || turn.prev_exclusive) ? turn.build_done[(turn.n - 1) & 1] : turn.sweep_done[(turn.n - 1) & 1], 0));
         if (u->ev.all) HIP_OK(hipEventRecord(u->ev.first, st));      // (every event record costs the stream a few microseconds: untimed builds record only what orders them)
         if (!u->expanded) {   // the unit's first build: the hits and runs out of their wire forms, then the conti-mer tables from their runs (agx_cmseg: count per position, scan, keys, heads); the read bases follow behind the binning
-            agx_launch_expand_hits(u->d_whits.p, u->d_wsides.p, u->d_wruns.p, u->d_hits.p, u->d_runs.p, nh, (agx_u32)u->n_runs, st);
+            agx_launch_expand_runs(u->d_wruns.p, u->d_runs.p, (agx_u32)u->n_runs, st);
             agx_launch_cm_tables(u->d_cntruns.p, u->d_cntchunks.p, (agx_u32)u->n_cntchunks, u->d_segs.p, u->d_segchunks.p, (agx_u32)u->n_segchunks, u->d_cm_start.p, u->d_cm.p, u->d_cm_head.p, n_pos, (agx_u32)u->n_cm, st);
         }
         {   // everything a build counts into or marks, zeroed by one kernel and one fill (every command on the stream costs a few microseconds)
@@ -843,16 +846,17 @@ void do_build(agx_unit *u) {
         }
         // ---- hit_prep + tile histogram ----
         u->ev.begin(); u->ev.mark(B_START, st);
-        agx_prep_args PA{u->d_hits.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
+        agx_prep_args PA{(const agx_whit *)u->d_whits.p, (const agx_wside *)u->d_wsides.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF,
+                         u->d_slots.p, u->slot_cap, u->d_words.p + W_SLOTOVF};
         agx_launch_hit_prep(&PA, st);
         AGX_CHECKPOINT("hit_prep");
         u->ev.mark(B_PREP, st);
         // ---- tile lists ----
         if (g_scan1) agx_launch_exclusive_scan1(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_desc.p, st);
         else agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
-        agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, (const uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF};
-        agx_launch_bin_fill(&BA, st);
-        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, u->d_runs.p, u->prm.k, st);
+        agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, (const uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF, u->d_words.p + W_SLOTOVF};
+        agx_launch_bin_fill(&BA, st);                   // (returns at once unless a list outgrew its tile's slots)
+        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, u->d_runs.p, u->prm.k, u->d_slots.p, u->slot_cap, u->d_words.p + W_RANKOVF, st);
         AGX_CHECKPOINT("tile_sort");
         if (!u->expanded) {   // the vote codes (and the region layout, the last copy of the upload) are first needed by the sweep
             const size_t n_bases = u->n_codes * 4;
@@ -1064,11 +1068,11 @@ void do_release(agx_unit *u) {
     join_dl_helper(u);                                 // (it fills the download buffers released below)
     if (u->uploaded) { (void)hipSetDevice(u->prm.device); (void)hipEventSynchronize(u->ev_uploaded); (void)hipEventSynchronize(u->ev_built); (void)hipEventSynchronize(u->ev_dl); }      // (its commands are done before its memory goes)
     for (auto *b : {&u->d_cm_start, &u->d_tile_cnt, &u->d_tile_off, &u->d_cursor, &u->d_unsorted, &u->d_tile_recs, &u->d_scan_tmp, &u->d_words, &u->d_pool_cnt, &u->d_region_off, &u->d_node_start,
-                    &u->d_slow_list, &u->d_rank4, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
+                    &u->d_slow_list, &u->d_rank4, &u->d_slots, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     for (auto *b : {&u->d_node_cnt, &u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
     u->d_other.release(); u->d_whits.release(); u->d_wsides.release(); u->d_wruns.release(); u->d_wref.release(); u->d_refx.release();
-    u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_cntruns.release(); u->d_cntchunks.release(); u->d_segchunks.release(); u->d_jump.release(); u->d_segindex.release(); u->d_sp_hop.release(); u->d_hits.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
+    u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_cntruns.release(); u->d_cntchunks.release(); u->d_segchunks.release(); u->d_jump.release(); u->d_segindex.release(); u->d_sp_hop.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
     u->d_ovf.release(); u->d_a_ovf.release(); u->d_huge_list.release(); u->d_scratch_huge.release(); u->huge = false; u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
     u->arena.reset();
     u->h_a_str.release(); u->h_a_meta.release(); u->h_side_xpos.release(); u->h_sp_rank.release(); u->h_sp_bits.release(); u->h_sp_node.release(); u->h_fetch.release(); u->h_a_ovf.release();

@@ -4,16 +4,19 @@
 #include "agx_core.h"
 
 struct agx_prep_args {
-    const agx_hit *hits;      // [n_hits] in SAM file order: a hit's number is its place in the file, the order the tile lists are sorted into
+    const agx_whit *whits; const agx_wside *sides;      // [n_hits] wire records in SAM file order: a hit's number is its place in the file, the order the tile lists are sorted into
     const agx_run *runs; agx_dhit *dhit; agx_u32 n_hits, k, n_pos;
     agx_u32 *tile_cnt;        // [n_tiles] number of hits overlapping each tile
     agx_u32 *err;             // bit 0: same-strand mates; bit 1: alignment beyond the unit sequence
     uint4 *rank4;             // [n_hits] what the histogram's atomicAdd returned for the hit's first four tiles = its slot in each tile's list
     agx_u32 *rank_overflow;   // set when some hit spans more than four tiles: the lists are then filled with a second round of atomics
+    // The tile lists without a second pass over the hits: every tile has slot_cap slots of its own and the rank IS the slot.  A list that outgrows its slots
+    // (slot_overflow) — or a hit beyond four tiles — sends the build through bin_fill's dense lists instead, as before r03.
+    agx_u32 *slots; agx_u32 slot_cap; agx_u32 *slot_overflow;
 };
 
 struct agx_bin_args { const agx_dhit *dhit; agx_u32 n_hits; const agx_u32 *tile_off; agx_u32 *cursor; agx_u32 *unsorted; agx_u32 cap;   // cap: entries the lists can hold
-                      const uint4 *rank4; const agx_u32 *rank_overflow; };
+                      const uint4 *rank4; const agx_u32 *rank_overflow; const agx_u32 *slot_overflow; };
 
 struct agx_node_kargs {
     agx_sweep_args S;
@@ -50,14 +53,15 @@ void agx_launch_cm_tables(const void *cnt_runs, const void *cnt_chunks, agx_u32 
                            agx_u32 *cm_start, agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, agx_u32 n_cm, hipStream_t);      // cm_start[n_pos + 1], cm, n_pos + 1 heads from the count runs and the conti-mer runs (agx_core.h: agx_cntrun, agx_chunk)
 void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t);      // n_pos + 1 heads
 void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16, const unsigned long long *other, size_t n_other, hipStream_t);      // 2-bit base classes (agx_pack_classes2) + the listed other bases -> agx_vote_code bytes; n_bases16 a multiple of 16
-void agx_launch_expand_hits(const void *whits, const void *sides, const void *wruns, agx_hit *hits, agx_run *runs, agx_u32 n_hits, agx_u32 n_runs, hipStream_t);      // wire formats (agx_core.h) -> working arrays
+void agx_launch_expand_runs(const void *wruns, agx_run *runs, agx_u32 n_runs, hipStream_t);      // wire formats (agx_core.h) -> working arrays
 void agx_launch_expand_ref(const void *packed, void *ref, size_t n_pos16, const void *refx, agx_u32 n_refx, hipStream_t);      // 2-bit reference bases + the stretches of other bytes -> letters; n_pos16 a multiple of 16
 void agx_launch_hit_prep(const agx_prep_args *, hipStream_t);
 // exclusive scan of in[0..n] (n+1 entries, in[n] must be 0) into out[0..n]; out[n] = total
 void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u32 *tmp, hipStream_t);
 void agx_launch_exclusive_scan1(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsigned long long *desc, hipStream_t);      // one launch; desc: ceil((n+1)/4096) zeroed words
 void agx_launch_bin_fill(const agx_bin_args *, hipStream_t);
-void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, const agx_run *runs, agx_u32 k, hipStream_t);
+void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, const agx_run *runs, agx_u32 k,
+                          const agx_u32 *slots, agx_u32 slot_cap, const agx_u32 *dense /* two words: rank_overflow, slot_overflow */, hipStream_t);
 void agx_launch_node_sweep(const agx_node_kargs *, hipStream_t);
 void agx_launch_node_sweep_big(const agx_node_kargs *, hipStream_t);
 void agx_launch_edge_sweep(const agx_edge_kargs *, hipStream_t);                   // pass A (lanes = positions)

@@ -112,9 +112,8 @@ __global__ void __launch_bounds__(256) agx_k_patch_codes(const unsigned long lon
 }
 
 // ---- the packed upload -> the working arrays (agx_core.h "wire formats"): head of a unit's first build ---------------------------------
-__global__ void __launch_bounds__(256) agx_k_expand_hits(const agx_whit *whits, const agx_wside *sides, const agx_wrun *wruns, agx_hit *hits, agx_run *runs, agx_u32 n_hits, agx_u32 n_runs) {
+__global__ void __launch_bounds__(256) agx_k_expand_runs(const agx_wrun *wruns, agx_run *runs, agx_u32 n_runs) {
     const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n_hits) hits[i] = agx_unpack_hit(whits[i], sides);
     if (i < n_runs) { const agx_wrun r = wruns[i]; runs[i] = agx_run{r.q, r.t, r.n}; }
 }
 // 16 positions per thread: one packed word in, sixteen letters out
@@ -144,8 +143,11 @@ __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
     const bool mine = h < A.n_hits;
     agx_dhit d; d.flags = AGX_HF_SKIP; d.x_lo = 1; d.x_hi = 0; d.a_nruns = 0;
     if (mine) {
-        const agx_hit H = A.hits[h];
-        const int rc = agx_hit_prep(H, H.back != 0 && agx_hit_dup(A.hits, A.runs, h), (H.pad[0] & 1u) != 0, H.slot1, A.runs, A.k, d);      // staged hit: slot1 = row of the a mate's bases
+        // the hit straight from its wire record (16 bytes, + 12 for the one in ten with a multi-run mate): r03 first expanded the records into an array of
+        // 40-byte hits that only this kernel ever read
+        const agx_whit *wh = A.whits; const agx_wside *sd = A.sides;
+        const agx_hit H = agx_unpack_hit(wh[h], sd);
+        const int rc = agx_hit_prep(H, H.back != 0 && agx_hit_dup_by([wh, sd](agx_u32 i) { return agx_unpack_hit(wh[i], sd); }, A.runs, h), (H.pad[0] & 1u) != 0, H.slot1, A.runs, A.k, d);      // staged hit: slot1 = row of the a mate's bases
         if (rc) atomicOr(A.err, 1u);
         if (!(d.flags & AGX_HF_SKIP) && (d.x_hi >= A.n_pos || d.x_lo > d.x_hi)) { atomicOr(A.err, 2u); d.flags |= AGX_HF_SKIP; }
     }
@@ -176,7 +178,12 @@ __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
         if (pend[s] && lane == lead[s]) base[s] = atomicAdd(&A.tile_cnt[t], (agx_u32)__popcll(p));
 #endif
     }
-    for (agx_u32 s = 0; s < 4; s++) { const agx_u32 bs = (agx_u32)__shfl((int)base[s], (int)lead[s], 64); r[s] = pend[s] ? r[s] + bs : 0u; }
+    bool over = false;
+    for (agx_u32 s = 0; s < 4; s++) {
+        const agx_u32 bs = (agx_u32)__shfl((int)base[s], (int)lead[s], 64); r[s] = pend[s] ? r[s] + bs : 0u;
+        if (pend[s]) { if (r[s] < A.slot_cap) A.slots[(size_t)(t0 + s) * A.slot_cap + r[s]] = h; else over = true; }      // the rank is the hit's slot in the tile's own list
+    }
+    if (__ballot(over) != 0ull && lane == 0) atomicOr(A.slot_overflow, 1u);
     if (kept && t1 - t0 >= 4) {                                              // spans more than four tiles: count the rest, and tell bin_fill to take its own slots
         for (agx_u32 t = t0 + 4; t <= t1; t++) atomicAdd(&A.tile_cnt[t], 1u);
         atomicOr(A.rank_overflow, 1u);
@@ -270,10 +277,13 @@ __global__ void __launch_bounds__(256) agx_k_scan_lookback(const agx_u32 *in, ag
 // ---- tile lists: scatter, then rank-sort each list so that hits are applied in SAM order ---------------------------
 __global__ void __launch_bounds__(256) agx_k_bin_fill(agx_bin_args A) {
     const agx_u32 h = blockIdx.x * 256u + threadIdx.x;
+    // (nothing to do where every list fitted the tiles' own slots: hit_prep has filled them)
+    const int ro = __builtin_amdgcn_readfirstlane((int)*A.rank_overflow);
+    if (ro == 0 && __builtin_amdgcn_readfirstlane((int)*A.slot_overflow) == 0) return;
     if (h >= A.n_hits) return;
     const agx_dhit d = A.dhit[h];
     if (d.flags & AGX_HF_SKIP) return;
-    if (__builtin_amdgcn_readfirstlane((int)*A.rank_overflow) == 0) {
+    if (ro == 0) {
         const uint4 r4 = A.rank4[h]; const agx_u32 r[4] = {r4.x, r4.y, r4.z, r4.w}; agx_u32 i = 0;
         for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++, i++) { const agx_u32 at = A.tile_off[t] + r[i & 3u]; if (at < A.cap) A.unsorted[at] = h; }
     } else      // some hit spans more than four tiles (reads beyond ~190 bases, long deletions): every hit takes its slots from a second counter
@@ -292,14 +302,17 @@ __device__ __forceinline__ void agx_put_rec(uint4 *recs, agx_u32 at, const agx_d
 }
 // (list entries are hit numbers = places in the SAM file: the sort key)
 __global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap,
-                                                       const agx_dhit *dhit, uint4 *recs, const agx_run *runs, agx_u32 k) {
+                                                       const agx_dhit *dhit, uint4 *recs, const agx_run *runs, agx_u32 k,
+                                                       const agx_u32 *slots, agx_u32 slot_cap, const agx_u32 *dense /* [2]: rank_overflow, slot_overflow */) {
     __shared__ agx_u32 sh[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
     if (tile >= n_tiles) return;
     const agx_u32 lo = tile_off[tile], n = tile_off[tile + 1] - lo;
     if (tile_off[tile + 1] > cap) return;                // lists did not fit: the host grows them and re-runs
-    const agx_u32 *src = unsorted + lo;
+    // the tile's own slots (hit_prep), or bin_fill's dense lists if some list outgrew its slots
+    const bool own = (__builtin_amdgcn_readfirstlane((int)dense[0]) | __builtin_amdgcn_readfirstlane((int)dense[1])) == 0;
+    const agx_u32 *src = own ? slots + (size_t)tile * slot_cap : unsorted + lo;
     if (n <= AGX_SORT_LDS) {
         for (agx_u32 i = lane; i < n; i += 64) sh[wave][i] = src[i];
         // single wavefront: LDS writes above are visible to its own later reads after the implicit waitcnt
@@ -703,9 +716,8 @@ void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16,
     if (n16) hipLaunchKernelGGL(agx_k_expand_codes, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const agx_u32 *)packed, (uint4 *)vcodes, n16);
     if (n_other) hipLaunchKernelGGL(agx_k_patch_codes, dim3((unsigned)((n_other + 255) / 256)), dim3(256), 0, st, other, n_other, (agx_u8 *)vcodes);
 }
-void agx_launch_expand_hits(const void *whits, const void *sides, const void *wruns, agx_hit *hits, agx_run *runs, agx_u32 n_hits, agx_u32 n_runs, hipStream_t st) {
-    const agx_u32 n = n_hits > n_runs ? n_hits : n_runs;
-    if (n) hipLaunchKernelGGL(agx_k_expand_hits, dim3((n + 255) / 256), dim3(256), 0, st, (const agx_whit *)whits, (const agx_wside *)sides, (const agx_wrun *)wruns, hits, runs, n_hits, n_runs);
+void agx_launch_expand_runs(const void *wruns, agx_run *runs, agx_u32 n_runs, hipStream_t st) {
+    if (n_runs) hipLaunchKernelGGL(agx_k_expand_runs, dim3((n_runs + 255) / 256), dim3(256), 0, st, (const agx_wrun *)wruns, runs, n_runs);
 }
 void agx_launch_expand_ref(const void *packed, void *ref, size_t n_pos16, const void *refx, agx_u32 n_refx, hipStream_t st) {
     const size_t n16 = n_pos16 / 16;
@@ -761,9 +773,10 @@ void agx_launch_exclusive_scan1(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsi
 void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_bin_fill, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
 }
-void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, const agx_run *runs, agx_u32 k, hipStream_t st) {
+void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, const agx_run *runs, agx_u32 k,
+                          const agx_u32 *slots, agx_u32 slot_cap, const agx_u32 *dense, hipStream_t st) {
     if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, n_tiles, cap, dhit,
-                                    (uint4 *)recs, runs, k);
+                                    (uint4 *)recs, runs, k, slots, slot_cap, dense);
 }
 void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;
