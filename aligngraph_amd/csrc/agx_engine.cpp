@@ -212,25 +212,22 @@ struct WalkerPool {
         }
     }
     int take() { std::lock_guard<std::mutex> l(take_m); start(); for (int i = 0; i < N; i++) if (!slot[i].taken) { slot[i].taken = true; return i; } return -1; }
-    int busy() { std::lock_guard<std::mutex> l(take_m); int n = 0; for (int i = 0; i < N; i++) n += slot[i].taken && slot[i].th.joinable() ? 1 : 0; return started ? n : 0; }      // walkers of other units at work right now
     void give(int i) { std::lock_guard<std::mutex> l(take_m); slot[i].taken = false; }
     void run(int i, std::function<void()> f) { Slot &s = slot[i]; std::unique_lock<std::mutex> l(s.m); s.cv.wait(l, [&s] { return !s.queued && !s.running; }); s.job = std::move(f); s.queued = true; s.cv.notify_all(); }
     void wait(int i) { Slot &s = slot[i]; std::unique_lock<std::mutex> l(s.m); s.cv.wait(l, [&s] { return !s.queued && !s.running; }); }
     ~WalkerPool() { for (Slot &s : slot) if (s.th.joinable()) { { std::lock_guard<std::mutex> l(s.m); s.stop = true; } s.cv.notify_all(); s.th.join(); } }
 };
 WalkerPool &walker_pool() { static WalkerPool p; return p; }
-// Units of this process that are uploaded (or on their way up) and whose walk has not begun: the walks that will follow the one that begins now.
-std::atomic<int> g_on_the_way{0};
-// Walkers for the unit whose walk begins now.  With other units on the way the walks of a pipelined job overlap, two or three at a time: each takes half the CPUs
-// this process may use at most.  The walk that has nothing behind it is the job's tail — the device is idle by then, the earlier walks are ending — and takes what
-// its size asks for (walkers_wanted) of all the CPUs that are not walking.
-inline int walkers_now(size_t n_pos, int behind) {
+// Walkers for the unit whose walk begins now: what its size asks for (walkers_wanted), one per CPU this process may use at most — its share of them when it is
+// one of several ranks on the host (LOCAL_WORLD_SIZE: torch.distributed's launcher sets it), four at least.  The walks of a pipelined job overlap two or three
+// at a time, so more walkers than CPUs are runnable for a millisecond or two; a CPU quota (cgroup cpu.max) bounds CPU time per period, not threads, and a job's
+// walks use well under a third of it (bench.py: host_cpu_ms_per_step).  r03 first gave a walk half the CPUs (8 of 16): cfg3 jobs of 36.2 ms instead of 35.1.
+inline int walkers_now(size_t n_pos) {
     const int want = walkers_wanted(n_pos);
     if (want <= 4 || getenv("AGX_WALK_SPLIT_WALKERS")) return want;
-    const int cpus = (int)usable_cpus(), half = cpus / 2 < 4 ? 4 : cpus / 2;
-    if (behind > 0) return want < half ? want : half;
-    const int idle = cpus - walker_pool().busy() - 1;
-    return want <= idle ? want : idle > half ? idle : want < half ? want : half;
+    static const int ranks = [] { const char *e = getenv("LOCAL_WORLD_SIZE"); const int n = e ? atoi(e) : 1; return n < 1 ? 1 : n; }();
+    const int cpus = (int)usable_cpus() / ranks;
+    return want <= cpus ? want : cpus < 4 ? 4 : cpus;
 }
 
 struct agx_unit {
@@ -241,7 +238,6 @@ struct agx_unit {
     struct Mapped { void *p = nullptr; size_t n = 0; void reset() { if (p) munmap(p, n); p = nullptr; n = 0; } ~Mapped() { reset(); } } cache_map;
     agx_u32 n_seg0 = 0, stride = 0, n_slots = 0, n_rows = 0; unsigned long long pairs_in_file = 0, sam_pairs = 0;
     bool have_ref = false, have_threads = false, staged = false, uploaded = false, built = false, downloaded = false;
-    bool counted_on_the_way = false;    // in g_on_the_way (below) since its upload, until its walk begins or it is released
     bool consumed = false;             // AGX_FLAG_ONE_SHOT: the download has overwritten the staged inputs
     bool expanded = false;             // the conti-mer tables and vote codes have been made from what was uploaded (opens the unit's first build)
     hipEvent_t ev_built = nullptr;     // this unit's build commands are done (waited for on the host; ev_dl: its download)
@@ -271,7 +267,7 @@ struct agx_unit {
     // node table
     agx_u32 pool_cap = 0, spill_lo = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
     DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
-    DBuf<agx_u32> d_node_start, d_slow_list, d_rank4, d_slots; agx_u32 slot_cap = 0; DBuf<agx_u8> d_node_cnt, d_pos_succ;
+    DBuf<agx_u32> d_node_start, d_slow_list, d_slots; agx_u32 slot_cap = 0; DBuf<agx_u8> d_node_cnt, d_pos_succ;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch, d_huge_list, d_scratch_huge; bool huge = false;      // huge: pass 3 of the node sweep is queued (a build met a position beyond AGX_MAXV_BIG variants)
     // walk graph (agx_core.h "walk preparation")
@@ -674,7 +670,7 @@ Plan plan_capacities(const agx_unit *u) {
     const size_t ids_cap = n_pos + P.pool_cap;
     P.sp_cap = u->sp_cap ? u->sp_cap : (agx_u32)std::min<size_t>(g_tiny ? 32 : ids_cap / 4 + 4096, 0xFFFFFF00ull);      // special ids: 8 % on the bench unit
     // what the takes of do_upload add up to, plus the alignment of ~90 buffers
-    const size_t per_pos = 4 + 16 + 1 + 4 + 1 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_dhit) + 16 + 4;
+    const size_t per_pos = 4 + 16 + 1 + 4 + 1 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_dhit) + 4;
     const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
     const size_t wire = nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 + (u->ref_packed ? n_pos / 4 + u->n_refx * sizeof(agx_refx) : 0) + 4096;
     const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + (size_t)n_tiles * P.slot_cap * 4 + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases + u->n_other * 8 +
@@ -694,7 +690,6 @@ void do_upload(agx_unit *u) {
     if (u->arena.used()) do_release(u);              // uploaded before: start over (the unit's blocks go through the cache)
     const double t0 = now_ms();
     HIP_OK(hipSetDevice(u->prm.device));
-    if (!u->counted_on_the_way) { u->counted_on_the_way = true; g_on_the_way.fetch_add(1); }
     const size_t n_pos = u->V.n_pos, nh = u->nh;
     u->arena.device = u->prm.device;
     u->n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
@@ -709,7 +704,7 @@ void do_upload(agx_unit *u) {
     u->d_runs.alloc(a, u->n_runs + 1); u->d_codes.alloc(a, u->n_codes + 16); u->d_vcodes.alloc(a, n_bases + 16); u->d_other.alloc(a, u->n_other + 1);
     u->d_whits.alloc(a, nh + 1); u->d_wsides.alloc(a, u->n_sides + 1); u->d_wruns.alloc(a, u->n_runs + 1); u->d_jump.alloc(a, u->n_jump + 1);
     if (u->ref_packed) { u->d_wref.alloc(a, (n_pos + 3) / 4 + 32); u->d_refx.alloc(a, u->n_refx + 1); }
-    u->d_dhit.alloc(a, nh + 1); u->d_rank4.alloc(a, 4 * (nh + 1));
+    u->d_dhit.alloc(a, nh + 1);
     u->slot_cap = plan.slot_cap; u->d_slots.alloc(a, (size_t)u->n_tiles * u->slot_cap + 1);
     u->d_tile_cnt.alloc(a, (size_t)u->n_tiles + 1); u->d_tile_off.alloc(a, (size_t)u->n_tiles + 2); u->d_cursor.alloc(a, (size_t)u->n_tiles + 1);
     u->d_words.alloc(a, W_N + 6 + 16); u->h_words.alloc(W_N + 6 + 16);
@@ -846,7 +841,7 @@ void do_build(agx_unit *u) {
         }
         // ---- hit_prep + tile histogram ----
         u->ev.begin(); u->ev.mark(B_START, st);
-        agx_prep_args PA{(const agx_whit *)u->d_whits.p, (const agx_wside *)u->d_wsides.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, (uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF,
+        agx_prep_args PA{(const agx_whit *)u->d_whits.p, (const agx_wside *)u->d_wsides.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, u->d_words.p + W_RANKOVF,
                          u->d_slots.p, u->slot_cap, u->d_words.p + W_SLOTOVF};
         agx_launch_hit_prep(&PA, st);
         AGX_CHECKPOINT("hit_prep");
@@ -854,7 +849,7 @@ void do_build(agx_unit *u) {
         // ---- tile lists ----
         if (g_scan1) agx_launch_exclusive_scan1(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_desc.p, st);
         else agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
-        agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, (const uint4 *)u->d_rank4.p, u->d_words.p + W_RANKOVF, u->d_words.p + W_SLOTOVF};
+        agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, u->d_words.p + W_RANKOVF, u->d_words.p + W_SLOTOVF};
         agx_launch_bin_fill(&BA, st);                   // (returns at once unless a list outgrew its tile's slots)
         agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, u->d_runs.p, u->prm.k, u->d_slots.p, u->slot_cap, u->d_words.p + W_RANKOVF, st);
         AGX_CHECKPOINT("tile_sort");
@@ -1063,12 +1058,11 @@ void do_download(agx_unit *u) {
 // them without a driver call).  The inputs stay staged: the unit can be uploaded again as if it were new.
 void do_release(agx_unit *u) {
     const double tr0 = now_ms();
-    if (u->counted_on_the_way) { u->counted_on_the_way = false; g_on_the_way.fetch_sub(1); }
     struct Tr { agx_unit *u; double t; ~Tr() { trace(u, "release", t, u->V.n_pos); } } tr{u, tr0};
     join_dl_helper(u);                                 // (it fills the download buffers released below)
     if (u->uploaded) { (void)hipSetDevice(u->prm.device); (void)hipEventSynchronize(u->ev_uploaded); (void)hipEventSynchronize(u->ev_built); (void)hipEventSynchronize(u->ev_dl); }      // (its commands are done before its memory goes)
     for (auto *b : {&u->d_cm_start, &u->d_tile_cnt, &u->d_tile_off, &u->d_cursor, &u->d_unsorted, &u->d_tile_recs, &u->d_scan_tmp, &u->d_words, &u->d_pool_cnt, &u->d_region_off, &u->d_node_start,
-                    &u->d_slow_list, &u->d_rank4, &u->d_slots, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
+                    &u->d_slow_list, &u->d_slots, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     for (auto *b : {&u->d_node_cnt, &u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
     u->d_other.release(); u->d_whits.release(); u->d_wsides.release(); u->d_wruns.release(); u->d_wref.release(); u->d_refx.release();
@@ -1342,8 +1336,6 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
         prepare_outputs(u);               // (a unit whose helper could not make them, or that is finished a second time)
         if (!u->out_ready) throw Error{E_ARG, "out of host memory"};
         u->downloaded = false;            // the walk marks the downloaded meta bytes: another finish downloads again
-        int behind = g_on_the_way.load();
-        if (u->counted_on_the_way) { u->counted_on_the_way = false; behind = g_on_the_way.fetch_sub(1) - 1; }
         u->out_ready = false;             // (an error below leaves the buffers to the next prepare_outputs)
         struct Helpers : Assistant {           // helper 0: the unit's own thread (formats the written records while the walk goes on, or walks a stretch); 1..: pool threads for further walkers
             agx_unit *u; int pool[GraphView::MAX_WALKERS] = {}; int n_pool = 0;
@@ -1355,7 +1347,7 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
                 else walker_pool().run(pool[who - 1], std::move(f));
             }
             void wait(int who) override { if (who == 0) u->helper.wait(UnitHelper::WALK); else walker_pool().wait(pool[who - 1]); }
-        } second(u, walkers_now(u->V.n_pos, behind) - 2);      // one thread per further walker: the unit's helper + pool threads
+        } second(u, walkers_now(u->V.n_pos) - 2);      // one thread per further walker: the unit's helper + pool threads
         walk_join_scaffold(u->V, view_of(u), u->out, u->helper.started ? &second : nullptr);
         u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = u->out.n_fetched;
         trace(u, "walk", t0, u->V.n_pos);

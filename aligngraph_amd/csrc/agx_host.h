@@ -166,7 +166,7 @@ template <class T> struct SBuf {
 unsigned usable_cpus();                   // CPUs this process can keep busy: its affinity mask capped by the CPU quota of its control group
 unsigned loader_threads(size_t bytes);      // AGX_LOAD_THREADS, else by the size of the input and the cores this process may use
 // walkers of a unit of n positions at most (agx_walk.cpp: walk_split): AGX_WALK_SPLIT_WALKERS, else one per 1.2 M positions, two to sixteen.  The engine hands
-// out fewer when the CPUs this process may use are busy with the walks of other units (agx_engine.cpp: agx_unit_finish).
+// out one per CPU this process may use at most (agx_engine.cpp: walkers_now).
 inline int walkers_for(size_t n) {
     const char *e = getenv("AGX_WALK_SPLIT_WALKERS");
     const int k = e ? atoi(e) : (int)(n / 1200000u);

@@ -8,15 +8,14 @@ struct agx_prep_args {
     const agx_run *runs; agx_dhit *dhit; agx_u32 n_hits, k, n_pos;
     agx_u32 *tile_cnt;        // [n_tiles] number of hits overlapping each tile
     agx_u32 *err;             // bit 0: same-strand mates; bit 1: alignment beyond the unit sequence
-    uint4 *rank4;             // [n_hits] what the histogram's atomicAdd returned for the hit's first four tiles = its slot in each tile's list
-    agx_u32 *rank_overflow;   // set when some hit spans more than four tiles: the lists are then filled with a second round of atomics
+    agx_u32 *rank_overflow;   // set when some hit spans more than four tiles (the histogram's atomicAdd gives a hit its place in the lists of its first four)
     // The tile lists without a second pass over the hits: every tile has slot_cap slots of its own and the rank IS the slot.  A list that outgrows its slots
     // (slot_overflow) — or a hit beyond four tiles — sends the build through bin_fill's dense lists instead, as before r03.
     agx_u32 *slots; agx_u32 slot_cap; agx_u32 *slot_overflow;
 };
 
 struct agx_bin_args { const agx_dhit *dhit; agx_u32 n_hits; const agx_u32 *tile_off; agx_u32 *cursor; agx_u32 *unsorted; agx_u32 cap;   // cap: entries the lists can hold
-                      const uint4 *rank4; const agx_u32 *rank_overflow; const agx_u32 *slot_overflow; };
+                      const agx_u32 *rank_overflow; const agx_u32 *slot_overflow; };
 
 struct agx_node_kargs {
     agx_sweep_args S;

@@ -189,7 +189,6 @@ __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
         atomicOr(A.rank_overflow, 1u);
     }
     if (!mine) return;
-    A.rank4[h] = make_uint4(r[0], r[1], r[2], r[3]);
     A.dhit[h] = d;
 }
 
@@ -278,16 +277,12 @@ __global__ void __launch_bounds__(256) agx_k_scan_lookback(const agx_u32 *in, ag
 __global__ void __launch_bounds__(256) agx_k_bin_fill(agx_bin_args A) {
     const agx_u32 h = blockIdx.x * 256u + threadIdx.x;
     // (nothing to do where every list fitted the tiles' own slots: hit_prep has filled them)
-    const int ro = __builtin_amdgcn_readfirstlane((int)*A.rank_overflow);
-    if (ro == 0 && __builtin_amdgcn_readfirstlane((int)*A.slot_overflow) == 0) return;
+    if (__builtin_amdgcn_readfirstlane((int)*A.rank_overflow) == 0 && __builtin_amdgcn_readfirstlane((int)*A.slot_overflow) == 0) return;
     if (h >= A.n_hits) return;
     const agx_dhit d = A.dhit[h];
     if (d.flags & AGX_HF_SKIP) return;
-    if (ro == 0) {
-        const uint4 r4 = A.rank4[h]; const agx_u32 r[4] = {r4.x, r4.y, r4.z, r4.w}; agx_u32 i = 0;
-        for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++, i++) { const agx_u32 at = A.tile_off[t] + r[i & 3u]; if (at < A.cap) A.unsorted[at] = h; }
-    } else      // some hit spans more than four tiles (reads beyond ~190 bases, long deletions): every hit takes its slots from a second counter
-        for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++) { const agx_u32 at = A.tile_off[t] + atomicAdd(&A.cursor[t], 1u); if (at < A.cap) A.unsorted[at] = h; }
+    // every hit takes its places in the dense lists from a second counter per tile (the order inside a list is tile_sort's business)
+    for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++) { const agx_u32 at = A.tile_off[t] + atomicAdd(&A.cursor[t], 1u); if (at < A.cap) A.unsorted[at] = h; }
 }
 
 // one wavefront per tile; a hit's place in the file is unique, so an element's rank is the number of smaller keys
