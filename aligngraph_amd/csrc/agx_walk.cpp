@@ -249,6 +249,7 @@ struct Walker {
     // A speculative walker (walk_split below) may only look at nodes of positions [look_lo, look_hi): what it finds anywhere else is not
     // what the sequential walk would find there.  It gives up (invalid) the moment an edge or a conti-mer chain leads outside.  (The record fetch hook serves both walkers: it must be callable from two threads.)
     bool spec = false; agx_u32 look_lo = 0, look_hi = 0xFFFFFFFFu; mutable bool invalid = false; mutable agx_u32 gave_up_at = AGX_NONE;
+    agx_u32 scan_hi = 0xFFFFFFFFu;               // (a walker behind a window: its visited bytes are only real below this position — a scan for the next unvisited node that ends at or behind it has told nothing)
     bool may_look(agx_u32 v) const { if (!spec) return true; const agx_u32 x = pos_of(v); if (x >= look_lo && x < look_hi) return true; invalid = true; gave_up_at = x; return false; }
     std::vector<agx_edge_ovf> ovf;                  // sorted, unique
     Walker(const UnitView &v, const GraphView &g) : V(v), G(g) {
@@ -505,6 +506,9 @@ struct WalkRun {
                 const agx_u32 sd = side_live;
                 const agx_u32 sp = sd < G.n_ids ? G.side_xpos[sd - G.n_pos] : G.n_pos;
                 cp = m < sp ? m : sp;
+                // (a walker behind a window: no unvisited node left inside it — where the scan stands next is not in its bytes.  Whichever of the two answers lies
+                // inside the window is true: the scan met it before it left the real bytes)
+                if (cp >= W.scan_hi) { W.invalid = true; W.gave_up_at = cp; }
             }
             AGX_PT(10);
     }
@@ -632,10 +636,11 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
             b.t_run = clk();
             struct Copied { std::atomic<int> &n; bool done = false; void now() { if (!done) { done = true; n.fetch_add(1, std::memory_order_release); } } ~Copied() { now(); } } copied_mark{copied};      // (the first walker waits for this count whatever happens here)
             try {
+                if (getenv("AGX_WALK_POISON")) memset(W.m, 0xA5, (size_t)G.n_ids + 64);      // test hook: whatever the last unit left outside the window must not matter
                 memcpy(W.m + b.win_lo, pristine + b.win_lo, (size_t)b.copy_hi - b.win_lo);
                 memcpy(W.m + b.side_copy_lo, pristine + b.side_copy_lo, (size_t)b.side_copy_hi - b.side_copy_lo + (b.side_copy_hi == G.n_ids ? 64 : 0));      // (+ the padding behind the table)
                 copied_mark.now(); b.t_copy = clk();
-                W.spec = true; W.look_lo = b.warm_lo; W.look_hi = b.warm_hi;
+                W.spec = true; W.look_lo = b.warm_lo; W.look_hi = b.warm_hi; W.scan_hi = b.warm_hi;
                 R.cancel = &cancel; R.st.cp = b.w0; R.keep = false; R.log = &b.log; R.log_main = 0; R.log_side = G.n_pos;
                 R.go(b.c);                                  // warm-up: decides records, keeps none; every mark is logged
                 b.at_c = R.st; b.n_warm = b.log.size(); b.t_warm = clk();

@@ -76,7 +76,7 @@ def test_walk_by_several_walkers_is_the_sequential_walk(built, tmp_path, monkeyp
     meta = H.read_meta(run)
     tmp = os.path.join(run, "tmp")
     o = H.run_oracle(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
-    for key, val in (("AGX_SIM_ASSISTANT", "1"), ("AGX_WALK_SPLIT_MIN", "0"), ("AGX_WALK_SPLIT_WARMUP", warm)):
+    for key, val in (("AGX_SIM_ASSISTANT", "1"), ("AGX_WALK_SPLIT_MIN", "0"), ("AGX_WALK_SPLIT_WARMUP", warm), ("AGX_WALK_POISON", "1")):      # (poison: the walkers' windows lie in memory full of junk, as in a process that has walked other units)
         monkeypatch.setenv(key, val)
     # look: the walkers see 20 kb of their stretch only: they give up.  More than four walkers share the three copies of the visited bytes, each behind
     # its own window of three stretches (short warm-ups only: the stretches must be longer than the warm-up for that)
@@ -234,7 +234,7 @@ def test_walkers_behind_windows_of_the_visited_bytes(built, tmp_path, monkeypatc
     meta = H.read_meta(run)
     tmp = os.path.join(run, "tmp")
     o = H.run_oracle(tmp, 0, meta["k"], meta["insert_variation"], meta["coverage"])
-    for key, val in (("AGX_SIM_ASSISTANT", "1"), ("AGX_WALK_SPLIT_MIN", "0"), ("AGX_WALK_TIMING", "1")):
+    for key, val in (("AGX_SIM_ASSISTANT", "1"), ("AGX_WALK_SPLIT_MIN", "0"), ("AGX_WALK_TIMING", "1"), ("AGX_WALK_POISON", "1")):
         monkeypatch.setenv(key, val)
     stood = {}
     for walkers, warm, look in (("5", "40000", None), ("6", "40000", None), ("7", "40000", None), ("8", "40000", None), ("8", "5000", None), ("8", "40000", "60000"),
