@@ -239,16 +239,29 @@ inline run_end_fn pick_run_end() {
     return run_end_scalar;
 }
 
+#ifdef AGX_WALK_CHECK
+#define AGX_WCHK(W_, v, where) (W_).wchk((v), (where))
+#else
+#define AGX_WCHK(W_, v, where) do { } while (0)
+#endif
 struct Walker {
     const UnitView &V; const GraphView &G;
     // meta bytes with the traversed flags in bit 7 (AGX_WM_VISITED): the caller's own array if it may be written (GraphView::meta_rw: the
     // engine's download buffer — no copy, no first-touch faults on the unit's critical path), else a copy
     agx_u8 *m = nullptr; agx_u8 *owned = nullptr;
     ~Walker() { free(owned); }
-    bool visited(agx_u32 v) const { return (m[v] & AGX_WM_VISITED) != 0; }
+    bool visited(agx_u32 v) const { AGX_WCHK(*this, v, "visited"); return (m[v] & AGX_WM_VISITED) != 0; }
     // A speculative walker (walk_split below) may only look at nodes of positions [look_lo, look_hi): what it finds anywhere else is not
     // what the sequential walk would find there.  It gives up (invalid) the moment an edge or a conti-mer chain leads outside.  (The record fetch hook serves both walkers: it must be callable from two threads.)
     bool spec = false; agx_u32 look_lo = 0, look_hi = 0xFFFFFFFFu; mutable bool invalid = false; mutable agx_u32 gave_up_at = AGX_NONE;
+#ifdef AGX_WALK_CHECK      // development aid (tests/hostsim builds it on request): every byte a decision rests on must lie in what the walker copied
+    agx_u32 chk_lo = 0, chk_hi = 0xFFFFFFFFu, chk_slo = 0, chk_shi = 0xFFFFFFFFu;
+    void wchk(agx_u32 v, const char *where) const {
+        if (!spec) return;
+        const bool ok = v < G.n_pos ? (v >= chk_lo && v < chk_hi) : (v >= chk_slo && v < chk_shi);
+        if (!ok && !invalid) { fprintf(stderr, "[agx walk check] %s looks at id %u outside the window [%u, %u) + [%u, %u)\n", where, v, chk_lo, chk_hi, chk_slo, chk_shi); abort(); }
+    }
+#endif
     agx_u32 scan_hi = 0xFFFFFFFFu;               // (a walker behind a window: its visited bytes are only real below this position — a scan for the next unvisited node that ends at or behind it has told nothing)
     bool may_look(agx_u32 v) const { if (!spec) return true; const agx_u32 x = pos_of(v); if (x >= look_lo && x < look_hi) return true; invalid = true; gave_up_at = x; return false; }
     std::vector<agx_edge_ovf> ovf;                  // sorted, unique
@@ -321,6 +334,7 @@ struct Walker {
     agx_u32 pos_of(agx_u32 v) const { return v < G.n_pos ? v : G.side_xpos[v - G.n_pos]; }      // main ids are positions
     // side ids of position x: [lo, hi)
     void side_range(agx_u32 x, agx_u32 &lo, agx_u32 &hi) const {
+        AGX_WCHK(*this, x, "side_range");
         if (!(m[x] & AGX_WM_SIDE)) { lo = hi = G.n_pos; return; }
         const agx_u32 *b = G.side_xpos, *e = G.side_xpos + (G.n_ids - G.n_pos);
         const agx_u32 *l = std::lower_bound(b, e, x), *h = l;
@@ -329,6 +343,7 @@ struct Walker {
     }
     // number of live (unvisited) successors of node v, capped at 2; target = the last one seen (AG:2020-2033)
     int live_successors(agx_u32 v, agx_u32 &target) const {
+        AGX_WCHK(*this, v, "live_successors");
         if (m[v] & AGX_WM_CONT) { if (spec && v >= G.n_pos && !may_look(v + 1)) return 2; if (visited(v + 1)) return 0; target = v + 1; return 1; }      // its only alive successor is v+1
         int n = 0;
         const agx_walknode rec = node(v);
@@ -394,7 +409,7 @@ struct WalkRun {
         agx_hop hcur{0, 0, 0};                       // hop entry of the position the walk is about to leave the k-mer graph at
         std::vector<Seg> segs;
         agx_u8 *const m = W.m;
-        auto done = [m](agx_u32 v) { return (m[v] & AGX_WM_VISITED) != 0; };
+        auto done = [m, this](agx_u32 v) { AGX_WCHK(W, v, "done"); (void)this; return (m[v] & AGX_WM_VISITED) != 0; };
         const mark_fn mark = pick_mark();
         AGX_PT_START;
         const run_end_fn run_end = pick_run_end();
@@ -440,11 +455,13 @@ struct WalkRun {
                         // forced run: while the cont bit holds and the next node is unvisited the reference steps cur -> cur+1 (its unique live
                         // successor).
                         agx_u8 seen = 0;
+                        AGX_WCHK(W, cur, "run start");
                         const agx_u32 j = run_end(m, cur, seen);
-                        const agx_u32 xj = W.pos_of(j);
+                        const agx_u32 xj = j < G.n_ids ? W.pos_of(j) : 0xFFFFFFFFu;      // (a run cannot leave the table: the bytes behind it are zero, and a walker's window ends in a byte that stops it)
                         // (a run over side ids ends on what the NEXT side id's byte says, and that id may lie many positions further)
                         if (W.spec && (xj < W.look_lo || xj >= W.look_hi || (j >= G.n_pos && j + 1 < G.n_ids && W.pos_of(j + 1) >= W.look_hi))) { W.invalid = true; W.gave_up_at = xj; mode = -2; break; }      // (the run left what this walker may look at: nothing is marked — the bytes out there may be another walker's)
                         AGX_PT(2);                             // most walks leave the k-mer graph here, onto a conti-mer chain
+                        AGX_WCHK(W, j, "run end"); if (j + 1 < G.n_ids && (j + 1 < G.n_pos) == (j < G.n_pos)) AGX_WCHK(W, j + 1, "behind the run");
                         segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!(m[j] & AGX_WM_CONT)) n_general++;
                         if (seen & AGX_WM_CONTIG) C.extended = 1;
                         mark(m, cur, j);
@@ -500,9 +517,11 @@ struct WalkRun {
                 // first unvisited main id (= position) after cp and first unvisited side id from s_hi on.  Visited nodes stay visited and both
                 // bounds only grow, so a previous answer is still the answer unless it has been passed or visited since: each block is scanned
                 // once over the whole walk, not once per step (a long record leaves thousands of side nodes behind, each a step of its own)
-                if (main_live <= cp || (main_live < G.n_pos && done(main_live))) main_live = W.next_live(main_live > cp + 1 ? main_live : cp + 1, G.n_pos);
+                // (behind a walker's window these two look at bytes that are not the table's: whatever they answer lies at or behind scan_hi, and is refused below)
+                auto stale = [m](agx_u32 v) { return (m[v] & AGX_WM_VISITED) != 0; };
+                if (main_live <= cp || (main_live < G.n_pos && stale(main_live))) main_live = W.next_live(main_live > cp + 1 ? main_live : cp + 1, G.n_pos);
                 const agx_u32 m = main_live;                                                     // main slot id == position
-                if (side_live < s_hi || (side_live < G.n_ids && done(side_live))) side_live = W.next_live(side_live > s_hi ? side_live : s_hi, G.n_ids);
+                if (side_live < s_hi || (side_live < G.n_ids && stale(side_live))) side_live = W.next_live(side_live > s_hi ? side_live : s_hi, G.n_ids);
                 const agx_u32 sd = side_live;
                 const agx_u32 sp = sd < G.n_ids ? G.side_xpos[sd - G.n_pos] : G.n_pos;
                 cp = m < sp ? m : sp;
@@ -636,11 +655,18 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
             b.t_run = clk();
             struct Copied { std::atomic<int> &n; bool done = false; void now() { if (!done) { done = true; n.fetch_add(1, std::memory_order_release); } } ~Copied() { now(); } } copied_mark{copied};      // (the first walker waits for this count whatever happens here)
             try {
-                if (getenv("AGX_WALK_POISON")) memset(W.m, 0xA5, (size_t)G.n_ids + 64);      // test hook: whatever the last unit left outside the window must not matter
+                if (const char *pz = getenv("AGX_WALK_POISON")) { const long v = strtol(pz, nullptr, 0); memset(W.m, v > 1 ? (int)(v & 0xFF) : 0xA5, (size_t)G.n_ids + 64); }      // test hook (1 or a byte value): whatever the last unit left outside the window must not matter
                 memcpy(W.m + b.win_lo, pristine + b.win_lo, (size_t)b.copy_hi - b.win_lo);
                 memcpy(W.m + b.side_copy_lo, pristine + b.side_copy_lo, (size_t)b.side_copy_hi - b.side_copy_lo + (b.side_copy_hi == G.n_ids ? 64 : 0));      // (+ the padding behind the table)
+                // what lies behind the window is whatever the last unit left there: a forced run that reaches the window's end must stop AT it (a visited byte without a
+                // cont bit ends every run in front of it) and so gives itself away — the run's last node then lies behind what the walker may look at
+                if (b.copy_hi < G.n_pos) W.m[b.copy_hi] = AGX_WM_VISITED;
+                if (b.side_copy_hi < G.n_ids) W.m[b.side_copy_hi] = AGX_WM_VISITED;
                 copied_mark.now(); b.t_copy = clk();
                 W.spec = true; W.look_lo = b.warm_lo; W.look_hi = b.warm_hi; W.scan_hi = b.warm_hi;
+#ifdef AGX_WALK_CHECK
+                W.chk_lo = b.win_lo; W.chk_hi = b.copy_hi; W.chk_slo = b.side_copy_lo; W.chk_shi = b.side_copy_hi;
+#endif
                 R.cancel = &cancel; R.st.cp = b.w0; R.keep = false; R.log = &b.log; R.log_main = 0; R.log_side = G.n_pos;
                 R.go(b.c);                                  // warm-up: decides records, keeps none; every mark is logged
                 b.at_c = R.st; b.n_warm = b.log.size(); b.t_warm = clk();

@@ -5,13 +5,15 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-LIB = os.path.join(HERE, "libagx_hostsim.so")
+LIB = os.environ.get("AGX_HOSTSIM_LIB", os.path.join(HERE, "libagx_hostsim.so"))      # (override: a variant build, e.g. -DAGX_WALK_CHECK, made by hand)
 SRC = [os.path.join(HERE, "agx_hostsim.cpp"), os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_host.cpp"),
        os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_walk.cpp"), os.path.join(ROOT, "aligngraph_amd", "csrc", "agx_load.cpp")]
 DEPS = SRC + [os.path.join(ROOT, "aligngraph_amd", "csrc", h) for h in ("agx_core.h", "agx_host.h", "agx_parse.h")]
 
 
 def build():
+    if "AGX_HOSTSIM_LIB" in os.environ:
+        return
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in DEPS):
         return
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-fPIC", "-shared", "-pthread", "-o", LIB] + SRC)
