@@ -24,6 +24,7 @@ Configurations (--config; BASELINE.json `configs`, synthetic data of that shape 
     cfg2            E. coli shape: one 4.6 Mb unit, 1 M pairs
     cfg4            human chr1 shape: 249 Mb --part 4 (4 units of 62 Mb), 60 M pairs (needs ~40 GB of scratch disk)
     cfg5s           whole-human shape SCALED 1/16: 24 units of 15.6 .. 3.6 Mb, 25 M 2x150 bp pairs (the shard shape of configs[4]; the default with --gpus N > 1)
+    cfg5q           the same at 1/4: 24 units of 62 .. 12 Mb, 100 M 2x150 bp pairs (48 GB of text: what fits the GPU box's scratch disk; minutes to generate)
     custom          --chroms / --pairs / --part
 
 Multi-GPU (driver: torch.distributed.run, one rank per GPU): units are the shard — assigned longest-first to the least
@@ -55,6 +56,10 @@ CONFIGS = {
     "cfg5s": ([c // 16 for c in (248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622,
                                 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415)],
               1, 25000000, 150, "configs[4] SCALED 1/16: GRCh38 chromosome lengths / 16 (24 units, 193 Mb), 25M 2x150 bp pairs — the 8-GPU shard shape, not the configuration itself"),
+    # the same at 1/4: the largest scale whose text files (48 GB) fit the GPU box's scratch disk; units of 62 .. 12 Mb
+    "cfg5q": ([c // 4 for c in (248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622,
+                               133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415)],
+              1, 100000000, 150, "configs[4] SCALED 1/4: GRCh38 chromosome lengths / 4 (24 units, 772 Mb), 100M 2x150 bp pairs — the 8-GPU shard shape, not the configuration itself"),
 }
 
 
