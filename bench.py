@@ -16,8 +16,8 @@ step: --pool host-cold, the default; --pool cold also gives the HBM blocks back 
 Text parsing of the five per-unit files (T_unit = parse + T_core: the scope of the reference's stages (1)-(5), the like-for-like comparison) is measured
 once while the inputs are loaded (a rank's units side by side, each on its share of the CPUs the process can keep busy) and reported beside it
 (`t_unit_s`, `value_t_unit`, `load_ms_per_unit`), and so is loading the units from their binary caches.  `roofline` carries `frac` (bytes the dominant
-kernel cannot avoid / its time / HBM peak), `frac_hbm` (counter traffic), `job_frac` (SURVEY 8(d)'s algorithmic bytes / T_core / peak), `frac_8d_model`
-(r01/r02's quantity, which passes 1) and a `pcie` block; `cpu_baseline` the reference binary on one CPU and, under `parallel`, one process per usable CPU.
+kernel cannot avoid / its time / HBM peak), `frac_hbm` (counter traffic), `job_frac` (SURVEY 8(d)'s algorithmic bytes / T_core / peak)
+and a `pcie` block; `cpu_baseline` the reference binary on one CPU and, under `parallel`, one process per usable CPU.
 
 Configurations (--config; BASELINE.json `configs`, synthetic data of that shape from tools/agx_synth, seeded):
     cfg3 (default)  A. thaliana shape: 5 units of 30.4 / 19.7 / 23.5 / 18.6 / 27.0 Mb, 20 M 2x100 bp pairs, k=5      <- the north-star 1-GPU target
@@ -65,8 +65,8 @@ CONFIGS = {
 
 def algorithmic_bytes(n_pairs, L, k, n_pos):
     """per pair (L-k)*40 + L + 32 bytes, plus 64 bytes per position for the extend pass — the bytes of the WHOLE path
-    (node state, votes, edge reads, the extend pass).  Used for `job_frac` (against the job's time) and kept as `frac_8d_model` against the node
-    sweep's time for continuity with r01/r02 — that quotient passes 1, because one kernel is charged the whole path's bytes."""
+    (node state, votes, edge reads, the extend pass).  Used for `job_frac` (against the job's time).  r01/r02 divided them by the node
+    sweep's time — a quotient that passes 1, because one kernel is charged the whole path's bytes; no longer printed."""
     return n_pairs * ((L - k) * 40 + L + 32) + 64 * n_pos
 
 
@@ -461,7 +461,6 @@ def main():
         # those units over the HIP-event time of their sweeps; next to it the HBM bytes the counters saw (profiles/) over the same time
         sw_ms = sum(unit_stats[uu]["ms_node_sweep"] for uu in mine)
         abytes = sum(algorithmic_bytes(unit_stats[uu]["sam_line_pairs"], L, k, unit_stats[uu]["n_pos"]) for uu in mine)
-        achieved_8d = abytes / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else 0.0
         cbytes = sum(sweep_compulsory_bytes(unit_stats[uu], L, k) for uu in mine)
         achieved = cbytes / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else 0.0
         up_bytes = sum(unit_stats[uu]["upload_bytes"] for uu in mine)
@@ -516,8 +515,8 @@ def main():
                          "traffic": traffic, "achieved_hbm": round(hbm_rate, 1) if hbm_rate else None,
                          "frac_hbm": round(hbm_rate / HBM_PEAK_GBS, 4) if hbm_rate else None,
                          "traffic_note": "HBM bytes from the PMC counters (profiles/pmc_traffic.json: bytes per tile-list entry of the sweep, measured with rocprofv3 --pmc) x this run's list entries; achieved_hbm = traffic / kernel_ms",
-                         "algorithmic_bytes_8d": abytes, "frac_8d_model": round(achieved_8d / HBM_PEAK_GBS, 4),
-                         "frac_8d_note": "SURVEY 8(d)'s algorithmic bytes of the WHOLE path / the node sweep's time / peak: r01/r02's `frac`, kept for continuity; it passes 1 because one kernel is charged the whole path's bytes",
+                         "algorithmic_bytes_8d": abytes,
+                         "algorithmic_bytes_8d_note": "SURVEY 8(d)'s algorithmic bytes of the WHOLE path (per pair (L-k)*40 + L + 32, plus 64 per position).  r01/r02 printed them / the node sweep's time / peak as `frac` (it reached 0.99-1.07: one kernel was charged the whole path's bytes); they are now only divided by the whole job's time (`job_frac`)",
                          "job_frac": round(abytes / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
                          "job_frac_note": "SURVEY 8(d)'s algorithmic bytes / T_core per job / peak: the whole path against the whole job's time (upload, kernels, download, host walk)",
                          "pcie": {"up_bytes": up_bytes, "down_bytes": down_bytes, "peak_GBs": 64.0,
