@@ -47,10 +47,8 @@ extern "C" {
 // one kernel that zeroes up to eight u32 ranges
 struct agx_zero_args { agx_u32 *p[8]; agx_u32 n[8]; };
 void agx_launch_zero(const agx_zero_args *, hipStream_t);
-void agx_launch_seg_expand(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 n_elems, agx_u32 *cnt, agx_u32 *cm_start, agx_cmkey *cm, agx_u32 n_pos, unsigned long long *desc, hipStream_t);      // runs -> cm_start[n_pos + 1], cm
 void agx_launch_cm_tables(const void *cnt_runs, const void *cnt_chunks, agx_u32 n_cnt_chunks, const agx_cmseg *segs, const void *seg_chunks, agx_u32 n_seg_chunks,
                            agx_u32 *cm_start, agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, agx_u32 n_cm, hipStream_t);      // cm_start[n_pos + 1], cm, n_pos + 1 heads from the count runs and the conti-mer runs (agx_core.h: agx_cntrun, agx_chunk)
-void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t);      // n_pos + 1 heads
 void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16, const unsigned long long *other, size_t n_other, hipStream_t);      // 2-bit base classes (agx_pack_classes2) + the listed other bases -> agx_vote_code bytes; n_bases16 a multiple of 16
 void agx_launch_expand_runs(const void *wruns, agx_run *runs, agx_u32 n_runs, hipStream_t);      // wire formats (agx_core.h) -> working arrays
 void agx_launch_expand_ref(const void *packed, void *ref, size_t n_pos16, const void *refx, agx_u32 n_refx, hipStream_t);      // 2-bit reference bases + the stretches of other bytes -> letters; n_pos16 a multiple of 16

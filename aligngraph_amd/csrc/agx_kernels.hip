@@ -26,38 +26,8 @@ static_assert(AGX_MAXV_LDS <= AGX_EM_W && AGX_MAXV_MID <= AGX_EM_W, "the LDS swe
 // every kernel behind the sweeps first looks at the status word the sweeps leave on the device and does nothing if it is set.
 #define AGX_RETURN_IF_ABORTED(word) do { if (__builtin_amdgcn_readfirstlane((int)*(word)) != 0) return; } while (0)
 
-// ---- upload time: the conti-mer tables from their runs (agx_cmseg), then the per-position heads -----------------------------------
-// one thread per conti-mer: cnt[x] = highest rank + 1 (the ranks of a position are 0 .. count - 1); after the scan of cnt, the keys
-// The run of element e: found ONCE per wavefront by bisection (for the wavefront's first element: wave-uniform, scalar loads), then every lane walks forward
-// from there — the runs average hundreds of elements, so most wavefronts sit inside one run and no lane takes a step.  (r02: every thread bisected for
-// itself, 17 dependent loads per element: 0.87 ms for the two kernels on a 30 Mb unit.)
-__device__ __forceinline__ agx_u32 agx_seg_of_elem_wave(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 e, agx_u32 e_wave) {
-    agx_u32 s = __builtin_amdgcn_readfirstlane(agx_seg_of_elem(segs, n_segs, e_wave));
-    while (s + 1 < n_segs && segs[s + 1].elem0 <= e) s++;
-    return s;
-}
-__global__ void __launch_bounds__(256) agx_k_seg_count(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 n_elems, agx_u32 *cnt) {
-    const agx_u32 e = blockIdx.x * 256u + threadIdx.x;
-    const agx_u32 e_wave = __builtin_amdgcn_readfirstlane(e & ~63u);
-    if (e_wave >= n_elems) return;
-    const agx_u32 si = agx_seg_of_elem_wave(segs, n_segs, e < n_elems ? e : n_elems - 1u, e_wave);
-    if (e >= n_elems) return;
-    const agx_cmseg g = segs[si];
-    // (a position's ranks are 0 .. count - 1: rank 0 alone — nearly every position — needs no read-modify-write beyond the maximum with 1)
-    atomicMax(&cnt[g.pos0 + (e - g.elem0)], g.rank + 1u);
-}
-__global__ void __launch_bounds__(256) agx_k_seg_fill(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 n_elems, const agx_u32 *cm_start, agx_cmkey *cm) {
-    const agx_u32 e = blockIdx.x * 256u + threadIdx.x;
-    const agx_u32 e_wave = __builtin_amdgcn_readfirstlane(e & ~63u);
-    if (e_wave >= n_elems) return;
-    const agx_u32 si = agx_seg_of_elem_wave(segs, n_segs, e < n_elems ? e : n_elems - 1u, e_wave);
-    if (e >= n_elems) return;
-    const agx_cmseg g = segs[si];
-    const agx_u32 j = e - g.elem0;
-    cm[cm_start[g.pos0 + j] + g.rank] = agx_cmkey{g.cid, g.coff0 + j * g.dcoff};
-}
-
-// ---- r03: the same tables in two streaming kernels (agx_core.h: agx_cntrun, agx_chunk) --------------------------------------------------
+// ---- upload time: the conti-mer tables from their runs in two streaming kernels (agx_core.h: agx_cmseg, agx_cntrun, agx_chunk).  (r02 counted per element with atomicMax,
+// scanned, filled and derived the heads — four kernels and a search per element: 1.06 ms for a 30 Mb unit.)
 // one block per chunk of a count run: cm_start of its positions (+ the heads of empty positions); thread 0 of block 0 closes the table
 __global__ void __launch_bounds__(256) agx_k_cm_layout(const agx_cntrun *runs, const agx_chunk *chunks, agx_u32 *cm_start, agx_cmhead *head, agx_u32 n_pos, agx_u32 n_cm) {
     const agx_chunk c = chunks[blockIdx.x];
@@ -72,10 +42,6 @@ __global__ void __launch_bounds__(256) agx_k_cm_fill(const agx_cmseg *segs, cons
     const agx_cmseg g = segs[c.run];
     const agx_u32 n = g.len - c.off < AGX_CM_CHUNK ? g.len - c.off : AGX_CM_CHUNK;
     for (agx_u32 j = threadIdx.x; j < n; j += 256u) agx_cm_fill_elem(g, c.off + j, cm_start, cm, head);
-}
-__global__ void __launch_bounds__(256) agx_k_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos) {
-    const agx_u32 x = blockIdx.x * 256u + threadIdx.x;
-    if (x <= n_pos) agx_cm_head_pos(cm_start, cm, head, x, n_pos);
 }
 __global__ void __launch_bounds__(256) agx_k_zero(agx_zero_args Z) {
     agx_u32 i = blockIdx.x * 256u + threadIdx.x;
@@ -688,19 +654,10 @@ __global__ void __launch_bounds__(256) agx_k_copy_out(agx_copy_args C) {
 // ---- host-callable launchers (kept in this translation unit so that the engine is plain C++) -------------------------
 extern "C" {
 
-// cnt: [n_pos + 1] zeroed; desc: the one-launch scan's zeroed descriptors (ceil((n_pos + 2) / 4096) words)
-void agx_launch_seg_expand(const agx_cmseg *segs, agx_u32 n_segs, agx_u32 n_elems, agx_u32 *cnt, agx_u32 *cm_start, agx_cmkey *cm, agx_u32 n_pos, unsigned long long *desc, hipStream_t st) {
-    if (n_elems) hipLaunchKernelGGL(agx_k_seg_count, dim3((n_elems + 255) / 256), dim3(256), 0, st, segs, n_segs, n_elems, cnt);
-    agx_launch_exclusive_scan1(cnt, cm_start, n_pos, desc, st);
-    if (n_elems) hipLaunchKernelGGL(agx_k_seg_fill, dim3((n_elems + 255) / 256), dim3(256), 0, st, segs, n_segs, n_elems, cm_start, cm);
-}
 void agx_launch_cm_tables(const void *cnt_runs, const void *cnt_chunks, agx_u32 n_cnt_chunks, const agx_cmseg *segs, const void *seg_chunks, agx_u32 n_seg_chunks,
                            agx_u32 *cm_start, agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, agx_u32 n_cm, hipStream_t st) {
     if (n_cnt_chunks) hipLaunchKernelGGL(agx_k_cm_layout, dim3(n_cnt_chunks), dim3(256), 0, st, (const agx_cntrun *)cnt_runs, (const agx_chunk *)cnt_chunks, cm_start, head, n_pos, n_cm);
     if (n_seg_chunks) hipLaunchKernelGGL(agx_k_cm_fill, dim3(n_seg_chunks), dim3(256), 0, st, segs, (const agx_chunk *)seg_chunks, cm_start, cm, head);
-}
-void agx_launch_cm_head(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, hipStream_t st) {
-    hipLaunchKernelGGL(agx_k_cm_head, dim3(n_pos / 256 + 1), dim3(256), 0, st, cm_start, cm, head, n_pos);
 }
 void agx_launch_zero(const agx_zero_args *Z, hipStream_t st) {
     unsigned long long total = 0; for (int s = 0; s < 8; s++) total += Z->n[s];
