@@ -406,6 +406,10 @@ void reserve_landing(agx_unit *u) {
 }
 void stage_inputs(agx_unit *u) {
     if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
+    // A one-shot unit's download lands in its staged buffers.  The general loader's pairs can be staged again from P; the fast loader wrote the hits, runs and
+    // codes straight into those buffers and kept nothing else: after the download there is nothing to stage from, and clearing `consumed` would send the walk
+    // graph's bytes to the device as wire records.
+    if (u->consumed && u->pairs_staged) throw Error{E_ARG, "one-shot unit: its staged read alignments were overwritten by the download; load the unit again"};
     const double t0 = now_ms();
     HIP_OK(hipSetDevice(u->prm.device));            // (registering host memory needs a current device)
     u->cache_map.reset(); u->reads_map.reset();
@@ -1322,7 +1326,7 @@ int agx_unit_hbm_needed(agx_unit *u, uint64_t *bytes) {
 int agx_unit_stage(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { stage_inputs(u); }); }
 int agx_unit_upload(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_upload(u); }); }
 int agx_unit_release(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_release(u); }); }
-void agx_pool_trim(int device) { if (device >= 0) dev_trim(device); else if (device == -1) host_trim(); else host_retire(); }
+void agx_pool_trim(int device) { if (device >= 0) dev_trim(device); else if (device == -1) { host_trim(); scratch_trim(); } else host_retire(); }      // (-1 also unmaps the loaders' cached scratch memory: up to 16 GB of touched pages per process otherwise stay until exit)
 int agx_unit_build(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_build(u); }); }
 int agx_unit_download(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_download(u); }); }
 

@@ -133,6 +133,10 @@ def main():
     ap.add_argument("--pairs", type=int, default=1000000)
     ap.add_argument("--L", type=int, default=100)
     ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--sam-seq", type=int, default=None, choices=[0, 1],
+                    help="1: the generated SAM carries SEQ, QUAL and tag columns like bowtie2's output (AG:3609) — ~290 bytes per 2x100 bp line; 0: those columns are '*' "
+                         "(~50 bytes per line).  Only T_unit (text parsing) depends on it.  Default: 1 for cfg2 / cfg3 / custom, 0 for the larger shapes (cfg4: 49 GB of text "
+                         "with the columns, more than the box's scratch disk is known to hold); config.workload says which")
     ap.add_argument("--coverage", type=int, default=5, help="--coverage of the run (the reference's default 20 is above the graph depth of these read sets: SURVEY §8d)")
     ap.add_argument("--pool", default="host-cold", choices=["cold", "host-cold", "warm"],
                     help="what the library's memory caches hold when a step starts.  host-cold (default): the pinned-host cache is emptied before every "
@@ -192,17 +196,19 @@ def main():
     else:
         chroms, part, pairs, L, label = CONFIGS[args.config]
     k = args.k
+    sam_seq = args.sam_seq if args.sam_seq is not None else (1 if args.config in ("cfg2", "cfg3", "custom") else 0)
+    label += ", SAM lines %s" % ("with SEQ/QUAL/tag columns as bowtie2 writes them" if sam_seq else "WITHOUT SEQ/QUAL/tag columns ('*': a sixth of an aligner's bytes per line; T_unit is optimistic)")
 
     # ---- synthetic inputs (text files like the reference's tmp/): rank 0 generates, every rank parses its own units ----
     extra = {}
     for kv in filter(None, os.environ.get("AGX_BENCH_SYNTH", "").split(",")):      # experiments only (e.g. contig_overlap=0): changes the workload, the
         key, _, val = kv.partition("=")                                             # JSON line then says so in config.workload
         extra[key] = val
-    run = os.path.join(args.workdir, "%s_p%d_k%d" % ("_".join(str(c) for c in chroms), pairs, k) + ("_x" if extra else ""))
+    run = os.path.join(args.workdir, "%s_p%d_k%d" % ("_".join(str(c) for c in chroms), pairs, k) + ("_x" if extra else "") + ("" if sam_seq else "_noseq"))
     t0 = time.perf_counter()
     stamp = os.path.join(run, "synth_meta.txt")
     if rank == 0 and not os.path.exists(stamp):
-        D.synth(run, seed=1000, chroms=",".join(str(c) for c in chroms), part=part, pairs=pairs, L=L, k=k, coverage=args.coverage, sam_seq=0,
+        D.synth(run, seed=1000, chroms=",".join(str(c) for c in chroms), part=part, pairs=pairs, L=L, k=k, coverage=args.coverage, sam_seq=sam_seq,
                 threads=min(32, os.cpu_count() or 1), **extra)
     if dist:
         dist.barrier()
@@ -350,7 +356,8 @@ def main():
         by_name["(threads that ended: the job's unit threads)"] = (0, cpu_s_per_step * max(1, args.steps) - sum(t for _, t in by_name.values()))
         for name, (n, tot) in sorted(by_name.items(), key=lambda kv: -kv[1][1]):
             print("[bench] threads %-16s x%-3d %8.1f ms of CPU per step" % (name, n, 1e3 * tot / max(1, args.steps)), file=sys.stderr)
-    tot = torch.tensor([elapsed, t_parse, t_stage, float(my_pairs), t_cached], dtype=torch.float64, device=gdev)
+    my_sam_bytes = sum(os.path.getsize(os.path.join(tmp, "_reads_genome.%d.bowtie" % uu)) for uu in mine)
+    tot = torch.tensor([elapsed, t_parse, t_stage, float(my_pairs), t_cached, float(my_sam_bytes)], dtype=torch.float64, device=gdev)
     if dist:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -359,6 +366,7 @@ def main():
     else:
         t_parse_max, t_cached_max = t_parse, t_cached
     sam_pairs_total = int(tot[3].item())
+    sam_bytes_total = int(tot[5].item())
 
     A.pool_trim(-1, host=True)
     # ---- N > 1: the SAME job on ONE GPU (rank 0 alone, all units), so that the speed-up does not rest on comparing different driver runs ----
@@ -500,6 +508,7 @@ def main():
             "speedup_vs_1gpu": round(single_ms / (1e3 * sec_per_step), 3) if single_ms else None,
             "t_core_s": round(sec_per_step, 4),
             "t_unit_s": round(sec_per_step + t_parse_max, 4),
+            "sam_text_bytes": sam_bytes_total, "sam_seq_columns": bool(sam_seq),
             "t_unit_note": "t_core_s + text parsing and staging of the per-unit input files: the five text files of every unit -> staged arrays in pinned memory (slowest rank; its units side by side, each on its share of the cores: %.3f s); the one-off index of tmp/_reads.fa (%.3f s on rank 0, shared by all units of a run) is not in it" % (t_parse_max, t_index),
             "load_ms_per_unit": {str(uu): load_ms[uu] for uu in mine},
             "load_note": "per unit, wall: contigs = unit sequence + contig threading (on a thread of its own, beside the read alignments); read_alignments = SAM parsing, left-mate decision, rows of 2-bit read bases straight into the pinned upload buffers; rest = what the load took beyond the read alignments",

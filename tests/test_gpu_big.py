@@ -74,7 +74,7 @@ CFG3 = [30427671, 19698289, 23459830, 18585056, 26975502]          # = bench.py 
 @slow
 def test_cfg3_full_size_every_unit_matches_the_oracle(agx, built, tmp_path):
     from aligngraph_amd import shard
-    run = H.synth(str(tmp_path / "run"), seed=1000, chroms=",".join(map(str, CFG3)), pairs=20000000, L=100, k=5, coverage=5, sam_seq=0, threads=THREADS)
+    run = H.synth(str(tmp_path / "run"), seed=1000, chroms=",".join(map(str, CFG3)), pairs=20000000, L=100, k=5, coverage=5, sam_seq=1, threads=THREADS)      # full-width SAM lines (SEQ, QUAL, tags: what bowtie2 writes, AG:3609): 12 GB of text for the loaders
     tmp = os.path.join(run, "tmp")
     meta = H.read_meta(run)
     assert meta["unit_len"] == CFG3

@@ -31,6 +31,15 @@ def check(agx, tmp, want, cov, expect_cache):
         with pytest.raises(agx.AgxError) as e:
             u.upload()
         assert e.value.code == agx.AGX_E_ARG and "one-shot" in e.value.msg
+        # nor may staging (or the size query, which stages what is not staged) clear the way for one: the fast loader's staged arrays ARE the buffers the
+        # download landed in, and a unit out of its cache file has nothing left to stage from
+        for again in (u.stage, u.hbm_needed):
+            with pytest.raises(agx.AgxError) as e:
+                again()
+            assert e.value.code == agx.AGX_E_ARG
+        with pytest.raises(agx.AgxError) as e:
+            u.upload()
+        assert e.value.code == agx.AGX_E_ARG and "one-shot" in e.value.msg
         u.load_files(tmp, 0)                     # the inputs handed over again: a new unit
         u.upload(); u.build()
         assert u.finish() == got
