@@ -1262,7 +1262,7 @@ int agx_unit_load_files_shared(agx_unit *u, const char *tmp_dir, int unit, const
         drop_outputs(u);
         HIP_OK(hipSetDevice(u->prm.device));              // (the fast loader writes into pinned memory, and registering it needs a current device)
         u->T = Threads(); u->P = Pairs(); u->pairs_staged = false; u->row_off.clear(); u->row_slot.clear(); u->reads_keep.reset(); u->reads_map.reset(); u->cache_map.reset();
-        u->staged = false; u->uploaded = false; u->built = false;
+        u->staged = false; u->uploaded = false; u->built = false; u->consumed = false;      // (new inputs: whatever a download did to the old staged ones no longer matters)
         double ms_thread = 0;
         std::exception_ptr thread_err;
         auto threads_job = [&] {
