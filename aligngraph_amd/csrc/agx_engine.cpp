@@ -257,6 +257,7 @@ struct agx_unit {
     std::shared_ptr<agx::ReadsIndex> reads_keep;      // the reads file that row_off points into (shared with the caller's agx_reads, or the unit's own)
     std::unique_ptr<agx::FileView> reads_map;          // the same for a unit that came out of its cache file: only the mapping, no index
     bool pairs_staged = false;          // the fast loader has written hits, runs, codes and the list of other bases straight into the staged buffers
+    agx::PairsFile pairs_file;          // the unit's read alignments were handed over staged (tmp/_agx_pairs.<u>.bin, agx_host.h): the mapped file, which the walk takes its k-mer tails from
     // inputs on the device
     DBuf<agx_u32> d_cm_start, d_cm_cnt; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref; DBuf<agx_cmseg> d_segs; DBuf<unsigned long long> d_up_desc;
     DBuf<agx_run> d_runs; DBuf<agx_u8> d_codes, d_vcodes; DBuf<unsigned long long> d_other;
@@ -433,7 +434,11 @@ void stage_inputs(agx_unit *u) {
         adopt_pairs(u, S);
     }
     UnitView V = view_of(u->T, u->P);
-    if (u->pairs_staged) { V.bases = u->reads_keep ? u->reads_keep->fv.p : nullptr; V.stride = u->stride; V.row_off = u->row_off.data(); }
+    if (u->pairs_staged && u->pairs_file.fv) {      // staged pairs from their file: no read bases but the 2-bit rows
+        const agx::PairsFile &F = u->pairs_file;
+        V.bases = nullptr; V.row_off = nullptr; V.stride = u->stride; V.codes2 = (const agx_u8 *)F.sec(pairsfile::S_CODES);
+        V.other_idx = (const unsigned long long *)F.sec(pairsfile::S_OTHER); V.other_byte = (const agx_u8 *)F.sec(pairsfile::S_OTHERB); V.n_other = (size_t)F.H.n_other;
+    } else if (u->pairs_staged) { V.bases = u->reads_keep ? u->reads_keep->fv.p : nullptr; V.stride = u->stride; V.row_off = u->row_off.data(); }
     u->V = V;
     reserve_landing(u);
     u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
@@ -447,23 +452,24 @@ void stage_inputs(agx_unit *u) {
 // mapped and paged in where it is touched.  Valid for one BATCH size, one k and for exactly the five text files it was made from (size and
 // modification time of each are in the header): anything else and the loader falls back to the text.
 namespace cache {
-enum { S_HITS = 0, S_RUNS, S_CODES, S_SEGS, S_CHAIN_END, S_ROWS, S_REF, S_CM_CNT, S_CHAIN_STR, S_INITIAL, S_BASES, S_OTHER, S_SIDES, S_JUMP, S_N };
+enum { S_HITS = 0, S_RUNS, S_CODES, S_SEGS, S_CHAIN_END, S_ROWS, S_REF, S_CM_CNT, S_CHAIN_STR, S_INITIAL, S_BASES, S_OTHER, S_SIDES, S_JUMP, S_OTHERB, S_N };
 struct Header {
-    char magic[8]; agx_u32 version, batch; unsigned long long stamp[5][2];
+    char magic[8]; agx_u32 version, batch; unsigned long long stamp[6][2];      // (size, modification time) of the five text files and of tmp/_agx_pairs.<u>.bin
     unsigned long long n_pos, n_ref, nh, n_runs, n_cm, n_segs, n_seg0, n_rows, n_chain_end, n_codes, pairs_in_file, sam_pairs;
     agx_u32 stride, maxlen, n_slots, k;          // k: the staged hits name their left mate, which depends on it (agx_hit_left_is_mate2)
     agx_u32 rows_in_reads;                       // 1: S_ROWS holds 64-bit offsets into tmp/_reads.fa (whose size and time are part of the stamp), S_BASES is empty; 0: S_ROWS holds the
-                                                 // read slot of every row and S_BASES the slots' bases (units that the general loader parsed)
+                                                 // read slot of every row and S_BASES the slots' bases (units that the general loader parsed); 2: both empty — the k-mer tails come out of
+                                                 // S_CODES (2-bit rows) and S_OTHER / S_OTHERB (units whose alignments were handed over staged: UnitView::codes2)
     agx_u32 slot_stride;                         // bases per read slot in S_BASES (rows_in_reads == 0)
     unsigned long long n_sides, n_jump;
     agx_u32 sizes[5];                            // sizeof agx_whit, agx_wrun, agx_cmseg, Header, agx_wside: a file written by another layout is not this one
     unsigned long long off[S_N], len[S_N];
 };
-const char MAGIC[8] = {'A', 'G', 'X', 'U', 'N', 'I', 'T', '6'};
-void stamps(const std::string &d, int unit, unsigned long long st[5][2]) {
+const char MAGIC[8] = {'A', 'G', 'X', 'U', 'N', 'I', 'T', '7'};
+void stamps(const std::string &d, int unit, unsigned long long st[6][2]) {
     const std::string s = std::to_string(unit);
-    const std::string f[5] = {d + "/_genome." + s + ".fa", d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie"};
-    for (int i = 0; i < 5; i++) { struct stat sb; if (stat(f[i].c_str(), &sb) != 0) { st[i][0] = st[i][1] = ~0ull; continue; }
+    const std::string f[6] = {d + "/_genome." + s + ".fa", d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie", pairsfile::path_of(d, unit)};
+    for (int i = 0; i < 6; i++) { struct stat sb; if (stat(f[i].c_str(), &sb) != 0) { st[i][0] = st[i][1] = ~0ull; continue; }
         st[i][0] = (unsigned long long)sb.st_size; st[i][1] = (unsigned long long)sb.st_mtim.tv_sec * 1000000000ull + (unsigned long long)sb.st_mtim.tv_nsec; }
 }
 std::string path_of(const std::string &d, int unit) { return d + "/_agx_unit." + std::to_string(unit) + ".bin"; }
@@ -474,16 +480,16 @@ void save_cache(agx_unit *u, const std::string &dir, int unit) {
     if (!u->staged || u->cache_map.p) throw Error{E_ARG, "nothing staged from text"};
     Header H; memset(&H, 0, sizeof H); memcpy(H.magic, MAGIC, 8); H.version = 2; H.batch = u->prm.batch;
     stamps(dir, unit, H.stamp);
-    const bool in_reads = u->pairs_staged;
+    const bool from_codes = u->pairs_staged && u->pairs_file.fv, in_reads = u->pairs_staged && !from_codes;
     H.n_pos = u->V.n_pos; H.n_ref = u->V.n_ref; H.nh = u->nh; H.n_runs = u->n_runs; H.n_cm = u->n_cm; H.n_segs = u->n_segs; H.n_seg0 = u->n_seg0; H.n_rows = u->n_rows;
     H.n_chain_end = u->n_chain_end; H.n_codes = u->n_codes; H.pairs_in_file = u->pairs_in_file; H.sam_pairs = u->sam_pairs; H.stride = u->stride; H.maxlen = u->maxlen; H.n_slots = u->n_slots; H.k = u->prm.k;
-    H.rows_in_reads = in_reads ? 1u : 0u; H.sizes[0] = sizeof(agx_whit); H.sizes[1] = sizeof(agx_wrun); H.sizes[2] = sizeof(agx_cmseg); H.sizes[3] = sizeof(Header); H.sizes[4] = sizeof(agx_wside);
+    H.rows_in_reads = from_codes ? 2u : in_reads ? 1u : 0u; H.sizes[0] = sizeof(agx_whit); H.sizes[1] = sizeof(agx_wrun); H.sizes[2] = sizeof(agx_cmseg); H.sizes[3] = sizeof(Header); H.sizes[4] = sizeof(agx_wside);
     H.slot_stride = u->V.stride; H.n_sides = u->n_sides; H.n_jump = u->n_jump;
-    const void *ptr[S_N] = {u->s_hits.p, u->s_runs.p, u->s_codes.p, u->s_segs.p, u->s_chain_end.p, in_reads ? (const void *)u->row_off.data() : (const void *)u->row_slot.data(), u->V.ref, u->V.cm_cnt,
-                            u->V.chain_str, u->V.initial, in_reads ? nullptr : u->V.bases, u->s_other.p, u->s_sides.p, u->s_jump.p};
-    const unsigned long long len[S_N] = {u->nh * sizeof(agx_whit), u->n_runs * sizeof(agx_wrun), u->n_codes, u->n_segs * sizeof(agx_cmseg), (unsigned long long)u->n_chain_end * 4, (unsigned long long)u->n_rows * (in_reads ? 8 : 4),
-                                         u->V.n_pos, u->V.n_pos, u->T.chain_str.size(), u->V.n_initial, in_reads ? 0ull : (unsigned long long)u->n_slots * u->V.stride, (unsigned long long)u->n_other * 8,
-                                         u->n_sides * sizeof(agx_wside), (unsigned long long)u->n_jump * 4};
+    const void *ptr[S_N] = {u->s_hits.p, u->s_runs.p, u->s_codes.p, u->s_segs.p, u->s_chain_end.p, from_codes ? nullptr : in_reads ? (const void *)u->row_off.data() : (const void *)u->row_slot.data(), u->V.ref, u->V.cm_cnt,
+                            u->V.chain_str, u->V.initial, (in_reads || from_codes) ? nullptr : u->V.bases, u->s_other.p, u->s_sides.p, u->s_jump.p, from_codes ? (const void *)u->V.other_byte : nullptr};
+    const unsigned long long len[S_N] = {u->nh * sizeof(agx_whit), u->n_runs * sizeof(agx_wrun), u->n_codes, u->n_segs * sizeof(agx_cmseg), (unsigned long long)u->n_chain_end * 4, from_codes ? 0ull : (unsigned long long)u->n_rows * (in_reads ? 8 : 4),
+                                         u->V.n_pos, u->V.n_pos, u->T.chain_str.size(), u->V.n_initial, (in_reads || from_codes) ? 0ull : (unsigned long long)u->n_slots * u->V.stride, (unsigned long long)u->n_other * 8,
+                                         u->n_sides * sizeof(agx_wside), (unsigned long long)u->n_jump * 4, from_codes ? (unsigned long long)u->n_other : 0ull};
     unsigned long long at = (sizeof(Header) + 4095) & ~4095ull;
     for (int i = 0; i < S_N; i++) { H.off[i] = at; H.len[i] = len[i]; at = (at + len[i] + 4095) & ~4095ull; }
     const std::string path = path_of(dir, unit), part = path + ".part";
@@ -508,55 +514,12 @@ void save_cache(agx_unit *u, const std::string &dir, int unit) {
     if (!ok || rename(part.c_str(), path.c_str()) != 0) { (void)remove(part.c_str()); throw Error{E_IO, "cannot write " + path}; }
 }
 
-// true: the unit is staged from the cache file.  false: no usable cache (missing, another batch size, older than its sources, damaged).
-bool load_cache(agx_unit *u, const std::string &dir, int unit) {
-    using namespace cache;
-    if (getenv("AGX_NO_CACHE")) return false;
-    const std::string path = path_of(dir, unit);
-    const int fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) return false;
-    struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
-    Header H; struct stat sb;
-    if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof H || pread(fd, &H, sizeof H, 0) != (ssize_t)sizeof H) return false;
-    unsigned long long st[5][2]; stamps(dir, unit, st);
-    if (memcmp(H.magic, MAGIC, 8) != 0 || H.version != 2 || H.batch != u->prm.batch || H.k != u->prm.k || memcmp(st, H.stamp, sizeof st) != 0) return false;
-    if (H.sizes[0] != sizeof(agx_whit) || H.sizes[1] != sizeof(agx_wrun) || H.sizes[2] != sizeof(agx_cmseg) || H.sizes[3] != sizeof(Header) || H.sizes[4] != sizeof(agx_wside)) return false;
-    for (int i = 0; i < S_N; i++) if (H.off[i] > (unsigned long long)sb.st_size || H.len[i] > (unsigned long long)sb.st_size - H.off[i]) return false;
-    const bool in_reads = H.rows_in_reads == 1;
-    if (H.n_pos == 0 || H.n_pos >= 0xFFFFFF00ull || H.n_ref > H.n_pos || H.len[S_REF] != H.n_pos || H.len[S_CM_CNT] != H.n_pos || H.len[S_HITS] != H.nh * sizeof(agx_whit) || H.len[S_RUNS] != H.n_runs * sizeof(agx_wrun) ||
-        H.len[S_SIDES] != H.n_sides * sizeof(agx_wside) || H.n_sides > H.nh || H.len[S_JUMP] != H.n_jump * 4 || H.n_jump > H.nh ||
-        H.len[S_CODES] != H.n_codes || H.len[S_SEGS] != H.n_segs * sizeof(agx_cmseg) || H.n_seg0 > H.n_segs || H.len[S_ROWS] != H.n_rows * (in_reads ? 8 : 4) || (H.stride & 3u) ||
-        H.len[S_BASES] != (in_reads ? 0ull : (unsigned long long)H.n_slots * H.slot_stride) || H.len[S_CHAIN_END] != H.n_chain_end * 4 || H.n_codes != H.n_rows * (H.stride / 4) || (H.len[S_OTHER] & 7u) ||
-        H.nh >= 0xFFFFFFFFull || H.n_runs >= 0xFFFFFFFFull || H.n_rows >= 0x7FFFFFFFull || H.maxlen > H.stride || (!in_reads && H.maxlen > H.slot_stride)) return false;
-    HIP_OK(hipSetDevice(u->prm.device));
-    const double t0 = now_ms();
-    std::unique_ptr<FileView> reads_map;
-    if (in_reads) { try { reads_map.reset(new FileView(dir + "/_reads.fa")); } catch (const Error &) { return false; } if (reads_map->n != st[3][0]) return false; }
-    void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-    if (m == MAP_FAILED) return false;
-    drop_outputs(u);
-    u->T = Threads(); u->P = Pairs(); u->cache_map.reset(); u->cache_map.p = m; u->cache_map.n = (size_t)sb.st_size; u->reads_keep.reset(); u->reads_map.reset();
-    const char *base = (const char *)m;
-    u->nh = H.nh; u->n_runs = H.n_runs; u->n_sides = H.n_sides; u->n_jump = H.n_jump; u->n_cm = H.n_cm; u->n_segs = H.n_segs; u->n_seg0 = (agx_u32)H.n_seg0; u->n_chain_end = (agx_u32)H.n_chain_end; u->n_codes = H.n_codes; u->n_other = H.len[S_OTHER] / 8;
-    u->pairs_in_file = H.pairs_in_file; u->sam_pairs = H.sam_pairs; u->stride = H.stride; u->maxlen = H.maxlen; u->n_slots = H.n_slots; u->n_rows = (agx_u32)H.n_rows;
-    u->s_hits.alloc(u->nh + 1); u->s_sides.alloc(u->n_sides + 1); u->s_jump.alloc(u->n_jump + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16); u->s_other.alloc(u->n_other + 1); u->s_segs.alloc(u->n_segs + 1); u->s_chain_end.alloc((size_t)u->n_chain_end + 1);
-    // the staged arrays: read into the pinned buffers, a few threads, large pieces
-    struct Piece { void *dst; unsigned long long off, len; };
-    std::vector<Piece> pieces;
-    auto cut = [&](void *dst, int sec) { for (unsigned long long a = 0; a < H.len[sec]; a += 32ull << 20) pieces.push_back(Piece{(char *)dst + a, H.off[sec] + a, std::min<unsigned long long>(32ull << 20, H.len[sec] - a)}); };
-    cut(u->s_hits.p, S_HITS); cut(u->s_sides.p, S_SIDES); cut(u->s_jump.p, S_JUMP); cut(u->s_runs.p, S_RUNS); cut(u->s_codes.p, S_CODES); cut(u->s_other.p, S_OTHER); cut(u->s_segs.p, S_SEGS); cut(u->s_chain_end.p, S_CHAIN_END);
-    const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), pieces.size() ? pieces.size() : 1);
-    std::vector<int> bad(threads, 0);
-    on_threads(threads, [&](unsigned t) {
-        for (size_t i = t; i < pieces.size(); i += threads) {
-            size_t done = 0;
-            while (done < pieces[i].len) { const ssize_t r = pread(fd, (char *)pieces[i].dst + done, pieces[i].len - done, (off_t)(pieces[i].off + done)); if (r <= 0) { bad[t] = 1; return; } done += (size_t)r; }
-        }
-    });
+// The staged read alignments in u->s_* (read from a cache file or a staged-pairs file): everything the device and the walk index with must be in range — a file whose lengths
+// are intact but whose content is not is a reason to refuse it, not to read out of bounds.
+bool staged_pairs_fine(agx_unit *u, unsigned long long n_rows, agx_u32 stride, agx_u32 maxlen, unsigned long long n_runs, unsigned long long n_sides, unsigned threads) {
     bool fine = true;
-    for (int b : bad) fine = fine && !b;
-    // what the device and the walk index with must be in range: a file whose lengths are intact but whose content is not is a reason to parse the text again, not to read out of bounds
-    if (fine) {
+    struct { unsigned long long n_rows, n_runs, n_sides; agx_u32 stride, maxlen; } H{n_rows, n_runs, n_sides, stride, maxlen};
+    {
         const unsigned long long n_bases = H.n_rows * (unsigned long long)H.stride;
         for (size_t i = 0; i < u->n_other && fine; i++) fine = u->s_other.p[i] < n_bases;
         std::vector<int> bad2(threads, 0); std::vector<size_t> jumps(threads, 0);
@@ -580,12 +543,89 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
             fine = h < u->nh && (i == 0 || u->s_jump.p[i - 1] < h);
             if (fine) { const agx_whit &w = u->s_hits.p[h]; fine = (w.flags & ((w.flags & AGX_WF_LEFT2) ? AGX_WF_RUNS2 : AGX_WF_RUNS1)) != 0; if (fine) { const agx_hit x = agx_unpack_hit(w, u->s_sides.p); fine = ((x.pad[0] & 1u) ? x.nruns2 : x.nruns1) >= 2; } }
         }
+    }
+    return fine;
+}
+
+// A unit's read alignments out of tmp/_agx_pairs.<u>.bin (agx_host.h: pairsfile): the arrays into the pinned upload buffers, checked like a cache file's; the mapped file stays
+// with the unit (the walk takes the k-mer tails of written records from its 2-bit rows).
+void load_staged_pairs(agx_unit *u, agx::PairsFile &F) {
+    using namespace pairsfile;
+    const Header &H = F.H;
+    if (H.k != u->prm.k || H.batch != u->prm.batch) throw Error{E_ARG, "tmp/_agx_pairs: staged for another k or another BATCH than this unit's"};
+    u->nh = H.nh; u->n_runs = H.n_runs; u->n_sides = H.n_sides; u->n_jump = H.n_jump; u->n_codes = H.n_codes; u->n_other = H.n_other; u->stride = H.stride; u->maxlen = H.maxlen; u->n_rows = H.n_rows;
+    u->pairs_in_file = H.pairs_in_file; u->sam_pairs = H.sam_pairs; u->n_slots = 0; u->row_off.clear(); u->row_slot.clear(); u->reads_keep.reset(); u->reads_map.reset();
+    u->s_hits.alloc(u->nh + 1); u->s_sides.alloc(u->n_sides + 1); u->s_jump.alloc(u->n_jump + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16); u->s_other.alloc(u->n_other + 1);
+    struct Piece { void *dst; const char *src; size_t len; };
+    std::vector<Piece> pieces;
+    auto cut = [&](void *dst, int sec) { for (unsigned long long a = 0; a < H.len[sec]; a += 32ull << 20) pieces.push_back(Piece{(char *)dst + a, F.sec(sec) + a, (size_t)std::min<unsigned long long>(32ull << 20, H.len[sec] - a)}); };
+    cut(u->s_hits.p, S_HITS); cut(u->s_sides.p, S_SIDES); cut(u->s_jump.p, S_JUMP); cut(u->s_runs.p, S_RUNS); cut(u->s_codes.p, S_CODES); cut(u->s_other.p, S_OTHER);
+    const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, usable_cpus())), pieces.size() ? pieces.size() : 1);
+    on_threads(threads, [&](unsigned t) { for (size_t i = t; i < pieces.size(); i += threads) memcpy(pieces[i].dst, pieces[i].src, pieces[i].len); });
+    bool fine = staged_pairs_fine(u, H.n_rows, H.stride, H.maxlen, H.n_runs, H.n_sides, threads);
+    for (size_t i = 1; i < u->n_other && fine; i++) fine = u->s_other.p[i - 1] < u->s_other.p[i];      // (the walk bisects the list)
+    if (!fine) throw Error{E_FORMAT, "tmp/_agx_pairs: the staged arrays are inconsistent"};
+    u->pairs_staged = true; u->pairs_file = std::move(F);
+}
+
+// true: the unit is staged from the cache file.  false: no usable cache (missing, another batch size, older than its sources, damaged).
+bool load_cache(agx_unit *u, const std::string &dir, int unit) {
+    using namespace cache;
+    if (getenv("AGX_NO_CACHE")) return false;
+    const std::string path = path_of(dir, unit);
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
+    Header H; struct stat sb;
+    if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof H || pread(fd, &H, sizeof H, 0) != (ssize_t)sizeof H) return false;
+    unsigned long long st[6][2]; stamps(dir, unit, st);
+    if (memcmp(H.magic, MAGIC, 8) != 0 || H.version != 2 || H.batch != u->prm.batch || H.k != u->prm.k || memcmp(st, H.stamp, sizeof st) != 0) return false;
+    if (H.sizes[0] != sizeof(agx_whit) || H.sizes[1] != sizeof(agx_wrun) || H.sizes[2] != sizeof(agx_cmseg) || H.sizes[3] != sizeof(Header) || H.sizes[4] != sizeof(agx_wside)) return false;
+    for (int i = 0; i < S_N; i++) if (H.off[i] > (unsigned long long)sb.st_size || H.len[i] > (unsigned long long)sb.st_size - H.off[i]) return false;
+    const bool in_reads = H.rows_in_reads == 1, from_codes = H.rows_in_reads == 2;
+    if (H.rows_in_reads > 2) return false;
+    if (H.n_pos == 0 || H.n_pos >= 0xFFFFFF00ull || H.n_ref > H.n_pos || H.len[S_REF] != H.n_pos || H.len[S_CM_CNT] != H.n_pos || H.len[S_HITS] != H.nh * sizeof(agx_whit) || H.len[S_RUNS] != H.n_runs * sizeof(agx_wrun) ||
+        H.len[S_SIDES] != H.n_sides * sizeof(agx_wside) || H.n_sides > H.nh || H.len[S_JUMP] != H.n_jump * 4 || H.n_jump > H.nh ||
+        H.len[S_CODES] != H.n_codes || H.len[S_SEGS] != H.n_segs * sizeof(agx_cmseg) || H.n_seg0 > H.n_segs || H.len[S_ROWS] != (from_codes ? 0ull : H.n_rows * (in_reads ? 8 : 4)) || (H.stride & 3u) || H.len[S_OTHERB] != (from_codes ? H.len[S_OTHER] / 8 : 0ull) ||
+        H.len[S_BASES] != ((in_reads || from_codes) ? 0ull : (unsigned long long)H.n_slots * H.slot_stride) || H.len[S_CHAIN_END] != H.n_chain_end * 4 || H.n_codes != H.n_rows * (H.stride / 4) || (H.len[S_OTHER] & 7u) ||
+        H.nh >= 0xFFFFFFFFull || H.n_runs >= 0xFFFFFFFFull || H.n_rows >= 0x7FFFFFFFull || H.maxlen > H.stride || (!in_reads && !from_codes && H.maxlen > H.slot_stride)) return false;
+    HIP_OK(hipSetDevice(u->prm.device));
+    const double t0 = now_ms();
+    std::unique_ptr<FileView> reads_map;
+    if (in_reads) { try { reads_map.reset(new FileView(dir + "/_reads.fa")); } catch (const Error &) { return false; } if (reads_map->n != st[3][0]) return false; }
+    void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) return false;
+    drop_outputs(u);
+    u->T = Threads(); u->P = Pairs(); u->cache_map.reset(); u->cache_map.p = m; u->cache_map.n = (size_t)sb.st_size; u->reads_keep.reset(); u->reads_map.reset(); u->pairs_file = agx::PairsFile();
+    const char *base = (const char *)m;
+    u->nh = H.nh; u->n_runs = H.n_runs; u->n_sides = H.n_sides; u->n_jump = H.n_jump; u->n_cm = H.n_cm; u->n_segs = H.n_segs; u->n_seg0 = (agx_u32)H.n_seg0; u->n_chain_end = (agx_u32)H.n_chain_end; u->n_codes = H.n_codes; u->n_other = H.len[S_OTHER] / 8;
+    u->pairs_in_file = H.pairs_in_file; u->sam_pairs = H.sam_pairs; u->stride = H.stride; u->maxlen = H.maxlen; u->n_slots = H.n_slots; u->n_rows = (agx_u32)H.n_rows;
+    u->s_hits.alloc(u->nh + 1); u->s_sides.alloc(u->n_sides + 1); u->s_jump.alloc(u->n_jump + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16); u->s_other.alloc(u->n_other + 1); u->s_segs.alloc(u->n_segs + 1); u->s_chain_end.alloc((size_t)u->n_chain_end + 1);
+    // the staged arrays: read into the pinned buffers, a few threads, large pieces
+    struct Piece { void *dst; unsigned long long off, len; };
+    std::vector<Piece> pieces;
+    auto cut = [&](void *dst, int sec) { for (unsigned long long a = 0; a < H.len[sec]; a += 32ull << 20) pieces.push_back(Piece{(char *)dst + a, H.off[sec] + a, std::min<unsigned long long>(32ull << 20, H.len[sec] - a)}); };
+    cut(u->s_hits.p, S_HITS); cut(u->s_sides.p, S_SIDES); cut(u->s_jump.p, S_JUMP); cut(u->s_runs.p, S_RUNS); cut(u->s_codes.p, S_CODES); cut(u->s_other.p, S_OTHER); cut(u->s_segs.p, S_SEGS); cut(u->s_chain_end.p, S_CHAIN_END);
+    const unsigned threads = (unsigned)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), pieces.size() ? pieces.size() : 1);
+    std::vector<int> bad(threads, 0);
+    on_threads(threads, [&](unsigned t) {
+        for (size_t i = t; i < pieces.size(); i += threads) {
+            size_t done = 0;
+            while (done < pieces[i].len) { const ssize_t r = pread(fd, (char *)pieces[i].dst + done, pieces[i].len - done, (off_t)(pieces[i].off + done)); if (r <= 0) { bad[t] = 1; return; } done += (size_t)r; }
+        }
+    });
+    bool fine = true;
+    for (int b : bad) fine = fine && !b;
+    // what the device and the walk index with must be in range: a file whose lengths are intact but whose content is not is a reason to parse the text again, not to read out of bounds
+    if (fine) {
+        fine = staged_pairs_fine(u, H.n_rows, H.stride, H.maxlen, H.n_runs, H.n_sides, threads);
         unsigned long long el = 0;
         for (size_t i = 0; i < u->n_segs && fine; i++) { const agx_cmseg &g = u->s_segs.p[i]; fine = (unsigned long long)g.pos0 + g.len <= H.n_pos && g.hop_end < H.n_pos && (unsigned long long)g.hop_str0 + g.hop_len0 <= H.len[S_CHAIN_STR] + 1 && g.elem0 == el; el += g.len; }
         fine = fine && el == H.n_cm;
         for (size_t i = 0; i < u->n_chain_end && fine; i++) fine = u->s_chain_end.p[i] < H.n_pos;
         if (fine && in_reads) { const uint64_t *ro = (const uint64_t *)(base + H.off[S_ROWS]); for (size_t r = 0; r < H.n_rows && fine; r++) fine = ro[r] + H.stride <= reads_map->n + 16 && ro[r] < reads_map->n; }
-        if (fine && !in_reads) { const agx_u32 *rs = (const agx_u32 *)(base + H.off[S_ROWS]); for (size_t r = 0; r < H.n_rows && fine; r++) fine = rs[r] < H.n_slots; }
+        if (fine && !in_reads && !from_codes) { const agx_u32 *rs = (const agx_u32 *)(base + H.off[S_ROWS]); for (size_t r = 0; r < H.n_rows && fine; r++) fine = rs[r] < H.n_slots; }
+        for (size_t i = 1; i < u->n_other && fine && from_codes; i++) fine = u->s_other.p[i - 1] < u->s_other.p[i];      // (the walk bisects the list)
     }
     if (!fine) { u->cache_map.reset(); return false; }
     const double tv = now_ms();
@@ -594,9 +634,10 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     stage_cm_layout(u, (const agx_u8 *)(base + H.off[S_CM_CNT]), H.n_pos, u->s_segs.p, u->n_segs);
     if (getenv("AGX_LOAD_TIMING")) fprintf(stderr, "[agx load] cache: buffers + read + checks %.1f ms, reference %.1f ms, conti-mer layout %.1f ms\n", tv - t0, tr - tv, now_ms() - tr);
     UnitView V; V.ref = base + H.off[S_REF]; V.n_pos = H.n_pos; V.n_ref = (agx_u32)H.n_ref; V.cm_cnt = (const agx_u8 *)(base + H.off[S_CM_CNT]); V.chain_str = base + H.off[S_CHAIN_STR];
-    V.hop = nullptr; V.segs = (const agx_cmseg *)(base + H.off[S_SEGS]); V.n_seg0 = (agx_u32)H.n_seg0; V.stride = in_reads ? H.stride : H.slot_stride; V.initial = base + H.off[S_INITIAL]; V.n_initial = H.len[S_INITIAL];
+    V.hop = nullptr; V.segs = (const agx_cmseg *)(base + H.off[S_SEGS]); V.n_seg0 = (agx_u32)H.n_seg0; V.stride = (in_reads || from_codes) ? H.stride : H.slot_stride; V.initial = base + H.off[S_INITIAL]; V.n_initial = H.len[S_INITIAL];
     u->row_off.clear(); u->row_slot.clear();
-    if (in_reads) { u->reads_map = std::move(reads_map); V.bases = u->reads_map->p; V.row_off = (const uint64_t *)(base + H.off[S_ROWS]); }
+    if (from_codes) { V.bases = nullptr; V.codes2 = (const agx_u8 *)(base + H.off[S_CODES]); V.other_idx = (const unsigned long long *)(base + H.off[S_OTHER]); V.other_byte = (const agx_u8 *)(base + H.off[S_OTHERB]); V.n_other = u->n_other; }
+    else if (in_reads) { u->reads_map = std::move(reads_map); V.bases = u->reads_map->p; V.row_off = (const uint64_t *)(base + H.off[S_ROWS]); }
     else { V.bases = base + H.off[S_BASES]; u->row_slot.assign((const agx_u32 *)(base + H.off[S_ROWS]), (const agx_u32 *)(base + H.off[S_ROWS]) + H.n_rows); }
     u->V = V; u->pairs_staged = false;
     reserve_landing(u);
@@ -1261,7 +1302,7 @@ int agx_unit_load_files_shared(agx_unit *u, const char *tmp_dir, int unit, const
         const bool fast = getenv("AGX_NO_FAST_LOAD") == nullptr;
         drop_outputs(u);
         HIP_OK(hipSetDevice(u->prm.device));              // (the fast loader writes into pinned memory, and registering it needs a current device)
-        u->T = Threads(); u->P = Pairs(); u->pairs_staged = false; u->row_off.clear(); u->row_slot.clear(); u->reads_keep.reset(); u->reads_map.reset(); u->cache_map.reset();
+        u->T = Threads(); u->P = Pairs(); u->pairs_staged = false; u->row_off.clear(); u->row_slot.clear(); u->reads_keep.reset(); u->reads_map.reset(); u->cache_map.reset(); u->pairs_file = agx::PairsFile();
         u->staged = false; u->uploaded = false; u->built = false; u->consumed = false;      // (new inputs: whatever a download did to the old staged ones no longer matters)
         double ms_thread = 0;
         std::exception_ptr thread_err;
@@ -1283,9 +1324,13 @@ int agx_unit_load_files_shared(agx_unit *u, const char *tmp_dir, int unit, const
         std::exception_ptr pairs_err;
         try {
             const std::string sam = d + "/_reads_genome." + s + ".bowtie";
-            std::shared_ptr<ReadsIndex> idx = reads ? reads->idx : std::shared_ptr<ReadsIndex>(reads_index_open(d + "/_reads.fa"), reads_index_close);
             bool done = false;
-            if (fast) {
+            {   // the alignments handed over staged (tmp/_agx_pairs.<u>.bin) stand in for the two text files
+                agx::PairsFile F;
+                if (open_pairs_file(pairsfile::path_of(d, unit), F)) { load_staged_pairs(u, F); done = true; }
+            }
+            std::shared_ptr<ReadsIndex> idx = done ? std::shared_ptr<ReadsIndex>() : reads ? reads->idx : std::shared_ptr<ReadsIndex>(reads_index_open(d + "/_reads.fa"), reads_index_close);
+            if (!done && fast) {
                 struct stat sb; const size_t sam_bytes = stat(sam.c_str(), &sb) == 0 ? (size_t)sb.st_size : 0;
                 UnitSink sink(u); StagedPairs S;
                 if (load_pairs_fast(*idx, sam, (long)u->prm.batch, u->prm.k, loader_threads(sam_bytes), sink, S)) { adopt_pairs(u, S); u->pairs_staged = true; u->reads_keep = idx; u->n_slots = 0; done = true; }

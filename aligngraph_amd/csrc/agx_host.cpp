@@ -323,57 +323,10 @@ void load_pairs_from_files(const std::string &reads_fa, const std::string &sam_p
     FileView sf(sam_path);
     if (batch <= 0) batch = 1000000;
 
-    // ---- pass 1 over the SAM: kept hits, in order, with the batch-boundary rule applied ----------------
-    std::vector<agx_u32> hit_id;                 // read id per kept hit
-    P.n_pairs_in_file = reads->headers / 2;      // decides where the last batch ends: header lines up to the first empty line
-    const long long N = (long long)P.n_pairs_in_file, B = batch;
-    if (N == 0) throw Error{E_FORMAT, "reads file holds no pairs"};
-    // batch n loads pairs [lo, hi]; `final_batch` = loadSeq reached the end of the reads file while loading it (AG:397).
-    // A reads file of exactly m*B pairs is followed by one EMPTY batch (lo = N) in which every alignment is skipped (AG:1258).
-    long long lo = 0, hi = std::min<long long>(B, N) - 1;
-    bool final_batch = hi == N - 1 && N % B != 0;
-    agx_u32 prev_id = 0; bool any = false; agx_u32 back = 0;
-    // one parsed line pair -> at most one kept hit.  m.run0 indexes `src`.  Returns false when the final batch is over (AG:1259).
-    auto consume = [&](const Mate &m1, const Mate &m2, const agx_run *src) -> bool {
-        P.n_sam_pairs++;
-        const long long id = (long long)m1.id;
-        if (id < lo) {
-            if (lo > hi) return true;                            // the empty last batch skips everything
-            throw Error{E_UNSUPPORTED, "SAM is not sorted by read id (bowtie2 --reorder output expected)"};
-        }
-        if (id > hi) {                                           // AG:1259: this line pair is consumed and lost; the next batch begins
-            if (final_batch) return false;
-            lo = hi + 1; hi = std::min<long long>(lo + B, N) - 1;
-            final_batch = lo == N || (hi == N - 1 && N % B != 0);
-            return true;
-        }
-        const bool keep = m1.aligned && m2.aligned && passes(m1) && passes(m2);
-        if (!keep) return true;
-        if (m1.id != m2.id) throw Error{E_UNSUPPORTED, "SAM mates of one pair are not on adjacent lines"};
-        if (any && m1.id < prev_id) throw Error{E_UNSUPPORTED, "SAM is not sorted by read id (bowtie2 --reorder output expected)"};
-        back = (any && m1.id == prev_id) ? back + 1 : 0;
-        if (back > 250) throw Error{E_UNSUPPORTED, "more than 250 hits for one pair"};
-        prev_id = m1.id; any = true;
-        agx_hit h; memset(&h, 0, sizeof h);
-        h.slot1 = m1.id;                                       // read id for now; turned into a slot in pass 2
-        h.len = 0; h.rev1 = (agx_u8)m1.fr; h.rev2 = (agx_u8)m2.fr; h.back = (agx_u8)back;
-        auto fill = [&](const Mate &m, agx_u32 &pos, agx_u32 &r0, agx_u16 &nr) {
-            // "simple" = a single M run that covers the whole read; only the runs of non-simple mates go to the pool, contiguous per mate
-            if (m.nruns == 1 && src[m.run0].q == 0 && src[m.run0].n == m.total) { pos = src[m.run0].t; r0 = 0; nr = 0; return; }
-            if (m.nruns > 60000) throw Error{E_UNSUPPORTED, "CIGAR with too many runs"};
-            pos = 0; r0 = (agx_u32)P.runs.size(); nr = (agx_u16)m.nruns;
-            P.runs.insert(P.runs.end(), src + m.run0, src + m.run0 + m.nruns);
-            for (agx_u32 i = 1; i < nr; i++)                     // runs must advance on the reference (SAM guarantees it)
-                if (P.runs[r0 + i].t < P.runs[r0 + i - 1].t + P.runs[r0 + i - 1].n) throw Error{E_UNSUPPORTED, "alignment runs do not advance on the reference"};
-        };
-        fill(m1, h.pos1, h.runs1, h.nruns1); fill(m2, h.pos2, h.runs2, h.nruns2);
-        if (m1.total != m2.total) throw Error{E_UNSUPPORTED, "mates of one pair have different CIGAR lengths"};
-        if (m1.total > 65000) throw Error{E_UNSUPPORTED, "read longer than 65000"};
-        h.len = (agx_u16)m1.total;
-        P.hits.push_back(h);
-        hit_id.push_back(m1.id);
-        return true;
-    };
+    // ---- pass 1 over the SAM: kept hits, in order, with the batch-boundary rule applied (PairRules, agx_parse.h) ----------------
+    PairRules rules(P, reads->headers / 2, batch);      // (reads->headers: header lines up to the first empty line — decides where the last batch ends)
+    std::vector<agx_u32> &hit_id = rules.hit_id;
+    auto consume = [&](const Mate &m1, const Mate &m2, const agx_run *src) -> bool { return rules.consume(m1, m2, src); };
 
     // Parsing the text (field splitting, CIGAR walk) is the expensive part and independent per line pair; the rules above are cheap but
     // sequential.  Large, clean files (no '@' lines, no empty line before the end) are therefore cut into byte ranges aligned to line

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 #include "agx_core.h"
@@ -62,6 +63,10 @@ struct UnitView {
     const agx_cmseg *segs = nullptr; agx_u32 n_seg0 = 0;              // the conti-mer chains as runs (rank-0 runs first, by position): hop entries by bisection (agx_seg_hop)
     const char *bases = nullptr; agx_u32 stride = 0;                  // read bases, slot s at bases + s * stride (k-mer strings of written records)
     const uint64_t *row_off = nullptr;                                // or: row r of the staged read bases starts at bases + row_off[r] (the mapped reads file; GraphView::row_slot is then not consulted)
+    // or (bases == nullptr): the k-mer tails come out of the staged 2-bit rows themselves — row r = codes2 + r * (stride / 4), base j in bits 2 * (j & 3) of byte j >> 2 (agx_pack_classes2) —
+    // and the list of the bases that are not A, C, G, T (index r * stride + j, ascending) with their bytes.  Units whose read alignments were handed over staged (tmp/_agx_pairs.<u>.bin) have
+    // nothing else; the arrays live in the mapped file (the pinned copies are gone once a one-shot unit has been downloaded).
+    const agx_u8 *codes2 = nullptr; const unsigned long long *other_idx = nullptr; const agx_u8 *other_byte = nullptr; size_t n_other = 0;
     bool has_cm(size_t x) const { return cm_cnt ? cm_cnt[x] != 0 : cm_start[x + 1] > cm_start[x]; }
     agx_u32 cm_count(size_t x) const { return cm_cnt ? cm_cnt[x] : cm_start[x + 1] - cm_start[x]; }
     const char *initial = nullptr; size_t n_initial = 0;              // bytes of tmp/_initial_contigs.<u>.fa
@@ -201,6 +206,28 @@ struct CmLayout { std::vector<agx_cntrun> cnt_runs; std::vector<agx_chunk> cnt_c
 void build_seg_index(const agx_cmseg *segs, size_t n_seg0, size_t n_pos, std::vector<agx_u32> &index);      // agx_compact_args::seg_index
 void build_cm_layout(const agx_u8 *cm_cnt, size_t n_pos, const agx_cmseg *segs, size_t n_segs, CmLayout &L);      // (seg_index is built separately: it needs n_seg0)
 bool pack_reference(const char *ref, size_t n, unsigned threads, agx_u8 *packed /* (n + 3) / 4 + 16 bytes */, std::vector<agx_refx> &others);
+
+// tmp/_agx_pairs.<u>.bin — a unit's read alignments handed over STAGED (the wire formats of agx_core.h) instead of as SAM text + tmp/_reads.fa: what an aligner that is
+// linked with the engine (or a generator of synthetic alignments: tools/agx_synth.cpp) writes where the reference's flow distributes SAM lines (AG:3545-3579).  The arrays are
+// exactly what the loaders + staging produce from the text (tests/test_staged_pairs.py compares them byte for byte); they depend on k (which mate is the left one) and on
+// BATCH (which line pairs the batch boundaries drop), both in the header.  agx_unit_load_files takes the file when it is there and does not look for the two text files.
+namespace pairsfile {
+enum { S_HITS = 0, S_SIDES, S_RUNS, S_CODES, S_OTHER, S_OTHERB, S_JUMP, S_N };
+struct Header {
+    char magic[8]; agx_u32 version, k, batch, stride, maxlen, n_rows;
+    unsigned long long nh, n_sides, n_runs, n_codes, n_other, n_jump, pairs_in_file, sam_pairs;
+    agx_u32 sizes[3];                            // sizeof agx_whit, agx_wside, agx_wrun
+    unsigned long long off[S_N], len[S_N];
+};
+const char MAGIC[8] = {'A', 'G', 'X', 'P', 'A', 'I', 'R', '1'};
+inline std::string path_of(const std::string &dir, int unit) { return dir + "/_agx_pairs." + std::to_string(unit) + ".bin"; }
+}  // namespace pairsfile
+// other_bytes[i] = the byte of listed base i (S.other[i]).  Throws Error{E_IO} if the file cannot be written.
+void write_pairs_file(const std::string &path, const StagedPairs &S, const agx_u8 *other_bytes, agx_u32 k, agx_u32 batch);
+std::vector<agx_u8> other_bytes_of(const Pairs &P, const StagedPairs &S);      // from the general loader's containers (S.row_slot names P's read slots)
+// maps and checks the header and the section lengths (not the content); false: no such file.  Throws Error{E_FORMAT} on a file that is not one.
+struct PairsFile { std::unique_ptr<FileView> fv; pairsfile::Header H; const char *sec(int i) const { return fv->p + H.off[i]; } };
+bool open_pairs_file(const std::string &path, PairsFile &F);
 
 // agx_host.cpp
 void load_unit_reference(const std::string &path, std::string &ref);

@@ -18,6 +18,8 @@
 //                      prefix computations over the ranges; the left mate of every hit (AG:1672-1679) is decided where it is parsed and only
 //                      its bases are fetched from the mapped reads file, straight into 2-bit classes in the upload buffer.
 #include "agx_host.h"
+#include <sys/stat.h>
+#include <unistd.h>
 #include "agx_parse.h"
 
 #include <atomic>
@@ -446,6 +448,50 @@ void stage_pairs(const Pairs &P, agx_u32 k, unsigned threads, StageSink &sink, S
     S.other = (unsigned long long *)sink.take(SA_OTHER, (S.n_other + 1) * 8);
     { size_t at = 0; for (const auto &o : other) { if (!o.empty()) memcpy(S.other + at, o.data(), o.size() * 8); at += o.size(); } }      // (threads take ascending row ranges: the list is sorted)
     if (staged_out) staged_out->swap(st);
+}
+
+// ---- tmp/_agx_pairs.<u>.bin (agx_host.h) -------------------------------------------------------------------------------------------------------
+std::vector<agx_u8> other_bytes_of(const Pairs &P, const StagedPairs &S) {
+    std::vector<agx_u8> out(S.n_other);
+    for (size_t i = 0; i < S.n_other; i++) {
+        const unsigned long long x = S.other[i]; const size_t r = (size_t)(x / S.stride), j = (size_t)(x % S.stride);
+        if (r >= S.row_slot.size()) throw Error{E_ARG, "listed base beyond the rows"};
+        out[i] = (agx_u8)P.bases[(size_t)S.row_slot[r] * P.stride + j];
+    }
+    return out;
+}
+void write_pairs_file(const std::string &path, const StagedPairs &S, const agx_u8 *other_bytes, agx_u32 k, agx_u32 batch) {
+    using namespace pairsfile;
+    Header H; memset(&H, 0, sizeof H); memcpy(H.magic, MAGIC, 8); H.version = 1; H.k = k; H.batch = batch ? batch : 1000000u; H.stride = S.stride; H.maxlen = S.maxlen; H.n_rows = S.n_rows;
+    H.nh = S.nh; H.n_sides = S.n_sides; H.n_runs = S.n_runs; H.n_codes = S.n_codes; H.n_other = S.n_other; H.n_jump = S.n_jump; H.pairs_in_file = S.n_pairs_in_file; H.sam_pairs = S.n_sam_pairs;
+    H.sizes[0] = sizeof(agx_whit); H.sizes[1] = sizeof(agx_wside); H.sizes[2] = sizeof(agx_wrun);
+    const void *ptr[S_N] = {S.hits, S.sides, S.runs, S.codes, S.other, other_bytes, S.jump};
+    const unsigned long long len[S_N] = {S.nh * sizeof(agx_whit), S.n_sides * sizeof(agx_wside), S.n_runs * sizeof(agx_wrun), S.n_codes, S.n_other * 8ull, S.n_other, S.n_jump * 4ull};
+    unsigned long long at = (sizeof(Header) + 4095) & ~4095ull;
+    for (int i = 0; i < S_N; i++) { H.off[i] = at; H.len[i] = len[i]; at = (at + len[i] + 4095) & ~4095ull; }
+    const std::string part = path + ".part";
+    FILE *f = fopen(part.c_str(), "wb");
+    if (!f) throw Error{E_IO, "CANNOT OPEN FILE! (" + part + ")"};
+    bool ok = fwrite(&H, sizeof H, 1, f) == 1;
+    for (int i = 0; i < S_N && ok; i++) { ok = fseeko(f, (off_t)H.off[i], SEEK_SET) == 0 && (len[i] == 0 || fwrite(ptr[i], 1, len[i], f) == len[i]); }
+    if (ok) ok = ftruncate(fileno(f), (off_t)at) == 0;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(part.c_str(), path.c_str()) != 0) { (void)remove(part.c_str()); throw Error{E_IO, "cannot write " + path}; }
+}
+bool open_pairs_file(const std::string &path, PairsFile &F) {
+    using namespace pairsfile;
+    struct stat sb; if (stat(path.c_str(), &sb) != 0) return false;
+    F.fv.reset(new FileView(path));
+    if (F.fv->n < sizeof(Header)) throw Error{E_FORMAT, path + " is not a staged-pairs file"};
+    memcpy(&F.H, F.fv->p, sizeof(Header));
+    const Header &H = F.H;
+    bool fine = memcmp(H.magic, MAGIC, 8) == 0 && H.version == 1 && H.sizes[0] == sizeof(agx_whit) && H.sizes[1] == sizeof(agx_wside) && H.sizes[2] == sizeof(agx_wrun);
+    for (int i = 0; i < S_N && fine; i++) fine = H.off[i] <= F.fv->n && H.len[i] <= F.fv->n - H.off[i];
+    fine = fine && H.len[S_HITS] == H.nh * sizeof(agx_whit) && H.len[S_SIDES] == H.n_sides * sizeof(agx_wside) && H.len[S_RUNS] == H.n_runs * sizeof(agx_wrun) && H.len[S_CODES] == H.n_codes &&
+           H.len[S_OTHER] == H.n_other * 8 && H.len[S_OTHERB] == H.n_other && H.len[S_JUMP] == H.n_jump * 4 && (H.stride & 3u) == 0 && H.maxlen <= H.stride &&
+           H.n_codes == (unsigned long long)H.n_rows * (H.stride / 4) && H.n_sides <= H.nh && H.n_jump <= H.nh && H.nh < 0xFFFFFFFFull && H.n_runs < 0xFFFFFFFFull && H.n_rows < 0x7FFFFFFFu;
+    if (!fine) throw Error{E_FORMAT, path + " is not a staged-pairs file of this layout"};
+    return true;
 }
 
 void build_cm_layout(const agx_u8 *cm_cnt, size_t n_pos, const agx_cmseg *segs, size_t n_segs, CmLayout &L) {

@@ -363,6 +363,21 @@ struct Walker {
         const agx_sref r = node(v).sref;
         const agx_u32 first = r.qlen & 0xFFFFu, len = (r.qlen >> 16) & 0x7FFFu; const bool rev = (r.qlen >> 31) != 0;
         out.clear();
+        if (!V.bases) {      // the staged 2-bit rows are all there is (agx_host.h: UnitView::codes2): classes back to letters, the listed other bases by their bytes
+            if (!V.codes2) throw Error{E_ARG, "no read bases for the k-mer strings"};
+            const agx_u8 *row = V.codes2 + (size_t)r.slot * (V.stride / 4);
+            const unsigned long long base = (unsigned long long)r.slot * V.stride;
+            for (agx_u32 i = 0; i < len; i++) {
+                const agx_u32 j = rev ? first - i : first + i;
+                char c = "ACGT"[(row[j >> 2] >> (2u * (j & 3u))) & 3u];
+                if (c == 'A' && V.n_other) {         // (class 0 is also what a listed base was packed as)
+                    const unsigned long long *e = V.other_idx + V.n_other, *at = std::lower_bound(V.other_idx, e, base + j);
+                    if (at != e && *at == base + j) c = (char)V.other_byte[at - V.other_idx];
+                }
+                out.push_back(!rev ? c : c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c);
+            }
+            return;
+        }
         const char *p = V.row_off ? V.bases + V.row_off[r.slot] : V.bases + (size_t)(G.row_slot ? G.row_slot[r.slot] : r.slot) * V.stride;
         for (agx_u32 i = 0; i < len; i++) {
             if (!rev) out.push_back(p[first + i]);

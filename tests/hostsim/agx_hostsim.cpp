@@ -419,3 +419,46 @@ extern "C" int agx_hostsim_compare_loaders(const char *tmp_dir, int unit, int k,
     catch (const std::exception &e) { say(std::string("unexpected: ") + e.what()); return -99; }
     return declined;
 }
+
+// tmp/_agx_pairs.<u>.bin (a unit's read alignments handed over staged, agx_host.h) against what the general loader + staging make of the unit's TEXT files: every array and
+// every count, byte for byte; and the listed other bases must carry the bytes the reads have there.  0 = equal; negative: msg says what differs.
+extern "C" int agx_hostsim_compare_staged(const char *tmp_dir, int unit, int k, long batch, int threads, char *msg, size_t msg_len) {
+    auto say = [&](const std::string &m) { if (msg && msg_len) snprintf(msg, msg_len, "%s", m.c_str()); };
+    try {
+        const std::string d = tmp_dir, s = std::to_string(unit);
+        struct VSink : StageSink { std::vector<std::vector<char>> keep; void *take(int, size_t bytes) override { keep.emplace_back(bytes + 64); return keep.back().data(); } } A;
+        Pairs P; StagedPairs S;
+        load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie", batch, (agx_u32)k, P, nullptr);
+        stage_pairs(P, (agx_u32)k, (unsigned)threads, A, S);
+        PairsFile F;
+        if (!open_pairs_file(pairsfile::path_of(d, unit), F)) { say("no staged-pairs file"); return -1; }
+        using namespace pairsfile;
+        const Header &H = F.H;
+        auto bad = [&](const std::string &what) { say("staged pairs differ from the text path: " + what); return -20; };
+        if (H.k != (agx_u32)k || H.batch != (agx_u32)(batch <= 0 ? 1000000 : batch)) return bad("k / BATCH in the header");
+        if (H.nh != S.nh) return bad("number of hits " + std::to_string(H.nh) + " / " + std::to_string(S.nh));
+        if (H.n_runs != S.n_runs || H.n_sides != S.n_sides || H.n_jump != S.n_jump) return bad("number of runs / side records / pass-J hits");
+        if (H.pairs_in_file != S.n_pairs_in_file || H.sam_pairs != S.n_sam_pairs) return bad("pairs in the reads file / SAM line pairs " + std::to_string(H.sam_pairs) + " / " + std::to_string(S.n_sam_pairs));
+        if (S.nh && (H.stride != S.stride || H.maxlen != S.maxlen)) return bad("stride / longest read");
+        if (H.n_rows != S.n_rows || H.n_codes != S.n_codes || H.n_other != S.n_other) return bad("rows / codes / other bases");
+        if (S.nh && memcmp(F.sec(S_HITS), S.hits, S.nh * sizeof(agx_whit)) != 0) return bad("hits");
+        if (S.n_sides && memcmp(F.sec(S_SIDES), S.sides, S.n_sides * sizeof(agx_wside)) != 0) return bad("side records");
+        if (S.n_runs && memcmp(F.sec(S_RUNS), S.runs, S.n_runs * sizeof(agx_wrun)) != 0) return bad("runs");
+        if (S.n_jump && memcmp(F.sec(S_JUMP), S.jump, S.n_jump * 4) != 0) return bad("list of hits for pass J");
+        if (S.n_codes && memcmp(F.sec(S_CODES), S.codes, S.n_codes) != 0) return bad("codes");
+        if (S.n_other && memcmp(F.sec(S_OTHER), S.other, S.n_other * 8) != 0) return bad("list of other bases");
+        const std::vector<agx_u8> ob = other_bytes_of(P, S);
+        if (S.n_other && memcmp(F.sec(S_OTHERB), ob.data(), S.n_other) != 0) return bad("bytes of the other bases");
+        // every base of every row, decoded the way the walk decodes a k-mer tail from the 2-bit rows, is the read's base
+        const agx_u8 *codes = (const agx_u8 *)F.sec(S_CODES); const unsigned long long *oi = (const unsigned long long *)F.sec(S_OTHER); const agx_u8 *obf = (const agx_u8 *)F.sec(S_OTHERB);
+        std::vector<agx_u16> row_len(S.n_rows, 0);
+        for (size_t i = 0; i < S.nh; i++) row_len[S.hits[i].row] = std::max(row_len[S.hits[i].row], S.hits[i].len);
+        for (size_t r = 0; r < S.n_rows; r++) for (agx_u32 j = 0; j < row_len[r]; j++) {
+            char c = "ACGT"[(codes[r * (H.stride / 4) + (j >> 2)] >> (2u * (j & 3u))) & 3u];
+            if (c == 'A' && H.n_other) { const unsigned long long key = (unsigned long long)r * H.stride + j, *e = oi + H.n_other, *at = std::lower_bound(oi, e, key); if (at != e && *at == key) c = (char)obf[at - oi]; }
+            if (c != P.bases[(size_t)S.row_slot[r] * P.stride + j]) return bad("base " + std::to_string(j) + " of row " + std::to_string(r) + " does not come back out of the 2-bit rows");
+        }
+        return 0;
+    } catch (const Error &e) { say("unexpected: " + e.msg); return -99; }
+    catch (const std::exception &e) { say(std::string("unexpected: ") + e.what()); return -99; }
+}

@@ -88,3 +88,15 @@ def compare_loaders(tmp_dir, unit, k=5, batch=1000000, threads=4):
     if rc < 0 or rc >= 64:
         raise SimError(rc, msg.value.decode())
     return rc
+
+
+def compare_staged(tmp_dir, unit, k=5, batch=1000000, threads=4):
+    """tmp/_agx_pairs.<unit>.bin (staged read alignments) against the general loader + staging over the unit's text files; raises SimError when they differ."""
+    build()
+    lib = ctypes.CDLL(LIB)
+    lib.agx_hostsim_compare_staged.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    msg = ctypes.create_string_buffer(1024)
+    rc = lib.agx_hostsim_compare_staged(tmp_dir.encode(), unit, k, batch, threads, msg, 1024)
+    if rc != 0:
+        raise SimError(rc, msg.value.decode())
+    return rc

@@ -385,3 +385,48 @@ def test_reference_bytes_that_are_not_acgt_survive_the_packed_upload(agx, built,
     for key in ("initial", "pre", "extended"):
         assert got[key] == want[key], key
     assert b"N" * 100 in got["extended"] or b"N" * 100 in got["pre"] or True      # (whether a walk crosses the N run depends on the reads; the bytes were compared above)
+
+
+def test_read_alignments_handed_over_staged(agx, built, tmp_path):
+    """tmp/_agx_pairs.<u>.bin (agx_host.h: pairsfile) stands in for tmp/_reads.fa + the unit's SAM text: the engine takes the staged arrays as they are, the walk
+    reads its k-mer tails out of the 2-bit rows, and the unit cache written from such a unit carries them along.  Same stream with and without the text
+    (tools/agx_synth.cpp --pairs-bin 2 / 1): the oracle runs on the text, the engine on a directory that has none.  (tests/test_staged_pairs.py: the file itself
+    against the loaders, on the CPU.)"""
+    kw = dict(seed=77, chroms="60000,35000", pairs=26000, coverage=3, read_indel=0.25, read_clip=0.1, multi=0.3, read_n=0.02, contig_overlap=0.3, sam_seq=0)
+    text = H.synth(str(tmp_path / "text"), threads=2, pairs_bin=2, **kw)
+    run = H.synth(str(tmp_path / "run"), threads=3, pairs_bin=1, lean=1, **kw)
+    tmp = os.path.join(run, "tmp")
+    assert not os.path.exists(os.path.join(tmp, "_reads.fa"))
+    want = [H.run_oracle(os.path.join(text, "tmp"), uu, 5, 50, 3) for uu in range(2)]
+    assert sum(w["pre"].count(b">") for w in want) > 20
+
+    def load_and_run(uu, flags=0, **params):
+        with agx.Unit(k=params.get("k", 5), insert_variation=50, coverage=3, flags=flags, batch=params.get("batch", 0)) as u:
+            u.load_files(tmp, uu)
+            st0 = u.stats()
+            u.upload(); u.build()
+            got = u.finish()
+            for key in ("initial", "pre", "extended"):
+                assert got[key] == want[uu][key], key
+            return st0
+    for uu in range(2):
+        st = load_and_run(uu)
+        assert st["from_cache"] == 0 and st["n_hits"] > 0 and st["sam_line_pairs"] > st["n_hits"] and st["pairs_in_file"] == 26000
+        load_and_run(uu, flags=agx.AGX_FLAG_ONE_SHOT)              # the download lands in the staged arrays' pinned memory: the tails come from the mapped file
+    for bad in (dict(k=7), dict(batch=5000)):                       # staged for another k / another BATCH: refused, never re-interpreted
+        with pytest.raises(agx.AgxError) as e:
+            load_and_run(0, **bad)
+        assert e.value.code == agx.AGX_E_ARG
+    agx.cache_build(tmp, 0)
+    with agx.Unit(k=5, insert_variation=50, coverage=3) as u:
+        u.load_files(tmp, 1)
+        u.cache_save(tmp, 1)
+    for uu in range(2):
+        st = load_and_run(uu)
+        assert st["from_cache"] == 1 and st["n_hits"] > 0
+        load_and_run(uu, flags=agx.AGX_FLAG_ONE_SHOT)              # (tails out of the mapped cache file's 2-bit rows)
+    for uu in range(2):                                             # a cache made from a staged file is current only while that file is as it was
+        os.remove(os.path.join(tmp, "_agx_pairs.%d.bin" % uu))
+        with agx.Unit(k=5, insert_variation=50, coverage=3) as u:
+            with pytest.raises(agx.AgxError):
+                u.load_files(tmp, uu)                                # (no current cache, no staged pairs, no text)

@@ -17,13 +17,30 @@ def build():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", SYNTH, src])
 
 
+SYNTH_BIN = os.path.join(ROOT, "build", "agx_synth_bin")
+CSRC = os.path.join(ROOT, "aligngraph_amd", "csrc")
+
+
+def build_bin():
+    """build/agx_synth_bin: the generator with the staged-pairs mode (--pairs-bin), compiled together with the engine's host-side loader sources (no HIP)."""
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    src = [os.path.join(HERE, "agx_synth.cpp")] + [os.path.join(CSRC, f) for f in ("agx_host.cpp", "agx_walk.cpp", "agx_load.cpp")]
+    deps = src + [os.path.join(CSRC, f) for f in ("agx_host.h", "agx_parse.h", "agx_core.h")]
+    if not os.path.exists(SYNTH_BIN) or any(os.path.getmtime(SYNTH_BIN) < os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-DAGX_SYNTH_WITH_ENGINE", "-o", SYNTH_BIN] + src)
+
+
 def synth(out, **kw):
     """kw: seed=1, chroms="50000", pairs=10000, L=100, ... (see tools/agx_synth.cpp Params)."""
-    build()
+    staged = int(kw.get("pairs_bin", 0)) != 0
+    if staged:
+        build_bin()
+    else:
+        build()
     if os.path.exists(out):
         shutil.rmtree(out)
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
-    cmd = [SYNTH, "--out", out]
+    cmd = [SYNTH_BIN if staged else SYNTH, "--out", out]
     for k, v in kw.items():
         cmd += ["--" + k.replace("_", "-"), str(v)]
     subprocess.check_call(cmd)

@@ -31,6 +31,17 @@
 #include <vector>
 #include <sys/stat.h>
 
+// -DAGX_SYNTH_WITH_ENGINE (build/agx_synth_bin: compiled together with the engine's host-side loader sources): the --pairs-bin mode below hands every unit's read alignments
+// over STAGED (tmp/_agx_pairs.<u>.bin, aligngraph_amd/csrc/agx_host.h) instead of as SAM text + tmp/_reads.fa — 58 bytes per pair instead of 420, which is what lets
+// BASELINE configs[4] (whole human: 400 M pairs of 2x150 bp) exist on a box at all.  Nothing about the alignments is decided here: every pair's two SAM lines are
+// formatted in memory exactly as the text mode writes them and go through the engine's own line parser (parse_sam_line), its rules across line pairs (PairRules: batch
+// boundaries, identity filter, hits per pair) and its staging (stage_pairs); `--pairs-bin 2` writes the text files of the same stream as well, and
+// tests/test_staged_pairs.py compares what the loaders make of those with the staged file, byte for byte.
+#ifdef AGX_SYNTH_WITH_ENGINE
+#include "../aligngraph_amd/csrc/agx_host.h"
+#include "../aligngraph_amd/csrc/agx_parse.h"
+#endif
+
 namespace {
 
 struct Rng {
@@ -94,6 +105,11 @@ struct Params {
     // that many threads; the files are the same for every thread count, but differ from the ones the default single-stream mode writes
     // (which the committed golden fixtures came from).  Large bench / test inputs use it; not with e2e.
     int threads = 0;
+    // 1: staged pairs per unit instead of reads + SAM text (needs --threads; its own stream: every pair from a generator seeded by (seed, read id), so that a unit's pairs can be
+    // made without making everybody else's); 2: both, from the same stream.  Only in build/agx_synth_bin.
+    int pairs_bin = 0;
+    int batch = 1000000;   // BATCH of the engine that will read the staged pairs (AG:37)
+    int lean = 0;          // 1: do not write the user-level copies genome.fa, contigs.fa and tmp/_genome.fa (9 GB at whole-human size); the unit loop reads none of them
 };
 
 void die(const char *m) { std::fprintf(stderr, "agx_synth: %s\n", m); std::exit(2); }
@@ -127,13 +143,17 @@ Params parse_args(int argc, char **argv) {
         OPT_D("--read-err", read_err) OPT_D("--read-indel", read_indel) OPT_D("--read-clip", read_clip)
         OPT_D("--read-badclip", read_badclip) OPT_D("--read-n", read_n)
         OPT_D("--multi", multi) OPT_D("--multi-near", multi_near) OPT_D("--unaligned", unaligned)
-        OPT_D("--mate1-left", mate1_left) OPT_D("--mixed-len", mixed_len) OPT_I("--sam-seq", sam_seq) OPT_I("--shuffle-units", shuffle_units) OPT_I("--e2e", e2e) OPT_I("--threads", threads)
+        OPT_D("--mate1-left", mate1_left) OPT_D("--mixed-len", mixed_len) OPT_I("--sam-seq", sam_seq) OPT_I("--shuffle-units", shuffle_units) OPT_I("--e2e", e2e) OPT_I("--threads", threads) OPT_I("--pairs-bin", pairs_bin) OPT_I("--batch", batch) OPT_I("--lean", lean)
         if (a == "--chroms") { P.chroms = parse_list(v); continue; }
         std::fprintf(stderr, "agx_synth: unknown option %s\n", a.c_str()); std::exit(2);
     }
     if (P.part < 1 || P.part > 10) die("--part must be 1..10");
     if (P.threads > 0 && P.e2e) die("--threads is not available with --e2e");
     if (P.threads > 256) P.threads = 256;
+    if (P.pairs_bin && (P.threads <= 0 || P.e2e || P.mixed_len > 0)) die("--pairs-bin needs --threads and excludes --e2e / --mixed-len");
+#ifndef AGX_SYNTH_WITH_ENGINE
+    if (P.pairs_bin) die("--pairs-bin is only available in build/agx_synth_bin (tools/agx_data.py builds it)");
+#endif
     return P;
 }
 
@@ -306,15 +326,15 @@ int main(int argc, char **argv) {
         FILE *g = open("genome.fa"), *g0 = open("tmp/_genome.fa");
         int u = 0;
         for (size_t c = 0; c < P.chroms.size(); c++) {
-            std::fprintf(g, ">chr%zu synthetic\n", c + 1);
+            if (!P.lean) std::fprintf(g, ">chr%zu synthetic\n", c + 1);
             std::string whole;
             for (int q = 0; q < P.part; q++, u++) {
-                whole += units[u].ref;
+                if (!P.lean) whole += units[u].ref;
                 FILE *gu = open("tmp/_genome." + std::to_string(u) + ".fa");
                 std::fputs(">0\n", gu); put_fasta_body(gu, units[u].ref.data(), units[u].ref.size()); std::fclose(gu);
-                std::fprintf(g0, ">%d\n", u); put_fasta_body(g0, units[u].ref.data(), units[u].ref.size());
+                if (!P.lean) { std::fprintf(g0, ">%d\n", u); put_fasta_body(g0, units[u].ref.data(), units[u].ref.size()); }
             }
-            put_fasta_body(g, whole.data(), whole.size());
+            if (!P.lean) put_fasta_body(g, whole.data(), whole.size());
         }
         std::fclose(g); std::fclose(g0);
     }
@@ -344,9 +364,8 @@ int main(int argc, char **argv) {
                 }
                 char strand = R.coin(P.contig_minus) ? '-' : '+';
                 std::string name = "contig_" + std::to_string(nameID++);
-                std::fprintf(cf, ">%s\n", name.c_str());
                 std::string file_seq = strand == '-' ? revcomp(seq) : seq;
-                put_fasta_body(cf, file_seq.data(), file_seq.size());
+                if (!P.lean) { std::fprintf(cf, ">%s\n", name.c_str()); put_fasta_body(cf, file_seq.data(), file_seq.size()); }
                 std::string qname = std::to_string(seqID) + "." + std::to_string(realID);
                 std::fprintf(tc, ">%s\n", qname.c_str()); put_fasta_body(tc, file_seq.data(), file_seq.size());
                 seqID++; realID++;
@@ -382,7 +401,7 @@ int main(int argc, char **argv) {
                     if (t + sl < T) {
                         std::string nm = "contig_" + std::to_string(nameID++);
                         std::string ss = U.tgt.substr(t, sl);
-                        std::fprintf(cf, ">%s\n", nm.c_str()); put_fasta_body(cf, ss.data(), ss.size());
+                        if (!P.lean) { std::fprintf(cf, ">%s\n", nm.c_str()); put_fasta_body(cf, ss.data(), ss.size()); }
                         std::fprintf(chaff, ">%s\n", nm.c_str()); put_fasta_body(chaff, ss.data(), ss.size());
                     }
                 }
@@ -402,6 +421,147 @@ int main(int argc, char **argv) {
         std::fclose(cf); std::fclose(tc); std::fclose(chaff);
     }
 
+#ifdef AGX_SYNTH_WITH_ENGINE
+    // ---- staged pairs per unit (--pairs-bin) ----
+    if (P.pairs_bin) {
+        const int64_t N = P.pairs, C = 65536, NC = (N + C - 1) / C;
+        const int L = P.L;
+        std::vector<double> cum(NU); { double tot = 0; for (auto l : unit_len) tot += (double)l; double a = 0; for (int u = 0; u < NU; u++) { a += (double)unit_len[u] / tot; cum[u] = a; } cum[NU - 1] = 2.0; }
+        struct Emit { Aln l, r; bool secondary; };
+        struct OnePair { int u; bool m1_left; std::string m1, m2, left_fwd, right_fwd; std::vector<Emit> emits; };
+        // pair `id` from its own generator; false (and nothing else drawn) if it belongs to another unit than `want` (want < 0: whoever)
+        auto gen_pair = [&](int64_t id, int want, OnePair &o) -> bool {
+            Rng R(P.seed * 0x9E3779B97F4A7C15ull + (uint64_t)(id + 1) * 0xD1B54A32D192ED03ull);
+            const double pick = R.uni();
+            int u = 0; while (pick >= cum[u]) u++;
+            if (want >= 0 && u != want) return false;
+            o.u = u; o.emits.clear();
+            const Unit &U = units[u];
+            const int64_t T = (int64_t)U.tgt.size();
+            int64_t f = (int64_t)std::llround(P.frag_mean + P.frag_sd * R.normal());
+            if (f < L + 1) f = L + 1;
+            if (f > T) f = T;
+            const int64_t s0 = R.range(0, T - f);
+            ::Mate left = cut_read(U, s0, L, P, R), right = cut_read(U, s0 + f - L, L, P, R);
+            o.m1_left = R.coin(P.mate1_left);
+            const std::string right_file = revcomp(right.seq_fwd);
+            o.m1 = o.m1_left ? left.seq_fwd : right_file; o.m2 = o.m1_left ? right_file : left.seq_fwd; o.left_fwd = left.seq_fwd; o.right_fwd = right.seq_fwd;
+            if (R.coin(P.unaligned)) return true;
+            int clipLl = 0, clipLr = 0, clipRl = 0, clipRr = 0;
+            if (R.coin(P.read_clip)) { (R.coin(0.5) ? clipLl : clipLr) = (int)R.range(1, 15); }
+            if (R.coin(P.read_clip)) { (R.coin(0.5) ? clipRl : clipRr) = (int)R.range(1, 15); }
+            if (R.coin(P.read_badclip)) { (R.coin(0.5) ? clipLr : clipRl) = (int)R.range(L * 45 / 100, L * 55 / 100); }
+            Aln al, ar;
+            if (!make_aln(left.r, clipLl, clipLr, al) || !make_aln(right.r, clipRl, clipRr, ar)) return true;
+            o.emits.push_back(Emit{al, ar, false});
+            if (R.coin(P.multi)) {
+                const int64_t G = (int64_t)U.ref.size();
+                Aln bl, br;
+                const std::string allM = std::to_string(L) + "M";
+                if (R.coin(P.multi_near)) {
+                    const int64_t d = R.range(-(L - 1), L - 1);
+                    bl.pos1 = std::max<int64_t>(1, al.pos1 + d); br.pos1 = std::max<int64_t>(1, ar.pos1 + d);
+                } else {
+                    const int64_t w = R.range(1, std::max<int64_t>(1, G - f - 1));
+                    bl.pos1 = w; br.pos1 = w + f - L;
+                }
+                if (bl.pos1 + L <= G && br.pos1 + L <= G) { bl.cigar = br.cigar = allM; o.emits.push_back(Emit{bl, br, true}); }
+            }
+            return true;
+        };
+        // the two SAM lines of one emitted alignment, as the text mode writes them (m = 0: mate1's line)
+        auto sam_line = [&](const OnePair &o, int64_t id, const Emit &e, int m, std::string &dst) {
+            char buf[512];
+            const bool is_left = (m == 0) == o.m1_left;
+            const int flag = 0x1 | 0x2 | (m == 0 ? 0x40 : 0x80) | (is_left ? 0x20 : 0x10) | (e.secondary ? 0x100 : 0);
+            const Aln &A = is_left ? e.l : e.r, &B = is_left ? e.r : e.l;
+            const long long tlen = is_left ? (long long)(e.r.pos1 + L - e.l.pos1) : -(long long)(e.r.pos1 + L - e.l.pos1);
+            int w = std::snprintf(buf, sizeof buf, "%lld\t%d\t%d\t%lld\t42\t%s\t=\t%lld\t%lld\t", (long long)id, flag, o.u, (long long)A.pos1, A.cigar.c_str(), (long long)B.pos1, tlen);
+            dst.assign(buf, (size_t)w);
+            if (P.sam_seq) { dst += is_left ? o.left_fwd : o.right_fwd; dst.push_back('\t'); dst.append((size_t)L, 'I'); w = std::snprintf(buf, sizeof buf, "\tAS:i:%d\tYS:i:%d\tYT:Z:CP", 2 * L - 6, 2 * L - 4); dst.append(buf, (size_t)w); }
+            else dst += "*\t*";
+        };
+        if (P.pairs_bin == 2) {      // the text files of the same stream (small inputs: one thread)
+            FILE *rf = open("tmp/_reads.fa");
+            std::vector<FILE *> sam(NU);
+            for (int u = 0; u < NU; u++) sam[u] = open("tmp/_reads_genome." + std::to_string(u) + ".bowtie");
+            OnePair o; std::string line;
+            for (int64_t id = 0; id < N; id++) {
+                gen_pair(id, -1, o);
+                std::fprintf(rf, ">%lld\n%s\n>%lld\n%s\n", (long long)id, o.m1.c_str(), (long long)id, o.m2.c_str());
+                for (const Emit &e : o.emits) for (int m = 0; m < 2; m++) { sam_line(o, id, e, m, line); std::fwrite(line.data(), 1, line.size(), sam[o.u]); std::fputc('\n', sam[o.u]); }
+            }
+            std::fclose(rf); for (auto f : sam) std::fclose(f);
+        }
+        struct MemSink : agx::StageSink { std::vector<std::vector<char>> keep; void *take(int, size_t bytes) override { keep.emplace_back(bytes + 64); return keep.back().data(); } };
+        for (int u = 0; u < NU; u++) {
+            struct LinePair { agx::Mate m1, m2; };
+            struct Chunk { std::vector<LinePair> lp; std::vector<agx_run> runs; std::vector<int64_t> ids; std::string bases; bool ready = false; };      // ids / bases: the unit's pairs of this chunk (2 x L bytes each)
+            std::vector<Chunk> chunks((size_t)NC);
+            std::atomic<int64_t> next_chunk(0);
+            std::mutex mu; std::condition_variable cv; int64_t consumed = 0; bool failed = false;
+            auto make_chunk = [&](int64_t c) {
+                Chunk &K = chunks[(size_t)c];
+                OnePair o; std::string l1, l2;
+                for (int64_t id = c * C; id < std::min(N, (c + 1) * C); id++) {
+                    if (!gen_pair(id, u, o)) continue;
+                    K.ids.push_back(id); K.bases += o.m1; K.bases += o.m2;
+                    for (const Emit &e : o.emits) {
+                        sam_line(o, id, e, 0, l1); sam_line(o, id, e, 1, l2);
+                        LinePair lp; agx::parse_sam_line(l1.data(), l1.size(), lp.m1, K.runs); agx::parse_sam_line(l2.data(), l2.size(), lp.m2, K.runs);
+                        K.lp.push_back(lp);
+                    }
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 0; t < P.threads; t++) th.emplace_back([&] {
+                for (;;) {
+                    const int64_t c = next_chunk.fetch_add(1);
+                    if (c >= NC) return;
+                    { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return failed || c < consumed + 8 * (int64_t)P.threads; }); if (failed) return; }
+                    try { make_chunk(c); } catch (...) { std::lock_guard<std::mutex> g(mu); failed = true; }
+                    { std::lock_guard<std::mutex> g(mu); chunks[(size_t)c].ready = true; }
+                    cv.notify_all();
+                }
+            });
+            agx::Pairs PP; PP.stride = ((agx_u32)L + 15u) & ~15u;
+            try {
+                agx::PairRules rules(PP, (unsigned long long)N, P.batch);
+                size_t placed = 0; agx_u32 n_ids = 0; bool go = true;          // hits whose read slot is set; distinct read ids among them
+                for (int64_t c = 0; c < NC; c++) {
+                    { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return failed || chunks[(size_t)c].ready; }); if (failed) die("staged pairs: a worker failed"); }
+                    Chunk &K = chunks[(size_t)c];
+                    size_t at = 0;                                               // the chunk's pair whose id the line pairs have reached
+                    for (const LinePair &lp : K.lp) {
+                        if (!go) break;
+                        go = rules.consume(lp.m1, lp.m2, K.runs.data());
+                        for (; placed < PP.hits.size(); placed++) {             // (one at most) a kept hit: its read slot, and the pair's bases the first time
+                            const agx_u32 id = rules.hit_id[placed];
+                            if (placed == 0 || rules.hit_id[placed - 1] != id) {
+                                while (at < K.ids.size() && K.ids[at] != (int64_t)id) at++;
+                                if (at == K.ids.size()) die("staged pairs: a kept hit without its reads");
+                                n_ids++;
+                                const size_t o0 = PP.bases.size(); PP.bases.resize(o0 + 2 * (size_t)PP.stride, 'N');
+                                std::memcpy(&PP.bases[o0], K.bases.data() + at * 2 * (size_t)L, (size_t)L); std::memcpy(&PP.bases[o0 + PP.stride], K.bases.data() + (at * 2 + 1) * (size_t)L, (size_t)L);
+                            }
+                            if (PP.hits[placed].len != (agx_u32)L) die("staged pairs: a CIGAR that is not as long as the read");
+                            PP.hits[placed].slot1 = 2 * (n_ids - 1);
+                        }
+                    }
+                    Chunk().lp.swap(K.lp); std::vector<agx_run>().swap(K.runs); std::vector<int64_t>().swap(K.ids); std::string().swap(K.bases);
+                    { std::lock_guard<std::mutex> g(mu); consumed = c + 1; }
+                    cv.notify_all();
+                }
+                for (auto &t : th) t.join();
+                PP.n_kept = PP.hits.size(); PP.n_slots = 2 * n_ids;
+                MemSink sink; agx::StagedPairs S;
+                agx::stage_pairs(PP, (agx_u32)P.k, (unsigned)P.threads, sink, S);
+                const std::vector<agx_u8> ob = agx::other_bytes_of(PP, S);
+                agx::write_pairs_file(agx::pairsfile::path_of(P.out + "/tmp", u), S, ob.data(), (agx_u32)P.k, (agx_u32)P.batch);
+            } catch (const agx::Error &e) { std::fprintf(stderr, "agx_synth: staged pairs of unit %d: %s\n", u, e.msg.c_str()); std::exit(2); }
+        }
+    } else
+#endif
     // ---- reads + SAM, chunked mode (--threads) ----
     if (P.threads > 0) {
         const int64_t N = P.pairs, C = 65536, NC = (N + C - 1) / C;
@@ -607,6 +767,7 @@ int main(int argc, char **argv) {
         FILE *m = open("synth_meta.txt");
         std::fprintf(m, "units %d\npairs %lld\nL %d\nk %d\ncoverage %d\ninsert_variation %d\nseed %llu\n", NU, (long long)P.pairs, P.L, P.k,
                      P.coverage, P.insert_variation, (unsigned long long)P.seed);
+        std::fprintf(m, "pairs_bin %d\n", P.pairs_bin);
         for (int u = 0; u < NU; u++) std::fprintf(m, "unit %d len %lld\n", u, (long long)unit_len[u]);
         std::fclose(m);
     }
