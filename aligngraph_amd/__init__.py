@@ -130,6 +130,15 @@ def lib():
     return _lib
 
 
+def device_memory(device=0):
+    """(free, total) bytes of HBM on one device (hipMemGetInfo)."""
+    f, t = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    rc = lib().agx_device_memory(device, ctypes.byref(f), ctypes.byref(t))
+    if rc != AGX_OK:
+        raise AgxError(rc, "agx_device_memory failed")
+    return f.value, t.value
+
+
 def device_count():
     return lib().agx_device_count()
 

@@ -26,30 +26,48 @@ def plan(unit_sizes, rank, world):
     return sorted(mine, key=lambda u: (-unit_sizes[u], u))
 
 
-def run_job(unit_sizes, rank, world, run_unit, dist, device, inflight=8, dst=0, start_unit=None):
+def run_job(unit_sizes, rank, world, run_unit, dist, device, inflight=8, dst=0, start_unit=None, hbm_need=None, hbm_budget=None):
     """One whole job the way bench.py --gpus N and the gloo test run it: this rank's units (plan) through run_unit(u) -> bytes on up to
     `inflight` worker threads that take the next unit as they finish one, then the path's ONLY exchange — one gather of every rank's
     per-unit bytes to rank `dst` (north_star: "gather of extended contigs at the end").  run_unit may return anything with
     the buffer interface (bytes, a numpy uint8 view of C memory).  start_unit(u), if given, is called when a worker TAKES unit u, in plan
     order and one at a time (bench.py queues the unit's upload there: uploads then reach the device largest unit first, whatever the
-    threads do next).  Returns {unit: bytes-like} of ALL units on dst, None elsewhere."""
+    threads do next).  hbm_need / hbm_budget: admission by device memory — {unit: bytes its upload will take (agx_unit_hbm_needed)} and what this rank's
+    device may hold at once: a unit is only taken when it fits beside the units in flight (a unit larger than the budget: when nothing else is in flight), in
+    plan order — whole-human units take up to 57 GB of HBM each, eight of them do not fit one device.  Returns {unit: bytes-like} of ALL units on dst, None elsewhere."""
     import threading
     mine = plan(unit_sizes, rank, world)
     out, errs = {}, []
     nxt, take = iter(mine), threading.Lock()
+    held, room = [0], threading.Condition()
 
     def worker():
         try:
             while True:
+                need = 0
                 with take:
                     u = next(nxt, None)
-                    if u is not None and start_unit is not None:
-                        start_unit(u)
+                    if u is not None:
+                        if hbm_need is not None and hbm_budget:
+                            need = hbm_need[u]
+                            with room:                 # (the next unit of the plan waits here, and everybody behind it at `take`: the order stands)
+                                room.wait_for(lambda: errs or held[0] == 0 or held[0] + need <= hbm_budget)
+                                held[0] += need
+                        if start_unit is not None:
+                            start_unit(u)
                 if u is None:
                     return
-                out[u] = run_unit(u)
+                try:
+                    out[u] = run_unit(u)
+                finally:
+                    if need:
+                        with room:
+                            held[0] -= need
+                            room.notify_all()
         except BaseException as e:                     # surfaces in the calling thread
             errs.append(e)
+            with room:
+                room.notify_all()
 
     threads = [threading.Thread(target=worker) for _ in range(max(1, min(inflight, len(mine))))]
     for t in threads:

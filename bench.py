@@ -46,6 +46,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+HUMAN = (248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622,
+         133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415)      # GRCh38: chr1..22, X, Y
+STAGED = {"cfg5"}      # configurations whose read alignments are generated staged (tmp/_agx_pairs.<u>.bin, tools/agx_synth.cpp --pairs-bin): as text they would not fit the box
+
 CONFIGS = {
     # name: (chromosome lengths, --part, pairs, L, label)
     "cfg2": ([4600000], 1, 1000000, 100, "configs[1]: E. coli K-12 shape, one 4.6 Mb unit, 1M 2x100 bp pairs"),
@@ -56,6 +60,10 @@ CONFIGS = {
     "cfg5s": ([c // 16 for c in (248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622,
                                 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415)],
               1, 25000000, 150, "configs[4] SCALED 1/16: GRCh38 chromosome lengths / 16 (24 units, 193 Mb), 25M 2x150 bp pairs — the 8-GPU shard shape, not the configuration itself"),
+    # configs[4] itself: 24 units of 249 .. 47 Mb, 3.1 Gb, 400 M pairs.  No SAM / reads text exists at this size (170 GB): the generator hands the alignments over staged,
+    # 23 GB, made by the engine's own line parser, batch rules and staging (tests/test_staged_pairs.py); 64 GB of disk with the unit caches, ~4 minutes to generate.
+    "cfg5": (list(HUMAN), 1, 400000000, 150, "configs[4]: whole human GRCh38 shape at FULL size (24 units / 3.1 Gb, 400M 2x150 bp pairs), read alignments handed over staged "
+                                              "(tmp/_agx_pairs.<u>.bin) instead of as 170 GB of SAM + reads text"),
     # the same at 1/4: the largest scale whose text files (48 GB) fit the GPU box's scratch disk; units of 62 .. 12 Mb
     "cfg5q": ([c // 4 for c in (248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622,
                                133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415)],
@@ -127,7 +135,9 @@ def main():
                          "three of eight ranks would idle)")
     ap.add_argument("--same-config-steps", type=int, default=4, help="N > 1: after the timed N-rank steps rank 0 runs the SAME job alone on its GPU for this many steps "
                                                                       "(single_gpu_ms_same_config, speedup_vs_1gpu in the JSON line); 0 = skip")
-    ap.add_argument("--host-gb", type=float, default=96.0, help="host memory a rank may hold in staged unit sets; more steps than fit re-upload the same unit objects (as --reupload)")
+    ap.add_argument("--host-gb", type=float, default=0.0, help="host memory a rank may hold in staged unit sets; more steps than fit re-upload the same unit objects (as --reupload).  "
+                                                               "0 (default): 96 GB or 40 %% of the control group's memory limit, whichever is less, divided by the ranks on this host")
+    ap.add_argument("--clean", action="store_true", help="delete the generated inputs at the end even for cfg5 (whose 64 GB are otherwise kept for the next run: N = 1, 2, 4, 8 back to back)")
     ap.add_argument("--chroms", default="4600000", help="custom: comma-separated chromosome lengths")
     ap.add_argument("--part", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1000000)
@@ -188,8 +198,27 @@ def main():
     gdev = torch.device("cpu") if share else torch.device("cuda", local_rank)
     numa_note = pin_to_gpu_numa_node(torch, local_rank) if os.environ.get("AGX_BENCH_NO_PIN") != "1" else "not pinned (AGX_BENCH_NO_PIN=1)"
 
+    def bytes_limit(path, default):
+        try:
+            v = open(path).read().strip()
+            return int(v) if v.isdigit() else default
+        except OSError:
+            return default
+    mem_limit = bytes_limit("/sys/fs/cgroup/memory.max", 1 << 50)
+    try:
+        mem_limit = min(mem_limit, os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE"))
+    except (ValueError, OSError):
+        pass
     if args.config is None:
-        args.config = "cfg3" if world == 1 else "cfg5s"
+        if world == 1:
+            args.config = "cfg3"
+        else:      # the whole-human configuration where the box can hold it (64 GB of disk, ~60 GB of host memory while it is generated), else its shape at 1/4
+            import shutil
+            os.makedirs(args.workdir, exist_ok=True)
+            have = os.path.exists(os.path.join(args.workdir, "cfg5_full", "synth_meta.txt"))
+            args.config = "cfg5" if (have or shutil.disk_usage(args.workdir).free > 70e9) and mem_limit > 150e9 else "cfg5q"
+    if not args.host_gb:
+        args.host_gb = min(96.0, 0.4 * mem_limit / 1e9) / max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if args.config == "custom":
         chroms, part, pairs, L = [int(x) for x in args.chroms.split(",")], args.part, args.pairs, args.L
         label = "custom: chromosomes %s, --part %d, %d 2x%d bp pairs" % (args.chroms, part, pairs, L)
@@ -204,12 +233,25 @@ def main():
     for kv in filter(None, os.environ.get("AGX_BENCH_SYNTH", "").split(",")):      # experiments only (e.g. contig_overlap=0): changes the workload, the
         key, _, val = kv.partition("=")                                             # JSON line then says so in config.workload
         extra[key] = val
-    run = os.path.join(args.workdir, "%s_p%d_k%d" % ("_".join(str(c) for c in chroms), pairs, k) + ("_x" if extra else "") + ("" if sam_seq else "_noseq"))
+    staged = args.config in STAGED or os.environ.get("AGX_BENCH_STAGED") == "1"      # (the variable: any configuration through the staged hand-over — plumbing tests)
+    run = os.path.join(args.workdir, "cfg5_full" if args.config in STAGED else "staged_%s_p%d" % ("_".join(str(c) for c in chroms), pairs) if staged else "%s_p%d_k%d" % ("_".join(str(c) for c in chroms), pairs, k) + ("_x" if extra else "") + ("" if sam_seq else "_noseq"))
+    if args.config in STAGED:
+        args.keep = not args.clean
+    if staged:
+        label = label[:label.index(", SAM lines ")] + ("" if args.config in STAGED else ", read alignments handed over staged (tmp/_agx_pairs.<u>.bin)")
     t0 = time.perf_counter()
     stamp = os.path.join(run, "synth_meta.txt")
     if rank == 0 and not os.path.exists(stamp):
-        D.synth(run, seed=1000, chroms=",".join(str(c) for c in chroms), part=part, pairs=pairs, L=L, k=k, coverage=args.coverage, sam_seq=sam_seq,
-                threads=min(32, os.cpu_count() or 1), **extra)
+        if staged:
+            import shutil
+            for other in os.listdir(args.workdir) if os.path.isdir(args.workdir) else []:      # 64 GB are about to be written: whatever other configurations left here goes first
+                if other != os.path.basename(run):
+                    shutil.rmtree(os.path.join(args.workdir, other), ignore_errors=True)
+            D.synth(run, seed=1000, chroms=",".join(str(c) for c in chroms), part=part, pairs=pairs, L=L, k=k, coverage=args.coverage, sam_seq=0,
+                    threads=min(32, max(4, A.usable_cpus())), pairs_bin=1, lean=1, **extra)
+        else:
+            D.synth(run, seed=1000, chroms=",".join(str(c) for c in chroms), part=part, pairs=pairs, L=L, k=k, coverage=args.coverage, sam_seq=sam_seq,
+                    threads=min(32, os.cpu_count() or 1), **extra)
     if dist:
         dist.barrier()
     t_gen = time.perf_counter() - t0
@@ -218,11 +260,11 @@ def main():
     n_units = len(unit_len)
     mine = shard.plan(unit_len, rank, world)                               # longest-first onto the least loaded rank, longest first within the rank
     t1 = time.perf_counter()
-    reads = A.Reads(os.path.join(tmp, "_reads.fa")) if mine else None      # tmp/_reads.fa mapped and indexed once for all units (agx_reads)
+    reads = A.Reads(os.path.join(tmp, "_reads.fa")) if mine and not staged else None      # tmp/_reads.fa mapped and indexed once for all units (agx_reads)
     t_index = time.perf_counter() - t1
     units, t_parse, t_stage, t_cached = {}, 0.0, 0.0, 0.0
     parse_threads = max(1, min(len(mine), 8))                              # units loaded side by side (each on its share of the cores: agx_host.cpp loader_threads)
-    stage_s, load_ms, un_bytes = {}, {}, {}
+    stage_s, load_ms, un_bytes, hbm_need = {}, {}, {}, {}
 
     def parse_unit(uu):
         un = A.Unit(k=k, insert_variation=50, coverage=args.coverage, device=local_rank)
@@ -230,7 +272,8 @@ def main():
         st = un.stats()
         stage_s[uu] = st["ms_stage"] * 1e-3
         load_ms[uu] = {"contigs": round(st["ms_thread"], 1), "read_alignments": round(st["ms_parse"], 1), "rest": round(st["ms_stage"], 1)}
-        un_bytes[uu] = un.hbm_needed() // 16 + st["n_pos"]             # what a staged one-shot unit holds in (pinned) host memory, generously: wire arrays + the download's landing area (cfg3's largest: 0.38 GB staged, 0.48 by this)
+        hbm_need[uu] = un.hbm_needed()                                  # what the upload will take of the device: units are admitted to it by this (shard.run_job)
+        un_bytes[uu] = hbm_need[uu] // 16 + st["n_pos"]             # what a staged one-shot unit holds in (pinned) host memory, generously: wire arrays + the download's landing area (cfg3's largest: 0.38 GB staged, 0.48 by this)
         return un
 
     os.environ["AGX_NO_CACHE"] = "1"
@@ -280,6 +323,7 @@ def main():
     my_pairs = sum(units[uu].stats()["sam_line_pairs"] for uu in mine)
 
     inflight = args.inflight or min(8, max(1, len(mine)))
+    hbm_budget = int(0.92 * A.device_memory(local_rank)[1])
     unit_stats, held, t_start = {}, {}, {}
 
     def run_unit(uu):
@@ -317,7 +361,7 @@ def main():
         elif args.pool == "host-cold":
             A.pool_trim(-1, retire_host=True)          # (the previous steps' buffers are unmapped after the timed region)
         units.clear(); units.update(unit_sets[step_no[0] % n_sets]); step_no[0] += 1
-        return shard.run_job(unit_len, rank, world, run_unit, dist, gdev, inflight=inflight, start_unit=start_unit)
+        return shard.run_job(unit_len, rank, world, run_unit, dist, gdev, inflight=inflight, start_unit=start_unit, hbm_need=hbm_need, hbm_budget=hbm_budget)
 
     for _ in range(args.warmup):
         run_job()
@@ -356,7 +400,7 @@ def main():
         by_name["(threads that ended: the job's unit threads)"] = (0, cpu_s_per_step * max(1, args.steps) - sum(t for _, t in by_name.values()))
         for name, (n, tot) in sorted(by_name.items(), key=lambda kv: -kv[1][1]):
             print("[bench] threads %-16s x%-3d %8.1f ms of CPU per step" % (name, n, 1e3 * tot / max(1, args.steps)), file=sys.stderr)
-    my_sam_bytes = sum(os.path.getsize(os.path.join(tmp, "_reads_genome.%d.bowtie" % uu)) for uu in mine)
+    my_sam_bytes = sum(os.path.getsize(os.path.join(tmp, ("_agx_pairs.%d.bin" if staged else "_reads_genome.%d.bowtie") % uu)) for uu in mine)
     tot = torch.tensor([elapsed, t_parse, t_stage, float(my_pairs), t_cached, float(my_sam_bytes)], dtype=torch.float64, device=gdev)
     if dist:
         mx = tot.clone()
@@ -381,9 +425,10 @@ def main():
                 with ThreadPoolExecutor(max_workers=parse_threads) as ex:
                     one = dict(zip(everything, ex.map(load_unit, everything)))
                 units.clear(); units.update(one)
+                hbm_all = {uu: un.hbm_needed() for uu, un in one.items()}
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                shard.run_job(unit_len, 0, 1, run_unit, None, gdev, inflight=min(8, len(everything)), start_unit=start_unit)
+                shard.run_job(unit_len, 0, 1, run_unit, None, gdev, inflight=min(8, len(everything)), start_unit=start_unit, hbm_need=hbm_all, hbm_budget=hbm_budget)
                 torch.cuda.synchronize()
                 if it:
                     ms.append(1e3 * (time.perf_counter() - t1))

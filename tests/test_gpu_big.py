@@ -7,8 +7,10 @@
     runs on five host threads beside the GPU work) — driven through the very job loop bench.py times (shard.run_job, pipelined units);
   * configs[3] (human chr1 shape, --part 4: four units of 62 Mb, 60 M pairs) at full size, all four slices through the job loop, every
     unit byte for byte against the oracle (four oracle runs on four host threads), plus a rebuild with every capacity started too small;
-  * the largest unit of configs[4] at its real size: chr1 whole (249 M positions, 32 M pairs of 2x150) as one unit — built once, HBM within
-    AlignGraph_amd's admission estimate, bytes equal to the serial CPU executor's (tests/hostsim) and to a rebuild from tiny capacities;
+  * configs[4] ITSELF (r04): whole human, GRCh38 lengths — 24 units of 249 .. 47 Mb, 3.1 Gb, 400 M pairs of 2x150 bp, 400 read batches — as one job through
+    shard.run_job on one GPU with admission by HBM: every unit built once with its first-guess capacities and within its admission estimate, the three
+    smallest chromosomes (chr21, chr22, chrY at their full lengths) byte for byte against the ORACLE and against rebuilds from tiny capacities.  The read
+    alignments are handed over staged (tmp/_agx_pairs.<u>.bin: as text the job is 170 GB), the checker's text exists for the three units only;
 
   * configs[4]'s 24-unit shard SHAPE (GRCh38 chromosome lengths / 256, 2x150 bp reads), one-shot units from their cache files through the
     job loop, every unit against the oracle.
@@ -181,45 +183,27 @@ def test_cfg5_shard_shape_at_1_256_every_unit_matches_the_oracle(agx, built, tmp
 
 
 @slow
-def test_human_sized_units_cfg4_slices_and_chr1_whole(agx, built, tmp_path, monkeypatch):
-    """The two human-scale shapes in ONE test, so that their CPU checkers (minutes each) run side by side while the GPU does both:
-
-    * configs[3] at full size: human chr1 (GRCh38 length) cut by --part 4 (formalizeGenome's rule, AG:3382-3413) into four units of 62 Mb, 60 M
-      pairs of 2x100 — all four through the job loop bench.py times, every unit byte for byte against the ORACLE (four oracle runs on four host
-      threads), then one slice again with every capacity started too small;
-    * the largest unit of configs[4] (whole human, 24 units) at its real size: chr1 WHOLE — 248 956 422 positions, 2x150 bp reads at the
-      configuration's depth (400 M pairs x 249 / 3100 Mb = 32 M pairs), --coverage 5 — as ONE unit: 4x the positions of anything else in the suite,
-      32 read batches (BATCH, AG:37: a line pair lost at each boundary, AG:1258-1259), four walkers.  Checked: one build with the first-guess
-      capacities, HBM = what AlignGraph_amd admits it by (agx_unit_hbm_needed), output bytes equal to those of the serial CPU executor of the
-      kernels' lane functions (tests/hostsim) and to a second build whose capacities all started too small."""
+def test_human_sized_units_cfg4_slices(agx, built, tmp_path, monkeypatch):
+    """configs[3] at full size: human chr1 (GRCh38 length) cut by --part 4 (formalizeGenome's rule, AG:3382-3413) into four units of 62 Mb, 60 M
+    pairs of 2x100 — all four through the job loop bench.py times, every unit byte for byte against the ORACLE (four oracle runs on four host
+    threads), then one slice again with every capacity started too small.  (chr1 WHOLE as one unit — r03 checked it here against the serial executor —
+    is unit 0 of the whole-human job below.)"""
     import shutil
     from aligngraph_amd import shard
-    from hostsim import sim
     run4 = H.synth(str(tmp_path / "cfg4"), seed=1004, chroms="248956422", part=4, pairs=60000000, L=100, k=5, coverage=5, sam_seq=0, threads=THREADS)
     tmp4 = os.path.join(run4, "tmp")
     lens = H.read_meta(run4)["unit_len"]
     assert len(lens) == 4 and sum(lens) == 248956422
-    n1, pairs1 = 248956422, 32000000
-    run1 = H.synth(str(tmp_path / "chr1"), seed=1006, chroms=str(n1), pairs=pairs1, L=150, k=5, coverage=5, sam_seq=0, threads=THREADS)
-    tmp1 = os.path.join(run1, "tmp")
-    want4, want1, errs = {}, {}, []
+    want4, errs = {}, []
 
     def oracle(uu):
         try:
             want4[uu] = H.run_oracle(tmp4, uu, 5, 50, 5)
         except BaseException as e:
             errs.append(e)
-
-    def serial():
-        try:
-            want1.update(sim.run(tmp1, 0, k=5, insert_variation=50, coverage=5))
-        except BaseException as e:
-            errs.append(e)
-    checkers = [threading.Thread(target=serial)] + [threading.Thread(target=oracle, args=(uu,)) for uu in range(4)]
+    checkers = [threading.Thread(target=oracle, args=(uu,)) for uu in range(4)]
     for t in checkers:
         t.start()
-
-    # ---- cfg4: four slices through the job loop ----
     units, got4, stats4 = {}, {}, {}
     with agx.Reads(os.path.join(tmp4, "_reads.fa")) as reads:
         for uu in range(4):
@@ -245,29 +229,9 @@ def test_human_sized_units_cfg4_slices_and_chr1_whole(agx, built, tmp_path, monk
         again4 = u2.finish()
         assert u2.stats()["build_attempts"] > 1
     monkeypatch.delenv("AGX_TEST_SMALL_CAPS")
-
-    # ---- chr1 whole as one unit ----
-    with agx.Unit(k=5, insert_variation=50, coverage=5) as u:
-        u.load_files(tmp1, 0)
-        estimate = u.hbm_needed()                          # what AlignGraph_amd admits the unit to a device by (agx_cli.cpp run_units)
-        u.upload(); u.build()
-        got1 = u.finish()
-        st = u.stats()
-    assert st["n_pos"] >= n1 and st["build_attempts"] == 1, st
-    assert st["pairs_in_file"] == pairs1 and st["sam_line_pairs"] - st["n_hits"] >= 31          # 31 batch boundaries, a line pair lost at each
-    assert st["device_bytes"] <= estimate < 100e9, "the unit took %.1f GB of HBM, AlignGraph_amd admits it with %.1f GB" % (st["device_bytes"] / 1e9, estimate / 1e9)
-    print("chr1-sized unit: %.1f GB of HBM (estimate %.1f GB), %d hits, %d nodes, node sweep %.2f ms, walk %.1f ms" % (st["device_bytes"] / 1e9, estimate / 1e9, st["n_hits"], st["n_nodes"], st["ms_node_sweep"], st["ms_walk"]))
-    monkeypatch.setenv("AGX_TEST_SMALL_CAPS", "1")
-    with agx.Unit(k=5, insert_variation=50, coverage=5) as u2:
-        u2.load_files(tmp1, 0)
-        u2.upload(); u2.build()
-        again1 = u2.finish()
-        assert u2.stats()["build_attempts"] > 1
-    monkeypatch.delenv("AGX_TEST_SMALL_CAPS")
-
     for t in checkers:
         t.join()
-    shutil.rmtree(run4, ignore_errors=True); shutil.rmtree(run1, ignore_errors=True)
+    shutil.rmtree(run4, ignore_errors=True)
     assert not errs, errs
     for uu in range(4):
         for key in ("initial", "pre", "extended"):
@@ -276,6 +240,84 @@ def test_human_sized_units_cfg4_slices_and_chr1_whole(agx, built, tmp_path, monk
     assert sum(stats4[uu]["sam_line_pairs"] for uu in range(4)) > 60000000
     for key in ("initial", "pre", "extended"):
         assert again4[key] == want4[3][key], "cfg4: %s of slice 3 differs from the oracle after its capacities regrew" % key
-        assert got1[key] == again1[key], "chr1: %s differs between a first build and one whose capacities regrew" % key
-        assert got1[key] == want1[key], "chr1: %s differs from the serial executor" % key
-    assert got1["extended"].count(b">") > 100 and len(got1["extended"]) > 0.9 * n1
+
+
+@slow
+def test_cfg5_whole_human_at_full_size(agx, built, tmp_path, monkeypatch):
+    """BASELINE configs[4] as a job: GRCh38's 24 chromosome lengths (3.1 Gb), 400 M pairs of 2x150 bp (400 read batches: BATCH, AG:37), --coverage 5, every unit a
+    one-shot unit, all of them through shard.run_job on ONE GPU, admitted by agx_unit_hbm_needed (eight units in flight at most; chr1 alone takes 57 GB of HBM).
+    The read alignments cross staged (tools/agx_synth.cpp --pairs-bin 1: the engine's own line parser, batch rules and staging make them; tests/test_staged_pairs.py
+    compares that hand-over with the text path byte for byte) — as SAM + reads text this job is 170 GB.  For chr21, chr22 and chrY (47 - 57 Mb at full length) the
+    generator also writes the checker's text (the unit's SAM lines + a reads file with placeholders for everybody else's reads): their bytes must be the ORACLE's,
+    and a rebuild from absurdly small capacities must give them again.  Every unit: one build, HBM within its admission estimate, the batch boundaries' lost line
+    pairs, records and N50 of the right order."""
+    import shutil
+    from concurrent.futures import ThreadPoolExecutor
+    from aligngraph_amd import shard
+    CHECK = (20, 21, 23)                                       # chr21, chr22, chrY
+    run = H.synth(str(tmp_path / "run"), seed=1000, chroms=",".join(map(str, HUMAN)), pairs=400000000, L=150, k=5, coverage=5, sam_seq=0, threads=THREADS,
+                  pairs_bin=1, lean=1, oracle_units=",".join(map(str, CHECK)))
+    tmp = os.path.join(run, "tmp")
+    lens = H.read_meta(run)["unit_len"]
+    assert lens == list(HUMAN)
+    want, errs = {}, []
+
+    def oracle(uu):
+        try:
+            want[uu] = H.run_oracle(os.path.join(run, "oracle_%d" % uu, "tmp"), uu, 5, 50, 5)
+        except BaseException as e:
+            errs.append(e)
+    checkers = [threading.Thread(target=oracle, args=(uu,)) for uu in CHECK]
+    for t in checkers:
+        t.start()
+
+    def load(uu):
+        un = agx.Unit(k=5, insert_variation=50, coverage=5, flags=agx.AGX_FLAG_ONE_SHOT)
+        un.load_files(tmp, uu)
+        return un
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        units = dict(zip(range(24), ex.map(load, range(24))))
+    need = {uu: units[uu].hbm_needed() for uu in range(24)}
+    total_hbm = agx.device_memory(0)[1]
+    assert need[0] == max(need.values()) and 40e9 < need[0] < 70e9 and sum(need.values()) > 2 * total_hbm      # the job does not fit the device at once: admission matters
+    got, stats = {}, {}
+
+    def run_unit(uu):
+        un = units[uu]
+        un.build(); un.download()
+        got[uu] = un.finish()
+        stats[uu] = un.stats()
+        un.release()
+        return got[uu]["extended"]
+    out = shard.run_job(lens, 0, 1, run_unit, None, None, inflight=8, start_unit=lambda uu: units[uu].upload(), hbm_need=need, hbm_budget=int(0.92 * total_hbm))
+    assert sorted(out) == list(range(24))
+    for un in units.values():
+        un.close()
+    agx.pool_trim(0, host=True)
+    again = {}
+    monkeypatch.setenv("AGX_TEST_SMALL_CAPS", "1")              # every capacity far too small: tile lists, node pool, sparse table all regrow
+    for uu in CHECK:
+        with agx.Unit(k=5, insert_variation=50, coverage=5) as u2:
+            u2.load_files(tmp, uu)
+            u2.upload(); u2.build()
+            again[uu] = u2.finish()
+            assert u2.stats()["build_attempts"] > 1
+    monkeypatch.delenv("AGX_TEST_SMALL_CAPS")
+    for t in checkers:
+        t.join()
+    shutil.rmtree(run, ignore_errors=True)
+    assert not errs, errs
+    for uu in range(24):
+        st = stats[uu]
+        assert st["build_attempts"] == 1 and st["n_pos"] >= lens[uu] and st["pairs_in_file"] == 400000000, (uu, st)
+        assert st["device_bytes"] <= need[uu], "unit %d took %.1f GB of HBM, it was admitted with %.1f GB" % (uu, st["device_bytes"] / 1e9, need[uu] / 1e9)
+        assert abs(st["sam_line_pairs"] / (400e6 * 1.03 * lens[uu] / sum(lens)) - 1) < 0.02          # its share of the pairs (5 % with a second hit, 2 % unaligned)
+        assert 300 <= st["sam_line_pairs"] - st["n_hits"] - 0 and st["n_hits"] > 0.9 * st["sam_line_pairs"]      # 399 batch boundaries, a line pair lost at (nearly) each, + the identity filter's
+        ext = got[uu]["extended"]
+        assert ext.count(b">") > lens[uu] / 1e6 and len(ext) > 0.9 * lens[uu], "unit %d: %d extended contigs, %d bytes" % (uu, ext.count(b">"), len(ext))
+    for uu in CHECK:
+        for key in ("initial", "pre", "extended"):
+            assert got[uu][key] == want[uu][key], "unit %d (%d positions): %s differs from the oracle" % (uu, lens[uu], key)
+            assert again[uu][key] == want[uu][key], "unit %d: %s differs from the oracle after its capacities regrew" % (uu, key)
+    print("whole human: 24 units, %d hits, largest unit %.1f GB of HBM, node sweeps %.1f ms in all, walks %.0f ms in all" %
+          (sum(s["n_hits"] for s in stats.values()), stats[0]["device_bytes"] / 1e9, sum(s["ms_node_sweep"] for s in stats.values()), sum(s["ms_walk"] for s in stats.values())))

@@ -81,3 +81,33 @@ def test_two_ranks_gloo_gather(built, tmp_path):
     assert sorted(merged) == [0, 1, 2]
     for u in range(3):
         assert merged[u] == H.run_oracle(os.path.join(run, "tmp"), u, meta["k"], meta["insert_variation"], meta["coverage"])["extended"]
+
+
+def test_units_are_admitted_by_device_memory():
+    """shard.run_job with hbm_need / hbm_budget: never more in flight than the device holds, plan order kept, a unit beyond the budget runs alone."""
+    import threading
+    import time
+    from aligngraph_amd import shard
+    sizes = [50, 48, 40, 30, 20, 10, 5, 120]
+    need = {u: s for u, s in enumerate(sizes)}
+    lock, now, peak, order, alone = threading.Lock(), [0], [0], [], []
+
+    def start_unit(u):
+        order.append(u)
+
+    def run_unit(u):
+        with lock:
+            now[0] += need[u]
+            peak[0] = max(peak[0], now[0])
+            if need[u] > 100:
+                alone.append(now[0] == need[u])
+        time.sleep(0.01 + 0.0005 * need[u])
+        with lock:
+            now[0] -= need[u]
+        return b"u%d" % u
+    out = shard.run_job(sizes, 0, 1, run_unit, None, None, inflight=8, start_unit=start_unit, hbm_need=need, hbm_budget=100)
+    assert sorted(out) == list(range(8)) and out[3] == b"u3"
+    assert order == shard.plan(sizes, 0, 1)                 # largest first, as planned
+    assert peak[0] <= 120 and alone == [True]               # 120 > budget: it ran with nothing beside it; everything else within 100
+    with lock:
+        assert now[0] == 0

@@ -48,3 +48,14 @@ def test_same_stream_with_and_without_text(built, tmp_path):
         assert open(pa, "rb").read() == open(pb, "rb").read()
     assert not os.path.exists(os.path.join(b, "tmp", "_reads.fa")) and not os.path.exists(os.path.join(b, "tmp", "_reads_genome.0.bowtie"))
     assert os.path.getsize(os.path.join(b, "tmp", "_genome.fa")) == 0 and os.path.getsize(os.path.join(b, "tmp", "_genome.0.fa")) > 40000      # --lean: only what the unit loop reads
+
+
+def test_checker_text_with_placeholder_reads(built, tmp_path):
+    """--oracle-units: the text a checker needs for single units of a job too large to exist as text — the unit's SAM lines and a reads file with the unit's reads in their
+    places and a one-base placeholder for everybody else's.  The oracle must get the same bytes out of it as out of the complete text, batch boundaries included."""
+    run = H.synth(str(tmp_path / "run"), seed=9, chroms="40000,30000,20000", pairs=9000, coverage=4, read_indel=0.2, multi=0.3, sam_seq=0, threads=3, pairs_bin=2, batch=2000, oracle_units="0,2")
+    for u in (0, 2):
+        full = H.run_oracle(os.path.join(run, "tmp"), u, 5, 50, 4, batch=2000)
+        thin = H.run_oracle(os.path.join(run, "oracle_%d" % u, "tmp"), u, 5, 50, 4, batch=2000)
+        assert full == thin and full["pre"].count(b">") > 3
+        sim.compare_staged(os.path.join(run, "tmp"), u, 5, 2000, 2)

@@ -30,6 +30,7 @@
 #include <thread>
 #include <vector>
 #include <sys/stat.h>
+#include <unistd.h>
 
 // -DAGX_SYNTH_WITH_ENGINE (build/agx_synth_bin: compiled together with the engine's host-side loader sources): the --pairs-bin mode below hands every unit's read alignments
 // over STAGED (tmp/_agx_pairs.<u>.bin, aligngraph_amd/csrc/agx_host.h) instead of as SAM text + tmp/_reads.fa — 58 bytes per pair instead of 420, which is what lets
@@ -109,6 +110,8 @@ struct Params {
     // made without making everybody else's); 2: both, from the same stream.  Only in build/agx_synth_bin.
     int pairs_bin = 0;
     int batch = 1000000;   // BATCH of the engine that will read the staged pairs (AG:37)
+    std::vector<int64_t> oracle_units;   // --pairs-bin: for these units ALSO the text a checker needs, under <out>/oracle_<u>/tmp: the unit's SAM lines, and a reads file that holds the unit's
+                                         // reads where they belong and a one-base placeholder record for everybody else's (4 bytes per read: 3.2 GB at 400 M pairs instead of 130)
     int lean = 0;          // 1: do not write the user-level copies genome.fa, contigs.fa and tmp/_genome.fa (9 GB at whole-human size); the unit loop reads none of them
 };
 
@@ -145,6 +148,7 @@ Params parse_args(int argc, char **argv) {
         OPT_D("--multi", multi) OPT_D("--multi-near", multi_near) OPT_D("--unaligned", unaligned)
         OPT_D("--mate1-left", mate1_left) OPT_D("--mixed-len", mixed_len) OPT_I("--sam-seq", sam_seq) OPT_I("--shuffle-units", shuffle_units) OPT_I("--e2e", e2e) OPT_I("--threads", threads) OPT_I("--pairs-bin", pairs_bin) OPT_I("--batch", batch) OPT_I("--lean", lean)
         if (a == "--chroms") { P.chroms = parse_list(v); continue; }
+        if (a == "--oracle-units") { P.oracle_units = parse_list(v); continue; }
         std::fprintf(stderr, "agx_synth: unknown option %s\n", a.c_str()); std::exit(2);
     }
     if (P.part < 1 || P.part > 10) die("--part must be 1..10");
@@ -496,8 +500,20 @@ int main(int argc, char **argv) {
         struct MemSink : agx::StageSink { std::vector<std::vector<char>> keep; void *take(int, size_t bytes) override { keep.emplace_back(bytes + 64); return keep.back().data(); } };
         for (int u = 0; u < NU; u++) {
             struct LinePair { agx::Mate m1, m2; };
-            struct Chunk { std::vector<LinePair> lp; std::vector<agx_run> runs; std::vector<int64_t> ids; std::string bases; bool ready = false; };      // ids / bases: the unit's pairs of this chunk (2 x L bytes each)
+            struct Chunk { std::vector<LinePair> lp; std::vector<agx_run> runs; std::vector<int64_t> ids; std::string bases, sam; bool ready = false; };      // ids / bases: the unit's pairs of this chunk (2 x L bytes each); sam: their lines, for --oracle-units
             std::vector<Chunk> chunks((size_t)NC);
+            const bool for_oracle = std::find(P.oracle_units.begin(), P.oracle_units.end(), (int64_t)u) != P.oracle_units.end();
+            FILE *o_reads = nullptr, *o_sam = nullptr; int64_t o_next = 0;       // o_next: the first read id the checker's reads file does not hold yet
+            std::string filler;
+            if (for_oracle) {
+                const std::string od = P.out + "/oracle_" + std::to_string(u), su = std::to_string(u);
+                mkdirs(od); mkdirs(od + "/tmp");
+                o_reads = std::fopen((od + "/tmp/_reads.fa").c_str(), "w"); o_sam = std::fopen((od + "/tmp/_reads_genome." + su + ".bowtie").c_str(), "w");
+                if (!o_reads || !o_sam) die("cannot open output");
+                for (const std::string &f : {"_genome." + su + ".fa", std::string("_contigs.fa"), "_contigs_genome." + su + ".psl"}) (void)!symlink(("../../tmp/" + f).c_str(), (od + "/tmp/" + f).c_str());
+                for (int i = 0; i < 65536; i++) filler += ">\nN\n>\nN\n";
+            }
+            auto fill_to = [&](int64_t id) { while (o_next < id) { const int64_t m = std::min<int64_t>(id - o_next, 65536); std::fwrite(filler.data(), 1, (size_t)m * 8, o_reads); o_next += m; } };
             std::atomic<int64_t> next_chunk(0);
             std::mutex mu; std::condition_variable cv; int64_t consumed = 0; bool failed = false;
             auto make_chunk = [&](int64_t c) {
@@ -510,6 +526,7 @@ int main(int argc, char **argv) {
                         sam_line(o, id, e, 0, l1); sam_line(o, id, e, 1, l2);
                         LinePair lp; agx::parse_sam_line(l1.data(), l1.size(), lp.m1, K.runs); agx::parse_sam_line(l2.data(), l2.size(), lp.m2, K.runs);
                         K.lp.push_back(lp);
+                        if (for_oracle) { K.sam += l1; K.sam.push_back('\n'); K.sam += l2; K.sam.push_back('\n'); }
                     }
                 }
             };
@@ -548,11 +565,22 @@ int main(int argc, char **argv) {
                             PP.hits[placed].slot1 = 2 * (n_ids - 1);
                         }
                     }
+                    if (for_oracle) {
+                        char hdr[32];
+                        for (size_t i = 0; i < K.ids.size(); i++) {
+                            fill_to(K.ids[i]);
+                            const int n = std::snprintf(hdr, sizeof hdr, ">%lld\n", (long long)K.ids[i]);
+                            for (int m = 0; m < 2; m++) { std::fwrite(hdr, 1, (size_t)n, o_reads); std::fwrite(K.bases.data() + (i * 2 + (size_t)m) * (size_t)L, 1, (size_t)L, o_reads); std::fputc('\n', o_reads); }
+                            o_next = K.ids[i] + 1;
+                        }
+                        std::fwrite(K.sam.data(), 1, K.sam.size(), o_sam); std::string().swap(K.sam);
+                    }
                     Chunk().lp.swap(K.lp); std::vector<agx_run>().swap(K.runs); std::vector<int64_t>().swap(K.ids); std::string().swap(K.bases);
                     { std::lock_guard<std::mutex> g(mu); consumed = c + 1; }
                     cv.notify_all();
                 }
                 for (auto &t : th) t.join();
+                if (for_oracle) { fill_to(N); std::fclose(o_reads); std::fclose(o_sam); }
                 PP.n_kept = PP.hits.size(); PP.n_slots = 2 * n_ids;
                 MemSink sink; agx::StagedPairs S;
                 agx::stage_pairs(PP, (agx_u32)P.k, (unsigned)P.threads, sink, S);
