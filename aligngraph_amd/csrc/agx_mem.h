@@ -17,6 +17,9 @@
 #include <cstdint>
 #include <map>
 #include <mutex>
+#include <condition_variable>
+#include <chrono>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -28,13 +31,15 @@ namespace agx {
 
 struct MemBlock { void *p = nullptr; size_t n = 0; };
 
-// free blocks of one kind, best fit: the smallest cached block that holds the request and is not more than twice as large
+// free blocks of one kind, best fit: the smallest cached block that holds the request and is not more than need / waste_div (+ 64 MB) larger — pinned host blocks: up to twice
+// the request; HBM blocks: a sixteenth more at most, because units are admitted to a device by what they NEED (agx_unit_hbm_needed, shard.run_job): a 32 GB unit that takes
+// over the 57 GB block of the chromosome before it holds 25 GB that nobody accounted for (r04: the first whole-human job ran out of HBM that way)
 class BlockCache {
 public:
-    bool take(size_t need, MemBlock &out) {
+    bool take(size_t need, MemBlock &out, size_t waste_div = 1) {
         std::lock_guard<std::mutex> g(m_);
         auto it = free_.lower_bound(need);
-        if (it == free_.end() || it->first > 2 * need + (64u << 20)) return false;
+        if (it == free_.end() || it->first > need + need / waste_div + (64u << 20)) return false;
         out = MemBlock{it->second, it->first}; held_ -= it->first; free_.erase(it);
         return true;
     }
@@ -50,9 +55,65 @@ inline size_t round_block(size_t n) { const size_t g = n < (64u << 20) ? (2u << 
 // ---- HBM ------------------------------------------------------------------------------------------------------------------------
 inline BlockCache &dev_cache(int device) { static BlockCache c[64]; return c[device & 63]; }
 
+// Units of very different sizes on one device (a whole-human job: 57 GB for chr1 down to 11 GB for chr21, eight in flight) defeat a cache of whole blocks: nothing fits
+// what the last unit left, and HBM that was just given back to the driver stalls the next hipMalloc for seconds (profiles/r02_recycle.txt; r04: the first whole-human job
+// spent 1-3 s per unit there, 19.5 s for a job whose copies, kernels and walks add up to 2 s).  Blocks from AGX_REGION_MIN bytes on are therefore cut from ONE region per device,
+// taken from the driver once (85 % of what is free then) and never given back while anything lives in it: first fit over a list of free ranges that merges neighbours.  A
+// request that finds no range waits for a unit to finish (units are admitted by their summed needs — shard.run_job — so room comes; the largest first, so what a finished unit
+// leaves holds whoever comes next); with nothing else in the region it fails at once.
+#define AGX_REGION_MIN ((size_t)8 << 30)
+class DevRegion {
+public:
+    bool owns(const void *p) const { return base_ && (const char *)p >= base_ && (const char *)p < base_ + size_; }
+    bool alloc(int device, size_t need, MemBlock &out) {      // false: this device has no region and none could be made (the caller takes the driver's path)
+        std::unique_lock<std::mutex> g(m_);
+        if (!base_) {
+            if (tried_) return false;
+            tried_ = true;
+            size_t fr = 0, tot = 0;
+            if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return false; }
+            size_t want = fr / 100 * 85 / ((size_t)16 << 20) * ((size_t)16 << 20);
+            if (const char *e = getenv("AGX_REGION_GB")) want = (size_t)atoll(e) << 30;      // (tests)
+            void *p = nullptr;
+            if (want < need || hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return false; }
+            base_ = (char *)p; size_ = want; free_[0] = want;
+        }
+        if (need > size_) return false;
+        for (;;) {
+            for (auto it = free_.begin(); it != free_.end(); ++it) if (it->second >= need) {
+                const size_t off = it->first, len = it->second;
+                free_.erase(it);
+                if (len > need) free_[off + need] = len - need;
+                in_use_++; out = MemBlock{base_ + off, need};
+                return true;
+            }
+            if (in_use_ == 0) return false;                   // (cannot happen: an empty region is one range)
+            if (cv_.wait_for(g, std::chrono::seconds(120)) == std::cv_status::timeout) throw Error{E_DEVICE, "no room in the device's memory region for two minutes: units in flight exceed the device"};
+        }
+    }
+    void give(const MemBlock &b) {
+        { std::lock_guard<std::mutex> g(m_);
+          size_t off = (size_t)((char *)b.p - base_), len = b.n;
+          auto nx = free_.lower_bound(off);
+          if (nx != free_.end() && off + len == nx->first) { len += nx->second; nx = free_.erase(nx); }
+          if (nx != free_.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == off) { off = pv->first; len += pv->second; free_.erase(pv); } }
+          free_[off] = len; in_use_--; }
+        cv_.notify_all();
+    }
+    void trim() {      // back to the driver, if nothing lives in it
+        std::lock_guard<std::mutex> g(m_);
+        if (base_ && in_use_ == 0) { (void)hipFree(base_); base_ = nullptr; size_ = 0; free_.clear(); tried_ = false; }
+    }
+private:
+    std::mutex m_; std::condition_variable cv_; char *base_ = nullptr; size_t size_ = 0; std::map<size_t, size_t> free_; size_t in_use_ = 0; bool tried_ = false;
+};
+inline DevRegion &dev_region(int device) { static DevRegion r[64]; return r[device & 63]; }
+inline void dev_give(int device, const MemBlock &b) { if (!b.p) return; if (dev_region(device).owns(b.p)) dev_region(device).give(b); else dev_cache(device).give(b); }
+
 inline MemBlock dev_block(int device, size_t need) {
     MemBlock b; need = round_block(need ? need : 1);
-    if (dev_cache(device).take(need, b)) return b;
+    if (need >= AGX_REGION_MIN && !getenv("AGX_NO_REGION") && dev_region(device).alloc(device, need, b)) return b;
+    if (dev_cache(device).take(need, b, 16)) return b;
     AGX_HIP_OK(hipSetDevice(device));
     hipError_t e = hipMalloc(&b.p, need);
     if (e != hipSuccess) {                       // out of HBM: give the cached blocks back to the driver and try once more
@@ -63,7 +124,7 @@ inline MemBlock dev_block(int device, size_t need) {
     b.n = need;
     return b;
 }
-inline void dev_trim(int device) { (void)hipSetDevice(device); for (const MemBlock &c : dev_cache(device).drain()) (void)hipFree(c.p); }
+inline void dev_trim(int device) { (void)hipSetDevice(device); for (const MemBlock &c : dev_cache(device).drain()) (void)hipFree(c.p); dev_region(device).trim(); }
 
 // A unit's device memory: blocks taken from the device's cache, handed out front to back (256-byte aligned), returned together.
 class DevArena {
@@ -77,7 +138,7 @@ public:
         void *p = (char *)blocks_.back().p + at_; at_ += bytes; used_ += bytes;
         return p;
     }
-    void reset() { for (const MemBlock &b : blocks_) dev_cache(device).give(b); blocks_.clear(); at_ = 0; used_ = 0; }
+    void reset() { for (const MemBlock &b : blocks_) dev_give(device, b); blocks_.clear(); at_ = 0; used_ = 0; }
     size_t used() const { return used_; }
     size_t capacity() const { size_t s = 0; for (const MemBlock &b : blocks_) s += b.n; return s; }
 private:

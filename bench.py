@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--same-config-steps", type=int, default=4, help="N > 1: after the timed N-rank steps rank 0 runs the SAME job alone on its GPU for this many steps "
                                                                       "(single_gpu_ms_same_config, speedup_vs_1gpu in the JSON line); 0 = skip")
     ap.add_argument("--host-gb", type=float, default=0.0, help="host memory a rank may hold in staged unit sets; more steps than fit re-upload the same unit objects (as --reupload).  "
-                                                               "0 (default): 96 GB or 40 %% of the control group's memory limit, whichever is less, divided by the ranks on this host")
+                                                               "0 (default): 160 GB or 40 %% of the control group's memory limit, whichever is less, divided by the ranks on this host")
     ap.add_argument("--clean", action="store_true", help="delete the generated inputs at the end even for cfg5 (whose 64 GB are otherwise kept for the next run: N = 1, 2, 4, 8 back to back)")
     ap.add_argument("--chroms", default="4600000", help="custom: comma-separated chromosome lengths")
     ap.add_argument("--part", type=int, default=1)
@@ -218,7 +218,7 @@ def main():
             have = os.path.exists(os.path.join(args.workdir, "cfg5_full", "synth_meta.txt"))
             args.config = "cfg5" if (have or shutil.disk_usage(args.workdir).free > 70e9) and mem_limit > 150e9 else "cfg5q"
     if not args.host_gb:
-        args.host_gb = min(96.0, 0.4 * mem_limit / 1e9) / max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+        args.host_gb = min(160.0, 0.4 * mem_limit / 1e9) / max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if args.config == "custom":
         chroms, part, pairs, L = [int(x) for x in args.chroms.split(",")], args.part, args.pairs, args.L
         label = "custom: chromosomes %s, --part %d, %d 2x%d bp pairs" % (args.chroms, part, pairs, L)
@@ -242,11 +242,14 @@ def main():
     t0 = time.perf_counter()
     stamp = os.path.join(run, "synth_meta.txt")
     if rank == 0 and not os.path.exists(stamp):
-        if staged:
-            import shutil
-            for other in os.listdir(args.workdir) if os.path.isdir(args.workdir) else []:      # 64 GB are about to be written: whatever other configurations left here goes first
+        import shutil
+        os.makedirs(args.workdir, exist_ok=True)
+        wanted = 68e9 if args.config in STAGED else pairs * (2.0 * (L + 12) + 2.0 * ((2 * L + 110) if sam_seq else 55) + 60) + 3.2 * sum(chroms)      # bytes about to be written (inputs + unit caches)
+        if shutil.disk_usage(args.workdir).free < 1.15 * wanted:      # whatever other configurations left here (the whole-human inputs are kept between runs) goes first
+            for other in os.listdir(args.workdir):
                 if other != os.path.basename(run):
                     shutil.rmtree(os.path.join(args.workdir, other), ignore_errors=True)
+        if staged:
             D.synth(run, seed=1000, chroms=",".join(str(c) for c in chroms), part=part, pairs=pairs, L=L, k=k, coverage=args.coverage, sam_seq=0,
                     threads=min(32, max(4, A.usable_cpus())), pairs_bin=1, lean=1, **extra)
         else:
@@ -273,7 +276,7 @@ def main():
         stage_s[uu] = st["ms_stage"] * 1e-3
         load_ms[uu] = {"contigs": round(st["ms_thread"], 1), "read_alignments": round(st["ms_parse"], 1), "rest": round(st["ms_stage"], 1)}
         hbm_need[uu] = un.hbm_needed()                                  # what the upload will take of the device: units are admitted to it by this (shard.run_job)
-        un_bytes[uu] = hbm_need[uu] // 16 + st["n_pos"]             # what a staged one-shot unit holds in (pinned) host memory, generously: wire arrays + the download's landing area (cfg3's largest: 0.38 GB staged, 0.48 by this)
+        un_bytes[uu] = hbm_need[uu] // 24 + 2 * st["n_pos"]             # what a staged one-shot unit holds in (pinned) host memory, generously: wire arrays + the download's landing area (cfg3's largest: 0.38 GB staged, 0.48 by this)
         return un
 
     os.environ["AGX_NO_CACHE"] = "1"
@@ -323,7 +326,7 @@ def main():
     my_pairs = sum(units[uu].stats()["sam_line_pairs"] for uu in mine)
 
     inflight = args.inflight or min(8, max(1, len(mine)))
-    hbm_budget = int(0.92 * A.device_memory(local_rank)[1])
+    hbm_budget = int(0.85 * min(A.device_memory(local_rank)))      # (free, total) before this process holds any of it: blocks recycled between units may be a sixteenth larger than the unit asked for, a build that has to grow a capacity takes more
     unit_stats, held, t_start = {}, {}, {}
 
     def run_unit(uu):

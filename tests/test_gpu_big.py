@@ -289,7 +289,7 @@ def test_cfg5_whole_human_at_full_size(agx, built, tmp_path, monkeypatch):
         stats[uu] = un.stats()
         un.release()
         return got[uu]["extended"]
-    out = shard.run_job(lens, 0, 1, run_unit, None, None, inflight=8, start_unit=lambda uu: units[uu].upload(), hbm_need=need, hbm_budget=int(0.92 * total_hbm))
+    out = shard.run_job(lens, 0, 1, run_unit, None, None, inflight=8, start_unit=lambda uu: units[uu].upload(), hbm_need=need, hbm_budget=int(0.85 * total_hbm))
     assert sorted(out) == list(range(24))
     for un in units.values():
         un.close()
