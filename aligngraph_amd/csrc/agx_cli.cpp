@@ -233,9 +233,27 @@ void distribute_alignments(int units) {
     const char *base = n ? (const char *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
     if (n && base == (const char *)MAP_FAILED) { close(fd); die("CANNOT OPEN FILE!"); }
     if (n) madvise((void *)base, n, MADV_SEQUENTIAL);
+    // Every unit's file is created and truncated up front (as the reference's ofstreams are), but only `open_max` descriptors are held at a time and the buffers
+    // share one budget: a draft reference with thousands of scaffolds must neither run into the descriptor limit nor hold 8 MB per unit.  A file that cannot be
+    // opened or written is fatal — silently dropped lines would make the unit run on truncated alignments and report success.
     vector<int> out(units, -1); vector<string> buf(units);
-    for (int u = 0; u < units; u++) { out[u] = open(("tmp/_reads_genome." + itoa(u) + ".bowtie").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666); buf[u].reserve((size_t)9 << 20); }
-    auto flush = [&](int u) { size_t done = 0; while (out[u] >= 0 && done < buf[u].size()) { const ssize_t w = write(out[u], buf[u].data() + done, buf[u].size() - done); if (w <= 0) break; done += (size_t)w; } buf[u].clear(); };
+    const size_t per_unit = std::max<size_t>((size_t)64 << 10, std::min<size_t>((size_t)8 << 20, ((size_t)1 << 30) / (size_t)std::max(1, units)));
+    const int open_max = 512; int n_open = 0; vector<int> lru;
+    for (int u = 0; u < units; u++) { const int f = open(("tmp/_reads_genome." + itoa(u) + ".bowtie").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666); if (f < 0) die("CANNOT OPEN FILE!"); close(f); }
+    auto fd_of = [&](int u) -> int {
+        if (out[u] >= 0) return out[u];
+        if (n_open >= open_max) { const int v = lru.front(); lru.erase(lru.begin()); close(out[v]); out[v] = -1; n_open--; }
+        out[u] = open(("tmp/_reads_genome." + itoa(u) + ".bowtie").c_str(), O_WRONLY | O_APPEND, 0666);
+        if (out[u] < 0) die("CANNOT OPEN FILE!");
+        n_open++; lru.push_back(u);
+        return out[u];
+    };
+    auto flush = [&](int u) {
+        if (buf[u].empty()) return;
+        const int f = fd_of(u); size_t done = 0;
+        while (done < buf[u].size()) { const ssize_t w = write(f, buf[u].data() + done, buf[u].size() - done); if (w <= 0) die(("CANNOT WRITE FILE! (tmp/_reads_genome." + itoa(u) + ".bowtie)").c_str()); done += (size_t)w; }
+        buf[u].clear();
+    };
     for (const char *c = base, *e = base + n; c < e;) {
         const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
         const char *le = nl ? nl : e;
@@ -250,7 +268,7 @@ void distribute_alignments(int units) {
         if (memchr(r0, '*', (size_t)(r1 - r0))) continue;
         char num[10]; const size_t k = std::min<size_t>(9, (size_t)(r1 - r0)); memcpy(num, r0, k); num[k] = 0;
         const int u = atoi(num);
-        if (u >= 0 && u < units) { buf[u].append(line, len); buf[u].push_back('\n'); if (buf[u].size() >= ((size_t)8 << 20)) flush(u); }
+        if (u >= 0 && u < units) { buf[u].append(line, len); buf[u].push_back('\n'); if (buf[u].size() >= per_unit) flush(u); }
     }
     for (int u = 0; u < units; u++) { flush(u); if (out[u] >= 0) close(out[u]); }
     if (n) munmap((void *)base, n);

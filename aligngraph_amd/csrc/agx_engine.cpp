@@ -622,8 +622,22 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
         unsigned long long el = 0;
         for (size_t i = 0; i < u->n_segs && fine; i++) { const agx_cmseg &g = u->s_segs.p[i]; fine = (unsigned long long)g.pos0 + g.len <= H.n_pos && g.hop_end < H.n_pos && (unsigned long long)g.hop_str0 + g.hop_len0 <= H.len[S_CHAIN_STR] + 1 && g.elem0 == el; el += g.len; }
         fine = fine && el == H.n_cm;
+        if (fine) {      // the device derives cm_start from the counts and writes every run element at cm[cm_start[x] + rank] (agx_k_cm_fill): the counts must add up to the
+            // conti-mers, and every element's rank must lie below its position's count — or a file with intact lengths writes out of bounds in HBM
+            const agx_u8 *cc = (const agx_u8 *)(base + H.off[S_CM_CNT]);
+            std::vector<unsigned long long> part(threads, 0); std::vector<int> bad3(threads, 0);
+            on_threads(threads, [&](unsigned t) {
+                unsigned long long sum = 0;
+                for (size_t x = (size_t)H.n_pos * t / threads, hi = (size_t)H.n_pos * (t + 1) / threads; x < hi; x++) sum += cc[x];
+                part[t] = sum;
+                for (size_t i = u->n_segs * t / threads, hi = u->n_segs * (t + 1) / threads; i < hi; i++) { const agx_cmseg &g = u->s_segs.p[i]; if (g.rank > 254) { bad3[t] = 1; return; }
+                    for (agx_u32 j = 0; j < g.len; j++) if (cc[(size_t)g.pos0 + j] <= g.rank) { bad3[t] = 1; return; } }
+            });
+            unsigned long long total = 0; for (unsigned t = 0; t < threads; t++) { total += part[t]; fine = fine && !bad3[t]; }
+            fine = fine && total == H.n_cm;
+        }
         for (size_t i = 0; i < u->n_chain_end && fine; i++) fine = u->s_chain_end.p[i] < H.n_pos;
-        if (fine && in_reads) { const uint64_t *ro = (const uint64_t *)(base + H.off[S_ROWS]); for (size_t r = 0; r < H.n_rows && fine; r++) fine = ro[r] + H.stride <= reads_map->n + 16 && ro[r] < reads_map->n; }
+        if (fine && in_reads) { const uint64_t *ro = (const uint64_t *)(base + H.off[S_ROWS]); for (size_t r = 0; r < H.n_rows && fine; r++) fine = ro[r] + H.maxlen <= reads_map->n && ro[r] < reads_map->n; }      // (a row is read up to the longest read's length)
         if (fine && !in_reads && !from_codes) { const agx_u32 *rs = (const agx_u32 *)(base + H.off[S_ROWS]); for (size_t r = 0; r < H.n_rows && fine; r++) fine = rs[r] < H.n_slots; }
         for (size_t i = 1; i < u->n_other && fine && from_codes; i++) fine = u->s_other.p[i - 1] < u->s_other.p[i];      // (the walk bisects the list)
     }
