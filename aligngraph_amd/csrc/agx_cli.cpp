@@ -11,6 +11,7 @@
 //
 // Everything here is text plumbing around the path; the compute is agx_run_unit's (include/agx.h).
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -373,6 +374,9 @@ void nucmer_to_psl(const string &ref, const string &qry, const string &prefix, c
 
 // task0 / task1 of parallelMap, AG:3581-3735: the two aligners run side by side, command strings unchanged
 void align_everything(const Options &o, int units) {
+    const bool timing = getenv("AGX_CLI_TIMING") != nullptr;      // (stderr: what the aligners' share of this stage was, and the distribution's and the caches')
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_in = now_s();
     std::thread reads([&]() {
         const string lo = itoa(o.distanceLow), hi = itoa(o.distanceHigh);
         const string opts = "bowtie2 -f --no-mixed -k 5 -p 8 --local --mp 3,1 --rdg 2,1 --rfg 2,1 --score-min G,5,2 -I " + lo + " -X " + hi + " --no-discordant -x ";
@@ -384,7 +388,9 @@ void align_everything(const Options &o, int units) {
         } else {
             run("bowtie2-build -f tmp/_genome.fa tmp/_genome > bowtie_doc.txt 2> bowtie_doc.txt");
             run(opts + "tmp/_genome -1 tmp/_reads_1.fa -2 tmp/_reads_2.fa --reorder > tmp/_reads_genome.bowtie 2> bowtie_doc.txt");
+            const double t_al = now_s();
             distribute_alignments(units);
+            if (timing) fprintf(stderr, "[agx cli]   bowtie2 (external)          %9.3f s\n[agx cli]   distribute alignments       %9.3f s\n", t_al - t_in, now_s() - t_al);
         }
     });
     std::thread contigs([&]() {
@@ -396,6 +402,7 @@ void align_everything(const Options &o, int units) {
         }
     });
     reads.join(); contigs.join();
+    const double t_joined = now_s();
     // The units' binary caches: the five text files of every unit parsed ONCE, here where the reference distributes the
     // alignments (AG:3545-3579), into tmp/_agx_unit.<u>.bin; the unit loop — of this run and of every --resume — then reads no text.  The
     // text files stay what the contract says they are.  Failures are not errors here: the unit loop falls back to the text and reports.
@@ -411,6 +418,7 @@ void align_everything(const Options &o, int units) {
         for (auto &t : th) t.join();
         agx_reads_close(rd);
     }
+    if (timing) fprintf(stderr, "[agx cli]   unit caches                 %9.3f s\n", now_s() - t_joined);
 }
 
 // the SAM fields checkRatio looks at (parseBOWTIE, AG:181-285) and its identity filter (AG:3790)
@@ -814,6 +822,11 @@ int main(int argc, char **argv) {
     cout << "AlignGraph: algorithm for secondary de novo genome assembly guided by closely related references" << endl;
     cout << "By Ergude Bao, CS Department, UC-Riverside. All Rights Reserved" << endl << endl;
     const time_t start = time(NULL);
+    // AGX_CLI_TIMING=1: wall time of every stage on stderr (the reference only reports whole seconds for the run and for the aligners)
+    const bool timing = getenv("AGX_CLI_TIMING") != nullptr;
+    auto clock_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_stage = clock_s();
+    auto stage = [&](const char *name) { const double t = clock_s(); if (timing) fprintf(stderr, "[agx cli] %-28s %9.3f s\n", name, t - t_stage); t_stage = t; };
     {
         std::ofstream wcmd("command.txt");
         if (!wcmd.is_open()) { cout << "CANNOT OPEN FILE!" << endl; return 0; }
@@ -832,11 +845,12 @@ int main(int argc, char **argv) {
         mkdir("tmp", 0777);
         { std::ofstream wcmd("tmp/_command.txt"); for (int i = 1; i < argc; i++) wcmd << argv[i] << endl; }
         wcp.open("tmp/_checkpoint.txt");
-        formalize_reads(o.read1, o.read2);
-        formalize_contigs(o.contig, contigIds);
-        units = formalize_genome(o.genome, o.part, genomeIds);
+        stage("start-up, aligner checks");
+        formalize_reads(o.read1, o.read2); stage("formalize reads");
+        formalize_contigs(o.contig, contigIds); stage("formalize contigs");
+        units = formalize_genome(o.genome, o.part, genomeIds); stage("formalize genome");
         startAlign = time(NULL);
-        align_everything(o, units);
+        align_everything(o, units); stage("aligners + distribute + caches");
         endAlign = time(NULL);
         cout << "(0) Alignment finished" << endl;
         wcp << "0" << endl;
@@ -854,8 +868,11 @@ int main(int argc, char **argv) {
         startAlign = endAlign = time(NULL);
     }
     if (o.ratioCheck == 1) check_ratio(units);
+    stage("resume / ratio check");
     if (cp < units) run_units(o, cp, units, wcp);
+    stage("unit loop");
     refinement(o, units, genomeIds, contigIds);
+    stage("refinement");
     if (o.misassemblyRemoval == 1) {                                          // AG:4787-4792
         remove_misassembly(o, o.ext, "extended", contigIds);
         remove_misassembly(o, o.rmn, "remaining", contigIds);

@@ -53,7 +53,7 @@ typedef uint8_t agx_u8;
 #endif
 #define AGX_MAXV_MID 4u       // pass 1, LDS again (13 KB per wavefront): the widest bucket whose x -> x+1 edges still fit the sweep's edge matrix
 #define AGX_MAXV_BIG 64u      // pass 2: buckets in global scratch
-#define AGX_MAXV_HUGE 255u    // pass 3, queued only for a unit that has met a position beyond 64 variants: as many as node_cnt (one byte) can count
+#define AGX_MAXV_HUGE 1024u   // pass 3, queued only for a unit that has met a position beyond 64 variants (r04: 1024, node_cnt is 16 bits wide; r03: 255, one byte) can count
 #define AGX_MAXE 4u           // out-edges stored inline per node; more go to the overflow list
 #define AGX_EP25 25           // 5*EP (AG:39, 1296)
 
@@ -437,7 +437,7 @@ struct agx_sweep_args {
     agx_u32 n_pos, n_tiles, k; int iv; int coverage;
     // node table
     agx_u32 *node_start;          // [n_pos]
-    agx_u8 *node_cnt;             // [n_pos]
+    agx_u16 *node_cnt;            // [n_pos] (16 bits: the reference's vector<KMer> is unbounded, AG:1375-1390; up to AGX_MAXV_HUGE variants are held, and 63 positions' side ids must fit side_pk's low half)
     agx_u8 *pos_succ;             // [n_pos] bit 0: some arrival at x steps to x+1 (written by the node sweep, read by the edge build)
     agx_u32 *side_pk;             // [n_pos] written with the nodes: surviving variants beyond the first ("side ids") of this position << 16 | side ids of the
                                   // tile's earlier positions; tile_side[tile] = side ids of the whole tile (input of the walk preparation's scan)
@@ -671,7 +671,7 @@ AGX_HD char agx_consensus(agx_u32 a, agx_u32 c, agx_u32 g, agx_u32 t, agx_u32 n)
 AGX_HD agx_u32 agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bucket &b, agx_u32 cnt, agx_u32 base, agx_u32 pflag,
                                    bool edges, agx_u32 emask, const agx_bucket &bn, agx_u32 nbase, agx_u32 ncnt) {
     if (X >= A.n_pos) return 0;
-    A.node_start[X] = base; A.node_cnt[X] = (agx_u8)cnt; A.pos_succ[X] = (agx_u8)(pflag | (edges ? 0x80u : 0u));
+    A.node_start[X] = base; A.node_cnt[X] = (agx_u16)cnt; A.pos_succ[X] = (agx_u8)(pflag | (edges ? 0x80u : 0u));
     agx_u32 alive = 0;
     for (agx_u32 v = 0; v < cnt; v++) {
         const agx_u32 id = base + v;
@@ -700,6 +700,7 @@ AGX_HD agx_u32 agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx
     }
     return alive ? alive - 1 : 0;                   // walk ids: the first surviving variant takes the position's main id, the others go to the side block
 }
+static_assert(63u * (AGX_MAXV_HUGE - 1u) < 65536u && AGX_MAXV_HUGE <= 65535u, "side ids of a tile's first 63 positions must fit 16 bits");
 AGX_HD agx_u32 agx_side_pack(agx_u32 before_in_tile, agx_u32 here) { return before_in_tile | (here << 16); }
 
 // ---- edge sweep (AG:1589-1623) ---------------------------------------------------------------------------------
@@ -909,7 +910,7 @@ enum { AGX_WM_CONT = 1, AGX_WM_CONTIG = 2, AGX_WM_SIDE = 4, AGX_WM_ANY = 8, AGX_
 // can start a walk in the middle of a forced run; the host then fetches that record from the full table that stays on the device.
 struct agx_compact_args {
     // node table, old ids
-    const agx_u32 *node_start; const agx_u8 *node_cnt; const agx_u8 *n_flags; const agx_u8 *n_base; const agx_u32 *n_xpos;
+    const agx_u32 *node_start; const agx_u16 *node_cnt; const agx_u8 *n_flags; const agx_u8 *n_base; const agx_u32 *n_xpos;
     const agx_u32 *nk_off0; const agx_sref *n_sref; const agx_u32 *n_next; const char *ref;
     agx_u32 n_pos;
     const agx_u32 *side_pk;        // [n_pos] agx_side_pack

@@ -268,7 +268,7 @@ struct agx_unit {
     // node table
     agx_u32 pool_cap = 0, spill_lo = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
     DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
-    DBuf<agx_u32> d_node_start, d_slow_list, d_slots; agx_u32 slot_cap = 0; DBuf<agx_u8> d_node_cnt, d_pos_succ;
+    DBuf<agx_u32> d_node_start, d_slow_list, d_slots; agx_u32 slot_cap = 0; DBuf<agx_u16> d_node_cnt; DBuf<agx_u8> d_pos_succ;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch, d_huge_list, d_scratch_huge; bool huge = false;      // huge: pass 3 of the node sweep is queued (a build met a position beyond AGX_MAXV_BIG variants)
     // walk graph (agx_core.h "walk preparation")
@@ -729,7 +729,7 @@ Plan plan_capacities(const agx_unit *u) {
     const size_t ids_cap = n_pos + P.pool_cap;
     P.sp_cap = u->sp_cap ? u->sp_cap : (agx_u32)std::min<size_t>(g_tiny ? 32 : ids_cap / 4 + 4096, 0xFFFFFF00ull);      // special ids: 8 % on the bench unit
     // what the takes of do_upload add up to, plus the alignment of ~90 buffers
-    const size_t per_pos = 4 + 16 + 1 + 4 + 1 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_dhit) + 4;
+    const size_t per_pos = 4 + 16 + 1 + 4 + 2 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_dhit) + 4;
     const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
     const size_t wire = nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 + (u->ref_packed ? n_pos / 4 + u->n_refx * sizeof(agx_refx) : 0) + 4096;
     const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + (size_t)n_tiles * P.slot_cap * 4 + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases + u->n_other * 8 +
@@ -1015,7 +1015,7 @@ void do_build(agx_unit *u) {
                 u->huge = true; u->d_huge_list.alloc(u->arena, (size_t)u->n_tiles + 1); u->d_scratch_huge.alloc(u->arena, (size_t)AGX_HUGE_WAVES * AGX_NF * AGX_MAXV_HUGE * 64);
                 HIP_OK(hipEventRecord(u->ev_uploaded, turn.down)); continue;
             }
-            if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 255 node variants at one position"};
+            if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 1024 node variants at one position"};
             if (w[W_STATUS] & 1u) {                  // the node pool ran out: cut the slices to what the regions asked for
                 std::vector<agx_u32> padded((size_t)u->n_regions * AGX_REGION_PAD), demand(u->n_regions);
                 HIP_OK(hipMemcpyAsync(padded.data(), u->d_pool_cnt.p, padded.size() * 4, hipMemcpyDeviceToHost, turn.down)); HIP_OK(hipStreamSynchronize(turn.down));
@@ -1033,7 +1033,7 @@ void do_build(agx_unit *u) {
         const unsigned long long ids = (unsigned long long)n_pos + w[W_N + 1];
         if (ids >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "walk graph exceeds 2^32 ids"};
         u->n_ids = (agx_u32)ids; u->n_special = w[W_N + 2];
-        u->stats.build_attempts = (uint32_t)attempt + 1; u->stats.n_spilled = w[W_SPILL];
+        u->stats.build_attempts = (uint32_t)attempt + 1; u->stats.n_spilled = w[W_SPILL]; u->stats.dense_lists = (w[W_RANKOVF] | w[W_SLOTOVF]) ? 1u : 0u;
 #ifdef AGX_SWEEP_STATS
         {   const agx_u32 *c = w + W_N + 6;
             fprintf(stderr, "[agx sweep stats] wave-entries %u (lanes with an arrival %u = %.1f per entry); leave the fast path: %u entries / %u lanes; of those not a first store: %u / %u; "
@@ -1123,7 +1123,8 @@ void do_release(agx_unit *u) {
     for (auto *b : {&u->d_cm_start, &u->d_tile_cnt, &u->d_tile_off, &u->d_cursor, &u->d_unsorted, &u->d_tile_recs, &u->d_scan_tmp, &u->d_words, &u->d_pool_cnt, &u->d_region_off, &u->d_node_start,
                     &u->d_slow_list, &u->d_slots, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
-    for (auto *b : {&u->d_node_cnt, &u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
+    u->d_node_cnt.release();
+    for (auto *b : {&u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
     u->d_other.release(); u->d_whits.release(); u->d_wsides.release(); u->d_wruns.release(); u->d_wref.release(); u->d_refx.release();
     u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_cntruns.release(); u->d_cntchunks.release(); u->d_segchunks.release(); u->d_jump.release(); u->d_segindex.release(); u->d_sp_hop.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
     u->d_ovf.release(); u->d_a_ovf.release(); u->d_huge_list.release(); u->d_scratch_huge.release(); u->huge = false; u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
@@ -1441,9 +1442,9 @@ int agx_unit_graph(agx_unit *u, agx_graph *g) {
         HIP_OK(wait_event(u->ev_built));
         // the pool has unused slots (one slice per region): the arrays come down whole, nodes are reached through node_start / node_cnt
         const agx_u32 n_pos = (agx_u32)u->V.n_pos, nn = u->n_nodes, cap = u->pool_cap;
-        std::vector<agx_u32> node_start(n_pos), cid(cap), coff(cap), cid0(cap), coff0(cap), off0(cap), next((size_t)cap * AGX_MAXE); std::vector<agx_u8> node_cnt(n_pos);
+        std::vector<agx_u32> node_start(n_pos), cid(cap), coff(cap), cid0(cap), coff0(cap), off0(cap), next((size_t)cap * AGX_MAXE); std::vector<agx_u16> node_cnt(n_pos);
         std::vector<agx_sref> sref(cap); std::vector<int> counts; std::vector<agx_edge_ovf> ovf(u->n_ovf);
-        HIP_OK(hipMemcpy(node_start.data(), u->d_node_start.p, (size_t)n_pos * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(node_cnt.data(), u->d_node_cnt.p, n_pos, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(node_start.data(), u->d_node_start.p, (size_t)n_pos * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(node_cnt.data(), u->d_node_cnt.p, (size_t)n_pos * 2, hipMemcpyDeviceToHost));
         if (cap) {
             HIP_OK(hipMemcpy(cid.data(), u->d_cid.p, (size_t)cap * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(coff.data(), u->d_coff.p, (size_t)cap * 4, hipMemcpyDeviceToHost));
             HIP_OK(hipMemcpy(cid0.data(), u->d_cid0.p, (size_t)cap * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(coff0.data(), u->d_coff0.p, (size_t)cap * 4, hipMemcpyDeviceToHost));

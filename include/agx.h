@@ -37,7 +37,7 @@ extern "C" {
 #define AGX_E_ALIGNMENT (-4)   /* "BOWTIE ALIGNMENT ERROR" (mates on the same strand)    AG:1669 */
 #define AGX_E_DEVICE (-5)      /* HIP runtime error */
 #define AGX_E_ARG (-6)
-#define AGX_E_OVERFLOW (-7)    /* more than 255 node variants at one position (the reference's vector<KMer> is unbounded, AG:1375-1390) */
+#define AGX_E_OVERFLOW (-7)    /* more than 1024 node variants at one position (the reference's vector<KMer> is unbounded, AG:1375-1390) */
 #define AGX_E_NOGPU (-8)
 
 typedef struct agx_unit agx_unit;
@@ -111,6 +111,8 @@ typedef struct {
     uint64_t n_spilled;                                          /* node ids taken from the pool's spill area (regions whose slice was full) */
     uint32_t build_attempts, from_cache;                         /* build_attempts: 1 unless a capacity had to grow and the build was repeated; from_cache: the unit was
                                                                     loaded from its cache file (agx_unit_cache_build), not from the text files */
+    uint32_t dense_lists, pad_;                                  /* 1: some tile's hit list outgrew its slots (or a hit spans more than four tiles) and the whole unit's lists went through the
+                                                                    dense second pass (agx_k_bin_fill) instead of the slots hit_prep fills: pile-ups, deep repeats */
 } agx_stats;
 
 /* Node/edge tables in canonical numbering (position-major, variant order), for parity tests. malloc'd; free with agx_graph_free. */

@@ -22,7 +22,7 @@ using namespace agx;
 namespace {
 
 struct SimGraph {
-    std::vector<agx_u32> node_start; std::vector<agx_u8> node_cnt, pos_succ;
+    std::vector<agx_u32> node_start; std::vector<agx_u16> node_cnt; std::vector<agx_u8> pos_succ;
     std::vector<agx_u32> cid, coff, cid0, coff0, off0, xpos, next;
     std::vector<agx_u8> base, flags; std::vector<agx_sref> sref; std::vector<int> counts;
     std::vector<agx_edge_ovf> ovf;
@@ -141,11 +141,11 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
         agx_u32 *store = lds.data(); agx_u32 maxv = maxv_first;
         if (!ok) {                                     // the fallback the engine runs for overflowed tiles
             n_big_tiles++;
-            big.assign((size_t)AGX_NF * AGX_MAXV_HUGE * AGX_TILE, 0); store = big.data(); maxv = AGX_MAXV_HUGE;      // (the engine: 4, then 64, then 255 variants)
+            big.assign((size_t)AGX_NF * AGX_MAXV_HUGE * AGX_TILE, 0); store = big.data(); maxv = AGX_MAXV_HUGE;      // (the engine: 4, then 64, then 1024 variants)
             agx_bucket bb{nullptr, AGX_TILE, maxv};
             for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
                 bb.base = store + lane;
-                if (!agx_node_sweep_lane<false>(A, t, t * AGX_TILE + lane, bb, cnt[lane], pflag[lane], get, [](agx_u32, agx_u32) {})) throw Error{E_OVERFLOW, "more than 255 node variants at one position"};
+                if (!agx_node_sweep_lane<false>(A, t, t * AGX_TILE + lane, bb, cnt[lane], pflag[lane], get, [](agx_u32, agx_u32) {})) throw Error{E_OVERFLOW, "more than 1024 node variants at one position"};
             }
         }
         agx_u32 total = 0; for (agx_u32 lane = 0; lane < AGX_TILE; lane++) total += cnt[lane];

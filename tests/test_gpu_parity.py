@@ -341,17 +341,17 @@ def test_unit_cache_file_replaces_the_text(agx, built, tmp_path, monkeypatch):
     assert load_and_run(1)["from_cache"] == 0
 
 
-@pytest.mark.parametrize("n_pairs,ok", [(100, True), (180, True), (300, False)])
+@pytest.mark.parametrize("n_pairs,ok", [(100, True), (180, True), (300, True), (1100, False)])
 def test_positions_beyond_64_variants_take_the_last_pass(agx, built, tmp_path, n_pairs, ok):
     """ADVICE r01 / VERDICT r01 item 8: a position with more than 64 node variants used to abort the unit (AGX_E_OVERFLOW) where the reference,
-    whose vector<KMer> is unbounded (AG:1375-1390), carries on.  Now a build that meets one queues a fourth sweep pass with 255 variants per
-    position (what the one-byte node_cnt can count) and repeats; only beyond 255 the unit is refused — loudly, never with a different graph."""
+    whose vector<KMer> is unbounded (AG:1375-1390), carries on.  Now a build that meets one queues a fourth sweep pass with 1024 variants per
+    position (r04: node_cnt is 16 bits wide; the 300-variant pile-up that r03 refused must equal the oracle) and repeats; only beyond 1024 the unit is refused — loudly, never with a different graph."""
     from conftest import write_pileup_unit
-    tmp = write_pileup_unit(str(tmp_path / "run"), n_pairs, spacing=300 if n_pairs <= 180 else 190)
+    tmp = write_pileup_unit(str(tmp_path / "run"), n_pairs, spacing=300 if n_pairs <= 180 else 190 if n_pairs <= 300 else 130, genome_len=60000 if n_pairs <= 300 else 150000)
     if not ok:
         with pytest.raises(agx.AgxError) as e:
             run_engine(agx, tmp, 0, 5, 50, 1)
-        assert e.value.code == agx.AGX_E_OVERFLOW and "255" in e.value.msg
+        assert e.value.code == agx.AGX_E_OVERFLOW and "1024" in e.value.msg
         return
     o = H.run_oracle(tmp, 0, 5, 50, 1, graph=True)
     g = run_engine(agx, tmp, 0, 5, 50, 1, graph=True)

@@ -207,17 +207,17 @@ def test_loader_rejects_what_the_reference_would_misread(built, tmp_path):
         sim.run(tmp, 0, 5, 50, 2)
 
 
-@pytest.mark.parametrize("n_pairs,ok", [(100, True), (180, True), (300, False)])
+@pytest.mark.parametrize("n_pairs,ok", [(100, True), (180, True), (300, True), (1100, False)])
 def test_positions_with_more_variants_than_the_sweeps_first_buckets(built, tmp_path, n_pairs, ok):
-    """The reference keeps an unbounded vector<KMer> per position (AG:1375-1390).  The engine sweeps a tile with 2, then 4, then 64, then 255
-    variants per position (node_cnt is one byte); beyond 255 it refuses with AGX_E_OVERFLOW instead of diverging.  Here: the serial executor."""
+    """The reference keeps an unbounded vector<KMer> per position (AG:1375-1390).  The engine sweeps a tile with 2, then 4, then 64, then 1024
+    variants per position (node_cnt is 16 bits wide since r04; 300 used to be refused); beyond 1024 it refuses with AGX_E_OVERFLOW instead of diverging.  Here: the serial executor."""
     from conftest import write_pileup_unit
-    tmp = write_pileup_unit(str(tmp_path / "run"), n_pairs, spacing=300 if n_pairs <= 180 else 190)
+    tmp = write_pileup_unit(str(tmp_path / "run"), n_pairs, spacing=300 if n_pairs <= 180 else 190 if n_pairs <= 300 else 130, genome_len=60000 if n_pairs <= 300 else 150000)
     o = H.run_oracle(tmp, 0, 5, 50, 1, graph=True)
     import numpy as np
     assert int(np.diff(o["graph"]["node_start"]).max()) == n_pairs
     if not ok:
-        with pytest.raises(sim.SimError, match="more than 255 node variants"):
+        with pytest.raises(sim.SimError, match="more than 1024 node variants"):
             sim.run(tmp, 0, k=5, insert_variation=50, coverage=1)
         return
     s = sim.run(tmp, 0, k=5, insert_variation=50, coverage=1, graph=True)
