@@ -59,7 +59,7 @@ def _worker(rank, world, port, run, meta, q):
         assert sorted(ran[-len(shard.plan(meta["unit_len"], rank, world)):]) == sorted(shard.plan(meta["unit_len"], rank, world))
         assert (merged is not None) == (rank == 0)
     if rank == 0:
-        q.put(merged)
+        q.put({u: bytes(v) for u, v in merged.items()})      # (run_job hands out views: of the C buffers for its own units, of its landing buffers — kept and overwritten by the next job — for the others')
     dist.barrier()
     dist.destroy_process_group()
 
