@@ -37,6 +37,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import datetime
 import sys
 import time
 
@@ -183,9 +184,9 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if share:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=90))
+        else:      # (the whole-human inputs take rank 0 five to seven minutes to generate while the others wait at a barrier)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=90))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     if not os.path.exists(A.LIB_PATH):
         if rank == 0:
@@ -303,6 +304,9 @@ def main():
     per_set = sum(un_bytes.values()) if un_bytes else 0
     fit = max(1, int(args.host_gb * 1e9 // max(1, per_set)))
     reupload = args.reupload or fit < args.steps + args.warmup      # (a one-shot unit is used once: every step needs a set of its own in host memory)
+    if reupload and not args.reupload and args.pool == "host-cold":
+        args.pool = "warm"      # the sets do not fit the host: the same units are uploaded again, and their downloads land in the pinned buffers the step before left in the library's
+                                # cache — what a long run's later units find.  (Emptying that cache first would bill every step for pinning 5 bytes per position again.)
     n_sets = 1 if reupload else args.steps + args.warmup
     unit_sets = []
 
