@@ -908,7 +908,7 @@ void do_build(agx_unit *u) {
         // ---- tile lists ----
         if (g_scan1) agx_launch_exclusive_scan1(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_desc.p, st);
         else agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
-        agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, u->d_words.p + W_RANKOVF, u->d_words.p + W_SLOTOVF};
+        agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, u->d_words.p + W_RANKOVF, u->d_words.p + W_SLOTOVF, u->slot_cap};
         agx_launch_bin_fill(&BA, st);                   // (returns at once unless a list outgrew its tile's slots)
         agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, u->d_runs.p, u->prm.k, u->d_slots.p, u->slot_cap, u->d_words.p + W_RANKOVF, st);
         AGX_CHECKPOINT("tile_sort");

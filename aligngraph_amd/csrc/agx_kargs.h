@@ -10,12 +10,12 @@ struct agx_prep_args {
     agx_u32 *err;             // bit 0: same-strand mates; bit 1: alignment beyond the unit sequence
     agx_u32 *rank_overflow;   // set when some hit spans more than four tiles (the histogram's atomicAdd gives a hit its place in the lists of its first four)
     // The tile lists without a second pass over the hits: every tile has slot_cap slots of its own and the rank IS the slot.  A list that outgrows its slots
-    // (slot_overflow) — or a hit beyond four tiles — sends the build through bin_fill's dense lists instead, as before r03.
+    // (slot_overflow) goes through bin_fill's dense lists — that list alone since r04; a hit beyond four tiles sends every list there, as before r03.
     agx_u32 *slots; agx_u32 slot_cap; agx_u32 *slot_overflow;
 };
 
 struct agx_bin_args { const agx_dhit *dhit; agx_u32 n_hits; const agx_u32 *tile_off; agx_u32 *cursor; agx_u32 *unsorted; agx_u32 cap;   // cap: entries the lists can hold
-                      const agx_u32 *rank_overflow; const agx_u32 *slot_overflow; };
+                      const agx_u32 *rank_overflow; const agx_u32 *slot_overflow; agx_u32 slot_cap; };
 
 struct agx_node_kargs {
     agx_sweep_args S;

@@ -247,8 +247,13 @@ __global__ void __launch_bounds__(256) agx_k_bin_fill(agx_bin_args A) {
     if (h >= A.n_hits) return;
     const agx_dhit d = A.dhit[h];
     if (d.flags & AGX_HF_SKIP) return;
-    // every hit takes its places in the dense lists from a second counter per tile (the order inside a list is tile_sort's business)
-    for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++) { const agx_u32 at = A.tile_off[t] + atomicAdd(&A.cursor[t], 1u); if (at < A.cap) A.unsorted[at] = h; }
+    // every hit takes its places in the dense lists from a second counter per tile (the order inside a list is tile_sort's business) — r04: only in the lists that outgrew
+    // their tile's slots (one pile-up used to send every tile of the unit through here), unless a hit beyond four tiles has left some tile's slots incomplete
+    const bool all = __builtin_amdgcn_readfirstlane((int)*A.rank_overflow) != 0;
+    for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++) {
+        if (!all && A.tile_off[t + 1] - A.tile_off[t] <= A.slot_cap) continue;
+        const agx_u32 at = A.tile_off[t] + atomicAdd(&A.cursor[t], 1u); if (at < A.cap) A.unsorted[at] = h;
+    }
 }
 
 // one wavefront per tile; a hit's place in the file is unique, so an element's rank is the number of smaller keys
@@ -271,8 +276,8 @@ __global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, 
     if (tile >= n_tiles) return;
     const agx_u32 lo = tile_off[tile], n = tile_off[tile + 1] - lo;
     if (tile_off[tile + 1] > cap) return;                // lists did not fit: the host grows them and re-runs
-    // the tile's own slots (hit_prep), or bin_fill's dense lists if some list outgrew its slots
-    const bool own = (__builtin_amdgcn_readfirstlane((int)dense[0]) | __builtin_amdgcn_readfirstlane((int)dense[1])) == 0;
+    // the tile's own slots (hit_prep), or bin_fill's dense list if THIS list outgrew them (or some hit spans more than four tiles: then every list is dense)
+    const bool own = __builtin_amdgcn_readfirstlane((int)dense[0]) == 0 && n <= slot_cap;
     const agx_u32 *src = own ? slots + (size_t)tile * slot_cap : unsorted + lo;
     if (n <= AGX_SORT_LDS) {
         for (agx_u32 i = lane; i < n; i += 64) sh[wave][i] = src[i];

@@ -323,6 +323,11 @@ int main(int argc, char **argv) {
     }
     int NU = (int)unit_len.size();
     std::vector<Unit> units(NU);
+    if (P.pairs_bin) {      // (the staged-pairs mode has a stream of its own anyway: every unit's sequences from a generator of their own, all units side by side — 3.1 Gb take a minute on one thread)
+        std::atomic<int> next_u(0); std::vector<std::thread> th;
+        for (int t = 0; t < std::min(P.threads, NU); t++) th.emplace_back([&] { for (int u; (u = next_u.fetch_add(1)) < NU;) { Rng Ru(P.seed * 0x2545F4914F6CDD1Dull + (uint64_t)(u + 1) * 0x9E3779B97F4A7C15ull); make_unit(units[u], unit_len[u], P, Ru); } });
+        for (auto &t : th) t.join();
+    } else
     for (int u = 0; u < NU; u++) make_unit(units[u], unit_len[u], P, R);
 
     // ---- genome files ----
