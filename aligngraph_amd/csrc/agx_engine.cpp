@@ -230,6 +230,9 @@ inline int walkers_now(size_t n_pos) {
     return want <= cpus ? want : cpus < 4 ? 4 : cpus;
 }
 
+// units of this process that are uploaded and not yet walked: the walk of the LAST one runs alone (the tail of a job) and may take every walker there is
+static std::atomic<int> g_walks_pending{0};
+
 struct agx_unit {
     agx_params prm{};
     std::string err;
@@ -239,6 +242,7 @@ struct agx_unit {
     agx_u32 n_seg0 = 0, stride = 0, n_slots = 0, n_rows = 0; unsigned long long pairs_in_file = 0, sam_pairs = 0;
     bool have_ref = false, have_threads = false, staged = false, uploaded = false, built = false, downloaded = false;
     bool consumed = false;             // AGX_FLAG_ONE_SHOT: the download has overwritten the staged inputs
+    bool pending_walk = false;         // counted in g_walks_pending: uploaded, not yet walked (or released)
     bool expanded = false;             // the conti-mer tables and vote codes have been made from what was uploaded (opens the unit's first build)
     hipEvent_t ev_built = nullptr;     // this unit's build commands are done (waited for on the host; ev_dl: its download)
     UnitOutput out; OutBuf out_initial; bool out_ready = false;      // output buffers of the next finish, reserved and touched by a helper thread while the unit is uploaded and built (prepare_outputs)
@@ -286,6 +290,7 @@ struct agx_unit {
     bool up_timed = false;
     agx_stats stats{};
     ~agx_unit() {
+        if (pending_walk) g_walks_pending.fetch_sub(1);
         ev.destroy();
         for (hipEvent_t e : {ev_front, ev_passA, ev_passJ, ev_up0, ev_uploaded, ev_dl, ev_built, ev_hits}) if (e) (void)hipEventDestroy(e);
         if (dl_signal.handle) (void)hsa_signal_destroy(dl_signal);
@@ -823,6 +828,7 @@ void do_upload(agx_unit *u) {
     start_helper(u);                                     // then the output buffers
 
     u->uploaded = true; u->built = false; u->downloaded = false;
+    if (!u->pending_walk) { u->pending_walk = true; g_walks_pending.fetch_add(1); }
     u->stats.ms_upload = now_ms() - t0;
     u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + u->n_cntruns * sizeof(agx_cntrun) + (u->n_cntchunks + u->n_segchunks) * sizeof(agx_chunk) + (u->ref_packed ? (n_pos + 3) / 4 + u->n_refx * sizeof(agx_refx) : n_pos) + nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 +
                             (size_t)u->n_chain_end * 4 + u->n_codes + u->n_other * 8 + ((size_t)u->n_regions + 1) * 4;
@@ -1117,6 +1123,7 @@ void do_download(agx_unit *u) {
 // them without a driver call).  The inputs stay staged: the unit can be uploaded again as if it were new.
 void do_release(agx_unit *u) {
     const double tr0 = now_ms();
+    if (u->pending_walk) { u->pending_walk = false; g_walks_pending.fetch_sub(1); }
     struct Tr { agx_unit *u; double t; ~Tr() { trace(u, "release", t, u->V.n_pos); } } tr{u, tr0};
     join_dl_helper(u);                                 // (it fills the download buffers released below)
     if (u->uploaded) { (void)hipSetDevice(u->prm.device); (void)hipEventSynchronize(u->ev_uploaded); (void)hipEventSynchronize(u->ev_built); (void)hipEventSynchronize(u->ev_dl); }      // (its commands are done before its memory goes)
@@ -1401,6 +1408,8 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
         if (!u->out_ready) throw Error{E_ARG, "out of host memory"};
         u->downloaded = false;            // the walk marks the downloaded meta bytes: another finish downloads again
         u->out_ready = false;             // (an error below leaves the buffers to the next prepare_outputs)
+        agx::walkers_cap = g_walks_pending.load() <= 1 ? (int)GraphView::MAX_WALKERS : 8;      // (nobody else on the way: this walk is the job's tail)
+        struct Walked { agx_unit *u; ~Walked() { if (u->pending_walk) { u->pending_walk = false; g_walks_pending.fetch_sub(1); } } } walked{u};
         struct Helpers : Assistant {           // helper 0: the unit's own thread (formats the written records while the walk goes on, or walks a stretch); 1..: pool threads for further walkers
             agx_unit *u; int pool[GraphView::MAX_WALKERS] = {}; int n_pool = 0;
             Helpers(agx_unit *x, int extra) : u(x) { for (int i = 0; i < extra && i < GraphView::MAX_WALKERS - 2; i++) { const int t = walker_pool().take(); if (t < 0) break; pool[n_pool++] = t; } }

@@ -170,11 +170,14 @@ template <class T> struct SBuf {
 
 unsigned usable_cpus();                   // CPUs this process can keep busy: its affinity mask capped by the CPU quota of its control group
 unsigned loader_threads(size_t bytes);      // AGX_LOAD_THREADS, else by the size of the input and the cores this process may use
-// walkers of a unit of n positions at most (agx_walk.cpp: walk_split): AGX_WALK_SPLIT_WALKERS, else one per 1.2 M positions, two to sixteen.  The engine hands
+// walkers of a unit of n positions at most (agx_walk.cpp: walk_split): AGX_WALK_SPLIT_WALKERS (two to sixteen), else one per 1.2 M positions, two to eight.  The engine hands
 // out one per CPU this process may use at most (agx_engine.cpp: walkers_now).
+inline thread_local int walkers_cap = 8;      // set by the engine for the walk that begins on this thread: sixteen when no other unit is on its way (the tail of a job), else eight
 inline int walkers_for(size_t n) {
     const char *e = getenv("AGX_WALK_SPLIT_WALKERS");
-    const int k = e ? atoi(e) : (int)(n / 1200000u);
+    // (r04: eight by default, sixteen on request.  Measured on the cfg3 job: 35.43 ms and 386 CPU-ms per job with up to sixteen, 35.58 ms and 299 CPU-ms with eight, 38.98 ms with
+    // four — every walker beyond what the walk's length needs is a window copy, a warm-up and a thread that spins up for nothing)
+    const int k = e ? atoi(e) : (int)std::min<size_t>(n / 1200000u, (size_t)walkers_cap);
     return k < 2 ? 2 : k > GraphView::MAX_WALKERS ? (int)GraphView::MAX_WALKERS : k;
 }
 

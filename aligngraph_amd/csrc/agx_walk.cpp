@@ -614,7 +614,7 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     const agx_u32 warm = getenv("AGX_WALK_SPLIT_WARMUP") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_WARMUP"), nullptr, 10) : 400000u;
     const agx_u32 n_ref = V.n_ref < G.n_pos ? V.n_ref : G.n_pos;
     if (!assistant || n_ref < min_ref || n_ref < 16 || getenv("AGX_WALK_NO_SPLIT")) return false;
-    // walkers: one per 1.2 M positions, two to sixteen, as many as there are helper threads.  Every further walker works on visited bytes of its own: a
+    // walkers: one per 1.2 M positions, two to eight (sixteen on request: walkers_for), as many as there are helper threads.  Every further walker works on visited bytes of its own: a
     // WINDOW of the meta bytes that it copies itself, before anybody walks, from the first walker's still pristine array — two warm-ups (one stretch at
     // most) back from its stretch, the stretch, one stretch ahead — and it may only look at nodes inside the window (walks are local: a record ends
     // at the next branch, a conti-mer chain lands a contig's length further; one that does lead further makes the walker give up, as a look in front of
