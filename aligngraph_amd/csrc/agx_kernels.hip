@@ -510,7 +510,9 @@ __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
 // kernels' time was the depth of that chain times 57 rounds of resident threads over a 30 M-position unit (r02: 0.21 + 0.64 ms).  r03: a thread takes
 // AGX_WP_POS positions (a block's threads side by side in each of them: the accesses stay coalesced) and issues the loads of all of them level by level; positions
 // with one variant — nearly all — are finished from those registers, the others go through the general lane function.
+#ifndef AGX_WP_POS
 #define AGX_WP_POS 4u
+#endif
 // (the first threads also mark the main ids of the chain-end positions: a_mark is complete before anything reads it)
 __global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A, const agx_u32 *chain_end, agx_u32 n_chain_end) {
     AGX_RETURN_IF_ABORTED(A.abort);

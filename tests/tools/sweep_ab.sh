@@ -20,5 +20,6 @@ with A.Unit(k=5, insert_variation=50, coverage=5, device=0, flags=A.AGX_FLAG_TIM
             print("build error (experiment):", e); break
         st = u.stats(); t.append(st["ms_node_sweep"])
     print(os.path.basename(os.environ["AGX_LIB_PATH"]), "node sweep ms:", ["%.3f" % x for x in t], "entries", st["n_tile_entries"])
+    print("   sections of the last build (ms):", {k: round(st[k], 3) for k in ("ms_prep", "ms_bin", "ms_node_sweep", "ms_node_big", "ms_edge_fast", "ms_edge_slow", "ms_compact", "ms_build_span")})
 PY
 done
