@@ -20,9 +20,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_ranks_deliver_what_one_rank_delivers(tmp_path):
+@pytest.mark.parametrize("staged", [False, True], ids=["text", "staged"])
+def test_two_ranks_deliver_what_one_rank_delivers(tmp_path, staged, monkeypatch):
+    """staged: the read alignments handed over as tmp/_agx_pairs.<u>.bin (AGX_BENCH_STAGED=1) — the way `bench.py --gpus N` runs the whole-human configuration: rank 0
+    generates, every rank loads its own units from the staged files and writes their caches."""
     import aligngraph_amd as A
     assert A.device_count() > 0
+    if staged:
+        monkeypatch.setenv("AGX_BENCH_STAGED", "1")
     common = ["--steps", "2", "--warmup", "1", "--config", "custom", "--chroms", "400000,250000,300000,150000,200000", "--pairs", "180000",
               "--cpu-sample-pairs", "0", "--workdir", str(tmp_path / "work")]
     env = dict(os.environ, AGX_BENCH_SHARE_GPU="1", AGX_BENCH_DIGEST=str(tmp_path / "two.json"))
