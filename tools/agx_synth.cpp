@@ -304,6 +304,41 @@ Mate cut_read(const Unit &U, int64_t s, int L, const Params &P, Rng &R) {
     return M;
 }
 
+// The same read model for the staged-pairs mode (a stream of its own): instead of two uniform draws per base for sequencing errors and N calls — 600 per pair, half of what a
+// pair costs to generate, and the whole-human configuration has 400 M of them — the distance to the next base that is hit is drawn (geometric), once per event.
+struct NextHit {
+    double log1m; int64_t at;
+    NextHit(double p, Rng &R) : log1m(p > 0 ? std::log1p(-p) : 0), at(0) { at = skip(R) ; }
+    int64_t skip(Rng &R) const { if (log1m == 0) return INT64_MAX / 2; double u = R.uni(); if (u < 1e-300) u = 1e-300; return (int64_t)std::floor(std::log(u) / log1m); }      // bases that are NOT hit in front of the next one
+    bool hit(int64_t i, Rng &R) { if (i < at) return false; at = i + 1 + skip(R); return true; }      // called with ascending i
+};
+Mate cut_read_fast(const Unit &U, int64_t s, int L, const Params &P, Rng &R) {
+    Mate M;
+    int64_t T = (int64_t)U.tgt.size();
+    bool indel = R.coin(P.read_indel);
+    int at = indel ? (int)R.range(10, L - 10) : -1;
+    bool ins = indel && R.coin(0.5);
+    int len = indel ? (int)R.range(1, ins ? 2 : 3) : 0;
+    NextHit err(P.read_err, R), nn(P.read_n, R);
+    int64_t t = s;
+    M.seq_fwd.reserve((size_t)L); M.r.reserve((size_t)L);
+    while ((int)M.seq_fwd.size() < L) {
+        const int i = (int)M.seq_fwd.size();
+        if (i == at && indel) {
+            indel = false;
+            if (ins) { for (int j = 0; j < len && (int)M.seq_fwd.size() < L; j++) { M.seq_fwd.push_back(ACGT[R.below(4)]); M.r.push_back(-1); } continue; }
+            t += len;
+        }
+        if (t >= T) { M.seq_fwd.push_back(ACGT[R.below(4)]); M.r.push_back(-1); continue; }
+        char c = U.tgt[t];
+        if (err.hit(i, R)) { char d; do d = ACGT[R.below(4)]; while (d == c); c = d; }
+        if (nn.hit(i, R)) c = 'N';
+        M.seq_fwd.push_back(c); M.r.push_back(U.t2r[t]);
+        t++;
+    }
+    return M;
+}
+
 void mkdirs(const std::string &p) { mkdir(p.c_str(), 0777); }
 
 }  // namespace
@@ -451,7 +486,7 @@ int main(int argc, char **argv) {
             if (f < L + 1) f = L + 1;
             if (f > T) f = T;
             const int64_t s0 = R.range(0, T - f);
-            ::Mate left = cut_read(U, s0, L, P, R), right = cut_read(U, s0 + f - L, L, P, R);
+            ::Mate left = cut_read_fast(U, s0, L, P, R), right = cut_read_fast(U, s0 + f - L, L, P, R);
             o.m1_left = R.coin(P.mate1_left);
             const std::string right_file = revcomp(right.seq_fwd);
             o.m1 = o.m1_left ? left.seq_fwd : right_file; o.m2 = o.m1_left ? right_file : left.seq_fwd; o.left_fwd = left.seq_fwd; o.right_fwd = right.seq_fwd;
