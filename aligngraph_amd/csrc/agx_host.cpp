@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
+#include <fstream>
 #include <map>
 #include <memory>
 #include <system_error>
@@ -222,18 +223,63 @@ void thread_contigs_from_files(const std::string &contigs_fa, const std::string 
 // loadReadAlignment's parsing half: batches of `batch` pairs (AG:37, 361-404), SAM line pairs (AG:1233-1277)
 // One pass over tmp/_reads.fa: where every line pair (header, sequence) starts, up to the first empty line (which ends the file for
 // the reference's getline loops), and how many header lines there are (what decides the batch boundaries, AG:361-404).
-// CPUs this process can keep busy: its affinity mask, capped by the CPU quota of its control group (cgroup v2 cpu.max "quota period": a container
-// on a 256-thread host may be allowed 16 CPUs' worth of time per period — threads beyond that only take turns being throttled)
+// CPUs this process can keep busy: its affinity mask, capped by the CPU quota of its control group (a container on a 256-thread host may be
+// allowed 16 CPUs' worth of time per period — threads beyond that only take turns being throttled).
+// cgroup_cpu_quota: the tightest quota between the process's own group and the root of the hierarchy, in CPUs rounded up; 0 when there is
+// none.  `proc_cgroup` is /proc/self/cgroup ("0::/a/b" for the unified hierarchy; "N:cpu,cpuacct:/a/b" for version 1), `sys_root` is
+// /sys/fs/cgroup.  Version 2 keeps "quota period" (or "max period") in cpu.max; version 1 keeps cpu.cfs_quota_us (-1 = none) and
+// cpu.cfs_period_us under the cpu controller's own mount.  A group path the mount does not show (a container sees its own group as the
+// root) falls back to the files at the mount's root.
+static long long read_ll(const std::string &path, bool *is_max = nullptr, long long *second = nullptr) {
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return -2;
+    char q[64] = {0}; long long b = 0;
+    const int got = fscanf(f, "%63s %lld", q, &b);
+    fclose(f);
+    if (got < 1) return -2;
+    if (is_max) *is_max = strcmp(q, "max") == 0;
+    if (second) *second = got == 2 ? b : 0;
+    return atoll(q);
+}
+unsigned cgroup_cpu_quota(const char *proc_cgroup, const char *sys_root) {
+    std::ifstream in(proc_cgroup);
+    std::string line; long long best = 0;
+    auto take = [&](long long quota, long long period) { if (quota > 0 && period > 0) { const long long c = std::max<long long>(1, (quota + period - 1) / period); if (!best || c < best) best = c; } };
+    auto walk_up = [&](const std::string &mount, std::string group, auto &&read_one) {           // the group itself, then every ancestor up to the mount
+        bool any = false;
+        for (;;) {
+            any |= read_one(mount + group);
+            if (group.empty() || group == "/") break;
+            const size_t cut = group.rfind('/');
+            group = cut == std::string::npos || cut == 0 ? std::string() : group.substr(0, cut);
+        }
+        return any;
+    };
+    while (std::getline(in, line)) {
+        const size_t a = line.find(':'), b = a == std::string::npos ? a : line.find(':', a + 1);
+        if (b == std::string::npos) continue;
+        const std::string ctl = "," + line.substr(a + 1, b - a - 1) + ",";
+        std::string group = line.substr(b + 1);
+        if (group.find("..") != std::string::npos) group = "/";
+        const std::string root = sys_root;
+        if (ctl == ",,") {                                                                          // unified hierarchy: at the mount itself, or under "unified" beside version 1
+            auto v2 = [&](const std::string &dir) { bool mx = false; long long period = 0; const long long q = read_ll(dir + "/cpu.max", &mx, &period); if (q == -2) return false; if (!mx) take(q, period); return true; };
+            if (!walk_up(root, group, v2)) v2(root);
+        } else if (ctl.find(",cpu,") != std::string::npos) {
+            auto v1 = [&](const std::string &dir) { const long long q = read_ll(dir + "/cpu.cfs_quota_us"); if (q == -2) return false; take(q, read_ll(dir + "/cpu.cfs_period_us")); return true; };
+            bool any = false;
+            for (const char *mnt : {"/cpu", "/cpu,cpuacct"}) any |= walk_up(root + mnt, group, v1);
+            if (!any) for (const char *mnt : {"/cpu", "/cpu,cpuacct"}) v1(root + mnt);
+        }
+    }
+    return (unsigned)std::min<long long>(best, 1 << 20);
+}
 unsigned usable_cpus() {
     static const unsigned cached = [] {
         unsigned n = std::max(1u, std::thread::hardware_concurrency());
         cpu_set_t set; CPU_ZERO(&set);
         if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = (unsigned)c; }
-        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-            char q[64]; long long period = 0;
-            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { const long long quota = atoll(q); if (quota > 0) n = (unsigned)std::max<long long>(1, std::min<long long>(n, (quota + period - 1) / period)); }
-            fclose(f);
-        }
+        if (const unsigned q = cgroup_cpu_quota("/proc/self/cgroup", "/sys/fs/cgroup")) n = std::min(n, q);
         return n;
     }();
     return cached;

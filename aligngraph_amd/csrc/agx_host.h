@@ -168,6 +168,7 @@ template <class T> struct SBuf {
     T *begin() { return p; } T *end() { return p + n; } const T *begin() const { return p; } const T *end() const { return p + n; } T *data() { return p; } const T *data() const { return p; }
 };
 
+unsigned cgroup_cpu_quota(const char *proc_cgroup, const char *sys_root);   // tightest CPU quota over the process's control groups (v1 and v2, nested), 0 = none
 unsigned usable_cpus();                   // CPUs this process can keep busy: its affinity mask capped by the CPU quota of its control group
 unsigned loader_threads(size_t bytes);      // AGX_LOAD_THREADS, else by the size of the input and the cores this process may use
 // walkers of a unit of n positions at most (agx_walk.cpp: walk_split): AGX_WALK_SPLIT_WALKERS (two to sixteen), else one per 1.2 M positions, two to eight.  The engine hands

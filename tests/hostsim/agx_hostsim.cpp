@@ -462,3 +462,7 @@ extern "C" int agx_hostsim_compare_staged(const char *tmp_dir, int unit, int k, 
     } catch (const Error &e) { say("unexpected: " + e.msg); return -99; }
     catch (const std::exception &e) { say(std::string("unexpected: ") + e.what()); return -99; }
 }
+
+// ---- the CPU quota reader (tests/test_host_misc.py): a made-up /proc/self/cgroup and /sys/fs/cgroup tree -------------------------------------
+extern "C" unsigned agx_hostsim_cgroup_quota(const char *proc_cgroup, const char *sys_root) { return agx::cgroup_cpu_quota(proc_cgroup, sys_root); }
+extern "C" unsigned agx_hostsim_usable_cpus() { return agx::usable_cpus(); }

@@ -100,3 +100,25 @@ def compare_staged(tmp_dir, unit, k=5, batch=1000000, threads=4):
     if rc != 0:
         raise SimError(rc, msg.value.decode())
     return rc
+
+
+def _lib_now():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(LIB)
+    return _lib
+
+
+def cgroup_quota(proc_cgroup, sys_root):
+    """agx::cgroup_cpu_quota on a made-up control-group tree: CPUs allowed (rounded up), 0 = no quota."""
+    L = _lib_now()
+    L.agx_hostsim_cgroup_quota.restype = ctypes.c_uint
+    L.agx_hostsim_cgroup_quota.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    return int(L.agx_hostsim_cgroup_quota(str(proc_cgroup).encode(), str(sys_root).encode()))
+
+
+def usable_cpus():
+    L = _lib_now()
+    L.agx_hostsim_usable_cpus.restype = ctypes.c_uint
+    return int(L.agx_hostsim_usable_cpus())
