@@ -66,7 +66,7 @@ class Stats(ctypes.Structure):
                [(n, ctypes.c_double) for n in ("ms_edge_fast", "ms_edge_slow")] + [("n_mid_tiles", ctypes.c_uint64), ("ms_build_span", ctypes.c_double)] + \
                [(n, ctypes.c_double) for n in ("ms_stage", "ms_upload_dev")] + \
                [(n, ctypes.c_uint64) for n in ("upload_bytes", "device_bytes", "pinned_bytes_cached", "device_bytes_cached", "n_spilled")] + \
-               [("build_attempts", ctypes.c_uint32), ("from_cache", ctypes.c_uint32), ("dense_lists", ctypes.c_uint32), ("pad_", ctypes.c_uint32)]
+               [("build_attempts", ctypes.c_uint32), ("from_cache", ctypes.c_uint32), ("dense_lists", ctypes.c_uint32), ("rows_by_reference", ctypes.c_uint32)]
 
 
 class Graph(ctypes.Structure):

@@ -118,13 +118,56 @@ void parse_params(const string &file, Options &o) {
     }
 }
 
+// A text file mapped read-only and read the way the reference's `getline` loops read theirs: lines without their '\n'; past the last byte a
+// read gives an empty line and the stream stops being good; a last line without '\n' is delivered and ends the stream too.  The multi-gigabyte
+// inputs (reads, SAM) go through this at memchr speed instead of through ifstream::getline + a vector of strings.
+struct Lines {
+    const char *p = nullptr; size_t n = 0, pos = 0; bool good = false, opened = false; int fd = -1;
+    explicit Lines(const string &path) {
+        fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) return;
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { close(fd); fd = -1; return; }
+        n = (size_t)sb.st_size;
+        if (n) { void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0); if (m == MAP_FAILED) { close(fd); fd = -1; n = 0; return; } p = (const char *)m; madvise(m, n, MADV_SEQUENTIAL); }
+        opened = good = true;
+    }
+    ~Lines() { if (p) munmap((void *)p, n); if (fd >= 0) close(fd); }
+    Lines(const Lines &) = delete; Lines &operator=(const Lines &) = delete;
+    void next(const char *&s, size_t &len) {
+        if (pos >= n) { s = p + n; len = 0; good = false; return; }
+        const char *nl = (const char *)memchr(p + pos, '\n', n - pos);
+        s = p + pos;
+        if (nl) { len = (size_t)(nl - s); pos += len + 1; } else { len = n - pos; pos = n; good = false; }
+    }
+};
+// Text gathered for one output file and written in 16 MB pieces; a failed write is fatal.
+struct Sink {
+    int fd; string buf, name;
+    explicit Sink(const string &path) : fd(open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666)), name(path) { buf.reserve((size_t)17 << 20); }
+    ~Sink() { flush(); if (fd >= 0) close(fd); }
+    Sink(const Sink &) = delete; Sink &operator=(const Sink &) = delete;
+    bool is_open() const { return fd >= 0; }
+    void put(const char *s, size_t len) { buf.append(s, len); if (buf.size() >= ((size_t)16 << 20)) flush(); }
+    void put(char c) { buf.push_back(c); }
+    void flush() {
+        if (fd < 0) { buf.clear(); return; }
+        for (size_t done = 0; done < buf.size();) { const ssize_t w = write(fd, buf.data() + done, buf.size() - done); if (w <= 0) { cout << "CANNOT WRITE FILE! (" << name << ")" << endl; exit(-1); } done += (size_t)w; }
+        buf.clear();
+    }
+};
+
 // maxReadLength, AG:3197-3226
 int max_read_length(const string &path) {
-    bool ok; vector<string> t = read_lines(path, ok);
-    if (!ok) die("CANNOT OPEN FILE!");
-    int mx = 0, len = 0;
-    for (const string &b : t) { if (b[0] == '>') { mx = std::max(mx, len); len = 0; } else len += (int)b.size(); }
-    return std::max(mx, len);
+    Lines in(path);
+    if (!in.opened) die("CANNOT OPEN FILE!");
+    long long mx = 0, len = 0;
+    while (in.good) {
+        const char *s; size_t l; in.next(s, l);
+        if (l == 0 || s[0] == 0) break;
+        if (s[0] == '>') { mx = std::max(mx, len); len = 0; } else len += (long long)l;
+    }
+    return (int)std::max(mx, len);
 }
 
 void put60(std::ostream &o, const string &s) {          // 60 columns, newline after the last base; nothing at all for an empty sequence
@@ -197,25 +240,27 @@ int formalize_genome(const string &path, int p, vector<string> &genomeIds) {
 
 // formalizeInput (reads), AG:3420-3518: pairs renamed 0..N-1, mates cut to the shorter of the two
 int formalize_reads(const string &p1, const string &p2) {
-    std::ifstream in1(p1.c_str()), in2(p2.c_str());
-    if (!in1.is_open() || !in2.is_open()) die("CANNOT OPEN FILE!");
-    std::ofstream out("tmp/_reads.fa"), out1("tmp/_reads_1.fa"), out2("tmp/_reads_2.fa");
-    string b1, b2, r1, r2; unsigned long id = 0;
+    Lines in1(p1), in2(p2);
+    if (!in1.opened || !in2.opened) die("CANNOT OPEN FILE!");
+    Sink out("tmp/_reads.fa"), out1("tmp/_reads_1.fa"), out2("tmp/_reads_2.fa");
+    string r1, r2; unsigned long id = 0; char head[32];
     auto flush = [&]() {
         if (r1.empty() || r2.empty()) return;
         const size_t n = std::min(r1.size(), r2.size());
-        out << ">" << id << '\n' << r1.substr(0, n) << '\n' << ">" << id << '\n' << r2.substr(0, n) << '\n';
-        out1 << ">" << id << '\n' << r1.substr(0, n) << '\n';
-        out2 << ">" << id << '\n' << r2.substr(0, n) << '\n';
+        const size_t h = (size_t)snprintf(head, sizeof head, ">%lu\n", id);
+        out.put(head, h); out.put(r1.data(), n); out.put('\n'); out.put(head, h); out.put(r2.data(), n); out.put('\n');
+        out1.put(head, h); out1.put(r1.data(), n); out1.put('\n');
+        out2.put(head, h); out2.put(r2.data(), n); out2.put('\n');
         id++;
     };
-    while (in1.good() && in2.good()) {
-        std::getline(in1, b1); std::getline(in2, b2);
-        const bool e1 = b1.empty() || b1[0] == 0, e2 = b2.empty() || b2[0] == 0;
+    while (in1.good && in2.good) {
+        const char *b1, *b2; size_t l1, l2;
+        in1.next(b1, l1); in2.next(b2, l2);
+        const bool e1 = l1 == 0 || b1[0] == 0, e2 = l2 == 0 || b2[0] == 0;
         if (e1 && e2) break;
         if (e1 != e2) die("INCONSISTENT PE FILES!");
         if (b1[0] == '>' && b2[0] == '>') { flush(); r1.clear(); r2.clear(); }
-        else if (b1[0] != '>' && b2[0] != '>') { r1 += b1; r2 += b2; }
+        else if (b1[0] != '>' && b2[0] != '>') { r1.append(b1, l1); r2.append(b2, l2); }
         else die("INCONSISTENT PE FILES!");
     }
     flush();

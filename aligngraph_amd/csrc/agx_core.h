@@ -484,6 +484,115 @@ AGX_HD agx_u8 agx_pack_classes2(agx_u32 c0, agx_u32 c1, agx_u32 c2, agx_u32 c3) 
     return (agx_u8)((agx_base_class(c0) & 3u) | ((agx_base_class(c1) & 3u) << 2) | ((agx_base_class(c2) & 3u) << 4) | ((agx_base_class(c3) & 3u) << 6));
 }
 
+// ---- read rows relative to the reference (upload form, r04) ----------------------------------------------------------------------------
+// The 2-bit rows are more than half of what a unit sends over PCIe, and nearly all of their bases equal the reference base they are aligned
+// to.  So a row crosses as the list of the bases that DIFFER from what the reference predicts for it, given the alignment of the row's
+// ANCHOR: the first hit (file order) that names the row.  Its left mate's runs (q, t, n) put read indices q .. q + n - 1 on positions
+// t .. t + n - 1 (a mate that is one full-length run: q = 0, t = the hit's offset, n = len); stored base j (file orientation) is read index j
+// of a forward mate and len - 1 - j of a reverse mate, complemented; a base no run covers (inserted, clipped) is predicted as class 0.
+// Per row one count byte (AGX_ROW_EXPLICIT: the row crosses as its 2-bit classes, as before — too many differences, an anchor whose runs
+// do not fit the read or the unit) and a stream of 16-bit units: a difference = index << 2 | class; an explicit row = its stride / 4 bytes
+// (rounded up to whole units).  Bases at and beyond the read's length are class 0 in both forms, so the expanded vote codes are the same
+// bytes either way (tests/test_row_diffs.py).  The codec is exact for ANY anchor geometry: the host makes the differences against the
+// very prediction the device will compute (agx_row_expected16, one function).
+#define AGX_ROW_EXPLICIT 255u
+#define AGX_ROW_MAXSTRIDE 256u                            // rows of longer reads keep the 2-bit form (agx_k_expand_rows holds 64 rows of vote codes in LDS; a difference's index has 14 bits)
+#define AGX_ROW_MAXRUNS 32u                               // anchors with more runs than this keep their rows as they are
+AGX_HD agx_u32 agx_row_explicit_units(agx_u32 stride) { return (stride / 4u + 1u) / 2u; }
+AGX_HD agx_u32 agx_row_units(agx_u32 cnt, agx_u32 stride) { return cnt == AGX_ROW_EXPLICIT ? agx_row_explicit_units(stride) : cnt; }
+// the geometry of a hit's left mate as the wire record has it: where its read index 0 sits if it is one full-length run, its strand, its runs if not
+// (fields are read into values before anything is chosen between them: a choice between two members is a choice between two addresses to the compiler, and
+// the record then lives in scratch memory on the device)
+AGX_HD agx_u32 agx_whit_left_t0(const agx_whit &w) { const agx_u32 a = w.a, b = w.b, f = w.flags; return (f & AGX_WF_LEFT2) ? b : a; }
+AGX_HD bool agx_whit_left_rev(const agx_whit &w) { const agx_u32 f = w.flags; return (f & ((f & AGX_WF_LEFT2) ? (agx_u32)AGX_WF_REV2 : (agx_u32)AGX_WF_REV1)) != 0; }
+AGX_HD bool agx_whit_left_simple(const agx_whit &w) { const agx_u32 f = w.flags; return (f & ((f & AGX_WF_LEFT2) ? (agx_u32)AGX_WF_RUNS2 : (agx_u32)AGX_WF_RUNS1)) == 0; }
+AGX_HD agx_u32 agx_whit_side(const agx_whit &w) { const agx_u32 a = w.a, b = w.b, f = w.flags; return (f & AGX_WF_RUNS1) ? a : b; }      // (of a hit with a multi-run mate)
+AGX_HD agx_u32 agx_wside_left_first(const agx_whit &w, const agx_wside &sd) { const agx_u32 r1 = sd.runs1, r2 = sd.runs2, f = w.flags; return (f & AGX_WF_LEFT2) ? r2 : r1; }
+AGX_HD agx_u32 agx_wside_left_count(const agx_whit &w, const agx_wside &sd) { const agx_u32 n = sd.nruns, f = w.flags; return (f & AGX_WF_LEFT2) ? n >> 16 : n & 0xFFFFu; }
+// the 2-bit codes of positions p .. p + 15 of the packed reference (position p in the low bits); positions below 0 read as 0.  Reads the
+// 32-bit words p >> 4 and (p >> 4) + 1: the buffer carries that much slack behind its last position.
+AGX_HD agx_u32 agx_ref_window16(const agx_u32 *wref, long long p) {
+    if (p <= -16) return 0u;
+    if (p < 0) return wref[0] << (2u * (agx_u32)(-p));
+    const size_t w = (size_t)(p >> 4); const agx_u32 sh = 2u * (agx_u32)(p & 15);
+    const agx_u32 lo = wref[w], hi = wref[w + 1];
+    return sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+}
+AGX_HD agx_u32 agx_reverse_pairs16(agx_u32 x) {          // the sixteen 2-bit groups of x in reverse order
+    x = (x >> 16) | (x << 16);
+    x = ((x & 0xFF00FF00u) >> 8) | ((x & 0x00FF00FFu) << 8);
+    x = ((x & 0xF0F0F0F0u) >> 4) | ((x & 0x0F0F0F0Fu) << 4);
+    return ((x & 0xCCCCCCCCu) >> 2) | ((x & 0x33333333u) << 2);
+}
+// what the reference predicts for stored bases j0 .. j0 + 15 of a row (j0 a multiple of 16): 2-bit classes, base j0 in the low bits.  Every run must lie
+// inside the read (q + n <= len) and inside the unit (t + n <= positions): the host checks that before it chooses this form for a row.
+AGX_HD agx_u32 agx_row_run16(const agx_u32 *wref, const agx_wrun r, agx_u32 len, bool rev, agx_u32 j0) {      // one run's share of the chunk
+    const agx_u32 lo = rev ? len - r.q - r.n : r.q, hi = lo + r.n;                         // the run's stored indices
+    const agx_u32 a = lo > j0 ? lo : j0, b = hi < j0 + 16u ? hi : j0 + 16u;
+    if (a >= b) return 0u;
+    const long long base = (long long)r.t - (long long)r.q;                               // position of read index 0, were the run that long
+    const agx_u32 win = rev ? ~agx_reverse_pairs16(agx_ref_window16(wref, base + (long long)len - 16ll - (long long)j0)) : agx_ref_window16(wref, base + (long long)j0);
+    const agx_u32 nb = b - a, m = (nb < 16u ? (1u << (2u * nb)) - 1u : 0xFFFFFFFFu) << (2u * (a - j0));
+    return win & m;
+}
+// left_runs / nruns = the runs of the anchor's left mate (nruns = 0: one full-length run at the hit's offset)
+AGX_HD agx_u32 agx_row_expected16(const agx_u32 *wref, const agx_whit &w, const agx_wrun *left_runs, agx_u32 nruns, agx_u32 j0) {
+    const agx_u32 len = w.len; const bool rev = agx_whit_left_rev(w);
+    if (j0 >= len) return 0u;
+    if (nruns == 0) return agx_row_run16(wref, agx_wrun{agx_whit_left_t0(w), (agx_u16)0, w.len}, len, rev, j0);
+    agx_u32 c = 0;
+    for (agx_u32 i = 0; i < nruns; i++) c |= agx_row_run16(wref, left_runs[i], len, rev, j0);
+    return c;
+}
+// the classes of stored bases j0 .. j0 + 15 of a row out of its upload form: cnt = the row's count byte, units = its part of the stream, w = its anchor,
+// left_runs / nruns = the runs of the anchor's left mate (nruns = 0: one full-length run at the hit's offset)
+AGX_HD agx_u32 agx_row_chunk16(const agx_u32 *wref, const agx_u16 *units, agx_u32 cnt, const agx_whit &w, const agx_wrun *left_runs, agx_u32 nruns, agx_u32 j0, agx_u32 stride) {
+    if (cnt == AGX_ROW_EXPLICIT) {
+        const agx_u32 nu = agx_row_explicit_units(stride), i = j0 / 8u;      // (a unit holds eight bases)
+        const agx_u32 lo = i < nu ? units[i] : 0u, hi = i + 1u < nu ? units[i + 1u] : 0u;
+        return lo | (hi << 16);
+    }
+    agx_u32 c = agx_row_expected16(wref, w, left_runs, nruns, j0);
+    for (agx_u32 i = 0; i < cnt; i++) {
+        const agx_u32 e = units[i], j = e >> 2, sh = 2u * (j & 15u);
+        if ((j >> 4) == (j0 >> 4)) c = (c & ~(3u << sh)) | ((e & 3u) << sh);
+    }
+    return c;
+}
+// the vote codes of four bases (classes in the low byte of c), one per byte
+AGX_HD agx_u32 agx_vote_codes4(agx_u32 c) {
+    agx_u32 o = 0;
+    for (int b = 0; b < 4; b++) o |= (agx_u32)agx_class_vote_code((c >> (2 * b)) & 3u) << (8 * b);
+    return o;
+}
+// The anchor of row 64 b + l, given the first anchor of the block (h0 = the anchor of row 64 b): rows are numbered in the order of their anchors (the host checks
+// it, and that a block's anchors lie within 224 hits of its first, before it chooses this form), so it is the l-th set bit of the anchor bits at or behind h0.
+// Reads up to eight 32-bit words from h0 >> 5 on.  NONE if there is no such bit there.
+AGX_HD agx_u32 agx_anchor_select(const agx_u32 *bits, agx_u32 h0, agx_u32 l) {
+    const agx_u32 w0 = h0 >> 5;
+    agx_u32 need = l;
+    for (agx_u32 i = 0; i < 8u; i++) {
+        agx_u32 x = bits[w0 + i];
+        if (i == 0) x &= ~0u << (h0 & 31u);
+        const agx_u32 pc = (agx_u32)__builtin_popcount(x);
+        if (need < pc) { for (agx_u32 k = 0; k < need; k++) x &= x - 1u; return (w0 + i) * 32u + (agx_u32)__builtin_ctz(x); }
+        need -= pc;
+    }
+    return AGX_NONE;
+}
+// A whole row out of its upload form into `out` (stride bytes of vote codes, 4-byte aligned; the bases that are not A, C, G, T are patched in afterwards from their list):
+// the prediction sixteen bases at a time, then one byte per difference.  What agx_k_expand_rows runs per lane (out = the lane's row in LDS) and the test executor per row.
+AGX_HD void agx_row_decode(const agx_u32 *wref, const agx_u16 *units, agx_u32 cnt, const agx_whit &w, const agx_wrun *left_runs, agx_u32 nruns, agx_u32 stride, agx_u8 *out) {
+    agx_u32 *o32 = (agx_u32 *)out;
+    const bool expl = cnt == AGX_ROW_EXPLICIT;
+    for (agx_u32 j0 = 0; j0 < stride; j0 += 16u) {
+        const agx_u32 cls = expl ? agx_row_chunk16(wref, units, cnt, w, left_runs, nruns, j0, stride) : agx_row_expected16(wref, w, left_runs, nruns, j0);
+        for (agx_u32 q = 0; q < 4u && j0 + 4u * q < stride; q++) o32[j0 / 4u + q] = agx_vote_codes4((cls >> (8u * q)) & 0xFFu);
+    }
+    if (expl) return;
+    for (agx_u32 i = 0; i < cnt; i++) { const agx_u32 e = units[i], j = e >> 2; if (j < stride) out[j] = agx_class_vote_code(e & 3u); }
+}
+
 // first compatible variant or append (AG:1375-1390 / 1493-1506).  Returns the index, or NONE when the bucket is full.
 AGX_HD agx_u32 agx_match_or_insert(const agx_bucket &b, agx_u32 &cnt, const agx_key &key, int iv, bool is_k1, agx_u32 s0, agx_u32 s1) {
     agx_u32 v = 0;

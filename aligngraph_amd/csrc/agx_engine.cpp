@@ -255,6 +255,9 @@ struct agx_unit {
     PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
     PBuf<char> s_landing;               // one-shot units: what the download needs beyond the dead staged inputs it lands in, pinned when the unit is staged (not inside T_core)
     PBuf<agx_cntrun> s_cntruns; PBuf<agx_chunk> s_cntchunks, s_segchunks; PBuf<agx_u32> s_segindex; size_t n_cntruns = 0, n_cntchunks = 0, n_segchunks = 0, n_segindex = 0;      // what the device builds the conti-mer tables from (build_cm_layout)
+    // the read rows in their upload form (agx_core.h "read rows relative to the reference"; made at the end of staging: stage_rows): count byte per row, offsets of the
+    // 64-row blocks in the stream, the stream of 16-bit units, one bit per hit (its row's anchor).  rows_diffed = false: the rows cross as their 2-bit classes (s_codes)
+    PBuf<agx_u16> s_units; PBuf<agx_u8> s_rowcnt; PBuf<agx_u32> s_blockoff, s_blockfirst, s_anchor; size_t n_units = 0, n_rowcnt = 0, n_blockoff = 0, n_blockfirst = 0, n_anchor = 0, n_rows_explicit = 0; bool rows_diffed = false;
     size_t nh = 0, n_runs = 0, n_cm = 0, n_codes = 0; agx_u32 maxlen = 0;      // n_codes: bytes of packed classes (four bases each); n_other: listed bases that are not A, C, G, T
     std::vector<agx_u32> row_slot;      // staged read bases: one row per (pair, a mate) that some hit uses; row -> read slot (general loader / agx_unit_push_pairs)
     std::vector<uint64_t> row_off;      // fast loader: row -> where the read's bases start in the mapped reads file (the bases are never copied: the walk reads the k-mer tails of written records there)
@@ -265,6 +268,7 @@ struct agx_unit {
     // inputs on the device
     DBuf<agx_u32> d_cm_start, d_cm_cnt; DBuf<agx_cmkey> d_cm; DBuf<agx_cmhead> d_cm_head; DBuf<char> d_ref; DBuf<agx_cmseg> d_segs; DBuf<unsigned long long> d_up_desc;
     DBuf<agx_run> d_runs; DBuf<agx_u8> d_codes, d_vcodes; DBuf<unsigned long long> d_other;
+    DBuf<agx_u16> d_units; DBuf<agx_u8> d_rowcnt; DBuf<agx_u32> d_blockoff, d_blockfirst, d_anchor;
     DBuf<agx_cntrun> d_cntruns; DBuf<agx_chunk> d_cntchunks, d_segchunks; DBuf<agx_u32> d_jump, d_segindex;
     DBuf<agx_whit> d_whits; DBuf<agx_wside> d_wsides; DBuf<agx_wrun> d_wruns; DBuf<agx_u8> d_wref; DBuf<agx_refx> d_refx;      // what was uploaded, until the first build has expanded it
     // derived
@@ -410,6 +414,26 @@ void reserve_landing(agx_unit *u) {
     // (a buffer must fit one block: count the blocks at 85 %)
     if (need > have * 85 / 100) u->s_landing.alloc(need - have * 85 / 100 + (ni + 512)); else u->s_landing.release();
 }
+// The read rows for the upload: differences against the reference where that is the shorter form (agx_core.h; build_row_diffs in agx_load.cpp).  Needs the packed
+// reference; AGX_NO_ROW_DIFF=1 keeps the 2-bit rows (tests compare the two).  The 2-bit rows stay where they are: the walk of a unit handed over staged reads k-mer
+// tails out of them, and a one-shot unit's download lands in their memory.
+void stage_rows(agx_unit *u, unsigned threads) {
+    u->rows_diffed = false; u->n_units = u->n_rowcnt = u->n_blockoff = u->n_blockfirst = u->n_anchor = u->n_rows_explicit = 0;
+    const char *off = getenv("AGX_NO_ROW_DIFF");
+    if ((off && atoi(off) != 0) || !u->ref_packed || u->n_rows == 0 || u->nh == 0) return;
+    const double t0 = now_ms();
+    RowDiffs D;
+    if (!build_row_diffs(u->s_hits.p, u->nh, u->s_sides.p, u->n_sides, u->s_runs.p, u->n_runs, u->s_codes.p, u->n_rows, u->stride, (const agx_u32 *)u->s_ref.p, u->V.n_pos ? u->V.n_pos : u->T.ref.size(), threads, D)) return;
+    if (D.n_units * 2 + D.cnt.size() + (D.block_off.size() + D.block_first.size() + D.anchor_bits.size()) * 4 >= u->n_codes) return;      // nothing gained (reads that do not resemble the reference)
+    u->n_units = D.n_units; u->n_rowcnt = D.cnt.size(); u->n_blockoff = D.block_off.size(); u->n_blockfirst = D.block_first.size(); u->n_anchor = D.anchor_bits.size(); u->n_rows_explicit = D.n_explicit;
+    u->s_units.alloc(u->n_units + 2); u->s_rowcnt.alloc(u->n_rowcnt); u->s_blockoff.alloc(u->n_blockoff); u->s_blockfirst.alloc(u->n_blockfirst); u->s_anchor.alloc(u->n_anchor);
+    const unsigned T = std::max(1u, std::min(threads, 8u));
+    on_threads(T, [&](unsigned t) { const size_t lo = u->n_units * t / T, hi = u->n_units * (t + 1) / T; if (hi > lo) memcpy(u->s_units.p + lo, D.units.data() + lo, (hi - lo) * 2); });
+    memcpy(u->s_rowcnt.p, D.cnt.data(), u->n_rowcnt); memcpy(u->s_blockoff.p, D.block_off.data(), u->n_blockoff * 4); memcpy(u->s_blockfirst.p, D.block_first.data(), u->n_blockfirst * 4); memcpy(u->s_anchor.p, D.anchor_bits.data(), u->n_anchor * 4);
+    u->rows_diffed = true;
+    if (getenv("AGX_LOAD_TIMING")) fprintf(stderr, "[agx load] read rows against the reference: %.1f ms, %zu rows (%zu as they are), %.1f -> %.1f bytes per row\n", now_ms() - t0, (size_t)u->n_rows, u->n_rows_explicit,
+                                          (double)u->n_codes / u->n_rows, (double)(u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4) / u->n_rows);
+}
 void stage_inputs(agx_unit *u) {
     if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
     // A one-shot unit's download lands in its staged buffers.  The general loader's pairs can be staged again from P; the fast loader wrote the hits, runs and
@@ -445,6 +469,7 @@ void stage_inputs(agx_unit *u) {
         V.other_idx = (const unsigned long long *)F.sec(pairsfile::S_OTHER); V.other_byte = (const agx_u8 *)F.sec(pairsfile::S_OTHERB); V.n_other = (size_t)F.H.n_other;
     } else if (u->pairs_staged) { V.bases = u->reads_keep ? u->reads_keep->fv.p : nullptr; V.stride = u->stride; V.row_off = u->row_off.data(); }
     u->V = V;
+    stage_rows(u, threads);
     reserve_landing(u);
     u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0;
@@ -659,6 +684,7 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     else if (in_reads) { u->reads_map = std::move(reads_map); V.bases = u->reads_map->p; V.row_off = (const uint64_t *)(base + H.off[S_ROWS]); }
     else { V.bases = base + H.off[S_BASES]; u->row_slot.assign((const agx_u32 *)(base + H.off[S_ROWS]), (const agx_u32 *)(base + H.off[S_ROWS]) + H.n_rows); }
     u->V = V; u->pairs_staged = false;
+    stage_rows(u, std::max(threads, std::min(8u, usable_cpus())));
     reserve_landing(u);
     u->have_ref = u->have_threads = true; u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0; u->stats.ms_parse = 0; u->stats.ms_thread = 0; u->stats.from_cache = 1;
@@ -737,7 +763,7 @@ Plan plan_capacities(const agx_unit *u) {
     const size_t per_pos = 4 + 16 + 1 + 4 + 2 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_dhit) + 4;
     const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
     const size_t wire = nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 + (u->ref_packed ? n_pos / 4 + u->n_refx * sizeof(agx_refx) : 0) + 4096;
-    const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + (size_t)n_tiles * P.slot_cap * 4 + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + u->n_codes + n_bases + u->n_other * 8 +
+    const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + (size_t)n_tiles * P.slot_cap * 4 + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + (u->rows_diffed ? u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4 : u->n_codes) + n_bases + u->n_other * 8 +
                          (size_t)P.pool_cap * per_slot + ids_cap * per_id + (size_t)P.list_cap * 36 + (size_t)P.ovf_cap * 16 + (size_t)P.sp_cap * (sizeof(agx_walknode) + sizeof(agx_hop)) +
                          (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64 * 4 + (size_t)n_regions * AGX_REGION_PAD * 4 + (64u << 10) * 100;
     P.total = total + total / 64;
@@ -765,7 +791,9 @@ void do_upload(agx_unit *u) {
     DevArena &a = u->arena;
     u->d_cm_start.alloc(a, n_pos + 2); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos + 16); u->d_cm_head.alloc(a, n_pos + 1);
     u->d_segs.alloc(a, u->n_segs + 1); u->d_cntruns.alloc(a, u->n_cntruns + 1); u->d_cntchunks.alloc(a, u->n_cntchunks + 1); u->d_segchunks.alloc(a, u->n_segchunks + 1); u->d_segindex.alloc(a, u->n_segindex + 1);
-    u->d_runs.alloc(a, u->n_runs + 1); u->d_codes.alloc(a, u->n_codes + 16); u->d_vcodes.alloc(a, n_bases + 16); u->d_other.alloc(a, u->n_other + 1);
+    u->d_runs.alloc(a, u->n_runs + 1); u->d_vcodes.alloc(a, n_bases + 16); u->d_other.alloc(a, u->n_other + 1);
+    if (u->rows_diffed) { u->d_units.alloc(a, u->n_units + 2); u->d_rowcnt.alloc(a, u->n_rowcnt); u->d_blockoff.alloc(a, u->n_blockoff); u->d_blockfirst.alloc(a, u->n_blockfirst); u->d_anchor.alloc(a, u->n_anchor); }
+    else u->d_codes.alloc(a, u->n_codes + 16);
     u->d_whits.alloc(a, nh + 1); u->d_wsides.alloc(a, u->n_sides + 1); u->d_wruns.alloc(a, u->n_runs + 1); u->d_jump.alloc(a, u->n_jump + 1);
     if (u->ref_packed) { u->d_wref.alloc(a, (n_pos + 3) / 4 + 32); u->d_refx.alloc(a, u->n_refx + 1); }
     u->d_dhit.alloc(a, nh + 1);
@@ -800,7 +828,9 @@ void do_upload(agx_unit *u) {
         up(u->d_cntchunks.p, u->s_cntchunks.p, u->n_cntchunks * sizeof(agx_chunk)); up(u->d_segchunks.p, u->s_segchunks.p, u->n_segchunks * sizeof(agx_chunk)); up(u->d_segindex.p, u->s_segindex.p, u->n_segindex * 4);
         up(u->d_whits.p, u->s_hits.p, nh * sizeof(agx_whit)); up(u->d_wsides.p, u->s_sides.p, u->n_sides * sizeof(agx_wside)); up(u->d_wruns.p, u->s_runs.p, u->n_runs * sizeof(agx_wrun)); up(u->d_jump.p, u->s_jump.p, u->n_jump * 4);
         HIP_OK(hipEventRecord(u->ev_hits, st));         // what the front of the build needs (conti-mer tables, hit preparation, binning) is there: it starts while the rest still travels
-        up(u->d_codes.p, u->s_codes.p, u->n_codes); up(u->d_other.p, u->s_other.p, u->n_other * 8);      // first needed by the sweep
+        if (u->rows_diffed) { up(u->d_units.p, u->s_units.p, u->n_units * 2); up(u->d_rowcnt.p, u->s_rowcnt.p, u->n_rowcnt); up(u->d_blockoff.p, u->s_blockoff.p, u->n_blockoff * 4); up(u->d_blockfirst.p, u->s_blockfirst.p, u->n_blockfirst * 4); up(u->d_anchor.p, u->s_anchor.p, u->n_anchor * 4); }
+        else up(u->d_codes.p, u->s_codes.p, u->n_codes);
+        up(u->d_other.p, u->s_other.p, u->n_other * 8);      // first needed by the sweep
         if (u->ref_packed) { up(u->d_wref.p, u->s_ref.p, (n_pos + 3) / 4); up(u->d_refx.p, u->s_refx.p, u->n_refx * sizeof(agx_refx)); } else up(u->d_ref.p, u->s_ref.p, n_pos);
         up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);      // first needed by the walk preparation
         layout_regions(u, nullptr, pool_cap - spill_min(u), true, st);
@@ -831,8 +861,9 @@ void do_upload(agx_unit *u) {
     if (!u->pending_walk) { u->pending_walk = true; g_walks_pending.fetch_add(1); }
     u->stats.ms_upload = now_ms() - t0;
     u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + u->n_cntruns * sizeof(agx_cntrun) + (u->n_cntchunks + u->n_segchunks) * sizeof(agx_chunk) + (u->ref_packed ? (n_pos + 3) / 4 + u->n_refx * sizeof(agx_refx) : n_pos) + nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 +
-                            (size_t)u->n_chain_end * 4 + u->n_codes + u->n_other * 8 + ((size_t)u->n_regions + 1) * 4;
+                            (size_t)u->n_chain_end * 4 + (u->rows_diffed ? u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4 : u->n_codes) + u->n_other * 8 + ((size_t)u->n_regions + 1) * 4;
     u->stats.device_bytes = u->arena.capacity();
+    u->stats.rows_by_reference = u->rows_diffed ? (uint32_t)(u->n_rows - u->n_rows_explicit) : 0u;
 }
 
 // The three output buffers of a unit: reserved by estimate (the walk grows what is too small), every page touched, the initial contigs
@@ -921,7 +952,8 @@ void do_build(agx_unit *u) {
         if (!u->expanded) {   // the vote codes (and the region layout, the last copy of the upload) are first needed by the sweep
             const size_t n_bases = u->n_codes * 4;
             if (early) HIP_OK(hipStreamWaitEvent(st, u->ev_uploaded, 0));      // (at most the tail of this unit's own upload: nothing else is ever waited for on a build stream)
-            agx_launch_expand_codes(u->d_codes.p, u->d_vcodes.p, (n_bases + 15) / 16 * 16, u->d_other.p, u->n_other, st);
+            if (u->rows_diffed) agx_launch_expand_rows(u->d_whits.p, (agx_u32)nh, u->d_wsides.p, u->d_wruns.p, u->d_anchor.p, u->d_blockfirst.p, u->d_rowcnt.p, u->d_blockoff.p, u->d_units.p, u->d_wref.p, u->d_vcodes.p, u->n_rows, u->stride, u->d_other.p, u->n_other, st);
+            else agx_launch_expand_codes(u->d_codes.p, u->d_vcodes.p, (n_bases + 15) / 16 * 16, u->d_other.p, u->n_other, st);
             if (u->ref_packed) agx_launch_expand_ref(u->d_wref.p, u->d_ref.p, ((size_t)n_pos + 15) / 16 * 16, u->d_refx.p, (agx_u32)u->n_refx, st);      // (the letters are first read by the sweep's write-out)
             u->expanded = true;
         }
@@ -1132,6 +1164,7 @@ void do_release(agx_unit *u) {
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     u->d_node_cnt.release();
     for (auto *b : {&u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();
+    u->d_units.release(); u->d_rowcnt.release(); u->d_blockoff.release(); u->d_blockfirst.release(); u->d_anchor.release();
     u->d_other.release(); u->d_whits.release(); u->d_wsides.release(); u->d_wruns.release(); u->d_wref.release(); u->d_refx.release();
     u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_cntruns.release(); u->d_cntchunks.release(); u->d_segchunks.release(); u->d_jump.release(); u->d_segindex.release(); u->d_sp_hop.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
     u->d_ovf.release(); u->d_a_ovf.release(); u->d_huge_list.release(); u->d_scratch_huge.release(); u->huge = false; u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();

@@ -210,6 +210,13 @@ struct CmLayout { std::vector<agx_cntrun> cnt_runs; std::vector<agx_chunk> cnt_c
 void build_seg_index(const agx_cmseg *segs, size_t n_seg0, size_t n_pos, std::vector<agx_u32> &index);      // agx_compact_args::seg_index
 void build_cm_layout(const agx_u8 *cm_cnt, size_t n_pos, const agx_cmseg *segs, size_t n_segs, CmLayout &L);      // (seg_index is built separately: it needs n_seg0)
 bool pack_reference(const char *ref, size_t n, unsigned threads, agx_u8 *packed /* (n + 3) / 4 + 16 bytes */, std::vector<agx_refx> &others);
+// The read rows in their upload form (agx_core.h "read rows relative to the reference").  cnt: one count byte per row, padded with zeros to whole 64-row blocks + 64;
+// block_off[i]: units in front of row 64 i (and the total behind the last block); anchor_bits: bit h = hit h is its row's anchor; units: the stream.
+// block_first[i]: the anchor of row 64 i.
+struct RowDiffs { std::vector<agx_u8> cnt; std::vector<agx_u32> block_off, block_first, anchor_bits; std::vector<agx_u16> units; size_t n_units = 0, n_explicit = 0; };
+// wref: the packed reference (pack_reference) as 32-bit words, readable one word beyond position n_pos + 15.  false: the form does not apply.
+bool build_row_diffs(const agx_whit *hits, size_t nh, const agx_wside *sides, size_t n_sides, const agx_wrun *runs, size_t n_runs, const agx_u8 *codes2, size_t n_rows, agx_u32 stride,
+                     const agx_u32 *wref, size_t n_pos, unsigned threads, RowDiffs &D);
 
 // tmp/_agx_pairs.<u>.bin — a unit's read alignments handed over STAGED (the wire formats of agx_core.h) instead of as SAM text + tmp/_reads.fa: what an aligner that is
 // linked with the engine (or a generator of synthetic alignments: tools/agx_synth.cpp) writes where the reference's flow distributes SAM lines (AG:3545-3579).  The arrays are

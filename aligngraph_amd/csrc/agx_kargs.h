@@ -50,6 +50,11 @@ void agx_launch_zero(const agx_zero_args *, hipStream_t);
 void agx_launch_cm_tables(const void *cnt_runs, const void *cnt_chunks, agx_u32 n_cnt_chunks, const agx_cmseg *segs, const void *seg_chunks, agx_u32 n_seg_chunks,
                            agx_u32 *cm_start, agx_cmkey *cm, agx_cmhead *head, agx_u32 n_pos, agx_u32 n_cm, hipStream_t);      // cm_start[n_pos + 1], cm, n_pos + 1 heads from the count runs and the conti-mer runs (agx_core.h: agx_cntrun, agx_chunk)
 void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16, const unsigned long long *other, size_t n_other, hipStream_t);      // 2-bit base classes (agx_pack_classes2) + the listed other bases -> agx_vote_code bytes; n_bases16 a multiple of 16
+// the rows from their upload form (differences against the reference under each row's anchor hit, or the 2-bit classes: agx_core.h) -> agx_vote_code bytes, then the listed other bases.
+// cnt: zeros up to the next multiple of 64 rows; anchor_bits: eight words readable behind any block's first anchor; wref: the packed reference, one 32-bit word of slack behind
+// position n_pos + 15; stride <= AGX_ROW_MAXSTRIDE
+void agx_launch_expand_rows(const void *whits, agx_u32 nh, const void *wsides, const void *wruns, const agx_u32 *anchor_bits, const agx_u32 *block_first, const agx_u8 *cnt, const agx_u32 *block_off,
+                            const agx_u16 *units, const void *wref, void *vcodes, agx_u32 n_rows, agx_u32 stride, const unsigned long long *other, size_t n_other, hipStream_t);
 void agx_launch_expand_runs(const void *wruns, agx_run *runs, agx_u32 n_runs, hipStream_t);      // wire formats (agx_core.h) -> working arrays
 void agx_launch_expand_ref(const void *packed, void *ref, size_t n_pos16, const void *refx, agx_u32 n_refx, hipStream_t);      // 2-bit reference bases + the stretches of other bytes -> letters; n_pos16 a multiple of 16
 void agx_launch_hit_prep(const agx_prep_args *, hipStream_t);

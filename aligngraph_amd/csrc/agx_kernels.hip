@@ -77,6 +77,35 @@ __global__ void __launch_bounds__(256) agx_k_patch_codes(const unsigned long lon
     if (i < n) vcodes[other[i]] = agx_class_vote_code(4u);
 }
 
+// The rows out of their upload form (agx_core.h "read rows relative to the reference"): a wavefront per block of 64 rows, a lane per row.  A lane finds its row's anchor
+// among the anchor bits behind the block's first anchor, its place in the stream from the block's offset and a scan of the count bytes in front of it, and decodes the
+// row into LDS (agx_row_decode: the reference's prediction sixteen bases at a time, then one byte per difference); the 64 rows — contiguous in the vote-code array —
+// then leave LDS in 16-byte pieces, lane after lane.  Dynamic LDS: 64 * stride bytes (stride <= AGX_ROW_MAXSTRIDE).
+__global__ void __launch_bounds__(64) agx_k_expand_rows(const agx_whit *hits, agx_u32 nh, const agx_wside *sides, const agx_wrun *runs, const agx_u32 *anchor_bits, const agx_u32 *block_first,
+                                                         const agx_u8 *cnt, const agx_u32 *block_off, const agx_u16 *units, const agx_u32 *wref, agx_u8 *vcodes, agx_u32 n_rows, agx_u32 stride) {
+    extern __shared__ __attribute__((aligned(16))) agx_u32 row_lds[];
+    const agx_u32 b = blockIdx.x, l = threadIdx.x, row = b * 64u + l;
+    const bool valid = row < n_rows;
+    const agx_u32 c = cnt[row];                               // (padded with zeros to whole blocks)
+    const agx_u32 u = valid ? agx_row_units(c, stride) : 0u;
+    agx_u32 incl = u;
+    for (agx_u32 o = 1; o < 64u; o <<= 1) { const agx_u32 t = __shfl_up(incl, o, 64); if (l >= o) incl += t; }
+    if (valid) {
+        const agx_u32 h = agx_anchor_select(anchor_bits, block_first[b], l);
+        if (h < nh) {
+            const agx_whit w = hits[h];
+            const agx_wrun *left = nullptr; agx_u32 nruns = 0;
+            if (c != AGX_ROW_EXPLICIT && !agx_whit_left_simple(w)) { const agx_wside sd = sides[agx_whit_side(w)]; left = runs + agx_wside_left_first(w, sd); nruns = agx_wside_left_count(w, sd); }
+            agx_row_decode(wref, units + (size_t)block_off[b] + (incl - u), c, w, left, nruns, stride, (agx_u8 *)row_lds + (size_t)l * stride);
+        }
+    }
+    __syncthreads();
+    const agx_u32 rows_here = n_rows - b * 64u < 64u ? n_rows - b * 64u : 64u, words = rows_here * (stride / 4u);
+    agx_u32 *dst = (agx_u32 *)(vcodes + (size_t)b * 64u * stride);
+    for (agx_u32 i = l; i < words / 4u; i += 64u) ((uint4 *)dst)[i] = ((const uint4 *)row_lds)[i];
+    for (agx_u32 i = (words & ~3u) + l; i < words; i += 64u) dst[i] = row_lds[i];
+}
+
 // ---- the packed upload -> the working arrays (agx_core.h "wire formats"): head of a unit's first build ---------------------------------
 __global__ void __launch_bounds__(256) agx_k_expand_runs(const agx_wrun *wruns, agx_run *runs, agx_u32 n_runs) {
     const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
@@ -673,6 +702,12 @@ void agx_launch_zero(const agx_zero_args *Z, hipStream_t st) {
 void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16, const unsigned long long *other, size_t n_other, hipStream_t st) {
     const size_t n16 = n_bases16 / 16;
     if (n16) hipLaunchKernelGGL(agx_k_expand_codes, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const agx_u32 *)packed, (uint4 *)vcodes, n16);
+    if (n_other) hipLaunchKernelGGL(agx_k_patch_codes, dim3((unsigned)((n_other + 255) / 256)), dim3(256), 0, st, other, n_other, (agx_u8 *)vcodes);
+}
+void agx_launch_expand_rows(const void *whits, agx_u32 nh, const void *wsides, const void *wruns, const agx_u32 *anchor_bits, const agx_u32 *block_first, const agx_u8 *cnt, const agx_u32 *block_off,
+                            const agx_u16 *units, const void *wref, void *vcodes, agx_u32 n_rows, agx_u32 stride, const unsigned long long *other, size_t n_other, hipStream_t st) {
+    if (n_rows) hipLaunchKernelGGL(agx_k_expand_rows, dim3((n_rows + 63u) / 64u), dim3(64), 64u * stride, st, (const agx_whit *)whits, nh, (const agx_wside *)wsides, (const agx_wrun *)wruns, anchor_bits, block_first,
+                                   cnt, block_off, units, (const agx_u32 *)wref, (agx_u8 *)vcodes, n_rows, stride);
     if (n_other) hipLaunchKernelGGL(agx_k_patch_codes, dim3((unsigned)((n_other + 255) / 256)), dim3(256), 0, st, other, n_other, (agx_u8 *)vcodes);
 }
 void agx_launch_expand_runs(const void *wruns, agx_run *runs, agx_u32 n_runs, hipStream_t st) {

@@ -547,6 +547,133 @@ bool pack_reference(const char *ref, size_t n, unsigned threads, agx_u8 *packed,
     return others.size() <= limit;
 }
 
+// The read rows in their upload form (agx_core.h "read rows relative to the reference"): every row against what the reference predicts for it
+// under its anchor hit.  Rows in ranges of whole 64-row blocks, one range after another handed to the threads; a range's units are gathered in a buffer of its own and
+// put together in row order at the end.  false: the form does not apply (rows too long for a 14-bit index, more than 2^32 units).
+// The prediction is agx_row_expected16's (the function the device calls), made 32 bases at a time here: the same reference codes, the same complement, the same zeros
+// at and beyond the read's length — tests/test_row_diffs.py decodes every row with the device's function.
+namespace {
+inline unsigned long long ref_window32(const agx_u8 *packed, long long p) {      // codes of positions p .. p + 31, position p in the low bits; positions below 0 read as 0
+    if (p <= -32) return 0ull;
+    if (p < 0) { unsigned long long lo; memcpy(&lo, packed, 8); return lo << (2u * (unsigned)(-p)); }
+    const size_t b = (size_t)(p >> 2); const unsigned sh = 2u * (unsigned)(p & 3);
+    unsigned long long lo; memcpy(&lo, packed + b, 8);
+    return sh ? (lo >> sh) | ((unsigned long long)packed[b + 8] << (64u - sh)) : lo;
+}
+inline unsigned long long reverse_pairs32(unsigned long long x) {
+    x = __builtin_bswap64(x);
+    x = ((x & 0xF0F0F0F0F0F0F0F0ull) >> 4) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return ((x & 0xCCCCCCCCCCCCCCCCull) >> 2) | ((x & 0x3333333333333333ull) << 2);
+}
+}
+bool build_row_diffs(const agx_whit *hits, size_t nh, const agx_wside *sides, size_t n_sides, const agx_wrun *runs, size_t n_runs, const agx_u8 *codes2, size_t n_rows, agx_u32 stride,
+                     const agx_u32 *wref, size_t n_pos, unsigned threads, RowDiffs &D) {
+    D = RowDiffs();
+    if (stride == 0 || (stride & 3u) || stride > AGX_ROW_MAXSTRIDE || n_rows >= 0x7FFFFFFFull || nh >= 0xFFFFFFFFull) return false;
+    const agx_u8 *packed = (const agx_u8 *)wref;
+    const size_t row_bytes = stride / 4, n_blocks = (n_rows + 63) / 64;
+    enum { W_MAX = AGX_ROW_MAXSTRIDE / 32 };
+    const agx_u32 n_words = (stride + 31u) / 32u;
+    const agx_u32 expl_units = agx_row_explicit_units(stride), max_diffs = std::min<agx_u32>(254u, expl_units ? expl_units - 1u : 0u);
+    // anchors: the first hit that names a row
+    std::vector<agx_u32> anchor(n_rows, AGX_NONE);
+    D.anchor_bits.assign(nh / 32 + 2, 0u);
+    for (size_t h = 0; h < nh; h++) { const agx_u32 r = hits[h].row; if (r < n_rows && anchor[r] == AGX_NONE) { anchor[r] = (agx_u32)h; D.anchor_bits[h >> 5] |= 1u << (h & 31); } }
+    // the device finds a row's anchor by counting anchor bits from its block's first anchor on (agx_anchor_select): every row needs an anchor, the anchors must come in row
+    // order (the loaders number the rows as the hits first name them), and a block's anchors must lie within the eight words the device reads
+    D.block_first.assign(n_blocks + 1, 0u);
+    for (size_t r = 0; r < n_rows; r++) {
+        if (anchor[r] == AGX_NONE || (r && anchor[r] <= anchor[r - 1])) { D = RowDiffs(); return false; }
+        if ((r & 63) == 0) D.block_first[r >> 6] = anchor[r];
+        else if (anchor[r] - (D.block_first[r >> 6] & ~31u) >= 256u) { D = RowDiffs(); return false; }
+    }
+    D.anchor_bits.resize(nh / 32 + 10, 0u);               // (eight words are read from a block's first anchor on)
+    D.cnt.assign(n_blocks * 64 + 64, 0);
+    const size_t per_range = 256;                         // blocks per range
+    const size_t n_ranges = (n_blocks + per_range - 1) / per_range;
+    std::vector<std::vector<agx_u16>> part(n_ranges);
+    std::vector<size_t> part_n(n_ranges, 0), n_expl(n_ranges, 0);
+    std::atomic<size_t> next{0};
+    Team team(std::max<unsigned>(1u, (unsigned)std::min<size_t>(threads, n_ranges ? n_ranges : 1)));
+    team.run([&](unsigned) {
+        std::vector<agx_u16> buf(per_range * 64 * expl_units + 4);          // a range's units (no row takes more than it does as it is); kept exact-size per range below
+        for (size_t g; (g = next.fetch_add(1)) < n_ranges;) {
+            const size_t r_lo = g * per_range * 64, r_hi = std::min(n_rows, (g + 1) * per_range * 64);
+            agx_u16 *const out0 = buf.data(), *out = out0;
+            for (size_t r = r_lo; r < r_hi; r++) {
+                const agx_u8 *row = codes2 + r * row_bytes;
+                agx_u16 *const mark = out;
+                bool diffed = false;
+                const agx_whit w = hits[anchor[r]];
+                const agx_u32 len = w.len;
+                // the anchor's left mate as runs inside the read and the unit, or the row stays as it is
+                agx_wrun one{agx_whit_left_t0(w), (agx_u16)0, w.len};
+                const agx_wrun *rr = &one; agx_u32 nr = 1;
+                bool fits = len != 0 && len <= stride;
+                if (fits && !agx_whit_left_simple(w)) {
+                    const size_t si = agx_whit_side(w);
+                    fits = si < n_sides;
+                    if (fits) { const agx_wside sd = sides[si]; const size_t first = agx_wside_left_first(w, sd); nr = agx_wside_left_count(w, sd); fits = nr >= 1 && nr <= AGX_ROW_MAXRUNS && first + nr <= n_runs; rr = runs + first; }
+                }
+                for (agx_u32 i = 0; i < nr && fits; i++) fits = (agx_u32)rr[i].q + rr[i].n <= len && (unsigned long long)rr[i].t + rr[i].n <= n_pos;
+                if (fits) {
+                    // the prediction for the whole row (agx_row_expected16's, 32 bases at a time, run by run), then the row against it
+                    unsigned long long E[W_MAX + 1] = {0}, A[W_MAX] = {0};
+                    const bool rev = agx_whit_left_rev(w);
+                    for (agx_u32 i = 0; i < nr; i++) {
+                        const agx_u32 n = rr[i].n, lo = rev ? len - rr[i].q - n : rr[i].q;
+                        const long long t = rr[i].t;
+                        for (agx_u32 k = 0; k < n; k += 32) {
+                            unsigned long long e = rev ? ~reverse_pairs32(ref_window32(packed, t + (long long)n - 32ll - (long long)k)) : ref_window32(packed, t + (long long)k);
+                            if (n - k < 32u) e &= (1ull << (2u * (n - k))) - 1ull;
+                            const agx_u32 bit = 2u * (lo + k), wd = bit >> 6, sh = bit & 63u;
+                            E[wd] |= e << sh;
+                            if (sh) E[wd + 1] |= e >> (64u - sh);
+                        }
+                    }
+                    memcpy(A, row, row_bytes);
+                    diffed = true;
+                    for (agx_u32 wd = 0; wd < n_words && diffed; wd++)
+                        for (unsigned long long x = E[wd] ^ A[wd]; x;) {
+                            const agx_u32 pair = (agx_u32)__builtin_ctzll(x) >> 1;
+                            if ((agx_u32)(out - mark) >= max_diffs) { diffed = false; break; }
+                            *out++ = (agx_u16)(((wd * 32u + pair) << 2) | (agx_u32)((A[wd] >> (2u * pair)) & 3ull));
+                            x &= ~(3ull << (2u * pair));
+                        }
+                }
+                if (diffed) { D.cnt[r] = (agx_u8)(out - mark); continue; }
+                out = mark;
+                out[expl_units - 1] = 0;                                    // (an odd number of bytes: the last unit's high byte)
+                memcpy(out, row, row_bytes);
+                out += expl_units;
+                D.cnt[r] = (agx_u8)AGX_ROW_EXPLICIT; n_expl[g]++;
+            }
+            part_n[g] = (size_t)(out - out0);
+            part[g].assign(out0, out);
+        }
+    });
+    unsigned long long total = 0;
+    for (size_t n : part_n) total += n;
+    if (total >= 0xFFFFFFF0ull) { D = RowDiffs(); return false; }
+    D.units.resize((size_t)total + 2);
+    D.block_off.assign(n_blocks + 2, 0u);
+    {   std::vector<size_t> at(n_ranges + 1, 0);
+        for (size_t g = 0; g < n_ranges; g++) { at[g + 1] = at[g] + part_n[g]; D.n_explicit += n_expl[g]; }
+        next = 0;
+        team.run([&](unsigned) {
+            for (size_t g; (g = next.fetch_add(1)) < n_ranges;) {
+                if (part_n[g]) memcpy(D.units.data() + at[g], part[g].data(), part_n[g] * 2);
+                std::vector<agx_u16>().swap(part[g]);
+                agx_u32 run = (agx_u32)at[g];
+                for (size_t b = g * per_range, hi = std::min(n_blocks, (g + 1) * per_range); b < hi; b++) { D.block_off[b] = run; for (size_t r = b * 64; r < b * 64 + 64; r++) run += agx_row_units(D.cnt[r], stride) * (r < n_rows ? 1u : 0u); }
+            }
+        });
+        D.block_off[n_blocks] = (agx_u32)total;
+    }
+    D.n_units = (size_t)total;
+    return true;
+}
+
 // loadReadAlignment's parsing half (loadSeq AG:361-404, loadReadAli AG:1233-1277 with parseBOWTIE AG:181-285 and updateContig AG:763-815) and the
 // staging, in one go.  See the head of the file.
 bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long batch, agx_u32 k, unsigned threads, StageSink &sink, StagedPairs &S) {

@@ -543,7 +543,7 @@ def main():
                               "ms_walk": round(unit_stats[uu]["ms_walk"], 2), "ms_upload_to_built": round(1e3 * unit_stats[uu]["s_upload_build"], 2),
                               "ms_unit_total": round(1e3 * unit_stats[uu]["s_total"], 2), "download_MB": round(unit_stats[uu]["download_bytes"] / 1e6, 1),
                               "build_attempts": unit_stats[uu]["build_attempts"], "spilled_ids": unit_stats[uu]["n_spilled"],
-                              "mid_tiles": unit_stats[uu]["n_mid_tiles"], "big_tiles": unit_stats[uu]["n_big_tiles"], "dense_lists": unit_stats[uu]["dense_lists"]} for uu in mine}
+                              "mid_tiles": unit_stats[uu]["n_mid_tiles"], "big_tiles": unit_stats[uu]["n_big_tiles"], "dense_lists": unit_stats[uu]["dense_lists"], "rows_by_reference": unit_stats[uu]["rows_by_reference"]} for uu in mine}
         line = {
             "metric": "aligned reads/sec through graph build+extend", "value": round(value, 1), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * sec_per_step, 3),

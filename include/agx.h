@@ -111,8 +111,10 @@ typedef struct {
     uint64_t n_spilled;                                          /* node ids taken from the pool's spill area (regions whose slice was full) */
     uint32_t build_attempts, from_cache;                         /* build_attempts: 1 unless a capacity had to grow and the build was repeated; from_cache: the unit was
                                                                     loaded from its cache file (agx_unit_cache_build), not from the text files */
-    uint32_t dense_lists, pad_;                                  /* 1: some tile's hit list outgrew its slots (or a hit spans more than four tiles) and the whole unit's lists went through the
-                                                                    dense second pass (agx_k_bin_fill) instead of the slots hit_prep fills: pile-ups, deep repeats */
+    uint32_t dense_lists, rows_by_reference;                     /* dense_lists = 1: some tile's hit list outgrew its slots (or a hit spans more than four tiles) and the whole unit's lists
+                                                                    went through the dense second pass (agx_k_bin_fill) instead of the slots hit_prep fills: pile-ups, deep repeats.
+                                                                    rows_by_reference: read rows the upload sent as their differences from the reference under their first hit's
+                                                                    alignment (0: all rows crossed as 2-bit classes — soft-masked reference, AGX_NO_ROW_DIFF=1, nothing gained) */
 } agx_stats;
 
 /* Node/edge tables in canonical numbering (position-major, variant order), for parity tests. malloc'd; free with agx_graph_free. */

@@ -466,3 +466,184 @@ extern "C" int agx_hostsim_compare_staged(const char *tmp_dir, int unit, int k, 
 // ---- the CPU quota reader (tests/test_host_misc.py): a made-up /proc/self/cgroup and /sys/fs/cgroup tree -------------------------------------
 extern "C" unsigned agx_hostsim_cgroup_quota(const char *proc_cgroup, const char *sys_root) { return agx::cgroup_cpu_quota(proc_cgroup, sys_root); }
 extern "C" unsigned agx_hostsim_usable_cpus() { return agx::usable_cpus(); }
+
+// ---- the read rows' upload form (tests/test_row_diffs.py): build_row_diffs against the decoder the device runs (agx_row_chunk16), on made-up rows ------
+// Rows are cut from a random reference under a random anchor geometry (either strand, either mate as the left one, simple or with runs, inside the unit or
+// hanging over its end), mutated at `mut_permille`; `dirty_tail` fills the bases beyond a read's length with noise (staging leaves zeros there: the codec must be
+// exact anyway).  Every row is decoded the way agx_k_expand_rows does — anchor bit -> hit -> block offset + counts in front of it -> chunks — and compared
+// with its 2-bit classes.  Returns 0 and the unit / explicit-row counts, or the first mismatch in msg.
+extern "C" int agx_hostsim_rowdiff_roundtrip(unsigned seed, unsigned n_pos, unsigned n_rows, unsigned stride, unsigned maxlen, unsigned mut_permille, int dirty_tail, unsigned threads,
+                                             unsigned long long *n_units, unsigned long long *n_explicit, char *msg, size_t msg_len) {
+    auto say = [&](const std::string &m) { if (msg && msg_len) snprintf(msg, msg_len, "%s", m.c_str()); };
+    say("");
+    try {
+        uint64_t st = seed * 0x9E3779B97F4A7C15ull + 12345;
+        auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (agx_u32)(st >> 11); };
+        std::string ref(n_pos, 'A');
+        for (auto &c : ref) { const agx_u32 r = rnd() % 1000; c = r < 3 ? 'N' : "ACGT"[r & 3]; }
+        std::vector<agx_u8> packed((n_pos + 3) / 4 + 64, 0xA5);
+        std::vector<agx_refx> others;
+        if (!pack_reference(ref.data(), n_pos, 2, packed.data(), others)) { say("reference did not pack"); return 2; }
+        std::vector<agx_u32> wref(packed.size() / 4 + 1); memcpy(wref.data(), packed.data(), packed.size());
+        const size_t row_bytes = stride / 4;
+        std::vector<agx_u8> codes((size_t)n_rows * row_bytes + 16, 0);
+        std::vector<agx_whit> hits; std::vector<agx_wside> sides; std::vector<agx_wrun> runs;
+        std::vector<agx_u32> order(n_rows);
+        for (agx_u32 r = 0; r < n_rows; r++) order[r] = r;
+        if ((seed & 3u) == 1u) for (agx_u32 r = n_rows; r > 1; r--) std::swap(order[r - 1], order[rnd() % r]);      // rows not in hit order: the form must be declined
+        for (agx_u32 i = 0; i < n_rows; i++) {
+            const agx_u32 r = order[i];
+            if ((seed & 3u) == 2u && rnd() % 50 == 0) continue;            // a row no hit names: declined as well
+            const agx_u32 len = 1 + rnd() % maxlen, nhit = 1 + (rnd() % 8 == 0);
+            for (agx_u32 e = 0; e < nhit; e++) {
+                agx_whit w; memset(&w, 0, sizeof w);
+                const bool left2 = rnd() & 1, rev = rnd() & 1, multi = rnd() % 4 == 0, over = rnd() % 40 == 0, other_multi = rnd() % 4 == 0;
+                const agx_u32 t0 = over ? n_pos - rnd() % len : (n_pos > len ? rnd() % (n_pos - len + 1) : 0);
+                w.row = r; w.len = (agx_u16)len; w.back = (agx_u8)e;
+                w.flags = (agx_u8)((left2 ? AGX_WF_LEFT2 : 0) | (rev ? (left2 ? AGX_WF_REV2 : AGX_WF_REV1) : (left2 ? AGX_WF_REV1 : AGX_WF_REV2)));
+                // the left mate's runs: pieces of the read with a few bases skipped between them in the read (insertion) or in the reference (deletion); now and then
+                // a run that does not fit the read or the unit (the encoder must keep such a row as it is)
+                std::vector<agx_wrun> mine;
+                if (multi) {
+                    agx_u32 q = rnd() % 3, t = t0;
+                    const agx_u32 nr = 1 + rnd() % 4;
+                    for (agx_u32 k = 0; k < nr && q < len; k++) {
+                        const agx_u32 n = 1 + rnd() % (len - q);
+                        mine.push_back(agx_wrun{t, (agx_u16)q, (agx_u16)n});
+                        q += n; t += n;
+                        if (rnd() & 1) q += 1 + rnd() % 3; else t += 1 + rnd() % 5;
+                    }
+                    if (rnd() % 30 == 0 && !mine.empty()) mine.back().n = (agx_u16)(mine.back().n + 1 + rnd() % 4);      // beyond the read
+                } else mine.push_back(agx_wrun{t0, 0, (agx_u16)len});
+                agx_wside sd{0, 0, 0};
+                if (multi) { (left2 ? sd.runs2 : sd.runs1) = (agx_u32)runs.size(); sd.nruns = left2 ? (agx_u32)mine.size() << 16 : (agx_u32)mine.size(); runs.insert(runs.end(), mine.begin(), mine.end()); w.flags |= left2 ? AGX_WF_RUNS2 : AGX_WF_RUNS1; }
+                if (other_multi) { (left2 ? sd.runs1 : sd.runs2) = (agx_u32)runs.size(); sd.nruns |= left2 ? 1u : 1u << 16; runs.push_back(agx_wrun{rnd() % n_pos, 0, 1}); w.flags |= left2 ? AGX_WF_RUNS1 : AGX_WF_RUNS2; }
+                (left2 ? w.b : w.a) = t0; (left2 ? w.a : w.b) = rnd();
+                if (multi || other_multi) { agx_u32 &field = (w.flags & AGX_WF_RUNS1) ? w.a : w.b; field = (agx_u32)sides.size(); sides.push_back(sd); }
+                if (e == 0) {                                              // the anchor: the row's bases follow its geometry
+                    for (agx_u32 j = 0; j < stride; j++) {
+                        agx_u32 cls;
+                        if (j >= len) cls = dirty_tail ? rnd() & 3u : 0u;
+                        else {
+                            const agx_u32 q = rev ? len - 1 - j : j;
+                            unsigned long long x = ~0ull;
+                            for (const agx_wrun &g : mine) if (q >= g.q && q < (agx_u32)g.q + g.n) x = (unsigned long long)g.t + (q - g.q);
+                            cls = x < n_pos ? (agx_ref_code((agx_u8)ref[x]) & 3u) : rnd() & 3u;      // (inserted and clipped bases: anything)
+                            if (rev && x < n_pos) cls = 3u - cls;
+                            if (rnd() % 1000 < mut_permille) cls = rnd() & 3u;
+                        }
+                        codes[(size_t)r * row_bytes + j / 4] |= (agx_u8)(cls << (2 * (j & 3)));
+                    }
+                }
+                hits.push_back(w);
+            }
+        }
+        RowDiffs D;
+        if (!build_row_diffs(hits.data(), hits.size(), sides.data(), sides.size(), runs.data(), runs.size(), codes.data(), n_rows, stride, wref.data(), n_pos, threads, D)) { say("build_row_diffs declined"); return 3; }
+        if (n_units) *n_units = D.n_units;
+        if (n_explicit) *n_explicit = D.n_explicit;
+        // as agx_k_expand_rows does it: a block of 64 rows, each row's anchor by counting anchor bits, its units by adding up the counts in front of it, the whole row decoded
+        {   std::vector<agx_u8> out(stride + 16);
+            for (agx_u32 row = 0; row < n_rows; row++) {
+                const agx_u32 blk = row >> 6, h = agx_anchor_select(D.anchor_bits.data(), D.block_first[blk], row & 63u);
+                if (h >= hits.size() || hits[h].row != row) { say("row " + std::to_string(row) + ": anchor_select names hit " + std::to_string(h)); return 7; }
+                agx_u32 off = D.block_off[blk];
+                for (agx_u32 r = row & ~63u; r < row; r++) off += agx_row_units(D.cnt[r], stride);
+                const agx_whit w = hits[h]; const agx_u32 cnt = D.cnt[row];
+                const agx_wrun *left = nullptr; agx_u32 nruns = 0;
+                if (cnt != AGX_ROW_EXPLICIT && !agx_whit_left_simple(w)) { const agx_wside sd = sides[agx_whit_side(w)]; left = runs.data() + agx_wside_left_first(w, sd); nruns = agx_wside_left_count(w, sd); }
+                std::fill(out.begin(), out.end(), (agx_u8)0xEE);
+                agx_row_decode(wref.data(), D.units.data() + off, cnt, w, left, nruns, stride, out.data());
+                for (agx_u32 j = 0; j < stride; j++) {
+                    const agx_u8 want = agx_class_vote_code((codes[(size_t)row * row_bytes + j / 4] >> (2 * (j & 3))) & 3u);
+                    if (out[j] != want) { say("row " + std::to_string(row) + " base " + std::to_string(j) + ": vote code " + std::to_string(out[j]) + " for " + std::to_string(want) + " (count byte " + std::to_string(cnt) + ")"); return 8; }
+                }
+                if (out[stride] != 0xEE) { say("row " + std::to_string(row) + " was written beyond its stride"); return 9; }
+            }
+        }
+        std::vector<agx_u8> seen(n_rows, 0);
+        for (size_t h = 0; h < hits.size(); h++) {
+            if (!((D.anchor_bits[h >> 5] >> (h & 31)) & 1u)) continue;
+            const agx_whit w = hits[h];
+            const agx_u32 row = w.row;
+            if (seen[row]) { say("two anchors for row " + std::to_string(row)); return 4; }
+            seen[row] = 1;
+            agx_u32 off = D.block_off[row >> 6];
+            for (agx_u32 r = row & ~63u; r < row; r++) off += agx_row_units(D.cnt[r], stride);
+            const agx_u32 cnt = D.cnt[row];
+            if ((size_t)off + agx_row_units(cnt, stride) > D.n_units) { say("row " + std::to_string(row) + " runs past the stream"); return 5; }
+            const agx_wrun *left = nullptr; agx_u32 nruns = 0;      // (as agx_k_expand_rows finds them)
+            if (cnt != AGX_ROW_EXPLICIT && !agx_whit_left_simple(w)) { const agx_wside sd = sides[agx_whit_side(w)]; left = runs.data() + agx_wside_left_first(w, sd); nruns = agx_wside_left_count(w, sd); }
+            for (agx_u32 j0 = 0; j0 < stride; j0 += 16) {
+                const agx_u32 c = agx_row_chunk16(wref.data(), D.units.data() + off, cnt, w, left, nruns, j0, stride);
+                for (agx_u32 j = j0; j < std::min(stride, j0 + 16); j++) {
+                    const agx_u32 want = (codes[(size_t)row * row_bytes + j / 4] >> (2 * (j & 3))) & 3u, got = (c >> (2 * (j - j0))) & 3u;
+                    if (want != got) { say("row " + std::to_string(row) + " base " + std::to_string(j) + ": " + std::to_string(got) + " for " + std::to_string(want) + " (count byte " + std::to_string(cnt) + ")"); return 1; }
+                }
+            }
+        }
+        for (const agx_whit &w : hits) if (!seen[w.row]) { say("row " + std::to_string(w.row) + " has hits but no anchor"); return 6; }
+        return 0;
+    } catch (const Error &e) { say(e.msg); return 100 + e.code; }
+    catch (const std::exception &e) { say(e.what()); return 99; }
+}
+
+// The same on a unit's real files: general loaders -> stage_pairs -> pack_reference -> build_row_diffs, every row decoded the device's way and compared with its
+// 2-bit classes; out[0..3] = rows, rows kept as they are, bytes of the 2-bit rows, bytes of the upload form.  -2: the unit sequence does not pack (soft-masked).
+extern "C" int agx_hostsim_rowdiff_unit(const char *tmp_dir, int unit, int k, long batch, int threads, unsigned long long *out, char *msg, size_t msg_len) {
+    auto say = [&](const std::string &m) { if (msg && msg_len) snprintf(msg, msg_len, "%s", m.c_str()); };
+    say("");
+    try {
+        const std::string d = tmp_dir, s = std::to_string(unit);
+        struct VSink : StageSink { std::vector<std::vector<char>> keep; void *take(int, size_t bytes) override { keep.emplace_back(bytes + 64); return keep.back().data(); } } A;
+        Threads T; Pairs P; StagedPairs S;
+        load_unit_reference(d + "/_genome." + s + ".fa", T.ref);
+        thread_contigs_from_files(d + "/_contigs.fa", d + "/_contigs_genome." + s + ".psl", T);      // (appends positions to the unit sequence)
+        load_pairs_from_files(d + "/_reads.fa", d + "/_reads_genome." + s + ".bowtie", batch, (agx_u32)k, P, nullptr);
+        stage_pairs(P, (agx_u32)k, (unsigned)threads, A, S);
+        const size_t n_pos = T.ref.size();
+        std::vector<agx_u8> packed((n_pos + 3) / 4 + 64, 0x5A);
+        std::vector<agx_refx> others;
+        if (!pack_reference(T.ref.data(), n_pos, 2, packed.data(), others)) return -2;
+        std::vector<agx_u32> wref(packed.size() / 4 + 1); memcpy(wref.data(), packed.data(), packed.size());
+        RowDiffs D;
+        if (!build_row_diffs(S.hits, S.nh, S.sides, S.n_sides, S.runs, S.n_runs, S.codes, S.n_rows, S.stride, wref.data(), n_pos, (unsigned)threads, D)) { say("build_row_diffs declined"); return 3; }
+        out[0] = S.n_rows; out[1] = D.n_explicit; out[2] = S.n_codes; out[3] = D.n_units * 2 + D.cnt.size() + (D.block_off.size() + D.block_first.size() + D.anchor_bits.size()) * 4;
+        {   std::vector<agx_u8> o(S.stride + 16);
+            for (agx_u32 row = 0; row < S.n_rows; row++) {
+                const agx_u32 blk = row >> 6, h = agx_anchor_select(D.anchor_bits.data(), D.block_first[blk], row & 63u);
+                if (h >= S.nh || S.hits[h].row != row) { say("row " + std::to_string(row) + ": anchor_select names hit " + std::to_string(h)); return 7; }
+                agx_u32 off = D.block_off[blk];
+                for (agx_u32 r = row & ~63u; r < row; r++) off += agx_row_units(D.cnt[r], S.stride);
+                const agx_whit w = S.hits[h]; const agx_u32 cnt = D.cnt[row];
+                const agx_wrun *left = nullptr; agx_u32 nruns = 0;
+                if (cnt != AGX_ROW_EXPLICIT && !agx_whit_left_simple(w)) { const agx_wside sd = S.sides[agx_whit_side(w)]; left = S.runs + agx_wside_left_first(w, sd); nruns = agx_wside_left_count(w, sd); }
+                agx_row_decode(wref.data(), D.units.data() + off, cnt, w, left, nruns, S.stride, o.data());
+                for (agx_u32 j = 0; j < S.stride; j++) {
+                    const agx_u8 want = agx_class_vote_code((S.codes[(size_t)row * (S.stride / 4) + j / 4] >> (2 * (j & 3))) & 3u);
+                    if (o[j] != want) { say("row " + std::to_string(row) + " base " + std::to_string(j) + ": vote code " + std::to_string(o[j]) + " for " + std::to_string(want)); return 8; }
+                }
+            }
+        }
+        const size_t row_bytes = S.stride / 4;
+        std::vector<agx_u8> seen(S.n_rows, 0);
+        for (size_t h = 0; h < S.nh; h++) {
+            if (!((D.anchor_bits[h >> 5] >> (h & 31)) & 1u)) continue;
+            const agx_whit w = S.hits[h]; const agx_u32 row = w.row;
+            if (seen[row]) { say("two anchors for row " + std::to_string(row)); return 4; }
+            seen[row] = 1;
+            agx_u32 off = D.block_off[row >> 6];
+            for (agx_u32 r = row & ~63u; r < row; r++) off += agx_row_units(D.cnt[r], S.stride);
+            const agx_wrun *left = nullptr; agx_u32 nruns = 0;
+            if (D.cnt[row] != AGX_ROW_EXPLICIT && !agx_whit_left_simple(w)) { const agx_wside sd = S.sides[agx_whit_side(w)]; left = S.runs + agx_wside_left_first(w, sd); nruns = agx_wside_left_count(w, sd); }
+            for (agx_u32 j0 = 0; j0 < S.stride; j0 += 16) {
+                const agx_u32 c = agx_row_chunk16(wref.data(), D.units.data() + off, D.cnt[row], w, left, nruns, j0, S.stride);
+                agx_u32 want = 0; memcpy(&want, S.codes + (size_t)row * row_bytes + j0 / 4, std::min<size_t>(4, row_bytes - j0 / 4));
+                if (c != want) { say("row " + std::to_string(row) + " bases " + std::to_string(j0) + "..: " + std::to_string(c) + " for " + std::to_string(want)); return 1; }
+            }
+        }
+        for (size_t r = 0; r < S.n_rows; r++) if (!seen[r]) { say("row " + std::to_string(r) + " has no anchor"); return 6; }
+        return 0;
+    } catch (const Error &e) { say(e.msg); return 100 + e.code; }
+    catch (const std::exception &e) { say(e.what()); return 99; }
+}

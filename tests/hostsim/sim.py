@@ -122,3 +122,33 @@ def usable_cpus():
     L = _lib_now()
     L.agx_hostsim_usable_cpus.restype = ctypes.c_uint
     return int(L.agx_hostsim_usable_cpus())
+
+
+def rowdiff_roundtrip(seed, n_pos, n_rows, stride, maxlen, mut_permille=20, dirty_tail=False, threads=4):
+    """build_row_diffs + the device's decoder on made-up rows; returns (units, explicit rows); raises SimError on a mismatch."""
+    L = _lib_now()
+    f = L.agx_hostsim_rowdiff_roundtrip
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_uint] * 6 + [ctypes.c_int, ctypes.c_uint, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_char_p, ctypes.c_size_t]
+    nu, ne = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+    msg = ctypes.create_string_buffer(512)
+    rc = f(seed, n_pos, n_rows, stride, maxlen, mut_permille, int(bool(dirty_tail)), threads, ctypes.byref(nu), ctypes.byref(ne), msg, 512)
+    if rc != 0:
+        raise SimError(rc, msg.value.decode())
+    return nu.value, ne.value
+
+
+def rowdiff_unit(tmp_dir, unit, k=5, batch=1000000, threads=4):
+    """The rows of a unit's real files through build_row_diffs and the device's decoder: {rows, explicit, bytes_2bit, bytes_upload}; None if the unit sequence does not pack."""
+    L = _lib_now()
+    f = L.agx_hostsim_rowdiff_unit
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_char_p, ctypes.c_size_t]
+    out = (ctypes.c_ulonglong * 4)()
+    msg = ctypes.create_string_buffer(512)
+    rc = f(str(tmp_dir).encode(), unit, k, batch, threads, out, msg, 512)
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise SimError(rc, msg.value.decode())
+    return {"rows": out[0], "explicit": out[1], "bytes_2bit": out[2], "bytes_upload": out[3]}

@@ -1,5 +1,6 @@
 """Parity tests proper (-m gpu): the HIP engine through the C-ABI against the oracle and the reference's golden vectors."""
 import os
+import shutil
 
 import pytest
 
@@ -430,3 +431,48 @@ def test_read_alignments_handed_over_staged(agx, built, tmp_path):
         with agx.Unit(k=5, insert_variation=50, coverage=3) as u:
             with pytest.raises(agx.AgxError):
                 u.load_files(tmp, uu)                                # (no current cache, no staged pairs, no text)
+
+
+@pytest.mark.gpu
+def test_read_rows_cross_as_differences_from_the_reference(agx, built, tmp_path, monkeypatch):
+    """The upload sends a unit's read rows as their differences from the reference under each row's first hit (agx_core.h "read rows relative to the reference";
+    agx_k_expand_rows turns them back into vote codes); AGX_NO_ROW_DIFF=1 keeps the 2-bit rows (agx_k_expand_codes).  Both ways give the oracle's three files and the
+    same node and edge tables — on reads with indels, clips, N bases, both strands, several hits per pair — and the first way sends fewer bytes.  A soft-masked unit
+    sequence (the reference crosses as bytes, nothing to predict from) keeps the 2-bit rows by itself.  (tests/test_row_diffs.py: the codec on the CPU.)"""
+    kw = dict(seed=91, chroms="70000,30000", pairs=30000, coverage=3, L=150, k=21, read_indel=0.25, read_clip=0.1, multi=0.3, read_n=0.02, indel=0.003, contig_overlap=0.3, sam_seq=0)
+    run = H.synth(str(tmp_path / "run"), **kw)
+    tmp = os.path.join(run, "tmp")
+
+    def both_ways(tmp_dir, uu, expect_diffed=True, flags=0):
+        graph = flags == 0
+        monkeypatch.setenv("AGX_NO_ROW_DIFF", "1")
+        a = run_engine(agx, tmp_dir, uu, 21, 50, 3, graph=graph, flags=flags)
+        monkeypatch.delenv("AGX_NO_ROW_DIFF")
+        b = run_engine(agx, tmp_dir, uu, 21, 50, 3, graph=graph, flags=flags)
+        sa, sb = a["stats"], b["stats"]
+        assert sa["rows_by_reference"] == 0
+        for key in ("initial", "pre", "extended"):
+            assert a[key] == b[key], key
+        if graph:
+            assert graph_mismatch(a["graph"], b["graph"]) is None
+        if expect_diffed:
+            assert sb["rows_by_reference"] > 0.4 * sb["n_hits"] and sb["upload_bytes"] < 0.85 * sa["upload_bytes"], (sa["upload_bytes"], sb["upload_bytes"], sb["rows_by_reference"])
+        else:
+            assert sb["rows_by_reference"] == 0 and sb["upload_bytes"] == sa["upload_bytes"]
+        return b
+
+    for uu in range(2):
+        want = H.run_oracle(tmp, uu, 21, 50, 3)
+        got = both_ways(tmp, uu)
+        for key in ("initial", "pre", "extended"):
+            assert got[key] == want[key], key
+    assert both_ways(tmp, 0, flags=agx.AGX_FLAG_ONE_SHOT)["extended"] == H.run_oracle(tmp, 0, 21, 50, 3)["extended"]
+    agx.cache_build(tmp, 1)                                          # from the unit cache: the rows are made again from the cached 2-bit rows
+    both_ways(tmp, 1)
+    # a soft-masked unit sequence
+    masked = str(tmp_path / "masked"); shutil.copytree(tmp, masked)
+    os.remove(os.path.join(masked, "_agx_unit.1.bin"))
+    gp = os.path.join(masked, "_genome.0.fa")
+    lines = open(gp).read().split("\n")
+    open(gp, "w").write("\n".join(ln if ln.startswith(">") else "".join(c.lower() if (i // 7) % 2 else c for i, c in enumerate(ln)) for ln in lines))
+    both_ways(masked, 0, expect_diffed=False)
