@@ -65,10 +65,11 @@ inline BlockCache &dev_cache(int device) { static BlockCache c[64]; return c[dev
 class DevRegion {
 public:
     bool owns(const void *p) const { return base_ && (const char *)p >= base_ && (const char *)p < base_ + size_; }
-    bool alloc(int device, size_t need, MemBlock &out) {      // false: this device has no region and none could be made (the caller takes the driver's path)
+    // false: this device has no region and none could be made — or none exists and `make` says not to make one — (the caller takes the driver's path)
+    bool alloc(int device, size_t need, MemBlock &out, bool make = true) {
         std::unique_lock<std::mutex> g(m_);
         if (!base_) {
-            if (tried_) return false;
+            if (tried_ || !make) return false;
             tried_ = true;
             size_t fr = 0, tot = 0;
             if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -112,8 +113,13 @@ inline void dev_give(int device, const MemBlock &b) { if (!b.p) return; if (dev_
 
 inline MemBlock dev_block(int device, size_t need) {
     MemBlock b; need = round_block(need ? need : 1);
-    if (need >= AGX_REGION_MIN && !getenv("AGX_NO_REGION") && dev_region(device).alloc(device, need, b)) return b;
+    const bool region = !getenv("AGX_NO_REGION");
+    if (need >= AGX_REGION_MIN && region && dev_region(device).alloc(device, need, b)) return b;
     if (dev_cache(device).take(need, b, 16)) return b;
+    // A device whose region exists (some unit was large enough to make it) has handed most of its memory to it: smaller blocks that the cache cannot serve come out of
+    // the region as well.  (r04: the quarter-size human job — 8 units of 8-15 GB beside 16 of 3-8 GB — ran out of the 15 % the region had left, gave its cached blocks back to
+    // the driver and then waited in hipMalloc: 2.4 s per job instead of 0.2.)  A device that never sees a large unit keeps recycling whole blocks, as before.
+    if (region && dev_region(device).alloc(device, need, b, false)) return b;
     AGX_HIP_OK(hipSetDevice(device));
     hipError_t e = hipMalloc(&b.p, need);
     if (e != hipSuccess) {                       // out of HBM: give the cached blocks back to the driver and try once more
