@@ -414,13 +414,15 @@ void reserve_landing(agx_unit *u) {
     // (a buffer must fit one block: count the blocks at 85 %)
     if (need > have * 85 / 100) u->s_landing.alloc(need - have * 85 / 100 + (ni + 512)); else u->s_landing.release();
 }
-// The read rows for the upload: differences against the reference where that is the shorter form (agx_core.h; build_row_diffs in agx_load.cpp).  Needs the packed
-// reference; AGX_NO_ROW_DIFF=1 keeps the 2-bit rows (tests compare the two).  The 2-bit rows stay where they are: the walk of a unit handed over staged reads k-mer
-// tails out of them, and a one-shot unit's download lands in their memory.
+// The read rows for the upload as differences against the reference (agx_core.h; build_row_diffs in agx_load.cpp): AGX_ROW_DIFF=1 asks for it.  It is NOT the default:
+// it takes 36-44 % off a unit's upload (66 -> 36 bytes per pair at 2x150) but no measured job is bound by its uploads — cfg3 36.4 against 36.5 ms, the 24-unit human
+// shapes 50.0 against 49.4 ms (1/16) and 187 against 183 ms (1/4) per job — while making the form costs the loader 30-60 ns per row (T_unit + 0.1 s at cfg3).  For hosts
+// whose ranks share a link or memory bandwidth.  Needs the packed reference.  The 2-bit rows stay where they are either way: the walk of a unit handed over staged reads
+// k-mer tails out of them, and a one-shot unit's download lands in their memory.
 void stage_rows(agx_unit *u, unsigned threads) {
     u->rows_diffed = false; u->n_units = u->n_rowcnt = u->n_blockoff = u->n_blockfirst = u->n_anchor = u->n_rows_explicit = 0;
-    const char *off = getenv("AGX_NO_ROW_DIFF");
-    if ((off && atoi(off) != 0) || !u->ref_packed || u->n_rows == 0 || u->nh == 0) return;
+    const char *on = getenv("AGX_ROW_DIFF");
+    if (!on || atoi(on) == 0 || !u->ref_packed || u->n_rows == 0 || u->nh == 0) return;
     const double t0 = now_ms();
     RowDiffs D;
     if (!build_row_diffs(u->s_hits.p, u->nh, u->s_sides.p, u->n_sides, u->s_runs.p, u->n_runs, u->s_codes.p, u->n_rows, u->stride, (const agx_u32 *)u->s_ref.p, u->V.n_pos ? u->V.n_pos : u->T.ref.size(), threads, D)) return;

@@ -114,7 +114,7 @@ typedef struct {
     uint32_t dense_lists, rows_by_reference;                     /* dense_lists = 1: some tile's hit list outgrew its slots (or a hit spans more than four tiles) and the whole unit's lists
                                                                     went through the dense second pass (agx_k_bin_fill) instead of the slots hit_prep fills: pile-ups, deep repeats.
                                                                     rows_by_reference: read rows the upload sent as their differences from the reference under their first hit's
-                                                                    alignment (0: all rows crossed as 2-bit classes — soft-masked reference, AGX_NO_ROW_DIFF=1, nothing gained) */
+                                                                    alignment (AGX_ROW_DIFF=1; 0: all rows crossed as 2-bit classes — the default; a soft-masked reference) */
 } agx_stats;
 
 /* Node/edge tables in canonical numbering (position-major, variant order), for parity tests. malloc'd; free with agx_graph_free. */

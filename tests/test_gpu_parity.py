@@ -435,20 +435,21 @@ def test_read_alignments_handed_over_staged(agx, built, tmp_path):
 
 @pytest.mark.gpu
 def test_read_rows_cross_as_differences_from_the_reference(agx, built, tmp_path, monkeypatch):
-    """The upload sends a unit's read rows as their differences from the reference under each row's first hit (agx_core.h "read rows relative to the reference";
-    agx_k_expand_rows turns them back into vote codes); AGX_NO_ROW_DIFF=1 keeps the 2-bit rows (agx_k_expand_codes).  Both ways give the oracle's three files and the
-    same node and edge tables — on reads with indels, clips, N bases, both strands, several hits per pair — and the first way sends fewer bytes.  A soft-masked unit
-    sequence (the reference crosses as bytes, nothing to predict from) keeps the 2-bit rows by itself.  (tests/test_row_diffs.py: the codec on the CPU.)"""
+    """AGX_ROW_DIFF=1: the upload sends a unit's read rows as their differences from the reference under each row's first hit (agx_core.h "read rows relative to the
+    reference"; agx_k_expand_rows turns them back into vote codes) instead of as 2-bit rows (agx_k_expand_codes, the default).  Both ways give the oracle's three files
+    and the same node and edge tables — on reads with indels, clips, N bases, both strands, several hits per pair — and the first way sends fewer bytes.  A soft-masked
+    unit sequence (the reference crosses as bytes, nothing to predict from) keeps the 2-bit rows by itself.  (tests/test_row_diffs.py: the codec on the CPU.)"""
     kw = dict(seed=91, chroms="70000,30000", pairs=30000, coverage=3, L=150, k=21, read_indel=0.25, read_clip=0.1, multi=0.3, read_n=0.02, indel=0.003, contig_overlap=0.3, sam_seq=0)
     run = H.synth(str(tmp_path / "run"), **kw)
     tmp = os.path.join(run, "tmp")
 
     def both_ways(tmp_dir, uu, expect_diffed=True, flags=0):
         graph = flags == 0
-        monkeypatch.setenv("AGX_NO_ROW_DIFF", "1")
+        monkeypatch.delenv("AGX_ROW_DIFF", raising=False)
         a = run_engine(agx, tmp_dir, uu, 21, 50, 3, graph=graph, flags=flags)
-        monkeypatch.delenv("AGX_NO_ROW_DIFF")
+        monkeypatch.setenv("AGX_ROW_DIFF", "1")
         b = run_engine(agx, tmp_dir, uu, 21, 50, 3, graph=graph, flags=flags)
+        monkeypatch.delenv("AGX_ROW_DIFF")
         sa, sb = a["stats"], b["stats"]
         assert sa["rows_by_reference"] == 0
         for key in ("initial", "pre", "extended"):
