@@ -65,11 +65,12 @@ inline BlockCache &dev_cache(int device) { static BlockCache c[64]; return c[dev
 class DevRegion {
 public:
     bool owns(const void *p) const { return base_ && (const char *)p >= base_ && (const char *)p < base_ + size_; }
-    // false: this device has no region and none could be made — or none exists and `make` says not to make one — (the caller takes the driver's path)
-    bool alloc(int device, size_t need, MemBlock &out, bool make = true) {
+    // false: this device has no region and none could be made (the caller takes the driver's path).  `large` = false (a block below AGX_REGION_MIN): no region is made
+    // for it and it does not wait for room either — a unit that grows a capacity while every other unit in flight waits for room would wait for itself
+    bool alloc(int device, size_t need, MemBlock &out, bool large = true) {
         std::unique_lock<std::mutex> g(m_);
         if (!base_) {
-            if (tried_ || !make) return false;
+            if (tried_ || !large) return false;
             tried_ = true;
             size_t fr = 0, tot = 0;
             if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -88,7 +89,7 @@ public:
                 in_use_++; out = MemBlock{base_ + off, need};
                 return true;
             }
-            if (in_use_ == 0) return false;                   // (cannot happen: an empty region is one range)
+            if (in_use_ == 0 || !large) return false;         // (the first cannot happen: an empty region is one range)
             if (cv_.wait_for(g, std::chrono::seconds(120)) == std::cv_status::timeout) throw Error{E_DEVICE, "no room in the device's memory region for two minutes: units in flight exceed the device"};
         }
     }
