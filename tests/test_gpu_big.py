@@ -254,6 +254,14 @@ def test_cfg5_whole_human_at_full_size(agx, built, tmp_path, monkeypatch):
     import shutil
     from concurrent.futures import ThreadPoolExecutor
     from aligngraph_amd import shard
+    # what the job needs of the box: 66 GB of scratch disk (staged alignments 23 GB, contig text, the checkers' SAM) and ~150 GB of host memory (24 staged units)
+    free_disk = shutil.disk_usage(str(tmp_path)).free
+    try:
+        mem_limit = int(open("/sys/fs/cgroup/memory.max").read())
+    except (OSError, ValueError):
+        mem_limit = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+    if free_disk < 70e9 or mem_limit < 200e9:
+        pytest.skip("configs[4] at full size needs 70 GB of scratch disk and 200 GB of host memory (here: %.0f GB, %.0f GB)" % (free_disk / 1e9, mem_limit / 1e9))
     CHECK = (20, 21, 23)                                       # chr21, chr22, chrY
     run = H.synth(str(tmp_path / "run"), seed=1000, chroms=",".join(map(str, HUMAN)), pairs=400000000, L=150, k=5, coverage=5, sam_seq=0, threads=THREADS,
                   pairs_bin=1, lean=1, oracle_units=",".join(map(str, CHECK)))
