@@ -213,11 +213,19 @@ def main():
     if args.config is None:
         if world == 1:
             args.config = "cfg3"
-        else:      # the whole-human configuration where the box can hold it (64 GB of disk, ~60 GB of host memory while it is generated), else its shape at 1/4
+        else:      # the whole-human configuration where the box can hold it (64 GB of disk, ~60 GB of host memory while it is generated), else its shape at 1/4.
+            # Rank 0 decides for everybody: a rank that looked at the disk after rank 0 had begun to write the inputs could decide otherwise.
             import shutil
-            os.makedirs(args.workdir, exist_ok=True)
-            have = os.path.exists(os.path.join(args.workdir, "cfg5_full", "synth_meta.txt"))
-            args.config = "cfg5" if (have or shutil.disk_usage(args.workdir).free > 70e9) and mem_limit > 150e9 else "cfg5q"
+            choice = [None]
+            if rank == 0:
+                os.makedirs(args.workdir, exist_ok=True)
+                have = os.path.exists(os.path.join(args.workdir, "cfg5_full", "synth_meta.txt"))
+                choice[0] = "cfg5" if (have or shutil.disk_usage(args.workdir).free > 70e9) and mem_limit > 150e9 else "cfg5q"
+            dist.broadcast_object_list(choice, src=0)
+            args.config = choice[0]
+            if args.config == "cfg5q":      # staged like cfg5 (17 GB instead of 49 GB of text, a minute to generate) and kept for the runs at the other rank counts
+                os.environ["AGX_BENCH_STAGED"] = "1"
+                args.keep = True
     if not args.host_gb:
         args.host_gb = min(160.0, 0.4 * mem_limit / 1e9) / max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if args.config == "custom":
