@@ -1055,7 +1055,7 @@ void do_build(agx_unit *u) {
                 u->huge = true; u->d_huge_list.alloc(u->arena, (size_t)u->n_tiles + 1); u->d_scratch_huge.alloc(u->arena, (size_t)AGX_HUGE_WAVES * AGX_NF * AGX_MAXV_HUGE * 64);
                 HIP_OK(hipEventRecord(u->ev_uploaded, turn.down)); continue;
             }
-            if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than 1024 node variants at one position"};
+            if (w[W_STATUS] & 2u) throw Error{E_OVERFLOW, "more than " + std::to_string(AGX_MAXV_HUGE) + " node variants at one position"};
             if (w[W_STATUS] & 1u) {                  // the node pool ran out: cut the slices to what the regions asked for
                 std::vector<agx_u32> padded((size_t)u->n_regions * AGX_REGION_PAD), demand(u->n_regions);
                 HIP_OK(hipMemcpyAsync(padded.data(), u->d_pool_cnt.p, padded.size() * 4, hipMemcpyDeviceToHost, turn.down)); HIP_OK(hipStreamSynchronize(turn.down));
@@ -1073,7 +1073,7 @@ void do_build(agx_unit *u) {
         const unsigned long long ids = (unsigned long long)n_pos + w[W_N + 1];
         if (ids >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "walk graph exceeds 2^32 ids"};
         u->n_ids = (agx_u32)ids; u->n_special = w[W_N + 2];
-        u->stats.build_attempts = (uint32_t)attempt + 1; u->stats.n_spilled = w[W_SPILL]; u->stats.dense_lists = (w[W_RANKOVF] | w[W_SLOTOVF]) ? 1u : 0u;
+        u->stats.build_attempts = (uint32_t)attempt + 1; u->stats.n_spilled = w[W_SPILL]; u->stats.dense_lists = w[W_RANKOVF] ? 2u : w[W_SLOTOVF] ? 1u : 0u;
 #ifdef AGX_SWEEP_STATS
         {   const agx_u32 *c = w + W_N + 6;
             fprintf(stderr, "[agx sweep stats] wave-entries %u (lanes with an arrival %u = %.1f per entry); leave the fast path: %u entries / %u lanes; of those not a first store: %u / %u; "

@@ -64,9 +64,12 @@ inline BlockCache &dev_cache(int device) { static BlockCache c[64]; return c[dev
 #define AGX_REGION_MIN ((size_t)8 << 30)
 class DevRegion {
 public:
-    bool owns(const void *p) const { return base_ && (const char *)p >= base_ && (const char *)p < base_ + size_; }
-    // false: this device has no region and none could be made (the caller takes the driver's path).  `large` = false (a block below AGX_REGION_MIN): no region is made
-    // for it and it does not wait for room either — a unit that grows a capacity while every other unit in flight waits for room would wait for itself
+    bool owns(const void *p) const { std::lock_guard<std::mutex> g(m_); return base_ && (const char *)p >= base_ && (const char *)p < base_ + size_; }      // (under the lock: another unit's thread may be making or trimming the region)
+    // false: this device has no region and none could be made (the caller takes the driver's path).  `large` = false (a block below AGX_REGION_MIN, or ANY block of an arena
+    // that already holds one — a unit that grows a capacity: dev_block's `may_wait`): no region is made for it and it does not wait for room either — a unit that holds a
+    // block and waits for more room waits for itself, or for peers that wait the same way; it falls through to the block cache and the driver instead.
+    // The region takes AGX_REGION_PERCENT (default 85) of what is free when it is made: ONE process per device is assumed while it exists (agx.h); a host that runs several
+    // processes on a device sets the percentage per process, or AGX_NO_REGION=1.
     bool alloc(int device, size_t need, MemBlock &out, bool large = true) {
         std::unique_lock<std::mutex> g(m_);
         if (!base_) {
@@ -74,7 +77,8 @@ public:
             tried_ = true;
             size_t fr = 0, tot = 0;
             if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return false; }
-            size_t want = fr / 100 * 85 / ((size_t)16 << 20) * ((size_t)16 << 20);
+            size_t pct = 85; if (const char *e = getenv("AGX_REGION_PERCENT")) { const long v = atol(e); if (v >= 1 && v <= 95) pct = (size_t)v; }
+            size_t want = fr / 100 * pct / ((size_t)16 << 20) * ((size_t)16 << 20);
             if (const char *e = getenv("AGX_REGION_GB")) want = (size_t)atoll(e) << 30;      // (tests)
             void *p = nullptr;
             if (want < need || hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -107,15 +111,16 @@ public:
         if (base_ && in_use_ == 0) { (void)hipFree(base_); base_ = nullptr; size_ = 0; free_.clear(); tried_ = false; }
     }
 private:
-    std::mutex m_; std::condition_variable cv_; char *base_ = nullptr; size_t size_ = 0; std::map<size_t, size_t> free_; size_t in_use_ = 0; bool tried_ = false;
+    mutable std::mutex m_; std::condition_variable cv_; char *base_ = nullptr; size_t size_ = 0; std::map<size_t, size_t> free_; size_t in_use_ = 0; bool tried_ = false;
 };
 inline DevRegion &dev_region(int device) { static DevRegion r[64]; return r[device & 63]; }
 inline void dev_give(int device, const MemBlock &b) { if (!b.p) return; if (dev_region(device).owns(b.p)) dev_region(device).give(b); else dev_cache(device).give(b); }
 
-inline MemBlock dev_block(int device, size_t need) {
+// may_wait: the caller holds nothing on the device yet (an arena's first block), so it may wait for room in the region; a later block of the same arena never waits
+inline MemBlock dev_block(int device, size_t need, bool may_wait = true) {
     MemBlock b; need = round_block(need ? need : 1);
     const bool region = !getenv("AGX_NO_REGION");
-    if (need >= AGX_REGION_MIN && region && dev_region(device).alloc(device, need, b)) return b;
+    if (need >= AGX_REGION_MIN && may_wait && region && dev_region(device).alloc(device, need, b)) return b;
     if (dev_cache(device).take(need, b, 16)) return b;
     // A device whose region exists (some unit was large enough to make it) has handed most of its memory to it: smaller blocks that the cache cannot serve come out of
     // the region as well.  (r04: the quarter-size human job — 8 units of 8-15 GB beside 16 of 3-8 GB — ran out of the 15 % the region had left, gave its cached blocks back to
@@ -151,7 +156,7 @@ public:
 private:
     std::vector<MemBlock> blocks_; size_t at_ = 0, used_ = 0;
     size_t room() const { return blocks_.empty() ? 0 : blocks_.back().n - at_; }
-    void add(size_t bytes) { blocks_.push_back(dev_block(device, bytes)); at_ = 0; }
+    void add(size_t bytes) { blocks_.push_back(dev_block(device, bytes, blocks_.empty())); at_ = 0; }
 };
 
 // typed view of arena memory.  alloc() only ever grows; memory that a regrow leaves behind stays in the arena until the unit is released.

@@ -115,6 +115,23 @@ def shutil_rm(path):
     shutil.rmtree(path, ignore_errors=True)
 
 
+def in_use(run_dir):
+    """Another bench.py is reading this input directory: it holds <dir>/.in_use with its process id (a stale file of a process that is gone does not count)."""
+    try:
+        pid = int(open(os.path.join(run_dir, ".in_use")).read().strip() or "0")
+    except (OSError, ValueError):
+        return False
+    if pid == os.getpid():
+        return False
+    try:
+        os.kill(pid, 0)
+        return True
+    except ProcessLookupError:
+        return False
+    except OSError:
+        return True
+
+
 def n50_of(fasta_bytes):
     """Eval-AlignGraph's rule, EV:372-380."""
     lens = sorted((len("".join(rec.split("\n")[1:])) for rec in fasta_bytes.decode().split(">")[1:]), reverse=True)
@@ -243,7 +260,14 @@ def main():
         key, _, val = kv.partition("=")                                             # JSON line then says so in config.workload
         extra[key] = val
     staged = args.config in STAGED or os.environ.get("AGX_BENCH_STAGED") == "1"      # (the variable: any configuration through the staged hand-over — plumbing tests)
-    run = os.path.join(args.workdir, "cfg5_full" if args.config in STAGED else "staged_%s_p%d" % ("_".join(str(c) for c in chroms), pairs) if staged else "%s_p%d_k%d" % ("_".join(str(c) for c in chroms), pairs, k) + ("_x" if extra else "") + ("" if sam_seq else "_noseq"))
+    # (the staged files depend on k — which mate is the left one — and on BATCH: both are part of a staged directory's name)
+    if args.config in STAGED:
+        run_name = "cfg5_full" if k == 5 else "cfg5_full_k%d" % k
+    elif staged:
+        run_name = "staged_%s_p%d_k%d" % ("_".join(str(c) for c in chroms), pairs, k) + ("_x" if extra else "")
+    else:
+        run_name = "%s_p%d_k%d" % ("_".join(str(c) for c in chroms), pairs, k) + ("_x" if extra else "") + ("" if sam_seq else "_noseq")
+    run = os.path.join(args.workdir, run_name)
     if args.config in STAGED:
         args.keep = not args.clean
     if staged:
@@ -254,10 +278,14 @@ def main():
         import shutil
         os.makedirs(args.workdir, exist_ok=True)
         wanted = 68e9 if args.config in STAGED else pairs * (2.0 * (L + 12) + 2.0 * ((2 * L + 110) if sam_seq else 55) + 60) + 3.2 * sum(chroms)      # bytes about to be written (inputs + unit caches)
-        if shutil.disk_usage(args.workdir).free < 1.15 * wanted:      # whatever other configurations left here (the whole-human inputs are kept between runs) goes first
-            for other in os.listdir(args.workdir):
-                if other != os.path.basename(run):
-                    shutil.rmtree(os.path.join(args.workdir, other), ignore_errors=True)
+        if shutil.disk_usage(args.workdir).free < 1.15 * wanted:      # what OTHER configurations of this script left here (the whole-human inputs are kept between runs) goes first:
+            for other in os.listdir(args.workdir):                    # only directories that carry the generator's stamp (tools/agx_synth.cpp writes synth_meta.txt last), are not
+                d = os.path.join(args.workdir, other)                  # in use (a run holds <dir>/.in_use while it reads its inputs) — never anything else a --workdir may hold
+                if other != os.path.basename(run) and os.path.isfile(os.path.join(d, "synth_meta.txt")) and not in_use(d):
+                    shutil.rmtree(d, ignore_errors=True)
+            if shutil.disk_usage(args.workdir).free < 1.05 * wanted:
+                raise SystemExit("bench.py: %s has %.0f GB free, the inputs of %s need %.0f GB (nothing that is not this script's own was deleted)" %
+                                 (args.workdir, shutil.disk_usage(args.workdir).free / 1e9, args.config, 1.05 * wanted / 1e9))
         if staged:
             D.synth(run, seed=1000, chroms=",".join(str(c) for c in chroms), part=part, pairs=pairs, L=L, k=k, coverage=args.coverage, sam_seq=0,
                     threads=min(32, max(4, A.usable_cpus())), pairs_bin=1, lean=1, **extra)
@@ -267,6 +295,9 @@ def main():
     if dist:
         dist.barrier()
     t_gen = time.perf_counter() - t0
+    if rank == 0:
+        with open(os.path.join(run, ".in_use"), "w") as f:      # (a later run that needs the disk must not delete these inputs under this one)
+            f.write(str(os.getpid()))
     tmp = os.path.join(run, "tmp")
     unit_len = D.read_meta(run)["unit_len"]
     n_units = len(unit_len)
@@ -611,6 +642,11 @@ def main():
         print(json.dumps(line))
     for r in held.values():
         r.free()
+    if rank == 0:
+        try:
+            os.remove(os.path.join(run, ".in_use"))
+        except OSError:
+            pass
     for one in unit_sets:
         for un in one.values():
             un.close()

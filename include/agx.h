@@ -18,7 +18,11 @@
  * across the boundary (the reference prints to stdout and exit(-1)s; INTEGRATION.md maps codes back to its
  * messages).  There is no CPU fallback: without a HIP device agx_unit_create() fails with AGX_E_NOGPU.
  *
- * Threading: an agx_unit is single-owner.  Distinct units may be driven concurrently on distinct devices.
+ * Threading: an agx_unit is single-owner.  Distinct units may be driven concurrently, on one device or several.
+ *
+ * Device memory: ONE process per device is assumed.  The first unit of 8 GB or more makes a per-device region of AGX_REGION_PERCENT (default 85) per cent of the HBM
+ * that is free at that moment and keeps it while anything lives in it (csrc/agx_mem.h: freed HBM stalls the next hipMalloc for seconds); a host that runs several
+ * processes on one device sets the percentage per process, or AGX_NO_REGION=1 (every block then comes from hipMalloc or the cache of whole blocks).
  */
 #ifndef AGX_H
 #define AGX_H
@@ -37,7 +41,7 @@ extern "C" {
 #define AGX_E_ALIGNMENT (-4)   /* "BOWTIE ALIGNMENT ERROR" (mates on the same strand)    AG:1669 */
 #define AGX_E_DEVICE (-5)      /* HIP runtime error */
 #define AGX_E_ARG (-6)
-#define AGX_E_OVERFLOW (-7)    /* more than 1024 node variants at one position (the reference's vector<KMer> is unbounded, AG:1375-1390) */
+#define AGX_E_OVERFLOW (-7)    /* more node variants at one position than the engine holds (AGX_MAXV_HUGE in agx_core.h: 1024; the reference's vector<KMer> is unbounded, AG:1375-1390) */
 #define AGX_E_NOGPU (-8)
 
 typedef struct agx_unit agx_unit;
@@ -111,10 +115,11 @@ typedef struct {
     uint64_t n_spilled;                                          /* node ids taken from the pool's spill area (regions whose slice was full) */
     uint32_t build_attempts, from_cache;                         /* build_attempts: 1 unless a capacity had to grow and the build was repeated; from_cache: the unit was
                                                                     loaded from its cache file (agx_unit_cache_build), not from the text files */
-    uint32_t dense_lists, rows_by_reference;                     /* dense_lists = 1: some tile's hit list outgrew its slots (or a hit spans more than four tiles) and the whole unit's lists
-                                                                    went through the dense second pass (agx_k_bin_fill) instead of the slots hit_prep fills: pile-ups, deep repeats.
+    uint32_t dense_lists, rows_by_reference;                     /* dense_lists: 0 = every tile's hit list fitted the tile's own slots; 1 = SOME list outgrew its slots (pile-ups, deep repeats) and
+                                                                    those lists alone went through the dense second pass (agx_k_bin_fill); 2 = a hit spans more than four tiles, so every list of
+                                                                    the unit went through it.
                                                                     rows_by_reference: read rows the upload sent as their differences from the reference under their first hit's
-                                                                    alignment (AGX_ROW_DIFF=1; 0: all rows crossed as 2-bit classes — the default; a soft-masked reference) */
+                                                                    alignment (AGX_ROW_DIFF, engine: stage_rows; 0: all rows crossed as 2-bit classes) */
 } agx_stats;
 
 /* Node/edge tables in canonical numbering (position-major, variant order), for parity tests. malloc'd; free with agx_graph_free. */

@@ -118,6 +118,23 @@ int main() {
         dev_trim(5);
         CHECK(g_live.empty() && g_free_bytes == 280 * GB);
     }
+    // --- a unit that holds a region block and grows a capacity by a LARGE block while the region is full: it must not wait (for itself, or for peers that wait the same
+    // way: ADVICE r04) but take the driver's path at once; AGX_REGION_PERCENT sizes the region ---
+    {   g_free_bytes = 100 * GB; setenv("AGX_REGION_PERCENT", "50", 1);
+        DevArena ar; ar.device = 6;
+        ar.reserve(40 * GB);                                                                 // makes the region: 50 GB
+        CHECK(g_free_bytes == 50 * GB);
+        (void)ar.take(30 * GB);
+        const size_t m0 = g_mallocs;
+        std::atomic<int> done{0};
+        std::thread grow([&] { (void)ar.take(20 * GB); done = 1; });                         // 40 + 20 > 50: no room in the region, and the arena's own block is what fills it
+        for (int i = 0; i < 100 && !done; i++) std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        CHECK(done == 1);                                                                    // (before r05: waited two minutes for itself, then threw)
+        grow.join();
+        CHECK(g_mallocs == m0 + 1 && ar.capacity() == 60 * GB);                              // the driver served it
+        ar.reset(); dev_trim(6); unsetenv("AGX_REGION_PERCENT");
+        CHECK(g_live.empty());
+    }
     printf("ok\n");
     return 0;
 }

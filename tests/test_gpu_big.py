@@ -12,6 +12,9 @@
     smallest chromosomes (chr21, chr22, chrY at their full lengths) byte for byte against the ORACLE and against rebuilds from tiny capacities.  The read
     alignments are handed over staged (tmp/_agx_pairs.<u>.bin: as text the job is 170 GB), the checker's text exists for the three units only;
 
+  * configs[4]'s chromosomes ONE AT A TIME at full size (r05; what fits any box: 6 GB of disk and 15 GB of memory per unit): chr21, chr22 and chrY — and chr1, 249 M positions,
+    behind AGX_BIG_CHR1=1 — each generated alone at its GRCh38 length with exactly its share of the whole job's 400 M pairs of 2x150 (the whole job's read ids, so the 400 read
+    batches and their lost line pairs, AG:1258-1259, fall where they fall in the job), handed over staged, one build, byte for byte against the ORACLE;
   * configs[4]'s 24-unit shard SHAPE (GRCh38 chromosome lengths / 256, 2x150 bp reads), one-shot units from their cache files through the
     job loop, every unit against the oracle.
 
@@ -180,6 +183,76 @@ def test_cfg5_shard_shape_at_1_256_every_unit_matches_the_oracle(agx, built, tmp
         for key in ("initial", "pre", "extended"):
             assert got[uu][key] == want[uu][key], "unit %d: %s differs from the oracle" % (uu, key)
         assert stats[uu]["build_attempts"] == 1 and stats[uu]["n_pos"] >= lens[uu]
+
+
+def _cfg5_unit_alone(agx, base, uu, threads):
+    """One chromosome of configs[4] alone: generator (--only-units), oracle on a thread beside the engine, the engine's three outputs and the oracle's."""
+    import shutil
+    run = H.synth(os.path.join(base, "u%d" % uu), seed=1000, chroms=",".join(map(str, HUMAN)), pairs=400000000, L=150, k=5, coverage=5, sam_seq=0, threads=threads,
+                  pairs_bin=1, lean=1, oracle_units=uu, only_units=uu)
+    tmp = os.path.join(run, "tmp")
+    assert H.read_meta(run)["unit_len"] == list(HUMAN)
+    want, errs = {}, []
+
+    def oracle():
+        try:
+            want.update(H.run_oracle(os.path.join(run, "oracle_%d" % uu, "tmp"), uu, 5, 50, 5))
+        except BaseException as e:
+            errs.append(e)
+    checker = threading.Thread(target=oracle)
+    checker.start()
+    with agx.Unit(k=5, insert_variation=50, coverage=5, flags=agx.AGX_FLAG_ONE_SHOT) as un:
+        un.load_files(tmp, uu)
+        need = un.hbm_needed()
+        un.upload(); un.build(); un.download()
+        got = un.finish()
+        st = un.stats()
+    checker.join()
+    shutil.rmtree(run, ignore_errors=True)
+    assert not errs, errs
+    return got, want, st, need
+
+
+def _check_cfg5_unit(uu, got, want, st, need):
+    assert st["build_attempts"] == 1 and st["n_pos"] >= HUMAN[uu] and st["pairs_in_file"] == 400000000, st
+    assert st["device_bytes"] <= need
+    assert abs(st["sam_line_pairs"] / (400e6 * 1.03 * HUMAN[uu] / sum(HUMAN)) - 1) < 0.02          # its share of the whole job's pairs (5 % with a second hit, 2 % unaligned)
+    assert 300 <= st["sam_line_pairs"] - st["n_hits"] and st["n_hits"] > 0.9 * st["sam_line_pairs"]      # 399 batch boundaries, a line pair lost at (nearly) each, + the identity filter's
+    for key in ("initial", "pre", "extended"):
+        assert got[key] == want[key], "configs[4] unit %d (%d positions): %s differs from the oracle" % (uu, HUMAN[uu], key)
+    assert got["extended"].count(b">") > HUMAN[uu] / 1e6 and len(got["extended"]) > 0.9 * HUMAN[uu]
+
+
+@slow
+def test_cfg5_chr21_chr22_chrY_alone_at_full_size_match_the_oracle(agx, built, tmp_path):
+    """BASELINE configs[4]'s three smallest chromosomes, each as the unit it is in the whole-human job: full GRCh38 length (47, 51, 57 Mb), its share of the 400 M pairs of
+    2x150 bp with the whole job's read numbering (400 read batches: every batch boundary loses a line pair, AG:1258-1259), staged hand-over, one-shot unit, ONE build — byte for
+    byte against the oracle.  Sized for any box (6 GB of disk, 15 GB of memory per unit; the whole job, test_cfg5_whole_human_at_full_size, needs 70 GB / 200 GB)."""
+    import shutil
+    from concurrent.futures import ThreadPoolExecutor
+    free_disk = shutil.disk_usage(str(tmp_path)).free
+    assert free_disk > 8e9, "this test needs 8 GB of scratch disk (here: %.1f GB)" % (free_disk / 1e9)
+    try:
+        mem_limit = int(open("/sys/fs/cgroup/memory.max").read())
+    except (OSError, ValueError):
+        mem_limit = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+    side_by_side = 3 if free_disk > 25e9 and mem_limit > 80e9 else 1
+    units = (20, 21, 23)
+    with ThreadPoolExecutor(max_workers=side_by_side) as ex:
+        res = list(ex.map(lambda uu: _cfg5_unit_alone(agx, str(tmp_path), uu, max(2, THREADS // side_by_side)), units))
+    for uu, (got, want, st, need) in zip(units, res):
+        _check_cfg5_unit(uu, got, want, st, need)
+    print("configs[4] alone: " + "; ".join("unit %d: %d hits, %.1f GB of HBM, node sweep %.1f ms, walk %.0f ms" % (uu, r[2]["n_hits"], r[2]["device_bytes"] / 1e9, r[2]["ms_node_sweep"], r[2]["ms_walk"])
+                                          for uu, r in zip(units, res)))
+
+
+@pytest.mark.skipif(os.environ.get("AGX_BIG_CHR1") != "1", reason="chr1 alone against the oracle takes the oracle ~15 minutes and 80 GB of host memory: AGX_BIG_CHR1=1 (a passing run's log: profiles/r05_chr1_oracle.txt)")
+def test_cfg5_chr1_alone_at_full_size_matches_the_oracle(agx, built, tmp_path):
+    """configs[4]'s LARGEST unit — chr1, 248 956 422 positions, 33 M pairs of 2x150, 57 GB of HBM — against the oracle (r03 checked it against the serial executor only)."""
+    got, want, st, need = _cfg5_unit_alone(agx, str(tmp_path), 0, THREADS)
+    _check_cfg5_unit(0, got, want, st, need)
+    print("configs[4] chr1 alone: %d positions, %d hits, %.1f GB of HBM, node sweep %.1f ms, download %.1f ms, walk %.0f ms; outputs %d / %d / %d bytes identical to the oracle" %
+          (st["n_pos"], st["n_hits"], st["device_bytes"] / 1e9, st["ms_node_sweep"], st["ms_download"], st["ms_walk"], len(got["initial"]), len(got["pre"]), len(got["extended"])))
 
 
 @slow

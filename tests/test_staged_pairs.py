@@ -59,3 +59,20 @@ def test_checker_text_with_placeholder_reads(built, tmp_path):
         thin = H.run_oracle(os.path.join(run, "oracle_%d" % u, "tmp"), u, 5, 50, 4, batch=2000)
         assert full == thin and full["pre"].count(b">") > 3
         sim.compare_staged(os.path.join(run, "tmp"), u, 5, 2000, 2)
+
+
+def test_a_unit_alone_has_the_whole_jobs_alignments(built, tmp_path):
+    """--only-units (r05: how configs[4]'s chromosomes are checked one at a time at full size): a unit made alone has the sequence, the staged read alignments (ids, batch
+    boundaries) and the checker's text that it has in the whole job; only its contigs come from a generator of their own.  Its outputs still equal the oracle's on the serial executor."""
+    kw = dict(seed=13, chroms="40000,30000,20000", pairs=9000, coverage=4, read_indel=0.2, multi=0.3, sam_seq=0, threads=3, lean=1, batch=2000)
+    whole = H.synth(str(tmp_path / "whole"), pairs_bin=1, oracle_units="1", **kw)
+    alone = H.synth(str(tmp_path / "alone"), pairs_bin=1, oracle_units="1", only_units="1", **kw)
+    for f in ("tmp/_agx_pairs.1.bin", "tmp/_genome.1.fa", "oracle_1/tmp/_reads.fa", "oracle_1/tmp/_reads_genome.1.bowtie"):
+        assert open(os.path.join(whole, f), "rb").read() == open(os.path.join(alone, f), "rb").read(), f
+    assert not os.path.exists(os.path.join(alone, "tmp", "_agx_pairs.0.bin")) and not os.path.exists(os.path.join(alone, "tmp", "_genome.2.fa"))
+    assert H.read_meta(alone)["unit_len"] == [40000, 30000, 20000]
+    want = H.run_oracle(os.path.join(alone, "oracle_1", "tmp"), 1, 5, 50, 4, batch=2000)
+    assert want["pre"].count(b">") > 3
+    got = sim.run(os.path.join(alone, "oracle_1", "tmp"), 1, 5, 50, 4, batch=2000)          # (the kernels' lane functions, serially, on the same text)
+    for key in ("initial", "pre", "extended"):
+        assert got[key] == want[key], key

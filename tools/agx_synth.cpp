@@ -112,6 +112,10 @@ struct Params {
     int batch = 1000000;   // BATCH of the engine that will read the staged pairs (AG:37)
     std::vector<int64_t> oracle_units;   // --pairs-bin: for these units ALSO the text a checker needs, under <out>/oracle_<u>/tmp: the unit's SAM lines, and a reads file that holds the unit's
                                          // reads where they belong and a one-base placeholder record for everybody else's (4 bytes per read: 3.2 GB at 400 M pairs instead of 130)
+    std::vector<int64_t> only_units;     // --pairs-bin: make ONLY these units' files (sequence, contigs, PSL, staged pairs, checker text), each exactly as long as in the whole job and with the whole job's
+                                         // read numbering — a pair belongs to a unit by its own generator (seed, read id), so a unit's share of the --pairs pairs keeps its ids and its batch boundaries
+                                         // (AG:1258-1259) without anybody else's reads being made.  The contigs of a unit then come from a generator of their own (seed, unit): the files are NOT those
+                                         // of the whole job's run, they are a unit of the same shape.  tests/test_gpu_big.py: configs[4]'s chromosomes one at a time against the oracle
     int lean = 0;          // 1: do not write the user-level copies genome.fa, contigs.fa and tmp/_genome.fa (9 GB at whole-human size); the unit loop reads none of them
 };
 
@@ -149,12 +153,14 @@ Params parse_args(int argc, char **argv) {
         OPT_D("--mate1-left", mate1_left) OPT_D("--mixed-len", mixed_len) OPT_I("--sam-seq", sam_seq) OPT_I("--shuffle-units", shuffle_units) OPT_I("--e2e", e2e) OPT_I("--threads", threads) OPT_I("--pairs-bin", pairs_bin) OPT_I("--batch", batch) OPT_I("--lean", lean)
         if (a == "--chroms") { P.chroms = parse_list(v); continue; }
         if (a == "--oracle-units") { P.oracle_units = parse_list(v); continue; }
+        if (a == "--only-units") { P.only_units = parse_list(v); continue; }
         std::fprintf(stderr, "agx_synth: unknown option %s\n", a.c_str()); std::exit(2);
     }
     if (P.part < 1 || P.part > 10) die("--part must be 1..10");
     if (P.threads > 0 && P.e2e) die("--threads is not available with --e2e");
     if (P.threads > 256) P.threads = 256;
     if (P.pairs_bin && (P.threads <= 0 || P.e2e || P.mixed_len > 0)) die("--pairs-bin needs --threads and excludes --e2e / --mixed-len");
+    if (!P.only_units.empty() && P.pairs_bin != 1) die("--only-units needs --pairs-bin 1");
 #ifndef AGX_SYNTH_WITH_ENGINE
     if (P.pairs_bin) die("--pairs-bin is only available in build/agx_synth_bin (tools/agx_data.py builds it)");
 #endif
@@ -358,9 +364,11 @@ int main(int argc, char **argv) {
     }
     int NU = (int)unit_len.size();
     std::vector<Unit> units(NU);
+    for (int64_t u : P.only_units) if (u < 0 || u >= NU) die("--only-units: no such unit");
+    auto wanted = [&](int u) { return P.only_units.empty() || std::find(P.only_units.begin(), P.only_units.end(), (int64_t)u) != P.only_units.end(); };
     if (P.pairs_bin) {      // (the staged-pairs mode has a stream of its own anyway: every unit's sequences from a generator of their own, all units side by side — 3.1 Gb take a minute on one thread)
         std::atomic<int> next_u(0); std::vector<std::thread> th;
-        for (int t = 0; t < std::min(P.threads, NU); t++) th.emplace_back([&] { for (int u; (u = next_u.fetch_add(1)) < NU;) { Rng Ru(P.seed * 0x2545F4914F6CDD1Dull + (uint64_t)(u + 1) * 0x9E3779B97F4A7C15ull); make_unit(units[u], unit_len[u], P, Ru); } });
+        for (int t = 0; t < std::min(P.threads, NU); t++) th.emplace_back([&] { for (int u; (u = next_u.fetch_add(1)) < NU;) { if (!wanted(u)) continue; Rng Ru(P.seed * 0x2545F4914F6CDD1Dull + (uint64_t)(u + 1) * 0x9E3779B97F4A7C15ull); make_unit(units[u], unit_len[u], P, Ru); } });
         for (auto &t : th) t.join();
     } else
     for (int u = 0; u < NU; u++) make_unit(units[u], unit_len[u], P, R);
@@ -373,6 +381,7 @@ int main(int argc, char **argv) {
             if (!P.lean) std::fprintf(g, ">chr%zu synthetic\n", c + 1);
             std::string whole;
             for (int q = 0; q < P.part; q++, u++) {
+                if (!wanted(u)) continue;
                 if (!P.lean) whole += units[u].ref;
                 FILE *gu = open("tmp/_genome." + std::to_string(u) + ".fa");
                 std::fputs(">0\n", gu); put_fasta_body(gu, units[u].ref.data(), units[u].ref.size()); std::fclose(gu);
@@ -387,8 +396,12 @@ int main(int argc, char **argv) {
     {
         FILE *cf = open("contigs.fa"), *tc = open("tmp/_contigs.fa"), *chaff = open("tmp/_chaff.fa");
         int64_t seqID = 0, realID = 0, nameID = 0;
+        Rng &Rwhole = R;
         for (int u = 0; u < NU; u++) {
+            if (!wanted(u)) continue;
             const Unit &U = units[u];
+            Rng Rown(P.seed * 0xA0761D6478BD642Full + (uint64_t)(u + 1) * 0xE7037ED1A0B428DBull);
+            Rng &R = P.only_units.empty() ? Rwhole : Rown;      // (--only-units: a unit's contigs do not depend on which other units are made)
             // every unit's PSL is written against the same tmp/_contigs.fa, so contigs of other units
             // simply have no line in this unit's file
             FILE *psl = open("tmp/_contigs_genome." + std::to_string(u) + ".psl");
@@ -539,6 +552,7 @@ int main(int argc, char **argv) {
         }
         struct MemSink : agx::StageSink { std::vector<std::vector<char>> keep; void *take(int, size_t bytes) override { keep.emplace_back(bytes + 64); return keep.back().data(); } };
         for (int u = 0; u < NU; u++) {
+            if (!wanted(u)) continue;
             struct LinePair { agx::Mate m1, m2; };
             struct Chunk { std::vector<LinePair> lp; std::vector<agx_run> runs; std::vector<int64_t> ids; std::string bases, sam; bool ready = false; };      // ids / bases: the unit's pairs of this chunk (2 x L bytes each); sam: their lines, for --oracle-units
             std::vector<Chunk> chunks((size_t)NC);
@@ -836,6 +850,7 @@ int main(int argc, char **argv) {
         std::fprintf(m, "units %d\npairs %lld\nL %d\nk %d\ncoverage %d\ninsert_variation %d\nseed %llu\n", NU, (long long)P.pairs, P.L, P.k,
                      P.coverage, P.insert_variation, (unsigned long long)P.seed);
         std::fprintf(m, "pairs_bin %d\n", P.pairs_bin);
+        std::fprintf(m, "only_units %zu\n", P.only_units.size());
         for (int u = 0; u < NU; u++) std::fprintf(m, "unit %d len %lld\n", u, (long long)unit_len[u]);
         std::fclose(m);
     }
