@@ -509,6 +509,27 @@ AGX_HD bool agx_whit_left_simple(const agx_whit &w) { const agx_u32 f = w.flags;
 AGX_HD agx_u32 agx_whit_side(const agx_whit &w) { const agx_u32 a = w.a, b = w.b, f = w.flags; return (f & AGX_WF_RUNS1) ? a : b; }      // (of a hit with a multi-run mate)
 AGX_HD agx_u32 agx_wside_left_first(const agx_whit &w, const agx_wside &sd) { const agx_u32 r1 = sd.runs1, r2 = sd.runs2, f = w.flags; return (f & AGX_WF_LEFT2) ? r2 : r1; }
 AGX_HD agx_u32 agx_wside_left_count(const agx_whit &w, const agx_wside &sd) { const agx_u32 n = sd.nruns, f = w.flags; return (f & AGX_WF_LEFT2) ? n >> 16 : n & 0xFFFFu; }
+// ---- hits in tile order (r05) ----------------------------------------------------------------------------------------------------------
+// The build walks a unit's hits in the order of the tile their first arrival falls in (the staging makes the permutation: stage_order in agx_engine.cpp): neighbouring
+// lanes of agx_k_hit_prep then want the same tiles' counters, and a tile's list is a filter over a WINDOW of that order (agx_k_tile_fill) instead of a scatter of
+// 4-byte slot words all over HBM (r04: 893 MB written per 30 Mb unit where 250 were needed).  The key: the position of the left mate's first aligned base —
+// what agx_hit_prep calls x_lo for every hit it keeps (a hit it drops has no arrivals: where it stands in the order does not matter).
+AGX_HD agx_u32 agx_whit_first_x(const agx_whit &w, const agx_wside *sides, const agx_wrun *wruns) {
+    if (agx_whit_left_simple(w)) return agx_whit_left_t0(w);
+    const agx_wside sd = sides[agx_whit_side(w)];
+    const agx_u32 f = agx_wside_left_first(w, sd), n = agx_wside_left_count(w, sd);
+    for (agx_u32 i = 0; i < n; i++) if (wruns[f + i].n) return wruns[f + i].t;
+    return 0u;
+}
+// tiles a tile's list looks back over: a hit's arrivals span len - k + 1 positions, i.e. at most 1 + ceil((len - k) / 64) tiles; hits that span more (long deletions)
+// are few and go through a list of their own (AGX_LONG_MAX of them at most: beyond that the unit's lists are made the dense way, by scatter)
+#define AGX_LOOKBACK_MAX 16u
+#define AGX_LONG_MAX 1024u
+AGX_HD agx_u32 agx_tile_lookback(agx_u32 maxlen, agx_u32 k) {
+    const agx_u32 span = maxlen > k ? maxlen - k : 0u, lb = 1u + (span + AGX_TILE - 1u) / AGX_TILE;
+    return lb < 2u ? 2u : lb > AGX_LOOKBACK_MAX ? AGX_LOOKBACK_MAX : lb;
+}
+
 // the 2-bit codes of positions p .. p + 15 of the packed reference (position p in the low bits); positions below 0 read as 0.  Reads the
 // 32-bit words p >> 4 and (p >> 4) + 1: the buffer carries that much slack behind its last position.
 AGX_HD agx_u32 agx_ref_window16(const agx_u32 *wref, long long p) {

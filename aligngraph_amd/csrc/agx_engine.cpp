@@ -253,6 +253,7 @@ struct agx_unit {
     PBuf<agx_whit> s_hits; PBuf<agx_wside> s_sides; PBuf<agx_wrun> s_runs; PBuf<agx_u8> s_codes; PBuf<unsigned long long> s_other; PBuf<agx_u32> s_jump; size_t n_other = 0, n_sides = 0, n_jump = 0;      // the read alignments in the wire formats of agx_core.h
     PBuf<agx_u8> s_ref; PBuf<agx_refx> s_refx; size_t n_refx = 0; bool ref_packed = false;      // the unit sequence: 2 bits per base + the stretches of other bytes (ref_packed), or the bytes as they are
     PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
+    PBuf<agx_u32> s_perm, s_tfirst, s_jump_at; agx_u32 lookback = 2;      // the hits in the order of their first tile (stage_order): perm[i] = the i-th hit of that order, tile_first[t] = hits in front of tile t's own; pass J's hits as places in it
     PBuf<char> s_landing;               // one-shot units: what the download needs beyond the dead staged inputs it lands in, pinned when the unit is staged (not inside T_core)
     PBuf<agx_cntrun> s_cntruns; PBuf<agx_chunk> s_cntchunks, s_segchunks; PBuf<agx_u32> s_segindex; size_t n_cntruns = 0, n_cntchunks = 0, n_segchunks = 0, n_segindex = 0;      // what the device builds the conti-mer tables from (build_cm_layout)
     // the read rows in their upload form (agx_core.h "read rows relative to the reference"; made at the end of staging: stage_rows): count byte per row, offsets of the
@@ -276,7 +277,7 @@ struct agx_unit {
     // node table
     agx_u32 pool_cap = 0, spill_lo = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
     DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
-    DBuf<agx_u32> d_node_start, d_slow_list, d_slots; agx_u32 slot_cap = 0; DBuf<agx_u16> d_node_cnt; DBuf<agx_u8> d_pos_succ;
+    DBuf<agx_u32> d_node_start, d_slow_list, d_perm, d_tfirst, d_ckey, d_long; DBuf<agx_u16> d_node_cnt; DBuf<agx_u8> d_pos_succ;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch, d_huge_list, d_scratch_huge; bool huge = false;      // huge: pass 3 of the node sweep is queued (a build met a position beyond AGX_MAXV_BIG variants)
     // walk graph (agx_core.h "walk preparation")
@@ -344,7 +345,7 @@ void join_dl_helper(agx_unit *u);
 void drop_outputs(agx_unit *u);     // before a unit's inputs change: the helper that prepares the output buffers reads them
 void start_helper(agx_unit *u);
 
-enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_RANKOVF = 6, W_SLOTOVF = 7 /* (behind W_RANKOVF: tile_sort reads the pair) */, W_MIDCOUNT = 8, W_JUMPCOUNT = 9, W_SPILL = 10, W_HUGECOUNT = 11, W_N = 12 };
+enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_LONGCOUNT = 6 /* hits that span more tiles than a list's window looks back over */, W_UNUSED7 = 7, W_MIDCOUNT = 8, W_JUMPCOUNT = 9, W_SPILL = 10, W_HUGECOUNT = 11, W_N = 12 };
 
 void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     memset(&S, 0, sizeof S);
@@ -436,6 +437,15 @@ void stage_rows(agx_unit *u, unsigned threads) {
     if (getenv("AGX_LOAD_TIMING")) fprintf(stderr, "[agx load] read rows against the reference: %.1f ms, %zu rows (%zu as they are), %.1f -> %.1f bytes per row\n", now_ms() - t0, (size_t)u->n_rows, u->n_rows_explicit,
                                           (double)u->n_codes / u->n_rows, (double)(u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4) / u->n_rows);
 }
+// The hits in the order of the tile their first arrival falls in (agx_core.h "hits in tile order"; order_hits in agx_load.cpp): 4 bytes per hit + 4 per tile more to upload.
+void stage_order(agx_unit *u, unsigned threads) {
+    const double t0 = now_ms();
+    const size_t n_pos = u->V.n_pos ? u->V.n_pos : u->T.ref.size(), n_tiles = (n_pos + AGX_TILE - 1) / AGX_TILE;
+    u->lookback = agx_tile_lookback(u->maxlen, u->prm.k);
+    u->s_perm.alloc(u->nh + 1); u->s_tfirst.alloc(n_tiles + 2); u->s_jump_at.alloc(u->n_jump + 1);
+    order_hits(u->s_hits.p, u->nh, u->s_sides.p, u->s_runs.p, u->s_jump.p, u->n_jump, n_pos, threads, u->s_perm.p, u->s_tfirst.p, u->s_jump_at.p);
+    if (getenv("AGX_LOAD_TIMING")) fprintf(stderr, "[agx load] hits in tile order: %.1f ms (%zu hits, %zu tiles, window of %u tiles)\n", now_ms() - t0, u->nh, n_tiles, u->lookback);
+}
 void stage_inputs(agx_unit *u) {
     if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
     // A one-shot unit's download lands in its staged buffers.  The general loader's pairs can be staged again from P; the fast loader wrote the hits, runs and
@@ -472,6 +482,7 @@ void stage_inputs(agx_unit *u) {
     } else if (u->pairs_staged) { V.bases = u->reads_keep ? u->reads_keep->fv.p : nullptr; V.stride = u->stride; V.row_off = u->row_off.data(); }
     u->V = V;
     stage_rows(u, threads);
+    stage_order(u, threads);
     reserve_landing(u);
     u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0;
@@ -687,6 +698,7 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     else { V.bases = base + H.off[S_BASES]; u->row_slot.assign((const agx_u32 *)(base + H.off[S_ROWS]), (const agx_u32 *)(base + H.off[S_ROWS]) + H.n_rows); }
     u->V = V; u->pairs_staged = false;
     stage_rows(u, std::max(threads, std::min(8u, usable_cpus())));
+    stage_order(u, std::max(threads, std::min(16u, usable_cpus())));
     reserve_landing(u);
     u->have_ref = u->have_threads = true; u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0; u->stats.ms_parse = 0; u->stats.ms_thread = 0; u->stats.from_cache = 1;
@@ -745,7 +757,7 @@ void do_release(agx_unit *u);
 
 // Capacities of a unit's first build and the HBM they add up to (what do_upload reserves as one block; AlignGraph_amd admits a unit to a device by it:
 // agx_unit_hbm_needed).  From the staged counts: positions, hits, runs, conti-mers, read rows.
-struct Plan { agx_u32 pool_cap, list_cap, ovf_cap, sp_cap, slot_cap; size_t total; };
+struct Plan { agx_u32 pool_cap, list_cap, ovf_cap, sp_cap; size_t total; };
 Plan plan_capacities(const agx_unit *u) {
     const size_t n_pos = u->V.n_pos, nh = u->nh;
     const agx_u32 n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE), n_regions = (n_tiles + AGX_REGION_TILES - 1) / AGX_REGION_TILES;
@@ -757,15 +769,13 @@ Plan plan_capacities(const agx_unit *u) {
     const double per_hit = 1.0 + (u->maxlen > u->prm.k ? (double)(u->maxlen - u->prm.k) : 0.0) / AGX_TILE;
     P.list_cap = u->list_cap ? u->list_cap : (agx_u32)std::min<double>(g_tiny ? (double)nh / 2 + 16 : (double)nh * per_hit * 1.1 + 4096, 4.0e9);
     P.ovf_cap = u->ovf_cap ? u->ovf_cap : (g_tiny ? 4u : 1u << 16);
-    // slots of a tile's own list (hit_prep): a power of two above twice the average list, 32 to 256 (lists beyond it go through bin_fill: agx_kargs.h)
-    {   const double avg = n_tiles ? (double)nh * per_hit / n_tiles : 0.0; agx_u32 c = 32; while (c < 256 && c < 2.2 * avg) c <<= 1; P.slot_cap = g_tiny ? 2u : c; }
     const size_t ids_cap = n_pos + P.pool_cap;
     P.sp_cap = u->sp_cap ? u->sp_cap : (agx_u32)std::min<size_t>(g_tiny ? 32 : ids_cap / 4 + 4096, 0xFFFFFF00ull);      // special ids: 8 % on the bench unit
     // what the takes of do_upload add up to, plus the alignment of ~90 buffers
-    const size_t per_pos = 4 + 16 + 1 + 4 + 2 + 1 + 4 + 4, per_tile = 4 * 3 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_dhit) + 4;
+    const size_t per_pos = 4 + 16 + 1 + 4 + 2 + 1 + 4 + 4, per_tile = 4 * 4 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_dhit) + 4 + 4 + 4;      // per hit: derived record, order, last-tile key, (pass J / long list)
     const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
     const size_t wire = nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 + (u->ref_packed ? n_pos / 4 + u->n_refx * sizeof(agx_refx) : 0) + 4096;
-    const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + (size_t)n_tiles * P.slot_cap * 4 + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + (u->rows_diffed ? u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4 : u->n_codes) + n_bases + u->n_other * 8 +
+    const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + (u->rows_diffed ? u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4 : u->n_codes) + n_bases + u->n_other * 8 +
                          (size_t)P.pool_cap * per_slot + ids_cap * per_id + (size_t)P.list_cap * 36 + (size_t)P.ovf_cap * 16 + (size_t)P.sp_cap * (sizeof(agx_walknode) + sizeof(agx_hop)) +
                          (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64 * 4 + (size_t)n_regions * AGX_REGION_PAD * 4 + (64u << 10) * 100;
     P.total = total + total / 64;
@@ -799,7 +809,7 @@ void do_upload(agx_unit *u) {
     u->d_whits.alloc(a, nh + 1); u->d_wsides.alloc(a, u->n_sides + 1); u->d_wruns.alloc(a, u->n_runs + 1); u->d_jump.alloc(a, u->n_jump + 1);
     if (u->ref_packed) { u->d_wref.alloc(a, (n_pos + 3) / 4 + 32); u->d_refx.alloc(a, u->n_refx + 1); }
     u->d_dhit.alloc(a, nh + 1);
-    u->slot_cap = plan.slot_cap; u->d_slots.alloc(a, (size_t)u->n_tiles * u->slot_cap + 1);
+    u->d_perm.alloc(a, nh + 1); u->d_tfirst.alloc(a, (size_t)u->n_tiles + 2); u->d_ckey.alloc(a, nh + 1); u->d_long.alloc(a, AGX_LONG_MAX);
     u->d_tile_cnt.alloc(a, (size_t)u->n_tiles + 1); u->d_tile_off.alloc(a, (size_t)u->n_tiles + 2); u->d_cursor.alloc(a, (size_t)u->n_tiles + 1);
     u->d_words.alloc(a, W_N + 6 + 16); u->h_words.alloc(W_N + 6 + 16);
     u->d_chain_end.alloc(a, (size_t)u->n_chain_end + 1);
@@ -828,7 +838,8 @@ void do_upload(agx_unit *u) {
         };
         up(u->d_segs.p, u->s_segs.p, u->n_segs * sizeof(agx_cmseg)); up(u->d_cntruns.p, u->s_cntruns.p, u->n_cntruns * sizeof(agx_cntrun));
         up(u->d_cntchunks.p, u->s_cntchunks.p, u->n_cntchunks * sizeof(agx_chunk)); up(u->d_segchunks.p, u->s_segchunks.p, u->n_segchunks * sizeof(agx_chunk)); up(u->d_segindex.p, u->s_segindex.p, u->n_segindex * 4);
-        up(u->d_whits.p, u->s_hits.p, nh * sizeof(agx_whit)); up(u->d_wsides.p, u->s_sides.p, u->n_sides * sizeof(agx_wside)); up(u->d_wruns.p, u->s_runs.p, u->n_runs * sizeof(agx_wrun)); up(u->d_jump.p, u->s_jump.p, u->n_jump * 4);
+        up(u->d_whits.p, u->s_hits.p, nh * sizeof(agx_whit)); up(u->d_wsides.p, u->s_sides.p, u->n_sides * sizeof(agx_wside)); up(u->d_wruns.p, u->s_runs.p, u->n_runs * sizeof(agx_wrun)); up(u->d_jump.p, u->s_jump_at.p, u->n_jump * 4);
+        up(u->d_perm.p, u->s_perm.p, nh * 4); up(u->d_tfirst.p, u->s_tfirst.p, ((size_t)u->n_tiles + 2) * 4);
         HIP_OK(hipEventRecord(u->ev_hits, st));         // what the front of the build needs (conti-mer tables, hit preparation, binning) is there: it starts while the rest still travels
         if (u->rows_diffed) { up(u->d_units.p, u->s_units.p, u->n_units * 2); up(u->d_rowcnt.p, u->s_rowcnt.p, u->n_rowcnt); up(u->d_blockoff.p, u->s_blockoff.p, u->n_blockoff * 4); up(u->d_blockfirst.p, u->s_blockfirst.p, u->n_blockfirst * 4); up(u->d_anchor.p, u->s_anchor.p, u->n_anchor * 4); }
         else up(u->d_codes.p, u->s_codes.p, u->n_codes);
@@ -862,7 +873,7 @@ void do_upload(agx_unit *u) {
     u->uploaded = true; u->built = false; u->downloaded = false;
     if (!u->pending_walk) { u->pending_walk = true; g_walks_pending.fetch_add(1); }
     u->stats.ms_upload = now_ms() - t0;
-    u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + u->n_cntruns * sizeof(agx_cntrun) + (u->n_cntchunks + u->n_segchunks) * sizeof(agx_chunk) + (u->ref_packed ? (n_pos + 3) / 4 + u->n_refx * sizeof(agx_refx) : n_pos) + nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 +
+    u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + u->n_cntruns * sizeof(agx_cntrun) + (u->n_cntchunks + u->n_segchunks) * sizeof(agx_chunk) + (u->ref_packed ? (n_pos + 3) / 4 + u->n_refx * sizeof(agx_refx) : n_pos) + nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 + nh * 4 + ((size_t)u->n_tiles + 2) * 4 +
                             (size_t)u->n_chain_end * 4 + (u->rows_diffed ? u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4 : u->n_codes) + u->n_other * 8 + ((size_t)u->n_regions + 1) * 4;
     u->stats.device_bytes = u->arena.capacity();
     u->stats.rows_by_reference = u->rows_diffed ? (uint32_t)(u->n_rows - u->n_rows_explicit) : 0u;
@@ -939,17 +950,25 @@ void do_build(agx_unit *u) {
         }
         // ---- hit_prep + tile histogram ----
         u->ev.begin(); u->ev.mark(B_START, st);
-        agx_prep_args PA{(const agx_whit *)u->d_whits.p, (const agx_wside *)u->d_wsides.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR, u->d_words.p + W_RANKOVF,
-                         u->d_slots.p, u->slot_cap, u->d_words.p + W_SLOTOVF};
+        agx_prep_args PA{(const agx_whit *)u->d_whits.p, (const agx_wside *)u->d_wsides.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR,
+                         u->d_perm.p, u->d_tfirst.p, u->d_ckey.p, u->lookback, u->d_long.p, u->d_words.p + W_LONGCOUNT};
         agx_launch_hit_prep(&PA, st);
         AGX_CHECKPOINT("hit_prep");
         u->ev.mark(B_PREP, st);
         // ---- tile lists ----
         if (g_scan1) agx_launch_exclusive_scan1(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_desc.p, st);
         else agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
-        agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, u->d_words.p + W_RANKOVF, u->d_words.p + W_SLOTOVF, u->slot_cap};
-        agx_launch_bin_fill(&BA, st);                   // (returns at once unless a list outgrew its tile's slots)
-        agx_launch_tile_sort(u->d_tile_off.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->d_dhit.p, u->d_tile_recs.p, u->d_runs.p, u->prm.k, u->d_slots.p, u->slot_cap, u->d_words.p + W_RANKOVF, st);
+        agx_fill_args FA{u->d_tile_off.p, u->d_tfirst.p, u->d_perm.p, u->d_ckey.p, u->d_dhit.p, u->d_runs.p, u->d_tile_recs.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->prm.k, u->lookback,
+                         u->d_long.p, u->d_words.p + W_LONGCOUNT, u->d_words.p + W_ERR};
+        agx_launch_tile_fill(&FA, st);                  // every tile's list from its window of the tile order
+        {   // the fallback for units with more long hits than a list's window scan takes (both return at once otherwise; queued only where such hits can exist at all:
+            // a unit whose reads fit the window and carry no run pool cannot have one)
+            if (u->n_runs || u->lookback >= AGX_LOOKBACK_MAX) {
+                agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, u->d_words.p + W_LONGCOUNT};
+                agx_launch_bin_fill(&BA, st);
+                agx_launch_tile_sort(&FA, st);
+            }
+        }
         AGX_CHECKPOINT("tile_sort");
         if (!u->expanded) {   // the vote codes (and the region layout, the last copy of the upload) are first needed by the sweep
             const size_t n_bases = u->n_codes * 4;
@@ -1045,6 +1064,7 @@ void do_build(agx_unit *u) {
         const agx_u32 *w = u->h_words.p;
         if (w[W_ERR] & 1u) throw Error{E_ALIGNMENT, "BOWTIE ALIGNMENT ERROR"};
         if (w[W_ERR] & 2u) throw Error{E_UNSUPPORTED, "read alignment beyond the end of the unit sequence"};
+        if (w[W_ERR] & (4u | 8u)) throw Error{E_DEVICE, (w[W_ERR] & 4u) ? "internal: the staged order of the hits is not the order of their first tiles" : "internal: a tile's list does not hold what its histogram counted"};
         u->n_tile_entries = w[W_N];
         // a capacity that was too small: take a larger buffer (the arena keeps the old one until the unit is released) and build again.
         // Whatever a retry changes on the device goes through the download stream and a fresh ev_uploaded, which the next attempt waits for.
@@ -1073,7 +1093,7 @@ void do_build(agx_unit *u) {
         const unsigned long long ids = (unsigned long long)n_pos + w[W_N + 1];
         if (ids >= 0xFFFFFF00ull) throw Error{E_OVERFLOW, "walk graph exceeds 2^32 ids"};
         u->n_ids = (agx_u32)ids; u->n_special = w[W_N + 2];
-        u->stats.build_attempts = (uint32_t)attempt + 1; u->stats.n_spilled = w[W_SPILL]; u->stats.dense_lists = w[W_RANKOVF] ? 2u : w[W_SLOTOVF] ? 1u : 0u;
+        u->stats.build_attempts = (uint32_t)attempt + 1; u->stats.n_spilled = w[W_SPILL]; u->stats.dense_lists = w[W_LONGCOUNT] > AGX_LONG_MAX ? 2u : w[W_LONGCOUNT] ? 1u : 0u;
 #ifdef AGX_SWEEP_STATS
         {   const agx_u32 *c = w + W_N + 6;
             fprintf(stderr, "[agx sweep stats] wave-entries %u (lanes with an arrival %u = %.1f per entry); leave the fast path: %u entries / %u lanes; of those not a first store: %u / %u; "
@@ -1162,7 +1182,7 @@ void do_release(agx_unit *u) {
     join_dl_helper(u);                                 // (it fills the download buffers released below)
     if (u->uploaded) { (void)hipSetDevice(u->prm.device); (void)hipEventSynchronize(u->ev_uploaded); (void)hipEventSynchronize(u->ev_built); (void)hipEventSynchronize(u->ev_dl); }      // (its commands are done before its memory goes)
     for (auto *b : {&u->d_cm_start, &u->d_tile_cnt, &u->d_tile_off, &u->d_cursor, &u->d_unsorted, &u->d_tile_recs, &u->d_scan_tmp, &u->d_words, &u->d_pool_cnt, &u->d_region_off, &u->d_node_start,
-                    &u->d_slow_list, &u->d_slots, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
+                    &u->d_slow_list, &u->d_perm, &u->d_tfirst, &u->d_ckey, &u->d_long, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     u->d_node_cnt.release();
     for (auto *b : {&u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();

@@ -204,6 +204,10 @@ bool thread_contigs_fast(const std::string &contigs_fa, const std::string &psl, 
 bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam, long batch, agx_u32 k, unsigned threads, StageSink &sink, StagedPairs &S);
 // the same arrays from what the general loader (or agx_unit_push_pairs) holds; staged_out (tests): the hits as the device will unpack them
 void stage_pairs(const Pairs &P, agx_u32 k, unsigned threads, StageSink &sink, StagedPairs &S, std::vector<agx_hit> *staged_out = nullptr);
+// The staged hits in the order of the tile their first arrival falls in (agx_core.h "hits in tile order"): perm[i] = the i-th hit of that order (hit numbers ascend inside a
+// tile), tile_first[t] = hits in front of tile t's own (n_tiles + 2 entries, the last two = nh), jump_at = pass J's list (`jump`, hit numbers) as places in the order, ascending
+void order_hits(const agx_whit *hits, size_t nh, const agx_wside *sides, const agx_wrun *runs, const agx_u32 *jump, size_t n_jump, size_t n_pos, unsigned threads,
+                agx_u32 *perm, agx_u32 *tile_first, agx_u32 *jump_at);
 // reference bases as 2 bits each + the stretches of other bytes (agx_core.h); false: too many such stretches (soft-masked sequence): the bases cross as they are
 // what the device builds the conti-mer tables from besides the runs themselves (agx_core.h: agx_cntrun, agx_chunk): the counts as runs, and both run lists in chunks
 struct CmLayout { std::vector<agx_cntrun> cnt_runs; std::vector<agx_chunk> cnt_chunks, seg_chunks; std::vector<agx_u32> seg_index; };

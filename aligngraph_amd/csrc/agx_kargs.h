@@ -5,17 +5,18 @@
 
 struct agx_prep_args {
     const agx_whit *whits; const agx_wside *sides;      // [n_hits] wire records in SAM file order: a hit's number is its place in the file, the order the tile lists are sorted into
-    const agx_run *runs; agx_dhit *dhit; agx_u32 n_hits, k, n_pos;
+    const agx_run *runs; agx_dhit *dhit; agx_u32 n_hits, k, n_pos;      // dhit[i]: the derived record of the i-th hit IN TILE ORDER (hit perm[i])
     agx_u32 *tile_cnt;        // [n_tiles] number of hits overlapping each tile
-    agx_u32 *err;             // bit 0: same-strand mates; bit 1: alignment beyond the unit sequence
-    agx_u32 *rank_overflow;   // set when some hit spans more than four tiles (the histogram's atomicAdd gives a hit its place in the lists of its first four)
-    // The tile lists without a second pass over the hits: every tile has slot_cap slots of its own and the rank IS the slot.  A list that outgrows its slots
-    // (slot_overflow) goes through bin_fill's dense lists — that list alone since r04; a hit beyond four tiles sends every list there, as before r03.
-    agx_u32 *slots; agx_u32 slot_cap; agx_u32 *slot_overflow;
+    agx_u32 *err;             // bit 0: same-strand mates; bit 1: alignment beyond the unit sequence; bit 2: the order the staging made is not the order of the hits' first tiles
+    // r05: the hits are walked in the order of their first tile (perm: stage_order; tile_first[t] = hits in front of tile t's own in that order), so a tile's list is a
+    // filter over a window of the order (agx_k_tile_fill).  ckey[i] = the last tile hit i reaches (NONE: dropped, or LONG — it spans `lookback` tiles or more and is
+    // listed in long_list instead; more than AGX_LONG_MAX of those: every list of the unit is made by scatter, agx_k_bin_fill + agx_k_tile_sort)
+    const agx_u32 *perm, *tile_first; agx_u32 *ckey; agx_u32 lookback; agx_u32 *long_list, *long_count;
 };
 
+// the fallback (more than AGX_LONG_MAX long hits): every hit takes its places in dense lists from a counter per tile
 struct agx_bin_args { const agx_dhit *dhit; agx_u32 n_hits; const agx_u32 *tile_off; agx_u32 *cursor; agx_u32 *unsorted; agx_u32 cap;   // cap: entries the lists can hold
-                      const agx_u32 *rank_overflow; const agx_u32 *slot_overflow; agx_u32 slot_cap; };
+                      const agx_u32 *long_count; };
 
 struct agx_node_kargs {
     agx_sweep_args S;
@@ -62,8 +63,11 @@ void agx_launch_hit_prep(const agx_prep_args *, hipStream_t);
 void agx_launch_exclusive_scan(const agx_u32 *in, agx_u32 *out, agx_u32 n, agx_u32 *tmp, hipStream_t);
 void agx_launch_exclusive_scan1(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsigned long long *desc, hipStream_t);      // one launch; desc: ceil((n+1)/4096) zeroed words
 void agx_launch_bin_fill(const agx_bin_args *, hipStream_t);
-void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, const agx_run *runs, agx_u32 k,
-                          const agx_u32 *slots, agx_u32 slot_cap, const agx_u32 *dense /* two words: rank_overflow, slot_overflow */, hipStream_t);
+// the tile lists as the sweeps read them (32-byte records in SAM order): agx_k_tile_fill from the window of the tile order, or — the fallback — agx_k_tile_sort from bin_fill's dense lists
+struct agx_fill_args { const agx_u32 *tile_off, *tile_first, *perm, *ckey; const agx_dhit *dhit; const agx_run *runs; void *recs; agx_u32 *scratch /* = bin_fill's `unsorted` */;
+                       agx_u32 n_tiles, cap, k, lookback; const agx_u32 *long_list, *long_count; agx_u32 *err; };
+void agx_launch_tile_fill(const agx_fill_args *, hipStream_t);
+void agx_launch_tile_sort(const agx_fill_args *, hipStream_t);
 void agx_launch_node_sweep(const agx_node_kargs *, hipStream_t);
 void agx_launch_node_sweep_big(const agx_node_kargs *, hipStream_t);
 void agx_launch_edge_sweep(const agx_edge_kargs *, hipStream_t);                   // pass A (lanes = positions)

@@ -126,65 +126,50 @@ __global__ void __launch_bounds__(256) agx_k_patch_ref(const agx_refx *x, agx_u8
     for (agx_u32 j = threadIdx.x; j < r.len; j += 256u) ref[(size_t)r.pos + j] = (agx_u8)r.byte;
 }
 
-// ---- hit_prep: one thread per hit -------------------------------------------------------------------------------
-// Hits arrive in SAM file order (a unit is built once: sorting them by tile first costs more than it saves the binning kernels).
-// Device-scope atomics are the expensive part of binning on this chip (8 L2s: they are resolved behind them): neighbouring lanes that want
-// the same tile add up and issue ONE atomicAdd, and what that returns is also each hit's slot in the tile's list, so that bin_fill
-// scatters without atomics.  The kernel also decides the one rule that needs the file order (a later hit of a pair landing on an earlier
-// one is dropped, AG:1650-1655).  (It used to append the hits with a multi-run mate to a list for pass J of the edge build: one returning
-// atomic per wavefront on ONE counter — 16 k of them, 0.18 ms of a 0.23 ms kernel: a single word takes ~88 such atomics per microsecond.)
+// ---- hit_prep: one thread per hit, hits in TILE order ------------------------------------------------------------------------------
+// Thread i takes hit perm[i]: the staging sorted the hits by the tile of their first arrival (stage_order, agx_engine.cpp; the SAM file's own order is random in
+// position).  Neighbouring lanes then want the same tiles: the histogram's device-scope atomics — the expensive part of binning on this chip (8 L2s: they are resolved
+// behind them) — collapse to one per run of equal tiles, and the derived records leave in the order the tile lists will read them.  r04 walked the hits in file order and
+// stored every (tile, hit) pair into a slot of the tile's own: 12.7 M scattered 4-byte stores per 30 Mb unit, 893 MB of write traffic for 250 MB of payload.
+// The kernel still decides the one rule that needs the file order (a later hit of a pair landing on an earlier one is dropped, AG:1650-1655): it reads the hit's file
+// neighbours through the wire records, which stay in file order.
 __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
-    const agx_u32 h = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
-    const bool mine = h < A.n_hits;
+    const agx_u32 i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool mine = i < A.n_hits;
     agx_dhit d; d.flags = AGX_HF_SKIP; d.x_lo = 1; d.x_hi = 0; d.a_nruns = 0;
     if (mine) {
-        // the hit straight from its wire record (16 bytes, + 12 for the one in ten with a multi-run mate): r03 first expanded the records into an array of
-        // 40-byte hits that only this kernel ever read
+        const agx_u32 h = A.perm[i];
+        // the hit straight from its wire record (16 bytes, + 12 for the three in eight with a multi-run mate)
         const agx_whit *wh = A.whits; const agx_wside *sd = A.sides;
         const agx_hit H = agx_unpack_hit(wh[h], sd);
-        const int rc = agx_hit_prep(H, H.back != 0 && agx_hit_dup_by([wh, sd](agx_u32 i) { return agx_unpack_hit(wh[i], sd); }, A.runs, h), (H.pad[0] & 1u) != 0, H.slot1, A.runs, A.k, d);      // staged hit: slot1 = row of the a mate's bases
+        const int rc = agx_hit_prep(H, H.back != 0 && agx_hit_dup_by([wh, sd](agx_u32 j) { return agx_unpack_hit(wh[j], sd); }, A.runs, h), (H.pad[0] & 1u) != 0, H.slot1, A.runs, A.k, d);      // staged hit: slot1 = row of the a mate's bases
         if (rc) atomicOr(A.err, 1u);
         if (!(d.flags & AGX_HF_SKIP) && (d.x_hi >= A.n_pos || d.x_lo > d.x_hi)) { atomicOr(A.err, 2u); d.flags |= AGX_HF_SKIP; }
     }
     const bool kept = mine && !(d.flags & AGX_HF_SKIP);
     const agx_u32 t0 = kept ? d.x_lo / AGX_TILE : 0u, t1 = kept ? d.x_hi / AGX_TILE : 0u;
-    // Lanes that want the same tile as their s-th one and are neighbours form a run of equal tile numbers (pile-ups, hits of one pair).
-    // The first pending lane of every run adds the run's pending lanes to the tile's counter — all runs in the same atomic instruction,
-    // and the four instructions (s = 0..3) back to back: the wavefront waits for one round trip, not for one per distinct tile.
-    // (Nothing depends on the order: equal tiles that are not neighbours just become two runs.)
-    agx_u32 r[4] = {0, 0, 0, 0}, base[4] = {0, 0, 0, 0}, lead[4] = {0, 0, 0, 0};
-    bool pend[4];
+    // the order is the staging's claim: a hit that is not where its first tile's hits stand would silently miss its tiles' lists
+    if (kept && !(A.tile_first[t0] <= i && i < A.tile_first[t0 + 1])) atomicOr(A.err, 4u);
+    const bool lng = kept && t1 - t0 >= A.lookback;
+    if (mine) A.ckey[i] = (kept && !lng) ? t1 : AGX_NONE;
+    if (lng) { const agx_u32 at = atomicAdd(A.long_count, 1u); if (at < AGX_LONG_MAX) A.long_list[at] = i; }
+    // Lanes that want the same tile as their s-th one and are neighbours form a run of equal tile numbers; the first pending lane of every run adds the run's
+    // pending lanes to the tile's counter — all runs in the same atomic instruction, nothing is returned (the lists are filled by agx_k_tile_fill from the order itself).
     const unsigned long long below = (1ull << lane) - 1ull;
     for (agx_u32 s = 0; s < 4; s++) {                                        // the hit's s-th tile
         const agx_u32 t = t0 + s;
-        pend[s] = kept && t <= t1;
+        const bool pend = kept && t <= t1;
         const agx_u32 tp = (agx_u32)__shfl_up((int)t, 1, 64);
-        const unsigned long long starts = __ballot(lane == 0 || t != tp) , pm = __ballot(pend[s]);
+        const unsigned long long starts = __ballot(lane == 0 || t != tp), pm = __ballot(pend);
         const agx_u32 first = 63u - (agx_u32)__builtin_clzll(starts & (below | (1ull << lane)));        // first lane of my run
         const unsigned long long after = starts & ~(below | (1ull << lane));                                 // run starts above me
         const agx_u32 end = after ? (agx_u32)__builtin_ctzll(after) : 64u;                                    // one past my run
         const unsigned long long run = (end == 64u ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << first) - 1ull);
         const unsigned long long p = pm & run;                                                                 // pending lanes of my run
-        lead[s] = p ? (agx_u32)__builtin_ctzll(p) : 0u;
-        r[s] = (agx_u32)__popcll(p & below);
-#ifdef AGX_EXP_WG_ATOMICS      // timing experiment only (results are wrong): what the histogram costs if its atomics stay in the XCD's L2
-        if (pend[s] && lane == lead[s]) base[s] = __hip_atomic_fetch_add(&A.tile_cnt[t], (agx_u32)__popcll(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-        if (pend[s] && lane == lead[s]) base[s] = atomicAdd(&A.tile_cnt[t], (agx_u32)__popcll(p));
-#endif
+        if (pend && lane == (agx_u32)__builtin_ctzll(p)) (void)atomicAdd(&A.tile_cnt[t], (agx_u32)__popcll(p));
     }
-    bool over = false;
-    for (agx_u32 s = 0; s < 4; s++) {
-        const agx_u32 bs = (agx_u32)__shfl((int)base[s], (int)lead[s], 64); r[s] = pend[s] ? r[s] + bs : 0u;
-        if (pend[s]) { if (r[s] < A.slot_cap) A.slots[(size_t)(t0 + s) * A.slot_cap + r[s]] = h; else over = true; }      // the rank is the hit's slot in the tile's own list
-    }
-    if (__ballot(over) != 0ull && lane == 0) atomicOr(A.slot_overflow, 1u);
-    if (kept && t1 - t0 >= 4) {                                              // spans more than four tiles: count the rest, and tell bin_fill to take its own slots
-        for (agx_u32 t = t0 + 4; t <= t1; t++) atomicAdd(&A.tile_cnt[t], 1u);
-        atomicOr(A.rank_overflow, 1u);
-    }
-    if (!mine) return;
-    A.dhit[h] = d;
+    if (kept && t1 - t0 >= 4) for (agx_u32 t = t0 + 4; t <= t1; t++) (void)atomicAdd(&A.tile_cnt[t], 1u);      // spans more than four tiles: the rest, one by one
+    if (mine) A.dhit[i] = d;
 }
 
 // ---- exclusive scan of a u32 array (three small kernels up to 16 M elements: blocks, block sums, add) --------------------
@@ -268,60 +253,100 @@ __global__ void __launch_bounds__(256) agx_k_scan_lookback(const agx_u32 *in, ag
     }
 }
 
-// ---- tile lists: scatter, then rank-sort each list so that hits are applied in SAM order ---------------------------
-__global__ void __launch_bounds__(256) agx_k_bin_fill(agx_bin_args A) {
-    const agx_u32 h = blockIdx.x * 256u + threadIdx.x;
-    // (nothing to do where every list fitted the tiles' own slots: hit_prep has filled them)
-    if (__builtin_amdgcn_readfirstlane((int)*A.rank_overflow) == 0 && __builtin_amdgcn_readfirstlane((int)*A.slot_overflow) == 0) return;
-    if (h >= A.n_hits) return;
-    const agx_dhit d = A.dhit[h];
-    if (d.flags & AGX_HF_SKIP) return;
-    // every hit takes its places in the dense lists from a second counter per tile (the order inside a list is tile_sort's business) — r04: only in the lists that outgrew
-    // their tile's slots (one pile-up used to send every tile of the unit through here), unless a hit beyond four tiles has left some tile's slots incomplete
-    const bool all = __builtin_amdgcn_readfirstlane((int)*A.rank_overflow) != 0;
-    for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++) {
-        if (!all && A.tile_off[t + 1] - A.tile_off[t] <= A.slot_cap) continue;
-        const agx_u32 at = A.tile_off[t] + atomicAdd(&A.cursor[t], 1u); if (at < A.cap) A.unsorted[at] = h;
-    }
-}
-
-// one wavefront per tile; a hit's place in the file is unique, so an element's rank is the number of smaller keys
+// ---- tile lists: the 32-byte record stream the sweeps read, hits of a tile in SAM order --------------------------------------------------
 #define AGX_SORT_LDS 512       // list entries of a tile sorted in LDS (a tile of the bench units holds ~27; 2048 — 32 KB per block — kept the kernel at 20 of a CU's 32 wavefronts)
-// The kernel writes the tile's RECORD list: 32 bytes per listed hit, in SAM (= hit id) order, so that the sweeps read one sequential,
-// wave-uniform stream (scalar loads) instead of chasing list entry -> record.  A record is the first 32 bytes of agx_tile_record(): the
-// hit's derived record, or the linear piece of it that covers this tile.
-__device__ __forceinline__ void agx_put_rec(uint4 *recs, agx_u32 at, const agx_dhit *dhit, agx_u32 h, const agx_run *runs, agx_u32 tile, agx_u32 k) {
-    const agx_dhit d = agx_tile_record(dhit[h], runs, tile, k);
+// A record is the first 32 bytes of agx_tile_record(): the hit's derived record, or the linear piece of it that covers this tile.  i: the hit's place in the tile order.
+__device__ __forceinline__ void agx_put_rec(uint4 *recs, agx_u32 at, const agx_dhit *dhit, agx_u32 i, const agx_run *runs, agx_u32 tile, agx_u32 k) {
+    const agx_dhit d = agx_tile_record(dhit[i], runs, tile, k);
     recs[2 * (size_t)at] = make_uint4(d.a_t0, d.b_t0, d.a_runs, d.b_runs);
     recs[2 * (size_t)at + 1] = make_uint4(d.a_slot, (agx_u32)d.len | ((agx_u32)d.jstar << 16), (agx_u32)d.a_nruns | ((agx_u32)d.b_nruns << 16), d.flags);
 }
-// (list entries are hit numbers = places in the SAM file: the sort key)
-__global__ void __launch_bounds__(256) agx_k_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap,
-                                                       const agx_dhit *dhit, uint4 *recs, const agx_run *runs, agx_u32 k,
-                                                       const agx_u32 *slots, agx_u32 slot_cap, const agx_u32 *dense /* [2]: rank_overflow, slot_overflow */) {
-    __shared__ agx_u32 sh[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS];
+// One wavefront per tile.  The hits are in the order of their first tile, so the hits that reach tile t are among those whose first tile is t - lookback + 1 .. t: a
+// contiguous WINDOW of the order (tile_first), filtered by the last tile each hit reaches (ckey) — coalesced reads of 4-byte keys, no scatter, no atomics — plus the few
+// hits that span more tiles than the window looks back over (long_list).  What is kept is ranked by hit number (= place in the SAM file; unique, so an entry's rank is
+// the number of smaller keys) and the records are written at tile_off[t] + rank.  The count must be the histogram's (hit_prep counted the same hits): err bit 3 otherwise.
+__global__ void __launch_bounds__(256) agx_k_tile_fill(agx_fill_args A) {
+    __shared__ agx_u32 sh_i[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS], sh_k[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
-    if (tile >= n_tiles) return;
-    const agx_u32 lo = tile_off[tile], n = tile_off[tile + 1] - lo;
-    if (tile_off[tile + 1] > cap) return;                // lists did not fit: the host grows them and re-runs
-    // the tile's own slots (hit_prep), or bin_fill's dense list if THIS list outgrew them (or some hit spans more than four tiles: then every list is dense)
-    const bool own = __builtin_amdgcn_readfirstlane((int)dense[0]) == 0 && n <= slot_cap;
-    const agx_u32 *src = own ? slots + (size_t)tile * slot_cap : unsorted + lo;
-    if (n <= AGX_SORT_LDS) {
-        for (agx_u32 i = lane; i < n; i += 64) sh[wave][i] = src[i];
-        // single wavefront: LDS writes above are visible to its own later reads after the implicit waitcnt
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        for (agx_u32 i = lane; i < n; i += 64) {
-            const agx_u32 key = sh[wave][i]; agx_u32 r = 0;
-            for (agx_u32 j = 0; j < n; j++) r += sh[wave][j] < key;
-            agx_put_rec(recs, lo + r, dhit, key, runs, tile, k);
+    if (tile >= A.n_tiles) return;
+    const agx_u32 n_long = __builtin_amdgcn_readfirstlane((int)*A.long_count);
+    if (n_long > AGX_LONG_MAX) return;                   // the fallback makes this unit's lists (agx_k_bin_fill, agx_k_tile_sort)
+    const agx_u32 lo = A.tile_off[tile], n = A.tile_off[tile + 1] - lo;
+    if (A.tile_off[tile + 1] > A.cap) return;            // lists did not fit: the host grows them and re-runs
+    if (n == 0) return;
+    const bool in_lds = n <= AGX_SORT_LDS;
+    agx_u32 *gi = A.scratch + lo;                        // pile-ups beyond the LDS window: the kept entries' places in the order, in the tile's share of the scratch list
+    const agx_u32 c_lo = A.tile_first[tile >= A.lookback - 1u ? tile - (A.lookback - 1u) : 0u], c_hi = A.tile_first[tile + 1];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    agx_u32 kept = 0;
+    auto take = [&](bool ok, agx_u32 i) {                // (called by all lanes together)
+        const unsigned long long m = __ballot(ok);
+        const agx_u32 at = kept + (agx_u32)__popcll(m & below);
+        if (ok && at < n) { if (in_lds) { sh_i[wave][at] = i; sh_k[wave][at] = A.perm[i]; } else gi[at] = i; }
+        kept += (agx_u32)__popcll(m);
+    };
+    for (agx_u32 base = c_lo; base < c_hi; base += 64) {
+        const agx_u32 i = base + lane; const bool in = i < c_hi;
+        const agx_u32 key = in ? A.ckey[i] : AGX_NONE;
+        take(in && key != AGX_NONE && key >= tile, i);
+    }
+    for (agx_u32 base = 0; base < n_long; base += 64) {
+        const agx_u32 j = base + lane; const bool in = j < n_long;
+        const agx_u32 i = in ? A.long_list[j] : 0u;
+        const agx_u32 x_lo = in ? A.dhit[i].x_lo : 1u, x_hi = in ? A.dhit[i].x_hi : 0u;
+        take(in && x_lo / AGX_TILE <= tile && tile <= x_hi / AGX_TILE, i);
+    }
+    if (kept != n) { if (lane == 0) atomicOr(A.err, 8u); return; }
+    // single wavefront: its LDS / global writes above are visible to its own later reads after the fence
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (in_lds) {
+        for (agx_u32 e = lane; e < n; e += 64) {
+            const agx_u32 key = sh_k[wave][e]; agx_u32 r = 0;
+            for (agx_u32 j = 0; j < n; j++) r += sh_k[wave][j] < key;
+            agx_put_rec((uint4 *)A.recs, lo + r, A.dhit, sh_i[wave][e], A.runs, tile, A.k);
         }
-    } else {                                            // pile-ups larger than the LDS window: same rank sort straight from L2
-        for (agx_u32 i = lane; i < n; i += 64) {
-            const agx_u32 key = src[i]; agx_u32 r = 0;
-            for (agx_u32 j = 0; j < n; j++) r += src[j] < key;
-            agx_put_rec(recs, lo + r, dhit, key, runs, tile, k);
+    } else {                                             // the same rank sort straight from L2
+        for (agx_u32 e = lane; e < n; e += 64) {
+            const agx_u32 i = gi[e], key = A.perm[i]; agx_u32 r = 0;
+            for (agx_u32 j = 0; j < n; j++) r += A.perm[gi[j]] < key;
+            agx_put_rec((uint4 *)A.recs, lo + r, A.dhit, i, A.runs, tile, A.k);
+        }
+    }
+}
+
+// The fallback — a unit with more than AGX_LONG_MAX hits that span more tiles than the window looks back over (very long reads, many long deletions): every hit takes
+// its places in dense lists from a second counter per tile (a scatter of 4-byte words, as r04 did for every unit), and a wavefront per tile rank-sorts its list.
+__global__ void __launch_bounds__(256) agx_k_bin_fill(agx_bin_args A) {
+    const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
+    if ((agx_u32)__builtin_amdgcn_readfirstlane((int)*A.long_count) <= AGX_LONG_MAX) return;      // (nothing to do: agx_k_tile_fill makes the lists)
+    if (i >= A.n_hits) return;
+    const agx_dhit d = A.dhit[i];
+    if (d.flags & AGX_HF_SKIP) return;
+    for (agx_u32 t = d.x_lo / AGX_TILE; t <= d.x_hi / AGX_TILE; t++) { const agx_u32 at = A.tile_off[t] + atomicAdd(&A.cursor[t], 1u); if (at < A.cap) A.unsorted[at] = i; }
+}
+__global__ void __launch_bounds__(256) agx_k_tile_sort(agx_fill_args A) {
+    __shared__ agx_u32 sh_i[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS], sh_k[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS];
+    const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
+    if (tile >= A.n_tiles) return;
+    if ((agx_u32)__builtin_amdgcn_readfirstlane((int)*A.long_count) <= AGX_LONG_MAX) return;
+    const agx_u32 lo = A.tile_off[tile], n = A.tile_off[tile + 1] - lo;
+    if (A.tile_off[tile + 1] > A.cap) return;            // lists did not fit: the host grows them and re-runs
+    const agx_u32 *src = A.scratch + lo;
+    if (n <= AGX_SORT_LDS) {
+        for (agx_u32 e = lane; e < n; e += 64) { const agx_u32 i = src[e]; sh_i[wave][e] = i; sh_k[wave][e] = A.perm[i]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        for (agx_u32 e = lane; e < n; e += 64) {
+            const agx_u32 key = sh_k[wave][e]; agx_u32 r = 0;
+            for (agx_u32 j = 0; j < n; j++) r += sh_k[wave][j] < key;
+            agx_put_rec((uint4 *)A.recs, lo + r, A.dhit, sh_i[wave][e], A.runs, tile, A.k);
+        }
+    } else {
+        for (agx_u32 e = lane; e < n; e += 64) {
+            const agx_u32 i = src[e], key = A.perm[i]; agx_u32 r = 0;
+            for (agx_u32 j = 0; j < n; j++) r += A.perm[src[j]] < key;
+            agx_put_rec((uint4 *)A.recs, lo + r, A.dhit, i, A.runs, tile, A.k);
         }
     }
 }
@@ -495,7 +520,7 @@ __global__ void __launch_bounds__(256) agx_k_edge_jump(agx_edge_kargs K) {
     AGX_RETURN_IF_ABORTED(K.abort);
     const agx_u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i >= K.n_jump) return;
-    const agx_u32 h = K.jump_list[i];
+    const agx_u32 h = K.jump_list[i];                   // (a place in the tile order: where the hit's derived record is)
     if (h >= K.n_hits) return;
     const agx_dhit d = K.S.dhit[h];
     agx_edge_jump_hit(K.S, d, [&](agx_u32 src, agx_u32 dst) { agx_slot_insert(K, src, dst); });
@@ -767,10 +792,11 @@ void agx_launch_exclusive_scan1(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsi
 void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_bin_fill, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
 }
-void agx_launch_tile_sort(const agx_u32 *tile_off, const agx_u32 *unsorted, agx_u32 n_tiles, agx_u32 cap, const agx_dhit *dhit, void *recs, const agx_run *runs, agx_u32 k,
-                          const agx_u32 *slots, agx_u32 slot_cap, const agx_u32 *dense, hipStream_t st) {
-    if (n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, tile_off, unsorted, n_tiles, cap, dhit,
-                                    (uint4 *)recs, runs, k, slots, slot_cap, dense);
+void agx_launch_tile_fill(const agx_fill_args *A, hipStream_t st) {
+    if (A->n_tiles) hipLaunchKernelGGL(agx_k_tile_fill, dim3((A->n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *A);
+}
+void agx_launch_tile_sort(const agx_fill_args *A, hipStream_t st) {
+    if (A->n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((A->n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *A);
 }
 void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
     const agx_u32 n = K->S.n_tiles;

@@ -948,4 +948,52 @@ bool load_pairs_fast(const ReadsIndex &reads, const std::string &sam_path, long 
     return true;
 }
 
+
+// ---- the hits in tile order (r05) -------------------------------------------------------------------------------------------------------
+// A stable two-level counting sort of (tile of the hit's first arrival, hit number) on the loader's threads: the upper bits of the tile first (a few thousand buckets, counted
+// per thread), then every bucket by the lower ten bits.  16 bytes per hit of temporary memory.
+void order_hits(const agx_whit *wh, size_t nh, const agx_wside *sd, const agx_wrun *wr, const agx_u32 *jump, size_t n_jump, size_t n_pos, unsigned threads,
+                agx_u32 *perm, agx_u32 *first, agx_u32 *jump_at) {
+    if (n_pos == 0 || nh >= 0xFFFFFFFFull) throw Error{E_ARG, "order_hits: empty unit or too many hits"};
+    const agx_u32 n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
+    Team team((unsigned)std::max<size_t>(1, std::min<size_t>(std::min(threads, 16u), nh / 65536 + 1)));
+    const unsigned T = team.size();
+    const agx_u32 B = (n_tiles >> 10) + 1;                                   // level-1 buckets: 1024 tiles each
+    Scratch keys_m(nh * 4 + 64), pairs_m(nh * 8 + 64);
+    agx_u32 *key = (agx_u32 *)keys_m.p; unsigned long long *pr = (unsigned long long *)pairs_m.p;      // pr: tile << 32 | hit number, by level-1 bucket
+    std::vector<size_t> cnt((size_t)T * B, 0);
+    team.run([&](unsigned t) {
+        size_t *c = cnt.data() + (size_t)t * B;
+        for (size_t i = nh * t / T, hi = nh * (t + 1) / T; i < hi; i++) {
+            agx_u32 tl = agx_whit_first_x(wh[i], sd, wr) / AGX_TILE; if (tl >= n_tiles) tl = n_tiles - 1;      // (an alignment beyond the unit: the build refuses the hit)
+            key[i] = tl; c[tl >> 10]++;
+        }
+    });
+    std::vector<size_t> bstart((size_t)B + 1, 0);
+    { size_t at = 0; for (agx_u32 b = 0; b < B; b++) { bstart[b] = at; for (unsigned t = 0; t < T; t++) { const size_t c = cnt[(size_t)t * B + b]; cnt[(size_t)t * B + b] = at; at += c; } } bstart[B] = at; }
+    team.run([&](unsigned t) {
+        size_t *c = cnt.data() + (size_t)t * B;
+        for (size_t i = nh * t / T, hi = nh * (t + 1) / T; i < hi; i++) pr[c[key[i] >> 10]++] = (unsigned long long)key[i] << 32 | (agx_u32)i;
+    });
+    std::atomic<agx_u32> next_b{0};
+    team.run([&](unsigned) {
+        agx_u32 local[1025];
+        for (agx_u32 b; (b = next_b.fetch_add(1)) < B;) {
+            const size_t lo = bstart[b], hi = bstart[b + 1];
+            memset(local, 0, sizeof local);
+            for (size_t j = lo; j < hi; j++) local[((agx_u32)(pr[j] >> 32) & 1023u) + 1]++;
+            for (agx_u32 q = 0; q < 1024; q++) { const agx_u32 tl = (b << 10) + q; if (tl < n_tiles) first[tl] = (agx_u32)lo + local[q]; local[q + 1] += local[q]; }
+            for (size_t j = lo; j < hi; j++) perm[lo + local[(agx_u32)(pr[j] >> 32) & 1023u]++] = (agx_u32)pr[j];      // stable: hit numbers ascend inside a tile
+        }
+    });
+    first[n_tiles] = (agx_u32)nh; first[n_tiles + 1] = (agx_u32)nh;
+    if (n_jump) {      // pass J's hits (those whose left mate has several runs) as places in the order
+        Scratch mark_m(nh + 64); agx_u8 *mk = (agx_u8 *)mark_m.p; memset(mk, 0, nh);
+        for (size_t j = 0; j < n_jump; j++) { if (jump[j] >= nh) throw Error{E_ARG, "pass J's list names a hit that does not exist"}; mk[jump[j]] = 1; }
+        size_t at = 0;
+        for (size_t i = 0; i < nh && at < n_jump; i++) if (mk[perm[i]]) jump_at[at++] = (agx_u32)i;
+        if (at != n_jump) throw Error{E_ARG, "pass J's list names a hit twice"};
+    }
+}
+
 }  // namespace agx

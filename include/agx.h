@@ -115,9 +115,9 @@ typedef struct {
     uint64_t n_spilled;                                          /* node ids taken from the pool's spill area (regions whose slice was full) */
     uint32_t build_attempts, from_cache;                         /* build_attempts: 1 unless a capacity had to grow and the build was repeated; from_cache: the unit was
                                                                     loaded from its cache file (agx_unit_cache_build), not from the text files */
-    uint32_t dense_lists, rows_by_reference;                     /* dense_lists: 0 = every tile's hit list fitted the tile's own slots; 1 = SOME list outgrew its slots (pile-ups, deep repeats) and
-                                                                    those lists alone went through the dense second pass (agx_k_bin_fill); 2 = a hit spans more than four tiles, so every list of
-                                                                    the unit went through it.
+    uint32_t dense_lists, rows_by_reference;                     /* dense_lists: 0 = every tile's hit list came out of its window of the hits' tile order (agx_k_tile_fill); 1 = some hits
+                                                                    span more tiles than the window looks back over (long deletions) and came through the list of long hits; 2 = more than
+                                                                    1024 such hits: every list of the unit was made by scatter (agx_k_bin_fill + agx_k_tile_sort).
                                                                     rows_by_reference: read rows the upload sent as their differences from the reference under their first hit's
                                                                     alignment (AGX_ROW_DIFF, engine: stage_rows; 0: all rows crossed as 2-bit classes) */
 } agx_stats;

@@ -100,3 +100,30 @@ def write_pileup_unit(run, n_pairs, spacing=300, genome_len=60000, seed=5):
             sf.write("%d\t99\t0\t%d\t42\t100M\t=\t%d\t%d\t*\t*\n" % (i, left + 1, right + 1, right + 100 - left))
             sf.write("%d\t147\t0\t%d\t42\t100M\t=\t%d\t%d\t*\t*\n" % (i, right + 1, left + 1, -(right + 100 - left)))
     return tmp
+
+
+def write_long_deletion_unit(run, n_pairs, deletion=60, genome_len=200000, seed=7):
+    """A hand-made unit (no contigs) whose left mates all carry ONE long deletion (40M<deletion>D60M: the longest the identity filter of loadReadAli lets through is
+    two thirds of the read, AG:1261): their arrivals span 160 positions, i.e. up to four tiles — more than a tile list's window looks back over at 2x100 bp (r05:
+    agx_tile_lookback), so they go through the list of long hits, or, beyond AGX_LONG_MAX of them, send the whole unit through the scatter fallback.  Returns tmp/."""
+    import random
+    rnd = random.Random(seed)
+    tmp = os.path.join(run, "tmp")
+    os.makedirs(tmp, exist_ok=True)
+    g = "".join(rnd.choice("ACGT") for _ in range(genome_len))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    with open(os.path.join(tmp, "_genome.0.fa"), "w") as f:
+        f.write(">0\n" + "".join(g[i:i + 60] + "\n" for i in range(0, genome_len, 60)))
+    open(os.path.join(tmp, "_contigs.fa"), "w").close()
+    open(os.path.join(tmp, "_contigs_genome.0.psl"), "w").close()
+    with open(os.path.join(tmp, "_reads.fa"), "w") as rf, open(os.path.join(tmp, "_reads_genome.0.bowtie"), "w") as sf:
+        for i in range(n_pairs):
+            left = rnd.randrange(100, genome_len - 1000)
+            right = left + 400 + rnd.randrange(0, 60)
+            plain = rnd.random() < 0.3                      # some ordinary pairs between them
+            m1 = g[left:left + 100] if plain else g[left:left + 40] + g[left + 40 + deletion:left + 100 + deletion]
+            m2 = "".join(comp[c] for c in reversed(g[right:right + 100]))
+            rf.write(">%d\n%s\n>%d\n%s\n" % (i, m1, i, m2))
+            sf.write("%d\t99\t0\t%d\t42\t%s\t=\t%d\t%d\t*\t*\n" % (i, left + 1, "100M" if plain else "40M%dD60M" % deletion, right + 1, right + 100 - left))
+            sf.write("%d\t147\t0\t%d\t42\t100M\t=\t%d\t%d\t*\t*\n" % (i, right + 1, left + 1, -(right + 100 - left)))
+    return tmp

@@ -447,6 +447,49 @@ extern "C" int agx_hostsim_compare_staged(const char *tmp_dir, int unit, int k, 
         if (S.n_jump && memcmp(F.sec(S_JUMP), S.jump, S.n_jump * 4) != 0) return bad("list of hits for pass J");
         if (S.n_codes && memcmp(F.sec(S_CODES), S.codes, S.n_codes) != 0) return bad("codes");
         if (S.n_other && memcmp(F.sec(S_OTHER), S.other, S.n_other * 8) != 0) return bad("list of other bases");
+        {   // the hits in tile order (order_hits, r05), against what the device's hit preparation will find: a permutation; the tile of every kept hit's first arrival (agx_hit_prep's x_lo)
+            // is its key; keys ascend, hit numbers ascend inside a key; tile_first counts; pass J's list names the same hits; every tile's list is what a filter over its
+            // window of the order (+ the long hits) gives — the very predicate agx_k_tile_fill applies
+            const size_t n_pos = [&] { std::string ref; load_unit_reference(d + "/_genome." + s + ".fa", ref); return ref.size(); }();
+            const agx_u32 n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
+            std::vector<agx_u32> perm(S.nh + 1), first((size_t)n_tiles + 2), jump_at(S.n_jump + 1);
+            order_hits(S.hits, S.nh, S.sides, S.runs, S.jump, S.n_jump, n_pos, (unsigned)threads, perm.data(), first.data(), jump_at.data());
+            std::vector<agx_run> runs(S.n_runs + 1); for (size_t i = 0; i < S.n_runs; i++) runs[i] = agx_run{S.runs[i].q, S.runs[i].t, S.runs[i].n};
+            std::vector<agx_u8> seen(S.nh, 0); std::vector<agx_dhit> dh(S.nh);
+            const agx_u32 lookback = agx_tile_lookback(S.maxlen, (agx_u32)k);
+            agx_u32 prev_t = 0, prev_h = 0; size_t jat = 0;
+            std::vector<agx_u32> longs;
+            for (size_t i = 0; i < S.nh; i++) {
+                const agx_u32 h = perm[i];
+                if (h >= S.nh || seen[h]) return bad("hits in tile order: not a permutation");
+                seen[h] = 1;
+                const agx_hit H = agx_unpack_hit(S.hits[h], S.sides);
+                (void)agx_hit_prep(H, false, (H.pad[0] & 1u) != 0, H.slot1, runs.data(), (agx_u32)k, dh[i]);
+                agx_u32 tl = agx_whit_first_x(S.hits[h], S.sides, S.runs) / AGX_TILE; if (tl >= n_tiles) tl = n_tiles - 1;
+                const bool kept = !(dh[i].flags & AGX_HF_SKIP) && dh[i].x_hi < n_pos;
+                if (kept && dh[i].x_lo / AGX_TILE != tl) return bad("hits in tile order: hit " + std::to_string(h) + " is keyed by tile " + std::to_string(tl) + " but its first arrival is at " + std::to_string(dh[i].x_lo));
+                if (i && (tl < prev_t || (tl == prev_t && h < prev_h))) return bad("hits in tile order: the order is not (tile, hit number)");
+                if (!(first[tl] <= i && i < first[tl + 1])) return bad("hits in tile order: tile_first does not hold hit " + std::to_string(h));
+                prev_t = tl; prev_h = h;
+                const bool is_jump = ((H.pad[0] & 1u) ? H.nruns2 : H.nruns1) >= 2;
+                if (is_jump) { if (jat >= S.n_jump || jump_at[jat] != i) return bad("hits in tile order: pass J's list"); jat++; }
+                if (kept && dh[i].x_hi / AGX_TILE - dh[i].x_lo / AGX_TILE >= lookback) longs.push_back((agx_u32)i);
+            }
+            if (jat != S.n_jump || first[0] != 0 || first[n_tiles] != S.nh) return bad("hits in tile order: counts");
+            for (agx_u32 t = 0; t < n_tiles; t++) {      // the window filter against the definition (every kept hit whose span holds the tile)
+                std::vector<agx_u32> want, got;
+                for (size_t i = first[t >= lookback - 1 ? t - (lookback - 1) : 0]; i < first[t + 1]; i++) {
+                    const bool kept = !(dh[i].flags & AGX_HF_SKIP) && dh[i].x_hi < n_pos, lng = kept && dh[i].x_hi / AGX_TILE - dh[i].x_lo / AGX_TILE >= lookback;
+                    if (kept && !lng && dh[i].x_hi / AGX_TILE >= t) got.push_back(perm[i]);
+                }
+                for (agx_u32 i : longs) if (dh[i].x_lo / AGX_TILE <= t && t <= dh[i].x_hi / AGX_TILE) got.push_back(perm[i]);
+                std::sort(got.begin(), got.end());
+                for (size_t i = 0; i < S.nh; i++) if (!(dh[i].flags & AGX_HF_SKIP) && dh[i].x_hi < n_pos && dh[i].x_lo / AGX_TILE <= t && t <= dh[i].x_hi / AGX_TILE) want.push_back(perm[i]);
+                std::sort(want.begin(), want.end());
+                if (want != got) return bad("hits in tile order: the window of tile " + std::to_string(t) + " does not give its list");
+                if (n_tiles > 2000 && t > 600 && t + 600 < n_tiles) t += 37;      // (large units: a sample of the tiles — the check is quadratic)
+            }
+        }
         const std::vector<agx_u8> ob = other_bytes_of(P, S);
         if (S.n_other && memcmp(F.sec(S_OTHERB), ob.data(), S.n_other) != 0) return bad("bytes of the other bases");
         // every base of every row, decoded the way the walk decodes a k-mer tail from the 2-bit rows, is the read's base

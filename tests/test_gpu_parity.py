@@ -362,6 +362,21 @@ def test_positions_beyond_64_variants_take_the_last_pass(agx, built, tmp_path, n
     assert g["stats"]["build_attempts"] == 2 and g["stats"]["n_big_tiles"] >= 1
 
 
+@pytest.mark.parametrize("n_pairs,mode", [(400, 1), (6000, 2)])
+def test_hits_that_span_more_tiles_than_the_window(agx, built, tmp_path, n_pairs, mode):
+    """r05: a tile's list is a filter over a window of the hits' tile order (agx_k_tile_fill); hits that reach further than the window looks back (here: 60-base deletions in
+    2x100 bp reads, four tiles) come through the list of long hits (mode 1), and a unit with more than 1024 of them makes all its lists by scatter (mode 2: agx_k_bin_fill +
+    agx_k_tile_sort).  Node and edge tables and the three outputs must be the oracle's either way."""
+    from conftest import write_long_deletion_unit
+    tmp = write_long_deletion_unit(str(tmp_path / "run"), n_pairs)
+    want = H.run_oracle(tmp, 0, 5, 50, 2, graph=True)
+    got = run_engine(agx, tmp, 0, 5, 50, 2, graph=True)
+    assert got["stats"]["dense_lists"] == mode, got["stats"]["dense_lists"]
+    assert graph_mismatch(want["graph"], got["graph"]) is None, graph_mismatch(want["graph"], got["graph"])
+    for key in ("initial", "pre", "extended"):
+        assert got[key] == want[key], key
+
+
 @pytest.mark.parametrize("masked", [False, True])
 def test_reference_bytes_that_are_not_acgt_survive_the_packed_upload(agx, built, tmp_path, masked):
     """The unit sequence crosses PCIe as 2 bits per base + the stretches of other bytes (agx_core.h wire formats); the reference emits a position's
