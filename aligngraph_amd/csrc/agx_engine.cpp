@@ -279,7 +279,7 @@ struct agx_unit {
     DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
     DBuf<agx_u32> d_node_start, d_slow_list, d_perm, d_tfirst, d_ckey, d_long; DBuf<agx_u16> d_node_cnt; DBuf<agx_u8> d_pos_succ;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
-    DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch, d_huge_list, d_scratch_huge; bool huge = false;      // huge: pass 3 of the node sweep is queued (a build met a position beyond AGX_MAXV_BIG variants)
+    DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch, d_huge_list, d_scratch_huge; bool huge = false, dense = false;      // dense: the scatter fallback of the tile lists is queued (a build met more than AGX_LONG_MAX long hits); huge: pass 3 of the node sweep is queued (a build met a position beyond AGX_MAXV_BIG variants)
     // walk graph (agx_core.h "walk preparation")
     agx_u32 n_ids = 0;
     DBuf<agx_u32> d_side_pk, d_tile_side, d_tile_side_start, d_aid_of; DBuf<char> d_a_str;
@@ -959,15 +959,12 @@ void do_build(agx_unit *u) {
         if (g_scan1) agx_launch_exclusive_scan1(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_desc.p, st);
         else agx_launch_exclusive_scan(u->d_tile_cnt.p, u->d_tile_off.p, u->n_tiles, u->d_scan_tmp.p, st);
         agx_fill_args FA{u->d_tile_off.p, u->d_tfirst.p, u->d_perm.p, u->d_ckey.p, u->d_dhit.p, u->d_runs.p, u->d_tile_recs.p, u->d_unsorted.p, u->n_tiles, u->list_cap, u->prm.k, u->lookback,
-                         u->d_long.p, u->d_words.p + W_LONGCOUNT, u->d_words.p + W_ERR};
+                         u->d_long.p, u->d_words.p + W_LONGCOUNT, u->d_words.p + W_ERR, u->d_words.p + W_STATUS, u->dense ? 1u : 0u};
         agx_launch_tile_fill(&FA, st);                  // every tile's list from its window of the tile order
-        {   // the fallback for units with more long hits than a list's window scan takes (both return at once otherwise; queued only where such hits can exist at all:
-            // a unit whose reads fit the window and carry no run pool cannot have one)
-            if (u->n_runs || u->lookback >= AGX_LOOKBACK_MAX) {
-                agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, u->d_words.p + W_LONGCOUNT};
-                agx_launch_bin_fill(&BA, st);
-                agx_launch_tile_sort(&FA, st);
-            }
+        if (u->dense) {                                 // the fallback for a unit with more long hits than a list's window scan takes: queued once a build has met them (an idle launch of a kernel per tile costs 0.1 ms)
+            agx_bin_args BA{u->d_dhit.p, nh, u->d_tile_off.p, u->d_cursor.p, u->d_unsorted.p, u->list_cap, u->d_words.p + W_LONGCOUNT};
+            agx_launch_bin_fill(&BA, st);
+            agx_launch_tile_sort(&FA, st);
         }
         AGX_CHECKPOINT("tile_sort");
         if (!u->expanded) {   // the vote codes (and the region layout, the last copy of the upload) are first needed by the sweep
@@ -1069,6 +1066,7 @@ void do_build(agx_unit *u) {
         // a capacity that was too small: take a larger buffer (the arena keeps the old one until the unit is released) and build again.
         // Whatever a retry changes on the device goes through the download stream and a fresh ev_uploaded, which the next attempt waits for.
         bool again = false;
+        if ((w[W_STATUS] & 16u) && !u->dense) { u->dense = true; HIP_OK(hipEventRecord(u->ev_uploaded, turn.down)); continue; }      // more long hits than the window scan takes: again, with the scatter fallback queued
         if (u->n_tile_entries > u->list_cap) { alloc_lists(u, u->n_tile_entries + u->n_tile_entries / 8 + 1024); again = true; }
         else {
             if ((w[W_STATUS] & 2u) && !u->huge) {     // a position beyond the 64 variants of pass 2 (deep repeats under a wide --distanceHigh): queue pass 3 and build again
@@ -1189,7 +1187,7 @@ void do_release(agx_unit *u) {
     u->d_units.release(); u->d_rowcnt.release(); u->d_blockoff.release(); u->d_blockfirst.release(); u->d_anchor.release();
     u->d_other.release(); u->d_whits.release(); u->d_wsides.release(); u->d_wruns.release(); u->d_wref.release(); u->d_refx.release();
     u->d_cm.release(); u->d_cm_head.release(); u->d_ref.release(); u->d_cm_cnt.release(); u->d_segs.release(); u->d_up_desc.release(); u->d_cntruns.release(); u->d_cntchunks.release(); u->d_segchunks.release(); u->d_jump.release(); u->d_segindex.release(); u->d_sp_hop.release(); u->d_runs.release(); u->d_dhit.release(); u->d_scan_desc.release(); u->d_sref.release(); u->d_counts.release();
-    u->d_ovf.release(); u->d_a_ovf.release(); u->d_huge_list.release(); u->d_scratch_huge.release(); u->huge = false; u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
+    u->d_ovf.release(); u->d_a_ovf.release(); u->d_huge_list.release(); u->d_scratch_huge.release(); u->huge = false; u->dense = false; u->d_a_str.release(); u->d_fetch.release(); u->d_sp_node.release(); u->d_sp_bits.release();
     u->arena.reset();
     u->h_a_str.release(); u->h_a_meta.release(); u->h_side_xpos.release(); u->h_sp_rank.release(); u->h_sp_bits.release(); u->h_sp_node.release(); u->h_fetch.release(); u->h_a_ovf.release();
     u->h_sp_hop.release();

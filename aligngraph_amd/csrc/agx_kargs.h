@@ -26,7 +26,8 @@ struct agx_node_kargs {
     agx_u32 *mid_count; agx_u32 *mid_list;   // tiles whose buckets did not fit pass 0's
     agx_u32 *big_count; agx_u32 *big_list;   // tiles whose buckets did not fit pass 1's either
     agx_u32 fallback_queued;   // the two fallback passes are queued behind the main pass (a unit's builds start without them: most units never overflow a bucket)
-    agx_u32 *status;           // bit 3: a tile overflowed the main pass and no fallback pass is queued; bit 0: a region's slice of the node pool exhausted; bit 1: bucket overflow in the global-scratch pass; bit 2: tile lists too small
+    agx_u32 *status;           // bit 3: a tile overflowed the main pass and no fallback pass is queued; bit 0: a region's slice of the node pool exhausted; bit 1: bucket overflow in the global-scratch pass; bit 2: tile lists too small;
+                               // bit 4 (set by agx_k_tile_fill, read by the main pass): the tile lists were not made
     agx_u32 list_cap;          // capacity of the tile lists: a tile whose list ends beyond it is skipped (the host re-runs with larger lists)
     const agx_u32 *big_n;      // passes 1 and 2: number of tiles in mid_list / big_list, read on the device (no host round trip)
     const agx_u32 *mid_n;
@@ -65,7 +66,8 @@ void agx_launch_exclusive_scan1(const agx_u32 *in, agx_u32 *out, agx_u32 n, unsi
 void agx_launch_bin_fill(const agx_bin_args *, hipStream_t);
 // the tile lists as the sweeps read them (32-byte records in SAM order): agx_k_tile_fill from the window of the tile order, or — the fallback — agx_k_tile_sort from bin_fill's dense lists
 struct agx_fill_args { const agx_u32 *tile_off, *tile_first, *perm, *ckey; const agx_dhit *dhit; const agx_run *runs; void *recs; agx_u32 *scratch /* = bin_fill's `unsorted` */;
-                       agx_u32 n_tiles, cap, k, lookback; const agx_u32 *long_list, *long_count; agx_u32 *err; };
+                       agx_u32 n_tiles, cap, k, lookback; const agx_u32 *long_list, *long_count; agx_u32 *err;
+                       agx_u32 *status; agx_u32 dense_queued; };      // status bit 4 (16): this unit needs the scatter fallback and it is not queued (dense_queued = 0): the build is repeated with it
 void agx_launch_tile_fill(const agx_fill_args *, hipStream_t);
 void agx_launch_tile_sort(const agx_fill_args *, hipStream_t);
 void agx_launch_node_sweep(const agx_node_kargs *, hipStream_t);

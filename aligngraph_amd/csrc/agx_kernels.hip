@@ -271,14 +271,40 @@ __global__ void __launch_bounds__(256) agx_k_tile_fill(agx_fill_args A) {
     const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
     if (tile >= A.n_tiles) return;
     const agx_u32 n_long = __builtin_amdgcn_readfirstlane((int)*A.long_count);
-    if (n_long > AGX_LONG_MAX) return;                   // the fallback makes this unit's lists (agx_k_bin_fill, agx_k_tile_sort)
-    const agx_u32 lo = A.tile_off[tile], n = A.tile_off[tile + 1] - lo;
-    if (A.tile_off[tile + 1] > A.cap) return;            // lists did not fit: the host grows them and re-runs
+    if (n_long > AGX_LONG_MAX) {                         // the fallback makes this unit's lists (agx_k_bin_fill, agx_k_tile_sort) — if it is queued; else nothing behind this kernel may run, and the host repeats the build with it
+        if (!A.dense_queued && tile == 0 && lane == 0) atomicOr(A.status, 16u);
+        return;
+    }
+    const agx_u32 lo = agx_uload(A.tile_off, tile), hi_off = agx_uload(A.tile_off, tile + 1), n = hi_off - lo;
+    const agx_u32 c_lo = agx_uload(A.tile_first, tile >= A.lookback - 1u ? tile - (A.lookback - 1u) : 0u), c_hi = agx_uload(A.tile_first, tile + 1);
+    if (hi_off > A.cap) return;                          // lists did not fit: the host grows them and re-runs
     if (n == 0) return;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (c_hi - c_lo <= 64u && n_long == 0) {
+        // The usual tile: its window holds at most 64 hits — a lane per hit.  Key, hit number and the derived record are loaded TOGETHER (a lane that turns out not to
+        // reach this tile has loaded 40 bytes for nothing; a dependent round trip less for everybody: the kernel's time is the depth of its chain of loads), the
+        // kept hits' numbers meet in LDS, and every kept lane writes its own record at its rank.
+        const agx_u32 i = c_lo + lane; const bool in = i < c_hi;
+        const agx_u32 key = in ? A.ckey[i] : AGX_NONE, h = in ? A.perm[i] : 0u;
+        const agx_dhit d = A.dhit[in ? i : c_lo];
+        const bool ok = in && key != AGX_NONE && key >= tile;
+        const unsigned long long m = __ballot(ok);
+        if ((agx_u32)__popcll(m) != n) { if (lane == 0) atomicOr(A.err, 8u); return; }
+        if (ok) sh_k[wave][__popcll(m & below)] = h;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (single wavefront: its LDS writes are visible to its own later reads)
+        if (ok) {
+            agx_u32 r = 0;
+            for (agx_u32 j = 0; j < n; j++) r += sh_k[wave][j] < h;
+            const agx_dhit p = agx_tile_record(d, A.runs, tile, A.k);
+            uint4 *recs = (uint4 *)A.recs;
+            recs[2 * (size_t)(lo + r)] = make_uint4(p.a_t0, p.b_t0, p.a_runs, p.b_runs);
+            recs[2 * (size_t)(lo + r) + 1] = make_uint4(p.a_slot, (agx_u32)p.len | ((agx_u32)p.jstar << 16), (agx_u32)p.a_nruns | ((agx_u32)p.b_nruns << 16), p.flags);
+        }
+        return;
+    }
+    // wider windows (pile-ups, long reads) and units with long hits: collect what is kept, then rank
     const bool in_lds = n <= AGX_SORT_LDS;
     agx_u32 *gi = A.scratch + lo;                        // pile-ups beyond the LDS window: the kept entries' places in the order, in the tile's share of the scratch list
-    const agx_u32 c_lo = A.tile_first[tile >= A.lookback - 1u ? tile - (A.lookback - 1u) : 0u], c_hi = A.tile_first[tile + 1];
-    const unsigned long long below = (1ull << lane) - 1ull;
     agx_u32 kept = 0;
     auto take = [&](bool ok, agx_u32 i) {                // (called by all lanes together)
         const unsigned long long m = __ballot(ok);
@@ -298,7 +324,6 @@ __global__ void __launch_bounds__(256) agx_k_tile_fill(agx_fill_args A) {
         take(in && x_lo / AGX_TILE <= tile && tile <= x_hi / AGX_TILE, i);
     }
     if (kept != n) { if (lane == 0) atomicOr(A.err, 8u); return; }
-    // single wavefront: its LDS / global writes above are visible to its own later reads after the fence
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     if (in_lds) {
         for (agx_u32 e = lane; e < n; e += 64) {
@@ -385,6 +410,7 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
     constexpr agx_u32 MAXV = PASS == 0 ? AGX_MAXV_LDS : AGX_MAXV_MID;
     __shared__ agx_u32 lds[BIG ? 1 : AGX_SWEEP_WAVES][BIG ? 1 : AGX_NF * MAXV * 64];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (PASS == 0 && (agx_uload(K.status, 0) & 16u)) return;      // the tile lists were not made (a unit whose long hits need the scatter fallback, which was not queued): the host repeats the build with it
     // Workgroups are handed to the 8 XCDs round-robin and every XCD has its own L2.  Neighbouring tiles read the same hit records, read
     // bases and conti-mer heads, so block b takes the (b / 8)-th block of tiles of XCD (b % 8)'s contiguous share of the unit rather than
     // tile block b: what one tile pulled into an L2 is there for its neighbours.
