@@ -106,7 +106,11 @@ struct agx_cmhead { agx_u32 cid, coff, n, start; };
 
 enum { AGX_HF_AREV = 1, AGX_HF_SKIP = 2, AGX_HF_BNONE = 4 };      // BNONE (tile records only): the b mate is unaligned over the whole piece
 
+#ifdef AGX_DHIT48
+struct alignas(16) agx_dhit {      // (experiment, r05: 48 bytes, 16-byte aligned, so that a lane fetches its record with three 16-byte loads instead of ten 4-byte ones: agx_k_tile_fill 0.80 ms instead of 0.53)
+#else
 struct agx_dhit {
+#endif
     agx_u32 a_t0, b_t0;       // simple mate: reference offset of read index 0 ("a" = the left mate, AG:1672-1679)
     agx_u32 a_runs, b_runs;
     agx_u32 a_slot;           // read slot of the a mate
@@ -114,6 +118,9 @@ struct agx_dhit {
     agx_u16 a_nruns, b_nruns; // 0 = simple
     agx_u32 flags;
     agx_u32 x_lo, x_hi;       // first / last position that receives an arrival (x_lo > x_hi: none)
+#ifdef AGX_DHIT48
+    agx_u32 pad[2];
+#endif
 };
 
 // ---- node table (device -> host) ----------------------------------------------------------------------
@@ -328,36 +335,69 @@ AGX_HD int agx_hit_prep(const agx_hit &H, bool dup, bool swap, agx_u32 a_slot, c
 // their mates, but a break point lies in one tile: the other tiles the hit touches see a single run of the a mate against a single run, or
 // a hole, of the b mate).  A piece must give, for every position of the tile, exactly what the general decode gives: the same index, type
 // and mate position, the successor on the next position with the next mate position.
-AGX_HD agx_dhit agx_tile_record(const agx_dhit &d, const agx_run *runs, agx_u32 tile, agx_u32 k) {
-    if ((d.a_nruns == 0 && d.b_nruns == 0) || (d.flags & AGX_HF_SKIP)) return d;
-    const agx_u32 L = d.len, js = d.jstar, t0 = tile * AGX_TILE;
-    const agx_u32 xs = d.x_lo > t0 ? d.x_lo : t0, xe = d.x_hi < t0 + AGX_TILE - 1u ? d.x_hi : t0 + AGX_TILE - 1u;
-    if (xs > xe || js == 0xFFFFu || L <= k) return d;
+// (agx_tile_piece hands the piece back as scalars: a record chosen between two structs is a choice between two addresses to the compiler, and both then live in scratch
+// memory on the device — r05 measured agx_k_tile_fill at 0.72 ms that way against 0.51)
+// (the record's fields come as values: a record that exists as a struct in a kernel's registers and is then chosen from — `runs ? runs[i].t : d.a_t0` — is a choice
+// between two addresses to the compiler, and the struct then lives in scratch memory on the device)
+AGX_HD bool agx_tile_piece_v(agx_u32 d_a_t0, agx_u32 d_b_t0, agx_u32 d_a_runs, agx_u32 d_b_runs, agx_u32 L, agx_u32 js, agx_u32 d_a_nruns, agx_u32 d_b_nruns, agx_u32 d_flags, agx_u32 d_x_lo, agx_u32 d_x_hi,
+                             const agx_run *runs, agx_u32 tile, agx_u32 k, agx_u32 &p_a_t0, agx_u32 &p_b_t0, agx_u32 &p_a_runs, bool &p_bnone) {
+    p_a_t0 = 0; p_b_t0 = 0; p_a_runs = 0; p_bnone = false;
+    if ((d_a_nruns == 0 && d_b_nruns == 0) || (d_flags & AGX_HF_SKIP)) return false;
+    const agx_u32 t0 = tile * AGX_TILE;
+    const agx_u32 xs = d_x_lo > t0 ? d_x_lo : t0, xe = d_x_hi < t0 + AGX_TILE - 1u ? d_x_hi : t0 + AGX_TILE - 1u;
+    if (xs > xe || js == 0xFFFFu || L <= k) return false;
     // the a run that holds xs must hold xe, and xe + 1 too if xe is an event source (its successor is then the next position)
-    const agx_u32 na = d.a_nruns ? d.a_nruns : 1u;
-    agx_run r = agx_run{0u, 0u, 0u}; bool found = false;
-    for (agx_u32 i = 0; i < na; i++) { const agx_run c = d.a_nruns ? runs[d.a_runs + i] : agx_run{0u, d.a_t0, L}; if (c.n && xs >= c.t && xs - c.t < c.n) { r = c; found = true; } }
-    if (!found || xe - r.t >= r.n) return d;
-    const agx_u32 qs = r.q + (xs - r.t), qe = r.q + (xe - r.t);
-    if (qe > js) return d;                                  // (cannot happen: x_hi is jstar's position)
-    if (qe < js && xe + 1u - r.t >= r.n) return d;
+    const agx_u32 na = d_a_nruns ? d_a_nruns : 1u;
+    agx_u32 r_q = 0, r_t = 0, r_n = 0; bool found = false;
+    for (agx_u32 i = 0; i < na; i++) {
+        agx_u32 c_q = 0, c_t = d_a_t0, c_n = L;
+        if (d_a_nruns) { const agx_run c = runs[d_a_runs + i]; c_q = c.q; c_t = c.t; c_n = c.n; }
+        if (c_n && xs >= c_t && xs - c_t < c_n) { r_q = c_q; r_t = c_t; r_n = c_n; found = true; }
+    }
+    if (!found || xe - r_t >= r_n) return false;
+    const agx_u32 qs = r_q + (xs - r_t), qe = r_q + (xe - r_t);
+    if (qe > js) return false;                              // (cannot happen: x_hi is jstar's position)
+    if (qe < js && xe + 1u - r_t >= r_n) return false;
     const agx_u32 qe2 = qe < js ? qe + 1u : qe;             // the last index whose mate position is looked at
     // the b mate over qs .. qe2: one run, or nothing at all
-    const agx_u32 nb = d.b_nruns ? d.b_nruns : 1u;
-    agx_run rb = agx_run{0u, 0u, 0u}; bool in_b = false, touches = false;
+    const agx_u32 nb = d_b_nruns ? d_b_nruns : 1u;
+    agx_u32 rb_q = 0, rb_t = 0, rb_n = 0; bool in_b = false, touches = false;
     for (agx_u32 i = 0; i < nb; i++) {
-        const agx_run c = d.b_nruns ? runs[d.b_runs + i] : agx_run{0u, d.b_t0, L};
-        if (!c.n) continue;
-        if (qs >= c.q && qs - c.q < c.n) { rb = c; in_b = true; }
-        if (c.q <= qe2 && c.q + c.n > qs) touches = true;
+        agx_u32 c_q = 0, c_t = d_b_t0, c_n = L;
+        if (d_b_nruns) { const agx_run c = runs[d_b_runs + i]; c_q = c.q; c_t = c.t; c_n = c.n; }
+        if (!c_n) continue;
+        if (qs >= c_q && qs - c_q < c_n) { rb_q = c_q; rb_t = c_t; rb_n = c_n; in_b = true; }
+        if (c_q <= qe2 && c_q + c_n > qs) touches = true;
     }
-    if (in_b && qe2 - rb.q >= rb.n) return d;
-    if (!in_b && touches) return d;
+    if (in_b && qe2 - rb_q >= rb_n) return false;
+    if (!in_b && touches) return false;
+    p_a_t0 = r_t - r_q; p_b_t0 = in_b ? rb_t - rb_q : 0u; p_a_runs = qs | (qe << 16); p_bnone = !in_b;
+    return true;
+}
+AGX_HD bool agx_tile_piece(const agx_dhit &d, const agx_run *runs, agx_u32 tile, agx_u32 k, agx_u32 &p_a_t0, agx_u32 &p_b_t0, agx_u32 &p_a_runs, bool &p_bnone) {
+    return agx_tile_piece_v(d.a_t0, d.b_t0, d.a_runs, d.b_runs, d.len, d.jstar, d.a_nruns, d.b_nruns, d.flags, d.x_lo, d.x_hi, runs, tile, k, p_a_t0, p_b_t0, p_a_runs, p_bnone);
+}
+AGX_HD agx_dhit agx_tile_record(const agx_dhit &d, const agx_run *runs, agx_u32 tile, agx_u32 k) {
+    agx_u32 a_t0, b_t0, a_runs; bool bnone;
     agx_dhit p = d;
-    p.a_t0 = r.t - r.q; p.b_t0 = in_b ? rb.t - rb.q : 0u; p.a_runs = qs | (qe << 16); p.b_runs = 0; p.a_nruns = p.b_nruns = 0;
-    if (!in_b) p.flags |= AGX_HF_BNONE;
+    if (agx_tile_piece(d, runs, tile, k, a_t0, b_t0, a_runs, bnone)) { p.a_t0 = a_t0; p.b_t0 = b_t0; p.a_runs = a_runs; p.b_runs = 0; p.a_nruns = p.b_nruns = 0; if (bnone) p.flags |= AGX_HF_BNONE; }
     return p;
 }
+// the two 16-byte halves of the 32-byte record agx_k_tile_fill / agx_k_tile_sort write for hit record d in the list of `tile` (what agx_tile_recs reads back)
+#if defined(__HIPCC__)
+// w0 .. w4: the record as its five 8-byte words (a_t0, b_t0 | a_runs, b_runs | a_slot, len + jstar | a_nruns + b_nruns, flags | x_lo, x_hi)
+AGX_HD void agx_tile_record_words_v(uint2 w0, uint2 w1, uint2 w2, uint2 w3, uint2 w4, const agx_run *runs, agx_u32 tile, agx_u32 k, uint4 &lo, uint4 &hi) {
+    agx_u32 a_t0, b_t0, a_runs; bool bnone;
+    const bool piece = agx_tile_piece_v(w0.x, w0.y, w1.x, w1.y, w2.y & 0xFFFFu, w2.y >> 16, w3.x & 0xFFFFu, w3.x >> 16, w3.y, w4.x, w4.y, runs, tile, k, a_t0, b_t0, a_runs, bnone);
+    lo = make_uint4(piece ? a_t0 : w0.x, piece ? b_t0 : w0.y, piece ? a_runs : w1.x, piece ? 0u : w1.y);
+    hi = make_uint4(w2.x, w2.y, piece ? 0u : w3.x, w3.y | ((piece && bnone) ? (agx_u32)AGX_HF_BNONE : 0u));
+}
+AGX_HD void agx_tile_record_words(const agx_dhit &d, const agx_run *runs, agx_u32 tile, agx_u32 k, uint4 &lo, uint4 &hi) {
+    static_assert(sizeof(agx_dhit) == 40, "a derived record is five 8-byte words");
+    const uint2 *w = reinterpret_cast<const uint2 *>(&d);
+    agx_tile_record_words_v(w[0], w[1], w[2], w[3], w[4], runs, tile, k, lo, hi);
+}
+#endif
 
 // conti-mer head of position x (upload-time kernel / test executor).  The table has n_pos + 1 entries: entry n_pos is the head of "no
 // position" (no conti-mers), which the node sweep loads for an arrival without a mate position instead of selecting afterwards.

@@ -257,79 +257,50 @@ __global__ void __launch_bounds__(256) agx_k_scan_lookback(const agx_u32 *in, ag
 #define AGX_SORT_LDS 512       // list entries of a tile sorted in LDS (a tile of the bench units holds ~27; 2048 — 32 KB per block — kept the kernel at 20 of a CU's 32 wavefronts)
 // A record is the first 32 bytes of agx_tile_record(): the hit's derived record, or the linear piece of it that covers this tile.  i: the hit's place in the tile order.
 __device__ __forceinline__ void agx_put_rec(uint4 *recs, agx_u32 at, const agx_dhit *dhit, agx_u32 i, const agx_run *runs, agx_u32 tile, agx_u32 k) {
-    const agx_dhit d = agx_tile_record(dhit[i], runs, tile, k);
-    recs[2 * (size_t)at] = make_uint4(d.a_t0, d.b_t0, d.a_runs, d.b_runs);
-    recs[2 * (size_t)at + 1] = make_uint4(d.a_slot, (agx_u32)d.len | ((agx_u32)d.jstar << 16), (agx_u32)d.a_nruns | ((agx_u32)d.b_nruns << 16), d.flags);
+    uint4 lo, hi; agx_tile_record_words(dhit[i], runs, tile, k, lo, hi);
+    recs[2 * (size_t)at] = lo; recs[2 * (size_t)at + 1] = hi;
 }
-// One wavefront per tile.  The hits are in the order of their first tile, so the hits that reach tile t are among those whose first tile is t - lookback + 1 .. t: a
-// contiguous WINDOW of the order (tile_first), filtered by the last tile each hit reaches (ckey) — coalesced reads of 4-byte keys, no scatter, no atomics — plus the few
-// hits that span more tiles than the window looks back over (long_list).  What is kept is ranked by hit number (= place in the SAM file; unique, so an entry's rank is
-// the number of smaller keys) and the records are written at tile_off[t] + rank.  The count must be the histogram's (hit_prep counted the same hits): err bit 3 otherwise.
-__global__ void __launch_bounds__(256) agx_k_tile_fill(agx_fill_args A) {
-    __shared__ agx_u32 sh_i[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS], sh_k[AGX_WAVES_PER_BLOCK][AGX_SORT_LDS];
-    const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const agx_u32 tile = __builtin_amdgcn_readfirstlane(blockIdx.x * AGX_WAVES_PER_BLOCK + wave);
-    if (tile >= A.n_tiles) return;
-    const agx_u32 n_long = __builtin_amdgcn_readfirstlane((int)*A.long_count);
-    if (n_long > AGX_LONG_MAX) {                         // the fallback makes this unit's lists (agx_k_bin_fill, agx_k_tile_sort) — if it is queued; else nothing behind this kernel may run, and the host repeats the build with it
-        if (!A.dense_queued && tile == 0 && lane == 0) atomicOr(A.status, 16u);
-        return;
-    }
-    const agx_u32 lo = agx_uload(A.tile_off, tile), hi_off = agx_uload(A.tile_off, tile + 1), n = hi_off - lo;
-    const agx_u32 c_lo = agx_uload(A.tile_first, tile >= A.lookback - 1u ? tile - (A.lookback - 1u) : 0u), c_hi = agx_uload(A.tile_first, tile + 1);
-    if (hi_off > A.cap) return;                          // lists did not fit: the host grows them and re-runs
-    if (n == 0) return;
+// The hits are in the order of their first tile, so the hits that reach tile t are among those whose first tile is t - lookback + 1 .. t: a contiguous WINDOW of the
+// order (tile_first), filtered by the last tile each hit reaches (ckey) — coalesced reads of 4-byte keys and hit numbers, no scatter, no atomics — plus the few hits that
+// span more tiles than the window looks back over (long_list).  What is kept is compacted into the wavefront's low lanes, ranked by hit number (= place in the SAM file;
+// unique, so an entry's rank is the number of smaller keys) and the records are written at tile_off[t] + rank.  The count must be the histogram's (hit_prep counted the
+// same hits): err bit 3 otherwise.
+//
+// The kernel's time is the depth of its chain of dependent loads (offsets -> keys -> derived records -> runs -> stores: ~9 us per tile) times the rounds of
+// resident wavefronts (a CU holds 32): 0.51 ms for the 476 k tiles of a 30 Mb unit with a wavefront per tile.  So a wavefront takes TWO tiles and issues each level
+// of loads for both before it waits for either.  (Measured on the way, one tile per wavefront: a lane per window hit that fetches its own record 0.74 ms — the kept lanes
+// lie scattered over the wavefront, and a vector memory instruction costs by the quads of lanes it touches: compacting the kept hits into the low lanes first is worth a
+// third; the window's records staged through LDS 0.65; records padded to 48 bytes for 16-byte loads 0.80.)
+// the general form, one tile: any window, any list length, long hits
+__device__ __forceinline__ void agx_tile_fill_general(const agx_fill_args &A, agx_u32 tile, agx_u32 lo, agx_u32 n, agx_u32 c_lo, agx_u32 c_hi, agx_u32 n_long, agx_u32 *sh_i, agx_u32 *sh_k, agx_u32 lane) {
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (c_hi - c_lo <= 64u && n_long == 0) {
-        // The usual tile: its window holds at most 64 hits — a lane per hit.  Key, hit number and the derived record are loaded TOGETHER (a lane that turns out not to
-        // reach this tile has loaded 40 bytes for nothing; a dependent round trip less for everybody: the kernel's time is the depth of its chain of loads), the
-        // kept hits' numbers meet in LDS, and every kept lane writes its own record at its rank.
-        const agx_u32 i = c_lo + lane; const bool in = i < c_hi;
-        const agx_u32 key = in ? A.ckey[i] : AGX_NONE, h = in ? A.perm[i] : 0u;
-        const agx_dhit d = A.dhit[in ? i : c_lo];
-        const bool ok = in && key != AGX_NONE && key >= tile;
-        const unsigned long long m = __ballot(ok);
-        if ((agx_u32)__popcll(m) != n) { if (lane == 0) atomicOr(A.err, 8u); return; }
-        if (ok) sh_k[wave][__popcll(m & below)] = h;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (single wavefront: its LDS writes are visible to its own later reads)
-        if (ok) {
-            agx_u32 r = 0;
-            for (agx_u32 j = 0; j < n; j++) r += sh_k[wave][j] < h;
-            const agx_dhit p = agx_tile_record(d, A.runs, tile, A.k);
-            uint4 *recs = (uint4 *)A.recs;
-            recs[2 * (size_t)(lo + r)] = make_uint4(p.a_t0, p.b_t0, p.a_runs, p.b_runs);
-            recs[2 * (size_t)(lo + r) + 1] = make_uint4(p.a_slot, (agx_u32)p.len | ((agx_u32)p.jstar << 16), (agx_u32)p.a_nruns | ((agx_u32)p.b_nruns << 16), p.flags);
-        }
-        return;
-    }
-    // wider windows (pile-ups, long reads) and units with long hits: collect what is kept, then rank
     const bool in_lds = n <= AGX_SORT_LDS;
     agx_u32 *gi = A.scratch + lo;                        // pile-ups beyond the LDS window: the kept entries' places in the order, in the tile's share of the scratch list
     agx_u32 kept = 0;
-    auto take = [&](bool ok, agx_u32 i) {                // (called by all lanes together)
+    auto take = [&](bool ok, agx_u32 i, agx_u32 h) {     // (called by all lanes together; h: the hit's number)
         const unsigned long long m = __ballot(ok);
         const agx_u32 at = kept + (agx_u32)__popcll(m & below);
-        if (ok && at < n) { if (in_lds) { sh_i[wave][at] = i; sh_k[wave][at] = A.perm[i]; } else gi[at] = i; }
+        if (ok && at < n) { if (in_lds) { sh_i[at] = i; sh_k[at] = h; } else gi[at] = i; }
         kept += (agx_u32)__popcll(m);
     };
     for (agx_u32 base = c_lo; base < c_hi; base += 64) {
         const agx_u32 i = base + lane; const bool in = i < c_hi;
-        const agx_u32 key = in ? A.ckey[i] : AGX_NONE;
-        take(in && key != AGX_NONE && key >= tile, i);
+        const agx_u32 key = in ? A.ckey[i] : AGX_NONE, h = in ? A.perm[i] : 0u;      // (both coalesced: the hit number travels with the key instead of behind the verdict)
+        take(in && key != AGX_NONE && key >= tile, i, h);
     }
     for (agx_u32 base = 0; base < n_long; base += 64) {
         const agx_u32 j = base + lane; const bool in = j < n_long;
         const agx_u32 i = in ? A.long_list[j] : 0u;
         const agx_u32 x_lo = in ? A.dhit[i].x_lo : 1u, x_hi = in ? A.dhit[i].x_hi : 0u;
-        take(in && x_lo / AGX_TILE <= tile && tile <= x_hi / AGX_TILE, i);
+        take(in && x_lo / AGX_TILE <= tile && tile <= x_hi / AGX_TILE, i, in ? A.perm[i] : 0u);
     }
     if (kept != n) { if (lane == 0) atomicOr(A.err, 8u); return; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (single wavefront: its LDS / global writes above are visible to its own later reads)
     if (in_lds) {
         for (agx_u32 e = lane; e < n; e += 64) {
-            const agx_u32 key = sh_k[wave][e]; agx_u32 r = 0;
-            for (agx_u32 j = 0; j < n; j++) r += sh_k[wave][j] < key;
-            agx_put_rec((uint4 *)A.recs, lo + r, A.dhit, sh_i[wave][e], A.runs, tile, A.k);
+            const agx_u32 key = sh_k[e]; agx_u32 r = 0;
+            for (agx_u32 j = 0; j < n; j++) r += sh_k[j] < key;
+            agx_put_rec((uint4 *)A.recs, lo + r, A.dhit, sh_i[e], A.runs, tile, A.k);
         }
     } else {                                             // the same rank sort straight from L2
         for (agx_u32 e = lane; e < n; e += 64) {
@@ -338,6 +309,79 @@ __global__ void __launch_bounds__(256) agx_k_tile_fill(agx_fill_args A) {
             agx_put_rec((uint4 *)A.recs, lo + r, A.dhit, i, A.runs, tile, A.k);
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (the wavefront's next tile uses the same LDS)
+}
+#ifndef AGX_FILL_TILES
+#define AGX_FILL_TILES 2u      // tiles per wavefront
+#endif
+__global__ void __launch_bounds__(256) agx_k_tile_fill(agx_fill_args A) {
+    // per wavefront 4 KB of LDS: the kept hits' places in the order [0, 512) and their hit numbers [512, 1024) (the general form); the usual tiles use 128 words each
+    __shared__ agx_u32 sh[AGX_WAVES_PER_BLOCK][2 * AGX_SORT_LDS];
+    static_assert(AGX_FILL_TILES * 128u <= 2u * AGX_SORT_LDS, "two tiles' kept hits must fit the wavefront's LDS");
+    const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const agx_u32 t_first = __builtin_amdgcn_readfirstlane((blockIdx.x * AGX_WAVES_PER_BLOCK + wave) * AGX_FILL_TILES);
+    if (t_first >= A.n_tiles) return;
+    const agx_u32 n_long = __builtin_amdgcn_readfirstlane((int)*A.long_count);
+    if (n_long > AGX_LONG_MAX) {                         // the fallback makes this unit's lists (agx_k_bin_fill, agx_k_tile_sort) — if it is queued; else nothing behind this kernel may run, and the host repeats the build with it
+        if (!A.dense_queued && t_first == 0 && lane == 0) atomicOr(A.status, 16u);
+        return;
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    agx_u32 tile[AGX_FILL_TILES], lo[AGX_FILL_TILES], n[AGX_FILL_TILES], c_lo[AGX_FILL_TILES], c_hi[AGX_FILL_TILES]; bool todo[AGX_FILL_TILES], fast[AGX_FILL_TILES];
+    // level 0 (scalar loads): list offsets and windows
+#pragma unroll
+    for (agx_u32 t = 0; t < AGX_FILL_TILES; t++) {
+        tile[t] = t_first + t;
+        const bool valid = tile[t] < A.n_tiles;
+        const agx_u32 tt = valid ? tile[t] : t_first;
+        lo[t] = agx_uload(A.tile_off, tt); const agx_u32 hi_off = agx_uload(A.tile_off, tt + 1); n[t] = hi_off - lo[t];
+        c_lo[t] = agx_uload(A.tile_first, tt >= A.lookback - 1u ? tt - (A.lookback - 1u) : 0u); c_hi[t] = agx_uload(A.tile_first, tt + 1);
+        todo[t] = valid && n[t] != 0 && hi_off <= A.cap;      // (lists that did not fit: the host grows them and re-runs)
+        fast[t] = todo[t] && n_long == 0 && c_hi[t] - c_lo[t] <= 64u;
+    }
+    // level 1: keys and hit numbers of the windows (a lane per hit), both tiles' loads in flight together
+    agx_u32 key[AGX_FILL_TILES], hn[AGX_FILL_TILES];
+#pragma unroll
+    for (agx_u32 t = 0; t < AGX_FILL_TILES; t++) {
+        const agx_u32 i = c_lo[t] + lane; const bool in = fast[t] && i < c_hi[t];
+        key[t] = in ? A.ckey[i] : AGX_NONE; hn[t] = in ? A.perm[i] : 0u;
+    }
+    // level 2: the kept hits into the low lanes (through LDS)
+#pragma unroll
+    for (agx_u32 t = 0; t < AGX_FILL_TILES; t++) {
+        const bool ok = fast[t] && key[t] != AGX_NONE && key[t] >= tile[t];
+        const unsigned long long m = __ballot(ok);
+        if (fast[t] && (agx_u32)__popcll(m) != n[t]) { if (lane == 0) atomicOr(A.err, 8u); fast[t] = false; todo[t] = false; }
+        if (ok && fast[t]) { const agx_u32 at = (agx_u32)__popcll(m & below); sh[wave][t * 128u + at] = c_lo[t] + lane; sh[wave][t * 128u + 64u + at] = hn[t]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (single wavefront: its LDS writes are visible to its own later reads)
+    // level 3: the derived records of the kept hits — as five 8-byte words each, never as a struct: a record that exists as a struct in registers ends up in scratch
+    // memory (agx_tile_piece_v; measured: 0.72 ms instead of 0.36)
+    bool act[AGX_FILL_TILES]; agx_u32 mine[AGX_FILL_TILES]; uint2 w[AGX_FILL_TILES][5];
+#pragma unroll
+    for (agx_u32 t = 0; t < AGX_FILL_TILES; t++) {
+        act[t] = fast[t] && lane < n[t];
+        const agx_u32 i = act[t] ? sh[wave][t * 128u + lane] : (fast[t] ? c_lo[t] : 0u); mine[t] = act[t] ? sh[wave][t * 128u + 64u + lane] : 0u;
+        const uint2 *g = reinterpret_cast<const uint2 *>(A.dhit + i);
+#pragma unroll
+        for (int q = 0; q < 5; q++) w[t][q] = g[q];
+    }
+    // level 4: ranks (while the records travel), level 5: the tile's pieces of the records, written at their ranks
+    agx_u32 r[AGX_FILL_TILES];
+#pragma unroll
+    for (agx_u32 t = 0; t < AGX_FILL_TILES; t++) {
+        r[t] = 0;
+        if (fast[t]) for (agx_u32 j = 0; j < n[t]; j++) r[t] += sh[wave][t * 128u + 64u + j] < mine[t];
+    }
+    uint4 *recs = (uint4 *)A.recs;
+#pragma unroll
+    for (agx_u32 t = 0; t < AGX_FILL_TILES; t++)
+        if (act[t]) { uint4 wl, wh; agx_tile_record_words_v(w[t][0], w[t][1], w[t][2], w[t][3], w[t][4], A.runs, tile[t], A.k, wl, wh); const size_t at = (size_t)lo[t] + r[t]; recs[2 * at] = wl; recs[2 * at + 1] = wh; }
+    // wider windows (pile-ups, long reads) and units with long hits: one tile after the other
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+    for (agx_u32 t = 0; t < AGX_FILL_TILES; t++)
+        if (todo[t] && !fast[t]) agx_tile_fill_general(A, tile[t], lo[t], n[t], c_lo[t], c_hi[t], n_long, sh[wave], sh[wave] + AGX_SORT_LDS, lane);
 }
 
 // The fallback — a unit with more than AGX_LONG_MAX hits that span more tiles than the window looks back over (very long reads, many long deletions): every hit takes
@@ -684,39 +728,74 @@ __global__ void __launch_bounds__(256) agx_k_special_bits(agx_compact_args A, ag
         if (lane == 0 && w0 + j < n_words) { A.sp_bits[w0 + j] = bits; A.sp_cnt[w0 + j] = (agx_u32)__popcll(bits); }
     }
 }
-// gather the special records in id order
+// gather the special records in id order.  A wavefront takes AGX_SE_WORDS 64-id words, a lane one id of each: one id in thirteen is special, so a lane that served a single
+// word had a load in flight one time in thirteen and the kernel's time was the depth of its chain (a_nid -> node fields -> the targets' walk ids -> the run of the position)
+// times the rounds of resident wavefronts.  Here the loads of the four ids go out level by level (r03 did the same for the walk preparation's other kernels).
+#define AGX_SE_WORDS 4u
 __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, agx_u32 n_words, agx_collect_args G) {
     if (blockIdx.x == 0) agx_collect_block(G);          // (also when the build was aborted: the host sizes the retry from these)
     AGX_RETURN_IF_ABORTED(A.abort);
-    const agx_u32 a = blockIdx.x * 256u + threadIdx.x, w = a >> 6;
-    if (w >= n_words) return;
-    const unsigned long long bits = A.sp_bits[w];
-    if (!bits) return;                                                        // wave-uniform
     const agx_u32 lane = threadIdx.x & 63u;
-    const bool on = ((bits >> lane) & 1ull) != 0;
-    const agx_u32 x = on ? (a < A.n_pos ? a : A.side_xpos[a - A.n_pos]) : 0xFFFFFFFFu;
-    // The hop entry of a position comes from the rank-0 run that holds it (agx_seg_hop: bisection over the runs, sorted by position).  The ids of a word
-    // are 64 neighbours — main ids are positions, side ids are in position order —, so the bisection runs ONCE per wavefront, for its lowest position,
-    // and every lane walks forward from there (r02: 17 dependent loads per special id; 0.62 ms of this kernel on a 30 Mb unit).
-    agx_u32 xmin = x;
-    for (agx_u32 o = 32; o; o >>= 1) { const agx_u32 t = (agx_u32)__shfl_xor((int)xmin, (int)o, 64); xmin = t < xmin ? t : xmin; }
-    // (r03, second step: not even one bisection per wavefront — 17 dependent loads in a kernel whose time IS its depth of dependent loads — but one look
-    // into the host's index of the runs, an entry per 1024 positions, and a few steps forward from there)
-    const agx_u32 s0 = A.n_seg0 && xmin != 0xFFFFFFFFu ? agx_uload(A.seg_index, xmin / AGX_SEG_INDEX) : 0u;
-    if (on) {
-        const agx_u32 at = A.sp_rank[w] + (agx_u32)__popcll(bits & ((1ull << lane) - 1ull));
-        if (at >= A.sp_cap) return;                                           // table too small: the host sees the count and repeats the build
-        A.sp_node[at] = agx_walk_record(A, a);
+    const agx_u32 w0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4u + (threadIdx.x >> 6)) * AGX_SE_WORDS);
+    if (w0 >= n_words) return;
+    unsigned long long bits[AGX_SE_WORDS]; unsigned long long any = 0;
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_SE_WORDS; j++) { bits[j] = w0 + j < n_words ? A.sp_bits[w0 + j] : 0ull; any |= bits[j]; }
+    if (!any) return;                                                         // wave-uniform
+    bool on[AGX_SE_WORDS]; agx_u32 a[AGX_SE_WORDS], x[AGX_SE_WORDS], v[AGX_SE_WORDS], at[AGX_SE_WORDS];
+    // level 1: the id's position (side ids: from the side table) and node
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_SE_WORDS; j++) {
+        a[j] = (w0 + j) * 64u + lane; on[j] = ((bits[j] >> lane) & 1ull) != 0;
+        x[j] = on[j] ? (a[j] < A.n_pos ? a[j] : A.side_xpos[a[j] - A.n_pos]) : 0xFFFFFFFFu;
+        v[j] = on[j] ? A.a_nid[a[j]] : AGX_NONE;
+        at[j] = on[j] ? A.sp_rank[w0 + j] + (agx_u32)__popcll(bits[j] & ((1ull << lane) - 1ull)) : AGX_NONE;
+        if (at[j] >= A.sp_cap) on[j] = false;                                 // table too small: the host sees the count and repeats the build
+    }
+    // level 2: the node's fields; the conti-mer count of its position; the index entry of the word's lowest position
+    agx_walknode wn[AGX_SE_WORDS]; uint4 nx[AGX_SE_WORDS]; agx_u32 cm_n[AGX_SE_WORDS], s0[AGX_SE_WORDS];
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_SE_WORDS; j++) {
+        const bool node = on[j] && v[j] != AGX_NONE;
+        const agx_u32 vv = node ? v[j] : 0u;
+        wn[j].off0 = node ? A.nk_off0[vv] : AGX_NONE; wn[j].xpos = node ? A.n_xpos[vv] : a[j]; wn[j].sref = node ? A.n_sref[vv] : agx_sref{0, 0};
+        nx[j] = node ? *reinterpret_cast<const uint4 *>(A.n_next + (size_t)vv * AGX_MAXE) : make_uint4(AGX_NONE, AGX_NONE, AGX_NONE, AGX_NONE);
+        cm_n[j] = (on[j] && A.n_seg0) ? A.cm_start[x[j] + 1] - A.cm_start[x[j]] : 0u;
+        // The hop entry of a position comes from the rank-0 run that holds it.  The ids of a word are 64 neighbours — main ids are positions, side ids are in position
+        // order —, so one look into the host's index of the runs (an entry per 1024 positions) for the word's lowest position, and every lane walks forward from there.
+        agx_u32 xmin = x[j];
+        for (agx_u32 o = 32; o; o >>= 1) { const agx_u32 t = (agx_u32)__shfl_xor((int)xmin, (int)o, 64); xmin = t < xmin ? t : xmin; }
+        s0[j] = A.n_seg0 && xmin != 0xFFFFFFFFu ? agx_uload(A.seg_index, xmin / AGX_SEG_INDEX) : 0u;
+    }
+    // level 3: the targets' walk ids (the slots are filled front to back: the first NONE ends the list; pruned targets are dropped)
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_SE_WORDS; j++) {
+        const agx_u32 t[AGX_MAXE] = {nx[j].x, nx[j].y, nx[j].z, nx[j].w};
+        agx_u32 ta[AGX_MAXE]; bool open = true;
+#pragma unroll
+        for (agx_u32 e = 0; e < AGX_MAXE; e++) { open = open && t[e] != AGX_NONE; ta[e] = open ? A.aid_of[t[e]] : AGX_NONE; }
+        agx_u32 k = 0;
+#pragma unroll
+        for (agx_u32 e = 0; e < AGX_MAXE; e++) wn[j].next[e] = AGX_NONE;
+#pragma unroll
+        for (agx_u32 e = 0; e < AGX_MAXE; e++) if (ta[e] != AGX_NONE) { for (agx_u32 q = 0; q < AGX_MAXE; q++) if (q == k) wn[j].next[q] = ta[e]; k++; }
+    }
+    // level 4: hop entries, then the stores
+#pragma unroll
+    for (agx_u32 j = 0; j < AGX_SE_WORDS; j++) {
+        if (!on[j]) continue;
+        A.sp_node[at[j]] = wn[j];
         agx_hop h; h.str_off = 0; h.len = 0; h.end_pos = 0;
-        if (A.n_seg0 && A.cm_start[x + 1] - A.cm_start[x] == 1u) {
-            agx_u32 si = s0, steps = 0;
-            while (si + 1 < A.n_seg0 && A.segs[si + 1].pos0 <= x && steps < 16u) { si++; steps++; }      // last rank-0 run with pos0 <= x: a few steps behind the index entry
-            if (steps == 16u) { agx_u32 lo = si, hi = A.n_seg0; while (hi - lo > 1) { const agx_u32 mid = lo + (hi - lo) / 2; if (A.segs[mid].pos0 <= x) lo = mid; else hi = mid; } si = lo; }      // (the one word that holds the last main ids and the first side ids)
+        if (cm_n[j] == 1u) {
+            const agx_u32 xx = x[j];
+            agx_u32 si = s0[j], steps = 0;
+            while (si + 1 < A.n_seg0 && A.segs[si + 1].pos0 <= xx && steps < 16u) { si++; steps++; }      // last rank-0 run with pos0 <= x: a few steps behind the index entry
+            if (steps == 16u) { agx_u32 lo = si, hi = A.n_seg0; while (hi - lo > 1) { const agx_u32 mid = lo + (hi - lo) / 2; if (A.segs[mid].pos0 <= xx) lo = mid; else hi = mid; } si = lo; }      // (the one word that holds the last main ids and the first side ids)
             const agx_cmseg g = A.segs[si];
-            const agx_u32 j = x - g.pos0;
-            if (x >= g.pos0 && j < g.len && j < g.hop_len0) { h.str_off = g.hop_str0 + j; h.len = g.hop_len0 - j; h.end_pos = g.hop_end; }
+            const agx_u32 jj = xx - g.pos0;
+            if (xx >= g.pos0 && jj < g.len && jj < g.hop_len0) { h.str_off = g.hop_str0 + jj; h.len = g.hop_len0 - jj; h.end_pos = g.hop_end; }
         }
-        A.sp_hop[at] = h;
+        A.sp_hop[at[j]] = h;
     }
 }
 
@@ -819,7 +898,8 @@ void agx_launch_bin_fill(const agx_bin_args *A, hipStream_t st) {
     if (A->n_hits) hipLaunchKernelGGL(agx_k_bin_fill, dim3((A->n_hits + 255) / 256), dim3(256), 0, st, *A);
 }
 void agx_launch_tile_fill(const agx_fill_args *A, hipStream_t st) {
-    if (A->n_tiles) hipLaunchKernelGGL(agx_k_tile_fill, dim3((A->n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *A);
+    const agx_u32 per_block = AGX_WAVES_PER_BLOCK * AGX_FILL_TILES;
+    if (A->n_tiles) hipLaunchKernelGGL(agx_k_tile_fill, dim3((A->n_tiles + per_block - 1) / per_block), dim3(256), 0, st, *A);
 }
 void agx_launch_tile_sort(const agx_fill_args *A, hipStream_t st) {
     if (A->n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((A->n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *A);
@@ -880,7 +960,7 @@ void agx_launch_compact(const agx_compact_args *A, const agx_u32 *chain_end, agx
 void agx_launch_special(const agx_compact_args *A, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, unsigned long long *desc,
                         agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, hipStream_t st) {
     const agx_collect_args G{out, a, b, sp_rank + n_words, pool_cnt, regions, sum};
-    const agx_u32 blocks = (agx_u32)(((unsigned long long)n_words * 64u + 255u) / 256u);
+    const agx_u32 blocks = (n_words + 4u * AGX_SE_WORDS - 1u) / (4u * AGX_SE_WORDS);
     hipLaunchKernelGGL(agx_k_special_bits, dim3((n_words + 4u * AGX_SB_WORDS - 1u) / (4u * AGX_SB_WORDS)), dim3(256), 0, st, *A, n_words);
     if (desc) agx_launch_exclusive_scan1(A->sp_cnt, sp_rank, n_words, desc, st); else agx_launch_exclusive_scan(A->sp_cnt, sp_rank, n_words, scan_tmp, st);
     hipLaunchKernelGGL(agx_k_special_emit, dim3(blocks), dim3(256), 0, st, *A, n_words, G);
