@@ -23,6 +23,7 @@ EXPORTS = [
     "agx_unit_finish", "agx_result_free", "agx_unit_stats", "agx_unit_graph", "agx_graph_free", "agx_run_unit",
     "agx_reads_open", "agx_reads_close", "agx_unit_load_files_shared", "agx_run_unit_shared",
     "agx_unit_stage", "agx_unit_release", "agx_pool_trim", "agx_unit_cache_build", "agx_unit_cache_save", "agx_unit_hbm_needed",
+    "agx_unit_trim",
 ]
 
 
@@ -114,6 +115,7 @@ def lib():
         L.agx_unit_cache_build.argtypes = [ctypes.POINTER(Params), ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         L.agx_unit_cache_save.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.agx_unit_hbm_needed.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        L.agx_unit_trim.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
         L.agx_pool_trim.argtypes = [ctypes.c_int]
         L.agx_pool_trim.restype = None
         for f in ("agx_unit_upload", "agx_unit_build", "agx_unit_download", "agx_unit_stage", "agx_unit_release"):
@@ -268,6 +270,12 @@ class Unit:
 
     def upload(self):
         self._check(lib().agx_unit_upload(self._h))
+
+    def trim(self):
+        """After download(): the part of the unit's HBM that the host walk cannot ask for goes back to the device's memory region (agx_unit_trim); returns the bytes given back."""
+        v = ctypes.c_uint64(0)
+        self._check(lib().agx_unit_trim(self._h, ctypes.byref(v)))
+        return v.value
 
     def release(self):
         """HBM and download buffers back to the library's caches; the staged inputs stay (upload again = a new unit)."""

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <unistd.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <fcntl.h>
 #include <ctime>
@@ -157,15 +158,67 @@ struct Sink {
     }
 };
 
-// maxReadLength, AG:3197-3226
+// threads for the front end's passes over the read files (AGX_CLI_THREADS; else the CPUs this process may run on, sixteen at most)
+unsigned cli_threads() {
+    if (const char *e = getenv("AGX_CLI_THREADS")) { const int v = atoi(e); if (v >= 1) return (unsigned)std::min(v, 64); }
+    cpu_set_t set; CPU_ZERO(&set);
+    unsigned n = sched_getaffinity(0, sizeof set, &set) == 0 ? (unsigned)CPU_COUNT(&set) : std::thread::hardware_concurrency();
+    return std::max(1u, std::min(n, 16u));
+}
+template <class F> void on_threads(unsigned T, F fn) {
+    vector<std::thread> th;
+    for (unsigned t = 1; t < T; t++) th.emplace_back([&fn, t] { fn(t); });
+    fn(0);
+    for (auto &x : th) x.join();
+}
+// [lo, hi) of piece t of T over n bytes, both ends moved forward to the next line start
+inline size_t line_start_at(const char *p, size_t n, size_t at) {
+    if (at == 0 || at >= n) return std::min(at, n);
+    const char *nl = (const char *)memchr(p + at - 1, '\n', n - (at - 1));
+    return nl ? (size_t)(nl - p) + 1 : n;
+}
+// where a `getline` loop that stops at the first empty line (or a line that begins with a NUL byte) stops reading: the offset of that line, n if there is none
+size_t scan_end(const char *p, size_t n, unsigned T) {
+    vector<size_t> first(T, n);
+    on_threads(T, [&](unsigned t) {
+        const size_t lo = line_start_at(p, n, n / T * t), hi = t + 1 == T ? n : line_start_at(p, n, n / T * (t + 1));
+        for (size_t at = lo; at < hi;) {
+            if (p[at] == '\n' || p[at] == 0) { first[t] = at; return; }
+            const char *nl = (const char *)memchr(p + at, '\n', hi - at);
+            if (!nl) return;
+            at = (size_t)(nl - p) + 1;
+        }
+    });
+    size_t e = n; for (size_t v : first) e = std::min(e, v);
+    return e;
+}
+
+// maxReadLength, AG:3197-3226 — the longest record of a read file (the sum of its sequence lines), the scan ending at the first empty line.  r05: on all the CPUs the
+// process may use (the file cut into pieces at line starts; a piece reports the sequence bytes in front of its first header, its longest whole record and the bytes behind
+// its last header; the pieces are joined in order) — a 20 M-pair run's two read files are 4.4 GB, and the option check reads both before anything else happens.
 int max_read_length(const string &path) {
     Lines in(path);
     if (!in.opened) die("CANNOT OPEN FILE!");
+    const unsigned T = in.n > ((size_t)8 << 20) ? cli_threads() : 1u;
+    const char *p = in.p; const size_t n = scan_end(p, in.n, T);
+    struct Piece { long long head = 0, inside = 0, tail = 0; bool header = false; };
+    vector<Piece> pc(T);
+    on_threads(T, [&](unsigned t) {
+        const size_t lo = line_start_at(p, n, n / T * t), hi = t + 1 == T ? n : line_start_at(p, n, n / T * (t + 1));
+        Piece &P = pc[t]; long long len = 0;
+        for (size_t at = lo; at < hi;) {
+            const char *nl = (const char *)memchr(p + at, '\n', n - at);
+            const size_t le = nl ? (size_t)(nl - p) : n, l = le - at;
+            if (p[at] == '>') { if (!P.header) { P.head = len; P.header = true; } else P.inside = std::max(P.inside, len); len = 0; }
+            else len += (long long)l;
+            at = nl ? le + 1 : n;
+        }
+        if (P.header) P.tail = len; else P.head = len;
+    });
     long long mx = 0, len = 0;
-    while (in.good) {
-        const char *s; size_t l; in.next(s, l);
-        if (l == 0 || s[0] == 0) break;
-        if (s[0] == '>') { mx = std::max(mx, len); len = 0; } else len += (long long)l;
+    for (const Piece &P : pc) {
+        if (!P.header) { len += P.head; continue; }
+        mx = std::max(mx, std::max(len + P.head, P.inside)); len = P.tail;
     }
     return (int)std::max(mx, len);
 }
@@ -238,10 +291,109 @@ int formalize_genome(const string &path, int p, vector<string> &genomeIds) {
     return unit;
 }
 
+// An output file of known size written in place by several threads: created, sized and mapped shared
+struct MappedOut {
+    int fd = -1; char *p = nullptr; size_t n = 0; string name;
+    MappedOut(const string &path, size_t bytes) : n(bytes), name(path) {
+        fd = open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0666);
+        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { cout << "CANNOT WRITE FILE! (" << name << ")" << endl; exit(-1); }
+        if (bytes) { void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0); if (m == MAP_FAILED) { cout << "CANNOT WRITE FILE! (" << name << ")" << endl; exit(-1); } p = (char *)m; }
+    }
+    ~MappedOut() { if (p) munmap(p, n); if (fd >= 0) close(fd); }
+};
+inline unsigned dec_digits(unsigned long v) { unsigned d = 1; while (v >= 10) { v /= 10; d++; } return d; }
+inline char *put_dec(char *w, unsigned long v) { char t[24]; int k = 0; do { t[k++] = (char)('0' + v % 10); v /= 10; } while (v); while (k) *w++ = t[--k]; return w; }
+
+// formalizeInput (reads), AG:3420-3518, for the inputs every aligner's users have — both files a header line and ONE sequence line per record, the same number of records, no
+// empty line — on all the CPUs the process may use: the files are cut into pieces at record starts, the pieces' records counted, a first pass sizes every thread's share of the
+// three outputs (a record's bytes follow from its id's digits and the shorter mate), a second one writes them in place.  Returns -1 (nothing written) for anything else:
+// multi-line records, a header without a sequence, files of different shape — the line-by-line form below then does what the reference does with them, message for message.
+long long formalize_reads_fast(const Lines &in1, const Lines &in2) {
+    const unsigned T = cli_threads();
+    const size_t least = getenv("AGX_CLI_FAST_MIN") ? (size_t)atoll(getenv("AGX_CLI_FAST_MIN")) : ((size_t)4 << 20);      // (tests: small files through the threaded form)
+    if (T < 2 || in1.n < least || in2.n < least || in1.n < 64 * (size_t)T || in2.n < 64 * (size_t)T) return -1;
+    const Lines *in[2] = {&in1, &in2};
+    size_t end[2]; for (int f = 0; f < 2; f++) { end[f] = scan_end(in[f]->p, in[f]->n, T); if (end[f] != in[f]->n) return -1; }      // (an empty line ends the reference's loop early: the general form)
+    // pieces at record starts; every piece: two-line records only?  how many?
+    vector<size_t> lo[2], cnt[2]; bool ok[2] = {true, true};
+    for (int f = 0; f < 2; f++) {
+        const char *p = in[f]->p; const size_t n = in[f]->n;
+        if (n == 0 || p[0] != '>' || p[n - 1] != '\n') return -1;
+        lo[f].assign(T + 1, n); cnt[f].assign(T, 0);
+        for (unsigned t = 0; t < T; t++) {          // the piece starts at the first header line at or behind its share's first byte
+            size_t at = line_start_at(p, n, n / T * t);
+            if (at < n && p[at] != '>') at = line_start_at(p, n, at + 1);
+            lo[f][t] = at;
+        }
+        lo[f][0] = 0;
+        vector<int> bad(T, 0);
+        on_threads(T, [&](unsigned t) {
+            const size_t a = lo[f][t], b = lo[f][t + 1]; size_t c = 0;
+            for (size_t at = a; at < b;) {
+                if (p[at] != '>') { bad[t] = 1; return; }
+                const char *h = (const char *)memchr(p + at, '\n', n - at);
+                if (!h || (size_t)(h - p) + 1 >= n) { bad[t] = 1; return; }
+                const size_t sq = (size_t)(h - p) + 1;
+                if (p[sq] == '>' || p[sq] == '\n') { bad[t] = 1; return; }
+                const char *e = (const char *)memchr(p + sq, '\n', n - sq);
+                if (!e) { bad[t] = 1; return; }
+                at = (size_t)(e - p) + 1; c++;
+            }
+            cnt[f][t] = c;
+        });
+        for (unsigned t = 0; t < T; t++) if (bad[t] || lo[f][t] > lo[f][t + 1]) ok[f] = false;
+    }
+    if (!ok[0] || !ok[1]) return -1;
+    size_t total[2] = {0, 0}; for (int f = 0; f < 2; f++) for (size_t c : cnt[f]) total[f] += c;
+    if (total[0] != total[1]) return -1;                // (the line-by-line form reports what the reference reports)
+    const size_t N = total[0];
+    // shares of records: file 1's pieces; where the same records begin in file 2
+    vector<size_t> rec0(T + 1, 0); for (unsigned t = 0; t < T; t++) rec0[t + 1] = rec0[t] + cnt[0][t];
+    vector<size_t> off2(T + 1, in2.n);
+    {   vector<size_t> r2(T + 1, 0); for (unsigned t = 0; t < T; t++) r2[t + 1] = r2[t] + cnt[1][t];
+        on_threads(T, [&](unsigned t) {
+            const size_t want = rec0[t];
+            if (want >= N) { off2[t] = in2.n; return; }
+            unsigned q = 0; while (q + 1 < T && r2[q + 1] <= want) q++;          // the piece of file 2 that holds record `want`
+            size_t at = lo[1][q];
+            for (size_t k = r2[q]; k < want; k++) { at = (size_t)((const char *)memchr(in2.p + at, '\n', in2.n - at) - in2.p) + 1; at = (size_t)((const char *)memchr(in2.p + at, '\n', in2.n - at) - in2.p) + 1; }
+            off2[t] = at;
+        });
+    }
+    // a record's two lines from its header's offset: the sequence and where the next record begins
+    auto record = [](const Lines &L, size_t at, const char *&seq, size_t &len) { const char *h = (const char *)memchr(L.p + at, '\n', L.n - at); seq = h + 1; const char *e = (const char *)memchr(seq, '\n', L.n - (size_t)(seq - L.p)); len = (size_t)(e - seq); return (size_t)(e - L.p) + 1; };
+    vector<size_t> bytes_all(T + 1, 0), bytes_one(T + 1, 0);
+    on_threads(T, [&](unsigned t) {
+        size_t a1 = lo[0][t], a2 = off2[t], all = 0, one = 0;
+        for (size_t id = rec0[t]; id < rec0[t + 1]; id++) {
+            const char *s1, *s2; size_t l1, l2; a1 = record(in1, a1, s1, l1); a2 = record(in2, a2, s2, l2);
+            const size_t m = std::min(l1, l2), rec = 1 + dec_digits(id) + 1 + m + 1;
+            one += rec; all += 2 * rec;
+        }
+        bytes_all[t + 1] = all; bytes_one[t + 1] = one;
+    });
+    for (unsigned t = 0; t < T; t++) { bytes_all[t + 1] += bytes_all[t]; bytes_one[t + 1] += bytes_one[t]; }
+    MappedOut out("tmp/_reads.fa", bytes_all[T]), out1("tmp/_reads_1.fa", bytes_one[T]), out2("tmp/_reads_2.fa", bytes_one[T]);
+    on_threads(T, [&](unsigned t) {
+        size_t a1 = lo[0][t], a2 = off2[t]; char *w = out.p + bytes_all[t], *w1 = out1.p + bytes_one[t], *w2 = out2.p + bytes_one[t];
+        for (size_t id = rec0[t]; id < rec0[t + 1]; id++) {
+            const char *s1, *s2; size_t l1, l2; a1 = record(in1, a1, s1, l1); a2 = record(in2, a2, s2, l2);
+            const size_t m = std::min(l1, l2);
+            char head[32]; char *h = head; *h++ = '>'; h = put_dec(h, (unsigned long)id); *h++ = '\n'; const size_t hl = (size_t)(h - head);
+            memcpy(w, head, hl); w += hl; memcpy(w, s1, m); w += m; *w++ = '\n'; memcpy(w, head, hl); w += hl; memcpy(w, s2, m); w += m; *w++ = '\n';
+            memcpy(w1, head, hl); w1 += hl; memcpy(w1, s1, m); w1 += m; *w1++ = '\n';
+            memcpy(w2, head, hl); w2 += hl; memcpy(w2, s2, m); w2 += m; *w2++ = '\n';
+        }
+    });
+    if (getenv("AGX_CLI_TIMING")) fprintf(stderr, "[agx cli] %zu pairs of reads on %u threads: %zu + %zu bytes in, %zu + 2 x %zu out\n", N, T, in1.n, in2.n, bytes_all[T], bytes_one[T]);
+    return (long long)N;
+}
+
 // formalizeInput (reads), AG:3420-3518: pairs renamed 0..N-1, mates cut to the shorter of the two
 int formalize_reads(const string &p1, const string &p2) {
     Lines in1(p1), in2(p2);
     if (!in1.opened || !in2.opened) die("CANNOT OPEN FILE!");
+    if (!getenv("AGX_CLI_SERIAL")) { const long long fast = formalize_reads_fast(in1, in2); if (fast >= 0) return (int)fast; }
     Sink out("tmp/_reads.fa"), out1("tmp/_reads_1.fa"), out2("tmp/_reads_2.fa");
     string r1, r2; unsigned long id = 0; char head[32];
     auto flush = [&]() {

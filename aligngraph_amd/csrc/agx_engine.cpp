@@ -733,14 +733,19 @@ void alloc_pool(agx_unit *u, agx_u32 cap) {
     u->pool_cap = cap;
     DevArena &a = u->arena;
     const size_t kcap = (size_t)cap + AGX_SLOW_V;      // slack: the edge pass reads whole AGX_SLOW_V-row batches of keys (agx_edge_slow_ctx)
-    for (auto *b : {&u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0}) { b->release(); b->alloc(a, kcap); }
-    u->d_xpos.release(); u->d_xpos.alloc(a, cap); u->d_next.release(); u->d_next.alloc(a, (size_t)cap * AGX_MAXE);
-    u->d_base.release(); u->d_base.alloc(a, cap); u->d_flags.release(); u->d_flags.alloc(a, cap); u->d_sref.release(); u->d_sref.alloc(a, cap);
+    // First what the host walk may still ask the device for after the download (agx_walk_record through fetch_records: the records of ids outside the sparse table): the walk id
+    // and node of every id, and four node arrays — 40 bytes per node slot + 4 per id, a quarter of the unit's block.  They lie at the FRONT of the block so that everything
+    // behind them can go back to the device when the download is done (agx_unit_trim), not when the walk is (r05: on the whole-human job a unit's walk takes longer than its
+    // upload and build, and the units waiting for room on the device were waiting for walks).
+    const size_t n_pos = u->V.n_pos, ids_cap = n_pos + cap;
+    u->d_aid_of.release(); u->d_aid_of.alloc(a, (size_t)cap + 1); u->d_a_nid.release(); u->d_a_nid.alloc(a, ids_cap + 1);
+    u->d_off0.release(); u->d_off0.alloc(a, kcap); u->d_xpos.release(); u->d_xpos.alloc(a, cap); u->d_sref.release(); u->d_sref.alloc(a, cap); u->d_next.release(); u->d_next.alloc(a, (size_t)cap * AGX_MAXE);
+    u->d_fetch.release(); u->d_fetch.alloc(a, 65536);
+    for (auto *b : {&u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0}) { b->release(); b->alloc(a, kcap); }
+    u->d_base.release(); u->d_base.alloc(a, cap); u->d_flags.release(); u->d_flags.alloc(a, cap);
     if (u->prm.flags & AGX_FLAG_KEEP_COUNTS) { u->d_counts.release(); u->d_counts.alloc(a, (size_t)cap * 6); }
     // walk-graph arrays indexed by walk id: side variants <= nodes <= pool_cap
-    const size_t n_pos = u->V.n_pos, ids_cap = n_pos + cap;
-    u->d_aid_of.release(); u->d_aid_of.alloc(a, (size_t)cap + 1);
-    u->d_a_str.release(); u->d_a_str.alloc(a, ids_cap + 1); u->d_a_meta.release(); u->d_a_meta.alloc(a, ids_cap + 16); u->d_a_nid.release(); u->d_a_nid.alloc(a, ids_cap + 1);
+    u->d_a_str.release(); u->d_a_str.alloc(a, ids_cap + 1); u->d_a_meta.release(); u->d_a_meta.alloc(a, ids_cap + 16);
     u->d_a_mark.release(); u->d_a_mark.alloc(a, ids_cap + 2); u->d_side_xpos.release(); u->d_side_xpos.alloc(a, (size_t)cap + 1);
     u->n_words = (agx_u32)(ids_cap / 64 + 1);
     u->d_sp_bits.release(); u->d_sp_bits.alloc(a, (size_t)u->n_words + 1); u->d_sp_cnt.release(); u->d_sp_cnt.alloc(a, (size_t)u->n_words + 1);
@@ -801,6 +806,7 @@ void do_upload(agx_unit *u) {
     const agx_u32 pool_cap = plan.pool_cap, list_cap = plan.list_cap, ovf_cap = plan.ovf_cap, sp_cap = plan.sp_cap;
     u->arena.reserve(plan.total);                        // one block for all of it
     DevArena &a = u->arena;
+    alloc_pool(u, pool_cap);                             // (first: what outlives the download lies at the front of the block, agx_unit_trim)
     u->d_cm_start.alloc(a, n_pos + 2); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos + 16); u->d_cm_head.alloc(a, n_pos + 1);
     u->d_segs.alloc(a, u->n_segs + 1); u->d_cntruns.alloc(a, u->n_cntruns + 1); u->d_cntchunks.alloc(a, u->n_cntchunks + 1); u->d_segchunks.alloc(a, u->n_segchunks + 1); u->d_segindex.alloc(a, u->n_segindex + 1);
     u->d_runs.alloc(a, u->n_runs + 1); u->d_vcodes.alloc(a, n_bases + 16); u->d_other.alloc(a, u->n_other + 1);
@@ -818,7 +824,7 @@ void do_upload(agx_unit *u) {
     u->d_big_list.alloc(a, (size_t)u->n_tiles + 1); u->d_mid_list.alloc(a, (size_t)u->n_tiles + 1);
     u->d_scratch.alloc(a, (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64);
     u->d_region_off.alloc(a, (size_t)u->n_regions + 1); u->d_pool_cnt.alloc(a, (size_t)u->n_regions * AGX_REGION_PAD);
-    alloc_pool(u, pool_cap); alloc_lists(u, list_cap); alloc_ovf(u, ovf_cap); alloc_sparse(u, sp_cap);
+    alloc_lists(u, list_cap); alloc_ovf(u, ovf_cap); alloc_sparse(u, sp_cap);
     // copies: all of them on the device's upload stream, behind those of the units queued before.  The kernels that expand what was copied
     // (conti-mer tables, vote codes) open the unit's first build instead of following the copies here: a kernel on this stream would wait for
     // CUs while another unit's node sweep holds them all, and every later unit's copies with it.
@@ -1171,6 +1177,24 @@ void do_download(agx_unit *u) {
     trace(u, u->dl_sdma ? "download (copy engines)" : "download (hipMemcpyAsync)", t0, n_pos);
 }
 
+// After the download: everything on the device that the walk cannot ask for (all but the arrays agx_walk_record reads, which lie at the front of the unit's block: alloc_pool)
+// goes back to the device's memory region.  The unit is no longer built: another build uploads it again.  Returns the bytes given back (0: the block is not the region's — a
+// unit below the region's threshold on a device without one —, or a capacity grew during the build and the arrays are no longer at the front).
+size_t do_trim(agx_unit *u) {
+    if (!u->downloaded) throw Error{E_ARG, "trim: the unit's walk graph has not been downloaded"};
+    HIP_OK(hipSetDevice(u->prm.device));
+    const char *base = (const char *)u->arena.base();
+    if (!base) return 0;
+    size_t keep = 0;
+    auto end_of = [&](const void *p, size_t bytes) { if (p) { const size_t e = (size_t)((const char *)p - base) + bytes; if (e > keep) keep = e; } };
+    end_of(u->d_aid_of.p, u->d_aid_of.n * 4); end_of(u->d_a_nid.p, u->d_a_nid.n * 4); end_of(u->d_off0.p, u->d_off0.n * 4); end_of(u->d_xpos.p, u->d_xpos.n * 4);
+    end_of(u->d_sref.p, u->d_sref.n * sizeof(agx_sref)); end_of(u->d_next.p, u->d_next.n * 4); end_of(u->d_fetch.p, u->d_fetch.n * sizeof(agx_walknode));
+    if (keep > u->arena.capacity()) return 0;            // (an array in a later block: nothing is given back)
+    const size_t freed = u->arena.shrink_to(keep);
+    if (freed) { u->built = false; u->uploaded = false; }      // what lay behind the kept arrays is gone: the build's buffers, the uploaded inputs
+    return freed;
+}
+
 // Gives back everything the unit holds on the device and its download buffers (to the caches of agx_mem.h: the next unit of the run takes
 // them without a driver call).  The inputs stay staged: the unit can be uploaded again as if it were new.
 void do_release(agx_unit *u) {
@@ -1446,6 +1470,7 @@ int agx_unit_hbm_needed(agx_unit *u, uint64_t *bytes) {
 int agx_unit_stage(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { stage_inputs(u); }); }
 int agx_unit_upload(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_upload(u); }); }
 int agx_unit_release(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_release(u); }); }
+int agx_unit_trim(agx_unit *u, uint64_t *freed) { if (!u) return AGX_E_ARG; if (freed) *freed = 0; return guarded(u, [&] { const size_t f = do_trim(u); if (freed) *freed = f; }); }
 void agx_pool_trim(int device) { if (device >= 0) dev_trim(device); else if (device == -1) { host_trim(); scratch_trim(); } else host_retire(); }      // (-1 also unmaps the loaders' cached scratch memory: up to 16 GB of touched pages per process otherwise stay until exit)
 int agx_unit_build(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_build(u); }); }
 int agx_unit_download(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_download(u); }); }
@@ -1461,7 +1486,14 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
         if (!u->out_ready) throw Error{E_ARG, "out of host memory"};
         u->downloaded = false;            // the walk marks the downloaded meta bytes: another finish downloads again
         u->out_ready = false;             // (an error below leaves the buffers to the next prepare_outputs)
-        agx::walkers_cap = g_walks_pending.load() <= 1 ? (int)GraphView::MAX_WALKERS : 8;      // (nobody else on the way: this walk is the job's tail)
+        // Walkers for this walk: eight, or up to sixteen while CPUs are free — nobody else on the way (the job's tail), or the walker threads of the walks that are
+        // running leave that many of this process's CPUs alone.  (r04 gave sixteen to the last walk only; since r05 a job's builds end closer together than its walks
+        // take, and the first walk of a job, which has every CPU to itself, is over before the third begins.)
+        static std::atomic<int> walkers_busy{0};
+        {   static const int ranks = [] { const char *e = getenv("LOCAL_WORLD_SIZE"); const int n = e ? atoi(e) : 1; return n < 1 ? 1 : n; }();
+            const int free_cpus = (int)usable_cpus() / ranks - walkers_busy.load();
+            agx::walkers_cap = g_walks_pending.load() <= 1 ? (int)GraphView::MAX_WALKERS : std::max(8, std::min((int)GraphView::MAX_WALKERS, free_cpus)); }
+        struct Busy { std::atomic<int> &n; int k; Busy(std::atomic<int> &c, int walkers) : n(c), k(walkers) { n.fetch_add(k); } ~Busy() { n.fetch_sub(k); } } busy{walkers_busy, walkers_now(u->V.n_pos)};
         struct Walked { agx_unit *u; ~Walked() { if (u->pending_walk) { u->pending_walk = false; g_walks_pending.fetch_sub(1); } } } walked{u};
         struct Helpers : Assistant {           // helper 0: the unit's own thread (formats the written records while the walk goes on, or walks a stretch); 1..: pool threads for further walkers
             agx_unit *u; int pool[GraphView::MAX_WALKERS] = {}; int n_pool = 0;

@@ -106,6 +106,19 @@ public:
           free_[off] = len; in_use_--; }
         cv_.notify_all();
     }
+    // the tail of a block that was cut from the region goes back to it: [b.p + keep, b.p + b.n) becomes a free range (merged with its neighbours), b keeps its first `keep`
+    // bytes (rounded up to 2 MB).  false: not a block of this region, or nothing to give
+    bool shrink(MemBlock &b, size_t keep) {
+        keep = (keep + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        { std::lock_guard<std::mutex> g(m_);
+          if (!base_ || (const char *)b.p < base_ || (const char *)b.p >= base_ + size_ || keep == 0 || keep >= b.n) return false;
+          size_t off = (size_t)((char *)b.p - base_) + keep, len = b.n - keep;
+          auto nx = free_.lower_bound(off);
+          if (nx != free_.end() && off + len == nx->first) { len += nx->second; nx = free_.erase(nx); }
+          free_[off] = len; b.n = keep; }
+        cv_.notify_all();
+        return true;
+    }
     void trim() {      // back to the driver, if nothing lives in it
         std::lock_guard<std::mutex> g(m_);
         if (base_ && in_use_ == 0) { (void)hipFree(base_); base_ = nullptr; size_ = 0; free_.clear(); tried_ = false; }
@@ -153,6 +166,16 @@ public:
     void reset() { for (const MemBlock &b : blocks_) dev_give(device, b); blocks_.clear(); at_ = 0; used_ = 0; }
     size_t used() const { return used_; }
     size_t capacity() const { size_t s = 0; for (const MemBlock &b : blocks_) s += b.n; return s; }
+    // Everything behind the first `keep` bytes of the arena's only block goes back to the device's region (the caller no longer uses what lies there); what is taken from
+    // the arena afterwards comes from a new block.  Returns the bytes given back: 0 if the arena holds several blocks, or its block is not the region's.
+    size_t shrink_to(size_t keep) {
+        if (blocks_.size() != 1) return 0;
+        const size_t before = blocks_[0].n;
+        if (!dev_region(device).shrink(blocks_[0], keep)) return 0;
+        at_ = blocks_[0].n;
+        return before - blocks_[0].n;
+    }
+    const void *base() const { return blocks_.empty() ? nullptr : blocks_[0].p; }
 private:
     std::vector<MemBlock> blocks_; size_t at_ = 0, used_ = 0;
     size_t room() const { return blocks_.empty() ? 0 : blocks_.back().n - at_; }

@@ -445,7 +445,8 @@ struct WalkRun {
                 Rec C(arena); C.sID = 0; C.sOff = cp; C.extended = 0;
                 segs.clear(); n_walks++;
                 agx_u32 cur = start;                 // current k-mer node (mode 1)
-                { const agx_u32 o = W.node(cur).off0; C.sID0 = o == AGX_NONE ? AGX_NONE : 0; C.sOff0 = o; }
+                // (the start node's mate offset — C.sID0 / C.sOff0, AG:1988 — is looked up when the record turns out to be written: thirteen walks in fourteen are dropped
+                // below, AG:2176, and the look-up into the sparse table was one of a dropped walk's two)
                 AGX_PT(0);
                 agx_u32 cpp = cp; int mode = 1;               // mode = kMerTag
                 agx_u32 last = cur;
@@ -503,6 +504,7 @@ struct WalkRun {
                 } else { C.eID0 = AGX_NONE; C.eOff0 = AGX_NONE; klen = 0; }
                 AGX_PT(5);
                 if (!contains(sIDBak, sOffBak, eIDBak, eOffBak, C.sID, C.sOff, C.eID, C.eOff)) {        // AG:2176-2189
+                    { const agx_u32 o = W.node(start).off0; C.sID0 = o == AGX_NONE ? AGX_NONE : 0; C.sOff0 = o; }
                     if (klen > 1) {                  // the record's trailing k-mer: its bytes go to the arena (every other range lives in the caller's tables)
                         W.kmer_string(klast, kmer);
                         char *t = (char *)arena->allocate(kmer.size() - 1, 1); memcpy(t, kmer.data() + 1, kmer.size() - 1);

@@ -34,7 +34,9 @@ def run_job(unit_sizes, rank, world, run_unit, dist, device, inflight=8, dst=0, 
     order and one at a time (bench.py queues the unit's upload there: uploads then reach the device largest unit first, whatever the
     threads do next).  hbm_need / hbm_budget: admission by device memory — {unit: bytes its upload will take (agx_unit_hbm_needed)} and what this rank's
     device may hold at once: a unit is only taken when it fits beside the units in flight (a unit larger than the budget: when nothing else is in flight), in
-    plan order — whole-human units take up to 57 GB of HBM each, eight of them do not fit one device.  Returns {unit: bytes-like} of ALL units on dst, None elsewhere."""
+    plan order — whole-human units take up to 57 GB of HBM each, eight of them do not fit one device.  A run_unit that declares `takes_release = True` is called as
+    run_unit(u, release) and may call release(nbytes) when the unit has given part of its device memory back before it is done (agx_unit_trim after the download: the
+    next unit is then admitted while this one is still being walked on the host).  Returns {unit: bytes-like} of ALL units on dst, None elsewhere."""
     import threading
     mine = plan(unit_sizes, rank, world)
     out, errs = {}, []
@@ -57,13 +59,19 @@ def run_job(unit_sizes, rank, world, run_unit, dist, device, inflight=8, dst=0, 
                             start_unit(u)
                 if u is None:
                     return
-                try:
-                    out[u] = run_unit(u)
-                finally:
-                    if need:
+                left = [need]                              # what this unit still holds of the budget
+
+                def release(nbytes, left=left):
+                    n = max(0, min(int(nbytes), left[0]))
+                    if n:
                         with room:
-                            held[0] -= need
+                            held[0] -= n
+                            left[0] -= n
                             room.notify_all()
+                try:
+                    out[u] = run_unit(u, release) if getattr(run_unit, "takes_release", False) else run_unit(u)
+                finally:
+                    release(left[0])
         except BaseException as e:                     # surfaces in the calling thread
             errs.append(e)
             with room:

@@ -372,7 +372,7 @@ def main():
     hbm_budget = int(0.85 * min(A.device_memory(local_rank)))      # (free, total) before this process holds any of it: blocks recycled between units may be a sixteenth larger than the unit asked for, a build that has to grow a capacity takes more
     unit_stats, held, t_start = {}, {}, {}
 
-    def run_unit(uu):
+    def run_unit(uu, release=None):
         """One unit from its staged packed arrays to its output bytes: (upload: start_unit) -> first build -> download -> walk -> release.  Runs on one of
         shard.run_job's worker threads (ctypes releases the interpreter lock, so the walks of several units run on several cores while
         libagx queues their kernel chains on the device's build streams)."""
@@ -381,6 +381,8 @@ def main():
         un.build()                         # hit prep, binning, node sweep (+ edges), edge passes, walk preparation: the unit's first build
         t_b = time.perf_counter()
         un.download()                      # walk graph -> pinned host memory
+        if release is not None and not reupload:
+            release(un.trim())             # three quarters of the unit's HBM back to the device now: the next unit is admitted while this one is walked (one-shot units only: a trimmed unit is uploaded again before another build)
         res = un.finish_views()            # host walk/join/scaffold; the outputs stay in C memory until they are packed for the gather
         st = un.stats()
         st["s_upload_build"], st["s_total"] = t_b - t_a, time.perf_counter() - t_a
@@ -390,6 +392,8 @@ def main():
         if old is not None:
             old.free()
         return res.view("extended")
+
+    run_unit.takes_release = True
 
     def start_unit(uu):
         """Called by shard.run_job when a worker takes the unit, in plan order: queues the upload (one HBM block, asynchronous PCIe copies,

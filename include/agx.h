@@ -178,6 +178,9 @@ int agx_unit_build(agx_unit *u);                 /* kernels: updateGenomeWithRea
 int agx_unit_download(agx_unit *u);              /* HBM -> pinned host memory (walk graph); implied by agx_unit_finish */
 int agx_unit_finish(agx_unit *u, agx_result *r); /* (download, then) extdContigs1/2 + scaffoldContigs (AG:1954-2464) on the host */
 void agx_result_free(agx_result *r);
+int agx_unit_trim(agx_unit *u, uint64_t *freed);  /* after agx_unit_download: gives the part of the unit's HBM that the host walk cannot ask for (three quarters of it) back to the device's memory
+                                                    region, so that the next unit is admitted when this one's DOWNLOAD is done, not when its walk is; *freed = bytes given back (0: nothing to give —
+                                                    small units on a device without a region).  The unit is no longer built afterwards: agx_unit_finish still works, another build uploads again */
 int agx_unit_release(agx_unit *u);               /* gives the unit's HBM and download buffers back to the library's caches; the staged inputs stay: upload again = a new unit (not AGX_FLAG_ONE_SHOT units: their inputs are gone after the download) */
 void agx_pool_trim(int device);                  /* device >= 0: frees the cached HBM blocks of that device; -1: frees the cached (and retired) pinned host blocks;
                                                     -2: retires the cached pinned host blocks (never handed out again, unmapped by the next -1): what a

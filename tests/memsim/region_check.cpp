@@ -135,6 +135,33 @@ int main() {
         ar.reset(); dev_trim(6); unsetenv("AGX_REGION_PERCENT");
         CHECK(g_live.empty());
     }
+    // --- a unit gives the tail of its block back before it is done (agx_unit_trim after the download): the room is there for the next unit at once, what the arena takes
+    // afterwards comes from a new block, and everything returns at reset ---
+    {   g_free_bytes = 100 * GB;
+        DevArena ar; ar.device = 7;
+        ar.reserve(60 * GB);                                                                 // makes the region: 85 GB
+        const char *b0 = (const char *)ar.take(10 * GB);
+        (void)ar.take(45 * GB);
+        MemBlock other; std::atomic<int> got{0};
+        std::thread waiter([&] { other = dev_block(7, 40 * GB); got = 1; });                 // 60 + 40 > 85: waits
+        std::this_thread::sleep_for(std::chrono::milliseconds(150));
+        CHECK(got == 0);
+        const size_t freed = ar.shrink_to(10 * GB + 12345);                                  // keep the front (rounded up to 2 MB), give the rest back
+        CHECK(freed == 60 * GB - (10 * GB + (2u << 20)) && ar.capacity() == 10 * GB + (2u << 20));
+        waiter.join();
+        CHECK(got == 1 && dev_region(7).owns(other.p) && (const char *)other.p == b0 + 10 * GB + (2u << 20));      // right behind what was kept
+        void *late = ar.take(1000);                                                          // (a record fetch after the trim: a new block, never the room that was given back)
+        CHECK(late != nullptr);
+        CHECK((const char *)late < b0 || (const char *)late >= (const char *)other.p + other.n);
+        CHECK(ar.shrink_to(1 * GB) == 0);                                                    // several blocks now: nothing more to give
+        dev_give(7, other); ar.reset(); dev_trim(7);
+        CHECK(g_live.empty() && g_free_bytes == 100 * GB);
+        DevArena small; small.device = 8; g_free_bytes = 100 * GB;                           // a unit below the region's threshold on a device without a region: nothing to give
+        small.reserve(2 * GB); (void)small.take(1 * GB);
+        CHECK(small.shrink_to(1 * GB) == 0 && small.capacity() == 2 * GB);
+        small.reset(); dev_trim(8);
+        CHECK(g_live.empty());
+    }
     printf("ok\n");
     return 0;
 }

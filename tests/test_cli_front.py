@@ -1,0 +1,71 @@
+"""AlignGraph_amd's front end on several threads (r05: maxReadLength AG:3197-3226 and formalizeInput for the reads AG:3420-3518; aligngraph_amd/csrc/agx_cli.cpp): the
+three read files it writes must be, byte for byte, what its line-by-line form writes (AGX_CLI_SERIAL=1: the form that r04 compared with the reference's own files and that
+tests/test_cli.py compares through whole runs) — for the inputs the threaded form takes (a header and one sequence line per record) and for the ones it hands back (records
+over several lines, a missing last newline, mates of different lengths cut to the shorter).  No GPU: the run stops where the unit loop would begin."""
+import os
+import subprocess
+
+import pytest
+
+import harness as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUBS = os.path.join(ROOT, "tests", "e2e_stubs")
+CLI = os.path.join(ROOT, "aligngraph_amd", "AlignGraph_amd")
+ARGS = ["--read1", "reads_1.fa", "--read2", "reads_2.fa", "--contig", "contigs.fa", "--genome", "genome.fa", "--distanceLow", "100", "--distanceHigh", "1500",
+        "--extendedContig", "e.fa", "--remainingContig", "r.fa", "--coverage", "5"]
+
+
+def front(work, **env):
+    import shutil
+    shutil.rmtree(os.path.join(work, "tmp"), ignore_errors=True)
+    e = dict(os.environ, PATH=STUBS + os.pathsep + os.environ["PATH"], AGX_STUB_DIR=os.path.join(work, "stub"), **env)
+    p = subprocess.run([CLI] + ARGS, cwd=work, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return p, {f: open(os.path.join(work, "tmp", f), "rb").read() for f in ("_reads.fa", "_reads_1.fa", "_reads_2.fa") if os.path.exists(os.path.join(work, "tmp", f))}
+
+
+@pytest.fixture(scope="module")
+def run_dir(tmp_path_factory):
+    from aligngraph_amd import build as B
+    B.build()
+    import aligngraph_amd as A
+    if A.device_count() > 0:
+        pytest.skip("a GPU is present: whole runs are covered by tests/test_cli.py")
+    return H.synth(str(tmp_path_factory.mktemp("front") / "run"), seed=77, chroms="60000,40000", pairs=30000, L=100, k=5, coverage=5, e2e=1, sam_seq=0)
+
+
+def test_threaded_front_end_writes_the_serial_files(built, run_dir):
+    ps, serial = front(run_dir, AGX_CLI_SERIAL="1")
+    assert b"(0) Alignment finished" in ps.stdout and len(serial) == 3 and serial["_reads.fa"].count(b">") == 60000
+    for threads in ("2", "5", "16"):
+        pt, got = front(run_dir, AGX_CLI_THREADS=threads, AGX_CLI_TIMING="1", AGX_CLI_FAST_MIN="0")
+        assert pt.stdout == ps.stdout
+        assert b"reads on %s threads" % threads.encode() in pt.stderr, pt.stderr[-300:]
+        assert got == serial, "threads=%s" % threads
+
+
+@pytest.mark.parametrize("shape", ["multiline", "no_final_newline", "unequal_mates", "empty_line"])
+def test_inputs_the_threaded_form_hands_back(built, run_dir, tmp_path, shape):
+    import shutil
+    work = str(tmp_path / "w")
+    shutil.copytree(run_dir, work)
+    r1 = open(os.path.join(work, "reads_1.fa"), "rb").read().split(b"\n")
+    r2 = open(os.path.join(work, "reads_2.fa"), "rb").read().split(b"\n")
+    if shape == "multiline":                          # one record of each file over two lines (at the same line numbers: the files stay consistent)
+        for r in (r1, r2):
+            s = r[20001]; r[20001:20002] = [s[:40], s[40:]]
+    elif shape == "no_final_newline":
+        r1, r2 = r1[:-1], r2[:-1]
+        r1[-1] = r1[-1]; r2[-1] = r2[-1]
+    elif shape == "unequal_mates":                    # taken by the threaded form: the longer mate is cut
+        r1[101] = r1[101][:77]; r2[4001] = r2[4001][:50]
+    else:                                              # the scan stops at the empty line, in both forms
+        r1[30000:30000] = [b""]; r2[30000:30000] = [b""]
+    open(os.path.join(work, "reads_1.fa"), "wb").write(b"\n".join(r1) + (b"" if shape == "no_final_newline" else b""))
+    open(os.path.join(work, "reads_2.fa"), "wb").write(b"\n".join(r2))
+    ps, serial = front(work, AGX_CLI_SERIAL="1")
+    pt, got = front(work, AGX_CLI_THREADS="6", AGX_CLI_FAST_MIN="0")
+    assert pt.returncode == ps.returncode and pt.stdout == ps.stdout
+    assert got == serial and len(serial) == 3
+    if shape == "unequal_mates":
+        assert b">50\n" + r1[101] + b"\n>50\n" + r2[101][:77] + b"\n" in serial["_reads.fa"]

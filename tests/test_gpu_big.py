@@ -24,6 +24,7 @@ import hashlib
 import json
 import os
 import threading
+import time
 
 import pytest
 
@@ -204,9 +205,14 @@ def _cfg5_unit_alone(agx, base, uu, threads):
     with agx.Unit(k=5, insert_variation=50, coverage=5, flags=agx.AGX_FLAG_ONE_SHOT) as un:
         un.load_files(tmp, uu)
         need = un.hbm_needed()
+        t0 = time.perf_counter()
         un.upload(); un.build(); un.download()
+        freed = un.trim()                                  # (r05) three quarters of the unit's HBM go back to the device before the walk; the walk's record fetches still find theirs
         got = un.finish()
+        chain_ms = 1e3 * (time.perf_counter() - t0)
         st = un.stats()
+        st["chain_ms"], st["trimmed"] = chain_ms, freed
+    assert freed > 0.6 * need, "agx_unit_trim gave %.1f GB of %.1f GB back" % (freed / 1e9, need / 1e9)
     checker.join()
     shutil.rmtree(run, ignore_errors=True)
     assert not errs, errs
@@ -242,7 +248,7 @@ def test_cfg5_chr21_chr22_chrY_alone_at_full_size_match_the_oracle(agx, built, t
         res = list(ex.map(lambda uu: _cfg5_unit_alone(agx, str(tmp_path), uu, max(2, THREADS // side_by_side)), units))
     for uu, (got, want, st, need) in zip(units, res):
         _check_cfg5_unit(uu, got, want, st, need)
-    print("configs[4] alone: " + "; ".join("unit %d: %d hits, %.1f GB of HBM, node sweep %.1f ms, walk %.0f ms" % (uu, r[2]["n_hits"], r[2]["device_bytes"] / 1e9, r[2]["ms_node_sweep"], r[2]["ms_walk"])
+    print("configs[4] alone: " + "; ".join("unit %d: %d hits, %.1f GB of HBM (%.1f given back after the download), node sweep %.1f ms, walk %.0f ms" % (uu, r[2]["n_hits"], r[2]["device_bytes"] / 1e9, r[2]["trimmed"] / 1e9, r[2]["ms_node_sweep"], r[2]["ms_walk"])
                                           for uu, r in zip(units, res)))
 
 
@@ -251,8 +257,8 @@ def test_cfg5_chr1_alone_at_full_size_matches_the_oracle(agx, built, tmp_path):
     """configs[4]'s LARGEST unit — chr1, 248 956 422 positions, 33 M pairs of 2x150, 57 GB of HBM — against the oracle (r03 checked it against the serial executor only)."""
     got, want, st, need = _cfg5_unit_alone(agx, str(tmp_path), 0, THREADS)
     _check_cfg5_unit(0, got, want, st, need)
-    print("configs[4] chr1 alone: %d positions, %d hits, %.1f GB of HBM, node sweep %.1f ms, download %.1f ms, walk %.0f ms; outputs %d / %d / %d bytes identical to the oracle" %
-          (st["n_pos"], st["n_hits"], st["device_bytes"] / 1e9, st["ms_node_sweep"], st["ms_download"], st["ms_walk"], len(got["initial"]), len(got["pre"]), len(got["extended"])))
+    print("configs[4] chr1 alone: %d positions, %d hits, %.1f GB of HBM (%.1f given back after the download), upload -> output bytes %.1f ms (node sweep %.1f ms, download %.1f ms, walk %.0f ms); outputs %d / %d / %d bytes identical to the oracle" %
+          (st["n_pos"], st["n_hits"], st["device_bytes"] / 1e9, st["trimmed"] / 1e9, st["chain_ms"], st["ms_node_sweep"], st["ms_download"], st["ms_walk"], len(got["initial"]), len(got["pre"]), len(got["extended"])))
 
 
 @slow

@@ -111,3 +111,37 @@ def test_units_are_admitted_by_device_memory():
     assert peak[0] <= 120 and alone == [True]               # 120 > budget: it ran with nothing beside it; everything else within 100
     with lock:
         assert now[0] == 0
+
+
+def test_a_unit_that_gives_memory_back_early_lets_the_next_one_in():
+    """r05: run_unit(u, release) — a unit that has trimmed its device memory after the download (agx_unit_trim) tells the job so, and the next unit of the plan is admitted
+    while this one is still being walked.  The budget is never exceeded by what the units hold at any moment, and a unit cannot release more than it was admitted with."""
+    import threading
+    import time
+    from aligngraph_amd import shard
+    sizes = [60, 50, 40, 30]
+    need = {u: s for u, s in enumerate(sizes)}
+    lock, now, peak, started, t0 = threading.Lock(), [0], [0], {}, time.perf_counter()
+
+    def start_unit(u):
+        started[u] = time.perf_counter() - t0
+
+    def run_unit(u, release):
+        with lock:
+            now[0] += need[u]
+            peak[0] = max(peak[0], now[0])
+        time.sleep(0.05)                                   # upload + build + download
+        keep = need[u] // 4
+        with lock:
+            now[0] -= need[u] - keep
+        release(need[u] - keep)
+        time.sleep(0.30)                                   # the walk
+        with lock:
+            now[0] -= keep
+        return b"u%d" % u
+    run_unit.takes_release = True
+    out = shard.run_job(sizes, 0, 1, run_unit, None, None, inflight=4, start_unit=start_unit, hbm_need=need, hbm_budget=100)
+    assert sorted(out) == [0, 1, 2, 3]
+    assert started[1] < 0.25 and started[2] < 0.30, started          # unit 1 (50) did not wait for unit 0's walk (0.35 s): it went in when unit 0 gave 45 back
+    with lock:
+        assert now[0] == 0
