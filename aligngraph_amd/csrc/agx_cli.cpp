@@ -987,6 +987,11 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
                 if (rc == AGX_OK) { std::unique_lock<std::mutex> g(mem_mu); mem_cv.wait(g, [&] { return used[d] == 0.0 || used[d] + est <= budget[d]; }); used[d] += est; admitted = true; }
                 if (rc == AGX_OK) rc = agx_unit_upload(un);
                 if (rc == AGX_OK) rc = agx_unit_build(un);
+                if (rc == AGX_OK) rc = agx_unit_download(un);
+                if (rc == AGX_OK) {      // r05: what the walk cannot ask the device for goes back now — the next unit is admitted while this one is walked on the host
+                    uint64_t freed = 0;
+                    if (agx_unit_trim(un, &freed) == AGX_OK && freed) { { std::lock_guard<std::mutex> g(mem_mu); const double f = std::min(est, (double)freed); used[d] -= f; est -= f; } mem_cv.notify_all(); }
+                }
                 if (rc == AGX_OK) rc = agx_unit_finish(un, &r);
                 if (rc != AGX_OK && un && !err[0]) snprintf(err, sizeof err, "%s", agx_unit_error(un));
                 agx_unit_destroy(un);                                          // (its HBM goes back before the next unit is admitted)

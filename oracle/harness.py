@@ -71,6 +71,7 @@ def build():
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     subprocess.check_call(["make", "-s", "-C", HERE, "all"])
     agx_data.build()
+    agx_data.build_bin()          # (the generator with the staged-pairs mode: the big GPU tests use it from several threads — built here, once)
     build_patched_reference()
 
 

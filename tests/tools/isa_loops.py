@@ -53,6 +53,13 @@ def main():
         out = os.path.join(d, "k.s")
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only"] + defs + [SRC, "-o", out], stderr=subprocess.DEVNULL)
         text = open(out).read().split("\n")
+    # what the kernel's descriptor says about its registers and its SCRATCH memory: a non-zero private segment means something that should be in registers is not (r05:
+    # a record kept as a struct cost agx_k_tile_fill a factor of two, and every timing read while it was there was wrong)
+    meta = {}
+    blocks = "\n".join(text).split("  - .agpr_count:")[1:]
+    for blk in blocks:
+        g = lambda k: (re.search(r"\." + k + r":\s+(\S+)", blk) or [None, "?"])[1]
+        meta[g("name")] = "vgpr %s, sgpr %s (spilled %s), LDS %s B, scratch (private segment) %s B" % (g("vgpr_count"), g("sgpr_count"), g("sgpr_spill_count"), g("group_segment_fixed_size"), g("private_segment_fixed_size"))
     # kernels: from "<name>:" to s_endpgm
     i = 0
     while i < len(text):
@@ -77,7 +84,7 @@ def main():
             op = ls.split()[0]
             ins.append((op, ls))
         total = collections.Counter(classify(op) for op, _ in ins)
-        print("%s\n  whole kernel: %d instructions  %s" % (name, len(ins), dict(total)))
+        print("%s\n  %s\n  whole kernel: %d instructions  %s" % (name, meta.get(name, ""), len(ins), dict(total)))
         loops = []
         for at, (op, ls) in enumerate(ins):
             if op.startswith(("s_cbranch", "s_branch")):

@@ -4,6 +4,15 @@ the algorithm, the oracle or the reference; bench.py, the tests and the tools al
 import os
 import shutil
 import subprocess
+import threading
+
+_build_lock = threading.Lock()      # (tests generate several units on several threads: one of them compiles, into a scratch name that is then renamed)
+
+
+def _compile(cmd, out):
+    tmp = "%s.%d.tmp" % (out, os.getpid())
+    subprocess.check_call(cmd + ["-o", tmp])
+    os.replace(tmp, out)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -13,8 +22,9 @@ SYNTH = os.path.join(ROOT, "build", "agx_synth")
 def build():
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     src = os.path.join(HERE, "agx_synth.cpp")
-    if not os.path.exists(SYNTH) or os.path.getmtime(SYNTH) < os.path.getmtime(src):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", SYNTH, src])
+    with _build_lock:
+        if not os.path.exists(SYNTH) or os.path.getmtime(SYNTH) < os.path.getmtime(src):
+            _compile(["g++", "-O2", "-std=c++17", "-pthread", src], SYNTH)
 
 
 SYNTH_BIN = os.path.join(ROOT, "build", "agx_synth_bin")
@@ -26,8 +36,9 @@ def build_bin():
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     src = [os.path.join(HERE, "agx_synth.cpp")] + [os.path.join(CSRC, f) for f in ("agx_host.cpp", "agx_walk.cpp", "agx_load.cpp")]
     deps = src + [os.path.join(CSRC, f) for f in ("agx_host.h", "agx_parse.h", "agx_core.h")]
-    if not os.path.exists(SYNTH_BIN) or any(os.path.getmtime(SYNTH_BIN) < os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-DAGX_SYNTH_WITH_ENGINE", "-o", SYNTH_BIN] + src)
+    with _build_lock:
+        if not os.path.exists(SYNTH_BIN) or any(os.path.getmtime(SYNTH_BIN) < os.path.getmtime(d) for d in deps):
+            _compile(["g++", "-O2", "-std=c++17", "-pthread", "-DAGX_SYNTH_WITH_ENGINE"] + src, SYNTH_BIN)
 
 
 def synth(out, **kw):
