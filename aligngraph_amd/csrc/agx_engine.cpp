@@ -1471,7 +1471,7 @@ int agx_unit_stage(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&
 int agx_unit_upload(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_upload(u); }); }
 int agx_unit_release(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_release(u); }); }
 int agx_unit_trim(agx_unit *u, uint64_t *freed) { if (!u) return AGX_E_ARG; if (freed) *freed = 0; return guarded(u, [&] { const size_t f = do_trim(u); if (freed) *freed = f; }); }
-void agx_pool_trim(int device) { if (device >= 0) dev_trim(device); else if (device == -1) { host_trim(); scratch_trim(); } else host_retire(); }      // (-1 also unmaps the loaders' cached scratch memory: up to 16 GB of touched pages per process otherwise stay until exit)
+void agx_pool_trim(int device) { if (device >= 0) dev_trim(device); else if (device == -1) { host_trim(); scratch_trim(); out_cache_trim(); } else host_retire(); }      // (-1 also unmaps the loaders' cached scratch memory: up to 16 GB of touched pages per process otherwise stay until exit)
 int agx_unit_build(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_build(u); }); }
 int agx_unit_download(agx_unit *u) { if (!u) return AGX_E_ARG; return guarded(u, [&] { do_download(u); }); }
 
@@ -1515,7 +1515,7 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
     });
 }
 
-void agx_result_free(agx_result *r) { if (!r) return; free(r->initial_contigs); free(r->pre_extended); free(r->extended); memset(r, 0, sizeof *r); }
+void agx_result_free(agx_result *r) { if (!r) return; out_cache_give(r->initial_contigs); out_cache_give(r->pre_extended); out_cache_give(r->extended); memset(r, 0, sizeof *r); }      // (kept for the next unit's outputs: agx_host.h)
 
 int agx_unit_stats(const agx_unit *u, agx_stats *s) {
     if (!u || !s) return AGX_E_ARG;

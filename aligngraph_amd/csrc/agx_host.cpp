@@ -13,6 +13,9 @@
 // (listed in DESIGN.md "Rejected inputs"): SAM not sorted by read id, CIGAR length != read length,
 // a RNAME / tName that does not resolve to the unit sequence, alignments beyond the unit sequence.
 #include "agx_host.h"
+#include <malloc.h>
+#include <map>
+#include <mutex>
 #include "agx_parse.h"
 
 #include <algorithm>
@@ -68,6 +71,32 @@ bool keeps_last(const std::vector<ContigSeq> &c, agx_u32 id, double thr) {
 }
 
 }  // namespace
+
+// ---- output buffers kept between units (agx_host.h: OutBuf) ----------------------------------------------------------------------------
+namespace {
+struct OutCache { std::mutex m; std::multimap<size_t, void *> kept; size_t bytes = 0; };
+OutCache &out_cache() { static OutCache c; return c; }
+}
+void *out_cache_take(size_t need, size_t &cap) {
+    OutCache &C = out_cache(); std::lock_guard<std::mutex> g(C.m);
+    auto it = C.kept.lower_bound(need);
+    if (it == C.kept.end() || it->first > 2 * need + ((size_t)16 << 20)) return nullptr;
+    void *p = it->second; cap = it->first; C.bytes -= it->first; C.kept.erase(it);
+    return p;
+}
+void out_cache_give(void *p) {
+    if (!p) return;
+    const size_t n = malloc_usable_size(p);
+    OutCache &C = out_cache();
+    { std::lock_guard<std::mutex> g(C.m);
+      if (n >= ((size_t)1 << 20) && C.kept.size() < 64 && C.bytes + n <= ((size_t)8 << 30) && !getenv("AGX_NO_OUT_CACHE")) { C.kept.emplace(n, p); C.bytes += n; return; } }
+    free(p);
+}
+void out_cache_trim() {
+    OutCache &C = out_cache(); std::multimap<size_t, void *> all;
+    { std::lock_guard<std::mutex> g(C.m); all.swap(C.kept); C.bytes = 0; }
+    for (auto &kv : all) free(kv.second);
+}
 
 void advise_huge(void *p, size_t n) {
 #if defined(__linux__) && defined(MADV_HUGEPAGE)

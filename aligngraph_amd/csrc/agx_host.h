@@ -103,12 +103,19 @@ struct GraphView {
 void advise_huge(void *p, size_t n);
 
 // malloc-backed output buffer whose storage can be handed to the C caller without another copy
+// Output buffers that were handed to a caller and given back (agx_result_free) are kept for the next unit instead of going back to the C library: a unit's three outputs
+// are 2.2 bytes per position of FRESH memory otherwise — page faults and the kernel's zeroing, a sixth of a whole-human job's host CPU time (r05) — and a run's units
+// follow each other.  malloc'd memory throughout (a caller may free() an output itself); at most 64 buffers / 8 GB are kept; agx_pool_trim(-1) frees them.
+void *out_cache_take(size_t need, size_t &cap);      // a kept buffer of at least `need` bytes and at most twice that (cap = its usable size); nullptr: none
+void out_cache_give(void *p);                        // (nullptr is fine)
+void out_cache_trim();
 struct OutBuf {
     char *p = nullptr; size_t n = 0, cap = 0;
     OutBuf() = default; OutBuf(const OutBuf &) = delete; OutBuf &operator=(const OutBuf &) = delete;
-    ~OutBuf() { free(p); }
+    ~OutBuf() { out_cache_give(p); }
     void reserve(size_t c) {
         if (c + 1 <= cap) return;
+        if (!p && c >= ((size_t)1 << 20)) { size_t got = 0; if (void *q = out_cache_take(c + 1, got)) { p = (char *)q; cap = got; return; } }
         char *q = (char *)realloc(p, c + 1); if (!q) throw Error{E_ARG, "out of host memory"};
         p = q; cap = c + 1; advise_huge(p, cap);
     }
@@ -118,7 +125,7 @@ struct OutBuf {
     // touches every page of the capacity: the first-touch faults (and the kernel's zeroing) of a 30 MB output happen where the caller has
     // time to spare instead of inside the walk
     void prefault() { for (size_t i = 0; i < cap; i += 4096) p[i] = 0; }
-    void clear() { free(p); p = nullptr; n = cap = 0; }
+    void clear() { out_cache_give(p); p = nullptr; n = cap = 0; }
 };
 struct UnitOutput { OutBuf pre_extended, extended; unsigned long long n_fetched = 0; };
 
