@@ -613,7 +613,18 @@ struct SpecWalker {
 // false: not split (too small, no assistant): the caller walks the usual way
 bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena, Arena *const *more_arenas, Assistant *assistant) {
     const agx_u32 min_ref = getenv("AGX_WALK_SPLIT_MIN") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_MIN"), nullptr, 10) : 4000000u;
-    const agx_u32 warm = getenv("AGX_WALK_SPLIT_WARMUP") ? (agx_u32)strtoul(getenv("AGX_WALK_SPLIT_WARMUP"), nullptr, 10) : 400000u;
+    // The warm-up in front of a walker's stretch must hold every walk that can reach into the stretch: walks are local, and what reaches furthest is a conti-mer chain, which lands
+    // where its contig's placement ends.  So: three times the longest reach of a chain in this unit (+ a margin), 100 k to 400 k positions (r03/r04: 400 k whatever the unit; a
+    // warm-up goes at half the speed of a stretch and the first walker's stretch is two warm-ups longer than the others': a 30 Mb unit's eight walkers spent a fifth of the
+    // walk's CPU time warming up).  Too short a warm-up is never wrong: the stretch then does not stand and the first walker walks it.
+    agx_u32 warm = 400000u;
+    if (const char *e = getenv("AGX_WALK_SPLIT_WARMUP")) warm = (agx_u32)strtoul(e, nullptr, 10);
+    else if (V.segs) {
+        agx_u32 reach = 0;
+        for (agx_u32 i = 0; i < V.n_seg0; i++) { const agx_cmseg &g = V.segs[i]; if (g.hop_len0 && g.hop_end > g.pos0 && g.hop_end - g.pos0 > reach) reach = g.hop_end - g.pos0; }
+        const unsigned long long w = 3ull * reach + 20000ull;
+        warm = (agx_u32)(w < 100000ull ? 100000ull : w > 400000ull ? 400000ull : w);
+    }
     const agx_u32 n_ref = V.n_ref < G.n_pos ? V.n_ref : G.n_pos;
     if (!assistant || n_ref < min_ref || n_ref < 16 || getenv("AGX_WALK_NO_SPLIT")) return false;
     // walkers: one per 1.2 M positions, two to eight (sixteen on request: walkers_for), as many as there are helper threads.  Every further walker works on visited bytes of its own: a
