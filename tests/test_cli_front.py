@@ -69,3 +69,45 @@ def test_inputs_the_threaded_form_hands_back(built, run_dir, tmp_path, shape):
     assert got == serial and len(serial) == 3
     if shape == "unequal_mates":
         assert b">50\n" + r1[101] + b"\n>50\n" + r2[101][:77] + b"\n" in serial["_reads.fa"]
+
+
+def _formalize_genome_model(chroms, p):
+    """formalizeGenome, AG:3347-3418, base by base: files of the units and tmp/_genome.fa."""
+    units, whole, unit = {}, [], 0
+    for s in chroms:
+        out = [">0\n"]; whole.append(">%d\n" % unit)
+        step, q = len(s) // p, 1
+        for c, ch in enumerate(s):
+            out.append(ch); whole.append(ch)
+            cut = step != 0 and (c + 1) % step == 0 and q < p
+            if (c + 1) % 60 == 0 or c == len(s) - 1 or cut:
+                out.append("\n"); whole.append("\n")
+            if c != len(s) - 1 and cut:
+                units[unit] = "".join(out); unit += 1; q += 1
+                out = [">0\n"]; whole.append(">%d\n" % unit)
+        units[unit] = "".join(out); unit += 1
+    return units, "".join(whole)
+
+
+@pytest.mark.parametrize("part", [1, 2, 3, 7])
+def test_formalize_genome_parts(built, run_dir, tmp_path, part):
+    """r05 writes the unit sequences a line at a time; the rule (a newline after every 60th base of the chromosome, at a part's end and at the chromosome's end; a cut on the last
+    base opens no unit) against a base-by-base model of AG:3382-3413, for lengths around the multiples of 60 and of the part count."""
+    import random
+    import shutil
+    work = str(tmp_path / "w")
+    shutil.copytree(run_dir, work)
+    rnd = random.Random(part)
+    chroms = ["".join(rnd.choice("ACGT") for _ in range(n)) for n in (1, 59, 60, 61, 119, 120, 121, 360, 361, 420 * part, 420 * part + 1, 1237)]
+    with open(os.path.join(work, "genome.fa"), "w") as f:
+        for i, s in enumerate(chroms):
+            f.write(">c%d\n" % i + "".join(s[j:j + 70] + "\n" for j in range(0, len(s), 70)))
+    args = list(ARGS) + ["--part", str(part)]
+    shutil.rmtree(os.path.join(work, "tmp"), ignore_errors=True)
+    e = dict(os.environ, PATH=STUBS + os.pathsep + os.environ["PATH"], AGX_STUB_DIR=os.path.join(work, "stub"))
+    subprocess.run([CLI] + args, cwd=work, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    units, whole = _formalize_genome_model(chroms, part)
+    assert open(os.path.join(work, "tmp", "_genome.fa")).read() == whole
+    for u, text in units.items():
+        assert open(os.path.join(work, "tmp", "_genome.%d.fa" % u)).read() == text, u
+    assert not os.path.exists(os.path.join(work, "tmp", "_genome.%d.fa" % len(units)))
