@@ -89,7 +89,7 @@ void out_cache_give(void *p) {
     const size_t n = malloc_usable_size(p);
     OutCache &C = out_cache();
     { std::lock_guard<std::mutex> g(C.m);
-      if (n >= ((size_t)1 << 20) && C.kept.size() < 64 && C.bytes + n <= ((size_t)8 << 30) && !getenv("AGX_NO_OUT_CACHE")) { C.kept.emplace(n, p); C.bytes += n; return; } }
+      if (n >= ((size_t)1 << 20) && C.kept.size() < 128 && C.bytes + n <= ((size_t)16 << 30) && !getenv("AGX_NO_OUT_CACHE")) { C.kept.emplace(n, p); C.bytes += n; return; } }
     free(p);
 }
 void out_cache_trim() {

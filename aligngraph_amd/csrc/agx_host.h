@@ -105,7 +105,7 @@ void advise_huge(void *p, size_t n);
 // malloc-backed output buffer whose storage can be handed to the C caller without another copy
 // Output buffers that were handed to a caller and given back (agx_result_free) are kept for the next unit instead of going back to the C library: a unit's three outputs
 // are 2.2 bytes per position of FRESH memory otherwise — page faults and the kernel's zeroing, a sixth of a whole-human job's host CPU time (r05) — and a run's units
-// follow each other.  malloc'd memory throughout (a caller may free() an output itself); at most 64 buffers / 8 GB are kept; agx_pool_trim(-1) frees them.
+// follow each other.  malloc'd memory throughout (a caller may free() an output itself); at most 128 buffers / 16 GB are kept (a whole-human job's 24 units hand back 72 buffers, 6.8 GB); agx_pool_trim(-1) frees them.
 void *out_cache_take(size_t need, size_t &cap);      // a kept buffer of at least `need` bytes and at most twice that (cap = its usable size); nullptr: none
 void out_cache_give(void *p);                        // (nullptr is fine)
 void out_cache_trim();

@@ -177,7 +177,7 @@ int agx_unit_upload(agx_unit *u);                /* staged arrays -> HBM: one de
 int agx_unit_build(agx_unit *u);                 /* kernels: updateGenomeWithRead/updateKMer (AG:1635-1870, 1353-1624) + filterLowCoverage (AG:1904-1918) */
 int agx_unit_download(agx_unit *u);              /* HBM -> pinned host memory (walk graph); implied by agx_unit_finish */
 int agx_unit_finish(agx_unit *u, agx_result *r); /* (download, then) extdContigs1/2 + scaffoldContigs (AG:1954-2464) on the host */
-void agx_result_free(agx_result *r);               /* (the buffers are malloc'd; the library keeps up to 8 GB of the ones given back here for the outputs of the next units — fresh memory for them is a
+void agx_result_free(agx_result *r);               /* (the buffers are malloc'd; the library keeps up to 16 GB of the ones given back here for the outputs of the next units — fresh memory for them is a
                                                     sixth of a whole-human job's host CPU time —, agx_pool_trim(-1) frees them) */
 int agx_unit_trim(agx_unit *u, uint64_t *freed);  /* after agx_unit_download: gives the part of the unit's HBM that the host walk cannot ask for (three quarters of it) back to the device's memory
                                                     region, so that the next unit is admitted when this one's DOWNLOAD is done, not when its walk is; *freed = bytes given back (0: nothing to give —
