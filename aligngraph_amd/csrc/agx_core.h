@@ -106,11 +106,7 @@ struct agx_cmhead { agx_u32 cid, coff, n, start; };
 
 enum { AGX_HF_AREV = 1, AGX_HF_SKIP = 2, AGX_HF_BNONE = 4 };      // BNONE (tile records only): the b mate is unaligned over the whole piece
 
-#ifdef AGX_DHIT48
-struct alignas(16) agx_dhit {      // (experiment, r05: 48 bytes, 16-byte aligned, so that a lane fetches its record with three 16-byte loads instead of ten 4-byte ones: agx_k_tile_fill 0.80 ms instead of 0.53)
-#else
-struct agx_dhit {
-#endif
+struct agx_dhit {             // 40 bytes = five 8-byte words (agx_k_tile_fill reads it that way; padded to 48 bytes for 16-byte loads it was slower: HISTORY.md r05)
     agx_u32 a_t0, b_t0;       // simple mate: reference offset of read index 0 ("a" = the left mate, AG:1672-1679)
     agx_u32 a_runs, b_runs;
     agx_u32 a_slot;           // read slot of the a mate
@@ -118,9 +114,6 @@ struct agx_dhit {
     agx_u16 a_nruns, b_nruns; // 0 = simple
     agx_u32 flags;
     agx_u32 x_lo, x_hi;       // first / last position that receives an arrival (x_lo > x_hi: none)
-#ifdef AGX_DHIT48
-    agx_u32 pad[2];
-#endif
 };
 
 // ---- node table (device -> host) ----------------------------------------------------------------------
