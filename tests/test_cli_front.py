@@ -11,7 +11,7 @@ import harness as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STUBS = os.path.join(ROOT, "tests", "e2e_stubs")
-CLI = os.path.join(ROOT, "aligngraph_amd", "AlignGraph_amd")
+CLI = os.environ.get("AGX_CLI_PATH", os.path.join(ROOT, "aligngraph_amd", "AlignGraph_amd"))      # (AGX_CLI_PATH: a sanitizer build of the same source)
 ARGS = ["--read1", "reads_1.fa", "--read2", "reads_2.fa", "--contig", "contigs.fa", "--genome", "genome.fa", "--distanceLow", "100", "--distanceHigh", "1500",
         "--extendedContig", "e.fa", "--remainingContig", "r.fa", "--coverage", "5"]
 
