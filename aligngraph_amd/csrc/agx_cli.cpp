@@ -481,7 +481,13 @@ void distribute_alignments(int units) {
     close(fd);
 }
 
-int run(const string &cmd) { return system(cmd.c_str()); }
+std::atomic<long long> g_run_ns{0};      // time inside external commands (AGX_CLI_TIMING reports it per stage; summed over the threads that wait)
+int run(const string &cmd) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = system(cmd.c_str());
+    g_run_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
 
 // parseDelta, AG:524-586: the first four blank-separated items of a .delta line as integers.  Item 0 drops every '>'; an item of
 // the form "a.b" yields a and "real" part b — except that the reference fills the second item's real part starting at the index where
@@ -786,7 +792,118 @@ inline int masb_overlap(unsigned x1, unsigned y1, unsigned x2, unsigned y2) {   
            (x1 <= x2 && x2 <= y2 && y2 <= y1 && (int)y2 - (int)x2 > 0) || (x2 <= x1 && x1 <= y1 && y1 <= y2 && (int)y1 - (int)x1 > 0);
 }
 
+// The columns of a SAM line that parseBOWTIE (AG:181-285) turns into a place on a target record: the record (the number in front of the '.' of RNAME, 0
+// without one; none — tid -1 — as soon as the column holds a '*'), the 0-based start (POS - 1, unsigned) and the end = start + the M, S and I lengths + the D
+// lengths - the I lengths.  `bad`: a CIGAR character the reference stops the program at ("unknown character").
+struct SamSpan { int tid; unsigned ts, te; char bad; };
+inline int field_atoi(const char *s, size_t n) {
+    char b[32];
+    if (n < sizeof b) { memcpy(b, s, n); b[n] = 0; return atoi(b); }
+    return atoi(string(s, n).c_str());
+}
+inline SamSpan sam_span(const char *s, size_t n) {
+    const char *f[6]; size_t fl[6]; size_t a = 0; int nf = 0;
+    for (; nf < 6; nf++) {
+        const char *tab = a <= n ? (const char *)memchr(s + a, '\t', n - a) : nullptr;
+        f[nf] = s + a; fl[nf] = tab ? (size_t)(tab - (s + a)) : n - a;
+        if (!tab) { nf++; break; }
+        a = (size_t)(tab - s) + 1;
+    }
+    for (; nf < 6; nf++) { f[nf] = s + n; fl[nf] = 0; }
+    SamSpan r{0, 0, 0, 0};
+    if (fl[2] && memchr(f[2], '*', fl[2])) { r.tid = -1; return r; }
+    const char *dot = fl[2] ? (const char *)memchr(f[2], '.', fl[2]) : nullptr;
+    r.tid = dot ? field_atoi(f[2], (size_t)(dot - f[2])) : 0;
+    int total = 0, ins = 0, del = 0; unsigned num = 0;
+    for (size_t i = 0; i < fl[5]; i++) {
+        const char c = f[5][i];
+        if (c >= '0' && c <= '9') { num = num * 10 + (unsigned)(c - '0'); continue; }
+        if (c == 'I') { ins += (int)num; total += (int)num; } else if (c == 'D') del += (int)num; else if (c == 'M' || c == 'S') total += (int)num;
+        else if (c == '*') continue;                   // (the digits in front of it stay in the reference's buffer)
+        else { r.bad = c; return r; }
+        num = 0;
+    }
+    r.ts = (unsigned)(field_atoi(f[3], fl[3]) - 1); r.te = r.ts + (unsigned)(total + del - ins);
+    return r;
+}
+
+// loadReadAlignment of the misassembly removal, AG:3940-3984: the per-base read coverage of the chunk records (len[i] bases each) from the SAM file of the reads
+// against them — +1 over [start, end) for both mates of every pair that has both mates placed; lines in pairs, '@' lines in front of a pair skipped, the file ends at
+// its first empty line.  cov[off[i] + bp] = coverage of base bp of record i.  The reference reads the file (9 GB for 30 M reads) a line at a time and counts base by base;
+// here every CPU the process may use parses a piece of the mapped file and adds +1 / -1 at the two ends of a span, and one running sum per record makes the counts.
+// A place outside its record counts as far as the record goes (the reference writes out of bounds there); a pair that names a record that does not exist counts nothing.
+void masb_read_coverage(const string &path, const vector<size_t> &len, vector<int> &cov, vector<size_t> &off) {
+    Lines in(path);
+    if (!in.opened) die("CANNOT OPEN FILE!");
+    off.assign(len.size() + 1, 0);
+    for (size_t i = 0; i < len.size(); i++) off[i + 1] = off[i] + len[i] + 1;      // (one more slot per record: where a span that reaches the record's end stops)
+    cov.assign(off.back() + 1, 0);
+    const size_t least = getenv("AGX_CLI_FAST_MIN") ? (size_t)atoll(getenv("AGX_CLI_FAST_MIN")) : ((size_t)8 << 20);      // (tests: small files on several threads)
+    const unsigned T = in.n >= least && in.n > 4096 && !getenv("AGX_CLI_SERIAL") ? cli_threads() : 1u;
+    const char *p = in.p; const size_t n = scan_end(p, in.n, T);
+    size_t body = 0;                                   // behind the '@' lines at the top
+    while (body < n && p[body] == '@') { const char *nl = (const char *)memchr(p + body, '\n', n - body); body = nl ? (size_t)(nl - p) + 1 : n; }
+    int *const d = cov.data();
+    const size_t n_rec = len.size();
+    auto add = [&](const SamSpan &x) {                 // (bp < targetEnd is an unsigned comparison in the reference: an empty span if start >= end)
+        if (x.ts >= x.te || (size_t)x.ts >= len[(size_t)x.tid]) return;
+        const size_t base = off[(size_t)x.tid], hi = std::min<size_t>(x.te, len[(size_t)x.tid]);
+        __atomic_fetch_add(d + base + x.ts, 1, __ATOMIC_RELAXED); __atomic_fetch_add(d + base + hi, -1, __ATOMIC_RELAXED);
+    };
+    struct Fatal { size_t at; char bad; bool broken; };
+    // lines [lo, hi) in pairs; the first of them is the first line of a pair.  The first thing the reference would stop at, if any.
+    auto pairs = [&](size_t lo, size_t hi, size_t end, Fatal &fatal) {
+        for (size_t at = lo; at < hi;) {
+            const char *nl = (const char *)memchr(p + at, '\n', end - at);
+            const size_t l1 = nl ? (size_t)(nl - p) - at : end - at, at2 = at + l1 + 1;
+            if (p[at] == '@') { at = at2; continue; }
+            const SamSpan x = sam_span(p + at, l1);
+            if (x.bad) { fatal = Fatal{at, x.bad, false}; return; }
+            if (at2 >= end) { fatal = Fatal{at, 0, true}; return; }
+            const char *nl2 = (const char *)memchr(p + at2, '\n', end - at2);
+            const size_t l2 = nl2 ? (size_t)(nl2 - p) - at2 : end - at2;
+            const SamSpan y = sam_span(p + at2, l2);
+            if (y.bad) { fatal = Fatal{at2, y.bad, false}; return; }
+            at = at2 + l2 + 1;
+            if (x.tid == -1 || y.tid == -1 || (size_t)x.tid >= n_rec || (size_t)y.tid >= n_rec) continue;
+            add(x); add(y);
+        }
+    };
+    vector<Fatal> fatal(T, Fatal{(size_t)-1, 0, false});
+    bool parallel = T > 1;
+    if (parallel) {
+        // the pieces' first lines must be first lines of pairs: count the lines of every piece (and look for '@' lines behind the top, which would shift the pairing)
+        vector<size_t> cut(T + 1), lines(T, 0); vector<char> at_sign(T, 0);
+        for (unsigned t = 0; t <= T; t++) cut[t] = t == T ? n : std::max(body, line_start_at(p, n, body + (n - body) / T * t));
+        on_threads(T, [&](unsigned t) {
+            size_t c = 0;
+            for (size_t at = cut[t]; at < cut[t + 1];) { if (p[at] == '@') at_sign[t] = 1; const char *nl = (const char *)memchr(p + at, '\n', cut[t + 1] - at); c++; if (!nl) break; at = (size_t)(nl - p) + 1; }
+            lines[t] = c;
+        });
+        for (unsigned t = 0; t < T; t++) if (at_sign[t]) parallel = false;
+        if (parallel) {
+            size_t before = 0; vector<size_t> lo(cut.begin(), cut.end() - 1);
+            for (unsigned t = 0; t < T; t++) {       // a piece that begins with the second line of a pair leaves that line to the piece in front of it (which reads past its own end for it)
+                if ((before & 1) && cut[t] < cut[t + 1]) { const char *nl = (const char *)memchr(p + cut[t], '\n', n - cut[t]); lo[t] = std::min(nl ? (size_t)(nl - p) + 1 : n, cut[t + 1]); }
+                before += lines[t];
+            }
+            on_threads(T, [&](unsigned t) { pairs(lo[t], cut[t + 1], n, fatal[t]); });
+        }
+    }
+    if (!parallel) pairs(body, n, n, fatal[0]);
+    if (getenv("AGX_CLI_TIMING")) fprintf(stderr, "[agx cli]   read coverage: %zu bytes of SAM on %u thread%s\n", n, parallel ? T : 1u, parallel ? "s" : "");
+    const Fatal *first = nullptr;
+    for (const Fatal &f : fatal) if (f.at != (size_t)-1 && (!first || f.at < first->at)) first = &f;
+    if (first) { if (first->broken) die("BROKEN BOWTIE FILE!"); cout << "unknown character: " << first->bad << endl; exit(-1); }
+    // +1 / -1 at the ends of the spans -> counts
+    const unsigned TS = len.size() > 64 ? T : 1u;
+    on_threads(TS, [&](unsigned t) { for (size_t i = len.size() * t / TS; i < len.size() * (t + 1) / TS; i++) { int run = 0; int *c = d + off[i]; for (size_t bp = 0; bp <= len[i]; bp++) { run += c[bp]; c[bp] = run; } } });
+}
+
 void remove_misassembly(const Options &o, const string &file, const string &id, vector<string> &contigIds) {
+    const bool timing = getenv("AGX_CLI_TIMING") != nullptr;      // (stderr: the aligners' share of this step, and its own)
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_in = now_s();
     const string fa = "tmp/_" + id + "_contigs.fa";
     formalize_contigs(file, contigIds, fa);                                        // AG:4288-4290; contigIds now names THIS file's records
     // makeAlignment, AG:3821-3851
@@ -800,6 +917,7 @@ void remove_misassembly(const Options &o, const string &file, const string &id, 
         if (run("pblat " + io + " -threads=8 > blat_doc.txt 2> blat_doc.txt") != 0)
             if (run("blat " + io + " > blat_doc.txt 2> blat_doc.txt") != 0) die("BLAT CALL FAILED!");
     }
+    const double t_aligned = now_s();
     // loadPreContigs, AG:3853-3891: one coverage counter per base of every chunk record
     bool ok; vector<string> lines = read_lines(fa, ok);
     if (!ok) die("CANNOT OPEN FILE!");
@@ -810,34 +928,17 @@ void remove_misassembly(const Options &o, const string &file, const string &id, 
     }
     // loadReadAlignment, AG:3940-3984: +1 over [POS-1, POS-1 + CIGAR span on the contig) for both mates of every aligned pair
     {
-        vector<string> sam = read_lines("tmp/_reads_" + id + "_contigs.bowtie", ok);
-        if (!ok) die("CANNOT OPEN FILE!");
-        auto span = [](const string &l, int &tid, unsigned &ts, unsigned &te) {
-            vector<string> f; size_t a = 0;
-            for (int i = 0; i < 6; i++) { size_t b = l.find('\t', a); f.push_back(l.substr(a, b == string::npos ? string::npos : b - a)); if (b == string::npos) break; a = b + 1; }
-            f.resize(6);
-            if (f[2].size() && f[2][0] == '*') { tid = -1; return; }
-            const size_t dot = f[2].find('.');
-            tid = dot == string::npos ? 0 : atoi(f[2].substr(0, dot).c_str());      // parseBOWTIE: RNAME "seqID.realID" -> seqID (AG:277-280)
-            int total = 0, ins = 0, del = 0; unsigned num = 0;
-            for (char c : f[5]) {
-                if (c >= '0' && c <= '9') { num = num * 10 + (unsigned)(c - '0'); continue; }
-                if (c == 'I') { ins += (int)num; total += (int)num; } else if (c == 'D') del += (int)num; else if (c == 'M' || c == 'S') total += (int)num;
-                else if (c != '*') { cout << "unknown character: " << c << endl; exit(-1); }
-                num = 0;
-            }
-            ts = (unsigned)(atoi(f[3].c_str()) - 1); te = ts + (unsigned)(total + del - ins);
-        };
-        for (size_t i = 0; i < sam.size(); i++) {
-            if (sam[i][0] == '@') continue;
-            if (i + 1 >= sam.size()) die("BROKEN BOWTIE FILE!");
-            int t1, t2; unsigned s1 = 0, e1 = 0, s2 = 0, e2 = 0;
-            span(sam[i], t1, s1, e1); span(sam[i + 1], t2, s2, e2); i++;
-            if (t1 == -1 || t2 == -1) continue;
-            if ((size_t)t1 >= pre.size() || (size_t)t2 >= pre.size()) continue;       // the reference would write out of bounds
-            for (int bp = (int)s1; bp < (int)e1; bp++) if ((size_t)bp < pre[t1].size()) pre[t1][bp].cov++;
-            for (int bp = (int)s2; bp < (int)e2; bp++) if ((size_t)bp < pre[t2].size()) pre[t2][bp].cov++;
+        vector<size_t> len(pre.size()); for (size_t i = 0; i < pre.size(); i++) len[i] = pre[i].size();
+        vector<int> cov; vector<size_t> off;
+        masb_read_coverage("tmp/_reads_" + id + "_contigs.bowtie", len, cov, off);
+        if (const char *dump = getenv("AGX_CLI_MASB_COV")) {      // (tests: the counts themselves, record after record, as 32-bit integers)
+            std::ofstream w((string(dump) + "." + id + ".bin").c_str(), std::ios::binary);
+            for (size_t i = 0; i < pre.size(); i++) w.write((const char *)(cov.data() + off[i]), (std::streamsize)(len[i] * sizeof(int)));
         }
+        on_threads(pre.size() > 64 ? cli_threads() : 1u, [&](unsigned t) {
+            const unsigned T = pre.size() > 64 ? cli_threads() : 1u;
+            for (size_t i = pre.size() * t / T; i < pre.size() * (t + 1) / T; i++) { const int *c = cov.data() + off[i]; vector<CBase> &P = pre[i]; for (size_t bp = 0; bp < P.size(); bp++) P[bp].cov = c[bp]; }
+        });
     }
     // loadContigs, AG:3893-3938: chunks of one real contig are concatenated (a new contig starts when realID grows)
     vector<vector<CBase> > contigs; int realBak = -1;
@@ -937,6 +1038,7 @@ void remove_misassembly(const Options &o, const string &file, const string &id, 
         }
     }
     if (id == "remaining") { vector<string> chaff = read_lines("tmp/_chaff.fa", ok); if (ok) for (const string &b : chaff) out << b << '\n'; }
+    if (timing) fprintf(stderr, "[agx cli]   %-9s contigs: aligners (external) %9.3f s, coverage + placements + cuts %9.3f s\n", id.c_str(), t_aligned - t_in, now_s() - t_aligned);
 }
 
 // ---- the unit loop on the GPUs --------------------------------------------------------------------------------------------------
@@ -1036,7 +1138,11 @@ int main(int argc, char **argv) {
     const bool timing = getenv("AGX_CLI_TIMING") != nullptr;
     auto clock_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_stage = clock_s();
-    auto stage = [&](const char *name) { const double t = clock_s(); if (timing) fprintf(stderr, "[agx cli] %-28s %9.3f s\n", name, t - t_stage); t_stage = t; };
+    auto stage = [&](const char *name) {
+        const double t = clock_s(), ext = (double)g_run_ns.exchange(0) * 1e-9;
+        if (timing) { if (ext > 0.0005) fprintf(stderr, "[agx cli] %-28s %9.3f s (%.3f s of it waiting for external commands)\n", name, t - t_stage, ext); else fprintf(stderr, "[agx cli] %-28s %9.3f s\n", name, t - t_stage); }
+        t_stage = t;
+    };
     {
         std::ofstream wcmd("command.txt");
         if (!wcmd.is_open()) { cout << "CANNOT OPEN FILE!" << endl; return 0; }
@@ -1087,6 +1193,7 @@ int main(int argc, char **argv) {
         remove_misassembly(o, o.ext, "extended", contigIds);
         remove_misassembly(o, o.rmn, "remaining", contigIds);
         cout << endl << "(6) Misassemblies removed" << endl;
+        stage("misassembly removal");
     }
     const time_t end = time(NULL);
     cout << endl << "FINISHED SUCCESSFULLY for " << end - start << " seconds (" << endAlign - startAlign << " seconds for alignment) :-)" << endl;
