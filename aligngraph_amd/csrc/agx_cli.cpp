@@ -833,6 +833,7 @@ inline SamSpan sam_span(const char *s, size_t n) {
 // here every CPU the process may use parses a piece of the mapped file and adds +1 / -1 at the two ends of a span, and one running sum per record makes the counts.
 // A place outside its record counts as far as the record goes (the reference writes out of bounds there); a pair that names a record that does not exist counts nothing.
 void masb_read_coverage(const string &path, const vector<size_t> &len, vector<int> &cov, vector<size_t> &off) {
+    const auto t_start = std::chrono::steady_clock::now();
     Lines in(path);
     if (!in.opened) die("CANNOT OPEN FILE!");
     off.assign(len.size() + 1, 0);
@@ -891,7 +892,7 @@ void masb_read_coverage(const string &path, const vector<size_t> &len, vector<in
         }
     }
     if (!parallel) pairs(body, n, n, fatal[0]);
-    if (getenv("AGX_CLI_TIMING")) fprintf(stderr, "[agx cli]   read coverage: %zu bytes of SAM on %u thread%s\n", n, parallel ? T : 1u, parallel ? "s" : "");
+    if (getenv("AGX_CLI_TIMING")) fprintf(stderr, "[agx cli]   read coverage: %zu bytes of SAM on %u thread%s, %.3f s\n", n, parallel ? T : 1u, parallel ? "s" : "", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
     const Fatal *first = nullptr;
     for (const Fatal &f : fatal) if (f.at != (size_t)-1 && (!first || f.at < first->at)) first = &f;
     if (first) { if (first->broken) die("BROKEN BOWTIE FILE!"); cout << "unknown character: " << first->bad << endl; exit(-1); }
