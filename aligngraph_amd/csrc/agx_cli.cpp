@@ -429,6 +429,58 @@ int formalize_reads(const string &p1, const string &p2) {
 
 // distributeAlignments, AG:3545-3579 with parseBT, AG:3520-3543: a SAM line goes to the unit its RNAME (atoi of <=9 chars) names; '@' lines
 // are dropped; an empty line ends the scan
+// the unit of one line (not empty, not beginning with a NUL byte): -1 = none ('@' lines, a '*' anywhere in RNAME, a unit that does not exist)
+inline int unit_of_line(const char *line, size_t len, int units) {
+    if (line[0] == '@') return -1;
+    const char *le = line + len;
+    // parseBT: third tab-separated field; any '*' in it means unaligned; a missing field reads as "" -> unit 0 (atoi)
+    const char *t1 = (const char *)memchr(line, '\t', len), *t2 = t1 ? (const char *)memchr(t1 + 1, '\t', (size_t)(le - t1 - 1)) : nullptr;
+    const char *r0 = t2 ? t2 + 1 : le, *r1 = t2 ? (const char *)memchr(r0, '\t', (size_t)(le - r0)) : le;
+    if (!r1) r1 = le;
+    if (memchr(r0, '*', (size_t)(r1 - r0))) return -1;
+    char num[10]; const size_t k = std::min<size_t>(9, (size_t)(r1 - r0)); memcpy(num, r0, k); num[k] = 0;
+    const int u = atoi(num);
+    return u >= 0 && u < units ? u : -1;
+}
+// r05: on all the CPUs the process may use — the mapped SAM cut into pieces at line starts, a first pass adds up every piece's bytes per unit, the units' files are made at their
+// final sizes and mapped, a second pass copies every line to its place (a 20 M-pair run distributes 11 GB).  Not for thousands of units (a mapping per unit): those take the form below.
+bool distribute_alignments_threaded(const char *base, size_t n_all, int units) {
+    const unsigned T = cli_threads();
+    const size_t least = getenv("AGX_CLI_FAST_MIN") ? (size_t)atoll(getenv("AGX_CLI_FAST_MIN")) : ((size_t)16 << 20);      // (tests: small files through this form)
+    if (T < 2 || getenv("AGX_CLI_SERIAL") || n_all < least || n_all < 64 * (size_t)T || units > 4096) return false;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now_s();
+    const size_t n = scan_end(base, n_all, T);
+    vector<size_t> cut(T + 1);
+    for (unsigned t = 0; t <= T; t++) cut[t] = t == T ? n : line_start_at(base, n, n / T * t);
+    vector<vector<size_t> > bytes(T, vector<size_t>((size_t)units, 0));
+    auto lines_of = [&](unsigned t, auto &&fn) {
+        for (size_t at = cut[t]; at < cut[t + 1];) {
+            const char *nl = (const char *)memchr(base + at, '\n', n - at);
+            const size_t len = nl ? (size_t)(nl - base) - at : n - at;
+            const int u = unit_of_line(base + at, len, units);
+            if (u >= 0) fn(u, base + at, len);
+            at += len + 1;
+        }
+    };
+    on_threads(T, [&](unsigned t) { vector<size_t> &b = bytes[t]; lines_of(t, [&](int u, const char *, size_t len) { b[(size_t)u] += len + 1; }); });
+    const double t1 = now_s();
+    // (written in place through shared mappings, like the read files: pwrite from gathered buffers — with or without the blocks allocated up front — was anything between twice as
+    // fast and five times slower on the CPU container, depending on how many dirty pages the aligner had left behind; the mappings took 7 s for 6.9 GB every time)
+    vector<std::unique_ptr<MappedOut> > out((size_t)units);
+    for (int u = 0; u < units; u++) {
+        size_t total = 0; for (unsigned t = 0; t < T; t++) { const size_t mine = bytes[t][(size_t)u]; bytes[t][(size_t)u] = total; total += mine; }      // bytes[t][u]: where piece t's lines of unit u begin
+        out[(size_t)u].reset(new MappedOut("tmp/_reads_genome." + itoa(u) + ".bowtie", total));
+        close(out[(size_t)u]->fd); out[(size_t)u]->fd = -1;                                                                                               // (the mapping stays; no descriptor per unit)
+    }
+    on_threads(T, [&](unsigned t) {
+        vector<size_t> &at = bytes[t];
+        lines_of(t, [&](int u, const char *line, size_t len) { char *w = out[(size_t)u]->p + at[(size_t)u]; memcpy(w, line, len); w[len] = '\n'; at[(size_t)u] += len + 1; });
+    });
+    for (auto &o : out) if (o->p && msync(o->p, o->n, MS_ASYNC) != 0) { cout << "CANNOT WRITE FILE! (" << o->name << ")" << endl; exit(-1); }
+    if (getenv("AGX_CLI_TIMING")) fprintf(stderr, "[agx cli]   %zu bytes of SAM to %d units on %u threads: sizing pass %.3f s, copying pass %.3f s\n", n, units, T, t1 - t0, now_s() - t1);
+    return true;
+}
 void distribute_alignments(int units) {
     // The whole SAM mapped and walked line by line with memchr, every unit's lines gathered in a buffer that goes out in 8 MB writes: the reference's
     // getline + operator<< loop (AG:3545-3579) moved ~0.2 GB/s, and a 20 M-pair run has 2.4 GB to distribute.  Same rules, same bytes.
@@ -439,6 +491,7 @@ void distribute_alignments(int units) {
     const char *base = n ? (const char *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
     if (n && base == (const char *)MAP_FAILED) { close(fd); die("CANNOT OPEN FILE!"); }
     if (n) madvise((void *)base, n, MADV_SEQUENTIAL);
+    if (n && distribute_alignments_threaded(base, n, units)) { munmap((void *)base, n); close(fd); return; }
     // Every unit's file is created and truncated up front (as the reference's ofstreams are), but only `open_max` descriptors are held at a time and the buffers
     // share one budget: a draft reference with thousands of scaffolds must neither run into the descriptor limit nor hold 8 MB per unit.  A file that cannot be
     // opened or written is fatal — silently dropped lines would make the unit run on truncated alignments and report success.
@@ -465,16 +518,9 @@ void distribute_alignments(int units) {
         const char *le = nl ? nl : e;
         const size_t len = (size_t)(le - c);
         const char *line = c; c = nl ? nl + 1 : e;
-        if (len && line[0] == '@') continue;
         if (len == 0 || line[0] == 0) break;
-        // parseBT: third tab-separated field; any '*' in it means unaligned; a missing field reads as "" -> unit 0 (atoi)
-        const char *t1 = (const char *)memchr(line, '\t', len), *t2 = t1 ? (const char *)memchr(t1 + 1, '\t', (size_t)(le - t1 - 1)) : nullptr;
-        const char *r0 = t2 ? t2 + 1 : le, *r1 = t2 ? (const char *)memchr(r0, '\t', (size_t)(le - r0)) : le;
-        if (!r1) r1 = le;
-        if (memchr(r0, '*', (size_t)(r1 - r0))) continue;
-        char num[10]; const size_t k = std::min<size_t>(9, (size_t)(r1 - r0)); memcpy(num, r0, k); num[k] = 0;
-        const int u = atoi(num);
-        if (u >= 0 && u < units) { buf[u].append(line, len); buf[u].push_back('\n'); if (buf[u].size() >= per_unit) flush(u); }
+        const int u = unit_of_line(line, len, units);
+        if (u >= 0) { buf[u].append(line, len); buf[u].push_back('\n'); if (buf[u].size() >= per_unit) flush(u); }
     }
     for (int u = 0; u < units; u++) { flush(u); if (out[u] >= 0) close(out[u]); }
     if (n) munmap((void *)base, n);

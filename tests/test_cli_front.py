@@ -111,3 +111,58 @@ def test_formalize_genome_parts(built, run_dir, tmp_path, part):
     for u, text in units.items():
         assert open(os.path.join(work, "tmp", "_genome.%d.fa" % u)).read() == text, u
     assert not os.path.exists(os.path.join(work, "tmp", "_genome.%d.fa" % len(units)))
+
+
+def _distribute_model(sam, units):
+    """distributeAlignments + parseBT, AG:3520-3579, line by line: '@' lines dropped, the scan ends at the first empty line, a '*' anywhere in RNAME = unplaced,
+    the unit = atoi of RNAME's first nine bytes"""
+    import re
+    out = {u: [] for u in range(units)}
+    for ln in sam.split(b"\n"):
+        if ln.startswith(b"@"):
+            continue
+        if not ln or ln[:1] == b"\0":
+            break
+        f = ln.split(b"\t")
+        rname = f[2] if len(f) > 2 else b""
+        if b"*" in rname:
+            continue
+        m = re.match(rb"\s*[+-]?\d+", rname[:9])
+        u = int(m.group(0)) if m else 0
+        if 0 <= u < units:
+            out[u].append(ln + b"\n")
+    return {u: b"".join(v) for u, v in out.items()}
+
+
+@pytest.mark.parametrize("shape", ["plain", "ragged", "empty_line", "no_final_newline"])
+def test_alignments_distributed_on_threads(built, run_dir, tmp_path, shape):
+    """r05: distributeAlignments (AG:3545-3579) on several threads (two passes over the mapped SAM, every unit's file written in place): the units' files against a line-by-line
+    model of the reference's rule and against the one-thread form."""
+    import shutil
+    work = str(tmp_path / "w")
+    shutil.copytree(run_dir, work)
+    path = os.path.join(work, "stub", "reads_genome.sam")
+    lines = open(path, "rb").read().split(b"\n")
+    assert lines[-1] == b""
+    lines = lines[:-1]
+    if shape == "ragged":                                  # comment lines in the body, unplaced lines, units that do not exist, a line without an RNAME column, a signed and a padded unit
+        lines[1000:1000] = [b"@CO\tin the middle", b"x\t4\t*\t0\t0\t*", b"y\t0\t7.1\t5\t42\t10M", b"z\t0", b"w\t0\t+1.9\t3\t42\t5M", b"v\t0\t 1.2\t3\t42\t5M", b"q\t0\t1*\t3\t42\t5M", b"p\t0\t-1.0\t1\t1\t1M"]
+    elif shape == "empty_line":
+        lines[40000:40000] = [b""]
+    data = b"\n".join(lines) + (b"" if shape == "no_final_newline" else b"\n")
+    open(path, "wb").write(data)
+    want = _distribute_model(data, 2)
+    assert all(len(v) > 1000 for v in want.values())
+
+    def units_files(**env):
+        shutil.rmtree(os.path.join(work, "tmp"), ignore_errors=True)
+        e = dict(os.environ, PATH=STUBS + os.pathsep + os.environ["PATH"], AGX_STUB_DIR=os.path.join(work, "stub"), AGX_CLI_TIMING="1", **env)
+        p = subprocess.run([CLI] + ARGS, cwd=work, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert b"(0) Alignment finished" in p.stdout
+        return p, {u: open(os.path.join(work, "tmp", "_reads_genome.%d.bowtie" % u), "rb").read() for u in range(2)}
+    ps, serial = units_files(AGX_CLI_SERIAL="1")
+    assert b"units on" not in ps.stderr and serial == want
+    for threads in ("2", "5", "16"):
+        pt, got = units_files(AGX_CLI_THREADS=threads, AGX_CLI_FAST_MIN="0")
+        assert b"to 2 units on %s threads" % threads.encode() in pt.stderr, pt.stderr[-300:]
+        assert got == want, "threads=%s" % threads
