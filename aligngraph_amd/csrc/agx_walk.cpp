@@ -995,7 +995,7 @@ void walk_join_scaffold(const UnitView &V, const GraphView &G, UnitOutput &out, 
     scaffold(V, G, recs, out.extended, &arena, assistant);
     double t3 = now();
     out.n_fetched = W.n_fetched;
-    if (timing) fprintf(stderr, "[agx walk] set-up %.1f ms, walk %.1f ms, join %.1f ms, scaffold %.1f ms, %zu records, %u special ids of %u, %llu records fetched\n", t0 - ts, t1 - t0, t2 - t1, t3 - t2, recs.size(), G.n_special, G.n_ids, W.n_fetched);
+    if (timing) fprintf(stderr, "[agx walk] set-up %.2f ms, walk %.2f ms, join %.2f ms, scaffold %.1f ms, %zu records, %u special ids of %u, %llu records fetched\n", t0 - ts, t1 - t0, t2 - t1, t3 - t2, recs.size(), G.n_special, G.n_ids, W.n_fetched);
 }
 
 }  // namespace agx
