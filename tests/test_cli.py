@@ -14,7 +14,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STUBS = os.path.join(ROOT, "tests", "e2e_stubs")
-CLI = os.path.join(ROOT, "aligngraph_amd", "AlignGraph_amd")
+CLI = os.environ.get("AGX_CLI_PATH", os.path.join(ROOT, "aligngraph_amd", "AlignGraph_amd"))      # (AGX_CLI_PATH: a sanitizer build of the same source)
 FINALS = ("e.fa", "r.fa", "in.fa", "ex.fa", "corrected_e.fa", "corrected_r.fa")   # corrected_*: --misassemblyRemoval (AG:4224)
 
 
