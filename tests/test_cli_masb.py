@@ -150,3 +150,48 @@ def test_read_coverage_on_threads_is_the_references(cli, tmp_path, comments):  #
         shutil.copytree(c.work, ref)
         theirs = _second_half(H.REF_O2, ref, stubs)
         assert theirs["corrected_e.fa"] == serial["corrected_e.fa"] and theirs["corrected_r.fa"] == serial["corrected_r.fa"]
+
+
+@pytest.mark.parametrize("fault", ["bad_cigar", "odd_lines"])
+def test_read_coverage_stops_where_the_reference_stops(cli, tmp_path, fault):  # noqa: F811
+    """A CIGAR character parseBOWTIE does not know ("unknown character: X", AG:263-267) and a pair without its second line ("BROKEN BOWTIE FILE!", AG:3961-3965) end the run —
+    with the message of the FIRST such line in file order, whatever thread met one first."""
+    c = Case("masb", tmp_path)
+    p = c.run(cli, c.args)
+    assert b"(0) Alignment finished" in p.stdout
+    for fn in os.listdir(os.path.join(c.exp, "tmp")):
+        if re.fullmatch(r"_(initial|pre_extended|extended)_contigs\.\d+\.fa", fn):
+            shutil.copy(os.path.join(c.exp, "tmp", fn), os.path.join(c.work, "tmp", fn))
+    with open(os.path.join(c.work, "tmp", "_checkpoint.txt"), "w") as f:
+        f.write("0\n%d\n" % c.units)
+    _second_half(cli, c.work, STUBS)
+    stubs = str(tmp_path / "stubs")
+    shutil.copytree(STUBS, stubs, ignore=shutil.ignore_patterns("fast"))
+    samdir = str(tmp_path / "sam")
+    os.makedirs(samdir)
+    for which in ("extended", "remaining"):
+        lines = open(os.path.join(c.work, "tmp", "_reads_%s_contigs.bowtie" % which), "rb").read().split(b"\n")[:-1]
+        placed = [i for i, ln in enumerate(lines) if not ln.startswith(b"@") and ln.split(b"\t")[2] != b"*"]
+        if fault == "bad_cigar":                           # two of them, far apart: the message names the first one's character
+            for at, ch in ((placed[len(placed) // 3], b"Q"), (placed[2 * len(placed) // 3], b"Z")):
+                f = lines[at].split(b"\t"); f[5] = b"50M1" + ch + b"49M"; lines[at] = b"\t".join(f)
+        else:
+            lines = lines[:-1]
+        open(os.path.join(samdir, "_%s_contigs.sam" % which), "wb").write(b"\n".join(lines) + b"\n")
+    with open(os.path.join(stubs, "bowtie2"), "w") as f:
+        f.write('#!/bin/sh\nx=""\nwhile [ $# -gt 0 ]; do case "$1" in -h) exit 0 ;; -x) x="$2"; shift ;; esac; shift; done\n'
+                'case "$x" in *_contigs) exec cat "%s/$(basename "$x").sam" ;; esac\nexec cat "$AGX_STUB_DIR/reads_genome.sam"\n' % samdir)
+    os.chmod(os.path.join(stubs, "bowtie2"), 0o755)
+
+    def ending(exe, work, **env):
+        e = dict(os.environ, PATH=stubs + os.pathsep + os.environ["PATH"], AGX_STUB_DIR=os.path.join(work, "stub"), **env)
+        p = subprocess.run([exe, "--resume"], cwd=work, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        return p.returncode, p.stdout.split(b"\n")[-2]
+    want = (255, b"unknown character: Q" if fault == "bad_cigar" else b"BROKEN BOWTIE FILE!")
+    assert ending(cli, c.work, AGX_CLI_SERIAL="1") == want
+    for threads in ("2", "7"):
+        assert ending(cli, c.work, AGX_CLI_THREADS=threads, AGX_CLI_FAST_MIN="0") == want, threads
+    if H.have_reference():
+        ref = c.work + ".ref"
+        shutil.copytree(c.work, ref)
+        assert ending(H.REF_O2, ref) == want
