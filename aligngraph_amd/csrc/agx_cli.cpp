@@ -1103,7 +1103,7 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
     // block of HBM sized from its staged counts) and admitted only while the blocks of the units in flight stay below 85 % of the device's memory
     // (a unit larger than that still runs, alone).  A build that has to grow a capacity takes more than its block: the 15 % are for that.
     auto file_bytes = [](const string &p) -> double { struct stat st; return stat(p.c_str(), &st) == 0 ? (double)st.st_size : 0.0; };
-    vector<double> budget(ndev, 0.0), used(ndev, 0.0);
+    vector<double> budget(ndev, 0.0), used(ndev, 0.0); vector<int> waiting(ndev, 0);      // waiting: units loaded and not yet admitted to the device
     for (int d = 0; d < ndev; d++) { uint64_t fr = 0, tot = 0; budget[d] = agx_device_memory(d, &fr, &tot) == AGX_OK ? 0.85 * (double)tot : 1e18; }
     std::mutex mem_mu; std::condition_variable mem_cv;
     // Longest unit first (its host walk then runs beside the uploads and kernels of the shorter ones); progress lines and
@@ -1141,15 +1141,16 @@ void run_units(const Options &o, int first, int units, std::ofstream &wcp) {
                 double est = 0; bool admitted = false;
                 if (rc == AGX_OK) rc = agx_unit_load_files_shared(un, "tmp", u, reads);
                 if (rc == AGX_OK) { uint64_t need = 0; rc = agx_unit_hbm_needed(un, &need); est = (double)need; }
-                if (rc == AGX_OK) { std::unique_lock<std::mutex> g(mem_mu); mem_cv.wait(g, [&] { return used[d] == 0.0 || used[d] + est <= budget[d]; }); used[d] += est; admitted = true; }
+                if (rc == AGX_OK) { std::unique_lock<std::mutex> g(mem_mu); waiting[d]++; mem_cv.wait(g, [&] { return used[d] == 0.0 || used[d] + est <= budget[d]; }); waiting[d]--; used[d] += est; admitted = true; }
                 if (rc == AGX_OK) rc = agx_unit_upload(un);
                 if (rc == AGX_OK) rc = agx_unit_build(un);
-                if (rc == AGX_OK) rc = agx_unit_download(un);
-                if (rc == AGX_OK) {      // r05: what the walk cannot ask the device for goes back now — the next unit is admitted while this one is walked on the host
+                bool wanted = false; if (rc == AGX_OK) { std::lock_guard<std::mutex> g(mem_mu); wanted = waiting[d] > 0; }
+                if (rc == AGX_OK && wanted) {      // r05: somebody waits for room on this device — the whole download first, then what the walk cannot ask the device for goes back: the next unit is admitted while this one is walked on the host
+                    rc = agx_unit_download(un);
                     uint64_t freed = 0;
-                    if (agx_unit_trim(un, &freed) == AGX_OK && freed) { { std::lock_guard<std::mutex> g(mem_mu); const double f = std::min(est, (double)freed); used[d] -= f; est -= f; } mem_cv.notify_all(); }
+                    if (rc == AGX_OK && agx_unit_trim(un, &freed) == AGX_OK && freed) { { std::lock_guard<std::mutex> g(mem_mu); const double f = std::min(est, (double)freed); used[d] -= f; est -= f; } mem_cv.notify_all(); }
                 }
-                if (rc == AGX_OK) rc = agx_unit_finish(un, &r);
+                if (rc == AGX_OK) rc = agx_unit_finish(un, &r);      // (r06: nothing downloaded yet — nobody waits for this unit's HBM — : the download is streamed and the walk begins on what has landed)
                 if (rc != AGX_OK && un && !err[0]) snprintf(err, sizeof err, "%s", agx_unit_error(un));
                 agx_unit_destroy(un);                                          // (its HBM goes back before the next unit is admitted)
                 if (admitted) { { std::lock_guard<std::mutex> g(mem_mu); used[d] -= est; if (used[d] < 1.0) used[d] = 0.0; } mem_cv.notify_all(); }

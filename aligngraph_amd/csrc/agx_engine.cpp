@@ -248,6 +248,11 @@ struct agx_unit {
     UnitOutput out; OutBuf out_initial; bool out_ready = false;      // output buffers of the next finish, reserved and touched by a helper thread while the unit is uploaded and built (prepare_outputs)
     UnitHelper helper;
     hsa_signal_t dl_signal{}; hsa_agent_t dl_agent{}; bool dl_sdma = false;      // downloads by the SDMA engines (HsaCopy)
+    // streamed download (begin_streamed_download): piece 0 = what the walk needs before it can plan (side positions, overflow edges), 1 .. n = position windows from the front,
+    // n + 1 = the bases; cut_main / cut_side: the ids in front of window w (entry n: all of them)
+    enum { DL_SIGNALS = AGX_DL_PIECES + 2 };
+    hsa_signal_t dl_piece[DL_SIGNALS] = {}; bool dl_piece_made = false, dl_streaming = false; agx_cut_args cuts{}; agx_u32 cut_main[AGX_DL_PIECES + 1] = {}, cut_side[AGX_DL_PIECES + 1] = {};
+    double dl_t0 = 0, dl_est_ms = 0; size_t dl_stream_bytes = 0; std::atomic<bool> dl_timed{false};
     DevArena arena;
     // staged inputs: what the device wants of T and P, in pinned memory (stage_inputs)
     PBuf<agx_whit> s_hits; PBuf<agx_wside> s_sides; PBuf<agx_wrun> s_runs; PBuf<agx_u8> s_codes; PBuf<unsigned long long> s_other; PBuf<agx_u32> s_jump; size_t n_other = 0, n_sides = 0, n_jump = 0;      // the read alignments in the wire formats of agx_core.h
@@ -299,6 +304,7 @@ struct agx_unit {
         ev.destroy();
         for (hipEvent_t e : {ev_front, ev_passA, ev_passJ, ev_up0, ev_uploaded, ev_dl, ev_built, ev_hits}) if (e) (void)hipEventDestroy(e);
         if (dl_signal.handle) (void)hsa_signal_destroy(dl_signal);
+        if (dl_piece_made) for (hsa_signal_t g : dl_piece) if (g.handle) (void)hsa_signal_destroy(g);
     }
 };
 
@@ -345,7 +351,23 @@ void join_dl_helper(agx_unit *u);
 void drop_outputs(agx_unit *u);     // before a unit's inputs change: the helper that prepares the output buffers reads them
 void start_helper(agx_unit *u);
 
+enum { W_CUT = 34 /* [2 * (AGX_DL_PIECES + 1)] the cuts of a streamed download: agx_cut_args */, W_TOTAL = W_CUT + 2 * (AGX_DL_PIECES + 1) };
 enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_LONGCOUNT = 6 /* hits that span more tiles than a list's window looks back over */, W_UNUSED7 = 7, W_MIDCOUNT = 8, W_JUMPCOUNT = 9, W_SPILL = 10, W_HUGECOUNT = 11, W_N = 12 };
+
+// Where a streamed download cuts a unit of n_pos positions (r06): windows of about 2 M positions, 2 to AGX_DL_PIECES of them, at multiples of 64 ids (a word of the special-id bitmap,
+// a tile of the side-id prefix).  None for units that one walker walks (nothing could begin earlier) or on request.  AGX_STREAM_PIECES=n forces n (tests: small units).
+agx_cut_args stream_cuts(agx_u32 n_pos) {
+    agx_cut_args C; memset(&C, 0, sizeof C);
+    const char *force = getenv("AGX_STREAM_PIECES");
+    if (getenv("AGX_NO_STREAM_DOWNLOAD") || n_pos < 4096) return C;
+    size_t m = force ? (size_t)atoi(force) : n_pos < AGX_TWO_WALKERS_MIN ? 0 : n_pos / 2000000u;
+    if (!force && m && m < 2) m = 2;
+    if (m > AGX_DL_PIECES) m = AGX_DL_PIECES;
+    if (m > n_pos / 1024u) m = n_pos / 1024u;
+    for (size_t w = 0; w < m; w++) C.word[w] = (agx_u32)(((unsigned long long)n_pos * w / m) >> 6);
+    C.word[m] = n_pos >> 6; C.n = (agx_u32)m;
+    return C;
+}
 
 void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     memset(&S, 0, sizeof S);
@@ -817,7 +839,7 @@ void do_upload(agx_unit *u) {
     u->d_dhit.alloc(a, nh + 1);
     u->d_perm.alloc(a, nh + 1); u->d_tfirst.alloc(a, (size_t)u->n_tiles + 2); u->d_ckey.alloc(a, nh + 1); u->d_long.alloc(a, AGX_LONG_MAX);
     u->d_tile_cnt.alloc(a, (size_t)u->n_tiles + 1); u->d_tile_off.alloc(a, (size_t)u->n_tiles + 2); u->d_cursor.alloc(a, (size_t)u->n_tiles + 1);
-    u->d_words.alloc(a, W_N + 6 + 16); u->h_words.alloc(W_N + 6 + 16);
+    u->d_words.alloc(a, W_TOTAL); u->h_words.alloc(W_TOTAL);
     u->d_chain_end.alloc(a, (size_t)u->n_chain_end + 1);
     u->d_node_start.alloc(a, n_pos); u->d_node_cnt.alloc(a, n_pos); u->d_pos_succ.alloc(a, n_pos); u->d_slow_list.alloc(a, n_pos + 64);
     u->d_side_pk.alloc(a, n_pos + 2); u->d_tile_side.alloc(a, (size_t)u->n_tiles + 2); u->d_tile_side_start.alloc(a, (size_t)u->n_tiles + 2);
@@ -948,7 +970,7 @@ void do_build(agx_unit *u) {
         {   // everything a build counts into or marks, zeroed by one kernel and one fill (every command on the stream costs a few microseconds)
             agx_zero_args Z; memset(&Z, 0, sizeof Z);
             auto seg = [&](int i, agx_u32 *ptr, size_t words) { Z.p[i] = ptr; Z.n[i] = (agx_u32)words; };
-            seg(0, u->d_words.p, W_N + 6 + 16); seg(1, u->d_tile_cnt.p, (size_t)u->n_tiles + 1); seg(2, u->d_cursor.p, (size_t)u->n_tiles + 1);
+            seg(0, u->d_words.p, W_TOTAL); seg(1, u->d_tile_cnt.p, (size_t)u->n_tiles + 1); seg(2, u->d_cursor.p, (size_t)u->n_tiles + 1);
             seg(3, u->d_pool_cnt.p, (size_t)u->n_regions * AGX_REGION_PAD); seg(4, u->d_tile_side.p + u->n_tiles, 1); seg(5, u->d_sp_cnt.p, (size_t)u->n_words + 1);
             seg(6, reinterpret_cast<agx_u32 *>(u->d_scan_desc.p), 6 * u->scan_desc_n); seg(7, reinterpret_cast<agx_u32 *>(u->d_sp_bits.p), 2 * ((size_t)u->n_words + 1));      // (the special-id kernels write and read the words of the live ids only)
             agx_launch_zero(&Z, st);
@@ -1043,8 +1065,9 @@ void do_build(agx_unit *u) {
         else agx_launch_exclusive_scan(u->d_tile_side.p, u->d_tile_side_start.p, u->n_tiles, u->d_scan_tmp.p, st);      // per tile: the sweep has scanned inside the tiles
         agx_launch_compact(&C, u->d_chain_end.p, u->n_chain_end, u->d_words.p + W_OVFCOUNT, u->ovf_cap, st);
         AGX_CHECKPOINT("compact");
+        u->cuts = stream_cuts(n_pos); u->cuts.cut_out = u->d_words.p + W_CUT;
         agx_launch_special(&C, u->n_words, u->d_sp_rank.p, u->d_scan_tmp.p, g_scan1 ? u->d_scan_desc.p + 2 * u->scan_desc_n : nullptr,
-                           u->d_words.p + W_N, u->d_tile_off.p + u->n_tiles, u->d_tile_side_start.p + u->n_tiles, u->d_pool_cnt.p, u->n_regions, u->d_words.p + W_POOL, st);
+                           u->d_words.p + W_N, u->d_tile_off.p + u->n_tiles, u->d_tile_side_start.p + u->n_tiles, u->d_pool_cnt.p, u->n_regions, u->d_words.p + W_POOL, u->cuts.n ? &u->cuts : nullptr, st);
         u->walk_args = C;
         AGX_CHECKPOINT("special");
         u->ev.mark(B_COMPACT, st);
@@ -1052,7 +1075,7 @@ void do_build(agx_unit *u) {
         u->stats.edge_sweep_launches++;
         if (u->ev.all) HIP_OK(hipEventRecord(u->ev.last, st));
         HIP_OK(hipEventRecord(turn.build_done[turn.n & 1], st));               // (a stream wait binds to the record that precedes it: the handle may be recorded again later)
-        {   void *dst = u->h_words.dev(); const void *src = u->d_words.p; const size_t bytes = (W_N + 6 + 16) * 4;      // the counters, by a kernel at the end of the chain (a copy
+        {   void *dst = u->h_words.dev(); const void *src = u->d_words.p; const size_t bytes = W_TOTAL * 4;      // the counters, by a kernel at the end of the chain (a copy
             agx_launch_copy_out(&dst, &src, &bytes, 1, st); }                                                              // command would queue behind the uploads on the copy engines)
         HIP_OK(hipEventRecord(u->ev_built, st));
         turn.n++; turn.prev_exclusive = u->ev.all;
@@ -1113,12 +1136,9 @@ void do_build(agx_unit *u) {
     if (u->up_timed) { float f = 0; if (hipEventElapsedTime(&f, u->ev_up0, u->ev_uploaded) == hipSuccess) u->stats.ms_upload_dev = f; else (void)hipGetLastError(); }
 }
 
-void do_download(agx_unit *u) {
-    if (!u->built) do_build(u);
-    HIP_OK(hipSetDevice(u->prm.device));             // the calling thread may never have touched this device
-    const double t0 = now_ms();
+// the pinned buffers a download lands in (a one-shot unit: cut from its dead staged inputs)
+void download_buffers(agx_unit *u) {
     const size_t n_pos = u->V.n_pos, ni = u->n_ids;
-    DeviceTurn &turn = turn_of(u->prm.device);
     const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
     join_dl_helper(u);
     if (u->prm.flags & AGX_FLAG_ONE_SHOT) {
@@ -1140,6 +1160,17 @@ void do_download(agx_unit *u) {
     u->h_a_str.alloc(ni + 1); u->h_a_meta.alloc(ni + 64); u->h_side_xpos.alloc(nside + 1);
     u->h_sp_bits.alloc(nw + 1); u->h_sp_rank.alloc(nw + 1); u->h_sp_node.alloc(ns + 1); u->h_sp_hop.alloc(ns + 2);
     u->h_a_ovf.alloc((size_t)u->n_ovf + 1);
+}
+
+void do_download(agx_unit *u) {
+    if (!u->built) do_build(u);
+    HIP_OK(hipSetDevice(u->prm.device));             // the calling thread may never have touched this device
+    const double t0 = now_ms();
+    const size_t n_pos = u->V.n_pos, ni = u->n_ids;
+    DeviceTurn &turn = turn_of(u->prm.device);
+    const size_t nw = ni / 64 + 1, ns = u->n_special, nside = ni - n_pos;
+    download_buffers(u);
+    u->dl_streaming = false;
     // the walk graph into the pinned buffers: plain copy commands on the device's download stream.  (r02 first used a kernel of its own for
     // this — copy commands seemed to queue behind other units' uploads; that was the hardware queue the streams shared.  Its stores to host
     // memory slowed whatever ran beside it, the next unit's binning most of all: the five builds of a cfg3 job ended at 45 ms with it, at
@@ -1177,6 +1208,80 @@ void do_download(agx_unit *u) {
     trace(u, u->dl_sdma ? "download (copy engines)" : "download (hipMemcpyAsync)", t0, n_pos);
 }
 
+// ---- streamed download (r06) ------------------------------------------------------------------------------------------------------------
+// A unit's chain used to be upload -> build -> download -> walk in series; the walk of a large unit is split between walkers that each look at a WINDOW of the walk graph
+// only (agx_walk.cpp: walk_split).  So the download goes out in position windows from the front — every window's meta bytes, bitmap words, ranks, records and hop entries of
+// its main ids and of its positions' side ids; the bases last: the walk only takes byte ranges of them — each with its own completion signal, and agx_unit_finish starts
+// the walk when the small head (side positions, overflow edges) is in.  A walker waits for its window (GraphView::wait_landed), the first walker — whose walks may lead anywhere
+// — for all of them, and the stretches are cut by when the windows land.  What it takes off a unit's chain: about half its download (chr1 of configs[4]: 29 ms of 149).
+// The cuts' ranks come with the build's counters (agx_cut_args).  Not for units that are trimmed after their download (agx_unit_download + agx_unit_trim: the caller wants the
+// HBM back before the walk) — agx_unit_finish streams when nothing has been downloaded yet.
+inline void wait_signal(hsa_signal_t g) { while (hsa_signal_wait_scacquire(g, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) { } }
+std::atomic<double> &download_rate() { static std::atomic<double> r{40e6}; return r; }      // bytes per millisecond the engines have delivered (40 GB/s until measured)
+void stream_wait_landed(void *ctx, agx_u32 main_hi, agx_u32 side_hi) {
+    agx_unit *u = (agx_unit *)ctx; const int n = (int)u->cuts.n; int need = 0;
+    while (need < n && (u->cut_main[need] < main_hi || u->cut_side[need] < side_hi)) need++;
+    for (int p = 1; p <= need; p++) wait_signal(u->dl_piece[p]);
+    if (need == n && !u->dl_timed.exchange(true)) {      // the last window is in: what the engines delivered per millisecond, for the next unit's estimate
+        const double ms = now_ms() - u->dl_t0; u->stats.ms_download = ms;
+        if (ms > 0.05 && u->dl_stream_bytes > (4u << 20)) download_rate().store(0.5 * download_rate().load() + 0.5 * std::min(std::max((double)u->dl_stream_bytes / ms, 2e6), 64e6));
+        trace(u, "download (streamed): last window", u->dl_t0, u->V.n_pos);
+    }
+}
+void stream_wait_str(void *ctx) { agx_unit *u = (agx_unit *)ctx; wait_signal(u->dl_piece[u->cuts.n + 1]); }
+void stream_wait_all(agx_unit *u) { if (!u->dl_streaming) return; for (agx_u32 p = 0; p <= u->cuts.n + 1; p++) wait_signal(u->dl_piece[p]); u->dl_streaming = false; }
+
+// false: this unit's download is not streamed (no cuts, no copy engines, counters that do not add up): the caller downloads the usual way
+bool begin_streamed_download(agx_unit *u) {
+    if (!u->built) do_build(u);
+    const agx_u32 M = u->cuts.n;
+    if (!M || !u->dl_sdma || getenv("AGX_NO_STREAM_DOWNLOAD")) return false;
+    HIP_OK(hipSetDevice(u->prm.device));
+    const double t0 = now_ms();
+    const size_t n_pos = u->V.n_pos, ni = u->n_ids, ns = u->n_special, nside = ni - n_pos;
+    const agx_u32 *rank = u->h_words.p + W_CUT, *side = rank + (AGX_DL_PIECES + 1);
+    // the cuts must be what the tables say: ranks and side counts ascending, every side id special, the last cut the whole table
+    if (rank[0] != 0 || side[0] != 0 || side[M] != nside || (size_t)rank[M] + nside != ns) return false;
+    for (agx_u32 w = 0; w < M; w++) if (rank[w] > rank[w + 1] || side[w] > side[w + 1]) return false;
+    if (!u->dl_piece_made) { for (hsa_signal_t &g : u->dl_piece) if (hsa_signal_create(0, 0, nullptr, &g) != HSA_STATUS_SUCCESS) { u->dl_sdma = false; return false; } u->dl_piece_made = true; }
+    download_buffers(u);
+    memset(u->h_a_meta.p + ni, 0, 64);
+    for (agx_u32 w = 0; w <= M; w++) { u->cut_main[w] = w == M ? (agx_u32)n_pos : u->cuts.word[w] * 64u; u->cut_side[w] = (agx_u32)n_pos + side[w]; }
+    struct Copy { void *dst; const void *src; size_t bytes; int piece; };
+    std::vector<Copy> copies; copies.reserve(12 * (size_t)M + 4);
+    auto add = [&](int piece, void *h, const void *d, size_t b) { if (b) copies.push_back(Copy{h, d, b, piece}); };
+    add(0, u->h_side_xpos.p, u->d_side_xpos.p, nside * 4); add(0, u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf));
+    size_t main_bytes = 0;
+    auto ids = [&](int piece, size_t lo, size_t hi, size_t r_lo, size_t r_hi) {      // everything about walk ids [lo, hi), whose records are [r_lo, r_hi) of the sparse table
+        if (lo >= hi) return;
+        add(piece, u->h_a_meta.p + lo, u->d_a_meta.p + lo, hi - lo);
+        const size_t w_lo = lo >> 6, w_hi = ((hi - 1) >> 6) + 1;
+        add(piece, u->h_sp_bits.p + w_lo, u->d_sp_bits.p + w_lo, (w_hi - w_lo) * 8); add(piece, u->h_sp_rank.p + w_lo, u->d_sp_rank.p + w_lo, (w_hi - w_lo) * 4);
+        add(piece, u->h_sp_node.p + r_lo, u->d_sp_node.p + r_lo, (r_hi - r_lo) * sizeof(agx_walknode)); add(piece, u->h_sp_hop.p + r_lo, u->d_sp_hop.p + r_lo, (r_hi - r_lo) * sizeof(agx_hop));
+        main_bytes += (hi - lo) + (w_hi - w_lo) * 12 + (r_hi - r_lo) * (sizeof(agx_walknode) + sizeof(agx_hop));
+    };
+    for (agx_u32 w = 0; w < M; w++) {
+        ids(1 + (int)w, u->cut_main[w], u->cut_main[w + 1], rank[w], rank[w + 1]);
+        ids(1 + (int)w, u->cut_side[w], u->cut_side[w + 1], (size_t)rank[M] + side[w], (size_t)rank[M] + side[w + 1]);
+    }
+    add((int)M + 1, u->h_a_str.p, u->d_a_str.p, ni);
+    int count[agx_unit::DL_SIGNALS] = {};
+    for (const Copy &c : copies) count[c.piece]++;
+    for (agx_u32 p = 0; p <= M + 1; p++) hsa_signal_store_relaxed(u->dl_piece[p], count[p]);
+    u->dl_streaming = true; u->dl_timed.store(false); u->dl_t0 = now_ms(); u->dl_stream_bytes = main_bytes; u->dl_est_ms = (double)main_bytes / download_rate().load();
+    size_t queued = 0;
+    for (; queued < copies.size(); queued++) { const Copy &c = copies[queued]; if (hsa_amd_memory_async_copy(c.dst, hsa_copy().cpu, c.src, u->dl_agent, c.bytes, 0, nullptr, u->dl_piece[c.piece]) != HSA_STATUS_SUCCESS) break; }
+    if (queued < copies.size()) {      // the engines refused: what was queued still counts down; then the usual way (through HIP from now on)
+        for (size_t i = queued; i < copies.size(); i++) hsa_signal_subtract_relaxed(u->dl_piece[copies[i].piece], 1);
+        stream_wait_all(u); u->dl_sdma = false; return false;
+    }
+    wait_signal(u->dl_piece[0]);
+    u->stats.n_walk_ids = ni; u->stats.n_special = ns;
+    u->stats.download_bytes = 2 * ni + (ni / 64 + 1) * 12 + nside * 4 + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + (size_t)u->n_ovf * sizeof(agx_edge_ovf);
+    trace(u, "download (streamed): queued, head in", t0, n_pos);
+    return true;
+}
+
 // After the download: everything on the device that the walk cannot ask for (all but the arrays agx_walk_record reads, which lie at the front of the unit's block: alloc_pool)
 // goes back to the device's memory region.  The unit is no longer built: another build uploads it again.  Returns the bytes given back (0: the block is not the region's — a
 // unit below the region's threshold on a device without one —, or a capacity grew during the build and the arrays are no longer at the front).
@@ -1202,6 +1307,7 @@ void do_release(agx_unit *u) {
     if (u->pending_walk) { u->pending_walk = false; g_walks_pending.fetch_sub(1); }
     struct Tr { agx_unit *u; double t; ~Tr() { trace(u, "release", t, u->V.n_pos); } } tr{u, tr0};
     join_dl_helper(u);                                 // (it fills the download buffers released below)
+    stream_wait_all(u);
     if (u->uploaded) { (void)hipSetDevice(u->prm.device); (void)hipEventSynchronize(u->ev_uploaded); (void)hipEventSynchronize(u->ev_built); (void)hipEventSynchronize(u->ev_dl); }      // (its commands are done before its memory goes)
     for (auto *b : {&u->d_cm_start, &u->d_tile_cnt, &u->d_tile_off, &u->d_cursor, &u->d_unsorted, &u->d_tile_recs, &u->d_scan_tmp, &u->d_words, &u->d_pool_cnt, &u->d_region_off, &u->d_node_start,
                     &u->d_slow_list, &u->d_perm, &u->d_tfirst, &u->d_ckey, &u->d_long, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
@@ -1479,7 +1585,10 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
     if (!u || !r) return AGX_E_ARG;
     memset(r, 0, sizeof *r);
     return guarded(u, [&] {
-        if (!u->downloaded) do_download(u);
+        // nothing downloaded yet: the download is streamed where it can be, and the walk begins on what has landed (begin_streamed_download)
+        const bool streamed = !u->downloaded && begin_streamed_download(u);
+        if (!u->downloaded && !streamed) do_download(u);
+        struct Landed { agx_unit *u; ~Landed() { stream_wait_all(u); } } landed{u};      // (also if the walk throws: the copies write into buffers that are released afterwards)
         const double t0 = now_ms();
         join_helper(u);
         prepare_outputs(u);               // (a unit whose helper could not make them, or that is finished a second time)
@@ -1508,7 +1617,9 @@ int agx_unit_finish(agx_unit *u, agx_result *r) {
             }
             void wait(int who) override { if (who == 0) u->helper.wait(UnitHelper::WALK); else walker_pool().wait(pool[who - 1]); }
         } second(u, walkers_now(u->V.n_pos) - 2);      // one thread per further walker: the unit's helper + pool threads
-        walk_join_scaffold(u->V, view_of(u), u->out, u->helper.started ? &second : nullptr);
+        GraphView G = view_of(u);
+        if (streamed) { G.wait_landed = stream_wait_landed; G.wait_str = stream_wait_str; G.land_ctx = u; G.land_ms = std::max(0.01, u->dl_est_ms - (now_ms() - u->dl_t0)); }
+        walk_join_scaffold(u->V, G, u->out, u->helper.started ? &second : nullptr);
         u->stats.ms_walk = now_ms() - t0; u->stats.n_fetched = u->out.n_fetched;
         trace(u, "walk", t0, u->V.n_pos);
         r->initial_len = u->out_initial.n; r->initial_contigs = u->out_initial.release();

@@ -96,6 +96,12 @@ struct GraphView {
     void (*fetch)(void *ctx, agx_u32 first, agx_u32 stride, agx_u32 rows, agx_u32 width, agx_walknode *out) = nullptr; void *fetch_ctx = nullptr;
     const agx_edge_ovf *ovf = nullptr; size_t n_ovf = 0;     // walk ids; NONE/NONE entries and duplicates are ignored
     const agx_u32 *row_slot = nullptr;                      // k-mer string references name rows of the staged read bases: row -> read slot (null: they name read slots)
+    // Streamed download (r06; agx_engine.cpp: begin_streamed_download): meta, sp_bits, sp_rank, sp_node and sp_hop fill in behind the walk's back, a position window at a
+    // time from the front — main ids [0, x) together with the side ids of the positions below x —, str last; side_xpos and ovf are in place from the start.
+    // wait_landed returns when everything about main ids [0, main_hi) and side ids [n_pos, side_hi) is in place; wait_str when str is.  The walk never looks at a byte it has
+    // not waited for: the further walkers of walk_split wait for their windows and are confined to them (as they always were), the first walker — the only one whose walks may lead
+    // anywhere — waits for everything and gets the shortest stretch in exchange (land_ms: what is left of the download when the walk begins, for that balance).
+    void (*wait_landed)(void *ctx, agx_u32 main_hi, agx_u32 side_hi) = nullptr; void (*wait_str)(void *ctx) = nullptr; void *land_ctx = nullptr; double land_ms = 0;
 };
 
 // Megabyte-sized buffers that are written once, front to back (outputs, the walk's visited bytes): ask for transparent huge pages where

@@ -83,8 +83,14 @@ void agx_launch_fetch_records(const agx_compact_args *, agx_u32 first, agx_u32 s
 void agx_launch_compact(const agx_compact_args *, const agx_u32 *chain_end, agx_u32 n_chain_end, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t);
 // special ids: bitmap, rank scan (desc: the one-launch scan; null: the three-launch one with scan_tmp), records; block 0 of the last kernel also leaves the
 // totals the host reads: out[0..2] = *a, *b, sp_rank[n_words]; *sum = nodes handed out = the sum of the region counters
+// r06: where a streamed download cuts the walk graph (agx_engine.cpp: begin_streamed_download): piece w holds main ids [64 * word[w], 64 * word[w + 1]) (the last one: up to n_pos)
+// and the side ids of those positions.  The host needs, before it can queue the copies, the special ids in front of every cut (sparse-table ranks: sp_rank at the cut's word)
+// and the side ids in front of it (tile_side_start at the cut's tile): block 0 of the build's last kernel leaves them next to the counters, cut_out[0 .. n] = ranks (entry n: all
+// main ids), cut_out[AGX_DL_PIECES + 1 ..] = side ids.
+#define AGX_DL_PIECES 16u
+struct agx_cut_args { agx_u32 n; agx_u32 word[AGX_DL_PIECES + 1]; agx_u32 *cut_out; };
 void agx_launch_special(const agx_compact_args *, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, unsigned long long *desc,
-                        agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, hipStream_t);
+                        agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, const agx_cut_args *cuts, hipStream_t);
 #define AGX_MID_WAVES 3072u     // wavefronts of pass 1 (3 per SIMD fit its LDS buckets); they stride over the list of tiles pass 0 gave up on
 #define AGX_BIG_WAVES 256u      // resident wavefronts of the global-scratch fallback pass
 #define AGX_HUGE_WAVES 32u      // wavefronts of pass 3 (0.85 MB of scratch each)

@@ -49,9 +49,18 @@ __global__ void __launch_bounds__(256) agx_k_zero(agx_zero_args Z) {
 }
 // The totals the host reads next to the counter words — out[0..2] = *a, *b, *c, *sum = nodes handed out (the sum of the region counters; a
 // unit has fewer than 2^32 nodes: the slices' layout is refused otherwise).  Done by block 0 of the build's last kernel.
-struct agx_collect_args { agx_u32 *out; const agx_u32 *a, *b, *c, *pool_cnt; agx_u32 regions; agx_u32 *sum; };
+struct agx_collect_args { agx_u32 *out; const agx_u32 *a, *b, *c, *pool_cnt; agx_u32 regions; agx_u32 *sum;
+                          agx_cut_args cuts; const agx_u32 *sp_rank, *tile_side_start; const unsigned long long *sp_bits; agx_u32 n_pos; };      // (the cuts of a streamed download: agx_kargs.h)
 __device__ __forceinline__ void agx_collect_block(const agx_collect_args &G) {
     __shared__ agx_u32 part[256];
+    if (G.cuts.n && threadIdx.x <= G.cuts.n) {
+        const agx_u32 t = threadIdx.x; const bool last = t == G.cuts.n;
+        const agx_u32 w = last ? G.n_pos >> 6 : G.cuts.word[t];
+        agx_u32 r = G.sp_rank[w];
+        if (last && (G.n_pos & 63u)) r += (agx_u32)__popcll(G.sp_bits[w] & ((1ull << (G.n_pos & 63u)) - 1ull));
+        G.cuts.cut_out[t] = r;
+        G.cuts.cut_out[AGX_DL_PIECES + 1u + t] = G.tile_side_start[last ? (G.n_pos + AGX_TILE - 1u) / AGX_TILE : w];
+    }
     agx_u32 t = 0;
     for (agx_u32 r = threadIdx.x; r < G.regions; r += 256u) t += G.pool_cnt[(size_t)r * AGX_REGION_PAD];
     part[threadIdx.x] = t; __syncthreads();
@@ -958,8 +967,9 @@ void agx_launch_compact(const agx_compact_args *A, const agx_u32 *chain_end, agx
 }
 // sparse record table over n_words 64-id words (the id capacity; the live id count is read on the device); scan_tmp as for the scans
 void agx_launch_special(const agx_compact_args *A, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, unsigned long long *desc,
-                        agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, hipStream_t st) {
-    const agx_collect_args G{out, a, b, sp_rank + n_words, pool_cnt, regions, sum};
+                        agx_u32 *out, const agx_u32 *a, const agx_u32 *b, const agx_u32 *pool_cnt, agx_u32 regions, agx_u32 *sum, const agx_cut_args *cuts, hipStream_t st) {
+    agx_collect_args G{out, a, b, sp_rank + n_words, pool_cnt, regions, sum, agx_cut_args{}, sp_rank, A->tile_side_start, A->sp_bits, A->n_pos};
+    if (cuts) G.cuts = *cuts; else G.cuts.n = 0;
     const agx_u32 blocks = (n_words + 4u * AGX_SE_WORDS - 1u) / (4u * AGX_SE_WORDS);
     hipLaunchKernelGGL(agx_k_special_bits, dim3((n_words + 4u * AGX_SB_WORDS - 1u) / (4u * AGX_SB_WORDS)), dim3(256), 0, st, *A, n_words);
     if (desc) agx_launch_exclusive_scan1(A->sp_cnt, sp_rank, n_words, desc, st); else agx_launch_exclusive_scan(A->sp_cnt, sp_rank, n_words, scan_tmp, st);

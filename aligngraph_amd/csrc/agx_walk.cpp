@@ -263,6 +263,19 @@ struct Walker {
     }
 #endif
     agx_u32 scan_hi = 0xFFFFFFFFu;               // (a walker behind a window: its visited bytes are only real below this position — a scan for the next unvisited node that ends at or behind it has told nothing)
+    // The first walker of walk_split marks in the array the other walkers copy their windows from.  It used to wait until every window was taken (1.3-1.5 ms in front of every
+    // large unit's walk, r05); now it walks at once and only a mark that reaches the first byte any window holds (guard_main / guard_side: the lowest window's start) waits for
+    // the copies — by then they are long done.
+    const std::atomic<int> *copies = nullptr; int copies_want = 0; agx_u32 guard_main = 0xFFFFFFFFu, guard_side = 0xFFFFFFFFu;
+    void before_mark(agx_u32 last) {             // `last`: the highest id about to be marked (a run lies in the main block or in the side block)
+        if (last < G.n_pos ? last < guard_main : last < guard_side) return;
+        while (copies->load(std::memory_order_acquire) < copies_want) {
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+        }
+        copies = nullptr;
+    }
     bool may_look(agx_u32 v) const { if (!spec) return true; const agx_u32 x = pos_of(v); if (x >= look_lo && x < look_hi) return true; invalid = true; gave_up_at = x; return false; }
     std::vector<agx_edge_ovf> ovf;                  // sorted, unique
     Walker(const UnitView &v, const GraphView &g) : V(v), G(g) {
@@ -480,6 +493,7 @@ struct WalkRun {
                         AGX_WCHK(W, j, "run end"); if (j + 1 < G.n_ids && (j + 1 < G.n_pos) == (j < G.n_pos)) AGX_WCHK(W, j + 1, "behind the run");
                         segs.push_back(Seg{G.str + cur, (size_t)j - cur + 1}); n_runs++; run_nodes += j - cur + 1; if (!(m[j] & AGX_WM_CONT)) n_general++;
                         if (seen & AGX_WM_CONTIG) C.extended = 1;
+                        if (W.copies) W.before_mark(j);
                         mark(m, cur, j);
                         if (log && j >= log_main) note_marks(cur, j);
                         if (j > cur) pos_bak = xj;
@@ -565,6 +579,8 @@ inline void walk_report(const WalkRun &r) {
 
 // The whole scan by one walker (the written records are formatted by the assistant while it goes on, if there is one).
 void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena, Assistant *assistant) {
+    if (W.G.wait_landed) W.G.wait_landed(W.G.land_ctx, W.G.n_pos, W.G.n_ids);      // (a streamed download: one walker looks everywhere, and its records are formatted as they come)
+    if (W.G.wait_str) W.G.wait_str(W.G.land_ctx);
     pre_out.reserve((size_t)W.G.n_ids + W.G.n_ids / 32 + 4096);
     PreFormat pre(pre_out, assistant, (size_t)W.G.n_pos / 256 + 65536);
     WalkRun run(W, arena, written, &pre);
@@ -582,6 +598,8 @@ void walk(Walker &W, OutBuf &pre_out, std::vector<Rec> &written, Arena *arena, A
 // in front of c or in the appended positions behind the reference (which A may have visited and B not) — B checks that as it goes and
 // gives up if an edge or a conti-mer chain leads there.  If anything differs A simply walks on through B's half: the
 // result is the sequential walk's either way, only the time differs.  The appended positions are walked last, by A, on the merged marks.
+// positions a walker's stretch covers per millisecond (measured by every split walk; the first guess is a 2 GHz server core's)
+inline std::atomic<double> &walker_speed() { static std::atomic<double> v{700000.0}; return v; }
 inline void clip_marks(const MarkLog &log, agx_u32 main_lo, agx_u32 main_hi, agx_u32 n_pos, agx_u32 side_lo, agx_u32 side_hi, MarkLog &out) {
     out.clear();
     for (const auto &r : log) {
@@ -641,7 +659,29 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     // the first walker has no window to copy and no warm-up to walk (which goes at half the speed of a stretch: cold memory, every mark logged): its stretch is
     // longer by two warm-ups, so that all arrive at about the same time
     const agx_u32 lead = n_ref / (unsigned)K > 4 * warm ? 2 * warm : 0;
-    auto cut_at = [&](int i) { return i >= K ? n_ref : i <= 0 ? 0 : lead + (agx_u32)((unsigned long long)(n_ref - lead) * (unsigned)i / (unsigned)K); };
+    std::vector<agx_u32> cuts((size_t)K + 1, n_ref); cuts[0] = 0;
+    for (int i = 1; i < K; i++) cuts[(size_t)i] = lead + (agx_u32)((unsigned long long)(n_ref - lead) * (unsigned)i / (unsigned)K);
+    // A streamed download (GraphView::wait_landed): the table arrives from the front while the walk goes on.  Walker i begins when its window is in place — the part of the
+    // download in front of the window's end, then its copy and its warm-up —, the first walker, whose walks may lead anywhere, when everything is.  The stretches are cut so that
+    // all of them END together: len_i = speed * (T - ready_i) with T from sum(len) = n_ref; the window's end depends on the cuts, so a few rounds from the even cuts.  Any cuts
+    // give the sequential walk's result (that is what the meeting points check): the model only decides who waits for whom.
+    const bool streamed = G.wait_landed != nullptr && G.land_ms > 0 && !getenv("AGX_WALK_EVEN_CUTS");
+    if (streamed) {
+        const double v = walker_speed().load(), D = G.land_ms, copy_ms = 0.6, warm_ms = 2.0 * (double)warm / v, floor_len = std::max(1024.0, (double)n_ref / (16.0 * K));
+        std::vector<double> len((size_t)K, (double)n_ref / K), ready((size_t)K, 0.0), at((size_t)K + 1, 0.0);
+        for (int round = 0; round < 6; round++) {
+            for (int i = 0; i < K; i++) at[(size_t)i + 1] = at[(size_t)i] + len[(size_t)i];
+            double sum = ready[0] = D;
+            for (int i = 1; i < K; i++) { const double hi = i + 2 >= K ? (double)G.n_pos : std::max(at[(size_t)i + 2], at[(size_t)i + 1] + (double)warm); sum += ready[(size_t)i] = D * std::min(1.0, hi / (double)G.n_pos) + copy_ms + warm_ms; }
+            const double T = ((double)n_ref / v + sum) / K;
+            double total = 0;
+            for (int i = 0; i < K; i++) total += len[(size_t)i] = std::max(v * (T - ready[(size_t)i]), floor_len);
+            for (int i = 0; i < K; i++) len[(size_t)i] *= (double)n_ref / total;
+        }
+        double acc = 0;
+        for (int i = 1; i < K; i++) { acc += len[(size_t)i - 1]; const agx_u32 lo = cuts[(size_t)i - 1] + 8 * slack, hi = n_ref - (agx_u32)(K - i) * 8 * slack; const agx_u32 c = (agx_u32)acc; cuts[(size_t)i] = c < lo ? lo : c > hi ? hi : c; }
+    }
+    auto cut_at = [&](int i) { return i >= K ? n_ref : i <= 0 ? 0u : cuts[(size_t)i]; };
     const agx_u32 n_side = G.n_ids - G.n_pos;
     auto side_of = [&](agx_u32 x) { return G.n_pos + (agx_u32)(std::lower_bound(G.side_xpos, G.side_xpos + n_side, x) - G.side_xpos); };
     const agx_u32 side_ref = side_of(n_ref);
@@ -660,10 +700,12 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
         b.side_c = side_of(b.c); b.side_next = side_of(b.c_next);
         // its window: main ids [win_lo, win_hi), or to the end of the table (the last two walkers: the appended positions behind the reference too); what it may
         // look at while it warms up / on its stretch lies `slack` inside
-        const bool open_end = i + 2 >= K;
+        // (uneven cuts: a short stretch's neighbour is short too — the window then reaches a warm-up's length, three times the longest chain's reach, beyond the stretch at least)
+        int ahead = i + 2; if (streamed) while (ahead < K && cut_at(ahead) < b.c_next + warm) ahead++;
+        const bool open_end = ahead >= K;
         // (behind it: the warm-up and as much again, one stretch at most)
         const agx_u32 back = 2 * warm + slack < b.c - cut_at(i - 1) ? 2 * warm + slack : b.c - cut_at(i - 1);
-        b.win_lo = b.c - back; b.win_hi = open_end ? n_ref : cut_at(i + 2); b.side_win_hi = open_end ? side_ref : side_of(b.win_hi);
+        b.win_lo = b.c - back; b.win_hi = open_end ? n_ref : cut_at(ahead); b.side_win_hi = open_end ? side_ref : side_of(b.win_hi);
         b.copy_hi = open_end ? G.n_pos : b.win_hi; b.side_copy_lo = side_of(b.win_lo); b.side_copy_hi = open_end ? G.n_ids : b.side_win_hi;
         b.warm_lo = b.win_lo ? b.win_lo + slack : 0; b.warm_hi = open_end ? 0xFFFFFFFFu : b.win_hi - slack; b.look_hi = open_end ? n_ref : b.win_hi - slack;
         b.w0 = b.c > warm ? b.c - warm : 0; if (b.w0 < b.warm_lo) b.w0 = b.warm_lo;
@@ -684,6 +726,7 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
             struct Copied { std::atomic<int> &n; bool done = false; void now() { if (!done) { done = true; n.fetch_add(1, std::memory_order_release); } } ~Copied() { now(); } } copied_mark{copied};      // (the first walker waits for this count whatever happens here)
             try {
                 if (const char *pz = getenv("AGX_WALK_POISON")) { const long v = strtol(pz, nullptr, 0); memset(W.m, v > 1 ? (int)(v & 0xFF) : 0xA5, (size_t)G.n_ids + 64); }      // test hook (1 or a byte value): whatever the last unit left outside the window must not matter
+                if (G.wait_landed) G.wait_landed(G.land_ctx, b.copy_hi, b.side_copy_hi);      // (a streamed download: the window — all this walker will ever look at — is in place)
                 memcpy(W.m + b.win_lo, pristine + b.win_lo, (size_t)b.copy_hi - b.win_lo);
                 memcpy(W.m + b.side_copy_lo, pristine + b.side_copy_lo, (size_t)b.side_copy_hi - b.side_copy_lo + (b.side_copy_hi == G.n_ids ? 64 : 0));      // (+ the padding behind the table)
                 // what lies behind the window is whatever the last unit left there: a forced run that reaches the window's end must stop AT it (a visited byte without a
@@ -711,12 +754,11 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
             } catch (const Error &e) { b.error = e.msg; } catch (const std::exception &e) { b.error = e.what(); }
         }, i - 1);
     }
-    // (the first walker's bytes are the source of the windows: it walks when they are all taken)
-    while (copied.load(std::memory_order_acquire) < K - 1) {
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
-    }
+    // (the first walker's bytes are the source of the windows: what it marks at or behind the lowest window's start waits until they are all taken — Walker::before_mark;
+    // r05 waited here, 1.3-1.5 ms in front of every large unit's walk)
+    WA.copies = &copied; WA.copies_want = K - 1; WA.guard_main = B[0].win_lo; WA.guard_side = B[0].side_copy_lo;
+    struct Unguard { Walker &w; ~Unguard() { w.copies = nullptr; } } unguard{WA};      // (`copied` lives in this frame)
+    if (G.wait_landed) G.wait_landed(G.land_ctx, G.n_pos, G.n_ids);      // a streamed download: the first walker may look anywhere
 
     const double tw0 = clock();
     // A: the sequential walk up to the first meeting point, its marks at and behind it logged
@@ -754,6 +796,12 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     }
     cancel.store(true);                                 // (walkers behind one that does not stand walk for nothing)
     for (int i = stood; i < K - 1; i++) join.now(i);
+    WA.copies = nullptr;                                // (every walker's thread is done: every window was taken)
+    {   // what a stretch costs, for the next streamed walk's cuts: positions per millisecond of the stretches that stood
+        double pos = 0, ms = 0;
+        for (int i = 1; i <= stood; i++) { const SpecWalker &b = B[(size_t)i - 1]; if (b.t_done > b.t_warm) { pos += (double)(b.c_next - b.c); ms += b.t_done - b.t_warm; } }
+        if (ms > 0.05 && pos > 1e5) { const double seen = pos / ms, old = walker_speed().load(); walker_speed().store(0.7 * old + 0.3 * std::min(std::max(seen, 1e5), 5e6)); }
+    }
     const double tw2 = clock();
     // what stands: the records behind A's, numbered on; the marks into A's bytes (the appended positions — and whatever did not stand — are walked on those).
     // The walkers' threads are idle now: each merges its own walker's marks (disjoint ranges of A's bytes), this thread the last one's.  (Nothing is
@@ -795,6 +843,7 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     auto header_len = [](const PreJob &j) { size_t n = 1 + 9 * 2 + 2; for (int i = 0; i < 10; i++) { agx_u32 v = j.f[i]; do { n++; v /= 10u; } while (v); } return n; };
     for (size_t i = 0; i < all.size(); i++) place[i + 1] = place[i] + header_len(all[i]) + all[i].total + (all[i].total + 59) / 60;
     const size_t total = place[all.size()];
+    if (G.wait_str) G.wait_str(G.land_ctx);             // (a streamed download: the bases come last — nothing has read them so far, the records hold byte ranges)
     pre_out.n = 0; char *base = pre_out.grow(total);
     auto format = [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; i++) {
@@ -813,7 +862,8 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
         for (int t = 0; t + 1 < shares; t++) { const size_t lo = cut[(size_t)t], hi = cut[(size_t)t + 1]; assistant->run([&format, lo, hi] { format(lo, hi); }, t); }
         format(cut[(size_t)shares - 1], all.size());
     }
-    if (timing) fprintf(stderr, "[agx walk] first walker began at %.2f ms; %u appended positions behind the reference\n", tw0 - t_enter, G.n_pos - n_ref);
+    if (timing) fprintf(stderr, "[agx walk] first walker began at %.2f ms; %u appended positions behind the reference%s\n", tw0 - t_enter, G.n_pos - n_ref, streamed ? " (streamed download: stretches cut by when their windows land)" : "");
+    if (timing && streamed) { fprintf(stderr, "[agx walk] cuts (%.1f ms of download left at the start, %.0f positions per ms):", G.land_ms, walker_speed().load()); for (int i = 1; i < K; i++) fprintf(stderr, " %u", cuts[(size_t)i]); fprintf(stderr, "\n"); }
     if (timing) fprintf(stderr, "[agx walk] %d walkers, %d stretches stood: first stretch %.1f ms, waited %.1f ms for the others, merge %.1f ms, rest %.1f ms, formatting %.1f ms\n", K, stood, tw1 - tw0, tw2 - tw1, tw3 - tw2, tw4 - tw3, clock() - tw4);
     walk_report(A);
     return true;

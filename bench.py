@@ -173,6 +173,7 @@ def main():
                          "kept (a fresh hipMalloc costs 0.2-0.7 ms per unit, profiles/r02_membench.txt — but HBM that was just given back to the "
                          "driver can stall the next hipMalloc for seconds, profiles/r02_recycle.txt: an artefact of the loop, not of the application).  "
                          "cold: both caches emptied.  warm: both keep what earlier steps left (units 6, 7, .. of a long run)")
+    ap.add_argument("--no-stream", action="store_true", help="A/B: every unit's download completes before its walk begins (r05), also where nobody waits for its HBM")
     ap.add_argument("--reupload", action="store_true",
                     help="time the SAME unit objects in every step (their staged inputs are uploaded again and again, the downloads land in freshly pinned "
                          "buffers).  Default: every step gets its own set of units, loaded from the unit caches before the clock starts and used once "
@@ -371,6 +372,7 @@ def main():
     inflight = args.inflight or min(8, max(1, len(mine)))
     hbm_budget = int(0.85 * min(A.device_memory(local_rank)))      # (free, total) before this process holds any of it: blocks recycled between units may be a sixteenth larger than the unit asked for, a build that has to grow a capacity takes more
     unit_stats, held, t_start = {}, {}, {}
+    job = {"hbm_pressure": sum(hbm_need[uu] for uu in mine) > hbm_budget}      # the units of this rank do not fit its device side by side: each gives HBM back after its download (agx_unit_trim) instead of streaming it into its walk
 
     def run_unit(uu, release=None):
         """One unit from its staged packed arrays to its output bytes: (upload: start_unit) -> first build -> download -> walk -> release.  Runs on one of
@@ -380,10 +382,13 @@ def main():
         t_a = t_start[uu]
         un.build()                         # hit prep, binning, node sweep (+ edges), edge passes, walk preparation: the unit's first build
         t_b = time.perf_counter()
-        un.download()                      # walk graph -> pinned host memory
-        if release is not None and not reupload:
-            release(un.trim())             # three quarters of the unit's HBM back to the device now: the next unit is admitted while this one is walked (one-shot units only: a trimmed unit is uploaded again before another build)
-        res = un.finish_views()            # host walk/join/scaffold; the outputs stay in C memory until they are packed for the gather
+        if job["hbm_pressure"] or args.no_stream:
+            un.download()                  # walk graph -> pinned host memory, all of it before the walk ...
+            if release is not None and not reupload:
+                release(un.trim())         # ... because three quarters of the unit's HBM go back to the device now: the next unit is admitted while this one is walked (one-shot units only: a trimmed unit is uploaded again before another build)
+        # else (r06): the rank's units all fit its device at once, nobody waits for this one's HBM: agx_unit_finish STREAMS the download — position windows from the front — and the
+        # walk begins on what has landed
+        res = un.finish_views()            # (download,) host walk/join/scaffold; the outputs stay in C memory until they are packed for the gather
         st = un.stats()
         st["s_upload_build"], st["s_total"] = t_b - t_a, time.perf_counter() - t_a
         un.release()                       # HBM and download buffers back to the library
@@ -476,6 +481,7 @@ def main():
                     one = dict(zip(everything, ex.map(load_unit, everything)))
                 units.clear(); units.update(one)
                 hbm_all = {uu: un.hbm_needed() for uu, un in one.items()}
+                job["hbm_pressure"] = sum(hbm_all.values()) > hbm_budget
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 shard.run_job(unit_len, 0, 1, run_unit, None, gdev, inflight=min(8, len(everything)), start_unit=start_unit, hbm_need=hbm_all, hbm_budget=hbm_budget)

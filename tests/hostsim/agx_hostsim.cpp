@@ -6,6 +6,7 @@
 // (merged arrivals, in-order tile sweeps, edges resolved against final buckets) against the oracle in a
 // container without a GPU.  It is never linked into libagx.so and the product API cannot reach it.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -270,6 +271,59 @@ int agx_hostsim_run_unit(const char *tmp_dir, int unit, int k, int iv, int cover
             double best = 1e30;
             for (int i = 0; i < atoi(rep); i++) { UnitOutput Q; const auto t0 = std::chrono::steady_clock::now(); walk_join_scaffold(view_of(T, P), G, Q); const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); if (ms < best) best = ms; }
             fprintf(stderr, "[hostsim] walk+join+scaffold best of %s: %.2f ms\n", rep, best);
+        }
+        // AGX_SIM_STREAM=<pieces>[,<microseconds per piece>]: the walk graph arrives the way the engine's streamed download delivers it (GraphView::wait_landed) — the arrays the walk
+        // is given are full of junk and a thread copies the real ones in, a position window at a time from the front (main ids and the side ids of their positions; the bases last).
+        // A walker that looks at anything it has not waited for reads junk, and the outputs differ from the oracle's.
+        struct Landing {
+            const SimGraph &S; agx_u32 n_pos, n_ids; int pieces; long us;
+            std::vector<agx_u8> meta; std::vector<char> str; std::vector<unsigned long long> bits; std::vector<agx_u32> rank; std::vector<agx_walknode> node; std::vector<agx_hop> hop;
+            std::vector<agx_u32> cut_main, cut_side;      // frontier after piece w: main ids below cut_main[w + 1], side ids below cut_side[w + 1]
+            std::atomic<int> landed{0}; std::atomic<bool> str_in{false}; std::thread th;
+            Landing(const SimGraph &g, agx_u32 np, int n, long u) : S(g), n_pos(np), n_ids(g.n_ids), pieces(n), us(u) {
+                meta.assign(S.a_meta.size(), 0x5A); str.assign(S.a_str.size(), '?'); bits.assign(S.sp_bits.size(), 0xDEADBEEFDEADBEEFull); rank.assign(S.sp_rank.size(), 0x7FFFFFF0u);
+                agx_walknode junk; memset(&junk, 0xEE, sizeof junk); node.assign(S.sp_node.size(), junk); agx_hop hj; memset(&hj, 0xEE, sizeof hj); hop.assign(S.sp_hop.size(), hj);
+                const agx_u32 n_side = n_ids - n_pos;
+                for (int w = 0; w <= pieces; w++) {
+                    const agx_u32 x = w == pieces ? n_pos : (agx_u32)((unsigned long long)n_pos * (unsigned)w / (unsigned)pieces) & ~63u;
+                    cut_main.push_back(x); cut_side.push_back(w == pieces ? n_ids : n_pos + (agx_u32)(std::lower_bound(S.side_xpos.begin(), S.side_xpos.begin() + n_side, x) - S.side_xpos.begin()));
+                }
+            }
+            agx_u32 rank_of(agx_u32 a) const { return a >= n_ids ? S.n_special : S.sp_rank[a >> 6] + (agx_u32)__builtin_popcountll(S.sp_bits[a >> 6] & ((1ull << (a & 63u)) - 1ull)); }
+            void ids(agx_u32 lo, agx_u32 hi) {          // everything about walk ids [lo, hi)
+                if (lo >= hi) return;
+                memcpy(meta.data() + lo, S.a_meta.data() + lo, hi - lo);
+                for (agx_u32 w = lo >> 6; w <= (hi - 1) >> 6; w++) { bits[w] = S.sp_bits[w]; rank[w] = S.sp_rank[w]; }
+                for (agx_u32 r = rank_of(lo), re = rank_of(hi); r < re; r++) { node[r] = S.sp_node[r]; hop[r] = S.sp_hop[r]; }
+            }
+            void start() {
+                th = std::thread([this] {
+                    for (int w = 0; w < pieces; w++) {
+                        if (us) std::this_thread::sleep_for(std::chrono::microseconds(us));
+                        ids(cut_main[(size_t)w], cut_main[(size_t)w + 1]); ids(cut_side[(size_t)w], cut_side[(size_t)w + 1]);
+                        if (w + 1 == pieces) memcpy(meta.data() + n_ids, S.a_meta.data() + n_ids, meta.size() - n_ids);      // (the padding behind the table)
+                        landed.store(w + 1, std::memory_order_release);
+                    }
+                    if (us) std::this_thread::sleep_for(std::chrono::microseconds(us));
+                    memcpy(str.data(), S.a_str.data(), str.size()); str_in.store(true, std::memory_order_release);
+                });
+            }
+            static void wait_landed(void *ctx, agx_u32 main_hi, agx_u32 side_hi) {
+                Landing *L = (Landing *)ctx; int need = 0;
+                while (need < L->pieces && (L->cut_main[(size_t)need] < main_hi || L->cut_side[(size_t)need] < side_hi)) need++;
+                while (L->landed.load(std::memory_order_acquire) < need) std::this_thread::yield();
+            }
+            static void wait_str(void *ctx) { Landing *L = (Landing *)ctx; while (!L->str_in.load(std::memory_order_acquire)) std::this_thread::yield(); }
+            ~Landing() { if (th.joinable()) th.join(); }
+        };
+        std::unique_ptr<Landing> landing;
+        if (const char *e = getenv("AGX_SIM_STREAM")) {
+            const int n = std::max(1, atoi(e)); const char *c = strchr(e, ',');
+            landing.reset(new Landing(S, G.n_pos, n, c ? atol(c + 1) : 0));
+            G.meta = landing->meta.data(); G.str = landing->str.data(); G.sp_bits = landing->bits.data(); G.sp_rank = landing->rank.data(); G.sp_node = landing->node.data(); G.sp_hop = landing->hop.data();
+            G.meta_rw = landing->meta.data();            // (the engine's download buffer is the first walker's own array)
+            G.wait_landed = Landing::wait_landed; G.wait_str = Landing::wait_str; G.land_ctx = landing.get(); G.land_ms = std::max(0.001, 1e-3 * (double)landing->us * n);
+            landing->start();
         }
         // AGX_SIM_ASSISTANT=1: with a second thread for the outputs, as the engine runs it (the written records are formatted while the walk goes on)
         struct ThreadAssistant : Assistant {

@@ -301,6 +301,46 @@ def test_walk_by_several_walkers_gives_the_same_bytes(agx, built, tmp_path, monk
                 assert got[key] == want[key], (walkers, warm, flags, key)
 
 
+def test_walk_begins_while_the_download_is_still_arriving(agx, built, tmp_path, monkeypatch):
+    """r06, the streamed download (agx_engine.cpp: begin_streamed_download): agx_unit_finish on a unit that has not been downloaded sends the walk graph down in position windows
+    from the front (forced here on a small unit: AGX_STREAM_PIECES), the walkers wait for their windows, the first one for all of them, the bases come last.  The walkers' own bytes
+    are poisoned, the landing buffers of a one-shot unit are its dead staged inputs (junk until the copies arrive): a byte looked at before it landed shows in the outputs.
+    agx_unit_download + agx_unit_finish (the whole download first: what a caller does who trims the unit's HBM in between) must give the same bytes, and so must a unit
+    streamed twice."""
+    run = H.synth(str(tmp_path / "run"), seed=79, chroms="500000", pairs=100000, coverage=4, read_indel=0.2, multi=0.2, contig_overlap=0.3, sam_seq=0)
+    tmp = os.path.join(run, "tmp")
+    want = H.run_oracle(tmp, 0, 5, 50, 4)
+    monkeypatch.setenv("AGX_WALK_SPLIT_MIN", "0")
+    monkeypatch.setenv("AGX_WALK_POISON", "1")
+    monkeypatch.setenv("AGX_WALK_SPLIT_WARMUP", "30000")
+    for pieces, walkers in (("1", "2"), ("2", "4"), ("5", "3"), ("5", "8"), ("16", "8"), ("16", "16"), ("7", "1")):
+        monkeypatch.setenv("AGX_STREAM_PIECES", pieces)
+        if walkers == "1":
+            monkeypatch.setenv("AGX_WALK_NO_SPLIT", "1")      # one walker on a streamed download: it waits for everything
+        else:
+            monkeypatch.setenv("AGX_WALK_SPLIT_WALKERS", walkers)
+        for flags in (0, agx.AGX_FLAG_ONE_SHOT):
+            got = run_engine(agx, tmp, 0, 5, 50, 4, flags=flags)
+            for key in ("initial", "pre", "extended"):
+                assert got[key] == want[key], (pieces, walkers, flags, key)
+            assert got["stats"]["ms_download"] > 0
+    monkeypatch.delenv("AGX_WALK_NO_SPLIT")
+    monkeypatch.setenv("AGX_STREAM_PIECES", "6")
+    monkeypatch.setenv("AGX_WALK_SPLIT_WALKERS", "6")
+    with agx.Unit(k=5, insert_variation=50, coverage=4) as u:
+        u.load_files(tmp, 0)
+        u.upload(); u.build()
+        a = u.finish()                    # streamed
+        b = u.finish()                    # the walk consumed the first download: streamed again
+        u.download()
+        c = u.finish()                    # the whole download, then the walk
+        u.download(); u.trim()            # (nothing to give back on a device without a region for a unit this small: the call must still leave the unit walkable)
+        d = u.finish()
+    for got in (a, b, c, d):
+        for key in ("initial", "pre", "extended"):
+            assert got[key] == want[key], key
+
+
 def test_unit_cache_file_replaces_the_text(agx, built, tmp_path, monkeypatch):
     """tmp/_agx_unit.<u>.bin holds a unit's staged arrays; load_files takes it instead of the five text files as long as it
     is current, and falls back to the text when a source file changed, when the batch size differs or when the file is damaged."""
