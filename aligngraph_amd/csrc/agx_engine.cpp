@@ -354,13 +354,13 @@ void start_helper(agx_unit *u);
 enum { W_CUT = 34 /* [2 * (AGX_DL_PIECES + 1)] the cuts of a streamed download: agx_cut_args */, W_TOTAL = W_CUT + 2 * (AGX_DL_PIECES + 1) };
 enum { W_ERR = 0, W_POOL = 1, W_BIGCOUNT = 2, W_STATUS = 3, W_OVFCOUNT = 4, W_SLOWCOUNT = 5, W_LONGCOUNT = 6 /* hits that span more tiles than a list's window looks back over */, W_UNUSED7 = 7, W_MIDCOUNT = 8, W_JUMPCOUNT = 9, W_SPILL = 10, W_HUGECOUNT = 11, W_N = 12 };
 
-// Where a streamed download cuts a unit of n_pos positions (r06): windows of about 2 M positions, 2 to AGX_DL_PIECES of them, at multiples of 64 ids (a word of the special-id bitmap,
+// Where a streamed download cuts a unit of n_pos positions (r06): windows of about 4 M positions, 2 to AGX_DL_PIECES of them, at multiples of 64 ids (a word of the special-id bitmap,
 // a tile of the side-id prefix).  None for units that one walker walks (nothing could begin earlier) or on request.  AGX_STREAM_PIECES=n forces n (tests: small units).
 agx_cut_args stream_cuts(agx_u32 n_pos) {
     agx_cut_args C; memset(&C, 0, sizeof C);
     const char *force = getenv("AGX_STREAM_PIECES");
     if (getenv("AGX_NO_STREAM_DOWNLOAD") || n_pos < 4096) return C;
-    size_t m = force ? (size_t)atoi(force) : n_pos < AGX_TWO_WALKERS_MIN ? 0 : n_pos / 2000000u;
+    size_t m = force ? (size_t)atoi(force) : n_pos < AGX_TWO_WALKERS_MIN ? 0 : n_pos / 4000000u;
     if (!force && m && m < 2) m = 2;
     if (m > AGX_DL_PIECES) m = AGX_DL_PIECES;
     if (m > n_pos / 1024u) m = n_pos / 1024u;
@@ -1216,7 +1216,12 @@ void do_download(agx_unit *u) {
 // — for all of them, and the stretches are cut by when the windows land.  What it takes off a unit's chain: about half its download (chr1 of configs[4]: 29 ms of 149).
 // The cuts' ranks come with the build's counters (agx_cut_args).  Not for units that are trimmed after their download (agx_unit_download + agx_unit_trim: the caller wants the
 // HBM back before the walk) — agx_unit_finish streams when nothing has been downloaded yet.
-inline void wait_signal(hsa_signal_t g) { while (hsa_signal_wait_scacquire(g, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) { } }
+// (asleep: hsa_signal_wait spins whatever wait state it is asked for — sixteen walkers waiting for their windows burned 150 CPU-ms per cfg3 job — so: a short spin for what is about
+// to land, then looks between short sleeps, like wait_event)
+inline void wait_signal(hsa_signal_t g) {
+    for (int i = 0; i < 64; i++) if (hsa_signal_load_scacquire(g) < 1) return;
+    for (;;) { const timespec ts{0, 20000}; nanosleep(&ts, nullptr); if (hsa_signal_load_scacquire(g) < 1) return; }
+}
 std::atomic<double> &download_rate() { static std::atomic<double> r{40e6}; return r; }      // bytes per millisecond the engines have delivered (40 GB/s until measured)
 void stream_wait_landed(void *ctx, agx_u32 main_hi, agx_u32 side_hi) {
     agx_unit *u = (agx_unit *)ctx; const int n = (int)u->cuts.n; int need = 0;
@@ -1224,7 +1229,7 @@ void stream_wait_landed(void *ctx, agx_u32 main_hi, agx_u32 side_hi) {
     for (int p = 1; p <= need; p++) wait_signal(u->dl_piece[p]);
     if (need == n && !u->dl_timed.exchange(true)) {      // the last window is in: what the engines delivered per millisecond, for the next unit's estimate
         const double ms = now_ms() - u->dl_t0; u->stats.ms_download = ms;
-        if (ms > 0.05 && u->dl_stream_bytes > (4u << 20)) download_rate().store(0.5 * download_rate().load() + 0.5 * std::min(std::max((double)u->dl_stream_bytes / ms, 2e6), 64e6));
+        if (ms > 0.05 && u->dl_stream_bytes > (4u << 20)) download_rate().store(0.5 * download_rate().load() + 0.5 * std::min(std::max((double)u->dl_stream_bytes / ms, 15e6), 60e6));      // (a download that queued behind another unit's says little about the link)
         trace(u, "download (streamed): last window", u->dl_t0, u->V.n_pos);
     }
 }
@@ -1251,14 +1256,13 @@ bool begin_streamed_download(agx_unit *u) {
     std::vector<Copy> copies; copies.reserve(12 * (size_t)M + 4);
     auto add = [&](int piece, void *h, const void *d, size_t b) { if (b) copies.push_back(Copy{h, d, b, piece}); };
     add(0, u->h_side_xpos.p, u->d_side_xpos.p, nside * 4); add(0, u->h_a_ovf.p, u->d_a_ovf.p, (size_t)u->n_ovf * sizeof(agx_edge_ovf));
+    add(0, u->h_sp_bits.p, u->d_sp_bits.p, (ni / 64 + 1) * 8); add(0, u->h_sp_rank.p, u->d_sp_rank.p, (ni / 64 + 1) * 4);      // (the bitmap and its ranks whole: 0.2 bytes per id, and two copies instead of four per window — a copy command costs the engines ~10 us)
     size_t main_bytes = 0;
     auto ids = [&](int piece, size_t lo, size_t hi, size_t r_lo, size_t r_hi) {      // everything about walk ids [lo, hi), whose records are [r_lo, r_hi) of the sparse table
         if (lo >= hi) return;
         add(piece, u->h_a_meta.p + lo, u->d_a_meta.p + lo, hi - lo);
-        const size_t w_lo = lo >> 6, w_hi = ((hi - 1) >> 6) + 1;
-        add(piece, u->h_sp_bits.p + w_lo, u->d_sp_bits.p + w_lo, (w_hi - w_lo) * 8); add(piece, u->h_sp_rank.p + w_lo, u->d_sp_rank.p + w_lo, (w_hi - w_lo) * 4);
         add(piece, u->h_sp_node.p + r_lo, u->d_sp_node.p + r_lo, (r_hi - r_lo) * sizeof(agx_walknode)); add(piece, u->h_sp_hop.p + r_lo, u->d_sp_hop.p + r_lo, (r_hi - r_lo) * sizeof(agx_hop));
-        main_bytes += (hi - lo) + (w_hi - w_lo) * 12 + (r_hi - r_lo) * (sizeof(agx_walknode) + sizeof(agx_hop));
+        main_bytes += (hi - lo) + (r_hi - r_lo) * (sizeof(agx_walknode) + sizeof(agx_hop));
     };
     for (agx_u32 w = 0; w < M; w++) {
         ids(1 + (int)w, u->cut_main[w], u->cut_main[w + 1], rank[w], rank[w + 1]);

@@ -665,9 +665,11 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
     // download in front of the window's end, then its copy and its warm-up —, the first walker, whose walks may lead anywhere, when everything is.  The stretches are cut so that
     // all of them END together: len_i = speed * (T - ready_i) with T from sum(len) = n_ref; the window's end depends on the cuts, so a few rounds from the even cuts.  Any cuts
     // give the sequential walk's result (that is what the meeting points check): the model only decides who waits for whom.
-    const bool streamed = G.wait_landed != nullptr && G.land_ms > 0 && !getenv("AGX_WALK_EVEN_CUTS");
-    if (streamed) {
-        const double v = walker_speed().load(), D = G.land_ms, copy_ms = 0.6, warm_ms = 2.0 * (double)warm / v, floor_len = std::max(1024.0, (double)n_ref / (16.0 * K));
+    // The same model cuts the stretches of a download that is complete (D = 0; r05: even cuts with the first walker's stretch two warm-ups longer): the first walker has no window to
+    // copy and no warm-up to walk — the others finished 0.5-0.8 ms behind it once it no longer waited for their copies.
+    const bool streamed = G.wait_landed != nullptr && G.land_ms > 0;
+    if (!getenv("AGX_WALK_EVEN_CUTS")) {
+        const double v = walker_speed().load(), D = streamed ? G.land_ms : 0.0, copy_ms = 0.15 + 3.2 * ((double)n_ref / K) / 12e6, warm_ms = 2.0 * (double)warm / v, floor_len = std::max(1024.0, (double)n_ref / (16.0 * K));
         std::vector<double> len((size_t)K, (double)n_ref / K), ready((size_t)K, 0.0), at((size_t)K + 1, 0.0);
         for (int round = 0; round < 6; round++) {
             for (int i = 0; i < K; i++) at[(size_t)i + 1] = at[(size_t)i] + len[(size_t)i];
@@ -701,7 +703,7 @@ bool walk_split(Walker &WA, const UnitView &V, const GraphView &G, OutBuf &pre_o
         // its window: main ids [win_lo, win_hi), or to the end of the table (the last two walkers: the appended positions behind the reference too); what it may
         // look at while it warms up / on its stretch lies `slack` inside
         // (uneven cuts: a short stretch's neighbour is short too — the window then reaches a warm-up's length, three times the longest chain's reach, beyond the stretch at least)
-        int ahead = i + 2; if (streamed) while (ahead < K && cut_at(ahead) < b.c_next + warm) ahead++;
+        int ahead = i + 2; while (ahead < K && cut_at(ahead) < b.c_next + warm) ahead++;
         const bool open_end = ahead >= K;
         // (behind it: the warm-up and as much again, one stretch at most)
         const agx_u32 back = 2 * warm + slack < b.c - cut_at(i - 1) ? 2 * warm + slack : b.c - cut_at(i - 1);

@@ -237,8 +237,15 @@ def test_walkers_behind_windows_of_the_visited_bytes(built, tmp_path, monkeypatc
     for key, val in (("AGX_SIM_ASSISTANT", "1"), ("AGX_WALK_SPLIT_MIN", "0"), ("AGX_WALK_TIMING", "1"), ("AGX_WALK_POISON", "1")):
         monkeypatch.setenv(key, val)
     stood = {}
+    # (even cuts: whether a stretch stands behind a warm-up this short depends on where it begins; r06 cuts the stretches by when the walkers can begin — the first one's is
+    # longer — which is tried at the end for the bytes alone)
+    monkeypatch.setenv("AGX_WALK_EVEN_CUTS", "1")
     for walkers, warm, look in (("5", "40000", None), ("6", "40000", None), ("7", "40000", None), ("8", "40000", None), ("8", "5000", None), ("8", "40000", "60000"),
-                                ("12", "20000", None), ("16", "20000", None)):
+                                ("12", "20000", None), ("16", "20000", None), ("8", "40000", "model"), ("16", "20000", "model")):
+        model = look == "model"
+        if model:
+            monkeypatch.delenv("AGX_WALK_EVEN_CUTS", raising=False)
+            look = None
         monkeypatch.setenv("AGX_WALK_SPLIT_WALKERS", walkers)
         monkeypatch.setenv("AGX_WALK_SPLIT_WARMUP", warm)
         if look:
@@ -252,11 +259,11 @@ def test_walkers_behind_windows_of_the_visited_bytes(built, tmp_path, monkeypatc
             assert o[key] == s[key], (walkers, warm, look, key)
         line = [ln for ln in err.splitlines() if "stretches stood" in ln]
         assert line and ("%s walkers" % walkers) in line[0], err[-2000:]
-        stood[(walkers, warm, look)] = int(line[0].split(" walkers, ")[1].split()[0])
+        stood[(walkers, warm, look, model)] = int(line[0].split(" walkers, ")[1].split()[0])
     assert max(stood.values()) >= 7, stood                      # most stretches of many walkers stood somewhere
 
 
-@pytest.mark.parametrize("stream", ["1", "4,300", "8,200", "16,50", "16,0"])
+@pytest.mark.parametrize("stream", ["1", "4,300", "16,50"])
 def test_walk_on_a_graph_that_is_still_arriving(built, tmp_path, monkeypatch, capfd, stream):
     # r06, the streamed download (agx_engine.cpp: begin_streamed_download; GraphView::wait_landed): the walk begins while the walk graph is still coming in, a position window at
     # a time from the front, the bases last.  The serial executor delivers it the same way — the arrays the walk is given are full of junk and a thread copies the real ones in
