@@ -173,6 +173,11 @@ def main():
                          "kept (a fresh hipMalloc costs 0.2-0.7 ms per unit, profiles/r02_membench.txt — but HBM that was just given back to the "
                          "driver can stall the next hipMalloc for seconds, profiles/r02_recycle.txt: an artefact of the loop, not of the application).  "
                          "cold: both caches emptied.  warm: both keep what earlier steps left (units 6, 7, .. of a long run)")
+    ap.add_argument("--emulate-rank", default=None, metavar="R/N",
+                    help="one GPU, one process: run only the units rank R of an N-rank job would get (shard.plan: longest-first onto the least loaded rank) on this process's "
+                         "share of the host's CPUs (usable_cpus / N, by affinity; --emulate-cpus overrides) — the makespan of that rank of the N-GPU job without an N-GPU node.  "
+                         "The line's value counts that rank's reads only; `emulated_rank` says what was run.  cfg5: only that rank's units are generated")
+    ap.add_argument("--emulate-cpus", type=int, default=0, help="--emulate-rank: CPUs the emulated rank may use (default: usable_cpus // N, at least 1)")
     ap.add_argument("--no-stream", action="store_true", help="A/B: every unit's download completes before its walk begins (r05), also where nobody waits for its HBM")
     ap.add_argument("--reupload", action="store_true",
                     help="time the SAME unit objects in every step (their staged inputs are uploaded again and again, the downloads land in freshly pinned "
@@ -192,6 +197,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    emu = None
+    if args.emulate_rank:
+        assert world == 1 and args.gpus == 1, "--emulate-rank runs one process on one GPU"
+        er, _, en = args.emulate_rank.partition("/")
+        emu = (int(er), int(en))
+        assert 0 <= emu[0] < emu[1], "--emulate-rank R/N with 0 <= R < N"
+        if args.config is None:
+            args.config = "cfg5"                # the configuration the 8-GPU target is quoted on
     dist = None
     # AGX_BENCH_SHARE_GPU=1 is a plumbing test for boxes with fewer GPUs than ranks: ranks share devices and the gather runs over
     # gloo with CPU tensors (RCCL refuses two ranks on one device).  Never set by the driver; numbers from it are not bench results.
@@ -262,8 +275,13 @@ def main():
         extra[key] = val
     staged = args.config in STAGED or os.environ.get("AGX_BENCH_STAGED") == "1"      # (the variable: any configuration through the staged hand-over — plumbing tests)
     # (the staged files depend on k — which mate is the left one — and on BATCH: both are part of a staged directory's name)
+    only = {}
     if args.config in STAGED:
         run_name = "cfg5_full" if k == 5 else "cfg5_full_k%d" % k
+        if emu and part == 1 and not os.path.exists(os.path.join(args.workdir, run_name, "synth_meta.txt")):
+            # the emulated rank's units alone (tools/agx_synth --only-units: each exactly as long as in the whole job, with its share of the whole job's pairs and their numbering)
+            only = {"only_units": ",".join(str(uu) for uu in sorted(shard.plan(chroms, emu[0], emu[1])))}
+            run_name += "_r%dof%d" % emu
     elif staged:
         run_name = "staged_%s_p%d_k%d" % ("_".join(str(c) for c in chroms), pairs, k) + ("_x" if extra else "")
     else:
@@ -289,7 +307,7 @@ def main():
                                  (args.workdir, shutil.disk_usage(args.workdir).free / 1e9, args.config, 1.05 * wanted / 1e9))
         if staged:
             D.synth(run, seed=1000, chroms=",".join(str(c) for c in chroms), part=part, pairs=pairs, L=L, k=k, coverage=args.coverage, sam_seq=0,
-                    threads=min(32, max(4, A.usable_cpus())), pairs_bin=1, lean=1, **extra)
+                    threads=min(32, max(4, A.usable_cpus())), pairs_bin=1, lean=1, **only, **extra)
         else:
             D.synth(run, seed=1000, chroms=",".join(str(c) for c in chroms), part=part, pairs=pairs, L=L, k=k, coverage=args.coverage, sam_seq=sam_seq,
                     threads=min(32, os.cpu_count() or 1), **extra)
@@ -303,6 +321,14 @@ def main():
     unit_len = D.read_meta(run)["unit_len"]
     n_units = len(unit_len)
     mine = shard.plan(unit_len, rank, world)                               # longest-first onto the least loaded rank, longest first within the rank
+    emu_note = None
+    if emu:
+        mine = shard.plan(unit_len, emu[0], emu[1])
+        have = sorted(os.sched_getaffinity(0))
+        n_cpu = args.emulate_cpus or max(1, A.usable_cpus() // emu[1])
+        os.sched_setaffinity(0, set(have[:max(1, min(n_cpu, len(have)))]))
+        emu_note = {"rank": emu[0], "of": emu[1], "units": mine, "unit_positions": [unit_len[uu] for uu in mine], "cpus": len(os.sched_getaffinity(0)),
+                    "note": "this rank's share of the N-rank job (shard.plan) alone on one GPU, on usable_cpus // N CPUs by affinity: ms_per_step is its makespan without the gather; value counts its reads only"}
     t1 = time.perf_counter()
     reads = A.Reads(os.path.join(tmp, "_reads.fa")) if mine and not staged else None      # tmp/_reads.fa mapped and indexed once for all units (agx_reads)
     t_index = time.perf_counter() - t1
@@ -561,9 +587,9 @@ def main():
 
     if rank == 0:
         outs = {uu: bytes(v) for uu, v in gathered.items()}
-        assert sorted(outs) == list(range(n_units)), "the gather did not deliver every unit"
-        all_ext = b"".join(outs[uu] for uu in range(n_units))
-        reads_per_step = 2.0 * pairs
+        assert sorted(outs) == (sorted(mine) if emu else list(range(n_units))), "the gather did not deliver every unit"
+        all_ext = b"".join(outs[uu] for uu in sorted(outs))
+        reads_per_step = 2.0 * (sam_pairs_total if emu else pairs)
         sec_per_step = elapsed / args.steps
         value = reads_per_step / sec_per_step
         # roofline of the dominant kernel (agx_k_node_sweep<0>) over rank 0's units in the last timed step: SURVEY §8d's algorithmic bytes of
@@ -634,6 +660,7 @@ def main():
                                   "upload_GBs_largest_unit": round(big_stats["upload_bytes"] / kern["ms_upload_dev"] / 1e6, 1) if (big_stats and kern.get("ms_upload_dev")) else None,
                                   "note": "host -> HBM and HBM -> host bytes of rank 0's units per job over T_core over 64 GB/s (PCIe 5 x16, one direction): how much of the job the link would be busy if nothing else ran; upload_GBs_largest_unit = the rate of the largest unit's copies alone on the device's upload stream"}},
             "cpu_baseline": cpu,
+            "emulated_rank": emu_note,
             "breakdown_ms_largest_unit": {k2: round(v, 3) for k2, v in kern.items()},
             "breakdown_note": "largest unit of rank 0, exclusive builds with section events after the timed region (4 uploads + first builds); ms_resident_rebuild = r01's headline quantity (rebuild of a resident unit, kernels only)",
             "units": per_unit,
@@ -648,7 +675,7 @@ def main():
         if os.environ.get("AGX_BENCH_DIGEST"):                                  # tests: what the job delivered to rank 0, unit by unit
             import hashlib
             with open(os.environ["AGX_BENCH_DIGEST"], "w") as f:
-                json.dump({str(uu): hashlib.md5(outs[uu]).hexdigest() for uu in range(n_units)}, f)
+                json.dump({str(uu): hashlib.md5(outs[uu]).hexdigest() for uu in sorted(outs)}, f)
         print(json.dumps(line))
     for r in held.values():
         r.free()
