@@ -26,7 +26,7 @@ def plan(unit_sizes, rank, world):
     return sorted(mine, key=lambda u: (-unit_sizes[u], u))
 
 
-def run_job(unit_sizes, rank, world, run_unit, dist, device, inflight=8, dst=0, start_unit=None, hbm_need=None, hbm_budget=None):
+def run_job(unit_sizes, rank, world, run_unit, dist, device, inflight=8, dst=0, start_unit=None, hbm_need=None, hbm_budget=None, plan_as=None):
     """One whole job the way bench.py --gpus N and the gloo test run it: this rank's units (plan) through run_unit(u) -> bytes on up to
     `inflight` worker threads that take the next unit as they finish one, then the path's ONLY exchange — one gather of every rank's
     per-unit bytes to rank `dst` (north_star: "gather of extended contigs at the end").  run_unit may return anything with
@@ -38,7 +38,7 @@ def run_job(unit_sizes, rank, world, run_unit, dist, device, inflight=8, dst=0, 
     run_unit(u, release) and may call release(nbytes) when the unit has given part of its device memory back before it is done (agx_unit_trim after the download: the
     next unit is then admitted while this one is still being walked on the host).  Returns {unit: bytes-like} of ALL units on dst, None elsewhere."""
     import threading
-    mine = plan(unit_sizes, rank, world)
+    mine = plan(unit_sizes, *plan_as) if plan_as else plan(unit_sizes, rank, world)      # plan_as = (R, N): one process runs rank R's share of an N-rank job alone (bench.py --emulate-rank)
     out, errs = {}, []
     nxt, take = iter(mine), threading.Lock()
     held, room = [0], threading.Condition()

@@ -442,7 +442,7 @@ def main():
         elif args.pool == "host-cold":
             A.pool_trim(-1, retire_host=True)          # (the previous steps' buffers are unmapped after the timed region)
         units.clear(); units.update(unit_sets[step_no[0] % n_sets]); step_no[0] += 1
-        return shard.run_job(unit_len, rank, world, run_unit, dist, gdev, inflight=inflight, start_unit=start_unit, hbm_need=hbm_need, hbm_budget=hbm_budget)
+        return shard.run_job(unit_len, rank, world, run_unit, dist, gdev, inflight=inflight, start_unit=start_unit, hbm_need=hbm_need, hbm_budget=hbm_budget, plan_as=emu)
 
     for _ in range(args.warmup):
         run_job()
