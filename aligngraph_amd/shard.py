@@ -78,15 +78,177 @@ def run_job(unit_sizes, rank, world, run_unit, dist, device, inflight=8, dst=0, 
                 room.notify_all()
 
     threads = [threading.Thread(target=worker) for _ in range(max(1, min(inflight, len(mine))))]
+    # r06: the exchange runs WHILE the units are computed (UnitStream below): a peer sends each unit's bytes as the unit finishes, the root receives them as they are
+    # announced.  AGX_GATHER=end: one gather after the last walk (gather_units; r02-r05).
+    import os
+    stream = None
+    if dist is not None and world > 1 and plan_as is None and os.environ.get("AGX_GATHER", "stream") != "end":
+        stream = UnitStream(unit_sizes, dist, device, rank, world, dst)
+        if rank != dst:
+            done_unit = run_unit
+
+            def run_and_send(u, *a, _inner=done_unit):
+                b = _inner(u, *a)
+                stream.send(u, b)
+                return b
+            run_and_send.takes_release = getattr(run_unit, "takes_release", False)
+            run_unit = run_and_send
     for t in threads:
         t.start()
     for t in threads:
         t.join()
+    if stream is not None:
+        return stream.finish(mine, out, errs[0] if errs else None)
     if errs:
         raise errs[0]
     if dist is None or world == 1:
         return out                                     # one rank: the outputs are where they are wanted already — nothing is copied
     return gather_units(mine, [out[u] for u in mine], dist, device, rank, world, dst)
+
+
+_streams = {"group": None, "job": 0, "arena": {}}
+
+
+class _Arena:
+    """Host landing memory for what one peer sends (pinned when the payload comes down from a device), kept between jobs: pinning costs 0.2 ms per MB and a job's sizes repeat."""
+
+    def __init__(self, torch, pinned):
+        self.torch, self.pinned, self.chunks, self.at = torch, pinned, [], (0, 0)
+
+    def reset(self):
+        self.at = (0, 0)
+
+    def take(self, n):
+        i, off = self.at
+        while i < len(self.chunks) and off + n > self.chunks[i].numel():
+            i, off = i + 1, 0
+        if i == len(self.chunks):
+            self.chunks.append(self.torch.empty(max(n + n // 8, 32 << 20), dtype=self.torch.uint8, pin_memory=self.pinned))
+        self.at = (i, off + n)
+        return self.chunks[i][off:off + n]
+
+
+class UnitStream:
+    """The gather as units finish.  One barrier gather after the last walk left the root's one PCIe link with everybody's bytes at once, behind the job's
+    last walk: 2.7 GB = 45 ms of a whole-human job whose critical rank has 95 ms.  Here every unit's bytes leave their rank when the unit is done, beside the units still in flight:
+
+      * the handshake is on the CPU: a peer ANNOUNCES a finished unit through the process group's key-value store ("<job>/<rank>/<n-th finished>" = "<unit>,<bytes>"), after it
+        has put the bytes where its send will read them, and only then sends; the root posts the matching receive only when it has read the announcement.  A receive is never
+        posted for a sender that is not ready: under RCCL a posted receive is a kernel on the root's GPU, and one that spins in front of the root's own node sweeps would stall
+        the rank that is the job's critical path (DESIGN §7: why r05 did not send early);
+      * the transfers use a process group of their own (nobody else's collectives interleave with them) from one sender thread per peer and one receiver thread per peer on the
+        root, the root's receives one at a time (they share its link anyway);
+      * nothing is gathered at the end: the root knows from the plan (assign_units is deterministic) which units each peer owes it and returns when it has them all.
+
+    gloo in the CPU tests (host tensors), RCCL on the GPU box (device tensors: host -> peer's HBM -> xGMI -> root's HBM -> pinned landing memory)."""
+
+    def __init__(self, unit_sizes, dist, device, rank, world, dst):
+        import queue
+        import threading
+        import torch
+        from torch.distributed import distributed_c10d as c10d
+        self.dist, self.device, self.rank, self.world, self.dst, self.torch = dist, device, rank, world, dst, torch
+        self.cuda = torch.device(device).type == "cuda"
+        if _streams["group"] is None:
+            _streams["group"] = dist.new_group()           # (collective: every rank's first job makes it)
+        self.group, self.store = _streams["group"], c10d._get_default_store()
+        _streams["job"] += 1
+        self.job = _streams["job"]
+        self.owed = assign_units(unit_sizes, world)         # what every rank computes
+        self.errs, self.merged = [], {}
+        self.lock = threading.Lock()                        # the root's receives, one at a time
+        self.threads = []
+        if rank != dst:
+            self.q = queue.Queue()
+            t = threading.Thread(target=self._sender)
+            t.start(); self.threads.append(t)
+        else:
+            for peer in range(world):
+                if peer != dst and self.owed[peer]:
+                    t = threading.Thread(target=self._receiver, args=(peer,))
+                    t.start(); self.threads.append(t)
+
+    def _key(self, rank, n):
+        return "agx/gather/%d/%d/%d" % (self.job, rank, n)
+
+    def send(self, u, blob):
+        """(a peer's worker thread, when unit u is done)"""
+        self.q.put((u, blob))
+
+    def _sender(self):
+        import numpy as np
+        torch, n_sent = self.torch, 0
+        try:
+            if self.cuda:
+                torch.cuda.set_device(self.device)          # (the current device is per thread)
+            while True:
+                item = self.q.get()
+                if item is None:
+                    return
+                u, blob = item
+                if isinstance(blob, BaseException):          # this rank failed: the root must not wait for the rest
+                    self.store.set(self._key(self.rank, n_sent), "error,%s" % type(blob).__name__)
+                    return
+                v = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob.view(np.uint8).reshape(-1)
+                t = torch.from_numpy(v if v.flags.writeable else v.copy()).to(self.device) if v.size else None      # (first where the send will read them ...)
+                self.store.set(self._key(self.rank, n_sent), "%d,%d" % (u, v.size))                                 # (... then the announcement ...)
+                n_sent += 1
+                if t is not None:
+                    self.dist.send(t, self.dst, group=self.group)                                                      # (... then the send: the root posts its receive when it has read it)
+        except BaseException as e:
+            self.errs.append(e)
+
+    def _receiver(self, peer):
+        torch = self.torch
+        try:
+            if self.cuda:
+                torch.cuda.set_device(self.device)
+            arena = _streams["arena"].setdefault((peer, self.cuda), _Arena(torch, self.cuda))
+            arena.reset()
+            for n_got in range(len(self.owed[peer])):
+                key = self._key(peer, n_got)
+                self.store.wait([key])                       # asleep on the CPU until the peer has announced its next unit
+                word = self.store.get(key).decode()
+                try:
+                    self.store.delete_key(key)
+                except Exception:
+                    pass
+                if word.startswith("error"):
+                    raise RuntimeError("rank %d failed (%s): its units will not arrive" % (peer, word.partition(",")[2]))
+                u, n = (int(x) for x in word.split(","))
+                if n == 0:
+                    self.merged[u] = memoryview(b"")
+                    continue
+                host = arena.take(n)
+                with self.lock:
+                    if self.cuda:
+                        buf = torch.empty(n, dtype=torch.uint8, device=self.device)
+                        self.dist.recv(buf, peer, group=self.group)
+                        host.copy_(buf, non_blocking=True)
+                        torch.cuda.current_stream().synchronize()
+                    else:
+                        self.dist.recv(host, peer, group=self.group)      # (gloo: straight into the landing memory)
+                self.merged[u] = memoryview(host.numpy())
+        except BaseException as e:
+            self.errs.append(e)
+
+    def finish(self, mine, out, err):
+        """(every rank, when its own units are done; err: what one of them raised) -> {unit: bytes-like} of ALL units on the root, None elsewhere"""
+        import numpy as np
+        if self.rank != self.dst:
+            self.q.put((None, err) if err is not None else None)
+        for t in self.threads:
+            t.join()
+        if err is not None:
+            raise err
+        if self.errs:
+            raise self.errs[0]
+        if self.rank != self.dst:
+            return None
+        for u in mine:
+            b = out[u]
+            self.merged[u] = memoryview(np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b.view(np.uint8).reshape(-1))
+        return self.merged
 
 
 _pinned = {}      # root's landing buffers for the gather, by peer: pinning host memory costs 0.2 ms per MB, a job's sizes repeat from step to step

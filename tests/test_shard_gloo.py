@@ -145,3 +145,75 @@ def test_a_unit_that_gives_memory_back_early_lets_the_next_one_in():
     assert started[1] < 0.25 and started[2] < 0.30, started          # unit 1 (50) did not wait for unit 0's walk (0.35 s): it went in when unit 0 gave 45 back
     with lock:
         assert now[0] == 0
+
+
+def _stream_worker(rank, world, port, case, q):
+    """shard.UnitStream under gloo: made-up units whose completion order and timing the case dictates."""
+    import time
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if case == "end":
+        os.environ["AGX_GATHER"] = "end"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = [90, 80, 70, 60, 50, 40, 30]                   # 2 ranks: rank 0 gets {0, 3, 4, 6}, rank 1 {1, 2, 5}
+    mine = shard.plan(sizes, rank, world)
+    took = {}
+
+    def payload(u, job):
+        return b"" if u == 5 else (b"unit %d of job %d;" % (u, job)) * (1000 * (u + 1))      # (unit 5: nothing extended — zero bytes travel as an announcement alone)
+
+    for job in range(3):
+        def run_unit(u, job=job):
+            t0 = time.perf_counter()
+            if case == "peer-first" and rank == 0:
+                time.sleep(0.5)                            # the root's units are still being built when the peer has long finished all of its own
+            if case == "reverse" and rank == 1:
+                time.sleep(0.05 * (10 - u))                # the peer's units finish in the reverse of the plan's order
+            if case == "fail" and rank == 1 and u == 2 and job == 1:
+                raise ValueError("unit 2 cannot be built")
+            took[u] = time.perf_counter() - t0
+            b = payload(u, job)
+            return np.frombuffer(b, dtype=np.uint8) if u % 2 else b      # (bench.py hands over numpy views of C memory, the tests bytes)
+        try:
+            merged = shard.run_job(sizes, rank, world, run_unit, dist, torch.device("cpu"), inflight=3)
+        except Exception as e:
+            q.put((rank, job, "raised", type(e).__name__, str(e)))
+            break
+        assert (merged is not None) == (rank == 0)
+        if rank == 0:
+            assert sorted(merged) == list(range(len(sizes)))
+            for u in merged:
+                assert bytes(merged[u]) == payload(u, job), (case, job, u)
+            q.put((rank, job, "ok", None, None))
+    dist.barrier() if case != "fail" else None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["plain", "reverse", "peer-first", "end", "fail"])
+def test_units_travel_to_the_root_as_they_finish(case):
+    """r06: the gather runs while the units are computed — a peer announces every finished unit through the process group's store and sends it, the root
+    posts the receive when it has read the announcement (shard.UnitStream).  Three jobs in a row per case (the job number is part of every key and every payload): units that
+    finish out of the plan's order, a peer that is done before the root's first unit, a unit of zero bytes, numpy views and bytes, AGX_GATHER=end (the gather at the end, r05),
+    and a peer whose unit fails: the root's job raises instead of waiting for bytes that will not come."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stream_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = []
+    want = 3 if case != "fail" else 3                       # fail: job 0 ok on the root, then one "raised" from each rank
+    while len(got) < want:
+        got.append(q.get(timeout=120))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if case != "fail":
+        assert [g[2] for g in got] == ["ok"] * 3
+    else:
+        assert sorted((g[0], g[1], g[2]) for g in got) == [(0, 0, "ok"), (0, 1, "raised"), (1, 1, "raised")], got
+        assert any(g[3] == "ValueError" for g in got) and any("rank 1 failed" in (g[4] or "") for g in got), got
