@@ -241,6 +241,8 @@ def main():
         mem_limit = min(mem_limit, os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE"))
     except (ValueError, OSError):
         pass
+    if args.config is None and os.environ.get("AGX_BENCH_CONFIG") in CONFIGS:
+        args.config = os.environ["AGX_BENCH_CONFIG"]      # (a driver that wants ONE workload at every N sets it: the defaults differ between N = 1 and N > 1)
     if args.config is None:
         if world == 1:
             args.config = "cfg3"
@@ -633,6 +635,7 @@ def main():
             "host_cpu_ms_per_step": round(1e3 * cpu_s_per_step, 2),      # CPU time of rank 0's process inside the timed region, per step (a 16-CPU quota gives 16 x ms_per_step)
             "single_gpu_ms_same_config": round(single_ms, 3) if single_ms else None,
             "speedup_vs_1gpu": round(single_ms / (1e3 * sec_per_step), 3) if single_ms else None,
+            "value_same_config_1gpu": round(reads_per_step / (single_ms * 1e-3), 1) if single_ms else None,      # the 1-GPU point of THIS configuration: a 1 -> N curve of `value` over driver runs with different default configurations (cfg3 at N = 1, the whole-human shape at N > 1) compares workloads, this pair does not
             "t_core_s": round(sec_per_step, 4),
             "t_unit_s": round(sec_per_step + t_parse_max, 4),
             "sam_text_bytes": sam_bytes_total, "sam_seq_columns": bool(sam_seq),
@@ -653,6 +656,8 @@ def main():
                          "traffic_note": "HBM bytes from the PMC counters (profiles/pmc_traffic.json: bytes per tile-list entry of the sweep, measured with rocprofv3 --pmc) x this run's list entries; achieved_hbm = traffic / kernel_ms",
                          "algorithmic_bytes_8d": abytes,
                          "algorithmic_bytes_8d_note": "SURVEY 8(d)'s algorithmic bytes of the WHOLE path (per pair (L-k)*40 + L + 32, plus 64 per position).  r01/r02 printed them / the node sweep's time / peak as `frac` (it reached 0.99-1.07: one kernel was charged the whole path's bytes); they are now only divided by the whole job's time (`job_frac`)",
+                         "frac_8d_kernel": round(abytes / (sw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sw_ms > 0 else None,
+                         "frac_8d_kernel_note": "the quotient SURVEY 8(d) prescribes, printed so that a reader sees why it is not used as `frac`: the WHOLE path's algorithmic bytes / the node sweep's time / peak.  It comes out near or above 1 — not a fraction of a roof — because one kernel is charged every byte of the path, 32 bytes per arrival of which (the node state) live in LDS and never touch HBM; `frac` (bytes the kernel cannot avoid) and `frac_hbm` (counter traffic) are the kernel's, `job_frac` is 8(d)'s bytes against the time of everything that moves them",
                          "job_frac": round(abytes / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
                          "job_frac_note": "SURVEY 8(d)'s algorithmic bytes / T_core per job / peak: the whole path against the whole job's time (upload, kernels, download, host walk)",
                          "pcie": {"up_bytes": up_bytes, "down_bytes": down_bytes, "peak_GBs": 64.0,
