@@ -65,7 +65,8 @@ typedef uint8_t agx_u8;
 // A unit's upload is what a cfg3 job waits for (1.5 GB at 56 GB/s = 29 of its 50 ms in r02), so the arrays cross in a packed form and a kernel
 // at the head of the unit's first build expands them into the working forms above (agx_k_expand_hits, agx_k_expand_ref): hits 32 -> 16 bytes
 // (+ 12 for the three in eight that have a multi-run mate), runs 12 -> 8, reference bases 8 -> 2 bits.
-enum { AGX_WF_REV1 = 1, AGX_WF_REV2 = 2, AGX_WF_LEFT2 = 4, AGX_WF_RUNS1 = 8, AGX_WF_RUNS2 = 16 };
+enum { AGX_WF_REV1 = 1, AGX_WF_REV2 = 2, AGX_WF_LEFT2 = 4, AGX_WF_RUNS1 = 8, AGX_WF_RUNS2 = 16,
+       AGX_WF_DUP = 32 };      // (tile-ordered upload, r06: the rule of AG:1650-1655 — a later hit of a pair that lands on an earlier one is dropped — decided where the arrays are staged: the hit's file neighbours are not its neighbours in that order)
 struct agx_whit {             // a: reference offset of mate1's read index 0 if mate1 is one full-length run, b: the same for mate2.  A hit with a multi-run
     agx_u32 a, b, row;        // mate has a side record; its index sits in the field of the first mate that has runs (a if RUNS1, else b)
     agx_u16 len; agx_u8 flags, back;

@@ -258,6 +258,10 @@ struct agx_unit {
     PBuf<agx_whit> s_hits; PBuf<agx_wside> s_sides; PBuf<agx_wrun> s_runs; PBuf<agx_u8> s_codes; PBuf<unsigned long long> s_other; PBuf<agx_u32> s_jump; size_t n_other = 0, n_sides = 0, n_jump = 0;      // the read alignments in the wire formats of agx_core.h
     PBuf<agx_u8> s_ref; PBuf<agx_refx> s_refx; size_t n_refx = 0; bool ref_packed = false;      // the unit sequence: 2 bits per base + the stretches of other bytes (ref_packed), or the bytes as they are
     PBuf<agx_u32> s_chain_end, s_region_off; PBuf<agx_cmseg> s_segs; size_t n_segs = 0;
+    // r06, tile-ordered upload (stage_tiled): the wire records and the read rows in the order of the hits' first tiles — what the device is sent instead of s_hits / s_perm / s_codes / s_other
+    PBuf<agx_whit> s_hits_t; PBuf<agx_u8> s_codes_t; PBuf<unsigned long long> s_other_t; size_t n_other_t = 0; bool tiled = false; std::vector<agx_u32> slot_row;      // slot_row[i] = staged row of the i-th hit's left mate (the walk's k-mer tails)
+    agx_u32 n_win = 1, win_tile[9] = {};      // a unit's first build sweeps windows of tiles as their rows land: window w = tiles [win_tile[w], win_tile[w + 1])
+    hipEvent_t ev_rows[8] = {}, ev_win[8] = {}, ev_sw0[8] = {}, ev_sw1[8] = {};      // rows of window w in HBM / expanded; around window w's sweep (its time is the sum over the windows)
     PBuf<agx_u32> s_perm, s_tfirst, s_jump_at; agx_u32 lookback = 2;      // the hits in the order of their first tile (stage_order): perm[i] = the i-th hit of that order, tile_first[t] = hits in front of tile t's own; pass J's hits as places in it
     PBuf<char> s_landing;               // one-shot units: what the download needs beyond the dead staged inputs it lands in, pinned when the unit is staged (not inside T_core)
     PBuf<agx_cntrun> s_cntruns; PBuf<agx_chunk> s_cntchunks, s_segchunks; PBuf<agx_u32> s_segindex; size_t n_cntruns = 0, n_cntchunks = 0, n_segchunks = 0, n_segindex = 0;      // what the device builds the conti-mer tables from (build_cm_layout)
@@ -303,6 +307,7 @@ struct agx_unit {
         if (pending_walk) g_walks_pending.fetch_sub(1);
         ev.destroy();
         for (hipEvent_t e : {ev_front, ev_passA, ev_passJ, ev_up0, ev_uploaded, ev_dl, ev_built, ev_hits}) if (e) (void)hipEventDestroy(e);
+        for (auto *arr : {ev_rows, ev_win, ev_sw0, ev_sw1}) for (int i = 0; i < 8; i++) if (arr[i]) (void)hipEventDestroy(arr[i]);
         if (dl_signal.handle) (void)hsa_signal_destroy(dl_signal);
         if (dl_piece_made) for (hsa_signal_t g : dl_piece) if (g.handle) (void)hsa_signal_destroy(g);
     }
@@ -433,7 +438,7 @@ void reserve_landing(agx_unit *u) {
     if (!(u->prm.flags & AGX_FLAG_ONE_SHOT)) { u->s_landing.release(); return; }
     const size_t n_pos = u->V.n_pos, ni = n_pos + n_pos / 16 + 4096, ns = ni / 10 + 4096;
     const size_t need = 2 * (ni + 512) + ns * (sizeof(agx_walknode) + sizeof(agx_hop)) + ni / 4 + (4u << 20);
-    const size_t have = u->s_codes.block_bytes() + u->s_hits.block_bytes() + u->s_runs.block_bytes() + u->s_sides.block_bytes() + u->s_other.block_bytes();
+    const size_t have = u->s_codes.block_bytes() + u->s_hits.block_bytes() + u->s_runs.block_bytes() + u->s_sides.block_bytes() + u->s_other.block_bytes() + u->s_codes_t.block_bytes() + u->s_hits_t.block_bytes();
     // (a buffer must fit one block: count the blocks at 85 %)
     if (need > have * 85 / 100) u->s_landing.alloc(need - have * 85 / 100 + (ni + 512)); else u->s_landing.release();
 }
@@ -468,6 +473,62 @@ void stage_order(agx_unit *u, unsigned threads) {
     order_hits(u->s_hits.p, u->nh, u->s_sides.p, u->s_runs.p, u->s_jump.p, u->n_jump, n_pos, threads, u->s_perm.p, u->s_tfirst.p, u->s_jump_at.p);
     if (getenv("AGX_LOAD_TIMING")) fprintf(stderr, "[agx load] hits in tile order: %.1f ms (%zu hits, %zu tiles, window of %u tiles)\n", now_ms() - t0, u->nh, n_tiles, u->lookback);
 }
+// r06: what the device is sent of the read alignments, in the order of the hits' first tiles (stage_order's permutation applied on the host).
+//   * the wire records: s_hits_t[i] = hit perm[i], its `row` field carrying the hit's NUMBER (the key the tile lists are ranked by) — the 4 bytes per hit of the permutation no
+//     longer cross PCIe, the device reads the records in order instead of gathering them — and AGX_WF_DUP what the rule of AG:1650-1655 says about it (it needs the hit's FILE
+//     neighbours, which are not its neighbours here);
+//   * the read rows: row i = the left-mate row of the i-th hit (a pair with a second hit sends its row twice: 5 % of the rows), so the rows that a WINDOW of tiles reads are one
+//     contiguous piece of the upload, in front of which lie the rows of every earlier tile: the unit's first build sweeps window w when its piece has landed, beside the
+//     upload of the pieces behind it (do_upload / do_build) — chr1 of configs[4]: 22 ms of node sweep that used to wait for the last read row;
+//   * the list of the bases that are not A, C, G, T, re-indexed to those rows.
+// The k-mer string references of the nodes then name places in the tile order: slot_row maps them back for the walk (UnitView::slot_row).
+// Not when the rows cross as differences from the reference (their codec numbers the rows by their anchors' file order): AGX_ROW_DIFF units keep r05's forms.
+void stage_tiled(agx_unit *u, unsigned threads) {
+    u->tiled = false; u->n_other_t = 0; u->slot_row.clear(); u->n_win = 1;
+    const size_t nh = u->nh, s4 = u->stride / 4;
+    if (u->rows_diffed || getenv("AGX_NO_TILED_UPLOAD") || nh == 0 || u->n_rows == 0) { u->s_hits_t.release(); u->s_codes_t.release(); u->s_other_t.release(); return; }
+    const double t0 = now_ms();
+    u->s_hits_t.alloc(nh + 1); u->s_codes_t.alloc(nh * s4 + 16); u->slot_row.resize(nh);
+    const agx_whit *wh = u->s_hits.p; const agx_wside *sd = u->s_sides.p; const agx_wrun *wr = u->s_runs.p; const agx_u32 *perm = u->s_perm.p;
+    // rows that carry a listed base (few): one bit per row
+    const size_t n_rows = u->n_rows; std::vector<agx_u8> has_other((n_rows + 7) / 8, 0);
+    for (size_t j = 0; j < u->n_other; j++) { const size_t r = (size_t)(u->s_other.p[j] / u->stride); if (r < n_rows) has_other[r >> 3] |= (agx_u8)(1u << (r & 7)); }
+    auto idx0 = [&](const agx_whit &w) -> agx_u32 {      // positionSets[hit][0] of mate1 (agx_idx0_pos on the wire forms)
+        if (!(w.flags & AGX_WF_RUNS1)) return w.a;
+        const agx_wside &g = sd[w.a]; const agx_wrun &r = wr[g.runs1];
+        return r.q == 0 ? r.t : AGX_NONE;
+    };
+    const unsigned T = std::max(1u, std::min(threads, 16u));
+    std::vector<std::vector<unsigned long long>> others(T);
+    on_threads(T, [&](unsigned t) {
+        for (size_t i = nh * t / T, hi = nh * (t + 1) / T; i < hi; i++) {
+            const agx_u32 h = perm[i]; agx_whit w = wh[h];
+            const agx_u32 row = w.row;
+            u->slot_row[i] = row;
+            memcpy(u->s_codes_t.p + i * s4, u->s_codes.p + (size_t)row * s4, s4);
+            bool dup = false;
+            if (w.back) { const agx_u32 me = idx0(w); for (agx_u32 e = 1; e <= w.back && !dup; e++) dup = agx_absdiff(me, idx0(wh[h - e])) < (int)w.len; }      // agx_hit_dup_by
+            w.row = h; if (dup) w.flags |= (agx_u8)AGX_WF_DUP;
+            u->s_hits_t.p[i] = w;
+            if (has_other[row >> 3] & (1u << (row & 7))) {
+                const unsigned long long lo = (unsigned long long)row * u->stride, *b = u->s_other.p, *e = b + u->n_other;
+                for (const unsigned long long *at = std::lower_bound(b, e, lo); at != e && *at < lo + u->stride; ++at) others[t].push_back((unsigned long long)i * u->stride + (*at - lo));
+            }
+        }
+    });
+    size_t no = 0; for (auto &v : others) no += v.size();
+    u->s_other_t.alloc(no + 1); u->n_other_t = no;
+    { size_t at = 0; for (auto &v : others) { if (!v.empty()) memcpy(u->s_other_t.p + at, v.data(), v.size() * 8); at += v.size(); } }
+    u->tiled = true;
+    // windows of the first build's sweep: about 8 M positions each, eight at most (AGX_UPLOAD_WINDOWS forces a number: tests), cut at tiles
+    const size_t n_pos = u->V.n_pos ? u->V.n_pos : u->T.ref.size(), n_tiles = (n_pos + AGX_TILE - 1) / AGX_TILE;
+    size_t W = getenv("AGX_UPLOAD_WINDOWS") ? (size_t)atoi(getenv("AGX_UPLOAD_WINDOWS")) : n_pos / 8000000u;
+    W = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(W, 8), n_tiles));
+    u->n_win = (agx_u32)W;
+    for (size_t w = 0; w <= W; w++) u->win_tile[w] = (agx_u32)(n_tiles * w / W);
+    if (getenv("AGX_LOAD_TIMING")) fprintf(stderr, "[agx load] tile-ordered upload forms: %.1f ms (%zu hits, %zu listed bases, %u windows)\n", now_ms() - t0, nh, no, u->n_win);
+}
+
 void stage_inputs(agx_unit *u) {
     if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
     // A one-shot unit's download lands in its staged buffers.  The general loader's pairs can be staged again from P; the fast loader wrote the hits, runs and
@@ -505,6 +566,8 @@ void stage_inputs(agx_unit *u) {
     u->V = V;
     stage_rows(u, threads);
     stage_order(u, threads);
+    stage_tiled(u, threads);
+    u->V.slot_row = u->tiled ? u->slot_row.data() : nullptr;
     reserve_landing(u);
     u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0;
@@ -721,6 +784,8 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     u->V = V; u->pairs_staged = false;
     stage_rows(u, std::max(threads, std::min(8u, usable_cpus())));
     stage_order(u, std::max(threads, std::min(16u, usable_cpus())));
+    stage_tiled(u, std::max(threads, std::min(16u, usable_cpus())));
+    u->V.slot_row = u->tiled ? u->slot_row.data() : nullptr;
     reserve_landing(u);
     u->have_ref = u->have_threads = true; u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
     u->stats.ms_stage = now_ms() - t0; u->stats.ms_parse = 0; u->stats.ms_thread = 0; u->stats.from_cache = 1;
@@ -785,10 +850,16 @@ void do_release(agx_unit *u);
 // Capacities of a unit's first build and the HBM they add up to (what do_upload reserves as one block; AlignGraph_amd admits a unit to a device by it:
 // agx_unit_hbm_needed).  From the staged counts: positions, hits, runs, conti-mers, read rows.
 struct Plan { agx_u32 pool_cap, list_cap, ovf_cap, sp_cap; size_t total; };
+// first row of window w's piece of a tile-ordered upload (w = n_win: all rows): the place in the tile order of the first hit of the window's first tile, rounded up to 16 rows —
+// a piece then begins on a 16-byte boundary of the packed classes and on a multiple of 16 bases (agx_k_expand_codes takes 16 bases per thread); the few rows of the next window's
+// hits that ride in this piece only arrive early
+inline size_t win_row(const agx_unit *u, agx_u32 w) { return w == 0 ? 0 : w >= u->n_win ? u->nh : std::min<size_t>(u->nh, ((size_t)u->s_tfirst.p[u->win_tile[w]] + 15) & ~(size_t)15); }
+inline size_t codes_bytes(const agx_unit *u) { return u->tiled ? u->nh * (u->stride / 4) : u->n_codes; }      // packed read rows as they are uploaded (tile-ordered: one row per hit)
+inline size_t others_up(const agx_unit *u) { return u->tiled ? u->n_other_t : u->n_other; }
 Plan plan_capacities(const agx_unit *u) {
     const size_t n_pos = u->V.n_pos, nh = u->nh;
     const agx_u32 n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE), n_regions = (n_tiles + AGX_REGION_TILES - 1) / AGX_REGION_TILES;
-    const size_t n_bases = u->n_codes * 4;
+    const size_t n_bases = codes_bytes(u) * 4;
     Plan P;
     const agx_u32 main_cap = (agx_u32)std::min<size_t>(g_tiny ? n_pos / 8 + 64 : n_pos + n_pos / 4 + 4096, 0xE0000000ull);
     P.pool_cap = u->pool_cap ? u->pool_cap : main_cap + spill_min(u);
@@ -802,7 +873,7 @@ Plan plan_capacities(const agx_unit *u) {
     const size_t per_pos = 4 + 16 + 1 + 4 + 2 + 1 + 4 + 4, per_tile = 4 * 4 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_dhit) + 4 + 4 + 4;      // per hit: derived record, order, last-tile key, (pass J / long list)
     const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
     const size_t wire = nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 + (u->ref_packed ? n_pos / 4 + u->n_refx * sizeof(agx_refx) : 0) + 4096;
-    const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + (u->rows_diffed ? u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4 : u->n_codes) + n_bases + u->n_other * 8 +
+    const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + (u->rows_diffed ? u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4 : codes_bytes(u)) + n_bases + others_up(u) * 8 +
                          (size_t)P.pool_cap * per_slot + ids_cap * per_id + (size_t)P.list_cap * 36 + (size_t)P.ovf_cap * 16 + (size_t)P.sp_cap * (sizeof(agx_walknode) + sizeof(agx_hop)) +
                          (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64 * 4 + (size_t)n_regions * AGX_REGION_PAD * 4 + (64u << 10) * 100;
     P.total = total + total / 64;
@@ -823,7 +894,7 @@ void do_upload(agx_unit *u) {
     u->arena.device = u->prm.device;
     u->n_tiles = (agx_u32)((n_pos + AGX_TILE - 1) / AGX_TILE);
     u->n_regions = (u->n_tiles + AGX_REGION_TILES - 1) / AGX_REGION_TILES;
-    const size_t n_bases = u->n_codes * 4;
+    const size_t n_bases = codes_bytes(u) * 4;
     const Plan plan = plan_capacities(u);
     const agx_u32 pool_cap = plan.pool_cap, list_cap = plan.list_cap, ovf_cap = plan.ovf_cap, sp_cap = plan.sp_cap;
     u->arena.reserve(plan.total);                        // one block for all of it
@@ -831,9 +902,9 @@ void do_upload(agx_unit *u) {
     alloc_pool(u, pool_cap);                             // (first: what outlives the download lies at the front of the block, agx_unit_trim)
     u->d_cm_start.alloc(a, n_pos + 2); u->d_cm.alloc(a, u->n_cm + 1); u->d_ref.alloc(a, n_pos + 16); u->d_cm_head.alloc(a, n_pos + 1);
     u->d_segs.alloc(a, u->n_segs + 1); u->d_cntruns.alloc(a, u->n_cntruns + 1); u->d_cntchunks.alloc(a, u->n_cntchunks + 1); u->d_segchunks.alloc(a, u->n_segchunks + 1); u->d_segindex.alloc(a, u->n_segindex + 1);
-    u->d_runs.alloc(a, u->n_runs + 1); u->d_vcodes.alloc(a, n_bases + 16); u->d_other.alloc(a, u->n_other + 1);
+    u->d_runs.alloc(a, u->n_runs + 1); u->d_vcodes.alloc(a, n_bases + 16); u->d_other.alloc(a, others_up(u) + 1);
     if (u->rows_diffed) { u->d_units.alloc(a, u->n_units + 2); u->d_rowcnt.alloc(a, u->n_rowcnt); u->d_blockoff.alloc(a, u->n_blockoff); u->d_blockfirst.alloc(a, u->n_blockfirst); u->d_anchor.alloc(a, u->n_anchor); }
-    else u->d_codes.alloc(a, u->n_codes + 16);
+    else u->d_codes.alloc(a, codes_bytes(u) + 16);
     u->d_whits.alloc(a, nh + 1); u->d_wsides.alloc(a, u->n_sides + 1); u->d_wruns.alloc(a, u->n_runs + 1); u->d_jump.alloc(a, u->n_jump + 1);
     if (u->ref_packed) { u->d_wref.alloc(a, (n_pos + 3) / 4 + 32); u->d_refx.alloc(a, u->n_refx + 1); }
     u->d_dhit.alloc(a, nh + 1);
@@ -866,15 +937,29 @@ void do_upload(agx_unit *u) {
         };
         up(u->d_segs.p, u->s_segs.p, u->n_segs * sizeof(agx_cmseg)); up(u->d_cntruns.p, u->s_cntruns.p, u->n_cntruns * sizeof(agx_cntrun));
         up(u->d_cntchunks.p, u->s_cntchunks.p, u->n_cntchunks * sizeof(agx_chunk)); up(u->d_segchunks.p, u->s_segchunks.p, u->n_segchunks * sizeof(agx_chunk)); up(u->d_segindex.p, u->s_segindex.p, u->n_segindex * 4);
-        up(u->d_whits.p, u->s_hits.p, nh * sizeof(agx_whit)); up(u->d_wsides.p, u->s_sides.p, u->n_sides * sizeof(agx_wside)); up(u->d_wruns.p, u->s_runs.p, u->n_runs * sizeof(agx_wrun)); up(u->d_jump.p, u->s_jump_at.p, u->n_jump * 4);
-        up(u->d_perm.p, u->s_perm.p, nh * 4); up(u->d_tfirst.p, u->s_tfirst.p, ((size_t)u->n_tiles + 2) * 4);
+        up(u->d_whits.p, u->tiled ? u->s_hits_t.p : u->s_hits.p, nh * sizeof(agx_whit)); up(u->d_wsides.p, u->s_sides.p, u->n_sides * sizeof(agx_wside)); up(u->d_wruns.p, u->s_runs.p, u->n_runs * sizeof(agx_wrun)); up(u->d_jump.p, u->s_jump_at.p, u->n_jump * 4);
+        if (!u->tiled) up(u->d_perm.p, u->s_perm.p, nh * 4);      // (tile-ordered records carry their hit numbers: agx_k_hit_prep writes the array)
+        up(u->d_tfirst.p, u->s_tfirst.p, ((size_t)u->n_tiles + 2) * 4);
         HIP_OK(hipEventRecord(u->ev_hits, st));         // what the front of the build needs (conti-mer tables, hit preparation, binning) is there: it starts while the rest still travels
-        if (u->rows_diffed) { up(u->d_units.p, u->s_units.p, u->n_units * 2); up(u->d_rowcnt.p, u->s_rowcnt.p, u->n_rowcnt); up(u->d_blockoff.p, u->s_blockoff.p, u->n_blockoff * 4); up(u->d_blockfirst.p, u->s_blockfirst.p, u->n_blockfirst * 4); up(u->d_anchor.p, u->s_anchor.p, u->n_anchor * 4); }
-        else up(u->d_codes.p, u->s_codes.p, u->n_codes);
-        up(u->d_other.p, u->s_other.p, u->n_other * 8);      // first needed by the sweep
-        if (u->ref_packed) { up(u->d_wref.p, u->s_ref.p, (n_pos + 3) / 4); up(u->d_refx.p, u->s_refx.p, u->n_refx * sizeof(agx_refx)); } else up(u->d_ref.p, u->s_ref.p, n_pos);
-        up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);      // first needed by the walk preparation
-        layout_regions(u, nullptr, pool_cap - spill_min(u), true, st);
+        if (u->tiled) {      // the small things first, the read rows last and window by window: a window's sweep starts when its rows are in (do_build)
+            up(u->d_other.p, u->s_other_t.p, u->n_other_t * 8);
+            if (u->ref_packed) { up(u->d_wref.p, u->s_ref.p, (n_pos + 3) / 4); up(u->d_refx.p, u->s_refx.p, u->n_refx * sizeof(agx_refx)); } else up(u->d_ref.p, u->s_ref.p, n_pos);
+            up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);
+            layout_regions(u, nullptr, pool_cap - spill_min(u), true, st);
+            const size_t s4 = u->stride / 4;
+            for (agx_u32 w = 0; w < u->n_win; w++) {      // rows of the hits whose first tile lies in window w (a tile's list also names hits that begin in earlier tiles: earlier pieces)
+                const size_t r_lo = win_row(u, w), r_hi = win_row(u, w + 1);
+                up(u->d_codes.p + r_lo * s4, u->s_codes_t.p + r_lo * s4, (r_hi - r_lo) * s4);
+                HIP_OK(hipEventRecord(u->ev_rows[w], st));
+            }
+        } else {
+            if (u->rows_diffed) { up(u->d_units.p, u->s_units.p, u->n_units * 2); up(u->d_rowcnt.p, u->s_rowcnt.p, u->n_rowcnt); up(u->d_blockoff.p, u->s_blockoff.p, u->n_blockoff * 4); up(u->d_blockfirst.p, u->s_blockfirst.p, u->n_blockfirst * 4); up(u->d_anchor.p, u->s_anchor.p, u->n_anchor * 4); }
+            else up(u->d_codes.p, u->s_codes.p, u->n_codes);
+            up(u->d_other.p, u->s_other.p, u->n_other * 8);      // first needed by the sweep
+            if (u->ref_packed) { up(u->d_wref.p, u->s_ref.p, (n_pos + 3) / 4); up(u->d_refx.p, u->s_refx.p, u->n_refx * sizeof(agx_refx)); } else up(u->d_ref.p, u->s_ref.p, n_pos);
+            up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);      // first needed by the walk preparation
+            layout_regions(u, nullptr, pool_cap - spill_min(u), true, st);
+        }
         HIP_OK(hipEventRecord(u->ev_uploaded, st));
     } catch (...) { (void)hipStreamSynchronize(st); throw; }      // (copies that were queued before the failure must not outlive the unit's HBM block)
     u->expanded = false;
@@ -902,7 +987,7 @@ void do_upload(agx_unit *u) {
     if (!u->pending_walk) { u->pending_walk = true; g_walks_pending.fetch_add(1); }
     u->stats.ms_upload = now_ms() - t0;
     u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + u->n_cntruns * sizeof(agx_cntrun) + (u->n_cntchunks + u->n_segchunks) * sizeof(agx_chunk) + (u->ref_packed ? (n_pos + 3) / 4 + u->n_refx * sizeof(agx_refx) : n_pos) + nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 + nh * 4 + ((size_t)u->n_tiles + 2) * 4 +
-                            (size_t)u->n_chain_end * 4 + (u->rows_diffed ? u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4 : u->n_codes) + u->n_other * 8 + ((size_t)u->n_regions + 1) * 4;
+                            (size_t)u->n_chain_end * 4 + (u->rows_diffed ? u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4 : codes_bytes(u)) + others_up(u) * 8 + ((size_t)u->n_regions + 1) * 4 - (u->tiled ? nh * 4 : 0);
     u->stats.device_bytes = u->arena.capacity();
     u->stats.rows_by_reference = u->rows_diffed ? (uint32_t)(u->n_rows - u->n_rows_explicit) : 0u;
 }
@@ -946,6 +1031,7 @@ void do_build(agx_unit *u) {
     const agx_u32 n_pos = (agx_u32)u->V.n_pos, nh = (agx_u32)u->nh;
     hipStream_t st = nullptr;              // the device's build stream, taken with the turn
     u->stats.node_sweep_launches = u->stats.edge_sweep_launches = 0;
+    agx_u32 swept_windows = 1;             // of the last attempt
     for (int attempt = 0;; attempt++) {
         if (attempt > 8) throw Error{E_DEVICE, "build did not converge"};
         const size_t ids_cap = (size_t)n_pos + u->pool_cap;                       // side variants <= nodes <= pool_cap
@@ -979,7 +1065,7 @@ void do_build(agx_unit *u) {
         // ---- hit_prep + tile histogram ----
         u->ev.begin(); u->ev.mark(B_START, st);
         agx_prep_args PA{(const agx_whit *)u->d_whits.p, (const agx_wside *)u->d_wsides.p, u->d_runs.p, u->d_dhit.p, nh, u->prm.k, n_pos, u->d_tile_cnt.p, u->d_words.p + W_ERR,
-                         u->d_perm.p, u->d_tfirst.p, u->d_ckey.p, u->lookback, u->d_long.p, u->d_words.p + W_LONGCOUNT};
+                         u->d_perm.p, u->d_tfirst.p, u->d_ckey.p, u->lookback, u->d_long.p, u->d_words.p + W_LONGCOUNT, u->tiled ? 1u : 0u, u->d_perm.p};
         agx_launch_hit_prep(&PA, st);
         AGX_CHECKPOINT("hit_prep");
         u->ev.mark(B_PREP, st);
@@ -995,15 +1081,39 @@ void do_build(agx_unit *u) {
             agx_launch_tile_sort(&FA, st);
         }
         AGX_CHECKPOINT("tile_sort");
+        // r06: a tile-ordered unit's first build expands its read rows and sweeps its tiles WINDOW BY WINDOW, each when its piece of the upload has landed (the rows of a window's
+        // hits are one piece, in front of which lie the rows of every earlier tile: stage_tiled) — the sweep of the unit's front runs beside the upload of its back
+        const agx_u32 n_win = (!u->expanded && u->tiled) ? u->n_win : 1u;
+        const bool windows = !u->expanded && u->tiled;
+        swept_windows = windows ? n_win : 1u;
         if (!u->expanded) {   // the vote codes (and the region layout, the last copy of the upload) are first needed by the sweep
-            const size_t n_bases = u->n_codes * 4;
-            if (early) HIP_OK(hipStreamWaitEvent(st, u->ev_uploaded, 0));      // (at most the tail of this unit's own upload: nothing else is ever waited for on a build stream)
-            if (u->rows_diffed) agx_launch_expand_rows(u->d_whits.p, (agx_u32)nh, u->d_wsides.p, u->d_wruns.p, u->d_anchor.p, u->d_blockfirst.p, u->d_rowcnt.p, u->d_blockoff.p, u->d_units.p, u->d_wref.p, u->d_vcodes.p, u->n_rows, u->stride, u->d_other.p, u->n_other, st);
-            else agx_launch_expand_codes(u->d_codes.p, u->d_vcodes.p, (n_bases + 15) / 16 * 16, u->d_other.p, u->n_other, st);
-            if (u->ref_packed) agx_launch_expand_ref(u->d_wref.p, u->d_ref.p, ((size_t)n_pos + 15) / 16 * 16, u->d_refx.p, (agx_u32)u->n_refx, st);      // (the letters are first read by the sweep's write-out)
+            if (!windows) {
+                const size_t n_bases = codes_bytes(u) * 4;
+                if (early) HIP_OK(hipStreamWaitEvent(st, u->ev_uploaded, 0));      // (at most the tail of this unit's own upload: nothing else is ever waited for on a build stream)
+                if (u->rows_diffed) agx_launch_expand_rows(u->d_whits.p, (agx_u32)nh, u->d_wsides.p, u->d_wruns.p, u->d_anchor.p, u->d_blockfirst.p, u->d_rowcnt.p, u->d_blockoff.p, u->d_units.p, u->d_wref.p, u->d_vcodes.p, u->n_rows, u->stride, u->d_other.p, u->n_other, st);
+                else agx_launch_expand_codes(u->d_codes.p, u->d_vcodes.p, (n_bases + 15) / 16 * 16, u->d_other.p, u->n_other, st);
+                if (u->ref_packed) agx_launch_expand_ref(u->d_wref.p, u->d_ref.p, ((size_t)n_pos + 15) / 16 * 16, u->d_refx.p, (agx_u32)u->n_refx, st);      // (the letters are first read by the sweep's write-out)
+            } else {
+                if (early) HIP_OK(hipStreamWaitEvent(st, u->ev_rows[0], 0));       // (the small arrays travel in front of the first piece of rows: with it the reference and the region layout are in)
+                if (u->ref_packed) agx_launch_expand_ref(u->d_wref.p, u->d_ref.p, ((size_t)n_pos + 15) / 16 * 16, u->d_refx.p, (agx_u32)u->n_refx, st);
+            }
             u->expanded = true;
         }
         HIP_OK(hipEventRecord(u->ev_front, st));
+        if (windows) {      // still on the front stream, behind ev_front: the rows of window w out of their 2-bit form when they are in, then the listed bases among them
+            const size_t s4 = u->stride / 4;
+            for (agx_u32 w = 0; w < n_win; w++) {
+                const size_t r_lo = win_row(u, w), r_hi = win_row(u, w + 1);
+                if (early && w) HIP_OK(hipStreamWaitEvent(st, u->ev_rows[w], 0));
+                const unsigned long long *ob = u->s_other_t.p, *oe = ob + u->n_other_t;
+                const size_t o_lo = (size_t)(std::lower_bound(ob, oe, (unsigned long long)r_lo * u->stride) - ob), o_hi = (size_t)(std::lower_bound(ob, oe, (unsigned long long)r_hi * u->stride) - ob);
+                // (pieces begin at multiples of 16 rows: whole 16-base groups, 16-byte aligned stores; the last piece is padded like the whole array was)
+                const size_t b_lo = r_lo * s4 * 4, b_hi = w + 1 == n_win ? (codes_bytes(u) * 4 + 15) / 16 * 16 : r_hi * s4 * 4;
+                agx_launch_expand_codes(u->d_codes.p + r_lo * s4, u->d_vcodes.p + b_lo, b_hi - b_lo, nullptr, 0, st);
+                agx_launch_patch_codes(u->d_other.p + o_lo, o_hi - o_lo, u->d_vcodes.p, st);
+                HIP_OK(hipEventRecord(u->ev_win[w], st));
+            }
+        }
         // ---- main stream ----
         st = turn.main;
         HIP_OK(hipStreamWaitEvent(st, u->ev_front, 0));
@@ -1019,7 +1129,12 @@ void do_build(agx_unit *u) {
         K.list_cap = u->list_cap; K.big_n = u->d_words.p + W_BIGCOUNT; K.scratch = u->d_scratch.p;
         K.slow_list = u->d_slow_list.p; K.slow_count = u->d_words.p + W_SLOWCOUNT; K.fallback_queued = 1u;
         K.huge_count = u->d_words.p + W_HUGECOUNT; K.huge_n = u->d_words.p + W_HUGECOUNT; K.huge_list = u->d_huge_list.p; K.scratch_huge = u->d_scratch_huge.p; K.huge_queued = u->huge ? 1u : 0u;
-        agx_launch_node_sweep(&K, st);
+        for (agx_u32 w = 0; w < n_win; w++) {
+            K.tile_lo = windows ? u->win_tile[w] : 0u; K.tile_hi = windows ? u->win_tile[w + 1] : u->n_tiles;
+            if (windows) { HIP_OK(hipStreamWaitEvent(st, u->ev_win[w], 0)); if (n_win > 1) HIP_OK(hipEventRecord(u->ev_sw0[w], st)); }
+            agx_launch_node_sweep(&K, st);
+            if (windows && n_win > 1) HIP_OK(hipEventRecord(u->ev_sw1[w], st));
+        }
         AGX_CHECKPOINT("node_sweep");
         u->ev.mark(B_NODE, st); u->stats.node_sweep_launches++;
         hipEvent_t trace_from = turn.prev_node; turn.prev_node = u->ev.e[B_NODE];
@@ -1132,6 +1247,10 @@ void do_build(agx_unit *u) {
     u->built = true; u->downloaded = false;
     u->stats.ms_build_span = u->ev.all ? u->ev.span() : 0.0;
     u->stats.ms_prep = u->ev.ms(B_PREP); u->stats.ms_bin = u->ev.ms(B_BIN); u->stats.ms_node_sweep = u->ev.ms(B_NODE);
+    if (swept_windows > 1) {      // a windowed first build: the sweep's time is the sum over its windows (between them the stream may have waited for rows that were still travelling)
+        double sum = 0; for (agx_u32 w = 0; w < swept_windows; w++) { float f = 0; if (hipEventElapsedTime(&f, u->ev_sw0[w], u->ev_sw1[w]) == hipSuccess) sum += f; else (void)hipGetLastError(); }
+        u->stats.ms_node_sweep = sum;
+    }
     u->stats.ms_node_big = u->ev.ms(B_BIG); u->stats.ms_edge_fast = u->ev.ms(B_EDGE); u->stats.ms_edge_slow = u->ev.ms(B_SLOW); u->stats.ms_edge_sweep = u->stats.ms_edge_fast + u->stats.ms_edge_slow; u->stats.ms_compact = u->ev.ms(B_COMPACT);
     if (u->up_timed) { float f = 0; if (hipEventElapsedTime(&f, u->ev_up0, u->ev_uploaded) == hipSuccess) u->stats.ms_upload_dev = f; else (void)hipGetLastError(); }
 }
@@ -1144,7 +1263,8 @@ void download_buffers(agx_unit *u) {
     if (u->prm.flags & AGX_FLAG_ONE_SHOT) {
         // The inputs are in HBM and will not be uploaded again: their staged copies are dead pinned memory.  The download's arrays are cut
         // from the largest of those blocks, largest array first; what does not fit (thin read sets) gets a buffer of its own below.
-        struct Room { char *at; size_t left; } room[6] = {{(char *)u->s_codes.p, u->s_codes.block_bytes()}, {(char *)u->s_hits.p, u->s_hits.block_bytes()}, {(char *)u->s_landing.p, u->s_landing.block_bytes()},
+        struct Room { char *at; size_t left; } room[8] = {{(char *)u->s_codes.p, u->s_codes.block_bytes()}, {(char *)u->s_hits.p, u->s_hits.block_bytes()}, {(char *)u->s_landing.p, u->s_landing.block_bytes()},
+                                                          {(char *)u->s_codes_t.p, u->s_codes_t.block_bytes()}, {(char *)u->s_hits_t.p, u->s_hits_t.block_bytes()},
                                                           {(char *)u->s_runs.p, u->s_runs.block_bytes()}, {(char *)u->s_sides.p, u->s_sides.block_bytes()}, {(char *)u->s_other.p, u->s_other.block_bytes()}};
         // (a loan from an earlier download of this unit object must not survive into alloc() below: the memory it names has been handed out again)
         u->h_sp_node.release(); u->h_a_meta.release(); u->h_a_str.release(); u->h_sp_hop.release(); u->h_side_xpos.release(); u->h_sp_bits.release(); u->h_sp_rank.release(); u->h_a_ovf.release();
@@ -1424,6 +1544,7 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
         for (hipEvent_t *e : {&u->ev_front, &u->ev_passA, &u->ev_passJ}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         for (hipEvent_t *e : {&u->ev_dl, &u->ev_built, &u->ev_hits}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         HIP_OK(hipEventCreate(&u->ev_up0)); HIP_OK(hipEventCreate(&u->ev_uploaded));
+        for (int i = 0; i < 8; i++) { HIP_OK(hipEventCreateWithFlags(&u->ev_rows[i], hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&u->ev_win[i], hipEventDisableTiming)); HIP_OK(hipEventCreate(&u->ev_sw0[i])); HIP_OK(hipEventCreate(&u->ev_sw1[i])); }
         u->dl_sdma = hsa_copy().agent_of(p->device, u->dl_agent) && hsa_signal_create(0, 0, nullptr, &u->dl_signal) == HSA_STATUS_SUCCESS;
     });
     if (rc != AGX_OK) { delete u; return rc; }

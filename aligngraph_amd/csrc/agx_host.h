@@ -67,6 +67,9 @@ struct UnitView {
     // and the list of the bases that are not A, C, G, T (index r * stride + j, ascending) with their bytes.  Units whose read alignments were handed over staged (tmp/_agx_pairs.<u>.bin) have
     // nothing else; the arrays live in the mapped file (the pinned copies are gone once a one-shot unit has been downloaded).
     const agx_u8 *codes2 = nullptr; const unsigned long long *other_idx = nullptr; const agx_u8 *other_byte = nullptr; size_t n_other = 0;
+    // r06, tile-ordered upload: the device numbers the read rows by the hit's place in the tile order (every hit's left-mate row travels at that place); slot_row[place] = the row
+    // of the staged arrays above (null: the k-mer string references name those rows themselves)
+    const agx_u32 *slot_row = nullptr;
     bool has_cm(size_t x) const { return cm_cnt ? cm_cnt[x] != 0 : cm_start[x + 1] > cm_start[x]; }
     agx_u32 cm_count(size_t x) const { return cm_cnt ? cm_cnt[x] : cm_start[x + 1] - cm_start[x]; }
     const char *initial = nullptr; size_t n_initial = 0;              // bytes of tmp/_initial_contigs.<u>.fa

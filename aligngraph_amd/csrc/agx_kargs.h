@@ -12,6 +12,9 @@ struct agx_prep_args {
     // filter over a window of the order (agx_k_tile_fill).  ckey[i] = the last tile hit i reaches (NONE: dropped, or LONG — it spans `lookback` tiles or more and is
     // listed in long_list instead; more than AGX_LONG_MAX of those: every list of the unit is made by scatter, agx_k_bin_fill + agx_k_tile_sort)
     const agx_u32 *perm, *tile_first; agx_u32 *ckey; agx_u32 lookback; agx_u32 *long_list, *long_count;
+    // r06, tile-ordered upload (tiled != 0): whits[i] IS the i-th hit of the tile order — its `row` field carries the hit's number, its left-mate row is row i, AGX_WF_DUP says
+    // what the file neighbours would have said — and perm_out[i] = that number is written here for the tile lists (4 bytes per hit less to upload, no gather of wire records)
+    agx_u32 tiled; agx_u32 *perm_out;
 };
 
 // the fallback (more than AGX_LONG_MAX long hits): every hit takes its places in dense lists from a counter per tile
@@ -20,6 +23,7 @@ struct agx_bin_args { const agx_dhit *dhit; agx_u32 n_hits; const agx_u32 *tile_
 
 struct agx_node_kargs {
     agx_sweep_args S;
+    agx_u32 tile_lo, tile_hi;  // pass 0 sweeps tiles [tile_lo, tile_hi): a unit's first build sweeps a window of tiles as soon as its read rows have landed (r06)
     agx_u32 *pool_cnt;         // node ids handed out per region (counter r at pool_cnt[r * AGX_REGION_PAD]); keeps counting past the slice's end
     const agx_u32 *region_off; // [regions + 1] first node id of every region's slice of the pool
     agx_u32 spill_lo; agx_u32 *spill_cnt;   // ids [spill_lo, pool_cap) behind the slices, for regions whose slice is full (one counter)
@@ -57,6 +61,7 @@ void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16,
 // position n_pos + 15; stride <= AGX_ROW_MAXSTRIDE
 void agx_launch_expand_rows(const void *whits, agx_u32 nh, const void *wsides, const void *wruns, const agx_u32 *anchor_bits, const agx_u32 *block_first, const agx_u8 *cnt, const agx_u32 *block_off,
                             const agx_u16 *units, const void *wref, void *vcodes, agx_u32 n_rows, agx_u32 stride, const unsigned long long *other, size_t n_other, hipStream_t);
+void agx_launch_patch_codes(const unsigned long long *other, size_t n_other, void *vcodes, hipStream_t);      // the listed bases alone (indices into the whole vote-code array)
 void agx_launch_expand_runs(const void *wruns, agx_run *runs, agx_u32 n_runs, hipStream_t);      // wire formats (agx_core.h) -> working arrays
 void agx_launch_expand_ref(const void *packed, void *ref, size_t n_pos16, const void *refx, agx_u32 n_refx, hipStream_t);      // 2-bit reference bases + the stretches of other bytes -> letters; n_pos16 a multiple of 16
 void agx_launch_hit_prep(const agx_prep_args *, hipStream_t);

@@ -147,11 +147,15 @@ __global__ void __launch_bounds__(256) agx_k_hit_prep(agx_prep_args A) {
     const bool mine = i < A.n_hits;
     agx_dhit d; d.flags = AGX_HF_SKIP; d.x_lo = 1; d.x_hi = 0; d.a_nruns = 0;
     if (mine) {
-        const agx_u32 h = A.perm[i];
         // the hit straight from its wire record (16 bytes, + 12 for the three in eight with a multi-run mate)
         const agx_whit *wh = A.whits; const agx_wside *sd = A.sides;
-        const agx_hit H = agx_unpack_hit(wh[h], sd);
-        const int rc = agx_hit_prep(H, H.back != 0 && agx_hit_dup_by([wh, sd](agx_u32 j) { return agx_unpack_hit(wh[j], sd); }, A.runs, h), (H.pad[0] & 1u) != 0, H.slot1, A.runs, A.k, d);      // staged hit: slot1 = row of the a mate's bases
+        const agx_u32 h = A.tiled ? i : A.perm[i];
+        const agx_whit w = wh[h];
+        const agx_hit H = agx_unpack_hit(w, sd);
+        bool dup; agx_u32 row;
+        if (A.tiled) { dup = (w.flags & AGX_WF_DUP) != 0; row = i; A.perm_out[i] = w.row; }      // (the record's row field carries the hit's number: the key the tile lists are ranked by)
+        else { dup = H.back != 0 && agx_hit_dup_by([wh, sd](agx_u32 j) { return agx_unpack_hit(wh[j], sd); }, A.runs, h); row = H.slot1; }
+        const int rc = agx_hit_prep(H, dup, (H.pad[0] & 1u) != 0, row, A.runs, A.k, d);      // staged hit: row of the a mate's bases
         if (rc) atomicOr(A.err, 1u);
         if (!(d.flags & AGX_HF_SKIP) && (d.x_hi >= A.n_pos || d.x_lo > d.x_hi)) { atomicOr(A.err, 2u); d.flags |= AGX_HF_SKIP; }
     }
@@ -474,8 +478,8 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
     if (BIG) { b.base = (PASS == 3 ? K.scratch_huge : K.scratch) + (size_t)slot * (AGX_NF * MAXV_G * 64) + lane; b.maxv = MAXV_G; }
     else { b.base = &lds[wave][lane]; b.maxv = MAXV; }
     // pass 0: one tile per wavefront.  Passes 1 and 2: a fixed set of wavefronts strides over the list of overflowed tiles.
-    const agx_u32 n_work = PASS == 0 ? K.S.n_tiles : __builtin_amdgcn_readfirstlane(*(PASS == 1 ? K.mid_n : PASS == 2 ? K.big_n : K.huge_n));
-    for (agx_u32 w = slot; w < n_work; w += PASS == 0 ? 0xFFFFFFFFu : PASS == 1 ? AGX_MID_WAVES : PASS == 2 ? AGX_BIG_WAVES : AGX_HUGE_WAVES) {
+    const agx_u32 n_work = PASS == 0 ? K.tile_hi : __builtin_amdgcn_readfirstlane(*(PASS == 1 ? K.mid_n : PASS == 2 ? K.big_n : K.huge_n));
+    for (agx_u32 w = (PASS == 0 ? K.tile_lo : 0u) + slot; w < n_work; w += PASS == 0 ? 0xFFFFFFFFu : PASS == 1 ? AGX_MID_WAVES : PASS == 2 ? AGX_BIG_WAVES : AGX_HUGE_WAVES) {
         const agx_u32 tile = PASS == 0 ? w : __builtin_amdgcn_readfirstlane((PASS == 1 ? K.mid_list : PASS == 2 ? K.big_list : K.huge_list)[w]);
         if (K.S.tile_off[tile + 1] > K.list_cap) { if (lane == 0) atomicOr(K.status, 4u); return; }      // lists did not fit: nothing after the sweeps may run
         const agx_u32 X = tile * AGX_TILE + lane;
@@ -843,6 +847,9 @@ void agx_launch_expand_codes(const void *packed, void *vcodes, size_t n_bases16,
     if (n16) hipLaunchKernelGGL(agx_k_expand_codes, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const agx_u32 *)packed, (uint4 *)vcodes, n16);
     if (n_other) hipLaunchKernelGGL(agx_k_patch_codes, dim3((unsigned)((n_other + 255) / 256)), dim3(256), 0, st, other, n_other, (agx_u8 *)vcodes);
 }
+void agx_launch_patch_codes(const unsigned long long *other, size_t n_other, void *vcodes, hipStream_t st) {
+    if (n_other) hipLaunchKernelGGL(agx_k_patch_codes, dim3((unsigned)((n_other + 255) / 256)), dim3(256), 0, st, other, n_other, (agx_u8 *)vcodes);
+}
 void agx_launch_expand_rows(const void *whits, agx_u32 nh, const void *wsides, const void *wruns, const agx_u32 *anchor_bits, const agx_u32 *block_first, const agx_u8 *cnt, const agx_u32 *block_off,
                             const agx_u16 *units, const void *wref, void *vcodes, agx_u32 n_rows, agx_u32 stride, const unsigned long long *other, size_t n_other, hipStream_t st) {
     if (n_rows) hipLaunchKernelGGL(agx_k_expand_rows, dim3((n_rows + 63u) / 64u), dim3(64), 64u * stride, st, (const agx_whit *)whits, nh, (const agx_wside *)wsides, (const agx_wrun *)wruns, anchor_bits, block_first,
@@ -914,7 +921,7 @@ void agx_launch_tile_sort(const agx_fill_args *A, hipStream_t st) {
     if (A->n_tiles) hipLaunchKernelGGL(agx_k_tile_sort, dim3((A->n_tiles + AGX_WAVES_PER_BLOCK - 1) / AGX_WAVES_PER_BLOCK), dim3(256), 0, st, *A);
 }
 void agx_launch_node_sweep(const agx_node_kargs *K, hipStream_t st) {
-    const agx_u32 n = K->S.n_tiles;
+    const agx_u32 n = K->tile_hi > K->tile_lo ? K->tile_hi - K->tile_lo : 0u;
     // a multiple of the XCD count so that every XCD's share has the same number of blocks (blocks past the last tile do nothing)
     const agx_u32 nb = (n + AGX_SWEEP_WAVES - 1) / AGX_SWEEP_WAVES, grid = (nb + AGX_XCDS - 1) / AGX_XCDS * AGX_XCDS;
     if (n) hipLaunchKernelGGL(agx_k_node_sweep<0>, dim3(grid), dim3(64 * AGX_SWEEP_WAVES), 0, st, *K);

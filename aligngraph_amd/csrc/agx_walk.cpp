@@ -373,7 +373,8 @@ struct Walker {
     }
     // k-mer string of node v from its read reference (agx_sref)
     void kmer_string(agx_u32 v, std::string &out) const {
-        const agx_sref r = node(v).sref;
+        agx_sref r = node(v).sref;
+        if (V.slot_row) r.slot = V.slot_row[r.slot];      // (tile-ordered upload: the device's row numbers are places in the tile order)
         const agx_u32 first = r.qlen & 0xFFFFu, len = (r.qlen >> 16) & 0x7FFFu; const bool rev = (r.qlen >> 31) != 0;
         out.clear();
         if (!V.bases) {      // the staged 2-bit rows are all there is (agx_host.h: UnitView::codes2): classes back to letters, the listed other bases by their bytes

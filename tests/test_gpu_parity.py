@@ -301,6 +301,31 @@ def test_walk_by_several_walkers_gives_the_same_bytes(agx, built, tmp_path, monk
                 assert got[key] == want[key], (walkers, warm, flags, key)
 
 
+@pytest.mark.parametrize("L", [100, 57])
+def test_tile_ordered_upload_and_a_sweep_by_windows(agx, built, tmp_path, monkeypatch, L):
+    """r06 (agx_engine.cpp: stage_tiled): the wire records and the read rows cross in the order of the hits' first tiles — the record carries the hit's number instead of a row, the
+    rule of AG:1650-1655 is decided where the arrays are staged, every hit's left-mate row travels at the hit's place — and a unit's first build expands the rows and sweeps the tiles
+    window by window as the pieces of the upload land (forced here on a small unit: AGX_UPLOAD_WINDOWS).  Reads with many second hits (rows sent twice, later hits dropped), many
+    bases that are not A, C, G, T (the re-indexed list of them, patched window by window) and a read length whose rows are not a multiple of 16 bytes; the node and edge tables and
+    the three outputs against the oracle for every number of windows, for r05's forms (AGX_NO_TILED_UPLOAD) and with every capacity regrown (the repeated builds sweep in one piece)."""
+    run = H.synth(str(tmp_path / "run"), seed=83, chroms="300000", pairs=70000, L=L, coverage=4, read_indel=0.2, multi=0.3, multi_near=0.5, read_n=0.01, contig_overlap=0.3, sam_seq=0)
+    tmp = os.path.join(run, "tmp")
+    want = H.run_oracle(tmp, 0, 5, 50, 4, graph=True)
+    for windows, flags, env in (("1", 0, {}), ("2", 0, {}), ("3", agx.AGX_FLAG_ONE_SHOT, {}), ("8", 0, {}), ("5", agx.AGX_FLAG_ONE_SHOT, {"AGX_NO_CACHE": "1"}), ("4", 0, {"AGX_TEST_SMALL_CAPS": "1"}),
+                                ("3", 0, {"AGX_NO_TILED_UPLOAD": "1"})):
+        monkeypatch.setenv("AGX_UPLOAD_WINDOWS", windows)
+        for k2, v2 in env.items():
+            monkeypatch.setenv(k2, v2)
+        got = run_engine(agx, tmp, 0, 5, 50, 4, graph=(flags == 0), flags=flags)
+        for k2 in env:
+            monkeypatch.delenv(k2)
+        for key in ("initial", "pre", "extended"):
+            assert got[key] == want[key], (windows, flags, env, key)
+        if flags == 0:
+            assert graph_mismatch(want["graph"], got["graph"]) is None, (windows, env)
+        assert got["stats"]["ms_node_sweep"] > 0
+
+
 def test_walk_begins_while_the_download_is_still_arriving(agx, built, tmp_path, monkeypatch):
     """r06, the streamed download (agx_engine.cpp: begin_streamed_download): agx_unit_finish on a unit that has not been downloaded sends the walk graph down in position windows
     from the front (forced here on a small unit: AGX_STREAM_PIECES), the walkers wait for their windows, the first one for all of them, the bases come last.  The walkers' own bytes
