@@ -501,7 +501,11 @@ void stage_tiled(agx_unit *u, unsigned threads) {
     const unsigned T = std::max(1u, std::min(threads, 16u));
     std::vector<std::vector<unsigned long long>> others(T);
     on_threads(T, [&](unsigned t) {
+        // (two dependent random reads per hit — its record, then its row: asked for a few hits ahead, or every hit costs two cache misses in a row: 0.16 s of cfg3's load)
+        const size_t AHEAD = 16, NEAR = 6;
         for (size_t i = nh * t / T, hi = nh * (t + 1) / T; i < hi; i++) {
+            if (i + AHEAD < hi) __builtin_prefetch(wh + perm[i + AHEAD]);
+            if (i + NEAR < hi) { const char *c = (const char *)(u->s_codes.p + (size_t)wh[perm[i + NEAR]].row * s4); __builtin_prefetch(c); if (s4 > 40) __builtin_prefetch(c + 64); }
             const agx_u32 h = perm[i]; agx_whit w = wh[h];
             const agx_u32 row = w.row;
             u->slot_row[i] = row;
@@ -1031,7 +1035,7 @@ void do_build(agx_unit *u) {
     const agx_u32 n_pos = (agx_u32)u->V.n_pos, nh = (agx_u32)u->nh;
     hipStream_t st = nullptr;              // the device's build stream, taken with the turn
     u->stats.node_sweep_launches = u->stats.edge_sweep_launches = 0;
-    agx_u32 swept_windows = 1;             // of the last attempt
+    agx_u32 swept_windows = 1; bool swept_timed = false;      // of the last attempt
     for (int attempt = 0;; attempt++) {
         if (attempt > 8) throw Error{E_DEVICE, "build did not converge"};
         const size_t ids_cap = (size_t)n_pos + u->pool_cap;                       // side variants <= nodes <= pool_cap
@@ -1085,7 +1089,7 @@ void do_build(agx_unit *u) {
         // hits are one piece, in front of which lie the rows of every earlier tile: stage_tiled) — the sweep of the unit's front runs beside the upload of its back
         const agx_u32 n_win = (!u->expanded && u->tiled) ? u->n_win : 1u;
         const bool windows = !u->expanded && u->tiled;
-        swept_windows = windows ? n_win : 1u;
+        swept_windows = windows ? n_win : 1u; swept_timed = windows;
         if (!u->expanded) {   // the vote codes (and the region layout, the last copy of the upload) are first needed by the sweep
             if (!windows) {
                 const size_t n_bases = codes_bytes(u) * 4;
@@ -1131,9 +1135,9 @@ void do_build(agx_unit *u) {
         K.huge_count = u->d_words.p + W_HUGECOUNT; K.huge_n = u->d_words.p + W_HUGECOUNT; K.huge_list = u->d_huge_list.p; K.scratch_huge = u->d_scratch_huge.p; K.huge_queued = u->huge ? 1u : 0u;
         for (agx_u32 w = 0; w < n_win; w++) {
             K.tile_lo = windows ? u->win_tile[w] : 0u; K.tile_hi = windows ? u->win_tile[w + 1] : u->n_tiles;
-            if (windows) { HIP_OK(hipStreamWaitEvent(st, u->ev_win[w], 0)); if (n_win > 1) HIP_OK(hipEventRecord(u->ev_sw0[w], st)); }
+            if (windows) { HIP_OK(hipStreamWaitEvent(st, u->ev_win[w], 0)); HIP_OK(hipEventRecord(u->ev_sw0[w], st)); }      // (behind the wait: the sweep's time must not hold the rows' journey)
             agx_launch_node_sweep(&K, st);
-            if (windows && n_win > 1) HIP_OK(hipEventRecord(u->ev_sw1[w], st));
+            if (windows) HIP_OK(hipEventRecord(u->ev_sw1[w], st));
         }
         AGX_CHECKPOINT("node_sweep");
         u->ev.mark(B_NODE, st); u->stats.node_sweep_launches++;
@@ -1247,7 +1251,7 @@ void do_build(agx_unit *u) {
     u->built = true; u->downloaded = false;
     u->stats.ms_build_span = u->ev.all ? u->ev.span() : 0.0;
     u->stats.ms_prep = u->ev.ms(B_PREP); u->stats.ms_bin = u->ev.ms(B_BIN); u->stats.ms_node_sweep = u->ev.ms(B_NODE);
-    if (swept_windows > 1) {      // a windowed first build: the sweep's time is the sum over its windows (between them the stream may have waited for rows that were still travelling)
+    if (swept_windows >= 1 && swept_timed) {      // a windowed first build: the sweep's time is the sum over its windows (between them the stream may have waited for rows that were still travelling)
         double sum = 0; for (agx_u32 w = 0; w < swept_windows; w++) { float f = 0; if (hipEventElapsedTime(&f, u->ev_sw0[w], u->ev_sw1[w]) == hipSuccess) sum += f; else (void)hipGetLastError(); }
         u->stats.ms_node_sweep = sum;
     }
