@@ -393,14 +393,19 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
 // upload that finds nothing staged).  The read bases cross PCIe as 2-bit classes plus a list of the few bases that are not A, C, G or T
 // (agx_pack_classes2): a quarter of the bytes of the largest array.  The read alignments are staged by stage_pairs() (agx_load.cpp) —
 // or were written into the staged buffers by the fast loader while it parsed (u->pairs_staged).
+// The file-order wire records and read rows of a unit that will upload their tile-ordered forms (stage_tiled) are only ever read by the host — the gather into those forms, the
+// cache file, the row codec — so they live in ordinary memory: pinning a second copy of a unit's two largest arrays cost its load 0.2 ms per MB.  r05's forms (AGX_ROW_DIFF,
+// AGX_NO_TILED_UPLOAD) are uploaded from them and keep them pinned.
+inline bool want_tiled() { const char *rd = getenv("AGX_ROW_DIFF"); return !getenv("AGX_NO_TILED_UPLOAD") && !(rd && atoi(rd) != 0); }
+template <class B> inline void alloc_file_order(B &buf, size_t count) { if (want_tiled()) buf.alloc_plain(count); else buf.alloc(count); }
 struct UnitSink : StageSink {
     agx_unit *u; explicit UnitSink(agx_unit *x) : u(x) {}
     void *take(int which, size_t bytes) override {
         switch (which) {
-        case SA_HITS:  u->s_hits.alloc(bytes / sizeof(agx_whit) + 1); return u->s_hits.p;
+        case SA_HITS:  alloc_file_order(u->s_hits, bytes / sizeof(agx_whit) + 1); return u->s_hits.p;
         case SA_SIDES: u->s_sides.alloc(bytes / sizeof(agx_wside) + 1); return u->s_sides.p;
         case SA_RUNS:  u->s_runs.alloc(bytes / sizeof(agx_wrun) + 1); return u->s_runs.p;
-        case SA_CODES: u->s_codes.alloc(bytes); return u->s_codes.p;
+        case SA_CODES: alloc_file_order(u->s_codes, bytes); return u->s_codes.p;
         case SA_JUMP:  u->s_jump.alloc(bytes / 4 + 1); return u->s_jump.p;
         default:       u->s_other.alloc(bytes / 8 + 1); return u->s_other.p;
         }
@@ -486,7 +491,7 @@ void stage_order(agx_unit *u, unsigned threads) {
 void stage_tiled(agx_unit *u, unsigned threads) {
     u->tiled = false; u->n_other_t = 0; u->slot_row.clear(); u->n_win = 1;
     const size_t nh = u->nh, s4 = u->stride / 4;
-    if (u->rows_diffed || getenv("AGX_NO_TILED_UPLOAD") || nh == 0 || u->n_rows == 0) { u->s_hits_t.release(); u->s_codes_t.release(); u->s_other_t.release(); return; }
+    if (u->rows_diffed || !want_tiled() || nh == 0 || u->n_rows == 0) { u->s_hits_t.release(); u->s_codes_t.release(); u->s_other_t.release(); return; }
     const double t0 = now_ms();
     u->s_hits_t.alloc(nh + 1); u->s_codes_t.alloc(nh * s4 + 16); u->slot_row.resize(nh);
     const agx_whit *wh = u->s_hits.p; const agx_wside *sd = u->s_sides.p; const agx_wrun *wr = u->s_runs.p; const agx_u32 *perm = u->s_perm.p;
@@ -502,7 +507,7 @@ void stage_tiled(agx_unit *u, unsigned threads) {
     std::vector<std::vector<unsigned long long>> others(T);
     on_threads(T, [&](unsigned t) {
         // (two dependent random reads per hit — its record, then its row: asked for a few hits ahead, or every hit costs two cache misses in a row: 0.16 s of cfg3's load)
-        const size_t AHEAD = 16, NEAR = 6;
+        const size_t AHEAD = 48, NEAR = 24;
         for (size_t i = nh * t / T, hi = nh * (t + 1) / T; i < hi; i++) {
             if (i + AHEAD < hi) __builtin_prefetch(wh + perm[i + AHEAD]);
             if (i + NEAR < hi) { const char *c = (const char *)(u->s_codes.p + (size_t)wh[perm[i + NEAR]].row * s4); __builtin_prefetch(c); if (s4 > 40) __builtin_prefetch(c + 64); }
@@ -687,7 +692,7 @@ void load_staged_pairs(agx_unit *u, agx::PairsFile &F) {
     if (H.k != u->prm.k || H.batch != u->prm.batch) throw Error{E_ARG, "tmp/_agx_pairs: staged for another k or another BATCH than this unit's"};
     u->nh = H.nh; u->n_runs = H.n_runs; u->n_sides = H.n_sides; u->n_jump = H.n_jump; u->n_codes = H.n_codes; u->n_other = H.n_other; u->stride = H.stride; u->maxlen = H.maxlen; u->n_rows = H.n_rows;
     u->pairs_in_file = H.pairs_in_file; u->sam_pairs = H.sam_pairs; u->n_slots = 0; u->row_off.clear(); u->row_slot.clear(); u->reads_keep.reset(); u->reads_map.reset();
-    u->s_hits.alloc(u->nh + 1); u->s_sides.alloc(u->n_sides + 1); u->s_jump.alloc(u->n_jump + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16); u->s_other.alloc(u->n_other + 1);
+    alloc_file_order(u->s_hits, u->nh + 1); u->s_sides.alloc(u->n_sides + 1); u->s_jump.alloc(u->n_jump + 1); u->s_runs.alloc(u->n_runs + 1); alloc_file_order(u->s_codes, u->n_codes + 16); u->s_other.alloc(u->n_other + 1);
     struct Piece { void *dst; const char *src; size_t len; };
     std::vector<Piece> pieces;
     auto cut = [&](void *dst, int sec) { for (unsigned long long a = 0; a < H.len[sec]; a += 32ull << 20) pieces.push_back(Piece{(char *)dst + a, F.sec(sec) + a, (size_t)std::min<unsigned long long>(32ull << 20, H.len[sec] - a)}); };
@@ -732,7 +737,7 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     const char *base = (const char *)m;
     u->nh = H.nh; u->n_runs = H.n_runs; u->n_sides = H.n_sides; u->n_jump = H.n_jump; u->n_cm = H.n_cm; u->n_segs = H.n_segs; u->n_seg0 = (agx_u32)H.n_seg0; u->n_chain_end = (agx_u32)H.n_chain_end; u->n_codes = H.n_codes; u->n_other = H.len[S_OTHER] / 8;
     u->pairs_in_file = H.pairs_in_file; u->sam_pairs = H.sam_pairs; u->stride = H.stride; u->maxlen = H.maxlen; u->n_slots = H.n_slots; u->n_rows = (agx_u32)H.n_rows;
-    u->s_hits.alloc(u->nh + 1); u->s_sides.alloc(u->n_sides + 1); u->s_jump.alloc(u->n_jump + 1); u->s_runs.alloc(u->n_runs + 1); u->s_codes.alloc(u->n_codes + 16); u->s_other.alloc(u->n_other + 1); u->s_segs.alloc(u->n_segs + 1); u->s_chain_end.alloc((size_t)u->n_chain_end + 1);
+    alloc_file_order(u->s_hits, u->nh + 1); u->s_sides.alloc(u->n_sides + 1); u->s_jump.alloc(u->n_jump + 1); u->s_runs.alloc(u->n_runs + 1); alloc_file_order(u->s_codes, u->n_codes + 16); u->s_other.alloc(u->n_other + 1); u->s_segs.alloc(u->n_segs + 1); u->s_chain_end.alloc((size_t)u->n_chain_end + 1);
     // the staged arrays: read into the pinned buffers, a few threads, large pieces
     struct Piece { void *dst; unsigned long long off, len; };
     std::vector<Piece> pieces;

@@ -215,13 +215,20 @@ inline void host_trim() {
 
 template <class T> struct PBuf {            // pinned host buffer: one cached block each
     T *p = nullptr; size_t n = 0; MemBlock blk;
+    Scratch plain;                           // alloc_plain: ordinary memory from the loaders' scratch cache instead (r06: the file-order forms of a unit that uploads tile-ordered ones are never copied from by the device)
     void alloc(size_t count) {
-        if (count <= n && p) return;
+        if (count <= n && p && blk.p) return;
         release();
         if (!count) return;
         blk = host_block(count * sizeof(T)); p = (T *)blk.p; n = blk.n / sizeof(T);
     }
-    void release() { host_cache().give(blk); blk = MemBlock(); p = nullptr; n = 0; }
+    void alloc_plain(size_t count) {
+        if (count <= n && p && !blk.p) return;
+        release();
+        if (!count) return;
+        plain.take(count * sizeof(T)); p = (T *)plain.p; n = plain.n / sizeof(T);
+    }
+    void release() { host_cache().give(blk); blk = MemBlock(); plain.give(); p = nullptr; n = 0; }
     void borrow(T *host, size_t count) { release(); p = host; n = count; }      // a piece of another buffer's block (pinned by its owner, who outlives the loan)
     size_t block_bytes() const { return blk.n; }
     void *dev() const { void *d = nullptr; if (p) AGX_HIP_OK(hipHostGetDevicePointer(&d, p, 0)); return d; }      // the address kernels use for this buffer
