@@ -217,13 +217,13 @@ template <class T> struct PBuf {            // pinned host buffer: one cached bl
     T *p = nullptr; size_t n = 0; MemBlock blk;
     Scratch plain;                           // alloc_plain: ordinary memory from the loaders' scratch cache instead (r06: the file-order forms of a unit that uploads tile-ordered ones are never copied from by the device)
     void alloc(size_t count) {
-        if (count <= n && p && blk.p) return;
+        if (count <= n && p && !plain.p) return;      // (also a loan from another buffer's block: borrow)
         release();
         if (!count) return;
         blk = host_block(count * sizeof(T)); p = (T *)blk.p; n = blk.n / sizeof(T);
     }
     void alloc_plain(size_t count) {
-        if (count <= n && p && !blk.p) return;
+        if (count <= n && p && plain.p) return;
         release();
         if (!count) return;
         plain.take(count * sizeof(T)); p = (T *)plain.p; n = plain.n / sizeof(T);
