@@ -491,7 +491,8 @@ void stage_order(agx_unit *u, unsigned threads) {
 void stage_tiled(agx_unit *u, unsigned threads) {
     u->tiled = false; u->n_other_t = 0; u->slot_row.clear(); u->n_win = 1;
     const size_t nh = u->nh, s4 = u->stride / 4;
-    if (u->rows_diffed || getenv("AGX_NO_TILED_UPLOAD") || nh == 0 || u->n_rows == 0) {      // (rows that were to cross as differences and do not — nothing gained — cross tile-ordered) u->s_hits_t.release(); u->s_codes_t.release(); u->s_other_t.release(); return; }
+    // (rows that were to cross as differences and do not — nothing gained — cross tile-ordered)
+    if (u->rows_diffed || getenv("AGX_NO_TILED_UPLOAD") || nh == 0 || u->n_rows == 0) { u->s_hits_t.release(); u->s_codes_t.release(); u->s_other_t.release(); return; }
     const double t0 = now_ms();
     u->s_hits_t.alloc(nh + 1); u->s_codes_t.alloc(nh * s4 + 16); u->slot_row.resize(nh);
     const agx_whit *wh = u->s_hits.p; const agx_wside *sd = u->s_sides.p; const agx_wrun *wr = u->s_runs.p; const agx_u32 *perm = u->s_perm.p;
