@@ -186,8 +186,10 @@ def test_cfg5_shard_shape_at_1_256_every_unit_matches_the_oracle(agx, built, tmp
         assert stats[uu]["build_attempts"] == 1 and stats[uu]["n_pos"] >= lens[uu]
 
 
-def _cfg5_unit_alone(agx, base, uu, threads):
-    """One chromosome of configs[4] alone: generator (--only-units), oracle on a thread beside the engine, the engine's three outputs and the oracle's."""
+def _cfg5_unit_alone(agx, base, uu, threads, stream=False):
+    """One chromosome of configs[4] alone: generator (--only-units), oracle on a thread beside the engine, the engine's three outputs and the oracle's.
+    stream (r06): agx_unit_finish on a unit that has not been downloaded — the walk graph comes down in position windows and the walk begins on what has landed — instead of
+    download, trim, finish."""
     import shutil
     run = H.synth(os.path.join(base, "u%d" % uu), seed=1000, chroms=",".join(map(str, HUMAN)), pairs=400000000, L=150, k=5, coverage=5, sam_seq=0, threads=threads,
                   pairs_bin=1, lean=1, oracle_units=uu, only_units=uu)
@@ -206,8 +208,12 @@ def _cfg5_unit_alone(agx, base, uu, threads):
         un.load_files(tmp, uu)
         need = un.hbm_needed()
         t0 = time.perf_counter()
-        un.upload(); un.build(); un.download()
-        freed = un.trim()                                  # (r05) three quarters of the unit's HBM go back to the device before the walk; the walk's record fetches still find theirs
+        un.upload(); un.build()
+        if stream:
+            freed = need                                   # (nothing is given back early: nobody waits for this unit's HBM)
+        else:
+            un.download()
+            freed = un.trim()                              # (r05) three quarters of the unit's HBM go back to the device before the walk; the walk's record fetches still find theirs
         got = un.finish()
         chain_ms = 1e3 * (time.perf_counter() - t0)
         st = un.stats()
@@ -252,10 +258,35 @@ def test_cfg5_chr21_chr22_chrY_alone_at_full_size_match_the_oracle(agx, built, t
                                           for uu, r in zip(units, res)))
 
 
+def _box():
+    import shutil
+    import tempfile
+    try:
+        mem_limit = int(open("/sys/fs/cgroup/memory.max").read())
+    except (OSError, ValueError):
+        mem_limit = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+    return shutil.disk_usage(tempfile.gettempdir()).free, mem_limit
+
+
+@slow
+def test_cfg5_chrX_alone_at_full_size_matches_the_oracle(agx, built, tmp_path):
+    """r06 (a LARGE unit in the default suite): chrX of configs[4] — 156 040 895 positions, 20 M pairs of 2x150 with the whole job's read numbering, 35 GB of
+    HBM — alone, one-shot, one build, its download STREAMED into its walk (eight position windows, sixteen walkers gated on them), byte for byte against the oracle.  The unit is
+    two and a half times the largest one the suite held so far (62 Mb); 32-bit offsets, the memory region, the tile-ordered upload in eight windows and the streamed download all run
+    at a size where they matter.  Needs 25 GB of scratch disk and 90 GB of host memory (the oracle holds 50): skipped where the box has less.  chr1 (249 Mb) the same way behind AGX_BIG_CHR1=1."""
+    free_disk, mem_limit = _box()
+    if free_disk < 25e9 or mem_limit < 90e9:
+        pytest.skip("chrX alone against the oracle needs 25 GB of scratch disk and 90 GB of host memory (here: %.0f GB, %.0f GB)" % (free_disk / 1e9, mem_limit / 1e9))
+    got, want, st, need = _cfg5_unit_alone(agx, str(tmp_path), 22, THREADS, stream=True)
+    _check_cfg5_unit(22, got, want, st, need)
+    print("configs[4] chrX alone, download streamed into the walk: %d positions, %d hits, %.1f GB of HBM, upload -> output bytes %.1f ms (node sweep %.1f ms, download %.1f ms, walk incl. the download %.0f ms)" %
+          (st["n_pos"], st["n_hits"], st["device_bytes"] / 1e9, st["chain_ms"], st["ms_node_sweep"], st["ms_download"], st["ms_walk"]))
+
+
 @pytest.mark.skipif(os.environ.get("AGX_BIG_CHR1") != "1", reason="chr1 alone against the oracle takes the oracle ~15 minutes and 80 GB of host memory: AGX_BIG_CHR1=1 (a passing run's log: profiles/r05_chr1_oracle.txt)")
 def test_cfg5_chr1_alone_at_full_size_matches_the_oracle(agx, built, tmp_path):
     """configs[4]'s LARGEST unit — chr1, 248 956 422 positions, 33 M pairs of 2x150, 57 GB of HBM — against the oracle (r03 checked it against the serial executor only)."""
-    got, want, st, need = _cfg5_unit_alone(agx, str(tmp_path), 0, THREADS)
+    got, want, st, need = _cfg5_unit_alone(agx, str(tmp_path), 0, THREADS, stream=os.environ.get("AGX_BIG_CHR1_NO_STREAM") != "1")
     _check_cfg5_unit(0, got, want, st, need)
     print("configs[4] chr1 alone: %d positions, %d hits, %.1f GB of HBM (%.1f given back after the download), upload -> output bytes %.1f ms (node sweep %.1f ms, download %.1f ms, walk %.0f ms); outputs %d / %d / %d bytes identical to the oracle" %
           (st["n_pos"], st["n_hits"], st["device_bytes"] / 1e9, st["trimmed"] / 1e9, st["chain_ms"], st["ms_node_sweep"], st["ms_download"], st["ms_walk"], len(got["initial"]), len(got["pre"]), len(got["extended"])))
