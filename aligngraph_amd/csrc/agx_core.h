@@ -477,7 +477,6 @@ struct agx_sweep_args {
                                   // tile's earlier positions; tile_side[tile] = side ids of the whole tile (input of the walk preparation's scan)
     agx_u32 *tile_side;
     agx_u32 *nk_cid, *nk_coff, *nk_cid0, *nk_coff0, *nk_off0;   // [pool]
-    agx_u32 *n_xpos;              // position of each node (the walk follows edges by node id)
     agx_u8 *n_base, *n_flags;     // consensus base ('X' = none: use the reference base, AG:1997-2001), AGX_NF_*
     agx_sref *n_sref;
     agx_u32 *n_next;              // [pool*AGX_MAXE]
@@ -842,7 +841,7 @@ AGX_HD agx_u32 agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx
         const agx_u32 cid = agx_b(b, v, AGX_F_CID), coff = agx_b(b, v, AGX_F_COFF), cov = agx_b(b, v, AGX_F_COV);
         const agx_u32 cid0 = agx_b(b, v, AGX_F_CID0), coff0 = agx_b(b, v, AGX_F_COFF0);
         A.nk_cid[id] = cid; A.nk_coff[id] = coff; A.nk_cid0[id] = cid0; A.nk_coff0[id] = coff0;
-        A.nk_off0[id] = agx_b(b, v, AGX_F_OFF0); A.n_xpos[id] = X;
+        A.nk_off0[id] = agx_b(b, v, AGX_F_OFF0);      // (r06: no per-node position array — a node's position is its walk id's: the id itself, or side_xpos — 4 bytes per node less to write)
         const agx_u32 va = agx_b(b, v, AGX_F_A), vc = agx_b(b, v, AGX_F_C), vg = agx_b(b, v, AGX_F_G), vt = agx_b(b, v, AGX_F_T), vn = agx_b(b, v, AGX_F_N);
         A.n_base[id] = (agx_u8)agx_consensus(va, vc, vg, vt, vn);
         agx_u8 fl = 0;
@@ -1074,7 +1073,7 @@ enum { AGX_WM_CONT = 1, AGX_WM_CONTIG = 2, AGX_WM_SIDE = 4, AGX_WM_ANY = 8, AGX_
 // can start a walk in the middle of a forced run; the host then fetches that record from the full table that stays on the device.
 struct agx_compact_args {
     // node table, old ids
-    const agx_u32 *node_start; const agx_u16 *node_cnt; const agx_u8 *n_flags; const agx_u8 *n_base; const agx_u32 *n_xpos;
+    const agx_u32 *node_start; const agx_u16 *node_cnt; const agx_u8 *n_flags; const agx_u8 *n_base;
     const agx_u32 *nk_off0; const agx_sref *n_sref; const agx_u32 *n_next; const char *ref;
     agx_u32 n_pos;
     const agx_u32 *side_pk;        // [n_pos] agx_side_pack
@@ -1137,7 +1136,7 @@ AGX_HD agx_walknode agx_walk_record(const agx_compact_args &A, agx_u32 a) {
     agx_walknode w; for (agx_u32 e = 0; e < AGX_MAXE; e++) w.next[e] = AGX_NONE;
     const agx_u32 v = A.a_nid[a];
     if (v == AGX_NONE) { w.off0 = AGX_NONE; w.xpos = a; w.sref = agx_sref{0, 0}; return w; }       // a main id without a surviving node
-    w.off0 = A.nk_off0[v]; w.xpos = A.n_xpos[v]; w.sref = A.n_sref[v];
+    w.off0 = A.nk_off0[v]; w.xpos = a < A.n_pos ? a : A.side_xpos[a - A.n_pos]; w.sref = A.n_sref[v];      // (a walk id's position: main ids are positions, the side block is position-major)
     agx_u32 k = 0;
     for (agx_u32 e = 0; e < AGX_MAXE; e++) {
         const agx_u32 t = A.n_next[(size_t)v * AGX_MAXE + e];

@@ -287,7 +287,7 @@ struct agx_unit {
     agx_u32 pool_cap = 0, spill_lo = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
     DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
     DBuf<agx_u32> d_node_start, d_slow_list, d_perm, d_tfirst, d_ckey, d_long; DBuf<agx_u16> d_node_cnt; DBuf<agx_u8> d_pos_succ;
-    DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_xpos, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
+    DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch, d_huge_list, d_scratch_huge; bool huge = false, dense = false;      // dense: the scatter fallback of the tile lists is queued (a build met more than AGX_LONG_MAX long hits); huge: pass 3 of the node sweep is queued (a build met a position beyond AGX_MAXV_BIG variants)
     // walk graph (agx_core.h "walk preparation")
     agx_u32 n_ids = 0;
@@ -382,7 +382,7 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     S.n_pos = (agx_u32)u->V.n_pos; S.n_tiles = u->n_tiles; S.k = u->prm.k; S.iv = (int)u->prm.insert_variation; S.coverage = (int)u->prm.coverage;
     S.node_start = u->d_node_start.p; S.node_cnt = u->d_node_cnt.p; S.pos_succ = u->d_pos_succ.p; S.side_pk = u->d_side_pk.p; S.tile_side = u->d_tile_side.p;
     S.nk_cid = u->d_cid.p; S.nk_coff = u->d_coff.p; S.nk_cid0 = u->d_cid0.p; S.nk_coff0 = u->d_coff0.p; S.nk_off0 = u->d_off0.p;
-    S.n_xpos = u->d_xpos.p; S.n_base = u->d_base.p; S.n_flags = u->d_flags.p; S.n_sref = u->d_sref.p; S.n_next = u->d_next.p;
+    S.n_base = u->d_base.p; S.n_flags = u->d_flags.p; S.n_sref = u->d_sref.p; S.n_next = u->d_next.p;
     S.n_counts = (u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? u->d_counts.p : nullptr;
     S.pool_cap = u->pool_cap;
     S.sweep_stats = nullptr;
@@ -836,7 +836,7 @@ void alloc_pool(agx_unit *u, agx_u32 cap) {
     // upload and build, and the units waiting for room on the device were waiting for walks).
     const size_t n_pos = u->V.n_pos, ids_cap = n_pos + cap;
     u->d_aid_of.release(); u->d_aid_of.alloc(a, (size_t)cap + 1); u->d_a_nid.release(); u->d_a_nid.alloc(a, ids_cap + 1);
-    u->d_off0.release(); u->d_off0.alloc(a, kcap); u->d_xpos.release(); u->d_xpos.alloc(a, cap); u->d_sref.release(); u->d_sref.alloc(a, cap); u->d_next.release(); u->d_next.alloc(a, (size_t)cap * AGX_MAXE);
+    u->d_off0.release(); u->d_off0.alloc(a, kcap); u->d_sref.release(); u->d_sref.alloc(a, cap); u->d_next.release(); u->d_next.alloc(a, (size_t)cap * AGX_MAXE);
     u->d_fetch.release(); u->d_fetch.alloc(a, 65536);
     for (auto *b : {&u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0}) { b->release(); b->alloc(a, kcap); }
     u->d_base.release(); u->d_base.alloc(a, cap); u->d_flags.release(); u->d_flags.alloc(a, cap);
@@ -1178,7 +1178,7 @@ void do_build(agx_unit *u) {
         if (side_j) HIP_OK(hipStreamWaitEvent(st, u->ev_passJ, 0));
         // ---- walk preparation: side counts -> scan -> walk ids, node records, rewritten edges, forced-run flags ----
         agx_compact_args C; memset(&C, 0, sizeof C);
-        C.node_start = u->d_node_start.p; C.node_cnt = u->d_node_cnt.p; C.n_flags = u->d_flags.p; C.n_base = u->d_base.p; C.n_xpos = u->d_xpos.p;
+        C.node_start = u->d_node_start.p; C.node_cnt = u->d_node_cnt.p; C.n_flags = u->d_flags.p; C.n_base = u->d_base.p;
         C.nk_off0 = u->d_off0.p; C.n_sref = u->d_sref.p; C.n_next = u->d_next.p; C.ref = u->d_ref.p; C.n_pos = n_pos;
         C.side_pk = u->d_side_pk.p; C.tile_side_start = u->d_tile_side_start.p; C.aid_of = u->d_aid_of.p;
         C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_nid = u->d_a_nid.p; C.ovf = u->d_ovf.p; C.n_ovf = 0; C.a_ovf = u->d_a_ovf.p;
@@ -1426,7 +1426,7 @@ size_t do_trim(agx_unit *u) {
     if (!base) return 0;
     size_t keep = 0;
     auto end_of = [&](const void *p, size_t bytes) { if (p) { const size_t e = (size_t)((const char *)p - base) + bytes; if (e > keep) keep = e; } };
-    end_of(u->d_aid_of.p, u->d_aid_of.n * 4); end_of(u->d_a_nid.p, u->d_a_nid.n * 4); end_of(u->d_off0.p, u->d_off0.n * 4); end_of(u->d_xpos.p, u->d_xpos.n * 4);
+    end_of(u->d_aid_of.p, u->d_aid_of.n * 4); end_of(u->d_a_nid.p, u->d_a_nid.n * 4); end_of(u->d_off0.p, u->d_off0.n * 4);
     end_of(u->d_sref.p, u->d_sref.n * sizeof(agx_sref)); end_of(u->d_next.p, u->d_next.n * 4); end_of(u->d_fetch.p, u->d_fetch.n * sizeof(agx_walknode));
     if (keep > u->arena.capacity()) return 0;            // (an array in a later block: nothing is given back)
     const size_t freed = u->arena.shrink_to(keep);
@@ -1444,7 +1444,7 @@ void do_release(agx_unit *u) {
     stream_wait_all(u);
     if (u->uploaded) { (void)hipSetDevice(u->prm.device); (void)hipEventSynchronize(u->ev_uploaded); (void)hipEventSynchronize(u->ev_built); (void)hipEventSynchronize(u->ev_dl); }      // (its commands are done before its memory goes)
     for (auto *b : {&u->d_cm_start, &u->d_tile_cnt, &u->d_tile_off, &u->d_cursor, &u->d_unsorted, &u->d_tile_recs, &u->d_scan_tmp, &u->d_words, &u->d_pool_cnt, &u->d_region_off, &u->d_node_start,
-                    &u->d_slow_list, &u->d_perm, &u->d_tfirst, &u->d_ckey, &u->d_long, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_xpos, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
+                    &u->d_slow_list, &u->d_perm, &u->d_tfirst, &u->d_ckey, &u->d_long, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     u->d_node_cnt.release();
     for (auto *b : {&u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();

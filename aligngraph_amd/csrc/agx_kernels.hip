@@ -771,7 +771,7 @@ __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, ag
     for (agx_u32 j = 0; j < AGX_SE_WORDS; j++) {
         const bool node = on[j] && v[j] != AGX_NONE;
         const agx_u32 vv = node ? v[j] : 0u;
-        wn[j].off0 = node ? A.nk_off0[vv] : AGX_NONE; wn[j].xpos = node ? A.n_xpos[vv] : a[j]; wn[j].sref = node ? A.n_sref[vv] : agx_sref{0, 0};
+        wn[j].off0 = node ? A.nk_off0[vv] : AGX_NONE; wn[j].xpos = x[j]; wn[j].sref = node ? A.n_sref[vv] : agx_sref{0, 0};
         nx[j] = node ? *reinterpret_cast<const uint4 *>(A.n_next + (size_t)vv * AGX_MAXE) : make_uint4(AGX_NONE, AGX_NONE, AGX_NONE, AGX_NONE);
         cm_n[j] = (on[j] && A.n_seg0) ? A.cm_start[x[j] + 1] - A.cm_start[x[j]] : 0u;
         // The hop entry of a position comes from the rank-0 run that holds it.  The ids of a word are 64 neighbours — main ids are positions, side ids are in position

@@ -121,7 +121,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     auto bind = [&]() {
         A.node_start = S.node_start.data(); A.node_cnt = S.node_cnt.data(); A.pos_succ = S.pos_succ.data(); A.side_pk = S.side_pk.data(); A.tile_side = S.tile_side.data();
         A.nk_cid = S.cid.data(); A.nk_coff = S.coff.data(); A.nk_cid0 = S.cid0.data(); A.nk_coff0 = S.coff0.data(); A.nk_off0 = S.off0.data();
-        A.n_xpos = S.xpos.data(); A.n_base = S.base.data(); A.n_flags = S.flags.data(); A.n_sref = S.sref.data(); A.n_next = S.next.data();
+        A.n_base = S.base.data(); A.n_flags = S.flags.data(); A.n_sref = S.sref.data(); A.n_next = S.next.data();
         A.n_counts = S.counts.data(); A.pool_cap = (agx_u32)S.cid.size();
     };
     bind();
@@ -192,7 +192,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
     // walk preparation, the same per-element functions the compaction kernels run
     agx_compact_args C; memset(&C, 0, sizeof C);
     S.tile_side_start.assign((size_t)n_tiles + 1, 0); S.aid_of.assign((size_t)S.n_nodes + 1, AGX_NONE);      // (side_pk / tile_side were written with the nodes)
-    C.node_start = S.node_start.data(); C.node_cnt = S.node_cnt.data(); C.n_flags = S.flags.data(); C.n_base = S.base.data(); C.n_xpos = S.xpos.data();
+    C.node_start = S.node_start.data(); C.node_cnt = S.node_cnt.data(); C.n_flags = S.flags.data(); C.n_base = S.base.data();
     C.nk_off0 = S.off0.data(); C.n_sref = S.sref.data(); C.n_next = S.next.data(); C.ref = T.ref.data(); C.n_pos = n_pos;
     C.side_pk = S.side_pk.data(); C.tile_side_start = S.tile_side_start.data(); C.aid_of = S.aid_of.data();
     agx_u32 run = 0; for (agx_u32 t = 0; t <= n_tiles; t++) { S.tile_side_start[t] = run; run += S.tile_side[t]; }
