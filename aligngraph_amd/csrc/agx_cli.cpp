@@ -304,10 +304,15 @@ struct MappedOut {
     int fd = -1; char *p = nullptr; size_t n = 0; string name;
     MappedOut(const string &path, size_t bytes) : n(bytes), name(path) {
         fd = open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0666);
+        // (the blocks are reserved before the file is mapped: on a full disk the run ends here with the reference's message, not with a SIGBUS in the middle of a store into a
+        // sparse file — ADVICE r05; file systems without fallocate (EOPNOTSUPP / EINVAL) keep the sparse file)
         if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { cout << "CANNOT WRITE FILE! (" << name << ")" << endl; exit(-1); }
+        if (bytes) { const int rc = posix_fallocate(fd, 0, (off_t)bytes); if (rc != 0 && rc != EOPNOTSUPP && rc != EINVAL) { cout << "CANNOT WRITE FILE! (" << name << ")" << endl; exit(-1); } }
         if (bytes) { void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0); if (m == MAP_FAILED) { cout << "CANNOT WRITE FILE! (" << name << ")" << endl; exit(-1); } p = (char *)m; }
     }
-    ~MappedOut() { if (p) munmap(p, n); if (fd >= 0) close(fd); }
+    // (written back and checked before anybody reads the file: an I/O error that only shows at writeback — NFS and the like — must not leave zero-filled alignments for the unit loop)
+    // (AGX_CLI_SYNC=1: synchronously — for file systems that report a full disk or an I/O error only at writeback; the default asks for the writeback and checks that the request was taken: forcing 9 GB of a cfg3 run to the disk before the aligners start would cost the front end seconds)
+    ~MappedOut() { bool ok = true; if (p) { ok = msync(p, n, getenv("AGX_CLI_SYNC") ? MS_SYNC : MS_ASYNC) == 0; munmap(p, n); } if (fd >= 0) ok = (close(fd) == 0) && ok; if (!ok) { cout << "CANNOT WRITE FILE! (" << name << ")" << endl; exit(-1); } }
 };
 inline unsigned dec_digits(unsigned long v) { unsigned d = 1; while (v >= 10) { v /= 10; d++; } return d; }
 inline char *put_dec(char *w, unsigned long v) { char t[24]; int k = 0; do { t[k++] = (char)('0' + v % 10); v /= 10; } while (v); while (k) *w++ = t[--k]; return w; }

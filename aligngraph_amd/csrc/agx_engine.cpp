@@ -232,6 +232,9 @@ inline int walkers_now(size_t n_pos) {
 
 // units of this process that are uploaded and not yet walked: the walk of the LAST one runs alone (the tail of a job) and may take every walker there is
 static std::atomic<int> g_walks_pending{0};
+// units that exist in this process: when the last one is destroyed the output buffers parked for "the next unit" (agx_host.h: out_cache) go back to the C library — an embedder
+// that never calls agx_pool_trim(-1) then keeps at most what it has itself given back since (up to 16 GB stayed resident until exit)
+static std::atomic<int> g_units_alive{0};
 
 struct agx_unit {
     agx_params prm{};
@@ -1558,11 +1561,12 @@ int agx_unit_create(const agx_params *p, agx_unit **out) {
         u->dl_sdma = hsa_copy().agent_of(p->device, u->dl_agent) && hsa_signal_create(0, 0, nullptr, &u->dl_signal) == HSA_STATUS_SUCCESS;
     });
     if (rc != AGX_OK) { delete u; return rc; }
+    g_units_alive.fetch_add(1);
     *out = u;
     return AGX_OK;
 }
 
-void agx_unit_destroy(agx_unit *u) { if (u) { (void)hipSetDevice(u->prm.device); do_release(u); delete u; } }
+void agx_unit_destroy(agx_unit *u) { if (u) { (void)hipSetDevice(u->prm.device); do_release(u); delete u; if (g_units_alive.fetch_sub(1) == 1) out_cache_trim(); } }
 
 const char *agx_unit_error(const agx_unit *u) { return u ? u->err.c_str() : "null unit"; }
 

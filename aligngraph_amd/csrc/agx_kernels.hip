@@ -772,6 +772,7 @@ __global__ void __launch_bounds__(256) agx_k_special_emit(agx_compact_args A, ag
         const bool node = on[j] && v[j] != AGX_NONE;
         const agx_u32 vv = node ? v[j] : 0u;
         wn[j].off0 = node ? A.nk_off0[vv] : AGX_NONE; wn[j].xpos = x[j]; wn[j].sref = node ? A.n_sref[vv] : agx_sref{0, 0};
+        static_assert(AGX_MAXE == 4, "a node's edge slots are read as one uint4 (the arena's 256-byte alignment keeps d_next 16-byte aligned)");
         nx[j] = node ? *reinterpret_cast<const uint4 *>(A.n_next + (size_t)vv * AGX_MAXE) : make_uint4(AGX_NONE, AGX_NONE, AGX_NONE, AGX_NONE);
         cm_n[j] = (on[j] && A.n_seg0) ? A.cm_start[x[j] + 1] - A.cm_start[x[j]] : 0u;
         // The hop entry of a position comes from the rank-0 run that holds it.  The ids of a word are 64 neighbours — main ids are positions, side ids are in position

@@ -116,20 +116,30 @@ def shutil_rm(path):
 
 
 def in_use(run_dir):
-    """Another bench.py is reading this input directory: it holds <dir>/.in_use with its process id (a stale file of a process that is gone does not count)."""
+    """Another bench.py is reading this input directory: it holds <dir>/.in_use.<its process id> (a marker of a process that is gone does not count, and is removed)."""
+    busy = False
     try:
-        pid = int(open(os.path.join(run_dir, ".in_use")).read().strip() or "0")
-    except (OSError, ValueError):
-        return False
-    if pid == os.getpid():
-        return False
-    try:
-        os.kill(pid, 0)
-        return True
-    except ProcessLookupError:
-        return False
+        names = [n for n in os.listdir(run_dir) if n.startswith(".in_use")]
     except OSError:
-        return True
+        return False
+    for n in names:
+        try:
+            pid = int(n.rpartition(".")[2]) if n != ".in_use" else int(open(os.path.join(run_dir, n)).read().strip() or "0")
+        except (OSError, ValueError):
+            continue
+        if pid == os.getpid():
+            continue
+        try:
+            os.kill(pid, 0)
+            busy = True
+        except ProcessLookupError:
+            try:
+                os.remove(os.path.join(run_dir, n))
+            except OSError:
+                pass
+        except OSError:
+            busy = True
+    return busy
 
 
 def n50_of(fasta_bytes):
@@ -317,7 +327,7 @@ def main():
         dist.barrier()
     t_gen = time.perf_counter() - t0
     if rank == 0:
-        with open(os.path.join(run, ".in_use"), "w") as f:      # (a later run that needs the disk must not delete these inputs under this one)
+        with open(os.path.join(run, ".in_use.%d" % os.getpid()), "w") as f:      # (a later run that needs the disk must not delete these inputs under this one; one marker per process: ADVICE r05)
             f.write(str(os.getpid()))
     tmp = os.path.join(run, "tmp")
     unit_len = D.read_meta(run)["unit_len"]
@@ -686,7 +696,7 @@ def main():
         r.free()
     if rank == 0:
         try:
-            os.remove(os.path.join(run, ".in_use"))
+            os.remove(os.path.join(run, ".in_use.%d" % os.getpid()))
         except OSError:
             pass
     for one in unit_sets:

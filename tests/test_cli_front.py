@@ -28,9 +28,6 @@ def front(work, **env):
 def run_dir(tmp_path_factory):
     from aligngraph_amd import build as B
     B.build()
-    import aligngraph_amd as A
-    if A.device_count() > 0:
-        pytest.skip("a GPU is present: whole runs are covered by tests/test_cli.py")
     return H.synth(str(tmp_path_factory.mktemp("front") / "run"), seed=77, chroms="60000,40000", pairs=30000, L=100, k=5, coverage=5, e2e=1, sam_seq=0)
 
 
