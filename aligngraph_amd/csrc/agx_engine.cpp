@@ -1096,8 +1096,10 @@ void do_build(agx_unit *u) {
         AGX_CHECKPOINT("tile_sort");
         // r06: a tile-ordered unit's first build expands its read rows and sweeps its tiles WINDOW BY WINDOW, each when its piece of the upload has landed (the rows of a window's
         // hits are one piece, in front of which lie the rows of every earlier tile: stage_tiled) — the sweep of the unit's front runs beside the upload of its back
-        const agx_u32 n_win = (!u->expanded && u->tiled) ? u->n_win : 1u;
         const bool windows = !u->expanded && u->tiled;
+        const agx_u32 n_win = (windows && early) ? u->n_win : 1u;      // (a build that has waited for the whole upload on the host — timed sections — has nothing to overlap: one window, no boundaries to pay for)
+        agx_u32 wt[9]; size_t wr[9];                                   // the windows' tiles and rows
+        for (agx_u32 w = 0; w <= n_win; w++) { wt[w] = n_win == 1 ? (w ? u->n_tiles : 0u) : u->win_tile[w]; wr[w] = n_win == 1 ? (w ? (size_t)nh : 0) : win_row(u, w); }
         swept_windows = windows ? n_win : 1u; swept_timed = windows;
         if (!u->expanded) {   // the vote codes (and the region layout, the last copy of the upload) are first needed by the sweep
             if (!windows) {
@@ -1116,7 +1118,7 @@ void do_build(agx_unit *u) {
         if (windows) {      // still on the front stream, behind ev_front: the rows of window w out of their 2-bit form when they are in, then the listed bases among them
             const size_t s4 = u->stride / 4;
             for (agx_u32 w = 0; w < n_win; w++) {
-                const size_t r_lo = win_row(u, w), r_hi = win_row(u, w + 1);
+                const size_t r_lo = wr[w], r_hi = wr[w + 1];
                 if (early && w) HIP_OK(hipStreamWaitEvent(st, u->ev_rows[w], 0));
                 const unsigned long long *ob = u->s_other_t.p, *oe = ob + u->n_other_t;
                 const size_t o_lo = (size_t)(std::lower_bound(ob, oe, (unsigned long long)r_lo * u->stride) - ob), o_hi = (size_t)(std::lower_bound(ob, oe, (unsigned long long)r_hi * u->stride) - ob);
@@ -1143,7 +1145,7 @@ void do_build(agx_unit *u) {
         K.slow_list = u->d_slow_list.p; K.slow_count = u->d_words.p + W_SLOWCOUNT; K.fallback_queued = 1u;
         K.huge_count = u->d_words.p + W_HUGECOUNT; K.huge_n = u->d_words.p + W_HUGECOUNT; K.huge_list = u->d_huge_list.p; K.scratch_huge = u->d_scratch_huge.p; K.huge_queued = u->huge ? 1u : 0u;
         for (agx_u32 w = 0; w < n_win; w++) {
-            K.tile_lo = windows ? u->win_tile[w] : 0u; K.tile_hi = windows ? u->win_tile[w + 1] : u->n_tiles;
+            K.tile_lo = windows ? wt[w] : 0u; K.tile_hi = windows ? wt[w + 1] : u->n_tiles;
             if (windows) { HIP_OK(hipStreamWaitEvent(st, u->ev_win[w], 0)); HIP_OK(hipEventRecord(u->ev_sw0[w], st)); }      // (behind the wait: the sweep's time must not hold the rows' journey)
             agx_launch_node_sweep(&K, st);
             if (windows) HIP_OK(hipEventRecord(u->ev_sw1[w], st));
@@ -1362,7 +1364,7 @@ void stream_wait_landed(void *ctx, agx_u32 main_hi, agx_u32 side_hi) {
     for (int p = 1; p <= need; p++) wait_signal(u->dl_piece[p]);
     if (need == n && !u->dl_timed.exchange(true)) {      // the last window is in: what the engines delivered per millisecond, for the next unit's estimate
         const double ms = now_ms() - u->dl_t0; u->stats.ms_download = ms;
-        if (ms > 0.05 && u->dl_stream_bytes > (4u << 20)) download_rate().store(0.5 * download_rate().load() + 0.5 * std::min(std::max((double)u->dl_stream_bytes / ms, 15e6), 60e6));      // (a download that queued behind another unit's says little about the link)
+        if (ms > 0.05 && u->dl_stream_bytes > (4u << 20)) download_rate().store(0.5 * download_rate().load() + 0.5 * std::min(std::max((double)u->dl_stream_bytes / ms, 35e6), 60e6));      // (clamped to what the link does: a download that queued behind another unit's, or whose last window was only looked at late, says little about it — chr1's 20 ms were once taken for 43)
         trace(u, "download (streamed): last window", u->dl_t0, u->V.n_pos);
     }
 }
