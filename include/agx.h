@@ -175,8 +175,11 @@ int agx_unit_hbm_needed(agx_unit *u, uint64_t *bytes);   /* the HBM block agx_un
                                                     device between units of very different sizes admits them by (AlignGraph_amd); a build that has to grow a capacity takes more */
 int agx_unit_upload(agx_unit *u);                /* staged arrays -> HBM: one device block, asynchronous copies behind those of the device's earlier uploads; returns without waiting */
 int agx_unit_build(agx_unit *u);                 /* kernels: updateGenomeWithRead/updateKMer (AG:1635-1870, 1353-1624) + filterLowCoverage (AG:1904-1918) */
-int agx_unit_download(agx_unit *u);              /* HBM -> pinned host memory (walk graph); implied by agx_unit_finish */
-int agx_unit_finish(agx_unit *u, agx_result *r); /* (download, then) extdContigs1/2 + scaffoldContigs (AG:1954-2464) on the host */
+int agx_unit_download(agx_unit *u);              /* HBM -> pinned host memory (the whole walk graph; returns when it is there).  Only needed by a caller that wants the unit's HBM back
+                                                    before the walk (agx_unit_trim): agx_unit_finish downloads what has not been downloaded, and does it better */
+int agx_unit_finish(agx_unit *u, agx_result *r); /* extdContigs1/2 + scaffoldContigs (AG:1954-2464) on the host.  On a unit that has not been downloaded (r06) the download is STREAMED: the
+                                                    walk graph comes down in position windows from the front and the walk begins on what has landed — the walkers of a large unit wait for
+                                                    their windows, the first one for all of them (csrc/agx_engine.cpp: begin_streamed_download; AGX_NO_STREAM_DOWNLOAD=1: the whole download first) */
 void agx_result_free(agx_result *r);               /* (the buffers are malloc'd; the library keeps up to 16 GB of the ones given back here for the outputs of the next units — fresh memory for them is a
                                                     sixth of a whole-human job's host CPU time —, agx_pool_trim(-1) frees them) */
 int agx_unit_trim(agx_unit *u, uint64_t *freed);  /* after agx_unit_download: gives the part of the unit's HBM that the host walk cannot ask for (three quarters of it) back to the device's memory
