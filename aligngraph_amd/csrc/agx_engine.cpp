@@ -397,9 +397,9 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
 // (agx_pack_classes2): a quarter of the bytes of the largest array.  The read alignments are staged by stage_pairs() (agx_load.cpp) —
 // or were written into the staged buffers by the fast loader while it parsed (u->pairs_staged).
 // The file-order wire records and read rows of a unit that will upload their tile-ordered forms (stage_tiled) are only ever read by the host — the gather into those forms, the
-// cache file, the row codec — so they live in ordinary memory: pinning a second copy of a unit's two largest arrays cost its load 0.2 ms per MB.  r05's forms (AGX_ROW_DIFF,
-// AGX_NO_TILED_UPLOAD) are uploaded from them and keep them pinned.
-inline bool want_tiled() { const char *rd = getenv("AGX_ROW_DIFF"); return !getenv("AGX_NO_TILED_UPLOAD") && !(rd && atoi(rd) != 0); }
+// cache file — so they live in ordinary memory: pinning a second copy of a unit's two largest arrays cost its load 0.2 ms per MB.  r05's forms (AGX_NO_TILED_UPLOAD) are uploaded
+// from them and keep them pinned.
+inline bool want_tiled() { return !getenv("AGX_NO_TILED_UPLOAD"); }
 template <class B> inline void alloc_file_order(B &buf, size_t count) { if (want_tiled()) buf.alloc_plain(count); else buf.alloc(count); }
 struct UnitSink : StageSink {
     agx_unit *u; explicit UnitSink(agx_unit *x) : u(x) {}
@@ -458,6 +458,7 @@ void reserve_landing(agx_unit *u) {
 void stage_rows(agx_unit *u, unsigned threads) {
     u->rows_diffed = false; u->n_units = u->n_rowcnt = u->n_blockoff = u->n_blockfirst = u->n_anchor = u->n_rows_explicit = 0;
     const char *on = getenv("AGX_ROW_DIFF");
+    if (want_tiled()) return;      // (r06: the tile-ordered forms have their own: stage_rows_tiled)
     if (!on || atoi(on) == 0 || !u->ref_packed || u->n_rows == 0 || u->nh == 0) return;
     const double t0 = now_ms();
     RowDiffs D;
@@ -542,6 +543,32 @@ void stage_tiled(agx_unit *u, unsigned threads) {
     if (getenv("AGX_LOAD_TIMING")) fprintf(stderr, "[agx load] tile-ordered upload forms: %.1f ms (%zu hits, %zu listed bases, %u windows)\n", now_ms() - t0, nh, no, u->n_win);
 }
 
+// r06: the read rows of the tile-ordered forms as their differences from the reference (agx_core.h "read rows relative to the reference"): row i is hit i's left mate, so every
+// row's anchor is its own hit — no anchor search, no order condition — and the encoder and the device's decoder are r04's (build_row_diffs with rows_are_hits; agx_k_expand_rows
+// over anchor bits that are all ones).  The stream of differences is in row order = tile order: a window's rows are one piece of it (do_upload), expanded when it has landed.
+// WHEN ("by a rule in code, not an environment variable"): the form takes a third off a unit's upload and costs its first build the slower expansion
+// (agx_k_expand_rows: +0.4 ms per 30 Mb) and the loader 30-60 ns per row.  It pays where the upload is the unit's own critical path — a LARGE unit, whose kernels cannot begin
+// before its first window has landed and end one window behind its last byte — and does not where a job's many small units hide each other's uploads behind each other's
+// kernels (cfg3: the chain of builds is as long as the chain of uploads).  Rule: units of 48 M positions and more.  AGX_ROW_DIFF=1 / =0 force it on / off (tests, A/B).
+void stage_rows_tiled(agx_unit *u, unsigned threads) {
+    if (!u->tiled || !u->ref_packed || u->stride > AGX_ROW_MAXSTRIDE) return;
+    const char *env = getenv("AGX_ROW_DIFF");
+    const size_t n_pos = u->V.n_pos ? u->V.n_pos : u->T.ref.size();
+    if (env ? atoi(env) == 0 : n_pos < 48000000u) return;
+    const double t0 = now_ms();
+    RowDiffs D;
+    if (!build_row_diffs(u->s_hits_t.p, u->nh, u->s_sides.p, u->n_sides, u->s_runs.p, u->n_runs, u->s_codes_t.p, u->nh, u->stride, (const agx_u32 *)u->s_ref.p, n_pos, threads, D, true)) return;
+    if (D.n_units * 2 + D.cnt.size() + (D.block_off.size() + D.block_first.size() + D.anchor_bits.size()) * 4 >= u->nh * (u->stride / 4)) return;      // nothing gained (reads that do not resemble the reference)
+    u->n_units = D.n_units; u->n_rowcnt = D.cnt.size(); u->n_blockoff = D.block_off.size(); u->n_blockfirst = D.block_first.size(); u->n_anchor = D.anchor_bits.size(); u->n_rows_explicit = D.n_explicit;
+    u->s_units.alloc(u->n_units + 2); u->s_rowcnt.alloc(u->n_rowcnt); u->s_blockoff.alloc(u->n_blockoff); u->s_blockfirst.alloc(u->n_blockfirst); u->s_anchor.alloc(u->n_anchor);
+    const unsigned T = std::max(1u, std::min(threads, 8u));
+    on_threads(T, [&](unsigned t) { const size_t lo = u->n_units * t / T, hi = u->n_units * (t + 1) / T; if (hi > lo) memcpy(u->s_units.p + lo, D.units.data() + lo, (hi - lo) * 2); });
+    memcpy(u->s_rowcnt.p, D.cnt.data(), u->n_rowcnt); memcpy(u->s_blockoff.p, D.block_off.data(), u->n_blockoff * 4); memcpy(u->s_blockfirst.p, D.block_first.data(), u->n_blockfirst * 4); memcpy(u->s_anchor.p, D.anchor_bits.data(), u->n_anchor * 4);
+    u->rows_diffed = true;
+    if (getenv("AGX_LOAD_TIMING")) fprintf(stderr, "[agx load] tile-ordered rows against the reference: %.1f ms, %zu rows (%zu as they are), %.1f -> %.1f bytes per row\n", now_ms() - t0, u->nh, u->n_rows_explicit,
+                                          (double)(u->stride / 4), (double)(u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4) / u->nh);
+}
+
 void stage_inputs(agx_unit *u) {
     if (!u->have_ref || !u->have_threads) throw Error{E_ARG, "reference and contig threads must be set before upload"};
     // A one-shot unit's download lands in its staged buffers.  The general loader's pairs can be staged again from P; the fast loader wrote the hits, runs and
@@ -580,6 +607,7 @@ void stage_inputs(agx_unit *u) {
     stage_rows(u, threads);
     stage_order(u, threads);
     stage_tiled(u, threads);
+    stage_rows_tiled(u, threads);
     u->V.slot_row = u->tiled ? u->slot_row.data() : nullptr;
     reserve_landing(u);
     u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
@@ -798,6 +826,7 @@ bool load_cache(agx_unit *u, const std::string &dir, int unit) {
     stage_rows(u, std::max(threads, std::min(8u, usable_cpus())));
     stage_order(u, std::max(threads, std::min(16u, usable_cpus())));
     stage_tiled(u, std::max(threads, std::min(16u, usable_cpus())));
+    stage_rows_tiled(u, std::max(threads, std::min(16u, usable_cpus())));
     u->V.slot_row = u->tiled ? u->slot_row.data() : nullptr;
     reserve_landing(u);
     u->have_ref = u->have_threads = true; u->staged = true; u->consumed = false; u->uploaded = false; u->built = false; u->downloaded = false;
@@ -866,7 +895,8 @@ struct Plan { agx_u32 pool_cap, list_cap, ovf_cap, sp_cap; size_t total; };
 // first row of window w's piece of a tile-ordered upload (w = n_win: all rows): the place in the tile order of the first hit of the window's first tile, rounded up to 16 rows —
 // a piece then begins on a 16-byte boundary of the packed classes and on a multiple of 16 bases (agx_k_expand_codes takes 16 bases per thread); the few rows of the next window's
 // hits that ride in this piece only arrive early
-inline size_t win_row(const agx_unit *u, agx_u32 w) { return w == 0 ? 0 : w >= u->n_win ? u->nh : std::min<size_t>(u->nh, ((size_t)u->s_tfirst.p[u->win_tile[w]] + 15) & ~(size_t)15); }
+inline size_t win_row(const agx_unit *u, agx_u32 w) { const size_t a = u->rows_diffed ? 63 : 15;      // (rows as differences: whole 64-row blocks of the stream)
+    return w == 0 ? 0 : w >= u->n_win ? u->nh : std::min<size_t>(u->nh, ((size_t)u->s_tfirst.p[u->win_tile[w]] + a) & ~a); }
 inline size_t codes_bytes(const agx_unit *u) { return u->tiled ? u->nh * (u->stride / 4) : u->n_codes; }      // packed read rows as they are uploaded (tile-ordered: one row per hit)
 inline size_t others_up(const agx_unit *u) { return u->tiled ? u->n_other_t : u->n_other; }
 Plan plan_capacities(const agx_unit *u) {
@@ -960,9 +990,14 @@ void do_upload(agx_unit *u) {
             up(u->d_chain_end.p, u->s_chain_end.p, (size_t)u->n_chain_end * 4);
             layout_regions(u, nullptr, pool_cap - spill_min(u), true, st);
             const size_t s4 = u->stride / 4;
+            if (u->rows_diffed) { up(u->d_blockoff.p, u->s_blockoff.p, u->n_blockoff * 4); up(u->d_blockfirst.p, u->s_blockfirst.p, u->n_blockfirst * 4); up(u->d_anchor.p, u->s_anchor.p, u->n_anchor * 4); }
             for (agx_u32 w = 0; w < u->n_win; w++) {      // rows of the hits whose first tile lies in window w (a tile's list also names hits that begin in earlier tiles: earlier pieces)
                 const size_t r_lo = win_row(u, w), r_hi = win_row(u, w + 1);
-                up(u->d_codes.p + r_lo * s4, u->s_codes_t.p + r_lo * s4, (r_hi - r_lo) * s4);
+                if (u->rows_diffed) {                     // the window's count bytes and its piece of the stream of differences (whole 64-row blocks)
+                    const size_t b_lo = r_lo / 64, b_hi = (r_hi + 63) / 64, c_hi = std::min<size_t>(u->n_rowcnt, b_hi * 64);
+                    up(u->d_rowcnt.p + r_lo, u->s_rowcnt.p + r_lo, c_hi - r_lo);
+                    up(u->d_units.p + u->s_blockoff.p[b_lo], u->s_units.p + u->s_blockoff.p[b_lo], ((size_t)u->s_blockoff.p[b_hi] - u->s_blockoff.p[b_lo]) * 2);
+                } else up(u->d_codes.p + r_lo * s4, u->s_codes_t.p + r_lo * s4, (r_hi - r_lo) * s4);
                 HIP_OK(hipEventRecord(u->ev_rows[w], st));
             }
         } else {
@@ -1002,7 +1037,7 @@ void do_upload(agx_unit *u) {
     u->stats.upload_bytes = u->n_segs * sizeof(agx_cmseg) + u->n_cntruns * sizeof(agx_cntrun) + (u->n_cntchunks + u->n_segchunks) * sizeof(agx_chunk) + (u->ref_packed ? (n_pos + 3) / 4 + u->n_refx * sizeof(agx_refx) : n_pos) + nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 + nh * 4 + ((size_t)u->n_tiles + 2) * 4 +
                             (size_t)u->n_chain_end * 4 + (u->rows_diffed ? u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4 : codes_bytes(u)) + others_up(u) * 8 + ((size_t)u->n_regions + 1) * 4 - (u->tiled ? nh * 4 : 0);
     u->stats.device_bytes = u->arena.capacity();
-    u->stats.rows_by_reference = u->rows_diffed ? (uint32_t)(u->n_rows - u->n_rows_explicit) : 0u;
+    u->stats.rows_by_reference = u->rows_diffed ? (uint32_t)((u->tiled ? u->nh : u->n_rows) - u->n_rows_explicit) : 0u;
 }
 
 // The three output buffers of a unit: reserved by estimate (the walk grows what is too small), every page touched, the initial contigs
@@ -1124,7 +1159,9 @@ void do_build(agx_unit *u) {
                 const size_t o_lo = (size_t)(std::lower_bound(ob, oe, (unsigned long long)r_lo * u->stride) - ob), o_hi = (size_t)(std::lower_bound(ob, oe, (unsigned long long)r_hi * u->stride) - ob);
                 // (pieces begin at multiples of 16 rows: whole 16-base groups, 16-byte aligned stores; the last piece is padded like the whole array was)
                 const size_t b_lo = r_lo * s4 * 4, b_hi = w + 1 == n_win ? (codes_bytes(u) * 4 + 15) / 16 * 16 : r_hi * s4 * 4;
-                agx_launch_expand_codes(u->d_codes.p + r_lo * s4, u->d_vcodes.p + b_lo, b_hi - b_lo, nullptr, 0, st);
+                if (u->rows_diffed) agx_launch_expand_rows(u->d_whits.p, (agx_u32)nh, u->d_wsides.p, u->d_wruns.p, u->d_anchor.p, u->d_blockfirst.p + r_lo / 64, u->d_rowcnt.p + r_lo, u->d_blockoff.p + r_lo / 64, u->d_units.p, u->d_wref.p,
+                                                           u->d_vcodes.p + b_lo, (agx_u32)(r_hi - r_lo), u->stride, nullptr, 0, st);      // (every row's anchor is its own hit: the anchor bits are all ones)
+                else agx_launch_expand_codes(u->d_codes.p + r_lo * s4, u->d_vcodes.p + b_lo, b_hi - b_lo, nullptr, 0, st);
                 agx_launch_patch_codes(u->d_other.p + o_lo, o_hi - o_lo, u->d_vcodes.p, st);
                 HIP_OK(hipEventRecord(u->ev_win[w], st));
             }

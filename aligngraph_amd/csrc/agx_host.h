@@ -236,7 +236,7 @@ bool pack_reference(const char *ref, size_t n, unsigned threads, agx_u8 *packed 
 struct RowDiffs { std::vector<agx_u8> cnt; std::vector<agx_u32> block_off, block_first, anchor_bits; std::vector<agx_u16> units; size_t n_units = 0, n_explicit = 0; };
 // wref: the packed reference (pack_reference) as 32-bit words, readable one word beyond position n_pos + 15.  false: the form does not apply.
 bool build_row_diffs(const agx_whit *hits, size_t nh, const agx_wside *sides, size_t n_sides, const agx_wrun *runs, size_t n_runs, const agx_u8 *codes2, size_t n_rows, agx_u32 stride,
-                     const agx_u32 *wref, size_t n_pos, unsigned threads, RowDiffs &D);
+                     const agx_u32 *wref, size_t n_pos, unsigned threads, RowDiffs &D, bool rows_are_hits = false);
 
 // tmp/_agx_pairs.<u>.bin — a unit's read alignments handed over STAGED (the wire formats of agx_core.h) instead of as SAM text + tmp/_reads.fa: what an aligner that is
 // linked with the engine (or a generator of synthetic alignments: tools/agx_synth.cpp) writes where the reference's flow distributes SAM lines (AG:3545-3579).  The arrays are

@@ -567,8 +567,9 @@ inline unsigned long long reverse_pairs32(unsigned long long x) {
 }
 }
 bool build_row_diffs(const agx_whit *hits, size_t nh, const agx_wside *sides, size_t n_sides, const agx_wrun *runs, size_t n_runs, const agx_u8 *codes2, size_t n_rows, agx_u32 stride,
-                     const agx_u32 *wref, size_t n_pos, unsigned threads, RowDiffs &D) {
+                     const agx_u32 *wref, size_t n_pos, unsigned threads, RowDiffs &D, bool rows_are_hits) {
     D = RowDiffs();
+    if (rows_are_hits && n_rows != nh) return false;
     if (stride == 0 || (stride & 3u) || stride > AGX_ROW_MAXSTRIDE || n_rows >= 0x7FFFFFFFull || nh >= 0xFFFFFFFFull) return false;
     const agx_u8 *packed = (const agx_u8 *)wref;
     const size_t row_bytes = stride / 4, n_blocks = (n_rows + 63) / 64;
@@ -578,7 +579,9 @@ bool build_row_diffs(const agx_whit *hits, size_t nh, const agx_wside *sides, si
     // anchors: the first hit that names a row
     std::vector<agx_u32> anchor(n_rows, AGX_NONE);
     D.anchor_bits.assign(nh / 32 + 2, 0u);
-    for (size_t h = 0; h < nh; h++) { const agx_u32 r = hits[h].row; if (r < n_rows && anchor[r] == AGX_NONE) { anchor[r] = (agx_u32)h; D.anchor_bits[h >> 5] |= 1u << (h & 31); } }
+    // (rows_are_hits, r06: the tile-ordered forms — row i is the left-mate row of hit i, whose `row` field carries something else: every row is its own hit's)
+    if (rows_are_hits) { for (size_t h = 0; h < nh; h++) { anchor[h] = (agx_u32)h; D.anchor_bits[h >> 5] |= 1u << (h & 31); } }
+    else for (size_t h = 0; h < nh; h++) { const agx_u32 r = hits[h].row; if (r < n_rows && anchor[r] == AGX_NONE) { anchor[r] = (agx_u32)h; D.anchor_bits[h >> 5] |= 1u << (h & 31); } }
     // the device finds a row's anchor by counting anchor bits from its block's first anchor on (agx_anchor_select): every row needs an anchor, the anchors must come in row
     // order (the loaders number the rows as the hits first name them), and a block's anchors must lie within the eight words the device reads
     D.block_first.assign(n_blocks + 1, 0u);

@@ -312,7 +312,8 @@ def test_tile_ordered_upload_and_a_sweep_by_windows(agx, built, tmp_path, monkey
     tmp = os.path.join(run, "tmp")
     want = H.run_oracle(tmp, 0, 5, 50, 4, graph=True)
     for windows, flags, env in (("1", 0, {}), ("2", 0, {}), ("3", agx.AGX_FLAG_ONE_SHOT, {}), ("8", 0, {}), ("5", agx.AGX_FLAG_ONE_SHOT, {"AGX_NO_CACHE": "1"}), ("4", 0, {"AGX_TEST_SMALL_CAPS": "1"}),
-                                ("3", 0, {"AGX_NO_TILED_UPLOAD": "1"})):
+                                ("3", 0, {"AGX_NO_TILED_UPLOAD": "1"}), ("1", 0, {"AGX_ROW_DIFF": "1"}), ("3", 0, {"AGX_ROW_DIFF": "1"}), ("7", agx.AGX_FLAG_ONE_SHOT, {"AGX_ROW_DIFF": "1"}),
+                                ("2", 0, {"AGX_ROW_DIFF": "1", "AGX_NO_TILED_UPLOAD": "1"})):      # (rows as differences: in tile-ordered form — a window's piece of the stream — and in r05's)
         monkeypatch.setenv("AGX_UPLOAD_WINDOWS", windows)
         for k2, v2 in env.items():
             monkeypatch.setenv(k2, v2)
@@ -324,6 +325,7 @@ def test_tile_ordered_upload_and_a_sweep_by_windows(agx, built, tmp_path, monkey
         if flags == 0:
             assert graph_mismatch(want["graph"], got["graph"]) is None, (windows, env)
         assert got["stats"]["ms_node_sweep"] > 0
+        assert (got["stats"]["rows_by_reference"] > 0.4 * got["stats"]["n_hits"]) == ("AGX_ROW_DIFF" in env), (windows, env, got["stats"]["rows_by_reference"])
 
 
 def test_walk_begins_while_the_download_is_still_arriving(agx, built, tmp_path, monkeypatch):
