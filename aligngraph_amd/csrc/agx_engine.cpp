@@ -546,15 +546,17 @@ void stage_tiled(agx_unit *u, unsigned threads) {
 // r06: the read rows of the tile-ordered forms as their differences from the reference (agx_core.h "read rows relative to the reference"): row i is hit i's left mate, so every
 // row's anchor is its own hit — no anchor search, no order condition — and the encoder and the device's decoder are r04's (build_row_diffs with rows_are_hits; agx_k_expand_rows
 // over anchor bits that are all ones).  The stream of differences is in row order = tile order: a window's rows are one piece of it (do_upload), expanded when it has landed.
-// WHEN ("by a rule in code, not an environment variable"): the form takes a third off a unit's upload and costs its first build the slower expansion
-// (agx_k_expand_rows: +0.4 ms per 30 Mb) and the loader 30-60 ns per row.  It pays where the upload is the unit's own critical path — a LARGE unit, whose kernels cannot begin
-// before its first window has landed and end one window behind its last byte — and does not where a job's many small units hide each other's uploads behind each other's
-// kernels (cfg3: the chain of builds is as long as the chain of uploads).  Rule: units of 48 M positions and more.  AGX_ROW_DIFF=1 / =0 force it on / off (tests, A/B).
+// WHEN ("by a rule in code ... or delete the lines"): measured on the round's last tree (profiles/r06_l_*), the rule is NEVER by itself.  The form takes 35-38 %
+// off a unit's upload (cfg3 1.13 -> 0.74 GB per job, rank 0 of 8 of configs[4] 3.76 -> 2.34 GB) and costs the unit's first build the slower expansion (agx_k_expand_rows: a
+// lane per row decodes its row into LDS; ~10 ms for chr1's 33 M rows of 150 bases against 1 ms of agx_k_expand_codes) and the loader 30-60 ns per row (t_unit_s 0.42 -> 0.62 s at
+// cfg3).  Since the windows, a unit's kernels run beside its upload and the two are about as long: with a third of the bytes gone the kernels bind, and they are the longer for
+// it — chr1 in the emulated rank is built at 66.9 ms instead of 61.9, the rank done at 132.6 instead of 128.7 ms; cfg3's builds end 0.6 ms later each.  It stays what it was
+// in r04/r05: an option for hosts whose link is scarcer than this one's (AGX_ROW_DIFF=1; =0 or unset: the 2-bit rows), parity-tested both ways in both upload forms.
 void stage_rows_tiled(agx_unit *u, unsigned threads) {
     if (!u->tiled || !u->ref_packed || u->stride > AGX_ROW_MAXSTRIDE) return;
     const char *env = getenv("AGX_ROW_DIFF");
     const size_t n_pos = u->V.n_pos ? u->V.n_pos : u->T.ref.size();
-    if (env ? atoi(env) == 0 : n_pos < 48000000u) return;
+    if (!env || atoi(env) == 0) return;
     const double t0 = now_ms();
     RowDiffs D;
     if (!build_row_diffs(u->s_hits_t.p, u->nh, u->s_sides.p, u->n_sides, u->s_runs.p, u->n_runs, u->s_codes_t.p, u->nh, u->stride, (const agx_u32 *)u->s_ref.p, n_pos, threads, D, true)) return;
