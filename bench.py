@@ -83,9 +83,9 @@ def sweep_compulsory_bytes(st, L, k):
     """HBM bytes agx_k_node_sweep<0> cannot avoid for one unit, every array once: the tile records it walks (32 B per (tile, hit) list
     entry) and the tile offsets, one vote-code byte per arrival (an arrival = one read index of a left mate landing on a position: hits x (L-k+1)),
     the 16-byte conti-mer head of every position (read for the mate side of the arrivals there), and the node table it writes: 9 B per position
-    (node_start, node_cnt, pos_succ, side ids) + 41 B per node (5-word key, position, base, flags, k-mer reference, 4 inline edge slots).  The buckets
+    (node_start, node_cnt, pos_succ, side ids) + 37 B per node (5-word key, base, flags, k-mer reference, 4 inline edge slots; r02-r05: 41 with a position word that r06 no longer writes).  The buckets
     themselves (the 32 B of node state per arrival that SURVEY §8(d) counts) live in LDS and never touch HBM."""
-    return (32 * st["n_tile_entries"] + 4 * st["n_tiles"] + st["n_hits"] * max(1, L - k + 1) + 16 * (st["n_pos"] + 1) + 9 * st["n_pos"] + 41 * st["n_nodes"])
+    return (32 * st["n_tile_entries"] + 4 * st["n_tiles"] + st["n_hits"] * max(1, L - k + 1) + 16 * (st["n_pos"] + 1) + 9 * st["n_pos"] + 37 * st["n_nodes"])
 
 
 def pin_to_gpu_numa_node(torch, index):
