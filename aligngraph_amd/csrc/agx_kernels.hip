@@ -666,111 +666,83 @@ __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
 #define AGX_WP_POS 4u
 #endif
 // (the first threads also mark the main ids of the chain-end positions: a_mark is complete before anything reads it)
-// The positions a block of the walk preparation's two position kernels works on.  LIST (r06): the positions that the node sweep did NOT finish (agx_finish_simple_lane), which it
-// listed per region of the node pool — 8 % of all positions.  The kernels' time is the depth of their chains of dependent loads times the ROUNDS of resident blocks: skipping the
-// finished positions inside a grid over all positions removed bytes, not rounds (0.75 -> 0.70 ms for the whole walk preparation), and so did a block per list (as many blocks as
-// before: 0.63).  So a block takes the lists of AGX_WP_GROUP consecutive regions as ONE dense index space — the 8 counts by scalar loads, their prefix in registers — 1024 entries
-// at a time, four per thread, level by level as before: a 30 Mb unit is 1 860 blocks, one round.
-#define AGX_WP_GROUP 8u
-struct agx_wp_lists { agx_u32 pre[AGX_WP_GROUP + 1]; agx_u32 r0; };
-template <bool LIST> __device__ __forceinline__ agx_wp_lists agx_wp_open(const agx_compact_args &A) {
-    agx_wp_lists L; L.r0 = blockIdx.x * AGX_WP_GROUP; L.pre[0] = 0;
-    if (LIST) {
-#pragma unroll
-        for (agx_u32 g = 0; g < AGX_WP_GROUP; g++) {
-            agx_u32 c = L.r0 + g < A.regions ? agx_uload(A.todo_cnt, (size_t)(L.r0 + g) * AGX_REGION_PAD + 1) : 0u;
-            L.pre[g + 1] = L.pre[g] + (c < AGX_TODO_CAP ? c : AGX_TODO_CAP);
-        }
-    }
-    return L;
-}
-template <bool LIST> __device__ __forceinline__ agx_u32 agx_wp_position(const agx_compact_args &A, const agx_wp_lists &L, agx_u32 chunk, agx_u32 j) {
+// The j-th position of this thread.  LIST (r06): the grid is two blocks per region of the node pool, each over half of the region's list of positions that the node sweep did
+// not finish — 8 % of all positions, dense in their lanes: the kernels' time is the depth of their chains of dependent loads times the rounds of resident threads, and skipping the
+// finished positions inside a grid over ALL positions removed bytes, not rounds (measured: 0.75 -> 0.70 ms for the whole walk preparation).  NONE: nothing for this slot.
+template <bool LIST> __device__ __forceinline__ agx_u32 agx_wp_position(const agx_compact_args &A, agx_u32 j) {
     if (!LIST) { const agx_u32 X = blockIdx.x * (256u * AGX_WP_POS) + threadIdx.x + j * 256u; return (X < A.n_pos && !(A.pos_succ[X] & AGX_PS_DONE)) ? X : AGX_NONE; }
-    const agx_u32 e = chunk * (256u * AGX_WP_POS) + threadIdx.x + j * 256u;
-    if (e >= L.pre[AGX_WP_GROUP]) return AGX_NONE;
-    agx_u32 g = 0;
-#pragma unroll
-    for (agx_u32 q = 1; q < AGX_WP_GROUP; q++) g += e >= L.pre[q] ? 1u : 0u;      // the list that holds entry e
-    agx_u32 lo = L.pre[0];
-#pragma unroll
-    for (agx_u32 q = 1; q < AGX_WP_GROUP; q++) lo = e >= L.pre[q] ? L.pre[q] : lo;
-    return A.todo_list[(size_t)(L.r0 + g) * AGX_TODO_CAP + (e - lo)];
+    const agx_u32 r = blockIdx.x >> 1, e = (blockIdx.x & 1u) * (256u * AGX_WP_POS) + threadIdx.x + j * 256u;
+    static_assert(2u * 256u * AGX_WP_POS == AGX_TODO_CAP, "two blocks cover a region's list");
+    const agx_u32 cnt = agx_uload(A.todo_cnt, (size_t)r * AGX_REGION_PAD + 1);
+    return e < cnt ? A.todo_list[(size_t)r * AGX_TODO_CAP + e] : AGX_NONE;
 }
 template <bool LIST> __global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A, const agx_u32 *chain_end, agx_u32 n_chain_end) {
     AGX_RETURN_IF_ABORTED(A.abort);
     for (agx_u32 g = blockIdx.x * 256u + threadIdx.x; g < n_chain_end; g += gridDim.x * 256u) A.a_mark[chain_end[g]] = 1;
-    const agx_wp_lists L = agx_wp_open<LIST>(A);
-    const agx_u32 n_chunks = LIST ? (L.pre[AGX_WP_GROUP] + 256u * AGX_WP_POS - 1u) / (256u * AGX_WP_POS) : 1u;
-    for (agx_u32 chunk = 0; chunk < n_chunks; chunk++) {
-        agx_u32 s[AGX_WP_POS], n[AGX_WP_POS], fl[AGX_WP_POS], XX[AGX_WP_POS];
+    agx_u32 s[AGX_WP_POS], n[AGX_WP_POS], fl[AGX_WP_POS], XX[AGX_WP_POS];
 #pragma unroll
-        for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
-            const agx_u32 X = XX[j] = agx_wp_position<LIST>(A, L, chunk, j);
-            const bool in = X != AGX_NONE;
-            s[j] = in ? A.node_start[X] : 0u; n[j] = in ? A.node_cnt[X] : 0xFFFFFFFFu;
-        }
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
+        const agx_u32 X = XX[j] = agx_wp_position<LIST>(A, j);
+        const bool in = X != AGX_NONE;      // (r06: the node sweep has finished most positions itself)
+        s[j] = in ? A.node_start[X] : 0u; n[j] = in ? A.node_cnt[X] : 0xFFFFFFFFu;
+    }
 #pragma unroll
-        for (agx_u32 j = 0; j < AGX_WP_POS; j++) fl[j] = n[j] == 1u ? A.n_flags[s[j]] : 0u;
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) fl[j] = n[j] == 1u ? A.n_flags[s[j]] : 0u;
 #pragma unroll
-        for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
-            const agx_u32 X = XX[j];
-            if (n[j] == 0xFFFFFFFFu) continue;
-            if (n[j] == 1u && !(fl[j] & AGX_NF_DEAD)) A.aid_of[s[j]] = X;                      // the position's only variant, alive: its main id
-            else if (n[j] <= 1u) {                                                           // no alive variant here
-                if (n[j]) A.aid_of[s[j]] = AGX_NONE;
-                A.a_meta[X] = (agx_u8)(AGX_WM_ABSENT | (n[j] ? AGX_WM_ANY : 0)); A.a_str[X] = 'N'; A.a_nid[X] = AGX_NONE;
-            } else agx_assign_aid_pos(A, X);
-        }
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
+        const agx_u32 X = XX[j];
+        if (n[j] == 0xFFFFFFFFu) continue;
+        if (n[j] == 1u && !(fl[j] & AGX_NF_DEAD)) A.aid_of[s[j]] = X;                      // the position's only variant, alive: its main id
+        else if (n[j] <= 1u) {                                                           // no alive variant here
+            if (n[j]) A.aid_of[s[j]] = AGX_NONE;
+            A.a_meta[X] = (agx_u8)(AGX_WM_ABSENT | (n[j] ? AGX_WM_ANY : 0)); A.a_str[X] = 'N'; A.a_nid[X] = AGX_NONE;
+        } else agx_assign_aid_pos(A, X);
     }
 }
-// (grid-stride: the overflow edges' rewrite)
+// (the first threads also rewrite the overflow edges)
 template <bool LIST> __global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap) {
     AGX_RETURN_IF_ABORTED(A.abort);
     const agx_u32 n_ovf = *n_ovf_dev; A.n_ovf = n_ovf < ovf_cap ? n_ovf : ovf_cap;
     for (agx_u32 g = blockIdx.x * 256u + threadIdx.x; g < A.n_ovf; g += gridDim.x * 256u) agx_emit_alive_ovf(A, g);
-    const agx_wp_lists L = agx_wp_open<LIST>(A);
-    const agx_u32 n_chunks = LIST ? (L.pre[AGX_WP_GROUP] + 256u * AGX_WP_POS - 1u) / (256u * AGX_WP_POS) : 1u;
-    for (agx_u32 chunk = 0; chunk < n_chunks; chunk++) {
-        agx_u32 s[AGX_WP_POS], n[AGX_WP_POS], a[AGX_WP_POS], fl[AGX_WP_POS], pk[AGX_WP_POS], XX[AGX_WP_POS]; char rf[AGX_WP_POS], bs[AGX_WP_POS]; uint4 nx[AGX_WP_POS];
+    agx_u32 s[AGX_WP_POS], n[AGX_WP_POS], a[AGX_WP_POS], fl[AGX_WP_POS], pk[AGX_WP_POS], XX[AGX_WP_POS]; char rf[AGX_WP_POS], bs[AGX_WP_POS]; uint4 nx[AGX_WP_POS];
 #pragma unroll
-        for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
-            const agx_u32 X = XX[j] = agx_wp_position<LIST>(A, L, chunk, j);
-            const bool in = X != AGX_NONE;
-            s[j] = in ? A.node_start[X] : 0u; n[j] = in ? A.node_cnt[X] : 0u; pk[j] = in ? A.side_pk[X] : 0u; rf[j] = in ? A.ref[X] : 'N';
-        }
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
+        const agx_u32 X = XX[j] = agx_wp_position<LIST>(A, j);
+        const bool in = X != AGX_NONE;
+        s[j] = in ? A.node_start[X] : 0u; n[j] = in ? A.node_cnt[X] : 0u; pk[j] = in ? A.side_pk[X] : 0u; rf[j] = in ? A.ref[X] : 'N';
+    }
 #pragma unroll
-        for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
-            const bool one = n[j] == 1u;
-            a[j] = one ? A.aid_of[s[j]] : AGX_NONE; fl[j] = one ? A.n_flags[s[j]] : 0u; bs[j] = one ? (char)A.n_base[s[j]] : 'X';
-            nx[j] = one ? *reinterpret_cast<const uint4 *>(A.n_next + (size_t)s[j] * AGX_MAXE) : make_uint4(AGX_NONE, AGX_NONE, AGX_NONE, AGX_NONE);
-        }
-        agx_u32 ta[AGX_WP_POS][AGX_MAXE];
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
+        const bool one = n[j] == 1u;
+        a[j] = one ? A.aid_of[s[j]] : AGX_NONE; fl[j] = one ? A.n_flags[s[j]] : 0u; bs[j] = one ? (char)A.n_base[s[j]] : 'X';
+        nx[j] = one ? *reinterpret_cast<const uint4 *>(A.n_next + (size_t)s[j] * AGX_MAXE) : make_uint4(AGX_NONE, AGX_NONE, AGX_NONE, AGX_NONE);
+    }
+    agx_u32 ta[AGX_WP_POS][AGX_MAXE];
 #pragma unroll
-        for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
-            const agx_u32 t[AGX_MAXE] = {nx[j].x, nx[j].y, nx[j].z, nx[j].w};
-            bool open = a[j] != AGX_NONE;                     // (the slots are filled front to back: the first NONE ends the list)
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
+        const agx_u32 t[AGX_MAXE] = {nx[j].x, nx[j].y, nx[j].z, nx[j].w};
+        bool open = a[j] != AGX_NONE;                     // (the slots are filled front to back: the first NONE ends the list)
 #pragma unroll
-            for (agx_u32 e = 0; e < AGX_MAXE; e++) { open = open && t[e] != AGX_NONE; ta[j][e] = open ? A.aid_of[t[e]] : AGX_NONE; }
-        }
+        for (agx_u32 e = 0; e < AGX_MAXE; e++) { open = open && t[e] != AGX_NONE; ta[j][e] = open ? A.aid_of[t[e]] : AGX_NONE; }
+    }
 #pragma unroll
-        for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
-            const agx_u32 X = XX[j];
-            if (n[j] > 1u) { agx_emit_alive_pos(A, X); continue; }
-            if (n[j] == 0u || a[j] == AGX_NONE) continue;
-            // agx_emit_alive_node() for the one variant of X, from what was loaded above
-            const agx_u32 v = s[j], id = a[j];
-            A.a_str[id] = bs[j] != 'X' ? bs[j] : rf[j];
-            A.a_nid[id] = v;
-            agx_u32 next[AGX_MAXE]; agx_u32 k = 0;
+    for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
+        const agx_u32 X = XX[j];
+        if (n[j] > 1u) { agx_emit_alive_pos(A, X); continue; }
+        if (n[j] == 0u || a[j] == AGX_NONE) continue;
+        // agx_emit_alive_node() for the one variant of X, from what was loaded above
+        const agx_u32 v = s[j], id = a[j];
+        A.a_str[id] = bs[j] != 'X' ? bs[j] : rf[j];
+        A.a_nid[id] = v;
+        agx_u32 next[AGX_MAXE]; agx_u32 k = 0;
 #pragma unroll
-            for (agx_u32 e = 0; e < AGX_MAXE; e++) if (ta[j][e] != AGX_NONE) next[k++] = ta[j][e];
-            const bool cont = k == 1 && !(fl[j] & AGX_NF_EOVF) && next[0] == id + 1;
-            agx_u8 m = (agx_u8)((cont ? AGX_WM_CONT : 0) | ((fl[j] & AGX_NF_CONTIG) ? AGX_WM_CONTIG : 0));
-            if (id < A.n_pos) m |= (agx_u8)(AGX_WM_ANY | ((pk[j] >> 16) ? AGX_WM_SIDE : 0));
-            else A.side_xpos[id - A.n_pos] = X;
-            A.a_meta[id] = m;
-            if (!cont) for (agx_u32 e = 0; e < k; e++) A.a_mark[next[e]] = 1;      // racing stores of the same value
-        }
+        for (agx_u32 e = 0; e < AGX_MAXE; e++) if (ta[j][e] != AGX_NONE) next[k++] = ta[j][e];
+        const bool cont = k == 1 && !(fl[j] & AGX_NF_EOVF) && next[0] == id + 1;
+        agx_u8 m = (agx_u8)((cont ? AGX_WM_CONT : 0) | ((fl[j] & AGX_NF_CONTIG) ? AGX_WM_CONTIG : 0));
+        if (id < A.n_pos) m |= (agx_u8)(AGX_WM_ANY | ((pk[j] >> 16) ? AGX_WM_SIDE : 0));
+        else A.side_xpos[id - A.n_pos] = X;
+        A.a_meta[id] = m;
+        if (!cont) for (agx_u32 e = 0; e < k; e++) A.a_mark[next[e]] = 1;      // racing stores of the same value
     }
 }
 // the special-id bitmap and its popcounts (input of the rank scan).  A wavefront takes four 64-id words — every lane one id of each, so that their loads
@@ -1020,10 +992,9 @@ void agx_launch_fetch_records(const agx_compact_args *A, agx_u32 first, agx_u32 
     if (n) hipLaunchKernelGGL(agx_k_fetch_records, dim3((n + 255) / 256), dim3(256), 0, st, *A, first, stride, rows, width, out);
 }
 void agx_launch_compact(const agx_compact_args *A, const agx_u32 *chain_end, agx_u32 n_chain_end, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t st) {
-    if (A->todo_list && A->regions) {      // over the lists of the positions the node sweep left (a block per AGX_WP_GROUP regions); the chain-end marks and the overflow edges ride in grid-stride loops
-        const agx_u32 grid = (A->regions + AGX_WP_GROUP - 1u) / AGX_WP_GROUP;
-        hipLaunchKernelGGL(agx_k_assign_aid<true>, dim3(grid), dim3(256), 0, st, *A, chain_end, n_chain_end);
-        hipLaunchKernelGGL(agx_k_emit_alive<true>, dim3(grid), dim3(256), 0, st, *A, n_ovf_dev, ovf_cap);
+    if (A->todo_list && A->regions) {      // over the lists of the positions the node sweep left (two blocks per region); the chain-end marks and the overflow edges ride in grid-stride loops
+        hipLaunchKernelGGL(agx_k_assign_aid<true>, dim3(2u * A->regions), dim3(256), 0, st, *A, chain_end, n_chain_end);
+        hipLaunchKernelGGL(agx_k_emit_alive<true>, dim3(2u * A->regions), dim3(256), 0, st, *A, n_ovf_dev, ovf_cap);
         return;
     }
     if (A->n_pos) hipLaunchKernelGGL(agx_k_assign_aid<false>, dim3((A->n_pos + 256 * AGX_WP_POS - 1) / (256 * AGX_WP_POS)), dim3(256), 0, st, *A, chain_end, n_chain_end);
