@@ -1125,11 +1125,7 @@ struct agx_compact_args {
     const agx_u32 *seg_index;   // device only: [n_pos / AGX_SEG_INDEX + 2] last rank-0 run that starts at or before position i * AGX_SEG_INDEX (0 if none does): where the search for a position's run begins
     const agx_u32 *abort;          // device only: the node sweeps' status word (non-zero: the node table is incomplete, the kernels do nothing)
     const agx_u8 *pos_succ;        // [n_pos] bit AGX_PS_DONE: the node sweep has written the position's walk-id data (agx_finish_simple_lane); null: it never does
-    // device only, r06: the positions the sweep did NOT finish, listed per region of the node pool (todo_list[r * AGX_TODO_CAP ..], todo_cnt[r * AGX_REGION_PAD + 1] of them): the walk
-    // preparation's two position kernels run over the lists — 8 % of the positions, dense in their lanes — instead of over every position; null: over every position
-    const agx_u32 *todo_list, *todo_cnt; agx_u32 regions;
 };
-#define AGX_TODO_CAP (AGX_REGION_TILES * AGX_TILE)      // a region's list holds each of its positions once at most
 
 // per position, after the scan: walk ids of its nodes; main slots without an alive node are marked absent (= visited from the start)
 AGX_HD void agx_assign_aid_pos(const agx_compact_args &A, agx_u32 X) {

@@ -288,7 +288,7 @@ struct agx_unit {
     DBuf<agx_dhit> d_dhit; DBuf<agx_u32> d_tile_cnt, d_tile_off, d_cursor, d_unsorted, d_tile_recs, d_scan_tmp, d_words; DBuf<unsigned long long> d_scan_desc; size_t scan_desc_n = 0;      // descriptors of the three one-launch scans   // d_words: counters/status
     // node table
     agx_u32 pool_cap = 0, spill_lo = 0, ovf_cap = 0, list_cap = 0, sp_cap = 0;
-    DBuf<agx_u32> d_pool_cnt, d_region_off, d_todo; agx_u32 n_regions = 0;      // d_todo: per region, the positions whose walk-id data the sweep did not finish      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
+    DBuf<agx_u32> d_pool_cnt, d_region_off; agx_u32 n_regions = 0;      // the node pool's slices (AGX_REGION_TILES tiles each) and their counters
     DBuf<agx_u32> d_node_start, d_slow_list, d_perm, d_tfirst, d_ckey, d_long; DBuf<agx_u16> d_node_cnt; DBuf<agx_u8> d_pos_succ;
     DBuf<agx_u32> d_cid, d_coff, d_cid0, d_coff0, d_off0, d_next; DBuf<agx_u8> d_base, d_flags; DBuf<agx_sref> d_sref; DBuf<int> d_counts;
     DBuf<agx_edge_ovf> d_ovf; DBuf<agx_u32> d_mid_list, d_big_list, d_scratch, d_huge_list, d_scratch_huge; bool huge = false, dense = false;      // dense: the scatter fallback of the tile lists is queued (a build met more than AGX_LONG_MAX long hits); huge: pass 3 of the node sweep is queued (a build met a position beyond AGX_MAXV_BIG variants)
@@ -917,7 +917,7 @@ Plan plan_capacities(const agx_unit *u) {
     const size_t ids_cap = n_pos + P.pool_cap;
     P.sp_cap = u->sp_cap ? u->sp_cap : (agx_u32)std::min<size_t>(g_tiny ? 32 : ids_cap / 4 + 4096, 0xFFFFFF00ull);      // special ids: 8 % on the bench unit
     // what the takes of do_upload add up to, plus the alignment of ~90 buffers
-    const size_t per_pos = 4 + 16 + 1 + 4 + 2 + 1 + 4 + 4 + 4, per_tile = 4 * 4 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_dhit) + 4 + 4 + 4;      // per hit: derived record, order, last-tile key, (pass J / long list)
+    const size_t per_pos = 4 + 16 + 1 + 4 + 2 + 1 + 4 + 4, per_tile = 4 * 4 + 4 * 2 + 4 * 2, per_hit_b = sizeof(agx_dhit) + 4 + 4 + 4;      // per hit: derived record, order, last-tile key, (pass J / long list)
     const size_t per_slot = 5 * 4 + 4 + 4 * AGX_MAXE + 1 + 1 + sizeof(agx_sref) + ((u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? 24 : 0) + 4 + 4, per_id = 1 + 1 + 4 + 1 + 3.0 * 8 / 64 + 1;
     const size_t wire = nh * sizeof(agx_whit) + u->n_sides * sizeof(agx_wside) + u->n_runs * sizeof(agx_wrun) + u->n_jump * 4 + (u->ref_packed ? n_pos / 4 + u->n_refx * sizeof(agx_refx) : 0) + 4096;
     const size_t total = wire + n_pos * per_pos + n_tiles * per_tile + nh * per_hit_b + u->n_runs * sizeof(agx_run) + u->n_cm * sizeof(agx_cmkey) + (u->rows_diffed ? u->n_units * 2 + u->n_rowcnt + (u->n_blockoff + u->n_blockfirst + u->n_anchor) * 4 : codes_bytes(u)) + n_bases + others_up(u) * 8 +
@@ -963,7 +963,7 @@ void do_upload(agx_unit *u) {
     u->d_side_pk.alloc(a, n_pos + 2); u->d_tile_side.alloc(a, (size_t)u->n_tiles + 2); u->d_tile_side_start.alloc(a, (size_t)u->n_tiles + 2);
     u->d_big_list.alloc(a, (size_t)u->n_tiles + 1); u->d_mid_list.alloc(a, (size_t)u->n_tiles + 1);
     u->d_scratch.alloc(a, (size_t)AGX_BIG_WAVES * AGX_NF * AGX_MAXV_BIG * 64);
-    u->d_region_off.alloc(a, (size_t)u->n_regions + 1); u->d_pool_cnt.alloc(a, (size_t)u->n_regions * AGX_REGION_PAD); u->d_todo.alloc(a, (size_t)u->n_regions * AGX_TODO_CAP);
+    u->d_region_off.alloc(a, (size_t)u->n_regions + 1); u->d_pool_cnt.alloc(a, (size_t)u->n_regions * AGX_REGION_PAD);
     alloc_lists(u, list_cap); alloc_ovf(u, ovf_cap); alloc_sparse(u, sp_cap);
     // copies: all of them on the device's upload stream, behind those of the units queued before.  The kernels that expand what was copied
     // (conti-mer tables, vote codes) open the unit's first build instead of following the copies here: a kernel on this stream would wait for
@@ -1184,7 +1184,6 @@ void do_build(agx_unit *u) {
         K.big_count = u->d_words.p + W_BIGCOUNT; K.big_list = u->d_big_list.p; K.status = u->d_words.p + W_STATUS;
         K.list_cap = u->list_cap; K.big_n = u->d_words.p + W_BIGCOUNT; K.scratch = u->d_scratch.p;
         K.slow_list = u->d_slow_list.p; K.slow_count = u->d_words.p + W_SLOWCOUNT; K.fallback_queued = 1u;
-        K.todo_list = K.S.a_meta ? u->d_todo.p : nullptr;
         K.huge_count = u->d_words.p + W_HUGECOUNT; K.huge_n = u->d_words.p + W_HUGECOUNT; K.huge_list = u->d_huge_list.p; K.scratch_huge = u->d_scratch_huge.p; K.huge_queued = u->huge ? 1u : 0u;
         for (agx_u32 w = 0; w < n_win; w++) {
             K.tile_lo = windows ? wt[w] : 0u; K.tile_hi = windows ? wt[w + 1] : u->n_tiles;
@@ -1230,7 +1229,6 @@ void do_build(agx_unit *u) {
         C.side_pk = u->d_side_pk.p; C.tile_side_start = u->d_tile_side_start.p; C.aid_of = u->d_aid_of.p;
         C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_nid = u->d_a_nid.p; C.ovf = u->d_ovf.p; C.n_ovf = 0; C.a_ovf = u->d_a_ovf.p;
         C.abort = u->d_words.p + W_STATUS; C.pos_succ = u->d_pos_succ.p;
-        C.todo_list = K.todo_list; C.todo_cnt = u->d_pool_cnt.p; C.regions = u->n_regions;
         C.a_mark = u->d_a_mark.p; C.side_xpos = u->d_side_xpos.p; C.sparse_min = (u->prm.flags & AGX_FLAG_SPARSE_MIN) ? 1u : 0u;
         C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p; C.sp_cap = u->sp_cap;
         C.segs = u->d_segs.p; C.n_seg0 = u->n_seg0; C.cm_start = u->d_cm_start.p; C.sp_hop = u->d_sp_hop.p; C.seg_index = u->d_segindex.p;
@@ -1492,7 +1490,7 @@ void do_release(agx_unit *u) {
     stream_wait_all(u);
     if (u->uploaded) { (void)hipSetDevice(u->prm.device); (void)hipEventSynchronize(u->ev_uploaded); (void)hipEventSynchronize(u->ev_built); (void)hipEventSynchronize(u->ev_dl); }      // (its commands are done before its memory goes)
     for (auto *b : {&u->d_cm_start, &u->d_tile_cnt, &u->d_tile_off, &u->d_cursor, &u->d_unsorted, &u->d_tile_recs, &u->d_scan_tmp, &u->d_words, &u->d_pool_cnt, &u->d_region_off, &u->d_node_start,
-                    &u->d_slow_list, &u->d_todo, &u->d_perm, &u->d_tfirst, &u->d_ckey, &u->d_long, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
+                    &u->d_slow_list, &u->d_perm, &u->d_tfirst, &u->d_ckey, &u->d_long, &u->d_cid, &u->d_coff, &u->d_cid0, &u->d_coff0, &u->d_off0, &u->d_next, &u->d_mid_list, &u->d_big_list, &u->d_scratch,
                     &u->d_side_pk, &u->d_tile_side, &u->d_tile_side_start, &u->d_aid_of, &u->d_a_nid, &u->d_chain_end, &u->d_side_xpos, &u->d_sp_cnt, &u->d_sp_rank}) b->release();
     u->d_node_cnt.release();
     for (auto *b : {&u->d_pos_succ, &u->d_base, &u->d_flags, &u->d_a_meta, &u->d_a_mark, &u->d_codes, &u->d_vcodes}) b->release();

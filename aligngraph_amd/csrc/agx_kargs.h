@@ -38,7 +38,6 @@ struct agx_node_kargs {
     agx_u32 *scratch;          // fallback pass: one [AGX_NF*AGX_MAXV_BIG*64] bucket area per resident wavefront
     agx_u32 *huge_count; agx_u32 *huge_list; const agx_u32 *huge_n; agx_u32 *scratch_huge; agx_u32 huge_queued;   // pass 3 (AGX_MAXV_HUGE variants): tiles pass 2 gave up on
     agx_u32 *slow_list; agx_u32 *slow_count;   // the edge build's pass-B list: the sweep itself enters multi-variant positions with a position-skipping step
-    agx_u32 *todo_list;        // r06: the positions whose walk-id data the sweep could not finish (agx_finish_simple_lane), per region: [regions * AGX_TODO_CAP], counted in pool_cnt[r * AGX_REGION_PAD + 1]; null: not listed
 };
 
 struct agx_edge_kargs {

@@ -528,18 +528,7 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
         const agx_u32 side = wr.side;
         // r06: the positions whose walk-id data needs nothing from anywhere else are finished here (the next position's surviving variants are one lane away)
         const agx_u32 nalive = (agx_u32)__shfl_down((int)wr.alive_mask, 1, 64);
-        const bool done = agx_finish_simple_lane(K.S, X, cnt, my_base, wr, edges, pflag, nalive);
-        if (done) K.S.pos_succ[X] = (agx_u8)(pflag | (edges ? 0x80u : 0u) | AGX_PS_DONE);
-        if (K.todo_list) {                                  // the others go on their region's list for the walk preparation (one counter update per tile, on the line of the region's pool counter)
-            const bool todo = X < K.S.n_pos && !done;
-            const unsigned long long tm = __ballot(todo);
-            if (tm) {
-                agx_u32 at = 0;
-                if (lane == 0) at = atomicAdd(K.pool_cnt + (size_t)region * AGX_REGION_PAD + 1, (agx_u32)__popcll(tm));
-                at = (agx_u32)__shfl((int)at, 0, 64);
-                if (todo) K.todo_list[(size_t)region * AGX_TODO_CAP + at + (agx_u32)__popcll(tm & ((1ull << lane) - 1ull))] = X;
-            }
-        }
+        if (agx_finish_simple_lane(K.S, X, cnt, my_base, wr, edges, pflag, nalive)) K.S.pos_succ[X] = (agx_u8)(pflag | (edges ? 0x80u : 0u) | AGX_PS_DONE);
         const agx_u32 side_incl = agx_wave_incl_scan(side, lane);
         if (X < K.S.n_pos) K.S.side_pk[X] = agx_side_pack(side_incl - side, side);
         if (lane == 63u) K.S.tile_side[tile] = side_incl;
@@ -666,31 +655,22 @@ __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
 #define AGX_WP_POS 4u
 #endif
 // (the first threads also mark the main ids of the chain-end positions: a_mark is complete before anything reads it)
-// The j-th position of this thread.  LIST (r06): the grid is two blocks per region of the node pool, each over half of the region's list of positions that the node sweep did
-// not finish — 8 % of all positions, dense in their lanes: the kernels' time is the depth of their chains of dependent loads times the rounds of resident threads, and skipping the
-// finished positions inside a grid over ALL positions removed bytes, not rounds (measured: 0.75 -> 0.70 ms for the whole walk preparation).  NONE: nothing for this slot.
-template <bool LIST> __device__ __forceinline__ agx_u32 agx_wp_position(const agx_compact_args &A, agx_u32 j) {
-    if (!LIST) { const agx_u32 X = blockIdx.x * (256u * AGX_WP_POS) + threadIdx.x + j * 256u; return (X < A.n_pos && !(A.pos_succ[X] & AGX_PS_DONE)) ? X : AGX_NONE; }
-    const agx_u32 r = blockIdx.x >> 1, e = (blockIdx.x & 1u) * (256u * AGX_WP_POS) + threadIdx.x + j * 256u;
-    static_assert(2u * 256u * AGX_WP_POS == AGX_TODO_CAP, "two blocks cover a region's list");
-    const agx_u32 cnt = agx_uload(A.todo_cnt, (size_t)r * AGX_REGION_PAD + 1);
-    return e < cnt ? A.todo_list[(size_t)r * AGX_TODO_CAP + e] : AGX_NONE;
-}
-template <bool LIST> __global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A, const agx_u32 *chain_end, agx_u32 n_chain_end) {
+__global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A, const agx_u32 *chain_end, agx_u32 n_chain_end) {
     AGX_RETURN_IF_ABORTED(A.abort);
-    for (agx_u32 g = blockIdx.x * 256u + threadIdx.x; g < n_chain_end; g += gridDim.x * 256u) A.a_mark[chain_end[g]] = 1;
-    agx_u32 s[AGX_WP_POS], n[AGX_WP_POS], fl[AGX_WP_POS], XX[AGX_WP_POS];
+    const agx_u32 base = blockIdx.x * (256u * AGX_WP_POS) + threadIdx.x;
+    agx_u32 s[AGX_WP_POS], n[AGX_WP_POS], fl[AGX_WP_POS];
 #pragma unroll
     for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
-        const agx_u32 X = XX[j] = agx_wp_position<LIST>(A, j);
-        const bool in = X != AGX_NONE;      // (r06: the node sweep has finished most positions itself)
+        const agx_u32 X = base + j * 256u;
+        if (X < n_chain_end) A.a_mark[chain_end[X]] = 1;
+        const bool in = X < A.n_pos && !(A.pos_succ[X] & AGX_PS_DONE);      // (r06: the node sweep has finished most positions itself — one flag byte instead of the node table)
         s[j] = in ? A.node_start[X] : 0u; n[j] = in ? A.node_cnt[X] : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (agx_u32 j = 0; j < AGX_WP_POS; j++) fl[j] = n[j] == 1u ? A.n_flags[s[j]] : 0u;
 #pragma unroll
     for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
-        const agx_u32 X = XX[j];
+        const agx_u32 X = base + j * 256u;
         if (n[j] == 0xFFFFFFFFu) continue;
         if (n[j] == 1u && !(fl[j] & AGX_NF_DEAD)) A.aid_of[s[j]] = X;                      // the position's only variant, alive: its main id
         else if (n[j] <= 1u) {                                                           // no alive variant here
@@ -700,15 +680,16 @@ template <bool LIST> __global__ void __launch_bounds__(256) agx_k_assign_aid(agx
     }
 }
 // (the first threads also rewrite the overflow edges)
-template <bool LIST> __global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap) {
+__global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap) {
     AGX_RETURN_IF_ABORTED(A.abort);
+    const agx_u32 base = blockIdx.x * (256u * AGX_WP_POS) + threadIdx.x;
     const agx_u32 n_ovf = *n_ovf_dev; A.n_ovf = n_ovf < ovf_cap ? n_ovf : ovf_cap;
-    for (agx_u32 g = blockIdx.x * 256u + threadIdx.x; g < A.n_ovf; g += gridDim.x * 256u) agx_emit_alive_ovf(A, g);
-    agx_u32 s[AGX_WP_POS], n[AGX_WP_POS], a[AGX_WP_POS], fl[AGX_WP_POS], pk[AGX_WP_POS], XX[AGX_WP_POS]; char rf[AGX_WP_POS], bs[AGX_WP_POS]; uint4 nx[AGX_WP_POS];
+    agx_u32 s[AGX_WP_POS], n[AGX_WP_POS], a[AGX_WP_POS], fl[AGX_WP_POS], pk[AGX_WP_POS]; char rf[AGX_WP_POS], bs[AGX_WP_POS]; uint4 nx[AGX_WP_POS];
 #pragma unroll
     for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
-        const agx_u32 X = XX[j] = agx_wp_position<LIST>(A, j);
-        const bool in = X != AGX_NONE;
+        const agx_u32 X = base + j * 256u;
+        agx_emit_alive_ovf(A, X);
+        const bool in = X < A.n_pos && !(A.pos_succ[X] & AGX_PS_DONE);
         s[j] = in ? A.node_start[X] : 0u; n[j] = in ? A.node_cnt[X] : 0u; pk[j] = in ? A.side_pk[X] : 0u; rf[j] = in ? A.ref[X] : 'N';
     }
 #pragma unroll
@@ -727,7 +708,7 @@ template <bool LIST> __global__ void __launch_bounds__(256) agx_k_emit_alive(agx
     }
 #pragma unroll
     for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
-        const agx_u32 X = XX[j];
+        const agx_u32 X = base + j * 256u;
         if (n[j] > 1u) { agx_emit_alive_pos(A, X); continue; }
         if (n[j] == 0u || a[j] == AGX_NONE) continue;
         // agx_emit_alive_node() for the one variant of X, from what was loaded above
@@ -992,13 +973,9 @@ void agx_launch_fetch_records(const agx_compact_args *A, agx_u32 first, agx_u32 
     if (n) hipLaunchKernelGGL(agx_k_fetch_records, dim3((n + 255) / 256), dim3(256), 0, st, *A, first, stride, rows, width, out);
 }
 void agx_launch_compact(const agx_compact_args *A, const agx_u32 *chain_end, agx_u32 n_chain_end, const agx_u32 *n_ovf_dev, agx_u32 ovf_cap, hipStream_t st) {
-    if (A->todo_list && A->regions) {      // over the lists of the positions the node sweep left (two blocks per region); the chain-end marks and the overflow edges ride in grid-stride loops
-        hipLaunchKernelGGL(agx_k_assign_aid<true>, dim3(2u * A->regions), dim3(256), 0, st, *A, chain_end, n_chain_end);
-        hipLaunchKernelGGL(agx_k_emit_alive<true>, dim3(2u * A->regions), dim3(256), 0, st, *A, n_ovf_dev, ovf_cap);
-        return;
-    }
-    if (A->n_pos) hipLaunchKernelGGL(agx_k_assign_aid<false>, dim3((A->n_pos + 256 * AGX_WP_POS - 1) / (256 * AGX_WP_POS)), dim3(256), 0, st, *A, chain_end, n_chain_end);
-    if (A->n_pos) hipLaunchKernelGGL(agx_k_emit_alive<false>, dim3((A->n_pos + 256 * AGX_WP_POS - 1) / (256 * AGX_WP_POS)), dim3(256), 0, st, *A, n_ovf_dev, ovf_cap);
+    const agx_u32 n1 = A->n_pos > n_chain_end ? A->n_pos : n_chain_end, n2 = A->n_pos > ovf_cap ? A->n_pos : ovf_cap;
+    if (n1) hipLaunchKernelGGL(agx_k_assign_aid, dim3((n1 + 256 * AGX_WP_POS - 1) / (256 * AGX_WP_POS)), dim3(256), 0, st, *A, chain_end, n_chain_end);
+    if (n2) hipLaunchKernelGGL(agx_k_emit_alive, dim3((n2 + 256 * AGX_WP_POS - 1) / (256 * AGX_WP_POS)), dim3(256), 0, st, *A, n_ovf_dev, ovf_cap);
 }
 // sparse record table over n_words 64-id words (the id capacity; the live id count is read on the device); scan_tmp as for the scans
 void agx_launch_special(const agx_compact_args *A, agx_u32 n_words, agx_u32 *sp_rank, agx_u32 *scan_tmp, unsigned long long *desc,
