@@ -481,8 +481,6 @@ struct agx_sweep_args {
     agx_sref *n_sref;
     agx_u32 *n_next;              // [pool*AGX_MAXE]
     int *n_counts;                // optional [pool*6] cov,A,C,G,T,N (parity/debug), may be null
-    // r06: the walk-id data of the positions the sweep can finish by itself (agx_finish_simple_lane), or null: the walk preparation does every position
-    char *a_str; agx_u8 *a_meta; agx_u32 *aid_of; agx_u32 *a_nid;
     agx_u32 pool_cap;
     agx_u32 *sweep_stats;         // profiling builds only (-DAGX_SWEEP_STATS): event counters of the node sweep, else null
 };
@@ -833,15 +831,9 @@ AGX_HD char agx_consensus(agx_u32 a, agx_u32 c, agx_u32 g, agx_u32 t, agx_u32 n)
 // AGX_EM_W variants): its x -> x+1 edges are written here — bn is the next position's bucket, [nbase, nbase+ncnt) its node ids — after the
 // contig-consistency test between the two stored keys (AG:1602-1615), and bit 7 of pos_succ tells the edge passes so.
 // Returns the position's side ids (surviving variants beyond the first); the caller turns them into side_pk / tile_side.
-// what a lane's write-out tells the caller: side ids; which of the position's variants survive the prune (bit v); the variants of the next position that variant 0 has an edge to
-// (bit w; only where `edges`); variant 0's consensus base and whether it carries a contig offset
-struct agx_wrote { agx_u32 side, alive_mask, tmask0; agx_u8 base0, contig0; };
-enum { AGX_WM_CONT = 1, AGX_WM_CONTIG = 2, AGX_WM_SIDE = 4, AGX_WM_ANY = 8, AGX_WM_ABSENT = 128 };      // a_meta bits (see "walk preparation" below)
-#define AGX_PS_DONE 0x40u      // pos_succ bit 6: the node sweep has written this position's walk-id data itself (agx_finish_simple_lane): the walk preparation skips it
-AGX_HD agx_wrote agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bucket &b, agx_u32 cnt, agx_u32 base, agx_u32 pflag,
+AGX_HD agx_u32 agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx_bucket &b, agx_u32 cnt, agx_u32 base, agx_u32 pflag,
                                    bool edges, agx_u32 emask, const agx_bucket &bn, agx_u32 nbase, agx_u32 ncnt) {
-    agx_wrote W; W.side = 0; W.alive_mask = 0; W.tmask0 = 0; W.base0 = 'X'; W.contig0 = 0;
-    if (X >= A.n_pos) return W;
+    if (X >= A.n_pos) return 0;
     A.node_start[X] = base; A.node_cnt[X] = (agx_u16)cnt; A.pos_succ[X] = (agx_u8)(pflag | (edges ? 0x80u : 0u));
     agx_u32 alive = 0;
     for (agx_u32 v = 0; v < cnt; v++) {
@@ -851,12 +843,10 @@ AGX_HD agx_wrote agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const a
         A.nk_cid[id] = cid; A.nk_coff[id] = coff; A.nk_cid0[id] = cid0; A.nk_coff0[id] = coff0;
         A.nk_off0[id] = agx_b(b, v, AGX_F_OFF0);      // (r06: no per-node position array — a node's position is its walk id's: the id itself, or side_xpos — 4 bytes per node less to write)
         const agx_u32 va = agx_b(b, v, AGX_F_A), vc = agx_b(b, v, AGX_F_C), vg = agx_b(b, v, AGX_F_G), vt = agx_b(b, v, AGX_F_T), vn = agx_b(b, v, AGX_F_N);
-        const agx_u8 cons = (agx_u8)agx_consensus(va, vc, vg, vt, vn);
-        A.n_base[id] = cons;
+        A.n_base[id] = (agx_u8)agx_consensus(va, vc, vg, vt, vn);
         agx_u8 fl = 0;
-        if (cid == AGX_NONE && (int)cov < A.coverage) fl |= AGX_NF_DEAD; else { alive++; if (v < 32u) W.alive_mask |= 1u << v; }
+        if (cid == AGX_NONE && (int)cov < A.coverage) fl |= AGX_NF_DEAD; else alive++;
         if (coff != AGX_NONE) fl |= AGX_NF_CONTIG;
-        if (v == 0) { W.base0 = cons; W.contig0 = coff != AGX_NONE ? 1 : 0; }
         A.n_flags[id] = fl;
         agx_sref s; s.slot = agx_b(b, v, AGX_F_S0); s.qlen = agx_b(b, v, AGX_F_S1); A.n_sref[id] = s;
         agx_u32 slot[AGX_MAXE]; agx_u32 k = 0;
@@ -866,34 +856,12 @@ AGX_HD agx_wrote agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const a
                 if (!((emask >> (v * AGX_EM_W + w)) & 1u)) continue;
                 const agx_u32 ok = agx_clause_ab(agx_b(bn, w, AGX_F_CID), agx_b(bn, w, AGX_F_COFF), cid, coff, AGX_EP25) &
                                    agx_clause_ab(agx_b(bn, w, AGX_F_CID0), agx_b(bn, w, AGX_F_COFF0), cid0, coff0, 2 * A.iv + AGX_EP25);       // agx_edge_allowed
-                if (ok) { slot[k++] = nbase + w; if (v == 0) W.tmask0 |= 1u << w; }
+                if (ok) slot[k++] = nbase + w;
             }
         for (agx_u32 e = 0; e < AGX_MAXE; e++) A.n_next[(size_t)id * AGX_MAXE + e] = slot[e];
         if (A.n_counts) { int *c = A.n_counts + (size_t)id * 6; c[0] = (int)cov; c[1] = (int)va; c[2] = (int)vc; c[3] = (int)vg; c[4] = (int)vt; c[5] = (int)vn; }
     }
-    W.side = alive ? alive - 1 : 0;                 // walk ids: the first surviving variant takes the position's main id, the others go to the side block
-    return W;
-}
-// r06: what the walk preparation (agx_assign_aid_pos + agx_emit_alive_node) would make of this position, made here where everything it needs is at hand — for the positions
-// that need nothing from anywhere else: no variant (the main id is absent), one pruned variant, or ONE surviving variant whose edges the sweep has completed (`edges`), from which
-// no arrival jumps elsewhere (pass J adds nothing) and whose surviving targets are none, or exactly the first surviving variant of the next position (its id is X + 1: the forced
-// step).  92 % of a unit's positions: the two kernels of the walk preparation then read one flag byte for them instead of 45 bytes of node table.  nalive: the next position's
-// alive_mask (its lane's, one shuffle away).  true: done — the caller sets AGX_PS_DONE.
-AGX_HD bool agx_finish_simple_lane(const agx_sweep_args &A, agx_u32 X, agx_u32 cnt, agx_u32 base, const agx_wrote &W, bool edges, agx_u32 pflag, agx_u32 nalive) {
-    if (!A.a_meta || X >= A.n_pos || cnt > 1) return false;
-    if (cnt == 0 || !(W.alive_mask & 1u)) {            // nothing survives here: the main id is absent (= visited from the start)
-        if (cnt) A.aid_of[base] = AGX_NONE;
-        A.a_meta[X] = (agx_u8)(AGX_WM_ABSENT | (cnt ? AGX_WM_ANY : 0)); A.a_str[X] = 'N'; A.a_nid[X] = AGX_NONE;
-        return true;
-    }
-    if (!edges || (pflag & 2u)) return false;
-    const agx_u32 t = W.tmask0 & nalive;               // the surviving targets
-    const bool cont = t != 0 && t == (nalive & (0u - nalive));      // exactly one, and it is the next position's first surviving variant: walk id X + 1
-    if (t != 0 && !cont) return false;                 // a branch, or a step onto a side variant: its targets must be marked (agx_emit_alive_node)
-    A.aid_of[base] = X; A.a_nid[X] = base;
-    A.a_str[X] = W.base0 != 'X' ? (char)W.base0 : A.ref[X];
-    A.a_meta[X] = (agx_u8)((cont ? AGX_WM_CONT : 0) | (W.contig0 ? AGX_WM_CONTIG : 0) | AGX_WM_ANY);
-    return true;
+    return alive ? alive - 1 : 0;                   // walk ids: the first surviving variant takes the position's main id, the others go to the side block
 }
 static_assert(63u * (AGX_MAXV_HUGE - 1u) < 65536u && AGX_MAXV_HUGE <= 65535u, "side ids of a tile's first 63 positions must fit 16 bits");
 AGX_HD agx_u32 agx_side_pack(agx_u32 before_in_tile, agx_u32 here) { return before_in_tile | (here << 16); }
@@ -1090,7 +1058,7 @@ struct agx_hop { agx_u32 str_off, len, end_pos; };
 
 // a_meta bits: forced step to id+1; contigOffset != -1 (AG:2004); (main ids) the position has further alive variants in the side
 // block; (main ids) the position holds at least one variant, pruned or not (scaffold gap rule, AG:2428); no node at this id
-// (the AGX_WM_* enum itself stands in front of agx_node_write_lane: the node sweep writes these bytes for the positions it can finish)
+enum { AGX_WM_CONT = 1, AGX_WM_CONTIG = 2, AGX_WM_SIDE = 4, AGX_WM_ANY = 8, AGX_WM_ABSENT = 128 };
 
 // The host walk reads a node's 32-byte record only where a walk can start, stop, branch or land: everything inside a forced run is
 // covered by the meta and base bytes.  The device therefore hands over a SPARSE record table: the records of the "special" ids in id
@@ -1124,12 +1092,11 @@ struct agx_compact_args {
     const agx_cmseg *segs; agx_u32 n_seg0; const agx_u32 *cm_start; agx_hop *sp_hop;   // device only: hop entries of the special ids' positions, from the runs
     const agx_u32 *seg_index;   // device only: [n_pos / AGX_SEG_INDEX + 2] last rank-0 run that starts at or before position i * AGX_SEG_INDEX (0 if none does): where the search for a position's run begins
     const agx_u32 *abort;          // device only: the node sweeps' status word (non-zero: the node table is incomplete, the kernels do nothing)
-    const agx_u8 *pos_succ;        // [n_pos] bit AGX_PS_DONE: the node sweep has written the position's walk-id data (agx_finish_simple_lane); null: it never does
 };
 
 // per position, after the scan: walk ids of its nodes; main slots without an alive node are marked absent (= visited from the start)
 AGX_HD void agx_assign_aid_pos(const agx_compact_args &A, agx_u32 X) {
-    if (X >= A.n_pos || (A.pos_succ && (A.pos_succ[X] & AGX_PS_DONE))) return;
+    if (X >= A.n_pos) return;
     const agx_u32 s = A.node_start[X], n = A.node_cnt[X]; agx_u32 side = A.n_pos + A.tile_side_start[X / AGX_TILE] + (A.side_pk[X] & 0xFFFFu); bool first = true;
     for (agx_u32 v = 0; v < n; v++) {
         if (A.n_flags[s + v] & AGX_NF_DEAD) { A.aid_of[s + v] = AGX_NONE; continue; }
@@ -1182,7 +1149,7 @@ AGX_HD agx_walknode agx_walk_record(const agx_compact_args &A, agx_u32 a) {
 
 // per position: its nodes (the node table is only ever entered through node_start / node_cnt: the pool it lives in has unused slots)
 AGX_HD void agx_emit_alive_pos(const agx_compact_args &A, agx_u32 X) {
-    if (X >= A.n_pos || (A.pos_succ && (A.pos_succ[X] & AGX_PS_DONE))) return;
+    if (X >= A.n_pos) return;
     const agx_u32 s = A.node_start[X], n = A.node_cnt[X];
     for (agx_u32 v = 0; v < n; v++) agx_emit_alive_node(A, s + v, X);
 }

@@ -389,8 +389,6 @@ void fill_sweep_args(agx_unit *u, agx_sweep_args &S) {
     S.n_counts = (u->prm.flags & AGX_FLAG_KEEP_COUNTS) ? u->d_counts.p : nullptr;
     S.pool_cap = u->pool_cap;
     S.sweep_stats = nullptr;
-    const bool finish = getenv("AGX_NO_SWEEP_FINISH") == nullptr;      // (A/B: the walk preparation does every position, as in r05)
-    S.a_str = finish ? u->d_a_str.p : nullptr; S.a_meta = finish ? u->d_a_meta.p : nullptr; S.aid_of = finish ? u->d_aid_of.p : nullptr; S.a_nid = finish ? u->d_a_nid.p : nullptr;
 }
 
 // ---- staging: the packed arrays a unit was handed, in the form and the memory the upload wants -------------------------------------
@@ -1228,7 +1226,7 @@ void do_build(agx_unit *u) {
         C.nk_off0 = u->d_off0.p; C.n_sref = u->d_sref.p; C.n_next = u->d_next.p; C.ref = u->d_ref.p; C.n_pos = n_pos;
         C.side_pk = u->d_side_pk.p; C.tile_side_start = u->d_tile_side_start.p; C.aid_of = u->d_aid_of.p;
         C.a_str = u->d_a_str.p; C.a_meta = u->d_a_meta.p; C.a_nid = u->d_a_nid.p; C.ovf = u->d_ovf.p; C.n_ovf = 0; C.a_ovf = u->d_a_ovf.p;
-        C.abort = u->d_words.p + W_STATUS; C.pos_succ = u->d_pos_succ.p;
+        C.abort = u->d_words.p + W_STATUS;
         C.a_mark = u->d_a_mark.p; C.side_xpos = u->d_side_xpos.p; C.sparse_min = (u->prm.flags & AGX_FLAG_SPARSE_MIN) ? 1u : 0u;
         C.sp_bits = u->d_sp_bits.p; C.sp_cnt = u->d_sp_cnt.p; C.sp_rank = u->d_sp_rank.p; C.sp_node = u->d_sp_node.p; C.sp_cap = u->sp_cap;
         C.segs = u->d_segs.p; C.n_seg0 = u->n_seg0; C.cm_start = u->d_cm_start.p; C.sp_hop = u->d_sp_hop.p; C.seg_index = u->d_segindex.p;

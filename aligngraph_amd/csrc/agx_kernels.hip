@@ -524,11 +524,7 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
         const agx_u32 nbase = (agx_u32)__shfl_down((int)my_base, 1, 64), ncnt = (agx_u32)__shfl_down((int)cnt, 1, 64);
         agx_bucket bn = b; bn.base = b.base + 1;           // the next position's bucket is the next lane's column
         const bool edges = !BIG && lane < 63u && X + 1 < K.S.n_pos && cnt <= AGX_EM_W && ncnt <= AGX_EM_W;
-        const agx_wrote wr = agx_node_write_lane(K.S, X, b, cnt, my_base, pflag, edges, emask, bn, nbase, ncnt);
-        const agx_u32 side = wr.side;
-        // r06: the positions whose walk-id data needs nothing from anywhere else are finished here (the next position's surviving variants are one lane away)
-        const agx_u32 nalive = (agx_u32)__shfl_down((int)wr.alive_mask, 1, 64);
-        if (agx_finish_simple_lane(K.S, X, cnt, my_base, wr, edges, pflag, nalive)) K.S.pos_succ[X] = (agx_u8)(pflag | (edges ? 0x80u : 0u) | AGX_PS_DONE);
+        const agx_u32 side = agx_node_write_lane(K.S, X, b, cnt, my_base, pflag, edges, emask, bn, nbase, ncnt);
         const agx_u32 side_incl = agx_wave_incl_scan(side, lane);
         if (X < K.S.n_pos) K.S.side_pk[X] = agx_side_pack(side_incl - side, side);
         if (lane == 63u) K.S.tile_side[tile] = side_incl;
@@ -663,7 +659,7 @@ __global__ void __launch_bounds__(256) agx_k_assign_aid(agx_compact_args A, cons
     for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
         const agx_u32 X = base + j * 256u;
         if (X < n_chain_end) A.a_mark[chain_end[X]] = 1;
-        const bool in = X < A.n_pos && !(A.pos_succ[X] & AGX_PS_DONE);      // (r06: the node sweep has finished most positions itself — one flag byte instead of the node table)
+        const bool in = X < A.n_pos;
         s[j] = in ? A.node_start[X] : 0u; n[j] = in ? A.node_cnt[X] : 0xFFFFFFFFu;
     }
 #pragma unroll
@@ -689,7 +685,7 @@ __global__ void __launch_bounds__(256) agx_k_emit_alive(agx_compact_args A, cons
     for (agx_u32 j = 0; j < AGX_WP_POS; j++) {
         const agx_u32 X = base + j * 256u;
         agx_emit_alive_ovf(A, X);
-        const bool in = X < A.n_pos && !(A.pos_succ[X] & AGX_PS_DONE);
+        const bool in = X < A.n_pos;
         s[j] = in ? A.node_start[X] : 0u; n[j] = in ? A.node_cnt[X] : 0u; pk[j] = in ? A.side_pk[X] : 0u; rf[j] = in ? A.ref[X] : 'N';
     }
 #pragma unroll

@@ -35,7 +35,7 @@ struct SimGraph {
     std::vector<agx_u32> side_xpos, sp_cnt, sp_rank; std::vector<unsigned long long> sp_bits; agx_u32 n_special = 0;
     void reserve(size_t cap) {
         cid.resize(cap); coff.resize(cap); cid0.resize(cap); coff0.resize(cap); off0.resize(cap); xpos.resize(cap); next.resize(cap * AGX_MAXE);
-        base.resize(cap); flags.resize(cap); sref.resize(cap); counts.resize(cap * 6); aid_of.resize(cap + 1, AGX_NONE);
+        base.resize(cap); flags.resize(cap); sref.resize(cap); counts.resize(cap * 6);
     }
 };
 
@@ -123,11 +123,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
         A.nk_cid = S.cid.data(); A.nk_coff = S.coff.data(); A.nk_cid0 = S.cid0.data(); A.nk_coff0 = S.coff0.data(); A.nk_off0 = S.off0.data();
         A.n_base = S.base.data(); A.n_flags = S.flags.data(); A.n_sref = S.sref.data(); A.n_next = S.next.data();
         A.n_counts = S.counts.data(); A.pool_cap = (agx_u32)S.cid.size();
-        // (r06: the sweep finishes the positions it can — agx_finish_simple_lane; AGX_SIM_NO_SWEEP_FINISH=1: the walk preparation does them all, as in r05)
-        const bool finish = getenv("AGX_SIM_NO_SWEEP_FINISH") == nullptr;
-        A.a_str = finish ? &S.a_str[0] : nullptr; A.a_meta = finish ? S.a_meta.data() : nullptr; A.aid_of = finish ? S.aid_of.data() : nullptr; A.a_nid = finish ? S.a_nid.data() : nullptr;
     };
-    S.a_str.assign((size_t)n_pos + 1, 0); S.a_meta.assign((size_t)n_pos + 65, 0); S.a_nid.assign((size_t)n_pos + 1, AGX_NONE);
     bind();
     n_big_tiles = 0;
     agx_u32 pool = 0;
@@ -157,7 +153,6 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
         if (pool + total > S.cid.size()) { S.reserve((pool + total) * 2); bind(); }
         agx_bucket wb{nullptr, AGX_TILE, maxv}, wn{nullptr, AGX_TILE, maxv};
         agx_u32 side_before = 0;                       // the kernel's wave scan
-        agx_wrote wrote[AGX_TILE]; agx_u32 first_id[AGX_TILE]; bool had_edges[AGX_TILE];
         for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
             const agx_u32 X = t * AGX_TILE + lane;
             wb.base = store + lane; wn.base = store + lane + 1;
@@ -165,16 +160,10 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
             const bool edges = ok && lane < AGX_TILE - 1 && X + 1 < n_pos && cnt[lane] <= AGX_EM_W && ncnt <= AGX_EM_W;
             agx_u32 emask = 0;
             if (edges) for (size_t i = 0; i < touched[lane].size(); i++) agx_edge_merge(emask, touched[lane][i].sp, touched[lane + 1][i].vm);
-            wrote[lane] = agx_node_write_lane(A, X, wb, cnt[lane], pool, pflag[lane], edges, emask, wn, pool + cnt[lane], ncnt);
-            first_id[lane] = pool; had_edges[lane] = edges;
-            const agx_u32 side = wrote[lane].side;
+            const agx_u32 side = agx_node_write_lane(A, X, wb, cnt[lane], pool, pflag[lane], edges, emask, wn, pool + cnt[lane], ncnt);
             if (X < n_pos) S.side_pk[X] = agx_side_pack(side_before, side);
             side_before += side;
             pool += cnt[lane];
-        }
-        for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {      // (the kernel: right behind the write-out, the next position's surviving variants one shuffle away)
-            const agx_u32 X = t * AGX_TILE + lane;
-            if (agx_finish_simple_lane(A, X, cnt[lane], first_id[lane], wrote[lane], had_edges[lane], pflag[lane], lane + 1 < AGX_TILE ? wrote[lane + 1].alive_mask : 0u)) S.pos_succ[X] |= (agx_u8)AGX_PS_DONE;
         }
         S.tile_side[t] = side_before;
     }
@@ -202,15 +191,15 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
 
     // walk preparation, the same per-element functions the compaction kernels run
     agx_compact_args C; memset(&C, 0, sizeof C);
-    S.tile_side_start.assign((size_t)n_tiles + 1, 0); if (S.aid_of.size() < (size_t)S.n_nodes + 1) S.aid_of.resize((size_t)S.n_nodes + 1, AGX_NONE);      // (side_pk / tile_side were written with the nodes; so were the walk ids of the positions the sweep finished)
+    S.tile_side_start.assign((size_t)n_tiles + 1, 0); S.aid_of.assign((size_t)S.n_nodes + 1, AGX_NONE);      // (side_pk / tile_side were written with the nodes)
     C.node_start = S.node_start.data(); C.node_cnt = S.node_cnt.data(); C.n_flags = S.flags.data(); C.n_base = S.base.data();
     C.nk_off0 = S.off0.data(); C.n_sref = S.sref.data(); C.n_next = S.next.data(); C.ref = T.ref.data(); C.n_pos = n_pos;
-    C.side_pk = S.side_pk.data(); C.tile_side_start = S.tile_side_start.data(); C.aid_of = S.aid_of.data(); C.pos_succ = S.pos_succ.data();
+    C.side_pk = S.side_pk.data(); C.tile_side_start = S.tile_side_start.data(); C.aid_of = S.aid_of.data();
     agx_u32 run = 0; for (agx_u32 t = 0; t <= n_tiles; t++) { S.tile_side_start[t] = run; run += S.tile_side[t]; }
     S.n_ids = n_pos + run;
     const size_t na = (size_t)S.n_ids + 1;
-    S.a_str.resize(na, 0); S.a_meta.resize(na + 64, 0);
-    S.a_nid.resize(na, AGX_NONE);
+    S.a_str.assign(na, 0); S.a_meta.assign(na + 64, 0);
+    S.a_nid.assign(na, AGX_NONE);
     S.a_ovf.assign(S.ovf.size() + 1, agx_edge_ovf{AGX_NONE, AGX_NONE});
     C.a_str = &S.a_str[0]; C.a_meta = S.a_meta.data(); C.a_nid = S.a_nid.data();
     C.ovf = S.ovf.data(); C.n_ovf = (agx_u32)S.ovf.size(); C.a_ovf = S.a_ovf.data();
