@@ -33,11 +33,35 @@ if a.engine == "hostsim":
         return sim.run(tmp, u, k, iv, cov, graph=True)
 else:
     import aligngraph_amd as A
+    knob_rng = random.Random(a.seed * 7919 + 13)
+    KNOBS = ("AGX_UPLOAD_WINDOWS", "AGX_STREAM_PIECES", "AGX_WALK_SPLIT_MIN", "AGX_WALK_SPLIT_WALKERS", "AGX_WALK_SPLIT_WARMUP", "AGX_ROW_DIFF", "AGX_NO_TILED_UPLOAD", "AGX_WALK_POISON", "AGX_WALK_EVEN_CUTS")
 
     def run(tmp, u, k, iv, cov):
-        with A.Unit(k=k, insert_variation=iv, coverage=cov, keep_counts=True) as un:
+        # r06: every unit with its own draw of the round's paths — the sweep by 1-8 windows of a tile-ordered upload, the download streamed in 1-16 windows into 2-16 walkers
+        # (or taken whole), the rows as differences, r05's upload forms, one-shot units (whose landing memory is their dead staged inputs)
+        for name in KNOBS:
+            os.environ.pop(name, None)
+        r = knob_rng
+        if r.random() < 0.7:
+            os.environ["AGX_UPLOAD_WINDOWS"] = str(r.choice([1, 2, 3, 5, 8]))
+        stream = r.random() < 0.6
+        if stream:
+            os.environ["AGX_STREAM_PIECES"] = str(r.choice([1, 2, 3, 7, 16]))
+        if r.random() < 0.7:
+            os.environ["AGX_WALK_SPLIT_MIN"] = "0"; os.environ["AGX_WALK_SPLIT_WALKERS"] = str(r.choice([2, 3, 4, 8, 16])); os.environ["AGX_WALK_SPLIT_WARMUP"] = str(r.choice([200, 2000, 20000])); os.environ["AGX_WALK_POISON"] = "1"
+            if r.random() < 0.3:
+                os.environ["AGX_WALK_EVEN_CUTS"] = "1"
+        if r.random() < 0.3:
+            os.environ["AGX_ROW_DIFF"] = "1"
+        if r.random() < 0.15:
+            os.environ["AGX_NO_TILED_UPLOAD"] = "1"
+        one_shot = r.random() < 0.4
+        with A.Unit(k=k, insert_variation=iv, coverage=cov, keep_counts=True, flags=A.AGX_FLAG_ONE_SHOT if one_shot else 0) as un:
             un.load_files(tmp, u); un.upload(); un.build()
-            out = un.finish(); out["graph"] = un.graph()
+            graph = un.graph()
+            if not stream and r.random() < 0.5:
+                un.download()
+            out = un.finish(); out["graph"] = graph
         return out
 
 rng = random.Random(a.seed)
@@ -75,7 +99,7 @@ for it in range(a.n):
         if bad is not None:
             keep = os.path.join(a.workdir, "FAILED_%d" % it)
             shutil.rmtree(keep, ignore_errors=True); shutil.copytree(runp, keep)
-            print("MISMATCH iteration %d unit %d: %s\ncfg=%r\nkept in %s" % (it, u, bad, cfg, keep), flush=True)
+            print("MISMATCH iteration %d unit %d: %s\ncfg=%r\nenv=%r\nkept in %s" % (it, u, bad, cfg, {n: os.environ[n] for n in os.environ if n.startswith("AGX_")}, keep), flush=True)
             sys.exit(1)
     print("iteration %d ok: L=%d k=%d units=%d pairs=%d nodes=%d edges=%d (%.0fs)" % (it, L, k, meta["units"], cfg["pairs"], g["graph"]["n_nodes"], g["graph"]["n_edges"], time.time() - t0), flush=True)
 print("all %d configurations identical" % a.n)
