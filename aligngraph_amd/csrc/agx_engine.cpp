@@ -1160,7 +1160,10 @@ void do_build(agx_unit *u) {
                 const unsigned long long *ob = u->s_other_t.p, *oe = ob + u->n_other_t;
                 const size_t o_lo = (size_t)(std::lower_bound(ob, oe, (unsigned long long)r_lo * u->stride) - ob), o_hi = (size_t)(std::lower_bound(ob, oe, (unsigned long long)r_hi * u->stride) - ob);
                 // (pieces begin at multiples of 16 rows: whole 16-base groups, 16-byte aligned stores; the last piece is padded like the whole array was)
-                const size_t b_lo = r_lo * s4 * 4, b_hi = w + 1 == n_win ? (codes_bytes(u) * 4 + 15) / 16 * 16 : r_hi * s4 * 4;
+                // (the piece that holds the LAST row — not always the last window's: a unit with few hits has windows without rows — is padded like the whole array was; r06's fuzz found the
+                // unpadded form: the last row's last bases stayed unexpanded where an earlier window already reached the last row)
+                const size_t b_lo = r_lo * s4 * 4, b_hi = r_hi == (size_t)nh ? (codes_bytes(u) * 4 + 15) / 16 * 16 : r_hi * s4 * 4;
+                if (r_hi <= r_lo) { HIP_OK(hipEventRecord(u->ev_win[w], st)); continue; }
                 if (u->rows_diffed) agx_launch_expand_rows(u->d_whits.p, (agx_u32)nh, u->d_wsides.p, u->d_wruns.p, u->d_anchor.p, u->d_blockfirst.p + r_lo / 64, u->d_rowcnt.p + r_lo, u->d_blockoff.p + r_lo / 64, u->d_units.p, u->d_wref.p,
                                                            u->d_vcodes.p + b_lo, (agx_u32)(r_hi - r_lo), u->stride, nullptr, 0, st);      // (every row's anchor is its own hit: the anchor bits are all ones)
                 else agx_launch_expand_codes(u->d_codes.p + r_lo * s4, u->d_vcodes.p + b_lo, b_hi - b_lo, nullptr, 0, st);

@@ -29,7 +29,19 @@ if a.engine == "hostsim":
     from hostsim import sim
     sim.build()
 
+    sim_rng = random.Random(a.seed * 104729 + 7)
+
     def run(tmp, u, k, iv, cov):
+        # r06: every unit with its own draw of how the walk graph arrives (all at once, or window by window into arrays full of junk) and of who walks it
+        for name in ("AGX_SIM_STREAM", "AGX_SIM_ASSISTANT", "AGX_WALK_SPLIT_MIN", "AGX_WALK_SPLIT_WALKERS", "AGX_WALK_SPLIT_WARMUP", "AGX_WALK_POISON", "AGX_WALK_EVEN_CUTS"):
+            os.environ.pop(name, None)
+        r = sim_rng
+        if r.random() < 0.6:
+            os.environ["AGX_SIM_STREAM"] = r.choice(["1", "3,30", "7,0", "16,10"])
+        if r.random() < 0.7:
+            os.environ["AGX_SIM_ASSISTANT"] = "1"; os.environ["AGX_WALK_SPLIT_MIN"] = "0"; os.environ["AGX_WALK_SPLIT_WALKERS"] = str(r.choice([2, 3, 5, 8, 16])); os.environ["AGX_WALK_SPLIT_WARMUP"] = str(r.choice([200, 2000, 20000])); os.environ["AGX_WALK_POISON"] = "1"
+            if r.random() < 0.3:
+                os.environ["AGX_WALK_EVEN_CUTS"] = "1"
         return sim.run(tmp, u, k, iv, cov, graph=True)
 else:
     import aligngraph_amd as A
