@@ -328,6 +328,30 @@ def test_tile_ordered_upload_and_a_sweep_by_windows(agx, built, tmp_path, monkey
         assert (got["stats"]["rows_by_reference"] > 0.4 * got["stats"]["n_hits"]) == ("AGX_ROW_DIFF" in env), (windows, env, got["stats"]["rows_by_reference"])
 
 
+def test_windows_without_rows(agx, built, tmp_path, monkeypatch):
+    """Found by the randomised sweep (tests/tools/fuzz_parity.py --engine gpu, seed 606, iteration 42): a unit with so few hits that an early window's piece of the upload already
+    holds the LAST read row (the windows behind it have no rows of their own).  The last row's piece is the one that is padded to whole 16-base groups; r06's first form padded the
+    last WINDOW's piece instead and left the last row's last bases unexpanded — node keys differed.  Every unit of that configuration, eight windows, against node and edge tables."""
+    cfg = {'seed': 92938, 'chroms': '25305,7448,22345', 'part': 2, 'pairs': 440, 'L': 250, 'k': 7, 'coverage': 1, 'insert_variation': 50, 'snp': 0, 'indel': 0.001, 'contig_min': 250, 'contig_max': 3000,
+           'contig_minus': 0.21803743656655059, 'contig_split': 0.15109879794405667, 'contig_dup': 0.008181960270310018, 'contig_overlap': 0.5785686444445618, 'contig_lowid': 0.09784268627746147, 'read_err': 0,
+           'read_indel': 0, 'read_clip': 0.05, 'read_n': 0.01, 'multi': 0.5, 'multi_near': 0.3, 'unaligned': 0.1, 'frag_mean': 300, 'frag_sd': 10, 'sam_seq': 0}
+    run = H.synth(str(tmp_path / "run"), **cfg)
+    meta = H.read_meta(run)
+    tmp = os.path.join(run, "tmp")
+    for windows in ("8", "3"):
+        monkeypatch.setenv("AGX_UPLOAD_WINDOWS", windows)
+        for u in range(meta["units"]):
+            o = H.run_oracle(tmp, u, meta["k"], meta["insert_variation"], meta["coverage"], graph=True)
+            for rowdiff in (False, True):
+                if rowdiff:
+                    monkeypatch.setenv("AGX_ROW_DIFF", "1")
+                g = run_engine(agx, tmp, u, meta["k"], meta["insert_variation"], meta["coverage"], graph=True)
+                monkeypatch.delenv("AGX_ROW_DIFF", raising=False)
+                assert graph_mismatch(o["graph"], g["graph"]) is None, (windows, u, rowdiff)
+                for key in ("initial", "pre", "extended"):
+                    assert o[key] == g[key], (windows, u, rowdiff, key)
+
+
 def test_walk_begins_while_the_download_is_still_arriving(agx, built, tmp_path, monkeypatch):
     """r06, the streamed download (agx_engine.cpp: begin_streamed_download): agx_unit_finish on a unit that has not been downloaded sends the walk graph down in position windows
     from the front (forced here on a small unit: AGX_STREAM_PIECES), the walkers wait for their windows, the first one for all of them, the bases come last.  The walkers' own bytes
