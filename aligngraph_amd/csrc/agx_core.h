@@ -393,6 +393,130 @@ AGX_HD void agx_tile_record_words(const agx_dhit &d, const agx_run *runs, agx_u3
 }
 #endif
 
+// ---- lean tile records (r06): what pass 0 of the node sweep reads per list entry ----------------------------------------------------------------
+// 32 bytes that describe a hit's arrivals INSIDE ONE TILE as one or two runs of lanes, each with its own pair of offsets: on lane l of a piece the arrival's read index
+// is l + qoff and its mate position l + boff (or none).  One piece = what agx_tile_record() calls a linear piece (five entries in six).  TWO pieces cover most of the rest —
+// the tile that holds a hit's one break point: an insertion or a deletion in the left mate (the pieces differ in qoff; behind a deletion the lanes between them have no
+// arrival and the last lane of piece 1 steps over them: JUMP1), a break in the other mate (the pieces differ in boff; with MID the lanes between them have arrivals without a
+// mate position — bases the other mate has inserted or clipped).  What fits neither (a third piece, a read insertion next to a reference gap with its CHAIN arrivals,
+// empty runs) is kind GENERAL: the sweep then decodes the hit's derived record, dhit[hit], the way every other reader of a tile list does (the wider passes, the edge
+// build's pass B: they only look at `hit`).  agx_lean_make() must produce a record only if agx_lean_decode() gives, on every lane of the tile, exactly the arrival
+// agx_decode_arrival() gives for the hit — tests/hostsim checks that for every entry of every list it makes.
+enum { AGX_LK_GENERAL = 0, AGX_LK_ONE = 1, AGX_LK_ONEX = 2, AGX_LK_TWO = 3 };      // ONE: one piece WITH mate positions and without a jump at its end — nothing to look at but lo1, span1, qoff1, boff1; ONEX: one piece with either; TWO: two pieces
+enum { AGX_LF_AREV = 1u << 24, AGX_LF_BN1 = 1u << 25, AGX_LF_BN2 = 1u << 26, AGX_LF_JUMP1 = 1u << 27, AGX_LF_MID = 1u << 28, AGX_LF_JUMP2 = 1u << 29 };
+struct agx_lrec {
+    agx_u32 qoff1, boff1, qoff2, boff2;      // (boff unused where BN1 / BN2 says the piece has no mate positions)
+    agx_u32 slot, lenjs;                     // read slot of the left mate; read length | jstar << 16
+    agx_u32 geo;                             // lo1 | span1 << 6 | lo2 << 12 | span2 << 18 (a piece = lanes lo .. lo + span) | AGX_LF_* | kind << 30
+    agx_u32 hit;                             // the hit's place in the tile order: dhit[hit]
+};
+struct agx_larr { agx_u32 has, last, q, p0, jump; };      // last: the K2ONLY arrival; jump: a K1 arrival whose successor is not position + 1 (every other K1 arrival's is)
+AGX_HD agx_larr agx_lean_decode(const agx_lrec &r, agx_u32 lane) {
+    const agx_u32 g = r.geo, kind = g >> 30;
+    const agx_u32 lo1 = g & 63u, sp1 = (g >> 6) & 63u, lo2 = (g >> 12) & 63u, sp2 = (g >> 18) & 63u, js = r.lenjs >> 16;
+    const bool in1 = lane - lo1 <= sp1, in2 = kind == AGX_LK_TWO && lane - lo2 <= sp2, mid = (g & AGX_LF_MID) && lane > lo1 + sp1 && lane < lo2;
+    agx_larr a;
+    a.has = (kind != AGX_LK_GENERAL && (in1 || in2 || mid)) ? 1u : 0u;
+    a.q = lane + (in2 ? r.qoff2 : r.qoff1);
+    a.p0 = in2 ? ((g & AGX_LF_BN2) ? AGX_NONE : lane + r.boff2) : (mid || (g & AGX_LF_BN1)) ? AGX_NONE : lane + r.boff1;
+    a.last = a.q == js ? 1u : 0u;
+    a.jump = (!a.last && (((g & AGX_LF_JUMP1) && lane == lo1 + sp1) || ((g & AGX_LF_JUMP2) && in2 && lane == lo2 + sp2))) ? 1u : 0u;
+    return a;
+}
+// the mate position of read indices qa .. qb as sections of constant offset: how many (0 = more than three, or runs that overlap), and for section i its first index,
+// whether it has no mate positions and, if it has, t - q of its run.  (No arrays: a table indexed by a running count lives in scratch memory on the device.  Runs come as
+// values: a run chosen between a table entry and the simple mate's pseudo-run must not be a choice between addresses — agx_tile_piece_v.)
+struct agx_bsec { agx_u32 n, q1, q2, none0, none1, none2, off0, off1, off2; };
+AGX_HD agx_bsec agx_lean_bsections(agx_u32 b_t0, agx_u32 b_runs, agx_u32 b_nruns, agx_u32 L, const agx_run *runs, agx_u32 qa, agx_u32 qb) {
+    // (section i's fields are separate variables, each updated by a select on the running count: stores chosen by the count into a struct's fields become ONE store through a
+    // computed address, and the struct then lives in scratch memory on the device)
+    agx_u32 n = 0, q1 = 0, q2 = 0, none0 = 1u, none1 = 1u, none2 = 1u, off0 = 0, off1 = 0, off2 = 0;
+    auto push = [&](bool on, agx_u32 q0, agx_u32 none, agx_u32 off) {
+        const bool a0 = on && n == 0u, a1 = on && n == 1u, a2 = on && n == 2u;
+        none0 = a0 ? none : none0; off0 = a0 ? off : off0;
+        q1 = a1 ? q0 : q1; none1 = a1 ? none : none1; off1 = a1 ? off : off1;
+        q2 = a2 ? q0 : q2; none2 = a2 ? none : none2; off2 = a2 ? off : off2;
+        n += on ? 1u : 0u;
+    };
+    const agx_u32 nb = b_nruns ? b_nruns : 1u;
+    agx_u32 next = qa;                        // first index not yet assigned to a section
+    bool bad = false;
+    for (agx_u32 i = 0; i < nb; i++) {
+        agx_u32 c_q = 0, c_t = b_t0, c_n = L;
+        if (b_nruns) { const agx_run c = runs[b_runs + i]; c_q = c.q; c_t = c.t; c_n = c.n; }
+        const bool touches = c_n != 0u && c_q + c_n > qa && c_q <= qb && next <= qb;      // a run that holds some of what is left of qa .. qb
+        const agx_u32 from = c_q > qa ? c_q : qa;
+        bad = bad || (touches && from < next);                              // runs that overlap, or out of order
+        push(touches && from > next, next, 1u, 0u);
+        push(touches, from, 0u, c_t - c_q);
+        next = touches ? c_q + c_n : next;                                  // (may lie beyond qb)
+    }
+    push(next <= qb, next, 1u, 0u);
+    agx_bsec s; s.n = (bad || n > 3u) ? 0u : n; s.q1 = q1; s.q2 = q2; s.none0 = none0; s.none1 = none1; s.none2 = none2; s.off0 = off0; s.off1 = off1; s.off2 = off2;
+    return s;
+}
+// the record of the hit with derived record (d_*) in the list of `tile`; hit = its place in the tile order
+AGX_HD agx_lrec agx_lean_make_v(agx_u32 d_a_t0, agx_u32 d_b_t0, agx_u32 d_a_runs, agx_u32 d_b_runs, agx_u32 d_a_slot, agx_u32 L, agx_u32 js, agx_u32 d_a_nruns, agx_u32 d_b_nruns,
+                                agx_u32 d_flags, agx_u32 d_x_lo, agx_u32 d_x_hi, const agx_run *runs, agx_u32 tile, agx_u32 k, agx_u32 hit) {
+    agx_lrec r; r.qoff1 = r.boff1 = r.qoff2 = r.boff2 = 0; r.slot = d_a_slot; r.lenjs = L | (js << 16); r.geo = 0; r.hit = hit;      // kind GENERAL
+    const agx_u32 T0 = tile * AGX_TILE;
+    const agx_u32 xs = d_x_lo > T0 ? d_x_lo : T0, xe = d_x_hi < T0 + AGX_TILE - 1u ? d_x_hi : T0 + AGX_TILE - 1u;
+    if ((d_flags & AGX_HF_SKIP) || xs > xe || js == 0xFFFFu || L <= k) return r;
+    // the left mate's runs that hold arrivals of this tile: at most two, no empty run anywhere (an empty run is still the "next run" of the one before it)
+    const agx_u32 na = d_a_nruns ? d_a_nruns : 1u;
+    agx_u32 np = 0, lo0 = 0, hi0 = 0, qoff0 = 0, jump0 = 0, lo1 = 0, hi1 = 0, qoff1 = 0, jump1 = 0;
+    bool bad = false;
+    for (agx_u32 i = 0; i < na; i++) {
+        agx_u32 c_q = 0, c_t = d_a_t0, c_n = L;
+        if (d_a_nruns) { const agx_run c = runs[d_a_runs + i]; c_q = c.q; c_t = c.t; c_n = c.n; }
+        if (!c_n) { bad = true; continue; }
+        const agx_u32 c_end = c_t + c_n - 1u;
+        agx_u32 nx_q = 0, nx_t = 0; const bool has_nx = d_a_nruns != 0 && i + 1u < na;
+        if (has_nx) { const agx_run nx = runs[d_a_runs + i + 1u]; nx_q = nx.q; nx_t = nx.t; }
+        const bool direct_q = has_nx && nx_q == c_q + c_n, direct_t = has_nx && nx_t == c_end + 1u;
+        // CHAIN arrivals between this run and the next (agx_decode_arrival's in_gap) that fall into the tile: not a lean record
+        if (has_nx && !direct_q && !direct_t && nx_t > c_end + 1u && c_end + 1u <= T0 + AGX_TILE - 1u && nx_t - 1u >= T0) bad = true;
+        if (c_end < xs || c_t > xe) continue;
+        if (np >= 2u) { bad = true; continue; }
+        const agx_u32 lo = c_t > xs ? c_t : xs, hi = c_end < xe ? c_end : xe;
+        // the piece ends where the run ends, on an event source (an index below jstar): where does its successor go?  To the next run's first index — on position + 1 (a read
+        // insertion, or a run cut in two: nothing special), over a gap of the reference (a read deletion: a JUMP), or, if the next run continues neither in the read nor on
+        // the reference, through CHAIN arrivals: not a lean record.  (No next run cannot happen: the read's last aligned index is not below jstar.)
+        agx_u32 jump = 0;
+        if (hi == c_end && c_q + c_n - 1u < js) { if (!has_nx || (!direct_q && !direct_t)) bad = true; else if (!direct_t) jump = 1u; }
+        if (np == 0u) { lo0 = lo - T0; hi0 = hi - T0; qoff0 = c_q - c_t + T0; jump0 = jump; }
+        else { lo1 = lo - T0; hi1 = hi - T0; qoff1 = c_q - c_t + T0; jump1 = jump; }
+        np++;
+    }
+    if (bad || np == 0u || (np == 2u && lo1 <= hi0)) return r;
+    agx_u32 geo = (d_flags & AGX_HF_AREV) ? (agx_u32)AGX_LF_AREV : 0u;
+    if (np == 2u) {
+        // two pieces of the left mate: the other mate must be one section under each
+        const agx_bsec s1 = agx_lean_bsections(d_b_t0, d_b_runs, d_b_nruns, L, runs, lo0 + qoff0, hi0 + qoff0);
+        const agx_bsec s2 = agx_lean_bsections(d_b_t0, d_b_runs, d_b_nruns, L, runs, lo1 + qoff1, hi1 + qoff1);
+        if (s1.n != 1u || s2.n != 1u) return r;
+        r.qoff1 = qoff0; r.qoff2 = qoff1; r.boff1 = qoff0 + s1.off0; r.boff2 = qoff1 + s2.off0;
+        geo |= (s1.none0 ? (agx_u32)AGX_LF_BN1 : 0u) | (s2.none0 ? (agx_u32)AGX_LF_BN2 : 0u) | (jump0 ? (agx_u32)AGX_LF_JUMP1 : 0u) | (jump1 ? (agx_u32)AGX_LF_JUMP2 : 0u);
+        r.geo = geo | lo0 | ((hi0 - lo0) << 6) | (lo1 << 12) | ((hi1 - lo1) << 18) | ((agx_u32)AGX_LK_TWO << 30);
+        return r;
+    }
+    // one piece of the left mate: the other mate in one, two, or three sections of which the middle one has no positions
+    const agx_bsec s = agx_lean_bsections(d_b_t0, d_b_runs, d_b_nruns, L, runs, lo0 + qoff0, hi0 + qoff0);
+    if (s.n == 0u || (s.n == 3u && !(s.none1 && !s.none0 && !s.none2))) return r;
+    r.qoff1 = r.qoff2 = qoff0; r.boff1 = qoff0 + s.off0;
+    geo |= s.none0 ? (agx_u32)AGX_LF_BN1 : 0u;
+    if (s.n == 1u) { r.geo = geo | lo0 | ((hi0 - lo0) << 6) | (jump0 ? (agx_u32)AGX_LF_JUMP1 : 0u) | ((agx_u32)((jump0 || s.none0) ? AGX_LK_ONEX : AGX_LK_ONE) << 30); return r; }
+    const agx_u32 q_last = s.n == 3u ? s.q2 : s.q1, none_last = s.n == 3u ? s.none2 : s.none1, off_last = s.n == 3u ? s.off2 : s.off1;
+    const agx_u32 l2 = q_last - qoff0, h1 = s.q1 - qoff0 - 1u;              // first lane of the last section, last lane of the first
+    r.boff2 = qoff0 + off_last;
+    geo |= (none_last ? (agx_u32)AGX_LF_BN2 : 0u) | (s.n == 3u ? (agx_u32)AGX_LF_MID : 0u) | (jump0 ? (agx_u32)AGX_LF_JUMP2 : 0u);      // (the run's end is piece 2's end)
+    r.geo = geo | lo0 | ((h1 - lo0) << 6) | (l2 << 12) | ((hi0 - l2) << 18) | ((agx_u32)AGX_LK_TWO << 30);
+    return r;
+}
+AGX_HD agx_lrec agx_lean_make(const agx_dhit &d, const agx_run *runs, agx_u32 tile, agx_u32 k, agx_u32 hit) {
+    return agx_lean_make_v(d.a_t0, d.b_t0, d.a_runs, d.b_runs, d.a_slot, d.len, d.jstar, d.a_nruns, d.b_nruns, d.flags, d.x_lo, d.x_hi, runs, tile, k, hit);
+}
+
 // conti-mer head of position x (upload-time kernel / test executor).  The table has n_pos + 1 entries: entry n_pos is the head of "no
 // position" (no conti-mers), which the node sweep loads for an arrival without a mate position instead of selecting afterwards.
 AGX_HD void agx_cm_head_pos(const agx_u32 *cm_start, const agx_cmkey *cm, agx_cmhead *head, agx_u32 x, agx_u32 n_pos) {
@@ -718,6 +842,47 @@ AGX_HD agx_u32 agx_edge_spread(agx_u32 vm) {
 // sp times the row (< 2^AGX_EM_W, so the partial products cannot overlap) puts a copy of the row at every touched variant.
 AGX_HD void agx_edge_merge(agx_u32 &emask, agx_u32 sp, agx_u32 vm_next) { emask |= sp * (vm_next & ((1u << AGX_EM_W) - 1u)); }
 
+// What an arrival that is NOT the straight-line case does to its position's bucket (shared by agx_node_sweep_lane and the device's lean pass-0 loop, agx_kernels.hip):
+// the first arrival at a position with one candidate key stores variant 0 directly; anything else walks its candidate keys, X-major (AG:1369-1477), through
+// agx_match_or_insert.  (cx_s, cx_n, cx0): the position's own conti-mers; (c0_s, c0_n, c0k): the mate position's (c0k NONE/NONE when there is no mate or it has none);
+// vfield: the counter the base votes for (meaningful if votes).  Updates cnt / ok and the lane's copy of variant 0's mate-side key (v0_*: agx_node_sweep_lane); returns in
+// vm the variants the arrival touched and in sp their agx_edge_spread form if it steps to position + 1.
+AGX_HD void agx_arrival_slow(const agx_sweep_args &A, const agx_bucket &b, agx_u32 &cnt, bool &ok, agx_u32 cx_s, agx_u32 cx_n, agx_cmkey cx0,
+                             agx_u32 p0, agx_u32 c0_s, agx_u32 c0_n, agx_cmkey c0k, agx_u32 s0, agx_u32 s1, agx_u32 is_k1, agx_u32 votes, agx_u32 vfield, agx_u32 step1,
+                             agx_u32 &v0_ok, agx_u32 &v0_c0, agx_u32 &v0_o0, agx_u32 &v0_m, agx_u32 &vm, agx_u32 &sp) {
+    if (AGX_SWEEP_FIRST && cnt == 0 && cx_n <= 1 && c0_n <= 1) {
+        // The first arrival at a position with one candidate key — most of what leaves the fast path (7 % of the list entries on the
+        // bench unit create a variant somewhere) — stores variant 0 without the general path's loops over candidates and variants.
+        agx_b(b, 0, AGX_F_CID) = cx0.cid; agx_b(b, 0, AGX_F_COFF) = cx0.coff; agx_b(b, 0, AGX_F_CID0) = c0k.cid; agx_b(b, 0, AGX_F_COFF0) = c0k.coff;
+        agx_b(b, 0, AGX_F_OFF0) = p0; agx_b(b, 0, AGX_F_COV) = is_k1;
+        agx_b(b, 0, AGX_F_A) = 0; agx_b(b, 0, AGX_F_C) = 0; agx_b(b, 0, AGX_F_G) = 0; agx_b(b, 0, AGX_F_T) = 0; agx_b(b, 0, AGX_F_N) = 0;
+        agx_b(b, 0, AGX_F_S0) = s0; agx_b(b, 0, AGX_F_S1) = s1;
+        if (votes) agx_b(b, 0, vfield) = 1;
+        cnt = 1; vm = 1u; sp = step1;
+        v0_ok = 1u; v0_c0 = c0k.cid; v0_o0 = c0k.coff; v0_m = p0;
+        return;
+    }
+    if (ok) {
+        const agx_u32 vf = votes ? vfield : (agx_u32)AGX_NF;
+        const agx_u32 nx = cx_n ? cx_n : 1u, n0 = c0_n ? c0_n : 1u;
+        for (agx_u32 ci = 0; ci < nx && ok; ci++) {                      // candidate keys, X-major (AG:1369-1477)
+            agx_key key; key.off0 = p0;
+            const agx_cmkey cx = cx_n ? (ci == 0 ? cx0 : A.cm[cx_s + ci]) : agx_cmkey{AGX_NONE, AGX_NONE};
+            key.cid = cx.cid; key.coff = cx.coff;
+            for (agx_u32 cj = 0; cj < n0; cj++) {
+                const agx_cmkey c0 = c0_n ? (cj == 0 ? c0k : A.cm[c0_s + cj]) : agx_cmkey{AGX_NONE, AGX_NONE};
+                key.cid0 = c0.cid; key.coff0 = c0.coff;
+                const agx_u32 v = agx_match_or_insert(b, cnt, key, A.iv, is_k1 != 0, s0, s1);
+                if (v == AGX_NONE) { ok = false; break; }
+                vm |= 1u << (v & 31u);
+                if (vf != AGX_NF) agx_b(b, v, vf) += 1;
+            }
+        }
+    }
+    sp = step1 ? agx_edge_spread(vm) : 0u;
+    if (cnt) { v0_ok = cx_n <= 1 ? 1u : 0u; v0_c0 = agx_b(b, 0, AGX_F_CID0); v0_o0 = agx_b(b, 0, AGX_F_COFF0); v0_m = agx_b(b, 0, AGX_F_OFF0); }
+}
+
 // The whole in-order sweep of one position.  get(i) returns the derived hit record of tile-list entry i (the kernels stage 64
 // records at a time across the lanes of the wavefront and broadcast them; the test executor reads memory directly).
 // Returns false if the bucket overflowed (the tile is then re-run with a larger bucket).
@@ -734,31 +899,14 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
     bool ok = true;
     const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
     // Branch-light on purpose: on wave64 every per-lane `if` costs exec-mask bookkeeping on the scalar unit, and the sweep runs
-    // this body ~35 times per position.  The common case — one candidate key, compatible with variant 0 — is straight-line
-    // code under a single `has` mask; everything else (several conti-mers, later variants, inserts) goes through slow().
-    auto slow = [&](const agx_pre &p, agx_u32 c0_s, agx_u32 c0_n, agx_cmkey c0_first, bool is_k1, agx_u32 vf, agx_u32 &vm) {
-        const agx_u32 nx = cx_n ? cx_n : 1u, n0 = c0_n ? c0_n : 1u;
-        for (agx_u32 ci = 0; ci < nx && ok; ci++) {                      // candidate keys, X-major (AG:1369-1477)
-            agx_key key; key.off0 = p.p0;
-            const agx_cmkey cx = cx_n ? (ci == 0 ? cx0 : A.cm[cx_s + ci]) : agx_cmkey{AGX_NONE, AGX_NONE};
-            key.cid = cx.cid; key.coff = cx.coff;
-            for (agx_u32 cj = 0; cj < n0; cj++) {
-                const agx_cmkey c0 = c0_n ? (cj == 0 ? c0_first : A.cm[c0_s + cj]) : agx_cmkey{AGX_NONE, AGX_NONE};
-                key.cid0 = c0.cid; key.coff0 = c0.coff;
-                const agx_u32 v = agx_match_or_insert(b, cnt, key, A.iv, is_k1, p.s0, p.s1);
-                if (v == AGX_NONE) { ok = false; break; }
-                vm |= 1u << (v & 31u);
-                if (vf != AGX_NF) agx_b(b, v, vf) += 1;
-            }
-        }
-    };
+    // this body ~35 times per position; everything but the common case (several conti-mers, later variants, inserts) goes through agx_arrival_slow().
     // The common case — one candidate key, compatible with variant 0 — is straight-line code without a lane-varying branch and without
     // a read of the bucket.  A variant's key never changes once it is stored, so the lane keeps variant 0's mate-side key words in
     // registers from the moment it exists (v0_*); the position-side clause (AG:1375) needs no test at all there: with at most one
     // conti-mer at X every arrival carries the same (contigID, contigOffset) that variant 0 stored, and with several the arrival goes
-    // through slow() anyway (v0_ok = 0).  The verdict is integer arithmetic and the two counter updates are LDS adds of 0 or 1
+    // through agx_arrival_slow() anyway (v0_ok = 0).  The verdict is integer arithmetic and the two counter updates are LDS adds of 0 or 1
     // (agx_bucket_add: ds_add_u32 in the LDS pass), so the loop's fast path never waits for LDS.  Only lanes that need another variant,
-    // an insert or several candidate keys enter slow().
+    // an insert or several candidate keys enter agx_arrival_slow().
     agx_u32 v0_ok = 0, v0_c0 = AGX_NONE, v0_o0 = AGX_NONE, v0_m = AGX_NONE;
     auto apply = [&](const agx_pre &p) {
         const agx_u32 has = p.has;                                                  // (a lane whose bucket overflowed keeps going: the tile is swept again)
@@ -777,23 +925,8 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
         AGX_STAT(A, 6, (has & (fast ^ 1u)) != 0 && !(cnt == 0 && cx_n <= 1 && c0_n <= 1));
         AGX_STAT(A, 8, (has & (fast ^ 1u)) != 0 && cnt != 0 && cx_n <= 1 && c0_n <= 1 && v0_ok && !compat);      // one candidate, variant 0 exists and is not it
         AGX_STAT(A, 10, (has & (fast ^ 1u)) != 0 && (cx_n > 1 || c0_n > 1));                                        // several candidate keys
-        if (has & (fast ^ 1u)) {
-            if (AGX_SWEEP_FIRST && cnt == 0 && cx_n <= 1 && c0_n <= 1) {
-                // The first arrival at a position with one candidate key — most of what leaves the fast path (7 % of the list entries on the
-                // bench unit create a variant somewhere) — stores variant 0 without the general path's loops over candidates and variants.
-                agx_b(b, 0, AGX_F_CID) = cx0.cid; agx_b(b, 0, AGX_F_COFF) = cx0.coff; agx_b(b, 0, AGX_F_CID0) = c0k.cid; agx_b(b, 0, AGX_F_COFF0) = c0k.coff;
-                agx_b(b, 0, AGX_F_OFF0) = p.p0; agx_b(b, 0, AGX_F_COV) = is_k1;
-                agx_b(b, 0, AGX_F_A) = 0; agx_b(b, 0, AGX_F_C) = 0; agx_b(b, 0, AGX_F_G) = 0; agx_b(b, 0, AGX_F_T) = 0; agx_b(b, 0, AGX_F_N) = 0;
-                agx_b(b, 0, AGX_F_S0) = p.s0; agx_b(b, 0, AGX_F_S1) = p.s1;
-                if (votes) agx_b(b, 0, vfield) = 1;
-                cnt = 1; vm = 1u; sp = p.step1;
-                v0_ok = 1u; v0_c0 = c0k.cid; v0_o0 = c0k.coff; v0_m = p.p0;
-            } else {
-                if (ok) slow(p, p.h.start, c0_n, c0k, is_k1 != 0, votes ? vfield : (agx_u32)AGX_NF, vm);
-                sp = p.step1 ? agx_edge_spread(vm) : 0u;
-                if (cnt) { v0_ok = cx_n <= 1 ? 1u : 0u; v0_c0 = agx_b(b, 0, AGX_F_CID0); v0_o0 = agx_b(b, 0, AGX_F_COFF0); v0_m = agx_b(b, 0, AGX_F_OFF0); }
-            }
-        }
+        if (has & (fast ^ 1u))
+            agx_arrival_slow(A, b, cnt, ok, cx_s, cx_n, cx0, p.p0, p.h.start, c0_n, c0k, p.s0, p.s1, is_k1, votes, vfield, p.step1, v0_ok, v0_c0, v0_o0, v0_m, vm, sp);
         exch(vm, sp);
     };
     // software pipeline over two arrival buffers that are never copied (a register copy would have to wait for the loads): buffer

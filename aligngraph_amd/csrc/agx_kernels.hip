@@ -268,10 +268,14 @@ __global__ void __launch_bounds__(256) agx_k_scan_lookback(const agx_u32 *in, ag
 
 // ---- tile lists: the 32-byte record stream the sweeps read, hits of a tile in SAM order --------------------------------------------------
 #define AGX_SORT_LDS 512       // list entries of a tile sorted in LDS (a tile of the bench units holds ~27; 2048 — 32 KB per block — kept the kernel at 20 of a CU's 32 wavefronts)
-// A record is the first 32 bytes of agx_tile_record(): the hit's derived record, or the linear piece of it that covers this tile.  i: the hit's place in the tile order.
+// A record is the hit's LEAN record for this tile (agx_core.h: agx_lrec — its arrivals in the tile as one or two runs of lanes, or "look at dhit[hit]").  i: the hit's place in the tile order.
+__device__ __forceinline__ void agx_put_lrec(uint4 *recs, size_t at, const agx_lrec &r) {
+    recs[2 * at] = make_uint4(r.qoff1, r.boff1, r.qoff2, r.boff2); recs[2 * at + 1] = make_uint4(r.slot, r.lenjs, r.geo, r.hit);
+}
 __device__ __forceinline__ void agx_put_rec(uint4 *recs, agx_u32 at, const agx_dhit *dhit, agx_u32 i, const agx_run *runs, agx_u32 tile, agx_u32 k) {
-    uint4 lo, hi; agx_tile_record_words(dhit[i], runs, tile, k, lo, hi);
-    recs[2 * (size_t)at] = lo; recs[2 * (size_t)at + 1] = hi;
+    const uint2 *g = reinterpret_cast<const uint2 *>(dhit + i);      // (five 8-byte words, never the struct: it would live in scratch memory)
+    const uint2 w0 = g[0], w1 = g[1], w2 = g[2], w3 = g[3], w4 = g[4];
+    agx_put_lrec(recs, at, agx_lean_make_v(w0.x, w0.y, w1.x, w1.y, w2.x, w2.y & 0xFFFFu, w2.y >> 16, w3.x & 0xFFFFu, w3.x >> 16, w3.y, w4.x, w4.y, runs, tile, k, i));
 }
 // The hits are in the order of their first tile, so the hits that reach tile t are among those whose first tile is t - lookback + 1 .. t: a contiguous WINDOW of the
 // order (tile_first), filtered by the last tile each hit reaches (ckey) — coalesced reads of 4-byte keys and hit numbers, no scatter, no atomics — plus the few hits that
@@ -324,6 +328,11 @@ __device__ __forceinline__ void agx_tile_fill_general(const agx_fill_args &A, ag
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (the wavefront's next tile uses the same LDS)
 }
+// the node sweep reads two records beyond a list's end (masked out): behind the LAST list they are these — kind GENERAL of hit 0, which decodes like any other record
+__device__ __forceinline__ void agx_zero_slack(const agx_fill_args &A, agx_u32 lane) {
+    const agx_u32 total = agx_uload(A.tile_off, A.n_tiles);
+    if (total <= A.cap && lane < 8u) ((uint4 *)A.recs)[2 * (size_t)total + lane] = make_uint4(0u, 0u, 0u, 0u);      // (the lists' buffer holds cap + 4 records)
+}
 #ifndef AGX_FILL_TILES
 #define AGX_FILL_TILES 2u      // tiles per wavefront
 #endif
@@ -334,6 +343,7 @@ __global__ void __launch_bounds__(256) agx_k_tile_fill(agx_fill_args A) {
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const agx_u32 t_first = __builtin_amdgcn_readfirstlane((blockIdx.x * AGX_WAVES_PER_BLOCK + wave) * AGX_FILL_TILES);
     if (t_first >= A.n_tiles) return;
+    if (t_first == 0) agx_zero_slack(A, lane);
     const agx_u32 n_long = __builtin_amdgcn_readfirstlane((int)*A.long_count);
     if (n_long > AGX_LONG_MAX) {                         // the fallback makes this unit's lists (agx_k_bin_fill, agx_k_tile_sort) — if it is queued; else nothing behind this kernel may run, and the host repeats the build with it
         if (!A.dense_queued && t_first == 0 && lane == 0) atomicOr(A.status, 16u);
@@ -370,11 +380,11 @@ __global__ void __launch_bounds__(256) agx_k_tile_fill(agx_fill_args A) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (single wavefront: its LDS writes are visible to its own later reads)
     // level 3: the derived records of the kept hits — as five 8-byte words each, never as a struct: a record that exists as a struct in registers ends up in scratch
     // memory (agx_tile_piece_v; measured: 0.72 ms instead of 0.36)
-    bool act[AGX_FILL_TILES]; agx_u32 mine[AGX_FILL_TILES]; uint2 w[AGX_FILL_TILES][5];
+    bool act[AGX_FILL_TILES]; agx_u32 mine[AGX_FILL_TILES], place[AGX_FILL_TILES]; uint2 w[AGX_FILL_TILES][5];
 #pragma unroll
     for (agx_u32 t = 0; t < AGX_FILL_TILES; t++) {
         act[t] = fast[t] && lane < n[t];
-        const agx_u32 i = act[t] ? sh[wave][t * 128u + lane] : (fast[t] ? c_lo[t] : 0u); mine[t] = act[t] ? sh[wave][t * 128u + 64u + lane] : 0u;
+        const agx_u32 i = act[t] ? sh[wave][t * 128u + lane] : (fast[t] ? c_lo[t] : 0u); mine[t] = act[t] ? sh[wave][t * 128u + 64u + lane] : 0u; place[t] = i;
         const uint2 *g = reinterpret_cast<const uint2 *>(A.dhit + i);
 #pragma unroll
         for (int q = 0; q < 5; q++) w[t][q] = g[q];
@@ -389,7 +399,8 @@ __global__ void __launch_bounds__(256) agx_k_tile_fill(agx_fill_args A) {
     uint4 *recs = (uint4 *)A.recs;
 #pragma unroll
     for (agx_u32 t = 0; t < AGX_FILL_TILES; t++)
-        if (act[t]) { uint4 wl, wh; agx_tile_record_words_v(w[t][0], w[t][1], w[t][2], w[t][3], w[t][4], A.runs, tile[t], A.k, wl, wh); const size_t at = (size_t)lo[t] + r[t]; recs[2 * at] = wl; recs[2 * at + 1] = wh; }
+        if (act[t]) agx_put_lrec(recs, (size_t)lo[t] + r[t], agx_lean_make_v(w[t][0].x, w[t][0].y, w[t][1].x, w[t][1].y, w[t][2].x, w[t][2].y & 0xFFFFu, w[t][2].y >> 16, w[t][3].x & 0xFFFFu, w[t][3].x >> 16,
+                                                                            w[t][3].y, w[t][4].x, w[t][4].y, A.runs, tile[t], A.k, place[t]));
     // wider windows (pile-ups, long reads) and units with long hits: one tile after the other
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #pragma unroll
@@ -439,17 +450,31 @@ __global__ void __launch_bounds__(256) agx_k_tile_sort(agx_fill_args A) {
 // kernel).  Scalar loads are counted by lgkmcnt, not vmcnt: waiting for a record never drains the per-lane global loads that the
 // sweep keeps in flight one hit ahead, and most of the arrival decode runs on the scalar unit.
 struct agx_tile_recs {
-    const uint4 *recs;
-    __device__ __forceinline__ agx_dhit operator()(agx_u32 i) const {
-        typedef agx_u32 v4 __attribute__((ext_vector_type(4)));
-        typedef const __attribute__((address_space(4))) v4 *cptr;
+    const uint4 *recs; const agx_dhit *dhit;
+    typedef agx_u32 v4 __attribute__((ext_vector_type(4)));
+    typedef agx_u32 v2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(4))) v4 *cptr;
+    typedef const __attribute__((address_space(4))) v2 *cptr2;
+    // the lean record of entry i (pass 0)
+    __device__ __forceinline__ agx_lrec lean(agx_u32 i) const {
         const cptr p = (cptr)(recs + 2 * (size_t)i);
         const v4 a = p[0], b = p[1];
+        return agx_lrec{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    }
+    // the derived record of the hit of entry i (every other reader: the wider passes decode the hit itself)
+    __device__ __forceinline__ agx_dhit of_hit(agx_u32 hit) const {
+        static_assert(sizeof(agx_dhit) == 40, "a derived record is ten words");
+        const cptr p = (cptr)(dhit + hit); const cptr2 p2 = (cptr2)((const char *)(dhit + hit) + 32);
+        const v4 a = p[0], b = p[1]; const v2 c = p2[0];
         agx_dhit d;
         d.a_t0 = a.x; d.b_t0 = a.y; d.a_runs = a.z; d.b_runs = a.w; d.a_slot = b.x;
         d.len = (agx_u16)(b.y & 0xFFFFu); d.jstar = (agx_u16)(b.y >> 16); d.a_nruns = (agx_u16)(b.z & 0xFFFFu); d.b_nruns = (agx_u16)(b.z >> 16);
-        d.flags = b.w; d.x_lo = 0; d.x_hi = 0;
+        d.flags = b.w; d.x_lo = c.x; d.x_hi = c.y;
         return d;
+    }
+    __device__ __forceinline__ agx_dhit operator()(agx_u32 i) const {
+        typedef const __attribute__((address_space(4))) agx_u32 *wptr;
+        return of_hit(((wptr)(recs + 2 * (size_t)i))[7]);
     }
 };
 
@@ -457,6 +482,170 @@ struct agx_tile_recs {
 __device__ __forceinline__ agx_u32 agx_wave_incl_scan(agx_u32 v, agx_u32 lane) {
     for (agx_u32 off = 1; off < 64; off <<= 1) { const agx_u32 t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
     return v;
+}
+
+// ---- pass 0's loop over a tile's list (r06) ----------------------------------------------------------------------------------------------
+// agx_node_sweep_lane (agx_core.h, shared with the CPU executor) keeps every lane predicate as a 0/1 word: the compiler then moves them between
+// VGPRs and SGPR masks all the time (v_cndmask 0,1 / v_cmp_ne 0) and the fast path of one list entry issues ~60 vector + ~60 scalar instructions.
+// Here a lane predicate IS a 64-bit scalar mask (ballot in, inverse ballot out): the logic between predicates runs on the scalar unit, the
+// counters take the mask as it is, the x -> x+1 edge of the straight-line case is two mask operations and a 64-bit shift instead of a DPP move
+// and a multiply per entry, the k-mer string word of an arrival is only made where a variant is stored, and a LINEAR record (five entries in six)
+// is decoded by six vector instructions.  What leaves the straight-line case goes through agx_arrival_slow() — the same function the shared lane
+// function calls — under ONE wave-uniform branch, behind which the per-lane edge exchange of the shared function is done for that entry alone.
+// Same results as agx_node_sweep_lane<true> by construction of the predicates; pinned by the GPU parity tests (node and edge tables field by field).
+#ifndef AGX_SWEEP_LEAN
+#define AGX_SWEEP_LEAN 1
+#endif
+typedef unsigned long long agx_m64;
+#define AGX_BAL(c) ((agx_m64)__builtin_amdgcn_ballot_w64(c))
+#define AGX_INV(m) (__builtin_amdgcn_inverse_ballot_w64(m))
+struct agx_lbuf {                    // one buffered arrival per lane
+    agx_m64 has, k1;                 // the arrival exists / counts for coverage (not K2ONLY)
+    agx_u32 p0, sq, fl;              // mate position; lean record: index of the arrival's base in the stored read, general record: the whole k-mer string word (agx_sref::qlen) and, in fl, bit 0: steps to
+                                     // position + 1; bit 1, all records: may not take the straight-line case (a CHAIN arrival, a step that skips positions: of all other lanes K1 <=> votes <=> steps to position + 1)
+    agx_cmhead h; agx_u32 cbyte;     // as loaded
+    agx_u32 slot, lenjs, geo;        // wave-uniform, from the record: read slot, read length | jstar << 16, strand and kind (agx_lrec::geo)
+};
+// The arrival that leaves the straight-line case, as a FUNCTION of its own (not inlined): agx_arrival_slow's nested lane-varying loops need some fifty scalar registers for their
+// exec masks; inlined into the loop they pushed the loop's own masks and pointers into spill lanes and kernel-argument reloads on EVERY entry.  Behind a call the loop's state
+// sits in callee-saved registers and the callee saves what it uses — only when it runs (one wave-entry in fifty: the first arrival at a position is stored without it).
+// State in and out by value (registers, no stack traffic).
+struct agx_slow_io { agx_u32 cnt, ok, v0_ok, v0_c0, v0_o0, v0_m, vm, sp; };
+__device__ __noinline__ agx_slow_io agx_lean_slow(__attribute__((address_space(3))) agx_u32 *lds_col, const agx_cmkey *cm, int iv, agx_slow_io io, agx_u32 cx_s, agx_u32 cx_n, agx_u32 cx0_cid, agx_u32 cx0_coff,
+                                                  agx_u32 p0, agx_u32 h_cid, agx_u32 h_coff, agx_u32 h_n, agx_u32 h_start, agx_u32 s0, agx_u32 s1, agx_u32 flags, agx_u32 vfield) {
+    agx_sweep_args R{}; R.cm = cm; R.iv = iv;
+    agx_bucket b; b.base = (agx_u32 *)lds_col; b.stride = 64; b.maxv = AGX_MAXV_LDS;
+    bool ok = io.ok != 0;
+    agx_arrival_slow(R, b, io.cnt, ok, cx_s, cx_n, agx_cmkey{cx0_cid, cx0_coff}, p0, h_start, h_n, agx_cmkey{h_cid, h_coff}, s0, s1, flags & 1u, (flags >> 1) & 1u, vfield, (flags >> 2) & 1u,
+                     io.v0_ok, io.v0_c0, io.v0_o0, io.v0_m, io.vm, io.sp);
+    io.ok = ok ? 1u : 0u;
+    return io;
+}
+template <class GET>
+__device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx_u32 tile, agx_u32 X, const agx_bucket &b, agx_u32 &cnt, agx_u32 &pflag, agx_u32 &emask, GET get) {
+    cnt = 0; pflag = 0;
+    const bool live = X < A.n_pos;
+    const agx_u32 lane = X & (AGX_TILE - 1u);
+    agx_u32 cx_s = 0, cx_n = 0; agx_cmkey cx0 = agx_cmkey{AGX_NONE, AGX_NONE};
+    if (live) { const agx_cmhead h = A.cm_head[X]; cx_s = h.start; cx_n = h.n; cx0 = agx_cmkey{h.cid, h.coff}; }
+    bool ok = true;
+    const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
+    if (lo == hi) return true;
+    const agx_u32 W = (agx_u32)(2 * A.iv + AGX_EP25), W2 = 2u * W;      // |a - b| <= W  <=>  (u32)(a - (b - W)) <= 2 W
+    const agx_cmhead *cm_head = A.cm_head; const agx_u8 *vcodes = A.vcodes; const agx_u32 n_pos = A.n_pos, stride = A.stride;
+    const GET recs = get;
+    // variant 0's mate-side key as the shared function keeps it (v0_*), and in the form the tests below want it: offsets with the window subtracted, the window of the mate
+    // position's clause per lane (everything passes where variant 0 has no mate position), the contig id with "none" replaced by an id no contig has (clause A/B passes when
+    // the arrival's id is none OR differs from variant 0's: with that replacement the second test covers the first)
+    agx_u32 v0_ok = 0, v0_c0 = AGX_NONE, v0_o0 = AGX_NONE, v0_m = AGX_NONE;
+    agx_u32 v0_c0x = AGX_NONE - 1u, v0_o0w = AGX_NONE - W, v0_mw = AGX_NONE - W, v0_mwin = AGX_NONE;
+    agx_m64 m_v0ok = 0, m_pf1 = 0, m_e0 = 0;
+
+    auto fetch = [&](const agx_lrec &r, bool valid, agx_lbuf &P) {
+        const agx_u32 g = r.geo, kind = g >> 30, L = r.lenjs & 0xFFFFu, js = r.lenjs >> 16;
+        const agx_u32 rev = (g >> 24) & 1u, mrev = 0u - rev, slot = r.slot;
+        agx_u32 p0, vaddr;
+        if (kind == AGX_LK_ONE) {
+            // one piece with mate positions and no jump (agx_lean_decode with everything else gone): lanes lo1 .. lo1 + span1, read index lane + qoff1, mate position lane + boff1
+            const agx_u32 q = lane + r.qoff1;
+            const agx_m64 last = AGX_BAL(q == js);
+            P.has = valid ? AGX_BAL(lane - (g & 63u) <= ((g >> 6) & 63u)) : 0ull; P.k1 = ~last;
+            m_pf1 |= P.has & ~last;
+            p0 = lane + r.boff1;
+            const agx_u32 stored = (q ^ mrev) + (L & mrev);            // forward: q; reverse: L - 1 - q
+            vaddr = min(stored, L - 1u);                              // (lanes outside the piece read some byte of the row)
+            P.sq = stored; P.fl = 0;
+        } else if (kind != AGX_LK_GENERAL) {
+            // two pieces, or one with a jump at its end or without mate positions (agx_lean_decode)
+            const agx_u32 lo1 = g & 63u, e1 = lo1 + ((g >> 6) & 63u), lo2 = (g >> 12) & 63u, e2 = lo2 + ((g >> 18) & 63u);
+            const bool in1 = lane - lo1 <= e1 - lo1, in2 = kind == AGX_LK_TWO && lane - lo2 <= e2 - lo2, mid = (g & AGX_LF_MID) && lane > e1 && lane < lo2;
+            const agx_u32 q = lane + (in2 ? r.qoff2 : r.qoff1);
+            p0 = in2 ? ((g & AGX_LF_BN2) ? AGX_NONE : lane + r.boff2) : (mid || (g & AGX_LF_BN1)) ? AGX_NONE : lane + r.boff1;
+            const bool lastb = q == js;
+            const bool hasb = valid && (in1 || in2 || mid);
+            const bool jump = hasb && !lastb && (((g & AGX_LF_JUMP1) && lane == e1) || ((g & AGX_LF_JUMP2) && in2 && lane == e2));
+            const agx_m64 last = AGX_BAL(lastb);
+            P.has = AGX_BAL(hasb); P.k1 = ~last;
+            m_pf1 |= P.has & ~last & ~AGX_BAL(jump); pflag |= jump ? 2u : 0u;
+            const agx_u32 stored = (q ^ mrev) + (L & mrev);
+            vaddr = min(stored, L - 1u);
+            P.sq = stored; P.fl = jump ? 2u : 0u;
+        } else {
+            // what does not fit a lean record: the hit's own derived record, decoded the general way
+            const agx_dhit d = recs.of_hit(r.hit);
+            const agx_arrival a = agx_decode_arrival(d, A.runs, X, A.k);
+            const bool has = valid && live && a.has != 0;
+            const bool step1 = has && a.has_succ && a.xs == X + 1, jump = has && a.has_succ && a.xs != X + 1;
+            P.has = AGX_BAL(has); P.k1 = AGX_BAL(a.type != AGX_AT_K2ONLY);
+            m_pf1 |= AGX_BAL(step1); pflag |= jump ? 2u : 0u;
+            p0 = a.p0;
+            const agx_u32 stored = rev ? L - 1u - a.q : a.q;
+            vaddr = (has && a.type == AGX_AT_K1) ? stored : 0u;
+            P.sq = (a.slen ? stored : 0u) | (a.slen << 16) | (rev ? 0x80000000u : 0u); P.fl = (step1 ? 1u : 0u) | ((jump || a.type == AGX_AT_CHAIN) ? 2u : 0u);
+        }
+        P.p0 = p0; P.slot = slot; P.lenjs = r.lenjs; P.geo = g;
+        // the two loads stand once, behind the branch (addresses are chosen, not data: HISTORY.md r04).  No mate, or no arrival: the empty head at n_pos.
+        P.h = cm_head[min(p0, n_pos)];
+        P.cbyte = vcodes[(size_t)slot * stride + vaddr];
+    };
+    auto apply = [&](const agx_lbuf &P) {
+        const agx_m64 cab = AGX_BAL(P.h.cid != v0_c0x) | AGX_BAL(P.h.coff - v0_o0w <= W2);                                     // agx_clause_ab against variant 0's mate-side key
+        const agx_m64 cc = AGX_BAL(P.p0 == AGX_NONE) | AGX_BAL(P.p0 - v0_mw <= v0_mwin);                                       // agx_clause_c
+        const agx_m64 fast = P.has & m_v0ok & cab & cc & AGX_BAL(P.h.n <= 1u) & AGX_BAL(!(P.fl & 2u));
+        const agx_m64 mk = fast & P.k1;                              // of the lanes in `fast`: counts = votes = steps to position + 1
+        const agx_u32 vfield = (P.cbyte >> ((P.geo >> 22) & 4u)) & 15u;      // (the strand's nibble of the vote code)
+        const bool votes = AGX_INV(mk);
+        const agx_u32 one = votes ? 1u : 0u;
+        agx_bucket_add<true>(agx_b(b, 0, AGX_F_COV), one);
+        agx_bucket_add<true>(agx_b(b, 0, votes ? vfield : (agx_u32)AGX_F_COV), one);
+        m_e0 |= mk & (fast >> 1);                                    // variant 0 here -> variant 0 of the next position (lane 63's right neighbour is another tile: the edge passes')
+        const agx_m64 slowm = P.has & ~fast;
+        if (slowm != 0) {                                            // wave-uniform
+            agx_u32 vm = AGX_INV(fast) ? 1u : 0u, sp = one;
+            if (AGX_INV(slowm)) {
+                const agx_u32 is_k1 = AGX_INV(P.k1) ? 1u : 0u, L = P.lenjs & 0xFFFFu, rev = (P.geo >> 24) & 1u;
+                agx_u32 s1 = P.sq, vt = is_k1, st1 = is_k1 & ~(P.fl >> 1);      // (a lean record's lane: a K1 arrival votes, and steps to position + 1 unless it jumps)
+                if ((P.geo >> 30) == AGX_LK_GENERAL) { vt = (is_k1 && ((P.sq >> 16) & 0x7FFFu) != 0) ? 1u : 0u; st1 = P.fl & 1u; }      // general record: a CHAIN arrival counts and does not vote (its k-mer is empty)
+                else {                                               // a lean record's k-mer string word (agx_arrival_fetch): k bases from the arrival's, fewer at the read's end (the K2ONLY arrival)
+                    const agx_u32 q = rev ? L - 1u - P.sq : P.sq, rest = L - q;
+                    const agx_u32 slen = is_k1 ? A.k : (rest < A.k ? rest : A.k);
+                    s1 = P.sq | (slen << 16) | (rev ? 0x80000000u : 0u);
+                }
+                if (AGX_SWEEP_FIRST && cnt == 0 && cx_n <= 1 && P.h.n <= 1) {
+                    // the first arrival at a position with one candidate key (five in six of what gets here) stores variant 0 on the spot: agx_arrival_slow's first arm, written out
+                    // so that only what is left pays for a call
+                    agx_b(b, 0, AGX_F_CID) = cx0.cid; agx_b(b, 0, AGX_F_COFF) = cx0.coff; agx_b(b, 0, AGX_F_CID0) = P.h.cid; agx_b(b, 0, AGX_F_COFF0) = P.h.coff;
+                    agx_b(b, 0, AGX_F_OFF0) = P.p0; agx_b(b, 0, AGX_F_COV) = is_k1;
+                    agx_b(b, 0, AGX_F_A) = 0; agx_b(b, 0, AGX_F_C) = 0; agx_b(b, 0, AGX_F_G) = 0; agx_b(b, 0, AGX_F_T) = 0; agx_b(b, 0, AGX_F_N) = 0;
+                    agx_b(b, 0, AGX_F_S0) = P.slot; agx_b(b, 0, AGX_F_S1) = s1;
+                    if (vt) agx_b(b, 0, vfield) = 1;
+                    cnt = 1; vm = 1u; sp = st1;
+                    v0_ok = 1u; v0_c0 = P.h.cid; v0_o0 = P.h.coff; v0_m = P.p0;
+                } else {
+                    agx_slow_io io{cnt, ok ? 1u : 0u, v0_ok, v0_c0, v0_o0, v0_m, vm, sp};
+                    io = agx_lean_slow((__attribute__((address_space(3))) agx_u32 *)b.base, A.cm, A.iv, io, cx_s, cx_n, cx0.cid, cx0.coff, P.p0, P.h.cid, P.h.coff, P.h.n, P.h.start, P.slot, s1,
+                                       is_k1 | (vt << 1) | (st1 << 2), vfield);
+                    cnt = io.cnt; ok = io.ok != 0; v0_ok = io.v0_ok; v0_c0 = io.v0_c0; v0_o0 = io.v0_o0; v0_m = io.v0_m; vm = io.vm; sp = io.sp;
+                }
+            }
+            v0_c0x = v0_c0 == AGX_NONE ? AGX_NONE - 1u : v0_c0; v0_o0w = v0_o0 - W; v0_mw = v0_m - W; v0_mwin = v0_m == AGX_NONE ? AGX_NONE : W2; m_v0ok = AGX_BAL(v0_ok != 0);
+            agx_edge_merge(emask, sp, (agx_u32)__builtin_amdgcn_update_dpp(0, (int)vm, 0x130, 0xF, 0xF, true));
+        }
+    };
+    // entries lo .. hi - 1, two buffers, each refilled for the entry two places ahead as soon as it has been applied (agx_node_sweep_lane).  Entries at and beyond hi are read
+    // like the others and masked out: they are the next tile's records, or the zeroed records agx_k_tile_fill leaves behind the last list (kind GENERAL of hit 0: decodable)
+    agx_lbuf pa, pb;
+    { const agx_lrec d0 = recs.lean(lo); fetch(d0, true, pa); }
+    { const agx_lrec d1 = recs.lean(lo + 1); fetch(d1, lo + 1 < hi, pb); }
+    for (agx_u32 i = lo; i < hi; i += 2) {
+        const agx_lrec da = recs.lean(i + 2);
+        apply(pa); fetch(da, i + 2 < hi, pa);
+        const agx_lrec db = recs.lean(i + 3);
+        apply(pb); fetch(db, i + 3 < hi, pb);
+    }
+    pflag |= AGX_INV(m_pf1) ? 1u : 0u;
+    emask |= AGX_INV(m_e0) ? 1u : 0u;
+    return ok;
 }
 
 template <int PASS>      // 0: every tile, AGX_MAXV_LDS variants in LDS; 1: the tiles pass 0 gave up on, AGX_MAXV_MID in LDS; 2: the rest, AGX_MAXV_BIG in global scratch;
@@ -484,10 +673,12 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
         if (K.S.tile_off[tile + 1] > K.list_cap) { if (lane == 0) atomicOr(K.status, 4u); return; }      // lists did not fit: nothing after the sweeps may run
         const agx_u32 X = tile * AGX_TILE + lane;
         agx_u32 cnt = 0, pflag = 0, emask = 0;
-        const agx_tile_recs hits{K.S.tile_recs};
+        const agx_tile_recs hits{K.S.tile_recs, K.S.dhit};
         // every lane hands the variants a hit touched to its left neighbour (agx_edge_merge): the x -> x+1 edges of 63 of the tile's 64
         // positions fall out of the sweep itself; the fallback pass leaves them to the edge passes (its buckets exceed the edge matrix)
-        const bool ok = agx_node_sweep_lane<!BIG>(K.S, tile, X, b, cnt, pflag, hits, [&](agx_u32 vm, agx_u32 sp) {
+        bool ok;
+        if (PASS == 0 && AGX_SWEEP_LEAN) ok = agx_sweep_tile_lean(K.S, tile, X, b, cnt, pflag, emask, hits);
+        else ok = agx_node_sweep_lane<!BIG>(K.S, tile, X, b, cnt, pflag, hits, [&](agx_u32 vm, agx_u32 sp) {
             // lane i reads lane i+1 with one DPP move (wave_shl:1; the last lane reads 0: its edges belong to the edge passes)
             if (!BIG) agx_edge_merge(emask, sp, (agx_u32)__builtin_amdgcn_update_dpp(0, (int)vm, 0x130, 0xF, 0xF, true));
         });
@@ -624,11 +815,8 @@ __global__ void __launch_bounds__(256) agx_k_edge_slow(agx_edge_kargs K) {
         for (agx_u32 base = lo; base < hi; base += 64) {                     // wave-uniform trip count
             const agx_u32 i = base + lane; const bool on = i < hi;
             const size_t at = on ? i : lo;
-            const uint4 ra = K.S.tile_recs[2 * at], rb = K.S.tile_recs[2 * at + 1];      // lanes = consecutive list entries
-            agx_dhit d;
-            d.a_t0 = ra.x; d.b_t0 = ra.y; d.a_runs = ra.z; d.b_runs = ra.w; d.a_slot = rb.x;
-            d.len = (agx_u16)(rb.y & 0xFFFFu); d.jstar = (agx_u16)(rb.y >> 16); d.a_nruns = (agx_u16)(rb.z & 0xFFFFu); d.b_nruns = (agx_u16)(rb.z >> 16);
-            d.flags = rb.w; d.x_lo = 0; d.x_hi = 0;
+            const agx_u32 hit = K.S.tile_recs[2 * at + 1].w;                             // lanes = consecutive list entries; a lean record names its hit (agx_lrec)
+            const agx_dhit d = K.S.dhit[hit];
             pairs |= agx_edge_slow_pair(K.S, c, X, d, on, [&](agx_u32 src, agx_u32 dst) { agx_slot_insert(K, src, dst); });
         }
         if (c.reg) {

@@ -55,6 +55,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
         for (agx_u32 t = dh[h].x_lo / AGX_TILE; t <= dh[h].x_hi / AGX_TILE; t++) lists[t].push_back(h);
     }
     std::vector<agx_u32> tile_off(n_tiles + 1, 0), tile_hits;
+    size_t lean_kinds[4] = {0, 0, 0, 0};
     std::vector<agx_dhit> tile_recs;                       // what agx_k_tile_sort writes: per list entry the hit's record for THAT tile (agx_tile_record)
     for (agx_u32 t = 0; t < n_tiles; t++) {
         tile_off[t] = (agx_u32)tile_hits.size(); tile_hits.insert(tile_hits.end(), lists[t].begin(), lists[t].end());
@@ -68,9 +69,35 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
                 if (!same) throw Error{E_ARG, "a tile record decodes differently from the hit's record"};
             }
             tile_recs.push_back(piece);
+            // the lean record of the entry (what pass 0 of the device's node sweep reads): wherever it is not kind GENERAL it must give the same arrival on every lane
+            const agx_lrec lr = agx_lean_make(dh[h], P.runs.data(), t, k, h);
+            lean_kinds[lr.geo >> 30]++;
+            if ((lr.geo >> 30) != AGX_LK_GENERAL) {
+                if (lr.slot != dh[h].a_slot || lr.hit != h || lr.lenjs != ((agx_u32)dh[h].len | ((agx_u32)dh[h].jstar << 16)) || (((lr.geo & AGX_LF_AREV) != 0) != ((dh[h].flags & AGX_HF_AREV) != 0)))
+                    throw Error{E_ARG, "a lean tile record names another read"};
+                for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
+                    const agx_u32 X = t * AGX_TILE + lane;
+                    const agx_arrival a = agx_decode_arrival(dh[h], P.runs.data(), X, k); const agx_larr l = agx_lean_decode(lr, lane);
+                    const bool a_has = a.has != 0 && X < n_pos;
+                    bool same = a_has == (l.has != 0);
+                    if (same && a_has) same = a.type != AGX_AT_CHAIN && (a.type == AGX_AT_K2ONLY) == (l.last != 0) && a.q == l.q && a.p0 == l.p0 &&
+                                              (a.has_succ != 0) == (l.last == 0) && (!a.has_succ || ((a.xs != X + 1) == (l.jump != 0)));
+                    if (!same) {
+                        if (getenv("AGX_SIM_STATS")) {
+                            const agx_dhit &d = dh[h];
+                            fprintf(stderr, "[hostsim] lean mismatch: hit %u tile %u lane %u: decode has %u type %u q %u p0 %u succ %u xs %u | lean has %u last %u q %u p0 %u jump %u | geo %08x qoff %u %u boff %u %u | L %u js %u x %u..%u a_t0 %u b_t0 %u\n",
+                                    h, t, lane, a.has, a.type, a.q, a.p0, a.has_succ, a.xs, l.has, l.last, l.q, l.p0, l.jump, lr.geo, lr.qoff1, lr.qoff2, lr.boff1, lr.boff2, d.len, d.jstar, d.x_lo, d.x_hi, d.a_t0, d.b_t0);
+                            for (agx_u32 i = 0; i < d.a_nruns; i++) fprintf(stderr, "   a run %u: q %u t %u n %u\n", i, P.runs[d.a_runs + i].q, P.runs[d.a_runs + i].t, P.runs[d.a_runs + i].n);
+                            for (agx_u32 i = 0; i < d.b_nruns; i++) fprintf(stderr, "   b run %u: q %u t %u n %u\n", i, P.runs[d.b_runs + i].q, P.runs[d.b_runs + i].t, P.runs[d.b_runs + i].n);
+                        }
+                        throw Error{E_ARG, "a lean tile record decodes differently from the hit's record"};
+                    }
+                }
+            }
         }
     }
     tile_off[n_tiles] = (agx_u32)tile_hits.size();
+    if (getenv("AGX_SIM_STATS")) fprintf(stderr, "[hostsim] lean records: %zu general, %zu one piece, %zu one piece with a jump or without mate positions, %zu two pieces\n", lean_kinds[0], lean_kinds[1], lean_kinds[2], lean_kinds[3]);
     if (getenv("AGX_SIM_STATS")) { size_t lin = 0, cx = 0, cx_hits = 0; for (const agx_dhit &r : tile_recs) (r.a_nruns | r.b_nruns) ? cx++ : lin++; for (const agx_dhit &r : dh) if (!(r.flags & AGX_HF_SKIP) && (r.a_nruns | r.b_nruns)) cx_hits++;
         fprintf(stderr, "[hostsim] tile-list entries: %zu linear pieces, %zu general records (%.1f %%); hits with a multi-run mate: %zu of %zu\n", lin, cx, 100.0 * cx / (lin + cx + 1e-9), cx_hits, dh.size()); }
 
