@@ -540,6 +540,15 @@ __device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx
     agx_u32 v0_ok = 0, v0_c0 = AGX_NONE, v0_o0 = AGX_NONE, v0_m = AGX_NONE;
     agx_u32 v0_c0x = AGX_NONE - 1u, v0_o0w = AGX_NONE - W, v0_mw = AGX_NONE - W, v0_mwin = AGX_NONE;
     agx_m64 m_v0ok = 0, m_pf1 = 0, m_e0 = 0;
+    // the straight-line case's votes for variant 0: A, C, G, T, N in 6 bits each (the arrivals that take it count AND vote: coverage = the sum)
+    agx_u32 acc = 0;
+    auto flush = [&]() {
+        agx_u32 total = 0;
+#pragma unroll
+        for (agx_u32 f = 0; f < 5u; f++) { const agx_u32 c = (acc >> (6u * f)) & 63u; total += c; agx_bucket_add<true>(agx_b(b, 0, (agx_u32)AGX_F_A + f), c); }
+        agx_bucket_add<true>(agx_b(b, 0, AGX_F_COV), total);
+        acc = 0;
+    };
 
     auto fetch = [&](const agx_lrec &r, bool valid, agx_lbuf &P) {
         const agx_u32 g = r.geo, kind = g >> 30, L = r.lenjs & 0xFFFFu, js = r.lenjs >> 16;
@@ -591,13 +600,11 @@ __device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx
     auto apply = [&](const agx_lbuf &P) {
         const agx_m64 cab = AGX_BAL(P.h.cid != v0_c0x) | AGX_BAL(P.h.coff - v0_o0w <= W2);                                     // agx_clause_ab against variant 0's mate-side key
         const agx_m64 cc = AGX_BAL(P.p0 == AGX_NONE) | AGX_BAL(P.p0 - v0_mw <= v0_mwin);                                       // agx_clause_c
-        const agx_m64 fast = P.has & m_v0ok & cab & cc & AGX_BAL(P.h.n <= 1u) & AGX_BAL(!(P.fl & 2u));
+        const agx_m64 fast = P.has & m_v0ok & cab & cc & AGX_BAL((P.h.n | (P.fl & 2u)) <= 1u);      // (at most one conti-mer at the mate position, and no lane that must not take this case)
         const agx_m64 mk = fast & P.k1;                              // of the lanes in `fast`: counts = votes = steps to position + 1
         const agx_u32 vfield = (P.cbyte >> ((P.geo >> 22) & 4u)) & 15u;      // (the strand's nibble of the vote code)
-        const bool votes = AGX_INV(mk);
-        const agx_u32 one = votes ? 1u : 0u;
-        agx_bucket_add<true>(agx_b(b, 0, AGX_F_COV), one);
-        agx_bucket_add<true>(agx_b(b, 0, votes ? vfield : (agx_u32)AGX_F_COV), one);
+        const agx_u32 one = AGX_INV(mk) ? 1u : 0u;
+        acc += one << ((vfield - (agx_u32)AGX_F_A) * 6u);           // (no LDS traffic in the straight-line case: five 6-bit counters in a register, added to the bucket every 62 entries)
         m_e0 |= mk & (fast >> 1);                                    // variant 0 here -> variant 0 of the next position (lane 63's right neighbour is another tile: the edge passes')
         const agx_m64 slowm = P.has & ~fast;
         if (slowm != 0) {                                            // wave-uniform
@@ -637,11 +644,16 @@ __device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx
     agx_lbuf pa, pb;
     { const agx_lrec d0 = recs.lean(lo); fetch(d0, true, pa); }
     { const agx_lrec d1 = recs.lean(lo + 1); fetch(d1, lo + 1 < hi, pb); }
-    for (agx_u32 i = lo; i < hi; i += 2) {
-        const agx_lrec da = recs.lean(i + 2);
-        apply(pa); fetch(da, i + 2 < hi, pa);
-        const agx_lrec db = recs.lean(i + 3);
-        apply(pb); fetch(db, i + 3 < hi, pb);
+    for (agx_u32 c = lo; c < hi; ) {                                // (62 entries at a time: the register counters hold 63)
+        const agx_u32 ce = hi - c > 62u ? c + 62u : hi;
+        for (agx_u32 i = c; i < ce; i += 2) {
+            const agx_lrec da = recs.lean(i + 2);
+            apply(pa); fetch(da, i + 2 < hi, pa);
+            const agx_lrec db = recs.lean(i + 3);
+            apply(pb); fetch(db, i + 3 < hi, pb);
+        }
+        flush();
+        c = ce + ((ce - c) & 1u);                                    // (an odd chunk — the last — has applied one masked entry beyond its end)
     }
     pflag |= AGX_INV(m_pf1) ? 1u : 0u;
     emask |= AGX_INV(m_e0) ? 1u : 0u;
