@@ -490,18 +490,18 @@ AGX_HD agx_lrec agx_lean_make_v(agx_u32 d_a_t0, agx_u32 d_b_t0, agx_u32 d_a_runs
     }
     if (bad || np == 0u || (np == 2u && lo1 <= hi0)) return r;
     agx_u32 geo = (d_flags & AGX_HF_AREV) ? (agx_u32)AGX_LF_AREV : 0u;
+    // (the sections under the first piece once, for both shapes: the function is inlined where it is called)
+    const agx_bsec s = agx_lean_bsections(d_b_t0, d_b_runs, d_b_nruns, L, runs, lo0 + qoff0, hi0 + qoff0);
     if (np == 2u) {
         // two pieces of the left mate: the other mate must be one section under each
-        const agx_bsec s1 = agx_lean_bsections(d_b_t0, d_b_runs, d_b_nruns, L, runs, lo0 + qoff0, hi0 + qoff0);
         const agx_bsec s2 = agx_lean_bsections(d_b_t0, d_b_runs, d_b_nruns, L, runs, lo1 + qoff1, hi1 + qoff1);
-        if (s1.n != 1u || s2.n != 1u) return r;
-        r.qoff1 = qoff0; r.qoff2 = qoff1; r.boff1 = qoff0 + s1.off0; r.boff2 = qoff1 + s2.off0;
-        geo |= (s1.none0 ? (agx_u32)AGX_LF_BN1 : 0u) | (s2.none0 ? (agx_u32)AGX_LF_BN2 : 0u) | (jump0 ? (agx_u32)AGX_LF_JUMP1 : 0u) | (jump1 ? (agx_u32)AGX_LF_JUMP2 : 0u);
+        if (s.n != 1u || s2.n != 1u) return r;
+        r.qoff1 = qoff0; r.qoff2 = qoff1; r.boff1 = qoff0 + s.off0; r.boff2 = qoff1 + s2.off0;
+        geo |= (s.none0 ? (agx_u32)AGX_LF_BN1 : 0u) | (s2.none0 ? (agx_u32)AGX_LF_BN2 : 0u) | (jump0 ? (agx_u32)AGX_LF_JUMP1 : 0u) | (jump1 ? (agx_u32)AGX_LF_JUMP2 : 0u);
         r.geo = geo | lo0 | ((hi0 - lo0) << 6) | (lo1 << 12) | ((hi1 - lo1) << 18) | ((agx_u32)AGX_LK_TWO << 30);
         return r;
     }
     // one piece of the left mate: the other mate in one, two, or three sections of which the middle one has no positions
-    const agx_bsec s = agx_lean_bsections(d_b_t0, d_b_runs, d_b_nruns, L, runs, lo0 + qoff0, hi0 + qoff0);
     if (s.n == 0u || (s.n == 3u && !(s.none1 && !s.none0 && !s.none2))) return r;
     r.qoff1 = r.qoff2 = qoff0; r.boff1 = qoff0 + s.off0;
     geo |= s.none0 ? (agx_u32)AGX_LF_BN1 : 0u;
