@@ -427,7 +427,8 @@ AGX_HD agx_larr agx_lean_decode(const agx_lrec &r, agx_u32 lane) {
 // whether it has no mate positions and, if it has, t - q of its run.  (No arrays: a table indexed by a running count lives in scratch memory on the device.  Runs come as
 // values: a run chosen between a table entry and the simple mate's pseudo-run must not be a choice between addresses — agx_tile_piece_v.)
 struct agx_bsec { agx_u32 n, q1, q2, none0, none1, none2, off0, off1, off2; };
-AGX_HD agx_bsec agx_lean_bsections(agx_u32 b_t0, agx_u32 b_runs, agx_u32 b_nruns, agx_u32 L, const agx_run *runs, agx_u32 qa, agx_u32 qb) {
+#define AGX_LEAN_MAXRUNS 3u      // a mate with more runs than this is kind GENERAL: the runs are fetched up front, side by side (a loop that loads run after run is a chain of waits: agx_k_tile_fill's time)
+AGX_HD agx_bsec agx_lean_bsections(agx_u32 b0q, agx_u32 b0t, agx_u32 b0n, agx_u32 b1q, agx_u32 b1t, agx_u32 b1n, agx_u32 b2q, agx_u32 b2t, agx_u32 b2n, agx_u32 nb, agx_u32 qa, agx_u32 qb) {      // (runs as values, never as structs that are chosen between)
     // (section i's fields are separate variables, each updated by a select on the running count: stores chosen by the count into a struct's fields become ONE store through a
     // computed address, and the struct then lives in scratch memory on the device)
     agx_u32 n = 0, q1 = 0, q2 = 0, none0 = 1u, none1 = 1u, none2 = 1u, off0 = 0, off1 = 0, off2 = 0;
@@ -438,18 +439,19 @@ AGX_HD agx_bsec agx_lean_bsections(agx_u32 b_t0, agx_u32 b_runs, agx_u32 b_nruns
         q2 = a2 ? q0 : q2; none2 = a2 ? none : none2; off2 = a2 ? off : off2;
         n += on ? 1u : 0u;
     };
-    const agx_u32 nb = b_nruns ? b_nruns : 1u;
     agx_u32 next = qa;                        // first index not yet assigned to a section
     bool bad = false;
-    for (agx_u32 i = 0; i < nb; i++) {
-        agx_u32 c_q = 0, c_t = b_t0, c_n = L;
-        if (b_nruns) { const agx_run c = runs[b_runs + i]; c_q = c.q; c_t = c.t; c_n = c.n; }
-        const bool touches = c_n != 0u && c_q + c_n > qa && c_q <= qb && next <= qb;      // a run that holds some of what is left of qa .. qb
-        const agx_u32 from = c_q > qa ? c_q : qa;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (agx_u32 i = 0; i < AGX_LEAN_MAXRUNS; i++) {
+        const agx_u32 cq = i == 0u ? b0q : i == 1u ? b1q : b2q, ct = i == 0u ? b0t : i == 1u ? b1t : b2t, cn = i == 0u ? b0n : i == 1u ? b1n : b2n;
+        const bool touches = i < nb && cn != 0u && cq + cn > qa && cq <= qb && next <= qb;      // a run that holds some of what is left of qa .. qb
+        const agx_u32 from = cq > qa ? cq : qa;
         bad = bad || (touches && from < next);                              // runs that overlap, or out of order
         push(touches && from > next, next, 1u, 0u);
-        push(touches, from, 0u, c_t - c_q);
-        next = touches ? c_q + c_n : next;                                  // (may lie beyond qb)
+        push(touches, from, 0u, ct - cq);
+        next = touches ? cq + cn : next;                                    // (may lie beyond qb)
     }
     push(next <= qb, next, 1u, 0u);
     agx_bsec s; s.n = (bad || n > 3u) ? 0u : n; s.q1 = q1; s.q2 = q2; s.none0 = none0; s.none1 = none1; s.none2 = none2; s.off0 = off0; s.off1 = off1; s.off2 = off2;
@@ -458,43 +460,57 @@ AGX_HD agx_bsec agx_lean_bsections(agx_u32 b_t0, agx_u32 b_runs, agx_u32 b_nruns
 // the record of the hit with derived record (d_*) in the list of `tile`; hit = its place in the tile order
 AGX_HD agx_lrec agx_lean_make_v(agx_u32 d_a_t0, agx_u32 d_b_t0, agx_u32 d_a_runs, agx_u32 d_b_runs, agx_u32 d_a_slot, agx_u32 L, agx_u32 js, agx_u32 d_a_nruns, agx_u32 d_b_nruns,
                                 agx_u32 d_flags, agx_u32 d_x_lo, agx_u32 d_x_hi, const agx_run *runs, agx_u32 tile, agx_u32 k, agx_u32 hit) {
-    agx_lrec r; r.qoff1 = r.boff1 = r.qoff2 = r.boff2 = 0; r.slot = d_a_slot; r.lenjs = L | (js << 16); r.geo = 0; r.hit = hit;      // kind GENERAL
+    agx_lrec r; r.qoff1 = r.boff1 = r.qoff2 = r.boff2 = 0; r.slot = d_a_slot; r.lenjs = L | (js << 16); r.hit = hit;
+    r.geo = (d_flags & AGX_HF_AREV) ? (agx_u32)AGX_LF_AREV : 0u;      // kind GENERAL (the read slot, the lengths and the strand are there whatever the kind)
     const agx_u32 T0 = tile * AGX_TILE;
     const agx_u32 xs = d_x_lo > T0 ? d_x_lo : T0, xe = d_x_hi < T0 + AGX_TILE - 1u ? d_x_hi : T0 + AGX_TILE - 1u;
-    if ((d_flags & AGX_HF_SKIP) || xs > xe || js == 0xFFFFu || L <= k) return r;
+    if ((d_flags & AGX_HF_SKIP) || xs > xe || js == 0xFFFFu || L <= k || d_a_nruns > AGX_LEAN_MAXRUNS || d_b_nruns > AGX_LEAN_MAXRUNS) return r;
+    // both mates' runs, all at once (a simple mate is one run of the whole read at its offset)
+    const agx_u32 na = d_a_nruns ? d_a_nruns : 1u, nb = d_b_nruns ? d_b_nruns : 1u;
+    agx_u32 a0q = 0, a0t = d_a_t0, a0n = L, a1q = 0, a1t = 0, a1n = 0, a2q = 0, a2t = 0, a2n = 0, b0q = 0, b0t = d_b_t0, b0n = L, b1q = 0, b1t = 0, b1n = 0, b2q = 0, b2t = 0, b2n = 0;
+    if (d_a_nruns) { const agx_run c = runs[d_a_runs]; a0q = c.q; a0t = c.t; a0n = c.n; }
+    if (d_a_nruns > 1u) { const agx_run c = runs[d_a_runs + 1u]; a1q = c.q; a1t = c.t; a1n = c.n; }
+    if (d_a_nruns > 2u) { const agx_run c = runs[d_a_runs + 2u]; a2q = c.q; a2t = c.t; a2n = c.n; }
+    if (d_b_nruns) { const agx_run c = runs[d_b_runs]; b0q = c.q; b0t = c.t; b0n = c.n; }
+    if (d_b_nruns > 1u) { const agx_run c = runs[d_b_runs + 1u]; b1q = c.q; b1t = c.t; b1n = c.n; }
+    if (d_b_nruns > 2u) { const agx_run c = runs[d_b_runs + 2u]; b2q = c.q; b2t = c.t; b2n = c.n; }
     // the left mate's runs that hold arrivals of this tile: at most two, no empty run anywhere (an empty run is still the "next run" of the one before it)
-    const agx_u32 na = d_a_nruns ? d_a_nruns : 1u;
     agx_u32 np = 0, lo0 = 0, hi0 = 0, qoff0 = 0, jump0 = 0, lo1 = 0, hi1 = 0, qoff1 = 0, jump1 = 0;
     bool bad = false;
-    for (agx_u32 i = 0; i < na; i++) {
-        agx_u32 c_q = 0, c_t = d_a_t0, c_n = L;
-        if (d_a_nruns) { const agx_run c = runs[d_a_runs + i]; c_q = c.q; c_t = c.t; c_n = c.n; }
-        if (!c_n) { bad = true; continue; }
-        const agx_u32 c_end = c_t + c_n - 1u;
-        agx_u32 nx_q = 0, nx_t = 0; const bool has_nx = d_a_nruns != 0 && i + 1u < na;
-        if (has_nx) { const agx_run nx = runs[d_a_runs + i + 1u]; nx_q = nx.q; nx_t = nx.t; }
-        const bool direct_q = has_nx && nx_q == c_q + c_n, direct_t = has_nx && nx_t == c_end + 1u;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (agx_u32 i = 0; i < AGX_LEAN_MAXRUNS; i++) {
+        const agx_u32 cq = i == 0u ? a0q : i == 1u ? a1q : a2q, ct = i == 0u ? a0t : i == 1u ? a1t : a2t, cn = i == 0u ? a0n : i == 1u ? a1n : a2n;
+        const agx_u32 nxq = i == 0u ? a1q : a2q, nxt = i == 0u ? a1t : a2t;      // (the next run: only looked at where has_nx)
+        const bool on = i < na;
+        const agx_u32 c_end = ct + cn - 1u;
+        const bool has_nx = i + 1u < na;
+        const bool direct_q = has_nx && nxq == cq + cn, direct_t = has_nx && nxt == c_end + 1u;
+        bad = bad || (on && cn == 0u);
         // CHAIN arrivals between this run and the next (agx_decode_arrival's in_gap) that fall into the tile: not a lean record
-        if (has_nx && !direct_q && !direct_t && nx_t > c_end + 1u && c_end + 1u <= T0 + AGX_TILE - 1u && nx_t - 1u >= T0) bad = true;
-        if (c_end < xs || c_t > xe) continue;
-        if (np >= 2u) { bad = true; continue; }
-        const agx_u32 lo = c_t > xs ? c_t : xs, hi = c_end < xe ? c_end : xe;
+        bad = bad || (on && has_nx && !direct_q && !direct_t && nxt > c_end + 1u && c_end + 1u <= T0 + AGX_TILE - 1u && nxt - 1u >= T0);
+        const bool holds = on && cn != 0u && !(c_end < xs || ct > xe);
+        bad = bad || (holds && np >= 2u);
+        const agx_u32 lo = ct > xs ? ct : xs, hi = c_end < xe ? c_end : xe;
         // the piece ends where the run ends, on an event source (an index below jstar): where does its successor go?  To the next run's first index — on position + 1 (a read
         // insertion, or a run cut in two: nothing special), over a gap of the reference (a read deletion: a JUMP), or, if the next run continues neither in the read nor on
         // the reference, through CHAIN arrivals: not a lean record.  (No next run cannot happen: the read's last aligned index is not below jstar.)
-        agx_u32 jump = 0;
-        if (hi == c_end && c_q + c_n - 1u < js) { if (!has_nx || (!direct_q && !direct_t)) bad = true; else if (!direct_t) jump = 1u; }
-        if (np == 0u) { lo0 = lo - T0; hi0 = hi - T0; qoff0 = c_q - c_t + T0; jump0 = jump; }
-        else { lo1 = lo - T0; hi1 = hi - T0; qoff1 = c_q - c_t + T0; jump1 = jump; }
-        np++;
+        const bool ends = holds && hi == c_end && cq + cn - 1u < js;
+        bad = bad || (ends && (!has_nx || (!direct_q && !direct_t)));
+        const agx_u32 jump = (ends && !direct_t) ? 1u : 0u;
+        const bool p0 = holds && np == 0u, p1 = holds && np == 1u;
+        lo0 = p0 ? lo - T0 : lo0; hi0 = p0 ? hi - T0 : hi0; qoff0 = p0 ? cq - ct + T0 : qoff0; jump0 = p0 ? jump : jump0;
+        lo1 = p1 ? lo - T0 : lo1; hi1 = p1 ? hi - T0 : hi1; qoff1 = p1 ? cq - ct + T0 : qoff1; jump1 = p1 ? jump : jump1;
+        np += holds ? 1u : 0u;
     }
     if (bad || np == 0u || (np == 2u && lo1 <= hi0)) return r;
-    agx_u32 geo = (d_flags & AGX_HF_AREV) ? (agx_u32)AGX_LF_AREV : 0u;
+    agx_u32 geo = r.geo;
     // (the sections under the first piece once, for both shapes: the function is inlined where it is called)
-    const agx_bsec s = agx_lean_bsections(d_b_t0, d_b_runs, d_b_nruns, L, runs, lo0 + qoff0, hi0 + qoff0);
+    const agx_bsec s = agx_lean_bsections(b0q, b0t, b0n, b1q, b1t, b1n, b2q, b2t, b2n, nb, lo0 + qoff0, hi0 + qoff0);
     if (np == 2u) {
         // two pieces of the left mate: the other mate must be one section under each
-        const agx_bsec s2 = agx_lean_bsections(d_b_t0, d_b_runs, d_b_nruns, L, runs, lo1 + qoff1, hi1 + qoff1);
+        const agx_bsec s2 = agx_lean_bsections(b0q, b0t, b0n, b1q, b1t, b1n, b2q, b2t, b2n, nb, lo1 + qoff1, hi1 + qoff1);
         if (s.n != 1u || s2.n != 1u) return r;
         r.qoff1 = qoff0; r.qoff2 = qoff1; r.boff1 = qoff0 + s.off0; r.boff2 = qoff1 + s2.off0;
         geo |= (s.none0 ? (agx_u32)AGX_LF_BN1 : 0u) | (s2.none0 ? (agx_u32)AGX_LF_BN2 : 0u) | (jump0 ? (agx_u32)AGX_LF_JUMP1 : 0u) | (jump1 ? (agx_u32)AGX_LF_JUMP2 : 0u);

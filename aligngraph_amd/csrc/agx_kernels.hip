@@ -496,6 +496,9 @@ __device__ __forceinline__ agx_u32 agx_wave_incl_scan(agx_u32 v, agx_u32 lane) {
 #ifndef AGX_SWEEP_LEAN
 #define AGX_SWEEP_LEAN 1
 #endif
+#ifndef AGX_LEAN_VEDGE
+#define AGX_LEAN_VEDGE 1          // the variant-0 edge of the straight-line case by a DPP move on the vector unit (0: three scalar mask operations — the scalar unit is the busier one: 2.47 against 2.43 ms)
+#endif
 typedef unsigned long long agx_m64;
 #define AGX_BAL(c) ((agx_m64)__builtin_amdgcn_ballot_w64(c))
 #define AGX_INV(m) (__builtin_amdgcn_inverse_ballot_w64(m))
@@ -605,7 +608,11 @@ __device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx
         const agx_u32 vfield = (P.cbyte >> ((P.geo >> 22) & 4u)) & 15u;      // (the strand's nibble of the vote code)
         const agx_u32 one = AGX_INV(mk) ? 1u : 0u;
         acc += one << ((vfield - (agx_u32)AGX_F_A) * 6u);           // (no LDS traffic in the straight-line case: five 6-bit counters in a register, added to the bucket every 62 entries)
+#if AGX_LEAN_VEDGE
+        emask |= one & (agx_u32)__builtin_amdgcn_update_dpp(0, (int)(AGX_INV(fast) ? 1u : 0u), 0x130, 0xF, 0xF, true);
+#else
         m_e0 |= mk & (fast >> 1);                                    // variant 0 here -> variant 0 of the next position (lane 63's right neighbour is another tile: the edge passes')
+#endif
         const agx_m64 slowm = P.has & ~fast;
         if (slowm != 0) {                                            // wave-uniform
             agx_u32 vm = AGX_INV(fast) ? 1u : 0u, sp = one;

@@ -72,6 +72,8 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
             // the lean record of the entry (what pass 0 of the device's node sweep reads): wherever it is not kind GENERAL it must give the same arrival on every lane
             const agx_lrec lr = agx_lean_make(dh[h], P.runs.data(), t, k, h);
             lean_kinds[lr.geo >> 30]++;
+            if (lr.slot != dh[h].a_slot || lr.hit != h || lr.lenjs != ((agx_u32)dh[h].len | ((agx_u32)dh[h].jstar << 16)) || (((lr.geo & AGX_LF_AREV) != 0) != ((dh[h].flags & AGX_HF_AREV) != 0)))
+                throw Error{E_ARG, "a lean tile record names another read"};
             if ((lr.geo >> 30) != AGX_LK_GENERAL) {
                 if (lr.slot != dh[h].a_slot || lr.hit != h || lr.lenjs != ((agx_u32)dh[h].len | ((agx_u32)dh[h].jstar << 16)) || (((lr.geo & AGX_LF_AREV) != 0) != ((dh[h].flags & AGX_HF_AREV) != 0)))
                     throw Error{E_ARG, "a lean tile record names another read"};

@@ -55,6 +55,12 @@ CONFIGS = [
     dict(seed=860528, chroms="5551,21059", part=2, pairs=9239, L=36, k=3, coverage=3, insert_variation=0, snp=0.02, indel=0.001, contig_min=2000,
          contig_max=3000, contig_minus=0.54, contig_split=0.23, contig_dup=0.09, contig_overlap=0.09, contig_lowid=0.12, read_indel=0.5, read_clip=0.05,
          multi=0.1),
+    # found by tests/tools/fuzz_parity.py --engine gpu (seed 606, iteration 10) on r06's lean tile records: reads of 36 bases with k = 31 and an indel in every second read — many list
+    # entries that fit no lean record (kind GENERAL: pass 0 decodes the hit's own derived record) on reverse-strand reads; the first form lost the strand of such a record and
+    # counted its votes from the wrong end of the read: node keys and edges equal, vote counters different
+    dict(seed=449022, chroms="34734,33365,11871", part=1, pairs=66641, L=36, k=31, coverage=5, insert_variation=10, snp=0.02, indel=0.01, contig_min=250, contig_max=20000,
+         contig_minus=0.09160248584068127, contig_split=0.46331666789922493, contig_dup=0.30874604567655217, contig_overlap=0.18161683683418484, contig_lowid=0.07560065568958672,
+         read_err=0, read_indel=0.5, read_clip=0.05),
 ]
 
 
