@@ -407,6 +407,7 @@ enum { AGX_LF_AREV = 1u << 24, AGX_LF_BN1 = 1u << 25, AGX_LF_BN2 = 1u << 26, AGX
 struct agx_lrec {
     agx_u32 qoff1, boff1, qoff2, boff2;      // (boff unused where BN1 / BN2 says the piece has no mate positions)
     agx_u32 slot, lenjs;                     // read slot of the left mate; read length | jstar << 16
+                                             // kind ONE only (it has no second piece): qoff2 = what the stored index of a lane's base is counted from — (lane ^ -reverse) + qoff2 —, boff2 = the lane of the K2ONLY arrival, jstar - qoff1 (any value: no such lane)
     agx_u32 geo;                             // lo1 | span1 << 6 | lo2 << 12 | span2 << 18 (a piece = lanes lo .. lo + span) | AGX_LF_* | kind << 30
     agx_u32 hit;                             // the hit's place in the tile order: dhit[hit]
 };
@@ -521,7 +522,11 @@ AGX_HD agx_lrec agx_lean_make_v(agx_u32 d_a_t0, agx_u32 d_b_t0, agx_u32 d_a_runs
     if (s.n == 0u || (s.n == 3u && !(s.none1 && !s.none0 && !s.none2))) return r;
     r.qoff1 = r.qoff2 = qoff0; r.boff1 = qoff0 + s.off0;
     geo |= s.none0 ? (agx_u32)AGX_LF_BN1 : 0u;
-    if (s.n == 1u) { r.geo = geo | lo0 | ((hi0 - lo0) << 6) | (jump0 ? (agx_u32)AGX_LF_JUMP1 : 0u) | ((agx_u32)((jump0 || s.none0) ? AGX_LK_ONEX : AGX_LK_ONE) << 30); return r; }
+    if (s.n == 1u) {
+        const bool plain = !jump0 && !s.none0;
+        if (plain) { r.qoff2 = (d_flags & AGX_HF_AREV) ? L - qoff0 : qoff0; r.boff2 = js - qoff0; }      // (what the sweep's arm for this kind reads instead of unpacking and subtracting: see agx_lrec)
+        r.geo = geo | lo0 | ((hi0 - lo0) << 6) | (jump0 ? (agx_u32)AGX_LF_JUMP1 : 0u) | ((agx_u32)(plain ? AGX_LK_ONE : AGX_LK_ONEX) << 30); return r;
+    }
     const agx_u32 q_last = s.n == 3u ? s.q2 : s.q1, none_last = s.n == 3u ? s.none2 : s.none1, off_last = s.n == 3u ? s.off2 : s.off1;
     const agx_u32 l2 = q_last - qoff0, h1 = s.q1 - qoff0 - 1u;              // first lane of the last section, last lane of the first
     r.boff2 = qoff0 + off_last;

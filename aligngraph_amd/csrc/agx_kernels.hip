@@ -558,13 +558,13 @@ __device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx
         const agx_u32 rev = (g >> 24) & 1u, mrev = 0u - rev, slot = r.slot;
         agx_u32 p0, vaddr;
         if (kind == AGX_LK_ONE) {
-            // one piece with mate positions and no jump (agx_lean_decode with everything else gone): lanes lo1 .. lo1 + span1, read index lane + qoff1, mate position lane + boff1
-            const agx_u32 q = lane + r.qoff1;
-            const agx_m64 last = AGX_BAL(q == js);
+            // one piece with mate positions and no jump (agx_lean_decode with everything else gone): lanes lo1 .. lo1 + span1, mate position lane + boff1; the lane of the K2ONLY
+            // arrival and the base the stored index is counted from come digested (agx_lrec)
+            const agx_m64 last = AGX_BAL(lane == r.boff2);
             P.has = valid ? AGX_BAL(lane - (g & 63u) <= ((g >> 6) & 63u)) : 0ull; P.k1 = ~last;
             m_pf1 |= P.has & ~last;
             p0 = lane + r.boff1;
-            const agx_u32 stored = (q ^ mrev) + (L & mrev);            // forward: q; reverse: L - 1 - q
+            const agx_u32 stored = (lane ^ mrev) + r.qoff2;           // forward: q; reverse: L - 1 - q
             vaddr = min(stored, L - 1u);                              // (lanes outside the piece read some byte of the row)
             P.sq = stored; P.fl = 0;
         } else if (kind != AGX_LK_GENERAL) {

@@ -74,6 +74,8 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
             lean_kinds[lr.geo >> 30]++;
             if (lr.slot != dh[h].a_slot || lr.hit != h || lr.lenjs != ((agx_u32)dh[h].len | ((agx_u32)dh[h].jstar << 16)) || (((lr.geo & AGX_LF_AREV) != 0) != ((dh[h].flags & AGX_HF_AREV) != 0)))
                 throw Error{E_ARG, "a lean tile record names another read"};
+            if ((lr.geo >> 30) == AGX_LK_ONE && (lr.qoff2 != ((dh[h].flags & AGX_HF_AREV) ? (agx_u32)dh[h].len - lr.qoff1 : lr.qoff1) || lr.boff2 != (agx_u32)dh[h].jstar - lr.qoff1 || (lr.geo & (AGX_LF_BN1 | AGX_LF_JUMP1))))
+                throw Error{E_ARG, "a one-piece lean record's digested fields are not what its offsets say"};
             if ((lr.geo >> 30) != AGX_LK_GENERAL) {
                 if (lr.slot != dh[h].a_slot || lr.hit != h || lr.lenjs != ((agx_u32)dh[h].len | ((agx_u32)dh[h].jstar << 16)) || (((lr.geo & AGX_LF_AREV) != 0) != ((dh[h].flags & AGX_HF_AREV) != 0)))
                     throw Error{E_ARG, "a lean tile record names another read"};
