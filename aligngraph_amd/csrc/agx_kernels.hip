@@ -18,7 +18,8 @@
 static_assert(AGX_MAXV_LDS <= AGX_EM_W && AGX_MAXV_MID <= AGX_EM_W, "the LDS sweep writes the x -> x+1 edges of every position it finishes: its buckets must fit the edge matrix");
 #define AGX_XCDS 8u                 // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
 #ifndef AGX_SWEEP_WAVES
-#define AGX_SWEEP_WAVES 4           // wavefronts (= consecutive tiles) per block of the node sweep: measured 0.655 / 0.656 / 0.640 / 0.779 / 0.706 ms for 1 / 2 / 4 / 6 / 8
+#define AGX_SWEEP_WAVES 1           // wavefronts (= consecutive tiles) per block of the node sweep.  r02 measured 0.655 / 0.656 / 0.640 / 0.779 / 0.706 ms for 1 / 2 / 4 / 6 / 8 and kept 4; r06's loop: 2.36 / 2.42 / 2.44 / - / 2.80 ms
+                                    // on the 30 Mb unit — a block's LDS is free again when its LAST tile is done, and the tiles' lists differ in length
 #endif
 
 // A build queues all its kernels before the host has seen a single counter.  If the node sweeps had to give up (node pool or tile lists too
