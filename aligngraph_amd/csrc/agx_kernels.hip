@@ -480,8 +480,17 @@ struct agx_tile_recs {
 };
 
 // ---- node sweep ------------------------------------------------------------------------------------------------------
+// inclusive scan over the wavefront by DPP moves: inside every row of 16 lanes by shifts of 1, 2, 4, 8 (a lane the shift would fetch from outside its row reads 0), then the
+// last lane of row 0 / row 2 added to all of row 1 / row 3 (row_bcast:15 on rows 1 and 3) and lane 31 to rows 2 and 3 (row_bcast:31).  Twelve vector instructions and no LDS
+// round trip (r02-r05: six ds_bpermute_b32, each waited for — twice per tile, in the write-out where a wavefront has nothing else to do)
 __device__ __forceinline__ agx_u32 agx_wave_incl_scan(agx_u32 v, agx_u32 lane) {
-    for (agx_u32 off = 1; off < 64; off <<= 1) { const agx_u32 t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
+    (void)lane;
+    v += (agx_u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);      // row_shr:1
+    v += (agx_u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);      // row_shr:2
+    v += (agx_u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);      // row_shr:4
+    v += (agx_u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);      // row_shr:8
+    v += (agx_u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1 and 3
+    v += (agx_u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2 and 3
     return v;
 }
 
@@ -712,7 +721,7 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
             if (PASS != 0) continue; else return;
         }
         const agx_u32 incl = agx_wave_incl_scan(cnt, lane);
-        const agx_u32 total = __shfl(incl, 63, 64);
+        const agx_u32 total = (agx_u32)__builtin_amdgcn_readlane((int)incl, 63);
         agx_u32 base = 0;
         // Node ids come from the slice of the pool that belongs to this tile's region, through the region's own counter: a single
         // counter for the whole unit is one address that every tile's returning device-scope atomic has to queue for (measured: 0.2 ms
@@ -729,10 +738,11 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
                 base = sp + total <= K.S.pool_cap ? (agx_u32)sp : AGX_NONE;
             }
         }
-        base = (agx_u32)__shfl(base, 0, 64);
+        base = (agx_u32)__builtin_amdgcn_readfirstlane((int)base);
         if (base == AGX_NONE) { if (lane == 0) atomicOr(K.status, 1u); if (PASS != 0) continue; else return; }
         const agx_u32 my_base = base + incl - cnt;
-        const agx_u32 nbase = (agx_u32)__shfl_down((int)my_base, 1, 64), ncnt = (agx_u32)__shfl_down((int)cnt, 1, 64);
+        // (the right neighbour's values by a DPP move, wave_shl:1; lane 63 reads 0 and does not use it)
+        const agx_u32 nbase = (agx_u32)__builtin_amdgcn_update_dpp(0, (int)my_base, 0x130, 0xF, 0xF, true), ncnt = (agx_u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x130, 0xF, 0xF, true);
         agx_bucket bn = b; bn.base = b.base + 1;           // the next position's bucket is the next lane's column
         const bool edges = !BIG && lane < 63u && X + 1 < K.S.n_pos && cnt <= AGX_EM_W && ncnt <= AGX_EM_W;
         const agx_u32 side = agx_node_write_lane(K.S, X, b, cnt, my_base, pflag, edges, emask, bn, nbase, ncnt);
