@@ -152,8 +152,13 @@ AGX_HD agx_u32 agx_uload(const agx_u32 *p, size_t i) { return p[i]; }
 #endif
 
 // A bucket view: base points at this lane's column; element (variant v, field f) is base[(v*AGX_NF+f)*stride]
-struct agx_bucket { agx_u32 *base; agx_u32 stride; agx_u32 maxv; };
-AGX_HD agx_u32 &agx_b(const agx_bucket &b, agx_u32 v, agx_u32 f) { return b.base[(v * AGX_NF + f) * b.stride]; }
+// packed (r06, pass 0 of the device's node sweep only): the six counters of a variant — coverage and the five votes — as 16-bit halves of three words, a variant = AGX_NFP words instead
+// of AGX_NF: 5 KB of LDS per wavefront instead of 6.5, eight wavefronts per SIMD instead of six.  A list of more than 65 535 entries (no counter can pass 16 bits below that)
+// leaves the tile to the next pass, whose buckets are not packed.  Counters are only reached through agx_cnt_*; agx_b serves the other fields in both layouts.
+struct agx_bucket { agx_u32 *base; agx_u32 stride; agx_u32 maxv; agx_u32 packed; };
+#define AGX_NFP 10u
+AGX_HD agx_u32 &agx_b(const agx_bucket &b, agx_u32 v, agx_u32 f) { return b.base[(b.packed ? v * AGX_NFP + (f >= (agx_u32)AGX_F_S0 ? f - 3u : f) : v * AGX_NF + f) * b.stride]; }
+AGX_HD agx_u32 &agx_cnt_word(const agx_bucket &b, agx_u32 v, agx_u32 f) { return b.base[(v * AGX_NFP + (agx_u32)AGX_F_COV + ((f - (agx_u32)AGX_F_COV) >> 1)) * b.stride]; }      // (packed layout: the word that holds counter f)
 // counter update of a bucket word.  In the LDS node sweep it is a wave-private LDS add (one ds_add_u32 instead of
 // read / wait / add / write); everywhere else it is the plain read-modify-write.
 template <bool LDS_ADD> AGX_HD void agx_bucket_add(agx_u32 &ref, agx_u32 val) {
@@ -161,6 +166,19 @@ template <bool LDS_ADD> AGX_HD void agx_bucket_add(agx_u32 &ref, agx_u32 val) {
     if (LDS_ADD) { (void)__hip_atomic_fetch_add(&ref, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); return; }
 #endif
     ref += val;
+}
+AGX_HD agx_u32 agx_cnt_get(const agx_bucket &b, agx_u32 v, agx_u32 f) {
+    if (b.packed) return (agx_cnt_word(b, v, f) >> (16u * ((f - (agx_u32)AGX_F_COV) & 1u))) & 0xFFFFu;
+    return agx_b(b, v, f);
+}
+template <bool LDS_ADD> AGX_HD void agx_cnt_add(const agx_bucket &b, agx_u32 v, agx_u32 f, agx_u32 val) {
+    if (b.packed) agx_bucket_add<LDS_ADD>(agx_cnt_word(b, v, f), val << (16u * ((f - (agx_u32)AGX_F_COV) & 1u)));
+    else agx_bucket_add<LDS_ADD>(agx_b(b, v, f), val);
+}
+// a new variant's counters: coverage cov, no votes
+AGX_HD void agx_cnt_init(const agx_bucket &b, agx_u32 v, agx_u32 cov) {
+    if (b.packed) { agx_cnt_word(b, v, AGX_F_COV) = cov; agx_cnt_word(b, v, AGX_F_C) = 0; agx_cnt_word(b, v, AGX_F_T) = 0; }
+    else { agx_b(b, v, AGX_F_COV) = cov; agx_b(b, v, AGX_F_A) = 0; agx_b(b, v, AGX_F_C) = 0; agx_b(b, v, AGX_F_G) = 0; agx_b(b, v, AGX_F_T) = 0; agx_b(b, v, AGX_F_N) = 0; }
 }
 
 AGX_HD bool agx_compatible(const agx_key &k, const agx_bucket &b, agx_u32 v, int iv) {
@@ -799,12 +817,11 @@ AGX_HD agx_u32 agx_match_or_insert(const agx_bucket &b, agx_u32 &cnt, const agx_
     if (v == cnt) {
         if (cnt == b.maxv) return AGX_NONE;
         agx_b(b, v, AGX_F_CID) = key.cid; agx_b(b, v, AGX_F_COFF) = key.coff; agx_b(b, v, AGX_F_CID0) = key.cid0; agx_b(b, v, AGX_F_COFF0) = key.coff0;
-        agx_b(b, v, AGX_F_OFF0) = key.off0; agx_b(b, v, AGX_F_COV) = 0;
-        agx_b(b, v, AGX_F_A) = 0; agx_b(b, v, AGX_F_C) = 0; agx_b(b, v, AGX_F_G) = 0; agx_b(b, v, AGX_F_T) = 0; agx_b(b, v, AGX_F_N) = 0;
+        agx_b(b, v, AGX_F_OFF0) = key.off0; agx_cnt_init(b, v, 0u);
         agx_b(b, v, AGX_F_S0) = s0; agx_b(b, v, AGX_F_S1) = s1;
         cnt++;
     }
-    if (is_k1) agx_b(b, v, AGX_F_COV) += 1;
+    if (is_k1) agx_cnt_add<false>(b, v, AGX_F_COV, 1u);
     return v;
 }
 
@@ -875,10 +892,9 @@ AGX_HD void agx_arrival_slow(const agx_sweep_args &A, const agx_bucket &b, agx_u
         // The first arrival at a position with one candidate key — most of what leaves the fast path (7 % of the list entries on the
         // bench unit create a variant somewhere) — stores variant 0 without the general path's loops over candidates and variants.
         agx_b(b, 0, AGX_F_CID) = cx0.cid; agx_b(b, 0, AGX_F_COFF) = cx0.coff; agx_b(b, 0, AGX_F_CID0) = c0k.cid; agx_b(b, 0, AGX_F_COFF0) = c0k.coff;
-        agx_b(b, 0, AGX_F_OFF0) = p0; agx_b(b, 0, AGX_F_COV) = is_k1;
-        agx_b(b, 0, AGX_F_A) = 0; agx_b(b, 0, AGX_F_C) = 0; agx_b(b, 0, AGX_F_G) = 0; agx_b(b, 0, AGX_F_T) = 0; agx_b(b, 0, AGX_F_N) = 0;
+        agx_b(b, 0, AGX_F_OFF0) = p0; agx_cnt_init(b, 0, is_k1);
         agx_b(b, 0, AGX_F_S0) = s0; agx_b(b, 0, AGX_F_S1) = s1;
-        if (votes) agx_b(b, 0, vfield) = 1;
+        if (votes) agx_cnt_add<false>(b, 0, vfield, 1u);
         cnt = 1; vm = 1u; sp = step1;
         v0_ok = 1u; v0_c0 = c0k.cid; v0_o0 = c0k.coff; v0_m = p0;
         return;
@@ -896,7 +912,7 @@ AGX_HD void agx_arrival_slow(const agx_sweep_args &A, const agx_bucket &b, agx_u
                 const agx_u32 v = agx_match_or_insert(b, cnt, key, A.iv, is_k1 != 0, s0, s1);
                 if (v == AGX_NONE) { ok = false; break; }
                 vm |= 1u << (v & 31u);
-                if (vf != AGX_NF) agx_b(b, v, vf) += 1;
+                if (vf != AGX_NF) agx_cnt_add<false>(b, v, vf, 1u);
             }
         }
     }
@@ -939,8 +955,8 @@ AGX_HD bool agx_node_sweep_lane(const agx_sweep_args &A, agx_u32 tile, agx_u32 X
         const agx_u32 compat = agx_clause_ab(c0k.cid, c0k.coff, v0_c0, v0_o0, 2 * A.iv + AGX_EP25) & agx_clause_c(p.p0, v0_m, 2 * A.iv + AGX_EP25);
         const agx_u32 fast = has & v0_ok & compat & (agx_u32)(c0_n <= 1);
         const agx_u32 vote = fast & votes;
-        agx_bucket_add<LDS_ADD>(agx_b(b, 0, AGX_F_COV), fast & is_k1);
-        agx_bucket_add<LDS_ADD>(agx_b(b, 0, vote ? vfield : (agx_u32)AGX_F_COV), vote);
+        agx_cnt_add<LDS_ADD>(b, 0, AGX_F_COV, fast & is_k1);
+        agx_cnt_add<LDS_ADD>(b, 0, vote ? vfield : (agx_u32)AGX_F_COV, vote);
         agx_u32 vm = fast, sp = fast & p.step1;                                     // the straight-line case touches variant 0
         AGX_STAT(A, 0, true); AGX_STAT(A, 2, has != 0); AGX_STAT(A, 4, (has & (fast ^ 1u)) != 0);
         AGX_STAT(A, 6, (has & (fast ^ 1u)) != 0 && !(cnt == 0 && cx_n <= 1 && c0_n <= 1));
@@ -992,11 +1008,11 @@ AGX_HD agx_u32 agx_node_write_lane(const agx_sweep_args &A, agx_u32 X, const agx
     agx_u32 alive = 0;
     for (agx_u32 v = 0; v < cnt; v++) {
         const agx_u32 id = base + v;
-        const agx_u32 cid = agx_b(b, v, AGX_F_CID), coff = agx_b(b, v, AGX_F_COFF), cov = agx_b(b, v, AGX_F_COV);
+        const agx_u32 cid = agx_b(b, v, AGX_F_CID), coff = agx_b(b, v, AGX_F_COFF), cov = agx_cnt_get(b, v, AGX_F_COV);
         const agx_u32 cid0 = agx_b(b, v, AGX_F_CID0), coff0 = agx_b(b, v, AGX_F_COFF0);
         A.nk_cid[id] = cid; A.nk_coff[id] = coff; A.nk_cid0[id] = cid0; A.nk_coff0[id] = coff0;
         A.nk_off0[id] = agx_b(b, v, AGX_F_OFF0);      // (r06: no per-node position array — a node's position is its walk id's: the id itself, or side_xpos — 4 bytes per node less to write)
-        const agx_u32 va = agx_b(b, v, AGX_F_A), vc = agx_b(b, v, AGX_F_C), vg = agx_b(b, v, AGX_F_G), vt = agx_b(b, v, AGX_F_T), vn = agx_b(b, v, AGX_F_N);
+        const agx_u32 va = agx_cnt_get(b, v, AGX_F_A), vc = agx_cnt_get(b, v, AGX_F_C), vg = agx_cnt_get(b, v, AGX_F_G), vt = agx_cnt_get(b, v, AGX_F_T), vn = agx_cnt_get(b, v, AGX_F_N);
         A.n_base[id] = (agx_u8)agx_consensus(va, vc, vg, vt, vn);
         agx_u8 fl = 0;
         if (cid == AGX_NONE && (int)cov < A.coverage) fl |= AGX_NF_DEAD; else alive++;

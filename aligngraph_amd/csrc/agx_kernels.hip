@@ -527,7 +527,7 @@ struct agx_slow_io { agx_u32 cnt, ok, v0_ok, v0_c0, v0_o0, v0_m, vm, sp; };
 __device__ __noinline__ agx_slow_io agx_lean_slow(__attribute__((address_space(3))) agx_u32 *lds_col, const agx_cmkey *cm, int iv, agx_slow_io io, agx_u32 cx_s, agx_u32 cx_n, agx_u32 cx0_cid, agx_u32 cx0_coff,
                                                   agx_u32 p0, agx_u32 h_cid, agx_u32 h_coff, agx_u32 h_n, agx_u32 h_start, agx_u32 s0, agx_u32 s1, agx_u32 flags, agx_u32 vfield) {
     agx_sweep_args R{}; R.cm = cm; R.iv = iv;
-    agx_bucket b; b.base = (agx_u32 *)lds_col; b.stride = 64; b.maxv = AGX_MAXV_LDS;
+    agx_bucket b; b.base = (agx_u32 *)lds_col; b.stride = 64; b.maxv = AGX_MAXV_LDS; b.packed = 1u;
     bool ok = io.ok != 0;
     agx_arrival_slow(R, b, io.cnt, ok, cx_s, cx_n, agx_cmkey{cx0_cid, cx0_coff}, p0, h_start, h_n, agx_cmkey{h_cid, h_coff}, s0, s1, flags & 1u, (flags >> 1) & 1u, vfield, (flags >> 2) & 1u,
                      io.v0_ok, io.v0_c0, io.v0_o0, io.v0_m, io.vm, io.sp);
@@ -544,6 +544,7 @@ __device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx
     bool ok = true;
     const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
     if (lo == hi) return true;
+    if (hi - lo > 65535u) return false;                             // (packed buckets count to 65 535: the next pass takes the tile)
     const agx_u32 W = (agx_u32)(2 * A.iv + AGX_EP25), W2 = 2u * W;      // |a - b| <= W  <=>  (u32)(a - (b - W)) <= 2 W
     const agx_cmhead *cm_head = A.cm_head; const agx_u8 *vcodes = A.vcodes; const agx_u32 n_pos = A.n_pos, stride = A.stride;
     const GET recs = get;
@@ -556,10 +557,11 @@ __device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx
     // the straight-line case's votes for variant 0: A, C, G, T, N in 6 bits each (the arrivals that take it count AND vote: coverage = the sum)
     agx_u32 acc = 0;
     auto flush = [&]() {
-        agx_u32 total = 0;
-#pragma unroll
-        for (agx_u32 f = 0; f < 5u; f++) { const agx_u32 c = (acc >> (6u * f)) & 63u; total += c; agx_bucket_add<true>(agx_b(b, 0, (agx_u32)AGX_F_A + f), c); }
-        agx_bucket_add<true>(agx_b(b, 0, AGX_F_COV), total);
+        // (the bucket's counters are 16-bit halves of three words — coverage | A, C | G, T | N: three adds)
+        const agx_u32 ca = acc & 63u, cc = (acc >> 6) & 63u, cg = (acc >> 12) & 63u, ct = (acc >> 18) & 63u, cn = (acc >> 24) & 63u;
+        agx_bucket_add<true>(agx_cnt_word(b, 0, AGX_F_COV), (ca + cc + cg + ct + cn) | (ca << 16));
+        agx_bucket_add<true>(agx_cnt_word(b, 0, AGX_F_C), cc | (cg << 16));
+        agx_bucket_add<true>(agx_cnt_word(b, 0, AGX_F_T), ct | (cn << 16));
         acc = 0;
     };
 
@@ -639,10 +641,9 @@ __device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx
                     // the first arrival at a position with one candidate key (five in six of what gets here) stores variant 0 on the spot: agx_arrival_slow's first arm, written out
                     // so that only what is left pays for a call
                     agx_b(b, 0, AGX_F_CID) = cx0.cid; agx_b(b, 0, AGX_F_COFF) = cx0.coff; agx_b(b, 0, AGX_F_CID0) = P.h.cid; agx_b(b, 0, AGX_F_COFF0) = P.h.coff;
-                    agx_b(b, 0, AGX_F_OFF0) = P.p0; agx_b(b, 0, AGX_F_COV) = is_k1;
-                    agx_b(b, 0, AGX_F_A) = 0; agx_b(b, 0, AGX_F_C) = 0; agx_b(b, 0, AGX_F_G) = 0; agx_b(b, 0, AGX_F_T) = 0; agx_b(b, 0, AGX_F_N) = 0;
+                    agx_b(b, 0, AGX_F_OFF0) = P.p0; agx_cnt_init(b, 0, is_k1);
                     agx_b(b, 0, AGX_F_S0) = P.slot; agx_b(b, 0, AGX_F_S1) = s1;
-                    if (vt) agx_b(b, 0, vfield) = 1;
+                    if (vt) agx_cnt_add<false>(b, 0, vfield, 1u);
                     cnt = 1; vm = 1u; sp = st1;
                     v0_ok = 1u; v0_c0 = P.h.cid; v0_o0 = P.h.coff; v0_m = P.p0;
                 } else {
@@ -679,11 +680,17 @@ __device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx
 
 template <int PASS>      // 0: every tile, AGX_MAXV_LDS variants in LDS; 1: the tiles pass 0 gave up on, AGX_MAXV_MID in LDS; 2: the rest, AGX_MAXV_BIG in global scratch;
                          // 3: what even that cannot hold, AGX_MAXV_HUGE in global scratch (only queued for units that need it)
-__global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_node_kargs K) {
+// wavefronts per SIMD the compiler fits the kernel's registers to: pass 0 holds 5 KB of LDS per wavefront (packed buckets) — eight fit a CU's 160 KB four times over — and wants 77 VGPRs:
+// six.  At seven (72 VGPRs, a 16-byte spill in front of the loop and behind the slow path's call) 2.10 against 2.14 ms; at eight (64) spills in the loop, 2.35
+#ifndef AGX_SWEEP_EU
+#define AGX_SWEEP_EU 7
+#endif
+__global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) __attribute__((amdgpu_waves_per_eu(PASS == 0 ? AGX_SWEEP_EU : 1))) agx_k_node_sweep(agx_node_kargs K) {
     constexpr bool BIG = PASS >= 2;
     constexpr agx_u32 MAXV_G = PASS == 3 ? AGX_MAXV_HUGE : AGX_MAXV_BIG;
     constexpr agx_u32 MAXV = PASS == 0 ? AGX_MAXV_LDS : AGX_MAXV_MID;
-    __shared__ agx_u32 lds[BIG ? 1 : AGX_SWEEP_WAVES][BIG ? 1 : AGX_NF * MAXV * 64];
+    constexpr bool PACKED = PASS == 0 && AGX_SWEEP_LEAN;          // (agx_bucket: pass 0's counters as 16-bit halves)
+    __shared__ agx_u32 lds[BIG ? 1 : AGX_SWEEP_WAVES][BIG ? 1 : (PACKED ? AGX_NFP : (agx_u32)AGX_NF) * MAXV * 64];
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     if (PASS == 0 && (agx_uload(K.status, 0) & 16u)) return;      // the tile lists were not made (a unit whose long hits need the scatter fallback, which was not queued): the host repeats the build with it
     // Workgroups are handed to the 8 XCDs round-robin and every XCD has its own L2.  Neighbouring tiles read the same hit records, read
@@ -692,7 +699,7 @@ __global__ void __launch_bounds__(64 * AGX_SWEEP_WAVES) agx_k_node_sweep(agx_nod
     agx_u32 blk = blockIdx.x;
     if (PASS == 0) { const agx_u32 share = (gridDim.x + AGX_XCDS - 1) / AGX_XCDS; blk = (blockIdx.x % AGX_XCDS) * share + blockIdx.x / AGX_XCDS; }
     const agx_u32 slot = __builtin_amdgcn_readfirstlane(blk * AGX_SWEEP_WAVES + wave);
-    agx_bucket b; b.stride = 64;
+    agx_bucket b; b.stride = 64; b.packed = PACKED ? 1u : 0u;
     if (BIG) { b.base = (PASS == 3 ? K.scratch_huge : K.scratch) + (size_t)slot * (AGX_NF * MAXV_G * 64) + lane; b.maxv = MAXV_G; }
     else { b.base = &lds[wave][lane]; b.maxv = MAXV; }
     // pass 0: one tile per wavefront.  Passes 1 and 2: a fixed set of wavefronts strides over the list of overflowed tiles.

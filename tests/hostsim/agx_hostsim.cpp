@@ -165,7 +165,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
         // what every lane hands to its left neighbour per hit (the kernel does it with a wave shuffle inside the sweep's loop)
         struct Touch { agx_u32 vm, sp; };
         std::vector<Touch> touched[AGX_TILE];
-        agx_bucket b{nullptr, AGX_TILE, maxv_first};
+        agx_bucket b{nullptr, AGX_TILE, maxv_first, 0u};
         for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
             b.base = lds.data() + lane;
             ok &= agx_node_sweep_lane<false>(A, t, t * AGX_TILE + lane, b, cnt[lane], pflag[lane], get, [&](agx_u32 vm, agx_u32 sp) { touched[lane].push_back(Touch{vm, sp}); });
@@ -174,7 +174,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
         if (!ok) {                                     // the fallback the engine runs for overflowed tiles
             n_big_tiles++;
             big.assign((size_t)AGX_NF * AGX_MAXV_HUGE * AGX_TILE, 0); store = big.data(); maxv = AGX_MAXV_HUGE;      // (the engine: 4, then 64, then 1024 variants)
-            agx_bucket bb{nullptr, AGX_TILE, maxv};
+            agx_bucket bb{nullptr, AGX_TILE, maxv, 0u};
             for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
                 bb.base = store + lane;
                 if (!agx_node_sweep_lane<false>(A, t, t * AGX_TILE + lane, bb, cnt[lane], pflag[lane], get, [](agx_u32, agx_u32) {})) throw Error{E_OVERFLOW, "more than 1024 node variants at one position"};
@@ -182,7 +182,7 @@ void simulate(const Threads &T, const Pairs &P, agx_u32 k, int iv, int coverage,
         }
         agx_u32 total = 0; for (agx_u32 lane = 0; lane < AGX_TILE; lane++) total += cnt[lane];
         if (pool + total > S.cid.size()) { S.reserve((pool + total) * 2); bind(); }
-        agx_bucket wb{nullptr, AGX_TILE, maxv}, wn{nullptr, AGX_TILE, maxv};
+        agx_bucket wb{nullptr, AGX_TILE, maxv, 0u}, wn{nullptr, AGX_TILE, maxv, 0u};
         agx_u32 side_before = 0;                       // the kernel's wave scan
         for (agx_u32 lane = 0; lane < AGX_TILE; lane++) {
             const agx_u32 X = t * AGX_TILE + lane;
