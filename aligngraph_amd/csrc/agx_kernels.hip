@@ -539,8 +539,6 @@ __device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx
     cnt = 0; pflag = 0;
     const bool live = X < A.n_pos;
     const agx_u32 lane = X & (AGX_TILE - 1u);
-    agx_u32 cx_s = 0, cx_n = 0; agx_cmkey cx0 = agx_cmkey{AGX_NONE, AGX_NONE};
-    if (live) { const agx_cmhead h = A.cm_head[X]; cx_s = h.start; cx_n = h.n; cx0 = agx_cmkey{h.cid, h.coff}; }
     bool ok = true;
     const agx_u32 lo = A.tile_off[tile], hi = A.tile_off[tile + 1];
     if (lo == hi) return true;
@@ -551,7 +549,7 @@ __device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx
     // variant 0's mate-side key as the shared function keeps it (v0_*), and in the form the tests below want it: offsets with the window subtracted, the window of the mate
     // position's clause per lane (everything passes where variant 0 has no mate position), the contig id with "none" replaced by an id no contig has (clause A/B passes when
     // the arrival's id is none OR differs from variant 0's: with that replacement the second test covers the first)
-    agx_u32 v0_ok = 0, v0_c0 = AGX_NONE, v0_o0 = AGX_NONE, v0_m = AGX_NONE;
+    // (ONLY in that form across the loop — the shared function's form is made from it where the slow path needs it: four registers less, which is what seven wavefronts per SIMD take)
     agx_u32 v0_c0x = AGX_NONE - 1u, v0_o0w = AGX_NONE - W, v0_mw = AGX_NONE - W, v0_mwin = AGX_NONE;
     agx_m64 m_v0ok = 0, m_pf1 = 0, m_e0 = 0;
     // the straight-line case's votes for variant 0: A, C, G, T, N in 6 bits each (the arrivals that take it count AND vote: coverage = the sum)
@@ -628,7 +626,13 @@ __device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx
         const agx_m64 slowm = P.has & ~fast;
         if (slowm != 0) {                                            // wave-uniform
             agx_u32 vm = AGX_INV(fast) ? 1u : 0u, sp = one;
+            agx_u32 v0_ok = AGX_INV(m_v0ok) ? 1u : 0u, v0_c0 = v0_c0x == AGX_NONE - 1u ? AGX_NONE : v0_c0x, v0_o0 = v0_o0w + W, v0_m = v0_mw + W;
             if (AGX_INV(slowm)) {
+                // the position's own conti-mers, fetched HERE (the index made opaque so that the load stays in this arm): four registers that only this arm reads would otherwise live
+                // across the whole loop — and, at seven wavefronts per SIMD, in scratch memory: a 1 KB store per tile
+                agx_u32 Xh = live ? X : n_pos; asm volatile("" : "+v"(Xh));
+                const agx_cmhead hx = cm_head[Xh];
+                const agx_u32 cx_s = hx.start, cx_n = hx.n; const agx_cmkey cx0 = agx_cmkey{hx.cid, hx.coff};
                 const agx_u32 is_k1 = AGX_INV(P.k1) ? 1u : 0u, L = P.lenjs & 0xFFFFu, rev = (P.geo >> 24) & 1u;
                 agx_u32 s1 = P.sq, vt = is_k1, st1 = is_k1 & ~(P.fl >> 1);      // (a lean record's lane: a K1 arrival votes, and steps to position + 1 unless it jumps)
                 if ((P.geo >> 30) == AGX_LK_GENERAL) { vt = (is_k1 && ((P.sq >> 16) & 0x7FFFu) != 0) ? 1u : 0u; st1 = P.fl & 1u; }      // general record: a CHAIN arrival counts and does not vote (its k-mer is empty)
