@@ -459,6 +459,21 @@ def test_positions_beyond_64_variants_take_the_last_pass(agx, built, tmp_path, n
     assert g["stats"]["build_attempts"] == 2 and g["stats"]["n_big_tiles"] >= 1
 
 
+def test_a_list_longer_than_the_packed_counters_hold(agx, built, tmp_path):
+    """r06: pass 0 of the node sweep keeps a variant's six counters as 16-bit halves (agx_bucket::packed), so a tile whose list holds more than 65 535 entries must be left to
+    pass 1, whose buckets are not packed.  70 000 pairs with ONE alignment: every position of the left mate counts 70 000 arrivals of the same variant; counters, node and
+    edge tables and the three outputs against the oracle."""
+    from conftest import write_pileup_unit
+    tmp = write_pileup_unit(str(tmp_path / "run"), 70000, spacing=0, genome_len=60000)
+    o = H.run_oracle(tmp, 0, 5, 50, 1, graph=True)
+    g = run_engine(agx, tmp, 0, 5, 50, 1, graph=True)
+    assert int(o["graph"]["node_cnt"].max()) > 65535
+    assert graph_mismatch(o["graph"], g["graph"]) is None
+    for key in ("initial", "pre", "extended"):
+        assert o[key] == g[key], key
+    assert g["stats"]["n_mid_tiles"] >= 1
+
+
 @pytest.mark.parametrize("n_pairs,mode", [(400, 1), (6000, 2)])
 def test_hits_that_span_more_tiles_than_the_window(agx, built, tmp_path, n_pairs, mode):
     """r05: a tile's list is a filter over a window of the hits' tile order (agx_k_tile_fill); hits that reach further than the window looks back (here: 60-base deletions in
