@@ -329,11 +329,6 @@ __device__ __forceinline__ void agx_tile_fill_general(const agx_fill_args &A, ag
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (the wavefront's next tile uses the same LDS)
 }
-// the node sweep reads two records beyond a list's end (masked out): behind the LAST list they are these — kind GENERAL of hit 0, which decodes like any other record
-__device__ __forceinline__ void agx_zero_slack(const agx_fill_args &A, agx_u32 lane) {
-    const agx_u32 total = agx_uload(A.tile_off, A.n_tiles);
-    if (total <= A.cap && lane < 8u) ((uint4 *)A.recs)[2 * (size_t)total + lane] = make_uint4(0u, 0u, 0u, 0u);      // (the lists' buffer holds cap + 4 records)
-}
 #ifndef AGX_FILL_TILES
 #define AGX_FILL_TILES 2u      // tiles per wavefront
 #endif
@@ -344,7 +339,6 @@ __global__ void __launch_bounds__(256) agx_k_tile_fill(agx_fill_args A) {
     const agx_u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const agx_u32 t_first = __builtin_amdgcn_readfirstlane((blockIdx.x * AGX_WAVES_PER_BLOCK + wave) * AGX_FILL_TILES);
     if (t_first >= A.n_tiles) return;
-    if (t_first == 0) agx_zero_slack(A, lane);
     const agx_u32 n_long = __builtin_amdgcn_readfirstlane((int)*A.long_count);
     if (n_long > AGX_LONG_MAX) {                         // the fallback makes this unit's lists (agx_k_bin_fill, agx_k_tile_sort) — if it is queued; else nothing behind this kernel may run, and the host repeats the build with it
         if (!A.dense_queued && t_first == 0 && lane == 0) atomicOr(A.status, 16u);
@@ -661,17 +655,18 @@ __device__ __forceinline__ bool agx_sweep_tile_lean(const agx_sweep_args &A, agx
             agx_edge_merge(emask, sp, (agx_u32)__builtin_amdgcn_update_dpp(0, (int)vm, 0x130, 0xF, 0xF, true));
         }
     };
-    // entries lo .. hi - 1, two buffers, each refilled for the entry two places ahead as soon as it has been applied (agx_node_sweep_lane).  Entries at and beyond hi are read
-    // like the others and masked out: they are the next tile's records, or the zeroed records agx_k_tile_fill leaves behind the last list (kind GENERAL of hit 0: decodable)
+    // entries lo .. hi - 1, two buffers, each refilled for the entry two places ahead as soon as it has been applied (agx_node_sweep_lane).  An index at or beyond hi reads
+    // the list's LAST record again and is masked out (what lies behind a list need not be a record at all: the next tile's list may not have fitted the lists' capacity)
+    const agx_u32 last = hi - 1u;
     agx_lbuf pa, pb;
     { const agx_lrec d0 = recs.lean(lo); fetch(d0, true, pa); }
-    { const agx_lrec d1 = recs.lean(lo + 1); fetch(d1, lo + 1 < hi, pb); }
+    { const agx_lrec d1 = recs.lean(min(lo + 1u, last)); fetch(d1, lo + 1 < hi, pb); }
     for (agx_u32 c = lo; c < hi; ) {                                // (62 entries at a time: the register counters hold 63)
         const agx_u32 ce = hi - c > 62u ? c + 62u : hi;
         for (agx_u32 i = c; i < ce; i += 2) {
-            const agx_lrec da = recs.lean(i + 2);
+            const agx_lrec da = recs.lean(min(i + 2u, last));
             apply(pa); fetch(da, i + 2 < hi, pa);
-            const agx_lrec db = recs.lean(i + 3);
+            const agx_lrec db = recs.lean(min(i + 3u, last));
             apply(pb); fetch(db, i + 3 < hi, pb);
         }
         flush();
