@@ -395,21 +395,8 @@ AGX_HD agx_dhit agx_tile_record(const agx_dhit &d, const agx_run *runs, agx_u32 
     if (agx_tile_piece(d, runs, tile, k, a_t0, b_t0, a_runs, bnone)) { p.a_t0 = a_t0; p.b_t0 = b_t0; p.a_runs = a_runs; p.b_runs = 0; p.a_nruns = p.b_nruns = 0; if (bnone) p.flags |= AGX_HF_BNONE; }
     return p;
 }
-// the two 16-byte halves of the 32-byte record agx_k_tile_fill / agx_k_tile_sort write for hit record d in the list of `tile` (what agx_tile_recs reads back)
-#if defined(__HIPCC__)
-// w0 .. w4: the record as its five 8-byte words (a_t0, b_t0 | a_runs, b_runs | a_slot, len + jstar | a_nruns + b_nruns, flags | x_lo, x_hi)
-AGX_HD void agx_tile_record_words_v(uint2 w0, uint2 w1, uint2 w2, uint2 w3, uint2 w4, const agx_run *runs, agx_u32 tile, agx_u32 k, uint4 &lo, uint4 &hi) {
-    agx_u32 a_t0, b_t0, a_runs; bool bnone;
-    const bool piece = agx_tile_piece_v(w0.x, w0.y, w1.x, w1.y, w2.y & 0xFFFFu, w2.y >> 16, w3.x & 0xFFFFu, w3.x >> 16, w3.y, w4.x, w4.y, runs, tile, k, a_t0, b_t0, a_runs, bnone);
-    lo = make_uint4(piece ? a_t0 : w0.x, piece ? b_t0 : w0.y, piece ? a_runs : w1.x, piece ? 0u : w1.y);
-    hi = make_uint4(w2.x, w2.y, piece ? 0u : w3.x, w3.y | ((piece && bnone) ? (agx_u32)AGX_HF_BNONE : 0u));
-}
-AGX_HD void agx_tile_record_words(const agx_dhit &d, const agx_run *runs, agx_u32 tile, agx_u32 k, uint4 &lo, uint4 &hi) {
-    static_assert(sizeof(agx_dhit) == 40, "a derived record is five 8-byte words");
-    const uint2 *w = reinterpret_cast<const uint2 *>(&d);
-    agx_tile_record_words_v(w[0], w[1], w[2], w[3], w[4], runs, tile, k, lo, hi);
-}
-#endif
+// (r05's 32-byte tile records were agx_tile_record() as two 16-byte halves; r06's tile lists hold lean records — below.  agx_tile_record() stays: the test executor sweeps with it and
+// checks that a piece decodes like the hit.)
 
 // ---- lean tile records (r06): what pass 0 of the node sweep reads per list entry ----------------------------------------------------------------
 // 32 bytes that describe a hit's arrivals INSIDE ONE TILE as one or two runs of lanes, each with its own pair of offsets: on lane l of a piece the arrival's read index
