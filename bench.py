@@ -308,7 +308,7 @@ def main():
     if rank == 0 and not os.path.exists(stamp):
         import shutil
         os.makedirs(args.workdir, exist_ok=True)
-        wanted = 68e9 if args.config in STAGED else pairs * (2.0 * (L + 12) + 2.0 * ((2 * L + 110) if sam_seq else 55) + 60) + 3.2 * sum(chroms)      # bytes about to be written (inputs + unit caches)
+        wanted = (68e9 * (1.3 * sum(chroms[int(uu)] for uu in only["only_units"].split(",")) / sum(chroms) if only else 1.0)) if args.config in STAGED else pairs * (2.0 * (L + 12) + 2.0 * ((2 * L + 110) if sam_seq else 55) + 60) + 3.2 * sum(chroms)      # bytes about to be written (inputs + unit caches)
         if shutil.disk_usage(args.workdir).free < 1.15 * wanted:      # what OTHER configurations of this script left here (the whole-human inputs are kept between runs) goes first:
             for other in os.listdir(args.workdir):                    # only directories that carry the generator's stamp (tools/agx_synth.cpp writes synth_meta.txt last), are not
                 d = os.path.join(args.workdir, other)                  # in use (a run holds <dir>/.in_use while it reads its inputs) — never anything else a --workdir may hold
