@@ -613,6 +613,7 @@ def main():
         up_bytes = sum(unit_stats[uu]["upload_bytes"] for uu in mine)
         down_bytes = sum(unit_stats[uu]["download_bytes"] for uu in mine)
         traffic = hbm_rate = None
+        issue = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
@@ -622,6 +623,13 @@ def main():
                 if per_entry:
                     traffic = int(per_entry * entries)
                     hbm_rate = traffic / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else None
+                ins = tab.get("node_sweep_insts_per_tile_entry_by_config", {}).get(args.config)
+                if ins and sw_ms > 0:
+                    # the roof the sweep is under: a SIMD issues one vector instruction of a wave64 every 4 cycles, a CU's scalar unit one instruction per cycle (MI355X: 256 CUs x 4 SIMDs, 2.4 GHz)
+                    cyc = sw_ms * 1e-3 * 2.4e9
+                    issue = {"valu_per_entry": ins["valu"], "salu_per_entry": ins["salu"], "frac_vector_port": round(ins["valu"] * entries * 4 / (1024 * cyc), 3), "frac_scalar_port": round(ins["salu"] * entries / (256 * cyc), 3),
+                             "note": "instructions per tile-list entry from the SQ counters (profiles/%s, measured with rocprofv3 --pmc like `traffic`) x this run's list entries over the issue slots of the same HIP-event time: the node sweep is "
+                                     "bound by instruction issue and the waits between dependent vector and scalar instructions, not by HBM" % ins.get("from", "pmc_traffic.json")}
             except Exception:
                 traffic = None
         per_unit = {str(uu): {"positions": unit_stats[uu]["n_pos"], "sam_pairs": unit_stats[uu]["sam_line_pairs"], "hits": unit_stats[uu]["n_hits"],
@@ -661,7 +669,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "achieved_note": "bytes the node sweep cannot avoid (bench.py sweep_compulsory_bytes: tile records, vote codes, conti-mer heads read once; node table written once — node state lives in LDS) of rank 0's units / HIP-event time of their node sweeps in the last timed step",
                          "compulsory_bytes": cbytes, "kernel_ms": round(sw_ms, 4),
-                         "traffic": traffic, "achieved_hbm": round(hbm_rate, 1) if hbm_rate else None,
+                         "traffic": traffic, "achieved_hbm": round(hbm_rate, 1) if hbm_rate else None, "issue": issue,
                          "frac_hbm": round(hbm_rate / HBM_PEAK_GBS, 4) if hbm_rate else None,
                          "traffic_note": "HBM bytes from the PMC counters (profiles/pmc_traffic.json: bytes per tile-list entry of the sweep, measured with rocprofv3 --pmc) x this run's list entries; achieved_hbm = traffic / kernel_ms",
                          "algorithmic_bytes_8d": abytes,

@@ -35,6 +35,15 @@ tab["node_sweep_bytes_per_tile_entry"] = round(per_entry, 2)
 tab["_method_%s" % cfg] = ("%s_pmc_hbm.csv (bash tests/tools/profile.sh %s %s; tests/tools/pmc_traffic.py): %d launches of agx_k_node_sweep<0> = %d builds (first builds sweep a window of tiles per launch), "
                            "FETCH %.3f GB x 1.575 + WRITE %.3f GB per build over %.2f M tile-list entries per build; with the guide's factor 2.0 for wide loads: %.2f bytes per entry"
                            % (os.path.basename(prefix), os.path.basename(prefix), cfg, launches, builds, fetch / builds / 1e9, write / builds / 1e9, entries / builds / 1e6, (fetch * 2.0 + write) / entries))
+# the same launches' instruction counters (profile.sh's SQ pass): vector and scalar instructions per list entry — what bench.py prints as roofline.issue, the roof the sweep is
+# actually under (it is not an HBM-bound kernel)
+sq_path = prefix + "_pmc_sq.csv"
+if os.path.exists(sq_path):
+    sq = next(r for r in csv.DictReader(open(sq_path)) if "agx_k_node_sweep<0>" in r["kernel"])
+    n_sq = int(sq["launches"])
+    tab.setdefault("node_sweep_insts_per_tile_entry_by_config", {})[cfg] = {
+        "valu": round(float(sq["SQ_INSTS_VALU_per_launch"]) * n_sq / entries, 2), "salu": round(float(sq["SQ_INSTS_SALU_per_launch"]) * n_sq / entries, 2),
+        "lds": round(float(sq["SQ_INSTS_LDS_per_launch"]) * n_sq / entries, 2), "vmem": round(float(sq["SQ_INSTS_VMEM_per_launch"]) * n_sq / entries, 2), "from": os.path.basename(sq_path)}
 tab["_regenerated_from"] = os.path.basename(prefix)
 json.dump(tab, open(out_path, "w"), indent=1)
 print(json.dumps({k: tab[k] for k in ("node_sweep_bytes_per_tile_entry_by_config", "_method_%s" % cfg)}, indent=1))
